@@ -1,0 +1,397 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the BBVI hot path from the upstream reference itself.
+
+Runs ONLY in the build container (needs the read-only reference tree); writes
+``tests/golden/*.npz``.  The reference's Python is imported through the
+container-only shims of ``_ref_stubs.py`` (autograd/paragami/pystan are absent
+here); see that file for exactly what is real reference code (all forward
+arithmetic, the RGE control-variate algebra, DIS tempering/bisection,
+alpha-divergence weights) and what is supplied (finite-difference / analytic
+derivatives in place of autograd).
+
+Each fixture stores inputs (theta, seed, the noise the reference drew) and the
+reference's outputs (samples, log densities, objective value, gradient), plus a
+``provenance`` string.  ``tests/test_oracle_golden.py`` checks the numpy oracle
+against them; the GPU parity tests check the HIP engine against the same files.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.stats
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _ref_stubs  # noqa: E402
+
+_ref_stubs.install('/root/reference')
+
+from viabel import approximations as ref_approx  # noqa: E402  (the reference)
+from viabel import objectives as ref_obj         # noqa: E402
+
+from oracle import families as ofam              # noqa: E402
+from oracle import models as omod                # noqa: E402
+from oracle import objectives as oobj            # noqa: E402
+
+norm = scipy.stats.norm
+
+
+# ----------------------------------------------------------------------------
+# models: the reference-side callable is written the way the reference's own
+# tests / docs write it (scipy logpdf calls), independent of the oracle formula
+# ----------------------------------------------------------------------------
+def make_model(spec):
+    kind = spec['kind']
+    if kind == 'gauss_diag':
+        mean = np.asarray(spec['mean'], dtype=float)[np.newaxis, :]
+        stdev = np.asarray(spec['stdev'], dtype=float)[np.newaxis, :]
+
+        def log_p(x):      # viabel/tests/test_objectives.py:18-19
+            x = np.atleast_2d(x)
+            return np.sum(norm.logpdf(x, loc=mean, scale=stdev), axis=1)
+        return log_p, omod.GaussDiag(spec['mean'], spec['stdev'])
+    if kind == 'funnel':
+        D, k, tau = spec['dim'], spec['scale_index'], spec['log_sigma_stdev']
+
+        def log_p(x):      # docs/source/quickstart.ipynb:23-29 generalised to D dims
+            x = np.atleast_2d(x)
+            log_sigma = x[:, k]
+            out = norm.logpdf(log_sigma, 0, tau)
+            for d in range(D):
+                if d != k:
+                    out = out + norm.logpdf(x[:, d], 0, np.exp(log_sigma))
+            return out
+        return log_p, omod.Funnel(D, k, tau)
+    raise ValueError(kind)
+
+
+def make_family(spec, seed):
+    kind, D = spec['kind'], spec['dim']
+    if kind == 'mf_gaussian':
+        return ref_approx.MFGaussian(D, seed=seed), ofam.MFGaussian(D)
+    if kind == 'mf_student_t':
+        return ref_approx.MFStudentT(D, spec['df'], seed=seed), ofam.MFStudentT(D, spec['df'])
+    if kind == 'multivariate_t':
+        return ref_approx.MultivariateT(D, spec['df'], seed=seed), ofam.MultivariateT(D, spec['df'])
+    raise ValueError(kind)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def snapshot_hook(approx, objective=None, np_seed=None):
+    rs_state = approx._rs.get_state()
+    obj_state = None
+    if objective is not None:
+        obj_state = {k: (v.copy() if isinstance(v, np.ndarray) else v)
+                     for k, v in objective.__dict__.items()
+                     if k.startswith('_state') or k in ('_eps', '_objective_step')}
+
+    def hook():
+        approx._rs.set_state(rs_state)
+        if np_seed is not None:
+            np.random.seed(np_seed)
+        if obj_state is not None:
+            for k in [k for k in objective.__dict__ if k.startswith('_state')]:
+                del objective.__dict__[k]
+            objective.__dict__.update(
+                {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in obj_state.items()})
+    return hook
+
+
+def theta_for(fspec, rng, kind='random'):
+    D = fspec['dim']
+    if fspec['kind'] in ('mf_gaussian', 'mf_student_t'):
+        return np.concatenate([0.3 * rng.randn(D), -0.5 + 0.3 * rng.randn(D)])
+    A = rng.randn(D, D)
+    S = A @ A.T / D + 0.5 * np.eye(D)
+    return np.concatenate([0.3 * rng.randn(D), ofam.psd_to_free(S)])
+
+
+SAVED = []
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez(path, **arrs)
+    SAVED.append(name)
+
+
+def spec_arrays(fspec, mspec):
+    out = {'family_kind': fspec['kind'], 'dim': fspec['dim'], 'df': fspec.get('df', 0.0),
+           'model_kind': mspec['kind']}
+    if mspec['kind'] == 'gauss_diag':
+        out['model_mean'] = np.asarray(mspec['mean'], dtype=float)
+        out['model_stdev'] = np.asarray(mspec['stdev'], dtype=float)
+    else:
+        out['model_scale_index'] = mspec['scale_index']
+        out['model_log_sigma_stdev'] = mspec['log_sigma_stdev']
+    return out
+
+
+def model_specs(D, rng):
+    return [
+        {'kind': 'gauss_diag', 'mean': rng.randn(D), 'stdev': np.exp(0.5 * rng.randn(D))},
+        {'kind': 'funnel', 'dim': D, 'scale_index': D - 1, 'log_sigma_stdev': 1.0},
+    ]
+
+
+# ----------------------------------------------------------------------------
+def gen_family_forward():
+    """sample / log_density / entropy / kl / mean_and_cov / pth_moment of the reference."""
+    rng = np.random.RandomState(11)
+    for fspec in ({'kind': 'mf_gaussian', 'dim': 3}, {'kind': 'mf_gaussian', 'dim': 10},
+                  {'kind': 'mf_student_t', 'dim': 3, 'df': 8},
+                  {'kind': 'mf_student_t', 'dim': 4, 'df': 100},
+                  {'kind': 'multivariate_t', 'dim': 3, 'df': 100},
+                  {'kind': 'multivariate_t', 'dim': 5, 'df': 7}):
+        seed, N = 5, 12
+        ref, orc = make_family(fspec, seed)
+        th0, th1 = theta_for(fspec, rng), theta_for(fspec, rng)
+        x = ref.sample(th0, N)
+        noise = orc.draw_noise(np.random.RandomState(seed), N)
+        xo = orc.sample_from_noise(th0, noise)
+        lq = ref.log_density(th1, x)
+        ent = ref.entropy(th0)
+        mean, cov = ref.mean_and_cov(th0)
+        out = dict(spec_arrays(fspec, {'kind': 'gauss_diag', 'mean': [0], 'stdev': [1]}),
+                   seed=seed, n=N, theta0=th0, theta1=th1, init_param=ref.init_param(),
+                   samples=x, log_density=lq, entropy=ent, mean=mean, cov=cov,
+                   pth2=ref.pth_moment(th0, 2), pth4=ref.pth_moment(th0, 4),
+                   provenance='reference forward code via autograd->numpy alias')
+        if ref.supports_kl:
+            out['kl'] = ref.kl(th0, th1)
+            assert rel_err(orc.kl(th0, th1), out['kl']) < 1e-13
+        if fspec['kind'] == 'multivariate_t':
+            out['noise_chi'], out['noise_z'] = noise
+        else:
+            out['noise'] = noise
+        assert rel_err(xo, x) < 1e-12, (fspec, rel_err(xo, x))
+        assert rel_err(orc.log_density(th1, x), lq) < 1e-12
+        assert rel_err(orc.entropy(th0), ent) < 1e-12
+        assert rel_err(orc.init_param(), ref.init_param()) < 1e-15
+        assert rel_err(orc.pth_moment(th0, 2), out['pth2']) < 1e-12
+        assert rel_err(orc.pth_moment(th0, 4), out['pth4']) < 1e-12
+        assert rel_err(orc.mean_and_cov(th0)[1], cov) < 1e-12
+        save('family_%s_d%d_df%s' % (fspec['kind'], fspec['dim'], fspec.get('df', 0)), **out)
+
+
+def gen_exclusive_kl():
+    rng = np.random.RandomState(21)
+    worst = 0.0
+    for fspec in ({'kind': 'mf_gaussian', 'dim': 2}, {'kind': 'mf_gaussian', 'dim': 10},
+                  {'kind': 'mf_gaussian', 'dim': 16}, {'kind': 'mf_student_t', 'dim': 3, 'df': 8},
+                  {'kind': 'mf_student_t', 'dim': 2, 'df': 100}):
+        D = fspec['dim']
+        for mspec in model_specs(D, rng):
+            for pd in (False, True):
+                for N in (8, 100):
+                    seed = 1
+                    ref, orc = make_family(fspec, seed)
+                    log_p, omodel = make_model(mspec)
+                    theta = theta_for(fspec, rng)
+                    objective = ref_obj.ExclusiveKL(ref, log_p, N, use_path_deriv=pd)
+                    _ref_stubs.STATE['before_eval'] = snapshot_hook(ref)
+                    value, grad_fd = objective(theta)
+                    _ref_stubs.STATE['before_eval'] = None
+                    noise = orc.draw_noise(np.random.RandomState(seed), N)
+                    ov, og = oobj.exclusive_kl(orc, omodel, theta, noise, use_path_deriv=pd)
+                    assert rel_err(ov, value) < 1e-12, (fspec, mspec['kind'], pd, ov, value)
+                    e = rel_err(og, grad_fd)
+                    worst = max(worst, e)
+                    assert e < 2e-7, (fspec, mspec['kind'], pd, N, e)
+                    name = 'ekl_%s_d%d_%s_pd%d_n%d' % (fspec['kind'], D, mspec['kind'], pd, N)
+                    save(name, **spec_arrays(fspec, mspec), seed=seed, n=N, theta=theta,
+                         noise=noise, use_path_deriv=pd, value=value, grad_fd=grad_fd,
+                         grad=og,
+                         provenance='value: reference closure; grad_fd: Richardson central '
+                                    'differences of the reference closure (getval replayed); '
+                                    'grad: analytic (oracle), agrees with grad_fd')
+    print('ExclusiveKL plain: worst analytic-vs-FD(reference) grad rel err %.2e' % worst)
+
+
+def gen_rge():
+    rng = np.random.RandomState(31)
+    worst = 0.0
+    for fspec in ({'kind': 'mf_gaussian', 'dim': 3}, {'kind': 'mf_student_t', 'dim': 2, 'df': 100},
+                  {'kind': 'mf_student_t', 'dim': 4, 'df': 8}, {'kind': 'mf_gaussian', 'dim': 10}):
+        D = fspec['dim']
+        for mspec in model_specs(D, rng):
+            for method in ('full', 'mean_only', 'loo_diag_approx', 'loo_direct_approx'):
+                for pd in (False, True):
+                    seed, N = 1, 24
+                    ref, orc = make_family(fspec, seed)
+                    log_p, omodel = make_model(mspec)
+                    theta = theta_for(fspec, rng)
+                    _ref_stubs.STATE['model'] = omodel
+                    objective = ref_obj.ExclusiveKL(ref, log_p, N, use_path_deriv=pd,
+                                                    hessian_approx_method=method)
+                    value, grad = objective(theta)     # reference RGE code, literally
+                    _ref_stubs.STATE['model'] = None
+                    noise = orc.draw_noise(np.random.RandomState(seed), N)
+                    lv, lg = oobj.rge_literal(orc, omodel, theta, noise, method, pd)
+                    rv, rg = oobj.rge_reduced(orc, omodel, theta, noise, method, pd)
+                    assert rel_err(lv, value) < 1e-12 and rel_err(lg, grad) < 1e-12
+                    e = rel_err(rg, grad)
+                    worst = max(worst, e)
+                    assert rel_err(rv, value) < 1e-12 and e < 1e-10, (fspec, mspec['kind'], method, e)
+                    name = 'rge_%s_d%d_%s_%s_pd%d' % (fspec['kind'], D, mspec['kind'], method, pd)
+                    save(name, **spec_arrays(fspec, mspec), seed=seed, n=N, theta=theta,
+                         noise=noise, use_path_deriv=pd, method=method, value=value, grad=grad,
+                         provenance='reference RGE code (objectives.py:170-271) run literally; '
+                                    'model derivatives analytic')
+    print('RGE: worst reduced-vs-reference grad rel err %.2e' % worst)
+
+
+def gen_alpha():
+    rng = np.random.RandomState(41)
+    worst = 0.0
+    for fspec in ({'kind': 'mf_gaussian', 'dim': 2}, {'kind': 'mf_student_t', 'dim': 3, 'df': 100},
+                  {'kind': 'mf_gaussian', 'dim': 10}):
+        D = fspec['dim']
+        for mspec in model_specs(D, rng):
+            for alpha in (2.0, 0.5):
+                N, np_seed = 32, 851
+                ref, orc = make_family(fspec, 1)
+                log_p, omodel = make_model(mspec)
+                theta = theta_for(fspec, rng)
+                objective = ref_obj.AlphaDivergence(ref, log_p, N, alpha)
+                np.random.seed(np_seed)
+                value, grad_fd = objective(theta)
+                np.random.seed(np_seed)
+                seed = np.random.randint(2 ** 32)                      # objectives.py:455
+                noise = orc.draw_noise(np.random.RandomState(seed), N)
+                ov, og = oobj.alpha_divergence(orc, omodel, theta, noise, alpha)
+                assert rel_err(ov, value) < 1e-12
+                e = rel_err(og, grad_fd)
+                worst = max(worst, e)
+                assert e < 2e-7, (fspec, mspec['kind'], alpha, e)
+                name = 'alpha_%s_d%d_%s_a%g' % (fspec['kind'], D, mspec['kind'], alpha)
+                save(name, **spec_arrays(fspec, mspec), np_seed=np_seed, seed=seed, n=N,
+                     theta=theta, noise=noise, alpha=alpha, value=value, grad_fd=grad_fd, grad=og,
+                     provenance='value: reference; grad_fd: FD of the reference log-weights '
+                                'closure contracted as in objectives.py:460; grad: analytic')
+    print('AlphaDivergence: worst analytic-vs-FD(reference) grad rel err %.2e' % worst)
+
+
+def gen_dis():
+    rng = np.random.RandomState(51)
+    worst = 0.0
+    for fspec in ({'kind': 'mf_student_t', 'dim': 2, 'df': 100}, {'kind': 'mf_gaussian', 'dim': 3},
+                  {'kind': 'multivariate_t', 'dim': 3, 'df': 100},
+                  {'kind': 'multivariate_t', 'dim': 4, 'df': 7}):
+        D = fspec['dim']
+        mspec = model_specs(D, rng)[0]
+        for use_resampling in (True, False):
+            N, ess_target, np_seed = 64, 20, 851
+            ref, orc = make_family(fspec, 1)
+            log_p, omodel = make_model(mspec)
+            theta = theta_for(fspec, rng)
+            prior_params = np.concatenate([[0] * D, [1] * D]).astype(float)   # test_objectives.py:85
+            objective = ref_obj.DISInclusiveKL(
+                ref, log_p, N, ess_target=ess_target, temper_prior=ref_approx.MFGaussian(D),
+                temper_prior_params=prior_params, use_resampling=use_resampling)
+            chosen = []
+            real_choice = np.random.choice
+
+            def rec_choice(*a, **k):
+                idx = real_choice(*a, **k)
+                chosen.append(np.array(idx))
+                return idx
+            np.random.choice = rec_choice
+            try:
+                np.random.seed(np_seed)
+                _ref_stubs.STATE['before_eval'] = snapshot_hook(ref, objective, np_seed)
+                value, grad_fd = objective(theta)
+            finally:
+                np.random.choice = real_choice
+                _ref_stubs.STATE['before_eval'] = None
+            noise = orc.draw_noise(np.random.RandomState(1), N)
+            od = oobj.DISInclusiveKL(orc, omodel, N, ess_target, ofam.MFGaussian(D), prior_params,
+                                     use_resampling=use_resampling)
+            indices = chosen[0] if use_resampling else None
+            ov, og = od(theta, noise=noise, indices=indices)
+            assert rel_err(ov, value) < 1e-11, (fspec, use_resampling, ov, value)
+            assert rel_err(od._eps, objective._eps) < 1e-12
+            assert rel_err(od._state_w_clipped, objective._state_w_clipped) < 1e-10
+            e = rel_err(og, grad_fd)
+            worst = max(worst, e)
+            assert e < 2e-6, (fspec, use_resampling, e)
+            out = dict(spec_arrays(fspec, mspec), np_seed=np_seed, seed=1, n=N,
+                       ess_target=ess_target, use_resampling=use_resampling, theta=theta,
+                       prior_params=prior_params, value=value, grad_fd=grad_fd, grad=og,
+                       eps=objective._eps, w_clipped=objective._state_w_clipped,
+                       log_q=objective._state_log_q, log_p=objective._state_log_p_unnormalized,
+                       samples=objective._state_samples,
+                       provenance='reference DISInclusiveKL code; grad_fd by FD with getval replay')
+            if use_resampling:
+                out['indices'] = indices
+            if fspec['kind'] == 'multivariate_t':
+                out['noise_chi'], out['noise_z'] = noise
+            else:
+                out['noise'] = noise
+            save('dis_%s_d%d_rs%d' % (fspec['kind'], D, use_resampling), **out)
+    print('DISInclusiveKL: worst analytic-vs-FD(reference) grad rel err %.2e' % worst)
+
+
+def gen_torch_crosscheck():
+    """Independent check of the analytic gradients with torch.autograd (fp64)."""
+    import torch
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.RandomState(61)
+    worst = 0.0
+    # model derivatives
+    for D in (3, 7):
+        for mspec in model_specs(D, rng):
+            _, om = make_model(mspec)
+            x = rng.randn(5, D)
+            xt = torch.tensor(x, requires_grad=True)
+            if mspec['kind'] == 'gauss_diag':
+                f = torch.distributions.Normal(torch.tensor(om.mean), torch.tensor(om.stdev)) \
+                    .log_prob(xt).sum(1)
+            else:
+                v = xt[:, om.k]
+                f = torch.distributions.Normal(0., om.tau).log_prob(v)
+                for d in range(D):
+                    if d != om.k:
+                        f = f + torch.distributions.Normal(0., torch.exp(v)).log_prob(xt[:, d])
+            g, = torch.autograd.grad(f.sum(), xt, create_graph=True)
+            assert rel_err(om.logp(x), f.detach().numpy()) < 1e-13
+            assert rel_err(om.grad(x), g.detach().numpy()) < 1e-12
+            m = torch.tensor(x[0], requires_grad=True)
+
+            def fm(mm):
+                if mspec['kind'] == 'gauss_diag':
+                    return torch.distributions.Normal(torch.tensor(om.mean), torch.tensor(om.stdev)) \
+                        .log_prob(mm).sum()
+                v = mm[om.k]
+                out = torch.distributions.Normal(0., om.tau).log_prob(v)
+                for d in range(D):
+                    if d != om.k:
+                        out = out + torch.distributions.Normal(0., torch.exp(v)).log_prob(mm[d])
+                return out
+            H = torch.autograd.functional.hessian(fm, m).numpy()
+            e = rel_err(om.hessian(x[0]), H)
+            worst = max(worst, e)
+            assert e < 1e-12
+    print('model derivatives vs torch.autograd fp64: worst hessian rel err %.2e' % worst)
+
+
+if __name__ == '__main__':
+    for f in os.listdir(HERE):
+        if f.endswith('.npz'):
+            os.remove(os.path.join(HERE, f))
+    gen_torch_crosscheck()
+    gen_family_forward()
+    gen_exclusive_kl()
+    gen_rge()
+    gen_alpha()
+    gen_dis()
+    print('wrote %d fixtures to %s' % (len(SAVED), HERE))
