@@ -1,0 +1,128 @@
+/*
+ * viabel_hip.h -- C ABI of the MI355X (gfx950) BBVI gradient engine.
+ *
+ * Drop-in boundary for the hot path of jhuggins/viabel:
+ *     objective(var_param) -> (value, grad)        viabel/objectives.py:32-44
+ * The reference has no FFI; its seam is the duck-typed Python call above
+ * (callers: viabel/optimization.py:95 and :539).  These entry points are what a
+ * ctypes binding inside viabel's VariationalObjective.__call__ would bind
+ * (INTEGRATION.md shows that binding).  Plain C: opaque handle, pointers, sizes,
+ * int status codes.  No C++ or torch types cross this boundary.
+ *
+ * Conventions
+ *   - every array is fp64, C order; `theta` follows viabel's flat parameter layout
+ *     (viabel/approximations.py:185-189 [mu | log_sigma], :315-319 [mu | free-Cholesky]);
+ *   - `value`/`grad` are caller-owned host buffers; the reference returns the NEGATIVE
+ *     lower bound and its gradient (objectives.py:164, :271) and so do these calls;
+ *   - one context per GPU; calls on one context are serialised by the caller; the
+ *     synchronous entry points return after the context's HIP stream has drained;
+ *   - return 0 on success, a VB_ERR_* code otherwise; vb_last_error() gives the text.
+ */
+#ifndef VIABEL_HIP_H
+#define VIABEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vb_ctx vb_ctx;
+
+/* status codes */
+#define VB_OK 0
+#define VB_ERR_INVALID 1     /* bad argument (Python raises ValueError)            */
+#define VB_ERR_HIP 2         /* HIP runtime failure (RuntimeError)                 */
+#define VB_ERR_UNSUPPORTED 3 /* combination not implemented (NotImplementedError)  */
+#define VB_ERR_STATE 4       /* call order / missing model or noise (RuntimeError) */
+#define VB_ERR_NUMERIC 5     /* e.g. 'All weights zero!' objectives.py:326-328      */
+#define VB_ERR_COMM 6        /* RCCL failure                                       */
+
+/* approximation families (viabel/approximations.py) */
+#define VB_FAMILY_MF_GAUSSIAN 0        /* :192-251 */
+#define VB_FAMILY_MF_STUDENT_T 1       /* :254-312 */
+#define VB_FAMILY_FULLRANK_GAUSSIAN 2  /* new family, layout of :315-319 */
+#define VB_FAMILY_MULTIVARIATE_T 3     /* :322-382 */
+
+/* device-resident target models (replace the Python callable of viabel/models.py:17-39) */
+#define VB_MODEL_GAUSS_DIAG 0  /* sum_d norm.logpdf(x_d; mean_d, sd_d)   dparams=[mean(D)|sd(D)]           */
+#define VB_MODEL_FUNNEL 1      /* quickstart funnel, D-dim               dparams=[tau], iparams=[scale_idx] */
+#define VB_MODEL_GAUSS_FULL 2  /* N(mean, P^-1)                          dparams=[mean(D)|P(DxD)|logdetP]   */
+
+/* noise kinds for vb_noise_generate */
+#define VB_NOISE_NORMAL 0
+#define VB_NOISE_STUDENT_T 1
+
+/* ExclusiveKL flags (viabel/objectives.py:123) */
+#define VB_FLAG_PATH_DERIV 1u          /* use_path_deriv=True */
+/* hessian_approx_method (objectives.py:144) */
+#define VB_CV_NONE 0
+#define VB_CV_FULL 1
+#define VB_CV_MEAN_ONLY 2
+#define VB_CV_LOO_DIAG 3
+#define VB_CV_LOO_DIRECT 4
+
+#define VB_MAX_SLOTS 64
+
+/* ---- library / context ------------------------------------------------------------ */
+const char* vb_version(void);
+int vb_device_count(int* count);
+int vb_create(int device_id, vb_ctx** out);
+int vb_destroy(vb_ctx* ctx);
+/* text of the last failure on `ctx` (ctx == NULL: last failure of vb_create / vb_device_count) */
+const char* vb_last_error(vb_ctx* ctx);
+/* name, CU count, HBM bytes of the context's device */
+int vb_device_info(vb_ctx* ctx, char* name, size_t name_len, int* n_cu, uint64_t* hbm_bytes);
+/* block until every enqueued call on the context's stream has finished */
+int vb_sync(vb_ctx* ctx);
+
+/* ---- noise slots: N x D fp64 matrices resident in HBM ------------------------------
+ * Replaces the RandomState draws inside approx.sample (approximations.py:212-216,
+ * :270-274).  Parity mode: the host draws RandomState(seed).randn(N, D) (the exact legacy
+ * MT19937 stream) and uploads it.  Throughput mode: counter-based Philox4x32-10
+ * on the device; element (row_offset + n, d) depends only on (seed, stream, global row, d),
+ * so results do not depend on how the Monte-Carlo axis is sharded.                       */
+int vb_noise_set_host(vb_ctx* ctx, int slot, const double* host, int64_t n, int64_t d);
+int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
+                      uint64_t stream, int64_t row_offset, int64_t n, int64_t d);
+int vb_noise_get_host(vb_ctx* ctx, int slot, double* host, int64_t n, int64_t d);
+
+/* ---- model ------------------------------------------------------------------------ */
+int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams,
+                 size_t n_dparams, const int64_t* iparams, size_t n_iparams);
+/* f(x_n), n < N, for host x (N x D): Model.__call__ (models.py:27-39) on the device */
+int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* out_host);
+
+/* ---- ExclusiveKL, mean-field families (objectives.py:150-273) ----------------------
+ * theta = [mu(D) | log_sigma(D)] on the host; noise slot holds the N x D base draws
+ * (normal for MF_GAUSSIAN, standard-t for MF_STUDENT_T).  n_total is the Monte-Carlo
+ * sample count of the WHOLE job (== n on one GPU; sum over ranks when a communicator is
+ * attached, in which case the partial sums are all-reduced before the epilogue).        */
+int vb_elbo_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
+                           int family, double df, const double* theta, unsigned flags,
+                           int cv_mode, double* value, double* grad);
+/* Same, enqueued without waiting: results land in result slot `rslot`; fetch them with
+ * vb_result_get after vb_sync.  Lets a caller keep several evaluations in flight.       */
+int vb_elbo_grad_meanfield_async(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
+                                 int family, double df, const double* theta, unsigned flags,
+                                 int cv_mode, int rslot);
+int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p);
+
+/* ---- multi-GPU: Monte-Carlo axis sharded, one RCCL all-reduce of the partial sums --- */
+#define VB_COMM_ID_BYTES 128
+int vb_comm_unique_id(char id[VB_COMM_ID_BYTES]);
+int vb_comm_init(vb_ctx* ctx, const char id[VB_COMM_ID_BYTES], int n_ranks, int rank);
+int vb_comm_destroy(vb_ctx* ctx);
+
+/* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernel ----------
+ * When enabled, every launch of the accumulation kernel is bracketed by HIP events on
+ * the context's stream; vb_profile_read returns launches and total milliseconds since the
+ * last reset.                                                                           */
+int vb_profile_enable(vb_ctx* ctx, int on);
+int vb_profile_read(vb_ctx* ctx, int64_t* launches, double* total_ms, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIABEL_HIP_H */

@@ -1,0 +1,234 @@
+"""GPU parity: the HIP mean-field ExclusiveKL path against the reference-derived golden
+vectors and against the numpy oracle, all through the C ABI (ctypes).
+
+Tolerances (fp64 kernels, different summation order than numpy): value 1e-12 relative;
+gradient 1e-11 relative to max|grad| (control-variate variants subtract nearly equal sums,
+so 1e-10 there); 2e-7 against the reference's finite-difference gradients.
+north_star asks for 1e-5 relative on the ELBO.
+"""
+import numpy as np
+import pytest
+
+import _golden as G
+from oracle import families as ofam
+from oracle import models as omod
+from oracle import objectives as oobj
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import viabel_amd
+    from viabel_amd import _lib
+    _lib.default_engine()          # raises if no GPU / no library: no silent fallback
+    return viabel_amd
+
+
+def product_family(vb, fx, seed):
+    kind, D = str(fx['family_kind']), int(fx['dim'])
+    if kind == 'mf_gaussian':
+        return vb.MFGaussian(D, seed=seed)
+    if kind == 'mf_student_t':
+        return vb.MFStudentT(D, float(fx['df']), seed=seed)
+    raise ValueError(kind)
+
+
+def product_model(vb, fx):
+    if str(fx['model_kind']) == 'gauss_diag':
+        return vb.GaussianModel(fx['model_mean'], fx['model_stdev'])
+    return vb.FunnelModel(int(fx['dim']), int(fx['model_scale_index']),
+                          float(fx['model_log_sigma_stdev']))
+
+
+@pytest.mark.parametrize('path', G.fixtures('ekl_'), ids=lambda p: p.split('/')[-1][:-4])
+def test_exclusive_kl_golden(vb, path):
+    fx = G.load(path)
+    approx = product_family(vb, fx, int(fx['seed']))
+    obj = vb.ExclusiveKL(approx, product_model(vb, fx), int(fx['n']),
+                         use_path_deriv=bool(fx['use_path_deriv']))
+    value, grad = obj(fx['theta'])
+    assert G.rel_err(value, fx['value']) < 1e-12
+    assert G.rel_err(grad, fx['grad']) < 1e-11
+    assert G.rel_err(grad, fx['grad_fd']) < 2e-7
+
+
+@pytest.mark.parametrize('path', G.fixtures('rge_'), ids=lambda p: p.split('/')[-1][:-4])
+def test_rge_golden(vb, path):
+    fx = G.load(path)
+    approx = product_family(vb, fx, int(fx['seed']))
+    obj = vb.ExclusiveKL(approx, product_model(vb, fx), int(fx['n']),
+                         use_path_deriv=bool(fx['use_path_deriv']),
+                         hessian_approx_method=str(fx['method']))
+    value, grad = obj(fx['theta'])
+    assert G.rel_err(value, fx['value']) < 1e-12
+    assert G.rel_err(grad, fx['grad']) < 1e-10
+
+
+def _theta(D, rng):
+    return np.concatenate([0.3 * rng.randn(D), -1.0 + 0.2 * rng.randn(D)])
+
+
+@pytest.mark.parametrize('D,N', [(1024, 4096), (10, 100), (1000, 333), (129, 7), (2, 1), (257, 4097)])
+@pytest.mark.parametrize('model_kind', ['gauss_diag', 'funnel'])
+def test_against_oracle_shapes(vb, D, N, model_kind):
+    """BASELINE configs C0 (D=10, N=100) and C1 (D=1024, N=4096) plus ragged shapes."""
+    rng = np.random.RandomState(D * 7 + N)
+    if model_kind == 'gauss_diag':
+        mean, sd = rng.randn(D), np.exp(0.3 * rng.randn(D))
+        model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    else:
+        k = D // 3
+        model, omodel = vb.FunnelModel(D, k, 1.3), omod.Funnel(D, k, 1.3)
+    theta = _theta(D, rng)
+    for pd in (False, True):
+        approx = vb.MFGaussian(D, seed=5)
+        value, grad = vb.ExclusiveKL(approx, model, N, use_path_deriv=pd)(theta)
+        noise = np.random.RandomState(5).randn(N, D)
+        ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omodel, theta, noise, pd)
+        assert G.rel_err(value, ov) < 1e-12, (pd, value, ov)
+        assert G.rel_err(grad, og) < 1e-11, (pd, G.rel_err(grad, og))
+
+
+@pytest.mark.parametrize('method', ['full', 'mean_only', 'loo_diag_approx', 'loo_direct_approx'])
+@pytest.mark.parametrize('family', ['gauss', 't'])
+def test_rge_against_oracle_large(vb, method, family):
+    D, N = 300, 513
+    rng = np.random.RandomState(17)
+    theta = _theta(D, rng)
+    for model, omodel in ((vb.FunnelModel(D, 7), omod.Funnel(D, 7)),
+                          (vb.GaussianModel(np.ones(D), 2 * np.ones(D)), omod.GaussDiag(np.ones(D), 2 * np.ones(D)))):
+        if family == 'gauss':
+            approx, ofamily = vb.MFGaussian(D, seed=3), ofam.MFGaussian(D)
+        else:
+            approx, ofamily = vb.MFStudentT(D, 9, seed=3), ofam.MFStudentT(D, 9)
+        for pd in (False, True):
+            value, grad = vb.ExclusiveKL(approx, model, N, use_path_deriv=pd,
+                                         hessian_approx_method=method)(theta)
+            noise = ofamily.draw_noise(np.random.RandomState(3), N)
+            if pd:   # the family's RandomState advanced: replay both calls
+                noise = ofamily.draw_noise(_advance(ofamily, 3, N), N)
+            ov, og = oobj.rge_reduced(ofamily, omodel, theta, noise, method, pd)
+            assert G.rel_err(value, ov) < 1e-12
+            assert G.rel_err(grad, og) < 1e-10
+
+
+def _advance(ofamily, seed, n):
+    rs = np.random.RandomState(seed)
+    ofamily.draw_noise(rs, n)
+    return rs
+
+
+def test_rng_stream_advances_like_reference(vb):
+    """Second call consumes draws [N*D, 2*N*D) of RandomState(seed)."""
+    D, N = 16, 50
+    approx = vb.MFGaussian(D, seed=1)
+    model = vb.GaussianModel(np.zeros(D), np.ones(D))
+    obj = vb.ExclusiveKL(approx, model, N)
+    theta = np.concatenate([np.zeros(D), np.zeros(D)])
+    rs = np.random.RandomState(1)
+    for _ in range(3):
+        value, grad = obj(theta)
+        ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omod.GaussDiag(np.zeros(D), np.ones(D)),
+                                   theta, rs.randn(N, D))
+        assert G.rel_err(value, ov) < 1e-12 and G.rel_err(grad, og) < 1e-11
+
+
+def test_float32_theta_accepted(vb):
+    """tests/test_objectives.py:24 passes a float32 init; computation stays fp64."""
+    D = 2
+    obj = vb.ExclusiveKL(vb.MFStudentT(D, 100), vb.GaussianModel([1., -1.], [2., 5.]), 100)
+    v, g = obj(np.array([0, 0, 1, 1], dtype=np.float32))
+    assert np.isfinite(v) and g.dtype == np.float64 and g.shape == (4,)
+
+
+def test_model_call_on_device(vb):
+    rng = np.random.RandomState(0)
+    for D in (2, 77, 1024):
+        x = rng.randn(33, D)
+        m, sd = rng.randn(D), np.exp(rng.randn(D))
+        np.testing.assert_allclose(vb.GaussianModel(m, sd)(x), omod.GaussDiag(m, sd).logp(x), rtol=1e-12)
+        np.testing.assert_allclose(vb.FunnelModel(D)(0.3 * x), omod.Funnel(D).logp(0.3 * x), rtol=1e-12)
+        assert vb.FunnelModel(D)(0.3 * x[0]).shape == (1,)
+
+
+def test_invalid_hessian_approx_method(vb):
+    with pytest.raises(ValueError) as info:
+        vb.ExclusiveKL(vb.MFGaussian(2), vb.GaussianModel([0, 0], [1, 1]), 10,
+                       hessian_approx_method='invalid method')
+    assert str(info.value) == ("Name of approximation must be one of 'full', 'mean_only', "
+                               "'loo_diag_approx', 'loo_direct_approx' or None object.")
+
+
+def test_host_callable_rejected(vb):
+    with pytest.raises(TypeError):
+        vb.ExclusiveKL(vb.MFGaussian(2), lambda x: -0.5 * np.sum(x ** 2, axis=1), 10)
+
+
+def test_philox_noise_is_standard_normal_and_shard_invariant(vb):
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    N, D = 4096, 257
+    eng.noise_generate(5, N, D, seed=9, stream=3)
+    full = eng.noise_get_host(5, N, D)
+    assert abs(full.mean()) < 5 / np.sqrt(N * D)
+    assert abs(full.var() - 1) < 0.01
+    assert abs(np.mean(full ** 4) - 3) < 0.05
+    # rows [1000, 1500) generated alone equal the same rows of the full matrix: sharding-invariant
+    eng.noise_generate(6, 500, D, seed=9, stream=3, row_offset=1000)
+    np.testing.assert_array_equal(eng.noise_get_host(6, 500, D), full[1000:1500])
+    eng.noise_generate(6, N, D, seed=9, stream=4)
+    assert np.abs(np.corrcoef(full.ravel(), eng.noise_get_host(6, N, D).ravel())[0, 1]) < 0.01
+
+
+def test_philox_objective_matches_oracle_on_same_noise(vb):
+    from viabel_amd import _lib
+    D, N = 512, 2048
+    approx = vb.MFGaussian(D, seed=7, rng='philox')
+    model = vb.FunnelModel(D)
+    theta = _theta(D, np.random.RandomState(2))
+    value, grad = vb.ExclusiveKL(approx, model, N)(theta)
+    eng = _lib.default_engine()
+    noise = eng.noise_get_host(0, N, D)        # what the kernel consumed
+    ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omod.Funnel(D), theta, noise)
+    assert G.rel_err(value, ov) < 1e-12 and G.rel_err(grad, og) < 1e-11
+
+
+def test_async_pipeline_matches_sync(vb):
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    D, N = 1024, 4096
+    model = vb.FunnelModel(D)
+    eng.set_model(model.device_spec())
+    theta = _theta(D, np.random.RandomState(4))
+    for s in range(4):
+        eng.noise_generate(10 + s, N, D, seed=1, stream=s)
+    sync = [eng.elbo_grad_meanfield(10 + s, N, D, theta, _lib.FAMILY_MF_GAUSSIAN) for s in range(4)]
+    for s in range(4):
+        eng.elbo_grad_meanfield_async(10 + s, N, D, theta, _lib.FAMILY_MF_GAUSSIAN, rslot=s)
+    eng.sync()
+    for s in range(4):
+        v, g = eng.result_get(s, 2 * D)
+        assert v == sync[s][0]
+        np.testing.assert_array_equal(g, sync[s][1])     # deterministic reductions: bitwise
+
+
+def test_full_size_properties(vb):
+    """C1 at full size: linearity in the sample axis (mean of halves = whole) and determinism."""
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    D, N = 1024, 4096
+    model = vb.FunnelModel(D)
+    eng.set_model(model.device_spec())
+    theta = _theta(D, np.random.RandomState(6))
+    eng.noise_generate(20, N, D, seed=3, stream=0)
+    full = eng.noise_get_host(20, N, D)
+    v, g = eng.elbo_grad_meanfield(20, N, D, theta, _lib.FAMILY_MF_GAUSSIAN)
+    v2, g2 = eng.elbo_grad_meanfield(20, N, D, theta, _lib.FAMILY_MF_GAUSSIAN)
+    assert v == v2 and np.array_equal(g, g2)
+    eng.noise_set_host(21, full[:N // 2])
+    eng.noise_set_host(22, full[N // 2:])
+    va, ga = eng.elbo_grad_meanfield(21, N // 2, D, theta, _lib.FAMILY_MF_GAUSSIAN)
+    vb_, gb = eng.elbo_grad_meanfield(22, N // 2, D, theta, _lib.FAMILY_MF_GAUSSIAN)
+    assert abs(0.5 * (va + vb_) - v) < 1e-12 * abs(v)
+    np.testing.assert_allclose(0.5 * (ga + gb), g, rtol=0, atol=1e-11 * np.max(np.abs(g)))

@@ -1,0 +1,270 @@
+"""ctypes binding of ``libviabel_hip.so`` (the C ABI in ``include/viabel_hip.h``).
+
+The shared library is the product: there is no CPU fallback.  If it is missing, or
+no MI355X is visible, every compute call raises -- loudly -- instead of silently
+computing something else.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libviabel_hip.so')
+CSRC_DIR = os.path.join(_HERE, 'csrc')
+
+VB_OK, VB_ERR_INVALID, VB_ERR_HIP, VB_ERR_UNSUPPORTED, VB_ERR_STATE, VB_ERR_NUMERIC, VB_ERR_COMM = range(7)
+
+FAMILY_MF_GAUSSIAN, FAMILY_MF_STUDENT_T, FAMILY_FULLRANK_GAUSSIAN, FAMILY_MULTIVARIATE_T = range(4)
+MODEL_GAUSS_DIAG, MODEL_FUNNEL, MODEL_GAUSS_FULL = range(3)
+NOISE_NORMAL, NOISE_STUDENT_T = range(2)
+FLAG_PATH_DERIV = 1
+CV_MODES = {None: 0, 'full': 1, 'mean_only': 2, 'loo_diag_approx': 3, 'loo_direct_approx': 4}
+MAX_SLOTS = 64
+COMM_ID_BYTES = 128
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+_ctx_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/viabel_hip.h
+SIGNATURES = {
+    'vb_version': (ctypes.c_char_p, []),
+    'vb_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'vb_create': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_ctx_p)]),
+    'vb_destroy': (ctypes.c_int, [_ctx_p]),
+    'vb_last_error': (ctypes.c_char_p, [_ctx_p]),
+    'vb_device_info': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_size_t,
+                                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
+    'vb_sync': (ctypes.c_int, [_ctx_p]),
+    'vb_noise_set_host': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_int64, ctypes.c_int64]),
+    'vb_noise_generate': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                         ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_int64]),
+    'vb_noise_get_host': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_int64, ctypes.c_int64]),
+    'vb_set_model': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, _c_double_p, ctypes.c_size_t,
+                                    _c_int64_p, ctypes.c_size_t]),
+    'vb_model_logp': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
+    'vb_elbo_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int64, ctypes.c_int, ctypes.c_double, _c_double_p,
+                                              ctypes.c_uint, ctypes.c_int, _c_double_p, _c_double_p]),
+    'vb_elbo_grad_meanfield_async': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                                    ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                                    _c_double_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int]),
+    'vb_result_get': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64]),
+    'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
+    'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    'vb_comm_destroy': (ctypes.c_int, [_ctx_p]),
+    'vb_profile_enable': (ctypes.c_int, [_ctx_p, ctypes.c_int]),
+    'vb_profile_read': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int64),
+                                       ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class EngineError(RuntimeError):
+    """The HIP engine is unavailable or a HIP call failed."""
+
+
+def build(verbose=False):
+    """Compile ``libviabel_hip.so`` for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC_DIR, '-j8']
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise EngineError('building libviabel_hip.so failed (see output above)')
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library and declare every entry point (no GPU needed for this)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                'libviabel_hip.so not found at %s: build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"` or `make -C viabel_amd/csrc`. '
+                'There is no CPU fallback.' % LIB_PATH)
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise EngineError('cannot load %s: %s' % (LIB_PATH, exc))
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+        return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Engine:
+    """One HIP context on one GPU (``vb_ctx``).  Calls are synchronous unless named ``*_async``."""
+
+    def __init__(self, device=None):
+        self._lib = load()
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0'))
+        n = ctypes.c_int(0)
+        rc = self._lib.vb_device_count(ctypes.byref(n))
+        if rc != VB_OK or n.value == 0:
+            raise EngineError('no MI355X visible to HIP (%s); the engine has no CPU fallback'
+                              % self._lib.vb_last_error(None).decode())
+        ctx = _ctx_p()
+        rc = self._lib.vb_create(int(device) % n.value, ctypes.byref(ctx))
+        if rc != VB_OK:
+            raise EngineError('vb_create failed: ' + self._lib.vb_last_error(None).decode())
+        self._ctx = ctx
+        self.device = int(device) % n.value
+        self._model_key = None
+        self.n_ranks, self.rank = 1, 0
+
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self._lib.vb_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ errors
+    def _check(self, rc):
+        if rc == VB_OK:
+            return
+        msg = self._lib.vb_last_error(self._ctx).decode()
+        if rc == VB_ERR_INVALID or rc == VB_ERR_NUMERIC:
+            raise ValueError(msg)
+        if rc == VB_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise EngineError(msg)
+
+    # ------------------------------------------------------------------ info
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        cu = ctypes.c_int(0)
+        hbm = ctypes.c_uint64(0)
+        self._check(self._lib.vb_device_info(self._ctx, name, 256, ctypes.byref(cu), ctypes.byref(hbm)))
+        return {'name': name.value.decode(), 'cus': cu.value, 'hbm_bytes': hbm.value}
+
+    def sync(self):
+        self._check(self._lib.vb_sync(self._ctx))
+
+    # ------------------------------------------------------------------ noise
+    def noise_set_host(self, slot, eps):
+        eps = _f64(eps)
+        n, d = eps.shape
+        self._check(self._lib.vb_noise_set_host(self._ctx, slot, _dptr(eps), n, d))
+
+    def noise_generate(self, slot, n, d, seed, stream=0, row_offset=0, kind=NOISE_NORMAL, df=0.0):
+        self._check(self._lib.vb_noise_generate(self._ctx, slot, kind, float(df), int(seed), int(stream),
+                                                int(row_offset), int(n), int(d)))
+
+    def noise_get_host(self, slot, n, d):
+        out = np.empty((n, d), dtype=np.float64)
+        self._check(self._lib.vb_noise_get_host(self._ctx, slot, _dptr(out), n, d))
+        return out
+
+    # ------------------------------------------------------------------ model
+    def set_model(self, spec):
+        """``spec`` = (model_id, dim, dparams ndarray, iparams ndarray) from ``DeviceModel.device_spec``."""
+        model_id, dim, dparams, iparams = spec
+        key = (model_id, dim, dparams.tobytes(), iparams.tobytes())
+        if key == self._model_key:
+            return
+        dparams = _f64(dparams)
+        iparams = np.ascontiguousarray(iparams, dtype=np.int64)
+        self._check(self._lib.vb_set_model(
+            self._ctx, model_id, dim, _dptr(dparams) if dparams.size else None, dparams.size,
+            iparams.ctypes.data_as(_c_int64_p) if iparams.size else None, iparams.size))
+        self._model_key = key
+
+    def model_logp(self, x):
+        x = _f64(x)
+        n, d = x.shape
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.vb_model_logp(self._ctx, _dptr(x), n, d, _dptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ ExclusiveKL, mean field
+    def elbo_grad_meanfield(self, slot, n, d, theta, family, df=0.0, flags=0, cv_mode=0, n_total=None):
+        theta = _f64(theta)
+        value = ctypes.c_double(0.0)
+        grad = np.empty(2 * d, dtype=np.float64)
+        self._check(self._lib.vb_elbo_grad_meanfield(
+            self._ctx, slot, n, d, n if n_total is None else n_total, family, float(df), _dptr(theta),
+            flags, cv_mode, ctypes.byref(value), _dptr(grad)))
+        return value.value, grad
+
+    def elbo_grad_meanfield_async(self, slot, n, d, theta, family, rslot, df=0.0, flags=0, cv_mode=0,
+                                  n_total=None):
+        theta = _f64(theta)
+        self._check(self._lib.vb_elbo_grad_meanfield_async(
+            self._ctx, slot, n, d, n if n_total is None else n_total, family, float(df), _dptr(theta),
+            flags, cv_mode, rslot))
+
+    def result_get(self, rslot, p):
+        value = ctypes.c_double(0.0)
+        grad = np.empty(p, dtype=np.float64)
+        self._check(self._lib.vb_result_get(self._ctx, rslot, ctypes.byref(value), _dptr(grad), p))
+        return value.value, grad
+
+    # ------------------------------------------------------------------ multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        lib = load()
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        rc = lib.vb_comm_unique_id(buf)
+        if rc != VB_OK:
+            raise EngineError('vb_comm_unique_id failed: ' + lib.vb_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        self._check(self._lib.vb_comm_init(self._ctx, unique_id, n_ranks, rank))
+        self.n_ranks, self.rank = n_ranks, rank
+
+    def comm_destroy(self):
+        self._check(self._lib.vb_comm_destroy(self._ctx))
+        self.n_ranks, self.rank = 1, 0
+
+    # ------------------------------------------------------------------ measurement
+    def profile_enable(self, on=True):
+        self._check(self._lib.vb_profile_enable(self._ctx, int(bool(on))))
+
+    def profile_read(self, reset=True):
+        n = ctypes.c_int64(0)
+        ms = ctypes.c_double(0.0)
+        self._check(self._lib.vb_profile_read(self._ctx, ctypes.byref(n), ctypes.byref(ms), int(reset)))
+        return n.value, ms.value
+
+
+_default_engine = None
+
+
+def default_engine():
+    """Process-wide engine on device ``LOCAL_RANK`` (0 if unset); created on first use."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine()
+    return _default_engine
+
+
+def set_default_engine(engine):
+    global _default_engine
+    _default_engine = engine

@@ -1,0 +1,433 @@
+"""Approximation families (host side of the reference's ``ApproximationFamily`` API).
+
+API surface of ``viabel/approximations.py:26-182`` kept: ``init_param``, ``sample(var_param,
+n_samples, seed=None)``, ``entropy``, ``kl``, ``log_density``, ``mean_and_cov``,
+``pth_moment``, ``supports_pth_moment``, ``dim``, ``var_param_dim``, ``supports_entropy``,
+``supports_kl``.  These are O(P) / O(N D) host conveniences used by optimisers and
+diagnostics; the Monte-Carlo objective itself (``objective(var_param)``) never goes through
+them -- it hands the family's *noise* and flat parameter to the HIP engine.
+
+Flat parameter layouts (paragami 0.42 "free" flattening, ``approximations.py:185-189`` and
+``:315-319``): ``[mu | log_sigma]`` for the mean-field families, ``[mu | vec(L)]`` for the
+dense ones, where ``L`` is the Cholesky factor of the scale matrix with the *log* of its
+diagonal, lower triangle in ``numpy.tril_indices`` order.
+
+Noise sources.  ``rng='numpy'`` (default) reproduces the reference bit for bit: a persistent
+``numpy.random.RandomState(seed)`` held by the family and advanced by every draw
+(``approximations.py:203``, ``:213-216``).  ``rng='philox'`` is the throughput mode: noise
+is generated on the GPU by a counter-based Philox stream and never touches the host.
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+from scipy import linalg as _sla
+from scipy import special as _special
+
+from . import _lib
+
+__all__ = ['ApproximationFamily', 'MFGaussian', 'MFStudentT', 'MultivariateT', 'FullRankGaussian']
+
+_LOG_2PI = float(np.log(2.0 * np.pi))
+
+
+class ApproximationFamily(ABC):
+    """Abstract variational family (``viabel/approximations.py:26-182``)."""
+
+    def __init__(self, dim, var_param_dim, supports_entropy, supports_kl):
+        self._dim = dim
+        self._var_param_dim = var_param_dim
+        self._supports_entropy = supports_entropy
+        self._supports_kl = supports_kl
+
+    def init_param(self):
+        return np.zeros(self.var_param_dim)
+
+    @abstractmethod
+    def sample(self, var_param, n_samples, seed=None):
+        """Draw ``(n_samples, dim)`` samples from the variational distribution."""
+
+    def entropy(self, var_param):
+        if self.supports_entropy:
+            return self._entropy(var_param)
+        raise NotImplementedError()
+
+    def _entropy(self, var_param):
+        raise NotImplementedError()
+
+    @property
+    def supports_entropy(self):
+        return self._supports_entropy
+
+    def kl(self, var_param0, var_param1):
+        if self.supports_kl:
+            return self._kl(var_param0, var_param1)
+        raise NotImplementedError()
+
+    def _kl(self, var_param0, var_param1):
+        raise NotImplementedError()
+
+    @property
+    def supports_kl(self):
+        return self._supports_kl
+
+    @abstractmethod
+    def log_density(self, var_param, x):
+        """Log density of the variational distribution at ``x``."""
+
+    @abstractmethod
+    def mean_and_cov(self, var_param):
+        """Mean and covariance of the variational distribution."""
+
+    def pth_moment(self, var_param, p):
+        if self.supports_pth_moment(p):
+            return self._pth_moment(var_param, p)
+        raise ValueError('p = {} is not a supported moment'.format(p))
+
+    @abstractmethod
+    def _pth_moment(self, var_param, p):
+        """Absolute p-th moment."""
+
+    @abstractmethod
+    def supports_pth_moment(self, p):
+        """Whether the p-th moment is available in closed form."""
+
+    @property
+    def dim(self):
+        return self._dim
+
+    @property
+    def var_param_dim(self):
+        return self._var_param_dim
+
+
+class _NoiseMixin:
+    """Noise bookkeeping shared by the device-backed families."""
+
+    def _init_rng(self, seed, rng):
+        if rng not in ('numpy', 'philox'):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        self._seed = seed
+        self._rng_kind = rng
+        self._rs = np.random.RandomState(seed)
+        self._philox_calls = 0
+
+    @property
+    def rng(self):
+        return self._rng_kind
+
+    def _random_state(self, seed):
+        return self._rs if seed is None else np.random.RandomState(seed)
+
+    def _next_philox_stream(self):
+        k = self._philox_calls
+        self._philox_calls += 1
+        return k
+
+
+def _as_rows(x):
+    x = np.asarray(x, dtype=np.float64)
+    return x[np.newaxis, :] if x.ndim == 1 else x
+
+
+# ------------------------------------------------------------------------------------------
+class MFGaussian(_NoiseMixin, ApproximationFamily):
+    """Mean-field Gaussian, ``var_param = [mu | log_sigma]`` (``approximations.py:192-251``)."""
+
+    _family_id = _lib.FAMILY_MF_GAUSSIAN
+
+    def __init__(self, dim, seed=1, rng='numpy'):
+        self._init_rng(seed, rng)
+        super().__init__(dim, 2 * dim, True, True)
+
+    # -- engine hooks ------------------------------------------------------------------------
+    def _device_family(self):
+        return self._family_id, 0.0
+
+    def _base_noise(self, n_samples, seed=None):
+        """The base draws the reference's ``sample`` would consume (``:216``)."""
+        return self._random_state(seed).randn(n_samples, self.dim)
+
+    def _unpack(self, var_param):
+        var_param = np.asarray(var_param, dtype=np.float64)
+        return var_param[:self.dim], var_param[self.dim:]
+
+    # -- reference API -----------------------------------------------------------------------
+    def init_param(self):
+        return np.concatenate([np.zeros(self.dim), np.full(self.dim, 2.0)])
+
+    def sample(self, var_param, n_samples, seed=None):
+        mu, log_sigma = self._unpack(var_param)
+        if self._rng_kind == 'philox':
+            noise = _philox_host_copy(self, n_samples, seed)
+        else:
+            noise = self._base_noise(n_samples, seed)
+        return mu + np.exp(log_sigma) * noise
+
+    def _entropy(self, var_param):
+        _, log_sigma = self._unpack(var_param)
+        return 0.5 * self.dim * (1.0 + _LOG_2PI) + np.sum(log_sigma)
+
+    def _kl(self, var_param0, var_param1):
+        mu0, ls0 = self._unpack(var_param0)
+        mu1, ls1 = self._unpack(var_param1)
+        dls = ls0 - ls1
+        return 0.5 * np.sum(np.exp(2 * dls) + (mu0 - mu1) ** 2 * np.exp(-2 * ls1) - 2 * dls - 1)
+
+    def log_density(self, var_param, x):
+        mu, log_sigma = self._unpack(var_param)
+        r = (_as_rows(x) - mu) * np.exp(-log_sigma)
+        return np.sum(-0.5 * r * r - log_sigma - 0.5 * _LOG_2PI, axis=-1)
+
+    def mean_and_cov(self, var_param):
+        mu, log_sigma = self._unpack(var_param)
+        return mu, np.diag(np.exp(2 * log_sigma))
+
+    def _pth_moment(self, var_param, p):
+        _, log_sigma = self._unpack(var_param)
+        var = np.exp(2 * log_sigma)
+        if p == 2:
+            return np.sum(var)
+        return 2 * np.sum(var ** 2) + np.sum(var) ** 2
+
+    def supports_pth_moment(self, p):
+        return p in [2, 4]
+
+
+class MFStudentT(_NoiseMixin, ApproximationFamily):
+    """Mean-field Student's t, ``var_param = [mu | log_sigma]`` (``approximations.py:254-312``)."""
+
+    _family_id = _lib.FAMILY_MF_STUDENT_T
+
+    def __init__(self, dim, df, seed=1, rng='numpy'):
+        if df <= 2:
+            raise ValueError('df must be greater than 2')
+        self._df = df
+        self._init_rng(seed, rng)
+        if rng != 'numpy':
+            raise NotImplementedError("MFStudentT draws its base noise on the host (rng='numpy')")
+        super().__init__(dim, 2 * dim, True, False)
+
+    def _device_family(self):
+        return self._family_id, float(self._df)
+
+    def _base_noise(self, n_samples, seed=None):
+        return self._random_state(seed).standard_t(self.df, size=(n_samples, self.dim))   # :273-274
+
+    def _unpack(self, var_param):
+        var_param = np.asarray(var_param, dtype=np.float64)
+        return var_param[:self.dim], var_param[self.dim:]
+
+    def init_param(self):
+        return np.concatenate([np.zeros(self.dim), np.full(self.dim, 2.0)])
+
+    def sample(self, var_param, n_samples, seed=None):
+        mu, log_sigma = self._unpack(var_param)
+        return mu + np.exp(log_sigma) * self._base_noise(n_samples, seed)
+
+    def entropy(self, var_param):
+        # the reference drops the df-only constants (approximations.py:276-279)
+        _, log_sigma = self._unpack(var_param)
+        return np.sum(log_sigma)
+
+    def log_density(self, var_param, x):
+        mu, log_sigma = self._unpack(var_param)
+        df = self.df
+        r = (_as_rows(x) - mu) * np.exp(-log_sigma)
+        const = (_special.gammaln(0.5 * (df + 1)) - _special.gammaln(0.5 * df)
+                 - 0.5 * np.log(df * np.pi))
+        return np.sum(const - 0.5 * (df + 1) * np.log1p(r * r / df) - log_sigma, axis=-1)
+
+    def mean_and_cov(self, var_param):
+        mu, log_sigma = self._unpack(var_param)
+        return mu, self.df / (self.df - 2) * np.diag(np.exp(2 * log_sigma))
+
+    def _pth_moment(self, var_param, p):
+        df = self.df
+        if df <= p:
+            raise ValueError('df must be greater than p')
+        _, log_sigma = self._unpack(var_param)
+        s2 = np.exp(2 * log_sigma)
+        c = df / (df - 2)
+        if p == 2:
+            return c * np.sum(s2)
+        return c ** 2 * (2 * (df - 1) / (df - 4) * np.sum(s2 ** 2) + np.sum(s2) ** 2)
+
+    def supports_pth_moment(self, p):
+        return p in [2, 4] and p < self.df
+
+    @property
+    def df(self):
+        return self._df
+
+
+# ------------------------------------------------------------------------------------------
+def _chol_from_free(vec, dim):
+    L = np.zeros((dim, dim))
+    L[np.tril_indices(dim)] = vec
+    L[np.diag_indices(dim)] = np.exp(np.diag(L))
+    return L
+
+
+def _free_from_chol(L):
+    dim = L.shape[0]
+    out = np.array(L, dtype=np.float64)
+    out[np.diag_indices(dim)] = np.log(np.diag(L))
+    return out[np.tril_indices(dim)]
+
+
+class FullRankGaussian(_NoiseMixin, ApproximationFamily):
+    """Gaussian with a dense covariance ``Sigma = L L'``; ``var_param = [mu | vec(L)]``.
+
+    Not in the reference: it has no dense *Gaussian* family.  Layout follows the
+    reference's other dense family (``approximations.py:315-319``); ``z = mu + L eps``.
+    """
+
+    _family_id = _lib.FAMILY_FULLRANK_GAUSSIAN
+
+    def __init__(self, dim, seed=1, rng='numpy'):
+        self._init_rng(seed, rng)
+        super().__init__(dim, dim + dim * (dim + 1) // 2, True, True)
+
+    def _device_family(self):
+        return self._family_id, 0.0
+
+    def _base_noise(self, n_samples, seed=None):
+        return self._random_state(seed).randn(n_samples, self.dim)
+
+    def _unpack(self, var_param):
+        var_param = np.asarray(var_param, dtype=np.float64)
+        return var_param[:self.dim], _chol_from_free(var_param[self.dim:], self.dim)
+
+    def pack(self, mu, L):
+        """Flat parameter from a mean and a lower-triangular factor with positive diagonal."""
+        return np.concatenate([np.asarray(mu, dtype=np.float64), _free_from_chol(np.asarray(L))])
+
+    def init_param(self):
+        return self.pack(np.zeros(self.dim), np.exp(2.0) * np.eye(self.dim))
+
+    def sample(self, var_param, n_samples, seed=None):
+        mu, L = self._unpack(var_param)
+        if self._rng_kind == 'philox':
+            noise = _philox_host_copy(self, n_samples, seed)
+        else:
+            noise = self._base_noise(n_samples, seed)
+        return mu + noise @ L.T
+
+    def _entropy(self, var_param):
+        _, L = self._unpack(var_param)
+        return 0.5 * self.dim * (1.0 + _LOG_2PI) + np.sum(np.log(np.diag(L)))
+
+    def _kl(self, var_param0, var_param1):
+        mu0, L0 = self._unpack(var_param0)
+        mu1, L1 = self._unpack(var_param1)
+        A = _sla.solve_triangular(L1, L0, lower=True)
+        dm = _sla.solve_triangular(L1, mu1 - mu0, lower=True)
+        return (0.5 * (np.sum(A * A) + dm @ dm - self.dim)
+                + np.sum(np.log(np.diag(L1))) - np.sum(np.log(np.diag(L0))))
+
+    def log_density(self, var_param, x):
+        mu, L = self._unpack(var_param)
+        e = _sla.solve_triangular(L, (_as_rows(x) - mu).T, lower=True).T
+        return -0.5 * np.sum(e * e, axis=-1) - np.sum(np.log(np.diag(L))) - 0.5 * self.dim * _LOG_2PI
+
+    def mean_and_cov(self, var_param):
+        mu, L = self._unpack(var_param)
+        return mu, L @ L.T
+
+    def _pth_moment(self, var_param, p):
+        _, L = self._unpack(var_param)
+        S = L @ L.T
+        if p == 2:
+            return np.trace(S)
+        return 2 * np.sum(S * S) + np.trace(S) ** 2
+
+    def supports_pth_moment(self, p):
+        return p in [2, 4]
+
+
+class MultivariateT(_NoiseMixin, ApproximationFamily):
+    """Full-rank multivariate t, ``var_param = [mu | vec(chol Sigma)]``
+    (``approximations.py:322-382``, log pdf ``_distributions.py:7-38``)."""
+
+    _family_id = _lib.FAMILY_MULTIVARIATE_T
+
+    def __init__(self, dim, df, seed=1, rng='numpy'):
+        if df <= 2:
+            raise ValueError('df must be greater than 2')
+        self._df = df
+        self._init_rng(seed, rng)
+        if rng != 'numpy':
+            raise NotImplementedError("MultivariateT draws its base noise on the host (rng='numpy')")
+        super().__init__(dim, dim + dim * (dim + 1) // 2, True, False)
+
+    def _device_family(self):
+        return self._family_id, float(self._df)
+
+    def _base_noise(self, n_samples, seed=None):
+        """Chi-square draws FIRST, then the normals (``approximations.py:345-347``)."""
+        rs = self._random_state(seed)
+        chi = rs.chisquare(self.df, n_samples)
+        z = rs.randn(n_samples, self.dim)
+        return chi, z
+
+    def _unpack(self, var_param):
+        var_param = np.asarray(var_param, dtype=np.float64)
+        L = _chol_from_free(var_param[self.dim:], self.dim)
+        return var_param[:self.dim], L
+
+    def init_param(self):
+        return np.concatenate([np.zeros(self.dim),
+                               _free_from_chol(np.sqrt(10.0) * np.eye(self.dim))])
+
+    def sample(self, var_param, n_samples, seed=None):
+        chi, z = self._base_noise(n_samples, seed)
+        mu, L = self._unpack(var_param)
+        root = _sla.sqrtm(L @ L.T).real          # the SYMMETRIC root, :348
+        return mu + (z @ root) / np.sqrt(chi / self.df)[:, np.newaxis]
+
+    def entropy(self, var_param):
+        # df-only constants dropped, as the reference does (:351-354)
+        _, L = self._unpack(var_param)
+        return np.sum(np.log(np.diag(L)))
+
+    def log_density(self, var_param, x):
+        mu, L = self._unpack(var_param)
+        df, d = self.df, self.dim
+        e = _sla.solve_triangular(L, (_as_rows(x) - mu).T, lower=True).T
+        maha = np.sum(e * e, axis=-1)
+        const = (_special.gammaln(0.5 * (df + d)) - _special.gammaln(0.5 * df)
+                 - 0.5 * d * np.log(np.pi * df) - np.sum(np.log(np.diag(L))))
+        return const - 0.5 * (df + d) * np.log1p(maha / df)
+
+    def mean_and_cov(self, var_param):
+        mu, L = self._unpack(var_param)
+        return mu, self.df / (self.df - 2.) * (L @ L.T)
+
+    def _pth_moment(self, var_param, p):
+        df = self.df
+        if df <= p:
+            raise ValueError('df must be greater than p')
+        _, L = self._unpack(var_param)
+        ev = np.linalg.eigvalsh(L @ L.T)
+        c = df / (df - 2)
+        if p == 2:
+            return c * np.sum(ev)
+        return c ** 2 * (2 * (df - 1) / (df - 4) * np.sum(ev ** 2) + np.sum(ev) ** 2)
+
+    def supports_pth_moment(self, p):
+        return p in [2, 4] and p < self.df
+
+    @property
+    def df(self):
+        return self._df
+
+
+def _philox_host_copy(family, n_samples, seed):
+    """Generate Philox noise on the GPU and read it back (host ``sample`` in throughput mode)."""
+    eng = _lib.default_engine()
+    slot = _lib.MAX_SLOTS - 1
+    if seed is None:
+        eng.noise_generate(slot, n_samples, family.dim, family._seed, family._next_philox_stream())
+    else:
+        eng.noise_generate(slot, n_samples, family.dim, seed, 0)
+    return eng.noise_get_host(slot, n_samples, family.dim)

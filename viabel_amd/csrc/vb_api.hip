@@ -1,0 +1,372 @@
+// C ABI of libviabel_hip.so: contexts, noise slots, model binding, synchronous / asynchronous
+// evaluators.  See include/viabel_hip.h for the contract and the reference seam it replaces.
+#include "vb_common.h"
+
+#include <mutex>
+
+namespace vb {
+
+static std::string g_last_error;
+static std::mutex g_err_mutex;
+
+int fail(vb_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) {
+    ctx->last_error = buf;
+  } else {
+    std::lock_guard<std::mutex> lk(g_err_mutex);
+    g_last_error = buf;
+  }
+  return code;
+}
+
+int ensure(vb_ctx* ctx, DeviceBuffer& b, size_t bytes) {
+  if (b.bytes >= bytes && b.ptr) return VB_OK;
+  if (b.ptr) {
+    // buffers may still be referenced by work in flight on the stream
+    VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VB_HIP(ctx, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+  }
+  size_t cap = bytes < 256 ? 256 : bytes;
+  VB_HIP(ctx, hipMalloc(&b.ptr, cap));
+  VB_HIP(ctx, hipMemsetAsync(b.ptr, 0, cap, ctx->stream));
+  b.bytes = cap;
+  return VB_OK;
+}
+
+void prof_begin(vb_ctx* ctx) {
+  if (!ctx->profile) return;
+  if (ctx->prof_used == ctx->prof_events.size()) {
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    ctx->prof_events.push_back({a, b});
+  }
+  (void)hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream);
+}
+
+void prof_end(vb_ctx* ctx) {
+  if (!ctx->profile) return;
+  (void)hipEventRecord(ctx->prof_events[ctx->prof_used].second, ctx->stream);
+  ctx->prof_used++;
+}
+
+static int check_slot(vb_ctx* ctx, int slot) {
+  if (slot < 0 || slot >= VB_MAX_SLOTS)
+    return fail(ctx, VB_ERR_INVALID, "slot %d out of range [0, %d)", slot, VB_MAX_SLOTS);
+  return VB_OK;
+}
+
+static int noise_alloc(vb_ctx* ctx, int slot, int64_t n, int64_t d) {
+  VB_TRY(check_slot(ctx, slot));
+  if (n <= 0 || d <= 0) return fail(ctx, VB_ERR_INVALID, "noise shape must be positive");
+  NoiseSlot& s = ctx->noise[slot];
+  const int64_t ld = round_up(d, 16);   // 128-B aligned rows
+  VB_TRY(ensure(ctx, s.buf, (size_t)n * ld * sizeof(double)));
+  s.n = n;
+  s.d = d;
+  s.ld = ld;
+  return VB_OK;
+}
+
+static int upload_theta(vb_ctx* ctx, ResultSlot& rs, const double* theta, int64_t p) {
+  const size_t need = (size_t)(1 + 2 * p) * sizeof(double);   // [theta staging | value | grad]
+  if (rs.p < p || !rs.host) {
+    if (rs.host) {
+      VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      VB_HIP(ctx, hipHostFree(rs.host));
+      rs.host = nullptr;
+    }
+    VB_HIP(ctx, hipHostMalloc((void**)&rs.host, need, hipHostMallocDefault));
+    rs.p = p;
+  }
+  memcpy(rs.host, theta, (size_t)p * sizeof(double));
+  VB_TRY(ensure(ctx, ctx->theta, (size_t)p * sizeof(double)));
+  VB_HIP(ctx, hipMemcpyAsync(ctx->theta.ptr, rs.host, (size_t)p * sizeof(double),
+                             hipMemcpyHostToDevice, ctx->stream));
+  return VB_OK;
+}
+
+static int download_result(vb_ctx* ctx, ResultSlot& rs, int64_t p) {
+  VB_HIP(ctx, hipMemcpyAsync(rs.host + rs.p, ctx->out.ptr, (size_t)(1 + p) * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  rs.pending = true;
+  return VB_OK;
+}
+
+}  // namespace vb
+
+using namespace vb;
+
+extern "C" {
+
+const char* vb_version(void) { return "viabel_hip 0.1.0 (gfx950)"; }
+
+int vb_device_count(int* count) {
+  if (!count) return fail(nullptr, VB_ERR_INVALID, "count is NULL");
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(nullptr, VB_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  return VB_OK;
+}
+
+int vb_create(int device_id, vb_ctx** out) {
+  if (!out) return fail(nullptr, VB_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(nullptr, VB_ERR_HIP, "no HIP device available (%s)",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= count)
+    return fail(nullptr, VB_ERR_INVALID, "device %d out of range [0, %d)", device_id, count);
+  vb_ctx* ctx = new vb_ctx();
+  ctx->device = device_id;
+  e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    fail(nullptr, VB_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+    delete ctx;
+    return VB_ERR_HIP;
+  }
+  *out = ctx;
+  return VB_OK;
+}
+
+int vb_destroy(vb_ctx* ctx) {
+  if (!ctx) return VB_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  vb_comm_destroy(ctx);
+  for (auto& s : ctx->noise)
+    if (s.buf.ptr) (void)hipFree(s.buf.ptr);
+  for (auto& r : ctx->results)
+    if (r.host) (void)hipHostFree(r.host);
+  if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
+  for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->partials, &ctx->sums, &ctx->out,
+                          &ctx->scratch, &ctx->scratch2, &ctx->rowvec})
+    if (b->ptr) (void)hipFree(b->ptr);
+  for (auto& ev : ctx->prof_events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return VB_OK;
+}
+
+const char* vb_last_error(vb_ctx* ctx) {
+  if (ctx) return ctx->last_error.c_str();
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  return g_last_error.c_str();
+}
+
+int vb_device_info(vb_ctx* ctx, char* name, size_t name_len, int* n_cu, uint64_t* hbm_bytes) {
+  if (!ctx) return VB_ERR_INVALID;
+  if (name && name_len) snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (uint64_t)ctx->prop.totalGlobalMem;
+  return VB_OK;
+}
+
+int vb_sync(vb_ctx* ctx) {
+  if (!ctx) return VB_ERR_INVALID;
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VB_OK;
+}
+
+// ---- noise ---------------------------------------------------------------------------------
+int vb_noise_set_host(vb_ctx* ctx, int slot, const double* host, int64_t n, int64_t d) {
+  if (!ctx || !host) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(noise_alloc(ctx, slot, n, d));
+  NoiseSlot& s = ctx->noise[slot];
+  VB_HIP(ctx, hipMemcpy2DAsync(s.buf.ptr, (size_t)s.ld * sizeof(double), host,
+                               (size_t)d * sizeof(double), (size_t)d * sizeof(double), (size_t)n,
+                               hipMemcpyHostToDevice, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller keeps ownership of `host`
+  return VB_OK;
+}
+
+int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed, uint64_t stream,
+                      int64_t row_offset, int64_t n, int64_t d) {
+  if (!ctx) return VB_ERR_INVALID;
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(noise_alloc(ctx, slot, n, d));
+  NoiseSlot& s = ctx->noise[slot];
+  return rng_fill(ctx, (double*)s.buf.ptr, s.ld, kind, df, seed, stream, row_offset, n, d);
+}
+
+int vb_noise_get_host(vb_ctx* ctx, int slot, double* host, int64_t n, int64_t d) {
+  if (!ctx || !host) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  NoiseSlot& s = ctx->noise[slot];
+  if (!s.buf.ptr || n > s.n || d != s.d)
+    return fail(ctx, VB_ERR_STATE, "noise slot %d does not hold a %lld x %lld matrix", slot,
+                (long long)n, (long long)d);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_HIP(ctx, hipMemcpy2DAsync(host, (size_t)d * sizeof(double), s.buf.ptr,
+                               (size_t)s.ld * sizeof(double), (size_t)d * sizeof(double), (size_t)n,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VB_OK;
+}
+
+// ---- model ---------------------------------------------------------------------------------
+int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams, size_t n_dparams,
+                 const int64_t* iparams, size_t n_iparams) {
+  if (!ctx) return VB_ERR_INVALID;
+  if (dim <= 0) return fail(ctx, VB_ERR_INVALID, "model dimension must be positive");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  const double kLog2Pi = 1.8378770664093454835606594728112;
+  ModelDev m;
+  m.id = model_id;
+  m.dim = (int)dim;
+  std::vector<double> dev;   // what is uploaded
+  if (model_id == VB_MODEL_GAUSS_DIAG) {
+    if (n_dparams != (size_t)(2 * dim) || !dparams)
+      return fail(ctx, VB_ERR_INVALID, "gauss_diag expects dparams = [mean(D) | stdev(D)]");
+    dev.resize(2 * dim);
+    double c0 = -0.5 * dim * kLog2Pi;
+    for (int64_t i = 0; i < dim; ++i) {
+      const double sd = dparams[dim + i];
+      if (!(sd > 0.0)) return fail(ctx, VB_ERR_INVALID, "gauss_diag stdev must be positive");
+      dev[i] = dparams[i];
+      dev[dim + i] = 1.0 / (sd * sd);
+      c0 -= log(sd);
+    }
+    m.c0 = c0;
+  } else if (model_id == VB_MODEL_FUNNEL) {
+    if (n_dparams != 1 || n_iparams != 1 || !dparams || !iparams)
+      return fail(ctx, VB_ERR_INVALID, "funnel expects dparams = [log_sigma_stdev], iparams = [scale_index]");
+    if (iparams[0] < 0 || iparams[0] >= dim || !(dparams[0] > 0.0))
+      return fail(ctx, VB_ERR_INVALID, "funnel scale_index / log_sigma_stdev out of range");
+    m.k = (int)iparams[0];
+    m.tau = dparams[0];
+    m.c0 = -log(m.tau) - 0.5 * kLog2Pi - 0.5 * (double)(dim - 1) * kLog2Pi;
+  } else if (model_id == VB_MODEL_GAUSS_FULL) {
+    if (n_dparams != (size_t)(dim + dim * dim + 1) || !dparams)
+      return fail(ctx, VB_ERR_INVALID, "gauss_full expects dparams = [mean(D) | P(DxD) | logdet P]");
+    dev.assign(dparams, dparams + dim + dim * dim);
+    m.c0 = 0.5 * dparams[dim + dim * dim] - 0.5 * dim * kLog2Pi;
+  } else {
+    return fail(ctx, VB_ERR_INVALID, "unknown model id %d", model_id);
+  }
+  if (!dev.empty()) {
+    VB_TRY(ensure(ctx, ctx->model_params, dev.size() * sizeof(double)));
+    VB_HIP(ctx, hipMemcpyAsync(ctx->model_params.ptr, dev.data(), dev.size() * sizeof(double),
+                               hipMemcpyHostToDevice, ctx->stream));
+    VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m.p0 = (const double*)ctx->model_params.ptr;
+    m.p1 = m.p0 + dim;
+  }
+  ctx->model = m;
+  return VB_OK;
+}
+
+int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* out_host) {
+  if (!ctx || !x_host || !out_host) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (d != ctx->model.dim)
+    return fail(ctx, VB_ERR_INVALID, "x has %lld columns, model dimension is %d", (long long)d,
+                ctx->model.dim);
+  if (n <= 0) return fail(ctx, VB_ERR_INVALID, "n must be positive");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t ld = round_up(d, 16);
+  VB_TRY(ensure(ctx, ctx->scratch, (size_t)n * ld * sizeof(double)));
+  VB_TRY(ensure(ctx, ctx->scratch2, (size_t)n * sizeof(double)));
+  double* xd = (double*)ctx->scratch.ptr;
+  double* od = (double*)ctx->scratch2.ptr;
+  VB_HIP(ctx, hipMemcpy2DAsync(xd, (size_t)ld * sizeof(double), x_host, (size_t)d * sizeof(double),
+                               (size_t)d * sizeof(double), (size_t)n, hipMemcpyHostToDevice,
+                               ctx->stream));
+  VB_TRY(model_logp_rows(ctx, xd, ld, n, d, od));
+  VB_HIP(ctx, hipMemcpyAsync(out_host, od, (size_t)n * sizeof(double), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VB_OK;
+}
+
+// ---- ExclusiveKL, mean field ------------------------------------------------------------------
+static int mf_call(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int family,
+                   double df, const double* theta, unsigned flags, int cv_mode, ResultSlot& rs) {
+  if (!ctx || !theta) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(upload_theta(ctx, rs, theta, 2 * d));
+  VB_TRY(mf_elbo_grad_enqueue(ctx, ctx->noise[slot], n, d, n_total, family, df, flags, cv_mode,
+                              nullptr, 0, 0.0));
+  return download_result(ctx, rs, 2 * d);
+}
+
+int vb_elbo_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
+                           int family, double df, const double* theta, unsigned flags,
+                           int cv_mode, double* value, double* grad) {
+  if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  ResultSlot& rs = ctx->sync_result;
+  VB_TRY(mf_call(ctx, slot, n, d, n_total, family, df, theta, flags, cv_mode, rs));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rs.pending = false;
+  *value = rs.host[rs.p];
+  memcpy(grad, rs.host + rs.p + 1, (size_t)(2 * d) * sizeof(double));
+  return VB_OK;
+}
+
+int vb_elbo_grad_meanfield_async(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
+                                 int family, double df, const double* theta, unsigned flags,
+                                 int cv_mode, int rslot) {
+  if (!ctx) return VB_ERR_INVALID;
+  VB_TRY(check_slot(ctx, rslot));
+  return mf_call(ctx, slot, n, d, n_total, family, df, theta, flags, cv_mode, ctx->results[rslot]);
+}
+
+int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p) {
+  if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, rslot));
+  ResultSlot& rs = ctx->results[rslot];
+  if (!rs.host || !rs.pending || p > rs.p)
+    return fail(ctx, VB_ERR_STATE, "result slot %d holds no pending result of size %lld", rslot,
+                (long long)p);
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *value = rs.host[rs.p];
+  memcpy(grad, rs.host + rs.p + 1, (size_t)p * sizeof(double));
+  return VB_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------------------
+int vb_profile_enable(vb_ctx* ctx, int on) {
+  if (!ctx) return VB_ERR_INVALID;
+  ctx->profile = on != 0;
+  return VB_OK;
+}
+
+int vb_profile_read(vb_ctx* ctx, int64_t* launches, double* total_ms, int reset) {
+  if (!ctx || !launches || !total_ms) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double ms = 0.0;
+  for (size_t i = 0; i < ctx->prof_used; ++i) {
+    float t = 0.f;
+    VB_HIP(ctx, hipEventElapsedTime(&t, ctx->prof_events[i].first, ctx->prof_events[i].second));
+    ms += t;
+  }
+  *launches = (int64_t)ctx->prof_used;
+  *total_ms = ms;
+  if (reset) ctx->prof_used = 0;
+  return VB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Multi-GPU: the Monte-Carlo axis is sharded over ranks (one process per GPU); the only exchange
+// is one sum all-reduce of the fp64 partial-sum vector per objective call, over RCCL / xGMI.
+// The reference has no distributed code at all; this is the natural sharding of
+// `mean_n phi(eps_n; theta)` (objectives.py:161, :216, :233, :255, :268).
+#include "vb_common.h"
+
+#include <rccl/rccl.h>
+
+namespace vb {
+
+int comm_allreduce_sum(vb_ctx* ctx, double* buf, size_t count) {
+  if (!ctx->comm) return VB_OK;
+  ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm,
+                                 ctx->stream);
+  if (r != ncclSuccess)
+    return fail(ctx, VB_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+  return VB_OK;
+}
+
+}  // namespace vb
+
+using namespace vb;
+
+extern "C" {
+
+int vb_comm_unique_id(char id[VB_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) <= VB_COMM_ID_BYTES, "ncclUniqueId larger than VB_COMM_ID_BYTES");
+  if (!id) return fail(nullptr, VB_ERR_INVALID, "id is NULL");
+  ncclUniqueId u;
+  ncclResult_t r = ncclGetUniqueId(&u);
+  if (r != ncclSuccess)
+    return fail(nullptr, VB_ERR_COMM, "ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+  memset(id, 0, VB_COMM_ID_BYTES);
+  memcpy(id, &u, sizeof u);
+  return VB_OK;
+}
+
+int vb_comm_init(vb_ctx* ctx, const char id[VB_COMM_ID_BYTES], int n_ranks, int rank) {
+  if (!ctx || !id) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+    return fail(ctx, VB_ERR_INVALID, "rank %d / n_ranks %d invalid", rank, n_ranks);
+  if (ctx->comm) return fail(ctx, VB_ERR_STATE, "communicator already attached");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclComm_t c;
+  ncclResult_t r = ncclCommInitRank(&c, n_ranks, u, rank);
+  if (r != ncclSuccess)
+    return fail(ctx, VB_ERR_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+  ctx->comm = c;
+  ctx->n_ranks = n_ranks;
+  ctx->rank = rank;
+  return VB_OK;
+}
+
+int vb_comm_destroy(vb_ctx* ctx) {
+  if (!ctx || !ctx->comm) return VB_OK;
+  ncclCommDestroy((ncclComm_t)ctx->comm);
+  ctx->comm = nullptr;
+  ctx->n_ranks = 1;
+  ctx->rank = 0;
+  return VB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""Target models.
+
+Mirrors ``viabel/models.py`` (``Model`` ``:11-77``).  The reference model is an arbitrary
+Python callable differentiated by autograd; a GPU engine needs targets whose log density
+and derivatives exist as device code, so the hot path accepts
+:class:`DeviceModel` instances.  Calling a device model evaluates ``f(x_n)`` on the GPU
+through the C ABI (``vb_model_logp``) -- same contract as ``Model.__call__``
+(``models.py:27-39``): ``(N, D) -> (N,)``, and ``(D,)`` is promoted to one row
+(``viabel/tests/test_models.py:14-15``).
+"""
+import numpy as np
+
+from . import _lib
+
+__all__ = ['Model', 'DeviceModel', 'GaussianModel', 'FunnelModel', 'CorrelatedGaussianModel']
+
+
+class Model(object):
+    """Base class for representing a model (``viabel/models.py:11-77``).
+
+    A plain ``Model(log_density)`` wraps a host callable.  It can be *called* (diagnostics),
+    but the HIP objectives need a :class:`DeviceModel`; handing them a host callable raises
+    ``TypeError`` rather than falling back to a CPU path.
+    """
+
+    def __init__(self, log_density):
+        self._log_density = log_density
+
+    def __call__(self, model_param):
+        return self._log_density(model_param)
+
+    def constrain(self, model_param):
+        raise NotImplementedError()
+
+    @property
+    def supports_tempering(self):
+        return False
+
+    def set_inverse_temperature(self, inverse_temp):
+        raise NotImplementedError()
+
+
+class DeviceModel(Model):
+    """A target whose log density / gradient / Hessian products are HIP device code."""
+
+    def __init__(self, dim):
+        self._dim = int(dim)
+        super().__init__(self._device_log_density)
+
+    @property
+    def dim(self):
+        return self._dim
+
+    def device_spec(self):
+        """``(model_id, dim, dparams, iparams)`` for ``vb_set_model``."""
+        raise NotImplementedError()
+
+    def _device_log_density(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        one = x.ndim == 1
+        if one:
+            x = x[np.newaxis, :]
+        if x.ndim != 2 or x.shape[1] != self._dim:
+            raise ValueError('model_param must have shape (N, {0}) or ({0},)'.format(self._dim))
+        eng = _lib.default_engine()
+        eng.set_model(self.device_spec())
+        return eng.model_logp(x)
+
+
+class GaussianModel(DeviceModel):
+    """``sum_d norm.logpdf(x_d; mean_d, stdev_d)`` -- the target of the reference's own
+    objective / convenience tests (``tests/test_objectives.py:15-19``)."""
+
+    def __init__(self, mean, stdev):
+        mean = np.asarray(mean, dtype=np.float64).ravel()
+        stdev = np.broadcast_to(np.asarray(stdev, dtype=np.float64).ravel(), mean.shape).copy()
+        if np.any(stdev <= 0):
+            raise ValueError('stdev must be positive')
+        self.mean, self.stdev = mean, stdev
+        super().__init__(mean.size)
+
+    def device_spec(self):
+        return (_lib.MODEL_GAUSS_DIAG, self._dim, np.concatenate([self.mean, self.stdev]),
+                np.zeros(0, dtype=np.int64))
+
+
+class FunnelModel(DeviceModel):
+    """D-dimensional funnel generalising ``docs/source/quickstart.ipynb:23-29``.
+
+    Coordinate ``scale_index`` (default: the last; index 1 at D=2 as in the notebook) is the
+    log-scale ``v ~ N(0, log_sigma_stdev)``; every other coordinate is ``N(0, exp(v))``.
+    """
+
+    def __init__(self, dim, scale_index=None, log_sigma_stdev=1.0):
+        dim = int(dim)
+        if dim < 2:
+            raise ValueError('the funnel needs at least 2 dimensions')
+        self.scale_index = dim - 1 if scale_index is None else int(scale_index)
+        if not 0 <= self.scale_index < dim:
+            raise ValueError('scale_index out of range')
+        if log_sigma_stdev <= 0:
+            raise ValueError('log_sigma_stdev must be positive')
+        self.log_sigma_stdev = float(log_sigma_stdev)
+        super().__init__(dim)
+
+    def device_spec(self):
+        return (_lib.MODEL_FUNNEL, self._dim, np.array([self.log_sigma_stdev]),
+                np.array([self.scale_index], dtype=np.int64))
+
+
+class CorrelatedGaussianModel(DeviceModel):
+    """``N(mean, covariance)`` with a dense covariance (target of the full-rank configs)."""
+
+    def __init__(self, mean, covariance=None, precision=None):
+        mean = np.asarray(mean, dtype=np.float64).ravel()
+        if (covariance is None) == (precision is None):
+            raise ValueError('give exactly one of covariance / precision')
+        if precision is None:
+            precision = np.linalg.inv(np.asarray(covariance, dtype=np.float64))
+        precision = np.asarray(precision, dtype=np.float64)
+        if precision.shape != (mean.size, mean.size):
+            raise ValueError('precision must be (D, D)')
+        self.mean = mean
+        self.precision = 0.5 * (precision + precision.T)
+        sign, self.logdet_precision = np.linalg.slogdet(self.precision)
+        if sign <= 0:
+            raise ValueError('precision must be positive definite')
+        super().__init__(mean.size)
+
+    def device_spec(self):
+        return (_lib.MODEL_GAUSS_FULL, self._dim,
+                np.concatenate([self.mean, self.precision.ravel(), [self.logdet_precision]]),
+                np.zeros(0, dtype=np.int64))

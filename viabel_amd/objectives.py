@@ -1,0 +1,221 @@
+"""Variational objectives evaluated by the HIP engine.
+
+Same classes, constructor signatures, properties and error behaviour as
+``viabel/objectives.py``; ``objective(var_param)`` returns ``(value, grad)`` exactly as the
+reference's ``VariationalObjective.__call__`` (``:32-44``) does, but the whole Monte-Carlo
+estimator -- sampling, model log density and gradient, entropy / log q, control variates,
+the mean over samples -- runs in hand-written gfx950 kernels behind the C ABI of
+``include/viabel_hip.h``.  There is no CPU path: without the shared library or a GPU the
+call raises.
+
+Multi-GPU: when a communicator is attached to the engine (``viabel_amd.distributed``), each
+rank evaluates its contiguous block of the ``num_mc_samples`` rows and the partial sums are
+all-reduced on the device before the epilogue; every rank returns the same ``(value, grad)``.
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+from . import _lib
+from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT
+from .models import DeviceModel
+
+__all__ = [
+    'VariationalObjective',
+    'StochasticVariationalObjective',
+    'ExclusiveKL',
+    'DISInclusiveKL',
+    'AlphaDivergence'
+]
+
+_NOISE_SLOT = 0
+
+
+def shard_rows(n, n_ranks, rank):
+    """Contiguous block ``[begin, end)`` of the Monte-Carlo axis owned by ``rank``."""
+    base, extra = divmod(n, n_ranks)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+class VariationalObjective(ABC):
+    """A variational objective to minimise (``viabel/objectives.py:17-79``)."""
+
+    def __init__(self, approx, model):
+        self._approx = approx
+        self._model = model
+        self._objective_and_grad = None
+        self._update_objective_and_grad()
+
+    def __call__(self, var_param):
+        if self._objective_and_grad is None:
+            raise RuntimeError("no objective and gradient available")
+        return self._objective_and_grad(var_param)
+
+    @abstractmethod
+    def _update_objective_and_grad(self):
+        """Rebuild the evaluator after ``approx`` / ``model`` / a setting changed."""
+
+    def update(self, var_param, direction):
+        return var_param - direction
+
+    @property
+    def approx(self):
+        return self._approx
+
+    @approx.setter
+    def approx(self, value):
+        self._approx = value
+        self._update_objective_and_grad()
+
+    @property
+    def model(self):
+        return self._model
+
+    @model.setter
+    def model(self, value):
+        self._model = value
+        self._update_objective_and_grad()
+
+    # -- engine plumbing shared by the concrete objectives --------------------------------------
+    def _engine(self):
+        return _lib.default_engine()
+
+    def _require_device_model(self):
+        if not isinstance(self._model, DeviceModel):
+            raise TypeError(
+                'the HIP engine needs a device-resident model (viabel_amd.models.DeviceModel: '
+                'GaussianModel, FunnelModel, CorrelatedGaussianModel); got %r. Arbitrary Python '
+                'log densities cannot run on the GPU and there is no CPU fallback.'
+                % type(self._model).__name__)
+        if self._model.dim != self._approx.dim:
+            raise ValueError('model dimension {} != approximation dimension {}'.format(
+                self._model.dim, self._approx.dim))
+
+    def _stage_noise(self, eng, n_samples, slot=_NOISE_SLOT, seed=None):
+        """Put this call's base noise into a device slot; returns (n_local, n_total).
+
+        numpy mode consumes exactly the draws the reference's ``approx.sample`` would
+        (``approximations.py:212-216``) and uploads this rank's row block; philox mode
+        generates the rank's rows on the device (global row index in the counter).
+        """
+        approx = self._approx
+        begin, end = shard_rows(n_samples, eng.n_ranks, eng.rank)
+        if approx.rng == 'philox':
+            if seed is None:
+                eng.noise_generate(slot, end - begin, approx.dim, approx._seed,
+                                   approx._next_philox_stream(), row_offset=begin)
+            else:
+                eng.noise_generate(slot, end - begin, approx.dim, seed, 0, row_offset=begin)
+        else:
+            noise = approx._base_noise(n_samples, seed)
+            eng.noise_set_host(slot, noise[begin:end])
+        return end - begin, n_samples
+
+
+class StochasticVariationalObjective(VariationalObjective):
+    """Objective approximated by Monte Carlo (``viabel/objectives.py:82-105``)."""
+
+    def __init__(self, approx, model, num_mc_samples):
+        self._num_mc_samples = num_mc_samples
+        super().__init__(approx, model)
+
+    @property
+    def num_mc_samples(self):
+        return self._num_mc_samples
+
+    @num_mc_samples.setter
+    def num_mc_samples(self, value):
+        self._num_mc_samples = value
+        self._update_objective_and_grad()
+
+
+class ExclusiveKL(StochasticVariationalObjective):
+    """Exclusive KL (negative ELBO) with the reparameterisation gradient and, optionally,
+    the control variates of Miller et al. (``viabel/objectives.py:108-277``)."""
+
+    def __init__(self, approx, model, num_mc_samples, use_path_deriv=False,
+                 hessian_approx_method=None):
+        self._use_path_deriv = use_path_deriv
+        if hessian_approx_method in [None, 'full', 'mean_only', 'loo_diag_approx',
+                                     'loo_direct_approx']:
+            self.hessian_approx_method = hessian_approx_method
+        else:
+            raise ValueError("Name of approximation must be one of 'full', 'mean_only', "
+                             "'loo_diag_approx', 'loo_direct_approx' or None object.")
+        super().__init__(approx, model, num_mc_samples)
+
+    def _update_objective_and_grad(self):
+        approx = self.approx
+        self._require_device_model()
+        flags = _lib.FLAG_PATH_DERIV if self._use_path_deriv else 0
+        cv_mode = _lib.CV_MODES[self.hessian_approx_method]
+
+        if isinstance(approx, (MFGaussian, MFStudentT)):
+            def objective_and_grad(var_param):
+                var_param = np.asarray(var_param, dtype=np.float64)
+                if var_param.shape != (approx.var_param_dim,):
+                    raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+                eng = self._engine()
+                eng.set_model(self.model.device_spec())
+                n_local, n_total = self._stage_noise(eng, self.num_mc_samples)
+                family, df = approx._device_family()
+                return eng.elbo_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, var_param, family,
+                                               df=df, flags=flags, cv_mode=cv_mode, n_total=n_total)
+        elif isinstance(approx, FullRankGaussian):
+            if cv_mode != 0:
+                raise NotImplementedError(
+                    'the RGE control variates treat var_param as [mean | log-scale] '
+                    '(objectives.py:196-198) and do not apply to a dense-covariance family')
+
+            def objective_and_grad(var_param):
+                var_param = np.asarray(var_param, dtype=np.float64)
+                if var_param.shape != (approx.var_param_dim,):
+                    raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+                eng = self._engine()
+                eng.set_model(self.model.device_spec())
+                n_local, n_total = self._stage_noise(eng, self.num_mc_samples)
+                return eng.elbo_grad_fullrank(_NOISE_SLOT, n_local, approx.dim, var_param,
+                                              flags=flags, n_total=n_total)
+        else:
+            raise NotImplementedError(
+                'ExclusiveKL on the HIP engine supports MFGaussian, MFStudentT and '
+                'FullRankGaussian; got {}'.format(type(approx).__name__))
+        self._objective_and_grad = objective_and_grad
+
+
+class DISInclusiveKL(StochasticVariationalObjective):
+    """Inclusive KL by distilled importance sampling (``viabel/objectives.py:280-416``)."""
+
+    def __init__(self, approx, model, num_mc_samples, ess_target,
+                 temper_prior, temper_prior_params, use_resampling=True,
+                 num_resampling_batches=1, w_clip_threshold=10):
+        self._ess_target = ess_target
+        self._w_clip_threshold = w_clip_threshold
+        self._max_bisection_its = 50
+        self._max_eps = self._eps = 1
+        self._use_resampling = use_resampling
+        self._num_resampling_batches = num_resampling_batches
+        self._resampling_batch_size = max(1, self._ess_target // num_resampling_batches)
+        self._objective_step = 0
+        self._temper_prior = temper_prior
+        self._temper_prior_params = np.asarray(temper_prior_params, dtype=np.float64)
+        super().__init__(approx, model, num_mc_samples)
+
+    def _update_objective_and_grad(self):
+        raise NotImplementedError('DISInclusiveKL device path: see viabel_amd/objectives_dis.py')
+
+
+class AlphaDivergence(StochasticVariationalObjective):
+    """Log of the alpha-divergence (``viabel/objectives.py:419-463``)."""
+
+    def __init__(self, approx, model, num_mc_samples, alpha):
+        self._alpha = alpha
+        super().__init__(approx, model, num_mc_samples)
+
+    @property
+    def alpha(self):
+        return self._alpha
+
+    def _update_objective_and_grad(self):
+        raise NotImplementedError('AlphaDivergence device path not built yet')
