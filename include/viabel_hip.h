@@ -107,6 +107,14 @@ int vb_elbo_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t 
 int vb_elbo_grad_meanfield_async(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
                                  int family, double df, const double* theta, unsigned flags,
                                  int cv_mode, int rslot);
+/* `count` independent evaluations in one call: evaluation b streams noise slot slots[b] with the
+ * parameter thetas[b * 2d ...] (row-major count x 2d) and lands in result slot rslots[b].  Up to 16
+ * evaluations share one launch of each kernel (blockIdx.y), which amortises launch latency and
+ * fills the chip; use it to evaluate the objective at many parameter vectors / noise draws at
+ * once (multi-start fits, gradient-variance estimates, line searches).                      */
+int vb_elbo_grad_meanfield_batch_async(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t d,
+                                       int64_t n_total, int family, double df, const double* thetas,
+                                       unsigned flags, int cv_mode, const int* rslots);
 int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p);
 
 /* ---- multi-GPU: Monte-Carlo axis sharded, one RCCL all-reduce of the partial sums --- */
@@ -116,11 +124,12 @@ int vb_comm_init(vb_ctx* ctx, const char id[VB_COMM_ID_BYTES], int n_ranks, int 
 int vb_comm_destroy(vb_ctx* ctx);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernel ----------
- * When enabled, every launch of the accumulation kernel is bracketed by HIP events on
- * the context's stream; vb_profile_read returns launches and total milliseconds since the
+ * When enabled, every launch of the accumulation kernel carries a start/stop event pair
+ * (hipExtLaunchKernel: the kernel's own begin/end timestamps on the context's stream);
+ * vb_profile_read returns launches, evaluations covered and total milliseconds since the
  * last reset.                                                                           */
 int vb_profile_enable(vb_ctx* ctx, int on);
-int vb_profile_read(vb_ctx* ctx, int64_t* launches, double* total_ms, int reset);
+int vb_profile_read(vb_ctx* ctx, int64_t* launches, int64_t* evals, double* total_ms, int reset);
 
 #ifdef __cplusplus
 }

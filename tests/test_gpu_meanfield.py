@@ -131,7 +131,8 @@ def test_rng_stream_advances_like_reference(vb):
         value, grad = obj(theta)
         ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omod.GaussDiag(np.zeros(D), np.ones(D)),
                                    theta, rs.randn(N, D))
-        assert G.rel_err(value, ov) < 1e-12 and G.rel_err(grad, og) < 1e-11
+        # the ELBO is ~0 here (q == p): compare on the scale of its two terms (entropy ~ 22.7)
+        assert abs(value - ov) < 1e-12 * 22.7 and G.rel_err(grad, og) < 1e-11
 
 
 def test_float32_theta_accepted(vb):
@@ -211,6 +212,51 @@ def test_async_pipeline_matches_sync(vb):
         v, g = eng.result_get(s, 2 * D)
         assert v == sync[s][0]
         np.testing.assert_array_equal(g, sync[s][1])     # deterministic reductions: bitwise
+
+
+@pytest.mark.parametrize('count,D,N', [(16, 1024, 4096), (5, 130, 77), (33, 64, 256)])
+def test_batch_matches_single(vb, count, D, N):
+    """`count` evaluations sharing one launch of each kernel == the same evaluations one by one."""
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    model = vb.FunnelModel(D, 3)
+    eng.set_model(model.device_spec())
+    rng = np.random.RandomState(count)
+    thetas = np.stack([_theta(D, rng) for _ in range(count)])
+    slots = [30 + (b % 20) for b in range(count)]
+    for s in sorted(set(slots)):
+        eng.noise_generate(s, N, D, seed=11, stream=s)
+    single = [eng.elbo_grad_meanfield(slots[b], N, D, thetas[b], _lib.FAMILY_MF_GAUSSIAN,
+                                      flags=_lib.FLAG_PATH_DERIV) for b in range(count)]
+    eng.elbo_grad_meanfield_batch_async(slots, N, D, thetas, _lib.FAMILY_MF_GAUSSIAN,
+                                        list(range(count)), flags=_lib.FLAG_PATH_DERIV)
+    eng.sync()
+    for b in range(count):
+        v, g = eng.result_get(b, 2 * D)
+        # a batch may pick a different row-block split than a single call: not bitwise
+        assert abs(v - single[b][0]) < 1e-12 * abs(single[b][0])
+        np.testing.assert_allclose(g, single[b][1], rtol=0, atol=1e-12 * np.max(np.abs(single[b][1])))
+    noise = eng.noise_get_host(slots[0], N, D)
+    ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omod.Funnel(D, 3), thetas[0], noise, True)
+    v, g = eng.result_get(0, 2 * D)
+    assert G.rel_err(v, ov) < 1e-12 and G.rel_err(g, og) < 1e-11
+
+
+def test_result_slot_reuse_is_safe(vb):
+    """Re-staging a result slot waits for the evaluation that last used it (different thetas)."""
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    D, N = 1024, 4096
+    eng.set_model(vb.FunnelModel(D).device_spec())
+    eng.noise_generate(40, N, D, seed=2, stream=0)
+    rng = np.random.RandomState(8)
+    thetas = [_theta(D, rng) for _ in range(6)]
+    want = [eng.elbo_grad_meanfield(40, N, D, t, _lib.FAMILY_MF_GAUSSIAN) for t in thetas]
+    got = []
+    for t in thetas:            # same result slot every time, no explicit sync in between
+        eng.elbo_grad_meanfield_async(40, N, D, t, _lib.FAMILY_MF_GAUSSIAN, rslot=7)
+    v, g = eng.result_get(7, 2 * D)
+    assert v == want[-1][0] and np.array_equal(g, want[-1][1])
 
 
 def test_full_size_properties(vb):

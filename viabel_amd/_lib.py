@@ -53,12 +53,17 @@ SIGNATURES = {
     'vb_elbo_grad_meanfield_async': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                     ctypes.c_int64, ctypes.c_int, ctypes.c_double,
                                                     _c_double_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int]),
+    'vb_elbo_grad_meanfield_batch_async': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                                          ctypes.c_int, ctypes.c_double, _c_double_p,
+                                                          ctypes.c_uint, ctypes.c_int,
+                                                          ctypes.POINTER(ctypes.c_int)]),
     'vb_result_get': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64]),
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_destroy': (ctypes.c_int, [_ctx_p]),
     'vb_profile_enable': (ctypes.c_int, [_ctx_p, ctypes.c_int]),
-    'vb_profile_read': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int64),
+    'vb_profile_read': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                        ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
 }
 
@@ -219,6 +224,19 @@ class Engine:
             self._ctx, slot, n, d, n if n_total is None else n_total, family, float(df), _dptr(theta),
             flags, cv_mode, rslot))
 
+    def elbo_grad_meanfield_batch_async(self, slots, n, d, thetas, family, rslots, df=0.0, flags=0,
+                                        cv_mode=0, n_total=None):
+        """Enqueue ``len(slots)`` independent evaluations; ``thetas`` is ``(count, 2d)``."""
+        thetas = _f64(thetas)
+        count = len(slots)
+        if thetas.shape != (count, 2 * d):
+            raise ValueError('thetas must have shape (count, 2 * d)')
+        c_slots = (ctypes.c_int * count)(*slots)
+        c_rslots = (ctypes.c_int * count)(*rslots)
+        self._check(self._lib.vb_elbo_grad_meanfield_batch_async(
+            self._ctx, count, c_slots, n, d, n if n_total is None else n_total, family, float(df),
+            _dptr(thetas), flags, cv_mode, c_rslots))
+
     def result_get(self, rslot, p):
         value = ctypes.c_double(0.0)
         grad = np.empty(p, dtype=np.float64)
@@ -249,9 +267,11 @@ class Engine:
 
     def profile_read(self, reset=True):
         n = ctypes.c_int64(0)
+        ev = ctypes.c_int64(0)
         ms = ctypes.c_double(0.0)
-        self._check(self._lib.vb_profile_read(self._ctx, ctypes.byref(n), ctypes.byref(ms), int(reset)))
-        return n.value, ms.value
+        self._check(self._lib.vb_profile_read(self._ctx, ctypes.byref(n), ctypes.byref(ev), ctypes.byref(ms),
+                                              int(reset)))
+        return n.value, ev.value, ms.value
 
 
 _default_engine = None

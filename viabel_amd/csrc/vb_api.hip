@@ -40,7 +40,8 @@ int ensure(vb_ctx* ctx, DeviceBuffer& b, size_t bytes) {
   return VB_OK;
 }
 
-void prof_begin(vb_ctx* ctx) {
+void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals) {
+  *ev0 = *ev1 = nullptr;
   if (!ctx->profile) return;
   if (ctx->prof_used == ctx->prof_events.size()) {
     hipEvent_t a, b;
@@ -48,13 +49,10 @@ void prof_begin(vb_ctx* ctx) {
     (void)hipEventCreate(&b);
     ctx->prof_events.push_back({a, b});
   }
-  (void)hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream);
-}
-
-void prof_end(vb_ctx* ctx) {
-  if (!ctx->profile) return;
-  (void)hipEventRecord(ctx->prof_events[ctx->prof_used].second, ctx->stream);
+  *ev0 = ctx->prof_events[ctx->prof_used].first;
+  *ev1 = ctx->prof_events[ctx->prof_used].second;
   ctx->prof_used++;
+  ctx->prof_evals += evals;
 }
 
 static int check_slot(vb_ctx* ctx, int slot) {
@@ -68,14 +66,21 @@ static int noise_alloc(vb_ctx* ctx, int slot, int64_t n, int64_t d) {
   if (n <= 0 || d <= 0) return fail(ctx, VB_ERR_INVALID, "noise shape must be positive");
   NoiseSlot& s = ctx->noise[slot];
   const int64_t ld = round_up(d, 16);   // 128-B aligned rows
+  const bool had = s.buf.ptr != nullptr && s.buf.bytes >= (size_t)n * ld * sizeof(double);
   VB_TRY(ensure(ctx, s.buf, (size_t)n * ld * sizeof(double)));
+  // invariant relied on by the streaming kernel: the pad columns [d, ld) hold zeros
+  if (had && (s.d != d || s.ld != ld))
+    VB_HIP(ctx, hipMemsetAsync(s.buf.ptr, 0, s.buf.bytes, ctx->stream));
   s.n = n;
   s.d = d;
   s.ld = ld;
   return VB_OK;
 }
 
-static int upload_theta(vb_ctx* ctx, ResultSlot& rs, const double* theta, int64_t p) {
+// Stage theta in the result slot's pinned, device-mapped buffer: the prep kernel reads it from
+// there and the finalize / epilogue kernel writes [value | grad] back into the same buffer, so an
+// evaluation needs no separate copy commands on the stream.
+static int stage_theta(vb_ctx* ctx, ResultSlot& rs, const double* theta, int64_t p) {
   const size_t need = (size_t)(1 + 2 * p) * sizeof(double);   // [theta staging | value | grad]
   if (rs.p < p || !rs.host) {
     if (rs.host) {
@@ -83,20 +88,28 @@ static int upload_theta(vb_ctx* ctx, ResultSlot& rs, const double* theta, int64_
       VB_HIP(ctx, hipHostFree(rs.host));
       rs.host = nullptr;
     }
-    VB_HIP(ctx, hipHostMalloc((void**)&rs.host, need, hipHostMallocDefault));
+    VB_HIP(ctx, hipHostMalloc((void**)&rs.host, need, hipHostMallocMapped));
+    VB_HIP(ctx, hipHostGetDevicePointer((void**)&rs.dev, rs.host, 0));
     rs.p = p;
   }
+  if (rs.batch_id > ctx->batch_done) {   // the evaluation that last used this slot may still be running
+    VB_HIP(ctx, hipEventSynchronize(ctx->batch_events[rs.batch_id % ctx->batch_events.size()]));
+    ctx->batch_done = rs.batch_id;
+  }
   memcpy(rs.host, theta, (size_t)p * sizeof(double));
-  VB_TRY(ensure(ctx, ctx->theta, (size_t)p * sizeof(double)));
-  VB_HIP(ctx, hipMemcpyAsync(ctx->theta.ptr, rs.host, (size_t)p * sizeof(double),
-                             hipMemcpyHostToDevice, ctx->stream));
+  rs.pending = true;
   return VB_OK;
 }
 
-static int download_result(vb_ctx* ctx, ResultSlot& rs, int64_t p) {
-  VB_HIP(ctx, hipMemcpyAsync(rs.host + rs.p, ctx->out.ptr, (size_t)(1 + p) * sizeof(double),
-                             hipMemcpyDeviceToHost, ctx->stream));
-  rs.pending = true;
+// record the completion ticket of the enqueue that just used `rs[0..count)`
+static int ticket(vb_ctx* ctx, ResultSlot** rs, int count) {
+  if (ctx->batch_events.empty()) {
+    ctx->batch_events.resize(32);
+    for (auto& e : ctx->batch_events) VB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const uint64_t id = ++ctx->batch_id;
+  VB_HIP(ctx, hipEventRecord(ctx->batch_events[id % ctx->batch_events.size()], ctx->stream));
+  for (int b = 0; b < count; ++b) rs[b]->batch_id = id;
   return VB_OK;
 }
 
@@ -152,9 +165,10 @@ int vb_destroy(vb_ctx* ctx) {
   for (auto& r : ctx->results)
     if (r.host) (void)hipHostFree(r.host);
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
-  for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->partials, &ctx->sums, &ctx->out,
+  for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec})
     if (b->ptr) (void)hipFree(b->ptr);
+  for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& ev : ctx->prof_events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -298,30 +312,52 @@ int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, doubl
 }
 
 // ---- ExclusiveKL, mean field ------------------------------------------------------------------
-static int mf_call(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int family,
-                   double df, const double* theta, unsigned flags, int cv_mode, ResultSlot& rs) {
-  if (!ctx || !theta) return fail(ctx, VB_ERR_INVALID, "NULL argument");
-  VB_TRY(check_slot(ctx, slot));
+// Enqueue `count` independent evaluations: evaluation b streams noise slot slots[b] with parameter
+// thetas[b * 2d ...] and lands in result slot *rs[b].
+static int mf_call(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t d, int64_t n_total,
+                   int family, double df, const double* thetas, unsigned flags, int cv_mode,
+                   ResultSlot** rs) {
+  if (!ctx || !thetas || !slots) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (count < 1) return fail(ctx, VB_ERR_INVALID, "count must be positive");
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
-  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
   if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
   VB_HIP(ctx, hipSetDevice(ctx->device));
-  VB_TRY(upload_theta(ctx, rs, theta, 2 * d));
-  VB_TRY(mf_elbo_grad_enqueue(ctx, ctx->noise[slot], n, d, n_total, family, df, flags, cv_mode,
-                              nullptr, 0, 0.0));
-  return download_result(ctx, rs, 2 * d);
+  for (int b0 = 0; b0 < count; b0 += kMaxBatch) {
+    MfCall c;
+    c.count = count - b0 < kMaxBatch ? count - b0 : kMaxBatch;
+    for (int b = 0; b < c.count; ++b) {
+      const int slot = slots[b0 + b];
+      VB_TRY(check_slot(ctx, slot));
+      if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+      ResultSlot& r = *rs[b0 + b];
+      VB_TRY(stage_theta(ctx, r, thetas + (size_t)(b0 + b) * 2 * d, 2 * d));
+      c.noise[b] = &ctx->noise[slot];
+      c.theta_src[b] = r.dev;
+      c.out[b] = r.dev + r.p;
+    }
+    c.n = n;
+    c.d = d;
+    c.n_total = n_total;
+    c.family = family;
+    c.df = df;
+    c.flags = flags;
+    c.cv_mode = cv_mode;
+    VB_TRY(mf_enqueue(ctx, c));
+    VB_TRY(ticket(ctx, rs + b0, c.count));
+  }
+  return VB_OK;
 }
 
 int vb_elbo_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
                            int family, double df, const double* theta, unsigned flags,
                            int cv_mode, double* value, double* grad) {
   if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
-  ResultSlot& rs = ctx->sync_result;
-  VB_TRY(mf_call(ctx, slot, n, d, n_total, family, df, theta, flags, cv_mode, rs));
+  ResultSlot* rs = &ctx->sync_result;
+  VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  rs.pending = false;
-  *value = rs.host[rs.p];
-  memcpy(grad, rs.host + rs.p + 1, (size_t)(2 * d) * sizeof(double));
+  rs->pending = false;
+  *value = rs->host[rs->p];
+  memcpy(grad, rs->host + rs->p + 1, (size_t)(2 * d) * sizeof(double));
   return VB_OK;
 }
 
@@ -330,7 +366,24 @@ int vb_elbo_grad_meanfield_async(vb_ctx* ctx, int slot, int64_t n, int64_t d, in
                                  int cv_mode, int rslot) {
   if (!ctx) return VB_ERR_INVALID;
   VB_TRY(check_slot(ctx, rslot));
-  return mf_call(ctx, slot, n, d, n_total, family, df, theta, flags, cv_mode, ctx->results[rslot]);
+  ResultSlot* rs = &ctx->results[rslot];
+  return mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs);
+}
+
+int vb_elbo_grad_meanfield_batch_async(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t d,
+                                       int64_t n_total, int family, double df, const double* thetas,
+                                       unsigned flags, int cv_mode, const int* rslots) {
+  if (!ctx || !rslots) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (count < 1 || count > VB_MAX_SLOTS)
+    return fail(ctx, VB_ERR_INVALID, "count %d outside [1, %d]", count, VB_MAX_SLOTS);
+  ResultSlot* rs[VB_MAX_SLOTS];
+  for (int b = 0; b < count; ++b) {
+    VB_TRY(check_slot(ctx, rslots[b]));
+    for (int a = 0; a < b; ++a)
+      if (rslots[a] == rslots[b]) return fail(ctx, VB_ERR_INVALID, "result slot %d used twice", rslots[b]);
+    rs[b] = &ctx->results[rslots[b]];
+  }
+  return mf_call(ctx, count, slots, n, d, n_total, family, df, thetas, flags, cv_mode, rs);
 }
 
 int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p) {
@@ -353,7 +406,7 @@ int vb_profile_enable(vb_ctx* ctx, int on) {
   return VB_OK;
 }
 
-int vb_profile_read(vb_ctx* ctx, int64_t* launches, double* total_ms, int reset) {
+int vb_profile_read(vb_ctx* ctx, int64_t* launches, int64_t* evals, double* total_ms, int reset) {
   if (!ctx || !launches || !total_ms) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -365,7 +418,11 @@ int vb_profile_read(vb_ctx* ctx, int64_t* launches, double* total_ms, int reset)
   }
   *launches = (int64_t)ctx->prof_used;
   *total_ms = ms;
-  if (reset) ctx->prof_used = 0;
+  if (evals) *evals = ctx->prof_evals;
+  if (reset) {
+    ctx->prof_used = 0;
+    ctx->prof_evals = 0;
+  }
   return VB_OK;
 }
 

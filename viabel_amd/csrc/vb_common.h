@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -21,10 +22,14 @@ constexpr int kMfThreads = 256;    // 4 waves per workgroup
 constexpr int kMfWaves = kMfThreads / kWave;
 constexpr int kMfCols = 128;       // columns per workgroup: 64 lanes x 2 doubles = one 1-KiB wave load
 constexpr int kMfChunk = 16;       // rows a wave keeps in flight (16 x 16-B loads per lane)
+constexpr int kMaxBatch = 16;      // independent evaluations per launch (blockIdx.y)
 
 // per-column partial sums (fields) and per-workgroup scalars written by the accumulation kernel
 enum ColField { CF_G = 0, CF_GE, CF_E, CF_EE, CF_EK, CF_SC, CF_SCE, CF_NUM };
-enum ScalField { SF_F = 0, SF_W, SF_Q, SF_QE, SF_L1P, SF_NUM = 8 };
+enum ScalField { SF_F = 0, SF_W, SF_Q, SF_QE, SF_L1P, SF_EE, SF_FK, SF_GK, SF_GEK, SF_NUM = 12 };
+// scalars written per workgroup by the accumulation kernel / by the prep kernel (SoA: [s][entry])
+enum KScal { KS_F = 0, KS_Q, KS_QE, KS_L1P, KS_EE, KS_NUM };
+enum PScal { PS_W = 0, PS_FK, PS_GK, PS_GEK, PS_NUM };
 
 struct ModelDev {
   int id = -1;
@@ -47,9 +52,11 @@ struct NoiseSlot {
 };
 
 struct ResultSlot {
-  double* host = nullptr;   // pinned [1 + p]
+  double* host = nullptr;   // pinned, device-mapped: [theta staging (p) | value | grad (p)]
+  double* dev = nullptr;    // device address of `host`
   int64_t p = 0;
   bool pending = false;
+  uint64_t batch_id = 0;    // enqueue ticket of the evaluation that last used this slot (0: none)
 };
 
 }  // namespace vb
@@ -69,7 +76,7 @@ struct vb_ctx {
   std::vector<double> model_host;       // host copy (epilogue constants)
 
   vb::DeviceBuffer theta;               // device copy of the variational parameter
-  vb::DeviceBuffer partials;            // per-workgroup partial sums
+  vb::DeviceBuffer workspace;           // per-evaluation work buffers of the mean-field pipeline
   vb::DeviceBuffer sums;                // reduced sums (the vector that is all-reduced)
   vb::DeviceBuffer out;                 // [value | grad] on the device
   vb::DeviceBuffer scratch;             // generic device scratch (x upload, ...)
@@ -82,6 +89,12 @@ struct vb_ctx {
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
+  int64_t prof_evals = 0;               // evaluations covered by the recorded launches
+
+  // completion tickets: enqueue k records batch_events[k % size] after its last kernel, so a
+  // result slot is never re-staged while the evaluation that used it is still in flight
+  std::vector<hipEvent_t> batch_events;
+  uint64_t batch_id = 0, batch_done = 0;
 };
 
 namespace vb {
@@ -103,11 +116,22 @@ int ensure(vb_ctx* ctx, DeviceBuffer& b, size_t bytes);
     if (rc__ != VB_OK) return rc__;    \
   } while (0)
 
-// mean-field ExclusiveKL pipeline (vb_meanfield.hip)
-int mf_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
-                         int family, double df, unsigned flags, int cv_mode,
-                         const double* roww /*device or null*/, int mode /*0 elbo*/,
-                         double alpha_or_scale);
+// mean-field ExclusiveKL pipeline (vb_meanfield.hip): a batch of independent evaluations
+struct MfCall {
+  int count = 0;
+  const NoiseSlot* noise[kMaxBatch] = {};
+  const double* theta_src[kMaxBatch] = {};   // device-visible [mu | log_sigma]
+  double* out[kMaxBatch] = {};               // device-visible [value | grad(2D)]
+  const double* roww[kMaxBatch] = {};        // device per-row weights or nullptr
+  int64_t n = 0, d = 0, n_total = 0;
+  int family = 0;
+  double df = 0.0;
+  unsigned flags = 0;
+  int cv_mode = 0;
+  int mode = 0;        // 0: ELBO (ExclusiveKL); 1: weighted gradient only
+  double scale = 0.0;  // mode 1
+};
+int mf_enqueue(vb_ctx* ctx, const MfCall& call);
 
 // Philox noise generation (vb_rng.hip)
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,
@@ -119,9 +143,8 @@ int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int
 // RCCL (vb_comm.hip)
 int comm_allreduce_sum(vb_ctx* ctx, double* buf, size_t count);
 
-// profiling helpers
-void prof_begin(vb_ctx* ctx);
-void prof_end(vb_ctx* ctx);
+// profiling: event pair for the next launch of the dominant kernel (nullptrs when disabled)
+void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals);
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 

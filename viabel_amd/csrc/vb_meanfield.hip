@@ -6,21 +6,27 @@
 // i.e. sample (approximations.py:212-216) + model log density and gradient + entropy /
 // log q + the Monte-Carlo mean, in ONE streaming pass over the noise matrix.
 //
-// Kernels
-//   mf_accum_kernel   HBM-bound.  Grid = row-blocks x column-blocks; a workgroup (4 waves)
-//                     owns 128 columns (one 1-KiB, 16-B-per-lane coalesced wave load per
-//                     row) and a block of rows; each wave keeps 16 rows (16 KiB) in flight.
-//                     Per-column sums live in registers, (mu, sigma, model column
-//                     parameters) are read once per lane, row-coupled model scalars
-//                     (funnel: exp(-2 v_n)) are computed by 16 lanes and broadcast with
-//                     v_readlane, the 4 waves are combined through LDS, and the workgroup
-//                     writes one partial per column.  No atomics: deterministic.
-//                     blockIdx -> (row-block, column-block) is XCD-aware: the column blocks
-//                     of one row block share an XCD (block b runs on XCD b % 8), so the
-//                     funnel's broadcast column is fetched into one L2 only.
-//   mf_reduce_kernel  sums the row-block partials (fixed order) into the sum vector that a
+// Kernels (all on the context's stream)
+//   mf_prep_kernel    O(D + N).  Reads theta (straight from pinned host memory), writes the
+//                     device copy plus per-column constants (mu - m, sigma = exp(log_sigma), 1/sd^2)
+//                     and, for row-coupled models (funnel) or weighted sums, per-row scalars
+//                     (exp(-2 v_n) * w_n, eps_nk, w_n) and the sums that involve the coupling
+//                     column only.  Keeps every transcendental out of the streaming kernel.
+//   mf_accum_kernel   HBM-bound, the dominant kernel.  Grid = row-blocks x column-blocks; a
+//                     workgroup (4 waves) owns 128 columns (one 1-KiB, 16-B-per-lane coalesced
+//                     wave load per row) and a block of rows; a wave issues 16 row loads (16 KiB)
+//                     before its first use.  Per-column sums live in registers, per-column
+//                     constants are loaded once, per-row scalars arrive through the scalar cache
+//                     (s_load: the row index is wave-uniform), the 4 waves are combined through
+//                     LDS, one partial per column per workgroup is written.  No atomics: the
+//                     result is deterministic.  blockIdx -> (row-block, column-block) keeps the
+//                     column blocks of one row block on one XCD (block b runs on XCD b % 8).
+//   mf_finalize_kernel  Dp/64 workgroups: fixed-order sum of the row-block partials and, for the
+//                     estimators without cross-column coupling, the O(D) epilogue straight into
+//                     pinned host memory.  In reduce-only mode it writes the sum vector that a
 //                     multi-GPU job all-reduces.
-//   mf_epilogue_kernel  O(D): turns sums into (value, grad) for every estimator variant.
+//   mf_epilogue_kernel  one workgroup, O(D): control-variate variants, weighted (alpha / DIS)
+//                     gradients and the post-all-reduce epilogue.
 //
 // Algorithmic HBM bytes per evaluation: N*D*8 (noise) + 4*D*8 (theta, grad) + 8.
 #include "vb_common.h"
@@ -29,44 +35,41 @@ namespace vb {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-struct MfArgs {
-  const double* noise;
-  int64_t ld;
-  int64_t n;
-  int d;
-  int Dp;               // n_cb * kMfCols
-  const double* theta;  // [mu | log_sigma]
-  const double* roww;   // per-row weights (WEIGHTED) or nullptr
-  double* partials;     // [n_rb][CF_NUM][Dp]
-  double* pscal;        // [n_rb][n_cb][SF_NUM]
+// Up to kMaxBatch independent evaluations (own noise matrix, own theta, own result buffer; same
+// shapes and estimator) ride in ONE launch of each kernel: blockIdx.y is the evaluation index.
+// Per-evaluation pointers travel in the kernel arguments; per-evaluation work buffers are
+// `stride` doubles apart in one workspace allocation.
+struct BatchPtrs {
+  const double* noise[kMaxBatch];
+  const double* theta_src[kMaxBatch];   // [mu | log_sigma], device-visible (pinned host or device)
+  double* out[kMaxBatch];               // [value | grad(2D)], device-visible
+  const double* roww[kMaxBatch];        // per-row weights or nullptr
+};
+
+struct Workspace {
+  double* base;
+  int64_t stride;          // doubles between consecutive evaluations
+  int64_t off_theta;       // [2D]            device copy of theta
+  int64_t off_colp;        // [3][Dp]         per-column constants
+  int64_t off_rowscal;     // [n][4]          per-row scalars {a, eps_k, w, 0}
+  int64_t off_prepscal;    // [PS_NUM][n_prep]
+  int64_t off_partials;    // [n_rb][CF_NUM][Dp]
+  int64_t off_pscal;       // [KS_NUM][n_rb * n_cb]
+  double* sums;            // [B][sum_len]: [SF_NUM] | [nf][Dp]   (the all-reduced vector)
+  int64_t sum_len;
+};
+
+struct Geom {
+  int64_t ld, n;
+  int d, Dp;
+  int n_rb, n_cb, n_prep;
   int rows_per_wg;
-  int n_rb;
-  int n_cb;
   int xcd_map;
-  ModelDev model;
+  int rows;                // 1: per-row scalars needed
   double df;
 };
 
-struct ColP {   // per-column constants held in registers
-  double mu, sg;
-  double m, iv;   // gauss_diag
-  bool isK;       // funnel: this is the log-scale column
-};
-struct ColAcc {
-  double G = 0, GE = 0, E = 0, EE = 0, EK = 0, SC = 0, SCE = 0;
-};
-struct ScalAcc {
-  double F = 0, W = 0, Q = 0, QE = 0, L1P = 0;
-};
-struct RowP {
-  double w, ek, wt;
-};
-
-__device__ __forceinline__ double bcast(double x, int src) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
-  return __hiloint2double(hi, lo);
-}
+constexpr double kLog2Pi = 1.8378770664093454835606594728112;
 
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
@@ -74,268 +77,8 @@ __device__ __forceinline__ double wave_sum(double x) {
   return x;
 }
 
-template <int MODEL, bool MOM, bool TSC, bool USEWT>
-__device__ __forceinline__ void accum(const double e, const ColP& c, const RowP& r,
-                                      const double inv_tau2, const double dm1, const double df,
-                                      ColAcc& A, ScalAcc& S) {
-  const double z = fma(c.sg, e, c.mu);
-  double g, fc, q = 0.0;
-  if (MODEL == VB_MODEL_GAUSS_DIAG) {
-    const double dz = z - c.m;
-    g = -dz * c.iv;
-    fc = 0.5 * dz * g;
-  } else {   // funnel
-    if (c.isK) {
-      g = fma(-z, inv_tau2, -dm1);
-      fc = z * fma(-0.5 * z, inv_tau2, -dm1);
-    } else {
-      g = -z * r.w;
-      q = -z * g;
-      fc = -0.5 * q;
-    }
-  }
-  double ew = e;
-  if (USEWT) {
-    g *= r.wt;
-    fc *= r.wt;
-    q *= r.wt;
-    ew = e * r.wt;
-  }
-  A.G += g;
-  A.GE = fma(g, e, A.GE);
-  S.F += fc;
-  if (MODEL == VB_MODEL_FUNNEL) {
-    S.Q += q;
-    S.QE = fma(q, r.ek, S.QE);
-  }
-  if (MOM) {
-    A.E += ew;
-    A.EE = fma(ew, e, A.EE);
-    if (MODEL == VB_MODEL_FUNNEL) A.EK = fma(ew, r.ek, A.EK);
-  }
-  if (TSC) {
-    const double e2 = e * e;
-    double sc = (df + 1.0) * e / (df + e2);
-    double l1p = log1p(e2 / df);
-    if (USEWT) {
-      sc *= r.wt;
-      l1p *= r.wt;
-    }
-    A.SC += sc;
-    A.SCE = fma(sc, e, A.SCE);
-    S.L1P += l1p;
-  }
-}
-
-template <int MODEL, bool MOM, bool TSC, bool WEIGHTED>
-__global__ void __launch_bounds__(kMfThreads) mf_accum_kernel(const MfArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  int rb, cb;
-  {
-    const int b = blockIdx.x;
-    if (a.xcd_map) {   // all column blocks of a row block on one XCD (block b -> XCD b % 8)
-      const int x = b & 7, j = b >> 3;
-      cb = j % a.n_cb;
-      rb = (j / a.n_cb) * 8 + x;
-    } else {
-      rb = b / a.n_cb;
-      cb = b % a.n_cb;
-    }
-  }
-  const int d = a.d;
-  const int c0 = cb * kMfCols + 2 * lane;
-  const bool val0 = c0 < d, val1 = c0 + 1 < d;
-  const int i0 = val0 ? c0 : 0, i1 = val1 ? c0 + 1 : 0;
-
-  ColP p0, p1;
-  p0.mu = a.theta[i0];
-  p1.mu = a.theta[i1];
-  p0.sg = exp(a.theta[d + i0]);
-  p1.sg = exp(a.theta[d + i1]);
-  p0.m = p1.m = p0.iv = p1.iv = 0.0;
-  p0.isK = p1.isK = false;
-  double muk = 0.0, sgk = 0.0, inv_tau2 = 0.0, dm1 = 0.0;
-  int kcol = 0;
-  if (MODEL == VB_MODEL_GAUSS_DIAG) {
-    p0.m = a.model.p0[i0];
-    p1.m = a.model.p0[i1];
-    p0.iv = a.model.p1[i0];
-    p1.iv = a.model.p1[i1];
-  } else {
-    kcol = a.model.k;
-    muk = a.theta[kcol];
-    sgk = exp(a.theta[d + kcol]);
-    inv_tau2 = 1.0 / (a.model.tau * a.model.tau);
-    dm1 = (double)(d - 1);
-    p0.isK = (c0 == kcol);
-    p1.isK = (c0 + 1 == kcol);
-  }
-  const double df = a.df;
-
-  ColAcc A0, A1;
-  ScalAcc S;
-
-  const int64_t r0 = (int64_t)rb * a.rows_per_wg;
-  const int64_t r1 = (r0 + a.rows_per_wg < a.n) ? r0 + a.rows_per_wg : a.n;
-  const double* __restrict__ noise = a.noise;
-  const int64_t ld = a.ld;
-
-  for (int64_t base = r0 + wave; base < r1; base += (int64_t)kMfWaves * kMfChunk) {
-    const bool full = base + (int64_t)kMfWaves * (kMfChunk - 1) < r1;
-    // ---- phase A: per-row scalars, one row per lane (lanes 0..15) -------------------------
-    RowP rs;
-    {
-      const int64_t r = base + (int64_t)kMfWaves * (lane & (kMfChunk - 1));
-      const bool ok = r < r1;
-      rs.wt = ok ? 1.0 : 0.0;
-      if (WEIGHTED) rs.wt = ok ? a.roww[r] : 0.0;
-      rs.ek = 0.0;
-      rs.w = 0.0;
-      if (MODEL == VB_MODEL_FUNNEL) {
-        rs.ek = ok ? noise[r * ld + kcol] : 0.0;
-        rs.w = exp(-2.0 * fma(sgk, rs.ek, muk));
-      }
-      if (cb == 0 && lane < kMfChunk) S.W += rs.wt;
-    }
-    // ---- phase B: 16 coalesced 1-KiB row segments in flight per wave ----------------------
-    d2 e[kMfChunk];
-    if (full) {
-      if (val0) {
-#pragma unroll
-        for (int j = 0; j < kMfChunk; ++j)
-          e[j] = __builtin_nontemporal_load(
-              reinterpret_cast<const d2*>(noise + (base + (int64_t)kMfWaves * j) * ld + c0));
-      }
-#pragma unroll
-      for (int j = 0; j < kMfChunk; ++j) {
-        RowP r;
-        r.w = bcast(rs.w, j);
-        r.ek = bcast(rs.ek, j);
-        r.wt = WEIGHTED ? bcast(rs.wt, j) : 1.0;
-        if (val0) accum<MODEL, MOM, TSC, WEIGHTED>(e[j].x, p0, r, inv_tau2, dm1, df, A0, S);
-        if (val1) accum<MODEL, MOM, TSC, WEIGHTED>(e[j].y, p1, r, inv_tau2, dm1, df, A1, S);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < kMfChunk; ++j) {
-        const int64_t r = base + (int64_t)kMfWaves * j;
-        e[j] = (d2){0.0, 0.0};
-        if (val0 && r < r1)
-          e[j] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(noise + r * ld + c0));
-      }
-#pragma unroll
-      for (int j = 0; j < kMfChunk; ++j) {
-        RowP r;
-        r.w = bcast(rs.w, j);
-        r.ek = bcast(rs.ek, j);
-        r.wt = bcast(rs.wt, j);
-        if (val0) accum<MODEL, MOM, TSC, true>(e[j].x, p0, r, inv_tau2, dm1, df, A0, S);
-        if (val1) accum<MODEL, MOM, TSC, true>(e[j].y, p1, r, inv_tau2, dm1, df, A1, S);
-      }
-    }
-  }
-
-  // ---- combine the 4 waves through LDS, one partial per column per workgroup ---------------
-  __shared__ d2 red[CF_NUM][kMfWaves][kWave];
-  __shared__ double reds[kMfWaves][SF_NUM];
-  red[CF_G][wave][lane] = (d2){A0.G, A1.G};
-  red[CF_GE][wave][lane] = (d2){A0.GE, A1.GE};
-  red[CF_E][wave][lane] = (d2){A0.E, A1.E};
-  red[CF_EE][wave][lane] = (d2){A0.EE, A1.EE};
-  red[CF_EK][wave][lane] = (d2){A0.EK, A1.EK};
-  red[CF_SC][wave][lane] = (d2){A0.SC, A1.SC};
-  red[CF_SCE][wave][lane] = (d2){A0.SCE, A1.SCE};
-  {
-    const double f = wave_sum(S.F), w = wave_sum(S.W), q = wave_sum(S.Q), qe = wave_sum(S.QE),
-                 l = wave_sum(S.L1P);
-    if (lane == 0) {
-      reds[wave][SF_F] = f;
-      reds[wave][SF_W] = w;
-      reds[wave][SF_Q] = q;
-      reds[wave][SF_QE] = qe;
-      reds[wave][SF_L1P] = l;
-      reds[wave][5] = reds[wave][6] = reds[wave][7] = 0.0;
-    }
-  }
-  __syncthreads();
-  for (int f = wave; f < CF_NUM; f += kMfWaves) {
-    d2 s = red[f][0][lane];
-#pragma unroll
-    for (int w = 1; w < kMfWaves; ++w) s += red[f][w][lane];
-    *reinterpret_cast<d2*>(a.partials + ((int64_t)rb * CF_NUM + f) * a.Dp + cb * kMfCols + 2 * lane) = s;
-  }
-  if (threadIdx.x < SF_NUM) {
-    double s = 0.0;
-#pragma unroll
-    for (int w = 0; w < kMfWaves; ++w) s += reds[w][threadIdx.x];
-    a.pscal[((int64_t)rb * a.n_cb + cb) * SF_NUM + threadIdx.x] = s;
-  }
-}
-
-// sums = [SF_NUM scalars | nf x Dp column sums]
-__global__ void __launch_bounds__(256) mf_reduce_kernel(const double* __restrict__ partials,
-                                                        const double* __restrict__ pscal,
-                                                        double* __restrict__ sums, int n_rb,
-                                                        int n_cb, int Dp, int nf) {
-  const int64_t total = (int64_t)nf * Dp;
-  if (blockIdx.x == gridDim.x - 1) {   // scalars
-    __shared__ double sh[256][SF_NUM];
-    double acc[SF_NUM];
-#pragma unroll
-    for (int s = 0; s < SF_NUM; ++s) acc[s] = 0.0;
-    const int entries = n_rb * n_cb;
-    for (int e = threadIdx.x; e < entries; e += 256) {
-#pragma unroll
-      for (int s = 0; s < SF_NUM; ++s) acc[s] += pscal[(int64_t)e * SF_NUM + s];
-    }
-#pragma unroll
-    for (int s = 0; s < SF_NUM; ++s) sh[threadIdx.x][s] = acc[s];
-    __syncthreads();
-    for (int stride = 128; stride > 0; stride >>= 1) {
-      if ((int)threadIdx.x < stride) {
-#pragma unroll
-        for (int s = 0; s < SF_NUM; ++s) sh[threadIdx.x][s] += sh[threadIdx.x + stride][s];
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x < SF_NUM) sums[threadIdx.x] = sh[0][threadIdx.x];
-    return;
-  }
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int f = (int)(idx / Dp);
-  const int c = (int)(idx % Dp);
-  const double* p = partials + (int64_t)f * Dp + c;
-  const int64_t stride = (int64_t)CF_NUM * Dp;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int rb = 0;
-  for (; rb + 4 <= n_rb; rb += 4) {
-    s0 += p[(rb + 0) * stride];
-    s1 += p[(rb + 1) * stride];
-    s2 += p[(rb + 2) * stride];
-    s3 += p[(rb + 3) * stride];
-  }
-  for (; rb < n_rb; ++rb) s0 += p[rb * stride];
-  sums[SF_NUM + idx] = (s0 + s1) + (s2 + s3);
-}
-
-struct EpiArgs {
-  const double* sums;
-  const double* theta;
-  double* out;   // [value | grad(2D)]
-  int d, Dp;
-  double n_total;
-  int family;
-  double df;
-  unsigned flags;
-  int cv_mode;
-  int mode;       // 0: ELBO (ExclusiveKL); 1: weighted gradient only (alpha / scale given)
-  double scale;   // mode 1: grad = scale * [G | GE*sigma + W]
-  ModelDev model;
-};
-
-__device__ double block_sum(double x, double* sh) {
+// block-wide sum for 256 threads; every thread gets the total
+__device__ __forceinline__ double block_sum(double x, double* sh) {
   x = wave_sum(x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
@@ -346,12 +89,483 @@ __device__ double block_sum(double x, double* sh) {
   return t;
 }
 
-constexpr double kLog2Pi = 1.8378770664093454835606594728112;
+// ------------------------------------------------------------------------------------------------
+// prep
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const ModelDev model) {
+  __shared__ double sh[4][PS_NUM];
+  const int b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int d = g.d;
+  const bool funnel = model.id == VB_MODEL_FUNNEL;
+  double* wsb = ws.base + b * ws.stride;
+  const double* theta_src = bp.theta_src[b];
+  if (i < g.Dp) {
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (i < d) {
+      const double mu = theta_src[i], ls = theta_src[d + i];
+      wsb[ws.off_theta + i] = mu;
+      wsb[ws.off_theta + d + i] = ls;
+      const double sg = exp(ls);
+      if (funnel) {
+        // the coupling column contributes through the per-row sums below, not elementwise
+        c0 = (i == model.k) ? 0.0 : mu;
+        c1 = (i == model.k) ? 0.0 : sg;
+      } else {
+        c0 = mu - model.p0[i];
+        c1 = sg;
+        c2 = model.p1[i];
+      }
+    }
+    double* colp = wsb + ws.off_colp;
+    colp[i] = c0;
+    colp[g.Dp + i] = c1;
+    colp[2 * (int64_t)g.Dp + i] = c2;
+  }
+  double W = 0.0, FK = 0.0, GK = 0.0, GEK = 0.0;
+  if (g.rows) {
+    if (i < g.n) {
+      const double* roww = bp.roww[b];
+      const double wt = roww ? roww[i] : 1.0;
+      double av = wt, ek = 0.0;
+      if (funnel) {
+        const int k = model.k;
+        const double muk = theta_src[k], sgk = exp(theta_src[d + k]);
+        const double it2 = 1.0 / (model.tau * model.tau), dm1 = (double)(d - 1);
+        ek = bp.noise[b][i * g.ld + k];
+        const double v = fma(sgk, ek, muk);
+        av = wt * exp(-2.0 * v);
+        const double gk = fma(-v, it2, -dm1);
+        FK = wt * v * fma(-0.5 * v, it2, -dm1);
+        GK = wt * gk;
+        GEK = wt * gk * ek;
+      }
+      W = wt;
+      d2* rs = reinterpret_cast<d2*>(wsb + ws.off_rowscal + 4 * i);
+      rs[0] = (d2){av, ek};
+      rs[1] = (d2){wt, 0.0};
+    }
+  } else if (i == 0) {
+    W = (double)g.n;
+  }
+  // one combined block reduction (a single barrier)
+  W = wave_sum(W);
+  FK = wave_sum(FK);
+  GK = wave_sum(GK);
+  GEK = wave_sum(GEK);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[wave][PS_W] = W;
+    sh[wave][PS_FK] = FK;
+    sh[wave][PS_GK] = GK;
+    sh[wave][PS_GEK] = GEK;
+  }
+  __syncthreads();
+  if (threadIdx.x < PS_NUM)
+    wsb[ws.off_prepscal + (int64_t)threadIdx.x * gridDim.x + blockIdx.x] =
+        (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
 
-__global__ void __launch_bounds__(256) mf_epilogue_kernel(const EpiArgs a) {
-  __shared__ double sh[8];
+// ------------------------------------------------------------------------------------------------
+// accumulate (the streaming kernel)
+// ------------------------------------------------------------------------------------------------
+struct ColAcc {
+  double G = 0, GE = 0, E = 0, EE = 0, EK = 0, SC = 0, SCE = 0;
+};
+
+// one element: e = base noise, (c0, c1, c2) column constants, (av, ek, wt) row scalars
+template <int MODEL, bool MOM, bool TSC, bool WEIGHTED>
+__device__ __forceinline__ void accum(const double e, const double c0, const double c1,
+                                      const double c2, const double av, const double ek,
+                                      const double wt, const double df, ColAcc& A, double& F,
+                                      double& Q, double& QE, double& L1P) {
+  if (MODEL == VB_MODEL_GAUSS_DIAG) {
+    const double dz = fma(c1, e, c0);          // z - m
+    double g = -dz * c2;
+    if (WEIGHTED) g *= wt;
+    A.G += g;
+    A.GE = fma(g, e, A.GE);
+    F = fma(0.5 * dz, g, F);
+  } else {                                       // funnel, non-coupling columns (c0 = c1 = 0 on column k)
+    const double z = fma(c1, e, c0);
+    const double g = -z * av;                  // av = w_n exp(-2 v_n)
+    const double q = -z * g;
+    A.G += g;
+    A.GE = fma(g, e, A.GE);
+    Q += q;
+    QE = fma(q, ek, QE);
+  }
+  if (MOM) {
+    A.E += e;
+    A.EE = fma(e, e, A.EE);
+    if (MODEL == VB_MODEL_FUNNEL) A.EK = fma(e, ek, A.EK);
+  }
+  if (TSC) {
+    const double e2 = e * e;
+    const double sc = (df + 1.0) * e / (df + e2);
+    A.SC += sc;
+    A.SCE = fma(sc, e, A.SCE);
+    L1P += log1p(e2 / df);
+  }
+}
+
+template <int MODEL, bool MOM, bool TSC, bool WEIGHTED>
+__global__ void __launch_bounds__(kMfThreads)
+mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bi = blockIdx.y;
+  int rb, cb;
+  {
+    const int b = blockIdx.x;
+    if (g.xcd_map) {   // all column blocks of a row block on one XCD (block b -> XCD b % 8)
+      const int x = b & 7, j = b >> 3;
+      cb = j % g.n_cb;
+      rb = (j / g.n_cb) * 8 + x;
+    } else {
+      rb = b / g.n_cb;
+      cb = b % g.n_cb;
+    }
+  }
+  constexpr bool ROWS = (MODEL == VB_MODEL_FUNNEL) || WEIGHTED;
+  double* wsb = ws.base + bi * ws.stride;
+  const double* __restrict__ colp = wsb + ws.off_colp;
+  const double* __restrict__ rowscal = wsb + ws.off_rowscal;
+  const double* __restrict__ noise_b = bp.noise[bi];
+  const int c0i = cb * kMfCols + 2 * lane;
+  const int64_t r0 = (int64_t)rb * g.rows_per_wg;
+  const int64_t r1 = (r0 + g.rows_per_wg < g.n) ? r0 + g.rows_per_wg : g.n;
+  const double* __restrict__ noise = noise_b + c0i;
+  const int64_t ld = g.ld;
+  const bool lane_ok = c0i < ld;   // columns [d, ld) are zero pads; beyond ld is another row
+  const double df = g.df;
+
+  ColAcc A0, A1;
+  double F = 0.0, Q = 0.0, QE = 0.0, L1P = 0.0;
+  // per-column constants: issued first (vmcnt is in-order and they are needed first)
+  const d2 cp0 = *reinterpret_cast<const d2*>(colp + c0i);
+  const d2 cp1 = *reinterpret_cast<const d2*>(colp + g.Dp + c0i);
+  d2 cp2 = (d2){0.0, 0.0};
+  if (MODEL == VB_MODEL_GAUSS_DIAG) cp2 = *reinterpret_cast<const d2*>(colp + 2 * (int64_t)g.Dp + c0i);
+  const bool cols_full = (cb + 1) * kMfCols <= ld;   // every lane's 16-B load stays inside the row
+
+  for (int64_t base = r0 + wave; base < r1; base += (int64_t)kMfWaves * kMfChunk) {
+    d2 e[kMfChunk];
+    double av[kMfChunk], ek[kMfChunk], wt[kMfChunk];
+    if (cols_full && base + (int64_t)kMfWaves * (kMfChunk - 1) < r1) {
+      // ---- full chunk: straight-line code, 16 coalesced 1-KiB row segments in flight -----------
+      // wave-uniform row base (SGPRs) + per-lane 32-bit byte offset: global_load saddr form
+      const char* rowp = reinterpret_cast<const char*>(noise_b + base * ld + cb * kMfCols);
+      const int64_t step = (int64_t)kMfWaves * ld * (int64_t)sizeof(double);
+      const unsigned voff = (unsigned)lane * 16u;
+#pragma unroll
+      for (int j = 0; j < kMfChunk; ++j) {
+        e[j] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(rowp + voff));
+        rowp += step;
+      }
+      __builtin_amdgcn_sched_barrier(0);   // all 16 row loads are issued before anything below
+      // per-row scalars: wave-uniform addresses => scalar loads, issued per half (SGPR budget)
+#pragma unroll
+      for (int h = 0; h < kMfChunk; h += kMfChunk / 2) {
+        if (ROWS) {
+#pragma unroll
+          for (int j = h; j < h + kMfChunk / 2; ++j) {
+            const double* rs = rowscal + 4 * (base + (int64_t)kMfWaves * j);
+            if (MODEL == VB_MODEL_FUNNEL) {
+              av[j] = rs[0];
+              ek[j] = rs[1];
+            } else {
+              wt[j] = rs[2];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = h; j < h + kMfChunk / 2; ++j) {
+          const double a_ = MODEL == VB_MODEL_FUNNEL ? av[j] : 1.0;
+          const double k_ = MODEL == VB_MODEL_FUNNEL ? ek[j] : 0.0;
+          const double w_ = (MODEL != VB_MODEL_FUNNEL && WEIGHTED) ? wt[j] : 1.0;
+          accum<MODEL, MOM, TSC, WEIGHTED>(e[j].x, cp0.x, cp1.x, cp2.x, a_, k_, w_, df, A0, F, Q, QE, L1P);
+          accum<MODEL, MOM, TSC, WEIGHTED>(e[j].y, cp0.y, cp1.y, cp2.y, a_, k_, w_, df, A1, F, Q, QE, L1P);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // ---- ragged chunk (last rows / last columns): one row at a time, predicated -------------
+#pragma unroll 1
+      for (int j = 0; j < kMfChunk; ++j) {
+        const int64_t r = base + (int64_t)kMfWaves * j;
+        if (r >= r1) break;   // wave-uniform
+        d2 ev = (d2){0.0, 0.0};
+        if (lane_ok) ev = __builtin_nontemporal_load(reinterpret_cast<const d2*>(noise + r * ld));
+        double a_ = 1.0, k_ = 0.0, w_ = 1.0;
+        if (MODEL == VB_MODEL_FUNNEL) {
+          a_ = rowscal[4 * r];
+          k_ = rowscal[4 * r + 1];
+        } else if (WEIGHTED) {
+          w_ = rowscal[4 * r + 2];
+        }
+        accum<MODEL, MOM, TSC, WEIGHTED>(ev.x, cp0.x, cp1.x, cp2.x, a_, k_, w_, df, A0, F, Q, QE, L1P);
+        accum<MODEL, MOM, TSC, WEIGHTED>(ev.y, cp0.y, cp1.y, cp2.y, a_, k_, w_, df, A1, F, Q, QE, L1P);
+      }
+    }
+  }
+
+  // ---- combine the 4 waves through LDS, one partial per column per workgroup ---------------
+  constexpr int NF = TSC ? CF_NUM : (MOM ? CF_EK + 1 : CF_GE + 1);
+  __shared__ d2 red[NF][kMfWaves][kWave];
+  __shared__ double reds[kMfWaves][KS_NUM];
+  red[CF_G][wave][lane] = (d2){A0.G, A1.G};
+  red[CF_GE][wave][lane] = (d2){A0.GE, A1.GE};
+  if (NF > CF_E) {
+    red[CF_E][wave][lane] = (d2){A0.E, A1.E};
+    red[CF_EE][wave][lane] = (d2){A0.EE, A1.EE};
+    red[CF_EK][wave][lane] = (d2){A0.EK, A1.EK};
+  }
+  if (NF > CF_SC) {
+    red[CF_SC][wave][lane] = (d2){A0.SC, A1.SC};
+    red[CF_SCE][wave][lane] = (d2){A0.SCE, A1.SCE};
+  }
+  {
+    const double f = wave_sum(F), q = wave_sum(Q), qe = wave_sum(QE), l = wave_sum(L1P),
+                 ee = wave_sum(A0.EE + A1.EE);
+    if (lane == 0) {   // wave_sum leaves the total in lane 0
+      reds[wave][KS_F] = f;
+      reds[wave][KS_Q] = q;
+      reds[wave][KS_QE] = qe;
+      reds[wave][KS_L1P] = l;
+      reds[wave][KS_EE] = ee;
+    }
+  }
+  __syncthreads();
+  for (int f = wave; f < NF; f += kMfWaves) {
+    d2 s = red[f][0][lane];
+#pragma unroll
+    for (int w = 1; w < kMfWaves; ++w) s += red[f][w][lane];
+    *reinterpret_cast<d2*>(wsb + ws.off_partials + ((int64_t)rb * CF_NUM + f) * g.Dp + c0i) = s;
+  }
+  if (threadIdx.x < KS_NUM) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kMfWaves; ++w) s += reds[w][threadIdx.x];
+    wsb[ws.off_pscal + (int64_t)threadIdx.x * (g.n_rb * g.n_cb) + (int64_t)rb * g.n_cb + cb] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize / epilogue
+// ------------------------------------------------------------------------------------------------
+struct EpiArgs {
+  const double* partials;   // [n_rb][CF_NUM][Dp]
+  const double* pscal;      // [KS_NUM][n_ps]
+  const double* prepscal;   // [PS_NUM][n_prep] or nullptr
+  int n_rb, n_ps, n_prep;
+  int nf;                   // column fields present
+  double* sums;             // reduce-only output: [SF_NUM] | [nf][Dp]
+  const double* theta;      // device [mu | log_sigma]
+  double* out;              // [value | grad(2D)], device-visible (pinned host or device)
+  int d, Dp;
+  double n_total;
+  int family;
+  double df;
+  unsigned flags;
+  int cv_mode;
+  int mode;                 // 0: ELBO; 1: weighted gradient only
+  double scale;             // mode 1: grad = scale * [G | GE*sigma + W]
+  int reduce_only;
+  ModelDev model;
+};
+
+struct Totals {
+  double v[SF_NUM];
+};
+
+// sum of the scalar partials of the accumulate and prep kernels (all 256 threads take part;
+// every load is issued before the first add, one barrier)
+__device__ Totals scalar_totals(const EpiArgs& a, double (*sh)[KS_NUM + PS_NUM]) {
+  double acc[KS_NUM + PS_NUM];
+#pragma unroll
+  for (int s = 0; s < KS_NUM + PS_NUM; ++s) acc[s] = 0.0;
+  for (int e = threadIdx.x; e < a.n_ps; e += blockDim.x) {
+#pragma unroll
+    for (int s = 0; s < KS_NUM; ++s) acc[s] += a.pscal[(int64_t)s * a.n_ps + e];
+  }
+  if (a.prepscal) {
+    for (int e = threadIdx.x; e < a.n_prep; e += blockDim.x) {
+#pragma unroll
+      for (int s = 0; s < PS_NUM; ++s) acc[KS_NUM + s] += a.prepscal[(int64_t)s * a.n_prep + e];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < KS_NUM + PS_NUM; ++s) acc[s] = wave_sum(acc[s]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int s = 0; s < KS_NUM + PS_NUM; ++s) sh[wave][s] = acc[s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < KS_NUM + PS_NUM; ++s) acc[s] = (sh[0][s] + sh[1][s]) + (sh[2][s] + sh[3][s]);
+  Totals t;
+#pragma unroll
+  for (int s = 0; s < SF_NUM; ++s) t.v[s] = 0.0;
+  t.v[SF_F] = acc[KS_F];
+  t.v[SF_Q] = acc[KS_Q];
+  t.v[SF_QE] = acc[KS_QE];
+  t.v[SF_L1P] = acc[KS_L1P];
+  t.v[SF_EE] = acc[KS_EE];
+  t.v[SF_W] = acc[KS_NUM + PS_W];
+  t.v[SF_FK] = acc[KS_NUM + PS_FK];
+  t.v[SF_GK] = acc[KS_NUM + PS_GK];
+  t.v[SF_GEK] = acc[KS_NUM + PS_GEK];
+  return t;
+}
+
+// -(lower bound), objectives.py:156-164
+__device__ double elbo_value(const EpiArgs& a, const Totals& t, double sum_ls) {
+  const int d = a.d;
+  const bool student = a.family == VB_FAMILY_MF_STUDENT_T;
+  const bool funnel = a.model.id == VB_MODEL_FUNNEL;
+  const double W = t.v[SF_W];
+  const double invN = 1.0 / a.n_total;
+  double F = t.v[SF_F] + W * a.model.c0;
+  if (funnel) F += t.v[SF_FK] - 0.5 * t.v[SF_Q];
+  if (a.flags & VB_FLAG_PATH_DERIV) {   // -mean(f - log q(theta_stop; z))
+    double logq;
+    if (student) {
+      const double ct = lgamma(0.5 * (a.df + 1.0)) - lgamma(0.5 * a.df) - 0.5 * log(a.df * M_PI);
+      logq = W * (d * ct - sum_ls) - 0.5 * (a.df + 1.0) * t.v[SF_L1P];
+    } else {
+      logq = -0.5 * t.v[SF_EE] - W * (0.5 * d * kLog2Pi + sum_ls);
+    }
+    return -(F - logq) * invN;
+  }
+  const double H = (student ? 0.0 : 0.5 * d * (1.0 + kLog2Pi)) + sum_ls;   // -(mean f + entropy)
+  return -(F * invN + H);
+}
+
+// gradient of the plain / path-derivative estimator for one column (what autograd returns for
+// objectives.py:154-164)
+__device__ __forceinline__ void plain_column(const EpiArgs& a, int i, double g, double ge, double sc,
+                                             double sce, double* gmu, double* gls) {
+  const double sg = exp(a.theta[a.d + i]);
+  const double invN = 1.0 / a.n_total;
+  if (a.flags & VB_FLAG_PATH_DERIV) {
+    gmu[i] = -(g + sc / sg) * invN;
+    gls[i] = -(ge * sg + sce) * invN;
+  } else {
+    gmu[i] = -g * invN;
+    gls[i] = -(ge * sg * invN + 1.0);
+  }
+}
+
+// grid = Dp / 64 workgroups of 256 threads: thread (c = t & 63, q = t >> 6) sums row blocks
+// rb = q, q + 4, ... of column 64 * blockIdx + c, for every field; fixed order => deterministic.
+__global__ void __launch_bounds__(256)
+mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
+  EpiArgs a = a_in;   // per-evaluation pointers (blockIdx.y = evaluation index)
+  {
+    const int b = blockIdx.y;
+    double* wsb = ws.base + b * ws.stride;
+    a.partials = wsb + ws.off_partials;
+    a.pscal = wsb + ws.off_pscal;
+    a.prepscal = wsb + ws.off_prepscal;
+    a.theta = wsb + ws.off_theta;
+    a.sums = ws.sums + b * ws.sum_len;
+    a.out = bp.out[b];
+  }
+  __shared__ double colsum[CF_NUM + 1][4][64];
+  __shared__ double sh[4];
+  __shared__ double sh2[4][KS_NUM + PS_NUM];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int Dp = a.Dp;
+  const int64_t fstride = Dp, rstride = (int64_t)CF_NUM * Dp;
+  // two fields per pass, 16 row blocks each: 32 independent loads in flight per thread
+  for (int f = 0; f < a.nf; f += 2) {
+    const bool two = f + 1 < a.nf;
+    const double* p0 = a.partials + f * fstride + col;
+    const double* p1 = p0 + fstride;
+    double t0 = 0.0, t1 = 0.0;
+    for (int rb0 = q; rb0 < a.n_rb; rb0 += 64) {
+      double v0[16], v1[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rb = rb0 + 4 * i;
+        v0[i] = rb < a.n_rb ? p0[rb * rstride] : 0.0;
+        v1[i] = (two && rb < a.n_rb) ? p1[rb * rstride] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        t0 += v0[i];
+        t1 += v1[i];
+      }
+    }
+    colsum[f][q][c] = t0;
+    if (two) colsum[f + 1][q][c] = t1;
+  }
+  __syncthreads();
+
+  const bool funnel = a.model.id == VB_MODEL_FUNNEL;
+  const int k = a.model.k;
+  const bool owns_k = funnel && (k / 64 == (int)blockIdx.x);
+  const bool need_tot = blockIdx.x == 0 || owns_k;   // workgroup-uniform
+  Totals tot;
+  if (need_tot) tot = scalar_totals(a, sh2);
+
+  if (a.reduce_only) {
+    if (q == 0) {
+      for (int f = 0; f < a.nf; ++f)
+        a.sums[SF_NUM + (int64_t)f * Dp + col] =
+            (colsum[f][0][c] + colsum[f][1][c]) + (colsum[f][2][c] + colsum[f][3][c]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < SF_NUM)
+      a.sums[threadIdx.x] = tot.v[threadIdx.x];
+    return;
+  }
+
+  // ---- fused epilogue (no cross-column coupling): plain and path-derivative ELBO gradients ----
+  const int d = a.d;
+  double* value = a.out;
+  double* gmu = a.out + 1;
+  double* gls = a.out + 1 + d;
+  if (q == 0 && col < d) {
+    double S[CF_NUM];
+    for (int f = 0; f < CF_NUM; ++f)
+      S[f] = f < a.nf ? (colsum[f][0][c] + colsum[f][1][c]) + (colsum[f][2][c] + colsum[f][3][c]) : 0.0;
+    double g = S[CF_G], ge = S[CF_GE];
+    if (funnel && col == k) {
+      g += tot.v[SF_GK] + tot.v[SF_Q];
+      ge += tot.v[SF_GEK] + tot.v[SF_QE];
+    }
+    const bool student = a.family == VB_FAMILY_MF_STUDENT_T;
+    plain_column(a, col, g, ge, student ? S[CF_SC] : S[CF_E], student ? S[CF_SCE] : S[CF_EE], gmu, gls);
+  }
+  if (blockIdx.x == 0) {
+    double t_ls = 0.0;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) t_ls += a.theta[d + i];
+    const double sum_ls = block_sum(t_ls, sh);
+    if (threadIdx.x == 0) value[0] = elbo_value(a, tot, sum_ls);
+  }
+}
+
+// one workgroup over the reduced sums: control variates, weighted gradients, post-all-reduce
+__global__ void __launch_bounds__(256)
+mf_epilogue_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
+  EpiArgs a = a_in;   // per-evaluation pointers (blockIdx.y = evaluation index)
+  {
+    const int b = blockIdx.y;
+    double* wsb = ws.base + b * ws.stride;
+    a.partials = wsb + ws.off_partials;
+    a.pscal = wsb + ws.off_pscal;
+    a.prepscal = wsb + ws.off_prepscal;
+    a.theta = wsb + ws.off_theta;
+    a.sums = ws.sums + b * ws.sum_len;
+    a.out = bp.out[b];
+  }
+  __shared__ double sh[4];
   const int d = a.d, Dp = a.Dp;
-  const double* S = a.sums;
   const double* G = a.sums + SF_NUM + (int64_t)CF_G * Dp;
   const double* GE = a.sums + SF_NUM + (int64_t)CF_GE * Dp;
   const double* E = a.sums + SF_NUM + (int64_t)CF_E * Dp;
@@ -359,13 +573,17 @@ __global__ void __launch_bounds__(256) mf_epilogue_kernel(const EpiArgs a) {
   const double* EK = a.sums + SF_NUM + (int64_t)CF_EK * Dp;
   const double* SC = a.sums + SF_NUM + (int64_t)CF_SC * Dp;
   const double* SCE = a.sums + SF_NUM + (int64_t)CF_SCE * Dp;
+  const double* S = a.sums;
+  Totals tot;
+#pragma unroll
+  for (int s = 0; s < SF_NUM; ++s) tot.v[s] = S[s];
   const double* mu = a.theta;
   const double* ls = a.theta + d;
   const bool funnel = a.model.id == VB_MODEL_FUNNEL;
-  const int k = a.model.k;
-  const double Wsum = S[SF_W];
-  const double gk_add = funnel ? S[SF_Q] : 0.0;     // row-coupled part of g_k (see accum)
-  const double gek_add = funnel ? S[SF_QE] : 0.0;
+  const int k = funnel ? a.model.k : -1;
+  const double Wsum = tot.v[SF_W];
+  const double gk_add = funnel ? tot.v[SF_GK] + tot.v[SF_Q] : 0.0;
+  const double gek_add = funnel ? tot.v[SF_GEK] + tot.v[SF_QE] : 0.0;
   double* value = a.out;
   double* gmu = a.out + 1;
   double* gls = a.out + 1 + d;
@@ -377,56 +595,26 @@ __global__ void __launch_bounds__(256) mf_epilogue_kernel(const EpiArgs a) {
       gmu[i] = a.scale * g;
       gls[i] = a.scale * (ge * exp(ls[i]) + Wsum);
     }
-    if (threadIdx.x == 0) value[0] = S[SF_F] + Wsum * a.model.c0;
+    if (threadIdx.x == 0) {
+      double F = tot.v[SF_F] + Wsum * a.model.c0;
+      if (funnel) F += tot.v[SF_FK] - 0.5 * tot.v[SF_Q];
+      value[0] = F;
+    }
     return;
   }
 
   const double invN = 1.0 / a.n_total;
   const bool student = a.family == VB_FAMILY_MF_STUDENT_T;
-  const bool pd = (a.flags & VB_FLAG_PATH_DERIV) != 0;
-
-  // ---- value -----------------------------------------------------------------------------
-  double t_ls = 0.0, t_ee = 0.0;
-  for (int i = threadIdx.x; i < d; i += blockDim.x) {
-    t_ls += ls[i];
-    if (pd && !student) t_ee += EE[i];
-  }
+  double t_ls = 0.0;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) t_ls += ls[i];
   const double sum_ls = block_sum(t_ls, sh);
-  const double sum_ee = block_sum(t_ee, sh);
-  const double F = S[SF_F] + Wsum * a.model.c0;
-  if (threadIdx.x == 0) {
-    double v;
-    if (pd) {   // objectives.py:156-159: -mean(f - log q(theta_stop; z))
-      double logq;
-      if (student) {
-        const double ct = lgamma(0.5 * (a.df + 1.0)) - lgamma(0.5 * a.df) - 0.5 * log(a.df * M_PI);
-        logq = Wsum * (d * ct - sum_ls) - 0.5 * (a.df + 1.0) * S[SF_L1P];
-      } else {
-        logq = -0.5 * sum_ee - Wsum * (0.5 * d * kLog2Pi + sum_ls);
-      }
-      v = -(F - logq) * invN;
-    } else {    // objectives.py:160-161: -(mean f + entropy)
-      const double H = (student ? 0.0 : 0.5 * d * (1.0 + kLog2Pi)) + sum_ls;
-      v = -(F * invN + H);
-    }
-    value[0] = v;
-  }
+  if (threadIdx.x == 0) value[0] = elbo_value(a, tot, sum_ls);
 
-  // ---- gradient, no control variate (what autograd returns for objectives.py:154-164) -----
   if (a.cv_mode == VB_CV_NONE) {
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
-      const double sg = exp(ls[i]);
       const double g = G[i] + (i == k ? gk_add : 0.0);
       const double ge = GE[i] + (i == k ? gek_add : 0.0);
-      if (pd) {
-        const double sc = student ? SC[i] : E[i];
-        const double sce = student ? SCE[i] : EE[i];
-        gmu[i] = -(g + sc / sg) * invN;
-        gls[i] = -(ge * sg + sce) * invN;
-      } else {
-        gmu[i] = -g * invN;
-        gls[i] = -(ge * sg * invN + 1.0);
-      }
+      plain_column(a, i, g, ge, student ? SC[i] : E[i], student ? SCE[i] : EE[i], gmu, gls);
     }
     return;
   }
@@ -488,21 +676,30 @@ __global__ void __launch_bounds__(256) mf_epilogue_kernel(const EpiArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+struct Launch {
+  dim3 grid;
+  hipStream_t st;
+  hipEvent_t ev0, ev1;   // exact kernel begin / end timestamps when profiling (else nullptr)
+};
+
 template <int MODEL, bool MOM, bool TSC>
-static void launch_accum(bool weighted, dim3 grid, hipStream_t st, const MfArgs& a) {
+static void launch_accum(bool weighted, const Launch& L, const BatchPtrs& bp, const Workspace& ws,
+                         const Geom& g) {
   if (weighted)
-    hipLaunchKernelGGL((mf_accum_kernel<MODEL, MOM, TSC, true>), grid, dim3(kMfThreads), 0, st, a);
+    hipExtLaunchKernelGGL((mf_accum_kernel<MODEL, MOM, TSC, true>), L.grid, dim3(kMfThreads), 0, L.st,
+                          L.ev0, L.ev1, 0, bp, ws, g);
   else
-    hipLaunchKernelGGL((mf_accum_kernel<MODEL, MOM, TSC, false>), grid, dim3(kMfThreads), 0, st, a);
+    hipExtLaunchKernelGGL((mf_accum_kernel<MODEL, MOM, TSC, false>), L.grid, dim3(kMfThreads), 0, L.st,
+                          L.ev0, L.ev1, 0, bp, ws, g);
 }
 
 template <int MODEL>
-static void launch_accum_model(bool mom, bool tsc, bool weighted, dim3 grid, hipStream_t st,
-                               const MfArgs& a) {
-  if (mom && tsc) launch_accum<MODEL, true, true>(weighted, grid, st, a);
-  else if (mom) launch_accum<MODEL, true, false>(weighted, grid, st, a);
-  else if (tsc) launch_accum<MODEL, false, true>(weighted, grid, st, a);
-  else launch_accum<MODEL, false, false>(weighted, grid, st, a);
+static void launch_accum_model(bool mom, bool tsc, bool weighted, const Launch& L, const BatchPtrs& bp,
+                               const Workspace& ws, const Geom& g) {
+  if (mom && tsc) launch_accum<MODEL, true, true>(weighted, L, bp, ws, g);
+  else if (mom) launch_accum<MODEL, true, false>(weighted, L, bp, ws, g);
+  else if (tsc) launch_accum<MODEL, false, true>(weighted, L, bp, ws, g);
+  else launch_accum<MODEL, false, false>(weighted, L, bp, ws, g);
 }
 
 static int env_int(const char* name, int dflt) {
@@ -510,11 +707,12 @@ static int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
-// Enqueue accumulate -> reduce -> [all-reduce] -> epilogue on ctx->stream.  ctx->theta holds
-// the variational parameter; the result lands in ctx->out = [value | grad(2D)].
-int mf_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
-                         int family, double df, unsigned flags, int cv_mode, const double* roww,
-                         int mode, double scale) {
+// Enqueue prep -> accumulate -> finalize [-> all-reduce -> epilogue] for a batch of `count`
+// independent evaluations on ctx->stream.
+int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
+  const int64_t n = c.n, d = c.d;
+  if (c.count < 1 || c.count > kMaxBatch)
+    return fail(ctx, VB_ERR_INVALID, "batch size %d outside [1, %d]", c.count, kMaxBatch);
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
     return fail(ctx, VB_ERR_UNSUPPORTED,
                 "mean-field path supports the gauss_diag and funnel models (model id %d bound)",
@@ -522,90 +720,121 @@ int mf_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   if (ctx->model.dim != d)
     return fail(ctx, VB_ERR_INVALID, "model dimension %d != family dimension %lld", ctx->model.dim,
                 (long long)d);
-  if (family != VB_FAMILY_MF_GAUSSIAN && family != VB_FAMILY_MF_STUDENT_T)
-    return fail(ctx, VB_ERR_INVALID, "family %d is not a mean-field family", family);
-  if (family == VB_FAMILY_MF_STUDENT_T && !(df > 2.0))
+  if (c.family != VB_FAMILY_MF_GAUSSIAN && c.family != VB_FAMILY_MF_STUDENT_T)
+    return fail(ctx, VB_ERR_INVALID, "family %d is not a mean-field family", c.family);
+  if (c.family == VB_FAMILY_MF_STUDENT_T && !(c.df > 2.0))
     return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
-  if (cv_mode < VB_CV_NONE || cv_mode > VB_CV_LOO_DIRECT)
-    return fail(ctx, VB_ERR_INVALID, "unknown control-variate mode %d", cv_mode);
-  if (n <= 0 || d <= 0 || n > ns.n || d != ns.d)
-    return fail(ctx, VB_ERR_INVALID, "noise slot holds %lld x %lld, evaluation asks %lld x %lld",
-                (long long)ns.n, (long long)ns.d, (long long)n, (long long)d);
+  if (c.cv_mode < VB_CV_NONE || c.cv_mode > VB_CV_LOO_DIRECT)
+    return fail(ctx, VB_ERR_INVALID, "unknown control-variate mode %d", c.cv_mode);
+  if (n <= 0 || d <= 0) return fail(ctx, VB_ERR_INVALID, "n and d must be positive");
+  for (int b = 0; b < c.count; ++b) {
+    const NoiseSlot* ns = c.noise[b];
+    if (!ns || !ns->buf.ptr || n > ns->n || d != ns->d)
+      return fail(ctx, VB_ERR_INVALID, "noise slot of evaluation %d does not hold a %lld x %lld matrix",
+                  b, (long long)n, (long long)d);
+  }
 
-  const bool pd = (flags & VB_FLAG_PATH_DERIV) != 0;
-  const bool student = family == VB_FAMILY_MF_STUDENT_T;
-  const bool mom = mode == 0 && ((pd && !student) || cv_mode != VB_CV_NONE);
-  const bool tsc = mode == 0 && pd && student;
+  const bool pd = (c.flags & VB_FLAG_PATH_DERIV) != 0;
+  const bool student = c.family == VB_FAMILY_MF_STUDENT_T;
+  const bool mom = c.mode == 0 && ((pd && !student) || c.cv_mode != VB_CV_NONE);
+  const bool tsc = c.mode == 0 && pd && student;
   const int nf = tsc ? CF_NUM : (mom ? CF_EK + 1 : CF_GE + 1);
+  const bool weighted = c.roww[0] != nullptr;
+  const bool funnel = ctx->model.id == VB_MODEL_FUNNEL;
+  const bool rows = funnel || weighted;
 
-  const int n_cb = (int)((d + kMfCols - 1) / kMfCols);
-  const int Dp = n_cb * kMfCols;
-  // ~2 workgroups per CU; rows per workgroup a multiple of the 4 waves
+  Geom g;
+  g.ld = c.noise[0]->ld;
+  g.n = n;
+  g.d = (int)d;
+  g.n_cb = (int)((d + kMfCols - 1) / kMfCols);
+  g.Dp = g.n_cb * kMfCols;
+  // ~2 workgroups per CU over the whole batch; rows per workgroup a multiple of the 4 waves
   const int target_wg = env_int("VB_MF_TARGET_WG", 2 * ctx->prop.multiProcessorCount);
-  int n_rb_target = target_wg / n_cb;
+  int n_rb_target = target_wg / g.n_cb / (c.count < 4 ? c.count : 4);
   if (n_rb_target < 8) n_rb_target = 8;
   n_rb_target = (n_rb_target + 7) / 8 * 8;
   int rows_per_wg = (int)((n + n_rb_target - 1) / n_rb_target);
   rows_per_wg = env_int("VB_MF_ROWS_PER_WG", rows_per_wg);
-  rows_per_wg = (int)round_up(rows_per_wg < kMfWaves ? kMfWaves : rows_per_wg, kMfWaves);
-  const int n_rb = (int)((n + rows_per_wg - 1) / rows_per_wg);
+  g.rows_per_wg = (int)round_up(rows_per_wg < kMfWaves ? kMfWaves : rows_per_wg, kMfWaves);
+  g.n_rb = (int)((n + g.rows_per_wg - 1) / g.rows_per_wg);
+  const int64_t prep_items = rows ? (n > g.Dp ? n : g.Dp) : g.Dp;
+  g.n_prep = (int)((prep_items + 255) / 256);
+  g.xcd_map = (g.n_rb % 8 == 0) ? env_int("VB_MF_XCD_MAP", 1) : 0;
+  g.rows = rows ? 1 : 0;
+  g.df = c.df;
 
-  VB_TRY(ensure(ctx, ctx->partials,
-                ((size_t)n_rb * CF_NUM * Dp + (size_t)n_rb * n_cb * SF_NUM) * sizeof(double)));
-  VB_TRY(ensure(ctx, ctx->sums, ((size_t)SF_NUM + (size_t)CF_NUM * Dp) * sizeof(double)));
-  VB_TRY(ensure(ctx, ctx->out, (size_t)(1 + 2 * d) * sizeof(double)));
+  // ---- workspace layout (per evaluation) ------------------------------------------------------
+  Workspace ws;
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);   // keep every sub-buffer 128-B aligned
+    return o;
+  };
+  ws.off_theta = carve(2 * d);
+  ws.off_colp = carve(3 * (int64_t)g.Dp);
+  ws.off_rowscal = carve(rows ? 4 * n : 0);
+  ws.off_prepscal = carve((int64_t)PS_NUM * g.n_prep);
+  ws.off_partials = carve((int64_t)g.n_rb * CF_NUM * g.Dp);
+  ws.off_pscal = carve((int64_t)KS_NUM * g.n_rb * g.n_cb);
+  ws.stride = off;
+  ws.sum_len = round_up((int64_t)SF_NUM + (int64_t)CF_NUM * g.Dp, 16);
+  VB_TRY(ensure(ctx, ctx->workspace, (size_t)ws.stride * c.count * sizeof(double)));
+  VB_TRY(ensure(ctx, ctx->sums, (size_t)ws.sum_len * c.count * sizeof(double)));
+  ws.base = (double*)ctx->workspace.ptr;
+  ws.sums = (double*)ctx->sums.ptr;
 
-  MfArgs a;
-  a.noise = (const double*)ns.buf.ptr;
-  a.ld = ns.ld;
-  a.n = n;
-  a.d = (int)d;
-  a.Dp = Dp;
-  a.theta = (const double*)ctx->theta.ptr;
-  a.roww = roww;
-  a.partials = (double*)ctx->partials.ptr;
-  a.pscal = a.partials + (size_t)n_rb * CF_NUM * Dp;
-  a.rows_per_wg = rows_per_wg;
-  a.n_rb = n_rb;
-  a.n_cb = n_cb;
-  a.xcd_map = (n_rb % 8 == 0) ? env_int("VB_MF_XCD_MAP", 1) : 0;
-  a.model = ctx->model;
-  a.df = df;
+  BatchPtrs bp;
+  for (int b = 0; b < kMaxBatch; ++b) {
+    const int s = b < c.count ? b : 0;
+    bp.noise[b] = (const double*)c.noise[s]->buf.ptr;
+    bp.theta_src[b] = c.theta_src[s];
+    bp.out[b] = c.out[s];
+    bp.roww[b] = c.roww[s];
+  }
 
-  const dim3 grid((unsigned)(n_rb * n_cb));
-  const bool weighted = roww != nullptr;
-  prof_begin(ctx);
+  hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)g.n_prep, (unsigned)c.count), dim3(256), 0,
+                     ctx->stream, bp, ws, g, ctx->model);
+  VB_HIP(ctx, hipGetLastError());
+
+  Launch L;
+  L.grid = dim3((unsigned)(g.n_rb * g.n_cb), (unsigned)c.count);
+  L.st = ctx->stream;
+  prof_events(ctx, &L.ev0, &L.ev1, c.count);
   if (ctx->model.id == VB_MODEL_GAUSS_DIAG)
-    launch_accum_model<VB_MODEL_GAUSS_DIAG>(mom, tsc, weighted, grid, ctx->stream, a);
+    launch_accum_model<VB_MODEL_GAUSS_DIAG>(mom, tsc, weighted, L, bp, ws, g);
   else
-    launch_accum_model<VB_MODEL_FUNNEL>(mom, tsc, weighted, grid, ctx->stream, a);
-  prof_end(ctx);
+    launch_accum_model<VB_MODEL_FUNNEL>(mom, tsc, weighted, L, bp, ws, g);
   VB_HIP(ctx, hipGetLastError());
-
-  const int64_t total = (int64_t)nf * Dp;
-  const unsigned rgrid = (unsigned)((total + 255) / 256 + 1);
-  hipLaunchKernelGGL(mf_reduce_kernel, dim3(rgrid), dim3(256), 0, ctx->stream,
-                     (const double*)a.partials, (const double*)a.pscal, (double*)ctx->sums.ptr,
-                     n_rb, n_cb, Dp, nf);
-  VB_HIP(ctx, hipGetLastError());
-
-  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, (double*)ctx->sums.ptr, (size_t)SF_NUM + (size_t)total));
 
   EpiArgs e;
-  e.sums = (const double*)ctx->sums.ptr;
-  e.theta = (const double*)ctx->theta.ptr;
-  e.out = (double*)ctx->out.ptr;
+  memset(&e, 0, sizeof e);
+  e.n_rb = g.n_rb;
+  e.n_ps = g.n_rb * g.n_cb;
+  e.n_prep = g.n_prep;
+  e.nf = nf;
   e.d = (int)d;
-  e.Dp = Dp;
-  e.n_total = (double)n_total;
-  e.family = family;
-  e.df = df;
-  e.flags = flags;
-  e.cv_mode = cv_mode;
-  e.mode = mode;
-  e.scale = scale;
+  e.Dp = g.Dp;
+  e.n_total = (double)c.n_total;
+  e.family = c.family;
+  e.df = c.df;
+  e.flags = c.flags;
+  e.cv_mode = c.cv_mode;
+  e.mode = c.mode;
+  e.scale = c.scale;
   e.model = ctx->model;
-  hipLaunchKernelGGL(mf_epilogue_kernel, dim3(1), dim3(256), 0, ctx->stream, e);
+  const bool fused = c.mode == 0 && c.cv_mode == VB_CV_NONE && !ctx->comm;
+  e.reduce_only = fused ? 0 : 1;
+  hipLaunchKernelGGL(mf_finalize_kernel, dim3((unsigned)(g.Dp / 64), (unsigned)c.count), dim3(256), 0,
+                     ctx->stream, e, bp, ws);
+  VB_HIP(ctx, hipGetLastError());
+  if (fused) return VB_OK;
+
+  if (ctx->comm)   // one all-reduce for the whole batch: [count][sum_len] doubles
+    VB_TRY(comm_allreduce_sum(ctx, ws.sums, (size_t)ws.sum_len * c.count));
+  hipLaunchKernelGGL(mf_epilogue_kernel, dim3(1, (unsigned)c.count), dim3(256), 0, ctx->stream, e, bp,
+                     ws);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
