@@ -64,7 +64,7 @@ def main():
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--ring', type=int, default=16, help='noise matrices cycled (16 x 33.5 MB > L3)')
-    ap.add_argument('--engines', type=int, default=2,
+    ap.add_argument('--engines', type=int, default=1,
                     help='independent HIP contexts (streams) the evaluations are spread over, so the '
                          'small prep / finalize kernels of one evaluation overlap the streaming kernel of another')
     ap.add_argument('--batch', type=int, default=16,

@@ -27,8 +27,8 @@ int fail(vb_ctx* ctx, int code, const char* fmt, ...) {
 int ensure(vb_ctx* ctx, DeviceBuffer& b, size_t bytes) {
   if (b.bytes >= bytes && b.ptr) return VB_OK;
   if (b.ptr) {
-    // buffers may still be referenced by work in flight on the stream
-    VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // buffers may still be referenced by work in flight on any of the context's streams
+    VB_TRY(sync_streams(ctx));
     VB_HIP(ctx, hipFree(b.ptr));
     b.ptr = nullptr;
     b.bytes = 0;
@@ -37,6 +37,28 @@ int ensure(vb_ctx* ctx, DeviceBuffer& b, size_t bytes) {
   VB_HIP(ctx, hipMalloc(&b.ptr, cap));
   VB_HIP(ctx, hipMemsetAsync(b.ptr, 0, cap, ctx->stream));
   b.bytes = cap;
+  return VB_OK;
+}
+
+int sync_streams(vb_ctx* ctx) {
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->pipe.pre) {
+    VB_HIP(ctx, hipStreamSynchronize(ctx->pipe.pre));
+    VB_HIP(ctx, hipStreamSynchronize(ctx->pipe.post));
+  }
+  ctx->pipe.post_pending = false;
+  return VB_OK;
+}
+
+// Main-stream work that writes buffers the pipeline may still be reading (noise, model parameters)
+// is ordered after everything the pipeline has in flight, and the next prep is ordered after it.
+static int main_stream_write(vb_ctx* ctx) {
+  Pipeline& P = ctx->pipe;
+  if (P.post_pending) {
+    VB_HIP(ctx, hipStreamWaitEvent(ctx->stream, P.ev_fin[P.last_set], 0));
+    P.post_pending = false;
+  }
+  P.main_dirty = true;
   return VB_OK;
 }
 
@@ -77,6 +99,14 @@ static int noise_alloc(vb_ctx* ctx, int slot, int64_t n, int64_t d) {
   return VB_OK;
 }
 
+// Block until the enqueue with completion ticket `id` has finished.
+static int wait_ticket(vb_ctx* ctx, uint64_t id) {
+  if (id == 0) return VB_OK;
+  if (ctx->batch_id - id >= ctx->batch_events.size()) return sync_streams(ctx);   // event slot recycled
+  VB_HIP(ctx, hipEventSynchronize(ctx->batch_events[id % ctx->batch_events.size()]));
+  return VB_OK;
+}
+
 // Stage theta in the result slot's pinned, device-mapped buffer: the prep kernel reads it from
 // there and the finalize / epilogue kernel writes [value | grad] back into the same buffer, so an
 // evaluation needs no separate copy commands on the stream.
@@ -84,7 +114,7 @@ static int stage_theta(vb_ctx* ctx, ResultSlot& rs, const double* theta, int64_t
   const size_t need = (size_t)(1 + 2 * p) * sizeof(double);   // [theta staging | value | grad]
   if (rs.p < p || !rs.host) {
     if (rs.host) {
-      VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      VB_TRY(sync_streams(ctx));
       VB_HIP(ctx, hipHostFree(rs.host));
       rs.host = nullptr;
     }
@@ -92,10 +122,7 @@ static int stage_theta(vb_ctx* ctx, ResultSlot& rs, const double* theta, int64_t
     VB_HIP(ctx, hipHostGetDevicePointer((void**)&rs.dev, rs.host, 0));
     rs.p = p;
   }
-  if (rs.batch_id > ctx->batch_done) {   // the evaluation that last used this slot may still be running
-    VB_HIP(ctx, hipEventSynchronize(ctx->batch_events[rs.batch_id % ctx->batch_events.size()]));
-    ctx->batch_done = rs.batch_id;
-  }
+  VB_TRY(wait_ticket(ctx, rs.batch_id));   // the evaluation that last used this slot may still be running
   memcpy(rs.host, theta, (size_t)p * sizeof(double));
   rs.pending = true;
   return VB_OK;
@@ -108,7 +135,8 @@ static int ticket(vb_ctx* ctx, ResultSlot** rs, int count) {
     for (auto& e : ctx->batch_events) VB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   const uint64_t id = ++ctx->batch_id;
-  VB_HIP(ctx, hipEventRecord(ctx->batch_events[id % ctx->batch_events.size()], ctx->stream));
+  VB_HIP(ctx, hipEventRecord(ctx->batch_events[id % ctx->batch_events.size()],
+                             ctx->result_stream ? ctx->result_stream : ctx->stream));
   for (int b = 0; b < count; ++b) rs[b]->batch_id = id;
   return VB_OK;
 }
@@ -158,8 +186,18 @@ int vb_create(int device_id, vb_ctx** out) {
 int vb_destroy(vb_ctx* ctx) {
   if (!ctx) return VB_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)sync_streams(ctx);
   vb_comm_destroy(ctx);
+  if (ctx->pipe.pre) {
+    (void)hipStreamDestroy(ctx->pipe.pre);
+    (void)hipStreamDestroy(ctx->pipe.post);
+    (void)hipEventDestroy(ctx->pipe.ev_main);
+    for (int i = 0; i < kPipeSets; ++i) {
+      (void)hipEventDestroy(ctx->pipe.ev_prep[i]);
+      (void)hipEventDestroy(ctx->pipe.ev_k1[i]);
+      (void)hipEventDestroy(ctx->pipe.ev_fin[i]);
+    }
+  }
   for (auto& s : ctx->noise)
     if (s.buf.ptr) (void)hipFree(s.buf.ptr);
   for (auto& r : ctx->results)
@@ -195,14 +233,14 @@ int vb_device_info(vb_ctx* ctx, char* name, size_t name_len, int* n_cu, uint64_t
 int vb_sync(vb_ctx* ctx) {
   if (!ctx) return VB_ERR_INVALID;
   VB_HIP(ctx, hipSetDevice(ctx->device));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return VB_OK;
+  return sync_streams(ctx);
 }
 
 // ---- noise ---------------------------------------------------------------------------------
 int vb_noise_set_host(vb_ctx* ctx, int slot, const double* host, int64_t n, int64_t d) {
   if (!ctx || !host) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
   VB_TRY(noise_alloc(ctx, slot, n, d));
   NoiseSlot& s = ctx->noise[slot];
   VB_HIP(ctx, hipMemcpy2DAsync(s.buf.ptr, (size_t)s.ld * sizeof(double), host,
@@ -216,6 +254,7 @@ int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
                       int64_t row_offset, int64_t n, int64_t d) {
   if (!ctx) return VB_ERR_INVALID;
   VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
   VB_TRY(noise_alloc(ctx, slot, n, d));
   NoiseSlot& s = ctx->noise[slot];
   return rng_fill(ctx, (double*)s.buf.ptr, s.ld, kind, df, seed, stream, row_offset, n, d);
@@ -242,6 +281,7 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams, 
   if (!ctx) return VB_ERR_INVALID;
   if (dim <= 0) return fail(ctx, VB_ERR_INVALID, "model dimension must be positive");
   VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
   const double kLog2Pi = 1.8378770664093454835606594728112;
   ModelDev m;
   m.id = model_id;
@@ -316,7 +356,7 @@ int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, doubl
 // thetas[b * 2d ...] and lands in result slot *rs[b].
 static int mf_call(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t d, int64_t n_total,
                    int family, double df, const double* thetas, unsigned flags, int cv_mode,
-                   ResultSlot** rs) {
+                   ResultSlot** rs, bool pipelined) {
   if (!ctx || !thetas || !slots) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (count < 1) return fail(ctx, VB_ERR_INVALID, "count must be positive");
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
@@ -342,6 +382,7 @@ static int mf_call(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t 
     c.df = df;
     c.flags = flags;
     c.cv_mode = cv_mode;
+    c.pipelined = pipelined;
     VB_TRY(mf_enqueue(ctx, c));
     VB_TRY(ticket(ctx, rs + b0, c.count));
   }
@@ -353,7 +394,7 @@ int vb_elbo_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t 
                            int cv_mode, double* value, double* grad) {
   if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   ResultSlot* rs = &ctx->sync_result;
-  VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs));
+  VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs, false));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rs->pending = false;
   *value = rs->host[rs->p];
@@ -367,7 +408,7 @@ int vb_elbo_grad_meanfield_async(vb_ctx* ctx, int slot, int64_t n, int64_t d, in
   if (!ctx) return VB_ERR_INVALID;
   VB_TRY(check_slot(ctx, rslot));
   ResultSlot* rs = &ctx->results[rslot];
-  return mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs);
+  return mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs, false);
 }
 
 int vb_elbo_grad_meanfield_batch_async(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t d,
@@ -383,7 +424,11 @@ int vb_elbo_grad_meanfield_batch_async(vb_ctx* ctx, int count, const int* slots,
       if (rslots[a] == rslots[b]) return fail(ctx, VB_ERR_INVALID, "result slot %d used twice", rslots[b]);
     rs[b] = &ctx->results[rslots[b]];
   }
-  return mf_call(ctx, count, slots, n, d, n_total, family, df, thetas, flags, cv_mode, rs);
+  // VB_PIPELINE=1 spreads prep / stream / finalize over three event-chained HIP streams.  Measured
+  // on MI355X (ROCm 7.2) the cross-stream event waits cost more than the overlap buys, so the
+  // default keeps a batch in order on the main stream; independent contexts overlap instead.
+  static const bool pipelined = getenv("VB_PIPELINE") && atoi(getenv("VB_PIPELINE")) != 0;
+  return mf_call(ctx, count, slots, n, d, n_total, family, df, thetas, flags, cv_mode, rs, pipelined);
 }
 
 int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p) {
@@ -393,7 +438,7 @@ int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p
   if (!rs.host || !rs.pending || p > rs.p)
     return fail(ctx, VB_ERR_STATE, "result slot %d holds no pending result of size %lld", rslot,
                 (long long)p);
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VB_TRY(wait_ticket(ctx, rs.batch_id));
   *value = rs.host[rs.p];
   memcpy(grad, rs.host + rs.p + 1, (size_t)p * sizeof(double));
   return VB_OK;
@@ -409,7 +454,7 @@ int vb_profile_enable(vb_ctx* ctx, int on) {
 int vb_profile_read(vb_ctx* ctx, int64_t* launches, int64_t* evals, double* total_ms, int reset) {
   if (!ctx || !launches || !total_ms) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_HIP(ctx, hipSetDevice(ctx->device));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VB_TRY(sync_streams(ctx));
   double ms = 0.0;
   for (size_t i = 0; i < ctx->prof_used; ++i) {
     float t = 0.f;

@@ -8,10 +8,10 @@
 
 namespace vb {
 
-int comm_allreduce_sum(vb_ctx* ctx, double* buf, size_t count) {
+int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count) {
   if (!ctx->comm) return VB_OK;
   ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm,
-                                 ctx->stream);
+                                 stream);
   if (r != ncclSuccess)
     return fail(ctx, VB_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
   return VB_OK;

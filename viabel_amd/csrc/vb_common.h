@@ -51,6 +51,20 @@ struct NoiseSlot {
   int64_t n = 0, d = 0, ld = 0;   // ld: row stride in doubles (multiple of 16)
 };
 
+// Software pipeline over three HIP streams (prep | streaming kernel | finalize + collectives), used
+// by the asynchronous batch entry points so that consecutive batches overlap.
+constexpr int kPipeSets = 3;
+struct Pipeline {
+  hipStream_t pre = nullptr, post = nullptr;
+  hipEvent_t ev_main = nullptr;
+  hipEvent_t ev_prep[kPipeSets] = {}, ev_k1[kPipeSets] = {}, ev_fin[kPipeSets] = {};
+  bool fin_valid[kPipeSets] = {};
+  uint64_t seq = 0;
+  int last_set = 0;
+  bool main_dirty = true;     // main-stream work was enqueued that `pre` has not been ordered after
+  bool post_pending = false;  // `post` holds work the main stream has not been ordered after
+};
+
 struct ResultSlot {
   double* host = nullptr;   // pinned, device-mapped: [theta staging (p) | value | grad (p)]
   double* dev = nullptr;    // device address of `host`
@@ -95,6 +109,9 @@ struct vb_ctx {
   // result slot is never re-staged while the evaluation that used it is still in flight
   std::vector<hipEvent_t> batch_events;
   uint64_t batch_id = 0, batch_done = 0;
+
+  vb::Pipeline pipe;
+  hipStream_t result_stream = nullptr;  // stream the last enqueue's results are produced on
 };
 
 namespace vb {
@@ -129,9 +146,12 @@ struct MfCall {
   unsigned flags = 0;
   int cv_mode = 0;
   int mode = 0;        // 0: ELBO (ExclusiveKL); 1: weighted gradient only
+  bool pipelined = false;   // spread prep / stream / finalize over the three pipeline streams
   double scale = 0.0;  // mode 1
 };
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
+int pipe_init(vb_ctx* ctx);
+int sync_streams(vb_ctx* ctx);   // main + pipeline streams
 
 // Philox noise generation (vb_rng.hip)
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,
@@ -141,7 +161,7 @@ int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t
 int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev);
 
 // RCCL (vb_comm.hip)
-int comm_allreduce_sum(vb_ctx* ctx, double* buf, size_t count);
+int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count);
 
 // profiling: event pair for the next launch of the dominant kernel (nullptrs when disabled)
 void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals);

@@ -708,7 +708,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 // Enqueue prep -> accumulate -> finalize [-> all-reduce -> epilogue] for a batch of `count`
-// independent evaluations on ctx->stream.
+// independent evaluations.
 int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   const int64_t n = c.n, d = c.d;
   if (c.count < 1 || c.count > kMaxBatch)
@@ -780,10 +780,13 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   ws.off_pscal = carve((int64_t)KS_NUM * g.n_rb * g.n_cb);
   ws.stride = off;
   ws.sum_len = round_up((int64_t)SF_NUM + (int64_t)CF_NUM * g.Dp, 16);
-  VB_TRY(ensure(ctx, ctx->workspace, (size_t)ws.stride * c.count * sizeof(double)));
-  VB_TRY(ensure(ctx, ctx->sums, (size_t)ws.sum_len * c.count * sizeof(double)));
-  ws.base = (double*)ctx->workspace.ptr;
-  ws.sums = (double*)ctx->sums.ptr;
+  // three rotating workspace sets: batch i+1 is prepared, and batch i-1 finalised, while batch i streams
+  const int set = (int)(ctx->pipe.seq % kPipeSets);
+  ctx->pipe.seq++;
+  VB_TRY(ensure(ctx, ctx->workspace, (size_t)ws.stride * kMaxBatch * kPipeSets * sizeof(double)));
+  VB_TRY(ensure(ctx, ctx->sums, (size_t)ws.sum_len * kMaxBatch * kPipeSets * sizeof(double)));
+  ws.base = (double*)ctx->workspace.ptr + (size_t)set * ws.stride * kMaxBatch;
+  ws.sums = (double*)ctx->sums.ptr + (size_t)set * ws.sum_len * kMaxBatch;
 
   BatchPtrs bp;
   for (int b = 0; b < kMaxBatch; ++b) {
@@ -794,19 +797,47 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
     bp.roww[b] = c.roww[s];
   }
 
-  hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)g.n_prep, (unsigned)c.count), dim3(256), 0,
-                     ctx->stream, bp, ws, g, ctx->model);
+  // ---- stream plan -----------------------------------------------------------------------------
+  // pipelined: prep on `pre`, the streaming kernel on the main stream, finalize (+ all-reduce,
+  // epilogue) on `post`, chained by events; otherwise everything in order on the main stream.
+  Pipeline& P = ctx->pipe;
+  hipStream_t st_pre = ctx->stream, st_main = ctx->stream, st_post = ctx->stream;
+  if (c.pipelined) {
+    VB_TRY(pipe_init(ctx));
+    st_pre = P.pre;
+    st_post = P.post;
+    if (P.main_dirty) {   // earlier main-stream work (noise generation, uploads, ...) precedes prep
+      VB_HIP(ctx, hipEventRecord(P.ev_main, ctx->stream));
+      VB_HIP(ctx, hipStreamWaitEvent(st_pre, P.ev_main, 0));
+      P.main_dirty = false;
+    }
+    if (P.fin_valid[set]) VB_HIP(ctx, hipStreamWaitEvent(st_pre, P.ev_fin[set], 0));   // set is free again
+  } else if (P.post_pending) {   // order this in-order call after everything the pipeline has in flight
+    VB_HIP(ctx, hipStreamWaitEvent(ctx->stream, P.ev_fin[P.last_set], 0));
+    P.post_pending = false;
+  }
+
+  hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)g.n_prep, (unsigned)c.count), dim3(256), 0, st_pre,
+                     bp, ws, g, ctx->model);
   VB_HIP(ctx, hipGetLastError());
+  if (c.pipelined) {
+    VB_HIP(ctx, hipEventRecord(P.ev_prep[set], st_pre));
+    VB_HIP(ctx, hipStreamWaitEvent(st_main, P.ev_prep[set], 0));
+  }
 
   Launch L;
   L.grid = dim3((unsigned)(g.n_rb * g.n_cb), (unsigned)c.count);
-  L.st = ctx->stream;
+  L.st = st_main;
   prof_events(ctx, &L.ev0, &L.ev1, c.count);
   if (ctx->model.id == VB_MODEL_GAUSS_DIAG)
     launch_accum_model<VB_MODEL_GAUSS_DIAG>(mom, tsc, weighted, L, bp, ws, g);
   else
     launch_accum_model<VB_MODEL_FUNNEL>(mom, tsc, weighted, L, bp, ws, g);
   VB_HIP(ctx, hipGetLastError());
+  if (c.pipelined) {
+    VB_HIP(ctx, hipEventRecord(P.ev_k1[set], st_main));
+    VB_HIP(ctx, hipStreamWaitEvent(st_post, P.ev_k1[set], 0));
+  }
 
   EpiArgs e;
   memset(&e, 0, sizeof e);
@@ -827,15 +858,38 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   const bool fused = c.mode == 0 && c.cv_mode == VB_CV_NONE && !ctx->comm;
   e.reduce_only = fused ? 0 : 1;
   hipLaunchKernelGGL(mf_finalize_kernel, dim3((unsigned)(g.Dp / 64), (unsigned)c.count), dim3(256), 0,
-                     ctx->stream, e, bp, ws);
+                     st_post, e, bp, ws);
   VB_HIP(ctx, hipGetLastError());
-  if (fused) return VB_OK;
+  if (!fused) {
+    if (ctx->comm)   // one all-reduce for the whole batch: [count][sum_len] doubles
+      VB_TRY(comm_allreduce_sum(ctx, st_post, ws.sums, (size_t)ws.sum_len * c.count));
+    hipLaunchKernelGGL(mf_epilogue_kernel, dim3(1, (unsigned)c.count), dim3(256), 0, st_post, e, bp, ws);
+    VB_HIP(ctx, hipGetLastError());
+  }
+  if (c.pipelined) {
+    VB_HIP(ctx, hipEventRecord(P.ev_fin[set], st_post));
+    P.fin_valid[set] = true;
+    P.post_pending = true;
+    P.last_set = set;
+  } else {
+    P.fin_valid[set] = false;   // ordered by the main stream itself ...
+    P.main_dirty = true;        // ... which a later pipelined prep must wait for
+  }
+  ctx->result_stream = st_post;
+  return VB_OK;
+}
 
-  if (ctx->comm)   // one all-reduce for the whole batch: [count][sum_len] doubles
-    VB_TRY(comm_allreduce_sum(ctx, ws.sums, (size_t)ws.sum_len * c.count));
-  hipLaunchKernelGGL(mf_epilogue_kernel, dim3(1, (unsigned)c.count), dim3(256), 0, ctx->stream, e, bp,
-                     ws);
-  VB_HIP(ctx, hipGetLastError());
+int pipe_init(vb_ctx* ctx) {
+  Pipeline& P = ctx->pipe;
+  if (P.pre) return VB_OK;
+  VB_HIP(ctx, hipStreamCreateWithFlags(&P.pre, hipStreamNonBlocking));
+  VB_HIP(ctx, hipStreamCreateWithFlags(&P.post, hipStreamNonBlocking));
+  VB_HIP(ctx, hipEventCreateWithFlags(&P.ev_main, hipEventDisableTiming));
+  for (int i = 0; i < kPipeSets; ++i) {
+    VB_HIP(ctx, hipEventCreateWithFlags(&P.ev_prep[i], hipEventDisableTiming));
+    VB_HIP(ctx, hipEventCreateWithFlags(&P.ev_k1[i], hipEventDisableTiming));
+    VB_HIP(ctx, hipEventCreateWithFlags(&P.ev_fin[i], hipEventDisableTiming));
+  }
   return VB_OK;
 }
 
