@@ -117,6 +117,19 @@ int vb_elbo_grad_meanfield_batch_async(vb_ctx* ctx, int count, const int* slots,
                                        unsigned flags, int cv_mode, const int* rslots);
 int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p);
 
+/* ---- ExclusiveKL, full-rank Gaussian family -------------------------------------------
+ * New family (no reference class) behind the ApproximationFamily API with the flat
+ * layout of viabel/approximations.py:315-319: theta = [mu (D) | free Cholesky (D(D+1)/2)],
+ * z = mu + L eps.  Estimator: objectives.py:154-164 (entropy form).  fp64 MFMA GEMMs.
+ * vb_elbo_grad_fullrank = set_theta + enqueue + get; the three-step form keeps theta and the
+ * result resident on the device (P = D + D(D+1)/2 doubles is 4.2 MB at D = 1024).          */
+int vb_elbo_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
+                          const double* theta, unsigned flags, double* value, double* grad);
+int vb_fullrank_set_theta(vb_ctx* ctx, const double* theta, int64_t d);
+int vb_elbo_grad_fullrank_enqueue(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
+                                  unsigned flags);
+int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p);
+
 /* ---- multi-GPU: Monte-Carlo axis sharded, one RCCL all-reduce of the partial sums --- */
 #define VB_COMM_ID_BYTES 128
 int vb_comm_unique_id(char id[VB_COMM_ID_BYTES]);

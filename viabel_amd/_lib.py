@@ -58,6 +58,13 @@ SIGNATURES = {
                                                           ctypes.c_int, ctypes.c_double, _c_double_p,
                                                           ctypes.c_uint, ctypes.c_int,
                                                           ctypes.POINTER(ctypes.c_int)]),
+    'vb_elbo_grad_fullrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_int64, _c_double_p, ctypes.c_uint, _c_double_p,
+                                             _c_double_p]),
+    'vb_fullrank_set_theta': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64]),
+    'vb_elbo_grad_fullrank_enqueue': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                                     ctypes.c_int64, ctypes.c_uint]),
+    'vb_fullrank_get': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64]),
     'vb_result_get': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64]),
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
@@ -241,6 +248,32 @@ class Engine:
         value = ctypes.c_double(0.0)
         grad = np.empty(p, dtype=np.float64)
         self._check(self._lib.vb_result_get(self._ctx, rslot, ctypes.byref(value), _dptr(grad), p))
+        return value.value, grad
+
+    # ------------------------------------------------------------------ ExclusiveKL, full rank
+    def elbo_grad_fullrank(self, slot, n, d, theta, flags=0, n_total=None):
+        theta = _f64(theta)
+        p = d + d * (d + 1) // 2
+        value = ctypes.c_double(0.0)
+        grad = np.empty(p, dtype=np.float64)
+        self._check(self._lib.vb_elbo_grad_fullrank(
+            self._ctx, slot, n, d, n if n_total is None else n_total, _dptr(theta), flags,
+            ctypes.byref(value), _dptr(grad)))
+        return value.value, grad
+
+    def fullrank_set_theta(self, theta, d):
+        theta = _f64(theta)
+        self._check(self._lib.vb_fullrank_set_theta(self._ctx, _dptr(theta), d))
+
+    def elbo_grad_fullrank_enqueue(self, slot, n, d, flags=0, n_total=None):
+        self._check(self._lib.vb_elbo_grad_fullrank_enqueue(
+            self._ctx, slot, n, d, n if n_total is None else n_total, flags))
+
+    def fullrank_get(self, d):
+        p = d + d * (d + 1) // 2
+        value = ctypes.c_double(0.0)
+        grad = np.empty(p, dtype=np.float64)
+        self._check(self._lib.vb_fullrank_get(self._ctx, ctypes.byref(value), _dptr(grad), p))
         return value.value, grad
 
     # ------------------------------------------------------------------ multi-GPU

@@ -204,7 +204,8 @@ int vb_destroy(vb_ctx* ctx) {
     if (r.host) (void)hipHostFree(r.host);
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
-                          &ctx->scratch, &ctx->scratch2, &ctx->rowvec})
+                          &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
+                          &ctx->fr_out})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& ev : ctx->prof_events) {
@@ -311,8 +312,13 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams, 
   } else if (model_id == VB_MODEL_GAUSS_FULL) {
     if (n_dparams != (size_t)(dim + dim * dim + 1) || !dparams)
       return fail(ctx, VB_ERR_INVALID, "gauss_full expects dparams = [mean(D) | P(DxD) | logdet P]");
-    dev.assign(dparams, dparams + dim + dim * dim);
     m.c0 = 0.5 * dparams[dim + dim * dim] - 0.5 * dim * kLog2Pi;
+    m.ldp = round_up(dim, 16);
+    // [mean (ldp) | P (dim x ldp)], rows padded so every GEMM operand row is 16-B aligned
+    dev.assign((size_t)m.ldp * (dim + 1), 0.0);
+    for (int64_t i = 0; i < dim; ++i) dev[i] = dparams[i];
+    for (int64_t i = 0; i < dim; ++i)
+      for (int64_t j = 0; j < dim; ++j) dev[(size_t)m.ldp * (i + 1) + j] = dparams[dim + i * dim + j];
   } else {
     return fail(ctx, VB_ERR_INVALID, "unknown model id %d", model_id);
   }
@@ -322,7 +328,7 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams, 
                                hipMemcpyHostToDevice, ctx->stream));
     VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m.p0 = (const double*)ctx->model_params.ptr;
-    m.p1 = m.p0 + dim;
+    m.p1 = m.p0 + (model_id == VB_MODEL_GAUSS_FULL ? m.ldp : dim);
   }
   ctx->model = m;
   return VB_OK;
@@ -442,6 +448,55 @@ int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p
   *value = rs.host[rs.p];
   memcpy(grad, rs.host + rs.p + 1, (size_t)p * sizeof(double));
   return VB_OK;
+}
+
+// ---- ExclusiveKL, full-rank Gaussian ---------------------------------------------------------------
+int vb_fullrank_set_theta(vb_ctx* ctx, const double* theta, int64_t d) {
+  if (!ctx || !theta || d <= 0) return fail(ctx, VB_ERR_INVALID, "bad argument");
+  const int64_t p = d + d * (d + 1) / 2;
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(ensure(ctx, ctx->fr_theta, (size_t)p * sizeof(double)));
+  VB_TRY(ensure(ctx, ctx->fr_out, (size_t)(1 + p) * sizeof(double)));
+  VB_HIP(ctx, hipMemcpyAsync(ctx->fr_theta.ptr, theta, (size_t)p * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller keeps ownership of `theta`
+  ctx->fr_p = p;
+  return VB_OK;
+}
+
+int vb_elbo_grad_fullrank_enqueue(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
+                                  unsigned flags) {
+  if (!ctx) return VB_ERR_INVALID;
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (ctx->fr_p != d + d * (d + 1) / 2)
+    return fail(ctx, VB_ERR_STATE, "no resident parameter of dimension %lld (vb_fullrank_set_theta)",
+                (long long)d);
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
+  if (flags & VB_FLAG_PATH_DERIV)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "use_path_deriv is not implemented for the full-rank family");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return fr_elbo_grad_enqueue(ctx, ctx->noise[slot], n, d, n_total, (const double*)ctx->fr_theta.ptr,
+                              (double*)ctx->fr_out.ptr);
+}
+
+int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p) {
+  if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (p != ctx->fr_p || !ctx->fr_out.ptr) return fail(ctx, VB_ERR_STATE, "no full-rank result of length %lld", (long long)p);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_HIP(ctx, hipMemcpyAsync(value, ctx->fr_out.ptr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipMemcpyAsync(grad, (const double*)ctx->fr_out.ptr + 1, (size_t)p * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VB_OK;
+}
+
+int vb_elbo_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
+                          const double* theta, unsigned flags, double* value, double* grad) {
+  VB_TRY(vb_fullrank_set_theta(ctx, theta, d));
+  VB_TRY(vb_elbo_grad_fullrank_enqueue(ctx, slot, n, d, n_total, flags));
+  return vb_fullrank_get(ctx, value, grad, d + d * (d + 1) / 2);
 }
 
 // ---- measurement --------------------------------------------------------------------------------

@@ -38,7 +38,8 @@ struct ModelDev {
   double tau = 1.0;    // funnel: log_sigma_stdev
   double c0 = 0.0;     // additive constant of f per sample
   const double* p0 = nullptr;   // gauss_diag: mean[D]       gauss_full: mean[D]
-  const double* p1 = nullptr;   // gauss_diag: 1/sd^2 [D]    gauss_full: P [D x D]
+  const double* p1 = nullptr;   // gauss_diag: 1/sd^2 [D]    gauss_full: P [D x ldp]
+  int64_t ldp = 0;              // gauss_full: row stride of P (multiple of 16)
 };
 
 struct DeviceBuffer {
@@ -96,6 +97,10 @@ struct vb_ctx {
   vb::DeviceBuffer scratch;             // generic device scratch (x upload, ...)
   vb::DeviceBuffer scratch2;            // per-row outputs
   vb::DeviceBuffer rowvec;              // per-row weights
+  vb::DeviceBuffer fr_work;             // full-rank pipeline work buffers
+  vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
+  vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
+  int64_t fr_p = 0;                     // length of the resident full-rank parameter
 
   void* comm = nullptr;                 // ncclComm_t when a communicator is attached
   int n_ranks = 1, rank = 0;
@@ -152,6 +157,10 @@ struct MfCall {
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
 int pipe_init(vb_ctx* ctx);
 int sync_streams(vb_ctx* ctx);   // main + pipeline streams
+
+// full-rank Gaussian ExclusiveKL (vb_fullrank.hip)
+int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
+                         const double* theta_dev, double* out_dev);
 
 // Philox noise generation (vb_rng.hip)
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,

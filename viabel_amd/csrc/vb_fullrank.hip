@@ -1,0 +1,351 @@
+// Full-rank Gaussian family: ExclusiveKL value and gradient on gfx950 fp64 matrix cores.
+//
+// The reference has no dense Gaussian family; this follows its ApproximationFamily
+// contract (viabel/approximations.py:26-182) with MultivariateT's parameter layout
+// (approximations.py:315-319): theta = [mu (D) | free Cholesky of Sigma (D(D+1)/2)], L = chol with
+// exp on the diagonal, z_n = mu + L eps_n.  The estimator is objectives.py:154-164 (entropy form):
+//   value  = -(mean_n f(z_n) + 1/2 D (1 + log 2 pi) + sum_i log L_ii)
+//   d/dmu  = -mean_n g_n                       g_n = grad f(z_n)
+//   d/dL   = -tril(mean_n g_n eps_n')          free diagonal: dL_ii * L_ii - 1
+//
+// Pipeline (one HIP stream):
+//   fr_unpack          theta -> mu, L^T (dense, zeros below the diagonal of L^T)
+//   GEMM 1 (MFMA)      Z = E L^T + mu      [N x D x D, triangular k-range]  fused model epilogue
+//   model              gauss_diag: G in the GEMM-1 epilogue; funnel: row kernel Z -> G;
+//                      gauss_full: GEMM 2 (MFMA)  G = -(Z - m) P
+//   fr_colsum          column sums of G (-> d/dmu) and sum_n f(z_n), per 128-row block
+//   GEMM 3 (MFMA)      C = G^T E           [D x D x N, lower-triangular tiles, split-K]
+//   fr_reduce          fixed-order sum of the split-K slabs / row-block partials -> sum vector
+//   [RCCL all-reduce of the sum vector when the Monte-Carlo axis is sharded]
+//   fr_epilogue        sum vector -> (value, grad) in the flat free-Cholesky layout
+//
+// Bound: fp64 MFMA (4 N D^2 flop dense convention vs N D 8 bytes: AI ~ D/2 flop/B >> ridge).
+#include "vb_gemm_f64.h"
+
+namespace vb {
+
+constexpr double kLog2PiFr = 1.8378770664093454835606594728112;
+
+__device__ __forceinline__ double fr_wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+
+// block-wide sum (256 threads), total returned to every thread
+__device__ __forceinline__ double fr_block_sum(double x, double* sh) {
+  x = fr_wave_sum(x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = x;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// ---- unpack ---------------------------------------------------------------------------------------
+// Lt[k][j] = L[j][k] (so Lt is upper triangular), row stride ldl; also copies mu.
+__global__ void __launch_bounds__(256) fr_unpack_kernel(const double* __restrict__ theta, int d,
+                                                        int64_t ldl, double* __restrict__ Lt,
+                                                        double* __restrict__ mu) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < d) mu[idx] = theta[idx];
+  if (idx >= (int64_t)d * d) return;
+  const int k = (int)(idx / d), j = (int)(idx % d);   // element Lt[k][j] = L[j][k]
+  double v = 0.0;
+  if (k <= j) {
+    v = theta[d + (int64_t)j * (j + 1) / 2 + k];
+    if (k == j) v = exp(v);
+  }
+  Lt[k * ldl + j] = v;
+}
+
+// ---- GEMM epilogues ---------------------------------------------------------------------------------
+struct EpiStoreZ {          // Z = acc + mu - shift   (shift = 0, or the target mean for gauss_full)
+  double* Z;
+  int64_t ldz;
+  const double* mu;
+  const double* shift;      // may be nullptr
+  __device__ void operator()(int, int row, int col, double acc) const {
+    double z = acc + mu[col];
+    if (shift) z -= shift[col];
+    Z[(int64_t)row * ldz + col] = z;
+  }
+};
+
+struct EpiGaussDiag {       // G = -(z - m) / sd^2  straight from the GEMM-1 accumulators
+  double* G;
+  int64_t ldz;
+  const double* mu;
+  const double* mean;
+  const double* ivar;
+  __device__ void operator()(int, int row, int col, double acc) const {
+    const double dz = acc + mu[col] - mean[col];
+    G[(int64_t)row * ldz + col] = -dz * ivar[col];
+  }
+};
+
+struct EpiNegate {          // G = -acc   (gauss_full: G = -(Z - m) P)
+  double* G;
+  int64_t ldz;
+  __device__ void operator()(int, int row, int col, double acc) const {
+    G[(int64_t)row * ldz + col] = -acc;
+  }
+};
+
+struct EpiSplitSlab {       // C_split[i][j] = acc
+  double* C;
+  int64_t ldc, slab;
+  __device__ void operator()(int split, int row, int col, double acc) const {
+    C[split * slab + (int64_t)row * ldc + col] = acc;
+  }
+};
+
+// ---- funnel: row kernel Z -> G, f ---------------------------------------------------------------
+// one wave per row; G[n][j] = -z_j w (j != k), G[n][k] = -v/tau^2 - (D-1) + w sum_{j != k} z_j^2
+__global__ void __launch_bounds__(256) fr_funnel_kernel(const double* __restrict__ Z, double* __restrict__ G,
+                                                        int64_t ldz, int64_t n, int d, ModelDev m,
+                                                        double* __restrict__ fpart) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  double f = 0.0;
+  if (row < n) {
+    const double* z = Z + row * ldz;
+    double* g = G + row * ldz;
+    const double v = z[m.k];
+    const double w = exp(-2.0 * v);
+    double ss = 0.0;
+    for (int c = lane; c < d; c += 64) {
+      if (c == m.k) continue;
+      const double zc = z[c];
+      g[c] = -zc * w;
+      ss = fma(zc, zc, ss);
+    }
+    ss = fr_wave_sum(ss);
+    if (lane == 0) {
+      const double it2 = 1.0 / (m.tau * m.tau), dm1 = (double)(d - 1);
+      g[m.k] = fma(-v, it2, -dm1) + w * ss;
+      f = v * fma(-0.5 * v, it2, -dm1) - 0.5 * w * ss;
+    }
+  }
+  f = fr_block_sum(f, sh);
+  if (threadIdx.x == 0) fpart[blockIdx.x] = f;
+}
+
+// ---- column sums of G and sum of f per 128-row block ------------------------------------------------
+// grid (ceil(D / 256), ceil(N / 128)); fmode 0: no f here, 1: gauss_diag f = -1/2 g^2 / ivar,
+// 2: gauss_full f = 1/2 zc g
+__global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict__ G,
+                                                        const double* __restrict__ Zc, int64_t ldz,
+                                                        int64_t n, int d, int fmode,
+                                                        const double* __restrict__ ivar,
+                                                        double* __restrict__ colpart,
+                                                        double* __restrict__ fpart) {
+  __shared__ double sh[4];
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * 128;
+  const int64_t r1 = r0 + 128 < n ? r0 + 128 : n;
+  double s = 0.0, f = 0.0;
+  if (col < d) {
+    const double hiv = fmode == 1 ? -0.5 / ivar[col] : 0.0;
+    for (int64_t r = r0; r < r1; ++r) {
+      const double g = G[r * ldz + col];
+      s += g;
+      if (fmode == 1) f = fma(hiv * g, g, f);
+      if (fmode == 2) f = fma(0.5 * Zc[r * ldz + col], g, f);
+    }
+    colpart[(int64_t)blockIdx.y * ldz + col] = s;
+  }
+  f = fr_block_sum(f, sh);
+  if (threadIdx.x == 0) fpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = f;
+}
+
+// ---- reduce: split-K slabs, row-block partials -> sum vector ------------------------------------------
+// sum vector layout: [F | colsum (ldz) | C (d x ldl)], F at index 0, colsum from 16, C from 16 + ldz
+struct FrSums {
+  double* sums;
+  int64_t off_col, off_c, len;
+};
+
+__global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict__ Cpart, int splits,
+                                                        int64_t slab, int d, int64_t ldl,
+                                                        const double* __restrict__ colpart, int n_rb,
+                                                        int64_t ldz, const double* __restrict__ fpart,
+                                                        int n_fpart, FrSums S) {
+  __shared__ double sh[4];
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nC = (int64_t)d * ldl;
+  if (idx < nC) {
+    const int i = (int)(idx / ldl), j = (int)(idx % ldl);
+    double s = 0.0;
+    if (j <= i)
+      for (int k = 0; k < splits; ++k) s += Cpart[k * slab + idx];
+    S.sums[S.off_c + idx] = s;
+  }
+  if (idx < ldz) {
+    double s = 0.0;
+    if (idx < d)
+      for (int rb = 0; rb < n_rb; ++rb) s += colpart[(int64_t)rb * ldz + idx];
+    S.sums[S.off_col + idx] = s;
+  }
+  if (blockIdx.x == 0) {
+    double f = 0.0;
+    for (int e = threadIdx.x; e < n_fpart; e += 256) f += fpart[e];
+    f = fr_block_sum(f, sh);
+    if (threadIdx.x == 0) S.sums[0] = f;
+  }
+}
+
+// ---- epilogue: sum vector -> (value, grad) in the flat layout --------------------------------------
+__global__ void __launch_bounds__(256) fr_epilogue_kernel(FrSums S, const double* __restrict__ theta,
+                                                          int d, int64_t ldl, double n_local_w,
+                                                          double n_total, double c0,
+                                                          double* __restrict__ out) {
+  __shared__ double sh[4];
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t np = (int64_t)d * (d + 1) / 2;
+  const double invN = 1.0 / n_total;
+  if (p < np) {
+    int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(i + 1) * (i + 2) / 2 <= p) ++i;
+    while ((int64_t)i * (i + 1) / 2 > p) --i;
+    const int j = (int)(p - (int64_t)i * (i + 1) / 2);
+    double g = -S.sums[S.off_c + (int64_t)i * ldl + j] * invN;     // d value / d L_ij
+    if (i == j) g = g * exp(theta[d + p]) - 1.0;                    // free (log) diagonal + entropy
+    out[1 + d + p] = g;
+  }
+  if (p < d) out[1 + p] = -S.sums[S.off_col + p] * invN;
+  if (blockIdx.x == 0) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < d; i += 256) t += theta[d + (int64_t)i * (i + 1) / 2 + i];
+    const double sum_logdiag = fr_block_sum(t, sh);
+    if (threadIdx.x == 0) {
+      const double F = S.sums[0] + n_local_w * c0;
+      const double H = 0.5 * d * (1.0 + kLog2PiFr) + sum_logdiag;
+      out[0] = -(F * invN + H);
+    }
+  }
+}
+
+// ---- host orchestration ------------------------------------------------------------------------------
+int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
+                         const double* theta_dev, double* out_dev) {
+  const ModelDev& m = ctx->model;
+  if (m.id != VB_MODEL_GAUSS_DIAG && m.id != VB_MODEL_FUNNEL && m.id != VB_MODEL_GAUSS_FULL)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "full-rank path: unsupported model id %d", m.id);
+  if (m.dim != d)
+    return fail(ctx, VB_ERR_INVALID, "model dimension %d != family dimension %lld", m.dim, (long long)d);
+  if (n <= 0 || d <= 0 || n > ns.n || d != ns.d)
+    return fail(ctx, VB_ERR_INVALID, "noise slot holds %lld x %lld, evaluation asks %lld x %lld",
+                (long long)ns.n, (long long)ns.d, (long long)n, (long long)d);
+  hipStream_t st = ctx->stream;
+  const int D = (int)d;
+  const int64_t ldl = round_up(d, 16), ldz = round_up(d, 16);
+  const int tiles = gemm_tiles(D, kGemmBM);
+  const int lower_tiles = tiles * (tiles + 1) / 2;
+  int splits = (ctx->prop.multiProcessorCount + lower_tiles - 1) / lower_tiles;
+  const int max_splits = (int)(n / 256) > 0 ? (int)(n / 256) : 1;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int n_rb = (int)((n + 127) / 128);
+  const int cs_gx = (D + 255) / 256;
+  const int n_fpart = m.id == VB_MODEL_FUNNEL ? (int)((n + 3) / 4) : n_rb * cs_gx;
+  const int64_t slab = d * ldl;
+
+  // device buffers (one allocation, carved)
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t o_mu = carve(ldz), o_lt = carve(slab), o_z = carve(n * ldz), o_g = carve(n * ldz),
+                o_cpart = carve((int64_t)splits * slab), o_col = carve((int64_t)n_rb * ldz),
+                o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx);
+  FrSums S;
+  S.off_col = 16;
+  S.off_c = 16 + ldz;
+  S.len = 16 + ldz + slab;
+  const int64_t o_sums = carve(S.len);
+  VB_TRY(ensure(ctx, ctx->fr_work, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->fr_work.ptr;
+  double *mu = base + o_mu, *Lt = base + o_lt, *Z = base + o_z, *G = base + o_g, *Cpart = base + o_cpart,
+         *colpart = base + o_col, *fpart = base + o_fpart;
+  S.sums = base + o_sums;
+
+  hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((d * d + 255) / 256)), dim3(256), 0, st, theta_dev,
+                     D, ldl, Lt, mu);
+  VB_HIP(ctx, hipGetLastError());
+
+  // GEMM 1: Z[n][j] = sum_k E[n][k] Lt[k][j]   (Lt[k][j] = 0 for k > j)
+  GemmArgs g1;
+  g1.A = (const double*)ns.buf.ptr;
+  g1.lda = ns.ld;
+  g1.B = Lt;
+  g1.ldb = ldl;
+  g1.M = (int)n;
+  g1.N = D;
+  g1.K = D;
+  g1.tri_mode = 1;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int fmode = 0;
+  if (m.id == VB_MODEL_GAUSS_DIAG) {
+    gemm_f64_launch<true>(st, g1, 1, EpiGaussDiag{G, ldz, mu, m.p0, m.p1});
+    fmode = 1;
+  } else if (m.id == VB_MODEL_FUNNEL) {
+    gemm_f64_launch<true>(st, g1, 1, EpiStoreZ{Z, ldz, mu, nullptr});
+    VB_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fr_funnel_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)Z,
+                       G, ldz, n, D, m, fpart);
+  } else {
+    gemm_f64_launch<true>(st, g1, 1, EpiStoreZ{Z, ldz, mu, m.p0});   // Z - m
+    VB_HIP(ctx, hipGetLastError());
+    GemmArgs g2;                                   // G = -(Z - m) P,  P symmetric: B[k][j] = P[k][j]
+    g2.A = Z;
+    g2.lda = ldz;
+    g2.B = m.p1;
+    g2.ldb = m.ldp;
+    g2.M = (int)n;
+    g2.N = D;
+    g2.K = D;
+    g2.tri_mode = 0;
+    gemm_f64_launch<true>(st, g2, 1, EpiNegate{G, ldz});
+    fmode = 2;
+  }
+  VB_HIP(ctx, hipGetLastError());
+
+  hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
+                     (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
+                     m.id == VB_MODEL_FUNNEL ? fpart + n_fpart /*unused tail*/ : fpart);
+  VB_HIP(ctx, hipGetLastError());
+
+  // GEMM 3: C[i][j] = sum_n G[n][i] E[n][j], lower-triangular tiles, split over n
+  GemmArgs g3;
+  g3.A = G;
+  g3.lda = ldz;
+  g3.B = (const double*)ns.buf.ptr;
+  g3.ldb = ns.ld;
+  g3.M = D;
+  g3.N = D;
+  g3.K = (int)n;
+  g3.tri_mode = 2;
+  (void)ev0;
+  (void)ev1;
+  gemm_f64_launch<false>(st, g3, splits, EpiSplitSlab{Cpart, ldl, slab});
+  VB_HIP(ctx, hipGetLastError());
+
+  const int64_t red_items = slab > ldz ? slab : ldz;
+  hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((red_items + 255) / 256)), dim3(256), 0, st,
+                     (const double*)Cpart, splits, slab, D, ldl, (const double*)colpart, n_rb, ldz,
+                     (const double*)fpart, n_fpart, S);
+  VB_HIP(ctx, hipGetLastError());
+  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
+
+  const int64_t np = d * (d + 1) / 2;
+  hipLaunchKernelGGL(fr_epilogue_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, S, theta_dev,
+                     D, ldl, (double)n_total, (double)n_total, m.c0, out_dev);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+}  // namespace vb
