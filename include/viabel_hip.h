@@ -117,6 +117,14 @@ int vb_elbo_grad_meanfield_batch_async(vb_ctx* ctx, int count, const int* slots,
                                        unsigned flags, int cv_mode, const int* rslots);
 int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p);
 
+/* ---- AlphaDivergence, mean-field families (objectives.py:443-463) -----------------------
+ * value = log(mean_n s_n)/alpha + max_n lw_n,  s_n = exp(lw_n - max)^alpha,
+ * lw_n = f(z_n) - log q(z_n; theta);  grad = alpha/N sum_n s_n d lw_n/d theta (s not normalised,
+ * objectives.py:460).  The noise slot holds the draws of RandomState(seed) for the seed the
+ * caller took from the global numpy RNG (objectives.py:455).                                  */
+int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+                            const double* theta, double alpha, double* value, double* grad);
+
 /* ---- ExclusiveKL, full-rank Gaussian family -------------------------------------------
  * New family (no reference class) behind the ApproximationFamily API with the flat
  * layout of viabel/approximations.py:315-319: theta = [mu (D) | free Cholesky (D(D+1)/2)],

@@ -58,6 +58,9 @@ SIGNATURES = {
                                                           ctypes.c_int, ctypes.c_double, _c_double_p,
                                                           ctypes.c_uint, ctypes.c_int,
                                                           ctypes.POINTER(ctypes.c_int)]),
+    'vb_alpha_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                               ctypes.c_int, ctypes.c_double, _c_double_p, ctypes.c_double,
+                                               _c_double_p, _c_double_p]),
     'vb_elbo_grad_fullrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_int64, _c_double_p, ctypes.c_uint, _c_double_p,
                                              _c_double_p]),
@@ -248,6 +251,15 @@ class Engine:
         value = ctypes.c_double(0.0)
         grad = np.empty(p, dtype=np.float64)
         self._check(self._lib.vb_result_get(self._ctx, rslot, ctypes.byref(value), _dptr(grad), p))
+        return value.value, grad
+
+    # ------------------------------------------------------------------ AlphaDivergence, mean field
+    def alpha_grad_meanfield(self, slot, n, d, theta, family, alpha, df=0.0):
+        theta = _f64(theta)
+        value = ctypes.c_double(0.0)
+        grad = np.empty(2 * d, dtype=np.float64)
+        self._check(self._lib.vb_alpha_grad_meanfield(self._ctx, slot, n, d, family, float(df), _dptr(theta),
+                                                      float(alpha), ctypes.byref(value), _dptr(grad)))
         return value.value, grad
 
     # ------------------------------------------------------------------ ExclusiveKL, full rank

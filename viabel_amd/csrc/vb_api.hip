@@ -450,6 +450,26 @@ int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p
   return VB_OK;
 }
 
+// ---- AlphaDivergence, mean field (objectives.py:443-463) -------------------------------------------
+int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+                            const double* theta, double alpha, double* value, double* grad) {
+  if (!ctx || !theta || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (family != VB_FAMILY_MF_GAUSSIAN && family != VB_FAMILY_MF_STUDENT_T)
+    return fail(ctx, VB_ERR_INVALID, "family %d is not a mean-field family", family);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  ResultSlot& rs = ctx->sync_result;
+  VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
+  VB_TRY(alpha_enqueue(ctx, ctx->noise[slot], n, d, family, df, alpha, rs.dev, rs.dev + rs.p));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rs.pending = false;
+  *value = rs.host[rs.p];
+  memcpy(grad, rs.host + rs.p + 1, (size_t)(2 * d) * sizeof(double));
+  return VB_OK;
+}
+
 // ---- ExclusiveKL, full-rank Gaussian ---------------------------------------------------------------
 int vb_fullrank_set_theta(vb_ctx* ctx, const double* theta, int64_t d) {
   if (!ctx || !theta || d <= 0) return fail(ctx, VB_ERR_INVALID, "bad argument");

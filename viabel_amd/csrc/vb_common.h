@@ -153,9 +153,17 @@ struct MfCall {
   int mode = 0;        // 0: ELBO (ExclusiveKL); 1: weighted gradient only
   bool pipelined = false;   // spread prep / stream / finalize over the three pipeline streams
   double scale = 0.0;  // mode 1
+  const double* value_src = nullptr;   // mode 1: device scalar reported as the objective value
 };
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
 int pipe_init(vb_ctx* ctx);
+
+// per-row log weights and AlphaDivergence (vb_rowstats.hip)
+int rowstats_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_src,
+                     const ModelDev& model, int student, double df, double* cols, double* scal,
+                     double* out_f, double* out_b);
+int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df, double alpha,
+                  const double* theta_src, double* out);
 int sync_streams(vb_ctx* ctx);   // main + pipeline streams
 
 // full-rank Gaussian ExclusiveKL (vb_fullrank.hip)

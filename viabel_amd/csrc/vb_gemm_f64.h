@@ -81,43 +81,43 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g, const E
 
   // ---- global -> register staging ---------------------------------------------------------------
   d2v ra[4], rb[4];
+  // Branch-free: indices are clamped into range and the value zeroed afterwards (every operand row
+  // is padded to a multiple of 16 doubles, so the 16-B load of a pair that straddles the logical
+  // edge stays inside the allocation).
   auto load_slab = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       // B (and k-major A): one 128-double row per wave-load
       const int p = i * 256 + t;
       const int krow = p >> 6, c = (p & 63) * 2;
+      const int k = k0 + krow;
+      const int kc = k < k_end ? k : k_end - 1;
       {
-        const int k = k0 + krow, n = n0 + c;
-        d2v v = (d2v){0.0, 0.0};
-        if (k < k_end) {
-          const double* src = g.B + (int64_t)k * g.ldb + n;
-          if (n + 1 < g.N) v = *reinterpret_cast<const d2v*>(src);
-          else if (n < g.N) v.x = src[0];
-        }
+        const int n = n0 + c;
+        const int nc = n < g.N ? n : 0;
+        d2v v = *reinterpret_cast<const d2v*>(g.B + (int64_t)kc * g.ldb + nc);
+        v.x = (k < k_end && n < g.N) ? v.x : 0.0;
+        v.y = (k < k_end && n + 1 < g.N) ? v.y : 0.0;
         rb[i] = v;
       }
       if (!A_KCONTIG) {
-        const int k = k0 + krow, m = m0 + c;
-        d2v v = (d2v){0.0, 0.0};
-        if (k < k_end) {
-          const double* src = g.A + (int64_t)k * g.lda + m;
-          if (m + 1 < g.M) v = *reinterpret_cast<const d2v*>(src);
-          else if (m < g.M) v.x = src[0];
-        }
+        const int m = m0 + c;
+        const int mc = m < g.M ? m : 0;
+        d2v v = *reinterpret_cast<const d2v*>(g.A + (int64_t)kc * g.lda + mc);
+        v.x = (k < k_end && m < g.M) ? v.x : 0.0;
+        v.y = (k < k_end && m + 1 < g.M) ? v.y : 0.0;
         ra[i] = v;
       } else {
         // A[m][k]: wave-load q covers 16 rows x 4 k-pairs; 16 consecutive lanes = 16 distinct rows
         const int q = i * 4 + wave;
         const int row = (q >> 1) * 16 + (lane & 15);
         const int kp = (q & 1) * 4 + (lane >> 4);
-        const int m = m0 + row, k = k0 + 2 * kp;
-        d2v v = (d2v){0.0, 0.0};
-        if (m < g.M) {
-          const double* src = g.A + (int64_t)m * g.lda + k;
-          if (k + 1 < k_end) v = *reinterpret_cast<const d2v*>(src);
-          else if (k < k_end) v.x = src[0];
-        }
+        const int m = m0 + row, ka = k0 + 2 * kp;
+        const int mc = m < g.M ? m : 0;
+        const int kac = ka < k_end ? ka : 0;
+        d2v v = *reinterpret_cast<const d2v*>(g.A + (int64_t)mc * g.lda + kac);
+        v.x = (m < g.M && ka < k_end) ? v.x : 0.0;
+        v.y = (m < g.M && ka + 1 < k_end) ? v.y : 0.0;
         ra[i] = v;
       }
     }
@@ -141,15 +141,7 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g, const E
   };
 
   const int fi = lane & 15, fk = lane >> 4;
-  int buf = 0;
-  if (k_begin < k_end) {
-    load_slab(k_begin);
-    store_slab(0);
-  }
-  __syncthreads();
-  for (int k0 = k_begin; k0 < k_end; k0 += kGemmBK) {
-    const bool more = k0 + kGemmBK < k_end;
-    if (more) load_slab(k0 + kGemmBK);     // in flight while the MFMAs below run
+  auto compute_slab = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < kGemmBK / 4; ++kk) {
       double af[4], bf[4];
@@ -164,9 +156,22 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g, const E
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_slab(buf ^ 1);
+  };
+
+  if (k_begin < k_end) {
+    load_slab(k_begin);
+    store_slab(0);
     __syncthreads();
-    buf ^= 1;
+    int buf = 0;
+    // steady state: a single basic block per slab (keeps the 128 accumulator registers in place)
+    for (int k0 = k_begin + kGemmBK; k0 < k_end; k0 += kGemmBK) {
+      load_slab(k0);          // in flight while the MFMAs below run
+      compute_slab(buf);
+      store_slab(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+    compute_slab(buf);
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------

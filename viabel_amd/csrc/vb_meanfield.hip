@@ -372,6 +372,7 @@ struct EpiArgs {
   int cv_mode;
   int mode;                 // 0: ELBO; 1: weighted gradient only
   double scale;             // mode 1: grad = scale * [G | GE*sigma + W]
+  const double* value_src;  // mode 1: device scalar reported as the value (may be nullptr)
   int reduce_only;
   ModelDev model;
 };
@@ -598,7 +599,7 @@ mf_epilogue_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
     if (threadIdx.x == 0) {
       double F = tot.v[SF_F] + Wsum * a.model.c0;
       if (funnel) F += tot.v[SF_FK] - 0.5 * tot.v[SF_Q];
-      value[0] = F;
+      value[0] = a.value_src ? a.value_src[0] : F;
     }
     return;
   }
@@ -854,6 +855,7 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   e.cv_mode = c.cv_mode;
   e.mode = c.mode;
   e.scale = c.scale;
+  e.value_src = c.value_src;
   e.model = ctx->model;
   const bool fused = c.mode == 0 && c.cv_mode == VB_CV_NONE && !ctx->comm;
   e.reduce_only = fused ? 0 : 1;

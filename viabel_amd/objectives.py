@@ -218,4 +218,26 @@ class AlphaDivergence(StochasticVariationalObjective):
         return self._alpha
 
     def _update_objective_and_grad(self):
-        raise NotImplementedError('AlphaDivergence device path not built yet')
+        approx = self.approx
+        self._require_device_model()
+        if not isinstance(approx, (MFGaussian, MFStudentT)):
+            raise NotImplementedError('AlphaDivergence on the HIP engine supports MFGaussian and '
+                                      'MFStudentT; got {}'.format(type(approx).__name__))
+        alpha = self.alpha
+
+        def objective_grad_and_log_norm(var_param):
+            var_param = np.asarray(var_param, dtype=np.float64)
+            if var_param.shape != (approx.var_param_dim,):
+                raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+            # the reference draws a shared seed from the GLOBAL numpy RNG (objectives.py:455) and
+            # samples from a fresh RandomState(seed) (approximations.py:213)
+            seed = np.random.randint(2 ** 32)
+            eng = self._engine()
+            if eng.n_ranks > 1:
+                raise NotImplementedError('AlphaDivergence is not sharded across GPUs yet')
+            eng.set_model(self.model.device_spec())
+            n_local, _ = self._stage_noise(eng, self.num_mc_samples, seed=seed)
+            family, df = approx._device_family()
+            return eng.alpha_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, var_param, family, alpha, df=df)
+
+        self._objective_and_grad = objective_grad_and_log_norm
