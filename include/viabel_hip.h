@@ -125,6 +125,25 @@ int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p
 int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
                             const double* theta, double alpha, double* value, double* grad);
 
+/* ---- DISInclusiveKL, mean-field families (objectives.py:283-416) ------------------------
+ * refresh (objectives.py:393-398, :338-368): the noise slot holds the base draws of the state
+ * samples z_n = mu + sigma eps_n (kept on the device; z is never materialised).  Computes
+ * log p(z_n), log q(z_n; theta), the tempering prior's log density (a diagonal Gaussian given as an
+ * MFGaussian parameter [mu | log_sigma], tests/test_objectives.py:82-87), runs the 50-step ESS
+ * bisection on the tempering parameter, and returns eps, ess and the unnormalised weights
+ * w_n = exp(eps log prior + (1 - eps) log p - log q) (no max shift, :330).  log_p / log_q may be
+ * NULL.  Returns VB_ERR_NUMERIC with 'All weights zero! ...' as objectives.py:326-328 does.
+ * Clipping (:370-386) and resampling (:408, global numpy RNG) stay with the caller, which hands
+ * the per-sample weights (clipped w, or resampling counts) to
+ * grad: value = -scale sum_n weights_n log q(z_n; theta), grad = d value / d theta (:405-414).  */
+int vb_dis_refresh_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+                             const double* theta, const double* prior_theta, double eps_prev,
+                             double ess_target, int max_bisection_its, double* eps, double* ess,
+                             double* w, double* log_p, double* log_q);
+int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+                          const double* theta, const double* weights, double scale, double* value,
+                          double* grad);
+
 /* ---- ExclusiveKL, full-rank Gaussian family -------------------------------------------
  * New family (no reference class) behind the ApproximationFamily API with the flat
  * layout of viabel/approximations.py:315-319: theta = [mu (D) | free Cholesky (D(D+1)/2)],

@@ -52,6 +52,82 @@ def test_alpha_golden(vb, path):
     assert G.rel_err(grad, fx['grad_fd']) < 2e-7
 
 
+def _dis_fixtures():
+    return [p for p in G.fixtures('dis_') if 'multivariate' not in p]
+
+
+@pytest.mark.parametrize('path', _dis_fixtures(), ids=lambda p: p.split('/')[-1][:-4])
+def test_dis_golden(vb, path):
+    fx = G.load(path)
+    D = int(fx['dim'])
+    obj = vb.DISInclusiveKL(product_family(vb, fx, int(fx['seed'])), product_model(vb, fx), int(fx['n']),
+                            ess_target=int(fx['ess_target']), temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=fx['prior_params'], use_resampling=bool(fx['use_resampling']))
+    np.random.seed(int(fx['np_seed']))
+    value, grad = obj(fx['theta'])
+    assert G.rel_err(obj._eps, fx['eps']) < 1e-12
+    assert G.rel_err(obj._state_log_p_unnormalized, fx['log_p']) < 1e-12
+    assert G.rel_err(obj._state_log_q, fx['log_q']) < 1e-11
+    assert G.rel_err(obj._state_w_clipped, fx['w_clipped']) < 1e-10
+    assert G.rel_err(value, fx['value']) < 1e-11
+    assert G.rel_err(grad, fx['grad']) < 1e-11
+    assert G.rel_err(grad, fx['grad_fd']) < 2e-6
+
+
+@pytest.mark.parametrize('family', ['gauss', 't'])
+@pytest.mark.parametrize('use_resampling', [True, False])
+def test_dis_against_oracle_multi_step(vb, family, use_resampling):
+    """Several calls with a moving theta and num_resampling_batches = 2: refreshes on even steps,
+    reuses the state samples (with the NEW theta in log q) on odd steps."""
+    D, N = 130, 2048
+    rng = np.random.RandomState(5)
+    if family == 'gauss':
+        approx, ofamily = vb.MFGaussian(D, seed=3), ofam.MFGaussian(D)
+    else:
+        approx, ofamily = vb.MFStudentT(D, 7, seed=3), ofam.MFStudentT(D, 7)
+    mean, sd = 0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
+    kw = dict(use_resampling=use_resampling, num_resampling_batches=2)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=400, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, **kw)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, 400, ofam.MFGaussian(D), prior, **kw)
+    rs = np.random.RandomState(3)
+    theta = np.concatenate([0.1 * rng.randn(D), -0.2 + 0.1 * rng.randn(D)])
+    np.random.seed(11)
+    for step in range(4):
+        state = np.random.get_state()
+        value, grad = obj(theta)
+        np.random.set_state(state)
+        noise = ofamily.draw_noise(rs, N) if ref.needs_refresh() else None
+        if use_resampling:
+            if ref.needs_refresh():
+                ref.refresh(theta, noise)      # what __call__ does first (objectives.py:392-401)
+            idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
+            ref._objective_step += 1
+            xs = ref._state_samples[idx]
+            scale = ref._state_w_sum / N
+            ov = np.mean(-ofamily.log_density(theta, xs)) * scale
+            og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+        else:
+            ov, og = ref(theta, noise=noise)
+        assert G.rel_err(obj._eps, ref._eps) < 1e-11
+        assert G.rel_err(value, ov) < 1e-11, (step, value, ov)
+        assert G.rel_err(grad, og) < 1e-10, (step, G.rel_err(grad, og))
+        theta = theta - 0.01 * grad / (1 + np.abs(grad))
+
+
+def test_dis_all_weights_zero_raises(vb):
+    D, N = 4, 16
+    # (z - 1e200)^2 overflows: log p = -inf for every sample, so every log weight is -inf
+    obj = vb.DISInclusiveKL(vb.MFGaussian(D), vb.GaussianModel(1e200 * np.ones(D), 1e-100 * np.ones(D)), N,
+                            ess_target=8, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=np.zeros(2 * D))
+    with pytest.raises(ValueError) as info:
+        obj(np.concatenate([np.zeros(D), np.zeros(D)]))
+    assert str(info.value).startswith('All weights zero!')
+
+
 @pytest.mark.parametrize('D,N', [(1024, 4096), (77, 333), (300, 1000)])
 @pytest.mark.parametrize('family', ['gauss', 't'])
 def test_alpha_against_oracle(vb, D, N, family):

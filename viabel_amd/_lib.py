@@ -61,6 +61,14 @@ SIGNATURES = {
     'vb_alpha_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                ctypes.c_int, ctypes.c_double, _c_double_p, ctypes.c_double,
                                                _c_double_p, _c_double_p]),
+    'vb_dis_refresh_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                                ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
+                                                ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                                _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+                                                _c_double_p]),
+    'vb_dis_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
+                                             ctypes.c_double, _c_double_p, _c_double_p]),
     'vb_elbo_grad_fullrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_int64, _c_double_p, ctypes.c_uint, _c_double_p,
                                              _c_double_p]),
@@ -260,6 +268,27 @@ class Engine:
         grad = np.empty(2 * d, dtype=np.float64)
         self._check(self._lib.vb_alpha_grad_meanfield(self._ctx, slot, n, d, family, float(df), _dptr(theta),
                                                       float(alpha), ctypes.byref(value), _dptr(grad)))
+        return value.value, grad
+
+    # ------------------------------------------------------------------ DISInclusiveKL, mean field
+    def dis_refresh_meanfield(self, slot, n, d, theta, prior_theta, family, eps_prev, ess_target,
+                              max_bisection_its=50, df=0.0):
+        theta, prior_theta = _f64(theta), _f64(prior_theta)
+        eps, ess = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        w, lp, lq = (np.empty(n, dtype=np.float64) for _ in range(3))
+        self._check(self._lib.vb_dis_refresh_meanfield(
+            self._ctx, slot, n, d, family, float(df), _dptr(theta), _dptr(prior_theta), float(eps_prev),
+            float(ess_target), int(max_bisection_its), ctypes.byref(eps), ctypes.byref(ess), _dptr(w),
+            _dptr(lp), _dptr(lq)))
+        return eps.value, ess.value, w, lp, lq
+
+    def dis_grad_meanfield(self, slot, n, d, theta, weights, scale, family, df=0.0):
+        theta, weights = _f64(theta), _f64(weights)
+        value = ctypes.c_double(0.0)
+        grad = np.empty(2 * d, dtype=np.float64)
+        self._check(self._lib.vb_dis_grad_meanfield(self._ctx, slot, n, d, family, float(df), _dptr(theta),
+                                                    _dptr(weights), float(scale), ctypes.byref(value),
+                                                    _dptr(grad)))
         return value.value, grad
 
     # ------------------------------------------------------------------ ExclusiveKL, full rank

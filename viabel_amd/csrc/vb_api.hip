@@ -205,7 +205,7 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
-                          &ctx->fr_out})
+                          &ctx->fr_out, &ctx->dis_state})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& ev : ctx->prof_events) {
@@ -463,6 +463,44 @@ int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int fam
   ResultSlot& rs = ctx->sync_result;
   VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
   VB_TRY(alpha_enqueue(ctx, ctx->noise[slot], n, d, family, df, alpha, rs.dev, rs.dev + rs.p));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rs.pending = false;
+  *value = rs.host[rs.p];
+  memcpy(grad, rs.host + rs.p + 1, (size_t)(2 * d) * sizeof(double));
+  return VB_OK;
+}
+
+// ---- DISInclusiveKL, mean field (objectives.py:283-416) ---------------------------------------------
+int vb_dis_refresh_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+                             const double* theta, const double* prior_theta, double eps_prev,
+                             double ess_target, int max_bisection_its, double* eps, double* ess,
+                             double* w, double* log_p, double* log_q) {
+  if (!ctx || !theta || !prior_theta || !eps || !ess || !w) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (family != VB_FAMILY_MF_GAUSSIAN && family != VB_FAMILY_MF_STUDENT_T)
+    return fail(ctx, VB_ERR_INVALID, "family %d is not a mean-field family", family);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  ResultSlot& rs = ctx->sync_result;
+  VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
+  int status = 0;
+  return dis_refresh_enqueue(ctx, ctx->noise[slot], n, d, family, df, rs.dev, prior_theta, eps_prev, ess_target,
+                             max_bisection_its, eps, ess, &status, w, log_p, log_q);
+}
+
+int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+                          const double* theta, const double* weights, double scale, double* value,
+                          double* grad) {
+  if (!ctx || !theta || !weights || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (family != VB_FAMILY_MF_GAUSSIAN && family != VB_FAMILY_MF_STUDENT_T)
+    return fail(ctx, VB_ERR_INVALID, "family %d is not a mean-field family", family);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  ResultSlot& rs = ctx->sync_result;
+  VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
+  VB_TRY(dis_grad_enqueue(ctx, ctx->noise[slot], n, d, family, df, rs.dev, weights, scale, rs.dev + rs.p));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rs.pending = false;
   *value = rs.host[rs.p];

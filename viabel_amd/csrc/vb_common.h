@@ -23,6 +23,7 @@ constexpr int kMfWaves = kMfThreads / kWave;
 constexpr int kMfCols = 128;       // columns per workgroup: 64 lanes x 2 doubles = one 1-KiB wave load
 constexpr int kMfChunk = 16;       // rows a wave keeps in flight (16 x 16-B loads per lane)
 constexpr int kMaxBatch = 16;      // independent evaluations per launch (blockIdx.y)
+constexpr int kModelLogQ = 3;      // internal pseudo model: weighted log q(z; theta) statistics (DIS)
 
 // per-column partial sums (fields) and per-workgroup scalars written by the accumulation kernel
 enum ColField { CF_G = 0, CF_GE, CF_E, CF_EE, CF_EK, CF_SC, CF_SCE, CF_NUM };
@@ -98,6 +99,8 @@ struct vb_ctx {
   vb::DeviceBuffer scratch2;            // per-row outputs
   vb::DeviceBuffer rowvec;              // per-row weights
   vb::DeviceBuffer fr_work;             // full-rank pipeline work buffers
+  vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
+  int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
@@ -154,6 +157,7 @@ struct MfCall {
   bool pipelined = false;   // spread prep / stream / finalize over the three pipeline streams
   double scale = 0.0;  // mode 1
   const double* value_src = nullptr;   // mode 1: device scalar reported as the objective value
+  const ModelDev* model = nullptr;     // overrides ctx->model (mode 2: the log-q pseudo model)
 };
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
 int pipe_init(vb_ctx* ctx);
@@ -162,6 +166,12 @@ int pipe_init(vb_ctx* ctx);
 int rowstats_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_src,
                      const ModelDev& model, int student, double df, double* cols, double* scal,
                      double* out_f, double* out_b);
+int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
+                        const double* theta_src, const double* prior_host, double eps_prev, double ess_target,
+                        int max_its, double* eps_out, double* ess_out, int* status_out, double* w_host,
+                        double* logp_host, double* logq_host);
+int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
+                     const double* theta_src, const double* w_host, double scale, double* out);
 int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df, double alpha,
                   const double* theta_src, double* out);
 int sync_streams(vb_ctx* ctx);   // main + pipeline streams

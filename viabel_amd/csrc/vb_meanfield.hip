@@ -108,7 +108,10 @@ mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const Model
       wsb[ws.off_theta + i] = mu;
       wsb[ws.off_theta + d + i] = ls;
       const double sg = exp(ls);
-      if (funnel) {
+      if (model.id == kModelLogQ) {   // p0 = mu_r, p1 = sigma_r of the refresh parameter
+        c0 = (model.p0[i] - mu) / sg;
+        c1 = model.p1[i] / sg;
+      } else if (funnel) {
         // the coupling column contributes through the per-row sums below, not elementwise
         c0 = (i == model.k) ? 0.0 : mu;
         c1 = (i == model.k) ? 0.0 : sg;
@@ -180,6 +183,22 @@ __device__ __forceinline__ void accum(const double e, const double c0, const dou
                                       const double c2, const double av, const double ek,
                                       const double wt, const double df, ColAcc& A, double& F,
                                       double& Q, double& QE, double& L1P) {
+  if (MODEL == kModelLogQ) {
+    // DIS (objectives.py:405-414): weighted statistics of log q(z_n; theta) for fixed samples
+    // z = mu_r + sigma_r e, i.e. of the standardised residual r = (z - mu)/sigma = c0 + c1 e
+    const double r = fma(c1, e, c0);
+    const double r2 = r * r;
+    double sc = r, l = r2;
+    if (TSC) {
+      sc = (df + 1.0) * r / (df + r2);
+      l = log1p(r2 / df);
+    }
+    const double wsc = wt * sc;
+    A.E += wsc;
+    A.EE = fma(wsc, r, A.EE);
+    L1P = fma(wt, l, L1P);
+    return;
+  }
   if (MODEL == VB_MODEL_GAUSS_DIAG) {
     const double dz = fma(c1, e, c0);          // z - m
     double g = -dz * c2;
@@ -589,6 +608,25 @@ mf_epilogue_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
   double* gmu = a.out + 1;
   double* gls = a.out + 1 + d;
 
+  if (a.mode == 2) {   // DIS: -scale * sum_n w_n log q(z_n; theta) and its gradient (objectives.py:405-414)
+    const bool st = a.family == VB_FAMILY_MF_STUDENT_T;
+    double t_ls = 0.0;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+      const double sg = exp(ls[i]);
+      gmu[i] = -a.scale * E[i] / sg;
+      gls[i] = -a.scale * (EE[i] - Wsum);
+      t_ls += ls[i];
+    }
+    const double sum_ls = block_sum(t_ls, sh);
+    if (threadIdx.x == 0) {
+      const double cb = st ? lgamma(0.5 * (a.df + 1.0)) - lgamma(0.5 * a.df) - 0.5 * log(a.df * M_PI)
+                           : -0.5 * kLog2Pi;
+      const double lterm = st ? -0.5 * (a.df + 1.0) * tot.v[SF_L1P] : -0.5 * tot.v[SF_L1P];
+      value[0] = -a.scale * (lterm + Wsum * (d * cb - sum_ls));
+    }
+    return;
+  }
+
   if (a.mode == 1) {   // weighted gradient only: scale * sum_n w_n [g_n | g_n eps_n sigma + 1]
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
       const double g = G[i] + (i == k ? gk_add : 0.0);
@@ -712,14 +750,14 @@ static int env_int(const char* name, int dflt) {
 // independent evaluations.
 int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   const int64_t n = c.n, d = c.d;
+  const ModelDev& model = c.model ? *c.model : ctx->model;
   if (c.count < 1 || c.count > kMaxBatch)
     return fail(ctx, VB_ERR_INVALID, "batch size %d outside [1, %d]", c.count, kMaxBatch);
-  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
+  if (model.id != VB_MODEL_GAUSS_DIAG && model.id != VB_MODEL_FUNNEL && model.id != kModelLogQ)
     return fail(ctx, VB_ERR_UNSUPPORTED,
-                "mean-field path supports the gauss_diag and funnel models (model id %d bound)",
-                ctx->model.id);
-  if (ctx->model.dim != d)
-    return fail(ctx, VB_ERR_INVALID, "model dimension %d != family dimension %lld", ctx->model.dim,
+                "mean-field path supports the gauss_diag and funnel models (model id %d bound)", model.id);
+  if (model.dim != d)
+    return fail(ctx, VB_ERR_INVALID, "model dimension %d != family dimension %lld", model.dim,
                 (long long)d);
   if (c.family != VB_FAMILY_MF_GAUSSIAN && c.family != VB_FAMILY_MF_STUDENT_T)
     return fail(ctx, VB_ERR_INVALID, "family %d is not a mean-field family", c.family);
@@ -737,11 +775,11 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
 
   const bool pd = (c.flags & VB_FLAG_PATH_DERIV) != 0;
   const bool student = c.family == VB_FAMILY_MF_STUDENT_T;
-  const bool mom = c.mode == 0 && ((pd && !student) || c.cv_mode != VB_CV_NONE);
-  const bool tsc = c.mode == 0 && pd && student;
+  const bool mom = (c.mode == 0 && ((pd && !student) || c.cv_mode != VB_CV_NONE)) || c.mode == 2;
+  const bool tsc = (c.mode == 0 && pd && student) || (c.mode == 2 && student);
   const int nf = tsc ? CF_NUM : (mom ? CF_EK + 1 : CF_GE + 1);
   const bool weighted = c.roww[0] != nullptr;
-  const bool funnel = ctx->model.id == VB_MODEL_FUNNEL;
+  const bool funnel = model.id == VB_MODEL_FUNNEL;
   const bool rows = funnel || weighted;
 
   Geom g;
@@ -819,7 +857,7 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   }
 
   hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)g.n_prep, (unsigned)c.count), dim3(256), 0, st_pre,
-                     bp, ws, g, ctx->model);
+                     bp, ws, g, model);
   VB_HIP(ctx, hipGetLastError());
   if (c.pipelined) {
     VB_HIP(ctx, hipEventRecord(P.ev_prep[set], st_pre));
@@ -830,10 +868,14 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   L.grid = dim3((unsigned)(g.n_rb * g.n_cb), (unsigned)c.count);
   L.st = st_main;
   prof_events(ctx, &L.ev0, &L.ev1, c.count);
-  if (ctx->model.id == VB_MODEL_GAUSS_DIAG)
+  if (model.id == VB_MODEL_GAUSS_DIAG)
     launch_accum_model<VB_MODEL_GAUSS_DIAG>(mom, tsc, weighted, L, bp, ws, g);
-  else
+  else if (model.id == VB_MODEL_FUNNEL)
     launch_accum_model<VB_MODEL_FUNNEL>(mom, tsc, weighted, L, bp, ws, g);
+  else if (tsc)
+    launch_accum<kModelLogQ, true, true>(true, L, bp, ws, g);
+  else
+    launch_accum<kModelLogQ, true, false>(true, L, bp, ws, g);
   VB_HIP(ctx, hipGetLastError());
   if (c.pipelined) {
     VB_HIP(ctx, hipEventRecord(P.ev_k1[set], st_main));
@@ -856,7 +898,7 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   e.mode = c.mode;
   e.scale = c.scale;
   e.value_src = c.value_src;
-  e.model = ctx->model;
+  e.model = model;
   const bool fused = c.mode == 0 && c.cv_mode == VB_CV_NONE && !ctx->comm;
   e.reduce_only = fused ? 0 : 1;
   hipLaunchKernelGGL(mf_finalize_kernel, dim3((unsigned)(g.Dp / 64), (unsigned)c.count), dim3(256), 0,

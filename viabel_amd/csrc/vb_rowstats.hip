@@ -12,6 +12,8 @@
 //   alpha_weights_kernel  max / exp / sum over the N log weights (one workgroup)        O(N)
 #include "vb_common.h"
 
+#include <vector>
+
 namespace vb {
 
 typedef double d2r __attribute__((ext_vector_type(2)));
@@ -189,6 +191,194 @@ int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int fa
   c.mode = 1;
   c.scale = alpha / (double)n;                // objectives.py:460: alpha * vjp / N
   c.value_src = base + o_scal + 8;
+  return mf_enqueue(ctx, c);
+}
+
+// ---- DISInclusiveKL state refresh (objectives.py:317-368) ---------------------------------------------
+// One workgroup: bisection on the tempering parameter for the effective sample size.
+//   logw(e) = e * log prior + (1 - e) * log p - log q,   w = exp(logw)   (no max shift, :330)
+//   ESS = (sum w)^2 / sum w^2   (:333-336);  50 bisection steps on [0, eps_prev], end-point snapping.
+// scal_out = [eps, ess, status]; status 1 = "all weights zero" (max logw == -inf, :325-328).
+__global__ void __launch_bounds__(1024) dis_bisect_kernel(const double* __restrict__ lp,
+                                                          const double* __restrict__ b,
+                                                          const double* __restrict__ lprior,
+                                                          const double* __restrict__ scal_in, int64_t n,
+                                                          double eps_prev, double ess_target, int max_its,
+                                                          double max_eps, double* __restrict__ w,
+                                                          double* __restrict__ lq_out,
+                                                          double* __restrict__ scal_out) {
+  __shared__ double sh1[16], sh2[16], shm[16];
+  __shared__ double bc[3];
+  const double sum_ls = scal_in[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double lower = 0.0, upper = eps_prev, guess = 0.5 * (lower + upper);
+  int status = 0;
+  double ess = 0.0;
+  for (int it = 0; it <= max_its; ++it) {
+    double s1 = 0.0, s2 = 0.0, mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+      const double lq = b[i] - sum_ls;
+      const double lw = guess * lprior[i] + (1.0 - guess) * lp[i] - lq;
+      const double wv = exp(lw);
+      mx = fmax(mx, lw);
+      s1 += wv;
+      s2 = fma(wv, wv, s2);
+      if (it == max_its) {
+        w[i] = wv;
+        lq_out[i] = lq;
+      }
+    }
+    s1 = rs_wave_sum(s1);
+    s2 = rs_wave_sum(s2);
+    mx = rs_wave_max(mx);
+    __syncthreads();
+    if (lane == 0) {
+      sh1[wave] = s1;
+      sh2[wave] = s2;
+      shm[wave] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t1 = 0.0, t2 = 0.0, tm = -INFINITY;
+      for (int k = 0; k < 16; ++k) {
+        t1 += sh1[k];
+        t2 += sh2[k];
+        tm = fmax(tm, shm[k]);
+      }
+      bc[0] = t1 * t1 / t2;
+      bc[1] = tm;
+    }
+    __syncthreads();
+    ess = bc[0];
+    if (bc[1] == -INFINITY) status = 1;
+    if (it < max_its) {
+      if (ess > ess_target) upper = guess;
+      else lower = guess;
+      guess = 0.5 * (lower + upper);
+    }
+  }
+  if (threadIdx.x == 0) {
+    double eps = guess;
+    if (lower == 0.0) eps = 0.0;          // :363-366
+    if (upper == max_eps) eps = max_eps;
+    scal_out[0] = eps;
+    scal_out[1] = ess;
+    scal_out[2] = (double)status;
+  }
+}
+
+// state layout (doubles): [cols_r 2 ld | scal 16 | out 16 | prior cols 2 ld | log p | b | log prior | w | lq]
+struct DisLayout {
+  int64_t o_cols, o_scal, o_out, o_prior, o_lp, o_b, o_lprior, o_w, o_lq, total;
+};
+static DisLayout dis_layout(int64_t n, int64_t ld) {
+  DisLayout L;
+  const int64_t nn = round_up(n, 16);
+  L.o_cols = 0;
+  L.o_scal = 2 * ld;
+  L.o_out = L.o_scal + 16;
+  L.o_prior = L.o_out + 16;
+  L.o_lp = L.o_prior + 2 * ld;
+  L.o_b = L.o_lp + nn;
+  L.o_lprior = L.o_b + nn;
+  L.o_w = L.o_lprior + nn;
+  L.o_lq = L.o_w + nn;
+  L.total = L.o_lq + nn;
+  return L;
+}
+
+int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
+                        const double* theta_src, const double* prior_host, double eps_prev, double ess_target,
+                        int max_its, double* eps_out, double* ess_out, int* status_out, double* w_host,
+                        double* logp_host, double* logq_host) {
+  if (ctx->comm) return fail(ctx, VB_ERR_UNSUPPORTED, "DISInclusiveKL is not sharded across GPUs yet");
+  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "mean-field path supports the gauss_diag and funnel models");
+  if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  const int student = family == VB_FAMILY_MF_STUDENT_T;
+  const int64_t ld = ns.ld;
+  const DisLayout L = dis_layout(n, ld);
+  VB_TRY(ensure(ctx, ctx->dis_state, (size_t)L.total * sizeof(double)));
+  double* base = (double*)ctx->dis_state.ptr;
+  hipStream_t st = ctx->stream;
+
+  // tempering prior: a diagonal Gaussian given as an MFGaussian parameter [mu | log_sigma]
+  std::vector<double> pr((size_t)2 * ld, 0.0);
+  double c0p = -0.5 * (double)d * kLog2PiRs;
+  for (int64_t i = 0; i < d; ++i) {
+    pr[i] = prior_host[i];
+    pr[ld + i] = exp(-2.0 * prior_host[d + i]);
+    c0p -= prior_host[d + i];
+  }
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));   // `pr` is a stack-scoped staging buffer
+  ModelDev prior;
+  prior.id = VB_MODEL_GAUSS_DIAG;
+  prior.dim = (int)d;
+  prior.c0 = c0p;
+  prior.p0 = base + L.o_prior;
+  prior.p1 = base + L.o_prior + ld;
+
+  VB_TRY(rowstats_enqueue(ctx, ns, n, d, theta_src, ctx->model, student, df, base + L.o_cols, base + L.o_scal,
+                          base + L.o_lp, base + L.o_b));
+  // second pass: log prior(z_n); its base sums land in the (later overwritten) lq area
+  hipLaunchKernelGGL(rs_rowstats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
+                     (const double*)ns.buf.ptr, ld, n, (int)d, (const double*)(base + L.o_cols), prior, student,
+                     df, base + L.o_lprior, base + L.o_lq);
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(dis_bisect_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_lp),
+                     (const double*)(base + L.o_b), (const double*)(base + L.o_lprior),
+                     (const double*)(base + L.o_scal), n, eps_prev, ess_target, max_its, 1.0, base + L.o_w,
+                     base + L.o_lq, base + L.o_out);
+  VB_HIP(ctx, hipGetLastError());
+  double res[3];
+  VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_out, sizeof res, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (logp_host)
+    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (logq_host)
+    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lq, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  *eps_out = res[0];
+  *ess_out = res[1];
+  *status_out = (int)res[2];
+  ctx->dis_n = n;
+  ctx->dis_d = d;
+  if (*status_out == 1)
+    return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
+  return VB_OK;
+}
+
+int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
+                     const double* theta_src, const double* w_host, double scale, double* out) {
+  if (ctx->dis_n != n || ctx->dis_d != d || !ctx->dis_state.ptr)
+    return fail(ctx, VB_ERR_STATE, "no DIS state of shape %lld x %lld (vb_dis_refresh_meanfield first)",
+                (long long)n, (long long)d);
+  if (n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  const DisLayout L = dis_layout(n, ns.ld);
+  double* base = (double*)ctx->dis_state.ptr;
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller keeps ownership of w_host
+  ModelDev logq;
+  logq.id = kModelLogQ;
+  logq.dim = (int)d;
+  logq.p0 = base + L.o_cols;            // mu_r
+  logq.p1 = base + L.o_cols + ns.ld;    // sigma_r
+  MfCall c;
+  c.count = 1;
+  c.noise[0] = &ns;
+  c.theta_src[0] = theta_src;
+  c.out[0] = out;
+  c.roww[0] = base + L.o_w;
+  c.n = n;
+  c.d = d;
+  c.n_total = n;
+  c.family = family;
+  c.df = df;
+  c.mode = 2;
+  c.scale = scale;
+  c.model = &logq;
   return mf_enqueue(ctx, c);
 }
 

@@ -29,6 +29,7 @@ __all__ = [
 ]
 
 _NOISE_SLOT = 0
+_DIS_SLOT = 1      # DIS keeps its state samples (as base noise) in a slot of its own
 
 
 def shard_rows(n, n_ranks, rank):
@@ -202,8 +203,71 @@ class DISInclusiveKL(StochasticVariationalObjective):
         self._temper_prior_params = np.asarray(temper_prior_params, dtype=np.float64)
         super().__init__(approx, model, num_mc_samples)
 
+    def _clip_weights(self, w):
+        """Clip weights to ``w_clip_threshold`` (``objectives.py:370-386``).
+
+        With the default threshold 10 no weight can exceed ``10 * sum(w)``, so this is a no-op; the
+        reference's clipping line (``:385``) calls a float and cannot run -- the evident intent is
+        written here."""
+        S = np.sum(w)
+        thr = self._w_clip_threshold
+        if not np.any(w > S * thr):
+            return w
+        to_clip = (w >= S * thr)
+        n_to_clip = np.sum(to_clip)
+        sum_unclipped = np.sum(w[~to_clip])
+        if sum_unclipped == 0:
+            return w
+        w = w.copy()
+        w[to_clip] = thr * sum_unclipped / (1. - thr * n_to_clip)
+        return self._clip_weights(w)
+
     def _update_objective_and_grad(self):
-        raise NotImplementedError('DISInclusiveKL device path: see viabel_amd/objectives_dis.py')
+        approx = self.approx
+        self._require_device_model()
+        if not isinstance(approx, (MFGaussian, MFStudentT)):
+            raise NotImplementedError('DISInclusiveKL on the HIP engine supports MFGaussian and '
+                                      'MFStudentT; got {}'.format(type(approx).__name__))
+        if not isinstance(self._temper_prior, MFGaussian) or self._temper_prior.dim != approx.dim:
+            raise NotImplementedError('temper_prior must be an MFGaussian of the same dimension '
+                                      '(tests/test_objectives.py:82-87)')
+        if self._temper_prior_params.shape != (2 * approx.dim,):
+            raise ValueError('temper_prior_params must have shape ({},)'.format(2 * approx.dim))
+        slot = _DIS_SLOT
+
+        def variational_objective(var_param):
+            var_param = np.asarray(var_param, dtype=np.float64)
+            if var_param.shape != (approx.var_param_dim,):
+                raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+            eng = self._engine()
+            if eng.n_ranks > 1:
+                raise NotImplementedError('DISInclusiveKL is not sharded across GPUs yet')
+            eng.set_model(self.model.device_spec())
+            family, df = approx._device_family()
+            N = self.num_mc_samples
+            if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
+                # state refresh (objectives.py:393-401): new samples (kept as noise on the device),
+                # log q, log p, tempering bisection, clipping
+                self._stage_noise(eng, N, slot=slot)
+                self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_meanfield(
+                    slot, N, approx.dim, var_param, self._temper_prior_params, family, self._eps,
+                    self._ess_target, self._max_bisection_its, df=df)
+                self._state_log_p_unnormalized = log_p
+                self._state_log_q = log_q
+                self._state_w_clipped = self._clip_weights(w)
+                self._state_w_sum = np.sum(self._state_w_clipped)
+                self._state_w_normalized = self._state_w_clipped / self._state_w_sum
+            self._objective_step += 1
+            if not self._use_resampling:     # :405-406
+                return eng.dis_grad_meanfield(slot, N, approx.dim, var_param, self._state_w_clipped, 1.0 / N,
+                                              family, df=df)
+            indices = np.random.choice(N, size=self._resampling_batch_size,
+                                       p=self._state_w_normalized)          # global RNG, :408
+            counts = np.bincount(indices, minlength=N).astype(np.float64)
+            scale = self._state_w_sum / N / self._resampling_batch_size       # :412-414
+            return eng.dis_grad_meanfield(slot, N, approx.dim, var_param, counts, scale, family, df=df)
+
+        self._objective_and_grad = variational_objective
 
 
 class AlphaDivergence(StochasticVariationalObjective):
