@@ -1,0 +1,106 @@
+"""GPU: the sharded code path (reduce-only finalize -> RCCL all-reduce -> epilogue kernel) with a
+one-rank communicator must reproduce the fused single-GPU path; with n_total > n it must scale like a
+shard of a larger job.  (N > 1 ranks need N GPUs: covered by the driver's multi-GPU bench; the
+sharding arithmetic itself is covered on CPU by tests/test_distributed_cpu.py.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engines():
+    import viabel_amd  # noqa: F401
+    from viabel_amd import _lib
+    plain = _lib.default_engine()
+    comm = _lib.Engine(plain.device)
+    comm.comm_init(_lib.Engine.comm_unique_id(), 1, 0)
+    yield plain, comm
+    comm.comm_destroy()
+    comm.close()
+
+
+def _theta(D, seed):
+    rng = np.random.RandomState(seed)
+    return np.concatenate([0.3 * rng.randn(D), -1.0 + 0.2 * rng.randn(D)])
+
+
+@pytest.mark.parametrize('flags,cv', [(0, 0), (1, 0), (0, 1), (1, 3)])
+def test_meanfield_comm_path_matches_fused(engines, flags, cv):
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    plain, comm = engines
+    D, N = 1024, 4096
+    spec = vb.FunnelModel(D).device_spec()
+    theta = _theta(D, 1)
+    out = []
+    for eng in (plain, comm):
+        eng.set_model(spec)
+        eng.noise_generate(3, N, D, seed=5, stream=1)
+        out.append(eng.elbo_grad_meanfield(3, N, D, theta, _lib.FAMILY_MF_GAUSSIAN, flags=flags, cv_mode=cv))
+    assert abs(out[0][0] - out[1][0]) < 1e-13 * abs(out[0][0])
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-13 * np.max(np.abs(out[0][1])))
+
+
+def test_meanfield_batch_through_comm(engines):
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    plain, comm = engines
+    D, N, B = 256, 1024, 5
+    spec = vb.GaussianModel(np.zeros(D), np.ones(D)).device_spec()
+    thetas = np.stack([_theta(D, s) for s in range(B)])
+    res = []
+    for eng in (plain, comm):
+        eng.set_model(spec)
+        for s in range(B):
+            eng.noise_generate(10 + s, N, D, seed=2, stream=s)
+        eng.elbo_grad_meanfield_batch_async(list(range(10, 10 + B)), N, D, thetas, _lib.FAMILY_MF_GAUSSIAN,
+                                            list(range(B)))
+        eng.sync()
+        res.append([eng.result_get(b, 2 * D) for b in range(B)])
+    for b in range(B):
+        assert abs(res[0][b][0] - res[1][b][0]) < 1e-13 * abs(res[0][b][0])
+        np.testing.assert_allclose(res[1][b][1], res[0][b][1], rtol=0, atol=1e-13)
+
+
+def test_shard_of_a_larger_job(engines):
+    """Two half-size shards evaluated with n_total = N: their (value + H, grad + dH) contributions add up."""
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    plain, comm = engines
+    D, N = 128, 512
+    spec = vb.FunnelModel(D).device_spec()
+    theta = _theta(D, 3)
+    plain.set_model(spec)
+    plain.noise_generate(4, N, D, seed=8, stream=0)
+    full = plain.noise_get_host(4, N, D)
+    v, g = plain.elbo_grad_meanfield(4, N, D, theta, _lib.FAMILY_MF_GAUSSIAN)
+    comm.set_model(spec)
+    parts = []
+    for h in range(2):
+        comm.noise_set_host(5, full[h * N // 2:(h + 1) * N // 2])
+        parts.append(comm.elbo_grad_meanfield(5, N // 2, D, theta, _lib.FAMILY_MF_GAUSSIAN, n_total=N))
+    H = 0.5 * D * (1 + np.log(2 * np.pi)) + theta[D:].sum()
+    # value_h = -(F_h / N + H): summing the two shards double counts the entropy terms
+    assert abs((parts[0][0] + parts[1][0] + H) - v) < 1e-12 * abs(v)
+    gsum = parts[0][1] + parts[1][1]
+    gsum[D:] += 1.0
+    np.testing.assert_allclose(gsum, g, rtol=0, atol=1e-12 * np.max(np.abs(g)))
+
+
+def test_fullrank_comm_path(engines):
+    import viabel_amd as vb
+    plain, comm = engines
+    D, N = 130, 400
+    rng = np.random.RandomState(2)
+    spec = vb.GaussianModel(rng.randn(D), np.exp(0.2 * rng.randn(D))).device_spec()
+    fr = vb.FullRankGaussian(D)
+    L = np.tril(0.05 * rng.randn(D, D), -1) + np.diag(np.exp(-1 + 0.1 * rng.randn(D)))
+    theta = fr.pack(0.2 * rng.randn(D), L)
+    out = []
+    for eng in (plain, comm):
+        eng.set_model(spec)
+        eng.noise_generate(6, N, D, seed=4, stream=0)
+        out.append(eng.elbo_grad_fullrank(6, N, D, theta))
+    assert abs(out[0][0] - out[1][0]) < 1e-13 * abs(out[0][0])
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-13 * np.max(np.abs(out[0][1])))
