@@ -384,6 +384,31 @@ def gen_torch_crosscheck():
     print('model derivatives vs torch.autograd fp64: worst hessian rel err %.2e' % worst)
 
 
+def gen_chain_stats():
+    """ess / MCSE / R-hat of the reference (viabel/_mc_diagnostics.py, pure numpy) on seeded chains."""
+    from viabel import _mc_diagnostics as ref
+    rng = np.random.RandomState(71)
+    chains, ess_ref, mcse_ref, rhat_ref = [], [], [], []
+    for n, phi in ((200, 0.0), (200, 0.9), (401, 0.5), (57, -0.4), (1000, 0.99), (16, 0.3), (9, 0.0)):
+        x = np.zeros((n, 3))
+        e = rng.randn(n, 3)
+        for t in range(1, n):
+            x[t] = phi * x[t - 1] + e[t]
+        x[:, 2] += np.linspace(0, 3, n)          # a drifting coordinate
+        chains.append(x)
+        ess_ref.append(np.array([ref.ess(x[:, i].reshape(1, n)) for i in range(3)]))
+        mcse_ref.append(ref.MCSE(x)[1])
+        rhat_ref.append(ref.compute_R_hat(x))
+    windows = np.array([50, 100, 150, 200])
+    ok, best = ref.R_hat_convergence_check(list(chains[1]), windows)
+    save('chainstats', n_chains=len(chains), windows=windows, rhat_ok=ok, rhat_best=best,
+         **{'chain%d' % i: c for i, c in enumerate(chains)},
+         **{'ess%d' % i: c for i, c in enumerate(ess_ref)},
+         **{'mcse%d' % i: c for i, c in enumerate(mcse_ref)},
+         **{'rhat%d' % i: c for i, c in enumerate(rhat_ref)},
+         provenance='reference viabel/_mc_diagnostics.py functions (pure numpy) run as they are')
+
+
 if __name__ == '__main__':
     for f in os.listdir(HERE):
         if f.endswith('.npz'):
@@ -394,4 +419,5 @@ if __name__ == '__main__':
     gen_rge()
     gen_alpha()
     gen_dis()
+    gen_chain_stats()
     print('wrote %d fixtures to %s' % (len(SAVED), HERE))
