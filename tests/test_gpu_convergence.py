@@ -1,0 +1,81 @@
+"""GPU ports of the reference's own end-to-end tests: every objective variant must drive the
+optimiser to the known Gaussian target (viabel/tests/test_objectives.py:11-91, decimal=1) and
+`bbvi` must fit it in its three optimiser modes (viabel/tests/test_convenience.py:10-37, decimal=2)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import viabel_amd
+    from viabel_amd import _lib
+    _lib.default_engine()
+    return viabel_amd
+
+
+def _run_objective(vb, objective_cls, num_mc_samples, **kwargs):
+    np.random.seed(851)                                   # test_objectives.py:12
+    mean, stdev = np.array([1., -1.]), np.array([2., 5.])
+    approx = vb.MFStudentT(2, 100)                        # :21
+    objective = objective_cls(approx, vb.GaussianModel(mean, stdev), num_mc_samples, **kwargs)
+    init_param = np.array([0, 0, 1, 1], dtype=np.float32)   # :24 (float32 on purpose)
+    results = vb.RMSProp(0.1).optimize(1000, objective, init_param)
+    est_mean, est_cov = approx.mean_and_cov(results['opt_param'])
+    np.testing.assert_almost_equal(mean, est_mean, decimal=1)
+    np.testing.assert_almost_equal(stdev, np.sqrt(np.diag(est_cov)), decimal=1)
+
+
+@pytest.mark.parametrize('kwargs', [
+    dict(), dict(use_path_deriv=True),
+    dict(hessian_approx_method='full'), dict(hessian_approx_method='mean_only'),
+    dict(hessian_approx_method='loo_diag_approx'), dict(hessian_approx_method='loo_direct_approx'),
+    dict(use_path_deriv=True, hessian_approx_method='full'),
+    dict(use_path_deriv=True, hessian_approx_method='mean_only'),
+    dict(use_path_deriv=True, hessian_approx_method='loo_diag_approx'),
+    dict(use_path_deriv=True, hessian_approx_method='loo_direct_approx'),
+], ids=lambda k: '-'.join('%s=%s' % kv for kv in k.items()) or 'plain')
+def test_ExclusiveKL_variants(vb, kwargs):
+    _run_objective(vb, vb.ExclusiveKL, 100, **kwargs)
+
+
+def test_DISInclusiveKL(vb):
+    dim = 2                                               # test_objectives.py:82-87
+    _run_objective(vb, vb.DISInclusiveKL, 100, temper_prior=vb.MFGaussian(dim),
+                   temper_prior_params=np.concatenate([[0] * dim, [1] * dim]), ess_target=50)
+
+
+def test_AlphaDivergence(vb):
+    _run_objective(vb, vb.AlphaDivergence, 100, alpha=2)   # test_objectives.py:90-91
+
+
+def test_bbvi_three_modes(vb):
+    np.random.seed(851)
+    mean, stdev = np.array([3., -4.]), np.array([2., 5.])
+    model = vb.GaussianModel(mean, stdev)
+    for adaptive, fixed_lr, n_mc in ((True, True, 1000), (True, False, 1000), (False, True, 50)):
+        results = vb.bbvi(2, log_density=model, num_mc_samples=n_mc,
+                          RAABBVI_kwargs=dict(mcse_threshold=.005, accuracy_threshold=.005),
+                          FASO_kwargs=dict(mcse_threshold=.005), adaptive=adaptive, fixed_lr=fixed_lr,
+                          n_iters=30000)
+        est_mean, est_cov = results['objective'].approx.mean_and_cov(results['opt_param'])
+        np.testing.assert_almost_equal(mean, est_mean, decimal=2)
+        np.testing.assert_almost_equal(stdev, np.sqrt(np.diag(est_cov)), decimal=2)
+
+
+def test_fullrank_bbvi_recovers_correlated_gaussian(vb):
+    """The new dense family end to end: FASO + RMSProp on a correlated Gaussian target."""
+    D = 6
+    rng = np.random.RandomState(0)
+    A = rng.randn(D, D)
+    S = A @ A.T / D + 0.5 * np.eye(D)
+    m = rng.randn(D)
+    approx = vb.FullRankGaussian(D)
+    objective = vb.ExclusiveKL(approx, vb.CorrelatedGaussianModel(m, covariance=S), 256)
+    init = approx.pack(np.zeros(D), np.eye(D))
+    results = vb.bbvi(D, objective=objective, init_var_param=init, fixed_lr=True, learning_rate=0.02,
+                      n_iters=8000, FASO_kwargs=dict(mcse_threshold=0.01))
+    est_mean, est_cov = approx.mean_and_cov(results['opt_param'])
+    np.testing.assert_allclose(est_mean, m, atol=0.05)
+    np.testing.assert_allclose(est_cov, S, atol=0.08)
