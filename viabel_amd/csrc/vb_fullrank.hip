@@ -256,9 +256,10 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   hipStream_t st = ctx->stream;
   const int D = (int)d;
   const int64_t ldl = round_up(d, 16), ldz = round_up(d, 16);
-  const int tiles = gemm_tiles(D, kGemmBM);
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int tiles = gemm_tiles(D, 128);
   const int lower_tiles = tiles * (tiles + 1) / 2;
-  int splits = (ctx->prop.multiProcessorCount + lower_tiles - 1) / lower_tiles;
+  int splits = n_cu / lower_tiles;   // one wave of workgroups: no second, mostly empty round
   const int max_splits = (int)(n / 256) > 0 ? (int)(n / 256) : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -305,15 +306,15 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int fmode = 0;
   if (m.id == VB_MODEL_GAUSS_DIAG) {
-    gemm_f64_launch<true>(st, g1, 1, EpiGaussDiag{G, ldz, mu, m.p0, m.p1});
+    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiag{G, ldz, mu, m.p0, m.p1});
     fmode = 1;
   } else if (m.id == VB_MODEL_FUNNEL) {
-    gemm_f64_launch<true>(st, g1, 1, EpiStoreZ{Z, ldz, mu, nullptr});
+    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, nullptr});
     VB_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(fr_funnel_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)Z,
                        G, ldz, n, D, m, fpart);
   } else {
-    gemm_f64_launch<true>(st, g1, 1, EpiStoreZ{Z, ldz, mu, m.p0});   // Z - m
+    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0});   // Z - m
     VB_HIP(ctx, hipGetLastError());
     GemmArgs g2;                                   // G = -(Z - m) P,  P symmetric: B[k][j] = P[k][j]
     g2.A = Z;
@@ -324,7 +325,7 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
     g2.N = D;
     g2.K = D;
     g2.tri_mode = 0;
-    gemm_f64_launch<true>(st, g2, 1, EpiNegate{G, ldz});
+    gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz});
     fmode = 2;
   }
   VB_HIP(ctx, hipGetLastError());
@@ -346,7 +347,7 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   g3.tri_mode = 2;
   (void)ev0;
   (void)ev1;
-  gemm_f64_launch<false>(st, g3, splits, EpiSplitSlab{Cpart, ldl, slab});
+  gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
   VB_HIP(ctx, hipGetLastError());
 
   const int64_t red_items = slab > ldz ? slab : ldz;

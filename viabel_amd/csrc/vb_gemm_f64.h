@@ -1,21 +1,28 @@
-// fp64 MFMA GEMM building block for gfx950 (v_mfma_f64_16x16x4_f64), used by the dense-covariance
-// paths (full-rank Gaussian: Z = E L', G' E; correlated-Gaussian target: (Z - m) P).
+// fp64 MFMA GEMM building block for gfx950, used by the dense-covariance paths (full-rank Gaussian:
+// Z = E L', G' E; correlated-Gaussian target: (Z - m) P).
 //
 //   C[M x N] (+)= A[M x K] * B[K x N]
 //   B is row-major [k][n] (ldb).  A is either row-major [m][k] (A_KCONTIG, e.g. the noise matrix
 //   E[n][k]) or k-major [k][m] (e.g. G'[i][n] given as G[n][i]).
 //
-// Workgroup = 256 threads = 4 waves (2 x 2); block tile 128 x 128 x 16; each wave owns a 64 x 64
-// sub-tile = 4 x 4 MFMA tiles (64 fp64 accumulators per lane).  Both operand tiles live in LDS
-// k-major ([k][m], row stride 128 + 16 doubles = 1152 B, i.e. +32 banks per k row, so the two k rows
-// a ds_read_b64 half-wave touches fall on disjoint banks); the A_KCONTIG loader transposes on the
-// way in with 16 distinct rows per 16-lane store group (conflict-free ds_write_b64).  Global loads
-// for slab k+1 are issued into registers before the MFMAs of slab k (register double buffering),
-// LDS is double buffered: one barrier per slab.  The fp64 MFMA issues once per 64 cycles per SIMD,
-// so 16 MFMAs per 8 ds_read_b64 keep the matrix pipe saturated from one wave per SIMD.
+// Matrix instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per issue).  Measured on
+// this MI355X (tools/fp64_peak.hip): the 4x4x4 4-block form sustains 63-73 TFLOP/s, the 16x16x4 form
+// only 33-36 TFLOP/s, so the tile loop is built on the former.  Lane layout (probed with
+// tools/mfma_f64_4x4x4_layout.hip): operand lane s holds A_blk[i][k] / B_blk[k][j] with
+// i or j = s & 3, blk = (s >> 2) & 3, k = s >> 4; result lane l holds D_blk[i][j] with j = l & 3,
+// blk = (l >> 2) & 3, i = l >> 4.
 //
-// Fragment layouts (cdna_hip_programming.md section 3): A lane l -> A[i = l & 15][k = l >> 4],
-// B lane l -> B[k = l >> 4][j = l & 15], C/D lane l, register r -> C[i = (l >> 4) + 4 r][j = l & 15].
+// Workgroup = 256 threads = 4 waves (2 x 2); block tile 128 x 128 x 16; each wave owns a 64 x 64
+// sub-tile = 16 x 16 blocks of 4 x 4.  Per k-step of 4 a wave loads 4 A fragments (16 rows each: the 4
+// blocks of an instruction are 4 consecutive row blocks) and 16 B fragments (arrangement r puts column
+// block (blk + r) mod 16 into block blk), and issues 4 x 16 = 64 MFMAs: instruction (a, r) produces the
+// blocks (4a + blk, (blk + r) mod 16), so every (row block, column block) pair is covered exactly once
+// and each lane accumulates 64 doubles.  20 ds_read_b64 per 64 MFMAs (1024 matrix-pipe cycles).
+// Operand tiles live in LDS k-major ([k][m], row stride 128 + 16 doubles = 1152 B = +32 banks per k
+// row, so the two k rows a ds_read_b64 half-wave touches fall on disjoint banks); the A_KCONTIG loader
+// transposes on the way in with 16 distinct rows per 16-lane store group (conflict-free ds_write_b64).
+// Global loads for slab k+1 are issued into registers before the MFMAs of slab k, LDS is double
+// buffered: one barrier per slab; edge handling is branch-free (clamped index + select).
 #pragma once
 
 #include "vb_common.h"
@@ -25,8 +32,8 @@ namespace vb {
 typedef double d2v __attribute__((ext_vector_type(2)));
 typedef double d4v __attribute__((ext_vector_type(4)));
 
-constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 16;
-constexpr int kGemmLds = kGemmBM + 16;   // LDS row stride in doubles
+constexpr int kGemmBN = 128, kGemmBK = 16;   // block tile: (32 AF) x 128 x 16, AF = A fragments per wave
+constexpr int kGemmLds = 128 + 16;           // LDS row stride in doubles
 
 struct GemmArgs {
   const double* A;
@@ -41,9 +48,14 @@ struct GemmArgs {
 
 // Epilogue functor interface:  void operator()(int split, int row, int col, double acc) const;
 // called for every in-range element of the block tile.
-template <bool A_KCONTIG, class Epi>
-__global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g, const Epi epi) {
-  __shared__ double As[2][kGemmBK][kGemmLds];
+// AF = 4: 128-row block tile, 64 accumulators per lane, one workgroup per CU;
+// AF = 2:  64-row block tile, 32 accumulators per lane, two workgroups per CU (stalls of one are
+//          covered by the MFMAs of the other) -- used when 128-row tiles would not fill the chip twice.
+template <bool A_KCONTIG, int AF, class Epi>
+__global__ void __launch_bounds__(256, AF == 2 ? 2 : 1) gemm_f64_kernel(const GemmArgs g, const Epi epi) {
+  constexpr int BM = 32 * AF;
+  constexpr int NA = BM / 32;   // staging iterations for the A tile
+  __shared__ double As[2][kGemmBK][BM + 16];
   __shared__ double Bs[2][kGemmBK][kGemmLds];
 
   const int t = threadIdx.x;
@@ -52,20 +64,26 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g, const E
 
   // ---- tile assignment --------------------------------------------------------------------------
   int bm, bn;
-  if (g.tri_mode == 2) {        // linear index over the lower-triangular tiles, row by row
+  if (g.tri_mode == 2) {
+    // compact enumeration of the tiles that touch the lower triangle, row by row: consecutive block
+    // ids (= consecutive XCDs) get equal work instead of XCD x owning tile row x
     int idx = blockIdx.x;
-    bm = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-    while ((bm + 1) * (bm + 2) / 2 <= idx) ++bm;
-    while (bm * (bm + 1) / 2 > idx) --bm;
-    bn = idx - bm * (bm + 1) / 2;
-  } else if (g.tri_mode == 1) { // heaviest column blocks (largest k range) first
+    bm = 0;
+    for (;;) {
+      const int cnt = min(g.tiles_n, (bm * BM + BM - 1) / kGemmBN + 1);
+      if (idx < cnt) break;
+      idx -= cnt;
+      ++bm;
+    }
+    bn = idx;
+  } else if (g.tri_mode == 1) {   // heaviest column blocks (largest k range) first
     bn = g.tiles_n - 1 - (int)(blockIdx.x / g.tiles_m);
     bm = blockIdx.x % g.tiles_m;
   } else {
     bn = blockIdx.x / g.tiles_m;
     bm = blockIdx.x % g.tiles_m;
   }
-  const int m0 = bm * kGemmBM, n0 = bn * kGemmBN;
+  const int m0 = bm * BM, n0 = bn * kGemmBN;
   int k_begin = blockIdx.z * g.k_split;
   int k_end = k_begin + g.k_split < g.K ? k_begin + g.k_split : g.K;
   if (g.tri_mode == 1) {
@@ -73,34 +91,39 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g, const E
     if (k_end > kmax) k_end = kmax;
   }
 
-  d4v acc[4][4];
+  double acc[AF][16];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < AF; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4v){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.0;
 
   // ---- global -> register staging ---------------------------------------------------------------
-  d2v ra[4], rb[4];
+  d2v ra[NA], rb[4];
   // Branch-free: indices are clamped into range and the value zeroed afterwards (every operand row
   // is padded to a multiple of 16 doubles, so the 16-B load of a pair that straddles the logical
   // edge stays inside the allocation).
   auto load_slab = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      // B (and k-major A): one 128-double row per wave-load
+      // B: one 128-double row per wave-load
       const int p = i * 256 + t;
       const int krow = p >> 6, c = (p & 63) * 2;
       const int k = k0 + krow;
       const int kc = k < k_end ? k : k_end - 1;
-      {
-        const int n = n0 + c;
-        const int nc = n < g.N ? n : 0;
-        d2v v = *reinterpret_cast<const d2v*>(g.B + (int64_t)kc * g.ldb + nc);
-        v.x = (k < k_end && n < g.N) ? v.x : 0.0;
-        v.y = (k < k_end && n + 1 < g.N) ? v.y : 0.0;
-        rb[i] = v;
-      }
-      if (!A_KCONTIG) {
+      const int n = n0 + c;
+      const int nc = n < g.N ? n : 0;
+      d2v v = *reinterpret_cast<const d2v*>(g.B + (int64_t)kc * g.ldb + nc);
+      v.x = (k < k_end && n < g.N) ? v.x : 0.0;
+      v.y = (k < k_end && n + 1 < g.N) ? v.y : 0.0;
+      rb[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if (!A_KCONTIG) {         // A[k][m]: BM/2 pairs per k row
+        const int p = i * 256 + t;
+        const int krow = p / (BM / 2), c = (p % (BM / 2)) * 2;
+        const int k = k0 + krow;
+        const int kc = k < k_end ? k : k_end - 1;
         const int m = m0 + c;
         const int mc = m < g.M ? m : 0;
         d2v v = *reinterpret_cast<const d2v*>(g.A + (int64_t)kc * g.lda + mc);
@@ -128,7 +151,12 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g, const E
       const int p = i * 256 + t;
       const int krow = p >> 6, c = (p & 63) * 2;
       *reinterpret_cast<d2v*>(&Bs[buf][krow][c]) = rb[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
       if (!A_KCONTIG) {
+        const int p = i * 256 + t;
+        const int krow = p / (BM / 2), c = (p % (BM / 2)) * 2;
         *reinterpret_cast<d2v*>(&As[buf][krow][c]) = ra[i];
       } else {
         const int q = i * 4 + wave;
@@ -140,21 +168,21 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g, const E
     }
   };
 
-  const int fi = lane & 15, fk = lane >> 4;
+  const int fi = lane & 15, fk = lane >> 4;          // A fragment: 16 consecutive rows, k = lane >> 4
+  const int fblk = (lane >> 2) & 3, fj = lane & 3;   // B fragment / result: block and column in block
   auto compute_slab = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < kGemmBK / 4; ++kk) {
-      double af[4], bf[4];
+      double af[AF], bf[16];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = As[buf][4 * kk + fk][wm * 64 + i * 16 + fi];
-        bf[i] = Bs[buf][4 * kk + fk][wn * 64 + i * 16 + fi];
-      }
+      for (int a = 0; a < AF; ++a) af[a] = As[buf][4 * kk + fk][wm * (16 * AF) + a * 16 + fi];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int r = 0; r < 16; ++r) bf[r] = Bs[buf][4 * kk + fk][wn * 64 + 4 * ((fblk + r) & 15) + fj];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+      for (int a = 0; a < AF; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[a][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[r], acc[a][r], 0, 0, 0);
     }
   };
 
@@ -175,32 +203,43 @@ __global__ void __launch_bounds__(256) gemm_f64_kernel(const GemmArgs g, const E
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------
+  // acc[a][r], lane l: row = 16 a + 4 blk + (l >> 4), col = 4 ((blk + r) mod 16) + (l & 3)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int a = 0; a < AF; ++a)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + fi;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + fk + 4 * r;
-        if (row < g.M && col < g.N) epi((int)blockIdx.z, row, col, acc[i][j][r]);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * (16 * AF) + a * 16 + 4 * fblk + fk;
+      const int col = n0 + wn * 64 + 4 * ((fblk + r) & 15) + fj;
+      if (row < g.M && col < g.N) epi((int)blockIdx.z, row, col, acc[a][r]);
     }
 }
 
 inline int gemm_tiles(int x, int b) { return (x + b - 1) / b; }
 
 template <bool A_KCONTIG, class Epi>
-inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, const Epi& epi) {
-  g.tiles_m = gemm_tiles(g.M, kGemmBM);
+inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi) {
   g.tiles_n = gemm_tiles(g.N, kGemmBN);
   if (splits < 1) splits = 1;
   int ks = gemm_tiles(g.K, splits);
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
-  const unsigned gx = g.tri_mode == 2 ? (unsigned)(g.tiles_m * (g.tiles_m + 1) / 2)
-                                      : (unsigned)(g.tiles_m * g.tiles_n);
-  hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, Epi>), dim3(gx, 1, (unsigned)splits), dim3(256), 0, st,
-                     g, epi);
+  // 128-row tiles (one workgroup per CU, 64 accumulators per lane) unless they would leave CUs idle
+  const long tm128 = gemm_tiles(g.M, 128);
+  const long tiles128 = (g.tri_mode == 2 ? tm128 * (tm128 + 1) / 2 : tm128 * g.tiles_n) * splits;
+  const int bm_rows = (20 * tiles128 >= 17L * n_cu) ? 128 : 64;
+  g.tiles_m = gemm_tiles(g.M, bm_rows);
+  long blocks = (long)g.tiles_m * g.tiles_n;
+  if (g.tri_mode == 2) {
+    blocks = 0;
+    for (int bm = 0; bm < g.tiles_m; ++bm) {
+      const int cnt = (bm * bm_rows + bm_rows - 1) / kGemmBN + 1;
+      blocks += cnt < g.tiles_n ? cnt : g.tiles_n;
+    }
+  }
+  const dim3 grid((unsigned)blocks, 1, (unsigned)splits);
+  if (bm_rows == 128)
+    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, Epi>), grid, dim3(256), 0, st, g, epi);
+  else
+    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 2, Epi>), grid, dim3(256), 0, st, g, epi);
 }
 
 }  // namespace vb
