@@ -29,6 +29,45 @@ if ROOT not in sys.path:
 D, N_MC = 1024, 4096
 ALGO_BYTES = N_MC * D * 8 + 4 * D * 8 + 8        # noise read + theta read + grad write + value
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM bytes per evaluation of the accumulate kernel from the PMC passes committed under
+# profiles/r01_meanfield_c1_pmc_hbm.txt: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) x 1024 / 16
+PMC_TRAFFIC_BYTES_PER_EVAL = (2 * 265252.0 + 4176.3) * 1024 / 16
+FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet; tools/fp64_peak.hip measures 63-73 (4x4x4 form)
+
+
+def fullrank_leg(eng, vb, steps=150, warmup=60):
+    """Secondary measurement: the dense (full-rank) Gaussian family named by north_star, D=1024, N=4096,
+    correlated-Gaussian target, parameter resident on the device.  fp64 MFMA-bound."""
+    d, n = 1024, N_MC
+    rng = np.random.RandomState(2)
+    A = rng.randn(d, d)
+    model = vb.CorrelatedGaussianModel(rng.randn(d), covariance=A @ A.T / d + np.eye(d))
+    eng.set_model(model.device_spec())
+    fr = vb.FullRankGaussian(d)
+    L = np.exp(-1.0) * np.eye(d) + 0.01 * np.tril(np.random.RandomState(3).randn(d, d))
+    eng.fullrank_set_theta(fr.pack(np.zeros(d), L), d)
+    ring = 8
+    for s in range(ring):
+        eng.noise_generate(40 + s, n, d, seed=2, stream=s)
+    for i in range(warmup):
+        eng.elbo_grad_fullrank_enqueue(40 + i % ring, n, d)
+    eng.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.elbo_grad_fullrank_enqueue(40 + i % ring, n, d)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    value, grad = eng.fullrank_get(d)
+    flops = 4.0 * n * d * d + 2.0 * n * d * d          # Z = E L^T, G^T E (dense convention) + target's (Z - m) P
+    return {
+        'workload': 'FullRankGaussian + ExclusiveKL, D=1024, N_mc=4096, correlated-Gaussian target, fp64',
+        'evals_per_s': 1.0 / dt, 'us_per_eval': 1e6 * dt, 'steps': steps,
+        'roofline': {'bound': 'mfma', 'achieved': flops / dt / 1e12, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': flops / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                     'flops_per_eval_dense_convention': flops,
+                     'note': 'whole evaluation (3 MFMA GEMMs + O(ND) kernels); kernel split in profiles/'},
+        'check': {'value': value, 'grad_norm': float(np.linalg.norm(grad))},
+    }
 
 
 def cpu_baseline(theta, budget_s=12.0):
@@ -70,6 +109,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16,
                     help='independent evaluations per API call (share one launch of each kernel)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fullrank', action='store_true', help='skip the secondary full-rank measurement')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -195,13 +235,17 @@ def main():
             'check': {'value': last_value, 'grad_norm': float(np.linalg.norm(last_grad))},
             'roofline': {
                 'bound': 'hbm', 'kernel': 'mf_accum_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                'traffic': PMC_TRAFFIC_BYTES_PER_EVAL * evals_timed / max(1, launches),
+                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_meanfield_c1_pmc_hbm.txt',
                 'algorithmic_bytes_per_launch': bytes_per_launch, 'evals_per_launch': evals_timed / max(1, launches),
                 'avg_kernel_us': kernel_us, 'launches_timed': launches,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(theta)
+        if world == 1 and not args.no_fullrank:
+            out['fullrank'] = fullrank_leg(eng, vb)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
