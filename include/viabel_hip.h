@@ -144,6 +144,23 @@ int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int famil
                           const double* theta, const double* weights, double scale, double* value,
                           double* grad);
 
+/* ---- DISInclusiveKL, MultivariateT family (approximations.py:322-382) -------------------
+ * theta = [mu | free Cholesky of Sigma].  The O(D^3) factor algebra stays with the caller, as in the
+ * reference (sqrtm at approximations.py:348, eigh at _distributions.py:26): refresh takes the symmetric
+ * root Sigma^{1/2} and L^-1 (row-major D x D), the chi-square draws (N) and the normal draws in the noise
+ * slot (drawn in that order, approximations.py:345-347); the device forms the samples
+ * x = mu + (z Sigma^{1/2}) / sqrt(chi/df) with an MFMA GEMM, keeps them, evaluates log p, log q, the
+ * tempering prior and runs the ESS bisection.  grad returns, for weights w_n and the CURRENT theta / L^-1,
+ *   w_sum = sum w,  w_logq = sum w log q(x_n),  d_mu[D] = sum w c_n u_n,  gram[D x D] (lower triangle) =
+ *   sum w c_n u_n u_n',  u_n = Sigma^-1 (x_n - mu),  c_n = (df + D)/(df + maha_n)
+ * from which the caller assembles d/dtheta.                                   */
+int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
+                       const double* chi, const double* sqrt_sigma, const double* l_inv,
+                       const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
+                       double* eps, double* ess, double* w, double* log_p, double* log_q);
+int vb_dis_grad_mvt(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* l_inv,
+                    const double* weights, double* w_sum, double* w_logq, double* d_mu, double* gram);
+
 /* ---- ExclusiveKL, full-rank Gaussian family -------------------------------------------
  * New family (no reference class) behind the ApproximationFamily API with the flat
  * layout of viabel/approximations.py:315-319: theta = [mu (D) | free Cholesky (D(D+1)/2)],

@@ -52,11 +52,7 @@ def test_alpha_golden(vb, path):
     assert G.rel_err(grad, fx['grad_fd']) < 2e-7
 
 
-def _dis_fixtures():
-    return [p for p in G.fixtures('dis_') if 'multivariate' not in p]
-
-
-@pytest.mark.parametrize('path', _dis_fixtures(), ids=lambda p: p.split('/')[-1][:-4])
+@pytest.mark.parametrize('path', G.fixtures('dis_'), ids=lambda p: p.split('/')[-1][:-4])
 def test_dis_golden(vb, path):
     fx = G.load(path)
     D = int(fx['dim'])
@@ -115,6 +111,47 @@ def test_dis_against_oracle_multi_step(vb, family, use_resampling):
         assert G.rel_err(value, ov) < 1e-11, (step, value, ov)
         assert G.rel_err(grad, og) < 1e-10, (step, G.rel_err(grad, og))
         theta = theta - 0.01 * grad / (1 + np.abs(grad))
+
+
+@pytest.mark.parametrize('use_resampling', [True, False])
+def test_dis_multivariate_t_against_oracle(vb, use_resampling):
+    """MultivariateT + DIS (BASELINE configs[3] family) at a size where the MFMA GEMMs tile: D=200, N=3000,
+    three calls with a moving theta and num_resampling_batches = 2."""
+    D, N, df = 200, 3000, 40
+    rng = np.random.RandomState(9)
+    approx, ofamily = vb.MultivariateT(D, df, seed=6), ofam.MultivariateT(D, df)
+    mean, sd = 0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
+    kw = dict(use_resampling=use_resampling, num_resampling_batches=2)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=600, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, **kw)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, 600, ofam.MFGaussian(D), prior, **kw)
+    A = rng.randn(D, D)
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(A @ A.T / D + 0.7 * np.eye(D))])
+    rs = np.random.RandomState(6)
+    np.random.seed(12)
+    for step in range(3):
+        state = np.random.get_state()
+        value, grad = obj(theta)
+        np.random.set_state(state)
+        noise = ofamily.draw_noise(rs, N) if ref.needs_refresh() else None
+        if use_resampling:
+            if ref.needs_refresh():
+                ref.refresh(theta, noise)
+            idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
+            ref._objective_step += 1
+            xs = ref._state_samples[idx]
+            scale = ref._state_w_sum / N
+            ov = np.mean(-ofamily.log_density(theta, xs)) * scale
+            og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+        else:
+            ov, og = ref(theta, noise=noise)
+        assert G.rel_err(obj._eps, ref._eps) < 1e-10
+        assert G.rel_err(obj._state_log_q, ref._state_log_q) < 1e-11
+        assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
+        assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
+        theta = theta - 0.002 * grad / (1 + np.abs(grad))
 
 
 def test_dis_all_weights_zero_raises(vb):

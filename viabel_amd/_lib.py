@@ -69,6 +69,13 @@ SIGNATURES = {
     'vb_dis_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
                                              ctypes.c_double, _c_double_p, _c_double_p]),
+    'vb_dis_refresh_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                          _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+                                          ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_double_p,
+                                          _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'vb_dis_grad_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
+                                       _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+                                       _c_double_p]),
     'vb_elbo_grad_fullrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_int64, _c_double_p, ctypes.c_uint, _c_double_p,
                                              _c_double_p]),
@@ -290,6 +297,28 @@ class Engine:
                                                     _dptr(weights), float(scale), ctypes.byref(value),
                                                     _dptr(grad)))
         return value.value, grad
+
+    # ------------------------------------------------------------------ DISInclusiveKL, multivariate t
+    def dis_refresh_mvt(self, slot, n, d, df, theta, chi, sqrt_sigma, l_inv, prior_theta, eps_prev, ess_target,
+                        max_bisection_its=50):
+        theta, chi, sqrt_sigma, l_inv, prior_theta = (_f64(a) for a in (theta, chi, sqrt_sigma, l_inv, prior_theta))
+        eps, ess = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        w, lp, lq = (np.empty(n, dtype=np.float64) for _ in range(3))
+        self._check(self._lib.vb_dis_refresh_mvt(
+            self._ctx, slot, n, d, float(df), _dptr(theta), _dptr(chi), _dptr(sqrt_sigma), _dptr(l_inv),
+            _dptr(prior_theta), float(eps_prev), float(ess_target), int(max_bisection_its), ctypes.byref(eps),
+            ctypes.byref(ess), _dptr(w), _dptr(lp), _dptr(lq)))
+        return eps.value, ess.value, w, lp, lq
+
+    def dis_grad_mvt(self, n, d, df, theta, l_inv, weights):
+        theta, l_inv, weights = _f64(theta), _f64(l_inv), _f64(weights)
+        w_sum, w_logq = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        d_mu = np.empty(d, dtype=np.float64)
+        gram = np.empty((d, d), dtype=np.float64)
+        self._check(self._lib.vb_dis_grad_mvt(self._ctx, n, d, float(df), _dptr(theta), _dptr(l_inv),
+                                              _dptr(weights), ctypes.byref(w_sum), ctypes.byref(w_logq),
+                                              _dptr(d_mu), _dptr(gram)))
+        return w_sum.value, w_logq.value, d_mu, gram
 
     # ------------------------------------------------------------------ ExclusiveKL, full rank
     def elbo_grad_fullrank(self, slot, n, d, theta, flags=0, n_total=None):

@@ -205,7 +205,7 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
-                          &ctx->fr_out, &ctx->dis_state})
+                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& ev : ctx->prof_events) {
@@ -506,6 +506,29 @@ int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int famil
   *value = rs.host[rs.p];
   memcpy(grad, rs.host + rs.p + 1, (size_t)(2 * d) * sizeof(double));
   return VB_OK;
+}
+
+// ---- DISInclusiveKL, MultivariateT (approximations.py:322-382, objectives.py:391-414) ----------------
+int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
+                       const double* chi, const double* sqrt_sigma, const double* l_inv,
+                       const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
+                       double* eps, double* ess, double* w, double* log_p, double* log_q) {
+  if (!ctx || !theta || !chi || !sqrt_sigma || !l_inv || !prior_theta || !eps || !ess || !w)
+    return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return mvt_dis_refresh(ctx, ctx->noise[slot], n, d, df, theta, chi, sqrt_sigma, l_inv, prior_theta, eps_prev,
+                         ess_target, max_bisection_its, eps, ess, w, log_p, log_q);
+}
+
+int vb_dis_grad_mvt(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* l_inv,
+                    const double* weights, double* w_sum, double* w_logq, double* d_mu, double* gram) {
+  if (!ctx || !theta || !l_inv || !weights || !w_sum || !w_logq || !d_mu || !gram)
+    return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return mvt_dis_grad(ctx, n, d, df, theta, l_inv, weights, w_sum, w_logq, d_mu, gram);
 }
 
 // ---- ExclusiveKL, full-rank Gaussian ---------------------------------------------------------------

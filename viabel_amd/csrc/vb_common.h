@@ -99,6 +99,8 @@ struct vb_ctx {
   vb::DeviceBuffer scratch2;            // per-row outputs
   vb::DeviceBuffer rowvec;              // per-row weights
   vb::DeviceBuffer fr_work;             // full-rank pipeline work buffers
+  vb::DeviceBuffer mvt_state;           // multivariate-t DIS: state samples X, scratch
+  int64_t mvt_n = 0, mvt_d = 0;
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
@@ -179,6 +181,32 @@ int sync_streams(vb_ctx* ctx);   // main + pipeline streams
 // full-rank Gaussian ExclusiveKL (vb_fullrank.hip)
 int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
                          const double* theta_dev, double* out_dev);
+
+// sum vector of the dense paths: [F | column sums (ldz) | C (d x ldl)]
+struct FrSums {
+  double* sums;
+  int64_t off_col, off_c, len;
+};
+int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,
+                      const double* ivar, double* colpart, double* fpart);
+int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab, int d, int64_t ldl,
+                      const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S);
+// lower triangle of C = A' B for k-major A, B (n x d, row stride ld), split over n into `splits` slabs
+int gram_lower_enqueue(vb_ctx* ctx, const double* A, const double* B, int64_t ld, int d, int64_t n, int splits,
+                       double* Cpart, int64_t ldc, int64_t slab);
+int gram_splits(vb_ctx* ctx, int d, int64_t n);
+// ESS bisection of DISInclusiveKL (vb_rowstats.hip); lq = b - scal_in[0]
+int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const double* lprior, const double* scal_in,
+                       int64_t n, double eps_prev, double ess_target, int max_its, double* w, double* lq_out,
+                       double* scal_out);
+
+// multivariate-t DIS (vb_mvt.hip)
+int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, const double* theta_host,
+                    const double* chi_host, const double* root_host, const double* linv_host,
+                    const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
+                    double* ess_out, double* w_host, double* logp_host, double* logq_host);
+int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
+                 const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out);
 
 // Philox noise generation (vb_rng.hip)
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,

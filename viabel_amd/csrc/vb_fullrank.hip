@@ -177,10 +177,6 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
 
 // ---- reduce: split-K slabs, row-block partials -> sum vector ------------------------------------------
 // sum vector layout: [F | colsum (ldz) | C (d x ldl)], F at index 0, colsum from 16, C from 16 + ldz
-struct FrSums {
-  double* sums;
-  int64_t off_col, off_c, len;
-};
 
 __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict__ Cpart, int splits,
                                                         int64_t slab, int d, int64_t ldl,
@@ -240,6 +236,50 @@ __global__ void __launch_bounds__(256) fr_epilogue_kernel(FrSums S, const double
       out[0] = -(F * invN + H);
     }
   }
+}
+
+// ---- wrappers shared with the multivariate-t path (vb_mvt.hip) ---------------------------------------
+int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,
+                      const double* ivar, double* colpart, double* fpart) {
+  const int n_rb = (int)((n + 127) / 128);
+  hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)n_rb), dim3(256), 0, ctx->stream,
+                     G, Zc, ldz, n, d, fmode, ivar, colpart, fpart);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab, int d, int64_t ldl,
+                      const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S) {
+  const int64_t items = slab > ldz ? slab : ldz;
+  hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, Cpart,
+                     splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+int gram_lower_enqueue(vb_ctx* ctx, const double* A, const double* B, int64_t ld, int d, int64_t n, int splits,
+                       double* Cpart, int64_t ldc, int64_t slab) {
+  GemmArgs g3;
+  g3.A = A;
+  g3.lda = ld;
+  g3.B = B;
+  g3.ldb = ld;
+  g3.M = d;
+  g3.N = d;
+  g3.K = (int)n;
+  g3.tri_mode = 2;
+  gemm_f64_launch<false>(ctx->stream, g3, splits, ctx->prop.multiProcessorCount, EpiSplitSlab{Cpart, ldc, slab});
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+int gram_splits(vb_ctx* ctx, int d, int64_t n) {
+  const int tiles = gemm_tiles(d, 128);
+  const int lower_tiles = tiles * (tiles + 1) / 2;
+  int splits = ctx->prop.multiProcessorCount / lower_tiles;
+  const int max_splits = (int)(n / 256) > 0 ? (int)(n / 256) : 1;
+  if (splits > max_splits) splits = max_splits;
+  return splits < 1 ? 1 : splits;
 }
 
 // ---- host orchestration ------------------------------------------------------------------------------

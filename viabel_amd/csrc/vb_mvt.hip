@@ -1,0 +1,356 @@
+// MultivariateT family on the device: DISInclusiveKL state refresh and weighted log-density gradient.
+//
+// Reference: viabel/approximations.py:322-382 (family), viabel/_distributions.py:7-38 (log pdf),
+// viabel/objectives.py:391-414 (DIS).  theta = [mu | free Cholesky of Sigma = L L'].
+//   sample   x_n = mu + (z_n Sigma^{1/2}) / s_n,  s_n = sqrt(chi2_n / df)   (symmetric root, :345-349)
+//   log q(x) = c(df, D) - sum log L_ii - (df + D)/2 log(1 + maha/df),  maha = |L^-1 (x - mu)|^2
+//   d log q / d mu = c_n u_n,  d log q / d Sigma = -1/2 Sigma^-1 + 1/2 c_n u_n u_n',
+//                  u_n = Sigma^-1 (x_n - mu), c_n = (df + D)/(df + maha_n)        
+// The O(D^3) factor algebra (sqrtm, L^-1, the chain rule to the free Cholesky parameters) stays on
+// the host as in the reference; everything O(N D^2) / O(N D) runs here:
+//   X  = mu + (Z R) / s              GEMM (MFMA), row-scaled epilogue           R = Sigma^{1/2}
+//   E' = (X - mu) L^-T               GEMM (MFMA)            -> maha_n, log q_n  (row kernel)
+//   U  = E' L^-1                     GEMM (MFMA)            = u_n as rows
+//   S  = U' diag(w c) U              GEMM (MFMA, lower-triangular tiles, split over n)
+// log p and the tempering prior are evaluated on X by the row kernel of vb_rows.hip; the ESS bisection
+// is the kernel shared with the mean-field DIS path.
+#include "vb_gemm_f64.h"
+
+#include <vector>
+
+namespace vb {
+
+struct EpiSampleT {         // X = mu + acc / s_n
+  double* X;
+  int64_t ld;
+  const double* mu;
+  const double* inv_s;
+  __device__ void operator()(int, int row, int col, double acc) const {
+    X[(int64_t)row * ld + col] = fma(acc, inv_s[row], mu[col]);
+  }
+};
+
+struct EpiSubVec {          // E = acc - c   (c = mu L^-T)
+  double* E;
+  int64_t ld;
+  const double* c;
+  __device__ void operator()(int, int row, int col, double acc) const {
+    E[(int64_t)row * ld + col] = acc - c[col];
+  }
+};
+
+struct EpiStore {
+  double* U;
+  int64_t ld;
+  __device__ void operator()(int, int row, int col, double acc) const { U[(int64_t)row * ld + col] = acc; }
+};
+
+__device__ __forceinline__ double mvt_wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+
+// one wave per row: maha_n = |E'_n|^2, log q_n
+__global__ void __launch_bounds__(256) mvt_rows_kernel(const double* __restrict__ E, int64_t ld, int64_t n, int d,
+                                                       double df, double lq_const, double* __restrict__ maha,
+                                                       double* __restrict__ lq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double* e = E + row * ld;
+  double s = 0.0;
+  for (int c = lane; c < d; c += 64) s = fma(e[c], e[c], s);
+  s = mvt_wave_sum(s);
+  if (lane == 0) {
+    maha[row] = s;
+    lq[row] = lq_const - 0.5 * (df + d) * log1p(s / df);
+  }
+}
+
+// UA[n][j] = a_n U[n][j], a_n = w_n (df + D)/(df + maha_n); per-block partial sums of w and w * log q
+__global__ void __launch_bounds__(256) mvt_scale_kernel(const double* __restrict__ U, double* __restrict__ UA,
+                                                        int64_t ld, int64_t n, int d, double df,
+                                                        const double* __restrict__ w,
+                                                        const double* __restrict__ maha,
+                                                        const double* __restrict__ lq, double* __restrict__ part) {
+  __shared__ double sh[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  double sw = 0.0, swl = 0.0;
+  if (row < n) {
+    const double wn = w[row];
+    const double a = wn * (df + d) / (df + maha[row]);
+    const double* u = U + row * ld;
+    double* ua = UA + row * ld;
+    for (int c = lane; c < d; c += 64) ua[c] = a * u[c];
+    if (lane == 0) {
+      sw = wn;
+      swl = wn * lq[row];
+    }
+  }
+  if (lane == 0) {
+    sh[0][wave] = sw;
+    sh[1][wave] = swl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * (int64_t)blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    part[2 * (int64_t)blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  }
+}
+
+// sum the (sum w, sum w log q) partials
+__global__ void __launch_bounds__(256) mvt_scalar_kernel(const double* __restrict__ part, int64_t n_part,
+                                                         double* __restrict__ out) {
+  __shared__ double sh[2][4];
+  double a = 0.0, b = 0.0;
+  for (int64_t i = threadIdx.x; i < n_part; i += 256) {
+    a += part[2 * i];
+    b += part[2 * i + 1];
+  }
+  a = mvt_wave_sum(a);
+  b = mvt_wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = a;
+    sh[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    out[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  }
+}
+
+// ---- state layout ----------------------------------------------------------------------------------------
+struct MvtLayout {
+  int64_t ld, nn;
+  int64_t o_x, o_e, o_u, o_ua, o_root, o_wt, o_li, o_mu, o_c, o_invs, o_maha, o_lq, o_lp, o_lprior, o_w,
+      o_prior, o_scal, o_cpart, o_col, o_part, o_sums, total;
+  int splits, n_rb;
+  FrSums S;
+};
+
+static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t d) {
+  MvtLayout L;
+  L.ld = round_up(d, 16);
+  L.nn = round_up(n, 16);
+  L.splits = gram_splits(ctx, (int)d, n);
+  L.n_rb = (int)((n + 127) / 128);
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t mat = n * L.ld, sq = d * L.ld;
+  L.o_x = carve(mat);
+  L.o_e = carve(mat);
+  L.o_u = carve(mat);
+  L.o_ua = carve(mat);
+  L.o_root = carve(sq);
+  L.o_wt = carve(sq);
+  L.o_li = carve(sq);
+  L.o_mu = carve(L.ld);
+  L.o_c = carve(L.ld);
+  L.o_invs = carve(L.nn);
+  L.o_maha = carve(L.nn);
+  L.o_lq = carve(L.nn);
+  L.o_lp = carve(L.nn);
+  L.o_lprior = carve(L.nn);
+  L.o_w = carve(L.nn);
+  L.o_prior = carve(2 * L.ld);
+  L.o_scal = carve(32);
+  L.o_cpart = carve((int64_t)L.splits * sq);
+  L.o_col = carve((int64_t)L.n_rb * L.ld);
+  L.o_part = carve(2 * ((n + 3) / 4) + (int64_t)L.n_rb * ((d + 63) / 64));
+  L.S.off_col = 16;
+  L.S.off_c = 16 + L.ld;
+  L.S.len = 16 + L.ld + sq;
+  L.o_sums = carve(L.S.len);
+  L.total = off;
+  return L;
+}
+
+static int upload_padded(vb_ctx* ctx, double* dst, int64_t ld, const double* src, int64_t rows, int64_t cols,
+                         bool transpose) {
+  std::vector<double> tmp((size_t)rows * ld, 0.0);
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t j = 0; j < cols; ++j) tmp[(size_t)i * ld + j] = transpose ? src[j * cols + i] : src[i * cols + j];
+  VB_HIP(ctx, hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VB_OK;
+}
+
+// E' = (X - mu) L^-T, maha, log q for the parameter `theta_host` with inverse factor `linv_host`
+static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t n, int64_t d, double df,
+                         const double* theta_host, const double* linv_host) {
+  const int n_cu = ctx->prop.multiProcessorCount;
+  // Wt[k][j] = Linv[j][k] (B operand of dev L^-T), Li[k][j] = Linv[k][j] (B operand of E' L^-1)
+  VB_TRY(upload_padded(ctx, base + L.o_wt, L.ld, linv_host, d, d, true));
+  VB_TRY(upload_padded(ctx, base + L.o_li, L.ld, linv_host, d, d, false));
+  std::vector<double> vec((size_t)2 * L.ld, 0.0);
+  double logdet_half = 0.0;
+  for (int64_t j = 0; j < d; ++j) {
+    vec[j] = theta_host[j];
+    double c = 0.0;                       // c_j = sum_k mu_k Linv[j][k]
+    for (int64_t k = 0; k <= j; ++k) c += theta_host[k] * linv_host[j * d + k];
+    vec[L.ld + j] = c;
+    logdet_half += theta_host[d + j * (j + 1) / 2 + j];
+  }
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, vec.data(), vec.size() * sizeof(double), hipMemcpyHostToDevice,
+                             ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  GemmArgs g;
+  g.A = base + L.o_x;
+  g.lda = L.ld;
+  g.B = base + L.o_wt;
+  g.ldb = L.ld;
+  g.M = (int)n;
+  g.N = (int)d;
+  g.K = (int)d;
+  g.tri_mode = 0;
+  gemm_f64_launch<true>(ctx->stream, g, 1, n_cu, EpiSubVec{base + L.o_e, L.ld, base + L.o_c});
+  VB_HIP(ctx, hipGetLastError());
+  const double lq_const = lgamma(0.5 * (df + d)) - lgamma(0.5 * df) - 0.5 * d * log(M_PI * df) - logdet_half;
+  hipLaunchKernelGGL(mvt_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
+                     (const double*)(base + L.o_e), L.ld, n, (int)d, df, lq_const, base + L.o_maha, base + L.o_lq);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, const double* theta_host,
+                    const double* chi_host, const double* root_host, const double* linv_host,
+                    const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
+                    double* ess_out, double* w_host, double* logp_host, double* logq_host) {
+  if (ctx->comm) return fail(ctx, VB_ERR_UNSUPPORTED, "DISInclusiveKL is not sharded across GPUs yet");
+  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density implements gauss_diag and funnel");
+  if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  const MvtLayout L = mvt_layout(ctx, n, d);
+  VB_TRY(ensure(ctx, ctx->mvt_state, (size_t)L.total * sizeof(double)));
+  double* base = (double*)ctx->mvt_state.ptr;
+  hipStream_t st = ctx->stream;
+  const int n_cu = ctx->prop.multiProcessorCount;
+
+  VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
+  std::vector<double> inv_s((size_t)n);
+  for (int64_t i = 0; i < n; ++i) inv_s[i] = 1.0 / sqrt(chi_host[i] / df);          // approximations.py:345
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_invs, inv_s.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  std::vector<double> pr((size_t)2 * L.ld, 0.0);
+  double c0p = -0.5 * (double)d * 1.8378770664093454835606594728112;
+  for (int64_t i = 0; i < d; ++i) {
+    pr[i] = prior_host[i];
+    pr[L.ld + i] = exp(-2.0 * prior_host[d + i]);
+    c0p -= prior_host[d + i];
+  }
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  std::vector<double> mu((size_t)L.ld, 0.0);
+  for (int64_t i = 0; i < d; ++i) mu[i] = theta_host[i];
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+
+  // X = mu + (Z R) / s
+  GemmArgs g;
+  g.A = (const double*)ns.buf.ptr;
+  g.lda = ns.ld;
+  g.B = base + L.o_root;
+  g.ldb = L.ld;
+  g.M = (int)n;
+  g.N = (int)d;
+  g.K = (int)d;
+  g.tri_mode = 0;
+  gemm_f64_launch<true>(st, g, 1, n_cu, EpiSampleT{base + L.o_x, L.ld, base + L.o_mu, base + L.o_invs});
+  VB_HIP(ctx, hipGetLastError());
+
+  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host));
+  VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp));
+  {   // tempering prior: a diagonal Gaussian evaluated by the same row kernel
+    const ModelDev saved = ctx->model;
+    ModelDev prior;
+    prior.id = VB_MODEL_GAUSS_DIAG;
+    prior.dim = (int)d;
+    prior.c0 = c0p;
+    prior.p0 = base + L.o_prior;
+    prior.p1 = base + L.o_prior + L.ld;
+    ctx->model = prior;
+    const int rc = model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lprior);
+    ctx->model = saved;
+    VB_TRY(rc);
+  }
+  VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is
+  VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_lq, base + L.o_lprior, base + L.o_scal, n, eps_prev,
+                            ess_target, max_its, base + L.o_w, base + L.o_maha /*scratch copy of lq*/,
+                            base + L.o_scal + 8));
+  double res[3];
+  VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_scal + 8, sizeof res, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (logp_host)
+    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (logq_host)
+    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lq, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  *eps_out = res[0];
+  *ess_out = res[1];
+  ctx->mvt_n = n;
+  ctx->mvt_d = d;
+  if ((int)res[2] == 1)
+    return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
+  return VB_OK;
+}
+
+// sum_n w_n [log q_n, d log q_n / d mu, u_n u_n' c_n] for the state samples at parameter theta_host
+int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
+                 const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out) {
+  if (ctx->mvt_n != n || ctx->mvt_d != d || !ctx->mvt_state.ptr)
+    return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state of shape %lld x %lld", (long long)n, (long long)d);
+  const MvtLayout L = mvt_layout(ctx, n, d);
+  double* base = (double*)ctx->mvt_state.ptr;
+  hipStream_t st = ctx->stream;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host));
+  // U = E' L^-1
+  GemmArgs g;
+  g.A = base + L.o_e;
+  g.lda = L.ld;
+  g.B = base + L.o_li;
+  g.ldb = L.ld;
+  g.M = (int)n;
+  g.N = (int)d;
+  g.K = (int)d;
+  g.tri_mode = 0;
+  gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{base + L.o_u, L.ld});
+  VB_HIP(ctx, hipGetLastError());
+  const int64_t n_part = (n + 3) / 4;
+  hipLaunchKernelGGL(mvt_scale_kernel, dim3((unsigned)n_part), dim3(256), 0, st, (const double*)(base + L.o_u),
+                     base + L.o_ua, L.ld, n, (int)d, df, (const double*)(base + L.o_w),
+                     (const double*)(base + L.o_maha), (const double*)(base + L.o_lq), base + L.o_part);
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(mvt_scalar_kernel, dim3(1), dim3(256), 0, st, (const double*)(base + L.o_part), n_part,
+                     base + L.o_scal + 16);
+  VB_HIP(ctx, hipGetLastError());
+  double* fpart = base + L.o_part + 2 * n_part;
+  VB_TRY(fr_colsum_enqueue(ctx, base + L.o_ua, nullptr, L.ld, n, (int)d, 0, nullptr, base + L.o_col, fpart));
+  const int64_t slab = d * L.ld;
+  VB_TRY(gram_lower_enqueue(ctx, base + L.o_ua, base + L.o_u, L.ld, (int)d, n, L.splits, base + L.o_cpart, L.ld,
+                            slab));
+  FrSums S = L.S;
+  S.sums = base + L.o_sums;
+  VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col, L.n_rb, L.ld, fpart,
+                           L.n_rb * (int)((d + 63) / 64), S));
+  double sc[2];
+  VB_HIP(ctx, hipMemcpyAsync(sc, base + L.o_scal + 16, sizeof sc, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(dmu_out, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(gram_out, (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)L.ld * sizeof(double),
+                               (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  *wsum_out = sc[0];
+  *wlogq_out = sc[1];
+  return VB_OK;
+}
+
+}  // namespace vb

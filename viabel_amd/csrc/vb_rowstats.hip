@@ -267,6 +267,15 @@ __global__ void __launch_bounds__(1024) dis_bisect_kernel(const double* __restri
   }
 }
 
+int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const double* lprior, const double* scal_in,
+                       int64_t n, double eps_prev, double ess_target, int max_its, double* w, double* lq_out,
+                       double* scal_out) {
+  hipLaunchKernelGGL(dis_bisect_kernel, dim3(1), dim3(1024), 0, ctx->stream, lp, b, lprior, scal_in, n, eps_prev,
+                     ess_target, max_its, 1.0, w, lq_out, scal_out);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 // state layout (doubles): [cols_r 2 ld | scal 16 | out 16 | prior cols 2 ld | log p | b | log prior | w | lq]
 struct DisLayout {
   int64_t o_cols, o_scal, o_out, o_prior, o_lp, o_b, o_lprior, o_w, o_lq, total;

@@ -225,15 +225,18 @@ class DISInclusiveKL(StochasticVariationalObjective):
     def _update_objective_and_grad(self):
         approx = self.approx
         self._require_device_model()
-        if not isinstance(approx, (MFGaussian, MFStudentT)):
-            raise NotImplementedError('DISInclusiveKL on the HIP engine supports MFGaussian and '
-                                      'MFStudentT; got {}'.format(type(approx).__name__))
+        if not isinstance(approx, (MFGaussian, MFStudentT, MultivariateT)):
+            raise NotImplementedError('DISInclusiveKL on the HIP engine supports MFGaussian, MFStudentT and '
+                                      'MultivariateT; got {}'.format(type(approx).__name__))
         if not isinstance(self._temper_prior, MFGaussian) or self._temper_prior.dim != approx.dim:
             raise NotImplementedError('temper_prior must be an MFGaussian of the same dimension '
                                       '(tests/test_objectives.py:82-87)')
         if self._temper_prior_params.shape != (2 * approx.dim,):
             raise ValueError('temper_prior_params must have shape ({},)'.format(2 * approx.dim))
         slot = _DIS_SLOT
+        if isinstance(approx, MultivariateT):
+            self._objective_and_grad = self._mvt_objective(approx, slot)
+            return
 
         def variational_objective(var_param):
             var_param = np.asarray(var_param, dtype=np.float64)
@@ -268,6 +271,58 @@ class DISInclusiveKL(StochasticVariationalObjective):
             return eng.dis_grad_meanfield(slot, N, approx.dim, var_param, counts, scale, family, df=df)
 
         self._objective_and_grad = variational_objective
+
+
+    def _mvt_objective(self, approx, slot):
+        """DIS for the MultivariateT family: O(D^3) factor algebra here (as the reference does with
+        sqrtm / eigh on the host), O(N D^2) sampling / log-density / Gram work on the device."""
+        from scipy import linalg as sla
+        D, df = approx.dim, approx.df
+        tril = np.tril_indices(D)
+
+        def factors(var_param):
+            L = approx._unpack(var_param)[1]
+            return L, sla.solve_triangular(L, np.eye(D), lower=True)
+
+        def variational_objective(var_param):
+            var_param = np.asarray(var_param, dtype=np.float64)
+            if var_param.shape != (approx.var_param_dim,):
+                raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+            eng = self._engine()
+            if eng.n_ranks > 1:
+                raise NotImplementedError('DISInclusiveKL is not sharded across GPUs yet')
+            eng.set_model(self.model.device_spec())
+            N = self.num_mc_samples
+            L, Linv = factors(var_param)
+            if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
+                chi, z = approx._base_noise(N)                 # chi-square draws first (approximations.py:345-347)
+                eng.noise_set_host(slot, z)
+                root = sla.sqrtm(L @ L.T).real                  # symmetric square root, :348
+                self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
+                    slot, N, D, df, var_param, chi, root, Linv, self._temper_prior_params, self._eps,
+                    self._ess_target, self._max_bisection_its)
+                self._state_log_p_unnormalized = log_p
+                self._state_log_q = log_q
+                self._state_w_clipped = self._clip_weights(w)
+                self._state_w_sum = np.sum(self._state_w_clipped)
+                self._state_w_normalized = self._state_w_clipped / self._state_w_sum
+            self._objective_step += 1
+            if not self._use_resampling:
+                weights, scale = self._state_w_clipped, 1.0 / N
+            else:
+                indices = np.random.choice(N, size=self._resampling_batch_size, p=self._state_w_normalized)
+                weights = np.bincount(indices, minlength=N).astype(np.float64)
+                scale = self._state_w_sum / N / self._resampling_batch_size
+            w_sum, w_logq, d_mu, gram = eng.dis_grad_mvt(N, D, df, var_param, Linv, weights)
+            # chain rule to the free Cholesky parameters (SURVEY App. A.5)
+            S = np.tril(gram) + np.tril(gram, -1).T
+            d_sigma = -0.5 * w_sum * (Linv.T @ Linv) + 0.5 * S
+            d_L = np.tril(2.0 * d_sigma @ L)
+            d_L[np.diag_indices(D)] *= np.diag(L)
+            grad_logq = np.concatenate([d_mu, d_L[tril]])
+            return -scale * w_logq, -scale * grad_logq
+
+        return variational_objective
 
 
 class AlphaDivergence(StochasticVariationalObjective):
