@@ -108,6 +108,8 @@ def main():
                          'small prep / finalize kernels of one evaluation overlap the streaming kernel of another')
     ap.add_argument('--batch', type=int, default=16,
                     help='independent evaluations per API call (share one launch of each kernel)')
+    ap.add_argument('--force-comm', action='store_true',
+                    help='attach an RCCL communicator even with one rank (exercises the sharded code path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fullrank', action='store_true', help='skip the secondary full-rank measurement')
     args = ap.parse_args()
@@ -121,12 +123,18 @@ def main():
     import viabel_amd as vb
 
     dist = None
-    if world > 1:
+    use_comm = world > 1 or args.force_comm
+    if use_comm:
         import torch.distributed as dist
+        if 'RANK' not in os.environ:      # plain `python bench.py --force-comm`
+            os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29531')
         dist.init_process_group(backend='gloo')
     eng = _lib.default_engine()
-    if world > 1:
-        distributed.attach(eng)
+    if use_comm:
+        if world > 1:
+            distributed.attach(eng)
+        else:
+            eng.comm_init(_lib.Engine.comm_unique_id(), 1, 0)
 
     model = vb.FunnelModel(D)
     theta = np.concatenate([np.zeros(D), -np.ones(D)])       # mu = 0, log sigma = -1
@@ -136,6 +144,9 @@ def main():
     if world > 1:
         for e in engines[1:]:
             distributed.attach(e)
+    elif use_comm:
+        for e in engines[1:]:
+            e.comm_init(_lib.Engine.comm_unique_id(), 1, 0)
     n_eng = len(engines)
     # noise matrices per engine: at least one batch, and > 256 MiB L3 over all engines
     ring = min(max(batch, (args.ring + n_eng - 1) // n_eng), _lib.MAX_SLOTS - 8)
