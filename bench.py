@@ -106,7 +106,7 @@ def main():
     ap.add_argument('--engines', type=int, default=1,
                     help='independent HIP contexts (streams) the evaluations are spread over, so the '
                          'small prep / finalize kernels of one evaluation overlap the streaming kernel of another')
-    ap.add_argument('--batch', type=int, default=16,
+    ap.add_argument('--batch', type=int, default=32,
                     help='independent evaluations per API call (share one launch of each kernel)')
     ap.add_argument('--force-comm', action='store_true',
                     help='attach an RCCL communicator even with one rank (exercises the sharded code path)')
@@ -139,7 +139,7 @@ def main():
     model = vb.FunnelModel(D)
     theta = np.concatenate([np.zeros(D), -np.ones(D)])       # mu = 0, log sigma = -1
     n_total = N_MC * world
-    batch = max(1, min(args.batch, 16))
+    batch = max(1, min(args.batch, 32))
     engines = [eng] + [_lib.Engine(eng.device) for _ in range(max(1, args.engines) - 1)]
     if world > 1:
         for e in engines[1:]:

@@ -108,7 +108,7 @@ int vb_elbo_grad_meanfield_async(vb_ctx* ctx, int slot, int64_t n, int64_t d, in
                                  int family, double df, const double* theta, unsigned flags,
                                  int cv_mode, int rslot);
 /* `count` independent evaluations in one call: evaluation b streams noise slot slots[b] with the
- * parameter thetas[b * 2d ...] (row-major count x 2d) and lands in result slot rslots[b].  Up to 16
+ * parameter thetas[b * 2d ...] (row-major count x 2d) and lands in result slot rslots[b].  Up to 32
  * evaluations share one launch of each kernel (blockIdx.y), which amortises launch latency and
  * fills the chip; use it to evaluate the objective at many parameter vectors / noise draws at
  * once (multi-start fits, gradient-variance estimates, line searches).                      */

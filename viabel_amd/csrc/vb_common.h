@@ -22,7 +22,7 @@ constexpr int kMfThreads = 256;    // 4 waves per workgroup
 constexpr int kMfWaves = kMfThreads / kWave;
 constexpr int kMfCols = 128;       // columns per workgroup: 64 lanes x 2 doubles = one 1-KiB wave load
 constexpr int kMfChunk = 16;       // rows a wave keeps in flight (16 x 16-B loads per lane)
-constexpr int kMaxBatch = 16;      // independent evaluations per launch (blockIdx.y)
+constexpr int kMaxBatch = 32;      // independent evaluations per launch (blockIdx.y)
 constexpr int kModelLogQ = 3;      // internal pseudo model: weighted log q(z; theta) statistics (DIS)
 
 // per-column partial sums (fields) and per-workgroup scalars written by the accumulation kernel
