@@ -49,6 +49,8 @@ typedef struct vb_ctx vb_ctx;
 #define VB_MODEL_GAUSS_DIAG 0  /* sum_d norm.logpdf(x_d; mean_d, sd_d)   dparams=[mean(D)|sd(D)]           */
 #define VB_MODEL_FUNNEL 1      /* quickstart funnel, D-dim               dparams=[tau], iparams=[scale_idx] */
 #define VB_MODEL_GAUSS_FULL 2  /* N(mean, P^-1)                          dparams=[mean(D)|P(DxD)|logdetP]   */
+#define VB_MODEL_LOGISTIC 3    /* Bayesian logistic regression, N(0, sd) prior (not in the reference)
+                                  dparams=[X(n_data x D)|y(n_data)|prior_sd], iparams=[n_data]             */
 
 /* noise kinds for vb_noise_generate */
 #define VB_NOISE_NORMAL 0

@@ -185,3 +185,28 @@ def test_alpha_against_oracle(vb, D, N, family):
             ov, og = oobj.alpha_divergence(ofamily, omodel, theta, noise, alpha)
             assert G.rel_err(value, ov) < 1e-12
             assert G.rel_err(grad, og) < 1e-11
+
+
+@pytest.mark.parametrize('D,n_data,N', [(7, 33, 50), (50, 200, 300), (200, 500, 1000)])
+def test_logistic_regression_target(vb, D, n_data, N):
+    """New target against the oracle's logistic model: plain and path-derivative ELBO,
+    Gaussian and Student-t mean-field families."""
+    rng = np.random.RandomState(D)
+    X = rng.randn(n_data, D) / np.sqrt(D)
+    beta = rng.randn(D)
+    y = (rng.rand(n_data) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    model, omodel = vb.LogisticRegressionModel(X, y, 10.0), omod.Logistic(X, y, 10.0)
+    theta = np.concatenate([0.3 * rng.randn(D), -1.0 + 0.2 * rng.randn(D)])
+    for approx, ofamily in ((vb.MFGaussian(D, seed=2), ofam.MFGaussian(D)),
+                            (vb.MFStudentT(D, 9, seed=2), ofam.MFStudentT(D, 9))):
+        for pd in (False, True):
+            value, grad = vb.ExclusiveKL(approx, model, N, use_path_deriv=pd)(theta)
+            rs = np.random.RandomState(2)
+            if pd:
+                ofamily.draw_noise(rs, N)
+            noise = ofamily.draw_noise(rs, N)
+            ov, og = oobj.exclusive_kl(ofamily, omodel, theta, noise, pd)
+            assert G.rel_err(value, ov) < 1e-12, (pd, value, ov)
+            assert G.rel_err(grad, og) < 1e-11, (pd, G.rel_err(grad, og))
+    with pytest.raises(NotImplementedError):
+        vb.ExclusiveKL(vb.MFGaussian(D), model, N, hessian_approx_method='full')(theta)

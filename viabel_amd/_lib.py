@@ -18,7 +18,7 @@ CSRC_DIR = os.path.join(_HERE, 'csrc')
 VB_OK, VB_ERR_INVALID, VB_ERR_HIP, VB_ERR_UNSUPPORTED, VB_ERR_STATE, VB_ERR_NUMERIC, VB_ERR_COMM = range(7)
 
 FAMILY_MF_GAUSSIAN, FAMILY_MF_STUDENT_T, FAMILY_FULLRANK_GAUSSIAN, FAMILY_MULTIVARIATE_T = range(4)
-MODEL_GAUSS_DIAG, MODEL_FUNNEL, MODEL_GAUSS_FULL = range(3)
+MODEL_GAUSS_DIAG, MODEL_FUNNEL, MODEL_GAUSS_FULL, MODEL_LOGISTIC = range(4)
 NOISE_NORMAL, NOISE_STUDENT_T = range(2)
 FLAG_PATH_DERIV = 1
 CV_MODES = {None: 0, 'full': 1, 'mean_only': 2, 'loo_diag_approx': 3, 'loo_direct_approx': 4}
@@ -215,9 +215,11 @@ class Engine:
     def set_model(self, spec):
         """``spec`` = (model_id, dim, dparams ndarray, iparams ndarray) from ``DeviceModel.device_spec``."""
         model_id, dim, dparams, iparams = spec
-        key = (model_id, dim, dparams.tobytes(), iparams.tobytes())
+        # models hand out the same (cached) parameter arrays every time: identity is the cache key
+        key = (model_id, dim, id(dparams), id(iparams))
         if key == self._model_key:
             return
+        self._model_arrays = (dparams, iparams)      # keep them alive so the ids stay unique
         dparams = _f64(dparams)
         iparams = np.ascontiguousarray(iparams, dtype=np.int64)
         self._check(self._lib.vb_set_model(

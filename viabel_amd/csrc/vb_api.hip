@@ -205,7 +205,7 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
-                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state})
+                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& ev : ctx->prof_events) {
@@ -319,6 +319,27 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams, 
     for (int64_t i = 0; i < dim; ++i) dev[i] = dparams[i];
     for (int64_t i = 0; i < dim; ++i)
       for (int64_t j = 0; j < dim; ++j) dev[(size_t)m.ldp * (i + 1) + j] = dparams[dim + i * dim + j];
+  } else if (model_id == VB_MODEL_LOGISTIC) {
+    if (n_iparams != 1 || !iparams || iparams[0] <= 0 || !dparams ||
+        n_dparams != (size_t)(iparams[0] * dim + iparams[0] + 1))
+      return fail(ctx, VB_ERR_INVALID, "logistic expects dparams = [X(n_data x D) | y(n_data) | prior_sd], iparams = [n_data]");
+    const int64_t nd = iparams[0];
+    const double sd = dparams[nd * dim + nd];
+    if (!(sd > 0.0)) return fail(ctx, VB_ERR_INVALID, "logistic prior_sd must be positive");
+    m.n_data = nd;
+    m.ldp = round_up(dim, 16);
+    m.ldq = round_up(nd, 16);
+    m.tau = sd;
+    m.c0 = -(double)dim * (log(sd) + 0.5 * kLog2Pi);
+    // [X (nd x ldp) | X' (dim x ldq) | y (ldq)], rows padded for the GEMM operand loads
+    dev.assign((size_t)nd * m.ldp + (size_t)dim * m.ldq + (size_t)m.ldq, 0.0);
+    for (int64_t i = 0; i < nd; ++i)
+      for (int64_t j = 0; j < dim; ++j) {
+        const double v = dparams[i * dim + j];
+        dev[(size_t)i * m.ldp + j] = v;
+        dev[(size_t)nd * m.ldp + (size_t)j * m.ldq + i] = v;
+      }
+    for (int64_t i = 0; i < nd; ++i) dev[(size_t)nd * m.ldp + (size_t)dim * m.ldq + i] = dparams[nd * dim + i];
   } else {
     return fail(ctx, VB_ERR_INVALID, "unknown model id %d", model_id);
   }
@@ -329,6 +350,10 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams, 
     VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m.p0 = (const double*)ctx->model_params.ptr;
     m.p1 = m.p0 + (model_id == VB_MODEL_GAUSS_FULL ? m.ldp : dim);
+    if (model_id == VB_MODEL_LOGISTIC) {
+      m.p1 = m.p0 + (size_t)m.n_data * m.ldp;
+      m.p2 = m.p1 + (size_t)dim * m.ldq;
+    }
   }
   ctx->model = m;
   return VB_OK;

@@ -23,7 +23,7 @@ constexpr int kMfWaves = kMfThreads / kWave;
 constexpr int kMfCols = 128;       // columns per workgroup: 64 lanes x 2 doubles = one 1-KiB wave load
 constexpr int kMfChunk = 16;       // rows a wave keeps in flight (16 x 16-B loads per lane)
 constexpr int kMaxBatch = 32;      // independent evaluations per launch (blockIdx.y)
-constexpr int kModelLogQ = 3;      // internal pseudo model: weighted log q(z; theta) statistics (DIS)
+constexpr int kModelLogQ = 99;     // internal pseudo model: weighted log q(z; theta) statistics (DIS)
 
 // per-column partial sums (fields) and per-workgroup scalars written by the accumulation kernel
 enum ColField { CF_G = 0, CF_GE, CF_E, CF_EE, CF_EK, CF_SC, CF_SCE, CF_NUM };
@@ -40,7 +40,10 @@ struct ModelDev {
   double c0 = 0.0;     // additive constant of f per sample
   const double* p0 = nullptr;   // gauss_diag: mean[D]       gauss_full: mean[D]
   const double* p1 = nullptr;   // gauss_diag: 1/sd^2 [D]    gauss_full: P [D x ldp]
-  int64_t ldp = 0;              // gauss_full: row stride of P (multiple of 16)
+  int64_t ldp = 0;              // gauss_full: row stride of P; logistic: row stride of X (multiples of 16)
+  const double* p2 = nullptr;   // logistic: y [n_data]   (p0 = X [n_data x ldp], p1 = X' [D x ldq])
+  int64_t ldq = 0;              // logistic: row stride of X'
+  int64_t n_data = 0;           // logistic: observations
 };
 
 struct DeviceBuffer {
@@ -99,6 +102,7 @@ struct vb_ctx {
   vb::DeviceBuffer scratch2;            // per-row outputs
   vb::DeviceBuffer rowvec;              // per-row weights
   vb::DeviceBuffer fr_work;             // full-rank pipeline work buffers
+  vb::DeviceBuffer lg_work;             // logistic-regression target: Z, R, G, partials
   vb::DeviceBuffer mvt_state;           // multivariate-t DIS: state samples X, scratch
   int64_t mvt_n = 0, mvt_d = 0;
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]

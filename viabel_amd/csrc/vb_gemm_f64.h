@@ -27,6 +27,9 @@
 
 #include "vb_common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace vb {
 
 typedef double d2v __attribute__((ext_vector_type(2)));
@@ -47,7 +50,14 @@ struct GemmArgs {
 };
 
 // Epilogue functor interface:  void operator()(int split, int row, int col, double acc) const;
-// called for every in-range element of the block tile.
+// called for every in-range element of the block tile.  A functor that defines `double* part` and
+// returns double from operator() additionally gets the per-workgroup sum of its return values written to
+// part[blockIdx.z * gridDim.x + blockIdx.x] (workgroups that exit early write nothing: zero `part` first).
+template <class E, class = void>
+struct EpiReduces : std::false_type {};
+template <class E>
+struct EpiReduces<E, std::void_t<decltype(std::declval<E>().part)>> : std::true_type {};
+
 // AF = 4: 128-row block tile, 64 accumulators per lane, one workgroup per CU;
 // AF = 2:  64-row block tile, 32 accumulators per lane, two workgroups per CU (stalls of one are
 //          covered by the MFMAs of the other) -- used when 128-row tiles would not fill the chip twice.
@@ -203,6 +213,7 @@ __global__ void __launch_bounds__(256, AF == 2 ? 2 : 1) gemm_f64_kernel(const Ge
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------
+  double local = 0.0;
   // acc[a][r], lane l: row = 16 a + 4 blk + (l >> 4), col = 4 ((blk + r) mod 16) + (l & 3)
 #pragma unroll
   for (int a = 0; a < AF; ++a)
@@ -210,8 +221,23 @@ __global__ void __launch_bounds__(256, AF == 2 ? 2 : 1) gemm_f64_kernel(const Ge
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * (16 * AF) + a * 16 + 4 * fblk + fk;
       const int col = n0 + wn * 64 + 4 * ((fblk + r) & 15) + fj;
-      if (row < g.M && col < g.N) epi((int)blockIdx.z, row, col, acc[a][r]);
+      if (row < g.M && col < g.N) {
+        if constexpr (EpiReduces<Epi>::value)
+          local += epi((int)blockIdx.z, row, col, acc[a][r]);
+        else
+          epi((int)blockIdx.z, row, col, acc[a][r]);
+      }
     }
+  // optional per-workgroup reduction of the values the epilogue returns (e.g. sum of log-likelihood terms)
+  if constexpr (EpiReduces<Epi>::value) {
+    __syncthreads();                       // the LDS slabs are free: reuse the first words
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    double* red = &As[0][0][0];
+    if (lane == 0) red[wave] = local;
+    __syncthreads();
+    if (t == 0) epi.part[(int64_t)blockIdx.z * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
 }
 
 inline int gemm_tiles(int x, int b) { return (x + b - 1) / b; }

@@ -714,6 +714,12 @@ mf_epilogue_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
   }
 }
 
+}  // namespace vb
+
+#include "vb_logistic.h"
+
+namespace vb {
+
 // ---------------------------------------------------------------------------------------------
 struct Launch {
   dim3 grid;
@@ -746,6 +752,75 @@ static int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
+// Logistic-regression target: sample, two MFMA GEMMs, then the explicit-gradient streaming pass.  Fills
+// the same workspace (theta copy, column constants, prep scalars, partials) the other models fill.
+static int logistic_accumulate(vb_ctx* ctx, hipStream_t st, const ModelDev& m, const NoiseSlot& ns,
+                               const BatchPtrs& bp, const Workspace& ws, const Geom& g, bool mom, bool tsc) {
+  const int64_t n = g.n, d = g.d, nd = m.n_data;
+  const int64_t ldz = round_up(d, 16), ldr = round_up(nd, 16);
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int64_t max_blocks = ((n + 63) / 64) * ((nd + 127) / 128);
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t o_z = carve(n * ldz), o_g = carve(n * ldz), o_r = carve(n * ldr), o_part = carve(max_blocks),
+                o_fsum = carve(16);
+  VB_TRY(ensure(ctx, ctx->lg_work, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->lg_work.ptr;
+  double *Z = base + o_z, *G = base + o_g, *Rm = base + o_r, *part = base + o_part, *fsum = base + o_fsum;
+  double* wsb = ws.base;
+  VB_HIP(ctx, hipMemsetAsync(part, 0, (size_t)max_blocks * sizeof(double), st));
+  VB_HIP(ctx, hipMemsetAsync(wsb + ws.off_colp, 0, (size_t)3 * g.Dp * sizeof(double), st));
+  hipLaunchKernelGGL(lg_sample_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)n), dim3(256), 0, st,
+                     bp.theta_src[0], wsb + ws.off_theta, wsb + ws.off_colp, g.Dp, (const double*)ns.buf.ptr, ns.ld,
+                     Z, ldz, n, (int)d);
+  VB_HIP(ctx, hipGetLastError());
+  GemmArgs gh;                       // H = Z X'   [n x n_data x d]
+  gh.A = Z;
+  gh.lda = ldz;
+  gh.B = m.p1;
+  gh.ldb = m.ldq;
+  gh.M = (int)n;
+  gh.N = (int)nd;
+  gh.K = (int)d;
+  gh.tri_mode = 0;
+  gemm_f64_launch<true>(st, gh, 1, n_cu, EpiLogit{Rm, ldr, m.p2, part});
+  VB_HIP(ctx, hipGetLastError());
+  GemmArgs gg;                       // G = R X - Z / sd^2   [n x d x n_data]
+  gg.A = Rm;
+  gg.lda = ldr;
+  gg.B = m.p0;
+  gg.ldb = m.ldp;
+  gg.M = (int)n;
+  gg.N = (int)d;
+  gg.K = (int)nd;
+  gg.tri_mode = 0;
+  const double ivp = 1.0 / (m.tau * m.tau);
+  gemm_f64_launch<true>(st, gg, 1, n_cu, EpiLogitGrad{G, ldz, Z, ivp});
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(lg_scalars_kernel, dim3(1), dim3(256), 0, st, (const double*)part, (int)max_blocks, fsum,
+                     wsb + ws.off_prepscal, (double)n);
+  VB_HIP(ctx, hipGetLastError());
+  const dim3 grid((unsigned)(g.n_rb * g.n_cb));
+  if (mom && tsc)
+    hipLaunchKernelGGL((lg_accum_kernel<true, true>), grid, dim3(kMfThreads), 0, st, (const double*)ns.buf.ptr, ns.ld,
+                       (const double*)G, ldz, ws, g, ivp, (const double*)fsum);
+  else if (mom)
+    hipLaunchKernelGGL((lg_accum_kernel<true, false>), grid, dim3(kMfThreads), 0, st, (const double*)ns.buf.ptr, ns.ld,
+                       (const double*)G, ldz, ws, g, ivp, (const double*)fsum);
+  else if (tsc)
+    hipLaunchKernelGGL((lg_accum_kernel<false, true>), grid, dim3(kMfThreads), 0, st, (const double*)ns.buf.ptr, ns.ld,
+                       (const double*)G, ldz, ws, g, ivp, (const double*)fsum);
+  else
+    hipLaunchKernelGGL((lg_accum_kernel<false, false>), grid, dim3(kMfThreads), 0, st, (const double*)ns.buf.ptr, ns.ld,
+                       (const double*)G, ldz, ws, g, ivp, (const double*)fsum);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 // Enqueue prep -> accumulate -> finalize [-> all-reduce -> epilogue] for a batch of `count`
 // independent evaluations.
 int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
@@ -753,7 +828,11 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   const ModelDev& model = c.model ? *c.model : ctx->model;
   if (c.count < 1 || c.count > kMaxBatch)
     return fail(ctx, VB_ERR_INVALID, "batch size %d outside [1, %d]", c.count, kMaxBatch);
-  if (model.id != VB_MODEL_GAUSS_DIAG && model.id != VB_MODEL_FUNNEL && model.id != kModelLogQ)
+  const bool logistic = model.id == VB_MODEL_LOGISTIC;
+  if (logistic && (c.count != 1 || c.mode != 0 || c.cv_mode != VB_CV_NONE || c.roww[0] != nullptr))
+    return fail(ctx, VB_ERR_UNSUPPORTED,
+                "the logistic-regression target supports single ExclusiveKL evaluations without control variates");
+  if (model.id != VB_MODEL_GAUSS_DIAG && model.id != VB_MODEL_FUNNEL && model.id != kModelLogQ && !logistic)
     return fail(ctx, VB_ERR_UNSUPPORTED,
                 "mean-field path supports the gauss_diag and funnel models (model id %d bound)", model.id);
   if (model.dim != d)
@@ -798,7 +877,7 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   g.rows_per_wg = (int)round_up(rows_per_wg < kMfWaves ? kMfWaves : rows_per_wg, kMfWaves);
   g.n_rb = (int)((n + g.rows_per_wg - 1) / g.rows_per_wg);
   const int64_t prep_items = rows ? (n > g.Dp ? n : g.Dp) : g.Dp;
-  g.n_prep = (int)((prep_items + 255) / 256);
+  g.n_prep = logistic ? 1 : (int)((prep_items + 255) / 256);
   g.xcd_map = (g.n_rb % 8 == 0) ? env_int("VB_MF_XCD_MAP", 1) : 0;
   g.rows = rows ? 1 : 0;
   g.df = c.df;
@@ -856,9 +935,11 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
     P.post_pending = false;
   }
 
-  hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)g.n_prep, (unsigned)c.count), dim3(256), 0, st_pre,
-                     bp, ws, g, model);
-  VB_HIP(ctx, hipGetLastError());
+  if (!logistic) {
+    hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)g.n_prep, (unsigned)c.count), dim3(256), 0, st_pre,
+                       bp, ws, g, model);
+    VB_HIP(ctx, hipGetLastError());
+  }
   if (c.pipelined) {
     VB_HIP(ctx, hipEventRecord(P.ev_prep[set], st_pre));
     VB_HIP(ctx, hipStreamWaitEvent(st_main, P.ev_prep[set], 0));
@@ -868,7 +949,9 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   L.grid = dim3((unsigned)(g.n_rb * g.n_cb), (unsigned)c.count);
   L.st = st_main;
   prof_events(ctx, &L.ev0, &L.ev1, c.count);
-  if (model.id == VB_MODEL_GAUSS_DIAG)
+  if (logistic)
+    VB_TRY(logistic_accumulate(ctx, st_main, model, *c.noise[0], bp, ws, g, mom, tsc));
+  else if (model.id == VB_MODEL_GAUSS_DIAG)
     launch_accum_model<VB_MODEL_GAUSS_DIAG>(mom, tsc, weighted, L, bp, ws, g);
   else if (model.id == VB_MODEL_FUNNEL)
     launch_accum_model<VB_MODEL_FUNNEL>(mom, tsc, weighted, L, bp, ws, g);

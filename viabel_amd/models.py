@@ -12,7 +12,8 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ['Model', 'DeviceModel', 'GaussianModel', 'FunnelModel', 'CorrelatedGaussianModel']
+__all__ = ['Model', 'DeviceModel', 'GaussianModel', 'FunnelModel', 'CorrelatedGaussianModel',
+           'LogisticRegressionModel']
 
 
 class Model(object):
@@ -52,7 +53,13 @@ class DeviceModel(Model):
         return self._dim
 
     def device_spec(self):
-        """``(model_id, dim, dparams, iparams)`` for ``vb_set_model``."""
+        """``(model_id, dim, dparams, iparams)`` for ``vb_set_model`` (built once, then cached)."""
+        spec = getattr(self, '_spec_cache', None)
+        if spec is None:
+            spec = self._spec_cache = self._build_spec()
+        return spec
+
+    def _build_spec(self):
         raise NotImplementedError()
 
     def _device_log_density(self, x):
@@ -79,7 +86,7 @@ class GaussianModel(DeviceModel):
         self.mean, self.stdev = mean, stdev
         super().__init__(mean.size)
 
-    def device_spec(self):
+    def _build_spec(self):
         return (_lib.MODEL_GAUSS_DIAG, self._dim, np.concatenate([self.mean, self.stdev]),
                 np.zeros(0, dtype=np.int64))
 
@@ -103,7 +110,7 @@ class FunnelModel(DeviceModel):
         self.log_sigma_stdev = float(log_sigma_stdev)
         super().__init__(dim)
 
-    def device_spec(self):
+    def _build_spec(self):
         return (_lib.MODEL_FUNNEL, self._dim, np.array([self.log_sigma_stdev]),
                 np.array([self.scale_index], dtype=np.int64))
 
@@ -127,7 +134,31 @@ class CorrelatedGaussianModel(DeviceModel):
             raise ValueError('precision must be positive definite')
         super().__init__(mean.size)
 
-    def device_spec(self):
+    def _build_spec(self):
         return (_lib.MODEL_GAUSS_FULL, self._dim,
                 np.concatenate([self.mean, self.precision.ravel(), [self.logdet_precision]]),
                 np.zeros(0, dtype=np.int64))
+
+
+class LogisticRegressionModel(DeviceModel):
+    """Bayesian logistic regression ``y_i ~ Bernoulli(sigmoid(x_i' b))`` with a ``N(0, prior_sd)`` prior.
+
+    Not in the reference (BASELINE configs[4] names a logistic-regression model that the
+    upstream tree does not contain); the prior scale 10 follows the Stan model of the reference's tests
+    (``viabel/tests/test_models.py:41``).  Its gradient couples all coordinates through ``X``, so the engine
+    evaluates it with two fp64 MFMA GEMMs per objective call.
+    """
+
+    def __init__(self, X, y, prior_sd=10.0):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64).ravel()
+        if X.ndim != 2 or y.shape != (X.shape[0],):
+            raise ValueError('X must be (n_data, dim) and y (n_data,)')
+        if prior_sd <= 0:
+            raise ValueError('prior_sd must be positive')
+        self.X, self.y, self.prior_sd = X, y, float(prior_sd)
+        super().__init__(X.shape[1])
+
+    def _build_spec(self):
+        return (_lib.MODEL_LOGISTIC, self._dim, np.concatenate([self.X.ravel(), self.y, [self.prior_sd]]),
+                np.array([self.X.shape[0]], dtype=np.int64))
