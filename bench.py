@@ -257,7 +257,14 @@ def main():
             out['cpu_baseline'] = cpu_baseline(theta)
         if world == 1 and not args.no_fullrank:
             out['fullrank'] = fullrank_leg(eng, vb)
-        print(json.dumps(out))
+        # RCCL prints a version banner through C stdio; push it out first so the JSON is the last line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -897,12 +897,13 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   ws.off_partials = carve((int64_t)g.n_rb * CF_NUM * g.Dp);
   ws.off_pscal = carve((int64_t)KS_NUM * g.n_rb * g.n_cb);
   ws.stride = off;
-  ws.sum_len = round_up((int64_t)SF_NUM + (int64_t)CF_NUM * g.Dp, 16);
+  ws.sum_len = round_up((int64_t)SF_NUM + (int64_t)nf * g.Dp, 16);   // only the fields in use are all-reduced
   // three rotating workspace sets: batch i+1 is prepared, and batch i-1 finalised, while batch i streams
   const int set = (int)(ctx->pipe.seq % kPipeSets);
   ctx->pipe.seq++;
   VB_TRY(ensure(ctx, ctx->workspace, (size_t)ws.stride * kMaxBatch * kPipeSets * sizeof(double)));
-  VB_TRY(ensure(ctx, ctx->sums, (size_t)ws.sum_len * kMaxBatch * kPipeSets * sizeof(double)));
+  VB_TRY(ensure(ctx, ctx->sums, (size_t)round_up((int64_t)SF_NUM + (int64_t)CF_NUM * g.Dp, 16) * kMaxBatch * kPipeSets *
+                                    sizeof(double)));
   ws.base = (double*)ctx->workspace.ptr + (size_t)set * ws.stride * kMaxBatch;
   ws.sums = (double*)ctx->sums.ptr + (size_t)set * ws.sum_len * kMaxBatch;
 
