@@ -124,7 +124,7 @@ int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p
  * lw_n = f(z_n) - log q(z_n; theta);  grad = alpha/N sum_n s_n d lw_n/d theta (s not normalised,
  * objectives.py:460).  The noise slot holds the draws of RandomState(seed) for the seed the
  * caller took from the global numpy RNG (objectives.py:455).                                  */
-int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int family, double df,
                             const double* theta, double alpha, double* value, double* grad);
 
 /* ---- DISInclusiveKL, mean-field families (objectives.py:283-416) ------------------------
@@ -135,10 +135,12 @@ int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int fam
  * bisection on the tempering parameter, and returns eps, ess and the unnormalised weights
  * w_n = exp(eps log prior + (1 - eps) log p - log q) (no max shift, :330).  log_p / log_q may be
  * NULL.  Returns VB_ERR_NUMERIC with 'All weights zero! ...' as objectives.py:326-328 does.
+ * Sharded jobs (n < n_total, n_total = n x ranks): every rank all-gathers the three per-sample vectors and
+ * runs the bisection redundantly; eps, w, log_p, log_q then cover all n_total samples on every rank.
  * Clipping (:370-386) and resampling (:408, global numpy RNG) stay with the caller, which hands
  * the per-sample weights (clipped w, or resampling counts) to
  * grad: value = -scale sum_n weights_n log q(z_n; theta), grad = d value / d theta (:405-414).  */
-int vb_dis_refresh_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+int vb_dis_refresh_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int family, double df,
                              const double* theta, const double* prior_theta, double eps_prev,
                              double ess_target, int max_bisection_its, double* eps, double* ess,
                              double* w, double* log_p, double* log_q);
@@ -156,7 +158,7 @@ int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int famil
  *   w_sum = sum w,  w_logq = sum w log q(x_n),  d_mu[D] = sum w c_n u_n,  gram[D x D] (lower triangle) =
  *   sum w c_n u_n u_n',  u_n = Sigma^-1 (x_n - mu),  c_n = (df + D)/(df + maha_n)
  * from which the caller assembles d/dtheta.                                   */
-int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
+int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q);

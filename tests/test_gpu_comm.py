@@ -104,3 +104,33 @@ def test_fullrank_comm_path(engines):
         out.append(eng.elbo_grad_fullrank(6, N, D, theta))
     assert abs(out[0][0] - out[1][0]) < 1e-13 * abs(out[0][0])
     np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-13 * np.max(np.abs(out[0][1])))
+
+
+def test_alpha_and_dis_through_comm(engines):
+    """AlphaDivergence / DISInclusiveKL with a one-rank communicator: the all-reduce(max/sum) and
+    all-gather steps of the sharded path must not change the result."""
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    plain, comm = engines
+    D, N = 96, 512
+    rng = np.random.RandomState(1)
+    model = vb.GaussianModel(rng.randn(D), np.exp(0.1 * rng.randn(D)))
+    theta = _theta(D, 7)
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    res = {}
+    for name, eng in (('plain', plain), ('comm', comm)):
+        _lib.set_default_engine(eng)
+        np.random.seed(3)
+        a = vb.AlphaDivergence(vb.MFGaussian(D), model, N, 2.0)(theta)
+        np.random.seed(3)
+        d = vb.DISInclusiveKL(vb.MFStudentT(D, 9, seed=2), model, N, ess_target=100, temper_prior=vb.MFGaussian(D),
+                              temper_prior_params=prior)(theta)
+        mvt = vb.MultivariateT(D, 30, seed=2)
+        np.random.seed(3)
+        m = vb.DISInclusiveKL(mvt, model, N, ess_target=100, temper_prior=vb.MFGaussian(D),
+                              temper_prior_params=prior)(mvt.init_param())
+        res[name] = (a, d, m)
+    _lib.set_default_engine(plain)
+    for x, y in zip(res['plain'], res['comm']):
+        assert abs(x[0] - y[0]) < 1e-12 * abs(x[0])
+        np.testing.assert_allclose(y[1], x[1], rtol=0, atol=1e-12 * np.max(np.abs(x[1])))

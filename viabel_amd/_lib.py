@@ -58,10 +58,10 @@ SIGNATURES = {
                                                           ctypes.c_int, ctypes.c_double, _c_double_p,
                                                           ctypes.c_uint, ctypes.c_int,
                                                           ctypes.POINTER(ctypes.c_int)]),
-    'vb_alpha_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+    'vb_alpha_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                ctypes.c_int, ctypes.c_double, _c_double_p, ctypes.c_double,
                                                _c_double_p, _c_double_p]),
-    'vb_dis_refresh_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+    'vb_dis_refresh_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                 ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
                                                 ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                                 _c_double_p, _c_double_p, _c_double_p, _c_double_p,
@@ -69,7 +69,8 @@ SIGNATURES = {
     'vb_dis_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
                                              ctypes.c_double, _c_double_p, _c_double_p]),
-    'vb_dis_refresh_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+    'vb_dis_refresh_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_double,
                                           _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_double_p,
                                           _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
@@ -271,22 +272,25 @@ class Engine:
         return value.value, grad
 
     # ------------------------------------------------------------------ AlphaDivergence, mean field
-    def alpha_grad_meanfield(self, slot, n, d, theta, family, alpha, df=0.0):
+    def alpha_grad_meanfield(self, slot, n, d, theta, family, alpha, df=0.0, n_total=None):
         theta = _f64(theta)
         value = ctypes.c_double(0.0)
         grad = np.empty(2 * d, dtype=np.float64)
-        self._check(self._lib.vb_alpha_grad_meanfield(self._ctx, slot, n, d, family, float(df), _dptr(theta),
+        self._check(self._lib.vb_alpha_grad_meanfield(self._ctx, slot, n, d, n if n_total is None else n_total,
+                                                      family, float(df), _dptr(theta),
                                                       float(alpha), ctypes.byref(value), _dptr(grad)))
         return value.value, grad
 
     # ------------------------------------------------------------------ DISInclusiveKL, mean field
     def dis_refresh_meanfield(self, slot, n, d, theta, prior_theta, family, eps_prev, ess_target,
-                              max_bisection_its=50, df=0.0):
+                              max_bisection_its=50, df=0.0, n_total=None):
+        """``n`` local rows; the returned weights / log p / log q cover all ``n_total`` samples."""
         theta, prior_theta = _f64(theta), _f64(prior_theta)
+        n_total = n if n_total is None else n_total
         eps, ess = ctypes.c_double(0.0), ctypes.c_double(0.0)
-        w, lp, lq = (np.empty(n, dtype=np.float64) for _ in range(3))
+        w, lp, lq = (np.empty(n_total, dtype=np.float64) for _ in range(3))
         self._check(self._lib.vb_dis_refresh_meanfield(
-            self._ctx, slot, n, d, family, float(df), _dptr(theta), _dptr(prior_theta), float(eps_prev),
+            self._ctx, slot, n, d, n_total, family, float(df), _dptr(theta), _dptr(prior_theta), float(eps_prev),
             float(ess_target), int(max_bisection_its), ctypes.byref(eps), ctypes.byref(ess), _dptr(w),
             _dptr(lp), _dptr(lq)))
         return eps.value, ess.value, w, lp, lq
@@ -302,12 +306,13 @@ class Engine:
 
     # ------------------------------------------------------------------ DISInclusiveKL, multivariate t
     def dis_refresh_mvt(self, slot, n, d, df, theta, chi, sqrt_sigma, l_inv, prior_theta, eps_prev, ess_target,
-                        max_bisection_its=50):
+                        max_bisection_its=50, n_total=None):
         theta, chi, sqrt_sigma, l_inv, prior_theta = (_f64(a) for a in (theta, chi, sqrt_sigma, l_inv, prior_theta))
+        n_total = n if n_total is None else n_total
         eps, ess = ctypes.c_double(0.0), ctypes.c_double(0.0)
-        w, lp, lq = (np.empty(n, dtype=np.float64) for _ in range(3))
+        w, lp, lq = (np.empty(n_total, dtype=np.float64) for _ in range(3))
         self._check(self._lib.vb_dis_refresh_mvt(
-            self._ctx, slot, n, d, float(df), _dptr(theta), _dptr(chi), _dptr(sqrt_sigma), _dptr(l_inv),
+            self._ctx, slot, n, d, n_total, float(df), _dptr(theta), _dptr(chi), _dptr(sqrt_sigma), _dptr(l_inv),
             _dptr(prior_theta), float(eps_prev), float(ess_target), int(max_bisection_its), ctypes.byref(eps),
             ctypes.byref(ess), _dptr(w), _dptr(lp), _dptr(lq)))
         return eps.value, ess.value, w, lp, lq

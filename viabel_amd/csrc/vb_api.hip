@@ -476,7 +476,7 @@ int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p
 }
 
 // ---- AlphaDivergence, mean field (objectives.py:443-463) -------------------------------------------
-int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int family, double df,
                             const double* theta, double alpha, double* value, double* grad) {
   if (!ctx || !theta || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_TRY(check_slot(ctx, slot));
@@ -487,7 +487,7 @@ int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int fam
   VB_HIP(ctx, hipSetDevice(ctx->device));
   ResultSlot& rs = ctx->sync_result;
   VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
-  VB_TRY(alpha_enqueue(ctx, ctx->noise[slot], n, d, family, df, alpha, rs.dev, rs.dev + rs.p));
+  VB_TRY(alpha_enqueue(ctx, ctx->noise[slot], n, n_total, d, family, df, alpha, rs.dev, rs.dev + rs.p));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rs.pending = false;
   *value = rs.host[rs.p];
@@ -496,7 +496,7 @@ int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int fam
 }
 
 // ---- DISInclusiveKL, mean field (objectives.py:283-416) ---------------------------------------------
-int vb_dis_refresh_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+int vb_dis_refresh_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int family, double df,
                              const double* theta, const double* prior_theta, double eps_prev,
                              double ess_target, int max_bisection_its, double* eps, double* ess,
                              double* w, double* log_p, double* log_q) {
@@ -510,7 +510,7 @@ int vb_dis_refresh_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int fa
   ResultSlot& rs = ctx->sync_result;
   VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
   int status = 0;
-  return dis_refresh_enqueue(ctx, ctx->noise[slot], n, d, family, df, rs.dev, prior_theta, eps_prev, ess_target,
+  return dis_refresh_enqueue(ctx, ctx->noise[slot], n, n_total, d, family, df, rs.dev, prior_theta, eps_prev, ess_target,
                              max_bisection_its, eps, ess, &status, w, log_p, log_q);
 }
 
@@ -534,7 +534,7 @@ int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int famil
 }
 
 // ---- DISInclusiveKL, MultivariateT (approximations.py:322-382, objectives.py:391-414) ----------------
-int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
+int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q) {
@@ -544,7 +544,7 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, c
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
   if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
   VB_HIP(ctx, hipSetDevice(ctx->device));
-  return mvt_dis_refresh(ctx, ctx->noise[slot], n, d, df, theta, chi, sqrt_sigma, l_inv, prior_theta, eps_prev,
+  return mvt_dis_refresh(ctx, ctx->noise[slot], n, n_total, d, df, theta, chi, sqrt_sigma, l_inv, prior_theta, eps_prev,
                          ess_target, max_bisection_its, eps, ess, w, log_p, log_q);
 }
 

@@ -17,6 +17,27 @@ int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t coun
   return VB_OK;
 }
 
+int comm_allreduce_max(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count) {
+  if (!ctx->comm) return VB_OK;
+  ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclMax, (ncclComm_t)ctx->comm, stream);
+  if (r != ncclSuccess)
+    return fail(ctx, VB_ERR_COMM, "ncclAllReduce(max) failed: %s", ncclGetErrorString(r));
+  return VB_OK;
+}
+
+// recv[r * count .. (r + 1) * count) = rank r's send[0 .. count); without a communicator: a copy
+int comm_allgather(vb_ctx* ctx, hipStream_t stream, const double* send, double* recv, size_t count) {
+  if (!ctx->comm) {
+    if (send != recv)
+      VB_HIP(ctx, hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    return VB_OK;
+  }
+  ncclResult_t r = ncclAllGather(send, recv, count, ncclDouble, (ncclComm_t)ctx->comm, stream);
+  if (r != ncclSuccess)
+    return fail(ctx, VB_ERR_COMM, "ncclAllGather failed: %s", ncclGetErrorString(r));
+  return VB_OK;
+}
+
 }  // namespace vb
 
 using namespace vb;

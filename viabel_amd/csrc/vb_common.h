@@ -104,9 +104,10 @@ struct vb_ctx {
   vb::DeviceBuffer fr_work;             // full-rank pipeline work buffers
   vb::DeviceBuffer lg_work;             // logistic-regression target: Z, R, G, partials
   vb::DeviceBuffer mvt_state;           // multivariate-t DIS: state samples X, scratch
-  int64_t mvt_n = 0, mvt_d = 0;
+  int64_t mvt_n = 0, mvt_d = 0, mvt_n_total = 0;
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
+  int64_t dis_n_total = 0;              // whole-job sample count of the DIS state
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
@@ -172,14 +173,14 @@ int pipe_init(vb_ctx* ctx);
 int rowstats_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_src,
                      const ModelDev& model, int student, double df, double* cols, double* scal,
                      double* out_f, double* out_b);
-int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
+int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, int family, double df,
                         const double* theta_src, const double* prior_host, double eps_prev, double ess_target,
                         int max_its, double* eps_out, double* ess_out, int* status_out, double* w_host,
                         double* logp_host, double* logq_host);
 int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
                      const double* theta_src, const double* w_host, double scale, double* out);
-int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df, double alpha,
-                  const double* theta_src, double* out);
+int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, int family, double df,
+                  double alpha, const double* theta_src, double* out);
 int sync_streams(vb_ctx* ctx);   // main + pipeline streams
 
 // full-rank Gaussian ExclusiveKL (vb_fullrank.hip)
@@ -205,7 +206,8 @@ int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const dou
                        double* scal_out);
 
 // multivariate-t DIS (vb_mvt.hip)
-int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, const double* theta_host,
+int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df,
+                    const double* theta_host,
                     const double* chi_host, const double* root_host, const double* linv_host,
                     const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
                     double* ess_out, double* w_host, double* logp_host, double* logq_host);
@@ -221,6 +223,8 @@ int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int
 
 // RCCL (vb_comm.hip)
 int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count);
+int comm_allreduce_max(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count);
+int comm_allgather(vb_ctx* ctx, hipStream_t stream, const double* send, double* recv, size_t count);
 
 // profiling: event pair for the next launch of the dominant kernel (nullptrs when disabled)
 void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals);

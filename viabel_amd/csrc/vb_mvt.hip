@@ -125,16 +125,17 @@ __global__ void __launch_bounds__(256) mvt_scalar_kernel(const double* __restric
 // ---- state layout ----------------------------------------------------------------------------------------
 struct MvtLayout {
   int64_t ld, nn;
-  int64_t o_x, o_e, o_u, o_ua, o_root, o_wt, o_li, o_mu, o_c, o_invs, o_maha, o_lq, o_lp, o_lprior, o_w,
+  int64_t o_x, o_e, o_u, o_ua, o_root, o_wt, o_li, o_mu, o_c, o_invs, o_maha, o_lq, o_lp, o_lprior, o_w, o_lqcopy,
       o_prior, o_scal, o_cpart, o_col, o_part, o_sums, total;
   int splits, n_rb;
   FrSums S;
 };
 
-static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t d) {
+// n: local rows; n_total: whole-job rows (the gathered per-sample vectors log p / log q / log prior / w)
+static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t d) {
   MvtLayout L;
   L.ld = round_up(d, 16);
-  L.nn = round_up(n, 16);
+  L.nn = round_up(n_total, 16);
   L.splits = gram_splits(ctx, (int)d, n);
   L.n_rb = (int)((n + 127) / 128);
   int64_t off = 0;
@@ -159,6 +160,7 @@ static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t d) {
   L.o_lp = carve(L.nn);
   L.o_lprior = carve(L.nn);
   L.o_w = carve(L.nn);
+  L.o_lqcopy = carve(L.nn);
   L.o_prior = carve(2 * L.ld);
   L.o_scal = carve(32);
   L.o_cpart = carve((int64_t)L.splits * sq);
@@ -184,7 +186,7 @@ static int upload_padded(vb_ctx* ctx, double* dst, int64_t ld, const double* src
 
 // E' = (X - mu) L^-T, maha, log q for the parameter `theta_host` with inverse factor `linv_host`
 static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t n, int64_t d, double df,
-                         const double* theta_host, const double* linv_host) {
+                         const double* theta_host, const double* linv_host, int64_t lq_off) {
   const int n_cu = ctx->prop.multiProcessorCount;
   // Wt[k][j] = Linv[j][k] (B operand of dev L^-T), Li[k][j] = Linv[k][j] (B operand of E' L^-1)
   VB_TRY(upload_padded(ctx, base + L.o_wt, L.ld, linv_host, d, d, true));
@@ -214,26 +216,30 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
   VB_HIP(ctx, hipGetLastError());
   const double lq_const = lgamma(0.5 * (df + d)) - lgamma(0.5 * df) - 0.5 * d * log(M_PI * df) - logdet_half;
   hipLaunchKernelGGL(mvt_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
-                     (const double*)(base + L.o_e), L.ld, n, (int)d, df, lq_const, base + L.o_maha, base + L.o_lq);
+                     (const double*)(base + L.o_e), L.ld, n, (int)d, df, lq_const, base + L.o_maha,
+                     base + L.o_lq + lq_off);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
 
-int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, const double* theta_host,
+int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df,
+                    const double* theta_host,
                     const double* chi_host, const double* root_host, const double* linv_host,
                     const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
                     double* ess_out, double* w_host, double* logp_host, double* logq_host) {
-  if (ctx->comm) return fail(ctx, VB_ERR_UNSUPPORTED, "DISInclusiveKL is not sharded across GPUs yet");
+  if (n * (int64_t)ctx->n_ranks != n_total)
+    return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
     return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density implements gauss_diag and funnel");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
-  const MvtLayout L = mvt_layout(ctx, n, d);
+  const MvtLayout L = mvt_layout(ctx, n, n_total, d);
   VB_TRY(ensure(ctx, ctx->mvt_state, (size_t)L.total * sizeof(double)));
   double* base = (double*)ctx->mvt_state.ptr;
   hipStream_t st = ctx->stream;
   const int n_cu = ctx->prop.multiProcessorCount;
+  const int64_t mine = (int64_t)ctx->rank * n;   // this rank's block inside the gathered vectors
 
   VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
   std::vector<double> inv_s((size_t)n);
@@ -265,8 +271,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, doub
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiSampleT{base + L.o_x, L.ld, base + L.o_mu, base + L.o_invs});
   VB_HIP(ctx, hipGetLastError());
 
-  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host));
-  VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp));
+  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine));
+  VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine));
   {   // tempering prior: a diagonal Gaussian evaluated by the same row kernel
     const ModelDev saved = ctx->model;
     ModelDev prior;
@@ -276,26 +282,31 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, doub
     prior.p0 = base + L.o_prior;
     prior.p1 = base + L.o_prior + L.ld;
     ctx->model = prior;
-    const int rc = model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lprior);
+    const int rc = model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lprior + mine);
     ctx->model = saved;
     VB_TRY(rc);
   }
+  if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
+    VB_TRY(comm_allgather(ctx, st, base + L.o_lp + mine, base + L.o_lp, (size_t)n));
+    VB_TRY(comm_allgather(ctx, st, base + L.o_lq + mine, base + L.o_lq, (size_t)n));
+    VB_TRY(comm_allgather(ctx, st, base + L.o_lprior + mine, base + L.o_lprior, (size_t)n));
+  }
   VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is
-  VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_lq, base + L.o_lprior, base + L.o_scal, n, eps_prev,
-                            ess_target, max_its, base + L.o_w, base + L.o_maha /*scratch copy of lq*/,
-                            base + L.o_scal + 8));
+  VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_lq, base + L.o_lprior, base + L.o_scal, n_total, eps_prev,
+                            ess_target, max_its, base + L.o_w, base + L.o_lqcopy, base + L.o_scal + 8));
   double res[3];
   VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_scal + 8, sizeof res, hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
   if (logp_host)
-    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
   if (logq_host)
-    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lq, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lq, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
   *eps_out = res[0];
   *ess_out = res[1];
   ctx->mvt_n = n;
   ctx->mvt_d = d;
+  ctx->mvt_n_total = n_total;
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   return VB_OK;
@@ -306,13 +317,13 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
                  const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out) {
   if (ctx->mvt_n != n || ctx->mvt_d != d || !ctx->mvt_state.ptr)
     return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state of shape %lld x %lld", (long long)n, (long long)d);
-  const MvtLayout L = mvt_layout(ctx, n, d);
+  const MvtLayout L = mvt_layout(ctx, n, ctx->mvt_n_total, d);
   double* base = (double*)ctx->mvt_state.ptr;
   hipStream_t st = ctx->stream;
   const int n_cu = ctx->prop.multiProcessorCount;
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
-  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host));
+  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, 0));
   // U = E' L^-1
   GemmArgs g;
   g.A = base + L.o_e;
@@ -330,20 +341,22 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
                      base + L.o_ua, L.ld, n, (int)d, df, (const double*)(base + L.o_w),
                      (const double*)(base + L.o_maha), (const double*)(base + L.o_lq), base + L.o_part);
   VB_HIP(ctx, hipGetLastError());
+  FrSums S = L.S;
+  S.sums = base + L.o_sums;
+  // (sum w, sum w log q) ride in slots 1 and 2 of the sum vector so that one all-reduce covers everything
   hipLaunchKernelGGL(mvt_scalar_kernel, dim3(1), dim3(256), 0, st, (const double*)(base + L.o_part), n_part,
-                     base + L.o_scal + 16);
+                     S.sums + 1);
   VB_HIP(ctx, hipGetLastError());
   double* fpart = base + L.o_part + 2 * n_part;
   VB_TRY(fr_colsum_enqueue(ctx, base + L.o_ua, nullptr, L.ld, n, (int)d, 0, nullptr, base + L.o_col, fpart));
   const int64_t slab = d * L.ld;
   VB_TRY(gram_lower_enqueue(ctx, base + L.o_ua, base + L.o_u, L.ld, (int)d, n, L.splits, base + L.o_cpart, L.ld,
                             slab));
-  FrSums S = L.S;
-  S.sums = base + L.o_sums;
   VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col, L.n_rb, L.ld, fpart,
                            L.n_rb * (int)((d + 63) / 64), S));
+  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
   double sc[2];
-  VB_HIP(ctx, hipMemcpyAsync(sc, base + L.o_scal + 16, sizeof sc, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(sc, S.sums + 1, sizeof sc, hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpyAsync(dmu_out, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpy2DAsync(gram_out, (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)L.ld * sizeof(double),
                                (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));

@@ -108,13 +108,11 @@ __global__ void __launch_bounds__(256) rs_rowstats_kernel(const double* __restri
 }
 
 // objectives.py:453-459: lw = f - log q, log_norm = max lw, s = exp(lw - log_norm)^alpha,
-// value = log(mean s)/alpha + log_norm.  log q(z_n) = b_n - sum(log_sigma).
-// One workgroup of 1024 threads; writes the per-row weights s_n and scal_out = [value, sum s].
-__global__ void __launch_bounds__(1024) alpha_weights_kernel(const double* __restrict__ f,
-                                                             const double* __restrict__ b,
-                                                             const double* __restrict__ scal_in, int64_t n,
-                                                             double alpha, double* __restrict__ roww,
-                                                             double* __restrict__ scal_out) {
+// value = log(mean s)/alpha + log_norm.  log q(z_n) = b_n - sum(log_sigma).  Three small one-workgroup
+// kernels so that a sharded job can all-reduce the max and the sum in between.
+__global__ void __launch_bounds__(1024) alpha_max_kernel(const double* __restrict__ f, const double* __restrict__ b,
+                                                         const double* __restrict__ scal_in, int64_t n,
+                                                         double* __restrict__ mx_out) {
   __shared__ double sh[16];
   const double sum_ls = scal_in[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -123,9 +121,22 @@ __global__ void __launch_bounds__(1024) alpha_weights_kernel(const double* __res
   mx = rs_wave_max(mx);
   if (lane == 0) sh[wave] = mx;
   __syncthreads();
-  mx = sh[0];
-  for (int w = 1; w < 16; ++w) mx = fmax(mx, sh[w]);
-  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = sh[0];
+    for (int w = 1; w < 16; ++w) mx = fmax(mx, sh[w]);
+    mx_out[0] = mx;
+  }
+}
+
+__global__ void __launch_bounds__(1024) alpha_weights_kernel(const double* __restrict__ f,
+                                                             const double* __restrict__ b,
+                                                             const double* __restrict__ scal_in,
+                                                             const double* __restrict__ mx_in, int64_t n,
+                                                             double alpha, double* __restrict__ roww,
+                                                             double* __restrict__ sum_out) {
+  __shared__ double sh[16];
+  const double sum_ls = scal_in[0], mx = mx_in[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double s = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += 1024) {
     const double sv = exp(alpha * (f[i] - b[i] + sum_ls - mx));
@@ -138,9 +149,13 @@ __global__ void __launch_bounds__(1024) alpha_weights_kernel(const double* __res
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int w = 0; w < 16; ++w) tot += sh[w];
-    scal_out[0] = log(tot / (double)n) / alpha + mx;
-    scal_out[1] = tot;
+    sum_out[0] = tot;
   }
+}
+
+__global__ void alpha_value_kernel(const double* mx, const double* sum_s, double n_total, double alpha,
+                                   double* value) {
+  value[0] = log(sum_s[0] / n_total) / alpha + mx[0];
 }
 
 // ---- host ---------------------------------------------------------------------------------------------
@@ -156,26 +171,34 @@ int rowstats_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, con
   return VB_OK;
 }
 
-// AlphaDivergence value and gradient for the mean-field families (objectives.py:453-461).
-int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df, double alpha,
-                  const double* theta_src, double* out) {
-  if (ctx->comm)
-    return fail(ctx, VB_ERR_UNSUPPORTED, "AlphaDivergence is not sharded across GPUs yet (global max needed)");
+// AlphaDivergence value and gradient for the mean-field families (objectives.py:453-461).  `n` rows are
+// local; with a communicator the max and the sum of the weights are all-reduced (n_total = global N).
+int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, int family, double df,
+                  double alpha, const double* theta_src, double* out) {
   if (!(alpha != 0.0)) return fail(ctx, VB_ERR_INVALID, "alpha must be non-zero");
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
     return fail(ctx, VB_ERR_UNSUPPORTED, "mean-field path supports the gauss_diag and funnel models");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
-  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  if (n <= 0 || n > ns.n || d != ns.d || n_total < n) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   const int student = family == VB_FAMILY_MF_STUDENT_T;
-  // scratch: [cols 2 ld | scal 16 | f n | b n | roww n]
+  hipStream_t st = ctx->stream;
+  // scratch: [cols 2 ld | scal 16 | f n | b n | roww n];  scal: [0] sum log sigma, [8] max, [9] sum s, [10] value
   const int64_t o_scal = 2 * ns.ld, o_f = o_scal + 16, o_b = o_f + round_up(n, 16), o_w = o_b + round_up(n, 16);
   VB_TRY(ensure(ctx, ctx->rowvec, (size_t)(o_w + round_up(n, 16)) * sizeof(double)));
   double* base = (double*)ctx->rowvec.ptr;
-  VB_TRY(rowstats_enqueue(ctx, ns, n, d, theta_src, ctx->model, student, df, base, base + o_scal, base + o_f,
-                          base + o_b));
-  hipLaunchKernelGGL(alpha_weights_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const double*)(base + o_f),
-                     (const double*)(base + o_b), (const double*)(base + o_scal), n, alpha, base + o_w,
-                     base + o_scal + 8);
+  double* scal = base + o_scal;
+  VB_TRY(rowstats_enqueue(ctx, ns, n, d, theta_src, ctx->model, student, df, base, scal, base + o_f, base + o_b));
+  hipLaunchKernelGGL(alpha_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + o_f),
+                     (const double*)(base + o_b), (const double*)scal, n, scal + 8);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(comm_allreduce_max(ctx, st, scal + 8, 1));
+  hipLaunchKernelGGL(alpha_weights_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + o_f),
+                     (const double*)(base + o_b), (const double*)scal, (const double*)(scal + 8), n, alpha,
+                     base + o_w, scal + 9);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(comm_allreduce_sum(ctx, st, scal + 9, 1));
+  hipLaunchKernelGGL(alpha_value_kernel, dim3(1), dim3(1), 0, st, (const double*)(scal + 8),
+                     (const double*)(scal + 9), (double)n_total, alpha, scal + 10);
   VB_HIP(ctx, hipGetLastError());
   MfCall c;
   c.count = 1;
@@ -185,12 +208,12 @@ int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int fa
   c.roww[0] = base + o_w;
   c.n = n;
   c.d = d;
-  c.n_total = n;
+  c.n_total = n_total;
   c.family = family;
   c.df = df;
   c.mode = 1;
-  c.scale = alpha / (double)n;                // objectives.py:460: alpha * vjp / N
-  c.value_src = base + o_scal + 8;
+  c.scale = alpha / (double)n_total;          // objectives.py:460: alpha * vjp / N
+  c.value_src = scal + 10;
   return mf_enqueue(ctx, c);
 }
 
@@ -296,21 +319,25 @@ static DisLayout dis_layout(int64_t n, int64_t ld) {
   return L;
 }
 
-int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
+int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, int family, double df,
                         const double* theta_src, const double* prior_host, double eps_prev, double ess_target,
                         int max_its, double* eps_out, double* ess_out, int* status_out, double* w_host,
                         double* logp_host, double* logq_host) {
-  if (ctx->comm) return fail(ctx, VB_ERR_UNSUPPORTED, "DISInclusiveKL is not sharded across GPUs yet");
+  if (n * (int64_t)ctx->n_ranks != n_total)
+    return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
     return fail(ctx, VB_ERR_UNSUPPORTED, "mean-field path supports the gauss_diag and funnel models");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   const int student = family == VB_FAMILY_MF_STUDENT_T;
   const int64_t ld = ns.ld;
-  const DisLayout L = dis_layout(n, ld);
+  // per-sample vectors are sized for the WHOLE job: every rank gathers all log p / log q / log prior and
+  // runs the (cheap, O(N)) bisection redundantly, so all ranks agree on eps and the weights
+  const DisLayout L = dis_layout(n_total, ld);
   VB_TRY(ensure(ctx, ctx->dis_state, (size_t)L.total * sizeof(double)));
   double* base = (double*)ctx->dis_state.ptr;
   hipStream_t st = ctx->stream;
+  const int64_t mine = (int64_t)ctx->rank * n;   // this rank's block inside the gathered vectors
 
   // tempering prior: a diagonal Gaussian given as an MFGaussian parameter [mu | log_sigma]
   std::vector<double> pr((size_t)2 * ld, 0.0);
@@ -330,29 +357,35 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   prior.p1 = base + L.o_prior + ld;
 
   VB_TRY(rowstats_enqueue(ctx, ns, n, d, theta_src, ctx->model, student, df, base + L.o_cols, base + L.o_scal,
-                          base + L.o_lp, base + L.o_b));
+                          base + L.o_lp + mine, base + L.o_b + mine));
   // second pass: log prior(z_n); its base sums land in the (later overwritten) lq area
   hipLaunchKernelGGL(rs_rowstats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
                      (const double*)ns.buf.ptr, ld, n, (int)d, (const double*)(base + L.o_cols), prior, student,
-                     df, base + L.o_lprior, base + L.o_lq);
+                     df, base + L.o_lprior + mine, base + L.o_lq);
   VB_HIP(ctx, hipGetLastError());
+  if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
+    VB_TRY(comm_allgather(ctx, st, base + L.o_lp + mine, base + L.o_lp, (size_t)n));
+    VB_TRY(comm_allgather(ctx, st, base + L.o_b + mine, base + L.o_b, (size_t)n));
+    VB_TRY(comm_allgather(ctx, st, base + L.o_lprior + mine, base + L.o_lprior, (size_t)n));
+  }
   hipLaunchKernelGGL(dis_bisect_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_lp),
                      (const double*)(base + L.o_b), (const double*)(base + L.o_lprior),
-                     (const double*)(base + L.o_scal), n, eps_prev, ess_target, max_its, 1.0, base + L.o_w,
+                     (const double*)(base + L.o_scal), n_total, eps_prev, ess_target, max_its, 1.0, base + L.o_w,
                      base + L.o_lq, base + L.o_out);
   VB_HIP(ctx, hipGetLastError());
   double res[3];
   VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_out, sizeof res, hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
   if (logp_host)
-    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
   if (logq_host)
-    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lq, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lq, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
   *eps_out = res[0];
   *ess_out = res[1];
   *status_out = (int)res[2];
   ctx->dis_n = n;
+  ctx->dis_n_total = n_total;
   ctx->dis_d = d;
   if (*status_out == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
@@ -365,7 +398,7 @@ int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int
     return fail(ctx, VB_ERR_STATE, "no DIS state of shape %lld x %lld (vb_dis_refresh_meanfield first)",
                 (long long)n, (long long)d);
   if (n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
-  const DisLayout L = dis_layout(n, ns.ld);
+  const DisLayout L = dis_layout(ctx->dis_n_total, ns.ld);
   double* base = (double*)ctx->dis_state.ptr;
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller keeps ownership of w_host

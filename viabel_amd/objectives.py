@@ -243,18 +243,19 @@ class DISInclusiveKL(StochasticVariationalObjective):
             if var_param.shape != (approx.var_param_dim,):
                 raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
             eng = self._engine()
-            if eng.n_ranks > 1:
-                raise NotImplementedError('DISInclusiveKL is not sharded across GPUs yet')
             eng.set_model(self.model.device_spec())
             family, df = approx._device_family()
             N = self.num_mc_samples
+            begin, end = shard_rows(N, eng.n_ranks, eng.rank)     # this rank's block of the samples
+            n_local = end - begin
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
                 # state refresh (objectives.py:393-401): new samples (kept as noise on the device),
-                # log q, log p, tempering bisection, clipping
+                # log q, log p, tempering bisection, clipping.  Sharded jobs gather the per-sample
+                # vectors, so eps and the weights cover all N samples on every rank.
                 self._stage_noise(eng, N, slot=slot)
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_meanfield(
-                    slot, N, approx.dim, var_param, self._temper_prior_params, family, self._eps,
-                    self._ess_target, self._max_bisection_its, df=df)
+                    slot, n_local, approx.dim, var_param, self._temper_prior_params, family, self._eps,
+                    self._ess_target, self._max_bisection_its, df=df, n_total=N)
                 self._state_log_p_unnormalized = log_p
                 self._state_log_q = log_q
                 self._state_w_clipped = self._clip_weights(w)
@@ -262,13 +263,14 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 self._state_w_normalized = self._state_w_clipped / self._state_w_sum
             self._objective_step += 1
             if not self._use_resampling:     # :405-406
-                return eng.dis_grad_meanfield(slot, N, approx.dim, var_param, self._state_w_clipped, 1.0 / N,
-                                              family, df=df)
-            indices = np.random.choice(N, size=self._resampling_batch_size,
-                                       p=self._state_w_normalized)          # global RNG, :408
+                return eng.dis_grad_meanfield(slot, n_local, approx.dim, var_param,
+                                              self._state_w_clipped[begin:end], 1.0 / N, family, df=df)
+            # global numpy RNG (:408): ranks of a sharded job must seed it identically
+            indices = np.random.choice(N, size=self._resampling_batch_size, p=self._state_w_normalized)
             counts = np.bincount(indices, minlength=N).astype(np.float64)
             scale = self._state_w_sum / N / self._resampling_batch_size       # :412-414
-            return eng.dis_grad_meanfield(slot, N, approx.dim, var_param, counts, scale, family, df=df)
+            return eng.dis_grad_meanfield(slot, n_local, approx.dim, var_param, counts[begin:end], scale,
+                                          family, df=df)
 
         self._objective_and_grad = variational_objective
 
@@ -289,18 +291,18 @@ class DISInclusiveKL(StochasticVariationalObjective):
             if var_param.shape != (approx.var_param_dim,):
                 raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
             eng = self._engine()
-            if eng.n_ranks > 1:
-                raise NotImplementedError('DISInclusiveKL is not sharded across GPUs yet')
             eng.set_model(self.model.device_spec())
             N = self.num_mc_samples
+            begin, end = shard_rows(N, eng.n_ranks, eng.rank)
+            n_local = end - begin
             L, Linv = factors(var_param)
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
                 chi, z = approx._base_noise(N)                 # chi-square draws first (approximations.py:345-347)
-                eng.noise_set_host(slot, z)
+                eng.noise_set_host(slot, z[begin:end])
                 root = sla.sqrtm(L @ L.T).real                  # symmetric square root, :348
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
-                    slot, N, D, df, var_param, chi, root, Linv, self._temper_prior_params, self._eps,
-                    self._ess_target, self._max_bisection_its)
+                    slot, n_local, D, df, var_param, chi[begin:end], root, Linv, self._temper_prior_params,
+                    self._eps, self._ess_target, self._max_bisection_its, n_total=N)
                 self._state_log_p_unnormalized = log_p
                 self._state_log_q = log_q
                 self._state_w_clipped = self._clip_weights(w)
@@ -313,7 +315,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 indices = np.random.choice(N, size=self._resampling_batch_size, p=self._state_w_normalized)
                 weights = np.bincount(indices, minlength=N).astype(np.float64)
                 scale = self._state_w_sum / N / self._resampling_batch_size
-            w_sum, w_logq, d_mu, gram = eng.dis_grad_mvt(N, D, df, var_param, Linv, weights)
+            w_sum, w_logq, d_mu, gram = eng.dis_grad_mvt(n_local, D, df, var_param, Linv, weights[begin:end])
             # chain rule to the free Cholesky parameters
             S = np.tril(gram) + np.tril(gram, -1).T
             d_sigma = -0.5 * w_sum * (Linv.T @ Linv) + 0.5 * S
@@ -352,11 +354,10 @@ class AlphaDivergence(StochasticVariationalObjective):
             # samples from a fresh RandomState(seed) (approximations.py:213)
             seed = np.random.randint(2 ** 32)
             eng = self._engine()
-            if eng.n_ranks > 1:
-                raise NotImplementedError('AlphaDivergence is not sharded across GPUs yet')
             eng.set_model(self.model.device_spec())
-            n_local, _ = self._stage_noise(eng, self.num_mc_samples, seed=seed)
+            n_local, n_total = self._stage_noise(eng, self.num_mc_samples, seed=seed)
             family, df = approx._device_family()
-            return eng.alpha_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, var_param, family, alpha, df=df)
+            return eng.alpha_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, var_param, family, alpha, df=df,
+                                            n_total=n_total)
 
         self._objective_and_grad = objective_grad_and_log_norm
