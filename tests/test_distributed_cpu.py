@@ -57,6 +57,50 @@ def _worker(rank, world, port, out):
         dist.all_gather(gathered, torch.from_numpy(partial.copy()))
         np.testing.assert_allclose(distributed.combine_partial_sums([x.numpy() for x in gathered]), s,
                                    rtol=1e-15)
+
+        # 4. AlphaDivergence exchange (vb_rowstats.hip alpha_enqueue): all-reduce(max) of the log
+        #    weights, then all-reduce(sum) of [sum s, sum s g, sum s (g e sigma + 1)]
+        N2 = 64
+        noise2 = np.random.RandomState(2).randn(N2, D)
+        alpha = 2.0
+        b, e = shard_rows(N2, world, rank)
+        z = mu + sig * noise2[b:e]
+        lw = model.logp(z) - fam.log_density(theta, z)
+        mx = torch.tensor([lw.max()])
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sv = np.exp(lw - mx.item()) ** alpha
+        g = model.grad(z)
+        part = np.concatenate([[sv.sum()], (sv[:, None] * g).sum(0),
+                               (sv[:, None] * (g * noise2[b:e] * sig + 1.0)).sum(0)])
+        t = torch.from_numpy(part)
+        dist.all_reduce(t)
+        s = t.numpy()
+        value = np.log(s[0] / N2) / alpha + mx.item()
+        grad = alpha * s[1:] / N2
+        ov, og = oobj.alpha_divergence(fam, model, theta, noise2, alpha)
+        assert abs(value - ov) < 1e-12 * abs(ov)
+        np.testing.assert_allclose(grad, og, rtol=0, atol=1e-12 * np.max(np.abs(og)))
+
+        # 5. DISInclusiveKL exchange (dis_refresh_enqueue): all-gather of the per-sample log p /
+        #    log q / log prior, every rank runs the same bisection over all N, then the weighted
+        #    score sums of the local block are all-reduced
+        tfam = ofam.MFGaussian(D)
+        prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
+        ref = oobj.DISInclusiveKL(fam, model, N2, 20, tfam, prior, use_resampling=False)
+        ov, og = ref(theta, noise2)
+        mine = oobj.DISInclusiveKL(fam, model, N2, 20, tfam, prior, use_resampling=False)
+        vecs = np.stack([model.logp(z), fam.log_density(theta, z), tfam.log_density(prior, z)])
+        gathered = [torch.zeros(3, e - b, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(vecs))
+        allv = np.concatenate([x.numpy() for x in gathered], axis=1)
+        _, _, w = mine._eps_and_weights(mine._eps, allv[2], allv[0], allv[1])
+        wc = mine._clip(w)
+        t = torch.from_numpy(np.concatenate([
+            fam.log_density_grad_weighted(theta, z, wc[b:e]), [np.dot(wc[b:e], vecs[1])]]))
+        dist.all_reduce(t)
+        s = t.numpy()
+        np.testing.assert_allclose(-s[:-1] / N2, og, rtol=0, atol=1e-12 * np.max(np.abs(og)))
+        assert abs(-s[-1] / N2 - ov) < 1e-12 * max(1.0, abs(ov))
         out[rank] = 1
     finally:
         dist.destroy_process_group()
