@@ -1,0 +1,240 @@
+// Dev tool: times the fp64 MFMA GEMM building block (viabel_amd/csrc/vb_gemm_f64.h) by itself and
+// measures the effective shader clock while it runs (clock64 = shader cycles, wall_clock64 = 100 MHz).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iviabel_amd/csrc tools/gemm_bench.hip -o tools/gemm_bench.bin
+// Run:   tools/gemm_bench.bin [M N K]
+#include "vb_gemm_f64.h"
+
+#include <cstdlib>
+
+using namespace vb;
+
+struct EpiStore {
+  double* C;
+  int64_t ldc;
+  __device__ void operator()(int, int row, int col, double acc) const { C[(int64_t)row * ldc + col] = acc; }
+};
+
+struct EpiSlab {
+  double* C;
+  int64_t ldc, slab;
+  __device__ void operator()(int split, int row, int col, double acc) const {
+    C[split * slab + (int64_t)row * ldc + col] = acc;
+  }
+};
+
+__global__ void clock_probe(long long* out, int iters) {
+  double acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = 0;
+  double a = threadIdx.x * 1e-3, b = blockIdx.x * 1e-3 + 1.0;
+  const long long c0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  double s = 0;
+  for (int i = 0; i < 16; ++i) s += acc[i];
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = w1 - w0;
+  }
+  if (s == 12345.678) out[0] = 0;
+}
+
+// Build-up probes: the GEMM's inner loop with its parts switched on one at a time.
+//   LEVEL 0: 64 MFMAs per k-step on register operands (4 A x 16 B fragments, as the 128 x 128 tile loop)
+//   LEVEL 1: + the 20 ds_read_b64 fragment loads per k-step (no barriers, LDS content constant)
+//   LEVEL 2: + one __syncthreads per 4 k-steps
+//   LEVEL 3: + the ds_write of a staged slab (register -> LDS) per 4 k-steps
+template <int LEVEL, int AF, int NB>
+__global__ void __launch_bounds__(256, 2) loop_probe(long long* out, double* sink, int slabs) {
+  __shared__ double As[2][16][32 * AF + 16];
+  __shared__ double Bs[2][16][8 * NB + 16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  for (int i = t; i < 2 * 16 * (32 * AF + 16); i += 256) (&As[0][0][0])[i] = 1e-3 * i;
+  for (int i = t; i < 2 * 16 * (8 * NB + 16); i += 256) (&Bs[0][0][0])[i] = 1e-3 * i + 1;
+  __syncthreads();
+  const int fi = lane & 15, fk = lane >> 4, fblk = (lane >> 2) & 3, fj = lane & 3;
+  double acc[AF][NB];
+  for (int a = 0; a < AF; ++a)
+    for (int r = 0; r < NB; ++r) acc[a][r] = 0;
+  double af[AF], bf[NB];
+  for (int a = 0; a < AF; ++a) af[a] = 1e-3 * (t + a);
+  for (int r = 0; r < NB; ++r) bf[r] = 1e-3 * (t - r);
+  d2v stage[6];
+  for (int i = 0; i < 6; ++i) stage[i] = (d2v){1e-3 * t, 2e-3 * i};
+  const long long c0 = clock64(), w0 = wall_clock64();
+  int buf = 0;
+  for (int s = 0; s < slabs; ++s) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (LEVEL >= 1) {
+#pragma unroll
+        for (int a = 0; a < AF; ++a) af[a] = As[buf][4 * kk + fk][wm * (16 * AF) + a * 16 + fi];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) bf[r] = Bs[buf][4 * kk + fk][wn * (4 * NB) + 4 * ((fblk + r) & (NB - 1)) + fj];
+      }
+#pragma unroll
+      for (int a = 0; a < AF; ++a)
+#pragma unroll
+        for (int r = 0; r < NB; ++r) acc[a][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[r], acc[a][r], 0, 0, 0);
+    }
+    if (LEVEL >= 3) {
+#pragma unroll
+      for (int i = 0; i < (AF + NB / 4); ++i) {
+        const int p = i * 256 + t;
+        if (i < NB / 4) *reinterpret_cast<d2v*>(&Bs[buf ^ 1][p / (4 * NB)][(p % (4 * NB)) * 2]) = stage[i];
+        else *reinterpret_cast<d2v*>(&As[buf ^ 1][(p - NB / 4 * 256) / (16 * AF)][((p - NB / 4 * 256) % (16 * AF)) * 2]) = stage[i];
+      }
+    }
+    if (LEVEL >= 2) {
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  const long long c1 = clock64(), w1 = wall_clock64();
+  double sum = 0;
+  for (int a = 0; a < AF; ++a)
+    for (int r = 0; r < NB; ++r) sum += acc[a][r];
+  sink[blockIdx.x * 256 + t] = sum;
+  if (t == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = w1 - w0;
+  }
+}
+
+template <int LEVEL, int AF, int NB>
+static void run_loop_probe(hipStream_t st, int n_cu, long long* d, double* sink) {
+  for (int wg = 1; wg <= 2; ++wg) {
+    const int slabs = 2000;
+    hipLaunchKernelGGL((loop_probe<LEVEL, AF, NB>), dim3(n_cu * wg), dim3(256), 0, st, d, sink, slabs);
+    hipDeviceSynchronize();
+    std::vector<long long> o(n_cu * wg * 2);
+    hipMemcpy(o.data(), d, o.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    double cyc = 0, wall = 0;
+    for (int i = 0; i < n_cu * wg; ++i) cyc += o[2 * i], wall += o[2 * i + 1];
+    cyc /= n_cu * wg, wall /= n_cu * wg;
+    const double us = wall / 100.0, mf = 4.0 * AF * NB * slabs;
+    printf("loop_probe level %d tile %dx%d wg/cu=%d: %.0f MHz, %.2f cycles per MFMA per SIMD, %.1f TFLOP/s\n", LEVEL, 32 * AF,
+           8 * NB, wg, cyc / us, cyc / mf / wg, 512.0 * mf * 4 * n_cu * wg / us / 1e6);
+  }
+}
+
+template <class F>
+static float time_it(F&& f, int reps) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) f();
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) f();
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 1024;
+  hipDeviceProp_t p;
+  hipGetDeviceProperties(&p, 0);
+  const int n_cu = p.multiProcessorCount;
+  printf("device %s, %d CUs, clock %d kHz\n", p.name, n_cu, p.clockRate);
+  const size_t big = (size_t)4096 * 4096;
+  double *A, *B, *C;
+  hipMalloc(&A, big * 8);
+  hipMalloc(&B, big * 8);
+  hipMalloc(&C, big * 8 * 2);
+  std::vector<double> h(big);
+  for (size_t i = 0; i < big; ++i) h[i] = (double)((i * 2654435761u) % 1000) * 1e-3 - 0.5;
+  hipMemcpy(A, h.data(), big * 8, hipMemcpyHostToDevice);
+  hipMemcpy(B, h.data(), big * 8, hipMemcpyHostToDevice);
+  hipStream_t st;
+  hipStreamCreate(&st);
+
+  if (argc > 4) {   // profiling mode: only the dense GEMM in tile configuration argv[4]
+    const int cfg = atoi(argv[4]);
+    if (argc > 5) {   // data pattern: 'z' all zero, 'o' all ones
+      const double v = argv[5][0] == 'z' ? 0.0 : 1.0;
+      for (size_t i = 0; i < big; ++i) h[i] = v;
+      hipMemcpy(A, h.data(), big * 8, hipMemcpyHostToDevice);
+      hipMemcpy(B, h.data(), big * 8, hipMemcpyHostToDevice);
+    }
+    GemmArgs g;
+    g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = 0;
+    float ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg); }, 20);
+    printf("cfg %d dense  A[m][k]  M=%d N=%d K=%d: %.1f us  %.2f TFLOP/s\n", cfg, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+#ifdef VB_GEMM_CLOCK
+    {
+      std::vector<long long> o(2 * 4096);
+      hipMemcpyFromSymbol(o.data(), HIP_SYMBOL(vb_gemm_dbg), o.size() * sizeof(long long));
+      const int nb = (M / (cfg == 3 ? 64 : 128)) * (N / (cfg == 1 ? 128 : 64));
+      double cyc = 0, wall = 0, wmax = 0;
+      for (int i = 0; i < nb; ++i) cyc += o[2 * i], wall += o[2 * i + 1], wmax = wmax > o[2 * i + 1] ? wmax : o[2 * i + 1];
+      cyc /= nb, wall /= nb;
+      printf("   main loop per workgroup: %.0f shader cycles in %.1f us (max %.1f us) -> %.0f MHz; %.1f cycles per slab\n", cyc, wall / 100.0,
+             wmax / 100.0, cyc / (wall / 100.0), cyc / (K / 16));
+    }
+#endif
+    return 0;
+  }
+  {  // effective clock under pure MFMA load
+    long long* d;
+    hipMalloc(&d, n_cu * 8 * 2 * sizeof(long long));
+    for (int wg = 1; wg <= 4; ++wg) {
+      for (int iters : {20000}) {
+        hipLaunchKernelGGL(clock_probe, dim3(n_cu * wg), dim3(256), 0, st, d, iters);
+        hipDeviceSynchronize();
+        std::vector<long long> o(n_cu * wg * 2);
+        hipMemcpy(o.data(), d, o.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        double cyc = 0, wall = 0;
+        for (int i = 0; i < n_cu * wg; ++i) cyc += o[2 * i], wall += o[2 * i + 1];
+        cyc /= n_cu * wg, wall /= n_cu * wg;
+        const double us = wall / 100.0;
+        printf("clock_probe wg/cu=%d iters=%d: %.0f shader cycles in %.1f us -> %.0f MHz; %.2f cycles per MFMA; %.1f TFLOP/s\n",
+               wg, iters, cyc, us, cyc / us, cyc / (16.0 * iters) / wg, 512.0 * 16 * iters * 4 * n_cu * wg / us / 1e6);
+      }
+    }
+  }
+
+  {
+    long long* d;
+    hipMalloc(&d, n_cu * 8 * 2 * sizeof(long long));
+    run_loop_probe<0, 4, 16>(st, n_cu, d, C);
+    run_loop_probe<1, 4, 16>(st, n_cu, d, C);
+    run_loop_probe<2, 4, 16>(st, n_cu, d, C);
+    run_loop_probe<3, 4, 16>(st, n_cu, d, C);
+    run_loop_probe<0, 4, 8>(st, n_cu, d, C);
+    run_loop_probe<1, 4, 8>(st, n_cu, d, C);
+    run_loop_probe<2, 4, 8>(st, n_cu, d, C);
+    run_loop_probe<3, 4, 8>(st, n_cu, d, C);
+  }
+  for (int cfg = 1; cfg <= 3; ++cfg) {
+    const char* name = cfg == 1 ? "128x128" : cfg == 2 ? "128x64" : "64x64";
+    // 1. dense, A k-contiguous (Z = E L', (Z - m) P)
+    GemmArgs g;
+    g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = 0;
+    float ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg); }, 20);
+    printf("%-8s dense  A[m][k]  M=%d N=%d K=%d: %.1f us  %.2f TFLOP/s\n", name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+    // 2. tri k-range
+    g.tri_mode = 1;
+    ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg); }, 20);
+    printf("%-8s tri-k  A[m][k]  M=%d N=%d K=%d: %.1f us  %.2f TFLOP/s (dense convention)\n", name, M, N, K, ms * 1e3,
+           2.0 * M * N * K / ms / 1e9);
+    // 3. C = G' E: M = N = D, K = n rows; lower-triangular tiles, split-K
+    GemmArgs g3;
+    g3.A = A, g3.B = B, g3.lda = N, g3.ldb = N, g3.M = N, g3.N = N, g3.K = M, g3.tri_mode = 2;
+    const long lower = gemm_count_blocks(g3, cfg == 3 ? 64 : 128, cfg == 1 ? 128 : 64);
+    for (int mult = 1; mult <= 4; mult *= 2) {
+      int splits = (int)(mult * n_cu / lower);
+      if (splits < 1) splits = 1;
+      if ((int64_t)splits * N * N > (int64_t)2 * 4096 * 4096) continue;
+      ms = time_it([&] { gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSlab{C, N, (int64_t)N * N}, cfg); }, 20);
+      printf("%-8s gram   A[k][m]  D=%d n=%d splits=%d: %.1f us  %.2f TFLOP/s (dense convention)\n", name, N, M, splits,
+             ms * 1e3, 2.0 * M * N * N / ms / 1e9);
+    }
+  }
+  return 0;
+}

@@ -35,8 +35,11 @@ namespace vb {
 typedef double d2v __attribute__((ext_vector_type(2)));
 typedef double d4v __attribute__((ext_vector_type(4)));
 
-constexpr int kGemmBN = 128, kGemmBK = 16;   // block tile: (32 AF) x 128 x 16, AF = A fragments per wave
-constexpr int kGemmLds = 128 + 16;           // LDS row stride in doubles
+constexpr int kGemmBK = 16;   // block tile: (32 AF) x (8 NB) x 16; AF / NB = A / B fragments per wave and k-step
+
+#ifdef VB_GEMM_CLOCK
+__device__ long long vb_gemm_dbg[2 * 4096];
+#endif
 
 struct GemmArgs {
   const double* A;
@@ -58,15 +61,17 @@ struct EpiReduces : std::false_type {};
 template <class E>
 struct EpiReduces<E, std::void_t<decltype(std::declval<E>().part)>> : std::true_type {};
 
-// AF = 4: 128-row block tile, 64 accumulators per lane, one workgroup per CU;
-// AF = 2:  64-row block tile, 32 accumulators per lane, two workgroups per CU (stalls of one are
-//          covered by the MFMAs of the other) -- used when 128-row tiles would not fill the chip twice.
-template <bool A_KCONTIG, int AF, class Epi>
-__global__ void __launch_bounds__(256, AF == 2 ? 2 : 1) gemm_f64_kernel(const GemmArgs g, const Epi epi) {
-  constexpr int BM = 32 * AF;
+// Block tile (32 AF) x (8 NB): (AF, NB) = (4, 16) 128 x 128, (4, 8) 128 x 64, (2, 8) 64 x 64.  One wave per
+// SIMD issues a 4x4x4 MFMA every 16.5 cycles, two waves sharing a SIMD one every 12.4 (measured,
+// tools/gemm_bench.hip): every variant fits two workgroups per CU (<= 256 registers, <= 74 KB LDS) and the
+// launcher picks the largest tile that still gives the chip two workgroups per CU.
+template <bool A_KCONTIG, int AF, int NB, class Epi>
+__global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(const GemmArgs g, const Epi epi) {
+  constexpr int BM = 32 * AF, BN = 8 * NB;
   constexpr int NA = BM / 32;   // staging iterations for the A tile
+  constexpr int NBL = BN / 32;  // staging iterations for the B tile
   __shared__ double As[2][kGemmBK][BM + 16];
-  __shared__ double Bs[2][kGemmBK][kGemmLds];
+  __shared__ double Bs[2][kGemmBK][BN + 16];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -80,52 +85,57 @@ __global__ void __launch_bounds__(256, AF == 2 ? 2 : 1) gemm_f64_kernel(const Ge
     int idx = blockIdx.x;
     bm = 0;
     for (;;) {
-      const int cnt = min(g.tiles_n, (bm * BM + BM - 1) / kGemmBN + 1);
+      const int cnt = min(g.tiles_n, (bm * BM + BM - 1) / BN + 1);
       if (idx < cnt) break;
       idx -= cnt;
       ++bm;
     }
     bn = idx;
-  } else if (g.tri_mode == 1) {   // heaviest column blocks (largest k range) first
-    bn = g.tiles_n - 1 - (int)(blockIdx.x / g.tiles_m);
+  } else if (g.tri_mode == 1) {
+    // first half of the grid: heaviest column blocks (largest k range) in descending order; second half:
+    // the light ones ascending, so the two workgroups a CU ends up with sum to the same k range
+    const int idx = blockIdx.x / g.tiles_m, half = (g.tiles_n + 1) / 2;
+    bn = idx < half ? g.tiles_n - 1 - idx : idx - half;
     bm = blockIdx.x % g.tiles_m;
   } else {
     bn = blockIdx.x / g.tiles_m;
     bm = blockIdx.x % g.tiles_m;
   }
-  const int m0 = bm * BM, n0 = bn * kGemmBN;
+  const int m0 = bm * BM, n0 = bn * BN;
   int k_begin = blockIdx.z * g.k_split;
   int k_end = k_begin + g.k_split < g.K ? k_begin + g.k_split : g.K;
   if (g.tri_mode == 1) {
-    const int kmax = n0 + kGemmBN;     // B[k][j] == 0 for k > j
+    const int kmax = n0 + BN;     // B[k][j] == 0 for k > j
     if (k_end > kmax) k_end = kmax;
   }
 
-  double acc[AF][16];
+  double acc[AF][NB];
 #pragma unroll
   for (int i = 0; i < AF; ++i)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.0;
+    for (int j = 0; j < NB; ++j) acc[i][j] = 0.0;
 
   // ---- global -> register staging ---------------------------------------------------------------
-  d2v ra[NA], rb[4];
-  // Branch-free: indices are clamped into range and the value zeroed afterwards (every operand row
-  // is padded to a multiple of 16 doubles, so the 16-B load of a pair that straddles the logical
-  // edge stays inside the allocation).
-  auto load_slab = [&](int k0) {
+  d2v ra[NA], rb[NBL];
+  unsigned keep = 0;   // validity bits of the staged values (2 per load: .x, .y), applied at the LDS store
+  // Branch-free: indices are clamped into range and out-of-range values are zeroed when they are
+  // written to LDS one iteration later -- nothing touches a loaded register before that, so the loads
+  // have a whole slab of MFMAs to land (every operand row is padded to a multiple of 16 doubles, so the
+  // 16-B load of a pair that straddles the logical edge stays inside the allocation).
+  auto load_slab = [&](int k0) __attribute__((always_inline)) {
+    keep = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // B: one 128-double row per wave-load
+    for (int i = 0; i < NBL; ++i) {
+      // B: BN / 2 pairs per k row
       const int p = i * 256 + t;
-      const int krow = p >> 6, c = (p & 63) * 2;
+      const int krow = p / (BN / 2), c = (p % (BN / 2)) * 2;
       const int k = k0 + krow;
       const int kc = k < k_end ? k : k_end - 1;
       const int n = n0 + c;
       const int nc = n < g.N ? n : 0;
-      d2v v = *reinterpret_cast<const d2v*>(g.B + (int64_t)kc * g.ldb + nc);
-      v.x = (k < k_end && n < g.N) ? v.x : 0.0;
-      v.y = (k < k_end && n + 1 < g.N) ? v.y : 0.0;
-      rb[i] = v;
+      rb[i] = *reinterpret_cast<const d2v*>(g.B + (int64_t)kc * g.ldb + nc);
+      keep |= (unsigned)(k < k_end && n < g.N) << (2 * i);
+      keep |= (unsigned)(k < k_end && n + 1 < g.N) << (2 * i + 1);
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -136,10 +146,9 @@ __global__ void __launch_bounds__(256, AF == 2 ? 2 : 1) gemm_f64_kernel(const Ge
         const int kc = k < k_end ? k : k_end - 1;
         const int m = m0 + c;
         const int mc = m < g.M ? m : 0;
-        d2v v = *reinterpret_cast<const d2v*>(g.A + (int64_t)kc * g.lda + mc);
-        v.x = (k < k_end && m < g.M) ? v.x : 0.0;
-        v.y = (k < k_end && m + 1 < g.M) ? v.y : 0.0;
-        ra[i] = v;
+        ra[i] = *reinterpret_cast<const d2v*>(g.A + (int64_t)kc * g.lda + mc);
+        keep |= (unsigned)(k < k_end && m < g.M) << (2 * (NBL + i));
+        keep |= (unsigned)(k < k_end && m + 1 < g.M) << (2 * (NBL + i) + 1);
       } else {
         // A[m][k]: wave-load q covers 16 rows x 4 k-pairs; 16 consecutive lanes = 16 distinct rows
         const int q = i * 4 + wave;
@@ -148,79 +157,128 @@ __global__ void __launch_bounds__(256, AF == 2 ? 2 : 1) gemm_f64_kernel(const Ge
         const int m = m0 + row, ka = k0 + 2 * kp;
         const int mc = m < g.M ? m : 0;
         const int kac = ka < k_end ? ka : 0;
-        d2v v = *reinterpret_cast<const d2v*>(g.A + (int64_t)mc * g.lda + kac);
-        v.x = (m < g.M && ka < k_end) ? v.x : 0.0;
-        v.y = (m < g.M && ka + 1 < k_end) ? v.y : 0.0;
-        ra[i] = v;
+        ra[i] = *reinterpret_cast<const d2v*>(g.A + (int64_t)mc * g.lda + kac);
+        keep |= (unsigned)(m < g.M && ka < k_end) << (2 * (NBL + i));
+        keep |= (unsigned)(m < g.M && ka + 1 < k_end) << (2 * (NBL + i) + 1);
       }
     }
   };
-  auto store_slab = [&](int buf) {
+  auto store_slab = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NBL; ++i) {
       const int p = i * 256 + t;
-      const int krow = p >> 6, c = (p & 63) * 2;
-      *reinterpret_cast<d2v*>(&Bs[buf][krow][c]) = rb[i];
+      const int krow = p / (BN / 2), c = (p % (BN / 2)) * 2;
+      d2v v = rb[i];
+      v.x = (keep >> (2 * i)) & 1u ? v.x : 0.0;
+      v.y = (keep >> (2 * i + 1)) & 1u ? v.y : 0.0;
+      *reinterpret_cast<d2v*>(&Bs[buf][krow][c]) = v;
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
+      d2v v = ra[i];
+      v.x = (keep >> (2 * (NBL + i))) & 1u ? v.x : 0.0;
+      v.y = (keep >> (2 * (NBL + i) + 1)) & 1u ? v.y : 0.0;
       if (!A_KCONTIG) {
         const int p = i * 256 + t;
         const int krow = p / (BM / 2), c = (p % (BM / 2)) * 2;
-        *reinterpret_cast<d2v*>(&As[buf][krow][c]) = ra[i];
+        *reinterpret_cast<d2v*>(&As[buf][krow][c]) = v;
       } else {
         const int q = i * 4 + wave;
         const int row = (q >> 1) * 16 + (lane & 15);
         const int kp = (q & 1) * 4 + (lane >> 4);
-        As[buf][2 * kp][row] = ra[i].x;
-        As[buf][2 * kp + 1][row] = ra[i].y;
+        As[buf][2 * kp][row] = v.x;
+        As[buf][2 * kp + 1][row] = v.y;
       }
     }
   };
 
   const int fi = lane & 15, fk = lane >> 4;          // A fragment: 16 consecutive rows, k = lane >> 4
   const int fblk = (lane >> 2) & 3, fj = lane & 3;   // B fragment / result: block and column in block
-  auto compute_slab = [&](int buf) {
+  // Software pipeline of one slab iteration (slab s in LDS buffer `buf`, KS = 4 k-steps of 4):
+  //   top     ds_write slab s+1 (global loads issued one iteration ago) into buf^1, then issue the
+  //           global loads of slab s+2 into the same staging registers
+  //   kk<KS-1 MFMAs of k-step kk interleaved with the fragment ds_reads of k-step kk+1
+  //   barrier (all waves have issued every read of slab s and every write of slab s+1)
+  //   kk=KS-1 MFMAs interleaved with the fragment reads of k-step 0 of slab s+1 (from buf^1)
+  // so neither the LDS fill nor the first fragment fetch of a slab is exposed; the only idle time is the
+  // barrier skew.  buf^1 is free at the top of the iteration: its last readers issued their reads before
+  // the previous barrier.  sched_group_barrier pins the read/MFMA interleave: left to itself the
+  // scheduler hoists every fragment read of a slab in front of the first MFMA and the matrix pipe idles
+  // while the LDS queue drains (20.6 instead of 16 cycles per MFMA, tools/gemm_bench.hip).
+  double fa[2][AF], fb[2][NB];
+  auto load_frags = [&](int buf, int kk, int set) __attribute__((always_inline)) {
 #pragma unroll
-    for (int kk = 0; kk < kGemmBK / 4; ++kk) {
-      double af[AF], bf[16];
+    for (int a = 0; a < AF; ++a) fa[set][a] = As[buf][4 * kk + fk][wm * (16 * AF) + a * 16 + fi];
 #pragma unroll
-      for (int a = 0; a < AF; ++a) af[a] = As[buf][4 * kk + fk][wm * (16 * AF) + a * 16 + fi];
+    for (int r = 0; r < NB; ++r)
+      fb[set][r] = Bs[buf][4 * kk + fk][wn * (4 * NB) + 4 * ((fblk + r) & (NB - 1)) + fj];
+  };
+  auto mfma_step = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bf[r] = Bs[buf][4 * kk + fk][wn * 64 + 4 * ((fblk + r) & 15) + fj];
+    for (int a = 0; a < AF; ++a)
 #pragma unroll
-      for (int a = 0; a < AF; ++a)
+      for (int r = 0; r < NB; ++r)
+        acc[a][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[set][a], fb[set][r], acc[a][r], 0, 0, 0);
+  };
+  constexpr int KS = kGemmBK / 4;
+  constexpr int kReads = AF + NB, kMfma = AF * NB;
+  constexpr int kPer = kMfma / kReads;        // MFMAs issued after each fragment read
+  auto interleave = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          acc[a][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[r], acc[a][r], 0, 0, 0);
+    for (int i = 0; i < kReads; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);   // kPer MFMAs
     }
+    __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kPer * kReads, 0);
   };
 
+#ifdef VB_GEMM_CLOCK
+  const long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
   if (k_begin < k_end) {
     load_slab(k_begin);
     store_slab(0);
+    load_slab(k_begin + kGemmBK);
     __syncthreads();
+    load_frags(0, 0, 0);
     int buf = 0;
-    // steady state: a single basic block per slab (keeps the 128 accumulator registers in place)
-    for (int k0 = k_begin + kGemmBK; k0 < k_end; k0 += kGemmBK) {
-      load_slab(k0);          // in flight while the MFMAs below run
-      compute_slab(buf);
-      store_slab(buf ^ 1);
-      __syncthreads();
+    // One uniform basic block per slab (keeps the accumulators in place; no peeled tail: loads beyond the
+    // last slab are clamped into range and zeroed, and their LDS copy is never used).
+    for (int k0 = k_begin; k0 < k_end; k0 += kGemmBK) {
+#ifndef VB_GEMM_SKIP
+#define VB_GEMM_SKIP 0     // tools/gemm_bench.hip builds ablation variants (bits: 1 global loads, 2 LDS fill, 4 barrier, 8 fragment reads)
+#endif
+      if (!(VB_GEMM_SKIP & 2)) store_slab(buf ^ 1);
+      if (!(VB_GEMM_SKIP & 1)) load_slab(k0 + 2 * kGemmBK);
+#pragma unroll
+      for (int kk = 0; kk < KS - 1; ++kk) {
+        if (!(VB_GEMM_SKIP & 8)) load_frags(buf, kk + 1, (kk + 1) & 1);
+        mfma_step(kk & 1);
+        interleave();
+      }
+      if (!(VB_GEMM_SKIP & 4)) __syncthreads();
+      if (!(VB_GEMM_SKIP & 8)) load_frags(buf ^ 1, 0, KS & 1);
+      mfma_step((KS - 1) & 1);
+      interleave();
       buf ^= 1;
     }
-    compute_slab(buf);
   }
 
+#ifdef VB_GEMM_CLOCK
+  if (t == 0) {
+    vb_gemm_dbg[2 * blockIdx.x] = clock64() - dbg_c0;
+    vb_gemm_dbg[2 * blockIdx.x + 1] = wall_clock64() - dbg_w0;
+  }
+#endif
   // ---- epilogue -----------------------------------------------------------------------------------
   double local = 0.0;
-  // acc[a][r], lane l: row = 16 a + 4 blk + (l >> 4), col = 4 ((blk + r) mod 16) + (l & 3)
+  // acc[a][r], lane l: row = 16 a + 4 blk + (l >> 4), col = 4 ((blk + r) mod NB) + (l & 3)
 #pragma unroll
   for (int a = 0; a < AF; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < NB; ++r) {
       const int row = m0 + wm * (16 * AF) + a * 16 + 4 * fblk + fk;
-      const int col = n0 + wn * 64 + 4 * ((fblk + r) & 15) + fj;
+      const int col = n0 + wn * (4 * NB) + 4 * ((fblk + r) & (NB - 1)) + fj;
       if (row < g.M && col < g.N) {
         if constexpr (EpiReduces<Epi>::value)
           local += epi((int)blockIdx.z, row, col, acc[a][r]);
@@ -242,30 +300,42 @@ __global__ void __launch_bounds__(256, AF == 2 ? 2 : 1) gemm_f64_kernel(const Ge
 
 inline int gemm_tiles(int x, int b) { return (x + b - 1) / b; }
 
+// upper bound on gridDim.x of any tile choice (sizes the `part` array of reducing epilogues)
+inline int64_t gemm_max_blocks(int64_t M, int64_t N) { return ((M + 63) / 64) * ((N + 63) / 64); }
+
+inline long gemm_count_blocks(const GemmArgs& g, int bm_rows, int bn_cols) {
+  const int tm = gemm_tiles(g.M, bm_rows), tn = gemm_tiles(g.N, bn_cols);
+  if (g.tri_mode != 2) return (long)tm * tn;
+  long blocks = 0;
+  for (int bm = 0; bm < tm; ++bm) {
+    const int cnt = (bm * bm_rows + bm_rows - 1) / bn_cols + 1;
+    blocks += cnt < tn ? cnt : tn;
+  }
+  return blocks;
+}
+
+// cfg: 0 = automatic, 1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 64 block tiles
 template <bool A_KCONTIG, class Epi>
-inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi) {
-  g.tiles_n = gemm_tiles(g.N, kGemmBN);
+inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi, int cfg = 0) {
   if (splits < 1) splits = 1;
   int ks = gemm_tiles(g.K, splits);
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
-  // 128-row tiles (one workgroup per CU, 64 accumulators per lane) unless they would leave CUs idle
-  const long tm128 = gemm_tiles(g.M, 128);
-  const long tiles128 = (g.tri_mode == 2 ? tm128 * (tm128 + 1) / 2 : tm128 * g.tiles_n) * splits;
-  const int bm_rows = (20 * tiles128 >= 17L * n_cu) ? 128 : 64;
-  g.tiles_m = gemm_tiles(g.M, bm_rows);
-  long blocks = (long)g.tiles_m * g.tiles_n;
-  if (g.tri_mode == 2) {
-    blocks = 0;
-    for (int bm = 0; bm < g.tiles_m; ++bm) {
-      const int cnt = (bm * bm_rows + bm_rows - 1) / kGemmBN + 1;
-      blocks += cnt < g.tiles_n ? cnt : g.tiles_n;
-    }
+  if (cfg == 0) {
+    // largest tile that gives every CU two workgroups (two waves per SIMD)
+    if (gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) cfg = 1;
+    else if (gemm_count_blocks(g, 128, 64) * splits >= 2L * n_cu) cfg = 2;
+    else cfg = 3;
   }
-  const dim3 grid((unsigned)blocks, 1, (unsigned)splits);
-  if (bm_rows == 128)
-    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, Epi>), grid, dim3(256), 0, st, g, epi);
+  const int bm_rows = cfg == 3 ? 64 : 128, bn_cols = cfg == 1 ? 128 : 64;
+  g.tiles_m = gemm_tiles(g.M, bm_rows);
+  g.tiles_n = gemm_tiles(g.N, bn_cols);
+  const dim3 grid((unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1, (unsigned)splits);
+  if (cfg == 1)
+    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, 16, Epi>), grid, dim3(256), 0, st, g, epi);
+  else if (cfg == 2)
+    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, 8, Epi>), grid, dim3(256), 0, st, g, epi);
   else
-    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 2, Epi>), grid, dim3(256), 0, st, g, epi);
+    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 2, 8, Epi>), grid, dim3(256), 0, st, g, epi);
 }
 
 }  // namespace vb

@@ -759,7 +759,7 @@ static int logistic_accumulate(vb_ctx* ctx, hipStream_t st, const ModelDev& m, c
   const int64_t n = g.n, d = g.d, nd = m.n_data;
   const int64_t ldz = round_up(d, 16), ldr = round_up(nd, 16);
   const int n_cu = ctx->prop.multiProcessorCount;
-  const int64_t max_blocks = ((n + 63) / 64) * ((nd + 127) / 128);
+  const int64_t max_blocks = gemm_max_blocks(n, nd);
   int64_t off = 0;
   auto carve = [&off](int64_t doubles) {
     const int64_t o = off;
