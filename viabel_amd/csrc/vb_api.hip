@@ -87,7 +87,11 @@ static int noise_alloc(vb_ctx* ctx, int slot, int64_t n, int64_t d) {
   VB_TRY(check_slot(ctx, slot));
   if (n <= 0 || d <= 0) return fail(ctx, VB_ERR_INVALID, "noise shape must be positive");
   NoiseSlot& s = ctx->noise[slot];
-  const int64_t ld = round_up(d, 16);   // 128-B aligned rows
+  // 128-B aligned rows; a row stride that is a multiple of 4 KiB would put one column of every row on the
+  // same HBM channel (the funnel's coupling column is read down the rows), so such strides get one more
+  // 128-B pad
+  int64_t ld = round_up(d, 16);
+  if (ld % 512 == 0) ld += 16;
   const bool had = s.buf.ptr != nullptr && s.buf.bytes >= (size_t)n * ld * sizeof(double);
   VB_TRY(ensure(ctx, s.buf, (size_t)n * ld * sizeof(double)));
   // invariant relied on by the streaming kernel: the pad columns [d, ld) hold zeros

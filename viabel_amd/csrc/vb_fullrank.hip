@@ -133,9 +133,12 @@ __global__ void __launch_bounds__(256) fr_funnel_kernel(const double* __restrict
 }
 
 // ---- column sums of G and sum of f per 128-row block ------------------------------------------------
-// grid (ceil(D / 64), ceil(N / 128)); thread (c = t & 63, q = t >> 6) sums rows r0 + q, q + 4, ... of
-// one column, 8 loads in flight; the 4 row groups are combined through LDS in fixed order.
+// grid (ceil(D / 128), ceil(N / 128)); thread (c = t & 63, q = t >> 6) sums rows r0 + q, q + 4, ... of
+// the column pair 2c, 2c + 1 (16-B loads, 8 rows in flight); the 4 row groups are combined through LDS in
+// fixed order.  Rows are padded to 16 doubles and pad columns of G / Zc are never written with non-finite
+// values by the producers, but they are masked anyway.
 // fmode 0: no f here, 1: gauss_diag f = -1/2 g^2 / ivar, 2: gauss_full f = 1/2 zc g
+typedef double fr_d2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict__ G,
                                                         const double* __restrict__ Zc, int64_t ldz,
                                                         int64_t n, int d, int fmode,
@@ -143,34 +146,45 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
                                                         double* __restrict__ colpart,
                                                         double* __restrict__ fpart) {
   __shared__ double sh[4];
-  __shared__ double cs[4][64];
+  __shared__ fr_d2 cs[4][64];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + c;
+  const int col = blockIdx.x * 128 + 2 * c;
   const int64_t r0 = (int64_t)blockIdx.y * 128;
   const int64_t r1 = r0 + 128 < n ? r0 + 128 : n;
-  double s = 0.0, f = 0.0;
-  if (col < d) {
-    const double hiv = fmode == 1 ? -0.5 / ivar[col] : 0.0;
+  const bool ok0 = col < d, ok1 = col + 1 < d;
+  fr_d2 s = (fr_d2){0.0, 0.0};
+  double f = 0.0;
+  if (ok0) {
+    fr_d2 hiv = (fr_d2){0.0, 0.0};
+    if (fmode == 1) hiv = (fr_d2){-0.5 / ivar[col], ok1 ? -0.5 / ivar[col + 1] : 0.0};
     for (int64_t rb = r0 + q; rb < r1; rb += 32) {
-      double g[8], z[8];
+      fr_d2 g[8], z[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int64_t r = rb + 4 * i;
-        g[i] = r < r1 ? G[r * ldz + col] : 0.0;
-        z[i] = (fmode == 2 && r < r1) ? Zc[r * ldz + col] : 0.0;
+        g[i] = (fr_d2){0.0, 0.0};
+        z[i] = (fr_d2){0.0, 0.0};
+        if (r < r1) {
+          g[i] = *reinterpret_cast<const fr_d2*>(G + r * ldz + col);
+          if (fmode == 2) z[i] = *reinterpret_cast<const fr_d2*>(Zc + r * ldz + col);
+          if (!ok1) g[i].y = 0.0, z[i].y = 0.0;
+        }
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         s += g[i];
-        if (fmode == 1) f = fma(hiv * g[i], g[i], f);
-        if (fmode == 2) f = fma(0.5 * z[i], g[i], f);
+        if (fmode == 1) f = fma(hiv.x * g[i].x, g[i].x, fma(hiv.y * g[i].y, g[i].y, f));
+        if (fmode == 2) f = fma(0.5 * z[i].x, g[i].x, fma(0.5 * z[i].y, g[i].y, f));
       }
     }
   }
   cs[q][c] = s;
   __syncthreads();
-  if (q == 0 && col < d)
-    colpart[(int64_t)blockIdx.y * ldz + col] = (cs[0][c] + cs[1][c]) + (cs[2][c] + cs[3][c]);
+  if (q == 0 && ok0) {
+    const fr_d2 tot = (cs[0][c] + cs[1][c]) + (cs[2][c] + cs[3][c]);
+    colpart[(int64_t)blockIdx.y * ldz + col] = tot.x;
+    if (ok1) colpart[(int64_t)blockIdx.y * ldz + col + 1] = tot.y;
+  }
   f = fr_block_sum(f, sh);
   if (threadIdx.x == 0) fpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = f;
 }
@@ -178,26 +192,45 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
 // ---- reduce: split-K slabs, row-block partials -> sum vector ------------------------------------------
 // sum vector layout: [F | colsum (ldz) | C (d x ldl)], F at index 0, colsum from 16, C from 16 + ldz
 
+// One thread per pair of adjacent C entries (16-B loads, up to 8 split slabs in flight, summed in slab
+// order); entries above the diagonal are not computed by the GEMM and are written as zero.
 __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict__ Cpart, int splits,
                                                         int64_t slab, int d, int64_t ldl,
                                                         const double* __restrict__ colpart, int n_rb,
                                                         int64_t ldz, const double* __restrict__ fpart,
                                                         int n_fpart, FrSums S) {
   __shared__ double sh[4];
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t idx = 2 * tid;
   const int64_t nC = (int64_t)d * ldl;
   if (idx < nC) {
     const int i = (int)(idx / ldl), j = (int)(idx % ldl);
-    double s = 0.0;
-    if (j <= i)
-      for (int k = 0; k < splits; ++k) s += Cpart[k * slab + idx];
-    S.sums[S.off_c + idx] = s;
+    fr_d2 s = (fr_d2){0.0, 0.0};
+    if (j <= i) {
+      for (int k0 = 0; k0 < splits; k0 += 8) {
+        fr_d2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = k0 + u < splits ? *reinterpret_cast<const fr_d2*>(Cpart + (k0 + u) * slab + idx) : (fr_d2){0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      if (j + 1 > i) s.y = 0.0;
+    }
+    *reinterpret_cast<fr_d2*>(S.sums + S.off_c + idx) = s;
   }
-  if (idx < ldz) {
+  if (tid < ldz) {
     double s = 0.0;
-    if (idx < d)
-      for (int rb = 0; rb < n_rb; ++rb) s += colpart[(int64_t)rb * ldz + idx];
-    S.sums[S.off_col + idx] = s;
+    if (tid < d) {
+      for (int rb0 = 0; rb0 < n_rb; rb0 += 16) {      // 16 loads in flight, summed in row-block order
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = rb0 + u < n_rb ? colpart[(int64_t)(rb0 + u) * ldz + tid] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+      }
+    }
+    S.sums[S.off_col + tid] = s;
   }
   if (blockIdx.x == 0) {
     double f = 0.0;
@@ -242,7 +275,7 @@ __global__ void __launch_bounds__(256) fr_epilogue_kernel(FrSums S, const double
 int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,
                       const double* ivar, double* colpart, double* fpart) {
   const int n_rb = (int)((n + 127) / 128);
-  hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)n_rb), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)((d + 127) / 128), (unsigned)n_rb), dim3(256), 0, ctx->stream,
                      G, Zc, ldz, n, d, fmode, ivar, colpart, fpart);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
@@ -250,7 +283,7 @@ int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ld
 
 int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab, int d, int64_t ldl,
                       const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S) {
-  const int64_t items = slab > ldz ? slab : ldz;
+  const int64_t items = slab / 2 > ldz ? slab / 2 : ldz;
   hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, Cpart,
                      splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S);
   VB_HIP(ctx, hipGetLastError());
@@ -304,7 +337,7 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const int n_rb = (int)((n + 127) / 128);
-  const int cs_gx = (D + 63) / 64;
+  const int cs_gx = (D + 127) / 128;
   const int n_fpart = m.id == VB_MODEL_FUNNEL ? (int)((n + 3) / 4) : n_rb * cs_gx;
   const int64_t slab = d * ldl;
 
@@ -390,7 +423,7 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
   VB_HIP(ctx, hipGetLastError());
 
-  const int64_t red_items = slab > ldz ? slab : ldz;
+  const int64_t red_items = slab / 2 > ldz ? slab / 2 : ldz;
   hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((red_items + 255) / 256)), dim3(256), 0, st,
                      (const double*)Cpart, splits, slab, D, ldl, (const double*)colpart, n_rb, ldz,
                      (const double*)fpart, n_fpart, S);

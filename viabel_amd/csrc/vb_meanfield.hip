@@ -128,13 +128,20 @@ mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const Model
   }
   double W = 0.0, FK = 0.0, GK = 0.0, GEK = 0.0;
   if (g.rows) {
+    // theta lives in pinned host memory: one lane fetches the coupling column's (mu, log sigma) across
+    // PCIe and broadcasts them through LDS instead of every wave issuing its own host reads
+    __shared__ double thk[2];
+    if (funnel) {
+      if (threadIdx.x < 2) thk[threadIdx.x] = theta_src[threadIdx.x * d + model.k];
+      __syncthreads();
+    }
     if (i < g.n) {
       const double* roww = bp.roww[b];
       const double wt = roww ? roww[i] : 1.0;
       double av = wt, ek = 0.0;
       if (funnel) {
         const int k = model.k;
-        const double muk = theta_src[k], sgk = exp(theta_src[d + k]);
+        const double muk = thk[0], sgk = exp(thk[1]);
         const double it2 = 1.0 / (model.tau * model.tau), dm1 = (double)(d - 1);
         ek = bp.noise[b][i * g.ld + k];
         const double v = fma(sgk, ek, muk);

@@ -353,7 +353,7 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   VB_TRY(gram_lower_enqueue(ctx, base + L.o_ua, base + L.o_u, L.ld, (int)d, n, L.splits, base + L.o_cpart, L.ld,
                             slab));
   VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col, L.n_rb, L.ld, fpart,
-                           L.n_rb * (int)((d + 63) / 64), S));
+                           L.n_rb * (int)((d + 127) / 128), S));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
   double sc[2];
   VB_HIP(ctx, hipMemcpyAsync(sc, S.sums + 1, sizeof sc, hipMemcpyDeviceToHost, st));
