@@ -30,8 +30,9 @@ D, N_MC = 1024, 4096
 ALGO_BYTES = N_MC * D * 8 + 4 * D * 8 + 8        # noise read + theta read + grad write + value
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per evaluation of the accumulate kernel from the PMC passes committed under
-# profiles/r01_meanfield_c1_pmc_hbm.txt: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) x 1024 / 16
-PMC_TRAFFIC_BYTES_PER_EVAL = (2 * 265252.0 + 4176.3) * 1024 / 16
+# profiles/r01_meanfield_c1_pmc_hbm.txt: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) KiB per
+# 32-evaluation launch
+PMC_TRAFFIC_BYTES_PER_EVAL = (2 * 530474.5 + 8352.7) * 1024 / 32
 FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet; tools/fp64_peak.hip measures 63-73 (4x4x4 form)
 
 

@@ -37,8 +37,10 @@ eng.sync()
 t0 = time.perf_counter()
 for i in range(steps):
     eng.elbo_grad_fullrank_enqueue(i % ring, N, D)
+t_enq = (time.perf_counter() - t0) / steps
 eng.sync()
 dt = (time.perf_counter() - t0) / steps
+print('host enqueue %.1f us/eval' % (t_enq * 1e6))
 flops = 4.0 * N * D * D + (2.0 * N * D * D if model_kind == 'gauss_full' else 0.0)
 print('D=%d N=%d model=%s: %.1f us/eval, %.0f evals/s, %.2f TFLOP/s (dense convention %.2f GFLOP/eval)'
       % (D, N, model_kind, dt * 1e6, 1 / dt, flops / dt / 1e12, flops / 1e9))
