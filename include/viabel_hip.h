@@ -165,6 +165,22 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
 int vb_dis_grad_mvt(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* l_inv,
                     const double* weights, double* w_sum, double* w_logq, double* d_mu, double* gram);
 
+/* ---- Importance weights and Pareto smoothing (diagnostics) ----------------------------
+ * vb_log_weights_meanfield: log p(z_n) - log q(z_n; theta) for the samples z = mu + sigma * eps of
+ * the noise staged in `slot` -- samples_and_log_weights, viabel/convenience.py:176-179.  The
+ * weights stay resident on the device for vb_psis_smooth; `lw` (n doubles) may be NULL.
+ * vb_psis_smooth: psislw of viabel/_psis.py:113-209 (tail size ceil(min(0.2 n, 3 sqrt(n / reff))),
+ * Zhang-Stephens GPD fit _psis.py:212-332, smoothed weights normalised to log-sum-exp 0) --
+ * psis_correction, viabel/convenience.py:166-169.  `lw_in` NULL smooths the device-resident
+ * weights of the last vb_log_weights_* call; otherwise n host log weights are uploaded first.
+ * Outputs: lw_out (n doubles, smoothed), khat (Pareto tail index; +inf when the tail has <= 4
+ * samples).  VB_ERR_UNSUPPORTED when the tail exceeds the on-chip sort capacity (4096 values,
+ * i.e. n > 1.86e6 at reff = 1).                                                              */
+int vb_log_weights_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+                             const double* theta, double* lw);
+int vb_psis_smooth(vb_ctx* ctx, const double* lw_in, int64_t n, double reff, double* lw_out,
+                   double* khat);
+
 /* ---- ExclusiveKL, full-rank Gaussian family -------------------------------------------
  * New family (no reference class) behind the ApproximationFamily API with the flat
  * layout of viabel/approximations.py:315-319: theta = [mu (D) | free Cholesky (D(D+1)/2)],

@@ -409,15 +409,112 @@ def gen_chain_stats():
          provenance='reference viabel/_mc_diagnostics.py functions (pure numpy) run as they are')
 
 
+def gen_optimizers():
+    """Iterate histories of the reference optimisers (viabel/optimization.py:51-518) on a seeded noisy
+    quadratic -- the same dummy objective tests/test_host_logic.py builds (modelled on the reference's
+    tests/test_optimization.py:20-32)."""
+    from viabel import optimization as ref_opt
+
+    class Family:
+        supports_kl = True
+
+    class Objective:
+        def __init__(self, target, noise=0.3, seed=3):
+            self.target, self.noise = target, noise
+            self.rs = np.random.RandomState(seed)
+            self.approx = Family()
+
+        def __call__(self, x):
+            g = (x - self.target) + self.noise * self.rs.randn(*x.shape)
+            return 0.5 * np.sum((x - self.target) ** 2), g
+
+        def update(self, x, d):
+            return x - d
+
+    target = np.array([1.0, -2.0, 0.5, 3.0])
+    ctors = {
+        'sgd': lambda: ref_opt.StochasticGradientOptimizer(0.05, diagnostics=True),
+        'rmsprop': lambda: ref_opt.RMSProp(0.05, diagnostics=True),
+        'avgrmsprop': lambda: ref_opt.AveragedRMSProp(0.05, diagnostics=True),
+        'adam': lambda: ref_opt.Adam(0.05, diagnostics=True),
+        'avgadam': lambda: ref_opt.AveragedAdam(0.05, diagnostics=True),
+        'adagrad': lambda: ref_opt.Adagrad(0.5, diagnostics=True),
+        'wadagrad': lambda: ref_opt.WindowedAdagrad(0.05, diagnostics=True),
+    }
+    out = {}
+    for name, ctor in ctors.items():
+        res = ctor().optimize(300, Objective(target), np.zeros(4))
+        out[name + '_opt_param'] = np.asarray(res['opt_param'])
+        out[name + '_last'] = np.asarray(res['variational_param_history'][-1])
+        out[name + '_values'] = np.asarray(res['value_history'])
+    save('optimizers', target=target, provenance='reference viabel/optimization.py optimisers on a seeded noisy quadratic',
+         **out)
+
+
+def gen_psis():
+    """psislw / gpdfitnew of the reference (viabel/_psis.py, pure numpy) and the bounds of
+    viabel/diagnostics.py on seeded log-weight vectors: heavy, moderate, light and bounded tails, ties,
+    tiny n, a 2-column input and a non-default Reff."""
+    from viabel import _psis as ref
+    from viabel import diagnostics as ref_diag
+    rng = np.random.RandomState(1234)
+    cases = {
+        'normal_heavy': 2.5 * rng.randn(2000),                    # log-normal weights, k-hat > 1/3
+        'normal_moderate': 1.0 * rng.randn(4000),
+        'normal_light': 0.2 * rng.randn(1500),                    # k < 1/3: no smoothing
+        'bounded': -rng.gamma(2.0, 1.0, size=3000),               # weights bounded above
+        'student': 1.5 * rng.standard_t(3, size=16384),           # the C3 sample count
+        'ties': np.round(1.5 * rng.randn(800), 1),
+        'tiny': rng.randn(12),
+        'five': rng.randn(5),
+        'big': 2.0 * rng.randn(100000),                           # vi_diagnostics' default n_samples
+    }
+    out = {'names': np.array(sorted(cases))}
+    for name, lw in cases.items():
+        sm, k = ref.psislw(lw.copy())
+        out[name + '_lw'] = lw
+        out[name + '_smoothed'] = sm
+        out[name + '_khat'] = np.float64(k)
+    sm, k = ref.psislw(cases['normal_heavy'].copy(), Reff=0.37)
+    out['reff_smoothed'], out['reff_khat'], out['reff_value'] = sm, np.float64(k), np.float64(0.37)
+    two = np.stack([cases['normal_heavy'], cases['normal_moderate'][:2000]], axis=1)
+    sm2, k2 = ref.psislw(two.copy())
+    out['two_lw'], out['two_smoothed'], out['two_khat'] = two, sm2, np.asarray(k2)
+    # GPD fit by itself
+    x = np.sort(rng.pareto(2.0, size=500))
+    kf, sf = ref.gpdfitnew(x, sort=False)
+    out['gpd_x'], out['gpd_k'], out['gpd_sigma'] = x, np.float64(kf), np.float64(sf)
+    # diagnostics.py on Gaussian q / p
+    samples = 3.0 * rng.randn(50000, 2)
+    lwd = scipy.stats.norm.logpdf(samples, scale=2.0).sum(1) - scipy.stats.norm.logpdf(samples, scale=3.0).sum(1)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        res = ref_diag.all_diagnostics(lwd, samples=samples)
+        res_q = ref_diag.all_diagnostics(lwd, samples=samples, q_var=9.0 * np.eye(2), p_var=4.0 * np.eye(2),
+                                         log_norm_bound=0.0)
+        d3 = ref_diag.divergence_bound(lwd, alpha=3.0)
+    out['diag_samples'], out['diag_lw'] = samples, lwd
+    for key in ('d2', 'log_norm_bound', 'W1', 'W2', 'mean_error', 'std_error', 'cov_error'):
+        out['diag_' + key] = np.float64(res[key])
+        out['diagq_' + key] = np.float64(res_q[key])
+    out['diag_d3'] = np.float64(d3)
+    save('psis', provenance='reference viabel/_psis.py and viabel/diagnostics.py functions (pure numpy) run as they are',
+         **out)
+
+
+GENERATORS = {}
+
 if __name__ == '__main__':
-    for f in os.listdir(HERE):
-        if f.endswith('.npz'):
-            os.remove(os.path.join(HERE, f))
-    gen_torch_crosscheck()
-    gen_family_forward()
-    gen_exclusive_kl()
-    gen_rge()
-    gen_alpha()
-    gen_dis()
-    gen_chain_stats()
+    GENERATORS.update(torch=gen_torch_crosscheck, family=gen_family_forward, ekl=gen_exclusive_kl, rge=gen_rge,
+                      alpha=gen_alpha, dis=gen_dis, chainstats=gen_chain_stats, optimizers=gen_optimizers,
+                      psis=gen_psis)
+    picked = sys.argv[1:]          # e.g. `make_golden.py psis optimizers` regenerates only those fixtures
+    if not picked:
+        for f in os.listdir(HERE):
+            if f.endswith('.npz'):
+                os.remove(os.path.join(HERE, f))
+        picked = list(GENERATORS)
+    for name in picked:
+        GENERATORS[name]()
     print('wrote %d fixtures to %s' % (len(SAVED), HERE))

@@ -11,5 +11,6 @@ from viabel_amd.models import *  # noqa: F401,F403
 from viabel_amd.objectives import *  # noqa: F401,F403
 from viabel_amd.optimization import *  # noqa: F401,F403
 from viabel_amd.convenience import *  # noqa: F401,F403
+from viabel_amd.diagnostics import *  # noqa: F401,F403
 
 __version__ = '0.1.0'

@@ -58,6 +58,10 @@ SIGNATURES = {
                                                           ctypes.c_int, ctypes.c_double, _c_double_p,
                                                           ctypes.c_uint, ctypes.c_int,
                                                           ctypes.POINTER(ctypes.c_int)]),
+    'vb_log_weights_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_double, _c_double_p, _c_double_p]),
+    'vb_psis_smooth': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_double, _c_double_p,
+                                      _c_double_p]),
     'vb_alpha_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                ctypes.c_int, ctypes.c_double, _c_double_p, ctypes.c_double,
                                                _c_double_p, _c_double_p]),
@@ -270,6 +274,30 @@ class Engine:
         grad = np.empty(p, dtype=np.float64)
         self._check(self._lib.vb_result_get(self._ctx, rslot, ctypes.byref(value), _dptr(grad), p))
         return value.value, grad
+
+    # ------------------------------------------------------------------ importance weights, PSIS
+    def log_weights_meanfield(self, slot, n, d, theta, family, df=0.0, fetch=True):
+        """log p(z_n) - log q(z_n) for the staged noise; the weights also stay on the device for
+        :meth:`psis_smooth`."""
+        theta = _f64(theta)
+        lw = np.empty(n, dtype=np.float64) if fetch else None
+        self._check(self._lib.vb_log_weights_meanfield(self._ctx, slot, n, d, family, float(df), _dptr(theta),
+                                                       _dptr(lw) if fetch else None))
+        return lw
+
+    def psis_smooth(self, n, log_weights=None, reff=1.0):
+        """Pareto-smoothed, normalised log weights and k-hat; ``log_weights=None`` smooths the weights
+        left on the device by :meth:`log_weights_meanfield`."""
+        out = np.empty(n, dtype=np.float64)
+        khat = ctypes.c_double(0.0)
+        src = None
+        if log_weights is not None:
+            log_weights = _f64(log_weights)
+            if log_weights.shape != (n,):
+                raise ValueError('log_weights must have shape ({},)'.format(n))
+            src = _dptr(log_weights)
+        self._check(self._lib.vb_psis_smooth(self._ctx, src, n, float(reff), _dptr(out), ctypes.byref(khat)))
+        return out, khat.value
 
     # ------------------------------------------------------------------ AlphaDivergence, mean field
     def alpha_grad_meanfield(self, slot, n, d, theta, family, alpha, df=0.0, n_total=None):

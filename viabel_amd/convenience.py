@@ -6,12 +6,17 @@ Same keyword interface, validation errors and optimiser wiring as the reference:
 a device model (``viabel_amd.models.DeviceModel``) rather than a Python callable, and ``fit`` (PyStan)
 is not supported.
 """
-from .approximations import MFGaussian
+import numpy as np
+
+from . import _lib
+from ._psis import psislw
+from .approximations import MFGaussian, MFStudentT
+from .diagnostics import all_diagnostics
 from .models import DeviceModel
 from .objectives import ExclusiveKL
 from .optimization import FASO, RAABBVI, RMSProp
 
-__all__ = ['bbvi', 'samples_and_log_weights']
+__all__ = ['bbvi', 'vi_diagnostics', 'psis_correction', 'samples_and_log_weights']
 
 
 def bbvi(dimension, *, n_iters=10000, num_mc_samples=10, log_density=None, approx=None, objective=None,
@@ -50,6 +55,78 @@ def bbvi(dimension, *, n_iters=10000, num_mc_samples=10, log_density=None, appro
     results = opt.optimize(n_iters, objective, init_var_param)
     results['objective'] = objective
     return results
+
+
+def vi_diagnostics(var_param, *, objective=None, model=None, approx=None, n_samples=100000):
+    """Pareto k-hat and 2-divergence diagnostics with mean / std / covariance error bounds
+    (``convenience.py:97-133``).  Returns a dict that also holds the samples and smoothed log weights."""
+    if objective is None:
+        if model is None or approx is None:
+            raise ValueError('either objective or both model and approx must be specified')
+    elif model is not None or approx is not None:
+        raise ValueError('model and/or approx cannot be specified if objective is')
+    else:
+        model, approx = objective.model, objective.approx
+    if n_samples <= 0:
+        raise ValueError('n_samples must be positive')
+    return _vi_diagnostics(var_param, model, approx, n_samples)
+
+
+def _vi_diagnostics(var_param, model, approx, n_samples):      # convenience.py:136-163
+    samples, smoothed_log_weights, khat = psis_correction(var_param, model, approx, n_samples)
+    results = dict(samples=samples, smoothed_log_weights=smoothed_log_weights, khat=khat)
+    print('Pareto k is estimated to be khat = {:.2f}'.format(khat))
+    if khat > 0.7:
+        print('WARNING: khat > 0.7 means importance sampling is not feasible.')
+        print('WARNING: not running further diagnostics')
+        return results
+    print()
+    moment_bound_fn = None
+    if approx.supports_pth_moment(2) and approx.supports_pth_moment(4):
+        def moment_bound_fn(p):
+            return approx.pth_moment(var_param, p)
+    _, q_var = approx.mean_and_cov(var_param)
+    # NB the reference hands all_diagnostics the (D, n) transpose that psis_correction returns; with
+    # pth_moment available (every in-scope family) the samples are not touched, so the orientation is moot
+    results.update(all_diagnostics(smoothed_log_weights, samples=samples, moment_bound_fn=moment_bound_fn,
+                                   q_var=q_var))
+    print('The 2-divergence is estimated to be d2 = {:.2g}'.format(results['d2']))
+    if results['d2'] > 4.6:
+        print('WARNING: d2 > 4.6 means the approximation is very inaccurate')
+    elif results['d2'] > 0.1:
+        print('WARNING: 0.1 < d2 < 4.6 means the approximation is somewhat '
+              'inaccurate. Use importance sampling to decrease error.')
+    else:
+        print('\nAll diagnostics pass.')
+    return results
+
+
+def psis_correction(var_param, model, approx, n_samples):
+    """Samples (transposed, as the reference returns them), PSIS-smoothed log weights and k-hat
+    (``convenience.py:166-169``).  For the mean-field families on an elementwise / funnel target the log
+    weights never leave the GPU between their evaluation and the smoothing."""
+    var_param = np.asarray(var_param, dtype=np.float64)
+    if _on_device_weights(model, approx):
+        eng = _lib.default_engine()
+        eng.set_model(model.device_spec())
+        noise = approx._base_noise(n_samples)
+        eng.noise_set_host(_DIAG_SLOT, noise)
+        family, df = approx._device_family()
+        eng.log_weights_meanfield(_DIAG_SLOT, n_samples, approx.dim, var_param, family, df=df, fetch=False)
+        smoothed, khat = eng.psis_smooth(n_samples)
+        samples = var_param[:approx.dim] + np.exp(var_param[approx.dim:]) * noise
+        return samples.T, smoothed, khat
+    samples, log_weights = samples_and_log_weights(var_param, model, approx, n_samples)
+    smoothed, khat = psislw(log_weights, overwrite_lw=True)
+    return samples.T, smoothed, khat
+
+
+_DIAG_SLOT = 2      # device noise slot used by the diagnostics (objectives use 0 and 1)
+
+
+def _on_device_weights(model, approx):
+    return (isinstance(approx, (MFGaussian, MFStudentT)) and isinstance(model, DeviceModel)
+            and model.device_spec()[0] in (_lib.MODEL_GAUSS_DIAG, _lib.MODEL_FUNNEL))
 
 
 def samples_and_log_weights(var_param, model, approx, n_samples):

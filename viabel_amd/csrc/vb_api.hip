@@ -209,7 +209,7 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
-                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work})
+                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& ev : ctx->prof_events) {
@@ -476,6 +476,50 @@ int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p
   VB_TRY(wait_ticket(ctx, rs.batch_id));
   *value = rs.host[rs.p];
   memcpy(grad, rs.host + rs.p + 1, (size_t)p * sizeof(double));
+  return VB_OK;
+}
+
+// ---- importance weights + PSIS (convenience.py:166-179, _psis.py:113-209) ---------------------------
+int vb_log_weights_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
+                             const double* theta, double* lw) {
+  if (!ctx || !theta) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (family != VB_FAMILY_MF_GAUSSIAN && family != VB_FAMILY_MF_STUDENT_T)
+    return fail(ctx, VB_ERR_INVALID, "family %d is not a mean-field family", family);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  ResultSlot& rs = ctx->sync_result;
+  VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
+  VB_TRY(log_weights_enqueue(ctx, ctx->noise[slot], n, d, family, df, rs.dev));
+  if (lw)
+    VB_HIP(ctx, hipMemcpyAsync(lw, ctx->psis_lw.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VB_OK;
+}
+
+int vb_psis_smooth(vb_ctx* ctx, const double* lw_in, int64_t n, double reff, double* lw_out, double* khat) {
+  if (!ctx || !lw_out || !khat) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (n <= 1) return fail(ctx, VB_ERR_INVALID, "More than one log-weight needed.");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  if (lw_in) {
+    VB_TRY(ensure(ctx, ctx->psis_lw, (size_t)(round_up(n, 16) + 16) * sizeof(double)));
+    VB_HIP(ctx, hipMemcpyAsync(ctx->psis_lw.ptr, lw_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice,
+                               ctx->stream));
+    ctx->psis_n = n;
+  } else if (ctx->psis_n != n) {
+    return fail(ctx, VB_ERR_STATE, "no device-resident log weights of length %lld (vb_log_weights_*)",
+                (long long)n);
+  }
+  VB_TRY(psis_enqueue(ctx, n, reff));
+  double res[4];
+  double* lw = (double*)ctx->psis_lw.ptr;
+  VB_HIP(ctx, hipMemcpyAsync(lw_out, lw, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipMemcpyAsync(res, lw + round_up(n, 16), sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->psis_n = 0;        // the resident weights have been smoothed in place
+  *khat = res[0];
   return VB_OK;
 }
 

@@ -108,6 +108,9 @@ struct vb_ctx {
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
   int64_t dis_n_total = 0;              // whole-job sample count of the DIS state
+  vb::DeviceBuffer rows_work;           // Model.__call__ for the dense targets: GEMM output rows
+  vb::DeviceBuffer psis_lw;             // PSIS: log importance weights (+ 16 result scalars)
+  int64_t psis_n = 0;                   // number of device-resident log weights (0: none)
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
@@ -179,6 +182,12 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
                         double* logp_host, double* logq_host);
 int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
                      const double* theta_src, const double* w_host, double scale, double* out);
+// vb_psis.hip
+int log_weights_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
+                        const double* theta_src);
+int psis_enqueue(vb_ctx* ctx, int64_t n, double reff);
+int psis_tail_size(int64_t n, double reff);
+
 int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, int family, double df,
                   double alpha, const double* theta_src, double* out);
 int sync_streams(vb_ctx* ctx);   // main + pipeline streams

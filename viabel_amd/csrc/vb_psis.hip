@@ -1,0 +1,289 @@
+// Pareto-smoothed importance sampling of N log weights on the device.
+// Reference: viabel/_psis.py:113-209 (psislw), :212-332 (gpdfitnew), :335-377 (gpinv), :380-396 (sumlogs);
+// caller viabel/convenience.py:166-179 (psis_correction / samples_and_log_weights).
+//
+// One workgroup of 1024 threads does the whole smoothing for one weight vector (N up to a few million; the
+// diagnostics use N = 1e5): max shift, exact selection of the tail cut-off (the (M+1)-th largest value,
+// M = ceil(min(0.2 N, 3 sqrt(N / Reff))), _psis.py:158) by an 8-pass byte-wise radix select on
+// order-preserving keys with an LDS histogram, gather + bitonic sort of the <= M tail values in LDS, the
+// Zhang-Stephens empirical-Bayes GPD fit (30 + sqrt(M) quadrature points), replacement of the tail by the
+// fitted quantiles, truncation at 0 and log-sum-exp normalisation.  Integer atomics only (histogram, gather
+// counter); the sorted order is by (value, index), so the result does not depend on the gather order.
+#include "vb_common.h"
+
+#include <cfloat>
+#include <cmath>
+
+namespace vb {
+
+constexpr int kPsisThreads = 1024;
+constexpr int kPsisTailCap = 4096;     // tail values sorted in LDS (M <= 4096  <=>  N <= 1.86e6 at Reff = 1)
+constexpr int kPsisQuadCap = 128;      // 30 + sqrt(4096) = 94 quadrature points at most
+
+__device__ __forceinline__ double ps_wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+__device__ __forceinline__ double ps_wave_max(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_down(x, off, 64));
+  return x;
+}
+
+// block-wide sum / max over 1024 threads; every thread gets the result (sh: 16 doubles + 1)
+__device__ double ps_block_sum(double x, double* sh) {
+  x = ps_wave_sum(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < kPsisThreads / 64; ++w) t += sh[w];
+  return t;
+}
+__device__ double ps_block_max(double x, double* sh) {
+  x = ps_wave_max(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+  __syncthreads();
+  double t = sh[0];
+#pragma unroll
+  for (int w = 1; w < kPsisThreads / 64; ++w) t = fmax(t, sh[w]);
+  return t;
+}
+
+__device__ __forceinline__ unsigned long long ps_key(double v) {   // ascending order-preserving key
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ps_unkey(unsigned long long k) {
+  const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+// (value, index) lexicographic "a after b"
+__device__ __forceinline__ bool ps_after(double av, int ai, double bv, int bi) {
+  return av > bv || (av == bv && ai > bi);
+}
+
+// lw = f - b + sum(log sigma): the log importance weights log p(z_n) - log q(z_n) of the mean-field families
+__global__ void __launch_bounds__(256) psis_lw_kernel(const double* __restrict__ f, const double* __restrict__ b,
+                                                      const double* __restrict__ scal, int64_t n,
+                                                      double* __restrict__ lw) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) lw[i] = f[i] - b[i] + scal[0];
+}
+
+// x: N log weights, smoothed in place.  out = [khat, n_tail, xcutoff (shifted), sigma]
+__global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__ x, int64_t n, int m_tail,
+                                                            double* __restrict__ out) {
+  __shared__ double sh[17];
+  __shared__ int hist[256];
+  __shared__ unsigned long long sel_prefix;
+  __shared__ long long sel_rank;
+  __shared__ int tail_count;
+  __shared__ double tv[kPsisTailCap];
+  __shared__ int ti[kPsisTailCap];
+  __shared__ double q_bs[kPsisQuadCap], q_ks[kPsisQuadCap], q_L[kPsisQuadCap], q_w[kPsisQuadCap];
+  __shared__ double bc[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+  // 1. improve numerical accuracy: x -= max(x)   (_psis.py:166)
+  double mx = -INFINITY;
+  for (int64_t i = t; i < n; i += kPsisThreads) mx = fmax(mx, x[i]);
+  mx = ps_block_max(mx, sh);
+  for (int64_t i = t; i < n; i += kPsisThreads) x[i] -= mx;
+  __syncthreads();
+
+  // 2. x_sorted[n - m_tail - 1] by radix select (8 bits per pass, most significant first)   (:170-173)
+  if (t == 0) {
+    sel_prefix = 0ull;
+    sel_rank = n - (long long)m_tail - 1;     // 0-based ascending rank
+  }
+  for (int pass = 7; pass >= 0; --pass) {
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const unsigned long long prefix = sel_prefix;
+    const unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+    for (int64_t i = t; i < n; i += kPsisThreads) {
+      const unsigned long long k = ps_key(x[i]);
+      if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> (8 * pass)) & 255ull)], 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+      long long r = sel_rank;
+      int bin = 0;
+      for (; bin < 255; ++bin) {
+        if (r < hist[bin]) break;
+        r -= hist[bin];
+      }
+      sel_rank = r;
+      sel_prefix = prefix | ((unsigned long long)bin << (8 * pass));
+    }
+    __syncthreads();
+  }
+  const double cutoffmin = log(DBL_MIN);                       // :159
+  const double xcutoff = fmax(ps_unkey(sel_prefix), cutoffmin);
+  const double expxc = exp(xcutoff);
+
+  // 3. right tail: x > xcutoff   (:175-177)
+  if (t == 0) tail_count = 0;
+  __syncthreads();
+  for (int64_t i = t; i < n; i += kPsisThreads) {
+    const double v = x[i];
+    if (v > xcutoff) {
+      const int p = atomicAdd(&tail_count, 1);
+      if (p < kPsisTailCap) {
+        tv[p] = v;
+        ti[p] = (int)i;
+      }
+    }
+  }
+  __syncthreads();
+  const int n2 = tail_count < kPsisTailCap ? tail_count : kPsisTailCap;
+  double k = INFINITY, sigma = NAN;
+  if (n2 > 4) {                                                 // :178-180
+    // 4. order of the tail samples: bitonic sort by (value, index), padded with +inf
+    int P = 1;
+    while (P < n2) P <<= 1;
+    for (int i = n2 + t; i < P; i += kPsisThreads) {
+      tv[i] = INFINITY;
+      ti[i] = 0x7fffffff;
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int e = t; e < (P >> 1); e += kPsisThreads) {
+          const int lo = ((e / stride) * 2 * stride) + (e % stride), hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          const double av = tv[lo], bv = tv[hi];
+          const int ai = ti[lo], bi = ti[hi];
+          if (ps_after(av, ai, bv, bi) == up) {
+            tv[lo] = bv, tv[hi] = av;
+            ti[lo] = bi, ti[hi] = ai;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // x2 = exp(x2) - exp(xcutoff)   (:185-186)
+    for (int i = t; i < n2; i += kPsisThreads) tv[i] = exp(tv[i]) - expxc;
+    __syncthreads();
+
+    // 5. gpdfitnew (:266-325): PRIOR = 3, m = 30 + int(sqrt(n2))
+    const int m = 30 + (int)sqrt((double)n2);
+    const double xq = tv[(int)(n2 / 4.0 + 0.5) - 1], xl = tv[n2 - 1];
+    if (t < m) q_bs[t] = (1.0 - sqrt((double)m / ((double)(t + 1) - 0.5))) / (3.0 * xq) + 1.0 / xl;
+    __syncthreads();
+    for (int j = wave; j < m; j += kPsisThreads / 64) {         // ks_j = mean log1p(-bs_j x)
+      const double nb = -q_bs[j];
+      double s = 0.0;
+      for (int i = lane; i < n2; i += 64) s += log1p(nb * tv[i]);
+      s = ps_wave_sum(s);
+      if (lane == 0) {
+        const double ks = s / n2;
+        q_ks[j] = ks;
+        q_L[j] = n2 * (log(-(q_bs[j] / ks)) - ks - 1.0);
+      }
+    }
+    __syncthreads();
+    if (t < m) {
+      double s = 0.0;
+      for (int i = 0; i < m; ++i) s += exp(q_L[i] - q_L[t]);
+      const double w = 1.0 / s;
+      q_w[t] = w >= 10.0 * DBL_EPSILON ? w : 0.0;                // remove negligible weights
+    }
+    __syncthreads();
+    if (t == 0) {
+      double ws = 0.0, bsum = 0.0;
+      for (int i = 0; i < m; ++i) ws += q_w[i];
+      for (int i = 0; i < m; ++i) bsum += q_bs[i] * (q_w[i] / ws);
+      bc[0] = bsum;                                              // posterior mean of b
+    }
+    __syncthreads();
+    const double b = bc[0];
+    double s = 0.0;
+    for (int i = t; i < n2; i += kPsisThreads) s += log1p(-b * tv[i]);
+    s = ps_block_sum(s, sh);
+    k = s / n2;
+    sigma = -k / b;
+    k = k * n2 / (n2 + 10.0) + 10.0 * 0.5 / (n2 + 10.0);        // weakly informative prior, a = 10
+
+    // 6. smoothed tail (:188-199): order statistics of the fitted GPD, truncated at the largest raw weight
+    if (k >= 1.0 / 3.0 && !isinf(k)) {
+      for (int i = t; i < n2; i += kPsisThreads) {
+        const double p = ((double)i + 0.5) / n2;
+        double qq = NAN;
+        if (sigma > 0.0) {
+          const double l = log1p(-p);
+          qq = (fabs(k) < DBL_EPSILON ? -l : expm1(-k * l) / k) * sigma;
+        }
+        double v = log(qq + expxc);
+        if (v > 0.0) v = 0.0;
+        x[ti[i]] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // 7. renormalise: x -= sumlogs(x)   (:201, :380-396)
+  double m2 = -INFINITY;
+  for (int64_t i = t; i < n; i += kPsisThreads) m2 = fmax(m2, x[i]);
+  m2 = ps_block_max(m2, sh);
+  double se = 0.0;
+  for (int64_t i = t; i < n; i += kPsisThreads) se += exp(x[i] - m2);
+  se = ps_block_sum(se, sh);
+  const double lse = log(se) + m2;
+  for (int64_t i = t; i < n; i += kPsisThreads) x[i] -= lse;
+  if (t == 0) {
+    out[0] = k;
+    out[1] = (double)tail_count;
+    out[2] = xcutoff;
+    out[3] = sigma;
+  }
+}
+
+// log importance weights of the mean-field families for the noise staged in `ns`; left in ctx->psis_lw
+int log_weights_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
+                        const double* theta_src) {
+  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "row-statistics path supports the gauss_diag and funnel models");
+  if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  const int student = family == VB_FAMILY_MF_STUDENT_T;
+  const int64_t o_scal = 2 * ns.ld, o_f = o_scal + 16, o_b = o_f + round_up(n, 16);
+  VB_TRY(ensure(ctx, ctx->rowvec, (size_t)(o_b + round_up(n, 16)) * sizeof(double)));
+  VB_TRY(ensure(ctx, ctx->psis_lw, (size_t)(round_up(n, 16) + 16) * sizeof(double)));
+  double* base = (double*)ctx->rowvec.ptr;
+  VB_TRY(rowstats_enqueue(ctx, ns, n, d, theta_src, ctx->model, student, df, base, base + o_scal, base + o_f,
+                          base + o_b));
+  hipLaunchKernelGGL(psis_lw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const double*)(base + o_f), (const double*)(base + o_b), (const double*)(base + o_scal), n,
+                     (double*)ctx->psis_lw.ptr);
+  VB_HIP(ctx, hipGetLastError());
+  ctx->psis_n = n;
+  return VB_OK;
+}
+
+int psis_tail_size(int64_t n, double reff) {   // _psis.py:158
+  const double a = 0.2 * (double)n, b = 3.0 * sqrt((double)n / reff);
+  return (int)ceil(a < b ? a : b);
+}
+
+// smooth the n log weights in ctx->psis_lw in place; out_dev = [khat, n_tail, xcutoff, sigma]
+int psis_enqueue(vb_ctx* ctx, int64_t n, double reff) {
+  if (n <= 1) return fail(ctx, VB_ERR_INVALID, "More than one log-weight needed.");
+  if (!(reff > 0.0)) return fail(ctx, VB_ERR_INVALID, "Reff must be positive");
+  const int m_tail = psis_tail_size(n, reff);
+  if (m_tail > kPsisTailCap)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "PSIS tail of %d values exceeds the on-chip sort capacity %d", m_tail,
+                kPsisTailCap);
+  double* lw = (double*)ctx->psis_lw.ptr;
+  hipLaunchKernelGGL(psis_kernel, dim3(1), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail,
+                     lw + round_up(n, 16));
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+}  // namespace vb

@@ -5,6 +5,7 @@
 // per-sample log weights (objectives.py:394-395, :445).  One wave per row, lanes stride the
 // columns (coalesced), DPP/shuffle reduction over the wave.
 #include "vb_common.h"
+#include "vb_gemm_f64.h"
 
 namespace vb {
 
@@ -42,10 +43,101 @@ __global__ void __launch_bounds__(256) model_logp_rows_kernel(const double* __re
   if (lane == 0) out[row] = acc + m.c0;
 }
 
+// ---- dense targets: f needs a GEMM -----------------------------------------------------------------
+struct EpiStoreRows {        // Y = acc
+  double* Y;
+  int64_t ldy;
+  __device__ void operator()(int, int row, int col, double acc) const { Y[(int64_t)row * ldy + col] = acc; }
+};
+
+struct EpiLogLikTerm {       // T = y eta - log(1 + exp(eta)), eta = acc
+  double* T;
+  int64_t ldt;
+  const double* y;
+  __device__ void operator()(int, int row, int col, double eta) const {
+    const double t = exp(-fabs(eta));
+    T[(int64_t)row * ldt + col] = y[col] * eta - (fmax(eta, 0.0) + log1p(t));
+  }
+};
+
+__global__ void __launch_bounds__(256) rows_center_kernel(const double* __restrict__ x, int64_t ld, int64_t n,
+                                                          int d, const double* __restrict__ mean,
+                                                          double* __restrict__ xc) {
+  const int64_t row = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < ld) xc[row * ld + c] = c < d ? x[row * ld + c] - mean[c] : 0.0;
+}
+
+// out[row] = scale * sum_c a[row][c] * (b ? b[row][c] : 1) + add_sq * sum_c sq[row][c]^2 + c0
+__global__ void __launch_bounds__(256) rows_dot_kernel(const double* __restrict__ a, int64_t lda,
+                                                       const double* __restrict__ b, int64_t ldb, int width,
+                                                       double scale, const double* __restrict__ sq, int64_t ldsq,
+                                                       int sq_width, double add_sq, double c0, int64_t n,
+                                                       double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  double acc = 0.0, s2 = 0.0;
+  for (int c = lane; c < width; c += 64) acc += a[row * lda + c] * (b ? b[row * ldb + c] : 1.0);
+  if (sq)
+    for (int c = lane; c < sq_width; c += 64) s2 = fma(sq[row * ldsq + c], sq[row * ldsq + c], s2);
+  acc = wave_sum_rows(acc);
+  s2 = wave_sum_rows(s2);
+  if (lane == 0) out[row] = fma(scale, acc, fma(add_sq, s2, c0));
+}
+
+// gauss_full: f = -1/2 (x - m)' P (x - m) + c0
+static int gauss_full_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev) {
+  const ModelDev& m = ctx->model;
+  hipStream_t st = ctx->stream;
+  VB_TRY(ensure(ctx, ctx->rows_work, (size_t)2 * n * ld * sizeof(double)));
+  double* Xc = (double*)ctx->rows_work.ptr;
+  double* Y = Xc + n * ld;
+  hipLaunchKernelGGL(rows_center_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)n), dim3(256), 0, st, x_dev, ld,
+                     n, (int)d, m.p0, Xc);
+  VB_HIP(ctx, hipGetLastError());
+  GemmArgs g;
+  g.A = Xc, g.lda = ld, g.B = m.p1, g.ldb = m.ldp;
+  g.M = (int)n, g.N = (int)d, g.K = (int)d, g.tri_mode = 0;
+  gemm_f64_launch<true>(st, g, 1, ctx->prop.multiProcessorCount, EpiStoreRows{Y, ld});
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)Xc, ld,
+                     (const double*)Y, ld, (int)d, -0.5, (const double*)nullptr, (int64_t)0, 0, 0.0, m.c0, n, out_dev);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+// logistic: f(b) = sum_i [y_i eta_i - log(1 + exp(eta_i))] - |b|^2 / (2 sd^2) + c0, eta = X b; row chunks bound
+// the n x n_data term matrix to 512 MB
+static int logistic_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev) {
+  const ModelDev& m = ctx->model;
+  hipStream_t st = ctx->stream;
+  const int64_t ldt = m.ldq;
+  int64_t chunk = ((int64_t)64 << 20) / ldt;
+  chunk = chunk < 128 ? 128 : (chunk > n ? n : chunk);
+  VB_TRY(ensure(ctx, ctx->rows_work, (size_t)chunk * ldt * sizeof(double)));
+  double* T = (double*)ctx->rows_work.ptr;
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t rows = n - r0 < chunk ? n - r0 : chunk;
+    GemmArgs g;
+    g.A = x_dev + r0 * ld, g.lda = ld, g.B = m.p1, g.ldb = m.ldq;
+    g.M = (int)rows, g.N = (int)m.n_data, g.K = (int)d, g.tri_mode = 0;
+    gemm_f64_launch<true>(st, g, 1, ctx->prop.multiProcessorCount, EpiLogLikTerm{T, ldt, m.p2});
+    VB_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const double*)T, ldt,
+                       (const double*)nullptr, (int64_t)0, (int)m.n_data, 1.0, x_dev + r0 * ld, ld, (int)d,
+                       -0.5 / (m.tau * m.tau), m.c0, rows, out_dev + r0);
+    VB_HIP(ctx, hipGetLastError());
+  }
+  return VB_OK;
+}
+
 int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d,
                     double* out_dev) {
+  if (ctx->model.id == VB_MODEL_GAUSS_FULL) return gauss_full_rows(ctx, x_dev, ld, n, d, out_dev);
+  if (ctx->model.id == VB_MODEL_LOGISTIC) return logistic_rows(ctx, x_dev, ld, n, d, out_dev);
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
-    return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density implements gauss_diag and funnel");
+    return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density: unknown model id %d", ctx->model.id);
   const unsigned grid = (unsigned)((n + 3) / 4);
   hipLaunchKernelGGL(model_logp_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, x_dev, ld, n,
                      (int)d, ctx->model, out_dev);
