@@ -165,6 +165,15 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
 int vb_dis_grad_mvt(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* l_inv,
                     const double* weights, double* w_sum, double* w_logq, double* d_mu, double* gram);
 
+/* ---- ExclusiveKL, low-rank-plus-diagonal Gaussian family ------------------------------
+ * LRGaussian, viabel/approximations.py:610-731: theta = [mu (D) | log_sigma (D) | B (D x k, row-major)],
+ * x = mu + z B' + sigma * eps with z (n x k, slot_z) drawn before eps (n x D, slot_eps) (:636-644);
+ * entropy via the matrix determinant lemma (:559-573, :646-652); estimator objectives.py:154-164
+ * (entropy form; flags must be 0).  grad has 2 D + D k entries in the theta layout.  1 <= k <= 16.  */
+int vb_elbo_grad_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k,
+                         int64_t n_total, const double* theta, unsigned flags, double* value,
+                         double* grad);
+
 /* ---- Importance weights and Pareto smoothing (diagnostics) ----------------------------
  * vb_log_weights_meanfield: log p(z_n) - log q(z_n; theta) for the samples z = mu + sigma * eps of
  * the noise staged in `slot` -- samples_and_log_weights, viabel/convenience.py:176-179.  The

@@ -349,3 +349,52 @@ class MultivariateT:
         if p == 2:
             return c * np.sum(sq)
         return c ** 2 * (2 * (df - 1) / (df - 4) * np.sum(sq ** 2) + np.sum(sq) ** 2)
+
+
+class LRGaussian:
+    """approximations.py:610-731: theta = [mu | log_sigma | B (D x k row-major)], x = mu + z B' + sigma eps."""
+
+    def __init__(self, dim, k):
+        self.dim, self.k = dim, k
+        self.var_param_dim = 2 * dim + dim * k
+
+    def split(self, theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        D = self.dim
+        return theta[:D], theta[D:2 * D], theta[2 * D:].reshape(D, self.k)
+
+    def draw_noise(self, rs, n):                  # :639-640: z first, then eps
+        z = rs.randn(n, self.k)
+        return z, rs.randn(n, self.dim)
+
+    def sample_from_noise(self, theta, noise):    # :636-644
+        mu, ls, B = self.split(theta)
+        z, eps = noise
+        return mu + z @ B.T + np.exp(ls) * eps
+
+    def cov(self, theta):                         # :709-713
+        _, ls, B = self.split(theta)
+        return B @ B.T + np.diag(np.exp(2 * ls))
+
+    def entropy(self, theta):                     # :646-652
+        return 0.5 * self.dim * (np.log(2 * np.pi) + 1) + 0.5 * np.linalg.slogdet(self.cov(theta))[1]
+
+    def log_density(self, theta, x):              # :685-707 (dense inverse instead of Woodbury)
+        mu = self.split(theta)[0]
+        S = self.cov(theta)
+        diff = np.atleast_2d(x) - mu
+        maha = np.sum(diff * np.linalg.solve(S, diff.T).T, axis=1)
+        return -0.5 * (self.dim * np.log(2 * np.pi) + np.linalg.slogdet(S)[1] + maha)
+
+    def kl(self, theta0, theta1):                 # :654-682
+        mu0, mu1 = self.split(theta0)[0], self.split(theta1)[0]
+        S0, S1 = self.cov(theta0), self.cov(theta1)
+        dm = mu0 - mu1
+        return 0.5 * (np.linalg.slogdet(S1)[1] - np.linalg.slogdet(S0)[1] - self.dim
+                      + dm @ np.linalg.solve(S1, dm) + np.trace(np.linalg.solve(S1, S0)))
+
+    def entropy_grad(self, theta):
+        """d entropy / d theta: [0 | diag(Sigma^-1) sigma^2 | Sigma^-1 B]."""
+        _, ls, B = self.split(theta)
+        Sinv = np.linalg.inv(self.cov(theta))
+        return np.concatenate([np.zeros(self.dim), np.diag(Sinv) * np.exp(2 * ls), (Sinv @ B).reshape(-1)])

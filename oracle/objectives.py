@@ -35,6 +35,10 @@ def exclusive_kl(family, model, theta, noise, use_path_deriv=False):
         return _exclusive_kl_fullrank(family, model, theta, noise, use_path_deriv)
     if isinstance(family, fam.MultivariateT):
         raise NotImplementedError('MultivariateT + ExclusiveKL needs d sqrtm / d theta')
+    if isinstance(family, fam.LRGaussian):
+        if use_path_deriv:
+            raise NotImplementedError('path derivative for LRGaussian')
+        return _exclusive_kl_lowrank(family, model, theta, noise)
     D = family.dim
     mu, ls = family.split(theta)
     sig = np.exp(ls)
@@ -51,6 +55,20 @@ def exclusive_kl(family, model, theta, noise, use_path_deriv=False):
         value = -(np.mean(f) + family.entropy(theta))
         grad = -np.concatenate([g.mean(0), (g * noise * sig).mean(0) + 1.0])
     return value, grad
+
+
+def _exclusive_kl_lowrank(family, model, theta, noise):
+    """Entropy form (objectives.py:160-164) for LRGaussian: d/dmu = -mean g, d/dlog_sigma = -mean(g eps) sigma,
+    d/dB = -mean g z', minus the entropy gradient."""
+    theta = np.asarray(theta, dtype=np.float64)
+    z, eps = noise
+    _, ls, _ = family.split(theta)
+    x = family.sample_from_noise(theta, noise)
+    g = model.grad(x)
+    N = x.shape[0]
+    value = -(np.mean(model.logp(x)) + family.entropy(theta))
+    data = np.concatenate([g.sum(0), (g * eps).sum(0) * np.exp(ls), (g.T @ z).reshape(-1)]) / N
+    return value, -(data + family.entropy_grad(theta))
 
 
 def _exclusive_kl_fullrank(family, model, theta, eps, use_path_deriv):

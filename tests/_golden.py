@@ -51,3 +51,7 @@ def noise_of(fx):
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
     return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def ids(paths):
+    return [os.path.splitext(os.path.basename(p))[0] for p in paths]

@@ -503,12 +503,60 @@ def gen_psis():
          **out)
 
 
+def gen_lowrank():
+    """LRGaussian (viabel/approximations.py:610-731): forward methods of the reference and its ExclusiveKL
+    closure (value exact, gradient by Richardson differences of the reference closure)."""
+    rng = np.random.RandomState(61)
+    worst = 0.0
+    for D, k in ((3, 1), (6, 2), (10, 4), (17, 5), (12, 9)):
+        seed, N = 7, 40
+        ref = ref_approx.LRGaussian(D, seed=seed, k=k)
+        orc = ofam.LRGaussian(D, k)
+        init = ref.init_param()                      # consumes D k draws of the family's stream
+        th0 = np.concatenate([0.3 * rng.randn(D), -0.4 + 0.3 * rng.randn(D), 0.4 * rng.randn(D * k)])
+        th1 = np.concatenate([0.3 * rng.randn(D), -0.2 + 0.3 * rng.randn(D), 0.4 * rng.randn(D * k)])
+        state = ref._rs.get_state()
+        x = ref.sample(th0, N)
+        rs = np.random.RandomState(seed)
+        rs.set_state(state)
+        noise = orc.draw_noise(rs, N)
+        assert rel_err(orc.sample_from_noise(th0, noise), x) < 1e-13
+        lq, ent, kl = ref.log_density(th1, x), ref.entropy(th0), ref.kl(th0, th1)
+        mean, cov = ref.mean_and_cov(th0)
+        assert rel_err(orc.log_density(th1, x), lq) < 1e-12 and rel_err(orc.entropy(th0), ent) < 1e-12
+        assert rel_err(orc.kl(th0, th1), kl) < 1e-11 and rel_err(orc.cov(th0), cov) < 1e-13
+        out = dict(dim=D, k=k, seed=seed, n=N, init_param=init, theta0=th0, theta1=th1, noise_z=noise[0],
+                   noise_eps=noise[1], samples=x, log_density=lq, entropy=ent, kl=kl, mean=mean, cov=cov,
+                   pth2=ref.pth_moment(th0, 2), pth4=ref.pth_moment(th0, 4))
+        for mi, mspec in enumerate(model_specs(D, rng)):
+            log_p, omodel = make_model(mspec)
+            ref2 = ref_approx.LRGaussian(D, seed=seed, k=k)
+            objective = ref_obj.ExclusiveKL(ref2, log_p, N)
+            _ref_stubs.STATE['before_eval'] = snapshot_hook(ref2)
+            value, grad_fd = objective(th0)
+            _ref_stubs.STATE['before_eval'] = None
+            noise2 = orc.draw_noise(np.random.RandomState(seed), N)
+            ov, og = oobj.exclusive_kl(orc, omodel, th0, noise2)
+            assert rel_err(ov, value) < 1e-12, (D, k, ov, value)
+            e = rel_err(og, grad_fd)
+            worst = max(worst, e)
+            assert e < 2e-7, (D, k, mspec['kind'], e)
+            tag = 'm%d_' % mi
+            out.update({tag + key: val for key, val in spec_arrays({'kind': 'lr_gaussian', 'dim': D}, mspec).items()})
+            out.update({tag + 'noise_z': noise2[0], tag + 'noise_eps': noise2[1], tag + 'value': value,
+                        tag + 'grad_fd': grad_fd, tag + 'grad': og})
+        save('lowrank_d%d_k%d' % (D, k), **out,
+             provenance='reference LRGaussian forward code and ExclusiveKL closure via the autograd->numpy alias; '
+                        'grad_fd: Richardson differences of the reference closure; grad: analytic (oracle)')
+    print('LRGaussian ExclusiveKL: worst analytic-vs-FD(reference) grad rel err %.2e' % worst)
+
+
 GENERATORS = {}
 
 if __name__ == '__main__':
     GENERATORS.update(torch=gen_torch_crosscheck, family=gen_family_forward, ekl=gen_exclusive_kl, rge=gen_rge,
                       alpha=gen_alpha, dis=gen_dis, chainstats=gen_chain_stats, optimizers=gen_optimizers,
-                      psis=gen_psis)
+                      psis=gen_psis, lowrank=gen_lowrank)
     picked = sys.argv[1:]          # e.g. `make_golden.py psis optimizers` regenerates only those fixtures
     if not picked:
         for f in os.listdir(HERE):

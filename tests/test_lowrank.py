@@ -1,0 +1,107 @@
+"""LRGaussian (viabel/approximations.py:610-731): oracle and host-side family against the reference's own forward
+code (tests/golden/lowrank_*.npz), and the HIP ExclusiveKL path against the reference closure / the oracle.
+
+Tolerances: forward values 1e-11 relative; device value 1e-12, gradient 1e-11 relative to max|grad|; 2e-7 against
+the reference's finite-difference gradients.
+"""
+import numpy as np
+import pytest
+
+import _golden as G
+from oracle import families as ofam
+from oracle import models as omod
+from oracle import objectives as oobj
+
+FIXTURES = G.fixtures('lowrank_')
+
+
+def _models(fx, tag, vb=None):
+    if str(fx[tag + 'model_kind']) == 'gauss_diag':
+        o = omod.GaussDiag(fx[tag + 'model_mean'], fx[tag + 'model_stdev'])
+        p = vb.GaussianModel(fx[tag + 'model_mean'], fx[tag + 'model_stdev']) if vb else None
+    else:
+        D = int(fx['dim'])
+        o = omod.Funnel(D, int(fx[tag + 'model_scale_index']), float(fx[tag + 'model_log_sigma_stdev']))
+        p = vb.FunnelModel(D, int(fx[tag + 'model_scale_index']), float(fx[tag + 'model_log_sigma_stdev'])) if vb else None
+    return o, p
+
+
+@pytest.mark.parametrize('path', FIXTURES, ids=G.ids(FIXTURES))
+def test_oracle_and_host_family_match_reference(path):
+    import viabel_amd as vb
+    fx = G.load(path)
+    D, k, seed, N = int(fx['dim']), int(fx['k']), int(fx['seed']), int(fx['n'])
+    th0, th1, x = fx['theta0'], fx['theta1'], fx['samples']
+    orc = ofam.LRGaussian(D, k)
+    fam = vb.LRGaussian(D, seed=seed, k=k)
+    np.testing.assert_allclose(fam.init_param(), fx['init_param'], rtol=1e-15)   # same D k draws
+    np.testing.assert_allclose(fam.sample(th0, N), x, rtol=1e-13, atol=1e-14)    # next: z then eps
+    for f in (orc, fam):
+        np.testing.assert_allclose(f.log_density(th1, x), fx['log_density'], rtol=1e-11)
+        np.testing.assert_allclose(f.entropy(th0), float(fx['entropy']), rtol=1e-12)
+        np.testing.assert_allclose(f.kl(th0, th1), float(fx['kl']), rtol=1e-10)
+    np.testing.assert_allclose(orc.sample_from_noise(th0, (fx['noise_z'], fx['noise_eps'])), x, rtol=1e-13, atol=1e-14)
+    mean, cov = fam.mean_and_cov(th0)
+    np.testing.assert_allclose(mean, fx['mean'], rtol=0, atol=0)
+    np.testing.assert_allclose(cov, fx['cov'], rtol=1e-13)
+    np.testing.assert_allclose(fam.pth_moment(th0, 2), float(fx['pth2']), rtol=1e-12)
+    np.testing.assert_allclose(fam.pth_moment(th0, 4), float(fx['pth4']), rtol=1e-12)
+    assert fam.var_param_dim == 2 * D + D * k and fam.supports_kl and fam.supports_entropy
+    assert fam.log_density(th1, x[0]).shape == (1,)
+    for m in (0, 1):
+        tag = 'm%d_' % m
+        omodel, _ = _models(fx, tag)
+        ov, og = oobj.exclusive_kl(orc, omodel, th0, (fx[tag + 'noise_z'], fx[tag + 'noise_eps']))
+        assert abs(ov - float(fx[tag + 'value'])) <= 1e-12 * abs(float(fx[tag + 'value']))
+        np.testing.assert_allclose(og, fx[tag + 'grad'], rtol=0, atol=1e-13 * np.max(np.abs(og)))
+        np.testing.assert_allclose(og, fx[tag + 'grad_fd'], rtol=0, atol=2e-7 * np.max(np.abs(og)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', FIXTURES, ids=G.ids(FIXTURES))
+def test_device_exclusive_kl_matches_reference(path):
+    import viabel_amd as vb
+    fx = G.load(path)
+    D, k, seed, N = int(fx['dim']), int(fx['k']), int(fx['seed']), int(fx['n'])
+    for m in (0, 1):
+        tag = 'm%d_' % m
+        _, model = _models(fx, tag, vb)
+        objective = vb.ExclusiveKL(vb.LRGaussian(D, seed=seed, k=k), model, N)
+        value, grad = objective(fx['theta0'])
+        ref_v, ref_g = float(fx[tag + 'value']), fx[tag + 'grad']
+        assert abs(value - ref_v) <= 1e-12 * abs(ref_v), (value, ref_v)
+        np.testing.assert_allclose(grad, ref_g, rtol=0, atol=1e-11 * np.max(np.abs(ref_g)))
+        np.testing.assert_allclose(grad, fx[tag + 'grad_fd'], rtol=0, atol=2e-7 * np.max(np.abs(ref_g)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('target', ['gauss_diag', 'funnel'])
+@pytest.mark.parametrize('D,k,N', [(1024, 8, 4096), (1000, 16, 777), (130, 3, 1), (257, 5, 1030), (64, 1, 300)])
+def test_device_exclusive_kl_matches_oracle(target, D, k, N):
+    """BASELINE-sized and ragged shapes (odd D, N not a multiple of the row tile, N = 1, k = 1 .. 16)."""
+    import viabel_amd as vb
+    rng = np.random.RandomState(D + k)
+    if target == 'gauss_diag':
+        mean, sd = rng.randn(D), np.exp(0.3 * rng.randn(D))
+        model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    else:
+        model, omodel = vb.FunnelModel(D, D // 3), omod.Funnel(D, D // 3)
+    fam = vb.LRGaussian(D, seed=4, k=k)
+    theta = fam.pack(0.2 * rng.randn(D), -1.0 + 0.1 * rng.randn(D), 0.1 * rng.randn(D, k))
+    value, grad = vb.ExclusiveKL(fam, model, N)(theta)
+    noise = ofam.LRGaussian(D, k).draw_noise(np.random.RandomState(4), N)
+    ov, og = oobj.exclusive_kl(ofam.LRGaussian(D, k), omodel, theta, noise)
+    assert abs(value - ov) <= 1e-12 * abs(ov), (value, ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-11 * np.max(np.abs(og)))
+
+
+@pytest.mark.gpu
+def test_lowrank_rejects_unsupported():
+    import viabel_amd as vb
+    model = vb.GaussianModel(np.zeros(4), np.ones(4))
+    with pytest.raises(NotImplementedError):
+        vb.ExclusiveKL(vb.LRGaussian(4, k=2), model, 10, use_path_deriv=True)
+    with pytest.raises(NotImplementedError):
+        vb.ExclusiveKL(vb.LRGaussian(4, k=17), model, 10)(np.zeros(4 * 2 + 4 * 17))
+    with pytest.raises(ValueError):
+        vb.ExclusiveKL(vb.LRGaussian(4, k=2), model, 10)(np.zeros(3))

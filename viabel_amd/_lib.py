@@ -58,6 +58,9 @@ SIGNATURES = {
                                                           ctypes.c_int, ctypes.c_double, _c_double_p,
                                                           ctypes.c_uint, ctypes.c_int,
                                                           ctypes.POINTER(ctypes.c_int)]),
+    'vb_elbo_grad_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_uint, _c_double_p,
+                                            _c_double_p]),
     'vb_log_weights_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                 ctypes.c_double, _c_double_p, _c_double_p]),
     'vb_psis_smooth': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_double, _c_double_p,
@@ -273,6 +276,16 @@ class Engine:
         value = ctypes.c_double(0.0)
         grad = np.empty(p, dtype=np.float64)
         self._check(self._lib.vb_result_get(self._ctx, rslot, ctypes.byref(value), _dptr(grad), p))
+        return value.value, grad
+
+    # ------------------------------------------------------------------ ExclusiveKL, low-rank Gaussian
+    def elbo_grad_lowrank(self, slot_eps, slot_z, n, d, k, theta, flags=0, n_total=None):
+        theta = _f64(theta)
+        value = ctypes.c_double(0.0)
+        grad = np.empty(2 * d + d * k, dtype=np.float64)
+        self._check(self._lib.vb_elbo_grad_lowrank(self._ctx, slot_eps, slot_z, n, d, k,
+                                                   n if n_total is None else n_total, _dptr(theta), flags,
+                                                   ctypes.byref(value), _dptr(grad)))
         return value.value, grad
 
     # ------------------------------------------------------------------ importance weights, PSIS

@@ -25,7 +25,7 @@ from scipy import special as _special
 
 from . import _lib
 
-__all__ = ['ApproximationFamily', 'MFGaussian', 'MFStudentT', 'MultivariateT', 'FullRankGaussian']
+__all__ = ['ApproximationFamily', 'MFGaussian', 'MFStudentT', 'MultivariateT', 'FullRankGaussian', 'LRGaussian']
 
 _LOG_2PI = float(np.log(2.0 * np.pi))
 
@@ -420,6 +420,95 @@ class MultivariateT(_NoiseMixin, ApproximationFamily):
     @property
     def df(self):
         return self._df
+
+
+class LRGaussian(_NoiseMixin, ApproximationFamily):
+    """Gaussian with covariance ``B B' + diag(sigma^2)`` (``viabel/approximations.py:610-731``).
+
+    ``var_param = [mu (D) | log_sigma (D) | B (D x k, row-major)]`` (``:551-556``).  All dense algebra goes
+    through the k x k capacitance matrix ``M = I + B' D^-1 B`` (Woodbury / determinant lemma), as in the
+    reference's helpers (``:559-607``).
+    """
+
+    def __init__(self, dim, seed=1, k=0, rng='numpy'):
+        if rng != 'numpy':
+            raise NotImplementedError("LRGaussian draws its two noise blocks from the numpy stream (rng='numpy')")
+        self._init_rng(seed, rng)
+        self._k = int(k)
+        super().__init__(dim, 2 * dim + dim * self._k, True, True)
+
+    @property
+    def k(self):
+        return self._k
+
+    def _unpack(self, var_param):
+        v = np.asarray(var_param, dtype=np.float64)
+        D, k = self.dim, self._k
+        return v[:D], v[D:2 * D], v[2 * D:].reshape(D, k)
+
+    def pack(self, mu, log_sigma, B):
+        return np.concatenate([np.asarray(mu, dtype=np.float64), np.asarray(log_sigma, dtype=np.float64),
+                               np.asarray(B, dtype=np.float64).reshape(-1)])
+
+    def _base_noise(self, n_samples, seed=None):
+        """``(z, eps)``: the low-rank block is drawn first (``:639-640``)."""
+        rs = self._random_state(seed)
+        z = rs.randn(n_samples, self._k)
+        return z, rs.randn(n_samples, self.dim)
+
+    def init_param(self):          # :630-634 (advances the family's stream by D k draws)
+        return self.pack(np.zeros(self.dim), np.ones(self.dim), self._rs.randn(self.dim, self._k))
+
+    def sample(self, var_param, n_samples, seed=None):
+        mu, ls, B = self._unpack(var_param)
+        z, eps = self._base_noise(n_samples, seed)
+        return mu + z @ B.T + np.exp(ls) * eps
+
+    def _capacitance(self, ls, B):
+        w = B * np.exp(-2.0 * ls)[:, np.newaxis]                 # D^-1 B
+        return w, np.eye(self._k) + B.T @ w
+
+    def _log_det(self, ls, B):
+        _, M = self._capacitance(ls, B)
+        return 2.0 * np.sum(ls) + np.linalg.slogdet(M)[1]
+
+    def _entropy(self, var_param):
+        _, ls, B = self._unpack(var_param)
+        return 0.5 * self.dim * (_LOG_2PI + 1.0) + 0.5 * self._log_det(ls, B)
+
+    def _solve(self, ls, B, rhs):
+        """``Sigma^-1 rhs`` for ``rhs`` of shape (D, m)."""
+        w, M = self._capacitance(ls, B)
+        y = rhs * np.exp(-2.0 * ls)[:, np.newaxis]
+        return y - w @ np.linalg.solve(M, w.T @ rhs)
+
+    def _kl(self, var_param0, var_param1):
+        mu0, ls0, B0 = self._unpack(var_param0)
+        mu1, ls1, B1 = self._unpack(var_param1)
+        dm = (mu0 - mu1)[:, np.newaxis]
+        # tr(Sigma1^-1 Sigma0) = tr(Sigma1^-1 diag(s0^2)) + tr(B0' Sigma1^-1 B0)
+        w1, M1 = self._capacitance(ls1, B1)
+        inv_diag = np.exp(-2.0 * ls1) - np.sum(w1 * np.linalg.solve(M1, w1.T).T, axis=1)
+        trace = np.sum(inv_diag * np.exp(2.0 * ls0)) + np.sum(B0 * self._solve(ls1, B1, B0))
+        maha = (dm.T @ self._solve(ls1, B1, dm)).item()
+        return 0.5 * (self._log_det(ls1, B1) - self._log_det(ls0, B0) - self.dim + maha + trace)
+
+    def log_density(self, var_param, x):
+        mu, ls, B = self._unpack(var_param)
+        diff = (_as_rows(x) - mu).T
+        maha = np.sum(diff * self._solve(ls, B, diff), axis=0)
+        return -0.5 * (self.dim * _LOG_2PI + self._log_det(ls, B) + maha)
+
+    def mean_and_cov(self, var_param):
+        mu, ls, B = self._unpack(var_param)
+        return mu, B @ B.T + np.diag(np.exp(2.0 * ls))
+
+    def _pth_moment(self, var_param, p):
+        ev = np.linalg.eigvalsh(self.mean_and_cov(var_param)[1])
+        return np.sum(ev) if p == 2 else 2 * np.sum(ev ** 2) + np.sum(ev) ** 2
+
+    def supports_pth_moment(self, p):
+        return p in [2, 4]
 
 
 def _philox_host_copy(family, n_samples, seed):

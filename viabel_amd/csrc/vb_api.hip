@@ -209,7 +209,7 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
-                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work})
+                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work, &ctx->lr_work})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& ev : ctx->prof_events) {
@@ -474,6 +474,30 @@ int vb_result_get(vb_ctx* ctx, int rslot, double* value, double* grad, int64_t p
     return fail(ctx, VB_ERR_STATE, "result slot %d holds no pending result of size %lld", rslot,
                 (long long)p);
   VB_TRY(wait_ticket(ctx, rs.batch_id));
+  *value = rs.host[rs.p];
+  memcpy(grad, rs.host + rs.p + 1, (size_t)p * sizeof(double));
+  return VB_OK;
+}
+
+// ---- ExclusiveKL, low-rank Gaussian family (approximations.py:610-731) ------------------------------
+int vb_elbo_grad_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, int64_t n_total,
+                         const double* theta, unsigned flags, double* value, double* grad) {
+  if (!ctx || !theta || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot_eps));
+  VB_TRY(check_slot(ctx, slot_z));
+  if (slot_eps == slot_z) return fail(ctx, VB_ERR_INVALID, "eps and z need different noise slots");
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot_eps].buf.ptr || !ctx->noise[slot_z].buf.ptr)
+    return fail(ctx, VB_ERR_STATE, "noise slot is empty");
+  if (flags != 0) return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank family: only the entropy-form estimator is implemented");
+  if (d <= 0 || k <= 0) return fail(ctx, VB_ERR_INVALID, "d and k must be positive");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t p = 2 * d + d * k;
+  ResultSlot& rs = ctx->sync_result;
+  VB_TRY(stage_theta(ctx, rs, theta, p));
+  VB_TRY(lr_elbo_grad_enqueue(ctx, ctx->noise[slot_eps], ctx->noise[slot_z], n, d, k, n_total, rs.dev, rs.dev + rs.p));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rs.pending = false;
   *value = rs.host[rs.p];
   memcpy(grad, rs.host + rs.p + 1, (size_t)p * sizeof(double));
   return VB_OK;

@@ -17,7 +17,7 @@ from abc import ABC, abstractmethod
 import numpy as np
 
 from . import _lib
-from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT
+from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT, LRGaussian
 from .models import DeviceModel
 
 __all__ = [
@@ -30,6 +30,7 @@ __all__ = [
 
 _NOISE_SLOT = 0
 _DIS_SLOT = 1      # DIS keeps its state samples (as base noise) in a slot of its own
+_LR_SLOT = 3       # low-rank family: the n x k block of its noise (slot 2 belongs to the diagnostics)
 
 
 def shard_rows(n, n_ranks, rank):
@@ -178,10 +179,27 @@ class ExclusiveKL(StochasticVariationalObjective):
                 n_local, n_total = self._stage_noise(eng, self.num_mc_samples)
                 return eng.elbo_grad_fullrank(_NOISE_SLOT, n_local, approx.dim, var_param,
                                               flags=flags, n_total=n_total)
+        elif isinstance(approx, LRGaussian):
+            if cv_mode != 0 or self._use_path_deriv:
+                raise NotImplementedError('LRGaussian supports the entropy-form ExclusiveKL estimator only')
+
+            def objective_and_grad(var_param):
+                var_param = np.asarray(var_param, dtype=np.float64)
+                if var_param.shape != (approx.var_param_dim,):
+                    raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+                eng = self._engine()
+                eng.set_model(self.model.device_spec())
+                N = self.num_mc_samples
+                begin, end = shard_rows(N, eng.n_ranks, eng.rank)
+                z, eps = approx._base_noise(N)          # low-rank block first (approximations.py:639-640)
+                eng.noise_set_host(_NOISE_SLOT, eps[begin:end])
+                eng.noise_set_host(_LR_SLOT, z[begin:end])
+                return eng.elbo_grad_lowrank(_NOISE_SLOT, _LR_SLOT, end - begin, approx.dim, approx.k, var_param,
+                                             n_total=N)
         else:
             raise NotImplementedError(
-                'ExclusiveKL on the HIP engine supports MFGaussian, MFStudentT and '
-                'FullRankGaussian; got {}'.format(type(approx).__name__))
+                'ExclusiveKL on the HIP engine supports MFGaussian, MFStudentT, FullRankGaussian and '
+                'LRGaussian; got {}'.format(type(approx).__name__))
         self._objective_and_grad = objective_and_grad
 
 
