@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Dev tool: BASELINE configs[3] shape -- MultivariateT(256, df=100) + DISInclusiveKL, N_mc=16384 on one GPU
+(the 8-GPU job gives each GPU 2048 rows), then PSIS of the 16384 log weights."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.')
+import viabel_amd as vb
+from viabel_amd._psis import psislw
+
+D, N = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+np.random.seed(5)
+model = vb.FunnelModel(D) if (len(sys.argv) > 2 and sys.argv[2] == 'funnel') else vb.GaussianModel(np.zeros(D), 3 * np.ones(D))
+rng_kind = sys.argv[3] if len(sys.argv) > 3 else 'philox'
+approx = vb.MultivariateT(D, 100, seed=1, rng=rng_kind)
+prior = np.concatenate([np.zeros(D), np.zeros(D)])
+theta = approx.init_param()
+for resample in (False, True):
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 2, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, use_resampling=resample, num_resampling_batches=1)
+    times = []
+    for i in range(6):
+        t0 = time.perf_counter()
+        v, g = obj(theta)
+        times.append(time.perf_counter() - t0)
+    print('C3 shape (rng=' + rng_kind + ', N=%d, resampling=%s): %.2f ms per objective call (min %.2f); value %.6g |grad| %.4g; eps %.3g ess %.0f'
+          % (N, resample, 1e3 * np.median(times[1:]), 1e3 * min(times), v, np.linalg.norm(g), obj._eps, obj._ess))
+lw = obj._state_log_p_unnormalized - obj._state_log_q
+t0 = time.perf_counter()
+for i in range(20):
+    sm, k = psislw(lw)
+print('PSIS of %d log weights: %.3f ms per call, khat %.3f' % (N, 1e3 * (time.perf_counter() - t0) / 20, k))

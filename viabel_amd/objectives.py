@@ -17,7 +17,7 @@ from abc import ABC, abstractmethod
 import numpy as np
 
 from . import _lib
-from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT, LRGaussian
+from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT, LRGaussian, symmetric_root
 from .models import DeviceModel
 
 __all__ = [
@@ -315,9 +315,13 @@ class DISInclusiveKL(StochasticVariationalObjective):
             n_local = end - begin
             L, Linv = factors(var_param)
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
-                chi, z = approx._base_noise(N)                 # chi-square draws first (approximations.py:345-347)
-                eng.noise_set_host(slot, z[begin:end])
-                root = sla.sqrtm(L @ L.T).real                  # symmetric square root, :348
+                if approx.rng == 'philox':                      # N chi-square draws on the host, N x D normals on the GPU
+                    chi = approx._rs.chisquare(df, N)
+                    eng.noise_generate(slot, n_local, D, approx._seed, approx._next_philox_stream(), row_offset=begin)
+                else:
+                    chi, z = approx._base_noise(N)             # chi-square draws first (approximations.py:345-347)
+                    eng.noise_set_host(slot, z[begin:end])
+                root = symmetric_root(L @ L.T)                  # symmetric square root, :348
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
                     slot, n_local, D, df, var_param, chi[begin:end], root, Linv, self._temper_prior_params,
                     self._eps, self._ess_target, self._max_bisection_its, n_total=N)
