@@ -166,6 +166,8 @@ struct MfCall {
   int cv_mode = 0;
   int mode = 0;        // 0: ELBO (ExclusiveKL); 1: weighted gradient only
   bool pipelined = false;   // spread prep / stream / finalize over the three pipeline streams
+  bool overlap_comm = false;   // sharded job: all-reduce + epilogue on the `post` stream, so the next batch's
+                               // kernels run on the main stream while RCCL moves this batch's sums
   double scale = 0.0;  // mode 1
   const double* value_src = nullptr;   // mode 1: device scalar reported as the objective value
   const ModelDev* model = nullptr;     // overrides ctx->model (mode 2: the log-q pseudo model)

@@ -926,9 +926,17 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   // ---- stream plan -----------------------------------------------------------------------------
   // pipelined: prep on `pre`, the streaming kernel on the main stream, finalize (+ all-reduce,
   // epilogue) on `post`, chained by events; otherwise everything in order on the main stream.
+  // overlap (sharded jobs, asynchronous batches): prep / streaming / finalize stay in order on the main
+  // stream; the all-reduce and the epilogue go to `post` behind ONE event, and nothing on the main stream
+  // waits for them except the re-use of this workspace set three batches later -- so RCCL moves batch i's
+  // sums while batch i+1 streams.
   Pipeline& P = ctx->pipe;
   hipStream_t st_pre = ctx->stream, st_main = ctx->stream, st_post = ctx->stream;
-  if (c.pipelined) {
+  const bool overlap = c.overlap_comm && !c.pipelined && ctx->comm != nullptr;
+  if (overlap) {
+    VB_TRY(pipe_init(ctx));
+    if (P.fin_valid[set]) VB_HIP(ctx, hipStreamWaitEvent(ctx->stream, P.ev_fin[set], 0));   // set is free again
+  } else if (c.pipelined) {
     VB_TRY(pipe_init(ctx));
     st_pre = P.pre;
     st_post = P.post;
@@ -995,13 +1003,18 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   hipLaunchKernelGGL(mf_finalize_kernel, dim3((unsigned)(g.Dp / 64), (unsigned)c.count), dim3(256), 0,
                      st_post, e, bp, ws);
   VB_HIP(ctx, hipGetLastError());
+  if (overlap) {   // hand the reduced sums over to the communication stream
+    VB_HIP(ctx, hipEventRecord(P.ev_k1[set], ctx->stream));
+    st_post = P.post;
+    VB_HIP(ctx, hipStreamWaitEvent(st_post, P.ev_k1[set], 0));
+  }
   if (!fused) {
     if (ctx->comm)   // one all-reduce for the whole batch: [count][sum_len] doubles
       VB_TRY(comm_allreduce_sum(ctx, st_post, ws.sums, (size_t)ws.sum_len * c.count));
     hipLaunchKernelGGL(mf_epilogue_kernel, dim3(1, (unsigned)c.count), dim3(256), 0, st_post, e, bp, ws);
     VB_HIP(ctx, hipGetLastError());
   }
-  if (c.pipelined) {
+  if (c.pipelined || overlap) {
     VB_HIP(ctx, hipEventRecord(P.ev_fin[set], st_post));
     P.fin_valid[set] = true;
     P.post_pending = true;
