@@ -134,3 +134,54 @@ def test_alpha_and_dis_through_comm(engines):
     for x, y in zip(res['plain'], res['comm']):
         assert abs(x[0] - y[0]) < 1e-12 * abs(x[0])
         np.testing.assert_allclose(y[1], x[1], rtol=0, atol=1e-12 * np.max(np.abs(x[1])))
+
+
+def test_lowrank_through_comm(engines):
+    """LRGaussian ExclusiveKL: sum vector all-reduced on a one-rank communicator == plain path; a shard of a
+    larger job (n_total > n) scales the data term only."""
+    import viabel_amd as vb
+    plain, comm = engines
+    D, N, k = 200, 600, 5
+    rng = np.random.RandomState(4)
+    spec = vb.FunnelModel(D, 7).device_spec()
+    fam = vb.LRGaussian(D, k=k)
+    theta = fam.pack(0.1 * rng.randn(D), -1.0 + 0.1 * rng.randn(D), 0.05 * rng.randn(D, k))
+    out = []
+    for eng in (plain, comm):
+        eng.set_model(spec)
+        eng.noise_generate(3, N, D, seed=5, stream=1)
+        eng.noise_generate(4, N, k, seed=6, stream=1)
+        out.append(eng.elbo_grad_lowrank(3, 4, N, D, k, theta))
+    assert abs(out[0][0] - out[1][0]) < 1e-13 * abs(out[0][0])
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-13 * np.max(np.abs(out[0][1])))
+
+
+def test_meanfield_overlapped_batches_through_comm(engines):
+    """Many asynchronous batches in flight with the all-reduce / epilogue on the communication stream: every
+    result equals the blocking single-call result for the same (noise, theta)."""
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    plain, comm = engines
+    D, N, B, rounds = 384, 2048, 8, 7
+    spec = vb.FunnelModel(D).device_spec()
+    for eng in (plain, comm):
+        eng.set_model(spec)
+        for s in range(B):
+            eng.noise_generate(20 + s, N, D, seed=3, stream=s)
+    thetas = np.stack([_theta(D, 100 + i) for i in range(B * rounds)])
+    ref = [plain.elbo_grad_meanfield(20 + i % B, N, D, thetas[i], _lib.FAMILY_MF_GAUSSIAN) for i in range(B * rounds)]
+    got = {}
+    for r in range(rounds):            # keep 3 batches in flight before collecting the oldest
+        idx = list(range(r * B, (r + 1) * B))
+        comm.elbo_grad_meanfield_batch_async([20 + i % B for i in idx], N, D, thetas[idx], _lib.FAMILY_MF_GAUSSIAN,
+                                             rslots=[(r % 3) * B + j for j in range(B)])
+        if r >= 2:
+            old = r - 2
+            for j in range(B):
+                got[old * B + j] = comm.result_get((old % 3) * B + j, 2 * D)
+    for old in (rounds - 2, rounds - 1):
+        for j in range(B):
+            got[old * B + j] = comm.result_get((old % 3) * B + j, 2 * D)
+    for i in range(B * rounds):
+        assert abs(got[i][0] - ref[i][0]) < 1e-13 * abs(ref[i][0])
+        np.testing.assert_allclose(got[i][1], ref[i][1], rtol=0, atol=1e-13 * np.max(np.abs(ref[i][1])))

@@ -222,16 +222,9 @@ __global__ void __launch_bounds__(256) lr_accum_kernel(const LrArgs a) {
       for (int u = 0; u < RIF; ++u) {
         const double* zr = zs[(int)(base - r0) + kLrWaves * u];
         double zj[KP];
-#ifdef VB_LR_NOZ
-#pragma unroll
-        for (int j = 0; j < KP; ++j) zj[j] = cp0.x * (j + 1);
-        row(e[u], zj, cp0.y, cp1.y);
-        (void)zr;
-#else
 #pragma unroll
         for (int j = 0; j < KP; ++j) zj[j] = zr[j];
         row(e[u], zj, zr[KP], zr[KP + 1]);
-#endif
       }
       base = next;
       if (!more) break;
