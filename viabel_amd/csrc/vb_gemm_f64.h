@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(con
   const int fblk = (lane >> 2) & 3, fj = lane & 3;   // B fragment / result: block and column in block
   // Software pipeline of one slab iteration (slab s in LDS buffer `buf`, KS = 4 k-steps of 4):
   //   top     ds_write slab s+1 (global loads issued one iteration ago) into buf^1, then issue the
-  //           global loads of slab s+2 into the same staging registers
+  //           global loads of slab s+2 into the same staging registers (the scheduler spreads the writes over
+  //           k-step 0 and the loads over k-step 1, one per fragment read, so no queue fills up)
   //   kk<KS-1 MFMAs of k-step kk interleaved with the fragment ds_reads of k-step kk+1
   //   barrier (all waves have issued every read of slab s and every write of slab s+1)
   //   kk=KS-1 MFMAs interleaved with the fragment reads of k-step 0 of slab s+1 (from buf^1)
@@ -223,9 +224,12 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(con
   constexpr int KS = kGemmBK / 4;
   constexpr int kReads = AF + NB, kMfma = AF * NB;
   constexpr int kPer = kMfma / kReads;        // MFMAs issued after each fragment read
-  auto interleave = [&]() __attribute__((always_inline)) {
+  // extra: 0 = none, 1 = also one LDS write per group (the slab fill), 2 = also one global load per group
+  auto interleave = [&](int extra) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < kReads; ++i) {
+      if (extra == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // one DS write
+      if (extra == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one VMEM read
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
       __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);   // kPer MFMAs
     }
@@ -254,12 +258,12 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(con
       for (int kk = 0; kk < KS - 1; ++kk) {
         if (!(VB_GEMM_SKIP & 8)) load_frags(buf, kk + 1, (kk + 1) & 1);
         mfma_step(kk & 1);
-        interleave();
+        interleave(kk == 0 ? 1 : (kk == 1 ? 2 : 0));
       }
       if (!(VB_GEMM_SKIP & 4)) __syncthreads();
       if (!(VB_GEMM_SKIP & 8)) load_frags(buf ^ 1, 0, KS & 1);
       mfma_step((KS - 1) & 1);
-      interleave();
+      interleave(0);
       buf ^= 1;
     }
   }
