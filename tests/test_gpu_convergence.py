@@ -79,3 +79,18 @@ def test_fullrank_bbvi_recovers_correlated_gaussian(vb):
     est_mean, est_cov = approx.mean_and_cov(results['opt_param'])
     np.testing.assert_allclose(est_mean, m, atol=0.05)
     np.testing.assert_allclose(est_cov, S, atol=0.08)
+
+
+def test_quickstart_example_runs(capsys):
+    """examples/quickstart.py (the reference's docs/source/quickstart.ipynb on the HIP engine), shortened."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'quickstart.py')
+    spec = importlib.util.spec_from_file_location('quickstart_example', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    results, diagnostics = mod.main(n_iters=3000)
+    capsys.readouterr()
+    opt = results['opt_param']
+    assert abs(opt[0]) < 0.5 and abs(opt[1]) < 1.0          # mean-field fit of the funnel sits near the origin
+    assert np.isfinite(diagnostics['khat']) and diagnostics['smoothed_log_weights'].shape == (100000,)
