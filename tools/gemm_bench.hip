@@ -4,6 +4,7 @@
 // Run:   tools/gemm_bench.bin [M N K]
 #include "vb_gemm_f64.h"
 
+#include <cmath>
 #include <cstdlib>
 
 using namespace vb;
@@ -211,6 +212,43 @@ int main(int argc, char** argv) {
     run_loop_probe<2, 4, 8>(st, n_cu, d, C);
     run_loop_probe<3, 4, 8>(st, n_cu, d, C);
   }
+  {   // correctness of the LDS-DMA kernel against the register-staged kernel (same inputs, all three tiles)
+    std::vector<double> c0((size_t)M * N), c1((size_t)M * N);
+    for (int cfg = 1; cfg <= 3; ++cfg)
+      for (int tri = 0; tri <= 1; ++tri) {
+        GemmArgs g;
+        g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = tri;
+        hipMemset(C, 0, (size_t)M * N * 8);
+        gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg, 1);
+        hipDeviceSynchronize();
+        hipMemcpy(c0.data(), C, c0.size() * 8, hipMemcpyDeviceToHost);
+        hipMemset(C, 0, (size_t)M * N * 8);
+        gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg, 0);
+        hipDeviceSynchronize();
+        hipMemcpy(c1.data(), C, c1.size() * 8, hipMemcpyDeviceToHost);
+        double md = 0, mx = 0;
+        for (size_t i = 0; i < c0.size(); ++i) {
+          md = fmax(md, fabs(c0[i] - c1[i]));
+          mx = fmax(mx, fabs(c0[i]));
+        }
+        printf("check cfg %d tri %d A[m][k]: max |dma - reg| = %.3e (max |C| %.3e)\n", cfg, tri, md, mx);
+      }
+    // k-major A, lower-triangular tiles, split-K
+    GemmArgs g3;
+    g3.A = A, g3.B = B, g3.lda = N, g3.ldb = N, g3.M = N, g3.N = N, g3.K = M, g3.tri_mode = 2;
+    std::vector<double> s0((size_t)2 * N * N), s1((size_t)2 * N * N);
+    for (int cfg = 1; cfg <= 3; ++cfg) {
+      for (int flag = 1; flag >= 0; --flag) {
+        hipMemset(C, 0, (size_t)2 * N * N * 8);
+        gemm_f64_launch<false>(st, g3, 2, n_cu, EpiSlab{C, N, (int64_t)N * N}, cfg, flag);
+        hipDeviceSynchronize();
+        hipMemcpy(flag ? s0.data() : s1.data(), C, s0.size() * 8, hipMemcpyDeviceToHost);
+      }
+      double md = 0;
+      for (size_t i = 0; i < s0.size(); ++i) md = fmax(md, fabs(s0[i] - s1[i]));
+      printf("check cfg %d gram A[k][m] splits 2: max |dma - reg| = %.3e\n", cfg, md);
+    }
+  }
   for (int cfg = 1; cfg <= 3; ++cfg) {
     const char* name = cfg == 1 ? "128x128" : cfg == 2 ? "128x64" : "64x64";
     // 1. dense, A k-contiguous (Z = E L', (Z - m) P)
@@ -218,6 +256,8 @@ int main(int argc, char** argv) {
     g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = 0;
     float ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg); }, 20);
     printf("%-8s dense  A[m][k]  M=%d N=%d K=%d: %.1f us  %.2f TFLOP/s\n", name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+    ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg, 1); }, 20);
+    printf("%-8s dense  A[m][k]  (register-staged kernel): %.1f us  %.2f TFLOP/s\n", name, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
     // 2. tri k-range
     g.tri_mode = 1;
     ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg); }, 20);

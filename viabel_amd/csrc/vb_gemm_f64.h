@@ -27,6 +27,7 @@
 
 #include "vb_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -302,6 +303,12 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(con
   }
 }
 
+}  // namespace vb
+
+#include "vb_gemm_f64_dma.h"
+
+namespace vb {
+
 inline int gemm_tiles(int x, int b) { return (x + b - 1) / b; }
 
 // upper bound on gridDim.x of any tile choice (sizes the `part` array of reducing epilogues)
@@ -320,7 +327,8 @@ inline long gemm_count_blocks(const GemmArgs& g, int bm_rows, int bn_cols) {
 
 // cfg: 0 = automatic, 1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 64 block tiles
 template <bool A_KCONTIG, class Epi>
-inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi, int cfg = 0) {
+inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi, int cfg = 0,
+                            int flags = 0) {   // flags bit 0: force the register-staged kernel
   if (splits < 1) splits = 1;
   int ks = gemm_tiles(g.K, splits);
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
@@ -334,6 +342,14 @@ inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, co
   g.tiles_m = gemm_tiles(g.M, bm_rows);
   g.tiles_n = gemm_tiles(g.N, bn_cols);
   const dim3 grid((unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1, (unsigned)splits);
+  // operands straight into LDS (vb_gemm_f64_dma.h) when every k range is a whole number of slabs
+  static const bool dma_ok = !(getenv("VB_GEMM_DMA") && atoi(getenv("VB_GEMM_DMA")) == 0);
+  if (dma_ok && g.K % kGemmBK == 0 && g.M > 0 && g.N > 0 && !(flags & 1)) {
+    if (cfg == 1) gemm_f64_dma_launch<A_KCONTIG, 4, 16, Epi>(st, g, grid, epi);
+    else if (cfg == 2) gemm_f64_dma_launch<A_KCONTIG, 4, 8, Epi>(st, g, grid, epi);
+    else gemm_f64_dma_launch<A_KCONTIG, 2, 8, Epi>(st, g, grid, epi);
+    return;
+  }
   if (cfg == 1)
     hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, 16, Epi>), grid, dim3(256), 0, st, g, epi);
   else if (cfg == 2)

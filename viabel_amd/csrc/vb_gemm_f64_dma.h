@@ -1,0 +1,265 @@
+// fp64 MFMA GEMM, operand tiles moved global -> LDS by `global_load_lds_dwordx4` (no VGPR staging, no
+// ds_write, no zeroing selects): the variant the launcher uses when every k range is a whole number of
+// 16-deep slabs (K % 16 == 0).  Same tiles, fragment arrangement and epilogue contract as gemm_f64_kernel in
+// vb_gemm_f64.h (included from there); what changes is how a slab gets into LDS:
+//
+//  * a wave-load moves 64 x 16 B = 1 KiB to LDS addresses M0 + 16 * lane, i.e. LDS rows are dense (no pad
+//    columns).  Bank conflicts are avoided by an XOR swizzle that is applied on the *global* side (each lane
+//    picks which 16-B pair it fetches) and undone in the fragment-read addresses (lane constants):
+//      k-major tiles [k][W] (B, and A given as A[k][m]):  pair slot p of row k holds pair p ^ 8 (k & 1)
+//        -> the two k rows a half-wave reads sit on disjoint halves of the 64 banks;
+//      A given as A[m][k], tile [m][16]:  pair slot p of row m holds k-pair p ^ ((m >> 1) & 7)
+//        -> the 16 rows x 2 k a half-wave reads hit 32 distinct bank pairs.
+//  * three LDS stages, prefetch distance two: at the top of iteration s the loads of slab s+2 are issued into
+//    the stage whose last readers passed the previous barrier; before the barrier of iteration s each wave
+//    waits with a counted vmcnt until only the loads of slab s+2 are outstanding, so a slab has a whole
+//    iteration (~2 us) more than in the register-staged kernel to arrive.  The barrier is a bare s_barrier:
+//    __syncthreads() would add a fence that drains vmcnt to zero and with it the prefetch.
+//  * rows / columns beyond M / N are fetched from clamped (in-range) addresses; they only feed output rows /
+//    columns that the epilogue masks.
+#pragma once
+
+namespace vb {
+
+typedef __attribute__((address_space(1))) const void* gemm_gptr;
+typedef __attribute__((address_space(3))) void* gemm_lptr;
+
+template <bool A_KCONTIG, int AF, int NB, class Epi>
+__global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel(const GemmArgs g, const Epi epi) {
+  constexpr int BM = 32 * AF, BN = 8 * NB;
+  constexpr int kStages = 3;
+  constexpr int kATile = BM * kGemmBK, kBTile = kGemmBK * BN;      // doubles per stage
+  constexpr int kAUnits = kATile / 128, kBUnits = kBTile / 128;    // 1-KiB wave-loads per stage
+  constexpr int UPW = (kAUnits + kBUnits) / 4;                     // wave-loads per wave per slab
+  static_assert((kAUnits + kBUnits) % 4 == 0, "units must divide over the 4 waves");
+  extern __shared__ double gemm_lds[];
+  double* As = gemm_lds;                         // [kStages][kATile]
+  double* Bs = gemm_lds + kStages * kATile;      // [kStages][kBTile]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- tile assignment (as gemm_f64_kernel) -----------------------------------------------------
+  int bm, bn;
+  if (g.tri_mode == 2) {
+    int idx = blockIdx.x;
+    bm = 0;
+    for (;;) {
+      const int cnt = min(g.tiles_n, (bm * BM + BM - 1) / BN + 1);
+      if (idx < cnt) break;
+      idx -= cnt;
+      ++bm;
+    }
+    bn = idx;
+  } else if (g.tri_mode == 1) {
+    const int idx = blockIdx.x / g.tiles_m, half = (g.tiles_n + 1) / 2;
+    bn = idx < half ? g.tiles_n - 1 - idx : idx - half;
+    bm = blockIdx.x % g.tiles_m;
+  } else {
+    bn = blockIdx.x / g.tiles_m;
+    bm = blockIdx.x % g.tiles_m;
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int k_begin = blockIdx.z * g.k_split;
+  int k_end = k_begin + g.k_split < g.K ? k_begin + g.k_split : g.K;
+  if (g.tri_mode == 1) {
+    const int kmax = n0 + BN;
+    if (k_end > kmax) k_end = kmax;
+  }
+  const int nslabs = (k_end - k_begin) / kGemmBK;
+
+  double acc[AF][NB];
+#pragma unroll
+  for (int i = 0; i < AF; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = 0.0;
+
+  // ---- global source of each of this wave's units (slab 0), advanced by one slab per issue -----------
+  // unit q = u * 4 + wave; q < kAUnits: A unit, else B unit.
+  const double* src[UPW];
+  int64_t step[UPW];
+  int lds_off[UPW];          // doubles from the start of the stage region (A region then B region)
+#pragma unroll
+  for (int u = 0; u < UPW; ++u) {
+    const int q = u * 4 + wave;
+    if (q < kAUnits) {
+      if (A_KCONTIG) {       // 8 rows x 8 pairs per unit
+        const int row = q * 8 + (lane >> 3), p = lane & 7;
+        const int kp = p ^ ((row >> 1) & 7);
+        int m = m0 + row;
+        m = m < g.M ? m : g.M - 1;
+        src[u] = g.A + (int64_t)m * g.lda + k_begin + 2 * kp;
+        step[u] = kGemmBK;
+      } else {               // k-major: (BM / 2) pairs per k row
+        constexpr int PPR = BM / 2, RPU = 64 / PPR > 0 ? 64 / PPR : 1;     // pairs per row, rows per unit
+        const int krow = (PPR >= 64) ? q / (PPR / 64) : q * RPU + lane / PPR;
+        const int p = (PPR >= 64) ? (q % (PPR / 64)) * 64 + lane : lane % PPR;
+        const int c = p ^ (8 * (krow & 1));
+        int64_t col = m0 + 2 * c;
+        col = col < g.lda - 1 ? col : g.lda - 2;
+        src[u] = g.A + (int64_t)(k_begin + krow) * g.lda + col;
+        step[u] = (int64_t)kGemmBK * g.lda;
+      }
+      lds_off[u] = q * 128;
+    } else {
+      const int qb = q - kAUnits;
+      constexpr int PPR = BN / 2, RPU = 64 / PPR > 0 ? 64 / PPR : 1;
+      const int krow = (PPR >= 64) ? qb / (PPR / 64) : qb * RPU + lane / PPR;
+      const int p = (PPR >= 64) ? (qb % (PPR / 64)) * 64 + lane : lane % PPR;
+      const int c = p ^ (8 * (krow & 1));
+      int64_t col = n0 + 2 * c;
+      col = col < g.ldb - 1 ? col : g.ldb - 2;
+      src[u] = g.B + (int64_t)(k_begin + krow) * g.ldb + col;
+      step[u] = (int64_t)kGemmBK * g.ldb;
+      lds_off[u] = kStages * kATile + qb * 128;
+    }
+  }
+  // stage `st` of the A region starts at st * kATile, of the B region at kStages * kATile + st * kBTile
+  auto issue = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+      const int q = u * 4 + wave;
+      double* dst = gemm_lds + lds_off[u] + st * (q < kAUnits ? kATile : kBTile);
+      __builtin_amdgcn_global_load_lds((gemm_gptr)src[u], (gemm_lptr)dst, 16, 0, 0);
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) src[u] += step[u];
+  };
+
+  // ---- fragment addresses (lane constants; doubles) -------------------------------------------------------
+  const int fi = lane & 15, fk = lane >> 4;
+  const int fblk = (lane >> 2) & 3, fj = lane & 3;
+  // A[m][k] tile: fragment a of k-step kk at a_off[kk] + 256 a (16 rows further: (row >> 1) & 7 unchanged);
+  // A[k][m] tile: fragment a of k-step kk at a_off[a] + 4 kk BM (parity of k = parity of fk)
+  constexpr int kAOffs = A_KCONTIG ? kGemmBK / 4 : AF;
+  int a_off[kAOffs];
+  int b_off[NB];                 // B fragment r of k-step 0; k-step kk adds 4 * kk * BN
+  if (A_KCONTIG) {
+#pragma unroll
+    for (int kk = 0; kk < kGemmBK / 4; ++kk) {
+      const int k = 4 * kk + fk;
+      const int row = wm * (16 * AF) + fi;
+      a_off[kk < kAOffs ? kk : 0] = row * kGemmBK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1);
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < AF; ++a) {
+      const int m = wm * (16 * AF) + a * 16 + fi;
+      a_off[a < kAOffs ? a : 0] = fk * BM + (m ^ (16 * (fk & 1)));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const int col = wn * (4 * NB) + 4 * ((fblk + r) & (NB - 1)) + fj;
+    b_off[r] = fk * BN + (col ^ (16 * (fk & 1)));          // k = 4 kk + fk: parity of k = parity of fk
+  }
+
+  double fa[2][AF], fb[2][NB];
+  auto load_frags = [&](int st, int kk, int set) __attribute__((always_inline)) {
+    const double* as = As + st * kATile;
+    const double* bs = Bs + st * kBTile;
+#pragma unroll
+    for (int a = 0; a < AF; ++a)
+      fa[set][a] = A_KCONTIG ? as[a_off[kk < kAOffs ? kk : 0] + a * (16 * kGemmBK)] : as[a_off[a < kAOffs ? a : 0] + 4 * kk * BM];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) fb[set][r] = bs[b_off[r] + 4 * kk * BN];
+  };
+  auto mfma_step = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < AF; ++a)
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+        acc[a][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[set][a], fb[set][r], acc[a][r], 0, 0, 0);
+  };
+  constexpr int KS = kGemmBK / 4;
+  constexpr int kReads = AF + NB, kMfma = AF * NB;
+  constexpr int kPer = kMfma / kReads;
+  auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < kReads; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kPer * kReads, 0);
+  };
+  // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+  auto wait_vm = [&](auto n) __attribute__((always_inline)) {
+    constexpr int N = decltype(n)::value;
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+  };
+
+  if (nslabs > 0) {
+    issue(0);                          // slab 0
+    if (nslabs > 1) advance();
+    issue(1);                          // slab 1 (or slab 0 again: keeps the vmcnt arithmetic uniform)
+    wait_vm(std::integral_constant<int, UPW>());
+    __asm__ volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __asm__ volatile("" ::: "memory");
+    load_frags(0, 0, 0);
+    int st = 0;
+    for (int s = 0; s < nslabs; ++s) {
+      const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
+      if (s + 2 < nslabs) advance();   // beyond the end: re-fetch the last slab into a free stage
+      issue(st2);
+#pragma unroll
+      for (int kk = 0; kk < KS - 1; ++kk) {
+        load_frags(st, kk + 1, (kk + 1) & 1);
+        mfma_step(kk & 1);
+        interleave();
+      }
+      wait_vm(std::integral_constant<int, UPW>());     // slab s + 1 has landed (this wave's share)
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's reads of stage st are done
+      __asm__ volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __asm__ volatile("" ::: "memory");
+      load_frags(st1, 0, KS & 1);
+      mfma_step((KS - 1) & 1);
+      interleave();
+      st = st1;
+    }
+    __builtin_amdgcn_s_waitcnt(0);     // nothing in flight into LDS when the epilogue reuses it
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue (as gemm_f64_kernel) -------------------------------------------------------------------------
+  double local = 0.0;
+#pragma unroll
+  for (int a = 0; a < AF; ++a)
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const int row = m0 + wm * (16 * AF) + a * 16 + 4 * fblk + fk;
+      const int col = n0 + wn * (4 * NB) + 4 * ((fblk + r) & (NB - 1)) + fj;
+      if (row < g.M && col < g.N) {
+        if constexpr (EpiReduces<Epi>::value)
+          local += epi((int)blockIdx.z, row, col, acc[a][r]);
+        else
+          epi((int)blockIdx.z, row, col, acc[a][r]);
+      }
+    }
+  if constexpr (EpiReduces<Epi>::value) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if (lane == 0) gemm_lds[wave] = local;
+    __syncthreads();
+    if (t == 0)
+      epi.part[(int64_t)blockIdx.z * gridDim.x + blockIdx.x] = (gemm_lds[0] + gemm_lds[1]) + (gemm_lds[2] + gemm_lds[3]);
+  }
+}
+
+template <bool A_KCONTIG, int AF, int NB, class Epi>
+inline void gemm_f64_dma_launch(hipStream_t st, const GemmArgs& g, dim3 grid, const Epi& epi) {
+  constexpr size_t lds = (size_t)3 * (32 * AF * kGemmBK + kGemmBK * 8 * NB) * sizeof(double);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma_kernel<A_KCONTIG, AF, NB, Epi>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = true;
+  }
+  hipLaunchKernelGGL((gemm_f64_dma_kernel<A_KCONTIG, AF, NB, Epi>), grid, dim3(256), lds, st, g, epi);
+}
+
+}  // namespace vb
