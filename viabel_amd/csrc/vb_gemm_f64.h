@@ -332,9 +332,15 @@ inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, co
   if (splits < 1) splits = 1;
   int ks = gemm_tiles(g.K, splits);
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
+  static const int cfg_env = getenv("VB_GEMM_CFG") ? atoi(getenv("VB_GEMM_CFG")) : 0;   // experiments: force a tile
+  if (cfg == 0 && cfg_env >= 1 && cfg_env <= 3) cfg = cfg_env;
+  // operands straight into LDS (vb_gemm_f64_dma.h) when every k range is a whole number of slabs
+  static const bool dma_ok = !(getenv("VB_GEMM_DMA") && atoi(getenv("VB_GEMM_DMA")) == 0);
+  const bool dma = dma_ok && g.K % kGemmBK == 0 && g.M > 0 && g.N > 0 && !(flags & 1);
   if (cfg == 0) {
-    // largest tile that gives every CU two workgroups (two waves per SIMD)
-    if (gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) cfg = 1;
+    // largest tile that gives every CU two workgroups; the LDS-DMA kernel's 128 x 128 tile needs 96 KB of LDS
+    // (one workgroup per CU) and measures slower than its 128 x 64 tile at every shape tried, so it is skipped
+    if (!dma && gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) cfg = 1;
     else if (gemm_count_blocks(g, 128, 64) * splits >= 2L * n_cu) cfg = 2;
     else cfg = 3;
   }
@@ -342,9 +348,7 @@ inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, co
   g.tiles_m = gemm_tiles(g.M, bm_rows);
   g.tiles_n = gemm_tiles(g.N, bn_cols);
   const dim3 grid((unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1, (unsigned)splits);
-  // operands straight into LDS (vb_gemm_f64_dma.h) when every k range is a whole number of slabs
-  static const bool dma_ok = !(getenv("VB_GEMM_DMA") && atoi(getenv("VB_GEMM_DMA")) == 0);
-  if (dma_ok && g.K % kGemmBK == 0 && g.M > 0 && g.N > 0 && !(flags & 1)) {
+  if (dma) {
     if (cfg == 1) gemm_f64_dma_launch<A_KCONTIG, 4, 16, Epi>(st, g, grid, epi);
     else if (cfg == 2) gemm_f64_dma_launch<A_KCONTIG, 4, 8, Epi>(st, g, grid, epi);
     else gemm_f64_dma_launch<A_KCONTIG, 2, 8, Epi>(st, g, grid, epi);
