@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <outdir-name> "<counter list>" <program> [args...]   (runs on the GPU box)
+# usage: tools/pmc.sh <outdir-name> "<counter list>" <program> [args...]   (runs on the GPU box)
 # one rocprofv3 --pmc pass per counter; prints the per-launch average of each counter per kernel
 name=$1; shift
 counters=$1; shift
@@ -9,5 +9,5 @@ mkdir -p $out
 cd $GRAFT_REPO_ROOT
 for c in $counters; do
   rocprofv3 --pmc $c -d $out -o pmc_$c -- "$@" > $out/run_$c.log 2>&1
-  echo "== $c"; python3 tools_rocpd_stats.py $out/pmc_${c}_results.db $c | grep -E "gemm|accum|kernel  " | cut -c1-40,65-200
+  echo "== $c"; python3 tools/rocpd_stats.py $out/pmc_${c}_results.db $c | grep -E "gemm|accum|kernel  " | cut -c1-40,65-200
 done

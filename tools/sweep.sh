@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick bench sweep on the GPU box (no profiler): tools_sweep.sh "<engines list>" "<batch list>" ["<VB_MF_TARGET_WG list>"]
+# quick bench sweep on the GPU box (no profiler): tools/sweep.sh "<engines list>" "<batch list>" ["<VB_MF_TARGET_WG list>"]
 cd $GRAFT_REPO_ROOT
 for w in ${3:-512}; do for e in ${1:-1 2 3}; do for b in ${2:-1 4 16}; do
   VB_MF_TARGET_WG=$w python bench.py --steps 4000 --warmup 400 --engines $e --batch $b --no-cpu-baseline --no-fullrank 2>&1 | tail -1 | python -c "
