@@ -278,3 +278,44 @@ def test_full_size_properties(vb):
     vb_, gb = eng.elbo_grad_meanfield(22, N // 2, D, theta, _lib.FAMILY_MF_GAUSSIAN)
     assert abs(0.5 * (va + vb_) - v) < 1e-12 * abs(v)
     np.testing.assert_allclose(0.5 * (ga + gb), g, rtol=0, atol=1e-11 * np.max(np.abs(g)))
+
+
+@pytest.mark.parametrize('df', [3.5, 8.0, 100.0])
+def test_philox_student_t_noise(vb, df):
+    """Device Student-t base noise (Philox + Marsaglia-Tsang gamma): distribution, shard invariance, and the
+    MFStudentT objective on it equals the oracle on the same draws."""
+    from scipy import stats
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    N, D = 4000, 101
+    eng.noise_generate(5, N, D, seed=13, stream=2, kind=_lib.NOISE_STUDENT_T, df=df)
+    full = eng.noise_get_host(5, N, D)
+    assert np.all(np.isfinite(full))
+    ks = stats.kstest(full.ravel()[::7], stats.t(df).cdf)
+    assert ks.pvalue > 1e-4, ks
+    assert abs(np.median(full)) < 0.01
+    eng.noise_generate(6, 300, D, seed=13, stream=2, row_offset=700, kind=_lib.NOISE_STUDENT_T, df=df)
+    np.testing.assert_array_equal(eng.noise_get_host(6, 300, D), full[700:1000])
+    # objective in throughput mode == oracle on the read-back noise
+    approx = vb.MFStudentT(D, df, seed=13, rng='philox')
+    model = vb.FunnelModel(D, 5)
+    theta = np.concatenate([0.1 * np.sin(np.arange(D)), -1.0 + 0.05 * np.cos(np.arange(D))])
+    value, grad = vb.ExclusiveKL(approx, model, N)(theta)             # stream 0 of the family
+    eng.noise_generate(7, N, D, seed=13, stream=0, kind=_lib.NOISE_STUDENT_T, df=df)
+    noise = eng.noise_get_host(7, N, D)
+    ov, og = oobj.exclusive_kl(ofam.MFStudentT(D, df), omod.Funnel(D, 5), theta, noise)
+    assert abs(value - ov) <= 1e-12 * abs(ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-11 * np.max(np.abs(og)))
+    assert approx.sample(theta, 10).shape == (10, D)
+
+
+def test_philox_many_rows(vb):
+    """More rows than one launch's gridDim.y covers (vi_diagnostics draws 1e5 samples; 6e5 rows here)."""
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    N, D = 600000, 2
+    eng.noise_generate(8, N, D, seed=1, stream=0)
+    x = eng.noise_get_host(8, N, D)
+    assert abs(x.mean()) < 0.01 and abs(x.var() - 1) < 0.01
+    eng.noise_generate(9, 1000, D, seed=1, stream=0, row_offset=599000)
+    np.testing.assert_array_equal(eng.noise_get_host(9, 1000, D), x[599000:])

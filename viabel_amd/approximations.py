@@ -123,6 +123,12 @@ class _NoiseMixin:
         self._philox_calls += 1
         return k
 
+    def _philox_kind(self):
+        """(noise kind, df) of the family's base noise for the device generator."""
+        if getattr(self, '_family_id', None) == _lib.FAMILY_MF_STUDENT_T:
+            return _lib.NOISE_STUDENT_T, float(self._df)
+        return _lib.NOISE_NORMAL, 0.0
+
 
 def _as_rows(x):
     x = np.asarray(x, dtype=np.float64)
@@ -203,8 +209,6 @@ class MFStudentT(_NoiseMixin, ApproximationFamily):
             raise ValueError('df must be greater than 2')
         self._df = df
         self._init_rng(seed, rng)
-        if rng != 'numpy':
-            raise NotImplementedError("MFStudentT draws its base noise on the host (rng='numpy')")
         super().__init__(dim, 2 * dim, True, False)
 
     def _device_family(self):
@@ -222,7 +226,11 @@ class MFStudentT(_NoiseMixin, ApproximationFamily):
 
     def sample(self, var_param, n_samples, seed=None):
         mu, log_sigma = self._unpack(var_param)
-        return mu + np.exp(log_sigma) * self._base_noise(n_samples, seed)
+        if self._rng_kind == 'philox':
+            noise = _philox_host_copy(self, n_samples, seed)
+        else:
+            noise = self._base_noise(n_samples, seed)
+        return mu + np.exp(log_sigma) * noise
 
     def entropy(self, var_param):
         # the reference drops the df-only constants (approximations.py:276-279)
@@ -523,8 +531,9 @@ def _philox_host_copy(family, n_samples, seed):
     """Generate Philox noise on the GPU and read it back (host ``sample`` in throughput mode)."""
     eng = _lib.default_engine()
     slot = _lib.MAX_SLOTS - 1
+    kind, df = family._philox_kind()
     if seed is None:
-        eng.noise_generate(slot, n_samples, family.dim, family._seed, family._next_philox_stream())
+        eng.noise_generate(slot, n_samples, family.dim, family._seed, family._next_philox_stream(), kind=kind, df=df)
     else:
-        eng.noise_generate(slot, n_samples, family.dim, seed, 0)
+        eng.noise_generate(slot, n_samples, family.dim, seed, 0, kind=kind, df=df)
     return eng.noise_get_host(slot, n_samples, family.dim)

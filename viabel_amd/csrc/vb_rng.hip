@@ -71,18 +71,78 @@ __global__ void __launch_bounds__(256) rng_normal_kernel(double* __restrict__ ds
   }
 }
 
+// Standard Student-t noise (the base draws of MFStudentT.sample, viabel/approximations.py:270-274):
+// t = n / sqrt(chi2_df / df), chi2_df = 2 Gamma(df / 2) by Marsaglia-Tsang (df > 2, so shape >= 1).  The
+// numerator pair of a thread comes from Philox sub-stream 0, the gamma attempts of column e from sub-streams
+// 1 + 2 (attempt) + e; every value is a pure function of (seed, stream, global row, column).
+__device__ __forceinline__ Philox4 philox_sub(uint64_t grow, uint32_t j, uint32_t stream, uint32_t sub, uint32_t k0,
+                                              uint32_t k1) {
+  Philox4 c;
+  c.x = (uint32_t)grow;
+  c.y = (uint32_t)(grow >> 32);
+  c.z = j;
+  c.w = stream + 0x9E3779B9u * sub;
+  return philox4x32_10(c, k0, k1 ^ (0x85EBCA6Bu * sub));
+}
+
+__device__ double gamma_mt(double shape, uint64_t grow, uint32_t j, uint32_t stream, uint32_t e, uint32_t k0,
+                           uint32_t k1) {
+  const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+  double v = 1.0;
+  for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+    const Philox4 o = philox_sub(grow, j, stream, 1 + 2 * attempt + e, k0, k1);
+    const Philox4 o2 = philox_sub(grow, j, stream, 0x40000000u + 2 * attempt + e, k0, k1);
+    const double x = sqrt(-2.0 * log(u01(o.x, o.y))) * cospi(2.0 * u01(o.z, o.w));
+    const double t = 1.0 + c * x;
+    if (t <= 0.0) continue;
+    v = t * t * t;
+    const double u = u01(o2.x, o2.y), x2 = x * x;
+    if (u < 1.0 - 0.0331 * x2 * x2) break;
+    if (log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) break;
+  }
+  return d * v;
+}
+
+__global__ void __launch_bounds__(256) rng_student_t_kernel(double* __restrict__ dst, int64_t ld, double df,
+                                                            uint64_t seed, uint64_t stream, int64_t row_offset,
+                                                            int64_t n, int64_t d) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int pairs = (int)((d + 1) / 2);
+  if (j >= pairs) return;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32);
+  const double half = 0.5 * df;
+  const int64_t r0 = (int64_t)blockIdx.y * kRngRows;
+  for (int u = 0; u < kRngRows; ++u) {
+    const int64_t r = r0 + u;
+    if (r >= n) break;
+    const uint64_t grow = (uint64_t)(row_offset + r);
+    const Philox4 o = philox_sub(grow, (uint32_t)j, (uint32_t)stream, 0, k0, k1);
+    const double rad = sqrt(-2.0 * log(u01(o.x, o.y)));
+    double s, co;
+    sincospi(2.0 * u01(o.z, o.w), &s, &co);
+    double* p = dst + r * ld + 2 * j;
+    p[0] = rad * co * sqrt(half / gamma_mt(half, grow, (uint32_t)j, (uint32_t)stream, 0, k0, k1));
+    if (2 * j + 1 < d) p[1] = rad * s * sqrt(half / gamma_mt(half, grow, (uint32_t)j, (uint32_t)stream, 1, k0, k1));
+  }
+}
+
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,
              uint64_t stream, int64_t row_offset, int64_t n, int64_t d) {
-  (void)df;
-  if (kind != VB_NOISE_NORMAL)
-    return fail(ctx, VB_ERR_UNSUPPORTED,
-                "device generation implements VB_NOISE_NORMAL; draw other base noise on the host "
-                "and upload it with vb_noise_set_host");
   const int64_t pairs = (d + 1) / 2;
-  const dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)((n + kRngRows - 1) / kRngRows));
-  hipLaunchKernelGGL(rng_normal_kernel, grid, dim3(256), 0, ctx->stream, dst, ld, seed,
-                     stream, row_offset, n, d);
-  VB_HIP(ctx, hipGetLastError());
+  if (kind != VB_NOISE_NORMAL && kind != VB_NOISE_STUDENT_T) return fail(ctx, VB_ERR_UNSUPPORTED, "unknown noise kind %d", kind);
+  if (kind == VB_NOISE_STUDENT_T && !(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  const int64_t chunk = (int64_t)65535 * kRngRows;          // gridDim.y limit
+  for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+    const int64_t rows = n - r0 < chunk ? n - r0 : chunk;
+    const dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)((rows + kRngRows - 1) / kRngRows));
+    if (kind == VB_NOISE_NORMAL)
+      hipLaunchKernelGGL(rng_normal_kernel, grid, dim3(256), 0, ctx->stream, dst + r0 * ld, ld, seed, stream,
+                         row_offset + r0, rows, d);
+    else
+      hipLaunchKernelGGL(rng_student_t_kernel, grid, dim3(256), 0, ctx->stream, dst + r0 * ld, ld, df, seed, stream,
+                         row_offset + r0, rows, d);
+    VB_HIP(ctx, hipGetLastError());
+  }
   return VB_OK;
 }
 

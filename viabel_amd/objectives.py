@@ -104,11 +104,12 @@ class VariationalObjective(ABC):
         approx = self._approx
         begin, end = shard_rows(n_samples, eng.n_ranks, eng.rank)
         if approx.rng == 'philox':
+            kind, df = approx._philox_kind()
             if seed is None:
                 eng.noise_generate(slot, end - begin, approx.dim, approx._seed,
-                                   approx._next_philox_stream(), row_offset=begin)
+                                   approx._next_philox_stream(), row_offset=begin, kind=kind, df=df)
             else:
-                eng.noise_generate(slot, end - begin, approx.dim, seed, 0, row_offset=begin)
+                eng.noise_generate(slot, end - begin, approx.dim, seed, 0, row_offset=begin, kind=kind, df=df)
         else:
             noise = approx._base_noise(n_samples, seed)
             eng.noise_set_host(slot, noise[begin:end])
