@@ -190,6 +190,19 @@ int vb_log_weights_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int fa
 int vb_psis_smooth(vb_ctx* ctx, const double* lw_in, int64_t n, double reff, double* lw_out,
                    double* khat);
 
+/* ---- ExclusiveKL, multivariate t family ------------------------------------------------
+ * ExclusiveKL closure (objectives.py:154-164, entropy form) for MultivariateT
+ * (approximations.py:322-382): x_n = mu + (z_n Sigma^{1/2}) / s_n with the normals z (n x D) in
+ * `slot`, sqrt_sigma the symmetric root (D x D, row-major) and inv_s[n] = 1 / sqrt(chi2_n / df)
+ * (:345-349).  Returns the sample sums f_sum = sum_n f(x_n), g_sum[D] = sum_n grad f(x_n) and
+ * c_full[D x D] = sum_n grad f(x_n) (z_n / s_n)' (= d f_sum / d sqrt_sigma for an unconstrained
+ * root); the O(D^3) chain rule root -> Sigma -> free Cholesky parameters stays with the caller,
+ * like the root itself.  Sums cover all ranks when a communicator is attached (f_sum: add the
+ * per-sample constant of the local rows only -- it is included).                              */
+int vb_elbo_sums_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, const double* mu,
+                     const double* sqrt_sigma, const double* inv_s, double* f_sum, double* g_sum,
+                     double* c_full);
+
 /* ---- ExclusiveKL, full-rank Gaussian family -------------------------------------------
  * New family (no reference class) behind the ApproximationFamily API with the flat
  * layout of viabel/approximations.py:315-319: theta = [mu (D) | free Cholesky (D(D+1)/2)],

@@ -34,7 +34,9 @@ def exclusive_kl(family, model, theta, noise, use_path_deriv=False):
     if isinstance(family, fam.FullRankGaussian):
         return _exclusive_kl_fullrank(family, model, theta, noise, use_path_deriv)
     if isinstance(family, fam.MultivariateT):
-        raise NotImplementedError('MultivariateT + ExclusiveKL needs d sqrtm / d theta')
+        if use_path_deriv:
+            raise NotImplementedError('path derivative for MultivariateT')
+        return _exclusive_kl_mvt(family, model, theta, noise)
     if isinstance(family, fam.LRGaussian):
         if use_path_deriv:
             raise NotImplementedError('path derivative for LRGaussian')
@@ -55,6 +57,34 @@ def exclusive_kl(family, model, theta, noise, use_path_deriv=False):
         value = -(np.mean(f) + family.entropy(theta))
         grad = -np.concatenate([g.mean(0), (g * noise * sig).mean(0) + 1.0])
     return value, grad
+
+
+def sqrt_root_vjp(S, G):
+    """dF/dS given dF/dR = G for R = S^{1/2} (symmetric): solve R X + X R = sym(G) in R's eigenbasis."""
+    w, U = np.linalg.eigh(S)
+    r = np.sqrt(w)
+    Gs = 0.5 * (G + G.T)
+    return U @ ((U.T @ Gs @ U) / (r[:, None] + r[None, :])) @ U.T
+
+
+def _exclusive_kl_mvt(family, model, theta, noise):
+    """Entropy form (objectives.py:160-164) for MultivariateT: x = mu + (z R) / s, R = sqrtm(L L')
+    (approximations.py:342-349), entropy = sum log L_ii (:351-354).  Chain rule: dF/dR = mean g (z / s)',
+    R -> Sigma by the Sylvester solve above, Sigma = L L' -> dL = tril(2 X L), free diagonal x L_ii."""
+    theta = np.asarray(theta, dtype=np.float64)
+    D = family.dim
+    chi, z = noise
+    mu, Sigma = family.split(theta)
+    L = fam.free_to_chol(theta[D:], D)
+    x = family.sample_from_noise(theta, noise)
+    g = model.grad(x)
+    N = x.shape[0]
+    value = -(np.mean(model.logp(x)) + family.entropy(theta))
+    zs = z / np.sqrt(chi / family.df)[:, None]
+    X = sqrt_root_vjp(Sigma, g.T @ zs / N)
+    dL = np.tril(2.0 * X @ L)
+    dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + 1.0          # free (log) diagonal + entropy
+    return value, -np.concatenate([g.mean(0), dL[np.tril_indices(D)]])
 
 
 def _exclusive_kl_lowrank(family, model, theta, noise):

@@ -551,12 +551,43 @@ def gen_lowrank():
     print('LRGaussian ExclusiveKL: worst analytic-vs-FD(reference) grad rel err %.2e' % worst)
 
 
+def gen_exclusive_kl_mvt():
+    """ExclusiveKL with the MultivariateT family (the reference differentiates scipy's sqrtm with autograd,
+    approximations.py:348): value from the reference closure, gradient by Richardson differences of it."""
+    rng = np.random.RandomState(81)
+    worst = 0.0
+    for fspec in ({'kind': 'multivariate_t', 'dim': 3, 'df': 100}, {'kind': 'multivariate_t', 'dim': 6, 'df': 7},
+                  {'kind': 'multivariate_t', 'dim': 10, 'df': 30}):
+        D = fspec['dim']
+        for mspec in model_specs(D, rng):
+            N, seed = 40, 1
+            ref, orc = make_family(fspec, seed)
+            log_p, omodel = make_model(mspec)
+            theta = theta_for(fspec, rng)
+            objective = ref_obj.ExclusiveKL(ref, log_p, N)
+            _ref_stubs.STATE['before_eval'] = snapshot_hook(ref)
+            value, grad_fd = objective(theta)
+            _ref_stubs.STATE['before_eval'] = None
+            noise = orc.draw_noise(np.random.RandomState(seed), N)
+            ov, og = oobj.exclusive_kl(orc, omodel, theta, noise)
+            assert rel_err(ov, value) < 1e-12, (fspec, mspec['kind'], ov, value)
+            e = rel_err(og, grad_fd)
+            worst = max(worst, e)
+            assert e < 2e-6, (fspec, mspec['kind'], e)
+            save('ekl_%s_d%d_%s_pd0_n%d' % (fspec['kind'], D, mspec['kind'], N), **spec_arrays(fspec, mspec),
+                 seed=seed, n=N, theta=theta, noise_chi=noise[0], noise_z=noise[1], use_path_deriv=False,
+                 value=value, grad_fd=grad_fd, grad=og,
+                 provenance='value: reference closure; grad_fd: Richardson central differences of the reference '
+                            'closure (through scipy sqrtm); grad: analytic (oracle, Sylvester solve), agrees with grad_fd')
+    print('ExclusiveKL MultivariateT: worst analytic-vs-FD(reference) grad rel err %.2e' % worst)
+
+
 GENERATORS = {}
 
 if __name__ == '__main__':
     GENERATORS.update(torch=gen_torch_crosscheck, family=gen_family_forward, ekl=gen_exclusive_kl, rge=gen_rge,
                       alpha=gen_alpha, dis=gen_dis, chainstats=gen_chain_stats, optimizers=gen_optimizers,
-                      psis=gen_psis, lowrank=gen_lowrank)
+                      psis=gen_psis, lowrank=gen_lowrank, ekl_mvt=gen_exclusive_kl_mvt)
     picked = sys.argv[1:]          # e.g. `make_golden.py psis optimizers` regenerates only those fixtures
     if not picked:
         for f in os.listdir(HERE):

@@ -185,3 +185,23 @@ def test_meanfield_overlapped_batches_through_comm(engines):
     for i in range(B * rounds):
         assert abs(got[i][0] - ref[i][0]) < 1e-13 * abs(ref[i][0])
         np.testing.assert_allclose(got[i][1], ref[i][1], rtol=0, atol=1e-13 * np.max(np.abs(ref[i][1])))
+
+
+def test_multivariate_t_elbo_sums_through_comm(engines):
+    """vb_elbo_sums_mvt: the sum vector [F | sum g | sum g (z / s)'] all-reduced on a one-rank communicator."""
+    import viabel_amd as vb
+    plain, comm = engines
+    D, N = 96, 700
+    rng = np.random.RandomState(9)
+    spec = vb.FunnelModel(D, 11).device_spec()
+    A = rng.randn(D, D)
+    root = A @ A.T / D + np.eye(D)
+    mu, inv_s = 0.1 * rng.randn(D), 1.0 / np.sqrt(rng.chisquare(8.0, N) / 8.0)
+    out = []
+    for eng in (plain, comm):
+        eng.set_model(spec)
+        eng.noise_generate(3, N, D, seed=5, stream=2)
+        out.append(eng.elbo_sums_mvt(3, N, D, mu, root, inv_s))
+    assert abs(out[0][0] - out[1][0]) < 1e-13 * abs(out[0][0])
+    for a, b in zip(out[0][1:], out[1][1:]):
+        np.testing.assert_allclose(b, a, rtol=0, atol=1e-13 * np.max(np.abs(a)))

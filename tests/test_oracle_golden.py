@@ -40,11 +40,12 @@ def test_family_forward(path):
 @pytest.mark.parametrize('path', G.fixtures('ekl_'), ids=lambda p: p.split('/')[-1][:-4])
 def test_exclusive_kl(path):
     fx = G.load(path)
-    v, g = oobj.exclusive_kl(G.oracle_family(fx), G.oracle_model(fx), fx['theta'], fx['noise'],
+    v, g = oobj.exclusive_kl(G.oracle_family(fx), G.oracle_model(fx), fx['theta'], G.noise_of(fx),
                              use_path_deriv=bool(fx['use_path_deriv']))
     assert G.rel_err(v, fx['value']) < 1e-12
     assert G.rel_err(g, fx['grad']) < 1e-12
-    assert G.rel_err(g, fx['grad_fd']) < 2e-7
+    # the MultivariateT reference closure differentiates scipy's sqrtm: its finite differences are noisier
+    assert G.rel_err(g, fx['grad_fd']) < (2e-6 if str(fx['family_kind']) == 'multivariate_t' else 2e-7)
 
 
 @pytest.mark.parametrize('path', G.fixtures('rge_'), ids=lambda p: p.split('/')[-1][:-4])

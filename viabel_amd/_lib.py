@@ -58,6 +58,9 @@ SIGNATURES = {
                                                           ctypes.c_int, ctypes.c_double, _c_double_p,
                                                           ctypes.c_uint, ctypes.c_int,
                                                           ctypes.POINTER(ctypes.c_int)]),
+    'vb_elbo_sums_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+                                        _c_double_p]),
     'vb_elbo_grad_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_uint, _c_double_p,
                                             _c_double_p]),
@@ -277,6 +280,18 @@ class Engine:
         grad = np.empty(p, dtype=np.float64)
         self._check(self._lib.vb_result_get(self._ctx, rslot, ctypes.byref(value), _dptr(grad), p))
         return value.value, grad
+
+    # ------------------------------------------------------------------ ExclusiveKL, multivariate t
+    def elbo_sums_mvt(self, slot, n, d, mu, sqrt_sigma, inv_s, n_total=None):
+        """(sum f, sum g (D,), sum g (z / s)' (D, D)) over the samples x = mu + (z sqrt_sigma) / s."""
+        mu, sqrt_sigma, inv_s = _f64(mu), _f64(sqrt_sigma), _f64(inv_s)
+        f = ctypes.c_double(0.0)
+        g = np.empty(d, dtype=np.float64)
+        c = np.empty((d, d), dtype=np.float64)
+        self._check(self._lib.vb_elbo_sums_mvt(self._ctx, slot, n, d, n if n_total is None else n_total,
+                                               _dptr(mu), _dptr(sqrt_sigma), _dptr(inv_s), ctypes.byref(f),
+                                               _dptr(g), _dptr(c)))
+        return f.value, g, c
 
     # ------------------------------------------------------------------ ExclusiveKL, low-rank Gaussian
     def elbo_grad_lowrank(self, slot_eps, slot_z, n, d, k, theta, flags=0, n_total=None):

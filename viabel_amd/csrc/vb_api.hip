@@ -209,7 +209,7 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
-                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work, &ctx->lr_work})
+                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work, &ctx->lr_work, &ctx->mvt_elbo})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& ev : ctx->prof_events) {
@@ -630,6 +630,18 @@ int vb_dis_grad_mvt(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* 
     return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   return mvt_dis_grad(ctx, n, d, df, theta, l_inv, weights, w_sum, w_logq, d_mu, gram);
+}
+
+int vb_elbo_sums_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, const double* mu,
+                     const double* sqrt_sigma, const double* inv_s, double* f_sum, double* g_sum, double* c_full) {
+  if (!ctx || !mu || !sqrt_sigma || !inv_s || !f_sum || !g_sum || !c_full)
+    return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return mvt_elbo_sums(ctx, ctx->noise[slot], n, d, n_total, mu, sqrt_sigma, inv_s, f_sum, g_sum, c_full);
 }
 
 // ---- ExclusiveKL, full-rank Gaussian ---------------------------------------------------------------

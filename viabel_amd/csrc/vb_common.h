@@ -108,6 +108,7 @@ struct vb_ctx {
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
   int64_t dis_n_total = 0;              // whole-job sample count of the DIS state
+  vb::DeviceBuffer mvt_elbo;            // multivariate-t ExclusiveKL: root, mean, row scales
   vb::DeviceBuffer lr_work;             // low-rank Gaussian family: workspace of the streaming pipeline
   vb::DeviceBuffer rows_work;           // Model.__call__ for the dense targets: GEMM output rows
   vb::DeviceBuffer psis_lw;             // PSIS: log importance weights (+ 16 result scalars)
@@ -185,6 +186,9 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
                         double* logp_host, double* logq_host);
 int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
                      const double* theta_src, const double* w_host, double scale, double* out);
+int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, const double* mu_host,
+                  const double* root_host, const double* inv_s_host, double* f_sum, double* g_sum, double* c_full);
+
 // vb_lowrank.hip
 int lr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
                          int64_t n_total, const double* theta_src, double* out);
@@ -200,6 +204,10 @@ int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, 
 int sync_streams(vb_ctx* ctx);   // main + pipeline streams
 
 // full-rank Gaussian ExclusiveKL (vb_fullrank.hip)
+struct FrSums;
+int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
+                        const double* theta_dev, double* out_dev, const double* mu_dev, const double* root_dev,
+                        const double* row_scale, FrSums* sums_out);
 int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
                          const double* theta_dev, double* out_dev);
 

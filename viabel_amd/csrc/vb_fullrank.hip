@@ -60,12 +60,14 @@ __global__ void __launch_bounds__(256) fr_unpack_kernel(const double* __restrict
 }
 
 // ---- GEMM epilogues ---------------------------------------------------------------------------------
-struct EpiStoreZ {          // Z = acc + mu - shift   (shift = 0, or the target mean for gauss_full)
+struct EpiStoreZ {          // Z = acc [* rs_n] + mu - shift   (shift = 0, or the target mean for gauss_full)
   double* Z;
   int64_t ldz;
   const double* mu;
   const double* shift;      // may be nullptr
+  const double* rs;         // per-row scale (multivariate t: 1 / s_n), may be nullptr
   __device__ void operator()(int, int row, int col, double acc) const {
+    if (rs) acc *= rs[row];
     double z = acc + mu[col];
     if (shift) z -= shift[col];
     Z[(int64_t)row * ldz + col] = z;
@@ -78,7 +80,9 @@ struct EpiGaussDiag {       // G = -(z - m) / sd^2  straight from the GEMM-1 acc
   const double* mu;
   const double* mean;
   const double* ivar;
+  const double* rs;         // per-row scale, may be nullptr
   __device__ void operator()(int, int row, int col, double acc) const {
+    if (rs) acc *= rs[row];
     const double dz = acc + mu[col] - mean[col];
     G[(int64_t)row * ldz + col] = -dz * ivar[col];
   }
@@ -198,7 +202,7 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
                                                         int64_t slab, int d, int64_t ldl,
                                                         const double* __restrict__ colpart, int n_rb,
                                                         int64_t ldz, const double* __restrict__ fpart,
-                                                        int n_fpart, FrSums S) {
+                                                        int n_fpart, FrSums S, int full) {
   __shared__ double sh[4];
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t idx = 2 * tid;
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
   if (idx < nC) {
     const int i = (int)(idx / ldl), j = (int)(idx % ldl);
     fr_d2 s = (fr_d2){0.0, 0.0};
-    if (j <= i) {
+    if (full || j <= i) {
       for (int k0 = 0; k0 < splits; k0 += 8) {
         fr_d2 v[8];
 #pragma unroll
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
       }
-      if (j + 1 > i) s.y = 0.0;
+      if (!full && j + 1 > i) s.y = 0.0;
     }
     *reinterpret_cast<fr_d2*>(S.sums + S.off_c + idx) = s;
   }
@@ -271,6 +275,14 @@ __global__ void __launch_bounds__(256) fr_epilogue_kernel(FrSums S, const double
   }
 }
 
+// G[n][:] *= rs[n]  (multivariate t: the Gram GEMM then yields sum_n g_n (z_n / s_n)')
+__global__ void __launch_bounds__(256) fr_rowscale_kernel(double* __restrict__ G, int64_t ldz, int64_t n, int d,
+                                                          const double* __restrict__ rs) {
+  const int64_t row = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < d) G[row * ldz + c] *= rs[row];
+}
+
 // ---- wrappers shared with the multivariate-t path (vb_mvt.hip) ---------------------------------------
 int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,
                       const double* ivar, double* colpart, double* fpart) {
@@ -285,7 +297,7 @@ int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab
                       const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S) {
   const int64_t items = slab / 2 > ldz ? slab / 2 : ldz;
   hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, Cpart,
-                     splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S);
+                     splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S, 0);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -316,9 +328,14 @@ int gram_splits(vb_ctx* ctx, int d, int64_t n) {
 }
 
 // ---- host orchestration ------------------------------------------------------------------------------
-int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
-                         const double* theta_dev, double* out_dev) {
+// theta_dev != nullptr: full-rank Gaussian (Z = E L' + mu, lower-triangular gradient, epilogue into the flat layout).
+// theta_dev == nullptr: multivariate t (X = (E R) / s + mu with the dense symmetric root R and the per-row scale
+// `row_scale`; the caller gets the raw sums [F | sum g | sum_n g_n (e_n / s_n)' (full D x D)] in `sums_out`).
+int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
+                        const double* theta_dev, double* out_dev, const double* mu_dev, const double* root_dev,
+                        const double* row_scale, FrSums* sums_out) {
   const ModelDev& m = ctx->model;
+  const bool mvt = theta_dev == nullptr;
   if (m.id != VB_MODEL_GAUSS_DIAG && m.id != VB_MODEL_FUNNEL && m.id != VB_MODEL_GAUSS_FULL)
     return fail(ctx, VB_ERR_UNSUPPORTED, "full-rank path: unsupported model id %d", m.id);
   if (m.dim != d)
@@ -331,7 +348,7 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   const int64_t ldl = round_up(d, 16), ldz = round_up(d, 16);
   const int n_cu = ctx->prop.multiProcessorCount;
   const int tiles = gemm_tiles(D, 128);
-  const int lower_tiles = tiles * (tiles + 1) / 2;
+  const int lower_tiles = mvt ? tiles * tiles : tiles * (tiles + 1) / 2;
   int splits = n_cu / lower_tiles;   // one wave of workgroups: no second, mostly empty round
   const int max_splits = (int)(n / 256) > 0 ? (int)(n / 256) : 1;
   if (splits > max_splits) splits = max_splits;
@@ -362,9 +379,15 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
          *colpart = base + o_col, *fpart = base + o_fpart;
   S.sums = base + o_sums;
 
-  hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((d * d + 255) / 256)), dim3(256), 0, st, theta_dev,
-                     D, ldl, Lt, mu);
-  VB_HIP(ctx, hipGetLastError());
+  if (mvt) {
+    VB_HIP(ctx, hipMemcpyAsync(mu, mu_dev, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
+    VB_HIP(ctx, hipMemcpy2DAsync(Lt, (size_t)ldl * sizeof(double), root_dev, (size_t)ldl * sizeof(double),
+                                 (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
+  } else {
+    hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((d * d + 255) / 256)), dim3(256), 0, st, theta_dev,
+                       D, ldl, Lt, mu);
+    VB_HIP(ctx, hipGetLastError());
+  }
 
   // GEMM 1: Z[n][j] = sum_k E[n][k] Lt[k][j]   (Lt[k][j] = 0 for k > j)
   GemmArgs g1;
@@ -375,19 +398,19 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   g1.M = (int)n;
   g1.N = D;
   g1.K = D;
-  g1.tri_mode = 1;
+  g1.tri_mode = mvt ? 0 : 1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int fmode = 0;
   if (m.id == VB_MODEL_GAUSS_DIAG) {
-    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiag{G, ldz, mu, m.p0, m.p1});
+    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiag{G, ldz, mu, m.p0, m.p1, row_scale});
     fmode = 1;
   } else if (m.id == VB_MODEL_FUNNEL) {
-    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, nullptr});
+    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, nullptr, row_scale});
     VB_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(fr_funnel_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)Z,
                        G, ldz, n, D, m, fpart);
   } else {
-    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0});   // Z - m
+    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0, row_scale});   // Z - m
     VB_HIP(ctx, hipGetLastError());
     GemmArgs g2;                                   // G = -(Z - m) P,  P symmetric: B[k][j] = P[k][j]
     g2.A = Z;
@@ -408,7 +431,12 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
                      m.id == VB_MODEL_FUNNEL ? fpart + n_fpart /*unused tail*/ : fpart);
   VB_HIP(ctx, hipGetLastError());
 
-  // GEMM 3: C[i][j] = sum_n G[n][i] E[n][j], lower-triangular tiles, split over n
+  if (row_scale) {
+    hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)n), dim3(256), 0, st, G, ldz, n,
+                       D, row_scale);
+    VB_HIP(ctx, hipGetLastError());
+  }
+  // GEMM 3: C[i][j] = sum_n G[n][i] E[n][j], lower-triangular tiles (all tiles for the t family), split over n
   GemmArgs g3;
   g3.A = G;
   g3.lda = ldz;
@@ -417,7 +445,7 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   g3.M = D;
   g3.N = D;
   g3.K = (int)n;
-  g3.tri_mode = 2;
+  g3.tri_mode = mvt ? 0 : 2;
   (void)ev0;
   (void)ev1;
   gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
@@ -426,15 +454,24 @@ int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d,
   const int64_t red_items = slab / 2 > ldz ? slab / 2 : ldz;
   hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((red_items + 255) / 256)), dim3(256), 0, st,
                      (const double*)Cpart, splits, slab, D, ldl, (const double*)colpart, n_rb, ldz,
-                     (const double*)fpart, n_fpart, S);
+                     (const double*)fpart, n_fpart, S, mvt ? 1 : 0);
   VB_HIP(ctx, hipGetLastError());
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
+  if (mvt) {
+    *sums_out = S;
+    return VB_OK;
+  }
 
   const int64_t np = d * (d + 1) / 2;
   hipLaunchKernelGGL(fr_epilogue_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, S, theta_dev,
                      D, ldl, (double)n_total, (double)n_total, m.c0, out_dev);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
+}
+
+int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
+                         const double* theta_dev, double* out_dev) {
+  return fr_pipeline_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev, nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // namespace vb

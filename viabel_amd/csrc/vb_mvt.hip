@@ -366,4 +366,37 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   return VB_OK;
 }
 
+// ---- ExclusiveKL (entropy form, objectives.py:154-164) for the multivariate t --------------------------------
+// x_n = mu + (z_n R) / s_n with R = Sigma^{1/2} (symmetric).  The device returns the sample sums
+//   F = sum_n f(x_n),  sum_n g_n,  C = sum_n g_n (z_n / s_n)'   (full D x D: dF / dR for an unconstrained R);
+// the O(D^3) chain rule R -> Sigma -> free Cholesky parameters is the caller's (host), like the symmetric root.
+int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, const double* mu_host,
+                  const double* root_host, const double* inv_s_host, double* f_sum, double* g_sum, double* c_full) {
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  const int64_t ld = round_up(d, 16);
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t o_root = carve(d * ld), o_mu = carve(ld), o_invs = carve(n);
+  VB_TRY(ensure(ctx, ctx->mvt_elbo, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->mvt_elbo.ptr;
+  VB_TRY(upload_padded(ctx, base + o_root, ld, root_host, d, d, false));
+  VB_HIP(ctx, hipMemcpyAsync(base + o_mu, mu_host, (size_t)d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VB_HIP(ctx, hipMemcpyAsync(base + o_invs, inv_s_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  FrSums S;
+  VB_TRY(fr_pipeline_enqueue(ctx, ns, n, d, n_total, nullptr, nullptr, base + o_mu, base + o_root, base + o_invs, &S));
+  hipStream_t st = ctx->stream;
+  VB_HIP(ctx, hipMemcpyAsync(f_sum, S.sums, sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(g_sum, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(c_full, (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)ld * sizeof(double),
+                               (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  // the per-sample additive constant of f; the all-reduced sums cover every rank's rows
+  *f_sum += (double)(ctx->comm ? n_total : n) * ctx->model.c0;
+  return VB_OK;
+}
+
 }  // namespace vb

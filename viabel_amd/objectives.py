@@ -180,6 +180,10 @@ class ExclusiveKL(StochasticVariationalObjective):
                 n_local, n_total = self._stage_noise(eng, self.num_mc_samples)
                 return eng.elbo_grad_fullrank(_NOISE_SLOT, n_local, approx.dim, var_param,
                                               flags=flags, n_total=n_total)
+        elif isinstance(approx, MultivariateT):
+            if cv_mode != 0 or self._use_path_deriv:
+                raise NotImplementedError('MultivariateT supports the entropy-form ExclusiveKL estimator only')
+            objective_and_grad = self._mvt_exclusive_kl(approx)
         elif isinstance(approx, LRGaussian):
             if cv_mode != 0 or self._use_path_deriv:
                 raise NotImplementedError('LRGaussian supports the entropy-form ExclusiveKL estimator only')
@@ -199,9 +203,47 @@ class ExclusiveKL(StochasticVariationalObjective):
                                              n_total=N)
         else:
             raise NotImplementedError(
-                'ExclusiveKL on the HIP engine supports MFGaussian, MFStudentT, FullRankGaussian and '
-                'LRGaussian; got {}'.format(type(approx).__name__))
+                'ExclusiveKL on the HIP engine supports MFGaussian, MFStudentT, FullRankGaussian, MultivariateT '
+                'and LRGaussian; got {}'.format(type(approx).__name__))
         self._objective_and_grad = objective_and_grad
+
+
+    def _mvt_exclusive_kl(self, approx):
+        """Entropy-form ELBO for the multivariate t: sampling, model gradient and the D x D contraction
+        sum_n g_n (z_n / s_n)' on the device; the O(D^3) chain rule through the symmetric root on the host (the
+        reference differentiates ``sqrtm`` with autograd, ``approximations.py:348``)."""
+        D, df = approx.dim, approx.df
+        tril = np.tril_indices(D)
+
+        def objective_and_grad(var_param):
+            var_param = np.asarray(var_param, dtype=np.float64)
+            if var_param.shape != (approx.var_param_dim,):
+                raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+            eng = self._engine()
+            eng.set_model(self.model.device_spec())
+            N = self.num_mc_samples
+            begin, end = shard_rows(N, eng.n_ranks, eng.rank)
+            if approx.rng == 'philox':
+                chi = approx._rs.chisquare(df, N)
+                eng.noise_generate(_NOISE_SLOT, end - begin, D, approx._seed, approx._next_philox_stream(),
+                                   row_offset=begin)
+            else:
+                chi, z = approx._base_noise(N)          # chi-square draws first (approximations.py:345-347)
+                eng.noise_set_host(_NOISE_SLOT, z[begin:end])
+            mu, L = approx._unpack(var_param)
+            w, U = np.linalg.eigh(L @ L.T)
+            r = np.sqrt(w)
+            root = (U * r) @ U.T
+            inv_s = 1.0 / np.sqrt(chi / df)
+            f_sum, g_sum, C = eng.elbo_sums_mvt(_NOISE_SLOT, end - begin, D, mu, root, inv_s[begin:end], n_total=N)
+            value = -(f_sum / N + approx.entropy(var_param))
+            Gs = 0.5 * (C + C.T) / N                                 # d mean f / d root, symmetrised
+            X = U @ ((U.T @ Gs @ U) / (r[:, None] + r[None, :])) @ U.T   # root -> Sigma (Sylvester solve)
+            dL = np.tril(2.0 * X @ L)
+            dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + 1.0  # free (log) diagonal, entropy gradient
+            return value, -np.concatenate([g_sum / N, dL[tril]])
+
+        return objective_and_grad
 
 
 class DISInclusiveKL(StochasticVariationalObjective):
