@@ -94,3 +94,27 @@ def test_quickstart_example_runs(capsys):
     opt = results['opt_param']
     assert abs(opt[0]) < 0.5 and abs(opt[1]) < 1.0          # mean-field fit of the funnel sits near the origin
     assert np.isfinite(diagnostics['khat']) and diagnostics['smoothed_log_weights'].shape == (100000,)
+
+
+def test_logistic_regression_raabbvi(vb, capsys):
+    """BASELINE configs[4] in miniature: mean-field Gaussian + ExclusiveKL on the logistic-regression target,
+    RMSProp with RAABBVI step-size adaptation (the default of `bbvi`).  The variational mean must land on the
+    posterior mode (Newton iterations on the host as the yardstick)."""
+    rng = np.random.RandomState(4)
+    D, n_data = 20, 400
+    X = rng.randn(n_data, D) / np.sqrt(D)
+    beta = rng.randn(D)
+    y = (rng.rand(n_data) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    model = vb.LogisticRegressionModel(X, y, prior_sd=10.0)
+    b = np.zeros(D)
+    for _ in range(50):                                   # MAP by Newton's method
+        p = 1 / (1 + np.exp(-X @ b))
+        g = X.T @ (y - p) - b / 100.0
+        H = -(X.T * (p * (1 - p))) @ X - np.eye(D) / 100.0
+        b = b - np.linalg.solve(H, g)
+    np.random.seed(7)
+    results = vb.bbvi(D, log_density=model, num_mc_samples=64, n_iters=6000, learning_rate=0.05)
+    capsys.readouterr()
+    mean = results['opt_param'][:D]
+    post_sd = np.sqrt(np.diag(np.linalg.inv(-H)))
+    assert np.max(np.abs(mean - b) / post_sd) < 0.6, np.max(np.abs(mean - b) / post_sd)
