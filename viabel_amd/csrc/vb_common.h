@@ -58,7 +58,7 @@ struct NoiseSlot {
 
 // Software pipeline over three HIP streams (prep | streaming kernel | finalize + collectives), used
 // by the asynchronous batch entry points so that consecutive batches overlap.
-constexpr int kPipeSets = 3;
+constexpr int kPipeSets = 4;
 struct Pipeline {
   hipStream_t pre = nullptr, post = nullptr;
   hipEvent_t ev_main = nullptr;
@@ -167,6 +167,9 @@ struct MfCall {
   int cv_mode = 0;
   int mode = 0;        // 0: ELBO (ExclusiveKL); 1: weighted gradient only
   bool pipelined = false;   // spread prep / stream / finalize over the three pipeline streams
+  bool alternate = false;      // single GPU, independent asynchronous batches: odd workspace sets run on the
+                               // `post` stream, even ones on the main stream, so the small prep / finalize kernels of
+                               // one batch overlap the streaming kernel of the other (no events between them)
   bool overlap_comm = false;   // sharded job: all-reduce + epilogue on the `post` stream, so the next batch's
                                // kernels run on the main stream while RCCL moves this batch's sums
   double scale = 0.0;  // mode 1

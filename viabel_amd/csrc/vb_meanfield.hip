@@ -933,9 +933,25 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   Pipeline& P = ctx->pipe;
   hipStream_t st_pre = ctx->stream, st_main = ctx->stream, st_post = ctx->stream;
   const bool overlap = c.overlap_comm && !c.pipelined && ctx->comm != nullptr;
+  // alternate: consecutive independent batches go to two streams.  The stream is a function of the workspace
+  // set (odd -> `post`), and a set comes round again four batches later, i.e. on the same stream, so no event is
+  // needed between batches; `post` only has to be ordered after earlier main-stream work (noise uploads, blocking
+  // calls), and later main-stream writers wait for `post` through post_pending as for the other modes.
+  const bool alt = c.alternate && !c.pipelined && !overlap && ctx->comm == nullptr;
+  const bool alt_b = alt && (set & 1);
   if (overlap) {
     VB_TRY(pipe_init(ctx));
     if (P.fin_valid[set]) VB_HIP(ctx, hipStreamWaitEvent(ctx->stream, P.ev_fin[set], 0));   // set is free again
+  } else if (alt) {
+    VB_TRY(pipe_init(ctx));
+    if (alt_b) {
+      if (P.main_dirty) {
+        VB_HIP(ctx, hipEventRecord(P.ev_main, ctx->stream));
+        VB_HIP(ctx, hipStreamWaitEvent(P.post, P.ev_main, 0));
+        P.main_dirty = false;
+      }
+      st_pre = st_main = st_post = P.post;
+    }
   } else if (c.pipelined) {
     VB_TRY(pipe_init(ctx));
     st_pre = P.pre;
@@ -1014,11 +1030,13 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
     hipLaunchKernelGGL(mf_epilogue_kernel, dim3(1, (unsigned)c.count), dim3(256), 0, st_post, e, bp, ws);
     VB_HIP(ctx, hipGetLastError());
   }
-  if (c.pipelined || overlap) {
+  if (c.pipelined || overlap || alt_b) {
     VB_HIP(ctx, hipEventRecord(P.ev_fin[set], st_post));
     P.fin_valid[set] = true;
     P.post_pending = true;
     P.last_set = set;
+  } else if (alt) {
+    // main-stream batch of an alternating pair: nothing on `post` depends on it
   } else {
     P.fin_valid[set] = false;   // ordered by the main stream itself ...
     P.main_dirty = true;        // ... which a later pipelined prep must wait for
