@@ -100,6 +100,17 @@ def cpu_baseline(theta, budget_s=12.0):
     }
 
 
+def parity_check(eng, theta, fam_id):
+    """BASELINE's second metric: relative ELBO error of the HIP path against the CPU restatement on the same
+    noise (one of the resident Philox matrices read back from the device).  north_star asks <= 1e-5."""
+    from oracle import families as ofam, models as omod, objectives as oobj
+    noise = eng.noise_get_host(0, N_MC, D)
+    dv, dg = eng.elbo_grad_meanfield(0, N_MC, D, theta, fam_id)
+    ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omod.Funnel(D), theta, noise)
+    return {'rel_elbo_err': abs(dv - ov) / abs(ov), 'rel_grad_err': float(np.max(np.abs(dg - og)) / np.max(np.abs(og))),
+            'tolerance': 1e-5, 'against': 'numpy oracle (oracle/objectives.py) on the same 4096 x 1024 noise matrix'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -264,6 +275,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(theta)
+            out['parity'] = parity_check(eng, theta, fam)
         if world == 1 and not args.no_fullrank:
             out['fullrank'] = fullrank_leg(eng, vb)
         # RCCL prints a version banner through C stdio; push it out first so the JSON is the last line
