@@ -165,3 +165,16 @@ def test_model_call_dense_targets(vb, kind):
     f, fo = model(x), omodel.logp(x)
     np.testing.assert_allclose(f, fo, rtol=0, atol=1e-12 * np.max(np.abs(fo)))
     assert model(x[0]).shape == (1,)
+
+
+def test_vi_diagnostics_philox_mode(vb, capsys):
+    """Throughput mode: the diagnostics' 1e5 base draws come from the device generator (normal and Student-t)."""
+    D = 6
+    model = vb.GaussianModel(np.zeros(D), np.ones(D))
+    for approx in (vb.MFGaussian(D, rng='philox'), vb.MFStudentT(D, 40.0, rng='philox')):
+        theta = np.concatenate([0.01 * np.ones(D), 0.02 * np.ones(D)])
+        res = vb.vi_diagnostics(theta, approx=approx, model=model)
+        capsys.readouterr()
+        assert res['khat'] < 0.7 and res['d2'] < 0.5
+        assert res['samples'].shape == (D, 100000)
+        assert abs(res['samples'].mean()) < 0.02

@@ -109,8 +109,14 @@ def psis_correction(var_param, model, approx, n_samples):
     if _on_device_weights(model, approx):
         eng = _lib.default_engine()
         eng.set_model(model.device_spec())
-        noise = approx._base_noise(n_samples)
-        eng.noise_set_host(_DIAG_SLOT, noise)
+        if approx.rng == 'philox':          # base noise drawn on the GPU; read back only for the returned samples
+            kind, kdf = approx._philox_kind()
+            eng.noise_generate(_DIAG_SLOT, n_samples, approx.dim, approx._seed, approx._next_philox_stream(),
+                               kind=kind, df=kdf)
+            noise = eng.noise_get_host(_DIAG_SLOT, n_samples, approx.dim)
+        else:
+            noise = approx._base_noise(n_samples)
+            eng.noise_set_host(_DIAG_SLOT, noise)
         family, df = approx._device_family()
         eng.log_weights_meanfield(_DIAG_SLOT, n_samples, approx.dim, var_param, family, df=df, fetch=False)
         smoothed, khat = eng.psis_smooth(n_samples)
