@@ -1,0 +1,103 @@
+"""GPU: property-based parity.  Random shapes (odd D, N below / across the row-tile and column-block edges),
+families, targets, estimator variants and parameters; the HIP path must match the oracle on the same draws.
+Tolerances: value 1e-12 relative (on the scale of its terms), gradient 1e-10 relative to max|grad|."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import families as ofam
+from oracle import models as omod
+from oracle import objectives as oobj
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(max_examples=40, deadline=None, derandomize=True,
+           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+
+
+def _models(vb, kind, D, rng):
+    if kind == 'gauss_diag':
+        mean, sd = rng.randn(D), np.exp(0.4 * rng.randn(D))
+        return vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    k = int(rng.randint(D))
+    return vb.FunnelModel(D, k, 0.7), omod.Funnel(D, k, 0.7)
+
+
+def _close(value, grad, ov, og, scale=None):
+    scale = max(abs(ov), 1.0) if scale is None else scale
+    assert abs(value - ov) <= 1e-12 * scale, (value, ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-10 * max(np.max(np.abs(og)), 1e-300))
+
+
+@settings(**CFG)
+@given(D=st.integers(2, 300), N=st.integers(1, 700), student=st.booleans(), pd=st.booleans(),
+       target=st.sampled_from(['gauss_diag', 'funnel']), seed=st.integers(0, 10 ** 6))
+def test_meanfield_exclusive_kl(D, N, student, pd, target, seed):
+    import viabel_amd as vb
+    rng = np.random.RandomState(seed)
+    model, omodel = _models(vb, target, D, rng)
+    if student:
+        approx, ofamily = vb.MFStudentT(D, 6.5, seed=seed), ofam.MFStudentT(D, 6.5)
+    else:
+        approx, ofamily = vb.MFGaussian(D, seed=seed), ofam.MFGaussian(D)
+    theta = np.concatenate([0.5 * rng.randn(D), -0.7 + 0.4 * rng.randn(D)])
+    value, grad = vb.ExclusiveKL(approx, model, N, use_path_deriv=pd)(theta)
+    noise = ofamily.draw_noise(np.random.RandomState(seed), N)
+    ov, og = oobj.exclusive_kl(ofamily, omodel, theta, noise, use_path_deriv=pd)
+    z = ofamily.sample_from_noise(theta, noise)
+    _close(value, grad, ov, og, scale=max(abs(ov), np.mean(np.abs(omodel.logp(z))), 1.0))
+
+
+@settings(**CFG)
+@given(D=st.integers(2, 200), N=st.integers(2, 500), method=st.sampled_from(['full', 'mean_only', 'loo_diag_approx',
+                                                                              'loo_direct_approx']),
+       target=st.sampled_from(['gauss_diag', 'funnel']), seed=st.integers(0, 10 ** 6))
+def test_meanfield_control_variates(D, N, method, target, seed):
+    import viabel_amd as vb
+    rng = np.random.RandomState(seed)
+    model, omodel = _models(vb, target, D, rng)
+    theta = np.concatenate([0.3 * rng.randn(D), -0.8 + 0.3 * rng.randn(D)])
+    value, grad = vb.ExclusiveKL(vb.MFGaussian(D, seed=seed), model, N, hessian_approx_method=method)(theta)
+    noise = np.random.RandomState(seed).randn(N, D)
+    ov, og = oobj.rge_reduced(ofam.MFGaussian(D), omodel, theta, noise, method)
+    z = theta[:D] + np.exp(theta[D:]) * noise
+    assert abs(value - ov) <= 1e-12 * max(abs(ov), np.mean(np.abs(omodel.logp(z))), 1.0)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-9 * np.max(np.abs(og)))
+
+
+@settings(**dict(CFG, max_examples=25))
+@given(D=st.integers(2, 150), N=st.integers(1, 400), k=st.integers(1, 16), target=st.sampled_from(['gauss_diag', 'funnel']),
+       seed=st.integers(0, 10 ** 6))
+def test_lowrank_exclusive_kl(D, N, k, target, seed):
+    import viabel_amd as vb
+    rng = np.random.RandomState(seed)
+    model, omodel = _models(vb, target, D, rng)
+    fam = vb.LRGaussian(D, seed=seed, k=k)
+    theta = fam.pack(0.3 * rng.randn(D), -0.8 + 0.2 * rng.randn(D), 0.2 * rng.randn(D, k))
+    value, grad = vb.ExclusiveKL(fam, model, N)(theta)
+    noise = ofam.LRGaussian(D, k).draw_noise(np.random.RandomState(seed), N)
+    ov, og = oobj.exclusive_kl(ofam.LRGaussian(D, k), omodel, theta, noise)
+    _close(value, grad, ov, og)
+
+
+@settings(**dict(CFG, max_examples=20))
+@given(D=st.integers(2, 140), N=st.integers(1, 400), target=st.sampled_from(['gauss_diag', 'funnel', 'gauss_full']),
+       seed=st.integers(0, 10 ** 6))
+def test_fullrank_exclusive_kl(D, N, target, seed):
+    import viabel_amd as vb
+    rng = np.random.RandomState(seed)
+    if target == 'gauss_full':
+        A = rng.randn(D, D)
+        S = A @ A.T / D + np.eye(D)
+        mean = rng.randn(D)
+        model, omodel = vb.CorrelatedGaussianModel(mean, covariance=S), omod.GaussFull(mean, np.linalg.inv(S))
+    else:
+        model, omodel = _models(vb, target, D, rng)
+    fam = vb.FullRankGaussian(D, seed=seed)
+    L = np.tril(0.1 * rng.randn(D, D))
+    L[np.diag_indices(D)] = np.exp(-0.8 + 0.2 * rng.randn(D))
+    theta = fam.pack(0.3 * rng.randn(D), L)
+    value, grad = vb.ExclusiveKL(fam, model, N)(theta)
+    noise = np.random.RandomState(seed).randn(N, D)
+    ov, og = oobj.exclusive_kl(ofam.FullRankGaussian(D), omodel, theta, noise)
+    _close(value, grad, ov, og)
