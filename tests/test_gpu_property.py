@@ -101,3 +101,47 @@ def test_fullrank_exclusive_kl(D, N, target, seed):
     noise = np.random.RandomState(seed).randn(N, D)
     ov, og = oobj.exclusive_kl(ofam.FullRankGaussian(D), omodel, theta, noise)
     _close(value, grad, ov, og)
+
+
+@settings(**dict(CFG, max_examples=25))
+@given(D=st.integers(2, 120), N=st.integers(2, 400), alpha=st.sampled_from([0.5, 2.0, 3.0]), student=st.booleans(),
+       target=st.sampled_from(['gauss_diag', 'funnel']), seed=st.integers(0, 10 ** 6))
+def test_alpha_divergence(D, N, alpha, student, target, seed):
+    import viabel_amd as vb
+    rng = np.random.RandomState(seed)
+    model, omodel = _models(vb, target, D, rng)
+    if student:
+        approx, ofamily = vb.MFStudentT(D, 9.0, seed=seed), ofam.MFStudentT(D, 9.0)
+    else:
+        approx, ofamily = vb.MFGaussian(D, seed=seed), ofam.MFGaussian(D)
+    theta = np.concatenate([0.2 * rng.randn(D), -0.5 + 0.2 * rng.randn(D)])
+    np.random.seed(seed)                         # AlphaDivergence seeds its draw from the global RNG (:455)
+    value, grad = vb.AlphaDivergence(approx, model, N, alpha)(theta)
+    np.random.seed(seed)
+    draw_seed = np.random.randint(2 ** 32)
+    noise = ofamily.draw_noise(np.random.RandomState(draw_seed), N)
+    ov, og = oobj.alpha_divergence(ofamily, omodel, theta, noise, alpha)
+    assert abs(value - ov) <= 1e-11 * max(abs(ov), 1.0), (value, ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-10 * max(np.max(np.abs(og)), 1e-300))
+
+
+@settings(**dict(CFG, max_examples=20))
+@given(D=st.integers(2, 80), N=st.integers(8, 300), student=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_dis_without_resampling(D, N, student, seed):
+    import viabel_amd as vb
+    rng = np.random.RandomState(seed)
+    model, omodel = _models(vb, 'gauss_diag', D, rng)
+    if student:
+        approx, ofamily = vb.MFStudentT(D, 9.0, seed=seed), ofam.MFStudentT(D, 9.0)
+    else:
+        approx, ofamily = vb.MFGaussian(D, seed=seed), ofam.MFGaussian(D)
+    theta = np.concatenate([0.2 * rng.randn(D), 0.1 * rng.randn(D)])
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    ess = max(2, N // 3)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=ess, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, use_resampling=False)
+    value, grad = obj(theta)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, ess, ofam.MFGaussian(D), prior, use_resampling=False)
+    ov, og = ref(theta, ofamily.draw_noise(np.random.RandomState(seed), N))
+    assert abs(value - ov) <= 1e-10 * max(abs(ov), 1e-300), (value, ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-9 * max(np.max(np.abs(og)), 1e-300))
