@@ -161,6 +161,11 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
   auto load_frags = [&](int st, int kk, int set) __attribute__((always_inline)) {
     const double* as = As + st * kATile;
     const double* bs = Bs + st * kBTile;
+    // The compiler merges the AF reads below into ds_read2st64_b64 pairs, which are serviced 16 lanes at a time
+    // on 32 banks: 2-way conflicts for the [m][16] tile (SQ_LDS_BANK_CONFLICT 8.4 M of 25 M LDS cycles per
+    // 4096 x 1024 x 1024 launch).  Forcing single ds_read_b64 (opaque addresses) removed the conflicts and halved
+    // the LDS cycles but ran 5 % slower (157 vs 149 us): the extra address arithmetic and the lost scheduling
+    // freedom cost more than the LDS time, which the MFMAs hide anyway.
 #pragma unroll
     for (int a = 0; a < AF; ++a)
       fa[set][a] = A_KCONTIG ? as[a_off[kk < kAOffs ? kk : 0] + a * (16 * kGemmBK)] : as[a_off[a < kAOffs ? a : 0] + 4 * kk * BM];
