@@ -38,6 +38,9 @@ struct LrArgs {
   double* partials;       // [n_rb][2 + KP][Dp]
   double* pscal;          // [3 + KP][n_rb * n_cb]
   double* sums;           // [kLrScal | (2 + KP) x Dp]
+  double* mpart;          // [n_mblk][KP x KP] partial B' D^-1 B of 256-row blocks (prep)
+  double* minv;           // [KP x KP] inverse capacitance matrix | [KP x KP] = log det M  (capacitance kernel)
+  int n_mblk;
 };
 
 __device__ __forceinline__ double lr_wave_sum(double x) {
@@ -61,14 +64,36 @@ __global__ void __launch_bounds__(256) lr_prep_kernel(const double* __restrict__
       thc[threadIdx.x] = (int)threadIdx.x - 2 < k ? theta_src[2 * (int64_t)d + (int64_t)m.k * k + (threadIdx.x - 2)] : 0.0;
     __syncthreads();
   }
+  // theta lives in pinned host memory: this block's 256 rows of B (contiguous, 256 k doubles) cross PCIe once,
+  // coalesced, into LDS; every later use (device copy, padded B, capacitance products) reads the LDS copy
+  __shared__ double Bl[256 * KP];
+  const int64_t row0 = (int64_t)blockIdx.x * 256;
+  const bool has_rows = row0 < d;
+  double my_ls = 0.0;
+  if (has_rows) {
+    const int64_t nel = (d - row0 < 256 ? d - row0 : 256) * k;
+    double tmp[KP];                       // all of a thread's PCIe reads in flight at once
+#pragma unroll
+    for (int u = 0; u < KP; ++u) {
+      const int64_t e = (int64_t)u * 256 + threadIdx.x;
+      tmp[u] = e < nel ? theta_src[2 * (int64_t)d + row0 * k + e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < KP; ++u) {
+      const int64_t e = (int64_t)u * 256 + threadIdx.x;
+      if (e < nel) Bl[e] = tmp[u];
+    }
+    __syncthreads();
+  }
   if (i < a.Dp) {
     double c0 = 0.0, c1 = 0.0, c2 = 0.0;
     const bool live = i < d && !(funnel && i == m.k);
     if (i < d) {
       const double mu = theta_src[i], ls = theta_src[d + i];
+      my_ls = ls;
       a.theta_dev[i] = mu;
       a.theta_dev[d + i] = ls;
-      for (int j = 0; j < k; ++j) a.theta_dev[2 * (int64_t)d + i * k + j] = theta_src[2 * (int64_t)d + i * k + j];
+      for (int j = 0; j < k; ++j) a.theta_dev[2 * (int64_t)d + i * k + j] = Bl[threadIdx.x * k + j];
       if (live) {
         c0 = funnel ? mu : mu - m.p0[i];
         c1 = exp(ls);
@@ -79,7 +104,7 @@ __global__ void __launch_bounds__(256) lr_prep_kernel(const double* __restrict__
     a.colp[a.Dp + i] = c1;
     a.colp[2 * (int64_t)a.Dp + i] = c2;
 #pragma unroll
-    for (int j = 0; j < KP; ++j) a.Bp[i * KP + j] = (live && j < k) ? theta_src[2 * (int64_t)d + i * k + j] : 0.0;
+    for (int j = 0; j < KP; ++j) a.Bp[i * KP + j] = (live && j < k) ? Bl[threadIdx.x * k + j] : 0.0;
   }
   double acc[3 + KP];
 #pragma unroll
@@ -114,6 +139,84 @@ __global__ void __launch_bounds__(256) lr_prep_kernel(const double* __restrict__
   if (threadIdx.x < 3 + KP)
     a.prepscal[(int64_t)threadIdx.x * a.n_prep + blockIdx.x] =
         (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  // this block's share of B' D^-1 B (the k x k capacitance matrix of the determinant lemma): its 256 rows, scaled
+  // by 1 / sigma, go through LDS; the 256 threads form G groups of KP^2 (p, q) pairs, group g sums rows g, g + G, ...
+  if ((int)blockIdx.x < a.n_mblk) {
+    constexpr int G = 256 / (KP * KP);
+    __shared__ double wt[256][KP + 1];
+    __shared__ double mg[G][KP * KP];
+    const int t = threadIdx.x;
+    const double iv = i < d ? exp(-my_ls) : 0.0;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) wt[t][j] = (i < d && j < k) ? Bl[t * k + j] * iv : 0.0;
+    __syncthreads();
+    const int pq = t % (KP * KP), grp = t / (KP * KP);
+    const int p = pq / KP, q = pq % KP;
+    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int r = grp; r < 256; r += 4 * G) {
+      acc4[0] = fma(wt[r][p], wt[r][q], acc4[0]);
+      acc4[1] = fma(wt[r + G][p], wt[r + G][q], acc4[1]);
+      acc4[2] = fma(wt[r + 2 * G][p], wt[r + 2 * G][q], acc4[2]);
+      acc4[3] = fma(wt[r + 3 * G][p], wt[r + 3 * G][q], acc4[3]);
+    }
+    mg[grp][pq] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+    __syncthreads();
+    if (t < KP * KP) {
+      double tot = 0.0;
+#pragma unroll
+      for (int g = 0; g < G; ++g) tot += mg[g][t];
+      a.mpart[(int64_t)blockIdx.x * (KP * KP) + t] = tot;
+    }
+  }
+}
+
+// ---- capacitance matrix M = I + B' D^-1 B: Cholesky, inverse, log det (one small workgroup) --------------------
+// Right-looking Cholesky in LDS with one thread per matrix entry (3 barriers per column); the inverse by one
+// thread per column (forward / back substitution with the factor in LDS).
+template <int KP>
+__global__ void __launch_bounds__(KP * KP) lr_capacitance_kernel(const LrArgs a) {
+  __shared__ double M[KP][KP + 1];
+  const int t = threadIdx.x, p = t / KP, q = t % KP;
+  double s = (p == q) ? 1.0 : 0.0;
+  for (int b = 0; b < a.n_mblk; ++b) s += a.mpart[(int64_t)b * (KP * KP) + t];
+  M[p][q] = s;
+  __syncthreads();
+  for (int j = 0; j < KP; ++j) {
+    if (t == 0) M[j][j] = sqrt(M[j][j]);
+    __syncthreads();
+    if (q == j && p > j) M[p][j] /= M[j][j];
+    __syncthreads();
+    if (p > j && q > j && q <= p) M[p][q] -= M[p][j] * M[q][j];
+    __syncthreads();
+  }
+  if (t < KP) {   // column t of M^-1: C y = e_t, C' x = y
+    double y[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      double v = (i == t) ? 1.0 : 0.0;
+#pragma unroll
+      for (int r = 0; r < KP; ++r)
+        if (r < i) v -= M[i][r] * y[r];
+      y[i] = v / M[i][i];
+    }
+#pragma unroll
+    for (int ii = 0; ii < KP; ++ii) {
+      const int i = KP - 1 - ii;
+      double v = y[i];
+#pragma unroll
+      for (int r = 0; r < KP; ++r)
+        if (r > i) v -= M[r][i] * y[r];
+      y[i] = v / M[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < KP; ++i) a.minv[i * KP + t] = y[i];
+  }
+  if (t == 0) {
+    double ld = 0.0;
+    for (int j = 0; j < KP; ++j) ld += log(M[j][j]);
+    a.minv[KP * KP] = 2.0 * ld;
+  }
 }
 
 // ---- the streaming pass --------------------------------------------------------------------------------
@@ -332,116 +435,21 @@ __global__ void __launch_bounds__(256) lr_finalize_kernel(const LrArgs a, int fu
 template <int KP>
 __global__ void __launch_bounds__(256) lr_epilogue_kernel(const LrArgs a, double n_total, double model_c0,
                                                           int coupling, double* __restrict__ out) {
-  __shared__ double M[KP][KP + 1], Minv[KP][KP + 1];
-  __shared__ double logdet_m;
+  __shared__ double Minv[KP][KP + 1];
   __shared__ double sh[4];
   const int d = a.d, k = a.k, t = threadIdx.x;
   const double* mu = a.theta_dev;
   const double* ls = a.theta_dev + d;
   const double* B = a.theta_dev + 2 * (int64_t)d;
-  // M = I + B' D^-1 B: rows staged through LDS 256 at a time (scaled by 1/sigma); the 256 threads form G groups
-  // of KP^2 (p, q) pairs, group g sums rows g, g + G, ... of the tile; groups are combined in fixed order
-  {
-    constexpr int G = 256 / (KP * KP);
-    __shared__ double wt[256][KP + 1];
-    __shared__ double mg[G][KP * KP];
-    const int pq = t % (KP * KP), grp = t / (KP * KP);
-    const int p = pq / KP, q = pq % KP;
-    double s = 0.0;
-    for (int i0 = 0; i0 < d; i0 += 256) {
-      const int i = i0 + t;
-      const double iv = i < d ? exp(-ls[i]) : 0.0;
-#pragma unroll
-      for (int j = 0; j < KP; ++j) wt[t][j] = (i < d && j < k) ? B[(int64_t)i * k + j] * iv : 0.0;
-      __syncthreads();
-      double acc4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-      for (int r = grp; r < 256; r += 4 * G) {
-        acc4[0] = fma(wt[r][p], wt[r][q], acc4[0]);
-        acc4[1] = fma(wt[r + G][p], wt[r + G][q], acc4[1]);
-        acc4[2] = fma(wt[r + 2 * G][p], wt[r + 2 * G][q], acc4[2]);
-        acc4[3] = fma(wt[r + 3 * G][p], wt[r + 3 * G][q], acc4[3]);
-      }
-      s += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-      __syncthreads();
-    }
-    mg[grp][pq] = s;
-    __syncthreads();
-    if (t < KP * KP) {
-      double tot = (p == q) ? 1.0 : 0.0;
-#pragma unroll
-      for (int g = 0; g < G; ++g) tot += mg[g][t];
-      M[p][q] = tot;
-    }
-  }
-  __syncthreads();
-  if (t == 0) {   // Cholesky M = C C' (lower) in registers: fully unrolled, no LDS round trips in the chain
-    double c[KP][KP];
-#pragma unroll
-    for (int i = 0; i < KP; ++i)
-#pragma unroll
-      for (int j = 0; j < KP; ++j) c[i][j] = M[i][j];
-    double ld = 0.0;
-#pragma unroll
-    for (int j = 0; j < KP; ++j) {
-      double sjj = c[j][j];
-#pragma unroll
-      for (int p = 0; p < KP; ++p)
-        if (p < j) sjj -= c[j][p] * c[j][p];
-      const double cjj = sqrt(sjj), inv = 1.0 / cjj;
-      c[j][j] = cjj;
-      ld += log(cjj);
-#pragma unroll
-      for (int i = 0; i < KP; ++i) {
-        if (i > j) {
-          double v = c[i][j];
-#pragma unroll
-          for (int p = 0; p < KP; ++p)
-            if (p < j) v -= c[i][p] * c[j][p];
-          c[i][j] = v * inv;
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < KP; ++i)
-#pragma unroll
-      for (int j = 0; j < KP; ++j) M[i][j] = c[i][j];
-    logdet_m = 2.0 * ld;
-  }
-  __syncthreads();
-  if (t < KP) {   // column t of M^-1: C y = e_t, C' x = y, with C in registers
-    double c[KP][KP], y[KP];
-#pragma unroll
-    for (int i = 0; i < KP; ++i)
-#pragma unroll
-      for (int j = 0; j < KP; ++j) c[i][j] = M[i][j];
-#pragma unroll
-    for (int i = 0; i < KP; ++i) {
-      double v = (i == t) ? 1.0 : 0.0;
-#pragma unroll
-      for (int p = 0; p < KP; ++p)
-        if (p < i) v -= c[i][p] * y[p];
-      y[i] = v / c[i][i];
-    }
-#pragma unroll
-    for (int ii = 0; ii < KP; ++ii) {
-      const int i = KP - 1 - ii;
-      double v = y[i];
-#pragma unroll
-      for (int p = 0; p < KP; ++p)
-        if (p > i) v -= c[p][i] * y[p];
-      y[i] = v / c[i][i];
-    }
-#pragma unroll
-    for (int i = 0; i < KP; ++i) Minv[i][t] = y[i];
-  }
+  if (t < KP * KP) Minv[t / KP][t % KP] = a.minv[t];
+  const double logdet_m = a.minv[KP * KP];
   __syncthreads();
   const double invN = 1.0 / n_total;
   const double* S = a.sums;
-  double sum_ls = 0.0;
-  for (int i = t; i < d; i += 256) {
+  {
+    const int i = blockIdx.x * 256 + t;       // one row of the gradient per thread
+    if (i < d) {
     const double lsi = ls[i], iv = exp(-2.0 * lsi);
-    sum_ls += lsi;
     double bi[KP], u[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) bi[j] = j < k ? B[(int64_t)i * k + j] : 0.0;
@@ -463,15 +471,20 @@ __global__ void __launch_bounds__(256) lr_epilogue_kernel(const LrArgs a, double
       const double GZ = cpl ? S[3 + j] : S[kLrScal + (int64_t)(2 + j) * a.Dp + i];
       out[1 + 2 * (int64_t)d + (int64_t)i * k + j] = -GZ * invN - u[j] * iv;
     }
+    }
   }
   (void)mu;
-  // value = -(mean f + H)
-  sum_ls = lr_wave_sum(sum_ls);
-  if ((t & 63) == 0) sh[t >> 6] = sum_ls;
-  __syncthreads();
-  if (t == 0) {
-    const double H = 0.5 * d * (kLog2PiLr + 1.0) + ((sh[0] + sh[1]) + (sh[2] + sh[3])) + 0.5 * logdet_m;
-    out[0] = -(S[0] * invN + model_c0 + H);
+  // value = -(mean f + H), by the first workgroup
+  if (blockIdx.x == 0) {
+    double sum_ls = 0.0;
+    for (int i = t; i < d; i += 256) sum_ls += ls[i];
+    sum_ls = lr_wave_sum(sum_ls);
+    if ((t & 63) == 0) sh[t >> 6] = sum_ls;
+    __syncthreads();
+    if (t == 0) {
+      const double H = 0.5 * d * (kLog2PiLr + 1.0) + ((sh[0] + sh[1]) + (sh[2] + sh[3])) + 0.5 * logdet_m;
+      out[0] = -(S[0] * invN + model_c0 + H);
+    }
   }
 }
 
@@ -505,11 +518,16 @@ static int lr_run(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
                 o_rows = carve(funnel ? 2 * n : 0), o_prep = carve((int64_t)(3 + KP) * a.n_prep),
                 o_part = carve((int64_t)a.n_rb * (2 + KP) * a.Dp), o_pscal = carve((int64_t)(3 + KP) * a.n_rb * a.n_cb),
                 o_sums = carve(kLrScal + (int64_t)(2 + KP) * a.Dp);
+  a.n_mblk = (int)((d + 255) / 256);
+  const int64_t o_mpart = carve((int64_t)a.n_mblk * KP * KP), o_minv = carve(KP * KP + 1);
   VB_TRY(ensure(ctx, ctx->lr_work, (size_t)off * sizeof(double)));
   double* base = (double*)ctx->lr_work.ptr;
   a.theta_dev = base + o_theta, a.colp = base + o_colp, a.Bp = base + o_bp, a.rowscal = base + o_rows;
   a.prepscal = base + o_prep, a.partials = base + o_part, a.pscal = base + o_pscal, a.sums = base + o_sums;
+  a.mpart = base + o_mpart, a.minv = base + o_minv;
   hipLaunchKernelGGL((lr_prep_kernel<KP>), dim3((unsigned)a.n_prep), dim3(256), 0, st, theta_src, a, m);
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL((lr_capacitance_kernel<KP>), dim3(1), dim3(KP * KP), 0, st, a);
   VB_HIP(ctx, hipGetLastError());
   const dim3 grid((unsigned)(a.n_rb * a.n_cb));
   if (funnel)
@@ -522,7 +540,7 @@ static int lr_run(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
                      funnel ? 1 : 0);
   VB_HIP(ctx, hipGetLastError());
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, a.sums, (size_t)(kLrScal + fin_items)));
-  hipLaunchKernelGGL((lr_epilogue_kernel<KP>), dim3(1), dim3(256), 0, st, a, (double)n_total, m.c0,
+  hipLaunchKernelGGL((lr_epilogue_kernel<KP>), dim3((unsigned)a.n_mblk), dim3(256), 0, st, a, (double)n_total, m.c0,
                      funnel ? m.k : -1, out);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
