@@ -36,10 +36,14 @@ PMC_TRAFFIC_BYTES_PER_EVAL = (2 * 530474.5 + 8352.7) * 1024 / 32
 FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet; tools/fp64_peak.hip measures 63-73 (4x4x4 form)
 
 
-def fullrank_leg(eng, vb, steps=150, warmup=60):
-    """Secondary measurement: the dense (full-rank) Gaussian family named by north_star, D=1024, N=4096,
-    correlated-Gaussian target, parameter resident on the device.  fp64 MFMA-bound."""
+def fullrank_leg(eng, vb, steps=150, warmup=60, world=1, rank=0, barrier=None):
+    """Secondary measurement: the dense (full-rank) Gaussian family named by north_star, D=1024, N=4096 rows
+    per GPU, correlated-Gaussian target, parameter resident on the device.  fp64 MFMA-bound.  With world > 1
+    the Monte-Carlo axis is sharded like the headline leg: every evaluation all-reduces its
+    1 + D + D(D+1)/2 partial sums over RCCL (4.2 MB), so all ranks have to call this together."""
     d, n = 1024, N_MC
+    n_total = n * world
+    barrier = barrier or (lambda: None)
     rng = np.random.RandomState(2)
     A = rng.randn(d, d)
     model = vb.CorrelatedGaussianModel(rng.randn(d), covariance=A @ A.T / d + np.eye(d))
@@ -49,22 +53,27 @@ def fullrank_leg(eng, vb, steps=150, warmup=60):
     eng.fullrank_set_theta(fr.pack(np.zeros(d), L), d)
     ring = 8
     for s in range(ring):
-        eng.noise_generate(40 + s, n, d, seed=2, stream=s)
+        eng.noise_generate(40 + s, n, d, seed=2, stream=s, row_offset=rank * n)
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.2:          # untimed clock ramp (see main)
-        for i in range(warmup):
-            eng.elbo_grad_fullrank_enqueue(40 + i % ring, n, d)
+    for _ in range(4 if world > 1 else 1000):          # untimed clock ramp (see main); fixed count when the
+        for i in range(warmup):                        # calls are collective so that every rank issues the same
+            eng.elbo_grad_fullrank_enqueue(40 + i % ring, n, d, n_total=n_total)
         eng.sync()
+        if world == 1 and time.perf_counter() - t_ramp > 0.2:
+            break
+    barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        eng.elbo_grad_fullrank_enqueue(40 + i % ring, n, d)
+        eng.elbo_grad_fullrank_enqueue(40 + i % ring, n, d, n_total=n_total)
     eng.sync()
     dt = (time.perf_counter() - t0) / steps
+    barrier()
     value, grad = eng.fullrank_get(d)
     flops = 4.0 * n * d * d + 2.0 * n * d * d          # Z = E L^T, G^T E (dense convention) + target's (Z - m) P
     return {
-        'workload': 'FullRankGaussian + ExclusiveKL, D=1024, N_mc=4096, correlated-Gaussian target, fp64',
-        'evals_per_s': 1.0 / dt, 'us_per_eval': 1e6 * dt, 'steps': steps,
+        'workload': 'FullRankGaussian + ExclusiveKL, D=1024, N_mc=4096 per GPU, correlated-Gaussian target, fp64',
+        'evals_per_s': world / dt, 'us_per_eval': 1e6 * dt, 'steps': steps, 'n_gpus': world,
+        'counting': '4096-sample evaluation units over all GPUs per second (rank 0 clock)',
         'roofline': {'bound': 'mfma', 'achieved': flops / dt / 1e12, 'peak': FP64_MFMA_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': flops / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                      'flops_per_eval_dense_convention': flops,
@@ -237,6 +246,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    out = None
     if rank == 0:
         kernel_us = 1e3 * kernel_ms / max(1, launches)
         bytes_per_launch = ALGO_BYTES * evals_timed / max(1, launches)
@@ -276,8 +286,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(theta)
             out['parity'] = parity_check(eng, theta, fam)
-        if world == 1 and not args.no_fullrank:
-            out['fullrank'] = fullrank_leg(eng, vb)
+    if not args.no_fullrank:                               # collective when world > 1: every rank runs it
+        fr_out = fullrank_leg(eng, vb, world=world, rank=rank, barrier=barrier)
+        if out is not None:
+            out['fullrank'] = fr_out
+    if rank == 0:
         # RCCL prints a version banner through C stdio; push it out first so the JSON is the last line
         import ctypes
         try:

@@ -656,6 +656,7 @@ int vb_fullrank_set_theta(vb_ctx* ctx, const double* theta, int64_t d) {
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(ensure(ctx, ctx->fr_theta, (size_t)p * sizeof(double)));
   VB_TRY(ensure(ctx, ctx->fr_out, (size_t)(1 + p) * sizeof(double)));
+  VB_TRY(main_stream_write(ctx));   // epilogues still in flight on `post` read the old parameter
   VB_HIP(ctx, hipMemcpyAsync(ctx->fr_theta.ptr, theta, (size_t)p * sizeof(double), hipMemcpyHostToDevice,
                              ctx->stream));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller keeps ownership of `theta`
@@ -684,6 +685,7 @@ int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p) {
   if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (p != ctx->fr_p || !ctx->fr_out.ptr) return fail(ctx, VB_ERR_STATE, "no full-rank result of length %lld", (long long)p);
   VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));   // a sharded evaluation finishes on `post`
   VB_HIP(ctx, hipMemcpyAsync(value, ctx->fr_out.ptr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VB_HIP(ctx, hipMemcpyAsync(grad, (const double*)ctx->fr_out.ptr + 1, (size_t)p * sizeof(double),
                              hipMemcpyDeviceToHost, ctx->stream));

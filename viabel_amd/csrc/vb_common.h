@@ -116,6 +116,7 @@ struct vb_ctx {
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
+  uint64_t fr_seq = 0;                  // sharded full-rank evaluations enqueued (selects the sum set)
 
   void* comm = nullptr;                 // ncclComm_t when a communicator is attached
   int n_ranks = 1, rank = 0;

@@ -244,11 +244,92 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
   }
 }
 
-// ---- epilogue: sum vector -> (value, grad) in the flat layout --------------------------------------
-__global__ void __launch_bounds__(256) fr_epilogue_kernel(FrSums S, const double* __restrict__ theta,
-                                                          int d, int64_t ldl, double n_local_w,
-                                                          double n_total, double c0,
-                                                          double* __restrict__ out) {
+// ---- full-rank Gaussian: split reduction straight into the flat (paragami) layout -----------------------
+// Same pair-per-thread reduction as fr_reduce_kernel (same summation order), but entry (i, j <= i) lands at the
+// packed position i (i + 1) / 2 + j -- the order of the free-Cholesky block of theta -- so a sharded job
+// all-reduces D (D + 1) / 2 doubles instead of D x ldl, and entries above the diagonal are never written.
+// FUSE (no communicator): the O(P) epilogue arithmetic is applied on the spot and `out` = [value | grad] is
+// written directly; otherwise the raw sums go to S for the all-reduce and fr_epilogue_packed_kernel finishes.
+template <bool FUSE>
+__global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
+    const double* __restrict__ Cpart, int splits, int64_t slab, int d, int64_t ldl,
+    const double* __restrict__ colpart, int n_rb, int64_t ldz, const double* __restrict__ fpart, int n_fpart,
+    FrSums S, const double* __restrict__ theta, double n_local_w, double n_total, double c0,
+    double* __restrict__ out) {
+  __shared__ double sh[4];
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t idx = 2 * tid;
+  const int64_t nC = (int64_t)d * ldl;
+  const double invN = 1.0 / n_total;
+  if (idx < nC) {
+    const int i = (int)(idx / ldl), j = (int)(idx % ldl);
+    if (j <= i) {
+      fr_d2 s = (fr_d2){0.0, 0.0};
+      for (int k0 = 0; k0 < splits; k0 += 8) {
+        fr_d2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = k0 + u < splits ? *reinterpret_cast<const fr_d2*>(Cpart + (k0 + u) * slab + idx) : (fr_d2){0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      const int64_t p = (int64_t)i * (i + 1) / 2 + j;
+      if (FUSE) {
+        double g0 = -s.x * invN;
+        if (j == i) g0 = g0 * exp(theta[d + p]) - 1.0;              // free (log) diagonal + entropy
+        out[1 + d + p] = g0;
+        if (j + 1 <= i) {
+          double g1 = -s.y * invN;
+          if (j + 1 == i) g1 = g1 * exp(theta[d + p + 1]) - 1.0;
+          out[1 + d + p + 1] = g1;
+        }
+      } else {
+        S.sums[S.off_c + p] = s.x;
+        if (j + 1 <= i) S.sums[S.off_c + p + 1] = s.y;
+      }
+    }
+  }
+  if (tid < ldz) {
+    double s = 0.0;
+    if (tid < d) {
+      for (int rb0 = 0; rb0 < n_rb; rb0 += 16) {      // 16 loads in flight, summed in row-block order
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = rb0 + u < n_rb ? colpart[(int64_t)(rb0 + u) * ldz + tid] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+      }
+    }
+    if (FUSE) {
+      if (tid < d) out[1 + tid] = -s * invN;
+    } else {
+      S.sums[S.off_col + tid] = s;
+    }
+  }
+  if (blockIdx.x == 0) {
+    double f = 0.0;
+    for (int e = threadIdx.x; e < n_fpart; e += 256) f += fpart[e];
+    f = fr_block_sum(f, sh);
+    if (FUSE) {
+      __syncthreads();
+      double t = 0.0;
+      for (int i = threadIdx.x; i < d; i += 256) t += theta[d + (int64_t)i * (i + 1) / 2 + i];
+      const double sum_logdiag = fr_block_sum(t, sh);
+      if (threadIdx.x == 0) {
+        const double F = f + n_local_w * c0;
+        const double H = 0.5 * d * (1.0 + kLog2PiFr) + sum_logdiag;
+        out[0] = -(F * invN + H);
+      }
+    } else if (threadIdx.x == 0) {
+      S.sums[0] = f;
+    }
+  }
+}
+
+// epilogue of the sharded job: all-reduced packed sums -> (value, grad)
+__global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const double* __restrict__ theta,
+                                                                 int d, double n_local_w, double n_total,
+                                                                 double c0, double* __restrict__ out) {
   __shared__ double sh[4];
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t np = (int64_t)d * (d + 1) / 2;
@@ -257,9 +338,8 @@ __global__ void __launch_bounds__(256) fr_epilogue_kernel(FrSums S, const double
     int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
     while ((int64_t)(i + 1) * (i + 2) / 2 <= p) ++i;
     while ((int64_t)i * (i + 1) / 2 > p) --i;
-    const int j = (int)(p - (int64_t)i * (i + 1) / 2);
-    double g = -S.sums[S.off_c + (int64_t)i * ldl + j] * invN;     // d value / d L_ij
-    if (i == j) g = g * exp(theta[d + p]) - 1.0;                    // free (log) diagonal + entropy
+    double g = -S.sums[S.off_c + p] * invN;                         // d value / d L_ij
+    if (p == (int64_t)i * (i + 1) / 2 + i) g = g * exp(theta[d + p]) - 1.0;
     out[1 + d + p] = g;
   }
   if (p < d) out[1 + p] = -S.sums[S.off_col + p] * invN;
@@ -368,16 +448,34 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   const int64_t o_mu = carve(ldz), o_lt = carve(slab), o_z = carve(n * ldz), o_g = carve(n * ldz),
                 o_cpart = carve((int64_t)splits * slab), o_col = carve((int64_t)n_rb * ldz),
                 o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx);
+  // sum vector: the t family takes the full D x ldl matrix; the Gaussian family packs the lower triangle in
+  // theta's own order, twice over when the all-reduce of one evaluation overlaps the kernels of the next
+  const int64_t np = d * (d + 1) / 2;
   FrSums S;
   S.off_col = 16;
   S.off_c = 16 + ldz;
-  S.len = 16 + ldz + slab;
-  const int64_t o_sums = carve(S.len);
+  S.len = 16 + ldz + (mvt ? slab : round_up(np, 16));
+  static const bool overlap_env = !(getenv("VB_COMM_OVERLAP") && atoi(getenv("VB_COMM_OVERLAP")) == 0);
+  const bool overlap = !mvt && ctx->comm != nullptr && overlap_env;
+  const int64_t o_sums = carve(S.len * (overlap ? 2 : 1));
   VB_TRY(ensure(ctx, ctx->fr_work, (size_t)off * sizeof(double)));
   double* base = (double*)ctx->fr_work.ptr;
   double *mu = base + o_mu, *Lt = base + o_lt, *Z = base + o_z, *G = base + o_g, *Cpart = base + o_cpart,
          *colpart = base + o_col, *fpart = base + o_fpart;
-  S.sums = base + o_sums;
+  // stream plan (as mf_enqueue's `overlap`): everything up to the split reduction stays in order on the main
+  // stream; the all-reduce and the epilogue go to `post` behind one event, into sum set `seq & 1`, and the main
+  // stream only waits for them when that set comes round again two evaluations later
+  Pipeline& P = ctx->pipe;
+  int set = 0;
+  if (overlap) {
+    VB_TRY(pipe_init(ctx));
+    set = (int)(ctx->fr_seq++ & 1);
+    if (P.fin_valid[set]) VB_HIP(ctx, hipStreamWaitEvent(st, P.ev_fin[set], 0));
+  } else if (P.post_pending) {   // order this in-order evaluation after everything `post` has in flight
+    VB_HIP(ctx, hipStreamWaitEvent(st, P.ev_fin[P.last_set], 0));
+    P.post_pending = false;
+  }
+  S.sums = base + o_sums + (int64_t)set * S.len;
 
   if (mvt) {
     VB_HIP(ctx, hipMemcpyAsync(mu, mu_dev, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -452,20 +550,42 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   VB_HIP(ctx, hipGetLastError());
 
   const int64_t red_items = slab / 2 > ldz ? slab / 2 : ldz;
-  hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((red_items + 255) / 256)), dim3(256), 0, st,
-                     (const double*)Cpart, splits, slab, D, ldl, (const double*)colpart, n_rb, ldz,
-                     (const double*)fpart, n_fpart, S, mvt ? 1 : 0);
-  VB_HIP(ctx, hipGetLastError());
-  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
+  const dim3 red_grid((unsigned)((red_items + 255) / 256));
   if (mvt) {
+    hipLaunchKernelGGL(fr_reduce_kernel, red_grid, dim3(256), 0, st, (const double*)Cpart, splits, slab, D, ldl,
+                       (const double*)colpart, n_rb, ldz, (const double*)fpart, n_fpart, S, 1);
+    VB_HIP(ctx, hipGetLastError());
+    if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
     *sums_out = S;
     return VB_OK;
   }
-
-  const int64_t np = d * (d + 1) / 2;
-  hipLaunchKernelGGL(fr_epilogue_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, S, theta_dev,
-                     D, ldl, (double)n_total, (double)n_total, m.c0, out_dev);
+  if (!ctx->comm) {   // single GPU: the split reduction writes (value, grad) itself
+    hipLaunchKernelGGL(fr_reduce_packed_kernel<true>, red_grid, dim3(256), 0, st, (const double*)Cpart, splits,
+                       slab, D, ldl, (const double*)colpart, n_rb, ldz, (const double*)fpart, n_fpart, S,
+                       theta_dev, (double)n_total, (double)n_total, m.c0, out_dev);
+    VB_HIP(ctx, hipGetLastError());
+    return VB_OK;
+  }
+  hipLaunchKernelGGL(fr_reduce_packed_kernel<false>, red_grid, dim3(256), 0, st, (const double*)Cpart, splits,
+                     slab, D, ldl, (const double*)colpart, n_rb, ldz, (const double*)fpart, n_fpart, S,
+                     theta_dev, (double)n_total, (double)n_total, m.c0, out_dev);
   VB_HIP(ctx, hipGetLastError());
+  hipStream_t st_post = st;
+  if (overlap) {
+    VB_HIP(ctx, hipEventRecord(P.ev_k1[set], st));
+    st_post = P.post;
+    VB_HIP(ctx, hipStreamWaitEvent(st_post, P.ev_k1[set], 0));
+  }
+  VB_TRY(comm_allreduce_sum(ctx, st_post, S.sums, (size_t)S.len));
+  hipLaunchKernelGGL(fr_epilogue_packed_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st_post, S,
+                     theta_dev, D, (double)n_total, (double)n_total, m.c0, out_dev);
+  VB_HIP(ctx, hipGetLastError());
+  if (overlap) {
+    VB_HIP(ctx, hipEventRecord(P.ev_fin[set], st_post));
+    P.fin_valid[set] = true;
+    P.post_pending = true;
+    P.last_set = set;
+  }
   return VB_OK;
 }
 
