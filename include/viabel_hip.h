@@ -216,6 +216,35 @@ int vb_elbo_grad_fullrank_enqueue(vb_ctx* ctx, int slot, int64_t n, int64_t d, i
                                   unsigned flags);
 int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p);
 
+/* ---- device-resident fit: the optimiser loop of optimization.py:83-127 without host round trips ----
+ * Replaces  for k in range(n_iters): value, grad = objective(theta); theta -= lr * descent_direction(grad)
+ * (StochasticGradientOptimizer.optimize, optimization.py:91-112) for an ExclusiveKL objective whose family
+ * draws Philox noise: iteration k generates its noise matrix (stream first_stream + k, rows row_offset ..
+ * row_offset + n of the global matrix) into `slot`, evaluates (value, grad) as vb_elbo_grad_meanfield /
+ * vb_elbo_grad_fullrank would, and applies one optimiser step on the device; all n_iters iterations are
+ * enqueued back to back and the call returns when the last one has finished.  The update arithmetic follows
+ * numpy's operation order without fused multiply-adds, so the trajectory equals the host loop's bit for bit.
+ *   family      VB_FAMILY_MF_GAUSSIAN / VB_FAMILY_MF_STUDENT_T (p = 2 d) or VB_FAMILY_FULLRANK_GAUSSIAN
+ *               (p = d + d (d + 1) / 2)
+ *   opt_kind    VB_OPT_SGD (:129-130), VB_OPT_RMSPROP (:188-197), VB_OPT_ADAM (:308-326), VB_OPT_ADAGRAD (:430-433)
+ *   hyper       [learning_rate, beta (RMSProp) or beta1 (Adam), beta2 (Adam), jitter]
+ *   theta       in: start, out: parameter after n_iters steps (p doubles)
+ *   state       in/out optimiser state [second moment (p) | momentum (p)]; read only if has_state != 0
+ *   values      out: objective value of every iteration (n_iters)
+ *   history     out: the last hist_len iterates (after their step), row-major hist_len x p; may be NULL
+ *   directions  out: descent direction of every iteration, row-major n_iters x p (the optimiser's
+ *               diagnostics log, optimization.py:108-109); may be NULL
+ * Sharded jobs (vb_comm_init): every rank passes its own n / row_offset and the same n_total; all ranks
+ * apply the same step to the same all-reduced gradient. */
+#define VB_OPT_SGD 0
+#define VB_OPT_RMSPROP 1
+#define VB_OPT_ADAM 2
+#define VB_OPT_ADAGRAD 3
+int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
+           double df, unsigned flags, int cv_mode, int noise_kind, double noise_df, uint64_t seed,
+           uint64_t first_stream, int opt_kind, const double hyper[4], int64_t n_iters, double* theta, int64_t p,
+           double* state, int has_state, double* values, double* history, int64_t hist_len, double* directions);
+
 /* ---- multi-GPU: Monte-Carlo axis sharded, one RCCL all-reduce of the partial sums --- */
 #define VB_COMM_ID_BYTES 128
 int vb_comm_unique_id(char id[VB_COMM_ID_BYTES]);

@@ -1,0 +1,177 @@
+"""GPU: the device-resident optimiser loop (vb_fit) against the host loop of optimization.py:83-127.
+
+Both run the same objective kernels on the same Philox noise; the host loop applies the numpy update, the
+device loop the fit_step kernel (numpy's operation order, no fused multiply-adds) -- so value history, iterate
+history, averaged optimum and the optimiser's carried state must agree bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(make):
+    """Two identical (objective, init) pairs with their own family objects (own Philox call counters)."""
+    return make(), make()
+
+
+def _mf_gaussian_funnel(D=24, N=64, **kw):
+    import viabel_amd as vb
+
+    def make():
+        return vb.ExclusiveKL(vb.MFGaussian(D, seed=3, rng='philox'), vb.FunnelModel(D), N, **kw)
+    return make, np.concatenate([np.zeros(D), -np.ones(D)])
+
+
+def _mf_student_gauss(D=17, N=50):
+    import viabel_amd as vb
+    rng = np.random.RandomState(0)
+    mean, sd = rng.randn(D), np.exp(0.3 * rng.randn(D))
+
+    def make():
+        return vb.ExclusiveKL(vb.MFStudentT(D, 8, seed=5, rng='philox'), vb.GaussianModel(mean, sd), N)
+    return make, np.concatenate([0.1 * rng.randn(D), -0.5 * np.ones(D)])
+
+
+def _fullrank_corr(D=20, N=96):
+    import viabel_amd as vb
+    rng = np.random.RandomState(1)
+    A = rng.randn(D, D)
+    m, S = rng.randn(D), A @ A.T / D + np.eye(D)
+
+    def make():
+        return vb.ExclusiveKL(vb.FullRankGaussian(D, seed=2, rng='philox'),
+                              vb.CorrelatedGaussianModel(m, covariance=S), N)
+    fr = vb.FullRankGaussian(D)
+    return make, fr.pack(np.zeros(D), np.exp(-1.0) * np.eye(D))
+
+
+def _optimizers():
+    from viabel_amd import optimization as opt
+    return {
+        'sgd': lambda: opt.StochasticGradientOptimizer(1e-3),
+        'rmsprop': lambda: opt.RMSProp(0.01),
+        'adam': lambda: opt.Adam(0.01),
+        'adagrad': lambda: opt.Adagrad(0.05),
+    }
+
+
+def _assert_same(host, dev):
+    assert set(host) == set(dev)
+    for key in host:
+        np.testing.assert_array_equal(dev[key], host[key], err_msg=key)
+
+
+@pytest.mark.parametrize('problem', ['mf_gaussian_funnel', 'mf_student_gauss', 'fullrank_corr'])
+@pytest.mark.parametrize('name', ['sgd', 'rmsprop', 'adam', 'adagrad'])
+def test_device_loop_reproduces_host_loop(problem, name):
+    make, init = {'mf_gaussian_funnel': _mf_gaussian_funnel, 'mf_student_gauss': _mf_student_gauss,
+                  'fullrank_corr': _fullrank_corr}[problem]()
+    obj_h, obj_d = _pair(make)
+    opt_h, opt_d = _pair(_optimizers()[name])
+    n_iters = 57
+    host = opt_h.optimize(n_iters, obj_h, init, on_device=False)
+    dev = opt_d.optimize(n_iters, obj_d, init, on_device=True)
+    assert host['value_history'].shape == (n_iters,)
+    _assert_same(host, dev)
+    # a second leg continues from the carried optimiser state and the advanced noise stream
+    host2 = opt_h.optimize(23, obj_h, host['opt_param'], on_device=False)
+    dev2 = opt_d.optimize(23, obj_d, dev['opt_param'], on_device=True)
+    _assert_same(host2, dev2)
+    assert not np.array_equal(host2['value_history'][:5], host['value_history'][:5])
+
+
+@pytest.mark.parametrize('kw', [dict(use_path_deriv=True), dict(hessian_approx_method='full'),
+                                dict(hessian_approx_method='loo_diag_approx', use_path_deriv=True)])
+def test_device_loop_estimator_variants(kw):
+    from viabel_amd import optimization as opt
+    make, init = _mf_gaussian_funnel(**kw)
+    obj_h, obj_d = _pair(make)
+    host = opt.RMSProp(0.01).optimize(31, obj_h, init, on_device=False)
+    dev = opt.RMSProp(0.01).optimize(31, obj_d, init, on_device=True)
+    _assert_same(host, dev)
+
+
+@pytest.mark.parametrize('tail', [None, 0.2, 1.0])
+def test_iterate_averaging_window(tail):
+    from viabel_amd import optimization as opt
+    make, init = _mf_gaussian_funnel()
+    obj_h, obj_d = _pair(make)
+    host = opt.RMSProp(0.01, iterate_avg_prop=tail).optimize(40, obj_h, init, on_device=False)
+    dev = opt.RMSProp(0.01, iterate_avg_prop=tail).optimize(40, obj_d, init, on_device=True)
+    _assert_same(host, dev)
+    if tail is None:
+        assert 'variational_param_history' not in dev
+
+
+@pytest.mark.parametrize('tail', [None, 0.2])
+def test_diagnostics_log(tail):
+    """diagnostics=True also returns every descent direction (optimization.py:108-109) and, without tail
+    averaging, every iterate."""
+    from viabel_amd import optimization as opt
+    make, init = _mf_gaussian_funnel()
+    obj_h, obj_d = _pair(make)
+    host = opt.Adam(0.01, diagnostics=True, iterate_avg_prop=tail).optimize(30, obj_h, init, on_device=False)
+    dev = opt.Adam(0.01, diagnostics=True, iterate_avg_prop=tail).optimize(30, obj_d, init, on_device=True)
+    _assert_same(host, dev)
+    assert dev['descent_dir_history'].shape == (30, init.size)
+    if tail is None:
+        assert dev['variational_param_history'].shape == (30, init.size)
+
+
+def test_default_dispatch_and_fallbacks():
+    """optimize() picks the device loop by itself when it can, and keeps the host loop otherwise."""
+    import viabel_amd as vb
+    from viabel_amd import optimization as opt
+    make, init = _mf_gaussian_funnel()
+    obj = make()
+    sgo = opt.RMSProp(0.01)
+    assert sgo._device_fit_possible(obj, init)
+    calls_before = obj.approx._philox_calls
+    res = sgo.optimize(10, obj, init)
+    assert obj.approx._philox_calls == calls_before + 10 and res['value_history'].shape == (10,)
+    # numpy-stream family: host loop only
+    D = 24
+    obj_np = vb.ExclusiveKL(vb.MFGaussian(D), vb.FunnelModel(D), 16)
+    assert not obj_np.supports_device_fit()
+    assert not sgo._device_fit_possible(obj_np, init)
+    with pytest.raises(NotImplementedError):
+        sgo.optimize(5, obj_np, init, on_device=True)
+    # optimisers without a device step stay on the host
+    assert not opt.AveragedRMSProp(0.01)._device_fit_possible(obj, init)
+    assert not opt.WindowedAdagrad(0.01)._device_fit_possible(obj, init)
+    res = opt.AveragedRMSProp(0.01).optimize(5, obj, init)
+    assert res['value_history'].shape == (5,)
+
+
+def test_fit_argument_errors():
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    D, N = 8, 16
+    eng.set_model(vb.FunnelModel(D).device_spec())
+    theta = np.zeros(2 * D)
+    hyper = [0.01, 0.9, 0.0, 1e-8]
+    with pytest.raises(ValueError):
+        eng.fit(0, N, D, _lib.FAMILY_MF_GAUSSIAN, theta, 0, _lib.OPT_RMSPROP, hyper)
+    with pytest.raises(ValueError):
+        eng.fit(0, N, D, _lib.FAMILY_MF_GAUSSIAN, theta, 5, 9, hyper)
+    with pytest.raises(ValueError):
+        eng.fit(0, N, D, _lib.FAMILY_MF_GAUSSIAN, theta[:-1], 5, _lib.OPT_RMSPROP, hyper)
+    with pytest.raises(NotImplementedError):
+        eng.fit(0, N, D, _lib.FAMILY_MULTIVARIATE_T, theta, 5, _lib.OPT_RMSPROP, hyper)
+    with pytest.raises(ValueError):
+        eng.fit(0, N, D, _lib.FAMILY_MF_GAUSSIAN, theta, 5, _lib.OPT_RMSPROP, hyper, hist_len=6)
+
+
+def test_bbvi_fixed_schedule_runs_on_device():
+    """bbvi(adaptive=False) -> RMSProp.optimize -> device loop; converges on the reference's Gaussian target
+    (tests/test_convenience.py:10-37 tolerance)."""
+    import viabel_amd as vb
+    D = 5
+    mean, sd = np.arange(D, dtype=float), np.ones(D) * 0.5
+    approx = vb.MFGaussian(D, rng='philox')
+    objective = vb.ExclusiveKL(approx, vb.GaussianModel(mean, sd), 50)
+    res = vb.bbvi(D, objective=objective, n_iters=4000, adaptive=False, fixed_lr=True, learning_rate=0.05)
+    m, cov = approx.mean_and_cov(res['opt_param'])
+    np.testing.assert_allclose(m, mean, atol=0.05)
+    np.testing.assert_allclose(np.sqrt(np.diag(cov)), sd, atol=0.05)

@@ -23,6 +23,7 @@ NOISE_NORMAL, NOISE_STUDENT_T = range(2)
 FLAG_PATH_DERIV = 1
 CV_MODES = {None: 0, 'full': 1, 'mean_only': 2, 'loo_diag_approx': 3, 'loo_direct_approx': 4}
 MAX_SLOTS = 64
+OPT_SGD, OPT_RMSPROP, OPT_ADAM, OPT_ADAGRAD = range(4)
 COMM_ID_BYTES = 128
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -64,6 +65,11 @@ SIGNATURES = {
     'vb_elbo_grad_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_uint, _c_double_p,
                                             _c_double_p]),
+    'vb_fit': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                              ctypes.c_int, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
+                              ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _c_double_p,
+                              ctypes.c_int64, _c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_int,
+                              _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p]),
     'vb_log_weights_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                 ctypes.c_double, _c_double_p, _c_double_p]),
     'vb_psis_smooth': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_double, _c_double_p,
@@ -408,6 +414,28 @@ class Engine:
         grad = np.empty(p, dtype=np.float64)
         self._check(self._lib.vb_fullrank_get(self._ctx, ctypes.byref(value), _dptr(grad), p))
         return value.value, grad
+
+    # ------------------------------------------------------------------ device-resident fit
+    def fit(self, slot, n, d, family, theta, n_iters, opt_kind, hyper, *, df=0.0, flags=0, cv_mode=0,
+            n_total=None, row_offset=0, noise_kind=NOISE_NORMAL, noise_df=0.0, seed=1, first_stream=0,
+            state=None, hist_len=0, log_directions=False):
+        """``n_iters`` iterations of {Philox noise -> objective -> optimiser step} enqueued back to back
+        (``vb_fit``).  Returns (theta, values, history, state, directions or None)."""
+        theta = _f64(theta).copy()
+        p = theta.size
+        hyper = _f64(np.asarray(hyper, dtype=np.float64))
+        has_state = state is not None
+        state = _f64(state).copy() if has_state else np.zeros(2 * p, dtype=np.float64)
+        values = np.empty(n_iters, dtype=np.float64)
+        history = np.empty((hist_len, p), dtype=np.float64)
+        directions = np.empty((n_iters, p), dtype=np.float64) if log_directions else None
+        self._check(self._lib.vb_fit(
+            self._ctx, slot, n, d, n if n_total is None else n_total, int(row_offset), family, float(df), flags,
+            cv_mode, noise_kind, float(noise_df), int(seed), int(first_stream), opt_kind, _dptr(hyper), int(n_iters),
+            _dptr(theta), p, _dptr(state), int(has_state), _dptr(values),
+            _dptr(history) if hist_len else None, int(hist_len),
+            _dptr(directions) if log_directions else None))
+        return theta, values, history, state, directions
 
     # ------------------------------------------------------------------ multi-GPU
     @staticmethod

@@ -700,6 +700,117 @@ int vb_elbo_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n
   return vb_fullrank_get(ctx, value, grad, d + d * (d + 1) / 2);
 }
 
+// ---- device-resident fit (optimization.py:83-127) ----------------------------------------------------
+int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
+           double df, unsigned flags, int cv_mode, int noise_kind, double noise_df, uint64_t seed,
+           uint64_t first_stream, int opt_kind, const double hyper[4], int64_t n_iters, double* theta, int64_t p,
+           double* state, int has_state, double* values, double* history, int64_t hist_len, double* directions) {
+  if (!ctx || !hyper || !theta || !values) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (n <= 0 || d <= 0 || n_iters <= 0) return fail(ctx, VB_ERR_INVALID, "n, d and n_iters must be positive");
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
+  if (opt_kind < VB_OPT_SGD || opt_kind > VB_OPT_ADAGRAD)
+    return fail(ctx, VB_ERR_INVALID, "unknown optimiser kind %d", opt_kind);
+  if (hist_len < 0 || hist_len > n_iters || (hist_len > 0 && !history))
+    return fail(ctx, VB_ERR_INVALID, "hist_len must be in [0, n_iters] with a history buffer");
+  if (has_state && !state) return fail(ctx, VB_ERR_INVALID, "has_state set without a state buffer");
+  const bool meanfield = family == VB_FAMILY_MF_GAUSSIAN || family == VB_FAMILY_MF_STUDENT_T;
+  const bool fullrank = family == VB_FAMILY_FULLRANK_GAUSSIAN;
+  if (!meanfield && !fullrank)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident fit: family %d is not supported", family);
+  if (p != (meanfield ? 2 * d : d + d * (d + 1) / 2))
+    return fail(ctx, VB_ERR_INVALID, "parameter length %lld does not match the family", (long long)p);
+  if (fullrank && (cv_mode != VB_CV_NONE || (flags & VB_FLAG_PATH_DERIV)))
+    return fail(ctx, VB_ERR_UNSUPPORTED, "full-rank family: entropy-form estimator only");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  VB_TRY(noise_alloc(ctx, slot, n, d));
+  NoiseSlot& ns = ctx->noise[slot];
+
+  // device state: [theta (p) | out (1 + p) | s1 (p) | s2 (p) | values (n_iters) | iterates (hist_len x p)]
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t o_theta = carve(p), o_out = carve(1 + p), o_s1 = carve(p), o_s2 = carve(p),
+                o_val = carve(n_iters), o_hist = carve(hist_len * p), o_dirs = carve(directions ? n_iters * p : 0);
+  VB_TRY(ensure(ctx, ctx->fit_work, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->fit_work.ptr;
+  double* theta_dev = base + o_theta;
+  double* out_dev = base + o_out;
+  hipStream_t st = ctx->stream;
+  VB_HIP(ctx, hipMemcpyAsync(theta_dev, theta, (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
+  if (has_state) {
+    VB_HIP(ctx, hipMemcpyAsync(base + o_s1, state, (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
+    VB_HIP(ctx, hipMemcpyAsync(base + o_s2, state + p, (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  VB_HIP(ctx, hipStreamSynchronize(st));   // the caller's buffers are pageable: copies above are staged
+
+  FitStep step;
+  step.kind = opt_kind;
+  step.p = p;
+  step.lr = hyper[0];
+  step.beta1 = hyper[1];
+  step.one_minus_beta1 = 1.0 - hyper[1];
+  step.beta2 = hyper[2];
+  step.one_minus_beta2 = 1.0 - hyper[2];
+  step.jitter = hyper[3];
+  step.out = out_dev;
+  step.theta = theta_dev;
+  step.s1 = base + o_s1;
+  step.s2 = base + o_s2;
+  step.values = base + o_val;
+  step.hist = hist_len > 0 ? base + o_hist : nullptr;
+  step.hist_first = n_iters - hist_len;
+  step.dirs = directions ? base + o_dirs : nullptr;
+
+  MfCall c;
+  if (meanfield) {
+    c.count = 1;
+    c.noise[0] = &ns;
+    c.theta_src[0] = theta_dev;
+    c.out[0] = out_dev;
+    c.n = n;
+    c.d = d;
+    c.n_total = n_total;
+    c.family = family;
+    c.df = df;
+    c.flags = flags;
+    c.cv_mode = cv_mode;
+  }
+  for (int64_t k = 0; k < n_iters; ++k) {
+    VB_TRY(rng_fill(ctx, (double*)ns.buf.ptr, ns.ld, noise_kind, noise_df, seed, first_stream + (uint64_t)k,
+                    row_offset, n, d));
+    if (meanfield)
+      VB_TRY(mf_enqueue(ctx, c));
+    else
+      VB_TRY(fr_elbo_grad_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev));
+    if (fullrank && ctx->pipe.post_pending) {   // sharded full-rank evaluations finish on the communication stream
+      VB_HIP(ctx, hipStreamWaitEvent(st, ctx->pipe.ev_fin[ctx->pipe.last_set], 0));
+      ctx->pipe.post_pending = false;
+    }
+    step.k = k;
+    step.first = (k == 0 && !has_state) ? 1 : 0;
+    VB_TRY(fit_step_enqueue(ctx, step));
+  }
+  VB_HIP(ctx, hipMemcpyAsync(theta, theta_dev, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(values, base + o_val, (size_t)n_iters * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (state) {
+    VB_HIP(ctx, hipMemcpyAsync(state, base + o_s1, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
+    VB_HIP(ctx, hipMemcpyAsync(state + p, base + o_s2, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  if (hist_len > 0)
+    VB_HIP(ctx, hipMemcpyAsync(history, base + o_hist, (size_t)(hist_len * p) * sizeof(double),
+                               hipMemcpyDeviceToHost, st));
+  if (directions)
+    VB_HIP(ctx, hipMemcpyAsync(directions, base + o_dirs, (size_t)(n_iters * p) * sizeof(double),
+                               hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  return VB_OK;
+}
+
 // ---- measurement --------------------------------------------------------------------------------
 int vb_profile_enable(vb_ctx* ctx, int on) {
   if (!ctx) return VB_ERR_INVALID;

@@ -113,6 +113,7 @@ struct vb_ctx {
   vb::DeviceBuffer rows_work;           // Model.__call__ for the dense targets: GEMM output rows
   vb::DeviceBuffer psis_lw;             // PSIS: log importance weights (+ 16 result scalars)
   int64_t psis_n = 0;                   // number of device-resident log weights (0: none)
+  vb::DeviceBuffer fit_work;            // device-resident fit: [theta | out | state | value history | iterates]
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
@@ -241,6 +242,23 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
                     double* ess_out, double* w_host, double* logp_host, double* logq_host);
 int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
                  const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out);
+
+// one optimiser step on the device (vb_fit.hip): (value, grad) at `out` -> state, theta, histories
+struct FitStep {
+  int kind = 0;                 // VB_OPT_*
+  int first = 0;                // the optimiser has no state yet (first descent_direction call)
+  int64_t p = 0, k = 0;         // parameter length, iteration index
+  double lr = 0.0, jitter = 0.0;
+  double beta1 = 0.0, one_minus_beta1 = 0.0, beta2 = 0.0, one_minus_beta2 = 0.0;
+  const double* out = nullptr;  // [value | grad (p)]
+  double* theta = nullptr;      // updated in place
+  double *s1 = nullptr, *s2 = nullptr;   // second-moment state, momentum
+  double* values = nullptr;     // values[k] = value
+  double* hist = nullptr;       // iterate k >= hist_first lands in row k - hist_first (nullptr: no history)
+  int64_t hist_first = 0;
+  double* dirs = nullptr;       // dirs[k * p + i] = descent direction (nullptr: not logged)
+};
+int fit_step_enqueue(vb_ctx* ctx, const FitStep& step);
 
 // Philox noise generation (vb_rng.hip)
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,

@@ -208,6 +208,40 @@ class ExclusiveKL(StochasticVariationalObjective):
         self._objective_and_grad = objective_and_grad
 
 
+    # ---- device-resident optimiser loop ---------------------------------------------------------------
+    def supports_device_fit(self):
+        """True when a whole stochastic-gradient fit can run on the device without host round trips: a
+        mean-field or full-rank family drawing Philox noise (``rng='philox'``)."""
+        approx = self.approx
+        return (isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian)) and approx.rng == 'philox'
+                and not (isinstance(approx, FullRankGaussian)
+                         and (self._use_path_deriv or self.hessian_approx_method is not None)))
+
+    def device_fit(self, n_iters, init_param, opt_kind, hyper, state=None, hist_len=0, log_directions=False):
+        """Run ``n_iters`` iterations of ``theta <- theta - lr * descent_direction(grad)`` on the device
+        (``vb_fit``): the loop of ``optimization.py:91-112`` with the noise of iteration k generated from the
+        family's Philox stream exactly as ``n_iters`` consecutive objective calls would consume it.
+        Returns (theta, value_history, iterate_history[-hist_len:], optimiser state, directions or None)."""
+        if not self.supports_device_fit():
+            raise NotImplementedError("device_fit needs a mean-field or full-rank family with rng='philox'")
+        approx = self.approx
+        init_param = np.asarray(init_param, dtype=np.float64)
+        if init_param.shape != (approx.var_param_dim,):
+            raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+        eng = self._engine()
+        eng.set_model(self.model.device_spec())
+        N = self.num_mc_samples
+        begin, end = shard_rows(N, eng.n_ranks, eng.rank)
+        family, df = approx._device_family()
+        kind, noise_df = approx._philox_kind()
+        first = approx._philox_calls
+        approx._philox_calls += n_iters
+        flags = _lib.FLAG_PATH_DERIV if self._use_path_deriv else 0
+        return eng.fit(_NOISE_SLOT, end - begin, approx.dim, family, init_param, n_iters, opt_kind, hyper,
+                       df=df, flags=flags, cv_mode=_lib.CV_MODES[self.hessian_approx_method], n_total=N,
+                       row_offset=begin, noise_kind=kind, noise_df=noise_df, seed=approx._seed,
+                       first_stream=first, state=state, hist_len=hist_len, log_directions=log_directions)
+
     def _mvt_exclusive_kl(self, approx):
         """Entropy-form ELBO for the multivariate t: sampling, model gradient and the D x D contraction
         sum_n g_n (z_n / s_n)' on the device; the O(D^3) chain rule through the symmetric root on the host (the

@@ -19,6 +19,7 @@ import time
 import numpy as np
 import tqdm
 
+from . import _lib
 from ._chain_stats import MCSE, R_hat_convergence_check
 from .approximations import MFGaussian
 
@@ -69,7 +70,16 @@ class StochasticGradientOptimizer(Optimizer):
         """Forget the optimiser's running statistics."""
 
     def optimize(self, n_iters, objective, init_param, init_hamflow_model_param=None,
-                 init_hamflow_rho_param=None):
+                 init_hamflow_rho_param=None, on_device=None):
+        """The reference's loop (``optimization.py:83-127``).  ``on_device``: run the whole loop on the GPU
+        without host round trips (``VariationalObjective.device_fit``); the default ``None`` does so whenever
+        the objective and the optimiser support it -- the trajectory is the same bit for bit."""
+        if on_device is None:
+            on_device = self._device_fit_possible(objective, init_param)
+        elif on_device and not self._device_fit_possible(objective, init_param):
+            raise NotImplementedError('this optimiser / objective pair has no device-resident loop')
+        if on_device:
+            return self._optimize_on_device(n_iters, objective, init_param)
         param = init_param.copy()
         tail = self._iterate_avg_prop
         log = defaultdict(list)
@@ -107,6 +117,51 @@ class StochasticGradientOptimizer(Optimizer):
         """Direction to step against; plain SGD uses the gradient itself."""
         return grad
 
+    # ---- device-resident loop -------------------------------------------------------------------------
+    _device_kind = _lib.OPT_SGD
+
+    def _device_hyper(self):
+        """[learning_rate, beta / beta1, beta2, jitter] for ``vb_fit``."""
+        return [self._learning_rate, 0.0, 0.0, 0.0]
+
+    def _device_state(self, p):
+        """Optimiser state as ``[second moment (p) | momentum (p)]`` or None before the first step."""
+        return None
+
+    def _set_device_state(self, state, p):
+        pass
+
+    def _device_fit_possible(self, objective, init_param):
+        return (self._device_kind is not None
+                and np.ndim(init_param) == 1 and np.ndim(self._learning_rate) == 0
+                and getattr(objective, 'supports_device_fit', lambda: False)())
+
+    def _optimize_on_device(self, n_iters, objective, init_param):
+        tail = self._iterate_avg_prop
+        # length of the iterate history the host loop ends with (append, then pop while len > tail * k)
+        kept = 0
+        if self._diagnostics or tail is not None:
+            for k in range(n_iters):
+                kept += 1
+                if tail is not None and kept > tail * k:
+                    kept -= 1
+        p = np.size(init_param)
+        theta, values, history, state, directions = objective.device_fit(
+            n_iters, init_param, self._device_kind, self._device_hyper(), state=self._device_state(p),
+            hist_len=kept, log_directions=self._diagnostics)
+        self._set_device_state(state, p)
+        log = {'value_history': values}
+        if self._diagnostics or tail is not None:
+            log['variational_param_history'] = history
+        if self._diagnostics:
+            log['descent_dir_history'] = directions
+        if tail is not None:
+            window = max(1, int((n_iters - 1) * tail))
+            log['opt_param'] = np.mean(history[-window:], axis=0)
+        else:
+            log['opt_param'] = theta
+        return log
+
 
 def _ema_update(state, decay, grad_sq):
     """state <- decay * state + (1 - decay) * grad_sq, starting from grad_sq."""
@@ -120,13 +175,17 @@ def _adam_moments(momentum, avg_grad_sq, beta1, beta2, grad):
     """One update of (momentum, second moment) for the reference's Adam variants.
 
     On the FIRST call the reference aliases ``momentum = grad`` and scales it in place
-    (``optimization.py:310-320``, ``:375-386``): the momentum becomes ``beta1 (2 - beta1) grad`` rather
-    than ``grad``, and -- because the aliased gradient was overwritten before the second moment is
-    refreshed -- the squared *momentum* enters the second-moment update.  Both values are reproduced so
-    that trajectories match the reference; the caller's gradient array is left untouched."""
+    (``optimization.py:310-320``, ``:375-386``): the gradient itself becomes ``beta1 grad`` before
+    ``(1 - beta1) grad`` is added, so the momentum is ``beta1 (2 - beta1) grad`` rather than ``grad``, and
+    -- because the aliased gradient was overwritten before the second moment is refreshed -- the squared
+    *momentum* enters the second-moment update.  Both are reproduced operation by operation so that
+    trajectories match the reference; the caller's gradient array is left untouched."""
     if momentum is None:
-        momentum = beta1 * (2.0 - beta1) * grad
-        avg_grad_sq = beta2 * grad ** 2 + (1.0 - beta2) * momentum ** 2
+        momentum = grad * beta1
+        momentum += (1.0 - beta1) * momentum
+        avg_grad_sq = grad ** 2
+        avg_grad_sq *= beta2
+        avg_grad_sq += (1.0 - beta2) * momentum ** 2
         return momentum, avg_grad_sq
     momentum *= beta1
     momentum += (1.0 - beta1) * grad
@@ -152,9 +211,24 @@ class RMSProp(StochasticGradientOptimizer):
         self._avg_grad_sq = _ema_update(self._avg_grad_sq, self._beta, grad ** 2)
         return grad / np.sqrt(self._jitter + self._avg_grad_sq)
 
+    _device_kind = _lib.OPT_RMSPROP
+
+    def _device_hyper(self):
+        return [self._learning_rate, self._beta, 0.0, self._jitter]
+
+    def _device_state(self, p):
+        if self._avg_grad_sq is None:
+            return None
+        return np.concatenate([self._avg_grad_sq, np.zeros(p)])
+
+    def _set_device_state(self, state, p):
+        self._avg_grad_sq = state[:p].copy()
+
 
 class AveragedRMSProp(StochasticGradientOptimizer):
     """RMSProp with ``beta_k = 1 - 1/k``: the plain average of all squared gradients."""
+
+    _device_kind = None      # host loop only
 
     def __init__(self, learning_rate, *, jitter=1e-8, diagnostics=False, component_wise=True):
         self._jitter = jitter
@@ -191,9 +265,24 @@ class Adam(StochasticGradientOptimizer):
                                                           self._beta2, grad)
         return self._momentum / np.sqrt(self._jitter + self._avg_grad_sq)
 
+    _device_kind = _lib.OPT_ADAM
+
+    def _device_hyper(self):
+        return [self._learning_rate, self._beta1, self._beta2, self._jitter]
+
+    def _device_state(self, p):
+        if self._momentum is None:
+            return None
+        return np.concatenate([self._avg_grad_sq, self._momentum])
+
+    def _set_device_state(self, state, p):
+        self._avg_grad_sq, self._momentum = state[:p].copy(), state[p:].copy()
+
 
 class AveragedAdam(StochasticGradientOptimizer):
     """Adam whose second moment is the plain average of all squared gradients."""
+
+    _device_kind = None      # host loop only
 
     def __init__(self, learning_rate, *, beta1=0.9, jitter=1e-8, diagnostics=False, component_wise=True):
         self._beta1 = beta1
@@ -230,9 +319,24 @@ class Adagrad(StochasticGradientOptimizer):
         self._sum_grad_sq = self._sum_grad_sq + grad ** 2
         return grad / np.sqrt(self._jitter + self._sum_grad_sq)
 
+    _device_kind = _lib.OPT_ADAGRAD
+
+    def _device_hyper(self):
+        return [self._learning_rate, 0.0, 0.0, self._jitter]
+
+    def _device_state(self, p):
+        if np.ndim(self._sum_grad_sq) == 0:
+            return None
+        return np.concatenate([self._sum_grad_sq, np.zeros(p)])
+
+    def _set_device_state(self, state, p):
+        self._sum_grad_sq = state[:p].copy()
+
 
 class WindowedAdagrad(StochasticGradientOptimizer):
     """Adagrad over a sliding window of the last ``window_size`` squared gradients."""
+
+    _device_kind = None      # host loop only
 
     def __init__(self, learning_rate, *, weight_decay=0, window_size=10, jitter=1e-8, diagnostics=False):
         self._window_size = window_size
