@@ -234,6 +234,8 @@ int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p);
  *   history     out: the last hist_len iterates (after their step), row-major hist_len x p; may be NULL
  *   directions  out: descent direction of every iteration, row-major n_iters x p (the optimiser's
  *               diagnostics log, optimization.py:108-109); may be NULL
+ *   gradients   out: objective gradient of every iteration, row-major n_iters x p (FASO's grad_history,
+ *               optimization.py:541); may be NULL
  * Sharded jobs (vb_comm_init): every rank passes its own n / row_offset and the same n_total; all ranks
  * apply the same step to the same all-reduced gradient. */
 #define VB_OPT_SGD 0
@@ -243,7 +245,8 @@ int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p);
 int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
            double df, unsigned flags, int cv_mode, int noise_kind, double noise_df, uint64_t seed,
            uint64_t first_stream, int opt_kind, const double hyper[4], int64_t n_iters, double* theta, int64_t p,
-           double* state, int has_state, double* values, double* history, int64_t hist_len, double* directions);
+           double* state, int has_state, double* values, double* history, int64_t hist_len, double* directions,
+           double* gradients);
 
 /* ---- multi-GPU: Monte-Carlo axis sharded, one RCCL all-reduce of the partial sums --- */
 #define VB_COMM_ID_BYTES 128

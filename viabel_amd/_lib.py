@@ -69,7 +69,7 @@ SIGNATURES = {
                               ctypes.c_int, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
                               ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _c_double_p,
                               ctypes.c_int64, _c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_int,
-                              _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p]),
+                              _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_log_weights_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                 ctypes.c_double, _c_double_p, _c_double_p]),
     'vb_psis_smooth': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_double, _c_double_p,
@@ -418,9 +418,9 @@ class Engine:
     # ------------------------------------------------------------------ device-resident fit
     def fit(self, slot, n, d, family, theta, n_iters, opt_kind, hyper, *, df=0.0, flags=0, cv_mode=0,
             n_total=None, row_offset=0, noise_kind=NOISE_NORMAL, noise_df=0.0, seed=1, first_stream=0,
-            state=None, hist_len=0, log_directions=False):
+            state=None, hist_len=0, log_directions=False, log_gradients=False):
         """``n_iters`` iterations of {Philox noise -> objective -> optimiser step} enqueued back to back
-        (``vb_fit``).  Returns (theta, values, history, state, directions or None)."""
+        (``vb_fit``).  Returns (theta, values, history, state, directions or None, gradients or None)."""
         theta = _f64(theta).copy()
         p = theta.size
         hyper = _f64(np.asarray(hyper, dtype=np.float64))
@@ -429,13 +429,14 @@ class Engine:
         values = np.empty(n_iters, dtype=np.float64)
         history = np.empty((hist_len, p), dtype=np.float64)
         directions = np.empty((n_iters, p), dtype=np.float64) if log_directions else None
+        gradients = np.empty((n_iters, p), dtype=np.float64) if log_gradients else None
         self._check(self._lib.vb_fit(
             self._ctx, slot, n, d, n if n_total is None else n_total, int(row_offset), family, float(df), flags,
             cv_mode, noise_kind, float(noise_df), int(seed), int(first_stream), opt_kind, _dptr(hyper), int(n_iters),
             _dptr(theta), p, _dptr(state), int(has_state), _dptr(values),
             _dptr(history) if hist_len else None, int(hist_len),
-            _dptr(directions) if log_directions else None))
-        return theta, values, history, state, directions
+            _dptr(directions) if log_directions else None, _dptr(gradients) if log_gradients else None))
+        return theta, values, history, state, directions, gradients
 
     # ------------------------------------------------------------------ multi-GPU
     @staticmethod

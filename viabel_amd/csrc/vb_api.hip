@@ -704,7 +704,8 @@ int vb_elbo_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n
 int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
            double df, unsigned flags, int cv_mode, int noise_kind, double noise_df, uint64_t seed,
            uint64_t first_stream, int opt_kind, const double hyper[4], int64_t n_iters, double* theta, int64_t p,
-           double* state, int has_state, double* values, double* history, int64_t hist_len, double* directions) {
+           double* state, int has_state, double* values, double* history, int64_t hist_len, double* directions,
+           double* gradients) {
   if (!ctx || !hyper || !theta || !values) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
   if (n <= 0 || d <= 0 || n_iters <= 0) return fail(ctx, VB_ERR_INVALID, "n, d and n_iters must be positive");
@@ -735,7 +736,8 @@ int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t
     return o;
   };
   const int64_t o_theta = carve(p), o_out = carve(1 + p), o_s1 = carve(p), o_s2 = carve(p),
-                o_val = carve(n_iters), o_hist = carve(hist_len * p), o_dirs = carve(directions ? n_iters * p : 0);
+                o_val = carve(n_iters), o_hist = carve(hist_len * p), o_dirs = carve(directions ? n_iters * p : 0),
+                o_grads = carve(gradients ? n_iters * p : 0);
   VB_TRY(ensure(ctx, ctx->fit_work, (size_t)off * sizeof(double)));
   double* base = (double*)ctx->fit_work.ptr;
   double* theta_dev = base + o_theta;
@@ -765,6 +767,7 @@ int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t
   step.hist = hist_len > 0 ? base + o_hist : nullptr;
   step.hist_first = n_iters - hist_len;
   step.dirs = directions ? base + o_dirs : nullptr;
+  step.grads = gradients ? base + o_grads : nullptr;
 
   MfCall c;
   if (meanfield) {
@@ -806,6 +809,9 @@ int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t
                                hipMemcpyDeviceToHost, st));
   if (directions)
     VB_HIP(ctx, hipMemcpyAsync(directions, base + o_dirs, (size_t)(n_iters * p) * sizeof(double),
+                               hipMemcpyDeviceToHost, st));
+  if (gradients)
+    VB_HIP(ctx, hipMemcpyAsync(gradients, base + o_grads, (size_t)(n_iters * p) * sizeof(double),
                                hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
   return VB_OK;

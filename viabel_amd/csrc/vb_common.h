@@ -257,6 +257,7 @@ struct FitStep {
   double* hist = nullptr;       // iterate k >= hist_first lands in row k - hist_first (nullptr: no history)
   int64_t hist_first = 0;
   double* dirs = nullptr;       // dirs[k * p + i] = descent direction (nullptr: not logged)
+  double* grads = nullptr;      // grads[k * p + i] = gradient (nullptr: not logged)
 };
 int fit_step_enqueue(vb_ctx* ctx, const FitStep& step);
 

@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(256) fit_step_kernel(FitStep a) {
     dir = m / sqrt(a.jitter + v);
   }
   if (a.dirs) a.dirs[a.k * a.p + i] = dir;
+  if (a.grads) a.grads[a.k * a.p + i] = g;
   const double t = a.theta[i] - a.lr * dir;                        // objective.update (objectives.py:57-59, optimization.py:97-98)
   a.theta[i] = t;
   if (a.hist && a.k >= a.hist_first) a.hist[(a.k - a.hist_first) * a.p + i] = t;

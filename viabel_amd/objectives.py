@@ -217,11 +217,13 @@ class ExclusiveKL(StochasticVariationalObjective):
                 and not (isinstance(approx, FullRankGaussian)
                          and (self._use_path_deriv or self.hessian_approx_method is not None)))
 
-    def device_fit(self, n_iters, init_param, opt_kind, hyper, state=None, hist_len=0, log_directions=False):
+    def device_fit(self, n_iters, init_param, opt_kind, hyper, state=None, hist_len=0, log_directions=False,
+                   log_gradients=False):
         """Run ``n_iters`` iterations of ``theta <- theta - lr * descent_direction(grad)`` on the device
         (``vb_fit``): the loop of ``optimization.py:91-112`` with the noise of iteration k generated from the
         family's Philox stream exactly as ``n_iters`` consecutive objective calls would consume it.
-        Returns (theta, value_history, iterate_history[-hist_len:], optimiser state, directions or None)."""
+        Returns (theta, value_history, iterate_history[-hist_len:], optimiser state, directions or None,
+        gradients or None)."""
         if not self.supports_device_fit():
             raise NotImplementedError("device_fit needs a mean-field or full-rank family with rng='philox'")
         approx = self.approx
@@ -240,7 +242,8 @@ class ExclusiveKL(StochasticVariationalObjective):
         return eng.fit(_NOISE_SLOT, end - begin, approx.dim, family, init_param, n_iters, opt_kind, hyper,
                        df=df, flags=flags, cv_mode=_lib.CV_MODES[self.hessian_approx_method], n_total=N,
                        row_offset=begin, noise_kind=kind, noise_df=noise_df, seed=approx._seed,
-                       first_stream=first, state=state, hist_len=hist_len, log_directions=log_directions)
+                       first_stream=first, state=state, hist_len=hist_len, log_directions=log_directions,
+                       log_gradients=log_gradients)
 
     def _mvt_exclusive_kl(self, approx):
         """Entropy-form ELBO for the multivariate t: sampling, model gradient and the D x D contraction

@@ -146,7 +146,7 @@ class StochasticGradientOptimizer(Optimizer):
                 if tail is not None and kept > tail * k:
                     kept -= 1
         p = np.size(init_param)
-        theta, values, history, state, directions = objective.device_fit(
+        theta, values, history, state, directions, _ = objective.device_fit(
             n_iters, init_param, self._device_kind, self._device_hyper(), state=self._device_state(p),
             hist_len=kept, log_directions=self._diagnostics)
         self._set_device_state(state, p)
@@ -391,7 +391,26 @@ class FASO(Optimizer):
             return ess, mcse
         return MCSE(iterates)
 
-    def optimize(self, n_iters, objective, init_param):
+    def _next_check(self, k, k_conv, W_check, n_iters):
+        """First iteration >= k whose bookkeeping can do anything: the next stationarity check (multiples of
+        k_check) before convergence, the next MCSE check (k_conv + W_check) after it."""
+        if k_conv is None:
+            k_end = -(-k // self._k_check) * self._k_check
+        else:
+            k_end = max(k, k_conv + W_check)
+        return min(k_end, n_iters - 1)
+
+    def optimize(self, n_iters, objective, init_param, on_device=None):
+        """``optimization.py:521-633``.  ``on_device`` (default: whenever possible): the iterations between two
+        convergence checks run as one device-resident chunk (``vb_fit``) instead of one blocking objective
+        call + numpy step each; iterates, gradients and values are the same bit for bit, only the wall-clock
+        ratio that paces the MCSE re-checks differs."""
+        sgo = self._sgo
+        if on_device is None:
+            on_device = sgo._device_fit_possible(objective, init_param)
+        elif on_device and not sgo._device_fit_possible(objective, init_param):
+            raise NotImplementedError('this optimiser / objective pair has no device-resident loop')
+        done_until = -1      # device mode: iterations up to here are already in `hist`
         diagnostics = self._sgo._diagnostics
         k_conv = k_stopped = k_Rhat = None
         lr = self._sgo._learning_rate
@@ -407,16 +426,35 @@ class FASO(Optimizer):
         with tqdm.trange(n_iters) as bar:
             try:
                 for k in bar:
-                    with _Stopwatch() as sw:
-                        value, grad = objective(param)
-                        hist['value_history'].append(value)
-                        hist['grad_history'].append(grad)
-                        direction = self._sgo.descent_direction(grad)
-                        param = objective.update(param, lr * direction)
-                        hist['variational_param_history'].append(param.copy())
-                        if diagnostics:
-                            hist['descent_dir_history'].append(direction)
-                    opt_time += sw.interval
+                    if on_device:
+                        if k > done_until:
+                            done_until = self._next_check(k, k_conv, W_check, n_iters)
+                            count = done_until - k + 1
+                            with _Stopwatch() as sw:
+                                param, values, iterates, state, dirs, grads = objective.device_fit(
+                                    count, param, sgo._device_kind, sgo._device_hyper(),
+                                    state=sgo._device_state(param.size), hist_len=count,
+                                    log_directions=diagnostics, log_gradients=True)
+                                sgo._set_device_state(state, param.size)
+                                hist['value_history'].extend(values)
+                                hist['grad_history'].extend(grads)
+                                hist['variational_param_history'].extend(iterates)
+                                if diagnostics:
+                                    hist['descent_dir_history'].extend(dirs)
+                            opt_time += sw.interval
+                        if k < done_until:
+                            continue
+                    else:
+                        with _Stopwatch() as sw:
+                            value, grad = objective(param)
+                            hist['value_history'].append(value)
+                            hist['grad_history'].append(grad)
+                            direction = self._sgo.descent_direction(grad)
+                            param = objective.update(param, lr * direction)
+                            hist['variational_param_history'].append(param.copy())
+                            if diagnostics:
+                                hist['descent_dir_history'].append(direction)
+                        opt_time += sw.interval
                     # stationarity: split R-hat over five trailing windows
                     if k_conv is None and k % self._k_check == 0:
                         W_upper = int(0.95 * k)
@@ -582,10 +620,10 @@ class RAABBVI(FASO):
         """True when fewer iterations were needed at larger learning rates (negative slope)."""
         return bool(slope < 0)
 
-    def optimize(self, K_max, objective, init_param):
+    def optimize(self, K_max, objective, init_param, on_device=None):
         if not objective.approx.supports_kl:
             print('WARNING: approximation family does not support KL. Using FASO.', flush=True)
-            return super().optimize(K_max, objective, init_param)
+            return super().optimize(K_max, objective, init_param, on_device=on_device)
         k_new = -1           # iterations spent at the current learning rate
         epoch = 0
         k_total = 0
@@ -605,9 +643,9 @@ class RAABBVI(FASO):
                 previous = average
                 if epoch == 0 and self._init_rmsprop:
                     opt = FASO(sgo=RMSProp(learning_rate=sgo._learning_rate, diagnostics=diagnostics)) \
-                        .optimize(K_max, objective, average)
+                        .optimize(K_max, objective, average, on_device=on_device)
                 else:
-                    opt = super().optimize(K_max, objective, average)
+                    opt = super().optimize(K_max, objective, average, on_device=on_device)
                 if opt['k_stopped'] is not None and epoch != 0:
                     hist['conv_iters_hist'].append(opt['k_stopped'])
                 average = opt['opt_param']
