@@ -17,13 +17,14 @@ __device__ __forceinline__ Philox4 philox4x32_10(Philox4 c, uint32_t k0, uint32_
   constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-    const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    // one 32 x 32 -> 64 product per word (v_mad_u64_u32) instead of a mul_hi / mul_lo pair: the quarter-rate
+    // integer multiplies are half of this kernel's issue cycles
+    const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
     Philox4 n;
-    n.x = hi1 ^ c.y ^ k0;
-    n.y = lo1;
-    n.z = hi0 ^ c.w ^ k1;
-    n.w = lo0;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
     c = n;
     k0 += W0;
     k1 += W1;
