@@ -82,6 +82,25 @@ def fullrank_leg(eng, vb, steps=150, warmup=60, world=1, rank=0, barrier=None):
     }
 
 
+def fit_leg(vb, theta, iters=1500):
+    """Secondary measurement: a whole RMSProp fit at the C1 shape (fresh Philox noise every iteration) through
+    the host loop (one blocking objective call + numpy step per iteration, optimization.py:91-112) and through
+    the device-resident loop (vb_fit); the two trajectories are the same bit for bit."""
+    from viabel_amd.optimization import RMSProp
+    out = {'workload': 'RMSProp(0.01), MFGaussian(rng=philox) + ExclusiveKL, D=1024 funnel, N_mc=4096, %d iterations'
+                       % iters}
+    hist = {}
+    for mode, on_device in (('host_loop', False), ('device_loop', True)):
+        obj = vb.ExclusiveKL(vb.MFGaussian(D, rng='philox'), vb.FunnelModel(D), N_MC)
+        opt = RMSProp(0.01)
+        opt.optimize(200, obj, theta, on_device=on_device)
+        t0 = time.perf_counter()
+        hist[mode] = opt.optimize(iters, obj, theta, on_device=on_device)['value_history']
+        out[mode + '_us_per_iteration'] = 1e6 * (time.perf_counter() - t0) / iters
+    out['trajectories_identical'] = bool(np.array_equal(hist['host_loop'], hist['device_loop']))
+    return out
+
+
 def cpu_baseline(theta, budget_s=12.0):
     """Oracle (numpy fp64 restatement of objectives.py:154-168) on the host cores, bounded."""
     from oracle import families as ofam, models as omod, objectives as oobj
@@ -134,6 +153,7 @@ def main():
     ap.add_argument('--force-comm', action='store_true',
                     help='attach an RCCL communicator even with one rank (exercises the sharded code path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fit', action='store_true', help='skip the secondary optimiser-loop measurement')
     ap.add_argument('--no-fullrank', action='store_true', help='skip the secondary full-rank measurement')
     args = ap.parse_args()
 
@@ -286,6 +306,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(theta)
             out['parity'] = parity_check(eng, theta, fam)
+    if out is not None and world == 1 and not args.no_fit:
+        import contextlib
+        import io
+        with contextlib.redirect_stderr(io.StringIO()):    # tqdm progress bars of the host loop
+            out['fit_loop'] = fit_leg(vb, theta)
     if not args.no_fullrank:                               # collective when world > 1: every rank runs it
         fr_out = fullrank_leg(eng, vb, world=world, rank=rank, barrier=barrier)
         if out is not None:
