@@ -216,6 +216,16 @@ int vb_elbo_grad_fullrank_enqueue(vb_ctx* ctx, int slot, int64_t n, int64_t d, i
                                   unsigned flags);
 int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p);
 
+/* ---- symmetric matrix square root on the device ------------------------------------------------------
+ * root = a^(1/2) for a symmetric positive definite d x d host matrix -- scipy.linalg.sqrtm(Sigma) in
+ * MultivariateT.sample (approximations.py:348) -- by coupled Newton-Schulz iterations (fp64 MFMA GEMMs only).
+ * With e != NULL also x = the solution of  root x + x root = e  (the derivative of the root in direction e, what
+ * autograd's sqrtm VJP computes for ExclusiveKL over a MultivariateT, objectives.py:154-164); e and x may be
+ * NULL.  info (3 doubles, may be NULL) = [iterations, final ||I - Z Y||_F, ||root root - a||_F / ||a||_F]:
+ * the caller decides from info[2] whether to keep the result or use its LAPACK path (the iteration resolves
+ * condition numbers up to ~1e12). */
+int vb_sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info);
+
 /* ---- device-resident fit: the optimiser loop of optimization.py:83-127 without host round trips ----
  * Replaces  for k in range(n_iters): value, grad = objective(theta); theta -= lr * descent_direction(grad)
  * (StochasticGradientOptimizer.optimize, optimization.py:91-112) for an ExclusiveKL objective whose family

@@ -10,6 +10,11 @@ sys.path.insert(0, '.')
 import viabel_amd as vb
 from viabel_amd._psis import psislw
 
+if '--blas-threads' in sys.argv:          # see viabel_amd.set_host_blas_threads
+    i = sys.argv.index('--blas-threads')
+    vb.set_host_blas_threads(int(sys.argv[i + 1]))
+    del sys.argv[i:i + 2]
+
 D, N = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 np.random.seed(5)
 model = vb.FunnelModel(D) if (len(sys.argv) > 2 and sys.argv[2] == 'funnel') else vb.GaussianModel(np.zeros(D), 3 * np.ones(D))

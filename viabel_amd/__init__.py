@@ -12,5 +12,6 @@ from viabel_amd.objectives import *  # noqa: F401,F403
 from viabel_amd.optimization import *  # noqa: F401,F403
 from viabel_amd.convenience import *  # noqa: F401,F403
 from viabel_amd.diagnostics import *  # noqa: F401,F403
+from viabel_amd._lib import set_host_blas_threads  # noqa: F401
 
 __version__ = '0.1.0'

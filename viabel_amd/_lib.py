@@ -65,6 +65,8 @@ SIGNATURES = {
     'vb_elbo_grad_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_int64, _c_double_p, ctypes.c_uint, _c_double_p,
                                             _c_double_p]),
+    'vb_sym_sqrt': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p,
+                                   _c_double_p]),
     'vb_fit': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                               ctypes.c_int, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
                               ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _c_double_p,
@@ -415,6 +417,23 @@ class Engine:
         self._check(self._lib.vb_fullrank_get(self._ctx, ctypes.byref(value), _dptr(grad), p))
         return value.value, grad
 
+    # ------------------------------------------------------------------ small dense linear algebra
+    def sym_sqrt(self, a, e=None):
+        """Symmetric square root of an SPD matrix on the device (``vb_sym_sqrt``); with ``e`` also the solution
+        ``x`` of ``root x + x root = e``.  Returns ``(root, x or None, info)`` with
+        ``info = [iterations, final residual, ||root root - a|| / ||a||]``."""
+        a = _f64(a)
+        d = a.shape[0]
+        root = np.empty((d, d), dtype=np.float64)
+        info = np.zeros(3, dtype=np.float64)
+        if e is None:
+            self._check(self._lib.vb_sym_sqrt(self._ctx, _dptr(a), None, d, _dptr(root), None, _dptr(info)))
+            return root, None, info
+        e = _f64(e)
+        x = np.empty((d, d), dtype=np.float64)
+        self._check(self._lib.vb_sym_sqrt(self._ctx, _dptr(a), _dptr(e), d, _dptr(root), _dptr(x), _dptr(info)))
+        return root, x, info
+
     # ------------------------------------------------------------------ device-resident fit
     def fit(self, slot, n, d, family, theta, n_iters, opt_kind, hyper, *, df=0.0, flags=0, cv_mode=0,
             n_total=None, row_offset=0, noise_kind=NOISE_NORMAL, noise_df=0.0, seed=1, first_stream=0,
@@ -470,6 +489,70 @@ class Engine:
 
 
 _default_engine = None
+
+
+_blas_controller = None
+
+
+def small_lapack(dim):
+    """Context manager for the O(D^3) host factorisations that stay on the CPU (``eigh`` of the D x D scale for
+    the symmetric root, ``approximations.py:348``): runs them on one BLAS thread when the matrix is small.
+    OpenBLAS's threaded ``dsyevd`` is an order of magnitude SLOWER than the serial one at these sizes (256 x 256:
+    94 vs 8 ms on 8 cores, 70-95 vs 5 ms on the 256-core GPU host), which made the whole MultivariateT objective
+    call host-bound.  No-op when ``threadpoolctl`` is unavailable or ``dim`` > 1024."""
+    global _blas_controller
+    import contextlib
+    if dim > 1024:
+        return contextlib.nullcontext()
+    if _blas_controller is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _blas_controller = ThreadpoolController()
+        except Exception:           # pragma: no cover
+            _blas_controller = False
+    if not _blas_controller:
+        return contextlib.nullcontext()
+    return _blas_controller.limit(limits=1, user_api='blas')
+
+
+_blas_sticky = None
+
+
+def set_host_blas_threads(n=1):
+    """Limit the BLAS thread pool of this process (sticky, via ``threadpoolctl``); returns True when applied.
+
+    The host side of the dense-covariance objectives is a handful of D x D numpy products per call.  A threaded
+    OpenBLAS leaves its worker threads spinning for ~30 ms after each of them (``OPENBLAS_THREAD_TIMEOUT``);
+    inside a CPU-quota cgroup (the MI355X boxes of this pool: 256 visible cores, 64 BLAS threads) the spinning
+    exhausts the quota and every few objective calls stall for 30-85 ms -- a 4.6 ms MultivariateT / DIS call
+    then averages 25 ms.  One or a few threads are the right setting for matrices of this size;
+    ``OPENBLAS_NUM_THREADS=1`` in the environment does the same."""
+    global _blas_sticky
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:               # pragma: no cover
+        return False
+    _blas_sticky = threadpool_limits(limits=int(n), user_api='blas')
+    return True
+
+
+_blas_policy_done = False
+
+
+def apply_host_blas_policy():
+    """Called once by the dense-covariance objectives before their first D x D host product: limits the BLAS pool
+    to ``VIABEL_AMD_HOST_BLAS_THREADS`` threads (default 1; ``0`` leaves the pool alone) -- see
+    ``set_host_blas_threads`` for why."""
+    global _blas_policy_done
+    if _blas_policy_done:
+        return
+    _blas_policy_done = True
+    try:
+        n = int(os.environ.get('VIABEL_AMD_HOST_BLAS_THREADS', '1'))
+    except ValueError:
+        n = 1
+    if n > 0 and _blas_sticky is None:
+        set_host_blas_threads(n)
 
 
 def default_engine():

@@ -40,6 +40,20 @@ int ensure(vb_ctx* ctx, DeviceBuffer& b, size_t bytes) {
   return VB_OK;
 }
 
+int ensure_pinned(vb_ctx* ctx, size_t bytes) {
+  if (ctx->pin_host && ctx->pin_bytes >= bytes) return VB_OK;
+  if (ctx->pin_host) {
+    VB_TRY(sync_streams(ctx));
+    VB_HIP(ctx, hipHostFree(ctx->pin_host));
+    ctx->pin_host = nullptr;
+    ctx->pin_bytes = 0;
+  }
+  VB_HIP(ctx, hipHostMalloc((void**)&ctx->pin_host, bytes, hipHostMallocMapped));
+  VB_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->pin_dev, ctx->pin_host, 0));
+  ctx->pin_bytes = bytes;
+  return VB_OK;
+}
+
 int sync_streams(vb_ctx* ctx) {
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->pipe.pre) {
@@ -207,6 +221,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (auto& r : ctx->results)
     if (r.host) (void)hipHostFree(r.host);
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
+  if (ctx->pin_host) (void)hipHostFree(ctx->pin_host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work, &ctx->lr_work, &ctx->mvt_elbo})
@@ -698,6 +713,16 @@ int vb_elbo_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n
   VB_TRY(vb_fullrank_set_theta(ctx, theta, d));
   VB_TRY(vb_elbo_grad_fullrank_enqueue(ctx, slot, n, d, n_total, flags));
   return vb_fullrank_get(ctx, value, grad, d + d * (d + 1) / 2);
+}
+
+// ---- symmetric square root (approximations.py:348) -------------------------------------------------------
+int vb_sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info) {
+  if (!ctx || !a || !root) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (d <= 0 || d > 8192) return fail(ctx, VB_ERR_INVALID, "matrix dimension %lld outside [1, 8192]", (long long)d);
+  if ((e == nullptr) != (x == nullptr)) return fail(ctx, VB_ERR_INVALID, "e and x go together");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  return sym_sqrt(ctx, a, e, d, root, x, info);
 }
 
 // ---- device-resident fit (optimization.py:83-127) ----------------------------------------------------

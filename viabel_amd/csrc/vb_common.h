@@ -113,6 +113,9 @@ struct vb_ctx {
   vb::DeviceBuffer rows_work;           // Model.__call__ for the dense targets: GEMM output rows
   vb::DeviceBuffer psis_lw;             // PSIS: log importance weights (+ 16 result scalars)
   int64_t psis_n = 0;                   // number of device-resident log weights (0: none)
+  double* pin_host = nullptr;           // pinned, device-mapped staging (vb_linalg.hip): host / device address
+  double* pin_dev = nullptr;
+  size_t pin_bytes = 0;
   vb::DeviceBuffer fit_work;            // device-resident fit: [theta | out | state | value history | iterates]
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
@@ -140,6 +143,7 @@ namespace vb {
 
 int fail(vb_ctx* ctx, int code, const char* fmt, ...);
 int ensure(vb_ctx* ctx, DeviceBuffer& b, size_t bytes);
+int ensure_pinned(vb_ctx* ctx, size_t bytes);   // ctx->pin_host / pin_dev hold at least `bytes`
 
 #define VB_HIP(ctx, expr)                                                              \
   do {                                                                                 \
@@ -242,6 +246,9 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
                     double* ess_out, double* w_host, double* logp_host, double* logq_host);
 int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
                  const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out);
+
+// symmetric square root / its derivative by coupled Newton-Schulz GEMM iterations (vb_linalg.hip)
+int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info);
 
 // one optimiser step on the device (vb_fit.hip): (value, grad) at `out` -> state, theta, histories
 struct FitStep {

@@ -17,7 +17,7 @@ from abc import ABC, abstractmethod
 import numpy as np
 
 from . import _lib
-from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT, LRGaussian, symmetric_root
+from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT, LRGaussian, symmetric_eig, symmetric_root
 from .models import DeviceModel
 
 __all__ = [
@@ -251,6 +251,7 @@ class ExclusiveKL(StochasticVariationalObjective):
         reference differentiates ``sqrtm`` with autograd, ``approximations.py:348``)."""
         D, df = approx.dim, approx.df
         tril = np.tril_indices(D)
+        _lib.apply_host_blas_policy()      # before the first D x D host product
 
         def objective_and_grad(var_param):
             var_param = np.asarray(var_param, dtype=np.float64)
@@ -268,19 +269,43 @@ class ExclusiveKL(StochasticVariationalObjective):
                 chi, z = approx._base_noise(N)          # chi-square draws first (approximations.py:345-347)
                 eng.noise_set_host(_NOISE_SLOT, z[begin:end])
             mu, L = approx._unpack(var_param)
-            w, U = np.linalg.eigh(L @ L.T)
-            r = np.sqrt(w)
-            root = (U * r) @ U.T
+            Sigma = L @ L.T
+            root, eig = _device_root(eng, Sigma)
             inv_s = 1.0 / np.sqrt(chi / df)
             f_sum, g_sum, C = eng.elbo_sums_mvt(_NOISE_SLOT, end - begin, D, mu, root, inv_s[begin:end], n_total=N)
             value = -(f_sum / N + approx.entropy(var_param))
             Gs = 0.5 * (C + C.T) / N                                 # d mean f / d root, symmetrised
-            X = U @ ((U.T @ Gs @ U) / (r[:, None] + r[None, :])) @ U.T   # root -> Sigma (Sylvester solve)
+            # root -> Sigma: the Sylvester equation  root X + X root = Gs
+            X = None
+            if eig is None:
+                _, X, info = eng.sym_sqrt(Sigma, Gs)
+                if not info[2] < _ROOT_TOL:
+                    X, eig = None, symmetric_eig(Sigma)
+            if X is None:
+                w, U = eig
+                r = np.sqrt(w)
+                X = U @ ((U.T @ Gs @ U) / (r[:, None] + r[None, :])) @ U.T
             dL = np.tril(2.0 * X @ L)
             dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + 1.0  # free (log) diagonal, entropy gradient
             return value, -np.concatenate([g_sum / N, dL[tril]])
 
         return objective_and_grad
+
+
+_ROOT_TOL = 1e-12     # ||root root - Sigma|| / ||Sigma|| accepted from the Newton-Schulz iteration
+
+
+def _device_root(eng, Sigma):
+    """Symmetric square root of the scale matrix (``scipy.linalg.sqrtm`` in ``approximations.py:348``) by GEMM
+    iterations on the device (``vb_sym_sqrt``); scale matrices the iteration cannot resolve to ``_ROOT_TOL``
+    (condition numbers beyond ~1e12) take the LAPACK route.  Returns ``(root, eig)``; ``eig = (w, U)`` only when
+    the eigen-decomposition had to be computed."""
+    _lib.apply_host_blas_policy()
+    root, _, info = eng.sym_sqrt(Sigma)
+    if info[2] < _ROOT_TOL:
+        return root, None
+    w, U = symmetric_eig(Sigma)
+    return (U * np.sqrt(w)) @ U.T, (w, U)
 
 
 class DISInclusiveKL(StochasticVariationalObjective):
@@ -380,6 +405,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
         D, df = approx.dim, approx.df
         tril = np.tril_indices(D)
 
+        _lib.apply_host_blas_policy()      # before the first D x D host product
+
         def factors(var_param):
             L = approx._unpack(var_param)[1]
             return L, sla.solve_triangular(L, np.eye(D), lower=True)
@@ -401,7 +428,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 else:
                     chi, z = approx._base_noise(N)             # chi-square draws first (approximations.py:345-347)
                     eng.noise_set_host(slot, z[begin:end])
-                root = symmetric_root(L @ L.T)                  # symmetric square root, :348
+                root, _ = _device_root(eng, L @ L.T)            # symmetric square root, :348
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
                     slot, n_local, D, df, var_param, chi[begin:end], root, Linv, self._temper_prior_params,
                     self._eps, self._ess_target, self._max_bisection_its, n_total=N)
