@@ -180,3 +180,31 @@ def test_family_errors():
         vb.MultivariateT(2, 1.5)
     assert not vb.MFStudentT(2, 3).supports_pth_moment(4)
     assert vb.MFGaussian(3).var_param_dim == 6 and vb.MultivariateT(3, 5).var_param_dim == 9
+
+
+def test_host_blas_thread_policy(monkeypatch):
+    """The dense-covariance objectives pin the host BLAS pool (viabel_amd._lib.apply_host_blas_policy): default one
+    thread, VIABEL_AMD_HOST_BLAS_THREADS=0 leaves it alone, an explicit set_host_blas_threads wins."""
+    threadpoolctl = pytest.importorskip('threadpoolctl')
+    from viabel_amd import _lib
+
+    def blas_threads():
+        return sorted({p['num_threads'] for p in threadpoolctl.threadpool_info() if p['user_api'] == 'blas'})
+
+    np.ones((4, 4)) @ np.ones((4, 4))            # make sure the BLAS library is loaded
+    before = blas_threads()
+    monkeypatch.setattr(_lib, '_blas_policy_done', False)
+    monkeypatch.setattr(_lib, '_blas_sticky', None)
+    monkeypatch.setenv('VIABEL_AMD_HOST_BLAS_THREADS', '0')
+    _lib.apply_host_blas_policy()
+    assert blas_threads() == before
+    monkeypatch.setattr(_lib, '_blas_policy_done', False)
+    monkeypatch.setenv('VIABEL_AMD_HOST_BLAS_THREADS', '1')
+    _lib.apply_host_blas_policy()
+    assert blas_threads() == [1]
+    _lib.apply_host_blas_policy()                # idempotent
+    assert _lib.set_host_blas_threads(2) and blas_threads() == [min(2, max(before))]
+    with _lib.small_lapack(8):
+        assert blas_threads() == [1]
+    threadpoolctl.threadpool_limits(limits=max(before), user_api='blas')      # back to the session's setting
+    assert blas_threads() == before
