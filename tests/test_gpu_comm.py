@@ -106,6 +106,29 @@ def test_fullrank_comm_path(engines):
     np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-13 * np.max(np.abs(out[0][1])))
 
 
+def test_fullrank_path_derivative_comm_path(engines):
+    """Path derivative through the sharded code path: tr(M2) and the L^-T M2 / L^-T e corrections ride in the
+    all-reduced sum vector."""
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    plain, comm = engines
+    D, N = 70, 300
+    rng = np.random.RandomState(8)
+    spec = vb.FunnelModel(D).device_spec()
+    fr = vb.FullRankGaussian(D)
+    L = np.tril(0.05 * rng.randn(D, D), -1) + np.diag(np.exp(-1 + 0.1 * rng.randn(D)))
+    theta = fr.pack(0.2 * rng.randn(D), L)
+    out = []
+    for eng in (plain, comm):
+        eng.set_model(spec)
+        eng.noise_generate(6, N, D, seed=4, stream=0)
+        out.append(eng.elbo_grad_fullrank(6, N, D, theta, flags=_lib.FLAG_PATH_DERIV))
+    assert out[0][0] == out[1][0]
+    np.testing.assert_array_equal(out[1][1], out[0][1])
+    ent = plain.elbo_grad_fullrank(6, N, D, theta)
+    assert ent[0] != out[0][0]
+
+
 def test_fullrank_overlapped_enqueues_through_comm(engines):
     """Back-to-back sharded full-rank evaluations: the all-reduce + epilogue of one runs on the communication
     stream while the next one's GEMMs run (two sum sets).  Every evaluation, interleaved with parameter changes

@@ -689,11 +689,9 @@ int vb_elbo_grad_fullrank_enqueue(vb_ctx* ctx, int slot, int64_t n, int64_t d, i
     return fail(ctx, VB_ERR_STATE, "no resident parameter of dimension %lld (vb_fullrank_set_theta)",
                 (long long)d);
   if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
-  if (flags & VB_FLAG_PATH_DERIV)
-    return fail(ctx, VB_ERR_UNSUPPORTED, "use_path_deriv is not implemented for the full-rank family");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   return fr_elbo_grad_enqueue(ctx, ctx->noise[slot], n, d, n_total, (const double*)ctx->fr_theta.ptr,
-                              (double*)ctx->fr_out.ptr);
+                              (double*)ctx->fr_out.ptr, flags);
 }
 
 int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p) {
@@ -746,8 +744,8 @@ int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t
     return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident fit: family %d is not supported", family);
   if (p != (meanfield ? 2 * d : d + d * (d + 1) / 2))
     return fail(ctx, VB_ERR_INVALID, "parameter length %lld does not match the family", (long long)p);
-  if (fullrank && (cv_mode != VB_CV_NONE || (flags & VB_FLAG_PATH_DERIV)))
-    return fail(ctx, VB_ERR_UNSUPPORTED, "full-rank family: entropy-form estimator only");
+  if (fullrank && cv_mode != VB_CV_NONE)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "full-rank family: the RGE control variates do not apply");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
   VB_TRY(noise_alloc(ctx, slot, n, d));
@@ -772,6 +770,8 @@ int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t
   if (has_state) {
     VB_HIP(ctx, hipMemcpyAsync(base + o_s1, state, (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
     VB_HIP(ctx, hipMemcpyAsync(base + o_s2, state + p, (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
+  } else {   // the part of the state an optimiser does not use is returned as zeros, not as stale workspace
+    VB_HIP(ctx, hipMemsetAsync(base + o_s1, 0, (size_t)(o_val - o_s1) * sizeof(double), st));
   }
   VB_HIP(ctx, hipStreamSynchronize(st));   // the caller's buffers are pageable: copies above are staged
 
@@ -814,7 +814,7 @@ int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t
     if (meanfield)
       VB_TRY(mf_enqueue(ctx, c));
     else
-      VB_TRY(fr_elbo_grad_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev));
+      VB_TRY(fr_elbo_grad_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev, flags));
     if (fullrank && ctx->pipe.post_pending) {   // sharded full-rank evaluations finish on the communication stream
       VB_HIP(ctx, hipStreamWaitEvent(st, ctx->pipe.ev_fin[ctx->pipe.last_set], 0));
       ctx->pipe.post_pending = false;

@@ -216,9 +216,9 @@ int sync_streams(vb_ctx* ctx);   // main + pipeline streams
 struct FrSums;
 int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
                         const double* theta_dev, double* out_dev, const double* mu_dev, const double* root_dev,
-                        const double* row_scale, FrSums* sums_out);
+                        const double* row_scale, FrSums* sums_out, unsigned flags = 0);
 int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
-                         const double* theta_dev, double* out_dev);
+                         const double* theta_dev, double* out_dev, unsigned flags = 0);
 
 // sum vector of the dense paths: [F | column sums (ldz) | C (d x ldl)]
 struct FrSums {

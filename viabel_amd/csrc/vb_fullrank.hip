@@ -255,8 +255,9 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
     const double* __restrict__ Cpart, int splits, int64_t slab, int d, int64_t ldl,
     const double* __restrict__ colpart, int n_rb, int64_t ldz, const double* __restrict__ fpart, int n_fpart,
     FrSums S, const double* __restrict__ theta, double n_local_w, double n_total, double c0,
-    double* __restrict__ out) {
+    double* __restrict__ out, int pd) {
   __shared__ double sh[4];
+  const double ent = pd ? 0.0 : 1.0;      // the entropy's -1 on the free diagonal (absent with the path derivative)
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t idx = 2 * tid;
   const int64_t nC = (int64_t)d * ldl;
@@ -276,11 +277,11 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
       const int64_t p = (int64_t)i * (i + 1) / 2 + j;
       if (FUSE) {
         double g0 = -s.x * invN;
-        if (j == i) g0 = g0 * exp(theta[d + p]) - 1.0;              // free (log) diagonal + entropy
+        if (j == i) g0 = g0 * exp(theta[d + p]) - ent;              // free (log) diagonal + entropy
         out[1 + d + p] = g0;
         if (j + 1 <= i) {
           double g1 = -s.y * invN;
-          if (j + 1 == i) g1 = g1 * exp(theta[d + p + 1]) - 1.0;
+          if (j + 1 == i) g1 = g1 * exp(theta[d + p + 1]) - ent;
           out[1 + d + p + 1] = g1;
         }
       } else {
@@ -317,7 +318,8 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
       const double sum_logdiag = fr_block_sum(t, sh);
       if (threadIdx.x == 0) {
         const double F = f + n_local_w * c0;
-        const double H = 0.5 * d * (1.0 + kLog2PiFr) + sum_logdiag;
+        const double half_sq = pd ? 0.5 * S.sums[1] * invN : 0.5 * d;    // 1/2 mean ||eps||^2 or its expectation
+        const double H = half_sq + 0.5 * d * kLog2PiFr + sum_logdiag;
         out[0] = -(F * invN + H);
       }
     } else if (threadIdx.x == 0) {
@@ -329,7 +331,7 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
 // epilogue of the sharded job: all-reduced packed sums -> (value, grad)
 __global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const double* __restrict__ theta,
                                                                  int d, double n_local_w, double n_total,
-                                                                 double c0, double* __restrict__ out) {
+                                                                 double c0, double* __restrict__ out, int pd) {
   __shared__ double sh[4];
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t np = (int64_t)d * (d + 1) / 2;
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const
     while ((int64_t)(i + 1) * (i + 2) / 2 <= p) ++i;
     while ((int64_t)i * (i + 1) / 2 > p) --i;
     double g = -S.sums[S.off_c + p] * invN;                         // d value / d L_ij
-    if (p == (int64_t)i * (i + 1) / 2 + i) g = g * exp(theta[d + p]) - 1.0;
+    if (p == (int64_t)i * (i + 1) / 2 + i) g = g * exp(theta[d + p]) - (pd ? 0.0 : 1.0);
     out[1 + d + p] = g;
   }
   if (p < d) out[1 + p] = -S.sums[S.off_col + p] * invN;
@@ -349,7 +351,8 @@ __global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const
     const double sum_logdiag = fr_block_sum(t, sh);
     if (threadIdx.x == 0) {
       const double F = S.sums[0] + n_local_w * c0;
-      const double H = 0.5 * d * (1.0 + kLog2PiFr) + sum_logdiag;
+      const double half_sq = pd ? 0.5 * S.sums[1] * invN : 0.5 * d;
+      const double H = half_sq + 0.5 * d * kLog2PiFr + sum_logdiag;
       out[0] = -(F * invN + H);
     }
   }
@@ -361,6 +364,111 @@ __global__ void __launch_bounds__(256) fr_rowscale_kernel(double* __restrict__ G
   const int64_t row = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c < d) G[row * ldz + c] *= rs[row];
+}
+
+// ---- path derivative ("sticking the landing", objectives.py:156-159) for the dense Gaussian ----------------
+// value = -mean(f(z) - log q(z; stop(theta))): the score -dlog q/dz = L^-T eps is added to the model gradient,
+// so with M2 = sum_n eps_n eps_n' (the noise Gram matrix) and e = sum_n eps_n the sums become
+//     C' = C + L^-T M2,      colsum' = colsum + L^-T e,      value: 1/2 tr(M2) / N replaces D / 2,
+// an O(D^3) correction instead of a third N x D x D product.  L^-T = (L')^-1 is formed explicitly (blocked
+// recursive inversion, see fr_triinv_leaf_kernel and the host loop), so the correction itself is one GEMM.
+struct EpiStoreD {          // C = sign * acc
+  double* C;
+  int64_t ld;
+  double sign;
+  __device__ void operator()(int, int row, int col, double acc) const { C[(int64_t)row * ld + col] = sign * acc; }
+};
+
+// Inverse of the diagonal blocks of U = L' (rows / columns [s, s + kTriLeaf)): one WAVE per column j of a block's
+// inverse, column-oriented back substitution.  Lane r keeps the running sum p_r = sum_{k > i} U[r][k] x_k of "its"
+// rows r and r + 64 in registers; step i reads p_i with v_readlane (i is wave-uniform), forms
+// x_i = (delta_ij - p_i) / U_ii and adds U[r][i] x_i to every p_r, r < i.  U[.][i] is row i of L -- contiguous in
+// the packed parameter -- and does not depend on x, so it is fetched eight steps ahead: the dependent chain per
+// step is a readlane, a subtract, a multiply and an FMA.  The D columns of all blocks run in parallel.
+constexpr int kTriLeaf = 128;
+__device__ __forceinline__ double fr_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__global__ void __launch_bounds__(256) fr_triinv_leaf_kernel(const double* __restrict__ theta,
+                                                             const double* __restrict__ U, int d, int64_t ld,
+                                                             double* __restrict__ X) {
+  const int lane = threadIdx.x & 63;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // global column
+  if (c >= d) return;
+  const int s = c / kTriLeaf * kTriLeaf, j = c - s;
+  double p0 = 0.0, p1 = 0.0, x0 = 0.0, x1 = 0.0;            // rows lane, lane + 64 of the block
+  // 1 / U_ii of "its" rows, computed by all lanes at once and read with v_readlane in the loop
+  double q0 = 1.0, q1 = 1.0;
+  if (lane <= j) q0 = 1.0 / U[(int64_t)(s + lane) * ld + s + lane];
+  if (lane + 64 <= j) q1 = 1.0 / U[(int64_t)(s + lane + 64) * ld + s + lane + 64];
+  constexpr int R = 8;
+  double l0[R], l1[R], n0[R], n1[R];
+  // step i needs row s + i of L (columns s .. s + i - 1)
+  auto fetch = [&](int i0, double* a0, double* a1) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = i0 - r;
+      a0[r] = 0.0;
+      a1[r] = 0.0;
+      if (i >= 0) {
+        const int64_t gi = s + i;
+        const double* lrow = theta + d + gi * (gi + 1) / 2 + s;
+        if (lane < i) a0[r] = lrow[lane];
+        if (lane + 64 < i) a1[r] = lrow[lane + 64];
+      }
+    }
+  };
+  fetch(j, l0, l1);
+  for (int i0 = j; i0 >= 0; i0 -= R) {
+    fetch(i0 - R, n0, n1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = i0 - r;
+      if (i < 0) break;                                      // wave-uniform
+      const double pi = i < 64 ? fr_readlane(p0, i) : fr_readlane(p1, i - 64);
+      const double qi = i < 64 ? fr_readlane(q0, i) : fr_readlane(q1, i - 64);
+      const double xi = ((i == j ? 1.0 : 0.0) - pi) * qi;
+      if (lane == i) x0 = xi;
+      if (lane + 64 == i) x1 = xi;
+      p0 = fma(l0[r], xi, p0);                               // l0 / l1 are zero for rows >= i
+      p1 = fma(l1[r], xi, p1);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      l0[r] = n0[r];
+      l1[r] = n1[r];
+    }
+  }
+  double* Xb = X + (int64_t)s * ld + s;
+  if (lane <= j) Xb[(int64_t)lane * ld + j] = x0;
+  if (lane + 64 <= j) Xb[(int64_t)(lane + 64) * ld + j] = x1;
+}
+
+// y = X e (one wave per row) into the extra column-sum row, and tr(M2) into the sum vector's slot 1
+__global__ void __launch_bounds__(256) fr_pd_matvec_kernel(const double* __restrict__ X, int64_t ld,
+                                                           const double* __restrict__ e,
+                                                           const double* __restrict__ M2, int64_t ldm, int d,
+                                                           double* __restrict__ yrow, int64_t ldz,
+                                                           double* __restrict__ trace_out) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;
+  if (i < d) {
+    double s = 0.0;
+    for (int k = i + lane; k < d; k += 64) s = fma(X[(int64_t)i * ld + k], e[k], s);   // X is upper triangular
+    s = fr_wave_sum(s);
+    if (lane == 0) yrow[i] = s;
+  } else if (i < ldz && lane == 0) {
+    yrow[i] = 0.0;
+  }
+  if (blockIdx.x == 0) {
+    double t = 0.0;
+    for (int k = threadIdx.x; k < d; k += 256) t += M2[(int64_t)k * ldm + k];
+    t = fr_block_sum(t, sh);
+    if (threadIdx.x == 0) *trace_out = t;
+  }
 }
 
 // ---- wrappers shared with the multivariate-t path (vb_mvt.hip) ---------------------------------------
@@ -413,9 +521,11 @@ int gram_splits(vb_ctx* ctx, int d, int64_t n) {
 // `row_scale`; the caller gets the raw sums [F | sum g | sum_n g_n (e_n / s_n)' (full D x D)] in `sums_out`).
 int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
                         const double* theta_dev, double* out_dev, const double* mu_dev, const double* root_dev,
-                        const double* row_scale, FrSums* sums_out) {
+                        const double* row_scale, FrSums* sums_out, unsigned flags) {
   const ModelDev& m = ctx->model;
   const bool mvt = theta_dev == nullptr;
+  const bool pd = (flags & VB_FLAG_PATH_DERIV) != 0;
+  if (pd && mvt) return fail(ctx, VB_ERR_UNSUPPORTED, "path derivative: dense Gaussian family only");
   if (m.id != VB_MODEL_GAUSS_DIAG && m.id != VB_MODEL_FUNNEL && m.id != VB_MODEL_GAUSS_FULL)
     return fail(ctx, VB_ERR_UNSUPPORTED, "full-rank path: unsupported model id %d", m.id);
   if (m.dim != d)
@@ -446,8 +556,13 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     return o;
   };
   const int64_t o_mu = carve(ldz), o_lt = carve(slab), o_z = carve(n * ldz), o_g = carve(n * ldz),
-                o_cpart = carve((int64_t)splits * slab), o_col = carve((int64_t)n_rb * ldz),
+                o_cpart = carve((int64_t)(splits + 1) * slab), o_col = carve((int64_t)(n_rb + 1) * ldz),
                 o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx);
+  // path derivative: (L')^-1 (Xa), a product buffer T, the noise Gram matrix [16 | e (ld_e) | M2 (d x ldl)], partial
+  // column sums of the noise (row stride = the noise matrix's)
+  const int64_t ld_e = ns.ld;
+  const int64_t o_xa = pd ? carve(slab) : 0, o_t = pd ? carve(slab) : 0,
+                o_m2 = pd ? carve(16 + ld_e + slab) : 0, o_cole = pd ? carve((int64_t)n_rb * ld_e) : 0;
   // sum vector: the t family takes the full D x ldl matrix; the Gaussian family packs the lower triangle in
   // theta's own order, twice over when the all-reduce of one evaluation overlaps the kernels of the next
   const int64_t np = d * (d + 1) / 2;
@@ -484,6 +599,78 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   } else {
     hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((d * d + 255) / 256)), dim3(256), 0, st, theta_dev,
                        D, ldl, Lt, mu);
+    VB_HIP(ctx, hipGetLastError());
+  }
+
+  if (pd) {
+    // (L')^-1 = U^-1 by recursive doubling: diagonal blocks of kTriLeaf rows are inverted by back substitution
+    // (one wave per column), then [[A, B], [0, C]]^-1 = [[A^-1, -A^-1 B C^-1], [0, C^-1]] level by level --
+    // two GEMMs per pair of blocks, D^3 / 3 flops in all instead of a triangular solve
+    double *Xa = base + o_xa, *T = base + o_t, *m2 = base + o_m2, *colE = base + o_cole;
+    VB_HIP(ctx, hipMemsetAsync(Xa, 0, (size_t)(2 * slab) * sizeof(double), st));   // Xa, T (contiguous)
+    hipLaunchKernelGGL(fr_triinv_leaf_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, theta_dev,
+                       (const double*)Lt, D, ldl, Xa);
+    VB_HIP(ctx, hipGetLastError());
+    GemmArgs gn;
+    gn.lda = ldl;
+    gn.ldb = ldl;
+    gn.tri_mode = 0;
+    for (int b = kTriLeaf; b < D; b *= 2) {
+      for (int s0 = 0; s0 + b < D; s0 += 2 * b) {
+        const int b2 = D - s0 - b < b ? D - s0 - b : b;
+        const int64_t oa = (int64_t)s0 * ldl + s0, ob = (int64_t)s0 * ldl + s0 + b,
+                      oc = (int64_t)(s0 + b) * ldl + s0 + b;
+        gn.A = Lt + ob;      // B block (b x b2)
+        gn.B = Xa + oc;      // C^-1 (b2 x b2)
+        gn.M = b;
+        gn.N = b2;
+        gn.K = b2;
+        gemm_f64_launch<true>(st, gn, 1, n_cu, EpiStoreD{T + ob, ldl, 1.0});
+        gn.A = Xa + oa;      // A^-1 (b x b)
+        gn.B = T + ob;
+        gn.K = b;
+        gemm_f64_launch<true>(st, gn, 1, n_cu, EpiStoreD{Xa + ob, ldl, -1.0});
+      }
+    }
+    VB_HIP(ctx, hipGetLastError());
+    GemmArgs gx;             // square D x D product below
+    gx.lda = ldl;
+    gx.ldb = ldl;
+    gx.M = D;
+    gx.N = D;
+    gx.K = D;
+    // noise Gram matrix (lower triangle) and column sums, reduced into [16 | e | M2]
+    const double* E = (const double*)ns.buf.ptr;
+    GemmArgs gg;
+    gg.A = E;
+    gg.lda = ns.ld;
+    gg.B = E;
+    gg.ldb = ns.ld;
+    gg.M = D;
+    gg.N = D;
+    gg.K = (int)n;
+    gg.tri_mode = 2;
+    gemm_f64_launch<false>(st, gg, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
+    hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st, E, E, ld_e, n, D,
+                       0, (const double*)nullptr, colE, fpart);
+    VB_HIP(ctx, hipGetLastError());
+    FrSums S2;
+    S2.sums = m2;
+    S2.off_col = 16;
+    S2.off_c = 16 + ld_e;
+    S2.len = 16 + ld_e + slab;
+    const int64_t items2 = slab / 2 > ld_e ? slab / 2 : ld_e;
+    hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((items2 + 255) / 256)), dim3(256), 0, st,
+                       (const double*)Cpart, splits, slab, D, ldl, (const double*)colE, n_rb, ld_e,
+                       (const double*)fpart, 0, S2, 0);
+    // L^-T e -> extra column-sum row, tr(M2) -> sums[1]; L^-T M2 -> extra split slab (lower tiles)
+    hipLaunchKernelGGL(fr_pd_matvec_kernel, dim3((unsigned)((ldz + 3) / 4)), dim3(256), 0, st, (const double*)Xa, ldl,
+                       (const double*)(m2 + S2.off_col), (const double*)(m2 + S2.off_c), ldl, D,
+                       colpart + (int64_t)n_rb * ldz, ldz, S.sums + 1);
+    gx.A = Xa;
+    gx.B = m2 + S2.off_c;
+    gx.tri_mode = 2;
+    gemm_f64_launch<true>(st, gx, 1, n_cu, EpiSplitSlab{Cpart + (int64_t)splits * slab, ldl, slab});
     VB_HIP(ctx, hipGetLastError());
   }
 
@@ -560,15 +747,17 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     return VB_OK;
   }
   if (!ctx->comm) {   // single GPU: the split reduction writes (value, grad) itself
-    hipLaunchKernelGGL(fr_reduce_packed_kernel<true>, red_grid, dim3(256), 0, st, (const double*)Cpart, splits,
-                       slab, D, ldl, (const double*)colpart, n_rb, ldz, (const double*)fpart, n_fpart, S,
-                       theta_dev, (double)n_total, (double)n_total, m.c0, out_dev);
+    hipLaunchKernelGGL(fr_reduce_packed_kernel<true>, red_grid, dim3(256), 0, st, (const double*)Cpart,
+                       splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb + (pd ? 1 : 0), ldz,
+                       (const double*)fpart, n_fpart, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
+                       pd ? 1 : 0);
     VB_HIP(ctx, hipGetLastError());
     return VB_OK;
   }
-  hipLaunchKernelGGL(fr_reduce_packed_kernel<false>, red_grid, dim3(256), 0, st, (const double*)Cpart, splits,
-                     slab, D, ldl, (const double*)colpart, n_rb, ldz, (const double*)fpart, n_fpart, S,
-                     theta_dev, (double)n_total, (double)n_total, m.c0, out_dev);
+  hipLaunchKernelGGL(fr_reduce_packed_kernel<false>, red_grid, dim3(256), 0, st, (const double*)Cpart,
+                     splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb + (pd ? 1 : 0), ldz,
+                     (const double*)fpart, n_fpart, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
+                     pd ? 1 : 0);
   VB_HIP(ctx, hipGetLastError());
   hipStream_t st_post = st;
   if (overlap) {
@@ -578,7 +767,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
   VB_TRY(comm_allreduce_sum(ctx, st_post, S.sums, (size_t)S.len));
   hipLaunchKernelGGL(fr_epilogue_packed_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st_post, S,
-                     theta_dev, D, (double)n_total, (double)n_total, m.c0, out_dev);
+                     theta_dev, D, (double)n_total, (double)n_total, m.c0, out_dev, pd ? 1 : 0);
   VB_HIP(ctx, hipGetLastError());
   if (overlap) {
     VB_HIP(ctx, hipEventRecord(P.ev_fin[set], st_post));
@@ -590,8 +779,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
 }
 
 int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
-                         const double* theta_dev, double* out_dev) {
-  return fr_pipeline_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev, nullptr, nullptr, nullptr, nullptr);
+                         const double* theta_dev, double* out_dev, unsigned flags) {
+  return fr_pipeline_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev, nullptr, nullptr, nullptr, nullptr, flags);
 }
 
 }  // namespace vb

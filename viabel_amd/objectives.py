@@ -214,8 +214,7 @@ class ExclusiveKL(StochasticVariationalObjective):
         mean-field or full-rank family drawing Philox noise (``rng='philox'``)."""
         approx = self.approx
         return (isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian)) and approx.rng == 'philox'
-                and not (isinstance(approx, FullRankGaussian)
-                         and (self._use_path_deriv or self.hessian_approx_method is not None)))
+                and not (isinstance(approx, FullRankGaussian) and self.hessian_approx_method is not None))
 
     def device_fit(self, n_iters, init_param, opt_kind, hyper, state=None, hist_len=0, log_directions=False,
                    log_gradients=False):
