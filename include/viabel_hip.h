@@ -44,6 +44,7 @@ typedef struct vb_ctx vb_ctx;
 #define VB_FAMILY_MF_STUDENT_T 1       /* :254-312 */
 #define VB_FAMILY_FULLRANK_GAUSSIAN 2  /* new family, layout of :315-319 */
 #define VB_FAMILY_MULTIVARIATE_T 3     /* :322-382 */
+#define VB_FAMILY_LOWRANK_GAUSSIAN 4   /* LRGaussian :610-731 */
 
 /* device-resident target models (replace the Python callable of viabel/models.py:17-39) */
 #define VB_MODEL_GAUSS_DIAG 0  /* sum_d norm.logpdf(x_d; mean_d, sd_d)   dparams=[mean(D)|sd(D)]           */
@@ -234,8 +235,10 @@ int vb_sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double
  * vb_elbo_grad_fullrank would, and applies one optimiser step on the device; all n_iters iterations are
  * enqueued back to back and the call returns when the last one has finished.  The update arithmetic follows
  * numpy's operation order without fused multiply-adds, so the trajectory equals the host loop's bit for bit.
- *   family      VB_FAMILY_MF_GAUSSIAN / VB_FAMILY_MF_STUDENT_T (p = 2 d) or VB_FAMILY_FULLRANK_GAUSSIAN
- *               (p = d + d (d + 1) / 2)
+ *   family      VB_FAMILY_MF_GAUSSIAN / VB_FAMILY_MF_STUDENT_T (p = 2 d), VB_FAMILY_FULLRANK_GAUSSIAN
+ *               (p = d + d (d + 1) / 2) or VB_FAMILY_LOWRANK_GAUSSIAN (p = 2 d + d k, 1 <= k <= 16: the n x k block
+ *               of its noise goes to `slot_aux`; iteration c draws the n x d block from Philox stream
+ *               2 (first_stream + c) and the n x k block from stream 2 (first_stream + c) + 1)
  *   opt_kind    VB_OPT_SGD (:129-130), VB_OPT_RMSPROP (:188-197), VB_OPT_ADAM (:308-326), VB_OPT_ADAGRAD (:430-433)
  *   hyper       [learning_rate, beta (RMSProp) or beta1 (Adam), beta2 (Adam), jitter]
  *   theta       in: start, out: parameter after n_iters steps (p doubles)
@@ -252,7 +255,7 @@ int vb_sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double
 #define VB_OPT_RMSPROP 1
 #define VB_OPT_ADAM 2
 #define VB_OPT_ADAGRAD 3
-int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
+int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
            double df, unsigned flags, int cv_mode, int noise_kind, double noise_df, uint64_t seed,
            uint64_t first_stream, int opt_kind, const double hyper[4], int64_t n_iters, double* theta, int64_t p,
            double* state, int has_state, double* values, double* history, int64_t hist_len, double* directions,

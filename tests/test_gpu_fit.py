@@ -239,3 +239,24 @@ def test_device_loop_fullrank_path_derivative():
     host = opt.RMSProp(0.01).optimize(40, obj_h, init, on_device=False)
     dev = opt.RMSProp(0.01).optimize(40, obj_d, init, on_device=True)
     _assert_same(host, dev)
+
+
+@pytest.mark.parametrize('name', ['rmsprop', 'adam'])
+def test_device_loop_lowrank_family(name):
+    """LRGaussian (approximations.py:610-731) in Philox mode: two noise blocks per iteration, same trajectory."""
+    import viabel_amd as vb
+    D, k, N = 30, 3, 64
+    rng = np.random.RandomState(6)
+    mean, sd = rng.randn(D), np.exp(0.2 * rng.randn(D))
+
+    def make():
+        return vb.ExclusiveKL(vb.LRGaussian(D, seed=9, k=k, rng='philox'), vb.GaussianModel(mean, sd), N)
+    init = vb.LRGaussian(D, k=k).pack(np.zeros(D), np.zeros(D), 0.1 * rng.randn(D, k))
+    obj_h, obj_d = _pair(make)
+    opt_h, opt_d = _pair(_optimizers()[name])
+    host = opt_h.optimize(45, obj_h, init, on_device=False)
+    dev = opt_d.optimize(45, obj_d, init, on_device=True)
+    _assert_same(host, dev)
+    host2 = opt_h.optimize(10, obj_h, host['opt_param'], on_device=False)
+    dev2 = opt_d.optimize(10, obj_d, dev['opt_param'], on_device=True)
+    _assert_same(host2, dev2)

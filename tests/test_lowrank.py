@@ -105,3 +105,33 @@ def test_lowrank_rejects_unsupported():
         vb.ExclusiveKL(vb.LRGaussian(4, k=17), model, 10)(np.zeros(4 * 2 + 4 * 17))
     with pytest.raises(ValueError):
         vb.ExclusiveKL(vb.LRGaussian(4, k=2), model, 10)(np.zeros(3))
+
+
+@pytest.mark.gpu
+def test_lowrank_philox_mode_matches_oracle_on_the_same_noise():
+    """rng='philox': both noise blocks are generated on the device (streams 2 c / 2 c + 1 of call c); read back and
+    fed to the oracle they reproduce the device objective, and the host sample() sees the same convention."""
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    D, k, N = 96, 4, 500
+    rng = np.random.RandomState(2)
+    mean, sd = rng.randn(D), np.exp(0.3 * rng.randn(D))
+    fam = vb.LRGaussian(D, seed=11, k=k, rng='philox')
+    theta = fam.pack(0.2 * rng.randn(D), -1.0 + 0.1 * rng.randn(D), 0.1 * rng.randn(D, k))
+    obj = vb.ExclusiveKL(fam, vb.GaussianModel(mean, sd), N)
+    assert obj.supports_device_fit()
+    for call in range(2):
+        value, grad = obj(theta)
+        eng = _lib.default_engine()
+        eps = eng.noise_get_host(0, N, D)
+        z = eng.noise_get_host(3, N, k)
+        ov, og = oobj.exclusive_kl(ofam.LRGaussian(D, k), omod.GaussDiag(mean, sd), theta, (z, eps))
+        assert abs(value - ov) <= 1e-12 * abs(ov)
+        np.testing.assert_allclose(grad, og, rtol=0, atol=1e-11 * np.max(np.abs(og)))
+        # the same call index through the generator directly
+        eng.noise_generate(40, N, D, 11, 2 * call)
+        eng.noise_generate(41, N, k, 11, 2 * call + 1)
+        np.testing.assert_array_equal(eng.noise_get_host(40, N, D), eps)
+        np.testing.assert_array_equal(eng.noise_get_host(41, N, k), z)
+    x = fam.sample(theta, 2000)
+    assert x.shape == (2000, D) and abs(x.mean() - theta[:D].mean()) < 0.1

@@ -17,7 +17,8 @@ CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 VB_OK, VB_ERR_INVALID, VB_ERR_HIP, VB_ERR_UNSUPPORTED, VB_ERR_STATE, VB_ERR_NUMERIC, VB_ERR_COMM = range(7)
 
-FAMILY_MF_GAUSSIAN, FAMILY_MF_STUDENT_T, FAMILY_FULLRANK_GAUSSIAN, FAMILY_MULTIVARIATE_T = range(4)
+FAMILY_MF_GAUSSIAN, FAMILY_MF_STUDENT_T, FAMILY_FULLRANK_GAUSSIAN, FAMILY_MULTIVARIATE_T, FAMILY_LOWRANK_GAUSSIAN = \
+    range(5)
 MODEL_GAUSS_DIAG, MODEL_FUNNEL, MODEL_GAUSS_FULL, MODEL_LOGISTIC = range(4)
 NOISE_NORMAL, NOISE_STUDENT_T = range(2)
 FLAG_PATH_DERIV = 1
@@ -67,7 +68,7 @@ SIGNATURES = {
                                             _c_double_p]),
     'vb_sym_sqrt': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p,
                                    _c_double_p]),
-    'vb_fit': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+    'vb_fit': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                               ctypes.c_int, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
                               ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _c_double_p,
                               ctypes.c_int64, _c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_int,
@@ -437,7 +438,7 @@ class Engine:
     # ------------------------------------------------------------------ device-resident fit
     def fit(self, slot, n, d, family, theta, n_iters, opt_kind, hyper, *, df=0.0, flags=0, cv_mode=0,
             n_total=None, row_offset=0, noise_kind=NOISE_NORMAL, noise_df=0.0, seed=1, first_stream=0,
-            state=None, hist_len=0, log_directions=False, log_gradients=False):
+            state=None, hist_len=0, log_directions=False, log_gradients=False, slot_aux=-1):
         """``n_iters`` iterations of {Philox noise -> objective -> optimiser step} enqueued back to back
         (``vb_fit``).  Returns (theta, values, history, state, directions or None, gradients or None)."""
         theta = _f64(theta).copy()
@@ -450,7 +451,7 @@ class Engine:
         directions = np.empty((n_iters, p), dtype=np.float64) if log_directions else None
         gradients = np.empty((n_iters, p), dtype=np.float64) if log_gradients else None
         self._check(self._lib.vb_fit(
-            self._ctx, slot, n, d, n if n_total is None else n_total, int(row_offset), family, float(df), flags,
+            self._ctx, slot, slot_aux, n, d, n if n_total is None else n_total, int(row_offset), family, float(df), flags,
             cv_mode, noise_kind, float(noise_df), int(seed), int(first_stream), opt_kind, _dptr(hyper), int(n_iters),
             _dptr(theta), p, _dptr(state), int(has_state), _dptr(values),
             _dptr(history) if hist_len else None, int(hist_len),

@@ -453,9 +453,9 @@ class LRGaussian(_NoiseMixin, ApproximationFamily):
     reference's helpers (``:559-607``).
     """
 
+    _family_id = _lib.FAMILY_LOWRANK_GAUSSIAN
+
     def __init__(self, dim, seed=1, k=0, rng='numpy'):
-        if rng != 'numpy':
-            raise NotImplementedError("LRGaussian draws its two noise blocks from the numpy stream (rng='numpy')")
         self._init_rng(seed, rng)
         self._k = int(k)
         super().__init__(dim, 2 * dim + dim * self._k, True, True)
@@ -475,9 +475,30 @@ class LRGaussian(_NoiseMixin, ApproximationFamily):
 
     def _base_noise(self, n_samples, seed=None):
         """``(z, eps)``: the low-rank block is drawn first (``:639-640``)."""
+        if self._rng_kind == 'philox':
+            return self._philox_noise(_lib.default_engine(), n_samples, seed, 0, _lib.MAX_SLOTS - 1,
+                                      _lib.MAX_SLOTS - 2, read_back=True)
         rs = self._random_state(seed)
         z = rs.randn(n_samples, self._k)
         return z, rs.randn(n_samples, self.dim)
+
+    def _device_family(self):
+        return self._family_id, 0.0
+
+    def _philox_noise(self, eng, n_rows, seed, row_offset, slot_eps, slot_z, read_back=False):
+        """Throughput mode: call c of the family fills the n x D block from Philox stream 2 c and the n x k block
+        from stream 2 c + 1 (the convention of ``vb_fit``); an explicit ``seed`` uses streams 0 / 1 of that seed."""
+        if seed is None:
+            seed, c = self._seed, self._next_philox_stream()
+        else:
+            c = 0
+        eng.noise_generate(slot_eps, n_rows, self.dim, seed, 2 * c, row_offset=row_offset)
+        if self._k > 0:
+            eng.noise_generate(slot_z, n_rows, self._k, seed, 2 * c + 1, row_offset=row_offset)
+        if not read_back:
+            return None
+        z = eng.noise_get_host(slot_z, n_rows, self._k) if self._k > 0 else np.zeros((n_rows, 0))
+        return z, eng.noise_get_host(slot_eps, n_rows, self.dim)
 
     def init_param(self):          # :630-634 (advances the family's stream by D k draws)
         return self.pack(np.zeros(self.dim), np.ones(self.dim), self._rs.randn(self.dim, self._k))

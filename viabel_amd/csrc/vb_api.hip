@@ -724,7 +724,7 @@ int vb_sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double
 }
 
 // ---- device-resident fit (optimization.py:83-127) ----------------------------------------------------
-int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
+int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
            double df, unsigned flags, int cv_mode, int noise_kind, double noise_df, uint64_t seed,
            uint64_t first_stream, int opt_kind, const double hyper[4], int64_t n_iters, double* theta, int64_t p,
            double* state, int has_state, double* values, double* history, int64_t hist_len, double* directions,
@@ -740,16 +740,27 @@ int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t
   if (has_state && !state) return fail(ctx, VB_ERR_INVALID, "has_state set without a state buffer");
   const bool meanfield = family == VB_FAMILY_MF_GAUSSIAN || family == VB_FAMILY_MF_STUDENT_T;
   const bool fullrank = family == VB_FAMILY_FULLRANK_GAUSSIAN;
-  if (!meanfield && !fullrank)
+  const bool lowrank = family == VB_FAMILY_LOWRANK_GAUSSIAN;
+  if (!meanfield && !fullrank && !lowrank)
     return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident fit: family %d is not supported", family);
-  if (p != (meanfield ? 2 * d : d + d * (d + 1) / 2))
+  const int64_t lr_k = lowrank ? (p - 2 * d) / d : 0;
+  if (lowrank) {
+    if (lr_k < 1 || lr_k > 16 || p != 2 * d + d * lr_k)
+      return fail(ctx, VB_ERR_INVALID, "low-rank family: parameter length %lld is not 2 d + d k with 1 <= k <= 16",
+                  (long long)p);
+    if (cv_mode != VB_CV_NONE || (flags & VB_FLAG_PATH_DERIV))
+      return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank family: entropy-form estimator only");
+    if (slot_aux == slot) return fail(ctx, VB_ERR_INVALID, "the two noise blocks need different slots");
+  } else if (p != (meanfield ? 2 * d : d + d * (d + 1) / 2)) {
     return fail(ctx, VB_ERR_INVALID, "parameter length %lld does not match the family", (long long)p);
+  }
   if (fullrank && cv_mode != VB_CV_NONE)
     return fail(ctx, VB_ERR_UNSUPPORTED, "full-rank family: the RGE control variates do not apply");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
   VB_TRY(noise_alloc(ctx, slot, n, d));
   NoiseSlot& ns = ctx->noise[slot];
+  if (lowrank) VB_TRY(noise_alloc(ctx, slot_aux, n, lr_k));
 
   // device state: [theta (p) | out (1 + p) | s1 (p) | s2 (p) | values (n_iters) | iterates (hist_len x p)]
   int64_t off = 0;
@@ -809,12 +820,20 @@ int vb_fit(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t
     c.cv_mode = cv_mode;
   }
   for (int64_t k = 0; k < n_iters; ++k) {
-    VB_TRY(rng_fill(ctx, (double*)ns.buf.ptr, ns.ld, noise_kind, noise_df, seed, first_stream + (uint64_t)k,
-                    row_offset, n, d));
-    if (meanfield)
-      VB_TRY(mf_enqueue(ctx, c));
-    else
-      VB_TRY(fr_elbo_grad_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev, flags));
+    if (lowrank) {
+      NoiseSlot& nz = ctx->noise[slot_aux];
+      const uint64_t s2 = 2 * (first_stream + (uint64_t)k);
+      VB_TRY(rng_fill(ctx, (double*)ns.buf.ptr, ns.ld, VB_NOISE_NORMAL, 0.0, seed, s2, row_offset, n, d));
+      VB_TRY(rng_fill(ctx, (double*)nz.buf.ptr, nz.ld, VB_NOISE_NORMAL, 0.0, seed, s2 + 1, row_offset, n, lr_k));
+      VB_TRY(lr_elbo_grad_enqueue(ctx, ns, nz, n, d, lr_k, n_total, theta_dev, out_dev));
+    } else {
+      VB_TRY(rng_fill(ctx, (double*)ns.buf.ptr, ns.ld, noise_kind, noise_df, seed, first_stream + (uint64_t)k,
+                      row_offset, n, d));
+      if (meanfield)
+        VB_TRY(mf_enqueue(ctx, c));
+      else
+        VB_TRY(fr_elbo_grad_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev, flags));
+    }
     if (fullrank && ctx->pipe.post_pending) {   // sharded full-rank evaluations finish on the communication stream
       VB_HIP(ctx, hipStreamWaitEvent(st, ctx->pipe.ev_fin[ctx->pipe.last_set], 0));
       ctx->pipe.post_pending = false;

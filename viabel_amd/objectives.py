@@ -196,9 +196,12 @@ class ExclusiveKL(StochasticVariationalObjective):
                 eng.set_model(self.model.device_spec())
                 N = self.num_mc_samples
                 begin, end = shard_rows(N, eng.n_ranks, eng.rank)
-                z, eps = approx._base_noise(N)          # low-rank block first (approximations.py:639-640)
-                eng.noise_set_host(_NOISE_SLOT, eps[begin:end])
-                eng.noise_set_host(_LR_SLOT, z[begin:end])
+                if approx.rng == 'philox':
+                    approx._philox_noise(eng, end - begin, None, begin, _NOISE_SLOT, _LR_SLOT)
+                else:
+                    z, eps = approx._base_noise(N)      # low-rank block first (approximations.py:639-640)
+                    eng.noise_set_host(_NOISE_SLOT, eps[begin:end])
+                    eng.noise_set_host(_LR_SLOT, z[begin:end])
                 return eng.elbo_grad_lowrank(_NOISE_SLOT, _LR_SLOT, end - begin, approx.dim, approx.k, var_param,
                                              n_total=N)
         else:
@@ -211,8 +214,11 @@ class ExclusiveKL(StochasticVariationalObjective):
     # ---- device-resident optimiser loop ---------------------------------------------------------------
     def supports_device_fit(self):
         """True when a whole stochastic-gradient fit can run on the device without host round trips: a
-        mean-field or full-rank family drawing Philox noise (``rng='philox'``)."""
+        mean-field, full-rank or low-rank family drawing Philox noise (``rng='philox'``)."""
         approx = self.approx
+        if isinstance(approx, LRGaussian):
+            return (approx.rng == 'philox' and 1 <= approx.k <= 16 and not self._use_path_deriv
+                    and self.hessian_approx_method is None)
         return (isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian)) and approx.rng == 'philox'
                 and not (isinstance(approx, FullRankGaussian) and self.hessian_approx_method is not None))
 
@@ -242,7 +248,7 @@ class ExclusiveKL(StochasticVariationalObjective):
                        df=df, flags=flags, cv_mode=_lib.CV_MODES[self.hessian_approx_method], n_total=N,
                        row_offset=begin, noise_kind=kind, noise_df=noise_df, seed=approx._seed,
                        first_stream=first, state=state, hist_len=hist_len, log_directions=log_directions,
-                       log_gradients=log_gradients)
+                       log_gradients=log_gradients, slot_aux=_LR_SLOT)
 
     def _mvt_exclusive_kl(self, approx):
         """Entropy-form ELBO for the multivariate t: sampling, model gradient and the D x D contraction
