@@ -372,11 +372,14 @@ __global__ void __launch_bounds__(256) fr_rowscale_kernel(double* __restrict__ G
 //     C' = C + L^-T M2,      colsum' = colsum + L^-T e,      value: 1/2 tr(M2) / N replaces D / 2,
 // an O(D^3) correction instead of a third N x D x D product.  L^-T = (L')^-1 is formed explicitly (blocked
 // recursive inversion, see fr_triinv_leaf_kernel and the host loop), so the correction itself is one GEMM.
-struct EpiStoreD {          // C = sign * acc
+struct EpiStoreD {          // C_z = sign * acc   (z: product index of a batched launch)
   double* C;
   int64_t ld;
   double sign;
-  __device__ void operator()(int, int row, int col, double acc) const { C[(int64_t)row * ld + col] = sign * acc; }
+  int64_t batch_c;
+  __device__ void operator()(int z, int row, int col, double acc) const {
+    C[z * batch_c + (int64_t)row * ld + col] = sign * acc;
+  }
 };
 
 // Inverse of the diagonal blocks of U = L' (rows / columns [s, s + kTriLeaf)): one WAVE per column j of a block's
@@ -616,20 +619,30 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     gn.ldb = ldl;
     gn.tri_mode = 0;
     for (int b = kTriLeaf; b < D; b *= 2) {
-      for (int s0 = 0; s0 + b < D; s0 += 2 * b) {
-        const int b2 = D - s0 - b < b ? D - s0 - b : b;
+      // the pairs of a level are independent products of one shape: one batched launch (blockIdx.z = pair) for
+      // the full pairs, one more for a ragged last pair
+      const int full = D / (2 * b);
+      const int64_t pair_stride = (int64_t)2 * b * ldl + 2 * b;
+      for (int pass = 0; pass < 2; ++pass) {
+        const int s0 = pass == 0 ? 0 : full * 2 * b;
+        const int count = pass == 0 ? full : (s0 + b < D ? 1 : 0);
+        if (count == 0) continue;
+        const int b2 = pass == 0 ? b : D - s0 - b;
         const int64_t oa = (int64_t)s0 * ldl + s0, ob = (int64_t)s0 * ldl + s0 + b,
                       oc = (int64_t)(s0 + b) * ldl + s0 + b;
+        gn.batch = 1;
+        gn.batch_a = pair_stride;
+        gn.batch_b = pair_stride;
         gn.A = Lt + ob;      // B block (b x b2)
         gn.B = Xa + oc;      // C^-1 (b2 x b2)
         gn.M = b;
         gn.N = b2;
         gn.K = b2;
-        gemm_f64_launch<true>(st, gn, 1, n_cu, EpiStoreD{T + ob, ldl, 1.0});
+        gemm_f64_launch<true>(st, gn, count, n_cu, EpiStoreD{T + ob, ldl, 1.0, pair_stride});
         gn.A = Xa + oa;      // A^-1 (b x b)
         gn.B = T + ob;
         gn.K = b;
-        gemm_f64_launch<true>(st, gn, 1, n_cu, EpiStoreD{Xa + ob, ldl, -1.0});
+        gemm_f64_launch<true>(st, gn, count, n_cu, EpiStoreD{Xa + ob, ldl, -1.0, pair_stride});
       }
     }
     VB_HIP(ctx, hipGetLastError());

@@ -51,6 +51,11 @@ struct GemmArgs {
   int tri_mode;     // 0: dense; 1: B[k][j] == 0 for k > j (k-range cut per column block);
                     // 2: only output tiles with bm >= bn (lower triangle of a square C)
   int k_split;      // K range per blockIdx.z (multiple of kGemmBK); splits = gridDim.z
+  // batch mode (batch != 0): blockIdx.z selects one of gridDim.z independent products of the same shape -- operand
+  // z starts batch_a / batch_b doubles after operand z - 1, every product runs over the whole K range and the
+  // epilogue receives z as its `split` argument
+  int batch = 0;
+  int64_t batch_a = 0, batch_b = 0;
 };
 
 // Epilogue functor interface:  void operator()(int split, int row, int col, double acc) const;
@@ -103,8 +108,10 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(con
     bm = blockIdx.x % g.tiles_m;
   }
   const int m0 = bm * BM, n0 = bn * BN;
-  int k_begin = blockIdx.z * g.k_split;
-  int k_end = k_begin + g.k_split < g.K ? k_begin + g.k_split : g.K;
+  int k_begin = g.batch ? 0 : blockIdx.z * g.k_split;
+  int k_end = (g.batch || k_begin + g.k_split >= g.K) ? g.K : k_begin + g.k_split;
+  const double* __restrict__ gA = g.A + (g.batch ? (int64_t)blockIdx.z * g.batch_a : 0);
+  const double* __restrict__ gB = g.B + (g.batch ? (int64_t)blockIdx.z * g.batch_b : 0);
   if (g.tri_mode == 1) {
     const int kmax = n0 + BN;     // B[k][j] == 0 for k > j
     if (k_end > kmax) k_end = kmax;
@@ -134,7 +141,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(con
       const int kc = k < k_end ? k : k_end - 1;
       const int n = n0 + c;
       const int nc = n < g.N ? n : 0;
-      rb[i] = *reinterpret_cast<const d2v*>(g.B + (int64_t)kc * g.ldb + nc);
+      rb[i] = *reinterpret_cast<const d2v*>(gB + (int64_t)kc * g.ldb + nc);
       keep |= (unsigned)(k < k_end && n < g.N) << (2 * i);
       keep |= (unsigned)(k < k_end && n + 1 < g.N) << (2 * i + 1);
     }
@@ -147,7 +154,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(con
         const int kc = k < k_end ? k : k_end - 1;
         const int m = m0 + c;
         const int mc = m < g.M ? m : 0;
-        ra[i] = *reinterpret_cast<const d2v*>(g.A + (int64_t)kc * g.lda + mc);
+        ra[i] = *reinterpret_cast<const d2v*>(gA + (int64_t)kc * g.lda + mc);
         keep |= (unsigned)(k < k_end && m < g.M) << (2 * (NBL + i));
         keep |= (unsigned)(k < k_end && m + 1 < g.M) << (2 * (NBL + i) + 1);
       } else {
@@ -158,7 +165,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(con
         const int m = m0 + row, ka = k0 + 2 * kp;
         const int mc = m < g.M ? m : 0;
         const int kac = ka < k_end ? ka : 0;
-        ra[i] = *reinterpret_cast<const d2v*>(g.A + (int64_t)mc * g.lda + kac);
+        ra[i] = *reinterpret_cast<const d2v*>(gA + (int64_t)mc * g.lda + kac);
         keep |= (unsigned)(m < g.M && ka < k_end) << (2 * (NBL + i));
         keep |= (unsigned)(m < g.M && ka + 1 < k_end) << (2 * (NBL + i) + 1);
       }
@@ -330,7 +337,7 @@ template <bool A_KCONTIG, class Epi>
 inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi, int cfg = 0,
                             int flags = 0) {   // flags bit 0: force the register-staged kernel
   if (splits < 1) splits = 1;
-  int ks = gemm_tiles(g.K, splits);
+  int ks = g.batch ? g.K : gemm_tiles(g.K, splits);   // batch mode: `splits` is the number of products
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
   static const int cfg_env = getenv("VB_GEMM_CFG") ? atoi(getenv("VB_GEMM_CFG")) : 0;   // experiments: force a tile
   if (cfg == 0 && cfg_env >= 1 && cfg_env <= 3) cfg = cfg_env;

@@ -61,8 +61,10 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
     bm = blockIdx.x % g.tiles_m;
   }
   const int m0 = bm * BM, n0 = bn * BN;
-  const int k_begin = blockIdx.z * g.k_split;
-  int k_end = k_begin + g.k_split < g.K ? k_begin + g.k_split : g.K;
+  const int k_begin = g.batch ? 0 : blockIdx.z * g.k_split;
+  int k_end = (g.batch || k_begin + g.k_split >= g.K) ? g.K : k_begin + g.k_split;
+  const double* __restrict__ gA = g.A + (g.batch ? (int64_t)blockIdx.z * g.batch_a : 0);
+  const double* __restrict__ gB = g.B + (g.batch ? (int64_t)blockIdx.z * g.batch_b : 0);
   if (g.tri_mode == 1) {
     const int kmax = n0 + BN;
     if (k_end > kmax) k_end = kmax;
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
         const int kp = p ^ ((row >> 1) & 7);
         int m = m0 + row;
         m = m < g.M ? m : g.M - 1;
-        src[u] = g.A + (int64_t)m * g.lda + k_begin + 2 * kp;
+        src[u] = gA + (int64_t)m * g.lda + k_begin + 2 * kp;
         step[u] = kGemmBK;
       } else {               // k-major: (BM / 2) pairs per k row
         constexpr int PPR = BM / 2, RPU = 64 / PPR > 0 ? 64 / PPR : 1;     // pairs per row, rows per unit
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
         const int c = p ^ (8 * (krow & 1));
         int64_t col = m0 + 2 * c;
         col = col < g.lda - 1 ? col : g.lda - 2;
-        src[u] = g.A + (int64_t)(k_begin + krow) * g.lda + col;
+        src[u] = gA + (int64_t)(k_begin + krow) * g.lda + col;
         step[u] = (int64_t)kGemmBK * g.lda;
       }
       lds_off[u] = q * 128;
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
       const int c = p ^ (8 * (krow & 1));
       int64_t col = n0 + 2 * c;
       col = col < g.ldb - 1 ? col : g.ldb - 2;
-      src[u] = g.B + (int64_t)(k_begin + krow) * g.ldb + col;
+      src[u] = gB + (int64_t)(k_begin + krow) * g.ldb + col;
       step[u] = (int64_t)kGemmBK * g.ldb;
       lds_off[u] = kStages * kATile + qb * 128;
     }
