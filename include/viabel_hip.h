@@ -54,6 +54,12 @@ typedef struct vb_ctx vb_ctx;
                                   dparams=[X(n_data x D)|y(n_data)|prior_sd], iparams=[n_data]             */
 
 /* noise kinds for vb_noise_generate */
+/* likelihoods of the regression target VB_MODEL_LOGISTIC (iparams = [n_data, link]; default Bernoulli-logit):
+ * eta = x_i' b, prior b ~ N(0, prior_sd).  Gaussian: dparams carries noise_sd after prior_sd. */
+#define VB_GLM_BERNOULLI_LOGIT 0   /* y_i ~ Bernoulli(sigmoid(eta_i)) */
+#define VB_GLM_POISSON 1           /* y_i ~ Poisson(exp(eta_i)) */
+#define VB_GLM_GAUSSIAN 2          /* y_i ~ N(eta_i, noise_sd) */
+
 #define VB_NOISE_NORMAL 0
 #define VB_NOISE_STUDENT_T 1
 

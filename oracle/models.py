@@ -159,3 +159,38 @@ class Logistic:
 
     def hvp(self, m, v):
         return _as2d(v) @ self.hessian(m).T
+
+
+class Poisson(Logistic):
+    """Poisson regression with log link, ``N(0, prior_sd)`` prior (test oracle for ``PoissonRegressionModel``)."""
+
+    def logp(self, b):
+        from scipy.special import gammaln
+        b = _as2d(b)
+        eta = b @ self.X.T
+        ll = np.sum(self.y * eta - np.exp(eta), axis=1) - np.sum(gammaln(self.y + 1.0))
+        pr = np.sum(-0.5 * (b / self.prior_sd) ** 2 - np.log(self.prior_sd) - 0.5 * LOG_2PI, axis=1)
+        return ll + pr
+
+    def grad(self, b):
+        b = _as2d(b)
+        return (self.y - np.exp(b @ self.X.T)) @ self.X - b / self.prior_sd ** 2
+
+
+class LinearRegression(Logistic):
+    """Linear regression with known noise scale (test oracle for ``LinearRegressionModel``)."""
+
+    def __init__(self, X, y, prior_sd=10.0, noise_sd=1.0):
+        super().__init__(X, y, prior_sd)
+        self.noise_sd = float(noise_sd)
+
+    def logp(self, b):
+        b = _as2d(b)
+        r = (self.y - b @ self.X.T) / self.noise_sd
+        ll = np.sum(-0.5 * r ** 2, axis=1) - self.y.size * (np.log(self.noise_sd) + 0.5 * LOG_2PI)
+        pr = np.sum(-0.5 * (b / self.prior_sd) ** 2 - np.log(self.prior_sd) - 0.5 * LOG_2PI, axis=1)
+        return ll + pr
+
+    def grad(self, b):
+        b = _as2d(b)
+        return ((self.y - b @ self.X.T) / self.noise_sd ** 2) @ self.X - b / self.prior_sd ** 2

@@ -210,3 +210,36 @@ def test_logistic_regression_target(vb, D, n_data, N):
             assert G.rel_err(grad, og) < 1e-11, (pd, G.rel_err(grad, og))
     with pytest.raises(NotImplementedError):
         vb.ExclusiveKL(vb.MFGaussian(D), model, N, hessian_approx_method='full')(theta)
+
+
+@pytest.mark.parametrize('kind', ['poisson', 'linear'])
+@pytest.mark.parametrize('D,n_data,N', [(7, 33, 50), (60, 250, 400)])
+def test_glm_regression_targets(vb, kind, D, n_data, N):
+    """Poisson (log link) and Gaussian (identity link) members of the regression target: same two-GEMM pipeline as
+    the logistic model, different likelihood in the GEMM epilogue; value, gradient and Model.__call__ against the
+    numpy oracle."""
+    rng = np.random.RandomState(3 * D + len(kind))
+    X = rng.randn(n_data, D) / np.sqrt(D)
+    beta = 0.5 * rng.randn(D)
+    if kind == 'poisson':
+        y = rng.poisson(np.exp(X @ beta)).astype(float)
+        model, omodel = vb.PoissonRegressionModel(X, y, 5.0), omod.Poisson(X, y, 5.0)
+    else:
+        y = X @ beta + 0.7 * rng.randn(n_data)
+        model, omodel = vb.LinearRegressionModel(X, y, 5.0, noise_sd=0.7), omod.LinearRegression(X, y, 5.0, 0.7)
+    theta = np.concatenate([0.3 * rng.randn(D), -1.5 + 0.2 * rng.randn(D)])
+    for pd in (False, True):
+        approx, ofamily = vb.MFGaussian(D, seed=2), ofam.MFGaussian(D)
+        value, grad = vb.ExclusiveKL(approx, model, N, use_path_deriv=pd)(theta)
+        noise = ofamily.draw_noise(np.random.RandomState(2), N)
+        ov, og = oobj.exclusive_kl(ofamily, omodel, theta, noise, pd)
+        assert G.rel_err(value, ov) < 1e-12, (pd, value, ov)
+        assert G.rel_err(grad, og) < 1e-11, (pd, G.rel_err(grad, og))
+    x = 0.3 * rng.randn(123, D)
+    fo = omodel.logp(x)
+    np.testing.assert_allclose(model(x), fo, rtol=0, atol=1e-12 * np.max(np.abs(fo)))
+    with pytest.raises(ValueError):
+        vb.LinearRegressionModel(X, y, 5.0, noise_sd=0.0)
+    if kind == 'poisson':
+        with pytest.raises(ValueError):
+            vb.PoissonRegressionModel(X, -np.ones(n_data))

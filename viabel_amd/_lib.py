@@ -20,6 +20,7 @@ VB_OK, VB_ERR_INVALID, VB_ERR_HIP, VB_ERR_UNSUPPORTED, VB_ERR_STATE, VB_ERR_NUME
 FAMILY_MF_GAUSSIAN, FAMILY_MF_STUDENT_T, FAMILY_FULLRANK_GAUSSIAN, FAMILY_MULTIVARIATE_T, FAMILY_LOWRANK_GAUSSIAN = \
     range(5)
 MODEL_GAUSS_DIAG, MODEL_FUNNEL, MODEL_GAUSS_FULL, MODEL_LOGISTIC = range(4)
+GLM_BERNOULLI_LOGIT, GLM_POISSON, GLM_GAUSSIAN = range(3)
 NOISE_NORMAL, NOISE_STUDENT_T = range(2)
 FLAG_PATH_DERIV = 1
 CV_MODES = {None: 0, 'full': 1, 'mean_only': 2, 'loo_diag_approx': 3, 'loo_direct_approx': 4}

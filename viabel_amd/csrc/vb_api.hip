@@ -339,9 +339,14 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams, 
     for (int64_t i = 0; i < dim; ++i)
       for (int64_t j = 0; j < dim; ++j) dev[(size_t)m.ldp * (i + 1) + j] = dparams[dim + i * dim + j];
   } else if (model_id == VB_MODEL_LOGISTIC) {
-    if (n_iparams != 1 || !iparams || iparams[0] <= 0 || !dparams ||
-        n_dparams != (size_t)(iparams[0] * dim + iparams[0] + 1))
-      return fail(ctx, VB_ERR_INVALID, "logistic expects dparams = [X(n_data x D) | y(n_data) | prior_sd], iparams = [n_data]");
+    const int link = (n_iparams == 2 && iparams) ? (int)iparams[1] : VB_GLM_BERNOULLI_LOGIT;
+    const size_t extra = link == VB_GLM_GAUSSIAN ? 2 : 1;
+    if ((n_iparams != 1 && n_iparams != 2) || !iparams || iparams[0] <= 0 || !dparams ||
+        link < VB_GLM_BERNOULLI_LOGIT || link > VB_GLM_GAUSSIAN ||
+        n_dparams != (size_t)(iparams[0] * dim + iparams[0]) + extra)
+      return fail(ctx, VB_ERR_INVALID,
+                  "regression target expects dparams = [X(n_data x D) | y(n_data) | prior_sd (| noise_sd)], "
+                  "iparams = [n_data (, link)]");
     const int64_t nd = iparams[0];
     const double sd = dparams[nd * dim + nd];
     if (!(sd > 0.0)) return fail(ctx, VB_ERR_INVALID, "logistic prior_sd must be positive");
@@ -349,7 +354,19 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams, 
     m.ldp = round_up(dim, 16);
     m.ldq = round_up(nd, 16);
     m.tau = sd;
+    m.link = link;
     m.c0 = -(double)dim * (log(sd) + 0.5 * kLog2Pi);
+    if (link == VB_GLM_POISSON) {           // - sum_i log(y_i !)
+      for (int64_t i = 0; i < nd; ++i) {
+        const double yi = dparams[nd * dim + i];
+        if (!(yi >= 0.0)) return fail(ctx, VB_ERR_INVALID, "Poisson counts must be non-negative");
+        m.c0 -= lgamma(yi + 1.0);
+      }
+    } else if (link == VB_GLM_GAUSSIAN) {
+      m.aux = dparams[nd * dim + nd + 1];
+      if (!(m.aux > 0.0)) return fail(ctx, VB_ERR_INVALID, "noise_sd must be positive");
+      m.c0 -= (double)nd * (log(m.aux) + 0.5 * kLog2Pi);
+    }
     // [X (nd x ldp) | X' (dim x ldq) | y (ldq)], rows padded for the GEMM operand loads
     dev.assign((size_t)nd * m.ldp + (size_t)dim * m.ldq + (size_t)m.ldq, 0.0);
     for (int64_t i = 0; i < nd; ++i)

@@ -44,7 +44,27 @@ struct ModelDev {
   const double* p2 = nullptr;   // logistic: y [n_data]   (p0 = X [n_data x ldp], p1 = X' [D x ldq])
   int64_t ldq = 0;              // logistic: row stride of X'
   int64_t n_data = 0;           // logistic: observations
+  int link = 0;                 // regression target: VB_GLM_* likelihood
+  double aux = 1.0;             // VB_GLM_GAUSSIAN: observation noise stdev
 };
+
+// per-observation log-likelihood term (without constants) and its derivative with respect to eta = x' b
+__device__ __forceinline__ double glm_term(int link, double aux, double y, double eta, double* dl) {
+  if (link == VB_GLM_POISSON) {           // y eta - exp(eta)
+    const double mu = exp(eta);
+    *dl = y - mu;
+    return y * eta - mu;
+  }
+  if (link == VB_GLM_GAUSSIAN) {          // -(y - eta)^2 / (2 s^2)
+    const double r = (y - eta) / (aux * aux);
+    *dl = r;
+    return -0.5 * r * (y - eta);
+  }
+  const double t = exp(-fabs(eta));       // Bernoulli-logit: y eta - log(1 + exp(eta)), overflow-safe
+  const double p = eta >= 0.0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
+  *dl = y - p;
+  return y * eta - (fmax(eta, 0.0) + log1p(t));
+}
 
 struct DeviceBuffer {
   void* ptr = nullptr;

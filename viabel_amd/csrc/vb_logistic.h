@@ -37,17 +37,18 @@ __global__ void __launch_bounds__(256) lg_sample_kernel(const double* __restrict
   Z[row * ldz + col] = fma(sg, noise[row * ld + col], mu);
 }
 
-struct EpiLogit {           // R = y - sigmoid(eta); returns the log-likelihood term y eta - softplus(eta)
+struct EpiLogit {           // R = d loglik / d eta (logit link: y - sigmoid(eta)); returns the log-likelihood term
   double* R;
   int64_t ldr;
   const double* y;
   double* part;
+  int link;
+  double aux;
   __device__ double operator()(int, int row, int col, double eta) const {
-    const double yv = y[col];
-    const double t = exp(-fabs(eta));
-    const double p = eta >= 0.0 ? 1.0 / (1.0 + t) : t / (1.0 + t);
-    R[(int64_t)row * ldr + col] = yv - p;
-    return yv * eta - (fmax(eta, 0.0) + log1p(t));
+    double dl;
+    const double ll = glm_term(link, aux, y[col], eta, &dl);
+    R[(int64_t)row * ldr + col] = dl;
+    return ll;
   }
 };
 

@@ -794,7 +794,7 @@ static int logistic_accumulate(vb_ctx* ctx, hipStream_t st, const ModelDev& m, c
   gh.N = (int)nd;
   gh.K = (int)d;
   gh.tri_mode = 0;
-  gemm_f64_launch<true>(st, gh, 1, n_cu, EpiLogit{Rm, ldr, m.p2, part});
+  gemm_f64_launch<true>(st, gh, 1, n_cu, EpiLogit{Rm, ldr, m.p2, part, m.link, m.aux});
   VB_HIP(ctx, hipGetLastError());
   GemmArgs gg;                       // G = R X - Z / sd^2   [n x d x n_data]
   gg.A = Rm;

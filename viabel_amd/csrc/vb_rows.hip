@@ -50,13 +50,15 @@ struct EpiStoreRows {        // Y = acc
   __device__ void operator()(int, int row, int col, double acc) const { Y[(int64_t)row * ldy + col] = acc; }
 };
 
-struct EpiLogLikTerm {       // T = y eta - log(1 + exp(eta)), eta = acc
+struct EpiLogLikTerm {       // T = log-likelihood term of observation `col` at eta = acc
   double* T;
   int64_t ldt;
   const double* y;
+  int link;
+  double aux;
   __device__ void operator()(int, int row, int col, double eta) const {
-    const double t = exp(-fabs(eta));
-    T[(int64_t)row * ldt + col] = y[col] * eta - (fmax(eta, 0.0) + log1p(t));
+    double dl;
+    T[(int64_t)row * ldt + col] = glm_term(link, aux, y[col], eta, &dl);
   }
 };
 
@@ -122,7 +124,7 @@ static int logistic_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n
     GemmArgs g;
     g.A = x_dev + r0 * ld, g.lda = ld, g.B = m.p1, g.ldb = m.ldq;
     g.M = (int)rows, g.N = (int)m.n_data, g.K = (int)d, g.tri_mode = 0;
-    gemm_f64_launch<true>(st, g, 1, ctx->prop.multiProcessorCount, EpiLogLikTerm{T, ldt, m.p2});
+    gemm_f64_launch<true>(st, g, 1, ctx->prop.multiProcessorCount, EpiLogLikTerm{T, ldt, m.p2, m.link, m.aux});
     VB_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const double*)T, ldt,
                        (const double*)nullptr, (int64_t)0, (int)m.n_data, 1.0, x_dev + r0 * ld, ld, (int)d,

@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 
 __all__ = ['Model', 'DeviceModel', 'GaussianModel', 'FunnelModel', 'CorrelatedGaussianModel',
-           'LogisticRegressionModel']
+           'LogisticRegressionModel', 'PoissonRegressionModel', 'LinearRegressionModel']
 
 
 class Model(object):
@@ -162,3 +162,33 @@ class LogisticRegressionModel(DeviceModel):
     def _build_spec(self):
         return (_lib.MODEL_LOGISTIC, self._dim, np.concatenate([self.X.ravel(), self.y, [self.prior_sd]]),
                 np.array([self.X.shape[0]], dtype=np.int64))
+
+
+class PoissonRegressionModel(LogisticRegressionModel):
+    """Bayesian Poisson regression ``y_i ~ Poisson(exp(x_i' b))`` with a ``N(0, prior_sd)`` prior: the same two-GEMM
+    pipeline as the logistic target with the log link in the GEMM epilogue (not in the reference)."""
+
+    def __init__(self, X, y, prior_sd=10.0):
+        super().__init__(X, y, prior_sd)
+        if np.any(self.y < 0):
+            raise ValueError('counts must be non-negative')
+
+    def _build_spec(self):
+        return (_lib.MODEL_LOGISTIC, self._dim, np.concatenate([self.X.ravel(), self.y, [self.prior_sd]]),
+                np.array([self.X.shape[0], _lib.GLM_POISSON], dtype=np.int64))
+
+
+class LinearRegressionModel(LogisticRegressionModel):
+    """Bayesian linear regression ``y_i ~ N(x_i' b, noise_sd)`` with a ``N(0, prior_sd)`` prior (known noise scale);
+    the identity-link member of the same pipeline (not in the reference)."""
+
+    def __init__(self, X, y, prior_sd=10.0, noise_sd=1.0):
+        super().__init__(X, y, prior_sd)
+        if noise_sd <= 0:
+            raise ValueError('noise_sd must be positive')
+        self.noise_sd = float(noise_sd)
+
+    def _build_spec(self):
+        return (_lib.MODEL_LOGISTIC, self._dim,
+                np.concatenate([self.X.ravel(), self.y, [self.prior_sd, self.noise_sd]]),
+                np.array([self.X.shape[0], _lib.GLM_GAUSSIAN], dtype=np.int64))
