@@ -123,3 +123,30 @@ def test_fullrank_family_api(vb):
     ofr = ofam.FullRankGaussian(D)
     np.testing.assert_allclose(fr.log_density(th, x), ofr.log_density(th, x), rtol=1e-13)
     np.testing.assert_allclose(fr.entropy(th), ofr.entropy(th), rtol=1e-14)
+
+
+@pytest.mark.parametrize('kind', ['logistic', 'poisson', 'linear'])
+@pytest.mark.parametrize('D,n_data,N', [(6, 40, 64), (48, 300, 500), (130, 257, 333)])
+def test_fullrank_regression_targets(vb, kind, D, n_data, N):
+    """Dense Gaussian family on the regression targets: the sampling GEMM feeds the eta / gradient GEMMs of the
+    GLM likelihood; entropy form and path derivative against the oracle."""
+    rng = np.random.RandomState(5 * D + len(kind))
+    X = rng.randn(n_data, D) / np.sqrt(D)
+    beta = 0.5 * rng.randn(D)
+    if kind == 'logistic':
+        y = (rng.rand(n_data) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+        model, omodel = vb.LogisticRegressionModel(X, y, 4.0), omod.Logistic(X, y, 4.0)
+    elif kind == 'poisson':
+        y = rng.poisson(np.exp(X @ beta)).astype(float)
+        model, omodel = vb.PoissonRegressionModel(X, y, 4.0), omod.Poisson(X, y, 4.0)
+    else:
+        y = X @ beta + 0.5 * rng.randn(n_data)
+        model, omodel = vb.LinearRegressionModel(X, y, 4.0, noise_sd=0.5), omod.LinearRegression(X, y, 4.0, 0.5)
+    ofr = ofam.FullRankGaussian(D)
+    theta = _theta(ofr, D, rng)
+    noise = np.random.RandomState(4).randn(N, D)
+    for pd in (False, True):
+        value, grad = vb.ExclusiveKL(vb.FullRankGaussian(D, seed=4), model, N, use_path_deriv=pd)(theta)
+        ov, og = oobj.exclusive_kl(ofr, omodel, theta, noise, use_path_deriv=pd)
+        assert G.rel_err(value, ov) < 1e-12, (kind, pd, value, ov)
+        assert G.rel_err(grad, og) < 1e-11, (kind, pd, G.rel_err(grad, og))

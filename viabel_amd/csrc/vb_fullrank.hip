@@ -74,6 +74,34 @@ struct EpiStoreZ {          // Z = acc [* rs_n] + mu - shift   (shift = 0, or th
   }
 };
 
+// regression targets (VB_MODEL_LOGISTIC with a VB_GLM_* likelihood): eta = Z X' -> R = dloglik / deta and the
+// log-likelihood sum, then G = R X - Z / prior_sd^2 (the two GEMMs of vb_logistic.h behind the sampling GEMM)
+struct EpiGlm {
+  double* R;
+  int64_t ldr;
+  const double* y;
+  double* part;
+  int link;
+  double aux;
+  __device__ double operator()(int, int row, int col, double eta) const {
+    double dl;
+    const double ll = glm_term(link, aux, y[col], eta, &dl);
+    R[(int64_t)row * ldr + col] = dl;
+    return ll;
+  }
+};
+
+struct EpiGlmGrad {         // G = acc - z / sd^2
+  double* G;
+  int64_t ldz;
+  const double* Z;
+  double ivp;
+  __device__ void operator()(int, int row, int col, double acc) const {
+    const int64_t i = (int64_t)row * ldz + col;
+    G[i] = fma(-ivp, Z[i], acc);
+  }
+};
+
 struct EpiGaussDiag {       // G = -(z - m) / sd^2  straight from the GEMM-1 accumulators
   double* G;
   int64_t ldz;
@@ -141,14 +169,15 @@ __global__ void __launch_bounds__(256) fr_funnel_kernel(const double* __restrict
 // the column pair 2c, 2c + 1 (16-B loads, 8 rows in flight); the 4 row groups are combined through LDS in
 // fixed order.  Rows are padded to 16 doubles and pad columns of G / Zc are never written with non-finite
 // values by the producers, but they are masked anyway.
-// fmode 0: no f here, 1: gauss_diag f = -1/2 g^2 / ivar, 2: gauss_full f = 1/2 zc g
+// fmode 0: no f here, 1: gauss_diag f = -1/2 g^2 / ivar, 2: gauss_full f = 1/2 zc g,
+// 3: regression prior f = -1/2 scal zc^2 (the likelihood part comes from the GEMM epilogue)
 typedef double fr_d2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict__ G,
                                                         const double* __restrict__ Zc, int64_t ldz,
                                                         int64_t n, int d, int fmode,
                                                         const double* __restrict__ ivar,
                                                         double* __restrict__ colpart,
-                                                        double* __restrict__ fpart) {
+                                                        double* __restrict__ fpart, double scal = 0.0) {
   __shared__ double sh[4];
   __shared__ fr_d2 cs[4][64];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -170,7 +199,7 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
         z[i] = (fr_d2){0.0, 0.0};
         if (r < r1) {
           g[i] = *reinterpret_cast<const fr_d2*>(G + r * ldz + col);
-          if (fmode == 2) z[i] = *reinterpret_cast<const fr_d2*>(Zc + r * ldz + col);
+          if (fmode >= 2) z[i] = *reinterpret_cast<const fr_d2*>(Zc + r * ldz + col);
           if (!ok1) g[i].y = 0.0, z[i].y = 0.0;
         }
       }
@@ -179,6 +208,7 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
         s += g[i];
         if (fmode == 1) f = fma(hiv.x * g[i].x, g[i].x, fma(hiv.y * g[i].y, g[i].y, f));
         if (fmode == 2) f = fma(0.5 * z[i].x, g[i].x, fma(0.5 * z[i].y, g[i].y, f));
+        if (fmode == 3) f = fma(-0.5 * scal * z[i].x, z[i].x, fma(-0.5 * scal * z[i].y, z[i].y, f));
       }
     }
   }
@@ -529,7 +559,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   const bool mvt = theta_dev == nullptr;
   const bool pd = (flags & VB_FLAG_PATH_DERIV) != 0;
   if (pd && mvt) return fail(ctx, VB_ERR_UNSUPPORTED, "path derivative: dense Gaussian family only");
-  if (m.id != VB_MODEL_GAUSS_DIAG && m.id != VB_MODEL_FUNNEL && m.id != VB_MODEL_GAUSS_FULL)
+  const bool glm = m.id == VB_MODEL_LOGISTIC;
+  if (m.id != VB_MODEL_GAUSS_DIAG && m.id != VB_MODEL_FUNNEL && m.id != VB_MODEL_GAUSS_FULL && !glm)
     return fail(ctx, VB_ERR_UNSUPPORTED, "full-rank path: unsupported model id %d", m.id);
   if (m.dim != d)
     return fail(ctx, VB_ERR_INVALID, "model dimension %d != family dimension %lld", m.dim, (long long)d);
@@ -548,7 +579,10 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   if (splits < 1) splits = 1;
   const int n_rb = (int)((n + 127) / 128);
   const int cs_gx = (D + 127) / 128;
-  const int n_fpart = m.id == VB_MODEL_FUNNEL ? (int)((n + 3) / 4) : n_rb * cs_gx;
+  // regression targets: the log-likelihood partials of the eta GEMM follow the column-sum kernel's f partials
+  const int64_t glm_part = glm ? gemm_max_blocks(n, m.n_data) : 0;
+  const int64_t ldr = glm ? round_up(m.n_data, 16) : 0;
+  const int n_fpart = m.id == VB_MODEL_FUNNEL ? (int)((n + 3) / 4) : n_rb * cs_gx + (int)glm_part;
   const int64_t slab = d * ldl;
 
   // device buffers (one allocation, carved)
@@ -560,7 +594,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   };
   const int64_t o_mu = carve(ldz), o_lt = carve(slab), o_z = carve(n * ldz), o_g = carve(n * ldz),
                 o_cpart = carve((int64_t)(splits + 1) * slab), o_col = carve((int64_t)(n_rb + 1) * ldz),
-                o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx);
+                o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx), o_r = carve(glm ? n * ldr : 0);
   // path derivative: (L')^-1 (Xa), a product buffer T, the noise Gram matrix [16 | e (ld_e) | M2 (d x ldl)], partial
   // column sums of the noise (row stride = the noise matrix's)
   const int64_t ld_e = ns.ld;
@@ -707,6 +741,34 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     VB_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(fr_funnel_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)Z,
                        G, ldz, n, D, m, fpart);
+  } else if (glm) {
+    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, nullptr, row_scale});
+    VB_HIP(ctx, hipGetLastError());
+    double* Rm = base + o_r;
+    double* part = fpart + (int64_t)n_rb * cs_gx;
+    VB_HIP(ctx, hipMemsetAsync(part, 0, (size_t)glm_part * sizeof(double), st));
+    GemmArgs gh;                                   // eta = Z X'   [n x n_data x d]
+    gh.A = Z;
+    gh.lda = ldz;
+    gh.B = m.p1;
+    gh.ldb = m.ldq;
+    gh.M = (int)n;
+    gh.N = (int)m.n_data;
+    gh.K = D;
+    gh.tri_mode = 0;
+    gemm_f64_launch<true>(st, gh, 1, n_cu, EpiGlm{Rm, ldr, m.p2, part, m.link, m.aux});
+    VB_HIP(ctx, hipGetLastError());
+    GemmArgs gg;                                   // G = R X - Z / sd^2   [n x d x n_data]
+    gg.A = Rm;
+    gg.lda = ldr;
+    gg.B = m.p0;
+    gg.ldb = m.ldp;
+    gg.M = (int)n;
+    gg.N = D;
+    gg.K = (int)m.n_data;
+    gg.tri_mode = 0;
+    gemm_f64_launch<true>(st, gg, 1, n_cu, EpiGlmGrad{G, ldz, Z, 1.0 / (m.tau * m.tau)});
+    fmode = 3;
   } else {
     gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0, row_scale});   // Z - m
     VB_HIP(ctx, hipGetLastError());
@@ -726,7 +788,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
 
   hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
                      (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
-                     m.id == VB_MODEL_FUNNEL ? fpart + n_fpart /*unused tail*/ : fpart);
+                     m.id == VB_MODEL_FUNNEL ? fpart + n_fpart /*unused tail*/ : fpart,
+                     glm ? 1.0 / (m.tau * m.tau) : 0.0);
   VB_HIP(ctx, hipGetLastError());
 
   if (row_scale) {
