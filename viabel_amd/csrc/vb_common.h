@@ -123,6 +123,7 @@ struct vb_ctx {
   vb::DeviceBuffer rowvec;              // per-row weights
   vb::DeviceBuffer fr_work;             // full-rank pipeline work buffers
   vb::DeviceBuffer lg_work;             // logistic-regression target: Z, R, G, partials
+  vb::DeviceBuffer glm_work;            // regression targets: split-K slabs of the gradient GEMM
   vb::DeviceBuffer mvt_state;           // multivariate-t DIS: state samples X, scratch
   int64_t mvt_n = 0, mvt_d = 0, mvt_n_total = 0;
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
@@ -291,6 +292,11 @@ int fit_step_enqueue(vb_ctx* ctx, const FitStep& step);
 // Philox noise generation (vb_rng.hip)
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,
              uint64_t stream, int64_t row_offset, int64_t n, int64_t d);
+
+// regression targets: G = R X - Z / prior_sd^2 (n x d, contraction over the n_data observations), split over the
+// observations when the output alone cannot fill the chip (vb_rows.hip)
+int glm_grad_enqueue(vb_ctx* ctx, hipStream_t st, const ModelDev& m, const double* R, int64_t ldr, const double* Z,
+                     double* G, int64_t ldz, int64_t n, int d);
 
 // model log density for explicit x (vb_rows.hip)
 int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev);

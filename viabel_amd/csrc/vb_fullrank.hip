@@ -758,16 +758,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     gh.tri_mode = 0;
     gemm_f64_launch<true>(st, gh, 1, n_cu, EpiGlm{Rm, ldr, m.p2, part, m.link, m.aux});
     VB_HIP(ctx, hipGetLastError());
-    GemmArgs gg;                                   // G = R X - Z / sd^2   [n x d x n_data]
-    gg.A = Rm;
-    gg.lda = ldr;
-    gg.B = m.p0;
-    gg.ldb = m.ldp;
-    gg.M = (int)n;
-    gg.N = D;
-    gg.K = (int)m.n_data;
-    gg.tri_mode = 0;
-    gemm_f64_launch<true>(st, gg, 1, n_cu, EpiGlmGrad{G, ldz, Z, 1.0 / (m.tau * m.tau)});
+    VB_TRY(glm_grad_enqueue(ctx, st, m, Rm, ldr, Z, G, ldz, n, D));   // G = R X - Z / sd^2
     fmode = 3;
   } else {
     gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0, row_scale});   // Z - m

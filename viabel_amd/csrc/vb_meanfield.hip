@@ -796,18 +796,8 @@ static int logistic_accumulate(vb_ctx* ctx, hipStream_t st, const ModelDev& m, c
   gh.tri_mode = 0;
   gemm_f64_launch<true>(st, gh, 1, n_cu, EpiLogit{Rm, ldr, m.p2, part, m.link, m.aux});
   VB_HIP(ctx, hipGetLastError());
-  GemmArgs gg;                       // G = R X - Z / sd^2   [n x d x n_data]
-  gg.A = Rm;
-  gg.lda = ldr;
-  gg.B = m.p0;
-  gg.ldb = m.ldp;
-  gg.M = (int)n;
-  gg.N = (int)d;
-  gg.K = (int)nd;
-  gg.tri_mode = 0;
   const double ivp = 1.0 / (m.tau * m.tau);
-  gemm_f64_launch<true>(st, gg, 1, n_cu, EpiLogitGrad{G, ldz, Z, ivp});
-  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(glm_grad_enqueue(ctx, st, m, Rm, ldr, Z, G, ldz, n, (int)d));   // G = R X - Z / sd^2
   hipLaunchKernelGGL(lg_scalars_kernel, dim3(1), dim3(256), 0, st, (const double*)part, (int)max_blocks, fsum,
                      wsb + ws.off_prepscal, (double)n);
   VB_HIP(ctx, hipGetLastError());

@@ -50,6 +50,37 @@ struct EpiStoreRows {        // Y = acc
   __device__ void operator()(int, int row, int col, double acc) const { Y[(int64_t)row * ldy + col] = acc; }
 };
 
+struct EpiGlmGradDirect {   // G = acc - z / sd^2
+  double* G;
+  int64_t ldz;
+  const double* Z;
+  double ivp;
+  __device__ void operator()(int, int row, int col, double acc) const {
+    const int64_t i = (int64_t)row * ldz + col;
+    G[i] = fma(-ivp, Z[i], acc);
+  }
+};
+
+struct EpiGlmGradSlab {     // slab_split = acc
+  double* W;
+  int64_t ldz, slab;
+  __device__ void operator()(int split, int row, int col, double acc) const {
+    W[split * slab + (int64_t)row * ldz + col] = acc;
+  }
+};
+
+// G = sum of the split slabs (fixed order) - z / sd^2
+__global__ void __launch_bounds__(256) glm_grad_reduce_kernel(const double* __restrict__ W, int splits, int64_t slab,
+                                                              const double* __restrict__ Z, double ivp,
+                                                              double* __restrict__ G, int64_t ldz, int64_t n, int d) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * ldz) return;
+  if ((int)(idx % ldz) >= d) return;
+  double s = 0.0;
+  for (int k = 0; k < splits; ++k) s += W[k * slab + idx];
+  G[idx] = fma(-ivp, Z[idx], s);
+}
+
 struct EpiLogLikTerm {       // T = log-likelihood term of observation `col` at eta = acc
   double* T;
   int64_t ldt;
@@ -131,6 +162,45 @@ static int logistic_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n
                        -0.5 / (m.tau * m.tau), m.c0, rows, out_dev + r0);
     VB_HIP(ctx, hipGetLastError());
   }
+  return VB_OK;
+}
+
+int glm_grad_enqueue(vb_ctx* ctx, hipStream_t st, const ModelDev& m, const double* R, int64_t ldr, const double* Z,
+                     double* G, int64_t ldz, int64_t n, int d) {
+  const int n_cu = ctx->prop.multiProcessorCount;
+  GemmArgs gg;                       // [n x d x n_data]
+  gg.A = R;
+  gg.lda = ldr;
+  gg.B = m.p0;
+  gg.ldb = m.ldp;
+  gg.M = (int)n;
+  gg.N = d;
+  gg.K = (int)m.n_data;
+  gg.tri_mode = 0;
+  const double ivp = 1.0 / (m.tau * m.tau);
+  // few output tiles and a long contraction: split the observations so that every CU gets a workgroup or two
+  const int64_t tiles = gemm_max_blocks(n, d);
+  int splits = 1;
+  if (tiles < n_cu) {
+    splits = (int)(2 * n_cu / tiles);
+    const int max_splits = (int)(m.n_data / 128);
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+  }
+  if (splits == 1) {
+    gemm_f64_launch<true>(st, gg, 1, n_cu, EpiGlmGradDirect{G, ldz, Z, ivp});
+    VB_HIP(ctx, hipGetLastError());
+    return VB_OK;
+  }
+  const int64_t slab = n * ldz;
+  VB_TRY(ensure(ctx, ctx->glm_work, (size_t)(splits * slab) * sizeof(double)));
+  double* W = (double*)ctx->glm_work.ptr;
+  gemm_f64_launch<true>(st, gg, splits, n_cu, EpiGlmGradSlab{W, ldz, slab});
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(glm_grad_reduce_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, (const double*)W,
+                     splits, slab, Z, ivp, G, ldz, n, d);
+  VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
 
