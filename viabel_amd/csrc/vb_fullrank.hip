@@ -75,7 +75,8 @@ struct EpiStoreZ {          // Z = acc [* rs_n] + mu - shift   (shift = 0, or th
 };
 
 // regression targets (VB_MODEL_LOGISTIC with a VB_GLM_* likelihood): eta = Z X' -> R = dloglik / deta and the
-// log-likelihood sum, then G = R X - Z / prior_sd^2 (the two GEMMs of vb_logistic.h behind the sampling GEMM)
+// log-likelihood sum, then G = R X - Z / prior_sd^2 by glm_grad_enqueue (the two GEMMs of vb_logistic.h behind the
+// sampling GEMM)
 struct EpiGlm {
   double* R;
   int64_t ldr;
@@ -88,17 +89,6 @@ struct EpiGlm {
     const double ll = glm_term(link, aux, y[col], eta, &dl);
     R[(int64_t)row * ldr + col] = dl;
     return ll;
-  }
-};
-
-struct EpiGlmGrad {         // G = acc - z / sd^2
-  double* G;
-  int64_t ldz;
-  const double* Z;
-  double ivp;
-  __device__ void operator()(int, int row, int col, double acc) const {
-    const int64_t i = (int64_t)row * ldz + col;
-    G[i] = fma(-ivp, Z[i], acc);
   }
 };
 

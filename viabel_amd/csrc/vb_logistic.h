@@ -52,17 +52,6 @@ struct EpiLogit {           // R = d loglik / d eta (logit link: y - sigmoid(eta
   }
 };
 
-struct EpiLogitGrad {       // G = acc - z / sd^2
-  double* G;
-  int64_t ldz;
-  const double* Z;
-  double ivp;
-  __device__ void operator()(int, int row, int col, double acc) const {
-    const int64_t i = (int64_t)row * ldz + col;
-    G[i] = fma(-ivp, Z[i], acc);
-  }
-};
-
 // sum the GEMM's per-workgroup log-likelihood partials; also the prep-kernel scalars (W = n)
 __global__ void __launch_bounds__(256) lg_scalars_kernel(const double* __restrict__ part, int n_part,
                                                          double* __restrict__ fsum, double* __restrict__ prepscal,
