@@ -55,7 +55,7 @@ def test_exclusive_kl_golden(vb, path):
     assert G.rel_err(grad, fx['grad_fd']) < (2e-6 if str(fx['family_kind']) == 'multivariate_t' else 2e-7)
 
 
-@pytest.mark.parametrize('model_kind', ['gauss_diag', 'funnel', 'gauss_full'])
+@pytest.mark.parametrize('model_kind', ['gauss_diag', 'funnel', 'gauss_full', 'logistic'])
 @pytest.mark.parametrize('D,N,rng_kind', [(256, 2048, 'numpy'), (70, 333, 'numpy'), (129, 1000, 'philox')])
 def test_multivariate_t_exclusive_kl_matches_oracle(vb, D, N, rng_kind, model_kind):
     """MultivariateT + ExclusiveKL (sampling, model gradient and the D x D contraction on the device, chain rule
@@ -67,6 +67,10 @@ def test_multivariate_t_exclusive_kl_matches_oracle(vb, D, N, rng_kind, model_ki
         model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
     elif model_kind == 'funnel':
         model, omodel = vb.FunnelModel(D, D // 2), omod.Funnel(D, D // 2)
+    elif model_kind == 'logistic':
+        X = rng.randn(3 * D, D) / np.sqrt(D)
+        y = (rng.rand(3 * D) < 0.5).astype(float)
+        model, omodel = vb.LogisticRegressionModel(X, y, 3.0), omod.Logistic(X, y, 3.0)
     else:
         A = rng.randn(D, D)
         S = A @ A.T / D + np.eye(D)
