@@ -164,7 +164,9 @@ int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int famil
  * tempering prior and runs the ESS bisection.  grad returns, for weights w_n and the CURRENT theta / L^-1,
  *   w_sum = sum w,  w_logq = sum w log q(x_n),  d_mu[D] = sum w c_n u_n,  gram[D x D] (lower triangle) =
  *   sum w c_n u_n u_n',  u_n = Sigma^-1 (x_n - mu),  c_n = (df + D)/(df + maha_n)
- * from which the caller assembles d/dtheta.                                   */
+ * from which the caller assembles d/dtheta.
+ * df = 0 selects the Gaussian limit (c_n = 1, no chi-square scaling, Gaussian log q): the dense Gaussian family
+ * passes sqrt_sigma = L' (so that x = mu + z L') and its L^-1.                                    */
 int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,

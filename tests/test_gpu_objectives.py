@@ -113,13 +113,18 @@ def test_dis_against_oracle_multi_step(vb, family, use_resampling):
         theta = theta - 0.01 * grad / (1 + np.abs(grad))
 
 
+@pytest.mark.parametrize('family', ['multivariate_t', 'fullrank_gaussian'])
 @pytest.mark.parametrize('use_resampling', [True, False])
-def test_dis_multivariate_t_against_oracle(vb, use_resampling):
+def test_dis_multivariate_t_against_oracle(vb, use_resampling, family):
     """MultivariateT + DIS (BASELINE configs[3] family) at a size where the MFMA GEMMs tile: D=200, N=3000,
-    three calls with a moving theta and num_resampling_batches = 2."""
+    three calls with a moving theta and num_resampling_batches = 2; and the dense Gaussian, which runs through the
+    same kernels as their df -> infinity member."""
     D, N, df = 200, 3000, 40
     rng = np.random.RandomState(9)
-    approx, ofamily = vb.MultivariateT(D, df, seed=6), ofam.MultivariateT(D, df)
+    if family == 'multivariate_t':
+        approx, ofamily = vb.MultivariateT(D, df, seed=6), ofam.MultivariateT(D, df)
+    else:
+        approx, ofamily = vb.FullRankGaussian(D, seed=6), ofam.FullRankGaussian(D)
     mean, sd = 0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))
     model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
     prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) mvt_rows_kernel(const double* __restrict_
   s = mvt_wave_sum(s);
   if (lane == 0) {
     maha[row] = s;
-    lq[row] = lq_const - 0.5 * (df + d) * log1p(s / df);
+    lq[row] = df > 0.0 ? lq_const - 0.5 * (df + d) * log1p(s / df) : lq_const - 0.5 * s;   // df = 0: Gaussian limit
   }
 }
 
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) mvt_scale_kernel(const double* __restrict
   double sw = 0.0, swl = 0.0;
   if (row < n) {
     const double wn = w[row];
-    const double a = wn * (df + d) / (df + maha[row]);
+    const double a = df > 0.0 ? wn * (df + d) / (df + maha[row]) : wn;
     const double* u = U + row * ld;
     double* ua = UA + row * ld;
     for (int c = lane; c < d; c += 64) ua[c] = a * u[c];
@@ -214,7 +214,9 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
   g.tri_mode = 0;
   gemm_f64_launch<true>(ctx->stream, g, 1, n_cu, EpiSubVec{base + L.o_e, L.ld, base + L.o_c});
   VB_HIP(ctx, hipGetLastError());
-  const double lq_const = lgamma(0.5 * (df + d)) - lgamma(0.5 * df) - 0.5 * d * log(M_PI * df) - logdet_half;
+  const double lq_const = df > 0.0
+                              ? lgamma(0.5 * (df + d)) - lgamma(0.5 * df) - 0.5 * d * log(M_PI * df) - logdet_half
+                              : -0.5 * d * log(2.0 * M_PI) - logdet_half;
   hipLaunchKernelGGL(mvt_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
                      (const double*)(base + L.o_e), L.ld, n, (int)d, df, lq_const, base + L.o_maha,
                      base + L.o_lq + lq_off);
@@ -233,7 +235,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density implements gauss_diag and funnel");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
-  if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  if (!(df > 2.0) && df != 0.0) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2 (or 0: Gaussian limit)");
   const MvtLayout L = mvt_layout(ctx, n, n_total, d);
   VB_TRY(ensure(ctx, ctx->mvt_state, (size_t)L.total * sizeof(double)));
   double* base = (double*)ctx->mvt_state.ptr;
@@ -243,7 +245,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
 
   VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
   std::vector<double> inv_s((size_t)n);
-  for (int64_t i = 0; i < n; ++i) inv_s[i] = 1.0 / sqrt(chi_host[i] / df);          // approximations.py:345
+  for (int64_t i = 0; i < n; ++i)
+    inv_s[i] = df > 0.0 ? 1.0 / sqrt(chi_host[i] / df) : 1.0;                         // approximations.py:345
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_invs, inv_s.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
   std::vector<double> pr((size_t)2 * L.ld, 0.0);
   double c0p = -0.5 * (double)d * 1.8378770664093454835606594728112;

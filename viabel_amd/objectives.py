@@ -353,16 +353,16 @@ class DISInclusiveKL(StochasticVariationalObjective):
     def _update_objective_and_grad(self):
         approx = self.approx
         self._require_device_model()
-        if not isinstance(approx, (MFGaussian, MFStudentT, MultivariateT)):
-            raise NotImplementedError('DISInclusiveKL on the HIP engine supports MFGaussian, MFStudentT and '
-                                      'MultivariateT; got {}'.format(type(approx).__name__))
+        if not isinstance(approx, (MFGaussian, MFStudentT, MultivariateT, FullRankGaussian)):
+            raise NotImplementedError('DISInclusiveKL on the HIP engine supports MFGaussian, MFStudentT, MultivariateT '
+                                      'and FullRankGaussian; got {}'.format(type(approx).__name__))
         if not isinstance(self._temper_prior, MFGaussian) or self._temper_prior.dim != approx.dim:
             raise NotImplementedError('temper_prior must be an MFGaussian of the same dimension '
                                       '(tests/test_objectives.py:82-87)')
         if self._temper_prior_params.shape != (2 * approx.dim,):
             raise ValueError('temper_prior_params must have shape ({},)'.format(2 * approx.dim))
         slot = _DIS_SLOT
-        if isinstance(approx, MultivariateT):
+        if isinstance(approx, (MultivariateT, FullRankGaussian)):
             self._objective_and_grad = self._mvt_objective(approx, slot)
             return
 
@@ -404,10 +404,12 @@ class DISInclusiveKL(StochasticVariationalObjective):
 
 
     def _mvt_objective(self, approx, slot):
-        """DIS for the MultivariateT family: O(D^3) factor algebra here (as the reference does with
-        sqrtm / eigh on the host), O(N D^2) sampling / log-density / Gram work on the device."""
+        """DIS for the dense families: O(D^3) factor algebra here (as the reference does with sqrtm / eigh on the
+        host), O(N D^2) sampling / log-density / Gram work on the device.  The dense Gaussian is the df -> infinity
+        member of the same kernels (``df = 0`` in the C ABI): no chi-square scaling, z = mu + L eps."""
         from scipy import linalg as sla
-        D, df = approx.dim, approx.df
+        gaussian = isinstance(approx, FullRankGaussian)
+        D, df = approx.dim, (0.0 if gaussian else approx.df)
         tril = np.tril_indices(D)
 
         _lib.apply_host_blas_policy()      # before the first D x D host product
@@ -427,13 +429,23 @@ class DISInclusiveKL(StochasticVariationalObjective):
             n_local = end - begin
             L, Linv = factors(var_param)
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
-                if approx.rng == 'philox':                      # N chi-square draws on the host, N x D normals on the GPU
-                    chi = approx._rs.chisquare(df, N)
-                    eng.noise_generate(slot, n_local, D, approx._seed, approx._next_philox_stream(), row_offset=begin)
+                if gaussian:
+                    chi = np.ones(N)
+                    if approx.rng == 'philox':
+                        eng.noise_generate(slot, n_local, D, approx._seed, approx._next_philox_stream(),
+                                           row_offset=begin)
+                    else:
+                        eng.noise_set_host(slot, approx._base_noise(N)[begin:end])
+                    root = np.ascontiguousarray(L.T)            # x = mu + eps L'
                 else:
-                    chi, z = approx._base_noise(N)             # chi-square draws first (approximations.py:345-347)
-                    eng.noise_set_host(slot, z[begin:end])
-                root, _ = _device_root(eng, L @ L.T)            # symmetric square root, :348
+                    if approx.rng == 'philox':                  # N chi-square draws on the host, N x D normals on the GPU
+                        chi = approx._rs.chisquare(df, N)
+                        eng.noise_generate(slot, n_local, D, approx._seed, approx._next_philox_stream(),
+                                           row_offset=begin)
+                    else:
+                        chi, z = approx._base_noise(N)         # chi-square draws first (approximations.py:345-347)
+                        eng.noise_set_host(slot, z[begin:end])
+                    root, _ = _device_root(eng, L @ L.T)        # symmetric square root, :348
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
                     slot, n_local, D, df, var_param, chi[begin:end], root, Linv, self._temper_prior_params,
                     self._eps, self._ess_target, self._max_bisection_its, n_total=N)
