@@ -406,8 +406,9 @@ struct EpiStoreD {          // C_z = sign * acc   (z: product index of a batched
 // inverse, column-oriented back substitution.  Lane r keeps the running sum p_r = sum_{k > i} U[r][k] x_k of "its"
 // rows r and r + 64 in registers; step i reads p_i with v_readlane (i is wave-uniform), forms
 // x_i = (delta_ij - p_i) / U_ii and adds U[r][i] x_i to every p_r, r < i.  U[.][i] is row i of L -- contiguous in
-// the packed parameter -- and does not depend on x, so it is fetched eight steps ahead: the dependent chain per
-// step is a readlane, a subtract, a multiply and an FMA.  The D columns of all blocks run in parallel.
+// the packed parameter; the four waves of a workgroup work on four columns of the same block and first stage the
+// block's rows in LDS (128 KB, all loads in flight at once), so the dependent chain per step is a readlane, a
+// subtract, a multiply and an FMA fed from LDS.  The D columns of all blocks run in parallel.
 constexpr int kTriLeaf = 128;
 __device__ __forceinline__ double fr_readlane(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -417,52 +418,40 @@ __device__ __forceinline__ double fr_readlane(double v, int l) {
 __global__ void __launch_bounds__(256) fr_triinv_leaf_kernel(const double* __restrict__ theta,
                                                              const double* __restrict__ U, int d, int64_t ld,
                                                              double* __restrict__ X) {
+  extern __shared__ double ls[];                            // ls[i * kTriLeaf + r] = L[s + i][s + r], r < i, else 0
   const int lane = threadIdx.x & 63;
-  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // global column
+  const int c0 = blockIdx.x * 4;                            // first of the workgroup's four columns
+  const int s = c0 / kTriLeaf * kTriLeaf;
+  const int jmax = (c0 + 3 < d ? c0 + 3 : d - 1) - s;       // last row any of the four waves needs
+  for (int e = threadIdx.x; e < (jmax + 1) * kTriLeaf; e += 256) {
+    const int i = e / kTriLeaf, r = e % kTriLeaf;
+    const int64_t gi = s + i;
+    ls[e] = r < i ? theta[d + gi * (gi + 1) / 2 + s + r] : 0.0;
+  }
+  __syncthreads();
+  const int c = __builtin_amdgcn_readfirstlane(c0 + (threadIdx.x >> 6));   // this wave's column
   if (c >= d) return;
-  const int s = c / kTriLeaf * kTriLeaf, j = c - s;
+  const int j = c - s;
   double p0 = 0.0, p1 = 0.0, x0 = 0.0, x1 = 0.0;            // rows lane, lane + 64 of the block
   // 1 / U_ii of "its" rows, computed by all lanes at once and read with v_readlane in the loop
   double q0 = 1.0, q1 = 1.0;
   if (lane <= j) q0 = 1.0 / U[(int64_t)(s + lane) * ld + s + lane];
   if (lane + 64 <= j) q1 = 1.0 / U[(int64_t)(s + lane + 64) * ld + s + lane + 64];
-  constexpr int R = 8;
-  double l0[R], l1[R], n0[R], n1[R];
-  // step i needs row s + i of L (columns s .. s + i - 1)
-  auto fetch = [&](int i0, double* a0, double* a1) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = i0 - r;
-      a0[r] = 0.0;
-      a1[r] = 0.0;
-      if (i >= 0) {
-        const int64_t gi = s + i;
-        const double* lrow = theta + d + gi * (gi + 1) / 2 + s;
-        if (lane < i) a0[r] = lrow[lane];
-        if (lane + 64 < i) a1[r] = lrow[lane + 64];
-      }
-    }
-  };
-  fetch(j, l0, l1);
-  for (int i0 = j; i0 >= 0; i0 -= R) {
-    fetch(i0 - R, n0, n1);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = i0 - r;
-      if (i < 0) break;                                      // wave-uniform
-      const double pi = i < 64 ? fr_readlane(p0, i) : fr_readlane(p1, i - 64);
-      const double qi = i < 64 ? fr_readlane(q0, i) : fr_readlane(q1, i - 64);
-      const double xi = ((i == j ? 1.0 : 0.0) - pi) * qi;
-      if (lane == i) x0 = xi;
-      if (lane + 64 == i) x1 = xi;
-      p0 = fma(l0[r], xi, p0);                               // l0 / l1 are zero for rows >= i
-      p1 = fma(l1[r], xi, p1);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      l0[r] = n0[r];
-      l1[r] = n1[r];
-    }
+  // two straight-line phases (no per-step selects): pivots in rows >= 64 touch both register slots, pivots in
+  // rows < 64 only the first (rows >= 64 lie below them: L[s + i][s + r] = 0 for r >= i)
+  int i = j;
+  for (; i >= 64; --i) {
+    const double l0 = ls[i * kTriLeaf + lane], l1 = ls[i * kTriLeaf + lane + 64];   // zero for rows >= i
+    const double xi = ((i == j ? 1.0 : 0.0) - fr_readlane(p1, i - 64)) * fr_readlane(q1, i - 64);
+    if (lane + 64 == i) x1 = xi;
+    p0 = fma(l0, xi, p0);
+    p1 = fma(l1, xi, p1);
+  }
+  for (; i >= 0; --i) {
+    const double l0 = ls[i * kTriLeaf + lane];
+    const double xi = ((i == j ? 1.0 : 0.0) - fr_readlane(p0, i)) * fr_readlane(q0, i);
+    if (lane == i) x0 = xi;
+    p0 = fma(l0, xi, p0);
   }
   double* Xb = X + (int64_t)s * ld + s;
   if (lane <= j) Xb[(int64_t)lane * ld + j] = x0;
@@ -635,8 +624,12 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     // two GEMMs per pair of blocks, D^3 / 3 flops in all instead of a triangular solve
     double *Xa = base + o_xa, *T = base + o_t, *m2 = base + o_m2, *colE = base + o_cole;
     VB_HIP(ctx, hipMemsetAsync(Xa, 0, (size_t)(2 * slab) * sizeof(double), st));   // Xa, T (contiguous)
-    hipLaunchKernelGGL(fr_triinv_leaf_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, theta_dev,
-                       (const double*)Lt, D, ldl, Xa);
+    static const hipError_t leaf_attr = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(fr_triinv_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        kTriLeaf * kTriLeaf * (int)sizeof(double));         // 128 KB of LDS per workgroup
+    VB_HIP(ctx, leaf_attr);
+    hipLaunchKernelGGL(fr_triinv_leaf_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256),
+                       kTriLeaf * kTriLeaf * sizeof(double), st, theta_dev, (const double*)Lt, D, ldl, Xa);
     VB_HIP(ctx, hipGetLastError());
     GemmArgs gn;
     gn.lda = ldl;
