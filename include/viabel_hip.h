@@ -234,6 +234,19 @@ int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p);
  * the caller decides from info[2] whether to keep the result or use its LAPACK path (the iteration resolves
  * condition numbers up to ~1e12). */
 int vb_sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info);
+/* the same with the inverse root a^(-1/2) (d x d, may be NULL), which the iteration produces alongside */
+int vb_sym_sqrt_inv(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info,
+                    double* inv_root);
+
+/* ---- ExclusiveKL with use_path_deriv=True over a MultivariateT (objectives.py:156-159) -----------------
+ * The score of the t density at a sample, -dlog q/dx = c_n Sigma^(-1/2) z_n / s_n with
+ * c_n = (df + D) / (df + |z_n|^2 / s_n^2), depends on the noise only.  Its contribution to the sums of
+ * vb_elbo_sums_mvt is Sigma^(-1/2) m_w and Sigma^(-1/2) e_w with
+ *   m_w[D x D] = sum_n (c_n / s_n^2) z_n z_n'   (symmetric; lower triangle computed, mirrored on return)
+ *   e_w[D]     = sum_n (c_n / s_n) z_n
+ * and the value needs log1p_sum = sum_n log(1 + |z_n|^2 / (s_n^2 df)).  inv_s[n] = 1 / s_n. */
+int vb_mvt_path_terms(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* inv_s,
+                      double* m_w, double* e_w, double* log1p_sum);
 
 /* ---- device-resident fit: the optimiser loop of optimization.py:83-127 without host round trips ----
  * Replaces  for k in range(n_iters): value, grad = objective(theta); theta -= lr * descent_direction(grad)

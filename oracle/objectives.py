@@ -34,9 +34,7 @@ def exclusive_kl(family, model, theta, noise, use_path_deriv=False):
     if isinstance(family, fam.FullRankGaussian):
         return _exclusive_kl_fullrank(family, model, theta, noise, use_path_deriv)
     if isinstance(family, fam.MultivariateT):
-        if use_path_deriv:
-            raise NotImplementedError('path derivative for MultivariateT')
-        return _exclusive_kl_mvt(family, model, theta, noise)
+        return _exclusive_kl_mvt(family, model, theta, noise, use_path_deriv)
     if isinstance(family, fam.LRGaussian):
         if use_path_deriv:
             raise NotImplementedError('path derivative for LRGaussian')
@@ -67,10 +65,14 @@ def sqrt_root_vjp(S, G):
     return U @ ((U.T @ Gs @ U) / (r[:, None] + r[None, :])) @ U.T
 
 
-def _exclusive_kl_mvt(family, model, theta, noise):
+def _exclusive_kl_mvt(family, model, theta, noise, use_path_deriv=False):
     """Entropy form (objectives.py:160-164) for MultivariateT: x = mu + (z R) / s, R = sqrtm(L L')
     (approximations.py:342-349), entropy = sum log L_ii (:351-354).  Chain rule: dF/dR = mean g (z / s)',
-    R -> Sigma by the Sylvester solve above, Sigma = L L' -> dL = tril(2 X L), free diagonal x L_ii."""
+    R -> Sigma by the Sylvester solve above, Sigma = L L' -> dL = tril(2 X L), free diagonal x L_ii.
+
+    Path derivative (:156-159): value = -mean(f(x) - log q(x; stop(theta))); only x moves, so the model gradient
+    is replaced by g - dlog q/dx = g + c_n R^-1 z_n / s_n with c_n = (df + D) / (df + maha_n) and
+    maha_n = |z_n|^2 / s_n^2 (the Mahalanobis distance of a sample depends on its noise only)."""
     theta = np.asarray(theta, dtype=np.float64)
     D = family.dim
     chi, z = noise
@@ -79,11 +81,21 @@ def _exclusive_kl_mvt(family, model, theta, noise):
     x = family.sample_from_noise(theta, noise)
     g = model.grad(x)
     N = x.shape[0]
-    value = -(np.mean(model.logp(x)) + family.entropy(theta))
     zs = z / np.sqrt(chi / family.df)[:, None]
+    if use_path_deriv:
+        df = family.df
+        value = -np.mean(model.logp(x) - family.log_density(theta, x))
+        w, U = np.linalg.eigh(Sigma)
+        Rinv = (U / np.sqrt(w)) @ U.T
+        c = (df + D) / (df + np.sum(zs * zs, axis=1))
+        g = g + c[:, None] * (zs @ Rinv)
+        ent = 0.0
+    else:
+        value = -(np.mean(model.logp(x)) + family.entropy(theta))
+        ent = 1.0
     X = sqrt_root_vjp(Sigma, g.T @ zs / N)
     dL = np.tril(2.0 * X @ L)
-    dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + 1.0          # free (log) diagonal + entropy
+    dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + ent          # free (log) diagonal (+ entropy)
     return value, -np.concatenate([g.mean(0), dL[np.tril_indices(D)]])
 
 

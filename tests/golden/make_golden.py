@@ -560,22 +560,23 @@ def gen_exclusive_kl_mvt():
                   {'kind': 'multivariate_t', 'dim': 10, 'df': 30}):
         D = fspec['dim']
         for mspec in model_specs(D, rng):
+          for pd in (False, True):
             N, seed = 40, 1
             ref, orc = make_family(fspec, seed)
             log_p, omodel = make_model(mspec)
-            theta = theta_for(fspec, rng)
-            objective = ref_obj.ExclusiveKL(ref, log_p, N)
+            theta = theta_for(fspec, rng) if not pd else theta
+            objective = ref_obj.ExclusiveKL(ref, log_p, N, use_path_deriv=pd)
             _ref_stubs.STATE['before_eval'] = snapshot_hook(ref)
             value, grad_fd = objective(theta)
             _ref_stubs.STATE['before_eval'] = None
             noise = orc.draw_noise(np.random.RandomState(seed), N)
-            ov, og = oobj.exclusive_kl(orc, omodel, theta, noise)
-            assert rel_err(ov, value) < 1e-12, (fspec, mspec['kind'], ov, value)
+            ov, og = oobj.exclusive_kl(orc, omodel, theta, noise, pd)
+            assert rel_err(ov, value) < 1e-12, (fspec, mspec['kind'], pd, ov, value)
             e = rel_err(og, grad_fd)
             worst = max(worst, e)
-            assert e < 2e-6, (fspec, mspec['kind'], e)
-            save('ekl_%s_d%d_%s_pd0_n%d' % (fspec['kind'], D, mspec['kind'], N), **spec_arrays(fspec, mspec),
-                 seed=seed, n=N, theta=theta, noise_chi=noise[0], noise_z=noise[1], use_path_deriv=False,
+            assert e < 2e-6, (fspec, mspec['kind'], pd, e)
+            save('ekl_%s_d%d_%s_pd%d_n%d' % (fspec['kind'], D, mspec['kind'], int(pd), N), **spec_arrays(fspec, mspec),
+                 seed=seed, n=N, theta=theta, noise_chi=noise[0], noise_z=noise[1], use_path_deriv=pd,
                  value=value, grad_fd=grad_fd, grad=og,
                  provenance='value: reference closure; grad_fd: Richardson central differences of the reference '
                             'closure (through scipy sqrtm); grad: analytic (oracle, Sylvester solve), agrees with grad_fd')

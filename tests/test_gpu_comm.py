@@ -337,3 +337,24 @@ def test_device_fit_through_comm(engines, family):
                 np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-12)
             else:
                 np.testing.assert_array_equal(b, a)
+
+
+def test_multivariate_t_path_terms_through_comm(engines):
+    """The noise-only sums of the t family's path-derivative estimator are all-reduced like the other sum vectors."""
+    plain, comm = engines
+    D, N, df = 90, 700, 12.0
+    rng = np.random.RandomState(31)
+    inv_s = 1.0 / np.sqrt(rng.chisquare(df, N) / df)
+    out = []
+    for eng in (plain, comm):
+        eng.noise_generate(12, N, D, seed=5, stream=2)
+        out.append(eng.mvt_path_terms(12, N, D, df, inv_s))
+    z = plain.noise_get_host(12, N, D)
+    maha = np.sum(z * z, axis=1) * inv_s ** 2
+    c = (df + D) / (df + maha)
+    want_m = (z * (c * inv_s ** 2)[:, None]).T @ z
+    np.testing.assert_allclose(out[0][0], want_m, rtol=0, atol=1e-12 * np.max(np.abs(want_m)))
+    np.testing.assert_allclose(out[0][1], (c * inv_s) @ z, rtol=0, atol=1e-12 * N)
+    assert abs(out[0][2] - np.sum(np.log1p(maha / df))) < 1e-12 * N
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(np.asarray(b), np.asarray(a))

@@ -55,9 +55,10 @@ def test_exclusive_kl_golden(vb, path):
     assert G.rel_err(grad, fx['grad_fd']) < (2e-6 if str(fx['family_kind']) == 'multivariate_t' else 2e-7)
 
 
+@pytest.mark.parametrize('pd', [False, True])
 @pytest.mark.parametrize('model_kind', ['gauss_diag', 'funnel', 'gauss_full', 'logistic'])
 @pytest.mark.parametrize('D,N,rng_kind', [(256, 2048, 'numpy'), (70, 333, 'numpy'), (129, 1000, 'philox')])
-def test_multivariate_t_exclusive_kl_matches_oracle(vb, D, N, rng_kind, model_kind):
+def test_multivariate_t_exclusive_kl_matches_oracle(vb, D, N, rng_kind, model_kind, pd):
     """MultivariateT + ExclusiveKL (sampling, model gradient and the D x D contraction on the device, chain rule
     through the symmetric root on the host) against the oracle on the same draws; C3's D = 256."""
     from viabel_amd import _lib
@@ -79,14 +80,14 @@ def test_multivariate_t_exclusive_kl_matches_oracle(vb, D, N, rng_kind, model_ki
     approx = vb.MultivariateT(D, 9.0, seed=6, rng=rng_kind)
     B = rng.randn(D, D)
     theta = np.concatenate([0.2 * rng.randn(D), ofam.psd_to_free(0.05 * (B @ B.T / D + 0.5 * np.eye(D)))])
-    value, grad = vb.ExclusiveKL(approx, model, N)(theta)
+    value, grad = vb.ExclusiveKL(approx, model, N, use_path_deriv=pd)(theta)
     if rng_kind == 'numpy':
         noise = ofam.MultivariateT(D, 9.0).draw_noise(np.random.RandomState(6), N)
     else:
         eng = _lib.default_engine()
         eng.noise_generate(30, N, D, seed=6, stream=0)
         noise = (np.random.RandomState(6).chisquare(9.0, N), eng.noise_get_host(30, N, D))
-    ov, og = oobj.exclusive_kl(ofam.MultivariateT(D, 9.0), omodel, theta, noise)
+    ov, og = oobj.exclusive_kl(ofam.MultivariateT(D, 9.0), omodel, theta, noise, pd)
     assert abs(value - ov) <= 1e-12 * abs(ov), (value, ov)
     np.testing.assert_allclose(grad, og, rtol=0, atol=1e-10 * np.max(np.abs(og)))
 

@@ -69,6 +69,10 @@ SIGNATURES = {
                                             _c_double_p]),
     'vb_sym_sqrt': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p,
                                    _c_double_p]),
+    'vb_sym_sqrt_inv': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p,
+                                       _c_double_p, _c_double_p]),
+    'vb_mvt_path_terms': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'vb_fit': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                               ctypes.c_int, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
                               ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _c_double_p,
@@ -435,6 +439,27 @@ class Engine:
         x = np.empty((d, d), dtype=np.float64)
         self._check(self._lib.vb_sym_sqrt(self._ctx, _dptr(a), _dptr(e), d, _dptr(root), _dptr(x), _dptr(info)))
         return root, x, info
+
+    def sym_sqrt_inv(self, a):
+        """``(root, inverse root, info)`` of an SPD matrix (``vb_sym_sqrt_inv``)."""
+        a = _f64(a)
+        d = a.shape[0]
+        root, inv_root = np.empty((d, d), dtype=np.float64), np.empty((d, d), dtype=np.float64)
+        info = np.zeros(3, dtype=np.float64)
+        self._check(self._lib.vb_sym_sqrt_inv(self._ctx, _dptr(a), None, d, _dptr(root), None, _dptr(info),
+                                              _dptr(inv_root)))
+        return root, inv_root, info
+
+    def mvt_path_terms(self, slot, n, d, df, inv_s, n_total=None):
+        """Noise-only sums of the t family's path-derivative estimator (``vb_mvt_path_terms``):
+        ``(m_w, e_w, log1p_sum)``."""
+        inv_s = _f64(inv_s)
+        m_w = np.empty((d, d), dtype=np.float64)
+        e_w = np.empty(d, dtype=np.float64)
+        l1p = ctypes.c_double(0.0)
+        self._check(self._lib.vb_mvt_path_terms(self._ctx, slot, n, d, n if n_total is None else n_total, float(df),
+                                                _dptr(inv_s), _dptr(m_w), _dptr(e_w), ctypes.byref(l1p)))
+        return m_w, e_w, l1p.value
 
     # ------------------------------------------------------------------ device-resident fit
     def fit(self, slot, n, d, family, theta, n_iters, opt_kind, hyper, *, df=0.0, flags=0, cv_mode=0,

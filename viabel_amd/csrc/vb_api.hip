@@ -740,6 +740,28 @@ int vb_sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double
   return sym_sqrt(ctx, a, e, d, root, x, info);
 }
 
+int vb_sym_sqrt_inv(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info,
+                    double* inv_root) {
+  if (!ctx || !a || !root) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (d <= 0 || d > 8192) return fail(ctx, VB_ERR_INVALID, "matrix dimension %lld outside [1, 8192]", (long long)d);
+  if ((e == nullptr) != (x == nullptr)) return fail(ctx, VB_ERR_INVALID, "e and x go together");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  return sym_sqrt(ctx, a, e, d, root, x, info, inv_root);
+}
+
+int vb_mvt_path_terms(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* inv_s,
+                      double* m_w, double* e_w, double* log1p_sum) {
+  if (!ctx || !inv_s || !m_w || !e_w || !log1p_sum) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  return mvt_path_terms(ctx, ctx->noise[slot], n, d, n_total, df, inv_s, m_w, e_w, log1p_sum);
+}
+
 // ---- device-resident fit (optimization.py:83-127) ----------------------------------------------------
 int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
            double df, unsigned flags, int cv_mode, int noise_kind, double noise_df, uint64_t seed,

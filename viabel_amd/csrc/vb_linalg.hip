@@ -69,7 +69,8 @@ GemmArgs square(const double* A, const double* B, int64_t ld, int m) {
 
 // host: a (d x d, symmetric positive definite), e (d x d or nullptr) -> root, x (d x d each), info = [iterations,
 // final ||I - Z Y||_F, ||R R - A||_F / ||A||_F]
-int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info) {
+int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info,
+             double* inv_root) {
   const int m = (int)(e ? 2 * d : d);
   const int64_t ld = round_up(m, 16);
   const int64_t mat = (int64_t)m * ld;
@@ -163,6 +164,16 @@ int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* r
     const double xs = e_scale > 0.0 ? sc / e_scale : 0.0;
     for (int64_t i = 0; i < d; ++i)
       for (int64_t j = 0; j < d; ++j) x[i * d + j] = h[i * ld + (j + d)] * xs;
+  }
+  if (inv_root) {   // Z -> (A / c)^(-1/2): the inverse root comes with the iteration
+    VB_HIP(ctx, hipMemcpyAsync(h, Z[cur], (size_t)mat * sizeof(double), hipMemcpyDeviceToHost, st));
+    VB_HIP(ctx, hipStreamSynchronize(st));
+    for (int64_t i = 0; i < d; ++i)
+      for (int64_t j = 0; j <= i; ++j) {
+        const double v = 0.5 * (h[i * ld + j] + h[j * ld + i]) / sc;
+        inv_root[i * d + j] = v;
+        inv_root[j * d + i] = v;
+      }
   }
   if (info) {
     info[0] = (double)it;

@@ -373,6 +373,87 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
 // x_n = mu + (z_n R) / s_n with R = Sigma^{1/2} (symmetric).  The device returns the sample sums
 //   F = sum_n f(x_n),  sum_n g_n,  C = sum_n g_n (z_n / s_n)'   (full D x D: dF / dR for an unconstrained R);
 // the O(D^3) chain rule R -> Sigma -> free Cholesky parameters is the caller's (host), like the symmetric root.
+// ---- path derivative over a multivariate t: noise-only sums (see vb_mvt_path_terms in the header) --------
+// one wave per row: maha_n = |z_n|^2 / s_n^2, c_n = (df + D) / (df + maha_n);  Es[n] = sqrt(c_n) z_n / s_n (so that
+// Es' Es = m_w), a_n = c_n / s_n, and per-block partial sums of log(1 + maha_n / df)
+__global__ void __launch_bounds__(256) mvt_path_rows_kernel(const double* __restrict__ E, int64_t ld, int64_t n, int d,
+                                                            double df, const double* __restrict__ inv_s,
+                                                            double* __restrict__ Es, int64_t ldw,
+                                                            double* __restrict__ a, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  double l1p = 0.0;
+  if (row < n) {
+    const double* e = E + row * ld;
+    double ss = 0.0;
+    for (int c = lane; c < d; c += 64) ss = fma(e[c], e[c], ss);
+    ss = mvt_wave_sum(ss);
+    ss = __shfl(ss, 0, 64);
+    const double is = inv_s[row];
+    const double maha = ss * is * is;
+    const double cn = (df + d) / (df + maha);
+    const double sc = sqrt(cn) * is;
+    double* w = Es + row * ldw;
+    for (int c = lane; c < d; c += 64) w[c] = sc * e[c];
+    if (lane == 0) {
+      a[row] = cn * is;
+      l1p = log1p(maha / df);
+    }
+  }
+  if (lane == 0) sh[wave] = l1p;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+int mvt_path_terms(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df,
+                   const double* inv_s_host, double* m_w, double* e_w, double* log1p_sum) {
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  const int64_t ldw = round_up(d, 16), slab = d * ldw;
+  const int splits = gram_splits(ctx, (int)d, n);
+  const int n_rb = (int)((n + 127) / 128);
+  const int n_part = (int)((n + 3) / 4);
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  FrSums S;
+  S.off_col = 16;
+  S.off_c = 16 + ns.ld;
+  S.len = 16 + ns.ld + slab;
+  const int64_t o_invs = carve(n), o_a = carve(n), o_es = carve(n * ldw), o_cpart = carve((int64_t)splits * slab),
+                o_col = carve((int64_t)n_rb * ns.ld), o_part = carve(n_part), o_sums = carve(S.len),
+                o_fdummy = carve((int64_t)n_rb * ((d + 127) / 128));   // the column-sum kernel's (zero) f partials
+  VB_TRY(ensure(ctx, ctx->mvt_elbo, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->mvt_elbo.ptr;
+  S.sums = base + o_sums;
+  hipStream_t st = ctx->stream;
+  VB_HIP(ctx, hipMemcpyAsync(base + o_invs, inv_s_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemsetAsync(base + o_es, 0, (size_t)(n * ldw) * sizeof(double), st));   // pad columns
+  const double* E = (const double*)ns.buf.ptr;
+  hipLaunchKernelGGL(mvt_path_rows_kernel, dim3((unsigned)n_part), dim3(256), 0, st, E, ns.ld, n, (int)d, df,
+                     (const double*)(base + o_invs), base + o_es, ldw, base + o_a, base + o_part);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(gram_lower_enqueue(ctx, base + o_es, base + o_es, ldw, (int)d, n, splits, base + o_cpart, ldw, slab));
+  VB_TRY(fr_colsum_enqueue(ctx, E, nullptr, ns.ld, n, (int)d, 0, nullptr, base + o_col, base + o_fdummy,
+                           base + o_a));
+  VB_TRY(fr_reduce_enqueue(ctx, base + o_cpart, splits, slab, (int)d, ldw, base + o_col, n_rb, ns.ld, base + o_part,
+                           n_part, S));
+  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
+  std::vector<double> low((size_t)d * d);
+  VB_HIP(ctx, hipMemcpyAsync(log1p_sum, S.sums, sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(e_w, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(low.data(), (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)ldw * sizeof(double),
+                               (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  for (int64_t i = 0; i < d; ++i)
+    for (int64_t j = 0; j <= i; ++j) m_w[i * d + j] = m_w[j * d + i] = low[(size_t)(i * d + j)];
+  (void)n_total;
+  return VB_OK;
+}
+
 int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, const double* mu_host,
                   const double* root_host, const double* inv_s_host, double* f_sum, double* g_sum, double* c_full) {
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");

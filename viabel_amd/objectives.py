@@ -15,6 +15,7 @@ all-reduced on the device before the epilogue; every rank returns the same ``(va
 from abc import ABC, abstractmethod
 
 import numpy as np
+from scipy import special as _special
 
 from . import _lib
 from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT, LRGaussian, symmetric_eig, symmetric_root
@@ -181,8 +182,9 @@ class ExclusiveKL(StochasticVariationalObjective):
                 return eng.elbo_grad_fullrank(_NOISE_SLOT, n_local, approx.dim, var_param,
                                               flags=flags, n_total=n_total)
         elif isinstance(approx, MultivariateT):
-            if cv_mode != 0 or self._use_path_deriv:
-                raise NotImplementedError('MultivariateT supports the entropy-form ExclusiveKL estimator only')
+            if cv_mode != 0:
+                raise NotImplementedError('the RGE control variates treat var_param as [mean | log-scale] '
+                                          '(objectives.py:196-198) and do not apply to MultivariateT')
             objective_and_grad = self._mvt_exclusive_kl(approx)
         elif isinstance(approx, LRGaussian):
             if cv_mode != 0 or self._use_path_deriv:
@@ -256,6 +258,7 @@ class ExclusiveKL(StochasticVariationalObjective):
         reference differentiates ``sqrtm`` with autograd, ``approximations.py:348``)."""
         D, df = approx.dim, approx.df
         tril = np.tril_indices(D)
+        path_deriv = self._use_path_deriv
         _lib.apply_host_blas_policy()      # before the first D x D host product
 
         def objective_and_grad(var_param):
@@ -275,10 +278,27 @@ class ExclusiveKL(StochasticVariationalObjective):
                 eng.noise_set_host(_NOISE_SLOT, z[begin:end])
             mu, L = approx._unpack(var_param)
             Sigma = L @ L.T
-            root, eig = _device_root(eng, Sigma)
             inv_s = 1.0 / np.sqrt(chi / df)
+            if path_deriv:
+                root, inv_root, info = eng.sym_sqrt_inv(Sigma)
+                eig = None
+                if not info[2] < _ROOT_TOL:
+                    eig = symmetric_eig(Sigma)
+                    root, inv_root = (eig[1] * np.sqrt(eig[0])) @ eig[1].T, (eig[1] / np.sqrt(eig[0])) @ eig[1].T
+            else:
+                root, eig = _device_root(eng, Sigma)
             f_sum, g_sum, C = eng.elbo_sums_mvt(_NOISE_SLOT, end - begin, D, mu, root, inv_s[begin:end], n_total=N)
-            value = -(f_sum / N + approx.entropy(var_param))
+            if path_deriv:
+                # -dlog q/dx = c_n Sigma^(-1/2) z_n / s_n depends on the noise only: its part of the sums is
+                # Sigma^(-1/2) m_w / Sigma^(-1/2) e_w, and the value takes the t log density of the samples
+                m_w, e_w, l1p = eng.mvt_path_terms(_NOISE_SLOT, end - begin, D, df, inv_s[begin:end], n_total=N)
+                C = C + inv_root @ m_w
+                g_sum = g_sum + inv_root @ e_w
+                lq_mean = (_special.gammaln(0.5 * (df + D)) - _special.gammaln(0.5 * df) - 0.5 * D * np.log(np.pi * df)
+                           - np.sum(np.log(np.diag(L))) - 0.5 * (df + D) * l1p / N)
+                value = -(f_sum / N - lq_mean)
+            else:
+                value = -(f_sum / N + approx.entropy(var_param))
             Gs = 0.5 * (C + C.T) / N                                 # d mean f / d root, symmetrised
             # root -> Sigma: the Sylvester equation  root X + X root = Gs
             X = None
@@ -291,8 +311,8 @@ class ExclusiveKL(StochasticVariationalObjective):
                 r = np.sqrt(w)
                 X = U @ ((U.T @ Gs @ U) / (r[:, None] + r[None, :])) @ U.T
             dL = np.tril(2.0 * X @ L)
-            dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + 1.0  # free (log) diagonal, entropy gradient
-            return value, -np.concatenate([g_sum / N, dL[tril]])
+            dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + (0.0 if path_deriv else 1.0)   # free (log) diagonal,
+            return value, -np.concatenate([g_sum / N, dL[tril]])                             # entropy gradient
 
         return objective_and_grad
 
