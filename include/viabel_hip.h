@@ -238,6 +238,15 @@ int vb_sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double
 int vb_sym_sqrt_inv(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info,
                     double* inv_root);
 
+/* ---- ExclusiveKL with use_path_deriv=True over an LRGaussian (objectives.py:156-159, approximations.py:610-731)
+ * The score Sigma^-1 (x - mu) of the low-rank Gaussian is linear in its two noise blocks (eps: n x d in slot_eps,
+ * z: n x k in slot_z), so its contribution to the entropy-form sums follows from second moments of the noise.
+ * With sw = sigma * (B / sigma^2) (d x k, row-major, host) and u_n = sw' eps_n, T = [z | u] (n x 2k), `out` receives
+ *   [ E'T (d x 2k, row-major) | T'T (2k x 2k) | sum_n eps_n (d) | sum_n eps_n^2 (d, per column) | sum_n T_n (2k) ]
+ * (d 2k + 4 k^2 + 2 d + 2k doubles); the O(d k^2) Woodbury algebra stays with the caller.  1 <= k <= 16. */
+int vb_lowrank_path_terms(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, int64_t n_total,
+                          const double* sw, double* out);
+
 /* ---- ExclusiveKL with use_path_deriv=True over a MultivariateT (objectives.py:156-159) -----------------
  * The score of the t density at a sample, -dlog q/dx = c_n Sigma^(-1/2) z_n / s_n with
  * c_n = (df + D) / (df + |z_n|^2 / s_n^2), depends on the noise only.  Its contribution to the sums of

@@ -36,9 +36,7 @@ def exclusive_kl(family, model, theta, noise, use_path_deriv=False):
     if isinstance(family, fam.MultivariateT):
         return _exclusive_kl_mvt(family, model, theta, noise, use_path_deriv)
     if isinstance(family, fam.LRGaussian):
-        if use_path_deriv:
-            raise NotImplementedError('path derivative for LRGaussian')
-        return _exclusive_kl_lowrank(family, model, theta, noise)
+        return _exclusive_kl_lowrank(family, model, theta, noise, use_path_deriv)
     D = family.dim
     mu, ls = family.split(theta)
     sig = np.exp(ls)
@@ -99,15 +97,22 @@ def _exclusive_kl_mvt(family, model, theta, noise, use_path_deriv=False):
     return value, -np.concatenate([g.mean(0), dL[np.tril_indices(D)]])
 
 
-def _exclusive_kl_lowrank(family, model, theta, noise):
+def _exclusive_kl_lowrank(family, model, theta, noise, use_path_deriv=False):
     """Entropy form (objectives.py:160-164) for LRGaussian: d/dmu = -mean g, d/dlog_sigma = -mean(g eps) sigma,
-    d/dB = -mean g z', minus the entropy gradient."""
+    d/dB = -mean g z', minus the entropy gradient.  Path derivative (:156-159): log q at stopped parameters, so
+    g is replaced by g - dlog q/dx = g + Sigma^-1 (x - mu) and the entropy gradient drops out."""
     theta = np.asarray(theta, dtype=np.float64)
     z, eps = noise
     _, ls, _ = family.split(theta)
     x = family.sample_from_noise(theta, noise)
     g = model.grad(x)
     N = x.shape[0]
+    if use_path_deriv:
+        mu = family.split(theta)[0]
+        g = g + np.linalg.solve(family.cov(theta), (x - mu).T).T
+        value = -np.mean(model.logp(x) - family.log_density(theta, x))
+        data = np.concatenate([g.sum(0), (g * eps).sum(0) * np.exp(ls), (g.T @ z).reshape(-1)]) / N
+        return value, -data
     value = -(np.mean(model.logp(x)) + family.entropy(theta))
     data = np.concatenate([g.sum(0), (g * eps).sum(0) * np.exp(ls), (g.T @ z).reshape(-1)]) / N
     return value, -(data + family.entropy_grad(theta))

@@ -545,6 +545,18 @@ def gen_lowrank():
             out.update({tag + key: val for key, val in spec_arrays({'kind': 'lr_gaussian', 'dim': D}, mspec).items()})
             out.update({tag + 'noise_z': noise2[0], tag + 'noise_eps': noise2[1], tag + 'value': value,
                         tag + 'grad_fd': grad_fd, tag + 'grad': og})
+            # the same closure with use_path_deriv=True (objectives.py:156-159)
+            ref3 = ref_approx.LRGaussian(D, seed=seed, k=k)
+            objective = ref_obj.ExclusiveKL(ref3, log_p, N, use_path_deriv=True)
+            _ref_stubs.STATE['before_eval'] = snapshot_hook(ref3)
+            pd_value, pd_grad_fd = objective(th0)
+            _ref_stubs.STATE['before_eval'] = None
+            pv, pg = oobj.exclusive_kl(orc, omodel, th0, noise2, True)
+            assert rel_err(pv, pd_value) < 1e-12, (D, k, pv, pd_value)
+            e = rel_err(pg, pd_grad_fd)
+            worst = max(worst, e)
+            assert e < 2e-7, (D, k, mspec['kind'], 'path_deriv', e)
+            out.update({tag + 'pd_value': pd_value, tag + 'pd_grad_fd': pd_grad_fd, tag + 'pd_grad': pg})
         save('lowrank_d%d_k%d' % (D, k), **out,
              provenance='reference LRGaussian forward code and ExclusiveKL closure via the autograd->numpy alias; '
                         'grad_fd: Richardson differences of the reference closure; grad: analytic (oracle)')

@@ -55,6 +55,9 @@ def test_oracle_and_host_family_match_reference(path):
         assert abs(ov - float(fx[tag + 'value'])) <= 1e-12 * abs(float(fx[tag + 'value']))
         np.testing.assert_allclose(og, fx[tag + 'grad'], rtol=0, atol=1e-13 * np.max(np.abs(og)))
         np.testing.assert_allclose(og, fx[tag + 'grad_fd'], rtol=0, atol=2e-7 * np.max(np.abs(og)))
+        pv, pg = oobj.exclusive_kl(orc, omodel, th0, (fx[tag + 'noise_z'], fx[tag + 'noise_eps']), True)
+        assert abs(pv - float(fx[tag + 'pd_value'])) <= 1e-12 * abs(pv)
+        np.testing.assert_allclose(pg, fx[tag + 'pd_grad_fd'], rtol=0, atol=2e-7 * np.max(np.abs(pg)))
 
 
 @pytest.mark.gpu
@@ -72,6 +75,13 @@ def test_device_exclusive_kl_matches_reference(path):
         assert abs(value - ref_v) <= 1e-12 * abs(ref_v), (value, ref_v)
         np.testing.assert_allclose(grad, ref_g, rtol=0, atol=1e-11 * np.max(np.abs(ref_g)))
         np.testing.assert_allclose(grad, fx[tag + 'grad_fd'], rtol=0, atol=2e-7 * np.max(np.abs(ref_g)))
+        # the reference closure with use_path_deriv=True (objectives.py:156-159)
+        objective = vb.ExclusiveKL(vb.LRGaussian(D, seed=seed, k=k), model, N, use_path_deriv=True)
+        value, grad = objective(fx['theta0'])
+        ref_v, ref_g = float(fx[tag + 'pd_value']), fx[tag + 'pd_grad']
+        assert abs(value - ref_v) <= 1e-11 * abs(ref_v), (value, ref_v)
+        np.testing.assert_allclose(grad, ref_g, rtol=0, atol=1e-10 * np.max(np.abs(ref_g)))
+        np.testing.assert_allclose(grad, fx[tag + 'pd_grad_fd'], rtol=0, atol=2e-7 * np.max(np.abs(ref_g)))
 
 
 @pytest.mark.gpu
@@ -93,6 +103,10 @@ def test_device_exclusive_kl_matches_oracle(target, D, k, N):
     ov, og = oobj.exclusive_kl(ofam.LRGaussian(D, k), omodel, theta, noise)
     assert abs(value - ov) <= 1e-12 * abs(ov), (value, ov)
     np.testing.assert_allclose(grad, og, rtol=0, atol=1e-11 * np.max(np.abs(og)))
+    value, grad = vb.ExclusiveKL(vb.LRGaussian(D, seed=4, k=k), model, N, use_path_deriv=True)(theta)
+    ov, og = oobj.exclusive_kl(ofam.LRGaussian(D, k), omodel, theta, noise, True)
+    assert abs(value - ov) <= 1e-11 * abs(ov), (value, ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-10 * np.max(np.abs(og)))
 
 
 @pytest.mark.gpu
@@ -100,7 +114,7 @@ def test_lowrank_rejects_unsupported():
     import viabel_amd as vb
     model = vb.GaussianModel(np.zeros(4), np.ones(4))
     with pytest.raises(NotImplementedError):
-        vb.ExclusiveKL(vb.LRGaussian(4, k=2), model, 10, use_path_deriv=True)
+        vb.ExclusiveKL(vb.LRGaussian(4, k=2), model, 10, hessian_approx_method='full')
     with pytest.raises(NotImplementedError):
         vb.ExclusiveKL(vb.LRGaussian(4, k=17), model, 10)(np.zeros(4 * 2 + 4 * 17))
     with pytest.raises(ValueError):
@@ -135,3 +149,32 @@ def test_lowrank_philox_mode_matches_oracle_on_the_same_noise():
         np.testing.assert_array_equal(eng.noise_get_host(41, N, k), z)
     x = fam.sample(theta, 2000)
     assert x.shape == (2000, D) and abs(x.mean() - theta[:D].mean()) < 0.1
+
+
+@pytest.mark.gpu
+def test_lowrank_path_terms_plain_and_sharded_context():
+    """vb_lowrank_path_terms against numpy second moments, and through a context with a (one-rank) communicator."""
+    import viabel_amd  # noqa: F401
+    from viabel_amd import _lib
+    D, k, N = 70, 5, 513
+    rng = np.random.RandomState(3)
+    sw = rng.randn(D, k)
+    plain = _lib.default_engine()
+    comm = _lib.Engine(plain.device)
+    comm.comm_init(_lib.Engine.comm_unique_id(), 1, 0)
+    try:
+        outs = []
+        for eng in (plain, comm):
+            eng.noise_generate(50, N, D, seed=2, stream=0)
+            eng.noise_generate(51, N, k, seed=2, stream=1)
+            outs.append(eng.lowrank_path_terms(50, 51, N, D, k, sw))
+        E, Z = plain.noise_get_host(50, N, D), plain.noise_get_host(51, N, k)
+        T = np.concatenate([Z, E @ sw], axis=1)
+        want = (E.T @ T, T.T @ T, E.sum(0), (E * E).sum(0), T.sum(0))
+        for got, ref in zip(outs[0], want):
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * max(1.0, np.max(np.abs(ref))))
+        for a, b in zip(outs[0], outs[1]):
+            np.testing.assert_array_equal(b, a)
+    finally:
+        comm.comm_destroy()
+        comm.close()

@@ -71,6 +71,8 @@ SIGNATURES = {
                                    _c_double_p]),
     'vb_sym_sqrt_inv': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p,
                                        _c_double_p, _c_double_p]),
+    'vb_lowrank_path_terms': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_mvt_path_terms': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'vb_fit': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -449,6 +451,17 @@ class Engine:
         self._check(self._lib.vb_sym_sqrt_inv(self._ctx, _dptr(a), None, d, _dptr(root), None, _dptr(info),
                                               _dptr(inv_root)))
         return root, inv_root, info
+
+    def lowrank_path_terms(self, slot_eps, slot_z, n, d, k, sw, n_total=None):
+        """Noise-only second moments of the low-rank family's path-derivative estimator (``vb_lowrank_path_terms``):
+        ``(E'T (d, 2k), T'T (2k, 2k), sum eps (d), sum eps^2 (d), sum T (2k))`` with ``T = [z | eps sw]``."""
+        sw = _f64(sw)
+        out = np.empty(d * 2 * k + 4 * k * k + 2 * d + 2 * k, dtype=np.float64)
+        self._check(self._lib.vb_lowrank_path_terms(self._ctx, slot_eps, slot_z, n, d, k,
+                                                    n if n_total is None else n_total, _dptr(sw), _dptr(out)))
+        a, b = d * 2 * k, d * 2 * k + 4 * k * k
+        return (out[:a].reshape(d, 2 * k), out[a:b].reshape(2 * k, 2 * k), out[b:b + d], out[b + d:b + 2 * d],
+                out[b + 2 * d:])
 
     def mvt_path_terms(self, slot, n, d, df, inv_s, n_total=None):
         """Noise-only sums of the t family's path-derivative estimator (``vb_mvt_path_terms``):

@@ -750,6 +750,19 @@ int vb_sym_sqrt_inv(vb_ctx* ctx, const double* a, const double* e, int64_t d, do
   return sym_sqrt(ctx, a, e, d, root, x, info, inv_root);
 }
 
+int vb_lowrank_path_terms(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, int64_t n_total,
+                          const double* sw, double* out) {
+  if (!ctx || !sw || !out) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot_eps));
+  VB_TRY(check_slot(ctx, slot_z));
+  if (!ctx->noise[slot_eps].buf.ptr || !ctx->noise[slot_z].buf.ptr)
+    return fail(ctx, VB_ERR_STATE, "noise slots %d / %d are empty", slot_eps, slot_z);
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  return lr_path_terms(ctx, ctx->noise[slot_eps], ctx->noise[slot_z], n, d, k, sw, out);
+}
+
 int vb_mvt_path_terms(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* inv_s,
                       double* m_w, double* e_w, double* log1p_sum) {
   if (!ctx || !inv_s || !m_w || !e_w || !log1p_sum) return fail(ctx, VB_ERR_INVALID, "NULL argument");

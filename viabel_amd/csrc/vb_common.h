@@ -247,7 +247,8 @@ struct FrSums {
   int64_t off_col, off_c, len;
 };
 int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,
-                      const double* ivar, double* colpart, double* fpart, const double* roww = nullptr);
+                      const double* ivar, double* colpart, double* fpart, const double* roww = nullptr,
+                      int square = 0);   // square: column sums of the squared entries
 int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab, int d, int64_t ldl,
                       const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S);
 // lower triangle of C = A' B for k-major A, B (n x d, row stride ld), split over n into `splits` slabs
@@ -271,6 +272,10 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
 // symmetric square root / its derivative by coupled Newton-Schulz GEMM iterations (vb_linalg.hip)
 int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info,
              double* inv_root = nullptr);
+// low-rank Gaussian, path derivative: noise-only sums (vb_linalg.hip); out = [E'T (d x 2k) | T'T (2k x 2k) |
+// sum eps (d) | sum eps^2 (d) | sum T (2k)], T = [z | u], u_n = sw' eps_n
+int lr_path_terms(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
+                  const double* sw_host, double* out_host);
 // multivariate t, path derivative: noise-only sums (vb_mvt.hip)
 int mvt_path_terms(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df,
                    const double* inv_s_host, double* m_w, double* e_w, double* log1p_sum);

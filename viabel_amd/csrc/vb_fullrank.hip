@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
                                                         const double* __restrict__ ivar,
                                                         double* __restrict__ colpart,
                                                         double* __restrict__ fpart, double scal = 0.0,
-                                                        const double* __restrict__ roww = nullptr) {
+                                                        const double* __restrict__ roww = nullptr,
+                                                        int square = 0) {
   __shared__ double sh[4];
   __shared__ fr_d2 cs[4][64];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -191,6 +192,7 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
         if (r < r1) {
           g[i] = *reinterpret_cast<const fr_d2*>(G + r * ldz + col);
           if (roww) g[i] *= roww[r];
+          if (square) g[i] *= g[i];
           if (fmode >= 2) z[i] = *reinterpret_cast<const fr_d2*>(Zc + r * ldz + col);
           if (!ok1) g[i].y = 0.0, z[i].y = 0.0;
         }
@@ -487,10 +489,10 @@ __global__ void __launch_bounds__(256) fr_pd_matvec_kernel(const double* __restr
 
 // ---- wrappers shared with the multivariate-t path (vb_mvt.hip) ---------------------------------------
 int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,
-                      const double* ivar, double* colpart, double* fpart, const double* roww) {
+                      const double* ivar, double* colpart, double* fpart, const double* roww, int square) {
   const int n_rb = (int)((n + 127) / 128);
   hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)((d + 127) / 128), (unsigned)n_rb), dim3(256), 0, ctx->stream,
-                     G, Zc, ldz, n, d, fmode, ivar, colpart, fpart, 0.0, roww);
+                     G, Zc, ldz, n, d, fmode, ivar, colpart, fpart, 0.0, roww, square);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }

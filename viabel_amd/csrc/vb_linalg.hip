@@ -183,4 +183,106 @@ int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* r
   return VB_OK;
 }
 
+// ---- low-rank Gaussian, path derivative (objectives.py:156-159 over approximations.py:610-731) ---------------
+// The score Sigma^-1 (x - mu), Sigma = B B' + diag(sigma^2), is linear in the two noise blocks, so everything the
+// estimator adds to the entropy-form sums follows from second moments of the noise: with u_n = (sigma W)' eps_n
+// (W = D^-2 B, a k-vector per sample) and T = [z | u] (n x 2k),
+//     E'T (d x 2k),   T'T (2k x 2k),   sum eps,   sum eps^2 (per column),   sum T
+// -- three skinny GEMMs and three column-sum passes; the O(D k^2) Woodbury algebra stays with the caller.
+namespace {
+
+__global__ void __launch_bounds__(256) lr_slab_sum_kernel(const double* __restrict__ W, int slabs, int64_t slab,
+                                                          double* __restrict__ out, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  double s = 0.0;
+  for (int k = 0; k < slabs; ++k) s += W[k * slab + i];   // fixed order
+  out[i] = s;
+}
+
+struct EpiSlab {            // slab_split = acc
+  double* W;
+  int64_t ld, slab;
+  __device__ void operator()(int split, int row, int col, double acc) const {
+    W[split * slab + (int64_t)row * ld + col] = acc;
+  }
+};
+
+}  // namespace
+
+int lr_path_terms(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
+                  const double* sw_host, double* out_host) {
+  if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d || k < 1 || k > 16)
+    return fail(ctx, VB_ERR_INVALID, "noise slots must hold n x d and n x k (k <= 16) matrices");
+  hipStream_t st = ctx->stream;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int k2 = (int)(2 * k);
+  const int64_t ldk = 16, ldt = 32;                 // row strides of sw (d x k) and T (n x 2k)
+  const int n_rb = (int)((n + 127) / 128);
+  int splits = (int)(n / 256);
+  if (splits > 32) splits = 32;
+  if (splits < 1) splits = 1;
+  const int64_t slab_et = d * ldt, slab_tt = (int64_t)k2 * ldt;
+  const int64_t out_len = d * k2 + (int64_t)k2 * k2 + 2 * d + k2;
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t o_sw = carve(d * ldk), o_t = carve(n * ldt), o_w1 = carve(splits * slab_et), o_w2 = carve(splits * slab_tt),
+                o_et = carve(slab_et), o_tt = carve(slab_tt), o_c1 = carve((int64_t)n_rb * ns.ld),
+                o_c2 = carve((int64_t)n_rb * ns.ld), o_c3 = carve((int64_t)n_rb * ldt), o_f = carve((int64_t)n_rb * ((d + 127) / 128 + 1)),
+                o_s1 = carve(ns.ld), o_s2 = carve(ns.ld), o_s3 = carve(ldt), o_pack = carve(out_len);
+  VB_TRY(ensure(ctx, ctx->glm_work, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->glm_work.ptr;
+  double *SW = base + o_sw, *T = base + o_t;
+  const double* E = (const double*)ns.buf.ptr;
+  VB_HIP(ctx, hipMemsetAsync(SW, 0, (size_t)(d * ldk) * sizeof(double), st));
+  VB_HIP(ctx, hipMemsetAsync(T, 0, (size_t)(n * ldt) * sizeof(double), st));
+  VB_HIP(ctx, hipMemcpy2DAsync(SW, (size_t)ldk * sizeof(double), sw_host, (size_t)k * sizeof(double),
+                               (size_t)k * sizeof(double), (size_t)d, hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(T, (size_t)ldt * sizeof(double), nz.buf.ptr, (size_t)nz.ld * sizeof(double),
+                               (size_t)k * sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, st));
+  GemmArgs g;                                   // U = E sw  -> columns k .. 2k of T
+  g.A = E, g.lda = ns.ld, g.B = SW, g.ldb = ldk;
+  g.M = (int)n, g.N = (int)k, g.K = (int)d, g.tri_mode = 0;
+  gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{T + k, ldt});
+  VB_HIP(ctx, hipGetLastError());
+  g.A = E, g.lda = ns.ld, g.B = T, g.ldb = ldt;  // E'T (d x 2k), contraction over the samples
+  g.M = (int)d, g.N = k2, g.K = (int)n;
+  gemm_f64_launch<false>(st, g, splits, n_cu, EpiSlab{base + o_w1, ldt, slab_et});
+  g.A = T, g.lda = ldt;                          // T'T (2k x 2k)
+  g.M = k2;
+  gemm_f64_launch<false>(st, g, splits, n_cu, EpiSlab{base + o_w2, ldt, slab_tt});
+  VB_HIP(ctx, hipGetLastError());
+  auto slab_sum = [&](const double* W, int slabs, int64_t slab, double* out, int64_t count) {
+    hipLaunchKernelGGL(lr_slab_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, W, slabs, slab, out,
+                       count);
+  };
+  slab_sum(base + o_w1, splits, slab_et, base + o_et, slab_et);
+  slab_sum(base + o_w2, splits, slab_tt, base + o_tt, slab_tt);
+  VB_TRY(fr_colsum_enqueue(ctx, E, nullptr, ns.ld, n, (int)d, 0, nullptr, base + o_c1, base + o_f));
+  VB_TRY(fr_colsum_enqueue(ctx, E, nullptr, ns.ld, n, (int)d, 0, nullptr, base + o_c2, base + o_f, nullptr, 1));
+  VB_TRY(fr_colsum_enqueue(ctx, T, nullptr, ldt, n, k2, 0, nullptr, base + o_c3, base + o_f));
+  slab_sum(base + o_c1, n_rb, ns.ld, base + o_s1, ns.ld);
+  slab_sum(base + o_c2, n_rb, ns.ld, base + o_s2, ns.ld);
+  slab_sum(base + o_c3, n_rb, ldt, base + o_s3, ldt);
+  VB_HIP(ctx, hipGetLastError());
+  // pack (dense rows) -> one vector to all-reduce and copy out
+  double* pack = base + o_pack;
+  VB_HIP(ctx, hipMemcpy2DAsync(pack, (size_t)k2 * sizeof(double), base + o_et, (size_t)ldt * sizeof(double),
+                               (size_t)k2 * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(pack + d * k2, (size_t)k2 * sizeof(double), base + o_tt, (size_t)ldt * sizeof(double),
+                               (size_t)k2 * sizeof(double), (size_t)k2, hipMemcpyDeviceToDevice, st));
+  double* tail = pack + d * k2 + (int64_t)k2 * k2;
+  VB_HIP(ctx, hipMemcpyAsync(tail, base + o_s1, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(tail + d, base + o_s2, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d, base + o_s3, (size_t)k2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));
+  VB_HIP(ctx, hipMemcpyAsync(out_host, pack, (size_t)out_len * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  return VB_OK;
+}
+
 }  // namespace vb

@@ -187,8 +187,10 @@ class ExclusiveKL(StochasticVariationalObjective):
                                           '(objectives.py:196-198) and do not apply to MultivariateT')
             objective_and_grad = self._mvt_exclusive_kl(approx)
         elif isinstance(approx, LRGaussian):
-            if cv_mode != 0 or self._use_path_deriv:
-                raise NotImplementedError('LRGaussian supports the entropy-form ExclusiveKL estimator only')
+            if cv_mode != 0:
+                raise NotImplementedError('the RGE control variates treat var_param as [mean | log-scale] '
+                                          '(objectives.py:196-198) and do not apply to LRGaussian')
+            path_deriv = self._use_path_deriv
 
             def objective_and_grad(var_param):
                 var_param = np.asarray(var_param, dtype=np.float64)
@@ -204,8 +206,11 @@ class ExclusiveKL(StochasticVariationalObjective):
                     z, eps = approx._base_noise(N)      # low-rank block first (approximations.py:639-640)
                     eng.noise_set_host(_NOISE_SLOT, eps[begin:end])
                     eng.noise_set_host(_LR_SLOT, z[begin:end])
-                return eng.elbo_grad_lowrank(_NOISE_SLOT, _LR_SLOT, end - begin, approx.dim, approx.k, var_param,
-                                             n_total=N)
+                value, grad = eng.elbo_grad_lowrank(_NOISE_SLOT, _LR_SLOT, end - begin, approx.dim, approx.k, var_param,
+                                                    n_total=N)
+                if path_deriv:
+                    value, grad = _lowrank_path_correction(eng, approx, var_param, value, grad, end - begin, N)
+                return value, grad
         else:
             raise NotImplementedError(
                 'ExclusiveKL on the HIP engine supports MFGaussian, MFStudentT, FullRankGaussian, MultivariateT '
@@ -220,7 +225,7 @@ class ExclusiveKL(StochasticVariationalObjective):
         approx = self.approx
         if isinstance(approx, LRGaussian):
             return (approx.rng == 'philox' and 1 <= approx.k <= 16 and not self._use_path_deriv
-                    and self.hessian_approx_method is None)
+                    and self.hessian_approx_method is None)     # the path-derivative correction is host algebra
         return (isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian)) and approx.rng == 'philox'
                 and not (isinstance(approx, FullRankGaussian) and self.hessian_approx_method is not None))
 
@@ -315,6 +320,45 @@ class ExclusiveKL(StochasticVariationalObjective):
             return value, -np.concatenate([g_sum / N, dL[tril]])                             # entropy gradient
 
         return objective_and_grad
+
+
+def _lowrank_path_correction(eng, approx, var_param, value, grad, n_local, N):
+    """Entropy-form (value, grad) of the low-rank family -> path-derivative form (objectives.py:156-159).
+
+    The score Sigma^-1 (x - mu), x - mu = B z + sigma eps, is linear in the noise, so what it adds to the sums
+    ``[sum g | sum g eps | sum g z']`` follows from second moments of the noise that the device forms with three
+    skinny GEMMs (``vb_lowrank_path_terms``); Sigma^-1 is applied through the k x k capacitance matrix
+    (Woodbury, approximations.py:559-607).  The entropy and its gradient, which the device result contains, are
+    taken out again."""
+    D, k = approx.dim, approx.k
+    mu, ls, B = approx._unpack(var_param)
+    sig, sig2 = np.exp(ls), np.exp(2.0 * ls)
+    W = B / sig2[:, None]                                   # D^-2 B
+    M = np.eye(k) + B.T @ W
+    Minv = np.linalg.inv(M)
+    Mm = M - np.eye(k)
+
+    def sinv(X):                                            # Sigma^-1 X, X: (D, m)
+        return X / sig2[:, None] - W @ (Minv @ (W.T @ X))
+
+    ET, TT, es, ee, ts = eng.lowrank_path_terms(_NOISE_SLOT, _LR_SLOT, n_local, D, k, sig[:, None] * W, n_total=N)
+    EZ, Q = ET[:, :k], ET[:, k:]
+    Z2, ZU, UU = TT[:k, :k], TT[:k, k:], TT[k:, k:]
+    zs = ts[:k]
+    a1 = sinv((B @ zs + sig * es)[:, None])[:, 0]           # sum_n s_n
+    a3 = sinv(B @ Z2 + sig[:, None] * EZ)                   # sum_n s_n z_n'
+    bez = np.sum(B * EZ, axis=1)
+    R = Mm @ EZ.T + Q.T                                     # sum_n (W' v_n) eps_n'   (k, D)
+    a2 = (bez + sig * ee) / sig2 - np.sum((W @ Minv) * R.T, axis=1)        # sum_n s_n * eps_n
+    maha = (np.sum((np.sum((B @ Z2) * B, axis=1) + 2.0 * sig * bez + sig2 * ee) / sig2)
+            - np.trace(Minv @ (Mm @ Z2 @ Mm.T + Mm @ ZU + ZU.T @ Mm.T + UU)))
+    logdet = 2.0 * np.sum(ls) + np.linalg.slogdet(M)[1]
+    entropy = 0.5 * D * (np.log(2.0 * np.pi) + 1.0) + 0.5 * logdet
+    mean_logq = -0.5 * (D * np.log(2.0 * np.pi) + logdet + maha / N)
+    d_entropy = np.concatenate([np.zeros(D), (1.0 / sig2 - np.sum((W @ Minv) * W, axis=1)) * sig2,
+                                sinv(B).reshape(-1)])
+    corr = np.concatenate([a1, sig * a2, a3.reshape(-1)]) / N
+    return value + entropy + mean_logq, grad + d_entropy - corr
 
 
 _ROOT_TOL = 1e-12     # ||root root - Sigma|| / ||Sigma|| accepted from the Newton-Schulz iteration
