@@ -871,6 +871,9 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
     c.flags = flags;
     c.cv_mode = cv_mode;
   }
+  static const bool gen_env = !(getenv("VB_FIT_GEN") && atoi(getenv("VB_FIT_GEN")) == 0);
+  const bool gen_in_kernel = gen_env && family == VB_FAMILY_MF_GAUSSIAN && noise_kind == VB_NOISE_NORMAL &&
+                             (ctx->model.id == VB_MODEL_GAUSS_DIAG || ctx->model.id == VB_MODEL_FUNNEL);
   for (int64_t k = 0; k < n_iters; ++k) {
     if (lowrank) {
       NoiseSlot& nz = ctx->noise[slot_aux];
@@ -878,6 +881,13 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
       VB_TRY(rng_fill(ctx, (double*)ns.buf.ptr, ns.ld, VB_NOISE_NORMAL, 0.0, seed, s2, row_offset, n, d));
       VB_TRY(rng_fill(ctx, (double*)nz.buf.ptr, nz.ld, VB_NOISE_NORMAL, 0.0, seed, s2 + 1, row_offset, n, lr_k));
       VB_TRY(lr_elbo_grad_enqueue(ctx, ns, nz, n, d, lr_k, n_total, theta_dev, out_dev));
+    } else if (gen_in_kernel) {
+      // single-use Gaussian noise never touches HBM: the streaming kernel generates it in registers
+      c.gen = 1;
+      c.gen_seed = seed;
+      c.gen_stream = first_stream + (uint64_t)k;
+      c.gen_row_offset = row_offset;
+      VB_TRY(mf_enqueue(ctx, c));
     } else {
       VB_TRY(rng_fill(ctx, (double*)ns.buf.ptr, ns.ld, noise_kind, noise_df, seed, first_stream + (uint64_t)k,
                       row_offset, n, d));

@@ -202,6 +202,12 @@ struct MfCall {
   double scale = 0.0;  // mode 1
   const double* value_src = nullptr;   // mode 1: device scalar reported as the objective value
   const ModelDev* model = nullptr;     // overrides ctx->model (mode 2: the log-q pseudo model)
+  // gen != 0 (single ELBO evaluation, Gaussian base noise, gauss_diag / funnel target): the streaming kernel
+  // generates its noise in registers -- element (gen_row_offset + n, col) of Philox stream (gen_seed, gen_stream),
+  // the values vb_noise_generate would have written -- instead of reading the noise slot
+  int gen = 0;
+  uint64_t gen_seed = 0, gen_stream = 0;
+  int64_t gen_row_offset = 0;
 };
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
 int pipe_init(vb_ctx* ctx);

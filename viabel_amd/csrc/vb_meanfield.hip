@@ -30,6 +30,7 @@
 //
 // Algorithmic HBM bytes per evaluation: N*D*8 (noise) + 4*D*8 (theta, grad) + 8.
 #include "vb_common.h"
+#include "vb_rng.h"
 
 namespace vb {
 
@@ -67,6 +68,9 @@ struct Geom {
   int xcd_map;
   int rows;                // 1: per-row scalars needed
   double df;
+  int gen;                 // 1: noise generated in registers (Philox key gk0 / gk1, stream word gw, first row grow0)
+  uint32_t gk0, gk1, gw;
+  int64_t grow0;
 };
 
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
@@ -143,7 +147,13 @@ mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const Model
         const int k = model.k;
         const double muk = thk[0], sgk = exp(thk[1]);
         const double it2 = 1.0 / (model.tau * model.tau), dm1 = (double)(d - 1);
-        ek = bp.noise[b][i * g.ld + k];
+        if (g.gen) {
+          double pa, pb;
+          philox_normal_pair(g.gk0, g.gk1, (uint64_t)(g.grow0 + i), (uint32_t)(k >> 1), g.gw, &pa, &pb);
+          ek = (k & 1) ? pb : pa;
+        } else {
+          ek = bp.noise[b][i * g.ld + k];
+        }
         const double v = fma(sgk, ek, muk);
         av = wt * exp(-2.0 * v);
         const double gk = fma(-v, it2, -dm1);
@@ -236,7 +246,7 @@ __device__ __forceinline__ void accum(const double e, const double c0, const dou
   }
 }
 
-template <int MODEL, bool MOM, bool TSC, bool WEIGHTED>
+template <int MODEL, bool MOM, bool TSC, bool WEIGHTED, bool GEN = false>
 __global__ void __launch_bounds__(kMfThreads)
 mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
   const int lane = threadIdx.x & 63;
@@ -276,7 +286,30 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
   if (MODEL == VB_MODEL_GAUSS_DIAG) cp2 = *reinterpret_cast<const d2*>(colp + 2 * (int64_t)g.Dp + c0i);
   const bool cols_full = (cb + 1) * kMfCols <= ld;   // every lane's 16-B load stays inside the row
 
-  for (int64_t base = r0 + wave; base < r1; base += (int64_t)kMfWaves * kMfChunk) {
+  if (GEN) {
+    // noise in registers: the lane's two columns of row r are one Philox pair (the same counter layout as
+    // rng_normal_kernel, so the values equal what the generator kernel would have stored); nothing is read
+    const uint32_t jp = (uint32_t)(c0i >> 1);
+    const bool ok0 = c0i < g.d, ok1 = c0i + 1 < g.d;
+    for (int64_t r = r0 + wave; r < r1; r += kMfWaves) {
+      d2 ev = (d2){0.0, 0.0};
+      if (ok0) {
+        double pa, pb;
+        philox_normal_pair(g.gk0, g.gk1, (uint64_t)(g.grow0 + r), jp, g.gw, &pa, &pb);
+        ev = (d2){pa, ok1 ? pb : 0.0};
+      }
+      double a_ = 1.0, k_ = 0.0, w_ = 1.0;
+      if (MODEL == VB_MODEL_FUNNEL) {
+        a_ = rowscal[4 * r];
+        k_ = rowscal[4 * r + 1];
+      } else if (WEIGHTED) {
+        w_ = rowscal[4 * r + 2];
+      }
+      accum<MODEL, MOM, TSC, WEIGHTED>(ev.x, cp0.x, cp1.x, cp2.x, a_, k_, w_, df, A0, F, Q, QE, L1P);
+      accum<MODEL, MOM, TSC, WEIGHTED>(ev.y, cp0.y, cp1.y, cp2.y, a_, k_, w_, df, A1, F, Q, QE, L1P);
+    }
+  }
+  for (int64_t base = r0 + wave; !GEN && base < r1; base += (int64_t)kMfWaves * kMfChunk) {
     d2 e[kMfChunk];
     double av[kMfChunk], ek[kMfChunk], wt[kMfChunk];
     if (cols_full && base + (int64_t)kMfWaves * (kMfChunk - 1) < r1) {
@@ -746,8 +779,19 @@ static void launch_accum(bool weighted, const Launch& L, const BatchPtrs& bp, co
 }
 
 template <int MODEL>
+static void launch_accum_gen(bool mom, const Launch& L, const BatchPtrs& bp, const Workspace& ws, const Geom& g) {
+  if (mom)
+    hipExtLaunchKernelGGL((mf_accum_kernel<MODEL, true, false, false, true>), L.grid, dim3(kMfThreads), 0, L.st,
+                          L.ev0, L.ev1, 0, bp, ws, g);
+  else
+    hipExtLaunchKernelGGL((mf_accum_kernel<MODEL, false, false, false, true>), L.grid, dim3(kMfThreads), 0, L.st,
+                          L.ev0, L.ev1, 0, bp, ws, g);
+}
+
+template <int MODEL>
 static void launch_accum_model(bool mom, bool tsc, bool weighted, const Launch& L, const BatchPtrs& bp,
                                const Workspace& ws, const Geom& g) {
+  if (g.gen) return launch_accum_gen<MODEL>(mom, L, bp, ws, g);
   if (mom && tsc) launch_accum<MODEL, true, true>(weighted, L, bp, ws, g);
   else if (mom) launch_accum<MODEL, true, false>(weighted, L, bp, ws, g);
   else if (tsc) launch_accum<MODEL, false, true>(weighted, L, bp, ws, g);
@@ -878,6 +922,20 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   g.xcd_map = (g.n_rb % 8 == 0) ? env_int("VB_MF_XCD_MAP", 1) : 0;
   g.rows = rows ? 1 : 0;
   g.df = c.df;
+  g.gen = 0;
+  g.gk0 = g.gk1 = g.gw = 0;
+  g.grow0 = 0;
+  if (c.gen) {
+    if (c.count != 1 || c.mode != 0 || tsc || weighted || logistic || student ||
+        (model.id != VB_MODEL_GAUSS_DIAG && model.id != VB_MODEL_FUNNEL))
+      return fail(ctx, VB_ERR_UNSUPPORTED,
+                  "in-register noise: single Gaussian mean-field ELBO evaluations on gauss_diag / funnel targets");
+    g.gen = 1;
+    g.gk0 = (uint32_t)c.gen_seed;
+    g.gk1 = (uint32_t)(c.gen_seed >> 32) ^ (uint32_t)(c.gen_stream >> 32);
+    g.gw = (uint32_t)c.gen_stream;
+    g.grow0 = c.gen_row_offset;
+  }
 
   // ---- workspace layout (per evaluation) ------------------------------------------------------
   Workspace ws;

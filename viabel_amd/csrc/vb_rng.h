@@ -1,0 +1,58 @@
+// Counter-based Philox4x32-10 + Box-Muller (fp64) device functions shared by the noise generator (vb_rng.hip)
+// and by the kernels that generate their noise in registers instead of reading it (vb_meanfield.hip, GEN mode).
+// Element (global_row, col) is a pure function of (seed, stream, global_row, col): see vb_rng.hip.
+#pragma once
+
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace vb {
+
+struct Philox4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(Philox4 c, uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    // one 32 x 32 -> 64 product per word (v_mad_u64_u32) instead of a mul_hi / mul_lo pair: the quarter-rate
+    // integer multiplies are half of the generator's issue cycles
+    const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
+    Philox4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return c;
+}
+
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {
+  const uint64_t x = ((uint64_t)hi << 32) | lo;
+  return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);   // (0, 1)
+}
+
+// the two standard normals of column pair j (columns 2 j, 2 j + 1) of global row `grow`; Box-Muller with
+// sincospi (no 2 pi range reduction).  k0 / k1: key words (seed, high stream bits), w: low stream bits
+__device__ __forceinline__ void philox_normal_pair(uint32_t k0, uint32_t k1, uint64_t grow, uint32_t j, uint32_t w,
+                                                   double* a, double* b) {
+  Philox4 c;
+  c.x = (uint32_t)grow;
+  c.y = (uint32_t)(grow >> 32);
+  c.z = j;
+  c.w = w;
+  const Philox4 o = philox4x32_10(c, k0, k1);
+  const double u1 = u01(o.x, o.y), u2 = u01(o.z, o.w);
+  const double rad = sqrt(-2.0 * log(u1));
+  double s, co;
+  sincospi(2.0 * u2, &s, &co);
+  *a = rad * co;
+  *b = rad * s;
+}
+
+}  // namespace vb

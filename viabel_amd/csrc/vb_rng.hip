@@ -6,36 +6,9 @@
 // numbers.  The exact numpy legacy stream (parity mode) is drawn on the host and uploaded with
 // vb_noise_set_host instead.
 #include "vb_common.h"
+#include "vb_rng.h"
 
 namespace vb {
-
-struct Philox4 {
-  uint32_t x, y, z, w;
-};
-
-__device__ __forceinline__ Philox4 philox4x32_10(Philox4 c, uint32_t k0, uint32_t k1) {
-  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    // one 32 x 32 -> 64 product per word (v_mad_u64_u32) instead of a mul_hi / mul_lo pair: the quarter-rate
-    // integer multiplies are half of this kernel's issue cycles
-    const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
-    Philox4 n;
-    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
-    n.y = (uint32_t)p1;
-    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
-    n.w = (uint32_t)p0;
-    c = n;
-    k0 += W0;
-    k1 += W1;
-  }
-  return c;
-}
-
-__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {
-  const uint64_t x = ((uint64_t)hi << 32) | lo;
-  return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);   // (0, 1)
-}
 
 // one thread = one pair of columns (2j, 2j+1) of one row; blockIdx.y = block of kRngRows rows (no 64-bit
 // division); Box-Muller with sincospi (no 2 pi range reduction)
@@ -53,21 +26,13 @@ __global__ void __launch_bounds__(256) rng_normal_kernel(double* __restrict__ ds
     const int64_t r = r0 + u;
     if (r >= n) break;
     const uint64_t grow = (uint64_t)(row_offset + r);
-    Philox4 c;
-    c.x = (uint32_t)grow;
-    c.y = (uint32_t)(grow >> 32);
-    c.z = (uint32_t)j;
-    c.w = (uint32_t)stream;
-    const Philox4 o = philox4x32_10(c, k0, k1);
-    const double u1 = u01(o.x, o.y), u2 = u01(o.z, o.w);
-    const double rad = sqrt(-2.0 * log(u1));
-    double s, co;
-    sincospi(2.0 * u2, &s, &co);
+    double va, vb2;
+    philox_normal_pair(k0, k1, grow, (uint32_t)j, (uint32_t)stream, &va, &vb2);
     double* p = dst + r * ld + 2 * j;
     if (2 * j + 1 < d) {
-      *reinterpret_cast<double2*>(p) = make_double2(rad * co, rad * s);
+      *reinterpret_cast<double2*>(p) = make_double2(va, vb2);
     } else {
-      p[0] = rad * co;
+      p[0] = va;
     }
   }
 }
