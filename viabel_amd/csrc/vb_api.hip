@@ -874,7 +874,15 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
   static const bool gen_env = !(getenv("VB_FIT_GEN") && atoi(getenv("VB_FIT_GEN")) == 0);
   const bool gen_in_kernel = gen_env && family == VB_FAMILY_MF_GAUSSIAN && noise_kind == VB_NOISE_NORMAL &&
                              (ctx->model.id == VB_MODEL_GAUSS_DIAG || ctx->model.id == VB_MODEL_FUNNEL);
+  bool step_done = false;
+  if (meanfield) {
+    c.step = &step;
+    c.step_done = &step_done;
+  }
   for (int64_t k = 0; k < n_iters; ++k) {
+    step.k = k;
+    step.first = (k == 0 && !has_state) ? 1 : 0;
+    step_done = false;
     if (lowrank) {
       NoiseSlot& nz = ctx->noise[slot_aux];
       const uint64_t s2 = 2 * (first_stream + (uint64_t)k);
@@ -900,9 +908,7 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
       VB_HIP(ctx, hipStreamWaitEvent(st, ctx->pipe.ev_fin[ctx->pipe.last_set], 0));
       ctx->pipe.post_pending = false;
     }
-    step.k = k;
-    step.first = (k == 0 && !has_state) ? 1 : 0;
-    VB_TRY(fit_step_enqueue(ctx, step));
+    if (!step_done) VB_TRY(fit_step_enqueue(ctx, step));
   }
   VB_HIP(ctx, hipMemcpyAsync(theta, theta_dev, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpyAsync(values, base + o_val, (size_t)n_iters * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -208,6 +208,11 @@ struct MfCall {
   int gen = 0;
   uint64_t gen_seed = 0, gen_stream = 0;
   int64_t gen_row_offset = 0;
+  // device-resident fit: optimiser step to apply to (value, grad); the finalize kernel does it itself when it
+  // also computes the gradient (single GPU, no control variate) and sets *step_done, otherwise the caller launches
+  // fit_step_kernel
+  const struct FitStep* step = nullptr;
+  bool* step_done = nullptr;
 };
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
 int pipe_init(vb_ctx* ctx);

@@ -30,6 +30,7 @@
 //
 // Algorithmic HBM bytes per evaluation: N*D*8 (noise) + 4*D*8 (theta, grad) + 8.
 #include "vb_common.h"
+#include "vb_fit.h"
 #include "vb_rng.h"
 
 namespace vb {
@@ -434,6 +435,8 @@ struct EpiArgs {
   const double* value_src;  // mode 1: device scalar reported as the value (may be nullptr)
   int reduce_only;
   ModelDev model;
+  int has_step;             // device-resident fit: apply the optimiser step to the columns finished here
+  FitStep step;
 };
 
 struct Totals {
@@ -601,12 +604,19 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
     }
     const bool student = a.family == VB_FAMILY_MF_STUDENT_T;
     plain_column(a, col, g, ge, student ? S[CF_SC] : S[CF_E], student ? S[CF_SCE] : S[CF_EE], gmu, gls);
+    if (a.has_step) {       // theta_src (the step's theta) is not read by this kernel: it works on the prep copy
+      fit_step_apply(a.step, col, gmu[col]);
+      fit_step_apply(a.step, (int64_t)d + col, gls[col]);
+    }
   }
   if (blockIdx.x == 0) {
     double t_ls = 0.0;
     for (int i = threadIdx.x; i < d; i += blockDim.x) t_ls += a.theta[d + i];
     const double sum_ls = block_sum(t_ls, sh);
-    if (threadIdx.x == 0) value[0] = elbo_value(a, tot, sum_ls);
+    if (threadIdx.x == 0) {
+      value[0] = elbo_value(a, tot, sum_ls);
+      if (a.has_step) a.step.values[a.step.k] = value[0];
+    }
   }
 }
 
@@ -1064,6 +1074,13 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   e.model = model;
   const bool fused = c.mode == 0 && c.cv_mode == VB_CV_NONE && !ctx->comm;
   e.reduce_only = fused ? 0 : 1;
+  if (c.step && c.step_done) {
+    *c.step_done = fused && c.count == 1;
+    if (*c.step_done) {
+      e.has_step = 1;
+      e.step = *c.step;
+    }
+  }
   hipLaunchKernelGGL(mf_finalize_kernel, dim3((unsigned)(g.Dp / 64), (unsigned)c.count), dim3(256), 0,
                      st_post, e, bp, ws);
   VB_HIP(ctx, hipGetLastError());
