@@ -321,7 +321,7 @@ def test_full_size_properties(vb):
 
 @pytest.mark.parametrize('df', [3.5, 8.0, 100.0])
 def test_philox_student_t_noise(vb, df):
-    """Device Student-t base noise (Philox + Marsaglia-Tsang gamma): distribution, shard invariance, and the
+    """Device Student-t base noise (Philox + Bailey's polar method): distribution, shard invariance, and the
     MFStudentT objective on it equals the oracle on the same draws."""
     from scipy import stats
     from viabel_amd import _lib

@@ -37,10 +37,12 @@ __global__ void __launch_bounds__(256) rng_normal_kernel(double* __restrict__ ds
   }
 }
 
-// Standard Student-t noise (the base draws of MFStudentT.sample, viabel/approximations.py:270-274):
-// t = n / sqrt(chi2_df / df), chi2_df = 2 Gamma(df / 2) by Marsaglia-Tsang (df > 2, so shape >= 1).  The
-// numerator pair of a thread comes from Philox sub-stream 0, the gamma attempts of column e from sub-streams
-// 1 + 2 (attempt) + e; every value is a pure function of (seed, stream, global row, column).
+// Standard Student-t noise (the base draws of MFStudentT.sample, viabel/approximations.py:270-274) by Bailey's polar
+// method (Math. Comp. 62 (1994) 779-781): (u, v) uniform on the unit disc, w = u^2 + v^2,
+//     t = u sqrt(df (w^(-2/df) - 1) / w)
+// is exactly t_df distributed for every df > 0 -- one Philox call per attempt (acceptance pi / 4), one log / expm1,
+// one sqrt; no gamma variate.  Attempt a of column e of pair j uses Philox sub-stream 2 a + e, so every value is a
+// pure function of (seed, stream, global row, column).
 __device__ __forceinline__ Philox4 philox_sub(uint64_t grow, uint32_t j, uint32_t stream, uint32_t sub, uint32_t k0,
                                               uint32_t k1) {
   Philox4 c;
@@ -51,22 +53,17 @@ __device__ __forceinline__ Philox4 philox_sub(uint64_t grow, uint32_t j, uint32_
   return philox4x32_10(c, k0, k1 ^ (0x85EBCA6Bu * sub));
 }
 
-__device__ double gamma_mt(double shape, uint64_t grow, uint32_t j, uint32_t stream, uint32_t e, uint32_t k0,
-                           uint32_t k1) {
-  const double d = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
-  double v = 1.0;
+__device__ double student_t_polar(double df, uint64_t grow, uint32_t j, uint32_t stream, uint32_t e, uint32_t k0,
+                                  uint32_t k1) {
+  double u = 0.0, w = 1.0;
   for (uint32_t attempt = 0; attempt < 64; ++attempt) {
-    const Philox4 o = philox_sub(grow, j, stream, 1 + 2 * attempt + e, k0, k1);
-    const Philox4 o2 = philox_sub(grow, j, stream, 0x40000000u + 2 * attempt + e, k0, k1);
-    const double x = sqrt(-2.0 * log(u01(o.x, o.y))) * cospi(2.0 * u01(o.z, o.w));
-    const double t = 1.0 + c * x;
-    if (t <= 0.0) continue;
-    v = t * t * t;
-    const double u = u01(o2.x, o2.y), x2 = x * x;
-    if (u < 1.0 - 0.0331 * x2 * x2) break;
-    if (log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) break;
+    const Philox4 o = philox_sub(grow, j, stream, 2 * attempt + e, k0, k1);
+    u = 2.0 * u01(o.x, o.y) - 1.0;
+    const double v = 2.0 * u01(o.z, o.w) - 1.0;
+    w = fma(u, u, v * v);
+    if (w <= 1.0 && w > 0.0) break;
   }
-  return d * v;
+  return u * sqrt(df * expm1(-2.0 / df * log(w)) / w);
 }
 
 __global__ void __launch_bounds__(256) rng_student_t_kernel(double* __restrict__ dst, int64_t ld, double df,
@@ -76,19 +73,14 @@ __global__ void __launch_bounds__(256) rng_student_t_kernel(double* __restrict__
   const int pairs = (int)((d + 1) / 2);
   if (j >= pairs) return;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32);
-  const double half = 0.5 * df;
   const int64_t r0 = (int64_t)blockIdx.y * kRngRows;
   for (int u = 0; u < kRngRows; ++u) {
     const int64_t r = r0 + u;
     if (r >= n) break;
     const uint64_t grow = (uint64_t)(row_offset + r);
-    const Philox4 o = philox_sub(grow, (uint32_t)j, (uint32_t)stream, 0, k0, k1);
-    const double rad = sqrt(-2.0 * log(u01(o.x, o.y)));
-    double s, co;
-    sincospi(2.0 * u01(o.z, o.w), &s, &co);
     double* p = dst + r * ld + 2 * j;
-    p[0] = rad * co * sqrt(half / gamma_mt(half, grow, (uint32_t)j, (uint32_t)stream, 0, k0, k1));
-    if (2 * j + 1 < d) p[1] = rad * s * sqrt(half / gamma_mt(half, grow, (uint32_t)j, (uint32_t)stream, 1, k0, k1));
+    p[0] = student_t_polar(df, grow, (uint32_t)j, (uint32_t)stream, 0, k0, k1);
+    if (2 * j + 1 < d) p[1] = student_t_polar(df, grow, (uint32_t)j, (uint32_t)stream, 1, k0, k1);
   }
 }
 
