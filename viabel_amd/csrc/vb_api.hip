@@ -872,8 +872,10 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
     c.cv_mode = cv_mode;
   }
   static const bool gen_env = !(getenv("VB_FIT_GEN") && atoi(getenv("VB_FIT_GEN")) == 0);
-  const bool gen_in_kernel = gen_env && family == VB_FAMILY_MF_GAUSSIAN && noise_kind == VB_NOISE_NORMAL &&
-                             (ctx->model.id == VB_MODEL_GAUSS_DIAG || ctx->model.id == VB_MODEL_FUNNEL);
+  const bool gen_in_kernel =
+      gen_env && (ctx->model.id == VB_MODEL_GAUSS_DIAG || ctx->model.id == VB_MODEL_FUNNEL) &&
+      ((family == VB_FAMILY_MF_GAUSSIAN && noise_kind == VB_NOISE_NORMAL) ||
+       (family == VB_FAMILY_MF_STUDENT_T && noise_kind == VB_NOISE_STUDENT_T && noise_df == df));
   bool step_done = false;
   if (meanfield) {
     c.step = &step;

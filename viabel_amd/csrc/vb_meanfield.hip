@@ -69,7 +69,9 @@ struct Geom {
   int xcd_map;
   int rows;                // 1: per-row scalars needed
   double df;
-  int gen;                 // 1: noise generated in registers (Philox key gk0 / gk1, stream word gw, first row grow0)
+  int gen;                 // 1 / 2: Gaussian / Student-t (df = gdf) noise generated in registers (Philox key gk0 / gk1,
+                           // stream word gw, first row grow0)
+  double gdf;
   uint32_t gk0, gk1, gw;
   int64_t grow0;
 };
@@ -148,7 +150,9 @@ mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const Model
         const int k = model.k;
         const double muk = thk[0], sgk = exp(thk[1]);
         const double it2 = 1.0 / (model.tau * model.tau), dm1 = (double)(d - 1);
-        if (g.gen) {
+        if (g.gen == 2) {
+          ek = student_t_polar(g.gdf, (uint64_t)(g.grow0 + i), (uint32_t)(k >> 1), g.gw, (uint32_t)(k & 1), g.gk0, g.gk1);
+        } else if (g.gen) {
           double pa, pb;
           philox_normal_pair(g.gk0, g.gk1, (uint64_t)(g.grow0 + i), (uint32_t)(k >> 1), g.gw, &pa, &pb);
           ek = (k & 1) ? pb : pa;
@@ -294,7 +298,11 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
     const bool ok0 = c0i < g.d, ok1 = c0i + 1 < g.d;
     for (int64_t r = r0 + wave; r < r1; r += kMfWaves) {
       d2 ev = (d2){0.0, 0.0};
-      if (ok0) {
+      if (ok0 && g.gen == 2) {
+        const uint64_t grow = (uint64_t)(g.grow0 + r);
+        ev.x = student_t_polar(g.gdf, grow, jp, g.gw, 0, g.gk0, g.gk1);
+        if (ok1) ev.y = student_t_polar(g.gdf, grow, jp, g.gw, 1, g.gk0, g.gk1);
+      } else if (ok0) {
         double pa, pb;
         philox_normal_pair(g.gk0, g.gk1, (uint64_t)(g.grow0 + r), jp, g.gw, &pa, &pb);
         ev = (d2){pa, ok1 ? pb : 0.0};
@@ -789,8 +797,15 @@ static void launch_accum(bool weighted, const Launch& L, const BatchPtrs& bp, co
 }
 
 template <int MODEL>
-static void launch_accum_gen(bool mom, const Launch& L, const BatchPtrs& bp, const Workspace& ws, const Geom& g) {
-  if (mom)
+static void launch_accum_gen(bool mom, bool tsc, const Launch& L, const BatchPtrs& bp, const Workspace& ws,
+                             const Geom& g) {
+  if (mom && tsc)
+    hipExtLaunchKernelGGL((mf_accum_kernel<MODEL, true, true, false, true>), L.grid, dim3(kMfThreads), 0, L.st,
+                          L.ev0, L.ev1, 0, bp, ws, g);
+  else if (tsc)
+    hipExtLaunchKernelGGL((mf_accum_kernel<MODEL, false, true, false, true>), L.grid, dim3(kMfThreads), 0, L.st,
+                          L.ev0, L.ev1, 0, bp, ws, g);
+  else if (mom)
     hipExtLaunchKernelGGL((mf_accum_kernel<MODEL, true, false, false, true>), L.grid, dim3(kMfThreads), 0, L.st,
                           L.ev0, L.ev1, 0, bp, ws, g);
   else
@@ -801,7 +816,7 @@ static void launch_accum_gen(bool mom, const Launch& L, const BatchPtrs& bp, con
 template <int MODEL>
 static void launch_accum_model(bool mom, bool tsc, bool weighted, const Launch& L, const BatchPtrs& bp,
                                const Workspace& ws, const Geom& g) {
-  if (g.gen) return launch_accum_gen<MODEL>(mom, L, bp, ws, g);
+  if (g.gen) return launch_accum_gen<MODEL>(mom, tsc, L, bp, ws, g);
   if (mom && tsc) launch_accum<MODEL, true, true>(weighted, L, bp, ws, g);
   else if (mom) launch_accum<MODEL, true, false>(weighted, L, bp, ws, g);
   else if (tsc) launch_accum<MODEL, false, true>(weighted, L, bp, ws, g);
@@ -935,12 +950,13 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   g.gen = 0;
   g.gk0 = g.gk1 = g.gw = 0;
   g.grow0 = 0;
+  g.gdf = c.df;
   if (c.gen) {
-    if (c.count != 1 || c.mode != 0 || tsc || weighted || logistic || student ||
+    if (c.count != 1 || c.mode != 0 || weighted || logistic ||
         (model.id != VB_MODEL_GAUSS_DIAG && model.id != VB_MODEL_FUNNEL))
       return fail(ctx, VB_ERR_UNSUPPORTED,
-                  "in-register noise: single Gaussian mean-field ELBO evaluations on gauss_diag / funnel targets");
-    g.gen = 1;
+                  "in-register noise: single mean-field ELBO evaluations on gauss_diag / funnel targets");
+    g.gen = student ? 2 : 1;     // the family's own base noise: t_df for MFStudentT
     g.gk0 = (uint32_t)c.gen_seed;
     g.gk1 = (uint32_t)(c.gen_seed >> 32) ^ (uint32_t)(c.gen_stream >> 32);
     g.gw = (uint32_t)c.gen_stream;

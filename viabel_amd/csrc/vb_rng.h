@@ -55,4 +55,28 @@ __device__ __forceinline__ void philox_normal_pair(uint32_t k0, uint32_t k1, uin
   *b = rad * s;
 }
 
+// Student-t by Bailey's polar method (see vb_rng.hip)
+__device__ __forceinline__ Philox4 philox_sub(uint64_t grow, uint32_t j, uint32_t stream, uint32_t sub, uint32_t k0,
+                                              uint32_t k1) {
+  Philox4 c;
+  c.x = (uint32_t)grow;
+  c.y = (uint32_t)(grow >> 32);
+  c.z = j;
+  c.w = stream + 0x9E3779B9u * sub;
+  return philox4x32_10(c, k0, k1 ^ (0x85EBCA6Bu * sub));
+}
+
+__device__ __forceinline__ double student_t_polar(double df, uint64_t grow, uint32_t j, uint32_t stream, uint32_t e, uint32_t k0,
+                                  uint32_t k1) {
+  double u = 0.0, w = 1.0;
+  for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+    const Philox4 o = philox_sub(grow, j, stream, 2 * attempt + e, k0, k1);
+    u = 2.0 * u01(o.x, o.y) - 1.0;
+    const double v = 2.0 * u01(o.z, o.w) - 1.0;
+    w = fma(u, u, v * v);
+    if (w <= 1.0 && w > 0.0) break;
+  }
+  return u * sqrt(df * expm1(-2.0 / df * log(w)) / w);
+}
+
 }  // namespace vb

@@ -43,29 +43,6 @@ __global__ void __launch_bounds__(256) rng_normal_kernel(double* __restrict__ ds
 // is exactly t_df distributed for every df > 0 -- one Philox call per attempt (acceptance pi / 4), one log / expm1,
 // one sqrt; no gamma variate.  Attempt a of column e of pair j uses Philox sub-stream 2 a + e, so every value is a
 // pure function of (seed, stream, global row, column).
-__device__ __forceinline__ Philox4 philox_sub(uint64_t grow, uint32_t j, uint32_t stream, uint32_t sub, uint32_t k0,
-                                              uint32_t k1) {
-  Philox4 c;
-  c.x = (uint32_t)grow;
-  c.y = (uint32_t)(grow >> 32);
-  c.z = j;
-  c.w = stream + 0x9E3779B9u * sub;
-  return philox4x32_10(c, k0, k1 ^ (0x85EBCA6Bu * sub));
-}
-
-__device__ double student_t_polar(double df, uint64_t grow, uint32_t j, uint32_t stream, uint32_t e, uint32_t k0,
-                                  uint32_t k1) {
-  double u = 0.0, w = 1.0;
-  for (uint32_t attempt = 0; attempt < 64; ++attempt) {
-    const Philox4 o = philox_sub(grow, j, stream, 2 * attempt + e, k0, k1);
-    u = 2.0 * u01(o.x, o.y) - 1.0;
-    const double v = 2.0 * u01(o.z, o.w) - 1.0;
-    w = fma(u, u, v * v);
-    if (w <= 1.0 && w > 0.0) break;
-  }
-  return u * sqrt(df * expm1(-2.0 / df * log(w)) / w);
-}
-
 __global__ void __launch_bounds__(256) rng_student_t_kernel(double* __restrict__ dst, int64_t ld, double df,
                                                             uint64_t seed, uint64_t stream, int64_t row_offset,
                                                             int64_t n, int64_t d) {
