@@ -113,6 +113,12 @@ int vb_elbo_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t 
                            int cv_mode, double* value, double* grad);
 /* Same, enqueued without waiting: results land in result slot `rslot`; fetch them with
  * vb_result_get after vb_sync.  Lets a caller keep several evaluations in flight.       */
+/* The same evaluation on fresh device noise without materialising it: element (row_offset + i, j) of Philox stream
+ * (seed, stream) -- exactly what vb_noise_generate(kind = the family's base noise) would have written to `slot` --
+ * is generated in registers by the streaming kernel (gauss_diag / funnel targets; `slot` only fixes the geometry). */
+int vb_elbo_grad_meanfield_philox(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t row_offset,
+                                  int family, double df, const double* theta, unsigned flags, int cv_mode,
+                                  uint64_t seed, uint64_t stream, double* value, double* grad);
 int vb_elbo_grad_meanfield_async(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
                                  int family, double df, const double* theta, unsigned flags,
                                  int cv_mode, int rslot);

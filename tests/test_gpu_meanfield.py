@@ -227,11 +227,20 @@ def test_philox_objective_matches_oracle_on_same_noise(vb):
     approx = vb.MFGaussian(D, seed=7, rng='philox')
     model = vb.FunnelModel(D)
     theta = _theta(D, np.random.RandomState(2))
-    value, grad = vb.ExclusiveKL(approx, model, N)(theta)
     eng = _lib.default_engine()
-    noise = eng.noise_get_host(0, N, D)        # what the kernel consumed
-    ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omod.Funnel(D), theta, noise)
-    assert G.rel_err(value, ov) < 1e-12 and G.rel_err(grad, og) < 1e-11
+    for call in range(2):
+        value, grad = vb.ExclusiveKL(approx, model, N)(theta)
+        # the kernel generated its noise in registers (call c of the family = Philox stream c); the generator
+        # kernel produces the same matrix
+        eng.noise_generate(9, N, D, seed=7, stream=call)
+        noise = eng.noise_get_host(9, N, D)
+        ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omod.Funnel(D), theta, noise)
+        assert G.rel_err(value, ov) < 1e-12 and G.rel_err(grad, og) < 1e-11
+    # control-variate estimators take the same route
+    value, grad = vb.ExclusiveKL(approx, model, N, hessian_approx_method='loo_diag_approx')(theta)
+    eng.noise_generate(9, N, D, seed=7, stream=2)
+    ov, og = oobj.rge_reduced(ofam.MFGaussian(D), omod.Funnel(D), theta, eng.noise_get_host(9, N, D), 'loo_diag_approx')
+    assert G.rel_err(value, ov) < 1e-12 and G.rel_err(grad, og) < 1e-10
 
 
 def test_async_pipeline_matches_sync(vb):

@@ -75,6 +75,10 @@ SIGNATURES = {
                                              ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_mvt_path_terms': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'vb_elbo_grad_meanfield_philox': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                                     ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
+                                                     _c_double_p, ctypes.c_uint, ctypes.c_int, ctypes.c_uint64,
+                                                     ctypes.c_uint64, _c_double_p, _c_double_p]),
     'vb_fit': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                               ctypes.c_int, ctypes.c_double, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
                               ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _c_double_p,
@@ -308,6 +312,18 @@ class Engine:
                                                _dptr(mu), _dptr(sqrt_sigma), _dptr(inv_s), ctypes.byref(f),
                                                _dptr(g), _dptr(c)))
         return f.value, g, c
+
+    def elbo_grad_meanfield_philox(self, slot, n, d, theta, family, seed, stream, df=0.0, flags=0, cv_mode=0,
+                                   n_total=None, row_offset=0):
+        """ExclusiveKL on fresh Philox noise generated inside the streaming kernel
+        (``vb_elbo_grad_meanfield_philox``)."""
+        theta = _f64(theta)
+        value = ctypes.c_double(0.0)
+        grad = np.empty(2 * d, dtype=np.float64)
+        self._check(self._lib.vb_elbo_grad_meanfield_philox(
+            self._ctx, slot, n, d, n if n_total is None else n_total, int(row_offset), family, float(df),
+            _dptr(theta), flags, cv_mode, int(seed), int(stream), ctypes.byref(value), _dptr(grad)))
+        return value.value, grad
 
     # ------------------------------------------------------------------ ExclusiveKL, low-rank Gaussian
     def elbo_grad_lowrank(self, slot_eps, slot_z, n, d, k, theta, flags=0, n_total=None):

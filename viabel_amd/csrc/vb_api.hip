@@ -421,9 +421,15 @@ int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, doubl
 // ---- ExclusiveKL, mean field ------------------------------------------------------------------
 // Enqueue `count` independent evaluations: evaluation b streams noise slot slots[b] with parameter
 // thetas[b * 2d ...] and lands in result slot *rs[b].
+struct GenNoise {            // in-register noise of a single evaluation (MfCall::gen)
+  uint64_t seed, stream;
+  int64_t row_offset;
+};
+
 static int mf_call(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t d, int64_t n_total,
                    int family, double df, const double* thetas, unsigned flags, int cv_mode,
-                   ResultSlot** rs, bool pipelined, bool overlap_comm = false, bool alternate = false) {
+                   ResultSlot** rs, bool pipelined, bool overlap_comm = false, bool alternate = false,
+                   const GenNoise* gen = nullptr) {
   if (!ctx || !thetas || !slots) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (count < 1) return fail(ctx, VB_ERR_INVALID, "count must be positive");
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
@@ -452,6 +458,12 @@ static int mf_call(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t 
     c.pipelined = pipelined;
     c.overlap_comm = overlap_comm;
     c.alternate = alternate;
+    if (gen) {
+      c.gen = 1;
+      c.gen_seed = gen->seed;
+      c.gen_stream = gen->stream;
+      c.gen_row_offset = gen->row_offset;
+    }
     VB_TRY(mf_enqueue(ctx, c));
     VB_TRY(ticket(ctx, rs + b0, c.count));
   }
@@ -464,6 +476,23 @@ int vb_elbo_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t 
   if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   ResultSlot* rs = &ctx->sync_result;
   VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs, false));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rs->pending = false;
+  *value = rs->host[rs->p];
+  memcpy(grad, rs->host + rs->p + 1, (size_t)(2 * d) * sizeof(double));
+  return VB_OK;
+}
+
+int vb_elbo_grad_meanfield_philox(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int64_t row_offset,
+                                  int family, double df, const double* theta, unsigned flags, int cv_mode,
+                                  uint64_t seed, uint64_t stream, double* value, double* grad) {
+  if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  VB_TRY(noise_alloc(ctx, slot, n, d));      // geometry only: the noise itself stays in registers
+  ResultSlot* rs = &ctx->sync_result;
+  const GenNoise gen{seed, stream, row_offset};
+  VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs, false, false, false, &gen));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rs->pending = false;
   *value = rs->host[rs->p];

@@ -161,9 +161,17 @@ class ExclusiveKL(StochasticVariationalObjective):
                 if var_param.shape != (approx.var_param_dim,):
                     raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
                 eng = self._engine()
-                eng.set_model(self.model.device_spec())
-                n_local, n_total = self._stage_noise(eng, self.num_mc_samples)
+                spec = self.model.device_spec()
+                eng.set_model(spec)
                 family, df = approx._device_family()
+                if approx.rng == 'philox' and spec[0] in (_lib.MODEL_GAUSS_DIAG, _lib.MODEL_FUNNEL):
+                    # fresh device noise is consumed where it is generated: it never goes through HBM
+                    N = self.num_mc_samples
+                    begin, end = shard_rows(N, eng.n_ranks, eng.rank)
+                    return eng.elbo_grad_meanfield_philox(
+                        _NOISE_SLOT, end - begin, approx.dim, var_param, family, approx._seed,
+                        approx._next_philox_stream(), df=df, flags=flags, cv_mode=cv_mode, n_total=N, row_offset=begin)
+                n_local, n_total = self._stage_noise(eng, self.num_mc_samples)
                 return eng.elbo_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, var_param, family,
                                                df=df, flags=flags, cv_mode=cv_mode, n_total=n_total)
         elif isinstance(approx, FullRankGaussian):
