@@ -259,6 +259,12 @@ def main():
     for i in range(n_sync):
         eng.elbo_grad_meanfield(i % ring, N_MC, D, theta, fam, n_total=n_total)
     sync_rate = n_sync / (time.perf_counter() - t2)
+    # the same blocking call on FRESH noise generated inside the streaming kernel (Philox + Box-Muller in
+    # registers: what an optimiser loop in rng='philox' mode issues every iteration)
+    t3 = time.perf_counter()
+    for i in range(n_sync):
+        eng.elbo_grad_meanfield_philox(0, N_MC, D, theta, fam, 1, 1000 + i, n_total=n_total, row_offset=rank * N_MC)
+    fresh_rate = n_sync / (time.perf_counter() - t3)
 
     if dist is not None:
         import torch
@@ -293,6 +299,7 @@ def main():
                               'one-evaluation blocking-call rate is sync_call_evals_per_s' % (batch, n_eng),
             },
             'sync_call_evals_per_s': world * sync_rate,
+            'fresh_noise_sync_call_evals_per_s': world * fresh_rate,
             'check': {'value': last_value, 'grad_norm': float(np.linalg.norm(last_grad))},
             'roofline': {
                 'bound': 'hbm', 'kernel': 'mf_accum_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
