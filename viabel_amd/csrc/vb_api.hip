@@ -905,10 +905,11 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
       gen_env && (ctx->model.id == VB_MODEL_GAUSS_DIAG || ctx->model.id == VB_MODEL_FUNNEL) &&
       ((family == VB_FAMILY_MF_GAUSSIAN && noise_kind == VB_NOISE_NORMAL) ||
        (family == VB_FAMILY_MF_STUDENT_T && noise_kind == VB_NOISE_STUDENT_T && noise_df == df));
-  bool step_done = false;
+  bool step_done = false, prep_done = false;
   if (meanfield) {
     c.step = &step;
     c.step_done = &step_done;
+    c.prep_done = &prep_done;
   }
   for (int64_t k = 0; k < n_iters; ++k) {
     step.k = k;
@@ -922,6 +923,9 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
       VB_TRY(lr_elbo_grad_enqueue(ctx, ns, nz, n, d, lr_k, n_total, theta_dev, out_dev));
     } else if (gen_in_kernel) {
       // single-use Gaussian noise never touches HBM: the streaming kernel generates it in registers
+      c.skip_prep = prep_done;                 // done by the previous iteration's finalize kernel
+      c.prep_next = k + 1 < n_iters;
+      prep_done = false;
       c.gen = 1;
       c.gen_seed = seed;
       c.gen_stream = first_stream + (uint64_t)k;

@@ -213,6 +213,10 @@ struct MfCall {
   // fit_step_kernel
   const struct FitStep* step = nullptr;
   bool* step_done = nullptr;
+  // ... and, with in-register noise, the prep of the NEXT iteration (its theta is final once the step is applied):
+  // prep_next asks for it, *prep_done reports it, skip_prep tells the next call that its prep has been done
+  bool prep_next = false, skip_prep = false;
+  bool* prep_done = nullptr;
 };
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
 int pipe_init(vb_ctx* ctx);

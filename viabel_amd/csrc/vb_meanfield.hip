@@ -99,56 +99,52 @@ __device__ __forceinline__ double block_sum(double x, double* sh) {
 // ------------------------------------------------------------------------------------------------
 // prep
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const ModelDev model) {
-  __shared__ double sh[4][PS_NUM];
-  const int b = blockIdx.y;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// column part: device copy of theta and the per-column constants of column i (i < Dp; zeros for the pad columns)
+__device__ __forceinline__ void prep_column(int64_t i, double mu, double ls, double* wsb, const Workspace& ws,
+                                            const Geom& g, const ModelDev& model) {
+  const int d = g.d;
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+  if (i < d) {
+    wsb[ws.off_theta + i] = mu;
+    wsb[ws.off_theta + d + i] = ls;
+    const double sg = exp(ls);
+    if (model.id == kModelLogQ) {   // p0 = mu_r, p1 = sigma_r of the refresh parameter
+      c0 = (model.p0[i] - mu) / sg;
+      c1 = model.p1[i] / sg;
+    } else if (model.id == VB_MODEL_FUNNEL) {
+      // the coupling column contributes through the per-row sums below, not elementwise
+      c0 = (i == model.k) ? 0.0 : mu;
+      c1 = (i == model.k) ? 0.0 : sg;
+    } else {
+      c0 = mu - model.p0[i];
+      c1 = sg;
+      c2 = model.p1[i];
+    }
+  }
+  double* colp = wsb + ws.off_colp;
+  colp[i] = c0;
+  colp[g.Dp + i] = c1;
+  colp[2 * (int64_t)g.Dp + i] = c2;
+}
+
+// row part of prep block `blk` of `nblk` (rows blk * 256 + t): per-row scalars and the block's partial sums of the
+// terms that involve the coupling column only; (muk, lsk) = theta of the funnel's coupling column.  All 256
+// threads of the workgroup take part (one barrier inside).
+__device__ __forceinline__ void prep_rows_block(int blk, int nblk, double* wsb, const Workspace& ws, const Geom& g,
+                                                const ModelDev& model, const double* __restrict__ noise,
+                                                const double* __restrict__ roww, double muk, double lsk,
+                                                double (*sh)[PS_NUM]) {
+  const int64_t i = (int64_t)blk * 256 + threadIdx.x;
   const int d = g.d;
   const bool funnel = model.id == VB_MODEL_FUNNEL;
-  double* wsb = ws.base + b * ws.stride;
-  const double* theta_src = bp.theta_src[b];
-  if (i < g.Dp) {
-    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-    if (i < d) {
-      const double mu = theta_src[i], ls = theta_src[d + i];
-      wsb[ws.off_theta + i] = mu;
-      wsb[ws.off_theta + d + i] = ls;
-      const double sg = exp(ls);
-      if (model.id == kModelLogQ) {   // p0 = mu_r, p1 = sigma_r of the refresh parameter
-        c0 = (model.p0[i] - mu) / sg;
-        c1 = model.p1[i] / sg;
-      } else if (funnel) {
-        // the coupling column contributes through the per-row sums below, not elementwise
-        c0 = (i == model.k) ? 0.0 : mu;
-        c1 = (i == model.k) ? 0.0 : sg;
-      } else {
-        c0 = mu - model.p0[i];
-        c1 = sg;
-        c2 = model.p1[i];
-      }
-    }
-    double* colp = wsb + ws.off_colp;
-    colp[i] = c0;
-    colp[g.Dp + i] = c1;
-    colp[2 * (int64_t)g.Dp + i] = c2;
-  }
   double W = 0.0, FK = 0.0, GK = 0.0, GEK = 0.0;
   if (g.rows) {
-    // theta lives in pinned host memory: one lane fetches the coupling column's (mu, log sigma) across
-    // PCIe and broadcasts them through LDS instead of every wave issuing its own host reads
-    __shared__ double thk[2];
-    if (funnel) {
-      if (threadIdx.x < 2) thk[threadIdx.x] = theta_src[threadIdx.x * d + model.k];
-      __syncthreads();
-    }
     if (i < g.n) {
-      const double* roww = bp.roww[b];
       const double wt = roww ? roww[i] : 1.0;
       double av = wt, ek = 0.0;
       if (funnel) {
         const int k = model.k;
-        const double muk = thk[0], sgk = exp(thk[1]);
+        const double sgk = exp(lsk);
         const double it2 = 1.0 / (model.tau * model.tau), dm1 = (double)(d - 1);
         if (g.gen == 2) {
           ek = student_t_polar(g.gdf, (uint64_t)(g.grow0 + i), (uint32_t)(k >> 1), g.gw, (uint32_t)(k & 1), g.gk0, g.gk1);
@@ -157,7 +153,7 @@ mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const Model
           philox_normal_pair(g.gk0, g.gk1, (uint64_t)(g.grow0 + i), (uint32_t)(k >> 1), g.gw, &pa, &pb);
           ek = (k & 1) ? pb : pa;
         } else {
-          ek = bp.noise[b][i * g.ld + k];
+          ek = noise[i * g.ld + k];
         }
         const double v = fma(sgk, ek, muk);
         av = wt * exp(-2.0 * v);
@@ -188,8 +184,33 @@ mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const Model
   }
   __syncthreads();
   if (threadIdx.x < PS_NUM)
-    wsb[ws.off_prepscal + (int64_t)threadIdx.x * gridDim.x + blockIdx.x] =
+    wsb[ws.off_prepscal + (int64_t)threadIdx.x * nblk + blk] =
         (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256)
+mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const ModelDev model) {
+  __shared__ double sh[4][PS_NUM];
+  const int b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int d = g.d;
+  double* wsb = ws.base + b * ws.stride;
+  const double* theta_src = bp.theta_src[b];
+  if (i < g.Dp) {
+    double mu = 0.0, ls = 0.0;
+    if (i < d) mu = theta_src[i], ls = theta_src[d + i];
+    prep_column(i, mu, ls, wsb, ws, g, model);
+  }
+  // theta lives in pinned host memory: one lane fetches the coupling column's (mu, log sigma) across PCIe and
+  // broadcasts them through LDS instead of every wave issuing its own host reads
+  __shared__ double thk[2];
+  thk[0] = thk[1] = 0.0;
+  if (g.rows && model.id == VB_MODEL_FUNNEL) {
+    __syncthreads();
+    if (threadIdx.x < 2) thk[threadIdx.x] = theta_src[threadIdx.x * d + model.k];
+    __syncthreads();
+  }
+  prep_rows_block((int)blockIdx.x, (int)gridDim.x, wsb, ws, g, model, bp.noise[b], bp.roww[b], thk[0], thk[1], sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,6 +466,9 @@ struct EpiArgs {
   ModelDev model;
   int has_step;             // device-resident fit: apply the optimiser step to the columns finished here
   FitStep step;
+  int prep_next;            // ... and prepare the next iteration (mf_prep_kernel's work) in its workspace set
+  double* next_wsb;
+  Geom next_g;              // geometry of the next iteration: the same shapes, the next Philox stream
 };
 
 struct Totals {
@@ -549,6 +573,8 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
   __shared__ double colsum[CF_NUM + 1][4][64];
   __shared__ double sh[4];
   __shared__ double sh2[4][KS_NUM + PS_NUM];
+  __shared__ double sh3[4][PS_NUM];
+  __shared__ double thk_next[2];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + c;
   const int Dp = a.Dp;
@@ -615,6 +641,29 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
     if (a.has_step) {       // theta_src (the step's theta) is not read by this kernel: it works on the prep copy
       fit_step_apply(a.step, col, gmu[col]);
       fit_step_apply(a.step, (int64_t)d + col, gls[col]);
+    }
+  }
+  if (a.prep_next) {
+    // prep of the next iteration (see mf_prep_kernel) for the columns this workgroup has just stepped ...
+    if (q == 0) {
+      double mu = 0.0, ls = 0.0;
+      if (col < d) {
+        mu = a.step.theta[col];
+        ls = a.step.theta[d + col];
+        if (funnel && col == k) thk_next[0] = mu, thk_next[1] = ls;
+      }
+      prep_column(col, mu, ls, a.next_wsb, ws, a.next_g, a.model);
+    }
+    // ... and its row part: by the workgroup that owns the funnel's coupling column (the per-row scalars need
+    // that column's new parameter only), block by block in the prep kernel's own order so that the partial sums
+    // are the same numbers; without row scalars workgroup 0 writes the constant partials
+    if (a.next_g.rows ? owns_k : blockIdx.x == 0) {
+      __syncthreads();
+      const double muk = a.next_g.rows ? thk_next[0] : 0.0, lsk = a.next_g.rows ? thk_next[1] : 0.0;
+      for (int blk = 0; blk < a.n_prep; ++blk) {
+        prep_rows_block(blk, a.n_prep, a.next_wsb, ws, a.next_g, a.model, nullptr, nullptr, muk, lsk, sh3);
+        __syncthreads();
+      }
     }
   }
   if (blockIdx.x == 0) {
@@ -1041,7 +1090,7 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
     P.post_pending = false;
   }
 
-  if (!logistic) {
+  if (!logistic && !c.skip_prep) {   // skip_prep: the previous iteration's finalize kernel has done it
     hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)g.n_prep, (unsigned)c.count), dim3(256), 0, st_pre,
                        bp, ws, g, model);
     VB_HIP(ctx, hipGetLastError());
@@ -1095,6 +1144,20 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
     if (*c.step_done) {
       e.has_step = 1;
       e.step = *c.step;
+    }
+  }
+  if (c.prep_done) {
+    // the row part (funnel) is done by ONE workgroup, block after block: worth it only while that is shorter than a
+    // launch (measured: 16 blocks add 17 us at N = 4096, four or fewer are hidden)
+    *c.prep_done = c.prep_next && e.has_step && g.gen && !weighted && !logistic && (!g.rows || g.n_prep <= 4);
+    if (*c.prep_done) {
+      e.prep_next = 1;
+      const int next_set = (int)(ctx->pipe.seq % kPipeSets);   // the set the next mf_enqueue will pick
+      e.next_wsb = (double*)ctx->workspace.ptr + (size_t)next_set * ws.stride * kMaxBatch;
+      e.next_g = g;
+      const uint64_t next_stream = c.gen_stream + 1;
+      e.next_g.gk1 = (uint32_t)(c.gen_seed >> 32) ^ (uint32_t)(next_stream >> 32);
+      e.next_g.gw = (uint32_t)next_stream;
     }
   }
   hipLaunchKernelGGL(mf_finalize_kernel, dim3((unsigned)(g.Dp / 64), (unsigned)c.count), dim3(256), 0,
