@@ -173,7 +173,10 @@ def main():
             os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29531')
         dist.init_process_group(backend='gloo')
     eng = _lib.default_engine()
-    if use_comm:
+    # VB_BENCH_NO_RCCL=1: control-flow dry run of the N > 1 branches on a box with fewer GPUs than ranks (the ranks
+    # then share a device, RCCL refuses that, and no communicator is attached: the numbers mean nothing)
+    no_rccl = world > 1 and os.environ.get('VB_BENCH_NO_RCCL') == '1'
+    if use_comm and not no_rccl:
         if world > 1:
             distributed.attach(eng)
         else:
@@ -184,7 +187,7 @@ def main():
     n_total = N_MC * world
     batch = max(1, min(args.batch, 32))
     engines = [eng] + [_lib.Engine(eng.device) for _ in range(max(1, args.engines) - 1)]
-    if world > 1:
+    if world > 1 and not no_rccl:
         for e in engines[1:]:
             distributed.attach(e)
     elif use_comm:
