@@ -260,3 +260,22 @@ def test_device_loop_lowrank_family(name):
     host2 = opt_h.optimize(10, obj_h, host['opt_param'], on_device=False)
     dev2 = opt_d.optimize(10, obj_d, dev['opt_param'], on_device=True)
     _assert_same(host2, dev2)
+
+
+def test_device_loop_regression_target():
+    """Mean-field family on the logistic-regression target: the loop materialises its noise (the GLM GEMMs read the
+    sample matrix) and still reproduces the host loop."""
+    import viabel_amd as vb
+    from viabel_amd import optimization as opt
+    D, n_data, N = 12, 90, 48
+    rng = np.random.RandomState(4)
+    X = rng.randn(n_data, D) / np.sqrt(D)
+    y = (rng.rand(n_data) < 0.5).astype(float)
+
+    def make():
+        return vb.ExclusiveKL(vb.MFGaussian(D, seed=8, rng='philox'), vb.LogisticRegressionModel(X, y, 5.0), N)
+    init = np.concatenate([np.zeros(D), -np.ones(D)])
+    obj_h, obj_d = _pair(make)
+    host = opt.Adam(0.02).optimize(35, obj_h, init, on_device=False)
+    dev = opt.Adam(0.02).optimize(35, obj_d, init, on_device=True)
+    _assert_same(host, dev)
