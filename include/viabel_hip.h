@@ -161,6 +161,11 @@ int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int famil
                           const double* theta, const double* weights, double scale, double* value,
                           double* grad);
 
+/* AlphaDivergence for the dense Gaussian family (theta = [mu | free Cholesky], z = mu + L eps): same value and
+ * gradient convention as vb_alpha_grad_meanfield; grad has d + d (d + 1) / 2 entries. */
+int vb_alpha_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, const double* theta,
+                           double alpha, double* value, double* grad);
+
 /* ---- DISInclusiveKL, MultivariateT family (approximations.py:322-382) -------------------
  * theta = [mu | free Cholesky of Sigma].  The O(D^3) factor algebra stays with the caller, as in the
  * reference (sqrtm at approximations.py:348, eigh at _distributions.py:26): refresh takes the symmetric

@@ -192,6 +192,35 @@ def test_alpha_against_oracle(vb, D, N, family):
             assert G.rel_err(grad, og) < 1e-11
 
 
+@pytest.mark.parametrize('D,N', [(3, 9), (70, 333), (200, 1000)])
+def test_alpha_fullrank_against_oracle(vb, D, N):
+    """AlphaDivergence for the dense Gaussian: per-row f on the samples, weights as for the mean-field families,
+    the entropy-form pipeline with the rows of G weighted; every target the pipeline knows."""
+    rng = np.random.RandomState(3 * D + N)
+    ofr = ofam.FullRankGaussian(D)
+    L = np.tril(0.05 * rng.randn(D, D), -1) + np.diag(np.exp(-1.0 + 0.2 * rng.randn(D)))
+    theta = ofr.pack(0.3 * rng.randn(D), L)
+    A = rng.randn(D, D)
+    S = A @ A.T / D + np.eye(D)
+    m2 = rng.randn(D)
+    X = rng.randn(2 * D + 5, D) / np.sqrt(D)
+    y = (rng.rand(2 * D + 5) < 0.5).astype(float)
+    models = [(vb.GaussianModel(np.ones(D), 2 * np.ones(D)), omod.GaussDiag(np.ones(D), 2 * np.ones(D))),
+              (vb.CorrelatedGaussianModel(m2, covariance=S), omod.GaussFull(m2, np.linalg.inv(S))),
+              (vb.LogisticRegressionModel(X, y, 3.0), omod.Logistic(X, y, 3.0))]
+    if D >= 2:
+        models.append((vb.FunnelModel(D, D // 2), omod.Funnel(D, D // 2)))
+    for model, omodel in models:
+        for alpha in (2.0, 0.5):
+            np.random.seed(11)
+            value, grad = vb.AlphaDivergence(vb.FullRankGaussian(D), model, N, alpha)(theta)
+            np.random.seed(11)
+            noise = np.random.RandomState(np.random.randint(2 ** 32)).randn(N, D)
+            ov, og = oobj.alpha_divergence(ofr, omodel, theta, noise, alpha)
+            assert G.rel_err(value, ov) < 1e-12, (type(omodel).__name__, alpha, value, ov)
+            assert G.rel_err(grad, og) < 1e-11, (type(omodel).__name__, alpha, G.rel_err(grad, og))
+
+
 @pytest.mark.parametrize('D,n_data,N', [(7, 33, 50), (50, 200, 300), (200, 500, 1000)])
 def test_logistic_regression_target(vb, D, n_data, N):
     """New target against the oracle's logistic model: plain and path-derivative ELBO,

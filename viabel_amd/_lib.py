@@ -69,6 +69,8 @@ SIGNATURES = {
                                             _c_double_p]),
     'vb_sym_sqrt': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p,
                                    _c_double_p]),
+    'vb_alpha_grad_fullrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                              _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
     'vb_sym_sqrt_inv': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p,
                                        _c_double_p, _c_double_p]),
     'vb_lowrank_path_terms': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
@@ -457,6 +459,15 @@ class Engine:
         x = np.empty((d, d), dtype=np.float64)
         self._check(self._lib.vb_sym_sqrt(self._ctx, _dptr(a), _dptr(e), d, _dptr(root), _dptr(x), _dptr(info)))
         return root, x, info
+
+    def alpha_grad_fullrank(self, slot, n, d, theta, alpha, n_total=None):
+        theta = _f64(theta)
+        p = d + d * (d + 1) // 2
+        value = ctypes.c_double(0.0)
+        grad = np.empty(p, dtype=np.float64)
+        self._check(self._lib.vb_alpha_grad_fullrank(self._ctx, slot, n, d, n if n_total is None else n_total,
+                                                     _dptr(theta), float(alpha), ctypes.byref(value), _dptr(grad)))
+        return value.value, grad
 
     def sym_sqrt_inv(self, a):
         """``(root, inverse root, info)`` of an SPD matrix (``vb_sym_sqrt_inv``)."""

@@ -637,6 +637,20 @@ int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t
   return VB_OK;
 }
 
+int vb_alpha_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, const double* theta,
+                           double alpha, double* value, double* grad) {
+  if (!ctx || !theta || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  VB_TRY(vb_fullrank_set_theta(ctx, theta, d));
+  double sum_log_diag = 0.0;
+  for (int64_t i = 0; i < d; ++i) sum_log_diag += theta[d + i * (i + 1) / 2 + i];   // free diagonal = log L_ii
+  VB_TRY(alpha_fullrank_enqueue(ctx, ctx->noise[slot], n, n_total, d, alpha, (const double*)ctx->fr_theta.ptr,
+                                sum_log_diag, (double*)ctx->fr_out.ptr));
+  return vb_fullrank_get(ctx, value, grad, d + d * (d + 1) / 2);
+}
+
 // ---- DISInclusiveKL, mean field (objectives.py:283-416) ---------------------------------------------
 int vb_dis_refresh_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int family, double df,
                              const double* theta, const double* prior_theta, double eps_prev,

@@ -234,6 +234,9 @@ int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int
 int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, const double* mu_host,
                   const double* root_host, const double* inv_s_host, double* f_sum, double* g_sum, double* c_full);
 
+int alpha_fullrank_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double alpha,
+                           const double* theta_dev, double sum_log_diag, double* out);
+
 // vb_lowrank.hip
 int lr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
                          int64_t n_total, const double* theta_src, double* out);
@@ -250,11 +253,22 @@ int sync_streams(vb_ctx* ctx);   // main + pipeline streams
 
 // full-rank Gaussian ExclusiveKL (vb_fullrank.hip)
 struct FrSums;
+// weighted sums of the dense-Gaussian pipeline (AlphaDivergence): rows of G scaled by roww[n]; result
+// scale * [sum s g | tril(sum s g eps'), free diagonal x L_ii + wsum[0]], value = value[0] (device scalars)
+struct FrWeighted {
+  const double* roww;
+  double scale;
+  const double* wsum;
+  const double* value;
+};
+int fr_sample_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_dev, double* Z);
 int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
                         const double* theta_dev, double* out_dev, const double* mu_dev, const double* root_dev,
-                        const double* row_scale, FrSums* sums_out, unsigned flags = 0);
+                        const double* row_scale, FrSums* sums_out, unsigned flags = 0,
+                        const FrWeighted* weighted = nullptr);
 int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
-                         const double* theta_dev, double* out_dev, unsigned flags = 0);
+                         const double* theta_dev, double* out_dev, unsigned flags = 0,
+                         const FrWeighted* weighted = nullptr);
 
 // sum vector of the dense paths: [F | column sums (ldz) | C (d x ldl)]
 struct FrSums {

@@ -279,9 +279,13 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
     const double* __restrict__ Cpart, int splits, int64_t slab, int d, int64_t ldl,
     const double* __restrict__ colpart, int n_rb, int64_t ldz, const double* __restrict__ fpart, int n_fpart,
     FrSums S, const double* __restrict__ theta, double n_local_w, double n_total, double c0,
-    double* __restrict__ out, int pd) {
+    double* __restrict__ out, int pd, FrWeighted wm) {
   __shared__ double sh[4];
   const double ent = pd ? 0.0 : 1.0;      // the entropy's -1 on the free diagonal (absent with the path derivative)
+  // weighted mode (AlphaDivergence, objectives.py:458-460): the rows of G carried the weights s_n, the result is
+  // scale * [sum s g | tril(sum s g eps') with the free diagonal x L_ii + sum s], the value comes from wm.value
+  const bool weighted = wm.scale != 0.0;
+  const double wsum = weighted ? wm.wsum[0] : 0.0;
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t idx = 2 * tid;
   const int64_t nC = (int64_t)d * ldl;
@@ -299,7 +303,16 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
         for (int u = 0; u < 8; ++u) s += v[u];
       }
       const int64_t p = (int64_t)i * (i + 1) / 2 + j;
-      if (FUSE) {
+      if (FUSE && weighted) {
+        double g0 = s.x;
+        if (j == i) g0 = g0 * exp(theta[d + p]) + wsum;
+        out[1 + d + p] = wm.scale * g0;
+        if (j + 1 <= i) {
+          double g1 = s.y;
+          if (j + 1 == i) g1 = g1 * exp(theta[d + p + 1]) + wsum;
+          out[1 + d + p + 1] = wm.scale * g1;
+        }
+      } else if (FUSE) {
         double g0 = -s.x * invN;
         if (j == i) g0 = g0 * exp(theta[d + p]) - ent;              // free (log) diagonal + entropy
         out[1 + d + p] = g0;
@@ -326,7 +339,7 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
       }
     }
     if (FUSE) {
-      if (tid < d) out[1 + tid] = -s * invN;
+      if (tid < d) out[1 + tid] = weighted ? wm.scale * s : -s * invN;
     } else {
       S.sums[S.off_col + tid] = s;
     }
@@ -344,7 +357,7 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
         const double F = f + n_local_w * c0;
         const double half_sq = pd ? 0.5 * S.sums[1] * invN : 0.5 * d;    // 1/2 mean ||eps||^2 or its expectation
         const double H = half_sq + 0.5 * d * kLog2PiFr + sum_logdiag;
-        out[0] = -(F * invN + H);
+        out[0] = weighted ? wm.value[0] : -(F * invN + H);
       }
     } else if (threadIdx.x == 0) {
       S.sums[0] = f;
@@ -355,7 +368,8 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
 // epilogue of the sharded job: all-reduced packed sums -> (value, grad)
 __global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const double* __restrict__ theta,
                                                                  int d, double n_local_w, double n_total,
-                                                                 double c0, double* __restrict__ out, int pd) {
+                                                                 double c0, double* __restrict__ out, int pd,
+                                                                 FrWeighted wm) {
   __shared__ double sh[4];
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t np = (int64_t)d * (d + 1) / 2;
@@ -364,11 +378,18 @@ __global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const
     int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
     while ((int64_t)(i + 1) * (i + 2) / 2 <= p) ++i;
     while ((int64_t)i * (i + 1) / 2 > p) --i;
-    double g = -S.sums[S.off_c + p] * invN;                         // d value / d L_ij
-    if (p == (int64_t)i * (i + 1) / 2 + i) g = g * exp(theta[d + p]) - (pd ? 0.0 : 1.0);
-    out[1 + d + p] = g;
+    const bool diag = p == (int64_t)i * (i + 1) / 2 + i;
+    if (wm.scale != 0.0) {
+      double g = S.sums[S.off_c + p];
+      if (diag) g = g * exp(theta[d + p]) + wm.wsum[0];
+      out[1 + d + p] = wm.scale * g;
+    } else {
+      double g = -S.sums[S.off_c + p] * invN;                       // d value / d L_ij
+      if (diag) g = g * exp(theta[d + p]) - (pd ? 0.0 : 1.0);
+      out[1 + d + p] = g;
+    }
   }
-  if (p < d) out[1 + p] = -S.sums[S.off_col + p] * invN;
+  if (p < d) out[1 + p] = wm.scale != 0.0 ? wm.scale * S.sums[S.off_col + p] : -S.sums[S.off_col + p] * invN;
   if (blockIdx.x == 0) {
     double t = 0.0;
     for (int i = threadIdx.x; i < d; i += 256) t += theta[d + (int64_t)i * (i + 1) / 2 + i];
@@ -377,7 +398,7 @@ __global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const
       const double F = S.sums[0] + n_local_w * c0;
       const double half_sq = pd ? 0.5 * S.sums[1] * invN : 0.5 * d;
       const double H = half_sq + 0.5 * d * kLog2PiFr + sum_logdiag;
-      out[0] = -(F * invN + H);
+      out[0] = wm.scale != 0.0 ? wm.value[0] : -(F * invN + H);
     }
   }
 }
@@ -537,9 +558,18 @@ int gram_splits(vb_ctx* ctx, int d, int64_t n) {
 // `row_scale`; the caller gets the raw sums [F | sum g | sum_n g_n (e_n / s_n)' (full D x D)] in `sums_out`).
 int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
                         const double* theta_dev, double* out_dev, const double* mu_dev, const double* root_dev,
-                        const double* row_scale, FrSums* sums_out, unsigned flags) {
+                        const double* row_scale, FrSums* sums_out, unsigned flags, const FrWeighted* weighted) {
   const ModelDev& m = ctx->model;
   const bool mvt = theta_dev == nullptr;
+  FrWeighted wm;
+  wm.roww = nullptr;
+  wm.scale = 0.0;
+  wm.wsum = wm.value = nullptr;
+  if (weighted) {
+    if (mvt || (flags & VB_FLAG_PATH_DERIV))
+      return fail(ctx, VB_ERR_UNSUPPORTED, "weighted sums: entropy-form pipeline of the dense Gaussian only");
+    wm = *weighted;
+  }
   const bool pd = (flags & VB_FLAG_PATH_DERIV) != 0;
   if (pd && mvt) return fail(ctx, VB_ERR_UNSUPPORTED, "path derivative: dense Gaussian family only");
   const bool glm = m.id == VB_MODEL_LOGISTIC;
@@ -764,6 +794,11 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
   VB_HIP(ctx, hipGetLastError());
 
+  if (wm.roww) {   // weighted sums: scale the rows of G before anything is summed
+    hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)n), dim3(256), 0, st, G, ldz, n,
+                       D, wm.roww);
+    VB_HIP(ctx, hipGetLastError());
+  }
   hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
                      (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
                      m.id == VB_MODEL_FUNNEL ? fpart + n_fpart /*unused tail*/ : fpart,
@@ -804,14 +839,14 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     hipLaunchKernelGGL(fr_reduce_packed_kernel<true>, red_grid, dim3(256), 0, st, (const double*)Cpart,
                        splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb + (pd ? 1 : 0), ldz,
                        (const double*)fpart, n_fpart, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
-                       pd ? 1 : 0);
+                       pd ? 1 : 0, wm);
     VB_HIP(ctx, hipGetLastError());
     return VB_OK;
   }
   hipLaunchKernelGGL(fr_reduce_packed_kernel<false>, red_grid, dim3(256), 0, st, (const double*)Cpart,
                      splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb + (pd ? 1 : 0), ldz,
                      (const double*)fpart, n_fpart, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
-                     pd ? 1 : 0);
+                     pd ? 1 : 0, wm);
   VB_HIP(ctx, hipGetLastError());
   hipStream_t st_post = st;
   if (overlap) {
@@ -821,7 +856,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
   VB_TRY(comm_allreduce_sum(ctx, st_post, S.sums, (size_t)S.len));
   hipLaunchKernelGGL(fr_epilogue_packed_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st_post, S,
-                     theta_dev, D, (double)n_total, (double)n_total, m.c0, out_dev, pd ? 1 : 0);
+                     theta_dev, D, (double)n_total, (double)n_total, m.c0, out_dev, pd ? 1 : 0, wm);
   VB_HIP(ctx, hipGetLastError());
   if (overlap) {
     VB_HIP(ctx, hipEventRecord(P.ev_fin[set], st_post));
@@ -832,9 +867,35 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   return VB_OK;
 }
 
+// Z = E L' + mu into `Z` (n x ldz, ldz = round_up(d, 16)): the samples themselves, for per-row evaluations
+int fr_sample_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_dev, double* Z) {
+  if (n <= 0 || d <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  const int D = (int)d;
+  const int64_t ldl = round_up(d, 16), ldz = ldl;
+  VB_TRY(ensure(ctx, ctx->fr_work, (size_t)(ldz + d * ldl) * sizeof(double)));
+  double* mu = (double*)ctx->fr_work.ptr;
+  double* Lt = mu + ldz;
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((d * d + 255) / 256)), dim3(256), 0, st, theta_dev, D, ldl, Lt,
+                     mu);
+  GemmArgs g1;
+  g1.A = (const double*)ns.buf.ptr;
+  g1.lda = ns.ld;
+  g1.B = Lt;
+  g1.ldb = ldl;
+  g1.M = (int)n;
+  g1.N = D;
+  g1.K = D;
+  g1.tri_mode = 1;
+  gemm_f64_launch<true>(st, g1, 1, ctx->prop.multiProcessorCount, EpiStoreZ{Z, ldz, mu, nullptr, nullptr});
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 int fr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
-                         const double* theta_dev, double* out_dev, unsigned flags) {
-  return fr_pipeline_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev, nullptr, nullptr, nullptr, nullptr, flags);
+                         const double* theta_dev, double* out_dev, unsigned flags, const FrWeighted* weighted) {
+  return fr_pipeline_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev, nullptr, nullptr, nullptr, nullptr, flags,
+                             weighted);
 }
 
 }  // namespace vb

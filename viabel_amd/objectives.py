@@ -559,9 +559,9 @@ class AlphaDivergence(StochasticVariationalObjective):
     def _update_objective_and_grad(self):
         approx = self.approx
         self._require_device_model()
-        if not isinstance(approx, (MFGaussian, MFStudentT)):
-            raise NotImplementedError('AlphaDivergence on the HIP engine supports MFGaussian and '
-                                      'MFStudentT; got {}'.format(type(approx).__name__))
+        if not isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian)):
+            raise NotImplementedError('AlphaDivergence on the HIP engine supports MFGaussian, MFStudentT and '
+                                      'FullRankGaussian; got {}'.format(type(approx).__name__))
         alpha = self.alpha
 
         def objective_grad_and_log_norm(var_param):
@@ -574,6 +574,8 @@ class AlphaDivergence(StochasticVariationalObjective):
             eng = self._engine()
             eng.set_model(self.model.device_spec())
             n_local, n_total = self._stage_noise(eng, self.num_mc_samples, seed=seed)
+            if isinstance(approx, FullRankGaussian):
+                return eng.alpha_grad_fullrank(_NOISE_SLOT, n_local, approx.dim, var_param, alpha, n_total=n_total)
             family, df = approx._device_family()
             return eng.alpha_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, var_param, family, alpha, df=df,
                                             n_total=n_total)
