@@ -226,7 +226,9 @@ int vb_elbo_sums_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_tota
 /* ---- ExclusiveKL, full-rank Gaussian family -------------------------------------------
  * New family (no reference class) behind the ApproximationFamily API with the flat
  * layout of viabel/approximations.py:315-319: theta = [mu (D) | free Cholesky (D(D+1)/2)],
- * z = mu + L eps.  Estimator: objectives.py:154-164 (entropy form).  fp64 MFMA GEMMs.
+ * z = mu + L eps.  Estimators: objectives.py:160-164 (entropy form) and, with VB_FLAG_PATH_DERIV, :156-159
+ * (path derivative: the score L^-T eps enters through the noise Gram matrix and an explicit triangular inverse on
+ * the device).  Targets: gauss_diag, funnel, gauss_full and the regression models.  fp64 MFMA GEMMs.
  * vb_elbo_grad_fullrank = set_theta + enqueue + get; the three-step form keeps theta and the
  * result resident on the device (P = D + D(D+1)/2 doubles is 4.2 MB at D = 1024).          */
 int vb_elbo_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
