@@ -270,6 +270,17 @@ int vb_lowrank_path_terms(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int6
 int vb_mvt_path_terms(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* inv_s,
                       double* m_w, double* e_w, double* log1p_sum);
 
+/* ---- AlphaDivergence over a MultivariateT (objectives.py:453-461 with approximations.py:342-357) --------
+ * Samples x_n = mu + (z_n sqrt_sigma) / s_n as vb_elbo_sums_mvt.  The Mahalanobis distance of a sample is
+ * |z_n|^2 / s_n^2 whatever the parameters are, so log q(x_n) = t-density constant - sum_log_diag
+ * - (df + D)/2 log1p(|z_n|^2 / (s_n^2 df)) and the log weights, their maximum, w_n = exp(alpha (lw_n - max)) and
+ * `value` = log(mean w) / alpha + max (:457-459) are formed on the device.  Returns w_sum = sum_n w_n,
+ * g_sum[D] = sum_n w_n g_n and c_full[D x D] = sum_n w_n g_n (z_n / s_n)'; the caller applies alpha / N, the
+ * chain rule through the symmetric root and adds w_sum to the free (log) diagonal.  Sums cover all ranks. */
+int vb_alpha_sums_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
+                      const double* mu, const double* sqrt_sigma, const double* inv_s, double sum_log_diag,
+                      double* value, double* w_sum, double* g_sum, double* c_full);
+
 /* ---- device-resident fit: the optimiser loop of optimization.py:83-127 without host round trips ----
  * Replaces  for k in range(n_iters): value, grad = objective(theta); theta -= lr * descent_direction(grad)
  * (StochasticGradientOptimizer.optimize, optimization.py:91-112) for an ExclusiveKL objective whose family

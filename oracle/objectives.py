@@ -281,6 +281,20 @@ def alpha_divergence(family, model, theta, noise, alpha):
         dfree[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + np.sum(sv)
         grad = alpha * np.concatenate([dmu, dfree[np.tril_indices(D)]]) / N
         return value, grad
+    if isinstance(family, fam.MultivariateT):
+        # z = mu + (e R) / s, R = sqrtm(L L'): the Mahalanobis distance of a sample is |e / s|^2 whatever theta
+        # is, so of log q(z(theta); theta) again only -sum log L_ii moves; R -> L as in _exclusive_kl_mvt
+        D = family.dim
+        chi, e = noise
+        _, Sigma = family.split(theta)
+        L = fam.free_to_chol(theta[D:], D)
+        es = e / np.sqrt(chi / family.df)[:, None]
+        sg = sv[:, None] * g
+        X = sqrt_root_vjp(Sigma, sg.T @ es)
+        dL = np.tril(2.0 * X @ L)
+        dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + np.sum(sv)
+        grad = alpha * np.concatenate([sg.sum(0), dL[np.tril_indices(D)]]) / N
+        return value, grad
     mu, ls = family.split(theta)
     sig = np.exp(ls)
     # log q(z(theta);theta) = sum_d base_logpdf(noise) - sum(ls): d/dls = -1, d/dmu = 0

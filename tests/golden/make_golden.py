@@ -254,7 +254,8 @@ def gen_alpha():
     rng = np.random.RandomState(41)
     worst = 0.0
     for fspec in ({'kind': 'mf_gaussian', 'dim': 2}, {'kind': 'mf_student_t', 'dim': 3, 'df': 100},
-                  {'kind': 'mf_gaussian', 'dim': 10}):
+                  {'kind': 'mf_gaussian', 'dim': 10}, {'kind': 'multivariate_t', 'dim': 3, 'df': 100},
+                  {'kind': 'multivariate_t', 'dim': 4, 'df': 7}):
         D = fspec['dim']
         for mspec in model_specs(D, rng):
             for alpha in (2.0, 0.5):
@@ -274,8 +275,12 @@ def gen_alpha():
                 worst = max(worst, e)
                 assert e < 2e-7, (fspec, mspec['kind'], alpha, e)
                 name = 'alpha_%s_d%d_%s_a%g' % (fspec['kind'], D, mspec['kind'], alpha)
+                if fspec['kind'] == 'multivariate_t':
+                    noise_kw = dict(noise_chi=noise[0], noise_z=noise[1])
+                else:
+                    noise_kw = dict(noise=noise)
                 save(name, **spec_arrays(fspec, mspec), np_seed=np_seed, seed=seed, n=N,
-                     theta=theta, noise=noise, alpha=alpha, value=value, grad_fd=grad_fd, grad=og,
+                     theta=theta, alpha=alpha, value=value, grad_fd=grad_fd, grad=og, **noise_kw,
                      provenance='value: reference; grad_fd: FD of the reference log-weights '
                                 'closure contracted as in objectives.py:460; grad: analytic')
     print('AlphaDivergence: worst analytic-vs-FD(reference) grad rel err %.2e' % worst)

@@ -221,6 +221,31 @@ def test_alpha_fullrank_against_oracle(vb, D, N):
             assert G.rel_err(grad, og) < 1e-11, (type(omodel).__name__, alpha, G.rel_err(grad, og))
 
 
+@pytest.mark.parametrize('D,N,df', [(3, 9, 100), (70, 333, 7), (200, 1000, 30)])
+def test_alpha_multivariate_t_against_oracle(vb, D, N, df):
+    """AlphaDivergence for the multivariate t (beyond the golden sizes): weights from the t density of the samples,
+    weighted sums through the t family's pipeline, chain rule through the symmetric root."""
+    rng = np.random.RandomState(5 * D + N)
+    omvt = ofam.MultivariateT(D, df)
+    L = np.tril(0.05 * rng.randn(D, D), -1) + np.diag(np.exp(-1.0 + 0.2 * rng.randn(D)))
+    theta = np.concatenate([0.3 * rng.randn(D), ofam.chol_to_free(L)])
+    A = rng.randn(D, D)
+    S = A @ A.T / D + np.eye(D)
+    m2 = rng.randn(D)
+    models = [(vb.GaussianModel(np.ones(D), 2 * np.ones(D)), omod.GaussDiag(np.ones(D), 2 * np.ones(D))),
+              (vb.CorrelatedGaussianModel(m2, covariance=S), omod.GaussFull(m2, np.linalg.inv(S))),
+              (vb.FunnelModel(D, D // 2), omod.Funnel(D, D // 2))]
+    for model, omodel in models:
+        for alpha in (2.0, 0.5):
+            np.random.seed(13)
+            value, grad = vb.AlphaDivergence(vb.MultivariateT(D, df), model, N, alpha)(theta)
+            np.random.seed(13)
+            noise = omvt.draw_noise(np.random.RandomState(np.random.randint(2 ** 32)), N)
+            ov, og = oobj.alpha_divergence(omvt, omodel, theta, noise, alpha)
+            assert G.rel_err(value, ov) < 1e-12, (type(omodel).__name__, alpha, value, ov)
+            assert G.rel_err(grad, og) < 1e-10, (type(omodel).__name__, alpha, G.rel_err(grad, og))
+
+
 @pytest.mark.parametrize('D,n_data,N', [(7, 33, 50), (50, 200, 300), (200, 500, 1000)])
 def test_logistic_regression_target(vb, D, n_data, N):
     """New target against the oracle's logistic model: plain and path-derivative ELBO,

@@ -63,7 +63,7 @@ def test_rge(path):
 def test_alpha(path):
     fx = G.load(path)
     v, g = oobj.alpha_divergence(G.oracle_family(fx), G.oracle_model(fx), fx['theta'],
-                                 fx['noise'], float(fx['alpha']))
+                                 G.noise_of(fx), float(fx['alpha']))
     assert G.rel_err(v, fx['value']) < 1e-12
     assert G.rel_err(g, fx['grad']) < 1e-12
     assert G.rel_err(g, fx['grad_fd']) < 2e-7

@@ -77,6 +77,9 @@ SIGNATURES = {
                                              ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_mvt_path_terms': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'vb_alpha_sums_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p, _c_double_p,
+                                         ctypes.c_double, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'vb_elbo_grad_meanfield_philox': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                      ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_double,
                                                      _c_double_p, ctypes.c_uint, ctypes.c_int, ctypes.c_uint64,
@@ -500,6 +503,19 @@ class Engine:
         self._check(self._lib.vb_mvt_path_terms(self._ctx, slot, n, d, n if n_total is None else n_total, float(df),
                                                 _dptr(inv_s), _dptr(m_w), _dptr(e_w), ctypes.byref(l1p)))
         return m_w, e_w, l1p.value
+
+    def alpha_sums_mvt(self, slot, n, d, df, alpha, mu, root, inv_s, sum_log_diag, n_total=None):
+        """Weighted sample sums of AlphaDivergence over a multivariate t (``vb_alpha_sums_mvt``):
+        ``(value, w_sum, g_sum, C)``."""
+        mu, root, inv_s = _f64(mu), _f64(root), _f64(inv_s)
+        g_sum = np.empty(d, dtype=np.float64)
+        C = np.empty((d, d), dtype=np.float64)
+        value, w_sum = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._check(self._lib.vb_alpha_sums_mvt(self._ctx, slot, n, d, n if n_total is None else n_total, float(df),
+                                                float(alpha), _dptr(mu), _dptr(root), _dptr(inv_s),
+                                                float(sum_log_diag), ctypes.byref(value), ctypes.byref(w_sum),
+                                                _dptr(g_sum), _dptr(C)))
+        return value.value, w_sum.value, g_sum, C
 
     # ------------------------------------------------------------------ device-resident fit
     def fit(self, slot, n, d, family, theta, n_iters, opt_kind, hyper, *, df=0.0, flags=0, cv_mode=0,

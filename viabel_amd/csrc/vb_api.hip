@@ -806,6 +806,21 @@ int vb_lowrank_path_terms(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int6
   return lr_path_terms(ctx, ctx->noise[slot_eps], ctx->noise[slot_z], n, d, k, sw, out);
 }
 
+int vb_alpha_sums_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
+                      const double* mu, const double* sqrt_sigma, const double* inv_s, double sum_log_diag,
+                      double* value, double* w_sum, double* g_sum, double* c_full) {
+  if (!ctx || !mu || !sqrt_sigma || !inv_s || !value || !w_sum || !g_sum || !c_full)
+    return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
+  if (!(df > 0.0)) return fail(ctx, VB_ERR_INVALID, "df must be positive");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return mvt_alpha_sums(ctx, ctx->noise[slot], n, d, n_total, df, alpha, mu, sqrt_sigma, inv_s, sum_log_diag, value,
+                        w_sum, g_sum, c_full);
+}
+
 int vb_mvt_path_terms(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* inv_s,
                       double* m_w, double* e_w, double* log1p_sum) {
   if (!ctx || !inv_s || !m_w || !e_w || !log1p_sum) return fail(ctx, VB_ERR_INVALID, "NULL argument");

@@ -234,6 +234,9 @@ int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int
 int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, const double* mu_host,
                   const double* root_host, const double* inv_s_host, double* f_sum, double* g_sum, double* c_full);
 
+int mvt_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
+                   const double* mu_host, const double* root_host, const double* inv_s_host, double sum_log_diag,
+                   double* value, double* w_sum, double* g_sum, double* c_full);
 int alpha_fullrank_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double alpha,
                            const double* theta_dev, double sum_log_diag, double* out);
 
@@ -261,7 +264,12 @@ struct FrWeighted {
   const double* wsum;
   const double* value;
 };
-int fr_sample_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_dev, double* Z);
+int fr_sample_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_dev, double* Z,
+                      const double* mu_dev = nullptr, const double* root_dev = nullptr,
+                      const double* row_scale = nullptr);
+int alpha_mvt_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df, double alpha,
+                      const double* mu_dev, const double* root_dev, const double* invs_dev, double sum_log_diag,
+                      FrSums* sums, const double** value_wsum);
 int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total,
                         const double* theta_dev, double* out_dev, const double* mu_dev, const double* root_dev,
                         const double* row_scale, FrSums* sums_out, unsigned flags = 0,

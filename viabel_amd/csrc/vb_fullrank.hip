@@ -565,9 +565,9 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   wm.roww = nullptr;
   wm.scale = 0.0;
   wm.wsum = wm.value = nullptr;
-  if (weighted) {
-    if (mvt || (flags & VB_FLAG_PATH_DERIV))
-      return fail(ctx, VB_ERR_UNSUPPORTED, "weighted sums: entropy-form pipeline of the dense Gaussian only");
+  if (weighted) {   // the t family takes the weighted raw sums (wm.scale / wsum / value are the caller's there)
+    if (flags & VB_FLAG_PATH_DERIV)
+      return fail(ctx, VB_ERR_UNSUPPORTED, "weighted sums: entropy-form pipeline only");
     wm = *weighted;
   }
   const bool pd = (flags & VB_FLAG_PATH_DERIV) != 0;
@@ -867,27 +867,35 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   return VB_OK;
 }
 
-// Z = E L' + mu into `Z` (n x ldz, ldz = round_up(d, 16)): the samples themselves, for per-row evaluations
-int fr_sample_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_dev, double* Z) {
+// Z = E L' + mu into `Z` (n x ldz, ldz = round_up(d, 16)): the samples themselves, for per-row evaluations.
+// theta_dev == nullptr: Z = (E root) * row_scale + mu with a full `root` (row stride ldz) as the t family has it
+int fr_sample_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_dev, double* Z,
+                      const double* mu_dev, const double* root_dev, const double* row_scale) {
   if (n <= 0 || d <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   const int D = (int)d;
   const int64_t ldl = round_up(d, 16), ldz = ldl;
-  VB_TRY(ensure(ctx, ctx->fr_work, (size_t)(ldz + d * ldl) * sizeof(double)));
-  double* mu = (double*)ctx->fr_work.ptr;
-  double* Lt = mu + ldz;
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((d * d + 255) / 256)), dim3(256), 0, st, theta_dev, D, ldl, Lt,
-                     mu);
   GemmArgs g1;
   g1.A = (const double*)ns.buf.ptr;
   g1.lda = ns.ld;
-  g1.B = Lt;
   g1.ldb = ldl;
   g1.M = (int)n;
   g1.N = D;
   g1.K = D;
-  g1.tri_mode = 1;
-  gemm_f64_launch<true>(st, g1, 1, ctx->prop.multiProcessorCount, EpiStoreZ{Z, ldz, mu, nullptr, nullptr});
+  if (theta_dev) {
+    VB_TRY(ensure(ctx, ctx->fr_work, (size_t)(ldz + d * ldl) * sizeof(double)));
+    double* mu = (double*)ctx->fr_work.ptr;
+    double* Lt = mu + ldz;
+    hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((d * d + 255) / 256)), dim3(256), 0, st, theta_dev, D, ldl,
+                       Lt, mu);
+    g1.B = Lt;
+    g1.tri_mode = 1;
+    gemm_f64_launch<true>(st, g1, 1, ctx->prop.multiProcessorCount, EpiStoreZ{Z, ldz, mu, nullptr, nullptr});
+  } else {
+    g1.B = root_dev;
+    g1.tri_mode = 0;
+    gemm_f64_launch<true>(st, g1, 1, ctx->prop.multiProcessorCount, EpiStoreZ{Z, ldz, mu_dev, nullptr, row_scale});
+  }
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }

@@ -483,4 +483,39 @@ int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_
   return VB_OK;
 }
 
+// AlphaDivergence sums for the multivariate t (see vb_alpha_sums_mvt in the header)
+int mvt_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
+                   const double* mu_host, const double* root_host, const double* inv_s_host, double sum_log_diag,
+                   double* value, double* w_sum, double* g_sum, double* c_full) {
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  const int64_t ld = round_up(d, 16);
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t o_root = carve(d * ld), o_mu = carve(ld), o_invs = carve(n);
+  VB_TRY(ensure(ctx, ctx->mvt_elbo, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->mvt_elbo.ptr;
+  hipStream_t st = ctx->stream;
+  VB_TRY(upload_padded(ctx, base + o_root, ld, root_host, d, d, false));
+  VB_HIP(ctx, hipMemsetAsync(base + o_mu, 0, (size_t)ld * sizeof(double), st));
+  VB_HIP(ctx, hipMemcpyAsync(base + o_mu, mu_host, (size_t)d * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(base + o_invs, inv_s_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  FrSums S;
+  const double* vw = nullptr;
+  VB_TRY(alpha_mvt_enqueue(ctx, ns, n, n_total, d, df, alpha, base + o_mu, base + o_root, base + o_invs, sum_log_diag,
+                           &S, &vw));
+  double two[2];
+  VB_HIP(ctx, hipMemcpyAsync(two, vw, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(g_sum, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(c_full, (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)ld * sizeof(double),
+                               (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  *w_sum = two[0];
+  *value = two[1];
+  return VB_OK;
+}
+
 }  // namespace vb

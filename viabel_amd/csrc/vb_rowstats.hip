@@ -271,6 +271,67 @@ int alpha_fullrank_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t 
   return fr_elbo_grad_enqueue(ctx, ns, n, d, n_total, theta_dev, out, 0, &wm);
 }
 
+// b_n = log t_df(x_n) + sum log L_ii for x_n = mu + (e_n R) / s_n: the Mahalanobis distance is |e_n|^2 / s_n^2
+// whatever (mu, R) are (_distributions.py:7-38); one wave per row
+__global__ void __launch_bounds__(256) rs_mvt_base_kernel(const double* __restrict__ E, int64_t ld, int64_t n, int d,
+                                                          double df, double lconst,
+                                                          const double* __restrict__ inv_s, double* __restrict__ b) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double* e = E + row * ld;
+  double s = 0.0;
+  for (int c = lane; c < d; c += 64) s = fma(e[c], e[c], s);
+  s = rs_wave_sum(s);
+  if (lane == 0) {
+    const double is = inv_s[row];
+    b[row] = lconst - 0.5 * (df + d) * log1p(s * is * is / df);
+  }
+}
+
+// AlphaDivergence for the multivariate t (objectives.py:453-461 with approximations.py:342-357): weights exactly
+// as for the dense Gaussian, then the t family's pipeline with the rows of G weighted.  Returns the raw sums
+// [. | sum w g | sum w g (e / s)'] and a pointer to [sum w, value]; the chain rule through the root is the caller's.
+int alpha_mvt_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df, double alpha,
+                      const double* mu_dev, const double* root_dev, const double* invs_dev, double sum_log_diag,
+                      FrSums* sums, const double** value_wsum) {
+  if (!(alpha != 0.0)) return fail(ctx, VB_ERR_INVALID, "alpha must be non-zero");
+  if (n <= 0 || n > ns.n || d != ns.d || n_total < n) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  hipStream_t st = ctx->stream;
+  const int64_t ldz = round_up(d, 16), nn = round_up(n, 16);
+  VB_TRY(ensure(ctx, ctx->rowvec, (size_t)(16 + 3 * nn) * sizeof(double)));
+  VB_TRY(ensure(ctx, ctx->scratch, (size_t)(n * ldz) * sizeof(double)));
+  double* scal = (double*)ctx->rowvec.ptr;
+  double *f = scal + 16, *b = f + nn, *roww = b + nn;
+  double* Z = (double*)ctx->scratch.ptr;
+  VB_HIP(ctx, hipMemsetAsync(Z, 0, (size_t)(n * ldz) * sizeof(double), st));
+  VB_HIP(ctx, hipMemcpyAsync(scal, &sum_log_diag, sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));   // sum_log_diag lives on the caller's stack
+  VB_TRY(fr_sample_enqueue(ctx, ns, n, d, nullptr, Z, mu_dev, root_dev, invs_dev));
+  VB_TRY(model_logp_rows(ctx, Z, ldz, n, d, f));
+  const double lconst = lgamma(0.5 * (df + (double)d)) - lgamma(0.5 * df) - 0.5 * (double)d * log(M_PI * df);
+  hipLaunchKernelGGL(rs_mvt_base_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)ns.buf.ptr,
+                     ns.ld, n, (int)d, df, lconst, invs_dev, b);
+  hipLaunchKernelGGL(alpha_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)f, (const double*)b,
+                     (const double*)scal, n, scal + 8);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(comm_allreduce_max(ctx, st, scal + 8, 1));
+  hipLaunchKernelGGL(alpha_weights_kernel, dim3(1), dim3(1024), 0, st, (const double*)f, (const double*)b,
+                     (const double*)scal, (const double*)(scal + 8), n, alpha, roww, scal + 9);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(comm_allreduce_sum(ctx, st, scal + 9, 1));
+  hipLaunchKernelGGL(alpha_value_kernel, dim3(1), dim3(1), 0, st, (const double*)(scal + 8),
+                     (const double*)(scal + 9), (double)n_total, alpha, scal + 10);
+  VB_HIP(ctx, hipGetLastError());
+  FrWeighted wm;
+  wm.roww = roww;
+  wm.scale = alpha / (double)n_total;
+  wm.wsum = scal + 9;
+  wm.value = scal + 10;
+  *value_wsum = scal + 9;                      // [sum w, value]
+  return fr_pipeline_enqueue(ctx, ns, n, d, n_total, nullptr, nullptr, mu_dev, root_dev, invs_dev, sums, 0, &wm);
+}
+
 // ---- DISInclusiveKL state refresh (objectives.py:317-368) ---------------------------------------------
 // One workgroup: bisection on the tempering parameter for the effective sample size.
 //   logw(e) = e * log prior + (1 - e) * log p - log q,   w = exp(logw)   (no max shift, :330)

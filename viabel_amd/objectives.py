@@ -559,10 +559,13 @@ class AlphaDivergence(StochasticVariationalObjective):
     def _update_objective_and_grad(self):
         approx = self.approx
         self._require_device_model()
-        if not isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian)):
-            raise NotImplementedError('AlphaDivergence on the HIP engine supports MFGaussian, MFStudentT and '
-                                      'FullRankGaussian; got {}'.format(type(approx).__name__))
+        if not isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian, MultivariateT)):
+            raise NotImplementedError('AlphaDivergence on the HIP engine supports MFGaussian, MFStudentT, '
+                                      'MultivariateT and FullRankGaussian; got {}'.format(type(approx).__name__))
         alpha = self.alpha
+        if isinstance(approx, MultivariateT):
+            self._objective_and_grad = self._mvt_alpha(approx, alpha)
+            return
 
         def objective_grad_and_log_norm(var_param):
             var_param = np.asarray(var_param, dtype=np.float64)
@@ -581,3 +584,49 @@ class AlphaDivergence(StochasticVariationalObjective):
                                             n_total=n_total)
 
         self._objective_and_grad = objective_grad_and_log_norm
+
+    def _mvt_alpha(self, approx, alpha):
+        """AlphaDivergence over the multivariate t: weights, value and the weighted sums on the device
+        (``vb_alpha_sums_mvt``); the chain rule through the symmetric root as in ``ExclusiveKL._mvt_exclusive_kl``.
+        Of ``log q(x(theta); theta)`` only ``-sum log L_ii`` moves (the Mahalanobis distance of a sample is a
+        function of its noise), which puts ``sum w`` on the free diagonal."""
+        D, df = approx.dim, approx.df
+        tril = np.tril_indices(D)
+        _lib.apply_host_blas_policy()
+
+        def objective_grad_and_log_norm(var_param):
+            var_param = np.asarray(var_param, dtype=np.float64)
+            if var_param.shape != (approx.var_param_dim,):
+                raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+            seed = np.random.randint(2 ** 32)              # objectives.py:455
+            eng = self._engine()
+            eng.set_model(self.model.device_spec())
+            N = self.num_mc_samples
+            begin, end = shard_rows(N, eng.n_ranks, eng.rank)
+            if approx.rng == 'philox':
+                chi = approx._random_state(seed).chisquare(df, N)
+                eng.noise_generate(_NOISE_SLOT, end - begin, D, seed, 0, row_offset=begin)
+            else:
+                chi, z = approx._base_noise(N, seed)        # chi-square draws first (approximations.py:345-347)
+                eng.noise_set_host(_NOISE_SLOT, z[begin:end])
+            mu, L = approx._unpack(var_param)
+            Sigma = L @ L.T
+            inv_s = 1.0 / np.sqrt(chi / df)
+            root, eig = _device_root(eng, Sigma)
+            value, w_sum, g_sum, C = eng.alpha_sums_mvt(_NOISE_SLOT, end - begin, D, df, alpha, mu, root,
+                                                        inv_s[begin:end], np.sum(np.log(np.diag(L))), n_total=N)
+            Gs = 0.5 * (C + C.T)
+            X = None
+            if eig is None:
+                _, X, info = eng.sym_sqrt(Sigma, Gs)
+                if not info[2] < _ROOT_TOL:
+                    X, eig = None, symmetric_eig(Sigma)
+            if X is None:
+                w, U = eig
+                r = np.sqrt(w)
+                X = U @ ((U.T @ Gs @ U) / (r[:, None] + r[None, :])) @ U.T
+            dL = np.tril(2.0 * X @ L)
+            dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + w_sum
+            return value, alpha * np.concatenate([g_sum, dL[tril]]) / N          # objectives.py:460
+
+        return objective_grad_and_log_norm
