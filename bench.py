@@ -314,6 +314,8 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
+            # the cpu_baseline leg, after the timed region: the only place this file touches oracle/ -- timed as
+            # the CPU baseline and, on the same inputs, used as the checker of the HIP result (never measured as ours)
             out['cpu_baseline'] = cpu_baseline(theta)
             out['parity'] = parity_check(eng, theta, fam)
     if out is not None and world == 1 and not args.no_fit:
