@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: ELBO-gradient evaluations per second (BASELINE.json `metric`).
 
-Workload = BASELINE.json configs[1]: MFGaussian + ExclusiveKL on the D=1024 funnel with
-N_mc=4096 Monte-Carlo samples per GPU, fp64.  One "step" = one objective evaluation
-(value + gradient) over one N x D noise matrix resident in HBM.  A ring of noise matrices
-larger than the 256-MiB Infinity Cache is cycled so every step streams its noise from HBM,
-as an optimisation loop (fresh noise per iteration) does.
+Workload = the north_star target: FullRankGaussian + ExclusiveKL, D=1024, N_mc=4096 Monte-Carlo samples,
+correlated-Gaussian target (dense precision matrix), fp64.  One "step" = one objective evaluation (value +
+gradient of all 525 824 parameters) over one N x D noise matrix resident in HBM: sampling GEMM Z = E L' + mu
+(triangular), model GEMM G = -(Z - m) P (dense), gradient GEMM C = G' E (lower triangle), reductions and the
+O(P) epilogue -- every evaluation is enqueued on ONE HIP stream behind the previous one, as an optimiser loop
+issues them.  A ring of 8 noise matrices (268 MB > the 256-MiB Infinity Cache) is cycled.
 
-N > 1 GPUs (launched by torch.distributed.run, one rank per GPU): the Monte-Carlo axis is
-sharded -- every rank holds 4096 rows (weak scaling, N_mc global = 4096 x GPUs) and the
-partial sums are all-reduced over RCCL inside every evaluation.  `value` counts
-4096-sample evaluation units: GPUs x evaluations / second.
+N > 1 GPUs (one rank per GPU, launched by torch.distributed.run; the ranks talk over RCCL, the control path is
+a plain TCP socket group -- no torch import anywhere):
+  --scaling weak   (default)  every rank holds 4096 rows, N_mc global = 4096 x GPUs, `value` counts
+                              4096-sample evaluation units: GPUs x evaluations / second;
+  --scaling strong            N_mc = 4096 global, rank r holds rows shard_rows(4096, G, r), `value` =
+                              evaluations / second of the whole job.
+Either way every evaluation all-reduces its 16 + D + D(D+1)/2 partial sums (4.2 MB) over RCCL.
+
+Secondary legs (rank 0 of a 1-GPU run only, after the timed region): BASELINE configs[1] (mean field, HBM-bound),
+configs[2] (D=512 full rank), the optimiser loop, the CPU baseline and the parity check.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,72 +34,200 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-D, N_MC = 1024, 4096
-ALGO_BYTES = N_MC * D * 8 + 4 * D * 8 + 8        # noise read + theta read + grad write + value
+FR_D, N_MC = 1024, 4096
+D1 = 1024                                        # configs[1] dimension
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per evaluation of the accumulate kernel from the PMC passes committed under
-# profiles/r01_meanfield_c1_pmc_hbm.txt: (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE) KiB per
-# 32-evaluation launch
-PMC_TRAFFIC_BYTES_PER_EVAL = (2 * 530474.5 + 8352.7) * 1024 / 32
-FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet; tools/fp64_peak.hip measures 63-73 (4x4x4 form)
+FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet fp64 matrix peak = 256 CUs x 4 SIMDs x 512 flop / 16 clk x 2.4 GHz;
+#                                                  tools/mfma_barrier_probe.hip measures 77.3 with constant operands
+MIN_TIMED_S = 0.05                               # the timed blocks are repeated until they cover at least this
 
 
-def fullrank_leg(eng, vb, steps=150, warmup=60, world=1, rank=0, barrier=None):
-    """Secondary measurement: the dense (full-rank) Gaussian family named by north_star, D=1024, N=4096 rows
-    per GPU, correlated-Gaussian target, parameter resident on the device.  fp64 MFMA-bound.  With world > 1
-    the Monte-Carlo axis is sharded like the headline leg: every evaluation all-reduces its
-    1 + D + D(D+1)/2 partial sums over RCCL (4.2 MB), so all ranks have to call this together."""
-    d, n = 1024, N_MC
-    n_total = n * world
-    barrier = barrier or (lambda: None)
-    rng = np.random.RandomState(2)
+def fr_flops(n, d):
+    """Executed-work model of one full-rank evaluation (exact triangles: the kernels skip the zero halves)."""
+    tri = float(n) * d * (d + 1)                 # sum_j 2 n (j + 1): Z = E L' with lower-triangular L; likewise tril(G' E)
+    dense = 2.0 * n * d * d
+    return {'sample_gemm': tri, 'model_gemm': dense, 'grad_gemm': tri, 'total': 2 * tri + dense,
+            'dense_convention': 3 * dense}
+
+
+def fr_setup(eng, vb, d, n_rows, rank_row_offset, ring, slot0, seed=2):
+    rng = np.random.RandomState(seed)
     A = rng.randn(d, d)
     model = vb.CorrelatedGaussianModel(rng.randn(d), covariance=A @ A.T / d + np.eye(d))
     eng.set_model(model.device_spec())
     fr = vb.FullRankGaussian(d)
     L = np.exp(-1.0) * np.eye(d) + 0.01 * np.tril(np.random.RandomState(3).randn(d, d))
-    eng.fullrank_set_theta(fr.pack(np.zeros(d), L), d)
-    ring = 8
+    theta = fr.pack(np.zeros(d), L)
+    eng.fullrank_set_theta(theta, d)
     for s in range(ring):
-        eng.noise_generate(40 + s, n, d, seed=2, stream=s, row_offset=rank * n)
-    t_ramp = time.perf_counter()
-    for _ in range(4 if world > 1 else 1000):          # untimed clock ramp (see main); fixed count when the
-        for i in range(warmup):                        # calls are collective so that every rank issues the same
-            eng.elbo_grad_fullrank_enqueue(40 + i % ring, n, d, n_total=n_total)
-        eng.sync()
-        if world == 1 and time.perf_counter() - t_ramp > 0.2:
-            break
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        eng.elbo_grad_fullrank_enqueue(40 + i % ring, n, d, n_total=n_total)
+        eng.noise_generate(slot0 + s, n_rows, d, seed=seed, stream=s, row_offset=rank_row_offset)
+    return model, theta
+
+
+def timed_blocks(run_block, sync, group, steps, min_total_s=MIN_TIMED_S, max_blocks=200):
+    """Time blocks of exactly `steps` steps, each bracketed by barrier + device sync on both sides and reduced
+    with MAX over ranks; blocks are repeated until the timed total reaches `min_total_s` (the number of blocks is
+    decided from the first block's all-reduced time, so every rank runs the same number).  Returns the list of
+    per-block seconds."""
+    times = []
+    n_blocks = 1
+    b = 0
+    while b < n_blocks:
+        sync()
+        group.barrier()
+        t0 = time.perf_counter()
+        run_block(steps)
+        sync()
+        dt = time.perf_counter() - t0
+        group.barrier()
+        dt = group.allreduce_max(dt)
+        times.append(dt)
+        if b == 0:
+            n_blocks = int(min(max_blocks, max(3, np.ceil(min_total_s / max(dt, 1e-9)))))
+        b += 1
+    return times
+
+
+def fullrank_leg(eng, vb, _lib, group, d, steps, warmup, scaling='weak', slot0=40, ring=8, profile=True):
+    """FullRankGaussian + ExclusiveKL on the correlated-Gaussian target with the parameter resident on the device."""
+    world, rank = group.world, group.rank
+    if scaling == 'strong':
+        from viabel_amd.objectives import shard_rows
+        lo, hi = shard_rows(N_MC, world, rank)
+        n_rows, n_total, row_off = hi - lo, N_MC, lo
+    else:
+        n_rows, n_total, row_off = N_MC, N_MC * world, rank * N_MC
+    model, theta = fr_setup(eng, vb, d, n_rows, row_off, ring, slot0)
+
+    def run(k):
+        for i in range(k):
+            eng.elbo_grad_fullrank_enqueue(slot0 + i % ring, n_rows, d, n_total=n_total)
+
+    # untimed clock ramp: the GPU's power state follows load with tens of milliseconds of lag; a FIXED number of
+    # evaluations, because with a communicator every evaluation is a collective and every rank must issue the same
+    # number of them (ADVICE r1: a wall-clock ramp can deadlock the ranks)
+    run(600 if d >= 1024 else 1500)
     eng.sync()
-    dt = (time.perf_counter() - t0) / steps
-    barrier()
+    run(warmup)
+    eng.sync()
+    if profile:
+        eng.profile_enable(True)
+        for k in (_lib.PROF_FR_SAMPLE_GEMM, _lib.PROF_FR_MODEL_GEMM, _lib.PROF_FR_GRAD_GEMM):
+            eng.profile_read(reset=True, kernel=k)
+    times = timed_blocks(run, eng.sync, group, steps)
+    kern = {}
+    if profile:
+        for name, k in (('sample_gemm', _lib.PROF_FR_SAMPLE_GEMM), ('model_gemm', _lib.PROF_FR_MODEL_GEMM),
+                        ('grad_gemm', _lib.PROF_FR_GRAD_GEMM)):
+            n_l, _, ms = eng.profile_read(reset=True, kernel=k)
+            kern[name] = (n_l, 1e3 * ms / max(1, n_l))
+        eng.profile_enable(False)
     value, grad = eng.fullrank_get(d)
-    flops = 4.0 * n * d * d + 2.0 * n * d * d          # Z = E L^T, G^T E (dense convention) + target's (Z - m) P
+    sec_per_step = statistics.median(times) / steps
+    fl = fr_flops(n_rows, d)
+    per_kernel = {}
+    for name, (n_l, us) in kern.items():
+        tf = fl[name] / (us * 1e-6) / 1e12 if us > 0 else 0.0
+        per_kernel[name] = {'avg_kernel_us': us, 'launches_timed': n_l, 'flops_per_launch': fl[name],
+                            'achieved': tf, 'frac': tf / FP64_MFMA_PEAK_TFLOPS}
+    whole_tf = fl['total'] / sec_per_step / 1e12
     return {
-        'workload': 'FullRankGaussian + ExclusiveKL, D=1024, N_mc=4096 per GPU, correlated-Gaussian target, fp64',
-        'evals_per_s': world / dt, 'us_per_eval': 1e6 * dt, 'steps': steps, 'n_gpus': world,
-        'counting': '4096-sample evaluation units over all GPUs per second (rank 0 clock)',
-        'roofline': {'bound': 'mfma', 'achieved': flops / dt / 1e12, 'peak': FP64_MFMA_PEAK_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': flops / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                     'flops_per_eval_dense_convention': flops,
-                     'note': 'whole evaluation (3 MFMA GEMMs + O(ND) kernels); kernel split in profiles/'},
-        'check': {'value': value, 'grad_norm': float(np.linalg.norm(grad))},
+        'sec_per_step': sec_per_step, 'block_seconds': times, 'n_rows': n_rows, 'n_total': n_total,
+        '_model': model, '_theta': theta,
+        'value': value, 'grad_norm': float(np.linalg.norm(grad)), 'per_kernel': per_kernel,
+        'whole_evaluation': {'flops_executed': fl['total'], 'us_per_eval': 1e6 * sec_per_step, 'achieved': whole_tf,
+                             'frac': whole_tf / FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'flops_dense_convention': fl['dense_convention'],
+                             'note': 'executed flops count the triangles exactly (n d (d+1) for each triangular GEMM); '
+                                     'the dense convention would count 6 n d^2'},
     }
 
 
+# --------------------------------------------------------------------------------------------------------------
+# secondary legs (1 GPU, rank 0)
+# --------------------------------------------------------------------------------------------------------------
+def meanfield_leg(eng, vb, _lib, steps=2000, warmup=200, batch=32, ring_total=16):
+    """BASELINE configs[1]: MFGaussian + ExclusiveKL, D=1024 funnel, N_mc=4096; HBM-bound streaming kernel.
+    `evals_per_s_batched` shares one launch of each kernel between 32 independent evaluations (own noise matrix,
+    own theta, own result); `sync_call_evals_per_s` is the one-evaluation blocking call an optimiser loop issues."""
+    d = D1
+    algo_bytes = N_MC * d * 8 + 4 * d * 8 + 8
+    model = vb.FunnelModel(d)
+    eng.set_model(model.device_spec())
+    theta = np.concatenate([np.zeros(d), -np.ones(d)])       # SURVEY 8(d) C1: mu = 0, log sigma = -1
+    ring = min(max(batch, ring_total), _lib.MAX_SLOTS - 24)
+    for s in range(ring):
+        eng.noise_generate(s, N_MC, d, seed=1, stream=s)
+    fam = _lib.FAMILY_MF_GAUSSIAN
+    thetas = np.tile(theta, (batch, 1))
+    n_rsets = _lib.MAX_SLOTS // batch
+
+    def run(k):
+        done, call = 0, 0
+        while done < k:
+            b = min(batch, k - done)
+            slots = [(call * batch + i) % ring for i in range(b)]
+            rslots = [(call % n_rsets) * batch + i for i in range(b)]
+            eng.elbo_grad_meanfield_batch_async(slots, N_MC, d, thetas[:b], fam, rslots)
+            done += b
+            call += 1
+
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.3:
+        run(4 * batch)
+        eng.sync()
+    run(warmup)
+    eng.sync()
+    eng.profile_enable(True)
+    eng.profile_read(reset=True)
+    t0 = time.perf_counter()
+    run(steps)
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    launches, evals_timed, kernel_ms = eng.profile_read(reset=True)
+    eng.profile_enable(False)
+    n_sync = 500
+    t2 = time.perf_counter()
+    for i in range(n_sync):
+        eng.elbo_grad_meanfield(i % ring, N_MC, d, theta, fam)
+    sync_rate = n_sync / (time.perf_counter() - t2)
+    t3 = time.perf_counter()
+    for i in range(n_sync):
+        eng.elbo_grad_meanfield_philox(0, N_MC, d, theta, fam, 1, 1000 + i)
+    fresh_rate = n_sync / (time.perf_counter() - t3)
+    kernel_us = 1e3 * kernel_ms / max(1, launches)
+    bytes_per_launch = algo_bytes * evals_timed / max(1, launches)
+    achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+    # parity on the same noise
+    from oracle import families as ofam, models as omod, objectives as oobj
+    noise = eng.noise_get_host(0, N_MC, d)
+    dv, dg = eng.elbo_grad_meanfield(0, N_MC, d, theta, fam)
+    ov, og = oobj.exclusive_kl(ofam.MFGaussian(d), omod.Funnel(d), theta, noise)
+    return {
+        'workload': 'BASELINE configs[1]: MFGaussian + ExclusiveKL, D=1024 funnel, N_mc=4096, fp64',
+        'evals_per_s_batched': steps / elapsed, 'evals_per_launch': batch,
+        'sync_call_evals_per_s': sync_rate, 'fresh_noise_sync_call_evals_per_s': fresh_rate,
+        'roofline': {'bound': 'hbm', 'kernel': 'mf_accum_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'avg_kernel_us': kernel_us,
+                     'launches_timed': launches, 'algorithmic_bytes_per_launch': bytes_per_launch,
+                     'traffic': None,
+                     'traffic_reference': 'profiles/r01_meanfield_c1_pmc_hbm.txt: 1.02 x the algorithmic bytes '
+                                          '(PMC pass of round 1, not re-measured in this run)'},
+        'parity': {'rel_elbo_err': abs(dv - ov) / abs(ov),
+                   'rel_grad_err': float(np.max(np.abs(dg - og)) / np.max(np.abs(og)))},
+    }, theta
+
+
 def fit_leg(vb, theta, iters=1500):
-    """Secondary measurement: a whole RMSProp fit at the C1 shape (fresh Philox noise every iteration) through
-    the host loop (one blocking objective call + numpy step per iteration, optimization.py:91-112) and through
-    the device-resident loop (vb_fit); the two trajectories are the same bit for bit."""
+    """A whole RMSProp fit at the C1 shape (fresh Philox noise every iteration) through the host loop (one
+    blocking objective call + numpy step per iteration, optimization.py:91-112) and through the device-resident
+    loop (vb_fit); the two trajectories are the same bit for bit."""
     from viabel_amd.optimization import RMSProp
     out = {'workload': 'RMSProp(0.01), MFGaussian(rng=philox) + ExclusiveKL, D=1024 funnel, N_mc=4096, %d iterations'
                        % iters}
     hist = {}
     for mode, on_device in (('host_loop', False), ('device_loop', True)):
-        obj = vb.ExclusiveKL(vb.MFGaussian(D, rng='philox'), vb.FunnelModel(D), N_MC)
+        obj = vb.ExclusiveKL(vb.MFGaussian(D1, rng='philox'), vb.FunnelModel(D1), N_MC)
         opt = RMSProp(0.01)
         opt.optimize(200, obj, theta, on_device=on_device)
         t0 = time.perf_counter()
@@ -101,60 +237,77 @@ def fit_leg(vb, theta, iters=1500):
     return out
 
 
-def cpu_baseline(theta, budget_s=12.0):
-    """Oracle (numpy fp64 restatement of objectives.py:154-168) on the host cores, bounded."""
-    from oracle import families as ofam, models as omod, objectives as oobj
-    fam, model = ofam.MFGaussian(D), omod.Funnel(D)
-    t0 = time.perf_counter()
-    noise = np.random.RandomState(1).randn(N_MC, D)
-    t_rng = time.perf_counter() - t0
-    oobj.exclusive_kl(fam, model, theta, noise)          # warm-up
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        oobj.exclusive_kl(fam, model, theta, noise)
-        n += 1
-    dt = time.perf_counter() - t0
+def blas_threads_for_baseline():
+    """Threads the CPU baseline's GEMMs run on: the GPU boxes of this pool show 256 cores to a container whose
+    cgroup quota is far smaller, and an oversubscribed OpenBLAS pool is slower than a modest one."""
     try:
-        import threadpoolctl
-        blas_threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+        quota = len(os.sched_getaffinity(0))
     except Exception:
-        blas_threads = 1
-    return {
-        'value': n / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
-        'sample': '%d evaluations of the numpy oracle at the full C1 shape (D=1024, N_mc=4096), noise '
-                  'pre-generated; RandomState.randn for one matrix took %.3f s on top; host has %d cpus, '
-                  'elementwise numpy is single-threaded (BLAS threads %d unused: no GEMM on this path)'
-                  % (n, t_rng, os.cpu_count(), blas_threads),
-    }
+        quota = os.cpu_count() or 1
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            q, p = fh.read().split()
+            if q != 'max':
+                quota = min(quota, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(quota, 16))
 
 
-def parity_check(eng, theta, fam_id):
-    """BASELINE's second metric: relative ELBO error of the HIP path against the CPU restatement on the same
-    noise (one of the resident Philox matrices read back from the device).  north_star asks <= 1e-5."""
+def cpu_baseline_and_parity(eng, d, slot, dev_model, theta, budget_s=12.0):
+    """Oracle (numpy fp64 restatement of objectives.py:154-164 for the dense Gaussian family, oracle/objectives.py)
+    on the host cores: timed as the CPU baseline and, on the same noise matrix read back from the device, used as
+    the checker of the HIP result.  The only place this file touches oracle/."""
     from oracle import families as ofam, models as omod, objectives as oobj
-    noise = eng.noise_get_host(0, N_MC, D)
-    dv, dg = eng.elbo_grad_meanfield(0, N_MC, D, theta, fam_id)
-    ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omod.Funnel(D), theta, noise)
-    return {'rel_elbo_err': abs(dv - ov) / abs(ov), 'rel_grad_err': float(np.max(np.abs(dg - og)) / np.max(np.abs(og))),
-            'tolerance': 1e-5, 'against': 'numpy oracle (oracle/objectives.py) on the same 4096 x 1024 noise matrix'}
+    fam, model = ofam.FullRankGaussian(d), omod.GaussFull(dev_model.mean, dev_model.precision)
+    noise = eng.noise_get_host(slot, N_MC, d)
+    eng.set_model(dev_model.device_spec())
+    eng.fullrank_set_theta(theta, d)
+    eng.elbo_grad_fullrank_enqueue(slot, N_MC, d)
+    dv, dg = eng.fullrank_get(d)
+    threads = blas_threads_for_baseline()
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads, user_api='blas')
+    except Exception:
+        limiter, threads = None, -1
+    try:
+        ov, og = oobj.exclusive_kl(fam, model, theta, noise)          # warm-up + parity
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and n < 200:
+            oobj.exclusive_kl(fam, model, theta, noise)
+            n += 1
+        dt = time.perf_counter() - t0
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits() if hasattr(limiter, 'restore_original_limits') else None
+    t0 = time.perf_counter()
+    np.random.RandomState(1).randn(N_MC // 8, d)
+    t_rng = 8 * (time.perf_counter() - t0)
+    base = {
+        'value': n / dt, 'unit': 'evals/s', 'cores': threads, 'kind': 'port',
+        'sample': '%d evaluations of the numpy oracle at the full headline shape (FullRankGaussian D=%d, N_mc=%d, '
+                  'correlated-Gaussian target: three %d x %d x %d fp64 GEMMs through the host BLAS on %d threads + '
+                  'elementwise numpy on one), noise pre-generated; RandomState.randn for one matrix would add ~%.2f s; '
+                  'host shows %d cpus' % (n, d, N_MC, N_MC, d, d, threads, t_rng, os.cpu_count()),
+    }
+    parity = {'rel_elbo_err': abs(dv - ov) / abs(ov), 'rel_grad_err': float(np.max(np.abs(dg - og)) / np.max(np.abs(og))),
+              'tolerance': 1e-5, 'against': 'numpy oracle (oracle/objectives.py) on the same %d x %d noise matrix read '
+                                            'back from the device; north_star asks 1e-5 on the ELBO' % (N_MC, d)}
+    return base, parity
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=200)
-    ap.add_argument('--ring', type=int, default=16, help='noise matrices cycled (16 x 33.5 MB > L3)')
-    ap.add_argument('--engines', type=int, default=1,
-                    help='independent HIP contexts (streams) the evaluations are spread over, so the '
-                         'small prep / finalize kernels of one evaluation overlap the streaming kernel of another')
-    ap.add_argument('--batch', type=int, default=32,
-                    help='independent evaluations per API call (share one launch of each kernel)')
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--force-comm', action='store_true',
                     help='attach an RCCL communicator even with one rank (exercises the sharded code path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-fit', action='store_true', help='skip the secondary optimiser-loop measurement')
-    ap.add_argument('--no-fullrank', action='store_true', help='skip the secondary full-rank measurement')
+    ap.add_argument('--no-legs', action='store_true', help='headline only (skip the secondary legs)')
+    ap.add_argument('--no-profile', action='store_true', help='no per-kernel HIP events in the timed region')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -165,168 +318,84 @@ def main():
     from viabel_amd import _lib, distributed
     import viabel_amd as vb
 
-    dist = None
-    use_comm = world > 1 or args.force_comm
-    if use_comm:
-        import torch.distributed as dist
-        if 'RANK' not in os.environ:      # plain `python bench.py --force-comm`
-            os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29531')
-        dist.init_process_group(backend='gloo')
-    eng = _lib.default_engine()
+    group = distributed.SocketGroup.from_env() if world > 1 else distributed.SocketGroup(0, 1)
     # VB_BENCH_NO_RCCL=1: control-flow dry run of the N > 1 branches on a box with fewer GPUs than ranks (the ranks
-    # then share a device, RCCL refuses that, and no communicator is attached: the numbers mean nothing)
+    # share device 0, RCCL refuses that, so no communicator is attached: the numbers mean nothing)
     no_rccl = world > 1 and os.environ.get('VB_BENCH_NO_RCCL') == '1'
-    if use_comm and not no_rccl:
-        if world > 1:
-            distributed.attach(eng)
-        else:
-            eng.comm_init(_lib.Engine.comm_unique_id(), 1, 0)
-
-    model = vb.FunnelModel(D)
-    theta = np.concatenate([np.zeros(D), -np.ones(D)])       # mu = 0, log sigma = -1
-    n_total = N_MC * world
-    batch = max(1, min(args.batch, 32))
-    engines = [eng] + [_lib.Engine(eng.device) for _ in range(max(1, args.engines) - 1)]
+    eng = _lib.Engine(0) if no_rccl else _lib.default_engine()
+    _lib.set_default_engine(eng)
     if world > 1 and not no_rccl:
-        for e in engines[1:]:
-            distributed.attach(e)
-    elif use_comm:
-        for e in engines[1:]:
-            e.comm_init(_lib.Engine.comm_unique_id(), 1, 0)
-    n_eng = len(engines)
-    # noise matrices per engine: at least one batch, and > 256 MiB L3 over all engines
-    ring = min(max(batch, (args.ring + n_eng - 1) // n_eng), _lib.MAX_SLOTS - 8)
-    for k, e in enumerate(engines):                              # synthetic noise, resident in HBM
-        e.set_model(model.device_spec())
-        for s in range(ring):
-            e.noise_generate(s, N_MC, D, seed=1, stream=k * ring + s, row_offset=rank * N_MC)
-    fam = _lib.FAMILY_MF_GAUSSIAN
-    thetas = np.tile(theta, (batch, 1))
-    n_rsets = _lib.MAX_SLOTS // batch
+        distributed.attach(eng, group)
+    elif args.force_comm and world == 1:
+        eng.comm_init(_lib.Engine.comm_unique_id(), 1, 0)
+    rccl_ranks = eng.comm_info()[0]
 
-    def sync_all():
-        for e in engines:
-            e.sync()
-
-    def barrier():
-        sync_all()
-        if dist is not None:
-            dist.barrier()
-
-    def run(steps):
-        """Enqueue exactly `steps` evaluations, `batch` per call, round-robin over the engines."""
-        done, call = 0, 0
-        last = None
-        while done < steps:
-            b = min(batch, steps - done)
-            e = engines[call % n_eng]
-            j = call // n_eng
-            slots = [(j * batch + i) % ring for i in range(b)]
-            rslots = [(j % n_rsets) * batch + i for i in range(b)]
-            e.elbo_grad_meanfield_batch_async(slots, N_MC, D, thetas[:b], fam, rslots, n_total=n_total)
-            last = (e, rslots[-1])
-            done += b
-            call += 1
-        return last
-
-    # untimed clock ramp: the GPU's power state follows load with tens of milliseconds of lag, and the timed
-    # region below is only ~13 ms long at the default K, so bring the device to its sustained clocks first
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.3:
-        run(4 * batch)
-        sync_all()
-    run(args.warmup)
-    barrier()
-    for e in engines:
-        e.profile_enable(True)
-        e.profile_read(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    last = run(args.steps)
-    sync_all()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    barrier()
-    launches, evals_timed, kernel_ms = 0, 0, 0.0
-    for e in engines:
-        n_l, n_e, ms = e.profile_read(reset=True)
-        launches += n_l
-        evals_timed += n_e
-        kernel_ms += ms
-        e.profile_enable(False)
-    last_value, last_grad = last[0].result_get(last[1], 2 * D)
-
-    # blocking-call rate (what a host-side optimiser loop sees: one evaluation per call, wait for it)
-    n_sync = min(args.steps, 500)
-    t2 = time.perf_counter()
-    for i in range(n_sync):
-        eng.elbo_grad_meanfield(i % ring, N_MC, D, theta, fam, n_total=n_total)
-    sync_rate = n_sync / (time.perf_counter() - t2)
-    # the same blocking call on FRESH noise generated inside the streaming kernel (Philox + Box-Muller in
-    # registers: what an optimiser loop in rng='philox' mode issues every iteration)
-    t3 = time.perf_counter()
-    for i in range(n_sync):
-        eng.elbo_grad_meanfield_philox(0, N_MC, D, theta, fam, 1, 1000 + i, n_total=n_total, row_offset=rank * N_MC)
-    fresh_rate = n_sync / (time.perf_counter() - t3)
-
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    head = fullrank_leg(eng, vb, _lib, group, FR_D, args.steps, args.warmup, scaling=args.scaling,
+                        profile=not args.no_profile)
+    other = None
+    if world > 1:          # the other scaling mode as a nested leg (collective: every rank runs it)
+        other_mode = 'strong' if args.scaling == 'weak' else 'weak'
+        other = fullrank_leg(eng, vb, _lib, group, FR_D, args.steps, args.warmup, scaling=other_mode, profile=False)
+        other['scaling'] = other_mode
 
     out = None
     if rank == 0:
-        kernel_us = 1e3 * kernel_ms / max(1, launches)
-        bytes_per_launch = ALGO_BYTES * evals_timed / max(1, launches)
-        achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+        sec = head['sec_per_step']
+        units = world if args.scaling == 'weak' else 1
+        mg = head['per_kernel'].get('model_gemm')
+        roof = {'bound': 'mfma', 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'traffic': None,
+                'whole_evaluation': head['whole_evaluation'], 'per_kernel': head['per_kernel']}
+        if mg:
+            roof.update({'kernel': 'gemm_f64_dma_kernel<A[m][k], 128x64, EpiNegate>: G = -(Z - m) P, dense %d x %d x %d '
+                                   '(the dominant kernel of the evaluation)' % (head['n_rows'], FR_D, FR_D),
+                         'achieved': mg['achieved'], 'frac': mg['frac'], 'avg_kernel_us': mg['avg_kernel_us'],
+                         'launches_timed': mg['launches_timed'], 'flops_per_launch': mg['flops_per_launch'],
+                         'peak_source': 'datasheet fp64 matrix = 128 flop/clk/CU x 256 CUs x 2.4 GHz; the part sustains '
+                                        '~1.93 GHz under this kernel with random operands (tools/gemm_bench.hip), '
+                                        'i.e. a clock-limited ceiling of ~63 TFLOP/s'})
+        else:
+            we = head['whole_evaluation']
+            roof.update({'kernel': 'whole evaluation', 'achieved': we['achieved'], 'frac': we['frac']})
         out = {
             'metric': 'ELBO-gradient evals/sec (D=1024, N_mc=4096)',
-            'value': world * args.steps / elapsed,
-            'unit': 'evals/s',
+            'value': units / sec, 'unit': 'evals/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': 1e3 * sec, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE configs[1]: MFGaussian + ExclusiveKL, D=1024 funnel, N_mc=4096 per GPU',
-                'family': 'MFGaussian', 'objective': 'ExclusiveKL (entropy form)', 'model': 'funnel',
-                'dim': D, 'n_mc_per_gpu': N_MC, 'n_mc_global': n_total,
-                'noise': 'Philox4x32-10 normals resident in HBM, %d matrices cycled (%.0f MB > 256 MiB L3)' % (
-                    ring * n_eng, ring * n_eng * N_MC * D * 8 / 1e6),
-                'parallelism': 'mc-axis dp%d, one RCCL all-reduce of %d doubles per evaluation' % (
-                    world, 8 + 2 * D) if world > 1 else 'single GPU',
-                'pipelining': '%d independent evaluations (own noise matrix, own theta, own result) per API '
-                              'call share one launch of each kernel; calls go round-robin to %d HIP streams; '
-                              'results are written to pinned host memory by the finalize kernel; the '
-                              'one-evaluation blocking-call rate is sync_call_evals_per_s' % (batch, n_eng),
+                'workload': 'north_star headline: FullRankGaussian + ExclusiveKL, D=1024, N_mc=4096%s, '
+                            'correlated-Gaussian target (dense precision)' % (' per GPU' if args.scaling == 'weak' and world > 1 else ''),
+                'family': 'FullRankGaussian (theta = [mu | free Cholesky], 525 824 parameters)',
+                'objective': 'ExclusiveKL (entropy form)', 'model': 'correlated Gaussian', 'dim': FR_D,
+                'n_mc_per_gpu': head['n_rows'], 'n_mc_global': head['n_total'],
+                'noise': 'Philox4x32-10 normals resident in HBM, 8 matrices cycled (268 MB > 256 MiB L3)',
+                'parallelism': ('mc-axis dp%d, one RCCL all-reduce of %d doubles per evaluation'
+                                % (world, 16 + FR_D + FR_D * (FR_D + 1) // 2)) if world > 1 else 'single GPU',
+                'pipelining': 'none: one evaluation per call, all calls on one HIP stream, each behind the previous one',
             },
-            'sync_call_evals_per_s': world * sync_rate,
-            'fresh_noise_sync_call_evals_per_s': world * fresh_rate,
-            'check': {'value': last_value, 'grad_norm': float(np.linalg.norm(last_grad))},
-            'roofline': {
-                'bound': 'hbm', 'kernel': 'mf_accum_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': PMC_TRAFFIC_BYTES_PER_EVAL * evals_timed / max(1, launches),
-                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_meanfield_c1_pmc_hbm.txt',
-                'algorithmic_bytes_per_launch': bytes_per_launch, 'evals_per_launch': evals_timed / max(1, launches),
-                'avg_kernel_us': kernel_us, 'launches_timed': launches,
-            },
+            'rccl_ranks': rccl_ranks,
+            'timing': {'timed_blocks': len(head['block_seconds']), 'steps_per_block': args.steps,
+                       'ms_per_step_of': 'median block', 'block_ms': [1e3 * t for t in head['block_seconds']],
+                       'timed_total_s': float(sum(head['block_seconds']))},
+            'check': {'value': head['value'], 'grad_norm': head['grad_norm']},
+            'roofline': roof,
         }
+        if other is not None:
+            u2 = world if other['scaling'] == 'weak' else 1
+            out['other_scaling'] = {'scaling': other['scaling'], 'value': u2 / other['sec_per_step'], 'unit': 'evals/s',
+                                    'ms_per_step': 1e3 * other['sec_per_step'], 'n_mc_per_gpu': other['n_rows'],
+                                    'n_mc_global': other['n_total']}
         if world == 1 and not args.no_cpu_baseline:
-            # the cpu_baseline leg, after the timed region: the only place this file touches oracle/ -- timed as
-            # the CPU baseline and, on the same inputs, used as the checker of the HIP result (never measured as ours)
-            out['cpu_baseline'] = cpu_baseline(theta)
-            out['parity'] = parity_check(eng, theta, fam)
-    if out is not None and world == 1 and not args.no_fit:
-        import contextlib
-        import io
-        with contextlib.redirect_stderr(io.StringIO()):    # tqdm progress bars of the host loop
-            out['fit_loop'] = fit_leg(vb, theta)
-    if not args.no_fullrank:                               # collective when world > 1: every rank runs it
-        fr_out = fullrank_leg(eng, vb, world=world, rank=rank, barrier=barrier)
-        if out is not None:
-            out['fullrank'] = fr_out
+            out['cpu_baseline'], out['parity'] = cpu_baseline_and_parity(eng, FR_D, 40, head['_model'], head['_theta'])
+        if world == 1 and not args.no_legs:
+            import contextlib
+            import io
+            out['c2_fullrank_d512'] = {k: v for k, v in fullrank_leg(
+                eng, vb, _lib, group, 512, max(args.steps, 200), args.warmup, profile=True).items()
+                if k in ('whole_evaluation', 'per_kernel', 'value', 'grad_norm')}
+            out['c1_meanfield'], theta1 = meanfield_leg(eng, vb, _lib)
+            with contextlib.redirect_stderr(io.StringIO()):    # tqdm progress bars of the host loop
+                out['fit_loop'] = fit_leg(vb, theta1)
     if rank == 0:
         # RCCL prints a version banner through C stdio; push it out first so the JSON is the last line
         import ctypes
@@ -336,9 +405,8 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.barrier()
+    group.close()
 
 
 if __name__ == '__main__':

@@ -320,14 +320,24 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
 int vb_comm_unique_id(char id[VB_COMM_ID_BYTES]);
 int vb_comm_init(vb_ctx* ctx, const char id[VB_COMM_ID_BYTES], int n_ranks, int rank);
 int vb_comm_destroy(vb_ctx* ctx);
+/* what the attached RCCL communicator itself reports (ncclCommCount / ncclCommUserRank); 1 / 0 without one */
+int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank);
 
-/* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernel ----------
- * When enabled, every launch of the accumulation kernel carries a start/stop event pair
- * (hipExtLaunchKernel: the kernel's own begin/end timestamps on the context's stream);
- * vb_profile_read returns launches, evaluations covered and total milliseconds since the
- * last reset.                                                                           */
+/* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels ---------
+ * When enabled, every launch of a profiled kernel carries a start/stop event pair
+ * (hipExtLaunchKernel: the kernel's own begin/end timestamps on the context's stream).
+ * vb_profile_read returns launches, evaluations covered and total milliseconds of the mean-field
+ * accumulation kernel (VB_PROF_MF_ACCUM) since the last reset; vb_profile_read_kernel does the same
+ * for one kernel id and leaves the records of the other kernels alone.                   */
+#define VB_PROF_MF_ACCUM 0        /* mean-field streaming kernel (mf_accum_kernel)                    */
+#define VB_PROF_FR_SAMPLE_GEMM 1  /* dense family: Z = E L' + mu (triangular k range)                 */
+#define VB_PROF_FR_MODEL_GEMM 2   /* correlated-Gaussian target: G = -(Z - m) P (dense)               */
+#define VB_PROF_FR_GRAD_GEMM 3    /* dense family: C = G' E (lower-triangular tiles, split over rows) */
+#define VB_PROF_NUM 4
 int vb_profile_enable(vb_ctx* ctx, int on);
 int vb_profile_read(vb_ctx* ctx, int64_t* launches, int64_t* evals, double* total_ms, int reset);
+int vb_profile_read_kernel(vb_ctx* ctx, int kernel_id, int64_t* launches, int64_t* evals, double* total_ms,
+                           int reset);
 
 #ifdef __cplusplus
 }

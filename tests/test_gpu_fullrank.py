@@ -43,7 +43,7 @@ def _theta(fr, D, rng):
     return fr.pack(0.3 * rng.randn(D), L)
 
 
-@pytest.mark.parametrize('D,N', [(3, 8), (5, 30), (64, 333), (130, 257), (200, 1000), (512, 4096)])
+@pytest.mark.parametrize('D,N', [(3, 8), (5, 30), (64, 333), (130, 257), (200, 1000), (512, 4096), (1024, 4096)])
 def test_fullrank_against_oracle(vb, D, N):
     rng = np.random.RandomState(D + N)
     ofr = ofam.FullRankGaussian(D)
@@ -57,7 +57,7 @@ def test_fullrank_against_oracle(vb, D, N):
         assert G.rel_err(grad, og) < 1e-11, (type(omodel).__name__, G.rel_err(grad, og))
 
 
-@pytest.mark.parametrize('D,N', [(1, 4), (3, 8), (5, 30), (64, 333), (130, 257), (200, 1000), (512, 4096)])
+@pytest.mark.parametrize('D,N', [(1, 4), (3, 8), (5, 30), (64, 333), (130, 257), (200, 1000), (512, 4096), (1024, 4096)])
 def test_fullrank_path_derivative_against_oracle(vb, D, N):
     """use_path_deriv=True (objectives.py:156-159) for the dense Gaussian: the score L^-T eps enters through the
     noise Gram matrix and a Newton-iteration inverse of L' on the device; the oracle solves the triangular

@@ -169,14 +169,22 @@ int main(int argc, char** argv) {
     printf("cfg %d dense  A[m][k]  M=%d N=%d K=%d: %.1f us  %.2f TFLOP/s\n", cfg, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
 #ifdef VB_GEMM_CLOCK
     {
-      std::vector<long long> o(2 * 4096);
+      std::vector<long long> o(8 * 4096);
       hipMemcpyFromSymbol(o.data(), HIP_SYMBOL(vb_gemm_dbg), o.size() * sizeof(long long));
       const int nb = (M / (cfg == 3 ? 64 : 128)) * (N / (cfg == 1 ? 128 : 64));
-      double cyc = 0, wall = 0, wmax = 0;
-      for (int i = 0; i < nb; ++i) cyc += o[2 * i], wall += o[2 * i + 1], wmax = wmax > o[2 * i + 1] ? wmax : o[2 * i + 1];
-      cyc /= nb, wall /= nb;
-      printf("   main loop per workgroup: %.0f shader cycles in %.1f us (max %.1f us) -> %.0f MHz; %.1f cycles per slab\n", cyc, wall / 100.0,
-             wmax / 100.0, cyc / (wall / 100.0), cyc / (K / 16));
+      const int nw = 4 * (nb < 1024 ? nb : 1024);
+      double pro = 0, loop = 0, epi = 0, wall = 0, first = 1e30, last = 0;
+      for (int i = 0; i < nw; ++i) {
+        pro += o[8 * i], loop += o[8 * i + 1], epi += o[8 * i + 2], wall += o[8 * i + 3];
+        first = o[8 * i + 4] < first ? (double)o[8 * i + 4] : first;
+        last = o[8 * i + 4] + o[8 * i + 3] > last ? (double)(o[8 * i + 4] + o[8 * i + 3]) : last;
+      }
+      pro /= nw, loop /= nw, epi /= nw, wall /= nw;
+      const double mhz = (pro + loop + epi) / (wall / 100.0);
+      printf("   per wave: prologue %.0f, main loop %.0f (%.1f per slab), epilogue %.0f shader cycles; lifetime %.1f us -> %.0f MHz; "
+             "first start to last end %.1f us\n", pro, loop, loop / (K / 16), epi, wall / 100.0, mhz, (last - first) / 100.0);
+      printf("   in us at that clock: prologue %.1f, loop %.1f, epilogue %.1f; MFMA floor of the loop (2 waves/SIMD x 16 cycles) %.1f us\n",
+             pro / mhz, loop / mhz, epi / mhz, 2.0 * (K / 16) * 4 * (cfg == 1 ? 64 : cfg == 2 ? 32 : 16) * 16 / mhz);
     }
 #endif
     return 0;

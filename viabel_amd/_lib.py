@@ -27,6 +27,7 @@ CV_MODES = {None: 0, 'full': 1, 'mean_only': 2, 'loo_diag_approx': 3, 'loo_direc
 MAX_SLOTS = 64
 OPT_SGD, OPT_RMSPROP, OPT_ADAM, OPT_ADAGRAD = range(4)
 COMM_ID_BYTES = 128
+PROF_MF_ACCUM, PROF_FR_SAMPLE_GEMM, PROF_FR_MODEL_GEMM, PROF_FR_GRAD_GEMM = range(4)
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int64_p = ctypes.POINTER(ctypes.c_int64)
@@ -123,9 +124,13 @@ SIGNATURES = {
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_destroy': (ctypes.c_int, [_ctx_p]),
+    'vb_comm_info': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     'vb_profile_enable': (ctypes.c_int, [_ctx_p, ctypes.c_int]),
     'vb_profile_read': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                        ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
+    'vb_profile_read_kernel': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
+                                              ctypes.c_int]),
 }
 
 _lib = None
@@ -191,11 +196,13 @@ class Engine:
             raise EngineError('no MI355X visible to HIP (%s); the engine has no CPU fallback'
                               % self._lib.vb_last_error(None).decode())
         ctx = _ctx_p()
-        rc = self._lib.vb_create(int(device) % n.value, ctypes.byref(ctx))
+        # no wrap-around: a rank whose LOCAL_RANK has no GPU must fail, not share another rank's device
+        rc = self._lib.vb_create(int(device), ctypes.byref(ctx))
         if rc != VB_OK:
-            raise EngineError('vb_create failed: ' + self._lib.vb_last_error(None).decode())
+            raise EngineError('vb_create(device=%d) failed: %s (%d device(s) visible)'
+                              % (int(device), self._lib.vb_last_error(None).decode(), n.value))
         self._ctx = ctx
-        self.device = int(device) % n.value
+        self.device = int(device)
         self._model_key = None
         self.n_ranks, self.rank = 1, 0
 
@@ -558,16 +565,23 @@ class Engine:
         self._check(self._lib.vb_comm_destroy(self._ctx))
         self.n_ranks, self.rank = 1, 0
 
+    def comm_info(self):
+        """(ranks, rank) as the RCCL communicator reports them; (1, 0) without a communicator."""
+        n, r = ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self._lib.vb_comm_info(self._ctx, ctypes.byref(n), ctypes.byref(r)))
+        return n.value, r.value
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, on=True):
         self._check(self._lib.vb_profile_enable(self._ctx, int(bool(on))))
 
-    def profile_read(self, reset=True):
+    def profile_read(self, reset=True, kernel=PROF_MF_ACCUM):
+        """(launches, evaluations, total ms) of one profiled kernel (``PROF_*``) since the last reset."""
         n = ctypes.c_int64(0)
         ev = ctypes.c_int64(0)
         ms = ctypes.c_double(0.0)
-        self._check(self._lib.vb_profile_read(self._ctx, ctypes.byref(n), ctypes.byref(ev), ctypes.byref(ms),
-                                              int(reset)))
+        self._check(self._lib.vb_profile_read_kernel(self._ctx, int(kernel), ctypes.byref(n), ctypes.byref(ev),
+                                                     ctypes.byref(ms), int(reset)))
         return n.value, ev.value, ms.value
 
 

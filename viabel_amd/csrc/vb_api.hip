@@ -76,19 +76,20 @@ static int main_stream_write(vb_ctx* ctx) {
   return VB_OK;
 }
 
-void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals) {
+void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals, int kernel_id) {
   *ev0 = *ev1 = nullptr;
-  if (!ctx->profile) return;
-  if (ctx->prof_used == ctx->prof_events.size()) {
+  if (!ctx->profile || kernel_id < 0 || kernel_id >= VB_PROF_NUM) return;
+  vb_ctx::ProfLog& log = ctx->prof[kernel_id];
+  if (log.used == log.events.size()) {
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
-    ctx->prof_events.push_back({a, b});
+    log.events.push_back({a, b});
   }
-  *ev0 = ctx->prof_events[ctx->prof_used].first;
-  *ev1 = ctx->prof_events[ctx->prof_used].second;
-  ctx->prof_used++;
-  ctx->prof_evals += evals;
+  *ev0 = log.events[log.used].first;
+  *ev1 = log.events[log.used].second;
+  log.used++;
+  log.evals += evals;
 }
 
 static int check_slot(vb_ctx* ctx, int slot) {
@@ -224,13 +225,15 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->pin_host) (void)hipHostFree(ctx->pin_host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
-                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work, &ctx->lr_work, &ctx->mvt_elbo})
+                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work,
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
-  for (auto& ev : ctx->prof_events) {
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
-  }
+  for (auto& log : ctx->prof)
+    for (auto& ev : log.events) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return VB_OK;
@@ -1000,24 +1003,32 @@ int vb_profile_enable(vb_ctx* ctx, int on) {
   return VB_OK;
 }
 
-int vb_profile_read(vb_ctx* ctx, int64_t* launches, int64_t* evals, double* total_ms, int reset) {
+int vb_profile_read_kernel(vb_ctx* ctx, int kernel_id, int64_t* launches, int64_t* evals, double* total_ms,
+                           int reset) {
   if (!ctx || !launches || !total_ms) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (kernel_id < 0 || kernel_id >= VB_PROF_NUM)
+    return fail(ctx, VB_ERR_INVALID, "profile kernel id %d out of range [0, %d)", kernel_id, VB_PROF_NUM);
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(sync_streams(ctx));
+  vb_ctx::ProfLog& log = ctx->prof[kernel_id];
   double ms = 0.0;
-  for (size_t i = 0; i < ctx->prof_used; ++i) {
+  for (size_t i = 0; i < log.used; ++i) {
     float t = 0.f;
-    VB_HIP(ctx, hipEventElapsedTime(&t, ctx->prof_events[i].first, ctx->prof_events[i].second));
+    VB_HIP(ctx, hipEventElapsedTime(&t, log.events[i].first, log.events[i].second));
     ms += t;
   }
-  *launches = (int64_t)ctx->prof_used;
+  *launches = (int64_t)log.used;
   *total_ms = ms;
-  if (evals) *evals = ctx->prof_evals;
+  if (evals) *evals = log.evals;
   if (reset) {
-    ctx->prof_used = 0;
-    ctx->prof_evals = 0;
+    log.used = 0;
+    log.evals = 0;
   }
   return VB_OK;
+}
+
+int vb_profile_read(vb_ctx* ctx, int64_t* launches, int64_t* evals, double* total_ms, int reset) {
+  return vb_profile_read_kernel(ctx, VB_PROF_MF_ACCUM, launches, evals, total_ms, reset);
 }
 
 }  // extern "C"

@@ -74,6 +74,17 @@ int vb_comm_init(vb_ctx* ctx, const char id[VB_COMM_ID_BYTES], int n_ranks, int 
   return VB_OK;
 }
 
+int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank) {
+  if (!ctx || !n_ranks || !rank) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  *n_ranks = 1;
+  *rank = 0;
+  if (!ctx->comm) return VB_OK;      // no communicator: a one-rank job
+  ncclResult_t r = ncclCommCount((ncclComm_t)ctx->comm, n_ranks);
+  if (r == ncclSuccess) r = ncclCommUserRank((ncclComm_t)ctx->comm, rank);
+  if (r != ncclSuccess) return fail(ctx, VB_ERR_COMM, "ncclCommCount failed: %s", ncclGetErrorString(r));
+  return VB_OK;
+}
+
 int vb_comm_destroy(vb_ctx* ctx) {
   if (!ctx || !ctx->comm) return VB_OK;
   ncclCommDestroy((ncclComm_t)ctx->comm);

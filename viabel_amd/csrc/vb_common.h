@@ -147,9 +147,11 @@ struct vb_ctx {
   int n_ranks = 1, rank = 0;
 
   bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-  size_t prof_used = 0;
-  int64_t prof_evals = 0;               // evaluations covered by the recorded launches
+  struct ProfLog {                      // one per profiled kernel id (VB_PROF_*)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t used = 0;
+    int64_t evals = 0;                  // evaluations covered by the recorded launches
+  } prof[VB_PROF_NUM];
 
   // completion tickets: enqueue k records batch_events[k % size] after its last kernel, so a
   // result slot is never re-staged while the evaluation that used it is still in flight
@@ -353,7 +355,7 @@ int comm_allreduce_max(vb_ctx* ctx, hipStream_t stream, double* buf, size_t coun
 int comm_allgather(vb_ctx* ctx, hipStream_t stream, const double* send, double* recv, size_t count);
 
 // profiling: event pair for the next launch of the dominant kernel (nullptrs when disabled)
-void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals);
+void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals, int kernel_id = VB_PROF_MF_ACCUM);
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 

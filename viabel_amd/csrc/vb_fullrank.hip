@@ -748,7 +748,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   g1.N = D;
   g1.K = D;
   g1.tri_mode = mvt ? 0 : 1;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  prof_events(ctx, &g1.ev0, &g1.ev1, 1, VB_PROF_FR_SAMPLE_GEMM);
   int fmode = 0;
   if (m.id == VB_MODEL_GAUSS_DIAG) {
     gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiag{G, ldz, mu, m.p0, m.p1, row_scale});
@@ -789,6 +789,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     g2.N = D;
     g2.K = D;
     g2.tri_mode = 0;
+    prof_events(ctx, &g2.ev0, &g2.ev1, 1, VB_PROF_FR_MODEL_GEMM);
     gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz});
     fmode = 2;
   }
@@ -820,8 +821,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   g3.N = D;
   g3.K = (int)n;
   g3.tri_mode = mvt ? 0 : 2;
-  (void)ev0;
-  (void)ev1;
+  prof_events(ctx, &g3.ev0, &g3.ev1, 1, VB_PROF_FR_GRAD_GEMM);
   gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
   VB_HIP(ctx, hipGetLastError());
 

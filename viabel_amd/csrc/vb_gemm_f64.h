@@ -39,7 +39,7 @@ typedef double d4v __attribute__((ext_vector_type(4)));
 constexpr int kGemmBK = 16;   // block tile: (32 AF) x (8 NB) x 16; AF / NB = A / B fragments per wave and k-step
 
 #ifdef VB_GEMM_CLOCK
-__device__ long long vb_gemm_dbg[2 * 4096];
+__device__ long long vb_gemm_dbg[8 * 4096];
 #endif
 
 struct GemmArgs {
@@ -56,6 +56,8 @@ struct GemmArgs {
   // epilogue receives z as its `split` argument
   int batch = 0;
   int64_t batch_a = 0, batch_b = 0;
+  // optional start / stop events of the launch (hipExtLaunchKernel: the kernel's own begin / end timestamps)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 // Epilogue functor interface:  void operator()(int split, int row, int col, double acc) const;
@@ -362,11 +364,11 @@ inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, co
     return;
   }
   if (cfg == 1)
-    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, 16, Epi>), grid, dim3(256), 0, st, g, epi);
+    hipExtLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, 16, Epi>), grid, dim3(256), 0, st, g.ev0, g.ev1, 0, g, epi);
   else if (cfg == 2)
-    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, 8, Epi>), grid, dim3(256), 0, st, g, epi);
+    hipExtLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, 8, Epi>), grid, dim3(256), 0, st, g.ev0, g.ev1, 0, g, epi);
   else
-    hipLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 2, 8, Epi>), grid, dim3(256), 0, st, g, epi);
+    hipExtLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 2, 8, Epi>), grid, dim3(256), 0, st, g.ev0, g.ev1, 0, g, epi);
 }
 
 }  // namespace vb

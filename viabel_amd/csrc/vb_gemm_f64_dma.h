@@ -39,6 +39,10 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+#ifdef VB_GEMM_CLOCK
+  const long long dbg_t0 = clock64(), dbg_w0 = wall_clock64();
+  long long dbg_t1 = dbg_t0, dbg_t2 = dbg_t0;
+#endif
 
   // ---- tile assignment (as gemm_f64_kernel) -----------------------------------------------------
   int bm, bn;
@@ -208,6 +212,9 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
     __asm__ volatile("" ::: "memory");
     load_frags(0, 0, 0);
     int st = 0;
+#ifdef VB_GEMM_CLOCK
+    dbg_t1 = clock64();
+#endif
     for (int s = 0; s < nslabs; ++s) {
       const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
       if (s + 2 < nslabs) advance();   // beyond the end: re-fetch the last slab into a free stage
@@ -230,6 +237,9 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
     }
     __builtin_amdgcn_s_waitcnt(0);     // nothing in flight into LDS when the epilogue reuses it
     __builtin_amdgcn_s_barrier();
+#ifdef VB_GEMM_CLOCK
+    dbg_t2 = clock64();
+#endif
   }
 
   // ---- epilogue (as gemm_f64_kernel) -------------------------------------------------------------------------
@@ -255,6 +265,17 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
     if (t == 0)
       epi.part[(int64_t)blockIdx.z * gridDim.x + blockIdx.x] = (gemm_lds[0] + gemm_lds[1]) + (gemm_lds[2] + gemm_lds[3]);
   }
+#ifdef VB_GEMM_CLOCK
+  __builtin_amdgcn_s_waitcnt(0);       // the epilogue's stores have left
+  if (lane == 0 && blockIdx.x < 1024) {
+    long long* o = vb_gemm_dbg + 8 * (4 * blockIdx.x + wave);
+    o[0] = dbg_t1 - dbg_t0;            // prologue (tile setup + first two slab fetches)
+    o[1] = dbg_t2 - dbg_t1;            // main loop
+    o[2] = clock64() - dbg_t2;         // epilogue
+    o[3] = wall_clock64() - dbg_w0;    // whole workgroup lifetime, 100 MHz ticks
+    o[4] = dbg_w0;
+  }
+#endif
 }
 
 template <bool A_KCONTIG, int AF, int NB, class Epi>
@@ -266,7 +287,7 @@ inline void gemm_f64_dma_launch(hipStream_t st, const GemmArgs& g, dim3 grid, co
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  hipLaunchKernelGGL((gemm_f64_dma_kernel<A_KCONTIG, AF, NB, Epi>), grid, dim3(256), lds, st, g, epi);
+  hipExtLaunchKernelGGL((gemm_f64_dma_kernel<A_KCONTIG, AF, NB, Epi>), grid, dim3(256), lds, st, g.ev0, g.ev1, 0, g, epi);
 }
 
 }  // namespace vb

@@ -6,15 +6,23 @@ weighted sum) over the ``num_mc_samples`` rows, so rank r evaluates the contiguo
 sum-all-reduced over RCCL/xGMI on the device before the O(P) epilogue
 (``vb_comm_init`` in ``include/viabel_hip.h``).  The variational parameter is replicated.
 
-``torch.distributed`` (any backend, gloo is enough) is used only to hand the 128-byte RCCL
-unique id from rank 0 to the other ranks; no tensor ever goes through torch.
+The data path is RCCL only.  The control path -- handing the 128-byte RCCL unique id from rank 0 to
+the other ranks, host barriers, a max over ranks of a host timing -- is a few bytes over plain TCP
+sockets (:class:`SocketGroup`, rendezvous on ``MASTER_ADDR`` / ``MASTER_PORT`` as exported by
+``torch.distributed.run``): no torch in the runtime path.  ``attach`` also accepts an initialised
+``torch.distributed`` process group (any backend) for callers that already have one.
 """
 import os
+import socket
+import struct
+import time
 
 import numpy as np
 
 from . import _lib
 from .objectives import shard_rows  # noqa: F401  (re-exported)
+
+_MAGIC = b'VBAMD1\0\0'
 
 
 def combine_partial_sums(partials):
@@ -22,35 +30,188 @@ def combine_partial_sums(partials):
     return np.sum(np.stack([np.asarray(p, dtype=np.float64) for p in partials]), axis=0)
 
 
-def broadcast_unique_id(rank, make_id):
-    """Rank 0 creates the RCCL unique id; everybody receives it via torch.distributed."""
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError('peer closed the control connection')
+        buf.extend(chunk)
+    return bytes(buf)
+
+
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack('<I', len(payload)) + payload)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack('<I', _recv_exact(sock, 4))
+    return _recv_exact(sock, n)
+
+
+class SocketGroup:
+    """Star-topology control group over TCP: rank 0 listens, ranks 1..G-1 connect.
+
+    Every operation is collective and is a gather to rank 0 followed by a scatter of the result, so ranks leave
+    it together (that is what makes it a barrier).  Payloads are a handful of bytes: this is the control plane
+    only -- gradients never travel here.
+
+    The listening port is ``MASTER_PORT + port_offset`` (torchrun's own store owns ``MASTER_PORT`` itself); if
+    that port is taken rank 0 walks upwards and the other ranks probe the same sequence until the handshake
+    (magic, world size) matches.
+    """
+
+    def __init__(self, rank, world, addr='127.0.0.1', port=29531, timeout=120.0, tries=16):
+        self.rank, self.world = int(rank), int(world)
+        self._peers = []
+        self._sock = None
+        if self.world == 1:
+            return
+        deadline = time.time() + timeout
+        hello = _MAGIC + struct.pack('<ii', self.world, self.rank)
+        if self.rank == 0:
+            srv = None
+            for k in range(tries):
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr, port + k))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise RuntimeError('no free control port in [%d, %d)' % (port, port + tries))
+            srv.listen(self.world)
+            peers = {}
+            while len(peers) < self.world - 1:
+                srv.settimeout(max(0.1, deadline - time.time()))
+                conn, _ = srv.accept()
+                conn.settimeout(timeout)
+                try:
+                    msg = _recv_exact(conn, len(hello))
+                except (ConnectionError, socket.timeout):
+                    conn.close()
+                    continue
+                w, r = struct.unpack('<ii', msg[len(_MAGIC):])
+                if msg[:len(_MAGIC)] != _MAGIC or w != self.world or not 0 < r < self.world or r in peers:
+                    conn.close()
+                    continue
+                conn.sendall(_MAGIC)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                peers[r] = conn
+            srv.close()
+            self._peers = [peers[r] for r in range(1, self.world)]
+        else:
+            k = 0
+            while True:
+                if time.time() > deadline:
+                    raise RuntimeError('rank %d: no control server on %s:%d..%d' % (self.rank, addr, port,
+                                                                                  port + tries - 1))
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                s.settimeout(5.0)
+                try:
+                    s.connect((addr, port + k % tries))
+                    s.sendall(hello)
+                    if _recv_exact(s, len(_MAGIC)) == _MAGIC:
+                        s.settimeout(timeout)
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self._sock = s
+                        break
+                except (OSError, ConnectionError):
+                    pass
+                s.close()
+                k += 1
+                if k % tries == 0:
+                    time.sleep(0.05)
+
+    @classmethod
+    def from_env(cls, port_offset=23):
+        """Group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (``torch.distributed.run`` exports them)."""
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        rank = int(os.environ.get('RANK', '0'))
+        addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+        port = int(os.environ.get('VIABEL_AMD_CONTROL_PORT', int(os.environ.get('MASTER_PORT', '29500')) + port_offset))
+        return cls(rank, world, addr, port)
+
+    # ---- collectives (gather to rank 0, combine, scatter) ------------------------------------------------------
+    def _exchange(self, payload, combine):
+        if self.world == 1:
+            return combine([payload])
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(c) for c in self._peers]
+            out = combine(parts)
+            for c in self._peers:
+                _send_msg(c, out)
+            return out
+        _send_msg(self._sock, payload)
+        return _recv_msg(self._sock)
+
+    def barrier(self):
+        self._exchange(b'', lambda parts: b'')
+
+    def broadcast_bytes(self, payload=None):
+        """Rank 0's ``payload`` on every rank."""
+        return self._exchange(payload if self.rank == 0 else b'', lambda parts: parts[0])
+
+    def allreduce_max(self, x):
+        out = self._exchange(struct.pack('<d', float(x)),
+                             lambda parts: struct.pack('<d', max(struct.unpack('<d', p)[0] for p in parts)))
+        return struct.unpack('<d', out)[0]
+
+    def allreduce_sum(self, x):
+        out = self._exchange(struct.pack('<d', float(x)),
+                             lambda parts: struct.pack('<d', sum(struct.unpack('<d', p)[0] for p in parts)))
+        return struct.unpack('<d', out)[0]
+
+    def close(self):
+        for c in self._peers:
+            c.close()
+        if self._sock is not None:
+            self._sock.close()
+        self._peers, self._sock = [], None
+
+
+def broadcast_unique_id(rank, make_id, group=None):
+    """Rank 0 creates the RCCL unique id; everybody receives it over ``group`` (a :class:`SocketGroup`) or,
+    without one, over an initialised ``torch.distributed`` process group."""
+    if group is not None:
+        return group.broadcast_bytes(make_id() if rank == 0 else None)
     import torch.distributed as dist
     if not dist.is_initialized():
-        raise RuntimeError('torch.distributed is not initialised; call init_process_group first')
+        raise RuntimeError('no control group: pass a SocketGroup or initialise torch.distributed first')
     box = [make_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     return box[0]
 
 
-def attach(engine=None):
-    """Attach an RCCL communicator spanning the torch.distributed world to ``engine``."""
-    import torch.distributed as dist
+def attach(engine=None, group=None):
+    """Attach an RCCL communicator spanning ``group`` (default: the torch.distributed world) to ``engine``."""
     engine = engine or _lib.default_engine()
-    world, rank = dist.get_world_size(), dist.get_rank()
+    if group is not None:
+        world, rank = group.world, group.rank
+    else:
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return engine
-    uid = broadcast_unique_id(rank, _lib.Engine.comm_unique_id)
+    uid = broadcast_unique_id(rank, _lib.Engine.comm_unique_id, group)
     engine.comm_init(uid, world, rank)
     return engine
 
 
-def init_from_env(backend='gloo'):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun) and attach RCCL."""
-    import torch.distributed as dist
+def init_from_env(backend=None):
+    """One process per GPU as launched by ``torch.distributed.run``: socket control group from RANK / WORLD_SIZE /
+    MASTER_*, RCCL communicator on the default engine (device ``LOCAL_RANK``).  ``backend`` (e.g. ``'gloo'``) uses
+    a torch.distributed process group for the control path instead.  Returns the engine."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend=backend)
     engine = _lib.default_engine()
-    if world > 1:
-        attach(engine)
-    return engine
+    if world == 1:
+        return engine
+    if backend is not None:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend)
+        return attach(engine)
+    engine.control_group = SocketGroup.from_env()
+    return attach(engine, engine.control_group)
