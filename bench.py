@@ -110,13 +110,20 @@ def fullrank_leg(eng, vb, _lib, group, d, steps, warmup, scaling='weak', slot0=4
     eng.sync()
     run(warmup)
     eng.sync()
-    if profile:
-        eng.profile_enable(True)
-        for k in (_lib.PROF_FR_SAMPLE_GEMM, _lib.PROF_FR_MODEL_GEMM, _lib.PROF_FR_GRAD_GEMM):
-            eng.profile_read(reset=True, kernel=k)
     times = timed_blocks(run, eng.sync, group, steps)
     kern = {}
     if profile:
+        # per-kernel durations: the same K steps once more with hipExtLaunchKernel start / stop events on the three
+        # GEMMs.  Kept out of the timed region: a launch that carries events costs ~4.7 us more on this stack
+        # (338.8 -> 353.0 us per evaluation with all three instrumented), the kernels themselves run the same.
+        eng.profile_enable(True)
+        for k in (_lib.PROF_FR_SAMPLE_GEMM, _lib.PROF_FR_MODEL_GEMM, _lib.PROF_FR_GRAD_GEMM):
+            eng.profile_read(reset=True, kernel=k)
+        group.barrier()
+        for _ in range(max(1, min(len(times), 5))):
+            run(steps)
+        eng.sync()
+        group.barrier()
         for name, k in (('sample_gemm', _lib.PROF_FR_SAMPLE_GEMM), ('model_gemm', _lib.PROF_FR_MODEL_GEMM),
                         ('grad_gemm', _lib.PROF_FR_GRAD_GEMM)):
             n_l, _, ms = eng.profile_read(reset=True, kernel=k)

@@ -241,11 +241,26 @@ int main(int argc, char** argv) {
         }
         printf("check cfg %d tri %d A[m][k]: max |dma - reg| = %.3e (max |C| %.3e)\n", cfg, tri, md, mx);
       }
+    for (int cfg = 4; cfg <= 5; ++cfg) {     // the two-stage kernels against the register-staged kernel
+      GemmArgs g;
+      g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = 1;
+      hipMemset(C, 0, (size_t)M * N * 8);
+      gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg == 4 ? 3 : 2, 1);
+      hipDeviceSynchronize();
+      hipMemcpy(c0.data(), C, c0.size() * 8, hipMemcpyDeviceToHost);
+      hipMemset(C, 0, (size_t)M * N * 8);
+      gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg, 0);
+      hipDeviceSynchronize();
+      hipMemcpy(c1.data(), C, c1.size() * 8, hipMemcpyDeviceToHost);
+      double md = 0;
+      for (size_t i = 0; i < c0.size(); ++i) md = fmax(md, fabs(c0[i] - c1[i]));
+      printf("check cfg %d tri 1: max |dma - reg| = %.3e\n", cfg, md);
+    }
     // k-major A, lower-triangular tiles, split-K
     GemmArgs g3;
     g3.A = A, g3.B = B, g3.lda = N, g3.ldb = N, g3.M = N, g3.N = N, g3.K = M, g3.tri_mode = 2;
     std::vector<double> s0((size_t)2 * N * N), s1((size_t)2 * N * N);
-    for (int cfg = 1; cfg <= 3; ++cfg) {
+    for (int cfg = 1; cfg <= 5; ++cfg) {
       for (int flag = 1; flag >= 0; --flag) {
         hipMemset(C, 0, (size_t)2 * N * N * 8);
         gemm_f64_launch<false>(st, g3, 2, n_cu, EpiSlab{C, N, (int64_t)N * N}, cfg, flag);
@@ -253,12 +268,17 @@ int main(int argc, char** argv) {
         hipMemcpy(flag ? s0.data() : s1.data(), C, s0.size() * 8, hipMemcpyDeviceToHost);
       }
       double md = 0;
-      for (size_t i = 0; i < s0.size(); ++i) md = fmax(md, fabs(s0[i] - s1[i]));
-      printf("check cfg %d gram A[k][m] splits 2: max |dma - reg| = %.3e\n", cfg, md);
+      for (int sp = 0; sp < 2; ++sp)
+        for (int i = 0; i < N; ++i)
+          for (int j = 0; j <= i; ++j) {
+            const size_t e = (size_t)sp * N * N + (size_t)i * N + j;
+            md = fmax(md, fabs(s0[e] - s1[e]));
+          }
+      printf("check cfg %d gram A[k][m] splits 2 (lower triangle): max |dma - reg| = %.3e\n", cfg, md);
     }
   }
-  for (int cfg = 1; cfg <= 3; ++cfg) {
-    const char* name = cfg == 1 ? "128x128" : cfg == 2 ? "128x64" : "64x64";
+  for (int cfg = 1; cfg <= 5; ++cfg) {
+    const char* name = cfg == 1 ? "128x128" : cfg == 2 ? "128x64" : cfg == 3 ? "64x64" : cfg == 4 ? "64x64/2st" : "128x64/2st";
     // 1. dense, A k-contiguous (Z = E L', (Z - m) P)
     GemmArgs g;
     g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = 0;
@@ -274,8 +294,8 @@ int main(int argc, char** argv) {
     // 3. C = G' E: M = N = D, K = n rows; lower-triangular tiles, split-K
     GemmArgs g3;
     g3.A = A, g3.B = B, g3.lda = N, g3.ldb = N, g3.M = N, g3.N = N, g3.K = M, g3.tri_mode = 2;
-    const long lower = gemm_count_blocks(g3, cfg == 3 ? 64 : 128, cfg == 1 ? 128 : 64);
-    for (int mult = 1; mult <= 4; mult *= 2) {
+    const long lower = gemm_count_blocks(g3, (cfg == 3 || cfg == 4) ? 64 : 128, cfg == 1 ? 128 : 64);
+    for (int mult = 1; mult <= 4; ++mult) {
       int splits = (int)(mult * n_cu / lower);
       if (splits < 1) splits = 1;
       if ((int64_t)splits * N * N > (int64_t)2 * 4096 * 4096) continue;

@@ -226,7 +226,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& log : ctx->prof)
@@ -739,6 +739,7 @@ int vb_fullrank_set_theta(vb_ctx* ctx, const double* theta, int64_t d) {
                              ctx->stream));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller keeps ownership of `theta`
   ctx->fr_p = p;
+  ctx->fr_lt_d = 0;                                 // the unpacked copy (mu, L') is stale
   return VB_OK;
 }
 

@@ -138,6 +138,8 @@ struct vb_ctx {
   double* pin_dev = nullptr;
   size_t pin_bytes = 0;
   vb::DeviceBuffer fit_work;            // device-resident fit: [theta | out | state | value history | iterates]
+  vb::DeviceBuffer fr_lt;               // full-rank: unpacked parameter [mu (ldz) | L' (d x ldl)]
+  int64_t fr_lt_d = 0;                  // dimension the unpacked copy of fr_theta was made for (0: stale)
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter

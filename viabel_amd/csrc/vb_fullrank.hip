@@ -122,6 +122,24 @@ struct EpiSplitSlab {       // C_split[i][j] = acc
   }
 };
 
+// C_split[i][j] = acc, plus -- for the correlated-Gaussian target -- the two sums that used to cost a pass over G
+// and Z: the functor's return value acc * L[i][j] (j <= i) is summed per workgroup into `part`, and the kernel's
+// EpiColsum hook writes the column sums of G per split.  With z - m = L eps + (mu - m) and f = 1/2 (z - m)' g:
+//   sum_n f(z_n) = 1/2 [ sum_{i >= j} L_ij C_ij + (mu - m)' sum_n g_n ],      C = G' E.
+struct EpiSplitSlabTrace {
+  double* C;
+  int64_t ldc, slab;
+  const double* Lt;         // Lt[j * ldl + i] = L[i][j]
+  int64_t ldl;
+  double* part;
+  double* colsum;
+  int64_t colsum_ld;
+  __device__ double operator()(int split, int row, int col, double acc) const {
+    C[split * slab + (int64_t)row * ldc + col] = acc;
+    return col <= row ? acc * Lt[(int64_t)col * ldl + row] : 0.0;
+  }
+};
+
 // ---- funnel: row kernel Z -> G, f ---------------------------------------------------------------
 // one wave per row; G[n][j] = -z_j w (j != k), G[n][k] = -v/tau^2 - (D-1) + w sum_{j != k} z_j^2
 __global__ void __launch_bounds__(256) fr_funnel_kernel(const double* __restrict__ Z, double* __restrict__ G,
@@ -279,7 +297,7 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
     const double* __restrict__ Cpart, int splits, int64_t slab, int d, int64_t ldl,
     const double* __restrict__ colpart, int n_rb, int64_t ldz, const double* __restrict__ fpart, int n_fpart,
     FrSums S, const double* __restrict__ theta, double n_local_w, double n_total, double c0,
-    double* __restrict__ out, int pd, FrWeighted wm) {
+    double* __restrict__ out, int pd, FrWeighted wm, const double* __restrict__ tr_mean) {
   __shared__ double sh[4];
   const double ent = pd ? 0.0 : 1.0;      // the entropy's -1 on the free diagonal (absent with the path derivative)
   // weighted mode (AlphaDivergence, objectives.py:458-460): the rows of G carried the weights s_n, the result is
@@ -348,6 +366,17 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
     double f = 0.0;
     for (int e = threadIdx.x; e < n_fpart; e += 256) f += fpart[e];
     f = fr_block_sum(f, sh);
+    if (tr_mean) {    // fpart holds the partials of sum_ij L_ij C_ij (EpiSplitSlabTrace): F = 1/2 (that + (mu - m)' colsum)
+      double dot = 0.0;
+      for (int c = threadIdx.x; c < d; c += 256) {
+        double cs = 0.0;
+        for (int rb = 0; rb < n_rb; ++rb) cs += colpart[(int64_t)rb * ldz + c];
+        dot = fma(theta[c] - tr_mean[c], cs, dot);
+      }
+      __syncthreads();
+      dot = fr_block_sum(dot, sh);
+      f = 0.5 * (f + dot);
+    }
     if (FUSE) {
       __syncthreads();
       double t = 0.0;
@@ -582,6 +611,10 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
                 (long long)ns.n, (long long)ns.d, (long long)n, (long long)d);
   hipStream_t st = ctx->stream;
   const int D = (int)d;
+  // tile-configuration overrides of the three GEMMs (experiments; 0 = the launcher's choice)
+  static const int cfg1 = getenv("VB_FR_G1_CFG") ? atoi(getenv("VB_FR_G1_CFG")) : 0;
+  static const int cfg2 = getenv("VB_FR_G2_CFG") ? atoi(getenv("VB_FR_G2_CFG")) : 0;
+  static const int cfg3 = getenv("VB_FR_G3_CFG") ? atoi(getenv("VB_FR_G3_CFG")) : 0;
   const int64_t ldl = round_up(d, 16), ldz = round_up(d, 16);
   const int n_cu = ctx->prop.multiProcessorCount;
   const int tiles = gemm_tiles(D, 128);
@@ -607,7 +640,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   };
   const int64_t o_mu = carve(ldz), o_lt = carve(slab), o_z = carve(n * ldz), o_g = carve(n * ldz),
                 o_cpart = carve((int64_t)(splits + 1) * slab), o_col = carve((int64_t)(n_rb + 1) * ldz),
-                o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx), o_r = carve(glm ? n * ldr : 0);
+                o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx + gemm_max_blocks(D, D) * splits),
+                o_r = carve(glm ? n * ldr : 0);
   // path derivative: (L')^-1 (Xa), a product buffer T, the noise Gram matrix [16 | e (ld_e) | M2 (d x ldl)], partial
   // column sums of the noise (row stride = the noise matrix's)
   const int64_t ld_e = ns.ld;
@@ -627,6 +661,18 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   double* base = (double*)ctx->fr_work.ptr;
   double *mu = base + o_mu, *Lt = base + o_lt, *Z = base + o_z, *G = base + o_g, *Cpart = base + o_cpart,
          *colpart = base + o_col, *fpart = base + o_fpart;
+  // the dense family keeps mu and L' in a buffer of their own: when the parameter is the resident one
+  // (vb_fullrank_set_theta) it is unpacked once per upload, not once per evaluation
+  bool lt_cached = false;
+  if (!mvt) {
+    VB_TRY(ensure(ctx, ctx->fr_lt, (size_t)(ldz + slab) * sizeof(double)));
+    mu = (double*)ctx->fr_lt.ptr;
+    Lt = mu + ldz;
+    static const bool cache_env = !(getenv("VB_FR_UNPACK_CACHE") && atoi(getenv("VB_FR_UNPACK_CACHE")) == 0);
+    const bool resident = theta_dev == (const double*)ctx->fr_theta.ptr;
+    lt_cached = cache_env && resident && ctx->fr_lt_d == d;
+    ctx->fr_lt_d = resident ? d : 0;     // (a foreign parameter leaves the copy stale for the resident one)
+  }
   // stream plan (as mf_enqueue's `overlap`): everything up to the split reduction stays in order on the main
   // stream; the all-reduce and the epilogue go to `post` behind one event, into sum set `seq & 1`, and the main
   // stream only waits for them when that set comes round again two evaluations later
@@ -646,7 +692,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     VB_HIP(ctx, hipMemcpyAsync(mu, mu_dev, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
     VB_HIP(ctx, hipMemcpy2DAsync(Lt, (size_t)ldl * sizeof(double), root_dev, (size_t)ldl * sizeof(double),
                                  (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
-  } else {
+  } else if (!lt_cached) {
     hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((d * d + 255) / 256)), dim3(256), 0, st, theta_dev,
                        D, ldl, Lt, mu);
     VB_HIP(ctx, hipGetLastError());
@@ -778,7 +824,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     VB_TRY(glm_grad_enqueue(ctx, st, m, Rm, ldr, Z, G, ldz, n, D));   // G = R X - Z / sd^2
     fmode = 3;
   } else {
-    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0, row_scale});   // Z - m
+    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0, row_scale}, cfg1);   // Z - m
     VB_HIP(ctx, hipGetLastError());
     GemmArgs g2;                                   // G = -(Z - m) P,  P symmetric: B[k][j] = P[k][j]
     g2.A = Z;
@@ -790,7 +836,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     g2.K = D;
     g2.tri_mode = 0;
     prof_events(ctx, &g2.ev0, &g2.ev1, 1, VB_PROF_FR_MODEL_GEMM);
-    gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz});
+    gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz}, cfg2);
     fmode = 2;
   }
   VB_HIP(ctx, hipGetLastError());
@@ -800,18 +846,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
                        D, wm.roww);
     VB_HIP(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
-                     (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
-                     m.id == VB_MODEL_FUNNEL ? fpart + n_fpart /*unused tail*/ : fpart,
-                     glm ? 1.0 / (m.tau * m.tau) : 0.0);
-  VB_HIP(ctx, hipGetLastError());
-
-  if (row_scale) {
-    hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)n), dim3(256), 0, st, G, ldz, n,
-                       D, row_scale);
-    VB_HIP(ctx, hipGetLastError());
-  }
-  // GEMM 3: C[i][j] = sum_n G[n][i] E[n][j], lower-triangular tiles (all tiles for the t family), split over n
+  // C = G' E: lower-triangular tiles (all tiles for the t family), split over the sample axis
   GemmArgs g3;
   g3.A = G;
   g3.lda = ldz;
@@ -821,8 +856,37 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   g3.N = D;
   g3.K = (int)n;
   g3.tri_mode = mvt ? 0 : 2;
+  // correlated-Gaussian target under the dense Gaussian family: sum f and the column sums of G come out of the
+  // gradient GEMM itself (EpiSplitSlabTrace) -- no pass over G and Z between the two GEMMs
+  static const bool fast_env = !(getenv("VB_FR_FUSED_SUMS") && atoi(getenv("VB_FR_FUSED_SUMS")) == 0);
+  const bool fused_sums = fast_env && !mvt && m.id == VB_MODEL_GAUSS_FULL && !wm.roww && !row_scale && !pd &&
+                          gemm_uses_dma(g3) && (int64_t)splits <= n_rb;
+  if (!fused_sums) {
+    hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
+                       (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
+                       m.id == VB_MODEL_FUNNEL ? fpart + n_fpart /*unused tail*/ : fpart,
+                       glm ? 1.0 / (m.tau * m.tau) : 0.0);
+    VB_HIP(ctx, hipGetLastError());
+  }
+
+  if (row_scale) {
+    hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)n), dim3(256), 0, st, G, ldz, n,
+                       D, row_scale);
+    VB_HIP(ctx, hipGetLastError());
+  }
+  // GEMM 3: C[i][j] = sum_n G[n][i] E[n][j]
   prof_events(ctx, &g3.ev0, &g3.ev1, 1, VB_PROF_FR_GRAD_GEMM);
-  gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
+  int n_rb_red = n_rb + (pd ? 1 : 0), n_fpart_red = n_fpart;
+  const double* tr_mean = nullptr;
+  if (fused_sums) {
+    const unsigned tiles3 = gemm_f64_launch<false>(
+        st, g3, splits, n_cu, EpiSplitSlabTrace{Cpart, ldl, slab, Lt, ldl, fpart, colpart, ldz}, cfg3);
+    n_rb_red = splits;                  // one row of column sums per split
+    n_fpart_red = (int)tiles3 * splits;   // one trace partial per tile and split
+    tr_mean = m.p0;
+  } else {
+    gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
+  }
   VB_HIP(ctx, hipGetLastError());
 
   const int64_t red_items = slab / 2 > ldz ? slab / 2 : ldz;
@@ -837,16 +901,16 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
   if (!ctx->comm) {   // single GPU: the split reduction writes (value, grad) itself
     hipLaunchKernelGGL(fr_reduce_packed_kernel<true>, red_grid, dim3(256), 0, st, (const double*)Cpart,
-                       splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb + (pd ? 1 : 0), ldz,
-                       (const double*)fpart, n_fpart, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
-                       pd ? 1 : 0, wm);
+                       splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb_red, ldz,
+                       (const double*)fpart, n_fpart_red, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
+                       pd ? 1 : 0, wm, tr_mean);
     VB_HIP(ctx, hipGetLastError());
     return VB_OK;
   }
   hipLaunchKernelGGL(fr_reduce_packed_kernel<false>, red_grid, dim3(256), 0, st, (const double*)Cpart,
-                     splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb + (pd ? 1 : 0), ldz,
-                     (const double*)fpart, n_fpart, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
-                     pd ? 1 : 0, wm);
+                     splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb_red, ldz,
+                     (const double*)fpart, n_fpart_red, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
+                     pd ? 1 : 0, wm, tr_mean);
   VB_HIP(ctx, hipGetLastError());
   hipStream_t st_post = st;
   if (overlap) {

@@ -69,6 +69,15 @@ struct EpiReduces : std::false_type {};
 template <class E>
 struct EpiReduces<E, std::void_t<decltype(std::declval<E>().part)>> : std::true_type {};
 
+// A functor that defines `double* colsum` and `int64_t colsum_ld` (LDS-DMA kernel, A given k-major) additionally gets
+// the column sums of A over the workgroup's k range, colsum[blockIdx.z * colsum_ld + m] = sum_k A[k][m], written by the
+// workgroups of column block 0 (one per row block and split): the operand tiles are in LDS anyway, so the sums cost
+// a few LDS reads per slab in the shadow of the MFMAs instead of another pass over A.
+template <class E, class = void>
+struct EpiColsum : std::false_type {};
+template <class E>
+struct EpiColsum<E, std::void_t<decltype(std::declval<E>().colsum)>> : std::true_type {};
+
 // Block tile (32 AF) x (8 NB): (AF, NB) = (4, 16) 128 x 128, (4, 8) 128 x 64, (2, 8) 64 x 64.  One wave per
 // SIMD issues a 4x4x4 MFMA every 16.5 cycles, two waves sharing a SIMD one every 12.4 (measured,
 // tools/gemm_bench.hip): every variant fits two workgroups per CU (<= 256 registers, <= 74 KB LDS) and the
@@ -334,34 +343,55 @@ inline long gemm_count_blocks(const GemmArgs& g, int bm_rows, int bn_cols) {
   return blocks;
 }
 
-// cfg: 0 = automatic, 1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 64 block tiles
+// cfg: 0 = automatic, 1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 64 block tiles (three LDS stages);
+//      4 = 64 x 64, 5 = 128 x 64 with two LDS stages (more workgroups per CU); LDS-DMA kernel only
+// flags bit 0: force the register-staged kernel
+// does a product of this shape go to the LDS-DMA kernel (which alone implements EpiColsum)?
+inline bool gemm_uses_dma(const GemmArgs& g) {
+  static const bool dma_ok = !(getenv("VB_GEMM_DMA") && atoi(getenv("VB_GEMM_DMA")) == 0);
+  return dma_ok && g.K % kGemmBK == 0 && g.M > 0 && g.N > 0;
+}
+
+// returns gridDim.x of the launch (the number of output tiles; reducing epilogues write one partial per tile and split)
 template <bool A_KCONTIG, class Epi>
-inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi, int cfg = 0,
-                            int flags = 0) {   // flags bit 0: force the register-staged kernel
+inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi, int cfg = 0,
+                                int flags = 0) {
   if (splits < 1) splits = 1;
   int ks = g.batch ? g.K : gemm_tiles(g.K, splits);   // batch mode: `splits` is the number of products
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
   static const int cfg_env = getenv("VB_GEMM_CFG") ? atoi(getenv("VB_GEMM_CFG")) : 0;   // experiments: force a tile
-  if (cfg == 0 && cfg_env >= 1 && cfg_env <= 3) cfg = cfg_env;
+  if (cfg == 0 && cfg_env >= 1 && cfg_env <= 5) cfg = cfg_env;
   // operands straight into LDS (vb_gemm_f64_dma.h) when every k range is a whole number of slabs
-  static const bool dma_ok = !(getenv("VB_GEMM_DMA") && atoi(getenv("VB_GEMM_DMA")) == 0);
-  const bool dma = dma_ok && g.K % kGemmBK == 0 && g.M > 0 && g.N > 0 && !(flags & 1);
+  const bool dma = gemm_uses_dma(g) && !(flags & 1);
   if (cfg == 0) {
-    // largest tile that gives every CU two workgroups; the LDS-DMA kernel's 128 x 128 tile needs 96 KB of LDS
-    // (one workgroup per CU) and measures slower than its 128 x 64 tile at every shape tried, so it is skipped
-    if (!dma && gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) cfg = 1;
-    else if (gemm_count_blocks(g, 128, 64) * splits >= 2L * n_cu) cfg = 2;
-    else cfg = 3;
+    if (dma && g.tri_mode == 1 && splits == 1 && gemm_count_blocks(g, 128, 64) < 4L * n_cu) {
+      // k ranges grow with the column block: with only a couple of tiles per CU the long ones finish alone.  The
+      // 64 x 64 tiles (three or four workgroups per CU, heaviest first) even that out: 89.9 -> 85.9 us at
+      // 4096 x 1024 x 1024 (tools/gemm_bench.hip; pairing a long and a short block inside one workgroup measured
+      // the same 85.9 us, so the simpler launch order is kept)
+      cfg = 3;
+    } else if (!dma && gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) {
+      // largest tile that gives every CU two workgroups; the LDS-DMA kernel's 128 x 128 tile needs 96 KB of LDS
+      // (one workgroup per CU) and measures slower than its 128 x 64 tile at every shape tried, so it is skipped
+      cfg = 1;
+    } else if (gemm_count_blocks(g, 128, 64) * splits * 100 >= 190L * n_cu) {
+      cfg = 2;    // (lower-triangular D = 1024 product in 7 row slabs: 504 workgroups on 256 CUs)
+    } else {
+      cfg = 3;
+    }
   }
-  const int bm_rows = cfg == 3 ? 64 : 128, bn_cols = cfg == 1 ? 128 : 64;
+  if (!dma && cfg > 3) cfg = cfg == 4 ? 3 : 2;
+  const int bm_rows = (cfg == 3 || cfg == 4) ? 64 : 128, bn_cols = cfg == 1 ? 128 : 64;
   g.tiles_m = gemm_tiles(g.M, bm_rows);
   g.tiles_n = gemm_tiles(g.N, bn_cols);
   const dim3 grid((unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1, (unsigned)splits);
   if (dma) {
-    if (cfg == 1) gemm_f64_dma_launch<A_KCONTIG, 4, 16, Epi>(st, g, grid, epi);
-    else if (cfg == 2) gemm_f64_dma_launch<A_KCONTIG, 4, 8, Epi>(st, g, grid, epi);
-    else gemm_f64_dma_launch<A_KCONTIG, 2, 8, Epi>(st, g, grid, epi);
-    return;
+    if (cfg == 1) gemm_f64_dma_launch<A_KCONTIG, 4, 16, 3, Epi>(st, g, grid, epi);
+    else if (cfg == 2) gemm_f64_dma_launch<A_KCONTIG, 4, 8, 3, Epi>(st, g, grid, epi);
+    else if (cfg == 3) gemm_f64_dma_launch<A_KCONTIG, 2, 8, 3, Epi>(st, g, grid, epi);
+    else if (cfg == 4) gemm_f64_dma_launch<A_KCONTIG, 2, 8, 2, Epi>(st, g, grid, epi);
+    else gemm_f64_dma_launch<A_KCONTIG, 4, 8, 2, Epi>(st, g, grid, epi);
+    return grid.x;
   }
   if (cfg == 1)
     hipExtLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, 16, Epi>), grid, dim3(256), 0, st, g.ev0, g.ev1, 0, g, epi);
@@ -369,6 +399,7 @@ inline void gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, co
     hipExtLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 4, 8, Epi>), grid, dim3(256), 0, st, g.ev0, g.ev1, 0, g, epi);
   else
     hipExtLaunchKernelGGL((gemm_f64_kernel<A_KCONTIG, 2, 8, Epi>), grid, dim3(256), 0, st, g.ev0, g.ev1, 0, g, epi);
+  return grid.x;
 }
 
 }  // namespace vb

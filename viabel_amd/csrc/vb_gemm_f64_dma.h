@@ -24,10 +24,12 @@ namespace vb {
 typedef __attribute__((address_space(1))) const void* gemm_gptr;
 typedef __attribute__((address_space(3))) void* gemm_lptr;
 
-template <bool A_KCONTIG, int AF, int NB, class Epi>
-__global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel(const GemmArgs g, const Epi epi) {
+template <bool A_KCONTIG, int AF, int NB, int STAGES, class Epi>
+__global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGES > 2 ? 2 : 4))
+    gemm_f64_dma_kernel(const GemmArgs g, const Epi epi) {
   constexpr int BM = 32 * AF, BN = 8 * NB;
-  constexpr int kStages = 3;
+  constexpr int kStages = STAGES;
+  static_assert(STAGES == 2 || STAGES == 3, "two or three LDS stages");
   constexpr int kATile = BM * kGemmBK, kBTile = kGemmBK * BN;      // doubles per stage
   constexpr int kAUnits = kATile / 128, kBUnits = kBTile / 128;    // 1-KiB wave-loads per stage
   constexpr int UPW = (kAUnits + kBUnits) / 4;                     // wave-loads per wave per slab
@@ -45,6 +47,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
 #endif
 
   // ---- tile assignment (as gemm_f64_kernel) -----------------------------------------------------
+  double local = 0.0;
   int bm, bn;
   if (g.tri_mode == 2) {
     int idx = blockIdx.x;
@@ -73,6 +76,16 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
     const int kmax = n0 + BN;
     if (k_end > kmax) k_end = kmax;
   }
+  // tri_mode 2: a wave whose whole sub-tile lies above the diagonal (first column > last row) has nothing to
+  // compute -- it still moves its share of the operands and keeps the barriers, but issues no MFMAs, which
+  // leaves its SIMD's matrix pipe to the co-resident workgroup
+  const bool idle_wave = g.tri_mode == 2 && n0 + wn * (4 * NB) > m0 + wm * (16 * AF) + 16 * AF - 1;
+  // column sums of the A operand (see EpiColsum): thread -> column cs_m of the tile, k rows cs_k0 .. cs_k0 + kCsRows - 1
+  constexpr bool kColsum = !A_KCONTIG && EpiColsum<Epi>::value;
+  constexpr int kCsRows = kGemmBK * BM / 256;
+  const bool cs_wg = kColsum && bn == 0;
+  const int cs_m = t & (BM - 1), cs_k0 = (t / BM) * kCsRows;
+  double cs = 0.0;
   const int nslabs = (k_end - k_begin) / kGemmBK;
 
   double acc[AF][NB];
@@ -188,6 +201,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
   constexpr int KS = kGemmBK / 4;
   constexpr int kReads = AF + NB, kMfma = AF * NB;
   constexpr int kPer = kMfma / kReads;
+  constexpr int kAhead = STAGES - 1;          // slabs in flight ahead of the one being multiplied
   auto interleave = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < kReads; ++i) {
@@ -204,35 +218,52 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
 
   if (nslabs > 0) {
     issue(0);                          // slab 0
-    if (nslabs > 1) advance();
-    issue(1);                          // slab 1 (or slab 0 again: keeps the vmcnt arithmetic uniform)
-    wait_vm(std::integral_constant<int, UPW>());
+    if (kAhead == 2) {
+      if (nslabs > 1) advance();
+      issue(1);                        // slab 1 (or slab 0 again: keeps the vmcnt arithmetic uniform)
+    }
+    wait_vm(std::integral_constant<int, UPW*(kAhead - 1)>());
     __asm__ volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __asm__ volatile("" ::: "memory");
-    load_frags(0, 0, 0);
+    if (!idle_wave) load_frags(0, 0, 0);
     int st = 0;
 #ifdef VB_GEMM_CLOCK
     dbg_t1 = clock64();
 #endif
     for (int s = 0; s < nslabs; ++s) {
-      const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
-      if (s + 2 < nslabs) advance();   // beyond the end: re-fetch the last slab into a free stage
-      issue(st2);
+      const int st1 = st == kStages - 1 ? 0 : st + 1;
+      const int st_new = kAhead == 2 ? (st1 == kStages - 1 ? 0 : st1 + 1) : st1;   // the stage slab s + kAhead goes to
+      if (s + kAhead < nslabs) advance();   // beyond the end: re-fetch the last slab into a free stage
+      issue(st_new);
+      if constexpr (kColsum) {
+        if (cs_wg) {
+          const double* as = As + st * kATile;
 #pragma unroll
-      for (int kk = 0; kk < KS - 1; ++kk) {
-        load_frags(st, kk + 1, (kk + 1) & 1);
-        mfma_step(kk & 1);
-        interleave();
+          for (int i = 0; i < kCsRows; ++i) {
+            const int k = cs_k0 + i;
+            cs += as[k * BM + (cs_m ^ (16 * (k & 1)))];
+          }
+        }
       }
-      wait_vm(std::integral_constant<int, UPW>());     // slab s + 1 has landed (this wave's share)
+      if (!idle_wave) {
+#pragma unroll
+        for (int kk = 0; kk < KS - 1; ++kk) {
+          load_frags(st, kk + 1, (kk + 1) & 1);
+          mfma_step(kk & 1);
+          interleave();
+        }
+      }
+      wait_vm(std::integral_constant<int, UPW*(kAhead - 1)>());     // slab s + 1 has landed (this wave's share)
       __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's reads of stage st are done
       __asm__ volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __asm__ volatile("" ::: "memory");
-      load_frags(st1, 0, KS & 1);
-      mfma_step((KS - 1) & 1);
-      interleave();
+      if (!idle_wave) {
+        load_frags(st1, 0, KS & 1);
+        mfma_step((KS - 1) & 1);
+        interleave();
+      }
       st = st1;
     }
     __builtin_amdgcn_s_waitcnt(0);     // nothing in flight into LDS when the epilogue reuses it
@@ -242,8 +273,20 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
 #endif
   }
 
+  if constexpr (kColsum) {
+    if (cs_wg) {                 // combine the k groups in fixed order (the slabs are no longer needed)
+      gemm_lds[t] = cs;
+      __syncthreads();
+      if (t < BM && m0 + t < g.M) {
+        double tot = gemm_lds[t];
+#pragma unroll
+        for (int q = 1; q < 256 / BM; ++q) tot += gemm_lds[q * BM + t];
+        epi.colsum[(int64_t)blockIdx.z * epi.colsum_ld + m0 + t] = tot;
+      }
+      __syncthreads();
+    }
+  }
   // ---- epilogue (as gemm_f64_kernel) -------------------------------------------------------------------------
-  double local = 0.0;
 #pragma unroll
   for (int a = 0; a < AF; ++a)
 #pragma unroll
@@ -278,16 +321,17 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_dma_kernel
 #endif
 }
 
-template <bool A_KCONTIG, int AF, int NB, class Epi>
+template <bool A_KCONTIG, int AF, int NB, int STAGES, class Epi>
 inline void gemm_f64_dma_launch(hipStream_t st, const GemmArgs& g, dim3 grid, const Epi& epi) {
-  constexpr size_t lds = (size_t)3 * (32 * AF * kGemmBK + kGemmBK * 8 * NB) * sizeof(double);
+  constexpr size_t lds = (size_t)STAGES * (32 * AF * kGemmBK + kGemmBK * 8 * NB) * sizeof(double);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma_kernel<A_KCONTIG, AF, NB, Epi>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma_kernel<A_KCONTIG, AF, NB, STAGES, Epi>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  hipExtLaunchKernelGGL((gemm_f64_dma_kernel<A_KCONTIG, AF, NB, Epi>), grid, dim3(256), lds, st, g.ev0, g.ev1, 0, g, epi);
+  hipExtLaunchKernelGGL((gemm_f64_dma_kernel<A_KCONTIG, AF, NB, STAGES, Epi>), grid, dim3(256), lds, st, g.ev0, g.ev1,
+                        0, g, epi);
 }
 
 }  // namespace vb
