@@ -1,0 +1,148 @@
+"""Parity at the sizes BASELINE.json states for configs[3] and configs[4] (the smaller shapes are covered in
+test_gpu_objectives.py / test_gpu_meanfield.py / test_gpu_convergence.py):
+
+  configs[3]  MultivariateT(256, df=100) + DISInclusiveKL, N_mc = 16 384, resampling on and off
+  configs[4]  MFGaussian + ExclusiveKL on Bayesian logistic regression, D = 2000, n_data = 8192, N_mc = 8192,
+              one evaluation against the oracle and the RAABBVI / FASO optimiser loop (device-resident chunks
+              against the host loop, bit for bit)
+
+The oracle (numpy, oracle/) needs a few seconds per evaluation at these sizes.  Tolerances as in the small-shape
+tests: values 1e-10..1e-11 relative, gradients 1e-9..1e-10 relative to max |grad|.
+
+The variational parameter of the configs[3] test is NOT `init_param()` (Sigma = 10 I): in 256 dimensions its
+importance weights against any unit-scale target collapse to a single sample (ESS = 1).  Here q sits
+on the tempering prior (mean 0, log sigma 0.5) up to a small correlated perturbation, and the target is shifted
+away from it, so ESS(eps = 0) is far below the target, ESS(eps = 1) far above, and the bisection has to find an
+interior eps: asserted below.
+"""
+import numpy as np
+import pytest
+
+import _golden as G
+from oracle import families as ofam
+from oracle import models as omod
+from oracle import objectives as oobj
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import viabel_amd
+    from viabel_amd import _lib
+    _lib.default_engine()
+    return viabel_amd
+
+
+def c3_problem(rng, D):
+    mean = 0.3 * rng.randn(D)
+    sd = np.exp(0.5 + 0.02 * rng.randn(D))
+    prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
+    A = rng.randn(D, D)
+    Sigma = np.e * np.eye(D) + 0.04 * (A @ A.T / D - np.eye(D))
+    theta = np.concatenate([0.02 * rng.randn(D), ofam.psd_to_free(Sigma)])
+    return mean, sd, prior, theta
+
+
+@pytest.mark.parametrize('use_resampling', [True, False])
+def test_c3_multivariate_t_dis_full_size(vb, use_resampling):
+    D, N, df, ess_target = 256, 16384, 100, 2048
+    rng = np.random.RandomState(33)
+    mean, sd, prior, theta = c3_problem(rng, D)
+    approx, ofamily = vb.MultivariateT(D, df, seed=6), ofam.MultivariateT(D, df)
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    kw = dict(use_resampling=use_resampling, num_resampling_batches=2)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=ess_target, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, **kw)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, ess_target, ofam.MFGaussian(D), prior, **kw)
+    rs = np.random.RandomState(6)
+    np.random.seed(12)
+    for step in range(2):
+        state = np.random.get_state()
+        value, grad = obj(theta)
+        np.random.set_state(state)
+        noise = ofamily.draw_noise(rs, N) if ref.needs_refresh() else None
+        if use_resampling:
+            if ref.needs_refresh():
+                ref.refresh(theta, noise)
+            idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
+            ref._objective_step += 1
+            xs = ref._state_samples[idx]
+            scale = ref._state_w_sum / N
+            ov = np.mean(-ofamily.log_density(theta, xs)) * scale
+            og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+        else:
+            ov, og = ref(theta, noise=noise)
+        if step == 0:
+            # the tempering had work to do: interior eps, effective sample size on target (not the ESS = 1 collapse)
+            assert 0.0 < ref._eps < 1.0, ref._eps
+            assert abs(ref._ess_val - ess_target) < 0.02 * ess_target, ref._ess_val
+            assert abs(obj._ess - ess_target) < 0.02 * ess_target, obj._ess
+        assert G.rel_err(obj._eps, ref._eps) < 1e-10, (obj._eps, ref._eps)
+        assert G.rel_err(obj._state_log_q, ref._state_log_q) < 1e-11
+        assert G.rel_err(obj._state_log_p_unnormalized, ref._state_log_p) < 1e-11
+        assert G.rel_err(obj._state_w_clipped, ref._state_w_clipped) < 1e-8     # exp of O(100) log weights
+        assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
+        assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
+        theta = theta - 0.002 * grad / (1 + np.abs(grad))
+
+
+def c4_problem(D=2000, n_data=8192, seed=4):
+    rng = np.random.RandomState(seed)
+    X = rng.randn(n_data, D) / np.sqrt(D)
+    beta = rng.randn(D)
+    y = (rng.rand(n_data) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    theta = np.concatenate([0.05 * rng.randn(D), -2.0 + 0.1 * rng.randn(D)])
+    return X, y, theta
+
+
+def test_c4_logistic_full_size_against_oracle(vb):
+    D, n_data, N = 2000, 8192, 8192
+    X, y, theta = c4_problem(D, n_data)
+    model, omodel = vb.LogisticRegressionModel(X, y, 10.0), omod.Logistic(X, y, 10.0)
+    for pd in (False, True):
+        approx = vb.MFGaussian(D, seed=9)
+        value, grad = vb.ExclusiveKL(approx, model, N, use_path_deriv=pd)(theta)
+        noise = np.random.RandomState(9).randn(N, D)
+        ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omodel, theta, noise, use_path_deriv=pd)
+        assert G.rel_err(value, ov) < 1e-12, (pd, value, ov)
+        assert G.rel_err(grad, og) < 1e-10, (pd, G.rel_err(grad, og))
+
+
+def test_c4_logistic_optimiser_loop_full_size(vb, capsys):
+    """The optimiser loop of configs[4] at full size: RMSProp iterations with fresh Philox noise through the host
+    loop (one blocking objective call + numpy step per iteration, optimization.py:91-112) and through the
+    device-resident loop that FASO / RAABBVI run between two convergence checks -- same iterates bit for bit; and
+    the objective goes down."""
+    from viabel_amd.optimization import RMSProp
+    D, n_data, N = 2000, 8192, 8192
+    X, y, _ = c4_problem(D, n_data)
+    model = vb.LogisticRegressionModel(X, y, 10.0)
+    theta0 = np.concatenate([np.zeros(D), -2.0 * np.ones(D)])
+    hist = {}
+    for mode, on_device in (('host', False), ('device', True)):
+        obj = vb.ExclusiveKL(vb.MFGaussian(D, rng='philox', seed=2), model, N)
+        res = RMSProp(0.02).optimize(12, obj, theta0, on_device=on_device)
+        hist[mode] = res
+    capsys.readouterr()
+    assert np.array_equal(hist['host']['value_history'], hist['device']['value_history'])
+    assert np.array_equal(hist['host']['opt_param'], hist['device']['opt_param'])
+    v = hist['device']['value_history']
+    assert v[-1] < v[0]
+
+
+def test_c4_logistic_raabbvi_runs_full_size(vb, capsys):
+    """`bbvi` with its default RAABBVI step-size adaptation on the full-size logistic target, a bounded number of
+    iterations: the adaptive loop runs its device-resident chunks and the ELBO estimate improves."""
+    D, n_data, N = 2000, 8192, 8192
+    X, y, _ = c4_problem(D, n_data)
+    model = vb.LogisticRegressionModel(X, y, 10.0)
+    np.random.seed(3)
+    approx = vb.MFGaussian(D, rng='philox', seed=2)
+    objective = vb.ExclusiveKL(approx, model, N)
+    init = np.concatenate([np.zeros(D), -2.0 * np.ones(D)])
+    v0, _ = objective(init)
+    results = vb.bbvi(D, objective=objective, init_var_param=init, n_iters=300, learning_rate=0.05)
+    capsys.readouterr()
+    v1, _ = objective(results['opt_param'])
+    assert np.isfinite(v1) and v1 < v0, (v0, v1)
