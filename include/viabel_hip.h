@@ -96,6 +96,11 @@ int vb_noise_set_host(vb_ctx* ctx, int slot, const double* host, int64_t n, int6
 int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
                       uint64_t stream, int64_t row_offset, int64_t n, int64_t d);
 int vb_noise_get_host(vb_ctx* ctx, int slot, double* host, int64_t n, int64_t d);
+/* Chi-square(df) draws on the device, df > 2: draw i is element (row_offset + i) of Philox stream (seed, stream) --
+ * the per-sample radial scales s = sqrt(chi2 / df) of MultivariateT.sample (approximations.py:345-347) in throughput
+ * mode.  The n draws stay in the context (one set at a time); vb_dis_refresh_mvt takes them when its `chi` is NULL. */
+int vb_chisq_generate(vb_ctx* ctx, double df, uint64_t seed, uint64_t stream, int64_t row_offset, int64_t n);
+int vb_chisq_get_host(vb_ctx* ctx, double* host, int64_t n);
 
 /* ---- model ------------------------------------------------------------------------ */
 int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams,
@@ -182,6 +187,9 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q);
+/* log p / log q of the state samples of the last refresh (all n_total of them; either pointer may be NULL), for
+ * callers that passed NULL to the refresh.  dense = 0: mean-field state, 1: MultivariateT / dense-Gaussian state. */
+int vb_dis_state_get(vb_ctx* ctx, int dense, double* log_p, double* log_q, int64_t n_total);
 int vb_dis_grad_mvt(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* l_inv,
                     const double* weights, double* w_sum, double* w_logq, double* d_mu, double* gram);
 

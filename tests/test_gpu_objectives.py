@@ -302,3 +302,74 @@ def test_glm_regression_targets(vb, kind, D, n_data, N):
     if kind == 'poisson':
         with pytest.raises(ValueError):
             vb.PoissonRegressionModel(X, -np.ones(n_data))
+
+
+@pytest.mark.parametrize('df', [2.5, 9.0, 100.0])
+def test_device_chisquare_draws(vb, df):
+    """The chi-square draws of MultivariateT in throughput mode (vb_chisq_generate: Philox + Marsaglia-Tsang):
+    right distribution, pure function of (seed, stream, global row) -- so sharding does not change them."""
+    from scipy import stats
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    n = 200000
+    eng.chisq_generate(df, n, seed=11, stream=3)
+    x = eng.chisq_get_host(n)
+    assert np.all(x > 0) and np.all(np.isfinite(x))
+    assert stats.kstest(x, 'chi2', args=(df,)).pvalue > 1e-3
+    assert abs(x.mean() - df) < 6 * np.sqrt(2 * df / n)
+    eng.chisq_generate(df, 1000, seed=11, stream=3, row_offset=150000)
+    assert np.array_equal(eng.chisq_get_host(1000), x[150000:151000])
+    eng.chisq_generate(df, 1000, seed=11, stream=4)
+    assert not np.array_equal(eng.chisq_get_host(1000), x[:1000])
+    with pytest.raises(ValueError):
+        eng.chisq_generate(2.0, 10, seed=1)
+
+
+@pytest.mark.parametrize('use_resampling', [True, False])
+def test_dis_multivariate_t_philox_mode_against_oracle(vb, use_resampling):
+    """rng='philox': the normals AND the chi-square draws of the state refresh are generated on the device; read
+    both back and the oracle must reproduce the step on them.  In this mode the state samples are
+    x = mu + (z L') / s with the Cholesky factor (same distribution as the reference's symmetric root, no D^3 root
+    on the hot path), so the oracle family used here samples the same way; everything downstream of the samples
+    (log q, log p, tempering, weights, gradient) is the reference's arithmetic."""
+    from viabel_amd import _lib
+    from viabel_amd.objectives import _DIS_SLOT
+
+    class CholeskySampledT(ofam.MultivariateT):
+        def sample_from_noise(self, theta, noise):
+            chi, z = noise
+            mu, S = self.split(theta)
+            return mu + (z @ np.linalg.cholesky(S).T) / np.sqrt(chi / self.df)[:, None]
+
+    D, N, df = 130, 2048, 12.0
+    rng = np.random.RandomState(19)
+    approx, ofamily = vb.MultivariateT(D, df, seed=8, rng='philox'), CholeskySampledT(D, df)
+    mean, sd = 0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=300, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, use_resampling=use_resampling)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, 300, ofam.MFGaussian(D), prior, use_resampling=use_resampling)
+    A = rng.randn(D, D)
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(A @ A.T / D + 0.7 * np.eye(D))])
+    np.random.seed(4)
+    state = np.random.get_state()
+    value, grad = obj(theta)
+    np.random.set_state(state)
+    eng = _lib.default_engine()
+    noise = (eng.chisq_get_host(N), eng.noise_get_host(_DIS_SLOT, N, D))
+    if use_resampling:
+        ref.refresh(theta, noise)
+        idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
+        xs = ref._state_samples[idx]
+        scale = ref._state_w_sum / N
+        ov = np.mean(-ofamily.log_density(theta, xs)) * scale
+        og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+    else:
+        ov, og = ref(theta, noise=noise)
+    assert G.rel_err(obj._eps, ref._eps) < 1e-10
+    assert G.rel_err(value, ov) < 1e-10, (value, ov)
+    assert G.rel_err(grad, og) < 1e-9, G.rel_err(grad, og)
+    # the per-sample logs stay on the device in this mode and are fetched on first access
+    assert G.rel_err(obj._state_log_q, ref._state_log_q) < 1e-11
+    assert G.rel_err(obj._state_log_p_unnormalized, ref._state_log_p) < 1e-11

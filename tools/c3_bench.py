@@ -17,13 +17,16 @@ if '--blas-threads' in sys.argv:          # see viabel_amd.set_host_blas_threads
 
 D, N = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 np.random.seed(5)
-model = vb.FunnelModel(D) if (len(sys.argv) > 2 and sys.argv[2] == 'funnel') else vb.GaussianModel(np.zeros(D), 3 * np.ones(D))
 rng_kind = sys.argv[3] if len(sys.argv) > 3 else 'philox'
 approx = vb.MultivariateT(D, 100, seed=1, rng=rng_kind)
-prior = np.concatenate([np.zeros(D), np.zeros(D)])
-theta = approx.init_param()
+# the problem of tests/test_gpu_full_size.py: q on the tempering prior, target shifted away -> interior eps, ESS on target
+# (init_param's Sigma = 10 I collapses the weights to ESS = 1 in 256 dimensions)
+sys.path.insert(0, 'tests')
+from test_gpu_full_size import c3_problem
+mean, sd, prior, theta = c3_problem(np.random.RandomState(33), D)
+model = vb.FunnelModel(D) if (len(sys.argv) > 2 and sys.argv[2] == 'funnel') else vb.GaussianModel(mean, sd)
 for resample in (False, True):
-    obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 2, temper_prior=vb.MFGaussian(D),
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
                             temper_prior_params=prior, use_resampling=resample, num_resampling_batches=1)
     times = []
     for i in range(6):

@@ -11,11 +11,13 @@ import viabel_amd as vb
 
 D, N = 256, 16384
 np.random.seed(5)
-model = vb.GaussianModel(np.zeros(D), 3 * np.ones(D))
+sys.path.insert(0, 'tests')
+from test_gpu_full_size import c3_problem
+mean, sd, prior, theta = c3_problem(np.random.RandomState(33), D)
+model = vb.GaussianModel(mean, sd)
 approx = vb.MultivariateT(D, 100, seed=1, rng='philox')
-obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 2, temper_prior=vb.MFGaussian(D),
-                        temper_prior_params=np.zeros(2 * D), use_resampling=True, num_resampling_batches=1)
-theta = approx.init_param() + 0.01 * np.random.randn(approx.var_param_dim)
+obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+                        temper_prior_params=prior, use_resampling=True, num_resampling_batches=1)
 for i in range(3):
     obj(theta)
 pr = cProfile.Profile()

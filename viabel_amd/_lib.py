@@ -47,6 +47,9 @@ SIGNATURES = {
     'vb_noise_generate': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                          ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int64]),
+    'vb_chisq_generate': (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
+                                         ctypes.c_int64]),
+    'vb_chisq_get_host': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64]),
     'vb_noise_get_host': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_int64, ctypes.c_int64]),
     'vb_set_model': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, _c_double_p, ctypes.c_size_t,
                                     _c_int64_p, ctypes.c_size_t]),
@@ -110,6 +113,7 @@ SIGNATURES = {
                                           _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_double_p,
                                           _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'vb_dis_state_get': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64]),
     'vb_dis_grad_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
                                        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
                                        _c_double_p]),
@@ -248,6 +252,15 @@ class Engine:
     def noise_generate(self, slot, n, d, seed, stream=0, row_offset=0, kind=NOISE_NORMAL, df=0.0):
         self._check(self._lib.vb_noise_generate(self._ctx, slot, kind, float(df), int(seed), int(stream),
                                                 int(row_offset), int(n), int(d)))
+
+    def chisq_generate(self, df, n, seed, stream=0, row_offset=0):
+        """``n`` chi-square(df) draws on the device (kept in the context for ``dis_refresh_mvt(chi=None)``)."""
+        self._check(self._lib.vb_chisq_generate(self._ctx, float(df), int(seed), int(stream), int(row_offset), int(n)))
+
+    def chisq_get_host(self, n):
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.vb_chisq_get_host(self._ctx, _dptr(out), n))
+        return out
 
     def noise_get_host(self, slot, n, d):
         out = np.empty((n, d), dtype=np.float64)
@@ -405,16 +418,26 @@ class Engine:
         return value.value, grad
 
     # ------------------------------------------------------------------ DISInclusiveKL, multivariate t
+    def dis_state_get(self, dense, n_total):
+        """(log p, log q) of the state samples of the last DIS refresh."""
+        lp, lq = np.empty(n_total, dtype=np.float64), np.empty(n_total, dtype=np.float64)
+        self._check(self._lib.vb_dis_state_get(self._ctx, int(bool(dense)), _dptr(lp), _dptr(lq), n_total))
+        return lp, lq
+
     def dis_refresh_mvt(self, slot, n, d, df, theta, chi, sqrt_sigma, l_inv, prior_theta, eps_prev, ess_target,
-                        max_bisection_its=50, n_total=None):
-        theta, chi, sqrt_sigma, l_inv, prior_theta = (_f64(a) for a in (theta, chi, sqrt_sigma, l_inv, prior_theta))
+                        max_bisection_its=50, n_total=None, fetch_logs=True):
+        theta, sqrt_sigma, l_inv, prior_theta = (_f64(a) for a in (theta, sqrt_sigma, l_inv, prior_theta))
+        chi = None if chi is None else _f64(chi)       # None: the device draws of chisq_generate
         n_total = n if n_total is None else n_total
         eps, ess = ctypes.c_double(0.0), ctypes.c_double(0.0)
-        w, lp, lq = (np.empty(n_total, dtype=np.float64) for _ in range(3))
+        w = np.empty(n_total, dtype=np.float64)
+        lp, lq = ((np.empty(n_total, dtype=np.float64), np.empty(n_total, dtype=np.float64)) if fetch_logs
+                  else (None, None))
         self._check(self._lib.vb_dis_refresh_mvt(
-            self._ctx, slot, n, d, n_total, float(df), _dptr(theta), _dptr(chi), _dptr(sqrt_sigma), _dptr(l_inv),
+            self._ctx, slot, n, d, n_total, float(df), _dptr(theta), None if chi is None else _dptr(chi),
+            _dptr(sqrt_sigma), _dptr(l_inv),
             _dptr(prior_theta), float(eps_prev), float(ess_target), int(max_bisection_its), ctypes.byref(eps),
-            ctypes.byref(ess), _dptr(w), _dptr(lp), _dptr(lq)))
+            ctypes.byref(ess), _dptr(w), None if lp is None else _dptr(lp), None if lq is None else _dptr(lq)))
         return eps.value, ess.value, w, lp, lq
 
     def dis_grad_mvt(self, n, d, df, theta, l_inv, weights):

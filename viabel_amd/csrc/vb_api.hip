@@ -226,7 +226,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& log : ctx->prof)
@@ -281,6 +281,28 @@ int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
   VB_TRY(noise_alloc(ctx, slot, n, d));
   NoiseSlot& s = ctx->noise[slot];
   return rng_fill(ctx, (double*)s.buf.ptr, s.ld, kind, df, seed, stream, row_offset, n, d);
+}
+
+int vb_chisq_generate(vb_ctx* ctx, double df, uint64_t seed, uint64_t stream, int64_t row_offset, int64_t n) {
+  if (!ctx) return VB_ERR_INVALID;
+  if (n <= 0) return fail(ctx, VB_ERR_INVALID, "n must be positive");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  VB_TRY(ensure(ctx, ctx->chi_dev, (size_t)n * sizeof(double)));
+  ctx->chi_n = 0;
+  VB_TRY(rng_chisquare(ctx, (double*)ctx->chi_dev.ptr, df, seed, stream, row_offset, n));
+  ctx->chi_n = n;
+  ctx->chi_df = df;
+  return VB_OK;
+}
+
+int vb_chisq_get_host(vb_ctx* ctx, double* host, int64_t n) {
+  if (!ctx || !host) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (n <= 0 || n != ctx->chi_n) return fail(ctx, VB_ERR_STATE, "no %lld device chi-square draws", (long long)n);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_HIP(ctx, hipMemcpyAsync(host, ctx->chi_dev.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VB_OK;
 }
 
 int vb_noise_get_host(vb_ctx* ctx, int slot, double* host, int64_t n, int64_t d) {
@@ -697,14 +719,20 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q) {
-  if (!ctx || !theta || !chi || !sqrt_sigma || !l_inv || !prior_theta || !eps || !ess || !w)
-    return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (!ctx || !theta || !sqrt_sigma || !l_inv || !prior_theta || !eps || !ess || !w)
+    return fail(ctx, VB_ERR_INVALID, "NULL argument");      // chi may be NULL: device draws (vb_chisq_generate)
   VB_TRY(check_slot(ctx, slot));
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
   if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
   VB_HIP(ctx, hipSetDevice(ctx->device));
   return mvt_dis_refresh(ctx, ctx->noise[slot], n, n_total, d, df, theta, chi, sqrt_sigma, l_inv, prior_theta, eps_prev,
                          ess_target, max_bisection_its, eps, ess, w, log_p, log_q);
+}
+
+int vb_dis_state_get(vb_ctx* ctx, int dense, double* log_p, double* log_q, int64_t n_total) {
+  if (!ctx) return VB_ERR_INVALID;
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return dense ? mvt_dis_state_get(ctx, log_p, log_q, n_total) : dis_state_get(ctx, log_p, log_q, n_total);
 }
 
 int vb_dis_grad_mvt(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* l_inv,

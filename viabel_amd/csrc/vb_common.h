@@ -129,6 +129,10 @@ struct vb_ctx {
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
   int64_t dis_n_total = 0;              // whole-job sample count of the DIS state
+  vb::DeviceBuffer chi_dev;             // device-generated chi-square draws (vb_chisq_generate)
+  int64_t chi_n = 0;                    // how many of them are valid (0: none)
+  double chi_df = 0.0;
+  vb::DeviceBuffer bisect_work;         // DIS tempering bisection: interval / ESS tables of the look-ahead rounds
   vb::DeviceBuffer mvt_elbo;            // multivariate-t ExclusiveKL: root, mean, row scales
   vb::DeviceBuffer lr_work;             // low-rank Gaussian family: workspace of the streaming pipeline
   vb::DeviceBuffer rows_work;           // Model.__call__ for the dense targets: GEMM output rows
@@ -307,6 +311,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
                     const double* chi_host, const double* root_host, const double* linv_host,
                     const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
                     double* ess_out, double* w_host, double* logp_host, double* logq_host);
+int mvt_dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t n_total);
+int dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t n_total);
 int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
                  const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out);
 
@@ -342,6 +348,7 @@ int fit_step_enqueue(vb_ctx* ctx, const FitStep& step);
 // Philox noise generation (vb_rng.hip)
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,
              uint64_t stream, int64_t row_offset, int64_t n, int64_t d);
+int rng_chisquare(vb_ctx* ctx, double* dst, double df, uint64_t seed, uint64_t stream, int64_t row_offset, int64_t n);
 
 // regression targets: G = R X - Z / prior_sd^2 (n x d, contraction over the n_data observations), split over the
 // observations when the output alone cannot fill the chip (vb_rows.hip)

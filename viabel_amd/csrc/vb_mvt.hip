@@ -224,6 +224,12 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
   return VB_OK;
 }
 
+__global__ void __launch_bounds__(256) mvt_inv_scale_kernel(const double* __restrict__ chi, double df, int64_t n,
+                                                            double* __restrict__ inv_s) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) inv_s[i] = 1.0 / sqrt(chi[i] / df);                                      // approximations.py:345
+}
+
 int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df,
                     const double* theta_host,
                     const double* chi_host, const double* root_host, const double* linv_host,
@@ -244,10 +250,20 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   const int64_t mine = (int64_t)ctx->rank * n;   // this rank's block inside the gathered vectors
 
   VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
-  std::vector<double> inv_s((size_t)n);
-  for (int64_t i = 0; i < n; ++i)
-    inv_s[i] = df > 0.0 ? 1.0 / sqrt(chi_host[i] / df) : 1.0;                         // approximations.py:345
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_invs, inv_s.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  std::vector<double> inv_s;
+  if (chi_host || df == 0.0) {
+    inv_s.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i)
+      inv_s[i] = df > 0.0 ? 1.0 / sqrt(chi_host[i] / df) : 1.0;                       // approximations.py:345
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_invs, inv_s.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  } else {   // the draws of vb_chisq_generate, already on the device
+    if (ctx->chi_n != n || ctx->chi_df != df)
+      return fail(ctx, VB_ERR_STATE, "chi == NULL needs %lld device chi-square(%g) draws (vb_chisq_generate)",
+                  (long long)n, df);
+    hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const double*)ctx->chi_dev.ptr, df, n, base + L.o_invs);
+    VB_HIP(ctx, hipGetLastError());
+  }
   std::vector<double> pr((size_t)2 * L.ld, 0.0);
   double c0p = -0.5 * (double)d * 1.8378770664093454835606594728112;
   for (int64_t i = 0; i < d; ++i) {
@@ -312,6 +328,21 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   ctx->mvt_n_total = n_total;
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
+  return VB_OK;
+}
+
+// log p / log q of the state samples (all n_total of them), for callers that did not take them from the refresh
+int mvt_dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t n_total) {
+  if (!ctx->mvt_state.ptr || ctx->mvt_n_total != n_total || n_total <= 0)
+    return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state with %lld samples", (long long)n_total);
+  const MvtLayout L = mvt_layout(ctx, ctx->mvt_n, ctx->mvt_n_total, ctx->mvt_d);
+  double* base = (double*)ctx->mvt_state.ptr;
+  hipStream_t st = ctx->stream;
+  if (logp_host)
+    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (logq_host)
+    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lqcopy, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
   return VB_OK;
 }
 

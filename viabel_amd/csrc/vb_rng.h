@@ -79,4 +79,28 @@ __device__ __forceinline__ double student_t_polar(double df, uint64_t grow, uint
   return u * sqrt(df * expm1(-2.0 / df * log(w)) / w);
 }
 
+// chi-square(df) draw number `grow` of a stream (the per-sample radial scale of MultivariateT.sample,
+// approximations.py:345: s = sqrt(chisquare(df) / df)), df > 2: twice a Gamma(df / 2) variate by Marsaglia and Tsang's
+// squeeze-free method (ACM TOMS 26 (2000) 363-372) -- x standard normal, v = (1 + x / sqrt(9 a - 3))^3, accept when
+// log u < x^2 / 2 + d - d v + d log v, d = a - 1/3 (acceptance > 95 % for a > 1).  Attempt t takes its normal from
+// Philox sub-stream 2 t and its uniform from sub-stream 2 t + 1 of pseudo column 0xFFFFFFFF, so the value is a pure
+// function of (seed, stream, global row) and does not depend on how the sample axis is sharded.
+__device__ __forceinline__ double philox_chisquare(double df, uint64_t grow, uint32_t stream, uint32_t k0, uint32_t k1) {
+  const double a = 0.5 * df, dd = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
+  double v = 1.0;
+  for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+    const Philox4 o = philox_sub(grow, 0xFFFFFFFFu, stream, 2 * attempt, k0, k1);
+    const double u1 = u01(o.x, o.y), u2 = u01(o.z, o.w);
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    const double x = sqrt(-2.0 * log(u1)) * cs;
+    const double t = 1.0 + c * x;
+    if (t <= 0.0) continue;
+    v = t * t * t;
+    const Philox4 q = philox_sub(grow, 0xFFFFFFFFu, stream, 2 * attempt + 1, k0, k1);
+    if (log(u01(q.x, q.y)) < 0.5 * x * x + dd - dd * v + dd * log(v)) break;
+  }
+  return 2.0 * dd * v;
+}
+
 }  // namespace vb

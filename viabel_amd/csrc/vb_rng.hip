@@ -61,6 +61,22 @@ __global__ void __launch_bounds__(256) rng_student_t_kernel(double* __restrict__
   }
 }
 
+__global__ void __launch_bounds__(256) rng_chisquare_kernel(double* __restrict__ dst, double df, uint64_t seed,
+                                                            uint64_t stream, int64_t row_offset, int64_t n) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32);
+  dst[r] = philox_chisquare(df, (uint64_t)(row_offset + r), (uint32_t)stream, k0, k1);
+}
+
+int rng_chisquare(vb_ctx* ctx, double* dst, double df, uint64_t seed, uint64_t stream, int64_t row_offset, int64_t n) {
+  if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  hipLaunchKernelGGL(rng_chisquare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dst, df, seed,
+                     stream, row_offset, n);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,
              uint64_t stream, int64_t row_offset, int64_t n, int64_t d) {
   const int64_t pairs = (d + 1) / 2;

@@ -333,83 +333,180 @@ int alpha_mvt_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_tot
 }
 
 // ---- DISInclusiveKL state refresh (objectives.py:317-368) ---------------------------------------------
-// One workgroup: bisection on the tempering parameter for the effective sample size.
+// Bisection on the tempering parameter for the effective sample size.
 //   logw(e) = e * log prior + (1 - e) * log p - log q,   w = exp(logw)   (no max shift, :330)
 //   ESS = (sum w)^2 / sum w^2   (:333-336);  50 bisection steps on [0, eps_prev], end-point snapping.
-// scal_out = [eps, ess, status]; status 1 = "all weights zero" (max logw == -inf, :325-328).
-__global__ void __launch_bounds__(1024) dis_bisect_kernel(const double* __restrict__ lp,
-                                                          const double* __restrict__ b,
-                                                          const double* __restrict__ lprior,
-                                                          const double* __restrict__ scal_in, int64_t n,
-                                                          double eps_prev, double ess_target, int max_its,
-                                                          double max_eps, double* __restrict__ w,
-                                                          double* __restrict__ lq_out,
-                                                          double* __restrict__ scal_out) {
-  __shared__ double sh1[16], sh2[16], shm[16];
-  __shared__ double bc[3];
-  const double sum_ls = scal_in[0];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double lower = 0.0, upper = eps_prev, guess = 0.5 * (lower + upper);
-  int status = 0;
-  double ess = 0.0;
-  for (int it = 0; it <= max_its; ++it) {
-    double s1 = 0.0, s2 = 0.0, mx = -INFINITY;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-      const double lq = b[i] - sum_ls;
-      const double lw = guess * lprior[i] + (1.0 - guess) * lp[i] - lq;
-      const double wv = exp(lw);
-      mx = fmax(mx, lw);
-      s1 += wv;
-      s2 = fma(wv, wv, s2);
-      if (it == max_its) {
-        w[i] = wv;
-        lq_out[i] = lq;
-      }
-    }
-    s1 = rs_wave_sum(s1);
-    s2 = rs_wave_sum(s2);
-    mx = rs_wave_max(mx);
-    __syncthreads();
-    if (lane == 0) {
-      sh1[wave] = s1;
-      sh2[wave] = s2;
-      shm[wave] = mx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double t1 = 0.0, t2 = 0.0, tm = -INFINITY;
-      for (int k = 0; k < 16; ++k) {
-        t1 += sh1[k];
-        t2 += sh2[k];
-        tm = fmax(tm, shm[k]);
-      }
-      bc[0] = t1 * t1 / t2;
-      bc[1] = tm;
-    }
-    __syncthreads();
-    ess = bc[0];
-    if (bc[1] == -INFINITY) status = 1;
-    if (it < max_its) {
-      if (ess > ess_target) upper = guess;
-      else lower = guess;
-      guess = 0.5 * (lower + upper);
+// The reference evaluates its 51 candidates one after the other; each needs all N weights, so a literal
+// restatement is 51 dependent passes on one CU (424 us at N = 16 384, bound by 51 N fp64 `exp`).  Here the next
+// kLook = 6 levels are looked ahead: one launch evaluates the ESS of all 2^6 - 1 = 63 midpoints the next six
+// decisions can possibly visit (one workgroup per midpoint, the N weights strided over its 256 threads), and the
+// following launch first replays those six decisions -- the same comparisons on the same numbers, in the same
+// order -- to find its own interval.  Midpoints are formed by the reference's own expression (lower + upper) / 2
+// from the same end points, so every candidate the reference visits is evaluated at the bit-identical eps, and the
+// "all weights zero" error (:325-328) is raised only for candidates on the visited path.  9 launches + a final
+// one that writes the weights: 51 x N exps on one CU become 63 x N / 63 per launch on 63 CUs.
+// dis_state: [lower, upper, status] at the start of a round; res: [round][node] = {ess, max logw}.
+constexpr int kLook = 6;
+constexpr int kLookNodes = 1 << kLook;       // heap order, node 1 = the interval's midpoint; index 0 unused
+
+struct BisectWalk {
+  double lower, upper;
+  int status;
+};
+// replay `levels` decisions of a finished round (objectives.py:349-357)
+__device__ __forceinline__ BisectWalk bisect_replay(double lower, double upper, int status, int levels,
+                                                    const double* __restrict__ res, double ess_target) {
+  int node = 1;
+  for (int l = 0; l < levels; ++l) {
+    const double guess = (lower + upper) / 2.0;
+    const double ess = res[2 * node], mx = res[2 * node + 1];
+    if (mx == -INFINITY) status = 1;
+    if (ess > ess_target) {
+      upper = guess;
+      node = 2 * node;
+    } else {
+      lower = guess;
+      node = 2 * node + 1;
     }
   }
+  return BisectWalk{lower, upper, status};
+}
+
+// one workgroup per candidate of the round
+__global__ void __launch_bounds__(256) dis_bisect_round_kernel(const double* __restrict__ lp,
+                                                               const double* __restrict__ b,
+                                                               const double* __restrict__ lprior,
+                                                               const double* __restrict__ scal_in, int64_t n,
+                                                               double ess_target, int prev_levels, int levels,
+                                                               const double* __restrict__ state_in,
+                                                               const double* __restrict__ res_in,
+                                                               double* __restrict__ state_out,
+                                                               double* __restrict__ res_out) {
+  __shared__ double sh1[4], sh2[4], shm[4];
+  const double sum_ls = scal_in[0];
+  BisectWalk wk = bisect_replay(state_in[0], state_in[1], (int)state_in[2], prev_levels, res_in, ess_target);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    state_out[0] = wk.lower;
+    state_out[1] = wk.upper;
+    state_out[2] = (double)wk.status;
+  }
+  // this workgroup's candidate: heap node blockIdx.x + 1 of the round's tree
+  const int node = blockIdx.x + 1;
+  if (node >= (1 << levels)) return;
+  int depth = 0;
+  while ((node >> (depth + 1)) != 0) ++depth;       // node = 1 b_{depth-1} ... b_0
+  double lower = wk.lower, upper = wk.upper;
+  for (int l = depth - 1; l >= 0; --l) {
+    const double guess = (lower + upper) / 2.0;
+    if ((node >> l) & 1) lower = guess;
+    else upper = guess;
+  }
+  const double guess = (lower + upper) / 2.0;
+  double s1 = 0.0, s2 = 0.0, mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const double lq = b[i] - sum_ls;
+    const double lw = guess * lprior[i] + (1.0 - guess) * lp[i] - lq;
+    const double wv = exp(lw);
+    mx = fmax(mx, lw);
+    s1 += wv;
+    s2 = fma(wv, wv, s2);
+  }
+  s1 = rs_wave_sum(s1);
+  s2 = rs_wave_sum(s2);
+  mx = rs_wave_max(mx);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh1[wave] = s1;
+    sh2[wave] = s2;
+    shm[wave] = mx;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    const double t1 = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]), t2 = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+    res_out[2 * node] = t1 * t1 / t2;
+    res_out[2 * node + 1] = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+  }
+}
+
+// last step (:358-366): replay the final round, evaluate the weights at the final midpoint, snap eps to the ends.
+// scal_out = [eps, ess, status]; status 1 = "all weights zero" (max logw == -inf, :325-328).
+__global__ void __launch_bounds__(1024) dis_bisect_final_kernel(const double* __restrict__ lp,
+                                                                const double* __restrict__ b,
+                                                                const double* __restrict__ lprior,
+                                                                const double* __restrict__ scal_in, int64_t n,
+                                                                double ess_target, int prev_levels,
+                                                                const double* __restrict__ state_in,
+                                                                const double* __restrict__ res_in, double max_eps,
+                                                                double* __restrict__ w, double* __restrict__ lq_out,
+                                                                double* __restrict__ scal_out) {
+  __shared__ double sh1[16], sh2[16], shm[16];
+  const double sum_ls = scal_in[0];
+  const BisectWalk wk = bisect_replay(state_in[0], state_in[1], (int)state_in[2], prev_levels, res_in, ess_target);
+  const double guess = (wk.lower + wk.upper) / 2.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s1 = 0.0, s2 = 0.0, mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double lq = b[i] - sum_ls;
+    const double lw = guess * lprior[i] + (1.0 - guess) * lp[i] - lq;
+    const double wv = exp(lw);
+    mx = fmax(mx, lw);
+    s1 += wv;
+    s2 = fma(wv, wv, s2);
+    w[i] = wv;
+    lq_out[i] = lq;
+  }
+  s1 = rs_wave_sum(s1);
+  s2 = rs_wave_sum(s2);
+  mx = rs_wave_max(mx);
+  if (lane == 0) {
+    sh1[wave] = s1;
+    sh2[wave] = s2;
+    shm[wave] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t1 = 0.0, t2 = 0.0, tm = -INFINITY;
+    for (int k = 0; k < 16; ++k) {
+      t1 += sh1[k];
+      t2 += sh2[k];
+      tm = fmax(tm, shm[k]);
+    }
     double eps = guess;
-    if (lower == 0.0) eps = 0.0;          // :363-366
-    if (upper == max_eps) eps = max_eps;
+    if (wk.lower == 0.0) eps = 0.0;          // :363-366
+    if (wk.upper == max_eps) eps = max_eps;
     scal_out[0] = eps;
-    scal_out[1] = ess;
-    scal_out[2] = (double)status;
+    scal_out[1] = t1 * t1 / t2;
+    scal_out[2] = (double)((wk.status != 0 || tm == -INFINITY) ? 1 : 0);
   }
 }
 
 int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const double* lprior, const double* scal_in,
                        int64_t n, double eps_prev, double ess_target, int max_its, double* w, double* lq_out,
                        double* scal_out) {
-  hipLaunchKernelGGL(dis_bisect_kernel, dim3(1), dim3(1024), 0, ctx->stream, lp, b, lprior, scal_in, n, eps_prev,
-                     ess_target, max_its, 1.0, w, lq_out, scal_out);
+  if (max_its < 0) return fail(ctx, VB_ERR_INVALID, "max_its must be >= 0");
+  const int rounds = (max_its + kLook - 1) / kLook;
+  // [state (rounds + 1) x 4 | res rounds x 2 kLookNodes]
+  const size_t need = ((size_t)(rounds + 1) * 4 + (size_t)rounds * 2 * kLookNodes + 16) * sizeof(double);
+  VB_TRY(ensure(ctx, ctx->bisect_work, need));
+  double* state = (double*)ctx->bisect_work.ptr;
+  double* res = state + (size_t)(rounds + 1) * 4;
+  hipStream_t st = ctx->stream;
+  const double init[3] = {0.0, eps_prev, 0.0};      // lower, upper = eps_guess (:346)
+  VB_HIP(ctx, hipMemcpyAsync(state, init, sizeof init, hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));              // `init` is on the stack
+  int prev_levels = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const int levels = max_its - r * kLook < kLook ? max_its - r * kLook : kLook;
+    hipLaunchKernelGGL(dis_bisect_round_kernel, dim3((unsigned)((1 << levels) - 1)), dim3(256), 0, st, lp, b, lprior,
+                       scal_in, n, ess_target, prev_levels, levels, (const double*)(state + 4 * r),
+                       (const double*)(res + (size_t)(r > 0 ? r - 1 : 0) * 2 * kLookNodes), state + 4 * (r + 1),
+                       res + (size_t)r * 2 * kLookNodes);
+    prev_levels = levels;
+  }
+  hipLaunchKernelGGL(dis_bisect_final_kernel, dim3(1), dim3(1024), 0, st, lp, b, lprior, scal_in, n, ess_target,
+                     prev_levels, (const double*)(state + 4 * rounds),
+                     (const double*)(res + (size_t)(rounds > 0 ? rounds - 1 : 0) * 2 * kLookNodes), 1.0, w, lq_out,
+                     scal_out);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -483,11 +580,8 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
     VB_TRY(comm_allgather(ctx, st, base + L.o_b + mine, base + L.o_b, (size_t)n));
     VB_TRY(comm_allgather(ctx, st, base + L.o_lprior + mine, base + L.o_lprior, (size_t)n));
   }
-  hipLaunchKernelGGL(dis_bisect_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_lp),
-                     (const double*)(base + L.o_b), (const double*)(base + L.o_lprior),
-                     (const double*)(base + L.o_scal), n_total, eps_prev, ess_target, max_its, 1.0, base + L.o_w,
-                     base + L.o_lq, base + L.o_out);
-  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_b, base + L.o_lprior, base + L.o_scal, n_total, eps_prev,
+                            ess_target, max_its, base + L.o_w, base + L.o_lq, base + L.o_out));
   double res[3];
   VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_out, sizeof res, hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -504,6 +598,21 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
   ctx->dis_d = d;
   if (*status_out == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
+  return VB_OK;
+}
+
+int dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t n_total) {
+  if (!ctx->dis_state.ptr || ctx->dis_n_total != n_total || n_total <= 0)
+    return fail(ctx, VB_ERR_STATE, "no mean-field DIS state with %lld samples", (long long)n_total);
+  const DisLayout L = dis_layout(ctx->dis_n_total, round_up(ctx->dis_d, 16) % 512 == 0 ? round_up(ctx->dis_d, 16) + 16
+                                                                                       : round_up(ctx->dis_d, 16));
+  double* base = (double*)ctx->dis_state.ptr;
+  hipStream_t st = ctx->stream;
+  if (logp_host)
+    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (logq_host)
+    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lq, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
   return VB_OK;
 }
 

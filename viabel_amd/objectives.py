@@ -403,6 +403,25 @@ class DISInclusiveKL(StochasticVariationalObjective):
         self._temper_prior_params = np.asarray(temper_prior_params, dtype=np.float64)
         super().__init__(approx, model, num_mc_samples)
 
+    # log p / log q of the state samples (objectives.py:394-395).  In throughput mode (rng='philox') they stay on the
+    # device and are fetched on first access: nothing on the hot path reads them.
+    def _set_state_logs(self, log_p, log_q, fetch=None):
+        self._lp_cache, self._lq_cache, self._logs_fetch = log_p, log_q, fetch
+
+    def _get_state_logs(self):
+        if getattr(self, '_lp_cache', None) is None and getattr(self, '_logs_fetch', None) is not None:
+            self._lp_cache, self._lq_cache = self._logs_fetch()
+            self._logs_fetch = None
+        return getattr(self, '_lp_cache', None), getattr(self, '_lq_cache', None)
+
+    @property
+    def _state_log_p_unnormalized(self):
+        return self._get_state_logs()[0]
+
+    @property
+    def _state_log_q(self):
+        return self._get_state_logs()[1]
+
     def _clip_weights(self, w):
         """Clip weights to ``w_clip_threshold`` (``objectives.py:370-386``).
 
@@ -456,8 +475,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_meanfield(
                     slot, n_local, approx.dim, var_param, self._temper_prior_params, family, self._eps,
                     self._ess_target, self._max_bisection_its, df=df, n_total=N)
-                self._state_log_p_unnormalized = log_p
-                self._state_log_q = log_q
+                self._set_state_logs(log_p, log_q)
                 self._state_w_clipped = self._clip_weights(w)
                 self._state_w_sum = np.sum(self._state_w_clipped)
                 self._state_w_normalized = self._state_w_clipped / self._state_w_sum
@@ -486,9 +504,16 @@ class DISInclusiveKL(StochasticVariationalObjective):
 
         _lib.apply_host_blas_policy()      # before the first D x D host product
 
+        from scipy.linalg import lapack
+        diag = np.diag_indices(D)
+        philox = approx.rng == 'philox'
+
         def factors(var_param):
             L = approx._unpack(var_param)[1]
-            return L, sla.solve_triangular(L, np.eye(D), lower=True)
+            Linv, info = lapack.dtrtri(L, lower=1)       # LAPACK directly: scipy's solve_triangular wrapper costs
+            if info != 0:                                # more than the D^3 / 3 flops at D = 256
+                raise ValueError('singular Cholesky factor')
+            return L, Linv
 
         def variational_objective(var_param):
             var_param = np.asarray(var_param, dtype=np.float64)
@@ -503,26 +528,32 @@ class DISInclusiveKL(StochasticVariationalObjective):
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
                 if gaussian:
                     chi = np.ones(N)
-                    if approx.rng == 'philox':
+                    if philox:
                         eng.noise_generate(slot, n_local, D, approx._seed, approx._next_philox_stream(),
                                            row_offset=begin)
                     else:
                         eng.noise_set_host(slot, approx._base_noise(N)[begin:end])
                     root = np.ascontiguousarray(L.T)            # x = mu + eps L'
+                elif philox:
+                    # throughput mode: chi-square draws and normals on the GPU, and x = mu + (z L') / s with the
+                    # Cholesky factor instead of the reference's symmetric root (approximations.py:348).  The samples
+                    # have the same distribution (z L' and z Sigma^1/2 are both N(0, Sigma)), DIS treats them as
+                    # constants, and no noise stream of the reference is being reproduced in this mode -- so the
+                    # D^3 root (0.9 ms of Newton-Schulz GEMMs at D = 256) is not computed at all.
+                    stream = approx._next_philox_stream()
+                    eng.chisq_generate(df, n_local, approx._seed, stream, row_offset=begin)
+                    eng.noise_generate(slot, n_local, D, approx._seed, stream, row_offset=begin)
+                    chi = None
+                    root = np.ascontiguousarray(L.T)
                 else:
-                    if approx.rng == 'philox':                  # N chi-square draws on the host, N x D normals on the GPU
-                        chi = approx._rs.chisquare(df, N)
-                        eng.noise_generate(slot, n_local, D, approx._seed, approx._next_philox_stream(),
-                                           row_offset=begin)
-                    else:
-                        chi, z = approx._base_noise(N)         # chi-square draws first (approximations.py:345-347)
-                        eng.noise_set_host(slot, z[begin:end])
+                    chi, z = approx._base_noise(N)             # chi-square draws first (approximations.py:345-347)
+                    eng.noise_set_host(slot, z[begin:end])
                     root, _ = _device_root(eng, L @ L.T)        # symmetric square root, :348
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
-                    slot, n_local, D, df, var_param, chi[begin:end], root, Linv, self._temper_prior_params,
-                    self._eps, self._ess_target, self._max_bisection_its, n_total=N)
-                self._state_log_p_unnormalized = log_p
-                self._state_log_q = log_q
+                    slot, n_local, D, df, var_param, None if chi is None else chi[begin:end], root, Linv,
+                    self._temper_prior_params, self._eps, self._ess_target, self._max_bisection_its, n_total=N,
+                    fetch_logs=not philox)
+                self._set_state_logs(log_p, log_q, (lambda: eng.dis_state_get(True, N)) if philox else None)
                 self._state_w_clipped = self._clip_weights(w)
                 self._state_w_sum = np.sum(self._state_w_clipped)
                 self._state_w_normalized = self._state_w_clipped / self._state_w_sum
@@ -535,10 +566,14 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 scale = self._state_w_sum / N / self._resampling_batch_size
             w_sum, w_logq, d_mu, gram = eng.dis_grad_mvt(n_local, D, df, var_param, Linv, weights[begin:end])
             # chain rule to the free Cholesky parameters
-            S = np.tril(gram) + np.tril(gram, -1).T
-            d_sigma = -0.5 * w_sum * (Linv.T @ Linv) + 0.5 * S
-            d_L = np.tril(2.0 * d_sigma @ L)
-            d_L[np.diag_indices(D)] *= np.diag(L)
+            # d log q / d Sigma = -1/2 w_sum Sigma^-1 + 1/2 S and Sigma = L L': d/dL = tril(2 (d/dSigma) L)
+            #   = tril(S L) - w_sum tril(L^-T): L^-T is upper triangular, so only its diagonal 1 / L_ii survives --
+            # one D x D product instead of three
+            S = np.tril(gram)
+            S = S + S.T
+            S[diag] *= 0.5
+            d_L = S @ L                                # only the lower triangle is read below
+            d_L[diag] = d_L[diag] * L[diag] - w_sum
             grad_logq = np.concatenate([d_mu, d_L[tril]])
             return -scale * w_logq, -scale * grad_logq
 
