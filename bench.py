@@ -17,7 +17,8 @@ a plain TCP socket group -- no torch import anywhere):
 Either way every evaluation all-reduces its 16 + D + D(D+1)/2 partial sums (4.2 MB) over RCCL.
 
 Secondary legs (rank 0 of a 1-GPU run only, after the timed region): BASELINE configs[1] (mean field, HBM-bound),
-configs[2] (D=512 full rank), the optimiser loop, the CPU baseline and the parity check.
+configs[2] (D=512 full rank), configs[3] (MultivariateT + DIS), configs[4] (logistic regression), the optimiser loop,
+the CPU baseline and the parity check.
 
 Prints ONE JSON line on rank 0.
 """
@@ -244,6 +245,86 @@ def fit_leg(vb, theta, iters=1500):
     return out
 
 
+def c3_leg(vb, calls=30):
+    """BASELINE configs[3]: MultivariateT(256, df=100) + DISInclusiveKL, N_mc = 16 384 (one GPU), throughput mode
+    (rng='philox': normals and chi-square draws on the device), state refresh on every call, with and without
+    resampling.  The problem is the one of tests/test_gpu_full_size.py (interior tempering eps, ESS on target)."""
+    D, N, df = 256, 16384, 100
+    rng = np.random.RandomState(33)
+    mean = 0.3 * rng.randn(D)
+    sd = np.exp(0.5 + 0.02 * rng.randn(D))
+    prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
+    A = rng.randn(D, D)
+    Sigma = np.e * np.eye(D) + 0.04 * (A @ A.T / D - np.eye(D))
+    approx = vb.MultivariateT(D, df, seed=1, rng='philox')
+    L = np.linalg.cholesky(Sigma)
+    Lf = L.copy()
+    Lf[np.diag_indices(D)] = np.log(np.diag(L))
+    theta = np.concatenate([0.02 * rng.randn(D), Lf[np.tril_indices(D)]])
+    model = vb.GaussianModel(mean, sd)
+    out = {'workload': 'BASELINE configs[3]: MultivariateT(256, df=100) + DISInclusiveKL, N_mc=16384, ess_target=2048, '
+                       'state refresh every call, rng=philox, one GPU'}
+    np.random.seed(5)
+    for resample in (False, True):
+        obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+                                temper_prior_params=prior, use_resampling=resample)
+        for _ in range(5):
+            obj(theta)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            v, g = obj(theta)
+        dt = (time.perf_counter() - t0) / calls
+        out['resampling' if resample else 'weighted'] = {
+            'ms_per_call': 1e3 * dt, 'calls_per_s': 1.0 / dt, 'eps': float(obj._eps), 'ess': float(obj._ess),
+            'value': float(v), 'grad_norm': float(np.linalg.norm(g))}
+    # executed work of one refresh + gradient: sample GEMM, residual GEMM (x2: refresh and gradient), Gram (lower)
+    flops = 3 * 2.0 * N * D * D + float(N) * D * (D + 1)
+    out['flops_executed_per_call'] = flops
+    out['note'] = ('the call is bound by launch latency and the host side of the O(D^3) factor algebra, not by the '
+                   '%.1f GFLOP of MFMA work (%.0f us at the dense GEMM rate)' % (flops / 1e9, flops / 57e12 * 1e6))
+    return out
+
+
+def c4_leg(eng, vb, steps=20):
+    """BASELINE configs[4]: MFGaussian + ExclusiveKL on Bayesian logistic regression, D=2000, n_data=8192,
+    N_mc=8192 (one GPU), fresh Philox noise per evaluation: blocking objective calls, and RMSProp iterations of the
+    device-resident loop that FASO / RAABBVI run between convergence checks.  MFMA-bound: eta = Z X' and
+    G = R X are two dense n_mc x n_data x D products."""
+    from viabel_amd.optimization import RMSProp
+    D, n_data, N = 2000, 8192, 8192
+    rng = np.random.RandomState(4)
+    X = rng.randn(n_data, D) / np.sqrt(D)
+    beta = rng.randn(D)
+    y = (rng.rand(n_data) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    model = vb.LogisticRegressionModel(X, y, 10.0)
+    eng.set_model(model.device_spec())
+    obj = vb.ExclusiveKL(vb.MFGaussian(D, rng='philox'), model, N)
+    theta = np.concatenate([np.zeros(D), -2 * np.ones(D)])
+    for _ in range(3):
+        v, g = obj(theta)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        v, g = obj(theta)
+    dt = (time.perf_counter() - t0) / steps
+    import contextlib
+    import io
+    with contextlib.redirect_stderr(io.StringIO()):
+        opt = RMSProp(0.02)
+        opt.optimize(5, obj, theta, on_device=True)
+        t0 = time.perf_counter()
+        opt.optimize(steps, obj, theta, on_device=True)
+        dt_loop = (time.perf_counter() - t0) / steps
+    flops = 2 * 2.0 * N * n_data * D
+    tf = flops / dt / 1e12
+    return {'workload': 'BASELINE configs[4]: MFGaussian + ExclusiveKL, logistic regression D=2000, n_data=8192, '
+                        'N_mc=8192, rng=philox, one GPU',
+            'ms_per_eval': 1e3 * dt, 'evals_per_s': 1.0 / dt, 'device_loop_ms_per_iteration': 1e3 * dt_loop,
+            'value': float(v), 'grad_norm': float(np.linalg.norm(g)),
+            'roofline': {'bound': 'mfma', 'flops_executed': flops, 'achieved': tf, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TFLOPS,
+                         'note': 'whole blocking call (two dense GEMMs + noise generation + streaming pass)'}}
+
+
 def blas_threads_for_baseline():
     """Threads the CPU baseline's GEMMs run on: the GPU boxes of this pool show 256 cores to a container whose
     cgroup quota is far smaller, and an oversubscribed OpenBLAS pool is slower than a modest one."""
@@ -403,6 +484,8 @@ def main():
             out['c1_meanfield'], theta1 = meanfield_leg(eng, vb, _lib)
             with contextlib.redirect_stderr(io.StringIO()):    # tqdm progress bars of the host loop
                 out['fit_loop'] = fit_leg(vb, theta1)
+            out['c3_mvt_dis'] = c3_leg(vb)
+            out['c4_logistic'] = c4_leg(eng, vb)
     if rank == 0:
         # RCCL prints a version banner through C stdio; push it out first so the JSON is the last line
         import ctypes

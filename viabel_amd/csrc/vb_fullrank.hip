@@ -370,7 +370,13 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
       double dot = 0.0;
       for (int c = threadIdx.x; c < d; c += 256) {
         double cs = 0.0;
-        for (int rb = 0; rb < n_rb; ++rb) cs += colpart[(int64_t)rb * ldz + c];
+        for (int rb0 = 0; rb0 < n_rb; rb0 += 8) {      // eight loads in flight, summed in split order
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = rb0 + u < n_rb ? colpart[(int64_t)(rb0 + u) * ldz + c] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) cs += v[u];
+        }
         dot = fma(theta[c] - tr_mean[c], cs, dot);
       }
       __syncthreads();

@@ -348,20 +348,29 @@ int alpha_mvt_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_tot
 // dis_state: [lower, upper, status] at the start of a round; res: [round][node] = {ess, max logw}.
 constexpr int kLook = 6;
 constexpr int kLookNodes = 1 << kLook;       // heap order, node 1 = the interval's midpoint; index 0 unused
+constexpr int kLookParts = 4;                // workgroups per candidate (the N samples in kLookParts blocks)
+constexpr int kLookTab = kLookNodes * kLookParts * 3;   // [node][part]{sum w, sum w^2, max log w}
 
 struct BisectWalk {
   double lower, upper;
   int status;
 };
-// replay `levels` decisions of a finished round (objectives.py:349-357)
+// replay `levels` decisions of a finished round (objectives.py:349-357); tab = that round's table
 __device__ __forceinline__ BisectWalk bisect_replay(double lower, double upper, int status, int levels,
-                                                    const double* __restrict__ res, double ess_target) {
+                                                    const double* tab, double ess_target) {
   int node = 1;
   for (int l = 0; l < levels; ++l) {
     const double guess = (lower + upper) / 2.0;
-    const double ess = res[2 * node], mx = res[2 * node + 1];
+    double t1 = 0.0, t2 = 0.0, mx = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < kLookParts; ++p) {          // fixed order: the ESS of a candidate is reproducible
+      const double* e = tab + (node * kLookParts + p) * 3;
+      t1 += e[0];
+      t2 += e[1];
+      mx = fmax(mx, e[2]);
+    }
     if (mx == -INFINITY) status = 1;
-    if (ess > ess_target) {
+    if (t1 * t1 / t2 > ess_target) {
       upper = guess;
       node = 2 * node;
     } else {
@@ -372,27 +381,92 @@ __device__ __forceinline__ BisectWalk bisect_replay(double lower, double upper, 
   return BisectWalk{lower, upper, status};
 }
 
-// one workgroup per candidate of the round
-__global__ void __launch_bounds__(256) dis_bisect_round_kernel(const double* __restrict__ lp,
-                                                               const double* __restrict__ b,
-                                                               const double* __restrict__ lprior,
-                                                               const double* __restrict__ scal_in, int64_t n,
-                                                               double ess_target, int prev_levels, int levels,
-                                                               const double* __restrict__ state_in,
-                                                               const double* __restrict__ res_in,
-                                                               double* __restrict__ state_out,
-                                                               double* __restrict__ res_out) {
-  __shared__ double sh1[4], sh2[4], shm[4];
+// stage the previous round's table and interval in LDS with one coalesced fetch (replaying from global memory
+// would be six dependent loads of freshly written lines)
+__device__ __forceinline__ BisectWalk bisect_stage_replay(double* tab, const double* __restrict__ res_in,
+                                                          const double* __restrict__ state_in, int prev_levels,
+                                                          double ess_target) {
+  for (int e = threadIdx.x; e < kLookTab; e += blockDim.x) tab[e] = prev_levels > 0 ? res_in[e] : 0.0;
+  if (threadIdx.x < 3) tab[kLookTab + threadIdx.x] = state_in[threadIdx.x];
+  __syncthreads();
+  return bisect_replay(tab[kLookTab], tab[kLookTab + 1], (int)tab[kLookTab + 2], prev_levels, tab, ess_target);
+}
+
+// sums of one candidate over the samples [i_begin, i_end): four independent elements per trip, so the dependent
+// fp64 chains of `exp` overlap (with the 16 waves of a 1024-thread workgroup: four per SIMD)
+template <bool STORE>
+__device__ __forceinline__ void bisect_sums(const double* __restrict__ lp, const double* __restrict__ b,
+                                            const double* __restrict__ lprior, double sum_ls, double guess,
+                                            int64_t i_begin, int64_t i_end, double* __restrict__ w,
+                                            double* __restrict__ lq_out, double* sh, double* out3) {
+  double s1 = 0.0, s2 = 0.0, mx = -INFINITY;
+  for (int64_t i0 = i_begin + threadIdx.x; i0 < i_end; i0 += 4 * 1024) {
+    double lw[4], lq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * 1024;
+      lq[u] = i < i_end ? b[i] - sum_ls : 0.0;
+      lw[u] = i < i_end ? guess * lprior[i] + (1.0 - guess) * lp[i] - lq[u] : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * 1024;
+      if (i < i_end) {
+        const double wv = exp(lw[u]);
+        mx = fmax(mx, lw[u]);
+        s1 += wv;
+        s2 = fma(wv, wv, s2);
+        if (STORE) {
+          w[i] = wv;
+          lq_out[i] = lq[u];
+        }
+      }
+    }
+  }
+  s1 = rs_wave_sum(s1);
+  s2 = rs_wave_sum(s2);
+  mx = rs_wave_max(mx);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+    sh[wave] = s1;
+    sh[16 + wave] = s2;
+    sh[32 + wave] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t1 = 0.0, t2 = 0.0, tm = -INFINITY;
+    for (int k = 0; k < 16; ++k) {
+      t1 += sh[k];
+      t2 += sh[16 + k];
+      tm = fmax(tm, sh[32 + k]);
+    }
+    out3[0] = t1;
+    out3[1] = t2;
+    out3[2] = tm;
+  }
+}
+
+// grid = candidates x kLookParts; workgroup (c, part) sums block `part` of the samples for heap node c + 1
+__global__ void __launch_bounds__(1024) dis_bisect_round_kernel(const double* __restrict__ lp,
+                                                                const double* __restrict__ b,
+                                                                const double* __restrict__ lprior,
+                                                                const double* __restrict__ scal_in, int64_t n,
+                                                                double ess_target, int prev_levels, int levels,
+                                                                const double* __restrict__ state_in,
+                                                                const double* __restrict__ res_in,
+                                                                double* __restrict__ state_out,
+                                                                double* __restrict__ res_out) {
+  __shared__ double sh[48];
+  __shared__ double tab[kLookTab + 4];
   const double sum_ls = scal_in[0];
-  BisectWalk wk = bisect_replay(state_in[0], state_in[1], (int)state_in[2], prev_levels, res_in, ess_target);
+  const BisectWalk wk = bisect_stage_replay(tab, res_in, state_in, prev_levels, ess_target);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     state_out[0] = wk.lower;
     state_out[1] = wk.upper;
     state_out[2] = (double)wk.status;
   }
-  // this workgroup's candidate: heap node blockIdx.x + 1 of the round's tree
-  const int node = blockIdx.x + 1;
-  if (node >= (1 << levels)) return;
+  const int node = blockIdx.x / kLookParts + 1, part = blockIdx.x % kLookParts;
   int depth = 0;
   while ((node >> (depth + 1)) != 0) ++depth;       // node = 1 b_{depth-1} ... b_0
   double lower = wk.lower, upper = wk.upper;
@@ -402,30 +476,10 @@ __global__ void __launch_bounds__(256) dis_bisect_round_kernel(const double* __r
     else upper = guess;
   }
   const double guess = (lower + upper) / 2.0;
-  double s1 = 0.0, s2 = 0.0, mx = -INFINITY;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const double lq = b[i] - sum_ls;
-    const double lw = guess * lprior[i] + (1.0 - guess) * lp[i] - lq;
-    const double wv = exp(lw);
-    mx = fmax(mx, lw);
-    s1 += wv;
-    s2 = fma(wv, wv, s2);
-  }
-  s1 = rs_wave_sum(s1);
-  s2 = rs_wave_sum(s2);
-  mx = rs_wave_max(mx);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    sh1[wave] = s1;
-    sh2[wave] = s2;
-    shm[wave] = mx;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double t1 = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]), t2 = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
-    res_out[2 * node] = t1 * t1 / t2;
-    res_out[2 * node + 1] = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
-  }
+  const int64_t per = (n + kLookParts - 1) / kLookParts;
+  const int64_t i_begin = part * per, i_end = i_begin + per < n ? i_begin + per : n;
+  bisect_sums<false>(lp, b, lprior, sum_ls, guess, i_begin, i_end, nullptr, nullptr, sh,
+                     res_out + (node * kLookParts + part) * 3);
 }
 
 // last step (:358-366): replay the final round, evaluate the weights at the final midpoint, snap eps to the ends.
@@ -439,44 +493,20 @@ __global__ void __launch_bounds__(1024) dis_bisect_final_kernel(const double* __
                                                                 const double* __restrict__ res_in, double max_eps,
                                                                 double* __restrict__ w, double* __restrict__ lq_out,
                                                                 double* __restrict__ scal_out) {
-  __shared__ double sh1[16], sh2[16], shm[16];
+  __shared__ double sh[48];
+  __shared__ double tab[kLookTab + 4];
+  __shared__ double tot[3];
   const double sum_ls = scal_in[0];
-  const BisectWalk wk = bisect_replay(state_in[0], state_in[1], (int)state_in[2], prev_levels, res_in, ess_target);
+  const BisectWalk wk = bisect_stage_replay(tab, res_in, state_in, prev_levels, ess_target);
   const double guess = (wk.lower + wk.upper) / 2.0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double s1 = 0.0, s2 = 0.0, mx = -INFINITY;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
-    const double lq = b[i] - sum_ls;
-    const double lw = guess * lprior[i] + (1.0 - guess) * lp[i] - lq;
-    const double wv = exp(lw);
-    mx = fmax(mx, lw);
-    s1 += wv;
-    s2 = fma(wv, wv, s2);
-    w[i] = wv;
-    lq_out[i] = lq;
-  }
-  s1 = rs_wave_sum(s1);
-  s2 = rs_wave_sum(s2);
-  mx = rs_wave_max(mx);
-  if (lane == 0) {
-    sh1[wave] = s1;
-    sh2[wave] = s2;
-    shm[wave] = mx;
-  }
-  __syncthreads();
+  bisect_sums<true>(lp, b, lprior, sum_ls, guess, 0, n, w, lq_out, sh, tot);
   if (threadIdx.x == 0) {
-    double t1 = 0.0, t2 = 0.0, tm = -INFINITY;
-    for (int k = 0; k < 16; ++k) {
-      t1 += sh1[k];
-      t2 += sh2[k];
-      tm = fmax(tm, shm[k]);
-    }
     double eps = guess;
     if (wk.lower == 0.0) eps = 0.0;          // :363-366
     if (wk.upper == max_eps) eps = max_eps;
     scal_out[0] = eps;
-    scal_out[1] = t1 * t1 / t2;
-    scal_out[2] = (double)((wk.status != 0 || tm == -INFINITY) ? 1 : 0);
+    scal_out[1] = tot[0] * tot[0] / tot[1];
+    scal_out[2] = (double)((wk.status != 0 || tot[2] == -INFINITY) ? 1 : 0);
   }
 }
 
@@ -485,8 +515,8 @@ int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const dou
                        double* scal_out) {
   if (max_its < 0) return fail(ctx, VB_ERR_INVALID, "max_its must be >= 0");
   const int rounds = (max_its + kLook - 1) / kLook;
-  // [state (rounds + 1) x 4 | res rounds x 2 kLookNodes]
-  const size_t need = ((size_t)(rounds + 1) * 4 + (size_t)rounds * 2 * kLookNodes + 16) * sizeof(double);
+  // [state (rounds + 1) x 4 | res rounds x kLookTab]
+  const size_t need = ((size_t)(rounds + 1) * 4 + (size_t)(rounds + 1) * kLookTab + 16) * sizeof(double);
   VB_TRY(ensure(ctx, ctx->bisect_work, need));
   double* state = (double*)ctx->bisect_work.ptr;
   double* res = state + (size_t)(rounds + 1) * 4;
@@ -497,15 +527,15 @@ int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const dou
   int prev_levels = 0;
   for (int r = 0; r < rounds; ++r) {
     const int levels = max_its - r * kLook < kLook ? max_its - r * kLook : kLook;
-    hipLaunchKernelGGL(dis_bisect_round_kernel, dim3((unsigned)((1 << levels) - 1)), dim3(256), 0, st, lp, b, lprior,
-                       scal_in, n, ess_target, prev_levels, levels, (const double*)(state + 4 * r),
-                       (const double*)(res + (size_t)(r > 0 ? r - 1 : 0) * 2 * kLookNodes), state + 4 * (r + 1),
-                       res + (size_t)r * 2 * kLookNodes);
+    hipLaunchKernelGGL(dis_bisect_round_kernel, dim3((unsigned)(((1 << levels) - 1) * kLookParts)), dim3(1024), 0, st,
+                       lp, b, lprior, scal_in, n, ess_target, prev_levels, levels, (const double*)(state + 4 * r),
+                       (const double*)(res + (size_t)(r > 0 ? r - 1 : 0) * kLookTab), state + 4 * (r + 1),
+                       res + (size_t)r * kLookTab);
     prev_levels = levels;
   }
   hipLaunchKernelGGL(dis_bisect_final_kernel, dim3(1), dim3(1024), 0, st, lp, b, lprior, scal_in, n, ess_target,
                      prev_levels, (const double*)(state + 4 * rounds),
-                     (const double*)(res + (size_t)(rounds > 0 ? rounds - 1 : 0) * 2 * kLookNodes), 1.0, w, lq_out,
+                     (const double*)(res + (size_t)(rounds > 0 ? rounds - 1 : 0) * kLookTab), 1.0, w, lq_out,
                      scal_out);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
