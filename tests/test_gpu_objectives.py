@@ -373,3 +373,100 @@ def test_dis_multivariate_t_philox_mode_against_oracle(vb, use_resampling):
     # the per-sample logs stay on the device in this mode and are fetched on first access
     assert G.rel_err(obj._state_log_q, ref._state_log_q) < 1e-11
     assert G.rel_err(obj._state_log_p_unnormalized, ref._state_log_p) < 1e-11
+
+
+@pytest.mark.parametrize('family', ['mf_gaussian', 'mf_student_t', 'fullrank'])
+def test_exclusive_kl_hessian_vector_product(vb, family):
+    """ExclusiveKL._hessian_vector_product (objectives.py:166, :275-277) against torch.autograd's exact
+    Hessian-vector product of the same objective on the same noise (fp64, CPU)."""
+    import torch
+    D, N = 24, 300
+    rng = np.random.RandomState(2)
+    mean, sd = rng.randn(D), np.exp(0.3 * rng.randn(D))
+    model = vb.GaussianModel(mean, sd)
+    if family == 'fullrank':
+        approx = vb.FullRankGaussian(D, seed=5)
+        L = np.tril(0.2 * rng.randn(D, D), -1) + np.diag(np.exp(-0.5 + 0.2 * rng.randn(D)))
+        theta = approx.pack(0.3 * rng.randn(D), L)
+        noise = np.random.RandomState(5).randn(N, D)
+    elif family == 'mf_student_t':
+        approx = vb.MFStudentT(D, 7.0, seed=5)
+        theta = np.concatenate([0.3 * rng.randn(D), -0.5 + 0.2 * rng.randn(D)])
+        noise = np.random.RandomState(5).standard_t(7.0, (N, D))
+    else:
+        approx = vb.MFGaussian(D, seed=5)
+        theta = np.concatenate([0.3 * rng.randn(D), -0.5 + 0.2 * rng.randn(D)])
+        noise = np.random.RandomState(5).randn(N, D)
+    x = rng.randn(theta.size)
+    obj = vb.ExclusiveKL(approx, model, N)
+    hv = obj._hessian_vector_product(theta, x)
+
+    E = torch.from_numpy(noise)
+    tm, tiv = torch.from_numpy(mean), torch.from_numpy(1.0 / sd ** 2)
+    tril = np.tril_indices(D)
+
+    def objective(t):
+        mu = t[:D]
+        if family == 'fullrank':
+            Lf = torch.zeros(D, D, dtype=torch.float64)
+            Lf[tril[0], tril[1]] = t[D:]
+            Lm = torch.tril(Lf, -1) + torch.diag(torch.exp(torch.diagonal(Lf)))
+            z = mu + E @ Lm.T
+            logdet = torch.sum(torch.diagonal(Lf))
+        else:
+            z = mu + torch.exp(t[D:]) * E
+            logdet = torch.sum(t[D:])
+        f = -0.5 * torch.sum((z - tm) ** 2 * tiv, 1)
+        return -(torch.mean(f) + logdet)          # the entropy's theta-independent terms do not matter here
+
+    _, ref = torch.autograd.functional.hvp(objective, torch.from_numpy(theta), torch.from_numpy(x))
+    ref = ref.numpy()
+    assert np.max(np.abs(hv - ref)) < 1e-7 * np.max(np.abs(ref)), np.max(np.abs(hv - ref)) / np.max(np.abs(ref))
+    assert np.array_equal(obj._hessian_vector_product(theta, np.zeros_like(x)), np.zeros_like(x))
+    with pytest.raises(AttributeError):
+        vb.ExclusiveKL(vb.MFGaussian(D), model, N, hessian_approx_method='full')._hessian_vector_product(
+            theta[:2 * D], x[:2 * D])
+    with pytest.raises(NotImplementedError):
+        vb.ExclusiveKL(vb.MFGaussian(D), model, N, use_path_deriv=True)._hessian_vector_product(theta[:2 * D], x[:2 * D])
+
+
+@pytest.mark.parametrize('family', ['mf_gaussian', 'multivariate_t'])
+def test_dis_psis_smoothed_weights(vb, family):
+    """psis_smooth=True (BASELINE configs[3]: 'DISInclusiveKL with PSIS reweighting'): the tempered weights go
+    through the reference's psislw (viabel/_psis.py:113-209, pinned by tests/golden/psis.npz) before clipping and
+    keep their sum; everything downstream uses the smoothed weights."""
+    from oracle import psis as opsis
+    D, N = 40, 4096
+    rng = np.random.RandomState(8)
+    mean, sd = 0.4 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    if family == 'mf_gaussian':
+        approx, ofamily = vb.MFGaussian(D, seed=3), ofam.MFGaussian(D)
+        theta = np.concatenate([0.1 * rng.randn(D), 0.2 + 0.1 * rng.randn(D)])
+    else:
+        approx, ofamily = vb.MultivariateT(D, 9.0, seed=3), ofam.MultivariateT(D, 9.0)
+        A = rng.randn(D, D)
+        theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(A @ A.T / D + np.eye(D))])
+    kw = dict(ess_target=500, use_resampling=False)
+    obj = vb.DISInclusiveKL(approx, model, N, temper_prior=vb.MFGaussian(D), temper_prior_params=prior,
+                            psis_smooth=True, **kw)
+    raw = vb.DISInclusiveKL(type(approx)(*((D,) if family == 'mf_gaussian' else (D, 9.0)), seed=3), model, N,
+                            temper_prior=vb.MFGaussian(D), temper_prior_params=prior, **kw)
+    value, grad = obj(theta)
+    raw(theta)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, 500, ofam.MFGaussian(D), prior, use_resampling=False)
+    ref.refresh(theta, ofamily.draw_noise(np.random.RandomState(3), N))
+    w = ref._state_w_clipped                       # the reference's tempered weights (no clipping happens at thr = 10)
+    smoothed, khat = opsis.psis_smooth(np.log(w))
+    w_s = np.sum(w) * np.exp(smoothed)
+    assert G.rel_err(raw._state_w_clipped, w) < 1e-10
+    assert G.rel_err(obj._state_w_clipped, w_s) < 1e-9
+    assert abs(obj._khat - khat) < 1e-8
+    assert abs(np.sum(obj._state_w_clipped) - np.sum(w)) < 1e-9 * np.sum(w)
+    assert not np.allclose(obj._state_w_clipped, w)          # the tail really was replaced
+    lq = ofamily.log_density(theta, ref._state_samples)
+    ov = -np.inner(w_s, lq) / N
+    og = -ofamily.log_density_grad_weighted(theta, ref._state_samples, w_s) / N
+    assert G.rel_err(value, ov) < 1e-9
+    assert G.rel_err(grad, og) < 1e-8
