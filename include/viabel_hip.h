@@ -323,6 +323,29 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
            double* state, int has_state, double* values, double* history, int64_t hist_len, double* directions,
            double* gradients);
 
+/* ---- LRGaussian (approximations.py:610-731) under DISInclusiveKL / AlphaDivergence (objectives.py:283-463) ----
+ * theta = [mu (d) | log_sigma (d) | B (d x k, row-major)], x = mu + B z + sigma eps with the n x d block of the noise
+ * in `slot_eps` and the n x k block in `slot_z` (1 <= k <= 16).  The caller passes the pieces of theta plus
+ * m_inv = (I + B' diag(sigma^-2) B)^-1 (k x k) and log_q_const = -(d log 2 pi + log det Sigma) / 2 (the O(d k^2)
+ * algebra through the capacitance matrix, approximations.py:559-607, stays on the host); per-sample work and every
+ * contraction over the samples run on the device.  gauss_diag and funnel targets.
+ *
+ * vb_dis_refresh_lowrank: state refresh (objectives.py:393-401) as vb_dis_refresh_mvt; the samples stay on the device.
+ * vb_dis_grad_lowrank: weighted sums of the state samples at a (new) parameter, with rho = (x - mu) / sigma,
+ *   tau = m_inv Bs' rho (Bs = B / sigma):  out = [sum w rho tau' (d x k) | sum w tau tau' (k x k) | sum w rho (d) |
+ *   sum w rho^2 (d) | sum w tau (k) | sum w | sum w log q]   (d k + k k + 2 d + k + 2 doubles).
+ * vb_alpha_sums_lowrank: value (objectives.py:459), sum of the weights s_n and, with t = m_inv (z - Bs' eps),
+ *   out = [sum s g z' (d x k) | sum s eps t' (d x k) | sum s t t' (k x k) | sum s g (d) | sum s g eps (d)]. */
+int vb_dis_refresh_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, int64_t n_total,
+                           const double* mu, const double* log_sigma, const double* b, const double* m_inv,
+                           double log_q_const, const double* prior_theta, double eps_prev, double ess_target,
+                           int max_bisection_its, double* eps, double* ess, double* w, double* log_p, double* log_q);
+int vb_dis_grad_lowrank(vb_ctx* ctx, int64_t n, int64_t d, int64_t k, const double* mu, const double* log_sigma,
+                        const double* b, const double* m_inv, double log_q_const, const double* weights, double* out);
+int vb_alpha_sums_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, int64_t n_total,
+                          double alpha, const double* mu, const double* log_sigma, const double* b, const double* m_inv,
+                          double log_q_const, double* value, double* w_sum, double* out);
+
 /* ---- multi-GPU: Monte-Carlo axis sharded, one RCCL all-reduce of the partial sums --- */
 #define VB_COMM_ID_BYTES 128
 int vb_comm_unique_id(char id[VB_COMM_ID_BYTES]);

@@ -386,6 +386,18 @@ class LRGaussian:
         maha = np.sum(diff * np.linalg.solve(S, diff.T).T, axis=1)
         return -0.5 * (self.dim * np.log(2 * np.pi) + np.linalg.slogdet(S)[1] + maha)
 
+    def log_density_grad_weighted(self, theta, x, w):
+        """sum_n w_n d/dtheta log q(x_n; theta) for fixed samples (what autograd gives DISInclusiveKL,
+        objectives.py:405-416, through approximations.py:685-707).  With a_n = Sigma^-1 (x_n - mu):
+        d/dmu = a, d/dSigma = -1/2 Sigma^-1 + 1/2 a a', Sigma = B B' + diag(sigma^2) so
+        d/dlog_sigma = 2 sigma^2 diag(d/dSigma) and d/dB = 2 (d/dSigma) B."""
+        mu, ls, B = self.split(theta)
+        Sinv = np.linalg.inv(self.cov(theta))
+        a = (np.atleast_2d(x) - mu) @ Sinv
+        w = np.asarray(w, dtype=np.float64)
+        dS = -0.5 * np.sum(w) * Sinv + 0.5 * (a * w[:, None]).T @ a
+        return np.concatenate([(a * w[:, None]).sum(0), 2.0 * np.exp(2 * ls) * np.diag(dS), (2.0 * dS @ B).reshape(-1)])
+
     def kl(self, theta0, theta1):                 # :654-682
         mu0, mu1 = self.split(theta0)[0], self.split(theta1)[0]
         S0, S1 = self.cov(theta0), self.cov(theta1)

@@ -295,6 +295,21 @@ def alpha_divergence(family, model, theta, noise, alpha):
         dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + np.sum(sv)
         grad = alpha * np.concatenate([sg.sum(0), dL[np.tril_indices(D)]]) / N
         return value, grad
+    if isinstance(family, fam.LRGaussian):
+        # x = mu + z B' + sigma eps; total derivative of lw_n = f(x_n(theta)) - log q(x_n(theta); theta).  With
+        # r = x - mu, a = Sigma^-1 r, Q = r' a:  dQ = 2 a' dr - a' dSigma a, dr = dB z + sigma eps dls,
+        # dSigma = dB B' + B dB' + 2 diag(sigma^2 dls), d logdet = tr(Sigma^-1 dSigma)
+        mu, ls, B = family.split(theta)
+        zl, eps = noise
+        sig = np.exp(ls)
+        Sinv = np.linalg.inv(family.cov(theta))
+        a = (z - mu) @ Sinv
+        sw = sv[:, None]
+        dmu = (sw * g).sum(0)
+        dls = (sw * (g * sig * eps + a * sig * eps - a ** 2 * sig ** 2)).sum(0) + np.sum(sv) * sig ** 2 * np.diag(Sinv)
+        dB = (sw * g).T @ zl + (sw * a).T @ (zl - a @ B) + np.sum(sv) * Sinv @ B
+        grad = alpha * np.concatenate([dmu, dls, dB.reshape(-1)]) / N
+        return value, grad
     mu, ls = family.split(theta)
     sig = np.exp(ls)
     # log q(z(theta);theta) = sum_d base_logpdf(noise) - sum(ls): d/dls = -1, d/dmu = 0

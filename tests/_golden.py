@@ -29,6 +29,8 @@ def oracle_family(fx):
         return ofam.MFStudentT(D, float(fx['df']))
     if kind == 'multivariate_t':
         return ofam.MultivariateT(D, float(fx['df']))
+    if kind == 'lr_gaussian':
+        return ofam.LRGaussian(D, int(fx['rank']))
     raise ValueError(kind)
 
 
@@ -45,6 +47,8 @@ def oracle_model(fx):
 def noise_of(fx):
     if 'noise' in fx:
         return fx['noise']
+    if 'noise_eps' in fx:                      # LRGaussian: low-rank block first (approximations.py:639-640)
+        return fx['noise_z'], fx['noise_eps']
     return fx['noise_chi'], fx['noise_z']
 
 

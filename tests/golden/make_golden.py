@@ -78,6 +78,8 @@ def make_family(spec, seed):
         return ref_approx.MFStudentT(D, spec['df'], seed=seed), ofam.MFStudentT(D, spec['df'])
     if kind == 'multivariate_t':
         return ref_approx.MultivariateT(D, spec['df'], seed=seed), ofam.MultivariateT(D, spec['df'])
+    if kind == 'lr_gaussian':
+        return ref_approx.LRGaussian(D, seed=seed, k=spec['k']), ofam.LRGaussian(D, spec['k'])
     raise ValueError(kind)
 
 
@@ -110,6 +112,8 @@ def theta_for(fspec, rng, kind='random'):
     D = fspec['dim']
     if fspec['kind'] in ('mf_gaussian', 'mf_student_t'):
         return np.concatenate([0.3 * rng.randn(D), -0.5 + 0.3 * rng.randn(D)])
+    if fspec['kind'] == 'lr_gaussian':
+        return np.concatenate([0.3 * rng.randn(D), -0.5 + 0.3 * rng.randn(D), 0.4 * rng.randn(D * fspec['k'])])
     A = rng.randn(D, D)
     S = A @ A.T / D + 0.5 * np.eye(D)
     return np.concatenate([0.3 * rng.randn(D), ofam.psd_to_free(S)])
@@ -126,7 +130,7 @@ def save(name, **arrs):
 
 def spec_arrays(fspec, mspec):
     out = {'family_kind': fspec['kind'], 'dim': fspec['dim'], 'df': fspec.get('df', 0.0),
-           'model_kind': mspec['kind']}
+           'rank': fspec.get('k', 0), 'model_kind': mspec['kind']}
     if mspec['kind'] == 'gauss_diag':
         out['model_mean'] = np.asarray(mspec['mean'], dtype=float)
         out['model_stdev'] = np.asarray(mspec['stdev'], dtype=float)
@@ -600,12 +604,94 @@ def gen_exclusive_kl_mvt():
     print('ExclusiveKL MultivariateT: worst analytic-vs-FD(reference) grad rel err %.2e' % worst)
 
 
+def gen_lowrank_alpha_dis():
+    """LRGaussian under AlphaDivergence and DISInclusiveKL: the reference's objectives are family-generic
+    (objectives.py:391-416, :443-463 over approximations.py:636-644, :685-707)."""
+    rng = np.random.RandomState(61)
+    worst_a = worst_d = 0.0
+    for fspec in ({'kind': 'lr_gaussian', 'dim': 4, 'k': 2}, {'kind': 'lr_gaussian', 'dim': 5, 'k': 1},
+                  {'kind': 'lr_gaussian', 'dim': 7, 'k': 3}):
+        D = fspec['dim']
+        for mspec in model_specs(D, rng):
+            for alpha in (2.0, 0.5):
+                N, np_seed = 32, 851
+                ref, orc = make_family(fspec, 1)
+                log_p, omodel = make_model(mspec)
+                theta = theta_for(fspec, rng)
+                objective = ref_obj.AlphaDivergence(ref, log_p, N, alpha)
+                np.random.seed(np_seed)
+                value, grad_fd = objective(theta)
+                np.random.seed(np_seed)
+                seed = np.random.randint(2 ** 32)                      # objectives.py:455
+                noise = orc.draw_noise(np.random.RandomState(seed), N)
+                ov, og = oobj.alpha_divergence(orc, omodel, theta, noise, alpha)
+                assert rel_err(ov, value) < 1e-12, (ov, value)
+                e = rel_err(og, grad_fd)
+                worst_a = max(worst_a, e)
+                assert e < 2e-7, (fspec, mspec['kind'], alpha, e)
+                save('alpha_lr_gaussian_d%d_k%d_%s_a%g' % (D, fspec['k'], mspec['kind'], alpha),
+                     **spec_arrays(fspec, mspec), np_seed=np_seed, seed=seed, n=N, theta=theta, alpha=alpha,
+                     value=value, grad_fd=grad_fd, grad=og, noise_z=noise[0], noise_eps=noise[1],
+                     provenance='value: reference; grad_fd: FD of the reference log-weights closure contracted as in '
+                                'objectives.py:460; grad: analytic (oracle)')
+        mspec = model_specs(D, rng)[0]
+        for use_resampling in (True, False):
+            N, ess_target, np_seed = 64, 20, 851
+            ref, orc = make_family(fspec, 1)
+            log_p, omodel = make_model(mspec)
+            theta = theta_for(fspec, rng)
+            prior_params = np.concatenate([[0] * D, [1] * D]).astype(float)   # test_objectives.py:85
+            objective = ref_obj.DISInclusiveKL(
+                ref, log_p, N, ess_target=ess_target, temper_prior=ref_approx.MFGaussian(D),
+                temper_prior_params=prior_params, use_resampling=use_resampling)
+            chosen = []
+            real_choice = np.random.choice
+
+            def rec_choice(*a, **k):
+                idx = real_choice(*a, **k)
+                chosen.append(np.array(idx))
+                return idx
+            np.random.choice = rec_choice
+            try:
+                np.random.seed(np_seed)
+                _ref_stubs.STATE['before_eval'] = snapshot_hook(ref, objective, np_seed)
+                value, grad_fd = objective(theta)
+            finally:
+                np.random.choice = real_choice
+                _ref_stubs.STATE['before_eval'] = None
+            noise = orc.draw_noise(np.random.RandomState(1), N)
+            od = oobj.DISInclusiveKL(orc, omodel, N, ess_target, ofam.MFGaussian(D), prior_params,
+                                     use_resampling=use_resampling)
+            indices = chosen[0] if use_resampling else None
+            ov, og = od(theta, noise=noise, indices=indices)
+            assert rel_err(ov, value) < 1e-11, (fspec, use_resampling, ov, value)
+            assert rel_err(od._eps, objective._eps) < 1e-12
+            assert rel_err(od._state_w_clipped, objective._state_w_clipped) < 1e-10
+            e = rel_err(og, grad_fd)
+            worst_d = max(worst_d, e)
+            assert e < 2e-6, (fspec, use_resampling, e)
+            out = dict(spec_arrays(fspec, mspec), np_seed=np_seed, seed=1, n=N,
+                       ess_target=ess_target, use_resampling=use_resampling, theta=theta,
+                       prior_params=prior_params, value=value, grad_fd=grad_fd, grad=og,
+                       eps=objective._eps, w_clipped=objective._state_w_clipped,
+                       log_q=objective._state_log_q, log_p=objective._state_log_p_unnormalized,
+                       samples=objective._state_samples, noise_z=noise[0], noise_eps=noise[1],
+                       provenance='reference DISInclusiveKL code over the reference LRGaussian; grad_fd by FD with '
+                                  'getval replay')
+            if use_resampling:
+                out['indices'] = indices
+            save('dis_lr_gaussian_d%d_k%d_rs%d' % (D, fspec['k'], use_resampling), **out)
+    print('LRGaussian AlphaDivergence / DISInclusiveKL: worst analytic-vs-FD(reference) grad rel err %.2e / %.2e'
+          % (worst_a, worst_d))
+
+
 GENERATORS = {}
 
 if __name__ == '__main__':
     GENERATORS.update(torch=gen_torch_crosscheck, family=gen_family_forward, ekl=gen_exclusive_kl, rge=gen_rge,
                       alpha=gen_alpha, dis=gen_dis, chainstats=gen_chain_stats, optimizers=gen_optimizers,
-                      psis=gen_psis, lowrank=gen_lowrank, ekl_mvt=gen_exclusive_kl_mvt)
+                      psis=gen_psis, lowrank=gen_lowrank, ekl_mvt=gen_exclusive_kl_mvt,
+                      lowrank_alpha_dis=gen_lowrank_alpha_dis)
     picked = sys.argv[1:]          # e.g. `make_golden.py psis optimizers` regenerates only those fixtures
     if not picked:
         for f in os.listdir(HERE):

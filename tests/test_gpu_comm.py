@@ -399,3 +399,31 @@ def test_alpha_multivariate_t_through_comm(engines):
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     np.testing.assert_array_equal(out[1][2], out[0][2])
     np.testing.assert_array_equal(out[1][3], out[0][3])
+
+
+def test_lowrank_alpha_and_dis_through_comm(engines):
+    """LRGaussian under AlphaDivergence / DISInclusiveKL: the all-reduced (alpha) and all-gathered (DIS) code paths
+    with a one-rank communicator reproduce the plain ones."""
+    import viabel_amd as vb
+    plain, comm = engines
+    D, k, N = 96, 5, 640
+    rng = np.random.RandomState(4)
+    spec = vb.GaussianModel(0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))).device_spec()
+    mu, ls, B = 0.1 * rng.randn(D), -0.3 + 0.1 * rng.randn(D), 0.3 * rng.randn(D, k)
+    Bs = B / np.exp(ls)[:, None]
+    M = np.eye(k) + Bs.T @ Bs
+    Minv = np.linalg.inv(M)
+    cq = -0.5 * (D * np.log(2 * np.pi) + 2 * np.sum(ls) + np.linalg.slogdet(M)[1])
+    prior = np.concatenate([np.zeros(D), 0.1 * np.ones(D)])
+    out = []
+    for eng in (plain, comm):
+        eng.set_model(spec)
+        eng.noise_generate(5, N, D, seed=9, stream=0)
+        eng.noise_generate(6, N, k, seed=9, stream=1)
+        a = eng.alpha_sums_lowrank(5, 6, N, D, k, 2.0, mu, ls, B, Minv, cq)
+        r = eng.dis_refresh_lowrank(5, 6, N, D, k, mu, ls, B, Minv, cq, prior, 1.0, N / 4)
+        g = eng.dis_grad_lowrank(N, D, k, mu + 0.01, ls, B, Minv, cq, r[2])
+        out.append((a, r, g))
+    for x, y in zip(out[0], out[1]):
+        for u, v in zip(x, y):
+            np.testing.assert_allclose(np.asarray(v), np.asarray(u), rtol=1e-13, atol=1e-13 * np.max(np.abs(u)))

@@ -31,6 +31,8 @@ def product_family(vb, fx, seed=1):
         return vb.MFStudentT(D, float(fx['df']), seed=seed)
     if kind == 'multivariate_t':
         return vb.MultivariateT(D, float(fx['df']), seed=seed)
+    if kind == 'lr_gaussian':
+        return vb.LRGaussian(D, seed=seed, k=int(fx['rank']))
     raise ValueError(kind)
 
 
@@ -470,3 +472,71 @@ def test_dis_psis_smoothed_weights(vb, family):
     og = -ofamily.log_density_grad_weighted(theta, ref._state_samples, w_s) / N
     assert G.rel_err(value, ov) < 1e-9
     assert G.rel_err(grad, og) < 1e-8
+
+
+@pytest.mark.parametrize('D,k,N', [(64, 4, 1000), (1024, 8, 4096), (130, 16, 777)])
+@pytest.mark.parametrize('rng_kind', ['numpy', 'philox'])
+def test_lowrank_alpha_against_oracle(vb, D, k, N, rng_kind):
+    """LRGaussian + AlphaDivergence (the reference's objective is family-generic, objectives.py:443-463 over
+    approximations.py:636-707) at sizes where the skinny GEMMs tile and split."""
+    from viabel_amd import _lib
+    from viabel_amd.objectives import _NOISE_SLOT, _LR_SLOT
+    rng = np.random.RandomState(D + k)
+    theta = np.concatenate([0.2 * rng.randn(D), -0.7 + 0.2 * rng.randn(D), 0.3 * rng.randn(D * k) / np.sqrt(k)])
+    ofamily = ofam.LRGaussian(D, k)
+    for model, omodel in ((vb.FunnelModel(D, 3), omod.Funnel(D, 3)),
+                          (vb.GaussianModel(0.3 * np.ones(D), 1.5 * np.ones(D)), omod.GaussDiag(0.3 * np.ones(D), 1.5 * np.ones(D)))):
+        for alpha in (2.0, 0.5):
+            approx = vb.LRGaussian(D, seed=2, k=k, rng=rng_kind)
+            obj = vb.AlphaDivergence(approx, model, N, alpha)
+            np.random.seed(77)
+            value, grad = obj(theta)
+            np.random.seed(77)
+            seed = np.random.randint(2 ** 32)
+            if rng_kind == 'numpy':
+                noise = ofamily.draw_noise(np.random.RandomState(seed), N)
+            else:
+                eng = _lib.default_engine()
+                noise = (eng.noise_get_host(_LR_SLOT, N, k), eng.noise_get_host(_NOISE_SLOT, N, D))
+            ov, og = oobj.alpha_divergence(ofamily, omodel, theta, noise, alpha)
+            assert G.rel_err(value, ov) < 1e-11, (value, ov)
+            assert G.rel_err(grad, og) < 1e-9, G.rel_err(grad, og)
+
+
+@pytest.mark.parametrize('D,k,N', [(64, 4, 1024), (256, 8, 4096), (130, 16, 800)])
+@pytest.mark.parametrize('use_resampling', [True, False])
+def test_lowrank_dis_against_oracle_multi_step(vb, D, k, N, use_resampling):
+    """LRGaussian + DISInclusiveKL: refresh on even steps, state samples reused with the NEW theta on odd steps."""
+    rng = np.random.RandomState(3 * D + k)
+    approx, ofamily = vb.LRGaussian(D, seed=5, k=k), ofam.LRGaussian(D, k)
+    mean, sd = 0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    prior = np.concatenate([np.zeros(D), 0.2 * np.ones(D)])
+    kw = dict(use_resampling=use_resampling, num_resampling_batches=2)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 5, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, **kw)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, N // 5, ofam.MFGaussian(D), prior, **kw)
+    theta = np.concatenate([0.1 * rng.randn(D), 0.1 + 0.1 * rng.randn(D), 0.3 * rng.randn(D * k) / np.sqrt(k)])
+    rs = np.random.RandomState(5)
+    np.random.seed(13)
+    for step in range(4):
+        state = np.random.get_state()
+        value, grad = obj(theta)
+        np.random.set_state(state)
+        noise = ofamily.draw_noise(rs, N) if ref.needs_refresh() else None
+        if use_resampling:
+            if ref.needs_refresh():
+                ref.refresh(theta, noise)
+            idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
+            ref._objective_step += 1
+            xs = ref._state_samples[idx]
+            scale = ref._state_w_sum / N
+            ov = np.mean(-ofamily.log_density(theta, xs)) * scale
+            og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+        else:
+            ov, og = ref(theta, noise=noise)
+        assert G.rel_err(obj._eps, ref._eps) < 1e-10
+        assert G.rel_err(obj._state_log_q, ref._state_log_q) < 1e-11
+        assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
+        assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
+        theta = theta - 0.005 * grad / (1 + np.abs(grad))

@@ -113,6 +113,18 @@ SIGNATURES = {
                                           _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_double_p,
                                           _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'vb_dis_refresh_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p,
+                                              _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
+                                              ctypes.c_double, ctypes.c_int, _c_double_p, _c_double_p, _c_double_p,
+                                              _c_double_p, _c_double_p]),
+    'vb_dis_grad_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _c_double_p,
+                                           _c_double_p, _c_double_p, _c_double_p, ctypes.c_double, _c_double_p,
+                                           _c_double_p]),
+    'vb_alpha_sums_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p, _c_double_p,
+                                             _c_double_p, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p,
+                                             _c_double_p]),
     'vb_dis_state_get': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64]),
     'vb_dis_grad_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
                                        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
@@ -418,6 +430,42 @@ class Engine:
         return value.value, grad
 
     # ------------------------------------------------------------------ DISInclusiveKL, multivariate t
+    # ------------------------------------------------------------------ low-rank Gaussian under DIS / alpha
+    def dis_refresh_lowrank(self, slot_eps, slot_z, n, d, k, mu, log_sigma, B, m_inv, log_q_const, prior_theta,
+                            eps_prev, ess_target, max_bisection_its=50, n_total=None):
+        mu, log_sigma, B, m_inv, prior_theta = (_f64(a) for a in (mu, log_sigma, B, m_inv, prior_theta))
+        n_total = n if n_total is None else n_total
+        eps, ess = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        w, lp, lq = (np.empty(n_total, dtype=np.float64) for _ in range(3))
+        self._check(self._lib.vb_dis_refresh_lowrank(
+            self._ctx, slot_eps, slot_z, n, d, k, n_total, _dptr(mu), _dptr(log_sigma), _dptr(B), _dptr(m_inv),
+            float(log_q_const), _dptr(prior_theta), float(eps_prev), float(ess_target), int(max_bisection_its),
+            ctypes.byref(eps), ctypes.byref(ess), _dptr(w), _dptr(lp), _dptr(lq)))
+        return eps.value, ess.value, w, lp, lq
+
+    def dis_grad_lowrank(self, n, d, k, mu, log_sigma, B, m_inv, log_q_const, weights):
+        """``(sum w rho tau' (d, k), sum w tau tau' (k, k), sum w rho, sum w rho^2, sum w tau, sum w, sum w log q)``."""
+        mu, log_sigma, B, m_inv, weights = (_f64(a) for a in (mu, log_sigma, B, m_inv, weights))
+        out = np.empty(d * k + k * k + 2 * d + k + 2, dtype=np.float64)
+        self._check(self._lib.vb_dis_grad_lowrank(self._ctx, n, d, k, _dptr(mu), _dptr(log_sigma), _dptr(B),
+                                                  _dptr(m_inv), float(log_q_const), _dptr(weights), _dptr(out)))
+        a, b = d * k, d * k + k * k
+        return (out[:a].reshape(d, k), out[a:b].reshape(k, k), out[b:b + d], out[b + d:b + 2 * d],
+                out[b + 2 * d:b + 2 * d + k], out[-2], out[-1])
+
+    def alpha_sums_lowrank(self, slot_eps, slot_z, n, d, k, alpha, mu, log_sigma, B, m_inv, log_q_const, n_total=None):
+        """``(value, sum s, sum s g z' (d, k), sum s eps t' (d, k), sum s t t' (k, k), sum s g, sum s g eps)``."""
+        mu, log_sigma, B, m_inv = (_f64(a) for a in (mu, log_sigma, B, m_inv))
+        out = np.empty(2 * d * k + k * k + 2 * d, dtype=np.float64)
+        value, w_sum = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._check(self._lib.vb_alpha_sums_lowrank(
+            self._ctx, slot_eps, slot_z, n, d, k, n if n_total is None else n_total, float(alpha), _dptr(mu),
+            _dptr(log_sigma), _dptr(B), _dptr(m_inv), float(log_q_const), ctypes.byref(value), ctypes.byref(w_sum),
+            _dptr(out)))
+        a, b, c = d * k, 2 * d * k, 2 * d * k + k * k
+        return (value.value, w_sum.value, out[:a].reshape(d, k), out[a:b].reshape(d, k), out[b:c].reshape(k, k),
+                out[c:c + d], out[c + d:])
+
     def dis_state_get(self, dense, n_total):
         """(log p, log q) of the state samples of the last DIS refresh."""
         lp, lq = np.empty(n_total, dtype=np.float64), np.empty(n_total, dtype=np.float64)

@@ -135,6 +135,8 @@ struct vb_ctx {
   vb::DeviceBuffer bisect_work;         // DIS tempering bisection: interval / ESS tables of the look-ahead rounds
   vb::DeviceBuffer mvt_elbo;            // multivariate-t ExclusiveKL: root, mean, row scales
   vb::DeviceBuffer lr_work;             // low-rank Gaussian family: workspace of the streaming pipeline
+  vb::DeviceBuffer lr_obj;              // low-rank Gaussian under DIS / alpha: samples, residuals, Woodbury vectors
+  int64_t lr_n = 0, lr_d = 0, lr_k = 0, lr_n_total = 0;   // shape of the low-rank DIS state (0: none)
   vb::DeviceBuffer rows_work;           // Model.__call__ for the dense targets: GEMM output rows
   vb::DeviceBuffer psis_lw;             // PSIS: log importance weights (+ 16 result scalars)
   int64_t psis_n = 0;                   // number of device-resident log weights (0: none)

@@ -1,0 +1,593 @@
+// LRGaussian (viabel/approximations.py:610-731) under DISInclusiveKL and AlphaDivergence
+// (viabel/objectives.py:283-416, :419-463): the reference's objectives are family-generic and differentiate
+// `approx.log_density` / `approx.sample` with autograd.  Here the per-sample work runs on the device and the
+// O(D k^2) algebra through the k x k capacitance matrix stays with the caller (as for the family's ExclusiveKL).
+//
+// Sigma = B B' + diag(sigma^2), Bs = B / sigma (rows scaled), M = I + Bs' Bs.  For a sample x and rho = (x - mu) / sigma:
+//     v = Bs' rho,   tau = M^-1 v,   Q = (x - mu)' Sigma^-1 (x - mu) = |rho|^2 - v' tau          (Woodbury, :692-700)
+//     a = Sigma^-1 (x - mu) = (rho - Bs tau) / sigma,            B' a = tau
+// DIS (samples fixed):   d log q / d mu = a,  d/d log_sigma = -sigma^2 diag(Sigma^-1) + sigma^2 a^2,
+//                        d/dB = -Sigma^-1 B + a tau'
+//     -> weighted sums of rho, rho^2, rho tau', tau tau', tau, log q  (two skinny GEMMs against T = [tau | 1 | log q]).
+// Alpha (x = mu + B z + sigma eps moves with theta; rho = Bs z + eps, t = z - tau = M^-1 (z - Bs' eps)):
+//     d lw / d mu = g,  d/d log_sigma = g sigma eps + sigma^2 diag(Sigma^-1) - c^2 - c eps  (c = Bs t),
+//     d/dB = g z' + ((c + eps) / sigma) t' + Sigma^-1 B
+//     -> weighted sums of g, g eps, g z', eps t', t t'.
+// Per row the device does O(D k) work plus the model; every D x k / k x k contraction over the samples is an fp64
+// MFMA GEMM (vb_gemm_f64.h) split over the sample axis and reduced in fixed order.
+#include "vb_common.h"
+#include "vb_gemm_f64.h"
+
+#include <cmath>
+#include <vector>
+
+namespace vb {
+namespace {
+
+constexpr int kLdk = 16;     // row stride of the D x k matrices and of the padded z block (k <= 16)
+constexpr int kLdt = 32;     // row stride of T = [tau or t (16) | 1 | log q | 0 ...]
+constexpr int kColOne = 16, kColLq = 17;
+
+__device__ __forceinline__ double lro_wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+__device__ __forceinline__ double lro_wave_max(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_down(x, off, 64));
+  return x;
+}
+
+// X = mu + Z B' + sigma E (approximations.py:636-644); Zp = [z | 0 ... | 1 at column 16] (row stride kLdt)
+__global__ void __launch_bounds__(256) lro_sample_kernel(const double* __restrict__ E, int64_t lde,
+                                                         const double* __restrict__ Z, int64_t ldz, int64_t n, int d,
+                                                         int k, const double* __restrict__ mu,
+                                                         const double* __restrict__ sigma,
+                                                         const double* __restrict__ B, double* __restrict__ X,
+                                                         int64_t ldx, double* __restrict__ Zp) {
+  const int64_t row = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const double* z = Z + row * ldz;
+  if (c < ldx) {
+    double x = 0.0;
+    if (c < d) {
+      x = fma(sigma[c], E[row * lde + c], mu[c]);
+      for (int j = 0; j < k; ++j) x = fma(B[(int64_t)c * kLdk + j], z[j], x);
+    }
+    X[row * ldx + c] = x;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < kLdt)
+    Zp[row * kLdt + threadIdx.x] = threadIdx.x < k ? z[threadIdx.x] : (threadIdx.x == kColOne ? 1.0 : 0.0);
+}
+
+// R = (X - mu) / sigma, rr[n] = |rho_n|^2; one wave per row
+__global__ void __launch_bounds__(256) lro_resid_kernel(const double* __restrict__ X, int64_t ld, int64_t n, int d,
+                                                        const double* __restrict__ mu,
+                                                        const double* __restrict__ isig, double* __restrict__ R,
+                                                        double* __restrict__ rr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  double s = 0.0;
+  for (int c = lane; c < (int)ld; c += 64) {
+    double r = 0.0;
+    if (c < d) r = (X[row * ld + c] - mu[c]) * isig[c];
+    R[row * ld + c] = r;
+    s = fma(r, r, s);
+  }
+  s = lro_wave_sum(s);
+  if (lane == 0) rr[row] = s;
+}
+
+// per row: tau = Minv v, Q = |rho|^2 - v' tau, log q = cq - Q / 2; T = [tau (or z - tau) | 1 | log q]
+__global__ void __launch_bounds__(256) lro_tau_kernel(const double* __restrict__ V, const double* __restrict__ rr,
+                                                      const double* __restrict__ Minv, int k, double cq, int64_t n,
+                                                      const double* __restrict__ Zp, int t_mode,
+                                                      double* __restrict__ T, double* __restrict__ logq) {
+  __shared__ double mi[kLdk * kLdk];
+  if (threadIdx.x < kLdk * kLdk) mi[threadIdx.x] = Minv[threadIdx.x];
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  double v[kLdk], tau[kLdk];
+#pragma unroll
+  for (int j = 0; j < kLdk; ++j) v[j] = j < k ? V[row * kLdk + j] : 0.0;
+  double vt = 0.0;
+#pragma unroll
+  for (int i = 0; i < kLdk; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < kLdk; ++j) s = fma(mi[i * kLdk + j], v[j], s);
+    tau[i] = i < k ? s : 0.0;
+    vt = fma(v[i], tau[i], vt);
+  }
+  const double lq = cq - 0.5 * (rr[row] - vt);
+  logq[row] = lq;
+  double* t = T + row * kLdt;
+#pragma unroll
+  for (int j = 0; j < kLdk; ++j) t[j] = t_mode ? (j < k ? Zp[row * kLdt + j] - tau[j] : 0.0) : tau[j];
+#pragma unroll
+  for (int j = kLdk; j < kLdt; ++j) t[j] = j == kColOne ? 1.0 : (j == kColLq ? lq : 0.0);
+}
+
+// Tw = w (.) T rows
+__global__ void __launch_bounds__(256) lro_scale_rows_kernel(const double* __restrict__ T, const double* __restrict__ w,
+                                                             int64_t n, double* __restrict__ Tw) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * kLdt) return;
+  Tw[i] = T[i] * w[i / kLdt];
+}
+
+// per 128-row block and column: sum_n w_n A_nc B_nc  -> part[rb][c]
+__global__ void __launch_bounds__(256) lro_colsum_prod_kernel(const double* __restrict__ A, int64_t lda,
+                                                              const double* __restrict__ B, int64_t ldb, int64_t ld,
+                                                              const double* __restrict__ w, int64_t n, int d,
+                                                              double* __restrict__ part) {
+  __shared__ double sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * 128, r1 = r0 + 128 < n ? r0 + 128 : n;
+  double s = 0.0;
+  if (c < d)
+    for (int64_t r = r0 + q; r < r1; r += 4) s = fma(w[r] * A[r * lda + c], B[r * ldb + c], s);
+  sh[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && c < d) part[(int64_t)blockIdx.y * ld + c] = (sh[0][c & 63] + sh[1][c & 63]) + (sh[2][c & 63] + sh[3][c & 63]);
+}
+
+__global__ void __launch_bounds__(256) lro_slab_sum_kernel(const double* __restrict__ W, int slabs, int64_t slab,
+                                                           double* __restrict__ out, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  double s = 0.0;
+  for (int k = 0; k < slabs; ++k) s += W[k * slab + i];   // fixed order
+  out[i] = s;
+}
+
+// model gradient rows G = grad f(X) for the targets without cross-sample structure (one wave per row)
+__global__ void __launch_bounds__(256) lro_model_grad_kernel(const double* __restrict__ X, int64_t ld, int64_t n, int d,
+                                                             ModelDev m, double* __restrict__ G) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double* x = X + row * ld;
+  double* g = G + row * ld;
+  if (m.id == VB_MODEL_GAUSS_DIAG) {
+    for (int c = lane; c < (int)ld; c += 64) g[c] = c < d ? -(x[c] - m.p0[c]) * m.p1[c] : 0.0;
+    return;
+  }
+  const double v = x[m.k], w = exp(-2.0 * v);       // funnel (see fr_funnel_kernel)
+  double ss = 0.0;
+  for (int c = lane; c < (int)ld; c += 64) {
+    double gc = 0.0;
+    if (c < d && c != m.k) {
+      gc = -x[c] * w;
+      ss = fma(x[c], x[c], ss);
+    }
+    if (c != m.k) g[c] = gc;
+  }
+  ss = lro_wave_sum(ss);
+  if (lane == 0) g[m.k] = fma(-v, 1.0 / (m.tau * m.tau), -(double)(d - 1)) + w * ss;
+}
+
+// AlphaDivergence weights (objectives.py:457-459): m = max lw, s = exp(alpha (lw - m)), S = sum s
+__global__ void __launch_bounds__(1024) lro_lw_max_kernel(const double* __restrict__ f, const double* __restrict__ lq,
+                                                          int64_t n, double* __restrict__ out) {
+  __shared__ double sh[16];
+  double mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) mx = fmax(mx, f[i] - lq[i]);
+  mx = lro_wave_max(mx);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) mx = fmax(mx, sh[w]);
+    out[0] = fmax(mx, sh[0]);
+  }
+}
+__global__ void __launch_bounds__(1024) lro_weights_kernel(const double* __restrict__ f, const double* __restrict__ lq,
+                                                           const double* __restrict__ mx_in, int64_t n, double alpha,
+                                                           double* __restrict__ w, double* __restrict__ sum_out) {
+  __shared__ double sh[16];
+  const double mx = mx_in[0];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double sv = exp(alpha * (f[i] - lq[i] - mx));
+    w[i] = sv;
+    s += sv;
+  }
+  s = lro_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < 16; ++k) tot += sh[k];
+    sum_out[0] = tot;
+  }
+}
+
+struct EpiStoreV {           // V = acc
+  double* V;
+  int64_t ld;
+  __device__ void operator()(int, int row, int col, double acc) const { V[(int64_t)row * ld + col] = acc; }
+};
+struct EpiSlabW {            // slab_split = acc
+  double* W;
+  int64_t ld, slab;
+  __device__ void operator()(int split, int row, int col, double acc) const {
+    W[split * slab + (int64_t)row * ld + col] = acc;
+  }
+};
+
+struct LroLayout {
+  int64_t ld, nn;
+  int splits, n_rb;
+  int64_t o_x, o_r, o_g, o_v, o_t, o_tw, o_zp, o_rr, o_f, o_lq, o_lpr, o_w, o_lqc, o_scal, o_mu, o_isig, o_bs, o_minv,
+      o_sig, o_b, o_prior, o_w1, o_w2, o_et, o_et2, o_tt, o_col, o_cs1, o_cs2, o_pack, total;
+};
+
+// n: local rows, n_total: whole-job rows (gathered per-sample vectors)
+LroLayout lro_layout(int64_t n, int64_t n_total, int64_t d) {
+  LroLayout L;
+  L.ld = round_up(d, 16);
+  L.nn = round_up(n_total, 16);
+  L.n_rb = (int)((n + 127) / 128);
+  int splits = (int)(n / 256);
+  L.splits = splits > 32 ? 32 : (splits < 1 ? 1 : splits);
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t mat = n * L.ld;
+  L.o_x = carve(mat);
+  L.o_r = carve(mat);
+  L.o_g = carve(mat);
+  L.o_v = carve(n * kLdk);
+  L.o_t = carve(n * kLdt);
+  L.o_tw = carve(n * kLdt);
+  L.o_zp = carve(n * kLdt);
+  L.o_rr = carve(n);
+  L.o_f = carve(L.nn);
+  L.o_lq = carve(L.nn);
+  L.o_lpr = carve(L.nn);
+  L.o_w = carve(L.nn);
+  L.o_lqc = carve(L.nn);
+  L.o_scal = carve(64);
+  L.o_mu = carve(L.ld);
+  L.o_isig = carve(L.ld);
+  L.o_bs = carve(d * kLdk);
+  L.o_minv = carve(kLdk * kLdk);
+  L.o_sig = carve(L.ld);
+  L.o_b = carve(d * kLdk);
+  L.o_prior = carve(2 * L.ld);
+  L.o_w1 = carve((int64_t)L.splits * d * kLdt);
+  L.o_w2 = carve((int64_t)L.splits * kLdt * kLdt);
+  L.o_et = carve(d * kLdt);
+  L.o_et2 = carve(d * kLdt);
+  L.o_tt = carve(kLdt * kLdt);
+  L.o_col = carve((int64_t)L.n_rb * L.ld);
+  L.o_cs1 = carve(L.ld);
+  L.o_cs2 = carve(L.ld);
+  L.o_pack = carve(2 * d * kLdk + kLdk * kLdk + 4 * d + 64);
+  L.total = off;
+  return L;
+}
+
+// the parameter at which log q is evaluated: mu, 1 / sigma, Bs = B / sigma, M^-1
+struct LroParam {
+  const double *mu, *log_sigma, *B, *minv;
+  double cq;     // -(D log 2 pi + log det Sigma) / 2
+};
+
+int lro_upload_param(vb_ctx* ctx, const LroLayout& L, double* base, int64_t d, int64_t k, const LroParam& p,
+                     bool sampling) {
+  std::vector<double> h((size_t)(3 * L.ld + 2 * d * kLdk + kLdk * kLdk), 0.0);
+  double *mu = h.data(), *isig = mu + L.ld, *sig = isig + L.ld, *bs = sig + L.ld, *b = bs + d * kLdk,
+         *mi = b + d * kLdk;
+  for (int64_t i = 0; i < d; ++i) {
+    const double s = exp(p.log_sigma[i]);
+    mu[i] = p.mu[i];
+    sig[i] = s;
+    isig[i] = 1.0 / s;
+    for (int64_t j = 0; j < k; ++j) {
+      b[i * kLdk + j] = p.B[i * k + j];
+      bs[i * kLdk + j] = p.B[i * k + j] / s;
+    }
+  }
+  for (int64_t i = 0; i < k; ++i)
+    for (int64_t j = 0; j < k; ++j) mi[i * kLdk + j] = p.minv[i * k + j];
+  hipStream_t st = ctx->stream;
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, mu, (size_t)L.ld * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_isig, isig, (size_t)L.ld * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_bs, bs, (size_t)(d * kLdk) * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_minv, mi, (size_t)(kLdk * kLdk) * sizeof(double), hipMemcpyHostToDevice, st));
+  if (sampling) {
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_sig, sig, (size_t)L.ld * sizeof(double), hipMemcpyHostToDevice, st));
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_b, b, (size_t)(d * kLdk) * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  VB_HIP(ctx, hipStreamSynchronize(st));      // `h` is a stack-scoped staging buffer
+  return VB_OK;
+}
+
+// R, V, T (and log q at `lq_out`) of the stored samples X at the uploaded parameter
+int lro_rows(vb_ctx* ctx, const LroLayout& L, double* base, int64_t n, int64_t d, int64_t k, double cq, int t_mode,
+             double* lq_out) {
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(lro_resid_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)(base + L.o_x),
+                     L.ld, n, (int)d, (const double*)(base + L.o_mu), (const double*)(base + L.o_isig), base + L.o_r,
+                     base + L.o_rr);
+  VB_HIP(ctx, hipGetLastError());
+  GemmArgs g;                                   // V = R Bs  (n x k)
+  g.A = base + L.o_r, g.lda = L.ld, g.B = base + L.o_bs, g.ldb = kLdk;
+  g.M = (int)n, g.N = (int)k, g.K = (int)d, g.tri_mode = 0;
+  gemm_f64_launch<true>(st, g, 1, ctx->prop.multiProcessorCount, EpiStoreV{base + L.o_v, kLdk});
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(lro_tau_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)(base + L.o_v),
+                     (const double*)(base + L.o_rr), (const double*)(base + L.o_minv), (int)k, cq, n,
+                     (const double*)(base + L.o_zp), t_mode, base + L.o_t, lq_out);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+// out (d x kLdt) = A' Tw, contraction over the n samples (A: n x ld, Tw: n x kLdt)
+int lro_atb(vb_ctx* ctx, const LroLayout& L, double* base, const double* A, int64_t lda, int m_rows, const double* Tw,
+            int64_t n, double* W, double* out) {
+  hipStream_t st = ctx->stream;
+  GemmArgs g;
+  g.A = A, g.lda = lda, g.B = Tw, g.ldb = kLdt;
+  g.M = m_rows, g.N = kLdt, g.K = (int)n, g.tri_mode = 0;
+  const int64_t slab = (int64_t)m_rows * kLdt;
+  gemm_f64_launch<false>(st, g, L.splits, ctx->prop.multiProcessorCount, EpiSlabW{W, kLdt, slab});
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(lro_slab_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, (const double*)W,
+                     L.splits, slab, out, slab);
+  VB_HIP(ctx, hipGetLastError());
+  (void)base;
+  return VB_OK;
+}
+
+// out[c] = sum_n w_n A_nc B_nc
+int lro_colsum_prod(vb_ctx* ctx, const LroLayout& L, double* base, const double* A, int64_t lda, const double* B,
+                    int64_t ldb, const double* w, int64_t n, int64_t d, double* out) {
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(lro_colsum_prod_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)L.n_rb), dim3(256), 0, st, A, lda,
+                     B, ldb, L.ld, w, n, (int)d, base + L.o_col);
+  hipLaunchKernelGGL(lro_slab_sum_kernel, dim3((unsigned)((L.ld + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + L.o_col), L.n_rb, L.ld, out, d);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+int lro_check(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k) {
+  if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d || k < 1 || k > kLdk)
+    return fail(ctx, VB_ERR_INVALID, "noise slots must hold n x d and n x k (1 <= k <= 16) matrices");
+  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank DIS / alpha objectives implement the gauss_diag and funnel models");
+  if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
+  return VB_OK;
+}
+
+}  // namespace
+
+// ---- DISInclusiveKL state refresh (objectives.py:393-401) --------------------------------------------------
+int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t n_total, int64_t d,
+                   int64_t k, const double* mu, const double* log_sigma, const double* B, const double* minv, double cq,
+                   const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
+                   double* ess_out, double* w_host, double* logp_host, double* logq_host) {
+  VB_TRY(lro_check(ctx, ns, nz, n, d, k));
+  if (n * (int64_t)ctx->n_ranks != n_total)
+    return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
+  const LroLayout L = lro_layout(n, n_total, d);
+  VB_TRY(ensure(ctx, ctx->lr_obj, (size_t)L.total * sizeof(double)));
+  double* base = (double*)ctx->lr_obj.ptr;
+  hipStream_t st = ctx->stream;
+  const int64_t mine = (int64_t)ctx->rank * n;
+  VB_TRY(lro_upload_param(ctx, L, base, d, k, LroParam{mu, log_sigma, B, minv, cq}, true));
+  std::vector<double> pr((size_t)2 * L.ld, 0.0);
+  double c0p = -0.5 * (double)d * 1.8378770664093454835606594728112;
+  for (int64_t i = 0; i < d; ++i) {
+    pr[i] = prior_host[i];
+    pr[L.ld + i] = exp(-2.0 * prior_host[d + i]);
+    c0p -= prior_host[d + i];
+  }
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  hipLaunchKernelGGL(lro_sample_kernel, dim3((unsigned)((L.ld + 255) / 256), (unsigned)n), dim3(256), 0, st,
+                     (const double*)ns.buf.ptr, ns.ld, (const double*)nz.buf.ptr, nz.ld, n, (int)d, (int)k,
+                     (const double*)(base + L.o_mu), (const double*)(base + L.o_sig), (const double*)(base + L.o_b),
+                     base + L.o_x, L.ld, base + L.o_zp);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 0, base + L.o_lq + mine));
+  VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_f + mine));
+  {
+    const ModelDev saved = ctx->model;
+    ModelDev prior;
+    prior.id = VB_MODEL_GAUSS_DIAG;
+    prior.dim = (int)d;
+    prior.c0 = c0p;
+    prior.p0 = base + L.o_prior;
+    prior.p1 = base + L.o_prior + L.ld;
+    ctx->model = prior;
+    const int rc = model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lpr + mine);
+    ctx->model = saved;
+    VB_TRY(rc);
+  }
+  if (ctx->comm) {
+    VB_TRY(comm_allgather(ctx, st, base + L.o_f + mine, base + L.o_f, (size_t)n));
+    VB_TRY(comm_allgather(ctx, st, base + L.o_lq + mine, base + L.o_lq, (size_t)n));
+    VB_TRY(comm_allgather(ctx, st, base + L.o_lpr + mine, base + L.o_lpr, (size_t)n));
+  }
+  VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is
+  VB_TRY(dis_bisect_enqueue(ctx, base + L.o_f, base + L.o_lq, base + L.o_lpr, base + L.o_scal, n_total, eps_prev,
+                            ess_target, max_its, base + L.o_w, base + L.o_lqc, base + L.o_scal + 8));
+  double res[3];
+  VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_scal + 8, sizeof res, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (logp_host)
+    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_f, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (logq_host)
+    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lqc, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  *eps_out = res[0];
+  *ess_out = res[1];
+  ctx->lr_n = n;
+  ctx->lr_d = d;
+  ctx->lr_k = k;
+  ctx->lr_n_total = n_total;
+  if ((int)res[2] == 1)
+    return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
+  return VB_OK;
+}
+
+// weighted sums of the state samples at a (new) parameter: out = [sum w rho tau' (d x k) | sum w tau tau' (k x k) |
+// sum w rho (d) | sum w rho^2 (d) | sum w tau (k) | sum w | sum w log q]
+int lr_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, int64_t k, const double* mu, const double* log_sigma, const double* B,
+                const double* minv, double cq, const double* w_host, double* out_host) {
+  if (ctx->lr_n != n || ctx->lr_d != d || ctx->lr_k != k || !ctx->lr_obj.ptr)
+    return fail(ctx, VB_ERR_STATE, "no low-rank DIS state of shape %lld x %lld (k = %lld)", (long long)n, (long long)d,
+                (long long)k);
+  const LroLayout L = lro_layout(n, ctx->lr_n_total, d);
+  double* base = (double*)ctx->lr_obj.ptr;
+  hipStream_t st = ctx->stream;
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_TRY(lro_upload_param(ctx, L, base, d, k, LroParam{mu, log_sigma, B, minv, cq}, false));   // (syncs: w_host is free)
+  VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 0, base + L.o_lq));
+  hipLaunchKernelGGL(lro_scale_rows_kernel, dim3((unsigned)((n * kLdt + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + L.o_t), (const double*)(base + L.o_w), n, base + L.o_tw);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(lro_atb(ctx, L, base, base + L.o_r, L.ld, (int)d, base + L.o_tw, n, base + L.o_w1, base + L.o_et));
+  VB_TRY(lro_atb(ctx, L, base, base + L.o_t, kLdt, kLdt, base + L.o_tw, n, base + L.o_w2, base + L.o_tt));
+  VB_TRY(lro_colsum_prod(ctx, L, base, base + L.o_r, L.ld, base + L.o_r, L.ld, base + L.o_w, n, d, base + L.o_cs1));
+  // pack
+  const int64_t out_len = d * k + k * k + 2 * d + k + 2;
+  double* pack = base + L.o_pack;
+  VB_HIP(ctx, hipMemcpy2DAsync(pack, (size_t)k * sizeof(double), base + L.o_et, (size_t)kLdt * sizeof(double),
+                               (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(pack + d * k, (size_t)k * sizeof(double), base + L.o_tt, (size_t)kLdt * sizeof(double),
+                               (size_t)k * sizeof(double), (size_t)k, hipMemcpyDeviceToDevice, st));
+  double* tail = pack + d * k + k * k;
+  VB_HIP(ctx, hipMemcpy2DAsync(tail, sizeof(double), base + L.o_et + kColOne, (size_t)kLdt * sizeof(double),
+                               sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));          // sum w rho
+  VB_HIP(ctx, hipMemcpyAsync(tail + d, base + L.o_cs1, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d, base + L.o_tt + (int64_t)kColOne * kLdt, (size_t)k * sizeof(double),
+                             hipMemcpyDeviceToDevice, st));                                       // sum w tau
+  VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d + k, base + L.o_tt + (int64_t)kColOne * kLdt + kColOne, 2 * sizeof(double),
+                             hipMemcpyDeviceToDevice, st));                                       // sum w, sum w log q
+  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));
+  VB_HIP(ctx, hipMemcpyAsync(out_host, pack, (size_t)out_len * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  return VB_OK;
+}
+
+// ---- AlphaDivergence (objectives.py:453-461) ------------------------------------------------------------------
+// out = [sum s g z' (d x k) | sum s eps t' (d x k) | sum s t t' (k x k) | sum s g (d) | sum s g eps (d)]
+int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t n_total, int64_t d,
+                  int64_t k, double alpha, const double* mu, const double* log_sigma, const double* B,
+                  const double* minv, double cq, double* value_out, double* wsum_out, double* out_host) {
+  VB_TRY(lro_check(ctx, ns, nz, n, d, k));
+  if (!(alpha != 0.0)) return fail(ctx, VB_ERR_INVALID, "alpha must be non-zero");
+  const LroLayout L = lro_layout(n, n_total, d);
+  VB_TRY(ensure(ctx, ctx->lr_obj, (size_t)L.total * sizeof(double)));
+  ctx->lr_n = 0;                       // the buffer no longer holds a DIS state
+  double* base = (double*)ctx->lr_obj.ptr;
+  hipStream_t st = ctx->stream;
+  const double* E = (const double*)ns.buf.ptr;
+  VB_TRY(lro_upload_param(ctx, L, base, d, k, LroParam{mu, log_sigma, B, minv, cq}, true));
+  hipLaunchKernelGGL(lro_sample_kernel, dim3((unsigned)((L.ld + 255) / 256), (unsigned)n), dim3(256), 0, st, E, ns.ld,
+                     (const double*)nz.buf.ptr, nz.ld, n, (int)d, (int)k, (const double*)(base + L.o_mu),
+                     (const double*)(base + L.o_sig), (const double*)(base + L.o_b), base + L.o_x, L.ld, base + L.o_zp);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 1, base + L.o_lq));          // T = [t | 1 | log q], t = z - tau
+  VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_f));
+  double* scal = base + L.o_scal;
+  hipLaunchKernelGGL(lro_lw_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_f),
+                     (const double*)(base + L.o_lq), n, scal + 8);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(comm_allreduce_max(ctx, st, scal + 8, 1));
+  hipLaunchKernelGGL(lro_weights_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_f),
+                     (const double*)(base + L.o_lq), (const double*)(scal + 8), n, alpha, base + L.o_w, scal + 9);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(comm_allreduce_sum(ctx, st, scal + 9, 1));
+  hipLaunchKernelGGL(lro_model_grad_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
+                     (const double*)(base + L.o_x), L.ld, n, (int)d, ctx->model, base + L.o_g);
+  VB_HIP(ctx, hipGetLastError());
+  const dim3 sgrid((unsigned)((n * kLdt + 255) / 256));
+  // E' (s T): sum s eps t';  T' (s T): sum s t t'
+  hipLaunchKernelGGL(lro_scale_rows_kernel, sgrid, dim3(256), 0, st, (const double*)(base + L.o_t),
+                     (const double*)(base + L.o_w), n, base + L.o_tw);
+  VB_TRY(lro_atb(ctx, L, base, E, ns.ld, (int)d, base + L.o_tw, n, base + L.o_w1, base + L.o_et));
+  VB_TRY(lro_atb(ctx, L, base, base + L.o_t, kLdt, kLdt, base + L.o_tw, n, base + L.o_w2, base + L.o_tt));
+  // G' (s [z | 1]): sum s g z', sum s g
+  hipLaunchKernelGGL(lro_scale_rows_kernel, sgrid, dim3(256), 0, st, (const double*)(base + L.o_zp),
+                     (const double*)(base + L.o_w), n, base + L.o_tw);
+  VB_TRY(lro_atb(ctx, L, base, base + L.o_g, L.ld, (int)d, base + L.o_tw, n, base + L.o_w1, base + L.o_et2));
+  VB_TRY(lro_colsum_prod(ctx, L, base, base + L.o_g, L.ld, E, ns.ld, base + L.o_w, n, d, base + L.o_cs1));
+  const int64_t out_len = 2 * d * k + k * k + 2 * d;
+  double* pack = base + L.o_pack;
+  VB_HIP(ctx, hipMemcpy2DAsync(pack, (size_t)k * sizeof(double), base + L.o_et2, (size_t)kLdt * sizeof(double),
+                               (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(pack + d * k, (size_t)k * sizeof(double), base + L.o_et, (size_t)kLdt * sizeof(double),
+                               (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(pack + 2 * d * k, (size_t)k * sizeof(double), base + L.o_tt, (size_t)kLdt * sizeof(double),
+                               (size_t)k * sizeof(double), (size_t)k, hipMemcpyDeviceToDevice, st));
+  double* tail = pack + 2 * d * k + k * k;
+  VB_HIP(ctx, hipMemcpy2DAsync(tail, sizeof(double), base + L.o_et2 + kColOne, (size_t)kLdt * sizeof(double),
+                               sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));          // sum s g
+  VB_HIP(ctx, hipMemcpyAsync(tail + d, base + L.o_cs1, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));
+  double sc[2];
+  VB_HIP(ctx, hipMemcpyAsync(sc, scal + 8, sizeof sc, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(out_host, pack, (size_t)out_len * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  *wsum_out = sc[1];
+  *value_out = log(sc[1] / (double)n_total) / alpha + sc[0];                     // objectives.py:459
+  return VB_OK;
+}
+
+}  // namespace vb
+
+using namespace vb;
+
+extern "C" {
+
+static int lr_args_ok(vb_ctx* ctx, int slot_eps, int slot_z) {
+  if (slot_eps < 0 || slot_eps >= VB_MAX_SLOTS || slot_z < 0 || slot_z >= VB_MAX_SLOTS)
+    return fail(ctx, VB_ERR_INVALID, "slot out of range [0, %d)", VB_MAX_SLOTS);
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot_eps].buf.ptr || !ctx->noise[slot_z].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot is empty");
+  return VB_OK;
+}
+
+int vb_dis_refresh_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, int64_t n_total,
+                           const double* mu, const double* log_sigma, const double* b, const double* m_inv,
+                           double log_q_const, const double* prior_theta, double eps_prev, double ess_target,
+                           int max_bisection_its, double* eps, double* ess, double* w, double* log_p, double* log_q) {
+  if (!ctx || !mu || !log_sigma || !b || !m_inv || !prior_theta || !eps || !ess || !w)
+    return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(lr_args_ok(ctx, slot_eps, slot_z));
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return lr_dis_refresh(ctx, ctx->noise[slot_eps], ctx->noise[slot_z], n, n_total, d, k, mu, log_sigma, b, m_inv,
+                        log_q_const, prior_theta, eps_prev, ess_target, max_bisection_its, eps, ess, w, log_p, log_q);
+}
+
+int vb_dis_grad_lowrank(vb_ctx* ctx, int64_t n, int64_t d, int64_t k, const double* mu, const double* log_sigma,
+                        const double* b, const double* m_inv, double log_q_const, const double* weights, double* out) {
+  if (!ctx || !mu || !log_sigma || !b || !m_inv || !weights || !out) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return lr_dis_grad(ctx, n, d, k, mu, log_sigma, b, m_inv, log_q_const, weights, out);
+}
+
+int vb_alpha_sums_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, int64_t n_total,
+                          double alpha, const double* mu, const double* log_sigma, const double* b, const double* m_inv,
+                          double log_q_const, double* value, double* w_sum, double* out) {
+  if (!ctx || !mu || !log_sigma || !b || !m_inv || !value || !w_sum || !out)
+    return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(lr_args_ok(ctx, slot_eps, slot_z));
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return lr_alpha_sums(ctx, ctx->noise[slot_eps], ctx->noise[slot_z], n, n_total, d, k, alpha, mu, log_sigma, b, m_inv,
+                       log_q_const, value, w_sum, out);
+}
+
+}  // extern "C"

@@ -412,6 +412,20 @@ def _lowrank_path_correction(eng, approx, var_param, value, grad, n_local, N):
     return value + entropy + mean_logq, grad + d_entropy - corr
 
 
+def _lowrank_pieces(approx, var_param):
+    """Pieces of the low-rank parameter the device entry points take, and the O(D k^2) quantities of the capacitance
+    matrix M = I + Bs' Bs (Bs = B / sigma; approximations.py:559-607): ``(mu, ls, B, Bs, Minv, log_q_const, BsMinv)``."""
+    mu, ls, B = approx._unpack(var_param)
+    sig = np.exp(ls)
+    Bs = B / sig[:, None]
+    M = np.eye(approx.k) + Bs.T @ Bs
+    Minv = np.linalg.inv(M)
+    Minv = 0.5 * (Minv + Minv.T)
+    logdet = 2.0 * np.sum(ls) + np.linalg.slogdet(M)[1]
+    cq = -0.5 * (approx.dim * np.log(2.0 * np.pi) + logdet)
+    return mu, ls, np.ascontiguousarray(B), Bs, Minv, cq, Bs @ Minv
+
+
 _ROOT_TOL = 1e-12     # ||root root - Sigma|| / ||Sigma|| accepted from the Newton-Schulz iteration
 
 
@@ -502,9 +516,11 @@ class DISInclusiveKL(StochasticVariationalObjective):
     def _update_objective_and_grad(self):
         approx = self.approx
         self._require_device_model()
-        if not isinstance(approx, (MFGaussian, MFStudentT, MultivariateT, FullRankGaussian)):
-            raise NotImplementedError('DISInclusiveKL on the HIP engine supports MFGaussian, MFStudentT, MultivariateT '
-                                      'and FullRankGaussian; got {}'.format(type(approx).__name__))
+        if not isinstance(approx, (MFGaussian, MFStudentT, MultivariateT, FullRankGaussian, LRGaussian)):
+            raise NotImplementedError('DISInclusiveKL on the HIP engine supports MFGaussian, MFStudentT, MultivariateT, '
+                                      'FullRankGaussian and LRGaussian; got {}'.format(type(approx).__name__))
+        if isinstance(approx, LRGaussian) and not 1 <= approx.k <= 16:
+            raise NotImplementedError('LRGaussian on the HIP engine: 1 <= k <= 16')
         if not isinstance(self._temper_prior, MFGaussian) or self._temper_prior.dim != approx.dim:
             raise NotImplementedError('temper_prior must be an MFGaussian of the same dimension '
                                       '(tests/test_objectives.py:82-87)')
@@ -513,6 +529,9 @@ class DISInclusiveKL(StochasticVariationalObjective):
         slot = _DIS_SLOT
         if isinstance(approx, (MultivariateT, FullRankGaussian)):
             self._objective_and_grad = self._mvt_objective(approx, slot)
+            return
+        if isinstance(approx, LRGaussian):
+            self._objective_and_grad = self._lowrank_objective(approx, slot)
             return
 
         def variational_objective(var_param):
@@ -550,6 +569,56 @@ class DISInclusiveKL(StochasticVariationalObjective):
 
         self._objective_and_grad = variational_objective
 
+
+    def _lowrank_objective(self, approx, slot):
+        """DIS for the low-rank Gaussian (``approximations.py:610-731``): sampling, the Woodbury log density
+        (``:685-707``), tempering and the weighted score sums on the device (``vb_dis_*_lowrank``); the O(D k^2)
+        algebra through the k x k capacitance matrix here.  With rho = (x - mu) / sigma, tau = M^-1 Bs' rho and
+        a = Sigma^-1 (x - mu) = (rho - Bs tau) / sigma:  d log q / d mu = a,
+        d/d log_sigma = -sigma^2 diag(Sigma^-1) + sigma^2 a^2,  d/dB = -Sigma^-1 B + a tau'."""
+        D, k = approx.dim, approx.k
+
+        def variational_objective(var_param):
+            var_param = np.asarray(var_param, dtype=np.float64)
+            if var_param.shape != (approx.var_param_dim,):
+                raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+            eng = self._engine()
+            eng.set_model(self.model.device_spec())
+            N = self.num_mc_samples
+            begin, end = shard_rows(N, eng.n_ranks, eng.rank)
+            n_local = end - begin
+            mu, ls, B, Bs, Minv, cq, BsMinv = _lowrank_pieces(approx, var_param)
+            if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
+                if approx.rng == 'philox':
+                    approx._philox_noise(eng, n_local, None, begin, slot, _LR_SLOT)
+                else:
+                    z, eps = approx._base_noise(N)          # low-rank block first (approximations.py:639-640)
+                    eng.noise_set_host(slot, eps[begin:end])
+                    eng.noise_set_host(_LR_SLOT, z[begin:end])
+                self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_lowrank(
+                    slot, _LR_SLOT, n_local, D, k, mu, ls, B, Minv, cq, self._temper_prior_params, self._eps,
+                    self._ess_target, self._max_bisection_its, n_total=N)
+                self._set_state_logs(log_p, log_q)
+                self._state_w_clipped = self._clip_weights(self._smooth_weights(eng, w))
+                self._state_w_sum = np.sum(self._state_w_clipped)
+                self._state_w_normalized = self._state_w_clipped / self._state_w_sum
+            self._objective_step += 1
+            if not self._use_resampling:
+                weights, scale = self._state_w_clipped, 1.0 / N
+            else:
+                indices = np.random.choice(N, size=self._resampling_batch_size, p=self._state_w_normalized)
+                weights = np.bincount(indices, minlength=N).astype(np.float64)
+                scale = self._state_w_sum / N / self._resampling_batch_size
+            Srt, Stt, Sr, Srr, St, W, Wlq = eng.dis_grad_lowrank(n_local, D, k, mu, ls, B, Minv, cq, weights[begin:end])
+            sig = np.exp(ls)
+            d_mu = (Sr - Bs @ St) / sig
+            quad = np.sum((Bs @ Stt) * Bs, axis=1)
+            d_ls = -W * (1.0 - np.sum(BsMinv * Bs, axis=1)) + (Srr - 2.0 * np.sum(Bs * Srt, axis=1) + quad)
+            d_B = (-W * BsMinv + Srt - Bs @ Stt) / sig[:, None]
+            grad_logq = np.concatenate([d_mu, d_ls, d_B.reshape(-1)])
+            return -scale * Wlq, -scale * grad_logq
+
+        return variational_objective
 
     def _mvt_objective(self, approx, slot):
         """DIS for the dense families: O(D^3) factor algebra here (as the reference does with sqrtm / eigh on the
@@ -652,12 +721,18 @@ class AlphaDivergence(StochasticVariationalObjective):
     def _update_objective_and_grad(self):
         approx = self.approx
         self._require_device_model()
-        if not isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian, MultivariateT)):
+        if not isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian, MultivariateT, LRGaussian)):
             raise NotImplementedError('AlphaDivergence on the HIP engine supports MFGaussian, MFStudentT, '
-                                      'MultivariateT and FullRankGaussian; got {}'.format(type(approx).__name__))
+                                      'MultivariateT, FullRankGaussian and LRGaussian; got {}'.format(
+                                          type(approx).__name__))
         alpha = self.alpha
         if isinstance(approx, MultivariateT):
             self._objective_and_grad = self._mvt_alpha(approx, alpha)
+            return
+        if isinstance(approx, LRGaussian):
+            if not 1 <= approx.k <= 16:
+                raise NotImplementedError('LRGaussian on the HIP engine: 1 <= k <= 16')
+            self._objective_and_grad = self._lowrank_alpha(approx, alpha)
             return
 
         def objective_grad_and_log_norm(var_param):
@@ -677,6 +752,40 @@ class AlphaDivergence(StochasticVariationalObjective):
                                             n_total=n_total)
 
         self._objective_and_grad = objective_grad_and_log_norm
+
+    def _lowrank_alpha(self, approx, alpha):
+        """AlphaDivergence over the low-rank Gaussian: weights, value and the weighted sums on the device
+        (``vb_alpha_sums_lowrank``), the capacitance-matrix algebra here.  Total derivative of
+        lw_n = f(x_n(theta)) - log q(x_n(theta); theta) with x = mu + B z + sigma eps, t = M^-1 (z - Bs' eps),
+        c = Bs t:  d/dmu = g,  d/d log_sigma = g sigma eps + sigma^2 diag(Sigma^-1) - c^2 - c eps,
+        d/dB = g z' + ((c + eps) / sigma) t' + Sigma^-1 B."""
+        D, k = approx.dim, approx.k
+
+        def objective_grad_and_log_norm(var_param):
+            var_param = np.asarray(var_param, dtype=np.float64)
+            if var_param.shape != (approx.var_param_dim,):
+                raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
+            seed = np.random.randint(2 ** 32)              # objectives.py:455
+            eng = self._engine()
+            eng.set_model(self.model.device_spec())
+            N = self.num_mc_samples
+            begin, end = shard_rows(N, eng.n_ranks, eng.rank)
+            if approx.rng == 'philox':
+                approx._philox_noise(eng, end - begin, seed, begin, _NOISE_SLOT, _LR_SLOT)
+            else:
+                z, eps = approx._base_noise(N, seed)
+                eng.noise_set_host(_NOISE_SLOT, eps[begin:end])
+                eng.noise_set_host(_LR_SLOT, z[begin:end])
+            mu, ls, B, Bs, Minv, cq, BsMinv = _lowrank_pieces(approx, var_param)
+            value, S, Sgz, Set, Stt, Sg, Sge = eng.alpha_sums_lowrank(_NOISE_SLOT, _LR_SLOT, end - begin, D, k, alpha,
+                                                                      mu, ls, B, Minv, cq, n_total=N)
+            sig = np.exp(ls)
+            g_ls = (sig * Sge - np.sum((Bs @ Stt) * Bs, axis=1) - np.sum(Bs * Set, axis=1)
+                    + S * (1.0 - np.sum(BsMinv * Bs, axis=1)))
+            g_B = Sgz + (Bs @ Stt + Set + S * BsMinv) / sig[:, None]
+            return value, alpha * np.concatenate([Sg, g_ls, g_B.reshape(-1)]) / N          # objectives.py:460
+
+        return objective_grad_and_log_norm
 
     def _mvt_alpha(self, approx, alpha):
         """AlphaDivergence over the multivariate t: weights, value and the weighted sums on the device
