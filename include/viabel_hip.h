@@ -187,6 +187,11 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q);
+/* The DIS state samples live in the context, one set per family kind (0: mean-field, 1: MultivariateT / dense
+ * Gaussian, 2: low-rank Gaussian); every refresh of a kind overwrites its set and bumps its generation counter.  A
+ * caller that keeps weights for a later vb_dis_grad_* call compares the counter with the one it saw after its own
+ * refresh: a mismatch means another objective refreshed in between and the weights no longer belong to the samples. */
+int vb_dis_generation(vb_ctx* ctx, int kind, uint64_t* generation);
 /* log p / log q of the state samples of the last refresh (all n_total of them; either pointer may be NULL), for
  * callers that passed NULL to the refresh.  dense = 0: mean-field state, 1: MultivariateT / dense-Gaussian state. */
 int vb_dis_state_get(vb_ctx* ctx, int dense, double* log_p, double* log_q, int64_t n_total);

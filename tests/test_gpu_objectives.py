@@ -540,3 +540,26 @@ def test_lowrank_dis_against_oracle_multi_step(vb, D, k, N, use_resampling):
         assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
         assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
         theta = theta - 0.005 * grad / (1 + np.abs(grad))
+
+
+def test_interleaved_dis_objectives_are_detected(vb):
+    """Two DISInclusiveKL objectives with num_resampling_batches > 1 on one engine: the state samples live in the
+    engine, so the second objective's refresh invalidates the first one's weights -- that must fail loudly, not
+    compute on the wrong samples; after a fresh refresh the objective works again."""
+    from viabel_amd import _lib
+    D, N = 16, 256
+    model = vb.GaussianModel(np.zeros(D), np.ones(D))
+    prior = np.zeros(2 * D)
+    kw = dict(ess_target=64, temper_prior=vb.MFGaussian(D), temper_prior_params=prior, num_resampling_batches=2)
+    a = vb.DISInclusiveKL(vb.MFGaussian(D, seed=1), model, N, **kw)
+    b = vb.DISInclusiveKL(vb.MFGaussian(D, seed=2), model, N, **kw)
+    theta = np.concatenate([np.zeros(D), 0.1 * np.ones(D)])
+    np.random.seed(0)
+    a(theta)            # a refreshes (step 0)
+    b(theta)            # b refreshes: overwrites the mean-field state
+    with pytest.raises(_lib.EngineError):
+        a(theta)        # a's step 1 would reuse its (gone) samples
+    b(theta)            # b's step 1 is fine: its samples are the resident ones
+    a._objective_step = 0
+    v, g = a(theta)     # a refresh makes a whole again
+    assert np.isfinite(v) and np.all(np.isfinite(g))

@@ -125,6 +125,7 @@ SIGNATURES = {
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p, _c_double_p,
                                              _c_double_p, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p,
                                              _c_double_p]),
+    'vb_dis_generation': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     'vb_dis_state_get': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64]),
     'vb_dis_grad_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
                                        _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
@@ -465,6 +466,12 @@ class Engine:
         a, b, c = d * k, 2 * d * k, 2 * d * k + k * k
         return (value.value, w_sum.value, out[:a].reshape(d, k), out[a:b].reshape(d, k), out[b:c].reshape(k, k),
                 out[c:c + d], out[c + d:])
+
+    def dis_generation(self, kind):
+        """Refresh counter of the DIS state of one family kind (0 mean-field, 1 dense, 2 low-rank)."""
+        g = ctypes.c_uint64(0)
+        self._check(self._lib.vb_dis_generation(self._ctx, int(kind), ctypes.byref(g)))
+        return g.value
 
     def dis_state_get(self, dense, n_total):
         """(log p, log q) of the state samples of the last DIS refresh."""

@@ -226,7 +226,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& log : ctx->prof)
@@ -466,10 +466,10 @@ static int mf_call(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t 
     for (int b = 0; b < c.count; ++b) {
       const int slot = slots[b0 + b];
       VB_TRY(check_slot(ctx, slot));
-      if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+      if (!gen && !ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
       ResultSlot& r = *rs[b0 + b];
       VB_TRY(stage_theta(ctx, r, thetas + (size_t)(b0 + b) * 2 * d, 2 * d));
-      c.noise[b] = &ctx->noise[slot];
+      c.noise[b] = gen ? &ctx->gen_geom : &ctx->noise[slot];
       c.theta_src[b] = r.dev;
       c.out[b] = r.dev + r.p;
     }
@@ -514,7 +514,19 @@ int vb_elbo_grad_meanfield_philox(vb_ctx* ctx, int slot, int64_t n, int64_t d, i
   if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
-  VB_TRY(noise_alloc(ctx, slot, n, d));      // geometry only: the noise itself stays in registers
+  if (n <= 0 || d <= 0) return fail(ctx, VB_ERR_INVALID, "noise shape must be positive");
+  // the noise stays in registers: the kernels only need the GEOMETRY of the matrix that vb_noise_generate would
+  // have written (row stride as noise_alloc pads it).  No slot is allocated or claimed (this used to
+  // allocate an n x ld buffer that was never read and left the slot describing stale data).
+  {
+    NoiseSlot& gslot = ctx->gen_geom;
+    int64_t ld = round_up(d, 16);
+    if (ld % 512 == 0) ld += 16;
+    VB_TRY(ensure(ctx, gslot.buf, 256));     // a valid address; never dereferenced in GEN mode
+    gslot.n = n;
+    gslot.d = d;
+    gslot.ld = ld;
+  }
   ResultSlot* rs = &ctx->sync_result;
   const GenNoise gen{seed, stream, row_offset};
   VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs, false, false, false, &gen));
@@ -727,6 +739,13 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
   VB_HIP(ctx, hipSetDevice(ctx->device));
   return mvt_dis_refresh(ctx, ctx->noise[slot], n, n_total, d, df, theta, chi, sqrt_sigma, l_inv, prior_theta, eps_prev,
                          ess_target, max_bisection_its, eps, ess, w, log_p, log_q);
+}
+
+int vb_dis_generation(vb_ctx* ctx, int kind, uint64_t* generation) {
+  if (!ctx || !generation) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (kind < 0 || kind > 2) return fail(ctx, VB_ERR_INVALID, "DIS state kind %d outside [0, 2]", kind);
+  *generation = ctx->dis_gen[kind];
+  return VB_OK;
 }
 
 int vb_dis_state_get(vb_ctx* ctx, int dense, double* log_p, double* log_q, int64_t n_total) {

@@ -107,6 +107,7 @@ struct vb_ctx {
   std::string last_error;
 
   vb::NoiseSlot noise[VB_MAX_SLOTS];
+  vb::NoiseSlot gen_geom;               // geometry of the matrix an in-register (GEN) evaluation stands for
   vb::ResultSlot results[VB_MAX_SLOTS];
   vb::ResultSlot sync_result;           // used by the synchronous entry points
 
@@ -137,6 +138,7 @@ struct vb_ctx {
   vb::DeviceBuffer lr_work;             // low-rank Gaussian family: workspace of the streaming pipeline
   vb::DeviceBuffer lr_obj;              // low-rank Gaussian under DIS / alpha: samples, residuals, Woodbury vectors
   int64_t lr_n = 0, lr_d = 0, lr_k = 0, lr_n_total = 0;   // shape of the low-rank DIS state (0: none)
+  uint64_t dis_gen[3] = {0, 0, 0};      // refresh counters of the DIS states: mean-field, dense (t / Gaussian), low-rank
   vb::DeviceBuffer rows_work;           // Model.__call__ for the dense targets: GEMM output rows
   vb::DeviceBuffer psis_lw;             // PSIS: log importance weights (+ 16 result scalars)
   int64_t psis_n = 0;                   // number of device-resident log weights (0: none)

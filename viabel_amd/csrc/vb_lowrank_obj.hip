@@ -435,6 +435,7 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
   ctx->lr_d = d;
   ctx->lr_k = k;
   ctx->lr_n_total = n_total;
+  ++ctx->dis_gen[2];
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   return VB_OK;
@@ -490,6 +491,7 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
   const LroLayout L = lro_layout(n, n_total, d);
   VB_TRY(ensure(ctx, ctx->lr_obj, (size_t)L.total * sizeof(double)));
   ctx->lr_n = 0;                       // the buffer no longer holds a DIS state
+  ++ctx->dis_gen[2];
   double* base = (double*)ctx->lr_obj.ptr;
   hipStream_t st = ctx->stream;
   const double* E = (const double*)ns.buf.ptr;

@@ -326,6 +326,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   ctx->mvt_n = n;
   ctx->mvt_d = d;
   ctx->mvt_n_total = n_total;
+  ++ctx->dis_gen[1];
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   return VB_OK;

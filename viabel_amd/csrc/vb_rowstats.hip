@@ -626,6 +626,7 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
   ctx->dis_n = n;
   ctx->dis_n_total = n_total;
   ctx->dis_d = d;
+  ++ctx->dis_gen[0];
   if (*status_out == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   return VB_OK;

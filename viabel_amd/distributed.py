@@ -197,6 +197,10 @@ def attach(engine=None, group=None):
         return engine
     uid = broadcast_unique_id(rank, _lib.Engine.comm_unique_id, group)
     engine.comm_init(uid, world, rank)
+    if group is not None:
+        # host-side random draws of the objectives (the alpha-divergence seed, the DIS resampling indices: the global
+        # numpy RNG in the reference) are taken on rank 0 and handed to the other ranks over this group
+        engine.control_group = group
     return engine
 
 
@@ -213,5 +217,4 @@ def init_from_env(backend=None):
         if not dist.is_initialized():
             dist.init_process_group(backend=backend)
         return attach(engine)
-    engine.control_group = SocketGroup.from_env()
-    return attach(engine, engine.control_group)
+    return attach(engine, SocketGroup.from_env())

@@ -41,6 +41,27 @@ def shard_rows(n, n_ranks, rank):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def _shared_randint(eng):
+    """``np.random.randint(2 ** 32)`` from the global numpy RNG (objectives.py:455), the same number on every rank
+    of a sharded job: rank 0's draw travels over the engine's control group when it has one
+    (``viabel_amd.distributed.attach(engine, group)``); without one the ranks must seed numpy identically."""
+    seed = int(np.random.randint(2 ** 32))
+    group = getattr(eng, 'control_group', None)
+    if eng.n_ranks > 1 and group is not None:
+        seed = int.from_bytes(group.broadcast_bytes(seed.to_bytes(8, 'little')), 'little')
+    return seed
+
+
+def _shared_choice(eng, n, size, p):
+    """``np.random.choice(n, size, p=p)`` on the global numpy RNG (objectives.py:408), rank 0's draw on every rank."""
+    indices = np.random.choice(n, size=size, p=p)
+    group = getattr(eng, 'control_group', None)
+    if eng.n_ranks > 1 and group is not None:
+        raw = group.broadcast_bytes(np.ascontiguousarray(indices, dtype=np.int64).tobytes())
+        indices = np.frombuffer(raw, dtype=np.int64)
+    return indices
+
+
 class VariationalObjective(ABC):
     """A variational objective to minimise (``viabel/objectives.py:17-79``)."""
 
@@ -484,6 +505,18 @@ class DISInclusiveKL(StochasticVariationalObjective):
     def _state_log_q(self):
         return self._get_state_logs()[1]
 
+    def _own_state(self, eng, kind, refreshed):
+        """The state samples live in the engine, one set per family kind: after a refresh remember its generation,
+        before a gradient on kept weights make sure nobody else refreshed in between (two interleaved
+        objectives with num_resampling_batches > 1 used to compute on each other's samples silently)."""
+        gen = eng.dis_generation(kind)
+        if refreshed:
+            self._state_gen = (id(eng), gen)
+        elif getattr(self, '_state_gen', None) != (id(eng), gen):
+            raise _lib.EngineError('the DIS state samples of this objective were overwritten by another objective on the '
+                                   'same engine between two refreshes; give each interleaved objective its own engine '
+                                   'or use num_resampling_batches=1')
+
     def _smooth_weights(self, eng, w):
         """``w -> sum(w) * exp(psislw(log w))``: the PSIS-smoothed weights on the scale of the raw ones."""
         if not self._psis_smooth:
@@ -556,12 +589,15 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 self._state_w_clipped = self._clip_weights(self._smooth_weights(eng, w))
                 self._state_w_sum = np.sum(self._state_w_clipped)
                 self._state_w_normalized = self._state_w_clipped / self._state_w_sum
+                self._own_state(eng, 0, True)
+            else:
+                self._own_state(eng, 0, False)
             self._objective_step += 1
             if not self._use_resampling:     # :405-406
                 return eng.dis_grad_meanfield(slot, n_local, approx.dim, var_param,
                                               self._state_w_clipped[begin:end], 1.0 / N, family, df=df)
             # global numpy RNG (:408): ranks of a sharded job must seed it identically
-            indices = np.random.choice(N, size=self._resampling_batch_size, p=self._state_w_normalized)
+            indices = _shared_choice(eng, N, self._resampling_batch_size, self._state_w_normalized)
             counts = np.bincount(indices, minlength=N).astype(np.float64)
             scale = self._state_w_sum / N / self._resampling_batch_size       # :412-414
             return eng.dis_grad_meanfield(slot, n_local, approx.dim, var_param, counts[begin:end], scale,
@@ -602,11 +638,14 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 self._state_w_clipped = self._clip_weights(self._smooth_weights(eng, w))
                 self._state_w_sum = np.sum(self._state_w_clipped)
                 self._state_w_normalized = self._state_w_clipped / self._state_w_sum
+                self._own_state(eng, 2, True)
+            else:
+                self._own_state(eng, 2, False)
             self._objective_step += 1
             if not self._use_resampling:
                 weights, scale = self._state_w_clipped, 1.0 / N
             else:
-                indices = np.random.choice(N, size=self._resampling_batch_size, p=self._state_w_normalized)
+                indices = _shared_choice(eng, N, self._resampling_batch_size, self._state_w_normalized)
                 weights = np.bincount(indices, minlength=N).astype(np.float64)
                 scale = self._state_w_sum / N / self._resampling_batch_size
             Srt, Stt, Sr, Srr, St, W, Wlq = eng.dis_grad_lowrank(n_local, D, k, mu, ls, B, Minv, cq, weights[begin:end])
@@ -684,11 +723,14 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 self._state_w_clipped = self._clip_weights(self._smooth_weights(eng, w))
                 self._state_w_sum = np.sum(self._state_w_clipped)
                 self._state_w_normalized = self._state_w_clipped / self._state_w_sum
+                self._own_state(eng, 1, True)
+            else:
+                self._own_state(eng, 1, False)
             self._objective_step += 1
             if not self._use_resampling:
                 weights, scale = self._state_w_clipped, 1.0 / N
             else:
-                indices = np.random.choice(N, size=self._resampling_batch_size, p=self._state_w_normalized)
+                indices = _shared_choice(eng, N, self._resampling_batch_size, self._state_w_normalized)
                 weights = np.bincount(indices, minlength=N).astype(np.float64)
                 scale = self._state_w_sum / N / self._resampling_batch_size
             w_sum, w_logq, d_mu, gram = eng.dis_grad_mvt(n_local, D, df, var_param, Linv, weights[begin:end])
@@ -741,8 +783,8 @@ class AlphaDivergence(StochasticVariationalObjective):
                 raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
             # the reference draws a shared seed from the GLOBAL numpy RNG (objectives.py:455) and
             # samples from a fresh RandomState(seed) (approximations.py:213)
-            seed = np.random.randint(2 ** 32)
             eng = self._engine()
+            seed = _shared_randint(eng)
             eng.set_model(self.model.device_spec())
             n_local, n_total = self._stage_noise(eng, self.num_mc_samples, seed=seed)
             if isinstance(approx, FullRankGaussian):
@@ -765,8 +807,8 @@ class AlphaDivergence(StochasticVariationalObjective):
             var_param = np.asarray(var_param, dtype=np.float64)
             if var_param.shape != (approx.var_param_dim,):
                 raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
-            seed = np.random.randint(2 ** 32)              # objectives.py:455
             eng = self._engine()
+            seed = _shared_randint(eng)                    # objectives.py:455
             eng.set_model(self.model.device_spec())
             N = self.num_mc_samples
             begin, end = shard_rows(N, eng.n_ranks, eng.rank)
@@ -800,8 +842,8 @@ class AlphaDivergence(StochasticVariationalObjective):
             var_param = np.asarray(var_param, dtype=np.float64)
             if var_param.shape != (approx.var_param_dim,):
                 raise ValueError('var_param must have shape ({},)'.format(approx.var_param_dim))
-            seed = np.random.randint(2 ** 32)              # objectives.py:455
             eng = self._engine()
+            seed = _shared_randint(eng)                    # objectives.py:455
             eng.set_model(self.model.device_spec())
             N = self.num_mc_samples
             begin, end = shard_rows(N, eng.n_ranks, eng.rank)
