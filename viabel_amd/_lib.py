@@ -12,7 +12,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libviabel_hip.so')
+# VIABEL_AMD_LIB: load another build of the same C ABI (the host-sanitizer build libviabel_hip_asan.so, `make asan`)
+LIB_PATH = os.environ.get('VIABEL_AMD_LIB') or os.path.join(_HERE, 'libviabel_hip.so')
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
 VB_OK, VB_ERR_INVALID, VB_ERR_HIP, VB_ERR_UNSUPPORTED, VB_ERR_STATE, VB_ERR_NUMERIC, VB_ERR_COMM = range(7)
