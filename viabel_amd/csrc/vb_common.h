@@ -127,6 +127,8 @@ struct vb_ctx {
   vb::DeviceBuffer glm_work;            // regression targets: split-K slabs of the gradient GEMM
   vb::DeviceBuffer mvt_state;           // multivariate-t DIS: state samples X, scratch
   int64_t mvt_n = 0, mvt_d = 0, mvt_n_total = 0;
+  std::vector<double> mvt_theta;        // parameter the device-side residuals of the DIS state belong to
+  std::vector<double> mvt_stage;        // host staging of the factor uploads (one synchronisation per pass)
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
   int64_t dis_n_total = 0;              // whole-job sample count of the DIS state

@@ -188,19 +188,28 @@ static int upload_padded(vb_ctx* ctx, double* dst, int64_t ld, const double* src
 static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t n, int64_t d, double df,
                          const double* theta_host, const double* linv_host, int64_t lq_off) {
   const int n_cu = ctx->prop.multiProcessorCount;
-  // Wt[k][j] = Linv[j][k] (B operand of dev L^-T), Li[k][j] = Linv[k][j] (B operand of E' L^-1)
-  VB_TRY(upload_padded(ctx, base + L.o_wt, L.ld, linv_host, d, d, true));
-  VB_TRY(upload_padded(ctx, base + L.o_li, L.ld, linv_host, d, d, false));
-  std::vector<double> vec((size_t)2 * L.ld, 0.0);
+  // Wt[k][j] = Linv[j][k] (B operand of dev L^-T), Li[k][j] = Linv[k][j] (B operand of E' L^-1), [mu | c]:
+  // staged in one host buffer, three copies, ONE synchronisation
+  const int64_t sq = d * L.ld;
+  std::vector<double>& st = ctx->mvt_stage;
+  st.assign((size_t)(2 * sq + 2 * L.ld), 0.0);
+  double *wt = st.data(), *li = wt + sq, *vec = li + sq;
   double logdet_half = 0.0;
   for (int64_t j = 0; j < d; ++j) {
-    vec[j] = theta_host[j];
     double c = 0.0;                       // c_j = sum_k mu_k Linv[j][k]
-    for (int64_t k = 0; k <= j; ++k) c += theta_host[k] * linv_host[j * d + k];
+    for (int64_t k = 0; k <= j; ++k) {
+      const double v = linv_host[j * d + k];
+      li[j * L.ld + k] = v;
+      wt[k * L.ld + j] = v;
+      c += theta_host[k] * v;
+    }
+    vec[j] = theta_host[j];
     vec[L.ld + j] = c;
     logdet_half += theta_host[d + j * (j + 1) / 2 + j];
   }
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, vec.data(), vec.size() * sizeof(double), hipMemcpyHostToDevice,
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_wt, wt, (size_t)sq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_li, li, (size_t)sq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, vec, (size_t)(2 * L.ld) * sizeof(double), hipMemcpyHostToDevice,
                              ctx->stream));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   GemmArgs g;
@@ -327,6 +336,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   ctx->mvt_d = d;
   ctx->mvt_n_total = n_total;
   ++ctx->dis_gen[1];
+  ctx->mvt_theta.assign(theta_host, theta_host + d + d * (d + 1) / 2);   // the residuals on the device belong to it
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   return VB_OK;
@@ -358,7 +368,18 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   const int n_cu = ctx->prop.multiProcessorCount;
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
-  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, 0));
+  {
+    // the residuals E' = (X - mu) L^-T, the Mahalanobis distances and log q on the device belong to the parameter of
+    // the last residual pass: a gradient at that same parameter (the call that follows a refresh when
+    // num_resampling_batches = 1) reuses them instead of repeating the N x D x D product and its uploads
+    const size_t p = (size_t)(d + d * (d + 1) / 2);
+    const bool same = ctx->n_ranks == 1 && ctx->mvt_theta.size() == p &&
+                      memcmp(ctx->mvt_theta.data(), theta_host, p * sizeof(double)) == 0;
+    if (!same) {
+      VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, 0));
+      ctx->mvt_theta.assign(theta_host, theta_host + p);
+    }
+  }
   // U = E' L^-1
   GemmArgs g;
   g.A = base + L.o_e;

@@ -670,16 +670,21 @@ class DISInclusiveKL(StochasticVariationalObjective):
 
         _lib.apply_host_blas_policy()      # before the first D x D host product
 
-        from scipy.linalg import lapack
+        from scipy.linalg import blas, lapack
         diag = np.diag_indices(D)
         philox = approx.rng == 'philox'
 
         def factors(var_param):
-            L = approx._unpack(var_param)[1]
-            Linv, info = lapack.dtrtri(L, lower=1)       # LAPACK directly: scipy's solve_triangular wrapper costs
-            if info != 0:                                # more than the D^3 / 3 flops at D = 256
+            # L from the flat parameter without the family's generic unpacking (index arrays cached), its inverse by
+            # LAPACK dtrtri on the transposed (Fortran-ordered) view: no copies, no scipy wrapper overhead -- at
+            # D = 256 the wrappers used to cost more than the D^3 / 3 flops
+            L = np.zeros((D, D))
+            L[tril] = var_param[D:]
+            L[diag] = np.exp(L[diag])
+            Ut, info = lapack.dtrtri(L.T, lower=0, overwrite_c=0)
+            if info != 0:
                 raise ValueError('singular Cholesky factor')
-            return L, Linv
+            return L, Ut.T
 
         def variational_objective(var_param):
             var_param = np.asarray(var_param, dtype=np.float64)
@@ -738,11 +743,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
             # d log q / d Sigma = -1/2 w_sum Sigma^-1 + 1/2 S and Sigma = L L': d/dL = tril(2 (d/dSigma) L)
             #   = tril(S L) - w_sum tril(L^-T): L^-T is upper triangular, so only its diagonal 1 / L_ii survives --
             # one D x D product instead of three
-            S = np.tril(gram)
-            S = S + S.T
-            S[diag] *= 0.5
-            d_L = S @ L                                # only the lower triangle is read below
-            d_L[diag] = d_L[diag] * L[diag] - w_sum
+            d_L = blas.dsymm(1.0, gram, L, side=0, lower=1)      # S L with S = S' given by its lower triangle; only
+            d_L[diag] = d_L[diag] * L[diag] - w_sum              # the lower triangle of the product is read below
             grad_logq = np.concatenate([d_mu, d_L[tril]])
             return -scale * w_logq, -scale * grad_logq
 
