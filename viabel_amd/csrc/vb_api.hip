@@ -226,7 +226,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& log : ctx->prof)

@@ -148,6 +148,9 @@ struct vb_ctx {
   double* pin_dev = nullptr;
   size_t pin_bytes = 0;
   vb::DeviceBuffer fit_work;            // device-resident fit: [theta | out | state | value history | iterates]
+  vb::DeviceBuffer tri_map;             // XCD-aware tile list of the lower-triangular gradient GEMM (int pairs)
+  int tri_map_key[3] = {0, 0, 0};       // (d, tile rows, tile columns) the list was built for
+  int tri_map_blocks = 0;
   vb::DeviceBuffer fr_lt;               // full-rank: unpacked parameter [mu (ldz) | L' (d x ldl)]
   int64_t fr_lt_d = 0;                  // dimension the unpacked copy of fr_theta was made for (0: stale)
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter

@@ -587,6 +587,47 @@ int gram_splits(vb_ctx* ctx, int d, int64_t n) {
   return splits < 1 ? 1 : splits;
 }
 
+// ---- XCD-aware tile order of the lower-triangular product C = G' E ------------------------------------------
+// Block x of a launch runs on XCD x % 8 and every XCD has its own 4-MiB L2.  In row-by-row order the tiles that share
+// an operand panel (same row block: the same 128 columns of G; same column block: the same 64 columns of E) land on
+// eight different XCDs and each XCD streams nearly every panel: 355 MB cross the fabric per launch against 67 MB of
+// operands (PMC FETCH_SIZE, D = 1024).  Here the tiles are walked in bands of two row blocks, column by column, and
+// cut into eight runs of equal length -- compact 2 x ~4.5 patches that touch few panels -- and run c gets the blocks
+// x = c, c + 8, c + 16, ...
+static int tri2_tile_map(vb_ctx* ctx, int d, int bm_rows, int bn_cols, const int** map_out, int* blocks_out) {
+  if (ctx->tri_map.ptr && ctx->tri_map_key[0] == d && ctx->tri_map_key[1] == bm_rows && ctx->tri_map_key[2] == bn_cols) {
+    *map_out = (const int*)ctx->tri_map.ptr;
+    *blocks_out = ctx->tri_map_blocks;
+    return VB_OK;
+  }
+  const int tm = gemm_tiles(d, bm_rows), tn = gemm_tiles(d, bn_cols);
+  std::vector<std::pair<int, int>> order;
+  for (int band = 0; band < tm; band += 2)
+    for (int bn = 0; bn < tn; ++bn)
+      for (int bm = band; bm < band + 2 && bm < tm; ++bm)
+        if (bn * bn_cols <= bm * bm_rows + bm_rows - 1) order.push_back({bm, bn});
+  const int total = (int)order.size(), per = (total + 7) / 8, blocks = per * 8;
+  std::vector<int> host((size_t)2 * blocks, -1);
+  for (int c = 0; c < 8; ++c)
+    for (int i = 0; i < per; ++i) {
+      const int src = c * per + i;
+      if (src >= total) break;
+      host[2 * (8 * i + c)] = order[src].first;
+      host[2 * (8 * i + c) + 1] = order[src].second;
+    }
+  VB_TRY(ensure(ctx, ctx->tri_map, host.size() * sizeof(int)));
+  VB_HIP(ctx, hipMemcpyAsync(ctx->tri_map.ptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice,
+                             ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `host` is stack-scoped
+  ctx->tri_map_key[0] = d;
+  ctx->tri_map_key[1] = bm_rows;
+  ctx->tri_map_key[2] = bn_cols;
+  ctx->tri_map_blocks = blocks;
+  *map_out = (const int*)ctx->tri_map.ptr;
+  *blocks_out = blocks;
+  return VB_OK;
+}
+
 // ---- host orchestration ------------------------------------------------------------------------------
 // theta_dev != nullptr: full-rank Gaussian (Z = E L' + mu, lower-triangular gradient, epilogue into the flat layout).
 // theta_dev == nullptr: multivariate t (X = (E R) / s + mu with the dense symmetric root R and the per-row scale
@@ -885,8 +926,14 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   int n_rb_red = n_rb + (pd ? 1 : 0), n_fpart_red = n_fpart;
   const double* tr_mean = nullptr;
   if (fused_sums) {
+    static const bool map_env = !(getenv("VB_FR_TILE_MAP") && atoi(getenv("VB_FR_TILE_MAP")) == 0);
+    int cfg3_used = cfg3;
+    if (map_env && cfg3 == 0 && gemm_count_blocks(g3, 128, 64) * splits * 100 >= 190L * n_cu) {
+      cfg3_used = 2;     // the launcher's own choice for this shape (128 x 64 tiles), made here so that the list fits it
+      VB_TRY(tri2_tile_map(ctx, D, 128, 64, &g3.tile_map, &g3.tile_blocks));
+    }
     const unsigned tiles3 = gemm_f64_launch<false>(
-        st, g3, splits, n_cu, EpiSplitSlabTrace{Cpart, ldl, slab, Lt, ldl, fpart, colpart, ldz}, cfg3);
+        st, g3, splits, n_cu, EpiSplitSlabTrace{Cpart, ldl, slab, Lt, ldl, fpart, colpart, ldz}, cfg3_used);
     n_rb_red = splits;                  // one row of column sums per split
     n_fpart_red = (int)tiles3 * splits;   // one trace partial per tile and split
     tr_mean = m.p0;

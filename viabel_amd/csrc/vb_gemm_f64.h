@@ -56,6 +56,11 @@ struct GemmArgs {
   // epilogue receives z as its `split` argument
   int batch = 0;
   int64_t batch_a = 0, batch_b = 0;
+  // tri_mode 2, optional: explicit tile list -- block x computes tile (tile_map[2 x], tile_map[2 x + 1]) (a negative
+  // row block: no tile), gridDim.x = tile_blocks.  Lets the caller place the tiles that share operand panels on the
+  // same XCD (block x runs on XCD x % 8 and each XCD has its own L2)
+  const int* tile_map = nullptr;
+  int tile_blocks = 0;
   // optional start / stop events of the launch (hipExtLaunchKernel: the kernel's own begin / end timestamps)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -384,7 +389,8 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
   const int bm_rows = (cfg == 3 || cfg == 4) ? 64 : 128, bn_cols = cfg == 1 ? 128 : 64;
   g.tiles_m = gemm_tiles(g.M, bm_rows);
   g.tiles_n = gemm_tiles(g.N, bn_cols);
-  const dim3 grid((unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1, (unsigned)splits);
+  const dim3 grid(g.tile_map ? (unsigned)g.tile_blocks : (unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1,
+                  (unsigned)splits);
   if (dma) {
     if (cfg == 1) gemm_f64_dma_launch<A_KCONTIG, 4, 16, 3, Epi>(st, g, grid, epi);
     else if (cfg == 2) gemm_f64_dma_launch<A_KCONTIG, 4, 8, 3, Epi>(st, g, grid, epi);

@@ -49,7 +49,15 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGE
   // ---- tile assignment (as gemm_f64_kernel) -----------------------------------------------------
   double local = 0.0;
   int bm, bn;
-  if (g.tri_mode == 2) {
+  if (g.tri_mode == 2 && g.tile_map) {
+    bm = g.tile_map[2 * blockIdx.x];
+    bn = g.tile_map[2 * blockIdx.x + 1];
+    if (bm < 0) {                        // padding entry of the tile list (uniform for the workgroup)
+      if constexpr (EpiReduces<Epi>::value)
+        if (t == 0) epi.part[(int64_t)blockIdx.z * gridDim.x + blockIdx.x] = 0.0;
+      return;
+    }
+  } else if (g.tri_mode == 2) {
     int idx = blockIdx.x;
     bm = 0;
     for (;;) {
