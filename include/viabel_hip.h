@@ -187,6 +187,13 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q);
+/* Throughput mode of the dense families: vb_dis_refresh_mvt with sqrt_sigma == NULL and l_inv == NULL forms mu, L and
+ * L^-1 from `theta` on the device (blocked triangular inverse, GEMM levels) and draws the state samples through the
+ * Cholesky factor, x = mu + (z L') / s -- same distribution as the symmetric root of approximations.py:348, which is
+ * only needed to reproduce the reference's noise stream.  vb_dis_grad_mvt_packed is vb_dis_grad_mvt plus the chain
+ * rule to the flat parameter on the device: value = -scale sum_n w_n log q(x_n; theta) and its gradient (d + d (d + 1) / 2). */
+int vb_dis_grad_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* weights,
+                           double scale, double* value, double* grad);
 /* The DIS state samples live in the context, one set per family kind (0: mean-field, 1: MultivariateT / dense
  * Gaussian, 2: low-rank Gaussian); every refresh of a kind overwrites its set and bumps its generation counter.  A
  * caller that keeps weights for a later vb_dis_grad_* call compares the counter with the one it saw after its own

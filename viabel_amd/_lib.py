@@ -126,6 +126,8 @@ SIGNATURES = {
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p, _c_double_p,
                                              _c_double_p, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p,
                                              _c_double_p]),
+    'vb_dis_grad_mvt_packed': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
+                                              _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
     'vb_dis_generation': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     'vb_dis_state_get': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64]),
     'vb_dis_grad_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
@@ -482,7 +484,9 @@ class Engine:
 
     def dis_refresh_mvt(self, slot, n, d, df, theta, chi, sqrt_sigma, l_inv, prior_theta, eps_prev, ess_target,
                         max_bisection_its=50, n_total=None, fetch_logs=True):
-        theta, sqrt_sigma, l_inv, prior_theta = (_f64(a) for a in (theta, sqrt_sigma, l_inv, prior_theta))
+        theta, prior_theta = _f64(theta), _f64(prior_theta)
+        sqrt_sigma = None if sqrt_sigma is None else _f64(sqrt_sigma)   # both None: factors from theta on the device
+        l_inv = None if l_inv is None else _f64(l_inv)
         chi = None if chi is None else _f64(chi)       # None: the device draws of chisq_generate
         n_total = n if n_total is None else n_total
         eps, ess = ctypes.c_double(0.0), ctypes.c_double(0.0)
@@ -491,10 +495,20 @@ class Engine:
                   else (None, None))
         self._check(self._lib.vb_dis_refresh_mvt(
             self._ctx, slot, n, d, n_total, float(df), _dptr(theta), None if chi is None else _dptr(chi),
-            _dptr(sqrt_sigma), _dptr(l_inv),
+            None if sqrt_sigma is None else _dptr(sqrt_sigma), None if l_inv is None else _dptr(l_inv),
             _dptr(prior_theta), float(eps_prev), float(ess_target), int(max_bisection_its), ctypes.byref(eps),
             ctypes.byref(ess), _dptr(w), None if lp is None else _dptr(lp), None if lq is None else _dptr(lq)))
         return eps.value, ess.value, w, lp, lq
+
+    def dis_grad_mvt_packed(self, n, d, df, theta, weights, scale):
+        """``(value, grad)`` of ``-scale sum_n w_n log q(x_n; theta)`` with the factor algebra and the chain rule on
+        the device (``vb_dis_grad_mvt_packed``)."""
+        theta, weights = _f64(theta), _f64(weights)
+        value = ctypes.c_double(0.0)
+        grad = np.empty(theta.size, dtype=np.float64)
+        self._check(self._lib.vb_dis_grad_mvt_packed(self._ctx, n, d, float(df), _dptr(theta), _dptr(weights),
+                                                     float(scale), ctypes.byref(value), _dptr(grad)))
+        return value.value, grad
 
     def dis_grad_mvt(self, n, d, df, theta, l_inv, weights):
         theta, l_inv, weights = _f64(theta), _f64(l_inv), _f64(weights)

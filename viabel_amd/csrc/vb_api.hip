@@ -731,8 +731,9 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q) {
-  if (!ctx || !theta || !sqrt_sigma || !l_inv || !prior_theta || !eps || !ess || !w)
-    return fail(ctx, VB_ERR_INVALID, "NULL argument");      // chi may be NULL: device draws (vb_chisq_generate)
+  if (!ctx || !theta || !prior_theta || !eps || !ess || !w)
+    return fail(ctx, VB_ERR_INVALID, "NULL argument");      // chi may be NULL: device draws (vb_chisq_generate);
+                                                            // sqrt_sigma and l_inv both NULL: factors on the device
   VB_TRY(check_slot(ctx, slot));
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
   if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
@@ -745,6 +746,18 @@ int vb_dis_generation(vb_ctx* ctx, int kind, uint64_t* generation) {
   if (!ctx || !generation) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (kind < 0 || kind > 2) return fail(ctx, VB_ERR_INVALID, "DIS state kind %d outside [0, 2]", kind);
   *generation = ctx->dis_gen[kind];
+  return VB_OK;
+}
+
+int vb_dis_grad_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* weights,
+                           double scale, double* value, double* grad) {
+  if (!ctx || !theta || !weights || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t p = (size_t)(d + d * (d + 1) / 2);
+  std::vector<double> out(1 + p);
+  VB_TRY(mvt_dis_grad(ctx, n, d, df, theta, nullptr, weights, nullptr, nullptr, nullptr, nullptr, scale, out.data()));
+  *value = out[0];
+  memcpy(grad, out.data() + 1, p * sizeof(double));
   return VB_OK;
 }
 

@@ -128,6 +128,7 @@ struct vb_ctx {
   vb::DeviceBuffer mvt_state;           // multivariate-t DIS: state samples X, scratch
   int64_t mvt_n = 0, mvt_d = 0, mvt_n_total = 0;
   std::vector<double> mvt_theta;        // parameter the device-side residuals of the DIS state belong to
+  bool mvt_dev_factors = false;         // ... and its factors (L, L', L^-1) were formed on the device
   std::vector<double> mvt_stage;        // host staging of the factor uploads (one synchronisation per pass)
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
@@ -300,6 +301,9 @@ struct FrSums {
   double* sums;
   int64_t off_col, off_c, len;
 };
+int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int D, int64_t ldl, double* Lt, double* mu);
+int fr_tri_inverse_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, const double* Lt, int D, int64_t ldl,
+                           double* Xa, double* T);
 int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,
                       const double* ivar, double* colpart, double* fpart, const double* roww = nullptr,
                       int square = 0);   // square: column sums of the squared entries
@@ -323,7 +327,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
 int mvt_dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t n_total);
 int dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t n_total);
 int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
-                 const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out);
+                 const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out,
+                 double scale = 0.0, double* packed_out = nullptr);
 
 // symmetric square root / its derivative by coupled Newton-Schulz GEMM iterations (vb_linalg.hip)
 int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* root, double* x, double* info,

@@ -568,6 +568,65 @@ __global__ void __launch_bounds__(256) fr_pd_matvec_kernel(const double* __restr
   }
 }
 
+// theta -> mu, L' (dense, row stride ldl) on stream st
+int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int D, int64_t ldl, double* Lt, double* mu) {
+  hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((D + 31) / 32), (unsigned)((D + 31) / 32)), dim3(256), 0, st,
+                     theta_dev, D, ldl, Lt, mu);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+// Xa = (L')^-1 = U^-1 (upper triangular, row stride ldl) by recursive doubling: diagonal blocks of kTriLeaf rows are
+// inverted by back substitution (one wave per column), then [[A, B], [0, C]]^-1 = [[A^-1, -A^-1 B C^-1], [0, C^-1]]
+// level by level -- two batched GEMMs per level, D^3 / 3 flops in all instead of a triangular solve.  T: D x ldl scratch.
+int fr_tri_inverse_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, const double* Lt, int D, int64_t ldl,
+                           double* Xa, double* T) {
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int64_t slab = (int64_t)D * ldl;
+  VB_HIP(ctx, hipMemsetAsync(Xa, 0, (size_t)slab * sizeof(double), st));
+  VB_HIP(ctx, hipMemsetAsync(T, 0, (size_t)slab * sizeof(double), st));
+  static const hipError_t leaf_attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(fr_triinv_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+      kTriLeaf * kTriLeaf * (int)sizeof(double));         // 128 KB of LDS per workgroup
+  VB_HIP(ctx, leaf_attr);
+  hipLaunchKernelGGL(fr_triinv_leaf_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256),
+                     kTriLeaf * kTriLeaf * sizeof(double), st, theta_dev, Lt, D, ldl, Xa);
+  VB_HIP(ctx, hipGetLastError());
+  GemmArgs gn;
+  gn.lda = ldl;
+  gn.ldb = ldl;
+  gn.tri_mode = 0;
+  for (int b = kTriLeaf; b < D; b *= 2) {
+    // the pairs of a level are independent products of one shape: one batched launch (blockIdx.z = pair) for
+    // the full pairs, one more for a ragged last pair
+    const int full = D / (2 * b);
+    const int64_t pair_stride = (int64_t)2 * b * ldl + 2 * b;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int s0 = pass == 0 ? 0 : full * 2 * b;
+      const int count = pass == 0 ? full : (s0 + b < D ? 1 : 0);
+      if (count == 0) continue;
+      const int b2 = pass == 0 ? b : D - s0 - b;
+      const int64_t oa = (int64_t)s0 * ldl + s0, ob = (int64_t)s0 * ldl + s0 + b,
+                    oc = (int64_t)(s0 + b) * ldl + s0 + b;
+      gn.batch = 1;
+      gn.batch_a = pair_stride;
+      gn.batch_b = pair_stride;
+      gn.A = Lt + ob;      // B block (b x b2)
+      gn.B = Xa + oc;      // C^-1 (b2 x b2)
+      gn.M = b;
+      gn.N = b2;
+      gn.K = b2;
+      gemm_f64_launch<true>(st, gn, count, n_cu, EpiStoreD{T + ob, ldl, 1.0, pair_stride});
+      gn.A = Xa + oa;      // A^-1 (b x b)
+      gn.B = T + ob;
+      gn.K = b;
+      gemm_f64_launch<true>(st, gn, count, n_cu, EpiStoreD{Xa + ob, ldl, -1.0, pair_stride});
+    }
+  }
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 // ---- wrappers shared with the multivariate-t path (vb_mvt.hip) ---------------------------------------
 int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,
                       const double* ivar, double* colpart, double* fpart, const double* roww, int square) {
@@ -775,45 +834,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     // (one wave per column), then [[A, B], [0, C]]^-1 = [[A^-1, -A^-1 B C^-1], [0, C^-1]] level by level --
     // two GEMMs per pair of blocks, D^3 / 3 flops in all instead of a triangular solve
     double *Xa = base + o_xa, *T = base + o_t, *m2 = base + o_m2, *colE = base + o_cole;
-    VB_HIP(ctx, hipMemsetAsync(Xa, 0, (size_t)(2 * slab) * sizeof(double), st));   // Xa, T (contiguous)
-    static const hipError_t leaf_attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(fr_triinv_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-        kTriLeaf * kTriLeaf * (int)sizeof(double));         // 128 KB of LDS per workgroup
-    VB_HIP(ctx, leaf_attr);
-    hipLaunchKernelGGL(fr_triinv_leaf_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256),
-                       kTriLeaf * kTriLeaf * sizeof(double), st, theta_dev, (const double*)Lt, D, ldl, Xa);
-    VB_HIP(ctx, hipGetLastError());
-    GemmArgs gn;
-    gn.lda = ldl;
-    gn.ldb = ldl;
-    gn.tri_mode = 0;
-    for (int b = kTriLeaf; b < D; b *= 2) {
-      // the pairs of a level are independent products of one shape: one batched launch (blockIdx.z = pair) for
-      // the full pairs, one more for a ragged last pair
-      const int full = D / (2 * b);
-      const int64_t pair_stride = (int64_t)2 * b * ldl + 2 * b;
-      for (int pass = 0; pass < 2; ++pass) {
-        const int s0 = pass == 0 ? 0 : full * 2 * b;
-        const int count = pass == 0 ? full : (s0 + b < D ? 1 : 0);
-        if (count == 0) continue;
-        const int b2 = pass == 0 ? b : D - s0 - b;
-        const int64_t oa = (int64_t)s0 * ldl + s0, ob = (int64_t)s0 * ldl + s0 + b,
-                      oc = (int64_t)(s0 + b) * ldl + s0 + b;
-        gn.batch = 1;
-        gn.batch_a = pair_stride;
-        gn.batch_b = pair_stride;
-        gn.A = Lt + ob;      // B block (b x b2)
-        gn.B = Xa + oc;      // C^-1 (b2 x b2)
-        gn.M = b;
-        gn.N = b2;
-        gn.K = b2;
-        gemm_f64_launch<true>(st, gn, count, n_cu, EpiStoreD{T + ob, ldl, 1.0, pair_stride});
-        gn.A = Xa + oa;      // A^-1 (b x b)
-        gn.B = T + ob;
-        gn.K = b;
-        gemm_f64_launch<true>(st, gn, count, n_cu, EpiStoreD{Xa + ob, ldl, -1.0, pair_stride});
-      }
-    }
+    VB_TRY(fr_tri_inverse_enqueue(ctx, st, theta_dev, Lt, D, ldl, Xa, T));
     VB_HIP(ctx, hipGetLastError());
     GemmArgs gx;             // square D x D product below
     gx.lda = ldl;

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) mvt_scalar_kernel(const double* __restric
 struct MvtLayout {
   int64_t ld, nn;
   int64_t o_x, o_e, o_u, o_ua, o_root, o_wt, o_li, o_mu, o_c, o_invs, o_maha, o_lq, o_lp, o_lprior, o_w, o_lqcopy,
-      o_prior, o_scal, o_cpart, o_col, o_part, o_sums, total;
+      o_prior, o_scal, o_cpart, o_col, o_part, o_sums, o_theta, o_lt, o_lfull, o_tscr, o_grad, total;
   int splits, n_rb;
   FrSums S;
 };
@@ -170,6 +170,12 @@ static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t d) 
   L.S.off_c = 16 + L.ld;
   L.S.len = 16 + L.ld + sq;
   L.o_sums = carve(L.S.len);
+  // device-side factor algebra (throughput mode): flat parameter, L', L, scratch, packed gradient
+  L.o_theta = carve(d + d * (d + 1) / 2);
+  L.o_lt = carve(sq);
+  L.o_lfull = carve(sq);
+  L.o_tscr = carve(sq);
+  L.o_grad = carve(1 + d + d * (d + 1) / 2);
   L.total = off;
   return L;
 }
@@ -184,34 +190,113 @@ static int upload_padded(vb_ctx* ctx, double* dst, int64_t ld, const double* src
   return VB_OK;
 }
 
+// ---- factor algebra on the device (throughput mode) ---------------------------------------------------------------
+// out = in' (d x d, row stride ld), pads left alone
+__global__ void __launch_bounds__(256) mvt_transpose_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                            int d, int64_t ld) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (r0 + r < d && c0 + tx < d) ? in[(int64_t)(r0 + r) * ld + c0 + tx] : 0.0;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (c0 + r < d && r0 + tx < d) out[(int64_t)(c0 + r) * ld + r0 + tx] = tile[tx][r];
+}
+
+// c_j = sum_k mu_k Linv[j][k] (one wave per row of the lower-triangular inverse)
+__global__ void __launch_bounds__(256) mvt_linv_mu_kernel(const double* __restrict__ Li, int64_t ld, int d,
+                                                          const double* __restrict__ mu, double* __restrict__ c) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= d) return;
+  double s = 0.0;
+  for (int k = lane; k <= j; k += 64) s = fma(mu[k], Li[(int64_t)j * ld + k], s);
+  s = mvt_wave_sum(s);
+  if (lane == 0) c[j] = s;
+}
+
+// S = symmetric matrix given by its lower triangle C (both d x d, row stride ld)
+__global__ void __launch_bounds__(256) mvt_symmetrize_kernel(const double* __restrict__ C, double* __restrict__ S,
+                                                             int d, int64_t ld) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)d * ld) return;
+  const int i = (int)(idx / ld), j = (int)(idx % ld);
+  S[idx] = j < d ? (j <= i ? C[idx] : C[(int64_t)j * ld + i]) : 0.0;
+}
+
+// packed gradient of -scale sum_n w_n log q(x_n; theta): d/dmu from the column sums, d/dL = tril(S L)
+// - w_sum tril(L^-T) (only the diagonal 1 / L_ii of the upper-triangular L^-T survives), free diagonal x L_ii
+__global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __restrict__ SL, const double* __restrict__ Lfull,
+                                                            int64_t ld, int d, const double* __restrict__ sums,
+                                                            int64_t off_col, double scale, double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const double w_sum = sums[1], w_logq = sums[2];
+  if (idx == 0) out[0] = -scale * w_logq;
+  if (idx < d) out[1 + idx] = -scale * sums[off_col + idx];
+  if (idx >= (int64_t)d * d) return;
+  const int i = (int)(idx / d), j = (int)(idx % d);
+  if (j > i) return;
+  double g = SL[(int64_t)i * ld + j];
+  if (i == j) g = g * Lfull[(int64_t)i * ld + i] - w_sum;
+  out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -scale * g;
+}
+
+// theta (host) -> device: mu, L' (o_lt), L (o_lfull), Wt = L^-T (o_wt), Li = L^-1 (o_li), c = L^-1 mu (o_c)
+static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t d, const double* theta_host) {
+  hipStream_t st = ctx->stream;
+  const int D = (int)d;
+  const size_t p = (size_t)(d + d * (d + 1) / 2);
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_theta, theta_host, p * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));       // the caller keeps ownership of theta_host
+  VB_HIP(ctx, hipMemsetAsync(base + L.o_mu, 0, (size_t)(2 * L.ld) * sizeof(double), st));
+  VB_TRY(fr_unpack_enqueue(ctx, st, base + L.o_theta, D, L.ld, base + L.o_lt, base + L.o_mu));
+  VB_TRY(fr_tri_inverse_enqueue(ctx, st, base + L.o_theta, base + L.o_lt, D, L.ld, base + L.o_wt, base + L.o_tscr));
+  const dim3 tg((unsigned)((D + 31) / 32), (unsigned)((D + 31) / 32));
+  VB_HIP(ctx, hipMemsetAsync(base + L.o_li, 0, (size_t)(d * L.ld) * sizeof(double), st));
+  VB_HIP(ctx, hipMemsetAsync(base + L.o_lfull, 0, (size_t)(d * L.ld) * sizeof(double), st));
+  hipLaunchKernelGGL(mvt_transpose_kernel, tg, dim3(256), 0, st, (const double*)(base + L.o_wt), base + L.o_li, D, L.ld);
+  hipLaunchKernelGGL(mvt_transpose_kernel, tg, dim3(256), 0, st, (const double*)(base + L.o_lt), base + L.o_lfull, D, L.ld);
+  hipLaunchKernelGGL(mvt_linv_mu_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, (const double*)(base + L.o_li),
+                     L.ld, D, (const double*)(base + L.o_mu), base + L.o_c);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 // E' = (X - mu) L^-T, maha, log q for the parameter `theta_host` with inverse factor `linv_host`
+// (linv_host == nullptr: the factors come from theta on the device, mvt_factors_device -- unless the caller has just
+// run it: factors_ready)
 static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t n, int64_t d, double df,
-                         const double* theta_host, const double* linv_host, int64_t lq_off) {
+                         const double* theta_host, const double* linv_host, int64_t lq_off, bool factors_ready = false) {
   const int n_cu = ctx->prop.multiProcessorCount;
-  // Wt[k][j] = Linv[j][k] (B operand of dev L^-T), Li[k][j] = Linv[k][j] (B operand of E' L^-1), [mu | c]:
-  // staged in one host buffer, three copies, ONE synchronisation
-  const int64_t sq = d * L.ld;
-  std::vector<double>& st = ctx->mvt_stage;
-  st.assign((size_t)(2 * sq + 2 * L.ld), 0.0);
-  double *wt = st.data(), *li = wt + sq, *vec = li + sq;
   double logdet_half = 0.0;
-  for (int64_t j = 0; j < d; ++j) {
-    double c = 0.0;                       // c_j = sum_k mu_k Linv[j][k]
-    for (int64_t k = 0; k <= j; ++k) {
-      const double v = linv_host[j * d + k];
-      li[j * L.ld + k] = v;
-      wt[k * L.ld + j] = v;
-      c += theta_host[k] * v;
+  for (int64_t j = 0; j < d; ++j) logdet_half += theta_host[d + j * (j + 1) / 2 + j];
+  if (linv_host) {
+    // Wt[k][j] = Linv[j][k] (B operand of dev L^-T), Li[k][j] = Linv[k][j] (B operand of E' L^-1), [mu | c]:
+    // staged in one host buffer, three copies, ONE synchronisation
+    const int64_t sq = d * L.ld;
+    std::vector<double>& st = ctx->mvt_stage;
+    st.assign((size_t)(2 * sq + 2 * L.ld), 0.0);
+    double *wt = st.data(), *li = wt + sq, *vec = li + sq;
+    for (int64_t j = 0; j < d; ++j) {
+      double c = 0.0;                       // c_j = sum_k mu_k Linv[j][k]
+      for (int64_t k = 0; k <= j; ++k) {
+        const double v = linv_host[j * d + k];
+        li[j * L.ld + k] = v;
+        wt[k * L.ld + j] = v;
+        c += theta_host[k] * v;
+      }
+      vec[j] = theta_host[j];
+      vec[L.ld + j] = c;
     }
-    vec[j] = theta_host[j];
-    vec[L.ld + j] = c;
-    logdet_half += theta_host[d + j * (j + 1) / 2 + j];
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_wt, wt, (size_t)sq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_li, li, (size_t)sq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, vec, (size_t)(2 * L.ld) * sizeof(double), hipMemcpyHostToDevice,
+                               ctx->stream));
+    VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else if (!factors_ready) {
+    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
   }
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_wt, wt, (size_t)sq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_li, li, (size_t)sq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, vec, (size_t)(2 * L.ld) * sizeof(double), hipMemcpyHostToDevice,
-                             ctx->stream));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   GemmArgs g;
   g.A = base + L.o_x;
   g.lda = L.ld;
@@ -258,7 +343,17 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   const int n_cu = ctx->prop.multiProcessorCount;
   const int64_t mine = (int64_t)ctx->rank * n;   // this rank's block inside the gathered vectors
 
-  VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
+  const bool dev_factors = root_host == nullptr && linv_host == nullptr;
+  if ((root_host == nullptr) != (linv_host == nullptr))
+    return fail(ctx, VB_ERR_INVALID, "sqrt_sigma and l_inv are given together or not at all");
+  if (dev_factors) {      // throughput mode: mu, L', L^-1 from theta on the device; the samples go through L' (see header)
+    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_root, base + L.o_lt, (size_t)(d * L.ld) * sizeof(double),
+                               hipMemcpyDeviceToDevice, st));
+  } else {
+    VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
+  }
+  ctx->mvt_dev_factors = dev_factors;
   std::vector<double> inv_s;
   if (chi_host || df == 0.0) {
     inv_s.resize((size_t)n);
@@ -299,7 +394,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiSampleT{base + L.o_x, L.ld, base + L.o_mu, base + L.o_invs});
   VB_HIP(ctx, hipGetLastError());
 
-  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine));
+  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors));
   VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine));
   {   // tempering prior: a diagonal Gaussian evaluated by the same row kernel
     const ModelDev saved = ctx->model;
@@ -358,8 +453,11 @@ int mvt_dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t
 }
 
 // sum_n w_n [log q_n, d log q_n / d mu, u_n u_n' c_n] for the state samples at parameter theta_host
+// packed_out != nullptr (throughput mode): the chain rule to the flat parameter runs on the device too and
+// packed_out = [value | grad] of -scale sum_n w_n log q(x_n; theta) comes back instead of the raw sums
 int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
-                 const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out) {
+                 const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out,
+                 double scale, double* packed_out) {
   if (ctx->mvt_n != n || ctx->mvt_d != d || !ctx->mvt_state.ptr)
     return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state of shape %lld x %lld", (long long)n, (long long)d);
   const MvtLayout L = mvt_layout(ctx, n, ctx->mvt_n_total, d);
@@ -378,6 +476,10 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     if (!same) {
       VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, 0));
       ctx->mvt_theta.assign(theta_host, theta_host + p);
+      ctx->mvt_dev_factors = linv_host == nullptr;
+    } else if (packed_out && !ctx->mvt_dev_factors) {
+      VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));      // the chain rule below needs L on the device
+      ctx->mvt_dev_factors = true;
     }
   }
   // U = E' L^-1
@@ -411,6 +513,31 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col, L.n_rb, L.ld, fpart,
                            L.n_rb * (int)((d + 127) / 128), S));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
+  if (packed_out) {
+    // S = sym(gram), dL = tril(S L) - w_sum diag(1 / L_ii), free diagonal x L_ii: one D x D x D product and a pack kernel
+    const int D = (int)d;
+    const int64_t sq = d * L.ld;
+    hipLaunchKernelGGL(mvt_symmetrize_kernel, dim3((unsigned)((sq + 255) / 256)), dim3(256), 0, st,
+                       (const double*)(S.sums + S.off_c), base + L.o_tscr, D, L.ld);
+    GemmArgs gs;
+    gs.A = base + L.o_tscr;
+    gs.lda = L.ld;
+    gs.B = base + L.o_lfull;
+    gs.ldb = L.ld;
+    gs.M = D;
+    gs.N = D;
+    gs.K = D;
+    gs.tri_mode = 0;
+    gemm_f64_launch<true>(st, gs, 1, n_cu, EpiStore{base + L.o_u, L.ld});      // (o_u is free again: U was consumed)
+    hipLaunchKernelGGL(mvt_pack_grad_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
+                       (const double*)(base + L.o_u), (const double*)(base + L.o_lfull), L.ld, D,
+                       (const double*)S.sums, S.off_col, scale, base + L.o_grad);
+    VB_HIP(ctx, hipGetLastError());
+    VB_HIP(ctx, hipMemcpyAsync(packed_out, base + L.o_grad, (size_t)(1 + d + d * (d + 1) / 2) * sizeof(double),
+                               hipMemcpyDeviceToHost, st));
+    VB_HIP(ctx, hipStreamSynchronize(st));
+    return VB_OK;
+  }
   double sc[2];
   VB_HIP(ctx, hipMemcpyAsync(sc, S.sums + 1, sizeof sc, hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpyAsync(dmu_out, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));

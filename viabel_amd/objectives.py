@@ -695,16 +695,18 @@ class DISInclusiveKL(StochasticVariationalObjective):
             N = self.num_mc_samples
             begin, end = shard_rows(N, eng.n_ranks, eng.rank)
             n_local = end - begin
-            L, Linv = factors(var_param)
+            # throughput mode: mu, L, L^-1 and the chain rule of the gradient are formed on the device from var_param
+            L, Linv = (None, None) if philox else factors(var_param)
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
                 if gaussian:
                     chi = np.ones(N)
                     if philox:
                         eng.noise_generate(slot, n_local, D, approx._seed, approx._next_philox_stream(),
                                            row_offset=begin)
+                        root = None
                     else:
                         eng.noise_set_host(slot, approx._base_noise(N)[begin:end])
-                    root = np.ascontiguousarray(L.T)            # x = mu + eps L'
+                        root = np.ascontiguousarray(L.T)        # x = mu + eps L'
                 elif philox:
                     # throughput mode: chi-square draws and normals on the GPU, and x = mu + (z L') / s with the
                     # Cholesky factor instead of the reference's symmetric root (approximations.py:348).  The samples
@@ -715,7 +717,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                     eng.chisq_generate(df, n_local, approx._seed, stream, row_offset=begin)
                     eng.noise_generate(slot, n_local, D, approx._seed, stream, row_offset=begin)
                     chi = None
-                    root = np.ascontiguousarray(L.T)
+                    root = None                                 # L' from var_param, on the device
                 else:
                     chi, z = approx._base_noise(N)             # chi-square draws first (approximations.py:345-347)
                     eng.noise_set_host(slot, z[begin:end])
@@ -738,6 +740,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 indices = _shared_choice(eng, N, self._resampling_batch_size, self._state_w_normalized)
                 weights = np.bincount(indices, minlength=N).astype(np.float64)
                 scale = self._state_w_sum / N / self._resampling_batch_size
+            if philox:
+                return eng.dis_grad_mvt_packed(n_local, D, df, var_param, weights[begin:end], scale)
             w_sum, w_logq, d_mu, gram = eng.dis_grad_mvt(n_local, D, df, var_param, Linv, weights[begin:end])
             # chain rule to the free Cholesky parameters
             # d log q / d Sigma = -1/2 w_sum Sigma^-1 + 1/2 S and Sigma = L L': d/dL = tril(2 (d/dSigma) L)
