@@ -37,8 +37,82 @@ __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {
   return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0);   // (0, 1)
 }
 
-// the two standard normals of column pair j (columns 2 j, 2 j + 1) of global row `grow`; Box-Muller with
-// sincospi (no 2 pi range reduction).  k0 / k1: key words (seed, high stream bits), w: low stream bits
+// ---- lean fp64 elementary functions for Box-Muller -------------------------------------------------------------
+// The generator is VALU-bound (profiles/r02_meanfield_gen_pmc_valu.txt: 130 instructions per normal, most of them
+// inside OCML's correctly-rounded log and sincospi with their double-double bookkeeping).  The transform needs the two
+// functions on (0, 1) only and to ~1e-16, not to the last bit, so they are written out here: about half the
+// instructions, 35 % less time (tools/rng_math_check.hip: log to 3.1e-16 relative, sin / cos to 1.5e-16 absolute against
+// 80-bit libm on 4 M arguments incl. tiny ones and ones next to 1).
+
+// log(u), 0 < u < 1 (finite, normal): u = m 2^e with m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m-1)/(m+1)
+__device__ __forceinline__ double vb_log_unit(double u) {
+  int e;
+  double m = frexp(u, &e);                       // m in [1/2, 1)
+  if (m < 0.70710678118654752440) {
+    m *= 2.0;
+    e -= 1;
+  }
+  const double f = m - 1.0;                      // exact
+  const double d = 2.0 + f;
+  double y = __builtin_amdgcn_rcp(d);            // 1 / d by two Newton steps on the hardware estimate
+  double r = fma(-d, y, 1.0);
+  y = fma(y, r, y);
+  r = fma(-d, y, 1.0);
+  y = fma(y, r, y);
+  double sq = f * y;
+  sq = fma(fma(-sq, d, f), y, sq);               // s = f / d, correctly rounded up to an ulp
+  const double z = sq * sq;                      // z <= 0.0295: 1 / (2 k + 1) z^k below 1e-17 from k = 11
+  double p = 1.0 / 23.0;
+  p = fma(p, z, 1.0 / 21.0);
+  p = fma(p, z, 1.0 / 19.0);
+  p = fma(p, z, 1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  const double lm = fma(2.0 * sq, p * z, 2.0 * sq);      // 2 s (1 + z p)
+  const double de = (double)e;
+  return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
+}
+
+// sin(2 pi t), cos(2 pi t), 0 <= t < 1: quarter-turn reduction t = k / 4 + f, |f| <= 1/8, Taylor series of the
+// remaining angle phi = 2 pi f in [-pi/4, pi/4] (degree 17 / 18), quadrant by selects
+__device__ __forceinline__ void vb_sincos_turn(double t, double* sn, double* cs) {
+  const double k = rint(4.0 * t);                // 0 .. 4
+  const double f = fma(-0.25, k, t);             // exact
+  const double phi = 6.28318530717958647692 * f;
+  const double z = phi * phi;
+  double ps = -1.0 / 355687428096000.0;          // -1 / 17!
+  ps = fma(ps, z, 1.0 / 1307674368000.0);        //  1 / 15!
+  ps = fma(ps, z, -1.0 / 6227020800.0);
+  ps = fma(ps, z, 1.0 / 39916800.0);
+  ps = fma(ps, z, -1.0 / 362880.0);
+  ps = fma(ps, z, 1.0 / 5040.0);
+  ps = fma(ps, z, -1.0 / 120.0);
+  ps = fma(ps, z, 1.0 / 6.0);
+  const double s0 = fma(-phi * z, ps, phi);      // phi - phi^3 (1/6 - ...)
+  double pc = 1.0 / 6402373705728000.0;          //  1 / 18!
+  pc = fma(pc, z, -1.0 / 20922789888000.0);      // -1 / 16!
+  pc = fma(pc, z, 1.0 / 87178291200.0);
+  pc = fma(pc, z, -1.0 / 479001600.0);
+  pc = fma(pc, z, 1.0 / 3628800.0);
+  pc = fma(pc, z, -1.0 / 40320.0);
+  pc = fma(pc, z, 1.0 / 720.0);
+  pc = fma(pc, z, -1.0 / 24.0);
+  pc = fma(pc, z, 0.5);
+  const double c0 = fma(-z, pc, 1.0);            // 1 - phi^2 (1/2 - ...)
+  const int q = (int)k & 3;                      // angle = q quarter turns + phi
+  const double ss = (q & 1) ? c0 : s0;
+  const double cc = (q & 1) ? s0 : c0;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = (q == 1 || q == 2) ? -cc : cc;
+}
+
+// the two standard normals of column pair j (columns 2 j, 2 j + 1) of global row `grow`: Box-Muller on two 53-bit
+// uniforms of one Philox call.  k0 / k1: key words (seed, high stream bits), w: low stream bits
 __device__ __forceinline__ void philox_normal_pair(uint32_t k0, uint32_t k1, uint64_t grow, uint32_t j, uint32_t w,
                                                    double* a, double* b) {
   Philox4 c;
@@ -48,9 +122,9 @@ __device__ __forceinline__ void philox_normal_pair(uint32_t k0, uint32_t k1, uin
   c.w = w;
   const Philox4 o = philox4x32_10(c, k0, k1);
   const double u1 = u01(o.x, o.y), u2 = u01(o.z, o.w);
-  const double rad = sqrt(-2.0 * log(u1));
+  const double rad = sqrt(-2.0 * vb_log_unit(u1));
   double s, co;
-  sincospi(2.0 * u2, &s, &co);
+  vb_sincos_turn(u2, &s, &co);
   *a = rad * co;
   *b = rad * s;
 }
