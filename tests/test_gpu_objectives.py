@@ -563,3 +563,43 @@ def test_interleaved_dis_objectives_are_detected(vb):
     a._objective_step = 0
     v, g = a(theta)     # a refresh makes a whole again
     assert np.isfinite(v) and np.all(np.isfinite(g))
+
+
+def test_more_than_65535_samples(vb):
+    """Row-indexed kernels put the sample index on gridDim.x: gridDim.y stops at 65 535 (the RNG launcher broke on that
+    limit in round 1).  N = 70 000 through the row-scaling (alpha, dense family), low-rank sampling, logistic sampling
+    and row-centring kernels, against the oracle."""
+    N, D, k = 70000, 6, 2
+    rng = np.random.RandomState(1)
+    mean, sd = 0.3 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    # AlphaDivergence over the dense Gaussian (fr_rowscale_kernel)
+    fr, ofr = vb.FullRankGaussian(D, seed=3), ofam.FullRankGaussian(D)
+    L = np.tril(0.1 * rng.randn(D, D), -1) + np.diag(np.exp(-0.3 + 0.1 * rng.randn(D)))
+    theta = ofr.pack(0.1 * rng.randn(D), L)
+    np.random.seed(5)
+    v, g = vb.AlphaDivergence(fr, model, N, 2.0)(theta)
+    np.random.seed(5)
+    noise = np.random.RandomState(np.random.randint(2 ** 32)).randn(N, D)
+    ov, og = oobj.alpha_divergence(ofr, omodel, theta, noise, 2.0)
+    assert G.rel_err(v, ov) < 1e-11 and G.rel_err(g, og) < 1e-9
+    # AlphaDivergence over the low-rank Gaussian (lro_sample_kernel)
+    olr = ofam.LRGaussian(D, k)
+    th = np.concatenate([0.1 * rng.randn(D), -0.3 + 0.1 * rng.randn(D), 0.2 * rng.randn(D * k)])
+    np.random.seed(6)
+    v, g = vb.AlphaDivergence(vb.LRGaussian(D, seed=3, k=k), model, N, 0.5)(th)
+    np.random.seed(6)
+    ov, og = oobj.alpha_divergence(olr, omodel, th, olr.draw_noise(np.random.RandomState(np.random.randint(2 ** 32)), N), 0.5)
+    assert G.rel_err(v, ov) < 1e-11 and G.rel_err(g, og) < 1e-9
+    # logistic target under the mean-field family (lg_sample_kernel) and the correlated-Gaussian row kernel
+    X = rng.randn(50, D)
+    y = (rng.rand(50) < 0.5).astype(float)
+    thm = np.concatenate([0.1 * rng.randn(D), -0.5 + 0.1 * rng.randn(D)])
+    v, g = vb.ExclusiveKL(vb.MFGaussian(D, seed=4), vb.LogisticRegressionModel(X, y, 3.0), N)(thm)
+    ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omod.Logistic(X, y, 3.0), thm, np.random.RandomState(4).randn(N, D))
+    assert G.rel_err(v, ov) < 1e-12 and G.rel_err(g, og) < 1e-10
+    A = rng.randn(D, D)
+    S = A @ A.T / D + np.eye(D)
+    cg = vb.CorrelatedGaussianModel(mean, covariance=S)
+    x = rng.randn(N, D)
+    np.testing.assert_allclose(cg(x), omod.GaussFull(cg.mean, cg.precision).logp(x), rtol=1e-12, atol=1e-12)

@@ -466,8 +466,8 @@ __global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const
 // G[n][:] *= rs[n]  (multivariate t: the Gram GEMM then yields sum_n g_n (z_n / s_n)')
 __global__ void __launch_bounds__(256) fr_rowscale_kernel(double* __restrict__ G, int64_t ldz, int64_t n, int d,
                                                           const double* __restrict__ rs) {
-  const int64_t row = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = blockIdx.x;            // rows on x: gridDim.y stops at 65 535
+  const int c = blockIdx.y * 256 + threadIdx.x;
   if (c < d) G[row * ldz + c] *= rs[row];
 }
 
@@ -935,7 +935,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   VB_HIP(ctx, hipGetLastError());
 
   if (wm.roww) {   // weighted sums: scale the rows of G before anything is summed
-    hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)n), dim3(256), 0, st, G, ldz, n,
+    hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)n, (unsigned)((D + 255) / 256)), dim3(256), 0, st, G, ldz, n,
                        D, wm.roww);
     VB_HIP(ctx, hipGetLastError());
   }
@@ -963,7 +963,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
 
   if (row_scale) {
-    hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)n), dim3(256), 0, st, G, ldz, n,
+    hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)n, (unsigned)((D + 255) / 256)), dim3(256), 0, st, G, ldz, n,
                        D, row_scale);
     VB_HIP(ctx, hipGetLastError());
   }

@@ -23,8 +23,8 @@ __global__ void __launch_bounds__(256) lg_sample_kernel(const double* __restrict
                                                         double* __restrict__ colp, int Dp,
                                                         const double* __restrict__ noise, int64_t ld,
                                                         double* __restrict__ Z, int64_t ldz, int64_t n, int d) {
-  const int64_t row = blockIdx.y;
-  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = blockIdx.x;            // rows on x: gridDim.y stops at 65 535
+  const int col = blockIdx.y * 256 + threadIdx.x;
   if (col >= d) return;
   const double mu = theta_src[col], ls = theta_src[d + col];
   const double sg = exp(ls);

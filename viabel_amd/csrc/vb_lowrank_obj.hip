@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(256) lro_sample_kernel(const double* __restric
                                                          const double* __restrict__ sigma,
                                                          const double* __restrict__ B, double* __restrict__ X,
                                                          int64_t ldx, double* __restrict__ Zp) {
-  const int64_t row = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = blockIdx.x;            // rows on x: gridDim.y stops at 65 535
+  const int c = blockIdx.y * 256 + threadIdx.x;
   const double* z = Z + row * ldz;
   if (c < ldx) {
     double x = 0.0;
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) lro_sample_kernel(const double* __restric
     }
     X[row * ldx + c] = x;
   }
-  if (blockIdx.x == 0 && threadIdx.x < kLdt)
+  if (blockIdx.y == 0 && threadIdx.x < kLdt)
     Zp[row * kLdt + threadIdx.x] = threadIdx.x < k ? z[threadIdx.x] : (threadIdx.x == kColOne ? 1.0 : 0.0);
 }
 
@@ -393,7 +393,7 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
   }
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
-  hipLaunchKernelGGL(lro_sample_kernel, dim3((unsigned)((L.ld + 255) / 256), (unsigned)n), dim3(256), 0, st,
+  hipLaunchKernelGGL(lro_sample_kernel, dim3((unsigned)n, (unsigned)((L.ld + 255) / 256)), dim3(256), 0, st,
                      (const double*)ns.buf.ptr, ns.ld, (const double*)nz.buf.ptr, nz.ld, n, (int)d, (int)k,
                      (const double*)(base + L.o_mu), (const double*)(base + L.o_sig), (const double*)(base + L.o_b),
                      base + L.o_x, L.ld, base + L.o_zp);
@@ -496,7 +496,7 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
   hipStream_t st = ctx->stream;
   const double* E = (const double*)ns.buf.ptr;
   VB_TRY(lro_upload_param(ctx, L, base, d, k, LroParam{mu, log_sigma, B, minv, cq}, true));
-  hipLaunchKernelGGL(lro_sample_kernel, dim3((unsigned)((L.ld + 255) / 256), (unsigned)n), dim3(256), 0, st, E, ns.ld,
+  hipLaunchKernelGGL(lro_sample_kernel, dim3((unsigned)n, (unsigned)((L.ld + 255) / 256)), dim3(256), 0, st, E, ns.ld,
                      (const double*)nz.buf.ptr, nz.ld, n, (int)d, (int)k, (const double*)(base + L.o_mu),
                      (const double*)(base + L.o_sig), (const double*)(base + L.o_b), base + L.o_x, L.ld, base + L.o_zp);
   VB_HIP(ctx, hipGetLastError());

@@ -899,7 +899,7 @@ static int logistic_accumulate(vb_ctx* ctx, hipStream_t st, const ModelDev& m, c
   double* wsb = ws.base;
   VB_HIP(ctx, hipMemsetAsync(part, 0, (size_t)max_blocks * sizeof(double), st));
   VB_HIP(ctx, hipMemsetAsync(wsb + ws.off_colp, 0, (size_t)3 * g.Dp * sizeof(double), st));
-  hipLaunchKernelGGL(lg_sample_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)n), dim3(256), 0, st,
+  hipLaunchKernelGGL(lg_sample_kernel, dim3((unsigned)n, (unsigned)((d + 255) / 256)), dim3(256), 0, st,
                      bp.theta_src[0], wsb + ws.off_theta, wsb + ws.off_colp, g.Dp, (const double*)ns.buf.ptr, ns.ld,
                      Z, ldz, n, (int)d);
   VB_HIP(ctx, hipGetLastError());

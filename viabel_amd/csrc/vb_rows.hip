@@ -96,8 +96,8 @@ struct EpiLogLikTerm {       // T = log-likelihood term of observation `col` at 
 __global__ void __launch_bounds__(256) rows_center_kernel(const double* __restrict__ x, int64_t ld, int64_t n,
                                                           int d, const double* __restrict__ mean,
                                                           double* __restrict__ xc) {
-  const int64_t row = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = blockIdx.x;            // rows on x: gridDim.y stops at 65 535
+  const int c = blockIdx.y * 256 + threadIdx.x;
   if (c < ld) xc[row * ld + c] = c < d ? x[row * ld + c] - mean[c] : 0.0;
 }
 
@@ -126,7 +126,7 @@ static int gauss_full_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t
   VB_TRY(ensure(ctx, ctx->rows_work, (size_t)2 * n * ld * sizeof(double)));
   double* Xc = (double*)ctx->rows_work.ptr;
   double* Y = Xc + n * ld;
-  hipLaunchKernelGGL(rows_center_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)n), dim3(256), 0, st, x_dev, ld,
+  hipLaunchKernelGGL(rows_center_kernel, dim3((unsigned)n, (unsigned)((ld + 255) / 256)), dim3(256), 0, st, x_dev, ld,
                      n, (int)d, m.p0, Xc);
   VB_HIP(ctx, hipGetLastError());
   GemmArgs g;
