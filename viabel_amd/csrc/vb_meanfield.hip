@@ -74,6 +74,13 @@ struct Geom {
   double gdf;
   uint32_t gk0, gk1, gw;
   int64_t grow0;
+  // in-register noise on the funnel: the streaming kernel also forms the per-row scalars of its own rows (the
+  // coupling column's draw e_nk and exp(-2 v_n)) and, in column block 0, the row block's partial sums of the terms
+  // that involve that column only -- what mf_prep_kernel's row part does for resident noise.  fk / ftau: the
+  // funnel's coupling column and log-scale stdev.
+  int inline_rows;
+  int fk;
+  double ftau;
 };
 
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
@@ -210,7 +217,8 @@ mf_prep_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const Model
     if (threadIdx.x < 2) thk[threadIdx.x] = theta_src[threadIdx.x * d + model.k];
     __syncthreads();
   }
-  prep_rows_block((int)blockIdx.x, (int)gridDim.x, wsb, ws, g, model, bp.noise[b], bp.roww[b], thk[0], thk[1], sh);
+  if (!g.inline_rows)
+    prep_rows_block((int)blockIdx.x, (int)gridDim.x, wsb, ws, g, model, bp.noise[b], bp.roww[b], thk[0], thk[1], sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -312,12 +320,13 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
   if (MODEL == VB_MODEL_GAUSS_DIAG) cp2 = *reinterpret_cast<const d2*>(colp + 2 * (int64_t)g.Dp + c0i);
   const bool cols_full = (cb + 1) * kMfCols <= ld;   // every lane's 16-B load stays inside the row
 
+  __shared__ double psw[kMfWaves][PS_NUM];      // inline_rows: per-wave partial sums of the coupling-column terms
   if (GEN) {
     // noise in registers: the lane's two columns of row r are one Philox pair (the same counter layout as
     // rng_normal_kernel, so the values equal what the generator kernel would have stored); nothing is read
     const uint32_t jp = (uint32_t)(c0i >> 1);
     const bool ok0 = c0i < g.d, ok1 = c0i + 1 < g.d;
-    for (int64_t r = r0 + wave; r < r1; r += kMfWaves) {
+    auto row_pair = [&](int64_t r) __attribute__((always_inline)) {
       d2 ev = (d2){0.0, 0.0};
       if (ok0 && g.gen == 2) {
         const uint64_t grow = (uint64_t)(g.grow0 + r);
@@ -328,15 +337,72 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
         philox_normal_pair(g.gk0, g.gk1, (uint64_t)(g.grow0 + r), jp, g.gw, &pa, &pb);
         ev = (d2){pa, ok1 ? pb : 0.0};
       }
-      double a_ = 1.0, k_ = 0.0, w_ = 1.0;
-      if (MODEL == VB_MODEL_FUNNEL) {
-        a_ = rowscal[4 * r];
-        k_ = rowscal[4 * r + 1];
-      } else if (WEIGHTED) {
-        w_ = rowscal[4 * r + 2];
+      return ev;
+    };
+    if (MODEL == VB_MODEL_FUNNEL && g.inline_rows) {
+      // per pass of 256 rows (64 per wave): lane l first forms the row scalars of "its" row cbase + wave + 4 l --
+      // the coupling column's draw from the same Philox counter the element kernel uses, v = mu_k + sigma_k e,
+      // exp(-2 v) -- into LDS (each wave reads back only what it wrote itself), then the wave walks its 64 rows
+      __shared__ double rsc[kMfWaves][kWave][2];
+      const int k = g.fk, d = g.d;
+      const double* th = wsb + ws.off_theta;
+      const double muk = th[k], sgk = exp(th[d + k]);
+      const double it2 = 1.0 / (g.ftau * g.ftau), dm1 = (double)(d - 1);
+      double pW = 0.0, pFK = 0.0, pGK = 0.0, pGEK = 0.0;
+      for (int64_t cbase = r0; cbase < r1; cbase += (int64_t)kMfWaves * kWave) {
+        const int64_t rl = cbase + wave + (int64_t)kMfWaves * lane;
+        double a_l = 0.0, e_l = 0.0;
+        if (rl < r1) {
+          if (g.gen == 2) {
+            e_l = student_t_polar(g.gdf, (uint64_t)(g.grow0 + rl), (uint32_t)(k >> 1), g.gw, (uint32_t)(k & 1), g.gk0,
+                                  g.gk1);
+          } else {
+            double pa, pb;
+            philox_normal_pair(g.gk0, g.gk1, (uint64_t)(g.grow0 + rl), (uint32_t)(k >> 1), g.gw, &pa, &pb);
+            e_l = (k & 1) ? pb : pa;
+          }
+          const double v = fma(sgk, e_l, muk);
+          a_l = exp(-2.0 * v);
+          const double gk = fma(-v, it2, -dm1);
+          pW += 1.0;
+          pFK += v * fma(-0.5 * v, it2, -dm1);
+          pGK += gk;
+          pGEK = fma(gk, e_l, pGEK);
+        }
+        rsc[wave][lane][0] = a_l;
+        rsc[wave][lane][1] = e_l;
+        for (int i = 0; i < kWave; ++i) {
+          const int64_t r = cbase + wave + (int64_t)kMfWaves * i;
+          if (r >= r1) break;   // wave-uniform
+          const d2 ev = row_pair(r);
+          const double a_ = rsc[wave][i][0], k_ = rsc[wave][i][1];
+          accum<MODEL, MOM, TSC, WEIGHTED>(ev.x, cp0.x, cp1.x, cp2.x, a_, k_, 1.0, df, A0, F, Q, QE, L1P);
+          accum<MODEL, MOM, TSC, WEIGHTED>(ev.y, cp0.y, cp1.y, cp2.y, a_, k_, 1.0, df, A1, F, Q, QE, L1P);
+        }
       }
-      accum<MODEL, MOM, TSC, WEIGHTED>(ev.x, cp0.x, cp1.x, cp2.x, a_, k_, w_, df, A0, F, Q, QE, L1P);
-      accum<MODEL, MOM, TSC, WEIGHTED>(ev.y, cp0.y, cp1.y, cp2.y, a_, k_, w_, df, A1, F, Q, QE, L1P);
+      pW = wave_sum(pW);
+      pFK = wave_sum(pFK);
+      pGK = wave_sum(pGK);
+      pGEK = wave_sum(pGEK);
+      if (lane == 0) {
+        psw[wave][PS_W] = pW;
+        psw[wave][PS_FK] = pFK;
+        psw[wave][PS_GK] = pGK;
+        psw[wave][PS_GEK] = pGEK;
+      }
+    } else {
+      for (int64_t r = r0 + wave; r < r1; r += kMfWaves) {
+        const d2 ev = row_pair(r);
+        double a_ = 1.0, k_ = 0.0, w_ = 1.0;
+        if (MODEL == VB_MODEL_FUNNEL) {
+          a_ = rowscal[4 * r];
+          k_ = rowscal[4 * r + 1];
+        } else if (WEIGHTED) {
+          w_ = rowscal[4 * r + 2];
+        }
+        accum<MODEL, MOM, TSC, WEIGHTED>(ev.x, cp0.x, cp1.x, cp2.x, a_, k_, w_, df, A0, F, Q, QE, L1P);
+        accum<MODEL, MOM, TSC, WEIGHTED>(ev.y, cp0.y, cp1.y, cp2.y, a_, k_, w_, df, A1, F, Q, QE, L1P);
+      }
     }
   }
   for (int64_t base = r0 + wave; !GEN && base < r1; base += (int64_t)kMfWaves * kMfChunk) {
@@ -439,6 +505,9 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
     for (int w = 0; w < kMfWaves; ++w) s += reds[w][threadIdx.x];
     wsb[ws.off_pscal + (int64_t)threadIdx.x * (g.n_rb * g.n_cb) + (int64_t)rb * g.n_cb + cb] = s;
   }
+  if (GEN && MODEL == VB_MODEL_FUNNEL && g.inline_rows && cb == 0 && threadIdx.x < PS_NUM)
+    wsb[ws.off_prepscal + (int64_t)threadIdx.x * g.n_prep + rb] =
+        (psw[0][threadIdx.x] + psw[1][threadIdx.x]) + (psw[2][threadIdx.x] + psw[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -657,7 +726,7 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
     // ... and its row part: by the workgroup that owns the funnel's coupling column (the per-row scalars need
     // that column's new parameter only), block by block in the prep kernel's own order so that the partial sums
     // are the same numbers; without row scalars workgroup 0 writes the constant partials
-    if (a.next_g.rows ? owns_k : blockIdx.x == 0) {
+    if (!a.next_g.inline_rows && (a.next_g.rows ? owns_k : blockIdx.x == 0)) {
       __syncthreads();
       const double muk = a.next_g.rows ? thk_next[0] : 0.0, lsk = a.next_g.rows ? thk_next[1] : 0.0;
       for (int blk = 0; blk < a.n_prep; ++blk) {
@@ -999,6 +1068,9 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   g.gen = 0;
   g.gk0 = g.gk1 = g.gw = 0;
   g.grow0 = 0;
+  g.inline_rows = 0;
+  g.fk = 0;
+  g.ftau = 1.0;
   g.gdf = c.df;
   if (c.gen) {
     if (c.count != 1 || c.mode != 0 || weighted || logistic ||
@@ -1010,7 +1082,20 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
     g.gk1 = (uint32_t)(c.gen_seed >> 32) ^ (uint32_t)(c.gen_stream >> 32);
     g.gw = (uint32_t)c.gen_stream;
     g.grow0 = c.gen_row_offset;
+    if (funnel && n >= 512 && env_int("VB_MF_INLINE_ROWS", 1)) {
+      // no row part in prep (nor in the previous iteration's finalize, where one workgroup would do it block after
+      // block: 17 us at N = 4096): the streaming kernel does it for its own rows, and the device-resident loop stays
+      // at two launches per iteration (C1: 35.0 -> 31.4 us; D = 256 / N = 1024: 23.7 -> 21.7 us).  For a handful of
+      // rows the fused prep of the finalize kernel is the shorter path (D = 100 / N = 10: 14.1 vs 15.4 us) and is kept
+      g.inline_rows = 1;
+      g.fk = model.k;
+      g.ftau = model.tau;
+      g.rows = 0;
+      g.n_prep = g.n_rb;          // one entry of coupling-column partials per row block (written by column block 0)
+    }
   }
+  const bool rows_ws = rows && !g.inline_rows;
+  const int prep_grid = g.inline_rows ? (g.Dp + 255) / 256 : g.n_prep;
 
   // ---- workspace layout (per evaluation) ------------------------------------------------------
   Workspace ws;
@@ -1022,7 +1107,7 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   };
   ws.off_theta = carve(2 * d);
   ws.off_colp = carve(3 * (int64_t)g.Dp);
-  ws.off_rowscal = carve(rows ? 4 * n : 0);
+  ws.off_rowscal = carve(rows_ws ? 4 * n : 0);
   ws.off_prepscal = carve((int64_t)PS_NUM * g.n_prep);
   ws.off_partials = carve((int64_t)g.n_rb * CF_NUM * g.Dp);
   ws.off_pscal = carve((int64_t)KS_NUM * g.n_rb * g.n_cb);
@@ -1091,7 +1176,7 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   }
 
   if (!logistic && !c.skip_prep) {   // skip_prep: the previous iteration's finalize kernel has done it
-    hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)g.n_prep, (unsigned)c.count), dim3(256), 0, st_pre,
+    hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)prep_grid, (unsigned)c.count), dim3(256), 0, st_pre,
                        bp, ws, g, model);
     VB_HIP(ctx, hipGetLastError());
   }
