@@ -544,10 +544,9 @@ struct Totals {
   double v[SF_NUM];
 };
 
-// sum of the scalar partials of the accumulate and prep kernels (all 256 threads take part;
-// every load is issued before the first add, one barrier)
-__device__ Totals scalar_totals(const EpiArgs& a, double (*sh)[KS_NUM + PS_NUM]) {
-  double acc[KS_NUM + PS_NUM];
+// sum of the scalar partials of the accumulate and prep kernels (all 256 threads take part).  Two phases so that the
+// caller can issue the loads (scalar_partials) ahead of its own reduction and combine them (scalar_totals) after it.
+__device__ __forceinline__ void scalar_partials(const EpiArgs& a, double* acc) {
 #pragma unroll
   for (int s = 0; s < KS_NUM + PS_NUM; ++s) acc[s] = 0.0;
   for (int e = threadIdx.x; e < a.n_ps; e += blockDim.x) {
@@ -560,6 +559,9 @@ __device__ Totals scalar_totals(const EpiArgs& a, double (*sh)[KS_NUM + PS_NUM])
       for (int s = 0; s < PS_NUM; ++s) acc[KS_NUM + s] += a.prepscal[(int64_t)s * a.n_prep + e];
     }
   }
+}
+
+__device__ Totals scalar_totals(const EpiArgs& a, double* acc, double (*sh)[KS_NUM + PS_NUM]) {
 #pragma unroll
   for (int s = 0; s < KS_NUM + PS_NUM; ++s) acc[s] = wave_sum(acc[s]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -612,8 +614,8 @@ __device__ double elbo_value(const EpiArgs& a, const Totals& t, double sum_ls) {
 // gradient of the plain / path-derivative estimator for one column (what autograd returns for
 // objectives.py:154-164)
 __device__ __forceinline__ void plain_column(const EpiArgs& a, int i, double g, double ge, double sc,
-                                             double sce, double* gmu, double* gls) {
-  const double sg = exp(a.theta[a.d + i]);
+                                             double sce, double* gmu, double* gls, double ls_i) {
+  const double sg = exp(ls_i);            // ls_i = a.theta[a.d + i], fetched by the caller ahead of its reduction
   const double invN = 1.0 / a.n_total;
   if (a.flags & VB_FLAG_PATH_DERIV) {
     gmu[i] = -(g + sc / sg) * invN;
@@ -648,6 +650,26 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
   const int col = blockIdx.x * 64 + c;
   const int Dp = a.Dp;
   const int64_t fstride = Dp, rstride = (int64_t)CF_NUM * Dp;
+  // What the per-column epilogue below reads -- log sigma of the column and, in the device-resident loop, the
+  // optimiser state and the parameter entries of its two steps -- is fetched NOW, next to the partial sums, instead
+  // of in three dependent round trips after them (the kernel is a chain of memory latencies: 9.3 -> ~6 us)
+  double pf_ls = 0.0, pf_s1[2] = {0.0, 0.0}, pf_s2[2] = {0.0, 0.0}, pf_th[2] = {0.0, 0.0};
+  if (!a.reduce_only && q == 0 && col < a.d) {
+    pf_ls = a.theta[a.d + col];
+    if (a.has_step) {
+      fit_step_load(a.step, col, &pf_s1[0], &pf_s2[0], &pf_th[0]);
+      fit_step_load(a.step, (int64_t)a.d + col, &pf_s1[1], &pf_s2[1], &pf_th[1]);
+    }
+  }
+  const bool funnel = a.model.id == VB_MODEL_FUNNEL;
+  const int k = a.model.k;
+  const bool owns_k = funnel && (k / 64 == (int)blockIdx.x);
+  const bool need_tot = blockIdx.x == 0 || owns_k;   // workgroup-uniform
+  double sacc[KS_NUM + PS_NUM];
+  if (need_tot) scalar_partials(a, sacc);            // (likewise: fetched before the reduction, combined after it)
+  double t_ls = 0.0;
+  if (blockIdx.x == 0 && !a.reduce_only)
+    for (int i = threadIdx.x; i < a.d; i += blockDim.x) t_ls += a.theta[a.d + i];
   // two fields per pass, 16 row blocks each: 32 independent loads in flight per thread
   for (int f = 0; f < a.nf; f += 2) {
     const bool two = f + 1 < a.nf;
@@ -673,12 +695,8 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
   }
   __syncthreads();
 
-  const bool funnel = a.model.id == VB_MODEL_FUNNEL;
-  const int k = a.model.k;
-  const bool owns_k = funnel && (k / 64 == (int)blockIdx.x);
-  const bool need_tot = blockIdx.x == 0 || owns_k;   // workgroup-uniform
   Totals tot;
-  if (need_tot) tot = scalar_totals(a, sh2);
+  if (need_tot) tot = scalar_totals(a, sacc, sh2);
 
   if (a.reduce_only) {
     if (q == 0) {
@@ -696,6 +714,7 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
   double* value = a.out;
   double* gmu = a.out + 1;
   double* gls = a.out + 1 + d;
+  double new_mu = 0.0, new_ls = 0.0;
   if (q == 0 && col < d) {
     double S[CF_NUM];
     for (int f = 0; f < CF_NUM; ++f)
@@ -706,10 +725,10 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
       ge += tot.v[SF_GEK] + tot.v[SF_QE];
     }
     const bool student = a.family == VB_FAMILY_MF_STUDENT_T;
-    plain_column(a, col, g, ge, student ? S[CF_SC] : S[CF_E], student ? S[CF_SCE] : S[CF_EE], gmu, gls);
+    plain_column(a, col, g, ge, student ? S[CF_SC] : S[CF_E], student ? S[CF_SCE] : S[CF_EE], gmu, gls, pf_ls);
     if (a.has_step) {       // theta_src (the step's theta) is not read by this kernel: it works on the prep copy
-      fit_step_apply(a.step, col, gmu[col]);
-      fit_step_apply(a.step, (int64_t)d + col, gls[col]);
+      new_mu = fit_step_apply_vals(a.step, col, gmu[col], pf_s1[0], pf_s2[0], pf_th[0]);
+      new_ls = fit_step_apply_vals(a.step, (int64_t)d + col, gls[col], pf_s1[1], pf_s2[1], pf_th[1]);
     }
   }
   if (a.prep_next) {
@@ -717,8 +736,8 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
     if (q == 0) {
       double mu = 0.0, ls = 0.0;
       if (col < d) {
-        mu = a.step.theta[col];
-        ls = a.step.theta[d + col];
+        mu = new_mu;          // = a.step.theta[col], a.step.theta[d + col] as just stored
+        ls = new_ls;
         if (funnel && col == k) thk_next[0] = mu, thk_next[1] = ls;
       }
       prep_column(col, mu, ls, a.next_wsb, ws, a.next_g, a.model);
@@ -736,8 +755,6 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
     }
   }
   if (blockIdx.x == 0) {
-    double t_ls = 0.0;
-    for (int i = threadIdx.x; i < d; i += blockDim.x) t_ls += a.theta[d + i];
     const double sum_ls = block_sum(t_ls, sh);
     if (threadIdx.x == 0) {
       value[0] = elbo_value(a, tot, sum_ls);
@@ -829,7 +846,7 @@ mf_epilogue_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
       const double g = G[i] + (i == k ? gk_add : 0.0);
       const double ge = GE[i] + (i == k ? gek_add : 0.0);
-      plain_column(a, i, g, ge, student ? SC[i] : E[i], student ? SCE[i] : EE[i], gmu, gls);
+      plain_column(a, i, g, ge, student ? SC[i] : E[i], student ? SCE[i] : EE[i], gmu, gls, ls[i]);
     }
     return;
   }
