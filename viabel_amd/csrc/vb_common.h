@@ -25,8 +25,34 @@ constexpr int kMfChunk = 16;       // rows a wave keeps in flight (16 x 16-B loa
 constexpr int kMaxBatch = 32;      // independent evaluations per launch (blockIdx.y)
 constexpr int kModelLogQ = 99;     // internal pseudo model: weighted log q(z; theta) statistics (DIS)
 
+// Touch every 64-byte line of the kernel-argument segment at the top of a kernel.  The argument block of a launch
+// is fresh device memory: the first scalar load of each line takes 0.3-0.4 us, later ones hit the scalar cache
+// (tools/kernarg_probe.hip), and the compiler fetches arguments where they are first needed, so a latency-bound
+// kernel with a large argument block (mf_finalize: 1.6 KB, 26 lines) meets those misses one after another.  One
+// batch of loads here brings all lines in for the price of one miss.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // All loads target ONE scalar register that stays reserved (in/out operand) until the wait below, so none of them
+  // can land in a register the compiler has given to something else; their values are never used.
+  typedef const uint32_t __attribute__((address_space(4))) * KernargPtr;
+  KernargPtr p = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t t = 0;
+#pragma unroll
+  for (int off = 0; off < BYTES; off += 64) asm volatile("s_load_dword %0, %1, %2" : "+s"(t) : "s"(p), "s"(off));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t));
+#endif
+}
+
 // per-column partial sums (fields) and per-workgroup scalars written by the accumulation kernel
 enum ColField { CF_G = 0, CF_GE, CF_E, CF_EE, CF_EK, CF_SC, CF_SCE, CF_NUM };
+
+// Where the partial sum of (row block rb, field f, column col) lives: [col / 64][rb][f][col % 64], i.e. everything
+// one finalize workgroup (64 columns) reads is one contiguous run of n_rb * CF_NUM * 512 bytes (57 KB for 4096
+// samples) instead of n_rb * CF_NUM separate 512-byte pieces spread over the whole array.
+__host__ __device__ __forceinline__ int64_t partial_index(int64_t rb, int f, int64_t col, int64_t n_rb) {
+  return (((col >> 6) * n_rb + rb) * CF_NUM + f) * 64 + (col & 63);
+}
 enum ScalField { SF_F = 0, SF_W, SF_Q, SF_QE, SF_L1P, SF_EE, SF_FK, SF_GK, SF_GEK, SF_NUM = 12 };
 // scalars written per workgroup by the accumulation kernel / by the prep kernel (SoA: [s][entry])
 enum KScal { KS_F = 0, KS_Q, KS_QE, KS_L1P, KS_EE, KS_NUM };

@@ -160,7 +160,7 @@ lg_accum_kernel(const double* __restrict__ noise, int64_t ld, const double* __re
       d2x s = red[f][0][lane];
 #pragma unroll
       for (int w = 1; w < kMfWaves; ++w) s += red[f][w][lane];
-      *reinterpret_cast<d2x*>(wsb + ws.off_partials + ((int64_t)rb * CF_NUM + f) * g.Dp + c0i) = s;
+      *reinterpret_cast<d2x*>(wsb + ws.off_partials + partial_index(rb, f, c0i, g.n_rb)) = s;
     }
   }
   if (threadIdx.x < KS_NUM) {

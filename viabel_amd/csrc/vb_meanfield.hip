@@ -55,7 +55,7 @@ struct Workspace {
   int64_t off_colp;        // [3][Dp]         per-column constants
   int64_t off_rowscal;     // [n][4]          per-row scalars {a, eps_k, w, 0}
   int64_t off_prepscal;    // [PS_NUM][n_prep]
-  int64_t off_partials;    // [n_rb][CF_NUM][Dp]
+  int64_t off_partials;    // [Dp / 64][n_rb][CF_NUM][64] (partial_index)
   int64_t off_pscal;       // [KS_NUM][n_rb * n_cb]
   double* sums;            // [B][sum_len]: [SF_NUM] | [nf][Dp]   (the all-reduced vector)
   int64_t sum_len;
@@ -497,7 +497,7 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
     d2 s = red[f][0][lane];
 #pragma unroll
     for (int w = 1; w < kMfWaves; ++w) s += red[f][w][lane];
-    *reinterpret_cast<d2*>(wsb + ws.off_partials + ((int64_t)rb * CF_NUM + f) * g.Dp + c0i) = s;
+    *reinterpret_cast<d2*>(wsb + ws.off_partials + partial_index(rb, f, c0i, g.n_rb)) = s;
   }
   if (threadIdx.x < KS_NUM) {
     double s = 0.0;
@@ -514,7 +514,7 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
 // finalize / epilogue
 // ------------------------------------------------------------------------------------------------
 struct EpiArgs {
-  const double* partials;   // [n_rb][CF_NUM][Dp]
+  const double* partials;   // [Dp / 64][n_rb][CF_NUM][64] (partial_index)
   const double* pscal;      // [KS_NUM][n_ps]
   const double* prepscal;   // [PS_NUM][n_prep] or nullptr
   int n_rb, n_ps, n_prep;
@@ -544,48 +544,146 @@ struct Totals {
   double v[SF_NUM];
 };
 
-// sum of the scalar partials of the accumulate and prep kernels (all 256 threads take part).  Two phases so that the
-// caller can issue the loads (scalar_partials) ahead of its own reduction and combine them (scalar_totals) after it.
-__device__ __forceinline__ void scalar_partials(const EpiArgs& a, double* acc) {
+// Sum of the scalar partials of the accumulate and prep kernels, plus sum(log sigma), over the 256 threads of a
+// finalize workgroup.  Three phases so that the kernel is ONE memory round trip deep: scalar_fetch issues the first
+// 256-entry chunk of every list into registers (no use => no wait; the caller issues its own column-partial loads
+// right behind), scalar_accumulate adds them up (and walks the rest of longer lists), scalar_reduce combines the
+// threads through LDS.  kNS values per thread: the KS_* and PS_* sums and the log-sigma sum.
+constexpr int kNS = KS_NUM + PS_NUM + 1;
+
+// x where `mask` is all ones, +0.0 where it is zero.  The mask comes from opaque_mask so that the compiler cannot
+// turn "load, then select" into "branch around the load": a load sunk to its use is one more memory round trip
+// (0.7 us here) in a kernel that is nothing but a chain of them.
+__device__ __forceinline__ double keep_masked(double x, unsigned long long mask) {
+  return __longlong_as_double(__double_as_longlong(x) & (long long)mask);
+}
+__device__ __forceinline__ unsigned long long opaque_mask(bool c) {
+  unsigned long long m = c ? ~0ull : 0ull;
+  asm volatile("" : "+v"(m));
+  return m;
+}
+constexpr int kLsChunks = 4;        // log-sigma entries fetched ahead per thread (d <= 1024 in one go)
+constexpr int kPsChunks = 2;        // accumulate-kernel scalar partials per thread (512 workgroups = 2 per CU)
+
+struct ScalarFetch {
+  double ks[kPsChunks][KS_NUM], ps[PS_NUM], ls[kLsChunks];
+};
+
+__device__ __forceinline__ void scalar_fetch(const EpiArgs& a, bool want_ls, ScalarFetch* f) {
+  // unconditional loads from clamped indices, discarded by selects: straight-line code (see mf_finalize_kernel)
+  const int e = threadIdx.x;
+  const int e_pr = min(e, a.n_prep - 1);
 #pragma unroll
-  for (int s = 0; s < KS_NUM + PS_NUM; ++s) acc[s] = 0.0;
-  for (int e = threadIdx.x; e < a.n_ps; e += blockDim.x) {
+  for (int j = 0; j < kPsChunks; ++j) {
+    const int e_ps = min(e + 256 * j, a.n_ps - 1);
+#pragma unroll
+    for (int s = 0; s < KS_NUM; ++s) f->ks[j][s] = a.pscal[(int64_t)s * a.n_ps + e_ps];
+  }
+#pragma unroll
+  for (int s = 0; s < PS_NUM; ++s) f->ps[s] = 0.0;
+#pragma unroll
+  for (int j = 0; j < kLsChunks; ++j) f->ls[j] = 0.0;
+  if (a.prepscal) {
+#pragma unroll
+    for (int s = 0; s < PS_NUM; ++s) f->ps[s] = a.prepscal[(int64_t)s * a.n_prep + e_pr];
+  }
+  if (want_ls) {
+#pragma unroll
+    for (int j = 0; j < kLsChunks; ++j) f->ls[j] = a.theta[a.d + min(e + 256 * j, a.d - 1)];
+  }
+}
+
+// acc[0 .. KS_NUM + PS_NUM) = this thread's share of the scalar sums, acc[kNS - 1] = its share of sum(log sigma);
+// entry order e = t, t + 256, ... as a plain strided loop would take them
+__device__ __forceinline__ void scalar_accumulate(const EpiArgs& a, bool want_ls, const ScalarFetch& f, double* acc) {
+  // (the entries scalar_fetch took from clamped indices are dropped HERE, at their first use, not next to the loads:
+  // a use is a wait, and the caller has more loads to issue in between)
+  const int e = threadIdx.x;
+  const unsigned long long m_pr = opaque_mask(a.prepscal && e < a.n_prep);
+#pragma unroll
+  for (int s = 0; s < KS_NUM; ++s) acc[s] = 0.0;
+#pragma unroll
+  for (int j = 0; j < kPsChunks; ++j) {
+    const unsigned long long m_ps = opaque_mask(e + 256 * j < a.n_ps);
+#pragma unroll
+    for (int s = 0; s < KS_NUM; ++s) acc[s] += keep_masked(f.ks[j][s], m_ps);
+  }
+#pragma unroll
+  for (int s = 0; s < PS_NUM; ++s) acc[KS_NUM + s] = 0.0 + keep_masked(f.ps[s], m_pr);
+  double t = 0.0;
+#pragma unroll
+  for (int j = 0; j < kLsChunks; ++j) t += keep_masked(f.ls[j], opaque_mask(want_ls && e + 256 * j < a.d));
+  for (int e = threadIdx.x + 256 * kPsChunks; e < a.n_ps; e += 256) {
 #pragma unroll
     for (int s = 0; s < KS_NUM; ++s) acc[s] += a.pscal[(int64_t)s * a.n_ps + e];
   }
   if (a.prepscal) {
-    for (int e = threadIdx.x; e < a.n_prep; e += blockDim.x) {
+    for (int e = threadIdx.x + 256; e < a.n_prep; e += 256) {
 #pragma unroll
       for (int s = 0; s < PS_NUM; ++s) acc[KS_NUM + s] += a.prepscal[(int64_t)s * a.n_prep + e];
     }
   }
+  if (want_ls)
+    for (int i = threadIdx.x + 256 * kLsChunks; i < a.d; i += 256) t += a.theta[a.d + i];
+  acc[kNS - 1] = t;
 }
 
-__device__ Totals scalar_totals(const EpiArgs& a, double* acc, double (*sh)[KS_NUM + PS_NUM]) {
+// LDS scratch of scalar_reduce: the per-thread values, 16 partial sums of each, the totals
+static_assert(16 * kNS <= 256, "scalar_reduce: one thread per (value, 16-entry group)");
+struct ScalarShared {
+  double v[kNS][256];
+  double p[kNS][16];
+  double t[kNS];
+};
+
+// Block-wide sums of acc[0 .. kNS): every thread stores its values (the caller's own LDS stores ride on the same
+// barrier), 16 x kNS threads add 16 entries each, kNS threads add the 16 partials.  Three barriers and ~40 LDS reads
+// on the critical path instead of 6 x kNS cross-lane shuffles (1.6 us -> 0.4 us).  *sum_ls gets sum(log sigma).
+__device__ __forceinline__ Totals scalar_reduce(const double* acc, ScalarShared* sh, double* sum_ls) {
+  const int t = threadIdx.x;
 #pragma unroll
-  for (int s = 0; s < KS_NUM + PS_NUM; ++s) acc[s] = wave_sum(acc[s]);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int s = 0; s < kNS; ++s) sh->v[s][t] = acc[s];
   __syncthreads();
-  if (lane == 0) {
+  if (t < 16 * kNS) {
+    const int s = t >> 4, j = t & 15;
+    double x[16];
 #pragma unroll
-    for (int s = 0; s < KS_NUM + PS_NUM; ++s) sh[wave][s] = acc[s];
+    for (int i = 0; i < 16; ++i) x[i] = sh->v[s][j + 16 * i];
+    double u = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u += x[i];
+    sh->p[s][j] = u;
   }
   __syncthreads();
+  if (t < kNS) {
+    double x[16];
 #pragma unroll
-  for (int s = 0; s < KS_NUM + PS_NUM; ++s) acc[s] = (sh[0][s] + sh[1][s]) + (sh[2][s] + sh[3][s]);
-  Totals t;
+    for (int i = 0; i < 16; ++i) x[i] = sh->p[t][i];
+    double u = 0.0;
 #pragma unroll
-  for (int s = 0; s < SF_NUM; ++s) t.v[s] = 0.0;
-  t.v[SF_F] = acc[KS_F];
-  t.v[SF_Q] = acc[KS_Q];
-  t.v[SF_QE] = acc[KS_QE];
-  t.v[SF_L1P] = acc[KS_L1P];
-  t.v[SF_EE] = acc[KS_EE];
-  t.v[SF_W] = acc[KS_NUM + PS_W];
-  t.v[SF_FK] = acc[KS_NUM + PS_FK];
-  t.v[SF_GK] = acc[KS_NUM + PS_GK];
-  t.v[SF_GEK] = acc[KS_NUM + PS_GEK];
-  return t;
+    for (int i = 0; i < 16; ++i) u += x[i];
+    sh->t[t] = u;
+  }
+  __syncthreads();
+  Totals r;
+#pragma unroll
+  for (int s = 0; s < SF_NUM; ++s) r.v[s] = 0.0;
+  r.v[SF_F] = sh->t[KS_F];
+  r.v[SF_Q] = sh->t[KS_Q];
+  r.v[SF_QE] = sh->t[KS_QE];
+  r.v[SF_L1P] = sh->t[KS_L1P];
+  r.v[SF_EE] = sh->t[KS_EE];
+  r.v[SF_W] = sh->t[KS_NUM + PS_W];
+  r.v[SF_FK] = sh->t[KS_NUM + PS_FK];
+  r.v[SF_GK] = sh->t[KS_NUM + PS_GK];
+  r.v[SF_GEK] = sh->t[KS_NUM + PS_GEK];
+  *sum_ls = sh->t[kNS - 1];
+  return r;
+}
+
+// log of the Student-t density's normaliser
+__device__ __forceinline__ double student_log_norm(double df) {
+  return lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df * M_PI);
 }
 
 // -(lower bound), objectives.py:156-164
@@ -600,7 +698,7 @@ __device__ double elbo_value(const EpiArgs& a, const Totals& t, double sum_ls) {
   if (a.flags & VB_FLAG_PATH_DERIV) {   // -mean(f - log q(theta_stop; z))
     double logq;
     if (student) {
-      const double ct = lgamma(0.5 * (a.df + 1.0)) - lgamma(0.5 * a.df) - 0.5 * log(a.df * M_PI);
+      const double ct = student_log_norm(a.df);
       logq = W * (d * ct - sum_ls) - 0.5 * (a.df + 1.0) * t.v[SF_L1P];
     } else {
       logq = -0.5 * t.v[SF_EE] - W * (0.5 * d * kLog2Pi + sum_ls);
@@ -614,15 +712,96 @@ __device__ double elbo_value(const EpiArgs& a, const Totals& t, double sum_ls) {
 // gradient of the plain / path-derivative estimator for one column (what autograd returns for
 // objectives.py:154-164)
 __device__ __forceinline__ void plain_column(const EpiArgs& a, int i, double g, double ge, double sc,
-                                             double sce, double* gmu, double* gls, double ls_i) {
+                                             double sce, double* gmu, double* gls, double ls_i,
+                                             double* gmu_i = nullptr, double* gls_i = nullptr) {
   const double sg = exp(ls_i);            // ls_i = a.theta[a.d + i], fetched by the caller ahead of its reduction
   const double invN = 1.0 / a.n_total;
+  double m, l;
   if (a.flags & VB_FLAG_PATH_DERIV) {
-    gmu[i] = -(g + sc / sg) * invN;
-    gls[i] = -(ge * sg + sce) * invN;
+    m = -(g + sc / sg) * invN;
+    l = -(ge * sg + sce) * invN;
   } else {
-    gmu[i] = -g * invN;
-    gls[i] = -(ge * sg * invN + 1.0);
+    m = -g * invN;
+    l = -(ge * sg * invN + 1.0);
+  }
+  gmu[i] = m;
+  gls[i] = l;
+  if (gmu_i) *gmu_i = m, *gls_i = l;      // for a caller that goes on with them (no store -> load round trip)
+}
+
+// Fixed-order sums of the row-block partials of NF fields for column c of the workgroup's run, row blocks
+// q, q + 4, q + 8, ... added in that order, into colsum[f][q][c].  NI row blocks of every field are requested at a
+// time (NF x NI loads in flight: one memory round trip per pass, and the launcher's geometry -- at most 64 row
+// blocks up to 2 workgroups per CU -- makes that one pass for NI = 16); row blocks past the end are read from the
+// last one (scalar clamps) and dropped by a mask afterwards.
+template <int NF, int NI>
+__device__ __forceinline__ void column_sums(const double* blk_partials, int q, int c, int n_rb,
+                                            double (*colsum)[4][64]) {
+  const int rb_last = n_rb - 1;
+  double t[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) t[f] = 0.0;
+  for (int rb0 = q; rb0 <= rb_last; rb0 += 4 * NI) {
+    double v[NF][NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const double* prb = blk_partials + min(rb0 + 4 * i, rb_last) * (CF_NUM * 64) + (uint32_t)c;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) v[f][i] = prb[f * 64];
+    }
+    // ---- everything below waits on those loads (and on everything the caller has requested before them) ----
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const unsigned long long m = opaque_mask(rb0 + 4 * i <= rb_last);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) t[f] += keep_masked(v[f][i], m);
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f) colsum[f][q][c] = t[f];
+}
+
+// one instantiation per field count; 4 row blocks per thread cover up to 16 (small sample counts), 16 cover the
+// launcher's usual 64, 8 at a time for the wide field sets (registers)
+template <int NF>
+__device__ __forceinline__ void column_sums_nf(const double* blk_partials, int q, int c, int n_rb,
+                                               double (*colsum)[4][64]) {
+  if (n_rb > 16)
+    column_sums<NF, (NF <= 2 ? 16 : 8)>(blk_partials, q, c, n_rb, colsum);
+  else
+    column_sums<NF, 4>(blk_partials, q, c, n_rb, colsum);
+}
+
+// reduce-only mode (the multi-rank path: the sums go to the all-reduce, mf_epilogue_kernel does the rest)
+__device__ __forceinline__ void finalize_reduce_only(const EpiArgs& a, const Totals& tot,
+                                                               double (*colsum)[4][64], ScalarShared* ssh, int q,
+                                                               int c, int col) {
+  if (q == 0) {
+    for (int f = 0; f < a.nf; ++f)
+      a.sums[SF_NUM + (int64_t)f * a.Dp + col] =
+          (colsum[f][0][c] + colsum[f][1][c]) + (colsum[f][2][c] + colsum[f][3][c]);
+  }
+  if (blockIdx.x == 0) {
+    // Totals is a register struct: hand it to the SF_NUM writing lanes through LDS, not through a dynamic index
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int s = 0; s < SF_NUM; ++s) ssh->p[0][s] = tot.v[s];
+    }
+    __syncthreads();
+    if (threadIdx.x < SF_NUM) a.sums[threadIdx.x] = ssh->p[0][threadIdx.x];
+  }
+}
+
+// Row part of the next iteration's prep, block by block in the prep kernel's own order so that the partial sums are
+// the same numbers (all 256 threads; thk_next = the coupling column's new (mu, log sigma), published by its owner).
+__device__ __forceinline__ void finalize_prep_rows(const EpiArgs& a, const Workspace& ws,
+                                                             const double* thk_next, double (*sh3)[PS_NUM]) {
+  __syncthreads();
+  const double muk = a.next_g.rows ? thk_next[0] : 0.0, lsk = a.next_g.rows ? thk_next[1] : 0.0;
+  for (int blk = 0; blk < a.n_prep; ++blk) {
+    prep_rows_block(blk, a.n_prep, a.next_wsb, ws, a.next_g, a.model, nullptr, nullptr, muk, lsk, sh3);
+    __syncthreads();
   }
 }
 
@@ -630,6 +809,7 @@ __device__ __forceinline__ void plain_column(const EpiArgs& a, int i, double g, 
 // rb = q, q + 4, ... of column 64 * blockIdx + c, for every field; fixed order => deterministic.
 __global__ void __launch_bounds__(256)
 mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
+  kernarg_warm<sizeof(EpiArgs) + sizeof(BatchPtrs) + sizeof(Workspace)>();
   EpiArgs a = a_in;   // per-evaluation pointers (blockIdx.y = evaluation index)
   {
     const int b = blockIdx.y;
@@ -642,17 +822,32 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
     a.out = bp.out[b];
   }
   __shared__ double colsum[CF_NUM + 1][4][64];
-  __shared__ double sh[4];
-  __shared__ double sh2[4][KS_NUM + PS_NUM];
+  __shared__ ScalarShared ssh;
   __shared__ double sh3[4][PS_NUM];
   __shared__ double thk_next[2];
-  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  // q (the wave index) in a scalar register: the row-block offsets and their bounds checks become scalar work
+  const int c = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = blockIdx.x * 64 + c;
-  const int Dp = a.Dp;
-  const int64_t fstride = Dp, rstride = (int64_t)CF_NUM * Dp;
-  // What the per-column epilogue below reads -- log sigma of the column and, in the device-resident loop, the
-  // optimiser state and the parameter entries of its two steps -- is fetched NOW, next to the partial sums, instead
-  // of in three dependent round trips after them (the kernel is a chain of memory latencies: 9.3 -> ~6 us)
+#ifdef VB_FIN_CLOCK
+  // Debug build (tools/build_clk.sh): three s_memrealtime stamps per launch -- entry, exit and ONE midpoint that
+  // moves with the iteration number (1500 + i) -- printed for two workgroups.
+  const int fc_mid = a.has_step ? (int)a.step.k - 1500 : -1;
+  long long fc_t0 = wall_clock64(), fc_tm = 0;
+#define VB_FC(i) if (fc_mid == (i)) fc_tm = wall_clock64()
+#else
+#define VB_FC(i)
+#endif
+  // This kernel is 16 workgroups of pure latency (profiled with the stamps above, tools/latency_probe.hip and
+  // tools/kernarg_probe.hip).  What it costs: (a) dependent global round trips, ~0.7 us each for data another XCD
+  // has just written -- so EVERYTHING it reads is requested up front, before anything is used: what the per-column
+  // epilogue needs (log sigma of the column and, in the device-resident loop, the optimiser state and the parameter
+  // entries of its two steps), the scalar partials, the log-sigma entries of the value, and every row block of
+  // every column field in one pass; values read from clamped indices are dropped with opaque masks, not selects,
+  // so that the compiler cannot sink a load to its use; (b) the first touch of each 64-byte line of its 1.6 KB
+  // argument block, 0.3-0.4 us each when met one by one (kernarg_warm); (c) scratch memory and real function
+  // calls: a build with the rare paths in noinline functions (632 B of stack) ran every phase 1.5x slower, so the
+  // rare paths (reduce-only mode of the multi-rank path, the row part of the next iteration's prep, the Student-t
+  // normaliser) are inlined behind unlikely branches and nothing indexes a register array dynamically.
   double pf_ls = 0.0, pf_s1[2] = {0.0, 0.0}, pf_s2[2] = {0.0, 0.0}, pf_th[2] = {0.0, 0.0};
   if (!a.reduce_only && q == 0 && col < a.d) {
     pf_ls = a.theta[a.d + col];
@@ -661,51 +856,39 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
       fit_step_load(a.step, (int64_t)a.d + col, &pf_s1[1], &pf_s2[1], &pf_th[1]);
     }
   }
+  VB_FC(10);
   const bool funnel = a.model.id == VB_MODEL_FUNNEL;
   const int k = a.model.k;
   const bool owns_k = funnel && (k / 64 == (int)blockIdx.x);
   const bool need_tot = blockIdx.x == 0 || owns_k;   // workgroup-uniform
-  double sacc[KS_NUM + PS_NUM];
-  if (need_tot) scalar_partials(a, sacc);            // (likewise: fetched before the reduction, combined after it)
-  double t_ls = 0.0;
-  if (blockIdx.x == 0 && !a.reduce_only)
-    for (int i = threadIdx.x; i < a.d; i += blockDim.x) t_ls += a.theta[a.d + i];
-  // two fields per pass, 16 row blocks each: 32 independent loads in flight per thread
-  for (int f = 0; f < a.nf; f += 2) {
-    const bool two = f + 1 < a.nf;
-    const double* p0 = a.partials + f * fstride + col;
-    const double* p1 = p0 + fstride;
-    double t0 = 0.0, t1 = 0.0;
-    for (int rb0 = q; rb0 < a.n_rb; rb0 += 64) {
-      double v0[16], v1[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int rb = rb0 + 4 * i;
-        v0[i] = rb < a.n_rb ? p0[rb * rstride] : 0.0;
-        v1[i] = (two && rb < a.n_rb) ? p1[rb * rstride] : 0.0;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        t0 += v0[i];
-        t1 += v1[i];
-      }
-    }
-    colsum[f][q][c] = t0;
-    if (two) colsum[f + 1][q][c] = t1;
-  }
-  __syncthreads();
-
+  const bool want_ls = blockIdx.x == 0 && !a.reduce_only;
+  ScalarFetch sf;
+  if (need_tot) scalar_fetch(a, want_ls, &sf);
+  VB_FC(11);
+  const double* blk_partials = a.partials + (int64_t)blockIdx.x * a.n_rb * (CF_NUM * 64);   // this workgroup's run
+  // CF_GE + 1, CF_EK + 1 or CF_NUM fields (see the launcher); the plain ELBO gradient (two fields) falls through
+  if (__builtin_expect(a.nf == CF_GE + 1, 1))
+    column_sums_nf<CF_GE + 1>(blk_partials, q, c, a.n_rb, colsum);
+  else if (a.nf == CF_EK + 1)
+    column_sums_nf<CF_EK + 1>(blk_partials, q, c, a.n_rb, colsum);
+  else
+    column_sums_nf<CF_NUM>(blk_partials, q, c, a.n_rb, colsum);
+  VB_FC(1);
   Totals tot;
-  if (need_tot) tot = scalar_totals(a, sacc, sh2);
+  double sum_ls = 0.0;
+  if (need_tot) {
+    double sacc[kNS];
+    scalar_accumulate(a, want_ls, sf, sacc);
+    VB_FC(2);
+    tot = scalar_reduce(sacc, &ssh, &sum_ls);     // its first barrier also publishes colsum
+  } else {
+    VB_FC(2);
+    __syncthreads();
+  }
+  VB_FC(3);
 
-  if (a.reduce_only) {
-    if (q == 0) {
-      for (int f = 0; f < a.nf; ++f)
-        a.sums[SF_NUM + (int64_t)f * Dp + col] =
-            (colsum[f][0][c] + colsum[f][1][c]) + (colsum[f][2][c] + colsum[f][3][c]);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < SF_NUM)
-      a.sums[threadIdx.x] = tot.v[threadIdx.x];
+  if (__builtin_expect(a.reduce_only, 0)) {
+    finalize_reduce_only(a, tot, colsum, &ssh, q, c, col);
     return;
   }
 
@@ -716,21 +899,28 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
   double* gls = a.out + 1 + d;
   double new_mu = 0.0, new_ls = 0.0;
   if (q == 0 && col < d) {
+    // fields beyond a.nf were not written by column_sums: whatever LDS holds there is read and dropped
     double S[CF_NUM];
-    for (int f = 0; f < CF_NUM; ++f)
-      S[f] = f < a.nf ? (colsum[f][0][c] + colsum[f][1][c]) + (colsum[f][2][c] + colsum[f][3][c]) : 0.0;
+#pragma unroll
+    for (int f = 0; f < CF_NUM; ++f) {
+      const double x = (colsum[f][0][c] + colsum[f][1][c]) + (colsum[f][2][c] + colsum[f][3][c]);
+      S[f] = f < a.nf ? x : 0.0;
+    }
     double g = S[CF_G], ge = S[CF_GE];
     if (funnel && col == k) {
       g += tot.v[SF_GK] + tot.v[SF_Q];
       ge += tot.v[SF_GEK] + tot.v[SF_QE];
     }
     const bool student = a.family == VB_FAMILY_MF_STUDENT_T;
-    plain_column(a, col, g, ge, student ? S[CF_SC] : S[CF_E], student ? S[CF_SCE] : S[CF_EE], gmu, gls, pf_ls);
+    double gm, gl;
+    plain_column(a, col, g, ge, student ? S[CF_SC] : S[CF_E], student ? S[CF_SCE] : S[CF_EE], gmu, gls, pf_ls,
+                 &gm, &gl);
     if (a.has_step) {       // theta_src (the step's theta) is not read by this kernel: it works on the prep copy
-      new_mu = fit_step_apply_vals(a.step, col, gmu[col], pf_s1[0], pf_s2[0], pf_th[0]);
-      new_ls = fit_step_apply_vals(a.step, (int64_t)d + col, gls[col], pf_s1[1], pf_s2[1], pf_th[1]);
+      new_mu = fit_step_apply_vals(a.step, col, gm, pf_s1[0], pf_s2[0], pf_th[0]);
+      new_ls = fit_step_apply_vals(a.step, (int64_t)d + col, gl, pf_s1[1], pf_s2[1], pf_th[1]);
     }
   }
+  VB_FC(4);
   if (a.prep_next) {
     // prep of the next iteration (see mf_prep_kernel) for the columns this workgroup has just stepped ...
     if (q == 0) {
@@ -743,24 +933,25 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
       prep_column(col, mu, ls, a.next_wsb, ws, a.next_g, a.model);
     }
     // ... and its row part: by the workgroup that owns the funnel's coupling column (the per-row scalars need
-    // that column's new parameter only), block by block in the prep kernel's own order so that the partial sums
-    // are the same numbers; without row scalars workgroup 0 writes the constant partials
-    if (!a.next_g.inline_rows && (a.next_g.rows ? owns_k : blockIdx.x == 0)) {
-      __syncthreads();
-      const double muk = a.next_g.rows ? thk_next[0] : 0.0, lsk = a.next_g.rows ? thk_next[1] : 0.0;
-      for (int blk = 0; blk < a.n_prep; ++blk) {
-        prep_rows_block(blk, a.n_prep, a.next_wsb, ws, a.next_g, a.model, nullptr, nullptr, muk, lsk, sh3);
-        __syncthreads();
-      }
-    }
+    // that column's new parameter only); without row scalars workgroup 0 writes the constant partials.  Not needed
+    // when the accumulate kernel computes the row scalars itself (512 samples or more).
+    if (__builtin_expect(!a.next_g.inline_rows && (a.next_g.rows ? owns_k : blockIdx.x == 0), 0))
+      finalize_prep_rows(a, ws, thk_next, sh3);
   }
-  if (blockIdx.x == 0) {
-    const double sum_ls = block_sum(t_ls, sh);
-    if (threadIdx.x == 0) {
-      value[0] = elbo_value(a, tot, sum_ls);
-      if (a.has_step) a.step.values[a.step.k] = value[0];
-    }
+  VB_FC(5);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double val = elbo_value(a, tot, sum_ls);
+    value[0] = val;
+    if (a.has_step) a.step.values[a.step.k] = val;
   }
+#ifdef VB_FIN_CLOCK
+  {
+    const long long fc_t1 = wall_clock64();
+    if (threadIdx.x == 0 && fc_mid >= 0 && fc_mid < 16 && (blockIdx.x == 0 || blockIdx.x == 5))
+      printf("finalize block %d  midpoint %2d: entry->mid %4lld  mid->exit %4lld  total %4lld  (10 ns ticks)\n", (int)blockIdx.x,
+             fc_mid, fc_tm ? fc_tm - fc_t0 : -1, fc_tm ? fc_t1 - fc_tm : -1, fc_t1 - fc_t0);
+  }
+#endif
 }
 
 // one workgroup over the reduced sums: control variates, weighted gradients, post-all-reduce
