@@ -40,6 +40,8 @@ D1 = 1024                                        # configs[1] dimension
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet fp64 matrix peak = 256 CUs x 4 SIMDs x 512 flop / 16 clk x 2.4 GHz;
 #                                                  tools/mfma_barrier_probe.hip measures 77.3 with constant operands
+# HBM-side bytes per launch of the headline's dense model GEMM at D=1024, N=4096 (see roofline.traffic_source)
+MODEL_GEMM_HBM_BYTES = int((2 * 49216.4 + 32817.8) * 1024)
 MIN_TIMED_S = 0.05                               # the timed blocks are repeated until they cover at least this
 
 
@@ -434,6 +436,14 @@ def main():
         roof = {'bound': 'mfma', 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'traffic': None,
                 'whole_evaluation': head['whole_evaluation'], 'per_kernel': head['per_kernel']}
         if mg:
+            # HBM-side bytes per launch of that kernel: PMC counters cannot be collected from inside this process,
+            # so the figure is the one measured with `tools/prof_r2.sh pmc` on this shape and committed under
+            # profiles/ (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
+            if head['n_rows'] == N_MC and FR_D == 1024:
+                roof['traffic'] = MODEL_GEMM_HBM_BYTES
+                roof['traffic_source'] = ('profiles/r02_fullrank_gemm_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                          'separate passes): 100.8 MB fetched + 33.6 MB written per launch vs 75.5 MB '
+                                          'algorithmic (P is fetched once per XCD); 0.98 TB/s, an eighth of HBM peak')
             roof.update({'kernel': 'gemm_f64_dma_kernel<A[m][k], 128x64, EpiNegate>: G = -(Z - m) P, dense %d x %d x %d '
                                    '(the dominant kernel of the evaluation)' % (head['n_rows'], FR_D, FR_D),
                          'achieved': mg['achieved'], 'frac': mg['frac'], 'avg_kernel_us': mg['avg_kernel_us'],

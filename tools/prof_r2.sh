@@ -26,4 +26,14 @@ if [ "$1" = "pmc" ]; then
     rm -rf $out/pmc_$c
   done
   cat $out/fr1024_pmc.txt
+  # HBM traffic of the same kernels (separate passes): FETCH_SIZE / WRITE_SIZE are in KiB-sized units of the L2's
+  # memory-side requests; on gfx950 FETCH_SIZE counts 128-B streaming requests at 64 B (MI355X_MICROARCH.md, HBM
+  # section), so the fetched bytes are 2 x FETCH_SIZE x 1024
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c -d $out/pmc_$c -o p -- python3 tools/fr_bench.py 1024 4096 gauss_full 100 > $out/pmc_$c.log 2>&1
+    echo "== $c" >> $out/fr1024_hbm.txt
+    python3 tools/rocpd_stats.py $out/pmc_$c/p_results.db $c | grep -E "gemm|reduce|kernel  " | cut -c1-44,65-200 >> $out/fr1024_hbm.txt
+    rm -rf $out/pmc_$c
+  done
+  cat $out/fr1024_hbm.txt
 fi
