@@ -4,6 +4,7 @@
 // Run:   tools/gemm_bench.bin [M N K]
 #include "vb_gemm_f64.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -163,15 +164,41 @@ int main(int argc, char** argv) {
       hipMemcpy(A, h.data(), big * 8, hipMemcpyHostToDevice);
       hipMemcpy(B, h.data(), big * 8, hipMemcpyHostToDevice);
     }
+    // argv[6]: 'd' dense (default), 't' triangular k range (Z = E L'), 'g' Gram C = A' B with lower-triangular
+    // tiles and argv[7] row slabs (M = N = D, K = rows)
+    const char mode = argc > 6 ? argv[6][0] : 'd';
+    const int splits = argc > 7 ? atoi(argv[7]) : 1;
     GemmArgs g;
-    g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = 0;
-    float ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg); }, 20);
-    printf("cfg %d dense  A[m][k]  M=%d N=%d K=%d: %.1f us  %.2f TFLOP/s\n", cfg, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+    g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = mode == 't' ? 1 : 0;
+    float ms;
+    long nb_mode = 0;
+    int slabs_per_wg = K / 16;
+    if (mode == 'g' || mode == 'G' || mode == 'D') {
+      // 'G': the same Gram product over all tiles (no triangle); 'D': the same shape and row slabs with A given
+      // as A[m][k] (what separates "k-major A" from "split-K geometry")
+      GemmArgs g3;
+      // GEMM_PAD_A / GEMM_PAD_B: extra doubles in the row stride of the k-major operands (power-of-two strides put
+      // every k row of a tile on the same L2 channels)
+      const int pad_a = getenv("GEMM_PAD_A") ? atoi(getenv("GEMM_PAD_A")) : 0, pad_b = getenv("GEMM_PAD_B") ? atoi(getenv("GEMM_PAD_B")) : 0;
+      g3.A = A, g3.B = B, g3.lda = mode == 'D' ? M : N + pad_a, g3.ldb = N + pad_b, g3.M = N, g3.N = N, g3.K = M, g3.tri_mode = mode == 'g' ? 2 : 0;
+      if (mode == 'D')
+        ms = time_it([&] { gemm_f64_launch<true>(st, g3, splits, n_cu, EpiSlab{C, N, (int64_t)N * N}, cfg); }, 20);
+      else
+        ms = time_it([&] { gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSlab{C, N, (int64_t)N * N}, cfg); }, 20);
+      nb_mode = gemm_count_blocks(g3, (cfg == 3 || cfg == 4) ? 64 : 128, cfg == 1 ? 128 : 64);
+      slabs_per_wg = ((M + splits - 1) / splits + 15) / 16;
+      printf("cfg %d gram A[k][m] D=%d rows=%d splits=%d (%ld tiles x %d): %.1f us  %.2f TFLOP/s (dense convention)\n", cfg, N, M,
+             splits, nb_mode, splits, ms * 1e3, 2.0 * M * N * N / ms / 1e9);
+    } else {
+      ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg); }, 20);
+      printf("cfg %d %s  A[m][k]  M=%d N=%d K=%d: %.1f us  %.2f TFLOP/s (dense convention)\n", cfg, mode == 't' ? "tri-k" : "dense",
+             M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+    }
 #ifdef VB_GEMM_CLOCK
     {
       std::vector<long long> o(8 * 4096);
       hipMemcpyFromSymbol(o.data(), HIP_SYMBOL(vb_gemm_dbg), o.size() * sizeof(long long));
-      const int nb = (M / (cfg == 3 ? 64 : 128)) * (N / (cfg == 1 ? 128 : 64));
+      const int nb = (mode == 'g' || mode == 'G' || mode == 'D') ? (int)nb_mode : (M / ((cfg == 3 || cfg == 4) ? 64 : 128)) * (N / (cfg == 1 ? 128 : 64));
       const int nw = 4 * (nb < 1024 ? nb : 1024);
       double pro = 0, loop = 0, epi = 0, wall = 0, first = 1e30, last = 0;
       for (int i = 0; i < nw; ++i) {
@@ -181,8 +208,18 @@ int main(int argc, char** argv) {
       }
       pro /= nw, loop /= nw, epi /= nw, wall /= nw;
       const double mhz = (pro + loop + epi) / (wall / 100.0);
-      printf("   per wave: prologue %.0f, main loop %.0f (%.1f per slab), epilogue %.0f shader cycles; lifetime %.1f us -> %.0f MHz; "
-             "first start to last end %.1f us\n", pro, loop, loop / (K / 16), epi, wall / 100.0, mhz, (last - first) / 100.0);
+      printf("   per wave: prologue %.0f, main loop %.0f (%.1f per slab of the longest k range), epilogue %.0f shader cycles; lifetime %.1f us -> %.0f MHz; "
+             "first start to last end %.1f us\n", pro, loop, loop / slabs_per_wg, epi, wall / 100.0, mhz, (last - first) / 100.0);
+      if (mode != 'd') {   // lifetimes of the individual workgroups (wave 0), sorted: the shape of the schedule
+        std::vector<double> life, start;
+        for (int i = 0; i < nw; i += 4) life.push_back(o[8 * i + 3] / 100.0), start.push_back((o[8 * i + 4] - first) / 100.0);
+        std::vector<double> sl = life, ss = start;
+        std::sort(sl.begin(), sl.end());
+        std::sort(ss.begin(), ss.end());
+        printf("   workgroup lifetimes (us): min %.1f  25%% %.1f  median %.1f  75%% %.1f  max %.1f;  start times: median %.1f  90%% %.1f  max %.1f\n",
+               sl.front(), sl[sl.size() / 4], sl[sl.size() / 2], sl[3 * sl.size() / 4], sl.back(), ss[ss.size() / 2],
+               ss[9 * ss.size() / 10], ss.back());
+      }
       printf("   in us at that clock: prologue %.1f, loop %.1f, epilogue %.1f; MFMA floor of the loop (2 waves/SIMD x 16 cycles) %.1f us\n",
              pro / mhz, loop / mhz, epi / mhz, 2.0 * (K / 16) * 4 * (cfg == 1 ? 64 : cfg == 2 ? 32 : 16) * 16 / mhz);
     }
