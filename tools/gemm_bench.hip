@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 using namespace vb;
 
@@ -15,6 +16,21 @@ struct EpiStore {
   int64_t ldc;
   __device__ void operator()(int, int row, int col, double acc) const { C[(int64_t)row * ldc + col] = acc; }
 };
+
+// store variants for the end-of-kernel write-back experiment (GEMM_STORE=nt|wt)
+struct EpiStoreNT {
+  double* C;
+  int64_t ldc;
+  __device__ void operator()(int, int row, int col, double acc) const { __builtin_nontemporal_store(acc, &C[(int64_t)row * ldc + col]); }
+};
+struct EpiStoreWT {
+  double* C;
+  int64_t ldc;
+  __device__ void operator()(int, int row, int col, double acc) const {
+    __hip_atomic_store(&C[(int64_t)row * ldc + col], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+__global__ void empty_kernel(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
 
 struct EpiSlab {
   double* C;
@@ -156,9 +172,34 @@ int main(int argc, char** argv) {
   hipStream_t st;
   hipStreamCreate(&st);
 
+  // GEMM_REPS: timed launches per measurement in profiling mode (default 20; thousands = seconds of sustained load,
+  // for power / clock sampling from the host with rocm-smi)
+  const int kReps = getenv("GEMM_REPS") ? atoi(getenv("GEMM_REPS")) : 20;
   if (argc > 4) {   // profiling mode: only the dense GEMM in tile configuration argv[4]
     const int cfg = atoi(argv[4]);
-    if (argc > 5) {   // data pattern: 'z' all zero, 'o' all ones
+    if (argc > 5 && argv[5][0] == 'n') {   // 'n<bits>[a]': standard normals, mantissa truncated to <bits> bits (0 = keep all 52);
+      // suffix 'a': only operand A is truncated.  Operand-dependent power is what sets the sustained clock.
+      const int bits = atoi(argv[5] + 1);
+      const bool only_a = argv[5][strlen(argv[5]) - 1] == 'a';
+      srand48(7);
+      std::vector<double> hb(big);
+      auto trunc = [&](double x) {
+        if (bits <= 0 || bits >= 52) return x;
+        unsigned long long u;
+        memcpy(&u, &x, 8);
+        u &= ~((1ull << (52 - bits)) - 1);
+        memcpy(&x, &u, 8);
+        return x;
+      };
+      for (size_t i = 0; i < big; i += 2) {
+        const double u1 = drand48() + 1e-300, u2 = drand48(), r = sqrt(-2.0 * log(u1));
+        const double a = r * cos(6.283185307179586 * u2), b = r * sin(6.283185307179586 * u2);
+        h[i] = trunc(a), h[i + 1] = trunc(b);
+        hb[i] = only_a ? b : trunc(b), hb[i + 1] = only_a ? a : trunc(a);
+      }
+      hipMemcpy(A, h.data(), big * 8, hipMemcpyHostToDevice);
+      hipMemcpy(B, hb.data(), big * 8, hipMemcpyHostToDevice);
+    } else if (argc > 5 && argv[5][0] != 'r') {   // data pattern: 'z' all zero, 'o' all ones, 'r' keep the pseudo-random fill
       const double v = argv[5][0] == 'z' ? 0.0 : 1.0;
       for (size_t i = 0; i < big; ++i) h[i] = v;
       hipMemcpy(A, h.data(), big * 8, hipMemcpyHostToDevice);
@@ -182,15 +223,22 @@ int main(int argc, char** argv) {
       const int pad_a = getenv("GEMM_PAD_A") ? atoi(getenv("GEMM_PAD_A")) : 0, pad_b = getenv("GEMM_PAD_B") ? atoi(getenv("GEMM_PAD_B")) : 0;
       g3.A = A, g3.B = B, g3.lda = mode == 'D' ? M : N + pad_a, g3.ldb = N + pad_b, g3.M = N, g3.N = N, g3.K = M, g3.tri_mode = mode == 'g' ? 2 : 0;
       if (mode == 'D')
-        ms = time_it([&] { gemm_f64_launch<true>(st, g3, splits, n_cu, EpiSlab{C, N, (int64_t)N * N}, cfg); }, 20);
+        ms = time_it([&] { gemm_f64_launch<true>(st, g3, splits, n_cu, EpiSlab{C, N, (int64_t)N * N}, cfg); }, kReps);
       else
-        ms = time_it([&] { gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSlab{C, N, (int64_t)N * N}, cfg); }, 20);
+        ms = time_it([&] { gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSlab{C, N, (int64_t)N * N}, cfg); }, kReps);
       nb_mode = gemm_count_blocks(g3, (cfg == 3 || cfg == 4) ? 64 : 128, cfg == 1 ? 128 : 64);
       slabs_per_wg = ((M + splits - 1) / splits + 15) / 16;
       printf("cfg %d gram A[k][m] D=%d rows=%d splits=%d (%ld tiles x %d): %.1f us  %.2f TFLOP/s (dense convention)\n", cfg, N, M,
              splits, nb_mode, splits, ms * 1e3, 2.0 * M * N * N / ms / 1e9);
     } else {
-      ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg); }, 20);
+      const char* sv = getenv("GEMM_STORE");
+      {
+        const float e = time_it([&] { hipLaunchKernelGGL(empty_kernel, dim3(512), dim3(256), 0, st, (int*)nullptr); }, 200);
+        printf("empty 512-workgroup kernel back to back: %.2f us per launch\n", e * 1e3);
+      }
+      if (sv && sv[0] == 'n') ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStoreNT{C, N}, cfg); }, kReps);
+      else if (sv && sv[0] == 'w') ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStoreWT{C, N}, cfg); }, kReps);
+      else ms = time_it([&] { gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg); }, kReps);
       printf("cfg %d %s  A[m][k]  M=%d N=%d K=%d: %.1f us  %.2f TFLOP/s (dense convention)\n", cfg, mode == 't' ? "tri-k" : "dense",
              M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
     }
@@ -210,7 +258,7 @@ int main(int argc, char** argv) {
       const double mhz = (pro + loop + epi) / (wall / 100.0);
       printf("   per wave: prologue %.0f, main loop %.0f (%.1f per slab of the longest k range), epilogue %.0f shader cycles; lifetime %.1f us -> %.0f MHz; "
              "first start to last end %.1f us\n", pro, loop, loop / slabs_per_wg, epi, wall / 100.0, mhz, (last - first) / 100.0);
-      if (mode != 'd') {   // lifetimes of the individual workgroups (wave 0), sorted: the shape of the schedule
+      {   // lifetimes of the individual workgroups (wave 0), sorted: the shape of the schedule
         std::vector<double> life, start;
         for (int i = 0; i < nw; i += 4) life.push_back(o[8 * i + 3] / 100.0), start.push_back((o[8 * i + 4] - first) / 100.0);
         std::vector<double> sl = life, ss = start;

@@ -311,6 +311,14 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
   }
 }
 
+#ifdef VB_DBG_IDLE
+// experiment (tools/build_variant.sh idle -DVB_DBG_IDLE): one wave that sleeps for `ticks` of the 100 MHz clock
+__global__ void dbg_idle_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+#endif
+
 // ---- full-rank Gaussian: split reduction straight into the flat (paragami) layout -----------------------
 // Same pair-per-thread reduction as fr_reduce_kernel (same summation order), but entry (i, j <= i) lands at the
 // packed position i (i + 1) / 2 + j -- the order of the free-Cholesky block of theta -- so a sharded job
@@ -934,6 +942,12 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
   VB_HIP(ctx, hipGetLastError());
 
+#ifdef VB_DBG_IDLE
+  {
+    static const int idle_us = getenv("VB_FR_IDLE_US") ? atoi(getenv("VB_FR_IDLE_US")) : 0;
+    if (idle_us > 0) hipLaunchKernelGGL(dbg_idle_kernel, dim3(1), dim3(64), 0, st, (long long)idle_us * 100);
+  }
+#endif
   if (wm.roww) {   // weighted sums: scale the rows of G before anything is summed
     hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)n, (unsigned)((D + 255) / 256)), dim3(256), 0, st, G, ldz, n,
                        D, wm.roww);

@@ -61,6 +61,9 @@ struct GemmArgs {
   // same XCD (block x runs on XCD x % 8 and each XCD has its own L2)
   const int* tile_map = nullptr;
   int tile_blocks = 0;
+  // wave-priority alternation (LDS-DMA kernel): workgroups of generation (linear id / prio_div) & 1 raise their
+  // wave priority on even slabs, the others on odd slabs (0: off).  Set by the launcher to the number of CUs.
+  int prio_div = 0;
   // optional start / stop events of the launch (hipExtLaunchKernel: the kernel's own begin / end timestamps)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -391,6 +394,8 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
   g.tiles_n = gemm_tiles(g.N, bn_cols);
   const dim3 grid(g.tile_map ? (unsigned)g.tile_blocks : (unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1,
                   (unsigned)splits);
+  static const int prio_env = getenv("VB_GEMM_PRIO") ? atoi(getenv("VB_GEMM_PRIO")) : 1;
+  g.prio_div = prio_env ? n_cu : 0;
   if (dma) {
     if (cfg == 1) gemm_f64_dma_launch<A_KCONTIG, 4, 16, 3, Epi>(st, g, grid, epi);
     else if (cfg == 2) gemm_f64_dma_launch<A_KCONTIG, 4, 8, 3, Epi>(st, g, grid, epi);

@@ -159,6 +159,24 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGE
   // ---- fragment addresses (lane constants; doubles) -------------------------------------------------------
   const int fi = lane & 15, fk = lane >> 4;
   const int fblk = (lane >> 2) & 3, fj = lane & 3;
+  // Which tile row / column a lane's fragment element stands for is bookkeeping: block slot blk of the instruction
+  // multiplies whatever 4 rows of A and 4 columns of B the lanes of that slot supply.  The assignment is chosen so
+  // that the two values a lane needs for fragments 2q and 2q + 1 are NEIGHBOURS in the k-major LDS row, i.e. one
+  // ds_read_b128 instead of two ds_read_b64 (half the LDS instructions of a k-step; the 16 lanes of one service
+  // pass still cover 256 consecutive bytes = every bank once):
+  //   B: fragment r, slot blk, lane column j -> column 8 ((blk + r / 2) mod NB/2) + 2 j + (r & 1) of the wave's 4 NB
+  //      (for a fixed slot, r = 0 .. NB-1 visits every column of the wave exactly once);
+  //   A given as A[k][m]: fragment a, lane row i (slot i / 4) -> row 32 (a / 2) + 2 i + (a & 1) of the wave's 16 AF.
+  // A given as A[m][k] keeps 16 consecutive rows per fragment (its reads are already merged, two fragments per
+  // ds_read2st64_b64).  The per-element order of the k sum does not depend on the assignment: results are bit-identical
+  // to the register-staged kernel's.
+  auto frag_row = [&](int a, int i) __attribute__((always_inline)) {
+    return A_KCONTIG ? wm * (16 * AF) + a * 16 + i : wm * (16 * AF) + 32 * (a >> 1) + 2 * i + (a & 1);
+  };
+  auto frag_col = [&](int r, int blk, int j) __attribute__((always_inline)) {
+    return wn * (4 * NB) + 8 * ((blk + (r >> 1)) & (NB / 2 - 1)) + 2 * j + (r & 1);
+  };
+  static_assert(AF % 2 == 0 && NB % 2 == 0, "fragments are read in pairs");
   // A[m][k] tile: fragment a of k-step kk at a_off[kk] + 256 a (16 rows further: (row >> 1) & 7 unchanged);
   // A[k][m] tile: fragment a of k-step kk at a_off[a] + 4 kk BM (parity of k = parity of fk)
   constexpr int kAOffs = A_KCONTIG ? kGemmBK / 4 : AF;
@@ -174,18 +192,21 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGE
   } else {
 #pragma unroll
     for (int a = 0; a < AF; ++a) {
-      const int m = wm * (16 * AF) + a * 16 + fi;
+      const int m = frag_row(a, fi);
       a_off[a < kAOffs ? a : 0] = fk * BM + (m ^ (16 * (fk & 1)));
     }
   }
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
-    const int col = wn * (4 * NB) + 4 * ((fblk + r) & (NB - 1)) + fj;
+    const int col = frag_col(r, fblk, fj);
     b_off[r] = fk * BN + (col ^ (16 * (fk & 1)));          // k = 4 kk + fk: parity of k = parity of fk
   }
 
   double fa[2][AF], fb[2][NB];
   auto load_frags = [&](int st, int kk, int set) __attribute__((always_inline)) {
+#ifdef VB_ABL_NO_READS
+    if (kk >= 0) return;
+#endif
     const double* as = As + st * kATile;
     const double* bs = Bs + st * kBTile;
     // The compiler merges the AF reads below into ds_read2st64_b64 pairs, which are serviced 16 lanes at a time
@@ -193,11 +214,21 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGE
     // 4096 x 1024 x 1024 launch).  Forcing single ds_read_b64 (opaque addresses) removed the conflicts and halved
     // the LDS cycles but ran 5 % slower (157 vs 149 us): the extra address arithmetic and the lost scheduling
     // freedom cost more than the LDS time, which the MFMAs hide anyway.
+    if constexpr (A_KCONTIG) {
 #pragma unroll
-    for (int a = 0; a < AF; ++a)
-      fa[set][a] = A_KCONTIG ? as[a_off[kk < kAOffs ? kk : 0] + a * (16 * kGemmBK)] : as[a_off[a < kAOffs ? a : 0] + 4 * kk * BM];
+      for (int a = 0; a < AF; ++a) fa[set][a] = as[a_off[kk < kAOffs ? kk : 0] + a * (16 * kGemmBK)];
+    } else {
 #pragma unroll
-    for (int r = 0; r < NB; ++r) fb[set][r] = bs[b_off[r] + 4 * kk * BN];
+      for (int a = 0; a < AF; a += 2) {
+        const d2v v = *reinterpret_cast<const d2v*>(as + a_off[a < kAOffs ? a : 0] + 4 * kk * BM);
+        fa[set][a] = v.x, fa[set][a + 1] = v.y;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NB; r += 2) {
+      const d2v v = *reinterpret_cast<const d2v*>(bs + b_off[r] + 4 * kk * BN);
+      fb[set][r] = v.x, fb[set][r + 1] = v.y;
+    }
   };
   auto mfma_step = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
@@ -207,16 +238,48 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGE
         acc[a][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(fa[set][a], fb[set][r], acc[a][r], 0, 0, 0);
   };
   constexpr int KS = kGemmBK / 4;
-  constexpr int kReads = AF + NB, kMfma = AF * NB;
+  // LDS *instructions* per k-step as the compiler emits them: AF / 2 for the A fragments (ds_read2st64_b64 pairs of
+  // the [m][16] tile, ds_read_b128 pairs of the k-major tile) and NB / 2 ds_read_b128 for the B fragments.  The
+  // interleave pattern below must ask for exactly that many DS groups: when it asked for more than a step has, the
+  // scheduler filled the surplus with the NEXT step's first read, and that read then sat right in front of the step
+  // boundary's s_waitcnt lgkmcnt(0) -- one exposed LDS round trip per k-step.
+#ifdef VB_GEMM_KREADS
+  constexpr int kReads = VB_GEMM_KREADS, kMfma = AF * NB;
+#else
+  constexpr int kReads = AF / 2 + NB / 2, kMfma = AF * NB;
+#endif
+#ifdef VB_GEMM_MFMA_FIRST
+  // the reads are spread over the first two thirds of the step's MFMAs, so that the last of them has a third of
+  // the step (>= 7 MFMAs = 112 cycles of this wave alone) to land before the boundary wait
+  constexpr int kPer = (2 * kMfma / 3) / kReads > 0 ? (2 * kMfma / 3) / kReads : 1;
+#else
   constexpr int kPer = kMfma / kReads;
+#endif
   constexpr int kAhead = STAGES - 1;          // slabs in flight ahead of the one being multiplied
   auto interleave = [&]() __attribute__((always_inline)) {
+#ifdef VB_GEMM_MFMA_FIRST
+    // MFMAs first: a k-step opens with the (compiler-placed) wait for ITS operands and its first MFMAs, and only
+    // then issues the first read for the step after -- a read in front of that wait would be waited for as well
+#pragma unroll
+    for (int i = 0; i < kReads; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kPer * kReads, 0);
+#else
 #pragma unroll
     for (int i = 0; i < kReads; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kPer * kReads, 0);
+#endif
+#ifdef VB_GEMM_STEP_FENCE
+    // nothing of the next k-step is scheduled into this one: without the fence the compiler hoists the next step's
+    // first A read above the step boundary, right in front of the boundary's s_waitcnt lgkmcnt(0), which then waits
+    // for a read nobody needs yet (one exposed LDS round trip per k-step)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   };
   // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
   auto wait_vm = [&](auto n) __attribute__((always_inline)) {
@@ -239,11 +302,24 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGE
 #ifdef VB_GEMM_CLOCK
     dbg_t1 = clock64();
 #endif
+    // Two (or three) workgroups share a CU, one wave of each per SIMD, and the SIMD's issue arbiter serves the
+    // oldest wave first: left alone, the older workgroup runs at its single-wave pace, the younger one gets the
+    // gaps, and after the older one is gone the younger finishes alone at ~60 % matrix-pipe utilisation (measured:
+    // workgroup lifetimes of 100 and 140 us side by side in the dense 4096 x 1024 x 1024 product).  Alternating the
+    // wave priority slab by slab, in opposite phase for the two generations of workgroups, lets them progress at
+    // the same pace and finish together.
+    const int prio_phase = g.prio_div > 0 ? (int)((blockIdx.x + gridDim.x * blockIdx.z) / (unsigned)g.prio_div) & 1 : -1;
     for (int s = 0; s < nslabs; ++s) {
+      if (prio_phase >= 0) {
+        if ((s ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
       const int st1 = st == kStages - 1 ? 0 : st + 1;
       const int st_new = kAhead == 2 ? (st1 == kStages - 1 ? 0 : st1 + 1) : st1;   // the stage slab s + kAhead goes to
       if (s + kAhead < nslabs) advance();   // beyond the end: re-fetch the last slab into a free stage
+#ifndef VB_ABL_NO_DMA     // timing ablations (tools/gemm_bench.hip): results are wrong with any of them defined
       issue(st_new);
+#endif
       if constexpr (kColsum) {
         if (cs_wg) {
           const double* as = As + st * kATile;
@@ -262,10 +338,16 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGE
           interleave();
         }
       }
+#ifndef VB_ABL_NO_DMA
       wait_vm(std::integral_constant<int, UPW*(kAhead - 1)>());     // slab s + 1 has landed (this wave's share)
+#endif
+#ifndef VB_ABL_NO_LGKM
       __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's reads of stage st are done
+#endif
       __asm__ volatile("" ::: "memory");
+#ifndef VB_ABL_NO_BARRIER
       __builtin_amdgcn_s_barrier();
+#endif
       __asm__ volatile("" ::: "memory");
       if (!idle_wave) {
         load_frags(st1, 0, KS & 1);
@@ -299,8 +381,8 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGE
   for (int a = 0; a < AF; ++a)
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      const int row = m0 + wm * (16 * AF) + a * 16 + 4 * fblk + fk;
-      const int col = n0 + wn * (4 * NB) + 4 * ((fblk + r) & (NB - 1)) + fj;
+      const int row = m0 + frag_row(a, 4 * fblk + fk);      // output lane (slot fblk, row fk, column fj)
+      const int col = n0 + frag_col(r, fblk, fj);
       if (row < g.M && col < g.N) {
         if constexpr (EpiReduces<Epi>::value)
           local += epi((int)blockIdx.z, row, col, acc[a][r]);
