@@ -331,7 +331,6 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
     const double* __restrict__ colpart, int n_rb, int64_t ldz, const double* __restrict__ fpart, int n_fpart,
     FrSums S, const double* __restrict__ theta, double n_local_w, double n_total, double c0,
     double* __restrict__ out, int pd, FrWeighted wm, const double* __restrict__ tr_mean) {
-  __shared__ double sh[4];
   const double ent = pd ? 0.0 : 1.0;      // the entropy's -1 on the free diagonal (absent with the path derivative)
   // weighted mode (AlphaDivergence, objectives.py:458-460): the rows of G carried the weights s_n, the result is
   // scale * [sum s g | tril(sum s g eps') with the free diagonal x L_ii + sum s], the value comes from wm.value
@@ -396,39 +395,73 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
     }
   }
   if (blockIdx.x == 0) {
-    double f = 0.0;
-    for (int e = threadIdx.x; e < n_fpart; e += 256) f += fpart[e];
-    f = fr_block_sum(f, sh);
-    if (tr_mean) {    // fpart holds the partials of sum_ij L_ij C_ij (EpiSplitSlabTrace): F = 1/2 (that + (mu - m)' colsum)
-      double dot = 0.0;
-      for (int c = threadIdx.x; c < d; c += 256) {
-        double cs = 0.0;
-        for (int rb0 = 0; rb0 < n_rb; rb0 += 8) {      // eight loads in flight, summed in split order
-          double v[8];
+    // The scalar tail: sum of the f partials, (mu - m)' colsum for the trace form, sum of the log-diagonal.  One
+    // workgroup, so it is written for latency: every load of a pass is requested before anything is summed (the
+    // three quantities used to be three dependent load -> reduce -> barrier rounds, 8.5 us of the kernel's 13.7 at
+    // D = 1024; the per-thread and cross-thread summation orders are unchanged), and the three block sums share one
+    // pair of barriers.
+    const int tx = threadIdx.x;
+    double f = 0.0, dot = 0.0, t = 0.0;
+    for (int e0 = 0; e0 < n_fpart; e0 += 4 * 256) {
+      double v[4];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = rb0 + u < n_rb ? colpart[(int64_t)(rb0 + u) * ldz + c] : 0.0;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) cs += v[u];
-        }
-        dot = fma(theta[c] - tr_mean[c], cs, dot);
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256 + tx;
+        v[u] = e < n_fpart ? fpart[e] : 0.0;
       }
-      __syncthreads();
-      dot = fr_block_sum(dot, sh);
-      f = 0.5 * (f + dot);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f += v[u];
     }
-    if (FUSE) {
-      __syncthreads();
-      double t = 0.0;
-      for (int i = threadIdx.x; i < d; i += 256) t += theta[d + (int64_t)i * (i + 1) / 2 + i];
-      const double sum_logdiag = fr_block_sum(t, sh);
-      if (threadIdx.x == 0) {
+    for (int c0 = 0; c0 < d; c0 += 4 * 256) {
+      double th[4], tm[4], dg[4], cs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 256 + tx, cc = c < d ? c : 0;
+        th[u] = theta[cc];
+        tm[u] = tr_mean ? tr_mean[cc] : 0.0;
+        dg[u] = FUSE ? theta[d + (int64_t)cc * (cc + 1) / 2 + cc] : 0.0;
+        cs[u] = 0.0;
+      }
+      if (tr_mean) {
+        for (int rb0 = 0; rb0 < n_rb; rb0 += 8) {      // 4 columns x 8 splits in flight, summed in split order
+          double v[4][8];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 256 + tx, cc = c < d ? c : 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[u][q] = rb0 + q < n_rb ? colpart[(int64_t)(rb0 + q) * ldz + cc] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs[u] += v[u][q];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (c0 + u * 256 + tx < d) {
+          dot = fma(th[u] - tm[u], cs[u], dot);
+          t += dg[u];
+        }
+      }
+    }
+    __shared__ double sh3[12];
+    f = fr_wave_sum(f), dot = fr_wave_sum(dot), t = fr_wave_sum(t);
+    if ((tx & 63) == 0) sh3[tx >> 6] = f, sh3[4 + (tx >> 6)] = dot, sh3[8 + (tx >> 6)] = t;
+    __syncthreads();
+    if (tx == 0) {
+      f = (sh3[0] + sh3[1]) + (sh3[2] + sh3[3]);
+      dot = (sh3[4] + sh3[5]) + (sh3[6] + sh3[7]);
+      const double sum_logdiag = (sh3[8] + sh3[9]) + (sh3[10] + sh3[11]);
+      if (tr_mean) f = 0.5 * (f + dot);   // fpart holds the partials of sum_ij L_ij C_ij (EpiSplitSlabTrace): F = 1/2 (that + (mu - m)' colsum)
+      if (FUSE) {
         const double F = f + n_local_w * c0;
         const double half_sq = pd ? 0.5 * S.sums[1] * invN : 0.5 * d;    // 1/2 mean ||eps||^2 or its expectation
         const double H = half_sq + 0.5 * d * kLog2PiFr + sum_logdiag;
         out[0] = weighted ? wm.value[0] : -(F * invN + H);
+      } else {
+        S.sums[0] = f;
       }
-    } else if (threadIdx.x == 0) {
-      S.sums[0] = f;
     }
   }
 }
