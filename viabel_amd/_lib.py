@@ -208,13 +208,18 @@ class Engine:
 
     def __init__(self, device=None):
         self._lib = load()
-        if device is None:
+        from_env = device is None
+        if from_env:
             device = int(os.environ.get('LOCAL_RANK', '0'))
         n = ctypes.c_int(0)
         rc = self._lib.vb_device_count(ctypes.byref(n))
         if rc != VB_OK or n.value == 0:
             raise EngineError('no MI355X visible to HIP (%s); the engine has no CPU fallback'
                               % self._lib.vb_last_error(None).decode())
+        if from_env and device >= n.value == 1 and any(
+                os.environ.get(v) for v in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')):
+            # a launcher that masks the devices per rank: this rank's one visible GPU is its own
+            device = 0
         ctx = _ctx_p()
         # no wrap-around: a rank whose LOCAL_RANK has no GPU must fail, not share another rank's device
         rc = self._lib.vb_create(int(device), ctypes.byref(ctx))

@@ -385,9 +385,12 @@ __device__ __forceinline__ BisectWalk bisect_replay(double lower, double upper, 
 // would be six dependent loads of freshly written lines)
 __device__ __forceinline__ BisectWalk bisect_stage_replay(double* tab, const double* __restrict__ res_in,
                                                           const double* __restrict__ state_in, int prev_levels,
-                                                          double ess_target) {
+                                                          double ess_target, double eps_prev) {
   for (int e = threadIdx.x; e < kLookTab; e += blockDim.x) tab[e] = prev_levels > 0 ? res_in[e] : 0.0;
-  if (threadIdx.x < 3) tab[kLookTab + threadIdx.x] = state_in[threadIdx.x];
+  // first round: the interval [0, eps_guess] (:346) comes as a kernel argument (an upload of it would put a host
+  // synchronisation in the middle of the refresh)
+  if (threadIdx.x < 3)
+    tab[kLookTab + threadIdx.x] = prev_levels > 0 ? state_in[threadIdx.x] : (threadIdx.x == 1 ? eps_prev : 0.0);
   __syncthreads();
   return bisect_replay(tab[kLookTab], tab[kLookTab + 1], (int)tab[kLookTab + 2], prev_levels, tab, ess_target);
 }
@@ -456,11 +459,11 @@ __global__ void __launch_bounds__(1024) dis_bisect_round_kernel(const double* __
                                                                 const double* __restrict__ state_in,
                                                                 const double* __restrict__ res_in,
                                                                 double* __restrict__ state_out,
-                                                                double* __restrict__ res_out) {
+                                                                double* __restrict__ res_out, double eps_prev) {
   __shared__ double sh[48];
   __shared__ double tab[kLookTab + 4];
   const double sum_ls = scal_in[0];
-  const BisectWalk wk = bisect_stage_replay(tab, res_in, state_in, prev_levels, ess_target);
+  const BisectWalk wk = bisect_stage_replay(tab, res_in, state_in, prev_levels, ess_target, eps_prev);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     state_out[0] = wk.lower;
     state_out[1] = wk.upper;
@@ -492,12 +495,12 @@ __global__ void __launch_bounds__(1024) dis_bisect_final_kernel(const double* __
                                                                 const double* __restrict__ state_in,
                                                                 const double* __restrict__ res_in, double max_eps,
                                                                 double* __restrict__ w, double* __restrict__ lq_out,
-                                                                double* __restrict__ scal_out) {
+                                                                double* __restrict__ scal_out, double eps_prev) {
   __shared__ double sh[48];
   __shared__ double tab[kLookTab + 4];
   __shared__ double tot[3];
   const double sum_ls = scal_in[0];
-  const BisectWalk wk = bisect_stage_replay(tab, res_in, state_in, prev_levels, ess_target);
+  const BisectWalk wk = bisect_stage_replay(tab, res_in, state_in, prev_levels, ess_target, eps_prev);
   const double guess = (wk.lower + wk.upper) / 2.0;
   bisect_sums<true>(lp, b, lprior, sum_ls, guess, 0, n, w, lq_out, sh, tot);
   if (threadIdx.x == 0) {
@@ -521,22 +524,19 @@ int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const dou
   double* state = (double*)ctx->bisect_work.ptr;
   double* res = state + (size_t)(rounds + 1) * 4;
   hipStream_t st = ctx->stream;
-  const double init[3] = {0.0, eps_prev, 0.0};      // lower, upper = eps_guess (:346)
-  VB_HIP(ctx, hipMemcpyAsync(state, init, sizeof init, hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));              // `init` is on the stack
   int prev_levels = 0;
   for (int r = 0; r < rounds; ++r) {
     const int levels = max_its - r * kLook < kLook ? max_its - r * kLook : kLook;
     hipLaunchKernelGGL(dis_bisect_round_kernel, dim3((unsigned)(((1 << levels) - 1) * kLookParts)), dim3(1024), 0, st,
                        lp, b, lprior, scal_in, n, ess_target, prev_levels, levels, (const double*)(state + 4 * r),
                        (const double*)(res + (size_t)(r > 0 ? r - 1 : 0) * kLookTab), state + 4 * (r + 1),
-                       res + (size_t)r * kLookTab);
+                       res + (size_t)r * kLookTab, eps_prev);
     prev_levels = levels;
   }
   hipLaunchKernelGGL(dis_bisect_final_kernel, dim3(1), dim3(1024), 0, st, lp, b, lprior, scal_in, n, ess_target,
                      prev_levels, (const double*)(state + 4 * rounds),
                      (const double*)(res + (size_t)(rounds > 0 ? rounds - 1 : 0) * kLookTab), 1.0, w, lq_out,
-                     scal_out);
+                     scal_out, eps_prev);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
