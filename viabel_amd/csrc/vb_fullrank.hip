@@ -792,7 +792,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   const int tiles = gemm_tiles(D, 128);
   const int lower_tiles = mvt ? tiles * tiles : tiles * (tiles + 1) / 2;
   int splits = n_cu / lower_tiles;   // one wave of workgroups: no second, mostly empty round
-  const int max_splits = (int)(n / 256) > 0 ? (int)(n / 256) : 1;
+  static const int split_rows = getenv("VB_FR_SPLIT_ROWS") ? atoi(getenv("VB_FR_SPLIT_ROWS")) : 256;
+  const int max_splits = (int)(n / split_rows) > 0 ? (int)(n / split_rows) : 1;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const int n_rb = (int)((n + 127) / 128);
