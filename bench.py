@@ -465,9 +465,10 @@ def main():
                                    '(the dominant kernel of the evaluation)' % (head['n_rows'], FR_D, FR_D),
                          'achieved': mg['achieved'], 'frac': mg['frac'], 'avg_kernel_us': mg['avg_kernel_us'],
                          'launches_timed': mg['launches_timed'], 'flops_per_launch': mg['flops_per_launch'],
-                         'peak_source': 'datasheet fp64 matrix = 128 flop/clk/CU x 256 CUs x 2.4 GHz; the part sustains '
-                                        '~1.93 GHz under this kernel with random operands (tools/gemm_bench.hip), '
-                                        'i.e. a clock-limited ceiling of ~63 TFLOP/s'})
+                         'peak_source': 'datasheet fp64 matrix = 128 flop/clk/CU x 256 CUs x 2.4 GHz; a stream of independent '
+                                        'v_mfma_f64_4x4x4_4b_f64 measures 77.3 TFLOP/s (tools/mfma_barrier_probe.hip); under this '
+                                        'kernel the part sustains 2.37-2.39 GHz at ~1300 W of its 1400 W limit '
+                                        '(profiles/r02_power_clock.txt; 1.85-1.95 GHz only in the first milliseconds of a burst)'})
         else:
             we = head['whole_evaluation']
             roof.update({'kernel': 'whole evaluation', 'achieved': we['achieved'], 'frac': we['frac']})
