@@ -208,3 +208,26 @@ def test_host_blas_thread_policy(monkeypatch):
         assert blas_threads() == [1]
     threadpoolctl.threadpool_limits(limits=max(before), user_api='blas')      # back to the session's setting
     assert blas_threads() == before
+
+
+def test_shared_choice_is_numpy_choice():
+    """The resampling draw of DISInclusiveKL (objectives.py:408) skips np.random.choice's argument checks but must
+    consume the global stream and pick the indices exactly as it does."""
+    from viabel_amd.objectives import _shared_choice
+
+    class _OneRank:
+        n_ranks = 1
+    rng = np.random.RandomState(3)
+    for n, size in ((16384, 2048), (100, 7), (5, 50)):
+        w = rng.rand(n) ** 4
+        p = w / w.sum()
+        np.random.seed(11)
+        want = np.random.choice(n, size=size, p=p)
+        after_want = np.random.random_sample()
+        np.random.seed(11)
+        got = _shared_choice(_OneRank(), n, size, p)
+        after_got = np.random.random_sample()
+        np.testing.assert_array_equal(got, want)
+        assert after_got == after_want
+    with pytest.raises(ValueError):
+        _shared_choice(_OneRank(), 4, 2, np.ones(3) / 3)
