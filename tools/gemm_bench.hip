@@ -246,7 +246,7 @@ int main(int argc, char** argv) {
     {
       std::vector<long long> o(8 * 4096);
       hipMemcpyFromSymbol(o.data(), HIP_SYMBOL(vb_gemm_dbg), o.size() * sizeof(long long));
-      const int nb = (mode == 'g' || mode == 'G' || mode == 'D') ? (int)nb_mode : (M / ((cfg == 3 || cfg == 4) ? 64 : 128)) * (N / (cfg == 1 ? 128 : 64));
+      const int nb = (mode == 'g' || mode == 'G' || mode == 'D') ? (int)nb_mode : (M / ((cfg == 3 || cfg == 4) ? 64 : 128)) * (N / ((cfg == 1 || cfg == 6) ? 128 : 64));
       const int nw = 4 * (nb < 1024 ? nb : 1024);
       double pro = 0, loop = 0, epi = 0, wall = 0, first = 1e30, last = 0;
       for (int i = 0; i < nw; ++i) {

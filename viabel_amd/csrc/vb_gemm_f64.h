@@ -352,7 +352,7 @@ inline long gemm_count_blocks(const GemmArgs& g, int bm_rows, int bn_cols) {
 }
 
 // cfg: 0 = automatic, 1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 64 block tiles (three LDS stages);
-//      4 = 64 x 64, 5 = 128 x 64 with two LDS stages (more workgroups per CU); LDS-DMA kernel only
+//      4 = 64 x 64, 5 = 128 x 64, 6 = 128 x 128 with two LDS stages (more workgroups per CU); LDS-DMA kernel only
 // flags bit 0: force the register-staged kernel
 // does a product of this shape go to the LDS-DMA kernel (which alone implements EpiColsum)?
 inline bool gemm_uses_dma(const GemmArgs& g) {
@@ -368,7 +368,7 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
   int ks = g.batch ? g.K : gemm_tiles(g.K, splits);   // batch mode: `splits` is the number of products
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
   static const int cfg_env = getenv("VB_GEMM_CFG") ? atoi(getenv("VB_GEMM_CFG")) : 0;   // experiments: force a tile
-  if (cfg == 0 && cfg_env >= 1 && cfg_env <= 5) cfg = cfg_env;
+  if (cfg == 0 && cfg_env >= 1 && cfg_env <= 6) cfg = cfg_env;
   // operands straight into LDS (vb_gemm_f64_dma.h) when every k range is a whole number of slabs
   const bool dma = gemm_uses_dma(g) && !(flags & 1);
   if (cfg == 0) {
@@ -378,6 +378,12 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
       // 4096 x 1024 x 1024 (tools/gemm_bench.hip; pairing a long and a short block inside one workgroup measured
       // the same 85.9 us, so the simpler launch order is kept)
       cfg = 3;
+    } else if (dma && g.tri_mode == 0 && g.batch == 0 && gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) {
+      // large dense products: 128 x 128 tiles with TWO LDS stages (64 KB: two workgroups per CU).  Per MFMA a third
+      // fewer fragment reads and LDS-DMA pieces than 128 x 64: 69.3 - 70.2 against 66.0 - 67.5 TFLOP/s on
+      // 4096 x {2048, 4096, 8192} x {2000 ... 4096} (tools/gemm_bench.hip).  Below two tiles per CU it loses
+      // (4096 x 1024 x 1024: 148 against 136 us), and the three-stage variant (96 KB, one workgroup per CU) always did
+      cfg = 6;
     } else if (!dma && gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) {
       // largest tile that gives every CU two workgroups; the LDS-DMA kernel's 128 x 128 tile needs 96 KB of LDS
       // (one workgroup per CU) and measures slower than its 128 x 64 tile at every shape tried, so it is skipped
@@ -388,8 +394,8 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
       cfg = 3;
     }
   }
-  if (!dma && cfg > 3) cfg = cfg == 4 ? 3 : 2;
-  const int bm_rows = (cfg == 3 || cfg == 4) ? 64 : 128, bn_cols = cfg == 1 ? 128 : 64;
+  if (!dma && cfg > 3) cfg = cfg == 4 ? 3 : cfg == 6 ? 1 : 2;
+  const int bm_rows = (cfg == 3 || cfg == 4) ? 64 : 128, bn_cols = (cfg == 1 || cfg == 6) ? 128 : 64;
   g.tiles_m = gemm_tiles(g.M, bm_rows);
   g.tiles_n = gemm_tiles(g.N, bn_cols);
   const dim3 grid(g.tile_map ? (unsigned)g.tile_blocks : (unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1,
@@ -401,6 +407,7 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
     else if (cfg == 2) gemm_f64_dma_launch<A_KCONTIG, 4, 8, 3, Epi>(st, g, grid, epi);
     else if (cfg == 3) gemm_f64_dma_launch<A_KCONTIG, 2, 8, 3, Epi>(st, g, grid, epi);
     else if (cfg == 4) gemm_f64_dma_launch<A_KCONTIG, 2, 8, 2, Epi>(st, g, grid, epi);
+    else if (cfg == 6) gemm_f64_dma_launch<A_KCONTIG, 4, 16, 2, Epi>(st, g, grid, epi);
     else gemm_f64_dma_launch<A_KCONTIG, 4, 8, 2, Epi>(st, g, grid, epi);
     return grid.x;
   }

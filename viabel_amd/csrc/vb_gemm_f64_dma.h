@@ -29,7 +29,7 @@ typedef __attribute__((address_space(1))) const void* gemm_gptr;
 typedef __attribute__((address_space(3))) void* gemm_lptr;
 
 template <bool A_KCONTIG, int AF, int NB, int STAGES, class Epi>
-__global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : (AF * NB > 16 || STAGES > 2 ? 2 : 4))
+__global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF * NB > 16 || STAGES > 2 ? 2 : 4))
     gemm_f64_dma_kernel(const GemmArgs g, const Epi epi) {
   constexpr int BM = 32 * AF, BN = 8 * NB;
   constexpr int kStages = STAGES;
