@@ -97,6 +97,17 @@ struct EpiStoreZ {          // Z = acc [* rs_n] + mu - shift   (shift = 0, or th
     if (shift) z -= shift[col];
     Z[(int64_t)row * ldz + col] = z;
   }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    if (rs) a0 *= rs[row], a1 *= rs[row];
+    const d2v m = *reinterpret_cast<const d2v*>(mu + col);
+    d2v z = (d2v){a0 + m.x, a1 + m.y};
+    if (shift) {
+      const d2v sh = *reinterpret_cast<const d2v*>(shift + col);
+      z.x -= sh.x, z.y -= sh.y;
+    }
+    *reinterpret_cast<d2v*>(Z + (int64_t)row * ldz + col) = z;
+    return z;
+  }
 };
 
 // regression targets (VB_MODEL_LOGISTIC with a VB_GLM_* likelihood): eta = Z X' -> R = dloglik / deta and the
@@ -137,6 +148,11 @@ struct EpiNegate {          // G = -acc   (gauss_full: G = -(Z - m) P)
   __device__ void operator()(int, int row, int col, double acc) const {
     G[(int64_t)row * ldz + col] = -acc;
   }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    const d2v v = (d2v){-a0, -a1};
+    *reinterpret_cast<d2v*>(G + (int64_t)row * ldz + col) = v;
+    return v;
+  }
 };
 
 struct EpiSplitSlab {       // C_split[i][j] = acc
@@ -144,6 +160,11 @@ struct EpiSplitSlab {       // C_split[i][j] = acc
   int64_t ldc, slab;
   __device__ void operator()(int split, int row, int col, double acc) const {
     C[split * slab + (int64_t)row * ldc + col] = acc;
+  }
+  __device__ d2v pair(int split, int row, int col, double a0, double a1) const {
+    const d2v v = (d2v){a0, a1};
+    *reinterpret_cast<d2v*>(C + split * slab + (int64_t)row * ldc + col) = v;
+    return v;
   }
 };
 
@@ -162,6 +183,11 @@ struct EpiSplitSlabTrace {
   __device__ double operator()(int split, int row, int col, double acc) const {
     C[split * slab + (int64_t)row * ldc + col] = acc;
     return col <= row ? acc * Lt[(int64_t)col * ldl + row] : 0.0;
+  }
+  __device__ d2v pair(int split, int row, int col, double a0, double a1) const {
+    *reinterpret_cast<d2v*>(C + split * slab + (int64_t)row * ldc + col) = (d2v){a0, a1};
+    return (d2v){col <= row ? a0 * Lt[(int64_t)col * ldl + row] : 0.0,
+                 col + 1 <= row ? a1 * Lt[(int64_t)(col + 1) * ldl + row] : 0.0};
   }
 };
 

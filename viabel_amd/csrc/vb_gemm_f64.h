@@ -81,6 +81,17 @@ struct EpiReduces<E, std::void_t<decltype(std::declval<E>().part)>> : std::true_
 // the column sums of A over the workgroup's k range, colsum[blockIdx.z * colsum_ld + m] = sum_k A[k][m], written by the
 // workgroups of column block 0 (one per row block and split): the operand tiles are in LDS anyway, so the sums cost
 // a few LDS reads per slab in the shadow of the MFMAs instead of another pass over A.
+// EpiPairs: epilogues that can take two horizontally adjacent elements at once --
+//   d2v pair(int split, int row, int col, double acc0, double acc1) const   (col even, col + 1 < N)
+// stores (row, col) and (row, col + 1) as one 16-byte access and returns what operator() would have returned for each
+// (ignored by non-reducing epilogues).  The LDS-DMA kernel's fragment assignment puts fragments 2q and 2q + 1 of a lane
+// on adjacent columns, so its epilogue issues half the store instructions, each lane covering 16 contiguous bytes.
+// Output bases are 256-B aligned and every row stride is even (round_up(., 16)), which is what the access relies on.
+template <class E, class = void>
+struct EpiPairs : std::false_type {};
+template <class E>
+struct EpiPairs<E, std::void_t<decltype(std::declval<E>().pair(0, 0, 0, 0.0, 0.0))>> : std::true_type {};
+
 template <class E, class = void>
 struct EpiColsum : std::false_type {};
 template <class E>

@@ -384,14 +384,27 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
 #pragma unroll
   for (int a = 0; a < AF; ++a)
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
+    for (int r = 0; r < NB; r += 2) {
       const int row = m0 + frag_row(a, 4 * fblk + fk);      // output lane (slot fblk, row fk, column fj)
-      const int col = n0 + frag_col(r, fblk, fj);
-      if (row < g.M && col < g.N) {
-        if constexpr (EpiReduces<Epi>::value)
-          local += epi((int)blockIdx.z, row, col, acc[a][r]);
-        else
-          epi((int)blockIdx.z, row, col, acc[a][r]);
+      const int col = n0 + frag_col(r, fblk, fj);           // even; fragment r + 1 is column col + 1
+      if constexpr (EpiPairs<Epi>::value && AF * NB <= 32) {     // (the 128 x 128 tile has no registers to spare)
+        if (row < g.M && col + 1 < g.N) {
+          const d2v v = epi.pair((int)blockIdx.z, row, col, acc[a][r], acc[a][r + 1]);
+          if constexpr (EpiReduces<Epi>::value) {
+            local += v.x;
+            local += v.y;
+          }
+          continue;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (row < g.M && col + q < g.N) {
+          if constexpr (EpiReduces<Epi>::value)
+            local += epi((int)blockIdx.z, row, col + q, acc[a][r + q]);
+          else
+            epi((int)blockIdx.z, row, col + q, acc[a][r + q]);
+        }
       }
     }
   if constexpr (EpiReduces<Epi>::value) {

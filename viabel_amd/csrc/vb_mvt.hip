@@ -28,6 +28,12 @@ struct EpiSampleT {         // X = mu + acc / s_n
   __device__ void operator()(int, int row, int col, double acc) const {
     X[(int64_t)row * ld + col] = fma(acc, inv_s[row], mu[col]);
   }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    const double is = inv_s[row];
+    const d2v v = (d2v){fma(a0, is, mu[col]), fma(a1, is, mu[col + 1])};
+    *reinterpret_cast<d2v*>(X + (int64_t)row * ld + col) = v;
+    return v;
+  }
 };
 
 struct EpiSubVec {          // E = acc - c   (c = mu L^-T)
@@ -37,12 +43,22 @@ struct EpiSubVec {          // E = acc - c   (c = mu L^-T)
   __device__ void operator()(int, int row, int col, double acc) const {
     E[(int64_t)row * ld + col] = acc - c[col];
   }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    const d2v v = (d2v){a0 - c[col], a1 - c[col + 1]};
+    *reinterpret_cast<d2v*>(E + (int64_t)row * ld + col) = v;
+    return v;
+  }
 };
 
 struct EpiStore {
   double* U;
   int64_t ld;
   __device__ void operator()(int, int row, int col, double acc) const { U[(int64_t)row * ld + col] = acc; }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    const d2v v = (d2v){a0, a1};
+    *reinterpret_cast<d2v*>(U + (int64_t)row * ld + col) = v;
+    return v;
+  }
 };
 
 __device__ __forceinline__ double mvt_wave_sum(double x) {

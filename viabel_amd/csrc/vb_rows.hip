@@ -59,6 +59,13 @@ struct EpiGlmGradDirect {   // G = acc - z / sd^2
     const int64_t i = (int64_t)row * ldz + col;
     G[i] = fma(-ivp, Z[i], acc);
   }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    const int64_t i = (int64_t)row * ldz + col;
+    const d2v z = *reinterpret_cast<const d2v*>(Z + i);
+    const d2v v = (d2v){fma(-ivp, z.x, a0), fma(-ivp, z.y, a1)};
+    *reinterpret_cast<d2v*>(G + i) = v;
+    return v;
+  }
 };
 
 struct EpiGlmGradSlab {     // slab_split = acc
