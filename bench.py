@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet fp64 matrix peak = 256 CUs x 4 SIMDs x 512 flop / 16 clk x 2.4 GHz;
 #                                                  tools/mfma_barrier_probe.hip measures 77.3 with constant operands
 # HBM-side bytes per launch of the headline's dense model GEMM at D=1024, N=4096 (see roofline.traffic_source)
-MODEL_GEMM_HBM_BYTES = int((2 * 49216.4 + 32817.8) * 1024)
+MODEL_GEMM_HBM_BYTES = int((2 * 49212.0 + 32886.2) * 1024)
 MIN_TIMED_S = 0.05                               # the timed blocks are repeated until they cover at least this
 
 
