@@ -247,43 +247,18 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
   // interleave pattern below must ask for exactly that many DS groups: when it asked for more than a step has, the
   // scheduler filled the surplus with the NEXT step's first read, and that read then sat right in front of the step
   // boundary's s_waitcnt lgkmcnt(0) -- one exposed LDS round trip per k-step.
-#ifdef VB_GEMM_KREADS
-  constexpr int kReads = VB_GEMM_KREADS, kMfma = AF * NB;
-#else
+  // (Measured and dropped: spreading the reads over only the first two thirds of a step's MFMAs, and a scheduling
+  // fence at the step boundary -- DESIGN 4.3.)
   constexpr int kReads = AF / 2 + NB / 2, kMfma = AF * NB;
-#endif
-#ifdef VB_GEMM_MFMA_FIRST
-  // the reads are spread over the first two thirds of the step's MFMAs, so that the last of them has a third of
-  // the step (>= 7 MFMAs = 112 cycles of this wave alone) to land before the boundary wait
-  constexpr int kPer = (2 * kMfma / 3) / kReads > 0 ? (2 * kMfma / 3) / kReads : 1;
-#else
   constexpr int kPer = kMfma / kReads;
-#endif
   constexpr int kAhead = STAGES - 1;          // slabs in flight ahead of the one being multiplied
   auto interleave = [&]() __attribute__((always_inline)) {
-#ifdef VB_GEMM_MFMA_FIRST
-    // MFMAs first: a k-step opens with the (compiler-placed) wait for ITS operands and its first MFMAs, and only
-    // then issues the first read for the step after -- a read in front of that wait would be waited for as well
-#pragma unroll
-    for (int i = 0; i < kReads; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kPer * kReads, 0);
-#else
 #pragma unroll
     for (int i = 0; i < kReads; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, kPer, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, kMfma - kPer * kReads, 0);
-#endif
-#ifdef VB_GEMM_STEP_FENCE
-    // nothing of the next k-step is scheduled into this one: without the fence the compiler hoists the next step's
-    // first A read above the step boundary, right in front of the boundary's s_waitcnt lgkmcnt(0), which then waits
-    // for a read nobody needs yet (one exposed LDS round trip per k-step)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
   };
   // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
   auto wait_vm = [&](auto n) __attribute__((always_inline)) {
