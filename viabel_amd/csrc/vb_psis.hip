@@ -5,7 +5,7 @@
 // One workgroup of 1024 threads does the whole smoothing for one weight vector (N up to a few million; the
 // diagnostics use N = 1e5): max shift, exact selection of the tail cut-off (the (M+1)-th largest value,
 // M = ceil(min(0.2 N, 3 sqrt(N / Reff))), _psis.py:158) by an 8-pass byte-wise radix select on
-// order-preserving keys with an LDS histogram, gather + bitonic sort of the <= M tail values in LDS, the
+// order-preserving keys with an LDS histogram, gather + rank sort of the <= M tail values in LDS, the
 // Zhang-Stephens empirical-Bayes GPD fit (30 + sqrt(M) quadrature points), replacement of the tail by the
 // fitted quantiles, truncation at 0 and log-sum-exp normalisation.  Integer atomics only (histogram, gather
 // counter); the sorted order is by (value, index), so the result does not depend on the gather order.
@@ -75,6 +75,27 @@ __global__ void __launch_bounds__(256) psis_lw_kernel(const double* __restrict__
   if (i < n) lw[i] = f[i] - b[i] + scal[0];
 }
 
+// The passes over the N weights are one workgroup's strided loops: a thread's loads are independent, but left as
+// `for (i = t; i < n; i += 1024) use(x[i])` every trip waits out its own L2 round trip (16 trips x 8 radix passes were
+// most of the kernel's time at N = 16 384).  ps_for_each requests kPsisBatch elements before it uses the first.
+constexpr int kPsisBatch = 8;
+template <class F>
+__device__ __forceinline__ void ps_for_each(const double* __restrict__ x, int64_t n, F&& f) {
+  for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)kPsisBatch * kPsisThreads) {
+    double v[kPsisBatch];
+#pragma unroll
+    for (int u = 0; u < kPsisBatch; ++u) {
+      const int64_t i = i0 + (int64_t)u * kPsisThreads;
+      v[u] = i < n ? x[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kPsisBatch; ++u) {
+      const int64_t i = i0 + (int64_t)u * kPsisThreads;
+      if (i < n) f(i, v[u]);
+    }
+  }
+}
+
 // x: N log weights, smoothed in place.  out = [khat, n_tail, xcutoff (shifted), sigma]
 __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__ x, int64_t n, int m_tail,
                                                             double* __restrict__ out) {
@@ -91,9 +112,9 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
 
   // 1. improve numerical accuracy: x -= max(x)   (_psis.py:166)
   double mx = -INFINITY;
-  for (int64_t i = t; i < n; i += kPsisThreads) mx = fmax(mx, x[i]);
+  ps_for_each(x, n, [&](int64_t, double v) { mx = fmax(mx, v); });
   mx = ps_block_max(mx, sh);
-  for (int64_t i = t; i < n; i += kPsisThreads) x[i] -= mx;
+  ps_for_each(x, n, [&](int64_t i, double v) { x[i] = v - mx; });
   __syncthreads();
 
   // 2. x_sorted[n - m_tail - 1] by radix select (8 bits per pass, most significant first)   (:170-173)
@@ -106,20 +127,34 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
     __syncthreads();
     const unsigned long long prefix = sel_prefix;
     const unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
-    for (int64_t i = t; i < n; i += kPsisThreads) {
-      const unsigned long long k = ps_key(x[i]);
+    ps_for_each(x, n, [&](int64_t, double v) {
+      const unsigned long long k = ps_key(v);
       if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> (8 * pass)) & 255ull)], 1);
-    }
+    });
     __syncthreads();
-    if (t == 0) {
-      long long r = sel_rank;
-      int bin = 0;
-      for (; bin < 255; ++bin) {
-        if (r < hist[bin]) break;
-        r -= hist[bin];
+    if (wave == 0) {
+      // the bin that holds rank r: wave 0 scans the 256 counts, four consecutive bins per lane (a serial walk by one
+      // thread was 3.5 us of every pass)
+      const long long r = sel_rank;
+      const int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+      long long incl = (long long)c0 + c1 + c2 + c3;          // inclusive prefix over lanes
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const long long up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
       }
-      sel_rank = r;
-      sel_prefix = prefix | ((unsigned long long)bin << (8 * pass));
+      const long long excl = incl - ((long long)c0 + c1 + c2 + c3);
+      // exactly one lane has excl <= r < incl (the total is > r); the last lane also takes r beyond the total's reach
+      const bool mine = (excl <= r && r < incl) || (lane == 63 && r >= incl);
+      if (mine) {
+        long long rr = r - excl;
+        int bin = 4 * lane;
+        if (rr >= c0 && bin < 255) { rr -= c0; ++bin;
+          if (rr >= c1 && bin < 255) { rr -= c1; ++bin;
+            if (rr >= c2 && bin < 255) { rr -= c2; ++bin; } } }
+        sel_rank = rr;
+        sel_prefix = prefix | ((unsigned long long)bin << (8 * pass));
+      }
     }
     __syncthreads();
   }
@@ -130,8 +165,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   // 3. right tail: x > xcutoff   (:175-177)
   if (t == 0) tail_count = 0;
   __syncthreads();
-  for (int64_t i = t; i < n; i += kPsisThreads) {
-    const double v = x[i];
+  ps_for_each(x, n, [&](int64_t i, double v) {
     if (v > xcutoff) {
       const int p = atomicAdd(&tail_count, 1);
       if (p < kPsisTailCap) {
@@ -139,34 +173,40 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
         ti[p] = (int)i;
       }
     }
-  }
+  });
   __syncthreads();
   const int n2 = tail_count < kPsisTailCap ? tail_count : kPsisTailCap;
   double k = INFINITY, sigma = NAN;
   if (n2 > 4) {                                                 // :178-180
-    // 4. order of the tail samples: bitonic sort by (value, index), padded with +inf
-    int P = 1;
-    while (P < n2) P <<= 1;
-    for (int i = n2 + t; i < P; i += kPsisThreads) {
-      tv[i] = INFINITY;
-      ti[i] = 0x7fffffff;
+    // 4. order of the tail samples by (value, index): every element counts the elements before it (n2^2 / 1024
+    // comparisons per thread on LDS broadcasts: 0.15 M in all at n2 = 384) and moves to that position -- two
+    // barriers instead of the 45 of a bitonic network
+    constexpr int kPerThread = kPsisTailCap / kPsisThreads;
+    double my_v[kPerThread];
+    int my_i[kPerThread], my_r[kPerThread];
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int e = t + u * kPsisThreads;
+      my_v[u] = e < n2 ? tv[e] : INFINITY;
+      my_i[u] = e < n2 ? ti[e] : 0x7fffffff;
+      my_r[u] = 0;
+    }
+    for (int j = 0; j < n2; ++j) {
+      const double v = tv[j];
+      const int ix = ti[j];
+#pragma unroll
+      for (int u = 0; u < kPerThread; ++u)
+        if (u * kPsisThreads < n2) my_r[u] += ps_after(my_v[u], my_i[u], v, ix) ? 1 : 0;     // (uniform condition)
     }
     __syncthreads();
-    for (int size = 2; size <= P; size <<= 1) {
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int e = t; e < (P >> 1); e += kPsisThreads) {
-          const int lo = ((e / stride) * 2 * stride) + (e % stride), hi = lo + stride;
-          const bool up = (lo & size) == 0;
-          const double av = tv[lo], bv = tv[hi];
-          const int ai = ti[lo], bi = ti[hi];
-          if (ps_after(av, ai, bv, bi) == up) {
-            tv[lo] = bv, tv[hi] = av;
-            ti[lo] = bi, ti[hi] = ai;
-          }
-        }
-        __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      if (t + u * kPsisThreads < n2) {
+        tv[my_r[u]] = my_v[u];
+        ti[my_r[u]] = my_i[u];
       }
     }
+    __syncthreads();
     // x2 = exp(x2) - exp(xcutoff)   (:185-186)
     for (int i = t; i < n2; i += kPsisThreads) tv[i] = exp(tv[i]) - expxc;
     __syncthreads();
@@ -229,13 +269,13 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
 
   // 7. renormalise: x -= sumlogs(x)   (:201, :380-396)
   double m2 = -INFINITY;
-  for (int64_t i = t; i < n; i += kPsisThreads) m2 = fmax(m2, x[i]);
+  ps_for_each(x, n, [&](int64_t, double v) { m2 = fmax(m2, v); });
   m2 = ps_block_max(m2, sh);
   double se = 0.0;
-  for (int64_t i = t; i < n; i += kPsisThreads) se += exp(x[i] - m2);
+  ps_for_each(x, n, [&](int64_t, double v) { se += exp(v - m2); });
   se = ps_block_sum(se, sh);
   const double lse = log(se) + m2;
-  for (int64_t i = t; i < n; i += kPsisThreads) x[i] -= lse;
+  ps_for_each(x, n, [&](int64_t i, double v) { x[i] = v - lse; });
   if (t == 0) {
     out[0] = k;
     out[1] = (double)tail_count;
