@@ -31,6 +31,13 @@ struct EpiStoreWT {
   }
 };
 __global__ void empty_kernel(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
+// tri_mode 1's contract: B[k][j] == 0 for k > j (the kernel may skip what the contract says is zero)
+__global__ void make_upper_kernel(const double* src, double* dst, int64_t ld, int K, int N) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)K * ld) return;
+  const int k = (int)(i / ld), j = (int)(i % ld);
+  dst[i] = (j < N && k > j) ? 0.0 : src[i];
+}
 
 struct EpiSlab {
   double* C;
@@ -307,10 +314,15 @@ int main(int argc, char** argv) {
   }
   {   // correctness of the LDS-DMA kernel against the register-staged kernel (same inputs, all three tiles)
     std::vector<double> c0((size_t)M * N), c1((size_t)M * N);
+    double* Bu;      // upper-triangular copy of B for the tri_mode 1 checks
+    hipMalloc(&Bu, (size_t)K * N * 8);
+    hipLaunchKernelGGL(make_upper_kernel, dim3((unsigned)(((size_t)K * N + 255) / 256)), dim3(256), 0, st, (const double*)B, Bu,
+                       (int64_t)N, K, N);
+    hipDeviceSynchronize();
     for (int cfg = 1; cfg <= 3; ++cfg)
       for (int tri = 0; tri <= 1; ++tri) {
         GemmArgs g;
-        g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = tri;
+        g.A = A, g.B = tri ? Bu : B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = tri;
         hipMemset(C, 0, (size_t)M * N * 8);
         gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg, 1);
         hipDeviceSynchronize();
@@ -328,7 +340,7 @@ int main(int argc, char** argv) {
       }
     for (int cfg = 4; cfg <= 5; ++cfg) {     // the two-stage kernels against the register-staged kernel
       GemmArgs g;
-      g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = 1;
+      g.A = A, g.B = Bu, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = 1;
       hipMemset(C, 0, (size_t)M * N * 8);
       gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg == 4 ? 3 : 2, 1);
       hipDeviceSynchronize();

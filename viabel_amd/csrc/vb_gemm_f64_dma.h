@@ -99,6 +99,15 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
   const int cs_m = t & (BM - 1), cs_k0 = (t / BM) * kCsRows;
   double cs = 0.0;
   const int nslabs = (k_end - k_begin) / kGemmBK;
+  // tri_mode 1: B[k][j] == 0 for k > j, so a wave whose last column is j_last has nothing to multiply in the slabs
+  // that start beyond it -- in a tile's diagonal block the waves of the left half skip the slabs of the lower half
+  // (1/34 of the MFMAs at D = 1024); like an idle wave it keeps moving operands and meeting the barriers
+  int my_nslabs = nslabs;
+  if (g.tri_mode == 1) {
+    const int j_last = n0 + wn * (4 * NB) + 4 * NB - 1;
+    const int need = (j_last - k_begin) / kGemmBK + 1;       // slabs with a k <= j_last
+    my_nslabs = need < nslabs ? (need > 0 ? need : 0) : nslabs;
+  }
 
   double acc[AF][NB];
 #pragma unroll
@@ -276,7 +285,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
     __asm__ volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __asm__ volatile("" ::: "memory");
-    if (!idle_wave) load_frags(0, 0, 0);
+    if (!idle_wave && my_nslabs > 0) load_frags(0, 0, 0);
     int st = 0;
 #ifdef VB_GEMM_CLOCK
     dbg_t1 = clock64();
@@ -309,7 +318,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
           }
         }
       }
-      if (!idle_wave) {
+      if (!idle_wave && s < my_nslabs) {
 #pragma unroll
         for (int kk = 0; kk < KS - 1; ++kk) {
           load_frags(st, kk + 1, (kk + 1) & 1);
@@ -328,7 +337,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
       __builtin_amdgcn_s_barrier();
 #endif
       __asm__ volatile("" ::: "memory");
-      if (!idle_wave) {
+      if (!idle_wave && s < my_nslabs) {
         load_frags(st1, 0, KS & 1);
         mfma_step((KS - 1) & 1);
         interleave();
