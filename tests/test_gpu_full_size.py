@@ -109,6 +109,20 @@ def test_c4_logistic_full_size_against_oracle(vb):
         assert G.rel_err(grad, og) < 1e-10, (pd, G.rel_err(grad, og))
 
 
+def test_logistic_ragged_large_tiles_against_oracle(vb):
+    """eta = Z X' of 2900 x 2950 x 48: 23 x 24 tiles of 128 x 128 -- the two-stage large-tile GEMM kernel with rows and
+    columns that end inside a tile (C4 itself only has a ragged column edge)."""
+    D, n_data, N = 48, 2950, 2900
+    X, y, theta = c4_problem(D, n_data, seed=12)
+    model, omodel = vb.LogisticRegressionModel(X, y, 10.0), omod.Logistic(X, y, 10.0)
+    approx = vb.MFGaussian(D, seed=9)
+    value, grad = vb.ExclusiveKL(approx, model, N)(theta)
+    noise = np.random.RandomState(9).randn(N, D)
+    ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omodel, theta, noise)
+    assert G.rel_err(value, ov) < 1e-12, (value, ov)
+    assert G.rel_err(grad, og) < 1e-10, G.rel_err(grad, og)
+
+
 def test_c4_logistic_optimiser_loop_full_size(vb, capsys):
     """The optimiser loop of configs[4] at full size: RMSProp iterations with fresh Philox noise through the host
     loop (one blocking objective call + numpy step per iteration, optimization.py:91-112) and through the
