@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Dev tool: RMSProp iterations of the dense Gaussian family at the headline shape (D = 1024, N = 4096, correlated-
+Gaussian target, Philox noise) through the device-resident loop (vb_fit) and through the host loop."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
