@@ -53,6 +53,8 @@ typedef struct vb_ctx vb_ctx;
 #define VB_MODEL_LOGISTIC 3    /* Bayesian logistic regression, N(0, sd) prior (not in the reference)
                                   dparams=[X(n_data x D)|y(n_data)|prior_sd], iparams=[n_data]             */
 
+#define VB_MODEL_SOURCE 4      /* a log density given as HIP source (vb_set_model_source): the adaptor for user models */
+
 /* noise kinds for vb_noise_generate */
 /* likelihoods of the regression target VB_MODEL_LOGISTIC (iparams = [n_data, link]; default Bernoulli-logit):
  * eta = x_i' b, prior b ~ N(0, prior_sd).  Gaussian: dparams carries noise_sd after prior_sd. */
@@ -105,6 +107,15 @@ int vb_chisq_get_host(vb_ctx* ctx, double* host, int64_t n);
 /* ---- model ------------------------------------------------------------------------ */
 int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams,
                  size_t n_dparams, const int64_t* iparams, size_t n_iparams);
+/* A model outside the built-in set, as device code.  Replaces what the reference does with an arbitrary Python
+ * callable and autograd (models.py:17-39; convenience.py:75 `bbvi(dim, log_density=...)`): `source` is HIP C++ that
+ * defines
+ *     __device__ double vb_log_density(const double* z, int d, const double* params, double* grad);
+ * returning f(z) for one sample z[0..d) and writing grad f to grad[0..d) unless grad is NULL.  `params` (n_params
+ * doubles: data, hyper-parameters) is uploaded with the model.  The source is compiled for this GPU with hiprtc;
+ * VB_ERR_INVALID carries the compiler's log.  Supported by ExclusiveKL over the mean-field families and the dense
+ * Gaussian family (entropy form and path derivative, no control variates) and by vb_model_logp.            */
+int vb_set_model_source(vb_ctx* ctx, int64_t dim, const char* source, const double* params, size_t n_params);
 /* f(x_n), n < N, for host x (N x D): Model.__call__ (models.py:27-39) on the device */
 int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* out_host);
 

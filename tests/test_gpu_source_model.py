@@ -1,0 +1,143 @@
+"""SourceModel (VB_MODEL_SOURCE): a log density handed to the engine as HIP device code -- the adaptor for what the
+reference does with an arbitrary Python callable and autograd (viabel/models.py:17-39, convenience.py:75).  The target
+is the robust (Student-t) regression of the reference's docs (docs/source/robust-regression.ipynb), whose Stan model
+is outside the built-in set; the oracle evaluates the same density and gradient in numpy."""
+import numpy as np
+import pytest
+
+import _golden as G
+from oracle import families as ofam, objectives as oobj
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import viabel_amd
+    from viabel_amd import _lib
+    _lib.default_engine()
+    return viabel_amd
+
+ROBUST_REGRESSION_SRC = r"""
+// params = [n, nu, s, tau | X (n x d, row-major) | y (n)]
+//   y_i ~ StudentT(nu, x_i' z, s),  z ~ N(0, tau^2 I)     (log density up to constants)
+__device__ double vb_log_density(const double* z, int d, const double* p, double* g) {
+  const int n = (int)p[0];
+  const double nu = p[1], s = p[2], tau = p[3];
+  const double* X = p + 4;
+  const double* y = X + (long long)n * d;
+  double f = 0.0;
+  for (int j = 0; j < d; ++j) {
+    f -= 0.5 * z[j] * z[j] / (tau * tau);
+    if (g) g[j] = -z[j] / (tau * tau);
+  }
+  for (int i = 0; i < n; ++i) {
+    double eta = 0.0;
+    for (int j = 0; j < d; ++j) eta += X[(long long)i * d + j] * z[j];
+    const double r = y[i] - eta, q = 1.0 + r * r / (nu * s * s);
+    f -= 0.5 * (nu + 1.0) * log(q);
+    if (g) {
+      const double c = (nu + 1.0) * r / (nu * s * s * q);
+      for (int j = 0; j < d; ++j) g[j] += c * X[(long long)i * d + j];
+    }
+  }
+  return f;
+}
+"""
+
+
+class RobustRegressionOracle:
+    def __init__(self, X, y, nu, s, tau):
+        self.X, self.y, self.nu, self.s, self.tau = X, y, nu, s, tau
+        self.dim = X.shape[1]
+
+    def logp(self, z):
+        z = np.atleast_2d(z)
+        r = self.y[None, :] - z @ self.X.T
+        q = 1.0 + r * r / (self.nu * self.s ** 2)
+        return -0.5 * np.sum(z * z, axis=1) / self.tau ** 2 - 0.5 * (self.nu + 1.0) * np.sum(np.log(q), axis=1)
+
+    def grad(self, z):
+        z = np.atleast_2d(z)
+        r = self.y[None, :] - z @ self.X.T
+        q = 1.0 + r * r / (self.nu * self.s ** 2)
+        c = (self.nu + 1.0) * r / (self.nu * self.s ** 2 * q)
+        return -z / self.tau ** 2 + c @ self.X
+
+
+def _problem(vb, D, n_data, seed=3):
+    rng = np.random.RandomState(seed)
+    X = rng.randn(n_data, D)
+    beta = rng.randn(D)
+    y = X @ beta + 0.3 * rng.standard_t(3.0, size=n_data)
+    nu, s, tau = 4.0, 0.5, 3.0
+    params = np.concatenate([[n_data, nu, s, tau], X.ravel(), y])
+    return vb.SourceModel(D, ROBUST_REGRESSION_SRC, params), RobustRegressionOracle(X, y, nu, s, tau)
+
+
+def test_source_model_call_matches_oracle(vb):
+    model, omodel = _problem(vb, 7, 40)
+    x = np.random.RandomState(0).randn(33, 7)
+    np.testing.assert_allclose(model(x), omodel.logp(x), rtol=1e-13, atol=1e-12)
+    assert model(x[0]).shape == (1,)
+
+
+@pytest.mark.parametrize('D,N,n_data', [(5, 64, 25), (24, 1000, 60), (130, 333, 40)])
+@pytest.mark.parametrize('pd', [False, True])
+def test_source_model_meanfield_against_oracle(vb, D, N, n_data, pd):
+    model, omodel = _problem(vb, D, n_data, seed=D)
+    rng = np.random.RandomState(D + N)
+    theta = np.concatenate([0.2 * rng.randn(D), -1.0 + 0.1 * rng.randn(D)])
+    for fam, ofamily in ((vb.MFGaussian(D, seed=5), ofam.MFGaussian(D)),
+                         (vb.MFStudentT(D, 8.0, seed=5), ofam.MFStudentT(D, 8.0))):
+        value, grad = vb.ExclusiveKL(fam, model, N, use_path_deriv=pd)(theta)
+        noise = ofamily.draw_noise(np.random.RandomState(5), N)
+        ov, og = oobj.exclusive_kl(ofamily, omodel, theta, noise, use_path_deriv=pd)
+        assert G.rel_err(value, ov) < 1e-12, (type(fam).__name__, value, ov)
+        assert G.rel_err(grad, og) < 1e-11, (type(fam).__name__, G.rel_err(grad, og))
+
+
+@pytest.mark.parametrize('D,N,n_data', [(6, 100, 30), (48, 512, 50), (70, 257, 33)])
+@pytest.mark.parametrize('pd', [False, True])
+def test_source_model_fullrank_against_oracle(vb, D, N, n_data, pd):
+    model, omodel = _problem(vb, D, n_data, seed=2 * D)
+    rng = np.random.RandomState(D)
+    ofr = ofam.FullRankGaussian(D)
+    L = np.tril(0.05 * rng.randn(D, D), -1) + np.diag(np.exp(-1.0 + 0.2 * rng.randn(D)))
+    theta = ofr.pack(0.1 * rng.randn(D), L)
+    value, grad = vb.ExclusiveKL(vb.FullRankGaussian(D, seed=4), model, N, use_path_deriv=pd)(theta)
+    noise = np.random.RandomState(4).randn(N, D)
+    ov, og = oobj.exclusive_kl(ofr, omodel, theta, noise, use_path_deriv=pd)
+    assert G.rel_err(value, ov) < 1e-12, (value, ov)
+    assert G.rel_err(grad, og) < 1e-11, G.rel_err(grad, og)
+
+
+def test_source_model_fit_recovers_coefficients(vb, capsys):
+    """bbvi-style use: a mean-field fit on the device (Philox noise, vb_fit) of the robust regression."""
+    from viabel_amd.optimization import RMSProp
+    D, n_data = 4, 400
+    rng = np.random.RandomState(1)
+    X = rng.randn(n_data, D)
+    beta = np.array([1.0, -2.0, 0.5, 3.0])
+    y = X @ beta + 0.2 * rng.standard_t(4.0, size=n_data)
+    params = np.concatenate([[n_data, 4.0, 0.2, 10.0], X.ravel(), y])
+    model = vb.SourceModel(D, ROBUST_REGRESSION_SRC, params)
+    obj = vb.ExclusiveKL(vb.MFGaussian(D, rng='philox', seed=2), model, 64)
+    res = RMSProp(0.05).optimize(1500, obj, np.zeros(2 * D))
+    capsys.readouterr()
+    mean = res['opt_param'][:D] if 'opt_param' in res else res['variational_param_history'][-1][:D]
+    assert np.max(np.abs(mean - beta)) < 0.1, mean
+
+
+def test_source_model_errors(vb):
+    bad = vb.SourceModel(3, '__device__ double vb_log_density(const double* z, int d) { return 0; }')   # wrong signature
+    with pytest.raises(ValueError, match='does not compile'):
+        bad(np.zeros(3))
+    ok = vb.SourceModel(3, '__device__ double vb_log_density(const double* z, int d, const double* p, double* g) '
+                           '{ double f = 0; for (int j = 0; j < d; ++j) { f -= 0.5 * z[j] * z[j]; if (g) g[j] = -z[j]; } return f; }')
+    with pytest.raises(NotImplementedError):
+        vb.AlphaDivergence(vb.MFGaussian(3), ok, 10, 2.0)
+    with pytest.raises(NotImplementedError):
+        vb.ExclusiveKL(vb.MultivariateT(3, 10), ok, 10)
+    with pytest.raises(ValueError):
+        vb.SourceModel(3, '')

@@ -20,7 +20,7 @@ VB_OK, VB_ERR_INVALID, VB_ERR_HIP, VB_ERR_UNSUPPORTED, VB_ERR_STATE, VB_ERR_NUME
 
 FAMILY_MF_GAUSSIAN, FAMILY_MF_STUDENT_T, FAMILY_FULLRANK_GAUSSIAN, FAMILY_MULTIVARIATE_T, FAMILY_LOWRANK_GAUSSIAN = \
     range(5)
-MODEL_GAUSS_DIAG, MODEL_FUNNEL, MODEL_GAUSS_FULL, MODEL_LOGISTIC = range(4)
+MODEL_GAUSS_DIAG, MODEL_FUNNEL, MODEL_GAUSS_FULL, MODEL_LOGISTIC, MODEL_SOURCE = range(5)
 GLM_BERNOULLI_LOGIT, GLM_POISSON, GLM_GAUSSIAN = range(3)
 NOISE_NORMAL, NOISE_STUDENT_T = range(2)
 FLAG_PATH_DERIV = 1
@@ -54,6 +54,7 @@ SIGNATURES = {
     'vb_noise_get_host': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_int64, ctypes.c_int64]),
     'vb_set_model': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, _c_double_p, ctypes.c_size_t,
                                     _c_int64_p, ctypes.c_size_t]),
+    'vb_set_model_source': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_char_p, _c_double_p, ctypes.c_size_t]),
     'vb_model_logp': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
     'vb_elbo_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_double, _c_double_p,
@@ -291,12 +292,18 @@ class Engine:
     # ------------------------------------------------------------------ model
     def set_model(self, spec):
         """``spec`` = (model_id, dim, dparams ndarray, iparams ndarray) from ``DeviceModel.device_spec``."""
-        model_id, dim, dparams, iparams = spec
+        model_id, dim, dparams, iparams = spec[:4]
         # models hand out the same (cached) parameter arrays every time: identity is the cache key
-        key = (model_id, dim, id(dparams), id(iparams))
+        key = (model_id, dim, id(dparams), id(iparams)) + tuple(id(x) for x in spec[4:])
         if key == self._model_key:
             return
-        self._model_arrays = (dparams, iparams)      # keep them alive so the ids stay unique
+        self._model_arrays = tuple(spec[2:])         # keep them alive so the ids stay unique
+        if model_id == MODEL_SOURCE:                 # spec = (id, dim, params, iparams (unused), source bytes)
+            params = _f64(dparams)
+            self._check(self._lib.vb_set_model_source(self._ctx, dim, spec[4], _dptr(params) if params.size else None,
+                                                      params.size))
+            self._model_key = key
+            return
         dparams = _f64(dparams)
         iparams = np.ascontiguousarray(iparams, dtype=np.int64)
         self._check(self._lib.vb_set_model(

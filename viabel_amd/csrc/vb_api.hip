@@ -206,6 +206,7 @@ int vb_destroy(vb_ctx* ctx) {
   if (!ctx) return VB_OK;
   (void)hipSetDevice(ctx->device);
   (void)sync_streams(ctx);
+  user_model_release(ctx);
   vb_comm_destroy(ctx);
   if (ctx->pipe.pre) {
     (void)hipStreamDestroy(ctx->pipe.pre);
@@ -225,7 +226,7 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->pin_host) (void)hipHostFree(ctx->pin_host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
-                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->psis_lw, &ctx->rows_work,
+                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->rows_work,
                           &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map})
     if (b->ptr) (void)hipFree(b->ptr);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
@@ -418,6 +419,13 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams, 
   }
   ctx->model = m;
   return VB_OK;
+}
+
+int vb_set_model_source(vb_ctx* ctx, int64_t dim, const char* source, const double* params, size_t n_params) {
+  if (!ctx) return VB_ERR_INVALID;
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  return user_model_set(ctx, dim, source, params, n_params);
 }
 
 int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* out_host) {

@@ -150,6 +150,9 @@ struct vb_ctx {
   vb::DeviceBuffer rowvec;              // per-row weights
   vb::DeviceBuffer fr_work;             // full-rank pipeline work buffers
   vb::DeviceBuffer lg_work;             // logistic-regression target: Z, R, G, partials
+  hipModule_t user_module = nullptr;    // VB_MODEL_SOURCE: the compiled user model (vb_usermodel.hip)
+  hipFunction_t user_fn = nullptr;
+  vb::DeviceBuffer user_params;
   vb::DeviceBuffer glm_work;            // regression targets: split-K slabs of the gradient GEMM
   vb::DeviceBuffer mvt_state;           // multivariate-t DIS: state samples X, scratch
   int64_t mvt_n = 0, mvt_d = 0, mvt_n_total = 0;
@@ -263,6 +266,11 @@ struct MfCall {
   bool* prep_done = nullptr;
 };
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
+// user model given as HIP source (vb_usermodel.hip)
+int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* params, size_t n_params);
+int user_rows_enqueue(vb_ctx* ctx, hipStream_t st, const double* Z, int64_t ldz, int64_t n, int d, double* G,
+                      int64_t ldg, double* f);
+void user_model_release(vb_ctx* ctx);
 int pipe_init(vb_ctx* ctx);
 
 // per-row log weights and AlphaDivergence (vb_rowstats.hip)

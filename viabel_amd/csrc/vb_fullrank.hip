@@ -800,7 +800,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   const bool pd = (flags & VB_FLAG_PATH_DERIV) != 0;
   if (pd && mvt) return fail(ctx, VB_ERR_UNSUPPORTED, "path derivative: dense Gaussian family only");
   const bool glm = m.id == VB_MODEL_LOGISTIC;
-  if (m.id != VB_MODEL_GAUSS_DIAG && m.id != VB_MODEL_FUNNEL && m.id != VB_MODEL_GAUSS_FULL && !glm)
+  const bool source = m.id == VB_MODEL_SOURCE;
+  if (m.id != VB_MODEL_GAUSS_DIAG && m.id != VB_MODEL_FUNNEL && m.id != VB_MODEL_GAUSS_FULL && !glm && !source)
     return fail(ctx, VB_ERR_UNSUPPORTED, "full-rank path: unsupported model id %d", m.id);
   if (m.dim != d)
     return fail(ctx, VB_ERR_INVALID, "model dimension %d != family dimension %lld", m.dim, (long long)d);
@@ -830,7 +831,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   // regression targets: the log-likelihood partials of the eta GEMM follow the column-sum kernel's f partials
   const int64_t glm_part = glm ? gemm_max_blocks(n, m.n_data) : 0;
   const int64_t ldr = glm ? round_up(m.n_data, 16) : 0;
-  const int n_fpart = m.id == VB_MODEL_FUNNEL ? (int)((n + 3) / 4) : n_rb * cs_gx + (int)glm_part;
+  const int n_fpart = m.id == VB_MODEL_FUNNEL ? (int)((n + 3) / 4) : source ? (int)n : n_rb * cs_gx + (int)glm_part;
   const int64_t slab = d * ldl;
 
   // device buffers (one allocation, carved)
@@ -968,6 +969,10 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     VB_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(fr_funnel_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)Z,
                        G, ldz, n, D, m, fpart);
+  } else if (source) {        // the user's row kernel: G and one f per sample (summed with the other f partials)
+    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, nullptr, row_scale});
+    VB_HIP(ctx, hipGetLastError());
+    VB_TRY(user_rows_enqueue(ctx, st, Z, ldz, n, D, G, ldz, fpart));
   } else if (glm) {
     gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, nullptr, row_scale});
     VB_HIP(ctx, hipGetLastError());
@@ -1034,7 +1039,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   if (!fused_sums) {
     hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
                        (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
-                       m.id == VB_MODEL_FUNNEL ? fpart + n_fpart /*unused tail*/ : fpart,
+                       (m.id == VB_MODEL_FUNNEL || source) ? fpart + n_fpart /*unused tail*/ : fpart,
                        glm ? 1.0 / (m.tau * m.tau) : 0.0);
     VB_HIP(ctx, hipGetLastError());
   }

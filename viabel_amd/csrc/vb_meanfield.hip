@@ -1213,6 +1213,50 @@ static int logistic_accumulate(vb_ctx* ctx, hipStream_t st, const ModelDev& m, c
   return VB_OK;
 }
 
+// Source model (VB_MODEL_SOURCE, vb_usermodel.hip): sample, the user's row kernel for (f, G), then the same
+// explicit-gradient streaming pass (no prior term: ivp = 0, everything is in the user's f).
+static int source_accumulate(vb_ctx* ctx, hipStream_t st, const NoiseSlot& ns, const BatchPtrs& bp, const Workspace& ws,
+                             const Geom& g, bool mom, bool tsc) {
+  const int64_t n = g.n, d = g.d;
+  const int64_t ldz = round_up(d, 16);
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t o_z = carve(n * ldz), o_g = carve(n * ldz), o_f = carve(n), o_fsum = carve(16);
+  VB_TRY(ensure(ctx, ctx->lg_work, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->lg_work.ptr;
+  double *Z = base + o_z, *G = base + o_g, *frow = base + o_f, *fsum = base + o_fsum;
+  double* wsb = ws.base;
+  VB_HIP(ctx, hipMemsetAsync(wsb + ws.off_colp, 0, (size_t)3 * g.Dp * sizeof(double), st));
+  VB_HIP(ctx, hipMemsetAsync(G, 0, (size_t)n * ldz * sizeof(double), st));     // pad columns of G are streamed too
+  hipLaunchKernelGGL(lg_sample_kernel, dim3((unsigned)n, (unsigned)((d + 255) / 256)), dim3(256), 0, st,
+                     bp.theta_src[0], wsb + ws.off_theta, wsb + ws.off_colp, g.Dp, (const double*)ns.buf.ptr, ns.ld,
+                     Z, ldz, n, (int)d);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(user_rows_enqueue(ctx, st, Z, ldz, n, (int)d, G, ldz, frow));
+  hipLaunchKernelGGL(lg_scalars_kernel, dim3(1), dim3(256), 0, st, (const double*)frow, (int)n, fsum,
+                     wsb + ws.off_prepscal, (double)n);
+  VB_HIP(ctx, hipGetLastError());
+  const dim3 grid((unsigned)(g.n_rb * g.n_cb));
+  if (mom && tsc)
+    hipLaunchKernelGGL((lg_accum_kernel<true, true>), grid, dim3(kMfThreads), 0, st, (const double*)ns.buf.ptr, ns.ld,
+                       (const double*)G, ldz, ws, g, 0.0, (const double*)fsum);
+  else if (mom)
+    hipLaunchKernelGGL((lg_accum_kernel<true, false>), grid, dim3(kMfThreads), 0, st, (const double*)ns.buf.ptr, ns.ld,
+                       (const double*)G, ldz, ws, g, 0.0, (const double*)fsum);
+  else if (tsc)
+    hipLaunchKernelGGL((lg_accum_kernel<false, true>), grid, dim3(kMfThreads), 0, st, (const double*)ns.buf.ptr, ns.ld,
+                       (const double*)G, ldz, ws, g, 0.0, (const double*)fsum);
+  else
+    hipLaunchKernelGGL((lg_accum_kernel<false, false>), grid, dim3(kMfThreads), 0, st, (const double*)ns.buf.ptr, ns.ld,
+                       (const double*)G, ldz, ws, g, 0.0, (const double*)fsum);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 // Enqueue prep -> accumulate -> finalize [-> all-reduce -> epilogue] for a batch of `count`
 // independent evaluations.
 int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
@@ -1220,10 +1264,13 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   const ModelDev& model = c.model ? *c.model : ctx->model;
   if (c.count < 1 || c.count > kMaxBatch)
     return fail(ctx, VB_ERR_INVALID, "batch size %d outside [1, %d]", c.count, kMaxBatch);
-  const bool logistic = model.id == VB_MODEL_LOGISTIC;
+  // `logistic` = "the model's gradient matrix is produced before the streaming pass and loaded by it": the regression
+  // targets (two GEMMs) and the source model (the user's row kernel)
+  const bool source = model.id == VB_MODEL_SOURCE;
+  const bool logistic = model.id == VB_MODEL_LOGISTIC || source;
   if (logistic && (c.count != 1 || c.mode != 0 || c.cv_mode != VB_CV_NONE || c.roww[0] != nullptr))
     return fail(ctx, VB_ERR_UNSUPPORTED,
-                "the logistic-regression target supports single ExclusiveKL evaluations without control variates");
+                "regression and source-model targets support single ExclusiveKL evaluations without control variates");
   if (model.id != VB_MODEL_GAUSS_DIAG && model.id != VB_MODEL_FUNNEL && model.id != kModelLogQ && !logistic)
     return fail(ctx, VB_ERR_UNSUPPORTED,
                 "mean-field path supports the gauss_diag and funnel models (model id %d bound)", model.id);
@@ -1397,7 +1444,9 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   L.grid = dim3((unsigned)(g.n_rb * g.n_cb), (unsigned)c.count);
   L.st = st_main;
   prof_events(ctx, &L.ev0, &L.ev1, c.count);
-  if (logistic)
+  if (source)
+    VB_TRY(source_accumulate(ctx, st_main, *c.noise[0], bp, ws, g, mom, tsc));
+  else if (logistic)
     VB_TRY(logistic_accumulate(ctx, st_main, model, *c.noise[0], bp, ws, g, mom, tsc));
   else if (model.id == VB_MODEL_GAUSS_DIAG)
     launch_accum_model<VB_MODEL_GAUSS_DIAG>(mom, tsc, weighted, L, bp, ws, g);

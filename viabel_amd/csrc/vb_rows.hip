@@ -215,6 +215,7 @@ int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int
                     double* out_dev) {
   if (ctx->model.id == VB_MODEL_GAUSS_FULL) return gauss_full_rows(ctx, x_dev, ld, n, d, out_dev);
   if (ctx->model.id == VB_MODEL_LOGISTIC) return logistic_rows(ctx, x_dev, ld, n, d, out_dev);
+  if (ctx->model.id == VB_MODEL_SOURCE) return user_rows_enqueue(ctx, ctx->stream, x_dev, ld, n, (int)d, nullptr, 0, out_dev);
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
     return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density: unknown model id %d", ctx->model.id);
   const unsigned grid = (unsigned)((n + 3) / 4);

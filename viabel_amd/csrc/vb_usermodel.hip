@@ -1,0 +1,142 @@
+// User model as HIP source (VB_MODEL_SOURCE): the adaptor for log densities outside the built-in set.
+//
+// The reference takes an arbitrary Python callable and differentiates it with autograd (viabel/models.py:17-39,
+// convenience.py:75 `bbvi(dim, log_density=...)`).  A GPU engine cannot run a Python callable; what it can take is the
+// log density and its gradient written as device code.  The caller hands a source snippet that defines
+//
+//     __device__ double vb_log_density(const double* z, int d, const double* params, double* grad);
+//
+// (returns f(z) for one sample z[0..d); writes grad f into grad[0..d) unless grad is NULL; `params` is an array of
+// doubles uploaded with the model -- data, hyper-parameters).  It is compiled for this GPU with hiprtc (resolved with
+// dlopen at the first use: the library itself keeps linking only libamdhip64 and librccl), wrapped in a row kernel and
+// launched wherever the pipelines need (f, G) of a sample matrix: the mean-field ExclusiveKL path streams the noise
+// against the G it returns (the "loaded gradient" pass of the regression targets, vb_logistic.h), the dense Gaussian
+// family uses it where the funnel's row kernel sits between the sampling GEMM and the gradient GEMM.
+#include "vb_common.h"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <string>
+
+namespace vb {
+
+namespace {
+
+struct Rtc {
+  void* handle = nullptr;
+  decltype(&hiprtcCreateProgram) create = nullptr;
+  decltype(&hiprtcCompileProgram) compile = nullptr;
+  decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+  decltype(&hiprtcGetProgramLog) log = nullptr;
+  decltype(&hiprtcGetCodeSize) code_size = nullptr;
+  decltype(&hiprtcGetCode) code = nullptr;
+  decltype(&hiprtcDestroyProgram) destroy = nullptr;
+};
+
+const Rtc* rtc_load() {
+  static Rtc rtc;
+  static bool tried = false;
+  if (tried) return rtc.handle ? &rtc : nullptr;
+  tried = true;
+  void* h = dlopen("libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) return nullptr;
+  rtc.create = (decltype(rtc.create))dlsym(h, "hiprtcCreateProgram");
+  rtc.compile = (decltype(rtc.compile))dlsym(h, "hiprtcCompileProgram");
+  rtc.log_size = (decltype(rtc.log_size))dlsym(h, "hiprtcGetProgramLogSize");
+  rtc.log = (decltype(rtc.log))dlsym(h, "hiprtcGetProgramLog");
+  rtc.code_size = (decltype(rtc.code_size))dlsym(h, "hiprtcGetCodeSize");
+  rtc.code = (decltype(rtc.code))dlsym(h, "hiprtcGetCode");
+  rtc.destroy = (decltype(rtc.destroy))dlsym(h, "hiprtcDestroyProgram");
+  if (!rtc.create || !rtc.compile || !rtc.log_size || !rtc.log || !rtc.code_size || !rtc.code || !rtc.destroy) {
+    dlclose(h);
+    return nullptr;
+  }
+  rtc.handle = h;
+  return &rtc;
+}
+
+// one thread per sample: the user function walks its row.  (Rows are ld doubles apart, 128-B aligned.)
+const char* const kWrapper = R"VBSRC(
+extern "C" __global__ void vb_user_rows(const double* __restrict__ Z, long long ldz, long long n, int d,
+                                        const double* __restrict__ params, double* __restrict__ G, long long ldg,
+                                        double* __restrict__ f) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  f[row] = vb_log_density(Z + row * ldz, d, params, G ? G + row * ldg : (double*)0);
+}
+)VBSRC";
+
+}  // namespace
+
+void user_model_release(vb_ctx* ctx) {
+  if (ctx->user_module) (void)hipModuleUnload(ctx->user_module);
+  ctx->user_module = nullptr;
+  ctx->user_fn = nullptr;
+}
+
+int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* params, size_t n_params) {
+  if (!source || !*source) return fail(ctx, VB_ERR_INVALID, "empty model source");
+  if (dim <= 0) return fail(ctx, VB_ERR_INVALID, "model dimension must be positive");
+  if (n_params > 0 && !params) return fail(ctx, VB_ERR_INVALID, "NULL params");
+  const Rtc* rtc = rtc_load();
+  if (!rtc) return fail(ctx, VB_ERR_UNSUPPORTED, "libhiprtc.so not found: a source model needs the HIP runtime compiler");
+  const std::string full = std::string(source) + "\n" + kWrapper;
+  hiprtcProgram prog = nullptr;
+  if (rtc->create(&prog, full.c_str(), "vb_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    return fail(ctx, VB_ERR_HIP, "hiprtcCreateProgram failed");
+  const std::string arch = std::string("--offload-arch=") + ctx->prop.gcnArchName;
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};
+  const hiprtcResult rc = rtc->compile(prog, 4, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    std::string log;
+    if (rtc->log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+      log.resize(ls);
+      (void)rtc->log(prog, &log[0]);
+    }
+    (void)rtc->destroy(&prog);
+    if (log.size() > 1500) log.resize(1500);
+    return fail(ctx, VB_ERR_INVALID, "model source does not compile: %s", log.c_str());
+  }
+  size_t cs = 0;
+  std::string code;
+  if (rtc->code_size(prog, &cs) != HIPRTC_SUCCESS || cs == 0) {
+    (void)rtc->destroy(&prog);
+    return fail(ctx, VB_ERR_HIP, "hiprtcGetCodeSize failed");
+  }
+  code.resize(cs);
+  const hiprtcResult rg = rtc->code(prog, &code[0]);
+  (void)rtc->destroy(&prog);
+  if (rg != HIPRTC_SUCCESS) return fail(ctx, VB_ERR_HIP, "hiprtcGetCode failed");
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));     // nothing in flight may still use the previous module
+  user_model_release(ctx);
+  VB_HIP(ctx, hipModuleLoadData(&ctx->user_module, code.data()));
+  VB_HIP(ctx, hipModuleGetFunction(&ctx->user_fn, ctx->user_module, "vb_user_rows"));
+  VB_TRY(ensure(ctx, ctx->user_params, (n_params > 0 ? n_params : 1) * sizeof(double)));
+  if (n_params > 0) {
+    VB_HIP(ctx, hipMemcpyAsync(ctx->user_params.ptr, params, n_params * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ModelDev m;
+  m.id = VB_MODEL_SOURCE;
+  m.dim = (int)dim;
+  m.c0 = 0.0;
+  m.p0 = (const double*)ctx->user_params.ptr;
+  ctx->model = m;
+  return VB_OK;
+}
+
+// f[row] = f(Z[row]), G[row] = grad f(Z[row]) (G may be NULL) for the bound source model
+int user_rows_enqueue(vb_ctx* ctx, hipStream_t st, const double* Z, int64_t ldz, int64_t n, int d, double* G,
+                      int64_t ldg, double* f) {
+  if (!ctx->user_fn || ctx->model.id != VB_MODEL_SOURCE) return fail(ctx, VB_ERR_STATE, "no source model bound");
+  long long ldz_ = ldz, n_ = n, ldg_ = ldg;
+  const double* params = (const double*)ctx->user_params.ptr;
+  void* args[] = {(void*)&Z, (void*)&ldz_, (void*)&n_, (void*)&d, (void*)&params, (void*)&G, (void*)&ldg_, (void*)&f};
+  VB_HIP(ctx, hipModuleLaunchKernel(ctx->user_fn, (unsigned)((n + 63) / 64), 1, 1, 64, 1, 1, 0, st, args, nullptr));
+  return VB_OK;
+}
+
+}  // namespace vb

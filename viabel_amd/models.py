@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 
 __all__ = ['Model', 'DeviceModel', 'GaussianModel', 'FunnelModel', 'CorrelatedGaussianModel',
-           'LogisticRegressionModel', 'PoissonRegressionModel', 'LinearRegressionModel']
+           'LogisticRegressionModel', 'PoissonRegressionModel', 'LinearRegressionModel', 'SourceModel']
 
 
 class Model(object):
@@ -72,6 +72,32 @@ class DeviceModel(Model):
         eng = _lib.default_engine()
         eng.set_model(self.device_spec())
         return eng.model_logp(x)
+
+
+class SourceModel(DeviceModel):
+    """A log density outside the built-in set, given as HIP device code -- the adaptor for what the reference
+    does with an arbitrary Python callable and autograd (``viabel/models.py:17-39``,
+    ``convenience.py:75`` ``bbvi(dim, log_density=...)``).
+
+    ``source`` is HIP C++ that defines::
+
+        __device__ double vb_log_density(const double* z, int d, const double* params, double* grad);
+
+    returning ``f(z)`` for one sample ``z[0..d)`` and writing its gradient to ``grad[0..d)`` unless ``grad`` is
+    NULL; ``params`` is the array given here (data, hyper-parameters), resident on the device.  The source is
+    compiled for the GPU with hiprtc when the model is first bound; a source that does not compile raises
+    ``ValueError`` with the compiler's log.  ``ExclusiveKL`` takes it with ``MFGaussian`` / ``MFStudentT`` /
+    ``FullRankGaussian`` (both estimator forms, no control variates); the model can be called on host samples."""
+
+    def __init__(self, dim, source, params=None):
+        if not isinstance(source, (str, bytes)) or not source:
+            raise ValueError('source must be a non-empty string of HIP code')
+        self._source = source.encode() if isinstance(source, str) else bytes(source)
+        self.params = np.ascontiguousarray(np.zeros(0) if params is None else params, dtype=np.float64).ravel()
+        super().__init__(dim)
+
+    def _build_spec(self):
+        return (_lib.MODEL_SOURCE, self._dim, self.params, np.zeros(0, dtype=np.int64), self._source)
 
 
 class GaussianModel(DeviceModel):

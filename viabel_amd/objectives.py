@@ -19,7 +19,7 @@ from scipy import special as _special
 
 from . import _lib
 from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT, LRGaussian, symmetric_eig, symmetric_root
-from .models import DeviceModel
+from .models import DeviceModel, SourceModel
 
 __all__ = [
     'VariationalObjective',
@@ -117,12 +117,18 @@ class VariationalObjective(ABC):
         if not isinstance(self._model, DeviceModel):
             raise TypeError(
                 'the HIP engine needs a device-resident model (viabel_amd.models.DeviceModel: '
-                'GaussianModel, FunnelModel, CorrelatedGaussianModel); got %r. Arbitrary Python '
+                'GaussianModel, FunnelModel, CorrelatedGaussianModel, the regression models, or a SourceModel '
+                'holding the log density as HIP code); got %r. Arbitrary Python '
                 'log densities cannot run on the GPU and there is no CPU fallback.'
                 % type(self._model).__name__)
         if self._model.dim != self._approx.dim:
             raise ValueError('model dimension {} != approximation dimension {}'.format(
                 self._model.dim, self._approx.dim))
+        if isinstance(self._model, SourceModel) and not (
+                type(self).__name__ == 'ExclusiveKL' and type(self._approx).__name__ in (
+                    'MFGaussian', 'MFStudentT', 'FullRankGaussian')):
+            raise NotImplementedError('SourceModel targets run under ExclusiveKL with MFGaussian, MFStudentT or '
+                                      'FullRankGaussian')
 
     def _stage_noise(self, eng, n_samples, slot=_NOISE_SLOT, seed=None):
         """Put this call's base noise into a device slot; returns (n_local, n_total).
