@@ -141,3 +141,19 @@ def test_source_model_errors(vb):
         vb.ExclusiveKL(vb.MultivariateT(3, 10), ok, 10)
     with pytest.raises(ValueError):
         vb.SourceModel(3, '')
+
+
+def test_bbvi_with_source_string(vb, capsys):
+    """`bbvi(dim, log_density=...)` -- the reference's primary entry (convenience.py:75) -- with the density as HIP source:
+    a banana-shaped 2-D target, default RAABBVI path, device-resident chunks."""
+    src = r'''
+    __device__ double vb_log_density(const double* z, int d, const double* p, double* g) {
+      const double b = 0.5, u = z[1] + b * (z[0] * z[0] - 1.0);        // N(0, 2^2) x N(0, 1) bent along z0^2
+      if (g) { g[0] = -z[0] / 4.0 - 2.0 * b * z[0] * u; g[1] = -u; }
+      return -0.5 * z[0] * z[0] / 4.0 - 0.5 * u * u;
+    }'''
+    res = vb.bbvi(2, log_density=src, n_iters=1500, num_mc_samples=64, learning_rate=0.05, RAABBVI_kwargs=dict(mcse_threshold=0.01))
+    capsys.readouterr()
+    assert isinstance(res['objective'].model, vb.SourceModel)
+    mean = res['opt_param'][:2]
+    assert abs(mean[0]) < 0.5 and np.all(np.isfinite(res['opt_param']))

@@ -12,7 +12,7 @@ from . import _lib
 from ._psis import psislw
 from .approximations import MFGaussian, MFStudentT
 from .diagnostics import all_diagnostics
-from .models import DeviceModel
+from .models import DeviceModel, SourceModel
 from .objectives import ExclusiveKL
 from .optimization import FASO, RAABBVI, RMSProp
 
@@ -35,9 +35,12 @@ def bbvi(dimension, *, n_iters=10000, num_mc_samples=10, log_density=None, appro
             raise NotImplementedError('PyStan fits are not supported by the HIP engine; pass a device model')
         elif fit is not None:
             raise ValueError('log_density and fit cannot both be specified')
+        if isinstance(log_density, (str, bytes)):      # the log density as HIP source (models.SourceModel)
+            log_density = SourceModel(dimension, log_density)
         if not isinstance(log_density, DeviceModel):
             raise TypeError('log_density must be a viabel_amd device model (GaussianModel, FunnelModel, '
-                            'CorrelatedGaussianModel): Python callables cannot run on the GPU')
+                            'CorrelatedGaussianModel, a regression model, or a SourceModel / HIP source string '
+                            'defining vb_log_density): Python callables cannot run on the GPU')
         if approx is None:
             approx = MFGaussian(dimension)
         objective = ExclusiveKL(approx, log_density, num_mc_samples)
