@@ -157,3 +157,20 @@ def test_bbvi_with_source_string(vb, capsys):
     assert isinstance(res['objective'].model, vb.SourceModel)
     mean = res['opt_param'][:2]
     assert abs(mean[0]) < 0.5 and np.all(np.isfinite(res['opt_param']))
+
+
+@pytest.mark.parametrize('D,N,n_data', [(6, 100, 30), (48, 512, 50)])
+def test_source_model_alpha_fullrank_against_oracle(vb, D, N, n_data):
+    model, omodel = _problem(vb, D, n_data, seed=5 * D)
+    rng = np.random.RandomState(D)
+    ofr = ofam.FullRankGaussian(D)
+    L = np.tril(0.05 * rng.randn(D, D), -1) + np.diag(np.exp(-1.0 + 0.2 * rng.randn(D)))
+    theta = ofr.pack(0.1 * rng.randn(D), L)
+    for alpha in (2.0, 0.5):
+        np.random.seed(11)
+        value, grad = vb.AlphaDivergence(vb.FullRankGaussian(D), model, N, alpha)(theta)
+        np.random.seed(11)
+        noise = np.random.RandomState(np.random.randint(2 ** 32)).randn(N, D)
+        ov, og = oobj.alpha_divergence(ofr, omodel, theta, noise, alpha)
+        assert G.rel_err(value, ov) < 1e-12, (alpha, value, ov)
+        assert G.rel_err(grad, og) < 1e-11, (alpha, G.rel_err(grad, og))

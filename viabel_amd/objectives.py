@@ -124,11 +124,12 @@ class VariationalObjective(ABC):
         if self._model.dim != self._approx.dim:
             raise ValueError('model dimension {} != approximation dimension {}'.format(
                 self._model.dim, self._approx.dim))
-        if isinstance(self._model, SourceModel) and not (
-                type(self).__name__ == 'ExclusiveKL' and type(self._approx).__name__ in (
-                    'MFGaussian', 'MFStudentT', 'FullRankGaussian')):
-            raise NotImplementedError('SourceModel targets run under ExclusiveKL with MFGaussian, MFStudentT or '
-                                      'FullRankGaussian')
+        if isinstance(self._model, SourceModel):
+            kind, fam = type(self).__name__, type(self._approx).__name__
+            if not ((kind == 'ExclusiveKL' and fam in ('MFGaussian', 'MFStudentT', 'FullRankGaussian')) or
+                    (kind == 'AlphaDivergence' and fam == 'FullRankGaussian')):
+                raise NotImplementedError('SourceModel targets run under ExclusiveKL with MFGaussian, MFStudentT or '
+                                          'FullRankGaussian, and under AlphaDivergence with FullRankGaussian')
 
     def _stage_noise(self, eng, n_samples, slot=_NOISE_SLOT, seed=None):
         """Put this call's base noise into a device slot; returns (n_local, n_total).
