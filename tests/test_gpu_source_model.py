@@ -138,7 +138,7 @@ def test_source_model_errors(vb):
     with pytest.raises(NotImplementedError):
         vb.AlphaDivergence(vb.MFGaussian(3), ok, 10, 2.0)
     with pytest.raises(NotImplementedError):
-        vb.ExclusiveKL(vb.MultivariateT(3, 10), ok, 10)
+        vb.ExclusiveKL(vb.LRGaussian(3, 1), ok, 10)
     with pytest.raises(ValueError):
         vb.SourceModel(3, '')
 
@@ -174,3 +174,17 @@ def test_source_model_alpha_fullrank_against_oracle(vb, D, N, n_data):
         ov, og = oobj.alpha_divergence(ofr, omodel, theta, noise, alpha)
         assert G.rel_err(value, ov) < 1e-12, (alpha, value, ov)
         assert G.rel_err(grad, og) < 1e-11, (alpha, G.rel_err(grad, og))
+
+
+@pytest.mark.parametrize('D,N,n_data', [(6, 100, 30), (70, 333, 40)])
+@pytest.mark.parametrize('pd', [False, True])
+def test_source_model_multivariate_t_against_oracle(vb, D, N, n_data, pd):
+    model, omodel = _problem(vb, D, n_data, seed=7 * D)
+    rng = np.random.RandomState(D)
+    B = rng.randn(D, D)
+    theta = np.concatenate([0.2 * rng.randn(D), ofam.psd_to_free(0.05 * (B @ B.T / D + 0.5 * np.eye(D)))])
+    value, grad = vb.ExclusiveKL(vb.MultivariateT(D, 9.0, seed=6), model, N, use_path_deriv=pd)(theta)
+    noise = ofam.MultivariateT(D, 9.0).draw_noise(np.random.RandomState(6), N)
+    ov, og = oobj.exclusive_kl(ofam.MultivariateT(D, 9.0), omodel, theta, noise, pd)
+    assert abs(value - ov) <= 1e-12 * abs(ov), (value, ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-10 * np.max(np.abs(og)))

@@ -87,7 +87,7 @@ class SourceModel(DeviceModel):
     NULL; ``params`` is the array given here (data, hyper-parameters), resident on the device.  The source is
     compiled for the GPU with hiprtc when the model is first bound; a source that does not compile raises
     ``ValueError`` with the compiler's log.  ``ExclusiveKL`` takes it with ``MFGaussian`` / ``MFStudentT`` /
-    ``FullRankGaussian`` (both estimator forms, no control variates) and ``AlphaDivergence`` with
+    ``FullRankGaussian`` / ``MultivariateT`` (both estimator forms, no control variates) and ``AlphaDivergence`` with
     ``FullRankGaussian``; the model can be called on host samples."""
 
     def __init__(self, dim, source, params=None):

@@ -126,10 +126,11 @@ class VariationalObjective(ABC):
                 self._model.dim, self._approx.dim))
         if isinstance(self._model, SourceModel):
             kind, fam = type(self).__name__, type(self._approx).__name__
-            if not ((kind == 'ExclusiveKL' and fam in ('MFGaussian', 'MFStudentT', 'FullRankGaussian')) or
+            if not ((kind == 'ExclusiveKL' and fam in ('MFGaussian', 'MFStudentT', 'FullRankGaussian', 'MultivariateT')) or
                     (kind == 'AlphaDivergence' and fam == 'FullRankGaussian')):
-                raise NotImplementedError('SourceModel targets run under ExclusiveKL with MFGaussian, MFStudentT or '
-                                          'FullRankGaussian, and under AlphaDivergence with FullRankGaussian')
+                raise NotImplementedError('SourceModel targets run under ExclusiveKL with MFGaussian, MFStudentT, '
+                                          'FullRankGaussian or MultivariateT, and under AlphaDivergence with '
+                                          'FullRankGaussian')
 
     def _stage_noise(self, eng, n_samples, slot=_NOISE_SLOT, seed=None):
         """Put this call's base noise into a device slot; returns (n_local, n_total).
