@@ -188,3 +188,46 @@ def test_source_model_multivariate_t_against_oracle(vb, D, N, n_data, pd):
     ov, og = oobj.exclusive_kl(ofam.MultivariateT(D, 9.0), omodel, theta, noise, pd)
     assert abs(value - ov) <= 1e-12 * abs(ov), (value, ov)
     np.testing.assert_allclose(grad, og, rtol=0, atol=1e-10 * np.max(np.abs(og)))
+
+
+@pytest.mark.parametrize('family', ['multivariate_t', 'fullrank_gaussian'])
+@pytest.mark.parametrize('use_resampling', [True, False])
+def test_source_model_dis_dense_against_oracle(vb, family, use_resampling):
+    """DISInclusiveKL over the dense families needs log p of the state samples only: the source model's row kernel with a
+    NULL gradient.  Three calls with a moving theta, as tests/test_gpu_objectives.py does for the built-in targets."""
+    D, N, df, n_data = 12, 900, 40, 30
+    model, omodel = _problem(vb, D, n_data, seed=21)
+    rng = np.random.RandomState(9)
+    if family == 'multivariate_t':
+        approx, ofamily = vb.MultivariateT(D, df, seed=6), ofam.MultivariateT(D, df)
+    else:
+        approx, ofamily = vb.FullRankGaussian(D, seed=6), ofam.FullRankGaussian(D)
+    prior = np.concatenate([np.zeros(D), np.log(3.0) * np.ones(D)])
+    kw = dict(use_resampling=use_resampling, num_resampling_batches=2)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=200, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, **kw)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, 200, ofam.MFGaussian(D), prior, **kw)
+    A = rng.randn(D, D)
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(A @ A.T / D + 0.7 * np.eye(D))])
+    rs = np.random.RandomState(6)
+    np.random.seed(12)
+    for step in range(3):
+        state = np.random.get_state()
+        value, grad = obj(theta)
+        np.random.set_state(state)
+        noise = ofamily.draw_noise(rs, N) if ref.needs_refresh() else None
+        if use_resampling:
+            if ref.needs_refresh():
+                ref.refresh(theta, noise)
+            idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
+            ref._objective_step += 1
+            xs = ref._state_samples[idx]
+            scale = ref._state_w_sum / N
+            ov = np.mean(-ofamily.log_density(theta, xs)) * scale
+            og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+        else:
+            ov, og = ref(theta, noise=noise)
+        assert G.rel_err(obj._eps, ref._eps) < 1e-10
+        assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
+        assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
+        theta = theta - 0.01 * grad / (1 + np.abs(grad))

@@ -347,8 +347,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
                     double* ess_out, double* w_host, double* logp_host, double* logq_host) {
   if (n * (int64_t)ctx->n_ranks != n_total)
     return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
-  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
-    return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density implements gauss_diag and funnel");
+  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL && ctx->model.id != VB_MODEL_SOURCE)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density implements gauss_diag, funnel and source models");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   if (!(df > 2.0) && df != 0.0) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2 (or 0: Gaussian limit)");

@@ -87,8 +87,9 @@ class SourceModel(DeviceModel):
     NULL; ``params`` is the array given here (data, hyper-parameters), resident on the device.  The source is
     compiled for the GPU with hiprtc when the model is first bound; a source that does not compile raises
     ``ValueError`` with the compiler's log.  ``ExclusiveKL`` takes it with ``MFGaussian`` / ``MFStudentT`` /
-    ``FullRankGaussian`` / ``MultivariateT`` (both estimator forms, no control variates) and ``AlphaDivergence`` with
-    ``FullRankGaussian``; the model can be called on host samples."""
+    ``FullRankGaussian`` / ``MultivariateT`` (both estimator forms, no control variates) ``AlphaDivergence`` with
+    ``FullRankGaussian`` and ``DISInclusiveKL`` with ``FullRankGaussian`` / ``MultivariateT``; the model can be called
+    on host samples."""
 
     def __init__(self, dim, source, params=None):
         if not isinstance(source, (str, bytes)) or not source:
