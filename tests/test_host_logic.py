@@ -231,3 +231,24 @@ def test_shared_choice_is_numpy_choice():
         assert after_got == after_want
     with pytest.raises(ValueError):
         _shared_choice(_OneRank(), 4, 2, np.ones(3) / 3)
+
+
+def test_source_model_host_side():
+    """SourceModel is plain data until it is bound to an engine: construction, spec layout and argument checks need no GPU."""
+    from viabel_amd import _lib
+    src = '__device__ double vb_log_density(const double* z, int d, const double* p, double* g) { return 0.0; }'
+    m = vb.SourceModel(4, src, params=[1, 2, 3])
+    spec = m.device_spec()
+    assert spec[0] == _lib.MODEL_SOURCE and spec[1] == 4 and spec[4] == src.encode()
+    np.testing.assert_array_equal(spec[2], [1.0, 2.0, 3.0])
+    assert m.device_spec() is spec                      # cached: the engine keys its model cache on identity
+    assert vb.SourceModel(2, src.encode()).params.size == 0
+    for bad in ('', None, 3):
+        with pytest.raises(ValueError):
+            vb.SourceModel(2, bad)
+    with pytest.raises(NotImplementedError):
+        vb.AlphaDivergence(vb.MFGaussian(4), m, 10, 2.0)
+    with pytest.raises(NotImplementedError):
+        vb.ExclusiveKL(vb.LRGaussian(4, 1), m, 10)
+    with pytest.raises(ValueError):
+        vb.ExclusiveKL(vb.MFGaussian(3), m, 10)         # dimension mismatch
