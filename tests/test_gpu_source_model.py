@@ -231,3 +231,63 @@ def test_source_model_dis_dense_against_oracle(vb, family, use_resampling):
         assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
         assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
         theta = theta - 0.01 * grad / (1 + np.abs(grad))
+
+
+@pytest.mark.parametrize('student', [False, True])
+@pytest.mark.parametrize('use_resampling', [True, False])
+def test_source_model_dis_meanfield_against_oracle(vb, student, use_resampling):
+    """Mean-field DIS: f of the state samples from the source model's row kernel (samples materialised for it), the base
+    log density from the row-statistics kernel as for the built-in targets."""
+    D, N, n_data = 10, 800, 30
+    model, omodel = _problem(vb, D, n_data, seed=31)
+    rng = np.random.RandomState(4)
+    if student:
+        approx, ofamily = vb.MFStudentT(D, 12.0, seed=6), ofam.MFStudentT(D, 12.0)
+    else:
+        approx, ofamily = vb.MFGaussian(D, seed=6), ofam.MFGaussian(D)
+    prior = np.concatenate([np.zeros(D), np.log(3.0) * np.ones(D)])
+    kw = dict(use_resampling=use_resampling, num_resampling_batches=2)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=200, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, **kw)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, 200, ofam.MFGaussian(D), prior, **kw)
+    theta = np.concatenate([0.1 * rng.randn(D), -0.5 + 0.1 * rng.randn(D)])
+    rs = np.random.RandomState(6)
+    np.random.seed(12)
+    for step in range(3):
+        state = np.random.get_state()
+        value, grad = obj(theta)
+        np.random.set_state(state)
+        noise = ofamily.draw_noise(rs, N) if ref.needs_refresh() else None
+        if use_resampling:
+            if ref.needs_refresh():
+                ref.refresh(theta, noise)
+            idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
+            ref._objective_step += 1
+            xs = ref._state_samples[idx]
+            scale = ref._state_w_sum / N
+            ov = np.mean(-ofamily.log_density(theta, xs)) * scale
+            og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+        else:
+            ov, og = ref(theta, noise=noise)
+        assert G.rel_err(obj._eps, ref._eps) < 1e-10
+        assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
+        assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
+        theta = theta - 0.01 * grad / (1 + np.abs(grad))
+
+
+def test_source_model_device_log_weights(vb):
+    """vi_diagnostics' importance log weights for a mean-field family on the device (vb_log_weights_meanfield) against
+    model(samples) - log q(samples) formed on the host."""
+    from viabel_amd import convenience
+    D = 9
+    model, omodel = _problem(vb, D, 25, seed=8)
+    approx = vb.MFGaussian(D, seed=3)
+    theta = np.concatenate([0.1 * np.arange(D), -0.7 * np.ones(D)])
+    assert convenience._on_device_weights(model, approx)
+    samples, lw, khat = convenience.psis_correction(theta, model, approx, 4000)
+    assert np.isfinite(khat) and lw.shape == (4000,)
+    x = samples.T
+    raw = omodel.logp(x) - ofam.MFGaussian(D).log_density(theta, x)
+    from viabel_amd._psis import psislw
+    want, _ = psislw(raw.copy())
+    assert G.rel_err(lw, want) < 1e-9

@@ -135,7 +135,7 @@ _DIAG_SLOT = 2      # device noise slot used by the diagnostics (objectives use 
 
 def _on_device_weights(model, approx):
     return (isinstance(approx, (MFGaussian, MFStudentT)) and isinstance(model, DeviceModel)
-            and model.device_spec()[0] in (_lib.MODEL_GAUSS_DIAG, _lib.MODEL_FUNNEL))
+            and model.device_spec()[0] in (_lib.MODEL_GAUSS_DIAG, _lib.MODEL_FUNNEL, _lib.MODEL_SOURCE))
 
 
 def samples_and_log_weights(var_param, model, approx, n_samples):

@@ -287,8 +287,8 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
 // log importance weights of the mean-field families for the noise staged in `ns`; left in ctx->psis_lw
 int log_weights_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
                         const double* theta_src) {
-  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
-    return fail(ctx, VB_ERR_UNSUPPORTED, "row-statistics path supports the gauss_diag and funnel models");
+  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL && ctx->model.id != VB_MODEL_SOURCE)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "row-statistics path supports the gauss_diag, funnel and source models");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   const int student = family == VB_FAMILY_MF_STUDENT_T;

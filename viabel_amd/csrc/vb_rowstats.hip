@@ -159,11 +159,40 @@ __global__ void alpha_value_kernel(const double* mx, const double* sum_s, double
 }
 
 // ---- host ---------------------------------------------------------------------------------------------
+// Z = mu + exp(log_sigma) * E, materialised for a source model's row kernel (the built-in targets never need it)
+__global__ void __launch_bounds__(256) rs_sample_kernel(const double* __restrict__ theta_src, const double* __restrict__ noise,
+                                                        int64_t ld, double* __restrict__ Z, int64_t ldz, int64_t n, int d) {
+  const int64_t row = blockIdx.x;
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  if (col >= d) return;
+  Z[row * ldz + col] = fma(exp(theta_src[d + col]), noise[row * ld + col], theta_src[col]);
+}
+
 int rowstats_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_src,
                      const ModelDev& model, int student, double df, double* cols, double* scal,
                      double* out_f, double* out_b) {
   hipLaunchKernelGGL(rs_cols_kernel, dim3(1), dim3(256), 0, ctx->stream, theta_src, (int)d, ns.ld, cols, scal);
   VB_HIP(ctx, hipGetLastError());
+  if (model.id == VB_MODEL_SOURCE) {
+    // the row kernel forms the base log density b_n as for any target (its own f is thrown away: a diagonal
+    // Gaussian over memory that exists); f_n comes from the user's kernel on the materialised samples
+    ModelDev stand_in;
+    stand_in.id = VB_MODEL_GAUSS_DIAG;
+    stand_in.dim = model.dim;
+    stand_in.p0 = cols;
+    stand_in.p1 = cols;
+    hipLaunchKernelGGL(rs_rowstats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
+                       (const double*)ns.buf.ptr, ns.ld, n, (int)d, (const double*)cols, stand_in, student, df,
+                       out_f, out_b);
+    VB_HIP(ctx, hipGetLastError());
+    const int64_t ldz = round_up(d, 16);
+    VB_TRY(ensure(ctx, ctx->lg_work, (size_t)n * ldz * sizeof(double)));
+    double* Z = (double*)ctx->lg_work.ptr;
+    hipLaunchKernelGGL(rs_sample_kernel, dim3((unsigned)n, (unsigned)((d + 255) / 256)), dim3(256), 0, ctx->stream,
+                       theta_src, (const double*)ns.buf.ptr, ns.ld, Z, ldz, n, (int)d);
+    VB_HIP(ctx, hipGetLastError());
+    return user_rows_enqueue(ctx, ctx->stream, Z, ldz, n, (int)d, nullptr, 0, out_f);
+  }
   hipLaunchKernelGGL(rs_rowstats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
                      (const double*)ns.buf.ptr, ns.ld, n, (int)d, (const double*)cols, model, student, df,
                      out_f, out_b);
@@ -567,8 +596,8 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
                         double* logp_host, double* logq_host) {
   if (n * (int64_t)ctx->n_ranks != n_total)
     return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
-  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
-    return fail(ctx, VB_ERR_UNSUPPORTED, "mean-field path supports the gauss_diag and funnel models");
+  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL && ctx->model.id != VB_MODEL_SOURCE)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "mean-field DIS supports the gauss_diag, funnel and source models");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   const int student = family == VB_FAMILY_MF_STUDENT_T;

@@ -128,11 +128,11 @@ class VariationalObjective(ABC):
             kind, fam = type(self).__name__, type(self._approx).__name__
             if not ((kind == 'ExclusiveKL' and fam in ('MFGaussian', 'MFStudentT', 'FullRankGaussian', 'MultivariateT')) or
                     (kind == 'AlphaDivergence' and fam == 'FullRankGaussian') or
-                    (kind == 'DISInclusiveKL' and fam in ('FullRankGaussian', 'MultivariateT'))):
+                    (kind == 'DISInclusiveKL' and fam in ('MFGaussian', 'MFStudentT', 'FullRankGaussian', 'MultivariateT'))):
                 raise NotImplementedError('SourceModel targets run under ExclusiveKL with MFGaussian, MFStudentT, '
                                           'FullRankGaussian or MultivariateT, under AlphaDivergence with '
-                                          'FullRankGaussian and under DISInclusiveKL with FullRankGaussian or '
-                                          'MultivariateT')
+                                          'FullRankGaussian and under DISInclusiveKL with every family but '
+                                          'LRGaussian')
 
     def _stage_noise(self, eng, n_samples, slot=_NOISE_SLOT, seed=None):
         """Put this call's base noise into a device slot; returns (n_local, n_total).
