@@ -291,3 +291,14 @@ def test_source_model_device_log_weights(vb):
     from viabel_amd._psis import psislw
     want, _ = psislw(raw.copy())
     assert G.rel_err(lw, want) < 1e-9
+
+
+def test_two_source_models_take_turns(vb):
+    """Binding a source model again (two objectives evaluated alternately) reuses the compiled module and re-uploads its
+    parameters: results stay those of each model."""
+    m1, o1 = _problem(vb, 6, 20, seed=1)
+    m2, o2 = _problem(vb, 6, 35, seed=2)
+    x = np.random.RandomState(0).randn(11, 6)
+    for _ in range(3):
+        np.testing.assert_allclose(m1(x), o1.logp(x), rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(m2(x), o2.logp(x), rtol=1e-13, atol=1e-12)

@@ -150,8 +150,14 @@ struct vb_ctx {
   vb::DeviceBuffer rowvec;              // per-row weights
   vb::DeviceBuffer fr_work;             // full-rank pipeline work buffers
   vb::DeviceBuffer lg_work;             // logistic-regression target: Z, R, G, partials
-  hipModule_t user_module = nullptr;    // VB_MODEL_SOURCE: the compiled user model (vb_usermodel.hip)
+  hipModule_t user_module = nullptr;    // VB_MODEL_SOURCE: the compiled user model in use (vb_usermodel.hip)
   hipFunction_t user_fn = nullptr;
+  struct UserModule {                   // every source compiled by this context, by content hash: binding a model
+    uint64_t hash;                      // again (two objectives taking turns) costs no second hiprtc run
+    hipModule_t module;
+    hipFunction_t fn;
+  };
+  std::vector<UserModule> user_modules;
   vb::DeviceBuffer user_params;
   vb::DeviceBuffer glm_work;            // regression targets: split-K slabs of the gradient GEMM
   vb::DeviceBuffer mvt_state;           // multivariate-t DIS: state samples X, scratch

@@ -70,8 +70,11 @@ extern "C" __global__ void vb_user_rows(const double* __restrict__ Z, long long 
 
 }  // namespace
 
-void user_model_release(vb_ctx* ctx) {
-  if (ctx->user_module) (void)hipModuleUnload(ctx->user_module);
+int user_model_bind(vb_ctx* ctx, int64_t dim, const double* params, size_t n_params);
+
+void user_model_release(vb_ctx* ctx) {      // vb_destroy: unload everything this context compiled
+  for (auto& m : ctx->user_modules) (void)hipModuleUnload(m.module);
+  ctx->user_modules.clear();
   ctx->user_module = nullptr;
   ctx->user_fn = nullptr;
 }
@@ -80,8 +83,20 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
   if (!source || !*source) return fail(ctx, VB_ERR_INVALID, "empty model source");
   if (dim <= 0) return fail(ctx, VB_ERR_INVALID, "model dimension must be positive");
   if (n_params > 0 && !params) return fail(ctx, VB_ERR_INVALID, "NULL params");
-  const Rtc* rtc = rtc_load();
-  if (!rtc) return fail(ctx, VB_ERR_UNSUPPORTED, "libhiprtc.so not found: a source model needs the HIP runtime compiler");
+  uint64_t hash = 1469598103934665603ull;      // FNV-1a of the source text
+  for (const char* c = source; *c; ++c) hash = (hash ^ (uint64_t)(unsigned char)*c) * 1099511628211ull;
+  const vb_ctx::UserModule* cached = nullptr;
+  for (const auto& m : ctx->user_modules)
+    if (m.hash == hash) cached = &m;
+  const Rtc* rtc = cached ? nullptr : rtc_load();
+  if (!cached && !rtc)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "libhiprtc.so not found: a source model needs the HIP runtime compiler");
+  if (cached) {
+    VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->user_module = cached->module;
+    ctx->user_fn = cached->fn;
+    return user_model_bind(ctx, dim, params, n_params);
+  }
   const std::string full = std::string(source) + "\n" + kWrapper;
   hiprtcProgram prog = nullptr;
   if (rtc->create(&prog, full.c_str(), "vb_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
@@ -110,10 +125,23 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
   const hiprtcResult rg = rtc->code(prog, &code[0]);
   (void)rtc->destroy(&prog);
   if (rg != HIPRTC_SUCCESS) return fail(ctx, VB_ERR_HIP, "hiprtcGetCode failed");
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));     // nothing in flight may still use the previous module
-  user_model_release(ctx);
-  VB_HIP(ctx, hipModuleLoadData(&ctx->user_module, code.data()));
-  VB_HIP(ctx, hipModuleGetFunction(&ctx->user_fn, ctx->user_module, "vb_user_rows"));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  VB_HIP(ctx, hipModuleLoadData(&mod, code.data()));
+  if (hipModuleGetFunction(&fn, mod, "vb_user_rows") != hipSuccess) {
+    (void)hipModuleUnload(mod);
+    return fail(ctx, VB_ERR_HIP, "compiled model has no vb_user_rows kernel");
+  }
+  ctx->user_modules.push_back({hash, mod, fn});
+  ctx->user_module = mod;
+  ctx->user_fn = fn;
+  return user_model_bind(ctx, dim, params, n_params);
+}
+
+// upload the parameter array and make the source model the context's model (the previous parameter buffer may still
+// be read by work in flight: the callers synchronised the stream)
+int user_model_bind(vb_ctx* ctx, int64_t dim, const double* params, size_t n_params) {
   VB_TRY(ensure(ctx, ctx->user_params, (n_params > 0 ? n_params : 1) * sizeof(double)));
   if (n_params > 0) {
     VB_HIP(ctx, hipMemcpyAsync(ctx->user_params.ptr, params, n_params * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
