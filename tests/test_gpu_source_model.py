@@ -302,3 +302,18 @@ def test_two_source_models_take_turns(vb):
     for _ in range(3):
         np.testing.assert_allclose(m1(x), o1.logp(x), rtol=1e-13, atol=1e-12)
         np.testing.assert_allclose(m2(x), o2.logp(x), rtol=1e-13, atol=1e-12)
+
+
+def test_source_model_fullrank_device_fit_matches_host_loop(vb, capsys):
+    """The dense family's device-resident loop (vb_fit) with a source model: same trajectory as the host loop."""
+    from viabel_amd.optimization import RMSProp
+    D = 6
+    model, _ = _problem(vb, D, 40, seed=13)
+    hist = {}
+    for on_device in (False, True):
+        fam = vb.FullRankGaussian(D, rng='philox', seed=3)
+        obj = vb.ExclusiveKL(fam, model, 128)
+        res = RMSProp(0.02).optimize(60, obj, fam.init_param(), on_device=on_device)
+        hist[on_device] = np.asarray(res['value_history'])
+    capsys.readouterr()
+    np.testing.assert_array_equal(hist[False], hist[True])
