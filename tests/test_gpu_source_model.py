@@ -317,3 +317,39 @@ def test_source_model_fullrank_device_fit_matches_host_loop(vb, capsys):
         hist[on_device] = np.asarray(res['value_history'])
     capsys.readouterr()
     np.testing.assert_array_equal(hist[False], hist[True])
+
+
+@pytest.mark.parametrize('use_resampling', [True, False])
+def test_source_model_dis_lowrank_against_oracle(vb, use_resampling):
+    D, k, N, n_data = 24, 4, 800, 30
+    model, omodel = _problem(vb, D, n_data, seed=41)
+    rng = np.random.RandomState(3 * D + k)
+    approx, ofamily = vb.LRGaussian(D, seed=5, k=k), ofam.LRGaussian(D, k)
+    prior = np.concatenate([np.zeros(D), np.log(3.0) * np.ones(D)])
+    kw = dict(use_resampling=use_resampling, num_resampling_batches=2)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 5, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, **kw)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, N // 5, ofam.MFGaussian(D), prior, **kw)
+    theta = np.concatenate([0.1 * rng.randn(D), -0.5 + 0.1 * rng.randn(D), 0.2 * rng.randn(D * k) / np.sqrt(k)])
+    rs = np.random.RandomState(5)
+    np.random.seed(13)
+    for step in range(3):
+        state = np.random.get_state()
+        value, grad = obj(theta)
+        np.random.set_state(state)
+        noise = ofamily.draw_noise(rs, N) if ref.needs_refresh() else None
+        if use_resampling:
+            if ref.needs_refresh():
+                ref.refresh(theta, noise)
+            idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
+            ref._objective_step += 1
+            xs = ref._state_samples[idx]
+            scale = ref._state_w_sum / N
+            ov = np.mean(-ofamily.log_density(theta, xs)) * scale
+            og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+        else:
+            ov, og = ref(theta, noise=noise)
+        assert G.rel_err(obj._eps, ref._eps) < 1e-10
+        assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
+        assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
+        theta = theta - 0.005 * grad / (1 + np.abs(grad))

@@ -359,11 +359,14 @@ int lro_colsum_prod(vb_ctx* ctx, const LroLayout& L, double* base, const double*
   return VB_OK;
 }
 
-int lro_check(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k) {
+// f_only: the objective needs f of the samples but not the model's gradient (DIS) -- a source model's row kernel will do
+int lro_check(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k, bool f_only = false) {
   if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d || k < 1 || k > kLdk)
     return fail(ctx, VB_ERR_INVALID, "noise slots must hold n x d and n x k (1 <= k <= 16) matrices");
-  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
-    return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank DIS / alpha objectives implement the gauss_diag and funnel models");
+  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL &&
+      !(f_only && ctx->model.id == VB_MODEL_SOURCE))
+    return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank DIS / alpha objectives implement the gauss_diag and funnel models "
+                "(DIS: source models too)");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
   return VB_OK;
 }
@@ -375,7 +378,7 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
                    int64_t k, const double* mu, const double* log_sigma, const double* B, const double* minv, double cq,
                    const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
                    double* ess_out, double* w_host, double* logp_host, double* logq_host) {
-  VB_TRY(lro_check(ctx, ns, nz, n, d, k));
+  VB_TRY(lro_check(ctx, ns, nz, n, d, k, true));
   if (n * (int64_t)ctx->n_ranks != n_total)
     return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
   const LroLayout L = lro_layout(n, n_total, d);
