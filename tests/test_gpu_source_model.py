@@ -136,7 +136,7 @@ def test_source_model_errors(vb):
     ok = vb.SourceModel(3, '__device__ double vb_log_density(const double* z, int d, const double* p, double* g) '
                            '{ double f = 0; for (int j = 0; j < d; ++j) { f -= 0.5 * z[j] * z[j]; if (g) g[j] = -z[j]; } return f; }')
     with pytest.raises(NotImplementedError):
-        vb.AlphaDivergence(vb.MFGaussian(3), ok, 10, 2.0)
+        vb.AlphaDivergence(vb.MultivariateT(3, 10), ok, 10, 2.0)
     with pytest.raises(NotImplementedError):
         vb.ExclusiveKL(vb.LRGaussian(3, 1), ok, 10)
     with pytest.raises(ValueError):
@@ -353,3 +353,25 @@ def test_source_model_dis_lowrank_against_oracle(vb, use_resampling):
         assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
         assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
         theta = theta - 0.005 * grad / (1 + np.abs(grad))
+
+
+@pytest.mark.parametrize('D,N,n_data', [(8, 200, 30), (77, 333, 40)])
+@pytest.mark.parametrize('family', ['gauss', 't'])
+def test_source_model_alpha_meanfield_against_oracle(vb, D, N, n_data, family):
+    """Mean-field AlphaDivergence: weights from the row kernel's f, weighted gradient from the row-scaled loaded G."""
+    model, omodel = _problem(vb, D, n_data, seed=3 * D)
+    rng = np.random.RandomState(D + N)
+    theta = np.concatenate([0.2 * rng.randn(D), -1.0 + 0.1 * rng.randn(D)])
+    if family == 'gauss':
+        approx, ofamily = vb.MFGaussian(D), ofam.MFGaussian(D)
+    else:
+        approx, ofamily = vb.MFStudentT(D, 12), ofam.MFStudentT(D, 12)
+    for alpha in (2.0, 0.5):
+        np.random.seed(7)
+        value, grad = vb.AlphaDivergence(approx, model, N, alpha)(theta)
+        np.random.seed(7)
+        seed = np.random.randint(2 ** 32)
+        noise = ofamily.draw_noise(np.random.RandomState(seed), N)
+        ov, og = oobj.alpha_divergence(ofamily, omodel, theta, noise, alpha)
+        assert G.rel_err(value, ov) < 1e-12, (alpha, value, ov)
+        assert G.rel_err(grad, og) < 1e-11, (alpha, G.rel_err(grad, og))

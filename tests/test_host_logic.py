@@ -247,7 +247,7 @@ def test_source_model_host_side():
         with pytest.raises(ValueError):
             vb.SourceModel(2, bad)
     with pytest.raises(NotImplementedError):
-        vb.AlphaDivergence(vb.MFGaussian(4), m, 10, 2.0)
+        vb.AlphaDivergence(vb.MultivariateT(4, 10), m, 10, 2.0)
     with pytest.raises(NotImplementedError):
         vb.ExclusiveKL(vb.LRGaussian(4, 1), m, 10)
     with pytest.raises(ValueError):

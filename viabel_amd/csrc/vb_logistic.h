@@ -52,19 +52,35 @@ struct EpiLogit {           // R = d loglik / d eta (logit link: y - sigmoid(eta
   }
 };
 
-// sum the GEMM's per-workgroup log-likelihood partials; also the prep-kernel scalars (W = n)
+// sum the GEMM's per-workgroup log-likelihood partials; also the prep-kernel scalars (W = n, or the sum of the row
+// weights of a weighted evaluation)
 __global__ void __launch_bounds__(256) lg_scalars_kernel(const double* __restrict__ part, int n_part,
                                                          double* __restrict__ fsum, double* __restrict__ prepscal,
-                                                         double n) {
-  __shared__ double sh[4];
-  double s = 0.0;
+                                                         double n, const double* __restrict__ roww = nullptr,
+                                                         int64_t n_rows = 0) {
+  __shared__ double sh[4], shw[4];
+  double s = 0.0, w = 0.0;
   for (int i = threadIdx.x; i < n_part; i += 256) s += part[i];
+  if (roww)
+    for (int64_t i = threadIdx.x; i < n_rows; i += 256) w += roww[i];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    w += __shfl_down(w, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s, shw[threadIdx.x >> 6] = w;
   __syncthreads();
   if (threadIdx.x == 0) fsum[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-  if (threadIdx.x < PS_NUM) prepscal[threadIdx.x] = threadIdx.x == PS_W ? n : 0.0;   // n_prep = 1
+  const double W = roww ? (shw[0] + shw[1]) + (shw[2] + shw[3]) : n;
+  if (threadIdx.x < PS_NUM) prepscal[threadIdx.x] = threadIdx.x == PS_W ? W : 0.0;   // n_prep = 1
+}
+
+// G[n][:] *= w_n: the weighted sums of a loaded gradient matrix are the plain sums of the scaled one
+__global__ void __launch_bounds__(256) lg_rowscale_kernel(double* __restrict__ G, int64_t ldz, int64_t n, int d,
+                                                          const double* __restrict__ roww) {
+  const int64_t row = blockIdx.x;
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  if (col < d) G[row * ldz + col] *= roww[row];
 }
 
 // Streaming pass with an explicit gradient matrix: same grid / partial layout as mf_accum_kernel.

@@ -1216,7 +1216,7 @@ static int logistic_accumulate(vb_ctx* ctx, hipStream_t st, const ModelDev& m, c
 // Source model (VB_MODEL_SOURCE, vb_usermodel.hip): sample, the user's row kernel for (f, G), then the same
 // explicit-gradient streaming pass (no prior term: ivp = 0, everything is in the user's f).
 static int source_accumulate(vb_ctx* ctx, hipStream_t st, const NoiseSlot& ns, const BatchPtrs& bp, const Workspace& ws,
-                             const Geom& g, bool mom, bool tsc) {
+                             const Geom& g, bool mom, bool tsc, const double* roww) {
   const int64_t n = g.n, d = g.d;
   const int64_t ldz = round_up(d, 16);
   int64_t off = 0;
@@ -1237,8 +1237,13 @@ static int source_accumulate(vb_ctx* ctx, hipStream_t st, const NoiseSlot& ns, c
                      Z, ldz, n, (int)d);
   VB_HIP(ctx, hipGetLastError());
   VB_TRY(user_rows_enqueue(ctx, st, Z, ldz, n, (int)d, G, ldz, frow));
+  if (roww) {      // weighted gradient (AlphaDivergence): sum_n w_n g_n = the plain sums of the row-scaled matrix
+    hipLaunchKernelGGL(lg_rowscale_kernel, dim3((unsigned)n, (unsigned)((d + 255) / 256)), dim3(256), 0, st, G, ldz, n,
+                       (int)d, roww);
+    VB_HIP(ctx, hipGetLastError());
+  }
   hipLaunchKernelGGL(lg_scalars_kernel, dim3(1), dim3(256), 0, st, (const double*)frow, (int)n, fsum,
-                     wsb + ws.off_prepscal, (double)n);
+                     wsb + ws.off_prepscal, (double)n, roww, n);
   VB_HIP(ctx, hipGetLastError());
   const dim3 grid((unsigned)(g.n_rb * g.n_cb));
   if (mom && tsc)
@@ -1268,7 +1273,10 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   // targets (two GEMMs) and the source model (the user's row kernel)
   const bool source = model.id == VB_MODEL_SOURCE;
   const bool logistic = model.id == VB_MODEL_LOGISTIC || source;
-  if (logistic && (c.count != 1 || c.mode != 0 || c.cv_mode != VB_CV_NONE || c.roww[0] != nullptr))
+  // (a source model also takes the weighted-gradient mode of AlphaDivergence: its G is scaled row by row)
+  const bool source_weighted = source && c.count == 1 && c.mode == 1 && c.cv_mode == VB_CV_NONE && c.roww[0] != nullptr;
+  if (logistic && !source_weighted &&
+      (c.count != 1 || c.mode != 0 || c.cv_mode != VB_CV_NONE || c.roww[0] != nullptr))
     return fail(ctx, VB_ERR_UNSUPPORTED,
                 "regression and source-model targets support single ExclusiveKL evaluations without control variates");
   if (model.id != VB_MODEL_GAUSS_DIAG && model.id != VB_MODEL_FUNNEL && model.id != kModelLogQ && !logistic)
@@ -1445,7 +1453,7 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   L.st = st_main;
   prof_events(ctx, &L.ev0, &L.ev1, c.count);
   if (source)
-    VB_TRY(source_accumulate(ctx, st_main, *c.noise[0], bp, ws, g, mom, tsc));
+    VB_TRY(source_accumulate(ctx, st_main, *c.noise[0], bp, ws, g, mom, tsc, c.roww[0]));
   else if (logistic)
     VB_TRY(logistic_accumulate(ctx, st_main, model, *c.noise[0], bp, ws, g, mom, tsc));
   else if (model.id == VB_MODEL_GAUSS_DIAG)

@@ -88,7 +88,7 @@ class SourceModel(DeviceModel):
     compiled for the GPU with hiprtc when the model is first bound; a source that does not compile raises
     ``ValueError`` with the compiler's log.  ``ExclusiveKL`` takes it with ``MFGaussian`` / ``MFStudentT`` /
     ``FullRankGaussian`` / ``MultivariateT`` (both estimator forms, no control variates) ``AlphaDivergence`` with
-    ``FullRankGaussian`` and ``DISInclusiveKL`` with every family; the model can be called on host
+    the mean-field families and ``FullRankGaussian``, and ``DISInclusiveKL`` with every family; the model can be called on host
     samples, and ``vi_diagnostics`` forms its importance weights on the device."""
 
     def __init__(self, dim, source, params=None):

@@ -127,11 +127,12 @@ class VariationalObjective(ABC):
         if isinstance(self._model, SourceModel):
             kind, fam = type(self).__name__, type(self._approx).__name__
             if not ((kind == 'ExclusiveKL' and fam in ('MFGaussian', 'MFStudentT', 'FullRankGaussian', 'MultivariateT')) or
-                    (kind == 'AlphaDivergence' and fam == 'FullRankGaussian') or
+                    (kind == 'AlphaDivergence' and fam in ('MFGaussian', 'MFStudentT', 'FullRankGaussian')) or
                     kind == 'DISInclusiveKL'):
                 raise NotImplementedError('SourceModel targets run under ExclusiveKL with MFGaussian, MFStudentT, '
-                                          'FullRankGaussian or MultivariateT, under AlphaDivergence with '
-                                          'FullRankGaussian and under DISInclusiveKL with every family')
+                                          'FullRankGaussian or MultivariateT, under AlphaDivergence with the '
+                                          'mean-field families or FullRankGaussian, and under DISInclusiveKL '
+                                          'with every family')
 
     def _stage_noise(self, eng, n_samples, slot=_NOISE_SLOT, seed=None):
         """Put this call's base noise into a device slot; returns (n_local, n_total).
