@@ -138,7 +138,7 @@ def test_source_model_errors(vb):
     with pytest.raises(NotImplementedError):
         vb.AlphaDivergence(vb.MultivariateT(3, 10), ok, 10, 2.0)
     with pytest.raises(NotImplementedError):
-        vb.ExclusiveKL(vb.LRGaussian(3, 1), ok, 10)
+        vb.AlphaDivergence(vb.LRGaussian(3, 1), ok, 10, 2.0)
     with pytest.raises(ValueError):
         vb.SourceModel(3, '')
 
@@ -375,3 +375,33 @@ def test_source_model_alpha_meanfield_against_oracle(vb, D, N, n_data, family):
         ov, og = oobj.alpha_divergence(ofamily, omodel, theta, noise, alpha)
         assert G.rel_err(value, ov) < 1e-12, (alpha, value, ov)
         assert G.rel_err(grad, og) < 1e-11, (alpha, G.rel_err(grad, og))
+
+
+@pytest.mark.parametrize('D,k,N,n_data', [(6, 1, 100, 30), (24, 4, 800, 30), (130, 7, 333, 40), (200, 16, 1030, 20)])
+@pytest.mark.parametrize('pd', [False, True])
+def test_source_model_lowrank_against_oracle(vb, D, k, N, n_data, pd):
+    """ExclusiveKL + LRGaussian: the streaming pass loads the user kernel's G beside the noise (vb_lowrank.hip)."""
+    model, omodel = _problem(vb, D, n_data, seed=D + k)
+    rng = np.random.RandomState(D + N)
+    fam, ofamily = vb.LRGaussian(D, seed=7, k=k), ofam.LRGaussian(D, k)
+    theta = fam.pack(0.2 * rng.randn(D), -1.0 + 0.1 * rng.randn(D), 0.2 * rng.randn(D, k) / np.sqrt(k))
+    value, grad = vb.ExclusiveKL(fam, model, N, use_path_deriv=pd)(theta)
+    noise = ofamily.draw_noise(np.random.RandomState(7), N)
+    ov, og = oobj.exclusive_kl(ofamily, omodel, theta, noise, pd)
+    assert G.rel_err(value, ov) < (1e-10 if pd else 1e-12), (value, ov)
+    assert G.rel_err(grad, og) < (1e-9 if pd else 1e-11), G.rel_err(grad, og)
+
+
+def test_source_model_lowrank_device_fit_matches_host_loop(vb, capsys):
+    """vb_fit with the low-rank family and a source model: the device-resident loop == the host loop (Philox noise)."""
+    from viabel_amd.optimization import RMSProp
+    D, k, N = 12, 3, 96
+    model, _ = _problem(vb, D, 50, seed=8)
+    init = vb.LRGaussian(D, k=k).pack(np.zeros(D), np.zeros(D), 0.05 * np.random.RandomState(0).randn(D, k))
+    hist = {}
+    for on_device in (False, True):
+        obj = vb.ExclusiveKL(vb.LRGaussian(D, seed=11, k=k, rng='philox'), model, N)
+        res = RMSProp(0.02).optimize(40, obj, init.copy(), on_device=on_device)
+        hist[on_device] = np.asarray(res['value_history'])
+    capsys.readouterr()
+    np.testing.assert_array_equal(hist[False], hist[True])

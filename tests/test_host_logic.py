@@ -249,6 +249,6 @@ def test_source_model_host_side():
     with pytest.raises(NotImplementedError):
         vb.AlphaDivergence(vb.MultivariateT(4, 10), m, 10, 2.0)
     with pytest.raises(NotImplementedError):
-        vb.ExclusiveKL(vb.LRGaussian(4, 1), m, 10)
+        vb.AlphaDivergence(vb.LRGaussian(4, 1), m, 10, 2.0)
     with pytest.raises(ValueError):
         vb.ExclusiveKL(vb.MFGaussian(3), m, 10)         # dimension mismatch

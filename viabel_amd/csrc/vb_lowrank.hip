@@ -41,6 +41,9 @@ struct LrArgs {
   double* mpart;          // [n_mblk][KP x KP] partial B' D^-1 B of 256-row blocks (prep)
   double* minv;           // [KP x KP] inverse capacitance matrix | [KP x KP] = log det M  (capacitance kernel)
   int n_mblk;
+  // source model (the user's row kernel ran on X = the samples): its gradient matrix and values
+  const double* G;        // N x d, row stride ld (the noise's), pad columns zero
+  const double* frow;     // [N]
 };
 
 __device__ __forceinline__ double lr_wave_sum(double x) {
@@ -95,9 +98,10 @@ __global__ void __launch_bounds__(256) lr_prep_kernel(const double* __restrict__
       a.theta_dev[d + i] = ls;
       for (int j = 0; j < k; ++j) a.theta_dev[2 * (int64_t)d + i * k + j] = Bl[threadIdx.x * k + j];
       if (live) {
-        c0 = funnel ? mu : mu - m.p0[i];
+        const bool centred = m.id == VB_MODEL_GAUSS_DIAG;     // funnel, source model: x itself
+        c0 = centred ? mu - m.p0[i] : mu;
         c1 = exp(ls);
-        c2 = funnel ? 0.0 : m.p1[i];
+        c2 = centred ? m.p1[i] : 0.0;
       }
     }
     a.colp[i] = c0;
@@ -219,9 +223,25 @@ __global__ void __launch_bounds__(KP * KP) lr_capacitance_kernel(const LrArgs a)
   }
 }
 
+// ---- source model: the samples X = mu + sigma * eps + z B' as a matrix for the user's row kernel -----------------
+template <int KP>
+__global__ void __launch_bounds__(256) lr_sample_kernel(const LrArgs a, double* __restrict__ X) {
+  __shared__ double zr[KP];
+  const int64_t row = blockIdx.x;            // rows on x: gridDim.y stops at 65 535
+  const int col = blockIdx.y * 256 + threadIdx.x;
+  if (threadIdx.x < KP) zr[threadIdx.x] = (int)threadIdx.x < a.k ? a.z[row * a.ldk + threadIdx.x] : 0.0;
+  __syncthreads();
+  if (col >= a.d) return;
+  double x = fma(a.colp[a.Dp + col], a.eps[row * a.ld + col], a.colp[col]);
+#pragma unroll
+  for (int j = 0; j < KP; ++j) x = fma(zr[j], a.Bp[(int64_t)col * KP + j], x);
+  X[row * a.ld + col] = x;
+}
+
 // ---- the streaming pass --------------------------------------------------------------------------------
 template <int MODEL, int KP>
 __global__ void __launch_bounds__(256) lr_accum_kernel(const LrArgs a) {
+  constexpr bool SRC = MODEL == VB_MODEL_SOURCE;           // g is loaded (the user's kernel made it), not computed
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rb = blockIdx.x / a.n_cb, cb = blockIdx.x % a.n_cb;
@@ -236,8 +256,8 @@ __global__ void __launch_bounds__(256) lr_accum_kernel(const LrArgs a) {
   double b0[KP], b1[KP];
 #pragma unroll
   for (int j = 0; j < KP; ++j) {
-    b0[j] = a.Bp[(int64_t)c0i * KP + j];
-    b1[j] = a.Bp[(int64_t)(c0i + 1) * KP + j];
+    b0[j] = SRC ? 0.0 : a.Bp[(int64_t)c0i * KP + j];
+    b1[j] = SRC ? 0.0 : a.Bp[(int64_t)(c0i + 1) * KP + j];
   }
   lr_d2 aG = (lr_d2){0.0, 0.0}, aGE = (lr_d2){0.0, 0.0};
   double gz0[KP], gz1[KP], qz[KP];
@@ -246,15 +266,20 @@ __global__ void __launch_bounds__(256) lr_accum_kernel(const LrArgs a) {
   double F = 0.0, QG = 0.0, QGE = 0.0;
 
   // one row: x = c0 + sigma e + z B', model gradient, accumulate
-  auto row = [&](const lr_d2 ev, const double* zj, double w, double ek) __attribute__((always_inline)) {
+  auto row = [&](const lr_d2 ev, const lr_d2 gv, const double* zj, double w, double ek) __attribute__((always_inline)) {
     double x0 = fma(cp1.x, ev.x, cp0.x), x1 = fma(cp1.y, ev.y, cp0.y);
+    if (!SRC) {
 #pragma unroll
-    for (int j = 0; j < KP; ++j) {
-      x0 = fma(zj[j], b0[j], x0);
-      x1 = fma(zj[j], b1[j], x1);
+      for (int j = 0; j < KP; ++j) {
+        x0 = fma(zj[j], b0[j], x0);
+        x1 = fma(zj[j], b1[j], x1);
+      }
     }
     double g0, g1;
-    if (MODEL == VB_MODEL_GAUSS_DIAG) {                   // x holds z - m
+    if (SRC) {
+      g0 = gv.x;
+      g1 = gv.y;
+    } else if (MODEL == VB_MODEL_GAUSS_DIAG) {            // x holds z - m
       g0 = -x0 * cp2.x;
       g1 = -x1 * cp2.y;
       F = fma(0.5 * x0, g0, fma(0.5 * x1, g1, F));
@@ -304,22 +329,26 @@ __global__ void __launch_bounds__(256) lr_accum_kernel(const LrArgs a) {
 
   constexpr int RIF = 8;                                   // eps rows in flight per wave (8 KiB)
   const double* __restrict__ eps = a.eps + c0i;
+  const double* __restrict__ gsrc = SRC ? a.G + c0i : nullptr;
   const bool cols_full = (cb + 1) * kLrCols <= a.ld;      // every lane's 16-B load stays inside the row
   int64_t base = r0 + wave;
   // full steps of RIF rows, software-pipelined: the loads of step s + 1 are issued before the arithmetic of step s
   auto full = [&](int64_t bs) { return cols_full && bs + (int64_t)kLrWaves * (RIF - 1) < r1; };
-  auto load_step = [&](int64_t bs, lr_d2* e) __attribute__((always_inline)) {
+  auto load_step = [&](int64_t bs, lr_d2* e, lr_d2* gq) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < RIF; ++u)
+    for (int u = 0; u < RIF; ++u) {
       e[u] = __builtin_nontemporal_load(reinterpret_cast<const lr_d2*>(eps + (bs + (int64_t)kLrWaves * u) * a.ld));
+      if constexpr (SRC)
+        gq[u] = __builtin_nontemporal_load(reinterpret_cast<const lr_d2*>(gsrc + (bs + (int64_t)kLrWaves * u) * a.ld));
+    }
   };
   if (full(base)) {
-    lr_d2 e[RIF], en[RIF];
-    load_step(base, e);
+    lr_d2 e[RIF], en[RIF], gq[SRC ? RIF : 1], gqn[SRC ? RIF : 1];
+    load_step(base, e, gq);
     for (;;) {
       const int64_t next = base + (int64_t)kLrWaves * RIF;
       const bool more = full(next);                       // wave-uniform
-      if (more) load_step(next, en);
+      if (more) load_step(next, en, gqn);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < RIF; ++u) {
@@ -327,24 +356,30 @@ __global__ void __launch_bounds__(256) lr_accum_kernel(const LrArgs a) {
         double zj[KP];
 #pragma unroll
         for (int j = 0; j < KP; ++j) zj[j] = zr[j];
-        row(e[u], zj, zr[KP], zr[KP + 1]);
+        row(e[u], SRC ? gq[SRC ? u : 0] : (lr_d2){0.0, 0.0}, zj, zr[KP], zr[KP + 1]);
       }
       base = next;
       if (!more) break;
 #pragma unroll
-      for (int u = 0; u < RIF; ++u) e[u] = en[u];
+      for (int u = 0; u < RIF; ++u) {
+        e[u] = en[u];
+        if constexpr (SRC) gq[u] = gqn[u];
+      }
     }
   }
   // ragged tail (last rows / last column block): one row at a time, predicated
   for (; base < r1; base += kLrWaves) {
-    lr_d2 ev = (lr_d2){0.0, 0.0};
+    lr_d2 ev = (lr_d2){0.0, 0.0}, gv = (lr_d2){0.0, 0.0};
     if (lane_ok) ev = __builtin_nontemporal_load(reinterpret_cast<const lr_d2*>(eps + base * a.ld));
+    if (SRC && lane_ok) gv = __builtin_nontemporal_load(reinterpret_cast<const lr_d2*>(gsrc + base * a.ld));
     const double* zr = zs[(int)(base - r0)];
     double zj[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) zj[j] = zr[j];
-    row(ev, zj, zr[KP], zr[KP + 1]);
+    row(ev, gv, zj, zr[KP], zr[KP + 1]);
   }
+  if (SRC && cb == 0)                                      // sum f of this row block, once per row
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) F += a.frow[r];
 
   // combine the 4 waves in fixed order, up to 6 fields per barrier pair; one partial per column per workgroup
   constexpr int kChunk = 6;
@@ -497,6 +532,7 @@ static int lr_run(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
   LrArgs a;
   a.eps = (const double*)ns.buf.ptr, a.z = (const double*)nz.buf.ptr;
   a.ld = ns.ld, a.ldk = nz.ld, a.n = n, a.d = (int)d, a.k = k;
+  a.G = nullptr, a.frow = nullptr;
   a.n_cb = (int)((d + kLrCols - 1) / kLrCols);
   a.Dp = a.n_cb * kLrCols;
   const char* wg_env = getenv("VB_LR_WG_PER_CU");
@@ -530,7 +566,19 @@ static int lr_run(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
   hipLaunchKernelGGL((lr_capacitance_kernel<KP>), dim3(1), dim3(KP * KP), 0, st, a);
   VB_HIP(ctx, hipGetLastError());
   const dim3 grid((unsigned)(a.n_rb * a.n_cb));
-  if (funnel)
+  if (m.id == VB_MODEL_SOURCE) {
+    // samples as a matrix -> the user's row kernel -> (f, G); the streaming pass then loads G beside the noise
+    const int64_t o_x = 0, o_g = round_up(n * a.ld, 16), o_f = o_g + round_up(n * a.ld, 16);
+    VB_TRY(ensure(ctx, ctx->lg_work, (size_t)(o_f + round_up(n, 16)) * sizeof(double)));
+    double* wb = (double*)ctx->lg_work.ptr;
+    double *X = wb + o_x, *G = wb + o_g, *frow = wb + o_f;
+    VB_HIP(ctx, hipMemsetAsync(G, 0, (size_t)n * a.ld * sizeof(double), st));     // pad columns are streamed too
+    hipLaunchKernelGGL((lr_sample_kernel<KP>), dim3((unsigned)n, (unsigned)((d + 255) / 256)), dim3(256), 0, st, a, X);
+    VB_HIP(ctx, hipGetLastError());
+    VB_TRY(user_rows_enqueue(ctx, st, X, a.ld, n, (int)d, G, a.ld, frow));
+    a.G = G, a.frow = frow;
+    hipLaunchKernelGGL((lr_accum_kernel<VB_MODEL_SOURCE, KP>), grid, dim3(256), 0, st, a);
+  } else if (funnel)
     hipLaunchKernelGGL((lr_accum_kernel<VB_MODEL_FUNNEL, KP>), grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((lr_accum_kernel<VB_MODEL_GAUSS_DIAG, KP>), grid, dim3(256), 0, st, a);
@@ -549,9 +597,9 @@ static int lr_run(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
 int lr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
                          int64_t n_total, const double* theta_src, double* out) {
   const ModelDev& m = ctx->model;
-  if (m.id != VB_MODEL_GAUSS_DIAG && m.id != VB_MODEL_FUNNEL)
-    return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank path supports the gauss_diag and funnel models (model id %d bound)",
-                m.id);
+  if (m.id != VB_MODEL_GAUSS_DIAG && m.id != VB_MODEL_FUNNEL && m.id != VB_MODEL_SOURCE)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank path supports the gauss_diag, funnel and source models (model id %d "
+                "bound)", m.id);
   if (m.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension %d != family dimension %lld", m.dim, (long long)d);
   if (k < 1 || k > 16) return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank path supports 1 <= k <= 16 (got %lld)", (long long)k);
   if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d)
