@@ -114,9 +114,9 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams,
  * returning f(z) for one sample z[0..d) and writing grad f to grad[0..d) unless grad is NULL.  `params` (n_params
  * doubles: data, hyper-parameters) is uploaded with the model.  The source is compiled for this GPU with hiprtc;
  * VB_ERR_INVALID carries the compiler's log.  Supported by ExclusiveKL over all five families (entropy form and path
- * derivative, no control variates), by the alpha-divergence of the mean-field and dense Gaussian families
- * (vb_alpha_grad_meanfield, vb_alpha_grad_fullrank), by the DIS refreshes (vb_dis_refresh_meanfield / _mvt /
- * _lowrank: log p of the state samples), by vb_log_weights_meanfield and by vb_model_logp.                   */
+ * derivative, no control variates), by the alpha-divergence entry points (vb_alpha_grad_meanfield,
+ * vb_alpha_grad_fullrank, vb_alpha_sums_mvt, vb_alpha_sums_lowrank), by the DIS refreshes (vb_dis_refresh_meanfield /
+ * _mvt / _lowrank: log p of the state samples), by vb_log_weights_meanfield and by vb_model_logp.            */
 int vb_set_model_source(vb_ctx* ctx, int64_t dim, const char* source, const double* params, size_t n_params);
 /* f(x_n), n < N, for host x (N x D): Model.__call__ (models.py:27-39) on the device */
 int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* out_host);

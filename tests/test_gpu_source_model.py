@@ -135,10 +135,8 @@ def test_source_model_errors(vb):
         bad(np.zeros(3))
     ok = vb.SourceModel(3, '__device__ double vb_log_density(const double* z, int d, const double* p, double* g) '
                            '{ double f = 0; for (int j = 0; j < d; ++j) { f -= 0.5 * z[j] * z[j]; if (g) g[j] = -z[j]; } return f; }')
-    with pytest.raises(NotImplementedError):
-        vb.AlphaDivergence(vb.MultivariateT(3, 10), ok, 10, 2.0)
-    with pytest.raises(NotImplementedError):
-        vb.AlphaDivergence(vb.LRGaussian(3, 1), ok, 10, 2.0)
+    with pytest.raises(NotImplementedError):        # the RGE control variates assume the built-in targets' Hessians
+        vb.ExclusiveKL(vb.MFGaussian(3), ok, 10, hessian_approx_method='full')(np.zeros(6))
     with pytest.raises(ValueError):
         vb.SourceModel(3, '')
 
@@ -405,3 +403,36 @@ def test_source_model_lowrank_device_fit_matches_host_loop(vb, capsys):
         hist[on_device] = np.asarray(res['value_history'])
     capsys.readouterr()
     np.testing.assert_array_equal(hist[False], hist[True])
+
+
+@pytest.mark.parametrize('D,N,n_data,df', [(6, 100, 30, 40.0), (70, 333, 40, 7.0)])
+def test_source_model_alpha_multivariate_t_against_oracle(vb, D, N, n_data, df):
+    model, omodel = _problem(vb, D, n_data, seed=7 * D)
+    rng = np.random.RandomState(D)
+    omvt = ofam.MultivariateT(D, df)
+    L = np.tril(0.05 * rng.randn(D, D), -1) + np.diag(np.exp(-1.0 + 0.2 * rng.randn(D)))
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.chol_to_free(L)])
+    for alpha in (2.0, 0.5):
+        np.random.seed(17)
+        value, grad = vb.AlphaDivergence(vb.MultivariateT(D, df), model, N, alpha)(theta)
+        np.random.seed(17)
+        noise = omvt.draw_noise(np.random.RandomState(np.random.randint(2 ** 32)), N)
+        ov, og = oobj.alpha_divergence(omvt, omodel, theta, noise, alpha)
+        assert G.rel_err(value, ov) < 1e-12, (alpha, value, ov)
+        assert G.rel_err(grad, og) < 1e-10, (alpha, G.rel_err(grad, og))
+
+
+@pytest.mark.parametrize('D,k,N,n_data', [(6, 1, 100, 30), (64, 4, 1000, 40), (130, 16, 777, 25)])
+def test_source_model_alpha_lowrank_against_oracle(vb, D, k, N, n_data):
+    model, omodel = _problem(vb, D, n_data, seed=D + 3 * k)
+    rng = np.random.RandomState(D + k)
+    ofamily = ofam.LRGaussian(D, k)
+    theta = np.concatenate([0.1 * rng.randn(D), -0.7 + 0.2 * rng.randn(D), 0.3 * rng.randn(D * k) / np.sqrt(k)])
+    for alpha in (2.0, 0.5):
+        np.random.seed(77)
+        value, grad = vb.AlphaDivergence(vb.LRGaussian(D, seed=2, k=k), model, N, alpha)(theta)
+        np.random.seed(77)
+        noise = ofamily.draw_noise(np.random.RandomState(np.random.randint(2 ** 32)), N)
+        ov, og = oobj.alpha_divergence(ofamily, omodel, theta, noise, alpha)
+        assert G.rel_err(value, ov) < 1e-11, (alpha, value, ov)
+        assert G.rel_err(grad, og) < 1e-9, (alpha, G.rel_err(grad, og))

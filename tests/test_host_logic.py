@@ -246,9 +246,8 @@ def test_source_model_host_side():
     for bad in ('', None, 3):
         with pytest.raises(ValueError):
             vb.SourceModel(2, bad)
-    with pytest.raises(NotImplementedError):
-        vb.AlphaDivergence(vb.MultivariateT(4, 10), m, 10, 2.0)
-    with pytest.raises(NotImplementedError):
-        vb.AlphaDivergence(vb.LRGaussian(4, 1), m, 10, 2.0)
+    for fam in (vb.MultivariateT(4, 10), vb.LRGaussian(4, k=1)):    # every objective x family takes a source model
+        vb.AlphaDivergence(fam, m, 10, 2.0)
+        vb.ExclusiveKL(fam, m, 10)
     with pytest.raises(ValueError):
         vb.ExclusiveKL(vb.MFGaussian(3), m, 10)         # dimension mismatch

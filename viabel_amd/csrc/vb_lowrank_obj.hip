@@ -359,14 +359,14 @@ int lro_colsum_prod(vb_ctx* ctx, const LroLayout& L, double* base, const double*
   return VB_OK;
 }
 
-// f_only: the objective needs f of the samples but not the model's gradient (DIS) -- a source model's row kernel will do
-int lro_check(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k, bool f_only = false) {
+// (every caller takes a source model: DIS needs f of the samples only, the alpha sums load the user kernel's G)
+int lro_check(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k) {
   if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d || k < 1 || k > kLdk)
     return fail(ctx, VB_ERR_INVALID, "noise slots must hold n x d and n x k (1 <= k <= 16) matrices");
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL &&
-      !(f_only && ctx->model.id == VB_MODEL_SOURCE))
-    return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank DIS / alpha objectives implement the gauss_diag and funnel models "
-                "(DIS: source models too)");
+      ctx->model.id != VB_MODEL_SOURCE)
+    return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank DIS / alpha objectives implement the gauss_diag, funnel and source "
+                "models");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
   return VB_OK;
 }
@@ -378,7 +378,7 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
                    int64_t k, const double* mu, const double* log_sigma, const double* B, const double* minv, double cq,
                    const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
                    double* ess_out, double* w_host, double* logp_host, double* logq_host) {
-  VB_TRY(lro_check(ctx, ns, nz, n, d, k, true));
+  VB_TRY(lro_check(ctx, ns, nz, n, d, k));
   if (n * (int64_t)ctx->n_ranks != n_total)
     return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
   const LroLayout L = lro_layout(n, n_total, d);
@@ -504,7 +504,13 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
                      (const double*)(base + L.o_sig), (const double*)(base + L.o_b), base + L.o_x, L.ld, base + L.o_zp);
   VB_HIP(ctx, hipGetLastError());
   VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 1, base + L.o_lq));          // T = [t | 1 | log q], t = z - tau
-  VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_f));
+  const bool source = ctx->model.id == VB_MODEL_SOURCE;
+  if (source) {      // the user's row kernel gives f and G in one pass (pad columns of G stay zero)
+    VB_HIP(ctx, hipMemsetAsync(base + L.o_g, 0, (size_t)n * L.ld * sizeof(double), st));
+    VB_TRY(user_rows_enqueue(ctx, st, base + L.o_x, L.ld, n, (int)d, base + L.o_g, L.ld, base + L.o_f));
+  } else {
+    VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_f));
+  }
   double* scal = base + L.o_scal;
   hipLaunchKernelGGL(lro_lw_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_f),
                      (const double*)(base + L.o_lq), n, scal + 8);
@@ -514,8 +520,9 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
                      (const double*)(base + L.o_lq), (const double*)(scal + 8), n, alpha, base + L.o_w, scal + 9);
   VB_HIP(ctx, hipGetLastError());
   VB_TRY(comm_allreduce_sum(ctx, st, scal + 9, 1));
-  hipLaunchKernelGGL(lro_model_grad_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
-                     (const double*)(base + L.o_x), L.ld, n, (int)d, ctx->model, base + L.o_g);
+  if (!source)
+    hipLaunchKernelGGL(lro_model_grad_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
+                       (const double*)(base + L.o_x), L.ld, n, (int)d, ctx->model, base + L.o_g);
   VB_HIP(ctx, hipGetLastError());
   const dim3 sgrid((unsigned)((n * kLdt + 255) / 256));
   // E' (s T): sum s eps t';  T' (s T): sum s t t'

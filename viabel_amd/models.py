@@ -86,9 +86,8 @@ class SourceModel(DeviceModel):
     returning ``f(z)`` for one sample ``z[0..d)`` and writing its gradient to ``grad[0..d)`` unless ``grad`` is
     NULL; ``params`` is the array given here (data, hyper-parameters), resident on the device.  The source is
     compiled for the GPU with hiprtc when the model is first bound; a source that does not compile raises
-    ``ValueError`` with the compiler's log.  ``ExclusiveKL`` and ``DISInclusiveKL`` take it with every family (both estimator
-    forms, no control variates), ``AlphaDivergence`` with the mean-field families and ``FullRankGaussian``; the
-    model can be called on host samples, and ``vi_diagnostics`` forms its importance weights on the device."""
+    ``ValueError`` with the compiler's log.  ``ExclusiveKL`` (both estimator forms, no control variates),
+    ``AlphaDivergence`` and ``DISInclusiveKL`` take it with every family; the model can be called on host samples, and ``vi_diagnostics`` forms its importance weights on the device."""
 
     def __init__(self, dim, source, params=None):
         if not isinstance(source, (str, bytes)) or not source:

@@ -124,14 +124,6 @@ class VariationalObjective(ABC):
         if self._model.dim != self._approx.dim:
             raise ValueError('model dimension {} != approximation dimension {}'.format(
                 self._model.dim, self._approx.dim))
-        if isinstance(self._model, SourceModel):
-            kind, fam = type(self).__name__, type(self._approx).__name__
-            if not (kind == 'ExclusiveKL' or
-                    (kind == 'AlphaDivergence' and fam in ('MFGaussian', 'MFStudentT', 'FullRankGaussian')) or
-                    kind == 'DISInclusiveKL'):
-                raise NotImplementedError('SourceModel targets run under ExclusiveKL and DISInclusiveKL with every '
-                                          'family, and under AlphaDivergence with the mean-field families or '
-                                          'FullRankGaussian')
 
     def _stage_noise(self, eng, n_samples, slot=_NOISE_SLOT, seed=None):
         """Put this call's base noise into a device slot; returns (n_local, n_total).
