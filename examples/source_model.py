@@ -47,6 +47,8 @@ beta = np.array([2.0, -1.0, 0.5, 0.0, 3.0])
 y = X @ beta + 0.3 * rng.standard_t(3.0, size=n)
 y[:10] += 15.0                                   # outliers the t likelihood shrugs off
 model = vb.SourceModel(D, SRC, np.concatenate([[n, 4.0, 0.3, 10.0], X.ravel(), y]))
+# the gradient above is hand-written: compare it with differences of the density before trusting a fit to it
+print('gradient check (max relative deviation from central differences): %.1e' % model.check_gradient(rng.randn(8, D)))
 
 res = vb.bbvi(D, log_density=model, approx=vb.MFGaussian(D, rng='philox'), n_iters=4000, num_mc_samples=64,
               learning_rate=0.05)

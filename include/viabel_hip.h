@@ -120,6 +120,10 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams,
 int vb_set_model_source(vb_ctx* ctx, int64_t dim, const char* source, const double* params, size_t n_params);
 /* f(x_n), n < N, for host x (N x D): Model.__call__ (models.py:27-39) on the device */
 int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* out_host);
+/* f(x_n) and grad f(x_n), n < N, for host x (N x D): what autograd's grad of Model.__call__ returns in the
+ * reference (models.py:17-39; tests/test_models.py:13-15 checks it with check_vjp).  g_host is N x D row-major;
+ * f_host (N) may be NULL.  Every built-in target and source models.                                            */
+int vb_model_grad(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* f_host, double* g_host);
 
 /* ---- ExclusiveKL, mean-field families (objectives.py:150-273) ----------------------
  * theta = [mu(D) | log_sigma(D)] on the host; noise slot holds the N x D base draws

@@ -56,6 +56,7 @@ SIGNATURES = {
                                     _c_int64_p, ctypes.c_size_t]),
     'vb_set_model_source': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_char_p, _c_double_p, ctypes.c_size_t]),
     'vb_model_logp': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
+    'vb_model_grad': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_elbo_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_double, _c_double_p,
                                               ctypes.c_uint, ctypes.c_int, _c_double_p, _c_double_p]),
@@ -317,6 +318,15 @@ class Engine:
         out = np.empty(n, dtype=np.float64)
         self._check(self._lib.vb_model_logp(self._ctx, _dptr(x), n, d, _dptr(out)))
         return out
+
+    def model_grad(self, x):
+        """(f(x_n), grad f(x_n)) of the bound model for host points x (N x D)."""
+        x = _f64(x)
+        n, d = x.shape
+        f = np.empty(n, dtype=np.float64)
+        g = np.empty((n, d), dtype=np.float64)
+        self._check(self._lib.vb_model_grad(self._ctx, _dptr(x), n, d, _dptr(f), _dptr(g)))
+        return f, g
 
     # ------------------------------------------------------------------ ExclusiveKL, mean field
     def elbo_grad_meanfield(self, slot, n, d, theta, family, df=0.0, flags=0, cv_mode=0, n_total=None):

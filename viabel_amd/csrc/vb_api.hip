@@ -451,6 +451,33 @@ int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, doubl
   return VB_OK;
 }
 
+int vb_model_grad(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* f_host, double* g_host) {
+  if (!ctx || !x_host || !g_host) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (d != ctx->model.dim)
+    return fail(ctx, VB_ERR_INVALID, "x has %lld columns, model dimension is %d", (long long)d,
+                ctx->model.dim);
+  if (n <= 0) return fail(ctx, VB_ERR_INVALID, "n must be positive");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t ld = round_up(d, 16);
+  VB_TRY(ensure(ctx, ctx->scratch, (size_t)2 * n * ld * sizeof(double)));
+  VB_TRY(ensure(ctx, ctx->scratch2, (size_t)n * sizeof(double)));
+  double* xd = (double*)ctx->scratch.ptr;
+  double* gd = xd + n * ld;
+  double* fd = (double*)ctx->scratch2.ptr;
+  VB_HIP(ctx, hipMemsetAsync(xd, 0, (size_t)n * ld * sizeof(double), ctx->stream));
+  VB_HIP(ctx, hipMemcpy2DAsync(xd, (size_t)ld * sizeof(double), x_host, (size_t)d * sizeof(double),
+                               (size_t)d * sizeof(double), (size_t)n, hipMemcpyHostToDevice,
+                               ctx->stream));
+  VB_TRY(model_grad_rows(ctx, xd, ld, n, d, gd, fd));
+  if (f_host)
+    VB_HIP(ctx, hipMemcpyAsync(f_host, fd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipMemcpy2DAsync(g_host, (size_t)d * sizeof(double), gd, (size_t)ld * sizeof(double),
+                               (size_t)d * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VB_OK;
+}
+
 // ---- ExclusiveKL, mean field ------------------------------------------------------------------
 // Enqueue `count` independent evaluations: evaluation b streams noise slot slots[b] with parameter
 // thetas[b * 2d ...] and lands in result slot *rs[b].

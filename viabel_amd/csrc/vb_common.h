@@ -411,6 +411,8 @@ int glm_grad_enqueue(vb_ctx* ctx, hipStream_t st, const ModelDev& m, const doubl
 
 // model log density for explicit x (vb_rows.hip)
 int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev);
+// G[row] = grad f(x[row]) (row stride ld, pad columns zero), f[row] = f(x[row]) for the bound model
+int model_grad_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* g_dev, double* f_dev);
 
 // RCCL (vb_comm.hip)
 int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count);

@@ -211,6 +211,107 @@ int glm_grad_enqueue(vb_ctx* ctx, hipStream_t st, const ModelDev& m, const doubl
   return VB_OK;
 }
 
+// ---- per-sample gradients (vb_model_grad): f and grad f of given points ----------------------------------------
+// The reference gets them from autograd (models.py:17-39; tests/test_models.py:13-15 checks the vjp); here every
+// target has its own device gradient, and this is the entry that shows it to the caller -- a hand-written
+// vb_log_density can be checked against differences of its own f (SourceModel.check_gradient).
+__global__ void __launch_bounds__(256) model_grad_rows_kernel(const double* __restrict__ X, int64_t ld, int64_t n, int d,
+                                                              ModelDev m, double* __restrict__ G) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double* x = X + row * ld;
+  double* g = G + row * ld;
+  if (m.id == VB_MODEL_GAUSS_DIAG) {
+    for (int c = lane; c < d; c += 64) g[c] = -(x[c] - m.p0[c]) * m.p1[c];
+    return;
+  }
+  // funnel: d/dx_c = -x_c e^{-2v} (c != k);  d/dv = -v / tau^2 - (d - 1) + e^{-2v} sum_{c != k} x_c^2
+  const double v = x[m.k], w = exp(-2.0 * v);
+  double ss = 0.0;
+  for (int c = lane; c < d; c += 64)
+    if (c != m.k) {
+      g[c] = -x[c] * w;
+      ss = fma(x[c], x[c], ss);
+    }
+  ss = wave_sum_rows(ss);
+  if (lane == 0) g[m.k] = fma(-v, 1.0 / (m.tau * m.tau), -(double)(d - 1)) + w * ss;
+}
+
+struct EpiStoreNegRows {     // Y = -acc
+  double* Y;
+  int64_t ldy;
+  __device__ void operator()(int, int row, int col, double acc) const { Y[(int64_t)row * ldy + col] = -acc; }
+};
+
+struct EpiTermResidual {     // T = log-likelihood term of observation `col` at eta = acc, R = its derivative in eta
+  double* T;
+  double* R;
+  int64_t ldt;
+  const double* y;
+  int link;
+  double aux;
+  __device__ void operator()(int, int row, int col, double eta) const {
+    double dl;
+    T[(int64_t)row * ldt + col] = glm_term(link, aux, y[col], eta, &dl);
+    R[(int64_t)row * ldt + col] = dl;
+  }
+};
+
+int model_grad_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* g_dev, double* f_dev) {
+  const ModelDev& m = ctx->model;
+  hipStream_t st = ctx->stream;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  VB_HIP(ctx, hipMemsetAsync(g_dev, 0, (size_t)n * ld * sizeof(double), st));
+  if (m.id == VB_MODEL_SOURCE) return user_rows_enqueue(ctx, st, x_dev, ld, n, (int)d, g_dev, ld, f_dev);
+  if (m.id == VB_MODEL_GAUSS_DIAG || m.id == VB_MODEL_FUNNEL) {
+    VB_TRY(model_logp_rows(ctx, x_dev, ld, n, d, f_dev));
+    hipLaunchKernelGGL(model_grad_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x_dev, ld, n, (int)d, m,
+                       g_dev);
+    VB_HIP(ctx, hipGetLastError());
+    return VB_OK;
+  }
+  if (m.id == VB_MODEL_GAUSS_FULL) {      // G = -(x - m) P (P symmetric), f = 1/2 (x - m) . G + c0
+    VB_TRY(ensure(ctx, ctx->rows_work, (size_t)n * ld * sizeof(double)));
+    double* Xc = (double*)ctx->rows_work.ptr;
+    hipLaunchKernelGGL(rows_center_kernel, dim3((unsigned)n, (unsigned)((ld + 255) / 256)), dim3(256), 0, st, x_dev, ld,
+                       n, (int)d, m.p0, Xc);
+    VB_HIP(ctx, hipGetLastError());
+    GemmArgs g;
+    g.A = Xc, g.lda = ld, g.B = m.p1, g.ldb = m.ldp;
+    g.M = (int)n, g.N = (int)d, g.K = (int)d, g.tri_mode = 0;
+    gemm_f64_launch<true>(st, g, 1, n_cu, EpiStoreNegRows{g_dev, ld});
+    VB_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)Xc, ld,
+                       (const double*)g_dev, ld, (int)d, 0.5, (const double*)nullptr, (int64_t)0, 0, 0.0, m.c0, n, f_dev);
+    VB_HIP(ctx, hipGetLastError());
+    return VB_OK;
+  }
+  if (m.id == VB_MODEL_LOGISTIC) {        // eta = x X' -> terms and residuals -> f, G = R X - x / sd^2; row chunks
+    const int64_t ldt = m.ldq;
+    int64_t chunk = ((int64_t)32 << 20) / ldt;
+    chunk = chunk < 128 ? 128 : (chunk > n ? n : chunk);
+    VB_TRY(ensure(ctx, ctx->rows_work, (size_t)2 * chunk * ldt * sizeof(double)));
+    double* T = (double*)ctx->rows_work.ptr;
+    double* R = T + chunk * ldt;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t rows = n - r0 < chunk ? n - r0 : chunk;
+      GemmArgs g;
+      g.A = x_dev + r0 * ld, g.lda = ld, g.B = m.p1, g.ldb = m.ldq;
+      g.M = (int)rows, g.N = (int)m.n_data, g.K = (int)d, g.tri_mode = 0;
+      gemm_f64_launch<true>(st, g, 1, n_cu, EpiTermResidual{T, R, ldt, m.p2, m.link, m.aux});
+      VB_HIP(ctx, hipGetLastError());
+      hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const double*)T, ldt,
+                         (const double*)nullptr, (int64_t)0, (int)m.n_data, 1.0, x_dev + r0 * ld, ld, (int)d,
+                         -0.5 / (m.tau * m.tau), m.c0, rows, f_dev + r0);
+      VB_HIP(ctx, hipGetLastError());
+      VB_TRY(glm_grad_enqueue(ctx, st, m, R, ldt, x_dev + r0 * ld, g_dev + r0 * ld, ld, rows, (int)d));
+    }
+    return VB_OK;
+  }
+  return fail(ctx, VB_ERR_UNSUPPORTED, "row gradient: unknown model id %d", m.id);
+}
+
 int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d,
                     double* out_dev) {
   if (ctx->model.id == VB_MODEL_GAUSS_FULL) return gauss_full_rows(ctx, x_dev, ld, n, d, out_dev);

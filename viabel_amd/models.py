@@ -73,6 +73,42 @@ class DeviceModel(Model):
         eng.set_model(self.device_spec())
         return eng.model_logp(x)
 
+    def _rows(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        one = x.ndim == 1
+        if one:
+            x = x[np.newaxis, :]
+        if x.ndim != 2 or x.shape[1] != self._dim:
+            raise ValueError('model_param must have shape (N, {0}) or ({0},)'.format(self._dim))
+        return np.ascontiguousarray(x), one
+
+    def grad(self, x):
+        """Gradient of the log density at each row of ``x`` -- what ``autograd.elementwise_grad(model)`` gives in the
+        reference (``objectives.py:191``; ``tests/test_models.py:13-15`` checks it) -- from the device code the
+        objectives use (``vb_model_grad``).  ``x``: (N, D) or (D,); returns the same shape."""
+        x, one = self._rows(x)
+        eng = _lib.default_engine()
+        eng.set_model(self.device_spec())
+        g = eng.model_grad(x)[1]
+        return g[0] if one else g
+
+    def check_gradient(self, x, step=1e-6):
+        """Largest deviation of the device gradient from central differences of the device log density at the rows of
+        ``x``, relative to the largest gradient entry there: the check the reference runs on its models with
+        ``autograd.test_util.check_vjp`` (``tests/test_models.py:13-15``).  For a ``SourceModel`` the gradient is
+        hand-written code and nothing else verifies it: a value above ~1e-6 means ``grad`` does not match ``f``."""
+        x, _ = self._rows(x)
+        n, d = x.shape
+        h = step * np.maximum(1.0, np.abs(x))                          # (N, D) per-coordinate steps
+        pts = np.repeat(x[:, np.newaxis, :], 2 * d, axis=1)          # (N, 2D, D): x + h e_j, then x - h e_j
+        idx = np.arange(d)
+        pts[:, idx, idx] += h
+        pts[:, d + idx, idx] -= h
+        f = self(pts.reshape(n * 2 * d, d)).reshape(n, 2 * d)
+        fd = (f[:, :d] - f[:, d:]) / (2.0 * h)
+        g = self.grad(x)
+        return float(np.max(np.abs(g - fd)) / max(np.max(np.abs(g)), np.max(np.abs(fd)), 1e-300))
+
 
 class SourceModel(DeviceModel):
     """A log density outside the built-in set, given as HIP device code -- the adaptor for what the reference
