@@ -9,5 +9,5 @@ for f in *.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $extra -c $f -o /tmp/vbvar_$name/${f%.hip}.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/vbvar_$name/*.o -shared -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -o ../../tools/libviabel_hip_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/vbvar_$name/*.o -shared -L/opt/rocm/lib -lrccl -ldl -Wl,-rpath,/opt/rocm/lib -o ../../tools/libviabel_hip_$name.so
 ls -la ../../tools/libviabel_hip_$name.so
