@@ -113,3 +113,18 @@ def test_model_grad_argument_checks(vb):
         model.grad(np.zeros((4, 2)))
     with pytest.raises(ValueError):
         model.grad(np.zeros((2, 2, 3)))
+
+
+def test_model_grad_edge_shapes(vb):
+    """One point, one dimension, ragged widths (row strides are padded to 16 doubles on the device)."""
+    rng = np.random.RandomState(9)
+    g = vb.GaussianModel([0.5], [2.0]).grad(np.array([[1.5]]))
+    np.testing.assert_allclose(g, [[-(1.5 - 0.5) / 4.0]], rtol=1e-15)
+    for D in (1, 15, 16, 17, 33):
+        m, sd = rng.randn(D), np.exp(0.2 * rng.randn(D))
+        x = rng.randn(3, D)
+        np.testing.assert_allclose(vb.GaussianModel(m, sd).grad(x), omod.GaussDiag(m, sd).grad(x), rtol=1e-13, atol=1e-14)
+    src = vb.SourceModel(17, GOOD, [1.5, -0.2])
+    x = rng.randn(1, 17)
+    assert src.check_gradient(x) < 1e-7
+    assert src.grad(x).shape == (1, 17) and src.grad(x[0]).shape == (17,)
