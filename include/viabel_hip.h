@@ -112,7 +112,13 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams,
  * defines
  *     __device__ double vb_log_density(const double* z, int d, const double* params, double* grad);
  * returning f(z) for one sample z[0..d) and writing grad f to grad[0..d) unless grad is NULL.  `params` (n_params
- * doubles: data, hyper-parameters) is uploaded with the model.  The source is compiled for this GPU with hiprtc;
+ * doubles: data, hyper-parameters) is uploaded with the model.  A model that is a sum over data may instead define
+ *     #define VB_LOG_DENSITY_PARTS K            (a power of two, 2 <= K <= 64; dim <= 128)
+ *     __device__ double vb_log_density_part(const double* z, int d, const double* params, double* grad,
+ *                                           int part, int n_parts);
+ * returning the share of f -- and ADDING the share of grad f to grad, which arrives zeroed -- that belongs to `part`
+ * (e.g. observations part, part + K, ...; the prior in part 0): K threads then work on every sample and their shares
+ * are added in a fixed order.  The source is compiled for this GPU with hiprtc;
  * VB_ERR_INVALID carries the compiler's log.  Supported by ExclusiveKL over all five families (entropy form and path
  * derivative, no control variates), by the alpha-divergence entry points (vb_alpha_grad_meanfield,
  * vb_alpha_grad_fullrank, vb_alpha_sums_mvt, vb_alpha_sums_lowrank), by the DIS refreshes (vb_dis_refresh_meanfield /

@@ -436,3 +436,66 @@ def test_source_model_alpha_lowrank_against_oracle(vb, D, k, N, n_data):
         ov, og = oobj.alpha_divergence(ofamily, omodel, theta, noise, alpha)
         assert G.rel_err(value, ov) < 1e-11, (alpha, value, ov)
         assert G.rel_err(grad, og) < 1e-9, (alpha, G.rel_err(grad, og))
+
+
+# the same density with VB_LOG_DENSITY_PARTS: K threads per sample, each summing its share of the observations
+ROBUST_REGRESSION_PARTS_SRC = r"""
+#define VB_LOG_DENSITY_PARTS %d
+__device__ double vb_log_density_part(const double* z, int d, const double* p, double* g, int part, int n_parts) {
+  const int n = (int)p[0];
+  const double nu = p[1], s = p[2], tau = p[3];
+  const double* X = p + 4;
+  const double* y = X + (long long)n * d;
+  double f = 0.0;
+  if (part == 0)                       // the prior belongs to one part (the wrapper zeroed g)
+    for (int j = 0; j < d; ++j) {
+      f -= 0.5 * z[j] * z[j] / (tau * tau);
+      if (g) g[j] = -z[j] / (tau * tau);
+    }
+  for (int i = part; i < n; i += n_parts) {
+    double eta = 0.0;
+    for (int j = 0; j < d; ++j) eta += X[(long long)i * d + j] * z[j];
+    const double r = y[i] - eta, q = 1.0 + r * r / (nu * s * s);
+    f -= 0.5 * (nu + 1.0) * log(q);
+    if (g) {
+      const double c = (nu + 1.0) * r / (nu * s * s * q);
+      for (int j = 0; j < d; ++j) g[j] += c * X[(long long)i * d + j];
+    }
+  }
+  return f;
+}
+"""
+
+
+@pytest.mark.parametrize('K', [2, 16, 64])
+@pytest.mark.parametrize('D,N,n_data', [(5, 64, 25), (24, 1000, 60), (128, 333, 40)])
+def test_source_model_parts_against_oracle(vb, K, D, N, n_data):
+    """K threads per sample: f, the gradient matrix and the objectives built on them against the numpy oracle (the K
+    shares are added in a fixed butterfly order, so the tolerance is rounding, not bit equality with K = 1)."""
+    rng = np.random.RandomState(D + K)
+    X = rng.randn(n_data, D)
+    y = X @ rng.randn(D) + 0.3 * rng.standard_t(3.0, size=n_data)
+    params = np.concatenate([[n_data, 4.0, 0.5, 3.0], X.ravel(), y])
+    model = vb.SourceModel(D, ROBUST_REGRESSION_PARTS_SRC % K, params)
+    omodel = RobustRegressionOracle(X, y, 4.0, 0.5, 3.0)
+    x = 0.3 * rng.randn(N, D)
+    fo, go = omodel.logp(x), omodel.grad(x)
+    np.testing.assert_allclose(model(x), fo, rtol=0, atol=1e-12 * np.max(np.abs(fo)))
+    np.testing.assert_allclose(model.grad(x), go, rtol=0, atol=1e-12 * np.max(np.abs(go)))
+    assert model.check_gradient(x[:3]) < 1e-6
+    theta = np.concatenate([0.2 * rng.randn(D), -1.0 + 0.1 * rng.randn(D)])
+    value, grad = vb.ExclusiveKL(vb.MFGaussian(D, seed=5), model, N)(theta)
+    noise = np.random.RandomState(5).randn(N, D)
+    ov, og = oobj.exclusive_kl(ofam.MFGaussian(D), omodel, theta, noise)
+    assert G.rel_err(value, ov) < 1e-12 and G.rel_err(grad, og) < 1e-11
+    again = vb.ExclusiveKL(vb.MFGaussian(D, seed=5), model, N)(theta)
+    assert again[0] == value and np.array_equal(again[1], grad)          # reproducible to the bit
+
+
+def test_source_model_parts_errors(vb):
+    bad = vb.SourceModel(3, ROBUST_REGRESSION_PARTS_SRC % 3, np.zeros(4))          # not a power of two
+    with pytest.raises(ValueError, match='power of two'):
+        bad(np.zeros(3))
+    wide = vb.SourceModel(200, ROBUST_REGRESSION_PARTS_SRC % 4, np.zeros(4))      # private arrays stop at 128
+    with pytest.raises(NotImplementedError):
+        wide(np.zeros(200))

@@ -156,7 +156,9 @@ struct vb_ctx {
     uint64_t hash;                      // again (two objectives taking turns) costs no second hiprtc run
     hipModule_t module;
     hipFunction_t fn;
+    int parts;                          // threads per sample (VB_LOG_DENSITY_PARTS of the source, 1 without)
   };
+  int user_parts = 1;                   // ... of the module in use
   std::vector<UserModule> user_modules;
   vb::DeviceBuffer user_params;
   vb::DeviceBuffer glm_work;            // regression targets: split-K slabs of the gradient GEMM

@@ -122,7 +122,11 @@ class SourceModel(DeviceModel):
     returning ``f(z)`` for one sample ``z[0..d)`` and writing its gradient to ``grad[0..d)`` unless ``grad`` is
     NULL; ``params`` is the array given here (data, hyper-parameters), resident on the device.  The source is
     compiled for the GPU with hiprtc when the model is first bound; a source that does not compile raises
-    ``ValueError`` with the compiler's log.  ``ExclusiveKL`` (both estimator forms, no control variates),
+    ``ValueError`` with the compiler's log.  One thread evaluates one sample; a density that is a sum over data
+    can have K threads per sample instead (``dim <= 128``): ``#define VB_LOG_DENSITY_PARTS K`` (a power of two up to
+    64) and define ``vb_log_density_part(z, d, params, grad, part, n_parts)`` returning the share of ``f`` and adding
+    the share of the gradient (``grad`` arrives zeroed) of, say, the observations ``part, part + K, ...`` with the
+    prior in part 0 -- several times faster for a few hundred observations (``DESIGN.md`` 4.8).  ``ExclusiveKL`` (both estimator forms, no control variates),
     ``AlphaDivergence`` and ``DISInclusiveKL`` take it with every family; the model can be called on host samples, and ``vi_diagnostics`` forms its importance weights on the device."""
 
     def __init__(self, dim, source, params=None):
