@@ -107,7 +107,7 @@ extern "C" __global__ void __launch_bounds__(64) vb_user_rows(const double* __re
   if (row >= n) return;
 #if VB_USER_DIM > 0
   double zl[VB_USER_DIM], gl[VB_USER_DIM];
-  for (int j = 0; j < VB_USER_DIM; ++j) zl[j] = Z[row * ldz + j];
+  for (int j = 0; j < VB_USER_DIM; ++j) zl[j] = Z[row * ldz + j], gl[j] = 0.0;
   f[row] = vb_log_density(zl, VB_USER_DIM, params, G ? gl : (double*)0);
   if (G)
     for (int j = 0; j < VB_USER_DIM; ++j) G[row * ldg + j] = gl[j];
