@@ -40,6 +40,8 @@ __device__ double vb_log_density(const double* z, int d, const double* p, double
 }
 """
 
+# (with more data: `#define VB_LOG_DENSITY_PARTS 8` + vb_log_density_part(z, d, p, g, part, n_parts) summing the
+#  observations part, part + 8, ... puts eight threads on every sample -- see SourceModel's docstring)
 rng = np.random.RandomState(0)
 D, n = 5, 300
 X = rng.randn(n, D)
