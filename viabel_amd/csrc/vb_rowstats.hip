@@ -375,9 +375,13 @@ int alpha_mvt_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_tot
 // "all weights zero" error (:325-328) is raised only for candidates on the visited path.  9 launches + a final
 // one that writes the weights: 51 x N exps on one CU become 63 x N / 63 per launch on 63 CUs.
 // dis_state: [lower, upper, status] at the start of a round; res: [round][node] = {ess, max logw}.
-constexpr int kLook = 6;
+#ifndef VB_LOOK
+#define VB_LOOK 6
+#define VB_LOOK_PARTS 4
+#endif
+constexpr int kLook = VB_LOOK;
 constexpr int kLookNodes = 1 << kLook;       // heap order, node 1 = the interval's midpoint; index 0 unused
-constexpr int kLookParts = 4;                // workgroups per candidate (the N samples in kLookParts blocks)
+constexpr int kLookParts = VB_LOOK_PARTS;    // workgroups per candidate (the N samples in kLookParts blocks)
 constexpr int kLookTab = kLookNodes * kLookParts * 3;   // [node][part]{sum w, sum w^2, max log w}
 
 struct BisectWalk {
