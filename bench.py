@@ -8,8 +8,9 @@ gradient of all 525 824 parameters) over one N x D noise matrix resident in HBM:
 O(P) epilogue -- every evaluation is enqueued on ONE HIP stream behind the previous one, as an optimiser loop
 issues them.  A ring of 8 noise matrices (268 MB > the 256-MiB Infinity Cache) is cycled.
 
-N > 1 GPUs (one rank per GPU, launched by torch.distributed.run; the ranks talk over RCCL, the control path is
-a plain TCP socket group -- no torch import anywhere):
+N > 1 GPUs: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE in the environment) this process IS a rank;
+a bare `python bench.py --gpus N` starts its own N rank processes (spawn_ranks: subprocesses, never exec) and relays
+rank 0's line.  The ranks talk over RCCL, the control path is a plain TCP socket group -- no torch import anywhere:
   --scaling weak   (default)  every rank holds 4096 rows, N_mc global = 4096 x GPUs, `value` counts
                               4096-sample evaluation units: GPUs x evaluations / second;
   --scaling strong            N_mc = 4096 global, rank r holds rows shard_rows(4096, G, r), `value` =
@@ -470,6 +471,108 @@ def cpu_baseline_and_parity(eng, d, slot, dev_model, theta, budget_s=12.0):
     return base, parity
 
 
+# --------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no launcher around it starts its own N ranks
+# --------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(world, child_argv, timeout_s=1500.0, extra_env=None, poll_s=0.05):
+    """Start `world` fresh child processes (rank r gets RANK / LOCAL_RANK = r, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a
+    free MASTER_PORT and a job id for the control handshake), wait for all of them and return
+    (exit code, rank 0's stdout lines).  The caller is a plain parent: it has not imported viabel_amd or touched HIP,
+    and nothing here replaces a process image (no os.exec*): children are subprocesses in their own sessions, so on
+    the first failing child or on the timeout every rank's whole process group is killed.  Exit code: 0 when every
+    rank exited 0, else the first failing rank's code (124 for the timeout)."""
+    import signal
+    import subprocess
+    import threading
+    import uuid
+    env0 = dict(os.environ)
+    env0.update({'WORLD_SIZE': str(world), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port()),
+                 'VIABEL_AMD_JOB_ID': uuid.uuid4().hex, 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    env0.update(extra_env or {})
+    procs, lines = [], []
+    for r in range(world):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(child_argv, env=env, start_new_session=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+
+    def pump():
+        for line in procs[0].stdout:
+            lines.append(line.rstrip('\n'))
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)       # the child's own session: pgid == pid
+                except (ProcessLookupError, PermissionError):
+                    pass
+        for p in procs:
+            try:
+                p.wait(10)
+            except Exception:
+                pass
+
+    rc, deadline = 0, time.time() + timeout_s
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                sys.stderr.write('bench launcher: rank %d exited with code %s; stopping the other ranks\n' % (r, c))
+                rc = c if c > 0 else 128 - c
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                sys.stderr.write('bench launcher: ranks still running after %.0f s; killing them\n' % timeout_s)
+                rc = 124
+                break
+            time.sleep(poll_s)
+    finally:
+        kill_all()
+    reader.join(5)
+    return rc, lines
+
+
+def launch_main(args, argv):
+    """Parent of a self-launched N-rank run: relay rank 0's JSON line as the LAST line of stdout after checking that
+    it really describes an N-rank job."""
+    rc, lines = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + argv, args.launch_timeout)
+    result = None
+    for line in lines:
+        try:
+            obj = json.loads(line)
+            if isinstance(obj, dict) and 'metric' in obj:
+                result = obj
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(line + '\n')           # banners of RCCL etc.: not on stdout
+    if rc != 0:
+        raise SystemExit(rc)
+    if result is None:
+        raise SystemExit('bench launcher: rank 0 printed no result line')
+    dry = os.environ.get('VB_BENCH_NO_RCCL') == '1'
+    if result.get('n_gpus') != args.gpus or (not dry and result.get('rccl_ranks') != args.gpus):
+        raise SystemExit('bench launcher: asked for %d GPUs, the ranks report n_gpus=%r rccl_ranks=%r -- refusing to '
+                         'print that line' % (args.gpus, result.get('n_gpus'), result.get('rccl_ranks')))
+    result['launcher'] = 'bench.py self-launch: %d child processes (subprocess), rank 0 relayed' % args.gpus
+    sys.stderr.flush()
+    print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -481,11 +584,20 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-legs', action='store_true', help='headline only (skip the secondary legs)')
     ap.add_argument('--no-profile', action='store_true', help='no per-kernel HIP events in the timed region')
+    ap.add_argument('--launch-timeout', type=float, default=1500.0,
+                    help='self-launched ranks (--gpus N > 1 without a launcher) are killed after this many seconds')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be at least 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher around us: become the parent of N fresh rank processes (nothing has touched HIP or imported
+        # viabel_amd in this process, and it never will)
+        return launch_main(args, sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
+        # a line whose n_gpus differs from what was asked for must never be printed
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
     from viabel_amd import _lib, distributed

@@ -72,3 +72,71 @@ def test_single_rank_group_is_trivial():
     assert g.allreduce_max(3.5) == 3.5
     assert g.broadcast_bytes(b'x') == b'x'
     g.close()
+
+
+def _token_worker(rank, world, port, token, q):
+    sys.path.insert(0, ROOT)
+    try:
+        from viabel_amd import distributed
+        g = distributed.SocketGroup(rank, world, '127.0.0.1', port, timeout=60.0, token=token)
+        got = g.broadcast_bytes(token if rank == 0 else None)
+        g.barrier()
+        g.close()
+        q.put((token, rank, got))
+    except Exception as exc:                 # pragma: no cover
+        q.put((token, rank, repr(exc)))
+
+
+def test_two_jobs_with_the_same_port_do_not_capture_each_other():
+    """two jobs of the same world size whose control ports collide (job B's rank 0 walks to the next
+    port) -- every rank must end up in its own job: the handshake carries a job token that both sides check."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_token_worker, args=(r, 2, port, tok, q)) for tok in (b'job-A', b'job-B') for r in (0, 1)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(30)
+    for tok, rank, got in results:
+        assert got == tok, results
+
+
+def test_job_token_from_env():
+    sys.path.insert(0, ROOT)
+    from viabel_amd.distributed import SocketGroup
+    a = SocketGroup.job_token({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29500', 'TORCHELASTIC_RUN_ID': 'x'})
+    b = SocketGroup.job_token({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29501', 'TORCHELASTIC_RUN_ID': 'x'})
+    c = SocketGroup.job_token({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29500', 'VIABEL_AMD_JOB_ID': 'y'})
+    assert len({a, b, c}) == 3
+
+
+def test_rendezvous_timeout_names_the_missing_ranks_and_ignores_silent_clients():
+    sys.path.insert(0, ROOT)
+    import threading
+    import time
+    from viabel_amd import distributed
+    port = _free_port()
+    stray = []
+
+    def silent_client():                     # connects, says nothing: must not stall the accept loop for the deadline
+        time.sleep(0.3)
+        s = socket.socket()
+        try:
+            s.connect(('127.0.0.1', port))
+            stray.append(s)
+        except OSError:
+            pass
+    t = threading.Thread(target=silent_client)
+    t.start()
+    t0 = time.time()
+    try:
+        distributed.SocketGroup(0, 3, '127.0.0.1', port, timeout=4.0)
+        raise AssertionError('rendezvous should have timed out')
+    except RuntimeError as exc:
+        assert 'ranks [1, 2] never arrived' in str(exc), exc
+    assert time.time() - t0 < 10
+    t.join()
+    for s in stray:
+        s.close()

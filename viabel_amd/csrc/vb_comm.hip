@@ -38,6 +38,26 @@ int comm_allgather(vb_ctx* ctx, hipStream_t stream, const double* send, double* 
   return VB_OK;
 }
 
+int comm_shard_begin(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t* begin) {
+  const int64_t g = ctx->n_ranks, r = ctx->rank;
+  const int64_t base = n_total / g, extra = n_total % g;
+  *begin = r * base + (r < extra ? r : extra);
+  const int64_t count = base + (r < extra ? 1 : 0);
+  if (n != count)
+    return fail(ctx, VB_ERR_INVALID, "rank %d of %d holds %lld of %lld samples, its shard is %lld (shard_rows)", (int)r,
+                (int)g, (long long)n, (long long)n_total, (long long)count);
+  return VB_OK;
+}
+
+int comm_gather_rows(vb_ctx* ctx, hipStream_t stream, double* vec, int64_t begin, int64_t n, int64_t n_total) {
+  if (!ctx->comm) return VB_OK;
+  if (n * (int64_t)ctx->n_ranks == n_total) return comm_allgather(ctx, stream, vec + begin, vec, (size_t)n);
+  if (begin > 0) VB_HIP(ctx, hipMemsetAsync(vec, 0, (size_t)begin * sizeof(double), stream));
+  if (begin + n < n_total)
+    VB_HIP(ctx, hipMemsetAsync(vec + begin + n, 0, (size_t)(n_total - begin - n) * sizeof(double), stream));
+  return comm_allreduce_sum(ctx, stream, vec, (size_t)n_total);
+}
+
 }  // namespace vb
 
 using namespace vb;

@@ -420,6 +420,14 @@ int model_grad_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int
 int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count);
 int comm_allreduce_max(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count);
 int comm_allgather(vb_ctx* ctx, hipStream_t stream, const double* send, double* recv, size_t count);
+// Monte-Carlo-axis shard of this rank: rows [begin, begin + count) of n_total, the contiguous blocks of
+// viabel_amd.objectives.shard_rows (the first n_total % n_ranks ranks hold one row more).  Fails when `n` is not
+// this rank's count.
+int comm_shard_begin(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t* begin);
+// vec[0 .. n_total) on every rank from the ranks' own blocks vec[begin .. begin + n): an in-place all-gather when the
+// shards are equal, otherwise zero fill outside the own block + sum all-reduce (x + 0 is exact, so the gathered
+// values are the owners' bits either way).  Without a communicator: nothing to do.
+int comm_gather_rows(vb_ctx* ctx, hipStream_t stream, double* vec, int64_t begin, int64_t n, int64_t n_total);
 
 // profiling: event pair for the next launch of the dominant kernel (nullptrs when disabled)
 void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals, int kernel_id = VB_PROF_MF_ACCUM);

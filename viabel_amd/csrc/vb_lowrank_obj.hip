@@ -379,13 +379,12 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
                    const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
                    double* ess_out, double* w_host, double* logp_host, double* logq_host) {
   VB_TRY(lro_check(ctx, ns, nz, n, d, k));
-  if (n * (int64_t)ctx->n_ranks != n_total)
-    return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
+  int64_t mine = 0;   // this rank's block inside the gathered per-sample vectors (shard_rows)
+  VB_TRY(comm_shard_begin(ctx, n, n_total, &mine));
   const LroLayout L = lro_layout(n, n_total, d);
   VB_TRY(ensure(ctx, ctx->lr_obj, (size_t)L.total * sizeof(double)));
   double* base = (double*)ctx->lr_obj.ptr;
   hipStream_t st = ctx->stream;
-  const int64_t mine = (int64_t)ctx->rank * n;
   VB_TRY(lro_upload_param(ctx, L, base, d, k, LroParam{mu, log_sigma, B, minv, cq}, true));
   std::vector<double> pr((size_t)2 * L.ld, 0.0);
   double c0p = -0.5 * (double)d * 1.8378770664093454835606594728112;
@@ -417,9 +416,9 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
     VB_TRY(rc);
   }
   if (ctx->comm) {
-    VB_TRY(comm_allgather(ctx, st, base + L.o_f + mine, base + L.o_f, (size_t)n));
-    VB_TRY(comm_allgather(ctx, st, base + L.o_lq + mine, base + L.o_lq, (size_t)n));
-    VB_TRY(comm_allgather(ctx, st, base + L.o_lpr + mine, base + L.o_lpr, (size_t)n));
+    VB_TRY(comm_gather_rows(ctx, st, base + L.o_f, mine, n, n_total));
+    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));
+    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lpr, mine, n, n_total));
   }
   VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is
   VB_TRY(dis_bisect_enqueue(ctx, base + L.o_f, base + L.o_lq, base + L.o_lpr, base + L.o_scal, n_total, eps_prev,

@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) mvt_scalar_kernel(const double* __restric
 // ---- state layout ----------------------------------------------------------------------------------------
 struct MvtLayout {
   int64_t ld, nn;
-  int64_t o_x, o_e, o_u, o_ua, o_root, o_wt, o_li, o_mu, o_c, o_invs, o_maha, o_lq, o_lp, o_lprior, o_w, o_lqcopy,
+  int64_t o_x, o_e, o_u, o_ua, o_sl, o_root, o_wt, o_li, o_mu, o_c, o_invs, o_maha, o_lq, o_lp, o_lprior, o_w, o_lqcopy,
       o_prior, o_scal, o_cpart, o_col, o_part, o_sums, o_theta, o_lt, o_lfull, o_tscr, o_grad, total;
   int splits, n_rb;
   FrSums S;
@@ -191,6 +191,7 @@ static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t d) 
   L.o_lt = carve(sq);
   L.o_lfull = carve(sq);
   L.o_tscr = carve(sq);
+  L.o_sl = carve(sq);      // S L of the packed chain rule (a carve of its own: n may be smaller than d)
   L.o_grad = carve(1 + d + d * (d + 1) / 2);
   L.total = off;
   return L;
@@ -345,8 +346,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
                     const double* chi_host, const double* root_host, const double* linv_host,
                     const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
                     double* ess_out, double* w_host, double* logp_host, double* logq_host) {
-  if (n * (int64_t)ctx->n_ranks != n_total)
-    return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
+  int64_t mine = 0;   // this rank's block inside the gathered per-sample vectors (shard_rows)
+  VB_TRY(comm_shard_begin(ctx, n, n_total, &mine));
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL && ctx->model.id != VB_MODEL_SOURCE)
     return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density implements gauss_diag, funnel and source models");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
@@ -357,8 +358,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   double* base = (double*)ctx->mvt_state.ptr;
   hipStream_t st = ctx->stream;
   const int n_cu = ctx->prop.multiProcessorCount;
-  const int64_t mine = (int64_t)ctx->rank * n;   // this rank's block inside the gathered vectors
 
+  ctx->mvt_theta.clear();   // until this refresh has succeeded the device residuals belong to no parameter
   const bool dev_factors = root_host == nullptr && linv_host == nullptr;
   if ((root_host == nullptr) != (linv_host == nullptr))
     return fail(ctx, VB_ERR_INVALID, "sqrt_sigma and l_inv are given together or not at all");
@@ -426,9 +427,9 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     VB_TRY(rc);
   }
   if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
-    VB_TRY(comm_allgather(ctx, st, base + L.o_lp + mine, base + L.o_lp, (size_t)n));
-    VB_TRY(comm_allgather(ctx, st, base + L.o_lq + mine, base + L.o_lq, (size_t)n));
-    VB_TRY(comm_allgather(ctx, st, base + L.o_lprior + mine, base + L.o_lprior, (size_t)n));
+    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lp, mine, n, n_total));
+    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));
+    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lprior, mine, n, n_total));
   }
   VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is
   VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_lq, base + L.o_lprior, base + L.o_scal, n_total, eps_prev,
@@ -544,9 +545,9 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     gs.N = D;
     gs.K = D;
     gs.tri_mode = 0;
-    gemm_f64_launch<true>(st, gs, 1, n_cu, EpiStore{base + L.o_u, L.ld});      // (o_u is free again: U was consumed)
+    gemm_f64_launch<true>(st, gs, 1, n_cu, EpiStore{base + L.o_sl, L.ld});
     hipLaunchKernelGGL(mvt_pack_grad_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
-                       (const double*)(base + L.o_u), (const double*)(base + L.o_lfull), L.ld, D,
+                       (const double*)(base + L.o_sl), (const double*)(base + L.o_lfull), L.ld, D,
                        (const double*)S.sums, S.off_col, scale, base + L.o_grad);
     VB_HIP(ctx, hipGetLastError());
     VB_HIP(ctx, hipMemcpyAsync(packed_out, base + L.o_grad, (size_t)(1 + d + d * (d + 1) / 2) * sizeof(double),

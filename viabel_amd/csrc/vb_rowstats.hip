@@ -598,8 +598,8 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
                         const double* theta_src, const double* prior_host, double eps_prev, double ess_target,
                         int max_its, double* eps_out, double* ess_out, int* status_out, double* w_host,
                         double* logp_host, double* logq_host) {
-  if (n * (int64_t)ctx->n_ranks != n_total)
-    return fail(ctx, VB_ERR_INVALID, "sharded DIS needs num_mc_samples divisible by the number of ranks");
+  int64_t mine = 0;   // this rank's block inside the gathered per-sample vectors (shard_rows)
+  VB_TRY(comm_shard_begin(ctx, n, n_total, &mine));
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL && ctx->model.id != VB_MODEL_SOURCE)
     return fail(ctx, VB_ERR_UNSUPPORTED, "mean-field DIS supports the gauss_diag, funnel and source models");
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
@@ -612,7 +612,6 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
   VB_TRY(ensure(ctx, ctx->dis_state, (size_t)L.total * sizeof(double)));
   double* base = (double*)ctx->dis_state.ptr;
   hipStream_t st = ctx->stream;
-  const int64_t mine = (int64_t)ctx->rank * n;   // this rank's block inside the gathered vectors
 
   // tempering prior: a diagonal Gaussian given as an MFGaussian parameter [mu | log_sigma]
   std::vector<double> pr((size_t)2 * ld, 0.0);
@@ -639,9 +638,9 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
                      df, base + L.o_lprior + mine, base + L.o_lq);
   VB_HIP(ctx, hipGetLastError());
   if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
-    VB_TRY(comm_allgather(ctx, st, base + L.o_lp + mine, base + L.o_lp, (size_t)n));
-    VB_TRY(comm_allgather(ctx, st, base + L.o_b + mine, base + L.o_b, (size_t)n));
-    VB_TRY(comm_allgather(ctx, st, base + L.o_lprior + mine, base + L.o_lprior, (size_t)n));
+    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lp, mine, n, n_total));
+    VB_TRY(comm_gather_rows(ctx, st, base + L.o_b, mine, n, n_total));
+    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lprior, mine, n, n_total));
   }
   VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_b, base + L.o_lprior, base + L.o_scal, n_total, eps_prev,
                             ess_target, max_its, base + L.o_w, base + L.o_lq, base + L.o_out));

@@ -73,6 +73,13 @@ const Rtc* rtc_load() {
 // shuffles (the same pairs in the same order on every lane: reproducible).  One thread per sample leaves the GPU
 // 94 % idle at N = 4096; a model that is a sum over data has this parallelism to give.
 const char* const kWrapper = R"VBSRC(
+// threads per sample the kernel below was compiled for; the host reads it back from the loaded module
+// (hipModuleGetGlobal) instead of guessing it from the source text
+#ifdef VB_LOG_DENSITY_PARTS
+extern "C" __device__ int vb_user_parts_k = VB_LOG_DENSITY_PARTS;
+#else
+extern "C" __device__ int vb_user_parts_k = 1;
+#endif
 #ifdef VB_LOG_DENSITY_PARTS
 extern "C" __global__ void __launch_bounds__(64) vb_user_rows(const double* __restrict__ Z, long long ldz, long long n, int d,
                                         const double* __restrict__ params, double* __restrict__ G, long long ldg,
@@ -123,22 +130,6 @@ constexpr int64_t kUserDimPrivate = 128;      // 2 x 8 x 128 B of private memory
 
 int user_model_bind(vb_ctx* ctx, int64_t dim, const double* params, size_t n_params);
 
-// K of a `#define VB_LOG_DENSITY_PARTS K` line in the source (1 if there is none, -1 if K is not usable): the launch
-// needs it on the host
-static int user_source_parts(const char* source) {
-  const char* key = "VB_LOG_DENSITY_PARTS";
-  for (const char* p = strstr(source, "#define"); p; p = strstr(p + 1, "#define")) {
-    const char* q = p + 7;
-    while (*q == ' ' || *q == '\t') ++q;
-    if (strncmp(q, key, strlen(key)) != 0) continue;
-    q += strlen(key);
-    if (*q != ' ' && *q != '\t') continue;
-    const long k = strtol(q, nullptr, 10);
-    return (k >= 2 && k <= 64 && (k & (k - 1)) == 0) ? (int)k : -1;
-  }
-  return 1;
-}
-
 void user_model_release(vb_ctx* ctx) {      // vb_destroy: unload everything this context compiled
   for (auto& m : ctx->user_modules) (void)hipModuleUnload(m.module);
   ctx->user_modules.clear();
@@ -152,11 +143,6 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
   if (n_params > 0 && !params) return fail(ctx, VB_ERR_INVALID, "NULL params");
   uint64_t hash = 1469598103934665603ull;      // FNV-1a of the source text
   for (const char* c = source; *c; ++c) hash = (hash ^ (uint64_t)(unsigned char)*c) * 1099511628211ull;
-  const int parts = user_source_parts(source);
-  if (parts < 0) return fail(ctx, VB_ERR_INVALID, "VB_LOG_DENSITY_PARTS must be a power of two between 2 and 64");
-  if (parts > 1 && dim > kUserDimPrivate)
-    return fail(ctx, VB_ERR_UNSUPPORTED, "VB_LOG_DENSITY_PARTS needs a model dimension of at most %lld",
-                (long long)kUserDimPrivate);
   const int64_t priv_dim = dim <= kUserDimPrivate ? dim : 0;      // compiled into the wrapper: part of the module's key
   hash = (hash ^ (uint64_t)priv_dim) * 1099511628211ull;
   const vb_ctx::UserModule* cached = nullptr;
@@ -207,6 +193,25 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
   if (hipModuleGetFunction(&fn, mod, "vb_user_rows") != hipSuccess) {
     (void)hipModuleUnload(mod);
     return fail(ctx, VB_ERR_HIP, "compiled model has no vb_user_rows kernel");
+  }
+  // K threads per sample, as compiled (a text scan of the source can be fooled by `# define`, macros or #if 0)
+  int parts = 0;
+  hipDeviceptr_t kptr = nullptr;
+  size_t kbytes = 0;
+  if (hipModuleGetGlobal(&kptr, &kbytes, mod, "vb_user_parts_k") != hipSuccess || kbytes != sizeof(int) ||
+      hipMemcpy(&parts, kptr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || parts < 1 || parts > 64 ||
+      (parts & (parts - 1)) != 0) {
+    (void)hipModuleUnload(mod);
+    return fail(ctx, VB_ERR_HIP, "compiled model does not report its threads per sample (vb_user_parts_k = %d)", parts);
+  }
+  // bounded cache: drop the least recently compiled module that is not the bound one (work in flight was drained above)
+  constexpr size_t kMaxUserModules = 16;
+  while (ctx->user_modules.size() >= kMaxUserModules) {
+    size_t victim = 0;
+    while (victim < ctx->user_modules.size() && ctx->user_modules[victim].module == ctx->user_module) ++victim;
+    if (victim == ctx->user_modules.size()) break;
+    (void)hipModuleUnload(ctx->user_modules[victim].module);
+    ctx->user_modules.erase(ctx->user_modules.begin() + (long)victim);
   }
   ctx->user_modules.push_back({hash, mod, fn, parts});
   ctx->user_module = mod;

@@ -12,6 +12,7 @@ sockets (:class:`SocketGroup`, rendezvous on ``MASTER_ADDR`` / ``MASTER_PORT`` a
 ``torch.distributed.run``): no torch in the runtime path.  ``attach`` also accepts an initialised
 ``torch.distributed`` process group (any backend) for callers that already have one.
 """
+import hashlib
 import os
 import socket
 import struct
@@ -22,7 +23,7 @@ import numpy as np
 from . import _lib
 from .objectives import shard_rows  # noqa: F401  (re-exported)
 
-_MAGIC = b'VBAMD1\0\0'
+_MAGIC = b'VBAMD2\0\0'
 
 
 def combine_partial_sums(partials):
@@ -57,23 +58,30 @@ class SocketGroup:
     only -- gradients never travel here.
 
     The listening port is ``MASTER_PORT + port_offset`` (torchrun's own store owns ``MASTER_PORT`` itself); if
-    that port is taken rank 0 walks upwards and the other ranks probe the same sequence until the handshake
-    (magic, world size) matches.
+    that port is taken rank 0 walks upwards and the other ranks probe the same sequence.  The handshake carries a
+    16-byte **job token** (``from_env``: a hash of MASTER_ADDR, MASTER_PORT and the launcher's run id) that BOTH
+    sides check, so two jobs on one host with neighbouring ports and the same world size cannot capture each
+    other's ranks while both are starting up: a mismatching hello is dropped by the server, a mismatching reply
+    makes the client move on to the next port.
     """
 
-    def __init__(self, rank, world, addr='127.0.0.1', port=29531, timeout=120.0, tries=16):
+    HELLO_TIMEOUT = 2.0          # a connection that does not send its hello within this is dropped
+
+    def __init__(self, rank, world, addr='127.0.0.1', port=29531, timeout=120.0, tries=16, token=b''):
         self.rank, self.world = int(rank), int(world)
         self._peers = []
         self._sock = None
         if self.world == 1:
             return
+        token = hashlib.sha256(bytes(token)).digest()[:16]
         deadline = time.time() + timeout
-        hello = _MAGIC + struct.pack('<ii', self.world, self.rank)
+        hello = _MAGIC + token + struct.pack('<ii', self.world, self.rank)
+        reply = _MAGIC + token
         if self.rank == 0:
             srv = None
             for k in range(tries):
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 try:
-                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
                     srv.bind((addr, port + k))
                     break
@@ -82,38 +90,50 @@ class SocketGroup:
                     srv = None
             if srv is None:
                 raise RuntimeError('no free control port in [%d, %d)' % (port, port + tries))
-            srv.listen(self.world)
+            srv.listen(self.world + 8)
             peers = {}
-            while len(peers) < self.world - 1:
-                srv.settimeout(max(0.1, deadline - time.time()))
-                conn, _ = srv.accept()
-                conn.settimeout(timeout)
-                try:
-                    msg = _recv_exact(conn, len(hello))
-                except (ConnectionError, socket.timeout):
-                    conn.close()
-                    continue
-                w, r = struct.unpack('<ii', msg[len(_MAGIC):])
-                if msg[:len(_MAGIC)] != _MAGIC or w != self.world or not 0 < r < self.world or r in peers:
-                    conn.close()
-                    continue
-                conn.sendall(_MAGIC)
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                peers[r] = conn
-            srv.close()
+            try:
+                while len(peers) < self.world - 1:
+                    left = deadline - time.time()
+                    if left <= 0:
+                        raise socket.timeout()
+                    srv.settimeout(left)
+                    conn, _ = srv.accept()
+                    conn.settimeout(self.HELLO_TIMEOUT)
+                    try:
+                        msg = _recv_exact(conn, len(hello))
+                    except (ConnectionError, OSError):
+                        conn.close()
+                        continue
+                    w, r = struct.unpack('<ii', msg[len(reply):])
+                    if msg[:len(reply)] != reply or w != self.world or not 0 < r < self.world or r in peers:
+                        conn.close()
+                        continue
+                    conn.sendall(reply)
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    peers[r] = conn
+            except socket.timeout:
+                for c in peers.values():
+                    c.close()
+                missing = [r for r in range(1, self.world) if r not in peers]
+                raise RuntimeError('control rendezvous on %s:%d timed out after %.0f s: ranks %s never arrived'
+                                   % (addr, srv.getsockname()[1], timeout, missing)) from None
+            finally:
+                srv.close()
             self._peers = [peers[r] for r in range(1, self.world)]
         else:
             k = 0
             while True:
                 if time.time() > deadline:
-                    raise RuntimeError('rank %d: no control server on %s:%d..%d' % (self.rank, addr, port,
-                                                                                  port + tries - 1))
+                    raise RuntimeError('rank %d: no control server of this job on %s:%d..%d'
+                                       % (self.rank, addr, port, port + tries - 1))
                 s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 s.settimeout(5.0)
                 try:
                     s.connect((addr, port + k % tries))
                     s.sendall(hello)
-                    if _recv_exact(s, len(_MAGIC)) == _MAGIC:
+                    if _recv_exact(s, len(reply)) == reply:
                         s.settimeout(timeout)
                         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                         self._sock = s
@@ -125,14 +145,22 @@ class SocketGroup:
                 if k % tries == 0:
                     time.sleep(0.05)
 
+    @staticmethod
+    def job_token(environ=None):
+        """Bytes that identify THIS job among others on the host: MASTER_ADDR:MASTER_PORT plus the launcher's run id
+        (``TORCHELASTIC_RUN_ID`` from torch.distributed.run, ``VIABEL_AMD_JOB_ID`` from bench.py's own launcher)."""
+        env = os.environ if environ is None else environ
+        return ('%s:%s|%s|%s' % (env.get('MASTER_ADDR', '127.0.0.1'), env.get('MASTER_PORT', '29500'),
+                                 env.get('TORCHELASTIC_RUN_ID', ''), env.get('VIABEL_AMD_JOB_ID', ''))).encode()
+
     @classmethod
-    def from_env(cls, port_offset=23):
+    def from_env(cls, port_offset=23, timeout=120.0):
         """Group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (``torch.distributed.run`` exports them)."""
         world = int(os.environ.get('WORLD_SIZE', '1'))
         rank = int(os.environ.get('RANK', '0'))
         addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
         port = int(os.environ.get('VIABEL_AMD_CONTROL_PORT', int(os.environ.get('MASTER_PORT', '29500')) + port_offset))
-        return cls(rank, world, addr, port)
+        return cls(rank, world, addr, port, timeout=timeout, token=cls.job_token())
 
     # ---- collectives (gather to rank 0, combine, scatter) ------------------------------------------------------
     def _exchange(self, payload, combine):

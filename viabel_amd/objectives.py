@@ -46,10 +46,30 @@ def _shared_randint(eng):
     of a sharded job: rank 0's draw travels over the engine's control group when it has one
     (``viabel_amd.distributed.attach(engine, group)``); without one the ranks must seed numpy identically."""
     seed = int(np.random.randint(2 ** 32))
-    group = getattr(eng, 'control_group', None)
-    if eng.n_ranks > 1 and group is not None:
-        seed = int.from_bytes(group.broadcast_bytes(seed.to_bytes(8, 'little')), 'little')
+    if eng.n_ranks > 1:
+        seed = int.from_bytes(_rank0_bytes(eng, seed.to_bytes(8, 'little')), 'little')
     return seed
+
+
+def _rank0_bytes(eng, payload):
+    """Rank 0's ``payload`` on every rank of a sharded job: over the engine's socket control group, else over an
+    initialised ``torch.distributed`` group (the caller attached with one); with neither the ranks would draw
+    independently and diverge silently, so that is an error, not a convention."""
+    group = getattr(eng, 'control_group', None)
+    if group is not None:
+        return group.broadcast_bytes(payload)
+    try:
+        import torch.distributed as dist
+        ok = dist.is_available() and dist.is_initialized()
+    except ImportError:
+        ok = False
+    if not ok:
+        raise RuntimeError('sharded job without a control group: attach the engine with a SocketGroup or an '
+                           'initialised torch.distributed process group, so that rank 0\'s host random draws '
+                           '(alpha-divergence seed, DIS resampling indices) reach every rank')
+    box = [payload]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 def _shared_choice(eng, n, size, p):
@@ -61,11 +81,15 @@ def _shared_choice(eng, n, size, p):
     if p.shape != (n,):
         raise ValueError("'a' and 'p' must have same size")
     cdf = p.cumsum()
+    # the two checks of np.random.choice that matter for normalised DIS weights (a zero or NaN weight sum)
+    if not np.isfinite(cdf[-1]):
+        raise ValueError('probabilities contain NaN')
+    if cdf[-1] <= 0 or p.min() < 0:
+        raise ValueError('probabilities are not non-negative')
     cdf /= cdf[-1]
     indices = cdf.searchsorted(np.random.random_sample(size), side='right')
-    group = getattr(eng, 'control_group', None)
-    if eng.n_ranks > 1 and group is not None:
-        raw = group.broadcast_bytes(np.ascontiguousarray(indices, dtype=np.int64).tobytes())
+    if eng.n_ranks > 1:
+        raw = _rank0_bytes(eng, np.ascontiguousarray(indices, dtype=np.int64).tobytes())
         indices = np.frombuffer(raw, dtype=np.int64)
     return indices
 
