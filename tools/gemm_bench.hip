@@ -145,6 +145,7 @@ static void run_loop_probe(hipStream_t st, int n_cu, long long* d, double* sink)
   }
 }
 
+static hipStream_t g_time_stream = nullptr;      // the stream the timed lambdas launch on (for GEMM_GRAPH)
 template <class F>
 static float time_it(F&& f, int reps) {
   hipEvent_t e0, e1;
@@ -152,6 +153,29 @@ static float time_it(F&& f, int reps) {
   hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) f();
   hipDeviceSynchronize();
+  // GEMM_GRAPH=n: the same launches as a captured graph of n kernel nodes, replayed reps / n times -- what is the
+  // launch-to-launch cost of dependent kernels inside a graph, against back-to-back stream launches?
+  const int gn = getenv("GEMM_GRAPH") ? atoi(getenv("GEMM_GRAPH")) : 0;
+  if (gn > 0 && g_time_stream) {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    if (hipStreamBeginCapture(g_time_stream, hipStreamCaptureModeGlobal) != hipSuccess) printf("capture failed\n");
+    for (int i = 0; i < gn; ++i) f();
+    if (hipStreamEndCapture(g_time_stream, &graph) != hipSuccess) printf("end capture failed\n");
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) printf("instantiate failed\n");
+    const int launches = reps / gn > 0 ? reps / gn : 1;
+    for (int i = 0; i < 3; ++i) hipGraphLaunch(exec, g_time_stream);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, g_time_stream);
+    for (int i = 0; i < launches; ++i) hipGraphLaunch(exec, g_time_stream);
+    hipEventRecord(e1, g_time_stream);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipGraphExecDestroy(exec);
+    hipGraphDestroy(graph);
+    return ms / (launches * gn);
+  }
   hipEventRecord(e0);
   for (int i = 0; i < reps; ++i) f();
   hipEventRecord(e1);
@@ -178,6 +202,7 @@ int main(int argc, char** argv) {
   hipMemcpy(B, h.data(), big * 8, hipMemcpyHostToDevice);
   hipStream_t st;
   hipStreamCreate(&st);
+  g_time_stream = st;
 
   // GEMM_REPS: timed launches per measurement in profiling mode (default 20; thousands = seconds of sustained load,
   // for power / clock sampling from the host with rocm-smi)
@@ -274,6 +299,28 @@ int main(int argc, char** argv) {
         printf("   workgroup lifetimes (us): min %.1f  25%% %.1f  median %.1f  75%% %.1f  max %.1f;  start times: median %.1f  90%% %.1f  max %.1f\n",
                sl.front(), sl[sl.size() / 4], sl[sl.size() / 2], sl[3 * sl.size() / 4], sl.back(), ss[ss.size() / 2],
                ss[9 * ss.size() / 10], ss.back());
+      }
+      if (mode == 't') {   // tri_mode 1: the schedule per column block (launch order: heaviest first, then the light half ascending)
+        const int bmr = (cfg == 3 || cfg == 4) ? 64 : 128, bnc = (cfg == 1 || cfg == 6) ? 128 : 64;
+        const int tm = M / bmr, tn = N / bnc, half = (tn + 1) / 2;
+        printf("   column block: k slabs | mean start, mean end (us from the first start) | mean lifetime | loop cycles per slab\n");
+        for (int idx = 0; idx < tn; ++idx) {
+          const int bn = idx < half ? tn - 1 - idx : idx - half;
+          double s0 = 0, e0 = 0, lf = 0, lp = 0, emax = 0;
+          int cnt = 0;
+          for (int bmi = 0; bmi < tm; ++bmi) {
+            const int b = idx * tm + bmi;
+            if (b >= 1024) break;
+            const long long* w = &o[8 * (4 * b)];
+            s0 += (w[4] - first) / 100.0, e0 += (w[4] + w[3] - first) / 100.0, lf += w[3] / 100.0, lp += (double)w[1];
+            emax = fmax(emax, (w[4] + w[3] - first) / 100.0);
+            ++cnt;
+          }
+          if (!cnt) continue;
+          const int ns = (bn + 1) * bnc / 16;
+          printf("   bn %2d: %3d slabs | start %6.1f end %6.1f (last %6.1f) | life %6.1f us | %7.0f cycles per slab\n", bn, ns, s0 / cnt,
+                 e0 / cnt, emax, lf / cnt, lp / cnt / ns);
+        }
       }
       printf("   in us at that clock: prologue %.1f, loop %.1f, epilogue %.1f; MFMA floor of the loop (2 waves/SIMD x 16 cycles) %.1f us\n",
              pro / mhz, loop / mhz, epi / mhz, 2.0 * (K / 16) * 4 * (cfg == 1 ? 64 : cfg == 2 ? 32 : 16) * 16 / mhz);

@@ -155,9 +155,33 @@ struct EpiNegate {          // G = -acc   (gauss_full: G = -(Z - m) P)
   }
 };
 
-struct EpiSplitSlab {       // C_split[i][j] = acc
+// G = -acc and, per workgroup, the sum of f = 1/2 (z - m)' g over the tile (gauss_full: log p(z) = c0 - 1/2 (z - m)' P
+// (z - m) = c0 + 1/2 (z - m)' g): Zc holds z - m, the very rows this workgroup has just multiplied (L2-resident), read
+// back with the store's own 16-byte pattern.  The model's log density of the materialised samples, not an identity of
+// the variational family.
+struct EpiNegateF {
+  double* G;
+  int64_t ldz;
+  const double* Zc;
+  double* part;
+  __device__ double operator()(int, int row, int col, double acc) const {
+    G[(int64_t)row * ldz + col] = -acc;
+    return -0.5 * acc * Zc[(int64_t)row * ldz + col];
+  }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    const d2v z = *reinterpret_cast<const d2v*>(Zc + (int64_t)row * ldz + col);
+    *reinterpret_cast<d2v*>(G + (int64_t)row * ldz + col) = (d2v){-a0, -a1};
+    return (d2v){-0.5 * a0 * z.x, -0.5 * a1 * z.y};
+  }
+};
+
+// C_split[i][j] = acc, and the column sums of G per split through the kernel's EpiColsum hook (the waves of the diagonal
+// tiles that have nothing to multiply add up the A tiles in LDS)
+struct EpiSplitSlabCs {
   double* C;
   int64_t ldc, slab;
+  double* colsum;
+  int64_t colsum_ld;
   __device__ void operator()(int split, int row, int col, double acc) const {
     C[split * slab + (int64_t)row * ldc + col] = acc;
   }
@@ -168,26 +192,16 @@ struct EpiSplitSlab {       // C_split[i][j] = acc
   }
 };
 
-// C_split[i][j] = acc, plus -- for the correlated-Gaussian target -- the two sums that used to cost a pass over G
-// and Z: the functor's return value acc * L[i][j] (j <= i) is summed per workgroup into `part`, and the kernel's
-// EpiColsum hook writes the column sums of G per split.  With z - m = L eps + (mu - m) and f = 1/2 (z - m)' g:
-//   sum_n f(z_n) = 1/2 [ sum_{i >= j} L_ij C_ij + (mu - m)' sum_n g_n ],      C = G' E.
-struct EpiSplitSlabTrace {
+struct EpiSplitSlab {       // C_split[i][j] = acc
   double* C;
   int64_t ldc, slab;
-  const double* Lt;         // Lt[j * ldl + i] = L[i][j]
-  int64_t ldl;
-  double* part;
-  double* colsum;
-  int64_t colsum_ld;
-  __device__ double operator()(int split, int row, int col, double acc) const {
+  __device__ void operator()(int split, int row, int col, double acc) const {
     C[split * slab + (int64_t)row * ldc + col] = acc;
-    return col <= row ? acc * Lt[(int64_t)col * ldl + row] : 0.0;
   }
   __device__ d2v pair(int split, int row, int col, double a0, double a1) const {
-    *reinterpret_cast<d2v*>(C + split * slab + (int64_t)row * ldc + col) = (d2v){a0, a1};
-    return (d2v){col <= row ? a0 * Lt[(int64_t)col * ldl + row] : 0.0,
-                 col + 1 <= row ? a1 * Lt[(int64_t)(col + 1) * ldl + row] : 0.0};
+    const d2v v = (d2v){a0, a1};
+    *reinterpret_cast<d2v*>(C + split * slab + (int64_t)row * ldc + col) = v;
+    return v;
   }
 };
 
@@ -356,7 +370,7 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
     const double* __restrict__ Cpart, int splits, int64_t slab, int d, int64_t ldl,
     const double* __restrict__ colpart, int n_rb, int64_t ldz, const double* __restrict__ fpart, int n_fpart,
     FrSums S, const double* __restrict__ theta, double n_local_w, double n_total, double c0,
-    double* __restrict__ out, int pd, FrWeighted wm, const double* __restrict__ tr_mean) {
+    double* __restrict__ out, int pd, FrWeighted wm) {
   const double ent = pd ? 0.0 : 1.0;      // the entropy's -1 on the free diagonal (absent with the path derivative)
   // weighted mode (AlphaDivergence, objectives.py:458-460): the rows of G carried the weights s_n, the result is
   // scale * [sum s g | tril(sum s g eps') with the free diagonal x L_ii + sum s], the value comes from wm.value
@@ -421,13 +435,11 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
     }
   }
   if (blockIdx.x == 0) {
-    // The scalar tail: sum of the f partials, (mu - m)' colsum for the trace form, sum of the log-diagonal.  One
-    // workgroup, so it is written for latency: every load of a pass is requested before anything is summed (the
-    // three quantities used to be three dependent load -> reduce -> barrier rounds, 8.5 us of the kernel's 13.7 at
-    // D = 1024; the per-thread and cross-thread summation orders are unchanged), and the three block sums share one
-    // pair of barriers.
+    // The scalar tail: sum of the f partials and sum of the log-diagonal.  One workgroup, so it is written for
+    // latency: every load of a pass is requested before anything is summed, and the block sums share one pair of
+    // barriers.
     const int tx = threadIdx.x;
-    double f = 0.0, dot = 0.0, t = 0.0;
+    double f = 0.0, t = 0.0;
     for (int e0 = 0; e0 < n_fpart; e0 += 4 * 256) {
       double v[4];
 #pragma unroll
@@ -439,47 +451,23 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
       for (int u = 0; u < 4; ++u) f += v[u];
     }
     for (int c0 = 0; c0 < d; c0 += 4 * 256) {
-      double th[4], tm[4], dg[4], cs[4];
+      double dg[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = c0 + u * 256 + tx, cc = c < d ? c : 0;
-        th[u] = theta[cc];
-        tm[u] = tr_mean ? tr_mean[cc] : 0.0;
         dg[u] = FUSE ? theta[d + (int64_t)cc * (cc + 1) / 2 + cc] : 0.0;
-        cs[u] = 0.0;
-      }
-      if (tr_mean) {
-        for (int rb0 = 0; rb0 < n_rb; rb0 += 8) {      // 4 columns x 8 splits in flight, summed in split order
-          double v[4][8];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * 256 + tx, cc = c < d ? c : 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[u][q] = rb0 + q < n_rb ? colpart[(int64_t)(rb0 + q) * ldz + cc] : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) cs[u] += v[u][q];
-        }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (c0 + u * 256 + tx < d) {
-          dot = fma(th[u] - tm[u], cs[u], dot);
-          t += dg[u];
-        }
-      }
+      for (int u = 0; u < 4; ++u)
+        if (c0 + u * 256 + tx < d) t += dg[u];
     }
-    __shared__ double sh3[12];
-    f = fr_wave_sum(f), dot = fr_wave_sum(dot), t = fr_wave_sum(t);
-    if ((tx & 63) == 0) sh3[tx >> 6] = f, sh3[4 + (tx >> 6)] = dot, sh3[8 + (tx >> 6)] = t;
+    __shared__ double sh3[8];
+    f = fr_wave_sum(f), t = fr_wave_sum(t);
+    if ((tx & 63) == 0) sh3[tx >> 6] = f, sh3[4 + (tx >> 6)] = t;
     __syncthreads();
     if (tx == 0) {
       f = (sh3[0] + sh3[1]) + (sh3[2] + sh3[3]);
-      dot = (sh3[4] + sh3[5]) + (sh3[6] + sh3[7]);
-      const double sum_logdiag = (sh3[8] + sh3[9]) + (sh3[10] + sh3[11]);
-      if (tr_mean) f = 0.5 * (f + dot);   // fpart holds the partials of sum_ij L_ij C_ij (EpiSplitSlabTrace): F = 1/2 (that + (mu - m)' colsum)
+      const double sum_logdiag = (sh3[4] + sh3[5]) + (sh3[6] + sh3[7]);
       if (FUSE) {
         const double F = f + n_local_w * c0;
         const double half_sq = pd ? 0.5 * S.sums[1] * invN : 0.5 * d;    // 1/2 mean ||eps||^2 or its expectation
@@ -843,7 +831,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   };
   const int64_t o_mu = carve(ldz), o_lt = carve(slab), o_z = carve(n * ldz), o_g = carve(n * ldz),
                 o_cpart = carve((int64_t)(splits + 1) * slab), o_col = carve((int64_t)(n_rb + 1) * ldz),
-                o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx + gemm_max_blocks(D, D) * splits),
+                o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx + gemm_max_blocks(n, D)),
                 o_r = carve(glm ? n * ldr : 0);
   // path derivative: (L')^-1 (Xa), a product buffer T, the noise Gram matrix [16 | e (ld_e) | M2 (d x ldl)], partial
   // column sums of the noise (row stride = the noise matrix's)
@@ -961,6 +949,12 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   g1.tri_mode = mvt ? 0 : 1;
   prof_events(ctx, &g1.ev0, &g1.ev1, 1, VB_PROF_FR_SAMPLE_GEMM);
   int fmode = 0;
+  // correlated-Gaussian target under the dense Gaussian family: no pass over G and Z between the GEMMs -- sum f comes
+  // out of the model GEMM's epilogue (EpiNegateF) and the column sums of G out of the gradient GEMM (EpiSplitSlabCs)
+  static const bool fast_env = !(getenv("VB_FR_FUSED_SUMS") && atoi(getenv("VB_FR_FUSED_SUMS")) == 0);
+  const bool fused_sums = fast_env && !mvt && m.id == VB_MODEL_GAUSS_FULL && !wm.roww && !row_scale && !pd &&
+                          n % kGemmBK == 0 && gemm_uses_dma(g1) && (int64_t)splits <= n_rb;
+  unsigned tiles2 = 0;
   if (m.id == VB_MODEL_GAUSS_DIAG) {
     gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiag{G, ldz, mu, m.p0, m.p1, row_scale});
     fmode = 1;
@@ -1005,7 +999,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     g2.K = D;
     g2.tri_mode = 0;
     prof_events(ctx, &g2.ev0, &g2.ev1, 1, VB_PROF_FR_MODEL_GEMM);
-    gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz}, cfg2);
+    if (fused_sums) tiles2 = gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegateF{G, ldz, Z, fpart}, cfg2);
+    else gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz}, cfg2);
     fmode = 2;
   }
   VB_HIP(ctx, hipGetLastError());
@@ -1031,11 +1026,6 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   g3.N = D;
   g3.K = (int)n;
   g3.tri_mode = mvt ? 0 : 2;
-  // correlated-Gaussian target under the dense Gaussian family: sum f and the column sums of G come out of the
-  // gradient GEMM itself (EpiSplitSlabTrace) -- no pass over G and Z between the two GEMMs
-  static const bool fast_env = !(getenv("VB_FR_FUSED_SUMS") && atoi(getenv("VB_FR_FUSED_SUMS")) == 0);
-  const bool fused_sums = fast_env && !mvt && m.id == VB_MODEL_GAUSS_FULL && !wm.roww && !row_scale && !pd &&
-                          gemm_uses_dma(g3) && (int64_t)splits <= n_rb;
   if (!fused_sums) {
     hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
                        (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
@@ -1052,7 +1042,6 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   // GEMM 3: C[i][j] = sum_n G[n][i] E[n][j]
   prof_events(ctx, &g3.ev0, &g3.ev1, 1, VB_PROF_FR_GRAD_GEMM);
   int n_rb_red = n_rb + (pd ? 1 : 0), n_fpart_red = n_fpart;
-  const double* tr_mean = nullptr;
   if (fused_sums) {
     static const bool map_env = !(getenv("VB_FR_TILE_MAP") && atoi(getenv("VB_FR_TILE_MAP")) == 0);
     int cfg3_used = cfg3;
@@ -1060,11 +1049,9 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
       cfg3_used = 2;     // the launcher's own choice for this shape (128 x 64 tiles), made here so that the list fits it
       VB_TRY(tri2_tile_map(ctx, D, 128, 64, &g3.tile_map, &g3.tile_blocks));
     }
-    const unsigned tiles3 = gemm_f64_launch<false>(
-        st, g3, splits, n_cu, EpiSplitSlabTrace{Cpart, ldl, slab, Lt, ldl, fpart, colpart, ldz}, cfg3_used);
+    gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlabCs{Cpart, ldl, slab, colpart, ldz}, cfg3_used);
     n_rb_red = splits;                  // one row of column sums per split
-    n_fpart_red = (int)tiles3 * splits;   // one trace partial per tile and split
-    tr_mean = m.p0;
+    n_fpart_red = (int)tiles2;          // one partial of sum f per tile of the model GEMM
   } else {
     gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
   }
@@ -1084,14 +1071,14 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     hipLaunchKernelGGL(fr_reduce_packed_kernel<true>, red_grid, dim3(256), 0, st, (const double*)Cpart,
                        splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb_red, ldz,
                        (const double*)fpart, n_fpart_red, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
-                       pd ? 1 : 0, wm, tr_mean);
+                       pd ? 1 : 0, wm);
     VB_HIP(ctx, hipGetLastError());
     return VB_OK;
   }
   hipLaunchKernelGGL(fr_reduce_packed_kernel<false>, red_grid, dim3(256), 0, st, (const double*)Cpart,
                      splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb_red, ldz,
                      (const double*)fpart, n_fpart_red, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
-                     pd ? 1 : 0, wm, tr_mean);
+                     pd ? 1 : 0, wm);
   VB_HIP(ctx, hipGetLastError());
   hipStream_t st_post = st;
   if (overlap) {

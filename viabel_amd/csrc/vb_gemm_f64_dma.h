@@ -95,9 +95,25 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
   // column sums of the A operand (see EpiColsum): thread -> column cs_m of the tile, k rows cs_k0 .. cs_k0 + kCsRows - 1
   constexpr bool kColsum = !A_KCONTIG && EpiColsum<Epi>::value;
   constexpr int kCsRows = kGemmBK * BM / 256;
-  const bool cs_wg = kColsum && bn == 0;
+  const bool cs_wg = kColsum && g.tri_mode != 2 && bn == 0;
   const int cs_m = t & (BM - 1), cs_k0 = (t / BM) * kCsRows;
   double cs = 0.0;
+  // tri_mode 2: the column sums of row block bm are formed in the row's LAST tile (the one on the diagonal) by its
+  // waves wm == 0 (for 64-row tiles: the one wave wm == 0, wn == 1) -- exactly the waves whose sub-tile lies above the
+  // diagonal and that issue no MFMAs there (128 x 64 and 64 x 64 tiles): one lane per column, all 16 k rows of a slab
+  // per lane, so no cross-thread combine and nothing added to the waves that
+  // multiply.  (Done by the workgroups of column block 0, the 8 LDS reads per thread and slab made those 56
+  // workgroups the last to finish: 88 against 81 us for the whole product at D = 1024.)
+  bool cs_lane = false;
+  int cs_col = 0;
+  if constexpr (kColsum) {
+    if (g.tri_mode == 2) {
+      const int cnt = min(g.tiles_n, (bm * BM + BM - 1) / BN + 1);
+      const bool mine = BM == 64 ? (wm == 0 && wn == 1) : wm == 0;
+      cs_lane = bn == cnt - 1 && mine;
+      cs_col = BM == 64 ? lane : wn * 64 + lane;
+    }
+  }
   const int nslabs = (k_end - k_begin) / kGemmBK;
   // tri_mode 1: B[k][j] == 0 for k > j, so a wave whose last column is j_last has nothing to multiply in the slabs
   // that start beyond it -- in a tile's diagonal block the waves of the left half skip the slabs of the lower half
@@ -317,6 +333,17 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
             cs += as[k * BM + cs_m];
           }
         }
+        if (cs_lane) {
+          const double* as = As + st * kATile + cs_col;
+#pragma unroll
+          for (int k0 = 0; k0 < kGemmBK; k0 += 4) {      // four reads in flight (the 128 x 128 tile has no registers to spare)
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = as[(k0 + k) * BM];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cs += v[k];
+          }
+        }
       }
       if (!idle_wave && s < my_nslabs) {
 #pragma unroll
@@ -352,6 +379,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
   }
 
   if constexpr (kColsum) {
+    if (cs_lane && m0 + cs_col < g.M) epi.colsum[(int64_t)blockIdx.z * epi.colsum_ld + m0 + cs_col] = cs;
     if (cs_wg) {                 // combine the k groups in fixed order (the slabs are no longer needed)
       gemm_lds[t] = cs;
       __syncthreads();

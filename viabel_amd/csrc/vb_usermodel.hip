@@ -173,6 +173,9 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
       (void)rtc->log(prog, &log[0]);
     }
     (void)rtc->destroy(&prog);
+    if (log.find("VB_LOG_DENSITY_PARTS needs a model dimension") != std::string::npos)      // the wrapper's static_assert
+      return fail(ctx, VB_ERR_UNSUPPORTED, "VB_LOG_DENSITY_PARTS needs a model dimension of at most %lld",
+                  (long long)kUserDimPrivate);
     if (log.size() > 1500) log.resize(1500);
     return fail(ctx, VB_ERR_INVALID, "model source does not compile: %s", log.c_str());
   }
