@@ -122,10 +122,39 @@ def theta_for(fspec, rng, kind='random'):
 SAVED = []
 
 
+OUT_DIR = HERE          # --check writes into a scratch directory instead and compares with the committed files
+
+
 def save(name, **arrs):
-    path = os.path.join(HERE, name + '.npz')
+    path = os.path.join(OUT_DIR, name + '.npz')
     np.savez(path, **arrs)
     SAVED.append(name)
+
+
+def compare_with_committed(fresh_dir, names):
+    """Every regenerated fixture against the committed file of the same name: same keys, every array equal bit for bit
+    (strings compared as strings).  Returns a list of human-readable differences (empty = no drift)."""
+    problems = []
+    for name in names:
+        old_path = os.path.join(HERE, name + '.npz')
+        if not os.path.exists(old_path):
+            problems.append('%s: not committed' % name)
+            continue
+        a, b = np.load(os.path.join(fresh_dir, name + '.npz'), allow_pickle=False), np.load(old_path, allow_pickle=False)
+        if set(a.files) != set(b.files):
+            problems.append('%s: keys differ (regenerated only: %s; committed only: %s)'
+                            % (name, sorted(set(a.files) - set(b.files)), sorted(set(b.files) - set(a.files))))
+            continue
+        for k in a.files:
+            x, y = a[k], b[k]
+            same = x.shape == y.shape and (np.array_equal(x, y, equal_nan=True) if x.dtype.kind in 'fc'
+                                            else np.array_equal(x, y))
+            if not same:
+                problems.append('%s[%s]: values differ' % (name, k))
+    committed = {f[:-4] for f in os.listdir(HERE) if f.endswith('.npz')}
+    for extra in sorted(committed - set(names)):
+        problems.append('%s: committed but no generator writes it' % extra)
+    return problems
 
 
 def spec_arrays(fspec, mspec):
@@ -693,6 +722,20 @@ if __name__ == '__main__':
                       psis=gen_psis, lowrank=gen_lowrank, ekl_mvt=gen_exclusive_kl_mvt,
                       lowrank_alpha_dis=gen_lowrank_alpha_dis)
     picked = sys.argv[1:]          # e.g. `make_golden.py psis optimizers` regenerates only those fixtures
+    if picked and picked[0] == '--check':
+        # regenerate everything into a scratch directory and diff against the committed fixtures (drift guard, run by
+        # tests/test_oracle_golden.py wherever the reference tree exists)
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            OUT_DIR = tmp
+            for name in (picked[1:] or list(GENERATORS)):
+                GENERATORS[name]()
+            diffs = compare_with_committed(tmp, SAVED) if not picked[1:] else [
+                d for d in compare_with_committed(tmp, SAVED) if 'no generator' not in d]
+        for d in diffs:
+            print('DRIFT ' + d)
+        print('checked %d fixtures: %s' % (len(SAVED), 'no drift' if not diffs else '%d differences' % len(diffs)))
+        sys.exit(1 if diffs else 0)
     if not picked:
         for f in os.listdir(HERE):
             if f.endswith('.npz'):

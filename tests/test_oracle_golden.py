@@ -5,6 +5,8 @@ analytic derivatives, see its header).  Tolerances: values 1e-12 relative (same 
 arithmetic, different summation order), gradients 1e-12 against the stored analytic
 gradient and 2e-7 against the reference finite differences.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -152,3 +154,15 @@ def test_fullrank_gradient_torch_fp64():
         gt, = torch.autograd.grad(val, th)
         assert abs(val.item() - v) < 1e-12 * max(1, abs(v))
         np.testing.assert_allclose(g, gt.numpy(), rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/viabel'), reason='the reference tree exists in the build container only')
+def test_committed_fixtures_match_a_fresh_run_of_the_reference():
+    """Drift guard: `make_golden.py --check` regenerates every fixture from the reference's own code into a scratch
+    directory and compares it with the committed file (same keys, every array bit for bit)."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'make_golden.py')
+    res = subprocess.run([sys.executable, script, '--check'], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert 'no drift' in res.stdout
