@@ -411,6 +411,79 @@ def c4_leg(eng, vb, steps=20):
                          'note': 'whole blocking call (two dense GEMMs + noise generation + streaming pass)'}}
 
 
+def fullrank_fit_leg(vb, iters=300):
+    """What an optimiser sees at the headline shape: RMSProp iterations of FullRankGaussian(1024) + ExclusiveKL on the
+    correlated-Gaussian target with FRESH Philox noise every iteration -- noise generation, the evaluation, the
+    optimiser step and the unpack of the stepped parameter all inside the timed region -- through the device-resident
+    loop (vb_fit, optimization.py:83-127 restated as one stream of launches) and through the host loop."""
+    from viabel_amd.optimization import RMSProp
+    d = FR_D
+    rng = np.random.RandomState(2)
+    A = rng.randn(d, d)
+    model = vb.CorrelatedGaussianModel(rng.randn(d), covariance=A @ A.T / d + np.eye(d))
+    fam = vb.FullRankGaussian(d, rng='philox')
+    obj = vb.ExclusiveKL(fam, model, N_MC)
+    theta = fam.init_param()
+    out = {'workload': 'RMSProp(0.001), FullRankGaussian(%d, rng=philox) + ExclusiveKL, correlated-Gaussian target, '
+                       'N_mc=%d, fresh noise every iteration' % (d, N_MC)}
+    hist = {}
+    for mode, on_device, n_it in (('device_loop', True, iters), ('host_loop', False, max(20, iters // 10))):
+        opt = RMSProp(0.001)
+        opt.optimize(30, obj, theta, on_device=on_device)
+        t0 = time.perf_counter()
+        res = opt.optimize(n_it, obj, theta, on_device=on_device)
+        out[mode + '_us_per_iteration'] = 1e6 * (time.perf_counter() - t0) / n_it
+        hist[mode] = np.asarray(res['value_history'])
+    m = min(len(hist['device_loop']), len(hist['host_loop']))
+    out['trajectories_identical'] = bool(np.array_equal(hist['device_loop'][:m], hist['host_loop'][:m]))
+    fl = fr_flops(N_MC, d)['total']
+    tf = fl / (out['device_loop_us_per_iteration'] * 1e-6) / 1e12
+    out['roofline'] = {'bound': 'mfma', 'flops_executed': fl, 'achieved': tf, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                       'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TFLOPS,
+                       'note': 'whole iteration incl. the iterate-history copy the reference API returns; per-kernel '
+                               'times: profiles/r03_fullrank_fit_kernel_stats.txt'}
+    return out
+
+
+def fullrank_funnel_leg(eng, vb, steps=200, ring=8, slot0=40):
+    """The headline shape on a target with no closed-form shortcuts: FullRankGaussian(1024) + ExclusiveKL on the
+    D-dimensional funnel, N_mc=4096 -- sampling GEMM, the funnel's row kernel (f and G per sample), the column-sum
+    pass, the gradient GEMM and the split reduction; parameter resident, one evaluation per call on one stream."""
+    d = FR_D
+    model = vb.FunnelModel(d)
+    eng.set_model(model.device_spec())
+    fr = vb.FullRankGaussian(d)
+    L = np.exp(-1.0) * np.eye(d) + 0.01 * np.tril(np.random.RandomState(3).randn(d, d))
+    theta = fr.pack(np.zeros(d), L)
+    eng.fullrank_set_theta(theta, d)
+    for s in range(ring):
+        eng.noise_generate(slot0 + s, N_MC, d, seed=2, stream=s)
+
+    def run(k):
+        for i in range(k):
+            eng.elbo_grad_fullrank_enqueue(slot0 + i % ring, N_MC, d)
+    run(300)
+    eng.sync()
+    t0 = time.perf_counter()
+    run(steps)
+    eng.sync()
+    us = 1e6 * (time.perf_counter() - t0) / steps
+    value, grad = eng.fullrank_get(d)
+    from oracle import families as ofam, models as omod, objectives as oobj
+    last = slot0 + (steps - 1) % ring
+    ov, og = oobj.exclusive_kl(ofam.FullRankGaussian(d), omod.Funnel(d), theta, eng.noise_get_host(last, N_MC, d))
+    fl = 2.0 * float(N_MC) * d * (d + 1)             # the two triangular GEMMs; the row kernel and sums are O(N D)
+    tf = fl / (us * 1e-6) / 1e12
+    return {'workload': 'FullRankGaussian(%d) + ExclusiveKL on the funnel target, N_mc=%d, fp64 (no target-specific '
+                        'identities: row kernel + column-sum pass between the two triangular GEMMs)' % (d, N_MC),
+            'us_per_eval': us, 'evals_per_s': 1e6 / us, 'value': float(value), 'grad_norm': float(np.linalg.norm(grad)),
+            'parity': {'rel_elbo_err': abs(value - ov) / abs(ov),
+                       'rel_grad_err': float(np.max(np.abs(grad - og)) / np.max(np.abs(og)))},
+            'roofline': {'bound': 'mfma', 'flops_executed': fl, 'achieved': tf, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TFLOPS,
+                         'note': 'per-kernel times: profiles/r03_fullrank_funnel_kernel_stats.txt'}}
+
+
 def blas_threads_for_baseline():
     """Threads the CPU baseline's GEMMs run on: the GPU boxes of this pool show 256 cores to a container whose
     cgroup quota is far smaller, and an oversubscribed OpenBLAS pool is slower than a modest one."""
@@ -687,6 +760,9 @@ def main():
             out['c2_fullrank_d512'] = {k: v for k, v in fullrank_leg(
                 eng, vb, _lib, group, 512, max(args.steps, 200), args.warmup, profile=True).items()
                 if k in ('whole_evaluation', 'per_kernel', 'value', 'grad_norm')}
+            out['fullrank_funnel'] = fullrank_funnel_leg(eng, vb)
+            with contextlib.redirect_stderr(io.StringIO()):
+                out['fullrank_fit_loop'] = fullrank_fit_leg(vb)
             out['c1_meanfield'], theta1 = meanfield_leg(eng, vb, _lib)
             with contextlib.redirect_stderr(io.StringIO()):    # tqdm progress bars of the host loop
                 out['fit_loop'] = fit_leg(vb, theta1)

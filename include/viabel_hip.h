@@ -98,6 +98,14 @@ int vb_noise_set_host(vb_ctx* ctx, int slot, const double* host, int64_t n, int6
 int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
                       uint64_t stream, int64_t row_offset, int64_t n, int64_t d);
 int vb_noise_get_host(vb_ctx* ctx, int slot, double* host, int64_t n, int64_t d);
+/* First and second moments of the noise matrix in `slot` over its first n rows (this rank's rows; with a communicator
+ * the sums are all-reduced): colsum[j] = sum_n eps_nj (d doubles) and, when `gram` is not NULL, gram[i * d + j] =
+ * sum_n eps_ni eps_nj (d x d row-major, symmetric).  What the reduced forms of the RGE control variates
+ * (objectives.py:200-268) need beside the plain estimator's own sums when the model's Hessian is not one of the
+ * built-in closed forms: mean eps (every method) and M2 = E'E / N (`full`).  One column-sum pass, one split-K lower-
+ * triangular MFMA Gram product.                                                                                   */
+int vb_noise_moments(vb_ctx* ctx, int slot, int64_t n, int64_t d, double* colsum, double* gram);
+
 /* Chi-square(df) draws on the device, df > 2: draw i is element (row_offset + i) of Philox stream (seed, stream) --
  * the per-sample radial scales s = sqrt(chi2 / df) of MultivariateT.sample (approximations.py:345-347) in throughput
  * mode.  The n draws stay in the context (one set at a time); vb_dis_refresh_mvt takes them when its `chi` is NULL. */

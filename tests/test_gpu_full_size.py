@@ -87,6 +87,67 @@ def test_c3_multivariate_t_dis_full_size(vb, use_resampling):
         theta = theta - 0.002 * grad / (1 + np.abs(grad))
 
 
+class CholeskySampledT(ofam.MultivariateT):
+    """rng='philox' draws the DIS state samples as x = mu + (z L') / s with the Cholesky factor; the oracle
+    family samples the same way, everything downstream of the samples is the reference's arithmetic."""
+
+    def sample_from_noise(self, theta, noise):
+        chi, z = noise
+        mu, S = self.split(theta)
+        return mu + (z @ np.linalg.cholesky(S).T) / np.sqrt(chi / self.df)[:, None]
+
+
+@pytest.mark.parametrize('use_resampling,psis_smooth', [(False, False), (True, False), (False, True)])
+def test_c3_multivariate_t_dis_full_size_throughput_mode(vb, use_resampling, psis_smooth):
+    """BASELINE configs[3] at full size through the path bench.py's c3_mvt_dis leg TIMES: rng='philox' (normals and
+    chi-square draws on the device), Cholesky sampling, device factor algebra and the packed chain rule
+    (vb_dis_grad_mvt_packed); the device noise is read back and the oracle must reproduce the step on it.  With
+    psis_smooth the tempered weights additionally go through psislw (_psis.py:113-209) at this size."""
+    from viabel_amd import _lib
+    from viabel_amd.objectives import _DIS_SLOT
+    from oracle import psis as opsis
+    D, N, df, ess_target = 256, 16384, 100, 2048
+    rng = np.random.RandomState(33)
+    mean, sd, prior, theta = c3_problem(rng, D)
+    approx, ofamily = vb.MultivariateT(D, df, seed=6, rng='philox'), CholeskySampledT(D, df)
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=ess_target, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, use_resampling=use_resampling, psis_smooth=psis_smooth)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, ess_target, ofam.MFGaussian(D), prior, use_resampling=use_resampling)
+    eng = _lib.default_engine()
+    np.random.seed(12)
+    for step in range(2):
+        state = np.random.get_state()
+        value, grad = obj(theta)
+        np.random.set_state(state)
+        noise = (eng.chisq_get_host(N), eng.noise_get_host(_DIS_SLOT, N, D))     # what the device drew for this refresh
+        ref.refresh(theta, noise)
+        if step == 0:      # the tempering had work to do: interior eps, effective sample size on target
+            assert 0.0 < ref._eps < 1.0 and abs(ref._ess_val - ess_target) < 0.02 * ess_target, (ref._eps, ref._ess_val)
+        assert G.rel_err(obj._eps, ref._eps) < 1e-10, (obj._eps, ref._eps)
+        assert G.rel_err(obj._state_log_q, ref._state_log_q) < 1e-11
+        assert G.rel_err(obj._state_log_p_unnormalized, ref._state_log_p) < 1e-11
+        w = ref._state_w_clipped
+        if psis_smooth:
+            smoothed, khat = opsis.psis_smooth(np.log(w))
+            w = np.sum(w) * np.exp(smoothed)
+            assert abs(obj._khat - khat) < 1e-7, (obj._khat, khat)
+            assert G.rel_err(obj._state_w_clipped, w) < 1e-8
+        if use_resampling:
+            idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
+            xs = ref._state_samples[idx]
+            scale = ref._state_w_sum / N
+            ov = np.mean(-ofamily.log_density(theta, xs)) * scale
+            og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+        else:
+            xs = ref._state_samples
+            ov = -np.sum(w * ofamily.log_density(theta, xs)) / N
+            og = -ofamily.log_density_grad_weighted(theta, xs, w) / N
+        assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
+        assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
+        theta = theta - 0.002 * grad / (1 + np.abs(grad))
+
+
 def c4_problem(D=2000, n_data=8192, seed=4):
     rng = np.random.RandomState(seed)
     X = rng.randn(n_data, D) / np.sqrt(D)

@@ -65,6 +65,18 @@ class RobustRegressionOracle:
         return -z / self.tau ** 2 + c @ self.X
 
 
+    def hessian(self, m):            # -I / tau^2 - X' diag(dc/dr) X at one point
+        m = np.asarray(m, dtype=float).ravel()
+        r = self.y - self.X @ m
+        a = self.nu * self.s ** 2
+        q = 1.0 + r * r / a
+        dc = (self.nu + 1.0) / a * (1.0 - r * r / a) / q ** 2
+        return -np.eye(self.dim) / self.tau ** 2 - (self.X * dc[:, None]).T @ self.X
+
+    def hvp(self, m, V):             # rows of V times the Hessian at m
+        return np.atleast_2d(V) @ self.hessian(m)
+
+
 def _problem(vb, D, n_data, seed=3):
     rng = np.random.RandomState(seed)
     X = rng.randn(n_data, D)
@@ -135,8 +147,11 @@ def test_source_model_errors(vb):
         bad(np.zeros(3))
     ok = vb.SourceModel(3, '__device__ double vb_log_density(const double* z, int d, const double* p, double* g) '
                            '{ double f = 0; for (int j = 0; j < d; ++j) { f -= 0.5 * z[j] * z[j]; if (g) g[j] = -z[j]; } return f; }')
-    with pytest.raises(NotImplementedError):        # the RGE control variates assume the built-in targets' Hessians
-        vb.ExclusiveKL(vb.MFGaussian(3), ok, 10, hessian_approx_method='full')(np.zeros(6))
+    # control variates of a source model (round 3): for this quadratic f the `full` variate is exact -- the mean block of
+    # the gradient is mu itself whatever the ten noise rows are
+    th = np.array([0.3, -0.2, 0.1, -0.5, 0.0, 0.2])
+    grad = vb.ExclusiveKL(vb.MFGaussian(3), ok, 10, hessian_approx_method='full')(th)[1]
+    assert np.max(np.abs(grad[:3] - th[:3])) < 1e-9
     with pytest.raises(ValueError):
         vb.SourceModel(3, '')
 
@@ -499,3 +514,65 @@ def test_source_model_parts_errors(vb):
     wide = vb.SourceModel(200, ROBUST_REGRESSION_PARTS_SRC % 4, np.zeros(4))      # private arrays stop at 128
     with pytest.raises(NotImplementedError):
         wide(np.zeros(200))
+
+
+@pytest.mark.parametrize('method', ['full', 'mean_only', 'loo_diag_approx', 'loo_direct_approx'])
+@pytest.mark.parametrize('student,pd', [(False, False), (False, True), (True, False)])
+def test_source_model_control_variates_against_literal_rge(vb, method, student, pd):
+    """The four RGE control variates (objectives.py:200-268) for a model given as device source: the reference needs
+    autograd Hessian-vector products of the callable; here the model's derivatives at the mean come from central
+    differences of its own device gradient and the noise moments from vb_noise_moments.  Checked against the literal
+    per-sample restatement of the reference code with the oracle model's ANALYTIC gradient / Hessian."""
+    D, N, n_data = 24, 1024, 96
+    model, omodel = _problem(vb, D, n_data)
+    rng = np.random.RandomState(17)
+    theta = np.concatenate([0.2 * rng.randn(D), -1.2 + 0.2 * rng.randn(D)])
+    if student:
+        approx, ofamily = vb.MFStudentT(D, 7.0, seed=5), ofam.MFStudentT(D, 7.0)
+    else:
+        approx, ofamily = vb.MFGaussian(D, seed=5), ofam.MFGaussian(D)
+    obj = vb.ExclusiveKL(approx, model, N, use_path_deriv=pd, hessian_approx_method=method)
+    value, grad = obj(theta)
+    noise = ofamily.draw_noise(np.random.RandomState(5), N)
+    ov, og = oobj.rge_literal(ofamily, omodel, theta, noise, method, use_path_deriv=pd)
+    assert G.rel_err(value, ov) < 1e-12, (value, ov)
+    assert G.rel_err(grad, og) < 1e-8, G.rel_err(grad, og)
+    plain = vb.ExclusiveKL(type(approx)(*((D, 7.0) if student else (D,)), seed=5), model, N)(theta)[1]
+    assert G.rel_err(grad, plain) > 1e-4                     # the control variate really changed the estimate
+    assert not obj.supports_device_fit()
+
+
+def test_noise_moments_against_numpy(vb):
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    for n, d in ((1000, 37), (4096, 200), (130, 16)):
+        e = np.random.RandomState(n).randn(n, d)
+        eng.noise_set_host(5, e)
+        cs, gram = eng.noise_moments(5, n, d, want_gram=True)
+        assert G.rel_err(cs, e.sum(0)) < 1e-12
+        assert G.rel_err(gram, e.T @ e) < 1e-12
+        assert np.array_equal(gram, gram.T)
+        assert eng.noise_moments(5, n, d)[1] is None
+    with pytest.raises(ValueError):
+        eng.noise_moments(5, 131, 16)
+
+
+def test_source_model_hessian_vector_product(vb):
+    """ExclusiveKL._hessian_vector_product (objectives.py:166, :275-277) with a source model, against the second
+    derivative of the oracle objective on the same noise (analytic model Hessian, chain rule by hand)."""
+    D, N, n_data = 12, 512, 64
+    model, omodel = _problem(vb, D, n_data)
+    rng = np.random.RandomState(18)
+    theta = np.concatenate([0.2 * rng.randn(D), -1.0 + 0.1 * rng.randn(D)])
+    obj = vb.ExclusiveKL(vb.MFGaussian(D, seed=9), model, N)
+    x = rng.randn(2 * D)
+    hv = obj._hessian_vector_product(theta, x)
+    noise = np.random.RandomState(9).randn(N, D)
+    h = 1e-5
+
+    def og(t):
+        return oobj.exclusive_kl(ofam.MFGaussian(D), omodel, t, noise)[1]
+    u = x / np.linalg.norm(x)
+    ref = (8 * (og(theta + h * u) - og(theta - h * u)) - (og(theta + 2 * h * u) - og(theta - 2 * h * u))) / (12 * h)
+    ref *= np.linalg.norm(x)
+    assert G.rel_err(hv, ref) < 1e-6, G.rel_err(hv, ref)

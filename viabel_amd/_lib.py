@@ -57,6 +57,7 @@ SIGNATURES = {
     'vb_set_model_source': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_char_p, _c_double_p, ctypes.c_size_t]),
     'vb_model_logp': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
     'vb_model_grad': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
+    'vb_noise_moments': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_elbo_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_double, _c_double_p,
                                               ctypes.c_uint, ctypes.c_int, _c_double_p, _c_double_p]),
@@ -327,6 +328,15 @@ class Engine:
         g = np.empty((n, d), dtype=np.float64)
         self._check(self._lib.vb_model_grad(self._ctx, _dptr(x), n, d, _dptr(f), _dptr(g)))
         return f, g
+
+    def noise_moments(self, slot, n, d, want_gram=False):
+        """(sum_n eps_n (d), sum_n eps_n eps_n' (d x d) or None) of the first n rows of a noise slot, summed over the
+        ranks of a sharded job."""
+        colsum = np.empty(d, dtype=np.float64)
+        gram = np.empty((d, d), dtype=np.float64) if want_gram else None
+        self._check(self._lib.vb_noise_moments(self._ctx, slot, n, d, _dptr(colsum),
+                                               _dptr(gram) if want_gram else None))
+        return colsum, gram
 
     # ------------------------------------------------------------------ ExclusiveKL, mean field
     def elbo_grad_meanfield(self, slot, n, d, theta, family, df=0.0, flags=0, cv_mode=0, n_total=None):

@@ -451,6 +451,15 @@ int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, doubl
   return VB_OK;
 }
 
+int vb_noise_moments(vb_ctx* ctx, int slot, int64_t n, int64_t d, double* colsum, double* gram) {
+  if (!ctx || !colsum) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (slot < 0 || slot >= VB_MAX_SLOTS || !ctx->noise[slot].buf.ptr)
+    return fail(ctx, VB_ERR_INVALID, "noise slot %d is empty", slot);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  return noise_moments(ctx, ctx->noise[slot], n, d, colsum, gram);
+}
+
 int vb_model_grad(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* f_host, double* g_host) {
   if (!ctx || !x_host || !g_host) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");

@@ -717,6 +717,45 @@ int gram_lower_enqueue(vb_ctx* ctx, const double* A, const double* B, int64_t ld
   return VB_OK;
 }
 
+// vb_noise_moments: column sums and (optionally) the Gram matrix of a noise slot -> host
+int noise_moments(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double* colsum_host, double* gram_host) {
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  const int D = (int)d;
+  const int64_t ld = ns.ld, ldl = round_up(d, 16), slab = d * ldl;
+  const int n_rb = (int)((n + 127) / 128), cs_gx = (D + 127) / 128;
+  const int splits = gram_host ? gram_splits(ctx, D, n) : 0;
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t o_col = carve((int64_t)n_rb * ld), o_f = carve((int64_t)n_rb * cs_gx), o_cpart = carve((int64_t)splits * slab),
+                o_sums = carve(16 + ld + slab);
+  VB_TRY(ensure(ctx, ctx->scratch, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->scratch.ptr;
+  const double* E = (const double*)ns.buf.ptr;
+  hipStream_t st = ctx->stream;
+  VB_TRY(fr_colsum_enqueue(ctx, E, E, ld, n, D, 0, nullptr, base + o_col, base + o_f, nullptr, 0));
+  if (gram_host) VB_TRY(gram_lower_enqueue(ctx, E, E, ld, D, n, splits, base + o_cpart, ldl, slab));
+  FrSums S;
+  S.sums = base + o_sums;
+  S.off_col = 16;
+  S.off_c = 16 + ld;
+  S.len = 16 + ld + slab;
+  VB_TRY(fr_reduce_enqueue(ctx, base + o_cpart, splits, slab, D, ldl, base + o_col, n_rb, ld, base + o_f, 0, S));
+  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)(gram_host ? S.len : 16 + ld)));
+  VB_HIP(ctx, hipMemcpyAsync(colsum_host, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (gram_host)
+    VB_HIP(ctx, hipMemcpy2DAsync(gram_host, (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)ldl * sizeof(double),
+                                 (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  if (gram_host)      // the product fills the lower triangle: mirror it
+    for (int64_t i = 0; i < d; ++i)
+      for (int64_t j = i + 1; j < d; ++j) gram_host[i * d + j] = gram_host[j * d + i];
+  return VB_OK;
+}
+
 int gram_splits(vb_ctx* ctx, int d, int64_t n) {
   const int tiles = gemm_tiles(d, 128);
   const int lower_tiles = tiles * (tiles + 1) / 2;

@@ -126,7 +126,8 @@ class SourceModel(DeviceModel):
     can have K threads per sample instead (``dim <= 128``): ``#define VB_LOG_DENSITY_PARTS K`` (a power of two up to
     64) and define ``vb_log_density_part(z, d, params, grad, part, n_parts)`` returning the share of ``f`` and adding
     the share of the gradient (``grad`` arrives zeroed) of, say, the observations ``part, part + K, ...`` with the
-    prior in part 0 -- several times faster for a few hundred observations (``DESIGN.md`` 4.8).  ``ExclusiveKL`` (both estimator forms, no control variates),
+    prior in part 0 -- several times faster for a few hundred observations (``DESIGN.md`` 4.8).  ``ExclusiveKL`` (both estimator forms; with the mean-field families also the four RGE control variates,
+    the model's Hessian terms taken as central differences of its device gradient),
     ``AlphaDivergence`` and ``DISInclusiveKL`` take it with every family; the model can be called on host samples, and ``vi_diagnostics`` forms its importance weights on the device."""
 
     def __init__(self, dim, source, params=None):

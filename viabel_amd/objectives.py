@@ -94,6 +94,65 @@ def _shared_choice(eng, n, size, p):
     return indices
 
 
+def _source_model_cv(eng, model, approx, var_param, plain_grad, n_local, n_total, method):
+    """RGE control variates (``objectives.py:200-268``) for a model given as device source.
+
+    The four variants reduce algebraically (``oracle.objectives.rge_reduced``, checked against the literal per-sample
+    code) to the plain estimator's own sums ``gbar = mean g``, ``ge = mean g * eps`` -- recovered here from the plain
+    device gradient ``-[gbar | ge sigma + 1]`` -- plus the noise moments ``ebar = mean eps`` and, for ``full``,
+    ``M2 = E'E / N`` (``vb_noise_moments``: one column-sum pass and one MFMA Gram product on the device), and three
+    derivatives of the model AT THE MEAN m: ``g_mu = grad f(m)``, ``H (s * ebar)`` and (``full``) ``H`` itself.  The
+    reference gets those from autograd Hessian-vector products of the Python callable; a source model carries its
+    gradient as device code, so they are fourth-order central differences of that device gradient (``vb_model_grad``
+    on 5 points, or 4 D + 1 points for the whole Hessian): relative error ~1e-11 for smooth densities.  Everything of
+    order N stays on the device; the O(D^2) combination below is host numpy, as for the low-rank family.
+
+    mean block (all methods)               gbar - H (s * ebar)
+    scale block mean_only / loo_direct     ge s + 1
+    scale block loo_diag                   ge s + 1 - g_mu s ebar
+    scale block full                       ... - s_i sum_j H_ij s_j M2_ij + H_ii s_i^2
+    (``s`` = the family's standard deviation, ``eps = (z - m) / s``; for MFStudentT ``s = sigma sqrt(df / (df - 2))``
+    and the moments of ``eps`` follow from those of the base noise.)"""
+    D = approx.dim
+    mu, sigma = var_param[:D], np.exp(var_param[D:])
+    c2 = 1.0
+    if isinstance(approx, MFStudentT):
+        c2 = (approx.df - 2.0) / approx.df                  # (sigma / s)^2
+    gbar = -plain_grad[:D]
+    scale_block = -plain_grad[D:]                           # ge s + 1 (g (z - m) does not care how z - m is factored)
+    colsum, gram = eng.noise_moments(_NOISE_SLOT, n_local, D, want_gram=(method == 'full'))
+    v = sigma * colsum / n_total                            # s * mean(eps) = sigma * mean(base noise)
+    h = 2e-3 * max(1.0, float(np.max(np.abs(mu))))
+
+    def stencil(directions):
+        """grad f at m and the fourth-order central difference of grad f along each row of ``directions``."""
+        k = directions.shape[0]
+        pts = np.concatenate([mu[None, :], mu + h * directions, mu - h * directions, mu + 2 * h * directions,
+                              mu - 2 * h * directions])
+        g = eng.model_grad(pts)[1]
+        d1 = g[1:1 + k] - g[1 + k:1 + 2 * k]
+        d2 = g[1 + 2 * k:1 + 3 * k] - g[1 + 3 * k:]
+        return g[0], (8.0 * d1 - d2) / (12.0 * h)
+
+    if method == 'full':
+        gmu, Ht = stencil(np.eye(D))                        # row j = d grad f / d z_j
+        H = 0.5 * (Ht + Ht.T)
+        Hv = H @ v
+        M2 = gram / n_total
+        scale_block = (scale_block - gmu * v - sigma * np.sum(H * M2 * sigma[None, :], axis=1)
+                       + np.diag(H) * sigma * sigma / c2)
+    else:
+        nv = np.linalg.norm(v)
+        if nv > 0.0:
+            gmu, Hu = stencil((v / nv)[None, :])
+            Hv = Hu[0] * nv
+        else:
+            gmu, Hv = eng.model_grad(mu[None, :])[1][0], np.zeros(D)
+        if method == 'loo_diag_approx':
+            scale_block = scale_block - gmu * v
+    return -np.concatenate([gbar - Hv, scale_block])
+
+
 class VariationalObjective(ABC):
     """A variational objective to minimise (``viabel/objectives.py:17-79``)."""
 
@@ -226,6 +285,16 @@ class ExclusiveKL(StochasticVariationalObjective):
                         _NOISE_SLOT, end - begin, approx.dim, var_param, family, approx._seed,
                         approx._next_philox_stream(), df=df, flags=flags, cv_mode=cv_mode, n_total=N, row_offset=begin)
                 n_local, n_total = self._stage_noise(eng, self.num_mc_samples)
+                if cv_mode != 0 and spec[0] == _lib.MODEL_SOURCE:
+                    # a user model's Hessian is not one of the device epilogue's closed forms: plain sums on the
+                    # device, the model's derivatives at the mean from its own device gradient (_source_model_cv)
+                    value, grad = eng.elbo_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, var_param, family,
+                                                          df=df, flags=flags, cv_mode=0, n_total=n_total)
+                    if flags:      # the path-derivative form changes the VALUE only (objectives.py:186-188); RGE's
+                        grad = eng.elbo_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, var_param, family, df=df,
+                                                       flags=0, cv_mode=0, n_total=n_total)[1]     # gradient does not
+                    return value, _source_model_cv(eng, self.model, approx, var_param, grad, n_local, n_total,
+                                                   self.hessian_approx_method)
                 return eng.elbo_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, var_param, family,
                                                df=df, flags=flags, cv_mode=cv_mode, n_total=n_total)
         elif isinstance(approx, FullRankGaussian):
@@ -331,6 +400,8 @@ class ExclusiveKL(StochasticVariationalObjective):
         if isinstance(approx, LRGaussian):
             return (approx.rng == 'philox' and 1 <= approx.k <= 16 and not self._use_path_deriv
                     and self.hessian_approx_method is None)     # the path-derivative correction is host algebra
+        if self.hessian_approx_method is not None and self.model.device_spec()[0] == _lib.MODEL_SOURCE:
+            return False                 # control variates of a source model combine host-side (_source_model_cv)
         return (isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian)) and approx.rng == 'philox'
                 and not (isinstance(approx, FullRankGaussian) and self.hessian_approx_method is not None))
 
