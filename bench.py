@@ -334,6 +334,26 @@ __device__ double vb_log_density_part(const double* z, int d, const double* p, d
 """
 
 
+SOURCE_LEG_AUTO_SRC = r"""
+template <class T>
+__device__ T vb_log_density(vb::vec<T> z, int d, const double* p) {
+  const int n = (int)p[0];
+  const double nu = p[1], s = p[2], tau = p[3];
+  const double* X = p + 4;
+  const double* y = X + (long long)n * d;
+  T f = 0.0;
+  for (int j = 0; j < d; ++j) f -= 0.5 * z[j] * z[j] / (tau * tau);
+  for (int i = 0; i < n; ++i) {
+    T eta = 0.0;
+    for (int j = 0; j < d; ++j) eta += X[(long long)i * d + j] * z[j];
+    const T r = y[i] - eta;
+    f -= 0.5 * (nu + 1.0) * log(1.0 + r * r / (nu * s * s));
+  }
+  return f;
+}
+"""
+
+
 def source_model_leg(vb, calls=100):
     """SURVEY 8(f) N4, the model adaptor: a log density handed over as HIP source (robust Student-t regression of the
     reference's docs, 64 coefficients, 512 observations), compiled with hiprtc and run inside ExclusiveKL; next to it
@@ -359,6 +379,24 @@ def source_model_leg(vb, calls=100):
             v, g = obj(theta)
         out[name] = {'us_per_call': 1e6 * (time.perf_counter() - t0) / calls, 'value': float(v),
                      'grad_norm': float(np.linalg.norm(g))}
+    # the same density with nothing but the density written down (grad='auto': forward-mode dual numbers on the device,
+    # ceil(D / 8) threads per sample) -- what it costs next to the hand-written gradient
+    auto = vb.SourceModel(D, SOURCE_LEG_AUTO_SRC, model.params, grad='auto')
+    xs = rng.randn(16, D)
+    out['auto_gradient'] = {'max_rel_diff_vs_hand_written': float(np.max(np.abs(auto.grad(xs) - model.grad(xs)))
+                                                                   / np.max(np.abs(model.grad(xs))))}
+    fam = vb.MFGaussian(D, rng='philox')
+    obj = vb.ExclusiveKL(fam, auto, N)
+    theta = fam.init_param()
+    theta[D:] = -1.0
+    for _ in range(3):
+        obj(theta)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        obj(theta)
+    out['auto_gradient']['mf_gaussian_us_per_call'] = 1e6 * (time.perf_counter() - t0) / 20
+    out['auto_gradient']['cost_ratio_vs_hand_written_8_threads'] = (out['auto_gradient']['mf_gaussian_us_per_call']
+                                                                    / out['mf_gaussian']['us_per_call'])
     z = rng.randn(N, D)
     t0 = time.perf_counter()
     r = y[None, :] - z @ X.T

@@ -576,3 +576,121 @@ def test_source_model_hessian_vector_product(vb):
     ref = (8 * (og(theta + h * u) - og(theta - h * u)) - (og(theta + 2 * h * u) - og(theta - 2 * h * u))) / (12 * h)
     ref *= np.linalg.norm(x)
     assert G.rel_err(hv, ref) < 1e-6, G.rel_err(hv, ref)
+
+
+# ---- grad='auto': the density alone, differentiated on the device (forward-mode dual numbers) ---------------------------
+ROBUST_REGRESSION_AUTO_SRC = r"""
+// robust regression, density only: params = [n, nu, s, tau | X (n x d) | y (n)]
+template <class T>
+__device__ T vb_log_density(vb::vec<T> z, int d, const double* p) {
+  const int n = (int)p[0];
+  const double nu = p[1], s = p[2], tau = p[3];
+  const double* X = p + 4;
+  const double* y = X + (long long)n * d;
+  T f = 0.0;
+  for (int j = 0; j < d; ++j) f -= 0.5 * z[j] * z[j] / (tau * tau);
+  for (int i = 0; i < n; ++i) {
+    T eta = 0.0;
+    for (int j = 0; j < d; ++j) eta += X[(long long)i * d + j] * z[j];
+    const T r = y[i] - eta;
+    f -= 0.5 * (nu + 1.0) * log(1.0 + r * r / (nu * s * s));
+  }
+  return f;
+}
+"""
+
+
+@pytest.mark.parametrize('D,n_data', [(7, 40), (24, 96), (130, 64)])
+def test_source_model_auto_gradient_matches_hand_written(vb, D, n_data):
+    """SourceModel(grad='auto') (models.py:17-39: the reference differentiates the callable): the gradient the device
+    derives from the density alone against the hand-written one and against the numpy oracle's analytic gradient."""
+    model, omodel = _problem(vb, D, n_data)
+    auto = vb.SourceModel(D, ROBUST_REGRESSION_AUTO_SRC, model.params, grad='auto')
+    x = np.random.RandomState(D).randn(50, D)
+    assert G.rel_err(auto(x), omodel.logp(x)) < 1e-13
+    assert G.rel_err(auto.grad(x), omodel.grad(x)) < 1e-12
+    assert G.rel_err(auto.grad(x), model.grad(x)) < 1e-12
+    assert auto.check_gradient(x[:4]) < 1e-6
+
+
+@pytest.mark.parametrize('family', ['mf_gaussian', 'fullrank'])
+def test_source_model_auto_gradient_under_exclusive_kl(vb, family):
+    D, N, n_data = 20, 1024, 64
+    model, omodel = _problem(vb, D, n_data)
+    auto = vb.SourceModel(D, ROBUST_REGRESSION_AUTO_SRC, model.params, grad='auto')
+    rng = np.random.RandomState(2)
+    if family == 'mf_gaussian':
+        approx, ofamily = vb.MFGaussian(D, seed=4), ofam.MFGaussian(D)
+        theta = np.concatenate([0.2 * rng.randn(D), -1.0 + 0.1 * rng.randn(D)])
+    else:
+        approx, ofamily = vb.FullRankGaussian(D, seed=4), ofam.FullRankGaussian(D)
+        L = np.tril(0.05 * rng.randn(D, D), -1) + np.diag(np.exp(-1.0 + 0.1 * rng.randn(D)))
+        theta = approx.pack(0.2 * rng.randn(D), L)
+    value, grad = vb.ExclusiveKL(approx, auto, N)(theta)
+    ov, og = oobj.exclusive_kl(ofamily, omodel, theta, np.random.RandomState(4).randn(N, D))
+    assert G.rel_err(value, ov) < 1e-12 and G.rel_err(grad, og) < 1e-11
+
+
+FUNCTION_ZOO_SRC = r"""
+template <class T>
+__device__ T vb_log_density(vb::vec<T> z, int d, const double* p) {
+  T f = 0.0;
+  for (int j = 0; j < d; ++j) {
+    const T x = z[j];
+    T t = log1p(exp(x)) + tanh(x) * sin(x) - sqrt(1.0 + x * x) + lgamma(2.0 + x * x) - pow(1.0 + x * x, 1.5) / 7.0;
+    t += erf(x) + atan(x) * cos(x) + expm1(-x * x) - fabs(x - 0.25) + fmax(x, 0.1) * fmin(x, 2.0);
+    t -= p[0] / (2.0 + x * x) + (3.0 - x) / (1.0 + exp(-x)) + pow(2.0 + sin(x), x);
+    if (x > 0.5) t += x * x * x; else t -= 2.0 * x;
+    f += t * (1.0 + 0.1 * j);
+  }
+  return f;
+}
+"""
+
+
+def test_source_model_auto_gradient_function_zoo(vb):
+    """Every overloaded operation of the dual-number header, against numpy / scipy closed forms."""
+    from scipy.special import digamma, erf, gammaln
+    D = 11
+    p0 = 0.7
+    model = vb.SourceModel(D, FUNCTION_ZOO_SRC, np.array([p0]), grad='auto')
+    x = np.random.RandomState(1).uniform(-1.5, 1.5, size=(64, D))
+    w = 1.0 + 0.1 * np.arange(D)
+
+    def f_and_g(x):
+        q = 1.0 + x * x
+        sg = 1.0 / (1.0 + np.exp(-x))
+        t = np.log1p(np.exp(x)) + np.tanh(x) * np.sin(x) - np.sqrt(q) + gammaln(2.0 + x * x) - q ** 1.5 / 7.0
+        g = sg + (1 - np.tanh(x) ** 2) * np.sin(x) + np.tanh(x) * np.cos(x) - x / np.sqrt(q) + digamma(2.0 + x * x) * 2 * x \
+            - 1.5 * np.sqrt(q) * 2 * x / 7.0
+        t = t + erf(x) + np.arctan(x) * np.cos(x) + np.expm1(-x * x) - np.abs(x - 0.25) + np.maximum(x, 0.1) * np.minimum(x, 2.0)
+        g = g + 2 / np.sqrt(np.pi) * np.exp(-x * x) + np.cos(x) / q - np.arctan(x) * np.sin(x) - 2 * x * np.exp(-x * x) \
+            - np.sign(x - 0.25) + (x >= 0.1) * np.minimum(x, 2.0) + np.maximum(x, 0.1) * (x <= 2.0)
+        b = 2.0 + np.sin(x)
+        t = t - (p0 / (2.0 + x * x) + (3.0 - x) * sg + b ** x)
+        g = g - (-p0 * 2 * x / (2.0 + x * x) ** 2 - sg + (3.0 - x) * sg * (1 - sg) + b ** x * (np.log(b) + x * np.cos(x) / b))
+        t = t + np.where(x > 0.5, x ** 3, -2.0 * x)
+        g = g + np.where(x > 0.5, 3 * x * x, -2.0)
+        return (t * w).sum(1), g * w
+    f, g = f_and_g(x)
+    assert G.rel_err(model(x), f) < 1e-13
+    assert G.rel_err(model.grad(x), g) < 1e-12, G.rel_err(model.grad(x), g)
+
+
+def test_bbvi_with_auto_gradient_source(vb, capsys):
+    """bbvi(dim, log_density=<density-only source>): the reference's primary entry (convenience.py:75) with nothing but
+    the log density written down, as with autograd."""
+    src = r"""
+    template <class T>
+    __device__ T vb_log_density(vb::vec<T> z, int d, const double* p) {       // banana: N(z0; 0, 2^2) N(z1; z0^2 / 4, 1)
+      const T m = z[1] - 0.25 * z[0] * z[0];
+      return -0.125 * z[0] * z[0] - 0.5 * m * m;
+    }
+    """
+    np.random.seed(0)
+    res = vb.bbvi(2, log_density=src, n_iters=2000, num_mc_samples=64, adaptive=False, fixed_lr=True, learning_rate=0.05)
+    assert res['objective'].model.grad_mode == 'auto'
+    mu = res['opt_param'][:2]
+    assert abs(mu[0]) < 0.4 and 0.0 < mu[1] < 2.0
+    with pytest.raises(ValueError):
+        vb.SourceModel(2, src, grad='finite-differences')

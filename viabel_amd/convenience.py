@@ -36,7 +36,9 @@ def bbvi(dimension, *, n_iters=10000, num_mc_samples=10, log_density=None, appro
         elif fit is not None:
             raise ValueError('log_density and fit cannot both be specified')
         if isinstance(log_density, (str, bytes)):      # the log density as HIP source (models.SourceModel)
-            log_density = SourceModel(dimension, log_density)
+            src = log_density.encode() if isinstance(log_density, str) else bytes(log_density)
+            # a density written generically over vb::vec<T> carries no gradient: the engine differentiates it
+            log_density = SourceModel(dimension, log_density, grad='auto' if b'vb::vec' in src else 'explicit')
         if not isinstance(log_density, DeviceModel):
             raise TypeError('log_density must be a viabel_amd device model (GaussianModel, FunnelModel, '
                             'CorrelatedGaussianModel, a regression model, or a SourceModel / HIP source string '

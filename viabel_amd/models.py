@@ -120,7 +120,13 @@ class SourceModel(DeviceModel):
         __device__ double vb_log_density(const double* z, int d, const double* params, double* grad);
 
     returning ``f(z)`` for one sample ``z[0..d)`` and writing its gradient to ``grad[0..d)`` unless ``grad`` is
-    NULL; ``params`` is the array given here (data, hyper-parameters), resident on the device.  The source is
+    NULL; ``params`` is the array given here (data, hyper-parameters), resident on the device.  With
+    ``grad='auto'`` the source gives only the density, generic in its scalar type --
+    ``template <class T> __device__ T vb_log_density(vb::vec<T> z, int d, const double* params);`` (``z[j]`` is a ``T``;
+    ``+ - * /``, comparisons, ``log exp sqrt log1p expm1 pow tanh sin cos atan erf fabs fmin fmax lgamma`` work on ``T``
+    and mix with ``double``) -- and the engine differentiates it like autograd does the reference's callable
+    (``models.py:17-39``): forward-mode dual numbers carrying 8 derivatives in registers, ``ceil(dim / 8)`` threads
+    per sample, exact to rounding.  The source is
     compiled for the GPU with hiprtc when the model is first bound; a source that does not compile raises
     ``ValueError`` with the compiler's log.  One thread evaluates one sample; a density that is a sum over data
     can have K threads per sample instead (``dim <= 128``): ``#define VB_LOG_DENSITY_PARTS K`` (a power of two up to
@@ -130,10 +136,18 @@ class SourceModel(DeviceModel):
     the model's Hessian terms taken as central differences of its device gradient),
     ``AlphaDivergence`` and ``DISInclusiveKL`` take it with every family; the model can be called on host samples, and ``vi_diagnostics`` forms its importance weights on the device."""
 
-    def __init__(self, dim, source, params=None):
+    def __init__(self, dim, source, params=None, grad='explicit'):
         if not isinstance(source, (str, bytes)) or not source:
             raise ValueError('source must be a non-empty string of HIP code')
+        if grad not in ('explicit', 'auto'):
+            raise ValueError("grad must be 'explicit' (the source writes the gradient) or 'auto'")
         self._source = source.encode() if isinstance(source, str) else bytes(source)
+        if grad == 'auto':
+            # the density alone, generic in its scalar type:
+            #     template <class T> __device__ T vb_log_density(vb::vec<T> z, int d, const double* params);
+            # differentiated on the device by forward-mode dual numbers, ceil(dim / 8) threads per sample
+            self._source = b'#define VB_AUTO_GRAD 1\n' + self._source
+        self.grad_mode = grad
         self.params = np.ascontiguousarray(np.zeros(0) if params is None else params, dtype=np.float64).ravel()
         super().__init__(dim)
 
