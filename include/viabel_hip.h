@@ -240,10 +240,19 @@ int vb_dis_grad_mvt(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* 
  * LRGaussian, viabel/approximations.py:610-731: theta = [mu (D) | log_sigma (D) | B (D x k, row-major)],
  * x = mu + z B' + sigma * eps with z (n x k, slot_z) drawn before eps (n x D, slot_eps) (:636-644);
  * entropy via the matrix determinant lemma (:559-573, :646-652); estimator objectives.py:154-164
- * (entropy form; flags must be 0).  grad has 2 D + D k entries in the theta layout.  1 <= k <= 16.  */
+ * (entropy form; flags must be 0).  grad has 2 D + D k entries in the theta layout.  1 <= k <= 16 (one streaming
+ * pass with a lane's rows of B in registers); larger ranks: vb_elbo_sums_lowrank.  */
 int vb_elbo_grad_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k,
                          int64_t n_total, const double* theta, unsigned flags, double* value,
                          double* grad);
+
+/* The same estimator's SUMS for any rank k >= 1 (the reference's family has no rank limit, approximations.py:610-644):
+ * out = [sum_n f(x_n) | sum_n g_n (D) | sum_n g_n * eps_n (D) | sum_n g_n z_n' (D x k, row-major)], 1 + 2 D + D k doubles,
+ * all-reduced over the ranks of a sharded job.  Samples through an n x k x D MFMA product, the model's (f, G) of the
+ * materialised samples (every built-in target and source models), G' Z split over the sample axis.  The entropy and its
+ * gradient -- O(D k^2) through the k x k capacitance matrix -- are the caller's, as for the other low-rank entry points. */
+int vb_elbo_sums_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, const double* theta,
+                         double* out);
 
 /* ---- Importance weights and Pareto smoothing (diagnostics) ----------------------------
  * vb_log_weights_meanfield: log p(z_n) - log q(z_n; theta) for the samples z = mu + sigma * eps of

@@ -546,7 +546,7 @@ def gen_lowrank():
     closure (value exact, gradient by Richardson differences of the reference closure)."""
     rng = np.random.RandomState(61)
     worst = 0.0
-    for D, k in ((3, 1), (6, 2), (10, 4), (17, 5), (12, 9)):
+    for D, k in ((3, 1), (6, 2), (10, 4), (17, 5), (12, 9), (24, 32), (12, 64), (21, 17)):
         seed, N = 7, 40
         ref = ref_approx.LRGaussian(D, seed=seed, k=k)
         orc = ofam.LRGaussian(D, k)

@@ -77,6 +77,10 @@ def test_device_exclusive_kl_matches_reference(path):
         np.testing.assert_allclose(grad, fx[tag + 'grad_fd'], rtol=0, atol=2e-7 * np.max(np.abs(ref_g)))
         # the reference closure with use_path_deriv=True (objectives.py:156-159)
         objective = vb.ExclusiveKL(vb.LRGaussian(D, seed=seed, k=k), model, N, use_path_deriv=True)
+        if k > 16:           # ranks beyond 16 take the GEMM-assembled sums: entropy form only
+            with pytest.raises(NotImplementedError):
+                objective(fx['theta0'])
+            continue
         value, grad = objective(fx['theta0'])
         ref_v, ref_g = float(fx[tag + 'pd_value']), fx[tag + 'pd_grad']
         assert abs(value - ref_v) <= 1e-11 * abs(ref_v), (value, ref_v)
@@ -110,13 +114,35 @@ def test_device_exclusive_kl_matches_oracle(target, D, k, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('target', ['gauss_diag', 'funnel'])
+@pytest.mark.parametrize('D,k,N', [(1024, 32, 4096), (1024, 64, 4096), (300, 17, 777), (130, 40, 33), (64, 100, 256)])
+def test_device_exclusive_kl_any_rank_matches_oracle(target, D, k, N):
+    """Ranks beyond the streaming kernel's 16 (the reference's LRGaussian has no limit, approximations.py:610-644):
+    samples, G' Z and the column sums from MFMA GEMMs (vb_elbo_sums_lowrank), entropy terms on the host."""
+    import viabel_amd as vb
+    rng = np.random.RandomState(D + k)
+    if target == 'gauss_diag':
+        mean, sd = rng.randn(D), np.exp(0.3 * rng.randn(D))
+        model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    else:
+        model, omodel = vb.FunnelModel(D, D // 3), omod.Funnel(D, D // 3)
+    fam = vb.LRGaussian(D, seed=4, k=k)
+    theta = fam.pack(0.2 * rng.randn(D), -1.0 + 0.1 * rng.randn(D), 0.05 * rng.randn(D, k))
+    value, grad = vb.ExclusiveKL(fam, model, N)(theta)
+    noise = ofam.LRGaussian(D, k).draw_noise(np.random.RandomState(4), N)
+    ov, og = oobj.exclusive_kl(ofam.LRGaussian(D, k), omodel, theta, noise)
+    assert abs(value - ov) <= 1e-12 * abs(ov), (value, ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-11 * np.max(np.abs(og)))
+
+
+@pytest.mark.gpu
 def test_lowrank_rejects_unsupported():
     import viabel_amd as vb
     model = vb.GaussianModel(np.zeros(4), np.ones(4))
     with pytest.raises(NotImplementedError):
         vb.ExclusiveKL(vb.LRGaussian(4, k=2), model, 10, hessian_approx_method='full')
     with pytest.raises(NotImplementedError):
-        vb.ExclusiveKL(vb.LRGaussian(4, k=17), model, 10)(np.zeros(4 * 2 + 4 * 17))
+        vb.ExclusiveKL(vb.LRGaussian(4, k=17), model, 10, use_path_deriv=True)(np.zeros(4 * 2 + 4 * 17))
     with pytest.raises(ValueError):
         vb.ExclusiveKL(vb.LRGaussian(4, k=2), model, 10)(np.zeros(3))
 

@@ -57,6 +57,8 @@ SIGNATURES = {
     'vb_set_model_source': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_char_p, _c_double_p, ctypes.c_size_t]),
     'vb_model_logp': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
     'vb_model_grad': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
+    'vb_elbo_sums_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                            _c_double_p, _c_double_p]),
     'vb_noise_moments': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_elbo_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_double, _c_double_p,
@@ -328,6 +330,13 @@ class Engine:
         g = np.empty((n, d), dtype=np.float64)
         self._check(self._lib.vb_model_grad(self._ctx, _dptr(x), n, d, _dptr(f), _dptr(g)))
         return f, g
+
+    def elbo_sums_lowrank(self, slot_eps, slot_z, n, d, k, theta):
+        """(sum f, sum g (d), sum g eps (d), sum g z' (d x k)) of the low-rank family's ExclusiveKL at any rank."""
+        theta = _f64(theta)
+        out = np.empty(1 + 2 * d + d * k, dtype=np.float64)
+        self._check(self._lib.vb_elbo_sums_lowrank(self._ctx, slot_eps, slot_z, n, d, k, _dptr(theta), _dptr(out)))
+        return out[0], out[1:1 + d], out[1 + d:1 + 2 * d], out[1 + 2 * d:].reshape(d, k)
 
     def noise_moments(self, slot, n, d, want_gram=False):
         """(sum_n eps_n (d), sum_n eps_n eps_n' (d x d) or None) of the first n rows of a noise slot, summed over the

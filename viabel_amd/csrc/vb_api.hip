@@ -654,6 +654,21 @@ int vb_elbo_grad_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64
   return VB_OK;
 }
 
+int vb_elbo_sums_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, const double* theta,
+                         double* out) {
+  if (!ctx || !theta || !out) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot_eps));
+  VB_TRY(check_slot(ctx, slot_z));
+  if (slot_eps == slot_z) return fail(ctx, VB_ERR_INVALID, "eps and z need different noise slots");
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot_eps].buf.ptr || !ctx->noise[slot_z].buf.ptr)
+    return fail(ctx, VB_ERR_STATE, "noise slot is empty");
+  if (d <= 0 || k <= 0) return fail(ctx, VB_ERR_INVALID, "d and k must be positive");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  return lr_elbo_sums_any_rank(ctx, ctx->noise[slot_eps], ctx->noise[slot_z], n, d, k, theta, out);
+}
+
 // ---- importance weights + PSIS (convenience.py:166-179, _psis.py:113-209) ---------------------------
 int vb_log_weights_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int family, double df,
                              const double* theta, double* lw) {

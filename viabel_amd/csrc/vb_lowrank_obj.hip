@@ -556,6 +556,139 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
   return VB_OK;
 }
 
+// ---- ExclusiveKL sums for ANY rank k (entropy form; the streaming kernel of vb_lowrank.hip keeps a lane's rows of B in
+// registers and stops at k = 16) ------------------------------------------------------------------------------------------
+// The reference's LRGaussian has no rank limit (approximations.py:610-644, :685-707).  For k > 16 the evaluation is
+// assembled from GEMMs: X = mu + sigma E + Z B' (n x kp x d product with the sampling epilogue), the model's (f, G) of
+// the materialised samples (model_grad_rows: every built-in target and source models), sum_n g and sum_n g eps
+// (column passes) and sum_n g z' = G' Z (d x kp, contraction over the samples split into slabs and summed in fixed order).
+// out = [sum f | sum g (d) | sum g eps (d) | sum g z' (d x k row-major)]; the entropy and its gradient are O(D k^2) host
+// algebra through the capacitance matrix, as for the k <= 16 objectives.
+namespace {
+
+struct EpiLrSample {         // X = acc + mu + sigma E
+  double* X;
+  int64_t ldx;
+  const double* mu;
+  const double* sigma;
+  const double* E;
+  int64_t lde;
+  __device__ void operator()(int, int row, int col, double acc) const {
+    X[(int64_t)row * ldx + col] = acc + fma(sigma[col], E[(int64_t)row * lde + col], mu[col]);
+  }
+};
+
+struct EpiSlabAny {          // slab_split[i][j] = acc, row stride ldc
+  double* C;
+  int64_t ldc, slab;
+  __device__ void operator()(int split, int row, int col, double acc) const {
+    C[split * slab + (int64_t)row * ldc + col] = acc;
+  }
+};
+
+__global__ void __launch_bounds__(256) lrs_ones_kernel(double* w, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) w[i] = 1.0;
+}
+
+// one workgroup: out[0] = sum_n f[n] in a fixed order
+__global__ void __launch_bounds__(1024) lrs_fsum_kernel(const double* __restrict__ f, int64_t n, double* __restrict__ out) {
+  __shared__ double sh[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += f[i];
+  s = lro_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int q = 0; q < 16; ++q) t += sh[q];
+    out[0] = t;
+  }
+}
+
+}  // namespace
+
+int lr_elbo_sums_any_rank(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
+                          const double* theta_host, double* out_host) {
+  if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d || k < 1)
+    return fail(ctx, VB_ERR_INVALID, "noise slots must hold n x d and n x k matrices");
+  if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
+  const int64_t ld = round_up(d, 16), kp = round_up(k, 16);
+  if (nz.ld < kp) return fail(ctx, VB_ERR_STATE, "low-rank noise slot row stride %lld < %lld", (long long)nz.ld, (long long)kp);
+  const int n_rb = (int)((n + 127) / 128);
+  int splits = (int)(n / 256);
+  splits = splits > 32 ? 32 : (splits < 1 ? 1 : splits);
+  int64_t off = 0;
+  auto carve = [&off](int64_t doubles) {
+    const int64_t o = off;
+    off += round_up(doubles, 16);
+    return o;
+  };
+  const int64_t o_x = carve(n * ld), o_g = carve(n * ld), o_f = carve(n), o_w = carve(n), o_mu = carve(ld), o_sig = carve(ld),
+                o_bt = carve(kp * ld), o_col = carve((int64_t)n_rb * ld), o_slabs = carve((int64_t)splits * d * kp),
+                o_out = carve(1 + 2 * ld + d * kp);
+  VB_TRY(ensure(ctx, ctx->lr_obj, (size_t)off * sizeof(double)));
+  double* base = (double*)ctx->lr_obj.ptr;
+  hipStream_t st = ctx->stream;
+  // parameter pieces: mu, sigma = exp(log sigma), B' (kp x ld, zero padded) -- O(D k) host work, like the objectives' upload
+  std::vector<double> h((size_t)(2 * ld + kp * ld), 0.0);
+  for (int64_t i = 0; i < d; ++i) {
+    h[i] = theta_host[i];
+    h[ld + i] = exp(theta_host[d + i]);
+    for (int64_t j = 0; j < k; ++j) h[2 * ld + j * ld + i] = theta_host[2 * d + i * k + j];
+  }
+  VB_HIP(ctx, hipMemcpyAsync(base + o_mu, h.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(base + o_sig, h.data() + ld, (size_t)ld * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(base + o_bt, h.data() + 2 * ld, (size_t)(kp * ld) * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));      // `h` is stack-scoped
+  const double* E = (const double*)ns.buf.ptr;
+  const double* Z = (const double*)nz.buf.ptr;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  GemmArgs g1;                                  // X = Z B' (+ mu + sigma E): n x d, contraction over the kp columns of Z
+  g1.A = Z, g1.lda = nz.ld, g1.B = base + o_bt, g1.ldb = ld;
+  g1.M = (int)n, g1.N = (int)d, g1.K = (int)kp, g1.tri_mode = 0;
+  gemm_f64_launch<true>(st, g1, 1, n_cu, EpiLrSample{base + o_x, ld, base + o_mu, base + o_sig, E, ns.ld});
+  VB_HIP(ctx, hipGetLastError());
+  VB_HIP(ctx, hipMemsetAsync(base + o_g, 0, (size_t)n * ld * sizeof(double), st));
+  VB_TRY(model_grad_rows(ctx, base + o_x, ld, n, d, base + o_g, base + o_f));
+  double* outd = base + o_out;
+  hipLaunchKernelGGL(lrs_fsum_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + o_f), n, outd);
+  hipLaunchKernelGGL(lrs_ones_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base + o_w, n);
+  VB_HIP(ctx, hipGetLastError());
+  VB_HIP(ctx, hipMemsetAsync(outd + 1, 0, (size_t)(2 * ld) * sizeof(double), st));
+  // sum_n g_n eps_n per column: the weighted column-product pass with unit weights
+  hipLaunchKernelGGL(lro_colsum_prod_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)n_rb), dim3(256), 0, st,
+                     (const double*)(base + o_g), ld, E, ns.ld, ld, (const double*)(base + o_w), n, (int)d, base + o_col);
+  hipLaunchKernelGGL(lro_slab_sum_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + o_col), n_rb, ld, outd + 1 + ld, d);
+  VB_HIP(ctx, hipGetLastError());
+  // sum_n g_n: the same pass against a row of ones re-read for every sample (row stride 0; X is free again)
+  hipLaunchKernelGGL(lrs_ones_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, st, base + o_x, ld);
+  hipLaunchKernelGGL(lro_colsum_prod_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)n_rb), dim3(256), 0, st,
+                     (const double*)(base + o_g), ld, (const double*)(base + o_x), (int64_t)0, ld,
+                     (const double*)(base + o_w), n, (int)d, base + o_col);
+  hipLaunchKernelGGL(lro_slab_sum_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + o_col), n_rb, ld, outd + 1, d);
+  VB_HIP(ctx, hipGetLastError());
+  GemmArgs g2;                                  // G' Z: d x kp, contraction over the n samples
+  g2.A = base + o_g, g2.lda = ld, g2.B = Z, g2.ldb = nz.ld;
+  g2.M = (int)d, g2.N = (int)kp, g2.K = (int)n, g2.tri_mode = 0;
+  const int64_t slab = d * kp;
+  gemm_f64_launch<false>(st, g2, splits, n_cu, EpiSlabAny{base + o_slabs, kp, slab});
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(lro_slab_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + o_slabs), splits, slab, outd + 1 + 2 * ld, slab);
+  VB_HIP(ctx, hipGetLastError());
+  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, outd, (size_t)(1 + 2 * ld + slab)));
+  VB_HIP(ctx, hipMemcpyAsync(out_host, outd, sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(out_host + 1, outd + 1, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(out_host + 1 + d, outd + 1 + ld, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpy2DAsync(out_host + 1 + 2 * d, (size_t)k * sizeof(double), outd + 1 + 2 * ld, (size_t)kp * sizeof(double),
+                               (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  return VB_OK;
+}
+
 }  // namespace vb
 
 using namespace vb;

@@ -337,6 +337,12 @@ class ExclusiveKL(StochasticVariationalObjective):
                     z, eps = approx._base_noise(N)      # low-rank block first (approximations.py:639-640)
                     eng.noise_set_host(_NOISE_SLOT, eps[begin:end])
                     eng.noise_set_host(_LR_SLOT, z[begin:end])
+                if approx.k > 16:
+                    # beyond the streaming kernel's register budget: the sums from GEMMs (vb_elbo_sums_lowrank), the
+                    # entropy and its gradient through the k x k capacitance matrix on the host (approximations.py:559-573)
+                    if path_deriv:
+                        raise NotImplementedError('LRGaussian with k > 16: entropy-form estimator only')
+                    return _lowrank_any_rank(eng, approx, var_param, end - begin, N)
                 value, grad = eng.elbo_grad_lowrank(_NOISE_SLOT, _LR_SLOT, end - begin, approx.dim, approx.k, var_param,
                                                     n_total=N)
                 if path_deriv:
@@ -535,6 +541,26 @@ def _lowrank_path_correction(eng, approx, var_param, value, grad, n_local, N):
                                 sinv(B).reshape(-1)])
     corr = np.concatenate([a1, sig * a2, a3.reshape(-1)]) / N
     return value + entropy + mean_logq, grad + d_entropy - corr
+
+
+def _lowrank_any_rank(eng, approx, var_param, n_local, N):
+    """ExclusiveKL (entropy form, objectives.py:160-164) of an LRGaussian of any rank from the device's sums
+    ``[sum f | sum g | sum g eps | sum g z']``: value = -(mean f + H), d/dmu = -mean g, d/dlog_sigma = -mean(g eps) sigma
+    - dH/dlog_sigma, d/dB = -mean g z' - dH/dB, with H = D/2 (log 2 pi + 1) + sum log sigma + 1/2 log det M,
+    M = I + B' D^-2 B (matrix determinant lemma, approximations.py:559-573, :646-652)."""
+    D, k = approx.dim, approx.k
+    mu, ls, B = approx._unpack(var_param)
+    sig2 = np.exp(2.0 * ls)
+    W = B / sig2[:, None]
+    M = np.eye(k) + B.T @ W
+    Minv = np.linalg.inv(M)
+    Minv = 0.5 * (Minv + Minv.T)
+    entropy = 0.5 * D * (np.log(2.0 * np.pi) + 1.0) + np.sum(ls) + 0.5 * np.linalg.slogdet(M)[1]
+    WM = W @ Minv
+    d_entropy = np.concatenate([np.zeros(D), 1.0 - np.sum(WM * W, axis=1) * sig2, WM.reshape(-1)])
+    f, g, ge, gz = eng.elbo_sums_lowrank(_NOISE_SLOT, _LR_SLOT, n_local, D, k, var_param)
+    grad = -np.concatenate([g, ge * np.exp(ls), gz.reshape(-1)]) / N - d_entropy
+    return -(f / N + entropy), grad
 
 
 def _lowrank_pieces(approx, var_param):
