@@ -298,6 +298,16 @@ int vb_elbo_grad_fullrank_enqueue(vb_ctx* ctx, int slot, int64_t n, int64_t d, i
                                   unsigned flags);
 int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p);
 
+/* ---- ExclusiveKL for the multivariate t, throughput mode (approximations.py:342-354, objectives.py:160-164) --------
+ * Samples through the CHOLESKY factor, x_n = mu + (L z_n) / s_n with s_n = sqrt(chi_n / df) from the device chi-square
+ * draws of vb_chisq_generate (same distribution as the reference's symmetric root, :348, which parity mode keeps): with
+ * the factor itself in the sampler, d/dL is tril(sum_n g_n (z_n / s_n)') directly -- no matrix square root, no
+ * Sylvester solve, nothing of order D^2 or more on the host.  theta = [mu | free Cholesky of the scale matrix]; the
+ * noise slot holds the n x d normals.  `value` is -(mean f + D/2 (1 + log 2 pi) + sum log L_ii): the caller swaps the
+ * Gaussian entropy constant for the family's own (a function of df and D only).  Entropy form only.              */
+int vb_elbo_grad_mvt_chol(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
+                          double* value, double* grad);
+
 /* ---- symmetric matrix square root on the device ------------------------------------------------------
  * root = a^(1/2) for a symmetric positive definite d x d host matrix -- scipy.linalg.sqrtm(Sigma) in
  * MultivariateT.sample (approximations.py:348) -- by coupled Newton-Schulz iterations (fp64 MFMA GEMMs only).

@@ -59,6 +59,8 @@ SIGNATURES = {
     'vb_model_grad': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_elbo_sums_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             _c_double_p, _c_double_p]),
+    'vb_elbo_grad_mvt_chol': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                             _c_double_p, _c_double_p, _c_double_p]),
     'vb_noise_moments': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_elbo_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_double, _c_double_p,
@@ -337,6 +339,15 @@ class Engine:
         out = np.empty(1 + 2 * d + d * k, dtype=np.float64)
         self._check(self._lib.vb_elbo_sums_lowrank(self._ctx, slot_eps, slot_z, n, d, k, _dptr(theta), _dptr(out)))
         return out[0], out[1:1 + d], out[1 + d:1 + 2 * d], out[1 + 2 * d:].reshape(d, k)
+
+    def elbo_grad_mvt_chol(self, slot, n, d, theta, df, n_total=None):
+        """Throughput-mode ExclusiveKL of the multivariate t (Cholesky sampling, device chi-square draws)."""
+        theta = _f64(theta)
+        value = ctypes.c_double(0.0)
+        grad = np.empty(d + d * (d + 1) // 2, dtype=np.float64)
+        self._check(self._lib.vb_elbo_grad_mvt_chol(self._ctx, slot, n, d, n if n_total is None else n_total, float(df),
+                                                    _dptr(theta), ctypes.byref(value), _dptr(grad)))
+        return value.value, grad
 
     def noise_moments(self, slot, n, d, want_gram=False):
         """(sum_n eps_n (d), sum_n eps_n eps_n' (d x d) or None) of the first n rows of a noise slot, summed over the

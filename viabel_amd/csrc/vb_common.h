@@ -171,6 +171,7 @@ struct vb_ctx {
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
   int64_t dis_n_total = 0;              // whole-job sample count of the DIS state
   vb::DeviceBuffer chi_dev;             // device-generated chi-square draws (vb_chisq_generate)
+  vb::DeviceBuffer mvt_invs;            // 1 / s_n of the throughput-mode t ExclusiveKL (vb_elbo_grad_mvt_chol)
   int64_t chi_n = 0;                    // how many of them are valid (0: none)
   double chi_df = 0.0;
   vb::DeviceBuffer bisect_work;         // DIS tempering bisection: interval / ESS tables of the look-ahead rounds
@@ -354,6 +355,8 @@ int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab
 // lower triangle of C = A' B for k-major A, B (n x d, row stride ld), split over n into `splits` slabs
 int lr_elbo_sums_any_rank(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
                           const double* theta_host, double* out_host);
+int mvt_elbo_chol_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df,
+                          const double* theta_dev, double* out_dev);
 int noise_moments(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double* colsum_host, double* gram_host);
 int gram_lower_enqueue(vb_ctx* ctx, const double* A, const double* B, int64_t ld, int d, int64_t n, int splits,
                        double* Cpart, int64_t ldc, int64_t slab);

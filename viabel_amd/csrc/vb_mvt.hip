@@ -715,4 +715,20 @@ int mvt_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64
   return VB_OK;
 }
 
+// ExclusiveKL, throughput mode: the dense-Gaussian pipeline (triangular sampling GEMM, model, lower-triangular gradient
+// GEMM, packed reduction) with the rows scaled by 1 / s_n -- x = mu + (L z) / s -- so the gradient comes out in the free-
+// Cholesky layout with no root and no Sylvester equation (vb_elbo_grad_mvt_chol)
+int mvt_elbo_chol_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df,
+                          const double* theta_dev, double* out_dev) {
+  if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  if (ctx->chi_n != n || ctx->chi_df != df || !ctx->chi_dev.ptr)
+    return fail(ctx, VB_ERR_STATE, "needs %lld device chi-square(%g) draws (vb_chisq_generate)", (long long)n, df);
+  VB_TRY(ensure(ctx, ctx->mvt_invs, (size_t)n * sizeof(double)));
+  hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const double*)ctx->chi_dev.ptr, df, n, (double*)ctx->mvt_invs.ptr);
+  VB_HIP(ctx, hipGetLastError());
+  return fr_pipeline_enqueue(ctx, ns, n, d, n_total, theta_dev, out_dev, nullptr, nullptr, (const double*)ctx->mvt_invs.ptr,
+                             nullptr, 0, nullptr);
+}
+
 }  // namespace vb

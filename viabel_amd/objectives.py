@@ -456,6 +456,18 @@ class ExclusiveKL(StochasticVariationalObjective):
             eng.set_model(self.model.device_spec())
             N = self.num_mc_samples
             begin, end = shard_rows(N, eng.n_ranks, eng.rank)
+            if approx.rng == 'philox' and not path_deriv:
+                # throughput mode: chi-square draws and normals on the GPU, samples through the Cholesky factor
+                # x = mu + (L z) / s instead of the symmetric root (approximations.py:348; same distribution, and no
+                # reference noise stream is being reproduced in this mode).  With L itself in the sampler the chain
+                # rule is d/dL = tril(sum g (z / s)'): the dense-Gaussian pipeline with scaled rows returns the
+                # gradient in the flat layout -- no root, no Sylvester solve, no D^2 host work.
+                stream = approx._next_philox_stream()
+                eng.chisq_generate(df, end - begin, approx._seed, stream, row_offset=begin)
+                eng.noise_generate(_NOISE_SLOT, end - begin, D, approx._seed, stream, row_offset=begin)
+                value, grad = eng.elbo_grad_mvt_chol(_NOISE_SLOT, end - begin, D, var_param, df, n_total=N)
+                # the device value carries the Gaussian entropy constant; the family's own drops the df-only terms
+                return value + 0.5 * D * (1.0 + np.log(2.0 * np.pi)), grad
             if approx.rng == 'philox':
                 chi = approx._rs.chisquare(df, N)
                 eng.noise_generate(_NOISE_SLOT, end - begin, D, approx._seed, approx._next_philox_stream(),
