@@ -77,6 +77,9 @@ def test_multivariate_t_exclusive_kl_matches_oracle(vb, D, N, rng_kind, model_ki
         S = A @ A.T / D + np.eye(D)
         mean = rng.randn(D)
         model, omodel = vb.CorrelatedGaussianModel(mean, covariance=S), omod.GaussFull(mean, np.linalg.inv(S))
+    if rng_kind == 'philox' and not pd:
+        pytest.skip("rng='philox' without the path derivative is the throughput mode (Cholesky sampling, device "
+                    "chi-square): tests/test_gpu_objectives.py::test_exclusive_kl_multivariate_t_throughput_mode_against_oracle")
     approx = vb.MultivariateT(D, 9.0, seed=6, rng=rng_kind)
     B = rng.randn(D, D)
     theta = np.concatenate([0.2 * rng.randn(D), ofam.psd_to_free(0.05 * (B @ B.T / D + 0.5 * np.eye(D)))])

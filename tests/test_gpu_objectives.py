@@ -605,7 +605,7 @@ def test_more_than_65535_samples(vb):
     np.testing.assert_allclose(cg(x), omod.GaussFull(cg.mean, cg.precision).logp(x), rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize('target', ['gauss_diag', 'funnel', 'gauss_full'])
+@pytest.mark.parametrize('target', ['gauss_diag', 'funnel', 'gauss_full', 'logistic'])
 @pytest.mark.parametrize('D,N', [(256, 4096), (130, 1000), (33, 77)])
 def test_exclusive_kl_multivariate_t_throughput_mode_against_oracle(vb, target, D, N):
     """MultivariateT + ExclusiveKL with rng='philox' (the family / objective pair of the reference's robust-regression
@@ -622,6 +622,10 @@ def test_exclusive_kl_multivariate_t_throughput_mode_against_oracle(vb, target, 
         model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
     elif target == 'funnel':
         model, omodel = vb.FunnelModel(D, D // 2), omod.Funnel(D, D // 2)
+    elif target == 'logistic':
+        X = rng.randn(3 * D, D) / np.sqrt(D)
+        y = (rng.rand(3 * D) < 0.5).astype(float)
+        model, omodel = vb.LogisticRegressionModel(X, y, 3.0), omod.Logistic(X, y, 3.0)
     else:
         A = rng.randn(D, D)
         model = vb.CorrelatedGaussianModel(0.2 * rng.randn(D), covariance=A @ A.T / D + np.eye(D))
