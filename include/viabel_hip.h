@@ -225,6 +225,19 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
  * rule to the flat parameter on the device: value = -scale sum_n w_n log q(x_n; theta) and its gradient (d + d (d + 1) / 2). */
 int vb_dis_grad_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* weights,
                            double scale, double* value, double* grad);
+/* Device-resident step of the throughput mode (one rank): after vb_dis_refresh_mvt(..., w = NULL) -- which only enqueues
+ * -- the tempered weights, eps, ess and the zero-weight status are still on the device.  This call takes the gradient of
+ * -scale sum_n w_n log q(x_n; theta) on those weights (resample_m == 0, objectives.py:405-406) or on the counts of
+ * resample_m multinomial draws from them (objectives.py:408-414: np.random.choice; here Philox uniforms of
+ * (seed, stream) inverted through the running sums of the weights; `scale` is then multiplied by sum_n w_n on the
+ * device), and returns (value, grad) together with eps and ess of the refresh after ONE synchronisation: no weight
+ * vector crosses PCIe, no host work of order N.  vb_dis_weights_get fetches the tempered weights for callers that
+ * want to look at them.  The weight clipping of objectives.py:370-386 is the identity for thresholds >= 1 (the
+ * default is 10): callers with a smaller threshold use the two-call path.                                      */
+int vb_dis_step_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, int64_t resample_m,
+                           uint64_t seed, uint64_t stream, double scale, double* eps, double* ess, double* value,
+                           double* grad);
+int vb_dis_weights_get(vb_ctx* ctx, double* w, int64_t n_total, int resampled /* 1: the counts of the last draw */);
 /* The DIS state samples live in the context, one set per family kind (0: mean-field, 1: MultivariateT / dense
  * Gaussian, 2: low-rank Gaussian); every refresh of a kind overwrites its set and bumps its generation counter.  A
  * caller that keeps weights for a later vb_dis_grad_* call compares the counter with the one it saw after its own

@@ -133,16 +133,22 @@ def test_c3_multivariate_t_dis_full_size_throughput_mode(vb, use_resampling, psi
             w = np.sum(w) * np.exp(smoothed)
             assert abs(obj._khat - khat) < 1e-7, (obj._khat, khat)
             assert G.rel_err(obj._state_w_clipped, w) < 1e-8
+        xs = ref._state_samples
         if use_resampling:
-            idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
-            xs = ref._state_samples[idx]
-            scale = ref._state_w_sum / N
-            ov = np.mean(-ofamily.log_density(theta, xs)) * scale
-            og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+            # the multinomial draw happens on the device in this mode (Philox uniforms inverted through the running
+            # sums of the weights): read the counts back; the objective is objectives.py:410-414 on those indices
+            counts = eng.dis_weights_get(N, resampled=True)
+            M = ref._resampling_batch_size
+            assert counts.sum() == M and np.all(counts == np.round(counts)) and counts.min() >= 0
+            top = np.argsort(w)[-200:]            # the draw follows the weights: the 200 heaviest samples take their share
+            assert abs(counts[top].sum() / M - w[top].sum() / w.sum()) < 0.05
+            scale = ref._state_w_sum / N / M
+            ov = -np.sum(counts * ofamily.log_density(theta, xs)) * scale
+            og = -ofamily.log_density_grad_weighted(theta, xs, counts) * scale
         else:
-            xs = ref._state_samples
             ov = -np.sum(w * ofamily.log_density(theta, xs)) / N
             og = -ofamily.log_density_grad_weighted(theta, xs, w) / N
+            assert G.rel_err(obj._state_w_clipped, w) < 1e-8          # fetched from the device on first access
         assert G.rel_err(value, ov) < 1e-10, (step, value, ov)
         assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
         theta = theta - 0.002 * grad / (1 + np.abs(grad))

@@ -362,11 +362,12 @@ def test_dis_multivariate_t_philox_mode_against_oracle(vb, use_resampling):
     noise = (eng.chisq_get_host(N), eng.noise_get_host(_DIS_SLOT, N, D))
     if use_resampling:
         ref.refresh(theta, noise)
-        idx = np.random.choice(N, size=ref._resampling_batch_size, p=ref._state_w_normalized)
-        xs = ref._state_samples[idx]
-        scale = ref._state_w_sum / N
-        ov = np.mean(-ofamily.log_density(theta, xs)) * scale
-        og = -ofamily.log_density_grad_weighted(theta, xs, np.ones(len(idx))) / len(idx) * scale
+        counts = eng.dis_weights_get(N, resampled=True)       # the device's multinomial draw (objectives.py:408)
+        M = ref._resampling_batch_size
+        assert counts.sum() == M
+        scale = ref._state_w_sum / N / M
+        ov = -np.sum(counts * ofamily.log_density(theta, ref._state_samples)) * scale
+        og = -ofamily.log_density_grad_weighted(theta, ref._state_samples, counts) * scale
     else:
         ov, og = ref(theta, noise=noise)
     assert G.rel_err(obj._eps, ref._eps) < 1e-10

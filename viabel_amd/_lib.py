@@ -61,6 +61,10 @@ SIGNATURES = {
                                             _c_double_p, _c_double_p]),
     'vb_elbo_grad_mvt_chol': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                              _c_double_p, _c_double_p, _c_double_p]),
+    'vb_dis_step_mvt_packed': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p, ctypes.c_int64,
+                                              ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double, _c_double_p, _c_double_p,
+                                              _c_double_p, _c_double_p]),
+    'vb_dis_weights_get': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int]),
     'vb_noise_moments': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_elbo_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_double, _c_double_p,
@@ -551,6 +555,30 @@ class Engine:
             _dptr(prior_theta), float(eps_prev), float(ess_target), int(max_bisection_its), ctypes.byref(eps),
             ctypes.byref(ess), _dptr(w), None if lp is None else _dptr(lp), None if lq is None else _dptr(lq)))
         return eps.value, ess.value, w, lp, lq
+
+    def dis_refresh_mvt_deferred(self, slot, n, d, df, theta, prior_theta, eps_prev, ess_target, max_bisection_its=50):
+        """Throughput-mode refresh that only ENQUEUES (one rank): samples, log p / log q, tempering bisection and the
+        weights stay on the device; ``dis_step_mvt_packed`` reads them and synchronises once."""
+        theta, prior_theta = _f64(theta), _f64(prior_theta)
+        self._check(self._lib.vb_dis_refresh_mvt(
+            self._ctx, slot, n, d, n, float(df), _dptr(theta), None, None, None, _dptr(prior_theta), float(eps_prev),
+            float(ess_target), int(max_bisection_its), None, None, None, None, None))
+
+    def dis_step_mvt_packed(self, n, d, df, theta, scale, resample_m=0, seed=0, stream=0):
+        """``(value, grad, eps, ess)``: gradient of ``-scale sum w log q`` on the device-resident tempered weights, or
+        on ``resample_m`` multinomial draws from them (then ``scale`` multiplies ``sum w`` on the device)."""
+        theta = _f64(theta)
+        value, eps, ess = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        grad = np.empty(theta.size, dtype=np.float64)
+        self._check(self._lib.vb_dis_step_mvt_packed(
+            self._ctx, n, d, float(df), _dptr(theta), int(resample_m), int(seed), int(stream), float(scale),
+            ctypes.byref(eps), ctypes.byref(ess), ctypes.byref(value), _dptr(grad)))
+        return value.value, grad, eps.value, ess.value
+
+    def dis_weights_get(self, n_total, resampled=False):
+        w = np.empty(n_total, dtype=np.float64)
+        self._check(self._lib.vb_dis_weights_get(self._ctx, _dptr(w), n_total, 1 if resampled else 0))
+        return w
 
     def dis_grad_mvt_packed(self, n, d, df, theta, weights, scale):
         """``(value, grad)`` of ``-scale sum_n w_n log q(x_n; theta)`` with the factor algebra and the chain rule on

@@ -790,9 +790,13 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q) {
-  if (!ctx || !theta || !prior_theta || !eps || !ess || !w)
-    return fail(ctx, VB_ERR_INVALID, "NULL argument");      // chi may be NULL: device draws (vb_chisq_generate);
-                                                            // sqrt_sigma and l_inv both NULL: factors on the device
+  if (!ctx || !theta || !prior_theta) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  // chi may be NULL: device draws (vb_chisq_generate); sqrt_sigma and l_inv both NULL: factors on the device;
+  // w NULL (throughput mode, one rank): device-resident step -- nothing is copied back and nothing waited for here,
+  // vb_dis_step_mvt_packed returns eps / ess with the gradient
+  if (!w && (chi || sqrt_sigma || l_inv || ctx->n_ranks != 1))
+    return fail(ctx, VB_ERR_INVALID, "w == NULL needs the throughput mode (chi, sqrt_sigma, l_inv NULL) on one rank");
+  if (w && (!eps || !ess)) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_TRY(check_slot(ctx, slot));
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
   if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
@@ -818,6 +822,32 @@ int vb_dis_grad_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const d
   *value = out[0];
   memcpy(grad, out.data() + 1, p * sizeof(double));
   return VB_OK;
+}
+
+int vb_dis_step_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, int64_t resample_m,
+                           uint64_t seed, uint64_t stream, double scale, double* eps, double* ess, double* value,
+                           double* grad) {
+  if (!ctx || !theta || !eps || !ess || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (resample_m < 0) return fail(ctx, VB_ERR_INVALID, "resample_m must be >= 0");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t p = (size_t)(d + d * (d + 1) / 2);
+  std::vector<double> out(1 + p);
+  double res[3] = {0.0, 0.0, 0.0};
+  VB_TRY(mvt_dis_grad(ctx, n, d, df, theta, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scale, out.data(),
+                      resample_m, seed, stream, res));
+  *eps = res[0];
+  *ess = res[1];
+  if ((int)res[2] == 1)
+    return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
+  *value = out[0];
+  memcpy(grad, out.data() + 1, p * sizeof(double));
+  return VB_OK;
+}
+
+int vb_dis_weights_get(vb_ctx* ctx, double* w, int64_t n_total, int resampled) {
+  if (!ctx || !w) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return mvt_dis_weights_get(ctx, w, n_total, resampled);
 }
 
 int vb_dis_state_get(vb_ctx* ctx, int dense, double* log_p, double* log_q, int64_t n_total) {

@@ -15,6 +15,7 @@
 // log p and the tempering prior are evaluated on X by the row kernel of vb_rows.hip; the ESS bisection
 // is the kernel shared with the mean-field DIS path.
 #include "vb_gemm_f64.h"
+#include "vb_rng.h"
 
 #include <vector>
 
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(256) mvt_scalar_kernel(const double* __restric
 // ---- state layout ----------------------------------------------------------------------------------------
 struct MvtLayout {
   int64_t ld, nn;
-  int64_t o_x, o_e, o_u, o_ua, o_sl, o_root, o_wt, o_li, o_mu, o_c, o_invs, o_maha, o_lq, o_lp, o_lprior, o_w, o_lqcopy,
+  int64_t o_x, o_e, o_u, o_ua, o_sl, o_root, o_wt, o_li, o_mu, o_c, o_invs, o_maha, o_lq, o_lp, o_lprior, o_w, o_wres, o_cdf, o_cnt, o_lqcopy,
       o_prior, o_scal, o_cpart, o_col, o_part, o_sums, o_theta, o_lt, o_lfull, o_tscr, o_grad, total;
   int splits, n_rb;
   FrSums S;
@@ -176,6 +177,9 @@ static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t d) 
   L.o_lp = carve(L.nn);
   L.o_lprior = carve(L.nn);
   L.o_w = carve(L.nn);
+  L.o_wres = carve(L.nn);      // resampled weights (multinomial counts) of the device-resident step
+  L.o_cdf = carve(L.nn + 16);  // running sums of the weights | their total at [nn]
+  L.o_cnt = carve(L.nn / 2 + 16);   // int counts
   L.o_lqcopy = carve(L.nn);
   L.o_prior = carve(2 * L.ld);
   L.o_scal = carve(32);
@@ -246,8 +250,10 @@ __global__ void __launch_bounds__(256) mvt_symmetrize_kernel(const double* __res
 // - w_sum tril(L^-T) (only the diagonal 1 / L_ii of the upper-triangular L^-T survives), free diagonal x L_ii
 __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __restrict__ SL, const double* __restrict__ Lfull,
                                                             int64_t ld, int d, const double* __restrict__ sums,
-                                                            int64_t off_col, double scale, double* __restrict__ out) {
+                                                            int64_t off_col, double scale, double* __restrict__ out,
+                                                            const double* __restrict__ scale_dev) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (scale_dev) scale *= scale_dev[0];      // (device-resident resampling: scale = sum w / (N M), sum w on the device)
   const double w_sum = sums[1], w_logq = sums[2];
   if (idx == 0) out[0] = -scale * w_logq;
   if (idx < d) out[1 + idx] = -scale * sums[off_col + idx];
@@ -339,6 +345,62 @@ __global__ void __launch_bounds__(256) mvt_inv_scale_kernel(const double* __rest
                                                             double* __restrict__ inv_s) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) inv_s[i] = 1.0 / sqrt(chi[i] / df);                                      // approximations.py:345
+}
+
+// ---- multinomial resampling on the device (objectives.py:408: np.random.choice(N, M, p = w / sum w)) -------------------
+// rng = 'philox' reproduces no noise stream of the reference, so the draw does not have to be numpy's: M uniforms from
+// the family's Philox stream, inverted through the running sums of the weights (the same searchsorted(side = 'right')
+// the host path uses); the result is the vector of counts as doubles -- what the weighted-score kernels take.
+// One workgroup forms the running sums in a fixed order (chunk per thread, chunk totals scanned by one thread).
+__global__ void __launch_bounds__(1024) mvt_cdf_kernel(const double* __restrict__ w, int64_t n, double* __restrict__ cdf,
+                                                       double* __restrict__ total, int* __restrict__ counts) {
+  __shared__ double part[1024];
+  const int t = threadIdx.x;
+  const int64_t c = (n + 1023) / 1024, b = t * c, e = b + c < n ? b + c : n;
+  double s = 0.0;
+  for (int64_t i = b; i < e; ++i) s += w[i];
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    double run = 0.0;
+    for (int q = 0; q < 1024; ++q) {
+      const double v = part[q];
+      part[q] = run;
+      run += v;
+    }
+    total[0] = run;
+  }
+  __syncthreads();
+  s = part[t];
+  for (int64_t i = b; i < e; ++i) {
+    s += w[i];
+    cdf[i] = s;
+    counts[i] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) mvt_draw_kernel(const double* __restrict__ cdf, const double* __restrict__ total,
+                                                       int64_t n, int64_t m, uint64_t seed, uint64_t stream,
+                                                       int* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  Philox4 c;
+  c.x = (uint32_t)i, c.y = (uint32_t)(i >> 32), c.z = (uint32_t)stream, c.w = 0x52534d50u;      // 'RSMP': its own sub-stream
+  const Philox4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const double x = u01(r.x, r.y) * total[0];
+  int64_t lo = 0, hi = n;                  // first index with cdf > x (searchsorted side = 'right')
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (cdf[mid] > x) hi = mid;
+    else lo = mid + 1;
+  }
+  if (lo >= n) lo = n - 1;
+  atomicAdd(&counts[lo], 1);               // integer: the counts do not depend on the order of arrival
+}
+
+__global__ void __launch_bounds__(256) mvt_counts_kernel(const int* __restrict__ counts, int64_t n, double* __restrict__ w) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) w[i] = (double)counts[i];
 }
 
 int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df,
@@ -434,6 +496,16 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is
   VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_lq, base + L.o_lprior, base + L.o_scal, n_total, eps_prev,
                             ess_target, max_its, base + L.o_w, base + L.o_lqcopy, base + L.o_scal + 8));
+  if (!w_host) {
+    // device-resident step (vb_dis_step_mvt_packed): nothing comes back here -- eps, ess, the zero-weight status and the
+    // weights stay on the device, the step call that follows reads them and synchronises once
+    ctx->mvt_n = n;
+    ctx->mvt_d = d;
+    ctx->mvt_n_total = n_total;
+    ++ctx->dis_gen[1];
+    ctx->mvt_theta.assign(theta_host, theta_host + d + d * (d + 1) / 2);
+    return VB_OK;
+  }
   double res[3];
   VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_scal + 8, sizeof res, hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -451,6 +523,17 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   ctx->mvt_theta.assign(theta_host, theta_host + d + d * (d + 1) / 2);   // the residuals on the device belong to it
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
+  return VB_OK;
+}
+
+// tempered weights of the last refresh (before any resampling), for callers that left them on the device
+int mvt_dis_weights_get(vb_ctx* ctx, double* w_host, int64_t n_total, int resampled) {
+  if (!ctx->mvt_state.ptr || ctx->mvt_n_total != n_total || n_total <= 0)
+    return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state with %lld samples", (long long)n_total);
+  const MvtLayout L = mvt_layout(ctx, ctx->mvt_n, ctx->mvt_n_total, ctx->mvt_d);
+  VB_HIP(ctx, hipMemcpyAsync(w_host, (double*)ctx->mvt_state.ptr + (resampled ? L.o_wres : L.o_w), (size_t)n_total * sizeof(double),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VB_OK;
 }
 
@@ -472,17 +555,40 @@ int mvt_dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t
 // sum_n w_n [log q_n, d log q_n / d mu, u_n u_n' c_n] for the state samples at parameter theta_host
 // packed_out != nullptr (throughput mode): the chain rule to the flat parameter runs on the device too and
 // packed_out = [value | grad] of -scale sum_n w_n log q(x_n; theta) comes back instead of the raw sums
+// w_host == nullptr (packed_out only): the weights are on the device already -- the refresh's own (resample_m == 0) or
+// multinomial counts drawn from them here (resample_m > 0, scale then multiplies sum w on the device); res_out receives
+// [eps, ess, zero-weight status] of the last refresh in the same synchronisation
 int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
                  const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out,
-                 double scale, double* packed_out) {
+                 double scale, double* packed_out, int64_t resample_m, uint64_t seed, uint64_t stream, double* res_out) {
   if (ctx->mvt_n != n || ctx->mvt_d != d || !ctx->mvt_state.ptr)
     return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state of shape %lld x %lld", (long long)n, (long long)d);
   const MvtLayout L = mvt_layout(ctx, n, ctx->mvt_n_total, d);
   double* base = (double*)ctx->mvt_state.ptr;
   hipStream_t st = ctx->stream;
   const int n_cu = ctx->prop.multiProcessorCount;
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
+  const double* wdev = base + L.o_w;
+  const double* scale_dev = nullptr;
+  if (w_host) {
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    VB_HIP(ctx, hipStreamSynchronize(st));
+  } else {
+    if (!packed_out || ctx->n_ranks != 1)
+      return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident weights: packed gradient on one rank only");
+    if (resample_m > 0) {
+      int* counts = (int*)(base + L.o_cnt);
+      hipLaunchKernelGGL(mvt_cdf_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_w), n, base + L.o_cdf,
+                         base + L.o_cdf + L.nn, counts);
+      hipLaunchKernelGGL(mvt_draw_kernel, dim3((unsigned)((resample_m + 255) / 256)), dim3(256), 0, st,
+                         (const double*)(base + L.o_cdf), (const double*)(base + L.o_cdf + L.nn), n, resample_m, seed,
+                         stream, counts);
+      hipLaunchKernelGGL(mvt_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int*)counts, n,
+                         base + L.o_wres);
+      VB_HIP(ctx, hipGetLastError());
+      wdev = base + L.o_wres;
+      scale_dev = base + L.o_cdf + L.nn;
+    }
+  }
   {
     // the residuals E' = (X - mu) L^-T, the Mahalanobis distances and log q on the device belong to the parameter of
     // the last residual pass: a gradient at that same parameter (the call that follows a refresh when
@@ -513,7 +619,7 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   VB_HIP(ctx, hipGetLastError());
   const int64_t n_part = (n + 3) / 4;
   hipLaunchKernelGGL(mvt_scale_kernel, dim3((unsigned)n_part), dim3(256), 0, st, (const double*)(base + L.o_u),
-                     base + L.o_ua, L.ld, n, (int)d, df, (const double*)(base + L.o_w),
+                     base + L.o_ua, L.ld, n, (int)d, df, wdev,
                      (const double*)(base + L.o_maha), (const double*)(base + L.o_lq), base + L.o_part);
   VB_HIP(ctx, hipGetLastError());
   FrSums S = L.S;
@@ -548,10 +654,11 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     gemm_f64_launch<true>(st, gs, 1, n_cu, EpiStore{base + L.o_sl, L.ld});
     hipLaunchKernelGGL(mvt_pack_grad_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
                        (const double*)(base + L.o_sl), (const double*)(base + L.o_lfull), L.ld, D,
-                       (const double*)S.sums, S.off_col, scale, base + L.o_grad);
+                       (const double*)S.sums, S.off_col, scale, base + L.o_grad, scale_dev);
     VB_HIP(ctx, hipGetLastError());
     VB_HIP(ctx, hipMemcpyAsync(packed_out, base + L.o_grad, (size_t)(1 + d + d * (d + 1) / 2) * sizeof(double),
                                hipMemcpyDeviceToHost, st));
+    if (res_out) VB_HIP(ctx, hipMemcpyAsync(res_out, base + L.o_scal + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     VB_HIP(ctx, hipStreamSynchronize(st));
     return VB_OK;
   }

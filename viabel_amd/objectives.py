@@ -647,6 +647,41 @@ class DISInclusiveKL(StochasticVariationalObjective):
     def _state_log_q(self):
         return self._get_state_logs()[1]
 
+    # the tempered weights: plain arrays on the two-call paths, fetched on first access after a device-resident step
+    def _set_state_weights(self, w=None, fetch=None):
+        self._w_cache, self._w_fetch, self._w_sum_cache, self._w_norm_cache = w, fetch, None, None
+
+    @property
+    def _state_w_clipped(self):
+        if getattr(self, '_w_cache', None) is None and getattr(self, '_w_fetch', None) is not None:
+            self._w_cache = self._w_fetch()
+            self._w_fetch = None
+        return getattr(self, '_w_cache', None)
+
+    @_state_w_clipped.setter
+    def _state_w_clipped(self, w):
+        self._set_state_weights(w)
+
+    @property
+    def _state_w_sum(self):
+        if getattr(self, '_w_sum_cache', None) is None:
+            self._w_sum_cache = np.sum(self._state_w_clipped)
+        return self._w_sum_cache
+
+    @_state_w_sum.setter
+    def _state_w_sum(self, value):
+        self._w_sum_cache = value
+
+    @property
+    def _state_w_normalized(self):
+        if getattr(self, '_w_norm_cache', None) is None:
+            self._w_norm_cache = self._state_w_clipped / self._state_w_sum
+        return self._w_norm_cache
+
+    @_state_w_normalized.setter
+    def _state_w_normalized(self, value):
+        self._w_norm_cache = value
+
     def _own_state(self, eng, kind, refreshed):
         """The state samples live in the engine, one set per family kind: after a refresh remember its generation,
         before a gradient on kept weights make sure nobody else refreshed in between (two interleaved
@@ -839,6 +874,10 @@ class DISInclusiveKL(StochasticVariationalObjective):
             n_local = end - begin
             # throughput mode: mu, L, L^-1 and the chain rule of the gradient are formed on the device from var_param
             L, Linv = (None, None) if philox else factors(var_param)
+            # ... and on one rank, without PSIS smoothing and with a clipping threshold >= 1 (objectives.py:370-386 is
+            # the identity then; the default is 10) the weights never leave the device either
+            resident = (philox and not gaussian and eng.n_ranks == 1 and not self._psis_smooth
+                        and self._w_clip_threshold >= 1.0)
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
                 if gaussian:
                     chi = np.ones(N)
@@ -860,22 +899,42 @@ class DISInclusiveKL(StochasticVariationalObjective):
                     eng.noise_generate(slot, n_local, D, approx._seed, stream, row_offset=begin)
                     chi = None
                     root = None                                 # L' from var_param, on the device
+                    if resident:
+                        # device-resident step: the refresh only enqueues; weights, eps, ess stay on the device and
+                        # come back (eps, ess) with the gradient after one synchronisation
+                        eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._temper_prior_params, self._eps,
+                                                     self._ess_target, self._max_bisection_its)
+                        self._set_state_logs(None, None, lambda: eng.dis_state_get(True, N))
+                        self._set_state_weights(None, lambda: eng.dis_weights_get(N))
+                        self._own_state(eng, 1, True)
                 else:
                     chi, z = approx._base_noise(N)             # chi-square draws first (approximations.py:345-347)
                     eng.noise_set_host(slot, z[begin:end])
                     root, _ = _device_root(eng, L @ L.T)        # symmetric square root, :348
-                self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
-                    slot, n_local, D, df, var_param, None if chi is None else chi[begin:end], root, Linv,
-                    self._temper_prior_params, self._eps, self._ess_target, self._max_bisection_its, n_total=N,
-                    fetch_logs=not philox)
-                self._set_state_logs(log_p, log_q, (lambda: eng.dis_state_get(True, N)) if philox else None)
-                self._state_w_clipped = self._clip_weights(self._smooth_weights(eng, w))
-                self._state_w_sum = np.sum(self._state_w_clipped)
-                self._state_w_normalized = self._state_w_clipped / self._state_w_sum
-                self._own_state(eng, 1, True)
+                if not resident:
+                    self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
+                        slot, n_local, D, df, var_param, None if chi is None else chi[begin:end], root, Linv,
+                        self._temper_prior_params, self._eps, self._ess_target, self._max_bisection_its, n_total=N,
+                        fetch_logs=not philox)
+                    self._set_state_logs(log_p, log_q, (lambda: eng.dis_state_get(True, N)) if philox else None)
+                    self._state_w_clipped = self._clip_weights(self._smooth_weights(eng, w))
+                    self._state_w_sum = np.sum(self._state_w_clipped)
+                    self._state_w_normalized = self._state_w_clipped / self._state_w_sum
+                    self._own_state(eng, 1, True)
             else:
                 self._own_state(eng, 1, False)
             self._objective_step += 1
+            if resident:
+                if not self._use_resampling:
+                    value, grad, self._eps, self._ess = eng.dis_step_mvt_packed(n_local, D, df, var_param, 1.0 / N)
+                else:
+                    # multinomial draw on the device from the family's Philox stream (objectives.py:408 draws from the
+                    # global numpy RNG; this mode reproduces no reference stream)
+                    M = self._resampling_batch_size
+                    value, grad, self._eps, self._ess = eng.dis_step_mvt_packed(
+                        n_local, D, df, var_param, 1.0 / N / M, resample_m=M, seed=approx._seed,
+                        stream=approx._next_philox_stream())
+                return value, grad
             if not self._use_resampling:
                 weights, scale = self._state_w_clipped, 1.0 / N
             else:
