@@ -289,8 +289,19 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
 // E' = (X - mu) L^-T, maha, log q for the parameter `theta_host` with inverse factor `linv_host`
 // (linv_host == nullptr: the factors come from theta on the device, mvt_factors_device -- unless the caller has just
 // run it: factors_ready)
+// E[n][c] = Z[n][c] / s_n: the residuals (x_n - mu) L^-T of samples that were drawn as x = mu + (z L') / s at this very
+// parameter ARE the scaled noise -- no N x D x D product
+__global__ void __launch_bounds__(256) mvt_noise_resid_kernel(const double* __restrict__ Z, int64_t ldz,
+                                                              const double* __restrict__ inv_s, int64_t n, int d,
+                                                              double* __restrict__ E, int64_t lde) {
+  const int64_t row = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (row < n && c < lde) E[row * lde + c] = c < d ? Z[row * ldz + c] * inv_s[row] : 0.0;
+}
+
 static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t n, int64_t d, double df,
-                         const double* theta_host, const double* linv_host, int64_t lq_off, bool factors_ready = false) {
+                         const double* theta_host, const double* linv_host, int64_t lq_off, bool factors_ready = false,
+                         const NoiseSlot* drawn_here = nullptr) {
   const int n_cu = ctx->prop.multiProcessorCount;
   double logdet_half = 0.0;
   for (int64_t j = 0; j < d; ++j) logdet_half += theta_host[d + j * (j + 1) / 2 + j];
@@ -320,16 +331,22 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
   } else if (!factors_ready) {
     VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
   }
-  GemmArgs g;
-  g.A = base + L.o_x;
-  g.lda = L.ld;
-  g.B = base + L.o_wt;
-  g.ldb = L.ld;
-  g.M = (int)n;
-  g.N = (int)d;
-  g.K = (int)d;
-  g.tri_mode = 0;
-  gemm_f64_launch<true>(ctx->stream, g, 1, n_cu, EpiSubVec{base + L.o_e, L.ld, base + L.o_c});
+  if (drawn_here) {      // throughput-mode refresh: the state samples were just drawn through this parameter's factor
+    hipLaunchKernelGGL(mvt_noise_resid_kernel, dim3((unsigned)n, (unsigned)((L.ld + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double*)drawn_here->buf.ptr, drawn_here->ld, (const double*)(base + L.o_invs), n, (int)d,
+                       base + L.o_e, L.ld);
+  } else {
+    GemmArgs g;
+    g.A = base + L.o_x;
+    g.lda = L.ld;
+    g.B = base + L.o_wt;
+    g.ldb = L.ld;
+    g.M = (int)n;
+    g.N = (int)d;
+    g.K = (int)d;
+    g.tri_mode = 0;
+    gemm_f64_launch<true>(ctx->stream, g, 1, n_cu, EpiSubVec{base + L.o_e, L.ld, base + L.o_c});
+  }
   VB_HIP(ctx, hipGetLastError());
   const double lq_const = df > 0.0
                               ? lgamma(0.5 * (df + d)) - lgamma(0.5 * df) - 0.5 * d * log(M_PI * df) - logdet_half
@@ -469,11 +486,11 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   g.M = (int)n;
   g.N = (int)d;
   g.K = (int)d;
-  g.tri_mode = 0;
+  g.tri_mode = dev_factors ? 1 : 0;      // throughput mode: the root is L' (zero below the diagonal) -- half the product
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiSampleT{base + L.o_x, L.ld, base + L.o_mu, base + L.o_invs});
   VB_HIP(ctx, hipGetLastError());
 
-  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors));
+  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors, dev_factors ? &ns : nullptr));
   VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine));
   {   // tempering prior: a diagonal Gaussian evaluated by the same row kernel
     const ModelDev saved = ctx->model;
