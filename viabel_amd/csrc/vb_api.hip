@@ -229,6 +229,7 @@ int vb_destroy(vb_ctx* ctx) {
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->rows_work,
                           &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs})
     if (b->ptr) (void)hipFree(b->ptr);
+  if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& log : ctx->prof)
     for (auto& ev : log.events) {
@@ -1138,8 +1139,15 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
       VB_HIP(ctx, hipStreamWaitEvent(st, ctx->pipe.ev_fin[ctx->pipe.last_set], 0));
       ctx->pipe.post_pending = false;
     }
+    static const bool fuse_env = !(getenv("VB_FIT_STEP_UNPACK") && atoi(getenv("VB_FIT_STEP_UNPACK")) == 0);
+    if (fullrank && fuse_env && !ctx->comm) {
+      // dense family: the step writes mu and L' of the stepped parameter itself, the next evaluation skips its unpack
+      VB_TRY(fr_step_unpack_enqueue(ctx, step, d));
+      step_done = true;
+    }
     if (!step_done) VB_TRY(fit_step_enqueue(ctx, step));
   }
+  ctx->fr_lt_owner = nullptr;      // (fit_work may be reused by the next fit with other contents)
   VB_HIP(ctx, hipMemcpyAsync(theta, theta_dev, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpyAsync(values, base + o_val, (size_t)n_iters * sizeof(double), hipMemcpyDeviceToHost, st));
   if (state) {

@@ -167,6 +167,10 @@ struct vb_ctx {
   std::vector<double> mvt_theta;        // parameter the device-side residuals of the DIS state belong to
   bool mvt_dev_factors = false;         // ... and its factors (L, L', L^-1) were formed on the device
   std::vector<double> mvt_stage;        // host staging of the factor uploads (one synchronisation per pass)
+  double* mvt_pin = nullptr;            // pinned staging of the throughput mode's parameter upload (no synchronisation)
+  size_t mvt_pin_doubles = 0;
+  int mvt_pin_slot = 0;
+  std::vector<double> mvt_prior;        // tempering-prior parameter the device copy was made from
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
   int64_t dis_n_total = 0;              // whole-job sample count of the DIS state
@@ -192,6 +196,7 @@ struct vb_ctx {
   int tri_map_blocks = 0;
   vb::DeviceBuffer fr_lt;               // full-rank: unpacked parameter [mu (ldz) | L' (d x ldl)]
   int64_t fr_lt_d = 0;                  // dimension the unpacked copy of fr_theta was made for (0: stale)
+  const double* fr_lt_owner = nullptr;  // a parameter other than fr_theta whose unpacked copy fr_lt currently holds (vb_fit's)
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
@@ -344,6 +349,10 @@ struct FrSums {
   double* sums;
   int64_t off_col, off_c, len;
 };
+struct FitStep;
+// optimiser step of the dense family fused with the unpack of the stepped parameter (vb_fit): theta <- step(theta, grad)
+// and mu, L' of the NEW theta into fr_lt in one kernel; the next evaluation of `theta_dev` skips its unpack
+int fr_step_unpack_enqueue(vb_ctx* ctx, const FitStep& a, int64_t d);
 int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int D, int64_t ldl, double* Lt, double* mu);
 int fr_tri_inverse_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, const double* Lt, int D, int64_t ldl,
                            double* Xa, double* T);

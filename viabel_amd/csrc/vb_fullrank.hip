@@ -21,6 +21,7 @@
 //
 // Bound: fp64 MFMA (4 N D^2 flop dense convention vs N D 8 bytes: AI ~ D/2 flop/B >> ridge).
 #include "vb_gemm_f64.h"
+#include "vb_fit.h"
 
 namespace vb {
 
@@ -631,6 +632,62 @@ int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int 
   return VB_OK;
 }
 
+// ---- optimiser step + unpack in one kernel (vb_fit, dense family) --------------------------------------------------------
+// The loop used to run fit_step_kernel (5.9 us at D = 1024) and, at the top of the next evaluation, fr_unpack_kernel
+// (6.6 us) on the parameter it had just written.  Same tiling as the unpack: a 32 x 32 tile of the packed triangle is
+// read along its rows -- here together with the gradient entry and the optimiser state of each element -- stepped
+// (fit_step_apply: numpy's operation order, no contraction, so the trajectory stays the host loop's bit for bit),
+// written back, and transposed through LDS into L'.  Tiles below the diagonal of L' hold zeros from the first
+// evaluation's full unpack and are not touched again.
+__global__ void __launch_bounds__(256) fr_step_unpack_kernel(FitStep a, int d, int64_t ldl, double* __restrict__ Lt,
+                                                             double* __restrict__ mu) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  if (blockIdx.y == 0) {
+    const int i = k0 + (int)threadIdx.x;
+    if (threadIdx.x < 32 && i < d) {
+      double s1, s2, th;
+      fit_step_load(a, i, &s1, &s2, &th);
+      mu[i] = fit_step_apply_vals(a, i, a.out[1 + i], s1, s2, th);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 32) a.values[a.k] = a.out[0];
+  }
+  if (k0 > j0 + 31) return;            // below the diagonal of L' (k > j): no parameter lives here
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {       // L[j0 + r][k0 + tx]
+    const int j = j0 + r, k = k0 + tx;
+    double v = 0.0;
+    if (j < d && k <= j) {
+      const int64_t p = d + (int64_t)j * (j + 1) / 2 + k;
+      double s1, s2, th;
+      fit_step_load(a, p, &s1, &s2, &th);
+      v = fit_step_apply_vals(a, p, a.out[1 + p], s1, s2, th);
+      if (k == j) v = exp(v);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {       // L'[k0 + r][j0 + tx]
+    const int k = k0 + r, j = j0 + tx;
+    if (k < d && j < d && k <= j) Lt[(int64_t)k * ldl + j] = tile[tx][r];
+  }
+}
+
+int fr_step_unpack_enqueue(vb_ctx* ctx, const FitStep& a, int64_t d) {
+  const int64_t ldl = round_up(d, 16);
+  if (!ctx->fr_lt.ptr || ctx->fr_lt.bytes < (size_t)(ldl + d * ldl) * sizeof(double))
+    return fail(ctx, VB_ERR_STATE, "no unpacked parameter buffer (the first evaluation makes it)");
+  double* mu = (double*)ctx->fr_lt.ptr;
+  hipLaunchKernelGGL(fr_step_unpack_kernel, dim3((unsigned)((d + 31) / 32), (unsigned)((d + 31) / 32)), dim3(256), 0,
+                     ctx->stream, a, (int)d, ldl, mu + ldl, mu);
+  VB_HIP(ctx, hipGetLastError());
+  ctx->fr_lt_owner = a.theta;
+  ctx->fr_lt_d = d;
+  return VB_OK;
+}
+
 // Xa = (L')^-1 = U^-1 (upper triangular, row stride ldl) by recursive doubling: diagonal blocks of kTriLeaf rows are
 // inverted by back substitution (one wave per column), then [[A, B], [0, C]]^-1 = [[A^-1, -A^-1 B C^-1], [0, C^-1]]
 // level by level -- two batched GEMMs per level, D^3 / 3 flops in all instead of a triangular solve.  T: D x ldl scratch.
@@ -900,8 +957,11 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     Lt = mu + ldz;
     static const bool cache_env = !(getenv("VB_FR_UNPACK_CACHE") && atoi(getenv("VB_FR_UNPACK_CACHE")) == 0);
     const bool resident = theta_dev == (const double*)ctx->fr_theta.ptr;
-    lt_cached = cache_env && resident && ctx->fr_lt_d == d;
-    ctx->fr_lt_d = resident ? d : 0;     // (a foreign parameter leaves the copy stale for the resident one)
+    // ... or vb_fit's parameter, whose step kernel wrote mu and L' of the stepped value itself (fr_step_unpack_enqueue)
+    const bool stepped = ctx->fr_lt_owner != nullptr && ctx->fr_lt_owner == theta_dev;
+    lt_cached = cache_env && (resident || stepped) && ctx->fr_lt_d == d;
+    if (!stepped) ctx->fr_lt_owner = nullptr;
+    ctx->fr_lt_d = (resident || stepped) ? d : 0;     // (a foreign parameter leaves the copy stale for the resident one)
   }
   // stream plan (as mf_enqueue's `overlap`): everything up to the split reduction stays in order on the main
   // stream; the all-reduce and the epilogue go to `post` behind one event, into sum set `seq & 1`, and the main

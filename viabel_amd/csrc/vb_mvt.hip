@@ -270,14 +270,28 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   hipStream_t st = ctx->stream;
   const int D = (int)d;
   const size_t p = (size_t)(d + d * (d + 1) / 2);
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_theta, theta_host, p * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));       // the caller keeps ownership of theta_host
+  // the caller keeps ownership of theta_host: it goes through a pinned staging buffer of the context, so the copy is
+  // asynchronous and nothing here waits for the stream
+  if (ctx->mvt_pin_doubles < p) {
+    if (ctx->mvt_pin) {
+      VB_HIP(ctx, hipStreamSynchronize(st));
+      VB_HIP(ctx, hipHostFree(ctx->mvt_pin));
+      ctx->mvt_pin = nullptr;
+    }
+    VB_HIP(ctx, hipHostMalloc((void**)&ctx->mvt_pin, 2 * p * sizeof(double), hipHostMallocDefault));
+    ctx->mvt_pin_doubles = p;
+  }
+  // two staging slots taken in turn: a call forms the factors at most twice (refresh, gradient at another parameter)
+  // and every call synchronises before it returns, so a slot's previous copy has always completed
+  ctx->mvt_pin_slot ^= 1;
+  double* stage = ctx->mvt_pin + (size_t)ctx->mvt_pin_slot * ctx->mvt_pin_doubles;
+  memcpy(stage, theta_host, p * sizeof(double));
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_theta, stage, p * sizeof(double), hipMemcpyHostToDevice, st));
   VB_HIP(ctx, hipMemsetAsync(base + L.o_mu, 0, (size_t)(2 * L.ld) * sizeof(double), st));
   VB_TRY(fr_unpack_enqueue(ctx, st, base + L.o_theta, D, L.ld, base + L.o_lt, base + L.o_mu));
   VB_TRY(fr_tri_inverse_enqueue(ctx, st, base + L.o_theta, base + L.o_lt, D, L.ld, base + L.o_wt, base + L.o_tscr));
   const dim3 tg((unsigned)((D + 31) / 32), (unsigned)((D + 31) / 32));
-  VB_HIP(ctx, hipMemsetAsync(base + L.o_li, 0, (size_t)(d * L.ld) * sizeof(double), st));
-  VB_HIP(ctx, hipMemsetAsync(base + L.o_lfull, 0, (size_t)(d * L.ld) * sizeof(double), st));
+  // (the transposes write every entry of the d x d blocks; the pad columns hold the zeros of the allocation)
   hipLaunchKernelGGL(mvt_transpose_kernel, tg, dim3(256), 0, st, (const double*)(base + L.o_wt), base + L.o_li, D, L.ld);
   hipLaunchKernelGGL(mvt_transpose_kernel, tg, dim3(256), 0, st, (const double*)(base + L.o_lt), base + L.o_lfull, D, L.ld);
   hipLaunchKernelGGL(mvt_linv_mu_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, (const double*)(base + L.o_li),
@@ -371,29 +385,35 @@ __global__ void __launch_bounds__(256) mvt_inv_scale_kernel(const double* __rest
 // One workgroup forms the running sums in a fixed order (chunk per thread, chunk totals scanned by one thread).
 __global__ void __launch_bounds__(1024) mvt_cdf_kernel(const double* __restrict__ w, int64_t n, double* __restrict__ cdf,
                                                        double* __restrict__ total, int* __restrict__ counts) {
-  __shared__ double part[1024];
-  const int t = threadIdx.x;
-  const int64_t c = (n + 1023) / 1024, b = t * c, e = b + c < n ? b + c : n;
-  double s = 0.0;
-  for (int64_t i = b; i < e; ++i) s += w[i];
-  part[t] = s;
+  // blocks of 1024 consecutive weights (coalesced), scanned by wave shuffles + one LDS hop over the 16 wave totals;
+  // the running total is carried from block to block -- a fixed summation tree, the same sums on every run
+  __shared__ double wave_tot[16];
+  __shared__ double carry_sh;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) carry_sh = 0.0;
   __syncthreads();
-  if (t == 0) {
-    double run = 0.0;
-    for (int q = 0; q < 1024; ++q) {
-      const double v = part[q];
-      part[q] = run;
-      run += v;
+  for (int64_t b = 0; b < n; b += 1024) {
+    const int64_t i = b + t;
+    double v = i < n ? w[i] : 0.0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
     }
-    total[0] = run;
+    if (lane == 63) wave_tot[wv] = v;
+    __syncthreads();
+    double before = carry_sh;
+    for (int q = 0; q < wv; ++q) before += wave_tot[q];
+    v += before;
+    if (i < n) {
+      cdf[i] = v;
+      counts[i] = 0;
+    }
+    __syncthreads();
+    if (t == 1023) carry_sh = v;
+    __syncthreads();
   }
-  __syncthreads();
-  s = part[t];
-  for (int64_t i = b; i < e; ++i) {
-    s += w[i];
-    cdf[i] = s;
-    counts[i] = 0;
-  }
+  if (t == 0) total[0] = carry_sh;
 }
 
 __global__ void __launch_bounds__(256) mvt_draw_kernel(const double* __restrict__ cdf, const double* __restrict__ total,
@@ -444,8 +464,6 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     return fail(ctx, VB_ERR_INVALID, "sqrt_sigma and l_inv are given together or not at all");
   if (dev_factors) {      // throughput mode: mu, L', L^-1 from theta on the device; the samples go through L' (see header)
     VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
-    VB_HIP(ctx, hipMemcpyAsync(base + L.o_root, base + L.o_lt, (size_t)(d * L.ld) * sizeof(double),
-                               hipMemcpyDeviceToDevice, st));
   } else {
     VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
   }
@@ -471,17 +489,31 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     pr[L.ld + i] = exp(-2.0 * prior_host[d + i]);
     c0p -= prior_host[d + i];
   }
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  // the tempering prior rarely changes between refreshes: its device copy is kept (keyed on the parameter values and
+  // the state buffer), and in throughput mode mu is on the device already (the unpack) -- then nothing is uploaded
+  // here and the refresh does not wait for the stream at all
+  bool uploads = false;
+  const bool prior_cached = ctx->mvt_prior.size() == (size_t)(2 * d + 1) && ctx->mvt_prior[2 * d] == (double)(uintptr_t)base &&
+                            memcmp(ctx->mvt_prior.data(), prior_host, (size_t)(2 * d) * sizeof(double)) == 0;
+  if (!prior_cached) {
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    ctx->mvt_prior.assign(prior_host, prior_host + 2 * d);
+    ctx->mvt_prior.push_back((double)(uintptr_t)base);
+    uploads = true;
+  }
   std::vector<double> mu((size_t)L.ld, 0.0);
-  for (int64_t i = 0; i < d; ++i) mu[i] = theta_host[i];
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
+  if (!dev_factors) {
+    for (int64_t i = 0; i < d; ++i) mu[i] = theta_host[i];
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    uploads = true;
+  }
+  if (uploads || chi_host || df == 0.0) VB_HIP(ctx, hipStreamSynchronize(st));      // stack-scoped staging buffers
 
   // X = mu + (Z R) / s
   GemmArgs g;
   g.A = (const double*)ns.buf.ptr;
   g.lda = ns.ld;
-  g.B = base + L.o_root;
+  g.B = dev_factors ? base + L.o_lt : base + L.o_root;      // throughput mode: L' itself
   g.ldb = L.ld;
   g.M = (int)n;
   g.N = (int)d;
