@@ -49,7 +49,8 @@ struct GemmArgs {
   int M, N, K;
   int tiles_m, tiles_n;
   int tri_mode;     // 0: dense; 1: B[k][j] == 0 for k > j (k-range cut per column block);
-                    // 2: only output tiles with bm >= bn (lower triangle of a square C)
+                    // 2: only output tiles with bm >= bn (lower triangle of a square C);
+                    // 3: B[k][j] == 0 for k < j (the mirror image of 1; LDS-DMA kernel, otherwise computed densely)
   int k_split;      // K range per blockIdx.z (multiple of kGemmBK); splits = gridDim.z
   // batch mode (batch != 0): blockIdx.z selects one of gridDim.z independent products of the same shape -- operand
   // z starts batch_a / batch_b doubles after operand z - 1, every product runs over the whole K range and the
@@ -382,8 +383,9 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
   if (cfg == 0 && cfg_env >= 1 && cfg_env <= 6) cfg = cfg_env;
   // operands straight into LDS (vb_gemm_f64_dma.h) when every k range is a whole number of slabs
   const bool dma = gemm_uses_dma(g) && !(flags & 1);
+  if (g.tri_mode == 3 && (!dma || splits != 1 || g.batch)) g.tri_mode = 0;      // the zeros are multiplied instead of skipped
   if (cfg == 0) {
-    if (dma && g.tri_mode == 1 && splits == 1 && gemm_count_blocks(g, 128, 64) < 4L * n_cu) {
+    if (dma && (g.tri_mode == 1 || g.tri_mode == 3) && splits == 1 && gemm_count_blocks(g, 128, 64) < 4L * n_cu) {
       // k ranges grow with the column block: with only a couple of tiles per CU the long ones finish alone.  The
       // 64 x 64 tiles (three or four workgroups per CU, heaviest first) even that out: 89.9 -> 85.9 us at
       // 4096 x 1024 x 1024 (tools/gemm_bench.hip; pairing a long and a short block inside one workgroup measured

@@ -71,17 +71,22 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
       ++bm;
     }
     bn = idx;
-  } else if (g.tri_mode == 1) {
+  } else if (g.tri_mode == 1 || g.tri_mode == 3) {
     const int idx = blockIdx.x / g.tiles_m, half = (g.tiles_n + 1) / 2;
     bn = idx < half ? g.tiles_n - 1 - idx : idx - half;
+    if (g.tri_mode == 3) bn = g.tiles_n - 1 - bn;      // mirrored triangle: column block 0 has the longest k range
     bm = blockIdx.x % g.tiles_m;
   } else {
     bn = blockIdx.x / g.tiles_m;
     bm = blockIdx.x % g.tiles_m;
   }
   const int m0 = bm * BM, n0 = bn * BN;
-  const int k_begin = g.batch ? 0 : blockIdx.z * g.k_split;
+  int k_begin = g.batch ? 0 : blockIdx.z * g.k_split;
   int k_end = (g.batch || k_begin + g.k_split >= g.K) ? g.K : k_begin + g.k_split;
+  if (g.tri_mode == 3) {         // B[k][j] == 0 for k < j: the k range of column block bn starts at its first column
+    const int kmin = n0 / kGemmBK * kGemmBK;
+    if (k_begin < kmin) k_begin = kmin < k_end ? kmin : k_end;
+  }
   const double* __restrict__ gA = g.A + (g.batch ? (int64_t)blockIdx.z * g.batch_a : 0);
   const double* __restrict__ gB = g.B + (g.batch ? (int64_t)blockIdx.z * g.batch_b : 0);
   if (g.tri_mode == 1) {

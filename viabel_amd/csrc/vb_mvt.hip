@@ -663,7 +663,7 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   g.M = (int)n;
   g.N = (int)d;
   g.K = (int)d;
-  g.tri_mode = 0;
+  g.tri_mode = 3;          // L^-1 is lower triangular: B[k][j] == 0 for k < j -- half the product
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{base + L.o_u, L.ld});
   VB_HIP(ctx, hipGetLastError());
   const int64_t n_part = (n + 3) / 4;
