@@ -42,7 +42,8 @@ HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet fp64 matrix peak = 256 CUs x 4 SIMDs x 512 flop / 16 clk x 2.4 GHz;
 #                                                  tools/mfma_barrier_probe.hip measures 77.3 with constant operands
 # HBM-side bytes per launch of the headline's dense model GEMM at D=1024, N=4096 (see roofline.traffic_source)
-MODEL_GEMM_HBM_BYTES = int((2 * 49212.0 + 32886.2) * 1024)
+MODEL_GEMM_HBM_BYTES = int((2 * 64314.1 + 34646.2) * 1024)      # profiles/r03_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
+MF_ACCUM_HBM_BYTES = int((2 * 530477.5 + 8352.7) * 1024)           # profiles/r03_meanfield_c1_pmc_hbm.txt, per 32-evaluation launch
 MIN_TIMED_S = 0.05                               # the timed blocks are repeated until they cover at least this
 
 
@@ -221,9 +222,10 @@ def meanfield_leg(eng, vb, _lib, steps=2000, warmup=200, batch=32, ring_total=16
         'roofline': {'bound': 'hbm', 'kernel': 'mf_accum_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'avg_kernel_us': kernel_us,
                      'launches_timed': launches, 'algorithmic_bytes_per_launch': bytes_per_launch,
-                     'traffic': None,
-                     'traffic_reference': 'profiles/r01_meanfield_c1_pmc_hbm.txt: 1.02 x the algorithmic bytes '
-                                          '(PMC pass of round 1, not re-measured in this run)'},
+                     'traffic': MF_ACCUM_HBM_BYTES if batch == 32 else None,
+                     'traffic_source': 'profiles/r03_meanfield_c1_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
+                                       'passes of tools/mf_stream_bench.py, this launch shape, round-3 kernel): 1 086.4 MB fetched '
+                                       '+ 8.6 MB written per 32-evaluation launch = 1.019 x the algorithmic 1 074.8 MB'},
         'parity': {'rel_elbo_err': abs(dv - ov) / abs(ov),
                    'rel_grad_err': float(np.max(np.abs(dg - og)) / np.max(np.abs(og)))},
     }, theta
@@ -794,9 +796,11 @@ def main():
             # profiles/ (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
             if head['n_rows'] == N_MC and FR_D == 1024:
                 roof['traffic'] = MODEL_GEMM_HBM_BYTES
-                roof['traffic_source'] = ('profiles/r02_fullrank_gemm_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-                                          'separate passes): 100.8 MB fetched + 33.6 MB written per launch vs 75.5 MB '
-                                          'algorithmic (P is fetched once per XCD); 0.98 TB/s, an eighth of HBM peak')
+                roof['traffic_source'] = ('profiles/r03_fullrank_gemm_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                          'separate passes, FETCH_SIZE doubled per the gfx950 note): 131.7 MB fetched + '
+                                          '35.5 MB written per launch vs 75.5 MB of operands and result (Z 33.6 + P 8.4 '
+                                          'read, G 33.6 written) + 33.6 MB for the epilogue reading z - m back for sum f; '
+                                          'P is fetched once per XCD; 1.25 TB/s, a sixth of HBM peak: MFMA-bound')
             roof.update({'kernel': 'gemm_f64_dma_kernel<A[m][k], 128x64, EpiNegate>: G = -(Z - m) P, dense %d x %d x %d '
                                    '(the dominant kernel of the evaluation)' % (head['n_rows'], FR_D, FR_D),
                          'achieved': mg['achieved'], 'frac': mg['frac'], 'avg_kernel_us': mg['avg_kernel_us'],

@@ -79,9 +79,10 @@ template <class E>
 struct EpiReduces<E, std::void_t<decltype(std::declval<E>().part)>> : std::true_type {};
 
 // A functor that defines `double* colsum` and `int64_t colsum_ld` (LDS-DMA kernel, A given k-major) additionally gets
-// the column sums of A over the workgroup's k range, colsum[blockIdx.z * colsum_ld + m] = sum_k A[k][m], written by the
-// workgroups of column block 0 (one per row block and split): the operand tiles are in LDS anyway, so the sums cost
-// a few LDS reads per slab in the shadow of the MFMAs instead of another pass over A.
+// the column sums of A over the workgroup's k range, colsum[blockIdx.z * colsum_ld + m] = sum_k A[k][m], written once per
+// row block and split: the operand tiles are in LDS anyway, so the sums cost a few LDS reads per slab instead of another
+// pass over A.  tri_mode 2: by the waves of the row block's diagonal tile that lie above the diagonal and multiply
+// nothing; otherwise by the workgroups of column block 0.
 // EpiPairs: epilogues that can take two horizontally adjacent elements at once --
 //   d2v pair(int split, int row, int col, double acc0, double acc1) const   (col even, col + 1 < N)
 // stores (row, col) and (row, col + 1) as one 16-byte access and returns what operator() would have returned for each
