@@ -171,6 +171,7 @@ struct vb_ctx {
   size_t mvt_pin_doubles = 0;
   int mvt_pin_slot = 0;
   std::vector<double> mvt_prior;        // tempering-prior parameter the device copy was made from
+  int64_t mvt_inv_key[4] = {0, 0, 0, 0};   // (state buffer, n, n_total, d) for which the inverse's zero triangle is known clean
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
   int64_t dis_n = 0, dis_d = 0;         // shape of the DIS state (0: none)
   int64_t dis_n_total = 0;              // whole-job sample count of the DIS state
@@ -355,7 +356,7 @@ struct FitStep;
 int fr_step_unpack_enqueue(vb_ctx* ctx, const FitStep& a, int64_t d);
 int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int D, int64_t ldl, double* Lt, double* mu);
 int fr_tri_inverse_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, const double* Lt, int D, int64_t ldl,
-                           double* Xa, double* T);
+                           double* Xa, double* T, bool clean = false);
 int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,
                       const double* ivar, double* colpart, double* fpart, const double* roww = nullptr,
                       int square = 0);   // square: column sums of the squared entries

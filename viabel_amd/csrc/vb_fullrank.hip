@@ -691,12 +691,17 @@ int fr_step_unpack_enqueue(vb_ctx* ctx, const FitStep& a, int64_t d) {
 // Xa = (L')^-1 = U^-1 (upper triangular, row stride ldl) by recursive doubling: diagonal blocks of kTriLeaf rows are
 // inverted by back substitution (one wave per column), then [[A, B], [0, C]]^-1 = [[A^-1, -A^-1 B C^-1], [0, C^-1]]
 // level by level -- two batched GEMMs per level, D^3 / 3 flops in all instead of a triangular solve.  T: D x ldl scratch.
+// clean == true: the caller vouches that Xa's strictly lower triangle still holds the zeros of an earlier call on the same
+// buffer and layout (nothing here ever writes below the diagonal, and every block of T is written before it is read), so
+// the two D x ld memsets are skipped
 int fr_tri_inverse_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, const double* Lt, int D, int64_t ldl,
-                           double* Xa, double* T) {
+                           double* Xa, double* T, bool clean) {
   const int n_cu = ctx->prop.multiProcessorCount;
   const int64_t slab = (int64_t)D * ldl;
-  VB_HIP(ctx, hipMemsetAsync(Xa, 0, (size_t)slab * sizeof(double), st));
-  VB_HIP(ctx, hipMemsetAsync(T, 0, (size_t)slab * sizeof(double), st));
+  if (!clean) {
+    VB_HIP(ctx, hipMemsetAsync(Xa, 0, (size_t)slab * sizeof(double), st));
+    VB_HIP(ctx, hipMemsetAsync(T, 0, (size_t)slab * sizeof(double), st));
+  }
   static const hipError_t leaf_attr = hipFuncSetAttribute(
       reinterpret_cast<const void*>(fr_triinv_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
       kTriLeaf * kTriLeaf * (int)sizeof(double));         // 128 KB of LDS per workgroup

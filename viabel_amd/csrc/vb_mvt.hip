@@ -289,7 +289,12 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_theta, stage, p * sizeof(double), hipMemcpyHostToDevice, st));
   VB_HIP(ctx, hipMemsetAsync(base + L.o_mu, 0, (size_t)(2 * L.ld) * sizeof(double), st));
   VB_TRY(fr_unpack_enqueue(ctx, st, base + L.o_theta, D, L.ld, base + L.o_lt, base + L.o_mu));
-  VB_TRY(fr_tri_inverse_enqueue(ctx, st, base + L.o_theta, base + L.o_lt, D, L.ld, base + L.o_wt, base + L.o_tscr));
+  // the inverse's strictly lower triangle (and the scratch) need zeroing only when the buffer or its layout changed:
+  // nothing else writes o_wt in throughput mode
+  const int64_t key[4] = {(int64_t)(uintptr_t)base, L.o_wt, L.o_tscr, d};
+  const bool clean = memcmp(key, ctx->mvt_inv_key, sizeof key) == 0;
+  memcpy(ctx->mvt_inv_key, key, sizeof key);
+  VB_TRY(fr_tri_inverse_enqueue(ctx, st, base + L.o_theta, base + L.o_lt, D, L.ld, base + L.o_wt, base + L.o_tscr, clean));
   const dim3 tg((unsigned)((D + 31) / 32), (unsigned)((D + 31) / 32));
   // (the transposes write every entry of the d x d blocks; the pad columns hold the zeros of the allocation)
   hipLaunchKernelGGL(mvt_transpose_kernel, tg, dim3(256), 0, st, (const double*)(base + L.o_wt), base + L.o_li, D, L.ld);
@@ -337,6 +342,7 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
       vec[j] = theta_host[j];
       vec[L.ld + j] = c;
     }
+    ctx->mvt_inv_key[0] = 0;      // (the uploaded factor overwrites what the device inverse keeps clean)
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_wt, wt, (size_t)sq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_li, li, (size_t)sq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, vec, (size_t)(2 * L.ld) * sizeof(double), hipMemcpyHostToDevice,
