@@ -391,7 +391,9 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
       // 64 x 64 tiles (three or four workgroups per CU, heaviest first) even that out: 89.9 -> 85.9 us at
       // 4096 x 1024 x 1024 (tools/gemm_bench.hip; pairing a long and a short block inside one workgroup measured
       // the same 85.9 us, so the simpler launch order is kept)
-      cfg = 3;
+      // round 3: with the priority alternation off for these launches (below) the two-stage variant -- 32 KB, four
+      // workgroups per CU instead of three -- is the faster one: 82.4 -> 78.2 us in the headline pipeline
+      cfg = 4;
     } else if (dma && g.tri_mode == 0 && g.batch == 0 && gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) {
       // large dense products: 128 x 128 tiles with TWO LDS stages (64 KB: two workgroups per CU).  Per MFMA a third
       // fewer fragment reads and LDS-DMA pieces than 128 x 64: 69.3 - 70.2 against 66.0 - 67.5 TFLOP/s on
