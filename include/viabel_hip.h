@@ -339,7 +339,7 @@ int vb_sym_sqrt_inv(vb_ctx* ctx, const double* a, const double* e, int64_t d, do
  * z: n x k in slot_z), so its contribution to the entropy-form sums follows from second moments of the noise.
  * With sw = sigma * (B / sigma^2) (d x k, row-major, host) and u_n = sw' eps_n, T = [z | u] (n x 2k), `out` receives
  *   [ E'T (d x 2k, row-major) | T'T (2k x 2k) | sum_n eps_n (d) | sum_n eps_n^2 (d, per column) | sum_n T_n (2k) ]
- * (d 2k + 4 k^2 + 2 d + 2k doubles); the O(d k^2) Woodbury algebra stays with the caller.  1 <= k <= 16. */
+ * (d 2k + 4 k^2 + 2 d + 2k doubles); the O(d k^2) Woodbury algebra stays with the caller.  1 <= k <= 256. */
 int vb_lowrank_path_terms(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int64_t d, int64_t k, int64_t n_total,
                           const double* sw, double* out);
 
@@ -400,7 +400,8 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
 
 /* ---- LRGaussian (approximations.py:610-731) under DISInclusiveKL / AlphaDivergence (objectives.py:283-463) ----
  * theta = [mu (d) | log_sigma (d) | B (d x k, row-major)], x = mu + B z + sigma eps with the n x d block of the noise
- * in `slot_eps` and the n x k block in `slot_z` (1 <= k <= 16).  The caller passes the pieces of theta plus
+ * in `slot_eps` and the n x k block in `slot_z` (1 <= k <= 64; beyond 16 the per-sample k x k products run one wave
+ * per sample).  The caller passes the pieces of theta plus
  * m_inv = (I + B' diag(sigma^-2) B)^-1 (k x k) and log_q_const = -(d log 2 pi + log det Sigma) / 2 (the O(d k^2)
  * algebra through the capacitance matrix, approximations.py:559-607, stays on the host); per-sample work and every
  * contraction over the samples run on the device.  gauss_diag and funnel targets.

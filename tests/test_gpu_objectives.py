@@ -475,7 +475,8 @@ def test_dis_psis_smoothed_weights(vb, family):
     assert G.rel_err(grad, og) < 1e-8
 
 
-@pytest.mark.parametrize('D,k,N', [(64, 4, 1000), (1024, 8, 4096), (130, 16, 777)])
+@pytest.mark.parametrize('D,k,N', [(64, 4, 1000), (1024, 8, 4096), (130, 16, 777), (96, 17, 500), (256, 32, 2048),
+                                   (130, 64, 777)])
 @pytest.mark.parametrize('rng_kind', ['numpy', 'philox'])
 def test_lowrank_alpha_against_oracle(vb, D, k, N, rng_kind):
     """LRGaussian + AlphaDivergence (the reference's objective is family-generic, objectives.py:443-463 over
@@ -504,7 +505,8 @@ def test_lowrank_alpha_against_oracle(vb, D, k, N, rng_kind):
             assert G.rel_err(grad, og) < 1e-9, G.rel_err(grad, og)
 
 
-@pytest.mark.parametrize('D,k,N', [(64, 4, 1024), (256, 8, 4096), (130, 16, 800)])
+@pytest.mark.parametrize('D,k,N', [(64, 4, 1024), (256, 8, 4096), (130, 16, 800), (96, 17, 512), (256, 32, 2048),
+                                   (130, 64, 800)])
 @pytest.mark.parametrize('use_resampling', [True, False])
 def test_lowrank_dis_against_oracle_multi_step(vb, D, k, N, use_resampling):
     """LRGaussian + DISInclusiveKL: refresh on even steps, state samples reused with the NEW theta on odd steps."""

@@ -77,10 +77,6 @@ def test_device_exclusive_kl_matches_reference(path):
         np.testing.assert_allclose(grad, fx[tag + 'grad_fd'], rtol=0, atol=2e-7 * np.max(np.abs(ref_g)))
         # the reference closure with use_path_deriv=True (objectives.py:156-159)
         objective = vb.ExclusiveKL(vb.LRGaussian(D, seed=seed, k=k), model, N, use_path_deriv=True)
-        if k > 16:           # ranks beyond 16 take the GEMM-assembled sums: entropy form only
-            with pytest.raises(NotImplementedError):
-                objective(fx['theta0'])
-            continue
         value, grad = objective(fx['theta0'])
         ref_v, ref_g = float(fx[tag + 'pd_value']), fx[tag + 'pd_grad']
         assert abs(value - ref_v) <= 1e-11 * abs(ref_v), (value, ref_v)
@@ -133,6 +129,10 @@ def test_device_exclusive_kl_any_rank_matches_oracle(target, D, k, N):
     ov, og = oobj.exclusive_kl(ofam.LRGaussian(D, k), omodel, theta, noise)
     assert abs(value - ov) <= 1e-12 * abs(ov), (value, ov)
     np.testing.assert_allclose(grad, og, rtol=0, atol=1e-11 * np.max(np.abs(og)))
+    value, grad = vb.ExclusiveKL(vb.LRGaussian(D, seed=4, k=k), model, N, use_path_deriv=True)(theta)
+    ov, og = oobj.exclusive_kl(ofam.LRGaussian(D, k), omodel, theta, noise, True)
+    assert abs(value - ov) <= 1e-11 * abs(ov), (value, ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-10 * np.max(np.abs(og)))
 
 
 @pytest.mark.gpu
@@ -142,7 +142,8 @@ def test_lowrank_rejects_unsupported():
     with pytest.raises(NotImplementedError):
         vb.ExclusiveKL(vb.LRGaussian(4, k=2), model, 10, hessian_approx_method='full')
     with pytest.raises(NotImplementedError):
-        vb.ExclusiveKL(vb.LRGaussian(4, k=17), model, 10, use_path_deriv=True)(np.zeros(4 * 2 + 4 * 17))
+        vb.DISInclusiveKL(vb.LRGaussian(4, k=65), model, 10, ess_target=5, temper_prior=vb.MFGaussian(4),
+                          temper_prior_params=np.zeros(8))(np.zeros(4 * 2 + 4 * 65))
     with pytest.raises(ValueError):
         vb.ExclusiveKL(vb.LRGaussian(4, k=2), model, 10)(np.zeros(3))
 

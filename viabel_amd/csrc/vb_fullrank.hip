@@ -913,6 +913,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   // stopped it at 16 splits); D = 1024 takes 7 either way
   static const int split_rows = getenv("VB_FR_SPLIT_ROWS") ? atoi(getenv("VB_FR_SPLIT_ROWS")) : 192;
   const int max_splits = (int)(n / split_rows) > 0 ? (int)(n / split_rows) : 1;
+  static const int splits_env = getenv("VB_FR_SPLITS") ? atoi(getenv("VB_FR_SPLITS")) : 0;      // experiment
+  if (splits_env > 0) splits = splits_env;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const int n_rb = (int)((n + 127) / 128);

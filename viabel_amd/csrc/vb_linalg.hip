@@ -212,12 +212,12 @@ struct EpiSlab {            // slab_split = acc
 
 int lr_path_terms(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
                   const double* sw_host, double* out_host) {
-  if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d || k < 1 || k > 16)
-    return fail(ctx, VB_ERR_INVALID, "noise slots must hold n x d and n x k (k <= 16) matrices");
+  if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d || k < 1 || k > 256)
+    return fail(ctx, VB_ERR_INVALID, "noise slots must hold n x d and n x k (k <= 256) matrices");
   hipStream_t st = ctx->stream;
   const int n_cu = ctx->prop.multiProcessorCount;
   const int k2 = (int)(2 * k);
-  const int64_t ldk = 16, ldt = 32;                 // row strides of sw (d x k) and T (n x 2k)
+  const int64_t ldk = round_up(k, 16), ldt = round_up(2 * k, 16) < 32 ? 32 : round_up(2 * k, 16);   // row strides of sw (d x k), T (n x 2k)
   const int n_rb = (int)((n + 127) / 128);
   int splits = (int)(n / 256);
   if (splits > 32) splits = 32;

@@ -24,9 +24,10 @@
 namespace vb {
 namespace {
 
-constexpr int kLdk = 16;     // row stride of the D x k matrices and of the padded z block (k <= 16)
-constexpr int kLdt = 32;     // row stride of T = [tau or t (16) | 1 | log q | 0 ...]
-constexpr int kColOne = 16, kColLq = 17;
+// Row strides (doubles): ldk = round_up(k, 16) for the D x k matrices, the k x k inverse capacitance matrix and the n x k
+// block V; ldt = ldk + 16 for T = [tau or t (ldk) | 1 | log q | 0 ...] and the padded z block Zp: the "ones" column sits at
+// ldk, log q at ldk + 1.  k <= 16 gives the 16 / 32 / 16 / 17 of rounds 1-2; round 3 lifts the rank to 64.
+constexpr int kMaxRank = 64;
 
 __device__ __forceinline__ double lro_wave_sum(double x) {
 #pragma unroll
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(256) lro_sample_kernel(const double* __restric
                                                          int k, const double* __restrict__ mu,
                                                          const double* __restrict__ sigma,
                                                          const double* __restrict__ B, double* __restrict__ X,
-                                                         int64_t ldx, double* __restrict__ Zp) {
+                                                         int64_t ldx, double* __restrict__ Zp, int ldk, int ldt) {
   const int64_t row = blockIdx.x;            // rows on x: gridDim.y stops at 65 535
   const int c = blockIdx.y * 256 + threadIdx.x;
   const double* z = Z + row * ldz;
@@ -53,12 +54,12 @@ __global__ void __launch_bounds__(256) lro_sample_kernel(const double* __restric
     double x = 0.0;
     if (c < d) {
       x = fma(sigma[c], E[row * lde + c], mu[c]);
-      for (int j = 0; j < k; ++j) x = fma(B[(int64_t)c * kLdk + j], z[j], x);
+      for (int j = 0; j < k; ++j) x = fma(B[(int64_t)c * ldk + j], z[j], x);
     }
     X[row * ldx + c] = x;
   }
-  if (blockIdx.y == 0 && threadIdx.x < kLdt)
-    Zp[row * kLdt + threadIdx.x] = threadIdx.x < k ? z[threadIdx.x] : (threadIdx.x == kColOne ? 1.0 : 0.0);
+  if (blockIdx.y == 0 && (int)threadIdx.x < ldt)
+    Zp[row * ldt + threadIdx.x] = (int)threadIdx.x < k ? z[threadIdx.x] : ((int)threadIdx.x == ldk ? 1.0 : 0.0);
 }
 
 // R = (X - mu) / sigma, rr[n] = |rho_n|^2; one wave per row
@@ -85,6 +86,7 @@ __global__ void __launch_bounds__(256) lro_tau_kernel(const double* __restrict__
                                                       const double* __restrict__ Minv, int k, double cq, int64_t n,
                                                       const double* __restrict__ Zp, int t_mode,
                                                       double* __restrict__ T, double* __restrict__ logq) {
+  constexpr int kLdk = 16, kLdt = 32, kColOne = 16, kColLq = 17;      // (this kernel: k <= 16)
   __shared__ double mi[kLdk * kLdk];
   if (threadIdx.x < kLdk * kLdk) mi[threadIdx.x] = Minv[threadIdx.x];
   __syncthreads();
@@ -111,12 +113,43 @@ __global__ void __launch_bounds__(256) lro_tau_kernel(const double* __restrict__
   for (int j = kLdk; j < kLdt; ++j) t[j] = j == kColOne ? 1.0 : (j == kColLq ? lq : 0.0);
 }
 
+// the same for 16 < k <= 64: one WAVE per row, lane i holds v_i and forms tau_i = sum_j Minv[i][j] v_j with v_j broadcast
+// lane by lane (Minv in LDS, 32 KB at k = 64); the row of T is written by the lanes in two passes
+__global__ void __launch_bounds__(256) lro_tau_wave_kernel(const double* __restrict__ V, const double* __restrict__ rr,
+                                                           const double* __restrict__ Minv, int k, int ldk, int ldt,
+                                                           double cq, int64_t n, const double* __restrict__ Zp, int t_mode,
+                                                           double* __restrict__ T, double* __restrict__ logq) {
+  extern __shared__ double mi_dyn[];
+  for (int e = threadIdx.x; e < k * ldk; e += 256) mi_dyn[e] = Minv[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double v = lane < k ? V[row * ldk + lane] : 0.0;
+  double tau = 0.0;
+  for (int j = 0; j < k; ++j) {
+    const double vj = __shfl(v, j, 64);
+    if (lane < k) tau = fma(mi_dyn[lane * ldk + j], vj, tau);
+  }
+  const double vt = lro_wave_sum(v * tau);          // (lanes >= k contribute zero)
+  const double lq = cq - 0.5 * (rr[row] - __shfl(vt, 0, 64));
+  if (lane == 0) logq[row] = lq;
+  double* t = T + row * ldt;
+  for (int c = lane; c < ldt; c += 64) {      // column c < k <= 64 is written by the lane that holds tau_c
+    double val = 0.0;
+    if (c < k) val = t_mode ? Zp[row * ldt + c] - tau : tau;
+    else if (c == ldk) val = 1.0;
+    else if (c == ldk + 1) val = lq;
+    t[c] = val;
+  }
+}
+
 // Tw = w (.) T rows
 __global__ void __launch_bounds__(256) lro_scale_rows_kernel(const double* __restrict__ T, const double* __restrict__ w,
-                                                             int64_t n, double* __restrict__ Tw) {
+                                                             int64_t n, double* __restrict__ Tw, int ldt) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n * kLdt) return;
-  Tw[i] = T[i] * w[i / kLdt];
+  if (i >= n * ldt) return;
+  Tw[i] = T[i] * w[i / ldt];
 }
 
 // per 128-row block and column: sum_n w_n A_nc B_nc  -> part[rb][c]
@@ -221,13 +254,17 @@ struct EpiSlabW {            // slab_split = acc
 struct LroLayout {
   int64_t ld, nn;
   int splits, n_rb;
+  int ldk, ldt, col1;      // strides of the k-wide and T matrices, column of the ones (log q sits at col1 + 1)
   int64_t o_x, o_r, o_g, o_v, o_t, o_tw, o_zp, o_rr, o_f, o_lq, o_lpr, o_w, o_lqc, o_scal, o_mu, o_isig, o_bs, o_minv,
       o_sig, o_b, o_prior, o_w1, o_w2, o_et, o_et2, o_tt, o_col, o_cs1, o_cs2, o_pack, total;
 };
 
 // n: local rows, n_total: whole-job rows (gathered per-sample vectors)
-LroLayout lro_layout(int64_t n, int64_t n_total, int64_t d) {
+LroLayout lro_layout(int64_t n, int64_t n_total, int64_t d, int64_t k) {
   LroLayout L;
+  L.ldk = (int)round_up(k, 16);
+  L.ldt = L.ldk + 16;
+  L.col1 = L.ldk;
   L.ld = round_up(d, 16);
   L.nn = round_up(n_total, 16);
   L.n_rb = (int)((n + 127) / 128);
@@ -243,10 +280,10 @@ LroLayout lro_layout(int64_t n, int64_t n_total, int64_t d) {
   L.o_x = carve(mat);
   L.o_r = carve(mat);
   L.o_g = carve(mat);
-  L.o_v = carve(n * kLdk);
-  L.o_t = carve(n * kLdt);
-  L.o_tw = carve(n * kLdt);
-  L.o_zp = carve(n * kLdt);
+  L.o_v = carve(n * L.ldk);
+  L.o_t = carve(n * L.ldt);
+  L.o_tw = carve(n * L.ldt);
+  L.o_zp = carve(n * L.ldt);
   L.o_rr = carve(n);
   L.o_f = carve(L.nn);
   L.o_lq = carve(L.nn);
@@ -256,20 +293,20 @@ LroLayout lro_layout(int64_t n, int64_t n_total, int64_t d) {
   L.o_scal = carve(64);
   L.o_mu = carve(L.ld);
   L.o_isig = carve(L.ld);
-  L.o_bs = carve(d * kLdk);
-  L.o_minv = carve(kLdk * kLdk);
+  L.o_bs = carve(d * L.ldk);
+  L.o_minv = carve(L.ldk * L.ldk);
   L.o_sig = carve(L.ld);
-  L.o_b = carve(d * kLdk);
+  L.o_b = carve(d * L.ldk);
   L.o_prior = carve(2 * L.ld);
-  L.o_w1 = carve((int64_t)L.splits * d * kLdt);
-  L.o_w2 = carve((int64_t)L.splits * kLdt * kLdt);
-  L.o_et = carve(d * kLdt);
-  L.o_et2 = carve(d * kLdt);
-  L.o_tt = carve(kLdt * kLdt);
+  L.o_w1 = carve((int64_t)L.splits * d * L.ldt);
+  L.o_w2 = carve((int64_t)L.splits * L.ldt * L.ldt);
+  L.o_et = carve(d * L.ldt);
+  L.o_et2 = carve(d * L.ldt);
+  L.o_tt = carve(L.ldt * L.ldt);
   L.o_col = carve((int64_t)L.n_rb * L.ld);
   L.o_cs1 = carve(L.ld);
   L.o_cs2 = carve(L.ld);
-  L.o_pack = carve(2 * d * kLdk + kLdk * kLdk + 4 * d + 64);
+  L.o_pack = carve(2 * d * L.ldk + L.ldk * L.ldk + 4 * d + 64);
   L.total = off;
   return L;
 }
@@ -282,29 +319,29 @@ struct LroParam {
 
 int lro_upload_param(vb_ctx* ctx, const LroLayout& L, double* base, int64_t d, int64_t k, const LroParam& p,
                      bool sampling) {
-  std::vector<double> h((size_t)(3 * L.ld + 2 * d * kLdk + kLdk * kLdk), 0.0);
-  double *mu = h.data(), *isig = mu + L.ld, *sig = isig + L.ld, *bs = sig + L.ld, *b = bs + d * kLdk,
-         *mi = b + d * kLdk;
+  std::vector<double> h((size_t)(3 * L.ld + 2 * d * L.ldk + L.ldk * L.ldk), 0.0);
+  double *mu = h.data(), *isig = mu + L.ld, *sig = isig + L.ld, *bs = sig + L.ld, *b = bs + d * L.ldk,
+         *mi = b + d * L.ldk;
   for (int64_t i = 0; i < d; ++i) {
     const double s = exp(p.log_sigma[i]);
     mu[i] = p.mu[i];
     sig[i] = s;
     isig[i] = 1.0 / s;
     for (int64_t j = 0; j < k; ++j) {
-      b[i * kLdk + j] = p.B[i * k + j];
-      bs[i * kLdk + j] = p.B[i * k + j] / s;
+      b[i * L.ldk + j] = p.B[i * k + j];
+      bs[i * L.ldk + j] = p.B[i * k + j] / s;
     }
   }
   for (int64_t i = 0; i < k; ++i)
-    for (int64_t j = 0; j < k; ++j) mi[i * kLdk + j] = p.minv[i * k + j];
+    for (int64_t j = 0; j < k; ++j) mi[i * L.ldk + j] = p.minv[i * k + j];
   hipStream_t st = ctx->stream;
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, mu, (size_t)L.ld * sizeof(double), hipMemcpyHostToDevice, st));
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_isig, isig, (size_t)L.ld * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_bs, bs, (size_t)(d * kLdk) * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_minv, mi, (size_t)(kLdk * kLdk) * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_bs, bs, (size_t)(d * L.ldk) * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemcpyAsync(base + L.o_minv, mi, (size_t)(L.ldk * L.ldk) * sizeof(double), hipMemcpyHostToDevice, st));
   if (sampling) {
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_sig, sig, (size_t)L.ld * sizeof(double), hipMemcpyHostToDevice, st));
-    VB_HIP(ctx, hipMemcpyAsync(base + L.o_b, b, (size_t)(d * kLdk) * sizeof(double), hipMemcpyHostToDevice, st));
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_b, b, (size_t)(d * L.ldk) * sizeof(double), hipMemcpyHostToDevice, st));
   }
   VB_HIP(ctx, hipStreamSynchronize(st));      // `h` is a stack-scoped staging buffer
   return VB_OK;
@@ -319,26 +356,31 @@ int lro_rows(vb_ctx* ctx, const LroLayout& L, double* base, int64_t n, int64_t d
                      base + L.o_rr);
   VB_HIP(ctx, hipGetLastError());
   GemmArgs g;                                   // V = R Bs  (n x k)
-  g.A = base + L.o_r, g.lda = L.ld, g.B = base + L.o_bs, g.ldb = kLdk;
+  g.A = base + L.o_r, g.lda = L.ld, g.B = base + L.o_bs, g.ldb = L.ldk;
   g.M = (int)n, g.N = (int)k, g.K = (int)d, g.tri_mode = 0;
-  gemm_f64_launch<true>(st, g, 1, ctx->prop.multiProcessorCount, EpiStoreV{base + L.o_v, kLdk});
+  gemm_f64_launch<true>(st, g, 1, ctx->prop.multiProcessorCount, EpiStoreV{base + L.o_v, L.ldk});
   VB_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(lro_tau_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)(base + L.o_v),
-                     (const double*)(base + L.o_rr), (const double*)(base + L.o_minv), (int)k, cq, n,
-                     (const double*)(base + L.o_zp), t_mode, base + L.o_t, lq_out);
+  if (k <= 16)
+    hipLaunchKernelGGL(lro_tau_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)(base + L.o_v),
+                       (const double*)(base + L.o_rr), (const double*)(base + L.o_minv), (int)k, cq, n,
+                       (const double*)(base + L.o_zp), t_mode, base + L.o_t, lq_out);
+  else
+    hipLaunchKernelGGL(lro_tau_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)(k * L.ldk) * sizeof(double), st,
+                       (const double*)(base + L.o_v), (const double*)(base + L.o_rr), (const double*)(base + L.o_minv),
+                       (int)k, L.ldk, L.ldt, cq, n, (const double*)(base + L.o_zp), t_mode, base + L.o_t, lq_out);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
 
-// out (d x kLdt) = A' Tw, contraction over the n samples (A: n x ld, Tw: n x kLdt)
+// out (d x L.ldt) = A' Tw, contraction over the n samples (A: n x ld, Tw: n x L.ldt)
 int lro_atb(vb_ctx* ctx, const LroLayout& L, double* base, const double* A, int64_t lda, int m_rows, const double* Tw,
             int64_t n, double* W, double* out) {
   hipStream_t st = ctx->stream;
   GemmArgs g;
-  g.A = A, g.lda = lda, g.B = Tw, g.ldb = kLdt;
-  g.M = m_rows, g.N = kLdt, g.K = (int)n, g.tri_mode = 0;
-  const int64_t slab = (int64_t)m_rows * kLdt;
-  gemm_f64_launch<false>(st, g, L.splits, ctx->prop.multiProcessorCount, EpiSlabW{W, kLdt, slab});
+  g.A = A, g.lda = lda, g.B = Tw, g.ldb = L.ldt;
+  g.M = m_rows, g.N = L.ldt, g.K = (int)n, g.tri_mode = 0;
+  const int64_t slab = (int64_t)m_rows * L.ldt;
+  gemm_f64_launch<false>(st, g, L.splits, ctx->prop.multiProcessorCount, EpiSlabW{W, L.ldt, slab});
   VB_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(lro_slab_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, (const double*)W,
                      L.splits, slab, out, slab);
@@ -361,8 +403,8 @@ int lro_colsum_prod(vb_ctx* ctx, const LroLayout& L, double* base, const double*
 
 // (every caller takes a source model: DIS needs f of the samples only, the alpha sums load the user kernel's G)
 int lro_check(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k) {
-  if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d || k < 1 || k > kLdk)
-    return fail(ctx, VB_ERR_INVALID, "noise slots must hold n x d and n x k (1 <= k <= 16) matrices");
+  if (n <= 0 || n > ns.n || d != ns.d || n > nz.n || k != nz.d || k < 1 || k > kMaxRank)
+    return fail(ctx, VB_ERR_INVALID, "noise slots must hold n x d and n x k (1 <= k <= 64) matrices");
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL &&
       ctx->model.id != VB_MODEL_SOURCE)
     return fail(ctx, VB_ERR_UNSUPPORTED, "low-rank DIS / alpha objectives implement the gauss_diag, funnel and source "
@@ -381,7 +423,7 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
   VB_TRY(lro_check(ctx, ns, nz, n, d, k));
   int64_t mine = 0;   // this rank's block inside the gathered per-sample vectors (shard_rows)
   VB_TRY(comm_shard_begin(ctx, n, n_total, &mine));
-  const LroLayout L = lro_layout(n, n_total, d);
+  const LroLayout L = lro_layout(n, n_total, d, k);
   VB_TRY(ensure(ctx, ctx->lr_obj, (size_t)L.total * sizeof(double)));
   double* base = (double*)ctx->lr_obj.ptr;
   hipStream_t st = ctx->stream;
@@ -398,7 +440,7 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
   hipLaunchKernelGGL(lro_sample_kernel, dim3((unsigned)n, (unsigned)((L.ld + 255) / 256)), dim3(256), 0, st,
                      (const double*)ns.buf.ptr, ns.ld, (const double*)nz.buf.ptr, nz.ld, n, (int)d, (int)k,
                      (const double*)(base + L.o_mu), (const double*)(base + L.o_sig), (const double*)(base + L.o_b),
-                     base + L.o_x, L.ld, base + L.o_zp);
+                     base + L.o_x, L.ld, base + L.o_zp, L.ldk, L.ldt);
   VB_HIP(ctx, hipGetLastError());
   VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 0, base + L.o_lq + mine));
   VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_f + mine));
@@ -450,32 +492,32 @@ int lr_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, int64_t k, const double* mu, 
   if (ctx->lr_n != n || ctx->lr_d != d || ctx->lr_k != k || !ctx->lr_obj.ptr)
     return fail(ctx, VB_ERR_STATE, "no low-rank DIS state of shape %lld x %lld (k = %lld)", (long long)n, (long long)d,
                 (long long)k);
-  const LroLayout L = lro_layout(n, ctx->lr_n_total, d);
+  const LroLayout L = lro_layout(n, ctx->lr_n_total, d, k);
   double* base = (double*)ctx->lr_obj.ptr;
   hipStream_t st = ctx->stream;
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
   VB_TRY(lro_upload_param(ctx, L, base, d, k, LroParam{mu, log_sigma, B, minv, cq}, false));   // (syncs: w_host is free)
   VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 0, base + L.o_lq));
-  hipLaunchKernelGGL(lro_scale_rows_kernel, dim3((unsigned)((n * kLdt + 255) / 256)), dim3(256), 0, st,
-                     (const double*)(base + L.o_t), (const double*)(base + L.o_w), n, base + L.o_tw);
+  hipLaunchKernelGGL(lro_scale_rows_kernel, dim3((unsigned)((n * L.ldt + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + L.o_t), (const double*)(base + L.o_w), n, base + L.o_tw, L.ldt);
   VB_HIP(ctx, hipGetLastError());
   VB_TRY(lro_atb(ctx, L, base, base + L.o_r, L.ld, (int)d, base + L.o_tw, n, base + L.o_w1, base + L.o_et));
-  VB_TRY(lro_atb(ctx, L, base, base + L.o_t, kLdt, kLdt, base + L.o_tw, n, base + L.o_w2, base + L.o_tt));
+  VB_TRY(lro_atb(ctx, L, base, base + L.o_t, L.ldt, L.ldt, base + L.o_tw, n, base + L.o_w2, base + L.o_tt));
   VB_TRY(lro_colsum_prod(ctx, L, base, base + L.o_r, L.ld, base + L.o_r, L.ld, base + L.o_w, n, d, base + L.o_cs1));
   // pack
   const int64_t out_len = d * k + k * k + 2 * d + k + 2;
   double* pack = base + L.o_pack;
-  VB_HIP(ctx, hipMemcpy2DAsync(pack, (size_t)k * sizeof(double), base + L.o_et, (size_t)kLdt * sizeof(double),
+  VB_HIP(ctx, hipMemcpy2DAsync(pack, (size_t)k * sizeof(double), base + L.o_et, (size_t)L.ldt * sizeof(double),
                                (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
-  VB_HIP(ctx, hipMemcpy2DAsync(pack + d * k, (size_t)k * sizeof(double), base + L.o_tt, (size_t)kLdt * sizeof(double),
+  VB_HIP(ctx, hipMemcpy2DAsync(pack + d * k, (size_t)k * sizeof(double), base + L.o_tt, (size_t)L.ldt * sizeof(double),
                                (size_t)k * sizeof(double), (size_t)k, hipMemcpyDeviceToDevice, st));
   double* tail = pack + d * k + k * k;
-  VB_HIP(ctx, hipMemcpy2DAsync(tail, sizeof(double), base + L.o_et + kColOne, (size_t)kLdt * sizeof(double),
+  VB_HIP(ctx, hipMemcpy2DAsync(tail, sizeof(double), base + L.o_et + L.col1, (size_t)L.ldt * sizeof(double),
                                sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));          // sum w rho
   VB_HIP(ctx, hipMemcpyAsync(tail + d, base + L.o_cs1, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d, base + L.o_tt + (int64_t)kColOne * kLdt, (size_t)k * sizeof(double),
+  VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d, base + L.o_tt + (int64_t)L.col1 * L.ldt, (size_t)k * sizeof(double),
                              hipMemcpyDeviceToDevice, st));                                       // sum w tau
-  VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d + k, base + L.o_tt + (int64_t)kColOne * kLdt + kColOne, 2 * sizeof(double),
+  VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d + k, base + L.o_tt + (int64_t)L.col1 * L.ldt + L.col1, 2 * sizeof(double),
                              hipMemcpyDeviceToDevice, st));                                       // sum w, sum w log q
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));
   VB_HIP(ctx, hipMemcpyAsync(out_host, pack, (size_t)out_len * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -490,7 +532,7 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
                   const double* minv, double cq, double* value_out, double* wsum_out, double* out_host) {
   VB_TRY(lro_check(ctx, ns, nz, n, d, k));
   if (!(alpha != 0.0)) return fail(ctx, VB_ERR_INVALID, "alpha must be non-zero");
-  const LroLayout L = lro_layout(n, n_total, d);
+  const LroLayout L = lro_layout(n, n_total, d, k);
   VB_TRY(ensure(ctx, ctx->lr_obj, (size_t)L.total * sizeof(double)));
   ctx->lr_n = 0;                       // the buffer no longer holds a DIS state
   ++ctx->dis_gen[2];
@@ -500,7 +542,7 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
   VB_TRY(lro_upload_param(ctx, L, base, d, k, LroParam{mu, log_sigma, B, minv, cq}, true));
   hipLaunchKernelGGL(lro_sample_kernel, dim3((unsigned)n, (unsigned)((L.ld + 255) / 256)), dim3(256), 0, st, E, ns.ld,
                      (const double*)nz.buf.ptr, nz.ld, n, (int)d, (int)k, (const double*)(base + L.o_mu),
-                     (const double*)(base + L.o_sig), (const double*)(base + L.o_b), base + L.o_x, L.ld, base + L.o_zp);
+                     (const double*)(base + L.o_sig), (const double*)(base + L.o_b), base + L.o_x, L.ld, base + L.o_zp, L.ldk, L.ldt);
   VB_HIP(ctx, hipGetLastError());
   VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 1, base + L.o_lq));          // T = [t | 1 | log q], t = z - tau
   const bool source = ctx->model.id == VB_MODEL_SOURCE;
@@ -523,27 +565,27 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
     hipLaunchKernelGGL(lro_model_grad_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
                        (const double*)(base + L.o_x), L.ld, n, (int)d, ctx->model, base + L.o_g);
   VB_HIP(ctx, hipGetLastError());
-  const dim3 sgrid((unsigned)((n * kLdt + 255) / 256));
+  const dim3 sgrid((unsigned)((n * L.ldt + 255) / 256));
   // E' (s T): sum s eps t';  T' (s T): sum s t t'
   hipLaunchKernelGGL(lro_scale_rows_kernel, sgrid, dim3(256), 0, st, (const double*)(base + L.o_t),
-                     (const double*)(base + L.o_w), n, base + L.o_tw);
+                     (const double*)(base + L.o_w), n, base + L.o_tw, L.ldt);
   VB_TRY(lro_atb(ctx, L, base, E, ns.ld, (int)d, base + L.o_tw, n, base + L.o_w1, base + L.o_et));
-  VB_TRY(lro_atb(ctx, L, base, base + L.o_t, kLdt, kLdt, base + L.o_tw, n, base + L.o_w2, base + L.o_tt));
+  VB_TRY(lro_atb(ctx, L, base, base + L.o_t, L.ldt, L.ldt, base + L.o_tw, n, base + L.o_w2, base + L.o_tt));
   // G' (s [z | 1]): sum s g z', sum s g
   hipLaunchKernelGGL(lro_scale_rows_kernel, sgrid, dim3(256), 0, st, (const double*)(base + L.o_zp),
-                     (const double*)(base + L.o_w), n, base + L.o_tw);
+                     (const double*)(base + L.o_w), n, base + L.o_tw, L.ldt);
   VB_TRY(lro_atb(ctx, L, base, base + L.o_g, L.ld, (int)d, base + L.o_tw, n, base + L.o_w1, base + L.o_et2));
   VB_TRY(lro_colsum_prod(ctx, L, base, base + L.o_g, L.ld, E, ns.ld, base + L.o_w, n, d, base + L.o_cs1));
   const int64_t out_len = 2 * d * k + k * k + 2 * d;
   double* pack = base + L.o_pack;
-  VB_HIP(ctx, hipMemcpy2DAsync(pack, (size_t)k * sizeof(double), base + L.o_et2, (size_t)kLdt * sizeof(double),
+  VB_HIP(ctx, hipMemcpy2DAsync(pack, (size_t)k * sizeof(double), base + L.o_et2, (size_t)L.ldt * sizeof(double),
                                (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
-  VB_HIP(ctx, hipMemcpy2DAsync(pack + d * k, (size_t)k * sizeof(double), base + L.o_et, (size_t)kLdt * sizeof(double),
+  VB_HIP(ctx, hipMemcpy2DAsync(pack + d * k, (size_t)k * sizeof(double), base + L.o_et, (size_t)L.ldt * sizeof(double),
                                (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
-  VB_HIP(ctx, hipMemcpy2DAsync(pack + 2 * d * k, (size_t)k * sizeof(double), base + L.o_tt, (size_t)kLdt * sizeof(double),
+  VB_HIP(ctx, hipMemcpy2DAsync(pack + 2 * d * k, (size_t)k * sizeof(double), base + L.o_tt, (size_t)L.ldt * sizeof(double),
                                (size_t)k * sizeof(double), (size_t)k, hipMemcpyDeviceToDevice, st));
   double* tail = pack + 2 * d * k + k * k;
-  VB_HIP(ctx, hipMemcpy2DAsync(tail, sizeof(double), base + L.o_et2 + kColOne, (size_t)kLdt * sizeof(double),
+  VB_HIP(ctx, hipMemcpy2DAsync(tail, sizeof(double), base + L.o_et2 + L.col1, (size_t)L.ldt * sizeof(double),
                                sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));          // sum s g
   VB_HIP(ctx, hipMemcpyAsync(tail + d, base + L.o_cs1, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));

@@ -340,9 +340,10 @@ class ExclusiveKL(StochasticVariationalObjective):
                 if approx.k > 16:
                     # beyond the streaming kernel's register budget: the sums from GEMMs (vb_elbo_sums_lowrank), the
                     # entropy and its gradient through the k x k capacitance matrix on the host (approximations.py:559-573)
+                    value, grad = _lowrank_any_rank(eng, approx, var_param, end - begin, N)
                     if path_deriv:
-                        raise NotImplementedError('LRGaussian with k > 16: entropy-form estimator only')
-                    return _lowrank_any_rank(eng, approx, var_param, end - begin, N)
+                        value, grad = _lowrank_path_correction(eng, approx, var_param, value, grad, end - begin, N)
+                    return value, grad
                 value, grad = eng.elbo_grad_lowrank(_NOISE_SLOT, _LR_SLOT, end - begin, approx.dim, approx.k, var_param,
                                                     n_total=N)
                 if path_deriv:
@@ -729,8 +730,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
         if not isinstance(approx, (MFGaussian, MFStudentT, MultivariateT, FullRankGaussian, LRGaussian)):
             raise NotImplementedError('DISInclusiveKL on the HIP engine supports MFGaussian, MFStudentT, MultivariateT, '
                                       'FullRankGaussian and LRGaussian; got {}'.format(type(approx).__name__))
-        if isinstance(approx, LRGaussian) and not 1 <= approx.k <= 16:
-            raise NotImplementedError('LRGaussian on the HIP engine: 1 <= k <= 16')
+        if isinstance(approx, LRGaussian) and not 1 <= approx.k <= 64:
+            raise NotImplementedError('LRGaussian under DISInclusiveKL on the HIP engine: 1 <= k <= 64')
         if not isinstance(self._temper_prior, MFGaussian) or self._temper_prior.dim != approx.dim:
             raise NotImplementedError('temper_prior must be an MFGaussian of the same dimension '
                                       '(tests/test_objectives.py:82-87)')
@@ -979,8 +980,8 @@ class AlphaDivergence(StochasticVariationalObjective):
             self._objective_and_grad = self._mvt_alpha(approx, alpha)
             return
         if isinstance(approx, LRGaussian):
-            if not 1 <= approx.k <= 16:
-                raise NotImplementedError('LRGaussian on the HIP engine: 1 <= k <= 16')
+            if not 1 <= approx.k <= 64:
+                raise NotImplementedError('LRGaussian under AlphaDivergence on the HIP engine: 1 <= k <= 64')
             self._objective_and_grad = self._lowrank_alpha(approx, alpha)
             return
 
