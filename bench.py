@@ -767,9 +767,15 @@ def main():
     # VB_BENCH_NO_RCCL=1: control-flow dry run of the N > 1 branches on a box with fewer GPUs than ranks (the ranks
     # share device 0, RCCL refuses that, so no communicator is attached: the numbers mean nothing)
     no_rccl = world > 1 and os.environ.get('VB_BENCH_NO_RCCL') == '1'
-    eng = _lib.Engine(0) if no_rccl else _lib.default_engine()
+    # VB_BENCH_TRANSPORT=host: the same N ranks with the host-staged transport (vb_comm_init_host) on device 0 -- every
+    # sharded code path and every collective runs, through pinned host memory and the control sockets instead of
+    # RCCL / xGMI (functional check of the N > 1 path on a one-GPU box; the numbers are not a scaling measurement)
+    host_transport = world > 1 and os.environ.get('VB_BENCH_TRANSPORT') == 'host'
+    eng = _lib.Engine(0) if (no_rccl or host_transport) else _lib.default_engine()
     _lib.set_default_engine(eng)
-    if world > 1 and not no_rccl:
+    if host_transport:
+        distributed.attach(eng, group, transport='host')
+    elif world > 1 and not no_rccl:
         distributed.attach(eng, group)
     elif args.force_comm and world == 1:
         eng.comm_init(_lib.Engine.comm_unique_id(), 1, 0)
@@ -830,6 +836,9 @@ def main():
                 'pipelining': 'none: one evaluation per call, all calls on one HIP stream, each behind the previous one',
             },
             'rccl_ranks': rccl_ranks,
+            'transport': ('host-staged (VB_BENCH_TRANSPORT=host): all ranks on device 0, collectives through pinned host '
+                          'memory and the control sockets -- a functional run of the N > 1 path, not a scaling figure')
+                         if host_transport else ('rccl' if rccl_ranks > 1 or args.force_comm else 'none'),
             'timing': {'timed_blocks': len(head['block_seconds']), 'steps_per_block': args.steps,
                        'ms_per_step_of': 'median block', 'block_ms': [1e3 * t for t in head['block_seconds']],
                        'timed_total_s': float(sum(head['block_seconds']))},

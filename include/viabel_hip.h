@@ -427,8 +427,19 @@ int vb_alpha_sums_lowrank(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int6
 int vb_comm_unique_id(char id[VB_COMM_ID_BYTES]);
 int vb_comm_init(vb_ctx* ctx, const char id[VB_COMM_ID_BYTES], int n_ranks, int rank);
 int vb_comm_destroy(vb_ctx* ctx);
-/* what the attached RCCL communicator itself reports (ncclCommCount / ncclCommUserRank); 1 / 0 without one */
+/* what the attached communicator itself reports (RCCL: ncclCommCount / ncclCommUserRank); 1 / 0 without one */
 int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank);
+/* Host-staged transport: the same sharded job with the caller's own collective in place of RCCL.  Every device
+ * collective becomes: copy the vector to pinned host memory, wait for the stream, call `fn`, copy the result back.
+ * `fn(user, buf, count, op)` must leave in `buf[0 .. count)` on every rank the elementwise sum (op VB_HOST_SUM) or
+ * maximum (VB_HOST_MAX) of the ranks' vectors, combined in rank order, and return 0; it is called on the thread
+ * that makes the vb_* call.  For ranks that RCCL cannot join -- two ranks on one GPU (RCCL refuses a duplicate
+ * device: that is how the two-rank tests run on a one-GPU box), or a node without xGMI / RCCL -- at the price of a
+ * stream synchronisation per collective; the arithmetic on the device is the sharded path's own.  */
+#define VB_HOST_SUM 0
+#define VB_HOST_MAX 1
+typedef int (*vb_host_collective_fn)(void* user, double* buf, size_t count, int op);
+int vb_comm_init_host(vb_ctx* ctx, vb_host_collective_fn fn, void* user, int n_ranks, int rank);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels ---------
  * When enabled, every launch of a profiled kernel carries a start/stop event pair

@@ -1,0 +1,74 @@
+"""A real two-rank job on ONE GPU: both ranks open device 0, the Monte-Carlo axis is sharded (ragged: odd sample
+counts), and every device collective of the sharded path runs -- through the host-staged transport
+(`vb_comm_init_host`, `distributed.attach(..., transport='host')`), because RCCL refuses two ranks on one device.
+What this covers that the one-rank communicator tests (test_gpu_comm.py) cannot: shard offsets of the second rank,
+ragged gathers of per-sample vectors, rank 0's host random draws reaching rank 1, the collective sequence of every
+objective staying paired across ranks (a mismatch deadlocks or trips the size check), the device fit loop with one
+all-reduce per iteration.  Results are compared with the same evaluations in a single process: the noise is indexed by
+global sample row, so only the order of the partial sums differs.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TESTS = os.path.join(ROOT, 'tests')
+
+WORKER = '''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np
+from viabel_amd import _lib, distributed
+import viabel_amd as vb
+eng = _lib.Engine(0)                                  # both ranks on the one GPU of the box
+_lib.set_default_engine(eng)
+group = distributed.SocketGroup.from_env(timeout=120.0)
+distributed.attach(eng, group, transport='host')
+assert eng.comm_info() == (2, group.rank)
+import _two_rank_scenarios as S
+res = S.run_all(vb)
+np.savez(os.path.join(%(out)r, 'rank%%d.npz' %% group.rank),
+         **{k + '__v': v[0] for k, v in res.items()}, **{k + '__g': v[1] for k, v in res.items()})
+group.barrier()
+group.close()
+print('{"rank": %%d, "done": true}' %% group.rank)
+'''
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def test_two_ranks_on_one_gpu_match_one_rank(tmp_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    import bench
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    import _two_rank_scenarios as S
+
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % {'root': ROOT, 'tests': TESTS, 'out': str(tmp_path)})
+    rc, lines = bench.spawn_ranks(2, [sys.executable, str(script)], timeout_s=900)
+    assert rc == 0, lines[-5:]
+
+    eng = _lib.default_engine()
+    assert eng.comm_info() == (1, 0)
+    single = S.run_all(vb)
+    ranks = [np.load(tmp_path / ('rank%d.npz' % r)) for r in (0, 1)]
+    worst = {}
+    for name, (v, g) in single.items():
+        for r in (0, 1):
+            rv, rg = ranks[r][name + '__v'], ranks[r][name + '__g']
+            assert rv.shape == v.shape and rg.shape == g.shape, name
+            worst[name] = max(worst.get(name, 0.0), _rel(rv, v), _rel(rg, g))
+        # the two ranks hold the same replicated result, bit for bit (they ran the same epilogue on the same sums)
+        assert np.array_equal(ranks[0][name + '__v'], ranks[1][name + '__v']), name
+        assert np.array_equal(ranks[0][name + '__g'], ranks[1][name + '__g']), name
+    bad = {k: e for k, e in worst.items() if not e < (1e-9 if k.startswith('fit_') else 1e-11)}
+    assert not bad, (bad, worst)

@@ -140,3 +140,38 @@ def test_rendezvous_timeout_names_the_missing_ranks_and_ignores_silent_clients()
     t.join()
     for s in stray:
         s.close()
+
+
+def _array_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    try:
+        import numpy as np
+        from viabel_amd import distributed
+        g = distributed.SocketGroup(rank, world, '127.0.0.1', port, timeout=60.0)
+        a = np.arange(1000, dtype=np.float64) * (rank + 1)
+        g.allreduce_array(a)
+        m = np.full((4, 5), float(rank))
+        g.allreduce_array(m, op=1)
+        big = np.full(600_000, 0.5 + rank)           # larger than one TCP segment / socket buffer
+        g.allreduce_array(big)
+        ok = (np.array_equal(a, np.arange(1000.0) * (world * (world + 1) / 2)) and np.all(m == world - 1)
+              and np.all(big == sum(0.5 + r for r in range(world))))
+        g.barrier()
+        g.close()
+        q.put((rank, 'ok' if ok else 'wrong result'))
+    except Exception as exc:                 # pragma: no cover
+        q.put((rank, repr(exc)))
+
+
+def test_allreduce_array_sum_and_max():
+    """The vector collective of the host-staged transport (`attach(..., transport='host')`)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_array_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(30)
+    assert results == {0: 'ok', 1: 'ok', 2: 'ok'}, results

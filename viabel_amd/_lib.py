@@ -154,6 +154,7 @@ SIGNATURES = {
     'vb_result_get': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64]),
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    'vb_comm_init_host': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_destroy': (ctypes.c_int, [_ctx_p]),
     'vb_comm_info': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     'vb_profile_enable': (ctypes.c_int, [_ctx_p, ctypes.c_int]),
@@ -166,6 +167,10 @@ SIGNATURES = {
 
 _lib = None
 _lib_lock = threading.Lock()
+
+
+HOST_COLLECTIVE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t,
+                                      ctypes.c_int)
 
 
 class EngineError(RuntimeError):
@@ -734,8 +739,25 @@ class Engine:
         self._check(self._lib.vb_comm_init(self._ctx, unique_id, n_ranks, rank))
         self.n_ranks, self.rank = n_ranks, rank
 
+    def comm_init_host(self, collective, n_ranks, rank):
+        """Host-staged transport (``vb_comm_init_host``): ``collective(array, op)`` must overwrite the float64
+        ``array`` in place with the ranks' elementwise sum (``op == 0``) or maximum (``op == 1``)."""
+        def trampoline(_user, buf, count, op):
+            try:
+                collective(np.ctypeslib.as_array(buf, shape=(count,)), op)
+                return 0
+            except Exception:                # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = HOST_COLLECTIVE_FN(trampoline)
+        self._check(self._lib.vb_comm_init_host(self._ctx, ctypes.cast(cb, ctypes.c_void_p), None, n_ranks, rank))
+        self._host_collective = cb           # the library keeps the pointer: keep the thunk alive with the engine
+        self.n_ranks, self.rank = n_ranks, rank
+
     def comm_destroy(self):
         self._check(self._lib.vb_comm_destroy(self._ctx))
+        self._host_collective = None
         self.n_ranks, self.rank = 1, 0
 
     def comm_info(self):

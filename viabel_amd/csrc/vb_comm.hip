@@ -8,8 +8,31 @@
 
 namespace vb {
 
+// host-staged transport (vb_comm_init_host): device -> pinned host, the caller's collective, host -> device; the
+// stream is drained on both sides, so the call is ordered like the RCCL kernel it stands in for
+static int host_collective(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count, int op) {
+  if (count == 0) return VB_OK;
+  if (ctx->host_stage_cap < count) {
+    if (ctx->host_stage) VB_HIP(ctx, hipHostFree(ctx->host_stage));
+    ctx->host_stage = nullptr;
+    ctx->host_stage_cap = 0;
+    const size_t cap = count + count / 4 + 1024;
+    VB_HIP(ctx, hipHostMalloc((void**)&ctx->host_stage, cap * sizeof(double), hipHostMallocDefault));
+    ctx->host_stage_cap = cap;
+  }
+  VB_HIP(ctx, hipMemcpyAsync(ctx->host_stage, buf, count * sizeof(double), hipMemcpyDeviceToHost, stream));
+  VB_HIP(ctx, hipStreamSynchronize(stream));
+  const int rc = ctx->host_fn(ctx->host_user, ctx->host_stage, count, op);
+  if (rc != 0) return fail(ctx, VB_ERR_COMM, "host collective (%s of %zu doubles) failed with code %d",
+                           op == VB_HOST_MAX ? "max" : "sum", count, rc);
+  VB_HIP(ctx, hipMemcpyAsync(buf, ctx->host_stage, count * sizeof(double), hipMemcpyHostToDevice, stream));
+  VB_HIP(ctx, hipStreamSynchronize(stream));     // the staging buffer is free again when this returns
+  return VB_OK;
+}
+
 int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count) {
   if (!ctx->comm) return VB_OK;
+  if (ctx->host_fn) return host_collective(ctx, stream, buf, count, VB_HOST_SUM);
   ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm,
                                  stream);
   if (r != ncclSuccess)
@@ -19,6 +42,7 @@ int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t coun
 
 int comm_allreduce_max(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count) {
   if (!ctx->comm) return VB_OK;
+  if (ctx->host_fn) return host_collective(ctx, stream, buf, count, VB_HOST_MAX);
   ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclMax, (ncclComm_t)ctx->comm, stream);
   if (r != ncclSuccess)
     return fail(ctx, VB_ERR_COMM, "ncclAllReduce(max) failed: %s", ncclGetErrorString(r));
@@ -31,6 +55,14 @@ int comm_allgather(vb_ctx* ctx, hipStream_t stream, const double* send, double* 
     if (send != recv)
       VB_HIP(ctx, hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
     return VB_OK;
+  }
+  if (ctx->host_fn) {    // zero everybody else's chunk, then a sum (x + 0 + ... + 0 is exact)
+    const size_t r = (size_t)ctx->rank, g = (size_t)ctx->n_ranks;
+    if (send != recv + r * count)
+      VB_HIP(ctx, hipMemcpyAsync(recv + r * count, send, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    if (r > 0) VB_HIP(ctx, hipMemsetAsync(recv, 0, r * count * sizeof(double), stream));
+    if (r + 1 < g) VB_HIP(ctx, hipMemsetAsync(recv + (r + 1) * count, 0, (g - r - 1) * count * sizeof(double), stream));
+    return host_collective(ctx, stream, recv, g * count, VB_HOST_SUM);
   }
   ncclResult_t r = ncclAllGather(send, recv, count, ncclDouble, (ncclComm_t)ctx->comm, stream);
   if (r != ncclSuccess)
@@ -94,11 +126,29 @@ int vb_comm_init(vb_ctx* ctx, const char id[VB_COMM_ID_BYTES], int n_ranks, int 
   return VB_OK;
 }
 
+int vb_comm_init_host(vb_ctx* ctx, vb_host_collective_fn fn, void* user, int n_ranks, int rank) {
+  if (!ctx || !fn) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+    return fail(ctx, VB_ERR_INVALID, "rank %d / n_ranks %d invalid", rank, n_ranks);
+  if (ctx->comm) return fail(ctx, VB_ERR_STATE, "communicator already attached");
+  ctx->host_fn = fn;
+  ctx->host_user = user;
+  ctx->comm = ctx;
+  ctx->n_ranks = n_ranks;
+  ctx->rank = rank;
+  return VB_OK;
+}
+
 int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank) {
   if (!ctx || !n_ranks || !rank) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   *n_ranks = 1;
   *rank = 0;
   if (!ctx->comm) return VB_OK;      // no communicator: a one-rank job
+  if (ctx->host_fn) {
+    *n_ranks = ctx->n_ranks;
+    *rank = ctx->rank;
+    return VB_OK;
+  }
   ncclResult_t r = ncclCommCount((ncclComm_t)ctx->comm, n_ranks);
   if (r == ncclSuccess) r = ncclCommUserRank((ncclComm_t)ctx->comm, rank);
   if (r != ncclSuccess) return fail(ctx, VB_ERR_COMM, "ncclCommCount failed: %s", ncclGetErrorString(r));
@@ -107,7 +157,15 @@ int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank) {
 
 int vb_comm_destroy(vb_ctx* ctx) {
   if (!ctx || !ctx->comm) return VB_OK;
-  ncclCommDestroy((ncclComm_t)ctx->comm);
+  if (ctx->host_fn) {
+    ctx->host_fn = nullptr;
+    ctx->host_user = nullptr;
+    if (ctx->host_stage) hipHostFree(ctx->host_stage);
+    ctx->host_stage = nullptr;
+    ctx->host_stage_cap = 0;
+  } else {
+    ncclCommDestroy((ncclComm_t)ctx->comm);
+  }
   ctx->comm = nullptr;
   ctx->n_ranks = 1;
   ctx->rank = 0;

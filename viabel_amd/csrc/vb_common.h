@@ -203,8 +203,13 @@ struct vb_ctx {
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
   uint64_t fr_seq = 0;                  // sharded full-rank evaluations enqueued (selects the sum set)
 
-  void* comm = nullptr;                 // ncclComm_t when a communicator is attached
+  void* comm = nullptr;                 // ncclComm_t when a communicator is attached (the context itself under a
+                                        // host-staged transport: non-NULL means "this is a sharded job" everywhere)
   int n_ranks = 1, rank = 0;
+  vb_host_collective_fn host_fn = nullptr;   // vb_comm_init_host: the caller's collective over host memory
+  void* host_user = nullptr;
+  double* host_stage = nullptr;         // pinned staging buffer of the host-staged transport
+  size_t host_stage_cap = 0;            // ... in doubles
 
   bool profile = false;
   struct ProfLog {                      // one per profiled kernel id (VB_PROF_*)

@@ -192,6 +192,24 @@ class SocketGroup:
                              lambda parts: struct.pack('<d', sum(struct.unpack('<d', p)[0] for p in parts)))
         return struct.unpack('<d', out)[0]
 
+    def allreduce_array(self, array, op=0):
+        """In-place elementwise sum (``op == 0``) or maximum (``op == 1``) of a float64 array over the ranks,
+        combined on rank 0 in rank order.  Only the host-staged transport (``attach(..., transport='host')``) sends
+        vectors this way."""
+        a = np.ascontiguousarray(array, dtype=np.float64)
+
+        def combine(parts):
+            acc = np.frombuffer(parts[0], dtype=np.float64).copy()
+            for p in parts[1:]:
+                other = np.frombuffer(p, dtype=np.float64)
+                if other.shape != acc.shape:
+                    raise RuntimeError('ranks entered a collective with %d and %d doubles' % (acc.size, other.size))
+                acc = np.maximum(acc, other) if op == 1 else acc + other
+            return acc.tobytes()
+        out = np.frombuffer(self._exchange(a.tobytes(), combine), dtype=np.float64)
+        array[...] = out.reshape(np.shape(array))
+        return array
+
     def close(self):
         for c in self._peers:
             c.close()
@@ -213,9 +231,16 @@ def broadcast_unique_id(rank, make_id, group=None):
     return box[0]
 
 
-def attach(engine=None, group=None):
-    """Attach an RCCL communicator spanning ``group`` (default: the torch.distributed world) to ``engine``."""
+def attach(engine=None, group=None, transport=None):
+    """Attach a communicator spanning ``group`` (default: the torch.distributed world) to ``engine``.
+
+    ``transport`` (default: ``$VIABEL_AMD_TRANSPORT`` or ``'rccl'``): ``'rccl'`` is the data path of a real job;
+    ``'host'`` stages every device collective through pinned host memory and ``group.allreduce_array`` -- for ranks
+    RCCL cannot join (two ranks sharing one GPU, as the two-rank tests on a one-GPU box do)."""
     engine = engine or _lib.default_engine()
+    transport = transport or os.environ.get('VIABEL_AMD_TRANSPORT', 'rccl')
+    if transport not in ('rccl', 'host'):
+        raise ValueError("transport must be 'rccl' or 'host', got %r" % (transport,))
     if group is not None:
         world, rank = group.world, group.rank
     else:
@@ -223,8 +248,20 @@ def attach(engine=None, group=None):
         world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return engine
-    uid = broadcast_unique_id(rank, _lib.Engine.comm_unique_id, group)
-    engine.comm_init(uid, world, rank)
+    if transport == 'host':
+        if group is None:
+            import torch
+            import torch.distributed as dist
+
+            def collective(array, op):
+                t = torch.from_numpy(array)          # shares the staging buffer's memory
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+        else:
+            collective = group.allreduce_array
+        engine.comm_init_host(collective, world, rank)
+    else:
+        uid = broadcast_unique_id(rank, _lib.Engine.comm_unique_id, group)
+        engine.comm_init(uid, world, rank)
     if group is not None:
         # host-side random draws of the objectives (the alpha-divergence seed, the DIS resampling indices: the global
         # numpy RNG in the reference) are taken on rank 0 and handed to the other ranks over this group
