@@ -441,6 +441,25 @@ int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank);
 typedef int (*vb_host_collective_fn)(void* user, double* buf, size_t count, int op);
 int vb_comm_init_host(vb_ctx* ctx, vb_host_collective_fn fn, void* user, int n_ranks, int rank);
 
+/* ---- numpy's legacy generator on the host (vb_legacy_rng.cpp) ------------------------------------
+ * `numpy.random.RandomState(seed)` restated in C++: MT19937 seeded as numpy seeds it from an integer, the polar-method
+ * normals with their one-value cache (`randn`, the noise of approximations.py:203), `standard_t` (:273-274) and
+ * `chisquare` (:342) -- values AND generator state bit-identical to numpy's, call after call
+ * (tests/test_legacy_rng_cpu.py).  Host code only, no vb_ctx, no GPU.  `randn` beyond 32 768 values evaluates the
+ * attempts of the polar method on `threads` host threads (0: $VIABEL_AMD_RNG_THREADS, else up to 16): every attempt
+ * consumes exactly four words of the stream, so the words are generated once, sequentially, and the log / sqrt of the
+ * transform -- most of numpy's time -- runs in parallel with a prefix sum over the acceptance counts. */
+typedef struct vb_legacy_rng vb_legacy_rng;
+int vb_legacy_rng_create(uint32_t seed, vb_legacy_rng** out);
+void vb_legacy_rng_destroy(vb_legacy_rng* rng);
+int vb_legacy_rng_randn(vb_legacy_rng* rng, double* out, int64_t n, int threads);
+int vb_legacy_rng_standard_t(vb_legacy_rng* rng, double df, double* out, int64_t n);
+int vb_legacy_rng_chisquare(vb_legacy_rng* rng, double df, double* out, int64_t n);
+int vb_legacy_rng_random_sample(vb_legacy_rng* rng, double* out, int64_t n);
+/* (key[624], pos, has_gauss, cached_gaussian) as `RandomState.get_state()` / `set_state()` carry them */
+int vb_legacy_rng_get_state(const vb_legacy_rng* rng, uint32_t key[624], int* pos, int* has_gauss, double* gauss);
+int vb_legacy_rng_set_state(vb_legacy_rng* rng, const uint32_t key[624], int pos, int has_gauss, double gauss);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels ---------
  * When enabled, every launch of a profiled kernel carries a start/stop event pair
  * (hipExtLaunchKernel: the kernel's own begin/end timestamps on the context's stream).

@@ -152,6 +152,16 @@ SIGNATURES = {
                                                      ctypes.c_int64, ctypes.c_uint]),
     'vb_fullrank_get': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64]),
     'vb_result_get': (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int64]),
+    'vb_legacy_rng_create': (ctypes.c_int, [ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
+    'vb_legacy_rng_destroy': (None, [ctypes.c_void_p]),
+    'vb_legacy_rng_randn': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, ctypes.c_int]),
+    'vb_legacy_rng_standard_t': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, _c_double_p, ctypes.c_int64]),
+    'vb_legacy_rng_chisquare': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, _c_double_p, ctypes.c_int64]),
+    'vb_legacy_rng_random_sample': (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    'vb_legacy_rng_get_state': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int),
+                                               ctypes.POINTER(ctypes.c_int), _c_double_p]),
+    'vb_legacy_rng_set_state': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_double]),
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_init_host': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),

@@ -13,8 +13,9 @@ dense ones, where ``L`` is the Cholesky factor of the scale matrix with the *log
 diagonal, lower triangle in ``numpy.tril_indices`` order.
 
 Noise sources.  ``rng='numpy'`` (default) reproduces the reference bit for bit: a persistent
-``numpy.random.RandomState(seed)`` held by the family and advanced by every draw
-(``approximations.py:203``, ``:213-216``).  ``rng='philox'`` is the throughput mode: noise
+``numpy.random.RandomState(seed)`` stream held by the family and advanced by every draw
+(``approximations.py:203``, ``:213-216``) -- drawn by the library's own restatement of numpy's legacy generator
+(``_legacy_rng.LegacyRandomState``: same values, same state, the big normal matrices on all host threads).  ``rng='philox'`` is the throughput mode: noise
 is generated on the GPU by a counter-based Philox stream and never touches the host.
 """
 from abc import ABC, abstractmethod
@@ -24,6 +25,7 @@ from scipy import linalg as _sla
 from scipy import special as _special
 
 from . import _lib
+from ._legacy_rng import LegacyRandomState
 
 __all__ = ['ApproximationFamily', 'MFGaussian', 'MFStudentT', 'MultivariateT', 'FullRankGaussian', 'LRGaussian']
 
@@ -108,7 +110,7 @@ class _NoiseMixin:
             raise ValueError("rng must be 'numpy' or 'philox'")
         self._seed = seed
         self._rng_kind = rng
-        self._rs = np.random.RandomState(seed)
+        self._rs = LegacyRandomState(seed)
         self._philox_calls = 0
 
     @property
@@ -116,7 +118,7 @@ class _NoiseMixin:
         return self._rng_kind
 
     def _random_state(self, seed):
-        return self._rs if seed is None else np.random.RandomState(seed)
+        return self._rs if seed is None else LegacyRandomState(seed)
 
     def _next_philox_stream(self):
         k = self._philox_calls

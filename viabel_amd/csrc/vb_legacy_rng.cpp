@@ -1,0 +1,359 @@
+// numpy's legacy generator on the host, in C++: MT19937 + the polar-method normals, Marsaglia-Tsang gammas,
+// chi-square and Student-t draws of `numpy.random.RandomState` -- the streams the reference's families draw their
+// noise from (approximations.py:203 `randn`, :273-274 `standard_t`, :342-345 `chisquare` then `randn`).  SURVEY 8(f)
+// N2: with this the parity mode (`rng='numpy'`) does not depend on numpy for its noise, and the big normal matrices
+// are produced several times faster than `RandomState.randn` does it:
+//
+//   * every attempt of the polar method consumes exactly four 32-bit words (two 53-bit doubles) whether it is
+//     accepted or not, so attempt i reads words [4 i, 4 i + 4) of the stream and the k-th ACCEPTED attempt writes
+//     outputs 2 k (= f x2, what legacy_gauss returns first) and 2 k + 1 (= f x1, the value it caches).  The words are
+//     generated sequentially (MT19937 is one recurrence), the attempts are then evaluated by all host threads with
+//     a prefix sum over the acceptance counts -- the log / sqrt / divide of the transform is 80 % of numpy's time;
+//   * the number of attempts a request needs is random: rounds deliberately ask for a few standard deviations fewer
+//     than expected, so that everything generated is consumed, and the short last round rewinds the generator to
+//     just behind the attempt that produced the last value -- the state left behind (key, position, cached normal)
+//     is exactly numpy's, call after call.
+//
+// The arithmetic per value is numpy's, operation by operation, in IEEE double with the C library's log / sqrt / pow
+// (the same libm numpy calls); this file is compiled with -ffp-contract=off so that no product-sum is fused that
+// numpy's build does not fuse.  tests/test_legacy_rng_cpu.py compares values AND generator state with numpy bit for
+// bit.  Host code only: nothing here touches the GPU.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/viabel_hip.h"
+
+namespace {
+
+constexpr int kN = 624, kM = 397;
+constexpr uint32_t kMatrixA = 0x9908b0dfu, kUpper = 0x80000000u, kLower = 0x7fffffffu;
+
+}  // namespace
+
+struct vb_legacy_rng {
+  uint32_t key[kN];
+  int pos;
+  int has_gauss;
+  double gauss;
+};
+
+namespace {
+
+void mt_seed(vb_legacy_rng& s, uint32_t seed) {          // numpy's mt19937_seed (Knuth's initialiser)
+  for (int i = 0; i < kN; ++i) {
+    s.key[i] = seed;
+    seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)i + 1u;
+  }
+  s.pos = kN;
+  s.has_gauss = 0;
+  s.gauss = 0.0;
+}
+
+void mt_refresh(uint32_t* key) {                          // the next 624 words of the recurrence, in place
+  int k = 0;
+  for (; k < kN - kM; ++k) {
+    const uint32_t y = (key[k] & kUpper) | (key[k + 1] & kLower);
+    key[k] = key[k + kM] ^ (y >> 1) ^ ((0u - (y & 1u)) & kMatrixA);
+  }
+  for (; k < kN - 1; ++k) {
+    const uint32_t y = (key[k] & kUpper) | (key[k + 1] & kLower);
+    key[k] = key[k + (kM - kN)] ^ (y >> 1) ^ ((0u - (y & 1u)) & kMatrixA);
+  }
+  const uint32_t y = (key[kN - 1] & kUpper) | (key[0] & kLower);
+  key[kN - 1] = key[kM - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & kMatrixA);
+}
+
+inline uint32_t temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+inline uint32_t next_u32(vb_legacy_rng& s) {
+  if (s.pos == kN) {
+    mt_refresh(s.key);
+    s.pos = 0;
+  }
+  return temper(s.key[s.pos++]);
+}
+
+inline double words_to_double(uint32_t w0, uint32_t w1) {       // numpy's 53-bit double from two words
+  const int32_t a = (int32_t)(w0 >> 5), b = (int32_t)(w1 >> 6);
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+inline double next_double(vb_legacy_rng& s) {
+  const uint32_t w0 = next_u32(s), w1 = next_u32(s);
+  return words_to_double(w0, w1);
+}
+
+// `count` tempered words into `out`, advancing the state
+void fill_words(vb_legacy_rng& s, uint32_t* out, size_t count) {
+  size_t done = 0;
+  while (done < count) {
+    if (s.pos == kN) {
+      mt_refresh(s.key);
+      s.pos = 0;
+    }
+    const size_t take = std::min<size_t>(count - done, (size_t)(kN - s.pos));
+    const uint32_t* src = s.key + s.pos;
+    for (size_t i = 0; i < take; ++i) out[done + i] = temper(src[i]);
+    s.pos += (int)take;
+    done += take;
+  }
+}
+
+void skip_words(vb_legacy_rng& s, size_t count) {
+  while (count > 0) {
+    if (s.pos == kN) {
+      mt_refresh(s.key);
+      s.pos = 0;
+    }
+    const size_t take = std::min<size_t>(count, (size_t)(kN - s.pos));
+    s.pos += (int)take;
+    count -= take;
+  }
+}
+
+// ---- numpy's legacy distributions (legacy-distributions.c), scalar ------------------------------------------
+double legacy_gauss(vb_legacy_rng& s) {
+  if (s.has_gauss) {
+    const double tmp = s.gauss;
+    s.has_gauss = 0;
+    s.gauss = 0.0;
+    return tmp;
+  }
+  double x1, x2, r2;
+  do {
+    x1 = 2.0 * next_double(s) - 1.0;
+    x2 = 2.0 * next_double(s) - 1.0;
+    r2 = x1 * x1 + x2 * x2;
+  } while (r2 >= 1.0 || r2 == 0.0);
+  const double f = std::sqrt(-2.0 * std::log(r2) / r2);       // polar method (Box-Muller without the trigonometry)
+  s.gauss = f * x1;
+  s.has_gauss = 1;
+  return f * x2;
+}
+
+double legacy_standard_exponential(vb_legacy_rng& s) { return -std::log(1.0 - next_double(s)); }
+
+double legacy_standard_gamma(vb_legacy_rng& s, double shape) {
+  if (shape == 1.0) return legacy_standard_exponential(s);
+  if (shape == 0.0) return 0.0;
+  if (shape < 1.0) {
+    for (;;) {
+      const double U = next_double(s);
+      const double V = legacy_standard_exponential(s);
+      if (U <= 1.0 - shape) {
+        const double X = std::pow(U, 1. / shape);
+        if (X <= V) return X;
+      } else {
+        const double Y = -std::log((1 - U) / shape);
+        const double X = std::pow(1.0 - shape + shape * Y, 1. / shape);
+        if (X <= (V + Y)) return X;
+      }
+    }
+  }
+  const double b = shape - 1. / 3.;
+  const double c = 1. / std::sqrt(9 * b);
+  for (;;) {
+    double X, V;
+    do {
+      X = legacy_gauss(s);
+      V = 1.0 + c * X;
+    } while (V <= 0.0);
+    V = V * V * V;
+    const double U = next_double(s);
+    if (U < 1.0 - 0.0331 * (X * X) * (X * X)) return (b * V);
+    if (std::log(U) < 0.5 * X * X + b * (1. - V + std::log(V))) return (b * V);
+  }
+}
+
+// ---- the big normal draws: attempts evaluated in parallel -------------------------------------------------------
+struct Attempt {
+  double x1, x2, r2;
+  bool ok;
+};
+
+inline Attempt attempt_at(const uint32_t* w) {
+  Attempt a;
+  a.x1 = 2.0 * words_to_double(w[0], w[1]) - 1.0;
+  a.x2 = 2.0 * words_to_double(w[2], w[3]) - 1.0;
+  a.r2 = a.x1 * a.x1 + a.x2 * a.x2;
+  a.ok = !(a.r2 >= 1.0 || a.r2 == 0.0);
+  return a;
+}
+
+int thread_count(int asked) {
+  if (asked <= 0) {
+    const char* env = getenv("VIABEL_AMD_RNG_THREADS");
+    asked = env ? atoi(env) : 0;
+  }
+  if (asked <= 0) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    asked = hw == 0 ? 4 : (int)std::min(hw, 16u);
+  }
+  return asked;
+}
+
+template <class F>
+void run_slices(int threads, size_t items, F&& body) {        // body(t, begin, end)
+  if (threads <= 1) {
+    body(0, (size_t)0, items);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)threads - 1);
+  const size_t per = (items + (size_t)threads - 1) / (size_t)threads;
+  for (int t = 1; t < threads; ++t) {
+    const size_t b = std::min(items, per * (size_t)t), e = std::min(items, b + per);
+    pool.emplace_back([&body, t, b, e]() { body(t, b, e); });
+  }
+  body(0, (size_t)0, std::min(items, per));
+  for (auto& th : pool) th.join();
+}
+
+constexpr double kAccept = 0.78539816339744830962;        // pi / 4: a point of the square falls inside the unit disc
+constexpr size_t kMaxRound = (size_t)1 << 22;              // attempts per round (64 MiB of words)
+constexpr int64_t kParallelFrom = (int64_t)1 << 15;        // below this many values the scalar loop is as fast
+
+void randn_parallel(vb_legacy_rng& s, double* out, int64_t n, int threads) {
+  if (n > 0 && s.has_gauss) {
+    *out++ = s.gauss;
+    s.has_gauss = 0;
+    s.gauss = 0.0;
+    --n;
+  }
+  if (n <= 0) return;
+  const int64_t pairs = (n + 1) / 2;
+  int64_t done = 0;
+  std::vector<uint32_t> words;
+  std::vector<int64_t> counts((size_t)threads + 1);
+  double last_x1f = 0.0;                 // f * x1 of the last pair (the value numpy caches when n is odd)
+  while (done < pairs) {
+    const int64_t rem = pairs - done;
+    const double expected = (double)rem / kAccept;
+    const double sigma = std::sqrt((double)rem * (1.0 - kAccept)) / kAccept;
+    // large remainders: fewer attempts than will be needed (8 sigma), so all of them are consumed and nothing has to
+    // be rewound; the short tail asks for more than enough and rewinds a few thousand words at most
+    size_t attempts = rem > 2048 ? (size_t)std::max(1.0, expected - 8.0 * sigma) : (size_t)(expected * 1.5) + 64;
+    attempts = std::min(attempts, kMaxRound);
+    const vb_legacy_rng snap = s;
+    words.resize(4 * attempts);
+    fill_words(s, words.data(), words.size());
+    const uint32_t* w = words.data();
+    const int use = attempts < 4096 ? 1 : threads;
+    std::fill(counts.begin(), counts.end(), 0);
+    run_slices(use, attempts, [&](int t, size_t b, size_t e) {
+      int64_t c = 0;
+      for (size_t i = b; i < e; ++i) c += attempt_at(w + 4 * i).ok ? 1 : 0;
+      counts[(size_t)t + 1] = c;
+    });
+    for (int t = 0; t < use; ++t) counts[(size_t)t + 1] += counts[(size_t)t];      // exclusive prefix in counts[t]
+    const int64_t total = counts[(size_t)use];
+    std::vector<int64_t> last_attempt((size_t)use, -1);         // per slice: index of the attempt that completed the request
+    run_slices(use, attempts, [&](int t, size_t b, size_t e) {
+      int64_t q = done + counts[(size_t)t];
+      for (size_t i = b; i < e && q < pairs; ++i) {
+        const Attempt a = attempt_at(w + 4 * i);
+        if (!a.ok) continue;
+        const double f = std::sqrt(-2.0 * std::log(a.r2) / a.r2);
+        out[2 * q] = f * a.x2;
+        if (2 * q + 1 < n) out[2 * q + 1] = f * a.x1;
+        if (q == pairs - 1) {
+          last_attempt[(size_t)t] = (int64_t)i;
+          last_x1f = f * a.x1;           // one slice only reaches the last pair
+        }
+        ++q;
+      }
+    });
+    if (total >= rem) {                  // the request completed inside this round: rewind to just behind that attempt
+      int64_t a_star = -1;
+      for (int t = 0; t < use; ++t) a_star = std::max(a_star, last_attempt[(size_t)t]);
+      s = snap;
+      skip_words(s, 4 * (size_t)(a_star + 1));
+      done = pairs;
+    } else {
+      done += total;
+    }
+  }
+  if (n & 1) {
+    s.gauss = last_x1f;
+    s.has_gauss = 1;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vb_legacy_rng_create(uint32_t seed, vb_legacy_rng** out) {
+  if (!out) return VB_ERR_INVALID;
+  vb_legacy_rng* s = new (std::nothrow) vb_legacy_rng;
+  if (!s) return VB_ERR_HIP;          // (out of host memory)
+  mt_seed(*s, seed);
+  *out = s;
+  return VB_OK;
+}
+
+void vb_legacy_rng_destroy(vb_legacy_rng* s) { delete s; }
+
+int vb_legacy_rng_get_state(const vb_legacy_rng* s, uint32_t key[624], int* pos, int* has_gauss, double* gauss) {
+  if (!s || !key || !pos || !has_gauss || !gauss) return VB_ERR_INVALID;
+  memcpy(key, s->key, sizeof s->key);
+  *pos = s->pos;
+  *has_gauss = s->has_gauss;
+  *gauss = s->gauss;
+  return VB_OK;
+}
+
+int vb_legacy_rng_set_state(vb_legacy_rng* s, const uint32_t key[624], int pos, int has_gauss, double gauss) {
+  if (!s || !key || pos < 0 || pos > kN) return VB_ERR_INVALID;
+  memcpy(s->key, key, sizeof s->key);
+  s->pos = pos;
+  s->has_gauss = has_gauss ? 1 : 0;
+  s->gauss = has_gauss ? gauss : 0.0;
+  return VB_OK;
+}
+
+int vb_legacy_rng_randn(vb_legacy_rng* s, double* out, int64_t n, int threads) {
+  if (!s || n < 0 || (n > 0 && !out)) return VB_ERR_INVALID;
+  if (n < kParallelFrom) {
+    for (int64_t i = 0; i < n; ++i) out[i] = legacy_gauss(*s);
+    return VB_OK;
+  }
+  randn_parallel(*s, out, n, thread_count(threads));
+  return VB_OK;
+}
+
+int vb_legacy_rng_standard_t(vb_legacy_rng* s, double df, double* out, int64_t n) {
+  if (!s || n < 0 || (n > 0 && !out) || !(df > 0.0)) return VB_ERR_INVALID;
+  for (int64_t i = 0; i < n; ++i) {
+    const double num = legacy_gauss(*s);
+    const double denom = legacy_standard_gamma(*s, df / 2);
+    out[i] = std::sqrt(df / 2) * num / std::sqrt(denom);
+  }
+  return VB_OK;
+}
+
+int vb_legacy_rng_chisquare(vb_legacy_rng* s, double df, double* out, int64_t n) {
+  if (!s || n < 0 || (n > 0 && !out) || !(df > 0.0)) return VB_ERR_INVALID;
+  for (int64_t i = 0; i < n; ++i) out[i] = 2.0 * legacy_standard_gamma(*s, df / 2.0);
+  return VB_OK;
+}
+
+int vb_legacy_rng_random_sample(vb_legacy_rng* s, double* out, int64_t n) {
+  if (!s || n < 0 || (n > 0 && !out)) return VB_ERR_INVALID;
+  for (int64_t i = 0; i < n; ++i) out[i] = next_double(*s);
+  return VB_OK;
+}
+
+}  // extern "C"
