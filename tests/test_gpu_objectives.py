@@ -378,10 +378,13 @@ def test_dis_multivariate_t_philox_mode_against_oracle(vb, use_resampling):
     assert G.rel_err(obj._state_log_p_unnormalized, ref._state_log_p) < 1e-11
 
 
+@pytest.mark.parametrize('pd', [False, True], ids=['entropy', 'path_deriv'])
 @pytest.mark.parametrize('family', ['mf_gaussian', 'mf_student_t', 'fullrank'])
-def test_exclusive_kl_hessian_vector_product(vb, family):
+def test_exclusive_kl_hessian_vector_product(vb, family, pd):
     """ExclusiveKL._hessian_vector_product (objectives.py:166, :275-277) against torch.autograd's exact
-    Hessian-vector product of the same objective on the same noise (fp64, CPU)."""
+    Hessian-vector product of the same objective on the same noise (fp64, CPU).  With use_path_deriv the reference's
+    objective is mean(f(z) - log q(z; stopped theta)) (objectives.py:156-159): the stopped copy is a constant of both
+    differentiations."""
     import torch
     D, N = 24, 300
     rng = np.random.RandomState(2)
@@ -401,8 +404,9 @@ def test_exclusive_kl_hessian_vector_product(vb, family):
         theta = np.concatenate([0.3 * rng.randn(D), -0.5 + 0.2 * rng.randn(D)])
         noise = np.random.RandomState(5).randn(N, D)
     x = rng.randn(theta.size)
-    obj = vb.ExclusiveKL(approx, model, N)
+    obj = vb.ExclusiveKL(approx, model, N, use_path_deriv=pd)
     hv = obj._hessian_vector_product(theta, x)
+    ts = torch.from_numpy(theta.copy())           # the stopped parameter
 
     E = torch.from_numpy(noise)
     tm, tiv = torch.from_numpy(mean), torch.from_numpy(1.0 / sd ** 2)
@@ -420,6 +424,18 @@ def test_exclusive_kl_hessian_vector_product(vb, family):
             z = mu + torch.exp(t[D:]) * E
             logdet = torch.sum(t[D:])
         f = -0.5 * torch.sum((z - tm) ** 2 * tiv, 1)
+        if pd:                                    # log q(z; stopped theta) up to constants
+            if family == 'fullrank':
+                Ls = torch.zeros(D, D, dtype=torch.float64)
+                Ls[tril[0], tril[1]] = ts[D:]
+                Ls = torch.tril(Ls, -1) + torch.diag(torch.exp(torch.diagonal(Ls)))
+                w = torch.linalg.solve_triangular(Ls, (z - ts[:D]).T, upper=False).T
+                logq = -0.5 * torch.sum(w * w, 1)
+            else:
+                u = (z - ts[:D]) / torch.exp(ts[D:])
+                logq = (torch.sum(-0.5 * (7.0 + 1.0) * torch.log1p(u * u / 7.0), 1) if family == 'mf_student_t'
+                        else -0.5 * torch.sum(u * u, 1))
+            return -torch.mean(f - logq)
         return -(torch.mean(f) + logdet)          # the entropy's theta-independent terms do not matter here
 
     _, ref = torch.autograd.functional.hvp(objective, torch.from_numpy(theta), torch.from_numpy(x))
@@ -430,7 +446,8 @@ def test_exclusive_kl_hessian_vector_product(vb, family):
         vb.ExclusiveKL(vb.MFGaussian(D), model, N, hessian_approx_method='full')._hessian_vector_product(
             theta[:2 * D], x[:2 * D])
     with pytest.raises(NotImplementedError):
-        vb.ExclusiveKL(vb.MFGaussian(D), model, N, use_path_deriv=True)._hessian_vector_product(theta[:2 * D], x[:2 * D])
+        t = vb.MultivariateT(D, 5.0)
+        vb.ExclusiveKL(t, model, N)._hessian_vector_product(np.zeros(t.var_param_dim), np.ones(t.var_param_dim))
 
 
 @pytest.mark.parametrize('family', ['mf_gaussian', 'multivariate_t'])

@@ -15,6 +15,7 @@ all-reduced on the device before the epilogue; every rank returns the same ``(va
 from abc import ABC, abstractmethod
 
 import numpy as np
+from scipy import linalg as _sla
 from scipy import special as _special
 
 from . import _lib
@@ -366,14 +367,17 @@ class ExclusiveKL(StochasticVariationalObjective):
         noise matrix, ``(grad(theta + h u) - grad(theta - h u)) / (2 h) * |x|`` with ``u = x / |x|``: two
         evaluations, O(h^2) truncation (h = 6e-6 (1 + |theta|_inf), relative error ~1e-9 in the tests; exact up to
         rounding wherever the gradient is affine in theta along ``u``).  Plain estimator only
-        (``hessian_approx_method=None``), as in the reference; mean-field and dense Gaussian families; entropy
-        form only: with ``use_path_deriv`` autograd keeps the stopped copy of theta fixed through BOTH
-        differentiations, which a difference of path-derivative gradients does not reproduce."""
+        (``hessian_approx_method=None``), as in the reference; mean-field and dense Gaussian families.
+
+        ``use_path_deriv=True`` (``objectives.py:156-159``): autograd keeps the stopped copy ``theta_s`` of the parameter
+        fixed through BOTH differentiations, which a difference of path-derivative gradients would not reproduce.  The
+        objective splits as ``-mean f(z(theta)) + mean log q(z(theta); theta_s)``.  The entropy of all three families
+        is linear in theta (sum of the log scales), so the first term has the Hessian of the entropy-form objective --
+        the device difference above.  The second term depends on the noise only through a handful of moments and its
+        Hessian at ``theta = theta_s`` is written out (``_path_logq_hvp``)."""
         approx = self.approx
         if self.hessian_approx_method is not None:
             raise AttributeError("'ExclusiveKL' object has no attribute '_hvp'")      # what the reference raises (:275)
-        if self._use_path_deriv:
-            raise NotImplementedError('_hessian_vector_product: entropy-form estimator only (use_path_deriv=False)')
         if not isinstance(approx, (MFGaussian, MFStudentT, FullRankGaussian)):
             raise NotImplementedError('_hessian_vector_product: MFGaussian, MFStudentT and FullRankGaussian')
         var_param = np.asarray(var_param, dtype=np.float64)
@@ -397,7 +401,55 @@ class ExclusiveKL(StochasticVariationalObjective):
             return eng.elbo_grad_meanfield(_NOISE_SLOT, n_local, approx.dim, theta, family, df=df, flags=flags,
                                            n_total=n_total)[1]
 
-        return (grad_at(var_param + h * u) - grad_at(var_param - h * u)) * (norm / (2.0 * h))
+        hv = (grad_at(var_param + h * u) - grad_at(var_param - h * u)) * (norm / (2.0 * h))
+        if self._use_path_deriv:
+            hv = hv + self._path_logq_hvp(eng, var_param, x, n_local, n_total)
+        return hv
+
+    def _path_logq_hvp(self, eng, theta, x, n_local, n_total):
+        """Hessian-vector product of ``T(theta) = mean_n log q(z_n(theta); theta_s)`` at ``theta = theta_s`` on the
+        staged noise (the part of the path-derivative objective that the stopped parameter enters).
+
+        Mean-field families, ``u = (z - mu_s) / sigma_s = a + r eps`` with ``a = (mu - mu_s) / sigma_s``,
+        ``r = sigma / sigma_s``, ``log q = sum_d phi(u_d) + const`` (``phi(u) = -u^2 / 2`` or the Student-t
+        ``-(nu + 1) / 2 log(1 + u^2 / nu)``): per coordinate
+        ``T_mumu = mean phi''(eps) / sigma^2``, ``T_mulam = mean phi''(eps) eps / sigma``,
+        ``T_lamlam = mean [phi''(eps) eps^2 + phi'(eps) eps]``.
+        Dense Gaussian, ``w = L_s^-1 (mu - mu_s) + L_s^-1 L eps``, ``T = -mean |w|^2 / 2``: the gradient is
+        ``(-A' mean w, -tril(A' mean w eps'))`` with ``A = L_s^-1``, its derivative along ``x`` needs ``mean eps`` and the
+        noise Gram matrix (``vb_noise_moments``), plus the chain rule through the log-diagonal."""
+        approx = self.approx
+        D = approx.dim
+        if isinstance(approx, FullRankGaussian):
+            colsum, gram = eng.noise_moments(_NOISE_SLOT, n_local, D, want_gram=True)      # summed over the ranks
+            e_bar, M = colsum / n_total, gram / n_total
+            _, L = approx._unpack(theta)
+            x_mu = x[:D]
+            X = np.zeros((D, D))
+            X[np.tril_indices(D)] = x[D:]
+            diag = np.diag(L).copy()
+            dL = np.tril(X, -1) + np.diag(diag * np.diag(X))
+            solve = lambda B, trans=0: _sla.solve_triangular(L, B, lower=True, trans=trans)     # noqa: E731
+            w_mean = solve(x_mu) + solve(dL @ e_bar)                     # mean of dw/dt
+            h_mu = -solve(w_mean, trans=1)
+            G0 = -np.tril(solve(M, trans=1))                             # gradient w.r.t. L at theta_s
+            G1 = -np.tril(solve(np.outer(solve(x_mu), e_bar) + solve(dL @ M), trans=1))
+            H = np.tril(G1, -1) + np.diag(diag * np.diag(X) * np.diag(G0) + diag * np.diag(G1))
+            return np.concatenate([h_mu, H[np.tril_indices(D)]])
+        if eng.n_ranks > 1:
+            raise NotImplementedError('_hessian_vector_product with use_path_deriv: mean-field families on one rank only')
+        eps = eng.noise_get_host(_NOISE_SLOT, n_local, D)
+        if isinstance(approx, MFStudentT):
+            nu = float(approx.df)
+            p1 = -(nu + 1.0) * eps / (nu + eps * eps)
+            p2 = -(nu + 1.0) * (nu - eps * eps) / (nu + eps * eps) ** 2
+        else:
+            p1, p2 = -eps, -np.ones_like(eps)
+        sigma = np.exp(theta[D:])
+        t_mm = p2.mean(0) / sigma ** 2
+        t_ml = (p2 * eps).mean(0) / sigma
+        t_ll = (p2 * eps * eps + p1 * eps).mean(0)
+        return np.concatenate([t_mm * x[:D] + t_ml * x[D:], t_ml * x[:D] + t_ll * x[D:]])
 
     # ---- device-resident optimiser loop ---------------------------------------------------------------
     def supports_device_fit(self):
