@@ -446,7 +446,7 @@ int vb_comm_init_host(vb_ctx* ctx, vb_host_collective_fn fn, void* user, int n_r
  * normals with their one-value cache (`randn`, the noise of approximations.py:203), `standard_t` (:273-274) and
  * `chisquare` (:342) -- values AND generator state bit-identical to numpy's, call after call
  * (tests/test_legacy_rng_cpu.py).  Host code only, no vb_ctx, no GPU.  `randn` beyond 32 768 values evaluates the
- * attempts of the polar method on `threads` host threads (0: $VIABEL_AMD_RNG_THREADS, else up to 16): every attempt
+ * attempts of the polar method on `threads` host threads (0: $VIABEL_AMD_RNG_THREADS, else up to 8): every attempt
  * consumes exactly four words of the stream, so the words are generated once, sequentially, and the log / sqrt of the
  * transform -- most of numpy's time -- runs in parallel with a prefix sum over the acceptance counts. */
 typedef struct vb_legacy_rng vb_legacy_rng;

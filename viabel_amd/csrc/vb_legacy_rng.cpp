@@ -41,9 +41,23 @@ struct vb_legacy_rng {
   int pos;
   int has_gauss;
   double gauss;
+  uint32_t out[kN];                  // key[] tempered (the block's output words), refreshed with it
+  std::vector<uint32_t> buf[2];      // word buffers of the threaded normal draws (kept: no page faults per call)
 };
 
 namespace {
+
+inline uint32_t temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+void temper_block(vb_legacy_rng& s) {
+  for (int i = 0; i < kN; ++i) s.out[i] = temper(s.key[i]);
+}
 
 void mt_seed(vb_legacy_rng& s, uint32_t seed) {          // numpy's mt19937_seed (Knuth's initialiser)
   for (int i = 0; i < kN; ++i) {
@@ -53,6 +67,7 @@ void mt_seed(vb_legacy_rng& s, uint32_t seed) {          // numpy's mt19937_seed
   s.pos = kN;
   s.has_gauss = 0;
   s.gauss = 0.0;
+  temper_block(s);
 }
 
 void mt_refresh(uint32_t* key) {                          // the next 624 words of the recurrence, in place
@@ -69,20 +84,15 @@ void mt_refresh(uint32_t* key) {                          // the next 624 words 
   key[kN - 1] = key[kM - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & kMatrixA);
 }
 
-inline uint32_t temper(uint32_t y) {
-  y ^= y >> 11;
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= y >> 18;
-  return y;
+inline void next_block(vb_legacy_rng& s) {
+  mt_refresh(s.key);
+  temper_block(s);
+  s.pos = 0;
 }
 
 inline uint32_t next_u32(vb_legacy_rng& s) {
-  if (s.pos == kN) {
-    mt_refresh(s.key);
-    s.pos = 0;
-  }
-  return temper(s.key[s.pos++]);
+  if (s.pos == kN) next_block(s);
+  return s.out[s.pos++];
 }
 
 inline double words_to_double(uint32_t w0, uint32_t w1) {       // numpy's 53-bit double from two words
@@ -99,13 +109,9 @@ inline double next_double(vb_legacy_rng& s) {
 void fill_words(vb_legacy_rng& s, uint32_t* out, size_t count) {
   size_t done = 0;
   while (done < count) {
-    if (s.pos == kN) {
-      mt_refresh(s.key);
-      s.pos = 0;
-    }
+    if (s.pos == kN) next_block(s);
     const size_t take = std::min<size_t>(count - done, (size_t)(kN - s.pos));
-    const uint32_t* src = s.key + s.pos;
-    for (size_t i = 0; i < take; ++i) out[done + i] = temper(src[i]);
+    memcpy(out + done, s.out + s.pos, take * sizeof(uint32_t));
     s.pos += (int)take;
     done += take;
   }
@@ -113,10 +119,7 @@ void fill_words(vb_legacy_rng& s, uint32_t* out, size_t count) {
 
 void skip_words(vb_legacy_rng& s, size_t count) {
   while (count > 0) {
-    if (s.pos == kN) {
-      mt_refresh(s.key);
-      s.pos = 0;
-    }
+    if (s.pos == kN) next_block(s);
     const size_t take = std::min<size_t>(count, (size_t)(kN - s.pos));
     s.pos += (int)take;
     count -= take;
@@ -199,7 +202,7 @@ int thread_count(int asked) {
   }
   if (asked <= 0) {
     const unsigned hw = std::thread::hardware_concurrency();
-    asked = hw == 0 ? 4 : (int)std::min(hw, 16u);
+    asked = hw == 0 ? 4 : (int)std::min(hw, 8u);     // (threads are started per chunk: beyond 8 the starts cost more than they save)
   }
   return asked;
 }
@@ -222,8 +225,57 @@ void run_slices(int threads, size_t items, F&& body) {        // body(t, begin, 
 }
 
 constexpr double kAccept = 0.78539816339744830962;        // pi / 4: a point of the square falls inside the unit disc
-constexpr size_t kMaxRound = (size_t)1 << 22;              // attempts per round (64 MiB of words)
+constexpr size_t kChunk = (size_t)1 << 18;                 // attempts per chunk: 4 MiB of words, two chunks in flight
 constexpr int64_t kParallelFrom = (int64_t)1 << 15;        // below this many values the scalar loop is as fast
+
+struct ChunkResult {
+  int64_t accepted = 0;      // accepted attempts in the chunk
+  int64_t a_star = -1;       // index of the attempt that produced the request's last pair (-1: not in this chunk)
+  double last_x1f = 0.0;     // f * x1 of that pair (the value numpy caches when n is odd)
+};
+
+// Evaluate `attempts` attempts on words `w`; the first accepted one is pair number `base` of the request.
+ChunkResult process_chunk(const uint32_t* w, size_t attempts, int64_t base, int64_t pairs, int64_t n, double* out,
+                          int threads) {
+  const int use = attempts < 4096 ? 1 : std::max(1, threads);
+  std::vector<int64_t> counts((size_t)use + 1, 0);
+  run_slices(use, attempts, [&](int t, size_t b, size_t e) {
+    int64_t c = 0;
+    for (size_t i = b; i < e; ++i) c += attempt_at(w + 4 * i).ok ? 1 : 0;
+    counts[(size_t)t + 1] = c;
+  });
+  for (int t = 0; t < use; ++t) counts[(size_t)t + 1] += counts[(size_t)t];      // exclusive prefix in counts[t]
+  ChunkResult r;
+  r.accepted = counts[(size_t)use];
+  std::vector<int64_t> last_attempt((size_t)use, -1);
+  std::vector<double> last_val((size_t)use, 0.0);
+  run_slices(use, attempts, [&](int t, size_t b, size_t e) {
+    int64_t q = base + counts[(size_t)t];
+    for (size_t i = b; i < e && q < pairs; ++i) {
+      const Attempt a = attempt_at(w + 4 * i);
+      if (!a.ok) continue;
+      const double f = std::sqrt(-2.0 * std::log(a.r2) / a.r2);
+      out[2 * q] = f * a.x2;
+      if (2 * q + 1 < n) out[2 * q + 1] = f * a.x1;
+      if (q == pairs - 1) {            // one slice only reaches the last pair
+        last_attempt[(size_t)t] = (int64_t)i;
+        last_val[(size_t)t] = f * a.x1;
+      }
+      ++q;
+    }
+  });
+  for (int t = 0; t < use; ++t)
+    if (last_attempt[(size_t)t] >= 0) {
+      r.a_star = last_attempt[(size_t)t];
+      r.last_x1f = last_val[(size_t)t];
+    }
+  return r;
+}
+
+struct MtCore {
+  uint32_t key[kN];
+  int pos;
+};
 
 void randn_parallel(vb_legacy_rng& s, double* out, int64_t n, int threads) {
   if (n > 0 && s.has_gauss) {
@@ -235,54 +287,53 @@ void randn_parallel(vb_legacy_rng& s, double* out, int64_t n, int threads) {
   if (n <= 0) return;
   const int64_t pairs = (n + 1) / 2;
   int64_t done = 0;
-  std::vector<uint32_t> words;
-  std::vector<int64_t> counts((size_t)threads + 1);
-  double last_x1f = 0.0;                 // f * x1 of the last pair (the value numpy caches when n is odd)
+  double last_x1f = 0.0;
+  auto save = [&s](MtCore& c) {
+    memcpy(c.key, s.key, sizeof c.key);
+    c.pos = s.pos;
+  };
+  auto restore = [&s](const MtCore& c) {
+    memcpy(s.key, c.key, sizeof c.key);
+    s.pos = c.pos;
+    temper_block(s);
+  };
   while (done < pairs) {
     const int64_t rem = pairs - done;
     const double expected = (double)rem / kAccept;
     const double sigma = std::sqrt((double)rem * (1.0 - kAccept)) / kAccept;
     // large remainders: fewer attempts than will be needed (8 sigma), so all of them are consumed and nothing has to
     // be rewound; the short tail asks for more than enough and rewinds a few thousand words at most
-    size_t attempts = rem > 2048 ? (size_t)std::max(1.0, expected - 8.0 * sigma) : (size_t)(expected * 1.5) + 64;
-    attempts = std::min(attempts, kMaxRound);
-    const vb_legacy_rng snap = s;
-    words.resize(4 * attempts);
-    fill_words(s, words.data(), words.size());
-    const uint32_t* w = words.data();
-    const int use = attempts < 4096 ? 1 : threads;
-    std::fill(counts.begin(), counts.end(), 0);
-    run_slices(use, attempts, [&](int t, size_t b, size_t e) {
-      int64_t c = 0;
-      for (size_t i = b; i < e; ++i) c += attempt_at(w + 4 * i).ok ? 1 : 0;
-      counts[(size_t)t + 1] = c;
-    });
-    for (int t = 0; t < use; ++t) counts[(size_t)t + 1] += counts[(size_t)t];      // exclusive prefix in counts[t]
-    const int64_t total = counts[(size_t)use];
-    std::vector<int64_t> last_attempt((size_t)use, -1);         // per slice: index of the attempt that completed the request
-    run_slices(use, attempts, [&](int t, size_t b, size_t e) {
-      int64_t q = done + counts[(size_t)t];
-      for (size_t i = b; i < e && q < pairs; ++i) {
-        const Attempt a = attempt_at(w + 4 * i);
-        if (!a.ok) continue;
-        const double f = std::sqrt(-2.0 * std::log(a.r2) / a.r2);
-        out[2 * q] = f * a.x2;
-        if (2 * q + 1 < n) out[2 * q + 1] = f * a.x1;
-        if (q == pairs - 1) {
-          last_attempt[(size_t)t] = (int64_t)i;
-          last_x1f = f * a.x1;           // one slice only reaches the last pair
-        }
-        ++q;
+    const size_t attempts = rem > 2048 ? (size_t)std::max(1.0, expected - 8.0 * sigma) : (size_t)(expected * 1.5) + 64;
+    // chunks of the round, double-buffered: while the workers evaluate chunk c the calling thread draws the words of
+    // chunk c + 1 (the recurrence is the one sequential part: ~12 ms per 10.7 M words, hidden behind the transform)
+    const size_t n_chunks = (attempts + kChunk - 1) / kChunk;
+    MtCore snap[2];
+    auto chunk_size = [&](size_t c) { return std::min(kChunk, attempts - c * kChunk); };
+    for (int b = 0; b < 2; ++b) s.buf[b].resize(4 * std::min(kChunk, attempts));
+    save(snap[0]);
+    fill_words(s, s.buf[0].data(), 4 * chunk_size(0));
+    bool finished = false;
+    for (size_t c = 0; c < n_chunks && !finished; ++c) {
+      const size_t m = chunk_size(c);
+      const uint32_t* w = s.buf[c & 1].data();
+      ChunkResult r;
+      if (c + 1 < n_chunks) {
+        std::thread stage([&]() { r = process_chunk(w, m, done, pairs, n, out, threads - 1); });
+        save(snap[(c + 1) & 1]);
+        fill_words(s, s.buf[(c + 1) & 1].data(), 4 * chunk_size(c + 1));
+        stage.join();
+      } else {
+        r = process_chunk(w, m, done, pairs, n, out, threads);
       }
-    });
-    if (total >= rem) {                  // the request completed inside this round: rewind to just behind that attempt
-      int64_t a_star = -1;
-      for (int t = 0; t < use; ++t) a_star = std::max(a_star, last_attempt[(size_t)t]);
-      s = snap;
-      skip_words(s, 4 * (size_t)(a_star + 1));
-      done = pairs;
-    } else {
-      done += total;
+      if (r.a_star >= 0) {             // the request completed inside this chunk: rewind to just behind that attempt
+        restore(snap[c & 1]);
+        skip_words(s, 4 * (size_t)(r.a_star + 1));
+        last_x1f = r.last_x1f;
+        done = pairs;
+        finished = true;
+      } else {
+        done += r.accepted;
+      }
     }
   }
   if (n & 1) {
@@ -321,6 +372,7 @@ int vb_legacy_rng_set_state(vb_legacy_rng* s, const uint32_t key[624], int pos, 
   s->pos = pos;
   s->has_gauss = has_gauss ? 1 : 0;
   s->gauss = has_gauss ? gauss : 0.0;
+  temper_block(*s);
   return VB_OK;
 }
 
