@@ -166,6 +166,8 @@ struct vb_ctx {
   int64_t mvt_n = 0, mvt_d = 0, mvt_n_total = 0;
   std::vector<double> mvt_theta;        // parameter the device-side residuals of the DIS state belong to
   bool mvt_dev_factors = false;         // ... and its factors (L, L', L^-1) were formed on the device
+  const double* mvt_e_noise = nullptr;  // the residuals E' of that parameter are NOT stored: E'_n = noise_n / s_n (this matrix,
+  int64_t mvt_e_noise_ld = 0;           // row stride mvt_e_noise_ld; see mvt_residuals)
   std::vector<double> mvt_stage;        // host staging of the factor uploads (one synchronisation per pass)
   double* mvt_pin = nullptr;            // pinned staging of the throughput mode's parameter upload (no synchronisation)
   size_t mvt_pin_doubles = 0;
@@ -375,6 +377,9 @@ int mvt_elbo_chol_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d
 int noise_moments(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double* colsum_host, double* gram_host);
 int gram_lower_enqueue(vb_ctx* ctx, const double* A, const double* B, int64_t ld, int d, int64_t n, int splits,
                        double* Cpart, int64_t ldc, int64_t slab);
+int gram_lower_colsum_enqueue(vb_ctx* ctx, const double* A, const double* B, int64_t ld, int d, int64_t n, int splits,
+                              double* Cpart, int64_t ldc, int64_t slab, double* colsum, int64_t colsum_ld,
+                              int colsum_rows, bool* fused);
 int gram_splits(vb_ctx* ctx, int d, int64_t n);
 // ESS bisection of DISInclusiveKL (vb_rowstats.hip); lq = b - scal_in[0]
 int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const double* lprior, const double* scal_in,
@@ -436,6 +441,8 @@ int glm_grad_enqueue(vb_ctx* ctx, hipStream_t st, const ModelDev& m, const doubl
 
 // model log density for explicit x (vb_rows.hip)
 int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev);
+int model_and_prior_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev,
+                              const double* prior_mean, const double* prior_ivar, double prior_c0, double* prior_out);
 // G[row] = grad f(x[row]) (row stride ld, pad columns zero), f[row] = f(x[row]) for the bound model
 int model_grad_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* g_dev, double* f_dev);
 

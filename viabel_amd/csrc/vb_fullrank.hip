@@ -564,10 +564,24 @@ __global__ void __launch_bounds__(256) fr_triinv_leaf_kernel(const double* __res
   const int c0 = blockIdx.x * 4;                            // first of the workgroup's four columns
   const int s = c0 / kTriLeaf * kTriLeaf;
   const int jmax = (c0 + 3 < d ? c0 + 3 : d - 1) - s;       // last row any of the four waves needs
-  for (int e = threadIdx.x; e < (jmax + 1) * kTriLeaf; e += 256) {
-    const int i = e / kTriLeaf, r = e % kTriLeaf;
-    const int64_t gi = s + i;
-    ls[e] = r < i ? theta[d + gi * (gi + 1) / 2 + s + r] : 0.0;
+  // staging: batches of 16 unconditional loads per thread (addresses clamped into the row, the value selected
+  // afterwards) -- written as `r < i ? theta[..] : 0` the compiler branched around each load and waited for it
+  // before the next one: 64 dependent round trips, 20 of the kernel's 27 us at D = 256
+  const int total = (jmax + 1) * kTriLeaf;
+  for (int e0 = threadIdx.x; e0 < total; e0 += 256 * 16) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = e0 + 256 * k < total ? e0 + 256 * k : total - 1;
+      const int i = e / kTriLeaf, r = e % kTriLeaf;
+      const int64_t gi = s + i;
+      v[k] = theta[d + gi * (gi + 1) / 2 + s + (r < i ? r : 0)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = e0 + 256 * k;
+      if (e < total) ls[e] = (e % kTriLeaf) < (e / kTriLeaf) ? v[k] : 0.0;
+    }
   }
   __syncthreads();
   const int c = __builtin_amdgcn_readfirstlane(c0 + (threadIdx.x >> 6));   // this wave's column
@@ -579,20 +593,27 @@ __global__ void __launch_bounds__(256) fr_triinv_leaf_kernel(const double* __res
   if (lane <= j) q0 = 1.0 / U[(int64_t)(s + lane) * ld + s + lane];
   if (lane + 64 <= j) q1 = 1.0 / U[(int64_t)(s + lane + 64) * ld + s + lane + 64];
   // two straight-line phases (no per-step selects): pivots in rows >= 64 touch both register slots, pivots in
-  // rows < 64 only the first (rows >= 64 lie below them: L[s + i][s + r] = 0 for r >= i)
+  // rows < 64 only the first (rows >= 64 lie below them: L[s + i][s + r] = 0 for r >= i).  The row of the NEXT step
+  // is read from LDS while this step's chain (readlane, subtract, multiply, FMA) runs.
   int i = j;
+  double l0 = ls[i * kTriLeaf + lane], l1 = ls[i * kTriLeaf + lane + 64];
   for (; i >= 64; --i) {
-    const double l0 = ls[i * kTriLeaf + lane], l1 = ls[i * kTriLeaf + lane + 64];   // zero for rows >= i
+    const int in = i > 0 ? i - 1 : 0;
+    const double l0n = ls[in * kTriLeaf + lane], l1n = ls[in * kTriLeaf + lane + 64];
     const double xi = ((i == j ? 1.0 : 0.0) - fr_readlane(p1, i - 64)) * fr_readlane(q1, i - 64);
     if (lane + 64 == i) x1 = xi;
     p0 = fma(l0, xi, p0);
     p1 = fma(l1, xi, p1);
+    l0 = l0n;
+    l1 = l1n;
   }
   for (; i >= 0; --i) {
-    const double l0 = ls[i * kTriLeaf + lane];
+    const int in = i > 0 ? i - 1 : 0;
+    const double l0n = ls[in * kTriLeaf + lane];
     const double xi = ((i == j ? 1.0 : 0.0) - fr_readlane(p0, i)) * fr_readlane(q0, i);
     if (lane == i) x0 = xi;
     p0 = fma(l0, xi, p0);
+    l0 = l0n;
   }
   double* Xb = X + (int64_t)s * ld + s;
   if (lane <= j) Xb[(int64_t)lane * ld + j] = x0;
@@ -775,6 +796,32 @@ int gram_lower_enqueue(vb_ctx* ctx, const double* A, const double* B, int64_t ld
   g3.K = (int)n;
   g3.tri_mode = 2;
   gemm_f64_launch<false>(ctx->stream, g3, splits, ctx->prop.multiProcessorCount, EpiSplitSlab{Cpart, ldc, slab});
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+// The same product with the column sums of A formed out of the gradient GEMM's LDS tiles (EpiSplitSlabCs: one row of
+// `colsum` per split, row stride colsum_ld) -- no separate pass over A.  *fused = false: the shape does not go through
+// the LDS-DMA kernel (or there are more splits than rows in the caller's column-sum buffer) and the caller needs
+// fr_colsum_enqueue as before.
+int gram_lower_colsum_enqueue(vb_ctx* ctx, const double* A, const double* B, int64_t ld, int d, int64_t n, int splits,
+                              double* Cpart, int64_t ldc, int64_t slab, double* colsum, int64_t colsum_ld,
+                              int colsum_rows, bool* fused) {
+  GemmArgs g3;
+  g3.A = A;
+  g3.lda = ld;
+  g3.B = B;
+  g3.ldb = ld;
+  g3.M = d;
+  g3.N = d;
+  g3.K = (int)n;
+  g3.tri_mode = 2;
+  *fused = n % kGemmBK == 0 && gemm_uses_dma(g3) && splits <= colsum_rows;
+  if (*fused)
+    gemm_f64_launch<false>(ctx->stream, g3, splits, ctx->prop.multiProcessorCount,
+                           EpiSplitSlabCs{Cpart, ldc, slab, colsum, colsum_ld});
+  else
+    gemm_f64_launch<false>(ctx->stream, g3, splits, ctx->prop.multiProcessorCount, EpiSplitSlab{Cpart, ldc, slab});
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }

@@ -443,20 +443,8 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
                      base + L.o_x, L.ld, base + L.o_zp, L.ldk, L.ldt);
   VB_HIP(ctx, hipGetLastError());
   VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 0, base + L.o_lq + mine));
-  VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_f + mine));
-  {
-    const ModelDev saved = ctx->model;
-    ModelDev prior;
-    prior.id = VB_MODEL_GAUSS_DIAG;
-    prior.dim = (int)d;
-    prior.c0 = c0p;
-    prior.p0 = base + L.o_prior;
-    prior.p1 = base + L.o_prior + L.ld;
-    ctx->model = prior;
-    const int rc = model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lpr + mine);
-    ctx->model = saved;
-    VB_TRY(rc);
-  }
+  VB_TRY(model_and_prior_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_f + mine, base + L.o_prior,
+                                   base + L.o_prior + L.ld, c0p, base + L.o_lpr + mine));
   if (ctx->comm) {
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_f, mine, n, n_total));
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));

@@ -51,6 +51,32 @@ struct EpiSubVec {          // E = acc - c   (c = mu L^-T)
   }
 };
 
+struct EpiStoreScaled {     // U = r_row * acc, UA = a_row * U (the two operands of the weighted Gram product in one epilogue)
+  double* U;
+  double* UA;
+  int64_t ld;
+  const double* w;          // a_row = w_row c_row: the weight and c_n = (df + D)/(df + maha_n) of the score
+  const double* c;
+  const double* r;          // nullptr: r_row = 1
+  __device__ void operator()(int, int row, int col, double acc) const {
+    const double u = r ? r[row] * acc : acc;
+    U[(int64_t)row * ld + col] = u;
+    UA[(int64_t)row * ld + col] = (w[row] * c[row]) * u;
+  }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    const double ar = w[row] * c[row];
+    if (r) {
+      const double rr = r[row];
+      a0 *= rr;
+      a1 *= rr;
+    }
+    const d2v v = (d2v){a0, a1};
+    *reinterpret_cast<d2v*>(U + (int64_t)row * ld + col) = v;
+    *reinterpret_cast<d2v*>(UA + (int64_t)row * ld + col) = (d2v){ar * a0, ar * a1};
+    return v;
+  }
+};
+
 struct EpiStore {
   double* U;
   int64_t ld;
@@ -69,73 +95,68 @@ __device__ __forceinline__ double mvt_wave_sum(double x) {
 }
 
 // one wave per row: maha_n = |E'_n|^2, log q_n
+// (rs != nullptr: the rows of E are rs_n times what is stored -- the noise matrix itself, see mvt_residuals)
 __global__ void __launch_bounds__(256) mvt_rows_kernel(const double* __restrict__ E, int64_t ld, int64_t n, int d,
                                                        double df, double lq_const, double* __restrict__ maha,
-                                                       double* __restrict__ lq) {
+                                                       double* __restrict__ lq, const double* __restrict__ rs,
+                                                       double* __restrict__ cn) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const double* e = E + row * ld;
   double s = 0.0;
-  for (int c = lane; c < d; c += 64) s = fma(e[c], e[c], s);
+  if (rs) {
+    const double r = rs[row];
+    for (int c = lane; c < d; c += 64) {
+      const double v = e[c] * r;          // the value the stored residual had: same rounding as before
+      s = fma(v, v, s);
+    }
+  } else {
+    for (int c = lane; c < d; c += 64) s = fma(e[c], e[c], s);
+  }
   s = mvt_wave_sum(s);
   if (lane == 0) {
     maha[row] = s;
     lq[row] = df > 0.0 ? lq_const - 0.5 * (df + d) * log1p(s / df) : lq_const - 0.5 * s;   // df = 0: Gaussian limit
+    cn[row] = df > 0.0 ? (df + d) / (df + s) : 1.0;      // c_n of the score: d log q / d mu = c_n u_n
   }
 }
 
-// UA[n][j] = a_n U[n][j], a_n = w_n (df + D)/(df + maha_n); per-block partial sums of w and w * log q
-__global__ void __launch_bounds__(256) mvt_scale_kernel(const double* __restrict__ U, double* __restrict__ UA,
-                                                        int64_t ld, int64_t n, int d, double df,
-                                                        const double* __restrict__ w,
-                                                        const double* __restrict__ maha,
-                                                        const double* __restrict__ lq, double* __restrict__ part) {
-  __shared__ double sh[2][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+// (sum w, sum w log q) in one workgroup, fixed order; eight loads of each vector in flight per thread (a plain strided
+// loop pays one memory round trip per 1024 elements: 16 us at N = 16 384)
+__global__ void __launch_bounds__(1024) mvt_wsums_kernel(const double* __restrict__ w, const double* __restrict__ lq,
+                                                         int64_t n, double* __restrict__ out) {
+  __shared__ double sh[2][16];
   double sw = 0.0, swl = 0.0;
-  if (row < n) {
-    const double wn = w[row];
-    const double a = df > 0.0 ? wn * (df + d) / (df + maha[row]) : wn;
-    const double* u = U + row * ld;
-    double* ua = UA + row * ld;
-    for (int c = lane; c < d; c += 64) ua[c] = a * u[c];
-    if (lane == 0) {
-      sw = wn;
-      swl = wn * lq[row];
+  for (int64_t i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
+    double wv[8], lv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = i0 + u * 1024;
+      wv[u] = i < n ? w[i] : 0.0;
+      lv[u] = i < n ? lq[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      sw += wv[u];
+      swl = fma(wv[u], lv[u], swl);
     }
   }
-  if (lane == 0) {
-    sh[0][wave] = sw;
-    sh[1][wave] = swl;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    part[2 * (int64_t)blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-    part[2 * (int64_t)blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
-  }
-}
-
-// sum the (sum w, sum w log q) partials
-__global__ void __launch_bounds__(256) mvt_scalar_kernel(const double* __restrict__ part, int64_t n_part,
-                                                         double* __restrict__ out) {
-  __shared__ double sh[2][4];
-  double a = 0.0, b = 0.0;
-  for (int64_t i = threadIdx.x; i < n_part; i += 256) {
-    a += part[2 * i];
-    b += part[2 * i + 1];
-  }
-  a = mvt_wave_sum(a);
-  b = mvt_wave_sum(b);
+  sw = mvt_wave_sum(sw);
+  swl = mvt_wave_sum(swl);
   if ((threadIdx.x & 63) == 0) {
-    sh[0][threadIdx.x >> 6] = a;
-    sh[1][threadIdx.x >> 6] = b;
+    sh[0][threadIdx.x >> 6] = sw;
+    sh[1][threadIdx.x >> 6] = swl;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    out[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-    out[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      t0 += sh[0][k];
+      t1 += sh[1][k];
+    }
+    out[0] = t0;
+    out[1] = t1;
   }
 }
 
@@ -185,7 +206,7 @@ static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t d) 
   L.o_scal = carve(32);
   L.o_cpart = carve((int64_t)L.splits * sq);
   L.o_col = carve((int64_t)L.n_rb * L.ld);
-  L.o_part = carve(2 * ((n + 3) / 4) + (int64_t)L.n_rb * ((d + 63) / 64));
+  L.o_part = carve(n + 2 * ((n + 3) / 4) + (int64_t)L.n_rb * ((d + 63) / 64));    // [a_n | ... | f partials]
   L.S.off_col = 16;
   L.S.off_c = 16 + L.ld;
   L.S.len = 16 + L.ld + sq;
@@ -308,16 +329,6 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
 // E' = (X - mu) L^-T, maha, log q for the parameter `theta_host` with inverse factor `linv_host`
 // (linv_host == nullptr: the factors come from theta on the device, mvt_factors_device -- unless the caller has just
 // run it: factors_ready)
-// E[n][c] = Z[n][c] / s_n: the residuals (x_n - mu) L^-T of samples that were drawn as x = mu + (z L') / s at this very
-// parameter ARE the scaled noise -- no N x D x D product
-__global__ void __launch_bounds__(256) mvt_noise_resid_kernel(const double* __restrict__ Z, int64_t ldz,
-                                                              const double* __restrict__ inv_s, int64_t n, int d,
-                                                              double* __restrict__ E, int64_t lde) {
-  const int64_t row = blockIdx.x;
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  if (row < n && c < lde) E[row * lde + c] = c < d ? Z[row * ldz + c] * inv_s[row] : 0.0;
-}
-
 static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t n, int64_t d, double df,
                          const double* theta_host, const double* linv_host, int64_t lq_off, bool factors_ready = false,
                          const NoiseSlot* drawn_here = nullptr) {
@@ -351,11 +362,12 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
   } else if (!factors_ready) {
     VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
   }
-  if (drawn_here) {      // throughput-mode refresh: the state samples were just drawn through this parameter's factor
-    hipLaunchKernelGGL(mvt_noise_resid_kernel, dim3((unsigned)n, (unsigned)((L.ld + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const double*)drawn_here->buf.ptr, drawn_here->ld, (const double*)(base + L.o_invs), n, (int)d,
-                       base + L.o_e, L.ld);
-  } else {
+  // throughput-mode refresh: the state samples were just drawn through this parameter's factor, x = mu + (z L') / s, so
+  // their residuals (x - mu) L^-T ARE the scaled noise z / s -- no product, and no copy either: the consumers (the row
+  // kernel below, the U = E' L^-1 product of the gradient) read the noise matrix and scale by 1 / s_n themselves
+  ctx->mvt_e_noise = drawn_here ? (const double*)drawn_here->buf.ptr : nullptr;
+  ctx->mvt_e_noise_ld = drawn_here ? drawn_here->ld : 0;
+  if (!drawn_here) {
     GemmArgs g;
     g.A = base + L.o_x;
     g.lda = L.ld;
@@ -372,8 +384,9 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
                               ? lgamma(0.5 * (df + d)) - lgamma(0.5 * df) - 0.5 * d * log(M_PI * df) - logdet_half
                               : -0.5 * d * log(2.0 * M_PI) - logdet_half;
   hipLaunchKernelGGL(mvt_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
-                     (const double*)(base + L.o_e), L.ld, n, (int)d, df, lq_const, base + L.o_maha,
-                     base + L.o_lq + lq_off);
+                     drawn_here ? ctx->mvt_e_noise : (const double*)(base + L.o_e), drawn_here ? drawn_here->ld : L.ld, n,
+                     (int)d, df, lq_const, base + L.o_maha, base + L.o_lq + lq_off,
+                     drawn_here ? (const double*)(base + L.o_invs) : (const double*)nullptr, base + L.o_part);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -398,26 +411,39 @@ __global__ void __launch_bounds__(1024) mvt_cdf_kernel(const double* __restrict_
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (t == 0) carry_sh = 0.0;
   __syncthreads();
-  for (int64_t b = 0; b < n; b += 1024) {
-    const int64_t i = b + t;
-    double v = i < n ? w[i] : 0.0;
+  // (sixteen blocks' worth of loads are issued before the first scan: the scans are sequential, the memory round trips
+  // need not be -- 24 -> 12 us at N = 16 384)
+  for (int64_t b0 = 0; b0 < n; b0 += 16 * 1024) {
+    double vals[16];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double u = __shfl_up(v, off, 64);
-      if (lane >= off) v += u;
+    for (int k = 0; k < 16; ++k) {
+      const int64_t i = b0 + k * 1024 + t;
+      vals[k] = i < n ? w[i] : 0.0;
     }
-    if (lane == 63) wave_tot[wv] = v;
-    __syncthreads();
-    double before = carry_sh;
-    for (int q = 0; q < wv; ++q) before += wave_tot[q];
-    v += before;
-    if (i < n) {
-      cdf[i] = v;
-      counts[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int64_t b = b0 + k * 1024;
+      if (b >= n) break;                    // uniform for the workgroup
+      const int64_t i = b + t;
+      double v = vals[k];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double u = __shfl_up(v, off, 64);
+        if (lane >= off) v += u;
+      }
+      if (lane == 63) wave_tot[wv] = v;
+      __syncthreads();
+      double before = carry_sh;
+      for (int q = 0; q < wv; ++q) before += wave_tot[q];
+      v += before;
+      if (i < n) {
+        cdf[i] = v;
+        counts[i] = 0;
+      }
+      __syncthreads();
+      if (t == 1023) carry_sh = v;
+      __syncthreads();
     }
-    __syncthreads();
-    if (t == 1023) carry_sh = v;
-    __syncthreads();
   }
   if (t == 0) total[0] = carry_sh;
 }
@@ -529,20 +555,9 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   VB_HIP(ctx, hipGetLastError());
 
   VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors, dev_factors ? &ns : nullptr));
-  VB_TRY(model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine));
-  {   // tempering prior: a diagonal Gaussian evaluated by the same row kernel
-    const ModelDev saved = ctx->model;
-    ModelDev prior;
-    prior.id = VB_MODEL_GAUSS_DIAG;
-    prior.dim = (int)d;
-    prior.c0 = c0p;
-    prior.p0 = base + L.o_prior;
-    prior.p1 = base + L.o_prior + L.ld;
-    ctx->model = prior;
-    const int rc = model_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lprior + mine);
-    ctx->model = saved;
-    VB_TRY(rc);
-  }
+  // model and tempering prior (a diagonal Gaussian) in one pass over the samples
+  VB_TRY(model_and_prior_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine, base + L.o_prior,
+                                   base + L.o_prior + L.ld, c0p, base + L.o_lprior + mine));
   if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lp, mine, n, n_total));
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));
@@ -662,34 +677,35 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   }
   // U = E' L^-1
   GemmArgs g;
-  g.A = base + L.o_e;
-  g.lda = L.ld;
+  g.A = ctx->mvt_e_noise ? ctx->mvt_e_noise : base + L.o_e;
+  g.lda = ctx->mvt_e_noise ? ctx->mvt_e_noise_ld : L.ld;
   g.B = base + L.o_li;
   g.ldb = L.ld;
   g.M = (int)n;
   g.N = (int)d;
   g.K = (int)d;
   g.tri_mode = 3;          // L^-1 is lower triangular: B[k][j] == 0 for k < j -- half the product
-  gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{base + L.o_u, L.ld});
-  VB_HIP(ctx, hipGetLastError());
-  const int64_t n_part = (n + 3) / 4;
-  hipLaunchKernelGGL(mvt_scale_kernel, dim3((unsigned)n_part), dim3(256), 0, st, (const double*)(base + L.o_u),
-                     base + L.o_ua, L.ld, n, (int)d, df, wdev,
-                     (const double*)(base + L.o_maha), (const double*)(base + L.o_lq), base + L.o_part);
-  VB_HIP(ctx, hipGetLastError());
   FrSums S = L.S;
   S.sums = base + L.o_sums;
-  // (sum w, sum w log q) ride in slots 1 and 2 of the sum vector so that one all-reduce covers everything
-  hipLaunchKernelGGL(mvt_scalar_kernel, dim3(1), dim3(256), 0, st, (const double*)(base + L.o_part), n_part,
-                     S.sums + 1);
+  // (sum w, sum w log q) ride in slots 1 and 2 of the sum vector so that one all-reduce covers everything; U and its
+  // row-scaled copy a_n U (a_n = w_n c_n, c_n left behind by the residual pass) leave the GEMM together
+  const int64_t n_part = (n + 3) / 4;
+  const double* cn = base + L.o_part;       // n doubles, written by mvt_rows_kernel
+  hipLaunchKernelGGL(mvt_wsums_kernel, dim3(1), dim3(1024), 0, st, wdev, (const double*)(base + L.o_lq), n, S.sums + 1);
+  gemm_f64_launch<true>(st, g, 1, n_cu, EpiStoreScaled{base + L.o_u, base + L.o_ua, L.ld, wdev, cn,
+                                                       ctx->mvt_e_noise ? (const double*)(base + L.o_invs) : nullptr});
   VB_HIP(ctx, hipGetLastError());
-  double* fpart = base + L.o_part + 2 * n_part;
-  VB_TRY(fr_colsum_enqueue(ctx, base + L.o_ua, nullptr, L.ld, n, (int)d, 0, nullptr, base + L.o_col, fpart));
+  double* fpart = base + L.o_part + n + 2 * n_part;
   const int64_t slab = d * L.ld;
-  VB_TRY(gram_lower_enqueue(ctx, base + L.o_ua, base + L.o_u, L.ld, (int)d, n, L.splits, base + L.o_cpart, L.ld,
-                            slab));
-  VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col, L.n_rb, L.ld, fpart,
-                           L.n_rb * (int)((d + 127) / 128), S));
+  // weighted Gram product U' diag(a) U (lower tiles) with the column sums of a U out of the same kernel
+  bool cs_fused = false;
+  VB_TRY(gram_lower_colsum_enqueue(ctx, base + L.o_ua, base + L.o_u, L.ld, (int)d, n, L.splits, base + L.o_cpart, L.ld,
+                                   slab, base + L.o_col, L.ld, L.n_rb, &cs_fused));
+  if (!cs_fused)
+    VB_TRY(fr_colsum_enqueue(ctx, base + L.o_ua, nullptr, L.ld, n, (int)d, 0, nullptr, base + L.o_col, fpart));
+  VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col,
+                           cs_fused ? L.splits : L.n_rb, L.ld, fpart,
+                           cs_fused ? 0 : L.n_rb * (int)((d + 127) / 128), S));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
   if (packed_out) {
     // S = sym(gram), dL = tril(S L) - w_sum diag(1 / L_ii), free diagonal x L_ii: one D x D x D product and a pack kernel

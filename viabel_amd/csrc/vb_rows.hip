@@ -15,18 +15,29 @@ __device__ __forceinline__ double wave_sum_rows(double x) {
   return x;
 }
 
+// PRIOR: the same pass also evaluates a diagonal Gaussian (mean q0, inverse variances q1, constant qc) into out2 --
+// the tempering prior of DISInclusiveKL (objectives.py:316-318) next to the model, one read of the samples instead of two
+template <bool PRIOR>
 __global__ void __launch_bounds__(256) model_logp_rows_kernel(const double* __restrict__ x,
                                                               int64_t ld, int64_t n, int d,
-                                                              ModelDev m, double* __restrict__ out) {
+                                                              ModelDev m, double* __restrict__ out,
+                                                              const double* __restrict__ q0,
+                                                              const double* __restrict__ q1, double qc,
+                                                              double* __restrict__ out2) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= n) return;
   const double* xr = x + row * ld;
-  double acc = 0.0;
+  double acc = 0.0, acc2 = 0.0;
   if (m.id == VB_MODEL_GAUSS_DIAG) {
     for (int c = lane; c < d; c += 64) {
-      const double dz = xr[c] - m.p0[c];
+      const double z = xr[c];
+      const double dz = z - m.p0[c];
       acc -= 0.5 * dz * dz * m.p1[c];
+      if (PRIOR) {
+        const double dq = z - q0[c];
+        acc2 -= 0.5 * dq * dq * q1[c];
+      }
     }
   } else {   // funnel
     const double v = xr[m.k];
@@ -37,10 +48,18 @@ __global__ void __launch_bounds__(256) model_logp_rows_kernel(const double* __re
         acc += -0.5 * z * z / (m.tau * m.tau) - (double)(d - 1) * z;
       else
         acc -= 0.5 * z * z * w;
+      if (PRIOR) {
+        const double dq = z - q0[c];
+        acc2 -= 0.5 * dq * dq * q1[c];
+      }
     }
   }
   acc = wave_sum_rows(acc);
-  if (lane == 0) out[row] = acc + m.c0;
+  if (PRIOR) acc2 = wave_sum_rows(acc2);
+  if (lane == 0) {
+    out[row] = acc + m.c0;
+    if (PRIOR) out2[row] = acc2 + qc;
+  }
 }
 
 // ---- dense targets: f needs a GEMM -----------------------------------------------------------------
@@ -320,10 +339,35 @@ int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL)
     return fail(ctx, VB_ERR_UNSUPPORTED, "row log-density: unknown model id %d", ctx->model.id);
   const unsigned grid = (unsigned)((n + 3) / 4);
-  hipLaunchKernelGGL(model_logp_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, x_dev, ld, n,
-                     (int)d, ctx->model, out_dev);
+  hipLaunchKernelGGL(model_logp_rows_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, x_dev, ld, n,
+                     (int)d, ctx->model, out_dev, (const double*)nullptr, (const double*)nullptr, 0.0, (double*)nullptr);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
+}
+
+// log density of the model AND of a diagonal Gaussian (mean, inverse variances, additive constant) at the same rows:
+// one pass when the model is evaluated by the row kernel, otherwise the model's own path followed by the row kernel
+int model_and_prior_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev,
+                              const double* prior_mean, const double* prior_ivar, double prior_c0, double* prior_out) {
+  if (ctx->model.id == VB_MODEL_GAUSS_DIAG || ctx->model.id == VB_MODEL_FUNNEL) {
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    hipLaunchKernelGGL(model_logp_rows_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, x_dev, ld, n, (int)d,
+                       ctx->model, out_dev, prior_mean, prior_ivar, prior_c0, prior_out);
+    VB_HIP(ctx, hipGetLastError());
+    return VB_OK;
+  }
+  VB_TRY(model_logp_rows(ctx, x_dev, ld, n, d, out_dev));
+  const ModelDev saved = ctx->model;
+  ModelDev prior;
+  prior.id = VB_MODEL_GAUSS_DIAG;
+  prior.dim = (int)d;
+  prior.c0 = prior_c0;
+  prior.p0 = prior_mean;
+  prior.p1 = prior_ivar;
+  ctx->model = prior;
+  const int rc = model_logp_rows(ctx, x_dev, ld, n, d, prior_out);
+  ctx->model = saved;
+  return rc;
 }
 
 }  // namespace vb
