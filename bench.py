@@ -299,11 +299,15 @@ def c3_leg(vb, calls=30):
         out['resampling' if resample else 'weighted'] = {
             'ms_per_call': 1e3 * dt, 'calls_per_s': 1.0 / dt, 'eps': float(obj._eps), 'ess': float(obj._ess),
             'value': float(v), 'grad_norm': float(np.linalg.norm(g))}
-    # executed work of one refresh + gradient: sample GEMM, residual GEMM (x2: refresh and gradient), Gram (lower)
-    flops = 3 * 2.0 * N * D * D + float(N) * D * (D + 1)
+    # executed work of one refresh + gradient in this mode: the sample GEMM through L' (triangular), U = E' L^-1
+    # (triangular; the residuals E' of freshly drawn samples are the scaled noise: no product) and the weighted Gram
+    # product (lower tiles) -- three half products
+    flops = 3.0 * N * D * (D + 1)
     out['flops_executed_per_call'] = flops
-    out['note'] = ('the call is bound by launch latency and the host side of the O(D^3) factor algebra, not by the '
-                   '%.1f GFLOP of MFMA work (%.0f us at the dense GEMM rate)' % (flops / 1e9, flops / 57e12 * 1e6))
+    out['note'] = ('about 45 dependent kernels per call, everything including the O(D^3) factor algebra on the device; ten of '
+                   'them are the tempering bisection (50 levels, 96 us), the three GEMMs take 100 us for %.1f GFLOP '
+                   '(%.0f us at the dense GEMM rate): the call is bound by dependent launches, not by the matrix pipe; '
+                   'per-kernel times: profiles/r03_c3_kernel_stats.txt' % (flops / 1e9, flops / 57e12 * 1e6))
     return out
 
 
