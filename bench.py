@@ -387,9 +387,7 @@ __device__ T vb_log_density(vb::vec<T> z, int d, const double* p) {
   T f = 0.0;
   for (int j = 0; j < d; ++j) f -= 0.5 * z[j] * z[j] / (tau * tau);
   for (int i = 0; i < n; ++i) {
-    T eta = 0.0;
-    for (int j = 0; j < d; ++j) eta += X[(long long)i * d + j] * z[j];
-    const T r = y[i] - eta;
+    const T r = y[i] - vb::dot(X + (long long)i * d, z, d);
     f -= 0.5 * (nu + 1.0) * log(1.0 + r * r / (nu * s * s));
   }
   return f;
@@ -424,22 +422,30 @@ def source_model_leg(vb, calls=100):
                      'grad_norm': float(np.linalg.norm(g))}
     # the same density with nothing but the density written down (grad='auto': forward-mode dual numbers on the device,
     # ceil(D / 8) threads per sample) -- what it costs next to the hand-written gradient
-    auto = vb.SourceModel(D, SOURCE_LEG_AUTO_SRC, model.params, grad='auto')
+    # grad='auto': the density alone.  Twice: the linear predictor as vb::dot(row, z, d) (one operation of the dual
+    # arithmetic, shared by the sample's threads) and as a plain loop over dual numbers
+    loop_src = SOURCE_LEG_AUTO_SRC.replace('const T r = y[i] - vb::dot(X + (long long)i * d, z, d);',
+                                           'T eta = 0.0;\n    for (int j = 0; j < d; ++j) eta += X[(long long)i * d + j] * z[j];\n'
+                                           '    const T r = y[i] - eta;')
+    assert 'vb::dot' not in loop_src
     xs = rng.randn(16, D)
-    out['auto_gradient'] = {'max_rel_diff_vs_hand_written': float(np.max(np.abs(auto.grad(xs) - model.grad(xs)))
-                                                                   / np.max(np.abs(model.grad(xs))))}
-    fam = vb.MFGaussian(D, rng='philox')
-    obj = vb.ExclusiveKL(fam, auto, N)
-    theta = fam.init_param()
-    theta[D:] = -1.0
-    for _ in range(3):
-        obj(theta)
-    t0 = time.perf_counter()
-    for _ in range(20):
-        obj(theta)
-    out['auto_gradient']['mf_gaussian_us_per_call'] = 1e6 * (time.perf_counter() - t0) / 20
-    out['auto_gradient']['cost_ratio_vs_hand_written_8_threads'] = (out['auto_gradient']['mf_gaussian_us_per_call']
-                                                                    / out['mf_gaussian']['us_per_call'])
+    out['auto_gradient'] = {}
+    for key, src in (('', SOURCE_LEG_AUTO_SRC), ('plain_loop_', loop_src)):
+        auto = vb.SourceModel(D, src, model.params, grad='auto')
+        out['auto_gradient'][key + 'max_rel_diff_vs_hand_written'] = float(
+            np.max(np.abs(auto.grad(xs) - model.grad(xs))) / np.max(np.abs(model.grad(xs))))
+        fam = vb.MFGaussian(D, rng='philox')
+        obj = vb.ExclusiveKL(fam, auto, N)
+        theta = fam.init_param()
+        theta[D:] = -1.0
+        for _ in range(3):
+            obj(theta)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            obj(theta)
+        out['auto_gradient'][key + 'mf_gaussian_us_per_call'] = 1e6 * (time.perf_counter() - t0) / 20
+        out['auto_gradient'][key + 'cost_ratio_vs_hand_written_8_threads'] = (
+            out['auto_gradient'][key + 'mf_gaussian_us_per_call'] / out['mf_gaussian']['us_per_call'])
     z = rng.randn(N, D)
     t0 = time.perf_counter()
     r = y[None, :] - z @ X.T

@@ -42,6 +42,19 @@ def main():
     assert lib.vb_create(1 << 20, ctypes.byref(ctx)) != 0 and not ctx.value
     assert lib.vb_comm_unique_id(None) != 0
     assert isinstance(lib.vb_last_error(None), bytes) and lib.vb_version().startswith(b'viabel_hip')
+    # the host-side generator (no context): NULL handles / outputs are rejected, destroy(NULL) is a no-op
+    h = ctypes.c_void_p()
+    assert lib.vb_legacy_rng_create(1, None) != 0
+    assert lib.vb_legacy_rng_create(1, ctypes.byref(h)) == 0 and h.value
+    for fn, args in (('vb_legacy_rng_randn', (None, None, 4, 0)), ('vb_legacy_rng_randn', (h, None, 4, 0)),
+                     ('vb_legacy_rng_randn', (h, None, -1, 0)), ('vb_legacy_rng_standard_t', (h, 0.0, None, 0)),
+                     ('vb_legacy_rng_chisquare', (None, 1.0, None, 1)), ('vb_legacy_rng_random_sample', (h, None, 2)),
+                     ('vb_legacy_rng_get_state', (h, None, None, None, None)),
+                     ('vb_legacy_rng_set_state', (h, None, 0, 0, 0.0))):
+        if getattr(lib, fn)(*args) == 0:
+            bad.append((fn, 0))
+    lib.vb_legacy_rng_destroy(h)
+    lib.vb_legacy_rng_destroy(None)
     if bad:
         print('entry points that did not reject a NULL context:', bad)
         return 1

@@ -11,4 +11,4 @@ export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1
 export UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
 export LD_PRELOAD=$rt
 python tests/cabi_null_probe.py
-python -m pytest tests/test_cabi_symbols.py tests/test_cabi_null_ctx.py -q -p no:cacheprovider
+python -m pytest tests/test_cabi_symbols.py tests/test_cabi_null_ctx.py tests/test_legacy_rng_cpu.py -q -p no:cacheprovider

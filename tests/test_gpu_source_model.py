@@ -613,6 +613,24 @@ def test_source_model_auto_gradient_matches_hand_written(vb, D, n_data):
     assert auto.check_gradient(x[:4]) < 1e-6
 
 
+@pytest.mark.parametrize('D,n_data', [(7, 40), (16, 40), (24, 96), (30, 64), (64, 96), (130, 64)])
+def test_source_model_auto_gradient_with_dot_helper(vb, D, n_data):
+    """`vb::dot(row, z, d)`: the linear predictor as ONE operation of the dual arithmetic -- its derivative with respect
+    to the thread's 8 coordinates is the row itself.  Same density, same gradient.  D = 16, 30, 64: 2 / 4 / 8 threads per
+    sample, a power of two -- the threads share the product through a lane butterfly (D = 30: ragged last window);
+    D = 7, 24, 130: 1 / 3 / 17 threads, every thread forms the whole product."""
+    model, omodel = _problem(vb, D, n_data)
+    src = ROBUST_REGRESSION_AUTO_SRC.replace('''    T eta = 0.0;
+    for (int j = 0; j < d; ++j) eta += X[(long long)i * d + j] * z[j];
+    const T r = y[i] - eta;''', '    const T r = y[i] - vb::dot(X + (long long)i * d, z, d);')
+    assert 'vb::dot' in src
+    auto = vb.SourceModel(D, src, model.params, grad='auto')
+    x = np.random.RandomState(D + 1).randn(50, D)
+    assert G.rel_err(auto(x), omodel.logp(x)) < 1e-13
+    assert G.rel_err(auto.grad(x), omodel.grad(x)) < 1e-12
+    assert auto.check_gradient(x[:4]) < 1e-6
+
+
 @pytest.mark.parametrize('family', ['mf_gaussian', 'fullrank'])
 def test_source_model_auto_gradient_under_exclusive_kl(vb, family):
     D, N, n_data = 20, 1024, 64

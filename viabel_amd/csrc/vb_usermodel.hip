@@ -87,6 +87,19 @@ const Rtc* rtc_load() {
 // exact to rounding (no step size).  A value-only call (grad == NULL) instantiates the density with T = double.
 const char* const kAutoHeader = R"VBSRC(
 #define VB_DUAL_K 8
+// threads per sample: one per window of VB_DUAL_K coordinates; a density that uses vb::dot (VB_PAD_CHUNKS, set by the host
+// when the source mentions it) gets the next power of two -- the surplus threads own empty windows -- so that the
+// sample's lanes can share the products through a butterfly
+constexpr int vb_chunks_of(int dim) {
+  int c = (dim + VB_DUAL_K - 1) / VB_DUAL_K;
+#ifdef VB_PAD_CHUNKS
+  int p = 1;
+  while (p < c) p <<= 1;
+  if (p <= 64) c = p;
+#endif
+  return c;
+}
+#define VB_CHUNKS vb_chunks_of(VB_USER_DIM_ANY)
 namespace vb {
 struct dual {
   double v;
@@ -209,16 +222,51 @@ template <> struct vec<dual> {
     return r;
   }
 };
+// sum_j a[j] z[j] over the whole sample (the linear predictor of a regression row): z[j] has derivative e_j, so the
+// derivative part of the product is a[lo .. lo + K - 1] itself -- d multiply-adds and K loads per pass instead of the
+// (K + 1) d a loop over dual numbers costs
+__device__ inline double dot(const double* a, const vec<double>& z, int d) {
+  double s = 0.0;
+  for (int j = 0; j < d; ++j) s = fma(a[j], z.p[j], s);
+  return s;
+}
+// The threads of one sample (consecutive lanes, see the wrapper) all call this with the same row: when their number is a
+// power of two each forms the partial product over ITS window -- the very a[lo .. lo + K - 1] that are its derivative
+// part -- and a butterfly over the sample's lanes adds them up (x + y == y + x: every lane gets the same bits), so a
+// row costs every thread K loads and K multiply-adds instead of d of each.
+__device__ inline dual dot(const double* a, const vec<dual>& z, int d) {
+  constexpr int C = VB_CHUNKS;                  // threads per sample
+  dual r;
+  double s = 0.0;
+  if constexpr (C > 1 && C <= 64 && (C & (C - 1)) == 0) {
+#pragma unroll
+    for (int k = 0; k < VB_DUAL_K; ++k) {
+      const int j = z.lo + k;
+      const double aj = j < d ? a[j] : 0.0;
+      r.d[k] = aj;
+      s = fma(aj, j < d ? z.p[j] : 0.0, s);
+    }
+#pragma unroll
+    for (int off = 1; off < C; off <<= 1) s += __shfl_xor(s, off, 64);
+    r.v = s;
+    return r;
+  }
+  for (int j = 0; j < d; ++j) s = fma(a[j], z.p[j], s);
+  r.v = s;
+#pragma unroll
+  for (int k = 0; k < VB_DUAL_K; ++k) r.d[k] = z.lo + k < d ? a[z.lo + k] : 0.0;
+  return r;
+}
 }  // namespace vb
 #line 1
 )VBSRC";
 
 const char* const kAutoWrapper = R"VBSRC(
-extern "C" __device__ int vb_user_parts_k = (VB_USER_DIM_ANY + VB_DUAL_K - 1) / VB_DUAL_K;
+extern "C" __device__ int vb_user_parts_k = VB_CHUNKS;
 extern "C" __global__ void __launch_bounds__(64) vb_user_rows(const double* __restrict__ Z, long long ldz, long long n, int d,
                                         const double* __restrict__ params, double* __restrict__ G, long long ldg,
                                         double* __restrict__ f) {
-  constexpr int C = (VB_USER_DIM_ANY + VB_DUAL_K - 1) / VB_DUAL_K;
+  constexpr int C = VB_CHUNKS;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long row = t / C;
   const int chunk = (int)(t % C);
@@ -327,7 +375,9 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
     return user_model_bind(ctx, dim, params, n_params);
   }
   const std::string full =
-      auto_grad ? "#define VB_USER_DIM_ANY " + std::to_string(dim) + "\n" + kAutoHeader + std::string(source) + "\n" + kAutoWrapper
+      auto_grad ? "#define VB_USER_DIM_ANY " + std::to_string(dim) + "\n" +
+                      (std::string(source).find("vb::dot") != std::string::npos ? "#define VB_PAD_CHUNKS 1\n" : "") + kAutoHeader +
+                      std::string(source) + "\n" + kAutoWrapper
                 : "#define VB_USER_DIM " + std::to_string(priv_dim) + "\n#line 1\n" + std::string(source) + "\n" + kWrapper;
   hiprtcProgram prog = nullptr;
   if (rtc->create(&prog, full.c_str(), "vb_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)

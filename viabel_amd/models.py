@@ -124,7 +124,9 @@ class SourceModel(DeviceModel):
     ``grad='auto'`` the source gives only the density, generic in its scalar type --
     ``template <class T> __device__ T vb_log_density(vb::vec<T> z, int d, const double* params);`` (``z[j]`` is a ``T``;
     ``+ - * /``, comparisons, ``log exp sqrt log1p expm1 pow tanh sin cos atan erf fabs fmin fmax lgamma`` work on ``T``
-    and mix with ``double``) -- and the engine differentiates it like autograd does the reference's callable
+    and mix with ``double``; ``vb::dot(row, z, d)`` is the inner product of a ``const double*`` row with the whole sample
+    as one operation -- the cheap way to write a regression's linear predictor) -- and the engine differentiates it like
+    autograd does the reference's callable
     (``models.py:17-39``): forward-mode dual numbers carrying 8 derivatives in registers, ``ceil(dim / 8)`` threads
     per sample, exact to rounding.  The source is
     compiled for the GPU with hiprtc when the model is first bound; a source that does not compile raises
