@@ -71,4 +71,6 @@ def test_two_ranks_on_one_gpu_match_one_rank(tmp_path):
         assert np.array_equal(ranks[0][name + '__v'], ranks[1][name + '__v']), name
         assert np.array_equal(ranks[0][name + '__g'], ranks[1][name + '__g']), name
     bad = {k: e for k, e in worst.items() if not e < (1e-9 if k.startswith('fit_') else 1e-11)}
-    assert not bad, (bad, worst)
+    print('two ranks vs one: %d scenarios, worst relative differences: %s'
+          % (len(worst), ', '.join('%s %.1e' % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1])[:6])))
+    assert len(worst) >= 24 and not bad, (bad, worst)
