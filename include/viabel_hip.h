@@ -235,8 +235,13 @@ int vb_dis_grad_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const d
  * want to look at them.  The weight clipping of objectives.py:370-386 is the identity for thresholds >= 1 (the
  * default is 10): callers with a smaller threshold use the two-call path.                                      */
 int vb_dis_step_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, int64_t resample_m,
-                           uint64_t seed, uint64_t stream, double scale, double* eps, double* ess, double* value,
-                           double* grad);
+                           uint64_t seed, uint64_t stream, double scale, double* eps, double* ess,
+                           double* khat /* NULL, or the tail shape of the last vb_dis_psis_mvt */, double* value, double* grad);
+/* Between the two: Pareto smoothing of the device-resident tempered weights, w -> sum(w) exp(psislw(log w)) in place
+ * (`DISInclusiveKL(psis_smooth=True)`: BASELINE configs[3] asks for "DISInclusiveKL with PSIS reweighting"; the smoothing
+ * is viabel/_psis.py:113-209 as vb_psis_smooth does it).  Enqueues only; the step that follows uses the smoothed weights
+ * and reports khat. */
+int vb_dis_psis_mvt(vb_ctx* ctx, int64_t n_total, double reff);
 int vb_dis_weights_get(vb_ctx* ctx, double* w, int64_t n_total, int resampled /* 1: the counts of the last draw */);
 /* The DIS state samples live in the context, one set per family kind (0: mean-field, 1: MultivariateT / dense
  * Gaussian, 2: low-rank Gaussian); every refresh of a kind overwrites its set and bumps its generation counter.  A

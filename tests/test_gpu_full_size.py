@@ -97,7 +97,7 @@ class CholeskySampledT(ofam.MultivariateT):
         return mu + (z @ np.linalg.cholesky(S).T) / np.sqrt(chi / self.df)[:, None]
 
 
-@pytest.mark.parametrize('use_resampling,psis_smooth', [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize('use_resampling,psis_smooth', [(False, False), (True, False), (False, True), (True, True)])
 def test_c3_multivariate_t_dis_full_size_throughput_mode(vb, use_resampling, psis_smooth):
     """BASELINE configs[3] at full size through the path bench.py's c3_mvt_dis leg TIMES: rng='philox' (normals and
     chi-square draws on the device), Cholesky sampling, device factor algebra and the packed chain rule

@@ -8,6 +8,7 @@ mkdir -p /tmp/vbvar_$name
 for f in *.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $extra -c $f -o /tmp/vbvar_$name/${f%.hip}.o &
 done
+/opt/rocm/bin/hipcc -x c++ -O3 -std=c++17 -fPIC -ffp-contract=off -pthread -Wall -c vb_legacy_rng.cpp -o /tmp/vbvar_$name/vb_legacy_rng.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/vbvar_$name/*.o -shared -L/opt/rocm/lib -lrccl -ldl -Wl,-rpath,/opt/rocm/lib -o ../../tools/libviabel_hip_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/vbvar_$name/*.o -shared -L/opt/rocm/lib -lrccl -ldl -pthread -Wl,-rpath,/opt/rocm/lib -o ../../tools/libviabel_hip_$name.so
 ls -la ../../tools/libviabel_hip_$name.so

@@ -63,7 +63,8 @@ SIGNATURES = {
                                              _c_double_p, _c_double_p, _c_double_p]),
     'vb_dis_step_mvt_packed': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p, ctypes.c_int64,
                                               ctypes.c_uint64, ctypes.c_uint64, ctypes.c_double, _c_double_p, _c_double_p,
-                                              _c_double_p, _c_double_p]),
+                                              _c_double_p, _c_double_p, _c_double_p]),
+    'vb_dis_psis_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_double]),
     'vb_dis_weights_get': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int]),
     'vb_noise_moments': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_elbo_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
@@ -583,12 +584,18 @@ class Engine:
         """``(value, grad, eps, ess)``: gradient of ``-scale sum w log q`` on the device-resident tempered weights, or
         on ``resample_m`` multinomial draws from them (then ``scale`` multiplies ``sum w`` on the device)."""
         theta = _f64(theta)
-        value, eps, ess = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        value, eps, ess, khat = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
         grad = np.empty(theta.size, dtype=np.float64)
         self._check(self._lib.vb_dis_step_mvt_packed(
             self._ctx, n, d, float(df), _dptr(theta), int(resample_m), int(seed), int(stream), float(scale),
-            ctypes.byref(eps), ctypes.byref(ess), ctypes.byref(value), _dptr(grad)))
+            ctypes.byref(eps), ctypes.byref(ess), ctypes.byref(khat), ctypes.byref(value), _dptr(grad)))
+        self.last_khat = khat.value          # tail shape of the last dis_psis_mvt (0.0 without one)
         return value.value, grad, eps.value, ess.value
+
+    def dis_psis_mvt(self, n_total, reff=1.0):
+        """Enqueue the Pareto smoothing of the device-resident tempered weights (between ``dis_refresh_mvt_deferred``
+        and ``dis_step_mvt_packed``; ``last_khat`` after the step)."""
+        self._check(self._lib.vb_dis_psis_mvt(self._ctx, int(n_total), float(reff)))
 
     def dis_weights_get(self, n_total, resampled=False):
         w = np.empty(n_total, dtype=np.float64)

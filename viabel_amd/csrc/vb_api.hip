@@ -709,6 +709,15 @@ int vb_psis_smooth(vb_ctx* ctx, const double* lw_in, int64_t n, double reff, dou
   VB_HIP(ctx, hipMemcpyAsync(lw_out, lw, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VB_HIP(ctx, hipMemcpyAsync(res, lw + round_up(n, 16), sizeof res, hipMemcpyDeviceToHost, ctx->stream));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef VB_PSIS_CLOCK
+  {
+    double dbg[16];
+    (void)hipMemcpy(dbg, lw + round_up(n, 16), sizeof dbg, hipMemcpyDeviceToHost);
+    fprintf(stderr, "psis phases (us):");
+    for (int i = 5; i < 12; ++i) fprintf(stderr, " %.1f", (dbg[i] - dbg[i - 1]) / 100.0);
+    fprintf(stderr, "\n");
+  }
+#endif
   ctx->psis_n = 0;        // the resident weights have been smoothed in place
   *khat = res[0];
   return VB_OK;
@@ -825,19 +834,27 @@ int vb_dis_grad_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const d
   return VB_OK;
 }
 
+int vb_dis_psis_mvt(vb_ctx* ctx, int64_t n_total, double reff) {
+  if (!ctx) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (!(reff > 0.0)) return fail(ctx, VB_ERR_INVALID, "Reff must be positive");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return mvt_dis_psis_enqueue(ctx, n_total, reff);
+}
+
 int vb_dis_step_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, int64_t resample_m,
-                           uint64_t seed, uint64_t stream, double scale, double* eps, double* ess, double* value,
-                           double* grad) {
+                           uint64_t seed, uint64_t stream, double scale, double* eps, double* ess, double* khat,
+                           double* value, double* grad) {
   if (!ctx || !theta || !eps || !ess || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (resample_m < 0) return fail(ctx, VB_ERR_INVALID, "resample_m must be >= 0");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   const size_t p = (size_t)(d + d * (d + 1) / 2);
   std::vector<double> out(1 + p);
-  double res[3] = {0.0, 0.0, 0.0};
+  double res[4] = {0.0, 0.0, 0.0, 0.0};
   VB_TRY(mvt_dis_grad(ctx, n, d, df, theta, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scale, out.data(),
                       resample_m, seed, stream, res));
   *eps = res[0];
   *ess = res[1];
+  if (khat) *khat = res[3];
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   *value = out[0];

@@ -596,6 +596,69 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   return VB_OK;
 }
 
+// ---- Pareto smoothing of the device-resident weights (DISInclusiveKL(psis_smooth=True) in throughput mode) -------------
+// w -> sum(w) exp(psislw(log w)) in place (objectives.py has no such step: BASELINE configs[3] asks for "DISInclusiveKL
+// with PSIS reweighting"; the smoothing itself is viabel/_psis.py:113-209, vb_psis.hip): logarithms and the total by one
+// workgroup with the loads in flight, the one-workgroup PSIS kernel on them, exponentials back into the weight vector;
+// khat lands next to (eps, ess, status) and comes back with the step's single synchronisation.
+__global__ void __launch_bounds__(1024) mvt_psis_prep_kernel(const double* __restrict__ w, int64_t n, double* __restrict__ lw,
+                                                             double* __restrict__ total_out) {
+  __shared__ double sh[16];
+  double sw = 0.0;
+  for (int64_t i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
+    double wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = i0 + u * 1024;
+      wv[u] = i < n ? w[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = i0 + u * 1024;
+      sw += wv[u];
+      if (i < n) lw[i] = log(wv[u]);          // log 0 = -inf: a weight that stays zero
+    }
+  }
+  sw = mvt_wave_sum(sw);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sw;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += sh[k];
+    total_out[0] = t;
+  }
+}
+
+__global__ void __launch_bounds__(256) mvt_psis_apply_kernel(const double* __restrict__ lw, const double* __restrict__ psis_out,
+                                                             const double* __restrict__ total, int64_t n,
+                                                             double* __restrict__ w, double* __restrict__ khat_out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) w[i] = total[0] * exp(lw[i]);
+  if (i == 0) khat_out[0] = psis_out[0];
+}
+
+int mvt_dis_psis_enqueue(vb_ctx* ctx, int64_t n_total, double reff) {
+  if (!ctx->mvt_state.ptr || ctx->mvt_n_total != n_total || n_total <= 1)
+    return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state with %lld samples", (long long)n_total);
+  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident weights: one rank only");
+  const MvtLayout L = mvt_layout(ctx, ctx->mvt_n, ctx->mvt_n_total, ctx->mvt_d);
+  double* base = (double*)ctx->mvt_state.ptr;
+  hipStream_t st = ctx->stream;
+  const int64_t nn = round_up(n_total, 16);
+  VB_TRY(ensure(ctx, ctx->psis_lw, (size_t)(nn + 16) * sizeof(double)));
+  double* lw = (double*)ctx->psis_lw.ptr;
+  hipLaunchKernelGGL(mvt_psis_prep_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_w), n_total, lw,
+                     base + L.o_scal + 12);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(psis_enqueue(ctx, n_total, reff));
+  hipLaunchKernelGGL(mvt_psis_apply_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, st, (const double*)lw,
+                     (const double*)(lw + nn), (const double*)(base + L.o_scal + 12), n_total, base + L.o_w,
+                     base + L.o_scal + 11);
+  VB_HIP(ctx, hipGetLastError());
+  ctx->psis_n = 0;
+  return VB_OK;
+}
+
 // tempered weights of the last refresh (before any resampling), for callers that left them on the device
 int mvt_dis_weights_get(vb_ctx* ctx, double* w_host, int64_t n_total, int resampled) {
   if (!ctx->mvt_state.ptr || ctx->mvt_n_total != n_total || n_total <= 0)
@@ -729,7 +792,7 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     VB_HIP(ctx, hipGetLastError());
     VB_HIP(ctx, hipMemcpyAsync(packed_out, base + L.o_grad, (size_t)(1 + d + d * (d + 1) / 2) * sizeof(double),
                                hipMemcpyDeviceToHost, st));
-    if (res_out) VB_HIP(ctx, hipMemcpyAsync(res_out, base + L.o_scal + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (res_out) VB_HIP(ctx, hipMemcpyAsync(res_out, base + L.o_scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     VB_HIP(ctx, hipStreamSynchronize(st));
     return VB_OK;
   }

@@ -109,6 +109,13 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   __shared__ double q_bs[kPsisQuadCap], q_ks[kPsisQuadCap], q_L[kPsisQuadCap], q_w[kPsisQuadCap];
   __shared__ double bc[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#ifdef VB_PSIS_CLOCK
+  int dbg_k = 4;
+#define PSIS_MARK() do { __syncthreads(); if (t == 0) out[dbg_k] = (double)wall_clock64(); ++dbg_k; } while (0)
+#else
+#define PSIS_MARK() do { } while (0)
+#endif
+  PSIS_MARK();
 
   // 1. improve numerical accuracy: x -= max(x)   (_psis.py:166)
   double mx = -INFINITY;
@@ -117,6 +124,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   ps_for_each(x, n, [&](int64_t i, double v) { x[i] = v - mx; });
   __syncthreads();
 
+  PSIS_MARK();
   // 2. x_sorted[n - m_tail - 1] by radix select (8 bits per pass, most significant first)   (:170-173)
   if (t == 0) {
     sel_prefix = 0ull;
@@ -158,6 +166,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
     }
     __syncthreads();
   }
+  PSIS_MARK();
   const double cutoffmin = log(DBL_MIN);                       // :159
   const double xcutoff = fmax(ps_unkey(sel_prefix), cutoffmin);
   const double expxc = exp(xcutoff);
@@ -176,6 +185,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   });
   __syncthreads();
   const int n2 = tail_count < kPsisTailCap ? tail_count : kPsisTailCap;
+  PSIS_MARK();
   double k = INFINITY, sigma = NAN;
   if (n2 > 4) {                                                 // :178-180
     // 4. order of the tail samples by (value, index): every element counts the elements before it (n2^2 / 1024
@@ -211,6 +221,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
     for (int i = t; i < n2; i += kPsisThreads) tv[i] = exp(tv[i]) - expxc;
     __syncthreads();
 
+    PSIS_MARK();
     // 5. gpdfitnew (:266-325): PRIOR = 3, m = 30 + int(sqrt(n2))
     const int m = 30 + (int)sqrt((double)n2);
     const double xq = tv[(int)(n2 / 4.0 + 0.5) - 1], xl = tv[n2 - 1];
@@ -250,6 +261,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
     sigma = -k / b;
     k = k * n2 / (n2 + 10.0) + 10.0 * 0.5 / (n2 + 10.0);        // weakly informative prior, a = 10
 
+    PSIS_MARK();
     // 6. smoothed tail (:188-199): order statistics of the fitted GPD, truncated at the largest raw weight
     if (k >= 1.0 / 3.0 && !isinf(k)) {
       for (int i = t; i < n2; i += kPsisThreads) {
@@ -267,6 +279,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   }
   __syncthreads();
 
+  PSIS_MARK();
   // 7. renormalise: x -= sumlogs(x)   (:201, :380-396)
   double m2 = -INFINITY;
   ps_for_each(x, n, [&](int64_t, double v) { m2 = fmax(m2, v); });
@@ -276,6 +289,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   se = ps_block_sum(se, sh);
   const double lse = log(se) + m2;
   ps_for_each(x, n, [&](int64_t i, double v) { x[i] = v - lse; });
+  PSIS_MARK();
   if (t == 0) {
     out[0] = k;
     out[1] = (double)tail_count;

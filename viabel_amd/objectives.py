@@ -927,10 +927,9 @@ class DISInclusiveKL(StochasticVariationalObjective):
             n_local = end - begin
             # throughput mode: mu, L, L^-1 and the chain rule of the gradient are formed on the device from var_param
             L, Linv = (None, None) if philox else factors(var_param)
-            # ... and on one rank, without PSIS smoothing and with a clipping threshold >= 1 (objectives.py:370-386 is
-            # the identity then; the default is 10) the weights never leave the device either
-            resident = (philox and not gaussian and eng.n_ranks == 1 and not self._psis_smooth
-                        and self._w_clip_threshold >= 1.0)
+            # ... and on one rank with a clipping threshold >= 1 (objectives.py:370-386 is the identity then; the default
+            # is 10) the weights never leave the device either -- Pareto smoothing included (vb_dis_psis_mvt)
+            resident = philox and not gaussian and eng.n_ranks == 1 and self._w_clip_threshold >= 1.0
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
                 if gaussian:
                     chi = np.ones(N)
@@ -957,6 +956,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
                         # come back (eps, ess) with the gradient after one synchronisation
                         eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._temper_prior_params, self._eps,
                                                      self._ess_target, self._max_bisection_its)
+                        if self._psis_smooth:
+                            eng.dis_psis_mvt(N)
                         self._set_state_logs(None, None, lambda: eng.dis_state_get(True, N))
                         self._set_state_weights(None, lambda: eng.dis_weights_get(N))
                         self._own_state(eng, 1, True)
@@ -987,6 +988,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
                     value, grad, self._eps, self._ess = eng.dis_step_mvt_packed(
                         n_local, D, df, var_param, 1.0 / N / M, resample_m=M, seed=approx._seed,
                         stream=approx._next_philox_stream())
+                if self._psis_smooth:
+                    self._khat = eng.last_khat
                 return value, grad
             if not self._use_resampling:
                 weights, scale = self._state_w_clipped, 1.0 / N
