@@ -287,18 +287,23 @@ def c3_leg(vb, calls=30):
     out = {'workload': 'BASELINE configs[3]: MultivariateT(256, df=100) + DISInclusiveKL, N_mc=16384, ess_target=2048, '
                        'state refresh every call, rng=philox, one GPU'}
     np.random.seed(5)
-    for resample in (False, True):
+    # "... with PSIS reweighting" (configs[3]): psis_smooth=True Pareto-smooths the tempered weights of every refresh
+    # (viabel/_psis.py:113-209, on the device-resident weights: vb_dis_psis_mvt) before they weight the score
+    for resample, psis in ((False, False), (True, False), (False, True), (True, True)):
         obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
-                                temper_prior_params=prior, use_resampling=resample)
+                                temper_prior_params=prior, use_resampling=resample, psis_smooth=psis)
         for _ in range(5):
             obj(theta)
         t0 = time.perf_counter()
         for _ in range(calls):
             v, g = obj(theta)
         dt = (time.perf_counter() - t0) / calls
-        out['resampling' if resample else 'weighted'] = {
+        key = ('resampling' if resample else 'weighted') + ('_psis' if psis else '')
+        out[key] = {
             'ms_per_call': 1e3 * dt, 'calls_per_s': 1.0 / dt, 'eps': float(obj._eps), 'ess': float(obj._ess),
             'value': float(v), 'grad_norm': float(np.linalg.norm(g))}
+        if psis:
+            out[key]['khat'] = float(obj._khat)
     # executed work of one refresh + gradient in this mode: the sample GEMM through L' (triangular), U = E' L^-1
     # (triangular; the residuals E' of freshly drawn samples are the scaled noise: no product) and the weighted Gram
     # product (lower tiles) -- three half products

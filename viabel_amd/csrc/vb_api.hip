@@ -714,7 +714,7 @@ int vb_psis_smooth(vb_ctx* ctx, const double* lw_in, int64_t n, double reff, dou
     double dbg[16];
     (void)hipMemcpy(dbg, lw + round_up(n, 16), sizeof dbg, hipMemcpyDeviceToHost);
     fprintf(stderr, "psis phases (us):");
-    for (int i = 5; i < 12; ++i) fprintf(stderr, " %.1f", (dbg[i] - dbg[i - 1]) / 100.0);
+    for (int i = 5; i < 13; ++i) fprintf(stderr, " %.1f", (dbg[i] - dbg[i - 1]) / 100.0);
     fprintf(stderr, "\n");
   }
 #endif

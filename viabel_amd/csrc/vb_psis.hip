@@ -64,7 +64,7 @@ __device__ __forceinline__ double ps_unkey(unsigned long long k) {
 
 // (value, index) lexicographic "a after b"
 __device__ __forceinline__ bool ps_after(double av, int ai, double bv, int bi) {
-  return av > bv || (av == bv && ai > bi);
+  return (av > bv) | ((av == bv) & (ai > bi));      // no short circuit: a branch per comparison cost 25 us per call
 }
 
 // lw = f - b + sum(log sigma): the log importance weights log p(z_n) - log q(z_n) of the mean-field families
@@ -96,7 +96,25 @@ __device__ __forceinline__ void ps_for_each(const double* __restrict__ x, int64_
   }
 }
 
+// Up to kPsisRegs * 1024 weights (16 384: BASELINE configs[3]) stay in registers from the shift to the tail gather and
+// again through the renormalisation: the eight radix passes, the gather and the three renormalisation sweeps then read
+// no memory at all.  Longer vectors take the batched loops.
+constexpr int kPsisRegs = 16;
+template <bool REGS, class F>
+__device__ __forceinline__ void ps_each(const double (&r)[kPsisRegs], const double* __restrict__ x, int64_t n, F&& f) {
+  if constexpr (REGS) {
+#pragma unroll
+    for (int u = 0; u < kPsisRegs; ++u) {
+      const int64_t i = threadIdx.x + (int64_t)u * kPsisThreads;
+      if (i < n) f(i, r[u]);
+    }
+  } else {
+    ps_for_each(x, n, f);
+  }
+}
+
 // x: N log weights, smoothed in place.  out = [khat, n_tail, xcutoff (shifted), sigma]
+template <bool REGS>
 __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__ x, int64_t n, int m_tail,
                                                             double* __restrict__ out) {
   __shared__ double sh[17];
@@ -107,6 +125,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   __shared__ double tv[kPsisTailCap];
   __shared__ int ti[kPsisTailCap];
   __shared__ double q_bs[kPsisQuadCap], q_ks[kPsisQuadCap], q_L[kPsisQuadCap], q_w[kPsisQuadCap];
+  __shared__ int rank_sh[kPsisThreads / 2];
   __shared__ double bc[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #ifdef VB_PSIS_CLOCK
@@ -118,10 +137,27 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   PSIS_MARK();
 
   // 1. improve numerical accuracy: x -= max(x)   (_psis.py:166)
+  double r[kPsisRegs];
+  if constexpr (REGS) {
+#pragma unroll
+    for (int u = 0; u < kPsisRegs; ++u) {
+      const int64_t i = t + (int64_t)u * kPsisThreads;
+      r[u] = i < n ? x[i] : 0.0;
+    }
+  }
   double mx = -INFINITY;
-  ps_for_each(x, n, [&](int64_t, double v) { mx = fmax(mx, v); });
+  ps_each<REGS>(r, x, n, [&](int64_t, double v) { mx = fmax(mx, v); });
   mx = ps_block_max(mx, sh);
-  ps_for_each(x, n, [&](int64_t i, double v) { x[i] = v - mx; });
+  if constexpr (REGS) {
+#pragma unroll
+    for (int u = 0; u < kPsisRegs; ++u) {
+      const int64_t i = t + (int64_t)u * kPsisThreads;
+      r[u] -= mx;
+      if (i < n) x[i] = r[u];
+    }
+  } else {
+    ps_for_each(x, n, [&](int64_t i, double v) { x[i] = v - mx; });
+  }
   __syncthreads();
 
   PSIS_MARK();
@@ -135,7 +171,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
     __syncthreads();
     const unsigned long long prefix = sel_prefix;
     const unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
-    ps_for_each(x, n, [&](int64_t, double v) {
+    ps_each<REGS>(r, x, n, [&](int64_t, double v) {
       const unsigned long long k = ps_key(v);
       if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> (8 * pass)) & 255ull)], 1);
     });
@@ -174,7 +210,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   // 3. right tail: x > xcutoff   (:175-177)
   if (t == 0) tail_count = 0;
   __syncthreads();
-  ps_for_each(x, n, [&](int64_t i, double v) {
+  ps_each<REGS>(r, x, n, [&](int64_t i, double v) {
     if (v > xcutoff) {
       const int p = atomicAdd(&tail_count, 1);
       if (p < kPsisTailCap) {
@@ -192,6 +228,47 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
     // comparisons per thread on LDS broadcasts: 0.15 M in all at n2 = 384) and moves to that position -- two
     // barriers instead of the 45 of a bitonic network
     constexpr int kPerThread = kPsisTailCap / kPsisThreads;
+    if (n2 <= kPsisThreads / 2) {
+      // few tail values (n2 = 384 at N = 16 384): the counting is a chain of dependent compare / select instructions,
+      // so it goes to ALL waves -- R = 1024 / round_up(n2, 64) threads per element, thread (e, rep) counts the comparands
+      // j = rep, rep + R, ... and the partial counts meet in an LDS integer (30 -> 15 us at R = 2)
+      const int n2p = (n2 + 63) & ~63, R = kPsisThreads / n2p;
+      const int e = t % n2p, rep = t / n2p;
+      int* rk = rank_sh;
+      if (t < n2) rk[t] = 0;
+      __syncthreads();
+      const double mv = e < n2 ? tv[e] : INFINITY;
+      const int mi = e < n2 ? ti[e] : 0x7fffffff;
+      int cnt = 0;
+      if (rep < R) {
+        for (int j0 = rep; j0 < n2; j0 += 8 * R) {
+          double v8[8];
+          int i8[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {        // unconditional reads (clamped), the sentinel selected afterwards
+            const int jx = j0 + q * R;
+            const int jc = jx < n2 ? jx : n2 - 1;
+            const double vv = tv[jc];
+            const int ii = ti[jc];
+            v8[q] = jx < n2 ? vv : INFINITY;
+            i8[q] = jx < n2 ? ii : 0x7fffffff;
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) cnt += ps_after(mv, mi, v8[q], i8[q]) ? 1 : 0;
+        }
+        if (e < n2) atomicAdd(&rk[e], cnt);               // integer: order does not matter
+      }
+      __syncthreads();
+      const int my_rank = t < n2 ? rk[t] : 0;
+      const double keep_v = t < n2 ? tv[t] : 0.0;
+      const int keep_i = t < n2 ? ti[t] : 0;
+      __syncthreads();
+      if (t < n2) {
+        tv[my_rank] = keep_v;
+        ti[my_rank] = keep_i;
+      }
+      __syncthreads();
+    } else {
     double my_v[kPerThread];
     int my_i[kPerThread], my_r[kPerThread];
 #pragma unroll
@@ -201,12 +278,24 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
       my_i[u] = e < n2 ? ti[e] : 0x7fffffff;
       my_r[u] = 0;
     }
-    for (int j = 0; j < n2; ++j) {
-      const double v = tv[j];
-      const int ix = ti[j];
+    // eight comparands are read from LDS before the first comparison; beyond n2 a sentinel nothing comes after
+    for (int j0 = 0; j0 < n2; j0 += 8) {
+      double v8[8];
+      int i8[8];
 #pragma unroll
-      for (int u = 0; u < kPerThread; ++u)
-        if (u * kPsisThreads < n2) my_r[u] += ps_after(my_v[u], my_i[u], v, ix) ? 1 : 0;     // (uniform condition)
+      for (int q = 0; q < 8; ++q) {
+        const int jx = j0 + q;
+        const int jc = jx < n2 ? jx : n2 - 1;
+        const double vv = tv[jc];
+        const int ii = ti[jc];
+        v8[q] = jx < n2 ? vv : INFINITY;
+        i8[q] = jx < n2 ? ii : 0x7fffffff;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int u = 0; u < kPerThread; ++u)
+          if (u * kPsisThreads < n2) my_r[u] += ps_after(my_v[u], my_i[u], v8[q], i8[q]) ? 1 : 0;     // (uniform condition)
     }
     __syncthreads();
 #pragma unroll
@@ -217,6 +306,8 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
       }
     }
     __syncthreads();
+    }
+    PSIS_MARK();
     // x2 = exp(x2) - exp(xcutoff)   (:185-186)
     for (int i = t; i < n2; i += kPsisThreads) tv[i] = exp(tv[i]) - expxc;
     __syncthreads();
@@ -227,23 +318,34 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
     const double xq = tv[(int)(n2 / 4.0 + 0.5) - 1], xl = tv[n2 - 1];
     if (t < m) q_bs[t] = (1.0 - sqrt((double)m / ((double)(t + 1) - 0.5))) / (3.0 * xq) + 1.0 / xl;
     __syncthreads();
-    for (int j = wave; j < m; j += kPsisThreads / 64) {         // ks_j = mean log1p(-bs_j x)
+    // sixteen lanes per quadrature point (64 points at a time: m <= 94), each a fixed stride of the tail, combined by a
+    // fixed butterfly -- the m n2 log1p evaluations spread over the whole workgroup instead of one wave per point
+    const int grp = t >> 4, gl = t & 15;
+    for (int j = grp; j < m; j += kPsisThreads / 16) {          // ks_j = mean log1p(-bs_j x)
       const double nb = -q_bs[j];
       double s = 0.0;
-      for (int i = lane; i < n2; i += 64) s += log1p(nb * tv[i]);
-      s = ps_wave_sum(s);
-      if (lane == 0) {
+      // log(1 + y) for log1p(y): the ABSOLUTE error of a term is what the mean sees, and that is one rounding of 1 + y
+      // (<= 1.1e-16) either way; log costs half of what log1p does, and these m n2 evaluations are the phase's time
+      for (int i = gl; i < n2; i += 16) s += log(fma(nb, tv[i], 1.0));
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (gl == 0) {
         const double ks = s / n2;
         q_ks[j] = ks;
         q_L[j] = n2 * (log(-(q_bs[j] / ks)) - ks - 1.0);
       }
     }
     __syncthreads();
-    if (t < m) {
+    for (int j = grp; j < m; j += kPsisThreads / 16) {
+      const double lj = q_L[j];
       double s = 0.0;
-      for (int i = 0; i < m; ++i) s += exp(q_L[i] - q_L[t]);
-      const double w = 1.0 / s;
-      q_w[t] = w >= 10.0 * DBL_EPSILON ? w : 0.0;                // remove negligible weights
+      for (int i = gl; i < m; i += 16) s += exp(q_L[i] - lj);
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (gl == 0) {
+        const double w = 1.0 / s;
+        q_w[j] = w >= 10.0 * DBL_EPSILON ? w : 0.0;              // remove negligible weights
+      }
     }
     __syncthreads();
     if (t == 0) {
@@ -281,14 +383,21 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
 
   PSIS_MARK();
   // 7. renormalise: x -= sumlogs(x)   (:201, :380-396)
+  if constexpr (REGS) {             // (the tail was rewritten in memory: read the vector once more)
+#pragma unroll
+    for (int u = 0; u < kPsisRegs; ++u) {
+      const int64_t i = t + (int64_t)u * kPsisThreads;
+      r[u] = i < n ? x[i] : 0.0;
+    }
+  }
   double m2 = -INFINITY;
-  ps_for_each(x, n, [&](int64_t, double v) { m2 = fmax(m2, v); });
+  ps_each<REGS>(r, x, n, [&](int64_t, double v) { m2 = fmax(m2, v); });
   m2 = ps_block_max(m2, sh);
   double se = 0.0;
-  ps_for_each(x, n, [&](int64_t, double v) { se += exp(v - m2); });
+  ps_each<REGS>(r, x, n, [&](int64_t, double v) { se += exp(v - m2); });
   se = ps_block_sum(se, sh);
   const double lse = log(se) + m2;
-  ps_for_each(x, n, [&](int64_t i, double v) { x[i] = v - lse; });
+  ps_each<REGS>(r, x, n, [&](int64_t i, double v) { x[i] = v - lse; });
   PSIS_MARK();
   if (t == 0) {
     out[0] = k;
@@ -334,8 +443,12 @@ int psis_enqueue(vb_ctx* ctx, int64_t n, double reff) {
     return fail(ctx, VB_ERR_UNSUPPORTED, "PSIS tail of %d values exceeds the on-chip sort capacity %d", m_tail,
                 kPsisTailCap);
   double* lw = (double*)ctx->psis_lw.ptr;
-  hipLaunchKernelGGL(psis_kernel, dim3(1), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail,
-                     lw + round_up(n, 16));
+  if (n <= (int64_t)kPsisRegs * kPsisThreads)
+    hipLaunchKernelGGL(psis_kernel<true>, dim3(1), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail,
+                       lw + round_up(n, 16));
+  else
+    hipLaunchKernelGGL(psis_kernel<false>, dim3(1), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail,
+                       lw + round_up(n, 16));
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
