@@ -84,3 +84,18 @@ def test_families_draw_the_reference_stream():
     ref = np.random.RandomState(8)
     assert np.array_equal(t._rs.chisquare(6.0, 50), ref.chisquare(6.0, 50))
     assert np.array_equal(t._rs.randn(50, 4), ref.randn(50, 4))
+
+
+def test_copies_and_pickles_carry_the_state():
+    import copy
+    import pickle
+    a = LegacyRandomState(11)
+    a.randn(7)                                   # a cached normal is pending
+    b, c, d = copy.deepcopy(a), pickle.loads(pickle.dumps(a)), copy.copy(a)
+    ref = a.randn(1001)
+    for other in (b, c, d):
+        assert np.array_equal(other.randn(1001), ref)
+    import viabel_amd as vb
+    fam = vb.MFGaussian(5, seed=3)
+    twin = copy.deepcopy(fam)
+    assert np.array_equal(fam._rs.randn(10, 5), twin._rs.randn(10, 5))

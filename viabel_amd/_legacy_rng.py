@@ -42,6 +42,21 @@ class LegacyRandomState:
         if h:
             self._lib.vb_legacy_rng_destroy(h)
 
+    # the handle is a pointer into the library: copies and pickles carry the state in numpy's format instead
+    def __getstate__(self):
+        return {'state': self.get_state()}
+
+    def __setstate__(self, d):
+        self.__init__(0)
+        self.set_state(d['state'])
+
+    def __deepcopy__(self, memo):
+        other = LegacyRandomState(0)
+        other.set_state(self.get_state())
+        return other
+
+    __copy__ = lambda self: self.__deepcopy__({})      # noqa: E731
+
     def _check(self, rc):
         if rc != _lib.VB_OK:
             raise ValueError('legacy generator: invalid argument')
