@@ -46,7 +46,10 @@ def _theta(fr, D, rng):
 # (48, 160) ... (272, 528): every k range a whole number of 16-deep slabs (the LDS-DMA GEMM kernels) with rows / columns
 # that end inside a tile: clamped operand fetches, masked and paired 16-byte epilogue stores, skipped zero slabs
 @pytest.mark.parametrize('D,N', [(3, 8), (5, 30), (64, 333), (130, 257), (200, 1000), (512, 4096), (1024, 4096),
-                                 (48, 160), (112, 400), (144, 137), (80, 1024), (272, 528)])
+                                 (48, 160), (112, 400), (144, 137), (80, 1024), (272, 528),
+                                 # short shards of a wide family: both N x D x D products with their k range cut into
+                                 # 4 / 4 / 2 / 3 pieces (fr_zsum_kernel, fr_gsum_kernel)
+                                 (1024, 256), (1024, 512), (1024, 1024), (768, 384)])
 def test_fullrank_against_oracle(vb, D, N):
     rng = np.random.RandomState(D + N)
     ofr = ofam.FullRankGaussian(D)

@@ -915,6 +915,50 @@ static int tri2_tile_map(vb_ctx* ctx, int d, int bm_rows, int bn_cols, const int
   return VB_OK;
 }
 
+// ---- short shards: split-k for the two N x D x D products ------------------------------------------------------------
+// With few sample rows (a strong-scaling shard: 512 rows at D = 1024 give 128 tiles of 64 x 64 for 256 CUs) the 64-slab k
+// range of ONE tile is the critical path of Z = E L' and of G = -(Z - m) P: 47 and 51 us with three quarters of the chip
+// idle.  The k range is then cut into `parts` pieces that run as separate workgroups into slabs of partial products
+// (EpiSplitSlab, the triangular one simply finds some of its pieces empty), and these kernels add the slabs in fixed
+// order and apply the epilogue of the unsplit product: Z = sum + mu - m, and G = -sum with the per-workgroup sum of
+// f = 1/2 (z - m)' g.
+__global__ void __launch_bounds__(256) fr_zsum_kernel(const double* __restrict__ P, int parts, int64_t pslab, int64_t n,
+                                                      int d, int64_t ldz, const double* __restrict__ mu,
+                                                      const double* __restrict__ shift, double* __restrict__ Z) {
+  const int64_t idx = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
+  if (idx >= n * ldz) return;
+  const int c = (int)(idx % ldz);
+  fr_d2 s = (fr_d2){0.0, 0.0};
+  for (int k = 0; k < parts; ++k) s += *reinterpret_cast<const fr_d2*>(P + k * pslab + idx);
+  if (c < d) s.x += mu[c] - (shift ? shift[c] : 0.0);
+  else s.x = 0.0;
+  if (c + 1 < d) s.y += mu[c + 1] - (shift ? shift[c + 1] : 0.0);
+  else s.y = 0.0;
+  *reinterpret_cast<fr_d2*>(Z + idx) = s;
+}
+
+__global__ void __launch_bounds__(256) fr_gsum_kernel(const double* __restrict__ P, int parts, int64_t pslab, int64_t n,
+                                                      int d, int64_t ldz, const double* __restrict__ Zc,
+                                                      double* __restrict__ G, double* __restrict__ fpart) {
+  __shared__ double sh[4];
+  const int64_t idx = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
+  double f = 0.0;
+  if (idx < n * ldz) {
+    const int c = (int)(idx % ldz);
+    fr_d2 s = (fr_d2){0.0, 0.0};
+    for (int k = 0; k < parts; ++k) s += *reinterpret_cast<const fr_d2*>(P + k * pslab + idx);
+    const fr_d2 z = *reinterpret_cast<const fr_d2*>(Zc + idx);
+    if (c >= d) s.x = 0.0;
+    if (c + 1 >= d) s.y = 0.0;
+    *reinterpret_cast<fr_d2*>(G + idx) = (fr_d2){-s.x, -s.y};
+    f = -0.5 * s.x * z.x - 0.5 * s.y * z.y;
+  }
+  f = fr_wave_sum(f);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) fpart[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 // ---- host orchestration ------------------------------------------------------------------------------
 // theta_dev != nullptr: full-rank Gaussian (Z = E L' + mu, lower-triangular gradient, epilogue into the flat layout).
 // theta_dev == nullptr: multivariate t (X = (E R) / s + mu with the dense symmetric root R and the per-row scale
@@ -981,7 +1025,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   };
   const int64_t o_mu = carve(ldz), o_lt = carve(slab), o_z = carve(n * ldz), o_g = carve(n * ldz),
                 o_cpart = carve((int64_t)(splits + 1) * slab), o_col = carve((int64_t)(n_rb + 1) * ldz),
-                o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx + gemm_max_blocks(n, D)),
+                o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx + gemm_max_blocks(n, D) + (n * ldz) / 512 + 1),
                 o_r = carve(glm ? n * ldr : 0);
   // path derivative: (L')^-1 (Xa), a product buffer T, the noise Gram matrix [16 | e (ld_e) | M2 (d x ldl)], partial
   // column sums of the noise (row stride = the noise matrix's)
@@ -1140,8 +1184,23 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     VB_TRY(glm_grad_enqueue(ctx, st, m, Rm, ldr, Z, G, ldz, n, D));   // G = R X - Z / sd^2
     fmode = 3;
   } else {
-    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0, row_scale}, cfg1);   // Z - m
-    VB_HIP(ctx, hipGetLastError());
+    // short shards (fewer than two 64 x 64 tiles per CU): both N x D x D products with their k range cut into `kparts`
+    // pieces (see fr_zsum_kernel); the slabs of partial products live in the split area of the gradient product, which
+    // is not in use yet
+    static const int kparts_env = getenv("VB_FR_KPARTS") ? atoi(getenv("VB_FR_KPARTS")) : -1;     // experiments; 1 = off
+    int kparts = 1;
+    const int64_t pslab = n * ldz;
+    if (fused_sums && !row_scale && cfg1 == 0 && cfg2 == 0) {
+      // measured (tools/fr_bench.py, D = 1024): 512 rows 126 -> 85 us per evaluation, 256 rows 118 -> 61 us, 1 024 rows
+      // 133 -> 128 us, 2 048 rows unchanged (not split).  At D = 512 a tile's 32 slabs are no longer than a piece plus
+      // the extra kernel: not split (pieces of at least 16 slabs out of at least 48).
+      const long tiles64 = gemm_count_blocks(g1, 64, 64);
+      if (tiles64 < 2L * n_cu && D >= 48 * kGemmBK) kparts = (int)((2L * n_cu + tiles64 - 1) / tiles64);
+      if (kparts > 4) kparts = 4;
+      if (kparts_env >= 1) kparts = kparts_env;
+      while (kparts > 1 && (D % (kGemmBK * kparts) != 0 || D / kparts < 16 * kGemmBK)) --kparts;
+      if ((int64_t)kparts * pslab > (int64_t)(splits + 1) * slab) kparts = 1;
+    }
     GemmArgs g2;                                   // G = -(Z - m) P,  P symmetric: B[k][j] = P[k][j]
     g2.A = Z;
     g2.lda = ldz;
@@ -1151,9 +1210,23 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     g2.N = D;
     g2.K = D;
     g2.tri_mode = 0;
-    prof_events(ctx, &g2.ev0, &g2.ev1, 1, VB_PROF_FR_MODEL_GEMM);
-    if (fused_sums) tiles2 = gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegateF{G, ldz, Z, fpart}, cfg2);
-    else gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz}, cfg2);
+    if (kparts > 1) {
+      const unsigned sum_blocks = (unsigned)((pslab / 2 + 255) / 256);
+      gemm_f64_launch<true>(st, g1, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
+      hipLaunchKernelGGL(fr_zsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,
+                         (const double*)mu, m.p0, Z);
+      VB_HIP(ctx, hipGetLastError());
+      gemm_f64_launch<true>(st, g2, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
+      hipLaunchKernelGGL(fr_gsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,
+                         (const double*)Z, G, fpart);
+      tiles2 = sum_blocks;
+    } else {
+      gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0, row_scale}, cfg1);   // Z - m
+      VB_HIP(ctx, hipGetLastError());
+      prof_events(ctx, &g2.ev0, &g2.ev1, 1, VB_PROF_FR_MODEL_GEMM);
+      if (fused_sums) tiles2 = gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegateF{G, ldz, Z, fpart}, cfg2);
+      else gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz}, cfg2);
+    }
     fmode = 2;
   }
   VB_HIP(ctx, hipGetLastError());
