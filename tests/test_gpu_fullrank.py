@@ -49,6 +49,7 @@ def _theta(fr, D, rng):
                                  (48, 160), (112, 400), (144, 137), (80, 1024), (272, 528),
                                  # short shards of a wide family: both N x D x D products with their k range cut into
                                  # 4 / 4 / 2 / 3 pieces (fr_zsum_kernel, fr_gsum_kernel)
+                                 # (the funnel's sampling product alone, the correlated Gaussian's two)
                                  (1024, 256), (1024, 512), (1024, 1024), (768, 384)])
 def test_fullrank_against_oracle(vb, D, N):
     rng = np.random.RandomState(D + N)

@@ -1151,21 +1151,49 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   static const bool fast_env = !(getenv("VB_FR_FUSED_SUMS") && atoi(getenv("VB_FR_FUSED_SUMS")) == 0);
   const bool fused_sums = fast_env && !mvt && m.id == VB_MODEL_GAUSS_FULL && !wm.roww && !row_scale && !pd &&
                           n % kGemmBK == 0 && gemm_uses_dma(g1) && (int64_t)splits <= n_rb;
+  // short shards (fewer than two 64 x 64 tiles per CU): the N x D x D products with their k range cut into `kparts`
+  // pieces (see fr_zsum_kernel); the slabs of partial products live in the split area of the gradient product, which
+  // is not in use yet
+  static const int kparts_env = getenv("VB_FR_KPARTS") ? atoi(getenv("VB_FR_KPARTS")) : -1;     // experiments; 1 = off
+  int kparts = 1;
+  const int64_t pslab = n * ldz;
+  if (!row_scale && !pd && cfg1 == 0 && cfg2 == 0 && m.id != VB_MODEL_GAUSS_DIAG) {      // (pd keeps a slab of its own there)
+    // measured (tools/fr_bench.py, D = 1024): 512 rows 126 -> 85 us per evaluation, 256 rows 118 -> 61 us, 1 024 rows
+    // 133 -> 128 us, 2 048 rows unchanged (not split).  At D = 512 a tile's 32 slabs are no longer than a piece plus
+    // the extra kernel: not split (pieces of at least 16 slabs out of at least 48).
+    const long tiles64 = gemm_count_blocks(g1, 64, 64);
+    if (tiles64 < 2L * n_cu && D >= 48 * kGemmBK) kparts = (int)((2L * n_cu + tiles64 - 1) / tiles64);
+    if (kparts > 4) kparts = 4;
+    if (kparts_env >= 1) kparts = kparts_env;
+    while (kparts > 1 && (D % (kGemmBK * kparts) != 0 || D / kparts < 16 * kGemmBK)) --kparts;
+    if ((int64_t)kparts * pslab > (int64_t)(splits + 1) * slab) kparts = 1;
+  }
+  const unsigned sum_blocks = (unsigned)((pslab / 2 + 255) / 256);
+  // Z = E L' + mu - shift into `Z` (the samples, or z - m for the correlated Gaussian target)
+  auto sample_gemm = [&](const double* shift, int cfg) {
+    if (kparts > 1) {
+      gemm_f64_launch<true>(st, g1, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
+      hipLaunchKernelGGL(fr_zsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,
+                         (const double*)mu, shift, Z);
+    } else {
+      gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, shift, row_scale}, cfg);
+    }
+  };
   unsigned tiles2 = 0;
   if (m.id == VB_MODEL_GAUSS_DIAG) {
     gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiag{G, ldz, mu, m.p0, m.p1, row_scale});
     fmode = 1;
   } else if (m.id == VB_MODEL_FUNNEL) {
-    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, nullptr, row_scale});
+    sample_gemm(nullptr, 0);
     VB_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(fr_funnel_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)Z,
                        G, ldz, n, D, m, fpart);
   } else if (source) {        // the user's row kernel: G and one f per sample (summed with the other f partials)
-    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, nullptr, row_scale});
+    sample_gemm(nullptr, 0);
     VB_HIP(ctx, hipGetLastError());
     VB_TRY(user_rows_enqueue(ctx, st, Z, ldz, n, D, G, ldz, fpart));
   } else if (glm) {
-    gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, nullptr, row_scale});
+    sample_gemm(nullptr, 0);
     VB_HIP(ctx, hipGetLastError());
     double* Rm = base + o_r;
     double* part = fpart + (int64_t)n_rb * cs_gx;
@@ -1184,23 +1212,6 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     VB_TRY(glm_grad_enqueue(ctx, st, m, Rm, ldr, Z, G, ldz, n, D));   // G = R X - Z / sd^2
     fmode = 3;
   } else {
-    // short shards (fewer than two 64 x 64 tiles per CU): both N x D x D products with their k range cut into `kparts`
-    // pieces (see fr_zsum_kernel); the slabs of partial products live in the split area of the gradient product, which
-    // is not in use yet
-    static const int kparts_env = getenv("VB_FR_KPARTS") ? atoi(getenv("VB_FR_KPARTS")) : -1;     // experiments; 1 = off
-    int kparts = 1;
-    const int64_t pslab = n * ldz;
-    if (fused_sums && !row_scale && cfg1 == 0 && cfg2 == 0) {
-      // measured (tools/fr_bench.py, D = 1024): 512 rows 126 -> 85 us per evaluation, 256 rows 118 -> 61 us, 1 024 rows
-      // 133 -> 128 us, 2 048 rows unchanged (not split).  At D = 512 a tile's 32 slabs are no longer than a piece plus
-      // the extra kernel: not split (pieces of at least 16 slabs out of at least 48).
-      const long tiles64 = gemm_count_blocks(g1, 64, 64);
-      if (tiles64 < 2L * n_cu && D >= 48 * kGemmBK) kparts = (int)((2L * n_cu + tiles64 - 1) / tiles64);
-      if (kparts > 4) kparts = 4;
-      if (kparts_env >= 1) kparts = kparts_env;
-      while (kparts > 1 && (D % (kGemmBK * kparts) != 0 || D / kparts < 16 * kGemmBK)) --kparts;
-      if ((int64_t)kparts * pslab > (int64_t)(splits + 1) * slab) kparts = 1;
-    }
     GemmArgs g2;                                   // G = -(Z - m) P,  P symmetric: B[k][j] = P[k][j]
     g2.A = Z;
     g2.lda = ldz;
@@ -1210,19 +1221,14 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     g2.N = D;
     g2.K = D;
     g2.tri_mode = 0;
-    if (kparts > 1) {
-      const unsigned sum_blocks = (unsigned)((pslab / 2 + 255) / 256);
-      gemm_f64_launch<true>(st, g1, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
-      hipLaunchKernelGGL(fr_zsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,
-                         (const double*)mu, m.p0, Z);
-      VB_HIP(ctx, hipGetLastError());
+    sample_gemm(m.p0, cfg1);                         // Z - m
+    VB_HIP(ctx, hipGetLastError());
+    if (kparts > 1 && fused_sums) {
       gemm_f64_launch<true>(st, g2, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
       hipLaunchKernelGGL(fr_gsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,
                          (const double*)Z, G, fpart);
       tiles2 = sum_blocks;
     } else {
-      gemm_f64_launch<true>(st, g1, 1, n_cu, EpiStoreZ{Z, ldz, mu, m.p0, row_scale}, cfg1);   // Z - m
-      VB_HIP(ctx, hipGetLastError());
       prof_events(ctx, &g2.ev0, &g2.ev1, 1, VB_PROF_FR_MODEL_GEMM);
       if (fused_sums) tiles2 = gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegateF{G, ldz, Z, fpart}, cfg2);
       else gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz}, cfg2);
