@@ -292,15 +292,19 @@ def c3_leg(vb, calls=30):
     for resample, psis in ((False, False), (True, False), (False, True), (True, True)):
         obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
                                 temper_prior_params=prior, use_resampling=resample, psis_smooth=psis)
-        for _ in range(5):
+        for _ in range(20):
             obj(theta)
-        t0 = time.perf_counter()
-        for _ in range(calls):
-            v, g = obj(theta)
-        dt = (time.perf_counter() - t0) / calls
+        blocks = []                      # three blocks of `calls` calls, the median block is reported (a call is ~45
+        for _ in range(3):               # dependent launches: a busy host moves a single block by tens of per cent)
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                v, g = obj(theta)
+            blocks.append((time.perf_counter() - t0) / calls)
+        dt = statistics.median(blocks)
         key = ('resampling' if resample else 'weighted') + ('_psis' if psis else '')
         out[key] = {
-            'ms_per_call': 1e3 * dt, 'calls_per_s': 1.0 / dt, 'eps': float(obj._eps), 'ess': float(obj._ess),
+            'ms_per_call': 1e3 * dt, 'calls_per_s': 1.0 / dt, 'block_ms': [1e3 * b for b in blocks],
+            'eps': float(obj._eps), 'ess': float(obj._ess),
             'value': float(v), 'grad_norm': float(np.linalg.norm(g))}
         if psis:
             out[key]['khat'] = float(obj._khat)
