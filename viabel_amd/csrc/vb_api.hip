@@ -102,6 +102,13 @@ static int noise_alloc(vb_ctx* ctx, int slot, int64_t n, int64_t d) {
   VB_TRY(check_slot(ctx, slot));
   if (n <= 0 || d <= 0) return fail(ctx, VB_ERR_INVALID, "noise shape must be positive");
   NoiseSlot& s = ctx->noise[slot];
+  // The t family's DIS state may be reading its residuals straight out of this slot (mvt_e_noise, vb_mvt.hip): new
+  // contents or a new buffer end that -- a gradient that comes without a refresh in between forms its residuals from
+  // the state samples again
+  if (ctx->mvt_e_noise && ctx->mvt_e_noise == (const double*)s.buf.ptr) {
+    ctx->mvt_e_noise = nullptr;
+    ctx->mvt_theta.clear();
+  }
   // 128-B aligned rows; a row stride that is a multiple of 4 KiB would put one column of every row on the
   // same HBM channel (the funnel's coupling column is read down the rows), so such strides get one more
   // 128-B pad
