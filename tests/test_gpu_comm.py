@@ -427,3 +427,47 @@ def test_lowrank_alpha_and_dis_through_comm(engines):
     for x, y in zip(out[0], out[1]):
         for u, v in zip(x, y):
             np.testing.assert_allclose(np.asarray(v), np.asarray(u), rtol=1e-13, atol=1e-13 * np.max(np.abs(u)))
+
+
+def test_host_staged_transport_one_rank_and_failing_collective():
+    """vb_comm_init_host: with one rank and an identity collective the sharded path reproduces the plain one; the
+    collective sees the sum vector and the max request; a collective that raises surfaces as EngineError (VB_ERR_COMM),
+    not as an exception unwinding through the C frames."""
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    plain = _lib.default_engine()
+    eng = _lib.Engine(plain.device)
+    calls = []
+
+    def collective(array, op):
+        calls.append((array.size, op))
+        if len(calls) > 1000:
+            raise RuntimeError('stop')
+
+    eng.comm_init_host(collective, 1, 0)
+    assert eng.comm_info() == (1, 0)
+    D, N = 40, 512
+    model = vb.GaussianModel(np.linspace(-1, 1, D), np.linspace(0.5, 1.5, D))
+    theta = _theta(D, 3)
+    out = []
+    for e in (plain, eng):
+        _lib.set_default_engine(e)
+        try:
+            np.random.seed(5)
+            out.append((vb.ExclusiveKL(vb.MFGaussian(D, seed=2, rng='philox'), model, N)(theta),
+                        vb.AlphaDivergence(vb.MFGaussian(D, seed=2, rng='philox'), model, N, 0.5)(theta)))
+        finally:
+            _lib.set_default_engine(plain)
+    for (v0, g0), (v1, g1) in zip(out[0], out[1]):
+        assert abs(v0 - v1) <= 1e-13 * abs(v0) and np.max(np.abs(g0 - g1)) <= 1e-13 * np.max(np.abs(g0))
+    assert {op for _, op in calls} == {0, 1}            # sums and the alpha divergence's max over log weights
+    calls.extend([(0, 0)] * 1001)                       # the next collective raises
+    _lib.set_default_engine(eng)
+    try:
+        with pytest.raises(_lib.EngineError):
+            vb.ExclusiveKL(vb.MFGaussian(D, seed=2, rng='philox'), model, N)(theta)
+    finally:
+        _lib.set_default_engine(plain)
+    eng.comm_destroy()
+    assert eng.comm_info() == (1, 0)
+    eng.close()
