@@ -487,10 +487,12 @@ __global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const
                                                                  double c0, double* __restrict__ out, int pd,
                                                                  FrWeighted wm) {
   __shared__ double sh[4];
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t np = (int64_t)d * (d + 1) / 2;
   const double invN = 1.0 / n_total;
-  if (p < np) {
+  // grid-stride: under the overlapped schedule the kernel runs beside the next evaluation's sampling product and is
+  // launched with a few dozen workgroups, so that it takes a few slots for a little longer instead of streaming two
+  // thousand workgroups through the dispatcher between the product's tiles (which cost that product 18 us)
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < np; p += (int64_t)gridDim.x * 256) {
     int i = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
     while ((int64_t)(i + 1) * (i + 2) / 2 <= p) ++i;
     while ((int64_t)i * (i + 1) / 2 > p) --i;
@@ -505,7 +507,8 @@ __global__ void __launch_bounds__(256) fr_epilogue_packed_kernel(FrSums S, const
       out[1 + d + p] = g;
     }
   }
-  if (p < d) out[1 + p] = wm.scale != 0.0 ? wm.scale * S.sums[S.off_col + p] : -S.sums[S.off_col + p] * invN;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < d; p += (int64_t)gridDim.x * 256)
+    out[1 + p] = wm.scale != 0.0 ? wm.scale * S.sums[S.off_col + p] : -S.sums[S.off_col + p] * invN;
   if (blockIdx.x == 0) {
     double t = 0.0;
     for (int i = threadIdx.x; i < d; i += 256) t += theta[d + (int64_t)i * (i + 1) / 2 + i];
@@ -1319,7 +1322,13 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     VB_HIP(ctx, hipStreamWaitEvent(st_post, P.ev_k1[set], 0));
   }
   VB_TRY(comm_allreduce_sum(ctx, st_post, S.sums, (size_t)S.len));
-  hipLaunchKernelGGL(fr_epilogue_packed_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st_post, S,
+  // one workgroup per CU: 328 -> 310 us per evaluation with a one-rank communicator (64: 312, 16: 350 -- the epilogue
+  // then is what the evaluation after next waits for; unlimited = 2 050 workgroups: 328)
+  static const int epi_env = getenv("VB_FR_EPI_WGS") ? atoi(getenv("VB_FR_EPI_WGS")) : -1;
+  const int epi_cap = epi_env >= 0 ? epi_env : n_cu;
+  const int64_t epi_full = (np + 255) / 256;
+  const unsigned epi_grid = (unsigned)((overlap && epi_cap > 0 && epi_full > epi_cap) ? epi_cap : epi_full);
+  hipLaunchKernelGGL(fr_epilogue_packed_kernel, dim3(epi_grid), dim3(256), 0, st_post, S,
                      theta_dev, D, (double)n_total, (double)n_total, m.c0, out_dev, pd ? 1 : 0, wm);
   VB_HIP(ctx, hipGetLastError());
   if (overlap) {
