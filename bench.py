@@ -249,20 +249,22 @@ def fit_leg(vb, theta, iters=1500):
     out['trajectories_identical'] = bool(np.array_equal(hist['host_loop'], hist['device_loop']))
     # What bounds an iteration of the device loop: its streaming kernel generates the noise in registers and is
     # VALU-bound (bytes are irrelevant: it fetches 0.5 MB).  The counters are from separate rocprofv3 --pmc passes
-    # (profiles/r02_meanfield_gen_pmc_valu.txt) and cannot be collected in this process; the floor below prices the
+    # (profiles/r03_meanfield_gen_pmc_valu.txt) and cannot be collected in this process; the floor below prices the
     # measured instruction count at the VALU issue rate of the chip.
     n_normals = D1 * N_MC
-    wave_instr = 8425664                      # SQ_INSTS_VALU per launch of mf_accum<GEN> at this shape
+    wave_instr = 6678165                      # SQ_INSTS_VALU per launch of mf_accum<GEN> at this shape (round 2: 8 425 664)
     simds, clock_ghz = 1024, 2.33             # 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE / duration under the counters
-    cycles_per_instr = (119 * 4 + 10 * 16) / 129.0    # 10 of the 129 per normal are quarter-rate v_mad_u64_u32 (Philox)
+    # of the 102 per normal 5 are quarter-rate v_mad_u64_u32 (Philox, four normals per call) and ~2 quarter-rate
+    # v_rcp_f64 / v_sqrt_f64 of the Box-Muller transform
+    cycles_per_instr = (95 * 4 + 7 * 16) / 102.0
     floor_us = wave_instr / simds * cycles_per_instr / (clock_ghz * 1e3)
     out['valu_roof'] = {
         'bound': 'VALU issue rate of the noise-generating streaming kernel (mf_accum<GEN>)',
         'valu_instructions_per_normal': round(wave_instr * 64.0 / n_normals, 1),
-        'kernel_us': 20.8, 'issue_floor_us': round(floor_us, 1), 'kernel_frac_of_floor': round(floor_us / 20.8, 2),
+        'kernel_us': 18.4, 'issue_floor_us': round(floor_us, 1), 'kernel_frac_of_floor': round(floor_us / 18.4, 2),
         'iteration_frac_of_floor': round(floor_us / out['device_loop_us_per_iteration'], 2),
-        'rest_of_iteration': 'mf_finalize 5.5 us (4.4 us of latency inside the kernel) + ~2 us of dispatch gaps',
-        'source': 'profiles/r02_meanfield_gen_pmc_valu.txt, profiles/r02_fit_loop_kernel_stats.txt',
+        'rest_of_iteration': 'mf_finalize 5.6 us (4.4 us of latency inside the kernel) + ~2 us of dispatch gaps',
+        'source': 'profiles/r03_meanfield_gen_pmc_valu.txt, profiles/r03_fit_loop_kernel_stats.txt',
     }
     return out
 

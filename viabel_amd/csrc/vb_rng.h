@@ -111,22 +111,57 @@ __device__ __forceinline__ void vb_sincos_turn(double t, double* sn, double* cs)
   *cs = (q == 1 || q == 2) ? -cc : cc;
 }
 
-// the two standard normals of column pair j (columns 2 j, 2 j + 1) of global row `grow`: Box-Muller on two 53-bit
-// uniforms of one Philox call.  k0 / k1: key words (seed, high stream bits), w: low stream bits
-__device__ __forceinline__ void philox_normal_pair(uint32_t k0, uint32_t k1, uint64_t grow, uint32_t j, uint32_t w,
-                                                   double* a, double* b) {
+// ---- normals: four per Philox call --------------------------------------------------------------------------------
+// One Philox4x32-10 call is 160 of the instructions a pair of normals used to cost (two 53-bit uniforms per Box-Muller
+// pair: 129 instructions per normal, the generator kernels are VALU-bound).  The four output words now feed TWO
+// Box-Muller pairs -- 102 instructions per normal (SQ_INSTS_VALU): word 0 / 2 is the radius uniform of pair A / B, word
+// 1 / 3 its angle.
+// A 32-bit angle is more than the transform resolves; a 32-bit radius uniform u = (k + 1/2) 2^-32 would cut the tails
+// at 6.66 sigma, so the rare small ones (k < 4096, probability 2^-20) take 32 more bits from a second call and keep
+// the resolution of a 64-bit uniform where it matters (|z| up to 9.4 sigma).
+// The two pairs are the column pair j of global rows g and g ^ 4 (g with bit 2 clear): the streaming kernels walk
+// rows in steps of four per wave, so a lane meets both rows of a quad in consecutive steps.  Element (row, col) stays a
+// pure function of (seed, stream, row, col): philox_normal_pair returns any row's pair by itself.
+__device__ __forceinline__ uint64_t philox_quad_id(uint64_t g) { return ((g >> 3) << 2) | (g & 3); }
+
+__device__ __forceinline__ double u01_32(uint32_t k) { return ((double)k + 0.5) * 2.3283064365386962890625e-10; }
+
+// out[0..1]: columns 2 j, 2 j + 1 of row g (bit 2 clear), out[2..3]: of row g + 4; qid = philox_quad_id(g)
+__device__ __forceinline__ void philox_normal_quad(uint32_t k0, uint32_t k1, uint64_t qid, uint32_t j, uint32_t w,
+                                                   double* out) {
   Philox4 c;
-  c.x = (uint32_t)grow;
-  c.y = (uint32_t)(grow >> 32);
+  c.x = (uint32_t)qid;
+  c.y = (uint32_t)(qid >> 32);
   c.z = j;
   c.w = w;
   const Philox4 o = philox4x32_10(c, k0, k1);
-  const double u1 = u01(o.x, o.y), u2 = u01(o.z, o.w);
-  const double rad = sqrt(-2.0 * vb_log_unit(u1));
+  double u1a = u01_32(o.x), u1b = u01_32(o.z);
+  if ((o.x < 4096u) | (o.z < 4096u)) {             // a tail radius: 32 more bits (one lane in 2^19 quads)
+    Philox4 c2 = c;
+    c2.w = w + 0x9E3779B9u * 0xEEu;
+    const Philox4 e = philox4x32_10(c2, k0, k1 ^ (0x85EBCA6Bu * 0xEEu));
+    if (o.x < 4096u) u1a = ((double)(((uint64_t)o.x << 32) | e.x) + 0.5) * 5.42101086242752217003726400434970855712890625e-20;
+    if (o.z < 4096u) u1b = ((double)(((uint64_t)o.z << 32) | e.z) + 0.5) * 5.42101086242752217003726400434970855712890625e-20;
+  }
+  const double ra = sqrt(-2.0 * vb_log_unit(u1a)), rb = sqrt(-2.0 * vb_log_unit(u1b));
   double s, co;
-  vb_sincos_turn(u2, &s, &co);
-  *a = rad * co;
-  *b = rad * s;
+  vb_sincos_turn(u01_32(o.y), &s, &co);
+  out[0] = ra * co;
+  out[1] = ra * s;
+  vb_sincos_turn(u01_32(o.w), &s, &co);
+  out[2] = rb * co;
+  out[3] = rb * s;
+}
+
+// the two standard normals of column pair j (columns 2 j, 2 j + 1) of global row `grow` (its half of the quad).
+// k0 / k1: key words (seed, high stream bits), w: low stream bits
+__device__ __forceinline__ void philox_normal_pair(uint32_t k0, uint32_t k1, uint64_t grow, uint32_t j, uint32_t w,
+                                                   double* a, double* b) {
+  double q[4];
+  philox_normal_quad(k0, k1, philox_quad_id(grow), j, w, q);
+  const bool hi = (grow >> 2) & 1;
+  *a = hi ? q[2] : q[0];
+  *b = hi ? q[3] : q[1];
 }
 
 // Student-t by Bailey's polar method (see vb_rng.hip)

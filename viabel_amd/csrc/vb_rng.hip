@@ -10,8 +10,8 @@
 
 namespace vb {
 
-// one thread = one pair of columns (2j, 2j+1) of one row; blockIdx.y = block of kRngRows rows (no 64-bit
-// division); Box-Muller with sincospi (no 2 pi range reduction)
+// one thread = one pair of columns (2j, 2j+1) of a block of kRngRows rows (blockIdx.y; no 64-bit division): four
+// Philox calls, each two Box-Muller pairs
 constexpr int kRngRows = 8;
 __global__ void __launch_bounds__(256) rng_normal_kernel(double* __restrict__ dst, int64_t ld,
                                                          uint64_t seed, uint64_t stream,
@@ -21,19 +21,30 @@ __global__ void __launch_bounds__(256) rng_normal_kernel(double* __restrict__ ds
   if (j >= pairs) return;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(stream >> 32);
   const int64_t r0 = (int64_t)blockIdx.y * kRngRows;
+  auto store = [&](int64_t r, double va, double vb2) {
+    double* p = dst + r * ld + 2 * j;
+    if (2 * j + 1 < d) *reinterpret_cast<double2*>(p) = make_double2(va, vb2);
+    else p[0] = va;
+  };
+  if (((row_offset + r0) & 7) == 0) {
+    // an aligned block of eight global rows is four quads: rows u and u + 4 share a Philox call (vb_rng.h)
 #pragma unroll
-  for (int u = 0; u < kRngRows; ++u) {
+    for (int u = 0; u < kRngRows / 2; ++u) {
+      const int64_t r = r0 + u;
+      if (r >= n) break;
+      double q[4];
+      philox_normal_quad(k0, k1, philox_quad_id((uint64_t)(row_offset + r)), (uint32_t)j, (uint32_t)stream, q);
+      store(r, q[0], q[1]);
+      if (r + 4 < n) store(r + 4, q[2], q[3]);
+    }
+    return;
+  }
+  for (int u = 0; u < kRngRows; ++u) {        // a shard that starts inside a block: row by row, half a quad each
     const int64_t r = r0 + u;
     if (r >= n) break;
-    const uint64_t grow = (uint64_t)(row_offset + r);
     double va, vb2;
-    philox_normal_pair(k0, k1, grow, (uint32_t)j, (uint32_t)stream, &va, &vb2);
-    double* p = dst + r * ld + 2 * j;
-    if (2 * j + 1 < d) {
-      *reinterpret_cast<double2*>(p) = make_double2(va, vb2);
-    } else {
-      p[0] = va;
-    }
+    philox_normal_pair(k0, k1, (uint64_t)(row_offset + r), (uint32_t)j, (uint32_t)stream, &va, &vb2);
+    store(r, va, vb2);
   }
 }
 
