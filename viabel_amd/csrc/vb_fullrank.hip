@@ -1261,7 +1261,11 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   g3.N = D;
   g3.K = (int)n;
   g3.tri_mode = mvt ? 0 : 2;
-  if (!fused_sums) {
+  // targets whose row kernel leaves sum f behind already (funnel, source models): the column sums of G are all the pass
+  // below would add, and they come out of the gradient product's LDS tiles as for the correlated Gaussian
+  const bool cs_only = fast_env && !fused_sums && !mvt && (m.id == VB_MODEL_FUNNEL || source) && !wm.roww && !row_scale &&
+                       !pd && n % kGemmBK == 0 && gemm_uses_dma(g3) && (int64_t)splits <= n_rb;
+  if (!fused_sums && !cs_only) {
     hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
                        (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
                        (m.id == VB_MODEL_FUNNEL || source) ? fpart + n_fpart /*unused tail*/ : fpart,
@@ -1277,7 +1281,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   // GEMM 3: C[i][j] = sum_n G[n][i] E[n][j]
   prof_events(ctx, &g3.ev0, &g3.ev1, 1, VB_PROF_FR_GRAD_GEMM);
   int n_rb_red = n_rb + (pd ? 1 : 0), n_fpart_red = n_fpart;
-  if (fused_sums) {
+  if (fused_sums || cs_only) {
     static const bool map_env = !(getenv("VB_FR_TILE_MAP") && atoi(getenv("VB_FR_TILE_MAP")) == 0);
     int cfg3_used = cfg3;
     if (map_env && cfg3 == 0 && gemm_count_blocks(g3, 128, 64) * splits * 100 >= 190L * n_cu) {
@@ -1286,7 +1290,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     }
     gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlabCs{Cpart, ldl, slab, colpart, ldz}, cfg3_used);
     n_rb_red = splits;                  // one row of column sums per split
-    n_fpart_red = (int)tiles2;          // one partial of sum f per tile of the model GEMM
+    if (fused_sums) n_fpart_red = (int)tiles2;          // one partial of sum f per tile of the model GEMM
   } else {
     gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
   }
