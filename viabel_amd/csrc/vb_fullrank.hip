@@ -253,7 +253,8 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
                                                         double* __restrict__ colpart,
                                                         double* __restrict__ fpart, double scal = 0.0,
                                                         const double* __restrict__ roww = nullptr,
-                                                        int square = 0) {
+                                                        int square = 0, double* __restrict__ Gscaled = nullptr,
+                                                        const double* __restrict__ rs_out = nullptr) {
   __shared__ double sh[4];
   __shared__ fr_d2 cs[4][64];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -279,6 +280,9 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
           if (square) g[i] *= g[i];
           if (fmode >= 2) z[i] = *reinterpret_cast<const fr_d2*>(Zc + r * ldz + col);
           if (!ok1) g[i].y = 0.0, z[i].y = 0.0;
+          // the t family's chain rule wants the rows of G scaled by 1 / s_n AFTER these (unscaled) sums: written back
+          // from here instead of by a pass of its own
+          if (Gscaled) *reinterpret_cast<fr_d2*>(Gscaled + r * ldz + col) = g[i] * rs_out[r];
         }
       }
 #pragma unroll
@@ -1269,11 +1273,10 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
                        (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
                        (m.id == VB_MODEL_FUNNEL || source) ? fpart + n_fpart /*unused tail*/ : fpart,
-                       glm ? 1.0 / (m.tau * m.tau) : 0.0);
+                       glm ? 1.0 / (m.tau * m.tau) : 0.0, (const double*)nullptr, 0, row_scale ? G : (double*)nullptr,
+                       row_scale);
     VB_HIP(ctx, hipGetLastError());
-  }
-
-  if (row_scale) {
+  } else if (row_scale) {
     hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)n, (unsigned)((D + 255) / 256)), dim3(256), 0, st, G, ldz, n,
                        D, row_scale);
     VB_HIP(ctx, hipGetLastError());
