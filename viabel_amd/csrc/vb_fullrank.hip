@@ -143,6 +143,28 @@ struct EpiGaussDiag {       // G = -(z - m) / sd^2  straight from the GEMM-1 acc
   }
 };
 
+// ... and, per workgroup, the sum of f = -1/2 (z - m)^2 / sd^2 over the tile (the diagonal Gaussian's log density of the
+// samples this tile has just formed): with the column sums of G out of the gradient product no pass over G is left
+struct EpiGaussDiagF {
+  double* G;
+  int64_t ldz;
+  const double* mu;
+  const double* mean;
+  const double* ivar;
+  double* part;
+  __device__ double operator()(int, int row, int col, double acc) const {
+    const double dz = acc + mu[col] - mean[col], iv = ivar[col];
+    G[(int64_t)row * ldz + col] = -dz * iv;
+    return -0.5 * dz * dz * iv;
+  }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    const double d0 = a0 + mu[col] - mean[col], d1 = a1 + mu[col + 1] - mean[col + 1];
+    const double i0 = ivar[col], i1 = ivar[col + 1];
+    *reinterpret_cast<d2v*>(G + (int64_t)row * ldz + col) = (d2v){-d0 * i0, -d1 * i1};
+    return (d2v){-0.5 * d0 * d0 * i0, -0.5 * d1 * d1 * i1};
+  }
+};
+
 struct EpiNegate {          // G = -acc   (gauss_full: G = -(Z - m) P)
   double* G;
   int64_t ldz;
@@ -1187,7 +1209,13 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     }
   };
   unsigned tiles2 = 0;
-  if (m.id == VB_MODEL_GAUSS_DIAG) {
+  // diagonal Gaussian target under the dense Gaussian family: sum f out of the sampling product's epilogue
+  const bool diag_f = fast_env && !mvt && m.id == VB_MODEL_GAUSS_DIAG && !wm.roww && !row_scale && !pd &&
+                      n % kGemmBK == 0 && gemm_uses_dma(g1) && (int64_t)splits <= n_rb;
+  if (m.id == VB_MODEL_GAUSS_DIAG && diag_f) {
+    tiles2 = gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiagF{G, ldz, mu, m.p0, m.p1, fpart});
+    fmode = 1;
+  } else if (m.id == VB_MODEL_GAUSS_DIAG) {
     gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiag{G, ldz, mu, m.p0, m.p1, row_scale});
     fmode = 1;
   } else if (m.id == VB_MODEL_FUNNEL) {
@@ -1267,8 +1295,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   g3.tri_mode = mvt ? 0 : 2;
   // targets whose row kernel leaves sum f behind already (funnel, source models): the column sums of G are all the pass
   // below would add, and they come out of the gradient product's LDS tiles as for the correlated Gaussian
-  const bool cs_only = fast_env && !fused_sums && !mvt && (m.id == VB_MODEL_FUNNEL || source) && !wm.roww && !row_scale &&
-                       !pd && n % kGemmBK == 0 && gemm_uses_dma(g3) && (int64_t)splits <= n_rb;
+  const bool cs_only = diag_f || (fast_env && !fused_sums && !mvt && (m.id == VB_MODEL_FUNNEL || source) && !wm.roww &&
+                                 !row_scale && !pd && n % kGemmBK == 0 && gemm_uses_dma(g3) && (int64_t)splits <= n_rb);
   if (!fused_sums && !cs_only) {
     hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
                        (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
@@ -1293,7 +1321,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     }
     gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlabCs{Cpart, ldl, slab, colpart, ldz}, cfg3_used);
     n_rb_red = splits;                  // one row of column sums per split
-    if (fused_sums) n_fpart_red = (int)tiles2;          // one partial of sum f per tile of the model GEMM
+    if (fused_sums || diag_f) n_fpart_red = (int)tiles2;          // one partial of sum f per tile of the model GEMM
   } else {
     gemm_f64_launch<false>(st, g3, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
   }
