@@ -469,6 +469,39 @@ def source_model_leg(vb, calls=100):
     return out
 
 
+def alpha_leg(vb, calls=30):
+    """AlphaDivergence (objectives.py:443-463), the third objective of the hot path: blocking objective(theta) calls with
+    fresh Philox noise at the C1 shape (mean field), the headline shape (dense Gaussian family; the call carries the
+    525 824-entry parameter up and the gradient down) and the configs[3] shape (MultivariateT, throughput mode)."""
+    out = {'workload': 'AlphaDivergence(alpha = 0.5), blocking objective(theta) calls, rng=philox, one GPU'}
+    rng = np.random.RandomState(2)
+    cases = (('mf_gaussian_funnel_d1024_n4096', vb.MFGaussian(1024, rng='philox'), vb.FunnelModel(1024), 4096),
+             ('fullrank_funnel_d1024_n4096', vb.FullRankGaussian(1024, rng='philox'), vb.FunnelModel(1024), 4096),
+             ('multivariate_t_gauss_diag_d256_n16384', vb.MultivariateT(256, 100, rng='philox'),
+              vb.GaussianModel(0.1 * rng.randn(256), np.exp(0.1 * rng.randn(256))), 16384))
+    for name, approx, model, n in cases:
+        D = approx.dim
+        if isinstance(approx, vb.FullRankGaussian):
+            theta = approx.pack(np.zeros(D), np.exp(-1.0) * np.eye(D))
+        else:
+            theta = approx.init_param()
+            if isinstance(approx, vb.MFGaussian):
+                theta[D:] = -1.0
+        obj = vb.AlphaDivergence(approx, model, n, 0.5)
+        np.random.seed(1)
+        for _ in range(10):
+            obj(theta)
+        blocks = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                v, g = obj(theta)
+            blocks.append((time.perf_counter() - t0) / calls)
+        out[name] = {'us_per_call': 1e6 * statistics.median(blocks), 'value': float(v),
+                     'grad_norm': float(np.linalg.norm(g))}
+    return out
+
+
 def c4_leg(eng, vb, steps=20):
     """BASELINE configs[4]: MFGaussian + ExclusiveKL on Bayesian logistic regression, D=2000, n_data=8192,
     N_mc=8192 (one GPU), fresh Philox noise per evaluation: blocking objective calls, and RMSProp iterations of the
@@ -887,6 +920,7 @@ def main():
                 out['fit_loop'] = fit_leg(vb, theta1)
             out['c3_mvt_dis'] = c3_leg(vb)
             out['mvt_ekl'] = mvt_ekl_leg(vb)
+            out['alpha_divergence'] = alpha_leg(vb)
             out['c4_logistic'] = c4_leg(eng, vb)
             try:
                 out['source_model'] = source_model_leg(vb)

@@ -364,7 +364,9 @@ int vb_mvt_path_terms(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_tot
  * - (df + D)/2 log1p(|z_n|^2 / (s_n^2 df)) and the log weights, their maximum, w_n = exp(alpha (lw_n - max)) and
  * `value` = log(mean w) / alpha + max (:457-459) are formed on the device.  Returns w_sum = sum_n w_n,
  * g_sum[D] = sum_n w_n g_n and c_full[D x D] = sum_n w_n g_n (z_n / s_n)'; the caller applies alpha / N, the
- * chain rule through the symmetric root and adds w_sum to the free (log) diagonal.  Sums cover all ranks. */
+ * chain rule through the symmetric root and adds w_sum to the free (log) diagonal.  Sums cover all ranks.
+ * Throughput mode: inv_s == NULL takes s_n from the device chi-square draws of vb_chisq_generate, and `sqrt_sigma` may
+ * be any root R with R' R = Sigma -- with R = L' (x = mu + L z / s) the chain rule is tril(c_full) itself. */
 int vb_alpha_sums_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
                       const double* mu, const double* sqrt_sigma, const double* inv_s, double sum_log_diag,
                       double* value, double* w_sum, double* g_sum, double* c_full);

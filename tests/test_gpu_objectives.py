@@ -699,3 +699,46 @@ def test_dis_throughput_state_survives_a_rewritten_noise_slot(vb):
     (f0, s0), (f1, s1) = results
     assert f0[0] == f1[0] and np.array_equal(f0[1], f1[1])
     assert G.rel_err(s1[0], s0[0]) < 1e-11 and G.rel_err(s1[1], s0[1]) < 1e-10
+
+
+@pytest.mark.parametrize('alpha', [0.5, 2.0])
+@pytest.mark.parametrize('target', ['gauss_diag', 'funnel', 'gauss_full'])
+def test_alpha_multivariate_t_throughput_mode_against_numpy(vb, target, alpha):
+    """AlphaDivergence over MultivariateT with rng='philox' (objectives.py:443-463): chi-square draws and normals on the
+    device, samples through the Cholesky factor x = mu + L z / s.  The device noise is read back and the estimator is
+    written out in numpy: lw = f(x) - log q(x), s = exp(lw - max)^alpha, value = log(mean s) / alpha + max (:457-459),
+    gradient alpha / N sum s d(lw)/dtheta with d/dL = tril(sum s g (z / s)') and -d log q / d log L_ii = 1."""
+    from viabel_amd import _lib
+    from viabel_amd.objectives import _NOISE_SLOT
+    D, N, df = 96, 1024, 9.0
+    rng = np.random.RandomState(D)
+    if target == 'gauss_diag':
+        mean, sd = 0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+        model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    elif target == 'funnel':
+        model, omodel = vb.FunnelModel(D, D // 2), omod.Funnel(D, D // 2)
+    else:
+        A = rng.randn(D, D)
+        model = vb.CorrelatedGaussianModel(0.2 * rng.randn(D), covariance=A @ A.T / D + np.eye(D))
+        omodel = omod.GaussFull(model.mean, model.precision)
+    approx, ofamily = vb.MultivariateT(D, df, seed=3, rng='philox'), ofam.MultivariateT(D, df)
+    A = rng.randn(D, D)
+    scale = 0.05 if target == 'funnel' else 0.7
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(scale * (A @ A.T / D + np.eye(D)))])
+    np.random.seed(21)
+    value, grad = vb.AlphaDivergence(approx, model, N, alpha)(theta)
+    eng = _lib.default_engine()
+    chi, z = eng.chisq_get_host(N), eng.noise_get_host(_NOISE_SLOT, N, D)
+    mu, L = theta[:D], ofam.free_to_chol(theta[D:], D)
+    zs = z / np.sqrt(chi / df)[:, None]
+    x = mu + zs @ L.T
+    lw = omodel.logp(x) - ofamily.log_density(theta, x)
+    mx = np.max(lw)
+    sv = np.exp(lw - mx) ** alpha
+    ov = np.log(np.mean(sv)) / alpha + mx
+    g = omodel.grad(x)
+    dL = np.tril((sv[:, None] * g).T @ zs)
+    dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + np.sum(sv)
+    og = alpha * np.concatenate([(sv[:, None] * g).sum(0), dL[np.tril_indices(D)]]) / N
+    assert G.rel_err(value, ov) < 1e-12, (value, ov)
+    assert G.rel_err(grad, og) < 1e-10, G.rel_err(grad, og)

@@ -709,12 +709,14 @@ class Engine:
     def alpha_sums_mvt(self, slot, n, d, df, alpha, mu, root, inv_s, sum_log_diag, n_total=None):
         """Weighted sample sums of AlphaDivergence over a multivariate t (``vb_alpha_sums_mvt``):
         ``(value, w_sum, g_sum, C)``."""
-        mu, root, inv_s = _f64(mu), _f64(root), _f64(inv_s)
+        mu, root = _f64(mu), _f64(root)
+        inv_s = None if inv_s is None else _f64(inv_s)      # None: the device chi-square draws (chisq_generate)
         g_sum = np.empty(d, dtype=np.float64)
         C = np.empty((d, d), dtype=np.float64)
         value, w_sum = ctypes.c_double(0.0), ctypes.c_double(0.0)
         self._check(self._lib.vb_alpha_sums_mvt(self._ctx, slot, n, d, n if n_total is None else n_total, float(df),
-                                                float(alpha), _dptr(mu), _dptr(root), _dptr(inv_s),
+                                                float(alpha), _dptr(mu), _dptr(root),
+                                                None if inv_s is None else _dptr(inv_s),
                                                 float(sum_log_diag), ctypes.byref(value), ctypes.byref(w_sum),
                                                 _dptr(g_sum), _dptr(C)))
         return value.value, w_sum.value, g_sum, C

@@ -1000,7 +1000,7 @@ int vb_lowrank_path_terms(vb_ctx* ctx, int slot_eps, int slot_z, int64_t n, int6
 int vb_alpha_sums_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
                       const double* mu, const double* sqrt_sigma, const double* inv_s, double sum_log_diag,
                       double* value, double* w_sum, double* g_sum, double* c_full) {
-  if (!ctx || !mu || !sqrt_sigma || !inv_s || !value || !w_sum || !g_sum || !c_full)
+  if (!ctx || !mu || !sqrt_sigma || !value || !w_sum || !g_sum || !c_full)      // (inv_s may be NULL: device draws)
     return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_TRY(check_slot(ctx, slot));
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");

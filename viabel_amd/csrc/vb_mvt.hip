@@ -940,7 +940,17 @@ int mvt_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64
   VB_TRY(upload_padded(ctx, base + o_root, ld, root_host, d, d, false));
   VB_HIP(ctx, hipMemsetAsync(base + o_mu, 0, (size_t)ld * sizeof(double), st));
   VB_HIP(ctx, hipMemcpyAsync(base + o_mu, mu_host, (size_t)d * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(base + o_invs, inv_s_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  if (inv_s_host) {
+    VB_HIP(ctx, hipMemcpyAsync(base + o_invs, inv_s_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  } else {      // throughput mode: the chi-square draws of vb_chisq_generate, already on the device
+    if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+    if (ctx->chi_n != n || ctx->chi_df != df || !ctx->chi_dev.ptr)
+      return fail(ctx, VB_ERR_STATE, "inv_s == NULL needs %lld device chi-square(%g) draws (vb_chisq_generate)",
+                  (long long)n, df);
+    hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const double*)ctx->chi_dev.ptr, df, n, base + o_invs);
+    VB_HIP(ctx, hipGetLastError());
+  }
   FrSums S;
   const double* vw = nullptr;
   VB_TRY(alpha_mvt_enqueue(ctx, ns, n, n_total, d, df, alpha, base + o_mu, base + o_root, base + o_invs, sum_log_diag,

@@ -1111,8 +1111,19 @@ class AlphaDivergence(StochasticVariationalObjective):
             N = self.num_mc_samples
             begin, end = shard_rows(N, eng.n_ranks, eng.rank)
             if approx.rng == 'philox':
-                chi = approx._random_state(seed).chisquare(df, N)
+                # throughput mode, as ExclusiveKL's: chi-square draws and normals on the device, samples through the
+                # Cholesky factor x = mu + L z / s (same distribution as the symmetric root of approximations.py:348; no
+                # reference stream is reproduced in this mode) -- the chain rule is tril(sum w g (z / s)') itself: no
+                # matrix root, no Sylvester solve
+                eng.chisq_generate(df, end - begin, seed, 0, row_offset=begin)
                 eng.noise_generate(_NOISE_SLOT, end - begin, D, seed, 0, row_offset=begin)
+                mu, L = approx._unpack(var_param)
+                value, w_sum, g_sum, C = eng.alpha_sums_mvt(_NOISE_SLOT, end - begin, D, df, alpha, mu,
+                                                            np.ascontiguousarray(L.T), None,
+                                                            np.sum(np.log(np.diag(L))), n_total=N)
+                dL = np.tril(C)
+                dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + w_sum
+                return value, alpha * np.concatenate([g_sum, dL[tril]]) / N          # objectives.py:460
             else:
                 chi, z = approx._base_noise(N, seed)        # chi-square draws first (approximations.py:345-347)
                 eng.noise_set_host(_NOISE_SLOT, z[begin:end])
