@@ -338,6 +338,10 @@ struct FrWeighted {
   double scale;
   const double* wsum;
   const double* value;
+  // the samples Z = mu + (E root) [/ s] of this very noise and parameter, already formed by the caller (row stride
+  // round_up(d, 16); the alpha-divergence weights needed them): the pipeline does not repeat the sampling product for
+  // the targets that read plain samples (funnel, regression, source models)
+  const double* z_ready = nullptr;
 };
 int fr_sample_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_dev, double* Z,
                       const double* mu_dev = nullptr, const double* root_dev = nullptr,

@@ -1200,6 +1200,10 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   const unsigned sum_blocks = (unsigned)((pslab / 2 + 255) / 256);
   // Z = E L' + mu - shift into `Z` (the samples, or z - m for the correlated Gaussian target)
   auto sample_gemm = [&](const double* shift, int cfg) {
+    if (wm.z_ready && !shift) {      // (the caller's samples: see FrWeighted)
+      Z = const_cast<double*>(wm.z_ready);
+      return;
+    }
     if (kparts > 1) {
       gemm_f64_launch<true>(st, g1, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
       hipLaunchKernelGGL(fr_zsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,

@@ -297,6 +297,7 @@ int alpha_fullrank_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t 
   wm.scale = alpha / (double)n_total;          // objectives.py:460: alpha * vjp / N
   wm.wsum = scal + 9;
   wm.value = scal + 10;
+  wm.z_ready = Z;
   return fr_elbo_grad_enqueue(ctx, ns, n, d, n_total, theta_dev, out, 0, &wm);
 }
 
@@ -357,6 +358,7 @@ int alpha_mvt_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_tot
   wm.scale = alpha / (double)n_total;
   wm.wsum = scal + 9;
   wm.value = scal + 10;
+  wm.z_ready = Z;
   *value_wsum = scal + 9;                      // [sum w, value]
   return fr_pipeline_enqueue(ctx, ns, n, d, n_total, nullptr, nullptr, mu_dev, root_dev, invs_dev, sums, 0, &wm);
 }
