@@ -391,6 +391,11 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
   return VB_OK;
 }
 
+__global__ void __launch_bounds__(256) mvt_fill_kernel(double* __restrict__ dst, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+
 __global__ void __launch_bounds__(256) mvt_inv_scale_kernel(const double* __restrict__ chi, double df, int64_t n,
                                                             double* __restrict__ inv_s) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -501,7 +506,11 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   }
   ctx->mvt_dev_factors = dev_factors;
   std::vector<double> inv_s;
-  if (chi_host || df == 0.0) {
+  if (!chi_host && df == 0.0 && dev_factors) {
+    // the Gaussian member in throughput mode: s_n = 1, written on the device (no host vector, no synchronisation)
+    hipLaunchKernelGGL(mvt_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base + L.o_invs, n, 1.0);
+    VB_HIP(ctx, hipGetLastError());
+  } else if (chi_host || df == 0.0) {
     inv_s.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i)
       inv_s[i] = df > 0.0 ? 1.0 / sqrt(chi_host[i] / df) : 1.0;                       // approximations.py:345
@@ -539,7 +548,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice, st));
     uploads = true;
   }
-  if (uploads || chi_host || df == 0.0) VB_HIP(ctx, hipStreamSynchronize(st));      // stack-scoped staging buffers
+  if (uploads || !inv_s.empty()) VB_HIP(ctx, hipStreamSynchronize(st));      // stack-scoped staging buffers
 
   // X = mu + (Z R) / s
   GemmArgs g;

@@ -929,7 +929,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
             L, Linv = (None, None) if philox else factors(var_param)
             # ... and on one rank with a clipping threshold >= 1 (objectives.py:370-386 is the identity then; the default
             # is 10) the weights never leave the device either -- Pareto smoothing included (vb_dis_psis_mvt)
-            resident = philox and not gaussian and eng.n_ranks == 1 and self._w_clip_threshold >= 1.0
+            resident = philox and eng.n_ranks == 1 and self._w_clip_threshold >= 1.0
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
                 if gaussian:
                     chi = np.ones(N)
@@ -937,6 +937,14 @@ class DISInclusiveKL(StochasticVariationalObjective):
                         eng.noise_generate(slot, n_local, D, approx._seed, approx._next_philox_stream(),
                                            row_offset=begin)
                         root = None
+                        if resident:     # as the t family below: df = 0 is the Gaussian member of the same kernels
+                            eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._temper_prior_params,
+                                                         self._eps, self._ess_target, self._max_bisection_its)
+                            if self._psis_smooth:
+                                eng.dis_psis_mvt(N)
+                            self._set_state_logs(None, None, lambda: eng.dis_state_get(True, N))
+                            self._set_state_weights(None, lambda: eng.dis_weights_get(N))
+                            self._own_state(eng, 1, True)
                     else:
                         eng.noise_set_host(slot, approx._base_noise(N)[begin:end])
                         root = np.ascontiguousarray(L.T)        # x = mu + eps L'
