@@ -38,6 +38,7 @@ typedef struct vb_ctx vb_ctx;
 #define VB_ERR_STATE 4       /* call order / missing model or noise (RuntimeError) */
 #define VB_ERR_NUMERIC 5     /* e.g. 'All weights zero!' objectives.py:326-328      */
 #define VB_ERR_COMM 6        /* RCCL failure                                       */
+#define VB_ERR_CALLBACK 7    /* a host model callback returned non-zero (Python re-raises its exception) */
 
 /* approximation families (viabel/approximations.py) */
 #define VB_FAMILY_MF_GAUSSIAN 0        /* :192-251 */
@@ -132,6 +133,18 @@ int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams,
  * vb_alpha_grad_fullrank, vb_alpha_sums_mvt, vb_alpha_sums_lowrank), by the DIS refreshes (vb_dis_refresh_meanfield /
  * _mvt / _lowrank: log p of the state samples), by vb_log_weights_meanfield and by vb_model_logp.            */
 int vb_set_model_source(vb_ctx* ctx, int64_t dim, const char* source, const double* params, size_t n_params);
+/* A model that exists only as host code WITH its gradient -- the contract of the reference's StanModel
+ * (models.py:80-104: log_prob / grad_log_prob behind a vjp) and, with a numerical gradient on the caller's side, of
+ * Model(log_density) (models.py:17-39).  Wherever a source model's row kernel would run, the engine instead copies the
+ * n x d samples (row-major, dense) to pinned host memory, waits for the stream, calls
+ *     fn(user, z, n, d, f, grad)      -> 0 on success, anything else aborts the call with VB_ERR_CALLBACK
+ * which fills f[0..n) and -- unless grad is NULL (value-only calls: vb_model_logp, DIS refreshes, diagnostics) --
+ * grad[0..n*d), and copies both back.  Sampling, the variational log density, the weights and every reduction over the
+ * Monte-Carlo axis stay on the device: this is an adaptor for targets nobody will write in HIP, not a CPU path of the
+ * estimator.  Supported wherever vb_set_model_source is; every evaluation contains a host synchronisation, so the
+ * *_enqueue entry points and vb_fit block once per evaluation.  `fn` and `user` must outlive the binding.          */
+typedef int (*vb_model_callback)(void* user, const double* z, int64_t n, int64_t d, double* f, double* grad);
+int vb_set_model_callback(vb_ctx* ctx, int64_t dim, vb_model_callback fn, void* user);
 /* f(x_n), n < N, for host x (N x D): Model.__call__ (models.py:27-39) on the device */
 int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* out_host);
 /* f(x_n) and grad f(x_n), n < N, for host x (N x D): what autograd's grad of Model.__call__ returns in the

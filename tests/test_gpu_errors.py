@@ -50,8 +50,8 @@ def test_objective_level_errors(env):
         vb.MFStudentT(3, 2)                                     # approximations.py:258-259
     with pytest.raises(ValueError):
         vb.MultivariateT(3, 1.0)
-    with pytest.raises(TypeError):                              # a Python callable cannot run on the GPU
-        vb.ExclusiveKL(vb.MFGaussian(3), vb.Model(lambda x: -0.5 * np.sum(x ** 2, axis=1)), 10)(np.zeros(6))
+    with pytest.raises(TypeError):                              # neither a model nor a callable
+        vb.ExclusiveKL(vb.MFGaussian(3), 3.0, 10)
     with pytest.raises(ValueError):                             # wrong parameter length
         vb.ExclusiveKL(vb.MFGaussian(3), model, 10)(np.zeros(5))
     class Unset(vb.VariationalObjective):                       # a subclass that never builds its closure

@@ -279,3 +279,31 @@ def test_device_loop_regression_target():
     host = opt.Adam(0.02).optimize(35, obj_h, init, on_device=False)
     dev = opt.Adam(0.02).optimize(35, obj_d, init, on_device=True)
     _assert_same(host, dev)
+
+
+def test_resident_parameter_survives_a_fit_of_the_same_dimension():
+    """Round-3 ADVICE (medium): vb_fit's fused step leaves mu / L' of the FIT's iterate in the unpacked copy.  The
+    set_theta-once / enqueue-many pattern of the C API must still be evaluated at the resident parameter afterwards:
+    set_theta, enqueue, vb_fit (dense family, same d), enqueue again -- the two results are the same numbers."""
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    D, N = 20, 96
+    rng = np.random.RandomState(1)
+    A = rng.randn(D, D)
+    m, S = rng.randn(D), A @ A.T / D + np.eye(D)
+    model = vb.CorrelatedGaussianModel(m, covariance=S)
+    eng = _lib.default_engine()
+    eng.set_model(model.device_spec())
+    fr = vb.FullRankGaussian(D)
+    theta = fr.pack(0.3 * rng.randn(D), np.tril(0.1 * rng.randn(D, D), -1) + np.exp(-0.5) * np.eye(D))
+    slot, fit_slot = 5, 6
+    eng.noise_generate(slot, N, D, seed=11, stream=3)
+    eng.fullrank_set_theta(theta, D)
+    eng.elbo_grad_fullrank_enqueue(slot, N, D)
+    v0, g0 = eng.fullrank_get(D)
+    init = fr.pack(np.zeros(D), np.exp(-1.0) * np.eye(D))
+    eng.fit(fit_slot, N, D, _lib.FAMILY_FULLRANK_GAUSSIAN, init, 5, _lib.OPT_RMSPROP, [0.01, 0.9, 0.9, 1e-8], seed=2)
+    eng.elbo_grad_fullrank_enqueue(slot, N, D)
+    v1, g1 = eng.fullrank_get(D)
+    assert v1 == v0
+    np.testing.assert_array_equal(g1, g0)

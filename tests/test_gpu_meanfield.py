@@ -203,9 +203,11 @@ def test_invalid_hessian_approx_method(vb):
                                "'loo_diag_approx', 'loo_direct_approx' or None object.")
 
 
-def test_host_callable_rejected(vb):
+def test_host_callable_is_bound_as_callable_model(vb):
+    obj = vb.ExclusiveKL(vb.MFGaussian(2), lambda x: -0.5 * np.sum(x ** 2, axis=1), 10)
+    assert isinstance(obj.model, vb.CallableModel) and obj.model.dim == 2
     with pytest.raises(TypeError):
-        vb.ExclusiveKL(vb.MFGaussian(2), lambda x: -0.5 * np.sum(x ** 2, axis=1), 10)
+        vb.ExclusiveKL(vb.MFGaussian(2), 'not a model', 10).model
 
 
 def test_philox_noise_is_standard_normal_and_shard_invariant(vb):

@@ -782,3 +782,31 @@ def test_dis_fullrank_philox_mode_against_oracle(vb, use_resampling):
         assert G.rel_err(grad, og) < 1e-9, (step, G.rel_err(grad, og))
         assert G.rel_err(obj._state_log_q, ref._state_log_q) < 1e-11
         theta = theta - 0.002 * grad / (1 + np.abs(grad))
+
+
+def test_dis_prior_copy_follows_the_layout_across_sample_counts(vb):
+    """Round-3 ADVICE (high): the device copy of the tempering prior sits at an offset that moves with
+    num_mc_samples.  Two DISInclusiveKL objectives on one engine, same D and same prior, N = 4096 then N = 1024
+    (the smaller job reuses the allocation): both must match the oracle on the read-back noise."""
+    from viabel_amd import _lib
+    from viabel_amd.objectives import _DIS_SLOT
+    D = 64
+    rng = np.random.RandomState(29)
+    mean, sd = 0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    prior = np.concatenate([0.1 * rng.randn(D), 0.3 + 0.05 * rng.randn(D)])
+    ofamily = ofam.FullRankGaussian(D)
+    eng = _lib.default_engine()
+    L = np.tril(0.05 * rng.randn(D, D), -1) + np.diag(np.exp(-0.2 + 0.1 * rng.randn(D)))
+    for N in (4096, 1024, 2048):
+        approx = vb.FullRankGaussian(D, seed=8, rng='philox')
+        theta = approx.pack(0.1 * rng.randn(D), L)
+        obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+                                temper_prior_params=prior, use_resampling=False)
+        ref = oobj.DISInclusiveKL(ofamily, omodel, N, N // 8, ofam.MFGaussian(D), prior, use_resampling=False)
+        value, grad = obj(theta)
+        noise = eng.noise_get_host(_DIS_SLOT, N, D)
+        ov, og = ref(theta, noise=noise)
+        assert G.rel_err(obj._eps, ref._eps) < 1e-10, (N, obj._eps, ref._eps)
+        assert G.rel_err(value, ov) < 1e-10, (N, value, ov)
+        assert G.rel_err(grad, og) < 1e-9, (N, G.rel_err(grad, og))

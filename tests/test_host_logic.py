@@ -143,7 +143,9 @@ def test_bbvi_argument_validation():
     with pytest.raises(ValueError):
         vb.bbvi(2, objective=True, log_density=True)
     with pytest.raises(TypeError):
-        vb.bbvi(2, log_density=lambda x: -x ** 2)
+        vb.bbvi(2, log_density=3.0)
+    with pytest.raises(ValueError):
+        vb.bbvi(2, log_density=vb.GaussianModel([0, 0], [1, 1]), grad_log_density=lambda x: -x)
 
 
 def test_family_parameter_space_methods_match_golden():

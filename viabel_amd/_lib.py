@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VIABEL_AMD_LIB') or os.path.join(_HERE, 'libviabel_hip.so')
 CSRC_DIR = os.path.join(_HERE, 'csrc')
 
-VB_OK, VB_ERR_INVALID, VB_ERR_HIP, VB_ERR_UNSUPPORTED, VB_ERR_STATE, VB_ERR_NUMERIC, VB_ERR_COMM = range(7)
+VB_OK, VB_ERR_INVALID, VB_ERR_HIP, VB_ERR_UNSUPPORTED, VB_ERR_STATE, VB_ERR_NUMERIC, VB_ERR_COMM, VB_ERR_CALLBACK = range(8)
 
 FAMILY_MF_GAUSSIAN, FAMILY_MF_STUDENT_T, FAMILY_FULLRANK_GAUSSIAN, FAMILY_MULTIVARIATE_T, FAMILY_LOWRANK_GAUSSIAN = \
     range(5)
@@ -27,6 +27,9 @@ FLAG_PATH_DERIV = 1
 CV_MODES = {None: 0, 'full': 1, 'mean_only': 2, 'loo_diag_approx': 3, 'loo_direct_approx': 4}
 MAX_SLOTS = 64
 OPT_SGD, OPT_RMSPROP, OPT_ADAM, OPT_ADAGRAD = range(4)
+# int fn(void* user, const double* z, int64 n, int64 d, double* f, double* grad)   (include/viabel_hip.h: vb_model_callback)
+MODEL_CALLBACK_TYPE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64,
+                                       ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
 COMM_ID_BYTES = 128
 PROF_MF_ACCUM, PROF_FR_SAMPLE_GEMM, PROF_FR_MODEL_GEMM, PROF_FR_GRAD_GEMM = range(4)
 
@@ -55,6 +58,7 @@ SIGNATURES = {
     'vb_set_model': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, _c_double_p, ctypes.c_size_t,
                                     _c_int64_p, ctypes.c_size_t]),
     'vb_set_model_source': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_char_p, _c_double_p, ctypes.c_size_t]),
+    'vb_set_model_callback': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     'vb_model_logp': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
     'vb_model_grad': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_elbo_sums_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -274,6 +278,11 @@ class Engine:
         if rc == VB_OK:
             return
         msg = self._lib.vb_last_error(self._ctx).decode()
+        if rc == VB_ERR_CALLBACK:                    # a host model callable raised: hand its own exception on
+            holder = getattr(self, '_callback_error', None)
+            if holder and holder[0] is not None:
+                exc, holder[0] = holder[0], None
+                raise exc
         if rc == VB_ERR_INVALID or rc == VB_ERR_NUMERIC:
             raise ValueError(msg)
         if rc == VB_ERR_UNSUPPORTED:
@@ -324,6 +333,12 @@ class Engine:
         if key == self._model_key:
             return
         self._model_arrays = tuple(spec[2:])         # keep them alive so the ids stay unique
+        if model_id == MODEL_SOURCE and isinstance(spec[4], MODEL_CALLBACK_TYPE):
+            # spec = (id, dim, -, -, ctypes callback, error holder): a host callable with its gradient
+            self._check(self._lib.vb_set_model_callback(self._ctx, dim, ctypes.cast(spec[4], ctypes.c_void_p), None))
+            self._callback_error = spec[5]
+            self._model_key = key
+            return
         if model_id == MODEL_SOURCE:                 # spec = (id, dim, params, iparams (unused), source bytes)
             params = _f64(dparams)
             self._check(self._lib.vb_set_model_source(self._ctx, dim, spec[4], _dptr(params) if params.size else None,

@@ -2,9 +2,9 @@
 
 Same keyword interface, validation errors and optimiser wiring as the reference:
 ``adaptive and not fixed_lr`` -> RAABBVI(RMSProp), ``adaptive and fixed_lr`` -> FASO(RMSProp),
-``not adaptive and fixed_lr`` -> RMSProp.  Differences forced by the GPU engine: ``log_density`` must be
-a device model (``viabel_amd.models.DeviceModel``) rather than a Python callable, and ``fit`` (PyStan)
-is not supported.
+``not adaptive and fixed_lr`` -> RMSProp.  ``log_density`` is a device model
+(``viabel_amd.models.DeviceModel``), HIP source, or a Python callable (bound as a ``CallableModel``: evaluated on the
+host between the device's sampling and reduction kernels); ``fit`` (PyStan) is not supported.
 """
 import numpy as np
 
@@ -12,7 +12,7 @@ from . import _lib
 from ._psis import psislw
 from .approximations import MFGaussian, MFStudentT
 from .diagnostics import all_diagnostics
-from .models import DeviceModel, SourceModel
+from .models import CallableModel, DeviceModel, SourceModel
 from .objectives import ExclusiveKL
 from .optimization import FASO, RAABBVI, RMSProp
 
@@ -21,9 +21,11 @@ __all__ = ['bbvi', 'vi_diagnostics', 'psis_correction', 'samples_and_log_weights
 
 def bbvi(dimension, *, n_iters=10000, num_mc_samples=10, log_density=None, approx=None, objective=None,
          fit=None, adaptive=True, fixed_lr=False, init_var_param=None, learning_rate=0.01,
-         RMS_kwargs=dict(), FASO_kwargs=dict(), RAABBVI_kwargs=dict()):
+         RMS_kwargs=dict(), FASO_kwargs=dict(), RAABBVI_kwargs=dict(), grad_log_density=None):
     """Fit a model with black-box variational inference; returns the optimiser's result dict plus
-    ``'objective'`` (``convenience.py:92-94``)."""
+    ``'objective'`` (``convenience.py:92-94``).  ``log_density``: a device model, HIP source, or -- the reference's
+    own form -- a callable ``(N, D) -> (N,)``, optionally with ``grad_log_density`` ``(N, D) -> (N, D)`` (an addition:
+    the reference differentiates the callable with autograd; without a gradient the engine uses central differences)."""
     if objective is not None:
         if fit is not None or log_density is not None or approx is not None:
             raise ValueError('if objective is specified, cannot specify fit, log_density, or approx')
@@ -40,9 +42,15 @@ def bbvi(dimension, *, n_iters=10000, num_mc_samples=10, log_density=None, appro
             # a density written generically over vb::vec<T> carries no gradient: the engine differentiates it
             log_density = SourceModel(dimension, log_density, grad='auto' if b'vb::vec' in src else 'explicit')
         if not isinstance(log_density, DeviceModel):
-            raise TypeError('log_density must be a viabel_amd device model (GaussianModel, FunnelModel, '
-                            'CorrelatedGaussianModel, a regression model, or a SourceModel / HIP source string '
-                            'defining vb_log_density): Python callables cannot run on the GPU')
+            # the reference's front door (convenience.py:69-75: Model(log_density) + autograd): a host callable, with
+            # `grad_log_density` when the caller has one (the StanModel contract, models.py:80-104)
+            if not callable(log_density):
+                raise TypeError('log_density must be a viabel_amd device model (GaussianModel, FunnelModel, '
+                                'CorrelatedGaussianModel, a regression model, a SourceModel / HIP source string '
+                                'defining vb_log_density) or a callable (N, D) -> (N,)')
+            log_density = CallableModel(dimension, log_density, grad_log_density)
+        elif grad_log_density is not None:
+            raise ValueError('grad_log_density goes with a callable log_density')
         if approx is None:
             approx = MFGaussian(dimension)
         objective = ExclusiveKL(approx, log_density, num_mc_samples)

@@ -32,6 +32,10 @@ int ensure(vb_ctx* ctx, DeviceBuffer& b, size_t bytes) {
     VB_HIP(ctx, hipFree(b.ptr));
     b.ptr = nullptr;
     b.bytes = 0;
+    if (&b == &ctx->mvt_state) {      // caches keyed on the state buffer: a new allocation may return the old address
+      ctx->mvt_prior.clear();
+      ctx->mvt_inv_key[0] = 0;
+    }
   }
   size_t cap = bytes < 256 ? 256 : bytes;
   VB_HIP(ctx, hipMalloc(&b.ptr, cap));
@@ -237,6 +241,9 @@ int vb_destroy(vb_ctx* ctx) {
                           &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
+  if (ctx->user_host_pin) (void)hipHostFree(ctx->user_host_pin);
+  for (hipEvent_t e : ctx->mvt_pin_ev)
+    if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& log : ctx->prof)
     for (auto& ev : log.events) {
@@ -434,6 +441,14 @@ int vb_set_model_source(vb_ctx* ctx, int64_t dim, const char* source, const doub
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
   return user_model_set(ctx, dim, source, params, n_params);
+}
+
+int vb_set_model_callback(vb_ctx* ctx, int64_t dim, vb_model_callback fn, void* user) {
+  if (!ctx) return VB_ERR_INVALID;
+  if (!fn) return fail(ctx, VB_ERR_INVALID, "NULL callback");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  return user_model_set_callback(ctx, dim, fn, user);
 }
 
 int vb_model_logp(vb_ctx* ctx, const double* x_host, int64_t n, int64_t d, double* out_host) {
@@ -1126,6 +1141,19 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
       ((family == VB_FAMILY_MF_GAUSSIAN && noise_kind == VB_NOISE_NORMAL) ||
        (family == VB_FAMILY_MF_STUDENT_T && noise_kind == VB_NOISE_STUDENT_T && noise_df == df));
   bool step_done = false, prep_done = false;
+  // the dense family's fused step leaves mu / L' of the FIT's iterate in fr_lt (fr_step_unpack_enqueue): on every way out
+  // of this function -- error returns included -- the copy is declared stale for the resident parameter too, or a later
+  // set_theta-once / enqueue-many caller with the same d would be evaluated at the fit's parameter
+  struct LtReset {
+    vb_ctx* c;
+    bool on;
+    ~LtReset() {
+      if (on) {
+        c->fr_lt_owner = nullptr;
+        c->fr_lt_d = 0;
+      }
+    }
+  } lt_reset{ctx, fullrank};
   if (meanfield) {
     c.step = &step;
     c.step_done = &step_done;
@@ -1171,7 +1199,6 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
     }
     if (!step_done) VB_TRY(fit_step_enqueue(ctx, step));
   }
-  ctx->fr_lt_owner = nullptr;      // (fit_work may be reused by the next fit with other contents)
   VB_HIP(ctx, hipMemcpyAsync(theta, theta_dev, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpyAsync(values, base + o_val, (size_t)n_iters * sizeof(double), hipMemcpyDeviceToHost, st));
   if (state) {

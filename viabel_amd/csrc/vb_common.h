@@ -159,6 +159,11 @@ struct vb_ctx {
     int parts;                          // threads per sample (VB_LOG_DENSITY_PARTS of the source, 1 without)
   };
   int user_parts = 1;                   // ... of the module in use
+  // a host callable with its gradient (vb_set_model_callback): the row "kernel" is a round trip through pinned memory
+  vb_model_callback user_host_fn = nullptr;
+  void* user_host_arg = nullptr;
+  double* user_host_pin = nullptr;      // [z (n x d) | f (n) | g (n x d)]
+  size_t user_host_pin_doubles = 0;
   std::vector<UserModule> user_modules;
   vb::DeviceBuffer user_params;
   vb::DeviceBuffer glm_work;            // regression targets: split-K slabs of the gradient GEMM
@@ -172,6 +177,7 @@ struct vb_ctx {
   double* mvt_pin = nullptr;            // pinned staging of the throughput mode's parameter upload (no synchronisation)
   size_t mvt_pin_doubles = 0;
   int mvt_pin_slot = 0;
+  hipEvent_t mvt_pin_ev[2] = {nullptr, nullptr};   // recorded behind each slot's staged copy; waited for before the slot is rewritten
   std::vector<double> mvt_prior;        // tempering-prior parameter the device copy was made from
   int64_t mvt_inv_key[4] = {0, 0, 0, 0};   // (state buffer, n, n_total, d) for which the inverse's zero triangle is known clean
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
@@ -293,6 +299,7 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
 int user_rows_enqueue(vb_ctx* ctx, hipStream_t st, const double* Z, int64_t ldz, int64_t n, int d, double* G,
                       int64_t ldg, double* f);
 void user_model_release(vb_ctx* ctx);
+int user_model_set_callback(vb_ctx* ctx, int64_t dim, vb_model_callback fn, void* user);
 int pipe_init(vb_ctx* ctx);
 
 // per-row log weights and AlphaDivergence (vb_rowstats.hip)

@@ -302,12 +302,17 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
     VB_HIP(ctx, hipHostMalloc((void**)&ctx->mvt_pin, 2 * p * sizeof(double), hipHostMallocDefault));
     ctx->mvt_pin_doubles = p;
   }
-  // two staging slots taken in turn: a call forms the factors at most twice (refresh, gradient at another parameter)
-  // and every call synchronises before it returns, so a slot's previous copy has always completed
+  // two staging slots taken in turn; an event behind each slot's copy is waited for before the slot is rewritten (a
+  // deferred refresh returns without a synchronisation, so back-to-back refreshes could otherwise overwrite a slot
+  // whose copy is still queued behind kernels)
   ctx->mvt_pin_slot ^= 1;
+  hipEvent_t& slot_ev = ctx->mvt_pin_ev[ctx->mvt_pin_slot];
+  if (!slot_ev) VB_HIP(ctx, hipEventCreateWithFlags(&slot_ev, hipEventDisableTiming));
+  else VB_HIP(ctx, hipEventSynchronize(slot_ev));
   double* stage = ctx->mvt_pin + (size_t)ctx->mvt_pin_slot * ctx->mvt_pin_doubles;
   memcpy(stage, theta_host, p * sizeof(double));
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_theta, stage, p * sizeof(double), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipEventRecord(slot_ev, st));
   VB_HIP(ctx, hipMemsetAsync(base + L.o_mu, 0, (size_t)(2 * L.ld) * sizeof(double), st));
   VB_TRY(fr_unpack_enqueue(ctx, st, base + L.o_theta, D, L.ld, base + L.o_lt, base + L.o_mu));
   // the inverse's strictly lower triangle (and the scratch) need zeroing only when the buffer or its layout changed:
@@ -534,12 +539,16 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   // the state buffer), and in throughput mode mu is on the device already (the unpack) -- then nothing is uploaded
   // here and the refresh does not wait for the stream at all
   bool uploads = false;
-  const bool prior_cached = ctx->mvt_prior.size() == (size_t)(2 * d + 1) && ctx->mvt_prior[2 * d] == (double)(uintptr_t)base &&
+  // (the key carries the copy's own offset and the layout's sizes: o_prior moves with n and n_total, and a smaller job
+  // reuses the allocation -- base alone would let a second objective with another num_mc_samples read a stale copy)
+  const double prior_key[5] = {(double)(uintptr_t)base, (double)L.o_prior, (double)n, (double)n_total, (double)L.ld};
+  const bool prior_cached = ctx->mvt_prior.size() == (size_t)(2 * d + 5) &&
+                            memcmp(ctx->mvt_prior.data() + 2 * d, prior_key, sizeof prior_key) == 0 &&
                             memcmp(ctx->mvt_prior.data(), prior_host, (size_t)(2 * d) * sizeof(double)) == 0;
   if (!prior_cached) {
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice, st));
     ctx->mvt_prior.assign(prior_host, prior_host + 2 * d);
-    ctx->mvt_prior.push_back((double)(uintptr_t)base);
+    ctx->mvt_prior.insert(ctx->mvt_prior.end(), prior_key, prior_key + 5);
     uploads = true;
   }
   std::vector<double> mu((size_t)L.ld, 0.0);

@@ -457,12 +457,53 @@ int user_model_bind(vb_ctx* ctx, int64_t dim, const double* params, size_t n_par
   m.c0 = 0.0;
   m.p0 = (const double*)ctx->user_params.ptr;
   ctx->model = m;
+  ctx->user_host_fn = nullptr;      // a compiled source replaces a host callback
+  ctx->user_host_arg = nullptr;
+  return VB_OK;
+}
+
+// A host callable with its gradient (vb_set_model_callback; models.py:80-104): to every pipeline it is a source model
+// whose row kernel happens to be a round trip through pinned host memory (user_rows_enqueue below).
+int user_model_set_callback(vb_ctx* ctx, int64_t dim, vb_model_callback fn, void* user) {
+  if (dim <= 0) return fail(ctx, VB_ERR_INVALID, "model dimension must be positive");
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VB_TRY(user_model_bind(ctx, dim, nullptr, 0));
+  ctx->user_host_fn = fn;
+  ctx->user_host_arg = user;
+  return VB_OK;
+}
+
+static int user_rows_host(vb_ctx* ctx, hipStream_t st, const double* Z, int64_t ldz, int64_t n, int d, double* G,
+                          int64_t ldg, double* f) {
+  const size_t nd = (size_t)n * (size_t)d, need = 2 * nd + (size_t)n;
+  if (ctx->user_host_pin_doubles < need) {
+    if (ctx->user_host_pin) {
+      VB_HIP(ctx, hipStreamSynchronize(st));
+      VB_HIP(ctx, hipHostFree(ctx->user_host_pin));
+      ctx->user_host_pin = nullptr;
+      ctx->user_host_pin_doubles = 0;
+    }
+    VB_HIP(ctx, hipHostMalloc((void**)&ctx->user_host_pin, need * sizeof(double), hipHostMallocDefault));
+    ctx->user_host_pin_doubles = need;
+  }
+  double *zh = ctx->user_host_pin, *fh = zh + nd, *gh = fh + n;
+  const size_t row = (size_t)d * sizeof(double);
+  VB_HIP(ctx, hipMemcpy2DAsync(zh, row, Z, (size_t)ldz * sizeof(double), row, (size_t)n, hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  const int rc = ctx->user_host_fn(ctx->user_host_arg, zh, n, (int64_t)d, fh, G ? gh : nullptr);
+  if (rc != 0) return fail(ctx, VB_ERR_CALLBACK, "model callback returned %d", rc);
+  VB_HIP(ctx, hipMemcpyAsync(f, fh, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  if (G)
+    VB_HIP(ctx, hipMemcpy2DAsync(G, (size_t)ldg * sizeof(double), gh, row, row, (size_t)n, hipMemcpyHostToDevice, st));
+  // the pinned buffer is reused by the next call: its copies must have left before that call's D2H lands in it, which
+  // stream order guarantees (the next D2H is enqueued behind these H2D copies on the same stream)
   return VB_OK;
 }
 
 // f[row] = f(Z[row]), G[row] = grad f(Z[row]) (G may be NULL) for the bound source model
 int user_rows_enqueue(vb_ctx* ctx, hipStream_t st, const double* Z, int64_t ldz, int64_t n, int d, double* G,
                       int64_t ldg, double* f) {
+  if (ctx->model.id == VB_MODEL_SOURCE && ctx->user_host_fn) return user_rows_host(ctx, st, Z, ldz, n, d, G, ldg, f);
   if (!ctx->user_fn || ctx->model.id != VB_MODEL_SOURCE) return fail(ctx, VB_ERR_STATE, "no source model bound");
   long long ldz_ = ldz, n_ = n, ldg_ = ldg;
   const double* params = (const double*)ctx->user_params.ptr;

@@ -13,15 +13,17 @@ import numpy as np
 from . import _lib
 
 __all__ = ['Model', 'DeviceModel', 'GaussianModel', 'FunnelModel', 'CorrelatedGaussianModel',
-           'LogisticRegressionModel', 'PoissonRegressionModel', 'LinearRegressionModel', 'SourceModel']
+           'LogisticRegressionModel', 'PoissonRegressionModel', 'LinearRegressionModel', 'SourceModel',
+           'CallableModel']
 
 
 class Model(object):
     """Base class for representing a model (``viabel/models.py:11-77``).
 
-    A plain ``Model(log_density)`` wraps a host callable.  It can be *called* (diagnostics),
-    but the HIP objectives need a :class:`DeviceModel`; handing them a host callable raises
-    ``TypeError`` rather than falling back to a CPU path.
+    A plain ``Model(log_density)`` wraps a host callable.  The objectives bind it as a
+    :class:`CallableModel` (the callable is evaluated on the host between the device's sampling and
+    reduction kernels, its gradient by central differences); the built-in device models and
+    :class:`SourceModel` are the fast routes.
     """
 
     def __init__(self, log_density):
@@ -155,6 +157,106 @@ class SourceModel(DeviceModel):
 
     def _build_spec(self):
         return (_lib.MODEL_SOURCE, self._dim, self.params, np.zeros(0, dtype=np.int64), self._source)
+
+
+class CallableModel(DeviceModel):
+    """A target that exists only as a host (Python) callable -- the reference's front door ``Model(log_density)``
+    (``viabel/models.py:17-39``, ``convenience.py:69-75``) and, with ``grad_log_density``, the contract of its
+    ``StanModel`` (``models.py:80-104``: ``log_prob`` with ``grad_log_prob`` as its vector-Jacobian product).
+
+    ``log_density``: ``(N, D) ndarray -> (N,)``; ``grad_log_density``: ``(N, D) -> (N, D)``.  Alternatively
+    ``value_and_grad``: ``(N, D) -> ((N,), (N, D))`` in one call.  Without a gradient the engine differentiates the
+    callable numerically (central differences, ``2 D`` extra calls per evaluation, relative error ~1e-9; the reference
+    uses autograd, which is not available to a foreign callable here) and says so once in a ``UserWarning``.
+
+    The estimator stays on the GPU: the engine draws the samples, hands them to the callable through pinned host
+    memory (``vb_set_model_callback``), takes ``f`` and ``grad f`` back and runs the variational log density, the
+    weights and every Monte-Carlo reduction on the device as for a :class:`SourceModel` -- so every objective x family
+    combination a source model supports is supported.  Each evaluation contains a host round trip of ``3 N D``
+    doubles plus the callable's own time; :class:`SourceModel` is the fast route."""
+
+    def __init__(self, dim, log_density=None, grad_log_density=None, value_and_grad=None, fd_step=1e-6):
+        if log_density is None and value_and_grad is None:
+            raise ValueError('give log_density or value_and_grad')
+        for fn in (log_density, grad_log_density, value_and_grad):
+            if fn is not None and not callable(fn):
+                raise TypeError('log_density / grad_log_density / value_and_grad must be callables')
+        self._f, self._g, self._fg = log_density, grad_log_density, value_and_grad
+        self._fd_step = float(fd_step)
+        self._warned = False
+        self._error = [None]
+        super().__init__(dim)
+        self._callback = _lib.MODEL_CALLBACK_TYPE(self._trampoline)
+
+    # -- host evaluation ------------------------------------------------------------------------------------------
+    def _values(self, z):
+        f = self._f(z) if self._f is not None else self._fg(z)[0]
+        f = np.asarray(f, dtype=np.float64)
+        if f.shape != (z.shape[0],):
+            raise ValueError('log_density returned shape {}, expected ({},)'.format(f.shape, z.shape[0]))
+        return f
+
+    def _values_and_grads(self, z):
+        n, d = z.shape
+        if self._fg is not None:
+            f, g = self._fg(z)
+        elif self._g is not None:
+            f, g = self._f(z), self._g(z)
+        else:
+            if not self._warned:
+                import warnings
+                warnings.warn('CallableModel without a gradient: differentiating the callable by central differences '
+                              '(2 D extra calls per evaluation); pass grad_log_density or value_and_grad, or write '
+                              'the density as a SourceModel', UserWarning, stacklevel=3)
+                self._warned = True
+            f = self._f(z)
+            h = self._fd_step * np.maximum(1.0, np.abs(z))
+            g = np.empty((n, d))
+            for j in range(d):                      # one batched call per coordinate and side
+                zp, zm = z.copy(), z.copy()
+                zp[:, j] += h[:, j]
+                zm[:, j] -= h[:, j]
+                g[:, j] = (np.asarray(self._f(zp), dtype=np.float64) - np.asarray(self._f(zm), dtype=np.float64)) \
+                    / (zp[:, j] - zm[:, j])
+        f = np.asarray(f, dtype=np.float64)
+        g = np.asarray(g, dtype=np.float64)
+        if f.shape != (n,) or g.shape != (n, d):
+            raise ValueError('model callables returned shapes {} / {}, expected ({},) / ({}, {})'.format(
+                f.shape, g.shape, n, n, d))
+        return f, g
+
+    def _trampoline(self, _user, zp, n, d, fp, gp):
+        try:
+            z = np.ctypeslib.as_array(zp, shape=(n, d)).copy()       # the callable may keep or modify its argument
+            if gp:
+                f, g = self._values_and_grads(z)
+                np.ctypeslib.as_array(gp, shape=(n, d))[...] = g
+            else:
+                f = self._values(z)
+            np.ctypeslib.as_array(fp, shape=(n,))[...] = f
+            return 0
+        except BaseException as exc:      # noqa: B902 -- an exception must not unwind through the C frames
+            self._error[0] = exc
+            return 1
+
+    def _build_spec(self):
+        empty = np.zeros(0)
+        return (_lib.MODEL_SOURCE, self._dim, empty, np.zeros(0, dtype=np.int64), self._callback, self._error)
+
+
+def as_device_model(model, dim):
+    """What the objectives bind: a :class:`DeviceModel` as it is; the reference's ``Model(log_density)`` or a bare
+    callable as a :class:`CallableModel` of dimension ``dim`` (gradient by central differences unless the caller
+    builds the ``CallableModel`` with one)."""
+    if isinstance(model, DeviceModel):
+        return model
+    if isinstance(model, Model):
+        return CallableModel(dim, model._log_density)
+    if callable(model):
+        return CallableModel(dim, model)
+    raise TypeError('model must be a viabel_amd device model (GaussianModel, FunnelModel, CorrelatedGaussianModel, a '
+                    'regression model, SourceModel), a Model(log_density) or a callable; got %r'
+                    % type(model).__name__)
 
 
 class GaussianModel(DeviceModel):

@@ -20,7 +20,7 @@ from scipy import special as _special
 
 from . import _lib
 from .approximations import MFGaussian, MFStudentT, FullRankGaussian, MultivariateT, LRGaussian, symmetric_eig, symmetric_root
-from .models import DeviceModel, SourceModel
+from .models import DeviceModel, SourceModel, as_device_model
 
 __all__ = [
     'VariationalObjective',
@@ -159,7 +159,7 @@ class VariationalObjective(ABC):
 
     def __init__(self, approx, model):
         self._approx = approx
-        self._model = model
+        self._model = as_device_model(model, approx.dim) if model is not None else None
         self._objective_and_grad = None
         self._update_objective_and_grad()
 
@@ -190,7 +190,7 @@ class VariationalObjective(ABC):
 
     @model.setter
     def model(self, value):
-        self._model = value
+        self._model = as_device_model(value, self._approx.dim) if value is not None else None
         self._update_objective_and_grad()
 
     # -- engine plumbing shared by the concrete objectives --------------------------------------
@@ -201,9 +201,8 @@ class VariationalObjective(ABC):
         if not isinstance(self._model, DeviceModel):
             raise TypeError(
                 'the HIP engine needs a device-resident model (viabel_amd.models.DeviceModel: '
-                'GaussianModel, FunnelModel, CorrelatedGaussianModel, the regression models, or a SourceModel '
-                'holding the log density as HIP code); got %r. Arbitrary Python '
-                'log densities cannot run on the GPU and there is no CPU fallback.'
+                'GaussianModel, FunnelModel, CorrelatedGaussianModel, the regression models, a SourceModel '
+                'holding the log density as HIP code, or a CallableModel around a host callable); got %r.'
                 % type(self._model).__name__)
         if self._model.dim != self._approx.dim:
             raise ValueError('model dimension {} != approximation dimension {}'.format(
