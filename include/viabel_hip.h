@@ -202,6 +202,21 @@ int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t
  * Clipping (:370-386) and resampling (:408, global numpy RNG) stay with the caller, which hands
  * the per-sample weights (clipped w, or resampling counts) to
  * grad: value = -scale sum_n weights_n log q(z_n; theta), grad = d value / d theta (:405-414).  */
+/* The tempering prior of DISInclusiveKL may be any approximation family (objectives.py:283-285, :317-319 call
+ * temper_prior.log_density(temper_prior_params, z)).  The refresh calls below take the common case -- an MFGaussian
+ * parameter (tests/test_objectives.py:82-87) -- as their `prior` argument; any other prior is installed here and then
+ * REPLACES that argument in every vb_dis_refresh_* of the context until VB_PRIOR_DIAG_GAUSSIAN is set again:
+ *   VB_PRIOR_DIAG_STUDENT_T  MFStudentT (approximations.py:281-286): loc (d), scale = log sigma (d), df > 0
+ *   VB_PRIOR_DENSE           log pi0(x) = c - log_det_l - 1/2 |L^-1 (x - loc)|^2 (df = 0: FullRankGaussian, or any
+ *                            Gaussian family through the Cholesky factor of its covariance) or the multivariate t
+ *                            log pdf of _distributions.py:7-38 (df > 0): loc (d), scale = L^-1 (d x d row-major, lower
+ *                            triangular), log_det_l = sum log L_ii.  One more N x d x d MFMA product per refresh.
+ * The state samples are materialised for it where the refresh would not need them (mean-field families).            */
+#define VB_PRIOR_DIAG_GAUSSIAN 0
+#define VB_PRIOR_DIAG_STUDENT_T 1
+#define VB_PRIOR_DENSE 2
+int vb_dis_set_temper_prior(vb_ctx* ctx, int kind, int64_t d, double df, const double* loc, const double* scale,
+                            double log_det_l);
 int vb_dis_refresh_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, int family, double df,
                              const double* theta, const double* prior_theta, double eps_prev,
                              double ess_target, int max_bisection_its, double* eps, double* ess,
@@ -246,7 +261,7 @@ int vb_dis_grad_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const d
  * device), and returns (value, grad) together with eps and ess of the refresh after ONE synchronisation: no weight
  * vector crosses PCIe, no host work of order N.  vb_dis_weights_get fetches the tempered weights for callers that
  * want to look at them.  The weight clipping of objectives.py:370-386 is the identity for thresholds >= 1 (the
- * default is 10): callers with a smaller threshold use the two-call path.                                      */
+ * default is 10); a smaller threshold is applied to the resident weights by vb_dis_clip_mvt before the step.      */
 int vb_dis_step_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, int64_t resample_m,
                            uint64_t seed, uint64_t stream, double scale, double* eps, double* ess,
                            double* khat /* NULL, or the tail shape of the last vb_dis_psis_mvt */, double* value, double* grad);
@@ -255,6 +270,12 @@ int vb_dis_step_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const d
  * is viabel/_psis.py:113-209 as vb_psis_smooth does it).  Enqueues only; the step that follows uses the smoothed weights
  * and reports khat. */
 int vb_dis_psis_mvt(vb_ctx* ctx, int64_t n_total, double reff);
+/* ... and weight clipping (objectives.py:370-386, w_clip_threshold < 1) of the device-resident weights in place, after
+ * the smoothing when both are on (the order of objectives.py:398-399 with psis_smooth in front).  The reference's own
+ * line :385 cannot run; what is computed is the fixed point its recursion aims at -- weights at or above
+ * threshold * sum(w_clipped) are set to exactly that value, the clipped set growing round by round until no unclipped
+ * weight reaches it (oracle.objectives.DISInclusiveKL._clip).  Enqueues only (one workgroup, fixed summation order). */
+int vb_dis_clip_mvt(vb_ctx* ctx, int64_t n_total, double threshold);
 int vb_dis_weights_get(vb_ctx* ctx, double* w, int64_t n_total, int resampled /* 1: the counts of the last draw */);
 /* The DIS state samples live in the context, one set per family kind (0: mean-field, 1: MultivariateT / dense
  * Gaussian, 2: low-rank Gaussian); every refresh of a kind overwrites its set and bumps its generation counter.  A

@@ -379,20 +379,38 @@ class DISInclusiveKL:
         return eps_guess, ess, w
 
     def _clip(self, w):                                             # :370-386
-        S = np.sum(w)
+        """Weight clipping.  The reference's recursion (``:370-386``) cannot run (``:385`` calls a float), and its
+        evident intent -- set every weight at or above ``thr * sum(w)`` to the value that makes it exactly
+        ``thr * sum(w_new)``, repeat -- is not well defined in floating point as a literal recursion: a clipped weight
+        EQUALS the next level's threshold up to rounding, so ``np.any(w > S * thr)`` re-triggers on rounding noise and
+        the recursion does not terminate for about one weight vector in ten (measured, thr in {0.01, 0.05, 0.2}).
+        Restated as the fixed point the recursion aims at: the clipped set only grows; each round the UNCLIPPED
+        weights are compared with ``thr * S``, ``S = U / (1 - thr n)`` the total after clipping ``n`` weights with
+        ``U`` the sum of the unclipped ones; stop when no unclipped weight reaches it.  Equal to the recursion in exact
+        arithmetic; the default threshold 10 never triggers (``w <= sum w``).  PARITY UNPINNED for this branch: no
+        reference output can exist for it."""
         thr = self._w_clip_threshold
-        if not np.any(w > S * thr):
+        w = np.asarray(w, dtype=np.float64)
+        clipped = np.zeros(w.shape, dtype=bool)
+        S = np.sum(w)
+        if not np.any(w > S * thr):                                 # :373-374
             return w
-        to_clip = (w >= S * thr)
-        n_to_clip = np.sum(to_clip)
-        sum_unclipped = np.sum(w[~to_clip])
-        if sum_unclipped == 0:
+        while True:
+            new = ~clipped & (w >= S * thr)                         # :375
+            if not np.any(new):
+                break
+            trial = clipped | new
+            n = np.sum(trial)                                       # :376
+            U = np.sum(w[~trial])                                   # :377
+            if U == 0 or 1. - thr * n <= 0:                         # :378-379
+                break
+            clipped = trial
+            S = U / (1. - thr * n)
+        if not np.any(clipped):
             return w
-        # reference line :385 calls a float (latent bug, unreachable for thr >= 1);
-        # evident intent written here.
-        w = w.copy()
-        w[to_clip] = thr * sum_unclipped / (1. - thr * n_to_clip)
-        return self._clip(w)
+        out = w.copy()
+        out[clipped] = thr * np.sum(w[~clipped]) / (1. - thr * np.sum(clipped))     # :385 (intent)
+        return out
 
     def refresh(self, theta, noise):                                # :393-401
         theta = np.asarray(theta, dtype=np.float64)

@@ -34,6 +34,18 @@ def oracle_family(fx):
     raise ValueError(kind)
 
 
+def oracle_prior_family(fx):
+    """The tempering prior of a `disprior_*` fixture as an oracle family."""
+    kind, D = str(fx['prior_kind']), int(fx['dim'])
+    if kind == 'mf_student_t':
+        return ofam.MFStudentT(D, float(fx['prior_df']))
+    if kind == 'multivariate_t':
+        return ofam.MultivariateT(D, float(fx['prior_df']))
+    if kind == 'lr_gaussian':
+        return ofam.LRGaussian(D, int(fx['prior_rank']))
+    raise ValueError(kind)
+
+
 def oracle_model(fx):
     kind = str(fx['model_kind'])
     if kind == 'gauss_diag':

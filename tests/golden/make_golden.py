@@ -714,13 +714,83 @@ def gen_lowrank_alpha_dis():
           % (worst_a, worst_d))
 
 
+def gen_dis_priors():
+    """DISInclusiveKL with a tempering prior that is NOT an MFGaussian (objectives.py:283-285 takes any family;
+    :317-319 calls its log_density): the reference's own MFStudentT, MultivariateT and LRGaussian as priors."""
+    rng = np.random.RandomState(57)
+    worst = 0.0
+    priors = ({'kind': 'mf_student_t', 'df': 5.0}, {'kind': 'multivariate_t', 'df': 7.0},
+              {'kind': 'lr_gaussian', 'k': 1})
+    for fspec in ({'kind': 'mf_gaussian', 'dim': 3}, {'kind': 'multivariate_t', 'dim': 3, 'df': 9},
+                  {'kind': 'lr_gaussian', 'dim': 3, 'k': 2}):
+        D = fspec['dim']
+        mspec = model_specs(D, rng)[0]
+        for pspec in priors:
+            pspec = dict(pspec, dim=D)
+            use_resampling = pspec['kind'] == 'multivariate_t'      # one resampled case per family
+            N, ess_target, np_seed = 64, 20, 851
+            ref, orc = make_family(fspec, 1)
+            ref_prior, orc_prior = make_family(pspec, 3)
+            log_p, omodel = make_model(mspec)
+            theta = theta_for(fspec, rng)
+            prior_params = theta_for(pspec, rng)
+            prior_params[:D] *= 0.3                       # a broad prior around the origin
+            prior_params[D:2 * D] += 0.8
+            objective = ref_obj.DISInclusiveKL(
+                ref, log_p, N, ess_target=ess_target, temper_prior=ref_prior,
+                temper_prior_params=prior_params, use_resampling=use_resampling)
+            chosen = []
+            real_choice = np.random.choice
+
+            def rec_choice(*a, **k):
+                idx = real_choice(*a, **k)
+                chosen.append(np.array(idx))
+                return idx
+            np.random.choice = rec_choice
+            try:
+                np.random.seed(np_seed)
+                _ref_stubs.STATE['before_eval'] = snapshot_hook(ref, objective, np_seed)
+                value, grad_fd = objective(theta)
+            finally:
+                np.random.choice = real_choice
+                _ref_stubs.STATE['before_eval'] = None
+            noise = orc.draw_noise(np.random.RandomState(1), N)
+            od = oobj.DISInclusiveKL(orc, omodel, N, ess_target, orc_prior, prior_params, use_resampling=use_resampling)
+            indices = chosen[0] if use_resampling else None
+            ov, og = od(theta, noise=noise, indices=indices)
+            assert rel_err(ov, value) < 1e-11, (fspec, pspec, ov, value)
+            assert rel_err(od._eps, objective._eps) < 1e-12, (fspec, pspec, od._eps, objective._eps)
+            assert rel_err(od._state_w_clipped, objective._state_w_clipped) < 1e-10
+            e = rel_err(og, grad_fd)
+            worst = max(worst, e)
+            assert e < 2e-6, (fspec, pspec, e)
+            out = dict(spec_arrays(fspec, mspec), np_seed=np_seed, seed=1, n=N,
+                       ess_target=ess_target, use_resampling=use_resampling, theta=theta,
+                       prior_kind=pspec['kind'], prior_df=pspec.get('df', 0.0), prior_rank=pspec.get('k', 0),
+                       prior_params=prior_params, value=value, grad_fd=grad_fd, grad=og,
+                       eps=objective._eps, w_clipped=objective._state_w_clipped,
+                       log_q=objective._state_log_q, log_p=objective._state_log_p_unnormalized,
+                       samples=objective._state_samples,
+                       provenance='reference DISInclusiveKL code with a non-MFGaussian temper_prior; grad_fd by FD with getval replay')
+            if use_resampling:
+                out['indices'] = indices
+            if fspec['kind'] == 'multivariate_t':
+                out['noise_chi'], out['noise_z'] = noise
+            elif fspec['kind'] == 'lr_gaussian':
+                out['noise_z'], out['noise_eps'] = noise
+            else:
+                out['noise'] = noise
+            save('disprior_%s_%s_d%d_rs%d' % (fspec['kind'], pspec['kind'], D, use_resampling), **out)
+    print('DISInclusiveKL, general tempering priors: worst analytic-vs-FD(reference) grad rel err %.2e' % worst)
+
+
 GENERATORS = {}
 
 if __name__ == '__main__':
     GENERATORS.update(torch=gen_torch_crosscheck, family=gen_family_forward, ekl=gen_exclusive_kl, rge=gen_rge,
                       alpha=gen_alpha, dis=gen_dis, chainstats=gen_chain_stats, optimizers=gen_optimizers,
                       psis=gen_psis, lowrank=gen_lowrank, ekl_mvt=gen_exclusive_kl_mvt,
-                      lowrank_alpha_dis=gen_lowrank_alpha_dis)
+                      lowrank_alpha_dis=gen_lowrank_alpha_dis, dis_priors=gen_dis_priors)
     picked = sys.argv[1:]          # e.g. `make_golden.py psis optimizers` regenerates only those fixtures
     if picked and picked[0] == '--check':
         # regenerate everything into a scratch directory and diff against the committed fixtures (drift guard, run by

@@ -810,3 +810,160 @@ def test_dis_prior_copy_follows_the_layout_across_sample_counts(vb):
         assert G.rel_err(obj._eps, ref._eps) < 1e-10, (N, obj._eps, ref._eps)
         assert G.rel_err(value, ov) < 1e-10, (N, value, ov)
         assert G.rel_err(grad, og) < 1e-9, (N, G.rel_err(grad, og))
+
+
+def _product_prior(vb, fx):
+    kind, D = str(fx['prior_kind']), int(fx['dim'])
+    if kind == 'mf_student_t':
+        return vb.MFStudentT(D, float(fx['prior_df']))
+    if kind == 'multivariate_t':
+        return vb.MultivariateT(D, float(fx['prior_df']))
+    return vb.LRGaussian(D, k=int(fx['prior_rank']))
+
+
+@pytest.mark.parametrize('path', G.fixtures('disprior_'), ids=G.ids(G.fixtures('disprior_')))
+def test_dis_general_tempering_prior_golden(vb, path):
+    """objectives.py:283-285: temper_prior may be any family -- fixtures from the reference's own DISInclusiveKL with
+    MFStudentT / MultivariateT / LRGaussian priors (vb_dis_set_temper_prior)."""
+    fx = G.load(path)
+    obj = vb.DISInclusiveKL(product_family(vb, fx, int(fx['seed'])), product_model(vb, fx), int(fx['n']),
+                            ess_target=int(fx['ess_target']), temper_prior=_product_prior(vb, fx),
+                            temper_prior_params=fx['prior_params'], use_resampling=bool(fx['use_resampling']))
+    np.random.seed(int(fx['np_seed']))
+    value, grad = obj(fx['theta'])
+    assert G.rel_err(obj._eps, fx['eps']) < 1e-11
+    assert G.rel_err(obj._state_w_clipped, fx['w_clipped']) < 1e-10
+    assert G.rel_err(value, fx['value']) < 1e-11
+    assert G.rel_err(grad, fx['grad']) < 1e-11
+    assert G.rel_err(grad, fx['grad_fd']) < 2e-6
+
+
+@pytest.mark.parametrize('prior_kind', ['mf_student_t', 'fullrank', 'multivariate_t'])
+@pytest.mark.parametrize('family', ['mf_gaussian', 'fullrank_philox', 'multivariate_t', 'lr_gaussian'])
+def test_dis_general_tempering_prior_against_oracle(vb, family, prior_kind):
+    """The same at sizes where the dense prior's N x D x D product runs real MFMA tiles; the MFGaussian prior on the
+    same engine before and after (the installed prior must not leak into an objective that does not use it)."""
+    from viabel_amd import _lib
+    from viabel_amd.objectives import _DIS_SLOT
+    D, N = 70, 1500
+    rng = np.random.RandomState(41)
+    mean, sd = 0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    A = rng.randn(D, D)
+    S = A @ A.T / D + np.eye(D)
+    if prior_kind == 'mf_student_t':
+        prior, oprior = vb.MFStudentT(D, 6.0), ofam.MFStudentT(D, 6.0)
+        pp = np.concatenate([0.1 * rng.randn(D), 0.5 + 0.1 * rng.randn(D)])
+    elif prior_kind == 'fullrank':
+        prior, oprior = vb.FullRankGaussian(D), ofam.FullRankGaussian(D)
+        pp = prior.pack(0.1 * rng.randn(D), np.linalg.cholesky(2.0 * S))
+    else:
+        prior, oprior = vb.MultivariateT(D, 8.0), ofam.MultivariateT(D, 8.0)
+        pp = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(2.0 * S)])
+    eng = _lib.default_engine()
+    if family == 'mf_gaussian':
+        approx, ofamily = vb.MFGaussian(D, seed=5), ofam.MFGaussian(D)
+        theta = np.concatenate([0.1 * rng.randn(D), -0.3 + 0.1 * rng.randn(D)])
+    elif family == 'fullrank_philox':
+        approx, ofamily = vb.FullRankGaussian(D, seed=5, rng='philox'), ofam.FullRankGaussian(D)
+        theta = approx.pack(0.1 * rng.randn(D), np.linalg.cholesky(0.6 * S))
+    elif family == 'multivariate_t':
+        approx, ofamily = vb.MultivariateT(D, 12.0, seed=5), ofam.MultivariateT(D, 12.0)
+        theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(0.6 * S)])
+    else:
+        approx, ofamily = vb.LRGaussian(D, seed=5, k=3), ofam.LRGaussian(D, 3)
+        theta = np.concatenate([0.1 * rng.randn(D), -0.3 + 0.1 * rng.randn(D), 0.2 * rng.randn(D * 3)])
+    for p_fam, p_ofam, p_par in ((vb.MFGaussian(D), ofam.MFGaussian(D), np.concatenate([np.zeros(D), 0.3 * np.ones(D)])),
+                                 (prior, oprior, pp),
+                                 (vb.MFGaussian(D), ofam.MFGaussian(D), np.concatenate([np.zeros(D), 0.3 * np.ones(D)]))):
+        obj = vb.DISInclusiveKL(approx, model, N, ess_target=200, temper_prior=p_fam, temper_prior_params=p_par,
+                                use_resampling=False)
+        ref = oobj.DISInclusiveKL(ofamily, omodel, N, 200, p_ofam, p_par, use_resampling=False)
+        if family == 'fullrank_philox':
+            value, grad = obj(theta)
+            noise = eng.noise_get_host(_DIS_SLOT, N, D)
+        else:
+            rs = np.random.RandomState(0)
+            rs.set_state(approx._rs.get_state())         # the draws this call is about to consume
+            value, grad = obj(theta)
+            noise = ofamily.draw_noise(rs, N)
+        ov, og = ref(theta, noise=noise)
+        assert ref._eps > 0.0                            # the prior takes part in the weights
+        assert G.rel_err(obj._eps, ref._eps) < 1e-9, (obj._eps, ref._eps)
+        assert G.rel_err(value, ov) < 1e-9, (value, ov)
+        assert G.rel_err(grad, og) < 1e-8, G.rel_err(grad, og)
+
+
+@pytest.mark.parametrize('thr', [0.02, 0.005])
+@pytest.mark.parametrize('use_resampling', [False, True])
+@pytest.mark.parametrize('family', ['fullrank_philox', 'multivariate_t_philox', 'mf_gaussian', 'multivariate_t'])
+def test_dis_clip_active_branch(vb, family, use_resampling, thr):
+    """objectives.py:370-386 with w_clip_threshold < 1 (the branch the default threshold 10 never takes): on the
+    device-resident step (vb_dis_clip_mvt) and on the host path, against the oracle's fixed-point restatement (the
+    reference's own line :385 cannot run: pinned by the oracle, see its _clip)."""
+    from viabel_amd import _lib
+    from viabel_amd.objectives import _DIS_SLOT
+    D, N = 40, 1024
+    rng = np.random.RandomState(43)
+    mean, sd = 0.5 * rng.randn(D), np.exp(0.2 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    A = rng.randn(D, D)
+    S = A @ A.T / D + np.eye(D)
+    eng = _lib.default_engine()
+    philox = family.endswith('philox')
+    if family == 'fullrank_philox':
+        approx, ofamily = vb.FullRankGaussian(D, seed=9, rng='philox'), ofam.FullRankGaussian(D)
+        theta = approx.pack(0.1 * rng.randn(D), np.linalg.cholesky(0.5 * S))
+    elif family.startswith('multivariate_t'):
+        approx = vb.MultivariateT(D, 10.0, seed=9, rng='philox' if philox else 'numpy')
+        theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(0.5 * S)])
+
+        class CholeskySampledT(ofam.MultivariateT):
+            def sample_from_noise(self, theta, noise):
+                chi, z = noise
+                mu, Sg = self.split(theta)
+                return mu + (z @ np.linalg.cholesky(Sg).T) / np.sqrt(chi / self.df)[:, None]
+        ofamily = CholeskySampledT(D, 10.0) if philox else ofam.MultivariateT(D, 10.0)
+    else:
+        approx, ofamily = vb.MFGaussian(D, seed=9), ofam.MFGaussian(D)
+        theta = np.concatenate([0.1 * rng.randn(D), -0.2 + 0.1 * rng.randn(D)])
+    # a large ESS target keeps eps at 1 (weights = prior / q: heavy-tailed) so that the clipping has work to do
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 2, temper_prior=vb.MFGaussian(D),
+                            temper_prior_params=prior, use_resampling=use_resampling, w_clip_threshold=thr)
+    ref = oobj.DISInclusiveKL(ofamily, omodel, N, N // 2, ofam.MFGaussian(D), prior, use_resampling=use_resampling,
+                              w_clip_threshold=thr)
+    np.random.seed(6)
+    rs_state = None if philox else approx._rs.get_state()
+    np_state = np.random.get_state()
+    value, grad = obj(theta)
+    if philox:
+        z = eng.noise_get_host(_DIS_SLOT, N, D)
+        noise = (eng.chisq_get_host(N), z) if family.startswith('multivariate_t') else z
+    else:
+        rs = np.random.RandomState(0)
+        rs.set_state(rs_state)
+        noise = ofamily.draw_noise(rs, N)
+    ref.refresh(theta, noise)
+    n_clipped = int(np.sum(ref._state_w_clipped != ref._weights(ref._eps, ofam.MFGaussian(D).log_density(
+        prior, ref._state_samples), ref._state_log_p, ref._state_log_q)))
+    assert n_clipped >= 1, 'the test needs weights above the threshold'
+    assert G.rel_err(obj._state_w_clipped, ref._state_w_clipped) < 1e-10
+    if not use_resampling:
+        w = ref._state_w_clipped
+        ov = -np.sum(w * ofamily.log_density(theta, ref._state_samples)) / N
+        og = -ofamily.log_density_grad_weighted(theta, ref._state_samples, w) / N
+    else:
+        M = ref._resampling_batch_size
+        if philox:
+            counts = eng.dis_weights_get(N, resampled=True)
+        else:
+            np.random.set_state(np_state)
+            counts = np.bincount(np.random.choice(N, size=M, p=ref._state_w_clipped / np.sum(ref._state_w_clipped)),
+                                 minlength=N).astype(float)
+        assert counts.sum() == M
+        scale = np.sum(ref._state_w_clipped) / N / M
+        ov = -np.sum(counts * ofamily.log_density(theta, ref._state_samples)) * scale
+        og = -ofamily.log_density_grad_weighted(theta, ref._state_samples, counts) * scale
+    assert G.rel_err(value, ov) < 1e-10, (value, ov)
+    assert G.rel_err(grad, og) < 1e-9, G.rel_err(grad, og)

@@ -89,6 +89,60 @@ def test_dis(path):
     assert G.rel_err(g, fx['grad_fd']) < 2e-6
 
 
+@pytest.mark.parametrize('path', G.fixtures('disprior_'), ids=G.ids(G.fixtures('disprior_')))
+def test_dis_general_tempering_prior(path):
+    """objectives.py:283-285 / :317-319: the tempering prior may be any family (fixtures: the reference's MFStudentT,
+    MultivariateT and LRGaussian as priors)."""
+    fx = G.load(path)
+    fam, model = G.oracle_family(fx), G.oracle_model(fx)
+    dis = oobj.DISInclusiveKL(fam, model, int(fx['n']), int(fx['ess_target']), G.oracle_prior_family(fx),
+                              fx['prior_params'], use_resampling=bool(fx['use_resampling']))
+    v, g = dis(fx['theta'], noise=G.noise_of(fx), indices=fx.get('indices'))
+    assert G.rel_err(dis._state_samples, fx['samples']) < 1e-12
+    assert G.rel_err(dis._eps, fx['eps']) < 1e-12
+    assert G.rel_err(dis._state_w_clipped, fx['w_clipped']) < 1e-10
+    assert G.rel_err(v, fx['value']) < 1e-11
+    assert G.rel_err(g, fx['grad']) < 1e-11
+    assert G.rel_err(g, fx['grad_fd']) < 2e-6
+
+
+def test_clip_is_the_fixed_point_of_the_reference_recursion():
+    """objectives.py:370-386 with :385's evident intent: where the literal recursion terminates the fixed-point
+    restatement returns the same numbers; where it does not (rounding re-triggers it) the restatement still does, and
+    every clipped weight sits at threshold * sum."""
+    def literal(w, thr, depth=0):
+        S = np.sum(w)
+        if not np.any(w > S * thr):
+            return w
+        to_clip = (w >= S * thr)
+        n_to_clip = np.sum(to_clip)
+        sum_unclipped = np.sum(w[~to_clip])
+        if sum_unclipped == 0:
+            return w
+        w = w.copy()
+        w[to_clip] = thr * sum_unclipped / (1. - thr * n_to_clip)
+        if depth > 100:
+            raise RecursionError
+        return literal(w, thr, depth + 1)
+
+    terminated = 0
+    for seed in range(120):
+        rng = np.random.RandomState(seed)
+        N = int(rng.choice([64, 500, 4096]))
+        w = np.exp(rng.randn(N) * rng.choice([1, 2, 4]))
+        for thr in (0.05, 0.2):
+            dis = oobj.DISInclusiveKL.__new__(oobj.DISInclusiveKL)
+            dis._w_clip_threshold = thr
+            out = dis._clip(w)
+            assert np.all(out <= thr * out.sum() * (1 + 1e-12))
+            try:
+                np.testing.assert_array_equal(out, literal(w, thr))
+                terminated += 1
+            except RecursionError:
+                pass
+    assert terminated > 150
+
+
 def test_fullrank_reduces_to_meanfield():
     """FullRankGaussian has no reference class: pin it by reduction to MFGaussian."""
     from oracle import models as omod

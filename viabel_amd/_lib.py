@@ -27,6 +27,7 @@ FLAG_PATH_DERIV = 1
 CV_MODES = {None: 0, 'full': 1, 'mean_only': 2, 'loo_diag_approx': 3, 'loo_direct_approx': 4}
 MAX_SLOTS = 64
 OPT_SGD, OPT_RMSPROP, OPT_ADAM, OPT_ADAGRAD = range(4)
+PRIOR_DIAG_GAUSSIAN, PRIOR_DIAG_STUDENT_T, PRIOR_DENSE = range(3)
 # int fn(void* user, const double* z, int64 n, int64 d, double* f, double* grad)   (include/viabel_hip.h: vb_model_callback)
 MODEL_CALLBACK_TYPE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64,
                                        ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
@@ -117,6 +118,9 @@ SIGNATURES = {
     'vb_alpha_grad_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                ctypes.c_int, ctypes.c_double, _c_double_p, ctypes.c_double,
                                                _c_double_p, _c_double_p]),
+    'vb_dis_clip_mvt': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_double]),
+    'vb_dis_set_temper_prior': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, _c_double_p,
+                                               _c_double_p, ctypes.c_double]),
     'vb_dis_refresh_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                                 ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p,
                                                 ctypes.c_double, ctypes.c_double, ctypes.c_int,
@@ -497,7 +501,22 @@ class Engine:
                                                       float(alpha), ctypes.byref(value), _dptr(grad)))
         return value.value, grad
 
-    # ------------------------------------------------------------------ DISInclusiveKL, mean field
+    # ------------------------------------------------------------------ DISInclusiveKL
+    def dis_set_temper_prior(self, spec):
+        """Install a tempering prior that is not an MFGaussian (``vb_dis_set_temper_prior``); ``spec`` =
+        ``(kind, df, loc, scale, log_det_l)`` or ``None`` for the refresh calls' own ``prior_theta`` argument.  The
+        spec object's identity is the cache key: objectives hand out the same tuple every time."""
+        if spec is getattr(self, '_temper_spec', None):
+            return
+        if spec is None:
+            self._check(self._lib.vb_dis_set_temper_prior(self._ctx, PRIOR_DIAG_GAUSSIAN, 0, 0.0, None, None, 0.0))
+        else:
+            kind, df, loc, scale, log_det_l = spec
+            loc, scale = _f64(loc), _f64(scale)
+            self._check(self._lib.vb_dis_set_temper_prior(self._ctx, int(kind), loc.size, float(df), _dptr(loc),
+                                                          _dptr(scale), float(log_det_l)))
+        self._temper_spec = spec
+
     def dis_refresh_meanfield(self, slot, n, d, theta, prior_theta, family, eps_prev, ess_target,
                               max_bisection_its=50, df=0.0, n_total=None):
         """``n`` local rows; the returned weights / log p / log q cover all ``n_total`` samples."""
@@ -611,6 +630,10 @@ class Engine:
         """Enqueue the Pareto smoothing of the device-resident tempered weights (between ``dis_refresh_mvt_deferred``
         and ``dis_step_mvt_packed``; ``last_khat`` after the step)."""
         self._check(self._lib.vb_dis_psis_mvt(self._ctx, int(n_total), float(reff)))
+
+    def dis_clip_mvt(self, n_total, threshold):
+        """Enqueue the weight clipping (``objectives.py:370-386``) of the device-resident weights, in place."""
+        self._check(self._lib.vb_dis_clip_mvt(self._ctx, int(n_total), float(threshold)))
 
     def dis_weights_get(self, n_total, resampled=False):
         w = np.empty(n_total, dtype=np.float64)

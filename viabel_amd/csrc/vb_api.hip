@@ -238,7 +238,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
   if (ctx->user_host_pin) (void)hipHostFree(ctx->user_host_pin);
@@ -441,6 +441,14 @@ int vb_set_model_source(vb_ctx* ctx, int64_t dim, const char* source, const doub
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
   return user_model_set(ctx, dim, source, params, n_params);
+}
+
+int vb_dis_set_temper_prior(vb_ctx* ctx, int kind, int64_t d, double df, const double* loc, const double* scale,
+                            double log_det_l) {
+  if (!ctx) return VB_ERR_INVALID;
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  return temper_prior_set(ctx, kind, d, df, loc, scale, log_det_l);
 }
 
 int vb_set_model_callback(vb_ctx* ctx, int64_t dim, vb_model_callback fn, void* user) {
@@ -861,6 +869,12 @@ int vb_dis_psis_mvt(vb_ctx* ctx, int64_t n_total, double reff) {
   if (!(reff > 0.0)) return fail(ctx, VB_ERR_INVALID, "Reff must be positive");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   return mvt_dis_psis_enqueue(ctx, n_total, reff);
+}
+
+int vb_dis_clip_mvt(vb_ctx* ctx, int64_t n_total, double threshold) {
+  if (!ctx) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  return mvt_dis_clip_enqueue(ctx, n_total, threshold);
 }
 
 int vb_dis_step_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, int64_t resample_m,

@@ -160,7 +160,7 @@ int vb_comm_destroy(vb_ctx* ctx) {
   if (ctx->host_fn) {
     ctx->host_fn = nullptr;
     ctx->host_user = nullptr;
-    if (ctx->host_stage) hipHostFree(ctx->host_stage);
+    if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     ctx->host_stage = nullptr;
     ctx->host_stage_cap = 0;
   } else {

@@ -192,6 +192,13 @@ struct vb_ctx {
   vb::DeviceBuffer lr_work;             // low-rank Gaussian family: workspace of the streaming pipeline
   vb::DeviceBuffer lr_obj;              // low-rank Gaussian under DIS / alpha: samples, residuals, Woodbury vectors
   int64_t lr_n = 0, lr_d = 0, lr_k = 0, lr_n_total = 0;   // shape of the low-rank DIS state (0: none)
+  struct TemperPrior {                  // vb_dis_set_temper_prior: a tempering prior other than the refresh's own argument
+    int kind = 0;                       // VB_PRIOR_*
+    int64_t d = 0, ld = 0;
+    double df = 0.0, c0 = 0.0;          // additive constant of the log density
+    vb::DeviceBuffer buf;               // diag t: [loc ld | 1/sigma ld];  dense: [W = L^-T (d x ld) | c = L^-1 loc (ld)]
+    vb::DeviceBuffer work;              // dense: U (n x ld), maha / c_n (n each)
+  } temper;
   uint64_t dis_gen[3] = {0, 0, 0};      // refresh counters of the DIS states: mean-field, dense (t / Gaussian), low-rank
   vb::DeviceBuffer rows_work;           // Model.__call__ for the dense targets: GEMM output rows
   vb::DeviceBuffer psis_lw;             // PSIS: log importance weights (+ 16 result scalars)
@@ -299,6 +306,10 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
 int user_rows_enqueue(vb_ctx* ctx, hipStream_t st, const double* Z, int64_t ldz, int64_t n, int d, double* G,
                       int64_t ldg, double* f);
 void user_model_release(vb_ctx* ctx);
+// log density of the installed tempering prior (ctx->temper.kind != 0) at the rows of X
+int mvt_dis_clip_enqueue(vb_ctx* ctx, int64_t n_total, double threshold);
+int temper_prior_rows(vb_ctx* ctx, const double* X, int64_t ld, int64_t n, int64_t d, double* out);
+int temper_prior_set(vb_ctx* ctx, int kind, int64_t d, double df, const double* loc, const double* scale, double log_det_l);
 int user_model_set_callback(vb_ctx* ctx, int64_t dim, vb_model_callback fn, void* user);
 int pipe_init(vb_ctx* ctx);
 

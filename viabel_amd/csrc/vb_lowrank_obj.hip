@@ -445,6 +445,8 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
   VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 0, base + L.o_lq + mine));
   VB_TRY(model_and_prior_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_f + mine, base + L.o_prior,
                                    base + L.o_prior + L.ld, c0p, base + L.o_lpr + mine));
+  if (ctx->temper.kind != VB_PRIOR_DIAG_GAUSSIAN)      // any other family as tempering prior (vb_dis_set_temper_prior)
+    VB_TRY(temper_prior_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lpr + mine));
   if (ctx->comm) {
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_f, mine, n, n_total));
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));

@@ -160,6 +160,96 @@ __global__ void __launch_bounds__(1024) mvt_wsums_kernel(const double* __restric
   }
 }
 
+// ---- tempering priors other than a diagonal Gaussian (vb_dis_set_temper_prior; objectives.py:317-319) ----------------
+// one wave per row: sum_d t.logpdf((x_d - loc_d) / sigma_d; df) - log sigma_d   (approximations.py:281-286)
+__global__ void __launch_bounds__(256) prior_diag_t_rows_kernel(const double* __restrict__ X, int64_t ld, int64_t n, int d,
+                                                                const double* __restrict__ loc,
+                                                                const double* __restrict__ isig, double df, double c0,
+                                                                double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double* x = X + row * ld;
+  double s = 0.0;
+  for (int c = lane; c < d; c += 64) {
+    const double r = (x[c] - loc[c]) * isig[c];
+    s += log1p(r * r / df);
+  }
+  s = mvt_wave_sum(s);
+  if (lane == 0) out[row] = c0 - 0.5 * (df + 1.0) * s;
+}
+
+int temper_prior_set(vb_ctx* ctx, int kind, int64_t d, double df, const double* loc, const double* scale,
+                     double log_det_l) {
+  vb_ctx::TemperPrior& T = ctx->temper;
+  if (kind == VB_PRIOR_DIAG_GAUSSIAN) {
+    T.kind = 0;
+    return VB_OK;
+  }
+  if (kind != VB_PRIOR_DIAG_STUDENT_T && kind != VB_PRIOR_DENSE) return fail(ctx, VB_ERR_INVALID, "unknown prior kind %d", kind);
+  if (d <= 0 || !loc || !scale) return fail(ctx, VB_ERR_INVALID, "prior needs d > 0, loc and scale");
+  if (kind == VB_PRIOR_DIAG_STUDENT_T && !(df > 0.0)) return fail(ctx, VB_ERR_INVALID, "df must be positive");
+  if (kind == VB_PRIOR_DENSE && !(df >= 0.0)) return fail(ctx, VB_ERR_INVALID, "df must be >= 0 (0: Gaussian)");
+  const int64_t ld = round_up(d, 16);
+  std::vector<double> host;
+  double c0 = 0.0;
+  if (kind == VB_PRIOR_DIAG_STUDENT_T) {
+    host.assign((size_t)(2 * ld), 0.0);
+    c0 = (double)d * (lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df * M_PI));
+    for (int64_t i = 0; i < d; ++i) {
+      host[i] = loc[i];
+      host[ld + i] = exp(-scale[i]);
+      c0 -= scale[i];
+    }
+  } else {
+    host.assign((size_t)(d * ld + ld), 0.0);      // W[k][j] = Linv[j][k]; c_j = sum_k Linv[j][k] loc_k
+    for (int64_t j = 0; j < d; ++j) {
+      double c = 0.0;
+      for (int64_t k = 0; k <= j; ++k) {
+        const double v = scale[j * d + k];
+        host[(size_t)(k * ld + j)] = v;
+        c += loc[k] * v;
+      }
+      host[(size_t)(d * ld + j)] = c;
+    }
+    c0 = df > 0.0 ? lgamma(0.5 * (df + d)) - lgamma(0.5 * df) - 0.5 * d * log(M_PI * df) - log_det_l
+                  : -0.5 * d * log(2.0 * M_PI) - log_det_l;
+  }
+  VB_TRY(ensure(ctx, T.buf, host.size() * sizeof(double)));
+  VB_HIP(ctx, hipMemcpyAsync(T.buf.ptr, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  T.kind = kind, T.d = d, T.ld = ld, T.df = df, T.c0 = c0;
+  return VB_OK;
+}
+
+int temper_prior_rows(vb_ctx* ctx, const double* X, int64_t ld, int64_t n, int64_t d, double* out) {
+  vb_ctx::TemperPrior& T = ctx->temper;
+  if (T.kind == 0) return fail(ctx, VB_ERR_STATE, "no tempering prior installed");
+  if (T.d != d) return fail(ctx, VB_ERR_INVALID, "tempering prior has dimension %lld, the family %lld", (long long)T.d,
+                            (long long)d);
+  hipStream_t st = ctx->stream;
+  const double* p = (const double*)T.buf.ptr;
+  const unsigned grid = (unsigned)((n + 3) / 4);
+  if (T.kind == VB_PRIOR_DIAG_STUDENT_T) {
+    hipLaunchKernelGGL(prior_diag_t_rows_kernel, dim3(grid), dim3(256), 0, st, X, ld, n, (int)d, p, p + T.ld, T.df, T.c0, out);
+    VB_HIP(ctx, hipGetLastError());
+    return VB_OK;
+  }
+  // dense: U = (X - loc) L^-T = X W - c (MFMA), then |u_n|^2 and the Gaussian / t log pdf per row
+  const int64_t nn = round_up(n, 16);
+  VB_TRY(ensure(ctx, T.work, (size_t)(n * T.ld + 2 * nn) * sizeof(double)));
+  double* U = (double*)T.work.ptr;
+  GemmArgs g;
+  g.A = X, g.lda = ld, g.B = p, g.ldb = T.ld;
+  g.M = (int)n, g.N = (int)d, g.K = (int)d, g.tri_mode = 0;
+  gemm_f64_launch<true>(st, g, 1, ctx->prop.multiProcessorCount, EpiSubVec{U, T.ld, p + d * T.ld});
+  VB_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(mvt_rows_kernel, dim3(grid), dim3(256), 0, st, (const double*)U, T.ld, n, (int)d, T.df, T.c0,
+                     U + n * T.ld, out, (const double*)nullptr, U + n * T.ld + nn);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 // ---- state layout ----------------------------------------------------------------------------------------
 struct MvtLayout {
   int64_t ld, nn;
@@ -576,6 +666,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   // model and tempering prior (a diagonal Gaussian) in one pass over the samples
   VB_TRY(model_and_prior_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine, base + L.o_prior,
                                    base + L.o_prior + L.ld, c0p, base + L.o_lprior + mine));
+  if (ctx->temper.kind != VB_PRIOR_DIAG_GAUSSIAN)      // any other family as tempering prior: one more pass over X
+    VB_TRY(temper_prior_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lprior + mine));
   if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lp, mine, n, n_total));
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));
@@ -674,6 +766,77 @@ int mvt_dis_psis_enqueue(vb_ctx* ctx, int64_t n_total, double reff) {
                      base + L.o_scal + 11);
   VB_HIP(ctx, hipGetLastError());
   ctx->psis_n = 0;
+  return VB_OK;
+}
+
+// ---- weight clipping on the device-resident weights (objectives.py:370-386) ------------------------------------------
+// The fixed point the reference's recursion aims at (oracle.objectives.DISInclusiveKL._clip: the literal recursion does
+// not terminate in floating point): the clipped set only grows; each round the unclipped weights are compared with
+// thr * S, S = U / (1 - thr n); in the end the clipped ones are set to thr U / (1 - thr n).  One workgroup; every sum in
+// a fixed order (strided per-thread partials, wave shuffles, sixteen wave totals added in order).
+__device__ __forceinline__ double clip_block_sum(double v, double* sh) {
+  v = mvt_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int k = 0; k < 16; ++k) t += sh[k];
+  return t;
+}
+
+__global__ void __launch_bounds__(1024) dis_clip_kernel(double* __restrict__ w, int64_t n, double thr,
+                                                        int* __restrict__ flag, double* __restrict__ info) {
+  __shared__ double sh[16];
+  const int t = threadIdx.x;
+  double part = 0.0, any = 0.0;
+  for (int64_t i = t; i < n; i += 1024) {
+    part += w[i];
+    flag[i] = 0;
+  }
+  double S = clip_block_sum(part, sh);
+  for (int64_t i = t; i < n; i += 1024) any += w[i] > S * thr ? 1.0 : 0.0;
+  any = clip_block_sum(any, sh);
+  double n_clipped = 0.0, U_acc = 0.0;
+  if (any > 0.0) {
+    for (int64_t round = 0; round <= n; ++round) {
+      double n_new = 0.0, u = 0.0;
+      for (int64_t i = t; i < n; i += 1024) {
+        if (flag[i]) continue;
+        const double wi = w[i];
+        if (wi >= S * thr) n_new += 1.0;
+        else u += wi;
+      }
+      n_new = clip_block_sum(n_new, sh);
+      if (n_new == 0.0) break;
+      u = clip_block_sum(u, sh);
+      const double n_trial = n_clipped + n_new;
+      if (u == 0.0 || 1.0 - thr * n_trial <= 0.0) break;
+      for (int64_t i = t; i < n; i += 1024)
+        if (!flag[i] && w[i] >= S * thr) flag[i] = 1;
+      n_clipped = n_trial;
+      U_acc = u;
+      S = u / (1.0 - thr * n_trial);
+      __syncthreads();
+    }
+  }
+  if (n_clipped > 0.0) {
+    const double v = thr * U_acc / (1.0 - thr * n_clipped);
+    for (int64_t i = t; i < n; i += 1024)
+      if (flag[i]) w[i] = v;
+  }
+  if (t == 0) info[0] = n_clipped;
+}
+
+int mvt_dis_clip_enqueue(vb_ctx* ctx, int64_t n_total, double threshold) {
+  if (!ctx->mvt_state.ptr || ctx->mvt_n_total != n_total || n_total <= 0)
+    return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state with %lld samples", (long long)n_total);
+  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident weights: one rank only");
+  if (!(threshold > 0.0)) return fail(ctx, VB_ERR_INVALID, "clipping threshold must be positive");
+  const MvtLayout L = mvt_layout(ctx, ctx->mvt_n, ctx->mvt_n_total, ctx->mvt_d);
+  double* base = (double*)ctx->mvt_state.ptr;
+  hipLaunchKernelGGL(dis_clip_kernel, dim3(1), dim3(1024), 0, ctx->stream, base + L.o_w, n_total, threshold,
+                     (int*)(base + L.o_cnt), base + L.o_scal + 13);
+  VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
 

@@ -639,6 +639,16 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
                      (const double*)ns.buf.ptr, ld, n, (int)d, (const double*)(base + L.o_cols), prior, student,
                      df, base + L.o_lprior + mine, base + L.o_lq);
   VB_HIP(ctx, hipGetLastError());
+  if (ctx->temper.kind != VB_PRIOR_DIAG_GAUSSIAN) {
+    // a tempering prior that is not a diagonal Gaussian (vb_dis_set_temper_prior) needs the samples themselves
+    const int64_t ldz = round_up(d, 16);
+    VB_TRY(ensure(ctx, ctx->lg_work, (size_t)n * ldz * sizeof(double)));
+    double* Z = (double*)ctx->lg_work.ptr;
+    hipLaunchKernelGGL(rs_sample_kernel, dim3((unsigned)n, (unsigned)((d + 255) / 256)), dim3(256), 0, st, theta_src,
+                       (const double*)ns.buf.ptr, ld, Z, ldz, n, (int)d);
+    VB_HIP(ctx, hipGetLastError());
+    VB_TRY(temper_prior_rows(ctx, Z, ldz, n, d, base + L.o_lprior + mine));
+  }
   if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lp, mine, n, n_total));
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_b, mine, n, n_total));

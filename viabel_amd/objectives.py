@@ -760,20 +760,64 @@ class DISInclusiveKL(StochasticVariationalObjective):
         """Clip weights to ``w_clip_threshold`` (``objectives.py:370-386``).
 
         With the default threshold 10 no weight can exceed ``10 * sum(w)``, so this is a no-op; the
-        reference's clipping line (``:385``) calls a float and cannot run -- the evident intent is
-        written here."""
-        S = np.sum(w)
+        reference's clipping line (``:385``) calls a float and cannot run, and its literal recursion does not
+        terminate in floating point (a clipped weight equals the next threshold up to rounding) -- the fixed point it
+        aims at is computed instead: the clipped set only grows, unclipped weights are compared with
+        ``thr * U / (1 - thr n)`` until none reaches it (``oracle.objectives.DISInclusiveKL._clip``; the same rounds as
+        ``vb_dis_clip_mvt`` runs on the device-resident weights)."""
         thr = self._w_clip_threshold
+        w = np.asarray(w, dtype=np.float64)
+        S = np.sum(w)
         if not np.any(w > S * thr):
             return w
-        to_clip = (w >= S * thr)
-        n_to_clip = np.sum(to_clip)
-        sum_unclipped = np.sum(w[~to_clip])
-        if sum_unclipped == 0:
+        clipped = np.zeros(w.shape, dtype=bool)
+        while True:
+            new = ~clipped & (w >= S * thr)
+            if not np.any(new):
+                break
+            trial = clipped | new
+            n, U = np.sum(trial), np.sum(w[~trial])
+            if U == 0 or 1. - thr * n <= 0:
+                break
+            clipped, S = trial, U / (1. - thr * n)
+        if not np.any(clipped):
             return w
-        w = w.copy()
-        w[to_clip] = thr * sum_unclipped / (1. - thr * n_to_clip)
-        return self._clip_weights(w)
+        out = w.copy()
+        out[clipped] = thr * np.sum(w[~clipped]) / (1. - thr * np.sum(clipped))
+        return out
+
+    def _build_prior_spec(self, D):
+        """The tempering prior (``objectives.py:283-285``: any family; ``:317-319`` calls its ``log_density``) as the
+        engine takes it: an MFGaussian parameter goes straight into the refresh calls (``tests/test_objectives.py:82-87``,
+        fused with the model's row pass); MFStudentT is one more row pass; FullRankGaussian / MultivariateT -- and
+        LRGaussian through the Cholesky factor of its covariance -- one more N x D x D product
+        (``vb_dis_set_temper_prior``).  Returns ``(spec or None, prior argument of the refresh calls)``."""
+        prior, params = self._temper_prior, self._temper_prior_params
+        if not isinstance(prior, (MFGaussian, MFStudentT, MultivariateT, FullRankGaussian, LRGaussian)):
+            raise NotImplementedError('temper_prior must be one of MFGaussian, MFStudentT, FullRankGaussian, '
+                                      'MultivariateT, LRGaussian; got {}'.format(type(prior).__name__))
+        if prior.dim != D:
+            raise ValueError('temper_prior has dimension {}, the approximation {}'.format(prior.dim, D))
+        if params.shape != (prior.var_param_dim,):
+            raise ValueError('temper_prior_params must have shape ({},)'.format(prior.var_param_dim))
+        if isinstance(prior, MFGaussian):
+            return None, params
+        if isinstance(prior, MFStudentT):
+            loc, log_sigma = prior._unpack(params)
+            spec = (_lib.PRIOR_DIAG_STUDENT_T, prior.df, np.array(loc), np.array(log_sigma), 0.0)
+        else:
+            if isinstance(prior, LRGaussian):
+                loc, log_sigma, B = prior._unpack(params)
+                L = np.linalg.cholesky(B @ B.T + np.diag(np.exp(2.0 * log_sigma)))
+                df = 0.0
+            else:
+                loc, L = prior._unpack(params)
+                df = prior.df if isinstance(prior, MultivariateT) else 0.0
+            Linv = _sla.solve_triangular(L, np.eye(D), lower=True)
+            spec = (_lib.PRIOR_DENSE, df, np.array(loc), np.ascontiguousarray(np.tril(Linv)),
+                    float(np.sum(np.log(np.diag(L)))))
+        # the refresh calls still take an MFGaussian parameter (its pass is overwritten by the installed prior's)
+        return spec, np.zeros(2 * D)
 
     def _update_objective_and_grad(self):
         approx = self.approx
@@ -783,11 +827,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                                       'FullRankGaussian and LRGaussian; got {}'.format(type(approx).__name__))
         if isinstance(approx, LRGaussian) and not 1 <= approx.k <= 64:
             raise NotImplementedError('LRGaussian under DISInclusiveKL on the HIP engine: 1 <= k <= 64')
-        if not isinstance(self._temper_prior, MFGaussian) or self._temper_prior.dim != approx.dim:
-            raise NotImplementedError('temper_prior must be an MFGaussian of the same dimension '
-                                      '(tests/test_objectives.py:82-87)')
-        if self._temper_prior_params.shape != (2 * approx.dim,):
-            raise ValueError('temper_prior_params must have shape ({},)'.format(2 * approx.dim))
+        self._prior_spec, self._prior_arg = self._build_prior_spec(approx.dim)
         slot = _DIS_SLOT
         if isinstance(approx, (MultivariateT, FullRankGaussian)):
             self._objective_and_grad = self._mvt_objective(approx, slot)
@@ -811,8 +851,9 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 # log q, log p, tempering bisection, clipping.  Sharded jobs gather the per-sample
                 # vectors, so eps and the weights cover all N samples on every rank.
                 self._stage_noise(eng, N, slot=slot)
+                eng.dis_set_temper_prior(self._prior_spec)
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_meanfield(
-                    slot, n_local, approx.dim, var_param, self._temper_prior_params, family, self._eps,
+                    slot, n_local, approx.dim, var_param, self._prior_arg, family, self._eps,
                     self._ess_target, self._max_bisection_its, df=df, n_total=N)
                 self._set_state_logs(log_p, log_q)
                 self._state_w_clipped = self._clip_weights(self._smooth_weights(eng, w))
@@ -860,8 +901,9 @@ class DISInclusiveKL(StochasticVariationalObjective):
                     z, eps = approx._base_noise(N)          # low-rank block first (approximations.py:639-640)
                     eng.noise_set_host(slot, eps[begin:end])
                     eng.noise_set_host(_LR_SLOT, z[begin:end])
+                eng.dis_set_temper_prior(self._prior_spec)
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_lowrank(
-                    slot, _LR_SLOT, n_local, D, k, mu, ls, B, Minv, cq, self._temper_prior_params, self._eps,
+                    slot, _LR_SLOT, n_local, D, k, mu, ls, B, Minv, cq, self._prior_arg, self._eps,
                     self._ess_target, self._max_bisection_its, n_total=N)
                 self._set_state_logs(log_p, log_q)
                 self._state_w_clipped = self._clip_weights(self._smooth_weights(eng, w))
@@ -926,10 +968,13 @@ class DISInclusiveKL(StochasticVariationalObjective):
             n_local = end - begin
             # throughput mode: mu, L, L^-1 and the chain rule of the gradient are formed on the device from var_param
             L, Linv = (None, None) if philox else factors(var_param)
-            # ... and on one rank with a clipping threshold >= 1 (objectives.py:370-386 is the identity then; the default
-            # is 10) the weights never leave the device either -- Pareto smoothing included (vb_dis_psis_mvt)
-            resident = philox and eng.n_ranks == 1 and self._w_clip_threshold >= 1.0
+            # ... and on one rank the weights never leave the device either -- Pareto smoothing (vb_dis_psis_mvt) and, for
+            # a clipping threshold below 1 (objectives.py:370-386; the identity otherwise, the default is 10), the
+            # clipping (vb_dis_clip_mvt) included
+            resident = philox and eng.n_ranks == 1
+            clip = self._w_clip_threshold < 1.0
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
+                eng.dis_set_temper_prior(self._prior_spec)
                 if gaussian:
                     chi = np.ones(N)
                     if philox:
@@ -937,10 +982,12 @@ class DISInclusiveKL(StochasticVariationalObjective):
                                            row_offset=begin)
                         root = None
                         if resident:     # as the t family below: df = 0 is the Gaussian member of the same kernels
-                            eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._temper_prior_params,
+                            eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._prior_arg,
                                                          self._eps, self._ess_target, self._max_bisection_its)
                             if self._psis_smooth:
                                 eng.dis_psis_mvt(N)
+                            if clip:
+                                eng.dis_clip_mvt(N, self._w_clip_threshold)
                             self._set_state_logs(None, None, lambda: eng.dis_state_get(True, N))
                             self._set_state_weights(None, lambda: eng.dis_weights_get(N))
                             self._own_state(eng, 1, True)
@@ -961,10 +1008,12 @@ class DISInclusiveKL(StochasticVariationalObjective):
                     if resident:
                         # device-resident step: the refresh only enqueues; weights, eps, ess stay on the device and
                         # come back (eps, ess) with the gradient after one synchronisation
-                        eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._temper_prior_params, self._eps,
+                        eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._prior_arg, self._eps,
                                                      self._ess_target, self._max_bisection_its)
                         if self._psis_smooth:
                             eng.dis_psis_mvt(N)
+                        if clip:
+                            eng.dis_clip_mvt(N, self._w_clip_threshold)
                         self._set_state_logs(None, None, lambda: eng.dis_state_get(True, N))
                         self._set_state_weights(None, lambda: eng.dis_weights_get(N))
                         self._own_state(eng, 1, True)
@@ -975,7 +1024,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 if not resident:
                     self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
                         slot, n_local, D, df, var_param, None if chi is None else chi[begin:end], root, Linv,
-                        self._temper_prior_params, self._eps, self._ess_target, self._max_bisection_its, n_total=N,
+                        self._prior_arg, self._eps, self._ess_target, self._max_bisection_its, n_total=N,
                         fetch_logs=not philox)
                     self._set_state_logs(log_p, log_q, (lambda: eng.dis_state_get(True, N)) if philox else None)
                     self._state_w_clipped = self._clip_weights(self._smooth_weights(eng, w))
