@@ -238,7 +238,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
   if (ctx->user_host_pin) (void)hipHostFree(ctx->user_host_pin);
@@ -969,7 +969,15 @@ int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p) {
   VB_HIP(ctx, hipMemcpyAsync(value, ctx->fr_out.ptr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VB_HIP(ctx, hipMemcpyAsync(grad, (const double*)ctx->fr_out.ptr + 1, (size_t)p * sizeof(double),
                              hipMemcpyDeviceToHost, ctx->stream));
+  unsigned fz_err = 0;       // fused evaluation (vb_fullrank_fused.h): a dependency poll that gave up
+  if (ctx->fz_words.ptr)
+    VB_HIP(ctx, hipMemcpyAsync(&fz_err, (const unsigned*)ctx->fz_words.ptr + 1, sizeof fz_err, hipMemcpyDeviceToHost,
+                               ctx->stream));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (fz_err) {
+    VB_HIP(ctx, hipMemsetAsync(ctx->fz_words.ptr, 0, 2 * sizeof(unsigned), ctx->stream));
+    return fail(ctx, VB_ERR_STATE, "fused full-rank evaluation: a tile gave up waiting for its input (results invalid)");
+  }
   return VB_OK;
 }
 

@@ -216,6 +216,12 @@ struct vb_ctx {
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
+  // fused full-rank evaluation (vb_fullrank_fused.h): ticket counter, error word and tile flags; the work list
+  vb::DeviceBuffer fz_words, fz_items;
+  int64_t fz_key[5] = {0, 0, 0, 0, 0};  // (n, d, splits, phases, tile_blocks) the list was built for
+  int fz_n_items = 0;
+  unsigned fz_epoch = 0;
+  int fr_fused_mode = -1;               // -1: VB_FR_FUSED from the environment; 0 off, 2 / 3 phases fused
   uint64_t fr_seq = 0;                  // sharded full-rank evaluations enqueued (selects the sum set)
 
   void* comm = nullptr;                 // ncclComm_t when a communicator is attached (the context itself under a

@@ -228,6 +228,10 @@ struct EpiSplitSlab {       // C_split[i][j] = acc
   }
 };
 
+}  // namespace vb
+#include "vb_fullrank_fused.h"
+namespace vb {
+
 // ---- funnel: row kernel Z -> G, f ---------------------------------------------------------------
 // one wave per row; G[n][j] = -z_j w (j != k), G[n][k] = -v/tau^2 - (D-1) + w sum_{j != k} z_j^2
 __global__ void __launch_bounds__(256) fr_funnel_kernel(const double* __restrict__ Z, double* __restrict__ G,
@@ -988,6 +992,113 @@ __global__ void __launch_bounds__(256) fr_gsum_kernel(const double* __restrict__
   if (threadIdx.x == 0) fpart[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// ---- the fused evaluation's launch (vb_fullrank_fused.h) --------------------------------------------------------------
+// phases == 2: Z and G by one persistent launch (returns the number of sum-f partials); phases == 3: C as well.
+static int fr_fused_enqueue(vb_ctx* ctx, hipStream_t st, int phases, GemmArgs g1, GemmArgs g2, GemmArgs g3, int splits,
+                            double* Z, double* G, int64_t ldz, const double* mu, const double* shift, double* fpart,
+                            const EpiSplitSlabCs& e3, unsigned* tiles2_out) {
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int n = g1.M, D = g1.N;
+  auto fill = [](GemmArgs& g, int splits_) {
+    const int ks = gemm_tiles(g.K, splits_);
+    g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
+    g.tiles_m = gemm_tiles(g.M, 128);
+    g.tiles_n = gemm_tiles(g.N, 64);
+    g.prio_div = 0;
+    g.ev0 = g.ev1 = nullptr;
+  };
+  fill(g1, 1);
+  fill(g2, 1);
+  fill(g3, splits);
+  const int tm = g1.tiles_m, tn = g1.tiles_n;
+  const int n_p1 = tm * tn, n_p2 = tm * tn;
+  const int n_p3 = g3.tile_map ? g3.tile_blocks : (int)gemm_count_blocks(g3, 128, 64);
+  // shared words: [head | err | 14 pad | zflag tm x tn | gflag tm x tn]
+  const size_t words = 16 + 2 * (size_t)tm * tn;
+  VB_TRY(ensure(ctx, ctx->fz_words, words * sizeof(unsigned)));      // (a new allocation is zeroed by ensure)
+  unsigned* wbase = (unsigned*)ctx->fz_words.ptr;
+  const int64_t key[5] = {n, D, splits, phases, n_p3};      // (the group count is read once per process)
+  if (memcmp(key, ctx->fz_key, sizeof key) != 0 || !ctx->fz_items.ptr) {
+    // the list, in a topological order: every Z tile heaviest k range first; then row block by row block the G tiles,
+    // and behind the last row block of a split the C tiles of that split
+    std::vector<int> host;
+    auto push = [&host](int phase, int bx, int bz) {
+      host.push_back(phase), host.push_back(bx), host.push_back(bz), host.push_back(0);
+    };
+    // (VB_FR_FUSED_GROUPS = g: the row blocks in g groups, each group's Z tiles followed by its G tiles -- measured, see
+    // profiles/r04_fused_timeline.txt)
+    static const int groups_env = getenv("VB_FR_FUSED_GROUPS") ? atoi(getenv("VB_FR_FUSED_GROUPS")) : 1;
+    const int groups = groups_env < 1 ? 1 : (groups_env > tm ? tm : groups_env);
+    std::vector<int> map;
+    if (phases == 3 && g3.tile_map) {
+      map.resize((size_t)2 * n_p3);
+      VB_HIP(ctx, hipMemcpy(map.data(), g3.tile_map, map.size() * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    int z_next = 0;
+    for (int grp = 0; grp < groups; ++grp) {
+      const int rb0 = (int)((int64_t)tm * grp / groups), rb1 = (int)((int64_t)tm * (grp + 1) / groups);
+      // block x of the triangular product: idx = x / tm selects the column block (heaviest first), x % tm the row block
+      for (int idx = 0; idx < tn; ++idx)
+        for (int rb = rb0; rb < rb1; ++rb) push(0, idx * tm + rb, 0);
+      for (int rb = rb0; rb < rb1; ++rb) {
+        for (int cb = 0; cb < tn; ++cb) push(1, cb * tm + rb, 0);
+        while (phases == 3 && z_next < splits) {
+          const int64_t last_row = std::min<int64_t>(n, (int64_t)(z_next + 1) * g3.k_split) - 1;
+          if (last_row / 128 > rb) break;
+          for (int bx = 0; bx < n_p3; ++bx)
+            if (map.empty() || map[2 * bx] >= 0) push(2, bx, z_next);
+          ++z_next;
+        }
+      }
+    }
+    VB_TRY(ensure(ctx, ctx->fz_items, host.size() * sizeof(int)));
+    VB_HIP(ctx, hipMemcpyAsync(ctx->fz_items.ptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    VB_HIP(ctx, hipStreamSynchronize(st));      // `host` is stack-scoped
+    memcpy(ctx->fz_key, key, sizeof key);
+    ctx->fz_n_items = (int)(host.size() / 4);
+  }
+  if (++ctx->fz_epoch == 0) ctx->fz_epoch = 1;
+  FzArgs a;
+  a.g1 = g1, a.g2 = g2, a.g3 = g3;
+  a.e1 = EpiStoreZPub{Z, ldz, mu, shift};
+  a.G = G, a.ldz = ldz, a.Zc = Z, a.fpart = fpart;
+  a.e3 = e3;
+  a.s.head = wbase, a.s.err = wbase + 1, a.s.zflag = wbase + 16, a.s.gflag = wbase + 16 + (size_t)tm * tn;
+  a.s.epoch = ctx->fz_epoch, a.s.tiles_n = tn;
+  a.items = (const int4*)ctx->fz_items.ptr;
+  a.n_items = ctx->fz_n_items, a.n_p1 = n_p1, a.n_p2 = n_p2, a.n_p3 = n_p3;
+  a.clk = nullptr;
+#ifdef VB_FUSED_CLOCK
+  VB_TRY(ensure(ctx, ctx->scratch2, (size_t)4 * a.n_items * sizeof(long long)));
+  a.clk = (long long*)ctx->scratch2.ptr;
+#endif
+  constexpr size_t lds = (size_t)3 * (128 * kGemmBK + kGemmBK * 64) * sizeof(double) + 16;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fr_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fr_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = true;
+  }
+  static const int wgs_env = getenv("VB_FR_FUSED_WGS") ? atoi(getenv("VB_FR_FUSED_WGS")) : 0;
+  const unsigned grid = (unsigned)(wgs_env > 0 ? wgs_env : 2 * n_cu);
+  if (phases == 3) hipLaunchKernelGGL(fr_fused_kernel<3>, dim3(grid), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(fr_fused_kernel<2>, dim3(grid), dim3(256), lds, st, a);
+  VB_HIP(ctx, hipGetLastError());
+#ifdef VB_FUSED_CLOCK
+  if (const char* path = getenv("VB_FUSED_CLOCK_DUMP")) {      // per-item clocks of THIS launch (tools/fused_clock.py)
+    VB_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<long long> h((size_t)4 * a.n_items);
+    VB_HIP(ctx, hipMemcpy(h.data(), a.clk, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(path, "wb")) {
+      fwrite(h.data(), sizeof(long long), h.size(), f);
+      fclose(f);
+    }
+  }
+#endif
+  *tiles2_out = (unsigned)n_p2;
+  return VB_OK;
+}
+
 // ---- host orchestration ------------------------------------------------------------------------------
 // theta_dev != nullptr: full-rank Gaussian (Z = E L' + mu, lower-triangular gradient, epilogue into the flat layout).
 // theta_dev == nullptr: multivariate t (X = (E R) / s + mu with the dense symmetric root R and the per-row scale
@@ -1197,6 +1308,16 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     while (kparts > 1 && (D % (kGemmBK * kparts) != 0 || D / kparts < 16 * kGemmBK)) --kparts;
     if ((int64_t)kparts * pslab > (int64_t)(splits + 1) * slab) kparts = 1;
   }
+  // the fused evaluation: 2 = Z and G in one persistent launch, 3 = the gradient product's split slabs as well
+  int fz_mode = ctx->fr_fused_mode;
+  if (fz_mode < 0) {
+    const char* e = getenv("VB_FR_FUSED");
+    fz_mode = e ? atoi(e) : 0;
+  }
+  if (!(fused_sums && kparts == 1 && cfg1 == 0 && cfg2 == 0 && cfg3 == 0 && n % 128 == 0 && D % 64 == 0 &&
+        (int64_t)n * ldz * 8 < ((int64_t)1 << 31)))
+    fz_mode = 0;
+  if (fz_mode != 2 && fz_mode != 3) fz_mode = 0;
   const unsigned sum_blocks = (unsigned)((pslab / 2 + 255) / 256);
   // Z = E L' + mu - shift into `Z` (the samples, or z - m for the correlated Gaussian target)
   auto sample_gemm = [&](const double* shift, int cfg) {
@@ -1260,9 +1381,20 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     g2.N = D;
     g2.K = D;
     g2.tri_mode = 0;
+    if (fz_mode >= 2) {
+      // one persistent launch for Z - m and G (and, fz_mode 3, the split slabs of C): vb_fullrank_fused.h
+      EpiSplitSlabCs e3{Cpart, ldl, slab, colpart, ldz};
+      GemmArgs g3f;
+      g3f.A = G, g3f.lda = ldz, g3f.B = (const double*)ns.buf.ptr, g3f.ldb = ns.ld;
+      g3f.M = D, g3f.N = D, g3f.K = (int)n, g3f.tri_mode = 2;
+      if (fz_mode == 3) VB_TRY(tri2_tile_map(ctx, D, 128, 64, &g3f.tile_map, &g3f.tile_blocks));
+      VB_TRY(fr_fused_enqueue(ctx, st, fz_mode, g1, g2, g3f, splits, Z, G, ldz, mu, m.p0, fpart, e3, &tiles2));
+    } else {
     sample_gemm(m.p0, cfg1);                         // Z - m
     VB_HIP(ctx, hipGetLastError());
-    if (kparts > 1 && fused_sums) {
+    }
+    if (fz_mode >= 2) {
+    } else if (kparts > 1 && fused_sums) {
       gemm_f64_launch<true>(st, g2, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
       hipLaunchKernelGGL(fr_gsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,
                          (const double*)Z, G, fpart);
@@ -1316,7 +1448,10 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   // GEMM 3: C[i][j] = sum_n G[n][i] E[n][j]
   prof_events(ctx, &g3.ev0, &g3.ev1, 1, VB_PROF_FR_GRAD_GEMM);
   int n_rb_red = n_rb + (pd ? 1 : 0), n_fpart_red = n_fpart;
-  if (fused_sums || cs_only) {
+  if (fz_mode == 3) {          // the fused launch has written the split slabs and their column sums
+    n_rb_red = splits;
+    n_fpart_red = (int)tiles2;
+  } else if (fused_sums || cs_only) {
     static const bool map_env = !(getenv("VB_FR_TILE_MAP") && atoi(getenv("VB_FR_TILE_MAP")) == 0);
     int cfg3_used = cfg3;
     if (map_env && cfg3 == 0 && gemm_count_blocks(g3, 128, 64) * splits * 100 >= 190L * n_cu) {

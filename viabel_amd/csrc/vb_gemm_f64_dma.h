@@ -28,9 +28,21 @@ namespace vb {
 typedef __attribute__((address_space(1))) const void* gemm_gptr;
 typedef __attribute__((address_space(3))) void* gemm_lptr;
 
-template <bool A_KCONTIG, int AF, int NB, int STAGES, class Epi>
-__global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF * NB > 16 || STAGES > 2 ? 2 : 4))
-    gemm_f64_dma_kernel(const GemmArgs g, const Epi epi) {
+// In-launch dependencies of a tile (the fused full-rank evaluation, vb_fullrank_fused.h): a `Dep` object is consulted
+// by every wave before it requests a k slab (`before_slab(bm, bn, slab, first)`: a consumer polls the producer's flag there), names the
+// cache policy of the A operand's loads (`kAuxA`: 16 = sc1, reads data another workgroup of the same launch stored
+// write-through) and is told when the tile's results have left (`publish`).  Stand-alone launches use GemmNoDep: no
+// code.
+struct GemmNoDep {
+  static constexpr int kAuxA = 0;
+  __device__ __forceinline__ void before_slab(int, int, int, bool) const {}
+  __device__ __forceinline__ void publish(int, int, int) const {}
+};
+
+// One output tile of the product: block x of a launch with gx blocks per split, split (or batch index) bz.
+template <bool A_KCONTIG, int AF, int NB, int STAGES, class Epi, class Dep>
+__device__ __forceinline__ void gemm_f64_dma_tile(const GemmArgs& g, const Epi& epi, const Dep& dep, const int bx,
+                                                  const int bz, const int gx) {
   constexpr int BM = 32 * AF, BN = 8 * NB;
   constexpr int kStages = STAGES;
   static_assert(STAGES == 2 || STAGES == 3, "two or three LDS stages");
@@ -54,15 +66,15 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
   double local = 0.0;
   int bm, bn;
   if (g.tri_mode == 2 && g.tile_map) {
-    bm = g.tile_map[2 * blockIdx.x];
-    bn = g.tile_map[2 * blockIdx.x + 1];
+    bm = g.tile_map[2 * bx];
+    bn = g.tile_map[2 * bx + 1];
     if (bm < 0) {                        // padding entry of the tile list (uniform for the workgroup)
       if constexpr (EpiReduces<Epi>::value)
-        if (t == 0) epi.part[(int64_t)blockIdx.z * gridDim.x + blockIdx.x] = 0.0;
+        if (t == 0) epi.part[(int64_t)bz * gx + bx] = 0.0;
       return;
     }
   } else if (g.tri_mode == 2) {
-    int idx = blockIdx.x;
+    int idx = bx;
     bm = 0;
     for (;;) {
       const int cnt = min(g.tiles_n, (bm * BM + BM - 1) / BN + 1);
@@ -72,23 +84,23 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
     }
     bn = idx;
   } else if (g.tri_mode == 1 || g.tri_mode == 3) {
-    const int idx = blockIdx.x / g.tiles_m, half = (g.tiles_n + 1) / 2;
+    const int idx = bx / g.tiles_m, half = (g.tiles_n + 1) / 2;
     bn = idx < half ? g.tiles_n - 1 - idx : idx - half;
     if (g.tri_mode == 3) bn = g.tiles_n - 1 - bn;      // mirrored triangle: column block 0 has the longest k range
-    bm = blockIdx.x % g.tiles_m;
+    bm = bx % g.tiles_m;
   } else {
-    bn = blockIdx.x / g.tiles_m;
-    bm = blockIdx.x % g.tiles_m;
+    bn = bx / g.tiles_m;
+    bm = bx % g.tiles_m;
   }
   const int m0 = bm * BM, n0 = bn * BN;
-  int k_begin = g.batch ? 0 : blockIdx.z * g.k_split;
+  int k_begin = g.batch ? 0 : bz * g.k_split;
   int k_end = (g.batch || k_begin + g.k_split >= g.K) ? g.K : k_begin + g.k_split;
   if (g.tri_mode == 3) {         // B[k][j] == 0 for k < j: the k range of column block bn starts at its first column
     const int kmin = n0 / kGemmBK * kGemmBK;
     if (k_begin < kmin) k_begin = kmin < k_end ? kmin : k_end;
   }
-  const double* __restrict__ gA = g.A + (g.batch ? (int64_t)blockIdx.z * g.batch_a : 0);
-  const double* __restrict__ gB = g.B + (g.batch ? (int64_t)blockIdx.z * g.batch_b : 0);
+  const double* __restrict__ gA = g.A + (g.batch ? (int64_t)bz * g.batch_a : 0);
+  const double* __restrict__ gB = g.B + (g.batch ? (int64_t)bz * g.batch_b : 0);
   if (g.tri_mode == 1) {
     const int kmax = n0 + BN;
     if (k_end > kmax) k_end = kmax;
@@ -182,7 +194,8 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
     for (int u = 0; u < UPW; ++u) {
       const int q = u * 4 + wave;
       double* dst = gemm_lds + lds_off[u] + st * (q < kAUnits ? kATile : kBTile);
-      __builtin_amdgcn_global_load_lds((gemm_gptr)src[u], (gemm_lptr)dst, 16, 0, 0);
+      if (q < kAUnits) __builtin_amdgcn_global_load_lds((gemm_gptr)src[u], (gemm_lptr)dst, 16, 0, Dep::kAuxA);
+      else __builtin_amdgcn_global_load_lds((gemm_gptr)src[u], (gemm_lptr)dst, 16, 0, 0);
     }
   };
   auto advance = [&]() __attribute__((always_inline)) {
@@ -296,10 +309,15 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
   };
 
+  const int slab0 = k_begin / kGemmBK;
   if (nslabs > 0) {
+    dep.before_slab(bm, bn, slab0, true);
     issue(0);                          // slab 0
     if (kAhead == 2) {
-      if (nslabs > 1) advance();
+      if (nslabs > 1) {
+        advance();
+        dep.before_slab(bm, bn, slab0 + 1, false);
+      }
       issue(1);                        // slab 1 (or slab 0 again: keeps the vmcnt arithmetic uniform)
     }
     wait_vm(std::integral_constant<int, UPW*(kAhead - 1)>());
@@ -317,7 +335,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
     // workgroup lifetimes of 100 and 140 us side by side in the dense 4096 x 1024 x 1024 product).  Alternating the
     // wave priority slab by slab, in opposite phase for the two generations of workgroups, lets them progress at
     // the same pace and finish together.
-    const int prio_phase = g.prio_div > 0 ? (int)((blockIdx.x + gridDim.x * blockIdx.z) / (unsigned)g.prio_div) & 1 : -1;
+    const int prio_phase = g.prio_div > 0 ? (int)((bx + gx * bz) / (unsigned)g.prio_div) & 1 : -1;
     for (int s = 0; s < nslabs; ++s) {
       if (prio_phase >= 0) {
         if ((s ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(1);
@@ -325,7 +343,10 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
       }
       const int st1 = st == kStages - 1 ? 0 : st + 1;
       const int st_new = kAhead == 2 ? (st1 == kStages - 1 ? 0 : st1 + 1) : st1;   // the stage slab s + kAhead goes to
-      if (s + kAhead < nslabs) advance();   // beyond the end: re-fetch the last slab into a free stage
+      if (s + kAhead < nslabs) {            // beyond the end: re-fetch the last slab into a free stage
+        advance();
+        dep.before_slab(bm, bn, slab0 + s + kAhead, false);
+      }
 #ifndef VB_ABL_NO_DMA     // timing ablations (tools/gemm_bench.hip): results are wrong with any of them defined
       issue(st_new);
 #endif
@@ -384,7 +405,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
   }
 
   if constexpr (kColsum) {
-    if (cs_lane && m0 + cs_col < g.M) epi.colsum[(int64_t)blockIdx.z * epi.colsum_ld + m0 + cs_col] = cs;
+    if (cs_lane && m0 + cs_col < g.M) epi.colsum[(int64_t)bz * epi.colsum_ld + m0 + cs_col] = cs;
     if (cs_wg) {                 // combine the k groups in fixed order (the slabs are no longer needed)
       gemm_lds[t] = cs;
       __syncthreads();
@@ -392,7 +413,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
         double tot = gemm_lds[t];
 #pragma unroll
         for (int q = 1; q < 256 / BM; ++q) tot += gemm_lds[q * BM + t];
-        epi.colsum[(int64_t)blockIdx.z * epi.colsum_ld + m0 + t] = tot;
+        epi.colsum[(int64_t)bz * epi.colsum_ld + m0 + t] = tot;
       }
       __syncthreads();
     }
@@ -406,7 +427,7 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
       const int col = n0 + frag_col(r, fblk, fj);           // even; fragment r + 1 is column col + 1
       if constexpr (EpiPairs<Epi>::value && AF * NB <= 32) {     // (the 128 x 128 tile has no registers to spare)
         if (row < g.M && col + 1 < g.N) {
-          const d2v v = epi.pair((int)blockIdx.z, row, col, acc[a][r], acc[a][r + 1]);
+          const d2v v = epi.pair((int)bz, row, col, acc[a][r], acc[a][r + 1]);
           if constexpr (EpiReduces<Epi>::value) {
             local += v.x;
             local += v.y;
@@ -418,9 +439,9 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
       for (int q = 0; q < 2; ++q) {
         if (row < g.M && col + q < g.N) {
           if constexpr (EpiReduces<Epi>::value)
-            local += epi((int)blockIdx.z, row, col + q, acc[a][r + q]);
+            local += epi((int)bz, row, col + q, acc[a][r + q]);
           else
-            epi((int)blockIdx.z, row, col + q, acc[a][r + q]);
+            epi((int)bz, row, col + q, acc[a][r + q]);
         }
       }
     }
@@ -430,12 +451,13 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
     if (lane == 0) gemm_lds[wave] = local;
     __syncthreads();
     if (t == 0)
-      epi.part[(int64_t)blockIdx.z * gridDim.x + blockIdx.x] = (gemm_lds[0] + gemm_lds[1]) + (gemm_lds[2] + gemm_lds[3]);
+      epi.part[(int64_t)bz * gx + bx] = (gemm_lds[0] + gemm_lds[1]) + (gemm_lds[2] + gemm_lds[3]);
   }
+  dep.publish(bm, bn, bz);
 #ifdef VB_GEMM_CLOCK
   __builtin_amdgcn_s_waitcnt(0);       // the epilogue's stores have left
-  if (lane == 0 && blockIdx.x < 1024) {
-    long long* o = vb_gemm_dbg + 8 * (4 * blockIdx.x + wave);
+  if (lane == 0 && bx < 1024) {
+    long long* o = vb_gemm_dbg + 8 * (4 * bx + wave);
     o[0] = dbg_t1 - dbg_t0;            // prologue (tile setup + first two slab fetches)
     o[1] = dbg_t2 - dbg_t1;            // main loop
     o[2] = clock64() - dbg_t2;         // epilogue
@@ -443,6 +465,14 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF
     o[4] = dbg_w0;
   }
 #endif
+}
+
+
+template <bool A_KCONTIG, int AF, int NB, int STAGES, class Epi>
+__global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF * NB > 16 || STAGES > 2 ? 2 : 4))
+    gemm_f64_dma_kernel(const GemmArgs g, const Epi epi) {
+  gemm_f64_dma_tile<A_KCONTIG, AF, NB, STAGES, Epi, GemmNoDep>(g, epi, GemmNoDep{}, (int)blockIdx.x, (int)blockIdx.z,
+                                                               (int)gridDim.x);
 }
 
 template <bool A_KCONTIG, int AF, int NB, int STAGES, class Epi>
