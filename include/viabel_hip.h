@@ -500,6 +500,15 @@ int vb_legacy_rng_random_sample(vb_legacy_rng* rng, double* out, int64_t n);
 /* (key[624], pos, has_gauss, cached_gaussian) as `RandomState.get_state()` / `set_state()` carry them */
 int vb_legacy_rng_get_state(const vb_legacy_rng* rng, uint32_t key[624], int* pos, int* has_gauss, double* gauss);
 int vb_legacy_rng_set_state(vb_legacy_rng* rng, const uint32_t key[624], int pos, int has_gauss, double gauss);
+/* The same stream ON THE DEVICE: rows [row_begin, row_begin + rows) of rng.randn(n_total, d) -- what the reference's
+ * families draw at approximations.py:203 / :213-216 / :343-347 -- written straight into noise slot `slot` (rows x d),
+ * bit for bit numpy's values, and `rng` advanced exactly as randn(n_total, d) advances it (position, cached value of
+ * an odd count): MT19937 in parallel streams through jump-ahead polynomials, the polar method's attempts, their
+ * prefix sums and the scatter on the device; only the attempts whose logarithm the device cannot pin to the host C
+ * library's rounding (about one in forty) are finished on the host.  VB_ERR_UNSUPPORTED (request beyond 1024 streams,
+ * ~64 M values): nothing was changed, draw with vb_legacy_rng_randn and upload.                                    */
+int vb_legacy_rng_randn_device(vb_ctx* ctx, vb_legacy_rng* rng, int slot, int64_t n_total, int64_t d, int64_t row_begin,
+                               int64_t rows);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels ---------
  * When enabled, every launch of a profiled kernel carries a start/stop event pair

@@ -171,6 +171,8 @@ SIGNATURES = {
                                                ctypes.POINTER(ctypes.c_int), _c_double_p]),
     'vb_legacy_rng_set_state': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_int,
                                                ctypes.c_double]),
+    'vb_legacy_rng_randn_device': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                                  ctypes.c_int64, ctypes.c_int64]),
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_init_host': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
@@ -322,6 +324,18 @@ class Engine:
         out = np.empty(n, dtype=np.float64)
         self._check(self._lib.vb_chisq_get_host(self._ctx, _dptr(out), n))
         return out
+
+    def noise_legacy_randn(self, slot, rng_handle, n_total, d, row_begin=0, rows=None):
+        """Rows ``[row_begin, row_begin + rows)`` of ``RandomState.randn(n_total, d)`` generated ON THE DEVICE into
+        ``slot``, bit for bit numpy's stream (``vb_legacy_rng_randn_device``); ``rng_handle`` is the ``vb_legacy_rng*``
+        of a ``LegacyRandomState`` and is advanced as numpy would advance it.  Returns False when the request is outside
+        the device path's range (the generator is untouched then: draw on the host and upload)."""
+        rows = n_total - row_begin if rows is None else rows
+        rc = self._lib.vb_legacy_rng_randn_device(self._ctx, rng_handle, slot, n_total, d, row_begin, rows)
+        if rc == VB_ERR_UNSUPPORTED:
+            return False
+        self._check(rc)
+        return True
 
     def noise_get_host(self, slot, n, d):
         out = np.empty((n, d), dtype=np.float64)

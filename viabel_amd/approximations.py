@@ -125,6 +125,25 @@ class _NoiseMixin:
         self._philox_calls += 1
         return k
 
+    # -- parity-mode noise into a device slot ---------------------------------------------------------------------------
+    _DEVICE_DRAW_FROM = 1 << 16      # values; below this the host draw + upload is as fast as the device path's launches
+
+    def _stage_normals(self, eng, rs, slot, n_total, d, begin, end):
+        """Rows ``[begin, end)`` of ``rs.randn(n_total, d)`` into ``slot``.  Big draws are generated ON THE DEVICE from the
+        generator's own state, bit for bit numpy's stream (``vb_legacy_rng_randn_device``: MT19937 in parallel streams,
+        the polar method's attempts and their prefix sums as kernels), which leaves ``rs`` where ``randn`` would have left
+        it; small ones, and anything outside the device path's range, are drawn on the host and uploaded."""
+        if (n_total * d >= self._DEVICE_DRAW_FROM and isinstance(rs, LegacyRandomState)
+                and eng.noise_legacy_randn(slot, rs._h, n_total, d, begin, end - begin)):
+            return
+        eng.noise_set_host(slot, rs.randn(n_total, d)[begin:end])
+
+    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
+        """This rank's rows of the family's base noise (what ``sample`` would consume) into ``slot``; returns what stays
+        on the host (nothing here).  Default: host draw + upload."""
+        eng.noise_set_host(slot, self._base_noise(n_total, seed)[begin:end])
+        return None
+
     def _philox_kind(self):
         """(noise kind, df) of the family's base noise for the device generator."""
         if getattr(self, '_family_id', None) == _lib.FAMILY_MF_STUDENT_T:
@@ -154,6 +173,9 @@ class MFGaussian(_NoiseMixin, ApproximationFamily):
     def _base_noise(self, n_samples, seed=None):
         """The base draws the reference's ``sample`` would consume (``:216``)."""
         return self._random_state(seed).randn(n_samples, self.dim)
+
+    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
+        self._stage_normals(eng, self._random_state(seed), slot, n_total, self.dim, begin, end)
 
     def _unpack(self, var_param):
         var_param = np.asarray(var_param, dtype=np.float64)
@@ -304,6 +326,9 @@ class FullRankGaussian(_NoiseMixin, ApproximationFamily):
     def _base_noise(self, n_samples, seed=None):
         return self._random_state(seed).randn(n_samples, self.dim)
 
+    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
+        self._stage_normals(eng, self._random_state(seed), slot, n_total, self.dim, begin, end)
+
     def _unpack(self, var_param):
         var_param = np.asarray(var_param, dtype=np.float64)
         return var_param[:self.dim], _chol_from_free(var_param[self.dim:], self.dim)
@@ -390,6 +415,13 @@ class MultivariateT(_NoiseMixin, ApproximationFamily):
         chi = rs.chisquare(self.df, n_samples)
         z = rs.randn(n_samples, self.dim)
         return chi, z
+
+    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
+        """The normals into ``slot``; returns the chi-square draws (all ``n_total`` of them: O(N) host work)."""
+        rs = self._random_state(seed)
+        chi = rs.chisquare(self.df, n_total)               # first, as ``sample`` draws them (:345-347)
+        self._stage_normals(eng, rs, slot, n_total, self.dim, begin, end)
+        return chi
 
     def _unpack(self, var_param):
         var_param = np.asarray(var_param, dtype=np.float64)
@@ -483,6 +515,17 @@ class LRGaussian(_NoiseMixin, ApproximationFamily):
         rs = self._random_state(seed)
         z = rs.randn(n_samples, self._k)
         return z, rs.randn(n_samples, self.dim)
+
+    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
+        """The low-rank block (drawn first, ``:639-640``) into ``slot_aux``, the diagonal block into ``slot``."""
+        if self._rng_kind == 'philox':
+            self._philox_noise(eng, end - begin, seed, begin, slot, slot_aux)
+            return None
+        rs = self._random_state(seed)
+        if self._k > 0:
+            self._stage_normals(eng, rs, slot_aux, n_total, self._k, begin, end)
+        self._stage_normals(eng, rs, slot, n_total, self.dim, begin, end)
+        return None
 
     def _device_family(self):
         return self._family_id, 0.0

@@ -238,7 +238,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items, &ctx->legacy_work})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
   if (ctx->user_host_pin) (void)hipHostFree(ctx->user_host_pin);
@@ -449,6 +449,25 @@ int vb_dis_set_temper_prior(vb_ctx* ctx, int kind, int64_t d, double df, const d
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
   return temper_prior_set(ctx, kind, d, df, loc, scale, log_det_l);
+}
+
+int vb_legacy_rng_randn_device(vb_ctx* ctx, vb_legacy_rng* rng, int slot, int64_t n_total, int64_t d, int64_t row_begin,
+                               int64_t rows) {
+  if (!ctx || !rng) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (n_total <= 0 || d <= 0 || row_begin < 0 || rows <= 0 || row_begin + rows > n_total)
+    return fail(ctx, VB_ERR_INVALID, "rows [%lld, %lld) of a %lld x %lld draw", (long long)row_begin,
+                (long long)(row_begin + rows), (long long)n_total, (long long)d);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  VB_TRY(noise_alloc(ctx, slot, rows, d));
+  uint32_t key[624];
+  int pos = 0, has_gauss = 0;
+  double gauss = 0.0;
+  VB_TRY(vb_legacy_rng_get_state(rng, key, &pos, &has_gauss, &gauss));
+  const int rc = legacy_dev_randn(ctx, key, &pos, &has_gauss, &gauss, ctx->noise[slot], n_total, d, row_begin, rows);
+  if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "device draw not available for this request: draw on the host");
+  VB_TRY(rc);
+  return vb_legacy_rng_set_state(rng, key, pos, has_gauss, gauss);
 }
 
 int vb_set_model_callback(vb_ctx* ctx, int64_t dim, vb_model_callback fn, void* user) {

@@ -216,6 +216,10 @@ struct vb_ctx {
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
+  // numpy's legacy normal stream on the device (vb_legacy_dev.hip): scratch; where the jump polynomials were uploaded
+  vb::DeviceBuffer legacy_work;
+  const void* legacy_poly_at = nullptr;
+  size_t legacy_poly_bytes = 0;
   // fused full-rank evaluation (vb_fullrank_fused.h): ticket counter, error word and tile flags; the work list
   vb::DeviceBuffer fz_words, fz_items;
   int64_t fz_key[5] = {0, 0, 0, 0, 0};  // (n, d, splits, phases, tile_blocks) the list was built for
@@ -312,6 +316,9 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
 int user_rows_enqueue(vb_ctx* ctx, hipStream_t st, const double* Z, int64_t ldz, int64_t n, int d, double* G,
                       int64_t ldg, double* f);
 void user_model_release(vb_ctx* ctx);
+int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, double* gauss, const NoiseSlot& ns,
+                     int64_t n_total, int64_t d, int64_t row_begin, int64_t rows);
+void vb_legacy_finish_pairs(const double* list, int64_t n, double* fixed);      // vb_legacy_rng.cpp (host libm)
 // log density of the installed tempering prior (ctx->temper.kind != 0) at the rows of X
 int mvt_dis_clip_enqueue(vb_ctx* ctx, int64_t n_total, double threshold);
 int temper_prior_rows(vb_ctx* ctx, const double* X, int64_t ld, int64_t n, int64_t d, double* out);

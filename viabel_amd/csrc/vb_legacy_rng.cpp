@@ -344,6 +344,23 @@ void randn_parallel(vb_legacy_rng& s, double* out, int64_t n, int threads) {
 
 }  // namespace
 
+// The attempts the device could not finish bit for bit (vb_legacy_dev.hip: the true log lies too close to a rounding
+// boundary to know which neighbour THIS C library returns): list entries (q, x1, x2, r2) -> (q, f x2, f x1) with the
+// host's own log, on all host threads.  Internal (declared in vb_common.h), not part of the C ABI.
+namespace vb {
+void vb_legacy_finish_pairs(const double* list, int64_t n, double* fixed) {
+  run_slices(n < 4096 ? 1 : thread_count(0), (size_t)n, [&](int, size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const double x1 = list[4 * i + 1], x2 = list[4 * i + 2], r2 = list[4 * i + 3];
+      const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+      fixed[3 * i] = list[4 * i];
+      fixed[3 * i + 1] = f * x2;
+      fixed[3 * i + 2] = f * x1;
+    }
+  });
+}
+}  // namespace vb
+
 extern "C" {
 
 int vb_legacy_rng_create(uint32_t seed, vb_legacy_rng** out) {

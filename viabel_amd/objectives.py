@@ -225,8 +225,7 @@ class VariationalObjective(ABC):
             else:
                 eng.noise_generate(slot, end - begin, approx.dim, seed, 0, row_offset=begin, kind=kind, df=df)
         else:
-            noise = approx._base_noise(n_samples, seed)
-            eng.noise_set_host(slot, noise[begin:end])
+            approx._stage_base_noise(eng, slot, n_samples, begin, end, seed)
         return end - begin, n_samples
 
 
@@ -334,9 +333,8 @@ class ExclusiveKL(StochasticVariationalObjective):
                 if approx.rng == 'philox':
                     approx._philox_noise(eng, end - begin, None, begin, _NOISE_SLOT, _LR_SLOT)
                 else:
-                    z, eps = approx._base_noise(N)      # low-rank block first (approximations.py:639-640)
-                    eng.noise_set_host(_NOISE_SLOT, eps[begin:end])
-                    eng.noise_set_host(_LR_SLOT, z[begin:end])
+                    # low-rank block first (approximations.py:639-640)
+                    approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, None, slot_aux=_LR_SLOT)
                 if approx.k > 16:
                     # beyond the streaming kernel's register budget: the sums from GEMMs (vb_elbo_sums_lowrank), the
                     # entropy and its gradient through the k x k capacitance matrix on the host (approximations.py:559-573)
@@ -525,8 +523,8 @@ class ExclusiveKL(StochasticVariationalObjective):
                 eng.noise_generate(_NOISE_SLOT, end - begin, D, approx._seed, approx._next_philox_stream(),
                                    row_offset=begin)
             else:
-                chi, z = approx._base_noise(N)          # chi-square draws first (approximations.py:345-347)
-                eng.noise_set_host(_NOISE_SLOT, z[begin:end])
+                # chi-square draws first (approximations.py:345-347)
+                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end)
             mu, L = approx._unpack(var_param)
             Sigma = L @ L.T
             inv_s = 1.0 / np.sqrt(chi / df)
@@ -898,9 +896,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 if approx.rng == 'philox':
                     approx._philox_noise(eng, n_local, None, begin, slot, _LR_SLOT)
                 else:
-                    z, eps = approx._base_noise(N)          # low-rank block first (approximations.py:639-640)
-                    eng.noise_set_host(slot, eps[begin:end])
-                    eng.noise_set_host(_LR_SLOT, z[begin:end])
+                    # low-rank block first (approximations.py:639-640)
+                    approx._stage_base_noise(eng, slot, N, begin, end, None, slot_aux=_LR_SLOT)
                 eng.dis_set_temper_prior(self._prior_spec)
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_lowrank(
                     slot, _LR_SLOT, n_local, D, k, mu, ls, B, Minv, cq, self._prior_arg, self._eps,
@@ -992,7 +989,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                             self._set_state_weights(None, lambda: eng.dis_weights_get(N))
                             self._own_state(eng, 1, True)
                     else:
-                        eng.noise_set_host(slot, approx._base_noise(N)[begin:end])
+                        approx._stage_base_noise(eng, slot, N, begin, end)
                         root = np.ascontiguousarray(L.T)        # x = mu + eps L'
                 elif philox:
                     # throughput mode: chi-square draws and normals on the GPU, and x = mu + (z L') / s with the
@@ -1018,8 +1015,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
                         self._set_state_weights(None, lambda: eng.dis_weights_get(N))
                         self._own_state(eng, 1, True)
                 else:
-                    chi, z = approx._base_noise(N)             # chi-square draws first (approximations.py:345-347)
-                    eng.noise_set_host(slot, z[begin:end])
+                    # chi-square draws first (approximations.py:345-347)
+                    chi = approx._stage_base_noise(eng, slot, N, begin, end)
                     root, _ = _device_root(eng, L @ L.T)        # symmetric square root, :348
                 if not resident:
                     self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
@@ -1134,9 +1131,7 @@ class AlphaDivergence(StochasticVariationalObjective):
             if approx.rng == 'philox':
                 approx._philox_noise(eng, end - begin, seed, begin, _NOISE_SLOT, _LR_SLOT)
             else:
-                z, eps = approx._base_noise(N, seed)
-                eng.noise_set_host(_NOISE_SLOT, eps[begin:end])
-                eng.noise_set_host(_LR_SLOT, z[begin:end])
+                approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed, slot_aux=_LR_SLOT)
             mu, ls, B, Bs, Minv, cq, BsMinv = _lowrank_pieces(approx, var_param)
             value, S, Sgz, Set, Stt, Sg, Sge = eng.alpha_sums_lowrank(_NOISE_SLOT, _LR_SLOT, end - begin, D, k, alpha,
                                                                       mu, ls, B, Minv, cq, n_total=N)
@@ -1181,8 +1176,8 @@ class AlphaDivergence(StochasticVariationalObjective):
                 dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + w_sum
                 return value, alpha * np.concatenate([g_sum, dL[tril]]) / N          # objectives.py:460
             else:
-                chi, z = approx._base_noise(N, seed)        # chi-square draws first (approximations.py:345-347)
-                eng.noise_set_host(_NOISE_SLOT, z[begin:end])
+                # chi-square draws first (approximations.py:345-347)
+                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed)
             mu, L = approx._unpack(var_param)
             Sigma = L @ L.T
             inv_s = 1.0 / np.sqrt(chi / df)
