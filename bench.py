@@ -586,6 +586,57 @@ def fullrank_fit_leg(vb, iters=300):
     return out
 
 
+def api_call_leg(eng, vb, calls=200):
+    """The API-level call the headline leaves out: a BLOCKING
+    ``ExclusiveKL(FullRankGaussian(1024, rng=...), CorrelatedGaussianModel, 4096)(theta) -> (value, grad)`` from a host
+    parameter to a host gradient (objectives.py:32-44 as an optimiser calls it, optimization.py:95), with fresh noise per
+    call: rng='philox' (device generator) and rng='numpy' (the reference's exact RandomState stream -- generated on the
+    device since round 4, vb_legacy_rng_randn_device).  The pieces are timed separately on the same engine:
+    parameter upload (4.2 MB H2D + unpack), noise, the evaluation's kernels, gradient download (4.2 MB D2H)."""
+    d = FR_D
+    rng = np.random.RandomState(2)
+    A = rng.randn(d, d)
+    model = vb.CorrelatedGaussianModel(rng.randn(d), covariance=A @ A.T / d + np.eye(d))
+    out = {'workload': 'blocking objective(theta) -> (value, grad), FullRankGaussian(%d) + ExclusiveKL, N_mc=%d, '
+                       'host parameter in, host gradient out, fresh noise per call' % (d, N_MC)}
+    for kind, n_calls in (('philox', calls), ('numpy', max(10, calls // 4))):
+        fam = vb.FullRankGaussian(d, seed=1, rng=kind)
+        obj = vb.ExclusiveKL(fam, model, N_MC)
+        theta = fam.pack(np.zeros(d), np.exp(-1.0) * np.eye(d) + 0.01 * np.tril(np.random.RandomState(3).randn(d, d)))
+        for _ in range(3):
+            obj(theta)
+        t0 = time.perf_counter()
+        for _ in range(n_calls):
+            value, grad = obj(theta)
+        out['%s_us_per_call' % kind] = 1e6 * (time.perf_counter() - t0) / n_calls
+    from viabel_amd._legacy_rng import LegacyRandomState
+    eng.set_model(model.device_spec())
+    rs = LegacyRandomState(1)
+    pieces = (('theta_upload_us', lambda: eng.fullrank_set_theta(theta, d)),
+              ('philox_noise_us', lambda: (eng.noise_generate(0, N_MC, d, seed=1, stream=1), eng.sync())),
+              ('numpy_stream_noise_on_device_us', lambda: eng.noise_legacy_randn(0, rs._h, N_MC, d)),
+              ('evaluation_kernels_us', lambda: (eng.elbo_grad_fullrank_enqueue(0, N_MC, d), eng.sync())),
+              ('gradient_download_us', lambda: eng.fullrank_get(d)))
+    split = {}
+    for name, fn in pieces:
+        for _ in range(3):
+            fn()
+        n_rep = 20 if 'numpy' in name else calls
+        t0 = time.perf_counter()
+        for _ in range(n_rep):
+            fn()
+        split[name] = 1e6 * (time.perf_counter() - t0) / n_rep
+    out['split'] = split
+    t0 = time.perf_counter()
+    host = np.random.RandomState(1).randn(N_MC, d)
+    out['numpy_randn_on_this_host_us'] = 1e6 * (time.perf_counter() - t0)
+    out['note'] = ('the headline value is the theta-resident enqueue rate (no PCIe in the timed region); this leg is the '
+                   'same evaluation with 2 x 4.2 MB across PCIe and one synchronisation per call.  Floor without '
+                   'overlapping transfers and kernels: upload + kernels + download')
+    del host
+    return out
+
+
 def fullrank_funnel_leg(eng, vb, steps=200, ring=8, slot0=40):
     """The headline shape on a target with no closed-form shortcuts: FullRankGaussian(1024) + ExclusiveKL on the
     D-dimensional funnel, N_mc=4096 -- sampling GEMM, the funnel's row kernel (f and G per sample), the column-sum
@@ -887,7 +938,9 @@ def main():
                 'noise': 'Philox4x32-10 normals resident in HBM, 8 matrices cycled (268 MB > 256 MiB L3)',
                 'parallelism': ('mc-axis dp%d, one RCCL all-reduce of %d doubles per evaluation'
                                 % (world, 16 + FR_D + FR_D * (FR_D + 1) // 2)) if world > 1 else 'single GPU',
-                'pipelining': 'none: one evaluation per call, all calls on one HIP stream, each behind the previous one',
+                'pipelining': 'none: one evaluation per call, all calls on one HIP stream, each behind the previous one; '
+                              'theta resident on the device, results not copied out inside the timed region (the '
+                              'blocking host-to-host call is the api_call leg)',
             },
             'rccl_ranks': rccl_ranks,
             'transport': ('host-staged (VB_BENCH_TRANSPORT=host): all ranks on device 0, collectives through pinned host '
@@ -913,6 +966,7 @@ def main():
                 eng, vb, _lib, group, 512, max(args.steps, 200), args.warmup, profile=True).items()
                 if k in ('whole_evaluation', 'per_kernel', 'value', 'grad_norm')}
             out['fullrank_funnel'] = fullrank_funnel_leg(eng, vb)
+            out['api_call'] = api_call_leg(eng, vb)
             with contextlib.redirect_stderr(io.StringIO()):
                 out['fullrank_fit_loop'] = fullrank_fit_leg(vb)
             out['c1_meanfield'], theta1 = meanfield_leg(eng, vb, _lib)

@@ -242,6 +242,7 @@ int vb_destroy(vb_ctx* ctx) {
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
   if (ctx->user_host_pin) (void)hipHostFree(ctx->user_host_pin);
+  if (ctx->legacy_pin) (void)hipHostFree(ctx->legacy_pin);
   for (hipEvent_t e : ctx->mvt_pin_ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);

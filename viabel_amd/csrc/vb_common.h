@@ -220,6 +220,8 @@ struct vb_ctx {
   vb::DeviceBuffer legacy_work;
   const void* legacy_poly_at = nullptr;
   size_t legacy_poly_bytes = 0;
+  double* legacy_pin = nullptr;         // pinned staging of the device draw's results
+  size_t legacy_pin_doubles = 0;
   // fused full-rank evaluation (vb_fullrank_fused.h): ticket counter, error word and tile flags; the work list
   vb::DeviceBuffer fz_words, fz_items;
   int64_t fz_key[5] = {0, 0, 0, 0, 0};  // (n, d, splits, phases, tile_blocks) the list was built for

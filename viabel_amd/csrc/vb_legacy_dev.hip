@@ -10,8 +10,8 @@
 //   * the word stream, in parallel.  MT19937 is one linear recurrence over GF(2); the state J words ahead of a known
 //     block is the correlation of the jump polynomial x^J mod phi (vb_mt_jump.h, made and checked against numpy by
 //     tools/make_mt_jump.py) with 20 560 words generated from that block.  Streams of 256 blocks each: the known
-//     stream starts double every round (mtd_seq_kernel + mtd_corr_kernel), then one workgroup per stream runs the
-//     recurrence (mtd_stream_kernel: 227-way parallel inside a block, three barriers per block).
+//     stream starts double every round (mtd_seq_kernel + mtd_corr_kernel), then one workgroup per stream runs the recurrence
+//     (mtd_stream_kernel: 227-way parallel inside a block, the block in registers, one barrier per block).
 //   * the attempts: words -> two 53-bit doubles -> x1, x2, r2, accepted? (exact arithmetic, no fused multiply-adds:
 //     this file is compiled with -ffp-contract=off, as numpy's build of that code has none), acceptance counts per
 //     workgroup, their prefix sums, and the scatter of the accepted pairs into the slot's row-major layout.
@@ -37,10 +37,9 @@ namespace vb {
 namespace {
 
 constexpr int kN = 624, kM = 397;
-constexpr int kSeqBlocks = 33;                    // 33 x 624 = 20 592 >= 19 937 + 623 words
-constexpr int kSeqWords = kSeqBlocks * kN;
-constexpr int kCorrSlices = 16;
+constexpr int kCorrSlices = 63;                   // 63 x 320 = 20 160 >= 19 937 coefficients (the table's words beyond 623 are zero)
 constexpr int kAttemptsPerWg = 1024;              // 256 threads x 4 attempts
+constexpr int kHardPerWg = 64;                    // list segment per workgroup: ~28 expected, sigma ~5
 
 __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b) {
   const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
@@ -55,78 +54,100 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   return y;
 }
 
-// The next 624 words of the recurrence, in place in LDS, by 256 threads (key consistent on entry).  key[k] <- key[k + 397]
-// ^ mix(key[k], key[k + 1]) for k < 227 only reads old words; k in [227, 454) reads the NEW key[k - 227], which is the
-// same thread's own first result; k in [454, 623) the same thread's second result; k = 623 needs the new key[0].
-__device__ __forceinline__ void mt_refresh_lds(uint32_t* key, int t) {
-  uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, m = 0;
+// The recurrence by 256 threads, thread t < 227 owning words t, t + 227 and (t < 170) t + 454 of the block in REGISTERS:
+// key[k] <- key[k + 397] ^ mix(key[k], key[k + 1]) reads, besides the thread's own words, its right neighbour's three
+// words and one word 397 ahead -- old values, taken from an LDS copy of the block -- while the new values it needs
+// (key[k - 227] for the second and third word) are the thread's own results; the last word needs the new key[0], which
+// thread 169 recomputes from old words instead of waiting for thread 0.  New blocks go to the other half of a
+// ping-pong LDS buffer: ONE barrier per block.
+struct MtRegs {
+  uint32_t w0, w1, w2;
+};
+__device__ __forceinline__ MtRegs mt_load(const uint32_t* key, int t) {
+  MtRegs r = {0u, 0u, 0u};
+  if (t < 227) r.w0 = key[t], r.w1 = key[t + 227];
+  if (t < 170) r.w2 = key[t + 454];
+  return r;
+}
+// cur: LDS copy of the block held in `r` (complete, visible); next: the other buffer.  Returns with `next` written and
+// NOT yet synchronised: the caller's barrier comes before anybody reads it.
+__device__ __forceinline__ void mt_step(MtRegs& r, const uint32_t* cur, uint32_t* next, int t) {
   if (t < 227) {
-    a0 = key[t], a1 = key[t + 1], m = key[t + kM];
-    b0 = key[t + 227], b1 = key[t + 228];
+    const uint32_t a1 = cur[t + 1], m = cur[t + kM], b1 = cur[t + 228];
+    const uint32_t n0 = m ^ mt_mix(r.w0, a1);
+    const uint32_t n1 = n0 ^ mt_mix(r.w1, b1);
+    next[t] = n0, next[t + 227] = n1;
+    if (t < 170) {
+      uint32_t c1;
+      if (t < 169) c1 = cur[t + 455];
+      else c1 = cur[kM] ^ mt_mix(cur[0], cur[1]);      // k = 623: the NEW key[0], from old words
+      const uint32_t n2 = n1 ^ mt_mix(r.w2, c1);
+      next[t + 454] = n2;
+      r.w2 = n2;
+    }
+    r.w0 = n0, r.w1 = n1;
   }
-  if (t < 170) {
-    c0 = key[t + 454];
-    c1 = t + 455 < kN ? key[t + 455] : 0u;
-  }
-  __syncthreads();
-  uint32_t n1 = 0;
-  if (t < 227) {
-    const uint32_t n0 = m ^ mt_mix(a0, a1);
-    key[t] = n0;
-    n1 = n0 ^ mt_mix(b0, b1);
-    key[t + 227] = n1;
-  }
-  if (t < 169) key[t + 454] = n1 ^ mt_mix(c0, c1);
-  __syncthreads();
-  if (t == 169) key[kN - 1] = n1 ^ mt_mix(c0, key[0]);
-  __syncthreads();
+}
+__device__ __forceinline__ void mt_store(const MtRegs& r, uint32_t* dst, int t) {      // the block to global memory
+  if (t < 227) dst[t] = r.w0, dst[t + 227] = r.w1;
+  if (t < 170) dst[t + 454] = r.w2;
 }
 
 // words[0 .. pre) = the unread rest of the current block (untempered), state0 = the next block
 __global__ void __launch_bounds__(256) mtd_first_kernel(const uint32_t* __restrict__ key_in, int pos,
                                                         uint32_t* __restrict__ words, uint32_t* __restrict__ state0) {
-  __shared__ uint32_t key[kN];
+  __shared__ uint32_t key[2][kN];
   const int t = threadIdx.x;
-  for (int i = t; i < kN; i += 256) key[i] = key_in[i];
+  for (int i = t; i < kN; i += 256) key[0][i] = key_in[i];
   __syncthreads();
-  for (int i = pos + t; i < kN; i += 256) words[i - pos] = key[i];
-  mt_refresh_lds(key, t);
-  for (int i = t; i < kN; i += 256) state0[i] = key[i];
+  for (int i = pos + t; i < kN; i += 256) words[i - pos] = key[0][i];
+  MtRegs r = mt_load(key[0], t);
+  mt_step(r, key[0], key[1], t);
+  mt_store(r, state0, t);
 }
 
-// seq[s] = 33 consecutive blocks starting with state[s]
+// state[count + s] = the block 624 * 256 * count words behind state[s] (one round of the ladder, two kernels):
+// mtd_seq_kernel writes the 34 blocks that start with state[s] (every u[i + j], i < 20 160, j < 624) and
+// mtd_corr_kernel's workgroup (s, slice, half) XORs its 320 coefficients' share of 312 words of the correlation into the target.
+constexpr int kSeqBlocks = 34;                    // 34 x 624 = 21 216 >= 20 160 + 623 words
+constexpr int kSeqWords = kSeqBlocks * kN;
+constexpr int kSlice = 320;                       // coefficients per slice (10 words of the polynomial)
+constexpr int kWindow = kSlice + kN;              // sequence words a slice reads
 __global__ void __launch_bounds__(256) mtd_seq_kernel(const uint32_t* __restrict__ state, uint32_t* __restrict__ seq) {
-  __shared__ uint32_t key[kN];
+  __shared__ uint32_t key[2][kN];
   const int t = threadIdx.x;
   const uint32_t* src = state + (size_t)blockIdx.x * kN;
   uint32_t* dst = seq + (size_t)blockIdx.x * kSeqWords;
-  for (int i = t; i < kN; i += 256) key[i] = src[i];
+  for (int i = t; i < kN; i += 256) key[0][i] = src[i];
   __syncthreads();
+  MtRegs r = mt_load(key[0], t);
   for (int b = 0; b < kSeqBlocks; ++b) {
-    for (int i = t; i < kN; i += 256) dst[(size_t)b * kN + i] = key[i];
-    if (b + 1 < kSeqBlocks) mt_refresh_lds(key, t);
+    mt_store(r, dst + (size_t)b * kN, t);
+    if (b + 1 < kSeqBlocks) {
+      mt_step(r, key[b & 1], key[(b + 1) & 1], t);
+      __syncthreads();
+    }
   }
 }
 
-// state[count + s][j] ^= XOR over the coefficients i of this slice of seq[s][i + j]   (dst zeroed beforehand)
-__global__ void __launch_bounds__(640) mtd_corr_kernel(const uint32_t* __restrict__ poly, const uint32_t* __restrict__ seq,
+constexpr int kCorrHalf = kN / 2;                 // outputs per workgroup: blockIdx.z selects words [0, 312) or [312, 624)
+__global__ void __launch_bounds__(320) mtd_corr_kernel(const uint32_t* __restrict__ poly, const uint32_t* __restrict__ seq,
                                                        uint32_t* __restrict__ state, int count, int n_new) {
-  constexpr int kSlice = (19937 + kCorrSlices - 1) / kCorrSlices;      // 1247 coefficients
-  __shared__ uint32_t u[kSlice + kN];
-  __shared__ uint32_t g[(kSlice + 31) / 32 + 2];
-  const int s = blockIdx.x, slice = blockIdx.y, t = threadIdx.x;
+  __shared__ uint32_t u[kSlice + kCorrHalf];
+  __shared__ uint32_t g[kSlice / 32];
+  const int s = blockIdx.x, slice = blockIdx.y, j0 = blockIdx.z * kCorrHalf, tt = threadIdx.x;
   if (s >= n_new) return;
-  const int i0 = slice * kSlice, i1 = min(19937, i0 + kSlice);
-  const uint32_t* src = seq + (size_t)s * kSeqWords + i0;
-  for (int i = t; i < i1 - i0 + kN - 1; i += 640) u[i] = src[i];
-  const int w0 = i0 >> 5, nw = ((i1 + 31) >> 5) - w0;
-  for (int i = t; i < nw; i += 640) g[i] = poly[w0 + i];
+  const uint32_t* src = seq + (size_t)s * kSeqWords + slice * kSlice + j0;
+  for (int i = tt; i < kSlice + kCorrHalf; i += 320) u[i] = src[i];
+  if (tt < kSlice / 32) g[tt] = slice * (kSlice / 32) + tt < kN ? poly[slice * (kSlice / 32) + tt] : 0u;
   __syncthreads();
-  if (t >= kN) return;
+  if (tt >= kCorrHalf) return;
+  const int t = j0 + tt;
   uint32_t acc = 0;
-  for (int i = i0; i < i1; ++i) {
-    const uint32_t bit = (g[(i >> 5) - w0] >> (i & 31)) & 1u;      // uniform across the workgroup
-    if (bit) acc ^= u[i - i0 + t];
+  for (int w = 0; w < kSlice / 32; ++w) {
+    const uint32_t gw = g[w];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) acc ^= (0u - ((gw >> b) & 1u)) & u[32 * w + b + tt];
   }
   atomicXor(&state[(size_t)(count + s) * kN + t], acc);      // integer: the result does not depend on the order
 }
@@ -134,17 +155,20 @@ __global__ void __launch_bounds__(640) mtd_corr_kernel(const uint32_t* __restric
 // stream s: blocks [s B, min((s + 1) B, n_blocks)) of the stream into words[pre + block * 624 ...] (untempered)
 __global__ void __launch_bounds__(256) mtd_stream_kernel(const uint32_t* __restrict__ state, uint32_t* __restrict__ words,
                                                          int64_t pre, int64_t n_blocks) {
-  __shared__ uint32_t key[kN];
+  __shared__ uint32_t key[2][kN];
   const int t = threadIdx.x;
   const int64_t b0 = (int64_t)blockIdx.x * kMtBlocksPerStream;
   const int64_t b1 = b0 + kMtBlocksPerStream < n_blocks ? b0 + kMtBlocksPerStream : n_blocks;
   const uint32_t* src = state + (size_t)blockIdx.x * kN;
-  for (int i = t; i < kN; i += 256) key[i] = src[i];
+  for (int i = t; i < kN; i += 256) key[0][i] = src[i];
   __syncthreads();
+  MtRegs r = mt_load(key[0], t);
   for (int64_t b = b0; b < b1; ++b) {
-    uint32_t* dst = words + pre + b * kN;
-    for (int i = t; i < kN; i += 256) dst[i] = key[i];
-    if (b + 1 < b1) mt_refresh_lds(key, t);
+    mt_store(r, words + pre + b * kN, t);
+    if (b + 1 < b1) {
+      mt_step(r, key[(b - b0) & 1], key[(b - b0 + 1) & 1], t);
+      __syncthreads();
+    }
   }
 }
 
@@ -217,19 +241,19 @@ __global__ void __launch_bounds__(1024) mtd_scan_kernel(const int* __restrict__ 
 struct dd {
   double hi, lo;
 };
-__device__ __forceinline__ dd two_sum(double a, double b) {
+__host__ __device__ __forceinline__ dd two_sum(double a, double b) {
   const double s = a + b, bb = s - a;
   return {s, (a - (s - bb)) + (b - bb)};
 }
-__device__ __forceinline__ dd quick_two_sum(double a, double b) {      // |a| >= |b|
+__host__ __device__ __forceinline__ dd quick_two_sum(double a, double b) {      // |a| >= |b|
   const double s = a + b;
   return {s, b - (s - a)};
 }
-__device__ __forceinline__ dd two_prod(double a, double b) {
+__host__ __device__ __forceinline__ dd two_prod(double a, double b) {
   const double p = a * b;
   return {p, fma(a, b, -p)};
 }
-__device__ __forceinline__ dd dd_add(dd a, dd b) {
+__host__ __device__ __forceinline__ dd dd_add(dd a, dd b) {
   dd s = two_sum(a.hi, b.hi);
   const dd t = two_sum(a.lo, b.lo);
   s.lo += t.hi;
@@ -237,41 +261,41 @@ __device__ __forceinline__ dd dd_add(dd a, dd b) {
   s.lo += t.lo;
   return quick_two_sum(s.hi, s.lo);
 }
-__device__ __forceinline__ dd dd_mul(dd a, dd b) {
+__host__ __device__ __forceinline__ dd dd_mul(dd a, dd b) {
   dd p = two_prod(a.hi, b.hi);
   p.lo += a.hi * b.lo + a.lo * b.hi;
   return quick_two_sum(p.hi, p.lo);
 }
-__device__ __forceinline__ dd dd_div(dd a, dd b) {      // three quotient digits
-  const double q1 = a.hi / b.hi;
-  dd r = dd_add(a, dd_mul(b, dd{-q1, 0.0}));
-  const double q2 = r.hi / b.hi;
-  r = dd_add(r, dd_mul(b, dd{-q2, 0.0}));
-  const double q3 = r.hi / b.hi;
-  dd q = quick_two_sum(q1, q2);
-  return dd_add(q, dd{q3, 0.0});
-}
 
-__constant__ double kLogCoefHi[24];      // 1 / (2 k + 1) as a double-double, filled once by the host
-__constant__ double kLogCoefLo[24];
+// log c for c = k / 32, k = 23 .. 45, as double-doubles (filled once by the host from the same series, 2^-100)
+__constant__ double kLogTabHi[23];
+__constant__ double kLogTabLo[23];
+
+// log x for 0 < x < 1 as a double-double with relative error < 2^-66 (6e-5 ulp of the rounded result): x = m 2^e with m in
+// [0.7071, 1.4142); c = the nearest multiple of 1/32, so that s = (m - c) / (m + c) has |s| <= 0.0112 and
+// log m = log c + 2 atanh(s) = log c + 2 s (1 + s^2 / 3 + s^4 / 5 + ...): s in double-double (the quotient's remainder
+// through one fma), the bracket's tail -- below 2^-14 -- in plain double.
+__host__ __device__ __forceinline__ dd dd_log_core(double m, int e, double c, dd logc) {
+  const double num = m - c;                      // exact (Sterbenz: c / 2 <= m <= 2 c)
+  const dd den = two_sum(m, c);
+  const double q1 = num / den.hi;
+  const double rem = fma(-q1, den.hi, num) - q1 * den.lo;      // num - q1 den, to double accuracy
+  const double q2 = rem / den.hi;
+  const dd s = quick_two_sum(q1, q2);
+  const double z = s.hi * s.hi;
+  const double tail = z * (1.0 / 3.0 + z * (1.0 / 5.0 + z * (1.0 / 7.0 + z * (1.0 / 9.0 + z * (1.0 / 11.0 + z * (1.0 / 13.0))))));
+  dd lm = dd_add(s, dd_mul(s, dd{tail, 0.0}));
+  lm.hi *= 2.0, lm.lo *= 2.0;
+  const dd ln2 = {0x1.62e42fefa39efp-1, 0x1.abc9e3b39803fp-56};
+  return dd_add(dd_add(dd_mul(ln2, dd{(double)e, 0.0}), logc), lm);
+}
 
 __device__ __forceinline__ dd dd_log(double x) {
   int e;
   double m = frexp(x, &e);                      // x = m 2^e, m in [0.5, 1)
   if (m < 0.70710678118654752440) m *= 2.0, e -= 1;      // m in [0.7071, 1.4142)
-  // log m = 2 atanh(s), s = (m - 1) / (m + 1): |s| <= 0.1716, s^2 <= 0.0295, 22 terms reach 2^-112
-  const dd num = {m - 1.0, 0.0};                // exact (Sterbenz)
-  const dd den = two_sum(m, 1.0);
-  const dd s = dd_div(num, den);
-  const dd s2 = dd_mul(s, s);
-  dd p = {kLogCoefHi[22], kLogCoefLo[22]};
-#pragma unroll
-  for (int k = 21; k >= 0; --k) p = dd_add(dd_mul(p, s2), dd{kLogCoefHi[k], kLogCoefLo[k]});
-  dd lm = dd_mul(s, p);
-  lm.hi *= 2.0, lm.lo *= 2.0;
-  const dd ln2 = {0x1.62e42fefa39efp-1, 0x1.abc9e3b39803fp-56};
-  const dd el = dd_mul(ln2, dd{(double)e, 0.0});
-  return dd_add(el, lm);
+  const int k = (int)rint(32.0 * m);            // 23 .. 45
+  return dd_log_core(m, e, (double)k * 0.03125, dd{kLogTabHi[k - 23], kLogTabLo[k - 23]});
 }
 
 struct EmitArgs {
@@ -281,9 +305,8 @@ struct EmitArgs {
   int64_t pairs, n_vals, first;   // pairs wanted; values wanted (after the cached one); index of the first value (0 / 1)
   int64_t d, row_begin, rows, ld;
   double* slot;
-  double* hard;                   // [cap][4]: q, x1, x2, r2 of attempts the host finishes
-  int64_t hard_cap;
-  unsigned long long* hard_n;
+  double* hard_seg;               // [n_wg][kHardPerWg][4]: q, x1, x2, r2 of attempts the host finishes, per workgroup
+  int* hard_cnt;                  // [n_wg]: entries of each segment (may exceed kHardPerWg: overflow, the host falls back)
   int64_t* a_star;                // attempt that produced the last pair
   double* last_x1f;               // its f x1 (the value numpy caches when the count is odd)
 };
@@ -295,6 +318,8 @@ __device__ __forceinline__ void put_value(const EmitArgs& a, int64_t o, double v
 
 __global__ void __launch_bounds__(256) mtd_emit_kernel(const EmitArgs a) {
   __shared__ int wave_cnt[4];
+  __shared__ int hard_fill;
+  if (threadIdx.x == 0) hard_fill = 0;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int64_t i0 = (int64_t)blockIdx.x * kAttemptsPerWg + 4 * t;
   Attempt at[4];
@@ -327,15 +352,19 @@ __global__ void __launch_bounds__(256) mtd_emit_kernel(const EmitArgs a) {
       double v0 = f * x2, v1 = f * x1;
       const double ulp = ldexp(1.0, ilogb(L.hi) - 52);
       bool hard = false;
-      if (fabs(L.lo) > 0.47 * ulp) {
+      // (L.hi a power of two: the spacing below it is half of `ulp`, the test would look at the wrong boundary -- a
+      // one-in-2^52 event, simply handed to the host)
+      int e_hi;
+      const bool pow2 = frexp(L.hi, &e_hi) == -0.5;
+      if (fabs(L.lo) > 0.47 * ulp || pow2) {
         const double alt = L.lo > 0.0 ? nextafter(L.hi, INFINITY) : nextafter(L.hi, -INFINITY);
         const double f2 = sqrt(-2.0 * alt / r2);
-        hard = (f2 * x2 != v0) || (f2 * x1 != v1);
+        hard = (f2 * x2 != v0) || (f2 * x1 != v1) || pow2;
       }
       if (hard) {
-        const unsigned long long h = atomicAdd(a.hard_n, 1ull);
-        if ((int64_t)h < a.hard_cap) {
-          double* o = a.hard + 4 * h;
+        const int h = atomicAdd(&hard_fill, 1);      // LDS: the order inside a segment is arbitrary, its content is not
+        if (h < kHardPerWg) {
+          double* o = a.hard_seg + 4 * ((int64_t)blockIdx.x * kHardPerWg + h);
           o[0] = (double)q, o[1] = x1, o[2] = x2, o[3] = r2;
         }
       } else {
@@ -349,6 +378,22 @@ __global__ void __launch_bounds__(256) mtd_emit_kernel(const EmitArgs a) {
       }
     }
     ++q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.hard_cnt[blockIdx.x] = hard_fill;
+}
+
+// the segments, one behind the other: list[hbase[wg] + i] = segment wg's entry i
+__global__ void __launch_bounds__(64) mtd_compact_kernel(const double* __restrict__ seg, const int* __restrict__ cnt,
+                                                         const int64_t* __restrict__ hbase, double* __restrict__ list,
+                                                         int64_t* __restrict__ overflow) {
+  const int n = min(cnt[blockIdx.x], kHardPerWg);
+  const int t = threadIdx.x;
+  if (t == 0 && cnt[blockIdx.x] > kHardPerWg) overflow[0] = 1;
+  if (t < n) {
+    const double* src = seg + 4 * ((int64_t)blockIdx.x * kHardPerWg + t);
+    double* dst = list + 4 * (hbase[blockIdx.x] + t);
+    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
   }
 }
 
@@ -371,17 +416,28 @@ __global__ void mtd_first_value_kernel(const EmitArgs a, double v) { put_value(a
 int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, double* gauss, const NoiseSlot& ns,
                      int64_t n_total, int64_t d, int64_t row_begin, int64_t rows) {
   hipStream_t st = ctx->stream;
-  static bool coef_ready = false;
-  if (!coef_ready) {
-    double hi[24], lo[24];
-    for (int k = 0; k < 24; ++k) {
-      const double n = 2.0 * k + 1.0;
-      hi[k] = 1.0 / n;
-      lo[k] = std::fma(-hi[k], n, 1.0) / n;      // the exact remainder of the division, divided once more
+  static bool table_ready = false;
+  if (!table_ready) {
+    // log(k / 32) in double-double by the long series on the host: 2 atanh(s), s = (c - 1) / (c + 1), |s| <= 0.17,
+    // 40 terms (s^2 <= 0.03: 2^-200), every operation in double-double
+    double hi[23], lo[23];
+    for (int k = 23; k <= 45; ++k) {
+      const double c = k * 0.03125;
+      const dd num = {c - 1.0, 0.0}, den = two_sum(c, 1.0);
+      const double q1 = num.hi / den.hi;
+      const double q2 = (std::fma(-q1, den.hi, num.hi) - q1 * den.lo) / den.hi;
+      const dd sv = quick_two_sum(q1, q2), z = dd_mul(sv, sv);
+      dd p = {0.0, 0.0};
+      for (int j = 40; j >= 0; --j) {
+        const double n = 2.0 * j + 1.0, ch = 1.0 / n, cl = std::fma(-ch, n, 1.0) / n;
+        p = dd_add(dd_mul(p, z), dd{ch, cl});
+      }
+      dd l = dd_mul(sv, p);
+      hi[k - 23] = 2.0 * l.hi, lo[k - 23] = 2.0 * l.lo;
     }
-    VB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(kLogCoefHi), hi, sizeof hi));
-    VB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(kLogCoefLo), lo, sizeof lo));
-    coef_ready = true;
+    VB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(kLogTabHi), hi, sizeof hi));
+    VB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(kLogTabLo), lo, sizeof lo));
+    table_ready = true;
   }
   const int64_t total = n_total * d;
   const int64_t first = (*has_gauss && total > 0) ? 1 : 0;
@@ -413,6 +469,7 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
                o_words = carve((size_t)(pre + n_blocks * kN) + 8), o_state = carve((size_t)pow2 * kN),
                o_seq = carve((size_t)(pow2 / 2 > 0 ? pow2 / 2 : 1) * kSeqWords), o_cnt = carve((size_t)n_wg),
                o_base = carve(2 * (size_t)(n_wg + 1)), o_hard = carve(2 * 4 * (size_t)hard_cap),
+               o_hseg = carve(2 * 4 * (size_t)n_wg * kHardPerWg), o_hcnt = carve((size_t)n_wg), o_hbase = carve(2 * (size_t)(n_wg + 1)),
                o_fixed = carve(2 * 3 * (size_t)hard_cap);
   VB_TRY(ensure(ctx, ctx->legacy_work, off * sizeof(uint32_t)));
   uint32_t* base = (uint32_t*)ctx->legacy_work.ptr;
@@ -430,7 +487,7 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
   for (int64_t count = 1; count < streams; count <<= 1, ++k) {
     const int n_new = (int)std::min<int64_t>(count, streams - count);
     hipLaunchKernelGGL(mtd_seq_kernel, dim3((unsigned)n_new), dim3(256), 0, st, (const uint32_t*)state, seq);
-    hipLaunchKernelGGL(mtd_corr_kernel, dim3((unsigned)n_new, kCorrSlices), dim3(640), 0, st,
+    hipLaunchKernelGGL(mtd_corr_kernel, dim3((unsigned)n_new, kCorrSlices, 2), dim3(320), 0, st,
                        (const uint32_t*)(poly + (size_t)k * kN), (const uint32_t*)seq, state, (int)count, n_new);
   }
   hipLaunchKernelGGL(mtd_stream_kernel, dim3((unsigned)streams), dim3(256), 0, st, (const uint32_t*)state, words, pre, n_blocks);
@@ -443,50 +500,73 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
   a.pairs = pairs, a.n_vals = n_vals, a.first = first;
   a.d = d, a.row_begin = row_begin, a.rows = rows, a.ld = ns.ld;
   a.slot = (double*)ns.buf.ptr;
-  a.hard = (double*)(base + o_hard), a.hard_cap = hard_cap;
-  int64_t* scal = (int64_t*)(base + o_scal);      // [0] a*, [1] last pair on the list?, [2] hard count, [3] f x1 of the last pair
-  a.hard_n = (unsigned long long*)(scal + 2);
+  a.hard_seg = (double*)(base + o_hseg), a.hard_cnt = (int*)(base + o_hcnt);
+  double* hard_list = (double*)(base + o_hard);
+  int64_t* hbase = (int64_t*)(base + o_hbase);
+  int64_t* scal = (int64_t*)(base + o_scal);      // [0] a*, [1] last pair on the list?, [3] f x1 of the last pair
   a.a_star = scal;
   a.last_x1f = (double*)(scal + 3);
   if (first) hipLaunchKernelGGL(mtd_first_value_kernel, dim3(1), dim3(1), 0, st, a, *gauss);
   hipLaunchKernelGGL(mtd_emit_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(mtd_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)a.hard_cnt, n_wg, hbase);
+  hipLaunchKernelGGL(mtd_compact_kernel, dim3((unsigned)n_wg), dim3(64), 0, st, (const double*)a.hard_seg,
+                     (const int*)a.hard_cnt, (const int64_t*)hbase, hard_list, scal + 4);
   VB_HIP(ctx, hipGetLastError());
-  int64_t res[4];
-  int64_t accepted = 0;
-  VB_HIP(ctx, hipMemcpyAsync(res, scal, sizeof res, hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(&accepted, pbase + n_wg, sizeof accepted, hipMemcpyDeviceToHost, st));
+  // results through one pinned buffer: [scalars 4 | accepted | list (first `spec` entries, speculatively) | fixed | key]
+  const int64_t spec = std::min<int64_t>(hard_cap, pairs / 20 + 256);      // ~1.7 x the expected list length
+  const size_t pin_doubles = 8 + (size_t)4 * hard_cap + (size_t)3 * hard_cap + kN / 2 + 8;
+  if (ctx->legacy_pin_doubles < pin_doubles) {
+    if (ctx->legacy_pin) VB_HIP(ctx, hipHostFree(ctx->legacy_pin));
+    ctx->legacy_pin = nullptr;
+    VB_HIP(ctx, hipHostMalloc((void**)&ctx->legacy_pin, pin_doubles * sizeof(double), hipHostMallocDefault));
+    ctx->legacy_pin_doubles = pin_doubles;
+  }
+  int64_t* res = (int64_t*)ctx->legacy_pin;                 // [0] a*, [1] last pair listed?, [2] list length, [3] f x1 bits
+  int64_t* accepted = res + 4;
+  double* list = ctx->legacy_pin + 8;
+  double* fixed = list + 4 * hard_cap;
+  uint32_t* key_pin = (uint32_t*)(fixed + 3 * hard_cap);
+  VB_HIP(ctx, hipMemcpyAsync(res, scal, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(res + 2, hbase + n_wg, sizeof(int64_t), hipMemcpyDeviceToHost, st));      // list length
+  VB_HIP(ctx, hipMemcpyAsync(res + 5, scal + 4, sizeof(int64_t), hipMemcpyDeviceToHost, st));          // segment overflow?
+  VB_HIP(ctx, hipMemcpyAsync(accepted, pbase + n_wg, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipMemcpyAsync(list, hard_list, (size_t)4 * spec * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
   const int64_t n_hard = res[2];
-  if (accepted < pairs || n_hard > hard_cap) return VB_ERR_UNSUPPORTED;      // (budget or list fell short: host path)
+  // (budget, list or a workgroup's segment fell short: host path)
+  if (*accepted < pairs || n_hard > hard_cap || res[5] != 0) return VB_ERR_UNSUPPORTED;
   double last_x1f;
   memcpy(&last_x1f, &res[3], sizeof last_x1f);
+  // where the generator stands afterwards: just behind the last consumed attempt
+  const int64_t w_star = 4 * (res[0] + 1);
+  int64_t key_block = -1;      // block (counted from the first refreshed one) whose words become numpy's key; -1: unchanged
+  int new_pos = 0;
+  if (w_star <= pre) {
+    new_pos = (int)(*pos + w_star);               // still inside the block the call started in
+  } else {
+    const int64_t offw = w_star - pre;
+    key_block = offw / kN;
+    new_pos = (int)(offw % kN);
+    if (new_pos == 0) key_block -= 1, new_pos = kN;      // exactly at a block end: numpy refreshes lazily
+    if (key_block < 0) return fail(ctx, VB_ERR_STATE, "legacy generator: inconsistent end position");
+    VB_HIP(ctx, hipMemcpyAsync(key_pin, words + pre + key_block * kN, kN * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  }
+  if (n_hard > spec)
+    VB_HIP(ctx, hipMemcpyAsync(list + 4 * spec, hard_list + 4 * spec, (size_t)4 * (n_hard - spec) * sizeof(double),
+                               hipMemcpyDeviceToHost, st));
+  if (n_hard > spec) VB_HIP(ctx, hipStreamSynchronize(st));
   if (n_hard > 0) {
-    std::vector<double> list((size_t)4 * n_hard), fixed((size_t)3 * n_hard);
-    VB_HIP(ctx, hipMemcpy(list.data(), a.hard, list.size() * sizeof(double), hipMemcpyDeviceToHost));
-    vb_legacy_finish_pairs(list.data(), n_hard, fixed.data());
+    vb_legacy_finish_pairs(list, n_hard, fixed);
     for (int64_t i = 0; i < n_hard; ++i)
       if ((int64_t)fixed[3 * i] == pairs - 1) last_x1f = fixed[3 * i + 2];
     double* fixed_dev = (double*)(base + o_fixed);
-    VB_HIP(ctx, hipMemcpyAsync(fixed_dev, fixed.data(), fixed.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    VB_HIP(ctx, hipMemcpyAsync(fixed_dev, fixed, (size_t)3 * n_hard * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(mtd_patch_kernel, dim3((unsigned)((n_hard + 255) / 256)), dim3(256), 0, st, a,
                        (const double*)fixed_dev, n_hard);
-    VB_HIP(ctx, hipStreamSynchronize(st));      // `fixed` is stack-scoped
   }
-  // numpy's state: just behind the last consumed attempt
-  const int64_t w_star = 4 * (res[0] + 1);
-  if (w_star <= pre) {
-    *pos = (int)(*pos + w_star);                  // still inside the block the call started in
-  } else {
-    const int64_t offw = w_star - pre;            // words consumed from block 1 onward (blocks counted from 0 here)
-    int64_t blk = offw / kN;
-    int p = (int)(offw % kN);
-    if (p == 0) blk -= 1, p = kN;                 // exactly at a block end: numpy refreshes lazily
-    if (blk < 0) {                                // (pre == 0 and nothing of block 1 consumed: cannot happen, w_star >= 4)
-      return fail(ctx, VB_ERR_STATE, "legacy generator: inconsistent end position");
-    }
-    VB_HIP(ctx, hipMemcpy(key, words + pre + blk * kN, kN * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    *pos = p;
-  }
+  VB_HIP(ctx, hipStreamSynchronize(st));          // the patch has read the pinned list; the key block has arrived
+  if (key_block >= 0) memcpy(key, key_pin, kN * sizeof(uint32_t));
+  *pos = new_pos;
   *has_gauss = (n_vals & 1) ? 1 : 0;
   *gauss = (n_vals & 1) ? last_x1f : 0.0;
   return VB_OK;
