@@ -487,18 +487,25 @@ def alpha_leg(vb, calls=30):
             theta = approx.init_param()
             if isinstance(approx, vb.MFGaussian):
                 theta[D:] = -1.0
-        obj = vb.AlphaDivergence(approx, model, n, 0.5)
-        np.random.seed(1)
-        for _ in range(10):
-            obj(theta)
-        blocks = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            for _ in range(calls):
-                v, g = obj(theta)
-            blocks.append((time.perf_counter() - t0) / calls)
-        out[name] = {'us_per_call': 1e6 * statistics.median(blocks), 'value': float(v),
-                     'grad_norm': float(np.linalg.norm(g))}
+        res = {}
+        # the same blocking call for ExclusiveKL on the same family / target / shape: the like-for-like reference (both
+        # carry the parameter up and the gradient down and draw fresh noise)
+        for key, obj in (('us_per_call', vb.AlphaDivergence(approx, model, n, 0.5)),
+                         ('exclusive_kl_same_call_us', vb.ExclusiveKL(approx, model, n))):
+            np.random.seed(1)
+            for _ in range(10):
+                obj(theta)
+            blocks = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(calls):
+                    v, g = obj(theta)
+                blocks.append((time.perf_counter() - t0) / calls)
+            res[key] = 1e6 * statistics.median(blocks)
+            if key == 'us_per_call':
+                res['value'], res['grad_norm'] = float(v), float(np.linalg.norm(g))
+        res['ratio_to_exclusive_kl'] = res['us_per_call'] / res['exclusive_kl_same_call_us']
+        out[name] = res
     return out
 
 

@@ -229,6 +229,12 @@ int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int famil
  * gradient convention as vb_alpha_grad_meanfield; grad has d + d (d + 1) / 2 entries. */
 int vb_alpha_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, const double* theta,
                            double alpha, double* value, double* grad);
+/* The same for the multivariate t in throughput mode (objectives.py:443-463 over approximations.py:322-382): samples
+ * x = mu + (L z) / s through the Cholesky factor with the device's normals (slot) and chi-square draws
+ * (vb_chisq_generate), weights, value and the gradient in the flat free-Cholesky layout -- tril(sum_n w_n g_n (z_n /
+ * s_n)') with sum w on the log-diagonal -- all on the device: no matrix root, no D x D array on the host. */
+int vb_alpha_grad_mvt_chol(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
+                           double alpha, double* value, double* grad);
 
 /* ---- DISInclusiveKL, MultivariateT family (approximations.py:322-382) -------------------
  * theta = [mu | free Cholesky of Sigma].  The O(D^3) factor algebra stays with the caller, as in the

@@ -93,6 +93,8 @@ SIGNATURES = {
                                    _c_double_p]),
     'vb_alpha_grad_fullrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                               _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
+    'vb_alpha_grad_mvt_chol': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_double, _c_double_p, ctypes.c_double, _c_double_p, _c_double_p]),
     'vb_sym_sqrt_inv': (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p,
                                        _c_double_p, _c_double_p]),
     'vb_lowrank_path_terms': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
@@ -716,6 +718,16 @@ class Engine:
         x = np.empty((d, d), dtype=np.float64)
         self._check(self._lib.vb_sym_sqrt(self._ctx, _dptr(a), _dptr(e), d, _dptr(root), _dptr(x), _dptr(info)))
         return root, x, info
+
+    def alpha_grad_mvt_chol(self, slot, n, d, df, theta, alpha, n_total=None):
+        """AlphaDivergence of the multivariate t in throughput mode (Cholesky sampling, device chi-square draws): value
+        and the gradient in the flat layout, nothing of order D^2 on the host."""
+        theta = _f64(theta)
+        value = ctypes.c_double(0.0)
+        grad = np.empty(d + d * (d + 1) // 2, dtype=np.float64)
+        self._check(self._lib.vb_alpha_grad_mvt_chol(self._ctx, slot, n, d, n if n_total is None else n_total, float(df),
+                                                     _dptr(theta), float(alpha), ctypes.byref(value), _dptr(grad)))
+        return value.value, grad
 
     def alpha_grad_fullrank(self, slot, n, d, theta, alpha, n_total=None):
         theta = _f64(theta)

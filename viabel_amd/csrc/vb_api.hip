@@ -238,7 +238,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items, &ctx->legacy_work})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items, &ctx->legacy_work, &ctx->alpha_g})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
   if (ctx->user_host_pin) (void)hipHostFree(ctx->user_host_pin);
@@ -803,6 +803,24 @@ int vb_alpha_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t 
   double sum_log_diag = 0.0;
   for (int64_t i = 0; i < d; ++i) sum_log_diag += theta[d + i * (i + 1) / 2 + i];   // free diagonal = log L_ii
   VB_TRY(alpha_fullrank_enqueue(ctx, ctx->noise[slot], n, n_total, d, alpha, (const double*)ctx->fr_theta.ptr,
+                                sum_log_diag, (double*)ctx->fr_out.ptr));
+  return vb_fullrank_get(ctx, value, grad, d + d * (d + 1) / 2);
+}
+
+int vb_alpha_grad_mvt_chol(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
+                           double alpha, double* value, double* grad) {
+  if (!ctx || !theta || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
+  if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  if (ctx->chi_n != n || ctx->chi_df != df || !ctx->chi_dev.ptr)
+    return fail(ctx, VB_ERR_STATE, "needs %lld device chi-square(%g) draws (vb_chisq_generate)", (long long)n, df);
+  VB_TRY(vb_fullrank_set_theta(ctx, theta, d));
+  double sum_log_diag = 0.0;
+  for (int64_t i = 0; i < d; ++i) sum_log_diag += theta[d + i * (i + 1) / 2 + i];   // free diagonal = log L_ii
+  VB_TRY(mvt_alpha_chol_enqueue(ctx, ctx->noise[slot], n, d, n_total, df, alpha, (const double*)ctx->fr_theta.ptr,
                                 sum_log_diag, (double*)ctx->fr_out.ptr));
   return vb_fullrank_get(ctx, value, grad, d + d * (d + 1) / 2);
 }

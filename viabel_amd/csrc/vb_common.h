@@ -217,6 +217,7 @@ struct vb_ctx {
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
   // numpy's legacy normal stream on the device (vb_legacy_dev.hip): scratch; where the jump polynomials were uploaded
+  vb::DeviceBuffer alpha_g;             // AlphaDivergence, correlated-Gaussian target: G of the samples (see FrWeighted::g_ready)
   vb::DeviceBuffer legacy_work;
   const void* legacy_poly_at = nullptr;
   size_t legacy_poly_bytes = 0;
@@ -341,11 +342,14 @@ int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int
 int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, const double* mu_host,
                   const double* root_host, const double* inv_s_host, double* f_sum, double* g_sum, double* c_full);
 
+int mvt_alpha_chol_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
+                           const double* theta_dev, double sum_log_diag, double* out_dev);
 int mvt_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
                    const double* mu_host, const double* root_host, const double* inv_s_host, double sum_log_diag,
                    double* value, double* w_sum, double* g_sum, double* c_full);
 int alpha_fullrank_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double alpha,
-                           const double* theta_dev, double sum_log_diag, double* out);
+                           const double* theta_dev, double sum_log_diag, double* out, double df = 0.0,
+                           const double* inv_s = nullptr);
 
 // vb_lowrank.hip
 int lr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
@@ -375,6 +379,9 @@ struct FrWeighted {
   // round_up(d, 16); the alpha-divergence weights needed them): the pipeline does not repeat the sampling product for
   // the targets that read plain samples (funnel, regression, source models)
   const double* z_ready = nullptr;
+  // ... and, for the correlated-Gaussian target, the model's gradient rows G of those samples (the weights needed f,
+  // which costs the same N x D x D product): the pipeline then skips its sampling and model products
+  const double* g_ready = nullptr;
 };
 int fr_sample_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_dev, double* Z,
                       const double* mu_dev = nullptr, const double* root_dev = nullptr,

@@ -234,9 +234,10 @@ namespace vb {
 
 // ---- funnel: row kernel Z -> G, f ---------------------------------------------------------------
 // one wave per row; G[n][j] = -z_j w (j != k), G[n][k] = -v/tau^2 - (D-1) + w sum_{j != k} z_j^2
+// roww != nullptr: the rows of G leave scaled by the sample's weight (AlphaDivergence: no separate pass over G)
 __global__ void __launch_bounds__(256) fr_funnel_kernel(const double* __restrict__ Z, double* __restrict__ G,
                                                         int64_t ldz, int64_t n, int d, ModelDev m,
-                                                        double* __restrict__ fpart) {
+                                                        double* __restrict__ fpart, const double* __restrict__ roww) {
   __shared__ double sh[4];
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -246,17 +247,20 @@ __global__ void __launch_bounds__(256) fr_funnel_kernel(const double* __restrict
     double* g = G + row * ldz;
     const double v = z[m.k];
     const double w = exp(-2.0 * v);
+    const double rw = roww ? roww[row] : 1.0;
     double ss = 0.0;
     for (int c = lane; c < d; c += 64) {
       if (c == m.k) continue;
       const double zc = z[c];
-      g[c] = -zc * w;
+      const double gc = -zc * w;
+      g[c] = roww ? gc * rw : gc;
       ss = fma(zc, zc, ss);
     }
     ss = fr_wave_sum(ss);
     if (lane == 0) {
       const double it2 = 1.0 / (m.tau * m.tau), dm1 = (double)(d - 1);
-      g[m.k] = fma(-v, it2, -dm1) + w * ss;
+      const double gk = fma(-v, it2, -dm1) + w * ss;
+      g[m.k] = roww ? gk * rw : gk;
       f = v * fma(-0.5 * v, it2, -dm1) - 0.5 * w * ss;
     }
   }
@@ -1334,6 +1338,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     }
   };
   unsigned tiles2 = 0;
+  bool g_prescaled = false;      // the target's own kernel wrote G already scaled by the row weights
   // diagonal Gaussian target under the dense Gaussian family: sum f out of the sampling product's epilogue
   const bool diag_f = fast_env && !mvt && m.id == VB_MODEL_GAUSS_DIAG && !wm.roww && !row_scale && !pd &&
                       n % kGemmBK == 0 && gemm_uses_dma(g1) && (int64_t)splits <= n_rb;
@@ -1347,7 +1352,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     sample_gemm(nullptr, 0);
     VB_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(fr_funnel_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)Z,
-                       G, ldz, n, D, m, fpart);
+                       G, ldz, n, D, m, fpart, wm.roww);
+    g_prescaled = wm.roww != nullptr;
   } else if (source) {        // the user's row kernel: G and one f per sample (summed with the other f partials)
     sample_gemm(nullptr, 0);
     VB_HIP(ctx, hipGetLastError());
@@ -1381,7 +1387,9 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     g2.N = D;
     g2.K = D;
     g2.tri_mode = 0;
-    if (fz_mode >= 2) {
+    if (wm.g_ready) {
+      G = const_cast<double*>(wm.g_ready);      // (the caller's G of these very samples: see FrWeighted)
+    } else if (fz_mode >= 2) {
       // one persistent launch for Z - m and G (and, fz_mode 3, the split slabs of C): vb_fullrank_fused.h
       EpiSplitSlabCs e3{Cpart, ldl, slab, colpart, ldz};
       GemmArgs g3f;
@@ -1393,7 +1401,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     sample_gemm(m.p0, cfg1);                         // Z - m
     VB_HIP(ctx, hipGetLastError());
     }
-    if (fz_mode >= 2) {
+    if (fz_mode >= 2 || wm.g_ready) {
     } else if (kparts > 1 && fused_sums) {
       gemm_f64_launch<true>(st, g2, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
       hipLaunchKernelGGL(fr_gsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,
@@ -1404,7 +1412,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
       if (fused_sums) tiles2 = gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegateF{G, ldz, Z, fpart}, cfg2);
       else gemm_f64_launch<true>(st, g2, 1, n_cu, EpiNegate{G, ldz}, cfg2);
     }
-    fmode = 2;
+    fmode = wm.g_ready ? 0 : 2;      // (weighted sums take their value from the weights: no f here)
   }
   VB_HIP(ctx, hipGetLastError());
 
@@ -1414,7 +1422,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
     if (idle_us > 0) hipLaunchKernelGGL(dbg_idle_kernel, dim3(1), dim3(64), 0, st, (long long)idle_us * 100);
   }
 #endif
-  if (wm.roww) {   // weighted sums: scale the rows of G before anything is summed
+  if (wm.roww && !g_prescaled) {   // weighted sums: scale the rows of G before anything is summed
     hipLaunchKernelGGL(fr_rowscale_kernel, dim3((unsigned)n, (unsigned)((D + 255) / 256)), dim3(256), 0, st, G, ldz, n,
                        D, wm.roww);
     VB_HIP(ctx, hipGetLastError());
@@ -1431,7 +1439,9 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   g3.tri_mode = mvt ? 0 : 2;
   // targets whose row kernel leaves sum f behind already (funnel, source models): the column sums of G are all the pass
   // below would add, and they come out of the gradient product's LDS tiles as for the correlated Gaussian
-  const bool cs_only = diag_f || (fast_env && !fused_sums && !mvt && (m.id == VB_MODEL_FUNNEL || source) && !wm.roww &&
+  // (weighted sums: the same, once G is scaled -- the column sums of the gradient product's operand tiles ARE sum w g)
+  const bool cs_only = diag_f || (fast_env && !fused_sums && !mvt && (m.id == VB_MODEL_FUNNEL || source) &&
+                                 (!wm.roww || g_prescaled) &&
                                  !row_scale && !pd && n % kGemmBK == 0 && gemm_uses_dma(g3) && (int64_t)splits <= n_rb);
   if (!fused_sums && !cs_only) {
     hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
@@ -1537,7 +1547,7 @@ int fr_sample_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, co
                        Lt, mu);
     g1.B = Lt;
     g1.tri_mode = 1;
-    gemm_f64_launch<true>(st, g1, 1, ctx->prop.multiProcessorCount, EpiStoreZ{Z, ldz, mu, nullptr, nullptr});
+    gemm_f64_launch<true>(st, g1, 1, ctx->prop.multiProcessorCount, EpiStoreZ{Z, ldz, mu, nullptr, row_scale});
   } else {
     g1.B = root_dev;
     g1.tri_mode = 0;

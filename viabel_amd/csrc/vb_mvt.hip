@@ -1163,4 +1163,16 @@ int mvt_elbo_chol_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d
                              nullptr, 0, nullptr);
 }
 
+// AlphaDivergence, throughput mode: the dense family's weighted pipeline with the rows scaled by 1 / s_n and the t
+// family's base density (alpha_fullrank_enqueue) -- weights, value and the gradient in the flat layout on the device
+int mvt_alpha_chol_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
+                           const double* theta_dev, double sum_log_diag, double* out_dev) {
+  VB_TRY(ensure(ctx, ctx->mvt_invs, (size_t)n * sizeof(double)));
+  hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const double*)ctx->chi_dev.ptr, df, n, (double*)ctx->mvt_invs.ptr);
+  VB_HIP(ctx, hipGetLastError());
+  return alpha_fullrank_enqueue(ctx, ns, n, n_total, d, alpha, theta_dev, sum_log_diag, out_dev, df,
+                                (const double*)ctx->mvt_invs.ptr);
+}
+
 }  // namespace vb

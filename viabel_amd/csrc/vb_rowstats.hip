@@ -259,11 +259,81 @@ __global__ void __launch_bounds__(256) rs_normal_base_kernel(const double* __res
   if (lane == 0) b[row] = -0.5 * s - 0.5 * d * 1.8378770664093454835606594728112;
 }
 
+__global__ void rs_set_scalar_kernel(double* dst, double v) { dst[0] = v; }
+__global__ void rs_mvt_base_kernel(const double* __restrict__ E, int64_t ld, int64_t n, int d, double df, double lconst,
+                                   const double* __restrict__ inv_s, double* __restrict__ b);
+
+// objectives.py:453-459 in ONE workgroup when no communicator sits between the steps: max, weights and their sum, value
+__global__ void __launch_bounds__(1024) alpha_one_rank_kernel(const double* __restrict__ f, const double* __restrict__ b,
+                                                              const double* __restrict__ scal_in, int64_t n, double alpha,
+                                                              double n_total, double* __restrict__ roww,
+                                                              double* __restrict__ out /* [max, sum s, value] */) {
+  __shared__ double sh[16];
+  __shared__ double bc;
+  const double sum_ls = scal_in[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) mx = fmax(mx, f[i] - b[i] + sum_ls);
+  mx = rs_wave_max(mx);
+  if (lane == 0) sh[wave] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m2 = sh[0];
+    for (int w = 1; w < 16; ++w) m2 = fmax(m2, sh[w]);
+    bc = m2;
+  }
+  __syncthreads();
+  mx = bc;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double sv = exp(alpha * (f[i] - b[i] + sum_ls - mx));
+    roww[i] = sv;
+    s += sv;
+  }
+  s = rs_wave_sum(s);
+  __syncthreads();
+  if (lane == 0) sh[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < 16; ++w) tot += sh[w];      // the order alpha_weights_kernel adds them in
+    out[0] = mx;
+    out[1] = tot;
+    out[2] = log(tot / n_total) / alpha + mx;
+  }
+}
+
+// max -> weights -> value of the dense families' alpha pipelines (scal: [0] sum log scale, [8] max, [9] sum s, [10] value)
+static int alpha_scalars_enqueue(vb_ctx* ctx, const double* f, const double* b, double* scal, int64_t n, int64_t n_total,
+                                 double alpha, double* roww) {
+  hipStream_t st = ctx->stream;
+  if (!ctx->comm) {
+    hipLaunchKernelGGL(alpha_one_rank_kernel, dim3(1), dim3(1024), 0, st, f, b, (const double*)scal, n, alpha,
+                       (double)n_total, roww, scal + 8);
+    VB_HIP(ctx, hipGetLastError());
+    return VB_OK;
+  }
+  hipLaunchKernelGGL(alpha_max_kernel, dim3(1), dim3(1024), 0, st, f, b, (const double*)scal, n, scal + 8);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(comm_allreduce_max(ctx, st, scal + 8, 1));
+  hipLaunchKernelGGL(alpha_weights_kernel, dim3(1), dim3(1024), 0, st, f, b, (const double*)scal,
+                     (const double*)(scal + 8), n, alpha, roww, scal + 9);
+  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(comm_allreduce_sum(ctx, st, scal + 9, 1));
+  hipLaunchKernelGGL(alpha_value_kernel, dim3(1), dim3(1), 0, st, (const double*)(scal + 8), (const double*)(scal + 9),
+                     (double)n_total, alpha, scal + 10);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 // AlphaDivergence for the dense Gaussian family (objectives.py:453-461 with z = mu + L eps):
 // log q(z_n) = b_n - sum log L_ii, so the weights follow from per-row f (model_logp_rows on the samples) exactly
 // as for the mean-field families; the gradient is the entropy-form pipeline with the rows of G weighted.
+// df > 0 with inv_s: the multivariate t sampled through its Cholesky factor, x = mu + (L eps) / s (throughput mode): the
+// same pipeline with the rows scaled by 1 / s_n and the t family's base density -- the gradient leaves in the flat
+// free-Cholesky layout, no matrix root and no D x D array on the host.
 int alpha_fullrank_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double alpha,
-                           const double* theta_dev, double sum_log_diag, double* out) {
+                           const double* theta_dev, double sum_log_diag, double* out, double df, const double* inv_s) {
   if (!(alpha != 0.0)) return fail(ctx, VB_ERR_INVALID, "alpha must be non-zero");
   if (n <= 0 || n > ns.n || d != ns.d || n_total < n) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   hipStream_t st = ctx->stream;
@@ -274,30 +344,39 @@ int alpha_fullrank_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t 
   double* scal = (double*)ctx->rowvec.ptr;
   double *f = scal + 16, *b = f + nn, *roww = b + nn;
   double* Z = (double*)ctx->scratch.ptr;
-  VB_HIP(ctx, hipMemsetAsync(Z, 0, (size_t)(n * ldz) * sizeof(double), st));
-  VB_HIP(ctx, hipMemcpyAsync(scal, &sum_log_diag, sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));   // sum_log_diag lives on the caller's stack
-  VB_TRY(fr_sample_enqueue(ctx, ns, n, d, theta_dev, Z));
-  VB_TRY(model_logp_rows(ctx, Z, ldz, n, d, f));
-  hipLaunchKernelGGL(rs_normal_base_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)ns.buf.ptr,
-                     ns.ld, n, (int)d, b);
-  hipLaunchKernelGGL(alpha_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)f, (const double*)b,
-                     (const double*)scal, n, scal + 8);
+  // (the pad columns of the sample matrix must hold zeros: the sampling product writes columns [0, d) only)
+  if (ldz != d) VB_HIP(ctx, hipMemsetAsync(Z, 0, (size_t)(n * ldz) * sizeof(double), st));
+  hipLaunchKernelGGL(rs_set_scalar_kernel, dim3(1), dim3(1), 0, st, scal, sum_log_diag);      // (no copy, no synchronisation)
+  VB_TRY(fr_sample_enqueue(ctx, ns, n, d, theta_dev, Z, nullptr, nullptr, inv_s));
+  const double* g_ready = nullptr;
+  if (ctx->model.id == VB_MODEL_GAUSS_FULL && !inv_s) {
+    // f of the correlated Gaussian costs the N x D x D product that also IS its gradient: keep G, the pipeline below
+    // then needs neither its sampling product nor its model product
+    VB_TRY(ensure(ctx, ctx->alpha_g, (size_t)(n * ldz) * sizeof(double)));
+    VB_TRY(model_grad_rows(ctx, Z, ldz, n, d, (double*)ctx->alpha_g.ptr, f));
+    g_ready = (const double*)ctx->alpha_g.ptr;
+  } else {
+    VB_TRY(model_logp_rows(ctx, Z, ldz, n, d, f));
+  }
+  if (inv_s) {
+    const double lconst = lgamma(0.5 * (df + (double)d)) - lgamma(0.5 * df) - 0.5 * (double)d * log(M_PI * df);
+    hipLaunchKernelGGL(rs_mvt_base_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)ns.buf.ptr,
+                       ns.ld, n, (int)d, df, lconst, inv_s, b);
+  } else {
+    hipLaunchKernelGGL(rs_normal_base_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)ns.buf.ptr,
+                       ns.ld, n, (int)d, b);
+  }
   VB_HIP(ctx, hipGetLastError());
-  VB_TRY(comm_allreduce_max(ctx, st, scal + 8, 1));
-  hipLaunchKernelGGL(alpha_weights_kernel, dim3(1), dim3(1024), 0, st, (const double*)f, (const double*)b,
-                     (const double*)scal, (const double*)(scal + 8), n, alpha, roww, scal + 9);
-  VB_HIP(ctx, hipGetLastError());
-  VB_TRY(comm_allreduce_sum(ctx, st, scal + 9, 1));
-  hipLaunchKernelGGL(alpha_value_kernel, dim3(1), dim3(1), 0, st, (const double*)(scal + 8),
-                     (const double*)(scal + 9), (double)n_total, alpha, scal + 10);
-  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(alpha_scalars_enqueue(ctx, f, b, scal, n, n_total, alpha, roww));
   FrWeighted wm;
   wm.roww = roww;
   wm.scale = alpha / (double)n_total;          // objectives.py:460: alpha * vjp / N
   wm.wsum = scal + 9;
   wm.value = scal + 10;
   wm.z_ready = Z;
+  wm.g_ready = g_ready;
+  if (inv_s)
+    return fr_pipeline_enqueue(ctx, ns, n, d, n_total, theta_dev, out, nullptr, nullptr, inv_s, nullptr, 0, &wm);
   return fr_elbo_grad_enqueue(ctx, ns, n, d, n_total, theta_dev, out, 0, &wm);
 }
 
@@ -334,25 +413,15 @@ int alpha_mvt_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_tot
   double* scal = (double*)ctx->rowvec.ptr;
   double *f = scal + 16, *b = f + nn, *roww = b + nn;
   double* Z = (double*)ctx->scratch.ptr;
-  VB_HIP(ctx, hipMemsetAsync(Z, 0, (size_t)(n * ldz) * sizeof(double), st));
-  VB_HIP(ctx, hipMemcpyAsync(scal, &sum_log_diag, sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));   // sum_log_diag lives on the caller's stack
+  if (ldz != d) VB_HIP(ctx, hipMemsetAsync(Z, 0, (size_t)(n * ldz) * sizeof(double), st));
+  hipLaunchKernelGGL(rs_set_scalar_kernel, dim3(1), dim3(1), 0, st, scal, sum_log_diag);
   VB_TRY(fr_sample_enqueue(ctx, ns, n, d, nullptr, Z, mu_dev, root_dev, invs_dev));
   VB_TRY(model_logp_rows(ctx, Z, ldz, n, d, f));
   const double lconst = lgamma(0.5 * (df + (double)d)) - lgamma(0.5 * df) - 0.5 * (double)d * log(M_PI * df);
   hipLaunchKernelGGL(rs_mvt_base_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const double*)ns.buf.ptr,
                      ns.ld, n, (int)d, df, lconst, invs_dev, b);
-  hipLaunchKernelGGL(alpha_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)f, (const double*)b,
-                     (const double*)scal, n, scal + 8);
   VB_HIP(ctx, hipGetLastError());
-  VB_TRY(comm_allreduce_max(ctx, st, scal + 8, 1));
-  hipLaunchKernelGGL(alpha_weights_kernel, dim3(1), dim3(1024), 0, st, (const double*)f, (const double*)b,
-                     (const double*)scal, (const double*)(scal + 8), n, alpha, roww, scal + 9);
-  VB_HIP(ctx, hipGetLastError());
-  VB_TRY(comm_allreduce_sum(ctx, st, scal + 9, 1));
-  hipLaunchKernelGGL(alpha_value_kernel, dim3(1), dim3(1), 0, st, (const double*)(scal + 8),
-                     (const double*)(scal + 9), (double)n_total, alpha, scal + 10);
-  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(alpha_scalars_enqueue(ctx, f, b, scal, n, n_total, alpha, roww));
   FrWeighted wm;
   wm.roww = roww;
   wm.scale = alpha / (double)n_total;

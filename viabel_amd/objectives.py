@@ -1168,13 +1168,9 @@ class AlphaDivergence(StochasticVariationalObjective):
                 # matrix root, no Sylvester solve
                 eng.chisq_generate(df, end - begin, seed, 0, row_offset=begin)
                 eng.noise_generate(_NOISE_SLOT, end - begin, D, seed, 0, row_offset=begin)
-                mu, L = approx._unpack(var_param)
-                value, w_sum, g_sum, C = eng.alpha_sums_mvt(_NOISE_SLOT, end - begin, D, df, alpha, mu,
-                                                            np.ascontiguousarray(L.T), None,
-                                                            np.sum(np.log(np.diag(L))), n_total=N)
-                dL = np.tril(C)
-                dL[np.diag_indices(D)] = np.diag(dL) * np.diag(L) + w_sum
-                return value, alpha * np.concatenate([g_sum, dL[tril]]) / N          # objectives.py:460
+                # the dense family's weighted pipeline with the rows scaled by 1 / s_n (vb_alpha_grad_mvt_chol): the
+                # gradient arrives in the flat layout, alpha / N applied on the device
+                return eng.alpha_grad_mvt_chol(_NOISE_SLOT, end - begin, D, df, var_param, alpha, n_total=N)
             else:
                 # chi-square draws first (approximations.py:345-347)
                 chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed)
