@@ -348,6 +348,39 @@ __global__ void __launch_bounds__(256) mvt_linv_mu_kernel(const double* __restri
   if (lane == 0) c[j] = s;
 }
 
+// The O(D^2) leftovers of the factor algebra in ONE launch (they were four: two transposes, L^-1 mu, the scal memset),
+// blockIdx.y = role: 0: Li = Wt' ; 1: Lfull = Lt' ; 2: c_j = sum_k mu_k Wt[k][j] (= (L^-1 mu)_j, read from the
+// untransposed inverse so that it does not wait for role 0) ; role 2's first block also zeroes the 32 scalars the
+// bisection accumulates into.
+__global__ void __launch_bounds__(256) mvt_prep_kernel(const double* __restrict__ Wt, const double* __restrict__ Lt,
+                                                       const double* __restrict__ mu, double* __restrict__ Li,
+                                                       double* __restrict__ Lfull, double* __restrict__ c,
+                                                       double* __restrict__ scal, int d, int64_t ld) {
+  const int role = blockIdx.y, tiles = (d + 31) / 32;
+  if (role < 2) {
+    if ((int)blockIdx.x >= tiles * tiles) return;
+    __shared__ double tile[32][33];
+    const double* in = role == 0 ? Wt : Lt;
+    double* out = role == 0 ? Li : Lfull;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = (blockIdx.x % tiles) * 32, r0 = (blockIdx.x / tiles) * 32;
+    for (int r = ty; r < 32; r += 8)
+      tile[r][tx] = (r0 + r < d && c0 + tx < d) ? in[(int64_t)(r0 + r) * ld + c0 + tx] : 0.0;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+      if (c0 + r < d && r0 + tx < d) out[(int64_t)(c0 + r) * ld + r0 + tx] = tile[tx][r];
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 32 && scal) scal[threadIdx.x] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= d) return;
+  double s = 0.0;
+  for (int k = lane; k <= j; k += 64) s = fma(mu[k], Wt[(int64_t)k * ld + j], s);      // Wt = L^-T is upper triangular
+  s = mvt_wave_sum(s);
+  if (lane == 0) c[j] = s;
+}
+
 // S = symmetric matrix given by its lower triangle C (both d x d, row stride ld)
 __global__ void __launch_bounds__(256) mvt_symmetrize_kernel(const double* __restrict__ C, double* __restrict__ S,
                                                              int d, int64_t ld) {
@@ -377,7 +410,10 @@ __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __rest
 }
 
 // theta (host) -> device: mu, L' (o_lt), L (o_lfull), Wt = L^-T (o_wt), Li = L^-1 (o_li), c = L^-1 mu (o_c)
-static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t d, const double* theta_host) {
+// zero_scal: the refresh's call also clears the 32 scalars the bisection accumulates into (a gradient at another
+// parameter must leave them alone: eps, ess and the status of the refresh live there)
+static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t d, const double* theta_host,
+                              bool zero_scal = false) {
   hipStream_t st = ctx->stream;
   const int D = (int)d;
   const size_t p = (size_t)(d + d * (d + 1) / 2);
@@ -403,7 +439,8 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   memcpy(stage, theta_host, p * sizeof(double));
   VB_HIP(ctx, hipMemcpyAsync(base + L.o_theta, stage, p * sizeof(double), hipMemcpyHostToDevice, st));
   VB_HIP(ctx, hipEventRecord(slot_ev, st));
-  VB_HIP(ctx, hipMemsetAsync(base + L.o_mu, 0, (size_t)(2 * L.ld) * sizeof(double), st));
+  if (L.ld != d)      // (pad columns of mu and c: the unpack and the prep kernel write columns [0, d) only)
+    VB_HIP(ctx, hipMemsetAsync(base + L.o_mu, 0, (size_t)(2 * L.ld) * sizeof(double), st));
   VB_TRY(fr_unpack_enqueue(ctx, st, base + L.o_theta, D, L.ld, base + L.o_lt, base + L.o_mu));
   // the inverse's strictly lower triangle (and the scratch) need zeroing only when the buffer or its layout changed:
   // nothing else writes o_wt in throughput mode
@@ -411,12 +448,11 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   const bool clean = memcmp(key, ctx->mvt_inv_key, sizeof key) == 0;
   memcpy(ctx->mvt_inv_key, key, sizeof key);
   VB_TRY(fr_tri_inverse_enqueue(ctx, st, base + L.o_theta, base + L.o_lt, D, L.ld, base + L.o_wt, base + L.o_tscr, clean));
-  const dim3 tg((unsigned)((D + 31) / 32), (unsigned)((D + 31) / 32));
   // (the transposes write every entry of the d x d blocks; the pad columns hold the zeros of the allocation)
-  hipLaunchKernelGGL(mvt_transpose_kernel, tg, dim3(256), 0, st, (const double*)(base + L.o_wt), base + L.o_li, D, L.ld);
-  hipLaunchKernelGGL(mvt_transpose_kernel, tg, dim3(256), 0, st, (const double*)(base + L.o_lt), base + L.o_lfull, D, L.ld);
-  hipLaunchKernelGGL(mvt_linv_mu_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, (const double*)(base + L.o_li),
-                     L.ld, D, (const double*)(base + L.o_mu), base + L.o_c);
+  const int tiles = (D + 31) / 32, gx = tiles * tiles > (D + 3) / 4 ? tiles * tiles : (D + 3) / 4;
+  hipLaunchKernelGGL(mvt_prep_kernel, dim3((unsigned)gx, 3), dim3(256), 0, st, (const double*)(base + L.o_wt),
+                     (const double*)(base + L.o_lt), (const double*)(base + L.o_mu), base + L.o_li, base + L.o_lfull,
+                     base + L.o_c, zero_scal ? base + L.o_scal : (double*)nullptr, D, L.ld);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -595,7 +631,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   if ((root_host == nullptr) != (linv_host == nullptr))
     return fail(ctx, VB_ERR_INVALID, "sqrt_sigma and l_inv are given together or not at all");
   if (dev_factors) {      // throughput mode: mu, L', L^-1 from theta on the device; the samples go through L' (see header)
-    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
+    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true));
   } else {
     VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
   }
@@ -673,7 +709,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lprior, mine, n, n_total));
   }
-  VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is
+  if (!dev_factors)      // (throughput mode: mvt_prep_kernel has zeroed them)
+    VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is
   VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_lq, base + L.o_lprior, base + L.o_scal, n_total, eps_prev,
                             ess_target, max_its, base + L.o_w, base + L.o_lqcopy, base + L.o_scal + 8));
   if (!w_host) {
