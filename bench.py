@@ -883,10 +883,16 @@ def main():
     # sharded code path and every collective runs, through pinned host memory and the control sockets instead of
     # RCCL / xGMI (functional check of the N > 1 path on a one-GPU box; the numbers are not a scaling measurement)
     host_transport = world > 1 and os.environ.get('VB_BENCH_TRANSPORT') == 'host'
-    eng = _lib.Engine(0) if (no_rccl or host_transport) else _lib.default_engine()
+    # VB_BENCH_TRANSPORT=ipc: the xGMI-native all-reduce (vb_comm_init_ipc) instead of RCCL -- one GPU per rank where the
+    # node has them, otherwise all ranks on device 0 (a functional run, as the host-staged one)
+    ipc_transport = world > 1 and os.environ.get('VB_BENCH_TRANSPORT') == 'ipc'
+    ipc_shared_gpu = ipc_transport and _lib.device_count() < world
+    eng = _lib.Engine(0) if (no_rccl or host_transport or ipc_shared_gpu) else _lib.default_engine()
     _lib.set_default_engine(eng)
     if host_transport:
         distributed.attach(eng, group, transport='host')
+    elif ipc_transport:
+        distributed.attach(eng, group, transport='ipc')
     elif world > 1 and not no_rccl:
         distributed.attach(eng, group)
     elif args.force_comm and world == 1:
@@ -952,7 +958,10 @@ def main():
             'rccl_ranks': rccl_ranks,
             'transport': ('host-staged (VB_BENCH_TRANSPORT=host): all ranks on device 0, collectives through pinned host '
                           'memory and the control sockets -- a functional run of the N > 1 path, not a scaling figure')
-                         if host_transport else ('rccl' if rccl_ranks > 1 or args.force_comm else 'none'),
+                         if host_transport else
+                         ('xGMI-native IPC all-reduce (VB_BENCH_TRANSPORT=ipc)' + (': all ranks on device 0, a functional run'
+                                                                                   if ipc_shared_gpu else ''))
+                         if ipc_transport else ('rccl' if rccl_ranks > 1 or args.force_comm else 'none'),
             'timing': {'timed_blocks': len(head['block_seconds']), 'steps_per_block': args.steps,
                        'ms_per_step_of': 'median block', 'block_ms': [1e3 * t for t in head['block_seconds']],
                        'timed_total_s': float(sum(head['block_seconds']))},

@@ -487,6 +487,17 @@ int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank);
 #define VB_HOST_MAX 1
 typedef int (*vb_host_collective_fn)(void* user, double* buf, size_t count, int op);
 int vb_comm_init_host(vb_ctx* ctx, vb_host_collective_fn fn, void* user, int n_ranks, int rank);
+/* xGMI-native transport: no ring, no host.  Every rank allocates a window (vb_comm_ipc_window: room for collectives of
+ * up to `cap_doubles` values; returns its hipIpcMemHandle), the caller exchanges the handles over its control plane
+ * (all-gather of n_ranks x VB_IPC_HANDLE_BYTES bytes), vb_comm_init_ipc maps the peers' windows.  An all-reduce is then
+ * three launches on the caller's stream: copy into the own window; reduce the own 1 / n_ranks slice reading the ranks'
+ * windows IN RANK ORDER (one rank sums each element, in a fixed order: every rank gets the same bits, whatever the
+ * timing -- which a ring does not promise); read the reduced slices back.  Device-side sequence flags in the windows
+ * order the phases across ranks (system-scope atomics; bounded polls, a give-up poisons the result with NaN).
+ * Functionally tested between two processes on one GPU; the 8-GPU timing is unmeasured.  At most 15 ranks. */
+#define VB_IPC_HANDLE_BYTES 64
+int vb_comm_ipc_window(vb_ctx* ctx, size_t cap_doubles, char handle[VB_IPC_HANDLE_BYTES]);
+int vb_comm_init_ipc(vb_ctx* ctx, const char* handles, int n_ranks, int rank);
 
 /* ---- numpy's legacy generator on the host (vb_legacy_rng.cpp) ------------------------------------
  * `numpy.random.RandomState(seed)` restated in C++: MT19937 seeded as numpy seeds it from an integer, the polar-method

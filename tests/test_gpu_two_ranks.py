@@ -1,6 +1,8 @@
 """A real two-rank job on ONE GPU: both ranks open device 0, the Monte-Carlo axis is sharded (ragged: odd sample
 counts), and every device collective of the sharded path runs -- through the host-staged transport
-(`vb_comm_init_host`, `distributed.attach(..., transport='host')`), because RCCL refuses two ranks on one device.
+(`vb_comm_init_host`, `distributed.attach(..., transport='host')`), because RCCL refuses two ranks on one device -- and through the xGMI-native transport (`vb_comm_init_ipc`,
+transport='ipc': the ranks map each other's windows through IPC handles and reduce on the device, device-side flags),
+which between two processes on one GPU runs exactly the code an 8-GPU node would.
 What this covers that the one-rank communicator tests (test_gpu_comm.py) cannot: shard offsets of the second rank,
 ragged gathers of per-sample vectors, rank 0's host random draws reaching rank 1, the collective sequence of every
 objective staying paired across ranks (a mismatch deadlocks or trips the size check), the device fit loop with one
@@ -27,7 +29,7 @@ import viabel_amd as vb
 eng = _lib.Engine(0)                                  # both ranks on the one GPU of the box
 _lib.set_default_engine(eng)
 group = distributed.SocketGroup.from_env(timeout=120.0)
-distributed.attach(eng, group, transport='host')
+distributed.attach(eng, group, transport=%(transport)r)
 assert eng.comm_info() == (2, group.rank)
 import _two_rank_scenarios as S
 res = S.run_all(vb)
@@ -44,7 +46,8 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
 
 
-def test_two_ranks_on_one_gpu_match_one_rank(tmp_path):
+@pytest.mark.parametrize('transport', ['host', 'ipc'])
+def test_two_ranks_on_one_gpu_match_one_rank(tmp_path, transport):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     import bench
@@ -53,7 +56,7 @@ def test_two_ranks_on_one_gpu_match_one_rank(tmp_path):
     import _two_rank_scenarios as S
 
     script = tmp_path / 'worker.py'
-    script.write_text(WORKER % {'root': ROOT, 'tests': TESTS, 'out': str(tmp_path)})
+    script.write_text(WORKER % {'root': ROOT, 'tests': TESTS, 'out': str(tmp_path), 'transport': transport})
     rc, lines = bench.spawn_ranks(2, [sys.executable, str(script)], timeout_s=900)
     assert rc == 0, lines[-5:]
 

@@ -175,6 +175,8 @@ SIGNATURES = {
                                                ctypes.c_double]),
     'vb_legacy_rng_randn_device': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                   ctypes.c_int64, ctypes.c_int64]),
+    'vb_comm_ipc_window': (ctypes.c_int, [_ctx_p, ctypes.c_size_t, ctypes.c_char_p]),
+    'vb_comm_init_ipc': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_init_host': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
@@ -820,6 +822,22 @@ class Engine:
 
     def comm_init(self, unique_id, n_ranks, rank):
         self._check(self._lib.vb_comm_init(self._ctx, unique_id, n_ranks, rank))
+        self.n_ranks, self.rank = n_ranks, rank
+
+    IPC_HANDLE_BYTES = 64
+
+    def comm_ipc_window(self, cap_doubles=1 << 21):
+        """Allocate this rank's window of the xGMI-native transport; returns its IPC handle (64 bytes)."""
+        buf = ctypes.create_string_buffer(self.IPC_HANDLE_BYTES)
+        self._check(self._lib.vb_comm_ipc_window(self._ctx, int(cap_doubles), buf))
+        return buf.raw
+
+    def comm_init_ipc(self, handles, n_ranks, rank):
+        """``handles``: the ranks' window handles in rank order (``n_ranks * 64`` bytes)."""
+        blob = b''.join(handles)
+        if len(blob) != n_ranks * self.IPC_HANDLE_BYTES:
+            raise ValueError('expected %d window handles of %d bytes' % (n_ranks, self.IPC_HANDLE_BYTES))
+        self._check(self._lib.vb_comm_init_ipc(self._ctx, blob, n_ranks, rank))
         self.n_ranks, self.rank = n_ranks, rank
 
     def comm_init_host(self, collective, n_ranks, rank):

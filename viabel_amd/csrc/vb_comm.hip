@@ -6,6 +6,8 @@
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
+
 namespace vb {
 
 // host-staged transport (vb_comm_init_host): device -> pinned host, the caller's collective, host -> device; the
@@ -30,8 +32,117 @@ static int host_collective(vb_ctx* ctx, hipStream_t stream, double* buf, size_t 
   return VB_OK;
 }
 
+// ---- xGMI-native transport (vb_comm_init_ipc) -------------------------------------------------------------------------
+// All-reduce without a ring: every rank copies its vector into its own window, then reduces ITS 1/G slice by reading the
+// G windows in RANK ORDER -- every element is summed once, by one rank, in a fixed order, so all ranks end with the same
+// bits whatever the timing (a ring's order depends on the slice) -- and finally reads the reduced slices back.  On an
+// 8-GPU xGMI node that is two passes of (G - 1) / G of the vector over seven point-to-point links in parallel (4.2 MB:
+// ~2 x 3.7 MB / (7 x ~50 GB/s achievable) ~ 20 us plus three launches) against the ring's 2 (G - 1) dependent steps;
+// UNMEASURED here (one GPU per box): tests/test_gpu_two_ranks.py runs it between two processes on one GPU.
+//
+// Synchronisation is on the device: window word 0 / 1 / 2 = sequence number of the last collective whose data /
+// reduced slice / read-back this rank has finished (system-scope atomics behind a system-scope fence; the last block
+// of a phase stores it).  A phase's blocks poll the peers' words before they touch peer memory:
+//   publish  waits done >= seq - 1 on every peer (nobody still reads the previous collective out of my window)
+//   reduce   waits data >= seq, gather waits reduced >= seq.          Polls are bounded; a give-up poisons the result with NaN.
+constexpr int kIpcFlagDoubles = 16;      // 128 B in front of the data area
+
+__device__ __forceinline__ bool ipc_wait(const double* const* win, int n_ranks, int self, int word, unsigned long long want) {
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    for (int p = 0; p < n_ranks; ++p) {
+      if (p == self) continue;
+      const unsigned long long* f = reinterpret_cast<const unsigned long long*>(win[p]) + word;
+      unsigned spins = 0;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 24)) {
+          ok = false;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: the peers' data behind their flags
+  }
+  return __syncthreads_and((int)ok) != 0;
+}
+
+__device__ __forceinline__ void ipc_signal(double* own, int word, unsigned long long seq, unsigned* ticket, int phase) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // this block's stores, system scope
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(ticket + phase, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {                       // the phase's last block: every block's stores are released
+      __hip_atomic_store(ticket + phase, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(own) + word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+struct IpcArgs {
+  const double* win[16];
+  int n_ranks, rank;
+  size_t cap;
+  unsigned long long seq;
+  unsigned* ticket;
+};
+
+__global__ void __launch_bounds__(256) ipc_publish_kernel(IpcArgs a, const double* __restrict__ buf, size_t count) {
+  double* own = const_cast<double*>(a.win[a.rank]);
+  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 2, a.seq - 1);
+  double* data = own + kIpcFlagDoubles;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+    data[i] = ok ? buf[i] : NAN;
+  ipc_signal(own, 0, a.seq, a.ticket, 0);
+}
+
+// slice of rank r: [r * per, min(count, (r + 1) * per)), per = ceil(count / G)
+__global__ void __launch_bounds__(256) ipc_reduce_kernel(IpcArgs a, size_t count, int op) {
+  double* own = const_cast<double*>(a.win[a.rank]);
+  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 0, a.seq);
+  const size_t per = (count + a.n_ranks - 1) / a.n_ranks, lo = (size_t)a.rank * per, hi = lo + per < count ? lo + per : count;
+  double* res = own + kIpcFlagDoubles + a.cap;
+  for (size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (size_t)gridDim.x * 256) {
+    double s = a.win[0][kIpcFlagDoubles + i];
+    for (int p = 1; p < a.n_ranks; ++p) {              // rank order: the same sum on every run and for every timing
+      const double v = a.win[p][kIpcFlagDoubles + i];
+      s = op == VB_HOST_MAX ? fmax(s, v) : s + v;
+    }
+    res[i] = ok ? s : NAN;
+  }
+  ipc_signal(own, 1, a.seq, a.ticket, 1);
+}
+
+__global__ void __launch_bounds__(256) ipc_gather_kernel(IpcArgs a, double* __restrict__ buf, size_t count) {
+  double* own = const_cast<double*>(a.win[a.rank]);
+  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 1, a.seq);
+  const size_t per = (count + a.n_ranks - 1) / a.n_ranks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    const int owner = (int)(i / per);
+    buf[i] = ok ? a.win[owner][kIpcFlagDoubles + a.cap + i] : NAN;
+  }
+  ipc_signal(own, 2, a.seq, a.ticket, 2);
+}
+
+static int ipc_collective(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count, int op) {
+  if (count == 0) return VB_OK;
+  vb_ctx::IpcComm& c = ctx->ipc;
+  if (count > c.cap)
+    return fail(ctx, VB_ERR_COMM, "IPC window holds %zu doubles, the collective has %zu (vb_comm_ipc_window)", c.cap, count);
+  IpcArgs a;
+  for (int p = 0; p < 16; ++p) a.win[p] = c.win[p];
+  a.n_ranks = ctx->n_ranks, a.rank = ctx->rank, a.cap = c.cap, a.seq = ++c.seq, a.ticket = c.ticket;
+  const unsigned blocks = (unsigned)std::min<size_t>(256, (count + 255) / 256);
+  hipLaunchKernelGGL(ipc_publish_kernel, dim3(blocks), dim3(256), 0, stream, a, (const double*)buf, count);
+  hipLaunchKernelGGL(ipc_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a, count, op);
+  hipLaunchKernelGGL(ipc_gather_kernel, dim3(blocks), dim3(256), 0, stream, a, buf, count);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count) {
   if (!ctx->comm) return VB_OK;
+  if (ctx->ipc.on) return ipc_collective(ctx, stream, buf, count, VB_HOST_SUM);
   if (ctx->host_fn) return host_collective(ctx, stream, buf, count, VB_HOST_SUM);
   ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm,
                                  stream);
@@ -42,6 +153,7 @@ int comm_allreduce_sum(vb_ctx* ctx, hipStream_t stream, double* buf, size_t coun
 
 int comm_allreduce_max(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count) {
   if (!ctx->comm) return VB_OK;
+  if (ctx->ipc.on) return ipc_collective(ctx, stream, buf, count, VB_HOST_MAX);
   if (ctx->host_fn) return host_collective(ctx, stream, buf, count, VB_HOST_MAX);
   ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclMax, (ncclComm_t)ctx->comm, stream);
   if (r != ncclSuccess)
@@ -56,12 +168,13 @@ int comm_allgather(vb_ctx* ctx, hipStream_t stream, const double* send, double* 
       VB_HIP(ctx, hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
     return VB_OK;
   }
-  if (ctx->host_fn) {    // zero everybody else's chunk, then a sum (x + 0 + ... + 0 is exact)
+  if (ctx->host_fn || ctx->ipc.on) {    // zero everybody else's chunk, then a sum (x + 0 + ... + 0 is exact)
     const size_t r = (size_t)ctx->rank, g = (size_t)ctx->n_ranks;
     if (send != recv + r * count)
       VB_HIP(ctx, hipMemcpyAsync(recv + r * count, send, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
     if (r > 0) VB_HIP(ctx, hipMemsetAsync(recv, 0, r * count * sizeof(double), stream));
     if (r + 1 < g) VB_HIP(ctx, hipMemsetAsync(recv + (r + 1) * count, 0, (g - r - 1) * count * sizeof(double), stream));
+    if (ctx->ipc.on) return ipc_collective(ctx, stream, recv, g * count, VB_HOST_SUM);
     return host_collective(ctx, stream, recv, g * count, VB_HOST_SUM);
   }
   ncclResult_t r = ncclAllGather(send, recv, count, ncclDouble, (ncclComm_t)ctx->comm, stream);
@@ -139,12 +252,64 @@ int vb_comm_init_host(vb_ctx* ctx, vb_host_collective_fn fn, void* user, int n_r
   return VB_OK;
 }
 
+int vb_comm_ipc_window(vb_ctx* ctx, size_t cap_doubles, char handle[VB_IPC_HANDLE_BYTES]) {
+  static_assert(sizeof(hipIpcMemHandle_t) <= VB_IPC_HANDLE_BYTES, "hipIpcMemHandle_t larger than VB_IPC_HANDLE_BYTES");
+  if (!ctx || !handle || cap_doubles == 0) return fail(ctx, VB_ERR_INVALID, "NULL argument or empty window");
+  if (ctx->comm || ctx->ipc.win[0] || ctx->ipc.cap) return fail(ctx, VB_ERR_STATE, "communicator or window already present");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (kIpcFlagDoubles + 2 * cap_doubles) * sizeof(double);
+  double* w = nullptr;
+  VB_HIP(ctx, hipMalloc((void**)&w, bytes));
+  VB_HIP(ctx, hipMemset(w, 0, bytes));
+  VB_HIP(ctx, hipMalloc((void**)&ctx->ipc.ticket, 4 * sizeof(unsigned)));
+  VB_HIP(ctx, hipMemset(ctx->ipc.ticket, 0, 4 * sizeof(unsigned)));
+  hipIpcMemHandle_t h;
+  VB_HIP(ctx, hipIpcGetMemHandle(&h, w));
+  memset(handle, 0, VB_IPC_HANDLE_BYTES);
+  memcpy(handle, &h, sizeof h);
+  ctx->ipc.cap = cap_doubles;
+  ctx->ipc.win[15] = w;                // parked until vb_comm_init_ipc knows the rank
+  return VB_OK;
+}
+
+int vb_comm_init_ipc(vb_ctx* ctx, const char* handles, int n_ranks, int rank) {
+  if (!ctx || !handles) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (n_ranks < 1 || n_ranks > 15 || rank < 0 || rank >= n_ranks)
+    return fail(ctx, VB_ERR_INVALID, "rank %d / n_ranks %d invalid (at most 15 ranks)", rank, n_ranks);
+  if (ctx->comm) return fail(ctx, VB_ERR_STATE, "communicator already attached");
+  if (!ctx->ipc.win[15]) return fail(ctx, VB_ERR_STATE, "no window (vb_comm_ipc_window first)");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  double* own = ctx->ipc.win[15];
+  ctx->ipc.win[15] = nullptr;
+  for (int p = 0; p < n_ranks; ++p) {
+    if (p == rank) {
+      ctx->ipc.win[p] = own;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)p * VB_IPC_HANDLE_BYTES, sizeof h);
+    void* ptr = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      ctx->ipc.win[15] = own;
+      return fail(ctx, VB_ERR_COMM, "hipIpcOpenMemHandle of rank %d's window failed: %s", p, hipGetErrorString(e));
+    }
+    ctx->ipc.win[p] = (double*)ptr;
+  }
+  ctx->ipc.on = true;
+  ctx->ipc.seq = 0;
+  ctx->comm = ctx;
+  ctx->n_ranks = n_ranks;
+  ctx->rank = rank;
+  return VB_OK;
+}
+
 int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank) {
   if (!ctx || !n_ranks || !rank) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   *n_ranks = 1;
   *rank = 0;
   if (!ctx->comm) return VB_OK;      // no communicator: a one-rank job
-  if (ctx->host_fn) {
+  if (ctx->host_fn || ctx->ipc.on) {
     *n_ranks = ctx->n_ranks;
     *rank = ctx->rank;
     return VB_OK;
@@ -157,7 +322,17 @@ int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank) {
 
 int vb_comm_destroy(vb_ctx* ctx) {
   if (!ctx || !ctx->comm) return VB_OK;
-  if (ctx->host_fn) {
+  if (ctx->ipc.on) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int p = 0; p < ctx->n_ranks; ++p) {
+      if (!ctx->ipc.win[p]) continue;
+      if (p == ctx->rank) (void)hipFree(ctx->ipc.win[p]);
+      else (void)hipIpcCloseMemHandle(ctx->ipc.win[p]);
+      ctx->ipc.win[p] = nullptr;
+    }
+    if (ctx->ipc.ticket) (void)hipFree(ctx->ipc.ticket);
+    ctx->ipc = vb_ctx::IpcComm();
+  } else if (ctx->host_fn) {
     ctx->host_fn = nullptr;
     ctx->host_user = nullptr;
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);

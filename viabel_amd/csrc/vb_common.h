@@ -238,6 +238,15 @@ struct vb_ctx {
   void* host_user = nullptr;
   double* host_stage = nullptr;         // pinned staging buffer of the host-staged transport
   size_t host_stage_cap = 0;            // ... in doubles
+  // xGMI-native transport (vb_comm_init_ipc): every rank's window [3 flag words | data cap | result cap], the peers'
+  // windows mapped through IPC handles; ipc_seq counts the collectives (the flags carry it)
+  struct IpcComm {
+    double* win[16] = {};               // [rank] window base (own allocation at [rank], the others hipIpcOpenMemHandle'd)
+    size_t cap = 0;                     // doubles per data / result area
+    unsigned long long seq = 0;
+    unsigned* ticket = nullptr;         // device: last-block tickets of the three phases
+    bool on = false;
+  } ipc;
 
   bool profile = false;
   struct ProfLog {                      // one per profiled kernel id (VB_PROF_*)

@@ -182,6 +182,14 @@ class SocketGroup:
         """Rank 0's ``payload`` on every rank."""
         return self._exchange(payload if self.rank == 0 else b'', lambda parts: parts[0])
 
+    def allgather_bytes(self, payload):
+        """Every rank's equal-length ``payload``, as a list in rank order, on every rank."""
+        n = len(payload)
+        out = self._exchange(payload, lambda parts: b''.join(parts))
+        if len(out) != n * self.world:
+            raise RuntimeError('allgather_bytes: ranks sent payloads of different lengths')
+        return [out[i * n:(i + 1) * n] for i in range(self.world)]
+
     def allreduce_max(self, x):
         out = self._exchange(struct.pack('<d', float(x)),
                              lambda parts: struct.pack('<d', max(struct.unpack('<d', p)[0] for p in parts)))
@@ -236,11 +244,14 @@ def attach(engine=None, group=None, transport=None):
 
     ``transport`` (default: ``$VIABEL_AMD_TRANSPORT`` or ``'rccl'``): ``'rccl'`` is the data path of a real job;
     ``'host'`` stages every device collective through pinned host memory and ``group.allreduce_array`` -- for ranks
-    RCCL cannot join (two ranks sharing one GPU, as the two-rank tests on a one-GPU box do)."""
+    RCCL cannot join (two ranks sharing one GPU, as the two-rank tests on a one-GPU box do); ``'ipc'`` is the
+    xGMI-native all-reduce over windows the ranks map from each other (``vb_comm_init_ipc``: every element summed by one
+    rank in rank order -- the same bits on every rank -- three launches, no ring; works between processes on one GPU
+    too)."""
     engine = engine or _lib.default_engine()
     transport = transport or os.environ.get('VIABEL_AMD_TRANSPORT', 'rccl')
-    if transport not in ('rccl', 'host'):
-        raise ValueError("transport must be 'rccl' or 'host', got %r" % (transport,))
+    if transport not in ('rccl', 'host', 'ipc'):
+        raise ValueError("transport must be 'rccl', 'host' or 'ipc', got %r" % (transport,))
     if group is not None:
         world, rank = group.world, group.rank
     else:
@@ -248,7 +259,14 @@ def attach(engine=None, group=None, transport=None):
         world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return engine
-    if transport == 'host':
+    if transport == 'ipc':
+        # xGMI-native all-reduce (vb_comm_init_ipc): every rank's window handle to every rank over the control group
+        if group is None:
+            raise ValueError("transport='ipc' needs a control group (SocketGroup) to exchange the window handles")
+        mine = engine.comm_ipc_window(int(os.environ.get('VIABEL_AMD_IPC_DOUBLES', 1 << 21)))
+        handles = group.allgather_bytes(mine)
+        engine.comm_init_ipc(handles, world, rank)
+    elif transport == 'host':
         if group is None:
             import torch
             import torch.distributed as dist
