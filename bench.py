@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet fp64 matrix peak = 256 CUs x 4 SIMDs x 512 flop / 16 clk x 2.4 GHz;
 #                                                  tools/mfma_barrier_probe.hip measures 77.3 with constant operands
 # HBM-side bytes per launch of the headline's dense model GEMM at D=1024, N=4096 (see roofline.traffic_source)
-MODEL_GEMM_HBM_BYTES = int((2 * 64296.3 + 34433.9) * 1024)      # profiles/r03_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
-MF_ACCUM_HBM_BYTES = int((2 * 530477.5 + 8352.6) * 1024)           # profiles/r03_meanfield_c1_pmc_hbm.txt, per 32-evaluation launch
+MODEL_GEMM_HBM_BYTES = int((2 * 64314.4 + 34442.3) * 1024)      # profiles/r04_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
+MF_ACCUM_HBM_BYTES = int((2 * 530474.5 + 8352.7) * 1024)           # profiles/r04_meanfield_c1_pmc_hbm.txt, per 32-evaluation launch
 MIN_TIMED_S = 0.05                               # the timed blocks are repeated until they cover at least this
 
 
@@ -223,7 +223,7 @@ def meanfield_leg(eng, vb, _lib, steps=2000, warmup=200, batch=32, ring_total=16
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'avg_kernel_us': kernel_us,
                      'launches_timed': launches, 'algorithmic_bytes_per_launch': bytes_per_launch,
                      'traffic': MF_ACCUM_HBM_BYTES if batch == 32 else None,
-                     'traffic_source': 'profiles/r03_meanfield_c1_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
+                     'traffic_source': 'profiles/r04_meanfield_c1_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
                                        'passes of tools/mf_stream_bench.py, this launch shape, round-3 kernel): 1 086.4 MB fetched '
                                        '+ 8.6 MB written per 32-evaluation launch = 1.019 x the algorithmic 1 074.8 MB'},
         'parity': {'rel_elbo_err': abs(dv - ov) / abs(ov),
@@ -264,7 +264,7 @@ def fit_leg(vb, theta, iters=1500):
         'kernel_us': 18.4, 'issue_floor_us': round(floor_us, 1), 'kernel_frac_of_floor': round(floor_us / 18.4, 2),
         'iteration_frac_of_floor': round(floor_us / out['device_loop_us_per_iteration'], 2),
         'rest_of_iteration': 'mf_finalize 5.6 us (4.4 us of latency inside the kernel) + ~2 us of dispatch gaps',
-        'source': 'profiles/r03_meanfield_gen_pmc_valu.txt, profiles/r03_fit_loop_kernel_stats.txt',
+        'source': 'profiles/r03_meanfield_gen_pmc_valu.txt, profiles/r04_fit_loop_kernel_stats.txt',
     }
     return out
 
@@ -318,7 +318,7 @@ def c3_leg(vb, calls=30):
     out['note'] = ('about 45 dependent kernels per call, everything including the O(D^3) factor algebra on the device; ten of '
                    'them are the tempering bisection (50 levels, 96 us), the three GEMMs take 100 us for %.1f GFLOP '
                    '(%.0f us at the dense GEMM rate): the call is bound by dependent launches, not by the matrix pipe; '
-                   'per-kernel times: profiles/r03_c3_kernel_stats.txt' % (flops / 1e9, flops / 57e12 * 1e6))
+                   'per-kernel times: profiles/r04_c3_kernel_stats.txt' % (flops / 1e9, flops / 57e12 * 1e6))
     return out
 
 
@@ -355,7 +355,7 @@ def mvt_ekl_leg(vb, calls=50):
     out['roofline'] = {'bound': 'mfma', 'flops_executed': flops, 'achieved': tf, 'peak': FP64_MFMA_PEAK_TFLOPS,
                        'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TFLOPS,
                        'note': 'whole blocking call incl. chi-square / normal generation (4.2 M normals) and the 264-KB '
-                               'parameter upload; per-kernel times: profiles/r03_mvt_ekl_kernel_stats.txt'}
+                               'parameter upload; per-kernel times: profiles/r04_mvt_ekl_kernel_stats.txt'}
     return out
 
 
@@ -589,7 +589,7 @@ def fullrank_fit_leg(vb, iters=300):
     tf = fl / (out['device_loop_us_per_iteration'] * 1e-6) / 1e12
     out['roofline'] = {'bound': 'mfma', 'flops_executed': fl, 'achieved': tf, 'peak': FP64_MFMA_PEAK_TFLOPS,
                        'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TFLOPS,
-                       'note': 'device_loop iteration; per-kernel times: profiles/r03_fullrank_fit_kernel_stats.txt'}
+                       'note': 'device_loop iteration; per-kernel times: profiles/r04_fullrank_fit_kernel_stats.txt'}
     return out
 
 
@@ -606,16 +606,20 @@ def api_call_leg(eng, vb, calls=200):
     model = vb.CorrelatedGaussianModel(rng.randn(d), covariance=A @ A.T / d + np.eye(d))
     out = {'workload': 'blocking objective(theta) -> (value, grad), FullRankGaussian(%d) + ExclusiveKL, N_mc=%d, '
                        'host parameter in, host gradient out, fresh noise per call' % (d, N_MC)}
-    for kind, n_calls in (('philox', calls), ('numpy', max(10, calls // 4))):
+    for kind, n_calls in (('philox', calls // 2), ('numpy', max(10, calls // 8))):
         fam = vb.FullRankGaussian(d, seed=1, rng=kind)
         obj = vb.ExclusiveKL(fam, model, N_MC)
         theta = fam.pack(np.zeros(d), np.exp(-1.0) * np.eye(d) + 0.01 * np.tril(np.random.RandomState(3).randn(d, d)))
         for _ in range(3):
             obj(theta)
-        t0 = time.perf_counter()
-        for _ in range(n_calls):
-            value, grad = obj(theta)
-        out['%s_us_per_call' % kind] = 1e6 * (time.perf_counter() - t0) / n_calls
+        blocks = []      # the median of three blocks: a blocking call is host-latency-sensitive (the CPU baseline's BLAS
+        for _ in range(3):      # threads may still be spinning down when this leg starts)
+            t0 = time.perf_counter()
+            for _ in range(n_calls):
+                value, grad = obj(theta)
+            blocks.append(1e6 * (time.perf_counter() - t0) / n_calls)
+        out['%s_us_per_call' % kind] = statistics.median(blocks)
+        out['%s_block_us' % kind] = blocks
     from viabel_amd._legacy_rng import LegacyRandomState
     eng.set_model(model.device_spec())
     rs = LegacyRandomState(1)
@@ -680,7 +684,7 @@ def fullrank_funnel_leg(eng, vb, steps=200, ring=8, slot0=40):
                        'rel_grad_err': float(np.max(np.abs(grad - og)) / np.max(np.abs(og)))},
             'roofline': {'bound': 'mfma', 'flops_executed': fl, 'achieved': tf, 'peak': FP64_MFMA_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': tf / FP64_MFMA_PEAK_TFLOPS,
-                         'note': 'per-kernel times: profiles/r03_fullrank_funnel_kernel_stats.txt'}}
+                         'note': 'per-kernel times: profiles/r04_fullrank_funnel_kernel_stats.txt'}}
 
 
 def blas_threads_for_baseline():
@@ -920,7 +924,7 @@ def main():
             # profiles/ (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
             if head['n_rows'] == N_MC and FR_D == 1024:
                 roof['traffic'] = MODEL_GEMM_HBM_BYTES
-                roof['traffic_source'] = ('profiles/r03_fullrank_gemm_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                roof['traffic_source'] = ('profiles/r04_fullrank_gemm_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                           'separate passes, FETCH_SIZE doubled per the gfx950 note): 131.7 MB fetched + '
                                           '35.5 MB written per launch vs 75.5 MB of operands and result (Z 33.6 + P 8.4 '
                                           'read, G 33.6 written) + 33.6 MB for the epilogue reading z - m back for sum f; '

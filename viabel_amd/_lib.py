@@ -244,6 +244,12 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def device_count():
+    """GPUs visible to HIP (0 without one)."""
+    n = ctypes.c_int(0)
+    return n.value if load().vb_device_count(ctypes.byref(n)) == VB_OK else 0
+
+
 class Engine:
     """One HIP context on one GPU (``vb_ctx``).  Calls are synchronous unless named ``*_async``."""
 
