@@ -1,6 +1,7 @@
 """CPU tests of the host-side logic around the hot path: optimisers, FASO / RAABBVI, chain statistics,
 families' parameter-space methods, argument validation.  Modelled on the reference's
 viabel/tests/test_optimization.py (dummy objective + dummy family) and test_convenience.py."""
+import os
 import numpy as np
 import pytest
 
@@ -253,3 +254,124 @@ def test_source_model_host_side():
         vb.ExclusiveKL(fam, m, 10)
     with pytest.raises(ValueError):
         vb.ExclusiveKL(vb.MFGaussian(3), m, 10)         # dimension mismatch
+
+
+def test_callable_model_host_side():
+    """CallableModel without a GPU: the trampoline the C library calls (vb_model_callback) fills f and grad through raw
+    pointers, a missing gradient is differenced numerically (and announced once), a raising callable returns non-zero
+    with its exception parked for the engine to re-raise."""
+    import ctypes
+    import warnings
+    rng = np.random.RandomState(0)
+    D, N = 4, 7
+    A = rng.randn(D, D)
+    P = A @ A.T + np.eye(D)
+
+    def f(z):
+        return -0.5 * np.einsum('ni,ij,nj->n', z, P, z)
+
+    def g(z):
+        return -z @ P
+    z = np.ascontiguousarray(rng.randn(N, D))
+    dp = ctypes.POINTER(ctypes.c_double)
+    for model, tol in ((vb.CallableModel(D, f, g), 0.0), (vb.CallableModel(D, value_and_grad=lambda x: (f(x), g(x))), 0.0),
+                       (vb.CallableModel(D, f), 1e-8)):
+        fo, go = np.full(N, np.nan), np.full((N, D), np.nan)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            assert model._trampoline(None, z.ctypes.data_as(dp), N, D, fo.ctypes.data_as(dp), go.ctypes.data_as(dp)) == 0
+            assert model._trampoline(None, z.ctypes.data_as(dp), N, D, fo.ctypes.data_as(dp), go.ctypes.data_as(dp)) == 0
+        assert len([x for x in w if 'central differences' in str(x.message)]) == (1 if tol else 0)
+        np.testing.assert_array_equal(fo, f(z))
+        assert np.max(np.abs(go - g(z))) <= tol * np.max(np.abs(g(z))) + (0.0 if tol else 0.0)
+        fo[:] = np.nan                                   # value-only call: grad pointer NULL
+        assert model._trampoline(None, z.ctypes.data_as(dp), N, D, fo.ctypes.data_as(dp), dp()) == 0
+        np.testing.assert_array_equal(fo, f(z))
+    bad = vb.CallableModel(D, lambda x: 1 / 0, g)
+    fo = np.zeros(N)
+    assert bad._trampoline(None, z.ctypes.data_as(dp), N, D, fo.ctypes.data_as(dp), dp()) == 1
+    assert isinstance(bad._error[0], ZeroDivisionError)
+    from viabel_amd.models import as_device_model
+    assert as_device_model(vb.GaussianModel([0, 0], [1, 1]), 2).dim == 2
+    assert isinstance(as_device_model(vb.Model(f), D), vb.CallableModel)
+    assert isinstance(as_device_model(f, D), vb.CallableModel)
+    with pytest.raises(TypeError):
+        as_device_model(3.0, D)
+    with pytest.raises(ValueError):
+        vb.CallableModel(D)
+
+
+def test_dis_tempering_prior_specs_and_clip_fixed_point():
+    """DISInclusiveKL host logic without a GPU: any family as tempering prior becomes the engine's spec
+    (objectives.py:283-285), and the clipping (``:370-386``) is the oracle's fixed point."""
+    from oracle import families as ofam
+    from oracle import objectives as oobj
+    from viabel_amd import _lib
+    from viabel_amd.objectives import DISInclusiveKL
+    D = 5
+    rng = np.random.RandomState(3)
+    dis = DISInclusiveKL.__new__(DISInclusiveKL)
+    A = rng.randn(D, D)
+    S = A @ A.T / D + np.eye(D)
+    x = rng.randn(6, D)
+    for prior, oprior, params in (
+            (vb.MFStudentT(D, 7.0), ofam.MFStudentT(D, 7.0), np.concatenate([rng.randn(D), 0.1 * rng.randn(D)])),
+            (vb.FullRankGaussian(D), ofam.FullRankGaussian(D), vb.FullRankGaussian(D).pack(rng.randn(D), np.linalg.cholesky(S))),
+            (vb.MultivariateT(D, 9.0), ofam.MultivariateT(D, 9.0), np.concatenate([rng.randn(D), ofam.psd_to_free(S)])),
+            (vb.LRGaussian(D, k=2), ofam.LRGaussian(D, 2), np.concatenate([rng.randn(D), 0.1 * rng.randn(D), rng.randn(2 * D)]))):
+        dis._temper_prior, dis._temper_prior_params = prior, np.asarray(params, dtype=float)
+        spec, arg = dis._build_prior_spec(D)
+        assert arg.shape == (2 * D,) and spec is not None
+        kind, df, loc, scale, logdet = spec
+        want = oprior.log_density(params, x)
+        if kind == _lib.PRIOR_DIAG_STUDENT_T:
+            from scipy import stats
+            got = np.sum(stats.t.logpdf((x - loc) * np.exp(-scale), df) - scale, axis=1)
+        else:
+            u = (x - loc) @ scale.T
+            maha = np.sum(u * u, axis=1)
+            if df > 0:
+                from scipy.special import gammaln
+                got = (gammaln(0.5 * (df + D)) - gammaln(0.5 * df) - 0.5 * D * np.log(np.pi * df) - logdet
+                       - 0.5 * (df + D) * np.log1p(maha / df))
+            else:
+                got = -0.5 * D * np.log(2 * np.pi) - logdet - 0.5 * maha
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    dis._temper_prior, dis._temper_prior_params = vb.MFGaussian(D), np.zeros(2 * D)
+    assert dis._build_prior_spec(D)[0] is None
+    dis._temper_prior_params = np.zeros(3)
+    with pytest.raises(ValueError):
+        dis._build_prior_spec(D)
+    ref = oobj.DISInclusiveKL.__new__(oobj.DISInclusiveKL)
+    for seed in range(40):
+        w = np.exp(np.random.RandomState(seed).randn(300) * 3)
+        for thr in (0.02, 0.1, 10):
+            dis._w_clip_threshold = ref._w_clip_threshold = thr
+            np.testing.assert_array_equal(dis._clip_weights(w), ref._clip(w))
+
+
+def test_mt19937_jump_table_against_numpy():
+    """The committed jump-ahead polynomials (viabel_amd/csrc/vb_mt_jump.h, tools/make_mt_jump.py): the correlation of
+    polynomial k with the sequence generated from a block equals the block 624 * 256 * 2^k words later, as numpy's own
+    generator reaches it (k = 0 and 3 here; the generator script checks 0-2 and the squaring chain when it writes them)."""
+    import re
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('make_mt_jump', os.path.join(root, 'tools', 'make_mt_jump.py'))
+    mj = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mj)
+    text = open(os.path.join(root, 'viabel_amd', 'csrc', 'vb_mt_jump.h')).read()
+    assert 'kMtBlocksPerStream = %d' % mj.BLOCKS_PER_STREAM in text
+    rows = re.findall(r'\{((?:0x[0-9a-f]{8}u,?)+)\}', text)
+    assert len(rows) == mj.K
+    for k in (0, 3):
+        words = [int(x[:-1], 16) for x in rows[k].split(',') if x]
+        assert len(words) == mj.N
+        g = sum(w << (32 * i) for i, w in enumerate(words))
+        m = mj.BLOCKS_PER_STREAM << k
+        rs = np.random.RandomState(4242 + k)
+        b1 = mj.refresh(rs.get_state()[1])
+        rs.random_sample(mj.N * m // 2)                  # two words per draw: 624 m words
+        st = rs.get_state()
+        assert st[2] == mj.N
+        assert mj.jump_by_correlation(b1, g) == [int(x) for x in mj.refresh(st[1])]

@@ -362,7 +362,17 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
       double s = 0.0;
       // log(1 + y) for log1p(y): the ABSOLUTE error of a term is what the mean sees, and that is one rounding of 1 + y
       // (<= 1.1e-16) either way; log costs half of what log1p does, and these m n2 evaluations are the phase's time
-      for (int i = gl; i < n2; i += 16) s += log(fma(nb, tv[i], 1.0));
+      // four logarithms in flight per lane (independent chains: the evaluation is latency-bound), added in the same order
+      int i = gl;
+      for (; i + 48 < n2; i += 64) {
+        const double l0 = log(fma(nb, tv[i], 1.0)), l1 = log(fma(nb, tv[i + 16], 1.0)), l2 = log(fma(nb, tv[i + 32], 1.0)),
+                     l3 = log(fma(nb, tv[i + 48], 1.0));
+        s += l0;
+        s += l1;
+        s += l2;
+        s += l3;
+      }
+      for (; i < n2; i += 16) s += log(fma(nb, tv[i], 1.0));
 #pragma unroll
       for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
       if (gl == 0) {
