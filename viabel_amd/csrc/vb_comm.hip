@@ -51,7 +51,10 @@ __device__ __forceinline__ bool ipc_wait(const double* const* win, int n_ranks, 
   bool ok = true;
   if (threadIdx.x == 0) {
     for (int p = 0; p < n_ranks; ++p) {
-      if (p == self) continue;
+      // (the own word too for the publish phase: a collective issued on another stream of this context must not
+      // overwrite the window before this rank's previous read-back has finished -- the peers could otherwise move on
+      // and rewrite the result areas it is still reading)
+      if (p == self && word != 2) continue;
       const unsigned long long* f = reinterpret_cast<const unsigned long long*>(win[p]) + word;
       unsigned spins = 0;
       while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {

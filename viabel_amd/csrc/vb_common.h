@@ -221,6 +221,7 @@ struct vb_ctx {
   vb::DeviceBuffer legacy_work;
   const void* legacy_poly_at = nullptr;
   size_t legacy_poly_bytes = 0;
+  bool legacy_table_ready = false;      // the double-double log's table is in this device's constant memory
   double* legacy_pin = nullptr;         // pinned staging of the device draw's results
   size_t legacy_pin_doubles = 0;
   // fused full-rank evaluation (vb_fullrank_fused.h): ticket counter, error word and tile flags; the work list

@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256) mtd_emit_kernel(const EmitArgs a) {
       // one-in-2^52 event, simply handed to the host)
       int e_hi;
       const bool pow2 = frexp(L.hi, &e_hi) == -0.5;
-      if (fabs(L.lo) > 0.47 * ulp || pow2) {
+      if (fabs(L.lo) > 0.478 * ulp || pow2) {
         const double alt = L.lo > 0.0 ? nextafter(L.hi, INFINITY) : nextafter(L.hi, -INFINITY);
         const double f2 = sqrt(-2.0 * alt / r2);
         hard = (f2 * x2 != v0) || (f2 * x1 != v1) || pow2;
@@ -416,8 +416,7 @@ __global__ void mtd_first_value_kernel(const EmitArgs a, double v) { put_value(a
 int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, double* gauss, const NoiseSlot& ns,
                      int64_t n_total, int64_t d, int64_t row_begin, int64_t rows) {
   hipStream_t st = ctx->stream;
-  static bool table_ready = false;
-  if (!table_ready) {
+  if (!ctx->legacy_table_ready) {      // (constant memory is per device: once per context, not once per process)
     // log(k / 32) in double-double by the long series on the host: 2 atanh(s), s = (c - 1) / (c + 1), |s| <= 0.17,
     // 40 terms (s^2 <= 0.03: 2^-200), every operation in double-double
     double hi[23], lo[23];
@@ -437,7 +436,7 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
     }
     VB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(kLogTabHi), hi, sizeof hi));
     VB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(kLogTabLo), lo, sizeof lo));
-    table_ready = true;
+    ctx->legacy_table_ready = true;
   }
   const int64_t total = n_total * d;
   const int64_t first = (*has_gauss && total > 0) ? 1 : 0;
