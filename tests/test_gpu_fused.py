@@ -63,3 +63,41 @@ def test_fused_evaluation_is_bit_identical_to_the_launch_chain(D, N, mode):
         ov, og = oobj.exclusive_kl(ofam.FullRankGaussian(D), omod.GaussFull(model.mean, model.precision), theta, noise)
         assert abs(v1 - ov) / abs(ov) < 1e-12
         assert np.max(np.abs(g1 - og)) / np.max(np.abs(og)) < 1e-11
+
+
+@pytest.mark.parametrize('mode', [2, 3])
+def test_fused_hand_offs_see_fresh_data_when_the_parameter_changes(mode):
+    """The hand-offs inside the launch (write-through stores, flags, sc1 loads) must deliver THIS evaluation's Z and G,
+    not lines of the previous evaluation that a cache still holds: evaluate at theta_a, then at a different theta_b in
+    the same buffers (noise slot changed too), and compare with the launch chain at theta_b -- same bits."""
+    from viabel_amd import _lib
+    D, N = 512, 2048
+    vb, model, theta_a = _problem(D, N, seed=5)
+    rng = np.random.RandomState(9)
+    approx = vb.FullRankGaussian(D)
+    L = np.tril(0.1 * rng.randn(D, D), -1) + np.diag(np.exp(-0.3 + 0.2 * rng.randn(D)))
+    theta_b = approx.pack(1.5 * rng.randn(D), L)
+    eng = _lib.default_engine()
+    eng.set_model(model.device_spec())
+    eng.noise_generate(3, N, D, seed=5, stream=1)
+    eng.noise_generate(4, N, D, seed=5, stream=2)
+    old = os.environ.get('VB_FR_FUSED')
+    try:
+        os.environ['VB_FR_FUSED'] = '0'
+        eng.fullrank_set_theta(theta_b, D)
+        eng.elbo_grad_fullrank_enqueue(4, N, D)
+        v_ref, g_ref = eng.fullrank_get(D)
+        os.environ['VB_FR_FUSED'] = str(mode)
+        for _ in range(2):
+            eng.fullrank_set_theta(theta_a, D)
+            eng.elbo_grad_fullrank_enqueue(3, N, D)
+            eng.fullrank_set_theta(theta_b, D)
+            eng.elbo_grad_fullrank_enqueue(4, N, D)
+            v, g = eng.fullrank_get(D)
+            assert abs(v - v_ref) <= 4e-15 * abs(v_ref)
+            np.testing.assert_array_equal(g, g_ref)
+    finally:
+        if old is None:
+            del os.environ['VB_FR_FUSED']
+        else:
+            os.environ['VB_FR_FUSED'] = old

@@ -27,6 +27,9 @@ def _worker(rank, world, port, q, occupy_first):
         g.barrier()
         assert g.allreduce_max(float(rank) + 0.25) == world - 1 + 0.25
         assert g.allreduce_sum(float(rank + 1)) == world * (world + 1) / 2
+        # every rank's 64-byte IPC window handle on every rank, in rank order (attach(..., transport='ipc'))
+        got = g.allgather_bytes(bytes([rank]) * 64)
+        assert got == [bytes([r]) * 64 for r in range(world)]
         for i in range(50):                  # many back-to-back collectives stay paired
             assert g.allreduce_max(i * 10.0 + rank) == i * 10.0 + world - 1
         g.barrier()
@@ -71,6 +74,7 @@ def test_single_rank_group_is_trivial():
     g.barrier()
     assert g.allreduce_max(3.5) == 3.5
     assert g.broadcast_bytes(b'x') == b'x'
+    assert g.allgather_bytes(b'abc') == [b'abc']
     g.close()
 
 
