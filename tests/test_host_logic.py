@@ -352,8 +352,8 @@ def test_dis_tempering_prior_specs_and_clip_fixed_point():
 
 def test_mt19937_jump_table_against_numpy():
     """The committed jump-ahead polynomials (viabel_amd/csrc/vb_mt_jump.h, tools/make_mt_jump.py): the correlation of
-    polynomial k with the sequence generated from a block equals the block 624 * 256 * 2^k words later, as numpy's own
-    generator reaches it (k = 0 and 3 here; the generator script checks 0-2 and the squaring chain when it writes them)."""
+    a polynomial with the sequence generated from a block equals the block that many words later, as numpy's own
+    generator reaches it (three rows here; the generator script checks five more when it writes the table)."""
     import re
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -363,13 +363,13 @@ def test_mt19937_jump_table_against_numpy():
     text = open(os.path.join(root, 'viabel_amd', 'csrc', 'vb_mt_jump.h')).read()
     assert 'kMtBlocksPerStream = %d' % mj.BLOCKS_PER_STREAM in text
     rows = re.findall(r'\{((?:0x[0-9a-f]{8}u,?)+)\}', text)
-    assert len(rows) == mj.K
-    for k in (0, 3):
-        words = [int(x[:-1], 16) for x in rows[k].split(',') if x]
+    assert len(rows) == 3 * mj.R
+    for row in (0, 4, 6):                                # jumps of 1, 2 x 4 and 1 x 16 streams
+        words = [int(x[:-1], 16) for x in rows[row].split(',') if x]
         assert len(words) == mj.N
         g = sum(w << (32 * i) for i, w in enumerate(words))
-        m = mj.BLOCKS_PER_STREAM << k
-        rs = np.random.RandomState(4242 + k)
+        m = mj.BLOCKS_PER_STREAM * (row % 3 + 1) * 4 ** (row // 3)
+        rs = np.random.RandomState(4242 + row)
         b1 = mj.refresh(rs.get_state()[1])
         rs.random_sample(mj.N * m // 2)                  # two words per draw: 624 m words
         st = rs.get_state()

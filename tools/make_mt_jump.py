@@ -7,8 +7,9 @@ found here with Berlekamp-Massey from one output bit stream.  For a jump of J wo
     u[n + J] = XOR over { i : coefficient i of g_J is 1 } of u[n + i]          (all 32 bits, n >= 0)
 for the sequence u of untempered state words from the first refreshed block onward (Haramoto, Matsumoto, Nishimura,
 Panneton, L'Ecuyer: "Efficient jump ahead for F2-linear random number generators", 2008) -- so the state 624 * B * 2^k
-words ahead of a known block is a correlation of g with 20 560 words generated from that block, and 2^k streams become
-2^(k+1) per round.  The table holds g for J = 624 * BLOCKS_PER_STREAM * 2^k, k = 0 .. K - 1.
+words ahead of a known block is a correlation of g with 20 560 words generated from that block, and 4^r streams become
+4^(r+1) per round (three jumps per known stream).  The table holds g for J = 624 * BLOCKS_PER_STREAM * a * 4^r,
+r = 0 .. R - 1, a = 1, 2, 3 (row 3 r + a - 1).
 
 Integer work: checked here against numpy's own generator (RandomState.random_sample consumes two words per draw) for
 the first rounds and by the squaring identity for all of them; tests/test_legacy_rng_cpu.py re-checks the committed
@@ -21,7 +22,7 @@ import numpy as np
 
 N, M, DEG = 624, 397, 19937
 BLOCKS_PER_STREAM = 256
-K = 10
+R = 5                     # rounds of the radix-4 ladder: up to 4^5 = 1024 streams
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), 'viabel_amd', 'csrc', 'vb_mt_jump.h')
 
@@ -134,33 +135,38 @@ def main():
                     acc ^= s[n + DEG - j]
             assert acc == s[n + DEG], lane
     W = N * BLOCKS_PER_STREAM
-    polys = [polypow_x(W, phi)]
-    for k in range(1, K):
-        polys.append(polymod(clmul(polys[-1], polys[-1]), phi))
+    polys, jumps = [], []                          # row 3 r + a - 1: jump of a 4^r streams
+    base = polypow_x(W, phi)
+    for r in range(R):
+        two = polymod(clmul(base, base), phi)
+        three = polymod(clmul(two, base), phi)
+        polys += [base, two, three]
+        jumps += [BLOCKS_PER_STREAM * a * 4 ** r for a in (1, 2, 3)]
+        base = polymod(clmul(two, two), phi)       # x^(W 4^(r+1))
     # against numpy: after consuming 624 m words from a fresh seed the state is block m with pos = 624
-    for k in range(3):
-        m = BLOCKS_PER_STREAM << k
-        rs2 = np.random.RandomState(99 + k)
+    for row in (0, 1, 2, 3, 5):
+        m = jumps[row]
+        rs2 = np.random.RandomState(99 + row)
         b1 = refresh(rs2.get_state()[1])
         rs2.random_sample(N * m // 2)               # two words per draw
         st = rs2.get_state()
         assert st[2] == N
-        want = refresh(st[1])                       # block m + 1 = the block W 2^k words after block 1
-        got = jump_by_correlation(b1, polys[k])
-        assert got == [int(x) for x in want], 'jump polynomial %d fails against numpy' % k
+        want = refresh(st[1])                       # block m + 1 = the block 624 m words after block 1
+        got = jump_by_correlation(b1, polys[row])
+        assert got == [int(x) for x in want], 'jump polynomial %d fails against numpy' % row
         print('jump 624 x %d words: correlation equals numpy\'s state' % m)
     with open(OUT, 'w') as f:
         f.write('// GENERATED by tools/make_mt_jump.py -- do not edit.  Jump-ahead polynomials of MT19937:\n'
-                '// kMtJump[k] = x^(624 * kMtBlocksPerStream * 2^k) mod phi(x), phi the characteristic polynomial of the\n'
-                '// recurrence (degree 19937), coefficient i in bit (i & 31) of word (i >> 5).\n#pragma once\n#include <cstdint>\n'
-                'namespace vb {\nconstexpr int kMtBlocksPerStream = %d;\nconstexpr int kMtJumpPolys = %d;\n'
-                'constexpr int kMtJumpWords = %d;\n' % (BLOCKS_PER_STREAM, K, N))
+                '// kMtJump[3 r + a - 1] = x^(624 * kMtBlocksPerStream * a * 4^r) mod phi(x), a = 1, 2, 3, phi the characteristic\n'
+                '// polynomial of the recurrence (degree 19937), coefficient i in bit (i & 31) of word (i >> 5).\n#pragma once\n'
+                '#include <cstdint>\nnamespace vb {\nconstexpr int kMtBlocksPerStream = %d;\nconstexpr int kMtJumpRounds = %d;\n'
+                'constexpr int kMtJumpPolys = %d;\nconstexpr int kMtJumpWords = %d;\n' % (BLOCKS_PER_STREAM, R, 3 * R, N))
         f.write('static const uint32_t kMtJump[kMtJumpPolys][kMtJumpWords] = {\n')
         for g in polys:
             words = [(g >> (32 * i)) & 0xffffffff for i in range(N)]
             f.write('{' + ','.join('0x%08xu' % x for x in words) + '},\n')
         f.write('};\n}  // namespace vb\n')
-    print('wrote %s (%d polynomials)' % (OUT, K))
+    print('wrote %s (%d polynomials)' % (OUT, 3 * R))
 
 
 if __name__ == '__main__':

@@ -10,7 +10,7 @@
 //   * the word stream, in parallel.  MT19937 is one linear recurrence over GF(2); the state J words ahead of a known
 //     block is the correlation of the jump polynomial x^J mod phi (vb_mt_jump.h, made and checked against numpy by
 //     tools/make_mt_jump.py) with 20 560 words generated from that block.  Streams of 256 blocks each: the known
-//     stream starts double every round (mtd_seq_kernel + mtd_corr_kernel), then one workgroup per stream runs the recurrence
+//     stream starts quadruple every round (mtd_seq_kernel + mtd_corr_kernel: three jumps per known stream), then one workgroup per stream runs the recurrence
 //     (mtd_stream_kernel: 227-way parallel inside a block, the block in registers, one barrier per block).
 //   * the attempts: words -> two 53-bit doubles -> x1, x2, r2, accepted? (exact arithmetic, no fused multiply-adds:
 //     this file is compiled with -ffp-contract=off, as numpy's build of that code has none), acceptance counts per
@@ -130,13 +130,17 @@ __global__ void __launch_bounds__(256) mtd_seq_kernel(const uint32_t* __restrict
   }
 }
 
-constexpr int kCorrHalf = kN / 2;                 // outputs per workgroup: blockIdx.z selects words [0, 312) or [312, 624)
-__global__ void __launch_bounds__(320) mtd_corr_kernel(const uint32_t* __restrict__ poly, const uint32_t* __restrict__ seq,
-                                                       uint32_t* __restrict__ state, int count, int n_new) {
+constexpr int kCorrHalf = kN / 2;                 // outputs per workgroup: blockIdx.z & 1 selects words [0, 312) or [312, 624)
+// blockIdx.z >> 1 = a - 1: the jump of a * count streams (polynomial row `poly_row0 + a - 1`), target stream a * count + s
+__global__ void __launch_bounds__(320) mtd_corr_kernel(const uint32_t* __restrict__ polys, int poly_row0,
+                                                       const uint32_t* __restrict__ seq, uint32_t* __restrict__ state,
+                                                       int count, int streams) {
   __shared__ uint32_t u[kSlice + kCorrHalf];
   __shared__ uint32_t g[kSlice / 32];
-  const int s = blockIdx.x, slice = blockIdx.y, j0 = blockIdx.z * kCorrHalf, tt = threadIdx.x;
-  if (s >= n_new) return;
+  const int s = blockIdx.x, slice = blockIdx.y, j0 = (blockIdx.z & 1) * kCorrHalf, a = (blockIdx.z >> 1) + 1, tt = threadIdx.x;
+  const int target = a * count + s;
+  if (target >= streams) return;
+  const uint32_t* poly = polys + (size_t)(poly_row0 + a - 1) * kN;
   const uint32_t* src = seq + (size_t)s * kSeqWords + slice * kSlice + j0;
   for (int i = tt; i < kSlice + kCorrHalf; i += 320) u[i] = src[i];
   if (tt < kSlice / 32) g[tt] = slice * (kSlice / 32) + tt < kN ? poly[slice * (kSlice / 32) + tt] : 0u;
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(320) mtd_corr_kernel(const uint32_t* __restric
 #pragma unroll
     for (int b = 0; b < 32; ++b) acc ^= (0u - ((gw >> b) & 1u)) & u[32 * w + b + tt];
   }
-  atomicXor(&state[(size_t)(count + s) * kN + t], acc);      // integer: the result does not depend on the order
+  atomicXor(&state[(size_t)target * kN + t], acc);      // integer: the result does not depend on the order
 }
 
 // stream s: blocks [s B, min((s + 1) B, n_blocks)) of the stream into words[pre + block * 624 ...] (untempered)
@@ -450,7 +454,7 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
   const int64_t pre = kN - *pos;                                      // unread words of the current block
   const int64_t n_blocks = n_words > pre ? (n_words - pre + kN - 1) / kN : 1;
   const int64_t streams = (n_blocks + kMtBlocksPerStream - 1) / kMtBlocksPerStream;
-  if (streams > ((int64_t)1 << kMtJumpPolys)) return VB_ERR_UNSUPPORTED;
+  if (streams > ((int64_t)1 << (2 * kMtJumpRounds))) return VB_ERR_UNSUPPORTED;
   const int64_t n_wg = (attempts + kAttemptsPerWg - 1) / kAttemptsPerWg;
   const int64_t hard_cap = pairs / 8 + 1024;
 
@@ -461,12 +465,12 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
     off += (words32 + 3) & ~(size_t)3;
     return o;
   };
-  int64_t pow2 = 1;
-  while (pow2 < streams) pow2 <<= 1;
+  int64_t pow2 = 1;      // (capacity of the state / sequence areas: a power of four)
+  while (pow2 < streams) pow2 <<= 2;
   // (fixed-size regions first: the polynomials stay where they were uploaded from call to call)
   const size_t o_poly = carve((size_t)kMtJumpPolys * kN), o_key = carve(kN), o_scal = carve(16),
                o_words = carve((size_t)(pre + n_blocks * kN) + 8), o_state = carve((size_t)pow2 * kN),
-               o_seq = carve((size_t)(pow2 / 2 > 0 ? pow2 / 2 : 1) * kSeqWords), o_cnt = carve((size_t)n_wg),
+               o_seq = carve((size_t)(pow2 / 4 > 0 ? pow2 / 4 : 1) * kSeqWords), o_cnt = carve((size_t)n_wg),
                o_base = carve(2 * (size_t)(n_wg + 1)), o_hard = carve(2 * 4 * (size_t)hard_cap),
                o_hseg = carve(2 * 4 * (size_t)n_wg * kHardPerWg), o_hcnt = carve((size_t)n_wg), o_hbase = carve(2 * (size_t)(n_wg + 1)),
                o_fixed = carve(2 * 3 * (size_t)hard_cap);
@@ -482,12 +486,12 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
   VB_HIP(ctx, hipMemsetAsync(state, 0, (size_t)pow2 * kN * sizeof(uint32_t), st));
   VB_HIP(ctx, hipMemsetAsync(base + o_scal, 0, 16 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(mtd_first_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)key_dev, *pos, words, state);
-  int k = 0;
-  for (int64_t count = 1; count < streams; count <<= 1, ++k) {
-    const int n_new = (int)std::min<int64_t>(count, streams - count);
-    hipLaunchKernelGGL(mtd_seq_kernel, dim3((unsigned)n_new), dim3(256), 0, st, (const uint32_t*)state, seq);
-    hipLaunchKernelGGL(mtd_corr_kernel, dim3((unsigned)n_new, kCorrSlices, 2), dim3(320), 0, st,
-                       (const uint32_t*)(poly + (size_t)k * kN), (const uint32_t*)seq, state, (int)count, n_new);
+  int r = 0;
+  for (int64_t count = 1; count < streams; count <<= 2, ++r) {      // radix 4: the known stream starts quadruple per round
+    const int n_src = (int)std::min<int64_t>(count, streams - count);      // sources with at least one target
+    hipLaunchKernelGGL(mtd_seq_kernel, dim3((unsigned)n_src), dim3(256), 0, st, (const uint32_t*)state, seq);
+    hipLaunchKernelGGL(mtd_corr_kernel, dim3((unsigned)n_src, kCorrSlices, 6), dim3(320), 0, st, (const uint32_t*)poly, 3 * r,
+                       (const uint32_t*)seq, state, (int)count, (int)streams);
   }
   hipLaunchKernelGGL(mtd_stream_kernel, dim3((unsigned)streams), dim3(256), 0, st, (const uint32_t*)state, words, pre, n_blocks);
   int* cnt = (int*)(base + o_cnt);
