@@ -159,6 +159,8 @@ __global__ void alpha_value_kernel(const double* mx, const double* sum_s, double
 }
 
 // ---- host ---------------------------------------------------------------------------------------------
+static int alpha_scalars_enqueue(vb_ctx* ctx, const double* f, const double* b, double* scal, int64_t n, int64_t n_total,
+                                 double alpha, double* roww);
 // Z = mu + exp(log_sigma) * E, materialised for a source model's row kernel (the built-in targets never need it)
 __global__ void __launch_bounds__(256) rs_sample_kernel(const double* __restrict__ theta_src, const double* __restrict__ noise,
                                                         int64_t ld, double* __restrict__ Z, int64_t ldz, int64_t n, int d) {
@@ -217,18 +219,7 @@ int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, 
   double* base = (double*)ctx->rowvec.ptr;
   double* scal = base + o_scal;
   VB_TRY(rowstats_enqueue(ctx, ns, n, d, theta_src, ctx->model, student, df, base, scal, base + o_f, base + o_b));
-  hipLaunchKernelGGL(alpha_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + o_f),
-                     (const double*)(base + o_b), (const double*)scal, n, scal + 8);
-  VB_HIP(ctx, hipGetLastError());
-  VB_TRY(comm_allreduce_max(ctx, st, scal + 8, 1));
-  hipLaunchKernelGGL(alpha_weights_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + o_f),
-                     (const double*)(base + o_b), (const double*)scal, (const double*)(scal + 8), n, alpha,
-                     base + o_w, scal + 9);
-  VB_HIP(ctx, hipGetLastError());
-  VB_TRY(comm_allreduce_sum(ctx, st, scal + 9, 1));
-  hipLaunchKernelGGL(alpha_value_kernel, dim3(1), dim3(1), 0, st, (const double*)(scal + 8),
-                     (const double*)(scal + 9), (double)n_total, alpha, scal + 10);
-  VB_HIP(ctx, hipGetLastError());
+  VB_TRY(alpha_scalars_enqueue(ctx, base + o_f, base + o_b, scal, n, n_total, alpha, base + o_w));      // max -> weights -> value
   MfCall c;
   c.count = 1;
   c.noise[0] = &ns;
