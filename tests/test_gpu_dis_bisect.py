@@ -1,0 +1,119 @@
+"""The tempering bisection of DISInclusiveKL (objectives.py:338-368) on the device: the speculative walk of
+vb_dis_bisect.hip against the look-ahead rounds it replaced (VB_DIS_BISECT=0: every midpoint of six levels per launch)
+and against itself with one round only (VB_DIS_ROUNDS=1: the final kernel finishes the walk level by level).  All
+three make the reference's comparisons at the reference's midpoints; they differ in the order in which a candidate's
+N weights are summed (two, four and one block), so a decision can flip only where ESS(eps) equals the target to
+rounding: eps agrees to 1e-13 absolute, ESS and the weights to 1e-9 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vb():
+    import viabel_amd
+    from viabel_amd import _lib
+    _lib.default_engine()
+    return viabel_amd
+
+
+def run(vb, D, N, target, its, eps_prev, shift, env):
+    saved = {k: os.environ.get(k) for k in ('VB_DIS_BISECT', 'VB_DIS_ROUNDS')}
+    for k in saved:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        rng = np.random.RandomState(7)
+        model = vb.GaussianModel(shift + 0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D)))
+        approx = vb.MFGaussian(D, seed=11, rng='philox')
+        # q next to the tempering prior (ESS(1) close to N), the target shifted away (ESS(0) small): interior root
+        prior = np.concatenate([np.zeros(D), np.zeros(D)])
+        obj = vb.DISInclusiveKL(approx, model, N, ess_target=target, temper_prior=vb.MFGaussian(D),
+                                temper_prior_params=prior, use_resampling=False)
+        obj._max_bisection_its = its
+        obj._eps = eps_prev
+        theta = prior + 0.02 * rng.randn(2 * D)
+        value, grad = obj(theta)
+        return obj._eps, obj._ess, np.array(obj._state_w_clipped), value, grad
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+CASES = [
+    # D, N, ess_target, max_bisection_its, eps_prev, mean shift of the target
+    (16, 4096, 400, 50, 1.0, 0.5),       # root inside (0, 1)
+    (16, 4096, 400, 50, 0.37, 0.5),      # an interval whose midpoints are not exact dyadic fractions
+    (64, 16384, 1500, 50, 1.0, 0.3),
+    (8, 1000, 999.99, 50, 1.0, 0.2),     # target above every ESS: lower moves 50 times, eps = max_eps
+    (8, 1000, 1.0, 50, 1.0, 0.2),        # target below every ESS: upper moves 50 times, eps = 0
+    (16, 4096, 400, 0, 1.0, 0.5),
+    (16, 4096, 400, 1, 1.0, 0.5),
+    (16, 4096, 400, 5, 1.0, 0.5),
+    (16, 4096, 400, 6, 1.0, 0.5),
+    (16, 4096, 400, 7, 1.0, 0.5),
+    (16, 4096, 400, 13, 0.8, 0.5),
+    (16, 4096, 400, 80, 1.0, 0.5),       # beyond the resolution of a double: the interval stops shrinking
+    (16, 4096, 400, 130, 0.61, 0.5),
+    (32, 333, 40, 50, 1.0, 1.0),         # ragged sample count
+]
+
+
+@pytest.mark.parametrize('D,N,target,its,eps_prev,shift', CASES)
+def test_speculative_walk_equals_lookahead_rounds(vb, D, N, target, its, eps_prev, shift):
+    new = run(vb, D, N, target, its, eps_prev, shift, {})
+    old = run(vb, D, N, target, its, eps_prev, shift, {'VB_DIS_BISECT': '0'})
+    one = run(vb, D, N, target, its, eps_prev, shift, {'VB_DIS_ROUNDS': '1'})
+    for other in (old, one):
+        assert abs(new[0] - other[0]) <= 1e-13, (new[0], other[0])
+        assert abs(new[1] - other[1]) <= 1e-9 * abs(other[1]), (new[1], other[1])
+        assert np.allclose(new[2], other[2], rtol=1e-9, atol=0.0)
+        assert abs(new[3] - other[3]) <= 1e-9 * abs(other[3])
+        assert np.max(np.abs(new[4] - other[4])) <= 1e-9 * np.max(np.abs(other[4]))
+    if target == 999.99:
+        assert new[0] == 1.0
+    if target == 400 and its >= 50 and eps_prev == 1.0:
+        assert 0.0 < new[0] < 1.0
+    if target == 1.0:
+        assert new[0] == 0.0
+
+
+def test_literal_bisection_on_the_returned_logs(vb):
+    """eps from the device equals the reference's loop run in numpy on the device's own log p / log q / log prior."""
+    D, N, target = 16, 4096, 400
+    rng = np.random.RandomState(7)
+    model = vb.GaussianModel(0.5 + 0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D)))
+    approx = vb.MFGaussian(D, seed=11, rng='philox')
+    prior = np.zeros(2 * D)
+    obj = vb.DISInclusiveKL(approx, model, N, ess_target=target, temper_prior=vb.MFGaussian(D), temper_prior_params=prior,
+                            use_resampling=False)
+    theta = prior + 0.02 * rng.randn(2 * D)
+    obj(theta)
+    log_p, log_q = obj._state_log_p_unnormalized, obj._state_log_q
+    # samples from the same noise: z = mu + sigma * eps with eps recovered from log q is not possible; the prior's log
+    # density follows from the weights instead: log w = eps log prior + (1 - eps) log p - log q
+    w = np.array(obj._state_w_clipped)
+    eps = obj._eps
+    assert 0.0 < eps < 1.0
+    log_prior = (np.log(w) + log_q - (1.0 - eps) * log_p) / eps
+
+    def ess_at(e):
+        ww = np.exp(e * log_prior + (1.0 - e) * log_p - log_q)
+        return ww.sum() ** 2 / (ww ** 2).sum()
+
+    lower, upper = 0.0, 1.0
+    guess = 0.5
+    for _ in range(50):
+        if ess_at(guess) > target:
+            upper = guess
+        else:
+            lower = guess
+        guess = (lower + upper) / 2.0
+    assert abs(guess - eps) < 1e-9       # log prior is reconstructed to ~1e-13 relative, ESS'(eps) is O(1e3)
+    assert abs(ess_at(eps) - obj._ess) < 1e-6 * obj._ess

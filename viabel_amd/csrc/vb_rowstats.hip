@@ -212,7 +212,6 @@ int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, 
   if (ctx->model.dim != d) return fail(ctx, VB_ERR_INVALID, "model dimension != family dimension");
   if (n <= 0 || n > ns.n || d != ns.d || n_total < n) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   const int student = family == VB_FAMILY_MF_STUDENT_T;
-  hipStream_t st = ctx->stream;
   // scratch: [cols 2 ld | scal 16 | f n | b n | roww n];  scal: [0] sum log sigma, [8] max, [9] sum s, [10] value
   const int64_t o_scal = 2 * ns.ld, o_f = o_scal + 16, o_b = o_f + round_up(n, 16), o_w = o_b + round_up(n, 16);
   VB_TRY(ensure(ctx, ctx->rowvec, (size_t)(o_w + round_up(n, 16)) * sizeof(double)));
@@ -608,9 +607,11 @@ __global__ void __launch_bounds__(1024) dis_bisect_final_kernel(const double* __
   }
 }
 
-int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const double* lprior, const double* scal_in,
-                       int64_t n, double eps_prev, double ess_target, int max_its, double* w, double* lq_out,
-                       double* scal_out) {
+// (round 4: dis_bisect_enqueue is the speculative walk of vb_dis_bisect.hip; this one stays as its cross-check,
+// VB_DIS_BISECT=0)
+int dis_bisect_lookahead_enqueue(vb_ctx* ctx, const double* lp, const double* b, const double* lprior,
+                                 const double* scal_in, int64_t n, double eps_prev, double ess_target, int max_its,
+                                 double* w, double* lq_out, double* scal_out) {
   if (max_its < 0) return fail(ctx, VB_ERR_INVALID, "max_its must be >= 0");
   const int rounds = (max_its + kLook - 1) / kLook;
   // [state (rounds + 1) x 4 | res rounds x kLookTab]
