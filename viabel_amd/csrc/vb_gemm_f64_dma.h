@@ -166,8 +166,9 @@ __device__ __forceinline__ void gemm_f64_dma_tile(const GemmArgs& g, const Epi& 
         step[u] = kGemmBK;
       } else {               // k-major: (BM / 2) pairs per k row
         constexpr int PPR = BM / 2, RPU = 64 / PPR > 0 ? 64 / PPR : 1;     // pairs per row, rows per unit
-        const int krow = (PPR >= 64) ? q / (PPR / 64) : q * RPU + lane / PPR;
-        const int p = (PPR >= 64) ? (q % (PPR / 64)) * 64 + lane : lane % PPR;
+        constexpr int UPR = PPR >= 64 ? PPR / 64 : 1;                      // units per row (wide tiles)
+        const int krow = (PPR >= 64) ? q / UPR : q * RPU + lane / PPR;
+        const int p = (PPR >= 64) ? (q % UPR) * 64 + lane : lane % PPR;
         const int c = p;
         int64_t col = m0 + 2 * c;
         col = col < g.lda - 1 ? col : g.lda - 2;
@@ -178,8 +179,9 @@ __device__ __forceinline__ void gemm_f64_dma_tile(const GemmArgs& g, const Epi& 
     } else {
       const int qb = q - kAUnits;
       constexpr int PPR = BN / 2, RPU = 64 / PPR > 0 ? 64 / PPR : 1;
-      const int krow = (PPR >= 64) ? qb / (PPR / 64) : qb * RPU + lane / PPR;
-      const int p = (PPR >= 64) ? (qb % (PPR / 64)) * 64 + lane : lane % PPR;
+      constexpr int UPR = PPR >= 64 ? PPR / 64 : 1;
+      const int krow = (PPR >= 64) ? qb / UPR : qb * RPU + lane / PPR;
+      const int p = (PPR >= 64) ? (qb % UPR) * 64 + lane : lane % PPR;
       const int c = p;
       int64_t col = n0 + 2 * c;
       col = col < g.ldb - 1 ? col : g.ldb - 2;

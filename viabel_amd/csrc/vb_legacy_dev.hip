@@ -112,7 +112,6 @@ __global__ void __launch_bounds__(256) mtd_first_kernel(const uint32_t* __restri
 constexpr int kSeqBlocks = 34;                    // 34 x 624 = 21 216 >= 20 160 + 623 words
 constexpr int kSeqWords = kSeqBlocks * kN;
 constexpr int kSlice = 320;                       // coefficients per slice (10 words of the polynomial)
-constexpr int kWindow = kSlice + kN;              // sequence words a slice reads
 __global__ void __launch_bounds__(256) mtd_seq_kernel(const uint32_t* __restrict__ state, uint32_t* __restrict__ seq) {
   __shared__ uint32_t key[2][kN];
   const int t = threadIdx.x;

@@ -618,23 +618,73 @@ struct EpiSlabAny {          // slab_split[i][j] = acc, row stride ldc
   }
 };
 
-__global__ void __launch_bounds__(256) lrs_ones_kernel(double* w, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) w[i] = 1.0;
+// theta = [mu | log sigma | B (d x k, row-major)] on the device -> mu, sigma = exp(log sigma) (pads zero) and
+// B' (kp x ld, zero padded): the transposition and the exponentials the host loop used to do
+__global__ void __launch_bounds__(256) lrs_prep_kernel(const double* __restrict__ theta, int d, int k, int64_t ld, int kp,
+                                                       double* __restrict__ mu, double* __restrict__ sigma,
+                                                       double* __restrict__ bt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over (kp + 1) x ld
+  if (i >= (int64_t)(kp + 1) * ld) return;
+  const int row = (int)(i / ld), c = (int)(i % ld);
+  if (row == kp) {
+    mu[c] = c < d ? theta[c] : 0.0;
+    sigma[c] = c < d ? exp(theta[d + c]) : 0.0;
+  } else {
+    bt[i] = (c < d && row < k) ? theta[2 * (int64_t)d + (int64_t)c * k + row] : 0.0;
+  }
 }
 
-// one workgroup: out[0] = sum_n f[n] in a fixed order
-__global__ void __launch_bounds__(1024) lrs_fsum_kernel(const double* __restrict__ f, int64_t n, double* __restrict__ out) {
-  __shared__ double sh[16];
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) s += f[i];
-  s = lro_wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+// per 128-row block and column: sum_n G_nc and sum_n G_nc E_nc (the two column passes of the gradient in one read of G)
+__global__ void __launch_bounds__(256) lrs_colsums_kernel(const double* __restrict__ G, int64_t ldg,
+                                                          const double* __restrict__ E, int64_t lde, int64_t ld, int64_t n,
+                                                          int d, double* __restrict__ part /* [n_rb][2][ld] */) {
+  __shared__ double sh[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * 128, r1 = r0 + 128 < n ? r0 + 128 : n;
+  double sg = 0.0, se = 0.0;
+  if (c < d)
+    for (int64_t r = r0 + q; r < r1; r += 4) {
+      const double g = G[r * ldg + c];
+      sg += g;
+      se = fma(g, E[r * lde + c], se);
+    }
+  sh[0][q][threadIdx.x & 63] = sg;
+  sh[1][q][threadIdx.x & 63] = se;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int q = 0; q < 16; ++q) t += sh[q];
-    out[0] = t;
+  if (q < 2 && c < d) {
+    const int l = c & 63;
+    part[((int64_t)blockIdx.y * 2 + q) * ld + c] = (sh[q][0][l] + sh[q][1][l]) + (sh[q][2][l] + sh[q][3][l]);
+  }
+}
+
+// out = [sum f | sum g (d) | sum g eps (d) | sum g z' (d x k row-major)], every sum in a fixed order: element i of the
+// vector is one thread's; sum f is the first workgroup's
+__global__ void __launch_bounds__(256) lrs_finish_kernel(const double* __restrict__ f, int64_t n,
+                                                         const double* __restrict__ colpart, int n_rb, int64_t ld,
+                                                         const double* __restrict__ slabs, int splits, int64_t slab, int kp,
+                                                         int d, int k, double* __restrict__ out) {
+  __shared__ double sh[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = 2 * (int64_t)d + (int64_t)d * k;
+  if (i < total) {
+    double s = 0.0;
+    if (i < 2 * (int64_t)d) {
+      const int which = (int)(i / d), c = (int)(i % d);
+      for (int rb = 0; rb < n_rb; ++rb) s += colpart[((int64_t)rb * 2 + which) * ld + c];
+    } else {
+      const int64_t e = i - 2 * (int64_t)d;
+      const int64_t src = (e / k) * kp + e % k;
+      for (int q = 0; q < splits; ++q) s += slabs[q * slab + src];
+    }
+    out[1 + i] = s;
+  }
+  if (blockIdx.x == 0) {
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < n; j += 256) s += f[j];
+    s = lro_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
   }
 }
 
@@ -650,29 +700,27 @@ int lr_elbo_sums_any_rank(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz,
   const int n_rb = (int)((n + 127) / 128);
   int splits = (int)(n / 256);
   splits = splits > 32 ? 32 : (splits < 1 ? 1 : splits);
+  const int64_t p = 2 * d + d * k, n_out = 1 + p;
   int64_t off = 0;
   auto carve = [&off](int64_t doubles) {
     const int64_t o = off;
     off += round_up(doubles, 16);
     return o;
   };
-  const int64_t o_x = carve(n * ld), o_g = carve(n * ld), o_f = carve(n), o_w = carve(n), o_mu = carve(ld), o_sig = carve(ld),
-                o_bt = carve(kp * ld), o_col = carve((int64_t)n_rb * ld), o_slabs = carve((int64_t)splits * d * kp),
-                o_out = carve(1 + 2 * ld + d * kp);
+  const int64_t o_x = carve(n * ld), o_g = carve(n * ld), o_f = carve(n), o_theta = carve(p), o_mu = carve(ld),
+                o_sig = carve(ld), o_bt = carve(kp * ld), o_col = carve((int64_t)n_rb * 2 * ld),
+                o_slabs = carve((int64_t)splits * d * kp), o_out = carve(n_out);
   VB_TRY(ensure(ctx, ctx->lr_obj, (size_t)off * sizeof(double)));
   double* base = (double*)ctx->lr_obj.ptr;
   hipStream_t st = ctx->stream;
-  // parameter pieces: mu, sigma = exp(log sigma), B' (kp x ld, zero padded) -- O(D k) host work, like the objectives' upload
-  std::vector<double> h((size_t)(2 * ld + kp * ld), 0.0);
-  for (int64_t i = 0; i < d; ++i) {
-    h[i] = theta_host[i];
-    h[ld + i] = exp(theta_host[d + i]);
-    for (int64_t j = 0; j < k; ++j) h[2 * ld + j * ld + i] = theta_host[2 * d + i * k + j];
-  }
-  VB_HIP(ctx, hipMemcpyAsync(base + o_mu, h.data(), (size_t)ld * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(base + o_sig, h.data() + ld, (size_t)ld * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(base + o_bt, h.data() + 2 * ld, (size_t)(kp * ld) * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));      // `h` is stack-scoped
+  // the parameter goes up as it is, through the pinned staging area (no synchronisation: the call's last statement
+  // waits for the stream, so the area is free again when the next call writes it)
+  VB_TRY(ensure_pinned(ctx, (size_t)(p + n_out) * sizeof(double)));
+  memcpy(ctx->pin_host, theta_host, (size_t)p * sizeof(double));
+  VB_HIP(ctx, hipMemcpyAsync(base + o_theta, ctx->pin_host, (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(lrs_prep_kernel, dim3((unsigned)(((kp + 1) * ld + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + o_theta), (int)d, (int)k, ld, (int)kp, base + o_mu, base + o_sig, base + o_bt);
+  VB_HIP(ctx, hipGetLastError());
   const double* E = (const double*)ns.buf.ptr;
   const double* Z = (const double*)nz.buf.ptr;
   const int n_cu = ctx->prop.multiProcessorCount;
@@ -681,26 +729,10 @@ int lr_elbo_sums_any_rank(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz,
   g1.M = (int)n, g1.N = (int)d, g1.K = (int)kp, g1.tri_mode = 0;
   gemm_f64_launch<true>(st, g1, 1, n_cu, EpiLrSample{base + o_x, ld, base + o_mu, base + o_sig, E, ns.ld});
   VB_HIP(ctx, hipGetLastError());
-  VB_HIP(ctx, hipMemsetAsync(base + o_g, 0, (size_t)n * ld * sizeof(double), st));
+  // (pad columns of G are never read: the column pass and the product below stop at d)
   VB_TRY(model_grad_rows(ctx, base + o_x, ld, n, d, base + o_g, base + o_f));
-  double* outd = base + o_out;
-  hipLaunchKernelGGL(lrs_fsum_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + o_f), n, outd);
-  hipLaunchKernelGGL(lrs_ones_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, base + o_w, n);
-  VB_HIP(ctx, hipGetLastError());
-  VB_HIP(ctx, hipMemsetAsync(outd + 1, 0, (size_t)(2 * ld) * sizeof(double), st));
-  // sum_n g_n eps_n per column: the weighted column-product pass with unit weights
-  hipLaunchKernelGGL(lro_colsum_prod_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)n_rb), dim3(256), 0, st,
-                     (const double*)(base + o_g), ld, E, ns.ld, ld, (const double*)(base + o_w), n, (int)d, base + o_col);
-  hipLaunchKernelGGL(lro_slab_sum_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, st,
-                     (const double*)(base + o_col), n_rb, ld, outd + 1 + ld, d);
-  VB_HIP(ctx, hipGetLastError());
-  // sum_n g_n: the same pass against a row of ones re-read for every sample (row stride 0; X is free again)
-  hipLaunchKernelGGL(lrs_ones_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, st, base + o_x, ld);
-  hipLaunchKernelGGL(lro_colsum_prod_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)n_rb), dim3(256), 0, st,
-                     (const double*)(base + o_g), ld, (const double*)(base + o_x), (int64_t)0, ld,
-                     (const double*)(base + o_w), n, (int)d, base + o_col);
-  hipLaunchKernelGGL(lro_slab_sum_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, st,
-                     (const double*)(base + o_col), n_rb, ld, outd + 1, d);
+  hipLaunchKernelGGL(lrs_colsums_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)n_rb), dim3(256), 0, st,
+                     (const double*)(base + o_g), ld, E, ns.ld, ld, n, (int)d, base + o_col);
   VB_HIP(ctx, hipGetLastError());
   GemmArgs g2;                                  // G' Z: d x kp, contraction over the n samples
   g2.A = base + o_g, g2.lda = ld, g2.B = Z, g2.ldb = nz.ld;
@@ -708,16 +740,16 @@ int lr_elbo_sums_any_rank(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz,
   const int64_t slab = d * kp;
   gemm_f64_launch<false>(st, g2, splits, n_cu, EpiSlabAny{base + o_slabs, kp, slab});
   VB_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(lro_slab_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st,
-                     (const double*)(base + o_slabs), splits, slab, outd + 1 + 2 * ld, slab);
+  double* outd = base + o_out;
+  hipLaunchKernelGGL(lrs_finish_kernel, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, st, (const double*)(base + o_f), n,
+                     (const double*)(base + o_col), n_rb, ld, (const double*)(base + o_slabs), splits, slab, (int)kp, (int)d,
+                     (int)k, outd);
   VB_HIP(ctx, hipGetLastError());
-  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, outd, (size_t)(1 + 2 * ld + slab)));
-  VB_HIP(ctx, hipMemcpyAsync(out_host, outd, sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(out_host + 1, outd + 1, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(out_host + 1 + d, outd + 1 + ld, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpy2DAsync(out_host + 1 + 2 * d, (size_t)k * sizeof(double), outd + 1 + 2 * ld, (size_t)kp * sizeof(double),
-                               (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, outd, (size_t)n_out));
+  double* stage = ctx->pin_host + p;
+  VB_HIP(ctx, hipMemcpyAsync(stage, outd, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
+  memcpy(out_host, stage, (size_t)n_out * sizeof(double));
   return VB_OK;
 }
 
