@@ -178,3 +178,54 @@ def test_vi_diagnostics_philox_mode(vb, capsys):
         assert res['khat'] < 0.7 and res['d2'] < 0.5
         assert res['samples'].shape == (D, 100000)
         assert abs(res['samples'].mean()) < 0.02
+
+
+def _psis_both(lw, reff=1.0):
+    import os
+    from viabel_amd._psis import psislw
+    saved = os.environ.get('VB_PSIS_GRID')
+    try:
+        os.environ['VB_PSIS_GRID'] = '1'
+        grid = psislw(lw, Reff=reff)
+        os.environ['VB_PSIS_GRID'] = '0'
+        single = psislw(lw, Reff=reff)
+    finally:
+        os.environ.pop('VB_PSIS_GRID', None)
+        if saved is not None:
+            os.environ['VB_PSIS_GRID'] = saved
+    return grid, single
+
+
+@pytest.mark.parametrize('n', [1025, 2048, 5000, 16384, 16385, 40000, 65536, 100000, 262144])
+@pytest.mark.parametrize('kind', ['student', 'clustered', 'ties', 'light'])
+def test_grid_kernel_equals_single_workgroup_kernel(vb, n, kind):
+    """The multi-workgroup smoothing (psis_grid_kernel: one slice per workgroup, grid barriers) against the
+    single-workgroup kernel on the same weights: the tail selection and the GPD fit make the same comparisons and add
+    in the same order (k-hat bit for bit); the normalising constant adds slice by slice instead of strided (1e-13)."""
+    rng = np.random.RandomState(n % 1000 + len(kind))
+    if kind == 'student':
+        lw = 2.0 * rng.standard_t(3.0, n)
+    elif kind == 'clustered':
+        lw = -50.0 + 0.3 * rng.randn(n)
+    elif kind == 'ties':
+        lw = np.round(1.5 * rng.standard_t(4.0, n), 1)          # many equal weights, also at the cut-off
+    else:
+        lw = -0.5 * rng.randn(n) ** 2                            # bounded above: k-hat below 1/3, nothing is replaced
+    (gs, gk), (ss, sk) = _psis_both(lw)
+    assert gk == sk or (np.isinf(gk) and np.isinf(sk)), (gk, sk)
+    np.testing.assert_allclose(gs, ss, rtol=0, atol=1e-12)
+    ref, rk = opsis.psis_smooth(lw)
+    assert _close_k(gk, rk)
+    np.testing.assert_allclose(gs, ref, rtol=0, atol=1e-10)
+
+
+def test_grid_kernel_repeated_launches_share_the_barrier_counter(vb):
+    """The barrier counter runs on from launch to launch (no reset between them): sizes with different workgroup counts
+    and pass counts in one process, twice."""
+    rng = np.random.RandomState(5)
+    for _ in range(2):
+        for n in (3000, 16384, 70000, 2000):
+            lw = 1.7 * rng.standard_t(3.5, n)
+            (gs, gk), (ss, sk) = _psis_both(lw)
+            assert gk == sk
+            np.testing.assert_allclose(gs, ss, rtol=0, atol=1e-12)

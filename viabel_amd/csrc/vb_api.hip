@@ -237,7 +237,7 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->pin_host) (void)hipHostFree(ctx->pin_host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
-                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->rows_work,
+                          &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->psis_work, &ctx->rows_work,
                           &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items, &ctx->legacy_work, &ctx->alpha_g})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
@@ -768,6 +768,13 @@ int vb_psis_smooth(vb_ctx* ctx, const double* lw_in, int64_t n, double reff, dou
     fprintf(stderr, "\n");
   }
 #endif
+  if (getenv("VB_PSIS_TRACE")) {
+    double dbg[16];
+    (void)hipMemcpy(dbg, lw + round_up(n, 16), sizeof dbg, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[psis] k %.10g tail %.0f xcutoff %.17g sigma %.10g |", dbg[0], dbg[1], dbg[2], dbg[3]);
+    for (int i = 4; i < 12; ++i) fprintf(stderr, " %.17g", dbg[i]);
+    fprintf(stderr, "\n");
+  }
   ctx->psis_n = 0;        // the resident weights have been smoothed in place
   *khat = res[0];
   return VB_OK;

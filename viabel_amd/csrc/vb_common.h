@@ -203,6 +203,8 @@ struct vb_ctx {
   vb::DeviceBuffer rows_work;           // Model.__call__ for the dense targets: GEMM output rows
   vb::DeviceBuffer psis_lw;             // PSIS: log importance weights (+ 16 result scalars)
   int64_t psis_n = 0;                   // number of device-resident log weights (0: none)
+  vb::DeviceBuffer psis_work;           // the multi-workgroup smoothing's exchange area (barrier counter, histograms, tail lists)
+  unsigned long long psis_bar_base = 0; // value of that counter before the next launch
   double* pin_host = nullptr;           // pinned, device-mapped staging (vb_linalg.hip): host / device address
   double* pin_dev = nullptr;
   size_t pin_bytes = 0;

@@ -13,6 +13,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 namespace vb {
 
@@ -176,10 +177,35 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
     __syncthreads();
     const unsigned long long prefix = sel_prefix;
     const unsigned long long mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
-    ps_each<REGS>(r, x, n, [&](int64_t, double v) {
-      const unsigned long long k = ps_key(v);
-      if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> (8 * pass)) & 255ull)], 1);
-    });
+    if constexpr (REGS) {
+      // the top bytes of log weights are sign and exponent: a wave's 64 keys fall into one or two bins, and 64 LDS
+      // atomics on one address are served one after the other.  Two rounds of "the first lane's bin: everybody in it
+      // is counted by one add"; what is left (the low bytes' spread-out bins) goes lane by lane.
+#pragma unroll
+      for (int u = 0; u < kPsisRegs; ++u) {
+        const int64_t i = t + (int64_t)u * kPsisThreads;
+        const unsigned long long k = ps_key(r[u]);
+        const int bin = (int)((k >> (8 * pass)) & 255ull);
+        bool act = i < n && (k & mask) == prefix;
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+          const unsigned long long todo = __ballot(act);
+          if (!todo) break;
+          const int leader = __builtin_ctzll(todo);
+          const int b = __shfl(bin, leader, 64);
+          const bool same = act && bin == b;
+          const unsigned long long m = __ballot(same);
+          if (lane == leader) atomicAdd(&hist[b], __builtin_popcountll(m));
+          act = act && !same;
+        }
+        if (act) atomicAdd(&hist[bin], 1);
+      }
+    } else {
+      ps_each<REGS>(r, x, n, [&](int64_t, double v) {
+        const unsigned long long k = ps_key(v);
+        if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> (8 * pass)) & 255ull)], 1);
+      });
+    }
     __syncthreads();
     if (wave == 0) {
       // the bin that holds rank r: wave 0 scans the 256 counts, four consecutive bins per lane (a serial walk by one
@@ -453,6 +479,507 @@ __global__ void __launch_bounds__(kPsisThreads) psis_kernel(double* __restrict__
   }
 }
 
+// ---- the same smoothing on G workgroups (round 4) --------------------------------------------------------------------
+// One workgroup spends its 80 us on dependent chains (sixteen exponentials per thread, 384^2 comparisons, 49 x 384
+// logarithms).  Here workgroup g of G = ceil(N / 1024) (at most 64) owns the weights [g S, (g + 1) S), E <= 4 per thread,
+// and the phases are separated by grid barriers (a returning atomic + a bounded poll: the G workgroups of a launch are
+// co-resident, one per CU):
+//   max                          | per-workgroup maxima, combined by everybody
+//   radix select, 12 bits a pass | LDS histogram (wave-aggregated adds) -> integer atomics on the global one; everybody
+//                                | scans it; two or three passes until the bin of the wanted rank has <= 1024 members
+//   gather                       | members of that bin and everything above it, per-workgroup lists -> one range
+//                                | reservation per workgroup; the cut-off is found among the bin's members by counting
+//   rank                         | workgroup g ranks its share of the tail by (value, index) and stores it sorted
+//   quadrature                   | point j on workgroup j mod G, sixteen lanes per point: the single-workgroup kernel's order
+//   fit, quantiles, log-sum-exp  | everybody fits (same numbers), patches its own slice; the new maximum is the largest
+//                                | smoothed value, so the sum of exponentials needs one more barrier only
+// Every floating-point sum is formed in a fixed order: results do not depend on timing; k-hat, sigma and the smoothed
+// tail are bit-identical to the single-workgroup kernel's, the normalising constant agrees to rounding (its terms are
+// added slice by slice instead of strided).
+constexpr int kPgBits = 12, kPgBins = 1 << kPgBits, kPgPasses = 6;
+constexpr int kPgMaxWg = 64, kPgRegs = 4;
+constexpr int kPgBinCap = kPsisThreads;
+constexpr int kPgBarriers = 12;            // per launch and workgroup: max 1 + select 6 + gather 1 + rank 1 + quadrature 1 + sum 1, padded
+// scratch (bytes from the base): [0] barrier counter (runs on from launch to launch: every launch adds exactly
+// G * kPgBarriers, its first target is a kernel argument), [16] poison
+constexpr size_t kPgOffVal = 64;                                              // double [3][64]
+constexpr size_t kPgOffCnt = kPgOffVal + 3 * kPgMaxWg * sizeof(double);       // int [16]: 0 bin members, 1 tail candidates
+constexpr size_t kPgOffHist = kPgOffCnt + 16 * sizeof(int);                   // int [6][4096]
+constexpr size_t kPgOffBk = kPgOffHist + (size_t)kPgPasses * kPgBins * sizeof(int);      // u64 [1024]
+constexpr size_t kPgOffBi = kPgOffBk + kPgBinCap * sizeof(unsigned long long);           // int [1024]
+constexpr size_t kPgOffTv = kPgOffBi + kPgBinCap * sizeof(int);                          // double [4096] candidates
+constexpr size_t kPgOffTi = kPgOffTv + kPsisTailCap * sizeof(double);                    // int [4096]
+constexpr size_t kPgOffSv = kPgOffTi + kPsisTailCap * sizeof(int);                       // double [4096] sorted
+constexpr size_t kPgOffSi = kPgOffSv + kPsisTailCap * sizeof(double);                    // int [4096]
+constexpr size_t kPgOffQ = kPgOffSi + kPsisTailCap * sizeof(int);                        // double [2][128]: L, ks
+constexpr size_t kPgBytes = kPgOffQ + 2 * kPsisQuadCap * sizeof(double);
+
+// Every word the workgroups exchange is stored and loaded as an agent-scope atomic (write-through `sc1` stores, `sc1`
+// loads): the eight XCDs' L2s are not coherent with each other, and a line this XCD has read or partly written before
+// -- a neighbour's slot of a shared array, a histogram it zeroed -- would be served stale to a plain load whatever
+// fences surround it.  With write-through payloads the barrier needs no fence: every wave drains its stores, one lane
+// adds to the counter and polls it.
+__device__ __forceinline__ void pg_st(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pg_st(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pg_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double pg_ld(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned long long pg_ld(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int pg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct PgBarrier {
+  unsigned long long* bar;
+  unsigned long long target;
+  int g_count, used;
+  __device__ __forceinline__ void wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      target += (unsigned long long)g_count;
+      ++used;
+#ifdef VB_PSIS_FENCE
+      __threadfence();
+#endif
+      atomicAdd(bar, 1ull);
+      int spins = 0;
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 24)) {        // (a workgroup that never arrives: poison the results instead of hanging)
+          atomicExch((unsigned long long*)(bar + 2), 1ull);
+          break;
+        }
+      }
+#ifdef VB_PSIS_FENCE
+      __threadfence();
+#endif
+    }
+    __syncthreads();
+  }
+};
+
+template <int E>
+__global__ void __launch_bounds__(kPsisThreads) psis_grid_kernel(double* __restrict__ x, int64_t n, int m_tail,
+                                                                 double* __restrict__ out, char* __restrict__ work,
+                                                                 unsigned long long bar_base) {
+  __shared__ double sh[17];
+  __shared__ int hist[kPgBins];
+  __shared__ double tv[kPsisTailCap];
+  __shared__ int ti[kPsisTailCap];
+  __shared__ unsigned long long bk[kPgBinCap];
+  __shared__ int bi[kPgBinCap];
+  __shared__ double q_bs[kPsisQuadCap], q_L[kPsisQuadCap], q_w[kPsisQuadCap];
+  __shared__ int rank_sh[kPsisThreads];
+  __shared__ double lbuf[kPsisTailCap];
+  __shared__ double bc[4];
+  __shared__ unsigned long long sel_prefix;
+  __shared__ long long sel_rank;
+  __shared__ int sel_bin_count, cnt_a, cnt_b, base_a, base_b;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int G = gridDim.x, g = blockIdx.x;
+  unsigned long long* bar = reinterpret_cast<unsigned long long*>(work);
+  double* wgval = reinterpret_cast<double*>(work + kPgOffVal);
+  int* gcnt = reinterpret_cast<int*>(work + kPgOffCnt);
+  int* ghist = reinterpret_cast<int*>(work + kPgOffHist);
+  unsigned long long* gbk = reinterpret_cast<unsigned long long*>(work + kPgOffBk);
+  int* gbi = reinterpret_cast<int*>(work + kPgOffBi);
+  double* gtv = reinterpret_cast<double*>(work + kPgOffTv);
+  int* gti = reinterpret_cast<int*>(work + kPgOffTi);
+  double* gsv = reinterpret_cast<double*>(work + kPgOffSv);
+  int* gsi = reinterpret_cast<int*>(work + kPgOffSi);
+  double* gq = reinterpret_cast<double*>(work + kPgOffQ);
+  PgBarrier barrier{bar, bar_base, G, 0};
+#ifdef VB_PSIS_CLOCK
+  int dbg_k = 4;
+#define PG_MARK() do { if (g == 0 && t == 0) out[dbg_k] = (double)wall_clock64(); ++dbg_k; } while (0)
+#else
+#define PG_MARK() do { } while (0)
+#endif
+  PG_MARK();
+  const int64_t slice = (int64_t)E * kPsisThreads;
+  const int64_t i0 = (int64_t)g * slice;
+
+  // 0. this launch's counters and histograms (used behind the first barrier only)
+  for (int e = g * kPsisThreads + t; e < kPgPasses * kPgBins; e += G * kPsisThreads) pg_st(&ghist[e], 0);
+  if (g == 0 && t < 16) pg_st(&gcnt[t], 0);
+
+  // 1. x -= max(x)   (_psis.py:166)
+  double r[E];
+  double mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
+    r[u] = i < n ? x[i] : 0.0;
+    if (i < n) mx = fmax(mx, r[u]);
+  }
+  mx = ps_block_max(mx, sh);
+  if (t == 0) pg_st(&wgval[g], mx);
+  barrier.wait();
+  mx = pg_ld(&wgval[0]);
+  for (int q = 1; q < G; ++q) mx = fmax(mx, pg_ld(&wgval[q]));
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
+    r[u] -= mx;
+    if (i < n) x[i] = r[u];
+  }
+
+  PG_MARK();
+  // 2. the key of x_sorted[n - m_tail - 1]   (:170-173)
+  if (t == 0) {
+    sel_prefix = 0ull;
+    sel_rank = n - (long long)m_tail - 1;
+    sel_bin_count = 0x7fffffff;
+  }
+  __syncthreads();
+  int shift_done = 64;            // bits [shift_done, 64) of the key are fixed
+  for (int pass = 0; pass < kPgPasses; ++pass) {
+    const int shift = pass < 5 ? 52 - kPgBits * pass : 0;
+    const int width = shift_done - shift;
+    const unsigned long long fixed_mask = shift_done == 64 ? 0ull : (~0ull << shift_done);
+    for (int e = t; e < kPgBins; e += kPsisThreads) hist[e] = 0;
+    __syncthreads();
+    const unsigned long long prefix = sel_prefix;
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
+      const unsigned long long k = ps_key(r[u]);
+      const int bin = (int)((k >> shift) & ((1ull << width) - 1ull));
+      bool act = i < n && (k & fixed_mask) == prefix;
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {      // (see psis_kernel: a wave's keys share their top bits)
+        const unsigned long long todo = __ballot(act);
+        if (!todo) break;
+        const int leader = __builtin_ctzll(todo);
+        const int b = __shfl(bin, leader, 64);
+        const bool same = act && bin == b;
+        const unsigned long long m = __ballot(same);
+        if (lane == leader) atomicAdd(&hist[b], __builtin_popcountll(m));
+        act = act && !same;
+      }
+      if (act) atomicAdd(&hist[bin], 1);
+    }
+    __syncthreads();
+    int* gh = ghist + pass * kPgBins;
+    for (int e = t; e < kPgBins; e += kPsisThreads)
+      if (hist[e]) atomicAdd(&gh[e], hist[e]);
+    barrier.wait();
+    // everybody scans the global histogram: four consecutive bins per thread
+    {
+      const long long want = sel_rank;
+      const int c0 = pg_ld(&gh[4 * t]), c1 = pg_ld(&gh[4 * t + 1]), c2 = pg_ld(&gh[4 * t + 2]), c3 = pg_ld(&gh[4 * t + 3]);
+      const long long mine4 = (long long)c0 + c1 + c2 + c3;
+      long long incl = mine4;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const long long up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+      }
+      long long* wtot = reinterpret_cast<long long*>(tv);       // 16 wave totals (tv is free here)
+      __syncthreads();
+      if (lane == 63) wtot[wave] = incl;
+      __syncthreads();
+      long long before = 0;
+      for (int w = 0; w < wave; ++w) before += wtot[w];
+      incl += before;
+      const long long excl = incl - mine4;
+      const bool last_thread = t == kPsisThreads - 1;
+      if ((excl <= want && want < incl) || (last_thread && want >= incl)) {
+        long long rr = want - excl;
+        int bin = 4 * t, cb = c0;
+        if (rr >= c0 && bin < kPgBins - 1) { rr -= c0; ++bin; cb = c1;
+          if (rr >= c1 && bin < kPgBins - 1) { rr -= c1; ++bin; cb = c2;
+            if (rr >= c2 && bin < kPgBins - 1) { rr -= c2; ++bin; cb = c3; } } }
+        sel_rank = rr;
+        sel_prefix = prefix | ((unsigned long long)bin << shift);
+        sel_bin_count = cb;
+      }
+      __syncthreads();
+    }
+    shift_done = shift;
+    if (shift > 0 && sel_bin_count <= kPgBinCap) break;
+  }
+  PG_MARK();
+  // 3. members of the selected bin (when bits are left to decide) and everything above it
+  {
+    const unsigned long long prefix = sel_prefix, fixed_mask = shift_done == 0 ? ~0ull : (~0ull << shift_done);
+    const bool need_bin = shift_done > 0;
+    if (t == 0) cnt_a = 0, cnt_b = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
+      if (i < n) {
+        const unsigned long long k = ps_key(r[u]);
+        const unsigned long long top = k & fixed_mask;
+        if (top > prefix) {
+          const int p = atomicAdd(&cnt_a, 1);
+          tv[p] = r[u];
+          ti[p] = (int)i;
+        } else if (need_bin && top == prefix) {
+          const int p = atomicAdd(&cnt_b, 1);
+          if (p < kPgBinCap) {
+            bk[p] = k;
+            bi[p] = (int)i;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (t == 0) {
+      base_a = cnt_a ? atomicAdd(&gcnt[1], cnt_a) : 0;
+      base_b = cnt_b ? atomicAdd(&gcnt[0], cnt_b) : 0;
+    }
+    __syncthreads();
+    for (int e = t; e < cnt_a; e += kPsisThreads)
+      if (base_a + e < kPsisTailCap) pg_st(&gtv[base_a + e], tv[e]), pg_st(&gti[base_a + e], ti[e]);
+    for (int e = t; e < cnt_b; e += kPsisThreads)
+      if (base_b + e < kPgBinCap) pg_st(&gbk[base_b + e], bk[e]), pg_st(&gbi[base_b + e], bi[e]);
+    barrier.wait();
+    int nb = pg_ld(&gcnt[0]);
+    nb = nb < kPgBinCap ? nb : kPgBinCap;
+    if (need_bin) {
+      if (t < nb) bk[t] = pg_ld(&gbk[t]), bi[t] = pg_ld(&gbi[t]);
+      __syncthreads();
+      const long long want = sel_rank;
+      if (t < nb) {
+        const unsigned long long mk = bk[t];
+        int lt = 0, le = 0;
+        for (int j = 0; j < nb; ++j) {
+          const unsigned long long o = bk[j];
+          lt += o < mk ? 1 : 0;
+          le += o <= mk ? 1 : 0;
+        }
+        if (lt <= want && want < le) sel_prefix = mk;
+      }
+      __syncthreads();
+    }
+  }
+  PG_MARK();
+  const double cutoffmin = log(DBL_MIN);                       // :159
+  const double xcutoff = fmax(ps_unkey(sel_prefix), cutoffmin);
+  const double expxc = exp(xcutoff);
+  // right tail: x > xcutoff (:175-177): the candidates above the bin, and the bin's members above the cut-off
+  int na = pg_ld(&gcnt[1]);
+  na = na < kPsisTailCap ? na : kPsisTailCap;
+  int nb = shift_done > 0 ? pg_ld(&gcnt[0]) : 0;
+  nb = nb < kPgBinCap ? nb : kPgBinCap;
+  {
+    if (t == 0) cnt_a = 0;
+    __syncthreads();
+    for (int e = t; e < na; e += kPsisThreads) {
+      const double v = pg_ld(&gtv[e]);
+      if (v > xcutoff) {
+        const int p = atomicAdd(&cnt_a, 1);
+        if (p < kPsisTailCap) {
+          tv[p] = v;
+          ti[p] = pg_ld(&gti[e]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = t; e < nb; e += kPsisThreads) {
+      const double v = ps_unkey(bk[e]);
+      if (v > xcutoff) {
+        const int p = atomicAdd(&cnt_a, 1);
+        if (p < kPsisTailCap) {
+          tv[p] = v;
+          ti[p] = bi[e];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int n2 = cnt_a < kPsisTailCap ? cnt_a : kPsisTailCap;
+  const int tail_count = cnt_a;
+  PG_MARK();
+  double k = INFINITY, sigma = NAN, new_max = 0.0;
+  if (n2 > 4) {                                                 // :178-180
+    // 4. this workgroup ranks its share of the tail by (value, index) and stores it at its ranks.  The share is a range
+    // of the GLOBAL candidate lists (the same for everybody); the LDS copy, whose order differs from workgroup to
+    // workgroup, only supplies the comparands
+    {
+      const int total = na + nb, per = (total + G - 1) / G, c0 = g * per;
+      const int cnt = c0 < total ? (c0 + per < total ? per : total - c0) : 0;
+      int R = cnt > 0 ? kPsisThreads / cnt : 1;       // threads per element
+      R = R < 1 ? 1 : (R > 64 ? 64 : R);
+      const int slots = kPsisThreads / R;
+      for (int eb = 0; eb < cnt; eb += slots) {
+        const int slot = t / R, el = eb + slot, rep = t % R;
+        bool live = el < cnt && slot < slots;
+        double mv = INFINITY;
+        int mi = 0x7fffffff;
+        if (live) {
+          const int c = c0 + el;
+          mv = c < na ? pg_ld(&gtv[c]) : ps_unkey(bk[c - na]);
+          mi = c < na ? pg_ld(&gti[c]) : bi[c - na];
+          live = mv > xcutoff;
+        }
+        if (t < slots) rank_sh[t] = 0;
+        __syncthreads();
+        int c = 0;
+        if (live)
+          for (int j = rep; j < n2; j += R) c += ps_after(mv, mi, tv[j], ti[j]) ? 1 : 0;
+        if (live) atomicAdd(&rank_sh[slot], c);
+        __syncthreads();
+        if (live && rep == 0) {
+          const int rk = rank_sh[slot];
+          pg_st(&gsv[rk], mv);
+          pg_st(&gsi[rk], mi);
+        }
+        __syncthreads();
+      }
+    }
+    barrier.wait();
+    PG_MARK();
+    // x2 = exp(x2) - exp(xcutoff)   (:185-186)
+    for (int i = t; i < n2; i += kPsisThreads) {
+      tv[i] = exp(pg_ld(&gsv[i])) - expxc;
+      ti[i] = pg_ld(&gsi[i]);
+    }
+    __syncthreads();
+    // 5. gpdfitnew (:266-325): PRIOR = 3, m = 30 + int(sqrt(n2)); point j on workgroup j mod G
+    const int m = 30 + (int)sqrt((double)n2);
+    const double xq = tv[(int)(n2 / 4.0 + 0.5) - 1], xl = tv[n2 - 1];
+    if (t < m) q_bs[t] = (1.0 - sqrt((double)m / ((double)(t + 1) - 0.5))) / (3.0 * xq) + 1.0 / xl;
+    __syncthreads();
+    const int grp = t >> 4, gl = t & 15;
+    // ks_j = mean log1p(-bs_j x) for the points j = g, g + G, ...: the logarithms by all threads into LDS (as many points
+    // at a time as fit), then sixteen lanes per point add them in psis_kernel's order (lane l takes i = l, l + 16, ..., a
+    // fixed butterfly joins the lanes)
+    const int npts = g < m ? (m - g + G - 1) / G : 0;
+    const int pc = kPsisTailCap / n2 > 0 ? kPsisTailCap / n2 : 1;
+    for (int p0 = 0; p0 < npts; p0 += pc) {
+      const int np = npts - p0 < pc ? npts - p0 : pc;
+      for (int e = t; e < np * n2; e += kPsisThreads) {
+        const int pp = e / n2, i = e - pp * n2;
+        lbuf[e] = log(fma(-q_bs[g + (p0 + pp) * G], tv[i], 1.0));
+      }
+      __syncthreads();
+      for (int pp = grp; pp < np; pp += kPsisThreads / 16) {
+        const double* lb = lbuf + pp * n2;
+        double s = 0.0;
+        int i = gl;
+        for (; i + 112 < n2; i += 128) {           // eight reads in flight, added in index order
+          double v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = lb[i + 16 * q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; i < n2; i += 16) s += lb[i];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (gl == 0) {
+          const int j = g + (p0 + pp) * G;
+          const double ks = s / n2;
+          pg_st(&gq[j], n2 * (log(-(q_bs[j] / ks)) - ks - 1.0));
+        }
+      }
+      __syncthreads();
+    }
+    barrier.wait();
+    PG_MARK();
+    if (t < m) q_L[t] = pg_ld(&gq[t]);
+    __syncthreads();
+    for (int j = grp; j < m; j += kPsisThreads / 16) {
+      const double lj = q_L[j];
+      double s = 0.0;
+      for (int i = gl; i < m; i += 16) s += exp(q_L[i] - lj);
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (gl == 0) {
+        const double w = 1.0 / s;
+        q_w[j] = w >= 10.0 * DBL_EPSILON ? w : 0.0;              // remove negligible weights
+      }
+    }
+    __syncthreads();
+    if (t == 0) {
+      double ws = 0.0, bsum = 0.0;
+      for (int i = 0; i < m; ++i) ws += q_w[i];
+      for (int i = 0; i < m; ++i) bsum += q_bs[i] * (q_w[i] / ws);
+      bc[0] = bsum;                                              // posterior mean of b
+    }
+    __syncthreads();
+    const double b = bc[0];
+    double s = 0.0;
+    for (int i = t; i < n2; i += kPsisThreads) s += log1p(-b * tv[i]);
+    s = ps_block_sum(s, sh);
+    k = s / n2;
+    sigma = -k / b;
+    k = k * n2 / (n2 + 10.0) + 10.0 * 0.5 / (n2 + 10.0);        // weakly informative prior, a = 10
+
+    // 6. smoothed tail (:188-199); every workgroup forms all of it and keeps what falls into its slice
+    if (k >= 1.0 / 3.0 && !isinf(k)) {
+      double vmax = -INFINITY;
+      for (int i = t; i < n2; i += kPsisThreads) {
+        const double p = ((double)i + 0.5) / n2;
+        double qq = NAN;
+        if (sigma > 0.0) {
+          const double l = log1p(-p);
+          qq = (fabs(k) < DBL_EPSILON ? -l : expm1(-k * l) / k) * sigma;
+        }
+        double v = log(qq + expxc);
+        if (v > 0.0) v = 0.0;
+        vmax = fmax(vmax, v);          // (fmax drops a NaN: the reference's max of the vector would not -- sigma <= 0 only)
+        const int64_t idx = ti[i];
+        if (idx >= i0 && idx < i0 + slice) x[idx] = v;
+      }
+      new_max = ps_block_max(vmax, sh);
+      // the untouched weights are <= xcutoff <= every smoothed value (the quantiles are >= 0); without a tail to the
+      // right of the cut-off the old maximum (0) stays
+      if (!(new_max > -INFINITY)) new_max = 0.0;
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < E; ++u) {
+        const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
+        if (i < n) r[u] = x[i];
+      }
+    }
+  }
+  PG_MARK();
+  // 7. renormalise: x -= sumlogs(x)   (:201, :380-396)
+  double se = 0.0;
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
+    if (i < n) se += exp(r[u] - new_max);
+  }
+  se = ps_block_sum(se, sh);
+  if (t == 0) pg_st(&wgval[kPgMaxWg + g], se);
+  barrier.wait();
+  double tot = 0.0;
+  for (int q = 0; q < G; ++q) tot += pg_ld(&wgval[kPgMaxWg + q]);
+  const double lse = log(tot) + new_max;
+  const bool poisoned = pg_ld(&bar[2]) != 0ull;
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
+    if (i < n) x[i] = poisoned ? NAN : r[u] - lse;
+  }
+  PG_MARK();
+  if (g == 0 && t == 0) {
+    out[0] = poisoned ? NAN : k;
+    out[1] = (double)tail_count;
+    out[2] = xcutoff;
+    out[3] = sigma;
+#ifdef VB_PSIS_DEBUG
+    out[4] = n2, out[5] = pg_ld(&gcnt[1]), out[6] = pg_ld(&gcnt[0]), out[7] = shift_done, out[8] = (double)sel_rank;
+    out[9] = mx, out[10] = new_max, out[11] = tot;
+#endif
+  }
+  // the barriers this launch did not need (the select leaves early): the counter advances by the same amount every launch
+  if (t == 0 && barrier.used < kPgBarriers) atomicAdd(bar, (unsigned long long)(kPgBarriers - barrier.used));
+}
+
 // log importance weights of the mean-field families for the noise staged in `ns`; left in ctx->psis_lw
 int log_weights_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
                         const double* theta_src) {
@@ -489,6 +1016,30 @@ int psis_enqueue(vb_ctx* ctx, int64_t n, double reff) {
     return fail(ctx, VB_ERR_UNSUPPORTED, "PSIS tail of %d values exceeds the on-chip sort capacity %d", m_tail,
                 kPsisTailCap);
   double* lw = (double*)ctx->psis_lw.ptr;
+  const char* grid_s = getenv("VB_PSIS_GRID");             // 0: the single-workgroup kernel (cross-check)
+  const int grid_env = grid_s ? atoi(grid_s) : 1;
+  int wgs = (int)((n + kPsisThreads - 1) / kPsisThreads);
+  wgs = wgs > kPgMaxWg ? kPgMaxWg : wgs;
+  const int per_thread = (int)((n + (int64_t)wgs * kPsisThreads - 1) / ((int64_t)wgs * kPsisThreads));
+  if (grid_env && wgs > 1 && per_thread <= kPgRegs && wgs <= ctx->prop.multiProcessorCount) {
+    if (!ctx->psis_work.ptr) {
+      VB_TRY(ensure(ctx, ctx->psis_work, kPgBytes));
+      VB_HIP(ctx, hipMemsetAsync(ctx->psis_work.ptr, 0, 64, ctx->stream));        // barrier counter, poison
+      ctx->psis_bar_base = 0;
+    }
+    const unsigned long long bar_base = ctx->psis_bar_base;
+    ctx->psis_bar_base += (unsigned long long)wgs * kPgBarriers;
+    char* work = (char*)ctx->psis_work.ptr;
+    double* out = lw + round_up(n, 16);
+    if (per_thread == 1)
+      hipLaunchKernelGGL(psis_grid_kernel<1>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base);
+    else if (per_thread == 2)
+      hipLaunchKernelGGL(psis_grid_kernel<2>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base);
+    else
+      hipLaunchKernelGGL(psis_grid_kernel<4>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base);
+    VB_HIP(ctx, hipGetLastError());
+    return VB_OK;
+  }
   if (n <= (int64_t)kPsisRegs * kPsisThreads)
     hipLaunchKernelGGL(psis_kernel<true>, dim3(1), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail,
                        lw + round_up(n, 16));
