@@ -66,9 +66,9 @@ def test_fullrank_against_oracle(vb, D, N):
 
 @pytest.mark.parametrize('D,N', [(1, 4), (3, 8), (5, 30), (64, 333), (130, 257), (200, 1000), (512, 4096), (1024, 4096)])
 def test_fullrank_path_derivative_against_oracle(vb, D, N):
-    """use_path_deriv=True (objectives.py:156-159) for the dense Gaussian: the score L^-T eps enters through the
-    noise Gram matrix and a Newton-iteration inverse of L' on the device; the oracle solves the triangular
-    system per sample."""
+    """use_path_deriv=True (objectives.py:156-159) for the dense Gaussian: the score L^-T eps is added to the rows of
+    G on the device (one more N x D x D / 2 product with a blocked triangular inverse of L); the oracle solves the
+    triangular system per sample.  Sizes below the fused path take the two-pass column sums."""
     rng = np.random.RandomState(7 * D + N)
     ofr = ofam.FullRankGaussian(D)
     theta = _theta(ofr, D, rng)

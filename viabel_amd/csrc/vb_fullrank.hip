@@ -178,6 +178,18 @@ struct EpiNegate {          // G = -acc   (gauss_full: G = -(Z - m) P)
   }
 };
 
+struct EpiAccumulate {      // G += acc   (path derivative: the rows of G take the score's L^-T eps)
+  double* G;
+  int64_t ldz;
+  __device__ void operator()(int, int row, int col, double acc) const { G[(int64_t)row * ldz + col] += acc; }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    d2v* p = reinterpret_cast<d2v*>(G + (int64_t)row * ldz + col);
+    const d2v v = *p + (d2v){a0, a1};
+    *p = v;
+    return v;
+  }
+};
+
 // G = -acc and, per workgroup, the sum of f = 1/2 (z - m)' g over the tile (gauss_full: log p(z) = c0 - 1/2 (z - m)' P
 // (z - m) = c0 + 1/2 (z - m)' g): Zc holds z - m, the very rows this workgroup has just multiplied (L2-resident), read
 // back with the store's own 16-byte pattern.  The model's log density of the materialised samples, not an identity of
@@ -658,6 +670,55 @@ __global__ void __launch_bounds__(256) fr_triinv_leaf_kernel(const double* __res
 }
 
 // y = X e (one wave per row) into the extra column-sum row, and tr(M2) into the sum vector's slot 1
+// out[j][i] = in[i][j] for a d x d matrix (row stride ld both sides), 32 x 32 tiles through LDS
+__global__ void __launch_bounds__(256) fr_transpose_kernel(const double* __restrict__ in, double* __restrict__ out, int d,
+                                                           int64_t ld) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, j = j0 + tx;
+    tile[r][tx] = (i < d && j < d) ? in[(int64_t)i * ld + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = j0 + r, i = i0 + tx;
+    if (i < d && j < d) out[(int64_t)j * ld + i] = tile[tx][r];
+  }
+}
+
+// sum of squares of the n x d noise matrix: one partial per workgroup (rows strided over the grid), summed in a fixed
+// order by fr_sumsq_final_kernel
+__global__ void __launch_bounds__(256) fr_sumsq_kernel(const double* __restrict__ E, int64_t ld, int64_t n, int d,
+                                                       double* __restrict__ part) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const double* e = E + r * ld;
+    for (int c = 2 * threadIdx.x; c < d; c += 512) {
+      const fr_d2 v = *reinterpret_cast<const fr_d2*>(e + c);
+      s = fma(v.x, v.x, s);
+      if (c + 1 < d) s = fma(v.y, v.y, s);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void __launch_bounds__(256) fr_sumsq_final_kernel(const double* __restrict__ part, int count,
+                                                             double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) s += part[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 __global__ void __launch_bounds__(256) fr_pd_matvec_kernel(const double* __restrict__ X, int64_t ld,
                                                            const double* __restrict__ e,
                                                            const double* __restrict__ M2, int64_t ldm, int d,
@@ -1171,11 +1232,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
                 o_cpart = carve((int64_t)(splits + 1) * slab), o_col = carve((int64_t)(n_rb + 1) * ldz),
                 o_fpart = carve((int64_t)n_fpart + (int64_t)n_rb * cs_gx + gemm_max_blocks(n, D) + (n * ldz) / 512 + 1),
                 o_r = carve(glm ? n * ldr : 0);
-  // path derivative: (L')^-1 (Xa), a product buffer T, the noise Gram matrix [16 | e (ld_e) | M2 (d x ldl)], partial
-  // column sums of the noise (row stride = the noise matrix's)
-  const int64_t ld_e = ns.ld;
-  const int64_t o_xa = pd ? carve(slab) : 0, o_t = pd ? carve(slab) : 0,
-                o_m2 = pd ? carve(16 + ld_e + slab) : 0, o_cole = pd ? carve((int64_t)n_rb * ld_e) : 0;
+  // path derivative: (L')^-1 (Xa), a product buffer T (then L^-1), partial sums of squares of the noise
+  const int64_t o_xa = pd ? carve(slab) : 0, o_t = pd ? carve(slab) : 0, o_m2 = pd ? carve(256) : 0;
   // sum vector: the t family takes the full D x ldl matrix; the Gaussian family packs the lower triangle in
   // theta's own order, twice over when the all-reduce of one evaluation overlaps the kernels of the next
   const int64_t np = d * (d + 1) / 2;
@@ -1231,50 +1289,23 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
 
   if (pd) {
+    // Path derivative (objectives.py:166-168: the score's own parameter dependence is stopped): with z = mu + L eps the
+    // gradient of -log q along the path is L^-T eps, so every row of G takes that term -- G~ = G + E L^-1, one more
+    // N x D x D / 2 product -- and the usual sums of G~ finish the job: no entropy term, no noise Gram matrix, no
+    // D x D x D product (round 4; rounds 2-3 formed L^-T (E'E / N): 620 -> ~500 us at D = 1024, N = 4096).
     // (L')^-1 = U^-1 by recursive doubling: diagonal blocks of kTriLeaf rows are inverted by back substitution
     // (one wave per column), then [[A, B], [0, C]]^-1 = [[A^-1, -A^-1 B C^-1], [0, C^-1]] level by level --
     // two GEMMs per pair of blocks, D^3 / 3 flops in all instead of a triangular solve
-    double *Xa = base + o_xa, *T = base + o_t, *m2 = base + o_m2, *colE = base + o_cole;
+    double *Xa = base + o_xa, *T = base + o_t, *sq = base + o_m2;
     VB_TRY(fr_tri_inverse_enqueue(ctx, st, theta_dev, Lt, D, ldl, Xa, T));
     VB_HIP(ctx, hipGetLastError());
-    GemmArgs gx;             // square D x D product below
-    gx.lda = ldl;
-    gx.ldb = ldl;
-    gx.M = D;
-    gx.N = D;
-    gx.K = D;
-    // noise Gram matrix (lower triangle) and column sums, reduced into [16 | e | M2]
-    const double* E = (const double*)ns.buf.ptr;
-    GemmArgs gg;
-    gg.A = E;
-    gg.lda = ns.ld;
-    gg.B = E;
-    gg.ldb = ns.ld;
-    gg.M = D;
-    gg.N = D;
-    gg.K = (int)n;
-    gg.tri_mode = 2;
-    gemm_f64_launch<false>(st, gg, splits, n_cu, EpiSplitSlab{Cpart, ldl, slab});
-    hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st, E, E, ld_e, n, D,
-                       0, (const double*)nullptr, colE, fpart);
-    VB_HIP(ctx, hipGetLastError());
-    FrSums S2;
-    S2.sums = m2;
-    S2.off_col = 16;
-    S2.off_c = 16 + ld_e;
-    S2.len = 16 + ld_e + slab;
-    const int64_t items2 = slab / 2 > ld_e ? slab / 2 : ld_e;
-    hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((items2 + 255) / 256)), dim3(256), 0, st,
-                       (const double*)Cpart, splits, slab, D, ldl, (const double*)colE, n_rb, ld_e,
-                       (const double*)fpart, 0, S2, 0);
-    // L^-T e -> extra column-sum row, tr(M2) -> sums[1]; L^-T M2 -> extra split slab (lower tiles)
-    hipLaunchKernelGGL(fr_pd_matvec_kernel, dim3((unsigned)((ldz + 3) / 4)), dim3(256), 0, st, (const double*)Xa, ldl,
-                       (const double*)(m2 + S2.off_col), (const double*)(m2 + S2.off_c), ldl, D,
-                       colpart + (int64_t)n_rb * ldz, ldz, S.sums + 1);
-    gx.A = Xa;
-    gx.B = m2 + S2.off_c;
-    gx.tri_mode = 2;
-    gemm_f64_launch<true>(st, gx, 1, n_cu, EpiSplitSlab{Cpart + (int64_t)splits * slab, ldl, slab});
+    // L^-1 = (U^-1)' with its rows k-major for the product below (T is free again)
+    hipLaunchKernelGGL(fr_transpose_kernel, dim3((unsigned)((D + 31) / 32), (unsigned)((D + 31) / 32)), dim3(256), 0, st,
+                       (const double*)Xa, T, D, ldl);
+    // sum ||eps_n||^2 -> sums[1]: the value's mean log q of the samples (:167)
+    const int sq_blocks = (int)(n < 256 ? n : 256);
+    hipLaunchKernelGGL(fr_sumsq_kernel, dim3((unsigned)sq_blocks), dim3(256), 0, st, (const double*)ns.buf.ptr, ns.ld, n, D, sq);
+    hipLaunchKernelGGL(fr_sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const double*)sq, sq_blocks, S.sums + 1);
     VB_HIP(ctx, hipGetLastError());
   }
 
@@ -1293,7 +1324,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   // correlated-Gaussian target under the dense Gaussian family: no pass over G and Z between the GEMMs -- sum f comes
   // out of the model GEMM's epilogue (EpiNegateF) and the column sums of G out of the gradient GEMM (EpiSplitSlabCs)
   static const bool fast_env = !(getenv("VB_FR_FUSED_SUMS") && atoi(getenv("VB_FR_FUSED_SUMS")) == 0);
-  const bool fused_sums = fast_env && !mvt && m.id == VB_MODEL_GAUSS_FULL && !wm.roww && !row_scale && !pd &&
+  const bool fused_sums = fast_env && !mvt && m.id == VB_MODEL_GAUSS_FULL && !wm.roww && !row_scale &&
                           n % kGemmBK == 0 && gemm_uses_dma(g1) && (int64_t)splits <= n_rb;
   // short shards (fewer than two 64 x 64 tiles per CU): the N x D x D products with their k range cut into `kparts`
   // pieces (see fr_zsum_kernel); the slabs of partial products live in the split area of the gradient product, which
@@ -1321,7 +1352,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   if (!(fused_sums && kparts == 1 && cfg1 == 0 && cfg2 == 0 && cfg3 == 0 && n % 128 == 0 && D % 64 == 0 &&
         (int64_t)n * ldz * 8 < ((int64_t)1 << 31)))
     fz_mode = 0;
-  if (fz_mode != 2 && fz_mode != 3) fz_mode = 0;
+  if ((fz_mode != 2 && fz_mode != 3) || pd) fz_mode = 0;      // (the path derivative changes G between the products)
   const unsigned sum_blocks = (unsigned)((pslab / 2 + 255) / 256);
   // Z = E L' + mu - shift into `Z` (the samples, or z - m for the correlated Gaussian target)
   auto sample_gemm = [&](const double* shift, int cfg) {
@@ -1340,7 +1371,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   unsigned tiles2 = 0;
   bool g_prescaled = false;      // the target's own kernel wrote G already scaled by the row weights
   // diagonal Gaussian target under the dense Gaussian family: sum f out of the sampling product's epilogue
-  const bool diag_f = fast_env && !mvt && m.id == VB_MODEL_GAUSS_DIAG && !wm.roww && !row_scale && !pd &&
+  const bool diag_f = fast_env && !mvt && m.id == VB_MODEL_GAUSS_DIAG && !wm.roww && !row_scale &&
                       n % kGemmBK == 0 && gemm_uses_dma(g1) && (int64_t)splits <= n_rb;
   if (m.id == VB_MODEL_GAUSS_DIAG && diag_f) {
     tiles2 = gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiagF{G, ldz, mu, m.p0, m.p1, fpart});
@@ -1442,11 +1473,36 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   // (weighted sums: the same, once G is scaled -- the column sums of the gradient product's operand tiles ARE sum w g)
   const bool cs_only = diag_f || (fast_env && !fused_sums && !mvt && (m.id == VB_MODEL_FUNNEL || source) &&
                                  (!wm.roww || g_prescaled) &&
-                                 !row_scale && !pd && n % kGemmBK == 0 && gemm_uses_dma(g3) && (int64_t)splits <= n_rb);
+                                 !row_scale && n % kGemmBK == 0 && gemm_uses_dma(g3) && (int64_t)splits <= n_rb);
+  // path derivative: sum f belongs to the model's G, the column sums and the gradient product to G~ = G + E L^-1.  Where
+  // the pass below forms f from G (every target but the funnel and source models, whose own kernels left it behind) it
+  // runs once before the score is added -- for f -- and once after, for the column sums only
+  const bool f_from_pass = !(m.id == VB_MODEL_FUNNEL || source);
+  const bool two_passes = pd && !fused_sums && !cs_only && f_from_pass;
+  if (two_passes) {
+    hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
+                       (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart, fpart,
+                       glm ? 1.0 / (m.tau * m.tau) : 0.0, (const double*)nullptr, 0, (double*)nullptr,
+                       (const double*)nullptr);
+    VB_HIP(ctx, hipGetLastError());
+  }
+  if (pd) {       // G~ = G + E L^-1   (L^-1[k][j] = 0 for k < j: tri_mode 3)
+    GemmArgs gy;
+    gy.A = (const double*)ns.buf.ptr;
+    gy.lda = ns.ld;
+    gy.B = base + o_t;
+    gy.ldb = ldl;
+    gy.M = (int)n;
+    gy.N = D;
+    gy.K = D;
+    gy.tri_mode = 3;
+    gemm_f64_launch<true>(st, gy, 1, n_cu, EpiAccumulate{G, ldz});
+    VB_HIP(ctx, hipGetLastError());
+  }
   if (!fused_sums && !cs_only) {
     hipLaunchKernelGGL(fr_colsum_kernel, dim3((unsigned)cs_gx, (unsigned)n_rb), dim3(256), 0, st,
-                       (const double*)G, (const double*)Z, ldz, n, D, fmode, m.p1, colpart,
-                       (m.id == VB_MODEL_FUNNEL || source) ? fpart + n_fpart /*unused tail*/ : fpart,
+                       (const double*)G, (const double*)Z, ldz, n, D, two_passes ? 0 : fmode, m.p1, colpart,
+                       (!f_from_pass || two_passes) ? fpart + n_fpart /*unused tail*/ : fpart,
                        glm ? 1.0 / (m.tau * m.tau) : 0.0, (const double*)nullptr, 0, row_scale ? G : (double*)nullptr,
                        row_scale);
     VB_HIP(ctx, hipGetLastError());
@@ -1457,7 +1513,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
   // GEMM 3: C[i][j] = sum_n G[n][i] E[n][j]
   prof_events(ctx, &g3.ev0, &g3.ev1, 1, VB_PROF_FR_GRAD_GEMM);
-  int n_rb_red = n_rb + (pd ? 1 : 0), n_fpart_red = n_fpart;
+  int n_rb_red = n_rb, n_fpart_red = n_fpart;
   if (fz_mode == 3) {          // the fused launch has written the split slabs and their column sums
     n_rb_red = splits;
     n_fpart_red = (int)tiles2;
@@ -1488,14 +1544,14 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
   if (!ctx->comm) {   // single GPU: the split reduction writes (value, grad) itself
     hipLaunchKernelGGL(fr_reduce_packed_kernel<true>, red_grid, dim3(256), 0, st, (const double*)Cpart,
-                       splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb_red, ldz,
+                       splits, slab, D, ldl, (const double*)colpart, n_rb_red, ldz,
                        (const double*)fpart, n_fpart_red, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
                        pd ? 1 : 0, wm);
     VB_HIP(ctx, hipGetLastError());
     return VB_OK;
   }
   hipLaunchKernelGGL(fr_reduce_packed_kernel<false>, red_grid, dim3(256), 0, st, (const double*)Cpart,
-                     splits + (pd ? 1 : 0), slab, D, ldl, (const double*)colpart, n_rb_red, ldz,
+                     splits, slab, D, ldl, (const double*)colpart, n_rb_red, ldz,
                      (const double*)fpart, n_fpart_red, S, theta_dev, (double)n_total, (double)n_total, m.c0, out_dev,
                      pd ? 1 : 0, wm);
   VB_HIP(ctx, hipGetLastError());
