@@ -577,11 +577,12 @@ __global__ void __launch_bounds__(256) fr_rowscale_kernel(double* __restrict__ G
 }
 
 // ---- path derivative ("sticking the landing", objectives.py:156-159) for the dense Gaussian ----------------
-// value = -mean(f(z) - log q(z; stop(theta))): the score -dlog q/dz = L^-T eps is added to the model gradient,
-// so with M2 = sum_n eps_n eps_n' (the noise Gram matrix) and e = sum_n eps_n the sums become
-//     C' = C + L^-T M2,      colsum' = colsum + L^-T e,      value: 1/2 tr(M2) / N replaces D / 2,
-// an O(D^3) correction instead of a third N x D x D product.  L^-T = (L')^-1 is formed explicitly (blocked
-// recursive inversion, see fr_triinv_leaf_kernel and the host loop), so the correction itself is one GEMM.
+// value = -mean(f(z) - log q(z; stop(theta))): the score -dlog q/dz = L^-T eps is added to the model gradient row by
+// row, G~ = G + E L^-1 (one N x D x D / 2 product, fr_pipeline_enqueue), and the sums of G~ are the entropy form's sums
+// without the entropy term; value: 1/2 sum ||eps_n||^2 / N replaces D / 2.  L^-1 = ((L')^-1)' is formed explicitly
+// (blocked recursive inversion, see fr_triinv_leaf_kernel and the host loop, then a transposition).  Rounds 2-3 went
+// through the noise Gram matrix (C' = C + L^-T sum eps eps'): the same N x D^2 flops for the Gram product plus a
+// D x D x D product and a second column pass.
 struct EpiStoreD {          // C_z = sign * acc   (z: product index of a batched launch)
   double* C;
   int64_t ld;
@@ -669,7 +670,6 @@ __global__ void __launch_bounds__(256) fr_triinv_leaf_kernel(const double* __res
   if (lane + 64 <= j) Xb[(int64_t)(lane + 64) * ld + j] = x1;
 }
 
-// y = X e (one wave per row) into the extra column-sum row, and tr(M2) into the sum vector's slot 1
 // out[j][i] = in[i][j] for a d x d matrix (row stride ld both sides), 32 x 32 tiles through LDS
 __global__ void __launch_bounds__(256) fr_transpose_kernel(const double* __restrict__ in, double* __restrict__ out, int d,
                                                            int64_t ld) {
@@ -717,30 +717,6 @@ __global__ void __launch_bounds__(256) fr_sumsq_final_kernel(const double* __res
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
-__global__ void __launch_bounds__(256) fr_pd_matvec_kernel(const double* __restrict__ X, int64_t ld,
-                                                           const double* __restrict__ e,
-                                                           const double* __restrict__ M2, int64_t ldm, int d,
-                                                           double* __restrict__ yrow, int64_t ldz,
-                                                           double* __restrict__ trace_out) {
-  __shared__ double sh[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + wave;
-  if (i < d) {
-    double s = 0.0;
-    for (int k = i + lane; k < d; k += 64) s = fma(X[(int64_t)i * ld + k], e[k], s);   // X is upper triangular
-    s = fr_wave_sum(s);
-    if (lane == 0) yrow[i] = s;
-  } else if (i < ldz && lane == 0) {
-    yrow[i] = 0.0;
-  }
-  if (blockIdx.x == 0) {
-    double t = 0.0;
-    for (int k = threadIdx.x; k < d; k += 256) t += M2[(int64_t)k * ldm + k];
-    t = fr_block_sum(t, sh);
-    if (threadIdx.x == 0) *trace_out = t;
-  }
 }
 
 // theta -> mu, L' (dense, row stride ldl) on stream st
