@@ -315,8 +315,9 @@ def c3_leg(vb, calls=30):
     # product (lower tiles) -- three half products
     flops = 3.0 * N * D * (D + 1)
     out['flops_executed_per_call'] = flops
-    out['note'] = ('about 45 dependent kernels per call, everything including the O(D^3) factor algebra on the device; ten of '
-                   'them are the tempering bisection (50 levels, 96 us), the three GEMMs take 100 us for %.1f GFLOP '
+    out['note'] = ('about 40 dependent kernels per call, everything including the O(D^3) factor algebra on the device; five of '
+                   'them are the tempering bisection (50 levels walked along two predicted paths: ~45 us, was ten launches and '
+                   '96 us), PSIS smoothing runs on 16 workgroups (43 us, was 80), the three GEMMs take 100 us for %.1f GFLOP '
                    '(%.0f us at the dense GEMM rate): the call is bound by dependent launches, not by the matrix pipe; '
                    'per-kernel times: profiles/r04_c3_kernel_stats.txt' % (flops / 1e9, flops / 57e12 * 1e6))
     return out
@@ -687,6 +688,85 @@ def fullrank_funnel_leg(eng, vb, steps=200, ring=8, slot0=40):
                          'note': 'per-kernel times: profiles/r04_fullrank_funnel_kernel_stats.txt'}}
 
 
+def other_paths_leg(eng, vb):
+    """Blocking calls of the paths next to the headline that round 4 reworked: LRGaussian at ranks 8 / 32 / 64 (the streaming
+    kernel up to 16, the GEMM-assembled sums beyond), the full-rank path derivative, PSIS of N log weights, and the DIS
+    state refresh of a fresh problem (tempering bisection from [0, 1])."""
+    from viabel_amd._psis import psislw
+    out = {}
+    D, N = 1024, N_MC
+    rng = np.random.RandomState(0)
+    model = vb.FunnelModel(D)
+    eng.set_model(model.device_spec())
+    lr = {}
+    for k in (8, 32, 64):
+        fam = vb.LRGaussian(D, k=k)
+        theta = fam.pack(np.zeros(D), -np.ones(D), 0.05 * rng.randn(D, k))
+        eng.noise_generate(0, N, D, seed=1, stream=0)
+        eng.noise_generate(1, N, k, seed=2, stream=0)
+        call = ((lambda: eng.elbo_sums_lowrank(0, 1, N, D, k, theta)) if k > 16
+                else (lambda: eng.elbo_grad_lowrank(0, 1, N, D, k, theta)))
+        for _ in range(10):
+            call()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            call()
+        lr['k=%d' % k] = 1e6 * (time.perf_counter() - t0) / 100
+    out['lr_gaussian_us_per_call'] = lr
+    out['lr_gaussian_note'] = ('D=1024, N_mc=4096, funnel target; ranks above 16 take the GEMM-assembled sums (526 / 700 us at '
+                               'k = 32 / 64 before the parameter pieces, the column passes and the copies were merged)')
+    # full-rank path derivative at the headline shape (theta resident, enqueue rate like the headline)
+    A = rng.randn(D, D)
+    gm = vb.CorrelatedGaussianModel(rng.randn(D), covariance=A @ A.T / D + np.eye(D))
+    fr = vb.FullRankGaussian(D, rng='philox')
+    theta = fr.pack(np.zeros(D), np.exp(-1.0) * np.eye(D) + 0.01 * np.tril(rng.randn(D, D)))
+    obj_pd = vb.ExclusiveKL(fr, gm, N, use_path_deriv=True)
+    obj_en = vb.ExclusiveKL(vb.FullRankGaussian(D, rng='philox'), gm, N)
+    res = {}
+    for name, obj in (('path_derivative', obj_pd), ('entropy_form', obj_en)):
+        for _ in range(5):
+            obj(theta)
+        t0 = time.perf_counter()
+        for _ in range(40):
+            obj(theta)
+        res[name] = 1e6 * (time.perf_counter() - t0) / 40
+    out['fullrank_path_derivative'] = {'blocking_call_us': res, 'ratio': res['path_derivative'] / res['entropy_form'],
+                                       'note': 'same blocking host-to-host call both ways (parameter up, gradient down); '
+                                               'the score enters as G~ = G + E L^-1 (one triangular product + a blocked '
+                                               'triangular inverse); kernels: profiles/r04_fullrank_path_deriv_kernel_stats.txt'}
+    ps = {}
+    for n in (16384, 100000):
+        lw = 2.0 * rng.standard_t(3.0, n)
+        for _ in range(5):
+            psislw(lw)
+        t0 = time.perf_counter()
+        for _ in range(40):
+            sm, khat = psislw(lw)
+        ps['n=%d' % n] = {'us_per_call': 1e6 * (time.perf_counter() - t0) / 40, 'khat': float(khat)}
+    out['psis'] = ps
+    out['psis_note'] = ('blocking psislw(lw): upload, kernel, download; the kernel runs on ceil(n / 1024) <= 64 workgroups '
+                        '(43 us at n = 16 384, 70 us at 100 000; the single-workgroup kernel: 80 / 477 us) -- '
+                        'profiles/r04_psis_kernel_stats.txt')
+    Dm, Nm = 64, 16384
+    mrng = np.random.RandomState(7)
+    model = vb.GaussianModel(0.3 + 0.3 * mrng.randn(Dm), np.exp(0.2 * mrng.randn(Dm)))
+    prior = np.zeros(2 * Dm)
+    theta = prior + 0.02 * mrng.randn(2 * Dm)
+    obj = vb.DISInclusiveKL(vb.MFGaussian(Dm, seed=11, rng='philox'), model, Nm, ess_target=Nm // 8,
+                            temper_prior=vb.MFGaussian(Dm), temper_prior_params=prior, use_resampling=False)
+    ts = []
+    for _ in range(30):
+        obj._eps = 1.0
+        t0 = time.perf_counter()
+        obj(theta)
+        ts.append(time.perf_counter() - t0)
+    out['dis_refresh_fresh_problem'] = {'us_per_call': 1e6 * float(np.median(ts[5:])), 'eps': float(obj._eps), 'ess': float(obj._ess),
+                                        'note': 'MFGaussian(64), N = 16 384, eps restarts at 1: the 50-level bisection is four '
+                                                'speculative launches + a final one (~50 us of kernels; ten launches and ~96 us '
+                                                'before) -- profiles/r04_dis_bisect_kernel_stats.txt'}
+    return out
+
+
 def blas_threads_for_baseline():
     """Threads the CPU baseline's GEMMs run on: the GPU boxes of this pool show 256 cores to a container whose
     cgroup quota is far smaller, and an oversubscribed OpenBLAS pool is slower than a modest one."""
@@ -996,6 +1076,7 @@ def main():
             out['mvt_ekl'] = mvt_ekl_leg(vb)
             out['alpha_divergence'] = alpha_leg(vb)
             out['c4_logistic'] = c4_leg(eng, vb)
+            out['other_paths'] = other_paths_leg(eng, vb)
             try:
                 out['source_model'] = source_model_leg(vb)
             except Exception as exc:       # (no hiprtc on the box: the adaptor is the one part that needs it)

@@ -23,6 +23,8 @@ MAP = {   # committed file: (tail file or None, table file)
     'r04_alpha_kernel_stats.txt': ('alpha_tail.txt', 'alpha_kernel_stats.txt'),
     'r04_legacy_dev_kernel_stats.txt': ('legacydev_tail.txt', 'legacydev_kernel_stats.txt'),
     'r04_api_call_kernel_stats.txt': ('apicall_tail.txt', 'apicall_kernel_stats.txt'),
+    'r04_psis_kernel_stats.txt': ('psis_tail.txt', 'psis_kernel_stats.txt'),
+    'r04_dis_bisect_kernel_stats.txt': ('disbisect_tail.txt', 'disbisect_kernel_stats.txt'),
 }
 
 

@@ -30,6 +30,8 @@ run legacydev tools/legacy_dev_bench.py 4096 1024 20
 run apicall tools/api_call_bench.py 1024 4096 60
 run lr32 tools/lr_bench.py 1024 4096 32 funnel 100
 run lr64 tools/lr_bench.py 1024 4096 64 funnel 100
+run psis tools/psis_bench.py
+run disbisect tools/dis_bisect_bench.py
 if [ "$1" = "pmc" ]; then
   for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c -d $out/pmc_$c -o p -- python3 tools/fr_bench.py 1024 4096 gauss_full 100 > $out/pmc_$c.log 2>&1
