@@ -229,3 +229,35 @@ def test_grid_kernel_repeated_launches_share_the_barrier_counter(vb):
             (gs, gk), (ss, sk) = _psis_both(lw)
             assert gk == sk
             np.testing.assert_allclose(gs, ss, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('n', [1500, 16384, 70000])
+def test_grid_kernel_degenerate_inputs(vb, n):
+    """All weights equal (no element above the cut-off: nothing to fit, k-hat infinite), a block of -inf weights
+    (zero importance weights stay zero), and a tail far narrower than a radix bin: the multi-workgroup kernel against
+    the single-workgroup one."""
+    rng = np.random.RandomState(n)
+    cases = {
+        'equal': np.full(n, -3.25),
+        'minus_inf': np.where(rng.rand(n) < 0.3, -np.inf, rng.randn(n)),
+        'narrow': -10.0 + 1e-9 * rng.rand(n),
+        'two_values': np.where(rng.rand(n) < 0.01, 0.5, -0.5),
+    }
+    for name, lw in cases.items():
+        (gs, gk), (ss, sk) = _psis_both(lw)
+        assert gk == sk or (np.isnan(gk) and np.isnan(sk)) or (np.isinf(gk) and np.isinf(sk)), (name, gk, sk)
+        fin = np.isfinite(ss)
+        assert np.array_equal(fin, np.isfinite(gs)), name
+        np.testing.assert_allclose(gs[fin], ss[fin], rtol=0, atol=1e-12, err_msg=name)
+        assert np.array_equal(gs[~fin], ss[~fin], equal_nan=True), name
+
+
+def test_grid_kernel_reff(vb):
+    rng = np.random.RandomState(12)
+    lw = 1.8 * rng.standard_t(3.0, 30000)
+    for reff in (0.3, 1.0, 2.5):
+        (gs, gk), (ss, sk) = _psis_both(lw, reff)
+        assert gk == sk
+        np.testing.assert_allclose(gs, ss, rtol=0, atol=1e-12)
+        ref, rk = opsis.psis_smooth(lw, reff)
+        assert _close_k(gk, rk)
