@@ -538,7 +538,7 @@ __device__ __forceinline__ int pg_ld(const int* p) { return __hip_atomic_load(p,
 
 struct PgBarrier {
   unsigned long long* bar;
-  unsigned long long target;
+  unsigned long long target, tag;       // tag: this launch's mark in the poison word (nothing is reset between launches)
   int g_count, used;
   __device__ __forceinline__ void wait() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its write-through stores have left
@@ -554,7 +554,7 @@ struct PgBarrier {
       while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 24)) {        // (a workgroup that never arrives: poison the results instead of hanging)
-          atomicExch((unsigned long long*)(bar + 2), 1ull);
+          atomicExch((unsigned long long*)(bar + 2), tag);
           break;
         }
       }
@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_grid_kernel(double* __restr
   double* gsv = reinterpret_cast<double*>(work + kPgOffSv);
   int* gsi = reinterpret_cast<int*>(work + kPgOffSi);
   double* gq = reinterpret_cast<double*>(work + kPgOffQ);
-  PgBarrier barrier{bar, bar_base, G, 0};
+  PgBarrier barrier{bar, bar_base, bar_base + 1, G, 0};
 #ifdef VB_PSIS_CLOCK
   int dbg_k = 4;
 #define PG_MARK() do { if (g == 0 && t == 0) out[dbg_k] = (double)wall_clock64(); ++dbg_k; } while (0)
@@ -959,7 +959,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_grid_kernel(double* __restr
   double tot = 0.0;
   for (int q = 0; q < G; ++q) tot += pg_ld(&wgval[kPgMaxWg + q]);
   const double lse = log(tot) + new_max;
-  const bool poisoned = pg_ld(&bar[2]) != 0ull;
+  const bool poisoned = pg_ld(&bar[2]) == bar_base + 1;
 #pragma unroll
   for (int u = 0; u < E; ++u) {
     const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
@@ -1028,7 +1028,6 @@ int psis_enqueue(vb_ctx* ctx, int64_t n, double reff) {
       ctx->psis_bar_base = 0;
     }
     const unsigned long long bar_base = ctx->psis_bar_base;
-    ctx->psis_bar_base += (unsigned long long)wgs * kPgBarriers;
     char* work = (char*)ctx->psis_work.ptr;
     double* out = lw + round_up(n, 16);
     if (per_thread == 1)
@@ -1038,6 +1037,7 @@ int psis_enqueue(vb_ctx* ctx, int64_t n, double reff) {
     else
       hipLaunchKernelGGL(psis_grid_kernel<4>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base);
     VB_HIP(ctx, hipGetLastError());
+    ctx->psis_bar_base += (unsigned long long)wgs * kPgBarriers;      // (a launch that did not happen adds nothing)
     return VB_OK;
   }
   if (n <= (int64_t)kPsisRegs * kPsisThreads)
