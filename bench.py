@@ -693,6 +693,16 @@ def other_paths_leg(eng, vb):
     kernel up to 16, the GEMM-assembled sums beyond), the full-rank path derivative, PSIS of N log weights, and the DIS
     state refresh of a fresh problem (tempering bisection from [0, 1])."""
     from viabel_amd._psis import psislw
+
+    def median_us(call, reps, blocks=3):      # median of `blocks` timed blocks (host jitter on short calls)
+        ts = []
+        for _ in range(blocks):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            ts.append((time.perf_counter() - t0) / reps)
+        return 1e6 * sorted(ts)[len(ts) // 2]
+
     out = {}
     D, N = 1024, N_MC
     rng = np.random.RandomState(0)
@@ -708,10 +718,7 @@ def other_paths_leg(eng, vb):
                 else (lambda: eng.elbo_grad_lowrank(0, 1, N, D, k, theta)))
         for _ in range(10):
             call()
-        t0 = time.perf_counter()
-        for _ in range(100):
-            call()
-        lr['k=%d' % k] = 1e6 * (time.perf_counter() - t0) / 100
+        lr['k=%d' % k] = median_us(call, 50)
     out['lr_gaussian_us_per_call'] = lr
     out['lr_gaussian_note'] = ('D=1024, N_mc=4096, funnel target; ranks above 16 take the GEMM-assembled sums (526 / 700 us at '
                                'k = 32 / 64 before the parameter pieces, the column passes and the copies were merged)')
@@ -726,10 +733,7 @@ def other_paths_leg(eng, vb):
     for name, obj in (('path_derivative', obj_pd), ('entropy_form', obj_en)):
         for _ in range(5):
             obj(theta)
-        t0 = time.perf_counter()
-        for _ in range(40):
-            obj(theta)
-        res[name] = 1e6 * (time.perf_counter() - t0) / 40
+        res[name] = median_us(lambda: obj(theta), 20)
     out['fullrank_path_derivative'] = {'blocking_call_us': res, 'ratio': res['path_derivative'] / res['entropy_form'],
                                        'note': 'same blocking host-to-host call both ways (parameter up, gradient down); '
                                                'the score enters as G~ = G + E L^-1 (one triangular product + a blocked '
@@ -738,11 +742,8 @@ def other_paths_leg(eng, vb):
     for n in (16384, 100000):
         lw = 2.0 * rng.standard_t(3.0, n)
         for _ in range(5):
-            psislw(lw)
-        t0 = time.perf_counter()
-        for _ in range(40):
             sm, khat = psislw(lw)
-        ps['n=%d' % n] = {'us_per_call': 1e6 * (time.perf_counter() - t0) / 40, 'khat': float(khat)}
+        ps['n=%d' % n] = {'us_per_call': median_us(lambda: psislw(lw), 20), 'khat': float(khat)}
     out['psis'] = ps
     out['psis_note'] = ('blocking psislw(lw): upload, kernel, download; the kernel runs on ceil(n / 1024) <= 64 workgroups '
                         '(43 us at n = 16 384, 70 us at 100 000; the single-workgroup kernel: 80 / 477 us) -- '
