@@ -289,7 +289,7 @@ static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t d) 
   L.o_lprior = carve(L.nn);
   L.o_w = carve(L.nn);
   L.o_wres = carve(L.nn);      // resampled weights (multinomial counts) of the device-resident step
-  L.o_cdf = carve(L.nn + 16);  // running sums of the weights | their total at [nn]
+  L.o_cdf = carve(L.nn + 32 + L.nn / 1024);  // running sums of the weights per chunk of 1024 | their total at [nn] | chunk totals at [nn + 16]
   L.o_cnt = carve(L.nn / 2 + 16);   // int counts
   L.o_lqcopy = carve(L.nn);
   L.o_prior = carve(2 * L.ld);
@@ -537,69 +537,93 @@ __global__ void __launch_bounds__(256) mvt_inv_scale_kernel(const double* __rest
 // rng = 'philox' reproduces no noise stream of the reference, so the draw does not have to be numpy's: M uniforms from
 // the family's Philox stream, inverted through the running sums of the weights (the same searchsorted(side = 'right')
 // the host path uses); the result is the vector of counts as doubles -- what the weighted-score kernels take.
-// One workgroup forms the running sums in a fixed order (chunk per thread, chunk totals scanned by one thread).
-__global__ void __launch_bounds__(1024) mvt_cdf_kernel(const double* __restrict__ w, int64_t n, double* __restrict__ cdf,
-                                                       double* __restrict__ total, int* __restrict__ counts) {
-  // blocks of 1024 consecutive weights (coalesced), scanned by wave shuffles + one LDS hop over the 16 wave totals;
-  // the running total is carried from block to block -- a fixed summation tree, the same sums on every run
+// Running sums in two levels, every sum in a fixed order: workgroup c of mvt_cdf_kernel scans its chunk of 1024 weights
+// (wave shuffles + one LDS hop over the 16 wave totals) and leaves the chunk's total behind; every workgroup of the draw
+// kernel scans the chunk totals (the same numbers in the same order everywhere) and searches chunk, then element.  (A
+// single workgroup forming all N running sums took 22 us at N = 16 384 -- one CU's dependent chains -- against 5.)
+constexpr int kCdfChunk = 1024, kCdfMaxChunks = 2048;
+__global__ void __launch_bounds__(kCdfChunk) mvt_cdf_kernel(const double* __restrict__ w, int64_t n, double* __restrict__ cdf,
+                                                            double* __restrict__ chunk_total, int* __restrict__ counts) {
   __shared__ double wave_tot[16];
-  __shared__ double carry_sh;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (t == 0) carry_sh = 0.0;
-  __syncthreads();
-  // (sixteen blocks' worth of loads are issued before the first scan: the scans are sequential, the memory round trips
-  // need not be -- 24 -> 12 us at N = 16 384)
-  for (int64_t b0 = 0; b0 < n; b0 += 16 * 1024) {
-    double vals[16];
+  const int64_t i = (int64_t)blockIdx.x * kCdfChunk + t;
+  double v = i < n ? w[i] : 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int64_t i = b0 + k * 1024 + t;
-      vals[k] = i < n ? w[i] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int64_t b = b0 + k * 1024;
-      if (b >= n) break;                    // uniform for the workgroup
-      const int64_t i = b + t;
-      double v = vals[k];
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const double u = __shfl_up(v, off, 64);
-        if (lane >= off) v += u;
-      }
-      if (lane == 63) wave_tot[wv] = v;
-      __syncthreads();
-      double before = carry_sh;
-      for (int q = 0; q < wv; ++q) before += wave_tot[q];
-      v += before;
-      if (i < n) {
-        cdf[i] = v;
-        counts[i] = 0;
-      }
-      __syncthreads();
-      if (t == 1023) carry_sh = v;
-      __syncthreads();
-    }
+  for (int off = 1; off < 64; off <<= 1) {
+    const double u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
   }
-  if (t == 0) total[0] = carry_sh;
+  if (lane == 63) wave_tot[wv] = v;
+  __syncthreads();
+  double before = 0.0;
+  for (int q = 0; q < wv; ++q) before += wave_tot[q];
+  v += before;
+  if (i < n) {
+    cdf[i] = v;
+    counts[i] = 0;
+  }
+  if (t == kCdfChunk - 1) chunk_total[blockIdx.x] = v;
 }
 
-__global__ void __launch_bounds__(256) mvt_draw_kernel(const double* __restrict__ cdf, const double* __restrict__ total,
-                                                       int64_t n, int64_t m, uint64_t seed, uint64_t stream,
-                                                       int* __restrict__ counts) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) mvt_draw_kernel(const double* __restrict__ cdf, const double* __restrict__ chunk_total,
+                                                       double* __restrict__ total, int64_t n, int64_t m, uint64_t seed,
+                                                       uint64_t stream, int* __restrict__ counts) {
+  // exclusive running sums of the chunk totals: eight consecutive chunks per thread, the threads' sums scanned by
+  // wave shuffles and one LDS hop; pre[nc] = the sum of all weights
+  __shared__ double pre[kCdfMaxChunks + 1];
+  __shared__ double wave_tot[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int nc = (int)((n + kCdfChunk - 1) / kCdfChunk);
+  constexpr int kPer = kCdfMaxChunks / 256;
+  double loc[kPer], run = 0.0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int c = t * kPer + k;
+    loc[k] = run;                                   // exclusive inside the thread
+    run += c < nc ? chunk_total[c] : 0.0;
+  }
+  double v = run;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  const double up = __shfl_up(v, 1, 64);
+  if (lane == 63) wave_tot[wv] = v;
+  __syncthreads();
+  double before = 0.0;
+  for (int q = 0; q < wv; ++q) before += wave_tot[q];
+  const double offset = before + (lane ? up : 0.0);
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int c = t * kPer + k;
+    if (c <= nc) pre[c] = offset + loc[k];
+  }
+  if (t == 255) pre[kCdfMaxChunks] = offset + run;      // (nc == kCdfMaxChunks: the slot no thread's chunk index reaches)
+  __syncthreads();
+  const double sum = pre[nc];
+  if (blockIdx.x == 0 && t == 0) total[0] = sum;
+  const int64_t i = (int64_t)blockIdx.x * 256 + t;
   if (i >= m) return;
   Philox4 c;
   c.x = (uint32_t)i, c.y = (uint32_t)(i >> 32), c.z = (uint32_t)stream, c.w = 0x52534d50u;      // 'RSMP': its own sub-stream
   const Philox4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const double x = u01(r.x, r.y) * total[0];
-  int64_t lo = 0, hi = n;                  // first index with cdf > x (searchsorted side = 'right')
+  const double x = u01(r.x, r.y) * sum;
+  int clo = 0, chi = nc;                   // the chunk: the last one whose running sum in front of it is <= x
+  while (chi - clo > 1) {
+    const int mid = (clo + chi) >> 1;
+    if (pre[mid] <= x) clo = mid;
+    else chi = mid;
+  }
+  const double base = pre[clo];
+  const int64_t first = (int64_t)clo * kCdfChunk, last = first + kCdfChunk < n ? first + kCdfChunk : n;
+  int64_t lo = first, hi = last;           // first index with running sum > x (searchsorted side = 'right')
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
-    if (cdf[mid] > x) hi = mid;
+    if (base + cdf[mid] > x) hi = mid;
     else lo = mid + 1;
   }
-  if (lo >= n) lo = n - 1;
+  if (lo >= last) lo = last - 1;
   atomicAdd(&counts[lo], 1);               // integer: the counts do not depend on the order of arrival
 }
 
@@ -928,11 +952,13 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
       return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident weights: packed gradient on one rank only");
     if (resample_m > 0) {
       int* counts = (int*)(base + L.o_cnt);
-      hipLaunchKernelGGL(mvt_cdf_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_w), n, base + L.o_cdf,
-                         base + L.o_cdf + L.nn, counts);
+      if ((n + kCdfChunk - 1) / kCdfChunk > kCdfMaxChunks)
+        return fail(ctx, VB_ERR_UNSUPPORTED, "device multinomial draw: at most %d weights", kCdfChunk * kCdfMaxChunks);
+      hipLaunchKernelGGL(mvt_cdf_kernel, dim3((unsigned)((n + kCdfChunk - 1) / kCdfChunk)), dim3(kCdfChunk), 0, st,
+                         (const double*)(base + L.o_w), n, base + L.o_cdf, base + L.o_cdf + L.nn + 16, counts);
       hipLaunchKernelGGL(mvt_draw_kernel, dim3((unsigned)((resample_m + 255) / 256)), dim3(256), 0, st,
-                         (const double*)(base + L.o_cdf), (const double*)(base + L.o_cdf + L.nn), n, resample_m, seed,
-                         stream, counts);
+                         (const double*)(base + L.o_cdf), (const double*)(base + L.o_cdf + L.nn + 16), base + L.o_cdf + L.nn, n,
+                         resample_m, seed, stream, counts);
       hipLaunchKernelGGL(mvt_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int*)counts, n,
                          base + L.o_wres);
       VB_HIP(ctx, hipGetLastError());
