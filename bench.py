@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet fp64 matrix peak = 256 CUs x 4 SIMDs x 512 flop / 16 clk x 2.4 GHz;
 #                                                  tools/mfma_barrier_probe.hip measures 77.3 with constant operands
 # HBM-side bytes per launch of the headline's dense model GEMM at D=1024, N=4096 (see roofline.traffic_source)
-MODEL_GEMM_HBM_BYTES = int((2 * 64314.4 + 34442.3) * 1024)      # profiles/r04_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
+MODEL_GEMM_HBM_BYTES = int((2 * 64291.8 + 34488.6) * 1024)      # profiles/r04_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
 MF_ACCUM_HBM_BYTES = int((2 * 530474.5 + 8352.7) * 1024)           # profiles/r04_meanfield_c1_pmc_hbm.txt, per 32-evaluation launch
 MIN_TIMED_S = 0.05                               # the timed blocks are repeated until they cover at least this
 
