@@ -142,6 +142,11 @@ def test_c3_multivariate_t_dis_full_size_throughput_mode(vb, use_resampling, psi
             assert counts.sum() == M and np.all(counts == np.round(counts)) and counts.min() >= 0
             top = np.argsort(w)[-200:]            # the draw follows the weights: the 200 heaviest samples take their share
             assert abs(counts[top].sum() / M - w[top].sum() / w.sum()) < 0.05
+            # ... and block by block (32 index ranges, across the chunk boundaries of the two-level running sums):
+            # Pearson's statistic against M w / sum w has 31 degrees of freedom (mean 31, sd 7.9)
+            expect = M * w.reshape(32, -1).sum(axis=1) / w.sum()
+            chi2 = float(np.sum((counts.reshape(32, -1).sum(axis=1) - expect) ** 2 / expect))
+            assert chi2 < 80.0, chi2
             scale = ref._state_w_sum / N / M
             ov = -np.sum(counts * ofamily.log_density(theta, xs)) * scale
             og = -ofamily.log_density_grad_weighted(theta, xs, counts) * scale
