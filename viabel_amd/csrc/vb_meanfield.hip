@@ -1353,6 +1353,11 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
   const int target_wg = env_int("VB_MF_TARGET_WG", 2 * ctx->prop.multiProcessorCount);
   int n_rb_target = target_wg / g.n_cb / (c.count < 4 ? c.count : 4);
   if (n_rb_target < 8) n_rb_target = 8;
+  // narrow families with the noise in memory: the finalize kernel adds one partial per row block and column in a
+  // dependent chain (512 of them: 21 us at D = 64, N = 16 384 -- three times the streaming pass over those 8 MB), so a
+  // small matrix is cut into at most 128 row blocks.  (Not with the noise generated in registers: that pass is bound by
+  // the generator's arithmetic and wants every workgroup it can get -- MFStudentT 67 -> 106 us with the cap.)
+  if (!c.gen && n_rb_target > 128 && n * d * 8 < (int64_t)16 << 20) n_rb_target = env_int("VB_MF_MAX_ROW_BLOCKS", 128);
   n_rb_target = (n_rb_target + 7) / 8 * 8;
   int rows_per_wg = (int)((n + n_rb_target - 1) / n_rb_target);
   rows_per_wg = env_int("VB_MF_ROWS_PER_WG", rows_per_wg);
