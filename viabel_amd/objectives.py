@@ -14,6 +14,8 @@ all-reduced on the device before the epilogue; every rank returns the same ``(va
 """
 from abc import ABC, abstractmethod
 
+import os
+
 import numpy as np
 from scipy import linalg as _sla
 from scipy import special as _special
@@ -529,9 +531,10 @@ class ExclusiveKL(StochasticVariationalObjective):
             Sigma = L @ L.T
             inv_s = 1.0 / np.sqrt(chi / df)
             if path_deriv:
-                root, inv_root, info = eng.sym_sqrt_inv(Sigma)
                 eig = None
-                if not info[2] < _ROOT_TOL:
+                if D > _HOST_ROOT_MAX_DIM:
+                    root, inv_root, info = eng.sym_sqrt_inv(Sigma)
+                if D <= _HOST_ROOT_MAX_DIM or not info[2] < _ROOT_TOL:
                     eig = symmetric_eig(Sigma)
                     root, inv_root = (eig[1] * np.sqrt(eig[0])) @ eig[1].T, (eig[1] / np.sqrt(eig[0])) @ eig[1].T
             else:
@@ -640,14 +643,22 @@ def _lowrank_pieces(approx, var_param):
 
 
 _ROOT_TOL = 1e-12     # ||root root - Sigma|| / ||Sigma|| accepted from the Newton-Schulz iteration
+# Up to this dimension the factor algebra of the parity mode stays on the host: one `eigh` (28 us at D = 10, 0.25 ms at
+# D = 50) gives the root and the Sylvester solve, where the device's two GEMM iterations are ~40 dependent launches
+# (0.5 ms whatever the size).  Measured per objective call (tools/mvt_root_bench.py, tools/small_shapes_bench.py):
+# D = 10: 650 -> 223 us, 50: 1042 -> 328, 100: 1593 -> 867, 160: 2100 -> 1687, 200: equal, 256: the device wins
+_HOST_ROOT_MAX_DIM = int(os.environ.get('VIABEL_AMD_HOST_ROOT_MAX_DIM', '160'))
 
 
 def _device_root(eng, Sigma):
     """Symmetric square root of the scale matrix (``scipy.linalg.sqrtm`` in ``approximations.py:348``) by GEMM
     iterations on the device (``vb_sym_sqrt``); scale matrices the iteration cannot resolve to ``_ROOT_TOL``
-    (condition numbers beyond ~1e12) take the LAPACK route.  Returns ``(root, eig)``; ``eig = (w, U)`` only when
-    the eigen-decomposition had to be computed."""
+    (condition numbers beyond ~1e12) and small ones (``_HOST_ROOT_MAX_DIM``) take the LAPACK route.  Returns
+    ``(root, eig)``; ``eig = (w, U)`` only when the eigen-decomposition had to be computed."""
     _lib.apply_host_blas_policy()
+    if Sigma.shape[0] <= _HOST_ROOT_MAX_DIM:
+        w, U = symmetric_eig(Sigma)
+        return (U * np.sqrt(w)) @ U.T, (w, U)
     root, _, info = eng.sym_sqrt(Sigma)
     if info[2] < _ROOT_TOL:
         return root, None
