@@ -902,10 +902,9 @@ int vb_dis_grad_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const d
   if (!ctx || !theta || !weights || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   const size_t p = (size_t)(d + d * (d + 1) / 2);
-  std::vector<double> out(1 + p);
-  VB_TRY(mvt_dis_grad(ctx, n, d, df, theta, nullptr, weights, nullptr, nullptr, nullptr, nullptr, scale, out.data()));
-  *value = out[0];
-  memcpy(grad, out.data() + 1, p * sizeof(double));
+  (void)p;
+  VB_TRY(mvt_dis_grad(ctx, n, d, df, theta, nullptr, weights, nullptr, nullptr, nullptr, nullptr, scale, value, 0, 0, 0,
+                      nullptr, grad));
   return VB_OK;
 }
 
@@ -929,17 +928,15 @@ int vb_dis_step_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const d
   if (resample_m < 0) return fail(ctx, VB_ERR_INVALID, "resample_m must be >= 0");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   const size_t p = (size_t)(d + d * (d + 1) / 2);
-  std::vector<double> out(1 + p);
+  (void)p;
   double res[4] = {0.0, 0.0, 0.0, 0.0};
-  VB_TRY(mvt_dis_grad(ctx, n, d, df, theta, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scale, out.data(),
-                      resample_m, seed, stream, res));
+  VB_TRY(mvt_dis_grad(ctx, n, d, df, theta, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scale, value,
+                      resample_m, seed, stream, res, grad));
   *eps = res[0];
   *ess = res[1];
   if (khat) *khat = res[3];
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
-  *value = out[0];
-  memcpy(grad, out.data() + 1, p * sizeof(double));
   return VB_OK;
 }
 

@@ -454,7 +454,7 @@ int dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t n_t
 int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
                  const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out,
                  double scale = 0.0, double* packed_out = nullptr, int64_t resample_m = 0, uint64_t seed = 0,
-                 uint64_t stream = 0, double* res_out = nullptr);
+                 uint64_t stream = 0, double* res_out = nullptr, double* grad_direct = nullptr);
 int mvt_dis_weights_get(vb_ctx* ctx, double* w_host, int64_t n_total, int resampled);
 
 // symmetric square root / its derivative by coupled Newton-Schulz GEMM iterations (vb_linalg.hip)

@@ -307,7 +307,7 @@ static MvtLayout mvt_layout(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t d) 
   L.o_lfull = carve(sq);
   L.o_tscr = carve(sq);
   L.o_sl = carve(sq);      // S L of the packed chain rule (a carve of its own: n may be smaller than d)
-  L.o_grad = carve(1 + d + d * (d + 1) / 2);
+  L.o_grad = carve(1 + d + d * (d + 1) / 2 + 8);      // value | packed gradient | [eps, ess, status, khat, value]
   L.total = off;
   return L;
 }
@@ -395,11 +395,19 @@ __global__ void __launch_bounds__(256) mvt_symmetrize_kernel(const double* __res
 __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __restrict__ SL, const double* __restrict__ Lfull,
                                                             int64_t ld, int d, const double* __restrict__ sums,
                                                             int64_t off_col, double scale, double* __restrict__ out,
-                                                            const double* __restrict__ scale_dev) {
+                                                            const double* __restrict__ scale_dev,
+                                                            const double* __restrict__ res) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (scale_dev) scale *= scale_dev[0];      // (device-resident resampling: scale = sum w / (N M), sum w on the device)
   const double w_sum = sums[1], w_logq = sums[2];
-  if (idx == 0) out[0] = -scale * w_logq;
+  if (idx == 0) {
+    out[0] = -scale * w_logq;
+    // tail behind the gradient: [eps, ess, status, khat | value] -- the scalars of a step leave in one small copy while
+    // the gradient goes straight into the caller's array
+    double* tail = out + 1 + d + (int64_t)d * (d + 1) / 2;
+    for (int q = 0; q < 4; ++q) tail[q] = res[q];
+    tail[4] = -scale * w_logq;
+  }
   if (idx < d) out[1 + idx] = -scale * sums[off_col + idx];
   if (idx >= (int64_t)d * d) return;
   const int i = (int)(idx / d), j = (int)(idx % d);
@@ -935,7 +943,8 @@ int mvt_dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t
 // [eps, ess, zero-weight status] of the last refresh in the same synchronisation
 int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,
                  const double* w_host, double* wsum_out, double* wlogq_out, double* dmu_out, double* gram_out,
-                 double scale, double* packed_out, int64_t resample_m, uint64_t seed, uint64_t stream, double* res_out) {
+                 double scale, double* packed_out, int64_t resample_m, uint64_t seed, uint64_t stream, double* res_out,
+                 double* grad_direct) {
   if (ctx->mvt_n != n || ctx->mvt_d != d || !ctx->mvt_state.ptr)
     return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state of shape %lld x %lld", (long long)n, (long long)d);
   const MvtLayout L = mvt_layout(ctx, n, ctx->mvt_n_total, d);
@@ -1032,10 +1041,21 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     gemm_f64_launch<true>(st, gs, 1, n_cu, EpiStore{base + L.o_sl, L.ld});
     hipLaunchKernelGGL(mvt_pack_grad_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
                        (const double*)(base + L.o_sl), (const double*)(base + L.o_lfull), L.ld, D,
-                       (const double*)S.sums, S.off_col, scale, base + L.o_grad, scale_dev);
+                       (const double*)S.sums, S.off_col, scale, base + L.o_grad, scale_dev,
+                       (const double*)(base + L.o_scal + 8));
     VB_HIP(ctx, hipGetLastError());
-    VB_HIP(ctx, hipMemcpyAsync(packed_out, base + L.o_grad, (size_t)(1 + d + d * (d + 1) / 2) * sizeof(double),
-                               hipMemcpyDeviceToHost, st));
+    const size_t plen = (size_t)(d + d * (d + 1) / 2);
+    if (grad_direct) {       // gradient into the caller's array, the five scalars in one small copy (no host staging)
+      double tail[5];
+      VB_HIP(ctx, hipMemcpyAsync(grad_direct, base + L.o_grad + 1, plen * sizeof(double), hipMemcpyDeviceToHost, st));
+      VB_HIP(ctx, hipMemcpyAsync(tail, base + L.o_grad + 1 + plen, sizeof tail, hipMemcpyDeviceToHost, st));
+      VB_HIP(ctx, hipStreamSynchronize(st));
+      packed_out[0] = tail[4];
+      if (res_out)
+        for (int q = 0; q < 4; ++q) res_out[q] = tail[q];
+      return VB_OK;
+    }
+    VB_HIP(ctx, hipMemcpyAsync(packed_out, base + L.o_grad, (1 + plen) * sizeof(double), hipMemcpyDeviceToHost, st));
     if (res_out) VB_HIP(ctx, hipMemcpyAsync(res_out, base + L.o_scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     VB_HIP(ctx, hipStreamSynchronize(st));
     return VB_OK;
