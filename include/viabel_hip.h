@@ -526,6 +526,20 @@ int vb_legacy_rng_set_state(vb_legacy_rng* rng, const uint32_t key[624], int pos
  * ~64 M values): nothing was changed, draw with vb_legacy_rng_randn and upload.                                    */
 int vb_legacy_rng_randn_device(vb_ctx* ctx, vb_legacy_rng* rng, int slot, int64_t n_total, int64_t d, int64_t row_begin,
                                int64_t rows);
+/* RandomState.standard_t(df, (n_total, d)) -- MFStudentT's noise, approximations.py:273-274 -- rows [row_begin,
+ * row_begin + rows) into noise slot `slot`, and RandomState.chisquare(df, n) -- MultivariateT's scales, :345 -- into
+ * the context's chi-square buffer (what vb_chisq_generate fills; also copied to host_out unless NULL): values and
+ * generator state bit for bit numpy's.  The Marsaglia-Tsang rejection loop is evaluated for every possible state of
+ * the stream in parallel and the true trajectory is stitched by composing per-chunk transition maps
+ * (vb_legacy_gamma.hip); its logarithms are the host C library's own operation sequence (vb_legacy_rng_log_proven).
+ * VB_ERR_UNSUPPORTED (df <= 2, log not proven on this host, request beyond the jump ladder): nothing was changed,
+ * draw with vb_legacy_rng_standard_t / _chisquare.                                                                */
+int vb_legacy_rng_standard_t_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, int slot, int64_t n_total, int64_t d,
+                                    int64_t row_begin, int64_t rows);
+int vb_legacy_rng_chisquare_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, int64_t n, double* host_out);
+/* 1 when this host's libm log() has been located and restated bit for bit (vb_glibc_log.h): the device draws above are
+ * available and vb_legacy_rng_randn_device needs no host round trip.                                               */
+int vb_legacy_rng_log_proven(void);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels ---------
  * When enabled, every launch of a profiled kernel carries a start/stop event pair

@@ -177,6 +177,10 @@ SIGNATURES = {
                                                ctypes.c_double]),
     'vb_legacy_rng_randn_device': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                                   ctypes.c_int64, ctypes.c_int64]),
+    'vb_legacy_rng_standard_t_device': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int64,
+                                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
+    'vb_legacy_rng_chisquare_device': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int64, _c_double_p]),
+    'vb_legacy_rng_log_proven': (ctypes.c_int, []),
     'vb_comm_ipc_window': (ctypes.c_int, [_ctx_p, ctypes.c_size_t, ctypes.c_char_p]),
     'vb_comm_init_ipc': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
@@ -350,6 +354,29 @@ class Engine:
             return False
         self._check(rc)
         return True
+
+    def noise_legacy_standard_t(self, slot, rng_handle, df, n_total, d, row_begin=0, rows=None):
+        """Rows ``[row_begin, row_begin + rows)`` of ``RandomState.standard_t(df, (n_total, d))`` generated ON THE DEVICE
+        into ``slot``, values and generator state bit for bit numpy's (``vb_legacy_rng_standard_t_device``).  False: the
+        request is outside the device path's range, the generator is untouched."""
+        rows = n_total - row_begin if rows is None else rows
+        rc = self._lib.vb_legacy_rng_standard_t_device(self._ctx, rng_handle, float(df), slot, n_total, d, row_begin, rows)
+        if rc == VB_ERR_UNSUPPORTED:
+            return False
+        self._check(rc)
+        return True
+
+    def chisq_legacy(self, rng_handle, df, n, to_host=True):
+        """``RandomState.chisquare(df, n)`` generated ON THE DEVICE into the context's chi-square buffer (where
+        ``chisq_generate`` puts the throughput mode's), bit for bit numpy's; returns the host copy (``to_host``), True, or
+        None when the request is outside the device path's range (generator untouched)."""
+        out = np.empty(n, dtype=np.float64) if to_host else None
+        rc = self._lib.vb_legacy_rng_chisquare_device(self._ctx, rng_handle, float(df), n,
+                                                      _dptr(out) if to_host else None)
+        if rc == VB_ERR_UNSUPPORTED:
+            return None
+        self._check(rc)
+        return out if to_host else True
 
     def noise_get_host(self, slot, n, d):
         out = np.empty((n, d), dtype=np.float64)

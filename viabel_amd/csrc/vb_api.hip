@@ -471,6 +471,72 @@ int vb_legacy_rng_randn_device(vb_ctx* ctx, vb_legacy_rng* rng, int slot, int64_
   return vb_legacy_rng_set_state(rng, key, pos, has_gauss, gauss);
 }
 
+// chisquare (prog 0) / standard_t (prog 1) on the device (vb_legacy_gamma.hip).  The device path starts from a generator
+// without a cached normal: while one is cached, the leading values are drawn one at a time by the host generator (each
+// such draw leaves the cache set with probability ~1/2) and copied to their places.
+static int legacy_gamma_device(vb_ctx* ctx, vb_legacy_rng* rng, int prog, double df, double* dst, int64_t ld, int64_t n_total,
+                               int64_t d, int64_t row_begin, int64_t rows) {
+  uint32_t key[624];
+  int pos = 0, has_gauss = 0;
+  double gauss = 0.0;
+  VB_TRY(vb_legacy_rng_get_state(rng, key, &pos, &has_gauss, &gauss));
+  uint32_t key0[624];
+  memcpy(key0, key, sizeof key0);
+  const int pos0 = pos, has0 = has_gauss;
+  const double gauss0 = gauss;
+  auto rewind = [&]() { return vb_legacy_rng_set_state(rng, key0, pos0, has0, gauss0); };
+  const int64_t n_out = n_total * d;
+  int64_t o = 0;
+  while (has_gauss && o < n_out) {
+    double v = 0.0;
+    VB_TRY(prog == 1 ? vb_legacy_rng_standard_t(rng, df, &v, 1) : vb_legacy_rng_chisquare(rng, df, &v, 1));
+    const int64_t row = o / d, col = o - row * d;
+    if (row >= row_begin && row < row_begin + rows)
+      VB_HIP(ctx, hipMemcpyAsync(dst + (row - row_begin) * ld + col, &v, sizeof v, hipMemcpyHostToDevice, ctx->stream));
+    VB_HIP(ctx, hipStreamSynchronize(ctx->stream));      // (`v` is on the stack)
+    ++o;
+    VB_TRY(vb_legacy_rng_get_state(rng, key, &pos, &has_gauss, &gauss));
+  }
+  if (o == n_out) return VB_OK;
+  const int rc = legacy_dev_gamma(ctx, prog, df, key, &pos, &has_gauss, &gauss, dst, ld, o, n_total, d, row_begin, rows);
+  if (rc != VB_OK) {
+    (void)rewind();
+    if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "device draw not available for this request: draw on the host");
+    return rc;
+  }
+  return vb_legacy_rng_set_state(rng, key, pos, has_gauss, gauss);
+}
+
+int vb_legacy_rng_standard_t_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, int slot, int64_t n_total, int64_t d,
+                                    int64_t row_begin, int64_t rows) {
+  if (!ctx || !rng) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (n_total <= 0 || d <= 0 || row_begin < 0 || rows <= 0 || row_begin + rows > n_total || !(df > 0.0))
+    return fail(ctx, VB_ERR_INVALID, "rows [%lld, %lld) of a %lld x %lld draw, df %g", (long long)row_begin,
+                (long long)(row_begin + rows), (long long)n_total, (long long)d, df);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  VB_TRY(noise_alloc(ctx, slot, rows, d));
+  NoiseSlot& ns = ctx->noise[slot];
+  return legacy_gamma_device(ctx, rng, 1, df, (double*)ns.buf.ptr, ns.ld, n_total, d, row_begin, rows);
+}
+
+int vb_legacy_rng_chisquare_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, int64_t n, double* host_out) {
+  if (!ctx || !rng) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (n <= 0 || !(df > 0.0)) return fail(ctx, VB_ERR_INVALID, "%lld chi-square draws, df %g", (long long)n, df);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  VB_TRY(ensure(ctx, ctx->chi_dev, (size_t)n * sizeof(double)));
+  ctx->chi_n = 0;
+  VB_TRY(legacy_gamma_device(ctx, rng, 0, df, (double*)ctx->chi_dev.ptr, 1, n, 1, 0, n));
+  ctx->chi_n = n;
+  ctx->chi_df = df;
+  if (host_out) {
+    VB_HIP(ctx, hipMemcpyAsync(host_out, ctx->chi_dev.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return VB_OK;
+}
+
 int vb_set_model_callback(vb_ctx* ctx, int64_t dim, vb_model_callback fn, void* user) {
   if (!ctx) return VB_ERR_INVALID;
   if (!fn) return fail(ctx, VB_ERR_INVALID, "NULL callback");

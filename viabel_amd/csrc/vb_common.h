@@ -333,6 +333,20 @@ int user_rows_enqueue(vb_ctx* ctx, hipStream_t st, const double* Z, int64_t ldz,
 void user_model_release(vb_ctx* ctx);
 int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, double* gauss, const NoiseSlot& ns,
                      int64_t n_total, int64_t d, int64_t row_begin, int64_t rows);
+// numpy's legacy word stream on the device (vb_legacy_dev.hip) for the draws built on it (vb_legacy_gamma.hip)
+struct LegacyWords {
+  const uint32_t* words = nullptr;   // untempered output words, words[0] = the word at the generator's position
+  int64_t* scal = nullptr;           // 8 zeroed 64-bit scalars
+  uint32_t* extra = nullptr;         // the caller's scratch
+  const void* logtab = nullptr;      // GlibcLogData on the device, or NULL when the host's log could not be restated
+  int64_t pre = 0, n_words = 0;      // words left in the generator's current block; words generated
+};
+int legacy_mt_words(vb_ctx* ctx, const uint32_t key[624], int pos, int64_t n_words, size_t extra_u32, LegacyWords* out);
+int legacy_mt_finish(vb_ctx* ctx, const LegacyWords& lw, int64_t w_star, uint32_t key[624], int* pos);
+// chisquare (prog 0) / standard_t (prog 1) draws, values o_first ... n - 1 of the request, into rows of a noise-slot-like
+// array (vb_legacy_gamma.hip); the generator must hold no cached normal
+int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* pos, int* has_gauss, double* gauss,
+                     double* dst, int64_t ld, int64_t o_first, int64_t n_total, int64_t d, int64_t row_begin, int64_t rows);
 void vb_legacy_finish_pairs(const double* list, int64_t n, double* fixed);      // vb_legacy_rng.cpp (host libm)
 // log density of the installed tempering prior (ctx->temper.kind != 0) at the rows of X
 int mvt_dis_clip_enqueue(vb_ctx* ctx, int64_t n_total, double threshold);

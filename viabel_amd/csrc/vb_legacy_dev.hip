@@ -27,6 +27,7 @@
 // Anything this path cannot take (more than 1024 streams, a list overflow, an attempt budget that fell short -- 10
 // sigma above the mean) returns VB_ERR_UNSUPPORTED with the generator untouched, and the caller draws on the host.
 #include "vb_common.h"
+#include "vb_glibc_log.h"
 #include "vb_mt_jump.h"
 
 #include <cmath>
@@ -319,9 +320,18 @@ __device__ __forceinline__ void put_value(const EmitArgs& a, int64_t o, double v
   if (row >= a.row_begin && row < a.row_begin + a.rows) a.slot[(row - a.row_begin) * a.ld + col] = v;
 }
 
-__global__ void __launch_bounds__(256) mtd_emit_kernel(const EmitArgs a) {
+// kExact: log(r2) by the host C library's own sequence of operations on its own table (vb_glibc_log.h; `logtab` proven
+// against the host's log by vb_glibc_log_locate): every value is final here, no list, nothing for the host to finish.
+template <bool kExact>
+__global__ void __launch_bounds__(256) mtd_emit_kernel(const EmitArgs a, const GlibcLogData* __restrict__ logtab) {
   __shared__ int wave_cnt[4];
   __shared__ int hard_fill;
+  __shared__ GlibcLogData lt;
+  if (kExact) {
+    const double* src = reinterpret_cast<const double*>(logtab);
+    double* dst = reinterpret_cast<double*>(&lt);
+    for (int i = threadIdx.x; i < (int)(sizeof(GlibcLogData) / sizeof(double)); i += 256) dst[i] = src[i];
+  }
   if (threadIdx.x == 0) hard_fill = 0;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int64_t i0 = (int64_t)blockIdx.x * kAttemptsPerWg + 4 * t;
@@ -348,6 +358,19 @@ __global__ void __launch_bounds__(256) mtd_emit_kernel(const EmitArgs a) {
     if (!at[k].ok) continue;
     if (q < a.pairs) {
       const double x1 = at[k].x1, x2 = at[k].x2, r2 = at[k].r2;
+      if (kExact) {
+        const double f = sqrt(-2.0 * glibc_log(r2, lt) / r2);
+        const double v0 = f * x2, v1 = f * x1;
+        put_value(a, a.first + 2 * q, v0);
+        if (2 * q + 1 < a.n_vals) put_value(a, a.first + 2 * q + 1, v1);
+        if (q == a.pairs - 1) {
+          a.a_star[0] = i0 + k;
+          a.last_x1f[0] = v1;
+          a.a_star[1] = 0;
+        }
+        ++q;
+        continue;
+      }
       const dd L = dd_log(r2);
       // correctly rounded log = L.hi; the C library's may be the neighbour on the side of L.lo when the true value is
       // within 0.03 ulp of the midpoint (its error bound is 0.52 ulp)
@@ -383,7 +406,7 @@ __global__ void __launch_bounds__(256) mtd_emit_kernel(const EmitArgs a) {
     ++q;
   }
   __syncthreads();
-  if (threadIdx.x == 0) a.hard_cnt[blockIdx.x] = hard_fill;
+  if (!kExact && threadIdx.x == 0) a.hard_cnt[blockIdx.x] = hard_fill;
 }
 
 // the segments, one behind the other: list[hbase[wg] + i] = segment wg's entry i
@@ -412,6 +435,80 @@ __global__ void __launch_bounds__(256) mtd_patch_kernel(const EmitArgs a, const 
 __global__ void mtd_first_value_kernel(const EmitArgs a, double v) { put_value(a, 0, v); }
 
 }  // namespace
+
+// The generator's next `n_words` output words (untempered) on the device, from the state (key, pos): out->words[0] is the
+// word at `pos`.  legacy_work is laid out [polynomials | key | 16 scalars (zeroed) | log table | words | stream states |
+// ladder sequences | `extra_u32` words for the caller]; every region starts 16-byte aligned.  VB_ERR_UNSUPPORTED: more
+// streams than the jump ladder reaches.
+int legacy_mt_words(vb_ctx* ctx, const uint32_t key[624], int pos, int64_t n_words, size_t extra_u32, LegacyWords* out) {
+  hipStream_t st = ctx->stream;
+  const int64_t pre = kN - pos;                                      // unread words of the current block
+  const int64_t n_blocks = n_words > pre ? (n_words - pre + kN - 1) / kN : 1;
+  const int64_t streams = (n_blocks + kMtBlocksPerStream - 1) / kMtBlocksPerStream;
+  if (streams > ((int64_t)1 << (2 * kMtJumpRounds))) return VB_ERR_UNSUPPORTED;
+  size_t off = 0;
+  auto carve = [&off](size_t words32) {
+    const size_t o = off;
+    off += (words32 + 3) & ~(size_t)3;
+    return o;
+  };
+  int64_t pow2 = 1;      // (capacity of the state / sequence areas: a power of four)
+  while (pow2 < streams) pow2 <<= 2;
+  // (fixed-size regions first: the polynomials and the log table stay where they were uploaded from call to call)
+  const size_t o_poly = carve((size_t)kMtJumpPolys * kN), o_key = carve(kN), o_scal = carve(16),
+               o_log = carve(sizeof(GlibcLogData) / sizeof(uint32_t)),
+               o_words = carve((size_t)(pre + n_blocks * kN) + 8), o_state = carve((size_t)pow2 * kN),
+               o_seq = carve((size_t)(pow2 / 4 > 0 ? pow2 / 4 : 1) * kSeqWords), o_extra = carve(extra_u32);
+  VB_TRY(ensure(ctx, ctx->legacy_work, off * sizeof(uint32_t)));
+  uint32_t* base = (uint32_t*)ctx->legacy_work.ptr;
+  uint32_t *words = base + o_words, *state = base + o_state, *seq = base + o_seq, *poly = base + o_poly, *key_dev = base + o_key;
+  const GlibcLogData* host_tab = vb_glibc_log_locate();
+  if (ctx->legacy_poly_at != (const void*)poly || ctx->legacy_poly_bytes != ctx->legacy_work.bytes) {      // (a new allocation is zeroed)
+    VB_HIP(ctx, hipMemcpyAsync(poly, kMtJump, sizeof kMtJump, hipMemcpyHostToDevice, st));
+    if (host_tab) VB_HIP(ctx, hipMemcpyAsync(base + o_log, host_tab, sizeof(GlibcLogData), hipMemcpyHostToDevice, st));
+    ctx->legacy_poly_at = poly;
+    ctx->legacy_poly_bytes = ctx->legacy_work.bytes;
+  }
+  VB_HIP(ctx, hipMemcpyAsync(key_dev, key, kN * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  VB_HIP(ctx, hipMemsetAsync(state, 0, (size_t)pow2 * kN * sizeof(uint32_t), st));
+  VB_HIP(ctx, hipMemsetAsync(base + o_scal, 0, 16 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(mtd_first_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)key_dev, pos, words, state);
+  int r = 0;
+  for (int64_t count = 1; count < streams; count <<= 2, ++r) {      // radix 4: the known stream starts quadruple per round
+    const int n_src = (int)std::min<int64_t>(count, streams - count);      // sources with at least one target
+    hipLaunchKernelGGL(mtd_seq_kernel, dim3((unsigned)n_src), dim3(256), 0, st, (const uint32_t*)state, seq);
+    hipLaunchKernelGGL(mtd_corr_kernel, dim3((unsigned)n_src, kCorrSlices, 6), dim3(320), 0, st, (const uint32_t*)poly, 3 * r,
+                       (const uint32_t*)seq, state, (int)count, (int)streams);
+  }
+  hipLaunchKernelGGL(mtd_stream_kernel, dim3((unsigned)streams), dim3(256), 0, st, (const uint32_t*)state, words, pre, n_blocks);
+  VB_HIP(ctx, hipGetLastError());
+  out->words = words;
+  out->scal = (int64_t*)(base + o_scal);
+  out->extra = base + o_extra;
+  out->logtab = host_tab ? (const void*)(base + o_log) : nullptr;
+  out->pre = pre;
+  out->n_words = pre + n_blocks * kN;
+  return VB_OK;
+}
+
+// Where the generator stands after consuming `w_star` of those words: the new position and, when the position has left
+// the block the call started in, that block's words into key[] (one small copy down + a synchronisation).
+int legacy_mt_finish(vb_ctx* ctx, const LegacyWords& lw, int64_t w_star, uint32_t key[624], int* pos) {
+  if (w_star <= lw.pre) {
+    *pos = (int)(*pos + w_star);               // still inside the block the call started in
+    return VB_OK;
+  }
+  const int64_t offw = w_star - lw.pre;
+  int64_t key_block = offw / kN;
+  int new_pos = (int)(offw % kN);
+  if (new_pos == 0) key_block -= 1, new_pos = kN;      // exactly at a block end: numpy refreshes lazily
+  if (key_block < 0 || lw.pre + (key_block + 1) * kN > lw.n_words)
+    return fail(ctx, VB_ERR_STATE, "legacy generator: inconsistent end position");
+  VB_HIP(ctx, hipMemcpyAsync(key, lw.words + lw.pre + key_block * kN, kN * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *pos = new_pos;
+  return VB_OK;
+}
 
 // The draws s.randn(n_total, d) of the generator whose state is (key, pos, has_gauss, gauss): rows [row_begin,
 // row_begin + rows) into `ns`; the state afterwards in the same variables.  VB_ERR_UNSUPPORTED: nothing changed, draw on
@@ -449,74 +546,56 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
   const double p_acc = 0.78539816339744830962;
   const double sigma = std::sqrt((double)pairs * (1.0 - p_acc)) / p_acc;
   const int64_t attempts = (int64_t)((double)pairs / p_acc + 10.0 * sigma) + 64;
-  const int64_t n_words = 4 * attempts;
-  const int64_t pre = kN - *pos;                                      // unread words of the current block
-  const int64_t n_blocks = n_words > pre ? (n_words - pre + kN - 1) / kN : 1;
-  const int64_t streams = (n_blocks + kMtBlocksPerStream - 1) / kMtBlocksPerStream;
-  if (streams > ((int64_t)1 << (2 * kMtJumpRounds))) return VB_ERR_UNSUPPORTED;
   const int64_t n_wg = (attempts + kAttemptsPerWg - 1) / kAttemptsPerWg;
   const int64_t hard_cap = pairs / 8 + 1024;
+  const bool exact = vb_glibc_log_locate() != nullptr;
 
-  // scratch (uint32 units, every region 16-byte aligned): words | states | seq | polys | key | cnt | base | hard | scalars
+  // the caller's part of the scratch (uint32 units, every region 16-byte aligned): cnt | base | hard | ...
   size_t off = 0;
   auto carve = [&off](size_t words32) {
     const size_t o = off;
     off += (words32 + 3) & ~(size_t)3;
     return o;
   };
-  int64_t pow2 = 1;      // (capacity of the state / sequence areas: a power of four)
-  while (pow2 < streams) pow2 <<= 2;
-  // (fixed-size regions first: the polynomials stay where they were uploaded from call to call)
-  const size_t o_poly = carve((size_t)kMtJumpPolys * kN), o_key = carve(kN), o_scal = carve(16),
-               o_words = carve((size_t)(pre + n_blocks * kN) + 8), o_state = carve((size_t)pow2 * kN),
-               o_seq = carve((size_t)(pow2 / 4 > 0 ? pow2 / 4 : 1) * kSeqWords), o_cnt = carve((size_t)n_wg),
-               o_base = carve(2 * (size_t)(n_wg + 1)), o_hard = carve(2 * 4 * (size_t)hard_cap),
-               o_hseg = carve(2 * 4 * (size_t)n_wg * kHardPerWg), o_hcnt = carve((size_t)n_wg), o_hbase = carve(2 * (size_t)(n_wg + 1)),
-               o_fixed = carve(2 * 3 * (size_t)hard_cap);
-  VB_TRY(ensure(ctx, ctx->legacy_work, off * sizeof(uint32_t)));
-  uint32_t* base = (uint32_t*)ctx->legacy_work.ptr;
-  uint32_t *words = base + o_words, *state = base + o_state, *seq = base + o_seq, *poly = base + o_poly, *key_dev = base + o_key;
-  if (ctx->legacy_poly_at != (const void*)poly || ctx->legacy_poly_bytes != ctx->legacy_work.bytes) {      // (a new allocation is zeroed)
-    VB_HIP(ctx, hipMemcpyAsync(poly, kMtJump, sizeof kMtJump, hipMemcpyHostToDevice, st));
-    ctx->legacy_poly_at = poly;
-    ctx->legacy_poly_bytes = ctx->legacy_work.bytes;
+  const size_t o_cnt = carve((size_t)n_wg), o_base = carve(2 * (size_t)(n_wg + 1));
+  size_t o_hard = 0, o_hseg = 0, o_hcnt = 0, o_hbase = 0, o_fixed = 0;
+  if (!exact) {
+    o_hard = carve(2 * 4 * (size_t)hard_cap), o_hseg = carve(2 * 4 * (size_t)n_wg * kHardPerWg), o_hcnt = carve((size_t)n_wg);
+    o_hbase = carve(2 * (size_t)(n_wg + 1)), o_fixed = carve(2 * 3 * (size_t)hard_cap);
   }
-  VB_HIP(ctx, hipMemcpyAsync(key_dev, key, kN * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipMemsetAsync(state, 0, (size_t)pow2 * kN * sizeof(uint32_t), st));
-  VB_HIP(ctx, hipMemsetAsync(base + o_scal, 0, 16 * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(mtd_first_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)key_dev, *pos, words, state);
-  int r = 0;
-  for (int64_t count = 1; count < streams; count <<= 2, ++r) {      // radix 4: the known stream starts quadruple per round
-    const int n_src = (int)std::min<int64_t>(count, streams - count);      // sources with at least one target
-    hipLaunchKernelGGL(mtd_seq_kernel, dim3((unsigned)n_src), dim3(256), 0, st, (const uint32_t*)state, seq);
-    hipLaunchKernelGGL(mtd_corr_kernel, dim3((unsigned)n_src, kCorrSlices, 6), dim3(320), 0, st, (const uint32_t*)poly, 3 * r,
-                       (const uint32_t*)seq, state, (int)count, (int)streams);
-  }
-  hipLaunchKernelGGL(mtd_stream_kernel, dim3((unsigned)streams), dim3(256), 0, st, (const uint32_t*)state, words, pre, n_blocks);
+  LegacyWords lw;
+  VB_TRY(legacy_mt_words(ctx, key, *pos, 4 * attempts, off, &lw));
+  uint32_t* base = lw.extra;
+  const uint32_t* words = lw.words;
   int* cnt = (int*)(base + o_cnt);
   int64_t* pbase = (int64_t*)(base + o_base);
-  hipLaunchKernelGGL(mtd_count_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, (const uint32_t*)words, attempts, cnt);
+  hipLaunchKernelGGL(mtd_count_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, words, attempts, cnt);
   hipLaunchKernelGGL(mtd_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)cnt, n_wg, pbase);
   EmitArgs a;
   a.words = words, a.attempts = attempts, a.base = pbase;
   a.pairs = pairs, a.n_vals = n_vals, a.first = first;
   a.d = d, a.row_begin = row_begin, a.rows = rows, a.ld = ns.ld;
   a.slot = (double*)ns.buf.ptr;
-  a.hard_seg = (double*)(base + o_hseg), a.hard_cnt = (int*)(base + o_hcnt);
+  a.hard_seg = exact ? nullptr : (double*)(base + o_hseg);
+  a.hard_cnt = exact ? nullptr : (int*)(base + o_hcnt);
   double* hard_list = (double*)(base + o_hard);
   int64_t* hbase = (int64_t*)(base + o_hbase);
-  int64_t* scal = (int64_t*)(base + o_scal);      // [0] a*, [1] last pair on the list?, [3] f x1 of the last pair
+  int64_t* scal = lw.scal;      // [0] a*, [1] last pair on the list?, [3] f x1 of the last pair
   a.a_star = scal;
   a.last_x1f = (double*)(scal + 3);
   if (first) hipLaunchKernelGGL(mtd_first_value_kernel, dim3(1), dim3(1), 0, st, a, *gauss);
-  hipLaunchKernelGGL(mtd_emit_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(mtd_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)a.hard_cnt, n_wg, hbase);
-  hipLaunchKernelGGL(mtd_compact_kernel, dim3((unsigned)n_wg), dim3(64), 0, st, (const double*)a.hard_seg,
-                     (const int*)a.hard_cnt, (const int64_t*)hbase, hard_list, scal + 4);
+  if (exact) {
+    hipLaunchKernelGGL(mtd_emit_kernel<true>, dim3((unsigned)n_wg), dim3(256), 0, st, a, (const GlibcLogData*)lw.logtab);
+  } else {
+    hipLaunchKernelGGL(mtd_emit_kernel<false>, dim3((unsigned)n_wg), dim3(256), 0, st, a, (const GlibcLogData*)nullptr);
+    hipLaunchKernelGGL(mtd_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)a.hard_cnt, n_wg, hbase);
+    hipLaunchKernelGGL(mtd_compact_kernel, dim3((unsigned)n_wg), dim3(64), 0, st, (const double*)a.hard_seg,
+                       (const int*)a.hard_cnt, (const int64_t*)hbase, hard_list, scal + 4);
+  }
   VB_HIP(ctx, hipGetLastError());
-  // results through one pinned buffer: [scalars 4 | accepted | list (first `spec` entries, speculatively) | fixed | key]
+  // results through one pinned buffer: [scalars 4 | accepted | list (first `spec` entries, speculatively) | fixed]
   const int64_t spec = std::min<int64_t>(hard_cap, pairs / 20 + 256);      // ~1.7 x the expected list length
-  const size_t pin_doubles = 8 + (size_t)4 * hard_cap + (size_t)3 * hard_cap + kN / 2 + 8;
+  const size_t pin_doubles = 8 + (exact ? 0 : (size_t)4 * hard_cap + (size_t)3 * hard_cap) + 8;
   if (ctx->legacy_pin_doubles < pin_doubles) {
     if (ctx->legacy_pin) VB_HIP(ctx, hipHostFree(ctx->legacy_pin));
     ctx->legacy_pin = nullptr;
@@ -527,36 +606,26 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
   int64_t* accepted = res + 4;
   double* list = ctx->legacy_pin + 8;
   double* fixed = list + 4 * hard_cap;
-  uint32_t* key_pin = (uint32_t*)(fixed + 3 * hard_cap);
+  res[2] = 0, res[5] = 0;
   VB_HIP(ctx, hipMemcpyAsync(res, scal, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(res + 2, hbase + n_wg, sizeof(int64_t), hipMemcpyDeviceToHost, st));      // list length
-  VB_HIP(ctx, hipMemcpyAsync(res + 5, scal + 4, sizeof(int64_t), hipMemcpyDeviceToHost, st));          // segment overflow?
   VB_HIP(ctx, hipMemcpyAsync(accepted, pbase + n_wg, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(list, hard_list, (size_t)4 * spec * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (!exact) {
+    VB_HIP(ctx, hipMemcpyAsync(res + 2, hbase + n_wg, sizeof(int64_t), hipMemcpyDeviceToHost, st));      // list length
+    VB_HIP(ctx, hipMemcpyAsync(res + 5, scal + 4, sizeof(int64_t), hipMemcpyDeviceToHost, st));          // segment overflow?
+    VB_HIP(ctx, hipMemcpyAsync(list, hard_list, (size_t)4 * spec * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   VB_HIP(ctx, hipStreamSynchronize(st));
-  const int64_t n_hard = res[2];
+  const int64_t n_hard = exact ? 0 : res[2];
   // (budget, list or a workgroup's segment fell short: host path)
-  if (*accepted < pairs || n_hard > hard_cap || res[5] != 0) return VB_ERR_UNSUPPORTED;
+  if (*accepted < pairs || n_hard > hard_cap || (!exact && res[5] != 0)) return VB_ERR_UNSUPPORTED;
   double last_x1f;
   memcpy(&last_x1f, &res[3], sizeof last_x1f);
-  // where the generator stands afterwards: just behind the last consumed attempt
-  const int64_t w_star = 4 * (res[0] + 1);
-  int64_t key_block = -1;      // block (counted from the first refreshed one) whose words become numpy's key; -1: unchanged
-  int new_pos = 0;
-  if (w_star <= pre) {
-    new_pos = (int)(*pos + w_star);               // still inside the block the call started in
-  } else {
-    const int64_t offw = w_star - pre;
-    key_block = offw / kN;
-    new_pos = (int)(offw % kN);
-    if (new_pos == 0) key_block -= 1, new_pos = kN;      // exactly at a block end: numpy refreshes lazily
-    if (key_block < 0) return fail(ctx, VB_ERR_STATE, "legacy generator: inconsistent end position");
-    VB_HIP(ctx, hipMemcpyAsync(key_pin, words + pre + key_block * kN, kN * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  }
-  if (n_hard > spec)
+  const int64_t w_star = 4 * (res[0] + 1);      // the generator stands just behind the last consumed attempt
+  if (n_hard > spec) {
     VB_HIP(ctx, hipMemcpyAsync(list + 4 * spec, hard_list + 4 * spec, (size_t)4 * (n_hard - spec) * sizeof(double),
                                hipMemcpyDeviceToHost, st));
-  if (n_hard > spec) VB_HIP(ctx, hipStreamSynchronize(st));
+    VB_HIP(ctx, hipStreamSynchronize(st));
+  }
   if (n_hard > 0) {
     vb_legacy_finish_pairs(list, n_hard, fixed);
     for (int64_t i = 0; i < n_hard; ++i)
@@ -565,9 +634,10 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
     VB_HIP(ctx, hipMemcpyAsync(fixed_dev, fixed, (size_t)3 * n_hard * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(mtd_patch_kernel, dim3((unsigned)((n_hard + 255) / 256)), dim3(256), 0, st, a,
                        (const double*)fixed_dev, n_hard);
+    VB_HIP(ctx, hipStreamSynchronize(st));          // the patch has read the pinned list
   }
-  VB_HIP(ctx, hipStreamSynchronize(st));          // the patch has read the pinned list; the key block has arrived
-  if (key_block >= 0) memcpy(key, key_pin, kN * sizeof(uint32_t));
+  int new_pos = *pos;
+  VB_TRY(legacy_mt_finish(ctx, lw, w_star, key, &new_pos));
   *pos = new_pos;
   *has_gauss = (n_vals & 1) ? 1 : 0;
   *gauss = (n_vals & 1) ? last_x1f : 0.0;
