@@ -207,6 +207,23 @@ def meanfield_leg(eng, vb, _lib, steps=2000, warmup=200, batch=32, ring_total=16
     for i in range(n_sync):
         eng.elbo_grad_meanfield_philox(0, N_MC, d, theta, fam, 1, 1000 + i)
     fresh_rate = n_sync / (time.perf_counter() - t3)
+    # the reference-identical mode (default rng='numpy'): every call draws RandomState(seed).randn(N, D) /
+    # .standard_t(df, (N, D)) -- approximations.py:216, :273-274 -- on the device, bit for bit (vb_legacy_dev.hip,
+    # vb_legacy_gamma.hip), then evaluates
+    parity_mode = {}
+    for name, approx_np in (('mf_gaussian', vb.MFGaussian(d)), ('mf_student_t_df7', vb.MFStudentT(d, 7))):
+        obj = vb.ExclusiveKL(approx_np, model, N_MC)
+        for _ in range(3):
+            obj(theta)
+        blocks = []
+        for _ in range(3):
+            t4 = time.perf_counter()
+            for _ in range(10):
+                obj(theta)
+            blocks.append((time.perf_counter() - t4) / 10)
+        parity_mode[name + '_ms_per_call'] = 1e3 * statistics.median(blocks)
+    parity_mode['note'] = ("blocking objective(theta) with the reference's own noise stream drawn per call on the device "
+                           '(4.2 M values); round 4: 14.1 ms / ~160 ms (host draw + upload)')
     kernel_us = 1e3 * kernel_ms / max(1, launches)
     bytes_per_launch = algo_bytes * evals_timed / max(1, launches)
     achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
@@ -219,6 +236,7 @@ def meanfield_leg(eng, vb, _lib, steps=2000, warmup=200, batch=32, ring_total=16
         'workload': 'BASELINE configs[1]: MFGaussian + ExclusiveKL, D=1024 funnel, N_mc=4096, fp64',
         'evals_per_s_batched': steps / elapsed, 'evals_per_launch': batch,
         'sync_call_evals_per_s': sync_rate, 'fresh_noise_sync_call_evals_per_s': fresh_rate,
+        'parity_mode': parity_mode,
         'roofline': {'bound': 'hbm', 'kernel': 'mf_accum_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'avg_kernel_us': kernel_us,
                      'launches_timed': launches, 'algorithmic_bytes_per_launch': bytes_per_launch,
@@ -310,6 +328,26 @@ def c3_leg(vb, calls=30):
             'value': float(v), 'grad_norm': float(np.linalg.norm(g))}
         if psis:
             out[key]['khat'] = float(obj._khat)
+    # the reference-identical mode (default rng='numpy'): RandomState(seed).chisquare then randn (approximations.py:345-347)
+    # generated on the device bit for bit, the symmetric root of :348, the global numpy generator's resampling draw (:408)
+    approx_np = vb.MultivariateT(D, df, seed=1)
+    for resample in (False, True):
+        obj = vb.DISInclusiveKL(approx_np, model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+                                temper_prior_params=prior, use_resampling=resample)
+        for _ in range(5):
+            obj(theta)
+        blocks = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                v, g = obj(theta)
+            blocks.append((time.perf_counter() - t0) / 10)
+        dt = statistics.median(blocks)
+        out['parity_mode_' + ('resampling' if resample else 'weighted')] = {
+            'ms_per_call': 1e3 * dt, 'block_ms': [1e3 * b for b in blocks], 'eps': float(obj._eps), 'ess': float(obj._ess),
+            'value': float(v), 'grad_norm': float(np.linalg.norm(g)),
+            'note': "rng='numpy': the reference's own noise stream (16 384 chi-square draws + 4.2 M normals per call, on the "
+                    'device) and its symmetric matrix root'}
     # executed work of one refresh + gradient in this mode: the sample GEMM through L' (triangular), U = E' L^-1
     # (triangular; the residuals E' of freshly drawn samples are the scaled noise: no product) and the weighted Gram
     # product (lower tiles) -- three half products

@@ -252,6 +252,15 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q);
+/* The reference-identical step resident on the device (one rank): as vb_dis_refresh_mvt with chi, sqrt_sigma, l_inv and
+ * w NULL -- factors from theta on the device, chi-square draws from the context's buffer (vb_legacy_rng_chisquare_device
+ * for numpy's stream), nothing copied back -- but the samples go through the SYMMETRIC root of Sigma = L L'
+ * (approximations.py:348), formed on the device by a Newton-Schulz iteration scaled by the infinity norm; root_info (3
+ * doubles, may be NULL) = [steps, last residual, ||R R - Sigma|| / ||Sigma||_inf].  vb_dis_step_mvt_packed follows.
+ * VB_ERR_UNSUPPORTED: the iteration did not resolve the root to 1e-12 (no state was installed): use the host route. */
+int vb_dis_refresh_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
+                               const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
+                               double* root_info);
 /* Throughput mode of the dense families: vb_dis_refresh_mvt with sqrt_sigma == NULL and l_inv == NULL forms mu, L and
  * L^-1 from `theta` on the device (blocked triangular inverse, GEMM levels) and draws the state samples through the
  * Cholesky factor, x = mu + (z L') / s -- same distribution as the symmetric root of approximations.py:348, which is
@@ -283,6 +292,9 @@ int vb_dis_psis_mvt(vb_ctx* ctx, int64_t n_total, double reff);
  * weight reaches it (oracle.objectives.DISInclusiveKL._clip).  Enqueues only (one workgroup, fixed summation order). */
 int vb_dis_clip_mvt(vb_ctx* ctx, int64_t n_total, double threshold);
 int vb_dis_weights_get(vb_ctx* ctx, double* w, int64_t n_total, int resampled /* 1: the counts of the last draw */);
+/* [eps, ess, zero-weight status, khat] of the last device-resident refresh (what vb_dis_step_mvt_packed returns with its
+ * gradient), for callers that weight the score themselves (vb_dis_grad_mvt_packed after a host resampling draw).   */
+int vb_dis_scalars_get(vb_ctx* ctx, double out[4]);
 /* The DIS state samples live in the context, one set per family kind (0: mean-field, 1: MultivariateT / dense
  * Gaussian, 2: low-rank Gaussian); every refresh of a kind overwrites its set and bumps its generation counter.  A
  * caller that keeps weights for a later vb_dis_grad_* call compares the counter with the one it saw after its own

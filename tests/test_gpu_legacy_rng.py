@@ -92,3 +92,117 @@ def test_multivariate_t_sequence_chi_square_then_device_normals(env):
     np.testing.assert_array_equal(chi, ref.chisquare(df, N))
     np.testing.assert_array_equal(eng.noise_get_host(4, N, D), ref.randn(N, D))
     _same_state(approx._rs, ref)
+
+
+# ---- chisquare / standard_t on the device (vb_legacy_gamma.hip): the t families' noise, approximations.py:273-274, :345 ----
+def _need_log(env):
+    from viabel_amd import _lib
+    if not _lib.load().vb_legacy_rng_log_proven():
+        pytest.skip("this host's libm log could not be restated: the device gamma path reports UNSUPPORTED by design")
+
+
+@pytest.mark.parametrize('n,d', [(4096, 1024), (4095, 1023), (1001, 77), (3, 5), (1, 1), (257, 2049)])
+@pytest.mark.parametrize('df', [2.5, 7, 100])
+def test_device_standard_t_equals_numpy(env, n, d, df):
+    _need_log(env)
+    vb, eng, LegacyRandomState = env
+    ours, ref = LegacyRandomState(226), np.random.RandomState(226)
+    assert eng.noise_legacy_standard_t(7, ours._h, df, n, d)
+    np.testing.assert_array_equal(eng.noise_get_host(7, n, d), ref.standard_t(df, (n, d)))
+    _same_state(ours, ref)
+    np.testing.assert_array_equal(ours.standard_t(df, 5), ref.standard_t(df, 5))     # the host generator goes on in step
+
+
+@pytest.mark.parametrize('n', [1, 2, 17, 1000, 4096, 16384, 16385, 262144])
+@pytest.mark.parametrize('df', [2.5, 7, 100])
+def test_device_chisquare_equals_numpy(env, n, df):
+    _need_log(env)
+    vb, eng, LegacyRandomState = env
+    ours, ref = LegacyRandomState(56), np.random.RandomState(56)
+    got = eng.chisq_legacy(ours._h, df, n)
+    assert got is not None
+    np.testing.assert_array_equal(got, ref.chisquare(df, n))
+    np.testing.assert_array_equal(eng.chisq_get_host(n), got)        # ... and they are the context's resident draws
+    _same_state(ours, ref)
+
+
+def test_device_gamma_draws_with_a_cached_normal_and_in_sequence(env):
+    """A cached normal carried INTO a draw (the leading values come from the host generator until the cache is empty),
+    draws that start in the middle of a generator block, and the three kinds of draw interleaved on one generator."""
+    _need_log(env)
+    vb, eng, LegacyRandomState = env
+    ours, ref = LegacyRandomState(12), np.random.RandomState(12)
+    for k, (kind, n, d, df) in enumerate([('t', 501, 129, 7), ('chi', 5000, 1, 3.5), ('n', 64, 1000, 0), ('t', 7, 3, 100),
+                                          ('chi', 4097, 1, 41), ('t', 1000, 333, 2.5), ('chi', 2, 1, 9), ('n', 3, 33, 0),
+                                          ('t', 300, 300, 4)]):
+        if k % 2 == 0:            # an odd number of host normals first: a cached value enters the device draw
+            np.testing.assert_array_equal(ours.randn(3 + 2 * k), ref.randn(3 + 2 * k))
+        if kind == 't':
+            assert eng.noise_legacy_standard_t(6, ours._h, df, n, d)
+            np.testing.assert_array_equal(eng.noise_get_host(6, n, d), ref.standard_t(df, (n, d)), err_msg=str(k))
+        elif kind == 'chi':
+            np.testing.assert_array_equal(eng.chisq_legacy(ours._h, df, n), ref.chisquare(df, n), err_msg=str(k))
+        else:
+            assert eng.noise_legacy_randn(6, ours._h, n, d)
+            np.testing.assert_array_equal(eng.noise_get_host(6, n, d), ref.randn(n, d), err_msg=str(k))
+        _same_state(ours, ref)
+
+
+def test_device_standard_t_row_blocks_of_a_sharded_draw(env):
+    _need_log(env)
+    vb, eng, LegacyRandomState = env
+    n, d, df = 1003, 200, 6.0
+    want = np.random.RandomState(9).standard_t(df, (n, d))
+    for begin, rows in ((0, 1003), (0, 502), (502, 501), (1002, 1)):
+        ours, ref = LegacyRandomState(9), np.random.RandomState(9)
+        ref.standard_t(df, (n, d))
+        assert eng.noise_legacy_standard_t(5, ours._h, df, n, d, begin, rows)
+        np.testing.assert_array_equal(eng.noise_get_host(5, rows, d), want[begin:begin + rows])
+        _same_state(ours, ref)
+
+
+def test_device_gamma_out_of_range_leaves_the_generator_alone(env):
+    """shape <= 1 (df <= 2) is numpy's other gamma algorithm: the device path declines and nothing has changed."""
+    vb, eng, LegacyRandomState = env
+    ours, ref = LegacyRandomState(4), np.random.RandomState(4)
+    assert eng.chisq_legacy(ours._h, 2.0, 5000) is None
+    assert not eng.noise_legacy_standard_t(5, ours._h, 1.5, 300, 300)
+    _same_state(ours, ref)
+    np.testing.assert_array_equal(ours.chisquare(2.0, 50), ref.chisquare(2.0, 50))
+
+
+def test_mfstudentt_default_mode_draws_on_the_device(env):
+    """ExclusiveKL(MFStudentT(1024, df)) with the DEFAULT rng='numpy': the noise the kernels stream is
+    RandomState(seed).standard_t(df, (N, D)), drawn on the device; generator in step over consecutive calls."""
+    _need_log(env)
+    vb, eng, LegacyRandomState = env
+    from oracle import families as ofam, models as omod, objectives as oobj
+    from viabel_amd.objectives import _NOISE_SLOT
+    D, N, df = 1024, 4096, 7
+    approx = vb.MFStudentT(D, df, seed=1)
+    ref = np.random.RandomState(1)
+    obj = vb.ExclusiveKL(approx, vb.GaussianModel(np.zeros(D), np.ones(D)), N)
+    theta = approx.init_param() * 0.1
+    for call in range(2):
+        value, grad = obj(theta)
+        noise = ref.standard_t(df, (N, D))
+        np.testing.assert_array_equal(eng.noise_get_host(_NOISE_SLOT, N, D), noise)
+        ov, og = oobj.exclusive_kl(ofam.MFStudentT(D, df), omod.GaussDiag(np.zeros(D), np.ones(D)), theta, noise)
+        assert abs(value - ov) <= 1e-12 * abs(ov)
+        assert np.max(np.abs(grad - og)) <= 1e-11 * np.max(np.abs(og))
+    _same_state(approx._rs, ref)
+
+
+def test_multivariate_t_sequence_all_on_the_device(env):
+    """MultivariateT.sample's order (approximations.py:345-347): N chi-square draws, then the N x D normals -- both on
+    the device at the C3 shape, the generator where numpy's is afterwards."""
+    _need_log(env)
+    vb, eng, LegacyRandomState = env
+    D, N, df = 256, 16384, 40.0
+    approx = vb.MultivariateT(D, df, seed=3)
+    ref = np.random.RandomState(3)
+    for call in range(2):
+        chi = approx._stage_base_noise(eng, 4, N, 0, N)
+        np.testing.assert_array_equal(chi, ref.chisquare(df, N))
+        np.testing.assert_array_equal(eng.noise_get_host(4, N, D), ref.randn(N, D))
+        _same_state(approx._rs, ref)

@@ -138,6 +138,10 @@ SIGNATURES = {
                                           _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_double_p,
                                           _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    'vb_dis_scalars_get': (ctypes.c_int, [_ctx_p, _c_double_p]),
+    'vb_dis_refresh_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                                  _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                                  _c_double_p]),
     'vb_dis_refresh_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int64, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p,
                                               _c_double_p, ctypes.c_double, _c_double_p, ctypes.c_double,
@@ -669,6 +673,20 @@ class Engine:
             self._ctx, slot, n, d, n, float(df), _dptr(theta), None, None, None, _dptr(prior_theta), float(eps_prev),
             float(ess_target), int(max_bisection_its), None, None, None, None, None))
 
+    def dis_refresh_mvt_symroot(self, slot, n, d, df, theta, prior_theta, eps_prev, ess_target, max_bisection_its=50):
+        """The reference-identical refresh resident on the device (``vb_dis_refresh_mvt_symroot``): the noise in ``slot``
+        and the context's chi-square draws are numpy's stream, the samples go through the symmetric root of ``Sigma``
+        formed on the device.  Returns ``info = [steps, residual, accuracy]`` of the root, or None when the iteration did
+        not resolve it (nothing was installed: take the host route)."""
+        theta, prior_theta = _f64(theta), _f64(prior_theta)
+        info = np.zeros(3, dtype=np.float64)
+        rc = self._lib.vb_dis_refresh_mvt_symroot(self._ctx, slot, n, d, float(df), _dptr(theta), _dptr(prior_theta),
+                                                  float(eps_prev), float(ess_target), int(max_bisection_its), _dptr(info))
+        if rc == VB_ERR_UNSUPPORTED:
+            return None
+        self._check(rc)
+        return info
+
     def dis_step_mvt_packed(self, n, d, df, theta, scale, resample_m=0, seed=0, stream=0):
         """``(value, grad, eps, ess)``: gradient of ``-scale sum w log q`` on the device-resident tempered weights, or
         on ``resample_m`` multinomial draws from them (then ``scale`` multiplies ``sum w`` on the device)."""
@@ -689,6 +707,12 @@ class Engine:
     def dis_clip_mvt(self, n_total, threshold):
         """Enqueue the weight clipping (``objectives.py:370-386``) of the device-resident weights, in place."""
         self._check(self._lib.vb_dis_clip_mvt(self._ctx, int(n_total), float(threshold)))
+
+    def dis_scalars_get(self):
+        """``(eps, ess, khat)`` of the last device-resident refresh."""
+        out = np.zeros(4, dtype=np.float64)
+        self._check(self._lib.vb_dis_scalars_get(self._ctx, _dptr(out)))
+        return out[0], out[1], out[3]
 
     def dis_weights_get(self, n_total, resampled=False):
         w = np.empty(n_total, dtype=np.float64)

@@ -127,6 +127,7 @@ class _NoiseMixin:
 
     # -- parity-mode noise into a device slot ---------------------------------------------------------------------------
     _DEVICE_DRAW_FROM = 1 << 16      # values; below this the host draw + upload is as fast as the device path's launches
+    _DEVICE_CHI_FROM = 1 << 12       # chi-square draws; the sequential host loop costs ~60 ns a draw, the device path ~0.2 ms
 
     def _stage_normals(self, eng, rs, slot, n_total, d, begin, end):
         """Rows ``[begin, end)`` of ``rs.randn(n_total, d)`` into ``slot``.  Big draws are generated ON THE DEVICE from the
@@ -240,6 +241,17 @@ class MFStudentT(_NoiseMixin, ApproximationFamily):
 
     def _base_noise(self, n_samples, seed=None):
         return self._random_state(seed).standard_t(self.df, size=(n_samples, self.dim))   # :273-274
+
+    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
+        """Rows ``[begin, end)`` of ``standard_t(df, (n_total, dim))`` into ``slot``: big draws ON THE DEVICE from the
+        generator's own state, values and state bit for bit numpy's (``vb_legacy_rng_standard_t_device``); small ones, and
+        anything the device path does not take, on the host."""
+        rs = self._random_state(seed)
+        if (n_total * self.dim >= self._DEVICE_DRAW_FROM and isinstance(rs, LegacyRandomState)
+                and eng.noise_legacy_standard_t(slot, rs._h, self.df, n_total, self.dim, begin, end - begin)):
+            return None
+        eng.noise_set_host(slot, rs.standard_t(self.df, size=(n_total, self.dim))[begin:end])
+        return None
 
     def _unpack(self, var_param):
         var_param = np.asarray(var_param, dtype=np.float64)
@@ -419,7 +431,12 @@ class MultivariateT(_NoiseMixin, ApproximationFamily):
     def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
         """The normals into ``slot``; returns the chi-square draws (all ``n_total`` of them: O(N) host work)."""
         rs = self._random_state(seed)
-        chi = rs.chisquare(self.df, n_total)               # first, as ``sample`` draws them (:345-347)
+        chi = None                                         # first, as ``sample`` draws them (:345-347)
+        if n_total >= self._DEVICE_CHI_FROM and isinstance(rs, LegacyRandomState):
+            chi = eng.chisq_legacy(rs._h, self.df, n_total)    # on the device, bit for bit numpy's (None: not this path's case)
+        self._chi_on_device = chi is not None              # ... and resident in the context (vb_dis_refresh_mvt_symroot)
+        if chi is None:
+            chi = rs.chisquare(self.df, n_total)
         self._stage_normals(eng, rs, slot, n_total, self.dim, begin, end)
         return chi
 

@@ -956,6 +956,22 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                          ess_target, max_bisection_its, eps, ess, w, log_p, log_q);
 }
 
+int vb_dis_refresh_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
+                               const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
+                               double* root_info) {
+  if (!ctx || !theta || !prior_theta) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident refresh: one rank");
+  if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  const int rc = mvt_dis_refresh(ctx, ctx->noise[slot], n, n, d, df, theta, nullptr, nullptr, nullptr, prior_theta, eps_prev,
+                                 ess_target, max_bisection_its, nullptr, nullptr, nullptr, nullptr, nullptr, true, root_info);
+  if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "matrix square root: not resolved on the device");
+  return rc;
+}
+
 int vb_dis_generation(vb_ctx* ctx, int kind, uint64_t* generation) {
   if (!ctx || !generation) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (kind < 0 || kind > 2) return fail(ctx, VB_ERR_INVALID, "DIS state kind %d outside [0, 2]", kind);
@@ -1010,6 +1026,14 @@ int vb_dis_weights_get(vb_ctx* ctx, double* w, int64_t n_total, int resampled) {
   if (!ctx || !w) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   return mvt_dis_weights_get(ctx, w, n_total, resampled);
+}
+
+int vb_dis_scalars_get(vb_ctx* ctx, double out[4]) {
+  if (!ctx || !out) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(mvt_dis_scalars_get(ctx, out));
+  if ((int)out[2] == 1) return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
+  return VB_OK;
 }
 
 int vb_dis_state_get(vb_ctx* ctx, int dense, double* log_p, double* log_q, int64_t n_total) {

@@ -350,6 +350,9 @@ int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* p
 void vb_legacy_finish_pairs(const double* list, int64_t n, double* fixed);      // vb_legacy_rng.cpp (host libm)
 // log density of the installed tempering prior (ctx->temper.kind != 0) at the rows of X
 int mvt_dis_clip_enqueue(vb_ctx* ctx, int64_t n_total, double threshold);
+int mvt_dis_scalars_get(vb_ctx* ctx, double out[4]);
+int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, int64_t ld, double* root, double tol,
+                 double* info);      // vb_linalg.hip
 int temper_prior_rows(vb_ctx* ctx, const double* X, int64_t ld, int64_t n, int64_t d, double* out);
 int temper_prior_set(vb_ctx* ctx, int kind, int64_t d, double df, const double* loc, const double* scale, double log_det_l);
 int user_model_set_callback(vb_ctx* ctx, int64_t dim, vb_model_callback fn, void* user);
@@ -462,7 +465,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
                     const double* theta_host,
                     const double* chi_host, const double* root_host, const double* linv_host,
                     const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
-                    double* ess_out, double* w_host, double* logp_host, double* logq_host);
+                    double* ess_out, double* w_host, double* logp_host, double* logq_host, bool sym_root = false,
+                    double* root_info = nullptr);
 int mvt_dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t n_total);
 int dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t n_total);
 int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta_host, const double* linv_host,

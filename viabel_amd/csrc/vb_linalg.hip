@@ -183,6 +183,137 @@ int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* r
   return VB_OK;
 }
 
+// ---- the same root with the matrix already on the device: Sigma = L L' from the unpacked factor ----------------------
+// (the reference-identical MultivariateT + DISInclusiveKL step, rng='numpy', resident on the device: approximations.py:348
+// needs sqrtm(Sigma) for the samples and nothing else of order D^3 on the host).  Differences from sym_sqrt above:
+//   * the scale c is the infinity norm max_i sum_j |Sigma_ij| >= lambda_max instead of the Frobenius norm -- for the
+//     well-conditioned scale matrices an optimiser visits the spectrum of Sigma / c then starts next to 1 and the
+//     iteration is quadratic from the first step (4-5 steps at D = 256 where the Frobenius scale, 1 / sqrt(D) of it,
+//     takes 10-12);
+//   * Y <- Y T and Z <- T Z are ONE batched launch ([Y | T | Z] contiguous);
+//   * the host reads the residuals of a GROUP of steps at a time (ring of partial sums in pinned memory) instead of
+//     synchronising inside every step.
+namespace {
+
+struct EpiStoreBatch {      // C_b = acc, C_b = C + b * stride
+  double* C;
+  int64_t ld, stride;
+  __device__ void operator()(int b, int row, int col, double acc) const { C[b * stride + (int64_t)row * ld + col] = acc; }
+};
+
+// one workgroup: c = max_i sum_j |A_ij|; A <- A / c (kept for the accuracy check), Y = A / c, Z = I (pads zero); scal[0] = c
+__global__ void __launch_bounds__(1024) ns_init_kernel(double* __restrict__ A, int d, int64_t ld, double* __restrict__ Y,
+                                                       double* __restrict__ Z, double* __restrict__ scal) {
+  __shared__ double wave_max[16];
+  __shared__ double c_sh;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  double mx = 0.0;
+  for (int i = wv; i < d; i += 16) {
+    double s = 0.0;
+    for (int j = lane; j < d; j += 64) s += fabs(A[(int64_t)i * ld + j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    mx = fmax(mx, s);      // (lane 0 holds the row sum)
+  }
+  if (lane == 0) wave_max[wv] = mx;
+  __syncthreads();
+  if (t == 0) {
+    double c = 0.0;
+    for (int w = 0; w < 16; ++w) c = fmax(c, wave_max[w]);
+    c_sh = c;
+    scal[0] = c;
+  }
+  __syncthreads();
+  const double inv = 1.0 / c_sh;
+  const int64_t total = (int64_t)d * ld;
+  for (int64_t k = t; k < total; k += 1024) {
+    const int i = (int)(k / ld), j = (int)(k - (int64_t)i * ld);
+    const double v = j < d ? A[k] * inv : 0.0;
+    A[k] = v;
+    Y[k] = v;
+    Z[k] = (i == j) ? 1.0 : 0.0;
+  }
+}
+
+// root = sqrt(c) (Y + Y') / 2 on the leading d x d block, pads zero
+__global__ void __launch_bounds__(256) ns_finish_kernel(const double* __restrict__ Y, int d, int64_t ld,
+                                                        const double* __restrict__ scal, double* __restrict__ root) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)d * ld) return;
+  const int i = (int)(k / ld), j = (int)(k - (int64_t)i * ld);
+  root[k] = j < d ? 0.5 * (Y[k] + Y[(int64_t)j * ld + i]) * sqrt(scal[0]) : 0.0;
+}
+
+}  // namespace
+
+// root (d x ld, device) = (Lfull Lt)^(1/2), Lfull = L (row-major, row stride ld = round_up(d, 16)), Lt = L'.
+// info (host) = [steps, last residual ||I - Z Y||_F, ||R R - Sigma||_F / c].  VB_ERR_UNSUPPORTED: not converged to `tol`.
+int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, int64_t ld, double* root, double tol,
+                 double* info) {
+  const int m = (int)d;
+  if (ld != round_up(d, 16)) return fail(ctx, VB_ERR_INVALID, "sym_sqrt_dev: row stride");
+  const int64_t mat = (int64_t)m * ld;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int64_t n_part = round_up(gemm_max_blocks(m, m), 16);
+  constexpr int kMaxSteps = 40;
+  // device: set p = [Y_p | T_p | Z_p] (p = 0, 1), A / c, one scalar line
+  VB_TRY(ensure(ctx, ctx->scratch, (size_t)(7 * mat + 16) * sizeof(double)));
+  VB_TRY(ensure_pinned(ctx, (size_t)((kMaxSteps + 2) * n_part) * sizeof(double)));
+  double* base = (double*)ctx->scratch.ptr;
+  double* set[2] = {base, base + 3 * mat};
+  double *M0 = base + 6 * mat, *scal = base + 7 * mat;
+  hipStream_t st = ctx->stream;
+  VB_HIP(ctx, hipStreamSynchronize(st));      // earlier users of the pinned partials are done
+  memset(ctx->pin_host, 0, (size_t)((kMaxSteps + 2) * n_part) * sizeof(double));
+  gemm_f64_launch<true>(st, square(Lfull, Lt, ld, m), 1, n_cu, EpiStore{M0, ld});
+  hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, st, M0, m, ld, set[0], set[0] + 2 * mat, scal);
+  VB_HIP(ctx, hipGetLastError());
+  auto residual = [&](int slot) {
+    double s = 0.0;
+    const double* hp = ctx->pin_host + (int64_t)slot * n_part;
+    for (int64_t i = 0; i < n_part; ++i) s += hp[i];
+    return sqrt(s);
+  };
+  int cur = 0, done = 0;
+  bool converged = false;
+  double res = 0.0, prev = 1e300;
+  const double floor_tol = 4e-16 * (double)m;
+  while (!converged && done < kMaxSteps) {
+    const int group = done == 0 ? 4 : 2;
+    for (int k = 0; k < group; ++k) {
+      double *Y = set[cur], *T = Y + mat, *Z = Y + 2 * mat;
+      // T = (3 I - Z Y) / 2 with ||I - Z Y||_F^2 of the state BEFORE this step into partial slot `done + k`
+      gemm_f64_launch<true>(st, square(Z, Y, ld, m), 1, n_cu, EpiNsT{T, ld, ctx->pin_dev + (int64_t)(done + k) * n_part});
+      GemmArgs g = square(Y, T, ld, m);      // batch 0: Y T, batch 1: T Z
+      g.batch = 1;
+      g.batch_a = mat, g.batch_b = mat;
+      gemm_f64_launch<true>(st, g, 2, n_cu, EpiStoreBatch{set[cur ^ 1], ld, 2 * mat});
+      cur ^= 1;
+    }
+    VB_HIP(ctx, hipGetLastError());
+    VB_HIP(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < group && !converged; ++k) {
+      res = residual(done + k);
+      if (!std::isfinite(res)) return VB_ERR_UNSUPPORTED;
+      if (res < floor_tol || (res < 1e-7 && res > 0.5 * prev)) converged = true;      // (later steps of the group: harmless)
+      prev = res;
+    }
+    done += group;
+  }
+  if (!converged) return VB_ERR_UNSUPPORTED;
+  // accuracy of the result: ||Y Y - Sigma / c||_F (||Sigma / c||_2 <= 1), and the root itself
+  double* Y = set[cur];
+  gemm_f64_launch<true>(st, square(Y, Y, ld, m), 1, n_cu, EpiResidual{M0, ld, m, ctx->pin_dev + (int64_t)kMaxSteps * n_part});
+  hipLaunchKernelGGL(ns_finish_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, (const double*)Y, m, ld,
+                     (const double*)scal, root);
+  VB_HIP(ctx, hipGetLastError());
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  const double acc = residual(kMaxSteps);
+  if (info) info[0] = (double)done, info[1] = res, info[2] = acc;
+  if (!(acc < tol)) return VB_ERR_UNSUPPORTED;
+  return VB_OK;
+}
+
 // ---- low-rank Gaussian, path derivative (objectives.py:156-159 over approximations.py:610-731) ---------------
 // The score Sigma^-1 (x - mu), Sigma = B B' + diag(sigma^2), is linear in the two noise blocks, so everything the
 // estimator adds to the entropy-form sums follows from second moments of the noise: with u_n = (sigma W)' eps_n

@@ -644,7 +644,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
                     const double* theta_host,
                     const double* chi_host, const double* root_host, const double* linv_host,
                     const double* prior_host, double eps_prev, double ess_target, int max_its, double* eps_out,
-                    double* ess_out, double* w_host, double* logp_host, double* logq_host) {
+                    double* ess_out, double* w_host, double* logp_host, double* logq_host, bool sym_root,
+                    double* root_info) {
   int64_t mine = 0;   // this rank's block inside the gathered per-sample vectors (shard_rows)
   VB_TRY(comm_shard_begin(ctx, n, n_total, &mine));
   if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL && ctx->model.id != VB_MODEL_SOURCE)
@@ -662,8 +663,12 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   const bool dev_factors = root_host == nullptr && linv_host == nullptr;
   if ((root_host == nullptr) != (linv_host == nullptr))
     return fail(ctx, VB_ERR_INVALID, "sqrt_sigma and l_inv are given together or not at all");
+  if (sym_root && !dev_factors) return fail(ctx, VB_ERR_INVALID, "the device's symmetric root goes with the device's factors");
   if (dev_factors) {      // throughput mode: mu, L', L^-1 from theta on the device; the samples go through L' (see header)
     VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true));
+    // reference-identical sampling (approximations.py:348): x = mu + (z Sigma^(1/2)) / s with the SYMMETRIC root, formed
+    // on the device from the unpacked factor (VB_ERR_UNSUPPORTED: not resolved to 1e-12 -- the caller's LAPACK route)
+    if (sym_root) VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, root_info));
   } else {
     VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
   }
@@ -721,16 +726,18 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   GemmArgs g;
   g.A = (const double*)ns.buf.ptr;
   g.lda = ns.ld;
-  g.B = dev_factors ? base + L.o_lt : base + L.o_root;      // throughput mode: L' itself
+  const bool chol_samples = dev_factors && !sym_root;
+  g.B = chol_samples ? base + L.o_lt : base + L.o_root;      // throughput mode: L' itself
   g.ldb = L.ld;
   g.M = (int)n;
   g.N = (int)d;
   g.K = (int)d;
-  g.tri_mode = dev_factors ? 1 : 0;      // throughput mode: the root is L' (zero below the diagonal) -- half the product
+  g.tri_mode = chol_samples ? 1 : 0;      // throughput mode: the root is L' (zero below the diagonal) -- half the product
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiSampleT{base + L.o_x, L.ld, base + L.o_mu, base + L.o_invs});
   VB_HIP(ctx, hipGetLastError());
 
-  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors, dev_factors ? &ns : nullptr));
+  // (samples through the symmetric root: their residuals (x - mu) L^-T are a product, not the scaled noise)
+  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors, chol_samples ? &ns : nullptr));
   // model and tempering prior (a diagonal Gaussian) in one pass over the samples
   VB_TRY(model_and_prior_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine, base + L.o_prior,
                                    base + L.o_prior + L.ld, c0p, base + L.o_lprior + mine));
@@ -932,6 +939,16 @@ int mvt_dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t
   if (logq_host)
     VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lqcopy, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
+  return VB_OK;
+}
+
+// [eps, ess, zero-weight status, khat] of the last device-resident refresh
+int mvt_dis_scalars_get(vb_ctx* ctx, double out[4]) {
+  if (!ctx->mvt_state.ptr || ctx->mvt_n <= 0) return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state");
+  const MvtLayout L = mvt_layout(ctx, ctx->mvt_n, ctx->mvt_n_total, ctx->mvt_d);
+  double* base = (double*)ctx->mvt_state.ptr;
+  VB_HIP(ctx, hipMemcpyAsync(out, base + L.o_scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VB_OK;
 }
 

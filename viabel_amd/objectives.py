@@ -975,13 +975,24 @@ class DISInclusiveKL(StochasticVariationalObjective):
             begin, end = shard_rows(N, eng.n_ranks, eng.rank)
             n_local = end - begin
             # throughput mode: mu, L, L^-1 and the chain rule of the gradient are formed on the device from var_param
-            L, Linv = (None, None) if philox else factors(var_param)
+            memo = []
+
+            def host_factors():             # (L, L^-1) on the host, only where a host route needs them
+                if not memo:
+                    memo.append(factors(var_param))
+                return memo[0]
             # ... and on one rank the weights never leave the device either -- Pareto smoothing (vb_dis_psis_mvt) and, for
             # a clipping threshold below 1 (objectives.py:370-386; the identity otherwise, the default is 10), the
             # clipping (vb_dis_clip_mvt) included
-            resident = philox and eng.n_ranks == 1
+            refresh_now = not self._use_resampling or self._objective_step % self._num_resampling_batches == 0
+            # The reference-identical mode of the t family (rng='numpy') is resident on the device as well where the
+            # symmetric root is the device's job anyway: numpy's chi-square and normal streams are generated there bit for
+            # bit, the root of approximations.py:348 by vb_dis_refresh_mvt_symroot
+            sym_try = not philox and not gaussian and eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
+            resident = (philox and eng.n_ranks == 1) or (not refresh_now and getattr(self, '_sym_resident', False))
             clip = self._w_clip_threshold < 1.0
-            if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
+            if refresh_now:
+                self._sym_resident = False
                 eng.dis_set_temper_prior(self._prior_spec)
                 if gaussian:
                     chi = np.ones(N)
@@ -1001,7 +1012,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                             self._own_state(eng, 1, True)
                     else:
                         approx._stage_base_noise(eng, slot, N, begin, end)
-                        root = np.ascontiguousarray(L.T)        # x = mu + eps L'
+                        root = np.ascontiguousarray(host_factors()[0].T)        # x = mu + eps L'
                 elif philox:
                     # throughput mode: chi-square draws and normals on the GPU, and x = mu + (z L') / s with the
                     # Cholesky factor instead of the reference's symmetric root (approximations.py:348).  The samples
@@ -1028,8 +1039,24 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 else:
                     # chi-square draws first (approximations.py:345-347)
                     chi = approx._stage_base_noise(eng, slot, N, begin, end)
-                    root, _ = _device_root(eng, L @ L.T)        # symmetric square root, :348
+                    if sym_try and getattr(approx, '_chi_on_device', False):
+                        # the whole step on the device: the context holds numpy's chi-square draws, the slot its normals
+                        info = eng.dis_refresh_mvt_symroot(slot, N, D, df, var_param, self._prior_arg, self._eps,
+                                                           self._ess_target, self._max_bisection_its)
+                        if info is not None:
+                            resident = self._sym_resident = True
+                            if self._psis_smooth:
+                                eng.dis_psis_mvt(N)
+                            if clip:
+                                eng.dis_clip_mvt(N, self._w_clip_threshold)
+                            self._set_state_logs(None, None, lambda: eng.dis_state_get(True, N))
+                            self._set_state_weights(None, lambda: eng.dis_weights_get(N))
+                            self._own_state(eng, 1, True)
+                    if not resident:
+                        L = host_factors()[0]
+                        root, _ = _device_root(eng, L @ L.T)        # symmetric square root, :348
                 if not resident:
+                    Linv = None if philox else host_factors()[1]
                     self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_mvt(
                         slot, n_local, D, df, var_param, None if chi is None else chi[begin:end], root, Linv,
                         self._prior_arg, self._eps, self._ess_target, self._max_bisection_its, n_total=N,
@@ -1045,6 +1072,17 @@ class DISInclusiveKL(StochasticVariationalObjective):
             if resident:
                 if not self._use_resampling:
                     value, grad, self._eps, self._ess = eng.dis_step_mvt_packed(n_local, D, df, var_param, 1.0 / N)
+                elif not philox:
+                    # the reference's resampling draw (objectives.py:408: the global numpy generator) on the fetched
+                    # weights; the weighted score and its chain rule stay on the device
+                    if refresh_now:
+                        self._eps, self._ess, khat = eng.dis_scalars_get()
+                        if self._psis_smooth:
+                            self._khat = khat
+                    indices = _shared_choice(eng, N, self._resampling_batch_size, self._state_w_normalized)
+                    weights = np.bincount(indices, minlength=N).astype(np.float64)
+                    return eng.dis_grad_mvt_packed(n_local, D, df, var_param, weights,
+                                                   self._state_w_sum / N / self._resampling_batch_size)
                 else:
                     # multinomial draw on the device from the family's Philox stream (objectives.py:408 draws from the
                     # global numpy RNG; this mode reproduces no reference stream)
@@ -1063,6 +1101,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 scale = self._state_w_sum / N / self._resampling_batch_size
             if philox:
                 return eng.dis_grad_mvt_packed(n_local, D, df, var_param, weights[begin:end], scale)
+            L, Linv = host_factors()
             w_sum, w_logq, d_mu, gram = eng.dis_grad_mvt(n_local, D, df, var_param, Linv, weights[begin:end])
             # chain rule to the free Cholesky parameters
             # d log q / d Sigma = -1/2 w_sum Sigma^-1 + 1/2 S and Sigma = L L': d/dL = tril(2 (d/dSigma) L)
