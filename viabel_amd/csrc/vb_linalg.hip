@@ -201,38 +201,29 @@ struct EpiStoreBatch {      // C_b = acc, C_b = C + b * stride
   __device__ void operator()(int b, int row, int col, double acc) const { C[b * stride + (int64_t)row * ld + col] = acc; }
 };
 
-// one workgroup: c = max_i sum_j |A_ij|; A <- A / c (kept for the accuracy check), Y = A / c, Z = I (pads zero); scal[0] = c
-__global__ void __launch_bounds__(1024) ns_init_kernel(double* __restrict__ A, int d, int64_t ld, double* __restrict__ Y,
-                                                       double* __restrict__ Z, double* __restrict__ scal) {
-  __shared__ double wave_max[16];
-  __shared__ double c_sh;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  double mx = 0.0;
-  for (int i = wv; i < d; i += 16) {
-    double s = 0.0;
-    for (int j = lane; j < d; j += 64) s += fabs(A[(int64_t)i * ld + j]);
+// c = max_i sum_j |A_ij| into scal[0] (zeroed before): one wave per row, the maximum over rows by an integer atomic on
+// the bits of the non-negative sums (order-preserving)
+__global__ void __launch_bounds__(256) ns_norm_kernel(const double* __restrict__ A, int d, int64_t ld, double* __restrict__ scal) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= d) return;
+  double s = 0.0;
+  for (int j = lane; j < d; j += 64) s += fabs(A[(int64_t)i * ld + j]);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    mx = fmax(mx, s);      // (lane 0 holds the row sum)
-  }
-  if (lane == 0) wave_max[wv] = mx;
-  __syncthreads();
-  if (t == 0) {
-    double c = 0.0;
-    for (int w = 0; w < 16; ++w) c = fmax(c, wave_max[w]);
-    c_sh = c;
-    scal[0] = c;
-  }
-  __syncthreads();
-  const double inv = 1.0 / c_sh;
-  const int64_t total = (int64_t)d * ld;
-  for (int64_t k = t; k < total; k += 1024) {
-    const int i = (int)(k / ld), j = (int)(k - (int64_t)i * ld);
-    const double v = j < d ? A[k] * inv : 0.0;
-    A[k] = v;
-    Y[k] = v;
-    Z[k] = (i == j) ? 1.0 : 0.0;
-  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) atomicMax((unsigned long long*)scal, (unsigned long long)__double_as_longlong(s));
+}
+
+// A <- A / c (kept for the accuracy check), Y = A / c, Z = I (pads zero)
+__global__ void __launch_bounds__(256) ns_scale_kernel(double* __restrict__ A, int d, int64_t ld, double* __restrict__ Y,
+                                                       double* __restrict__ Z, const double* __restrict__ scal) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)d * ld) return;
+  const int i = (int)(k / ld), j = (int)(k - (int64_t)i * ld);
+  const double v = j < d ? A[k] / scal[0] : 0.0;
+  A[k] = v;
+  Y[k] = v;
+  Z[k] = (i == j) ? 1.0 : 0.0;
 }
 
 // root = sqrt(c) (Y + Y') / 2 on the leading d x d block, pads zero
@@ -265,8 +256,11 @@ int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, 
   hipStream_t st = ctx->stream;
   VB_HIP(ctx, hipStreamSynchronize(st));      // earlier users of the pinned partials are done
   memset(ctx->pin_host, 0, (size_t)((kMaxSteps + 2) * n_part) * sizeof(double));
+  VB_HIP(ctx, hipMemsetAsync(scal, 0, sizeof(double), st));
   gemm_f64_launch<true>(st, square(Lfull, Lt, ld, m), 1, n_cu, EpiStore{M0, ld});
-  hipLaunchKernelGGL(ns_init_kernel, dim3(1), dim3(1024), 0, st, M0, m, ld, set[0], set[0] + 2 * mat, scal);
+  hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, (const double*)M0, m, ld, scal);
+  hipLaunchKernelGGL(ns_scale_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, M0, m, ld, set[0],
+                     set[0] + 2 * mat, (const double*)scal);
   VB_HIP(ctx, hipGetLastError());
   auto residual = [&](int slot) {
     double s = 0.0;
@@ -278,8 +272,12 @@ int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, 
   bool converged = false;
   double res = 0.0, prev = 1e300;
   const double floor_tol = 4e-16 * (double)m;
+  // The iteration is quadratic: a residual below 1e-4 BEFORE step k is ~1e-8 after it and at the rounding floor after
+  // step k + 1 -- so once such a residual has been read, two steps from there finish the job (the accuracy check at the
+  // end is the safety net), and the floor itself need not be observed.
+  int stop_at = kMaxSteps + 1;      // steps to apply in all (known once a small residual has been seen)
   while (!converged && done < kMaxSteps) {
-    const int group = done == 0 ? 4 : 2;
+    const int group = done == 0 ? 4 : (stop_at <= kMaxSteps ? stop_at - done : 1);
     for (int k = 0; k < group; ++k) {
       double *Y = set[cur], *T = Y + mat, *Z = Y + 2 * mat;
       // T = (3 I - Z Y) / 2 with ||I - Z Y||_F^2 of the state BEFORE this step into partial slot `done + k`
@@ -296,9 +294,11 @@ int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, 
       res = residual(done + k);
       if (!std::isfinite(res)) return VB_ERR_UNSUPPORTED;
       if (res < floor_tol || (res < 1e-7 && res > 0.5 * prev)) converged = true;      // (later steps of the group: harmless)
+      if (res < 1e-4 && stop_at > kMaxSteps) stop_at = done + k + 2;
       prev = res;
     }
     done += group;
+    if (done >= stop_at) converged = true;
   }
   if (!converged) return VB_ERR_UNSUPPORTED;
   // accuracy of the result: ||Y Y - Sigma / c||_F (||Sigma / c||_2 <= 1), and the root itself
