@@ -726,6 +726,46 @@ def fullrank_funnel_leg(eng, vb, steps=200, ring=8, slot0=40):
                          'note': 'per-kernel times: profiles/r04_fullrank_funnel_kernel_stats.txt'}}
 
 
+def bbvi_quickstart_leg(vb, n_iters=6000):
+    """The one workload the reference publishes a rate for: docs/source/quickstart.ipynb:431,
+    ``bbvi(2, log_density=<2-D funnel>, learning_rate=0.5, n_iters=30000)`` -- MFGaussian + ExclusiveKL, num_mc_samples=10,
+    RAABBVI over RMSProp -- 623-661 it/s in the notebook's tqdm output (CPU, hardware not stated: context, not a like-for-like
+    baseline).  Iterations/s through ``bbvi()`` here with the device funnel and with the notebook's own Python callable.
+    At D = 2 / N = 10 an iteration is pure latency: one blocking objective call + the optimiser's O(D) host arithmetic."""
+    import warnings
+
+    def log_density(x):                       # the notebook's density (quickstart.ipynb:23-29), numpy instead of autograd
+        mu, log_sigma = x[:, 0], x[:, 1]
+        return (-0.5 * log_sigma ** 2 - 0.5 * np.log(2 * np.pi)
+                - 0.5 * (mu * np.exp(-log_sigma)) ** 2 - log_sigma - 0.5 * np.log(2 * np.pi))
+
+    def grad_log_density(x):
+        mu, v = x[:, 0], x[:, 1]
+        q = (mu * np.exp(-v)) ** 2
+        return np.stack([-mu * np.exp(-2 * v), -v + q - 1.0], axis=1)
+
+    out = {'workload': 'docs/source/quickstart.ipynb:431: bbvi(2, log_density=funnel, learning_rate=0.5), MFGaussian + '
+                       'ExclusiveKL, num_mc_samples=10, RAABBVI(RMSProp); %d iterations asked for' % n_iters,
+           'reference_notebook_it_per_s': [623.5, 661.0, 642.4, 644.8],
+           'reference_hardware': 'unknown CPU (tqdm rates in the notebook cell outputs; BASELINE.md 1)'}
+    cases = (('device_funnel_model', dict(log_density=vb.FunnelModel(2))),
+             ('python_callable_with_gradient', dict(log_density=log_density, grad_log_density=grad_log_density)),
+             ('python_callable_central_differences', dict(log_density=log_density)))
+    for name, kw in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            vb.bbvi(2, learning_rate=0.5, n_iters=300, **kw)                  # warm-up (kernels, buffers)
+            t0 = time.perf_counter()
+            res = vb.bbvi(2, learning_rate=0.5, n_iters=n_iters, **kw)
+            dt = time.perf_counter() - t0
+        its = int(len(res['value_history']))
+        out[name] = {'it_per_s': its / dt, 'iterations_run': its, 'us_per_iteration': 1e6 * dt / max(1, its),
+                     'vs_reference_notebook': (its / dt) / 642.4}
+    out['note'] = ('vs_reference_notebook divides by the median of the four notebook rates; the notebook differentiates the '
+                   'callable with autograd, the callable cases here take an explicit gradient or central differences')
+    return out
+
+
 def other_paths_leg(eng, vb):
     """Blocking calls of the paths next to the headline that round 4 reworked: LRGaussian at ranks 8 / 32 / 64 (the streaming
     kernel up to 16, the GEMM-assembled sums beyond), the full-rank path derivative, PSIS of N log weights, and the DIS
@@ -1116,6 +1156,8 @@ def main():
             out['alpha_divergence'] = alpha_leg(vb)
             out['c4_logistic'] = c4_leg(eng, vb)
             out['other_paths'] = other_paths_leg(eng, vb)
+            with contextlib.redirect_stderr(io.StringIO()):
+                out['bbvi_quickstart'] = bbvi_quickstart_leg(vb)
             try:
                 out['source_model'] = source_model_leg(vb)
             except Exception as exc:       # (no hiprtc on the box: the adaptor is the one part that needs it)
