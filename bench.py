@@ -155,6 +155,34 @@ def fullrank_leg(eng, vb, _lib, group, d, steps, warmup, scaling='weak', slot0=4
     }
 
 
+def dependent_chain_leg(eng, vb, group, iters=60):
+    """N > 1: what an OPTIMISER sees under the communicator.  The headline enqueues independent evaluations of one resident
+    theta, so evaluation k's all-reduce runs beside evaluation k + 1's GEMMs -- an overlap no optimiser has
+    (optimization.py:95-97: theta_{k+1} needs grad_k).  Here: RMSProp iterations of the device-resident loop (vb_fit: fresh
+    Philox noise -> sharded evaluation -> all-reduce of the 4.2 MB sum vector -> step -> unpack), every iteration behind
+    the previous one's collective; weak (N_mc per GPU fixed) and strong (N_mc global fixed) sharding.  Collective: every
+    rank runs it; max over ranks."""
+    from viabel_amd.optimization import RMSProp
+    d, world = FR_D, group.world
+    rng = np.random.RandomState(2)
+    A = rng.randn(d, d)
+    model = vb.CorrelatedGaussianModel(rng.randn(d), covariance=A @ A.T / d + np.eye(d))
+    out = {'workload': 'RMSProp iterations of vb_fit under the communicator: FullRankGaussian(%d, rng=philox) + ExclusiveKL, '
+                       'fresh noise and one all-reduce of %d doubles per iteration' % (d, 16 + d + d * (d + 1) // 2)}
+    for scaling, n_global in (('weak', N_MC * world), ('strong', N_MC)):
+        obj = vb.ExclusiveKL(vb.FullRankGaussian(d, rng='philox'), model, n_global)
+        theta = obj.approx.init_param()
+        ropt = RMSProp(0.001)
+        obj.device_fit(10, theta, ropt._device_kind, ropt._device_hyper())
+
+        def run(k):
+            obj.device_fit(k, theta, ropt._device_kind, ropt._device_hyper())
+        times = timed_blocks(run, eng.sync, group, iters, min_total_s=0.5, max_blocks=5)
+        out[scaling] = {'us_per_iteration': 1e6 * statistics.median(times) / iters, 'n_mc_global': n_global,
+                        'iterations_per_s': iters / statistics.median(times), 'blocks': len(times)}
+    return out
+
+
 # --------------------------------------------------------------------------------------------------------------
 # secondary legs (1 GPU, rank 0)
 # --------------------------------------------------------------------------------------------------------------
@@ -1070,6 +1098,13 @@ def main():
         other = fullrank_leg(eng, vb, _lib, group, FR_D, args.steps, args.warmup, scaling=other_mode, profile=False)
         other['scaling'] = other_mode
 
+    chain, allreduce_us = None, None
+    if world > 1:          # collective legs: every rank runs them
+        chain = dependent_chain_leg(eng, vb, group)
+        n_sum = 16 + FR_D + FR_D * (FR_D + 1) // 2
+        group.barrier()
+        allreduce_us = group.allreduce_max(eng.comm_allreduce_time(n_sum, warm=5, reps=30))
+
     out = None
     if rank == 0:
         sec = head['sec_per_step']
@@ -1114,9 +1149,13 @@ def main():
                 'noise': 'Philox4x32-10 normals resident in HBM, 8 matrices cycled (268 MB > 256 MiB L3)',
                 'parallelism': ('mc-axis dp%d, one RCCL all-reduce of %d doubles per evaluation'
                                 % (world, 16 + FR_D + FR_D * (FR_D + 1) // 2)) if world > 1 else 'single GPU',
-                'pipelining': 'none: one evaluation per call, all calls on one HIP stream, each behind the previous one; '
-                              'theta resident on the device, results not copied out inside the timed region (the '
-                              'blocking host-to-host call is the api_call leg)',
+                'pipelining': ('none: one evaluation per call, all calls on one HIP stream, each behind the previous one; '
+                               'theta resident on the device, results not copied out inside the timed region (the '
+                               'blocking host-to-host call is the api_call leg)') if world == 1 else
+                              ('the timed evaluations are INDEPENDENT (one resident theta): evaluation k\'s all-reduce runs on '
+                               'the post stream beside evaluation k + 1\'s GEMMs (two sum sets, vb_fullrank.hip), so `value` is '
+                               'an enqueue rate with the collective hidden -- an overlap no optimiser has (theta_{k+1} needs '
+                               'grad_k); the rate of the dependent chain is `dependent_chain`, the collective alone `allreduce_us`'),
             },
             'rccl_ranks': rccl_ranks,
             'transport': ('host-staged (VB_BENCH_TRANSPORT=host): all ranks on device 0, collectives through pinned host '
@@ -1131,6 +1170,12 @@ def main():
             'check': {'value': head['value'], 'grad_norm': head['grad_norm']},
             'roofline': roof,
         }
+        if chain is not None:
+            out['dependent_chain'] = chain
+            out['allreduce_us'] = {'us_per_allreduce': allreduce_us, 'doubles': 16 + FR_D + FR_D * (FR_D + 1) // 2,
+                                   'note': 'sum all-reduce of the full-rank sum vector alone, back to back on one stream '
+                                           'between HIP events (vb_comm_allreduce_time), max over ranks; transport as in '
+                                           '`transport`'}
         if other is not None:
             u2 = world if other['scaling'] == 'weak' else 1
             out['other_scaling'] = {'scaling': other['scaling'], 'value': u2 / other['sec_per_step'], 'unit': 'evals/s',

@@ -510,6 +510,14 @@ int vb_comm_init_host(vb_ctx* ctx, vb_host_collective_fn fn, void* user, int n_r
 #define VB_IPC_HANDLE_BYTES 64
 int vb_comm_ipc_window(vb_ctx* ctx, size_t cap_doubles, char handle[VB_IPC_HANDLE_BYTES]);
 int vb_comm_init_ipc(vb_ctx* ctx, const char* handles, int n_ranks, int rank);
+/* VB_ERR_COMM when a device-side wait of the IPC transport gave up (a peer did not arrive within 2^VB_IPC_POLL_LOG2
+ * polls, default 2^27: minutes) -- the affected results are NaN by construction; also checked by the next collective,
+ * vb_sync and vb_fullrank_get.  VB_OK on every other transport.                                                     */
+int vb_comm_check(vb_ctx* ctx);
+/* Duration of the collective alone: `reps` back-to-back sum all-reduces of `count` doubles on the context's stream
+ * between two HIP events (after `warm` untimed ones), microseconds per collective.  Collective: every rank calls it with
+ * the same arguments.  Without a communicator the "collective" is nothing and the time is the events' own.           */
+int vb_comm_allreduce_time(vb_ctx* ctx, size_t count, int warm, int reps, double* us_per_collective);
 
 /* ---- numpy's legacy generator on the host (vb_legacy_rng.cpp) ------------------------------------
  * `numpy.random.RandomState(seed)` restated in C++: MT19937 seeded as numpy seeds it from an integer, the polar-method

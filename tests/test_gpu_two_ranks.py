@@ -2,7 +2,9 @@
 counts), and every device collective of the sharded path runs -- through the host-staged transport
 (`vb_comm_init_host`, `distributed.attach(..., transport='host')`), because RCCL refuses two ranks on one device -- and through the xGMI-native transport (`vb_comm_init_ipc`,
 transport='ipc': the ranks map each other's windows through IPC handles and reduce on the device, device-side flags),
-which between two processes on one GPU runs exactly the code an 8-GPU node would.
+which between two processes on one GPU runs the same kernels and flag protocol an 8-GPU node would -- but both ranks
+share one L2 here, so nothing of the cross-device visibility the transport depends on (fine-grained windows, system-scope
+flags over xGMI) is exercised: that needs two GPUs and is unmeasured; RCCL stays the default transport.
 What this covers that the one-rank communicator tests (test_gpu_comm.py) cannot: shard offsets of the second rank,
 ragged gathers of per-sample vectors, rank 0's host random draws reaching rank 1, the collective sequence of every
 objective staying paired across ranks (a mismatch deadlocks or trips the size check), the device fit loop with one

@@ -187,6 +187,8 @@ SIGNATURES = {
     'vb_legacy_rng_log_proven': (ctypes.c_int, []),
     'vb_comm_ipc_window': (ctypes.c_int, [_ctx_p, ctypes.c_size_t, ctypes.c_char_p]),
     'vb_comm_init_ipc': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    'vb_comm_check': (ctypes.c_int, [_ctx_p]),
+    'vb_comm_allreduce_time': (ctypes.c_int, [_ctx_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_init_host': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
@@ -304,7 +306,11 @@ class Engine:
     # ------------------------------------------------------------------ errors
     def _check(self, rc):
         if rc == VB_OK:
-            return
+            # IPC transport: a device-side wait that gave up has poisoned the results with NaN -- every call says so
+            if getattr(self, '_ipc_on', False) and self._lib.vb_comm_check(self._ctx) != VB_OK:
+                rc = VB_ERR_COMM
+            else:
+                return
         msg = self._lib.vb_last_error(self._ctx).decode()
         if rc == VB_ERR_CALLBACK:                    # a host model callable raised: hand its own exception on
             holder = getattr(self, '_callback_error', None)
@@ -900,6 +906,7 @@ class Engine:
             raise ValueError('expected %d window handles of %d bytes' % (n_ranks, self.IPC_HANDLE_BYTES))
         self._check(self._lib.vb_comm_init_ipc(self._ctx, blob, n_ranks, rank))
         self.n_ranks, self.rank = n_ranks, rank
+        self._ipc_on = True
 
     def comm_init_host(self, collective, n_ranks, rank):
         """Host-staged transport (``vb_comm_init_host``): ``collective(array, op)`` must overwrite the float64
@@ -918,9 +925,17 @@ class Engine:
         self.n_ranks, self.rank = n_ranks, rank
 
     def comm_destroy(self):
+        self._ipc_on = False
         self._check(self._lib.vb_comm_destroy(self._ctx))
         self._host_collective = None
         self.n_ranks, self.rank = 1, 0
+
+    def comm_allreduce_time(self, count, warm=5, reps=50):
+        """Microseconds per sum all-reduce of ``count`` doubles, the collective alone (``vb_comm_allreduce_time``; every
+        rank calls it)."""
+        us = ctypes.c_double(0.0)
+        self._check(self._lib.vb_comm_allreduce_time(self._ctx, int(count), int(warm), int(reps), ctypes.byref(us)))
+        return us.value
 
     def comm_info(self):
         """(ranks, rank) as the RCCL communicator reports them; (1, 0) without a communicator."""

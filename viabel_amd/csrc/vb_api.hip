@@ -65,7 +65,7 @@ int sync_streams(vb_ctx* ctx) {
     VB_HIP(ctx, hipStreamSynchronize(ctx->pipe.post));
   }
   ctx->pipe.post_pending = false;
-  return VB_OK;
+  return comm_check(ctx);
 }
 
 // Main-stream work that writes buffers the pipeline may still be reading (noise, model parameters)
@@ -1106,6 +1106,7 @@ int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p) {
     VB_HIP(ctx, hipMemcpyAsync(&fz_err, (const unsigned*)ctx->fz_words.ptr + 1, sizeof fz_err, hipMemcpyDeviceToHost,
                                ctx->stream));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VB_TRY(comm_check(ctx));
   if (fz_err) {
     VB_HIP(ctx, hipMemsetAsync(ctx->fz_words.ptr, 0, 2 * sizeof(unsigned), ctx->stream));
     return fail(ctx, VB_ERR_STATE, "fused full-rank evaluation: a tile gave up waiting for its input (results invalid)");

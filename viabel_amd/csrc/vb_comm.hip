@@ -47,7 +47,12 @@ static int host_collective(vb_ctx* ctx, hipStream_t stream, double* buf, size_t 
 //   reduce   waits data >= seq, gather waits reduced >= seq.          Polls are bounded; a give-up poisons the result with NaN.
 constexpr int kIpcFlagDoubles = 16;      // 128 B in front of the data area
 
-__device__ __forceinline__ bool ipc_wait(const double* const* win, int n_ranks, int self, int word, unsigned long long want) {
+// `max_spins`: the poll bound (vb_comm_init_ipc: 2^VB_IPC_POLL_LOG2 polls, default 2^27 -- minutes; a rank that compiles a
+// source model or runs a host callable is late by seconds, not by that).  A give-up is RECORDED: `err` is a word in pinned
+// host memory that the host reads at the next collective, at every synchronising entry point and through vb_comm_check --
+// the poisoned result never passes for data.
+__device__ __forceinline__ bool ipc_wait(const double* const* win, int n_ranks, int self, int word, unsigned long long want,
+                                         unsigned max_spins, unsigned* err) {
   bool ok = true;
   if (threadIdx.x == 0) {
     for (int p = 0; p < n_ranks; ++p) {
@@ -59,8 +64,9 @@ __device__ __forceinline__ bool ipc_wait(const double* const* win, int n_ranks, 
       unsigned spins = 0;
       while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 24)) {
+        if (++spins > max_spins) {
           ok = false;
+          __hip_atomic_store(err, 1u + (unsigned)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
       }
@@ -88,11 +94,13 @@ struct IpcArgs {
   size_t cap;
   unsigned long long seq;
   unsigned* ticket;
+  unsigned* err;            // pinned host word: a poll gave up (1 + the flag word it waited for)
+  unsigned max_spins;
 };
 
 __global__ void __launch_bounds__(256) ipc_publish_kernel(IpcArgs a, const double* __restrict__ buf, size_t count) {
   double* own = const_cast<double*>(a.win[a.rank]);
-  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 2, a.seq - 1);
+  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 2, a.seq - 1, a.max_spins, a.err);
   double* data = own + kIpcFlagDoubles;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
     data[i] = ok ? buf[i] : NAN;
@@ -102,7 +110,7 @@ __global__ void __launch_bounds__(256) ipc_publish_kernel(IpcArgs a, const doubl
 // slice of rank r: [r * per, min(count, (r + 1) * per)), per = ceil(count / G)
 __global__ void __launch_bounds__(256) ipc_reduce_kernel(IpcArgs a, size_t count, int op) {
   double* own = const_cast<double*>(a.win[a.rank]);
-  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 0, a.seq);
+  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 0, a.seq, a.max_spins, a.err);
   const size_t per = (count + a.n_ranks - 1) / a.n_ranks, lo = (size_t)a.rank * per, hi = lo + per < count ? lo + per : count;
   double* res = own + kIpcFlagDoubles + a.cap;
   for (size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (size_t)gridDim.x * 256) {
@@ -118,7 +126,7 @@ __global__ void __launch_bounds__(256) ipc_reduce_kernel(IpcArgs a, size_t count
 
 __global__ void __launch_bounds__(256) ipc_gather_kernel(IpcArgs a, double* __restrict__ buf, size_t count) {
   double* own = const_cast<double*>(a.win[a.rank]);
-  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 1, a.seq);
+  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 1, a.seq, a.max_spins, a.err);
   const size_t per = (count + a.n_ranks - 1) / a.n_ranks;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
     const int owner = (int)(i / per);
@@ -127,14 +135,26 @@ __global__ void __launch_bounds__(256) ipc_gather_kernel(IpcArgs a, double* __re
   ipc_signal(own, 2, a.seq, a.ticket, 2);
 }
 
+// A poll of an earlier collective gave up: its result (and everything computed from it) is NaN by construction; say so.
+int comm_check(vb_ctx* ctx) {
+  vb_ctx::IpcComm& c = ctx->ipc;
+  if (!c.on || !c.err_host || *(volatile unsigned*)c.err_host == 0) return VB_OK;
+  const unsigned word = *(volatile unsigned*)c.err_host - 1;
+  return fail(ctx, VB_ERR_COMM, "IPC transport: a peer did not reach collective phase %u within the poll bound (2^%d polls, "
+                               "VB_IPC_POLL_LOG2); results since then are invalid -- the communicator must be rebuilt",
+              word, c.poll_log2);
+}
+
 static int ipc_collective(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count, int op) {
   if (count == 0) return VB_OK;
   vb_ctx::IpcComm& c = ctx->ipc;
+  VB_TRY(comm_check(ctx));
   if (count > c.cap)
     return fail(ctx, VB_ERR_COMM, "IPC window holds %zu doubles, the collective has %zu (vb_comm_ipc_window)", c.cap, count);
   IpcArgs a;
   for (int p = 0; p < 16; ++p) a.win[p] = c.win[p];
   a.n_ranks = ctx->n_ranks, a.rank = ctx->rank, a.cap = c.cap, a.seq = ++c.seq, a.ticket = c.ticket;
+  a.err = c.err_dev, a.max_spins = c.poll_log2 >= 32 ? 0xffffffffu : (1u << c.poll_log2);
   const unsigned blocks = (unsigned)std::min<size_t>(256, (count + 255) / 256);
   hipLaunchKernelGGL(ipc_publish_kernel, dim3(blocks), dim3(256), 0, stream, a, (const double*)buf, count);
   hipLaunchKernelGGL(ipc_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a, count, op);
@@ -262,15 +282,40 @@ int vb_comm_ipc_window(vb_ctx* ctx, size_t cap_doubles, char handle[VB_IPC_HANDL
   VB_HIP(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (kIpcFlagDoubles + 2 * cap_doubles) * sizeof(double);
   double* w = nullptr;
-  VB_HIP(ctx, hipMalloc((void**)&w, bytes));
-  VB_HIP(ctx, hipMemset(w, 0, bytes));
-  VB_HIP(ctx, hipMalloc((void**)&ctx->ipc.ticket, 4 * sizeof(unsigned)));
-  VB_HIP(ctx, hipMemset(ctx->ipc.ticket, 0, 4 * sizeof(unsigned)));
+  // The window -- flag words and data -- is polled and read by PEER GPUs while kernels run on both sides: fine-grained
+  // (system-coherent) device memory, as RCCL allocates its own flag and buffer areas; coarse-grained hipMalloc memory is
+  // only guaranteed visible across devices at kernel boundaries.  VB_IPC_COARSE=1 keeps the plain allocation (debugging).
+  static const bool coarse = getenv("VB_IPC_COARSE") && atoi(getenv("VB_IPC_COARSE")) != 0;
+  hipError_t e = coarse ? hipMalloc((void**)&w, bytes) : hipExtMallocWithFlags((void**)&w, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) return fail(ctx, VB_ERR_HIP, "IPC window (%zu bytes, %s): %s", bytes, coarse ? "coarse" : "fine-grained",
+                                   hipGetErrorString(e));
+  unsigned* ticket = nullptr;
+  unsigned* err_host = nullptr;
+  void* err_dev = nullptr;
+  auto undo = [&]() {
+    (void)hipFree(w);
+    if (ticket) (void)hipFree(ticket);
+    if (err_host) (void)hipHostFree(err_host);
+  };
   hipIpcMemHandle_t h;
-  VB_HIP(ctx, hipIpcGetMemHandle(&h, w));
+  if ((e = hipMemset(w, 0, bytes)) != hipSuccess || (e = hipMalloc((void**)&ticket, 4 * sizeof(unsigned))) != hipSuccess ||
+      (e = hipMemset(ticket, 0, 4 * sizeof(unsigned))) != hipSuccess ||
+      (e = hipHostMalloc((void**)&err_host, 64, hipHostMallocMapped)) != hipSuccess ||
+      (e = hipHostGetDevicePointer(&err_dev, err_host, 0)) != hipSuccess ||
+      (e = hipDeviceSynchronize()) != hipSuccess ||      // the zeroed flags are in place before any peer can map the window
+      (e = hipIpcGetMemHandle(&h, w)) != hipSuccess) {
+    undo();
+    return fail(ctx, VB_ERR_HIP, "IPC window set-up: %s", hipGetErrorString(e));
+  }
+  memset(err_host, 0, 64);
   memset(handle, 0, VB_IPC_HANDLE_BYTES);
   memcpy(handle, &h, sizeof h);
   ctx->ipc.cap = cap_doubles;
+  ctx->ipc.ticket = ticket;
+  ctx->ipc.err_host = err_host;
+  ctx->ipc.err_dev = (unsigned*)err_dev;
+  const char* pl = getenv("VB_IPC_POLL_LOG2");
+  ctx->ipc.poll_log2 = pl ? std::max(8, std::min(32, atoi(pl))) : 27;
   ctx->ipc.win[15] = w;                // parked until vb_comm_init_ipc knows the rank
   return VB_OK;
 }
@@ -294,6 +339,10 @@ int vb_comm_init_ipc(vb_ctx* ctx, const char* handles, int n_ranks, int rank) {
     void* ptr = nullptr;
     hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) {
+      for (int q = 0; q < p; ++q) {      // close what was opened: a retry maps everything afresh
+        if (q != rank && ctx->ipc.win[q]) (void)hipIpcCloseMemHandle(ctx->ipc.win[q]);
+        ctx->ipc.win[q] = nullptr;
+      }
       ctx->ipc.win[15] = own;
       return fail(ctx, VB_ERR_COMM, "hipIpcOpenMemHandle of rank %d's window failed: %s", p, hipGetErrorString(e));
     }
@@ -323,8 +372,49 @@ int vb_comm_info(vb_ctx* ctx, int* n_ranks, int* rank) {
   return VB_OK;
 }
 
+// The collective ALONE (bench.py --gpus N: `allreduce_us`): `reps` back-to-back sum all-reduces of `count` doubles on the
+// context's stream between two HIP events, after `warm` untimed ones; every rank must call it with the same arguments.
+int vb_comm_allreduce_time(vb_ctx* ctx, size_t count, int warm, int reps, double* us_per_collective) {
+  if (!ctx || !us_per_collective || count == 0 || reps < 1 || warm < 0) return fail(ctx, VB_ERR_INVALID, "invalid argument");
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(ensure(ctx, ctx->scratch, count * sizeof(double)));
+  double* buf = (double*)ctx->scratch.ptr;
+  hipStream_t st = ctx->stream;
+  VB_HIP(ctx, hipMemsetAsync(buf, 0, count * sizeof(double), st));
+  for (int i = 0; i < warm; ++i) VB_TRY(comm_allreduce_sum(ctx, st, buf, count));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  VB_HIP(ctx, hipEventCreate(&e0));
+  VB_HIP(ctx, hipEventCreate(&e1));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  VB_HIP(ctx, hipEventRecord(e0, st));
+  int rc = VB_OK;
+  for (int i = 0; i < reps && rc == VB_OK; ++i) rc = comm_allreduce_sum(ctx, st, buf, count);
+  VB_HIP(ctx, hipEventRecord(e1, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  float ms = 0.f;
+  VB_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  VB_TRY(rc);
+  *us_per_collective = 1e3 * (double)ms / reps;
+  return comm_check(ctx);
+}
+
+int vb_comm_check(vb_ctx* ctx) {
+  if (!ctx) return VB_ERR_INVALID;
+  return comm_check(ctx);
+}
+
 int vb_comm_destroy(vb_ctx* ctx) {
-  if (!ctx || !ctx->comm) return VB_OK;
+  if (!ctx) return VB_OK;
+  if (!ctx->comm) {
+    // a window that never became a communicator (vb_comm_ipc_window without vb_comm_init_ipc, or a failed init)
+    if (ctx->ipc.win[15]) (void)hipFree(ctx->ipc.win[15]);
+    if (ctx->ipc.ticket) (void)hipFree(ctx->ipc.ticket);
+    if (ctx->ipc.err_host) (void)hipHostFree(ctx->ipc.err_host);
+    ctx->ipc = vb_ctx::IpcComm();
+    return VB_OK;
+  }
   if (ctx->ipc.on) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int p = 0; p < ctx->n_ranks; ++p) {
@@ -334,6 +424,7 @@ int vb_comm_destroy(vb_ctx* ctx) {
       ctx->ipc.win[p] = nullptr;
     }
     if (ctx->ipc.ticket) (void)hipFree(ctx->ipc.ticket);
+    if (ctx->ipc.err_host) (void)hipHostFree(ctx->ipc.err_host);
     ctx->ipc = vb_ctx::IpcComm();
   } else if (ctx->host_fn) {
     ctx->host_fn = nullptr;

@@ -248,6 +248,9 @@ struct vb_ctx {
     size_t cap = 0;                     // doubles per data / result area
     unsigned long long seq = 0;
     unsigned* ticket = nullptr;         // device: last-block tickets of the three phases
+    unsigned* err_host = nullptr;       // pinned, device-mapped: a poll gave up (checked by comm_check)
+    unsigned* err_dev = nullptr;
+    int poll_log2 = 27;                 // poll bound of the device-side waits (VB_IPC_POLL_LOG2)
     bool on = false;
   } ipc;
 
@@ -394,6 +397,7 @@ int psis_tail_size(int64_t n, double reff);
 int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, int family, double df,
                   double alpha, const double* theta_src, double* out);
 int sync_streams(vb_ctx* ctx);   // main + pipeline streams
+int comm_check(vb_ctx* ctx);     // VB_ERR_COMM when a device-side wait of the IPC transport has given up (vb_comm.hip)
 
 // full-rank Gaussian ExclusiveKL (vb_fullrank.hip)
 struct FrSums;
