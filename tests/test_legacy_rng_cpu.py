@@ -99,3 +99,16 @@ def test_copies_and_pickles_carry_the_state():
     fam = vb.MFGaussian(5, seed=3)
     twin = copy.deepcopy(fam)
     assert np.array_equal(fam._rs.randn(10, 5), twin._rs.randn(10, 5))
+
+
+def test_host_libm_log_is_located_and_proven():
+    """vb_glibc_log.h: the device draws' logarithm is the host libm's own operation sequence on its own table, found in the
+    loaded libm and proven against log() on ~1.3 M arguments at first use.  On this image's glibc (x86-64, FMA) the proof
+    succeeds; elsewhere 0 is a legitimate answer (the device paths then decline and the host generator draws)."""
+    from viabel_amd import _lib
+    lib = _lib.load()
+    proven = lib.vb_legacy_rng_log_proven()
+    assert proven in (0, 1)
+    import platform
+    if platform.machine() == 'x86_64' and 'fma' in open('/proc/cpuinfo').read() and platform.libc_ver()[0] == 'glibc':
+        assert proven == 1

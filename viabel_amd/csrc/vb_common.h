@@ -144,6 +144,8 @@ struct vb_ctx {
   vb::DeviceBuffer theta;               // device copy of the variational parameter
   vb::DeviceBuffer workspace;           // per-evaluation work buffers of the mean-field pipeline
   vb::DeviceBuffer sums;                // reduced sums (the vector that is all-reduced)
+  vb::DeviceBuffer mf_one;              // one-launch mean-field evaluation: tickets, publication flags, parked sums
+  unsigned mf_one_epoch = 0;
   vb::DeviceBuffer out;                 // [value | grad] on the device
   vb::DeviceBuffer scratch;             // generic device scratch (x upload, ...)
   vb::DeviceBuffer scratch2;            // per-row outputs
@@ -327,6 +329,7 @@ struct MfCall {
   // prep_next asks for it, *prep_done reports it, skip_prep tells the next call that its prep has been done
   bool prep_next = false, skip_prep = false;
   bool* prep_done = nullptr;
+  bool theta_on_device = false;   // theta_src[0] is device memory (the fit loop's iterate), not a pinned staging copy
 };
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
 // user model given as HIP source (vb_usermodel.hip)

@@ -91,6 +91,25 @@ __device__ __forceinline__ double wave_sum(double x) {
   return x;
 }
 
+// Words that workgroups of ONE launch hand to each other (the one-launch evaluation, mf_one_kernel): agent-scope atomics --
+// write-through `sc1` stores, `sc1` loads.  The eight XCDs' L2s are not coherent with each other; a plain load could be
+// served a stale line whatever fences surround it (vb_psis.hip has the long version).
+template <bool COH>
+__device__ __forceinline__ double cld(const double* p) {
+  if (COH)
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+  return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void cst(double* p, double v) {
+  if (COH)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  else
+    *p = v;
+}
+
 // block-wide sum for 256 threads; every thread gets the total
 __device__ __forceinline__ double block_sum(double x, double* sh) {
   x = wave_sum(x);
@@ -280,24 +299,34 @@ __device__ __forceinline__ void accum(const double e, const double c0, const dou
   }
 }
 
-template <int MODEL, bool MOM, bool TSC, bool WEIGHTED, bool GEN = false>
-__global__ void __launch_bounds__(kMfThreads)
-mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
+// (row block, column block) of workgroup b
+__device__ __forceinline__ void mf_wg_coords(const Geom& g, int b, int* rb, int* cb) {
+  if (g.xcd_map) {   // all column blocks of a row block on one XCD (block b -> XCD b % 8)
+    const int x = b & 7, j = b >> 3;
+    *cb = j % g.n_cb;
+    *rb = (j / g.n_cb) * 8 + x;
+  } else {
+    *rb = b / g.n_cb;
+    *cb = b % g.n_cb;
+  }
+}
+
+// What the one-launch evaluation (mf_one_kernel) hands to the streaming body instead of mf_prep_kernel's arrays: the
+// lane's column constants and the funnel's coupling-column parameter, in registers.
+struct OnePro {
+  d2 cp0, cp1, cp2;
+  double muk, lsk;
+};
+
+// ONE: the body of mf_one_kernel -- column constants from `pro`, partial sums stored write-through (another workgroup of
+// the same launch reads them).
+template <int MODEL, bool MOM, bool TSC, bool WEIGHTED, bool GEN, bool ONE>
+__device__ __forceinline__ void mf_accum_body(const BatchPtrs& bp, const Workspace& ws, const Geom& g, const OnePro& pro) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bi = blockIdx.y;
   int rb, cb;
-  {
-    const int b = blockIdx.x;
-    if (g.xcd_map) {   // all column blocks of a row block on one XCD (block b -> XCD b % 8)
-      const int x = b & 7, j = b >> 3;
-      cb = j % g.n_cb;
-      rb = (j / g.n_cb) * 8 + x;
-    } else {
-      rb = b / g.n_cb;
-      cb = b % g.n_cb;
-    }
-  }
+  mf_wg_coords(g, (int)blockIdx.x, &rb, &cb);
   constexpr bool ROWS = (MODEL == VB_MODEL_FUNNEL) || WEIGHTED;
   double* wsb = ws.base + bi * ws.stride;
   const double* __restrict__ colp = wsb + ws.off_colp;
@@ -314,10 +343,14 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
   ColAcc A0, A1;
   double F = 0.0, Q = 0.0, QE = 0.0, L1P = 0.0;
   // per-column constants: issued first (vmcnt is in-order and they are needed first)
-  const d2 cp0 = *reinterpret_cast<const d2*>(colp + c0i);
-  const d2 cp1 = *reinterpret_cast<const d2*>(colp + g.Dp + c0i);
-  d2 cp2 = (d2){0.0, 0.0};
-  if (MODEL == VB_MODEL_GAUSS_DIAG) cp2 = *reinterpret_cast<const d2*>(colp + 2 * (int64_t)g.Dp + c0i);
+  d2 cp0, cp1, cp2 = (d2){0.0, 0.0};
+  if (ONE) {
+    cp0 = pro.cp0, cp1 = pro.cp1, cp2 = pro.cp2;
+  } else {
+    cp0 = *reinterpret_cast<const d2*>(colp + c0i);
+    cp1 = *reinterpret_cast<const d2*>(colp + g.Dp + c0i);
+    if (MODEL == VB_MODEL_GAUSS_DIAG) cp2 = *reinterpret_cast<const d2*>(colp + 2 * (int64_t)g.Dp + c0i);
+  }
   const bool cols_full = (cb + 1) * kMfCols <= ld;   // every lane's 16-B load stays inside the row
 
   __shared__ double psw[kMfWaves][PS_NUM];      // inline_rows: per-wave partial sums of the coupling-column terms
@@ -358,7 +391,7 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
       __shared__ double rsc[kMfWaves][kWave][2];
       const int k = g.fk, d = g.d;
       const double* th = wsb + ws.off_theta;
-      const double muk = th[k], sgk = exp(th[d + k]);
+      const double muk = ONE ? pro.muk : th[k], sgk = exp(ONE ? pro.lsk : th[d + k]);
       const double it2 = 1.0 / (g.ftau * g.ftau), dm1 = (double)(d - 1);
       double pW = 0.0, pFK = 0.0, pGK = 0.0, pGEK = 0.0;
       for (int64_t cbase = r0; cbase < r1; cbase += (int64_t)kMfWaves * kWave) {
@@ -532,17 +565,29 @@ mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
     d2 s = red[f][0][lane];
 #pragma unroll
     for (int w = 1; w < kMfWaves; ++w) s += red[f][w][lane];
-    *reinterpret_cast<d2*>(wsb + ws.off_partials + partial_index(rb, f, c0i, g.n_rb)) = s;
+    double* dst = wsb + ws.off_partials + partial_index(rb, f, c0i, g.n_rb);
+    if (ONE) {
+      cst<true>(dst, s.x);
+      cst<true>(dst + 1, s.y);
+    } else {
+      *reinterpret_cast<d2*>(dst) = s;
+    }
   }
   if (threadIdx.x < KS_NUM) {
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < kMfWaves; ++w) s += reds[w][threadIdx.x];
-    wsb[ws.off_pscal + (int64_t)threadIdx.x * (g.n_rb * g.n_cb) + (int64_t)rb * g.n_cb + cb] = s;
+    cst<ONE>(wsb + ws.off_pscal + (int64_t)threadIdx.x * (g.n_rb * g.n_cb) + (int64_t)rb * g.n_cb + cb, s);
   }
   if (GEN && MODEL == VB_MODEL_FUNNEL && g.inline_rows && cb == 0 && threadIdx.x < PS_NUM)
-    wsb[ws.off_prepscal + (int64_t)threadIdx.x * g.n_prep + rb] =
-        (psw[0][threadIdx.x] + psw[1][threadIdx.x]) + (psw[2][threadIdx.x] + psw[3][threadIdx.x]);
+    cst<ONE>(wsb + ws.off_prepscal + (int64_t)threadIdx.x * g.n_prep + rb,
+             (psw[0][threadIdx.x] + psw[1][threadIdx.x]) + (psw[2][threadIdx.x] + psw[3][threadIdx.x]));
+}
+
+template <int MODEL, bool MOM, bool TSC, bool WEIGHTED, bool GEN = false>
+__global__ void __launch_bounds__(kMfThreads)
+mf_accum_kernel(const BatchPtrs bp, const Workspace ws, const Geom g) {
+  mf_accum_body<MODEL, MOM, TSC, WEIGHTED, GEN, false>(bp, ws, g, OnePro());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -604,6 +649,7 @@ struct ScalarFetch {
   double ks[kPsChunks][KS_NUM], ps[PS_NUM], ls[kLsChunks];
 };
 
+template <bool COH = false>
 __device__ __forceinline__ void scalar_fetch(const EpiArgs& a, bool want_ls, ScalarFetch* f) {
   // unconditional loads from clamped indices, discarded by selects: straight-line code (see mf_finalize_kernel)
   const int e = threadIdx.x;
@@ -612,7 +658,7 @@ __device__ __forceinline__ void scalar_fetch(const EpiArgs& a, bool want_ls, Sca
   for (int j = 0; j < kPsChunks; ++j) {
     const int e_ps = min(e + 256 * j, a.n_ps - 1);
 #pragma unroll
-    for (int s = 0; s < KS_NUM; ++s) f->ks[j][s] = a.pscal[(int64_t)s * a.n_ps + e_ps];
+    for (int s = 0; s < KS_NUM; ++s) f->ks[j][s] = cld<COH>(a.pscal + (int64_t)s * a.n_ps + e_ps);
   }
 #pragma unroll
   for (int s = 0; s < PS_NUM; ++s) f->ps[s] = 0.0;
@@ -620,16 +666,17 @@ __device__ __forceinline__ void scalar_fetch(const EpiArgs& a, bool want_ls, Sca
   for (int j = 0; j < kLsChunks; ++j) f->ls[j] = 0.0;
   if (a.prepscal) {
 #pragma unroll
-    for (int s = 0; s < PS_NUM; ++s) f->ps[s] = a.prepscal[(int64_t)s * a.n_prep + e_pr];
+    for (int s = 0; s < PS_NUM; ++s) f->ps[s] = cld<COH>(a.prepscal + (int64_t)s * a.n_prep + e_pr);
   }
   if (want_ls) {
 #pragma unroll
-    for (int j = 0; j < kLsChunks; ++j) f->ls[j] = a.theta[a.d + min(e + 256 * j, a.d - 1)];
+    for (int j = 0; j < kLsChunks; ++j) f->ls[j] = cld<COH>(a.theta + a.d + min(e + 256 * j, a.d - 1));
   }
 }
 
 // acc[0 .. KS_NUM + PS_NUM) = this thread's share of the scalar sums, acc[kNS - 1] = its share of sum(log sigma);
 // entry order e = t, t + 256, ... as a plain strided loop would take them
+template <bool COH = false>
 __device__ __forceinline__ void scalar_accumulate(const EpiArgs& a, bool want_ls, const ScalarFetch& f, double* acc) {
   // (the entries scalar_fetch took from clamped indices are dropped HERE, at their first use, not next to the loads:
   // a use is a wait, and the caller has more loads to issue in between)
@@ -650,16 +697,16 @@ __device__ __forceinline__ void scalar_accumulate(const EpiArgs& a, bool want_ls
   for (int j = 0; j < kLsChunks; ++j) t += keep_masked(f.ls[j], opaque_mask(want_ls && e + 256 * j < a.d));
   for (int e = threadIdx.x + 256 * kPsChunks; e < a.n_ps; e += 256) {
 #pragma unroll
-    for (int s = 0; s < KS_NUM; ++s) acc[s] += a.pscal[(int64_t)s * a.n_ps + e];
+    for (int s = 0; s < KS_NUM; ++s) acc[s] += cld<COH>(a.pscal + (int64_t)s * a.n_ps + e);
   }
   if (a.prepscal) {
     for (int e = threadIdx.x + 256; e < a.n_prep; e += 256) {
 #pragma unroll
-      for (int s = 0; s < PS_NUM; ++s) acc[KS_NUM + s] += a.prepscal[(int64_t)s * a.n_prep + e];
+      for (int s = 0; s < PS_NUM; ++s) acc[KS_NUM + s] += cld<COH>(a.prepscal + (int64_t)s * a.n_prep + e);
     }
   }
   if (want_ls)
-    for (int i = threadIdx.x + 256 * kLsChunks; i < a.d; i += 256) t += a.theta[a.d + i];
+    for (int i = threadIdx.x + 256 * kLsChunks; i < a.d; i += 256) t += cld<COH>(a.theta + a.d + i);
   acc[kNS - 1] = t;
 }
 
@@ -769,7 +816,7 @@ __device__ __forceinline__ void plain_column(const EpiArgs& a, int i, double g, 
 // time (NF x NI loads in flight: one memory round trip per pass, and the launcher's geometry -- at most 64 row
 // blocks up to 2 workgroups per CU -- makes that one pass for NI = 16); row blocks past the end are read from the
 // last one (scalar clamps) and dropped by a mask afterwards.
-template <int NF, int NI>
+template <int NF, int NI, bool COH = false>
 __device__ __forceinline__ void column_sums(const double* blk_partials, int q, int c, int n_rb,
                                             double (*colsum)[4][64]) {
   const int rb_last = n_rb - 1;
@@ -782,7 +829,7 @@ __device__ __forceinline__ void column_sums(const double* blk_partials, int q, i
     for (int i = 0; i < NI; ++i) {
       const double* prb = blk_partials + min(rb0 + 4 * i, rb_last) * (CF_NUM * 64) + (uint32_t)c;
 #pragma unroll
-      for (int f = 0; f < NF; ++f) v[f][i] = prb[f * 64];
+      for (int f = 0; f < NF; ++f) v[f][i] = cld<COH>(prb + f * 64);
     }
     // ---- everything below waits on those loads (and on everything the caller has requested before them) ----
 #pragma unroll
@@ -798,13 +845,13 @@ __device__ __forceinline__ void column_sums(const double* blk_partials, int q, i
 
 // one instantiation per field count; 4 row blocks per thread cover up to 16 (small sample counts), 16 cover the
 // launcher's usual 64, 8 at a time for the wide field sets (registers)
-template <int NF>
+template <int NF, bool COH = false>
 __device__ __forceinline__ void column_sums_nf(const double* blk_partials, int q, int c, int n_rb,
                                                double (*colsum)[4][64]) {
   if (n_rb > 16)
-    column_sums<NF, (NF <= 2 ? 16 : 8)>(blk_partials, q, c, n_rb, colsum);
+    column_sums<NF, (NF <= 2 ? 16 : 8), COH>(blk_partials, q, c, n_rb, colsum);
   else
-    column_sums<NF, 4>(blk_partials, q, c, n_rb, colsum);
+    column_sums<NF, 4, COH>(blk_partials, q, c, n_rb, colsum);
 }
 
 // reduce-only mode (the multi-rank path: the sums go to the all-reduce, mf_epilogue_kernel does the rest)
@@ -987,6 +1034,262 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
              fc_mid, fc_tm ? fc_tm - fc_t0 : -1, fc_tm ? fc_t1 - fc_tm : -1, fc_t1 - fc_t0);
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// the whole evaluation in ONE launch (north_star: "... fused into one launch")
+// ------------------------------------------------------------------------------------------------
+// mf_one_kernel = prep + accumulate + finalize of a single plain ELBO evaluation on one rank:
+//   prologue   every workgroup forms what mf_prep_kernel would have left it in memory: the column constants of its 128
+//              columns in registers, and (funnel, noise in memory) the row scalars of its own rows -- written to the
+//              row-scalar array the streaming loop loads through the scalar cache, by every column block of the row
+//              block alike (identical values: no hand-off, no waiting).  theta is read from device memory when it
+//              lives there (the device-resident fit loop); a parameter staged in pinned host memory is fetched across
+//              PCIe ONCE per column block, by the row-block-0 workgroup, and published through a device copy and an
+//              epoch flag the other row blocks poll (bounded; a give-up reads the host copy itself).
+//   body       mf_accum_body, unchanged arithmetic; its partial sums leave write-through.
+//   tail       tickets instead of a launch boundary: the last workgroup of a column block to arrive sums that
+//              block's row-block partials in mf_finalize_kernel's order and writes the gradient (and applies the
+//              optimiser step) for its 128 columns; the last workgroup of all adds up the scalar partials, writes
+//              the value and finishes the funnel's coupling column, whose gradient needs those totals.
+struct OneArgs {
+  unsigned* cnt;            // [0]: workgroups that are through; [1 + cb]: accumulate passes of column block cb finished
+  unsigned* flag;           // [cb]: epoch of the last publication of column block cb's theta
+  double* kbuf;             // the coupling column's sums, parked for the last workgroup: [CF_NUM | ls | s1 s2 theta (x2)]
+  unsigned epoch;
+  int theta_on_device;      // theta_src is device memory: no publication needed
+};
+
+// finalize_kernel's column part for the 64 columns of group `grp` (see mf_finalize_kernel: same sums, same order)
+template <bool MOMF, bool TSCF>
+__device__ __forceinline__ void one_tail_group(const EpiArgs& a, const OneArgs& o, int grp, double (*colsum)[4][64]) {
+  constexpr int NF = TSCF ? CF_NUM : (MOMF ? CF_EK + 1 : CF_GE + 1);
+  const int c = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = grp * 64 + c, d = a.d;
+  const bool funnel = a.model.id == VB_MODEL_FUNNEL;
+  const int k = a.model.k;
+  double pf_ls = 0.0, pf_s1[2] = {0.0, 0.0}, pf_s2[2] = {0.0, 0.0}, pf_th[2] = {0.0, 0.0};
+  if (q == 0 && col < d) {
+    pf_ls = cld<true>(a.theta + d + col);
+    if (a.has_step) {
+      fit_step_load(a.step, col, &pf_s1[0], &pf_s2[0], &pf_th[0]);
+      fit_step_load(a.step, (int64_t)d + col, &pf_s1[1], &pf_s2[1], &pf_th[1]);
+    }
+  }
+  const double* blk_partials = a.partials + (int64_t)grp * a.n_rb * (CF_NUM * 64);
+  column_sums_nf<NF, true>(blk_partials, q, c, a.n_rb, colsum);
+  __syncthreads();
+  if (q == 0 && col < d) {
+    double S[CF_NUM];
+#pragma unroll
+    for (int f = 0; f < CF_NUM; ++f) {
+      const double x = (colsum[f][0][c] + colsum[f][1][c]) + (colsum[f][2][c] + colsum[f][3][c]);
+      S[f] = f < NF ? x : 0.0;
+    }
+    if (funnel && col == k) {      // needs the scalar totals: parked for the last workgroup
+#pragma unroll
+      for (int f = 0; f < CF_NUM; ++f) cst<true>(o.kbuf + f, S[f]);
+      cst<true>(o.kbuf + CF_NUM, pf_ls);
+      cst<true>(o.kbuf + CF_NUM + 1, pf_s1[0]), cst<true>(o.kbuf + CF_NUM + 2, pf_s2[0]), cst<true>(o.kbuf + CF_NUM + 3, pf_th[0]);
+      cst<true>(o.kbuf + CF_NUM + 4, pf_s1[1]), cst<true>(o.kbuf + CF_NUM + 5, pf_s2[1]), cst<true>(o.kbuf + CF_NUM + 6, pf_th[1]);
+    } else {
+      const bool student = a.family == VB_FAMILY_MF_STUDENT_T;
+      double gm, gl;
+      plain_column(a, col, S[CF_G], S[CF_GE], student ? S[CF_SC] : S[CF_E], student ? S[CF_SCE] : S[CF_EE], a.out + 1,
+                   a.out + 1 + d, pf_ls, &gm, &gl);
+      if (a.has_step) {
+        fit_step_apply_vals(a.step, col, gm, pf_s1[0], pf_s2[0], pf_th[0]);
+        fit_step_apply_vals(a.step, (int64_t)d + col, gl, pf_s1[1], pf_s2[1], pf_th[1]);
+      }
+    }
+  }
+  __syncthreads();      // colsum is reused by the next group
+}
+
+template <int MODEL, bool MOM, bool TSC, bool GEN>
+__global__ void __launch_bounds__(kMfThreads)
+mf_one_kernel(const BatchPtrs bp, const Workspace ws, const Geom g, const EpiArgs a_in, const OneArgs o) {
+  __shared__ double colsum[CF_NUM + 1][4][64];
+  __shared__ ScalarShared ssh;
+  __shared__ double thk[2];
+  __shared__ int role;
+  const int t = threadIdx.x, lane = t & 63;
+  int rb, cb;
+  mf_wg_coords(g, (int)blockIdx.x, &rb, &cb);
+  double* wsb = ws.base;
+  const int d = g.d;
+  const double* theta_src = bp.theta_src[0];
+  double* theta_dev = wsb + ws.off_theta;
+  constexpr bool FUN = MODEL == VB_MODEL_FUNNEL;
+  const int k = a_in.model.k;
+
+  // ---- prologue: theta of this column block (and of the coupling column) ---------------------------------------------
+  const int c0i = cb * kMfCols + 2 * lane;
+  double mu[2] = {0.0, 0.0}, ls[2] = {0.0, 0.0};
+  if (o.theta_on_device) {
+    // (the optimiser's own array: the step of THIS launch rewrites a column only after every workgroup that reads it --
+    // the column block's own row blocks, and for the coupling column everybody -- has taken its ticket)
+    if (t < 64) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (c0i + j < d) mu[j] = theta_src[c0i + j], ls[j] = theta_src[d + c0i + j];
+    }
+    if (FUN && t == 64) thk[0] = theta_src[k], thk[1] = theta_src[d + k];
+    if (rb == 0 && t < 64) {       // the copy the tail reads (the step overwrites theta_src itself)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (c0i + j < d) cst<true>(theta_dev + c0i + j, mu[j]), cst<true>(theta_dev + d + c0i + j, ls[j]);
+    }
+  } else if (rb == 0) {
+    if (t < 64) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (c0i + j < d) {
+          mu[j] = theta_src[c0i + j], ls[j] = theta_src[d + c0i + j];      // across PCIe, once per column block
+          cst<true>(theta_dev + c0i + j, mu[j]), cst<true>(theta_dev + d + c0i + j, ls[j]);
+        }
+    }
+    if (FUN && t == 64) thk[0] = theta_src[k], thk[1] = theta_src[d + k];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(o.flag + cb, o.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (t == 0) {
+      int ok = 1, spins = 0;
+      const int kcb = FUN ? k / kMfCols : cb;
+      while (__hip_atomic_load(o.flag + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != o.epoch ||
+             __hip_atomic_load(o.flag + kcb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != o.epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 16)) {      // (a publisher that has not been scheduled: take the host copy ourselves)
+          ok = 0;
+          break;
+        }
+      }
+      role = ok;
+    }
+    __syncthreads();
+    const double* src = role ? (const double*)theta_dev : theta_src;
+    if (t < 64) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (c0i + j < d) {
+          mu[j] = role ? cld<true>(src + c0i + j) : src[c0i + j];
+          ls[j] = role ? cld<true>(src + d + c0i + j) : src[d + c0i + j];
+        }
+    }
+    if (FUN && t == 64) thk[0] = role ? cld<true>(src + k) : src[k], thk[1] = role ? cld<true>(src + d + k) : src[d + k];
+  }
+  // the four waves of the workgroup own the same 128 columns: wave 0's values to all of them through LDS
+  double* xch = &colsum[0][0][0];
+  __syncthreads();
+  if (t < 64) xch[4 * lane] = mu[0], xch[4 * lane + 1] = mu[1], xch[4 * lane + 2] = ls[0], xch[4 * lane + 3] = ls[1];
+  __syncthreads();
+  OnePro pro;
+  {
+    const double m0 = xch[4 * lane], m1 = xch[4 * lane + 1], l0 = xch[4 * lane + 2], l1 = xch[4 * lane + 3];
+    const bool in0 = c0i < d, in1 = c0i + 1 < d;
+    const double s0 = in0 ? exp(l0) : 0.0, s1 = in1 ? exp(l1) : 0.0;
+    if (FUN) {      // the coupling column contributes through the per-row sums, not elementwise (prep_column)
+      pro.cp0 = (d2){(in0 && c0i != k) ? m0 : 0.0, (in1 && c0i + 1 != k) ? m1 : 0.0};
+      pro.cp1 = (d2){(in0 && c0i != k) ? s0 : 0.0, (in1 && c0i + 1 != k) ? s1 : 0.0};
+      pro.cp2 = (d2){0.0, 0.0};
+    } else {
+      const double* p0 = a_in.model.p0;
+      const double* p1 = a_in.model.p1;
+      pro.cp0 = (d2){in0 ? m0 - p0[c0i] : 0.0, in1 ? m1 - p0[c0i + 1] : 0.0};
+      pro.cp1 = (d2){s0, s1};
+      pro.cp2 = (d2){in0 ? p1[c0i] : 0.0, in1 ? p1[c0i + 1] : 0.0};
+    }
+    pro.muk = FUN ? thk[0] : 0.0;
+    pro.lsk = FUN ? thk[1] : 0.0;
+  }
+  // ---- prologue: row scalars of this row block (funnel, noise in memory) and the coupling column's partial sums ------
+  if (FUN && !GEN) {
+    const int64_t r0 = (int64_t)rb * g.rows_per_wg;
+    const int64_t r1 = (r0 + g.rows_per_wg < g.n) ? r0 + g.rows_per_wg : g.n;
+    const double sgk = exp(pro.lsk), muk = pro.muk;
+    const double it2 = 1.0 / (a_in.model.tau * a_in.model.tau), dm1 = (double)(d - 1);
+    const double* noise = bp.noise[0];
+    double W = 0.0, FK = 0.0, GK = 0.0, GEK = 0.0;
+    for (int64_t r = r0 + t; r < r1; r += kMfThreads) {
+      const double ek = noise[r * g.ld + k];
+      const double v = fma(sgk, ek, muk);
+      const double gk = fma(-v, it2, -dm1);
+      d2* rs = reinterpret_cast<d2*>(wsb + ws.off_rowscal + 4 * r);
+      rs[0] = (d2){exp(-2.0 * v), ek};
+      rs[1] = (d2){1.0, 0.0};
+      W += 1.0;
+      FK += v * fma(-0.5 * v, it2, -dm1);
+      GK += gk;
+      GEK += gk * ek;
+    }
+    if (cb == 0) {      // (workgroup-uniform)
+      W = wave_sum(W), FK = wave_sum(FK), GK = wave_sum(GK), GEK = wave_sum(GEK);
+      double(*sh)[PS_NUM] = reinterpret_cast<double(*)[PS_NUM]>(&colsum[1][0][0]);
+      if (lane == 0) sh[t >> 6][PS_W] = W, sh[t >> 6][PS_FK] = FK, sh[t >> 6][PS_GK] = GK, sh[t >> 6][PS_GEK] = GEK;
+      __syncthreads();
+      if (t < PS_NUM)
+        cst<true>(wsb + ws.off_prepscal + (int64_t)t * g.n_prep + rb, (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row scalars are in L2 before the scalar cache asks for them
+    __syncthreads();
+  } else if (!FUN && rb == 0 && cb == 0 && t < PS_NUM) {
+    cst<true>(wsb + ws.off_prepscal + t, t == PS_W ? (double)g.n : 0.0);      // (n_prep = 1)
+  }
+
+  // ---- the streaming pass -----------------------------------------------------------------------------------------------
+  mf_accum_body<MODEL, MOM, TSC, false, GEN, true>(bp, ws, g, pro);
+
+  // ---- tail: tickets instead of launch boundaries -----------------------------------------------------------------------
+  EpiArgs a = a_in;
+  a.partials = wsb + ws.off_partials;
+  a.pscal = wsb + ws.off_pscal;
+  a.prepscal = wsb + ws.off_prepscal;
+  a.theta = theta_dev;
+  a.out = bp.out[0];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's write-through partials have left
+  __syncthreads();
+  if (t == 0) role = atomicAdd(o.cnt + 1 + cb, 1u) == (unsigned)g.n_rb - 1 ? 1 : 0;
+  __syncthreads();
+  if (role) {      // the column block is complete: its two groups of 64 columns
+    one_tail_group<MOM, TSC>(a, o, 2 * cb, colsum);
+    if (2 * cb + 1 < g.Dp / 64) one_tail_group<MOM, TSC>(a, o, 2 * cb + 1, colsum);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (t == 0) role = atomicAdd(o.cnt, 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!role) return;
+  // the last workgroup of all: scalar totals, the value, the coupling column
+  if (t < g.n_cb + 1)                    // (everybody has taken both tickets: ready for the next launch)
+    __hip_atomic_store(o.cnt + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ScalarFetch sf;
+  scalar_fetch<true>(a, true, &sf);
+  double kb[CF_NUM + 7];
+  const bool funnel = a.model.id == VB_MODEL_FUNNEL;
+  if (funnel && t == 0) {
+#pragma unroll
+    for (int i = 0; i < CF_NUM + 7; ++i) kb[i] = cld<true>(o.kbuf + i);
+  }
+  double sacc[kNS], sum_ls = 0.0;
+  scalar_accumulate<true>(a, true, sf, sacc);
+  const Totals tot = scalar_reduce(sacc, &ssh, &sum_ls);
+  if (t == 0) {
+    if (funnel) {
+      const bool student = a.family == VB_FAMILY_MF_STUDENT_T;
+      const double gsum = kb[CF_G] + (tot.v[SF_GK] + tot.v[SF_Q]), ge = kb[CF_GE] + (tot.v[SF_GEK] + tot.v[SF_QE]);
+      double gm, gl;
+      plain_column(a, k, gsum, ge, student ? kb[CF_SC] : kb[CF_E], student ? kb[CF_SCE] : kb[CF_EE], a.out + 1, a.out + 1 + d,
+                   kb[CF_NUM], &gm, &gl);
+      if (a.has_step) {
+        fit_step_apply_vals(a.step, k, gm, kb[CF_NUM + 1], kb[CF_NUM + 2], kb[CF_NUM + 3]);
+        fit_step_apply_vals(a.step, (int64_t)d + k, gl, kb[CF_NUM + 4], kb[CF_NUM + 5], kb[CF_NUM + 6]);
+      }
+    }
+    const double val = elbo_value(a, tot, sum_ls);
+    a.out[0] = val;
+    if (a.has_step) a.step.values[a.step.k] = val;
+  }
 }
 
 // one workgroup over the reduced sums: control variates, weighted gradients, post-all-reduce
@@ -1182,6 +1485,27 @@ static void launch_accum_model(bool mom, bool tsc, bool weighted, const Launch& 
   else if (mom) launch_accum<MODEL, true, false>(weighted, L, bp, ws, g);
   else if (tsc) launch_accum<MODEL, false, true>(weighted, L, bp, ws, g);
   else launch_accum<MODEL, false, false>(weighted, L, bp, ws, g);
+}
+
+template <int MODEL, bool GEN>
+static void launch_one_mg(bool mom, bool tsc, const Launch& L, const BatchPtrs& bp, const Workspace& ws, const Geom& g,
+                          const EpiArgs& e, const OneArgs& o) {
+  if (mom && tsc)
+    hipExtLaunchKernelGGL((mf_one_kernel<MODEL, true, true, GEN>), L.grid, dim3(kMfThreads), 0, L.st, L.ev0, L.ev1, 0, bp, ws, g, e, o);
+  else if (tsc)
+    hipExtLaunchKernelGGL((mf_one_kernel<MODEL, false, true, GEN>), L.grid, dim3(kMfThreads), 0, L.st, L.ev0, L.ev1, 0, bp, ws, g, e, o);
+  else if (mom)
+    hipExtLaunchKernelGGL((mf_one_kernel<MODEL, true, false, GEN>), L.grid, dim3(kMfThreads), 0, L.st, L.ev0, L.ev1, 0, bp, ws, g, e, o);
+  else
+    hipExtLaunchKernelGGL((mf_one_kernel<MODEL, false, false, GEN>), L.grid, dim3(kMfThreads), 0, L.st, L.ev0, L.ev1, 0, bp, ws, g, e, o);
+}
+
+static void launch_one(bool funnel, bool mom, bool tsc, bool gen, const Launch& L, const BatchPtrs& bp, const Workspace& ws,
+                       const Geom& g, const EpiArgs& e, const OneArgs& o) {
+  if (funnel && gen) launch_one_mg<VB_MODEL_FUNNEL, true>(mom, tsc, L, bp, ws, g, e, o);
+  else if (funnel) launch_one_mg<VB_MODEL_FUNNEL, false>(mom, tsc, L, bp, ws, g, e, o);
+  else if (gen) launch_one_mg<VB_MODEL_GAUSS_DIAG, true>(mom, tsc, L, bp, ws, g, e, o);
+  else launch_one_mg<VB_MODEL_GAUSS_DIAG, false>(mom, tsc, L, bp, ws, g, e, o);
 }
 
 static int env_int(const char* name, int dflt) {
@@ -1397,6 +1721,25 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
       g.n_prep = g.n_rb;          // one entry of coupling-column partials per row block (written by column block 0)
     }
   }
+  // The whole evaluation in ONE launch (mf_one_kernel): a single plain ELBO evaluation on one rank, on the main stream.
+  // Built as VERDICT r4 item 5 asked, results equal to the launch chain's (tests/test_gpu_one_launch.py) -- and MEASURED
+  // SLOWER, so it is off unless VB_MF_ONE=1: C1 blocking call 43.1 against 32.2 us, device-loop iteration 31.4 against
+  // 24.3 us; C0 28.9 / 18.5 against 27.3 / 14.3 us (tools/one_launch_bench.py).  Inside one launch a hand-off
+  // between workgroups on different XCDs is a write-through store, a ticket and an L2-bypassing load -- a memory round
+  // trip each (~2 us), three of them in sequence behind the last streaming workgroup -- where the launch boundary costs
+  // ~2 us once and leaves the partial sums in an L2 every workgroup of the next kernel may hit.
+  const bool one = env_int("VB_MF_ONE", 0) && c.count == 1 && c.mode == 0 && c.cv_mode == VB_CV_NONE && !ctx->comm &&
+                   !logistic && !weighted && !c.pipelined && !c.alternate && !c.skip_prep &&
+                   (model.id == VB_MODEL_GAUSS_DIAG || funnel);
+  if (one) {
+    if (funnel && g.gen) {          // the streaming kernel forms the row scalars of its own rows, whatever n
+      g.inline_rows = 1;
+      g.fk = model.k;
+      g.ftau = model.tau;
+      g.rows = 0;
+    }
+    g.n_prep = funnel ? g.n_rb : 1;      // coupling-column partials per row block (column block 0) / the constant entry
+  }
   const bool rows_ws = rows && !g.inline_rows;
   const int prep_grid = g.inline_rows ? (g.Dp + 255) / 256 : g.n_prep;
 
@@ -1478,6 +1821,50 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
     P.post_pending = false;
   }
 
+  if (one) {
+    // counters / flags / the coupling column's parked sums: 64 words + 16 doubles, zeroed once
+    if (!ctx->mf_one.ptr) {
+      VB_TRY(ensure(ctx, ctx->mf_one, 512));
+      VB_HIP(ctx, hipMemsetAsync(ctx->mf_one.ptr, 0, 512, st_main));
+    }
+    OneArgs o;
+    o.cnt = (unsigned*)ctx->mf_one.ptr;                       // [0 .. 32]
+    o.flag = (unsigned*)ctx->mf_one.ptr + 40;                 // [40 .. 72)
+    o.kbuf = (double*)ctx->mf_one.ptr + 40;                   // bytes [320, 448)
+    o.epoch = ++ctx->mf_one_epoch;
+    if (o.epoch == 0) o.epoch = ++ctx->mf_one_epoch;
+    o.theta_on_device = c.theta_on_device ? 1 : 0;
+    if (g.n_cb > 31) return fail(ctx, VB_ERR_UNSUPPORTED, "one-launch evaluation: at most 31 column blocks");
+    EpiArgs e1;
+    memset(&e1, 0, sizeof e1);
+    e1.n_rb = g.n_rb;
+    e1.n_ps = g.n_rb * g.n_cb;
+    e1.n_prep = g.n_prep;
+    e1.nf = nf;
+    e1.d = (int)d;
+    e1.Dp = g.Dp;
+    e1.n_total = (double)c.n_total;
+    e1.family = c.family;
+    e1.df = c.df;
+    e1.flags = c.flags;
+    e1.model = model;
+    if (c.step && c.step_done) {
+      *c.step_done = true;
+      e1.has_step = 1;
+      e1.step = *c.step;
+    }
+    if (c.prep_done) *c.prep_done = false;
+    Launch L1;
+    L1.grid = dim3((unsigned)(g.n_rb * g.n_cb), 1);
+    L1.st = st_main;
+    prof_events(ctx, &L1.ev0, &L1.ev1, 1);
+    launch_one(model.id == VB_MODEL_FUNNEL, mom, tsc, g.gen != 0, L1, bp, ws, g, e1, o);
+    VB_HIP(ctx, hipGetLastError());
+    P.fin_valid[set] = false;
+    P.main_dirty = true;
+    ctx->result_stream = st_main;
+    return VB_OK;
+  }
   if (!logistic && !c.skip_prep) {   // skip_prep: the previous iteration's finalize kernel has done it
     hipLaunchKernelGGL(mf_prep_kernel, dim3((unsigned)prep_grid, (unsigned)c.count), dim3(256), 0, st_pre,
                        bp, ws, g, model);
