@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) mtd_first_kernel(const uint32_t* __restri
 
 // state[count + s] = the block 624 * 256 * count words behind state[s] (one round of the ladder, two kernels):
 // mtd_seq_kernel writes the 34 blocks that start with state[s] (every u[i + j], i < 20 160, j < 624) and
-// mtd_corr_kernel's workgroup (s, slice, half) XORs its 320 coefficients' share of 312 words of the correlation into the target.
+// mtd_corr_kernel's workgroup (s, slice, a) XORs its 320 coefficients' share of the 624 words of the correlation into the target.
 constexpr int kSeqBlocks = 34;                    // 34 x 624 = 21 216 >= 20 160 + 623 words
 constexpr int kSeqWords = kSeqBlocks * kN;
 constexpr int kSlice = 320;                       // coefficients per slice (10 words of the polynomial)
@@ -130,30 +130,46 @@ __global__ void __launch_bounds__(256) mtd_seq_kernel(const uint32_t* __restrict
   }
 }
 
-constexpr int kCorrHalf = kN / 2;                 // outputs per workgroup: blockIdx.z & 1 selects words [0, 312) or [312, 624)
-// blockIdx.z >> 1 = a - 1: the jump of a * count streams (polynomial row `poly_row0 + a - 1`), target stream a * count + s
-__global__ void __launch_bounds__(320) mtd_corr_kernel(const uint32_t* __restrict__ polys, int poly_row0,
-                                                       const uint32_t* __restrict__ seq, uint32_t* __restrict__ state,
-                                                       int count, int streams) {
-  __shared__ uint32_t u[kSlice + kCorrHalf];
+// blockIdx.z = a - 1: the jump of a * count streams (polynomial row `poly_row0 + a - 1`), target stream a * count + s.
+// Thread tt forms FOUR consecutive words 4 tt .. 4 tt + 3 of the correlation: coefficient bit i contributes u[i + j] to
+// word j, so the four words share a sliding window of the sequence -- 36 words from LDS (nine 16-byte reads) serve 32
+// coefficients x 4 outputs, a quarter of the LDS traffic of one output per thread (the kernel's bound).
+constexpr int kCorrThreads = 192;                 // 156 of them own outputs (624 / 4)
+__global__ void __launch_bounds__(kCorrThreads) mtd_corr_kernel(const uint32_t* __restrict__ polys, int poly_row0,
+                                                                const uint32_t* __restrict__ seq, uint32_t* __restrict__ state,
+                                                                int count, int streams) {
+  __shared__ __attribute__((aligned(16))) uint32_t u[kSlice + kN + 8];
   __shared__ uint32_t g[kSlice / 32];
-  const int s = blockIdx.x, slice = blockIdx.y, j0 = (blockIdx.z & 1) * kCorrHalf, a = (blockIdx.z >> 1) + 1, tt = threadIdx.x;
+  const int s = blockIdx.x, slice = blockIdx.y, a = blockIdx.z + 1, tt = threadIdx.x;
   const int target = a * count + s;
   if (target >= streams) return;
   const uint32_t* poly = polys + (size_t)(poly_row0 + a - 1) * kN;
-  const uint32_t* src = seq + (size_t)s * kSeqWords + slice * kSlice + j0;
-  for (int i = tt; i < kSlice + kCorrHalf; i += 320) u[i] = src[i];
+  const uint32_t* src = seq + (size_t)s * kSeqWords + slice * kSlice;
+  for (int i = tt; i < kSlice + kN + 8; i += kCorrThreads) u[i] = i < kSlice + kN ? src[i] : 0u;
   if (tt < kSlice / 32) g[tt] = slice * (kSlice / 32) + tt < kN ? poly[slice * (kSlice / 32) + tt] : 0u;
   __syncthreads();
-  if (tt >= kCorrHalf) return;
-  const int t = j0 + tt;
-  uint32_t acc = 0;
+  if (tt >= kN / 4) return;
+  uint32_t acc[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 1
   for (int w = 0; w < kSlice / 32; ++w) {
     const uint32_t gw = g[w];
+    uint32_t r[36];
+    const uint4* win = reinterpret_cast<const uint4*>(u + 32 * w + 4 * tt);
 #pragma unroll
-    for (int b = 0; b < 32; ++b) acc ^= (0u - ((gw >> b) & 1u)) & u[32 * w + b + tt];
+    for (int q = 0; q < 9; ++q) {
+      const uint4 v = win[q];
+      r[4 * q] = v.x, r[4 * q + 1] = v.y, r[4 * q + 2] = v.z, r[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+      const uint32_t m = 0u - ((gw >> b) & 1u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] ^= m & r[b + k];
+    }
   }
-  atomicXor(&state[(size_t)target * kN + t], acc);      // integer: the result does not depend on the order
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    atomicXor(&state[(size_t)target * kN + 4 * tt + k], acc[k]);      // integer: the result does not depend on the order
 }
 
 // stream s: blocks [s B, min((s + 1) B, n_blocks)) of the stream into words[pre + block * 624 ...] (untempered)
@@ -477,7 +493,7 @@ int legacy_mt_words(vb_ctx* ctx, const uint32_t key[624], int pos, int64_t n_wor
   for (int64_t count = 1; count < streams; count <<= 2, ++r) {      // radix 4: the known stream starts quadruple per round
     const int n_src = (int)std::min<int64_t>(count, streams - count);      // sources with at least one target
     hipLaunchKernelGGL(mtd_seq_kernel, dim3((unsigned)n_src), dim3(256), 0, st, (const uint32_t*)state, seq);
-    hipLaunchKernelGGL(mtd_corr_kernel, dim3((unsigned)n_src, kCorrSlices, 6), dim3(320), 0, st, (const uint32_t*)poly, 3 * r,
+    hipLaunchKernelGGL(mtd_corr_kernel, dim3((unsigned)n_src, kCorrSlices, 3), dim3(kCorrThreads), 0, st, (const uint32_t*)poly, 3 * r,
                        (const uint32_t*)seq, state, (int)count, (int)streams);
   }
   hipLaunchKernelGGL(mtd_stream_kernel, dim3((unsigned)streams), dim3(256), 0, st, (const uint32_t*)state, words, pre, n_blocks);

@@ -66,48 +66,74 @@ __device__ __forceinline__ double lg_double(uint32_t w0, uint32_t w1) {      // 
   return (a * 67108864.0 + b) / 9007199254740992.0;
 }
 
+constexpr int kP2 = kC + kJ;              // positions a node can have: the chunk's own and the kJ exit positions behind it
+constexpr int kN2 = 2 * kP2;              // nodes: ctl * kP2 + p
+constexpr int kLv = 4;                    // jump tables J1, J2, J4, J8 (macro steps per application)
+constexpr int kStride = 1 << (kLv - 1);
+
+// LDS of a chunk.  Every normal the chunk can produce and the outcome of every trial it can make are settled ONCE,
+// position by position, before any node looks at them: a trial with normal t of the attempt at a reads its uniform at a + 2
+// or (t = 1 behind a trial with normal 0) a + 3 -- three (normal, uniform) pairs per attempt.  The first test
+// (U < 1 - 0.0331 X^4, ~97 % of the trials) is decided in the dense pass; the pairs it leaves open go on a list and
+// get their two logarithms from consecutive lanes (a divergent branch would make every wave pay for them).
+constexpr int kSlowCap = 512;             // list capacity (expected ~60 entries; an overflow makes the chunk's steps undefined)
 struct ChunkLds {
   double dbl[kL];                         // the chunk's doubles (+ halo)
-  double g0[kL], g1[kL];                  // polar attempt at (p, p + 1): f x2 (returned first), f x1 (cached); g0 = NaN: rejected
-  uint32_t step[2][kC];                   // macro step of node (p, ctl): dp | (a - p) << 7 | xmask << 13 | ctl' << 15
+  uint32_t fl[kL + 2];                    // attempt at (p, p + 1): 1 accepted; 2 / 4: V = 1 + c g > 0 for normal 0 / 1;
+                                          //   8 / 16 / 32: trial (normal 0, U at p + 2) / (1, p + 2) / (1, p + 3) accepts
+  uint32_t j1[kN2];                       // J1: next node | outputs << 16 | (a - p) << 24 | xmask << 30
+  union {
+    uint32_t jump[2][kN2];                // J2 -> [0], J4 -> [1], J8 -> [0]: the stride table ends up in jump[0]
+    struct {
+      uint32_t slow[kSlowCap];            // open pairs: a | pair << 16 (dead before the first jump table is written)
+      double slow_g[kSlowCap];            //   ... and the normal of each
+    } l;
+  } w;
+  int n_slow;
   GlibcLogData lt;
 };
+static_assert(kLv == 4, "the ping-pong of the jump tables ends in jump[0] for three doublings");
 
-// One Marsaglia-Tsang trial with the normal g and the uniform U: numpy's two tests, in its order and association
-__device__ __forceinline__ bool mt_trial_accepts(double g, double V3, double U, const GammaPar& par, const GlibcLogData& lt) {
-  if (U < 1.0 - 0.0331 * (g * g) * (g * g)) return true;
-  if (U == 0.0) return true;              // log(0) = -inf < anything finite
-  return glibc_log(U, lt) < 0.5 * g * g + par.b * (1. - V3 + glibc_log(V3, lt));
+// the two normals of the accepted polar attempt at doubles (p, p + 1): numpy's f x2 (returned first), f x1 (cached)
+__device__ __forceinline__ void lg_normals(const ChunkLds& s, int p, double* g0, double* g1) {
+  const double x1 = 2.0 * s.dbl[p] - 1.0, x2 = 2.0 * s.dbl[p + 1] - 1.0;
+  const double r2 = x1 * x1 + x2 * x2;
+  const double fac = sqrt(-2.0 * glibc_log(r2, s.lt) / r2);
+  *g0 = fac * x2, *g1 = fac * x1;
 }
 
-// successor of node (p, ctl); lim: doubles of this chunk that exist
+__device__ __forceinline__ int lg_node_p(int n) { return n >= kP2 ? n - kP2 : n; }
+
+// successor of node (p, ctl), p < kC; lim: doubles of this chunk that exist
 template <int PROG>
-__device__ __forceinline__ uint32_t lg_node_step(const ChunkLds& s, int p, int ctl, int lim, const GammaPar& par) {
+__device__ __forceinline__ uint32_t lg_node_step(const ChunkLds& s, int p, int ctl, int lim) {
   int a = p;
   for (;; a += 2) {
     if (a + 1 >= lim || a - p > 62) return kBadStep;
-    if (s.g0[a] == s.g0[a]) break;
+    if (s.fl[a] & 1) break;
   }
+  const uint32_t f = s.fl[a];
   int q = a + 2, state = ctl, xmask = 0;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const double g = t ? s.g1[a] : s.g0[a];
     if (PROG == 1 && state == kA) {       // the numerator of the next output
       state = kB;
       continue;
     }
-    const double V = 1.0 + par.c * g;
-    if (V <= 0.0) continue;
+    if (!(f & (2u << t))) continue;       // V <= 0: the next normal
     if (q >= lim) return kBadStep;
-    const double U = s.dbl[q++];
-    if (mt_trial_accepts(g, V * V * V, U, par, s.lt)) {
+    const uint32_t bit = t == 0 ? 8u : (q == a + 2 ? 16u : 32u);
+    ++q;
+    if (f & bit) {
       xmask |= 1 << t;
       state = PROG == 1 ? kA : kB;
     }
   }
-  return (uint32_t)(q - p) | (uint32_t)(a - p) << 7 | (uint32_t)xmask << 13 | (uint32_t)state << 15;
+  if (q >= kP2) return kBadStep;          // (a step that ends behind the exit window: not this path's case)
+  return (uint32_t)(state * kP2 + q) | (uint32_t)__popc(xmask) << 16 | (uint32_t)(a - p) << 24 | (uint32_t)xmask << 30;
 }
 
+// normals and trial outcomes -> J1 -> J2, J4, J8
 template <int PROG>
 __device__ __forceinline__ int lg_build(ChunkLds& s, const uint32_t* __restrict__ words, int64_t n_dbl, const GammaPar& par,
                                         const GlibcLogData* __restrict__ logtab) {
@@ -119,6 +145,7 @@ __device__ __forceinline__ int lg_build(ChunkLds& s, const uint32_t* __restrict_
     double* dst = reinterpret_cast<double*>(&s.lt);
     for (int i = t; i < (int)(sizeof(GlibcLogData) / sizeof(double)); i += 256) dst[i] = src[i];
   }
+  if (t == 0) s.n_slow = 0;
   const uint2* w2 = reinterpret_cast<const uint2*>(words) + base;
   for (int i = t; i < kL; i += 256) {
     double v = 0.0;
@@ -130,23 +157,88 @@ __device__ __forceinline__ int lg_build(ChunkLds& s, const uint32_t* __restrict_
   }
   __syncthreads();
   for (int i = t; i < kL; i += 256) {
-    double v0 = __builtin_nan(""), v1 = 0.0;
+    uint32_t f = 0;
+    double v0 = 0.0, v1 = 0.0;
     if (i + 1 < lim) {
       const double x1 = 2.0 * s.dbl[i] - 1.0, x2 = 2.0 * s.dbl[i + 1] - 1.0;
       const double r2 = x1 * x1 + x2 * x2;
       if (!(r2 >= 1.0 || r2 == 0.0)) {
-        const double f = sqrt(-2.0 * glibc_log(r2, s.lt) / r2);
-        v0 = f * x2, v1 = f * x1;
+        lg_normals(s, i, &v0, &v1);
+        f = 1;
       }
     }
-    s.g0[i] = v0, s.g1[i] = v1;
+    if (f) {
+      // (uniforms beyond the staged doubles: the pair is left undecided -- a step that would read it is undefined anyway)
+      const double u2 = i + 2 < kL ? s.dbl[i + 2] : 2.0, u3 = i + 3 < kL ? s.dbl[i + 3] : 2.0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const double g = k ? v1 : v0;
+        if (!(1.0 + par.c * g > 0.0)) continue;
+        f |= 2u << k;
+        const double sq = 1.0 - 0.0331 * (g * g) * (g * g);      // numpy: U < 1.0 - 0.0331 * (X * X) * (X * X)
+#pragma unroll
+        for (int which = 0; which < (k ? 2 : 1); ++which) {
+          const double U = which ? u3 : u2;
+          const int pair = k + which;        // 0: (normal 0, a + 2)   1: (1, a + 2)   2: (1, a + 3)
+          if (U < sq) {
+            f |= 8u << pair;
+          } else if (U < 1.5) {
+            const int at = atomicAdd(&s.n_slow, 1);
+            if (at < kSlowCap) s.w.l.slow[at] = (uint32_t)i | (uint32_t)pair << 16, s.w.l.slow_g[at] = g;
+          }
+        }
+      }
+    }
+    s.fl[i] = f;
   }
   __syncthreads();
-  for (int node = t; node < 2 * kC; node += 256) {
-    const int ctl = node / kC, p = node - ctl * kC;
-    s.step[ctl][p] = (PROG == 0 && ctl == kA) ? kBadStep : lg_node_step<PROG>(s, p, ctl, lim, par);
+  {
+    const int ns = s.n_slow < kSlowCap ? s.n_slow : kSlowCap;
+    for (int e = t; e < ns; e += 256) {   // log(U) < 0.5 X^2 + b (1 - V + log V), numpy's association
+      const uint32_t w = s.w.l.slow[e];
+      const int a = (int)(w & 0xffff), pair = (int)(w >> 16);
+      const double g = s.w.l.slow_g[e], U = s.dbl[a + (pair == 2 ? 3 : 2)];
+      double V = 1.0 + par.c * g;
+      V = V * V * V;
+      const bool acc = U == 0.0 || glibc_log(U, s.lt) < 0.5 * g * g + par.b * (1. - V + glibc_log(V, s.lt));
+      if (acc) atomicOr(&s.fl[a], 8u << pair);
+    }
   }
   __syncthreads();
+  const bool overflow = s.n_slow > kSlowCap;
+  uint32_t mine[(kN2 + 255) / 256];
+#pragma unroll
+  for (int k = 0; k < (kN2 + 255) / 256; ++k) {
+    const int n = t + 256 * k;
+    uint32_t e = kBadStep;
+    if (n < kN2) {
+      const int ctl = n >= kP2 ? 1 : 0, pp = n - ctl * kP2;
+      if (pp >= kC) e = (uint32_t)n;      // an exit node: fixed point, no outputs
+      else if (!(PROG == 0 && ctl == kA) && !overflow) e = lg_node_step<PROG>(s, pp, ctl, lim);
+      s.j1[n] = e;
+    }
+    mine[k] = e;
+  }
+  __syncthreads();
+  const uint32_t* prev = s.j1;
+#pragma unroll
+  for (int l = 0; l < kLv - 1; ++l) {
+#pragma unroll
+    for (int k = 0; k < (kN2 + 255) / 256; ++k) {
+      const int n = t + 256 * k;
+      if (n < kN2) {
+        uint32_t e = mine[k];
+        if (e != kBadStep) {
+          const uint32_t e2 = prev[e & 2047];
+          e = e2 == kBadStep ? kBadStep : ((e2 & 2047) | (((e >> 16) & 255) + ((e2 >> 16) & 255)) << 16);
+        }
+        s.w.jump[l & 1][n] = e;
+        mine[k] = e;
+      }
+    }
+    __syncthreads();
+    prev = s.w.jump[l & 1];
+  }
   return lim;
 }
 
@@ -158,31 +250,36 @@ __global__ void __launch_bounds__(256) lg_summary_kernel(const uint32_t* __restr
   lg_build<PROG>(s, words, n_dbl, par, logtab);
   const int t = threadIdx.x;
   if (t >= kNodes) return;
-  int p = t & (kJ - 1), ctl = t >> 6;
+  int n = (t >> 6) * kP2 + (t & (kJ - 1));
   uint64_t count = 0;
   bool bad = false;
-  while (p < kC) {
-    const uint32_t e = s.step[ctl][p];
+  const uint32_t* J = s.w.jump[0];
+  while (lg_node_p(n) < kC) {              // kStride macro steps at a time; exit nodes are fixed points
+    const uint32_t e = J[n];
     if (e == kBadStep) {
       bad = true;
       break;
     }
-    count += __popc((e >> 13) & 3);
-    p += e & 127;
-    ctl = (e >> 15) & 1;
+    count += (e >> 16) & 255;
+    n = (int)(e & 2047);
   }
-  if (p - kC >= kJ) bad = true;
-  S[(size_t)blockIdx.x * kNodes + t] = bad ? kBadSum : ((uint64_t)(p - kC) | (uint64_t)ctl << 6 | count << 8);
+  const int pe = lg_node_p(n) - kC;
+  S[(size_t)blockIdx.x * kNodes + t] = bad ? kBadSum : ((uint64_t)pe | (uint64_t)(n >= kP2 ? 1 : 0) << 6 | count << 8);
 }
 
 // one level up: Sout[g] = Sin[g kF + kF - 1] o ... o Sin[g kF]
-__global__ void __launch_bounds__(kNodes) lg_compose_kernel(const uint64_t* __restrict__ Sin, int64_t n_in, uint64_t* __restrict__ Sout) {
-  __shared__ uint64_t sh[kF * kNodes];
+__global__ void __launch_bounds__(256) lg_compose_kernel(const uint64_t* __restrict__ Sin, int64_t n_in, uint64_t* __restrict__ Sout) {
+  __shared__ __attribute__((aligned(16))) uint64_t sh[kF * kNodes];
   const int t = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.x * kF;
   const int cnt = (int)(n_in - i0 < kF ? n_in - i0 : kF);
-  for (int k = t; k < cnt * kNodes; k += kNodes) sh[k] = Sin[i0 * kNodes + k];
+  {
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Sin + i0 * kNodes);
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(sh);
+    for (int k = t; k < cnt * kNodes / 2; k += 256) dst[k] = src[k];
+  }
   __syncthreads();
+  if (t >= kNodes) return;
   int node = t;
   uint64_t count = 0;
   bool bad = false;
@@ -200,19 +297,23 @@ __global__ void __launch_bounds__(kNodes) lg_compose_kernel(const uint64_t* __re
 
 // one level down: the children of group blockIdx.x learn their entry nodes and the index of their first output.  A child
 // behind the last wanted output, or behind a child whose map is undefined at its entry node, is dead.
-__global__ void __launch_bounds__(kNodes) lg_expand_kernel(const uint64_t* __restrict__ Sin, int64_t n_in,
-                                                           const uint8_t* __restrict__ entry_up, const int64_t* __restrict__ first_up,
-                                                           uint8_t* __restrict__ entry, int64_t* __restrict__ first, int64_t n_out) {
-  __shared__ uint64_t sh[kF * kNodes];
+__global__ void __launch_bounds__(256) lg_expand_kernel(const uint64_t* __restrict__ Sin, int64_t n_in,
+                                                        const uint8_t* __restrict__ entry_up, const int64_t* __restrict__ first_up,
+                                                        uint8_t* __restrict__ entry, int64_t* __restrict__ first, int64_t n_out) {
+  __shared__ __attribute__((aligned(16))) uint64_t sh[kF * kNodes];
   const int t = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.x * kF;
   const int cnt = (int)(n_in - i0 < kF ? n_in - i0 : kF);
   const uint8_t e_up = entry_up[blockIdx.x];
   if (e_up == kDead) {
-    for (int i = t; i < cnt; i += kNodes) entry[i0 + i] = kDead;
+    for (int i = t; i < cnt; i += 256) entry[i0 + i] = kDead;
     return;
   }
-  for (int k = t; k < cnt * kNodes; k += kNodes) sh[k] = Sin[i0 * kNodes + k];
+  {
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Sin + i0 * kNodes);
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(sh);
+    for (int k = t; k < cnt * kNodes / 2; k += 256) dst[k] = src[k];
+  }
   __syncthreads();
   if (t != 0) return;
   int node = e_up;
@@ -267,37 +368,66 @@ __global__ void __launch_bounds__(256) lg_emit_kernel(const uint32_t* __restrict
   const uint8_t e0 = entry[blockIdx.x];
   if (e0 == kDead) return;
   __shared__ ChunkLds s;
-  __shared__ uint16_t visited[kC / 2 + 2];
-  __shared__ int n_steps, walk_bad;
+  __shared__ uint16_t visited[kC / 2 + 2 * kStride];
+  __shared__ uint16_t mile[kC / 2 / kStride + 4];
+  __shared__ int n_mile, n_steps, walk_bad, slow_from;
   __shared__ int wave_cnt[4], wave_set[4];
   __shared__ double set_val[256];
   __shared__ int last_set[256];
   lg_build<PROG>(s, words, n_dbl, par, logtab);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  // the chunk's piece of the trajectory: thread 0 strides through it kStride macro steps at a time (J8), then one thread
+  // per milestone fills in the steps between two milestones (J1) -- ~1/5 of the dependent LDS round trips of a plain walk
   if (t == 0) {
-    int p = e0 & (kJ - 1), ctl = e0 >> 6, ns = 0, bad = 0;
-    while (p < kC) {
-      const uint32_t e = s.step[ctl][p];
-      if (e == kBadStep) {
-        bad = 1;
+    int n = (e0 >> 6) * kP2 + (e0 & (kJ - 1)), nm = 0, slow = -1;
+    const uint32_t* J = s.w.jump[0];
+    while (lg_node_p(n) < kC) {
+      mile[nm++] = (uint16_t)n;
+      const uint32_t e = J[n];
+      if (e == kBadStep) {                // the generated words end inside this stride: step by step from here
+        slow = nm - 1;
         break;
       }
-      visited[ns++] = (uint16_t)(p | ctl << 15);
-      p += e & 127;
-      ctl = (e >> 15) & 1;
+      n = (int)(e & 2047);
     }
-    n_steps = ns, walk_bad = bad;
+    n_mile = nm, slow_from = slow, walk_bad = 0;
+    n_steps = slow >= 0 ? -1 : 0;
+  }
+  __syncthreads();
+  if (t < n_mile && t != slow_from) {
+    int n = mile[t], k = 0;
+    for (; k < kStride && lg_node_p(n) < kC; ++k) {
+      visited[kStride * t + k] = (uint16_t)n;
+      n = (int)(s.j1[n] & 2047);
+    }
+    if (t == n_mile - 1) n_steps = kStride * t + k;      // (every earlier milestone has exactly kStride steps)
+  }
+  if (t == 0 && slow_from >= 0) {
+    int n = mile[slow_from], k = kStride * slow_from;
+    while (lg_node_p(n) < kC) {
+      const uint32_t e = s.j1[n];
+      if (e == kBadStep) {
+        walk_bad = 1;
+        break;
+      }
+      visited[k++] = (uint16_t)n;
+      n = (int)(e & 2047);
+    }
+    n_steps = k;
   }
   __syncthreads();
   const int ns = n_steps;                 // <= kC / 2: a step is at least two doubles long
   const bool live = t < ns;
   int p = 0, ctl = 0, a_pos = 0, xmask = 0, dp = 0;
   if (live) {
-    const uint16_t v = visited[t];
-    p = v & 0x7fff, ctl = v >> 15;
-    const uint32_t e = s.step[ctl][p];
-    dp = e & 127, a_pos = p + ((e >> 7) & 63), xmask = (e >> 13) & 3;
+    const int n = visited[t];
+    ctl = n >= kP2 ? 1 : 0, p = n - ctl * kP2;
+    const uint32_t e = s.j1[n];
+    dp = lg_node_p((int)(e & 2047)) - p, a_pos = p + (int)((e >> 24) & 63), xmask = (int)(e >> 30);
   }
+  // the two normals of the step's attempt (the same arithmetic as in lg_build: nothing of it was kept)
+  double gn0 = 0.0, gn1 = 0.0;
+  if (live) lg_normals(s, a_pos, &gn0, &gn1);
   const int nout = __popc(xmask);
   // standard_t: a step SETS the pending numerator when it starts at A and its trial fails (g0), or starts at B and its
   // first trial is accepted (g1 is the next output's numerator)
@@ -309,7 +439,7 @@ __global__ void __launch_bounds__(256) lg_emit_kernel(const uint32_t* __restrict
     if (lane >= off) incl += u, sidx = max(sidx, w);
   }
   if (lane == 63) wave_cnt[wv] = incl, wave_set[wv] = sidx;
-  if (PROG == 1) set_val[t] = sets ? (ctl == kA ? s.g0[a_pos] : s.g1[a_pos]) : 0.0;
+  if (PROG == 1) set_val[t] = sets ? (ctl == kA ? gn0 : gn1) : 0.0;
   __syncthreads();
   int before = 0;
   for (int w = 0; w < wv; ++w) before += wave_cnt[w], sidx = max(sidx, wave_set[w]);
@@ -328,8 +458,8 @@ __global__ void __launch_bounds__(256) lg_emit_kernel(const uint32_t* __restrict
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (!(xmask & (1 << k))) continue;
-      const double X = k ? s.g1[a_pos] : s.g0[a_pos];
-      if (PROG == 1 && ctl == kA) num = s.g0[a_pos];
+      const double X = k ? gn1 : gn0;
+      if (PROG == 1 && ctl == kA) num = gn0;
       if (o < a.n_out) {
         if (inherited) {
           a.pend_x[blockIdx.x] = X, a.pend_o[blockIdx.x] = o;
@@ -338,7 +468,7 @@ __global__ void __launch_bounds__(256) lg_emit_kernel(const uint32_t* __restrict
         }
         if (o == a.n_out - 1) {           // the request ends here: U of this trial consumed; g1 cached if the trial used g0
           const int64_t base = (int64_t)blockIdx.x * kC;
-          double cached = s.g1[a_pos];
+          double cached = gn1;
           a.end[0] = k == 0 ? base + a_pos + 3 : base + p + dp;
           a.end[1] = k == 0 ? 1 : 0;
           memcpy(&a.end[2], &cached, sizeof cached);
@@ -436,10 +566,10 @@ int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* p
   else
     hipLaunchKernelGGL(lg_summary_kernel<1>, dim3((unsigned)n_chunks), dim3(256), 0, st, lw.words, have_dbl, par, logtab, sum(0));
   for (int l = 0; l < levels; ++l)
-    hipLaunchKernelGGL(lg_compose_kernel, dim3((unsigned)cnt[l + 1]), dim3(kNodes), 0, st, (const uint64_t*)sum(l), cnt[l], sum(l + 1));
+    hipLaunchKernelGGL(lg_compose_kernel, dim3((unsigned)cnt[l + 1]), dim3(256), 0, st, (const uint64_t*)sum(l), cnt[l], sum(l + 1));
   hipLaunchKernelGGL(lg_seed_kernel, dim3(1), dim3(1), 0, st, entry(levels), first(levels), prog == 1 ? (kA << 6) : (kB << 6));
   for (int l = levels; l > 0; --l)
-    hipLaunchKernelGGL(lg_expand_kernel, dim3((unsigned)cnt[l]), dim3(kNodes), 0, st, (const uint64_t*)sum(l - 1), cnt[l - 1],
+    hipLaunchKernelGGL(lg_expand_kernel, dim3((unsigned)cnt[l]), dim3(256), 0, st, (const uint64_t*)sum(l - 1), cnt[l - 1],
                        (const uint8_t*)entry(l), (const int64_t*)first(l), entry(l - 1), first(l - 1), n);
   EmitOut a;
   a.dst = dst, a.ld = ld, a.d = d, a.row_begin = row_begin, a.rows = rows;
