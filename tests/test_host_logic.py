@@ -375,3 +375,23 @@ def test_mt19937_jump_table_against_numpy():
         st = rs.get_state()
         assert st[2] == mj.N
         assert mj.jump_by_correlation(b1, g) == [int(x) for x in mj.refresh(st[1])]
+
+
+def test_dptr_call_sites_pass_names():
+    """``_lib._dptr`` returns a bare address (ctypes ``c_void_p``): the array behind it must outlive the call, so every
+    call site passes a plain local name -- never a temporary such as ``_dptr(_f64(x))`` or ``_dptr(a[1:].copy())``, which
+    would be freed before the C function reads it."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'viabel_amd')
+    bad = []
+    for name in sorted(os.listdir(root)):
+        if not name.endswith('.py'):
+            continue
+        text = open(os.path.join(root, name)).read()
+        for m in re.finditer(r'_dptr\(([^()]*(?:\([^()]*\))?[^()]*)\)', text):
+            arg = m.group(1).strip()
+            if name == '_lib.py' and arg == 'a':          # the definition itself
+                continue
+            if not re.fullmatch(r'[A-Za-z_][A-Za-z_0-9]*', arg):
+                bad.append((name, arg))
+    assert not bad, bad

@@ -248,9 +248,16 @@ def load():
         return lib
 
 
+_DPTR_CHECKS = bool(os.environ.get('VIABEL_AMD_CHECK_POINTERS'))
+
+
 def _dptr(a):
     """Address of a contiguous float64 array (the caller keeps the array alive across the call: every call site
-    passes a local name, never a temporary)."""
+    passes a local NAME, never a temporary -- ``tests/test_host_logic.py::test_dptr_call_sites_pass_names`` enforces it,
+    and ``VIABEL_AMD_CHECK_POINTERS=1`` checks dtype and contiguity on every call)."""
+    if _DPTR_CHECKS:
+        assert isinstance(a, np.ndarray) and a.flags.c_contiguous and a.dtype in (np.float64, np.int64, np.int32), \
+            'C-ABI array argument must be a contiguous float64 / int array'
     return a.__array_interface__['data'][0]
 
 

@@ -825,6 +825,11 @@ int vb_psis_smooth(vb_ctx* ctx, const double* lw_in, int64_t n, double reff, dou
   VB_HIP(ctx, hipMemcpyAsync(lw_out, lw, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   VB_HIP(ctx, hipMemcpyAsync(res, lw + round_up(n, 16), sizeof res, hipMemcpyDeviceToHost, ctx->stream));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // (the multi-workgroup kernel poisons its results with NaN when a workgroup did not reach a grid barrier within the
+  // poll bound: k-hat and the tail count both NaN)
+  if (res[0] != res[0] && res[1] != res[1])
+    return fail(ctx, VB_ERR_STATE, "PSIS: a workgroup of the smoothing kernel did not arrive at a grid barrier (results invalid); "
+                                   "VB_PSIS_GRID=0 selects the single-workgroup kernel");
 #ifdef VB_PSIS_CLOCK
   {
     double dbg[16];

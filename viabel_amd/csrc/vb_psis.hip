@@ -968,7 +968,7 @@ __global__ void __launch_bounds__(kPsisThreads) psis_grid_kernel(double* __restr
   PG_MARK();
   if (g == 0 && t == 0) {
     out[0] = poisoned ? NAN : k;
-    out[1] = (double)tail_count;
+    out[1] = poisoned ? NAN : (double)tail_count;      // (k-hat AND the tail count NaN: the poison's signature)
     out[2] = xcutoff;
     out[3] = sigma;
 #ifdef VB_PSIS_DEBUG
@@ -1021,7 +1021,20 @@ int psis_enqueue(vb_ctx* ctx, int64_t n, double reff) {
   int wgs = (int)((n + kPsisThreads - 1) / kPsisThreads);
   wgs = wgs > kPgMaxWg ? kPgMaxWg : wgs;
   const int per_thread = (int)((n + (int64_t)wgs * kPsisThreads - 1) / ((int64_t)wgs * kPsisThreads));
-  if (grid_env && wgs > 1 && per_thread <= kPgRegs && wgs <= ctx->prop.multiProcessorCount) {
+  // The grid barrier needs every workgroup of the launch resident at once: ask the runtime how many of these 1024-thread,
+  // ~115 KB-LDS workgroups one CU takes (once per context and variant) and keep to the single-workgroup kernel when the
+  // grid would not fit -- other streams' work or another process can still delay residency, which the bounded polls turn
+  // into a poisoned (NaN) result and vb_psis_smooth into VB_ERR_STATE, not into a hang.
+  static int per_cu[3] = {-1, -1, -1};
+  const int variant = per_thread == 1 ? 0 : (per_thread == 2 ? 1 : 2);
+  if (grid_env && wgs > 1 && per_thread <= kPgRegs && per_cu[variant] < 0) {
+    int nb = 0;
+    hipError_t e = variant == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psis_grid_kernel<1>, kPsisThreads, 0)
+                   : variant == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psis_grid_kernel<2>, kPsisThreads, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, psis_grid_kernel<4>, kPsisThreads, 0);
+    per_cu[variant] = e == hipSuccess ? nb : 0;
+  }
+  if (grid_env && wgs > 1 && per_thread <= kPgRegs && (int64_t)wgs <= (int64_t)per_cu[variant] * ctx->prop.multiProcessorCount) {
     if (!ctx->psis_work.ptr) {
       VB_TRY(ensure(ctx, ctx->psis_work, kPgBytes));
       VB_HIP(ctx, hipMemsetAsync(ctx->psis_work.ptr, 0, 64, ctx->stream));        // barrier counter, poison
