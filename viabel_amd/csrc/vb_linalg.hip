@@ -80,16 +80,23 @@ int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* r
   // All traffic goes through the pinned buffer: pageable hipMemcpy on this stack occasionally stalls in 10-ms
   // quanta, which would dwarf the ~2 ms of GEMMs; the reducing epilogues write their partials straight into it.
   VB_TRY(ensure(ctx, ctx->scratch, (size_t)(6 * mat) * sizeof(double)));
-  VB_TRY(ensure_pinned(ctx, (size_t)(mat + round_up(n_part, 16)) * sizeof(double)));
+  constexpr int kMaxSteps = 100;
+  const int64_t pstride = round_up(n_part, 16);      // residual slots behind the staging matrix: one per step + the check's
+  VB_TRY(ensure_pinned(ctx, (size_t)(mat + (int64_t)(kMaxSteps + 2) * pstride) * sizeof(double)));
   double* base = (double*)ctx->scratch.ptr;
   double *Y[2] = {base, base + mat}, *Z[2] = {base + 2 * mat, base + 3 * mat}, *T = base + 4 * mat,
          *M0 = base + 5 * mat;
-  double *h = ctx->pin_host, *hp = ctx->pin_host + mat, *part = ctx->pin_dev + mat;
+  double* h = ctx->pin_host;
   hipStream_t st = ctx->stream;
 
+  // scale: the infinity norm max_i sum_j |a_ij| >= lambda_max (round 5; rounds 2-4 used the Frobenius norm, which leaves a
+  // well-conditioned spectrum at ~1 / sqrt(d) of the unit interval and costs the iteration five or six linear steps)
   double fro = 0.0, fro_e = 0.0;
-  for (int64_t i = 0; i < d * d; ++i) fro += a[i] * a[i];
-  fro = sqrt(fro);
+  for (int64_t i = 0; i < d; ++i) {
+    double r = 0.0;
+    for (int64_t j = 0; j < d; ++j) r += fabs(a[i * d + j]);
+    if (r > fro || !(r == r)) fro = r;
+  }
   if (!(fro > 0.0) || !std::isfinite(fro)) return fail(ctx, VB_ERR_NUMERIC, "matrix square root: zero or non-finite matrix");
   if (e) {
     for (int64_t i = 0; i < d * d; ++i) fro_e += e[i] * e[i];
@@ -116,40 +123,49 @@ int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* r
   VB_HIP(ctx, hipMemcpyAsync(Y[0], h, (size_t)mat * sizeof(double), hipMemcpyHostToDevice, st));
   VB_HIP(ctx, hipMemcpyAsync(M0, h, (size_t)mat * sizeof(double), hipMemcpyHostToDevice, st));
 
-  auto zero_part = [&]() {
-    for (int64_t i = 0; i < n_part; ++i) hp[i] = 0.0;
-  };
-  auto read_part = [&](double* out) -> int {
-    VB_HIP(ctx, hipStreamSynchronize(st));
+  // residual slots: one per step (the epilogue of step k's first GEMM adds into slot k), read a GROUP of steps at a time
+  double* hp_base = ctx->pin_host + mat;
+  double* part_base = ctx->pin_dev + mat;
+  for (int64_t i = 0; i < (kMaxSteps + 2) * pstride; ++i) hp_base[i] = 0.0;
+  auto residual = [&](int slot) {
     double s = 0.0;
+    const double* hp = hp_base + (int64_t)slot * pstride;
     for (int64_t i = 0; i < n_part; ++i) s += hp[i];
-    *out = sqrt(s);
-    return VB_OK;
+    return sqrt(s);
   };
 
   int cur = 0, it = 0;
   double res = 0.0, prev = 1e300;
   const double floor_tol = 4e-16 * (double)m;
-  for (it = 0; it < 100; ++it) {
-    zero_part();   // the stream is idle here (read_part synchronised) or has only copies in flight
-    gemm_f64_launch<true>(st, square(Z[cur], Y[cur], ld, m), 1, n_cu, EpiNsT{T, ld, part});
+  bool converged = false;
+  int stop_at = kMaxSteps + 1;      // quadratic convergence: two steps after a residual below 1e-4 the iteration is at its floor
+  while (!converged && it < kMaxSteps) {
+    const int group = it == 0 ? 4 : (stop_at <= kMaxSteps ? stop_at - it : 1);
+    for (int k = 0; k < group; ++k) {
+      gemm_f64_launch<true>(st, square(Z[cur], Y[cur], ld, m), 1, n_cu, EpiNsT{T, ld, part_base + (int64_t)(it + k) * pstride});
+      gemm_f64_launch<true>(st, square(Y[cur], T, ld, m), 1, n_cu, EpiStore{Y[cur ^ 1], ld});
+      gemm_f64_launch<true>(st, square(T, Z[cur], ld, m), 1, n_cu, EpiStore{Z[cur ^ 1], ld});
+      cur ^= 1;
+    }
     VB_HIP(ctx, hipGetLastError());
-    VB_TRY(read_part(&res));
-    if (!std::isfinite(res)) return fail(ctx, VB_ERR_NUMERIC, "matrix square root: iteration diverged");
-    // converged: the residual is at the rounding floor, or small and no longer contracting
-    if (res < floor_tol || (res < 1e-7 && res > 0.5 * prev)) break;
-    prev = res;
-    gemm_f64_launch<true>(st, square(Y[cur], T, ld, m), 1, n_cu, EpiStore{Y[cur ^ 1], ld});
-    gemm_f64_launch<true>(st, square(T, Z[cur], ld, m), 1, n_cu, EpiStore{Z[cur ^ 1], ld});
-    VB_HIP(ctx, hipGetLastError());
-    cur ^= 1;
+    VB_HIP(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < group && !converged; ++k) {
+      res = residual(it + k);
+      if (!std::isfinite(res)) return fail(ctx, VB_ERR_NUMERIC, "matrix square root: iteration diverged");
+      if (res < floor_tol || (res < 1e-7 && res > 0.5 * prev)) converged = true;
+      if (res < 1e-4 && stop_at > kMaxSteps) stop_at = it + k + 2;
+      prev = res;
+    }
+    it += group;
+    if (it >= stop_at) converged = true;
   }
-  // accuracy of the leading block: ||Y Y - A / c||_F relative to ||A / c||_F = 1
+  // accuracy of the leading block: ||Y Y - A / c||_F (||A / c||_2 <= 1)
   double acc = 0.0;
-  zero_part();
-  gemm_f64_launch<true>(st, square(Y[cur], Y[cur], ld, m), 1, n_cu, EpiResidual{M0, ld, (int)d, part});
+  gemm_f64_launch<true>(st, square(Y[cur], Y[cur], ld, m), 1, n_cu,
+                        EpiResidual{M0, ld, (int)d, part_base + (int64_t)kMaxSteps * pstride});
   VB_HIP(ctx, hipGetLastError());
-  VB_TRY(read_part(&acc));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  acc = residual(kMaxSteps);
 
   VB_HIP(ctx, hipMemcpyAsync(h, Y[cur], (size_t)mat * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipStreamSynchronize(st));
