@@ -243,6 +243,14 @@ int main(int argc, char** argv) {
     const int splits = argc > 7 ? atoi(argv[7]) : 1;
     GemmArgs g;
     g.A = A, g.B = B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = mode == 't' ? 1 : 0;
+#ifdef VB_GEMM_CLOCK
+    if (getenv("GEMM_BN_MIN")) g.dbg_bn_min = atoi(getenv("GEMM_BN_MIN"));
+    if (getenv("GEMM_BN_MAX")) g.dbg_bn_max = atoi(getenv("GEMM_BN_MAX"));
+    if (getenv("GEMM_PRIO_SLABS")) g.dbg_prio_slabs = atoi(getenv("GEMM_PRIO_SLABS"));
+    if (g.dbg_prio_slabs) printf("PROBE: wave priority 3 for tiles of %s %d k slabs\n", g.dbg_prio_slabs > 0 ? "at most" : "more than", abs(g.dbg_prio_slabs));
+    if (g.dbg_bn_min > 0 || g.dbg_bn_max < (1 << 30))
+      printf("PROBE: only the column blocks %d .. %d of the triangle do work (the others leave at once)\n", g.dbg_bn_min, g.dbg_bn_max);
+#endif
     float ms;
     long nb_mode = 0;
     int slabs_per_wg = K / 16;

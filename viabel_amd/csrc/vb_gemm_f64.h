@@ -67,6 +67,12 @@ struct GemmArgs {
   int prio_div = 0;
   // optional start / stop events of the launch (hipExtLaunchKernel: the kernel's own begin / end timestamps)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+#ifdef VB_GEMM_CLOCK
+  // probe builds only (tools/gemm_bench.hip): tri_mode 1 tiles whose column block lies outside [dbg_bn_min, dbg_bn_max]
+  // leave at once -- "what does the heavy half of the triangle cost alone?"
+  int dbg_bn_min = 0, dbg_bn_max = 1 << 30;
+  int dbg_prio_slabs = 0;      // > 0: tiles of at most that many k slabs run at wave priority 3; < 0: tiles of more than -that many
+#endif
 };
 
 // Epilogue functor interface:  void operator()(int split, int row, int col, double acc) const;

@@ -88,6 +88,9 @@ __device__ __forceinline__ void gemm_f64_dma_tile(const GemmArgs& g, const Epi& 
     bn = idx < half ? g.tiles_n - 1 - idx : idx - half;
     if (g.tri_mode == 3) bn = g.tiles_n - 1 - bn;      // mirrored triangle: column block 0 has the longest k range
     bm = bx % g.tiles_m;
+#ifdef VB_GEMM_CLOCK
+    if (bn < g.dbg_bn_min || bn > g.dbg_bn_max) return;
+#endif
   } else {
     bn = bx / g.tiles_m;
     bm = bx % g.tiles_m;
@@ -338,6 +341,10 @@ __device__ __forceinline__ void gemm_f64_dma_tile(const GemmArgs& g, const Epi& 
     // wave priority slab by slab, in opposite phase for the two generations of workgroups, lets them progress at
     // the same pace and finish together.
     const int prio_phase = g.prio_div > 0 ? (int)((bx + gx * bz) / (unsigned)g.prio_div) & 1 : -1;
+#ifdef VB_GEMM_CLOCK
+    if (g.dbg_prio_slabs > 0 && nslabs <= g.dbg_prio_slabs) __builtin_amdgcn_s_setprio(3);
+    if (g.dbg_prio_slabs < 0 && nslabs > -g.dbg_prio_slabs) __builtin_amdgcn_s_setprio(3);
+#endif
     for (int s = 0; s < nslabs; ++s) {
       if (prio_phase >= 0) {
         if ((s ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(1);
