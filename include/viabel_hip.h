@@ -252,6 +252,16 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        const double* chi, const double* sqrt_sigma, const double* l_inv,
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q);
+/* ExclusiveKL (entropy form, objectives.py:154-164) of the multivariate t in the reference-identical mode, resident on the
+ * device (one rank): noise slot and the context's chi-square draws hold numpy's streams (vb_legacy_rng_chisquare_device,
+ * then vb_legacy_rng_randn_device -- approximations.py:345-347), the samples go through the SYMMETRIC root of Sigma = L L'
+ * (:348) and the gradient through the root's Frechet derivative (the Sylvester equation R X + X R = sym(C) / N), both by
+ * Newton-Schulz iterations on the device; value and the gradient in the flat [mu | free Cholesky] layout come back after
+ * one copy.  info (4 doubles, may be NULL) = [root steps, root accuracy, derivative steps, its accuracy].
+ * VB_ERR_UNSUPPORTED: an iteration did not resolve to 1e-12 -- use vb_elbo_sums_mvt with a host-side root.            */
+int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
+                             double* grad, double* info);
+
 /* The reference-identical step resident on the device (one rank): as vb_dis_refresh_mvt with chi, sqrt_sigma, l_inv and
  * w NULL -- factors from theta on the device, chi-square draws from the context's buffer (vb_legacy_rng_chisquare_device
  * for numpy's stream), nothing copied back -- but the samples go through the SYMMETRIC root of Sigma = L L'

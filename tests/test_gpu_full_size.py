@@ -232,3 +232,48 @@ def test_c4_logistic_raabbvi_runs_full_size(vb, capsys):
     capsys.readouterr()
     v1, _ = objective(results['opt_param'])
     assert np.isfinite(v1) and v1 < v0, (v0, v1)
+
+
+@pytest.mark.parametrize('target', ['gauss_diag', 'funnel', 'gauss_full'])
+def test_multivariate_t_exclusive_kl_reference_mode_resident(vb, target):
+    """MultivariateT(256) + ExclusiveKL with the DEFAULT rng='numpy' at N = 16 384: the reference's chi-square and normal
+    streams generated on the device, its symmetric root (approximations.py:348) and the root's Frechet derivative by
+    device iterations, the chain rule to the free Cholesky parameters on the device (vb_elbo_grad_mvt_symroot) -- against
+    the oracle's eigen-decomposition route on numpy's own draws, and against the host-root route it replaces."""
+    import os
+    from viabel_amd import objectives as vobj
+    D, N, df = 256, 16384, 9.0
+    rng = np.random.RandomState(41)
+    if target == 'gauss_diag':
+        mean, sd = 0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D))
+        model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    elif target == 'funnel':
+        model, omodel = vb.FunnelModel(D, D // 2), omod.Funnel(D, D // 2)
+    else:
+        A = rng.randn(D, D)
+        S = A @ A.T / D + np.eye(D)
+        mean = rng.randn(D)
+        model, omodel = vb.CorrelatedGaussianModel(mean, covariance=S), omod.GaussFull(mean, np.linalg.inv(S))
+    B = rng.randn(D, D)
+    theta = np.concatenate([0.2 * rng.randn(D), ofam.psd_to_free(0.05 * (B @ B.T / D + 0.5 * np.eye(D)))])
+    approx = vb.MultivariateT(D, df, seed=6)
+    obj = vb.ExclusiveKL(approx, model, N)
+    ref = np.random.RandomState(6)
+    for call in range(2):
+        value, grad = obj(theta)
+        noise = ofam.MultivariateT(D, df).draw_noise(ref, N)
+        ov, og = oobj.exclusive_kl(ofam.MultivariateT(D, df), omodel, theta, noise, False)
+        assert abs(value - ov) <= 1e-11 * abs(ov), (call, value, ov)
+        np.testing.assert_allclose(grad, og, rtol=0, atol=1e-9 * np.max(np.abs(og)))
+    # the host-root route on the same draws (the resident path switched off through its dimension gate)
+    keep = vobj._HOST_ROOT_MAX_DIM
+    try:
+        vobj._HOST_ROOT_MAX_DIM = 10 ** 6
+        approx2 = vb.MultivariateT(D, df, seed=6)
+        v2, g2 = vb.ExclusiveKL(approx2, model, N)(theta)
+    finally:
+        vobj._HOST_ROOT_MAX_DIM = keep
+    approx3 = vb.MultivariateT(D, df, seed=6)
+    v3, g3 = vb.ExclusiveKL(approx3, model, N)(theta)
+    assert abs(v3 - v2) <= 1e-11 * abs(v2)
+    np.testing.assert_allclose(g3, g2, rtol=0, atol=1e-9 * np.max(np.abs(g2)))

@@ -206,3 +206,24 @@ def test_multivariate_t_sequence_all_on_the_device(env):
         np.testing.assert_array_equal(chi, ref.chisquare(df, N))
         np.testing.assert_array_equal(eng.noise_get_host(4, N, D), ref.randn(N, D))
         _same_state(approx._rs, ref)
+
+
+def test_device_gamma_budget_short_falls_back_without_touching_the_generator(env, monkeypatch):
+    """How much of the stream a draw consumes is random; the device path generates a budget of words (mean + 14 sigma)
+    and declines -- generator untouched, nothing written that matters -- when the walk falls off its end before the
+    request is complete.  Forced here with a budget cut to 60 %: the family then draws on the host, same values."""
+    _need_log(env)
+    vb, eng, LegacyRandomState = env
+    import os
+    ours, ref = LegacyRandomState(31), np.random.RandomState(31)
+    monkeypatch.setenv('VB_LEGACY_BUDGET_SCALE', '0.6')
+    assert not eng.noise_legacy_standard_t(5, ours._h, 7.0, 600, 500)
+    assert eng.chisq_legacy(ours._h, 9.0, 20000) is None
+    _same_state(ours, ref)
+    approx = vb.MFStudentT(512, 7, seed=31)
+    approx._stage_base_noise(eng, 5, 300, 0, 300)            # the family's staging: device declines, host draws
+    np.testing.assert_array_equal(eng.noise_get_host(5, 300, 512), np.random.RandomState(31).standard_t(7, (300, 512)))
+    monkeypatch.delenv('VB_LEGACY_BUDGET_SCALE')
+    assert eng.noise_legacy_standard_t(5, ours._h, 7.0, 600, 500)
+    np.testing.assert_array_equal(eng.noise_get_host(5, 600, 500), ref.standard_t(7.0, (600, 500)))
+    _same_state(ours, ref)

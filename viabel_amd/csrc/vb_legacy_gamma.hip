@@ -527,7 +527,9 @@ int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* p
   par.scale = std::sqrt(df / 2);
   // doubles per output: a polar attempt is accepted with probability pi / 4 and yields two normals; a Marsaglia-Tsang
   // trial is accepted with probability >= 0.95 for shape >= 1 and costs a normal and a uniform
-  const double per_out = prog == 1 ? 3.72 : 2.44;
+  // (VB_LEGACY_BUDGET_SCALE < 1: tests force the "budget fell short" way out -- VB_ERR_UNSUPPORTED, generator untouched)
+  const char* scale_env = getenv("VB_LEGACY_BUDGET_SCALE");
+  const double per_out = (prog == 1 ? 3.72 : 2.44) * (scale_env ? atof(scale_env) : 1.0);
   const int64_t n_dbl = (int64_t)(per_out * (double)n + 14.0 * std::sqrt(4.0 * (double)n)) + 4 * kL;
   const int64_t n_chunks = (n_dbl + kC - 1) / kC;
   // levels of the summary tree: level 0 = chunks

@@ -253,31 +253,18 @@ __global__ void __launch_bounds__(256) ns_finish_kernel(const double* __restrict
 
 }  // namespace
 
-// root (d x ld, device) = (Lfull Lt)^(1/2), Lfull = L (row-major, row stride ld = round_up(d, 16)), Lt = L'.
-// info (host) = [steps, last residual ||I - Z Y||_F, ||R R - Sigma||_F / c].  VB_ERR_UNSUPPORTED: not converged to `tol`.
-int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, int64_t ld, double* root, double tol,
-                 double* info) {
-  const int m = (int)d;
-  if (ld != round_up(d, 16)) return fail(ctx, VB_ERR_INVALID, "sym_sqrt_dev: row stride");
+// The coupled Newton-Schulz iteration on an m x m problem whose start (Y = M / c in set[0], Z = I in set[0] + 2 mat) and
+// reference M0 = M / c are on the device (m x ld, ld = round_up(m, 16)).  Returns the set holding the result in *cur_out;
+// info = [steps, last residual, ||Y Y - M0||_F over the leading d_check x d_check block].  VB_ERR_UNSUPPORTED: no
+// convergence.  Pinned partial-sum ring: the caller has called ensure_pinned for (kNsMaxSteps + 2) * n_part doubles.
+constexpr int kNsMaxSteps = 40;
+static int ns_run(vb_ctx* ctx, int m, int64_t ld, double* set0, double* set1, const double* M0, int d_check, int* cur_out,
+                  double* info) {
   const int64_t mat = (int64_t)m * ld;
   const int n_cu = ctx->prop.multiProcessorCount;
   const int64_t n_part = round_up(gemm_max_blocks(m, m), 16);
-  constexpr int kMaxSteps = 40;
-  // device: set p = [Y_p | T_p | Z_p] (p = 0, 1), A / c, one scalar line
-  VB_TRY(ensure(ctx, ctx->scratch, (size_t)(7 * mat + 16) * sizeof(double)));
-  VB_TRY(ensure_pinned(ctx, (size_t)((kMaxSteps + 2) * n_part) * sizeof(double)));
-  double* base = (double*)ctx->scratch.ptr;
-  double* set[2] = {base, base + 3 * mat};
-  double *M0 = base + 6 * mat, *scal = base + 7 * mat;
   hipStream_t st = ctx->stream;
-  VB_HIP(ctx, hipStreamSynchronize(st));      // earlier users of the pinned partials are done
-  memset(ctx->pin_host, 0, (size_t)((kMaxSteps + 2) * n_part) * sizeof(double));
-  VB_HIP(ctx, hipMemsetAsync(scal, 0, sizeof(double), st));
-  gemm_f64_launch<true>(st, square(Lfull, Lt, ld, m), 1, n_cu, EpiStore{M0, ld});
-  hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, (const double*)M0, m, ld, scal);
-  hipLaunchKernelGGL(ns_scale_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, M0, m, ld, set[0],
-                     set[0] + 2 * mat, (const double*)scal);
-  VB_HIP(ctx, hipGetLastError());
+  double* set[2] = {set0, set1};
   auto residual = [&](int slot) {
     double s = 0.0;
     const double* hp = ctx->pin_host + (int64_t)slot * n_part;
@@ -291,9 +278,9 @@ int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, 
   // The iteration is quadratic: a residual below 1e-4 BEFORE step k is ~1e-8 after it and at the rounding floor after
   // step k + 1 -- so once such a residual has been read, two steps from there finish the job (the accuracy check at the
   // end is the safety net), and the floor itself need not be observed.
-  int stop_at = kMaxSteps + 1;      // steps to apply in all (known once a small residual has been seen)
-  while (!converged && done < kMaxSteps) {
-    const int group = done == 0 ? 4 : (stop_at <= kMaxSteps ? stop_at - done : 1);
+  int stop_at = kNsMaxSteps + 1;      // steps to apply in all (known once a small residual has been seen)
+  while (!converged && done < kNsMaxSteps) {
+    const int group = done == 0 ? 4 : (stop_at <= kNsMaxSteps ? stop_at - done : 1);
     for (int k = 0; k < group; ++k) {
       double *Y = set[cur], *T = Y + mat, *Z = Y + 2 * mat;
       // T = (3 I - Z Y) / 2 with ||I - Z Y||_F^2 of the state BEFORE this step into partial slot `done + k`
@@ -310,22 +297,149 @@ int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, 
       res = residual(done + k);
       if (!std::isfinite(res)) return VB_ERR_UNSUPPORTED;
       if (res < floor_tol || (res < 1e-7 && res > 0.5 * prev)) converged = true;      // (later steps of the group: harmless)
-      if (res < 1e-4 && stop_at > kMaxSteps) stop_at = done + k + 2;
+      if (res < 1e-4 && stop_at > kNsMaxSteps) stop_at = done + k + 2;
       prev = res;
     }
     done += group;
     if (done >= stop_at) converged = true;
   }
   if (!converged) return VB_ERR_UNSUPPORTED;
-  // accuracy of the result: ||Y Y - Sigma / c||_F (||Sigma / c||_2 <= 1), and the root itself
   double* Y = set[cur];
-  gemm_f64_launch<true>(st, square(Y, Y, ld, m), 1, n_cu, EpiResidual{M0, ld, m, ctx->pin_dev + (int64_t)kMaxSteps * n_part});
-  hipLaunchKernelGGL(ns_finish_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, (const double*)Y, m, ld,
-                     (const double*)scal, root);
+  gemm_f64_launch<true>(st, square(Y, Y, ld, m), 1, n_cu, EpiResidual{M0, ld, d_check, ctx->pin_dev + (int64_t)kNsMaxSteps * n_part});
+  VB_HIP(ctx, hipGetLastError());
+  *cur_out = cur;
+  info[0] = (double)done, info[1] = res, info[2] = -1.0;      // [2]: read by the caller after its own last launch + sync
+  return VB_OK;
+}
+
+// root (d x ld, device) = (Lfull Lt)^(1/2), Lfull = L (row-major, row stride ld = round_up(d, 16)), Lt = L'.
+// info (host) = [steps, last residual ||I - Z Y||_F, ||R R - Sigma||_F / c].  VB_ERR_UNSUPPORTED: not converged to `tol`.
+int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, int64_t ld, double* root, double tol,
+                 double* info) {
+  const int m = (int)d;
+  if (ld != round_up(d, 16)) return fail(ctx, VB_ERR_INVALID, "sym_sqrt_dev: row stride");
+  const int64_t mat = (int64_t)m * ld;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int64_t n_part = round_up(gemm_max_blocks(m, m), 16);
+  // device: set p = [Y_p | T_p | Z_p] (p = 0, 1), A / c, one scalar line
+  VB_TRY(ensure(ctx, ctx->scratch, (size_t)(7 * mat + 16) * sizeof(double)));
+  VB_TRY(ensure_pinned(ctx, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double)));
+  double* base = (double*)ctx->scratch.ptr;
+  double *M0 = base + 6 * mat, *scal = base + 7 * mat;
+  hipStream_t st = ctx->stream;
+  VB_HIP(ctx, hipStreamSynchronize(st));      // earlier users of the pinned partials are done
+  memset(ctx->pin_host, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double));
+  VB_HIP(ctx, hipMemsetAsync(scal, 0, sizeof(double), st));
+  gemm_f64_launch<true>(st, square(Lfull, Lt, ld, m), 1, n_cu, EpiStore{M0, ld});
+  hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, (const double*)M0, m, ld, scal);
+  hipLaunchKernelGGL(ns_scale_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, M0, m, ld, base,
+                     base + 2 * mat, (const double*)scal);
+  VB_HIP(ctx, hipGetLastError());
+  int cur = 0;
+  double loc[3];
+  VB_TRY(ns_run(ctx, m, ld, base, base + 3 * mat, M0, m, &cur, loc));
+  hipLaunchKernelGGL(ns_finish_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + (int64_t)cur * 3 * mat), m, ld, (const double*)scal, root);
   VB_HIP(ctx, hipGetLastError());
   VB_HIP(ctx, hipStreamSynchronize(st));
-  const double acc = residual(kMaxSteps);
-  if (info) info[0] = (double)done, info[1] = res, info[2] = acc;
+  double acc = 0.0;
+  for (int64_t i = 0; i < n_part; ++i) acc += ctx->pin_host[(int64_t)kNsMaxSteps * n_part + i];
+  acc = sqrt(acc);
+  if (info) info[0] = loc[0], info[1] = loc[1], info[2] = acc;
+  if (!(acc < tol)) return VB_ERR_UNSUPPORTED;
+  return VB_OK;
+}
+
+// ---- the root's Frechet derivative on the device: X with R X + X R = E, R = (L L')^(1/2) ---------------------------------
+// (MultivariateT under ExclusiveKL in the reference-identical mode: the gradient flows through sqrtm, objectives.py:154-164
+// over approximations.py:348).  The same iteration on the block matrix [[Sigma, es E], [0, Sigma]] / c, whose root is
+// [[R, es X], [0, R]] / sqrt(c); es scales the off-diagonal block to a tenth of the diagonal blocks' norm.
+namespace {
+
+// scal[1] += sum of squares of the leading d x d block of E (one workgroup)
+__global__ void __launch_bounds__(1024) ns_sumsq_kernel(const double* __restrict__ E, int d, int64_t ld, double* __restrict__ scal) {
+  __shared__ double sh[16];
+  double s = 0.0;
+  for (int64_t k = threadIdx.x; k < (int64_t)d * d; k += 1024) {
+    const double v = E[(k / d) * ld + (k % d)];
+    s += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    scal[1] = t;
+  }
+}
+
+// Y = M0 = [[A, es E], [0, A]] / c, Z = I on the 2 d x ld2 block layout; A = Sigma (d x ld), c = scal[0], es = 0.1 c / ||E||_F
+__global__ void __launch_bounds__(256) ns_block_init_kernel(const double* __restrict__ A, const double* __restrict__ E, int d,
+                                                            int64_t ld, int64_t ld2, double* __restrict__ Y, double* __restrict__ Z,
+                                                            double* __restrict__ M0, double* __restrict__ scal) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int m = 2 * d;
+  if (k >= (int64_t)m * ld2) return;
+  const int i = (int)(k / ld2), j = (int)(k - (int64_t)i * ld2);
+  const double c = scal[0], fe = sqrt(scal[1]);
+  const double es = fe > 0.0 ? 0.1 * c / fe : 0.0;
+  if (k == 0) scal[2] = es;
+  double v = 0.0;
+  if (j < m) {
+    if (i < d && j < d) v = A[(int64_t)i * ld + j] / c;
+    else if (i >= d && j >= d) v = A[(int64_t)(i - d) * ld + (j - d)] / c;
+    else if (i < d && j >= d) v = E[(int64_t)i * ld + (j - d)] * es / c;
+  }
+  Y[k] = v, M0[k] = v;
+  Z[k] = (i == j) ? 1.0 : 0.0;
+}
+
+// X = Y12 sqrt(c) / es on the d x ld layout (pads zero)
+__global__ void __launch_bounds__(256) ns_block_finish_kernel(const double* __restrict__ Y, int d, int64_t ld, int64_t ld2,
+                                                              const double* __restrict__ scal, double* __restrict__ X) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)d * ld) return;
+  const int i = (int)(k / ld), j = (int)(k - (int64_t)i * ld);
+  const double es = scal[2];
+  X[k] = (j < d && es > 0.0) ? Y[(int64_t)i * ld2 + (j + d)] * sqrt(scal[0]) / es : 0.0;
+}
+
+}  // namespace
+
+int sym_sqrt_frechet_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, const double* E, int64_t d, int64_t ld, double* X,
+                         double tol, double* info) {
+  const int m = (int)(2 * d);
+  if (ld != round_up(d, 16)) return fail(ctx, VB_ERR_INVALID, "sym_sqrt_frechet_dev: row stride");
+  const int64_t ld2 = round_up(m, 16), mat = (int64_t)m * ld2, small = d * ld;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int64_t n_part = round_up(gemm_max_blocks(m, m), 16);
+  VB_TRY(ensure(ctx, ctx->scratch, (size_t)(7 * mat + small + 16) * sizeof(double)));
+  VB_TRY(ensure_pinned(ctx, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double)));
+  double* base = (double*)ctx->scratch.ptr;
+  double *M0 = base + 6 * mat, *A = base + 7 * mat, *scal = A + small;
+  hipStream_t st = ctx->stream;
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  memset(ctx->pin_host, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double));
+  VB_HIP(ctx, hipMemsetAsync(scal, 0, 4 * sizeof(double), st));
+  gemm_f64_launch<true>(st, square(Lfull, Lt, ld, (int)d), 1, n_cu, EpiStore{A, ld});
+  hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, st, (const double*)A, (int)d, ld, scal);
+  hipLaunchKernelGGL(ns_sumsq_kernel, dim3(1), dim3(1024), 0, st, E, (int)d, ld, scal);
+  hipLaunchKernelGGL(ns_block_init_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, (const double*)A, E, (int)d, ld, ld2,
+                     base, base + 2 * mat, M0, scal);
+  VB_HIP(ctx, hipGetLastError());
+  int cur = 0;
+  double loc[3];
+  VB_TRY(ns_run(ctx, m, ld2, base, base + 3 * mat, M0, (int)d, &cur, loc));
+  hipLaunchKernelGGL(ns_block_finish_kernel, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + (int64_t)cur * 3 * mat), (int)d, ld, ld2, (const double*)scal, X);
+  VB_HIP(ctx, hipGetLastError());
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  double acc = 0.0;
+  for (int64_t i = 0; i < n_part; ++i) acc += ctx->pin_host[(int64_t)kNsMaxSteps * n_part + i];
+  acc = sqrt(acc);
+  if (info) info[0] = loc[0], info[1] = loc[1], info[2] = acc;
   if (!(acc < tol)) return VB_ERR_UNSUPPORTED;
   return VB_OK;
 }

@@ -1202,6 +1202,94 @@ int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_
   return VB_OK;
 }
 
+// ---- the reference-identical ExclusiveKL of the multivariate t, resident on the device ------------------------------------
+// (objectives.py:154-164 over approximations.py:342-349, rng='numpy', one rank.)  The noise slot and the context's
+// chi-square draws hold numpy's streams (vb_legacy_rng_chisquare_device, _randn_device); mu, L, L' come from theta on the
+// device; the symmetric root R of Sigma = L L' by sym_sqrt_dev; the sample sums F, sum g, C = sum g (z / s)' by the
+// dense-family pipeline; then the chain rule the host used to run in numpy:
+//     Gs = (C + C') / (2 N);   R X + X R = Gs (sym_sqrt_frechet_dev);   dL = tril(2 X L), free (log) diagonal x L_ii, + 1
+//     value = -(F / N + c0 + sum log L_ii),   grad = -[sum g / N | dL]          (the family's entropy drops the df-only terms)
+namespace {
+
+// Gs = (C + C') / (2 N) on the d x ld layout
+__global__ void __launch_bounds__(256) mvt_gs_kernel(const double* __restrict__ C, double* __restrict__ Gs, int d, int64_t ld,
+                                                     double inv_2n) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)d * ld) return;
+  const int i = (int)(idx / ld), j = (int)(idx % ld);
+  Gs[idx] = j < d ? (C[idx] + C[(int64_t)j * ld + i]) * inv_2n : 0.0;
+}
+
+// out = [value | grad]: XL = X L (d x ld), Lfull = L, theta's log-diagonal for the entropy
+__global__ void __launch_bounds__(256) mvt_ekl_pack_kernel(const double* __restrict__ XL, const double* __restrict__ Lfull,
+                                                           const double* __restrict__ theta, int64_t ld, int d,
+                                                           const double* __restrict__ sums, int64_t off_col, double inv_n,
+                                                           double c0, double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0) {      // value: one workgroup adds the log-diagonal in a fixed order
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int j = threadIdx.x; j < d; j += 256) s += theta[d + (int64_t)j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = -((sums[0] * inv_n + c0) + ((sh[0] + sh[1]) + (sh[2] + sh[3])));
+  }
+  if (idx < d) out[1 + idx] = -(sums[off_col + idx] * inv_n);
+  if (idx >= (int64_t)d * d) return;
+  const int i = (int)(idx / d), j = (int)(idx % d);
+  if (j > i) return;
+  double g = 2.0 * XL[(int64_t)i * ld + j];
+  if (i == j) g = g * Lfull[(int64_t)i * ld + i] + 1.0;
+  out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -g;
+}
+
+}  // namespace
+
+// value_grad_host: 1 + d + d (d + 1) / 2 doubles.  VB_ERR_UNSUPPORTED: a root iteration did not resolve (nothing returned).
+int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, const double* theta_host,
+                     double* value_grad_host, double* info) {
+  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "resident ExclusiveKL of the t family: one rank");
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  if (ctx->chi_n != n || ctx->chi_df != df || !ctx->chi_dev.ptr)
+    return fail(ctx, VB_ERR_STATE, "needs %lld device chi-square(%g) draws (vb_legacy_rng_chisquare_device)", (long long)n, df);
+  const MvtLayout L = mvt_layout(ctx, n, n, d);
+  VB_TRY(ensure(ctx, ctx->mvt_state, (size_t)L.total * sizeof(double)));
+  double* base = (double*)ctx->mvt_state.ptr;
+  hipStream_t st = ctx->stream;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int D = (int)d;
+  const int64_t sq = d * L.ld;
+  ctx->mvt_theta.clear();      // (the DIS state of this buffer, if any, is gone)
+  ctx->mvt_n = 0;
+  VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
+  double rinfo[3] = {0.0, 0.0, 0.0};
+  VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, rinfo));
+  hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ctx->chi_dev.ptr,
+                     df, n, base + L.o_invs);
+  FrSums S;
+  VB_TRY(fr_pipeline_enqueue(ctx, ns, n, d, n, nullptr, nullptr, base + L.o_mu, base + L.o_root, base + L.o_invs, &S));
+  hipLaunchKernelGGL(mvt_gs_kernel, dim3((unsigned)((sq + 255) / 256)), dim3(256), 0, st, (const double*)(S.sums + S.off_c),
+                     base + L.o_tscr, D, L.ld, 0.5 / (double)n);
+  VB_HIP(ctx, hipGetLastError());
+  double xinfo[3] = {0.0, 0.0, 0.0};
+  VB_TRY(sym_sqrt_frechet_dev(ctx, base + L.o_lfull, base + L.o_lt, base + L.o_tscr, d, L.ld, base + L.o_sl, 1e-12, xinfo));
+  GemmArgs g;      // X L
+  g.A = base + L.o_sl, g.lda = L.ld, g.B = base + L.o_lfull, g.ldb = L.ld;
+  g.M = D, g.N = D, g.K = D, g.tri_mode = 0;
+  gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{base + L.o_tscr, L.ld});
+  hipLaunchKernelGGL(mvt_ekl_pack_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + L.o_tscr), (const double*)(base + L.o_lfull), (const double*)(base + L.o_theta), L.ld, D,
+                     (const double*)S.sums, S.off_col, 1.0 / (double)n, ctx->model.c0, base + L.o_grad);
+  VB_HIP(ctx, hipGetLastError());
+  const size_t plen = (size_t)(1 + d + d * (d + 1) / 2);
+  VB_HIP(ctx, hipMemcpyAsync(value_grad_host, base + L.o_grad, plen * sizeof(double), hipMemcpyDeviceToHost, st));
+  VB_HIP(ctx, hipStreamSynchronize(st));
+  if (info) info[0] = rinfo[0], info[1] = rinfo[2], info[2] = xinfo[0], info[3] = xinfo[2];
+  return VB_OK;
+}
+
 // AlphaDivergence sums for the multivariate t (see vb_alpha_sums_mvt in the header)
 int mvt_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
                    const double* mu_host, const double* root_host, const double* inv_s_host, double sum_log_diag,

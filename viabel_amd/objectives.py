@@ -527,6 +527,14 @@ class ExclusiveKL(StochasticVariationalObjective):
             else:
                 # chi-square draws first (approximations.py:345-347)
                 chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end)
+                if (not path_deriv and eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
+                        and getattr(approx, '_chi_on_device', False)):
+                    # the whole evaluation resident on the device: both noise streams are there already, the symmetric
+                    # root and its Frechet derivative are device iterations, the chain rule to the free Cholesky
+                    # parameters two more kernels (vb_elbo_grad_mvt_symroot); None: an iteration did not resolve
+                    resident = eng.elbo_grad_mvt_symroot(_NOISE_SLOT, N, D, df, var_param)
+                    if resident is not None:
+                        return resident
             mu, L = approx._unpack(var_param)
             Sigma = L @ L.T
             inv_s = 1.0 / np.sqrt(chi / df)
