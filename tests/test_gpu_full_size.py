@@ -277,3 +277,30 @@ def test_multivariate_t_exclusive_kl_reference_mode_resident(vb, target):
     v3, g3 = vb.ExclusiveKL(approx3, model, N)(theta)
     assert abs(v3 - v2) <= 1e-11 * abs(v2)
     np.testing.assert_allclose(g3, g2, rtol=0, atol=1e-9 * np.max(np.abs(g2)))
+
+
+def test_reference_mode_falls_back_when_the_device_root_does_not_resolve(vb):
+    """A scale matrix beyond the Newton-Schulz iteration's reach (condition number ~1e10: the accuracy check
+    ||R R - Sigma|| / ||Sigma||_inf < 1e-12 fails): vb_elbo_grad_mvt_symroot / vb_dis_refresh_mvt_symroot decline and the
+    objectives take the LAPACK route -- same call, same results as the oracle's eigen-decomposition to the accuracy such
+    a matrix allows."""
+    from viabel_amd import _lib
+    D, N, df = 192, 4096, 9.0           # (N at the threshold from which the chi-square draws are generated on the device)
+    rng = np.random.RandomState(3)
+    Q, _ = np.linalg.qr(rng.randn(D, D))
+    Sigma = (Q * np.logspace(-7, 3, D)) @ Q.T
+    Sigma = 0.5 * (Sigma + Sigma.T)
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(Sigma)])
+    mean, sd = 0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    eng = _lib.default_engine()
+    approx = vb.MultivariateT(D, df, seed=8)
+    value, grad = vb.ExclusiveKL(approx, model, N)(theta)
+    # the resident entry point itself: declines (None), nothing raised
+    approx._stage_base_noise(eng, 9, N, 0, N)
+    eng.set_model(model.device_spec())
+    assert eng.elbo_grad_mvt_symroot(9, N, D, df, theta) is None
+    noise = ofam.MultivariateT(D, df).draw_noise(np.random.RandomState(8), N)
+    ov, og = oobj.exclusive_kl(ofam.MultivariateT(D, df), omodel, theta, noise, False)
+    assert abs(value - ov) <= 1e-7 * abs(ov), (value, ov)
+    assert np.max(np.abs(grad - og)) <= 1e-5 * np.max(np.abs(og))
