@@ -76,7 +76,7 @@ constexpr int kStride = 1 << (kLv - 1);
 // or (t = 1 behind a trial with normal 0) a + 3 -- three (normal, uniform) pairs per attempt.  The first test
 // (U < 1 - 0.0331 X^4, ~97 % of the trials) is decided in the dense pass; the pairs it leaves open go on a list and
 // get their two logarithms from consecutive lanes (a divergent branch would make every wave pay for them).
-constexpr int kSlowCap = 512;             // list capacity (expected ~60 entries; an overflow makes the chunk's steps undefined)
+constexpr int kSlowCap = 512;             // list capacity (expected ~135 entries; an overflow makes the chunk's steps undefined)
 struct ChunkLds {
   double dbl[kL];                         // the chunk's doubles (+ halo)
   uint32_t fl[kL + 2];                    // attempt at (p, p + 1): 1 accepted; 2 / 4: V = 1 + c g > 0 for normal 0 / 1;
@@ -133,10 +133,11 @@ __device__ __forceinline__ uint32_t lg_node_step(const ChunkLds& s, int p, int c
   return (uint32_t)(state * kP2 + q) | (uint32_t)__popc(xmask) << 16 | (uint32_t)(a - p) << 24 | (uint32_t)xmask << 30;
 }
 
-// normals and trial outcomes -> J1 -> J2, J4, J8
-template <int PROG>
-__device__ __forceinline__ int lg_build(ChunkLds& s, const uint32_t* __restrict__ words, int64_t n_dbl, const GammaPar& par,
-                                        const GlibcLogData* __restrict__ logtab) {
+constexpr int kFlStride = 640;            // bytes per chunk of the decision table the summary pass leaves for the emitting pass
+
+// the chunk's doubles into LDS; returns how many of them exist
+__device__ __forceinline__ int lg_load(ChunkLds& s, const uint32_t* __restrict__ words, int64_t n_dbl,
+                                       const GlibcLogData* __restrict__ logtab) {
   const int t = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * kC;
   const int lim = (int)(n_dbl - base < kL ? n_dbl - base : kL);
@@ -155,6 +156,13 @@ __device__ __forceinline__ int lg_build(ChunkLds& s, const uint32_t* __restrict_
     }
     s.dbl[i] = v;
   }
+  return lim;
+}
+
+// normals and trial outcomes of every attempt of the chunk -> s.fl (the transcendental part: done ONCE per chunk, by the
+// summary pass, which hands the flags to the emitting pass through `fl_out`)
+__device__ __forceinline__ void lg_decide(ChunkLds& s, int lim, const GammaPar& par, uint8_t* __restrict__ fl_out) {
+  const int t = threadIdx.x;
   __syncthreads();
   for (int i = t; i < kL; i += 256) {
     uint32_t f = 0;
@@ -205,7 +213,17 @@ __device__ __forceinline__ int lg_build(ChunkLds& s, const uint32_t* __restrict_
     }
   }
   __syncthreads();
-  const bool overflow = s.n_slow > kSlowCap;
+  if (s.n_slow > kSlowCap)                // (the list overflowed: no attempt of this chunk counts as accepted -> every step undefined)
+    for (int i = t; i < kL; i += 256) s.fl[i] = 0;
+  __syncthreads();
+  uint8_t* dst = fl_out + (size_t)blockIdx.x * kFlStride;
+  for (int i = t; i < kL; i += 256) dst[i] = (uint8_t)s.fl[i];
+}
+
+// s.fl -> J1 -> J2, J4, J8 (integer work only)
+template <int PROG>
+__device__ __forceinline__ void lg_tables(ChunkLds& s, int lim) {
+  const int t = threadIdx.x;
   uint32_t mine[(kN2 + 255) / 256];
 #pragma unroll
   for (int k = 0; k < (kN2 + 255) / 256; ++k) {
@@ -214,7 +232,7 @@ __device__ __forceinline__ int lg_build(ChunkLds& s, const uint32_t* __restrict_
     if (n < kN2) {
       const int ctl = n >= kP2 ? 1 : 0, pp = n - ctl * kP2;
       if (pp >= kC) e = (uint32_t)n;      // an exit node: fixed point, no outputs
-      else if (!(PROG == 0 && ctl == kA) && !overflow) e = lg_node_step<PROG>(s, pp, ctl, lim);
+      else if (!(PROG == 0 && ctl == kA)) e = lg_node_step<PROG>(s, pp, ctl, lim);
       s.j1[n] = e;
     }
     mine[k] = e;
@@ -239,15 +257,17 @@ __device__ __forceinline__ int lg_build(ChunkLds& s, const uint32_t* __restrict_
     __syncthreads();
     prev = s.w.jump[l & 1];
   }
-  return lim;
 }
 
 // summary of chunk blockIdx.x: S[chunk][entry node] = exit node | outputs << 8
 template <int PROG>
 __global__ void __launch_bounds__(256) lg_summary_kernel(const uint32_t* __restrict__ words, int64_t n_dbl, const GammaPar par,
-                                                         const GlibcLogData* __restrict__ logtab, uint64_t* __restrict__ S) {
+                                                         const GlibcLogData* __restrict__ logtab, uint64_t* __restrict__ S,
+                                                         uint8_t* __restrict__ fl_out) {
   __shared__ ChunkLds s;
-  lg_build<PROG>(s, words, n_dbl, par, logtab);
+  const int lim = lg_load(s, words, n_dbl, logtab);
+  lg_decide(s, lim, par, fl_out);
+  lg_tables<PROG>(s, lim);
   const int t = threadIdx.x;
   if (t >= kNodes) return;
   int n = (t >> 6) * kP2 + (t & (kJ - 1));
@@ -364,7 +384,8 @@ __device__ __forceinline__ double lg_value(double num, double X, const GammaPar&
 template <int PROG>
 __global__ void __launch_bounds__(256) lg_emit_kernel(const uint32_t* __restrict__ words, int64_t n_dbl, const GammaPar par,
                                                       const GlibcLogData* __restrict__ logtab, const uint8_t* __restrict__ entry,
-                                                      const int64_t* __restrict__ first, const EmitOut a) {
+                                                      const int64_t* __restrict__ first, const EmitOut a,
+                                                      const uint8_t* __restrict__ fl_in) {
   const uint8_t e0 = entry[blockIdx.x];
   if (e0 == kDead) return;
   __shared__ ChunkLds s;
@@ -374,8 +395,16 @@ __global__ void __launch_bounds__(256) lg_emit_kernel(const uint32_t* __restrict
   __shared__ int wave_cnt[4], wave_set[4];
   __shared__ double set_val[256];
   __shared__ int last_set[256];
-  lg_build<PROG>(s, words, n_dbl, par, logtab);
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  {
+    // the decisions were made by the summary pass: only the doubles (for the normals of the steps actually taken) and
+    // the flags are loaded, the tables are integer work
+    const int lim = lg_load(s, words, n_dbl, logtab);
+    const uint8_t* src = fl_in + (size_t)blockIdx.x * kFlStride;
+    for (int i = t; i < kL; i += 256) s.fl[i] = src[i];
+    __syncthreads();
+    lg_tables<PROG>(s, lim);
+  }
   // the chunk's piece of the trajectory: thread 0 strides through it kStride macro steps at a time (J8), then one thread
   // per milestone fills in the steps between two milestones (J1) -- ~1/5 of the dependent LDS round trips of a plain walk
   if (t == 0) {
@@ -425,7 +454,7 @@ __global__ void __launch_bounds__(256) lg_emit_kernel(const uint32_t* __restrict
     const uint32_t e = s.j1[n];
     dp = lg_node_p((int)(e & 2047)) - p, a_pos = p + (int)((e >> 24) & 63), xmask = (int)(e >> 30);
   }
-  // the two normals of the step's attempt (the same arithmetic as in lg_build: nothing of it was kept)
+  // the two normals of the step's attempt (the same arithmetic as in the summary pass, which kept only its decisions)
   double gn0 = 0.0, gn1 = 0.0;
   if (live) lg_normals(s, a_pos, &gn0, &gn1);
   const int nout = __popc(xmask);
@@ -555,6 +584,7 @@ int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* p
     o_first_o[l] = carve(2 * (size_t)cnt[l]);
   }
   const size_t o_carry = carve(2 * (size_t)n_chunks), o_pend_x = carve(2 * (size_t)n_chunks), o_pend_o = carve(2 * (size_t)n_chunks);
+  const size_t o_fl = carve((size_t)n_chunks * kFlStride / 4);
   LegacyWords lw;
   VB_TRY(legacy_mt_words(ctx, key, *pos, 2 * n_dbl, off, &lw));
   uint32_t* base = lw.extra;
@@ -564,9 +594,11 @@ int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* p
   auto entry = [&](int l) { return (uint8_t*)(base + o_entry[l]); };
   auto first = [&](int l) { return (int64_t*)(base + o_first_o[l]); };
   if (prog == 0)
-    hipLaunchKernelGGL(lg_summary_kernel<0>, dim3((unsigned)n_chunks), dim3(256), 0, st, lw.words, have_dbl, par, logtab, sum(0));
+    hipLaunchKernelGGL(lg_summary_kernel<0>, dim3((unsigned)n_chunks), dim3(256), 0, st, lw.words, have_dbl, par, logtab, sum(0),
+                       (uint8_t*)(base + o_fl));
   else
-    hipLaunchKernelGGL(lg_summary_kernel<1>, dim3((unsigned)n_chunks), dim3(256), 0, st, lw.words, have_dbl, par, logtab, sum(0));
+    hipLaunchKernelGGL(lg_summary_kernel<1>, dim3((unsigned)n_chunks), dim3(256), 0, st, lw.words, have_dbl, par, logtab, sum(0),
+                       (uint8_t*)(base + o_fl));
   for (int l = 0; l < levels; ++l)
     hipLaunchKernelGGL(lg_compose_kernel, dim3((unsigned)cnt[l + 1]), dim3(256), 0, st, (const uint64_t*)sum(l), cnt[l], sum(l + 1));
   hipLaunchKernelGGL(lg_seed_kernel, dim3(1), dim3(1), 0, st, entry(levels), first(levels), prog == 1 ? (kA << 6) : (kB << 6));
@@ -582,10 +614,10 @@ int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* p
   VB_HIP(ctx, hipMemsetAsync(a.pend_o, 0xff, (size_t)n_chunks * sizeof(int64_t), st));    // no pending outputs
   if (prog == 0) {
     hipLaunchKernelGGL(lg_emit_kernel<0>, dim3((unsigned)n_chunks), dim3(256), 0, st, lw.words, have_dbl, par, logtab,
-                       (const uint8_t*)entry(0), (const int64_t*)first(0), a);
+                       (const uint8_t*)entry(0), (const int64_t*)first(0), a, (const uint8_t*)(base + o_fl));
   } else {
     hipLaunchKernelGGL(lg_emit_kernel<1>, dim3((unsigned)n_chunks), dim3(256), 0, st, lw.words, have_dbl, par, logtab,
-                       (const uint8_t*)entry(0), (const int64_t*)first(0), a);
+                       (const uint8_t*)entry(0), (const int64_t*)first(0), a, (const uint8_t*)(base + o_fl));
     hipLaunchKernelGGL(lg_pending_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, a, par, n_chunks);
   }
   VB_HIP(ctx, hipGetLastError());
