@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(kCorrThreads) mtd_corr_kernel(const uint32_t* 
   uint32_t acc[4] = {0u, 0u, 0u, 0u};
 #pragma unroll 1
   for (int w = 0; w < kSlice / 32; ++w) {
-    const uint32_t gw = g[w];
+    // (the coefficient word is the same for every lane: in a scalar register the bit masks are scalar work)
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(g[w]);
     uint32_t r[36];
     const uint4* win = reinterpret_cast<const uint4*>(u + 32 * w + 4 * tt);
 #pragma unroll
@@ -162,9 +163,10 @@ __global__ void __launch_bounds__(kCorrThreads) mtd_corr_kernel(const uint32_t* 
     }
 #pragma unroll
     for (int b = 0; b < 32; ++b) {
-      const uint32_t m = 0u - ((gw >> b) & 1u);
+      const uint32_t m = (uint32_t)((int32_t)(gw << (31 - b)) >> 31);      // scalar: all ones where coefficient bit b is set
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] ^= m & r[b + k];
+      for (int k = 0; k < 4; ++k)      // acc ^ (m & r) in ONE three-input bit operation (truth table 0xF0 ^ (0xCC & 0xAA))
+        acc[k] = __builtin_amdgcn_bitop3_b32(acc[k], m, r[b + k], 0x78);
     }
   }
 #pragma unroll
