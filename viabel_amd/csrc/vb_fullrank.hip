@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
   if (idx < nC) {
     const int i = (int)(idx / ldl), j = (int)(idx % ldl);
     fr_d2 s = (fr_d2){0.0, 0.0};
-    if (full || j <= i) {
+    if (full == 1 || j <= i) {
       for (int k0 = 0; k0 < splits; k0 += 8) {
         fr_d2 v[8];
 #pragma unroll
@@ -373,9 +373,28 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
       }
-      if (!full && j + 1 > i) s.y = 0.0;
+      if (full != 1 && j + 1 > i) s.y = 0.0;
     }
-    *reinterpret_cast<fr_d2*>(S.sums + S.off_c + idx) = s;
+    if (full == 2) {
+      // mirrored: the symmetric matrix given by its lower triangle, both halves written here (entry (i, j <= i) and its
+      // image (j, i) by the thread that owns the lower one; the upper entries' own threads write nothing) -- the caller
+      // multiplies by it next and needs no symmetrising pass
+      double* C = S.sums + S.off_c;
+      if (j < d && j <= i) {
+        C[idx] = s.x;
+        if (j < i) C[(int64_t)j * ldl + i] = s.x;
+      } else if (j >= d) {
+        C[idx] = 0.0;
+      }
+      if (j + 1 < d && j + 1 <= i) {
+        C[idx + 1] = s.y;
+        if (j + 1 < i) C[(int64_t)(j + 1) * ldl + i] = s.y;
+      } else if (j + 1 >= d) {
+        C[idx + 1] = 0.0;
+      }
+    } else {
+      *reinterpret_cast<fr_d2*>(S.sums + S.off_c + idx) = s;
+    }
   }
   if (tid < ldz) {
     double s = 0.0;
@@ -850,10 +869,10 @@ int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ld
 }
 
 int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab, int d, int64_t ldl,
-                      const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S) {
+                      const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S, bool mirror) {
   const int64_t items = slab / 2 > ldz ? slab / 2 : ldz;
   hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, Cpart,
-                     splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S, 0);
+                     splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S, mirror ? 2 : 0);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }

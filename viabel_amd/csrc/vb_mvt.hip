@@ -355,8 +355,15 @@ __global__ void __launch_bounds__(256) mvt_linv_mu_kernel(const double* __restri
 __global__ void __launch_bounds__(256) mvt_prep_kernel(const double* __restrict__ Wt, const double* __restrict__ Lt,
                                                        const double* __restrict__ mu, double* __restrict__ Li,
                                                        double* __restrict__ Lfull, double* __restrict__ c,
-                                                       double* __restrict__ scal, int d, int64_t ld) {
+                                                       double* __restrict__ scal, int d, int64_t ld,
+                                                       const double* __restrict__ chi, double df, int64_t n_inv,
+                                                       double* __restrict__ inv_s) {
   const int role = blockIdx.y, tiles = (d + 31) / 32;
+  if (role == 3) {      // the t family's row scales 1 / s_n = 1 / sqrt(chi_n / df) (approximations.py:345): no launch of their own
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_inv; i += (int64_t)gridDim.x * 256)
+      inv_s[i] = 1.0 / sqrt(chi[i] / df);
+    return;
+  }
   if (role < 2) {
     if ((int)blockIdx.x >= tiles * tiles) return;
     __shared__ double tile[32][33];
@@ -379,15 +386,6 @@ __global__ void __launch_bounds__(256) mvt_prep_kernel(const double* __restrict_
   for (int k = lane; k <= j; k += 64) s = fma(mu[k], Wt[(int64_t)k * ld + j], s);      // Wt = L^-T is upper triangular
   s = mvt_wave_sum(s);
   if (lane == 0) c[j] = s;
-}
-
-// S = symmetric matrix given by its lower triangle C (both d x d, row stride ld)
-__global__ void __launch_bounds__(256) mvt_symmetrize_kernel(const double* __restrict__ C, double* __restrict__ S,
-                                                             int d, int64_t ld) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)d * ld) return;
-  const int i = (int)(idx / ld), j = (int)(idx % ld);
-  S[idx] = j < d ? (j <= i ? C[idx] : C[(int64_t)j * ld + i]) : 0.0;
 }
 
 // packed gradient of -scale sum_n w_n log q(x_n; theta): d/dmu from the column sums, d/dL = tril(S L)
@@ -420,8 +418,9 @@ __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __rest
 // theta (host) -> device: mu, L' (o_lt), L (o_lfull), Wt = L^-T (o_wt), Li = L^-1 (o_li), c = L^-1 mu (o_c)
 // zero_scal: the refresh's call also clears the 32 scalars the bisection accumulates into (a gradient at another
 // parameter must leave them alone: eps, ess and the status of the refresh live there)
+// chi != nullptr: the same launch also forms the n_inv row scales 1 / sqrt(chi / df) into L.o_invs
 static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t d, const double* theta_host,
-                              bool zero_scal = false) {
+                              bool zero_scal = false, const double* chi = nullptr, double df = 0.0, int64_t n_inv = 0) {
   hipStream_t st = ctx->stream;
   const int D = (int)d;
   const size_t p = (size_t)(d + d * (d + 1) / 2);
@@ -458,9 +457,9 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   VB_TRY(fr_tri_inverse_enqueue(ctx, st, base + L.o_theta, base + L.o_lt, D, L.ld, base + L.o_wt, base + L.o_tscr, clean));
   // (the transposes write every entry of the d x d blocks; the pad columns hold the zeros of the allocation)
   const int tiles = (D + 31) / 32, gx = tiles * tiles > (D + 3) / 4 ? tiles * tiles : (D + 3) / 4;
-  hipLaunchKernelGGL(mvt_prep_kernel, dim3((unsigned)gx, 3), dim3(256), 0, st, (const double*)(base + L.o_wt),
+  hipLaunchKernelGGL(mvt_prep_kernel, dim3((unsigned)gx, chi ? 4 : 3), dim3(256), 0, st, (const double*)(base + L.o_wt),
                      (const double*)(base + L.o_lt), (const double*)(base + L.o_mu), base + L.o_li, base + L.o_lfull,
-                     base + L.o_c, zero_scal ? base + L.o_scal : (double*)nullptr, D, L.ld);
+                     base + L.o_c, zero_scal ? base + L.o_scal : (double*)nullptr, D, L.ld, chi, df, n_inv, base + L.o_invs);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -664,8 +663,13 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   if ((root_host == nullptr) != (linv_host == nullptr))
     return fail(ctx, VB_ERR_INVALID, "sqrt_sigma and l_inv are given together or not at all");
   if (sym_root && !dev_factors) return fail(ctx, VB_ERR_INVALID, "the device's symmetric root goes with the device's factors");
+  // the context's chi-square draws (vb_chisq_generate / vb_legacy_rng_chisquare_device) become row scales in the factor
+  // kernel's own launch
+  const bool chi_dev_rows = !chi_host && df != 0.0;
+  if (chi_dev_rows && (ctx->chi_n != n || ctx->chi_df != df))
+    return fail(ctx, VB_ERR_STATE, "chi == NULL needs %lld device chi-square(%g) draws (vb_chisq_generate)", (long long)n, df);
   if (dev_factors) {      // throughput mode: mu, L', L^-1 from theta on the device; the samples go through L' (see header)
-    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true));
+    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true, chi_dev_rows ? (const double*)ctx->chi_dev.ptr : nullptr, df, n));
     // reference-identical sampling (approximations.py:348): x = mu + (z Sigma^(1/2)) / s with the SYMMETRIC root, formed
     // on the device from the unpacked factor (VB_ERR_UNSUPPORTED: not resolved to 1e-12 -- the caller's LAPACK route)
     if (sym_root) VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, root_info));
@@ -683,10 +687,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     for (int64_t i = 0; i < n; ++i)
       inv_s[i] = df > 0.0 ? 1.0 / sqrt(chi_host[i] / df) : 1.0;                       // approximations.py:345
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_invs, inv_s.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
-  } else {   // the draws of vb_chisq_generate, already on the device
-    if (ctx->chi_n != n || ctx->chi_df != df)
-      return fail(ctx, VB_ERR_STATE, "chi == NULL needs %lld device chi-square(%g) draws (vb_chisq_generate)",
-                  (long long)n, df);
+  } else if (!dev_factors) {   // the draws of vb_chisq_generate, already on the device (dev_factors: done by the factor kernel)
     hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                        (const double*)ctx->chi_dev.ptr, df, n, base + L.o_invs);
     VB_HIP(ctx, hipGetLastError());
@@ -1036,18 +1037,16 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
                                    slab, base + L.o_col, L.ld, L.n_rb, &cs_fused));
   if (!cs_fused)
     VB_TRY(fr_colsum_enqueue(ctx, base + L.o_ua, nullptr, L.ld, n, (int)d, 0, nullptr, base + L.o_col, fpart));
+  // (packed chain rule: the Gram matrix leaves the reduction symmetric -- both triangles -- and S L reads it where it is)
   VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col,
                            cs_fused ? L.splits : L.n_rb, L.ld, fpart,
-                           cs_fused ? 0 : L.n_rb * (int)((d + 127) / 128), S));
+                           cs_fused ? 0 : L.n_rb * (int)((d + 127) / 128), S, packed_out != nullptr));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
   if (packed_out) {
     // S = sym(gram), dL = tril(S L) - w_sum diag(1 / L_ii), free diagonal x L_ii: one D x D x D product and a pack kernel
     const int D = (int)d;
-    const int64_t sq = d * L.ld;
-    hipLaunchKernelGGL(mvt_symmetrize_kernel, dim3((unsigned)((sq + 255) / 256)), dim3(256), 0, st,
-                       (const double*)(S.sums + S.off_c), base + L.o_tscr, D, L.ld);
     GemmArgs gs;
-    gs.A = base + L.o_tscr;
+    gs.A = S.sums + S.off_c;
     gs.lda = L.ld;
     gs.B = base + L.o_lfull;
     gs.ldb = L.ld;
