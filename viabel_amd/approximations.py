@@ -428,14 +428,21 @@ class MultivariateT(_NoiseMixin, ApproximationFamily):
         z = rs.randn(n_samples, self.dim)
         return chi, z
 
-    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
-        """The normals into ``slot``; returns the chi-square draws (all ``n_total`` of them: O(N) host work)."""
+    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None, host_chi=True):
+        """The normals into ``slot``; returns the chi-square draws (all ``n_total`` of them).  ``host_chi=False``: a caller
+        that means to stay on the device takes None when the draws were generated there (``_chi_on_device``; they are
+        resident in the context, ``eng.chisq_get_host(n_total)`` fetches them should the host route be needed after all)."""
         rs = self._random_state(seed)
         chi = None                                         # first, as ``sample`` draws them (:345-347)
+        on_device = False
         if n_total >= self._DEVICE_CHI_FROM and isinstance(rs, LegacyRandomState):
-            chi = eng.chisq_legacy(rs._h, self.df, n_total)    # on the device, bit for bit numpy's (None: not this path's case)
-        self._chi_on_device = chi is not None              # ... and resident in the context (vb_dis_refresh_mvt_symroot)
-        if chi is None:
+            # on the device, bit for bit numpy's (None: not this path's case)
+            chi = eng.chisq_legacy(rs._h, self.df, n_total, to_host=host_chi)
+            on_device = chi is not None
+            if on_device and not host_chi:
+                chi = None
+        self._chi_on_device = on_device                    # ... and resident in the context (vb_dis_refresh_mvt_symroot)
+        if chi is None and not on_device:
             chi = rs.chisquare(self.df, n_total)
         self._stage_normals(eng, rs, slot, n_total, self.dim, begin, end)
         return chi

@@ -526,15 +526,16 @@ class ExclusiveKL(StochasticVariationalObjective):
                                    row_offset=begin)
             else:
                 # chi-square draws first (approximations.py:345-347)
-                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end)
-                if (not path_deriv and eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
-                        and getattr(approx, '_chi_on_device', False)):
+                want_resident = not path_deriv and eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
+                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, host_chi=not want_resident)
+                if want_resident and getattr(approx, '_chi_on_device', False):
                     # the whole evaluation resident on the device: both noise streams are there already, the symmetric
                     # root and its Frechet derivative are device iterations, the chain rule to the free Cholesky
                     # parameters two more kernels (vb_elbo_grad_mvt_symroot); None: an iteration did not resolve
                     resident = eng.elbo_grad_mvt_symroot(_NOISE_SLOT, N, D, df, var_param)
                     if resident is not None:
                         return resident
+                    chi = eng.chisq_get_host(N)          # the host route after all: the draws come down
             mu, L = approx._unpack(var_param)
             Sigma = L @ L.T
             inv_s = 1.0 / np.sqrt(chi / df)
@@ -1046,7 +1047,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                         self._own_state(eng, 1, True)
                 else:
                     # chi-square draws first (approximations.py:345-347)
-                    chi = approx._stage_base_noise(eng, slot, N, begin, end)
+                    chi = approx._stage_base_noise(eng, slot, N, begin, end, host_chi=not sym_try)
                     if sym_try and getattr(approx, '_chi_on_device', False):
                         # the whole step on the device: the context holds numpy's chi-square draws, the slot its normals
                         info = eng.dis_refresh_mvt_symroot(slot, N, D, df, var_param, self._prior_arg, self._eps,
@@ -1061,6 +1062,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
                             self._set_state_weights(None, lambda: eng.dis_weights_get(N))
                             self._own_state(eng, 1, True)
                     if not resident:
+                        if chi is None:
+                            chi = eng.chisq_get_host(N)          # the host route after all: the draws come down
                         L = host_factors()[0]
                         root, _ = _device_root(eng, L @ L.T)        # symmetric square root, :348
                 if not resident:
