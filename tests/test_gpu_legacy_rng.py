@@ -227,3 +227,32 @@ def test_device_gamma_budget_short_falls_back_without_touching_the_generator(env
     assert eng.noise_legacy_standard_t(5, ours._h, 7.0, 600, 500)
     np.testing.assert_array_equal(eng.noise_get_host(5, 600, 500), ref.standard_t(7.0, (600, 500)))
     _same_state(ours, ref)
+
+
+def test_host_sample_draws_big_legacy_noise_on_the_device(env):
+    """``family.sample(var_param, n)`` in the default mode (what vi_diagnostics calls with 10^5 draws): from 2^18 values on
+    the base noise is generated on the device from the family's own generator and read back -- the same samples as the
+    reference's ``sample`` (approximations.py:212-216, :270-274, :342-349) on the same seed, generator in step."""
+    _need_log(env)
+    vb, eng, LegacyRandomState = env
+    n = 70000
+    for fam, ref_draw in ((vb.MFGaussian(8, seed=4), lambda rs: rs.randn(n, 8)),
+                          (vb.MFStudentT(8, 6.0, seed=4), lambda rs: rs.standard_t(6.0, size=(n, 8))),
+                          (vb.FullRankGaussian(8, seed=4), lambda rs: rs.randn(n, 8))):
+        theta = fam.init_param() * 0.1
+        ref = np.random.RandomState(4)
+        for call in range(2):
+            x = fam.sample(theta, n)
+            noise = ref_draw(ref)
+            if isinstance(fam, vb.FullRankGaussian):
+                mu, L = fam._unpack(theta)
+                np.testing.assert_allclose(x, mu + noise @ L.T, rtol=1e-13, atol=1e-13)
+            else:
+                np.testing.assert_array_equal(x, theta[:8] + np.exp(theta[8:]) * noise)
+        _same_state(fam._rs, ref)
+    t = vb.MultivariateT(8, 9.0, seed=4)
+    ref = np.random.RandomState(4)
+    chi, z = t._base_noise(n)
+    np.testing.assert_array_equal(chi, ref.chisquare(9.0, n))
+    np.testing.assert_array_equal(z, ref.randn(n, 8))
+    _same_state(t._rs, ref)

@@ -173,7 +173,9 @@ class MFGaussian(_NoiseMixin, ApproximationFamily):
 
     def _base_noise(self, n_samples, seed=None):
         """The base draws the reference's ``sample`` would consume (``:216``)."""
-        return self._random_state(seed).randn(n_samples, self.dim)
+        rs = self._random_state(seed)
+        noise = _legacy_host_copy(rs, 'n', 0.0, n_samples, self.dim)
+        return rs.randn(n_samples, self.dim) if noise is None else noise
 
     def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
         self._stage_normals(eng, self._random_state(seed), slot, n_total, self.dim, begin, end)
@@ -240,7 +242,9 @@ class MFStudentT(_NoiseMixin, ApproximationFamily):
         return self._family_id, float(self._df)
 
     def _base_noise(self, n_samples, seed=None):
-        return self._random_state(seed).standard_t(self.df, size=(n_samples, self.dim))   # :273-274
+        rs = self._random_state(seed)
+        noise = _legacy_host_copy(rs, 't', self.df, n_samples, self.dim)
+        return rs.standard_t(self.df, size=(n_samples, self.dim)) if noise is None else noise   # :273-274
 
     def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
         """Rows ``[begin, end)`` of ``standard_t(df, (n_total, dim))`` into ``slot``: big draws ON THE DEVICE from the
@@ -336,7 +340,9 @@ class FullRankGaussian(_NoiseMixin, ApproximationFamily):
         return self._family_id, 0.0
 
     def _base_noise(self, n_samples, seed=None):
-        return self._random_state(seed).randn(n_samples, self.dim)
+        rs = self._random_state(seed)
+        noise = _legacy_host_copy(rs, 'n', 0.0, n_samples, self.dim)
+        return rs.randn(n_samples, self.dim) if noise is None else noise
 
     def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
         self._stage_normals(eng, self._random_state(seed), slot, n_total, self.dim, begin, end)
@@ -425,8 +431,8 @@ class MultivariateT(_NoiseMixin, ApproximationFamily):
         """Chi-square draws FIRST, then the normals (``approximations.py:345-347``)."""
         rs = self._random_state(seed)
         chi = rs.chisquare(self.df, n_samples)
-        z = rs.randn(n_samples, self.dim)
-        return chi, z
+        z = _legacy_host_copy(rs, 'n', 0.0, n_samples, self.dim)
+        return chi, (rs.randn(n_samples, self.dim) if z is None else z)
 
     def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None, host_chi=True):
         """The normals into ``slot``; returns the chi-square draws (all ``n_total`` of them).  ``host_chi=False``: a caller
@@ -622,6 +628,25 @@ class LRGaussian(_NoiseMixin, ApproximationFamily):
 
     def supports_pth_moment(self, p):
         return p in [2, 4]
+
+
+_HOST_SAMPLE_DEVICE_FROM = 1 << 18      # values: from here on a host `sample()` draws its legacy noise on the GPU and reads it back
+
+
+def _legacy_host_copy(rs, kind, df, n_samples, dim):
+    """``rs.randn(n, d)`` / ``rs.standard_t(df, (n, d))`` for a HOST caller (``sample``, ``vi_diagnostics``: 10^5 draws),
+    generated on the device from the generator's own state -- values and state bit for bit numpy's -- and read back; None
+    when there is no engine, the draw is small, or the device path declines (the caller draws on the host)."""
+    if n_samples * dim < _HOST_SAMPLE_DEVICE_FROM or not isinstance(rs, LegacyRandomState):
+        return None
+    try:
+        eng = _lib.default_engine()
+    except Exception:
+        return None
+    slot = _lib.MAX_SLOTS - 1
+    ok = (eng.noise_legacy_standard_t(slot, rs._h, df, n_samples, dim) if kind == 't'
+          else eng.noise_legacy_randn(slot, rs._h, n_samples, dim))
+    return eng.noise_get_host(slot, n_samples, dim) if ok else None
 
 
 def _philox_host_copy(family, n_samples, seed):
