@@ -256,3 +256,28 @@ def test_host_sample_draws_big_legacy_noise_on_the_device(env):
     np.testing.assert_array_equal(chi, ref.chisquare(9.0, n))
     np.testing.assert_array_equal(z, ref.randn(n, 8))
     _same_state(t._rs, ref)
+
+
+def test_device_gamma_random_requests(env):
+    """Sixty random (seed, df, shape, preceding draws) requests, from one value to a few chunks of the stream (the
+    single-chunk case has no summary tree at all; shapes near 1 reject most; huge df puts every log in its near-1
+    branch): values and generator state against numpy every time."""
+    _need_log(env)
+    vb, eng, LegacyRandomState = env
+    gen = np.random.RandomState(2026)
+    for case in range(60):
+        seed = int(gen.randint(0, 2 ** 31 - 1))
+        df = float([2.0001, 2.3, 3.0, 7.5, 33.0, 1e3, 1e6][gen.randint(7)])
+        n, d = int(gen.randint(1, 400)), int(gen.randint(1, 120))
+        pre = int(gen.randint(0, 6))
+        ours, ref = LegacyRandomState(seed), np.random.RandomState(seed)
+        if pre:
+            np.testing.assert_array_equal(ours.randn(pre), ref.randn(pre))
+        if case % 2:
+            assert eng.noise_legacy_standard_t(6, ours._h, df, n, d), (case, seed, df, n, d)
+            np.testing.assert_array_equal(eng.noise_get_host(6, n, d), ref.standard_t(df, (n, d)), err_msg=str((case, seed, df, n, d)))
+        else:
+            got = eng.chisq_legacy(ours._h, df, n * d)
+            assert got is not None, (case, seed, df, n, d)
+            np.testing.assert_array_equal(got, ref.chisquare(df, n * d), err_msg=str((case, seed, df, n, d)))
+        _same_state(ours, ref)
