@@ -234,6 +234,7 @@ int vb_destroy(vb_ctx* ctx) {
   for (auto& r : ctx->results)
     if (r.host) (void)hipHostFree(r.host);
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
+  if (ctx->done_host) (void)hipHostFree(ctx->done_host);
   if (ctx->pin_host) (void)hipHostFree(ctx->pin_host);
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
@@ -615,7 +616,7 @@ struct GenNoise {            // in-register noise of a single evaluation (MfCall
 static int mf_call(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t d, int64_t n_total,
                    int family, double df, const double* thetas, unsigned flags, int cv_mode,
                    ResultSlot** rs, bool pipelined, bool overlap_comm = false, bool alternate = false,
-                   const GenNoise* gen = nullptr) {
+                   const GenNoise* gen = nullptr, bool blocking = false) {
   if (!ctx || !thetas || !slots) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (count < 1) return fail(ctx, VB_ERR_INVALID, "count must be positive");
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
@@ -650,9 +651,42 @@ static int mf_call(vb_ctx* ctx, int count, const int* slots, int64_t n, int64_t 
       c.gen_stream = gen->stream;
       c.gen_row_offset = gen->row_offset;
     }
+    ctx->done_groups = 0;
+    static const bool flagsync = !(getenv("VB_MF_FLAGSYNC") && atoi(getenv("VB_MF_FLAGSYNC")) == 0);
+    if (blocking && flagsync && count == 1) {
+      if (!ctx->done_host) {
+        VB_HIP(ctx, hipHostMalloc((void**)&ctx->done_host, 64 * 8 * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(ctx->done_host, 0, 64 * 8 * sizeof(unsigned long long));
+        VB_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->done_dev, ctx->done_host, 0));
+      }
+      c.done_dev = ctx->done_dev;
+      c.done_seq = ++ctx->done_seq;
+      c.done_groups = &ctx->done_groups;
+    }
     VB_TRY(mf_enqueue(ctx, c));
     VB_TRY(ticket(ctx, rs + b0, c.count));
   }
+  return VB_OK;
+}
+
+// Wait for the blocking mean-field evaluation just enqueued: on the finalize kernel's completion words when it signals
+// (mf_call(..., blocking)), else -- or after 2 ms of polling -- on the stream.
+static int mf_wait_blocking(vb_ctx* ctx) {
+  const int groups = ctx->done_groups;
+  if (groups > 0) {
+    const unsigned long long seq = ctx->done_seq;
+    volatile unsigned long long* w = ctx->done_host;
+    for (unsigned spins = 0; spins < 400000u; ++spins) {
+      int g = 0;
+      while (g < groups && w[8 * g] == seq) ++g;
+      if (g == groups) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return comm_check(ctx);
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VB_OK;
 }
 
@@ -661,8 +695,8 @@ int vb_elbo_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t 
                            int cv_mode, double* value, double* grad) {
   if (!ctx || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   ResultSlot* rs = &ctx->sync_result;
-  VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs, false));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs, false, false, false, nullptr, true));
+  VB_TRY(mf_wait_blocking(ctx));
   rs->pending = false;
   *value = rs->host[rs->p];
   memcpy(grad, rs->host + rs->p + 1, (size_t)(2 * d) * sizeof(double));
@@ -690,8 +724,8 @@ int vb_elbo_grad_meanfield_philox(vb_ctx* ctx, int slot, int64_t n, int64_t d, i
   }
   ResultSlot* rs = &ctx->sync_result;
   const GenNoise gen{seed, stream, row_offset};
-  VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs, false, false, false, &gen));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VB_TRY(mf_call(ctx, 1, &slot, n, d, n_total, family, df, theta, flags, cv_mode, &rs, false, false, false, &gen, true));
+  VB_TRY(mf_wait_blocking(ctx));
   rs->pending = false;
   *value = rs->host[rs->p];
   memcpy(grad, rs->host + rs->p + 1, (size_t)(2 * d) * sizeof(double));

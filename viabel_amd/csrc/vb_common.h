@@ -136,6 +136,13 @@ struct vb_ctx {
   vb::NoiseSlot gen_geom;               // geometry of the matrix an in-register (GEN) evaluation stands for
   vb::ResultSlot results[VB_MAX_SLOTS];
   vb::ResultSlot sync_result;           // used by the synchronous entry points
+  // completion words of the blocking mean-field call (pinned, device-mapped): finalize workgroup g stores the call's
+  // sequence number into done_host[8 g] behind its results, the host polls them instead of waking up through
+  // hipStreamSynchronize (VB_MF_FLAGSYNC=0 turns this off)
+  unsigned long long* done_host = nullptr;
+  unsigned long long* done_dev = nullptr;
+  unsigned long long done_seq = 0;
+  int done_groups = 0;                  // workgroups that signal for the call in flight (0: wait on the stream)
 
   vb::ModelDev model;
   vb::DeviceBuffer model_params;        // device copy of the model's double parameters
@@ -330,6 +337,11 @@ struct MfCall {
   bool prep_next = false, skip_prep = false;
   bool* prep_done = nullptr;
   bool theta_on_device = false;   // theta_src[0] is device memory (the fit loop's iterate), not a pinned staging copy
+  // blocking call: ask the finalize kernel to signal completion through these words (see vb_ctx::done_host); *done_groups
+  // reports how many workgroups will (0: this evaluation does not end in the fused finalize -- wait on the stream)
+  unsigned long long* done_dev = nullptr;
+  unsigned long long done_seq = 0;
+  int* done_groups = nullptr;
 };
 int mf_enqueue(vb_ctx* ctx, const MfCall& call);
 // user model given as HIP source (vb_usermodel.hip)

@@ -618,6 +618,8 @@ struct EpiArgs {
   int prep_next;            // ... and prepare the next iteration (mf_prep_kernel's work) in its workspace set
   double* next_wsb;
   Geom next_g;              // geometry of the next iteration: the same shapes, the next Philox stream
+  unsigned long long* done; // blocking call: done[8 * workgroup] = done_seq behind this workgroup's results (or nullptr)
+  unsigned long long done_seq;
 };
 
 struct Totals {
@@ -1025,6 +1027,14 @@ mf_finalize_kernel(const EpiArgs a_in, const BatchPtrs bp, const Workspace ws) {
     const double val = elbo_value(a, tot, sum_ls);
     value[0] = val;
     if (a.has_step) a.step.values[a.step.k] = val;
+  }
+  if (a.done) {
+    // the blocking caller polls these words instead of synchronising the stream: every thread's result stores are
+    // released to the host before the workgroup's word carries the call's sequence number
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(a.done + 8 * blockIdx.x, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 #ifdef VB_FIN_CLOCK
   {
@@ -1936,6 +1946,12 @@ int mf_enqueue(vb_ctx* ctx, const MfCall& c) {
       e.next_g.gk1 = (uint32_t)(c.gen_seed >> 32) ^ (uint32_t)(next_stream >> 32);
       e.next_g.gw = (uint32_t)next_stream;
     }
+  }
+  if (c.done_groups) *c.done_groups = 0;
+  if (c.done_dev && c.done_groups && fused && c.count == 1 && g.Dp / 64 <= 64 && !e.has_step) {
+    e.done = c.done_dev;
+    e.done_seq = c.done_seq;
+    *c.done_groups = g.Dp / 64;
   }
   hipLaunchKernelGGL(mf_finalize_kernel, dim3((unsigned)(g.Dp / 64), (unsigned)c.count), dim3(256), 0,
                      st_post, e, bp, ws);
