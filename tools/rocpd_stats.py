@@ -44,5 +44,24 @@ def main(path, counter=None):
         print(line)
 
 
+def timeline(path, first, count):
+    """Dispatches `first` .. `first + count` in start order: offset from the first one's start, duration, and the gap
+    to the previous dispatch's end (negative: they overlapped -- another stream)."""
+    db = sqlite3.connect(path)
+    rows = db.cursor().execute(
+        "select s.kernel_name, d.start, d.end, d.grid_size_x, d.queue_id from rocpd_kernel_dispatch d "
+        "join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start").fetchall()
+    rows = rows[first:first + count]
+    t0, prev_end = rows[0][1], rows[0][1]
+    print('%9s %9s %8s %6s  %s' % ('start_us', 'dur_us', 'gap_us', 'queue', 'kernel (grid x)'))
+    for name, st, en, gx, q in rows:
+        short = name[:70]
+        print('%9.1f %9.1f %8.1f %6s  %s (%d)' % ((st - t0) / 1e3, (en - st) / 1e3, (st - prev_end) / 1e3, q, short, gx))
+        prev_end = max(prev_end, en)
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    if len(sys.argv) > 2 and sys.argv[2] == '--timeline':
+        timeline(sys.argv[1], int(sys.argv[3]), int(sys.argv[4]))
+    else:
+        main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)

@@ -64,6 +64,7 @@ int sync_streams(vb_ctx* ctx) {
     VB_HIP(ctx, hipStreamSynchronize(ctx->pipe.pre));
     VB_HIP(ctx, hipStreamSynchronize(ctx->pipe.post));
   }
+  if (ctx->mvt_side) VB_HIP(ctx, hipStreamSynchronize(ctx->mvt_side));
   ctx->pipe.post_pending = false;
   return comm_check(ctx);
 }
@@ -239,13 +240,20 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->psis_work, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items, &ctx->legacy_work, &ctx->alpha_g, &ctx->mf_one})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items, &ctx->legacy_work, &ctx->alpha_g, &ctx->mf_one, &ctx->mvt_ticket})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
+  if (ctx->mvt_out_host) (void)hipHostFree(ctx->mvt_out_host);
   if (ctx->user_host_pin) (void)hipHostFree(ctx->user_host_pin);
   if (ctx->legacy_pin) (void)hipHostFree(ctx->legacy_pin);
   for (hipEvent_t e : ctx->mvt_pin_ev)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->mvt_side) {
+    (void)hipStreamSynchronize(ctx->mvt_side);
+    (void)hipStreamDestroy(ctx->mvt_side);
+    (void)hipEventDestroy(ctx->mvt_ev_fork);
+    (void)hipEventDestroy(ctx->mvt_ev_join);
+  }
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& log : ctx->prof)
     for (auto& ev : log.events) {

@@ -187,6 +187,22 @@ struct vb_ctx {
   size_t mvt_pin_doubles = 0;
   int mvt_pin_slot = 0;
   hipEvent_t mvt_pin_ev[2] = {nullptr, nullptr};   // recorded behind each slot's staged copy; waited for before the slot is rewritten
+  double* mvt_out_host = nullptr;       // mapped host memory the blocking step's pack kernel writes [value | grad | scalars |
+  double* mvt_out_dev = nullptr;        // completion word] into (mvt_dis_grad), and its device address
+  size_t mvt_out_doubles = 0;
+  unsigned long long mvt_done_seq = 0;
+  vb::DeviceBuffer mvt_ticket;          // the pack kernel's workgroup ticket (zero between launches)
+  hipStream_t mvt_side = nullptr;       // side stream of the deferred triangular inverse (mvt_factors_device)
+  hipEvent_t mvt_ev_fork = nullptr, mvt_ev_join = nullptr;
+  bool mvt_inv_pending = false;         // the main stream has not yet waited for the side stream's inverse
+  bool mvt_inv_queued = false;          // ... which has been enqueued already (else mvt_inv_args describes it)
+  struct {
+    double* base = nullptr;
+    int64_t o_theta = 0, o_lt = 0, o_wt = 0, o_tscr = 0, o_mu = 0, o_li = 0, o_lfull = 0, o_c = 0, ld = 0;
+    int d = 0;
+    bool clean = false;
+  } mvt_inv_args;
+  double* mvt_pin_dev = nullptr;        // device address of mvt_pin (mapped: the unpack reads the parameter in place)
   std::vector<double> mvt_prior;        // tempering-prior parameter the device copy was made from
   int64_t mvt_inv_key[4] = {0, 0, 0, 0};   // (state buffer, n, n_total, d) for which the inverse's zero triangle is known clean
   vb::DeviceBuffer dis_state;           // DIS: [cols of the refresh theta | log p | base b | log prior | w]
@@ -458,7 +474,8 @@ struct FitStep;
 // optimiser step of the dense family fused with the unpack of the stepped parameter (vb_fit): theta <- step(theta, grad)
 // and mu, L' of the NEW theta into fr_lt in one kernel; the next evaluation of `theta_dev` skips its unpack
 int fr_step_unpack_enqueue(vb_ctx* ctx, const FitStep& a, int64_t d);
-int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int D, int64_t ldl, double* Lt, double* mu);
+int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int D, int64_t ldl, double* Lt, double* mu,
+                      double* theta_copy = nullptr);
 int fr_tri_inverse_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, const double* Lt, int D, int64_t ldl,
                            double* Xa, double* T, bool clean = false);
 int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ldz, int64_t n, int d, int fmode,

@@ -49,15 +49,21 @@ __device__ __forceinline__ double fr_block_sum(double x, double* sh) {
 // through LDS so that both the reads (along k within a packed row) and the writes (along j within a row of Lt) are
 // contiguous 256-B runs; a thread-per-element gather took 10.6 us at D = 1024, this takes a third of it.  grid =
 // (tiles over k, tiles over j); block (32, 8).
+// copy != nullptr: theta is read ONCE -- it may be mapped host memory -- and every entry is also written to `copy`
+// (the device-resident parameter the triangular inverse and the fit kernels read)
 __global__ void __launch_bounds__(256) fr_unpack_kernel(const double* __restrict__ theta, int d,
                                                         int64_t ldl, double* __restrict__ Lt,
-                                                        double* __restrict__ mu) {
+                                                        double* __restrict__ mu, double* __restrict__ copy = nullptr) {
   __shared__ double tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int k0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
   if (blockIdx.y == 0) {
     const int i = k0 + (int)threadIdx.x;
-    if (threadIdx.x < 32 && i < d) mu[i] = theta[i];
+    if (threadIdx.x < 32 && i < d) {
+      const double v = theta[i];
+      mu[i] = v;
+      if (copy) copy[i] = v;
+    }
   }
   if (k0 > j0 + 31) {            // the whole tile lies below the diagonal of Lt (k > j): zeros
 #pragma unroll
@@ -73,6 +79,7 @@ __global__ void __launch_bounds__(256) fr_unpack_kernel(const double* __restrict
     double v = 0.0;
     if (j < d && k <= j) {
       v = theta[d + (int64_t)j * (j + 1) / 2 + k];
+      if (copy) copy[d + (int64_t)j * (j + 1) / 2 + k] = v;
       if (k == j) v = exp(v);
     }
     tile[r][tx] = v;
@@ -739,9 +746,10 @@ __global__ void __launch_bounds__(256) fr_sumsq_final_kernel(const double* __res
 }
 
 // theta -> mu, L' (dense, row stride ldl) on stream st
-int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int D, int64_t ldl, double* Lt, double* mu) {
+int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int D, int64_t ldl, double* Lt, double* mu,
+                      double* theta_copy) {
   hipLaunchKernelGGL(fr_unpack_kernel, dim3((unsigned)((D + 31) / 32), (unsigned)((D + 31) / 32)), dim3(256), 0, st,
-                     theta_dev, D, ldl, Lt, mu);
+                     theta_dev, D, ldl, Lt, mu, theta_copy);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -964,6 +972,11 @@ int gram_splits(vb_ctx* ctx, int d, int64_t n) {
   int splits = ctx->prop.multiProcessorCount / lower_tiles;
   const int max_splits = (int)(n / 256) > 0 ? (int)(n / 256) : 1;
   if (splits > max_splits) splits = max_splits;
+  static const int forced = [] {
+    const char* e = getenv("VB_GRAM_SPLITS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0 && forced < splits) splits = forced;
   return splits < 1 ? 1 : splits;
 }
 

@@ -160,6 +160,63 @@ __global__ void __launch_bounds__(1024) mvt_wsums_kernel(const double* __restric
   }
 }
 
+// Packed chain rule, one pass over the residual rows Y (N x D): with a_n = w_n c_n r_n (r_n = 1 / s_n when Y is the noise
+// matrix itself, 1 when Y holds the residuals) it leaves
+//   YA_n = a_n r_n Y_n      -- the scaled operand of the weighted Gram product M = sum_n a'_n y_n y_n',  y_n = r_n Y_n
+//   colpart[rb][j] = sum over the 128 rows of block rb of a_n Y_nj      -- sum_n a'_n y_n, reduced by fr_reduce_kernel
+// grid (ceil(D / 64), ceil(N / 128)): thread (c = t & 31, q = t >> 5) owns the column pair 2c, 2c + 1 of the rows
+// r0 + q, q + 8, ... (eight 16-byte loads in flight); the eight row groups are combined through LDS in fixed order.
+typedef double mvt_d2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) mvt_scale_colsum_kernel(const double* __restrict__ Y, int64_t ld, int64_t n, int d,
+                                                               const double* __restrict__ w, const double* __restrict__ cn,
+                                                               const double* __restrict__ r, double* __restrict__ YA,
+                                                               double* __restrict__ colpart) {
+  __shared__ mvt_d2 cs[8][32];
+  __shared__ double a_s[128], r_s[128];
+  const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int col = blockIdx.x * 64 + 2 * c;
+  const int64_t r0 = (int64_t)blockIdx.y * 128;
+  const bool ok0 = col < d, ok1 = col + 1 < d;
+  if (threadIdx.x < 128) {      // the block's row weights once, through LDS
+    const int64_t row = r0 + threadIdx.x;
+    double av = 0.0, rv = 1.0;
+    if (row < n) {
+      rv = r ? r[row] : 1.0;
+      av = (w[row] * cn[row]) * rv;
+    }
+    a_s[threadIdx.x] = av;
+    r_s[threadIdx.x] = rv;
+  }
+  __syncthreads();
+  mvt_d2 s = (mvt_d2){0.0, 0.0};
+  if (ok0) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      mvt_d2 g[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t row = r0 + q + 8 * (8 * half + i);
+        g[i] = row < n ? *reinterpret_cast<const mvt_d2*>(Y + row * ld + col) : (mvt_d2){0.0, 0.0};
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int lr = q + 8 * (8 * half + i);
+        if (!ok1) g[i].y = 0.0;
+        g[i] *= a_s[lr];
+        s += g[i];
+        if (r0 + lr < n) *reinterpret_cast<mvt_d2*>(YA + (r0 + lr) * ld + col) = g[i] * r_s[lr];
+      }
+    }
+  }
+  cs[q][c] = s;
+  __syncthreads();
+  if (q == 0 && ok0) {
+    const mvt_d2 tot = ((cs[0][c] + cs[1][c]) + (cs[2][c] + cs[3][c])) + ((cs[4][c] + cs[5][c]) + (cs[6][c] + cs[7][c]));
+    colpart[(int64_t)blockIdx.y * ld + col] = tot.x;
+    if (ok1) colpart[(int64_t)blockIdx.y * ld + col + 1] = tot.y;
+  }
+}
+
 // ---- tempering priors other than a diagonal Gaussian (vb_dis_set_temper_prior; objectives.py:317-319) ----------------
 // one wave per row: sum_d t.logpdf((x_d - loc_d) / sigma_d; df) - log sigma_d   (approximations.py:281-286)
 __global__ void __launch_bounds__(256) prior_diag_t_rows_kernel(const double* __restrict__ X, int64_t ld, int64_t n, int d,
@@ -357,8 +414,14 @@ __global__ void __launch_bounds__(256) mvt_prep_kernel(const double* __restrict_
                                                        double* __restrict__ Lfull, double* __restrict__ c,
                                                        double* __restrict__ scal, int d, int64_t ld,
                                                        const double* __restrict__ chi, double df, int64_t n_inv,
-                                                       double* __restrict__ inv_s) {
-  const int role = blockIdx.y, tiles = (d + 31) / 32;
+                                                       double* __restrict__ inv_s, int roles) {
+  // roles: bit r set = role r is part of this launch; blockIdx.y counts the set bits (the inverse may be formed on a
+  // side stream: then roles 1 and 3 -- which need L' only -- go first and roles 0 and 2 follow the inverse)
+  int role = 0;
+  for (int seen = -1; role < 4; ++role)
+    if ((roles >> role & 1) && ++seen == (int)blockIdx.y) break;
+  const int tiles = (d + 31) / 32;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 32 && scal) scal[threadIdx.x] = 0.0;
   if (role == 3) {      // the t family's row scales 1 / s_n = 1 / sqrt(chi_n / df) (approximations.py:345): no launch of their own
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_inv; i += (int64_t)gridDim.x * 256)
       inv_s[i] = 1.0 / sqrt(chi[i] / df);
@@ -378,7 +441,6 @@ __global__ void __launch_bounds__(256) mvt_prep_kernel(const double* __restrict_
       if (c0 + r < d && r0 + tx < d) out[(int64_t)(c0 + r) * ld + r0 + tx] = tile[tx][r];
     return;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 32 && scal) scal[threadIdx.x] = 0.0;
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= d) return;
@@ -390,13 +452,29 @@ __global__ void __launch_bounds__(256) mvt_prep_kernel(const double* __restrict_
 
 // packed gradient of -scale sum_n w_n log q(x_n; theta): d/dmu from the column sums, d/dL = tril(S L)
 // - w_sum tril(L^-T) (only the diagonal 1 / L_ii of the upper-triangular L^-T survives), free diagonal x L_ii
-__global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __restrict__ SL, const double* __restrict__ Lfull,
-                                                            int64_t ld, int d, const double* __restrict__ sums,
-                                                            int64_t off_col, double scale, double* __restrict__ out,
-                                                            const double* __restrict__ scale_dev,
-                                                            const double* __restrict__ res) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// `out` may be mapped host memory (the blocking step): then `done` is a mapped completion word, `ticket` a device
+// counter (zero between launches) -- every workgroup publishes its stores system-wide and draws a ticket, the last one
+// stores `seq` into the word, and the host polls it instead of waking up through hipStreamSynchronize (vb_ctx::done_host).
+__device__ __forceinline__ void mvt_pack_grad_body(const double* __restrict__ SL, const double* __restrict__ Lfull,
+                                                   int64_t ld, int d, const double* __restrict__ sums, int64_t off_col,
+                                                   double scale, double* __restrict__ out,
+                                                   const double* __restrict__ scale_dev, const double* __restrict__ res,
+                                                   const double* __restrict__ Wt) {
   if (scale_dev) scale *= scale_dev[0];      // (device-resident resampling: scale = sum w / (N M), sum w on the device)
+  const int64_t n_flat = ((int64_t)d * d + 255) / 256;
+  if ((int64_t)blockIdx.x >= n_flat) {
+    // (Wt given) the column sums are v = sum_n a_n y_n of the residuals y = L^-1 (x - mu): d/dmu = L^-T v, one wave per
+    // component over the upper-triangular Wt = L^-T
+    const int lane = threadIdx.x & 63;
+    const int j = (int)(blockIdx.x - n_flat) * 4 + (threadIdx.x >> 6);
+    if (j >= d) return;
+    double a = 0.0;
+    for (int k = j + lane; k < d; k += 64) a = fma(Wt[(int64_t)j * ld + k], sums[off_col + k], a);
+    a = mvt_wave_sum(a);
+    if (lane == 0) out[1 + j] = -scale * a;
+    return;
+  }
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const double w_sum = sums[1], w_logq = sums[2];
   if (idx == 0) {
     out[0] = -scale * w_logq;
@@ -406,7 +484,7 @@ __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __rest
     for (int q = 0; q < 4; ++q) tail[q] = res[q];
     tail[4] = -scale * w_logq;
   }
-  if (idx < d) out[1 + idx] = -scale * sums[off_col + idx];
+  if (idx < d && !Wt) out[1 + idx] = -scale * sums[off_col + idx];
   if (idx >= (int64_t)d * d) return;
   const int i = (int)(idx / d), j = (int)(idx % d);
   if (j > i) return;
@@ -415,12 +493,69 @@ __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __rest
   out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -scale * g;
 }
 
+__global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __restrict__ SL, const double* __restrict__ Lfull,
+                                                            int64_t ld, int d, const double* __restrict__ sums,
+                                                            int64_t off_col, double scale, double* __restrict__ out,
+                                                            const double* __restrict__ scale_dev,
+                                                            const double* __restrict__ res,
+                                                            const double* __restrict__ Wt = nullptr,
+                                                            unsigned* __restrict__ ticket = nullptr,
+                                                            unsigned long long* __restrict__ done = nullptr,
+                                                            unsigned long long seq = 0) {
+  mvt_pack_grad_body(SL, Lfull, ld, d, sums, off_col, scale, out, scale_dev, res, Wt);
+  if (!done) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // theta (host) -> device: mu, L' (o_lt), L (o_lfull), Wt = L^-T (o_wt), Li = L^-1 (o_li), c = L^-1 mu (o_c)
 // zero_scal: the refresh's call also clears the 32 scalars the bisection accumulates into (a gradient at another
 // parameter must leave them alone: eps, ess and the status of the refresh live there)
 // chi != nullptr: the same launch also forms the n_inv row scales 1 / sqrt(chi / df) into L.o_invs
+// defer_inverse: the inverse and what is read off it (Wt, Li, c) are formed on a SIDE stream behind the unpack while the
+// main stream goes on with what needs L' only (the sampling product, the row kernels, the bisection); whoever reads
+// Wt / Li / c calls mvt_join_inverse first.  Thirty-odd microseconds of small dependent launches (a 128 x 128 leaf
+// inversion and two D/2-sized products at D = 256) leave the critical path of a throughput-mode step.
+// The side stream's launches are enqueued LATE (mvt_side_enqueue, called by the refresh once the main stream has its
+// sampling product and row kernels queued): eight API calls ahead of them starve the main queue for ~30 us.
+static int mvt_side_enqueue(vb_ctx* ctx) {
+  if (!ctx->mvt_inv_pending || ctx->mvt_inv_queued) return VB_OK;
+  ctx->mvt_inv_queued = true;
+  const auto& a = ctx->mvt_inv_args;
+  hipStream_t sd = ctx->mvt_side;
+  VB_HIP(ctx, hipStreamWaitEvent(sd, ctx->mvt_ev_fork, 0));
+  VB_TRY(fr_tri_inverse_enqueue(ctx, sd, a.base + a.o_theta, a.base + a.o_lt, a.d, a.ld, a.base + a.o_wt, a.base + a.o_tscr,
+                                a.clean));
+  const int tiles = (a.d + 31) / 32, gx = tiles * tiles > (a.d + 3) / 4 ? tiles * tiles : (a.d + 3) / 4;
+  hipLaunchKernelGGL(mvt_prep_kernel, dim3((unsigned)gx, 2), dim3(256), 0, sd, (const double*)(a.base + a.o_wt),
+                     (const double*)(a.base + a.o_lt), (const double*)(a.base + a.o_mu), a.base + a.o_li, a.base + a.o_lfull,
+                     a.base + a.o_c, (double*)nullptr, a.d, a.ld, (const double*)nullptr, 0.0, (int64_t)0, (double*)nullptr,
+                     0x5);
+  VB_HIP(ctx, hipGetLastError());
+  VB_HIP(ctx, hipEventRecord(ctx->mvt_ev_join, sd));
+  return VB_OK;
+}
+
+static int mvt_join_inverse(vb_ctx* ctx) {
+  if (!ctx->mvt_inv_pending) return VB_OK;
+  VB_TRY(mvt_side_enqueue(ctx));
+  ctx->mvt_inv_pending = false;
+  VB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->mvt_ev_join, 0));
+  return VB_OK;
+}
+
 static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t d, const double* theta_host,
-                              bool zero_scal = false, const double* chi = nullptr, double df = 0.0, int64_t n_inv = 0) {
+                              bool zero_scal = false, const double* chi = nullptr, double df = 0.0, int64_t n_inv = 0,
+                              bool defer_inverse = false) {
+  VB_TRY(mvt_join_inverse(ctx));      // (the unpack below overwrites what a pending inverse still reads)
   hipStream_t st = ctx->stream;
   const int D = (int)d;
   const size_t p = (size_t)(d + d * (d + 1) / 2);
@@ -432,7 +567,8 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
       VB_HIP(ctx, hipHostFree(ctx->mvt_pin));
       ctx->mvt_pin = nullptr;
     }
-    VB_HIP(ctx, hipHostMalloc((void**)&ctx->mvt_pin, 2 * p * sizeof(double), hipHostMallocDefault));
+    VB_HIP(ctx, hipHostMalloc((void**)&ctx->mvt_pin, 2 * p * sizeof(double), hipHostMallocMapped));
+    VB_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->mvt_pin_dev, ctx->mvt_pin, 0));
     ctx->mvt_pin_doubles = p;
   }
   // two staging slots taken in turn; an event behind each slot's copy is waited for before the slot is rewritten (a
@@ -444,22 +580,48 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   else VB_HIP(ctx, hipEventSynchronize(slot_ev));
   double* stage = ctx->mvt_pin + (size_t)ctx->mvt_pin_slot * ctx->mvt_pin_doubles;
   memcpy(stage, theta_host, p * sizeof(double));
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_theta, stage, p * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipEventRecord(slot_ev, st));
   if (L.ld != d)      // (pad columns of mu and c: the unpack and the prep kernel write columns [0, d) only)
     VB_HIP(ctx, hipMemsetAsync(base + L.o_mu, 0, (size_t)(2 * L.ld) * sizeof(double), st));
-  VB_TRY(fr_unpack_enqueue(ctx, st, base + L.o_theta, D, L.ld, base + L.o_lt, base + L.o_mu));
+  // the unpack reads the staged parameter IN PLACE (mapped host memory, every entry once) and leaves the device copy
+  // behind: no DMA-engine round trip between the host's memcpy and the first kernel
+  VB_TRY(fr_unpack_enqueue(ctx, st, ctx->mvt_pin_dev + (size_t)ctx->mvt_pin_slot * ctx->mvt_pin_doubles, D, L.ld,
+                           base + L.o_lt, base + L.o_mu, base + L.o_theta));
+  VB_HIP(ctx, hipEventRecord(slot_ev, st));
   // the inverse's strictly lower triangle (and the scratch) need zeroing only when the buffer or its layout changed:
   // nothing else writes o_wt in throughput mode
   const int64_t key[4] = {(int64_t)(uintptr_t)base, L.o_wt, L.o_tscr, d};
   const bool clean = memcmp(key, ctx->mvt_inv_key, sizeof key) == 0;
   memcpy(ctx->mvt_inv_key, key, sizeof key);
-  VB_TRY(fr_tri_inverse_enqueue(ctx, st, base + L.o_theta, base + L.o_lt, D, L.ld, base + L.o_wt, base + L.o_tscr, clean));
   // (the transposes write every entry of the d x d blocks; the pad columns hold the zeros of the allocation)
   const int tiles = (D + 31) / 32, gx = tiles * tiles > (D + 3) / 4 ? tiles * tiles : (D + 3) / 4;
+  static const bool side_env = [] {
+    const char* e = getenv("VB_MVT_SIDE_INVERSE");
+    return !(e && atoi(e) == 0);
+  }();
+  if (defer_inverse && side_env) {
+    if (!ctx->mvt_side) {
+      VB_HIP(ctx, hipStreamCreateWithFlags(&ctx->mvt_side, hipStreamNonBlocking));
+      VB_HIP(ctx, hipEventCreateWithFlags(&ctx->mvt_ev_fork, hipEventDisableTiming));
+      VB_HIP(ctx, hipEventCreateWithFlags(&ctx->mvt_ev_join, hipEventDisableTiming));
+    }
+    VB_HIP(ctx, hipEventRecord(ctx->mvt_ev_fork, st));           // behind the unpack (and everything of earlier calls)
+    auto& a = ctx->mvt_inv_args;
+    a.base = base, a.o_theta = L.o_theta, a.o_lt = L.o_lt, a.o_wt = L.o_wt, a.o_tscr = L.o_tscr, a.o_mu = L.o_mu;
+    a.o_li = L.o_li, a.o_lfull = L.o_lfull, a.o_c = L.o_c, a.ld = L.ld, a.d = D, a.clean = clean;
+    ctx->mvt_inv_pending = true;
+    ctx->mvt_inv_queued = false;
+    hipLaunchKernelGGL(mvt_prep_kernel, dim3((unsigned)gx, chi ? 2 : 1), dim3(256), 0, st, (const double*)(base + L.o_wt),
+                       (const double*)(base + L.o_lt), (const double*)(base + L.o_mu), base + L.o_li, base + L.o_lfull,
+                       base + L.o_c, zero_scal ? base + L.o_scal : (double*)nullptr, D, L.ld, chi, df, n_inv, base + L.o_invs,
+                       chi ? 0xA : 0x2);
+    VB_HIP(ctx, hipGetLastError());
+    return VB_OK;
+  }
+  VB_TRY(fr_tri_inverse_enqueue(ctx, st, base + L.o_theta, base + L.o_lt, D, L.ld, base + L.o_wt, base + L.o_tscr, clean));
   hipLaunchKernelGGL(mvt_prep_kernel, dim3((unsigned)gx, chi ? 4 : 3), dim3(256), 0, st, (const double*)(base + L.o_wt),
                      (const double*)(base + L.o_lt), (const double*)(base + L.o_mu), base + L.o_li, base + L.o_lfull,
-                     base + L.o_c, zero_scal ? base + L.o_scal : (double*)nullptr, D, L.ld, chi, df, n_inv, base + L.o_invs);
+                     base + L.o_c, zero_scal ? base + L.o_scal : (double*)nullptr, D, L.ld, chi, df, n_inv, base + L.o_invs,
+                     chi ? 0xF : 0x7);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -473,6 +635,7 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
   const int n_cu = ctx->prop.multiProcessorCount;
   double logdet_half = 0.0;
   for (int64_t j = 0; j < d; ++j) logdet_half += theta_host[d + j * (j + 1) / 2 + j];
+  if (linv_host || !drawn_here) VB_TRY(mvt_join_inverse(ctx));
   if (linv_host) {
     // Wt[k][j] = Linv[j][k] (B operand of dev L^-T), Li[k][j] = Linv[k][j] (B operand of E' L^-1), [mu | c]:
     // staged in one host buffer, three copies, ONE synchronisation
@@ -669,10 +832,14 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   if (chi_dev_rows && (ctx->chi_n != n || ctx->chi_df != df))
     return fail(ctx, VB_ERR_STATE, "chi == NULL needs %lld device chi-square(%g) draws (vb_chisq_generate)", (long long)n, df);
   if (dev_factors) {      // throughput mode: mu, L', L^-1 from theta on the device; the samples go through L' (see header)
-    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true, chi_dev_rows ? (const double*)ctx->chi_dev.ptr : nullptr, df, n));
+    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true, chi_dev_rows ? (const double*)ctx->chi_dev.ptr : nullptr, df, n,
+                              ctx->n_ranks == 1));
     // reference-identical sampling (approximations.py:348): x = mu + (z Sigma^(1/2)) / s with the SYMMETRIC root, formed
     // on the device from the unpacked factor (VB_ERR_UNSUPPORTED: not resolved to 1e-12 -- the caller's LAPACK route)
-    if (sym_root) VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, root_info));
+    if (sym_root) {
+      VB_TRY(mvt_side_enqueue(ctx));      // (the inverse runs beside the root's iteration)
+      VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, root_info));
+    }
   } else {
     VB_TRY(upload_padded(ctx, base + L.o_root, L.ld, root_host, d, d, false));
   }
@@ -744,6 +911,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
                                    base + L.o_prior + L.ld, c0p, base + L.o_lprior + mine));
   if (ctx->temper.kind != VB_PRIOR_DIAG_GAUSSIAN)      // any other family as tempering prior: one more pass over X
     VB_TRY(temper_prior_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lprior + mine));
+  VB_TRY(mvt_side_enqueue(ctx));      // (a deferred inverse: its launches go out now that the main stream is fed)
   if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lp, mine, n, n_total));
     VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));
@@ -1009,28 +1177,52 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
       ctx->mvt_dev_factors = true;
     }
   }
+  FrSums S = L.S;
+  S.sums = base + L.o_sums;
+  const int64_t n_part = (n + 3) / 4;
+  const double* cn = base + L.o_part;       // n doubles, written by mvt_rows_kernel
+  double* fpart = base + L.o_part + n + 2 * n_part;
+  const int64_t slab = d * L.ld;
+  // The residuals y_n = L^-1 (x_n - mu) as rows: the noise matrix (scaled by 1 / s_n on the fly) or E'.
+  const bool noise_rows = ctx->mvt_e_noise != nullptr;
+  const double* Y = noise_rows ? ctx->mvt_e_noise : (const double*)(base + L.o_e);
+  const int64_t ldy = noise_rows ? ctx->mvt_e_noise_ld : L.ld;
+  // Packed chain rule (round 5): sum_n a_n u_n y_n' = L^-T M with M = sum_n a_n y_n y_n' and d/dmu = L^-T sum_n a_n y_n
+  // (u_n = L^-T y_n), so the N x D x D product U = E' L^-1 is not formed at all: one pass over Y leaves the scaled
+  // operand a_n y_n and the weighted column sums, the Gram product runs on Y itself, and L^-T enters once, in the
+  // D x D x D product of the chain rule (where L used to).  VB_MVT_DIRECT=0: the route through U.
+  static const bool direct_env = [] {
+    const char* e = getenv("VB_MVT_DIRECT");
+    return !(e && atoi(e) == 0);
+  }();
+  const bool direct = packed_out != nullptr && ldy == L.ld && direct_env;
+  if (!direct) VB_TRY(mvt_join_inverse(ctx));
+  if (direct) {
+    const double* rs = noise_rows ? (const double*)(base + L.o_invs) : nullptr;
+    hipLaunchKernelGGL(mvt_wsums_kernel, dim3(1), dim3(1024), 0, st, wdev, (const double*)(base + L.o_lq), n, S.sums + 1);
+    hipLaunchKernelGGL(mvt_scale_colsum_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)L.n_rb), dim3(256), 0, st, Y, L.ld, n,
+                       (int)d, wdev, cn, rs, base + L.o_ua, base + L.o_col);
+    VB_HIP(ctx, hipGetLastError());
+    VB_TRY(gram_lower_enqueue(ctx, base + L.o_ua, Y, L.ld, (int)d, n, L.splits, base + L.o_cpart, L.ld, slab));
+    VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col, L.n_rb, L.ld, fpart, 0, S,
+                             true));
+  } else {
   // U = E' L^-1
   GemmArgs g;
-  g.A = ctx->mvt_e_noise ? ctx->mvt_e_noise : base + L.o_e;
-  g.lda = ctx->mvt_e_noise ? ctx->mvt_e_noise_ld : L.ld;
+  g.A = Y;
+  g.lda = ldy;
   g.B = base + L.o_li;
   g.ldb = L.ld;
   g.M = (int)n;
   g.N = (int)d;
   g.K = (int)d;
   g.tri_mode = 3;          // L^-1 is lower triangular: B[k][j] == 0 for k < j -- half the product
-  FrSums S = L.S;
-  S.sums = base + L.o_sums;
   // (sum w, sum w log q) ride in slots 1 and 2 of the sum vector so that one all-reduce covers everything; U and its
   // row-scaled copy a_n U (a_n = w_n c_n, c_n left behind by the residual pass) leave the GEMM together
-  const int64_t n_part = (n + 3) / 4;
-  const double* cn = base + L.o_part;       // n doubles, written by mvt_rows_kernel
   hipLaunchKernelGGL(mvt_wsums_kernel, dim3(1), dim3(1024), 0, st, wdev, (const double*)(base + L.o_lq), n, S.sums + 1);
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiStoreScaled{base + L.o_u, base + L.o_ua, L.ld, wdev, cn,
-                                                       ctx->mvt_e_noise ? (const double*)(base + L.o_invs) : nullptr});
+                                                       noise_rows ? (const double*)(base + L.o_invs) : nullptr});
   VB_HIP(ctx, hipGetLastError());
-  double* fpart = base + L.o_part + n + 2 * n_part;
-  const int64_t slab = d * L.ld;
   // weighted Gram product U' diag(a) U (lower tiles) with the column sums of a U out of the same kernel
   bool cs_fused = false;
   VB_TRY(gram_lower_colsum_enqueue(ctx, base + L.o_ua, base + L.o_u, L.ld, (int)d, n, L.splits, base + L.o_cpart, L.ld,
@@ -1041,26 +1233,72 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col,
                            cs_fused ? L.splits : L.n_rb, L.ld, fpart,
                            cs_fused ? 0 : L.n_rb * (int)((d + 127) / 128), S, packed_out != nullptr));
+  }
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
   if (packed_out) {
     // S = sym(gram), dL = tril(S L) - w_sum diag(1 / L_ii), free diagonal x L_ii: one D x D x D product and a pack kernel
     const int D = (int)d;
+    VB_TRY(mvt_join_inverse(ctx));
     GemmArgs gs;
-    gs.A = S.sums + S.off_c;
+    gs.A = direct ? base + L.o_wt : S.sums + S.off_c;      // direct: L^-T M instead of S L
     gs.lda = L.ld;
-    gs.B = base + L.o_lfull;
+    gs.B = direct ? S.sums + S.off_c : base + L.o_lfull;
     gs.ldb = L.ld;
     gs.M = D;
     gs.N = D;
     gs.K = D;
     gs.tri_mode = 0;
     gemm_f64_launch<true>(st, gs, 1, n_cu, EpiStore{base + L.o_sl, L.ld});
-    hipLaunchKernelGGL(mvt_pack_grad_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
-                       (const double*)(base + L.o_sl), (const double*)(base + L.o_lfull), L.ld, D,
-                       (const double*)S.sums, S.off_col, scale, base + L.o_grad, scale_dev,
-                       (const double*)(base + L.o_scal + 8));
-    VB_HIP(ctx, hipGetLastError());
     const size_t plen = (size_t)(d + d * (d + 1) / 2);
+    // Blocking step on one rank: the pack kernel writes [value | gradient | scalars] into MAPPED host memory and signals
+    // through a completion word; the host polls it (a wake-up through hipStreamSynchronize costs tens of microseconds
+    // behind a ~0.3 ms step, and a device-to-pageable copy adds a staging kernel and its own wait) and copies the
+    // gradient into the caller's array.  VB_MVT_FLAGSYNC=0: the copy + stream synchronisation of round 4.
+    static const bool flag_env = [] {
+      const char* e = getenv("VB_MVT_FLAGSYNC");
+      return !(e && atoi(e) == 0);
+    }();
+    const bool flagged = grad_direct && flag_env && ctx->n_ranks == 1;
+    if (flagged) {
+      const size_t need = 1 + plen + 8 + 8;      // ... | completion word (its own 64 bytes)
+      if (ctx->mvt_out_doubles < need) {
+        if (ctx->mvt_out_host) {
+          VB_HIP(ctx, hipStreamSynchronize(st));
+          VB_HIP(ctx, hipHostFree(ctx->mvt_out_host));
+          ctx->mvt_out_host = nullptr;
+        }
+        VB_HIP(ctx, hipHostMalloc((void**)&ctx->mvt_out_host, need * sizeof(double), hipHostMallocMapped));
+        memset(ctx->mvt_out_host, 0, need * sizeof(double));
+        VB_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->mvt_out_dev, ctx->mvt_out_host, 0));
+        ctx->mvt_out_doubles = need;
+      }
+      VB_TRY(ensure(ctx, ctx->mvt_ticket, 64));      // (ensure() zero-fills a new allocation; the kernel leaves it zero)
+    }
+    const size_t o_done = ctx->mvt_out_doubles - 8;
+    const unsigned long long seq = flagged ? ++ctx->mvt_done_seq : 0;
+    hipLaunchKernelGGL(mvt_pack_grad_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256 + (direct ? (D + 3) / 4 : 0))), dim3(256), 0, st,
+                       (const double*)(base + L.o_sl), (const double*)(base + L.o_lfull), L.ld, D,
+                       (const double*)S.sums, S.off_col, scale, flagged ? ctx->mvt_out_dev : base + L.o_grad, scale_dev,
+                       (const double*)(base + L.o_scal + 8), direct ? (const double*)(base + L.o_wt) : (const double*)nullptr,
+                       flagged ? (unsigned*)ctx->mvt_ticket.ptr : (unsigned*)nullptr,
+                       flagged ? (unsigned long long*)(ctx->mvt_out_dev + o_done) : (unsigned long long*)nullptr, seq);
+    VB_HIP(ctx, hipGetLastError());
+    if (flagged) {
+      volatile unsigned long long* word = (volatile unsigned long long*)(ctx->mvt_out_host + o_done);
+      bool seen = false;
+      for (unsigned spins = 0; spins < 2000000u && !seen; ++spins) {      // ~10 ms, then the stream
+        seen = *word == seq;
+        if (!seen) __builtin_ia32_pause();
+      }
+      if (!seen) VB_HIP(ctx, hipStreamSynchronize(st));
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      const double* o = ctx->mvt_out_host;
+      memcpy(grad_direct, o + 1, plen * sizeof(double));
+      packed_out[0] = o[1 + plen + 4];
+      if (res_out)
+        for (int q = 0; q < 4; ++q) res_out[q] = o[1 + plen + q];
+      return VB_OK;
+    }
     if (grad_direct) {       // gradient into the caller's array, the five scalars in one small copy (no host staging)
       double tail[5];
       VB_HIP(ctx, hipMemcpyAsync(grad_direct, base + L.o_grad + 1, plen * sizeof(double), hipMemcpyDeviceToHost, st));
