@@ -452,14 +452,12 @@ __global__ void __launch_bounds__(256) mvt_prep_kernel(const double* __restrict_
 
 // packed gradient of -scale sum_n w_n log q(x_n; theta): d/dmu from the column sums, d/dL = tril(S L)
 // - w_sum tril(L^-T) (only the diagonal 1 / L_ii of the upper-triangular L^-T survives), free diagonal x L_ii
-// `out` may be mapped host memory (the blocking step): then `done` is a mapped completion word, `ticket` a device
-// counter (zero between launches) -- every workgroup publishes its stores system-wide and draws a ticket, the last one
-// stores `seq` into the word, and the host polls it instead of waking up through hipStreamSynchronize (vb_ctx::done_host).
-__device__ __forceinline__ void mvt_pack_grad_body(const double* __restrict__ SL, const double* __restrict__ Lfull,
-                                                   int64_t ld, int d, const double* __restrict__ sums, int64_t off_col,
-                                                   double scale, double* __restrict__ out,
-                                                   const double* __restrict__ scale_dev, const double* __restrict__ res,
-                                                   const double* __restrict__ Wt) {
+__global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __restrict__ SL, const double* __restrict__ Lfull,
+                                                            int64_t ld, int d, const double* __restrict__ sums,
+                                                            int64_t off_col, double scale, double* __restrict__ out,
+                                                            const double* __restrict__ scale_dev,
+                                                            const double* __restrict__ res,
+                                                            const double* __restrict__ Wt = nullptr) {
   if (scale_dev) scale *= scale_dev[0];      // (device-resident resampling: scale = sum w / (N M), sum w on the device)
   const int64_t n_flat = ((int64_t)d * d + 255) / 256;
   if ((int64_t)blockIdx.x >= n_flat) {
@@ -493,17 +491,16 @@ __device__ __forceinline__ void mvt_pack_grad_body(const double* __restrict__ SL
   out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -scale * g;
 }
 
-__global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __restrict__ SL, const double* __restrict__ Lfull,
-                                                            int64_t ld, int d, const double* __restrict__ sums,
-                                                            int64_t off_col, double scale, double* __restrict__ out,
-                                                            const double* __restrict__ scale_dev,
-                                                            const double* __restrict__ res,
-                                                            const double* __restrict__ Wt = nullptr,
-                                                            unsigned* __restrict__ ticket = nullptr,
-                                                            unsigned long long* __restrict__ done = nullptr,
-                                                            unsigned long long seq = 0) {
-  mvt_pack_grad_body(SL, Lfull, ld, d, sums, off_col, scale, out, scale_dev, res, Wt);
-  if (!done) return;
+// The blocking step's results to the host without a copy engine and without a wake-up: `n2` pairs of doubles from device
+// memory into MAPPED host memory by full-width contiguous stores (the packed triangle's rows start at odd offsets: written
+// from the pack kernel itself they cross the bus as partial lines, 35 us for 265 KB), then a completion word -- every
+// workgroup publishes its stores system-wide and draws a ticket (a device counter, zero between launches), the last one
+// stores `seq`; the host polls the word instead of waking up through hipStreamSynchronize (cf. vb_ctx::done_host).
+typedef double mvt_out2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) mvt_copy_out_kernel(const mvt_out2* __restrict__ src, mvt_out2* __restrict__ dst,
+                                                           int64_t n2, unsigned* __restrict__ ticket,
+                                                           unsigned long long* __restrict__ done, unsigned long long seq) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -524,6 +521,12 @@ __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __rest
 // main stream goes on with what needs L' only (the sampling product, the row kernels, the bisection); whoever reads
 // Wt / Li / c calls mvt_join_inverse first.  Thirty-odd microseconds of small dependent launches (a 128 x 128 leaf
 // inversion and two D/2-sized products at D = 256) leave the critical path of a throughput-mode step.
+// (dev / test switches, read per call: VB_MVT_DIRECT, VB_MVT_SIDE_INVERSE, VB_MVT_FLAGSYNC -- "0" turns the round-5 route off)
+static bool mvt_env_on(const char* name) {
+  const char* e = getenv(name);
+  return !(e && atoi(e) == 0);
+}
+
 // The side stream's launches are enqueued LATE (mvt_side_enqueue, called by the refresh once the main stream has its
 // sampling product and row kernels queued): eight API calls ahead of them starve the main queue for ~30 us.
 static int mvt_side_enqueue(vb_ctx* ctx) {
@@ -594,10 +597,7 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   memcpy(ctx->mvt_inv_key, key, sizeof key);
   // (the transposes write every entry of the d x d blocks; the pad columns hold the zeros of the allocation)
   const int tiles = (D + 31) / 32, gx = tiles * tiles > (D + 3) / 4 ? tiles * tiles : (D + 3) / 4;
-  static const bool side_env = [] {
-    const char* e = getenv("VB_MVT_SIDE_INVERSE");
-    return !(e && atoi(e) == 0);
-  }();
+  const bool side_env = mvt_env_on("VB_MVT_SIDE_INVERSE");
   if (defer_inverse && side_env) {
     if (!ctx->mvt_side) {
       VB_HIP(ctx, hipStreamCreateWithFlags(&ctx->mvt_side, hipStreamNonBlocking));
@@ -1191,10 +1191,7 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   // (u_n = L^-T y_n), so the N x D x D product U = E' L^-1 is not formed at all: one pass over Y leaves the scaled
   // operand a_n y_n and the weighted column sums, the Gram product runs on Y itself, and L^-T enters once, in the
   // D x D x D product of the chain rule (where L used to).  VB_MVT_DIRECT=0: the route through U.
-  static const bool direct_env = [] {
-    const char* e = getenv("VB_MVT_DIRECT");
-    return !(e && atoi(e) == 0);
-  }();
+  const bool direct_env = mvt_env_on("VB_MVT_DIRECT");
   const bool direct = packed_out != nullptr && ldy == L.ld && direct_env;
   if (!direct) VB_TRY(mvt_join_inverse(ctx));
   if (direct) {
@@ -1254,13 +1251,10 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     // through a completion word; the host polls it (a wake-up through hipStreamSynchronize costs tens of microseconds
     // behind a ~0.3 ms step, and a device-to-pageable copy adds a staging kernel and its own wait) and copies the
     // gradient into the caller's array.  VB_MVT_FLAGSYNC=0: the copy + stream synchronisation of round 4.
-    static const bool flag_env = [] {
-      const char* e = getenv("VB_MVT_FLAGSYNC");
-      return !(e && atoi(e) == 0);
-    }();
+    const bool flag_env = mvt_env_on("VB_MVT_FLAGSYNC");
     const bool flagged = grad_direct && flag_env && ctx->n_ranks == 1;
     if (flagged) {
-      const size_t need = 1 + plen + 8 + 8;      // ... | completion word (its own 64 bytes)
+      const size_t need = (1 + plen + 8 + 1) / 2 * 2 + 8;      // ... | completion word (its own 64 bytes)
       if (ctx->mvt_out_doubles < need) {
         if (ctx->mvt_out_host) {
           VB_HIP(ctx, hipStreamSynchronize(st));
@@ -1278,12 +1272,16 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     const unsigned long long seq = flagged ? ++ctx->mvt_done_seq : 0;
     hipLaunchKernelGGL(mvt_pack_grad_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256 + (direct ? (D + 3) / 4 : 0))), dim3(256), 0, st,
                        (const double*)(base + L.o_sl), (const double*)(base + L.o_lfull), L.ld, D,
-                       (const double*)S.sums, S.off_col, scale, flagged ? ctx->mvt_out_dev : base + L.o_grad, scale_dev,
-                       (const double*)(base + L.o_scal + 8), direct ? (const double*)(base + L.o_wt) : (const double*)nullptr,
-                       flagged ? (unsigned*)ctx->mvt_ticket.ptr : (unsigned*)nullptr,
-                       flagged ? (unsigned long long*)(ctx->mvt_out_dev + o_done) : (unsigned long long*)nullptr, seq);
+                       (const double*)S.sums, S.off_col, scale, base + L.o_grad, scale_dev,
+                       (const double*)(base + L.o_scal + 8), direct ? (const double*)(base + L.o_wt) : (const double*)nullptr);
     VB_HIP(ctx, hipGetLastError());
     if (flagged) {
+      const int64_t n2 = (int64_t)(1 + plen + 8) / 2;
+      const unsigned blocks = (unsigned)((n2 + 1023) / 1024 < 1 ? 1 : (n2 + 1023) / 1024);      // four pairs per thread
+      hipLaunchKernelGGL(mvt_copy_out_kernel, dim3(blocks), dim3(256), 0, st, (const mvt_out2*)(base + L.o_grad),
+                         (mvt_out2*)ctx->mvt_out_dev, n2, (unsigned*)ctx->mvt_ticket.ptr,
+                         (unsigned long long*)(ctx->mvt_out_dev + o_done), seq);
+      VB_HIP(ctx, hipGetLastError());
       volatile unsigned long long* word = (volatile unsigned long long*)(ctx->mvt_out_host + o_done);
       bool seen = false;
       for (unsigned spins = 0; spins < 2000000u && !seen; ++spins) {      // ~10 ms, then the stream
