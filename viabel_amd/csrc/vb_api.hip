@@ -58,6 +58,153 @@ int ensure_pinned(vb_ctx* ctx, size_t bytes) {
   return VB_OK;
 }
 
+// ---- small results to the host without a copy engine and without a wake-up ------------------------------------------------
+// A blocking call that ends in hipMemcpyAsync(pageable destination) + hipStreamSynchronize pays a staging kernel, a second
+// wait and an interrupt-driven wake-up: 40-50 us behind a 0.3 ms step (measured on the multivariate-t DIS step, C3 shape:
+// 0.32 -> 0.27 ms).  fetch_blocking() gathers up to eight device segments into MAPPED host memory with one kernel
+// (contiguous full-width stores: whole lines on the bus), whose last workgroup -- a ticket counter, zero between launches --
+// stores a sequence number into a completion word behind a system-scope fence; the host polls the word and copies the
+// segments out.  Above kFetchMaxBytes (the host-side copy out of the mapped buffer costs more than the runtime's pinned
+// DMA then) and with VB_FETCH_FLAGSYNC=0 it is the plain copies + synchronisation.
+constexpr size_t kFetchMaxBytes = (size_t)1 << 20;
+constexpr int kFetchMaxSegs = 8;
+struct FetchArgs {
+  const unsigned long long* src[kFetchMaxSegs];
+  long long first[kFetchMaxSegs + 1];      // first word of segment k in the mapped buffer (64-byte aligned); [n] = total
+  long long words[kFetchMaxSegs];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) fetch_copy_kernel(FetchArgs a, unsigned long long* __restrict__ dst,
+                                                         unsigned* __restrict__ ticket, unsigned long long* __restrict__ done,
+                                                         unsigned long long seq) {
+  for (int k = 0; k < a.n; ++k) {
+    const unsigned long long* __restrict__ src = a.src[k];
+    unsigned long long* __restrict__ out = dst + a.first[k];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.words[k]; i += (long long)gridDim.x * 256)
+      out[i] = src[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs) {
+  size_t total = 0;
+  bool ok = n_segs <= kFetchMaxSegs;
+  for (int k = 0; k < n_segs; ++k) {
+    ok = ok && segs[k].bytes % 8 == 0 && ((uintptr_t)segs[k].src & 7) == 0;
+    total += (segs[k].bytes + 63) / 64 * 64;
+  }
+  const char* e = getenv("VB_FETCH_FLAGSYNC");
+  if (!ok || total > kFetchMaxBytes || (e && atoi(e) == 0)) {
+    for (int k = 0; k < n_segs; ++k)
+      if (segs[k].bytes)
+        VB_HIP(ctx, hipMemcpyAsync(segs[k].dst, segs[k].src, segs[k].bytes, hipMemcpyDeviceToHost, st));
+    VB_HIP(ctx, hipStreamSynchronize(st));
+    return comm_check(ctx);
+  }
+  const size_t need = total + 64;      // ... | completion word (a line of its own)
+  if (ctx->fetch_bytes < need) {
+    if (ctx->fetch_host) {
+      VB_TRY(sync_streams(ctx));
+      VB_HIP(ctx, hipHostFree(ctx->fetch_host));
+      ctx->fetch_host = nullptr;
+      ctx->fetch_bytes = 0;
+    }
+    const size_t cap = need < (size_t)1 << 16 ? (size_t)1 << 16 : need;
+    VB_HIP(ctx, hipHostMalloc((void**)&ctx->fetch_host, cap, hipHostMallocMapped));
+    memset(ctx->fetch_host, 0, cap);
+    VB_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->fetch_dev, ctx->fetch_host, 0));
+    ctx->fetch_bytes = cap;
+  }
+  VB_TRY(ensure(ctx, ctx->fetch_ticket, 64));      // (zero-filled when new; the kernel leaves it zero)
+  FetchArgs a;
+  a.n = n_segs;
+  long long at = 0;
+  for (int k = 0; k < n_segs; ++k) {
+    a.src[k] = (const unsigned long long*)segs[k].src;
+    a.first[k] = at;
+    a.words[k] = (long long)(segs[k].bytes / 8);
+    at += (long long)((segs[k].bytes + 63) / 64 * 8);
+  }
+  a.first[n_segs] = at;
+  unsigned long long* hostw = (unsigned long long*)ctx->fetch_host;
+  unsigned long long* devw = (unsigned long long*)ctx->fetch_dev;
+  const size_t o_done = ctx->fetch_bytes / 8 - 8;
+  const unsigned long long seq = ++ctx->fetch_seq;
+  long long blocks = (at + 1023) / 1024;      // ~four words per thread
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(fetch_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, devw, (unsigned*)ctx->fetch_ticket.ptr,
+                     devw + o_done, seq);
+  VB_HIP(ctx, hipGetLastError());
+  volatile unsigned long long* word = hostw + o_done;
+  bool seen = false;
+  for (unsigned spins = 0; spins < 2000000u && !seen; ++spins) {      // ~10 ms, then the stream
+    seen = *word == seq;
+    if (!seen) __builtin_ia32_pause();
+  }
+  if (!seen) VB_HIP(ctx, hipStreamSynchronize(st));
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int k = 0; k < n_segs; ++k)
+    if (segs[k].bytes) memcpy(segs[k].dst, hostw + a.first[k], segs[k].bytes);
+  return comm_check(ctx);
+}
+
+// The other direction: `bytes` of a caller-owned (pageable) host array into device memory without a synchronisation -- the
+// bytes are copied into one of two mapped staging slots (an event behind each slot's reader guards its reuse) and a
+// kernel reads them across the bus.  The runtime's own pageable path stages too, but then the call has to wait for the
+// stream (the caller may rewrite its array as soon as we return).  Above kFetchMaxBytes: copy + synchronisation.
+__global__ void __launch_bounds__(256) push_copy_kernel(const unsigned long long* __restrict__ src,
+                                                        unsigned long long* __restrict__ dst, long long words) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, void* dev_dst) {
+  const char* e = getenv("VB_FETCH_FLAGSYNC");
+  if (bytes % 8 != 0 || bytes > kFetchMaxBytes || ((uintptr_t)dev_dst & 7) != 0 || (e && atoi(e) == 0)) {
+    VB_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st));
+    VB_HIP(ctx, hipStreamSynchronize(st));      // caller keeps ownership of `host_src`
+    return VB_OK;
+  }
+  if (ctx->push_bytes < bytes) {
+    if (ctx->push_host) {
+      VB_TRY(sync_streams(ctx));
+      VB_HIP(ctx, hipHostFree(ctx->push_host));
+      ctx->push_host = nullptr;
+      ctx->push_bytes = 0;
+    }
+    const size_t cap = bytes < (size_t)1 << 16 ? (size_t)1 << 16 : (bytes + 63) / 64 * 64;
+    VB_HIP(ctx, hipHostMalloc((void**)&ctx->push_host, 2 * cap, hipHostMallocMapped));
+    VB_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->push_dev, ctx->push_host, 0));
+    ctx->push_bytes = cap;
+  }
+  ctx->push_slot ^= 1;
+  hipEvent_t& ev = ctx->push_ev[ctx->push_slot];
+  if (!ev) VB_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  else VB_HIP(ctx, hipEventSynchronize(ev));
+  char* slot = (char*)ctx->push_host + (size_t)ctx->push_slot * ctx->push_bytes;
+  memcpy(slot, host_src, bytes);
+  const long long words = (long long)(bytes / 8);
+  long long blocks = (words + 1023) / 1024;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(push_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                     (const unsigned long long*)((char*)ctx->push_dev + (size_t)ctx->push_slot * ctx->push_bytes),
+                     (unsigned long long*)dev_dst, words);
+  VB_HIP(ctx, hipGetLastError());
+  VB_HIP(ctx, hipEventRecord(ev, st));
+  return VB_OK;
+}
+
 int sync_streams(vb_ctx* ctx) {
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->pipe.pre) {
@@ -240,10 +387,13 @@ int vb_destroy(vb_ctx* ctx) {
   for (DeviceBuffer* b : {&ctx->model_params, &ctx->theta, &ctx->workspace, &ctx->sums, &ctx->out,
                           &ctx->scratch, &ctx->scratch2, &ctx->rowvec, &ctx->fr_work, &ctx->fr_theta,
                           &ctx->fr_out, &ctx->dis_state, &ctx->mvt_state, &ctx->lg_work, &ctx->user_params, &ctx->psis_lw, &ctx->psis_work, &ctx->rows_work,
-                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items, &ctx->legacy_work, &ctx->alpha_g, &ctx->mf_one, &ctx->mvt_ticket})
+                          &ctx->lr_work, &ctx->mvt_elbo, &ctx->fit_work, &ctx->glm_work, &ctx->fr_lt, &ctx->bisect_work, &ctx->chi_dev, &ctx->lr_obj, &ctx->gen_geom.buf, &ctx->tri_map, &ctx->mvt_invs, &ctx->temper.buf, &ctx->temper.work, &ctx->fz_words, &ctx->fz_items, &ctx->legacy_work, &ctx->alpha_g, &ctx->mf_one, &ctx->fetch_ticket})
     if (b->ptr) (void)hipFree(b->ptr);
   if (ctx->mvt_pin) (void)hipHostFree(ctx->mvt_pin);
-  if (ctx->mvt_out_host) (void)hipHostFree(ctx->mvt_out_host);
+  if (ctx->fetch_host) (void)hipHostFree(ctx->fetch_host);
+  if (ctx->push_host) (void)hipHostFree(ctx->push_host);
+  for (hipEvent_t e : ctx->push_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->user_host_pin) (void)hipHostFree(ctx->user_host_pin);
   if (ctx->legacy_pin) (void)hipHostFree(ctx->legacy_pin);
   for (hipEvent_t e : ctx->mvt_pin_ev)
@@ -864,9 +1014,8 @@ int vb_psis_smooth(vb_ctx* ctx, const double* lw_in, int64_t n, double reff, dou
   VB_TRY(psis_enqueue(ctx, n, reff));
   double res[4];
   double* lw = (double*)ctx->psis_lw.ptr;
-  VB_HIP(ctx, hipMemcpyAsync(lw_out, lw, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  VB_HIP(ctx, hipMemcpyAsync(res, lw + round_up(n, 16), sizeof res, hipMemcpyDeviceToHost, ctx->stream));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const FetchSeg psis_segs[2] = {{lw, (size_t)n * sizeof(double), lw_out}, {lw + round_up(n, 16), sizeof res, res}};
+  VB_TRY(fetch_blocking(ctx, ctx->stream, psis_segs, 2));
   // (the multi-workgroup kernel poisons its results with NaN when a workgroup did not reach a grid barrier within the
   // poll bound: k-hat and the tail count both NaN)
   if (res[0] != res[0] && res[1] != res[1])
@@ -1137,9 +1286,7 @@ int vb_fullrank_set_theta(vb_ctx* ctx, const double* theta, int64_t d) {
   VB_TRY(ensure(ctx, ctx->fr_theta, (size_t)p * sizeof(double)));
   VB_TRY(ensure(ctx, ctx->fr_out, (size_t)(1 + p) * sizeof(double)));
   VB_TRY(main_stream_write(ctx));   // epilogues still in flight on `post` read the old parameter
-  VB_HIP(ctx, hipMemcpyAsync(ctx->fr_theta.ptr, theta, (size_t)p * sizeof(double), hipMemcpyHostToDevice,
-                             ctx->stream));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller keeps ownership of `theta`
+  VB_TRY(push_small(ctx, ctx->stream, theta, (size_t)p * sizeof(double), ctx->fr_theta.ptr));   // caller keeps `theta`
   ctx->fr_p = p;
   ctx->fr_lt_d = 0;                                 // the unpacked copy (mu, L') is stale
   return VB_OK;
@@ -1165,15 +1312,12 @@ int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p) {
   if (p != ctx->fr_p || !ctx->fr_out.ptr) return fail(ctx, VB_ERR_STATE, "no full-rank result of length %lld", (long long)p);
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));   // a sharded evaluation finishes on `post`
-  VB_HIP(ctx, hipMemcpyAsync(value, ctx->fr_out.ptr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  VB_HIP(ctx, hipMemcpyAsync(grad, (const double*)ctx->fr_out.ptr + 1, (size_t)p * sizeof(double),
-                             hipMemcpyDeviceToHost, ctx->stream));
-  unsigned fz_err = 0;       // fused evaluation (vb_fullrank_fused.h): a dependency poll that gave up
-  if (ctx->fz_words.ptr)
-    VB_HIP(ctx, hipMemcpyAsync(&fz_err, (const unsigned*)ctx->fz_words.ptr + 1, sizeof fz_err, hipMemcpyDeviceToHost,
-                               ctx->stream));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  VB_TRY(comm_check(ctx));
+  unsigned fz_pair[2] = {0, 0};       // fused evaluation (vb_fullrank_fused.h): [1] = a dependency poll that gave up
+  const FetchSeg segs[3] = {{ctx->fr_out.ptr, sizeof(double), value},
+                            {(const double*)ctx->fr_out.ptr + 1, (size_t)p * sizeof(double), grad},
+                            {ctx->fz_words.ptr, sizeof fz_pair, fz_pair}};
+  VB_TRY(fetch_blocking(ctx, ctx->stream, segs, ctx->fz_words.ptr ? 3 : 2));      // (plain copies above 1 MB; comm_check inside)
+  const unsigned fz_err = fz_pair[1];
   if (fz_err) {
     VB_HIP(ctx, hipMemsetAsync(ctx->fz_words.ptr, 0, 2 * sizeof(unsigned), ctx->stream));
     return fail(ctx, VB_ERR_STATE, "fused full-rank evaluation: a tile gave up waiting for its input (results invalid)");

@@ -187,11 +187,16 @@ struct vb_ctx {
   size_t mvt_pin_doubles = 0;
   int mvt_pin_slot = 0;
   hipEvent_t mvt_pin_ev[2] = {nullptr, nullptr};   // recorded behind each slot's staged copy; waited for before the slot is rewritten
-  double* mvt_out_host = nullptr;       // mapped host memory the blocking step's pack kernel writes [value | grad | scalars |
-  double* mvt_out_dev = nullptr;        // completion word] into (mvt_dis_grad), and its device address
-  size_t mvt_out_doubles = 0;
-  unsigned long long mvt_done_seq = 0;
-  vb::DeviceBuffer mvt_ticket;          // the pack kernel's workgroup ticket (zero between launches)
+  void* push_host = nullptr;            // two mapped staging slots of push_small (vb_api.hip) and their device address
+  void* push_dev = nullptr;
+  size_t push_bytes = 0;                // ... per slot
+  int push_slot = 0;
+  hipEvent_t push_ev[2] = {nullptr, nullptr};
+  void* fetch_host = nullptr;           // mapped host memory of fetch_blocking (vb_api.hip): segments | completion word,
+  void* fetch_dev = nullptr;            // and its device address
+  size_t fetch_bytes = 0;
+  unsigned long long fetch_seq = 0;
+  vb::DeviceBuffer fetch_ticket;        // the copy kernel's workgroup ticket (zero between launches)
   hipStream_t mvt_side = nullptr;       // side stream of the deferred triangular inverse (mvt_factors_device)
   hipEvent_t mvt_ev_fork = nullptr, mvt_ev_join = nullptr;
   bool mvt_inv_pending = false;         // the main stream has not yet waited for the side stream's inverse
@@ -432,6 +437,16 @@ int psis_tail_size(int64_t n, double reff);
 int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, int family, double df,
                   double alpha, const double* theta_src, double* out);
 int sync_streams(vb_ctx* ctx);   // main + pipeline streams
+struct FetchSeg {                  // `bytes` (a multiple of 8) from device address `src` (8-byte aligned) to host address `dst`
+  const void* src;
+  size_t bytes;
+  void* dst;
+};
+// blocking device -> host fetch of small results: one gathering kernel into mapped memory + a polled completion word
+// (vb_api.hip); plain copies + hipStreamSynchronize above 1 MB
+int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs);
+// host -> device copy of a small caller-owned array without a synchronisation (mapped staging slots + a copy kernel)
+int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, void* dev_dst);
 int comm_check(vb_ctx* ctx);     // VB_ERR_COMM when a device-side wait of the IPC transport has given up (vb_comm.hip)
 
 // full-rank Gaussian ExclusiveKL (vb_fullrank.hip)

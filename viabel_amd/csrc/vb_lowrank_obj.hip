@@ -510,9 +510,8 @@ int lr_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, int64_t k, const double* mu, 
   VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d + k, base + L.o_tt + (int64_t)L.col1 * L.ldt + L.col1, 2 * sizeof(double),
                              hipMemcpyDeviceToDevice, st));                                       // sum w, sum w log q
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));
-  VB_HIP(ctx, hipMemcpyAsync(out_host, pack, (size_t)out_len * sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
-  return VB_OK;
+  const FetchSeg seg{pack, (size_t)out_len * sizeof(double), out_host};
+  return fetch_blocking(ctx, st, &seg, 1);
 }
 
 // ---- AlphaDivergence (objectives.py:453-461) ------------------------------------------------------------------
@@ -580,9 +579,8 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
   VB_HIP(ctx, hipMemcpyAsync(tail + d, base + L.o_cs1, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));
   double sc[2];
-  VB_HIP(ctx, hipMemcpyAsync(sc, scal + 8, sizeof sc, hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(out_host, pack, (size_t)out_len * sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
+  const FetchSeg segs[2] = {{scal + 8, sizeof sc, sc}, {pack, (size_t)out_len * sizeof(double), out_host}};
+  VB_TRY(fetch_blocking(ctx, st, segs, 2));
   *wsum_out = sc[1];
   *value_out = log(sc[1] / (double)n_total) / alpha + sc[0];                     // objectives.py:459
   return VB_OK;
@@ -746,11 +744,8 @@ int lr_elbo_sums_any_rank(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz,
                      (int)k, outd);
   VB_HIP(ctx, hipGetLastError());
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, outd, (size_t)n_out));
-  double* stage = ctx->pin_host + p;
-  VB_HIP(ctx, hipMemcpyAsync(stage, outd, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
-  memcpy(out_host, stage, (size_t)n_out * sizeof(double));
-  return VB_OK;
+  const FetchSeg seg{outd, (size_t)n_out * sizeof(double), out_host};
+  return fetch_blocking(ctx, st, &seg, 1);
 }
 
 }  // namespace vb

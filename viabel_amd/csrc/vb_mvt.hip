@@ -491,28 +491,6 @@ __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __rest
   out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -scale * g;
 }
 
-// The blocking step's results to the host without a copy engine and without a wake-up: `n2` pairs of doubles from device
-// memory into MAPPED host memory by full-width contiguous stores (the packed triangle's rows start at odd offsets: written
-// from the pack kernel itself they cross the bus as partial lines, 35 us for 265 KB), then a completion word -- every
-// workgroup publishes its stores system-wide and draws a ticket (a device counter, zero between launches), the last one
-// stores `seq`; the host polls the word instead of waking up through hipStreamSynchronize (cf. vb_ctx::done_host).
-typedef double mvt_out2 __attribute__((ext_vector_type(2)));
-__global__ void __launch_bounds__(256) mvt_copy_out_kernel(const mvt_out2* __restrict__ src, mvt_out2* __restrict__ dst,
-                                                           int64_t n2, unsigned* __restrict__ ticket,
-                                                           unsigned long long* __restrict__ done, unsigned long long seq) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-
 // theta (host) -> device: mu, L' (o_lt), L (o_lfull), Wt = L^-T (o_wt), Li = L^-1 (o_li), c = L^-1 mu (o_c)
 // zero_scal: the refresh's call also clears the 32 scalars the bisection accumulates into (a gradient at another
 // parameter must leave them alone: eps, ess and the status of the refresh live there)
@@ -1247,54 +1225,20 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     gs.tri_mode = 0;
     gemm_f64_launch<true>(st, gs, 1, n_cu, EpiStore{base + L.o_sl, L.ld});
     const size_t plen = (size_t)(d + d * (d + 1) / 2);
-    // Blocking step on one rank: the pack kernel writes [value | gradient | scalars] into MAPPED host memory and signals
-    // through a completion word; the host polls it (a wake-up through hipStreamSynchronize costs tens of microseconds
-    // behind a ~0.3 ms step, and a device-to-pageable copy adds a staging kernel and its own wait) and copies the
-    // gradient into the caller's array.  VB_MVT_FLAGSYNC=0: the copy + stream synchronisation of round 4.
-    const bool flag_env = mvt_env_on("VB_MVT_FLAGSYNC");
-    const bool flagged = grad_direct && flag_env && ctx->n_ranks == 1;
-    if (flagged) {
-      const size_t need = (1 + plen + 8 + 1) / 2 * 2 + 8;      // ... | completion word (its own 64 bytes)
-      if (ctx->mvt_out_doubles < need) {
-        if (ctx->mvt_out_host) {
-          VB_HIP(ctx, hipStreamSynchronize(st));
-          VB_HIP(ctx, hipHostFree(ctx->mvt_out_host));
-          ctx->mvt_out_host = nullptr;
-        }
-        VB_HIP(ctx, hipHostMalloc((void**)&ctx->mvt_out_host, need * sizeof(double), hipHostMallocMapped));
-        memset(ctx->mvt_out_host, 0, need * sizeof(double));
-        VB_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->mvt_out_dev, ctx->mvt_out_host, 0));
-        ctx->mvt_out_doubles = need;
-      }
-      VB_TRY(ensure(ctx, ctx->mvt_ticket, 64));      // (ensure() zero-fills a new allocation; the kernel leaves it zero)
-    }
-    const size_t o_done = ctx->mvt_out_doubles - 8;
-    const unsigned long long seq = flagged ? ++ctx->mvt_done_seq : 0;
     hipLaunchKernelGGL(mvt_pack_grad_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256 + (direct ? (D + 3) / 4 : 0))), dim3(256), 0, st,
                        (const double*)(base + L.o_sl), (const double*)(base + L.o_lfull), L.ld, D,
                        (const double*)S.sums, S.off_col, scale, base + L.o_grad, scale_dev,
                        (const double*)(base + L.o_scal + 8), direct ? (const double*)(base + L.o_wt) : (const double*)nullptr);
     VB_HIP(ctx, hipGetLastError());
-    if (flagged) {
-      const int64_t n2 = (int64_t)(1 + plen + 8) / 2;
-      const unsigned blocks = (unsigned)((n2 + 1023) / 1024 < 1 ? 1 : (n2 + 1023) / 1024);      // four pairs per thread
-      hipLaunchKernelGGL(mvt_copy_out_kernel, dim3(blocks), dim3(256), 0, st, (const mvt_out2*)(base + L.o_grad),
-                         (mvt_out2*)ctx->mvt_out_dev, n2, (unsigned*)ctx->mvt_ticket.ptr,
-                         (unsigned long long*)(ctx->mvt_out_dev + o_done), seq);
-      VB_HIP(ctx, hipGetLastError());
-      volatile unsigned long long* word = (volatile unsigned long long*)(ctx->mvt_out_host + o_done);
-      bool seen = false;
-      for (unsigned spins = 0; spins < 2000000u && !seen; ++spins) {      // ~10 ms, then the stream
-        seen = *word == seq;
-        if (!seen) __builtin_ia32_pause();
-      }
-      if (!seen) VB_HIP(ctx, hipStreamSynchronize(st));
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      const double* o = ctx->mvt_out_host;
-      memcpy(grad_direct, o + 1, plen * sizeof(double));
-      packed_out[0] = o[1 + plen + 4];
+    if (grad_direct && mvt_env_on("VB_MVT_FLAGSYNC")) {
+      // gradient and the five scalars through mapped memory behind a polled completion word (fetch_blocking)
+      double tail[5];
+      const FetchSeg segs[2] = {{base + L.o_grad + 1, plen * sizeof(double), grad_direct},
+                                {base + L.o_grad + 1 + plen, sizeof tail, tail}};
+      VB_TRY(fetch_blocking(ctx, st, segs, 2));
+      packed_out[0] = tail[4];
       if (res_out)
-        for (int q = 0; q < 4; ++q) res_out[q] = o[1 + plen + q];
+        for (int q = 0; q < 4; ++q) res_out[q] = tail[q];
       return VB_OK;
     }
     if (grad_direct) {       // gradient into the caller's array, the five scalars in one small copy (no host staging)
@@ -1519,8 +1463,8 @@ int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, dou
                      (const double*)S.sums, S.off_col, 1.0 / (double)n, ctx->model.c0, base + L.o_grad);
   VB_HIP(ctx, hipGetLastError());
   const size_t plen = (size_t)(1 + d + d * (d + 1) / 2);
-  VB_HIP(ctx, hipMemcpyAsync(value_grad_host, base + L.o_grad, plen * sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
+  const FetchSeg seg{base + L.o_grad, plen * sizeof(double), value_grad_host};
+  VB_TRY(fetch_blocking(ctx, st, &seg, 1));
   if (info) info[0] = rinfo[0], info[1] = rinfo[2], info[2] = xinfo[0], info[3] = xinfo[2];
   return VB_OK;
 }
