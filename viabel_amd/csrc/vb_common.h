@@ -497,7 +497,8 @@ int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ld
                       const double* ivar, double* colpart, double* fpart, const double* roww = nullptr,
                       int square = 0);   // square: column sums of the squared entries
 int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab, int d, int64_t ldl,
-                      const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S, bool mirror = false);
+                      const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S, bool mirror = false,
+                      const double* wpart = nullptr);
 // lower triangle of C = A' B for k-major A, B (n x d, row stride ld), split over n into `splits` slabs
 int lr_elbo_sums_any_rank(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t n, int64_t d, int64_t k,
                           const double* theta_host, double* out_host);

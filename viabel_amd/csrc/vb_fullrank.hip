@@ -363,7 +363,8 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
                                                         int64_t slab, int d, int64_t ldl,
                                                         const double* __restrict__ colpart, int n_rb,
                                                         int64_t ldz, const double* __restrict__ fpart,
-                                                        int n_fpart, FrSums S, int full) {
+                                                        int n_fpart, FrSums S, int full,
+                                                        const double* __restrict__ wpart = nullptr) {
   __shared__ double sh[4];
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t idx = 2 * tid;
@@ -421,6 +422,14 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
     for (int e = threadIdx.x; e < n_fpart; e += 256) f += fpart[e];
     f = fr_block_sum(f, sh);
     if (threadIdx.x == 0) S.sums[0] = f;
+    if (wpart) {      // two more scalars given as per-row-block partials (wpart[q n_rb + rb]) -> sums[1], sums[2]
+      for (int q = 0; q < 2; ++q) {
+        double t = 0.0;
+        for (int e = threadIdx.x; e < n_rb; e += 256) t += wpart[(int64_t)q * n_rb + e];
+        t = fr_block_sum(t, sh);
+        if (threadIdx.x == 0) S.sums[1 + q] = t;
+      }
+    }
   }
 }
 
@@ -877,10 +886,11 @@ int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ld
 }
 
 int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab, int d, int64_t ldl,
-                      const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S, bool mirror) {
+                      const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S, bool mirror,
+                      const double* wpart) {
   const int64_t items = slab / 2 > ldz ? slab / 2 : ldz;
   hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, Cpart,
-                     splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S, mirror ? 2 : 0);
+                     splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S, mirror ? 2 : 0, wpart);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }

@@ -170,9 +170,10 @@ typedef double mvt_d2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) mvt_scale_colsum_kernel(const double* __restrict__ Y, int64_t ld, int64_t n, int d,
                                                                const double* __restrict__ w, const double* __restrict__ cn,
                                                                const double* __restrict__ r, double* __restrict__ YA,
-                                                               double* __restrict__ colpart) {
+                                                               double* __restrict__ colpart,
+                                                               const double* __restrict__ lq, double* __restrict__ wpart) {
   __shared__ mvt_d2 cs[8][32];
-  __shared__ double a_s[128], r_s[128];
+  __shared__ double a_s[128], r_s[128], ws[2][2];
   const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
   const int col = blockIdx.x * 64 + 2 * c;
   const int64_t r0 = (int64_t)blockIdx.y * 128;
@@ -186,8 +187,17 @@ __global__ void __launch_bounds__(256) mvt_scale_colsum_kernel(const double* __r
     }
     a_s[threadIdx.x] = av;
     r_s[threadIdx.x] = rv;
+    if (blockIdx.x == 0) {
+      // (sum w, sum w log q) of the block's rows -- wpart[rb], wpart[n_rb + rb]; fr_reduce_kernel adds the blocks in order
+      // (they were a one-workgroup kernel of their own, 5-7 us on the step's critical path)
+      const double wv = row < n ? w[row] : 0.0;
+      const double s0 = mvt_wave_sum(wv), s1 = mvt_wave_sum(row < n ? wv * lq[row] : 0.0);
+      if ((threadIdx.x & 63) == 0) ws[0][threadIdx.x >> 6] = s0, ws[1][threadIdx.x >> 6] = s1;
+    }
   }
   __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < 2)
+    wpart[(int64_t)threadIdx.x * gridDim.y + blockIdx.y] = ws[threadIdx.x][0] + ws[threadIdx.x][1];
   mvt_d2 s = (mvt_d2){0.0, 0.0};
   if (ok0) {
 #pragma unroll
@@ -1174,13 +1184,13 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   if (!direct) VB_TRY(mvt_join_inverse(ctx));
   if (direct) {
     const double* rs = noise_rows ? (const double*)(base + L.o_invs) : nullptr;
-    hipLaunchKernelGGL(mvt_wsums_kernel, dim3(1), dim3(1024), 0, st, wdev, (const double*)(base + L.o_lq), n, S.sums + 1);
+    double* wpart = base + L.o_part + n;      // 2 n_rb doubles: the scale pass's (sum w, sum w log q) per row block
     hipLaunchKernelGGL(mvt_scale_colsum_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)L.n_rb), dim3(256), 0, st, Y, L.ld, n,
-                       (int)d, wdev, cn, rs, base + L.o_ua, base + L.o_col);
+                       (int)d, wdev, cn, rs, base + L.o_ua, base + L.o_col, (const double*)(base + L.o_lq), wpart);
     VB_HIP(ctx, hipGetLastError());
     VB_TRY(gram_lower_enqueue(ctx, base + L.o_ua, Y, L.ld, (int)d, n, L.splits, base + L.o_cpart, L.ld, slab));
     VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col, L.n_rb, L.ld, fpart, 0, S,
-                             true));
+                             true, wpart));
   } else {
   // U = E' L^-1
   GemmArgs g;
