@@ -401,7 +401,6 @@ int vb_destroy(vb_ctx* ctx) {
   if (ctx->mvt_side) {
     (void)hipStreamSynchronize(ctx->mvt_side);
     (void)hipStreamDestroy(ctx->mvt_side);
-    (void)hipEventDestroy(ctx->mvt_ev_fork);
     (void)hipEventDestroy(ctx->mvt_ev_join);
   }
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);

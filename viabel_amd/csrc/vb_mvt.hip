@@ -589,10 +589,10 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   if (defer_inverse && side_env) {
     if (!ctx->mvt_side) {
       VB_HIP(ctx, hipStreamCreateWithFlags(&ctx->mvt_side, hipStreamNonBlocking));
-      VB_HIP(ctx, hipEventCreateWithFlags(&ctx->mvt_ev_fork, hipEventDisableTiming));
       VB_HIP(ctx, hipEventCreateWithFlags(&ctx->mvt_ev_join, hipEventDisableTiming));
     }
-    VB_HIP(ctx, hipEventRecord(ctx->mvt_ev_fork, st));           // behind the unpack (and everything of earlier calls)
+    // (the fork: the staging slot's event, recorded right behind the unpack above -- no event of its own)
+    ctx->mvt_ev_fork = slot_ev;
     auto& a = ctx->mvt_inv_args;
     a.base = base, a.o_theta = L.o_theta, a.o_lt = L.o_lt, a.o_wt = L.o_wt, a.o_tscr = L.o_tscr, a.o_mu = L.o_mu;
     a.o_li = L.o_li, a.o_lfull = L.o_lfull, a.o_c = L.o_c, a.ld = L.ld, a.d = D, a.clean = clean;
