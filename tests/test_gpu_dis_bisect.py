@@ -4,6 +4,11 @@ and against itself with one round only (VB_DIS_ROUNDS=1: the final kernel finish
 three make the reference's comparisons at the reference's midpoints; they differ in the order in which a candidate's
 N weights are summed (two, four and one block), so a decision can flip only where ESS(eps) equals the target to
 rounding: eps agrees to 1e-13 absolute, ESS and the weights to 1e-9 relative.
+
+Round 5: the rounds as ONE resident launch (grid barriers; VB_DIS_RESIDENT=1, opt-in: measured no faster and unsafe when
+processes share a GPU) against the launch chain:
+the same functions on the same partition of the samples -- bit-identical, also when a single round leaves the rest of
+the walk to the final step.
 """
 import os
 
@@ -22,7 +27,7 @@ def vb():
 
 
 def run(vb, D, N, target, its, eps_prev, shift, env):
-    saved = {k: os.environ.get(k) for k in ('VB_DIS_BISECT', 'VB_DIS_ROUNDS')}
+    saved = {k: os.environ.get(k) for k in ('VB_DIS_BISECT', 'VB_DIS_ROUNDS', 'VB_DIS_RESIDENT')}
     for k in saved:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -117,3 +122,24 @@ def test_literal_bisection_on_the_returned_logs(vb):
         guess = (lower + upper) / 2.0
     assert abs(guess - eps) < 1e-9       # log prior is reconstructed to ~1e-13 relative, ESS'(eps) is O(1e3)
     assert abs(ess_at(eps) - obj._ess) < 1e-6 * obj._ess
+
+
+@pytest.mark.parametrize('D,N,target,its,eps_prev,shift', CASES)
+@pytest.mark.parametrize('rounds', [None, '1', '2'])
+def test_resident_launch_equals_launch_chain(vb, D, N, target, its, eps_prev, shift, rounds):
+    extra = {} if rounds is None else {'VB_DIS_ROUNDS': rounds}
+    res = run(vb, D, N, target, its, eps_prev, shift, dict(extra, VB_DIS_RESIDENT='1'))
+    chain = run(vb, D, N, target, its, eps_prev, shift, dict(extra))
+    assert res[0] == chain[0] and res[1] == chain[1]
+    np.testing.assert_array_equal(res[2], chain[2])
+    assert res[3] == chain[3]
+    np.testing.assert_array_equal(res[4], chain[4])
+
+
+def test_resident_launches_back_to_back(vb):
+    """The barrier counter runs on from launch to launch (no reset between them): many refreshes in a row, of two
+    different problems (another table layout re-zeroes it), give what the launch chain gives."""
+    seq = [CASES[0], CASES[2], CASES[0], CASES[11], CASES[13], CASES[2]] * 3
+    got = [run(vb, *c, {'VB_DIS_RESIDENT': '1'})[:2] for c in seq]
+    want = [run(vb, *c, {})[:2] for c in seq]
+    assert got == want

@@ -1232,6 +1232,7 @@ int vb_dis_step_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const d
   *eps = res[0];
   *ess = res[1];
   if (khat) *khat = res[3];
+  if ((int)(res[2]) == 3) return fail(ctx, VB_ERR_STATE, "tempering bisection: a workgroup of the resident kernel did not arrive at a grid barrier (results invalid); VB_DIS_RESIDENT=0 selects the launch chain");
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   return VB_OK;
@@ -1247,6 +1248,7 @@ int vb_dis_scalars_get(vb_ctx* ctx, double out[4]) {
   if (!ctx || !out) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(mvt_dis_scalars_get(ctx, out));
+  if ((int)(out[2]) == 3) return fail(ctx, VB_ERR_STATE, "tempering bisection: a workgroup of the resident kernel did not arrive at a grid barrier (results invalid); VB_DIS_RESIDENT=0 selects the launch chain");
   if ((int)out[2] == 1) return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   return VB_OK;
 }

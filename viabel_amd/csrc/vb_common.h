@@ -218,6 +218,9 @@ struct vb_ctx {
   int64_t chi_n = 0;                    // how many of them are valid (0: none)
   double chi_df = 0.0;
   vb::DeviceBuffer bisect_work;         // DIS tempering bisection: interval / ESS tables of the look-ahead rounds
+  unsigned long long bisect_bar_base = 0;   // the resident bisection kernel's barrier counter before the next launch,
+  size_t bisect_bar_words = 0;              // where in bisect_work it lives (doubles) and for which allocation it was zeroed
+  void* bisect_bar_ptr = nullptr;
   vb::DeviceBuffer mvt_elbo;            // multivariate-t ExclusiveKL: root, mean, row scales
   vb::DeviceBuffer lr_work;             // low-rank Gaussian family: workspace of the streaming pipeline
   vb::DeviceBuffer lr_obj;              // low-rank Gaussian under DIS / alpha: samples, residuals, Woodbury vectors

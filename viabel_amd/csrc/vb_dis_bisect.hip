@@ -522,6 +522,171 @@ __global__ void __launch_bounds__(1024) dis_spec_final_kernel(const double* __re
   }
 }
 
+
+// ---- the same walk as ONE resident launch (round 5) ------------------------------------------------------------------------
+// The rounds above are launches because round r + 1 replays round r's table.  Here the workgroups of one launch -- two per
+// candidate, all resident: checked against the occupancy the runtime reports -- keep the plan in LDS and their first trip
+// of samples in registers, exchange only the result table (write-through agent-scope stores, agent-scope loads: the
+// XCDs' L2s are not coherent with each other) and meet at a grid barrier per round (a counter that runs on from launch
+// to launch: every launch adds exactly G * kBsMaxBarriers, workgroups that leave early add the rest in one step).  Every
+// workgroup replays and plans alike, so all of them see `nothing left to evaluate` in the same round and go on to the
+// final step together: the spare rounds of the launch chain (two launches of ~5 us that normally find the walk
+// finished) do not exist, and a round costs its sums + one barrier instead of a launch's ramp and tail (measured: no
+// gain, see dis_bisect_enqueue -- opt-in).  Same functions,
+// same partition of the samples, same order of every sum: the results are the launch chain's bit for bit
+// (tests/test_gpu_dis_bisect.py runs both).  A workgroup that does not arrive within the poll bound poisons the launch:
+// status 3 in scal_out[2], which the callers turn into VB_ERR_STATE.
+constexpr int kBsMaxBarriers = 8;
+
+__device__ __forceinline__ void bsp_st(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double bsp_ld(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+
+struct BsBarrier {
+  unsigned long long* bar;        // [0] counter, [2] poison
+  unsigned long long target, tag;
+  int g_count, used;
+  __device__ __forceinline__ void wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      target += (unsigned long long)g_count;
+      ++used;
+      atomicAdd(bar, 1ull);
+      int spins = 0;
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 24)) {
+          atomicExch(bar + 2, tag);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
+};
+
+__global__ void __launch_bounds__(1024) dis_spec_resident_kernel(const double* __restrict__ lp, const double* __restrict__ b,
+                                                                 const double* __restrict__ lprior,
+                                                                 const double* __restrict__ scal_in, int64_t n,
+                                                                 double ess_target, int max_its, double eps_prev, int rounds,
+                                                                 double max_eps, double* __restrict__ res,
+                                                                 unsigned long long* __restrict__ bar,
+                                                                 unsigned long long bar_base, double* __restrict__ w,
+                                                                 double* __restrict__ lq_out, double* __restrict__ scal_out,
+                                                                 double* __restrict__ plans_out) {
+  __shared__ double plan[kBsPlan];
+  __shared__ double tab[kBsRes];
+  __shared__ double sh[48];
+  __shared__ double tot[3];
+  const int c = blockIdx.x / kBsParts, part = blockIdx.x % kBsParts;
+  const int64_t per = (n + kBsParts - 1) / kBsParts;
+  const int64_t i_begin = part * per, i_end = i_begin + per < n ? i_begin + per : n;
+  BsSample pre[4];
+  bs_preload(lp, b, lprior, i_begin, i_end, pre);
+  const double sum_ls = scal_in[0];
+  BsBarrier barrier{bar, bar_base, bar_base + 1, (int)gridDim.x, 0};
+  bool have_prev = false;
+  int r = 0;
+  for (; r < rounds; ++r) {
+    if (have_prev) {
+      const double* prev = res + (size_t)(r - 1) * kBsRes;
+      for (int e = threadIdx.x; e < kBsRes; e += blockDim.x) tab[e] = bsp_ld(prev + e);
+      __syncthreads();
+    }
+    if (threadIdx.x < 64) {
+      BsState s;
+      if (have_prev) {
+        s = bs_load_state(plan);
+        bs_walk(s, plan, tab, ess_target, max_its);
+      } else {
+        s.lower = 0.0, s.upper = eps_prev, s.lo2 = s.up2 = 0.0;
+        s.ess_lo = s.ess_up = s.ess_lo2 = s.ess_up2 = NAN;
+        s.level = 0, s.status = 0, s.fin = 0;
+        s.fin_s1 = s.fin_s2 = s.fin_mx = s.fin_eps = 0.0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      bs_build(s, plan, ess_target, max_its);
+    }
+    __syncthreads();
+    if (plans_out && blockIdx.x == 0)      // (development trace, VB_DIS_TRACE: what each round planned)
+      for (int e = threadIdx.x; e < kBsPlan; e += blockDim.x) plans_out[(size_t)r * kBsPlan + e] = plan[e];
+    const int ncand = (int)plan[H_NCAND];
+    if (ncand == 0) break;            // the walk is over (every workgroup finds the same): on to the final step
+    if (c < ncand) {
+      bs_sums<false>(lp, b, lprior, pre, sum_ls, plan[kBsHdr + c], i_begin, i_end, nullptr, nullptr, sh, tot);
+      if (threadIdx.x == 0) {
+        double* out3 = res + (size_t)r * kBsRes + (c * kBsParts + part) * 3;
+        bsp_st(out3, tot[0]);
+        bsp_st(out3 + 1, tot[1]);
+        bsp_st(out3 + 2, tot[2]);
+      }
+    }
+    barrier.wait();
+    have_prev = true;
+  }
+  if (threadIdx.x == 0 && barrier.used < kBsMaxBarriers)
+    atomicAdd(bar, (unsigned long long)(kBsMaxBarriers - barrier.used));
+  if (r == rounds && have_prev) {     // the last round's candidates were evaluated: replay them (state only)
+    const double* prev = res + (size_t)(rounds - 1) * kBsRes;
+    __syncthreads();
+    for (int e = threadIdx.x; e < kBsRes; e += blockDim.x) tab[e] = bsp_ld(prev + e);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      BsState s = bs_load_state(plan);
+      bs_walk(s, plan, tab, ess_target, max_its);
+      __builtin_amdgcn_wave_barrier();
+      if (threadIdx.x == 0) {
+        plan[H_LOWER] = s.lower, plan[H_UPPER] = s.upper;
+        plan[H_LEVEL] = s.level, plan[H_STATUS] = s.status;
+        plan[H_FIN] = s.fin, plan[H_FIN_S1] = s.fin_s1, plan[H_FIN_S2] = s.fin_s2, plan[H_FIN_MX] = s.fin_mx;
+        plan[H_FIN_EPS] = s.fin_eps;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- the final step (dis_spec_final_kernel's, on this grid) ----
+  double lower = plan[H_LOWER], upper = plan[H_UPPER];
+  int level = (int)plan[H_LEVEL], status = (int)plan[H_STATUS];
+  const bool fin = plan[H_FIN] != 0.0;
+  double s1 = plan[H_FIN_S1], s2 = plan[H_FIN_S2], mx = plan[H_FIN_MX];
+  if (!fin) {
+    while (level < max_its) {
+      const double guess = (lower + upper) / 2.0;
+      __syncthreads();
+      bs_sums<false>(lp, b, lprior, nullptr, sum_ls, guess, 0, n, nullptr, nullptr, sh, tot);
+      __syncthreads();
+      if (tot[2] == -INFINITY) status = 1;
+      if (tot[0] * tot[0] / tot[1] > ess_target) upper = guess;
+      else lower = guess;
+      ++level;
+    }
+    __syncthreads();
+    bs_sums<false>(lp, b, lprior, nullptr, sum_ls, (lower + upper) / 2.0, 0, n, nullptr, nullptr, sh, tot);
+    __syncthreads();
+    s1 = tot[0], s2 = tot[1], mx = tot[2];
+  }
+  const double guess = (lower + upper) / 2.0;
+  const int64_t fper = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t f_begin = blockIdx.x * fper, f_end = f_begin + fper < n ? f_begin + fper : n;
+  __syncthreads();
+  if (f_begin < n) bs_sums<true>(lp, b, lprior, nullptr, sum_ls, guess, f_begin, f_end, w, lq_out, sh, tot);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double eps = guess;
+    if (lower == 0.0) eps = 0.0;          // :363-366
+    if (upper == max_eps) eps = max_eps;
+    const bool poisoned = __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == bar_base + 1;
+    scal_out[0] = eps;
+    scal_out[1] = s1 * s1 / s2;
+    scal_out[2] = poisoned ? 3.0 : (double)((status != 0 || mx == -INFINITY) ? 1 : 0);
+  }
+}
+
 }  // namespace
 
 int dis_bisect_lookahead_enqueue(vb_ctx* ctx, const double* lp, const double* b, const double* lprior,
@@ -533,6 +698,7 @@ int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const dou
                        double* scal_out) {
   if (max_its < 0) return fail(ctx, VB_ERR_INVALID, "max_its must be >= 0");
   const char* env = getenv("VB_DIS_BISECT");                // 0: the look-ahead rounds of round 3 (cross-check)
+  if (env && atoi(env) == 0) ctx->bisect_bar_ptr = nullptr;      // (the look-ahead rounds lay the work buffer out their own way)
   if (env && atoi(env) == 0)
     return dis_bisect_lookahead_enqueue(ctx, lp, b, lprior, scal_in, n, eps_prev, ess_target, max_its, w, lq_out, scal_out);
   // rounds: one covers max_its + 1 <= 6 levels outright; the typical 50-level walk is over after three (6, ~20, 50)
@@ -540,7 +706,7 @@ int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const dou
   int rounds = max_its + 1 <= kBsHeapLevels ? 1 : 4 + (max_its > 50 ? (max_its - 50 + kBsPath - 1) / kBsPath : 0);
   if (const char* r = getenv("VB_DIS_ROUNDS")) rounds = atoi(r) > 0 ? atoi(r) : rounds;
   const size_t need = (size_t)rounds * (kBsPlan + kBsRes) * sizeof(double);
-  VB_TRY(ensure(ctx, ctx->bisect_work, need));
+  VB_TRY(ensure(ctx, ctx->bisect_work, need + 64));
   double* plans = (double*)ctx->bisect_work.ptr;
   double* res = plans + (size_t)rounds * kBsPlan;
   hipStream_t st = ctx->stream;
@@ -549,6 +715,47 @@ int dis_bisect_enqueue(vb_ctx* ctx, const double* lp, const double* b, const dou
   const int heap_cands = (1 << (max_its + 1 < kBsHeapLevels ? max_its + 1 : kBsHeapLevels)) - 1;
   int path_cands = max_its + 1 - kBsHeapLevels;
   path_cands = 2 * (path_cands < 1 ? 1 : (path_cands > kBsPath ? kBsPath : path_cands));
+  {
+    // VB_DIS_RESIDENT=1: one resident launch when all its workgroups fit the device at once.  OFF by default -- measured
+    // (C3 shape, MI355X): 36 us against the chain's 39-40 us of kernels, no difference in the call (0.25-0.27 ms both
+    // ways, four A/B runs): a round costs its sums (~1 us) + a 180-workgroup barrier across the XCDs (~3 us) + the table's
+    // reload through agent-scope loads (~2.5 us) + replay and planning (~1.5 us), which is what a queued launch costs
+    // too.  And two PROCESSES sharing a GPU (tests/test_gpu_two_ranks.py) each hold half of the slots the other's grid
+    // waits for: both time out (status 3).  Kept for the record and for tests/test_gpu_dis_bisect.py.
+    const char* re = getenv("VB_DIS_RESIDENT");
+    static int per_cu = -1;
+    if (per_cu < 0) {
+      int nb = 0;
+      per_cu = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dis_spec_resident_kernel, 1024, 0) == hipSuccess ? nb : 0;
+    }
+    const int grid = (heap_cands > path_cands ? heap_cands : path_cands) * kBsParts;
+    if (re && atoi(re) != 0 && rounds <= kBsMaxBarriers && grid <= per_cu * ctx->prop.multiProcessorCount) {
+      const size_t o_bar = (size_t)rounds * (kBsPlan + kBsRes);      // behind the tables: counter | - | poison
+      if (ctx->bisect_bar_words != o_bar || ctx->bisect_bar_ptr != (void*)plans) {      // (a new or re-laid-out allocation)
+        VB_HIP(ctx, hipMemsetAsync(plans + o_bar, 0, 64, st));
+        ctx->bisect_bar_base = 0;
+        ctx->bisect_bar_words = o_bar;
+        ctx->bisect_bar_ptr = (void*)plans;
+      }
+      hipLaunchKernelGGL(dis_spec_resident_kernel, dim3((unsigned)grid), dim3(1024), 0, st, lp, b, lprior, scal_in, n, ess_target,
+                         max_its, eps_prev, rounds, 1.0, res, (unsigned long long*)(plans + o_bar), ctx->bisect_bar_base, w,
+                         lq_out, scal_out, getenv("VB_DIS_TRACE") ? plans : (double*)nullptr);
+      VB_HIP(ctx, hipGetLastError());
+      ctx->bisect_bar_base += (unsigned long long)grid * kBsMaxBarriers;
+      if (getenv("VB_DIS_TRACE")) {
+        std::vector<double> h((size_t)rounds * kBsPlan);
+        VB_HIP(ctx, hipStreamSynchronize(st));
+        VB_HIP(ctx, hipMemcpy(h.data(), plans, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int r = 0; r < rounds; ++r) {
+          const double* q = h.data() + (size_t)r * kBsPlan;
+          fprintf(stderr, "[dis bisect, resident] round %d: level %d mode %d candidates %d len %d div %d fin %d interval [%.17g, %.17g]\n",
+                  r, (int)q[H_LEVEL], (int)q[H_MODE], (int)q[H_NCAND], (int)q[H_LEN_A], (int)q[H_DIV], (int)q[H_FIN], q[H_LOWER],
+                  q[H_UPPER]);
+        }
+      }
+      return VB_OK;
+    }
+  }
   for (int r = 0; r < rounds; ++r) {
     const double* pp = r > 0 ? plans + (size_t)(r - 1) * kBsPlan : nullptr;
     const double* pr = r > 0 ? res + (size_t)(r - 1) * kBsRes : nullptr;

@@ -470,6 +470,7 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
   ctx->lr_k = k;
   ctx->lr_n_total = n_total;
   ++ctx->dis_gen[2];
+  if ((int)(res[2]) == 3) return fail(ctx, VB_ERR_STATE, "tempering bisection: a workgroup of the resident kernel did not arrive at a grid barrier (results invalid); VB_DIS_RESIDENT=0 selects the launch chain");
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   return VB_OK;

@@ -934,6 +934,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   ctx->mvt_n_total = n_total;
   ++ctx->dis_gen[1];
   ctx->mvt_theta.assign(theta_host, theta_host + d + d * (d + 1) / 2);   // the residuals on the device belong to it
+  if ((int)(res[2]) == 3) return fail(ctx, VB_ERR_STATE, "tempering bisection: a workgroup of the resident kernel did not arrive at a grid barrier (results invalid); VB_DIS_RESIDENT=0 selects the launch chain");
   if ((int)res[2] == 1)
     return fail(ctx, VB_ERR_NUMERIC, "All weights zero! Suggests overflow in importance density.");
   return VB_OK;
