@@ -456,13 +456,10 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
   VB_TRY(dis_bisect_enqueue(ctx, base + L.o_f, base + L.o_lq, base + L.o_lpr, base + L.o_scal, n_total, eps_prev,
                             ess_target, max_its, base + L.o_w, base + L.o_lqc, base + L.o_scal + 8));
   double res[3];
-  VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_scal + 8, sizeof res, hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (logp_host)
-    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_f, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (logq_host)
-    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lqc, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
+  const size_t vec = (size_t)n_total * sizeof(double);
+  const FetchSeg segs[4] = {{base + L.o_scal + 8, sizeof res, res}, {base + L.o_w, vec, w_host},
+                            {base + L.o_f, logp_host ? vec : 0, logp_host}, {base + L.o_lqc, logq_host ? vec : 0, logq_host}};
+  VB_TRY(fetch_blocking(ctx, st, segs, 4));
   *eps_out = res[0];
   *ess_out = res[1];
   ctx->lr_n = n;

@@ -920,13 +920,10 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     return VB_OK;
   }
   double res[3];
-  VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_scal + 8, sizeof res, hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (logp_host)
-    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (logq_host)
-    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lq, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
+  const size_t vec = (size_t)n_total * sizeof(double);
+  const FetchSeg segs[4] = {{base + L.o_scal + 8, sizeof res, res}, {base + L.o_w, vec, w_host},
+                            {base + L.o_lp, logp_host ? vec : 0, logp_host}, {base + L.o_lq, logq_host ? vec : 0, logq_host}};
+  VB_TRY(fetch_blocking(ctx, st, segs, 4));
   *eps_out = res[0];
   *ess_out = res[1];
   ctx->mvt_n = n;

@@ -684,8 +684,7 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
     pr[ld + i] = exp(-2.0 * prior_host[d + i]);
     c0p -= prior_host[d + i];
   }
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));   // `pr` is a stack-scoped staging buffer
+  VB_TRY(push_small(ctx, st, pr.data(), pr.size() * sizeof(double), base + L.o_prior));   // (staged: `pr` may go)
   ModelDev prior;
   prior.id = VB_MODEL_GAUSS_DIAG;
   prior.dim = (int)d;
@@ -718,13 +717,10 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
   VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_b, base + L.o_lprior, base + L.o_scal, n_total, eps_prev,
                             ess_target, max_its, base + L.o_w, base + L.o_lq, base + L.o_out));
   double res[3];
-  VB_HIP(ctx, hipMemcpyAsync(res, base + L.o_out, sizeof res, hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipMemcpyAsync(w_host, base + L.o_w, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (logp_host)
-    VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (logq_host)
-    VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lq, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
+  const size_t vec = (size_t)n_total * sizeof(double);
+  const FetchSeg segs[4] = {{base + L.o_out, sizeof res, res}, {base + L.o_w, vec, w_host},
+                            {base + L.o_lp, logp_host ? vec : 0, logp_host}, {base + L.o_lq, logq_host ? vec : 0, logq_host}};
+  VB_TRY(fetch_blocking(ctx, st, segs, 4));
   *eps_out = res[0];
   *ess_out = res[1];
   *status_out = (int)res[2];
@@ -761,8 +757,7 @@ int dis_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int
   if (n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   const DisLayout L = dis_layout(ctx->dis_n_total, ns.ld);
   double* base = (double*)ctx->dis_state.ptr;
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller keeps ownership of w_host
+  VB_TRY(push_small(ctx, ctx->stream, w_host, (size_t)n * sizeof(double), base + L.o_w));   // caller keeps w_host
   ModelDev logq;
   logq.id = kModelLogQ;
   logq.dim = (int)d;
