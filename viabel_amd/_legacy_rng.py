@@ -21,7 +21,10 @@ def _size(shape):
     shape = tuple(int(s) for s in shape)
     if any(s < 0 for s in shape):
         raise ValueError('negative dimensions are not allowed')
-    return shape, int(np.prod(shape, dtype=np.int64)) if shape else 1
+    n = 1
+    for s in shape:      # (np.prod costs microseconds per call: this runs once per objective call at small shapes)
+        n *= s
+    return shape, n
 
 
 class LegacyRandomState:

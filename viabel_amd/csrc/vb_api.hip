@@ -163,15 +163,25 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
 // bytes are copied into one of two mapped staging slots (an event behind each slot's reader guards its reuse) and a
 // kernel reads them across the bus.  The runtime's own pageable path stages too, but then the call has to wait for the
 // stream (the caller may rewrite its array as soon as we return).  Above kFetchMaxBytes: copy + synchronisation.
+// (row_words / dst_stride: the source's rows of row_words words land row_stride words apart -- a dense host matrix into a
+// padded device one; row_words == 0: a flat copy)
 __global__ void __launch_bounds__(256) push_copy_kernel(const unsigned long long* __restrict__ src,
-                                                        unsigned long long* __restrict__ dst, long long words) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256) dst[i] = src[i];
+                                                        unsigned long long* __restrict__ dst, long long words,
+                                                        long long row_words, long long dst_stride) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256)
+    dst[row_words ? (i / row_words) * dst_stride + i % row_words : i] = src[i];
 }
 
-int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, void* dev_dst) {
+int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, void* dev_dst, size_t row_bytes,
+               size_t dst_stride_bytes) {
   const char* e = getenv("VB_FETCH_FLAGSYNC");
-  if (bytes % 8 != 0 || bytes > kFetchMaxBytes || ((uintptr_t)dev_dst & 7) != 0 || (e && atoi(e) == 0)) {
-    VB_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st));
+  if (bytes % 8 != 0 || bytes > kFetchMaxBytes || ((uintptr_t)dev_dst & 7) != 0 || row_bytes % 8 != 0 ||
+      dst_stride_bytes % 8 != 0 || (e && atoi(e) == 0)) {
+    if (row_bytes)
+      VB_HIP(ctx, hipMemcpy2DAsync(dev_dst, dst_stride_bytes, host_src, row_bytes, row_bytes, bytes / row_bytes,
+                                   hipMemcpyHostToDevice, st));
+    else
+      VB_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st));
     VB_HIP(ctx, hipStreamSynchronize(st));      // caller keeps ownership of `host_src`
     return VB_OK;
   }
@@ -199,7 +209,7 @@ int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, 
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(push_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
                      (const unsigned long long*)((char*)ctx->push_dev + (size_t)ctx->push_slot * ctx->push_bytes),
-                     (unsigned long long*)dev_dst, words);
+                     (unsigned long long*)dev_dst, words, (long long)(row_bytes / 8), (long long)(dst_stride_bytes / 8));
   VB_HIP(ctx, hipGetLastError());
   VB_HIP(ctx, hipEventRecord(ev, st));
   return VB_OK;
@@ -441,11 +451,10 @@ int vb_noise_set_host(vb_ctx* ctx, int slot, const double* host, int64_t n, int6
   VB_TRY(main_stream_write(ctx));
   VB_TRY(noise_alloc(ctx, slot, n, d));
   NoiseSlot& s = ctx->noise[slot];
-  VB_HIP(ctx, hipMemcpy2DAsync(s.buf.ptr, (size_t)s.ld * sizeof(double), host,
-                               (size_t)d * sizeof(double), (size_t)d * sizeof(double), (size_t)n,
-                               hipMemcpyHostToDevice, ctx->stream));
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));   // caller keeps ownership of `host`
-  return VB_OK;
+  // (caller keeps ownership of `host`: small matrices are staged and scattered by a kernel, no wait; large ones are
+  // copied and waited for)
+  return push_small(ctx, ctx->stream, host, (size_t)(n * d) * sizeof(double), s.buf.ptr, (size_t)d * sizeof(double),
+                    (size_t)s.ld * sizeof(double));
 }
 
 int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed, uint64_t stream,

@@ -449,7 +449,8 @@ struct FetchSeg {                  // `bytes` (a multiple of 8) from device addr
 // (vb_api.hip); plain copies + hipStreamSynchronize above 1 MB
 int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs);
 // host -> device copy of a small caller-owned array without a synchronisation (mapped staging slots + a copy kernel)
-int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, void* dev_dst);
+int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, void* dev_dst, size_t row_bytes = 0,
+               size_t dst_stride_bytes = 0);      // row_bytes != 0: rows of row_bytes land dst_stride_bytes apart
 int comm_check(vb_ctx* ctx);     // VB_ERR_COMM when a device-side wait of the IPC transport has given up (vb_comm.hip)
 
 // full-rank Gaussian ExclusiveKL (vb_fullrank.hip)
