@@ -94,31 +94,47 @@ __device__ __forceinline__ double mvt_wave_sum(double x) {
   return x;
 }
 
-// one wave per row: maha_n = |E'_n|^2, log q_n
+// kMvtRowsPerWave rows per wave: maha_n = |E'_n|^2, log q_n; a lane adds its columns c = lane, lane + 64, ... of a row
+// in that order.  (Four rows per wave -- more loads in flight, a quarter of the workgroups -- measured SLOWER here,
+// 16.2 against 13.6 us at 16 384 x 256 beside the side stream's inverse; the model's row kernel, which shares its
+// parameter loads between the rows, gains 2-3 us from the same change: vb_rows.hip.)
 // (rs != nullptr: the rows of E are rs_n times what is stored -- the noise matrix itself, see mvt_residuals)
+constexpr int kMvtRowsPerWave = 1;
 __global__ void __launch_bounds__(256) mvt_rows_kernel(const double* __restrict__ E, int64_t ld, int64_t n, int d,
                                                        double df, double lq_const, double* __restrict__ maha,
                                                        double* __restrict__ lq, const double* __restrict__ rs,
                                                        double* __restrict__ cn) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  const double* e = E + row * ld;
-  double s = 0.0;
-  if (rs) {
-    const double r = rs[row];
-    for (int c = lane; c < d; c += 64) {
-      const double v = e[c] * r;          // the value the stored residual had: same rounding as before
-      s = fma(v, v, s);
-    }
-  } else {
-    for (int c = lane; c < d; c += 64) s = fma(e[c], e[c], s);
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kMvtRowsPerWave;
+  if (row0 >= n) return;
+  const double* e[kMvtRowsPerWave];
+  double r[kMvtRowsPerWave], s[kMvtRowsPerWave];
+#pragma unroll
+  for (int q = 0; q < kMvtRowsPerWave; ++q) {
+    const int64_t row = row0 + q < n ? row0 + q : n - 1;      // (clamped: loads only)
+    e[q] = E + row * ld;
+    r[q] = rs ? rs[row] : 1.0;
+    s[q] = 0.0;
   }
-  s = mvt_wave_sum(s);
-  if (lane == 0) {
-    maha[row] = s;
-    lq[row] = df > 0.0 ? lq_const - 0.5 * (df + d) * log1p(s / df) : lq_const - 0.5 * s;   // df = 0: Gaussian limit
-    cn[row] = df > 0.0 ? (df + d) / (df + s) : 1.0;      // c_n of the score: d log q / d mu = c_n u_n
+  for (int c = lane; c < d; c += 64) {
+    double v[kMvtRowsPerWave];
+#pragma unroll
+    for (int q = 0; q < kMvtRowsPerWave; ++q) v[q] = e[q][c];
+#pragma unroll
+    for (int q = 0; q < kMvtRowsPerWave; ++q) {
+      if (rs) v[q] *= r[q];               // the value the stored residual had: same rounding as before
+      s[q] = fma(v[q], v[q], s[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kMvtRowsPerWave; ++q) {
+    const double t = mvt_wave_sum(s[q]);
+    const int64_t row = row0 + q;
+    if (lane == 0 && row < n) {
+      maha[row] = t;
+      lq[row] = df > 0.0 ? lq_const - 0.5 * (df + d) * log1p(t / df) : lq_const - 0.5 * t;   // df = 0: Gaussian limit
+      cn[row] = df > 0.0 ? (df + d) / (df + t) : 1.0;      // c_n of the score: d log q / d mu = c_n u_n
+    }
   }
 }
 
@@ -311,7 +327,8 @@ int temper_prior_rows(vb_ctx* ctx, const double* X, int64_t ld, int64_t n, int64
   g.M = (int)n, g.N = (int)d, g.K = (int)d, g.tri_mode = 0;
   gemm_f64_launch<true>(st, g, 1, ctx->prop.multiProcessorCount, EpiSubVec{U, T.ld, p + d * T.ld});
   VB_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(mvt_rows_kernel, dim3(grid), dim3(256), 0, st, (const double*)U, T.ld, n, (int)d, T.df, T.c0,
+  hipLaunchKernelGGL(mvt_rows_kernel, dim3((unsigned)((n + 4 * kMvtRowsPerWave - 1) / (4 * kMvtRowsPerWave))), dim3(256), 0, st,
+                     (const double*)U, T.ld, n, (int)d, T.df, T.c0,
                      U + n * T.ld, out, (const double*)nullptr, U + n * T.ld + nn);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
@@ -672,7 +689,7 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
   const double lq_const = df > 0.0
                               ? lgamma(0.5 * (df + d)) - lgamma(0.5 * df) - 0.5 * d * log(M_PI * df) - logdet_half
                               : -0.5 * d * log(2.0 * M_PI) - logdet_half;
-  hipLaunchKernelGGL(mvt_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(mvt_rows_kernel, dim3((unsigned)((n + 4 * kMvtRowsPerWave - 1) / (4 * kMvtRowsPerWave))), dim3(256), 0, ctx->stream,
                      drawn_here ? ctx->mvt_e_noise : (const double*)(base + L.o_e), drawn_here ? drawn_here->ld : L.ld, n,
                      (int)d, df, lq_const, base + L.o_maha, base + L.o_lq + lq_off,
                      drawn_here ? (const double*)(base + L.o_invs) : (const double*)nullptr, base + L.o_part);
