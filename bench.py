@@ -417,6 +417,26 @@ def mvt_ekl_leg(vb, calls=50):
         dt = (time.perf_counter() - t0) / n_calls
         key = 'throughput_mode' if mode == 'philox' else 'parity_mode'
         out[key] = {'ms_per_call': 1e3 * dt, 'value': float(v), 'grad_norm': float(np.linalg.norm(g))}
+    # the path-derivative form of the same call (objectives.py:156-159), resident since late round 5; the host-root route it
+    # replaces is timed beside it through the route's dimension gate
+    from viabel_amd import objectives as _vobj
+    pd = {}
+    for name, gate in (('resident', None), ('host_root_route', 10 ** 6)):
+        keep = _vobj._HOST_ROOT_MAX_DIM
+        try:
+            if gate is not None:
+                _vobj._HOST_ROOT_MAX_DIM = gate
+            obj = vb.ExclusiveKL(vb.MultivariateT(D, df, seed=1), vb.GaussianModel(mean, sd), N, use_path_deriv=True)
+            for _ in range(2):
+                obj(theta)
+            t0 = time.perf_counter()
+            for _ in range(6):
+                v, g = obj(theta)
+            pd[name + '_ms_per_call'] = 1e3 * (time.perf_counter() - t0) / 6
+        finally:
+            _vobj._HOST_ROOT_MAX_DIM = keep
+    pd['value'] = float(v)
+    out['parity_mode_path_deriv'] = pd
     out['parity_mode']['note'] = ("rng='numpy': the reference's chi-square + normal streams on the device, its symmetric root "
                                   '(approximations.py:348) and the root\'s Frechet derivative by device iterations, chain rule '
                                   'on the device (vb_elbo_grad_mvt_symroot); rounds 3-4: host root, 5.1 ms')

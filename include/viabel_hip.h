@@ -261,6 +261,12 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
  * VB_ERR_UNSUPPORTED: an iteration did not resolve to 1e-12 -- use vb_elbo_sums_mvt with a host-side root.            */
 int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
                              double* grad, double* info);
+/* The same evaluation in the path-derivative form (ExclusiveKL(use_path_deriv=True), objectives.py:156-159): the value takes
+ * the samples' mean log density instead of the entropy, and the score -d log q / dx (x_n) = c_n Sigma^(-1/2) z_n / s_n joins
+ * the model gradient -- its part of the sums depends on the noise only (the sums of vb_mvt_path_terms, formed on the
+ * device) and enters through Sigma^(-1/2), the second limit of the root's coupled iteration.                             */
+int vb_elbo_grad_mvt_symroot_path(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
+                                  double* value, double* grad, double* info);
 
 /* The reference-identical step resident on the device (one rank): as vb_dis_refresh_mvt with chi, sqrt_sigma, l_inv and
  * w NULL -- factors from theta on the device, chi-square draws from the context's buffer (vb_legacy_rng_chisquare_device

@@ -234,12 +234,15 @@ def test_c4_logistic_raabbvi_runs_full_size(vb, capsys):
     assert np.isfinite(v1) and v1 < v0, (v0, v1)
 
 
+@pytest.mark.parametrize('path_deriv', [False, True])
 @pytest.mark.parametrize('target', ['gauss_diag', 'funnel', 'gauss_full'])
-def test_multivariate_t_exclusive_kl_reference_mode_resident(vb, target):
+def test_multivariate_t_exclusive_kl_reference_mode_resident(vb, target, path_deriv):
     """MultivariateT(256) + ExclusiveKL with the DEFAULT rng='numpy' at N = 16 384: the reference's chi-square and normal
     streams generated on the device, its symmetric root (approximations.py:348) and the root's Frechet derivative by
     device iterations, the chain rule to the free Cholesky parameters on the device (vb_elbo_grad_mvt_symroot) -- against
-    the oracle's eigen-decomposition route on numpy's own draws, and against the host-root route it replaces."""
+    the oracle's eigen-decomposition route on numpy's own draws, and against the host-root route it replaces.
+    path_deriv: objectives.py:156-159 (vb_elbo_grad_mvt_symroot_path: the score's noise-only sums and the inverse root on
+    the device as well)."""
     import os
     from viabel_amd import objectives as vobj
     D, N, df = 256, 16384, 9.0
@@ -257,24 +260,31 @@ def test_multivariate_t_exclusive_kl_reference_mode_resident(vb, target):
     B = rng.randn(D, D)
     theta = np.concatenate([0.2 * rng.randn(D), ofam.psd_to_free(0.05 * (B @ B.T / D + 0.5 * np.eye(D)))])
     approx = vb.MultivariateT(D, df, seed=6)
-    obj = vb.ExclusiveKL(approx, model, N)
+    obj = vb.ExclusiveKL(approx, model, N, use_path_deriv=path_deriv)
+    calls = []
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    real = eng.elbo_grad_mvt_symroot
+    eng.elbo_grad_mvt_symroot = lambda *a, **k: (calls.append(k.get('path_deriv', False)), real(*a, **k))[1]
     ref = np.random.RandomState(6)
     for call in range(2):
         value, grad = obj(theta)
         noise = ofam.MultivariateT(D, df).draw_noise(ref, N)
-        ov, og = oobj.exclusive_kl(ofam.MultivariateT(D, df), omodel, theta, noise, False)
+        ov, og = oobj.exclusive_kl(ofam.MultivariateT(D, df), omodel, theta, noise, path_deriv)
         assert abs(value - ov) <= 1e-11 * abs(ov), (call, value, ov)
         np.testing.assert_allclose(grad, og, rtol=0, atol=1e-9 * np.max(np.abs(og)))
+    eng.elbo_grad_mvt_symroot = real
+    assert calls == [path_deriv, path_deriv]      # (the resident entry point ran, in the right form)
     # the host-root route on the same draws (the resident path switched off through its dimension gate)
     keep = vobj._HOST_ROOT_MAX_DIM
     try:
         vobj._HOST_ROOT_MAX_DIM = 10 ** 6
         approx2 = vb.MultivariateT(D, df, seed=6)
-        v2, g2 = vb.ExclusiveKL(approx2, model, N)(theta)
+        v2, g2 = vb.ExclusiveKL(approx2, model, N, use_path_deriv=path_deriv)(theta)
     finally:
         vobj._HOST_ROOT_MAX_DIM = keep
     approx3 = vb.MultivariateT(D, df, seed=6)
-    v3, g3 = vb.ExclusiveKL(approx3, model, N)(theta)
+    v3, g3 = vb.ExclusiveKL(approx3, model, N, use_path_deriv=path_deriv)(theta)
     assert abs(v3 - v2) <= 1e-11 * abs(v2)
     np.testing.assert_allclose(g3, g2, rtol=0, atol=1e-9 * np.max(np.abs(g2)))
 

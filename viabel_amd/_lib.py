@@ -141,6 +141,8 @@ SIGNATURES = {
     'vb_dis_scalars_get': (ctypes.c_int, [_ctx_p, _c_double_p]),
     'vb_elbo_grad_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
                                                 ctypes.POINTER(ctypes.c_double), _c_double_p, _c_double_p]),
+    'vb_elbo_grad_mvt_symroot_path': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                                     _c_double_p, ctypes.POINTER(ctypes.c_double), _c_double_p, _c_double_p]),
     'vb_dis_refresh_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                                   _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                                   _c_double_p]),
@@ -688,16 +690,16 @@ class Engine:
             self._ctx, slot, n, d, n, float(df), _dptr(theta), None, None, None, _dptr(prior_theta), float(eps_prev),
             float(ess_target), int(max_bisection_its), None, None, None, None, None))
 
-    def elbo_grad_mvt_symroot(self, slot, n, d, df, theta):
+    def elbo_grad_mvt_symroot(self, slot, n, d, df, theta, path_deriv=False):
         """``(value, grad)`` of the t family's ExclusiveKL in the reference-identical mode, resident on the device
-        (``vb_elbo_grad_mvt_symroot``: symmetric root and its Frechet derivative by device iterations), or None when an
-        iteration did not resolve (take the host route)."""
+        (``vb_elbo_grad_mvt_symroot`` / ``_path``: symmetric root and its Frechet derivative by device iterations), or None
+        when an iteration did not resolve (take the host route)."""
         theta = _f64(theta)
         value = ctypes.c_double(0.0)
         grad = np.empty(d + d * (d + 1) // 2, dtype=np.float64)
         info = np.zeros(4, dtype=np.float64)
-        rc = self._lib.vb_elbo_grad_mvt_symroot(self._ctx, slot, n, d, float(df), _dptr(theta), ctypes.byref(value),
-                                                _dptr(grad), _dptr(info))
+        fn = self._lib.vb_elbo_grad_mvt_symroot_path if path_deriv else self._lib.vb_elbo_grad_mvt_symroot
+        rc = fn(self._ctx, slot, n, d, float(df), _dptr(theta), ctypes.byref(value), _dptr(grad), _dptr(info))
         if rc == VB_ERR_UNSUPPORTED:
             return None
         self._check(rc)

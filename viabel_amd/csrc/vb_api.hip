@@ -1176,8 +1176,8 @@ int vb_dis_refresh_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, doub
   return rc;
 }
 
-int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
-                             double* grad, double* info) {
+static int elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
+                                 double* grad, double* info, bool path_deriv) {
   if (!ctx || !theta || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
   VB_TRY(check_slot(ctx, slot));
@@ -1188,12 +1188,22 @@ int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double
   const size_t p = (size_t)(d + d * (d + 1) / 2);
   std::vector<double>& vg = ctx->mvt_stage;
   vg.resize(1 + p);
-  const int rc = mvt_elbo_symroot(ctx, ctx->noise[slot], n, d, df, theta, vg.data(), info);
+  const int rc = mvt_elbo_symroot(ctx, ctx->noise[slot], n, d, df, theta, vg.data(), info, path_deriv);
   if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "matrix square root: not resolved on the device");
   VB_TRY(rc);
   *value = vg[0];
   memcpy(grad, vg.data() + 1, p * sizeof(double));
   return VB_OK;
+}
+
+int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
+                             double* grad, double* info) {
+  return elbo_grad_mvt_symroot(ctx, slot, n, d, df, theta, value, grad, info, false);
+}
+
+int vb_elbo_grad_mvt_symroot_path(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
+                                  double* grad, double* info) {
+  return elbo_grad_mvt_symroot(ctx, slot, n, d, df, theta, value, grad, info, true);
 }
 
 int vb_dis_generation(vb_ctx* ctx, int kind, uint64_t* generation) {

@@ -242,13 +242,16 @@ __global__ void __launch_bounds__(256) ns_scale_kernel(double* __restrict__ A, i
   Z[k] = (i == j) ? 1.0 : 0.0;
 }
 
-// root = sqrt(c) (Y + Y') / 2 on the leading d x d block, pads zero
+// root = sqrt(c) (Y + Y') / 2 on the leading d x d block, pads zero  (inverse != 0: Y is the iteration's Z, the result
+// (Z + Z') / (2 sqrt(c)) = Sigma^(-1/2))
 __global__ void __launch_bounds__(256) ns_finish_kernel(const double* __restrict__ Y, int d, int64_t ld,
-                                                        const double* __restrict__ scal, double* __restrict__ root) {
+                                                        const double* __restrict__ scal, double* __restrict__ root,
+                                                        int inverse = 0) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= (int64_t)d * ld) return;
   const int i = (int)(k / ld), j = (int)(k - (int64_t)i * ld);
-  root[k] = j < d ? 0.5 * (Y[k] + Y[(int64_t)j * ld + i]) * sqrt(scal[0]) : 0.0;
+  const double f = inverse ? 1.0 / sqrt(scal[0]) : sqrt(scal[0]);
+  root[k] = j < d ? 0.5 * (Y[k] + Y[(int64_t)j * ld + i]) * f : 0.0;
 }
 
 }  // namespace
@@ -314,8 +317,10 @@ static int ns_run(vb_ctx* ctx, int m, int64_t ld, double* set0, double* set1, co
 
 // root (d x ld, device) = (Lfull Lt)^(1/2), Lfull = L (row-major, row stride ld = round_up(d, 16)), Lt = L'.
 // info (host) = [steps, last residual ||I - Z Y||_F, ||R R - Sigma||_F / c].  VB_ERR_UNSUPPORTED: not converged to `tol`.
+// inv_root != nullptr: also Sigma^(-1/2), the iteration's second limit (checked by the caller where it matters:
+// the coupled iteration's residual ||I - Z Y|| bounds both)
 int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, int64_t ld, double* root, double tol,
-                 double* info) {
+                 double* info, double* inv_root) {
   const int m = (int)d;
   if (ld != round_up(d, 16)) return fail(ctx, VB_ERR_INVALID, "sym_sqrt_dev: row stride");
   const int64_t mat = (int64_t)m * ld;
@@ -339,7 +344,10 @@ int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, 
   double loc[3];
   VB_TRY(ns_run(ctx, m, ld, base, base + 3 * mat, M0, m, &cur, loc));
   hipLaunchKernelGGL(ns_finish_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st,
-                     (const double*)(base + (int64_t)cur * 3 * mat), m, ld, (const double*)scal, root);
+                     (const double*)(base + (int64_t)cur * 3 * mat), m, ld, (const double*)scal, root, 0);
+  if (inv_root)
+    hipLaunchKernelGGL(ns_finish_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st,
+                       (const double*)(base + (int64_t)cur * 3 * mat + 2 * mat), m, ld, (const double*)scal, inv_root, 1);
   VB_HIP(ctx, hipGetLastError());
   VB_HIP(ctx, hipStreamSynchronize(st));
   double acc = 0.0;

@@ -1329,9 +1329,11 @@ __global__ void __launch_bounds__(256) mvt_path_rows_kernel(const double* __rest
   if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-int mvt_path_terms(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df,
-                   const double* inv_s_host, double* m_w, double* e_w, double* log1p_sum) {
-  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+// The noise-only sums of the path derivative on the device: S->sums = [sum log1p(maha / df) | e_w (from off_col) | m_w
+// (from off_c, row stride round_up(d, 16); mirror: both triangles)] in ctx->mvt_elbo.  inv_s_dev: n row scales on the
+// device; inv_s_host != nullptr: uploaded first.
+static int mvt_path_terms_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df,
+                                  const double* inv_s_host, const double* inv_s_dev, bool mirror, FrSums* S_out) {
   const int64_t ldw = round_up(d, 16), slab = d * ldw;
   const int splits = gram_splits(ctx, (int)d, n);
   const int n_rb = (int)((n + 127) / 128);
@@ -1353,18 +1355,32 @@ int mvt_path_terms(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64
   double* base = (double*)ctx->mvt_elbo.ptr;
   S.sums = base + o_sums;
   hipStream_t st = ctx->stream;
-  VB_HIP(ctx, hipMemcpyAsync(base + o_invs, inv_s_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  if (inv_s_host) {
+    VB_HIP(ctx, hipMemcpyAsync(base + o_invs, inv_s_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    inv_s_dev = base + o_invs;
+  }
   VB_HIP(ctx, hipMemsetAsync(base + o_es, 0, (size_t)(n * ldw) * sizeof(double), st));   // pad columns
   const double* E = (const double*)ns.buf.ptr;
   hipLaunchKernelGGL(mvt_path_rows_kernel, dim3((unsigned)n_part), dim3(256), 0, st, E, ns.ld, n, (int)d, df,
-                     (const double*)(base + o_invs), base + o_es, ldw, base + o_a, base + o_part);
+                     inv_s_dev, base + o_es, ldw, base + o_a, base + o_part);
   VB_HIP(ctx, hipGetLastError());
   VB_TRY(gram_lower_enqueue(ctx, base + o_es, base + o_es, ldw, (int)d, n, splits, base + o_cpart, ldw, slab));
   VB_TRY(fr_colsum_enqueue(ctx, E, nullptr, ns.ld, n, (int)d, 0, nullptr, base + o_col, base + o_fdummy,
                            base + o_a));
   VB_TRY(fr_reduce_enqueue(ctx, base + o_cpart, splits, slab, (int)d, ldw, base + o_col, n_rb, ns.ld, base + o_part,
-                           n_part, S));
+                           n_part, S, mirror));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
+  *S_out = S;
+  return VB_OK;
+}
+
+int mvt_path_terms(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df,
+                   const double* inv_s_host, double* m_w, double* e_w, double* log1p_sum) {
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  const int64_t ldw = round_up(d, 16);
+  FrSums S;
+  VB_TRY(mvt_path_terms_enqueue(ctx, ns, n, d, df, inv_s_host, nullptr, false, &S));
+  hipStream_t st = ctx->stream;
   std::vector<double> low((size_t)d * d);
   VB_HIP(ctx, hipMemcpyAsync(log1p_sum, S.sums, sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpyAsync(e_w, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1424,11 +1440,28 @@ __global__ void __launch_bounds__(256) mvt_gs_kernel(const double* __restrict__ 
   Gs[idx] = j < d ? (C[idx] + C[(int64_t)j * ld + i]) * inv_2n : 0.0;
 }
 
+// v_i += sum_k A[i][k] x_k, one wave per component (the path derivative's sum g += Sigma^(-1/2) e_w)
+__global__ void __launch_bounds__(256) mvt_matvec_add_kernel(const double* __restrict__ A, int64_t ld, int d,
+                                                             const double* __restrict__ x, double* __restrict__ v) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= d) return;
+  double a = 0.0;
+  for (int k = lane; k < d; k += 64) a = fma(A[(int64_t)i * ld + k], x[k], a);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+  if (lane == 0) v[i] += a;
+}
+
 // out = [value | grad]: XL = X L (d x ld), Lfull = L, theta's log-diagonal for the entropy
+// l1p != nullptr: the path-derivative form (objectives.py:156-159) -- the value takes the samples' mean log density
+// lqc - sum log L_ii - half_dfd l1p[0] / N instead of the entropy, and the free diagonal has no entropy term
 __global__ void __launch_bounds__(256) mvt_ekl_pack_kernel(const double* __restrict__ XL, const double* __restrict__ Lfull,
                                                            const double* __restrict__ theta, int64_t ld, int d,
                                                            const double* __restrict__ sums, int64_t off_col, double inv_n,
-                                                           double c0, double* __restrict__ out) {
+                                                           double c0, double* __restrict__ out,
+                                                           const double* __restrict__ l1p = nullptr, double lqc = 0.0,
+                                                           double half_dfd = 0.0) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x == 0) {      // value: one workgroup adds the log-diagonal in a fixed order
     __shared__ double sh[4];
@@ -1438,22 +1471,41 @@ __global__ void __launch_bounds__(256) mvt_ekl_pack_kernel(const double* __restr
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = -((sums[0] * inv_n + c0) + ((sh[0] + sh[1]) + (sh[2] + sh[3])));
+    if (threadIdx.x == 0) {
+      double v = (sums[0] * inv_n + c0) + ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+      if (l1p) v += half_dfd * l1p[0] * inv_n - lqc;
+      out[0] = -v;
+    }
   }
   if (idx < d) out[1 + idx] = -(sums[off_col + idx] * inv_n);
   if (idx >= (int64_t)d * d) return;
   const int i = (int)(idx / d), j = (int)(idx % d);
   if (j > i) return;
   double g = 2.0 * XL[(int64_t)i * ld + j];
-  if (i == j) g = g * Lfull[(int64_t)i * ld + i] + 1.0;
+  if (i == j) g = g * Lfull[(int64_t)i * ld + i] + (l1p ? 0.0 : 1.0);
   out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -g;
 }
 
 }  // namespace
 
 // value_grad_host: 1 + d + d (d + 1) / 2 doubles.  VB_ERR_UNSUPPORTED: a root iteration did not resolve (nothing returned).
+// path_deriv: objectives.py:156-159 -- the model gradient g_n gives way to g_n - d log q / dx (x_n) = g_n + c_n
+// Sigma^(-1/2) z_n / s_n, whose part of the sums depends on the noise only: C += Sigma^(-1/2) m_w, sum g += Sigma^(-1/2) e_w
+// (mvt_path_terms_enqueue); Sigma^(-1/2) is the coupled iteration's second limit.
+struct EpiAddTo {           // C += acc
+  double* C;
+  int64_t ld;
+  __device__ void operator()(int, int row, int col, double acc) const { C[(int64_t)row * ld + col] += acc; }
+  __device__ d2v pair(int, int row, int col, double a0, double a1) const {
+    d2v* p = reinterpret_cast<d2v*>(C + (int64_t)row * ld + col);
+    const d2v v = (d2v){p->x + a0, p->y + a1};
+    *p = v;
+    return v;
+  }
+};
+
 int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, const double* theta_host,
-                     double* value_grad_host, double* info) {
+                     double* value_grad_host, double* info, bool path_deriv) {
   if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "resident ExclusiveKL of the t family: one rank");
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
   if (ctx->chi_n != n || ctx->chi_df != df || !ctx->chi_dev.ptr)
@@ -1469,11 +1521,25 @@ int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, dou
   ctx->mvt_n = 0;
   VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
   double rinfo[3] = {0.0, 0.0, 0.0};
-  VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, rinfo));
+  // (the inverse root, when asked for, lands in the slot of L^-1, which this path does not read)
+  VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, rinfo,
+                      path_deriv ? base + L.o_li : (double*)nullptr));
   hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ctx->chi_dev.ptr,
                      df, n, base + L.o_invs);
   FrSums S;
   VB_TRY(fr_pipeline_enqueue(ctx, ns, n, d, n, nullptr, nullptr, base + L.o_mu, base + L.o_root, base + L.o_invs, &S));
+  FrSums P;
+  P.sums = nullptr;
+  if (path_deriv) {
+    VB_TRY(mvt_path_terms_enqueue(ctx, ns, n, d, df, nullptr, base + L.o_invs, true, &P));
+    GemmArgs gp;      // C += Sigma^(-1/2) m_w
+    gp.A = base + L.o_li, gp.lda = L.ld, gp.B = P.sums + P.off_c, gp.ldb = L.ld;
+    gp.M = D, gp.N = D, gp.K = D, gp.tri_mode = 0;
+    gemm_f64_launch<true>(st, gp, 1, n_cu, EpiAddTo{S.sums + S.off_c, L.ld});
+    hipLaunchKernelGGL(mvt_matvec_add_kernel, dim3((unsigned)((D + 3) / 4)), dim3(256), 0, st, (const double*)(base + L.o_li),
+                       L.ld, D, (const double*)(P.sums + P.off_col), S.sums + S.off_col);
+    VB_HIP(ctx, hipGetLastError());
+  }
   hipLaunchKernelGGL(mvt_gs_kernel, dim3((unsigned)((sq + 255) / 256)), dim3(256), 0, st, (const double*)(S.sums + S.off_c),
                      base + L.o_tscr, D, L.ld, 0.5 / (double)n);
   VB_HIP(ctx, hipGetLastError());
@@ -1485,7 +1551,9 @@ int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, dou
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{base + L.o_tscr, L.ld});
   hipLaunchKernelGGL(mvt_ekl_pack_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
                      (const double*)(base + L.o_tscr), (const double*)(base + L.o_lfull), (const double*)(base + L.o_theta), L.ld, D,
-                     (const double*)S.sums, S.off_col, 1.0 / (double)n, ctx->model.c0, base + L.o_grad);
+                     (const double*)S.sums, S.off_col, 1.0 / (double)n, ctx->model.c0, base + L.o_grad,
+                     path_deriv ? (const double*)P.sums : (const double*)nullptr,
+                     lgamma(0.5 * (df + (double)d)) - lgamma(0.5 * df) - 0.5 * (double)d * log(M_PI * df), 0.5 * (df + (double)d));
   VB_HIP(ctx, hipGetLastError());
   const size_t plen = (size_t)(1 + d + d * (d + 1) / 2);
   const FetchSeg seg{base + L.o_grad, plen * sizeof(double), value_grad_host};

@@ -526,13 +526,13 @@ class ExclusiveKL(StochasticVariationalObjective):
                                    row_offset=begin)
             else:
                 # chi-square draws first (approximations.py:345-347)
-                want_resident = not path_deriv and eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
+                want_resident = eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
                 chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, host_chi=not want_resident)
                 if want_resident and getattr(approx, '_chi_on_device', False):
                     # the whole evaluation resident on the device: both noise streams are there already, the symmetric
                     # root and its Frechet derivative are device iterations, the chain rule to the free Cholesky
                     # parameters two more kernels (vb_elbo_grad_mvt_symroot); None: an iteration did not resolve
-                    resident = eng.elbo_grad_mvt_symroot(_NOISE_SLOT, N, D, df, var_param)
+                    resident = eng.elbo_grad_mvt_symroot(_NOISE_SLOT, N, D, df, var_param, path_deriv=path_deriv)
                     if resident is not None:
                         return resident
                     chi = eng.chisq_get_host(N)          # the host route after all: the draws come down
