@@ -596,6 +596,30 @@ def alpha_leg(vb, calls=30):
                 res['value'], res['grad_norm'] = float(v), float(np.linalg.norm(g))
         res['ratio_to_exclusive_kl'] = res['us_per_call'] / res['exclusive_kl_same_call_us']
         out[name] = res
+    # the t family in the reference-identical mode (rng='numpy', the call's fresh RandomState drawn on the device, the
+    # symmetric root): resident since late round 5 (vb_alpha_grad_mvt_symroot); the host-root route through its gate
+    from viabel_amd import objectives as _vobj
+    mrng = np.random.RandomState(2)
+    mean, sd = 0.1 * mrng.randn(256), np.exp(0.1 * mrng.randn(256))
+    par = {}
+    for name, gate in (('resident', None), ('host_root_route', 10 ** 6)):
+        keep = _vobj._HOST_ROOT_MAX_DIM
+        try:
+            if gate is not None:
+                _vobj._HOST_ROOT_MAX_DIM = gate
+            approx = vb.MultivariateT(256, 100)
+            obj = vb.AlphaDivergence(approx, vb.GaussianModel(mean, sd), 16384, 0.5)
+            theta = approx.init_param()
+            np.random.seed(1)
+            for _ in range(2):
+                obj(theta)
+            t0 = time.perf_counter()
+            for _ in range(6):
+                v, g = obj(theta)
+            par[name + '_ms_per_call'] = 1e3 * (time.perf_counter() - t0) / 6
+        finally:
+            _vobj._HOST_ROOT_MAX_DIM = keep
+    out['multivariate_t_gauss_diag_d256_n16384']['parity_mode'] = par
     return out
 
 

@@ -267,6 +267,13 @@ int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double
  * device) and enters through Sigma^(-1/2), the second limit of the root's coupled iteration.                             */
 int vb_elbo_grad_mvt_symroot_path(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
                                   double* value, double* grad, double* info);
+/* AlphaDivergence (objectives.py:443-463) of the multivariate t in the reference-identical mode, resident on the device (one
+ * rank): noise as for vb_elbo_grad_mvt_symroot (the caller's fresh RandomState(seed) of :455-456 drawn on the device), the
+ * samples through the symmetric root, weights / value / weighted sums by the kernels of vb_alpha_sums_mvt, the chain rule
+ * through the root's Frechet derivative with sum s on the free diagonal; value = the log-normaliser estimate, grad =
+ * alpha / N times the weighted score.  VB_ERR_UNSUPPORTED: an iteration did not resolve -- vb_alpha_sums_mvt + host root. */
+int vb_alpha_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, double alpha, const double* theta,
+                              double* value, double* grad, double* info);
 
 /* The reference-identical step resident on the device (one rank): as vb_dis_refresh_mvt with chi, sqrt_sigma, l_inv and
  * w NULL -- factors from theta on the device, chi-square draws from the context's buffer (vb_legacy_rng_chisquare_device

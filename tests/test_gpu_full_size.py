@@ -289,6 +289,56 @@ def test_multivariate_t_exclusive_kl_reference_mode_resident(vb, target, path_de
     np.testing.assert_allclose(g3, g2, rtol=0, atol=1e-9 * np.max(np.abs(g2)))
 
 
+@pytest.mark.parametrize('alpha', [2.0, 0.5])
+@pytest.mark.parametrize('target', ['gauss_diag', 'funnel', 'gauss_full'])
+def test_multivariate_t_alpha_reference_mode_resident(vb, target, alpha):
+    """MultivariateT(256) + AlphaDivergence with the DEFAULT rng='numpy' at N = 16 384, resident on the device
+    (vb_alpha_grad_mvt_symroot: the call's fresh RandomState(seed) of objectives.py:455-456 drawn there, the symmetric
+    root and its Frechet derivative by device iterations) -- against the oracle on numpy's own draws and against the
+    host-root route it replaces."""
+    from viabel_amd import _lib
+    from viabel_amd import objectives as vobj
+    D, N, df = 256, 16384, 9.0
+    rng = np.random.RandomState(43)
+    if target == 'gauss_diag':
+        mean, sd = 0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D))
+        model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    elif target == 'funnel':
+        model, omodel = vb.FunnelModel(D, D // 2), omod.Funnel(D, D // 2)
+    else:
+        A = rng.randn(D, D)
+        S = A @ A.T / D + np.eye(D)
+        mean = rng.randn(D)
+        model, omodel = vb.CorrelatedGaussianModel(mean, covariance=S), omod.GaussFull(mean, np.linalg.inv(S))
+    B = rng.randn(D, D)
+    theta = np.concatenate([0.2 * rng.randn(D), ofam.psd_to_free(0.05 * (B @ B.T / D + 0.5 * np.eye(D)))])
+    omvt = ofam.MultivariateT(D, df)
+    eng = _lib.default_engine()
+    calls = []
+    real = eng.alpha_grad_mvt_symroot
+    eng.alpha_grad_mvt_symroot = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        np.random.seed(17)
+        value, grad = vb.AlphaDivergence(vb.MultivariateT(D, df), model, N, alpha)(theta)
+    finally:
+        eng.alpha_grad_mvt_symroot = real
+    assert calls == [1]
+    np.random.seed(17)
+    noise = omvt.draw_noise(np.random.RandomState(np.random.randint(2 ** 32)), N)
+    ov, og = oobj.alpha_divergence(omvt, omodel, theta, noise, alpha)
+    assert abs(value - ov) <= 1e-11 * abs(ov), (value, ov)
+    np.testing.assert_allclose(grad, og, rtol=0, atol=1e-9 * np.max(np.abs(og)))
+    keep = vobj._HOST_ROOT_MAX_DIM
+    try:
+        vobj._HOST_ROOT_MAX_DIM = 10 ** 6
+        np.random.seed(17)
+        v2, g2 = vb.AlphaDivergence(vb.MultivariateT(D, df), model, N, alpha)(theta)
+    finally:
+        vobj._HOST_ROOT_MAX_DIM = keep
+    assert abs(value - v2) <= 1e-11 * abs(v2)
+    np.testing.assert_allclose(grad, g2, rtol=0, atol=1e-9 * np.max(np.abs(g2)))
+
+
 def test_reference_mode_falls_back_when_the_device_root_does_not_resolve(vb):
     """A scale matrix beyond the Newton-Schulz iteration's reach (condition number ~1e10: the accuracy check
     ||R R - Sigma|| / ||Sigma||_inf < 1e-12 fails): vb_elbo_grad_mvt_symroot / vb_dis_refresh_mvt_symroot decline and the

@@ -141,6 +141,9 @@ SIGNATURES = {
     'vb_dis_scalars_get': (ctypes.c_int, [_ctx_p, _c_double_p]),
     'vb_elbo_grad_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
                                                 ctypes.POINTER(ctypes.c_double), _c_double_p, _c_double_p]),
+    'vb_alpha_grad_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                                 ctypes.c_double, _c_double_p, ctypes.POINTER(ctypes.c_double), _c_double_p,
+                                                 _c_double_p]),
     'vb_elbo_grad_mvt_symroot_path': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                                      _c_double_p, ctypes.POINTER(ctypes.c_double), _c_double_p, _c_double_p]),
     'vb_dis_refresh_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
@@ -700,6 +703,21 @@ class Engine:
         info = np.zeros(4, dtype=np.float64)
         fn = self._lib.vb_elbo_grad_mvt_symroot_path if path_deriv else self._lib.vb_elbo_grad_mvt_symroot
         rc = fn(self._ctx, slot, n, d, float(df), _dptr(theta), ctypes.byref(value), _dptr(grad), _dptr(info))
+        if rc == VB_ERR_UNSUPPORTED:
+            return None
+        self._check(rc)
+        self.last_root_info = info
+        return value.value, grad
+
+    def alpha_grad_mvt_symroot(self, slot, n, d, df, alpha, theta):
+        """``(value, grad)`` of the t family's AlphaDivergence in the reference-identical mode, resident on the device
+        (``vb_alpha_grad_mvt_symroot``), or None when a root iteration did not resolve (take the host route)."""
+        theta = _f64(theta)
+        value = ctypes.c_double(0.0)
+        grad = np.empty(d + d * (d + 1) // 2, dtype=np.float64)
+        info = np.zeros(4, dtype=np.float64)
+        rc = self._lib.vb_alpha_grad_mvt_symroot(self._ctx, slot, n, d, float(df), float(alpha), _dptr(theta),
+                                                 ctypes.byref(value), _dptr(grad), _dptr(info))
         if rc == VB_ERR_UNSUPPORTED:
             return None
         self._check(rc)

@@ -1201,6 +1201,26 @@ int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double
   return elbo_grad_mvt_symroot(ctx, slot, n, d, df, theta, value, grad, info, false);
 }
 
+int vb_alpha_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, double alpha, const double* theta,
+                              double* value, double* grad, double* info) {
+  if (!ctx || !theta || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  VB_TRY(check_slot(ctx, slot));
+  if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
+  if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  const size_t p = (size_t)(d + d * (d + 1) / 2);
+  std::vector<double>& vg = ctx->mvt_stage;
+  vg.resize(1 + p);
+  const int rc = mvt_alpha_symroot(ctx, ctx->noise[slot], n, d, df, alpha, theta, vg.data(), info);
+  if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "matrix square root: not resolved on the device");
+  VB_TRY(rc);
+  *value = vg[0];
+  memcpy(grad, vg.data() + 1, p * sizeof(double));
+  return VB_OK;
+}
+
 int vb_elbo_grad_mvt_symroot_path(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
                                   double* grad, double* info) {
   return elbo_grad_mvt_symroot(ctx, slot, n, d, df, theta, value, grad, info, true);

@@ -395,6 +395,8 @@ int mvt_dis_clip_enqueue(vb_ctx* ctx, int64_t n_total, double threshold);
 int mvt_dis_scalars_get(vb_ctx* ctx, double out[4]);
 int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, const double* theta_host,
                      double* value_grad_host, double* info, bool path_deriv = false);
+int mvt_alpha_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, double alpha, const double* theta_host,
+                      double* value_grad_host, double* info);
 int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, int64_t ld, double* root, double tol,
                  double* info, double* inv_root = nullptr);      // vb_linalg.hip
 int sym_sqrt_frechet_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, const double* E, int64_t d, int64_t ld, double* X,

@@ -1562,6 +1562,75 @@ int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, dou
   return VB_OK;
 }
 
+// ---- AlphaDivergence of the multivariate t in the reference-identical mode, resident on the device (round 5, late) -----
+// objectives.py:443-463 over approximations.py:342-349: the weighted sums of alpha_mvt_enqueue (weights, value, sum s g,
+// C = sum s g (z / s)') with the samples through the device's symmetric root, then the chain rule of mvt_elbo_symroot --
+// Gs = sym(C), the root's Frechet derivative, X L -- with sum s on the free diagonal (of log q(x(theta); theta) only
+// -sum log L_ii moves) and alpha / N in front.  value_grad_host: 1 + d + d (d + 1) / 2 doubles.
+namespace {
+
+__global__ void __launch_bounds__(256) mvt_alpha_pack_kernel(const double* __restrict__ XL, const double* __restrict__ Lfull,
+                                                             int64_t ld, int d, const double* __restrict__ sums,
+                                                             int64_t off_col, const double* __restrict__ vw, double scale,
+                                                             double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx == 0) out[0] = vw[1];
+  if (idx < d) out[1 + idx] = scale * sums[off_col + idx];
+  if (idx >= (int64_t)d * d) return;
+  const int i = (int)(idx / d), j = (int)(idx % d);
+  if (j > i) return;
+  double g = 2.0 * XL[(int64_t)i * ld + j];
+  if (i == j) g = g * Lfull[(int64_t)i * ld + i] + vw[0];
+  out[1 + d + (int64_t)i * (i + 1) / 2 + j] = scale * g;
+}
+
+}  // namespace
+
+int mvt_alpha_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, double alpha, const double* theta_host,
+                      double* value_grad_host, double* info) {
+  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "resident AlphaDivergence of the t family: one rank");
+  if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
+  if (ctx->chi_n != n || ctx->chi_df != df || !ctx->chi_dev.ptr)
+    return fail(ctx, VB_ERR_STATE, "needs %lld device chi-square(%g) draws (vb_legacy_rng_chisquare_device)", (long long)n, df);
+  const MvtLayout L = mvt_layout(ctx, n, n, d);
+  VB_TRY(ensure(ctx, ctx->mvt_state, (size_t)L.total * sizeof(double)));
+  double* base = (double*)ctx->mvt_state.ptr;
+  hipStream_t st = ctx->stream;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int D = (int)d;
+  const int64_t sq = d * L.ld;
+  ctx->mvt_theta.clear();      // (the DIS state of this buffer, if any, is gone)
+  ctx->mvt_n = 0;
+  VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
+  double rinfo[3] = {0.0, 0.0, 0.0};
+  VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, rinfo));
+  hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ctx->chi_dev.ptr,
+                     df, n, base + L.o_invs);
+  double sum_log_diag = 0.0;
+  for (int64_t j = 0; j < d; ++j) sum_log_diag += theta_host[d + j * (j + 1) / 2 + j];
+  FrSums S;
+  const double* vw = nullptr;
+  VB_TRY(alpha_mvt_enqueue(ctx, ns, n, n, d, df, alpha, base + L.o_mu, base + L.o_root, base + L.o_invs, sum_log_diag, &S, &vw));
+  hipLaunchKernelGGL(mvt_gs_kernel, dim3((unsigned)((sq + 255) / 256)), dim3(256), 0, st, (const double*)(S.sums + S.off_c),
+                     base + L.o_tscr, D, L.ld, 0.5);
+  VB_HIP(ctx, hipGetLastError());
+  double xinfo[3] = {0.0, 0.0, 0.0};
+  VB_TRY(sym_sqrt_frechet_dev(ctx, base + L.o_lfull, base + L.o_lt, base + L.o_tscr, d, L.ld, base + L.o_sl, 1e-12, xinfo));
+  GemmArgs g;      // X L
+  g.A = base + L.o_sl, g.lda = L.ld, g.B = base + L.o_lfull, g.ldb = L.ld;
+  g.M = D, g.N = D, g.K = D, g.tri_mode = 0;
+  gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{base + L.o_tscr, L.ld});
+  hipLaunchKernelGGL(mvt_alpha_pack_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
+                     (const double*)(base + L.o_tscr), (const double*)(base + L.o_lfull), L.ld, D, (const double*)S.sums,
+                     S.off_col, vw, alpha / (double)n, base + L.o_grad);
+  VB_HIP(ctx, hipGetLastError());
+  const size_t plen = (size_t)(1 + d + d * (d + 1) / 2);
+  const FetchSeg seg{base + L.o_grad, plen * sizeof(double), value_grad_host};
+  VB_TRY(fetch_blocking(ctx, st, &seg, 1));
+  if (info) info[0] = rinfo[0], info[1] = rinfo[2], info[2] = xinfo[0], info[3] = xinfo[2];
+  return VB_OK;
+}
+
 // AlphaDivergence sums for the multivariate t (see vb_alpha_sums_mvt in the header)
 int mvt_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
                    const double* mu_host, const double* root_host, const double* inv_s_host, double sum_log_diag,

@@ -1234,7 +1234,15 @@ class AlphaDivergence(StochasticVariationalObjective):
                 return eng.alpha_grad_mvt_chol(_NOISE_SLOT, end - begin, D, df, var_param, alpha, n_total=N)
             else:
                 # chi-square draws first (approximations.py:345-347)
-                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed)
+                want_resident = eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
+                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed, host_chi=not want_resident)
+                if want_resident and getattr(approx, '_chi_on_device', False):
+                    # the whole evaluation resident on the device (vb_alpha_grad_mvt_symroot), as ExclusiveKL's; None: a
+                    # root iteration did not resolve
+                    resident = eng.alpha_grad_mvt_symroot(_NOISE_SLOT, N, D, df, alpha, var_param)
+                    if resident is not None:
+                        return resident
+                    chi = eng.chisq_get_host(N)          # the host route after all: the draws come down
             mu, L = approx._unpack(var_param)
             Sigma = L @ L.T
             inv_s = 1.0 / np.sqrt(chi / df)
