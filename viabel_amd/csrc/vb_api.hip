@@ -35,6 +35,10 @@ int ensure(vb_ctx* ctx, DeviceBuffer& b, size_t bytes) {
     if (&b == &ctx->mvt_state) {      // caches keyed on the state buffer: a new allocation may return the old address
       ctx->mvt_prior.clear();
       ctx->mvt_inv_key[0] = 0;
+      // a deferred inverse that was never enqueued (an error between the factor call and the refresh's end) describes
+      // the buffer that is about to go: drop it (what WAS enqueued has finished: sync_streams above)
+      ctx->mvt_inv_pending = false;
+      ctx->mvt_inv_queued = false;
     }
   }
   size_t cap = bytes < 256 ? 256 : bytes;
