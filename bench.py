@@ -376,16 +376,18 @@ def c3_leg(vb, calls=30):
             'value': float(v), 'grad_norm': float(np.linalg.norm(g)),
             'note': "rng='numpy': the reference's own noise stream (16 384 chi-square draws + 4.2 M normals per call, on the "
                     'device) and its symmetric matrix root'}
-    # executed work of one refresh + gradient in this mode: the sample GEMM through L' (triangular), U = E' L^-1
-    # (triangular; the residuals E' of freshly drawn samples are the scaled noise: no product) and the weighted Gram
-    # product (lower tiles) -- three half products
-    flops = 3.0 * N * D * (D + 1)
+    # executed work of one refresh + gradient in this mode (late round 5): the sample GEMM through L' (triangular) and the
+    # weighted Gram product of the residuals (lower tiles) -- two half products; the U = E' L^-1 product of rounds 2-4 is
+    # gone (the chain rule takes L^-T once, in a D x D x D product), and the residuals of freshly drawn samples are the
+    # scaled noise (no product)
+    flops = 2.0 * N * D * (D + 1) + 2.0 * D * D * D
     out['flops_executed_per_call'] = flops
-    out['note'] = ('about 40 dependent kernels per call, everything including the O(D^3) factor algebra on the device; five of '
-                   'them are the tempering bisection (50 levels walked along two predicted paths: ~45 us, was ten launches and '
-                   '96 us), PSIS smoothing runs on 16 workgroups (43 us, was 80), the three GEMMs take 100 us for %.1f GFLOP '
-                   '(%.0f us at the dense GEMM rate): the call is bound by dependent launches, not by the matrix pipe; '
-                   'per-kernel times: profiles/r04_c3_kernel_stats.txt' % (flops / 1e9, flops / 57e12 * 1e6))
+    out['note'] = ('22 kernels per call (18 on the critical path: the triangular inverse runs on a side stream), everything '
+                   'including the O(D^3) factor algebra on the device; five of them are the tempering bisection (50 levels '
+                   'walked along two predicted paths: ~40 us), PSIS smoothing runs on 16 workgroups (43 us), the two N x D x D '
+                   'half products take 66 us for %.1f GFLOP: the call is a chain of short dependent kernels (~225 us) plus '
+                   '~30 us of host turn-around, not matrix-pipe time; timeline: profiles/r05_c3_timeline.txt, per kernel: '
+                   'profiles/r05_c3_kernel_stats.txt' % (flops / 1e9))
     return out
 
 
