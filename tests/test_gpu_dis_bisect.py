@@ -26,6 +26,18 @@ def vb():
     return viabel_amd
 
 
+def _resident(call):
+    """The opt-in resident launch needs all its workgroups on the device at once; when something else holds the slots
+    (another process on the same GPU) it gives up at its poll bound with VB_ERR_STATE: skip, do not fail."""
+    from viabel_amd._lib import EngineError
+    try:
+        return call()
+    except EngineError as e:
+        if 'did not arrive at a grid barrier' in str(e):
+            pytest.skip('resident bisection launch was not co-resident on this GPU: ' + str(e))
+        raise
+
+
 def run(vb, D, N, target, its, eps_prev, shift, env):
     saved = {k: os.environ.get(k) for k in ('VB_DIS_BISECT', 'VB_DIS_ROUNDS', 'VB_DIS_RESIDENT')}
     for k in saved:
@@ -128,7 +140,7 @@ def test_literal_bisection_on_the_returned_logs(vb):
 @pytest.mark.parametrize('rounds', [None, '1', '2'])
 def test_resident_launch_equals_launch_chain(vb, D, N, target, its, eps_prev, shift, rounds):
     extra = {} if rounds is None else {'VB_DIS_ROUNDS': rounds}
-    res = run(vb, D, N, target, its, eps_prev, shift, dict(extra, VB_DIS_RESIDENT='1'))
+    res = _resident(lambda: run(vb, D, N, target, its, eps_prev, shift, dict(extra, VB_DIS_RESIDENT='1')))
     chain = run(vb, D, N, target, its, eps_prev, shift, dict(extra))
     assert res[0] == chain[0] and res[1] == chain[1]
     np.testing.assert_array_equal(res[2], chain[2])
@@ -140,6 +152,6 @@ def test_resident_launches_back_to_back(vb):
     """The barrier counter runs on from launch to launch (no reset between them): many refreshes in a row, of two
     different problems (another table layout re-zeroes it), give what the launch chain gives."""
     seq = [CASES[0], CASES[2], CASES[0], CASES[11], CASES[13], CASES[2]] * 3
-    got = [run(vb, *c, {'VB_DIS_RESIDENT': '1'})[:2] for c in seq]
+    got = _resident(lambda: [run(vb, *c, {'VB_DIS_RESIDENT': '1'})[:2] for c in seq])
     want = [run(vb, *c, {})[:2] for c in seq]
     assert got == want
