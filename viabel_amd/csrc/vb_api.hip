@@ -112,6 +112,7 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
     for (int k = 0; k < n_segs; ++k)
       if (segs[k].bytes)
         VB_HIP(ctx, hipMemcpyAsync(segs[k].dst, segs[k].src, segs[k].bytes, hipMemcpyDeviceToHost, st));
+    if (st == ctx->stream) noise_prefetch(ctx);      // the next call's noise behind this call's copies, while the host waits
     VB_HIP(ctx, hipStreamSynchronize(st));
     return comm_check(ctx);
   }
@@ -150,6 +151,7 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
   hipLaunchKernelGGL(fetch_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, devw, (unsigned*)ctx->fetch_ticket.ptr,
                      devw + o_done, seq);
   VB_HIP(ctx, hipGetLastError());
+  if (st == ctx->stream) noise_prefetch(ctx);      // the next call's noise behind the gathering kernel, while the host polls
   volatile unsigned long long* word = hostw + o_done;
   bool seen = false;
   for (unsigned spins = 0; spins < 2000000u && !seen; ++spins) {      // ~10 ms, then the stream
@@ -242,6 +244,63 @@ static int main_stream_write(vb_ctx* ctx) {
   return VB_OK;
 }
 
+// ---- look-ahead generation (see NoiseAhead, vb_common.h) -------------------------------------------------------------------
+static bool req_same_but_stream(const NoiseReq& a, const NoiseReq& b) {
+  return a.kind == b.kind && a.df == b.df && a.seed == b.seed && a.row_offset == b.row_offset && a.n == b.n && a.d == b.d;
+}
+static void req_observe(NoiseAhead& h, const NoiseReq& r) {
+  if (h.last.valid && req_same_but_stream(h.last, r)) {
+    const int64_t step = (int64_t)(r.stream - h.last.stream);
+    if (step != 0 && step == h.delta) {
+      if (h.streak < 1000) ++h.streak;
+    } else {
+      h.delta = step;
+      h.streak = step != 0 ? 1 : 0;
+    }
+  } else {
+    h.delta = 0;
+    h.streak = 0;
+  }
+  h.last = r;
+  h.last.valid = true;
+}
+static bool noise_ahead_on() {
+  const char* e = getenv("VB_NOISE_AHEAD");
+  return !(e && atoi(e) == 0);
+}
+
+void noise_prefetch(vb_ctx* ctx) {
+  if (!ctx || !noise_ahead_on()) return;
+  bool ordered = false;      // main_stream_write once, and only when something is generated
+  for (int slot = 0; slot < VB_MAX_SLOTS; ++slot) {
+    NoiseSlot& s = ctx->noise[slot];
+    NoiseAhead& h = s.ahead;
+    if (h.streak < 2 || !h.last.valid || h.pre.valid || !s.buf.ptr || s.n != h.last.n || s.d != h.last.d) continue;
+    const size_t bytes = (size_t)s.n * s.ld * sizeof(double);
+    const bool fresh = !h.shadow.ptr || h.shadow.bytes < bytes;
+    if (ensure(ctx, h.shadow, bytes) != VB_OK) continue;      // (zero-filled when new)
+    if (!ordered && main_stream_write(ctx) != VB_OK) return;
+    ordered = true;
+    if (!fresh && (h.shadow_d != s.d || h.shadow_ld != s.ld) &&
+        hipMemsetAsync(h.shadow.ptr, 0, h.shadow.bytes, ctx->stream) != hipSuccess)      // pad columns [d, ld) must be zero
+      continue;
+    h.shadow_d = s.d, h.shadow_ld = s.ld;
+    NoiseReq nx = h.last;
+    nx.stream = h.last.stream + (uint64_t)h.delta;
+    if (rng_fill(ctx, (double*)h.shadow.ptr, s.ld, nx.kind, nx.df, nx.seed, nx.stream, nx.row_offset, nx.n, nx.d) != VB_OK) continue;
+    h.pre = nx;
+  }
+  NoiseAhead& c = ctx->chi_ahead;
+  if (c.streak >= 2 && c.last.valid && !c.pre.valid && ctx->chi_n == c.last.n && ctx->chi_dev.ptr) {
+    if (ensure(ctx, c.shadow, (size_t)c.last.n * sizeof(double)) != VB_OK) return;
+    if (!ordered && main_stream_write(ctx) != VB_OK) return;
+    NoiseReq nx = c.last;
+    nx.stream = c.last.stream + (uint64_t)c.delta;
+    if (rng_chisquare(ctx, (double*)c.shadow.ptr, nx.df, nx.seed, nx.stream, nx.row_offset, nx.n) == VB_OK) c.pre = nx;
+  }
+}
+
+
 void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals, int kernel_id) {
   *ev0 = *ev1 = nullptr;
   if (!ctx->profile || kernel_id < 0 || kernel_id >= VB_PROF_NUM) return;
@@ -264,10 +323,14 @@ static int check_slot(vb_ctx* ctx, int slot) {
   return VB_OK;
 }
 
-static int noise_alloc(vb_ctx* ctx, int slot, int64_t n, int64_t d) {
+static int noise_alloc(vb_ctx* ctx, int slot, int64_t n, int64_t d, bool keep_history = false) {
   VB_TRY(check_slot(ctx, slot));
   if (n <= 0 || d <= 0) return fail(ctx, VB_ERR_INVALID, "noise shape must be positive");
   NoiseSlot& s = ctx->noise[slot];
+  if (!keep_history) {      // a writer other than vb_noise_generate: the look-ahead's history ends here
+    s.ahead.last.valid = s.ahead.pre.valid = false;
+    s.ahead.streak = 0;
+  }
   // The t family's DIS state may be reading its residuals straight out of this slot (mvt_e_noise, vb_mvt.hip): new
   // contents or a new buffer end that -- a gradient that comes without a refresh in between forms its residuals from
   // the state samples again
@@ -391,8 +454,11 @@ int vb_destroy(vb_ctx* ctx) {
       (void)hipEventDestroy(ctx->pipe.ev_fin[i]);
     }
   }
-  for (auto& s : ctx->noise)
+  for (auto& s : ctx->noise) {
     if (s.buf.ptr) (void)hipFree(s.buf.ptr);
+    if (s.ahead.shadow.ptr) (void)hipFree(s.ahead.shadow.ptr);
+  }
+  if (ctx->chi_ahead.shadow.ptr) (void)hipFree(ctx->chi_ahead.shadow.ptr);
   for (auto& r : ctx->results)
     if (r.host) (void)hipHostFree(r.host);
   if (ctx->sync_result.host) (void)hipHostFree(ctx->sync_result.host);
@@ -466,9 +532,31 @@ int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
   if (!ctx) return VB_ERR_INVALID;
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
-  VB_TRY(noise_alloc(ctx, slot, n, d));
+  VB_TRY(check_slot(ctx, slot));
+  NoiseReq r;
+  r.kind = kind, r.df = df, r.seed = seed, r.stream = stream, r.row_offset = row_offset, r.n = n, r.d = d, r.valid = true;
+  {
+    NoiseSlot& s = ctx->noise[slot];
+    NoiseAhead& h = s.ahead;
+    if (h.pre.valid && h.shadow.ptr && s.buf.ptr && s.n == n && s.d == d && req_same_but_stream(h.pre, r) &&
+        h.pre.stream == stream && h.shadow.bytes >= (size_t)n * s.ld * sizeof(double) && noise_ahead_on()) {
+      // the look-ahead generated exactly this request: adopt its buffer (same geometry: n, d, ld stay)
+      if (ctx->mvt_e_noise && ctx->mvt_e_noise == (const double*)s.buf.ptr) {      // (as noise_alloc: new contents)
+        ctx->mvt_e_noise = nullptr;
+        ctx->mvt_theta.clear();
+      }
+      std::swap(s.buf, h.shadow);
+      h.pre.valid = false;
+      req_observe(h, r);
+      return VB_OK;
+    }
+  }
+  VB_TRY(noise_alloc(ctx, slot, n, d, true));
   NoiseSlot& s = ctx->noise[slot];
-  return rng_fill(ctx, (double*)s.buf.ptr, s.ld, kind, df, seed, stream, row_offset, n, d);
+  s.ahead.pre.valid = false;      // (a shadow that was not asked for is dropped)
+  VB_TRY(rng_fill(ctx, (double*)s.buf.ptr, s.ld, kind, df, seed, stream, row_offset, n, d));
+  req_observe(s.ahead, r);
+  return VB_OK;
 }
 
 int vb_chisq_generate(vb_ctx* ctx, double df, uint64_t seed, uint64_t stream, int64_t row_offset, int64_t n) {
@@ -476,11 +564,25 @@ int vb_chisq_generate(vb_ctx* ctx, double df, uint64_t seed, uint64_t stream, in
   if (n <= 0) return fail(ctx, VB_ERR_INVALID, "n must be positive");
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
+  NoiseReq r;
+  r.kind = -1, r.df = df, r.seed = seed, r.stream = stream, r.row_offset = row_offset, r.n = n, r.d = 1, r.valid = true;
+  NoiseAhead& c = ctx->chi_ahead;
+  if (c.pre.valid && c.shadow.ptr && ctx->chi_dev.ptr && req_same_but_stream(c.pre, r) && c.pre.stream == stream &&
+      c.shadow.bytes >= (size_t)n * sizeof(double) && ctx->chi_dev.bytes >= (size_t)n * sizeof(double) && noise_ahead_on()) {
+    std::swap(ctx->chi_dev, c.shadow);
+    c.pre.valid = false;
+    ctx->chi_n = n;
+    ctx->chi_df = df;
+    req_observe(c, r);
+    return VB_OK;
+  }
+  c.pre.valid = false;
   VB_TRY(ensure(ctx, ctx->chi_dev, (size_t)n * sizeof(double)));
   ctx->chi_n = 0;
   VB_TRY(rng_chisquare(ctx, (double*)ctx->chi_dev.ptr, df, seed, stream, row_offset, n));
   ctx->chi_n = n;
   ctx->chi_df = df;
+  req_observe(c, r);
   return VB_OK;
 }
 
@@ -698,6 +800,8 @@ int vb_legacy_rng_chisquare_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, i
   VB_TRY(main_stream_write(ctx));
   VB_TRY(ensure(ctx, ctx->chi_dev, (size_t)n * sizeof(double)));
   ctx->chi_n = 0;
+  ctx->chi_ahead.last.valid = ctx->chi_ahead.pre.valid = false;      // (not a Philox request: the look-ahead's history ends)
+  ctx->chi_ahead.streak = 0;
   VB_TRY(legacy_gamma_device(ctx, rng, 0, df, (double*)ctx->chi_dev.ptr, 1, n, 1, 0, n));
   ctx->chi_n = n;
   ctx->chi_df = df;
@@ -1067,6 +1171,7 @@ int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t
   ResultSlot& rs = ctx->sync_result;
   VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
   VB_TRY(alpha_enqueue(ctx, ctx->noise[slot], n, n_total, d, family, df, alpha, rs.dev, rs.dev + rs.p));
+  noise_prefetch(ctx);      // (the next call's noise while the host waits: NoiseAhead)
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rs.pending = false;
   *value = rs.host[rs.p];
@@ -1137,6 +1242,7 @@ int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int famil
   ResultSlot& rs = ctx->sync_result;
   VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
   VB_TRY(dis_grad_enqueue(ctx, ctx->noise[slot], n, d, family, df, rs.dev, weights, scale, rs.dev + rs.p));
+  noise_prefetch(ctx);
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   rs.pending = false;
   *value = rs.host[rs.p];

@@ -97,9 +97,30 @@ struct DeviceBuffer {
   size_t bytes = 0;
 };
 
+// a Philox generation request (vb_noise_generate / vb_chisq_generate): what a buffer holds
+struct NoiseReq {
+  int kind = 0;
+  double df = 0.0;
+  uint64_t seed = 0, stream = 0;
+  int64_t row_offset = 0, n = 0, d = 0;
+  bool valid = false;
+};
+// Look-ahead generation (vb_api.hip, noise_prefetch): a blocking call draws fresh Philox noise, runs its kernels, and
+// leaves the GPU idle while the host turns around.  When the last requests for a buffer walked the stream index in equal
+// steps (two confirmations), the NEXT request's values are generated into `shadow` behind the call's last kernel, while
+// the host waits and returns; the next vb_noise_generate with exactly those arguments adopts the shadow (a pointer swap)
+// instead of launching.  Counter-based streams: the values are the ones the request would have generated.
+struct NoiseAhead {
+  DeviceBuffer shadow;
+  int64_t shadow_d = 0, shadow_ld = 0;   // geometry the shadow's pad columns were zeroed for
+  NoiseReq last, pre;                    // what the live buffer holds; what the shadow holds (pre.valid)
+  int64_t delta = 0;
+  int streak = 0;
+};
 struct NoiseSlot {
   DeviceBuffer buf;
   int64_t n = 0, d = 0, ld = 0;   // ld: row stride in doubles (multiple of 16)
+  NoiseAhead ahead;
 };
 
 // Software pipeline over three HIP streams (prep | streaming kernel | finalize + collectives), used
@@ -215,6 +236,7 @@ struct vb_ctx {
   int64_t dis_n_total = 0;              // whole-job sample count of the DIS state
   vb::DeviceBuffer chi_dev;             // device-generated chi-square draws (vb_chisq_generate)
   vb::DeviceBuffer mvt_invs;            // 1 / s_n of the throughput-mode t ExclusiveKL (vb_elbo_grad_mvt_chol)
+  vb::NoiseAhead chi_ahead;             // look-ahead generation of the next chi-square draws (noise_prefetch)
   int64_t chi_n = 0;                    // how many of them are valid (0: none)
   double chi_df = 0.0;
   vb::DeviceBuffer bisect_work;         // DIS tempering bisection: interval / ESS tables of the look-ahead rounds
@@ -453,6 +475,7 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
 // host -> device copy of a small caller-owned array without a synchronisation (mapped staging slots + a copy kernel)
 int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, void* dev_dst, size_t row_bytes = 0,
                size_t dst_stride_bytes = 0);      // row_bytes != 0: rows of row_bytes land dst_stride_bytes apart
+void noise_prefetch(vb_ctx* ctx);   // look-ahead Philox generation; call right before a blocking call starts to wait (vb_api.hip)
 int comm_check(vb_ctx* ctx);     // VB_ERR_COMM when a device-side wait of the IPC transport has given up (vb_comm.hip)
 
 // full-rank Gaussian ExclusiveKL (vb_fullrank.hip)
