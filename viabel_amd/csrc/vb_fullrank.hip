@@ -377,13 +377,13 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
     const int i = (int)(idx / ldl), j = (int)(idx % ldl);
     fr_d2 s = (fr_d2){0.0, 0.0};
     if (full == 1 || j <= i) {
-      for (int k0 = 0; k0 < splits; k0 += 8) {
-        fr_d2 v[8];
+      for (int k0 = 0; k0 < splits; k0 += 16) {      // sixteen slabs in flight (eight until round 5), added in slab order
+        fr_d2 v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
           v[u] = k0 + u < splits ? *reinterpret_cast<const fr_d2*>(Cpart + (k0 + u) * slab + idx) : (fr_d2){0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 16; ++u) s += v[u];
       }
       if (full != 1 && j + 1 > i) s.y = 0.0;
     }
@@ -411,12 +411,12 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
   if (tid < ldz) {
     double s = 0.0;
     if (tid < d) {
-      for (int rb0 = 0; rb0 < n_rb; rb0 += 16) {      // 16 loads in flight, summed in row-block order
-        double v[16];
+      for (int rb0 = 0; rb0 < n_rb; rb0 += 32) {      // 32 loads in flight (16 until round 5), summed in row-block order
+        double v[32];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = rb0 + u < n_rb ? colpart[(int64_t)(rb0 + u) * ldz + tid] : 0.0;
+        for (int u = 0; u < 32; ++u) v[u] = rb0 + u < n_rb ? colpart[(int64_t)(rb0 + u) * ldz + tid] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += v[u];
+        for (int u = 0; u < 32; ++u) s += v[u];
       }
     }
     S.sums[S.off_col + tid] = s;
@@ -470,13 +470,13 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
     const int i = (int)(idx / ldl), j = (int)(idx % ldl);
     if (j <= i) {
       fr_d2 s = (fr_d2){0.0, 0.0};
-      for (int k0 = 0; k0 < splits; k0 += 8) {
-        fr_d2 v[8];
+      for (int k0 = 0; k0 < splits; k0 += 16) {      // sixteen slabs in flight (eight until round 5), added in slab order
+        fr_d2 v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
           v[u] = k0 + u < splits ? *reinterpret_cast<const fr_d2*>(Cpart + (k0 + u) * slab + idx) : (fr_d2){0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 16; ++u) s += v[u];
       }
       const int64_t p = (int64_t)i * (i + 1) / 2 + j;
       if (FUSE && weighted) {
@@ -506,12 +506,12 @@ __global__ void __launch_bounds__(256) fr_reduce_packed_kernel(
   if (tid < ldz) {
     double s = 0.0;
     if (tid < d) {
-      for (int rb0 = 0; rb0 < n_rb; rb0 += 16) {      // 16 loads in flight, summed in row-block order
-        double v[16];
+      for (int rb0 = 0; rb0 < n_rb; rb0 += 32) {      // 32 loads in flight (16 until round 5), summed in row-block order
+        double v[32];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = rb0 + u < n_rb ? colpart[(int64_t)(rb0 + u) * ldz + tid] : 0.0;
+        for (int u = 0; u < 32; ++u) v[u] = rb0 + u < n_rb ? colpart[(int64_t)(rb0 + u) * ldz + tid] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += v[u];
+        for (int u = 0; u < 32; ++u) s += v[u];
       }
     }
     if (FUSE) {
