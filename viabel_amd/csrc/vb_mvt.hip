@@ -959,22 +959,27 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
 // with PSIS reweighting"; the smoothing itself is viabel/_psis.py:113-209, vb_psis.hip): logarithms and the total by one
 // workgroup with the loads in flight, the one-workgroup PSIS kernel on them, exponentials back into the weight vector;
 // khat lands next to (eps, ess, status) and comes back with the step's single synchronisation.
+// (round 5: on up to kPsisPrepWg workgroups -- one workgroup took 15 us for 16 384 logarithms -- each leaving the sum of
+// its slice in total_out[g]; the apply kernel adds the slices in order)
+constexpr int kPsisPrepWg = 16;
 __global__ void __launch_bounds__(1024) mvt_psis_prep_kernel(const double* __restrict__ w, int64_t n, double* __restrict__ lw,
                                                              double* __restrict__ total_out) {
   __shared__ double sh[16];
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t i_begin = blockIdx.x * per, i_end = i_begin + per < n ? i_begin + per : n;
   double sw = 0.0;
-  for (int64_t i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
+  for (int64_t i0 = i_begin + threadIdx.x; i0 < i_end; i0 += 8 * 1024) {
     double wv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int64_t i = i0 + u * 1024;
-      wv[u] = i < n ? w[i] : 0.0;
+      wv[u] = i < i_end ? w[i] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int64_t i = i0 + u * 1024;
       sw += wv[u];
-      if (i < n) lw[i] = log(wv[u]);          // log 0 = -inf: a weight that stays zero
+      if (i < i_end) lw[i] = log(wv[u]);          // log 0 = -inf: a weight that stays zero
     }
   }
   sw = mvt_wave_sum(sw);
@@ -983,15 +988,17 @@ __global__ void __launch_bounds__(1024) mvt_psis_prep_kernel(const double* __res
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int k = 0; k < 16; ++k) t += sh[k];
-    total_out[0] = t;
+    total_out[blockIdx.x] = t;
   }
 }
 
 __global__ void __launch_bounds__(256) mvt_psis_apply_kernel(const double* __restrict__ lw, const double* __restrict__ psis_out,
-                                                             const double* __restrict__ total, int64_t n,
+                                                             const double* __restrict__ total, int n_slices, int64_t n,
                                                              double* __restrict__ w, double* __restrict__ khat_out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) w[i] = total[0] * exp(lw[i]);
+  double t = 0.0;
+  for (int g = 0; g < n_slices; ++g) t += total[g];      // (uniform, out of the scalar cache; every thread the same order)
+  if (i < n) w[i] = t * exp(lw[i]);
   if (i == 0) khat_out[0] = psis_out[0];
 }
 
@@ -1003,15 +1010,17 @@ int mvt_dis_psis_enqueue(vb_ctx* ctx, int64_t n_total, double reff) {
   double* base = (double*)ctx->mvt_state.ptr;
   hipStream_t st = ctx->stream;
   const int64_t nn = round_up(n_total, 16);
-  VB_TRY(ensure(ctx, ctx->psis_lw, (size_t)(nn + 16) * sizeof(double)));
+  VB_TRY(ensure(ctx, ctx->psis_lw, (size_t)(nn + 32) * sizeof(double)));
   double* lw = (double*)ctx->psis_lw.ptr;
-  hipLaunchKernelGGL(mvt_psis_prep_kernel, dim3(1), dim3(1024), 0, st, (const double*)(base + L.o_w), n_total, lw,
-                     base + L.o_scal + 12);
+  // (slice totals: 16 doubles behind the smoothed vector's 16-double result area)
+  double* totals = lw + nn + 16;
+  const int slices = (int)((n_total + 1023) / 1024) < kPsisPrepWg ? (int)((n_total + 1023) / 1024) : kPsisPrepWg;
+  hipLaunchKernelGGL(mvt_psis_prep_kernel, dim3((unsigned)slices), dim3(1024), 0, st, (const double*)(base + L.o_w), n_total, lw,
+                     totals);
   VB_HIP(ctx, hipGetLastError());
   VB_TRY(psis_enqueue(ctx, n_total, reff));
   hipLaunchKernelGGL(mvt_psis_apply_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, st, (const double*)lw,
-                     (const double*)(lw + nn), (const double*)(base + L.o_scal + 12), n_total, base + L.o_w,
-                     base + L.o_scal + 11);
+                     (const double*)(lw + nn), (const double*)totals, slices, n_total, base + L.o_w, base + L.o_scal + 11);
   VB_HIP(ctx, hipGetLastError());
   ctx->psis_n = 0;
   return VB_OK;
