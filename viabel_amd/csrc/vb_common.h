@@ -398,15 +398,29 @@ void user_model_release(vb_ctx* ctx);
 int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, double* gauss, const NoiseSlot& ns,
                      int64_t n_total, int64_t d, int64_t row_begin, int64_t rows);
 // numpy's legacy word stream on the device (vb_legacy_dev.hip) for the draws built on it (vb_legacy_gamma.hip)
+struct FetchSeg {                  // `bytes` (a multiple of 8) from device address `src` (8-byte aligned) to host address `dst`
+  const void* src;
+  size_t bytes;
+  void* dst;
+};
 struct LegacyWords {
   const uint32_t* words = nullptr;   // untempered output words, words[0] = the word at the generator's position
   int64_t* scal = nullptr;           // 8 zeroed 64-bit scalars
   uint32_t* extra = nullptr;         // the caller's scratch
   const void* logtab = nullptr;      // GlibcLogData on the device, or NULL when the host's log could not be restated
   int64_t pre = 0, n_words = 0;      // words left in the generator's current block; words generated
+  uint32_t* key_io = nullptr;        // 624 words: the uploaded key; legacy_mt_finish_fetch gathers the end block here
+  int64_t* meta = nullptr;           // 2 scalars of that gather: [status, new position]
 };
 int legacy_mt_words(vb_ctx* ctx, const uint32_t key[624], int pos, int64_t n_words, size_t extra_u32, LegacyWords* out);
 int legacy_mt_finish(vb_ctx* ctx, const LegacyWords& lw, int64_t w_star, uint32_t key[624], int* pos);
+// The same with the end position still on the device: w_star = mult * (src_dev[0] + add).  A one-workgroup kernel finds
+// the end block and gathers its words; ONE fetch_blocking brings the caller's result segments (extra), the block and the
+// new position.  accept(extra results) decides on the host whether the draw stands (false: nothing is changed, returns
+// VB_ERR_UNSUPPORTED).
+int legacy_mt_finish_fetch(vb_ctx* ctx, const LegacyWords& lw, const int64_t* src_dev, int64_t mult, int64_t add,
+                           const FetchSeg* extra, int n_extra, bool (*accept)(void*), void* accept_arg, uint32_t key[624],
+                           int* pos);
 // chisquare (prog 0) / standard_t (prog 1) draws, values o_first ... n - 1 of the request, into rows of a noise-slot-like
 // array (vb_legacy_gamma.hip); the generator must hold no cached normal
 int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* pos, int* has_gauss, double* gauss,
@@ -464,11 +478,6 @@ int psis_tail_size(int64_t n, double reff);
 int alpha_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, int family, double df,
                   double alpha, const double* theta_src, double* out);
 int sync_streams(vb_ctx* ctx);   // main + pipeline streams
-struct FetchSeg {                  // `bytes` (a multiple of 8) from device address `src` (8-byte aligned) to host address `dst`
-  const void* src;
-  size_t bytes;
-  void* dst;
-};
 // blocking device -> host fetch of small results: one gathering kernel into mapped memory + a polled completion word
 // (vb_api.hip); plain copies + hipStreamSynchronize above 1 MB
 int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs);

@@ -473,7 +473,7 @@ int legacy_mt_words(vb_ctx* ctx, const uint32_t key[624], int pos, int64_t n_wor
   int64_t pow2 = 1;      // (capacity of the state / sequence areas: a power of four)
   while (pow2 < streams) pow2 <<= 2;
   // (fixed-size regions first: the polynomials and the log table stay where they were uploaded from call to call)
-  const size_t o_poly = carve((size_t)kMtJumpPolys * kN), o_key = carve(kN), o_scal = carve(16),
+  const size_t o_poly = carve((size_t)kMtJumpPolys * kN), o_key = carve(kN), o_scal = carve(16), o_meta = carve(4),
                o_log = carve(sizeof(GlibcLogData) / sizeof(uint32_t)),
                o_words = carve((size_t)(pre + n_blocks * kN) + 8), o_state = carve((size_t)pow2 * kN),
                o_seq = carve((size_t)(pow2 / 4 > 0 ? pow2 / 4 : 1) * kSeqWords), o_extra = carve(extra_u32);
@@ -487,7 +487,8 @@ int legacy_mt_words(vb_ctx* ctx, const uint32_t key[624], int pos, int64_t n_wor
     ctx->legacy_poly_at = poly;
     ctx->legacy_poly_bytes = ctx->legacy_work.bytes;
   }
-  VB_HIP(ctx, hipMemcpyAsync(key_dev, key, kN * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  // (the key through a mapped staging slot and a copy kernel: a pageable source makes the runtime stage and wait)
+  VB_TRY(push_small(ctx, st, key, kN * sizeof(uint32_t), key_dev));
   VB_HIP(ctx, hipMemsetAsync(state, 0, (size_t)pow2 * kN * sizeof(uint32_t), st));
   VB_HIP(ctx, hipMemsetAsync(base + o_scal, 0, 16 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(mtd_first_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)key_dev, pos, words, state);
@@ -506,6 +507,8 @@ int legacy_mt_words(vb_ctx* ctx, const uint32_t key[624], int pos, int64_t n_wor
   out->logtab = host_tab ? (const void*)(base + o_log) : nullptr;
   out->pre = pre;
   out->n_words = pre + n_blocks * kN;
+  out->key_io = key_dev;
+  out->meta = (int64_t*)(base + o_meta);
   return VB_OK;
 }
 
@@ -525,6 +528,58 @@ int legacy_mt_finish(vb_ctx* ctx, const LegacyWords& lw, int64_t w_star, uint32_
   VB_HIP(ctx, hipMemcpyAsync(key, lw.words + lw.pre + key_block * kN, kN * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *pos = new_pos;
+  return VB_OK;
+}
+
+namespace {
+// the end block of a draw whose consumed word count is still on the device: meta = [status, new position]; status 0: the
+// block's words are in key_out; 2: the draw ended inside the block it started in (position += w_star, key unchanged);
+// 1: inconsistent end position
+__global__ void __launch_bounds__(256) mtd_key_gather_kernel(const uint32_t* __restrict__ words, int64_t pre, int64_t n_words,
+                                                             const int64_t* __restrict__ src, int64_t mult, int64_t add,
+                                                             uint32_t* __restrict__ key_out, int64_t* __restrict__ meta) {
+  const int64_t w_star = mult * (src[0] + add);
+  int64_t status = 0, new_pos = 0, key_block = 0;
+  if (w_star <= pre) {
+    status = 2;
+    new_pos = w_star;
+  } else {
+    const int64_t offw = w_star - pre;
+    key_block = offw / kN;
+    new_pos = offw % kN;
+    if (new_pos == 0) key_block -= 1, new_pos = kN;      // exactly at a block end: numpy refreshes lazily
+    if (key_block < 0 || pre + (key_block + 1) * kN > n_words) status = 1;
+  }
+  if (status == 0)
+    for (int t = threadIdx.x; t < kN; t += 256) key_out[t] = words[pre + key_block * kN + t];
+  if (threadIdx.x == 0) meta[0] = status, meta[1] = new_pos;
+}
+}  // namespace
+
+int legacy_mt_finish_fetch(vb_ctx* ctx, const LegacyWords& lw, const int64_t* src_dev, int64_t mult, int64_t add,
+                           const FetchSeg* extra, int n_extra, bool (*accept)(void*), void* accept_arg, uint32_t key[624],
+                           int* pos) {
+  if (n_extra > 5) return fail(ctx, VB_ERR_INVALID, "legacy_mt_finish_fetch: too many segments");
+  hipLaunchKernelGGL(mtd_key_gather_kernel, dim3(1), dim3(256), 0, ctx->stream, lw.words, lw.pre, lw.n_words, src_dev, mult, add,
+                     lw.key_io, lw.meta);
+  VB_HIP(ctx, hipGetLastError());
+  uint32_t block[kN];
+  int64_t meta[2] = {1, 0};
+  int64_t wsrc = 0;
+  FetchSeg segs[8];
+  for (int k = 0; k < n_extra; ++k) segs[k] = extra[k];
+  segs[n_extra] = FetchSeg{lw.key_io, kN * sizeof(uint32_t), block};
+  segs[n_extra + 1] = FetchSeg{lw.meta, sizeof meta, meta};
+  segs[n_extra + 2] = FetchSeg{src_dev, sizeof wsrc, &wsrc};
+  VB_TRY(fetch_blocking(ctx, ctx->stream, segs, n_extra + 3));
+  if (accept && !accept(accept_arg)) return VB_ERR_UNSUPPORTED;
+  if (meta[0] == 1) return fail(ctx, VB_ERR_STATE, "legacy generator: inconsistent end position");
+  if (meta[0] == 2) {
+    *pos = (int)(*pos + mult * (wsrc + add));      // still inside the block the call started in
+    return VB_OK;
+  }
+  memcpy(key, block, sizeof block);
+  *pos = (int)meta[1];
   return VB_OK;
 }
 
@@ -611,6 +666,27 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
                        (const int*)a.hard_cnt, (const int64_t*)hbase, hard_list, scal + 4);
   }
   VB_HIP(ctx, hipGetLastError());
+  if (exact) {
+    // no list, no host arithmetic: the scalars, the acceptance count and the generator's end block in ONE fetch (the
+    // end position is a device scalar: legacy_mt_finish_fetch finds and gathers the block there)
+    int64_t res4[4] = {0, 0, 0, 0}, got = 0;
+    struct Check {
+      const int64_t* got;
+      int64_t pairs;
+    } chk{&got, pairs};
+    const FetchSeg extra[2] = {{scal, sizeof res4, res4}, {pbase + n_wg, sizeof got, &got}};
+    int new_pos = *pos;
+    const int rc = legacy_mt_finish_fetch(ctx, lw, scal, 4, 1, extra, 2,
+                                          [](void* p) { return *((Check*)p)->got >= ((Check*)p)->pairs; }, &chk, key, &new_pos);
+    if (rc == VB_ERR_UNSUPPORTED) return rc;      // (the word budget fell short: host path, nothing changed)
+    VB_TRY(rc);
+    double last_x1f;
+    memcpy(&last_x1f, &res4[3], sizeof last_x1f);
+    *pos = new_pos;
+    *has_gauss = (n_vals & 1) ? 1 : 0;
+    *gauss = (n_vals & 1) ? last_x1f : 0.0;
+    return VB_OK;
+  }
   // results through one pinned buffer: [scalars 4 | accepted | list (first `spec` entries, speculatively) | fixed]
   const int64_t spec = std::min<int64_t>(hard_cap, pairs / 20 + 256);      // ~1.7 x the expected list length
   const size_t pin_doubles = 8 + (exact ? 0 : (size_t)4 * hard_cap + (size_t)3 * hard_cap) + 8;

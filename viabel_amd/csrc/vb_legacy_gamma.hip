@@ -621,12 +621,14 @@ int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* p
     hipLaunchKernelGGL(lg_pending_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, a, par, n_chunks);
   }
   VB_HIP(ctx, hipGetLastError());
-  int64_t end[4];
-  VB_HIP(ctx, hipMemcpyAsync(end, a.end, sizeof end, hipMemcpyDeviceToHost, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
-  if (end[0] < 0 || end[3] != 0) return VB_ERR_UNSUPPORTED;      // budget short, or a case the path does not take
+  int64_t end[4] = {-1, 0, 0, 1};
+  const FetchSeg extra[1] = {{a.end, sizeof end, end}};
   int new_pos = *pos;
-  VB_TRY(legacy_mt_finish(ctx, lw, 2 * end[0], key, &new_pos));
+  // (the end scalars and the generator's end block in one fetch: the block is found and gathered on the device)
+  const int rc = legacy_mt_finish_fetch(ctx, lw, a.end, 2, 0, extra, 1,
+                                        [](void* p) { return ((int64_t*)p)[0] >= 0 && ((int64_t*)p)[3] == 0; }, end, key, &new_pos);
+  if (rc == VB_ERR_UNSUPPORTED) return rc;      // budget short, or a case the path does not take
+  VB_TRY(rc);
   *pos = new_pos;
   *has_gauss = end[1] ? 1 : 0;
   double cached = 0.0;

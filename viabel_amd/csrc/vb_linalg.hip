@@ -332,8 +332,9 @@ int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, 
   double* base = (double*)ctx->scratch.ptr;
   double *M0 = base + 6 * mat, *scal = base + 7 * mat;
   hipStream_t st = ctx->stream;
-  VB_HIP(ctx, hipStreamSynchronize(st));      // earlier users of the pinned partials are done
-  memset(ctx->pin_host, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double));
+  // the ring of partial sums starts from zero -- cleared by the DEVICE, in stream order (a host memset would have to wait
+  // for the stream first: one wake-up per root, ~20 us of a 0.2 ms iteration)
+  VB_HIP(ctx, hipMemsetAsync(ctx->pin_dev, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double), st));
   VB_HIP(ctx, hipMemsetAsync(scal, 0, sizeof(double), st));
   gemm_f64_launch<true>(st, square(Lfull, Lt, ld, m), 1, n_cu, EpiStore{M0, ld});
   hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, (const double*)M0, m, ld, scal);
@@ -428,8 +429,7 @@ int sym_sqrt_frechet_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, con
   double* base = (double*)ctx->scratch.ptr;
   double *M0 = base + 6 * mat, *A = base + 7 * mat, *scal = A + small;
   hipStream_t st = ctx->stream;
-  VB_HIP(ctx, hipStreamSynchronize(st));
-  memset(ctx->pin_host, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double));
+  VB_HIP(ctx, hipMemsetAsync(ctx->pin_dev, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double), st));      // (as sym_sqrt_dev)
   VB_HIP(ctx, hipMemsetAsync(scal, 0, 4 * sizeof(double), st));
   gemm_f64_launch<true>(st, square(Lfull, Lt, ld, (int)d), 1, n_cu, EpiStore{A, ld});
   hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, st, (const double*)A, (int)d, ld, scal);
