@@ -445,7 +445,8 @@ int pipe_init(vb_ctx* ctx);
 // per-row log weights and AlphaDivergence (vb_rowstats.hip)
 int rowstats_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_src,
                      const ModelDev& model, int student, double df, double* cols, double* scal,
-                     double* out_f, double* out_b);
+                     double* out_f, double* out_b, const ModelDev* prior = nullptr,
+                     double* out_prior = nullptr);
 int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, int family, double df,
                         const double* theta_src, const double* prior_host, double eps_prev, double ess_target,
                         int max_its, double* eps_out, double* ess_out, int* status_out, double* w_host,

@@ -59,7 +59,13 @@ __global__ void __launch_bounds__(256) rs_rowstats_kernel(const double* __restri
                                                           int64_t n, int d, const double* __restrict__ cols,
                                                           ModelDev m, int student, double df,
                                                           double* __restrict__ out_f,
-                                                          double* __restrict__ out_b) {
+                                                          double* __restrict__ out_b,
+                                                          const double* __restrict__ q0 = nullptr,
+                                                          const double* __restrict__ q1 = nullptr, double qc = 0.0,
+                                                          double* __restrict__ out_q = nullptr) {
+  // q0 != nullptr: the same pass also evaluates a diagonal Gaussian (mean q0, inverse variances q1, constant qc) at the
+  // samples into out_q -- DISInclusiveKL's tempering prior next to the target, one read of the noise instead of two
+  // (the sum runs in the order the second pass used: the same bits)
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
@@ -69,7 +75,7 @@ __global__ void __launch_bounds__(256) rs_rowstats_kernel(const double* __restri
   const bool funnel = m.id == VB_MODEL_FUNNEL;
   double v = 0.0;
   if (funnel) v = fma(sg[m.k], e_row[m.k], mu[m.k]);
-  double af = 0.0, ab = 0.0;
+  double af = 0.0, ab = 0.0, aq = 0.0;
   for (int64_t c = 2 * lane; c < ld; c += 128) {   // columns [d, ld) are zero pads of noise and cols
     const d2r e = *reinterpret_cast<const d2r*>(e_row + c);
     const d2r mm = *reinterpret_cast<const d2r*>(mu + c);
@@ -86,13 +92,19 @@ __global__ void __launch_bounds__(256) rs_rowstats_kernel(const double* __restri
           const double dz = z - m.p0[col];
           af = fma(-0.5 * dz * dz, m.p1[col], af);
         }
+        if (q0) {
+          const double dq = z - q0[col];
+          aq = fma(-0.5 * dq * dq, q1[col], aq);
+        }
       }
       ab += student ? -0.5 * (df + 1.0) * log1p(eh * eh / df) : -0.5 * eh * eh;
     }
   }
   af = rs_wave_sum(af);
   ab = rs_wave_sum(ab);
+  if (q0) aq = rs_wave_sum(aq);
   if (lane == 0) {
+    if (q0) out_q[row] = aq + qc;
     double f;
     if (funnel) {
       const double it2 = 1.0 / (m.tau * m.tau), dm1 = (double)(d - 1);
@@ -172,7 +184,7 @@ __global__ void __launch_bounds__(256) rs_sample_kernel(const double* __restrict
 
 int rowstats_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, const double* theta_src,
                      const ModelDev& model, int student, double df, double* cols, double* scal,
-                     double* out_f, double* out_b) {
+                     double* out_f, double* out_b, const ModelDev* prior, double* out_prior) {
   hipLaunchKernelGGL(rs_cols_kernel, dim3(1), dim3(256), 0, ctx->stream, theta_src, (int)d, ns.ld, cols, scal);
   VB_HIP(ctx, hipGetLastError());
   if (model.id == VB_MODEL_SOURCE) {
@@ -197,7 +209,8 @@ int rowstats_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, con
   }
   hipLaunchKernelGGL(rs_rowstats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream,
                      (const double*)ns.buf.ptr, ns.ld, n, (int)d, (const double*)cols, model, student, df,
-                     out_f, out_b);
+                     out_f, out_b, prior ? prior->p0 : (const double*)nullptr, prior ? prior->p1 : (const double*)nullptr,
+                     prior ? prior->c0 : 0.0, prior ? out_prior : (double*)nullptr);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -692,13 +705,18 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
   prior.p0 = base + L.o_prior;
   prior.p1 = base + L.o_prior + ld;
 
+  // (built-in targets: the tempering prior's log density comes out of the same pass; a source model's pass is its own)
+  const bool fused_prior = ctx->model.id != VB_MODEL_SOURCE;
   VB_TRY(rowstats_enqueue(ctx, ns, n, d, theta_src, ctx->model, student, df, base + L.o_cols, base + L.o_scal,
-                          base + L.o_lp + mine, base + L.o_b + mine));
-  // second pass: log prior(z_n); its base sums land in the (later overwritten) lq area
-  hipLaunchKernelGGL(rs_rowstats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
-                     (const double*)ns.buf.ptr, ld, n, (int)d, (const double*)(base + L.o_cols), prior, student,
-                     df, base + L.o_lprior + mine, base + L.o_lq);
-  VB_HIP(ctx, hipGetLastError());
+                          base + L.o_lp + mine, base + L.o_b + mine, fused_prior ? &prior : nullptr,
+                          base + L.o_lprior + mine));
+  if (!fused_prior) {
+    // second pass: log prior(z_n); its base sums land in the (later overwritten) lq area
+    hipLaunchKernelGGL(rs_rowstats_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
+                       (const double*)ns.buf.ptr, ld, n, (int)d, (const double*)(base + L.o_cols), prior, student,
+                       df, base + L.o_lprior + mine, base + L.o_lq);
+    VB_HIP(ctx, hipGetLastError());
+  }
   if (ctx->temper.kind != VB_PRIOR_DIAG_GAUSSIAN) {
     // a tempering prior that is not a diagonal Gaussian (vb_dis_set_temper_prior) needs the samples themselves
     const int64_t ldz = round_up(d, 16);
