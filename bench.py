@@ -424,10 +424,10 @@ def mvt_ekl_leg(vb, calls=50):
     from viabel_amd import objectives as _vobj
     pd = {}
     for name, gate in (('resident', None), ('host_root_route', 10 ** 6)):
-        keep = _vobj._HOST_ROOT_MAX_DIM
+        keep = _vobj._HOST_ROOT_MAX_DIM, _vobj._RESIDENT_GATE
         try:
             if gate is not None:
-                _vobj._HOST_ROOT_MAX_DIM = gate
+                _vobj._HOST_ROOT_MAX_DIM = _vobj._RESIDENT_GATE = gate
             obj = vb.ExclusiveKL(vb.MultivariateT(D, df, seed=1), vb.GaussianModel(mean, sd), N, use_path_deriv=True)
             for _ in range(2):
                 obj(theta)
@@ -436,7 +436,7 @@ def mvt_ekl_leg(vb, calls=50):
                 v, g = obj(theta)
             pd[name + '_ms_per_call'] = 1e3 * (time.perf_counter() - t0) / 6
         finally:
-            _vobj._HOST_ROOT_MAX_DIM = keep
+            _vobj._HOST_ROOT_MAX_DIM, _vobj._RESIDENT_GATE = keep
     pd['value'] = float(v)
     out['parity_mode_path_deriv'] = pd
     out['parity_mode']['note'] = ("rng='numpy': the reference's chi-square + normal streams on the device, its symmetric root "
@@ -605,10 +605,10 @@ def alpha_leg(vb, calls=30):
     mean, sd = 0.1 * mrng.randn(256), np.exp(0.1 * mrng.randn(256))
     par = {}
     for name, gate in (('resident', None), ('host_root_route', 10 ** 6)):
-        keep = _vobj._HOST_ROOT_MAX_DIM
+        keep = _vobj._HOST_ROOT_MAX_DIM, _vobj._RESIDENT_GATE
         try:
             if gate is not None:
-                _vobj._HOST_ROOT_MAX_DIM = gate
+                _vobj._HOST_ROOT_MAX_DIM = _vobj._RESIDENT_GATE = gate
             approx = vb.MultivariateT(256, 100)
             obj = vb.AlphaDivergence(approx, vb.GaussianModel(mean, sd), 16384, 0.5)
             theta = approx.init_param()
@@ -620,7 +620,7 @@ def alpha_leg(vb, calls=30):
                 v, g = obj(theta)
             par[name + '_ms_per_call'] = 1e3 * (time.perf_counter() - t0) / 6
         finally:
-            _vobj._HOST_ROOT_MAX_DIM = keep
+            _vobj._HOST_ROOT_MAX_DIM, _vobj._RESIDENT_GATE = keep
     out['multivariate_t_gauss_diag_d256_n16384']['parity_mode'] = par
     return out
 

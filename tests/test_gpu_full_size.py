@@ -276,13 +276,13 @@ def test_multivariate_t_exclusive_kl_reference_mode_resident(vb, target, path_de
     eng.elbo_grad_mvt_symroot = real
     assert calls == [path_deriv, path_deriv]      # (the resident entry point ran, in the right form)
     # the host-root route on the same draws (the resident path switched off through its dimension gate)
-    keep = vobj._HOST_ROOT_MAX_DIM
+    keep = vobj._HOST_ROOT_MAX_DIM, vobj._RESIDENT_GATE
     try:
-        vobj._HOST_ROOT_MAX_DIM = 10 ** 6
+        vobj._HOST_ROOT_MAX_DIM = vobj._RESIDENT_GATE = 10 ** 6
         approx2 = vb.MultivariateT(D, df, seed=6)
         v2, g2 = vb.ExclusiveKL(approx2, model, N, use_path_deriv=path_deriv)(theta)
     finally:
-        vobj._HOST_ROOT_MAX_DIM = keep
+        vobj._HOST_ROOT_MAX_DIM, vobj._RESIDENT_GATE = keep
     approx3 = vb.MultivariateT(D, df, seed=6)
     v3, g3 = vb.ExclusiveKL(approx3, model, N, use_path_deriv=path_deriv)(theta)
     assert abs(v3 - v2) <= 1e-11 * abs(v2)
@@ -328,15 +328,61 @@ def test_multivariate_t_alpha_reference_mode_resident(vb, target, alpha):
     ov, og = oobj.alpha_divergence(omvt, omodel, theta, noise, alpha)
     assert abs(value - ov) <= 1e-11 * abs(ov), (value, ov)
     np.testing.assert_allclose(grad, og, rtol=0, atol=1e-9 * np.max(np.abs(og)))
-    keep = vobj._HOST_ROOT_MAX_DIM
+    keep = vobj._HOST_ROOT_MAX_DIM, vobj._RESIDENT_GATE
     try:
-        vobj._HOST_ROOT_MAX_DIM = 10 ** 6
+        vobj._HOST_ROOT_MAX_DIM = vobj._RESIDENT_GATE = 10 ** 6
         np.random.seed(17)
         v2, g2 = vb.AlphaDivergence(vb.MultivariateT(D, df), model, N, alpha)(theta)
     finally:
-        vobj._HOST_ROOT_MAX_DIM = keep
+        vobj._HOST_ROOT_MAX_DIM, vobj._RESIDENT_GATE = keep
     assert abs(value - v2) <= 1e-11 * abs(v2)
     np.testing.assert_allclose(grad, g2, rtol=0, atol=1e-9 * np.max(np.abs(g2)))
+
+
+@pytest.mark.parametrize('D', [2, 5, 16, 33, 100, 160])
+def test_resident_reference_mode_at_small_dimensions(vb, D):
+    """The resident reference-identical routes of the t family are taken for every D once the chi-square draws are on the
+    device (N >= 4096; objectives._RESIDENT_GATE, measured faster than the host-root route from D = 2 up): ExclusiveKL in
+    both forms, AlphaDivergence and the DIS step against the oracle on numpy's own draws, at dimensions where rounds 3-4
+    went through LAPACK on the host."""
+    from viabel_amd import _lib
+    N, df = 4096, 9.0
+    rng = np.random.RandomState(100 + D)
+    mean, sd = 0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D))
+    model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
+    B = rng.randn(D, D)
+    theta = np.concatenate([0.2 * rng.randn(D), ofam.psd_to_free(0.3 * (B @ B.T / D + 0.5 * np.eye(D)))])
+    omvt = ofam.MultivariateT(D, df)
+    eng = _lib.default_engine()
+    used = []
+    real = {k: getattr(eng, k) for k in ('elbo_grad_mvt_symroot', 'alpha_grad_mvt_symroot', 'dis_refresh_mvt_symroot')}
+    for k, f in real.items():
+        setattr(eng, k, (lambda name, fn: lambda *a, **kw: (used.append(name), fn(*a, **kw))[1])(k, f))
+    try:
+        for pd in (False, True):
+            v, g = vb.ExclusiveKL(vb.MultivariateT(D, df, seed=6), model, N, use_path_deriv=pd)(theta)
+            ov, og = oobj.exclusive_kl(omvt, omodel, theta, omvt.draw_noise(np.random.RandomState(6), N), pd)
+            assert abs(v - ov) <= 1e-10 * abs(ov), (pd, v, ov)
+            np.testing.assert_allclose(g, og, rtol=0, atol=1e-8 * np.max(np.abs(og)))
+        np.random.seed(17)
+        v, g = vb.AlphaDivergence(vb.MultivariateT(D, df), model, N, 0.5)(theta)
+        np.random.seed(17)
+        noise = omvt.draw_noise(np.random.RandomState(np.random.randint(2 ** 32)), N)
+        ov, og = oobj.alpha_divergence(omvt, omodel, theta, noise, 0.5)
+        assert abs(v - ov) <= 1e-10 * abs(ov)
+        np.testing.assert_allclose(g, og, rtol=0, atol=1e-8 * np.max(np.abs(og)))
+        prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
+        obj = vb.DISInclusiveKL(vb.MultivariateT(D, df, seed=6), model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+                                temper_prior_params=prior, use_resampling=False)
+        ref = oobj.DISInclusiveKL(omvt, omodel, N, N // 8, ofam.MFGaussian(D), prior, use_resampling=False)
+        v, g = obj(theta)
+        ov, og = ref(theta, noise=omvt.draw_noise(np.random.RandomState(6), N))
+        assert abs(obj._eps - ref._eps) <= 1e-10 and abs(v - ov) <= 1e-9 * abs(ov), (obj._eps, ref._eps, v, ov)
+        np.testing.assert_allclose(g, og, rtol=0, atol=1e-8 * np.max(np.abs(og)))
+    finally:
+        for k, f in real.items():
+            setattr(eng, k, f)
+    assert used.count('elbo_grad_mvt_symroot') == 2 and 'alpha_grad_mvt_symroot' in used and 'dis_refresh_mvt_symroot' in used, used
 
 
 def test_reference_mode_falls_back_when_the_device_root_does_not_resolve(vb):

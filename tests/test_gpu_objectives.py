@@ -967,3 +967,31 @@ def test_dis_clip_active_branch(vb, family, use_resampling, thr):
         og = -ofamily.log_density_grad_weighted(theta, ref._state_samples, counts) * scale
     assert G.rel_err(value, ov) < 1e-10, (value, ov)
     assert G.rel_err(grad, og) < 1e-9, G.rel_err(grad, og)
+
+
+def test_lazy_dis_state_survives_another_objective(vb):
+    """A device-resident step leaves its weights / per-sample logs on the device until they are read.  Another objective
+    refreshing on the same engine -- or the t family's resident ExclusiveKL, which reuses the buffers -- must not change
+    what the first one reports afterwards (the reference's ``_state_*`` are plain arrays of their own refresh)."""
+    D, N = 12, 4096
+    rng = np.random.RandomState(21)
+    model = vb.GaussianModel(0.3 * rng.randn(D), np.exp(0.1 * rng.randn(D)))
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    A = rng.randn(D, D)
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(A @ A.T / D + np.eye(D))])
+
+    def make(seed, **kw):
+        return vb.DISInclusiveKL(vb.MultivariateT(D, 9.0, seed=seed, rng=kw.pop('rng', 'numpy')), model, N, ess_target=500,
+                                 temper_prior=vb.MFGaussian(D), temper_prior_params=prior, use_resampling=False, **kw)
+    for rng_kind in ('numpy', 'philox'):
+        a, b = make(3, rng=rng_kind), make(3, rng=rng_kind)
+        a(theta)
+        want_w, want_lp = np.array(a._state_w_clipped), np.array(a._state_log_p_unnormalized)
+        b(theta)                                    # read at once: the reference values
+        c = make(4, rng=rng_kind)                   # another stream: another state
+        b2 = make(3, rng=rng_kind)
+        b2(theta)                                   # same draws as `a`; nothing read yet
+        c(theta)                                    # overwrites the engine's state
+        vb.ExclusiveKL(vb.MultivariateT(D, 9.0, seed=8), model, N)(theta)      # reuses the buffers (resident route)
+        np.testing.assert_array_equal(b2._state_w_clipped, want_w)
+        np.testing.assert_array_equal(b2._state_log_p_unnormalized, want_lp)

@@ -15,6 +15,7 @@ all-reduced on the device before the epilogue; every rank returns the same ``(va
 from abc import ABC, abstractmethod
 
 import os
+import weakref
 
 import numpy as np
 from scipy import linalg as _sla
@@ -42,6 +43,18 @@ def shard_rows(n, n_ranks, rank):
     base, extra = divmod(n, n_ranks)
     begin = rank * base + min(rank, extra)
     return begin, begin + base + (1 if rank < extra else 0)
+
+
+def _claim_engine_state(eng, kind, owner):
+    """The engine keeps one DIS state per family kind; `owner` (an objective, or None for a call that merely reuses the
+    state's buffers: the resident ExclusiveKL / AlphaDivergence of the t family) is about to overwrite it.  The previous
+    owner fetches what it left on the device first (``DISInclusiveKL._materialize_state``)."""
+    owners = eng.__dict__.setdefault('_dis_state_owner', {})
+    ref = owners.get(kind)
+    other = ref() if ref is not None else None
+    if other is not None and other is not owner:
+        other._materialize_state()
+    owners[kind] = weakref.ref(owner) if owner is not None else None
 
 
 def _shared_randint(eng):
@@ -526,12 +539,13 @@ class ExclusiveKL(StochasticVariationalObjective):
                                    row_offset=begin)
             else:
                 # chi-square draws first (approximations.py:345-347)
-                want_resident = eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
+                want_resident = eng.n_ranks == 1 and D > _RESIDENT_GATE
                 chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, host_chi=not want_resident)
                 if want_resident and getattr(approx, '_chi_on_device', False):
                     # the whole evaluation resident on the device: both noise streams are there already, the symmetric
                     # root and its Frechet derivative are device iterations, the chain rule to the free Cholesky
                     # parameters two more kernels (vb_elbo_grad_mvt_symroot); None: an iteration did not resolve
+                    _claim_engine_state(eng, 1, None)      # (the call reuses the DIS state's buffers)
                     resident = eng.elbo_grad_mvt_symroot(_NOISE_SLOT, N, D, df, var_param, path_deriv=path_deriv)
                     if resident is not None:
                         return resident
@@ -657,6 +671,12 @@ _ROOT_TOL = 1e-12     # ||root root - Sigma|| / ||Sigma|| accepted from the Newt
 # (0.5 ms whatever the size).  Measured per objective call (tools/mvt_root_bench.py, tools/small_shapes_bench.py):
 # D = 10: 650 -> 223 us, 50: 1042 -> 328, 100: 1593 -> 867, 160: 2100 -> 1687, 200: equal, 256: the device wins
 _HOST_ROOT_MAX_DIM = int(os.environ.get('VIABEL_AMD_HOST_ROOT_MAX_DIM', '160'))
+# The RESIDENT reference-identical routes of the t family (vb_dis_refresh_mvt_symroot, vb_elbo_grad_mvt_symroot[_path],
+# vb_alpha_grad_mvt_symroot) are taken for D > _RESIDENT_GATE whenever the chi-square draws are on the device (N >= 4096).
+# Measured (tools/mvt_root_gate_probe.py, N = 4096 and 16 384): they beat the host-root route at every D from 2 upwards
+# (D = 32: 0.58 against 0.83 ms, D = 160: 0.79 against 2.4 ms) -- the gate of 160 that round 4 chose for the HOST route's
+# root (LAPACK below, device iteration above) does not apply to them.
+_RESIDENT_GATE = int(os.environ.get('VIABEL_AMD_RESIDENT_GATE', '0'))
 
 
 def _device_root(eng, Sigma):
@@ -751,6 +771,16 @@ class DISInclusiveKL(StochasticVariationalObjective):
     @_state_w_normalized.setter
     def _state_w_normalized(self, value):
         self._w_norm_cache = value
+
+    def _claim_state(self, eng, kind):
+        """Before a refresh overwrites the engine's state of `kind`: an objective that left its weights / per-sample logs
+        on the device to be fetched on first access (the device-resident steps) fetches them NOW, so that they remain
+        the arrays of ITS refresh -- as the reference's ``_state_*`` attributes do -- whoever refreshes next."""
+        _claim_engine_state(eng, kind, self)
+
+    def _materialize_state(self):
+        self._state_w_clipped           # (properties: the pending fetches run)
+        self._get_state_logs()
 
     def _own_state(self, eng, kind, refreshed):
         """The state samples live in the engine, one set per family kind: after a refresh remember its generation,
@@ -997,10 +1027,11 @@ class DISInclusiveKL(StochasticVariationalObjective):
             # The reference-identical mode of the t family (rng='numpy') is resident on the device as well where the
             # symmetric root is the device's job anyway: numpy's chi-square and normal streams are generated there bit for
             # bit, the root of approximations.py:348 by vb_dis_refresh_mvt_symroot
-            sym_try = not philox and not gaussian and eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
+            sym_try = not philox and not gaussian and eng.n_ranks == 1 and D > _RESIDENT_GATE
             resident = (philox and eng.n_ranks == 1) or (not refresh_now and getattr(self, '_sym_resident', False))
             clip = self._w_clip_threshold < 1.0
             if refresh_now:
+                self._claim_state(eng, 1)
                 self._sym_resident = False
                 eng.dis_set_temper_prior(self._prior_spec)
                 if gaussian:
@@ -1234,11 +1265,12 @@ class AlphaDivergence(StochasticVariationalObjective):
                 return eng.alpha_grad_mvt_chol(_NOISE_SLOT, end - begin, D, df, var_param, alpha, n_total=N)
             else:
                 # chi-square draws first (approximations.py:345-347)
-                want_resident = eng.n_ranks == 1 and D > _HOST_ROOT_MAX_DIM
+                want_resident = eng.n_ranks == 1 and D > _RESIDENT_GATE
                 chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed, host_chi=not want_resident)
                 if want_resident and getattr(approx, '_chi_on_device', False):
                     # the whole evaluation resident on the device (vb_alpha_grad_mvt_symroot), as ExclusiveKL's; None: a
                     # root iteration did not resolve
+                    _claim_engine_state(eng, 1, None)      # (the call reuses the DIS state's buffers)
                     resident = eng.alpha_grad_mvt_symroot(_NOISE_SLOT, N, D, df, alpha, var_param)
                     if resident is not None:
                         return resident
