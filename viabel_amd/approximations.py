@@ -126,7 +126,12 @@ class _NoiseMixin:
         return k
 
     # -- parity-mode noise into a device slot ---------------------------------------------------------------------------
-    _DEVICE_DRAW_FROM = 1 << 16      # values; below this the host draw + upload is as fast as the device path's launches
+    # values; below these the host draw + upload beats the device path's ~20 launches (tools/legacy_draw_gate_probe.py, late
+    # round 5: randn host 83 / device 71 us at 8 192 values, 147 / 81 at 16 384, 453 / 100 at 32 768; standard_t 130 / 117
+    # at 4 096, 231 / 145 at 8 192, 1 664 / 224 at 65 536 -- the gate stood at 65 536 before the draws lost their host
+    # round trips)
+    _DEVICE_DRAW_FROM = 1 << 13
+    _DEVICE_T_FROM = 1 << 12
     _DEVICE_CHI_FROM = 1 << 12       # chi-square draws; the sequential host loop costs ~60 ns a draw, the device path ~0.2 ms
 
     def _stage_normals(self, eng, rs, slot, n_total, d, begin, end):
@@ -251,7 +256,7 @@ class MFStudentT(_NoiseMixin, ApproximationFamily):
         generator's own state, values and state bit for bit numpy's (``vb_legacy_rng_standard_t_device``); small ones, and
         anything the device path does not take, on the host."""
         rs = self._random_state(seed)
-        if (n_total * self.dim >= self._DEVICE_DRAW_FROM and isinstance(rs, LegacyRandomState)
+        if (n_total * self.dim >= self._DEVICE_T_FROM and isinstance(rs, LegacyRandomState)
                 and eng.noise_legacy_standard_t(slot, rs._h, self.df, n_total, self.dim, begin, end - begin)):
             return None
         eng.noise_set_host(slot, rs.standard_t(self.df, size=(n_total, self.dim))[begin:end])
