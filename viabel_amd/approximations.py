@@ -635,7 +635,10 @@ class LRGaussian(_NoiseMixin, ApproximationFamily):
         return p in [2, 4]
 
 
-_HOST_SAMPLE_DEVICE_FROM = 1 << 18      # values: from here on a host `sample()` draws its legacy noise on the GPU and reads it back
+# values: from here on a host `sample()` draws its legacy noise on the GPU and reads it back (host randn 453 us against 100 us
+# on the device + a 256-KB copy at 32 768 values, tools/legacy_draw_gate_probe.py; the gate stood at 262 144 while a
+# device draw still cost several host round trips)
+_HOST_SAMPLE_DEVICE_FROM = 1 << 15
 
 
 def _legacy_host_copy(rs, kind, df, n_samples, dim):
