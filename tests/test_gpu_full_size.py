@@ -339,14 +339,16 @@ def test_multivariate_t_alpha_reference_mode_resident(vb, target, alpha):
     np.testing.assert_allclose(grad, g2, rtol=0, atol=1e-9 * np.max(np.abs(g2)))
 
 
-@pytest.mark.parametrize('D', [2, 5, 16, 33, 100, 160])
-def test_resident_reference_mode_at_small_dimensions(vb, D):
+@pytest.mark.parametrize('D,N', [(2, 4096), (5, 4096), (16, 4096), (33, 4096), (100, 4096), (160, 4096), (48, 100), (64, 300),
+                                 (130, 777), (256, 1000)])
+def test_resident_reference_mode_at_small_dimensions(vb, D, N):
     """The resident reference-identical routes of the t family are taken for every D once the chi-square draws are on the
     device (N >= 4096; objectives._RESIDENT_GATE, measured faster than the host-root route from D = 2 up): ExclusiveKL in
     both forms, AlphaDivergence and the DIS step against the oracle on numpy's own draws, at dimensions where rounds 3-4
-    went through LAPACK on the host."""
+    went through LAPACK on the host.  Below N = 4096 the chi-square draws move to the device for the resident route's sake
+    from D = 48 on (objectives._RESIDENT_SMALL_N_MIN_DIM)."""
     from viabel_amd import _lib
-    N, df = 4096, 9.0
+    df = 9.0
     rng = np.random.RandomState(100 + D)
     mean, sd = 0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D))
     model, omodel = vb.GaussianModel(mean, sd), omod.GaussDiag(mean, sd)
@@ -372,9 +374,9 @@ def test_resident_reference_mode_at_small_dimensions(vb, D):
         assert abs(v - ov) <= 1e-10 * abs(ov)
         np.testing.assert_allclose(g, og, rtol=0, atol=1e-8 * np.max(np.abs(og)))
         prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
-        obj = vb.DISInclusiveKL(vb.MultivariateT(D, df, seed=6), model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+        obj = vb.DISInclusiveKL(vb.MultivariateT(D, df, seed=6), model, N, ess_target=max(2, N // 8), temper_prior=vb.MFGaussian(D),
                                 temper_prior_params=prior, use_resampling=False)
-        ref = oobj.DISInclusiveKL(omvt, omodel, N, N // 8, ofam.MFGaussian(D), prior, use_resampling=False)
+        ref = oobj.DISInclusiveKL(omvt, omodel, N, max(2, N // 8), ofam.MFGaussian(D), prior, use_resampling=False)
         v, g = obj(theta)
         ov, og = ref(theta, noise=omvt.draw_noise(np.random.RandomState(6), N))
         assert abs(obj._eps - ref._eps) <= 1e-10 and abs(v - ov) <= 1e-9 * abs(ov), (obj._eps, ref._eps, v, ov)

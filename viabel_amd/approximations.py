@@ -439,14 +439,16 @@ class MultivariateT(_NoiseMixin, ApproximationFamily):
         z = _legacy_host_copy(rs, 'n', 0.0, n_samples, self.dim)
         return chi, (rs.randn(n_samples, self.dim) if z is None else z)
 
-    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None, host_chi=True):
+    def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None, host_chi=True, device_chi=False):
         """The normals into ``slot``; returns the chi-square draws (all ``n_total`` of them).  ``host_chi=False``: a caller
         that means to stay on the device takes None when the draws were generated there (``_chi_on_device``; they are
-        resident in the context, ``eng.chisq_get_host(n_total)`` fetches them should the host route be needed after all)."""
+        resident in the context, ``eng.chisq_get_host(n_total)`` fetches them should the host route be needed after all).
+        ``device_chi``: draw them on the device below ``_DEVICE_CHI_FROM`` too (slower than the host loop by ~50 us there,
+        but the resident routes need them on the device and save far more at larger dimensions)."""
         rs = self._random_state(seed)
         chi = None                                         # first, as ``sample`` draws them (:345-347)
         on_device = False
-        if n_total >= self._DEVICE_CHI_FROM and isinstance(rs, LegacyRandomState):
+        if (n_total >= self._DEVICE_CHI_FROM or device_chi) and isinstance(rs, LegacyRandomState):
             # on the device, bit for bit numpy's (None: not this path's case)
             chi = eng.chisq_legacy(rs._h, self.df, n_total, to_host=host_chi)
             on_device = chi is not None

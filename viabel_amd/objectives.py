@@ -540,7 +540,8 @@ class ExclusiveKL(StochasticVariationalObjective):
             else:
                 # chi-square draws first (approximations.py:345-347)
                 want_resident = eng.n_ranks == 1 and D > _RESIDENT_GATE
-                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, host_chi=not want_resident)
+                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, host_chi=not want_resident,
+                                               device_chi=want_resident and D >= _RESIDENT_SMALL_N_MIN_DIM)
                 if want_resident and getattr(approx, '_chi_on_device', False):
                     # the whole evaluation resident on the device: both noise streams are there already, the symmetric
                     # root and its Frechet derivative are device iterations, the chain rule to the free Cholesky
@@ -677,6 +678,11 @@ _HOST_ROOT_MAX_DIM = int(os.environ.get('VIABEL_AMD_HOST_ROOT_MAX_DIM', '160'))
 # (D = 32: 0.58 against 0.83 ms, D = 160: 0.79 against 2.4 ms) -- the gate of 160 that round 4 chose for the HOST route's
 # root (LAPACK below, device iteration above) does not apply to them.
 _RESIDENT_GATE = int(os.environ.get('VIABEL_AMD_RESIDENT_GATE', '0'))
+# Below N = 4096 the chi-square draws are cheaper on the host (17 against 70 us at 1000 draws) and the host route is taken
+# with them -- unless the dimension makes the host's O(D^3) algebra the larger cost: from here on the draws are made on
+# the device whatever N, for the resident route's sake (N = 1000: host route 1.1 ms at D = 100, 2.0-2.5 ms at D = 160;
+# the resident route ~0.6 / ~0.8 ms)
+_RESIDENT_SMALL_N_MIN_DIM = int(os.environ.get('VIABEL_AMD_RESIDENT_SMALL_N_MIN_DIM', '48'))
 
 
 def _device_root(eng, Sigma):
@@ -1078,7 +1084,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
                         self._own_state(eng, 1, True)
                 else:
                     # chi-square draws first (approximations.py:345-347)
-                    chi = approx._stage_base_noise(eng, slot, N, begin, end, host_chi=not sym_try)
+                    chi = approx._stage_base_noise(eng, slot, N, begin, end, host_chi=not sym_try,
+                                                   device_chi=sym_try and D >= _RESIDENT_SMALL_N_MIN_DIM)
                     if sym_try and getattr(approx, '_chi_on_device', False):
                         # the whole step on the device: the context holds numpy's chi-square draws, the slot its normals
                         info = eng.dis_refresh_mvt_symroot(slot, N, D, df, var_param, self._prior_arg, self._eps,
@@ -1266,7 +1273,8 @@ class AlphaDivergence(StochasticVariationalObjective):
             else:
                 # chi-square draws first (approximations.py:345-347)
                 want_resident = eng.n_ranks == 1 and D > _RESIDENT_GATE
-                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed, host_chi=not want_resident)
+                chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed, host_chi=not want_resident,
+                                               device_chi=want_resident and D >= _RESIDENT_SMALL_N_MIN_DIM)
                 if want_resident and getattr(approx, '_chi_on_device', False):
                     # the whole evaluation resident on the device (vb_alpha_grad_mvt_symroot), as ExclusiveKL's; None: a
                     # root iteration did not resolve
