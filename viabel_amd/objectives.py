@@ -1058,7 +1058,23 @@ class DISInclusiveKL(StochasticVariationalObjective):
                             self._own_state(eng, 1, True)
                     else:
                         approx._stage_base_noise(eng, slot, N, begin, end)
-                        root = np.ascontiguousarray(host_factors()[0].T)        # x = mu + eps L'
+                        if eng.n_ranks == 1:
+                            # the dense Gaussian samples through L itself (x = mu + eps L'): with the family's own normal
+                            # stream in the slot this IS the device's factor path -- resident like the throughput mode
+                            # (the reference's resampling draw, when asked for, on the fetched weights as for the t family)
+                            root = None
+                            resident = self._sym_resident = True
+                            eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._prior_arg,
+                                                         self._eps, self._ess_target, self._max_bisection_its)
+                            if self._psis_smooth:
+                                eng.dis_psis_mvt(N)
+                            if clip:
+                                eng.dis_clip_mvt(N, self._w_clip_threshold)
+                            self._set_state_logs(None, None, lambda: eng.dis_state_get(True, N))
+                            self._set_state_weights(None, lambda: eng.dis_weights_get(N))
+                            self._own_state(eng, 1, True)
+                        else:
+                            root = np.ascontiguousarray(host_factors()[0].T)        # x = mu + eps L'
                 elif philox:
                     # throughput mode: chi-square draws and normals on the GPU, and x = mu + (z L') / s with the
                     # Cholesky factor instead of the reference's symmetric root (approximations.py:348).  The samples
