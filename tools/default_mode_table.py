@@ -24,8 +24,9 @@ for D, N in ((10, 100), (50, 500), (100, 1000), (100, 8000), (300, 2000)):
     rng = np.random.RandomState(D)
     model = vb.GaussianModel(0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D)))
     prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
-    fams = {'MFGaussian': vb.MFGaussian(D), 'MFStudentT': vb.MFStudentT(D, 7.0), 'FullRank': vb.FullRankGaussian(D),
-            'MultivariateT': vb.MultivariateT(D, 9.0), 'LRGaussian(k=4)': vb.LRGaussian(D, k=4)}
+    kw = {'rng': sys.argv[1]} if len(sys.argv) > 1 else {}
+    fams = {'MFGaussian': vb.MFGaussian(D, **kw), 'MFStudentT': vb.MFStudentT(D, 7.0, **kw), 'FullRank': vb.FullRankGaussian(D, **kw),
+            'MultivariateT': vb.MultivariateT(D, 9.0, **kw), 'LRGaussian(k=4)': vb.LRGaussian(D, k=4, **kw)}
     print('D = %d, N = %d   (median / max ms per call)' % (D, N))
     for name, fam in fams.items():
         theta = fam.init_param()

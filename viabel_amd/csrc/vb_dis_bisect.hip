@@ -211,13 +211,13 @@ __device__ bool bs_predict(const BsState& s, double target, double& a, double& b
     x[0] = s.lower, f[0] = f_lo, x[1] = s.lo2, f[1] = f_lo2, n = 2;
   } else if (v_up && v_up2) {
     x[0] = s.upper, f[0] = f_up, x[1] = s.up2, f[1] = f_up2, n = 2;
-  } else if (v_lo && !v_up) {
+  } else if (!v_up && s.level > 0) {      // (the upper end never moved; the lower end's ESS may even be NaN: underflown weights)
     // every decision so far moved the lower end and the evaluated points give no usable model (ESS falling towards the
     // upper end, say): the walk most likely goes on hugging that end -- one path straight to it (a heap round would
     // cover six levels; a wrong guess here costs progress, never correctness: the replay makes the reference's decisions)
     a = b = s.upper;
     return true;
-  } else if (v_up && !v_lo) {
+  } else if (!v_lo && s.level > 0) {
     a = b = s.lower;
     return true;
   } else {
