@@ -268,7 +268,12 @@ LroLayout lro_layout(int64_t n, int64_t n_total, int64_t d, int64_t k) {
   L.ld = round_up(d, 16);
   L.nn = round_up(n_total, 16);
   L.n_rb = (int)((n + 127) / 128);
-  int splits = (int)(n / 256);
+  static const int rows_per_split = [] {
+    const char* e = getenv("VB_LR_SPLIT_ROWS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 16 ? v : 64;
+  }();
+  int splits = (int)(n / rows_per_split);
   L.splits = splits > 32 ? 32 : (splits < 1 ? 1 : splits);
   int64_t off = 0;
   auto carve = [&off](int64_t doubles) {
@@ -317,33 +322,66 @@ struct LroParam {
   double cq;     // -(D log 2 pi + log det Sigma) / 2
 };
 
+// One staged upload (push_small: no stream wait): the device layout carves mu | 1/sigma | Bs | M^-1 | sigma | B in this
+// order without gaps (every piece a multiple of 16 doubles), so the host image is built in the same order and the
+// evaluation-only case sends its prefix.
 int lro_upload_param(vb_ctx* ctx, const LroLayout& L, double* base, int64_t d, int64_t k, const LroParam& p,
                      bool sampling) {
-  std::vector<double> h((size_t)(3 * L.ld + 2 * d * L.ldk + L.ldk * L.ldk), 0.0);
-  double *mu = h.data(), *isig = mu + L.ld, *sig = isig + L.ld, *bs = sig + L.ld, *b = bs + d * L.ldk,
-         *mi = b + d * L.ldk;
+  const int64_t eval_len = L.o_sig - L.o_mu, all_len = L.o_prior - L.o_mu;
+  if (L.o_isig - L.o_mu != L.ld || L.o_bs - L.o_isig != L.ld || L.o_minv - L.o_bs != d * L.ldk ||
+      L.o_sig - L.o_minv != (int64_t)L.ldk * L.ldk || L.o_b - L.o_sig != L.ld || L.o_prior - L.o_b != d * L.ldk)
+    return fail(ctx, VB_ERR_STATE, "low-rank parameter block is not contiguous");
+  std::vector<double> h((size_t)(sampling ? all_len : eval_len), 0.0);
+  double *mu = h.data(), *isig = mu + L.ld, *bs = isig + L.ld, *mi = bs + d * L.ldk;
+  double *sig = sampling ? mi + (int64_t)L.ldk * L.ldk : nullptr, *b = sampling ? sig + L.ld : nullptr;
   for (int64_t i = 0; i < d; ++i) {
     const double s = exp(p.log_sigma[i]);
     mu[i] = p.mu[i];
-    sig[i] = s;
     isig[i] = 1.0 / s;
+    if (sampling) sig[i] = s;
     for (int64_t j = 0; j < k; ++j) {
-      b[i * L.ldk + j] = p.B[i * k + j];
+      if (sampling) b[i * L.ldk + j] = p.B[i * k + j];
       bs[i * L.ldk + j] = p.B[i * k + j] / s;
     }
   }
   for (int64_t i = 0; i < k; ++i)
     for (int64_t j = 0; j < k; ++j) mi[i * L.ldk + j] = p.minv[i * k + j];
-  hipStream_t st = ctx->stream;
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, mu, (size_t)L.ld * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_isig, isig, (size_t)L.ld * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_bs, bs, (size_t)(d * L.ldk) * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_minv, mi, (size_t)(L.ldk * L.ldk) * sizeof(double), hipMemcpyHostToDevice, st));
-  if (sampling) {
-    VB_HIP(ctx, hipMemcpyAsync(base + L.o_sig, sig, (size_t)L.ld * sizeof(double), hipMemcpyHostToDevice, st));
-    VB_HIP(ctx, hipMemcpyAsync(base + L.o_b, b, (size_t)(d * L.ldk) * sizeof(double), hipMemcpyHostToDevice, st));
+  return push_small(ctx, ctx->stream, h.data(), h.size() * sizeof(double), base + L.o_mu);   // copies `h` before returning
+}
+
+// The packed result of the weighted-sum calls: up to 8 strided blocks gathered into the contiguous `pack` in one launch
+// (six 2-D device copies of ~5 us each before).
+struct LroPackSeg {
+  const double* src;
+  double* dst;
+  int rows, cols;
+  int64_t src_ld, dst_ld;
+};
+struct LroPackArgs {
+  LroPackSeg s[8];
+};
+
+__global__ __launch_bounds__(256) void lro_pack_kernel(const LroPackArgs a) {
+  const LroPackSeg g = a.s[blockIdx.y];
+  const int64_t total = (int64_t)g.rows * g.cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / g.cols, c = i - r * g.cols;
+    g.dst[r * g.dst_ld + c] = g.src[r * g.src_ld + c];
   }
-  VB_HIP(ctx, hipStreamSynchronize(st));      // `h` is a stack-scoped staging buffer
+}
+
+int lro_pack_enqueue(vb_ctx* ctx, hipStream_t st, const LroPackSeg* segs, int n_seg) {
+  LroPackArgs a{};
+  int64_t most = 1;
+  for (int i = 0; i < n_seg; ++i) {
+    a.s[i] = segs[i];
+    const int64_t t = (int64_t)segs[i].rows * segs[i].cols;
+    if (t > most) most = t;
+  }
+  int64_t bx = (most + 1023) / 1024;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(lro_pack_kernel, dim3((unsigned)bx, (unsigned)n_seg), dim3(256), 0, st, a);
+  VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
 
@@ -435,8 +473,7 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
     pr[L.ld + i] = exp(-2.0 * prior_host[d + i]);
     c0p -= prior_host[d + i];
   }
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_prior, pr.data(), pr.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
+  VB_TRY(push_small(ctx, st, pr.data(), pr.size() * sizeof(double), base + L.o_prior));
   hipLaunchKernelGGL(lro_sample_kernel, dim3((unsigned)n, (unsigned)((L.ld + 255) / 256)), dim3(256), 0, st,
                      (const double*)ns.buf.ptr, ns.ld, (const double*)nz.buf.ptr, nz.ld, n, (int)d, (int)k,
                      (const double*)(base + L.o_mu), (const double*)(base + L.o_sig), (const double*)(base + L.o_b),
@@ -483,8 +520,8 @@ int lr_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, int64_t k, const double* mu, 
   const LroLayout L = lro_layout(n, ctx->lr_n_total, d, k);
   double* base = (double*)ctx->lr_obj.ptr;
   hipStream_t st = ctx->stream;
-  VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
-  VB_TRY(lro_upload_param(ctx, L, base, d, k, LroParam{mu, log_sigma, B, minv, cq}, false));   // (syncs: w_host is free)
+  VB_TRY(push_small(ctx, st, w_host, (size_t)n * sizeof(double), base + L.o_w));
+  VB_TRY(lro_upload_param(ctx, L, base, d, k, LroParam{mu, log_sigma, B, minv, cq}, false));
   VB_TRY(lro_rows(ctx, L, base, n, d, k, cq, 0, base + L.o_lq));
   hipLaunchKernelGGL(lro_scale_rows_kernel, dim3((unsigned)((n * L.ldt + 255) / 256)), dim3(256), 0, st,
                      (const double*)(base + L.o_t), (const double*)(base + L.o_w), n, base + L.o_tw, L.ldt);
@@ -495,18 +532,15 @@ int lr_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, int64_t k, const double* mu, 
   // pack
   const int64_t out_len = d * k + k * k + 2 * d + k + 2;
   double* pack = base + L.o_pack;
-  VB_HIP(ctx, hipMemcpy2DAsync(pack, (size_t)k * sizeof(double), base + L.o_et, (size_t)L.ldt * sizeof(double),
-                               (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
-  VB_HIP(ctx, hipMemcpy2DAsync(pack + d * k, (size_t)k * sizeof(double), base + L.o_tt, (size_t)L.ldt * sizeof(double),
-                               (size_t)k * sizeof(double), (size_t)k, hipMemcpyDeviceToDevice, st));
   double* tail = pack + d * k + k * k;
-  VB_HIP(ctx, hipMemcpy2DAsync(tail, sizeof(double), base + L.o_et + L.col1, (size_t)L.ldt * sizeof(double),
-                               sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));          // sum w rho
-  VB_HIP(ctx, hipMemcpyAsync(tail + d, base + L.o_cs1, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
-  VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d, base + L.o_tt + (int64_t)L.col1 * L.ldt, (size_t)k * sizeof(double),
-                             hipMemcpyDeviceToDevice, st));                                       // sum w tau
-  VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d + k, base + L.o_tt + (int64_t)L.col1 * L.ldt + L.col1, 2 * sizeof(double),
-                             hipMemcpyDeviceToDevice, st));                                       // sum w, sum w log q
+  const double* ones_row = base + L.o_tt + (int64_t)L.col1 * L.ldt;
+  const LroPackSeg ps[6] = {{base + L.o_et, pack, (int)d, (int)k, L.ldt, k},
+                            {base + L.o_tt, pack + d * k, (int)k, (int)k, L.ldt, k},
+                            {base + L.o_et + L.col1, tail, (int)d, 1, L.ldt, 1},            // sum w rho
+                            {base + L.o_cs1, tail + d, 1, (int)d, 0, 0},                    // sum w rho^2
+                            {ones_row, tail + 2 * d, 1, (int)k, 0, 0},                      // sum w tau
+                            {ones_row + L.col1, tail + 2 * d + k, 1, 2, 0, 0}};             // sum w, sum w log q
+  VB_TRY(lro_pack_enqueue(ctx, st, ps, 6));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));
   const FetchSeg seg{pack, (size_t)out_len * sizeof(double), out_host};
   return fetch_blocking(ctx, st, &seg, 1);
@@ -565,16 +599,13 @@ int lr_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
   VB_TRY(lro_colsum_prod(ctx, L, base, base + L.o_g, L.ld, E, ns.ld, base + L.o_w, n, d, base + L.o_cs1));
   const int64_t out_len = 2 * d * k + k * k + 2 * d;
   double* pack = base + L.o_pack;
-  VB_HIP(ctx, hipMemcpy2DAsync(pack, (size_t)k * sizeof(double), base + L.o_et2, (size_t)L.ldt * sizeof(double),
-                               (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
-  VB_HIP(ctx, hipMemcpy2DAsync(pack + d * k, (size_t)k * sizeof(double), base + L.o_et, (size_t)L.ldt * sizeof(double),
-                               (size_t)k * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));
-  VB_HIP(ctx, hipMemcpy2DAsync(pack + 2 * d * k, (size_t)k * sizeof(double), base + L.o_tt, (size_t)L.ldt * sizeof(double),
-                               (size_t)k * sizeof(double), (size_t)k, hipMemcpyDeviceToDevice, st));
   double* tail = pack + 2 * d * k + k * k;
-  VB_HIP(ctx, hipMemcpy2DAsync(tail, sizeof(double), base + L.o_et2 + L.col1, (size_t)L.ldt * sizeof(double),
-                               sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, st));          // sum s g
-  VB_HIP(ctx, hipMemcpyAsync(tail + d, base + L.o_cs1, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
+  const LroPackSeg ps[5] = {{base + L.o_et2, pack, (int)d, (int)k, L.ldt, k},
+                            {base + L.o_et, pack + d * k, (int)d, (int)k, L.ldt, k},
+                            {base + L.o_tt, pack + 2 * d * k, (int)k, (int)k, L.ldt, k},
+                            {base + L.o_et2 + L.col1, tail, (int)d, 1, L.ldt, 1},           // sum s g
+                            {base + L.o_cs1, tail + d, 1, (int)d, 0, 0}};                   // sum s g eps
+  VB_TRY(lro_pack_enqueue(ctx, st, ps, 5));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));
   double sc[2];
   const FetchSeg segs[2] = {{scal + 8, sizeof sc, sc}, {pack, (size_t)out_len * sizeof(double), out_host}};
