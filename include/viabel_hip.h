@@ -112,6 +112,14 @@ int vb_noise_moments(vb_ctx* ctx, int slot, int64_t n, int64_t d, double* colsum
  * mode.  The n draws stay in the context (one set at a time); vb_dis_refresh_mvt takes them when its `chi` is NULL. */
 int vb_chisq_generate(vb_ctx* ctx, double df, uint64_t seed, uint64_t stream, int64_t row_offset, int64_t n);
 int vb_chisq_get_host(vb_ctx* ctx, double* host, int64_t n);
+/* A prediction, never a request: "the NEXT vb_noise_generate for each slot in `slot_mask` (bit i: slot i) -- and, when
+ * with_chi != 0, the next vb_chisq_generate -- will repeat the last one with this seed".  AlphaDivergence seeds every call
+ * from the host's global generator (objectives.py:455: seed = npr.randint(2**32)), so the engine's own look-ahead, which
+ * follows a walking stream index, has nothing to follow; a host that can name its generator's next output lets the next
+ * call's noise be generated behind this call's last kernel, while the host waits and turns around.  The shadow is adopted
+ * only by a request that matches it exactly; after a wrong hint the request generates as usual.  The hint is consumed by
+ * the next blocking call of this context.                                                                              */
+int vb_noise_hint_seed(vb_ctx* ctx, unsigned slot_mask, int with_chi, uint64_t seed);
 
 /* ---- model ------------------------------------------------------------------------ */
 int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams,

@@ -116,3 +116,63 @@ def test_objective_sequence_is_unchanged(env, resample):
     for (v0, g0, e0, s0), (v1, g1, e1, s1) in zip(plain, ahead):
         assert (v0, e0, s0) == (v1, e1, s1)
         np.testing.assert_array_equal(g0, g1)
+
+
+def test_hinted_seed_is_adopted_bit_for_bit_and_a_wrong_hint_is_harmless(env):
+    """vb_noise_hint_seed: the host names the next request's seed (AlphaDivergence draws it from numpy's global generator
+    every call, objectives.py:455); right hints, wrong hints and missing hints all give the values of a plain generation."""
+    vb, eng, _lib = env
+    slot, n, d = 13, 777, 96
+    seeds = [11, 4000000000, 12, 12, 99, 5, 6]
+    hints = [4000000000, 12, 12, 1234, None, 6, 7]      # right, right, right (a repeat), wrong, none, right, unused
+
+    def run():
+        out = []
+        for seed, hint in zip(seeds, hints):
+            eng.noise_generate(slot, n, d, seed=seed, stream=0)
+            eng.chisq_generate(9.0, n, seed=seed, stream=0)
+            if hint is not None:
+                eng.noise_hint_seed(1 << slot, hint, with_chi=True)
+            v, g = _blocking_call(vb, eng, _lib, slot, n, d)
+            out.append((eng.noise_get_host(slot, n, d).copy(), eng.chisq_get_host(n).copy(), v, g.copy()))
+        return out
+    plain = _with('0', run)
+    ahead = _with('1', run)
+    for (e0, c0, v0, g0), (e1, c1, v1, g1) in zip(plain, ahead):
+        np.testing.assert_array_equal(e0, e1)
+        np.testing.assert_array_equal(c0, c1)
+        assert v0 == v1
+        np.testing.assert_array_equal(g0, g1)
+
+
+@pytest.mark.parametrize('family', ['mf_gaussian', 'mf_student_t', 'fullrank', 'lowrank', 'multivariate_t'])
+def test_alpha_divergence_with_the_next_seed_hinted(env, family):
+    """AlphaDivergence in throughput mode hints the next call's seed (read off numpy's generator state without drawing):
+    the calls return what they return without the look-ahead, and numpy's global stream is consumed as before."""
+    vb, eng, _lib = env
+    D, N = 24, 600
+    rng = np.random.RandomState(5)
+    model = vb.GaussianModel(0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D)))
+    make = {'mf_gaussian': lambda: vb.MFGaussian(D, rng='philox'), 'mf_student_t': lambda: vb.MFStudentT(D, 7, rng='philox'),
+            'fullrank': lambda: vb.FullRankGaussian(D, rng='philox'), 'lowrank': lambda: vb.LRGaussian(D, k=3, rng='philox'),
+            'multivariate_t': lambda: vb.MultivariateT(D, 9, rng='philox')}[family]
+
+    def run():
+        fam = make()
+        obj = vb.AlphaDivergence(fam, model, N, 0.5)
+        theta = fam.init_param()
+        np.random.seed(17)
+        out = []
+        for i in range(6):
+            if i == 3:
+                np.random.randn(5)       # the caller draws in between: the hinted seed is still the generator's next word
+            if i == 4:
+                np.random.seed(3)        # ... and after a reseed the stale shadow is not adopted
+            v, g = obj(theta)
+            out.append((v, g.copy()))
+        return out, np.random.randint(2 ** 32)
+    (plain, tail0), (ahead, tail1) = _with('0', run), _with('1', run)
+    assert tail0 == tail1
+    for (v0, g0), (v1, g1) in zip(plain, ahead):
+        assert v0 == v1
+        np.testing.assert_array_equal(g0, g1)

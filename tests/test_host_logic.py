@@ -395,3 +395,29 @@ def test_dptr_call_sites_pass_names():
             if not re.fullmatch(r'[A-Za-z_][A-Za-z_0-9]*', arg):
                 bad.append((name, arg))
     assert not bad, bad
+
+
+def test_peek_of_numpys_next_randint():
+    """objectives._peek_next_randint: the seed AlphaDivergence will draw next (objectives.py:455), read off the global
+    generator's state without consuming it -- across block boundaries (the twist), after other draws, after reseeding and
+    set_state -- and the peek itself leaves the stream untouched."""
+    from viabel_amd.objectives import _peek_next_randint
+    saved = np.random.get_state()
+    try:
+        for seed in (0, 1, 12345, 2 ** 32 - 1):
+            np.random.seed(seed)
+            for i in range(1500):                       # more than two 624-word blocks
+                peek = _peek_next_randint()
+                assert peek == _peek_next_randint()     # no side effect
+                assert peek == int(np.random.randint(2 ** 32))
+                if i % 5 == 0:
+                    np.random.randn(3)
+                if i % 11 == 0:
+                    np.random.standard_t(7, 4)
+        st = np.random.get_state()
+        a = _peek_next_randint()
+        np.random.randint(2 ** 32, size=1000)
+        np.random.set_state(st)
+        assert _peek_next_randint() == a == int(np.random.randint(2 ** 32))
+    finally:
+        np.random.set_state(saved)

@@ -54,6 +54,7 @@ SIGNATURES = {
     'vb_noise_generate': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                          ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int64]),
+    'vb_noise_hint_seed': (ctypes.c_int, [_ctx_p, ctypes.c_uint, ctypes.c_int, ctypes.c_uint64]),
     'vb_chisq_generate': (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
                                          ctypes.c_int64]),
     'vb_chisq_get_host': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64]),
@@ -353,6 +354,11 @@ class Engine:
         eps = _f64(eps)
         n, d = eps.shape
         self._check(self._lib.vb_noise_set_host(self._ctx, slot, _dptr(eps), n, d))
+
+    def noise_hint_seed(self, slot_mask, seed, with_chi=False):
+        """Tell the look-ahead generator the seed of the NEXT call's Philox requests (``vb_noise_hint_seed``): a
+        prediction only -- a shadow that does not match the request is never adopted."""
+        self._check(self._lib.vb_noise_hint_seed(self._ctx, int(slot_mask), 1 if with_chi else 0, int(seed)))
 
     def noise_generate(self, slot, n, d, seed, stream=0, row_offset=0, kind=NOISE_NORMAL, df=0.0):
         self._check(self._lib.vb_noise_generate(self._ctx, slot, kind, float(df), int(seed), int(stream),

@@ -275,7 +275,9 @@ void noise_prefetch(vb_ctx* ctx) {
   for (int slot = 0; slot < VB_MAX_SLOTS; ++slot) {
     NoiseSlot& s = ctx->noise[slot];
     NoiseAhead& h = s.ahead;
-    if (h.streak < 2 || !h.last.valid || h.pre.valid || !s.buf.ptr || s.n != h.last.n || s.d != h.last.d) continue;
+    const bool hinted = h.hint.valid;
+    h.hint.valid = false;      // (a hint speaks for the call it was given in)
+    if ((h.streak < 2 && !hinted) || !h.last.valid || h.pre.valid || !s.buf.ptr || s.n != h.last.n || s.d != h.last.d) continue;
     const size_t bytes = (size_t)s.n * s.ld * sizeof(double);
     const bool fresh = !h.shadow.ptr || h.shadow.bytes < bytes;
     if (ensure(ctx, h.shadow, bytes) != VB_OK) continue;      // (zero-filled when new)
@@ -286,20 +288,34 @@ void noise_prefetch(vb_ctx* ctx) {
       continue;
     h.shadow_d = s.d, h.shadow_ld = s.ld;
     NoiseReq nx = h.last;
-    nx.stream = h.last.stream + (uint64_t)h.delta;
+    if (hinted) nx.seed = h.hint.seed, nx.stream = h.hint.stream;
+    else nx.stream = h.last.stream + (uint64_t)h.delta;
     if (rng_fill(ctx, (double*)h.shadow.ptr, s.ld, nx.kind, nx.df, nx.seed, nx.stream, nx.row_offset, nx.n, nx.d) != VB_OK) continue;
     h.pre = nx;
   }
   NoiseAhead& c = ctx->chi_ahead;
-  if (c.streak >= 2 && c.last.valid && !c.pre.valid && ctx->chi_n == c.last.n && ctx->chi_dev.ptr) {
+  const bool chi_hinted = c.hint.valid;
+  c.hint.valid = false;
+  if ((c.streak >= 2 || chi_hinted) && c.last.valid && !c.pre.valid && ctx->chi_n == c.last.n && ctx->chi_dev.ptr) {
     if (ensure(ctx, c.shadow, (size_t)c.last.n * sizeof(double)) != VB_OK) return;
     if (!ordered && main_stream_write(ctx) != VB_OK) return;
     NoiseReq nx = c.last;
-    nx.stream = c.last.stream + (uint64_t)c.delta;
+    if (chi_hinted) nx.seed = c.hint.seed, nx.stream = c.hint.stream;
+    else nx.stream = c.last.stream + (uint64_t)c.delta;
     if (rng_chisquare(ctx, (double*)c.shadow.ptr, nx.df, nx.seed, nx.stream, nx.row_offset, nx.n) == VB_OK) c.pre = nx;
   }
 }
 
+
+// A blocking call whose results reach mapped host memory from its last kernel: the event marks that kernel, the next
+// call's noise (NoiseAhead) is enqueued behind it, and the host waits for the event only.
+int wait_then_prefetch(vb_ctx* ctx) {
+  if (!ctx->done_ev) VB_HIP(ctx, hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming));
+  VB_HIP(ctx, hipEventRecord(ctx->done_ev, ctx->stream));
+  noise_prefetch(ctx);
+  VB_HIP(ctx, hipEventSynchronize(ctx->done_ev));
+  return VB_OK;
+}
 
 void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals, int kernel_id) {
   *ev0 = *ev1 = nullptr;
@@ -328,7 +344,7 @@ static int noise_alloc(vb_ctx* ctx, int slot, int64_t n, int64_t d, bool keep_hi
   if (n <= 0 || d <= 0) return fail(ctx, VB_ERR_INVALID, "noise shape must be positive");
   NoiseSlot& s = ctx->noise[slot];
   if (!keep_history) {      // a writer other than vb_noise_generate: the look-ahead's history ends here
-    s.ahead.last.valid = s.ahead.pre.valid = false;
+    s.ahead.last.valid = s.ahead.pre.valid = s.ahead.hint.valid = false;
     s.ahead.streak = 0;
   }
   // The t family's DIS state may be reading its residuals straight out of this slot (mvt_e_noise, vb_mvt.hip): new
@@ -483,6 +499,7 @@ int vb_destroy(vb_ctx* ctx) {
     (void)hipStreamDestroy(ctx->mvt_side);
     (void)hipEventDestroy(ctx->mvt_ev_join);
   }
+  if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& log : ctx->prof)
     for (auto& ev : log.events) {
@@ -556,6 +573,22 @@ int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
   s.ahead.pre.valid = false;      // (a shadow that was not asked for is dropped)
   VB_TRY(rng_fill(ctx, (double*)s.buf.ptr, s.ld, kind, df, seed, stream, row_offset, n, d));
   req_observe(s.ahead, r);
+  return VB_OK;
+}
+
+int vb_noise_hint_seed(vb_ctx* ctx, unsigned slot_mask, int with_chi, uint64_t seed) {
+  if (!ctx) return VB_ERR_INVALID;
+  for (int slot = 0; slot < VB_MAX_SLOTS; ++slot) {
+    NoiseAhead& h = ctx->noise[slot].ahead;
+    if (!((slot_mask >> slot) & 1u) || !h.last.valid) continue;
+    h.hint = h.last;
+    h.hint.seed = seed;
+  }
+  NoiseAhead& c = ctx->chi_ahead;
+  if (with_chi && c.last.valid) {
+    c.hint = c.last;
+    c.hint.seed = seed;
+  }
   return VB_OK;
 }
 
@@ -1180,8 +1213,7 @@ int vb_alpha_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t
   ResultSlot& rs = ctx->sync_result;
   VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
   VB_TRY(alpha_enqueue(ctx, ctx->noise[slot], n, n_total, d, family, df, alpha, rs.dev, rs.dev + rs.p));
-  noise_prefetch(ctx);      // (the next call's noise while the host waits: NoiseAhead)
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VB_TRY(wait_then_prefetch(ctx));
   rs.pending = false;
   *value = rs.host[rs.p];
   memcpy(grad, rs.host + rs.p + 1, (size_t)(2 * d) * sizeof(double));
@@ -1251,8 +1283,7 @@ int vb_dis_grad_meanfield(vb_ctx* ctx, int slot, int64_t n, int64_t d, int famil
   ResultSlot& rs = ctx->sync_result;
   VB_TRY(stage_theta(ctx, rs, theta, 2 * d));
   VB_TRY(dis_grad_enqueue(ctx, ctx->noise[slot], n, d, family, df, rs.dev, weights, scale, rs.dev + rs.p));
-  noise_prefetch(ctx);
-  VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VB_TRY(wait_then_prefetch(ctx));
   rs.pending = false;
   *value = rs.host[rs.p];
   memcpy(grad, rs.host + rs.p + 1, (size_t)(2 * d) * sizeof(double));

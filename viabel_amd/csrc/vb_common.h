@@ -110,10 +110,13 @@ struct NoiseReq {
 // steps (two confirmations), the NEXT request's values are generated into `shadow` behind the call's last kernel, while
 // the host waits and returns; the next vb_noise_generate with exactly those arguments adopts the shadow (a pointer swap)
 // instead of launching.  Counter-based streams: the values are the ones the request would have generated.
+// A caller whose next request is not a walk of the stream index (AlphaDivergence seeds every call from the host's
+// generator, objectives.py:455) can name it instead: vb_noise_hint_seed.  A wrong prediction is never adopted.
 struct NoiseAhead {
   DeviceBuffer shadow;
   int64_t shadow_d = 0, shadow_ld = 0;   // geometry the shadow's pad columns were zeroed for
   NoiseReq last, pre;                    // what the live buffer holds; what the shadow holds (pre.valid)
+  NoiseReq hint;                         // the caller's own prediction of the next request (vb_noise_hint_seed), used once
   int64_t delta = 0;
   int streak = 0;
 };
@@ -220,6 +223,7 @@ struct vb_ctx {
   vb::DeviceBuffer fetch_ticket;        // the copy kernel's workgroup ticket (zero between launches)
   hipStream_t mvt_side = nullptr;       // side stream of the deferred triangular inverse (mvt_factors_device)
   hipEvent_t mvt_ev_fork = nullptr, mvt_ev_join = nullptr;
+  hipEvent_t done_ev = nullptr;      // wait_then_prefetch
   bool mvt_inv_pending = false;         // the main stream has not yet waited for the side stream's inverse
   bool mvt_inv_queued = false;          // ... which has been enqueued already (else mvt_inv_args describes it)
   struct {
@@ -485,6 +489,7 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
 // host -> device copy of a small caller-owned array without a synchronisation (mapped staging slots + a copy kernel)
 int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, void* dev_dst, size_t row_bytes = 0,
                size_t dst_stride_bytes = 0);      // row_bytes != 0: rows of row_bytes land dst_stride_bytes apart
+int wait_then_prefetch(vb_ctx* ctx);   // host waits for the work enqueued so far; the look-ahead noise goes behind it
 void noise_prefetch(vb_ctx* ctx);   // look-ahead Philox generation; call right before a blocking call starts to wait (vb_api.hip)
 int comm_check(vb_ctx* ctx);     // VB_ERR_COMM when a device-side wait of the IPC transport has given up (vb_comm.hip)
 

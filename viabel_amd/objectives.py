@@ -14,6 +14,7 @@ all-reduced on the device before the epilogue; every rank returns the same ``(va
 """
 from abc import ABC, abstractmethod
 
+import ctypes
 import os
 import weakref
 
@@ -65,6 +66,40 @@ def _shared_randint(eng):
     if eng.n_ranks > 1:
         seed = int.from_bytes(_rank0_bytes(eng, seed.to_bytes(8, 'little')), 'little')
     return seed
+
+
+def _peek_next_randint():
+    """What the NEXT ``np.random.randint(2 ** 32)`` of the global numpy generator will return, without drawing it; None
+    when it cannot be told.  ``randint(2 ** 32)`` is one tempered 32-bit word of the legacy MT19937 (numpy's bounded-integer
+    routine takes the 32-bit path unmasked when the range is exactly 2^32 - 1), so the value is read off the generator's
+    state through its ctypes interface: word ``pos`` of the key, or, when the block is used up, the first word of the next
+    block by the twist recurrence.  Used only as a HINT for the engine's look-ahead noise (``vb_noise_hint_seed``):
+    AlphaDivergence draws its seed this way every call (objectives.py:455), and a wrong hint costs a wasted generation,
+    never a wrong result (``tests/test_host_logic.py`` pins the prediction against numpy's draws)."""
+    try:
+        key = (ctypes.c_uint32 * 625).from_address(np.random.mtrand._rand._bit_generator.ctypes.state_address)
+    except Exception:        # another bit generator behind np.random, an interface that moved
+        return None
+    pos = key[624]
+    if pos < 624:
+        y = key[pos]
+    elif pos == 624:
+        y1 = key[1]
+        y = key[397] ^ (((key[0] & 0x80000000) | (y1 & 0x7fffffff)) >> 1) ^ (0x9908b0df if y1 & 1 else 0)
+    else:
+        return None
+    y ^= y >> 11
+    y ^= (y << 7) & 0x9d2c5680
+    y ^= (y << 15) & 0xefc60000
+    return y ^ (y >> 18)
+
+
+def _hint_next_seed(eng, slot_mask, with_chi=False):
+    """Philox mode of AlphaDivergence, one process: name the next call's seed to the engine before this call blocks."""
+    if eng.n_ranks == 1:
+        nxt = _peek_next_randint()
+        if nxt is not None:
+            eng.noise_hint_seed(slot_mask, nxt, with_chi)
 
 
 def _rank0_bytes(eng, payload):
@@ -1218,6 +1253,8 @@ class AlphaDivergence(StochasticVariationalObjective):
             seed = _shared_randint(eng)
             eng.set_model(self.model.device_spec())
             n_local, n_total = self._stage_noise(eng, self.num_mc_samples, seed=seed)
+            if approx.rng == 'philox':
+                _hint_next_seed(eng, 1 << _NOISE_SLOT)
             if isinstance(approx, FullRankGaussian):
                 return eng.alpha_grad_fullrank(_NOISE_SLOT, n_local, approx.dim, var_param, alpha, n_total=n_total)
             family, df = approx._device_family()
@@ -1245,6 +1282,7 @@ class AlphaDivergence(StochasticVariationalObjective):
             begin, end = shard_rows(N, eng.n_ranks, eng.rank)
             if approx.rng == 'philox':
                 approx._philox_noise(eng, end - begin, seed, begin, _NOISE_SLOT, _LR_SLOT)
+                _hint_next_seed(eng, (1 << _NOISE_SLOT) | (1 << _LR_SLOT))
             else:
                 approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed, slot_aux=_LR_SLOT)
             mu, ls, B, Bs, Minv, cq, BsMinv = _lowrank_pieces(approx, var_param)
@@ -1283,6 +1321,7 @@ class AlphaDivergence(StochasticVariationalObjective):
                 # matrix root, no Sylvester solve
                 eng.chisq_generate(df, end - begin, seed, 0, row_offset=begin)
                 eng.noise_generate(_NOISE_SLOT, end - begin, D, seed, 0, row_offset=begin)
+                _hint_next_seed(eng, 1 << _NOISE_SLOT, with_chi=True)
                 # the dense family's weighted pipeline with the rows scaled by 1 / s_n (vb_alpha_grad_mvt_chol): the
                 # gradient arrives in the flat layout, alpha / N applied on the device
                 return eng.alpha_grad_mvt_chol(_NOISE_SLOT, end - begin, D, df, var_param, alpha, n_total=N)
