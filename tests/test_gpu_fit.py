@@ -307,3 +307,43 @@ def test_resident_parameter_survives_a_fit_of_the_same_dimension():
     v1, g1 = eng.fullrank_get(D)
     assert v1 == v0
     np.testing.assert_array_equal(g1, g0)
+
+
+@pytest.mark.parametrize('family', ['meanfield', 'fullrank', 'lowrank'])
+@pytest.mark.parametrize('n_iters,hist_len', [(1, 1), (3, 2), (4, 4), (5, 0), (11, 7), (23, 23)])
+def test_streamed_rows_equal_the_single_copy(family, n_iters, hist_len):
+    """vb_fit's per-iteration rows (iterates, directions, gradients) through the copy stream + pinned ring (long rows by
+    default; here forced for short ones) are the rows of the one copy after the last step -- fewer iterations than ring
+    slots, exactly as many, more, and a history shorter than the run."""
+    import os
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    D, N = 12, 40
+    rng = np.random.RandomState(3)
+    eng.set_model(vb.GaussianModel(rng.randn(D), np.exp(0.2 * rng.randn(D))).device_spec())
+    if family == 'meanfield':
+        theta, fam_id, aux = np.concatenate([np.zeros(D), -np.ones(D)]), _lib.FAMILY_MF_GAUSSIAN, -1
+    elif family == 'fullrank':
+        theta, fam_id, aux = vb.FullRankGaussian(D).pack(np.zeros(D), np.eye(D)), _lib.FAMILY_FULLRANK_GAUSSIAN, -1
+    else:
+        fam = vb.LRGaussian(D, k=2, seed=1)
+        theta, fam_id, aux = fam.init_param(), _lib.FAMILY_LOWRANK_GAUSSIAN, 5
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            return eng.fit(4, N, D, fam_id, theta, n_iters, _lib.OPT_RMSPROP, [0.01, 0.9, 0.0, 1e-8], seed=9, hist_len=hist_len,
+                           log_directions=True, log_gradients=True, slot_aux=aux)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+    plain = run({'VB_FIT_STREAM_ROWS': '0'})
+    streamed = run({'VB_FIT_STREAM_ROWS': '1', 'VB_FIT_STREAM_MIN_BYTES': '0'})
+    for a, b in zip(plain, streamed):
+        np.testing.assert_array_equal(a, b)
+    assert plain[2].shape == (hist_len, theta.size) and np.isfinite(plain[4]).all() and np.isfinite(plain[5]).all()

@@ -228,6 +228,7 @@ int sync_streams(vb_ctx* ctx) {
     VB_HIP(ctx, hipStreamSynchronize(ctx->pipe.post));
   }
   if (ctx->mvt_side) VB_HIP(ctx, hipStreamSynchronize(ctx->mvt_side));
+  if (ctx->fit_copy_st) VB_HIP(ctx, hipStreamSynchronize(ctx->fit_copy_st));
   ctx->pipe.post_pending = false;
   return comm_check(ctx);
 }
@@ -500,6 +501,15 @@ int vb_destroy(vb_ctx* ctx) {
     (void)hipEventDestroy(ctx->mvt_ev_join);
   }
   if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
+  if (ctx->fit_copy_st) {
+    (void)hipStreamSynchronize(ctx->fit_copy_st);
+    (void)hipStreamDestroy(ctx->fit_copy_st);
+  }
+  if (ctx->fit_ring) (void)hipHostFree(ctx->fit_ring);
+  for (int i = 0; i < vb_ctx::kFitRing; ++i) {
+    if (ctx->fit_ev_step[i]) (void)hipEventDestroy(ctx->fit_ev_step[i]);
+    if (ctx->fit_ev_copy[i]) (void)hipEventDestroy(ctx->fit_ev_copy[i]);
+  }
   for (auto& e : ctx->batch_events) (void)hipEventDestroy(e);
   for (auto& log : ctx->prof)
     for (auto& ev : log.events) {
@@ -1596,6 +1606,80 @@ int vb_mvt_path_terms(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_tot
 }
 
 // ---- device-resident fit (optimization.py:83-127) ----------------------------------------------------
+// The rows vb_fit logs per iteration (iterate, descent direction, gradient: optimization.py:83-127 returns every iterate,
+// :541 FASO's gradient history) used to leave in one pageable copy after the last step: at p = 525 312 (D = 1024 dense)
+// 4.2 MB per row at ~13 GB/s, as long again as the iteration that produced it.  With long rows each iteration's rows go,
+// behind an event, through a copy stream into a ring of pinned slots while the following iterations run; the enqueuing
+// thread, which is R iterations ahead of the GPU at most, moves a slot to the caller's arrays before it reuses it.
+namespace {
+struct FitRowStream {
+  vb_ctx* ctx = nullptr;
+  bool on = false;
+  int64_t p = 0, n_iters = 0, hist_first = 0;
+  const double *d_hist = nullptr, *d_dirs = nullptr, *d_grads = nullptr;     // device rows
+  double *h_hist = nullptr, *h_dirs = nullptr, *h_grads = nullptr;           // caller's arrays
+  int64_t drained = 0;          // iterations whose rows have reached the caller
+
+  static size_t min_row_bytes() {
+    const char* e = getenv("VB_FIT_STREAM_MIN_BYTES");
+    return e ? (size_t)atoll(e) : (size_t)1 << 18;
+  }
+  int begin() {
+    const char* e = getenv("VB_FIT_STREAM_ROWS");
+    on = (h_hist || h_dirs || h_grads) && !(e && atoi(e) == 0) && (size_t)p * sizeof(double) >= min_row_bytes();
+    if (!on) return VB_OK;
+    if (!ctx->fit_copy_st) VB_HIP(ctx, hipStreamCreateWithFlags(&ctx->fit_copy_st, hipStreamNonBlocking));
+    const size_t slot = (size_t)round_up(3 * p, 16);
+    if (ctx->fit_ring_doubles < slot) {
+      VB_HIP(ctx, hipStreamSynchronize(ctx->fit_copy_st));
+      if (ctx->fit_ring) VB_HIP(ctx, hipHostFree(ctx->fit_ring));
+      ctx->fit_ring = nullptr;
+      ctx->fit_ring_doubles = 0;
+      VB_HIP(ctx, hipHostMalloc((void**)&ctx->fit_ring, vb_ctx::kFitRing * slot * sizeof(double), hipHostMallocDefault));
+      ctx->fit_ring_doubles = slot;
+    }
+    for (int i = 0; i < vb_ctx::kFitRing; ++i) {
+      if (!ctx->fit_ev_step[i]) VB_HIP(ctx, hipEventCreateWithFlags(&ctx->fit_ev_step[i], hipEventDisableTiming));
+      if (!ctx->fit_ev_copy[i]) VB_HIP(ctx, hipEventCreateWithFlags(&ctx->fit_ev_copy[i], hipEventDisableTiming));
+    }
+    return VB_OK;
+  }
+  int drain_one() {           // iteration `drained`: wait for its copies, hand the rows over
+    const int64_t k = drained;
+    const int slot = (int)(k % vb_ctx::kFitRing);
+    VB_HIP(ctx, hipEventSynchronize(ctx->fit_ev_copy[slot]));
+    const double* src = ctx->fit_ring + (size_t)slot * ctx->fit_ring_doubles;
+    const size_t row = (size_t)p * sizeof(double);
+    if (h_hist && k >= hist_first) memcpy(h_hist + (k - hist_first) * p, src, row);
+    if (h_dirs) memcpy(h_dirs + k * p, src + p, row);
+    if (h_grads) memcpy(h_grads + k * p, src + 2 * p, row);
+    ++drained;
+    return VB_OK;
+  }
+  int after_step(int64_t k) {      // iteration k's kernels (its step included) are enqueued on the main stream
+    if (!on) return VB_OK;
+    if (k >= vb_ctx::kFitRing) VB_TRY(drain_one());      // the slot's previous tenant: iteration k - R
+    const int slot = (int)(k % vb_ctx::kFitRing);
+    hipStream_t cs = ctx->fit_copy_st;
+    VB_HIP(ctx, hipEventRecord(ctx->fit_ev_step[slot], ctx->stream));
+    VB_HIP(ctx, hipStreamWaitEvent(cs, ctx->fit_ev_step[slot], 0));
+    double* dst = ctx->fit_ring + (size_t)slot * ctx->fit_ring_doubles;
+    const size_t row = (size_t)p * sizeof(double);
+    if (h_hist && k >= hist_first)
+      VB_HIP(ctx, hipMemcpyAsync(dst, d_hist + (k - hist_first) * p, row, hipMemcpyDeviceToHost, cs));
+    if (h_dirs) VB_HIP(ctx, hipMemcpyAsync(dst + p, d_dirs + k * p, row, hipMemcpyDeviceToHost, cs));
+    if (h_grads) VB_HIP(ctx, hipMemcpyAsync(dst + 2 * p, d_grads + k * p, row, hipMemcpyDeviceToHost, cs));
+    VB_HIP(ctx, hipEventRecord(ctx->fit_ev_copy[slot], cs));
+    return VB_OK;
+  }
+  int finish() {
+    if (!on) return VB_OK;
+    while (drained < n_iters) VB_TRY(drain_one());
+    return VB_OK;
+  }
+};
+}  // namespace
+
 int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_total, int64_t row_offset, int family,
            double df, unsigned flags, int cv_mode, int noise_kind, double noise_df, uint64_t seed,
            uint64_t first_stream, int opt_kind, const double hyper[4], int64_t n_iters, double* theta, int64_t p,
@@ -1676,6 +1760,11 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
   step.hist_first = n_iters - hist_len;
   step.dirs = directions ? base + o_dirs : nullptr;
   step.grads = gradients ? base + o_grads : nullptr;
+  FitRowStream rows;
+  rows.ctx = ctx, rows.p = p, rows.n_iters = n_iters, rows.hist_first = n_iters - hist_len;
+  rows.d_hist = step.hist, rows.d_dirs = step.dirs, rows.d_grads = step.grads;
+  rows.h_hist = hist_len > 0 ? history : nullptr, rows.h_dirs = directions, rows.h_grads = gradients;
+  VB_TRY(rows.begin());
 
   MfCall c;
   if (meanfield) {
@@ -1755,6 +1844,7 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
       step_done = true;
     }
     if (!step_done) VB_TRY(fit_step_enqueue(ctx, step));
+    VB_TRY(rows.after_step(k));
   }
   VB_HIP(ctx, hipMemcpyAsync(theta, theta_dev, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpyAsync(values, base + o_val, (size_t)n_iters * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1762,15 +1852,16 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
     VB_HIP(ctx, hipMemcpyAsync(state, base + o_s1, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
     VB_HIP(ctx, hipMemcpyAsync(state + p, base + o_s2, (size_t)p * sizeof(double), hipMemcpyDeviceToHost, st));
   }
-  if (hist_len > 0)
+  if (hist_len > 0 && !rows.on)
     VB_HIP(ctx, hipMemcpyAsync(history, base + o_hist, (size_t)(hist_len * p) * sizeof(double),
                                hipMemcpyDeviceToHost, st));
-  if (directions)
+  if (directions && !rows.on)
     VB_HIP(ctx, hipMemcpyAsync(directions, base + o_dirs, (size_t)(n_iters * p) * sizeof(double),
                                hipMemcpyDeviceToHost, st));
-  if (gradients)
+  if (gradients && !rows.on)
     VB_HIP(ctx, hipMemcpyAsync(gradients, base + o_grads, (size_t)(n_iters * p) * sizeof(double),
                                hipMemcpyDeviceToHost, st));
+  VB_TRY(rows.finish());
   VB_HIP(ctx, hipStreamSynchronize(st));
   return VB_OK;
 }

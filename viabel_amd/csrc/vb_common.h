@@ -268,6 +268,13 @@ struct vb_ctx {
   double* pin_dev = nullptr;
   size_t pin_bytes = 0;
   vb::DeviceBuffer fit_work;            // device-resident fit: [theta | out | state | value history | iterates]
+  // vb_fit's per-iteration rows (iterates, directions, gradients) leave while the next iterations run: a copy stream, a
+  // ring of pinned slots, one event pair per slot (vb_api.hip, FitRowStream)
+  static constexpr int kFitRing = 4;
+  hipStream_t fit_copy_st = nullptr;
+  double* fit_ring = nullptr;
+  size_t fit_ring_doubles = 0;          // capacity of ONE slot
+  hipEvent_t fit_ev_step[kFitRing] = {}, fit_ev_copy[kFitRing] = {};
   vb::DeviceBuffer tri_map;             // XCD-aware tile list of the lower-triangular gradient GEMM (int pairs)
   int tri_map_key[3] = {0, 0, 0};       // (d, tile rows, tile columns) the list was built for
   int tri_map_blocks = 0;
