@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet fp64 matrix peak = 256 CUs x 4 SIMDs x 512 flop / 16 clk x 2.4 GHz;
 #                                                  tools/mfma_barrier_probe.hip measures 77.3 with constant operands
 # HBM-side bytes per launch of the headline's dense model GEMM at D=1024, N=4096 (see roofline.traffic_source)
-MODEL_GEMM_HBM_BYTES = int((2 * 64291.8 + 34488.6) * 1024)      # profiles/r04_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
+MODEL_GEMM_HBM_BYTES = int((2 * 64295.8 + 34414.4) * 1024)      # profiles/r05_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
 MF_ACCUM_HBM_BYTES = int((2 * 530474.5 + 8352.7) * 1024)           # profiles/r04_meanfield_c1_pmc_hbm.txt, per 32-evaluation launch
 MIN_TIMED_S = 0.05                               # the timed blocks are repeated until they cover at least this
 
@@ -1167,9 +1167,9 @@ def main():
             # profiles/ (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
             if head['n_rows'] == N_MC and FR_D == 1024:
                 roof['traffic'] = MODEL_GEMM_HBM_BYTES
-                roof['traffic_source'] = ('profiles/r04_fullrank_gemm_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                roof['traffic_source'] = ('profiles/r05_fullrank_gemm_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                           'separate passes, FETCH_SIZE doubled per the gfx950 note): 131.7 MB fetched + '
-                                          '35.5 MB written per launch vs 75.5 MB of operands and result (Z 33.6 + P 8.4 '
+                                          '35.2 MB written per launch vs 75.5 MB of operands and result (Z 33.6 + P 8.4 '
                                           'read, G 33.6 written) + 33.6 MB for the epilogue reading z - m back for sum f; '
                                           'P is fetched once per XCD; 1.25 TB/s, a sixth of HBM peak: MFMA-bound')
             roof.update({'kernel': 'gemm_f64_dma_kernel<A[m][k], 128x64, EpiNegate>: G = -(Z - m) P, dense %d x %d x %d '
