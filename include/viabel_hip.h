@@ -120,6 +120,10 @@ int vb_chisq_get_host(vb_ctx* ctx, double* host, int64_t n);
  * only by a request that matches it exactly; after a wrong hint the request generates as usual.  The hint is consumed by
  * the next blocking call of this context.                                                                              */
 int vb_noise_hint_seed(vb_ctx* ctx, unsigned slot_mask, int with_chi, uint64_t seed);
+/* How many look-ahead buffers (noise matrices and chi-square vectors) this context has generated and how many of them a
+ * request adopted: an observability counter -- a caller whose hints or stream walks stop matching sees the ratio drop
+ * (results never depend on it).                                                                                       */
+int vb_noise_ahead_stats(vb_ctx* ctx, uint64_t* generated, uint64_t* adopted);
 
 /* ---- model ------------------------------------------------------------------------ */
 int vb_set_model(vb_ctx* ctx, int model_id, int64_t dim, const double* dparams,

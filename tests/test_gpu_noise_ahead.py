@@ -176,3 +176,43 @@ def test_alpha_divergence_with_the_next_seed_hinted(env, family):
     for (v0, g0), (v1, g1) in zip(plain, ahead):
         assert v0 == v1
         np.testing.assert_array_equal(g0, g1)
+
+
+@pytest.mark.parametrize('family', ['mf_gaussian', 'lowrank', 'multivariate_t'])
+def test_hinted_seeds_are_actually_adopted(env, family):
+    """The point of the hint, observed: in a plain loop of AlphaDivergence calls every call but the first adopts the
+    look-ahead buffers (one noise matrix; two for the low-rank family; a noise matrix and the chi-square draws for the t
+    family) -- if numpy's generator layout ever stops matching `_peek_next_randint`, results stay right and THIS fails."""
+    vb, eng, _lib = env
+    D, N, calls = 20, 500, 12
+    rng = np.random.RandomState(6)
+    model = vb.GaussianModel(0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D)))
+    fam, per_call = {'mf_gaussian': (lambda: vb.MFGaussian(D, rng='philox'), 1), 'lowrank': (lambda: vb.LRGaussian(D, k=3, rng='philox'), 2),
+                     'multivariate_t': (lambda: vb.MultivariateT(D, 9, rng='philox'), 2)}[family]
+    approx = fam()
+    obj = vb.AlphaDivergence(approx, model, N, 0.5)
+    theta = approx.init_param()
+    np.random.seed(2)
+    obj(theta)
+    g0, a0 = eng.noise_ahead_stats()
+    for _ in range(calls):
+        obj(theta)
+    g1, a1 = eng.noise_ahead_stats()
+    assert a1 - a0 == per_call * calls, (g1 - g0, a1 - a0)
+    assert g1 - g0 == per_call * calls
+
+
+def test_stream_walks_are_adopted(env):
+    """ExclusiveKL / DISInclusiveKL count their Philox streams 0, 1, 2, ...: from the third call on every request adopts."""
+    vb, eng, _lib = env
+    D, N, calls = 16, 400, 10
+    approx = vb.FullRankGaussian(D, rng='philox')
+    obj = vb.ExclusiveKL(approx, vb.GaussianModel(np.zeros(D), np.ones(D)), N)
+    theta = approx.init_param()
+    for _ in range(3):
+        obj(theta)
+    g0, a0 = eng.noise_ahead_stats()
+    for _ in range(calls):
+        obj(theta)
+    g1, a1 = eng.noise_ahead_stats()
+    assert a1 - a0 == calls and g1 - g0 == calls

@@ -55,6 +55,7 @@ SIGNATURES = {
                                          ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int64]),
     'vb_noise_hint_seed': (ctypes.c_int, [_ctx_p, ctypes.c_uint, ctypes.c_int, ctypes.c_uint64]),
+    'vb_noise_ahead_stats': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     'vb_chisq_generate': (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
                                          ctypes.c_int64]),
     'vb_chisq_get_host': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64]),
@@ -359,6 +360,12 @@ class Engine:
         """Tell the look-ahead generator the seed of the NEXT call's Philox requests (``vb_noise_hint_seed``): a
         prediction only -- a shadow that does not match the request is never adopted."""
         self._check(self._lib.vb_noise_hint_seed(self._ctx, int(slot_mask), 1 if with_chi else 0, int(seed)))
+
+    def noise_ahead_stats(self):
+        """``(generated, adopted)``: look-ahead buffers this engine has generated / requests that adopted one."""
+        g, a = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._lib.vb_noise_ahead_stats(self._ctx, ctypes.byref(g), ctypes.byref(a)))
+        return int(g.value), int(a.value)
 
     def noise_generate(self, slot, n, d, seed, stream=0, row_offset=0, kind=NOISE_NORMAL, df=0.0):
         self._check(self._lib.vb_noise_generate(self._ctx, slot, kind, float(df), int(seed), int(stream),

@@ -293,6 +293,7 @@ void noise_prefetch(vb_ctx* ctx) {
     else nx.stream = h.last.stream + (uint64_t)h.delta;
     if (rng_fill(ctx, (double*)h.shadow.ptr, s.ld, nx.kind, nx.df, nx.seed, nx.stream, nx.row_offset, nx.n, nx.d) != VB_OK) continue;
     h.pre = nx;
+    ++ctx->ahead_generated;
   }
   NoiseAhead& c = ctx->chi_ahead;
   const bool chi_hinted = c.hint.valid;
@@ -303,7 +304,10 @@ void noise_prefetch(vb_ctx* ctx) {
     NoiseReq nx = c.last;
     if (chi_hinted) nx.seed = c.hint.seed, nx.stream = c.hint.stream;
     else nx.stream = c.last.stream + (uint64_t)c.delta;
-    if (rng_chisquare(ctx, (double*)c.shadow.ptr, nx.df, nx.seed, nx.stream, nx.row_offset, nx.n) == VB_OK) c.pre = nx;
+    if (rng_chisquare(ctx, (double*)c.shadow.ptr, nx.df, nx.seed, nx.stream, nx.row_offset, nx.n) == VB_OK) {
+      c.pre = nx;
+      ++ctx->ahead_generated;
+    }
   }
 }
 
@@ -574,6 +578,7 @@ int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
       }
       std::swap(s.buf, h.shadow);
       h.pre.valid = false;
+      ++ctx->ahead_adopted;
       req_observe(h, r);
       return VB_OK;
     }
@@ -583,6 +588,13 @@ int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
   s.ahead.pre.valid = false;      // (a shadow that was not asked for is dropped)
   VB_TRY(rng_fill(ctx, (double*)s.buf.ptr, s.ld, kind, df, seed, stream, row_offset, n, d));
   req_observe(s.ahead, r);
+  return VB_OK;
+}
+
+int vb_noise_ahead_stats(vb_ctx* ctx, uint64_t* generated, uint64_t* adopted) {
+  if (!ctx || !generated || !adopted) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  *generated = ctx->ahead_generated;
+  *adopted = ctx->ahead_adopted;
   return VB_OK;
 }
 
@@ -614,6 +626,7 @@ int vb_chisq_generate(vb_ctx* ctx, double df, uint64_t seed, uint64_t stream, in
       c.shadow.bytes >= (size_t)n * sizeof(double) && ctx->chi_dev.bytes >= (size_t)n * sizeof(double) && noise_ahead_on()) {
     std::swap(ctx->chi_dev, c.shadow);
     c.pre.valid = false;
+    ++ctx->ahead_adopted;
     ctx->chi_n = n;
     ctx->chi_df = df;
     req_observe(c, r);

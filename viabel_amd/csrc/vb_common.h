@@ -224,6 +224,7 @@ struct vb_ctx {
   hipStream_t mvt_side = nullptr;       // side stream of the deferred triangular inverse (mvt_factors_device)
   hipEvent_t mvt_ev_fork = nullptr, mvt_ev_join = nullptr;
   hipEvent_t done_ev = nullptr;      // wait_then_prefetch
+  uint64_t ahead_generated = 0, ahead_adopted = 0;      // look-ahead buffers generated / adopted (vb_noise_ahead_stats)
   bool mvt_inv_pending = false;         // the main stream has not yet waited for the side stream's inverse
   bool mvt_inv_queued = false;          // ... which has been enqueued already (else mvt_inv_args describes it)
   struct {
