@@ -1250,7 +1250,8 @@ def main():
             out['alpha_divergence'] = alpha_leg(vb)
             out['c4_logistic'] = c4_leg(eng, vb)
             out['other_paths'] = other_paths_leg(eng, vb)
-            with contextlib.redirect_stderr(io.StringIO()):
+            # (the optimisers report through print(), as the reference's do: stdout carries the JSON line only)
+            with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):
                 out['bbvi_quickstart'] = bbvi_quickstart_leg(vb)
             try:
                 out['source_model'] = source_model_leg(vb)
