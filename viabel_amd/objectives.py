@@ -77,8 +77,11 @@ def _peek_next_randint():
     AlphaDivergence draws its seed this way every call (objectives.py:455), and a wrong hint costs a wasted generation,
     never a wrong result (``tests/test_host_logic.py`` pins the prediction against numpy's draws)."""
     try:
-        key = (ctypes.c_uint32 * 625).from_address(np.random.mtrand._rand._bit_generator.ctypes.state_address)
-    except Exception:        # another bit generator behind np.random, an interface that moved
+        bit_generator = np.random.mtrand._rand._bit_generator
+        if type(bit_generator).__name__ != 'MT19937':      # np.random.set_bit_generator: another state layout
+            return None
+        key = (ctypes.c_uint32 * 625).from_address(bit_generator.ctypes.state_address)
+    except Exception:        # an interface that moved
         return None
     pos = key[624]
     if pos < 624:
