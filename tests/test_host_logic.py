@@ -421,3 +421,18 @@ def test_peek_of_numpys_next_randint():
         assert _peek_next_randint() == a == int(np.random.randint(2 ** 32))
     finally:
         np.random.set_state(saved)
+
+
+def test_peek_declines_another_bit_generator():
+    """np.random.set_bit_generator can put a generator with another state layout behind the global functions: no hint."""
+    from viabel_amd.objectives import _peek_next_randint
+    if not hasattr(np.random, 'set_bit_generator'):
+        pytest.skip('numpy without set_bit_generator')
+    old = np.random.get_bit_generator()
+    try:
+        np.random.set_bit_generator(np.random.PCG64(1))
+        assert _peek_next_randint() is None
+    finally:
+        np.random.set_bit_generator(old)
+    np.random.seed(4)
+    assert _peek_next_randint() == int(np.random.randint(2 ** 32))
