@@ -1238,6 +1238,10 @@ def main():
             out['c2_fullrank_d512'] = {k: v for k, v in fullrank_leg(
                 eng, vb, _lib, group, 512, max(args.steps, 200), args.warmup, profile=True).items()
                 if k in ('whole_evaluation', 'per_kernel', 'value', 'grad_norm')}
+            # the same evaluation at D = 256: the sub-30-us GEMMs of C3's shape class
+            out['fullrank_d256'] = {k: v for k, v in fullrank_leg(
+                eng, vb, _lib, group, 256, max(args.steps, 200), args.warmup, profile=True).items()
+                if k in ('whole_evaluation', 'per_kernel', 'value', 'grad_norm')}
             out['fullrank_funnel'] = fullrank_funnel_leg(eng, vb)
             out['api_call'] = api_call_leg(eng, vb)
             with contextlib.redirect_stderr(io.StringIO()):
