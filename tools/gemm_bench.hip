@@ -393,6 +393,22 @@ int main(int argc, char** argv) {
         }
         printf("check cfg %d tri %d A[m][k]: max |dma - reg| = %.3e (max |C| %.3e)\n", cfg, tri, md, mx);
       }
+    for (int cfg = 7; cfg <= 8; ++cfg)      // the 64 x 32 tiles (LDS-DMA only) against the register-staged 64 x 64 kernel
+      for (int tri = 0; tri <= 1; ++tri) {
+        GemmArgs g;
+        g.A = A, g.B = tri ? Bu : B, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = tri;
+        hipMemset(C, 0, (size_t)M * N * 8);
+        gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, 3, 1);
+        hipDeviceSynchronize();
+        hipMemcpy(c0.data(), C, c0.size() * 8, hipMemcpyDeviceToHost);
+        hipMemset(C, 0, (size_t)M * N * 8);
+        gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{C, N}, cfg, 0);
+        hipDeviceSynchronize();
+        hipMemcpy(c1.data(), C, c1.size() * 8, hipMemcpyDeviceToHost);
+        double md = 0;
+        for (size_t i = 0; i < c0.size(); ++i) md = fmax(md, fabs(c0[i] - c1[i]));
+        printf("check cfg %d tri %d (64 x 32 tiles): max |dma - reg 64 x 64| = %.3e\n", cfg, tri, md);
+      }
     for (int cfg = 4; cfg <= 5; ++cfg) {     // the two-stage kernels against the register-staged kernel
       GemmArgs g;
       g.A = A, g.B = Bu, g.lda = K, g.ldb = N, g.M = M, g.N = N, g.K = K, g.tri_mode = 1;

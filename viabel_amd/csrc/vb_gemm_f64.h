@@ -372,6 +372,8 @@ inline long gemm_count_blocks(const GemmArgs& g, int bm_rows, int bn_cols) {
 
 // cfg: 0 = automatic, 1 = 128 x 128, 2 = 128 x 64, 3 = 64 x 64 block tiles (three LDS stages);
 //      4 = 64 x 64, 5 = 128 x 64, 6 = 128 x 128 with two LDS stages (more workgroups per CU); LDS-DMA kernel only
+//      7 = 64 x 32 with three, 8 = 64 x 32 with two LDS stages: LDS-DMA kernel, A[m][k], epilogues that neither reduce nor
+//      take column sums (element values do not depend on the tile: bit-identical to the 64 x 64 tiles, tools/gemm_bench.hip)
 // flags bit 0: force the register-staged kernel
 // does a product of this shape go to the LDS-DMA kernel (which alone implements EpiColsum)?
 inline bool gemm_uses_dma(const GemmArgs& g) {
@@ -383,11 +385,13 @@ inline bool gemm_uses_dma(const GemmArgs& g) {
 template <bool A_KCONTIG, class Epi>
 inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi, int cfg = 0,
                                 int flags = 0) {
+  // 64 x 32 tiles: only where the result cannot depend on the tiling (no per-tile partial sums, no column sums)
+  constexpr bool kNarrowOk = A_KCONTIG && !EpiReduces<Epi>::value && !EpiColsum<Epi>::value;
   if (splits < 1) splits = 1;
   int ks = g.batch ? g.K : gemm_tiles(g.K, splits);   // batch mode: `splits` is the number of products
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
   static const int cfg_env = getenv("VB_GEMM_CFG") ? atoi(getenv("VB_GEMM_CFG")) : 0;   // experiments: force a tile
-  if (cfg == 0 && cfg_env >= 1 && cfg_env <= 6) cfg = cfg_env;
+  if (cfg == 0 && cfg_env >= 1 && cfg_env <= 8) cfg = cfg_env;
   // operands straight into LDS (vb_gemm_f64_dma.h) when every k range is a whole number of slabs
   const bool dma = gemm_uses_dma(g) && !(flags & 1);
   if (g.tri_mode == 3 && (!dma || splits != 1 || g.batch)) g.tri_mode = 0;      // the zeros are multiplied instead of skipped
@@ -400,6 +404,11 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
       // round 3: with the priority alternation off for these launches (below) the two-stage variant -- 32 KB, four
       // workgroups per CU instead of three -- is the faster one: 82.4 -> 78.2 us in the headline pipeline
       cfg = 4;
+      // at most two 64 x 64 tiles per CU (D <= 512 at 4096 samples): the launch is one heavy tile's k loop, and half
+      // as wide a tile halves the MFMAs of every slab of it -- 4096 x 256 x 256: 15.2 -> 11.9 us, 4096 x 512 x 512:
+      // 28.9 -> 26.9 us; with more tiles per CU it loses (16 384 x 256 x 256: 29.3 -> 30.8 us, D = 1024: 82 -> 92 us)
+      // (tools/tile32_probe.sh)
+      if (kNarrowOk && !g.batch && gemm_count_blocks(g, 64, 64) <= 2L * n_cu) cfg = 8;
     } else if (dma && g.tri_mode == 0 && g.batch == 0 && gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) {
       // large dense products: 128 x 128 tiles with TWO LDS stages (64 KB: two workgroups per CU).  Per MFMA a third
       // fewer fragment reads and LDS-DMA pieces than 128 x 64: 69.3 - 70.2 against 66.0 - 67.5 TFLOP/s on
@@ -414,10 +423,14 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
       cfg = 2;    // (lower-triangular D = 1024 product in 7 row slabs: 504 workgroups on 256 CUs)
     } else {
       cfg = 3;
+      // dense products with at most one 64 x 64 tile per CU: 4096 x 256 x 256 17.2 -> 15.8 us (at two per CU it loses:
+      // 4096 x 512 x 512 42.9 -> 45.4 us)
+      if (kNarrowOk && dma && g.tri_mode == 0 && !g.batch && gemm_count_blocks(g, 64, 64) * splits <= (long)n_cu) cfg = 7;
     }
   }
-  if (!dma && cfg > 3) cfg = cfg == 4 ? 3 : cfg == 6 ? 1 : 2;
-  const int bm_rows = (cfg == 3 || cfg == 4) ? 64 : 128, bn_cols = (cfg == 1 || cfg == 6) ? 128 : 64;
+  if (!kNarrowOk && cfg >= 7) cfg = 4;
+  if (!dma && cfg > 3) cfg = (cfg == 4 || cfg >= 7) ? 3 : cfg == 6 ? 1 : 2;
+  const int bm_rows = (cfg == 3 || cfg == 4 || cfg >= 7) ? 64 : 128, bn_cols = cfg >= 7 ? 32 : (cfg == 1 || cfg == 6) ? 128 : 64;
   g.tiles_m = gemm_tiles(g.M, bm_rows);
   g.tiles_n = gemm_tiles(g.N, bn_cols);
   const dim3 grid(g.tile_map ? (unsigned)g.tile_blocks : (unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1,
@@ -432,6 +445,12 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
     else if (cfg == 3) gemm_f64_dma_launch<A_KCONTIG, 2, 8, 3, Epi>(st, g, grid, epi);
     else if (cfg == 4) gemm_f64_dma_launch<A_KCONTIG, 2, 8, 2, Epi>(st, g, grid, epi);
     else if (cfg == 6) gemm_f64_dma_launch<A_KCONTIG, 4, 16, 2, Epi>(st, g, grid, epi);
+    else if (cfg >= 7) {
+      if constexpr (kNarrowOk) {
+        if (cfg == 7) gemm_f64_dma_launch<A_KCONTIG, 2, 4, 3, Epi>(st, g, grid, epi);
+        else gemm_f64_dma_launch<A_KCONTIG, 2, 4, 2, Epi>(st, g, grid, epi);
+      }
+    }
     else gemm_f64_dma_launch<A_KCONTIG, 4, 8, 2, Epi>(st, g, grid, epi);
     return grid.x;
   }
