@@ -265,35 +265,39 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                        double* eps, double* ess, double* w, double* log_p, double* log_q);
 /* ExclusiveKL (entropy form, objectives.py:154-164) of the multivariate t in the reference-identical mode, resident on the
- * device (one rank): noise slot and the context's chi-square draws hold numpy's streams (vb_legacy_rng_chisquare_device,
+ * device: noise slot and the context's chi-square draws hold numpy's streams (vb_legacy_rng_chisquare_device,
  * then vb_legacy_rng_randn_device -- approximations.py:345-347), the samples go through the SYMMETRIC root of Sigma = L L'
  * (:348) and the gradient through the root's Frechet derivative (the Sylvester equation R X + X R = sym(C) / N), both by
  * Newton-Schulz iterations on the device; value and the gradient in the flat [mu | free Cholesky] layout come back after
  * one copy.  info (4 doubles, may be NULL) = [root steps, root accuracy, derivative steps, its accuracy].
+ * Sharded jobs (round 6): `n` = this rank's rows (the slot holds rows [shard begin, +n) of randn(n_total, d); the context's
+ * chi-square buffer holds either those n draws or all n_total of numpy's -- the shard's block is taken), the sample sums
+ * are all-reduced on the device and the O(D^3) chain rule runs redundantly on every rank: the same bits everywhere.
  * VB_ERR_UNSUPPORTED: an iteration did not resolve to 1e-12 -- use vb_elbo_sums_mvt with a host-side root.            */
-int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
-                             double* grad, double* info);
+int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
+                             double* value, double* grad, double* info);
 /* The same evaluation in the path-derivative form (ExclusiveKL(use_path_deriv=True), objectives.py:156-159): the value takes
  * the samples' mean log density instead of the entropy, and the score -d log q / dx (x_n) = c_n Sigma^(-1/2) z_n / s_n joins
  * the model gradient -- its part of the sums depends on the noise only (the sums of vb_mvt_path_terms, formed on the
  * device) and enters through Sigma^(-1/2), the second limit of the root's coupled iteration.                             */
-int vb_elbo_grad_mvt_symroot_path(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
-                                  double* value, double* grad, double* info);
-/* AlphaDivergence (objectives.py:443-463) of the multivariate t in the reference-identical mode, resident on the device (one
- * rank): noise as for vb_elbo_grad_mvt_symroot (the caller's fresh RandomState(seed) of :455-456 drawn on the device), the
+int vb_elbo_grad_mvt_symroot_path(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df,
+                                  const double* theta, double* value, double* grad, double* info);
+/* AlphaDivergence (objectives.py:443-463) of the multivariate t in the reference-identical mode, resident on the device
+ * (n / n_total as above): noise as for vb_elbo_grad_mvt_symroot (the caller's fresh RandomState(seed) of :455-456 drawn on the device), the
  * samples through the symmetric root, weights / value / weighted sums by the kernels of vb_alpha_sums_mvt, the chain rule
  * through the root's Frechet derivative with sum s on the free diagonal; value = the log-normaliser estimate, grad =
  * alpha / N times the weighted score.  VB_ERR_UNSUPPORTED: an iteration did not resolve -- vb_alpha_sums_mvt + host root. */
-int vb_alpha_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, double alpha, const double* theta,
-                              double* value, double* grad, double* info);
+int vb_alpha_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
+                              const double* theta, double* value, double* grad, double* info);
 
-/* The reference-identical step resident on the device (one rank): as vb_dis_refresh_mvt with chi, sqrt_sigma, l_inv and
+/* The reference-identical step resident on the device: as vb_dis_refresh_mvt with chi, sqrt_sigma, l_inv and
  * w NULL -- factors from theta on the device, chi-square draws from the context's buffer (vb_legacy_rng_chisquare_device
- * for numpy's stream), nothing copied back -- but the samples go through the SYMMETRIC root of Sigma = L L'
+ * for numpy's stream: this rank's n draws, or all n_total of them -- the shard's block is taken), nothing copied back --
+ * but the samples go through the SYMMETRIC root of Sigma = L L'
  * (approximations.py:348), formed on the device by a Newton-Schulz iteration scaled by the infinity norm; root_info (3
  * doubles, may be NULL) = [steps, last residual, ||R R - Sigma|| / ||Sigma||_inf].  vb_dis_step_mvt_packed follows.
  * VB_ERR_UNSUPPORTED: the iteration did not resolve the root to 1e-12 (no state was installed): use the host route. */
-int vb_dis_refresh_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
+int vb_dis_refresh_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
                                const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                                double* root_info);
 /* Throughput mode of the dense families: vb_dis_refresh_mvt with sqrt_sigma == NULL and l_inv == NULL forms mu, L and
@@ -303,8 +307,13 @@ int vb_dis_refresh_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, doub
  * rule to the flat parameter on the device: value = -scale sum_n w_n log q(x_n; theta) and its gradient (d + d (d + 1) / 2). */
 int vb_dis_grad_mvt_packed(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* theta, const double* weights,
                            double scale, double* value, double* grad);
-/* Device-resident step of the throughput mode (one rank): after vb_dis_refresh_mvt(..., w = NULL) -- which only enqueues
- * -- the tempered weights, eps, ess and the zero-weight status are still on the device.  This call takes the gradient of
+/* Device-resident step of the throughput mode: after vb_dis_refresh_mvt(..., w = NULL) -- which only enqueues
+ * -- the tempered weights, eps, ess and the zero-weight status are still on the device.  Sharded jobs (round 6; SURVEY
+ * 8(e), objectives.py:391-414): every rank samples and scores its `n` rows, [log p | log q | log prior] are all-gathered on
+ * the device (3 n_total doubles), the bisection / smoothing / clipping / multinomial draw run REDUNDANTLY on the whole
+ * vectors on every rank (the same kernels on the same bits: the same weights everywhere), each rank forms the weighted
+ * sums over its own rows, ONE all-reduce of [sum w, sum w log q, sum a y, M (D x D)] follows and the D x D x D chain rule
+ * is redundant again: every rank returns the same bits.  This call takes the gradient of
  * -scale sum_n w_n log q(x_n; theta) on those weights (resample_m == 0, objectives.py:405-406) or on the counts of
  * resample_m multinomial draws from them (objectives.py:408-414: np.random.choice; here Philox uniforms of
  * (seed, stream) inverted through the running sums of the weights; `scale` is then multiplied by sum_n w_n on the

@@ -90,4 +90,100 @@ def run_all(vb):
         obj = vb.ExclusiveKL(fam, model, 257)
         res = vb.RMSProp(0.01, diagnostics=True).optimize(30, obj, theta)
         out['fit_' + fam_name] = (np.asarray(res['value_history'], dtype=float), np.asarray(res['opt_param'], dtype=float))
+    out.update(run_resident_dense(vb))
+    out.update(run_c3(vb))
     return {k: (np.atleast_1d(np.asarray(v[0], dtype=float)), np.asarray(v[1], dtype=float)) for k, v in out.items()}
+
+
+def _dis_calls(obj, theta, n_calls, step=0.002):
+    """`n_calls` objective calls along a short descent path (kept weights meet a moved parameter when
+    num_resampling_batches > 1); returns ([values..., eps, ess-or-0, khat-or-0], gradients concatenated)."""
+    vals, grads = [], []
+    for _ in range(n_calls):
+        v, g = obj(theta)
+        vals.append(v)
+        grads.append(g)
+        theta = theta - step * g / (1.0 + np.abs(g))
+    tail = [obj._eps, float(getattr(obj, '_ess', 0.0) or 0.0), float(getattr(obj, '_khat', 0.0) or 0.0)]
+    return np.array(vals + tail), np.concatenate(grads)
+
+
+def run_resident_dense(vb):
+    """The device-resident routes of the dense families at ragged sizes (round 6: they used to refuse more than one rank):
+    the throughput-mode DIS step with the device's multinomial draw, smoothing and clipping on the resident weights, and
+    every reference-identical (rng='numpy') objective of the t family -- chi-square draws and normals of numpy's streams on
+    the device, symmetric root, Frechet derivative -- with the sample sums all-reduced and the D^3 algebra redundant."""
+    out = {}
+    rng = np.random.RandomState(15)
+    D = 48
+    mean, sd = 0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D))
+    gauss = vb.GaussianModel(mean, sd)
+    funnel = vb.FunnelModel(D, D // 2)
+    thc = _theta_chol(D, rng)
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    kw = dict(ess_target=150, temper_prior=vb.MFGaussian(D), temper_prior_params=prior)
+    np.random.seed(21)
+    # device multinomial draw over the gathered weights (Philox: the same counts on every rank)
+    obj = vb.DISInclusiveKL(vb.MultivariateT(D, 9.0, seed=8, rng='philox'), gauss, 1003, use_resampling=True,
+                            num_resampling_batches=2, **kw)
+    out['res_dis_mvt_philox_resampling'] = _dis_calls(obj, thc, 3)
+    obj = vb.DISInclusiveKL(vb.MultivariateT(D, 9.0, seed=8, rng='philox'), gauss, 1003, use_resampling=False,
+                            psis_smooth=True, w_clip_threshold=0.02, **kw)
+    out['res_dis_mvt_philox_psis_clip'] = _dis_calls(obj, thc, 2)
+    obj = vb.DISInclusiveKL(vb.FullRankGaussian(D, seed=8, rng='philox'), funnel, 1003, use_resampling=True, **kw)
+    out['res_dis_fr_philox_resampling'] = _dis_calls(obj, thc, 2)
+    # reference-identical mode: numpy's streams on the device, host resampling draw on rank 0 for everybody
+    obj = vb.DISInclusiveKL(vb.MultivariateT(D, 9.0, seed=8), gauss, 1003, use_resampling=False, **kw)
+    out['res_dis_mvt_numpy_weighted'] = _dis_calls(obj, thc, 2)
+    obj = vb.DISInclusiveKL(vb.MultivariateT(D, 9.0, seed=8), gauss, 1003, use_resampling=True, num_resampling_batches=2,
+                            w_clip_threshold=0.02, **kw)
+    out['res_dis_mvt_numpy_resampling_clip'] = _dis_calls(obj, thc, 3)
+    obj = vb.DISInclusiveKL(vb.FullRankGaussian(D, seed=8), gauss, 1003, use_resampling=True, num_resampling_batches=2, **kw)
+    out['res_dis_fr_numpy_resampling'] = _dis_calls(obj, thc, 3)
+    A = rng.randn(D, D)
+    corr = vb.CorrelatedGaussianModel(0.2 * rng.randn(D), covariance=A @ A.T / D + np.eye(D))
+    out['res_ekl_mvt_numpy'] = vb.ExclusiveKL(vb.MultivariateT(D, 9.0, seed=5), corr, 1005)(thc)
+    out['res_ekl_mvt_numpy_pd'] = vb.ExclusiveKL(vb.MultivariateT(D, 9.0, seed=5), funnel, 1005, use_path_deriv=True)(thc)
+    np.random.seed(22)
+    out['res_alpha_mvt_numpy'] = vb.AlphaDivergence(vb.MultivariateT(D, 9.0, seed=7), gauss, 1005, 0.5)(thc)
+    return out
+
+
+def c3_problem(rng, D):
+    """BASELINE configs[3]'s problem as tests/test_gpu_full_size.py poses it: q on the tempering prior up to a small
+    correlated perturbation, the target shifted away -- the tempering bisection has to find an interior eps."""
+    from oracle import families as ofam
+    mean = 0.3 * rng.randn(D)
+    sd = np.exp(0.5 + 0.02 * rng.randn(D))
+    prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
+    A = rng.randn(D, D)
+    Sigma = np.e * np.eye(D) + 0.04 * (A @ A.T / D - np.eye(D))
+    theta = np.concatenate([0.02 * rng.randn(D), ofam.psd_to_free(Sigma)])
+    return mean, sd, prior, theta
+
+
+def run_c3(vb):
+    """BASELINE configs[3] at FULL size -- MultivariateT(256, df = 100) + DISInclusiveKL, N_mc = 16 384, the MC axis
+    sharded -- weighted / resampling / PSIS, throughput mode and reference-identical mode, plus the t family's
+    reference-identical ExclusiveKL (both forms) and AlphaDivergence at the same shape."""
+    out = {}
+    D, N, df, ess_target = 256, 16384, 100, 2048
+    rng = np.random.RandomState(33)
+    mean, sd, prior, theta = c3_problem(rng, D)
+    model = vb.GaussianModel(mean, sd)
+    kw = dict(ess_target=ess_target, temper_prior=vb.MFGaussian(D), temper_prior_params=prior)
+    np.random.seed(31)
+    for mode in ('philox', 'numpy'):
+        def family():
+            return vb.MultivariateT(D, df, seed=6, rng=mode)
+        out['c3_%s_weighted' % mode] = _dis_calls(vb.DISInclusiveKL(family(), model, N, use_resampling=False, **kw), theta, 2)
+        out['c3_%s_resampling' % mode] = _dis_calls(
+            vb.DISInclusiveKL(family(), model, N, use_resampling=True, num_resampling_batches=2, **kw), theta, 3)
+        out['c3_%s_weighted_psis' % mode] = _dis_calls(
+            vb.DISInclusiveKL(family(), model, N, use_resampling=False, psis_smooth=True, **kw), theta, 2)
+        out['c3_%s_resampling_psis' % mode] = _dis_calls(
+            vb.DISInclusiveKL(family(), model, N, use_resampling=True, psis_smooth=True, **kw), theta, 2)
+    out['c3_ekl_numpy'] = vb.ExclusiveKL(vb.MultivariateT(D, df, seed=6), model, N)(theta)
+    out['c3_ekl_numpy_pd'] = vb.ExclusiveKL(vb.MultivariateT(D, df, seed=6), model, N, use_path_deriv=True)(theta)
+    out['c3_alpha_numpy'] = vb.AlphaDivergence(vb.MultivariateT(D, df, seed=6), model, N, 0.5)(theta)
+    return out

@@ -141,14 +141,14 @@ SIGNATURES = {
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_double_p,
                                           _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     'vb_dis_scalars_get': (ctypes.c_int, [_ctx_p, _c_double_p]),
-    'vb_elbo_grad_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
+    'vb_elbo_grad_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _c_double_p,
                                                 ctypes.POINTER(ctypes.c_double), _c_double_p, _c_double_p]),
-    'vb_alpha_grad_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+    'vb_alpha_grad_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                                  ctypes.c_double, _c_double_p, ctypes.POINTER(ctypes.c_double), _c_double_p,
                                                  _c_double_p]),
-    'vb_elbo_grad_mvt_symroot_path': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+    'vb_elbo_grad_mvt_symroot_path': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                                      _c_double_p, ctypes.POINTER(ctypes.c_double), _c_double_p, _c_double_p]),
-    'vb_dis_refresh_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+    'vb_dis_refresh_mvt_symroot': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
                                                   _c_double_p, _c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                                   _c_double_p]),
     'vb_dis_refresh_lowrank': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
@@ -698,15 +698,17 @@ class Engine:
             ctypes.byref(ess), _dptr(w), None if lp is None else _dptr(lp), None if lq is None else _dptr(lq)))
         return eps.value, ess.value, w, lp, lq
 
-    def dis_refresh_mvt_deferred(self, slot, n, d, df, theta, prior_theta, eps_prev, ess_target, max_bisection_its=50):
-        """Throughput-mode refresh that only ENQUEUES (one rank): samples, log p / log q, tempering bisection and the
-        weights stay on the device; ``dis_step_mvt_packed`` reads them and synchronises once."""
+    def dis_refresh_mvt_deferred(self, slot, n, d, df, theta, prior_theta, eps_prev, ess_target, max_bisection_its=50,
+                                 n_total=None):
+        """Throughput-mode refresh that only ENQUEUES: samples, log p / log q, tempering bisection and the weights stay
+        on the device; ``dis_step_mvt_packed`` reads them and synchronises once.  Sharded jobs: ``n`` rows of ``n_total``
+        (the three per-sample vectors are gathered on the device, the weights formed redundantly on every rank)."""
         theta, prior_theta = _f64(theta), _f64(prior_theta)
         self._check(self._lib.vb_dis_refresh_mvt(
-            self._ctx, slot, n, d, n, float(df), _dptr(theta), None, None, None, _dptr(prior_theta), float(eps_prev),
-            float(ess_target), int(max_bisection_its), None, None, None, None, None))
+            self._ctx, slot, n, d, n if n_total is None else n_total, float(df), _dptr(theta), None, None, None,
+            _dptr(prior_theta), float(eps_prev), float(ess_target), int(max_bisection_its), None, None, None, None, None))
 
-    def elbo_grad_mvt_symroot(self, slot, n, d, df, theta, path_deriv=False):
+    def elbo_grad_mvt_symroot(self, slot, n, d, df, theta, path_deriv=False, n_total=None):
         """``(value, grad)`` of the t family's ExclusiveKL in the reference-identical mode, resident on the device
         (``vb_elbo_grad_mvt_symroot`` / ``_path``: symmetric root and its Frechet derivative by device iterations), or None
         when an iteration did not resolve (take the host route)."""
@@ -715,37 +717,40 @@ class Engine:
         grad = np.empty(d + d * (d + 1) // 2, dtype=np.float64)
         info = np.zeros(4, dtype=np.float64)
         fn = self._lib.vb_elbo_grad_mvt_symroot_path if path_deriv else self._lib.vb_elbo_grad_mvt_symroot
-        rc = fn(self._ctx, slot, n, d, float(df), _dptr(theta), ctypes.byref(value), _dptr(grad), _dptr(info))
+        rc = fn(self._ctx, slot, n, d, n if n_total is None else n_total, float(df), _dptr(theta), ctypes.byref(value),
+                _dptr(grad), _dptr(info))
         if rc == VB_ERR_UNSUPPORTED:
             return None
         self._check(rc)
         self.last_root_info = info
         return value.value, grad
 
-    def alpha_grad_mvt_symroot(self, slot, n, d, df, alpha, theta):
+    def alpha_grad_mvt_symroot(self, slot, n, d, df, alpha, theta, n_total=None):
         """``(value, grad)`` of the t family's AlphaDivergence in the reference-identical mode, resident on the device
         (``vb_alpha_grad_mvt_symroot``), or None when a root iteration did not resolve (take the host route)."""
         theta = _f64(theta)
         value = ctypes.c_double(0.0)
         grad = np.empty(d + d * (d + 1) // 2, dtype=np.float64)
         info = np.zeros(4, dtype=np.float64)
-        rc = self._lib.vb_alpha_grad_mvt_symroot(self._ctx, slot, n, d, float(df), float(alpha), _dptr(theta),
-                                                 ctypes.byref(value), _dptr(grad), _dptr(info))
+        rc = self._lib.vb_alpha_grad_mvt_symroot(self._ctx, slot, n, d, n if n_total is None else n_total, float(df),
+                                                 float(alpha), _dptr(theta), ctypes.byref(value), _dptr(grad), _dptr(info))
         if rc == VB_ERR_UNSUPPORTED:
             return None
         self._check(rc)
         self.last_root_info = info
         return value.value, grad
 
-    def dis_refresh_mvt_symroot(self, slot, n, d, df, theta, prior_theta, eps_prev, ess_target, max_bisection_its=50):
+    def dis_refresh_mvt_symroot(self, slot, n, d, df, theta, prior_theta, eps_prev, ess_target, max_bisection_its=50,
+                                n_total=None):
         """The reference-identical refresh resident on the device (``vb_dis_refresh_mvt_symroot``): the noise in ``slot``
         and the context's chi-square draws are numpy's stream, the samples go through the symmetric root of ``Sigma``
         formed on the device.  Returns ``info = [steps, residual, accuracy]`` of the root, or None when the iteration did
         not resolve it (nothing was installed: take the host route)."""
         theta, prior_theta = _f64(theta), _f64(prior_theta)
         info = np.zeros(3, dtype=np.float64)
-        rc = self._lib.vb_dis_refresh_mvt_symroot(self._ctx, slot, n, d, float(df), _dptr(theta), _dptr(prior_theta),
-                                                  float(eps_prev), float(ess_target), int(max_bisection_its), _dptr(info))
+        rc = self._lib.vb_dis_refresh_mvt_symroot(self._ctx, slot, n, d, n if n_total is None else n_total, float(df),
+                                                  _dptr(theta), _dptr(prior_theta), float(eps_prev), float(ess_target),
+                                                  int(max_bisection_its), _dptr(info))
         if rc == VB_ERR_UNSUPPORTED:
             return None
         self._check(rc)

@@ -1320,10 +1320,11 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                        double* eps, double* ess, double* w, double* log_p, double* log_q) {
   if (!ctx || !theta || !prior_theta) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   // chi may be NULL: device draws (vb_chisq_generate); sqrt_sigma and l_inv both NULL: factors on the device;
-  // w NULL (throughput mode, one rank): device-resident step -- nothing is copied back and nothing waited for here,
-  // vb_dis_step_mvt_packed returns eps / ess with the gradient
-  if (!w && (chi || sqrt_sigma || l_inv || ctx->n_ranks != 1))
-    return fail(ctx, VB_ERR_INVALID, "w == NULL needs the throughput mode (chi, sqrt_sigma, l_inv NULL) on one rank");
+  // w NULL (throughput mode): device-resident step -- nothing is copied back and nothing waited for here,
+  // vb_dis_step_mvt_packed returns eps / ess with the gradient (sharded jobs: the three per-sample vectors are gathered
+  // on the device, the weights are formed redundantly on every rank)
+  if (!w && (chi || sqrt_sigma || l_inv))
+    return fail(ctx, VB_ERR_INVALID, "w == NULL needs the throughput mode (chi, sqrt_sigma, l_inv NULL)");
   if (w && (!eps || !ess)) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   VB_TRY(check_slot(ctx, slot));
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
@@ -1333,26 +1334,27 @@ int vb_dis_refresh_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_to
                          ess_target, max_bisection_its, eps, ess, w, log_p, log_q);
 }
 
-int vb_dis_refresh_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta,
+int vb_dis_refresh_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
                                const double* prior_theta, double eps_prev, double ess_target, int max_bisection_its,
                                double* root_info) {
   if (!ctx || !theta || !prior_theta) return fail(ctx, VB_ERR_INVALID, "NULL argument");
-  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident refresh: one rank");
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
   if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
   VB_TRY(check_slot(ctx, slot));
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
   if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
   VB_HIP(ctx, hipSetDevice(ctx->device));
-  const int rc = mvt_dis_refresh(ctx, ctx->noise[slot], n, n, d, df, theta, nullptr, nullptr, nullptr, prior_theta, eps_prev,
+  const int rc = mvt_dis_refresh(ctx, ctx->noise[slot], n, n_total, d, df, theta, nullptr, nullptr, nullptr, prior_theta, eps_prev,
                                  ess_target, max_bisection_its, nullptr, nullptr, nullptr, nullptr, nullptr, true, root_info);
   if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "matrix square root: not resolved on the device");
   return rc;
 }
 
-static int elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
-                                 double* grad, double* info, bool path_deriv) {
+static int elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
+                                 double* value, double* grad, double* info, bool path_deriv) {
   if (!ctx || !theta || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
   VB_TRY(check_slot(ctx, slot));
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
   if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
@@ -1361,7 +1363,7 @@ static int elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, do
   const size_t p = (size_t)(d + d * (d + 1) / 2);
   std::vector<double>& vg = ctx->mvt_stage;
   vg.resize(1 + p);
-  const int rc = mvt_elbo_symroot(ctx, ctx->noise[slot], n, d, df, theta, vg.data(), info, path_deriv);
+  const int rc = mvt_elbo_symroot(ctx, ctx->noise[slot], n, n_total, d, df, theta, vg.data(), info, path_deriv);
   if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "matrix square root: not resolved on the device");
   VB_TRY(rc);
   *value = vg[0];
@@ -1369,15 +1371,16 @@ static int elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, do
   return VB_OK;
 }
 
-int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
-                             double* grad, double* info) {
-  return elbo_grad_mvt_symroot(ctx, slot, n, d, df, theta, value, grad, info, false);
+int vb_elbo_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, const double* theta,
+                             double* value, double* grad, double* info) {
+  return elbo_grad_mvt_symroot(ctx, slot, n, d, n_total, df, theta, value, grad, info, false);
 }
 
-int vb_alpha_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, double alpha, const double* theta,
-                              double* value, double* grad, double* info) {
+int vb_alpha_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df, double alpha,
+                              const double* theta, double* value, double* grad, double* info) {
   if (!ctx || !theta || !value || !grad) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (!(df > 2.0)) return fail(ctx, VB_ERR_INVALID, "df must be greater than 2");
+  if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
   VB_TRY(check_slot(ctx, slot));
   if (ctx->model.id < 0) return fail(ctx, VB_ERR_STATE, "no model bound (vb_set_model)");
   if (!ctx->noise[slot].buf.ptr) return fail(ctx, VB_ERR_STATE, "noise slot %d is empty", slot);
@@ -1386,7 +1389,7 @@ int vb_alpha_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, doubl
   const size_t p = (size_t)(d + d * (d + 1) / 2);
   std::vector<double>& vg = ctx->mvt_stage;
   vg.resize(1 + p);
-  const int rc = mvt_alpha_symroot(ctx, ctx->noise[slot], n, d, df, alpha, theta, vg.data(), info);
+  const int rc = mvt_alpha_symroot(ctx, ctx->noise[slot], n, n_total, d, df, alpha, theta, vg.data(), info);
   if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "matrix square root: not resolved on the device");
   VB_TRY(rc);
   *value = vg[0];
@@ -1394,9 +1397,9 @@ int vb_alpha_grad_mvt_symroot(vb_ctx* ctx, int slot, int64_t n, int64_t d, doubl
   return VB_OK;
 }
 
-int vb_elbo_grad_mvt_symroot_path(vb_ctx* ctx, int slot, int64_t n, int64_t d, double df, const double* theta, double* value,
-                                  double* grad, double* info) {
-  return elbo_grad_mvt_symroot(ctx, slot, n, d, df, theta, value, grad, info, true);
+int vb_elbo_grad_mvt_symroot_path(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total, double df,
+                                  const double* theta, double* value, double* grad, double* info) {
+  return elbo_grad_mvt_symroot(ctx, slot, n, d, n_total, df, theta, value, grad, info, true);
 }
 
 int vb_dis_generation(vb_ctx* ctx, int kind, uint64_t* generation) {

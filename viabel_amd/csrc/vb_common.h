@@ -202,6 +202,10 @@ struct vb_ctx {
   vb::DeviceBuffer glm_work;            // regression targets: split-K slabs of the gradient GEMM
   vb::DeviceBuffer mvt_state;           // multivariate-t DIS: state samples X, scratch
   int64_t mvt_n = 0, mvt_d = 0, mvt_n_total = 0;
+  int64_t mvt_lq_off = 0;               // where this rank's log q of the residual pass start inside o_lq (the refresh writes them
+                                        // at the shard's offset of the gathered vector, a gradient at another parameter at 0)
+  vb::DeviceBuffer mvt_ekl_state;       // the resident ExclusiveKL / AlphaDivergence of the t family: factor algebra + sums (NOT the
+                                        // DIS state's buffer: an ELBO monitor beside a DIS fit must leave its samples alone)
   std::vector<double> mvt_theta;        // parameter the device-side residuals of the DIS state belong to
   bool mvt_dev_factors = false;         // ... and its factors (L, L', L^-1) were formed on the device
   const double* mvt_e_noise = nullptr;  // the residuals E' of that parameter are NOT stored: E'_n = noise_n / s_n (this matrix,
@@ -441,10 +445,10 @@ void vb_legacy_finish_pairs(const double* list, int64_t n, double* fixed);      
 // log density of the installed tempering prior (ctx->temper.kind != 0) at the rows of X
 int mvt_dis_clip_enqueue(vb_ctx* ctx, int64_t n_total, double threshold);
 int mvt_dis_scalars_get(vb_ctx* ctx, double out[4]);
-int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, const double* theta_host,
-                     double* value_grad_host, double* info, bool path_deriv = false);
-int mvt_alpha_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, double alpha, const double* theta_host,
-                      double* value_grad_host, double* info);
+int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df,
+                     const double* theta_host, double* value_grad_host, double* info, bool path_deriv = false);
+int mvt_alpha_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df, double alpha,
+                      const double* theta_host, double* value_grad_host, double* info);
 int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, int64_t ld, double* root, double tol,
                  double* info, double* inv_root = nullptr);      // vb_linalg.hip
 int sym_sqrt_frechet_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, const double* E, int64_t d, int64_t ld, double* X,

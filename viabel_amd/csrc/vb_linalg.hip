@@ -40,13 +40,14 @@ struct EpiStore {           // C = acc
   __device__ void operator()(int, int row, int col, double acc) const { C[(int64_t)row * ld + col] = acc; }
 };
 
-struct EpiResidual {        // returns (acc - A)^2 over the leading d x d block (R R - A)
+struct EpiResidual {        // returns (acc - A)^2 over the leading d x dc block (R R - A; dc = 0: d x d)
   const double* A;
   int64_t ld;
   int d;
   double* part;
+  int dc = 0;
   __device__ double operator()(int, int row, int col, double acc) const {
-    if (row >= d || col >= d) return 0.0;
+    if (row >= d || col >= (dc ? dc : d)) return 0.0;
     const double r = acc - A[(int64_t)row * ld + col];
     return r * r;
   }
@@ -258,11 +259,11 @@ __global__ void __launch_bounds__(256) ns_finish_kernel(const double* __restrict
 
 // The coupled Newton-Schulz iteration on an m x m problem whose start (Y = M / c in set[0], Z = I in set[0] + 2 mat) and
 // reference M0 = M / c are on the device (m x ld, ld = round_up(m, 16)).  Returns the set holding the result in *cur_out;
-// info = [steps, last residual, ||Y Y - M0||_F over the leading d_check x d_check block].  VB_ERR_UNSUPPORTED: no
+// info = [steps, last residual, ||Y Y - M0||_F over the leading d_check x d_cols block].  VB_ERR_UNSUPPORTED: no
 // convergence.  Pinned partial-sum ring: the caller has called ensure_pinned for (kNsMaxSteps + 2) * n_part doubles.
 constexpr int kNsMaxSteps = 40;
 static int ns_run(vb_ctx* ctx, int m, int64_t ld, double* set0, double* set1, const double* M0, int d_check, int* cur_out,
-                  double* info) {
+                  double* info, int d_cols = 0) {
   const int64_t mat = (int64_t)m * ld;
   const int n_cu = ctx->prop.multiProcessorCount;
   const int64_t n_part = round_up(gemm_max_blocks(m, m), 16);
@@ -308,7 +309,7 @@ static int ns_run(vb_ctx* ctx, int m, int64_t ld, double* set0, double* set1, co
   }
   if (!converged) return VB_ERR_UNSUPPORTED;
   double* Y = set[cur];
-  gemm_f64_launch<true>(st, square(Y, Y, ld, m), 1, n_cu, EpiResidual{M0, ld, d_check, ctx->pin_dev + (int64_t)kNsMaxSteps * n_part});
+  gemm_f64_launch<true>(st, square(Y, Y, ld, m), 1, n_cu, EpiResidual{M0, ld, d_check, ctx->pin_dev + (int64_t)kNsMaxSteps * n_part, d_cols});
   VB_HIP(ctx, hipGetLastError());
   *cur_out = cur;
   info[0] = (double)done, info[1] = res, info[2] = -1.0;      // [2]: read by the caller after its own last launch + sync
@@ -439,7 +440,10 @@ int sym_sqrt_frechet_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, con
   VB_HIP(ctx, hipGetLastError());
   int cur = 0;
   double loc[3];
-  VB_TRY(ns_run(ctx, m, ld2, base, base + 3 * mat, M0, (int)d, &cur, loc));
+  // the safety net covers the block that CARRIES the derivative too: rows [0, d) x columns [0, 2 d) of
+  // Y Y - M0, i.e. R R - Sigma and (es / c) (R X + X R - E) -- the latter relative to an off-diagonal block scaled to a tenth
+  // of the diagonal blocks' norm; an ill-conditioned Sigma whose X has not converged hands the call to the host route
+  VB_TRY(ns_run(ctx, m, ld2, base, base + 3 * mat, M0, (int)d, &cur, loc, m));
   hipLaunchKernelGGL(ns_block_finish_kernel, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, st,
                      (const double*)(base + (int64_t)cur * 3 * mat), (int)d, ld, ld2, (const double*)scal, X);
   VB_HIP(ctx, hipGetLastError());

@@ -807,6 +807,16 @@ __global__ void __launch_bounds__(256) mvt_counts_kernel(const int* __restrict__
   if (i < n) w[i] = (double)counts[i];
 }
 
+// The context's chi-square draws of this rank's rows: `n` of them (vb_chisq_generate with the shard's row offset) or all
+// n_total of numpy's stream (vb_legacy_rng_chisquare_device draws the whole vector on every rank -- the generator must end
+// where numpy's does), of which the shard's block is taken.  nullptr: neither.
+static const double* mvt_chi_rows(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t mine, double df) {
+  if (!ctx->chi_dev.ptr || ctx->chi_df != df) return nullptr;
+  if (ctx->chi_n == n) return (const double*)ctx->chi_dev.ptr;
+  if (ctx->chi_n == n_total) return (const double*)ctx->chi_dev.ptr + mine;
+  return nullptr;
+}
+
 int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df,
                     const double* theta_host,
                     const double* chi_host, const double* root_host, const double* linv_host,
@@ -834,11 +844,12 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   // the context's chi-square draws (vb_chisq_generate / vb_legacy_rng_chisquare_device) become row scales in the factor
   // kernel's own launch
   const bool chi_dev_rows = !chi_host && df != 0.0;
-  if (chi_dev_rows && (ctx->chi_n != n || ctx->chi_df != df))
-    return fail(ctx, VB_ERR_STATE, "chi == NULL needs %lld device chi-square(%g) draws (vb_chisq_generate)", (long long)n, df);
+  const double* chi_rows = chi_dev_rows ? mvt_chi_rows(ctx, n, n_total, mine, df) : nullptr;
+  if (chi_dev_rows && !chi_rows)
+    return fail(ctx, VB_ERR_STATE, "chi == NULL needs %lld (or all %lld) device chi-square(%g) draws (vb_chisq_generate)",
+                (long long)n, (long long)n_total, df);
   if (dev_factors) {      // throughput mode: mu, L', L^-1 from theta on the device; the samples go through L' (see header)
-    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true, chi_dev_rows ? (const double*)ctx->chi_dev.ptr : nullptr, df, n,
-                              ctx->n_ranks == 1));
+    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true, chi_rows, df, n, true));
     // reference-identical sampling (approximations.py:348): x = mu + (z Sigma^(1/2)) / s with the SYMMETRIC root, formed
     // on the device from the unpacked factor (VB_ERR_UNSUPPORTED: not resolved to 1e-12 -- the caller's LAPACK route)
     if (sym_root) {
@@ -860,8 +871,8 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
       inv_s[i] = df > 0.0 ? 1.0 / sqrt(chi_host[i] / df) : 1.0;                       // approximations.py:345
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_invs, inv_s.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
   } else if (!dev_factors) {   // the draws of vb_chisq_generate, already on the device (dev_factors: done by the factor kernel)
-    hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                       (const double*)ctx->chi_dev.ptr, df, n, base + L.o_invs);
+    hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, chi_rows, df, n,
+                       base + L.o_invs);
     VB_HIP(ctx, hipGetLastError());
   }
   std::vector<double> pr((size_t)2 * L.ld, 0.0);
@@ -932,6 +943,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     ctx->mvt_n = n;
     ctx->mvt_d = d;
     ctx->mvt_n_total = n_total;
+    ctx->mvt_lq_off = mine;
     ++ctx->dis_gen[1];
     ctx->mvt_theta.assign(theta_host, theta_host + d + d * (d + 1) / 2);
     return VB_OK;
@@ -946,6 +958,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   ctx->mvt_n = n;
   ctx->mvt_d = d;
   ctx->mvt_n_total = n_total;
+  ctx->mvt_lq_off = mine;
   ++ctx->dis_gen[1];
   ctx->mvt_theta.assign(theta_host, theta_host + d + d * (d + 1) / 2);   // the residuals on the device belong to it
   if ((int)(res[2]) == 3) return fail(ctx, VB_ERR_STATE, "tempering bisection: a workgroup of the resident kernel did not arrive at a grid barrier (results invalid); VB_DIS_RESIDENT=0 selects the launch chain");
@@ -1005,7 +1018,8 @@ __global__ void __launch_bounds__(256) mvt_psis_apply_kernel(const double* __res
 int mvt_dis_psis_enqueue(vb_ctx* ctx, int64_t n_total, double reff) {
   if (!ctx->mvt_state.ptr || ctx->mvt_n_total != n_total || n_total <= 1)
     return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state with %lld samples", (long long)n_total);
-  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident weights: one rank only");
+  // (sharded jobs: the weight vector covers all n_total samples on every rank -- the smoothing runs redundantly, the same
+  // kernels on the same bits)
   const MvtLayout L = mvt_layout(ctx, ctx->mvt_n, ctx->mvt_n_total, ctx->mvt_d);
   double* base = (double*)ctx->mvt_state.ptr;
   hipStream_t st = ctx->stream;
@@ -1087,7 +1101,6 @@ __global__ void __launch_bounds__(1024) dis_clip_kernel(double* __restrict__ w, 
 int mvt_dis_clip_enqueue(vb_ctx* ctx, int64_t n_total, double threshold) {
   if (!ctx->mvt_state.ptr || ctx->mvt_n_total != n_total || n_total <= 0)
     return fail(ctx, VB_ERR_STATE, "no multivariate-t DIS state with %lld samples", (long long)n_total);
-  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident weights: one rank only");
   if (!(threshold > 0.0)) return fail(ctx, VB_ERR_INVALID, "clipping threshold must be positive");
   const MvtLayout L = mvt_layout(ctx, ctx->mvt_n, ctx->mvt_n_total, ctx->mvt_d);
   double* base = (double*)ctx->mvt_state.ptr;
@@ -1149,27 +1162,35 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   double* base = (double*)ctx->mvt_state.ptr;
   hipStream_t st = ctx->stream;
   const int n_cu = ctx->prop.multiProcessorCount;
-  const double* wdev = base + L.o_w;
+  // this rank's rows inside the whole-job vectors (weights, counts): shard_rows
+  int64_t mine = 0;
+  VB_TRY(comm_shard_begin(ctx, n, ctx->mvt_n_total, &mine));
+  const int64_t n_all = ctx->mvt_n_total;
+  const double* wdev = base + L.o_w + mine;
   const double* scale_dev = nullptr;
   if (w_host) {
-    VB_HIP(ctx, hipMemcpyAsync(base + L.o_w, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    // the caller's weights of THIS rank's rows (resampling counts of a host draw, or weights it smoothed / clipped itself)
+    // go into the count area: the resident tempered weights of the refresh stay what they are
+    VB_HIP(ctx, hipMemcpyAsync(base + L.o_wres, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
     VB_HIP(ctx, hipStreamSynchronize(st));
+    wdev = base + L.o_wres;
   } else {
-    if (!packed_out || ctx->n_ranks != 1)
-      return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident weights: packed gradient on one rank only");
+    if (!packed_out) return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident weights: packed gradient only");
     if (resample_m > 0) {
+      // the multinomial draw over ALL n_total weights, redundantly on every rank of a sharded job (counter-based
+      // uniforms, integer counts: the same counts everywhere); each rank then weights its own rows with its block
       int* counts = (int*)(base + L.o_cnt);
-      if ((n + kCdfChunk - 1) / kCdfChunk > kCdfMaxChunks)
+      if ((n_all + kCdfChunk - 1) / kCdfChunk > kCdfMaxChunks)
         return fail(ctx, VB_ERR_UNSUPPORTED, "device multinomial draw: at most %d weights", kCdfChunk * kCdfMaxChunks);
-      hipLaunchKernelGGL(mvt_cdf_kernel, dim3((unsigned)((n + kCdfChunk - 1) / kCdfChunk)), dim3(kCdfChunk), 0, st,
-                         (const double*)(base + L.o_w), n, base + L.o_cdf, base + L.o_cdf + L.nn + 16, counts);
+      hipLaunchKernelGGL(mvt_cdf_kernel, dim3((unsigned)((n_all + kCdfChunk - 1) / kCdfChunk)), dim3(kCdfChunk), 0, st,
+                         (const double*)(base + L.o_w), n_all, base + L.o_cdf, base + L.o_cdf + L.nn + 16, counts);
       hipLaunchKernelGGL(mvt_draw_kernel, dim3((unsigned)((resample_m + 255) / 256)), dim3(256), 0, st,
-                         (const double*)(base + L.o_cdf), (const double*)(base + L.o_cdf + L.nn + 16), base + L.o_cdf + L.nn, n,
+                         (const double*)(base + L.o_cdf), (const double*)(base + L.o_cdf + L.nn + 16), base + L.o_cdf + L.nn, n_all,
                          resample_m, seed, stream, counts);
-      hipLaunchKernelGGL(mvt_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int*)counts, n,
+      hipLaunchKernelGGL(mvt_counts_kernel, dim3((unsigned)((n_all + 255) / 256)), dim3(256), 0, st, (const int*)counts, n_all,
                          base + L.o_wres);
       VB_HIP(ctx, hipGetLastError());
-      wdev = base + L.o_wres;
+      wdev = base + L.o_wres + mine;
       scale_dev = base + L.o_cdf + L.nn;
     }
   }
@@ -1178,10 +1199,10 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     // the last residual pass: a gradient at that same parameter (the call that follows a refresh when
     // num_resampling_batches = 1) reuses them instead of repeating the N x D x D product and its uploads
     const size_t p = (size_t)(d + d * (d + 1) / 2);
-    const bool same = ctx->n_ranks == 1 && ctx->mvt_theta.size() == p &&
-                      memcmp(ctx->mvt_theta.data(), theta_host, p * sizeof(double)) == 0;
+    const bool same = ctx->mvt_theta.size() == p && memcmp(ctx->mvt_theta.data(), theta_host, p * sizeof(double)) == 0;
     if (!same) {
       VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, 0));
+      ctx->mvt_lq_off = 0;      // (this rank's log q now start the vector; the gathered copy of the refresh is in o_lqcopy)
       ctx->mvt_theta.assign(theta_host, theta_host + p);
       ctx->mvt_dev_factors = linv_host == nullptr;
     } else if (packed_out && !ctx->mvt_dev_factors) {
@@ -1189,6 +1210,7 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
       ctx->mvt_dev_factors = true;
     }
   }
+  const double* lq_rows = base + L.o_lq + ctx->mvt_lq_off;      // log q of this rank's rows at theta_host
   FrSums S = L.S;
   S.sums = base + L.o_sums;
   const int64_t n_part = (n + 3) / 4;
@@ -1210,7 +1232,7 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     const double* rs = noise_rows ? (const double*)(base + L.o_invs) : nullptr;
     double* wpart = base + L.o_part + n;      // 2 n_rb doubles: the scale pass's (sum w, sum w log q) per row block
     hipLaunchKernelGGL(mvt_scale_colsum_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)L.n_rb), dim3(256), 0, st, Y, L.ld, n,
-                       (int)d, wdev, cn, rs, base + L.o_ua, base + L.o_col, (const double*)(base + L.o_lq), wpart);
+                       (int)d, wdev, cn, rs, base + L.o_ua, base + L.o_col, lq_rows, wpart);
     VB_HIP(ctx, hipGetLastError());
     VB_TRY(gram_lower_enqueue(ctx, base + L.o_ua, Y, L.ld, (int)d, n, L.splits, base + L.o_cpart, L.ld, slab));
     VB_TRY(fr_reduce_enqueue(ctx, base + L.o_cpart, L.splits, slab, (int)d, L.ld, base + L.o_col, L.n_rb, L.ld, fpart, 0, S,
@@ -1228,7 +1250,7 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   g.tri_mode = 3;          // L^-1 is lower triangular: B[k][j] == 0 for k < j -- half the product
   // (sum w, sum w log q) ride in slots 1 and 2 of the sum vector so that one all-reduce covers everything; U and its
   // row-scaled copy a_n U (a_n = w_n c_n, c_n left behind by the residual pass) leave the GEMM together
-  hipLaunchKernelGGL(mvt_wsums_kernel, dim3(1), dim3(1024), 0, st, wdev, (const double*)(base + L.o_lq), n, S.sums + 1);
+  hipLaunchKernelGGL(mvt_wsums_kernel, dim3(1), dim3(1024), 0, st, wdev, lq_rows, n, S.sums + 1);
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiStoreScaled{base + L.o_u, base + L.o_ua, L.ld, wdev, cn,
                                                        noise_rows ? (const double*)(base + L.o_invs) : nullptr});
   VB_HIP(ctx, hipGetLastError());
@@ -1432,7 +1454,7 @@ int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_
 }
 
 // ---- the reference-identical ExclusiveKL of the multivariate t, resident on the device ------------------------------------
-// (objectives.py:154-164 over approximations.py:342-349, rng='numpy', one rank.)  The noise slot and the context's
+// (objectives.py:154-164 over approximations.py:342-349, rng='numpy'.)  The noise slot and the context's
 // chi-square draws hold numpy's streams (vb_legacy_rng_chisquare_device, _randn_device); mu, L, L' come from theta on the
 // device; the symmetric root R of Sigma = L L' by sym_sqrt_dev; the sample sums F, sum g, C = sum g (z / s)' by the
 // dense-family pipeline; then the chain rule the host used to run in numpy:
@@ -1513,30 +1535,34 @@ struct EpiAddTo {           // C += acc
   }
 };
 
-int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, const double* theta_host,
-                     double* value_grad_host, double* info, bool path_deriv) {
-  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "resident ExclusiveKL of the t family: one rank");
+int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df,
+                     const double* theta_host, double* value_grad_host, double* info, bool path_deriv) {
+  // Sharded jobs (round 6): this rank's rows of numpy's streams, the sample sums all-reduced inside fr_pipeline_enqueue /
+  // mvt_path_terms_enqueue, everything of order D^3 -- both Newton-Schulz iterations, the chain rule -- redundantly on
+  // every rank from the same bits.
+  int64_t mine = 0;
+  VB_TRY(comm_shard_begin(ctx, n, n_total, &mine));
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
-  if (ctx->chi_n != n || ctx->chi_df != df || !ctx->chi_dev.ptr)
-    return fail(ctx, VB_ERR_STATE, "needs %lld device chi-square(%g) draws (vb_legacy_rng_chisquare_device)", (long long)n, df);
-  const MvtLayout L = mvt_layout(ctx, n, n, d);
-  VB_TRY(ensure(ctx, ctx->mvt_state, (size_t)L.total * sizeof(double)));
-  double* base = (double*)ctx->mvt_state.ptr;
+  const double* chi_rows = mvt_chi_rows(ctx, n, n_total, mine, df);
+  if (!chi_rows)
+    return fail(ctx, VB_ERR_STATE, "needs %lld (or all %lld) device chi-square(%g) draws (vb_legacy_rng_chisquare_device)",
+                (long long)n, (long long)n_total, df);
+  // (a buffer of its own: the DIS state of ctx->mvt_state -- an interleaved DISInclusiveKL's samples -- is left alone)
+  const MvtLayout L = mvt_layout(ctx, n, n_total, d);
+  VB_TRY(ensure(ctx, ctx->mvt_ekl_state, (size_t)L.total * sizeof(double)));
+  double* base = (double*)ctx->mvt_ekl_state.ptr;
   hipStream_t st = ctx->stream;
   const int n_cu = ctx->prop.multiProcessorCount;
   const int D = (int)d;
   const int64_t sq = d * L.ld;
-  ctx->mvt_theta.clear();      // (the DIS state of this buffer, if any, is gone)
-  ctx->mvt_n = 0;
   VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
   double rinfo[3] = {0.0, 0.0, 0.0};
   // (the inverse root, when asked for, lands in the slot of L^-1, which this path does not read)
   VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, rinfo,
                       path_deriv ? base + L.o_li : (double*)nullptr));
-  hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ctx->chi_dev.ptr,
-                     df, n, base + L.o_invs);
+  hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, chi_rows, df, n, base + L.o_invs);
   FrSums S;
-  VB_TRY(fr_pipeline_enqueue(ctx, ns, n, d, n, nullptr, nullptr, base + L.o_mu, base + L.o_root, base + L.o_invs, &S));
+  VB_TRY(fr_pipeline_enqueue(ctx, ns, n, d, n_total, nullptr, nullptr, base + L.o_mu, base + L.o_root, base + L.o_invs, &S));
   FrSums P;
   P.sums = nullptr;
   if (path_deriv) {
@@ -1550,7 +1576,7 @@ int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, dou
     VB_HIP(ctx, hipGetLastError());
   }
   hipLaunchKernelGGL(mvt_gs_kernel, dim3((unsigned)((sq + 255) / 256)), dim3(256), 0, st, (const double*)(S.sums + S.off_c),
-                     base + L.o_tscr, D, L.ld, 0.5 / (double)n);
+                     base + L.o_tscr, D, L.ld, 0.5 / (double)n_total);
   VB_HIP(ctx, hipGetLastError());
   double xinfo[3] = {0.0, 0.0, 0.0};
   VB_TRY(sym_sqrt_frechet_dev(ctx, base + L.o_lfull, base + L.o_lt, base + L.o_tscr, d, L.ld, base + L.o_sl, 1e-12, xinfo));
@@ -1560,7 +1586,7 @@ int mvt_elbo_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, dou
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{base + L.o_tscr, L.ld});
   hipLaunchKernelGGL(mvt_ekl_pack_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
                      (const double*)(base + L.o_tscr), (const double*)(base + L.o_lfull), (const double*)(base + L.o_theta), L.ld, D,
-                     (const double*)S.sums, S.off_col, 1.0 / (double)n, ctx->model.c0, base + L.o_grad,
+                     (const double*)S.sums, S.off_col, 1.0 / (double)n_total, ctx->model.c0, base + L.o_grad,
                      path_deriv ? (const double*)P.sums : (const double*)nullptr,
                      lgamma(0.5 * (df + (double)d)) - lgamma(0.5 * df) - 0.5 * (double)d * log(M_PI * df), 0.5 * (df + (double)d));
   VB_HIP(ctx, hipGetLastError());
@@ -1595,31 +1621,31 @@ __global__ void __launch_bounds__(256) mvt_alpha_pack_kernel(const double* __res
 
 }  // namespace
 
-int mvt_alpha_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, double df, double alpha, const double* theta_host,
-                      double* value_grad_host, double* info) {
-  if (ctx->n_ranks != 1) return fail(ctx, VB_ERR_UNSUPPORTED, "resident AlphaDivergence of the t family: one rank");
+int mvt_alpha_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total, int64_t d, double df, double alpha,
+                      const double* theta_host, double* value_grad_host, double* info) {
+  int64_t mine = 0;      // (sharded jobs as mvt_elbo_symroot: alpha_mvt_enqueue all-reduces the maximum and the weighted sums)
+  VB_TRY(comm_shard_begin(ctx, n, n_total, &mine));
   if (n <= 0 || n > ns.n || d != ns.d) return fail(ctx, VB_ERR_INVALID, "noise slot shape mismatch");
-  if (ctx->chi_n != n || ctx->chi_df != df || !ctx->chi_dev.ptr)
-    return fail(ctx, VB_ERR_STATE, "needs %lld device chi-square(%g) draws (vb_legacy_rng_chisquare_device)", (long long)n, df);
-  const MvtLayout L = mvt_layout(ctx, n, n, d);
-  VB_TRY(ensure(ctx, ctx->mvt_state, (size_t)L.total * sizeof(double)));
-  double* base = (double*)ctx->mvt_state.ptr;
+  const double* chi_rows = mvt_chi_rows(ctx, n, n_total, mine, df);
+  if (!chi_rows)
+    return fail(ctx, VB_ERR_STATE, "needs %lld (or all %lld) device chi-square(%g) draws (vb_legacy_rng_chisquare_device)",
+                (long long)n, (long long)n_total, df);
+  const MvtLayout L = mvt_layout(ctx, n, n_total, d);
+  VB_TRY(ensure(ctx, ctx->mvt_ekl_state, (size_t)L.total * sizeof(double)));
+  double* base = (double*)ctx->mvt_ekl_state.ptr;
   hipStream_t st = ctx->stream;
   const int n_cu = ctx->prop.multiProcessorCount;
   const int D = (int)d;
   const int64_t sq = d * L.ld;
-  ctx->mvt_theta.clear();      // (the DIS state of this buffer, if any, is gone)
-  ctx->mvt_n = 0;
   VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
   double rinfo[3] = {0.0, 0.0, 0.0};
   VB_TRY(sym_sqrt_dev(ctx, base + L.o_lfull, base + L.o_lt, d, L.ld, base + L.o_root, 1e-12, rinfo));
-  hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ctx->chi_dev.ptr,
-                     df, n, base + L.o_invs);
+  hipLaunchKernelGGL(mvt_inv_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, chi_rows, df, n, base + L.o_invs);
   double sum_log_diag = 0.0;
   for (int64_t j = 0; j < d; ++j) sum_log_diag += theta_host[d + j * (j + 1) / 2 + j];
   FrSums S;
   const double* vw = nullptr;
-  VB_TRY(alpha_mvt_enqueue(ctx, ns, n, n, d, df, alpha, base + L.o_mu, base + L.o_root, base + L.o_invs, sum_log_diag, &S, &vw));
+  VB_TRY(alpha_mvt_enqueue(ctx, ns, n, n_total, d, df, alpha, base + L.o_mu, base + L.o_root, base + L.o_invs, sum_log_diag, &S, &vw));
   hipLaunchKernelGGL(mvt_gs_kernel, dim3((unsigned)((sq + 255) / 256)), dim3(256), 0, st, (const double*)(S.sums + S.off_c),
                      base + L.o_tscr, D, L.ld, 0.5);
   VB_HIP(ctx, hipGetLastError());
@@ -1631,7 +1657,7 @@ int mvt_alpha_symroot(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, do
   gemm_f64_launch<true>(st, g, 1, n_cu, EpiStore{base + L.o_tscr, L.ld});
   hipLaunchKernelGGL(mvt_alpha_pack_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256)), dim3(256), 0, st,
                      (const double*)(base + L.o_tscr), (const double*)(base + L.o_lfull), L.ld, D, (const double*)S.sums,
-                     S.off_col, vw, alpha / (double)n, base + L.o_grad);
+                     S.off_col, vw, alpha / (double)n_total, base + L.o_grad);
   VB_HIP(ctx, hipGetLastError());
   const size_t plen = (size_t)(1 + d + d * (d + 1) / 2);
   const FetchSeg seg{base + L.o_grad, plen * sizeof(double), value_grad_host};

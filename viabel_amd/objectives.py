@@ -577,15 +577,17 @@ class ExclusiveKL(StochasticVariationalObjective):
                                    row_offset=begin)
             else:
                 # chi-square draws first (approximations.py:345-347)
-                want_resident = eng.n_ranks == 1 and D > _RESIDENT_GATE
+                want_resident = D > _RESIDENT_GATE
                 chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, host_chi=not want_resident,
                                                device_chi=want_resident and D >= _RESIDENT_SMALL_N_MIN_DIM)
                 if want_resident and getattr(approx, '_chi_on_device', False):
                     # the whole evaluation resident on the device: both noise streams are there already, the symmetric
                     # root and its Frechet derivative are device iterations, the chain rule to the free Cholesky
-                    # parameters two more kernels (vb_elbo_grad_mvt_symroot); None: an iteration did not resolve
-                    _claim_engine_state(eng, 1, None)      # (the call reuses the DIS state's buffers)
-                    resident = eng.elbo_grad_mvt_symroot(_NOISE_SLOT, N, D, df, var_param, path_deriv=path_deriv)
+                    # parameters two more kernels (vb_elbo_grad_mvt_symroot; a buffer of its own -- an interleaved DIS
+                    # objective's state samples are left alone; sharded jobs: the sample sums all-reduced on the
+                    # device, the O(D^3) algebra redundantly on every rank); None: an iteration did not resolve
+                    resident = eng.elbo_grad_mvt_symroot(_NOISE_SLOT, end - begin, D, df, var_param, path_deriv=path_deriv,
+                                                         n_total=N)
                     if resident is not None:
                         return resident
                     chi = eng.chisq_get_host(N)          # the host route after all: the draws come down
@@ -1064,15 +1066,18 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 if not memo:
                     memo.append(factors(var_param))
                 return memo[0]
-            # ... and on one rank the weights never leave the device either -- Pareto smoothing (vb_dis_psis_mvt) and, for
-            # a clipping threshold below 1 (objectives.py:370-386; the identity otherwise, the default is 10), the
-            # clipping (vb_dis_clip_mvt) included
+            # ... and the weights never leave the device either -- Pareto smoothing (vb_dis_psis_mvt) and, for a clipping
+            # threshold below 1 (objectives.py:370-386; the identity otherwise, the default is 10), the clipping
+            # (vb_dis_clip_mvt) included.  Sharded jobs (round 6): every rank samples and scores its own
+            # rows, [log p | log q | log prior] are all-gathered ON THE DEVICE, bisection / smoothing / clipping / the
+            # multinomial draw run redundantly on the whole vectors on every rank, each rank forms the weighted sums of
+            # its rows, one all-reduce, and the D^3 chain rule redundantly again: the same bits on every rank
             refresh_now = not self._use_resampling or self._objective_step % self._num_resampling_batches == 0
             # The reference-identical mode of the t family (rng='numpy') is resident on the device as well where the
             # symmetric root is the device's job anyway: numpy's chi-square and normal streams are generated there bit for
             # bit, the root of approximations.py:348 by vb_dis_refresh_mvt_symroot
-            sym_try = not philox and not gaussian and eng.n_ranks == 1 and D > _RESIDENT_GATE
-            resident = (philox and eng.n_ranks == 1) or (not refresh_now and getattr(self, '_sym_resident', False))
+            sym_try = not philox and not gaussian and D > _RESIDENT_GATE
+            resident = philox or (not refresh_now and getattr(self, '_sym_resident', False))
             clip = self._w_clip_threshold < 1.0
             if refresh_now:
                 self._claim_state(eng, 1)
@@ -1086,7 +1091,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                         root = None
                         if resident:     # as the t family below: df = 0 is the Gaussian member of the same kernels
                             eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._prior_arg,
-                                                         self._eps, self._ess_target, self._max_bisection_its)
+                                                         self._eps, self._ess_target, self._max_bisection_its, n_total=N)
                             if self._psis_smooth:
                                 eng.dis_psis_mvt(N)
                             if clip:
@@ -1096,23 +1101,20 @@ class DISInclusiveKL(StochasticVariationalObjective):
                             self._own_state(eng, 1, True)
                     else:
                         approx._stage_base_noise(eng, slot, N, begin, end)
-                        if eng.n_ranks == 1:
-                            # the dense Gaussian samples through L itself (x = mu + eps L'): with the family's own normal
-                            # stream in the slot this IS the device's factor path -- resident like the throughput mode
-                            # (the reference's resampling draw, when asked for, on the fetched weights as for the t family)
-                            root = None
-                            resident = self._sym_resident = True
-                            eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._prior_arg,
-                                                         self._eps, self._ess_target, self._max_bisection_its)
-                            if self._psis_smooth:
-                                eng.dis_psis_mvt(N)
-                            if clip:
-                                eng.dis_clip_mvt(N, self._w_clip_threshold)
-                            self._set_state_logs(None, None, lambda: eng.dis_state_get(True, N))
-                            self._set_state_weights(None, lambda: eng.dis_weights_get(N))
-                            self._own_state(eng, 1, True)
-                        else:
-                            root = np.ascontiguousarray(host_factors()[0].T)        # x = mu + eps L'
+                        # the dense Gaussian samples through L itself (x = mu + eps L'): with the family's own normal
+                        # stream in the slot this IS the device's factor path -- resident like the throughput mode
+                        # (the reference's resampling draw, when asked for, on the fetched weights as for the t family)
+                        root = None
+                        resident = self._sym_resident = True
+                        eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._prior_arg,
+                                                     self._eps, self._ess_target, self._max_bisection_its, n_total=N)
+                        if self._psis_smooth:
+                            eng.dis_psis_mvt(N)
+                        if clip:
+                            eng.dis_clip_mvt(N, self._w_clip_threshold)
+                        self._set_state_logs(None, None, lambda: eng.dis_state_get(True, N))
+                        self._set_state_weights(None, lambda: eng.dis_weights_get(N))
+                        self._own_state(eng, 1, True)
                 elif philox:
                     # throughput mode: chi-square draws and normals on the GPU, and x = mu + (z L') / s with the
                     # Cholesky factor instead of the reference's symmetric root (approximations.py:348).  The samples
@@ -1128,7 +1130,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                         # device-resident step: the refresh only enqueues; weights, eps, ess stay on the device and
                         # come back (eps, ess) with the gradient after one synchronisation
                         eng.dis_refresh_mvt_deferred(slot, n_local, D, df, var_param, self._prior_arg, self._eps,
-                                                     self._ess_target, self._max_bisection_its)
+                                                     self._ess_target, self._max_bisection_its, n_total=N)
                         if self._psis_smooth:
                             eng.dis_psis_mvt(N)
                         if clip:
@@ -1142,8 +1144,8 @@ class DISInclusiveKL(StochasticVariationalObjective):
                                                    device_chi=sym_try and D >= _RESIDENT_SMALL_N_MIN_DIM)
                     if sym_try and getattr(approx, '_chi_on_device', False):
                         # the whole step on the device: the context holds numpy's chi-square draws, the slot its normals
-                        info = eng.dis_refresh_mvt_symroot(slot, N, D, df, var_param, self._prior_arg, self._eps,
-                                                           self._ess_target, self._max_bisection_its)
+                        info = eng.dis_refresh_mvt_symroot(slot, n_local, D, df, var_param, self._prior_arg, self._eps,
+                                                           self._ess_target, self._max_bisection_its, n_total=N)
                         if info is not None:
                             resident = self._sym_resident = True
                             if self._psis_smooth:
@@ -1184,7 +1186,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                             self._khat = khat
                     indices = _shared_choice(eng, N, self._resampling_batch_size, self._state_w_normalized)
                     weights = np.bincount(indices, minlength=N).astype(np.float64)
-                    return eng.dis_grad_mvt_packed(n_local, D, df, var_param, weights,
+                    return eng.dis_grad_mvt_packed(n_local, D, df, var_param, weights[begin:end],
                                                    self._state_w_sum / N / self._resampling_batch_size)
                 else:
                     # multinomial draw on the device from the family's Philox stream (objectives.py:408 draws from the
@@ -1330,14 +1332,14 @@ class AlphaDivergence(StochasticVariationalObjective):
                 return eng.alpha_grad_mvt_chol(_NOISE_SLOT, end - begin, D, df, var_param, alpha, n_total=N)
             else:
                 # chi-square draws first (approximations.py:345-347)
-                want_resident = eng.n_ranks == 1 and D > _RESIDENT_GATE
+                want_resident = D > _RESIDENT_GATE
                 chi = approx._stage_base_noise(eng, _NOISE_SLOT, N, begin, end, seed, host_chi=not want_resident,
                                                device_chi=want_resident and D >= _RESIDENT_SMALL_N_MIN_DIM)
                 if want_resident and getattr(approx, '_chi_on_device', False):
-                    # the whole evaluation resident on the device (vb_alpha_grad_mvt_symroot), as ExclusiveKL's; None: a
-                    # root iteration did not resolve
-                    _claim_engine_state(eng, 1, None)      # (the call reuses the DIS state's buffers)
-                    resident = eng.alpha_grad_mvt_symroot(_NOISE_SLOT, N, D, df, alpha, var_param)
+                    # the whole evaluation resident on the device (vb_alpha_grad_mvt_symroot), as ExclusiveKL's (its own
+                    # buffer; sharded jobs: maximum and weighted sums all-reduced on the device); None: a root
+                    # iteration did not resolve
+                    resident = eng.alpha_grad_mvt_symroot(_NOISE_SLOT, end - begin, D, df, alpha, var_param, n_total=N)
                     if resident is not None:
                         return resident
                     chi = eng.chisq_get_host(N)          # the host route after all: the draws come down
