@@ -119,7 +119,7 @@ int vb_chisq_get_host(vb_ctx* ctx, double* host, int64_t n);
  * call's noise be generated behind this call's last kernel, while the host waits and turns around.  The shadow is adopted
  * only by a request that matches it exactly; after a wrong hint the request generates as usual.  The hint is consumed by
  * the next blocking call of this context.                                                                              */
-int vb_noise_hint_seed(vb_ctx* ctx, unsigned slot_mask, int with_chi, uint64_t seed);
+int vb_noise_hint_seed(vb_ctx* ctx, uint64_t slot_mask /* bit s: noise slot s (VB_MAX_SLOTS = 64) */, int with_chi, uint64_t seed);
 /* How many look-ahead buffers (noise matrices and chi-square vectors) this context has generated and how many of them a
  * request adopted: an observability counter -- a caller whose hints or stream walks stop matching sees the ratio drop
  * (results never depend on it).                                                                                       */
@@ -554,8 +554,8 @@ int vb_comm_init_host(vb_ctx* ctx, vb_host_collective_fn fn, void* user, int n_r
 #define VB_IPC_HANDLE_BYTES 64
 int vb_comm_ipc_window(vb_ctx* ctx, size_t cap_doubles, char handle[VB_IPC_HANDLE_BYTES]);
 int vb_comm_init_ipc(vb_ctx* ctx, const char* handles, int n_ranks, int rank);
-/* VB_ERR_COMM when a device-side wait of the IPC transport gave up (a peer did not arrive within 2^VB_IPC_POLL_LOG2
- * polls, default 2^27: minutes) -- the affected results are NaN by construction; also checked by the next collective,
+/* VB_ERR_COMM when a device-side wait of the IPC transport gave up (a peer did not arrive within VB_IPC_TIMEOUT_S
+ * seconds of wall time, default 20; VB_IPC_POLL_LOG2 adds a poll-count bound) -- the affected results are NaN by construction; also checked by the next collective,
  * vb_sync and vb_fullrank_get.  VB_OK on every other transport.                                                     */
 int vb_comm_check(vb_ctx* ctx);
 /* Duration of the collective alone: `reps` back-to-back sum all-reduces of `count` doubles on the context's stream

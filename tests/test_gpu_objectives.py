@@ -995,3 +995,42 @@ def test_lazy_dis_state_survives_another_objective(vb):
         vb.ExclusiveKL(vb.MultivariateT(D, 9.0, seed=8), model, N)(theta)      # reuses the buffers (resident route)
         np.testing.assert_array_equal(b2._state_w_clipped, want_w)
         np.testing.assert_array_equal(b2._state_log_p_unnormalized, want_lp)
+
+
+@pytest.mark.parametrize('rng_kind', ['numpy', 'philox'])
+def test_resident_elbo_monitor_beside_a_dis_fit_with_kept_weights(vb, rng_kind):
+    """the resident ExclusiveKL / AlphaDivergence routes of the t family used the DIS state's buffer as scratch
+    without bumping its generation, so a DISInclusiveKL with num_resampling_batches > 1 on the same engine failed its
+    next kept-weights step with a bare 'no multivariate-t DIS state'.  They have a buffer of their own now: an ELBO /
+    alpha monitor evaluated between the steps leaves the fit's values and gradients exactly what they are without it."""
+    D, N = 64, 4096
+    rng = np.random.RandomState(23)
+    model = vb.GaussianModel(0.3 * rng.randn(D), np.exp(0.1 * rng.randn(D)))
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    A = rng.randn(D, D)
+    theta0 = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(A @ A.T / D + np.eye(D))])
+
+    def fit(monitor):
+        obj = vb.DISInclusiveKL(vb.MultivariateT(D, 9.0, seed=3, rng=rng_kind), model, N, ess_target=500,
+                                temper_prior=vb.MFGaussian(D), temper_prior_params=prior, use_resampling=True,
+                                num_resampling_batches=3)
+        elbo = vb.ExclusiveKL(vb.MultivariateT(D, 9.0, seed=8), model, N)
+        alpha = vb.AlphaDivergence(vb.MultivariateT(D, 9.0, seed=9), model, N, 0.5)
+        np.random.seed(5)
+        theta, out = theta0.copy(), []
+        for it in range(7):
+            state = np.random.get_state()
+            v, g = obj(theta)
+            if monitor:
+                after = np.random.get_state()
+                elbo(theta)
+                alpha(theta)
+                np.random.set_state(after)       # (the alpha monitor draws its seed from the global generator)
+            del state
+            out.append((v, g))
+            theta = theta - 0.01 * g / (1.0 + np.abs(g))
+        return out
+    plain, watched = fit(False), fit(True)
+    for (v0, g0), (v1, g1) in zip(plain, watched):
+        assert v0 == v1
+        np.testing.assert_array_equal(g0, g1)

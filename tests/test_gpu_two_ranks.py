@@ -92,3 +92,40 @@ def test_two_ranks_on_one_gpu_match_one_rank(tmp_path, transport):
           % (len(worst), ', '.join('%s %.1e' % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1])[:6])))
     assert len(worst) >= 44 and not bad, (bad, worst)
     assert sum(k.startswith('c3_') for k in worst) >= 11
+
+
+GIVE_UP_WORKER = '''
+import os, sys, time
+os.environ['VB_IPC_TIMEOUT_S'] = '1'
+sys.path.insert(0, %(root)r)
+from viabel_amd import _lib, distributed
+eng = _lib.Engine(0)
+group = distributed.SocketGroup.from_env(timeout=120.0)
+distributed.attach(eng, group, transport='ipc')
+group.barrier()
+if group.rank == 0:
+    t0 = time.time()
+    try:
+        eng.comm_allreduce_time(1024, warm=0, reps=1)      # the peer never joins this collective
+        raise SystemExit('the abandoned collective returned without an error')
+    except _lib.EngineError as e:
+        assert 'did not reach collective phase' in str(e) and 'VB_IPC_TIMEOUT_S' in str(e), str(e)
+    waited = time.time() - t0
+    assert 0.8 < waited < 10.0, waited      # seconds of wall time, not minutes of polls
+else:
+    time.sleep(3.0)
+group.barrier()
+print('{"rank": %%d, "done": true}' %% group.rank, flush=True)
+os._exit(0)       # (the communicator is poisoned by design: no orderly teardown of a collective that never completed)
+'''
+
+
+def test_ipc_wait_gives_up_after_wall_time_not_poll_counts(tmp_path):
+    """ADVICE r5: a peer that never arrives used to keep the spinning kernels resident for minutes (2^27 polls); the bound is
+    wall time now (VB_IPC_TIMEOUT_S), the give-up is reported as VB_ERR_COMM by the call that ran into it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    script = tmp_path / 'give_up.py'
+    script.write_text(GIVE_UP_WORKER % {'root': ROOT})
+    rc, lines = bench.spawn_ranks(2, [sys.executable, str(script)], timeout_s=300)
+    assert rc == 0, lines[-8:]

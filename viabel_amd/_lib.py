@@ -54,7 +54,7 @@ SIGNATURES = {
     'vb_noise_generate': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                          ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int64]),
-    'vb_noise_hint_seed': (ctypes.c_int, [_ctx_p, ctypes.c_uint, ctypes.c_int, ctypes.c_uint64]),
+    'vb_noise_hint_seed': (ctypes.c_int, [_ctx_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64]),
     'vb_noise_ahead_stats': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     'vb_chisq_generate': (ctypes.c_int, [_ctx_p, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
                                          ctypes.c_int64]),

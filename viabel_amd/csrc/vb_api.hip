@@ -598,11 +598,12 @@ int vb_noise_ahead_stats(vb_ctx* ctx, uint64_t* generated, uint64_t* adopted) {
   return VB_OK;
 }
 
-int vb_noise_hint_seed(vb_ctx* ctx, unsigned slot_mask, int with_chi, uint64_t seed) {
+int vb_noise_hint_seed(vb_ctx* ctx, uint64_t slot_mask, int with_chi, uint64_t seed) {
   if (!ctx) return VB_ERR_INVALID;
+  static_assert(VB_MAX_SLOTS <= 64, "slot_mask is one bit per noise slot");
   for (int slot = 0; slot < VB_MAX_SLOTS; ++slot) {
     NoiseAhead& h = ctx->noise[slot].ahead;
-    if (!((slot_mask >> slot) & 1u) || !h.last.valid) continue;
+    if (!((slot_mask >> slot) & 1ull) || !h.last.valid) continue;
     h.hint = h.last;
     h.hint.seed = seed;
   }
@@ -820,19 +821,29 @@ static int legacy_gamma_device(vb_ctx* ctx, vb_legacy_rng* rng, int prog, double
   // (a couple on average, now and then dozens: each value flips the cache an unpredictable number of times).  They are
   // collected and uploaded in row runs through push_small -- one staged copy per run, no wait; a copy + stream wait PER
   // VALUE made a 0.17 ms draw take 0.5-3 ms every other call.
+  // (declined or failed means generator untouched: every failure below rewinds before it returns -- ADVICE r5)
   std::vector<double> head;
   while (has_gauss && o < n_out) {
     double v = 0.0;
-    VB_TRY(prog == 1 ? vb_legacy_rng_standard_t(rng, df, &v, 1) : vb_legacy_rng_chisquare(rng, df, &v, 1));
+    int rc = prog == 1 ? vb_legacy_rng_standard_t(rng, df, &v, 1) : vb_legacy_rng_chisquare(rng, df, &v, 1);
+    if (rc == VB_OK) rc = vb_legacy_rng_get_state(rng, key, &pos, &has_gauss, &gauss);
+    if (rc != VB_OK) {
+      (void)rewind();
+      return rc;
+    }
     head.push_back(v);
     ++o;
-    VB_TRY(vb_legacy_rng_get_state(rng, key, &pos, &has_gauss, &gauss));
   }
   for (int64_t i = 0; i < o;) {      // value i is entry (i / d, i % d) of the request
     const int64_t row = i / d, col = i - row * d;
     int64_t run = d - col < o - i ? d - col : o - i;
-    if (row >= row_begin && row < row_begin + rows)
-      VB_TRY(push_small(ctx, ctx->stream, head.data() + i, (size_t)run * sizeof(double), dst + (row - row_begin) * ld + col));
+    if (row >= row_begin && row < row_begin + rows) {
+      const int rc = push_small(ctx, ctx->stream, head.data() + i, (size_t)run * sizeof(double), dst + (row - row_begin) * ld + col);
+      if (rc != VB_OK) {
+        (void)rewind();
+        return rc;
+      }
+    }
     i += run;
   }
   if (o == n_out) return VB_OK;

@@ -47,14 +47,17 @@ static int host_collective(vb_ctx* ctx, hipStream_t stream, double* buf, size_t 
 //   reduce   waits data >= seq, gather waits reduced >= seq.          Polls are bounded; a give-up poisons the result with NaN.
 constexpr int kIpcFlagDoubles = 16;      // 128 B in front of the data area
 
-// `max_spins`: the poll bound (vb_comm_init_ipc: 2^VB_IPC_POLL_LOG2 polls, default 2^27 -- minutes; a rank that compiles a
-// source model or runs a host callable is late by seconds, not by that).  A give-up is RECORDED: `err` is a word in pinned
-// host memory that the host reads at the next collective, at every synchronising entry point and through vb_comm_check --
-// the poisoned result never passes for data.
+// The poll bound is WALL TIME (2^27 polls kept the spinning kernels resident and the host blocked for minutes
+// behind a dead peer): `max_ticks` of the 100 MHz constant clock -- VB_IPC_TIMEOUT_S seconds, default 20 (a rank that
+// compiles a source model or runs a host callable is late by seconds, not by that; slow peers opt in to more) -- read every
+// 64 polls; `max_spins` (2^VB_IPC_POLL_LOG2, only when that variable is set) bounds the poll count as before.  A give-up is
+// RECORDED: `err` is a word in pinned host memory that the host reads at the next collective, at every synchronising entry
+// point and through vb_comm_check -- the poisoned result never passes for data.
 __device__ __forceinline__ bool ipc_wait(const double* const* win, int n_ranks, int self, int word, unsigned long long want,
-                                         unsigned max_spins, unsigned* err) {
+                                         unsigned max_spins, unsigned* err, unsigned long long max_ticks) {
   bool ok = true;
   if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
     for (int p = 0; p < n_ranks; ++p) {
       // (the own word too for the publish phase: a collective issued on another stream of this context must not
       // overwrite the window before this rank's previous read-back has finished -- the peers could otherwise move on
@@ -64,7 +67,7 @@ __device__ __forceinline__ bool ipc_wait(const double* const* win, int n_ranks, 
       unsigned spins = 0;
       while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > max_spins) {
+        if (++spins > max_spins || ((spins & 63u) == 0 && wall_clock64() - t0 > max_ticks)) {
           ok = false;
           __hip_atomic_store(err, 1u + (unsigned)word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
@@ -96,11 +99,12 @@ struct IpcArgs {
   unsigned* ticket;
   unsigned* err;            // pinned host word: a poll gave up (1 + the flag word it waited for)
   unsigned max_spins;
+  unsigned long long max_ticks;
 };
 
 __global__ void __launch_bounds__(256) ipc_publish_kernel(IpcArgs a, const double* __restrict__ buf, size_t count) {
   double* own = const_cast<double*>(a.win[a.rank]);
-  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 2, a.seq - 1, a.max_spins, a.err);
+  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 2, a.seq - 1, a.max_spins, a.err, a.max_ticks);
   double* data = own + kIpcFlagDoubles;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
     data[i] = ok ? buf[i] : NAN;
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(256) ipc_publish_kernel(IpcArgs a, const doubl
 // slice of rank r: [r * per, min(count, (r + 1) * per)), per = ceil(count / G)
 __global__ void __launch_bounds__(256) ipc_reduce_kernel(IpcArgs a, size_t count, int op) {
   double* own = const_cast<double*>(a.win[a.rank]);
-  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 0, a.seq, a.max_spins, a.err);
+  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 0, a.seq, a.max_spins, a.err, a.max_ticks);
   const size_t per = (count + a.n_ranks - 1) / a.n_ranks, lo = (size_t)a.rank * per, hi = lo + per < count ? lo + per : count;
   double* res = own + kIpcFlagDoubles + a.cap;
   for (size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (size_t)gridDim.x * 256) {
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(256) ipc_reduce_kernel(IpcArgs a, size_t count
 
 __global__ void __launch_bounds__(256) ipc_gather_kernel(IpcArgs a, double* __restrict__ buf, size_t count) {
   double* own = const_cast<double*>(a.win[a.rank]);
-  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 1, a.seq, a.max_spins, a.err);
+  const bool ok = ipc_wait(a.win, a.n_ranks, a.rank, 1, a.seq, a.max_spins, a.err, a.max_ticks);
   const size_t per = (count + a.n_ranks - 1) / a.n_ranks;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
     const int owner = (int)(i / per);
@@ -140,9 +144,9 @@ int comm_check(vb_ctx* ctx) {
   vb_ctx::IpcComm& c = ctx->ipc;
   if (!c.on || !c.err_host || *(volatile unsigned*)c.err_host == 0) return VB_OK;
   const unsigned word = *(volatile unsigned*)c.err_host - 1;
-  return fail(ctx, VB_ERR_COMM, "IPC transport: a peer did not reach collective phase %u within the poll bound (2^%d polls, "
-                               "VB_IPC_POLL_LOG2); results since then are invalid -- the communicator must be rebuilt",
-              word, c.poll_log2);
+  return fail(ctx, VB_ERR_COMM, "IPC transport: a peer did not reach collective phase %u within the poll bound (%g s, "
+                               "VB_IPC_TIMEOUT_S); results since then are invalid -- the communicator must be rebuilt",
+              word, c.timeout_s);
 }
 
 static int ipc_collective(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count, int op) {
@@ -155,6 +159,7 @@ static int ipc_collective(vb_ctx* ctx, hipStream_t stream, double* buf, size_t c
   for (int p = 0; p < 16; ++p) a.win[p] = c.win[p];
   a.n_ranks = ctx->n_ranks, a.rank = ctx->rank, a.cap = c.cap, a.seq = ++c.seq, a.ticket = c.ticket;
   a.err = c.err_dev, a.max_spins = c.poll_log2 >= 32 ? 0xffffffffu : (1u << c.poll_log2);
+  a.max_ticks = (unsigned long long)(c.timeout_s * 1e8);      // wall_clock64: 100 MHz
   const unsigned blocks = (unsigned)std::min<size_t>(256, (count + 255) / 256);
   hipLaunchKernelGGL(ipc_publish_kernel, dim3(blocks), dim3(256), 0, stream, a, (const double*)buf, count);
   hipLaunchKernelGGL(ipc_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a, count, op);
@@ -314,8 +319,10 @@ int vb_comm_ipc_window(vb_ctx* ctx, size_t cap_doubles, char handle[VB_IPC_HANDL
   ctx->ipc.ticket = ticket;
   ctx->ipc.err_host = err_host;
   ctx->ipc.err_dev = (unsigned*)err_dev;
-  const char* pl = getenv("VB_IPC_POLL_LOG2");
-  ctx->ipc.poll_log2 = pl ? std::max(8, std::min(32, atoi(pl))) : 27;
+  const char* pl = getenv("VB_IPC_POLL_LOG2");      // (an explicit poll-count bound on top of the wall-time one)
+  ctx->ipc.poll_log2 = pl ? std::max(8, std::min(32, atoi(pl))) : 32;
+  const char* ts = getenv("VB_IPC_TIMEOUT_S");
+  ctx->ipc.timeout_s = ts && atof(ts) > 0.0 ? atof(ts) : 20.0;
   ctx->ipc.win[15] = w;                // parked until vb_comm_init_ipc knows the rank
   return VB_OK;
 }
@@ -383,18 +390,20 @@ int vb_comm_allreduce_time(vb_ctx* ctx, size_t count, int warm, int reps, double
   VB_HIP(ctx, hipMemsetAsync(buf, 0, count * sizeof(double), st));
   for (int i = 0; i < warm; ++i) VB_TRY(comm_allreduce_sum(ctx, st, buf, count));
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  VB_HIP(ctx, hipEventCreate(&e0));
-  VB_HIP(ctx, hipEventCreate(&e1));
-  VB_HIP(ctx, hipStreamSynchronize(st));
-  VB_HIP(ctx, hipEventRecord(e0, st));
-  int rc = VB_OK;
-  for (int i = 0; i < reps && rc == VB_OK; ++i) rc = comm_allreduce_sum(ctx, st, buf, count);
-  VB_HIP(ctx, hipEventRecord(e1, st));
-  VB_HIP(ctx, hipStreamSynchronize(st));
   float ms = 0.f;
-  VB_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  int rc = VB_OK;
+  // (every exit destroys both events: ADVICE r5)
+  hipError_t he = hipEventCreate(&e0);
+  if (he == hipSuccess) he = hipEventCreate(&e1);
+  if (he == hipSuccess) he = hipStreamSynchronize(st);
+  if (he == hipSuccess) he = hipEventRecord(e0, st);
+  for (int i = 0; he == hipSuccess && i < reps && rc == VB_OK; ++i) rc = comm_allreduce_sum(ctx, st, buf, count);
+  if (he == hipSuccess) he = hipEventRecord(e1, st);
+  if (he == hipSuccess) he = hipStreamSynchronize(st);
+  if (he == hipSuccess && rc == VB_OK) he = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (he != hipSuccess) return fail(ctx, VB_ERR_HIP, "vb_comm_allreduce_time: %s", hipGetErrorString(he));
   VB_TRY(rc);
   *us_per_collective = 1e3 * (double)ms / reps;
   return comm_check(ctx);

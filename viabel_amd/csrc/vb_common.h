@@ -321,7 +321,8 @@ struct vb_ctx {
     unsigned* ticket = nullptr;         // device: last-block tickets of the three phases
     unsigned* err_host = nullptr;       // pinned, device-mapped: a poll gave up (checked by comm_check)
     unsigned* err_dev = nullptr;
-    int poll_log2 = 27;                 // poll bound of the device-side waits (VB_IPC_POLL_LOG2)
+    int poll_log2 = 32;                 // optional poll-count bound of the device-side waits (VB_IPC_POLL_LOG2; 32: none)
+    double timeout_s = 20.0;            // their wall-time bound (VB_IPC_TIMEOUT_S)
     bool on = false;
   } ipc;
 
