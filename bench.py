@@ -43,7 +43,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet fp64 matrix peak = 
 #                                                  tools/mfma_barrier_probe.hip measures 77.3 with constant operands
 # HBM-side bytes per launch of the headline's dense model GEMM at D=1024, N=4096 (see roofline.traffic_source)
 MODEL_GEMM_HBM_BYTES = int((2 * 64295.8 + 34414.4) * 1024)      # profiles/r05_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
-MF_ACCUM_HBM_BYTES = int((2 * 530474.5 + 8352.7) * 1024)           # profiles/r04_meanfield_c1_pmc_hbm.txt, per 32-evaluation launch
+MF_ACCUM_HBM_BYTES = int((2 * 530477.5 + 8352.7) * 1024)           # profiles/r05_meanfield_c1_pmc_hbm.txt, per 32-evaluation launch
 MIN_TIMED_S = 0.05                               # the timed blocks are repeated until they cover at least this
 
 
@@ -184,6 +184,240 @@ def dependent_chain_leg(eng, vb, group, iters=60):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# sharded legs (N > 1: collective -- every rank runs them; times are max over ranks)
+# --------------------------------------------------------------------------------------------------------------
+def _c3_problem(vb, D=256):
+    """The problem of c3_leg / tests/test_gpu_full_size.py: interior tempering eps, ESS on target."""
+    rng = np.random.RandomState(33)
+    mean = 0.3 * rng.randn(D)
+    sd = np.exp(0.5 + 0.02 * rng.randn(D))
+    prior = np.concatenate([np.zeros(D), 0.5 * np.ones(D)])
+    A = rng.randn(D, D)
+    Sigma = np.e * np.eye(D) + 0.04 * (A @ A.T / D - np.eye(D))
+    L = np.linalg.cholesky(Sigma)
+    Lf = L.copy()
+    Lf[np.diag_indices(D)] = np.log(np.diag(L))
+    theta = np.concatenate([0.02 * rng.randn(D), Lf[np.tril_indices(D)]])
+    return vb.GaussianModel(mean, sd), prior, theta
+
+
+def sharded_c3_leg(eng, vb, group, calls=20):
+    """BASELINE configs[3] AS IT IS STATED: MultivariateT(256, df=100) + DISInclusiveKL, N_mc = 16 384, the MC axis sharded
+    over the ranks -- on the device-resident route (round 6: it used to refuse more than one rank).  Per blocking call:
+    every rank samples and scores its rows, ONE device all-gather of [log p | log q | log prior] (3 N doubles), bisection /
+    multinomial draw redundantly on the whole vectors, per-rank weighted Gram product, ONE all-reduce of
+    [16 + D + D x D] doubles, the D^3 chain rule redundantly.  strong: N_mc = 16 384 global; weak: 16 384 per GPU."""
+    D, df, world = 256, 100, group.world
+    model, prior, theta = _c3_problem(vb, D)
+    ld = (D + 15) // 16 * 16
+    out = {'workload': 'BASELINE configs[3] sharded: MultivariateT(256, df=100) + DISInclusiveKL, state refresh every call, '
+                       'rng=philox, MC axis over %d ranks; max over ranks of blocks of %d blocking calls' % (world, calls),
+           'allreduce_doubles_per_call': 16 + ld + D * ld}
+    np.random.seed(5)
+    for scaling, N in (('strong', 16384), ('weak', 16384 * world)):
+        leg = {'n_mc_global': N, 'n_mc_per_gpu': N // world, 'allgather_doubles_per_call': 3 * N}
+        for mode, resample, n_warm in (('weighted', False, 10), ('resampling', True, 10), ('parity_mode_weighted', False, 3)):
+            if mode.startswith('parity') and scaling == 'weak':
+                continue
+            approx = vb.MultivariateT(D, df, seed=1, rng='numpy' if mode.startswith('parity') else 'philox')
+            obj = vb.DISInclusiveKL(approx, model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+                                    temper_prior_params=prior, use_resampling=resample)
+            last = {}
+            if os.environ.get('VB_BENCH_TRACE'):
+                sys.stderr.write('rank %d: c3 %s %s\n' % (group.rank, scaling, mode))
+
+            def run(k):
+                for _ in range(k):
+                    last['vg'] = obj(theta)
+            run(n_warm)
+            times = timed_blocks(run, eng.sync, group, calls if n_warm > 3 else max(3, calls // 4), min_total_s=0.1, max_blocks=5)
+            per = statistics.median(times) / (calls if n_warm > 3 else max(3, calls // 4))
+            v, g = last['vg']
+            leg[mode] = {'ms_per_call': 1e3 * per, 'calls_per_s': 1.0 / per, 'blocks': len(times), 'eps': float(obj._eps),
+                         'ess': float(obj._ess), 'value': float(v), 'grad_norm': float(np.linalg.norm(g))}
+        out[scaling] = leg
+    return out
+
+
+def sharded_c4_leg(eng, vb, group, steps=10):
+    """BASELINE configs[4] sharded: MFGaussian + ExclusiveKL on Bayesian logistic regression, D = 2000, n_data = 8192,
+    N_mc = 8192 GLOBAL (strong scaling: 8192 / world rows per GPU), fresh Philox noise per evaluation; one all-reduce of
+    the mean-field sum vector per evaluation.  Blocking objective calls, and RMSProp iterations of the device-resident
+    loop (vb_fit) that FASO / RAABBVI run between convergence checks."""
+    from viabel_amd.optimization import RMSProp
+    D, n_data, N = 2000, 8192, 8192
+    rng = np.random.RandomState(4)
+    X = rng.randn(n_data, D) / np.sqrt(D)
+    beta = rng.randn(D)
+    y = (rng.rand(n_data) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    model = vb.LogisticRegressionModel(X, y, 10.0)
+    obj = vb.ExclusiveKL(vb.MFGaussian(D, rng='philox'), model, N)
+    theta = np.concatenate([np.zeros(D), -2 * np.ones(D)])
+    last = {}
+
+    def run(k):
+        for _ in range(k):
+            last['vg'] = obj(theta)
+    run(3)
+    times = timed_blocks(run, eng.sync, group, steps, min_total_s=0.1, max_blocks=5)
+    dt = statistics.median(times) / steps
+    ropt = RMSProp(0.02)
+    obj.device_fit(5, theta, ropt._device_kind, ropt._device_hyper())
+
+    def loop(k):
+        obj.device_fit(k, theta, ropt._device_kind, ropt._device_hyper())
+    ltimes = timed_blocks(loop, eng.sync, group, steps, min_total_s=0.1, max_blocks=5)
+    v, g = last['vg']
+    flops = 2 * 2.0 * N * n_data * D
+    return {'workload': 'BASELINE configs[4] sharded: MFGaussian + ExclusiveKL, logistic regression D=2000, n_data=8192, '
+                        'N_mc=8192 global over %d ranks (strong), rng=philox' % group.world,
+            'n_mc_global': N, 'n_mc_per_gpu': N // group.world, 'allreduce_doubles_per_evaluation': 2 * D + 12,
+            'ms_per_eval': 1e3 * dt, 'evals_per_s': 1.0 / dt,
+            'device_loop_ms_per_iteration': 1e3 * statistics.median(ltimes) / steps,
+            'value': float(v), 'grad_norm': float(np.linalg.norm(g)),
+            'whole_job_tflops': flops / dt / 1e12}
+
+
+def sharded_c1_leg(eng, vb, group, iters=400):
+    """BASELINE configs[1] as an optimiser sees it under the communicator: RMSProp iterations of vb_fit with
+    MFGaussian(1024, rng=philox) + ExclusiveKL on the funnel -- noise in registers, one streaming pass, ONE all-reduce of
+    2 060 doubles (16 KB: the latency-bound collective SURVEY 5 warns about), finalize + step -- every iteration behind
+    the previous one's collective.  strong: N_mc = 4096 global; weak: 4096 per GPU."""
+    from viabel_amd.optimization import RMSProp
+    d, world = D1, group.world
+    model = vb.FunnelModel(d)
+    theta = np.concatenate([np.zeros(d), -np.ones(d)])
+    out = {'workload': 'RMSProp iterations of vb_fit under the communicator: MFGaussian(%d, rng=philox) + ExclusiveKL, funnel, '
+                       'one all-reduce of %d doubles per iteration' % (d, 2 * d + 12)}
+    for scaling, n_global in (('strong', N_MC), ('weak', N_MC * world)):
+        obj = vb.ExclusiveKL(vb.MFGaussian(d, rng='philox'), model, n_global)
+        ropt = RMSProp(0.01)
+        obj.device_fit(50, theta, ropt._device_kind, ropt._device_hyper())
+
+        def run(k):
+            obj.device_fit(k, theta, ropt._device_kind, ropt._device_hyper())
+        times = timed_blocks(run, eng.sync, group, iters, min_total_s=0.2, max_blocks=5)
+        out[scaling] = {'us_per_iteration': 1e6 * statistics.median(times) / iters, 'n_mc_global': n_global,
+                        'iterations_per_s': iters / statistics.median(times), 'blocks': len(times)}
+    return out
+
+
+def transport_legs(eng, vb, group):
+    """The legs that depend on the TRANSPORT alone: the dependent full-rank chain, the 4.2-MB collective by itself and the
+    mean-field chain with its 16-KB collective.  Run under the job's own transport by the ranks themselves and, for the
+    other transport, by the children of `second_transport_probe`."""
+    n_sum = 16 + FR_D + FR_D * (FR_D + 1) // 2
+    chain = dependent_chain_leg(eng, vb, group)
+    group.barrier()
+    big = group.allreduce_max(eng.comm_allreduce_time(n_sum, warm=5, reps=30))
+    group.barrier()
+    small = group.allreduce_max(eng.comm_allreduce_time(2 * D1 + 12, warm=10, reps=200))
+    return {'dependent_chain': chain,
+            'allreduce_us': {'us_per_allreduce': big, 'doubles': n_sum,
+                             'note': 'sum all-reduce of the full-rank sum vector alone, back to back on one stream between HIP '
+                                     'events (vb_comm_allreduce_time), max over ranks'},
+            'allreduce_small_us': {'us_per_allreduce': small, 'doubles': 2 * D1 + 12,
+                                   'note': 'the mean-field sum vector (16 KB): latency-bound'},
+            'c1_meanfield_chain': sharded_c1_leg(eng, vb, group)}
+
+
+def prewarm_shared_device(eng, vb, distributed, which=('transport', 'c3', 'c4')):
+    """Functional N > 1 runs on ONE GPU (VB_BENCH_TRANSPORT=host|ipc on a box with fewer GPUs than ranks) only: every leg
+    once WITHOUT a communicator before it is attached.  Measured in round 6 (tools/r6_ipc_first_call_probe.py): when a
+    process sets up device queues / streams / copy engines for the first time (the first call of a new code path) while
+    the OTHER process's collective kernel is spinning on the same GPU, that call stalls for tens of seconds -- 42 s seen --
+    or until the spinning kernel gives up (VB_IPC_TIMEOUT_S), and the give-up poisons the communicator: two processes
+    cannot always make progress against each other on one device.  With its own GPU per rank (the case the transport
+    exists for) nothing of the kind can happen; here the first-time set-up is simply done before anything can spin."""
+    solo = distributed.SocketGroup(0, 1)
+    if 'transport' in which:
+        dependent_chain_leg(eng, vb, solo, iters=3)
+        sharded_c1_leg(eng, vb, solo, iters=20)
+        eng.comm_allreduce_time(16 + FR_D + FR_D * (FR_D + 1) // 2, warm=1, reps=1)
+    if 'c3' in which:
+        sharded_c3_leg(eng, vb, solo, calls=2)
+    if 'c4' in which:
+        sharded_c4_leg(eng, vb, solo, steps=1)
+    eng.sync()
+
+
+def run_probe_child(argv, env, timeout_s, want_stdout):
+    """One child process of a rank (its own session; never an exec of this process): returns (exit code or 124 on
+    timeout, its stdout lines).  A child that is still running at the deadline has its whole process group killed."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(argv, env=env, start_new_session=True, text=True,
+                         stdout=subprocess.PIPE if want_stdout else subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        out, _ = p.communicate(timeout=timeout_s)
+        return p.returncode, (out or '').splitlines()
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            p.communicate(timeout=10)
+        except Exception:
+            pass
+        return 124, []
+
+
+def second_transport_probe(group, transport, timeout_s=240.0, child_argv=None):
+    """`transports[<the other transport>]` of an N > 1 line WITHOUT putting the line at risk: every rank starts ONE child
+    process (rank / world / device as its own, a control port and a job token of their own) that attaches the other
+    transport, runs `transport_legs` and -- rank 0's child -- prints them as one JSON line.  The xGMI-native IPC
+    transport has never crossed a device boundary on this pool: whatever it does on a real node -- a refused
+    handle, a give-up of its device-side waits, a fault -- ends a CHILD; the parent ranks report the error text instead
+    of the numbers and the headline line is printed regardless.  Collective: every rank calls this; rank 0 gets the dict."""
+    env = dict(os.environ)
+    base_port = int(env.get('VIABEL_AMD_CONTROL_PORT', int(env.get('MASTER_PORT', '29500')) + 23))
+    env['VIABEL_AMD_CONTROL_PORT'] = str(base_port + 41)
+    env['VIABEL_AMD_JOB_ID'] = env.get('VIABEL_AMD_JOB_ID', '') + '-probe-' + transport
+    env['VB_BENCH_TRANSPORT'] = transport
+    argv = child_argv or [sys.executable, os.path.abspath(__file__), '--gpus', str(group.world), '--probe-transport', transport]
+    group.barrier()
+    rc, lines = run_probe_child(argv, env, timeout_s, want_stdout=group.rank == 0)
+    worst = group.allreduce_max(float(rc if rc >= 0 else 128 - rc))
+    if group.rank != 0:
+        return None
+    result = None
+    for line in lines:
+        try:
+            obj = json.loads(line)
+            if isinstance(obj, dict) and 'dependent_chain' in obj:
+                result = obj
+        except ValueError:
+            pass
+    if worst != 0 or result is None:
+        return {'error': 'probe children of the %s transport: worst exit code %d over the ranks%s -- the numbers of this '
+                         'transport are missing, nothing else is affected' % (transport, int(worst), '' if result is not None
+                                                                              else ', no result line')}
+    return result
+
+
+def probe_main(args):
+    """A child of `second_transport_probe`: this rank's share of `transport_legs` under the named transport."""
+    from viabel_amd import _lib, distributed
+    import viabel_amd as vb
+    world = int(os.environ['WORLD_SIZE'])
+    group = distributed.SocketGroup.from_env()
+    shared = _lib.device_count() < world
+    eng = _lib.Engine(0) if shared else _lib.default_engine()
+    _lib.set_default_engine(eng)
+    if shared:
+        prewarm_shared_device(eng, vb, distributed, which=('transport',))
+        group.barrier()
+    distributed.attach(eng, group, transport=args.probe_transport)
+    legs = transport_legs(eng, vb, group)
+    if group.rank == 0:
+        legs['transport'] = args.probe_transport + (' (all ranks on device 0: a functional run)' if shared else '')
+        print(json.dumps(legs), flush=True)
+    group.barrier()
+    group.close()
+
+
+# --------------------------------------------------------------------------------------------------------------
 # secondary legs (1 GPU, rank 0)
 # --------------------------------------------------------------------------------------------------------------
 def meanfield_leg(eng, vb, _lib, steps=2000, warmup=200, batch=32, ring_total=16):
@@ -269,9 +503,9 @@ def meanfield_leg(eng, vb, _lib, steps=2000, warmup=200, batch=32, ring_total=16
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'avg_kernel_us': kernel_us,
                      'launches_timed': launches, 'algorithmic_bytes_per_launch': bytes_per_launch,
                      'traffic': MF_ACCUM_HBM_BYTES if batch == 32 else None,
-                     'traffic_source': 'profiles/r04_meanfield_c1_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
-                                       'passes of tools/mf_stream_bench.py, this launch shape, round-3 kernel): 1 086.4 MB fetched '
-                                       '+ 8.6 MB written per 32-evaluation launch = 1.019 x the algorithmic 1 074.8 MB'},
+                     'traffic_source': 'profiles/r05_meanfield_c1_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
+                                       'passes of tools/mf_stream_bench.py, this launch shape, kernel unchanged since): 1 086.4 MB '
+                                       'fetched + 8.6 MB written per 32-evaluation launch = 1.019 x the algorithmic 1 074.8 MB'},
         'parity': {'rel_elbo_err': abs(dv - ov) / abs(ov),
                    'rel_grad_err': float(np.max(np.abs(dg - og)) / np.max(np.abs(og)))},
     }, theta
@@ -1098,6 +1332,8 @@ def main():
     ap.add_argument('--no-profile', action='store_true', help='no per-kernel HIP events in the timed region')
     ap.add_argument('--launch-timeout', type=float, default=1500.0,
                     help='self-launched ranks (--gpus N > 1 without a launcher) are killed after this many seconds')
+    ap.add_argument('--probe-transport', choices=['rccl', 'ipc', 'host'], default=None,
+                    help='internal: a child of second_transport_probe (runs transport_legs under that transport)')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -1111,6 +1347,8 @@ def main():
     if world != args.gpus:
         # a line whose n_gpus differs from what was asked for must never be printed
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.probe_transport:
+        return probe_main(args)
 
     from viabel_amd import _lib, distributed
     import viabel_amd as vb
@@ -1129,6 +1367,9 @@ def main():
     ipc_shared_gpu = ipc_transport and _lib.device_count() < world
     eng = _lib.Engine(0) if (no_rccl or host_transport or ipc_shared_gpu) else _lib.default_engine()
     _lib.set_default_engine(eng)
+    if world > 1 and (host_transport or ipc_shared_gpu):
+        prewarm_shared_device(eng, vb, distributed)      # (one-GPU functional runs only: see there)
+        group.barrier()
     if host_transport:
         distributed.attach(eng, group, transport='host')
     elif ipc_transport:
@@ -1147,12 +1388,18 @@ def main():
         other = fullrank_leg(eng, vb, _lib, group, FR_D, args.steps, args.warmup, scaling=other_mode, profile=False)
         other['scaling'] = other_mode
 
-    chain, allreduce_us = None, None
-    if world > 1:          # collective legs: every rank runs them
-        chain = dependent_chain_leg(eng, vb, group)
-        n_sum = 16 + FR_D + FR_D * (FR_D + 1) // 2
-        group.barrier()
-        allreduce_us = group.allreduce_max(eng.comm_allreduce_time(n_sum, warm=5, reps=30))
+    tlegs, sharded, transports = None, None, None
+    if world > 1 and not no_rccl:          # collective legs: every rank runs them
+        primary = 'host' if host_transport else 'ipc' if ipc_transport else 'rccl'
+        tlegs = transport_legs(eng, vb, group)
+        # the configs that NAME 8 GPUs (BASELINE configs[3], configs[4]) on their sharded device-resident routes
+        sharded = {'c3_mvt_dis': sharded_c3_leg(eng, vb, group), 'c4_logistic': sharded_c4_leg(eng, vb, group)}
+        # ... and the transport-dependent legs once more under the OTHER transport, by child processes (see there)
+        other_t = os.environ.get('VB_BENCH_SECOND_TRANSPORT', 'host' if primary == 'ipc' else 'ipc')
+        transports = {primary: tlegs}
+        if other_t not in ('0', 'none', primary):
+            eng.sync()
+            transports[other_t] = second_transport_probe(group, other_t)
 
     out = None
     if rank == 0:
@@ -1219,12 +1466,13 @@ def main():
             'check': {'value': head['value'], 'grad_norm': head['grad_norm']},
             'roofline': roof,
         }
-        if chain is not None:
-            out['dependent_chain'] = chain
-            out['allreduce_us'] = {'us_per_allreduce': allreduce_us, 'doubles': 16 + FR_D + FR_D * (FR_D + 1) // 2,
-                                   'note': 'sum all-reduce of the full-rank sum vector alone, back to back on one stream '
-                                           'between HIP events (vb_comm_allreduce_time), max over ranks; transport as in '
-                                           '`transport`'}
+        if tlegs is not None:
+            out['dependent_chain'] = tlegs['dependent_chain']
+            out['allreduce_us'] = tlegs['allreduce_us']
+            out['c1_meanfield'] = {'dependent_chain': tlegs['c1_meanfield_chain'], 'allreduce_us': tlegs['allreduce_small_us']}
+            out['c3_mvt_dis'] = sharded['c3_mvt_dis']
+            out['c4_logistic'] = sharded['c4_logistic']
+            out['transports'] = transports
         if other is not None:
             u2 = world if other['scaling'] == 'weak' else 1
             out['other_scaling'] = {'scaling': other['scaling'], 'value': u2 / other['sec_per_step'], 'unit': 'evals/s',

@@ -152,3 +152,60 @@ def test_rank_refuses_world_size_mismatch():
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], capture_output=True, text=True,
                          env=env, timeout=120)
     assert res.returncode != 0 and 'WORLD_SIZE=1' in res.stderr and res.stdout.strip() == ''
+
+
+# ---- round 6: the second transport of an N > 1 line is measured by CHILD processes of the ranks -------------------------
+def _probe_job(tmp_path, child_body, timeout_s=60.0):
+    """Two rank processes (bench.spawn_ranks) that each call bench.second_transport_probe with a stub child; rank 0 prints
+    what it got."""
+    import bench
+    child = tmp_path / 'probe_child.py'
+    child.write_text(textwrap.dedent(child_body))
+    rank = tmp_path / 'probe_rank.py'
+    rank.write_text(textwrap.dedent('''
+        import json, os, sys
+        sys.path.insert(0, %r)
+        import bench
+        from viabel_amd import distributed
+        g = distributed.SocketGroup.from_env(timeout=60.0)
+        res = bench.second_transport_probe(g, 'ipc', timeout_s=%r, child_argv=[sys.executable, %r])
+        g.barrier(); g.close()
+        if g.rank == 0:
+            print(json.dumps({'metric': 'm', 'probe': res}))
+    ''') % (ROOT, timeout_s, str(child)))
+    rc, lines = bench.spawn_ranks(2, [sys.executable, str(rank)], timeout_s=180)
+    assert rc == 0, lines
+    return json.loads(lines[-1])['probe']
+
+
+def test_second_transport_probe_relays_the_childs_line(tmp_path):
+    res = _probe_job(tmp_path, '''
+        import json, os
+        # the children get a control port and a job token of their own, and the transport's name
+        assert os.environ['VB_BENCH_TRANSPORT'] == 'ipc' and os.environ['VIABEL_AMD_JOB_ID'].endswith('-probe-ipc')
+        assert int(os.environ['VIABEL_AMD_CONTROL_PORT']) == int(os.environ['MASTER_PORT']) + 23 + 41
+        print('a banner')
+        if os.environ['RANK'] == '0':
+            print(json.dumps({'dependent_chain': {'weak': {'us_per_iteration': 1.5}}, 'allreduce_us': {'us_per_allreduce': 2.5}}))
+    ''')
+    assert res['dependent_chain']['weak']['us_per_iteration'] == 1.5 and res['allreduce_us']['us_per_allreduce'] == 2.5
+
+
+def test_second_transport_probe_reports_a_failing_child_and_goes_on(tmp_path):
+    """A child that dies (on ANY rank) costs this transport's numbers, not the line: rank 0 gets the error text."""
+    res = _probe_job(tmp_path, '''
+        import json, os, sys
+        if os.environ['RANK'] == '1':
+            sys.exit(9)
+        print(json.dumps({'dependent_chain': {}, 'allreduce_us': {}}))
+    ''')
+    assert set(res) == {'error'} and 'exit code 9' in res['error'] and 'ipc' in res['error']
+
+
+def test_second_transport_probe_kills_children_at_the_deadline(tmp_path):
+    t0 = time.time()
+    res = _probe_job(tmp_path, '''
+        import time
+        time.sleep(600)
+    ''', timeout_s=2.0)
+    assert set(res) == {'error'} and 'exit code 124' in res['error'] and time.time() - t0 < 60

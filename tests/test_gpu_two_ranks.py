@@ -31,9 +31,15 @@ import viabel_amd as vb
 eng = _lib.Engine(0)                                  # both ranks on the one GPU of the box
 _lib.set_default_engine(eng)
 group = distributed.SocketGroup.from_env(timeout=120.0)
+import _two_rank_scenarios as S
+# Two processes on ONE device: a process that sets up queues / streams / copy engines for the first time while the other
+# process's collective kernel spins on the same GPU can stall for tens of seconds (round 6, tools/r6_ipc_first_call_probe.py:
+# 42 s, or until the spinning kernel gives up and poisons the communicator).  Every code path once without a communicator
+# first -- the scenarios reseed everything they draw from, so the sharded pass below computes what it would have anyway.
+S.run_all(vb)
+group.barrier()
 distributed.attach(eng, group, transport=%(transport)r)
 assert eng.comm_info() == (2, group.rank)
-import _two_rank_scenarios as S
 # round 6: every dense-family objective stays on its device-resident route under a communicator -- the host-root / host-weight
 # entry points the sharded jobs used to fall back to must not be called at all
 fallbacks = {}

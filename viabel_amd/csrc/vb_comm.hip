@@ -144,9 +144,17 @@ int comm_check(vb_ctx* ctx) {
   vb_ctx::IpcComm& c = ctx->ipc;
   if (!c.on || !c.err_host || *(volatile unsigned*)c.err_host == 0) return VB_OK;
   const unsigned word = *(volatile unsigned*)c.err_host - 1;
+  // where everybody stood: [data, reduced, done] sequence numbers of every rank's window against this rank's own count
+  char where[512];
+  int at = snprintf(where, sizeof where, "issued %llu;", (unsigned long long)c.seq);
+  for (int p = 0; p < ctx->n_ranks && at < (int)sizeof where - 64; ++p) {
+    unsigned long long f[3] = {0, 0, 0};
+    if (c.win[p] && hipMemcpy(f, c.win[p], sizeof f, hipMemcpyDeviceToHost) == hipSuccess)
+      at += snprintf(where + at, sizeof where - at, " rank %d [%llu %llu %llu]", p, f[0], f[1], f[2]);
+  }
   return fail(ctx, VB_ERR_COMM, "IPC transport: a peer did not reach collective phase %u within the poll bound (%g s, "
-                               "VB_IPC_TIMEOUT_S); results since then are invalid -- the communicator must be rebuilt",
-              word, c.timeout_s);
+                               "VB_IPC_TIMEOUT_S); results since then are invalid -- the communicator must be rebuilt (%s)",
+              word, c.timeout_s, where);
 }
 
 static int ipc_collective(vb_ctx* ctx, hipStream_t stream, double* buf, size_t count, int op) {
@@ -229,6 +237,33 @@ int comm_gather_rows(vb_ctx* ctx, hipStream_t stream, double* vec, int64_t begin
   if (begin + n < n_total)
     VB_HIP(ctx, hipMemsetAsync(vec + begin + n, 0, (size_t)(n_total - begin - n) * sizeof(double), stream));
   return comm_allreduce_sum(ctx, stream, vec, (size_t)n_total);
+}
+
+// The three per-sample vectors of a DIS refresh ([log p | log q | log prior] in one order or another: v0 < v1 < v2, `stride`
+// doubles apart, each holding this rank's rows at [begin, begin + n)) in ONE collective (round 6; they were three): a kernel
+// zeroes everything that is not this rank's block -- the other ranks' rows and the pads up to `stride` -- and one sum
+// all-reduce over the 3 x stride doubles puts every rank's rows in place (x + 0 + ... + 0 is exact).  On RCCL an all-reduce
+// of 3 N doubles (393 KB at BASELINE configs[3]) moves twice what three all-gathers would, but at this size each collective is its
+// launch + handshake latency, not its bytes: two fewer of them per objective call.
+__global__ void __launch_bounds__(256) gather3_zero_kernel(double* __restrict__ v, int64_t stride, int64_t begin, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * stride) return;
+  const int64_t j = i % stride;
+  if (j < begin || j >= begin + n) v[i] = 0.0;
+}
+
+int comm_gather_rows3(vb_ctx* ctx, hipStream_t stream, double* v0, double* v1, double* v2, int64_t begin, int64_t n,
+                      int64_t n_total) {
+  if (!ctx->comm) return VB_OK;
+  const int64_t stride = v1 - v0;
+  if (stride < n_total || v2 - v1 != stride) {      // (not one block: vector by vector)
+    VB_TRY(comm_gather_rows(ctx, stream, v0, begin, n, n_total));
+    VB_TRY(comm_gather_rows(ctx, stream, v1, begin, n, n_total));
+    return comm_gather_rows(ctx, stream, v2, begin, n, n_total);
+  }
+  hipLaunchKernelGGL(gather3_zero_kernel, dim3((unsigned)((3 * stride + 255) / 256)), dim3(256), 0, stream, v0, stride, begin, n);
+  VB_HIP(ctx, hipGetLastError());
+  return comm_allreduce_sum(ctx, stream, v0, (size_t)(3 * stride));
 }
 
 }  // namespace vb

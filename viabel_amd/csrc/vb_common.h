@@ -646,6 +646,8 @@ int comm_shard_begin(vb_ctx* ctx, int64_t n, int64_t n_total, int64_t* begin);
 // shards are equal, otherwise zero fill outside the own block + sum all-reduce (x + 0 is exact, so the gathered
 // values are the owners' bits either way).  Without a communicator: nothing to do.
 int comm_gather_rows(vb_ctx* ctx, hipStream_t stream, double* vec, int64_t begin, int64_t n, int64_t n_total);
+int comm_gather_rows3(vb_ctx* ctx, hipStream_t stream, double* v0, double* v1, double* v2, int64_t begin, int64_t n,
+                      int64_t n_total);
 
 // profiling: event pair for the next launch of the dominant kernel (nullptrs when disabled)
 void prof_events(vb_ctx* ctx, hipEvent_t* ev0, hipEvent_t* ev1, int evals, int kernel_id = VB_PROF_MF_ACCUM);

@@ -485,9 +485,7 @@ int lr_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_
   if (ctx->temper.kind != VB_PRIOR_DIAG_GAUSSIAN)      // any other family as tempering prior (vb_dis_set_temper_prior)
     VB_TRY(temper_prior_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lpr + mine));
   if (ctx->comm) {
-    VB_TRY(comm_gather_rows(ctx, st, base + L.o_f, mine, n, n_total));
-    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));
-    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lpr, mine, n, n_total));
+    VB_TRY(comm_gather_rows3(ctx, st, base + L.o_f, base + L.o_lq, base + L.o_lpr, mine, n, n_total));
   }
   VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is
   VB_TRY(dis_bisect_enqueue(ctx, base + L.o_f, base + L.o_lq, base + L.o_lpr, base + L.o_scal, n_total, eps_prev,

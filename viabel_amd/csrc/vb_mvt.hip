@@ -929,9 +929,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     VB_TRY(temper_prior_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lprior + mine));
   VB_TRY(mvt_side_enqueue(ctx));      // (a deferred inverse: its launches go out now that the main stream is fed)
   if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
-    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lp, mine, n, n_total));
-    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lq, mine, n, n_total));
-    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lprior, mine, n, n_total));
+    VB_TRY(comm_gather_rows3(ctx, st, base + L.o_lq, base + L.o_lp, base + L.o_lprior, mine, n, n_total));
   }
   if (!dev_factors)      // (throughput mode: mvt_prep_kernel has zeroed them)
     VB_HIP(ctx, hipMemsetAsync(base + L.o_scal, 0, 32 * sizeof(double), st));   // scal[0] = 0: lq is used as is

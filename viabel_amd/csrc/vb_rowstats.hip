@@ -728,9 +728,7 @@ int dis_refresh_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_t
     VB_TRY(temper_prior_rows(ctx, Z, ldz, n, d, base + L.o_lprior + mine));
   }
   if (ctx->comm) {   // in-place all-gather: every rank contributed its own block
-    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lp, mine, n, n_total));
-    VB_TRY(comm_gather_rows(ctx, st, base + L.o_b, mine, n, n_total));
-    VB_TRY(comm_gather_rows(ctx, st, base + L.o_lprior, mine, n, n_total));
+    VB_TRY(comm_gather_rows3(ctx, st, base + L.o_lp, base + L.o_b, base + L.o_lprior, mine, n, n_total));
   }
   VB_TRY(dis_bisect_enqueue(ctx, base + L.o_lp, base + L.o_b, base + L.o_lprior, base + L.o_scal, n_total, eps_prev,
                             ess_target, max_its, base + L.o_w, base + L.o_lq, base + L.o_out));
