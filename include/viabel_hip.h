@@ -339,6 +339,12 @@ int vb_dis_weights_get(vb_ctx* ctx, double* w, int64_t n_total, int resampled /*
 /* [eps, ess, zero-weight status, khat] of the last device-resident refresh (what vb_dis_step_mvt_packed returns with its
  * gradient), for callers that weight the score themselves (vb_dis_grad_mvt_packed after a host resampling draw).   */
 int vb_dis_scalars_get(vb_ctx* ctx, double out[4]);
+/* Page-locked host memory for large result arrays (hipHostMalloc / hipHostFree; no context: any thread).  A gradient of
+ * 525 824 doubles copied into PAGEABLE memory is staged by the runtime (118 us at D = 1024); into a block from here the
+ * copy engine writes directly.  A binding may allocate the arrays it returns from such blocks (the Python one does:
+ * viabel_amd/_lib.py, PinnedPool -- the reference returns freshly allocated numpy arrays, objectives.py:32-44).        */
+int vb_host_alloc(size_t bytes, void** ptr);
+int vb_host_free(void* ptr);
 /* The DIS state samples live in the context, one set per family kind (0: mean-field, 1: MultivariateT / dense
  * Gaussian, 2: low-rank Gaussian); every refresh of a kind overwrites its set and bumps its generation counter.  A
  * caller that keeps weights for a later vb_dis_grad_* call compares the counter with the one it saw after its own
@@ -404,7 +410,12 @@ int vb_elbo_sums_mvt(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_tota
  * (path derivative: the score L^-T eps enters through the noise Gram matrix and an explicit triangular inverse on
  * the device).  Targets: gauss_diag, funnel, gauss_full and the regression models.  fp64 MFMA GEMMs.
  * vb_elbo_grad_fullrank = set_theta + enqueue + get; the three-step form keeps theta and the
- * result resident on the device (P = D + D(D+1)/2 doubles is 4.2 MB at D = 1024).          */
+ * result resident on the device (P = D + D(D+1)/2 doubles is 4.2 MB at D = 1024).  Hand the blocking call a
+ * gradient array from vb_host_alloc and the download is a direct DMA.  VB_FR_UPLOAD_PIPE=1 (round 6: bit-identical,
+ * measured slower, off): the flat parameter crosses PCIe in three row chunks of L, last rows first, and the sampling
+ * product of a chunk's column blocks starts behind its copy.          */
+/* how many vb_elbo_grad_fullrank calls of this context took the pipelined upload (observability: tests) */
+int vb_fullrank_upload_stats(vb_ctx* ctx, uint64_t* pipelined_calls);
 int vb_elbo_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
                           const double* theta, unsigned flags, double* value, double* grad);
 int vb_fullrank_set_theta(vb_ctx* ctx, const double* theta, int64_t d);
@@ -601,6 +612,18 @@ int vb_legacy_rng_randn_device(vb_ctx* ctx, vb_legacy_rng* rng, int slot, int64_
 int vb_legacy_rng_standard_t_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, int slot, int64_t n_total, int64_t d,
                                     int64_t row_begin, int64_t rows);
 int vb_legacy_rng_chisquare_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, int64_t n, double* host_out);
+/* Look-ahead generation of the NEXT call's draws (round 6).  A family in the reference-identical mode makes the same device
+ * draws call after call from one persistent generator (approximations.py:213-216, :270-274, :342-349).  The binding calls
+ * vb_legacy_round_end(ctx, rng) when a call's draws are done: if the round just ended asked for what the round before it
+ * asked for, the same requests are started from the generator's CURRENT state on a stream of their own, into shadow
+ * buffers -- beside the objective's kernels that follow on the main stream.  The next vb_legacy_rng_*_device call that
+ * finds the generator in exactly that state (all 624 words, position, cached normal) and asks for exactly that draw takes
+ * the shadow by a pointer swap and sets the generator to the speculated end state; any other request, or a generator that
+ * moved in between (a host draw, a reseed, set_state), discards the speculation and draws as before.  Values and generator
+ * states are numpy's either way (tests/test_gpu_legacy_rng.py).  VB_LEGACY_AHEAD=0 turns it off.  A binding that does
+ * not call vb_legacy_round_end gets no speculation.  vb_legacy_ahead_stats: jobs launched, requests adopted, jobs discarded. */
+int vb_legacy_round_end(vb_ctx* ctx, vb_legacy_rng* rng);
+int vb_legacy_ahead_stats(vb_ctx* ctx, uint64_t* launched, uint64_t* adopted, uint64_t* discarded);
 /* 1 when this host's libm log() has been located and restated bit for bit (vb_glibc_log.h): the device draws above are
  * available and vb_legacy_rng_randn_device needs no host round trip.                                               */
 int vb_legacy_rng_log_proven(void);

@@ -471,3 +471,30 @@ def test_host_staged_transport_one_rank_and_failing_collective():
     eng.comm_destroy()
     assert eng.comm_info() == (1, 0)
     eng.close()
+
+
+def test_resident_dense_routes_and_c3_through_a_one_rank_rccl_communicator(engines):
+    """Round 6: the device-resident DIS step and the t family's reference-identical ExclusiveKL / AlphaDivergence under a
+    communicator -- here RCCL itself with one rank (RCCL refuses two ranks on one device; the two-rank runs of
+    tests/test_gpu_two_ranks.py use the other transports): the fused three-vector gather (one in-place ncclAllReduce over
+    [log q | log p | log prior]), the sum all-reduce in front of the chain rule, the all-reduced sample sums in front of the
+    Frechet derivative are the calls an 8-GPU job issues, and the results are the communicator-free ones."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import viabel_amd as vb
+    from viabel_amd import _lib
+    import _two_rank_scenarios as S
+    plain, comm = engines
+    want = {**S.run_resident_dense(vb), **S.run_c3(vb)}
+    _lib.set_default_engine(comm)
+    try:
+        assert comm.comm_info() == (1, 0) and comm._lib.vb_comm_check(comm._ctx) == 0
+        got = {**S.run_resident_dense(vb), **S.run_c3(vb)}
+    finally:
+        _lib.set_default_engine(plain)
+    assert set(got) == set(want) and len(got) >= 20
+    for name in want:
+        v0, g0 = np.asarray(want[name][0], dtype=float), np.asarray(want[name][1], dtype=float)
+        v1, g1 = np.asarray(got[name][0], dtype=float), np.asarray(got[name][1], dtype=float)
+        assert np.max(np.abs(v1 - v0)) <= 1e-12 * np.max(np.abs(v0)), name
+        assert np.max(np.abs(g1 - g0)) <= 1e-12 * np.max(np.abs(g0)), name

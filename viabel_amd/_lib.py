@@ -5,6 +5,7 @@ no MI355X is visible, every compute call raises -- loudly -- instead of silently
 computing something else.
 """
 import ctypes
+import weakref
 import os
 import subprocess
 import threading
@@ -197,6 +198,12 @@ SIGNATURES = {
     'vb_comm_ipc_window': (ctypes.c_int, [_ctx_p, ctypes.c_size_t, ctypes.c_char_p]),
     'vb_comm_init_ipc': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_check': (ctypes.c_int, [_ctx_p]),
+    'vb_legacy_round_end': (ctypes.c_int, [_ctx_p, ctypes.c_void_p]),
+    'vb_legacy_ahead_stats': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                            ctypes.POINTER(ctypes.c_uint64)]),
+    'vb_fullrank_upload_stats': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_uint64)]),
+    'vb_host_alloc': (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    'vb_host_free': (ctypes.c_int, [ctypes.c_void_p]),
     'vb_comm_allreduce_time': (ctypes.c_int, [_ctx_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     'vb_comm_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'vb_comm_init': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
@@ -278,6 +285,60 @@ def device_count():
     """GPUs visible to HIP (0 without one)."""
     n = ctypes.c_int(0)
     return n.value if load().vb_device_count(ctypes.byref(n)) == VB_OK else 0
+
+
+class PinnedPool:
+    """Page-locked host blocks (``vb_host_alloc``) handed out as the float64 arrays the engine RETURNS.
+
+    The reference returns a freshly allocated gradient per call (``objectives.py:32-44``); so does this binding, but a
+    4.2-MB gradient copied into pageable memory is staged by the runtime (118 us at D = 1024: 36 GB/s), while the copy
+    engine writes straight into a pinned block.  ``array(n)`` is an ordinary ``ndarray`` whose memory is such a block; when
+    the array (and every view of it) is gone the block returns to the free list of its size and the next call reuses it --
+    an optimiser loop that drops its gradients cycles through two or three blocks.  At most ``keep`` idle blocks per size
+    stay allocated; arrays smaller than ``MIN_BYTES`` are plain ``np.empty`` (the small-result path copies through the
+    engine's own mapped buffer anyway)."""
+
+    MIN_BYTES = 1 << 20
+
+    def __init__(self, lib, keep=4):
+        self._lib, self._keep, self._free = lib, keep, {}
+
+    def array(self, n):
+        nbytes = 8 * int(n)
+        if nbytes < self.MIN_BYTES:
+            return np.empty(n, dtype=np.float64)
+        free = self._free.setdefault(nbytes, [])
+        if free:
+            ptr = free.pop()
+        else:
+            box = ctypes.c_void_p()
+            if self._lib.vb_host_alloc(nbytes, ctypes.byref(box)) != VB_OK or not box.value:
+                return np.empty(n, dtype=np.float64)          # (no pinned memory left: a pageable array still works)
+            ptr = box.value
+        buf = (ctypes.c_double * int(n)).from_address(ptr)
+        weakref.finalize(buf, self._give_back, nbytes, ptr)     # buf is the array's base: it dies with the last view
+        return np.frombuffer(buf, dtype=np.float64)
+
+    def _give_back(self, nbytes, ptr):
+        free = self._free.setdefault(nbytes, [])
+        if len(free) < self._keep:
+            free.append(ptr)
+        else:
+            self._lib.vb_host_free(ptr)
+
+    def idle_blocks(self):
+        return sum(len(v) for v in self._free.values())
+
+
+_pinned_pool = None
+
+
+def pinned_array(n):
+    """A float64 result array of ``n`` entries in page-locked memory (see :class:`PinnedPool`)."""
+    global _pinned_pool
+    if _pinned_pool is None:
+        _pinned_pool = PinnedPool(load())
+    return _pinned_pool.array(n)
 
 
 class Engine:
@@ -414,6 +475,17 @@ class Engine:
             return None
         self._check(rc)
         return out if to_host else True
+
+    def legacy_round_end(self, rng_handle):
+        """A call's device draws from ``rng_handle`` are done (``vb_legacy_round_end``): the engine may start the next call's
+        -- the same requests, from the generator's current state -- beside the kernels that follow."""
+        self._check(self._lib.vb_legacy_round_end(self._ctx, rng_handle))
+
+    def legacy_ahead_stats(self):
+        """``(launched, adopted, discarded)`` of the look-ahead generation of numpy's streams."""
+        a, b, c = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._lib.vb_legacy_ahead_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
 
     def noise_get_host(self, slot, n, d):
         out = np.empty((n, d), dtype=np.float64)
@@ -813,11 +885,17 @@ class Engine:
         theta = _f64(theta)
         p = d + d * (d + 1) // 2
         value = ctypes.c_double(0.0)
-        grad = np.empty(p, dtype=np.float64)
+        grad = pinned_array(p)
         self._check(self._lib.vb_elbo_grad_fullrank(
             self._ctx, slot, n, d, n if n_total is None else n_total, _dptr(theta), flags,
             ctypes.byref(value), _dptr(grad)))
         return value.value, grad
+
+    def fullrank_upload_stats(self):
+        """How many blocking full-rank calls took the pipelined parameter upload (``vb_fullrank_upload_stats``)."""
+        n = ctypes.c_uint64(0)
+        self._check(self._lib.vb_fullrank_upload_stats(self._ctx, ctypes.byref(n)))
+        return n.value
 
     def fullrank_set_theta(self, theta, d):
         theta = _f64(theta)
@@ -830,7 +908,7 @@ class Engine:
     def fullrank_get(self, d):
         p = d + d * (d + 1) // 2
         value = ctypes.c_double(0.0)
-        grad = np.empty(p, dtype=np.float64)
+        grad = pinned_array(p)
         self._check(self._lib.vb_fullrank_get(self._ctx, ctypes.byref(value), _dptr(grad), p))
         return value.value, grad
 

@@ -144,6 +144,13 @@ class _NoiseMixin:
             return
         eng.noise_set_host(slot, rs.randn(n_total, d)[begin:end])
 
+    def _round_end(self, eng, rs, seed):
+        """This call's draws from the family's PERSISTENT generator are done: the engine may start the next call's -- the
+        same requests from the generator's current state -- beside the objective's kernels (``vb_legacy_round_end``).  A
+        fresh ``RandomState(seed)`` (``seed=`` calls, AlphaDivergence) is used once: nothing to look ahead to."""
+        if seed is None and isinstance(rs, LegacyRandomState):
+            eng.legacy_round_end(rs._h)
+
     def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
         """This rank's rows of the family's base noise (what ``sample`` would consume) into ``slot``; returns what stays
         on the host (nothing here).  Default: host draw + upload."""
@@ -183,7 +190,9 @@ class MFGaussian(_NoiseMixin, ApproximationFamily):
         return rs.randn(n_samples, self.dim) if noise is None else noise
 
     def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
-        self._stage_normals(eng, self._random_state(seed), slot, n_total, self.dim, begin, end)
+        rs = self._random_state(seed)
+        self._stage_normals(eng, rs, slot, n_total, self.dim, begin, end)
+        self._round_end(eng, rs, seed)
 
     def _unpack(self, var_param):
         var_param = np.asarray(var_param, dtype=np.float64)
@@ -258,6 +267,7 @@ class MFStudentT(_NoiseMixin, ApproximationFamily):
         rs = self._random_state(seed)
         if (n_total * self.dim >= self._DEVICE_T_FROM and isinstance(rs, LegacyRandomState)
                 and eng.noise_legacy_standard_t(slot, rs._h, self.df, n_total, self.dim, begin, end - begin)):
+            self._round_end(eng, rs, seed)
             return None
         eng.noise_set_host(slot, rs.standard_t(self.df, size=(n_total, self.dim))[begin:end])
         return None
@@ -350,7 +360,9 @@ class FullRankGaussian(_NoiseMixin, ApproximationFamily):
         return rs.randn(n_samples, self.dim) if noise is None else noise
 
     def _stage_base_noise(self, eng, slot, n_total, begin, end, seed=None, slot_aux=None):
-        self._stage_normals(eng, self._random_state(seed), slot, n_total, self.dim, begin, end)
+        rs = self._random_state(seed)
+        self._stage_normals(eng, rs, slot, n_total, self.dim, begin, end)
+        self._round_end(eng, rs, seed)
 
     def _unpack(self, var_param):
         var_param = np.asarray(var_param, dtype=np.float64)
@@ -458,6 +470,7 @@ class MultivariateT(_NoiseMixin, ApproximationFamily):
         if chi is None and not on_device:
             chi = rs.chisquare(self.df, n_total)
         self._stage_normals(eng, rs, slot, n_total, self.dim, begin, end)
+        self._round_end(eng, rs, seed)
         return chi
 
     def _unpack(self, var_param):
@@ -562,6 +575,7 @@ class LRGaussian(_NoiseMixin, ApproximationFamily):
         if self._k > 0:
             self._stage_normals(eng, rs, slot_aux, n_total, self._k, begin, end)
         self._stage_normals(eng, rs, slot, n_total, self.dim, begin, end)
+        self._round_end(eng, rs, seed)
         return None
 
     def _device_family(self):

@@ -4,6 +4,8 @@
 
 #include <mutex>
 
+static void legacy_spec_poll(vb_ctx* ctx);      // (look-ahead draws of numpy's streams: defined with the legacy entry points)
+
 namespace vb {
 
 static std::string g_last_error;
@@ -156,7 +158,10 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
   bool seen = false;
   for (unsigned spins = 0; spins < 2000000u && !seen; ++spins) {      // ~10 ms, then the stream
     seen = *word == seq;
-    if (!seen) __builtin_ia32_pause();
+    if (!seen) {
+      __builtin_ia32_pause();
+      if ((spins & 255u) == 255u) ::legacy_spec_poll(ctx);      // (a look-ahead draw's finish may have landed: start the next one)
+    }
   }
   if (!seen) VB_HIP(ctx, hipStreamSynchronize(st));
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -229,6 +234,13 @@ int sync_streams(vb_ctx* ctx) {
   }
   if (ctx->mvt_side) VB_HIP(ctx, hipStreamSynchronize(ctx->mvt_side));
   if (ctx->fit_copy_st) VB_HIP(ctx, hipStreamSynchronize(ctx->fit_copy_st));
+  if (ctx->up_stream) {
+    VB_HIP(ctx, hipStreamSynchronize(ctx->up_stream));
+    VB_HIP(ctx, hipStreamSynchronize(ctx->up_side[0]));
+    VB_HIP(ctx, hipStreamSynchronize(ctx->up_side[1]));
+  }
+  if (ctx->legacy_spec && ctx->legacy_spec->stream) VB_HIP(ctx, hipStreamSynchronize(ctx->legacy_spec->stream));
+  ctx->fr_busy = false;
   ctx->pipe.post_pending = false;
   return comm_check(ctx);
 }
@@ -505,6 +517,33 @@ int vb_destroy(vb_ctx* ctx) {
     (void)hipEventDestroy(ctx->mvt_ev_join);
   }
   if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
+  if (ctx->legacy_spec) {
+    LegacySpec* S = ctx->legacy_spec;
+    if (S->stream) {
+      (void)hipStreamSynchronize(S->stream);
+      (void)hipStreamDestroy(S->stream);
+    }
+    if (S->ev_main) (void)hipEventDestroy(S->ev_main);
+    if (S->land_host) (void)hipHostFree(S->land_host);
+    for (DeviceBuffer& b : S->shadow)
+      if (b.ptr) (void)hipFree(b.ptr);
+    if (S->work.ptr) (void)hipFree(S->work.ptr);
+    if (S->clone) vb_legacy_rng_destroy(S->clone);
+    delete S;
+    ctx->legacy_spec = nullptr;
+  }
+  if (ctx->up_stream) {
+    (void)hipStreamSynchronize(ctx->up_stream);
+    (void)hipStreamDestroy(ctx->up_stream);
+    for (int i = 0; i < 2; ++i) {
+      (void)hipStreamSynchronize(ctx->up_side[i]);
+      (void)hipStreamDestroy(ctx->up_side[i]);
+      (void)hipEventDestroy(ctx->up_ev_join[i]);
+    }
+    (void)hipEventDestroy(ctx->up_ev_main);
+    for (hipEvent_t e : ctx->fr_up.ev)
+      if (e) (void)hipEventDestroy(e);
+  }
   if (ctx->fit_copy_st) {
     (void)hipStreamSynchronize(ctx->fit_copy_st);
     (void)hipStreamDestroy(ctx->fit_copy_st);
@@ -782,6 +821,188 @@ int vb_dis_set_temper_prior(vb_ctx* ctx, int kind, int64_t d, double df, const d
   return temper_prior_set(ctx, kind, d, df, loc, scale, log_det_l);
 }
 
+// ---- look-ahead generation of numpy's legacy streams (LegacySpec, vb_common.h) --------------------------------------------
+static int legacy_gamma_device(vb_ctx* ctx, vb_legacy_rng* rng, int prog, double df, double* dst, int64_t ld, int64_t n_total,
+                               int64_t d, int64_t row_begin, int64_t rows, LegacyFinish* defer);
+
+static bool legacy_spec_on() {
+  const char* e = getenv("VB_LEGACY_AHEAD");      // (read per call: the tests switch it)
+  return !(e && atoi(e) == 0);
+}
+
+static void gen_state_get(const vb_legacy_rng* g, LegacyGenState* s) {
+  (void)vb_legacy_rng_get_state(g, s->key, &s->pos, &s->has_gauss, &s->gauss);
+}
+static bool gen_state_same(const LegacyGenState& a, const LegacyGenState& b) {
+  return a.pos == b.pos && a.has_gauss == b.has_gauss && memcmp(a.key, b.key, sizeof a.key) == 0 &&
+         (!a.has_gauss || memcmp(&a.gauss, &b.gauss, sizeof(double)) == 0);
+}
+
+// main <-> speculation: the draw functions take their stream and their scratch from the context
+struct LegacySpecGuard {
+  vb_ctx* ctx;
+  explicit LegacySpecGuard(vb_ctx* c) : ctx(c) { swap(); }
+  ~LegacySpecGuard() { swap(); }
+  void swap() {
+    LegacySpec& S = *ctx->legacy_spec;
+    std::swap(ctx->stream, S.stream);
+    std::swap(ctx->legacy_work, S.work);
+    std::swap(ctx->legacy_poly_at, S.poly_at);
+    std::swap(ctx->legacy_poly_bytes, S.poly_bytes);
+  }
+};
+
+static int64_t noise_row_stride(int64_t d) {
+  int64_t ld = round_up(d, 16);
+  if (ld % 512 == 0) ld += 16;
+  return ld;
+}
+
+static int legacy_spec_create(vb_ctx* ctx) {
+  if (ctx->legacy_spec) return VB_OK;
+  LegacySpec* S = new (std::nothrow) LegacySpec;
+  if (!S) return fail(ctx, VB_ERR_HIP, "out of host memory");
+  ctx->legacy_spec = S;
+  VB_HIP(ctx, hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
+  VB_HIP(ctx, hipEventCreateWithFlags(&S->ev_main, hipEventDisableTiming));
+  VB_HIP(ctx, hipHostMalloc((void**)&S->land_host, kLegacyFinishWords * sizeof(unsigned long long), hipHostMallocMapped));
+  memset(S->land_host, 0, kLegacyFinishWords * sizeof(unsigned long long));
+  VB_HIP(ctx, hipHostGetDevicePointer((void**)&S->land_dev, S->land_host, 0));
+  VB_TRY(vb_legacy_rng_create(0, &S->clone));
+  return VB_OK;
+}
+
+static void legacy_spec_cancel(vb_ctx* ctx) {
+  LegacySpec* S = ctx->legacy_spec;
+  if (!S || !S->active) return;
+  (void)hipStreamSynchronize(S->stream);      // its kernels write the shadows and its scratch: quiescent before anything reuses them
+  S->active = false;
+  S->in_flight = -1;
+  ++S->discarded;
+  if (++S->discard_streak >= 2) S->cooldown = 64;
+}
+
+// enqueue the next unfinished request of the job (nothing in flight): draw kernels + the deferred finish on the speculation's stream
+static void legacy_spec_enqueue_next(vb_ctx* ctx) {
+  LegacySpec& S = *ctx->legacy_spec;
+  if (!S.active || S.failed || S.in_flight >= 0 || S.n_finished >= S.n_reqs) return;
+  const int i = S.n_finished;
+  const LegacyReq& r = S.reqs[i];
+  const LegacyGenState& g = S.state[i];
+  if (vb_legacy_rng_set_state(S.clone, g.key, g.pos, g.has_gauss, g.gauss) != VB_OK) {
+    S.failed = true;
+    return;
+  }
+  int rc = VB_OK;
+  {
+    LegacySpecGuard guard(ctx);
+    const int64_t ld = r.prog == 0 ? 1 : noise_row_stride(r.d);
+    rc = ensure(ctx, S.shadow[i], (size_t)r.rows * ld * sizeof(double));
+    // (the noise slots' invariant -- pad columns [d, ld) hold zeros -- for a buffer that last held another layout)
+    if (rc == VB_OK && r.prog != 0 && (S.shadow_d[i] != r.d || S.shadow_ld[i] != ld)) {
+      if (hipMemsetAsync(S.shadow[i].ptr, 0, S.shadow[i].bytes, ctx->stream) != hipSuccess) rc = VB_ERR_HIP;
+      S.shadow_d[i] = r.d, S.shadow_ld[i] = ld;
+    }
+    if (rc == VB_OK && r.prog == -1) {
+      NoiseSlot view;
+      view.buf = S.shadow[i], view.n = r.rows, view.d = r.d, view.ld = ld;
+      LegacyGenState h = g;
+      rc = legacy_dev_randn(ctx, h.key, &h.pos, &h.has_gauss, &h.gauss, view, r.n_total, r.d, r.row_begin, r.rows, &S.fin);
+      S.head_state = g;      // (no host-drawn head: the finish starts from the request's own start state)
+    } else if (rc == VB_OK) {
+      rc = legacy_gamma_device(ctx, S.clone, r.prog, r.df, (double*)S.shadow[i].ptr, ld, r.n_total, r.d, r.row_begin, r.rows, &S.fin);
+      if (rc == VB_OK) gen_state_get(S.clone, &S.head_state);
+    }
+    if (rc == VB_OK) rc = legacy_finish_launch(ctx, ctx->stream, S.fin, S.land_dev, ++S.seq);
+  }
+  if (rc != VB_OK) {
+    S.failed = true;      // (declined or failed: nothing of this request is ever adopted; the caller draws as before)
+    return;
+  }
+  S.in_flight = i;
+}
+
+// has the request in flight landed?  Then complete it on the host and start the next one.  Cheap when nothing is pending;
+// called from the draw entry points and from fetch_blocking's wait.
+static void legacy_spec_poll(vb_ctx* ctx) {
+  LegacySpec* Sp = ctx->legacy_spec;
+  if (!Sp || !Sp->active || Sp->in_flight < 0) return;
+  LegacySpec& S = *Sp;
+  if (*(volatile unsigned long long*)(S.land_host + 344) != S.seq) return;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  LegacyGenState e = S.head_state;
+  const int rc = legacy_finish_complete(ctx, S.fin, S.land_host, e.key, &e.pos, &e.has_gauss, &e.gauss);
+  const int i = S.in_flight;
+  S.in_flight = -1;
+  if (rc != VB_OK) {
+    S.failed = true;
+    return;
+  }
+  S.state[i + 1] = e;
+  S.n_finished = i + 1;
+  legacy_spec_enqueue_next(ctx);
+}
+
+// The draw `r` of generator `rng` is being asked for: is it the job's next request, from the state the job assumed?  Then wait
+// for it (it has usually landed), and report the shadow to adopt and the generator's end state.  false: not ours (the job, if
+// any, is discarded) -- the caller draws.
+static bool legacy_spec_take(vb_ctx* ctx, vb_legacy_rng* rng, const LegacyReq& r, int* index) {
+  LegacySpec* Sp = ctx->legacy_spec;
+  if (!Sp || !Sp->active) return false;
+  LegacySpec& S = *Sp;
+  const int i = S.n_adopted;
+  LegacyGenState now;
+  gen_state_get(rng, &now);
+  if (!legacy_spec_on() || i >= S.n_reqs || !r.same(S.reqs[i]) || (i <= S.n_finished && !gen_state_same(now, S.state[i])) ||
+      i > S.n_finished) {
+    // (i > n_finished: request i - 1 was adopted, so i <= n_finished always -- kept as a guard)
+    legacy_spec_cancel(ctx);
+    return false;
+  }
+  unsigned spins = 0;
+  while (S.n_finished <= i && !S.failed) {
+    if (S.in_flight < 0) legacy_spec_enqueue_next(ctx);
+    legacy_spec_poll(ctx);
+    if (S.n_finished > i || S.failed) break;
+    if (++spins > 200000u) {      // ~1 ms of polling: the draw is long -- sleep on its stream instead
+      (void)hipStreamSynchronize(S.stream);
+      spins = 0;
+    } else {
+      __builtin_ia32_pause();
+    }
+  }
+  if (S.failed) {
+    legacy_spec_cancel(ctx);
+    return false;
+  }
+  *index = i;
+  return true;
+}
+
+static void legacy_spec_adopted(vb_ctx* ctx, vb_legacy_rng* rng, int i) {
+  LegacySpec& S = *ctx->legacy_spec;
+  const LegacyGenState& e = S.state[i + 1];
+  (void)vb_legacy_rng_set_state(rng, e.key, e.pos, e.has_gauss, e.gauss);
+  ++S.adopted;
+  S.discard_streak = 0;
+  S.n_adopted = i + 1;
+  if (S.n_adopted >= S.n_reqs) S.active = false;      // the job is used up
+}
+
+static void legacy_round_note(vb_ctx* ctx, const vb_legacy_rng* rng, const LegacyReq& r) {
+  if (legacy_spec_create(ctx) != VB_OK) return;
+  LegacySpec& S = *ctx->legacy_spec;
+  if (S.round_rng != rng) {
+    S.round_rng = rng;
+    S.n_round = 0;
+    S.round_overflow = false;
+    S.n_prev = -1;
+    S.discard_streak = S.cooldown = 0;
+  }
+  if (S.n_round < LegacySpec::kMaxReqs) S.round[S.n_round++] = r;
+  else S.round_overflow = true;
+}
+
 int vb_legacy_rng_randn_device(vb_ctx* ctx, vb_legacy_rng* rng, int slot, int64_t n_total, int64_t d, int64_t row_begin,
                                int64_t rows) {
   if (!ctx || !rng) return fail(ctx, VB_ERR_INVALID, "NULL argument");
@@ -791,6 +1012,20 @@ int vb_legacy_rng_randn_device(vb_ctx* ctx, vb_legacy_rng* rng, int slot, int64_
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
   VB_TRY(noise_alloc(ctx, slot, rows, d));
+  LegacyReq req;
+  req.prog = -1, req.n_total = n_total, req.d = d, req.row_begin = row_begin, req.rows = rows, req.slot = slot;
+  int si = 0;
+  legacy_spec_poll(ctx);
+  if (legacy_spec_take(ctx, rng, req, &si)) {      // the look-ahead drew exactly this: its buffer becomes the slot's
+    LegacySpec& S = *ctx->legacy_spec;
+    if (S.shadow[si].bytes >= (size_t)rows * ctx->noise[slot].ld * sizeof(double)) {
+      std::swap(ctx->noise[slot].buf, S.shadow[si]);
+      legacy_spec_adopted(ctx, rng, si);
+      legacy_round_note(ctx, rng, req);
+      return VB_OK;
+    }
+    legacy_spec_cancel(ctx);
+  }
   uint32_t key[624];
   int pos = 0, has_gauss = 0;
   double gauss = 0.0;
@@ -798,6 +1033,7 @@ int vb_legacy_rng_randn_device(vb_ctx* ctx, vb_legacy_rng* rng, int slot, int64_
   const int rc = legacy_dev_randn(ctx, key, &pos, &has_gauss, &gauss, ctx->noise[slot], n_total, d, row_begin, rows);
   if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "device draw not available for this request: draw on the host");
   VB_TRY(rc);
+  legacy_round_note(ctx, rng, req);
   return vb_legacy_rng_set_state(rng, key, pos, has_gauss, gauss);
 }
 
@@ -805,7 +1041,7 @@ int vb_legacy_rng_randn_device(vb_ctx* ctx, vb_legacy_rng* rng, int slot, int64_
 // without a cached normal: while one is cached, the leading values are drawn one at a time by the host generator (each
 // such draw leaves the cache set with probability ~1/2) and copied to their places.
 static int legacy_gamma_device(vb_ctx* ctx, vb_legacy_rng* rng, int prog, double df, double* dst, int64_t ld, int64_t n_total,
-                               int64_t d, int64_t row_begin, int64_t rows) {
+                               int64_t d, int64_t row_begin, int64_t rows, LegacyFinish* defer = nullptr) {
   uint32_t key[624];
   int pos = 0, has_gauss = 0;
   double gauss = 0.0;
@@ -846,8 +1082,15 @@ static int legacy_gamma_device(vb_ctx* ctx, vb_legacy_rng* rng, int prog, double
     }
     i += run;
   }
-  if (o == n_out) return VB_OK;
-  const int rc = legacy_dev_gamma(ctx, prog, df, key, &pos, &has_gauss, &gauss, dst, ld, o, n_total, d, row_begin, rows);
+  if (o == n_out) {
+    if (defer) {      // (nothing left for the device: a look-ahead draw needs a finish to poll -- not this path's case)
+      (void)rewind();
+      return VB_ERR_UNSUPPORTED;
+    }
+    return VB_OK;
+  }
+  const int rc = legacy_dev_gamma(ctx, prog, df, key, &pos, &has_gauss, &gauss, dst, ld, o, n_total, d, row_begin, rows, defer);
+  if (defer && rc == VB_OK) return VB_OK;      // (the generator stands behind the host-drawn head; the caller completes the draw)
   if (rc != VB_OK) {
     (void)rewind();
     if (rc == VB_ERR_UNSUPPORTED) return fail(ctx, VB_ERR_UNSUPPORTED, "device draw not available for this request: draw on the host");
@@ -865,8 +1108,24 @@ int vb_legacy_rng_standard_t_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, 
   VB_HIP(ctx, hipSetDevice(ctx->device));
   VB_TRY(main_stream_write(ctx));
   VB_TRY(noise_alloc(ctx, slot, rows, d));
+  LegacyReq req;
+  req.prog = 1, req.df = df, req.n_total = n_total, req.d = d, req.row_begin = row_begin, req.rows = rows, req.slot = slot;
+  int si = 0;
+  legacy_spec_poll(ctx);
+  if (legacy_spec_take(ctx, rng, req, &si)) {
+    LegacySpec& S = *ctx->legacy_spec;
+    if (S.shadow[si].bytes >= (size_t)rows * ctx->noise[slot].ld * sizeof(double)) {
+      std::swap(ctx->noise[slot].buf, S.shadow[si]);
+      legacy_spec_adopted(ctx, rng, si);
+      legacy_round_note(ctx, rng, req);
+      return VB_OK;
+    }
+    legacy_spec_cancel(ctx);
+  }
   NoiseSlot& ns = ctx->noise[slot];
-  return legacy_gamma_device(ctx, rng, 1, df, (double*)ns.buf.ptr, ns.ld, n_total, d, row_begin, rows);
+  VB_TRY(legacy_gamma_device(ctx, rng, 1, df, (double*)ns.buf.ptr, ns.ld, n_total, d, row_begin, rows));
+  legacy_round_note(ctx, rng, req);
+  return VB_OK;
 }
 
 int vb_legacy_rng_chisquare_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, int64_t n, double* host_out) {
@@ -878,13 +1137,76 @@ int vb_legacy_rng_chisquare_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, i
   ctx->chi_n = 0;
   ctx->chi_ahead.last.valid = ctx->chi_ahead.pre.valid = false;      // (not a Philox request: the look-ahead's history ends)
   ctx->chi_ahead.streak = 0;
-  VB_TRY(legacy_gamma_device(ctx, rng, 0, df, (double*)ctx->chi_dev.ptr, 1, n, 1, 0, n));
+  LegacyReq req;
+  req.prog = 0, req.df = df, req.n_total = n, req.d = 1, req.row_begin = 0, req.rows = n, req.slot = -1;
+  int si = 0;
+  bool adopted = false;
+  legacy_spec_poll(ctx);
+  if (legacy_spec_take(ctx, rng, req, &si)) {
+    LegacySpec& S = *ctx->legacy_spec;
+    if (S.shadow[si].bytes >= (size_t)n * sizeof(double)) {
+      std::swap(ctx->chi_dev, S.shadow[si]);
+      legacy_spec_adopted(ctx, rng, si);
+      adopted = true;
+    } else {
+      legacy_spec_cancel(ctx);
+    }
+  }
+  if (!adopted) VB_TRY(legacy_gamma_device(ctx, rng, 0, df, (double*)ctx->chi_dev.ptr, 1, n, 1, 0, n));
+  legacy_round_note(ctx, rng, req);
   ctx->chi_n = n;
   ctx->chi_df = df;
   if (host_out) {
     VB_HIP(ctx, hipMemcpyAsync(host_out, ctx->chi_dev.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  return VB_OK;
+}
+
+int vb_legacy_round_end(vb_ctx* ctx, vb_legacy_rng* rng) {
+  if (!ctx || !rng) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  LegacySpec* Sp = ctx->legacy_spec;
+  if (!Sp || Sp->round_rng != rng) return VB_OK;      // no device draw of this generator since the last round end
+  LegacySpec& S = *Sp;
+  bool same = !S.round_overflow && S.n_round > 0 && S.n_round == S.n_prev;
+  for (int i = 0; same && i < S.n_round; ++i) same = S.round[i].same(S.prev_round[i]);
+  S.n_prev = S.round_overflow ? -1 : S.n_round;
+  for (int i = 0; i < S.n_round; ++i) S.prev_round[i] = S.round[i];
+  S.n_round = 0;
+  S.round_overflow = false;
+  if (!legacy_spec_on() || !vb_legacy_rng_log_proven()) return VB_OK;
+  if (S.active) {      // (a job whose requests were not all asked for: the rounds changed)
+    legacy_spec_cancel(ctx);
+    return VB_OK;
+  }
+  if (!same) return VB_OK;
+  if (S.cooldown > 0) {
+    if (--S.cooldown == 0) S.discard_streak = 0;
+    return VB_OK;
+  }
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  // the next round's draws, from where the generator stands now.  The shadows were the slots' buffers until the last adoption:
+  // whatever is queued on the main stream may still read them
+  VB_HIP(ctx, hipEventRecord(S.ev_main, ctx->stream));
+  VB_HIP(ctx, hipStreamWaitEvent(S.stream, S.ev_main, 0));
+  S.n_reqs = S.n_prev;
+  for (int i = 0; i < S.n_reqs; ++i) S.reqs[i] = S.prev_round[i];
+  gen_state_get(rng, &S.state[0]);
+  S.n_adopted = S.n_finished = 0;
+  S.in_flight = -1;
+  S.failed = false;
+  S.active = true;
+  ++S.launched;
+  legacy_spec_enqueue_next(ctx);
+  return VB_OK;
+}
+
+int vb_legacy_ahead_stats(vb_ctx* ctx, uint64_t* launched, uint64_t* adopted, uint64_t* discarded) {
+  if (!ctx || !launched || !adopted || !discarded) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  const LegacySpec* S = ctx->legacy_spec;
+  *launched = S ? S->launched : 0;
+  *adopted = S ? S->adopted : 0;
+  *discarded = S ? S->discarded : 0;
   return VB_OK;
 }
 
@@ -1413,6 +1735,30 @@ int vb_elbo_grad_mvt_symroot_path(vb_ctx* ctx, int slot, int64_t n, int64_t d, i
   return elbo_grad_mvt_symroot(ctx, slot, n, d, n_total, df, theta, value, grad, info, true);
 }
 
+int vb_fullrank_upload_stats(vb_ctx* ctx, uint64_t* pipelined_calls) {
+  if (!ctx || !pipelined_calls) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  *pipelined_calls = ctx->fr_up_calls;
+  return VB_OK;
+}
+
+// Page-locked host memory for result arrays (round 6): a 4.2-MB gradient copied into pageable memory is staged by the runtime
+// (118 us at D = 1024: 36 GB/s); into a pinned block the DMA engine writes it directly.  The Python binding hands such
+// blocks out as the numpy arrays it returns and takes them back when the arrays die (viabel_amd/_lib.py: PinnedPool).
+int vb_host_alloc(size_t bytes, void** ptr) {
+  if (!ptr || bytes == 0) return fail(nullptr, VB_ERR_INVALID, "vb_host_alloc: NULL pointer or zero bytes");
+  *ptr = nullptr;
+  const hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(nullptr, VB_ERR_HIP, "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+  return VB_OK;
+}
+
+int vb_host_free(void* ptr) {
+  if (!ptr) return VB_OK;
+  const hipError_t e = hipHostFree(ptr);
+  if (e != hipSuccess) return fail(nullptr, VB_ERR_HIP, "hipHostFree: %s", hipGetErrorString(e));
+  return VB_OK;
+}
+
 int vb_dis_generation(vb_ctx* ctx, int kind, uint64_t* generation) {
   if (!ctx || !generation) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (kind < 0 || kind > 2) return fail(ctx, VB_ERR_INVALID, "DIS state kind %d outside [0, 2]", kind);
@@ -1530,6 +1876,7 @@ int vb_elbo_grad_fullrank_enqueue(vb_ctx* ctx, int slot, int64_t n, int64_t d, i
                 (long long)d);
   if (n_total < n) return fail(ctx, VB_ERR_INVALID, "n_total must be >= n");
   VB_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->fr_busy = true;      // (asynchronous: the next parameter upload must stay behind this evaluation's reads)
   return fr_elbo_grad_enqueue(ctx, ctx->noise[slot], n, d, n_total, (const double*)ctx->fr_theta.ptr,
                               (double*)ctx->fr_out.ptr, flags);
 }
@@ -1554,8 +1901,42 @@ int vb_fullrank_get(vb_ctx* ctx, double* value, double* grad, int64_t p) {
 
 int vb_elbo_grad_fullrank(vb_ctx* ctx, int slot, int64_t n, int64_t d, int64_t n_total,
                           const double* theta, unsigned flags, double* value, double* grad) {
+  if (!ctx || !theta || d <= 0) return fail(ctx, VB_ERR_INVALID, "bad argument");
+  const int64_t p = d + d * (d + 1) / 2;
+  // Round 6, built and MEASURED SLOWER -- off unless VB_FR_UPLOAD_PIPE=1: a parameter too large for the
+  // staged small-copy path (4.2 MB at D = 1024) crosses PCIe in row chunks, heaviest rows of L first, and the sampling
+  // product of a chunk's column blocks starts behind its copy while the rest is in flight (fr_upload_begin); the noise
+  // generated for this call (already queued on the main stream) runs beside the first chunk.  Results are bit-identical
+  // (tests/test_gpu_fetch_routes.py).  tools/r6_api_call_probe.py, D = 1024 / N = 4096, blocking call with a pinned
+  // gradient array: one copy + synchronisation in front 539 us; this route with 1 / 2 / 3 / 4 chunks 561 / 612 / 636 /
+  // 708 us from a pageable parameter and 556 / 572 / 586 / 605 us from a pinned one.  Every hipMemcpyAsync costs 15-35 us
+  // whatever its size (a pageable source is pinned and unpinned per call), every cross-stream event wait ~10 us: the ~70 us
+  // of overlap the chunks buy are spent twice over.  What did pay: the gradient lands in page-locked memory (vb_host_alloc,
+  // PinnedPool in the Python binding): 549 -> 539 us.
+  const char* pe = getenv("VB_FR_UPLOAD_PIPE");      // (read per call: the tests switch it)
+  const bool pipe_env = pe && atoi(pe) != 0;
+  const bool pipelined = pipe_env && !ctx->comm && (size_t)p * sizeof(double) > kFetchMaxBytes && d % 16 == 0 &&
+                         !(flags & VB_FLAG_PATH_DERIV);
+  if (pipelined) {
+    VB_HIP(ctx, hipSetDevice(ctx->device));
+    VB_TRY(ensure(ctx, ctx->fr_theta, (size_t)p * sizeof(double)));
+    VB_TRY(ensure(ctx, ctx->fr_out, (size_t)(1 + p) * sizeof(double)));
+    VB_TRY(main_stream_write(ctx));
+    ctx->fr_p = p;
+    VB_TRY(fr_upload_begin(ctx, theta, d));
+    ++ctx->fr_up_calls;
+    const int rc = vb_elbo_grad_fullrank_enqueue(ctx, slot, n, d, n_total, flags);
+    ctx->fr_busy = false;
+    if (rc != VB_OK) {
+      ctx->fr_up_active = false;
+      (void)hipStreamSynchronize(ctx->up_stream);      // the caller's array must not be read after we return
+      return rc;
+    }
+    return vb_fullrank_get(ctx, value, grad, p);
+  }
   VB_TRY(vb_fullrank_set_theta(ctx, theta, d));
   VB_TRY(vb_elbo_grad_fullrank_enqueue(ctx, slot, n, d, n_total, flags));
+  ctx->fr_busy = false;
   return vb_fullrank_get(ctx, value, grad, d + d * (d + 1) / 2);
 }
 

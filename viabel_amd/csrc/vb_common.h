@@ -150,6 +150,8 @@ struct ResultSlot {
 
 }  // namespace vb
 
+namespace vb { struct LegacySpec; }
+
 struct vb_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -289,12 +291,29 @@ struct vb_ctx {
   vb::DeviceBuffer fr_theta;            // full-rank: resident flat parameter
   vb::DeviceBuffer fr_out;              // full-rank: [value | grad] on the device
   int64_t fr_p = 0;                     // length of the resident full-rank parameter
+  // the blocking call's pipelined parameter upload (vb_elbo_grad_fullrank, round 6): the flat parameter crosses PCIe in
+  // row chunks of L, HEAVIEST rows first, on `up_stream`; behind each chunk its columns of L' are unpacked and an event is
+  // recorded; the sampling product of a chunk's column blocks starts behind its event (column block b of Z = E L' + mu needs
+  // rows [64 b, 64 b + 64) of L only) while the lighter rows are still in flight.
+  struct FrUpload {
+    int n_chunks = 0;
+    int bn_begin[4] = {0, 0, 0, 0}, bn_count[4] = {0, 0, 0, 0};      // column blocks of 64 per chunk, chunk 0 = the last rows
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};           // behind chunk c's copy + unpack
+    bool consumed = false;               // the pipeline started the sampling product chunk by chunk (else it waits for ev[last])
+  } fr_up;
+  bool fr_up_active = false;            // fr_up describes THIS evaluation's parameter
+  bool fr_busy = false;                 // an asynchronous evaluation (vb_elbo_grad_fullrank_enqueue) may still read fr_theta / fr_lt
+  hipStream_t up_stream = nullptr;      // copies + unpacks of the chunks
+  hipStream_t up_side[2] = {nullptr, nullptr};   // sampling products of chunks 1, 2 (chunk 0's runs on the main stream)
+  hipEvent_t up_ev_main = nullptr, up_ev_join[2] = {nullptr, nullptr};
+  uint64_t fr_up_calls = 0;             // evaluations that took the pipelined route (observability: tests)
   // numpy's legacy normal stream on the device (vb_legacy_dev.hip): scratch; where the jump polynomials were uploaded
   vb::DeviceBuffer alpha_g;             // AlphaDivergence, correlated-Gaussian target: G of the samples (see FrWeighted::g_ready)
   vb::DeviceBuffer legacy_work;
   const void* legacy_poly_at = nullptr;
   size_t legacy_poly_bytes = 0;
   bool legacy_table_ready = false;      // the double-double log's table is in this device's constant memory
+  vb::LegacySpec* legacy_spec = nullptr;   // look-ahead generation of the next call's numpy-stream draws (created on first use)
   double* legacy_pin = nullptr;         // pinned staging of the device draw's results
   size_t legacy_pin_doubles = 0;
   // fused full-rank evaluation (vb_fullrank_fused.h): ticket counter, error word and tile flags; the work list
@@ -412,8 +431,11 @@ int user_model_set(vb_ctx* ctx, int64_t dim, const char* source, const double* p
 int user_rows_enqueue(vb_ctx* ctx, hipStream_t st, const double* Z, int64_t ldz, int64_t n, int d, double* G,
                       int64_t ldg, double* f);
 void user_model_release(vb_ctx* ctx);
+struct LegacyFinish;
+// (defer != nullptr: the kernels are enqueued, the state is left untouched and *defer describes the finish -- exact path only,
+// VB_ERR_UNSUPPORTED otherwise)
 int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, double* gauss, const NoiseSlot& ns,
-                     int64_t n_total, int64_t d, int64_t row_begin, int64_t rows);
+                     int64_t n_total, int64_t d, int64_t row_begin, int64_t rows, LegacyFinish* defer = nullptr);
 // numpy's legacy word stream on the device (vb_legacy_dev.hip) for the draws built on it (vb_legacy_gamma.hip)
 struct FetchSeg {                  // `bytes` (a multiple of 8) from device address `src` (8-byte aligned) to host address `dst`
   const void* src;
@@ -429,6 +451,26 @@ struct LegacyWords {
   uint32_t* key_io = nullptr;        // 624 words: the uploaded key; legacy_mt_finish_fetch gathers the end block here
   int64_t* meta = nullptr;           // 2 scalars of that gather: [status, new position]
 };
+// What the host still has to do when a device draw's kernels have run (legacy_dev_randn / legacy_dev_gamma with `defer`):
+// find the generator's end block, bring the draw's scalars and that block to the host, decide whether the draw stands
+// (word budget), and form the generator's new state.  The blocking draws do all of it at once (legacy_mt_finish_fetch);
+// the look-ahead draws of round 6 (LegacySpec, vb_api.hip) launch it behind the draw on their own stream
+// (legacy_finish_launch), poll for it from the main thread's waits and complete it when the next call asks for the values.
+struct LegacyFinish {
+  LegacyWords lw;
+  const int64_t* src_dev = nullptr;      // consumed words w_star = mult * (src_dev[0] + add)
+  int64_t mult = 0, add = 0;
+  const void* extra_src[2] = {nullptr, nullptr};      // up to two segments of at most 8 int64 each
+  int extra_words[2] = {0, 0};
+  int kind = 0;                          // 0: randn (extras: 4 scalars | accepted pairs), 1: gamma-based (extras: 4 end scalars)
+  int64_t pairs = 0, n_vals = 0;         // randn
+  int pos_in = 0;
+};
+constexpr int kLegacyFinishWords = 352;      // uint64 words of the host landing area: [extras 16 | block 312 | meta 2 | w | ... | done]
+int legacy_finish_launch(vb_ctx* ctx, hipStream_t st, const LegacyFinish& f, unsigned long long* landing_dev, unsigned long long seq);
+// VB_OK: the draw stands, (key, pos, has_gauss, gauss) are the generator's state behind it; VB_ERR_UNSUPPORTED: declined
+int legacy_finish_complete(vb_ctx* ctx, const LegacyFinish& f, const unsigned long long* landing, uint32_t key[624], int* pos,
+                           int* has_gauss, double* gauss);
 int legacy_mt_words(vb_ctx* ctx, const uint32_t key[624], int pos, int64_t n_words, size_t extra_u32, LegacyWords* out);
 int legacy_mt_finish(vb_ctx* ctx, const LegacyWords& lw, int64_t w_star, uint32_t key[624], int* pos);
 // The same with the end position still on the device: w_star = mult * (src_dev[0] + add).  A one-workgroup kernel finds
@@ -441,8 +483,67 @@ int legacy_mt_finish_fetch(vb_ctx* ctx, const LegacyWords& lw, const int64_t* sr
 // chisquare (prog 0) / standard_t (prog 1) draws, values o_first ... n - 1 of the request, into rows of a noise-slot-like
 // array (vb_legacy_gamma.hip); the generator must hold no cached normal
 int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* pos, int* has_gauss, double* gauss,
-                     double* dst, int64_t ld, int64_t o_first, int64_t n_total, int64_t d, int64_t row_begin, int64_t rows);
+                     double* dst, int64_t ld, int64_t o_first, int64_t n_total, int64_t d, int64_t row_begin, int64_t rows,
+                     LegacyFinish* defer = nullptr);
 void vb_legacy_finish_pairs(const double* list, int64_t n, double* fixed);      // vb_legacy_rng.cpp (host libm)
+
+// ---- look-ahead generation of numpy's legacy streams (round 6; vb_api.hip: legacy_spec_*) --------------------------------
+// A family in the reference-identical mode asks for the same draws call after call (randn(N, D); standard_t(df, (N, D));
+// chisquare(df, N) then randn(N, D)) from one persistent RandomState.  The draws' host decisions need the generator's state
+// BEFORE them, and that is known the moment the previous call's draws are complete: at the end of a call's draws
+// (vb_legacy_round_end) the NEXT call's draws are started from that state on a stream of their own, into shadow buffers,
+// with scratch of their own -- beside the objective's kernels, which the reference-identical mode used to run strictly
+// behind 0.3-1.1 ms of generation.  A draw request that finds the generator where the speculation started (all 624 words,
+// position, cached normal) and asks for exactly what was speculated adopts the shadow by a pointer swap and sets the
+// generator to the speculated end state; anything else (a host draw in between, another shape, a reseed) discards the
+// speculation and draws as before -- values and states are numpy's either way.  No thread: the second request of a round
+// is enqueued from the main thread's waits (fetch_blocking polls legacy_spec_poll) once the first one's finish has landed.
+struct LegacyReq {
+  int prog = -2;            // -1: randn, 0: chisquare, 1: standard_t
+  double df = 0.0;
+  int64_t n_total = 0, d = 0, row_begin = 0, rows = 0;
+  int slot = -1;
+  bool same(const LegacyReq& o) const {
+    return prog == o.prog && df == o.df && n_total == o.n_total && d == o.d && row_begin == o.row_begin && rows == o.rows &&
+           slot == o.slot;
+  }
+};
+struct LegacyGenState {
+  uint32_t key[624];
+  int pos = 0, has_gauss = 0;
+  double gauss = 0.0;
+};
+struct LegacySpec {
+  static constexpr int kMaxReqs = 3;
+  LegacyReq round[kMaxReqs], prev_round[kMaxReqs];      // the draws since the last round end; of the round before
+  int n_round = 0, n_prev = -1;
+  const void* round_rng = nullptr;
+  bool round_overflow = false;
+  bool active = false, failed = false;
+  LegacyReq reqs[kMaxReqs];
+  int n_reqs = 0, n_adopted = 0, n_finished = 0, in_flight = -1;
+  LegacyGenState state[kMaxReqs + 1];      // state[i]: the generator before request i
+  LegacyGenState head_state;               // ... and behind the host-drawn head of the request in flight
+  LegacyFinish fin;
+  DeviceBuffer shadow[kMaxReqs];
+  int64_t shadow_d[kMaxReqs] = {0, 0, 0}, shadow_ld[kMaxReqs] = {0, 0, 0};      // layout the shadow's pad columns are zero for
+  DeviceBuffer work;                   // the speculation's own scratch (ctx->legacy_work's twin) and what goes with it
+  const void* poly_at = nullptr;
+  size_t poly_bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_main = nullptr;
+  unsigned long long* land_host = nullptr;   // mapped landing area of the deferred finish (kLegacyFinishWords)
+  unsigned long long* land_dev = nullptr;
+  unsigned long long seq = 0;
+  ::vb_legacy_rng* clone = nullptr;
+  uint64_t launched = 0, adopted = 0, discarded = 0;
+  // a caller whose rounds look alike but whose generator moves in between (host draws: a chi-square vector below the device
+  // gate, sample() calls) would pay a wasted generation and a wait for it every call: two jobs discarded in a row stop the
+  // speculation for the next 64 rounds of this generator
+  int discard_streak = 0, cooldown = 0;
+};
+
+
 // log density of the installed tempering prior (ctx->temper.kind != 0) at the rows of X
 int mvt_dis_clip_enqueue(vb_ctx* ctx, int64_t n_total, double threshold);
 int mvt_dis_scalars_get(vb_ctx* ctx, double out[4]);
@@ -546,6 +647,7 @@ struct FitStep;
 // optimiser step of the dense family fused with the unpack of the stepped parameter (vb_fit): theta <- step(theta, grad)
 // and mu, L' of the NEW theta into fr_lt in one kernel; the next evaluation of `theta_dev` skips its unpack
 int fr_step_unpack_enqueue(vb_ctx* ctx, const FitStep& a, int64_t d);
+int fr_upload_begin(vb_ctx* ctx, const double* theta_host, int64_t d);
 int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int D, int64_t ldl, double* Lt, double* mu,
                       double* theta_copy = nullptr);
 int fr_tri_inverse_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, const double* Lt, int D, int64_t ldl,

@@ -767,6 +767,110 @@ int fr_unpack_enqueue(vb_ctx* ctx, hipStream_t st, const double* theta_dev, int 
   return VB_OK;
 }
 
+// ---- the blocking call's pipelined parameter upload (FrUpload, vb_common.h) -------------------------------------------
+// L' columns [32 jt0, 32 (jt0 + gridDim.y)) from the flat parameter: fr_unpack_kernel's tiles with the column tile index
+// offset by jt0; mu is written by the launch that has with_mu set.
+__global__ void __launch_bounds__(256) fr_unpack_cols_kernel(const double* __restrict__ theta, int d, int64_t ldl,
+                                                             double* __restrict__ Lt, double* __restrict__ mu, int jt0,
+                                                             int with_mu) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k0 = blockIdx.x * 32, j0 = (jt0 + (int)blockIdx.y) * 32;
+  if (with_mu && blockIdx.y == 0) {
+    const int i = k0 + (int)threadIdx.x;
+    if (threadIdx.x < 32 && i < d) mu[i] = theta[i];
+  }
+  if (k0 > j0 + 31) {            // below the diagonal of L' (k > j): zeros
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int k = k0 + r, j = j0 + tx;
+      if (k < d && j < d) Lt[(int64_t)k * ldl + j] = 0.0;
+    }
+    return;
+  }
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {       // read L[j0 + r][k0 + tx]
+    const int j = j0 + r, k = k0 + tx;
+    double v = 0.0;
+    if (j < d && k <= j) {
+      v = theta[d + (int64_t)j * (j + 1) / 2 + k];
+      if (k == j) v = exp(v);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, j = j0 + tx;
+    if (k < d && j < d) Lt[(int64_t)k * ldl + j] = tile[tx][r];
+  }
+}
+
+// Start the upload of `theta_host` (caller's pageable array) into ctx->fr_theta and its unpacked copy (ctx->fr_lt): mu and
+// the LAST rows of L first.  The sampling product Z = E L' + mu cuts its k range per column block (tri_mode 1), so column
+// block b needs rows [64 b, 64 b + 64) of L -- contiguous in the flat parameter -- and the heaviest blocks need the last
+// rows: they go first, their product starts behind the first chunk's event, and the light blocks' rows arrive while the
+// heavy tiles run.  Three chunks of about equal bytes (boundaries at multiples of 64 rows).  Everything else that reads the
+// parameter is ordered behind the last chunk's event by fr_pipeline_enqueue.
+int fr_upload_begin(vb_ctx* ctx, const double* theta_host, int64_t d) {
+  vb_ctx::FrUpload& U = ctx->fr_up;
+  const int D = (int)d;
+  const int64_t ldl = round_up(d, 16);
+  const int tn = gemm_tiles(D, 64);
+  if (!ctx->up_stream) {
+    VB_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      VB_HIP(ctx, hipStreamCreateWithFlags(&ctx->up_side[i], hipStreamNonBlocking));
+      VB_HIP(ctx, hipEventCreateWithFlags(&ctx->up_ev_join[i], hipEventDisableTiming));
+    }
+    VB_HIP(ctx, hipEventCreateWithFlags(&ctx->up_ev_main, hipEventDisableTiming));
+    for (int c = 0; c < 4; ++c) VB_HIP(ctx, hipEventCreateWithFlags(&U.ev[c], hipEventDisableTiming));
+  }
+  VB_TRY(ensure(ctx, ctx->fr_lt, (size_t)(ldl + d * ldl) * sizeof(double)));
+  double* mu = (double*)ctx->fr_lt.ptr;
+  double* Lt = mu + ldl;
+  double* dev = (double*)ctx->fr_theta.ptr;
+  // chunk boundaries in column blocks of 64: equal areas of the triangle, from the bottom
+  const char* ce = getenv("VB_FR_UPLOAD_CHUNKS");      // (experiments; read per call)
+  const int want = ce ? atoi(ce) : 3;
+  int nc = want < 1 ? 1 : want > 4 ? 4 : want;
+  if (nc > tn) nc = tn;
+  int edge[5];
+  edge[0] = tn;
+  for (int c = 1; c < nc; ++c) {
+    int e = (int)(tn * sqrt((double)(nc - c) / nc) + 0.5);
+    if (e >= edge[c - 1]) e = edge[c - 1] - 1;
+    if (e < nc - c) e = nc - c;
+    edge[c] = e;
+  }
+  edge[nc] = 0;
+  U.n_chunks = nc;
+  U.consumed = false;
+  hipStream_t us = ctx->up_stream;
+  // what is in flight on the main stream may still read the previous parameter
+  VB_HIP(ctx, hipEventRecord(ctx->up_ev_main, ctx->stream));
+  if (ctx->fr_busy) VB_HIP(ctx, hipStreamWaitEvent(us, ctx->up_ev_main, 0));
+  ctx->fr_busy = false;
+  VB_HIP(ctx, hipMemcpyAsync(dev, theta_host, (size_t)d * sizeof(double), hipMemcpyHostToDevice, us));      // mu
+  for (int c = 0; c < nc; ++c) {
+    const int b0 = edge[c + 1], b1 = edge[c];
+    const int64_t r0 = (int64_t)b0 * 64, r1 = (int64_t)b1 * 64 < d ? (int64_t)b1 * 64 : d;
+    const int64_t o0 = d + r0 * (r0 + 1) / 2, o1 = d + r1 * (r1 + 1) / 2;
+    U.bn_begin[c] = b0;
+    U.bn_count[c] = b1 - b0;
+    VB_HIP(ctx, hipMemcpyAsync(dev + o0, theta_host + o0, (size_t)(o1 - o0) * sizeof(double), hipMemcpyHostToDevice, us));
+    const int jt0 = (int)(r0 / 32), jt1 = (int)((r1 + 31) / 32);
+    hipLaunchKernelGGL(fr_unpack_cols_kernel, dim3((unsigned)((D + 31) / 32), (unsigned)(jt1 - jt0)), dim3(256), 0, us,
+                       (const double*)dev, D, ldl, Lt, mu, jt0, c == 0 ? 1 : 0);
+    VB_HIP(ctx, hipGetLastError());
+    VB_HIP(ctx, hipEventRecord(U.ev[c], us));
+  }
+  ctx->fr_up_active = true;
+  ctx->fr_lt_d = d;                 // the unpacked copy is (being made) current: the pipeline must not unpack again
+  ctx->fr_lt_owner = nullptr;
+  return VB_OK;
+}
+
 // ---- optimiser step + unpack in one kernel (vb_fit, dense family) --------------------------------------------------------
 // The loop used to run fit_step_kernel (5.9 us at D = 1024) and, at the top of the next evaluation, fr_unpack_kernel
 // (6.6 us) on the parameter it had just written.  Same tiling as the unpack: a 32 x 32 tile of the packed triangle is
@@ -1300,6 +1404,20 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   }
   S.sums = base + o_sums + (int64_t)set * S.len;
 
+  // a pipelined upload of this evaluation's parameter is in flight (vb_elbo_grad_fullrank): the sampling product below may
+  // consume it chunk by chunk; whoever else reads the parameter or its unpacked copy first waits for the last chunk
+  vb_ctx::FrUpload* up = (ctx->fr_up_active && !mvt && lt_cached) ? &ctx->fr_up : nullptr;
+  ctx->fr_up_active = false;
+  bool up_waited = false;
+  auto up_wait_all = [&]() -> int {
+    if (up && !up_waited) {
+      VB_HIP(ctx, hipStreamWaitEvent(st, up->ev[up->n_chunks - 1], 0));
+      up_waited = true;
+    }
+    return VB_OK;
+  };
+  if (up && pd) VB_TRY(up_wait_all());      // (the triangular inverse reads the whole parameter at once)
+
   if (mvt) {
     VB_HIP(ctx, hipMemcpyAsync(mu, mu_dev, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, st));
     VB_HIP(ctx, hipMemcpy2DAsync(Lt, (size_t)ldl * sizeof(double), root_dev, (size_t)ldl * sizeof(double),
@@ -1382,6 +1500,30 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
       Z = const_cast<double*>(wm.z_ready);
       return;
     }
+    if (up && !up_waited && kparts == 1 && cfg == 0 && !row_scale && gemm_uses_dma(g1) && up->n_chunks > 1 &&
+        gemm_count_blocks(g1, 128, 64) < 4L * n_cu) {
+      // chunk 0 (the heaviest column blocks) on the main stream behind its event; the lighter chunks on side streams
+      // behind theirs (and behind everything the main stream had queued before: the noise), joined below
+      up->consumed = true;
+      (void)hipEventRecord(ctx->up_ev_main, st);
+      for (int c = 0; c < up->n_chunks; ++c) {
+        hipStream_t sc = c == 0 ? st : ctx->up_side[(c - 1) & 1];
+        if (c > 0) (void)hipStreamWaitEvent(sc, ctx->up_ev_main, 0);
+        (void)hipStreamWaitEvent(sc, up->ev[c], 0);
+        GemmArgs gc = g1;
+        gc.ev0 = gc.ev1 = nullptr;
+        gc.bn_begin = up->bn_begin[c];
+        gc.bn_count = up->bn_count[c];
+        gemm_f64_launch<true>(sc, gc, 1, n_cu, EpiStoreZ{Z, ldz, mu, shift, row_scale}, 4);
+      }
+      for (int i = 0; i < 2 && i < up->n_chunks - 1; ++i) {
+        (void)hipEventRecord(ctx->up_ev_join[i], ctx->up_side[i]);
+        (void)hipStreamWaitEvent(st, ctx->up_ev_join[i], 0);
+      }
+      up_waited = true;      // (the main stream is now behind the last chunk's event as well)
+      return;
+    }
+    (void)up_wait_all();
     if (kparts > 1) {
       gemm_f64_launch<true>(st, g1, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
       hipLaunchKernelGGL(fr_zsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,
@@ -1395,6 +1537,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   // diagonal Gaussian target under the dense Gaussian family: sum f out of the sampling product's epilogue
   const bool diag_f = fast_env && !mvt && m.id == VB_MODEL_GAUSS_DIAG && !wm.roww && !row_scale &&
                       n % kGemmBK == 0 && gemm_uses_dma(g1) && (int64_t)splits <= n_rb;
+  if (m.id == VB_MODEL_GAUSS_DIAG) VB_TRY(up_wait_all());      // (a reducing epilogue: one launch)
   if (m.id == VB_MODEL_GAUSS_DIAG && diag_f) {
     tiles2 = gemm_f64_launch<true>(st, g1, 1, n_cu, EpiGaussDiagF{G, ldz, mu, m.p0, m.p1, fpart});
     fmode = 1;
@@ -1449,6 +1592,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
       g3f.A = G, g3f.lda = ldz, g3f.B = (const double*)ns.buf.ptr, g3f.ldb = ns.ld;
       g3f.M = D, g3f.N = D, g3f.K = (int)n, g3f.tri_mode = 2;
       if (fz_mode == 3) VB_TRY(tri2_tile_map(ctx, D, 128, 64, &g3f.tile_map, &g3f.tile_blocks));
+      VB_TRY(up_wait_all());
       VB_TRY(fr_fused_enqueue(ctx, st, fz_mode, g1, g2, g3f, splits, Z, G, ldz, mu, m.p0, fpart, e3, &tiles2));
     } else {
     sample_gemm(m.p0, cfg1);                         // Z - m
@@ -1556,6 +1700,7 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
 
   const int64_t red_items = slab / 2 > ldz ? slab / 2 : ldz;
   const dim3 red_grid((unsigned)((red_items + 255) / 256));
+  VB_TRY(up_wait_all());      // (the epilogue reads the flat parameter's diagonal)
   if (mvt) {
     hipLaunchKernelGGL(fr_reduce_kernel, red_grid, dim3(256), 0, st, (const double*)Cpart, splits, slab, D, ldl,
                        (const double*)colpart, n_rb, ldz, (const double*)fpart, n_fpart, S, 1);

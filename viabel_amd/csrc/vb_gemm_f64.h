@@ -62,6 +62,11 @@ struct GemmArgs {
   // same XCD (block x runs on XCD x % 8 and each XCD has its own L2)
   const int* tile_map = nullptr;
   int tile_blocks = 0;
+  // tri_mode 1, optional: only the column blocks [bn_begin, bn_begin + bn_count) of the product (bn_count == 0: all) --
+  // the launch covers tiles_m x bn_count tiles in the usual heavy-first order; rows, columns and k ranges keep their
+  // global indices.  (The blocking full-rank call starts the sampling product of the heaviest column blocks while the rest
+  // of the parameter is still crossing PCIe: vb_fullrank.hip, FrUpload.)
+  int bn_begin = 0, bn_count = 0;
   // wave-priority alternation (LDS-DMA kernel): workgroups of generation (linear id / prio_div) & 1 raise their
   // wave priority on even slabs, the others on odd slabs (0: off).  Set by the launcher to the number of CUs.
   int prio_div = 0;
@@ -138,8 +143,9 @@ __global__ void __launch_bounds__(256, AF * NB > 32 ? 1 : 2) gemm_f64_kernel(con
   } else if (g.tri_mode == 1) {
     // first half of the grid: heaviest column blocks (largest k range) in descending order; second half:
     // the light ones ascending, so the two workgroups a CU ends up with sum to the same k range
-    const int idx = blockIdx.x / g.tiles_m, half = (g.tiles_n + 1) / 2;
-    bn = idx < half ? g.tiles_n - 1 - idx : idx - half;
+    const int tn = g.bn_count ? g.bn_count : g.tiles_n;
+    const int idx = blockIdx.x / g.tiles_m, half = (tn + 1) / 2;
+    bn = g.bn_begin + (idx < half ? tn - 1 - idx : idx - half);
     bm = blockIdx.x % g.tiles_m;
   } else {
     bn = blockIdx.x / g.tiles_m;
@@ -433,7 +439,9 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
   const int bm_rows = (cfg == 3 || cfg == 4 || cfg >= 7) ? 64 : 128, bn_cols = cfg >= 7 ? 32 : (cfg == 1 || cfg == 6) ? 128 : 64;
   g.tiles_m = gemm_tiles(g.M, bm_rows);
   g.tiles_n = gemm_tiles(g.N, bn_cols);
-  const dim3 grid(g.tile_map ? (unsigned)g.tile_blocks : (unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1,
+  if (g.bn_count && (g.tri_mode != 1 || g.bn_begin + g.bn_count > g.tiles_n)) g.bn_begin = g.bn_count = 0;
+  const dim3 grid(g.tile_map ? (unsigned)g.tile_blocks
+                             : g.bn_count ? (unsigned)(g.tiles_m * g.bn_count) : (unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1,
                   (unsigned)splits);
   static const int prio_env = getenv("VB_GEMM_PRIO") ? atoi(getenv("VB_GEMM_PRIO")) : 1;
   // (triangular k ranges: the tiles of a CU differ in length anyway, and the alternation costs 1 - 3 us there --

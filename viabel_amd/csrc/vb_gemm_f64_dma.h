@@ -84,9 +84,11 @@ __device__ __forceinline__ void gemm_f64_dma_tile(const GemmArgs& g, const Epi& 
     }
     bn = idx;
   } else if (g.tri_mode == 1 || g.tri_mode == 3) {
-    const int idx = bx / g.tiles_m, half = (g.tiles_n + 1) / 2;
-    bn = idx < half ? g.tiles_n - 1 - idx : idx - half;
+    const int tn = (g.tri_mode == 1 && g.bn_count) ? g.bn_count : g.tiles_n;      // (a column-block sub-range: GemmArgs)
+    const int idx = bx / g.tiles_m, half = (tn + 1) / 2;
+    bn = idx < half ? tn - 1 - idx : idx - half;
     if (g.tri_mode == 3) bn = g.tiles_n - 1 - bn;      // mirrored triangle: column block 0 has the longest k range
+    else bn += g.bn_begin;
     bm = bx % g.tiles_m;
 #ifdef VB_GEMM_CLOCK
     if (bn < g.dbg_bn_min || bn > g.dbg_bn_max) return;

@@ -583,11 +583,75 @@ int legacy_mt_finish_fetch(vb_ctx* ctx, const LegacyWords& lw, const int64_t* sr
   return VB_OK;
 }
 
+namespace {
+// the deferred finish's landing area in mapped host memory (uint64 words): [0, 8) extras 0 | [8, 16) extras 1 | [16, 328) the
+// end block's 624 words | [328, 330) meta | [330] consumed-word source | [344] completion word.  One workgroup.
+__global__ void __launch_bounds__(256) mtd_finish_copy_kernel(const unsigned long long* __restrict__ e0, int n0,
+                                                              const unsigned long long* __restrict__ e1, int n1,
+                                                              const unsigned long long* __restrict__ block,
+                                                              const unsigned long long* __restrict__ meta,
+                                                              const unsigned long long* __restrict__ src,
+                                                              unsigned long long* __restrict__ out, unsigned long long seq) {
+  const int t = threadIdx.x;
+  if (t < n0) out[t] = e0[t];
+  if (t < n1) out[8 + t] = e1[t];
+  for (int i = t; i < kN / 2; i += 256) out[16 + i] = block[i];
+  if (t < 2) out[328 + t] = meta[t];
+  if (t == 0) out[330] = src[0];
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(out + 344, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+int legacy_finish_launch(vb_ctx* ctx, hipStream_t st, const LegacyFinish& f, unsigned long long* landing_dev, unsigned long long seq) {
+  hipLaunchKernelGGL(mtd_key_gather_kernel, dim3(1), dim3(256), 0, st, f.lw.words, f.lw.pre, f.lw.n_words, f.src_dev, f.mult, f.add,
+                     f.lw.key_io, f.lw.meta);
+  hipLaunchKernelGGL(mtd_finish_copy_kernel, dim3(1), dim3(256), 0, st, (const unsigned long long*)f.extra_src[0], f.extra_words[0],
+                     (const unsigned long long*)f.extra_src[1], f.extra_words[1], (const unsigned long long*)f.lw.key_io,
+                     (const unsigned long long*)f.lw.meta, (const unsigned long long*)f.src_dev, landing_dev, seq);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
+int legacy_finish_complete(vb_ctx* ctx, const LegacyFinish& f, const unsigned long long* landing, uint32_t key[624], int* pos,
+                           int* has_gauss, double* gauss) {
+  int64_t e0[8], e1[8], meta[2], wsrc;
+  memcpy(e0, landing, sizeof e0);
+  memcpy(e1, landing + 8, sizeof e1);
+  memcpy(meta, landing + 328, sizeof meta);
+  memcpy(&wsrc, landing + 330, sizeof wsrc);
+  if (f.kind == 0) {
+    if (e1[0] < f.pairs) return VB_ERR_UNSUPPORTED;      // the word budget fell short
+  } else {
+    if (!(e0[0] >= 0 && e0[3] == 0)) return VB_ERR_UNSUPPORTED;
+  }
+  if (meta[0] == 1) return fail(ctx, VB_ERR_STATE, "legacy generator: inconsistent end position");
+  if (meta[0] == 2) {
+    *pos = (int)(f.pos_in + f.mult * (wsrc + f.add));      // still inside the block the draw started in: key unchanged
+  } else {
+    memcpy(key, landing + 16, kN * sizeof(uint32_t));
+    *pos = (int)meta[1];
+  }
+  if (f.kind == 0) {
+    double last_x1f;
+    memcpy(&last_x1f, &e0[3], sizeof last_x1f);
+    *has_gauss = (f.n_vals & 1) ? 1 : 0;
+    *gauss = (f.n_vals & 1) ? last_x1f : 0.0;
+  } else {
+    *has_gauss = e0[1] ? 1 : 0;
+    double cached = 0.0;
+    if (e0[1]) memcpy(&cached, &e0[2], sizeof cached);
+    *gauss = cached;
+  }
+  return VB_OK;
+}
+
 // The draws s.randn(n_total, d) of the generator whose state is (key, pos, has_gauss, gauss): rows [row_begin,
 // row_begin + rows) into `ns`; the state afterwards in the same variables.  VB_ERR_UNSUPPORTED: nothing changed, draw on
 // the host.
 int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, double* gauss, const NoiseSlot& ns,
-                     int64_t n_total, int64_t d, int64_t row_begin, int64_t rows) {
+                     int64_t n_total, int64_t d, int64_t row_begin, int64_t rows, LegacyFinish* defer) {
   hipStream_t st = ctx->stream;
   if (!ctx->legacy_table_ready) {      // (constant memory is per device: once per context, not once per process)
     // log(k / 32) in double-double by the long series on the host: 2 atanh(s), s = (c - 1) / (c + 1), |s| <= 0.17,
@@ -622,6 +686,7 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
   const int64_t n_wg = (attempts + kAttemptsPerWg - 1) / kAttemptsPerWg;
   const int64_t hard_cap = pairs / 8 + 1024;
   const bool exact = vb_glibc_log_locate() != nullptr;
+  if (defer && !exact) return VB_ERR_UNSUPPORTED;
 
   // the caller's part of the scratch (uint32 units, every region 16-byte aligned): cnt | base | hard | ...
   size_t off = 0;
@@ -666,6 +731,14 @@ int legacy_dev_randn(vb_ctx* ctx, uint32_t key[624], int* pos, int* has_gauss, d
                        (const int*)a.hard_cnt, (const int64_t*)hbase, hard_list, scal + 4);
   }
   VB_HIP(ctx, hipGetLastError());
+  if (exact && defer) {      // (look-ahead draw: the finish is launched, polled and completed by the caller)
+    defer->lw = lw;
+    defer->src_dev = scal, defer->mult = 4, defer->add = 1;
+    defer->extra_src[0] = scal, defer->extra_words[0] = 4;
+    defer->extra_src[1] = pbase + n_wg, defer->extra_words[1] = 1;
+    defer->kind = 0, defer->pairs = pairs, defer->n_vals = n_vals, defer->pos_in = *pos;
+    return VB_OK;
+  }
   if (exact) {
     // no list, no host arithmetic: the scalars, the acceptance count and the generator's end block in ONE fetch (the
     // end position is a device scalar: legacy_mt_finish_fetch finds and gathers the block there)

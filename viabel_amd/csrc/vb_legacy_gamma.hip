@@ -544,7 +544,8 @@ __global__ void lg_seed_kernel(uint8_t* entry, int64_t* first, int node) {
 // that fall into rows [row_begin, row_begin + rows) are written to dst (row stride ld).  The state afterwards in
 // (key, pos, has_gauss, gauss).
 int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* pos, int* has_gauss, double* gauss,
-                     double* dst, int64_t ld, int64_t o_first, int64_t n_total, int64_t d, int64_t row_begin, int64_t rows) {
+                     double* dst, int64_t ld, int64_t o_first, int64_t n_total, int64_t d, int64_t row_begin, int64_t rows,
+                     LegacyFinish* defer) {
   hipStream_t st = ctx->stream;
   const double shape = df / 2.0;
   if (!vb_glibc_log_locate() || !(shape > 1.0) || *has_gauss || (prog != 0 && prog != 1)) return VB_ERR_UNSUPPORTED;
@@ -621,6 +622,14 @@ int legacy_dev_gamma(vb_ctx* ctx, int prog, double df, uint32_t key[624], int* p
     hipLaunchKernelGGL(lg_pending_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, a, par, n_chunks);
   }
   VB_HIP(ctx, hipGetLastError());
+  if (defer) {      // (look-ahead draw: the finish is launched, polled and completed by the caller)
+    defer->lw = lw;
+    defer->src_dev = a.end, defer->mult = 2, defer->add = 0;
+    defer->extra_src[0] = a.end, defer->extra_words[0] = 4;
+    defer->extra_src[1] = a.end, defer->extra_words[1] = 0;
+    defer->kind = 1, defer->pairs = 0, defer->n_vals = 0, defer->pos_in = *pos;
+    return VB_OK;
+  }
   int64_t end[4] = {-1, 0, 0, 1};
   const FetchSeg extra[1] = {{a.end, sizeof end, end}};
   int new_pos = *pos;
