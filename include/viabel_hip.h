@@ -344,7 +344,7 @@ int vb_dis_scalars_get(vb_ctx* ctx, double out[4]);
  * copy engine writes directly.  A binding may allocate the arrays it returns from such blocks (the Python one does:
  * viabel_amd/_lib.py, PinnedPool -- the reference returns freshly allocated numpy arrays, objectives.py:32-44).        */
 int vb_host_alloc(size_t bytes, void** ptr);
-int vb_host_free(void* ptr);
+int vb_host_free(void* ptr);      /* NULL: a no-op, as free(NULL) */
 /* The DIS state samples live in the context, one set per family kind (0: mean-field, 1: MultivariateT / dense
  * Gaussian, 2: low-rank Gaussian); every refresh of a kind overwrites its set and bumps its generation counter.  A
  * caller that keeps weights for a later vb_dis_grad_* call compares the counter with the one it saw after its own
