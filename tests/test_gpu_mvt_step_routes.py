@@ -5,7 +5,11 @@
   VB_MVT_SIDE_INVERSE=0  the triangular inverse on the main stream instead of beside the sampling product: same kernels,
                          same inputs -- bit-identical;
   VB_MVT_FLAGSYNC=0      gradient by a device-to-host copy + stream synchronisation instead of mapped memory and a
-                         polled completion word: the same numbers through another door -- bit-identical.
+                         polled completion word: the same numbers through another door -- bit-identical;
+  VB_MVT_FUSED_ROWS=0    (round 6) log p / log prior and maha / log q / c_n by two row kernels instead of one pass over samples
+                         and noise: every sum is formed in the same order -- bit-identical;
+  VB_MVT_CHAIN=0         (round 6) the chain rule's D x D x D product as an MFMA launch + a pack kernel instead of one launch
+                         over the lower 32 x 32 tiles: another order of the k sum -- equal to rounding.
 Parity with the oracle is tests/test_gpu_objectives.py / test_gpu_full_size.py (all switches at their defaults)."""
 import os
 
@@ -67,6 +71,7 @@ def test_step_routes_agree(vb, D, N, df, resample, batches):
     call = lambda: _step(vb, D, N, df, resample, batches, steps=3, seed=D + N)
     base = call()
     for env, exact in (({'VB_MVT_SIDE_INVERSE': '0'}, True), ({'VB_MVT_FLAGSYNC': '0'}, True),
+                       ({'VB_MVT_FUSED_ROWS': '0'}, True), ({'VB_MVT_CHAIN': '0'}, False),
                        ({'VB_MVT_DIRECT': '0'}, False),
                        ({'VB_MVT_DIRECT': '0', 'VB_MVT_SIDE_INVERSE': '0', 'VB_MVT_FLAGSYNC': '0'}, False)):
         other = _with(env, call)

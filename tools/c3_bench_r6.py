@@ -1,0 +1,15 @@
+"""Round 6: the C3 blocking call in a plain loop (for rocprofv3 timelines / kernel stats)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import viabel_amd as vb
+
+D, N, df = 256, 16384, 100
+model, prior, theta = bench._c3_problem(vb, D)
+mode = sys.argv[1] if len(sys.argv) > 1 else 'philox'
+obj = vb.DISInclusiveKL(vb.MultivariateT(D, df, seed=1, rng=mode), model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+                        temper_prior_params=prior, use_resampling=False)
+for _ in range(40):
+    obj(theta)

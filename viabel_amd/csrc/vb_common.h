@@ -731,6 +731,10 @@ int glm_grad_enqueue(vb_ctx* ctx, hipStream_t st, const ModelDev& m, const doubl
 
 // model log density for explicit x (vb_rows.hip)
 int model_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev);
+int model_prior_maha_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev,
+                          const double* prior_mean, const double* prior_ivar, double prior_c0, double* prior_out,
+                          const double* E, int64_t lde, const double* rs, double df, double lq_const, double* maha, double* lq,
+                          double* cn);
 int model_and_prior_logp_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev,
                               const double* prior_mean, const double* prior_ivar, double prior_c0, double* prior_out);
 // G[row] = grad f(x[row]) (row stride ld, pad columns zero), f[row] = f(x[row]) for the bound model

@@ -118,6 +118,57 @@ struct EpiStoreZ {          // Z = acc [* rs_n] + mu - shift   (shift = 0, or th
   }
 };
 
+// The sampling product with the k range of its HEAVY column blocks cut in two (round 6; VB_FR_HSPLIT=1):
+// split 0 (k < k_half, the whole product for the columns whose k range ends there) stores Z as EpiStoreZ does; split 1
+// (k >= k_half: only the column blocks to the right of k_half have any) stores its partial products into `slab`, and
+// fr_zfix_kernel adds them to Z's right half.  Deterministic (fixed order: split 0 + split 1).
+struct EpiStoreZHeavy {
+  double* Z;
+  int64_t ldz;
+  const double* mu;
+  const double* shift;      // may be nullptr
+  double* slab;
+  int k_half;
+  __device__ void operator()(int split, int row, int col, double acc) const {
+    if (split == 0) {
+      double z = acc + mu[col];
+      if (shift) z -= shift[col];
+      Z[(int64_t)row * ldz + col] = z;
+    } else if (col >= k_half) {
+      slab[(int64_t)row * ldz + col] = acc;
+    }
+  }
+  __device__ d2v pair(int split, int row, int col, double a0, double a1) const {
+    if (split == 0) {
+      const d2v m = *reinterpret_cast<const d2v*>(mu + col);
+      d2v z = (d2v){a0 + m.x, a1 + m.y};
+      if (shift) {
+        const d2v sh = *reinterpret_cast<const d2v*>(shift + col);
+        z.x -= sh.x, z.y -= sh.y;
+      }
+      *reinterpret_cast<d2v*>(Z + (int64_t)row * ldz + col) = z;
+      return z;
+    }
+    if (col >= k_half) *reinterpret_cast<d2v*>(slab + (int64_t)row * ldz + col) = (d2v){a0, a1};
+    return (d2v){a0, a1};
+  }
+};
+
+__global__ void __launch_bounds__(256) fr_zfix_kernel(const double* __restrict__ slab, int64_t n, int d, int64_t ldz, int k_half,
+                                                      double* __restrict__ Z) {
+  const int half_pairs = (d - k_half + 1) / 2;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * half_pairs) return;
+  const int64_t row = t / half_pairs;
+  const int c = k_half + 2 * (int)(t % half_pairs);
+  const int64_t idx = row * ldz + c;
+  d2v z = *reinterpret_cast<const d2v*>(Z + idx);
+  const d2v p = *reinterpret_cast<const d2v*>(slab + idx);
+  z.x += p.x;
+  if (c + 1 < d) z.y += p.y;
+  *reinterpret_cast<d2v*>(Z + idx) = z;
+}
+
 // regression targets (VB_MODEL_LOGISTIC with a VB_GLM_* likelihood): eta = Z X' -> R = dloglik / deta and the
 // log-likelihood sum, then G = R X - Z / prior_sd^2 by glm_grad_enqueue (the two GEMMs of vb_logistic.h behind the
 // sampling GEMM)
@@ -1524,6 +1575,20 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
       return;
     }
     (void)up_wait_all();
+    {
+      // experiment: two-way k split of the heavy column blocks only
+      const char* he = getenv("VB_FR_HSPLIT");
+      const int k_half = gemm_tiles(gemm_tiles(D, 2), kGemmBK) * kGemmBK;
+      if (he && atoi(he) != 0 && kparts == 1 && !mvt && !row_scale && gemm_uses_dma(g1) && D % 2 == 0 && D >= 384 &&
+          gemm_count_blocks(g1, 64, 64) <= 2L * n_cu && k_half % 64 == 0 && pslab <= (int64_t)(splits + 1) * slab) {
+        const int hc = atoi(he) == 2 ? 4 : 8;
+        gemm_f64_launch<true>(st, g1, 2, n_cu, EpiStoreZHeavy{Z, ldz, mu, shift, Cpart, k_half}, cfg ? cfg : hc);
+        const int64_t items = n * ((D - k_half + 1) / 2);
+        hipLaunchKernelGGL(fr_zfix_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (const double*)Cpart, n, D, ldz,
+                           k_half, Z);
+        return;
+      }
+    }
     if (kparts > 1) {
       gemm_f64_launch<true>(st, g1, kparts, n_cu, EpiSplitSlab{Cpart, ldz, pslab});
       hipLaunchKernelGGL(fr_zsum_kernel, dim3(sum_blocks), dim3(256), 0, st, (const double*)Cpart, kparts, pslab, n, D, ldz,

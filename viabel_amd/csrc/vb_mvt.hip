@@ -518,6 +518,120 @@ __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __rest
   out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -scale * g;
 }
 
+// The packed chain rule of the direct route in ONE launch (round 6): dL = tril(L^-T M) and d/dmu = L^-T v straight into
+// the flat gradient -- the D x D x D product used to be a full MFMA launch (one 64 x 64 tile per CU, 16 dependent slabs:
+// 14.5 us at D = 256 for 33 MFLOP) followed by a pack kernel (4.9 us).  Here: one workgroup per LOWER 32 x 32 tile of the
+// result (the upper triangle is never needed), k from the tile's first row (L^-T is upper triangular), plain fp64 FMAs on
+// LDS tiles -- 36 workgroups at D = 256, at most 8 slabs of 32 deep.  M = sums + off_c (symmetric, both triangles: the
+// mirrored reduction), v = sums + off_col, (sum w, sum w log q) = sums[1], sums[2]; diagonal tiles also form d/dmu for their
+// rows.  Sums are formed in a fixed order: the same bits on every rank of a sharded job.
+__global__ void __launch_bounds__(256) mvt_chain_kernel(const double* __restrict__ Wt, const double* __restrict__ Lfull,
+                                                        int64_t ld, int d, const double* __restrict__ sums, int64_t off_col,
+                                                        int64_t off_c, double scale, double* __restrict__ out,
+                                                        const double* __restrict__ scale_dev, const double* __restrict__ res) {
+  // four k groups of 64 threads; a group walks its quarter of every 64-deep k step (16 deep per group) with a 4 x 4 micro
+  // tile per thread; the groups' partial tiles are added in group order at the end.  (One group walking the whole k range
+  // in 32-deep steps -- the first version -- was a chain of eight load-wait-multiply rounds: 50 us at D = 256.)
+  __shared__ double buf[4 * 2 * 16 * 33];      // per group: W tile k-major [16][33] | M tile [16][33]; later the partial tiles
+  const int t = threadIdx.x, kg = t >> 6, l = t & 63;
+  int ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+  const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
+  const int i0 = ti * 32, j0 = tj * 32;
+  if (scale_dev) scale *= scale_dev[0];      // (device-resident resampling: scale = sum w / (N M), sum w on the device)
+  const double* __restrict__ M = sums + off_c;
+  double* Wk = buf + kg * (2 * 16 * 33);
+  double* Mk = Wk + 16 * 33;
+  const int r0 = (l >> 3) * 4, c0 = (l & 7) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int k0 = i0; k0 < d; k0 += 64) {
+    const int kb = k0 + 16 * kg;      // this group's 16 k values
+    // W tile: rows i0 .. i0 + 31, k = kb .. kb + 15 (k contiguous in memory): 512 entries, 8 per thread; M tile: k = kb ..
+    // kb + 15, columns j0 .. j0 + 31 (j contiguous).  All sixteen loads are issued UNCONDITIONALLY from clamped addresses and
+    // masked afterwards: a load inside a condition compiles to a branch with its own wait -- sixteen memory round trips
+    // per step instead of one (the first version of this loop: 29 us for the launch)
+    double wv[8], mv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = l + 64 * q;
+      const int i = i0 + (e >> 4), k = kb + (e & 15);
+      wv[q] = Wt[(int64_t)(i < d ? i : d - 1) * ld + (k < d ? k : d - 1)];
+      const int k2 = kb + (e >> 5), j = j0 + (e & 31);
+      mv[q] = M[(int64_t)(k2 < d ? k2 : d - 1) * ld + (j < d ? j : d - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = l + 64 * q;
+      const int r = e >> 4, kk = e & 15, i = i0 + r, k = kb + kk;
+      Wk[kk * 33 + r] = (i < d && k < d && k >= i) ? wv[q] : 0.0;      // upper triangular: zero below the diagonal
+      const int kk2 = e >> 5, c = e & 31, k2 = kb + kk2, j = j0 + c;
+      Mk[kk2 * 33 + c] = (k2 < d && j < d) ? mv[q] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      double w[4], m[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) w[a] = Wk[kk * 33 + r0 + a], m[a] = Mk[kk * 33 + c0 + a];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fma(w[a], m[b], acc[a][b]);
+    }
+    __syncthreads();
+  }
+  // partial tiles -> LDS (group-major), added in group order by the thread that owns the entry
+  double* red = buf;      // [4][32][33]  (4 * 32 * 33 = 4224 doubles = the buffer's size)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) red[(kg * 32 + r0 + a) * 33 + c0 + b] = acc[a][b];
+  __syncthreads();
+  const double w_sum = sums[1], w_logq = sums[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = t + 256 * q, r = e >> 5, c = e & 31;
+    const int i = i0 + r, j = j0 + c;
+    if (i < d && j <= i) {
+      double g = ((red[(0 * 32 + r) * 33 + c] + red[(1 * 32 + r) * 33 + c]) + red[(2 * 32 + r) * 33 + c]) + red[(3 * 32 + r) * 33 + c];
+      if (i == j) g = g * Lfull[(int64_t)i * ld + i] - w_sum;
+      out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -scale * g;
+    }
+  }
+  if (ti == tj) {      // d/dmu for the tile's rows: eight lanes per row over k >= i, combined by shuffles in a fixed order
+    const int r = t >> 3, s8 = t & 7, i = i0 + r;
+    double a = 0.0;
+    if (i < d) {
+      // (eight loads of each operand in flight per round: a plain loop waits for memory once per k -- 32 round trips)
+      for (int kb = i + s8; kb < d; kb += 64) {
+        double wv[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = kb + 8 * u;
+          wv[u] = k < d ? Wt[(int64_t)i * ld + k] : 0.0;
+          vv[u] = k < d ? sums[off_col + k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a = fma(wv[u], vv[u], a);
+      }
+    }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 4, 64);
+    if (s8 == 0 && i < d) out[1 + i] = -scale * a;
+  }
+  if (blockIdx.x == 0 && t == 0) {
+    out[0] = -scale * w_logq;
+    double* tail = out + 1 + d + (int64_t)d * (d + 1) / 2;      // [eps, ess, status, khat | value]: see mvt_pack_grad_kernel
+    for (int q = 0; q < 4; ++q) tail[q] = res[q];
+    tail[4] = -scale * w_logq;
+  }
+}
+
 // theta (host) -> device: mu, L' (o_lt), L (o_lfull), Wt = L^-T (o_wt), Li = L^-1 (o_li), c = L^-1 mu (o_c)
 // zero_scal: the refresh's call also clears the 32 scalars the bisection accumulates into (a gradient at another
 // parameter must leave them alone: eps, ess and the status of the refresh live there)
@@ -636,7 +750,7 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
 // run it: factors_ready)
 static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t n, int64_t d, double df,
                          const double* theta_host, const double* linv_host, int64_t lq_off, bool factors_ready = false,
-                         const NoiseSlot* drawn_here = nullptr) {
+                         const NoiseSlot* drawn_here = nullptr, double* defer_rows = nullptr) {
   const int n_cu = ctx->prop.multiProcessorCount;
   double logdet_half = 0.0;
   for (int64_t j = 0; j < d; ++j) logdet_half += theta_host[d + j * (j + 1) / 2 + j];
@@ -689,6 +803,10 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
   const double lq_const = df > 0.0
                               ? lgamma(0.5 * (df + d)) - lgamma(0.5 * df) - 0.5 * d * log(M_PI * df) - logdet_half
                               : -0.5 * d * log(2.0 * M_PI) - logdet_half;
+  if (defer_rows && drawn_here) {      // (the caller's row pass over the samples takes maha / log q / c_n along: model_prior_maha_rows)
+    *defer_rows = lq_const;
+    return VB_OK;
+  }
   hipLaunchKernelGGL(mvt_rows_kernel, dim3((unsigned)((n + 4 * kMvtRowsPerWave - 1) / (4 * kMvtRowsPerWave))), dim3(256), 0, ctx->stream,
                      drawn_here ? ctx->mvt_e_noise : (const double*)(base + L.o_e), drawn_here ? drawn_here->ld : L.ld, n,
                      (int)d, df, lq_const, base + L.o_maha, base + L.o_lq + lq_off,
@@ -921,10 +1039,21 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   VB_HIP(ctx, hipGetLastError());
 
   // (samples through the symmetric root: their residuals (x - mu) L^-T are a product, not the scaled noise)
-  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors, chol_samples ? &ns : nullptr));
+  // throughput mode with a row-kernel target: ONE pass over samples and noise for log p, log prior, maha, log q, c_n
+  const bool fuse_rows = chol_samples && mvt_env_on("VB_MVT_FUSED_ROWS") &&
+                         (ctx->model.id == VB_MODEL_GAUSS_DIAG || ctx->model.id == VB_MODEL_FUNNEL);
+  double lq_const = 0.0;
+  VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors, chol_samples ? &ns : nullptr,
+                       fuse_rows ? &lq_const : nullptr));
+  if (fuse_rows) {
+    VB_TRY(model_prior_maha_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine, base + L.o_prior, base + L.o_prior + L.ld,
+                                 c0p, base + L.o_lprior + mine, (const double*)ns.buf.ptr, ns.ld, base + L.o_invs, df, lq_const,
+                                 base + L.o_maha, base + L.o_lq + mine, base + L.o_part));
+  } else {
   // model and tempering prior (a diagonal Gaussian) in one pass over the samples
   VB_TRY(model_and_prior_logp_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine, base + L.o_prior,
                                    base + L.o_prior + L.ld, c0p, base + L.o_lprior + mine));
+  }
   if (ctx->temper.kind != VB_PRIOR_DIAG_GAUSSIAN)      // any other family as tempering prior: one more pass over X
     VB_TRY(temper_prior_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lprior + mine));
   VB_TRY(mvt_side_enqueue(ctx));      // (a deferred inverse: its launches go out now that the main stream is fed)
@@ -1268,6 +1397,15 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     // S = sym(gram), dL = tril(S L) - w_sum diag(1 / L_ii), free diagonal x L_ii: one D x D x D product and a pack kernel
     const int D = (int)d;
     VB_TRY(mvt_join_inverse(ctx));
+    const size_t plen = (size_t)(d + d * (d + 1) / 2);
+    if (direct && d <= 512 && mvt_env_on("VB_MVT_CHAIN")) {
+      // (direct route, moderate D: product and pack as ONE launch over the lower 32 x 32 tiles -- mvt_chain_kernel)
+      const int nt = (D + 31) / 32;
+      hipLaunchKernelGGL(mvt_chain_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, (const double*)(base + L.o_wt),
+                         (const double*)(base + L.o_lfull), L.ld, D, (const double*)S.sums, S.off_col, S.off_c, scale,
+                         base + L.o_grad, scale_dev, (const double*)(base + L.o_scal + 8));
+      VB_HIP(ctx, hipGetLastError());
+    } else {
     GemmArgs gs;
     gs.A = direct ? base + L.o_wt : S.sums + S.off_c;      // direct: L^-T M instead of S L
     gs.lda = L.ld;
@@ -1278,12 +1416,12 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     gs.K = D;
     gs.tri_mode = 0;
     gemm_f64_launch<true>(st, gs, 1, n_cu, EpiStore{base + L.o_sl, L.ld});
-    const size_t plen = (size_t)(d + d * (d + 1) / 2);
     hipLaunchKernelGGL(mvt_pack_grad_kernel, dim3((unsigned)(((int64_t)D * D + 255) / 256 + (direct ? (D + 3) / 4 : 0))), dim3(256), 0, st,
                        (const double*)(base + L.o_sl), (const double*)(base + L.o_lfull), L.ld, D,
                        (const double*)S.sums, S.off_col, scale, base + L.o_grad, scale_dev,
                        (const double*)(base + L.o_scal + 8), direct ? (const double*)(base + L.o_wt) : (const double*)nullptr);
     VB_HIP(ctx, hipGetLastError());
+    }
     if (grad_direct && mvt_env_on("VB_MVT_FLAGSYNC")) {
       // gradient and the five scalars through mapped memory behind a polled completion word (fetch_blocking)
       double tail[5];

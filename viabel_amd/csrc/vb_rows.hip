@@ -88,6 +88,83 @@ __global__ void __launch_bounds__(256) model_logp_rows_kernel(const double* __re
   }
 }
 
+// The same pass with the multivariate t's own row statistics riding along (round 6): the device-resident DIS refresh in
+// throughput mode reads TWO N x D matrices row by row -- the samples X for log p / log prior (above) and the noise E, whose
+// rows scaled by 1 / s_n ARE the residuals L^-1 (x_n - mu), for maha_n, log q_n and c_n (mvt_rows_kernel, vb_mvt.hip) -- in
+// two one-wave-per-row launches of ~13 and ~10 us at 16 384 x 256 (dispatch-bound: 2.5-3 TB/s).  One launch, four rows per
+// wave, both matrices' loads in flight together.  Every sum is formed as the two kernels form it (a lane adds its columns
+// c = lane, lane + 64, ... of a row in that order; v = e * r first, then fma(v, v, s)): the same bits.
+__global__ void __launch_bounds__(256) model_prior_maha_rows_kernel(const double* __restrict__ x, int64_t ld, int64_t n, int d,
+                                                                    ModelDev m, double* __restrict__ out,
+                                                                    const double* __restrict__ q0, const double* __restrict__ q1,
+                                                                    double qc, double* __restrict__ out2,
+                                                                    const double* __restrict__ E, int64_t lde,
+                                                                    const double* __restrict__ rs, double df, double lq_const,
+                                                                    double* __restrict__ maha, double* __restrict__ lq,
+                                                                    double* __restrict__ cn) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kRowsPerWave;
+  if (row0 >= n) return;
+  const double *xr[kRowsPerWave], *er[kRowsPerWave];
+  double rr[kRowsPerWave], acc[kRowsPerWave], acc2[kRowsPerWave], ss[kRowsPerWave], w[kRowsPerWave];
+#pragma unroll
+  for (int r = 0; r < kRowsPerWave; ++r) {
+    const int64_t row = row0 + r < n ? row0 + r : n - 1;      // (clamped: loads only)
+    xr[r] = x + row * ld;
+    er[r] = E + row * lde;
+    rr[r] = rs ? rs[row] : 1.0;
+    acc[r] = 0.0, acc2[r] = 0.0, ss[r] = 0.0;
+    w[r] = m.id == VB_MODEL_FUNNEL ? exp(-2.0 * xr[r][m.k]) : 0.0;
+  }
+  for (int c = lane; c < d; c += 64) {
+    const double mc = m.id == VB_MODEL_GAUSS_DIAG ? m.p0[c] : 0.0, iv = m.id == VB_MODEL_GAUSS_DIAG ? m.p1[c] : 0.0;
+    const double qm = q0[c], qi = q1[c];
+    double z[kRowsPerWave], e[kRowsPerWave];
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) z[r] = xr[r][c], e[r] = er[r][c];
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) {
+      if (m.id == VB_MODEL_GAUSS_DIAG) {
+        const double dz = z[r] - mc;
+        acc[r] -= 0.5 * dz * dz * iv;
+      } else if (c == m.k) {
+        acc[r] += -0.5 * z[r] * z[r] / (m.tau * m.tau) - (double)(d - 1) * z[r];
+      } else {
+        acc[r] -= 0.5 * z[r] * z[r] * w[r];
+      }
+      const double dq = z[r] - qm;
+      acc2[r] -= 0.5 * dq * dq * qi;
+      double v = e[r];
+      if (rs) v *= rr[r];
+      ss[r] = fma(v, v, ss[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kRowsPerWave; ++r) {
+    const double a = wave_sum_rows(acc[r]), a2 = wave_sum_rows(acc2[r]), t = wave_sum_rows(ss[r]);
+    if (lane == 0 && row0 + r < n) {
+      const int64_t row = row0 + r;
+      out[row] = a + m.c0;
+      out2[row] = a2 + qc;
+      maha[row] = t;
+      lq[row] = df > 0.0 ? lq_const - 0.5 * (df + d) * log1p(t / df) : lq_const - 0.5 * t;
+      cn[row] = df > 0.0 ? (df + d) / (df + t) : 1.0;
+    }
+  }
+}
+
+int model_prior_maha_rows(vb_ctx* ctx, const double* x_dev, int64_t ld, int64_t n, int64_t d, double* out_dev,
+                          const double* prior_mean, const double* prior_ivar, double prior_c0, double* prior_out,
+                          const double* E, int64_t lde, const double* rs, double df, double lq_const, double* maha, double* lq,
+                          double* cn) {
+  if (ctx->model.id != VB_MODEL_GAUSS_DIAG && ctx->model.id != VB_MODEL_FUNNEL) return VB_ERR_UNSUPPORTED;
+  const unsigned grid = (unsigned)((n + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave));
+  hipLaunchKernelGGL(model_prior_maha_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, x_dev, ld, n, (int)d, ctx->model, out_dev,
+                     prior_mean, prior_ivar, prior_c0, prior_out, E, lde, rs, df, lq_const, maha, lq, cn);
+  VB_HIP(ctx, hipGetLastError());
+  return VB_OK;
+}
+
 // ---- dense targets: f needs a GEMM -----------------------------------------------------------------
 struct EpiStoreRows {        // Y = acc
   double* Y;
