@@ -350,6 +350,17 @@ int vb_host_free(void* ptr);      /* NULL: a no-op, as free(NULL) */
  * caller that keeps weights for a later vb_dis_grad_* call compares the counter with the one it saw after its own
  * refresh: a mismatch means another objective refreshed in between and the weights no longer belong to the samples. */
 int vb_dis_generation(vb_ctx* ctx, int kind, uint64_t* generation);
+/* Parking a DIS state (round 6).  The reference keeps a DISInclusiveKL's state per OBJECT (objectives.py:391-403), so two
+ * objectives with num_resampling_batches > 1 may take turns; here it lives in the context.  vb_dis_state_park DETACHES the
+ * context's state of `kind` -- buffers (pointer moves, no copies), shapes, the parameter its residuals belong to, the
+ * generation counter, and noise slot `slot` (the state's samples for the mean-field kind, the residuals of a
+ * throughput-mode dense state; -1: none) -- into *handle; the context then has no state of that kind and allocates afresh
+ * for whoever refreshes next.  vb_dis_state_unpark installs a parked state again (consuming the handle; what the context
+ * held of that kind is released -- park it first if it is still needed).  vb_dis_state_drop frees a handle.  All three
+ * synchronise the context's streams: they are for the rare hand-over, not for the hot path.                        */
+int vb_dis_state_park(vb_ctx* ctx, int kind, int slot, void** handle);
+int vb_dis_state_unpark(vb_ctx* ctx, void* handle);
+int vb_dis_state_drop(void* handle);
 /* log p / log q of the state samples of the last refresh (all n_total of them; either pointer may be NULL), for
  * callers that passed NULL to the refresh.  dense = 0: mean-field state, 1: MultivariateT / dense-Gaussian state. */
 int vb_dis_state_get(vb_ctx* ctx, int dense, double* log_p, double* log_q, int64_t n_total);

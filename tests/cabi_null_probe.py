@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from viabel_amd import _lib  # noqa: E402
 
-NOOP_OK = {'vb_destroy', 'vb_comm_destroy', 'vb_host_free'}       # documented: NULL context (NULL block: free(NULL)) is a no-op
+NOOP_OK = {'vb_destroy', 'vb_comm_destroy', 'vb_host_free', 'vb_dis_state_drop'}       # documented: NULL context (NULL block: free(NULL)) is a no-op
 SKIP = {'vb_version', 'vb_device_count', 'vb_comm_unique_id', 'vb_last_error', 'vb_create'}
 
 

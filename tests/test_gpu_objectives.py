@@ -562,27 +562,68 @@ def test_lowrank_dis_against_oracle_multi_step(vb, D, k, N, use_resampling):
         theta = theta - 0.005 * grad / (1 + np.abs(grad))
 
 
-def test_interleaved_dis_objectives_are_detected(vb):
-    """Two DISInclusiveKL objectives with num_resampling_batches > 1 on one engine: the state samples live in the
-    engine, so the second objective's refresh invalidates the first one's weights -- that must fail loudly, not
-    compute on the wrong samples; after a fresh refresh the objective works again."""
-    from viabel_amd import _lib
-    D, N = 16, 256
-    model = vb.GaussianModel(np.zeros(D), np.ones(D))
-    prior = np.zeros(2 * D)
-    kw = dict(ess_target=64, temper_prior=vb.MFGaussian(D), temper_prior_params=prior, num_resampling_batches=2)
-    a = vb.DISInclusiveKL(vb.MFGaussian(D, seed=1), model, N, **kw)
-    b = vb.DISInclusiveKL(vb.MFGaussian(D, seed=2), model, N, **kw)
-    theta = np.concatenate([np.zeros(D), 0.1 * np.ones(D)])
-    np.random.seed(0)
-    a(theta)            # a refreshes (step 0)
-    b(theta)            # b refreshes: overwrites the mean-field state
-    with pytest.raises(_lib.EngineError):
-        a(theta)        # a's step 1 would reuse its (gone) samples
-    b(theta)            # b's step 1 is fine: its samples are the resident ones
-    a._objective_step = 0
-    v, g = a(theta)     # a refresh makes a whole again
-    assert np.isfinite(v) and np.all(np.isfinite(g))
+@pytest.mark.parametrize('kind', ['mf', 'mvt_numpy', 'mvt_philox', 'fr_philox', 'lr'])
+def test_interleaved_dis_objectives_keep_their_own_states(vb, kind):
+    """Two DISInclusiveKL objectives with num_resampling_batches > 1 taking turns on ONE engine.  The reference keeps the
+    state samples per object (objectives.py:391-403); here they live in the engine, one set per family kind -- until round 6
+    the second objective's refresh invalidated the first one's kept weights and the call raised.  Now the state
+    leaves the context with its owner (vb_dis_state_park: buffers detached) and comes back for the owner's next
+    kept-weights step: each objective's values and gradients are exactly what it computes running alone -- with a third
+    objective (no kept weights) refreshing in between as well."""
+    D, N = (16, 600) if kind in ('mf', 'lr') else (48, 4200)
+    rng = np.random.RandomState(3)
+    model = vb.GaussianModel(0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D)))
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    A = rng.randn(D, D)
+    th_ch = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(0.7 * (A @ A.T / D + np.eye(D)))])
+    th_mf = np.concatenate([0.1 * rng.randn(D), -0.5 + 0.1 * rng.randn(D)])
+
+    def make(seed, batches):
+        kw = dict(ess_target=N // 6, temper_prior=vb.MFGaussian(D), temper_prior_params=prior, use_resampling=True,
+                  num_resampling_batches=batches)
+        if kind == 'mf':
+            return vb.DISInclusiveKL(vb.MFGaussian(D, seed=seed), model, N, **kw), th_mf
+        if kind == 'lr':
+            fam = vb.LRGaussian(D, seed=seed, k=3)
+            return vb.DISInclusiveKL(fam, model, N, **kw), fam.pack(np.zeros(D), -0.5 * np.ones(D), 0.1 * np.ones((D, 3)))
+        if kind == 'fr_philox':
+            return vb.DISInclusiveKL(vb.FullRankGaussian(D, seed=seed, rng='philox'), model, N, **kw), th_ch
+        return vb.DISInclusiveKL(vb.MultivariateT(D, 9.0, seed=seed, rng='numpy' if kind == 'mvt_numpy' else 'philox'),
+                                 model, N, **kw), th_ch
+
+    def alone(seed, batches, calls, np_seed):
+        obj, th = make(seed, batches)
+        np.random.seed(np_seed)
+        out = []
+        for _ in range(calls):
+            v, g = obj(th)
+            out.append((v, g.copy()))
+            th = th - 0.01 * g / (1.0 + np.abs(g))
+        return out
+
+    want_a, want_b = alone(1, 3, 7, 100), alone(2, 2, 7, 200)
+    a, tha = make(1, 3)
+    b, thb = make(2, 2)
+    c, thc = make(5, 1)
+    sa, sb = np.random.RandomState(100).get_state(), np.random.RandomState(200).get_state()
+    got_a, got_b = [], []
+    for it in range(7):
+        np.random.set_state(sa)                 # (each objective sees the global generator it would see alone)
+        v, g = a(tha)
+        sa = np.random.get_state()
+        got_a.append((v, g.copy()))
+        tha = tha - 0.01 * g / (1.0 + np.abs(g))
+        if it % 2:
+            c(thc)                              # a refresh without kept weights in between
+        np.random.set_state(sb)
+        v, g = b(thb)
+        sb = np.random.get_state()
+        got_b.append((v, g.copy()))
+        thb = thb - 0.01 * g / (1.0 + np.abs(g))
+    for want, got in ((want_a, got_a), (want_b, got_b)):
+        for (v0, g0), (v1, g1) in zip(want, got):
+            assert v0 == v1
+            np.testing.assert_array_equal(g0, g1)
 
 
 def test_more_than_65535_samples(vb):

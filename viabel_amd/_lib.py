@@ -201,6 +201,9 @@ SIGNATURES = {
     'vb_legacy_round_end': (ctypes.c_int, [_ctx_p, ctypes.c_void_p]),
     'vb_legacy_ahead_stats': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
                                             ctypes.POINTER(ctypes.c_uint64)]),
+    'vb_dis_state_park': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    'vb_dis_state_unpark': (ctypes.c_int, [_ctx_p, ctypes.c_void_p]),
+    'vb_dis_state_drop': (ctypes.c_int, [ctypes.c_void_p]),
     'vb_fullrank_upload_stats': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_uint64)]),
     'vb_host_alloc': (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
     'vb_host_free': (ctypes.c_int, [ctypes.c_void_p]),
@@ -745,6 +748,18 @@ class Engine:
         g = ctypes.c_uint64(0)
         self._check(self._lib.vb_dis_generation(self._ctx, int(kind), ctypes.byref(g)))
         return g.value
+
+    def dis_state_park(self, kind, slot=-1):
+        """Detach the context's DIS state of ``kind`` (and noise slot ``slot``) into a handle (``vb_dis_state_park``)."""
+        h = ctypes.c_void_p()
+        self._check(self._lib.vb_dis_state_park(self._ctx, int(kind), int(slot), ctypes.byref(h)))
+        return h
+
+    def dis_state_unpark(self, handle):
+        self._check(self._lib.vb_dis_state_unpark(self._ctx, handle))
+
+    def dis_state_drop(self, handle):
+        self._lib.vb_dis_state_drop(handle)
 
     def dis_state_get(self, dense, n_total):
         """(log p, log q) of the state samples of the last DIS refresh."""

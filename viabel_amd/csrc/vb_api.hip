@@ -1759,6 +1759,126 @@ int vb_host_free(void* ptr) {
   return VB_OK;
 }
 
+// ---- parking a DIS state (round 6) ---------------------------------------------------------------------
+// The reference keeps the state of a DISInclusiveKL per OBJECT (objectives.py:391-403): two objectives with
+// num_resampling_batches > 1 may take turns.  Here the state samples live in the context, one set per family kind; an
+// objective about to refresh over another one's kept state parks that state first -- the buffers are DETACHED (pointer
+// moves, no copies: the context allocates afresh for the newcomer) together with the shapes, the parameter the residuals
+// belong to, the generation counter and the noise slot the state reads -- and the owner re-installs it (parking whoever
+// holds the context then) before its next kept-weights step.
+namespace {
+struct DisParked {
+  int kind = -1, slot = -1;
+  DeviceBuffer state, noise;
+  int64_t noise_n = 0, noise_d = 0, noise_ld = 0;
+  int64_t n = 0, d = 0, n_total = 0, k = 0, lq_off = 0;
+  std::vector<double> theta;
+  bool dev_factors = false, e_noise = false, has_noise = false;
+  uint64_t gen = 0;
+};
+
+void dis_detach(vb_ctx* ctx, int kind, int slot, DisParked* P) {
+  P->kind = kind, P->slot = slot, P->gen = ctx->dis_gen[kind];
+  if (kind == 0) {
+    std::swap(P->state, ctx->dis_state);
+    P->n = ctx->dis_n, P->d = ctx->dis_d, P->n_total = ctx->dis_n_total;
+    ctx->dis_n = ctx->dis_d = ctx->dis_n_total = 0;
+  } else if (kind == 1) {
+    std::swap(P->state, ctx->mvt_state);
+    P->n = ctx->mvt_n, P->d = ctx->mvt_d, P->n_total = ctx->mvt_n_total, P->lq_off = ctx->mvt_lq_off;
+    P->theta.swap(ctx->mvt_theta);
+    P->dev_factors = ctx->mvt_dev_factors;
+    P->e_noise = ctx->mvt_e_noise != nullptr;
+    ctx->mvt_n = ctx->mvt_d = ctx->mvt_n_total = 0;
+    ctx->mvt_e_noise = nullptr;
+    ctx->mvt_prior.clear();      // (caches keyed on the state buffer)
+    ctx->mvt_inv_key[0] = 0;
+  } else {
+    std::swap(P->state, ctx->lr_obj);
+    P->n = ctx->lr_n, P->d = ctx->lr_d, P->k = ctx->lr_k, P->n_total = ctx->lr_n_total;
+    ctx->lr_n = ctx->lr_d = ctx->lr_k = ctx->lr_n_total = 0;
+  }
+  if (slot >= 0 && slot < VB_MAX_SLOTS && ctx->noise[slot].buf.ptr) {
+    NoiseSlot& s = ctx->noise[slot];
+    std::swap(P->noise, s.buf);
+    P->noise_n = s.n, P->noise_d = s.d, P->noise_ld = s.ld;
+    s.n = s.d = s.ld = 0;
+    s.ahead.last.valid = s.ahead.pre.valid = s.ahead.hint.valid = false;
+    s.ahead.streak = 0;
+    P->has_noise = true;
+  }
+}
+
+void dis_attach(vb_ctx* ctx, DisParked* P) {
+  const int kind = P->kind;
+  ctx->dis_gen[kind] = P->gen;
+  if (kind == 0) {
+    std::swap(P->state, ctx->dis_state);
+    ctx->dis_n = P->n, ctx->dis_d = P->d, ctx->dis_n_total = P->n_total;
+  } else if (kind == 1) {
+    std::swap(P->state, ctx->mvt_state);
+    ctx->mvt_n = P->n, ctx->mvt_d = P->d, ctx->mvt_n_total = P->n_total, ctx->mvt_lq_off = P->lq_off;
+    ctx->mvt_theta.swap(P->theta);
+    ctx->mvt_dev_factors = P->dev_factors;
+    ctx->mvt_prior.clear();
+    ctx->mvt_inv_key[0] = 0;
+  } else {
+    std::swap(P->state, ctx->lr_obj);
+    ctx->lr_n = P->n, ctx->lr_d = P->d, ctx->lr_k = P->k, ctx->lr_n_total = P->n_total;
+  }
+  if (P->has_noise) {
+    NoiseSlot& s = ctx->noise[P->slot];
+    std::swap(P->noise, s.buf);
+    s.n = P->noise_n, s.d = P->noise_d, s.ld = P->noise_ld;
+    s.ahead.last.valid = s.ahead.pre.valid = s.ahead.hint.valid = false;
+    s.ahead.streak = 0;
+    if (kind == 1 && P->e_noise) {
+      ctx->mvt_e_noise = (const double*)s.buf.ptr;
+      ctx->mvt_e_noise_ld = s.ld;
+    }
+  }
+}
+
+void dis_parked_free(DisParked* P) {
+  if (P->state.ptr) (void)hipFree(P->state.ptr);
+  if (P->noise.ptr) (void)hipFree(P->noise.ptr);
+  delete P;
+}
+}  // namespace
+
+int vb_dis_state_park(vb_ctx* ctx, int kind, int slot, void** handle) {
+  if (!ctx || !handle) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  if (kind < 0 || kind > 2) return fail(ctx, VB_ERR_INVALID, "DIS state kind %d outside [0, 2]", kind);
+  if (slot >= VB_MAX_SLOTS) return fail(ctx, VB_ERR_INVALID, "noise slot %d out of range", slot);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  legacy_spec_cancel(ctx);            // (a look-ahead draw may be aimed at the slot's shadow)
+  VB_TRY(sync_streams(ctx));          // nothing in flight reads what is being moved
+  ctx->mvt_inv_pending = ctx->mvt_inv_queued = false;
+  DisParked* P = new (std::nothrow) DisParked;
+  if (!P) return fail(ctx, VB_ERR_HIP, "out of host memory");
+  dis_detach(ctx, kind, slot, P);
+  *handle = P;
+  return VB_OK;
+}
+
+int vb_dis_state_unpark(vb_ctx* ctx, void* handle) {
+  if (!ctx || !handle) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  DisParked* P = (DisParked*)handle;
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  legacy_spec_cancel(ctx);
+  VB_TRY(sync_streams(ctx));
+  ctx->mvt_inv_pending = ctx->mvt_inv_queued = false;
+  // what the context holds now (the caller parked it first if anybody still needs it) goes away with the handle
+  dis_attach(ctx, P);
+  dis_parked_free(P);      // (after the swaps: the handle owns what the context held)
+  return VB_OK;
+}
+
+int vb_dis_state_drop(void* handle) {
+  if (handle) dis_parked_free((DisParked*)handle);
+  return VB_OK;
+}
+
 int vb_dis_generation(vb_ctx* ctx, int kind, uint64_t* generation) {
   if (!ctx || !generation) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   if (kind < 0 || kind > 2) return fail(ctx, VB_ERR_INVALID, "DIS state kind %d outside [0, 2]", kind);

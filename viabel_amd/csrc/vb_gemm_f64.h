@@ -392,7 +392,10 @@ template <bool A_KCONTIG, class Epi>
 inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu, const Epi& epi, int cfg = 0,
                                 int flags = 0) {
   // 64 x 32 tiles: only where the result cannot depend on the tiling (no per-tile partial sums, no column sums)
-  constexpr bool kNarrowOk = A_KCONTIG && !EpiReduces<Epi>::value && !EpiColsum<Epi>::value;
+  // (round 6: a REDUCING epilogue may take them too when the caller asks for it by cfg = 7 / 8 -- its per-tile partial sums
+  // are then grouped by 64 x 32 tiles: another, equally fixed, summation order)
+  constexpr bool kNarrowOk = A_KCONTIG && !EpiColsum<Epi>::value;
+  constexpr bool kNarrowAuto = kNarrowOk && !EpiReduces<Epi>::value;
   if (splits < 1) splits = 1;
   int ks = g.batch ? g.K : gemm_tiles(g.K, splits);   // batch mode: `splits` is the number of products
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;
@@ -414,7 +417,7 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
       // as wide a tile halves the MFMAs of every slab of it -- 4096 x 256 x 256: 15.2 -> 11.9 us, 4096 x 512 x 512:
       // 28.9 -> 26.9 us; with more tiles per CU it loses (16 384 x 256 x 256: 29.3 -> 30.8 us, D = 1024: 82 -> 92 us)
       // (tools/tile32_probe.sh)
-      if (kNarrowOk && !g.batch && gemm_count_blocks(g, 64, 64) <= 2L * n_cu) cfg = 8;
+      if (kNarrowAuto && !g.batch && gemm_count_blocks(g, 64, 64) <= 2L * n_cu) cfg = 8;
     } else if (dma && g.tri_mode == 0 && g.batch == 0 && gemm_count_blocks(g, 128, 128) * splits >= 2L * n_cu) {
       // large dense products: 128 x 128 tiles with TWO LDS stages (64 KB: two workgroups per CU).  Per MFMA a third
       // fewer fragment reads and LDS-DMA pieces than 128 x 64: 69.3 - 70.2 against 66.0 - 67.5 TFLOP/s on
@@ -431,7 +434,7 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
       cfg = 3;
       // dense products with at most one 64 x 64 tile per CU: 4096 x 256 x 256 17.2 -> 15.8 us (at two per CU it loses:
       // 4096 x 512 x 512 42.9 -> 45.4 us)
-      if (kNarrowOk && dma && g.tri_mode == 0 && !g.batch && gemm_count_blocks(g, 64, 64) * splits <= (long)n_cu) cfg = 7;
+      if (kNarrowAuto && dma && g.tri_mode == 0 && !g.batch && gemm_count_blocks(g, 64, 64) * splits <= (long)n_cu) cfg = 7;
     }
   }
   if (!kNarrowOk && cfg >= 7) cfg = 4;

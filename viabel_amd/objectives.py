@@ -55,6 +55,7 @@ def _claim_engine_state(eng, kind, owner):
     other = ref() if ref is not None else None
     if other is not None and other is not owner:
         other._materialize_state()
+        other._park_state(eng, kind)      # (kept weights mid-batch: its state samples leave the context with it)
     owners[kind] = weakref.ref(owner) if owner is not None else None
 
 
@@ -821,8 +822,30 @@ class DISInclusiveKL(StochasticVariationalObjective):
     def _claim_state(self, eng, kind):
         """Before a refresh overwrites the engine's state of `kind`: an objective that left its weights / per-sample logs
         on the device to be fetched on first access (the device-resident steps) fetches them NOW, so that they remain
-        the arrays of ITS refresh -- as the reference's ``_state_*`` attributes do -- whoever refreshes next."""
+        the arrays of ITS refresh -- as the reference's ``_state_*`` attributes do -- whoever refreshes next; one that is
+        in the middle of a batch of kept-weights steps (``num_resampling_batches > 1``) parks its state samples."""
+        self._drop_parked()             # (a state of our own that was parked: this refresh replaces it)
         _claim_engine_state(eng, kind, self)
+
+    def _drop_parked(self):
+        parked = getattr(self, '_parked', None)
+        if parked is not None:
+            eng, _, handle, fin = parked
+            fin.detach()
+            eng.dis_state_drop(handle)
+            self._parked = None
+
+    def _park_state(self, eng, kind):
+        """Another objective is about to refresh over this one's state.  The reference keeps ``_state_samples`` per object
+        (``objectives.py:391-403``): two objectives with ``num_resampling_batches > 1`` may take turns.  If this one's next
+        call is a kept-weights step on a state that is still intact, the state leaves the context with it
+        (``vb_dis_state_park``: buffers detached, no copies) and comes back in ``_own_state``."""
+        if (not self._use_resampling or self._num_resampling_batches <= 1 or getattr(self, '_parked', None) is not None
+                or self._objective_step % self._num_resampling_batches == 0
+                or getattr(self, '_state_gen', None) != (id(eng), eng.dis_generation(kind))):
+            return
+        handle = eng.dis_state_park(kind, _DIS_SLOT if kind in (0, 1) else -1)
+        self._parked = (eng, kind, handle, weakref.finalize(self, eng.dis_state_drop, handle))
 
     def _materialize_state(self):
         self._state_w_clipped           # (properties: the pending fetches run)
@@ -832,6 +855,14 @@ class DISInclusiveKL(StochasticVariationalObjective):
         """The state samples live in the engine, one set per family kind: after a refresh remember its generation,
         before a gradient on kept weights make sure nobody else refreshed in between (two interleaved
         objectives with num_resampling_batches > 1 used to compute on each other's samples silently)."""
+        parked = getattr(self, '_parked', None)
+        if parked is not None and not refreshed and parked[0] is eng and parked[1] == kind:
+            # our state was parked when another objective refreshed: whoever holds the context's state now may be in the
+            # middle of a batch too (it parks), then ours is installed again
+            _claim_engine_state(eng, kind, self)
+            parked[3].detach()
+            eng.dis_state_unpark(parked[2])
+            self._parked = None
         gen = eng.dis_generation(kind)
         if refreshed:
             self._state_gen = (id(eng), gen)
@@ -944,6 +975,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 # state refresh (objectives.py:393-401): new samples (kept as noise on the device),
                 # log q, log p, tempering bisection, clipping.  Sharded jobs gather the per-sample
                 # vectors, so eps and the weights cover all N samples on every rank.
+                self._claim_state(eng, 0)
                 self._stage_noise(eng, N, slot=slot)
                 eng.dis_set_temper_prior(self._prior_spec)
                 self._eps, self._ess, w, log_p, log_q = eng.dis_refresh_meanfield(
@@ -989,6 +1021,7 @@ class DISInclusiveKL(StochasticVariationalObjective):
             n_local = end - begin
             mu, ls, B, Bs, Minv, cq, BsMinv = _lowrank_pieces(approx, var_param)
             if not self._use_resampling or self._objective_step % self._num_resampling_batches == 0:
+                self._claim_state(eng, 2)
                 if approx.rng == 'philox':
                     approx._philox_noise(eng, n_local, None, begin, slot, _LR_SLOT)
                 else:
