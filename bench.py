@@ -406,6 +406,7 @@ def probe_main(args):
     eng = _lib.Engine(0) if shared else _lib.default_engine()
     _lib.set_default_engine(eng)
     if shared:
+        os.environ.setdefault('VB_IPC_TIMEOUT_S', '150')      # (a stall between two processes on one GPU resolves itself; see prewarm_shared_device)
         prewarm_shared_device(eng, vb, distributed, which=('transport',))
         group.barrier()
     distributed.attach(eng, group, transport=args.probe_transport)
@@ -1368,6 +1369,7 @@ def main():
     eng = _lib.Engine(0) if (no_rccl or host_transport or ipc_shared_gpu) else _lib.default_engine()
     _lib.set_default_engine(eng)
     if world > 1 and (host_transport or ipc_shared_gpu):
+        os.environ.setdefault('VB_IPC_TIMEOUT_S', '150')
         prewarm_shared_device(eng, vb, distributed)      # (one-GPU functional runs only: see there)
         group.barrier()
     if host_transport:
