@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6                     # datasheet fp64 matrix peak = 256 CUs x 4 SIMDs x 512 flop / 16 clk x 2.4 GHz;
 #                                                  tools/mfma_barrier_probe.hip measures 77.3 with constant operands
 # HBM-side bytes per launch of the headline's dense model GEMM at D=1024, N=4096 (see roofline.traffic_source)
-MODEL_GEMM_HBM_BYTES = int((2 * 64295.8 + 34414.4) * 1024)      # profiles/r05_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
-MF_ACCUM_HBM_BYTES = int((2 * 530477.5 + 8352.7) * 1024)           # profiles/r05_meanfield_c1_pmc_hbm.txt, per 32-evaluation launch
+MODEL_GEMM_HBM_BYTES = int((2 * 64267.8 + 34348.7) * 1024)      # profiles/r06_fullrank_gemm_pmc.txt (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
+MF_ACCUM_HBM_BYTES = int((2 * 530477.5 + 8352.6) * 1024)           # profiles/r06_meanfield_c1_pmc_hbm.txt, per 32-evaluation launch
 MIN_TIMED_S = 0.05                               # the timed blocks are repeated until they cover at least this
 
 
@@ -504,7 +504,7 @@ def meanfield_leg(eng, vb, _lib, steps=2000, warmup=200, batch=32, ring_total=16
                      'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'avg_kernel_us': kernel_us,
                      'launches_timed': launches, 'algorithmic_bytes_per_launch': bytes_per_launch,
                      'traffic': MF_ACCUM_HBM_BYTES if batch == 32 else None,
-                     'traffic_source': 'profiles/r05_meanfield_c1_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
+                     'traffic_source': 'profiles/r06_meanfield_c1_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
                                        'passes of tools/mf_stream_bench.py, this launch shape, kernel unchanged since): 1 086.4 MB '
                                        'fetched + 8.6 MB written per 32-evaluation launch = 1.019 x the algorithmic 1 074.8 MB'},
         'parity': {'rel_elbo_err': abs(dv - ov) / abs(ov),
@@ -617,12 +617,13 @@ def c3_leg(vb, calls=30):
     # scaled noise (no product)
     flops = 2.0 * N * D * (D + 1) + 2.0 * D * D * D
     out['flops_executed_per_call'] = flops
-    out['note'] = ('22 kernels per call (18 on the critical path: the triangular inverse runs on a side stream), everything '
+    out['note'] = ('19 kernels per call (15 on the critical path: the triangular inverse runs on a side stream), everything '
                    'including the O(D^3) factor algebra on the device; five of them are the tempering bisection (50 levels '
-                   'walked along two predicted paths: ~40 us), PSIS smoothing runs on 16 workgroups (43 us), the two N x D x D '
-                   'half products take 66 us for %.1f GFLOP: the call is a chain of short dependent kernels (~225 us) plus '
-                   '~30 us of host turn-around, not matrix-pipe time; timeline: profiles/r05_c3_timeline.txt, per kernel: '
-                   'profiles/r05_c3_kernel_stats.txt' % (flops / 1e9))
+                   'walked along two predicted paths: ~38 us), PSIS smoothing runs on 16 workgroups (43 us), the two N x D x D '
+                   'half products take 64 us for %.1f GFLOP, the chain rule is one launch over the lower tiles (14 us): the '
+                   'call is a chain of short dependent kernels (~187 us) plus ~30 us of host turn-around, not matrix-pipe time; '
+                   'timeline: profiles/r06_c3_timeline.txt, per kernel: profiles/r06_c3_kernel_stats.txt; the parity_mode_* '
+                   "calls run the NEXT call's numpy-stream draws beside this call's kernels (look-ahead, DESIGN 4.11)" % (flops / 1e9))
     return out
 
 
@@ -971,6 +972,8 @@ def api_call_leg(eng, vb, calls=200):
             blocks.append(1e6 * (time.perf_counter() - t0) / n_calls)
         out['%s_us_per_call' % kind] = statistics.median(blocks)
         out['%s_block_us' % kind] = blocks
+        if kind == 'numpy':      # look-ahead generation of numpy's stream: jobs launched / requests adopted / discarded
+            out['numpy_look_ahead'] = dict(zip(('launched', 'adopted', 'discarded'), eng.legacy_ahead_stats()))
     from viabel_amd._legacy_rng import LegacyRandomState
     eng.set_model(model.device_spec())
     rs = LegacyRandomState(1)
@@ -994,7 +997,9 @@ def api_call_leg(eng, vb, calls=200):
     out['numpy_randn_on_this_host_us'] = 1e6 * (time.perf_counter() - t0)
     out['note'] = ('the headline value is the theta-resident enqueue rate (no PCIe in the timed region); this leg is the '
                    'same evaluation with 2 x 4.2 MB across PCIe and one synchronisation per call.  Floor without '
-                   'overlapping transfers and kernels: upload + kernels + download')
+                   'overlapping transfers and kernels: upload + kernels + download (the overlap was built in round 6 and '
+                   "measured slower: DESIGN 4.4).  rng='numpy': the NEXT call's randn(4096, 1024) is generated on the device "
+                   "beside this call's GEMMs and adopted by a pointer swap (values and generator state numpy's: DESIGN 4.11)")
     del host
     return out
 
@@ -1416,8 +1421,8 @@ def main():
             # profiles/ (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE)
             if head['n_rows'] == N_MC and FR_D == 1024:
                 roof['traffic'] = MODEL_GEMM_HBM_BYTES
-                roof['traffic_source'] = ('profiles/r05_fullrank_gemm_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
-                                          'separate passes, FETCH_SIZE doubled per the gfx950 note): 131.7 MB fetched + '
+                roof['traffic_source'] = ('profiles/r06_fullrank_gemm_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                          'separate passes, FETCH_SIZE doubled per the gfx950 note): 131.6 MB fetched + '
                                           '35.2 MB written per launch vs 75.5 MB of operands and result (Z 33.6 + P 8.4 '
                                           'read, G 33.6 written) + 33.6 MB for the epilogue reading z - m back for sum f; '
                                           'P is fetched once per XCD; 1.25 TB/s, a sixth of HBM peak: MFMA-bound')
