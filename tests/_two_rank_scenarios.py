@@ -187,3 +187,36 @@ def run_c3(vb):
     out['c3_ekl_numpy_pd'] = vb.ExclusiveKL(vb.MultivariateT(D, df, seed=6), model, N, use_path_deriv=True)(theta)
     out['c3_alpha_numpy'] = vb.AlphaDivergence(vb.MultivariateT(D, df, seed=6), model, N, 0.5)(theta)
     return out
+
+
+
+def run_three_ranks(vb):
+    """A reduced set for a THREE-rank job (tests/test_gpu_two_ranks.py::test_three_ranks...): the middle rank's shard begins
+    inside the vectors and ends inside them -- offsets neither of the two-rank job's ranks has -- with ragged shards
+    (1003 = 335 + 334 + 334; 16 384 = 5462 + 5461 + 5461)."""
+    out = dict(run_resident_dense(vb))
+    D, N, df, ess_target = 256, 16384, 100, 2048
+    rng = np.random.RandomState(33)
+    mean, sd, prior, theta = c3_problem(rng, D)
+    model = vb.GaussianModel(mean, sd)
+    kw = dict(ess_target=ess_target, temper_prior=vb.MFGaussian(D), temper_prior_params=prior)
+    np.random.seed(41)
+    for mode in ('philox', 'numpy'):
+        out['c3x3_%s_resampling_psis' % mode] = _dis_calls(
+            vb.DISInclusiveKL(vb.MultivariateT(D, df, seed=6, rng=mode), model, N, use_resampling=True, psis_smooth=True,
+                              num_resampling_batches=2, **kw), theta, 3)
+    out['c3x3_ekl_numpy_pd'] = vb.ExclusiveKL(vb.MultivariateT(D, df, seed=6), model, N, use_path_deriv=True)(theta)
+    # the mean-field and low-rank refreshes gather their three vectors through the same collective
+    D2 = 48
+    g2 = vb.GaussianModel(np.zeros(D2), np.ones(D2))
+    pr2 = np.concatenate([np.zeros(D2), 0.3 * np.ones(D2)])
+    th2 = np.concatenate([0.1 * np.ones(D2), -0.5 * np.ones(D2)])
+    np.random.seed(42)
+    out['x3_dis_mf'] = _dis_calls(vb.DISInclusiveKL(vb.MFGaussian(D2, seed=8, rng='philox'), g2, 1003, ess_target=150,
+                                                    temper_prior=vb.MFGaussian(D2), temper_prior_params=pr2,
+                                                    use_resampling=False), th2, 2)
+    lr = vb.LRGaussian(D2, seed=8, k=5, rng='philox')
+    out['x3_dis_lr'] = _dis_calls(vb.DISInclusiveKL(lr, g2, 1003, ess_target=150, temper_prior=vb.MFGaussian(D2),
+                                                    temper_prior_params=pr2, use_resampling=False),
+                                  lr.pack(np.zeros(D2), -0.5 * np.ones(D2), 0.1 * np.ones((D2, 5))), 2)
+    return {k: (np.atleast_1d(np.asarray(v[0], dtype=float)), np.asarray(v[1], dtype=float)) for k, v in out.items()}

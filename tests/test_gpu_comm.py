@@ -498,3 +498,34 @@ def test_resident_dense_routes_and_c3_through_a_one_rank_rccl_communicator(engin
         v1, g1 = np.asarray(got[name][0], dtype=float), np.asarray(got[name][1], dtype=float)
         assert np.max(np.abs(v1 - v0)) <= 1e-12 * np.max(np.abs(v0)), name
         assert np.max(np.abs(g1 - g0)) <= 1e-12 * np.max(np.abs(g0)), name
+
+
+def test_bench_sharded_legs_under_a_one_rank_rccl_communicator(engines):
+    """bench.py's N > 1 legs (sharded C3 / C4 / C1, the transport legs) run through RCCL itself with a one-rank communicator:
+    every collective the 8-GPU line issues is a real ncclAllReduce here, and the legs' results are what the one-GPU legs
+    report."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import viabel_amd as vb
+    from viabel_amd import _lib, distributed
+    plain, comm = engines
+    solo = distributed.SocketGroup(0, 1)
+    _lib.set_default_engine(comm)
+    try:
+        c3 = bench.sharded_c3_leg(comm, vb, solo, calls=4)
+        c1 = bench.sharded_c1_leg(comm, vb, solo, iters=40)
+        c4 = bench.sharded_c4_leg(comm, vb, solo, steps=2)
+        t_big = comm.comm_allreduce_time(16 + 1024 + 1024 * 1025 // 2, warm=1, reps=3)
+    finally:
+        _lib.set_default_engine(plain)
+    for scaling in ('strong', 'weak'):
+        leg = c3[scaling]
+        assert leg['n_mc_global'] == 16384 and leg['allgather_doubles_per_call'] == 3 * 16384
+        for mode in ('weighted', 'resampling'):
+            # (eps only ever moves down from call to call -- objectives.py:347-368 bisects on [0, eps_prev] -- so after the
+            # warm-up calls the effective sample size sits at or above what the first refresh hit)
+            assert 0.0 < leg[mode]['eps'] < 1.0 and 1000 < leg[mode]['ess'] < 16384 and np.isfinite(leg[mode]['value'])
+            assert 0.05 < leg[mode]['ms_per_call'] < 5.0
+    assert 1000 < c3['strong']['parity_mode_weighted']['ess'] < 16384
+    assert c1['strong']['us_per_iteration'] > 5.0 and c4['ms_per_eval'] > 1.0 and np.isfinite(c4['value']) and t_big > 0.0

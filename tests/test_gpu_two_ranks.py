@@ -140,3 +140,29 @@ def test_ipc_wait_gives_up_after_wall_time_not_poll_counts(tmp_path):
     script.write_text(GIVE_UP_WORKER % {'root': ROOT})
     rc, lines = bench.spawn_ranks(2, [sys.executable, str(script)], timeout_s=300)
     assert rc == 0, lines[-8:]
+
+
+def test_three_ranks_on_one_gpu_match_one_rank(tmp_path):
+    """Three ranks (host-staged transport) on one GPU: the MIDDLE rank's shard starts and ends inside the gathered vectors --
+    shard offsets, ragged block lengths and the one-collective gather of [log q | log p | log prior] as an 8-GPU job's inner
+    ranks have them -- on the device-resident routes of the dense families and at the C3 size."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    import bench
+    import viabel_amd as vb
+    import _two_rank_scenarios as S
+    script = tmp_path / 'worker3.py'
+    script.write_text((WORKER % {'root': ROOT, 'tests': TESTS, 'out': str(tmp_path), 'transport': 'host'})
+                      .replace('S.run_all(vb)', 'S.run_three_ranks(vb)').replace('== (2, group.rank)', '== (3, group.rank)'))
+    rc, lines = bench.spawn_ranks(3, [sys.executable, str(script)], timeout_s=1500)
+    assert rc == 0, lines[-5:]
+    single = S.run_three_ranks(vb)
+    ranks = [np.load(tmp_path / ('rank%d.npz' % r)) for r in (0, 1, 2)]
+    worst = {}
+    for name, (v, g) in single.items():
+        for r in (0, 1, 2):
+            worst[name] = max(worst.get(name, 0.0), _rel(ranks[r][name + '__v'], v), _rel(ranks[r][name + '__g'], g))
+            assert np.array_equal(ranks[r][name + '__v'], ranks[0][name + '__v']), name      # every rank: the same bits
+            assert np.array_equal(ranks[r][name + '__g'], ranks[0][name + '__g']), name
+    bad = {k: e for k, e in worst.items() if not e < 1e-11}
+    assert len(worst) >= 14 and not bad, (bad, worst)
