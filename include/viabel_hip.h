@@ -638,6 +638,9 @@ int vb_legacy_ahead_stats(vb_ctx* ctx, uint64_t* launched, uint64_t* adopted, ui
 /* 1 when this host's libm log() has been located and restated bit for bit (vb_glibc_log.h): the device draws above are
  * available and vb_legacy_rng_randn_device needs no host round trip.                                               */
 int vb_legacy_rng_log_proven(void);
+/* a number unique to this generator object for the life of the process (0 for NULL): a destroyed generator's address may be
+ * handed out again, its uid never (the look-ahead draws key their per-generator history on it).                         */
+uint64_t vb_legacy_rng_uid(const vb_legacy_rng* rng);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the dominant kernels ---------
  * When enabled, every launch of a profiled kernel carries a start/stop event pair

@@ -195,6 +195,7 @@ SIGNATURES = {
                                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     'vb_legacy_rng_chisquare_device': (ctypes.c_int, [_ctx_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_int64, _c_double_p]),
     'vb_legacy_rng_log_proven': (ctypes.c_int, []),
+    'vb_legacy_rng_uid': (ctypes.c_uint64, [ctypes.c_void_p]),
     'vb_comm_ipc_window': (ctypes.c_int, [_ctx_p, ctypes.c_size_t, ctypes.c_char_p]),
     'vb_comm_init_ipc': (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     'vb_comm_check': (ctypes.c_int, [_ctx_p]),

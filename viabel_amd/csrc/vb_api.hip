@@ -992,8 +992,9 @@ static void legacy_spec_adopted(vb_ctx* ctx, vb_legacy_rng* rng, int i) {
 static void legacy_round_note(vb_ctx* ctx, const vb_legacy_rng* rng, const LegacyReq& r) {
   if (legacy_spec_create(ctx) != VB_OK) return;
   LegacySpec& S = *ctx->legacy_spec;
-  if (S.round_rng != rng) {
+  if (S.round_rng != rng || S.round_uid != vb_legacy_rng_uid(rng)) {
     S.round_rng = rng;
+    S.round_uid = vb_legacy_rng_uid(rng);
     S.n_round = 0;
     S.round_overflow = false;
     S.n_prev = -1;
@@ -1166,7 +1167,8 @@ int vb_legacy_rng_chisquare_device(vb_ctx* ctx, vb_legacy_rng* rng, double df, i
 int vb_legacy_round_end(vb_ctx* ctx, vb_legacy_rng* rng) {
   if (!ctx || !rng) return fail(ctx, VB_ERR_INVALID, "NULL argument");
   LegacySpec* Sp = ctx->legacy_spec;
-  if (!Sp || Sp->round_rng != rng) return VB_OK;      // no device draw of this generator since the last round end
+  if (!Sp || Sp->round_rng != rng || Sp->round_uid != vb_legacy_rng_uid(rng))
+    return VB_OK;      // no device draw of this generator since the last round end
   LegacySpec& S = *Sp;
   bool same = !S.round_overflow && S.n_round > 0 && S.n_round == S.n_prev;
   for (int i = 0; same && i < S.n_round; ++i) same = S.round[i].same(S.prev_round[i]);

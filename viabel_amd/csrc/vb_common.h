@@ -518,6 +518,7 @@ struct LegacySpec {
   LegacyReq round[kMaxReqs], prev_round[kMaxReqs];      // the draws since the last round end; of the round before
   int n_round = 0, n_prev = -1;
   const void* round_rng = nullptr;
+  uint64_t round_uid = 0;                   // ... and its uid: a new generator may live at a destroyed one's address
   bool round_overflow = false;
   bool active = false, failed = false;
   LegacyReq reqs[kMaxReqs];

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <new>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 #include <link.h>
@@ -46,6 +47,7 @@ struct vb_legacy_rng {
   double gauss;
   uint32_t out[kN];                  // key[] tempered (the block's output words), refreshed with it
   std::vector<uint32_t> buf[2];      // word buffers of the threaded normal draws (kept: no page faults per call)
+  uint64_t uid = 0;                  // unique per created generator (an address may be handed out again after a destroy)
 };
 
 namespace {
@@ -457,9 +459,13 @@ int vb_legacy_rng_create(uint32_t seed, vb_legacy_rng** out) {
   vb_legacy_rng* s = new (std::nothrow) vb_legacy_rng;
   if (!s) return VB_ERR_HIP;          // (out of host memory)
   mt_seed(*s, seed);
+  static std::atomic<uint64_t> next_uid{1};
+  s->uid = next_uid.fetch_add(1);
   *out = s;
   return VB_OK;
 }
+
+uint64_t vb_legacy_rng_uid(const vb_legacy_rng* s) { return s ? s->uid : 0; }
 
 void vb_legacy_rng_destroy(vb_legacy_rng* s) { delete s; }
 
