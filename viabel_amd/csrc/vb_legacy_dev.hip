@@ -74,14 +74,16 @@ __device__ __forceinline__ MtRegs mt_load(const uint32_t* key, int t) {
 // NOT yet synchronised: the caller's barrier comes before anybody reads it.
 __device__ __forceinline__ void mt_step(MtRegs& r, const uint32_t* cur, uint32_t* next, int t) {
   if (t < 227) {
+    // every LDS read of the step is issued up front (round 6): the third word's operand sat behind the first two words'
+    // write in program order -- a second LDS round trip per block on the loop's critical path
     const uint32_t a1 = cur[t + 1], m = cur[t + kM], b1 = cur[t + 228];
+    const uint32_t c_in = cur[t < 169 ? t + 455 : kN - 1];                     // (clamped: lanes 169 .. 226 do not use it)
+    const uint32_t k0 = cur[0], k1 = cur[1], km = cur[kM];                       // broadcast reads: the NEW key[0], for k = 623
     const uint32_t n0 = m ^ mt_mix(r.w0, a1);
     const uint32_t n1 = n0 ^ mt_mix(r.w1, b1);
     next[t] = n0, next[t + 227] = n1;
     if (t < 170) {
-      uint32_t c1;
-      if (t < 169) c1 = cur[t + 455];
-      else c1 = cur[kM] ^ mt_mix(cur[0], cur[1]);      // k = 623: the NEW key[0], from old words
+      const uint32_t c1 = t < 169 ? c_in : (km ^ mt_mix(k0, k1));
       const uint32_t n2 = n1 ^ mt_mix(r.w2, c1);
       next[t + 454] = n2;
       r.w2 = n2;
