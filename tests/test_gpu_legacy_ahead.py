@@ -170,3 +170,48 @@ def test_objective_loops_equal_the_loops_without_look_ahead(env, family):
         np.testing.assert_array_equal(g0, g1)
     np.testing.assert_array_equal(st_plain[1], st_ahead[1])
     assert st_plain[2:] == st_ahead[2:]
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_random_sequences_of_draws_rounds_and_host_draws_stay_numpy(env, seed):
+    """Fuzz: 60 random steps on two generators -- device draws of random kinds and shapes (repeated often enough for the
+    look-ahead to start and to be adopted), round ends at random, host draws of all kinds, get_state / set_state round trips --
+    every value and every generator state against numpy.random.RandomState."""
+    vb, eng, LegacyRandomState = env
+    rnd = np.random.RandomState(1000 + seed)
+    gens = [(LegacyRandomState(10 + seed), np.random.RandomState(10 + seed)), (LegacyRandomState(20 + seed), np.random.RandomState(20 + seed))]
+    menus = [[('n', 2048, 48)], [('c', 12.0, 4500), ('n', 4500, 16)], [('t', 5.0, 1500, 32)], [('n', 999, 7), ('n', 999, 41)]]
+    before = eng.legacy_ahead_stats()
+    current = [menus[rnd.randint(len(menus))] for _ in gens]
+    for step in range(60):
+        g = rnd.randint(len(gens))
+        ours, ref = gens[g]
+        action = rnd.rand()
+        if action < 0.62:                       # the generator's usual round (so that speculation gets going)
+            _round(eng, ours, ref, current[g], slot0=30 + 4 * g)
+        elif action < 0.72:                     # another round shape from now on
+            current[g] = menus[rnd.randint(len(menus))]
+        elif action < 0.82:                     # a host draw in between
+            k = 1 + rnd.randint(5)
+            kind = rnd.randint(3)
+            if kind == 0:
+                np.testing.assert_array_equal(ours.randn(k), ref.randn(k))
+            elif kind == 1:
+                np.testing.assert_array_equal(ours.standard_t(4.0, size=k), ref.standard_t(4.0, size=k))
+            else:
+                np.testing.assert_array_equal(ours.chisquare(3.0, k), ref.chisquare(3.0, k))
+        elif action < 0.9:                      # a device draw outside any round pattern, no round end
+            n, d = 1 + rnd.randint(3000), 1 + rnd.randint(40)
+            if n * d >= 2:
+                assert eng.noise_legacy_randn(29, ours._h, n, d)
+                np.testing.assert_array_equal(eng.noise_get_host(29, n, d), ref.randn(n, d))
+        else:                                   # state out and in again (and into the OTHER generator now and then)
+            st = ref.get_state()
+            ours.set_state(st)
+            if rnd.rand() < 0.3:
+                o2, r2 = gens[1 - g]
+                o2.set_state(st), r2.set_state(st)
+        _same_state(ours, ref)
+    launched, adopted, discarded = (b - a for a, b in zip(before, eng.legacy_ahead_stats()))
+    assert launched > 0 and adopted > 0, (launched, adopted, discarded)      # the fuzz did exercise the look-ahead
+    eng.sync()
