@@ -195,3 +195,19 @@ def test_pinned_result_arrays_are_ordinary_arrays_and_recycled(env):
     c = _lib.pinned_array(200000)               # ... and the block comes back once the last view is gone
     assert c.ctypes.data == addr
     assert type(_lib.pinned_array(10)) is np.ndarray
+
+
+def test_pinned_pool_stops_pinning_for_callers_that_keep_everything(env):
+    """A caller that keeps every gradient (FASO's history) must not pin the host's memory: beyond MAX_OUTSTANDING the result
+    arrays are ordinary pageable ones again -- and pinned ones come back once the kept arrays are dropped."""
+    vb, eng, _lib = env
+    pool = _lib.PinnedPool(_lib.load(), keep=2)
+    pool.MAX_OUTSTANDING = 3 * 8 * 200000
+    kept = [pool.array(200000) for _ in range(5)]
+    for a in kept:
+        a[:] = 2.0
+    assert pool._out == 3 * 8 * 200000             # three page-locked blocks out, the other two arrays pageable
+    del kept, a
+    assert pool._out == 0 and pool.idle_blocks() == 2      # (keep = 2: the third block was freed)
+    b = pool.array(200000)
+    assert pool._out == 8 * 200000 and pool.idle_blocks() == 1

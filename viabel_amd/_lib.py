@@ -303,13 +303,15 @@ class PinnedPool:
     engine's own mapped buffer anyway)."""
 
     MIN_BYTES = 1 << 20
+    MAX_OUTSTANDING = 1 << 30      # page-locked bytes in the callers' hands; beyond it the arrays are pageable again (a caller
+                                   # that KEEPS every gradient -- FASO's history -- must not pin the host's memory)
 
     def __init__(self, lib, keep=4):
-        self._lib, self._keep, self._free = lib, keep, {}
+        self._lib, self._keep, self._free, self._out = lib, keep, {}, 0
 
     def array(self, n):
         nbytes = 8 * int(n)
-        if nbytes < self.MIN_BYTES:
+        if nbytes < self.MIN_BYTES or self._out + nbytes > self.MAX_OUTSTANDING:
             return np.empty(n, dtype=np.float64)
         free = self._free.setdefault(nbytes, [])
         if free:
@@ -321,9 +323,11 @@ class PinnedPool:
             ptr = box.value
         buf = (ctypes.c_double * int(n)).from_address(ptr)
         weakref.finalize(buf, self._give_back, nbytes, ptr)     # buf is the array's base: it dies with the last view
+        self._out += nbytes
         return np.frombuffer(buf, dtype=np.float64)
 
     def _give_back(self, nbytes, ptr):
+        self._out -= nbytes
         free = self._free.setdefault(nbytes, [])
         if len(free) < self._keep:
             free.append(ptr)
