@@ -343,24 +343,30 @@ def prewarm_shared_device(eng, vb, distributed, which=('transport', 'c3', 'c4'))
 
 def run_probe_child(argv, env, timeout_s, want_stdout):
     """One child process of a rank (its own session; never an exec of this process): returns (exit code or 124 on
-    timeout, its stdout lines).  A child that is still running at the deadline has its whole process group killed."""
+    timeout, its stdout lines, the tail of its stderr).  A child that is still running at the deadline has its whole
+    process group killed."""
     import signal
     import subprocess
-    p = subprocess.Popen(argv, env=env, start_new_session=True, text=True,
-                         stdout=subprocess.PIPE if want_stdout else subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    try:
-        out, _ = p.communicate(timeout=timeout_s)
-        return p.returncode, (out or '').splitlines()
-    except subprocess.TimeoutExpired:
+    import tempfile
+    with tempfile.TemporaryFile(mode='w+') as err:
+        p = subprocess.Popen(argv, env=env, start_new_session=True, text=True,
+                             stdout=subprocess.PIPE if want_stdout else subprocess.DEVNULL, stderr=err)
         try:
-            os.killpg(p.pid, signal.SIGKILL)
-        except (ProcessLookupError, PermissionError):
-            pass
-        try:
-            p.communicate(timeout=10)
-        except Exception:
-            pass
-        return 124, []
+            out, _ = p.communicate(timeout=timeout_s)
+            rc, lines = p.returncode, (out or '').splitlines()
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            try:
+                p.communicate(timeout=10)
+            except Exception:
+                pass
+            rc, lines = 124, []
+        err.seek(0)
+        tail = [ln for ln in err.read().splitlines() if ln.strip() and 'RCCL version' not in ln and 'version  :' not in ln]
+        return rc, lines, ' | '.join(tail[-3:])[-400:]
 
 
 def second_transport_probe(group, transport, timeout_s=240.0, child_argv=None):
@@ -377,7 +383,7 @@ def second_transport_probe(group, transport, timeout_s=240.0, child_argv=None):
     env['VB_BENCH_TRANSPORT'] = transport
     argv = child_argv or [sys.executable, os.path.abspath(__file__), '--gpus', str(group.world), '--probe-transport', transport]
     group.barrier()
-    rc, lines = run_probe_child(argv, env, timeout_s, want_stdout=group.rank == 0)
+    rc, lines, err_tail = run_probe_child(argv, env, timeout_s, want_stdout=group.rank == 0)
     worst = group.allreduce_max(float(rc if rc >= 0 else 128 - rc))
     if group.rank != 0:
         return None
@@ -392,7 +398,8 @@ def second_transport_probe(group, transport, timeout_s=240.0, child_argv=None):
     if worst != 0 or result is None:
         return {'error': 'probe children of the %s transport: worst exit code %d over the ranks%s -- the numbers of this '
                          'transport are missing, nothing else is affected' % (transport, int(worst), '' if result is not None
-                                                                              else ', no result line')}
+                                                                              else ', no result line'),
+                'rank0_child_stderr_tail': err_tail}
     return result
 
 

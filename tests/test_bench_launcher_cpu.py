@@ -197,9 +197,11 @@ def test_second_transport_probe_reports_a_failing_child_and_goes_on(tmp_path):
         import json, os, sys
         if os.environ['RANK'] == '1':
             sys.exit(9)
+        sys.stderr.write('what the rank-0 child said on stderr\\n')
         print(json.dumps({'dependent_chain': {}, 'allreduce_us': {}}))
     ''')
-    assert set(res) == {'error'} and 'exit code 9' in res['error'] and 'ipc' in res['error']
+    assert 'what the rank-0 child said' in res['rank0_child_stderr_tail']
+    assert set(res) == {'error', 'rank0_child_stderr_tail'} and 'exit code 9' in res['error'] and 'ipc' in res['error']
 
 
 def test_second_transport_probe_kills_children_at_the_deadline(tmp_path):
@@ -208,4 +210,4 @@ def test_second_transport_probe_kills_children_at_the_deadline(tmp_path):
         import time
         time.sleep(600)
     ''', timeout_s=2.0)
-    assert set(res) == {'error'} and 'exit code 124' in res['error'] and time.time() - t0 < 60
+    assert set(res) == {'error', 'rank0_child_stderr_tail'} and 'exit code 124' in res['error'] and time.time() - t0 < 60

@@ -322,7 +322,8 @@ class PinnedPool:
                 return np.empty(n, dtype=np.float64)          # (no pinned memory left: a pageable array still works)
             ptr = box.value
         buf = (ctypes.c_double * int(n)).from_address(ptr)
-        weakref.finalize(buf, self._give_back, nbytes, ptr)     # buf is the array's base: it dies with the last view
+        fin = weakref.finalize(buf, self._give_back, nbytes, ptr)     # buf is the array's base: it dies with the last view
+        fin.atexit = False      # (at interpreter exit the HIP runtime may be gone before the arrays: the OS takes the pages back)
         self._out += nbytes
         return np.frombuffer(buf, dtype=np.float64)
 

@@ -845,7 +845,9 @@ class DISInclusiveKL(StochasticVariationalObjective):
                 or getattr(self, '_state_gen', None) != (id(eng), eng.dis_generation(kind))):
             return
         handle = eng.dis_state_park(kind, _DIS_SLOT if kind in (0, 1) else -1)
-        self._parked = (eng, kind, handle, weakref.finalize(self, eng.dis_state_drop, handle))
+        fin = weakref.finalize(self, eng.dis_state_drop, handle)
+        fin.atexit = False      # (not at interpreter exit: the HIP runtime may be gone by then)
+        self._parked = (eng, kind, handle, fin)
 
     def _materialize_state(self):
         self._state_w_clipped           # (properties: the pending fetches run)
