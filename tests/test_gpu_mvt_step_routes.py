@@ -9,7 +9,14 @@
   VB_MVT_FUSED_ROWS=0    (round 6) log p / log prior and maha / log q / c_n by two row kernels instead of one pass over samples
                          and noise: every sum is formed in the same order -- bit-identical;
   VB_MVT_CHAIN=0         (round 6) the chain rule's D x D x D product as an MFMA launch + a pack kernel instead of one launch
-                         over the lower 32 x 32 tiles: another order of the k sum -- equal to rounding.
+                         over the lower 32 x 32 tiles: another order of the k sum -- equal to rounding;
+  VB_MVT_CHAIN_FETCH=0   (round 6) the gradient gathered into mapped memory by a launch of its own behind the chain-rule kernel
+                         instead of that kernel's own second stores: the same numbers -- bit-identical;
+  VB_MVT_UNPACK=0        (round 6) the parameter read across the bus as the 32 x 32 tiles it is transposed in, and a prep launch on the
+                         main stream for the row scales, instead of one coalesced pass that takes them along: the same values by
+                         the same expressions -- bit-identical;
+  VB_GRAM_XCD=0          (round 6) the Gram product's split workgroups in plain dispatch order instead of one split per XCD:
+                         the same tiles and slabs, placed elsewhere -- bit-identical.
 Parity with the oracle is tests/test_gpu_objectives.py / test_gpu_full_size.py (all switches at their defaults)."""
 import os
 
@@ -72,6 +79,7 @@ def test_step_routes_agree(vb, D, N, df, resample, batches):
     base = call()
     for env, exact in (({'VB_MVT_SIDE_INVERSE': '0'}, True), ({'VB_MVT_FLAGSYNC': '0'}, True),
                        ({'VB_MVT_FUSED_ROWS': '0'}, True), ({'VB_MVT_CHAIN': '0'}, False),
+                       ({'VB_MVT_CHAIN_FETCH': '0'}, True), ({'VB_GRAM_XCD': '0'}, True), ({'VB_MVT_UNPACK': '0'}, True),
                        ({'VB_MVT_DIRECT': '0'}, False),
                        ({'VB_MVT_DIRECT': '0', 'VB_MVT_SIDE_INVERSE': '0', 'VB_MVT_FLAGSYNC': '0'}, False)):
         other = _with(env, call)

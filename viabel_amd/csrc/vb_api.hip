@@ -102,7 +102,14 @@ __global__ void __launch_bounds__(256) fetch_copy_kernel(FetchArgs a, unsigned l
   }
 }
 
-int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs) {
+// fetch_blocking in two halves, for a producer kernel that stores its results into the mapped buffer ITSELF (round 6: the
+// chain-rule kernel of the multivariate t's DIS step -- a gathering launch of its own cost 10.6 us behind a 14-us producer):
+// fetch_plan lays the segments out and hands the device addresses over (plan.ok == false: the segments do not qualify,
+// nothing was changed -- the caller takes fetch_blocking's route); the producer's workgroups store their share of segment k
+// from word plan.first[k] on, then each does what fetch_copy_kernel's do (system-scope fence, ticket, the last one stores
+// plan.seq into plan.done_dev); fetch_wait polls and copies the segments out.
+int fetch_plan(vb_ctx* ctx, const FetchSeg* segs, int n_segs, FetchPlan* plan) {
+  plan->ok = false;
   size_t total = 0;
   bool ok = n_segs <= kFetchMaxSegs;
   for (int k = 0; k < n_segs; ++k) {
@@ -110,14 +117,7 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
     total += (segs[k].bytes + 63) / 64 * 64;
   }
   const char* e = getenv("VB_FETCH_FLAGSYNC");
-  if (!ok || total > kFetchMaxBytes || (e && atoi(e) == 0)) {
-    for (int k = 0; k < n_segs; ++k)
-      if (segs[k].bytes)
-        VB_HIP(ctx, hipMemcpyAsync(segs[k].dst, segs[k].src, segs[k].bytes, hipMemcpyDeviceToHost, st));
-    if (st == ctx->stream) noise_prefetch(ctx);      // the next call's noise behind this call's copies, while the host waits
-    VB_HIP(ctx, hipStreamSynchronize(st));
-    return comm_check(ctx);
-  }
+  if (!ok || total > kFetchMaxBytes || (e && atoi(e) == 0)) return VB_OK;
   const size_t need = total + 64;      // ... | completion word (a line of its own)
   if (ctx->fetch_bytes < need) {
     if (ctx->fetch_host) {
@@ -132,32 +132,30 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
     VB_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->fetch_dev, ctx->fetch_host, 0));
     ctx->fetch_bytes = cap;
   }
-  VB_TRY(ensure(ctx, ctx->fetch_ticket, 64));      // (zero-filled when new; the kernel leaves it zero)
-  FetchArgs a;
-  a.n = n_segs;
+  VB_TRY(ensure(ctx, ctx->fetch_ticket, 64));      // (zero-filled when new; the kernels leave it zero)
   long long at = 0;
   for (int k = 0; k < n_segs; ++k) {
-    a.src[k] = (const unsigned long long*)segs[k].src;
-    a.first[k] = at;
-    a.words[k] = (long long)(segs[k].bytes / 8);
+    plan->first[k] = at;
     at += (long long)((segs[k].bytes + 63) / 64 * 8);
   }
-  a.first[n_segs] = at;
-  unsigned long long* hostw = (unsigned long long*)ctx->fetch_host;
-  unsigned long long* devw = (unsigned long long*)ctx->fetch_dev;
-  const size_t o_done = ctx->fetch_bytes / 8 - 8;
-  const unsigned long long seq = ++ctx->fetch_seq;
-  long long blocks = (at + 1023) / 1024;      // ~four words per thread
-  if (blocks < 1) blocks = 1;
-  if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(fetch_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, devw, (unsigned*)ctx->fetch_ticket.ptr,
-                     devw + o_done, seq);
-  VB_HIP(ctx, hipGetLastError());
-  if (st == ctx->stream) noise_prefetch(ctx);      // the next call's noise behind the gathering kernel, while the host polls
-  volatile unsigned long long* word = hostw + o_done;
+  plan->first[n_segs] = at;
+  plan->n = n_segs;
+  plan->host = (unsigned long long*)ctx->fetch_host;
+  plan->dev = (unsigned long long*)ctx->fetch_dev;
+  plan->o_done = ctx->fetch_bytes / 8 - 8;
+  plan->done_dev = plan->dev + plan->o_done;
+  plan->ticket = (unsigned*)ctx->fetch_ticket.ptr;
+  plan->seq = ++ctx->fetch_seq;
+  plan->ok = true;
+  return VB_OK;
+}
+
+int fetch_wait(vb_ctx* ctx, hipStream_t st, const FetchPlan& plan, const FetchSeg* segs) {
+  if (st == ctx->stream) noise_prefetch(ctx);      // the next call's noise behind the producing kernel, while the host polls
+  volatile unsigned long long* word = plan.host + plan.o_done;
   bool seen = false;
   for (unsigned spins = 0; spins < 2000000u && !seen; ++spins) {      // ~10 ms, then the stream
-    seen = *word == seq;
+    seen = *word == plan.seq;
     if (!seen) {
       __builtin_ia32_pause();
       if ((spins & 255u) == 255u) ::legacy_spec_poll(ctx);      // (a look-ahead draw's finish may have landed: start the next one)
@@ -165,9 +163,36 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
   }
   if (!seen) VB_HIP(ctx, hipStreamSynchronize(st));
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  for (int k = 0; k < n_segs; ++k)
-    if (segs[k].bytes) memcpy(segs[k].dst, hostw + a.first[k], segs[k].bytes);
+  for (int k = 0; k < plan.n; ++k)
+    if (segs[k].bytes) memcpy(segs[k].dst, plan.host + plan.first[k], segs[k].bytes);
   return comm_check(ctx);
+}
+
+int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs) {
+  FetchPlan plan;
+  VB_TRY(fetch_plan(ctx, segs, n_segs, &plan));
+  if (!plan.ok) {
+    for (int k = 0; k < n_segs; ++k)
+      if (segs[k].bytes)
+        VB_HIP(ctx, hipMemcpyAsync(segs[k].dst, segs[k].src, segs[k].bytes, hipMemcpyDeviceToHost, st));
+    if (st == ctx->stream) noise_prefetch(ctx);      // the next call's noise behind this call's copies, while the host waits
+    VB_HIP(ctx, hipStreamSynchronize(st));
+    return comm_check(ctx);
+  }
+  FetchArgs a;
+  a.n = n_segs;
+  for (int k = 0; k < n_segs; ++k) {
+    a.src[k] = (const unsigned long long*)segs[k].src;
+    a.first[k] = plan.first[k];
+    a.words[k] = (long long)(segs[k].bytes / 8);
+  }
+  a.first[n_segs] = plan.first[n_segs];
+  long long blocks = (plan.first[n_segs] + 1023) / 1024;      // ~four words per thread
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(fetch_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, plan.dev, plan.ticket, plan.done_dev, plan.seq);
+  VB_HIP(ctx, hipGetLastError());
+  return fetch_wait(ctx, st, plan, segs);
 }
 
 // The other direction: `bytes` of a caller-owned (pageable) host array into device memory without a synchronisation -- the

@@ -238,6 +238,7 @@ struct vb_ctx {
     int64_t o_theta = 0, o_lt = 0, o_wt = 0, o_tscr = 0, o_mu = 0, o_li = 0, o_lfull = 0, o_c = 0, ld = 0;
     int d = 0;
     bool clean = false;
+    bool lfull_here = false;            // the side stream's prep also forms L = (L')' (the main stream had no prep launch)
   } mvt_inv_args;
   double* mvt_pin_dev = nullptr;        // device address of mvt_pin (mapped: the unpack reads the parameter in place)
   std::vector<double> mvt_prior;        // tempering-prior parameter the device copy was made from
@@ -601,6 +602,20 @@ int sync_streams(vb_ctx* ctx);   // main + pipeline streams
 // blocking device -> host fetch of small results: one gathering kernel into mapped memory + a polled completion word
 // (vb_api.hip); plain copies + hipStreamSynchronize above 1 MB
 int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs);
+// the same in two halves around a producer kernel that writes the mapped buffer itself (vb_api.hip)
+struct FetchPlan {
+  bool ok = false;
+  int n = 0;
+  long long first[9] = {0};            // first word of segment k in the mapped buffer (64-byte aligned); [n] = total
+  unsigned long long* host = nullptr;  // the mapped buffer, host / device address
+  unsigned long long* dev = nullptr;
+  size_t o_done = 0;                   // word index of the completion word
+  unsigned long long* done_dev = nullptr;
+  unsigned* ticket = nullptr;          // device counter, zero between launches
+  unsigned long long seq = 0;
+};
+int fetch_plan(vb_ctx* ctx, const FetchSeg* segs, int n_segs, FetchPlan* plan);
+int fetch_wait(vb_ctx* ctx, hipStream_t st, const FetchPlan& plan, const FetchSeg* segs);
 // host -> device copy of a small caller-owned array without a synchronisation (mapped staging slots + a copy kernel)
 int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, void* dev_dst, size_t row_bytes = 0,
                size_t dst_stride_bytes = 0);      // row_bytes != 0: rows of row_bytes land dst_stride_bytes apart

@@ -412,29 +412,38 @@ __global__ void __launch_bounds__(256) fr_colsum_kernel(const double* __restrict
 // ---- reduce: split-K slabs, row-block partials -> sum vector ------------------------------------------
 // sum vector layout: [F | colsum (ldz) | C (d x ldl)], F at index 0, colsum from 16, C from 16 + ldz
 
-// One thread per pair of adjacent C entries (16-B loads, up to 8 split slabs in flight, summed in slab
-// order); entries above the diagonal are not computed by the GEMM and are written as zero.
+// One thread per pair of adjacent C entries (16-B loads, CHUNK split slabs in flight, summed in slab order); entries above
+// the diagonal are not computed by the GEMM and are written as zero.
+// Round 6: the three reductions have workgroups of their own -- blocks [0, nb_c) the C pairs, the next ceil(ldz / 256) the
+// column sums, the last one the scalars -- where block 0 used to do all three one after the other (at D = 256 with 64 slabs
+// and 128 row blocks: ten dependent round trips in one workgroup, 10.6 us for 21 MB); CHUNK = 64 for launches that leave
+// the SIMDs a wave or two each anyway (the registers cost nothing there: every slab's load in flight at once).  The sums are
+// formed in the same order as before: the same bits.
+template <int CHUNK>
 __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict__ Cpart, int splits,
                                                         int64_t slab, int d, int64_t ldl,
                                                         const double* __restrict__ colpart, int n_rb,
                                                         int64_t ldz, const double* __restrict__ fpart,
                                                         int n_fpart, FrSums S, int full,
-                                                        const double* __restrict__ wpart = nullptr) {
+                                                        const double* __restrict__ wpart, int nb_c) {
   __shared__ double sh[4];
-  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t idx = 2 * tid;
-  const int64_t nC = (int64_t)d * ldl;
-  if (idx < nC) {
+  const int nb_col = (int)((ldz + 255) / 256);
+  if ((int)blockIdx.x < nb_c) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t idx = 2 * tid;
+    const int64_t nC = (int64_t)d * ldl;
+    if (idx >= nC) return;
     const int i = (int)(idx / ldl), j = (int)(idx % ldl);
     fr_d2 s = (fr_d2){0.0, 0.0};
     if (full == 1 || j <= i) {
-      for (int k0 = 0; k0 < splits; k0 += 16) {      // sixteen slabs in flight (eight until round 5), added in slab order
-        fr_d2 v[16];
+      for (int k0 = 0; k0 < splits; k0 += CHUNK) {
+        fr_d2 v[CHUNK];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-          v[u] = k0 + u < splits ? *reinterpret_cast<const fr_d2*>(Cpart + (k0 + u) * slab + idx) : (fr_d2){0.0, 0.0};
+        for (int u = 0; u < CHUNK; ++u)      // (clamped, not predicated: no load behind a branch; the surplus is not added)
+          v[u] = *reinterpret_cast<const fr_d2*>(Cpart + (k0 + u < splits ? k0 + u : splits - 1) * slab + idx);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += v[u];
+        for (int u = 0; u < CHUNK; ++u)
+          if (k0 + u < splits) s += v[u];
       }
       if (full != 1 && j + 1 > i) s.y = 0.0;
     }
@@ -458,8 +467,11 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
     } else {
       *reinterpret_cast<fr_d2*>(S.sums + S.off_c + idx) = s;
     }
+    return;
   }
-  if (tid < ldz) {
+  if ((int)blockIdx.x < nb_c + nb_col) {
+    const int64_t tid = (int64_t)((int)blockIdx.x - nb_c) * 256 + threadIdx.x;
+    if (tid >= ldz) return;
     double s = 0.0;
     if (tid < d) {
       for (int rb0 = 0; rb0 < n_rb; rb0 += 32) {      // 32 loads in flight (16 until round 5), summed in row-block order
@@ -471,21 +483,34 @@ __global__ void __launch_bounds__(256) fr_reduce_kernel(const double* __restrict
       }
     }
     S.sums[S.off_col + tid] = s;
+    return;
   }
-  if (blockIdx.x == 0) {
-    double f = 0.0;
-    for (int e = threadIdx.x; e < n_fpart; e += 256) f += fpart[e];
-    f = fr_block_sum(f, sh);
-    if (threadIdx.x == 0) S.sums[0] = f;
-    if (wpart) {      // two more scalars given as per-row-block partials (wpart[q n_rb + rb]) -> sums[1], sums[2]
-      for (int q = 0; q < 2; ++q) {
-        double t = 0.0;
-        for (int e = threadIdx.x; e < n_rb; e += 256) t += wpart[(int64_t)q * n_rb + e];
-        t = fr_block_sum(t, sh);
-        if (threadIdx.x == 0) S.sums[1 + q] = t;
-      }
+  double f = 0.0;
+  for (int e = threadIdx.x; e < n_fpart; e += 256) f += fpart[e];
+  f = fr_block_sum(f, sh);
+  if (threadIdx.x == 0) S.sums[0] = f;
+  if (wpart) {      // two more scalars given as per-row-block partials (wpart[q n_rb + rb]) -> sums[1], sums[2]
+    for (int q = 0; q < 2; ++q) {
+      double t = 0.0;
+      for (int e = threadIdx.x; e < n_rb; e += 256) t += wpart[(int64_t)q * n_rb + e];
+      t = fr_block_sum(t, sh);
+      if (threadIdx.x == 0) S.sums[1 + q] = t;
     }
   }
+}
+
+// (both launch sites: the C pairs' blocks, the column sums' blocks, one block of scalars)
+static void fr_reduce_launch(vb_ctx* ctx, hipStream_t st, const double* Cpart, int splits, int64_t slab, int d, int64_t ldl,
+                             const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S, int full,
+                             const double* wpart) {
+  const int nb_c = (int)((slab / 2 + 255) / 256), nb_col = (int)((ldz + 255) / 256);
+  const dim3 grid((unsigned)(nb_c + nb_col + 1));
+  if (splits > 16 && nb_c <= 2 * ctx->prop.multiProcessorCount)
+    hipLaunchKernelGGL(fr_reduce_kernel<64>, grid, dim3(256), 0, st, Cpart, splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart,
+                       S, full, wpart, nb_c);
+  else
+    hipLaunchKernelGGL(fr_reduce_kernel<16>, grid, dim3(256), 0, st, Cpart, splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart,
+                       S, full, wpart, nb_c);
 }
 
 #ifdef VB_DBG_IDLE
@@ -1047,9 +1072,7 @@ int fr_colsum_enqueue(vb_ctx* ctx, const double* G, const double* Zc, int64_t ld
 int fr_reduce_enqueue(vb_ctx* ctx, const double* Cpart, int splits, int64_t slab, int d, int64_t ldl,
                       const double* colpart, int n_rb, int64_t ldz, const double* fpart, int n_fpart, FrSums S, bool mirror,
                       const double* wpart) {
-  const int64_t items = slab / 2 > ldz ? slab / 2 : ldz;
-  hipLaunchKernelGGL(fr_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, Cpart,
-                     splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S, mirror ? 2 : 0, wpart);
+  fr_reduce_launch(ctx, ctx->stream, Cpart, splits, slab, d, ldl, colpart, n_rb, ldz, fpart, n_fpart, S, mirror ? 2 : 0, wpart);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -1065,7 +1088,11 @@ int gram_lower_enqueue(vb_ctx* ctx, const double* A, const double* B, int64_t ld
   g3.N = d;
   g3.K = (int)n;
   g3.tri_mode = 2;
-  gemm_f64_launch<false>(ctx->stream, g3, splits, ctx->prop.multiProcessorCount, EpiSplitSlab{Cpart, ldc, slab});
+  const char* cfg_env = getenv("VB_GRAM_CFG");      // experiments: the tile configuration of this product alone (vb_gemm_f64.h)
+  const char* xcd_env = getenv("VB_GRAM_XCD");
+  g3.xcd_group = xcd_env ? atoi(xcd_env) : 1;
+  gemm_f64_launch<false>(ctx->stream, g3, splits, ctx->prop.multiProcessorCount, EpiSplitSlab{Cpart, ldc, slab},
+                         cfg_env ? atoi(cfg_env) : 0);
   VB_HIP(ctx, hipGetLastError());
   return VB_OK;
 }
@@ -1767,8 +1794,8 @@ int fr_pipeline_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, 
   const dim3 red_grid((unsigned)((red_items + 255) / 256));
   VB_TRY(up_wait_all());      // (the epilogue reads the flat parameter's diagonal)
   if (mvt) {
-    hipLaunchKernelGGL(fr_reduce_kernel, red_grid, dim3(256), 0, st, (const double*)Cpart, splits, slab, D, ldl,
-                       (const double*)colpart, n_rb, ldz, (const double*)fpart, n_fpart, S, 1);
+    fr_reduce_launch(ctx, st, (const double*)Cpart, splits, slab, D, ldl, (const double*)colpart, n_rb, ldz, (const double*)fpart,
+                     n_fpart, S, 1, nullptr);
     VB_HIP(ctx, hipGetLastError());
     if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, S.sums, (size_t)S.len));
     *sums_out = S;

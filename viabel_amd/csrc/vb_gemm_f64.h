@@ -67,6 +67,11 @@ struct GemmArgs {
   // global indices.  (The blocking full-rank call starts the sampling product of the heaviest column blocks while the rest
   // of the parameter is still crossing PCIe: vb_fullrank.hip, FrUpload.)
   int bn_begin = 0, bn_count = 0;
+  // split products, optional (LDS-DMA kernel; the launcher clears it unless gridDim.z % 8 == 0): the workgroups of ONE split
+  // -- which read the same k range of both operands -- are dispatched to ONE XCD.  Workgroups go to the XCDs round robin
+  // in linear order (x fastest), so the gridDim.x tiles of a split land on all eight L2s and every L2 streams every
+  // panel; remapped, workgroup L computes tile (L / 8) % gridDim.x of split L % 8 + 8 (L / (8 gridDim.x)).
+  int xcd_group = 0;
   // wave-priority alternation (LDS-DMA kernel): workgroups of generation (linear id / prio_div) & 1 raise their
   // wave priority on even slabs, the others on odd slabs (0: off).  Set by the launcher to the number of CUs.
   int prio_div = 0;
@@ -443,6 +448,7 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
   g.tiles_m = gemm_tiles(g.M, bm_rows);
   g.tiles_n = gemm_tiles(g.N, bn_cols);
   if (g.bn_count && (g.tri_mode != 1 || g.bn_begin + g.bn_count > g.tiles_n)) g.bn_begin = g.bn_count = 0;
+  if (splits % 8 != 0 || g.batch) g.xcd_group = 0;
   const dim3 grid(g.tile_map ? (unsigned)g.tile_blocks
                              : g.bn_count ? (unsigned)(g.tiles_m * g.bn_count) : (unsigned)gemm_count_blocks(g, bm_rows, bn_cols), 1,
                   (unsigned)splits);

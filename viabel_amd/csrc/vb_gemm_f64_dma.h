@@ -482,8 +482,13 @@ __device__ __forceinline__ void gemm_f64_dma_tile(const GemmArgs& g, const Epi& 
 template <bool A_KCONTIG, int AF, int NB, int STAGES, class Epi>
 __global__ void __launch_bounds__(256, AF * NB > 32 ? (STAGES > 2 ? 1 : 2) : (AF * NB > 16 || STAGES > 2 ? 2 : 4))
     gemm_f64_dma_kernel(const GemmArgs g, const Epi epi) {
-  gemm_f64_dma_tile<A_KCONTIG, AF, NB, STAGES, Epi, GemmNoDep>(g, epi, GemmNoDep{}, (int)blockIdx.x, (int)blockIdx.z,
-                                                               (int)gridDim.x);
+  int bx = (int)blockIdx.x, bz = (int)blockIdx.z;
+  if (g.xcd_group) {      // (GemmArgs::xcd_group: the tiles of a split on one XCD)
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z, slot = lin >> 3;
+    bz = (int)((lin & 7) + 8 * (slot / gridDim.x));
+    bx = (int)(slot % gridDim.x);
+  }
+  gemm_f64_dma_tile<A_KCONTIG, AF, NB, STAGES, Epi, GemmNoDep>(g, epi, GemmNoDep{}, bx, bz, (int)gridDim.x);
 }
 
 template <bool A_KCONTIG, int AF, int NB, int STAGES, class Epi>

@@ -518,6 +518,17 @@ __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __rest
   out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -scale * g;
 }
 
+// mvt_chain_kernel's optional second destination: the mapped host buffer of a blocking call (fetch_plan, vb_api.hip) -- the
+// gradient's entries go there with the same stores that write them to device memory, the last workgroup to finish publishes
+// the completion word: no gathering launch behind the producer (10.6 us at D = 256 for 265 KB).  grad == nullptr: off.
+struct ChainHost {
+  double* grad = nullptr;                 // plen doubles: the flat gradient (out + 1)
+  double* tail = nullptr;                 // [eps, ess, status, khat | value]
+  unsigned* ticket = nullptr;
+  unsigned long long* done = nullptr;
+  unsigned long long seq = 0;
+};
+
 // The packed chain rule of the direct route in ONE launch (round 6): dL = tril(L^-T M) and d/dmu = L^-T v straight into
 // the flat gradient -- the D x D x D product used to be a full MFMA launch (one 64 x 64 tile per CU, 16 dependent slabs:
 // 14.5 us at D = 256 for 33 MFLOP) followed by a pack kernel (4.9 us).  Here: one workgroup per LOWER 32 x 32 tile of the
@@ -528,7 +539,8 @@ __global__ void __launch_bounds__(256) mvt_pack_grad_kernel(const double* __rest
 __global__ void __launch_bounds__(256) mvt_chain_kernel(const double* __restrict__ Wt, const double* __restrict__ Lfull,
                                                         int64_t ld, int d, const double* __restrict__ sums, int64_t off_col,
                                                         int64_t off_c, double scale, double* __restrict__ out,
-                                                        const double* __restrict__ scale_dev, const double* __restrict__ res) {
+                                                        const double* __restrict__ scale_dev, const double* __restrict__ res,
+                                                        ChainHost H) {
   // four k groups of 64 threads; a group walks its quarter of every 64-deep k step (16 deep per group) with a 4 x 4 micro
   // tile per thread; the groups' partial tiles are added in group order at the end.  (One group walking the whole k range
   // in 32-deep steps -- the first version -- was a chain of eight load-wait-multiply rounds: 50 us at D = 256.)
@@ -600,6 +612,7 @@ __global__ void __launch_bounds__(256) mvt_chain_kernel(const double* __restrict
       double g = ((red[(0 * 32 + r) * 33 + c] + red[(1 * 32 + r) * 33 + c]) + red[(2 * 32 + r) * 33 + c]) + red[(3 * 32 + r) * 33 + c];
       if (i == j) g = g * Lfull[(int64_t)i * ld + i] - w_sum;
       out[1 + d + (int64_t)i * (i + 1) / 2 + j] = -scale * g;
+      if (H.grad) H.grad[d + (int64_t)i * (i + 1) / 2 + j] = -scale * g;
     }
   }
   if (ti == tj) {      // d/dmu for the tile's rows: eight lanes per row over k >= i, combined by shuffles in a fixed order
@@ -622,14 +635,100 @@ __global__ void __launch_bounds__(256) mvt_chain_kernel(const double* __restrict
     a += __shfl_xor(a, 1, 64);
     a += __shfl_xor(a, 2, 64);
     a += __shfl_xor(a, 4, 64);
-    if (s8 == 0 && i < d) out[1 + i] = -scale * a;
+    if (s8 == 0 && i < d) {
+      out[1 + i] = -scale * a;
+      if (H.grad) H.grad[i] = -scale * a;
+    }
   }
   if (blockIdx.x == 0 && t == 0) {
     out[0] = -scale * w_logq;
     double* tail = out + 1 + d + (int64_t)d * (d + 1) / 2;      // [eps, ess, status, khat | value]: see mvt_pack_grad_kernel
     for (int q = 0; q < 4; ++q) tail[q] = res[q];
     tail[4] = -scale * w_logq;
+    if (H.grad) {
+      for (int q = 0; q < 4; ++q) H.tail[q] = res[q];
+      H.tail[4] = -scale * w_logq;
+    }
   }
+  if (H.grad) {      // what fetch_copy_kernel's workgroups do behind their stores (vb_api.hip): the last one publishes
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) {
+      const unsigned tk = __hip_atomic_fetch_add(H.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk == gridDim.x - 1) {
+        __hip_atomic_store(H.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        __hip_atomic_store(H.done, H.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+// The throughput mode's parameter upload (round 6): the flat parameter sits in MAPPED host memory and is read across the bus
+// once, in 1-KiB wave-loads of consecutive entries (fr_unpack_kernel reads it as the 32 x 32 tiles of L it transposes: 256-byte
+// runs that start anywhere in a line -- 11.3 us for 265 KB at D = 256, 23 GB/s); every entry goes to the device-resident copy
+// (coalesced) and to its place in mu or L' (Lt[k][j] = L[j][k], exp on the diagonal: scattered 8-byte stores, 33 K of them
+// at D = 256).  The same launch has the workgroups that zero L' below the diagonal and, when the caller asks for it, the
+// two pieces of mvt_prep_kernel that do not depend on the unpacked factor -- the t family's row scales 1 / sqrt(chi_n / df) and the
+// 32 scalars of the bisection -- so that the main stream needs no prep launch before its sampling product (the transposed copy
+// L goes to the side stream's prep).  The values are fr_unpack_kernel's and mvt_prep_kernel's (same expressions): bit-identical.
+// blocks [0, nb_t): 1024 entries each; [nb_t, nb_t + nb_z): the lower 32 x 32 tiles (diagonal ones included); the rest: chi.
+__global__ void __launch_bounds__(256) mvt_unpack_kernel(const double* __restrict__ theta, int d, int64_t ld,
+                                                         double* __restrict__ Lt, double* __restrict__ mu,
+                                                         double* __restrict__ copy, const double* __restrict__ chi, double df,
+                                                         int64_t n_inv, double* __restrict__ inv_s, double* __restrict__ scal,
+                                                         int nb_t, int nb_z) {
+  const int b = (int)blockIdx.x, t = (int)threadIdx.x;
+  const int64_t p = (int64_t)d + (int64_t)d * (d + 1) / 2;
+  if (b == 0 && scal && t < 32) scal[t] = 0.0;
+  if (b < nb_t) {
+    mvt_d2 v[2];
+    int64_t at[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {      // (the staging slot is padded to whole 64-byte lines: a pair may reach past p, never past the slot)
+      at[q] = (int64_t)b * 1024 + 2 * (t + 256 * q);
+      v[q] = *reinterpret_cast<const mvt_d2*>(theta + (at[q] < p ? at[q] : 0));
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (at[q] >= p) continue;
+      if (at[q] + 1 < p) *reinterpret_cast<mvt_d2*>(copy + at[q]) = v[q];
+      else copy[at[q]] = v[q].x;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t e = at[q] + h;
+        if (e >= p) break;
+        const double x = h ? v[q].y : v[q].x;
+        if (e < d) {
+          mu[e] = x;
+          continue;
+        }
+        const int64_t tt = e - d;
+        int64_t j = (int64_t)((sqrt(8.0 * (double)tt + 1.0) - 1.0) * 0.5);
+        while ((j + 1) * (j + 2) / 2 <= tt) ++j;
+        while (j * (j + 1) / 2 > tt) --j;
+        const int64_t k = tt - j * (j + 1) / 2;
+        Lt[k * ld + j] = k == j ? exp(x) : x;
+      }
+    }
+    return;
+  }
+  if (b < nb_t + nb_z) {
+    int kt = 0;
+    const int z = b - nb_t;
+    while ((kt + 1) * (kt + 2) / 2 <= z) ++kt;
+    const int jt = z - kt * (kt + 1) / 2;
+    const int tx = t & 31, ty = t >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int k = kt * 32 + r, j = jt * 32 + tx;
+      if (k < d && j < d && k > j) Lt[(int64_t)k * ld + j] = 0.0;
+    }
+    return;
+  }
+  const int nb_i = (int)gridDim.x - nb_t - nb_z;
+  for (int64_t i = (int64_t)(b - nb_t - nb_z) * 256 + t; i < n_inv; i += (int64_t)nb_i * 256)
+    inv_s[i] = 1.0 / sqrt(chi[i] / df);      // (mvt_prep_kernel, role 3)
 }
 
 // theta (host) -> device: mu, L' (o_lt), L (o_lfull), Wt = L^-T (o_wt), Li = L^-1 (o_li), c = L^-1 mu (o_c)
@@ -657,10 +756,11 @@ static int mvt_side_enqueue(vb_ctx* ctx) {
   VB_TRY(fr_tri_inverse_enqueue(ctx, sd, a.base + a.o_theta, a.base + a.o_lt, a.d, a.ld, a.base + a.o_wt, a.base + a.o_tscr,
                                 a.clean));
   const int tiles = (a.d + 31) / 32, gx = tiles * tiles > (a.d + 3) / 4 ? tiles * tiles : (a.d + 3) / 4;
-  hipLaunchKernelGGL(mvt_prep_kernel, dim3((unsigned)gx, 2), dim3(256), 0, sd, (const double*)(a.base + a.o_wt),
+  // (roles 0 and 2 -- Li and c, read off the inverse -- and, when the main stream did not form it, role 1: L = (L')')
+  hipLaunchKernelGGL(mvt_prep_kernel, dim3((unsigned)gx, a.lfull_here ? 3 : 2), dim3(256), 0, sd, (const double*)(a.base + a.o_wt),
                      (const double*)(a.base + a.o_lt), (const double*)(a.base + a.o_mu), a.base + a.o_li, a.base + a.o_lfull,
                      a.base + a.o_c, (double*)nullptr, a.d, a.ld, (const double*)nullptr, 0.0, (int64_t)0, (double*)nullptr,
-                     0x5);
+                     a.lfull_here ? 0x7 : 0x5);
   VB_HIP(ctx, hipGetLastError());
   VB_HIP(ctx, hipEventRecord(ctx->mvt_ev_join, sd));
   return VB_OK;
@@ -676,7 +776,7 @@ static int mvt_join_inverse(vb_ctx* ctx) {
 
 static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t d, const double* theta_host,
                               bool zero_scal = false, const double* chi = nullptr, double df = 0.0, int64_t n_inv = 0,
-                              bool defer_inverse = false) {
+                              bool defer_inverse = false, bool lfull_main = true) {
   VB_TRY(mvt_join_inverse(ctx));      // (the unpack below overwrites what a pending inverse still reads)
   hipStream_t st = ctx->stream;
   const int D = (int)d;
@@ -689,9 +789,10 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
       VB_HIP(ctx, hipHostFree(ctx->mvt_pin));
       ctx->mvt_pin = nullptr;
     }
-    VB_HIP(ctx, hipHostMalloc((void**)&ctx->mvt_pin, 2 * p * sizeof(double), hipHostMallocMapped));
+    const size_t pr = (p + 7) / 8 * 8;      // (whole 64-byte lines per slot: mvt_unpack_kernel reads 16-byte pairs)
+    VB_HIP(ctx, hipHostMalloc((void**)&ctx->mvt_pin, 2 * pr * sizeof(double), hipHostMallocMapped));
     VB_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->mvt_pin_dev, ctx->mvt_pin, 0));
-    ctx->mvt_pin_doubles = p;
+    ctx->mvt_pin_doubles = pr;
   }
   // two staging slots taken in turn; an event behind each slot's copy is waited for before the slot is rewritten (a
   // deferred refresh returns without a synchronisation, so back-to-back refreshes could otherwise overwrite a slot
@@ -706,8 +807,23 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
     VB_HIP(ctx, hipMemsetAsync(base + L.o_mu, 0, (size_t)(2 * L.ld) * sizeof(double), st));
   // the unpack reads the staged parameter IN PLACE (mapped host memory, every entry once) and leaves the device copy
   // behind: no DMA-engine round trip between the host's memcpy and the first kernel
-  VB_TRY(fr_unpack_enqueue(ctx, st, ctx->mvt_pin_dev + (size_t)ctx->mvt_pin_slot * ctx->mvt_pin_doubles, D, L.ld,
-                           base + L.o_lt, base + L.o_mu, base + L.o_theta));
+  const bool side_env = mvt_env_on("VB_MVT_SIDE_INVERSE");
+  const bool unpack_env = mvt_env_on("VB_MVT_UNPACK");      // 0: fr_unpack_kernel's tiles + the main stream's prep launch
+  // (the one-launch front: nothing but the unpack in front of the sampling product -- row scales and scalars ride along, L goes
+  // to the side stream)
+  const bool front = unpack_env && defer_inverse && side_env && !lfull_main;
+  const double* theta_mapped = ctx->mvt_pin_dev + (size_t)ctx->mvt_pin_slot * ctx->mvt_pin_doubles;
+  if (unpack_env) {
+    const int nt = (D + 31) / 32, nb_t = (int)((p + 1023) / 1024), nb_z = nt * (nt + 1) / 2;
+    int nb_i = front && chi ? (int)((n_inv + 1023) / 1024) : 0;
+    nb_i = nb_i > 64 ? 64 : nb_i;
+    hipLaunchKernelGGL(mvt_unpack_kernel, dim3((unsigned)(nb_t + nb_z + nb_i)), dim3(256), 0, st, theta_mapped, D, L.ld,
+                       base + L.o_lt, base + L.o_mu, base + L.o_theta, front ? chi : (const double*)nullptr, df, n_inv,
+                       base + L.o_invs, front && zero_scal ? base + L.o_scal : (double*)nullptr, nb_t, nb_z);
+    VB_HIP(ctx, hipGetLastError());
+  } else {
+    VB_TRY(fr_unpack_enqueue(ctx, st, theta_mapped, D, L.ld, base + L.o_lt, base + L.o_mu, base + L.o_theta));
+  }
   VB_HIP(ctx, hipEventRecord(slot_ev, st));
   // the inverse's strictly lower triangle (and the scratch) need zeroing only when the buffer or its layout changed:
   // nothing else writes o_wt in throughput mode
@@ -716,7 +832,6 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   memcpy(ctx->mvt_inv_key, key, sizeof key);
   // (the transposes write every entry of the d x d blocks; the pad columns hold the zeros of the allocation)
   const int tiles = (D + 31) / 32, gx = tiles * tiles > (D + 3) / 4 ? tiles * tiles : (D + 3) / 4;
-  const bool side_env = mvt_env_on("VB_MVT_SIDE_INVERSE");
   if (defer_inverse && side_env) {
     if (!ctx->mvt_side) {
       VB_HIP(ctx, hipStreamCreateWithFlags(&ctx->mvt_side, hipStreamNonBlocking));
@@ -727,8 +842,10 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
     auto& a = ctx->mvt_inv_args;
     a.base = base, a.o_theta = L.o_theta, a.o_lt = L.o_lt, a.o_wt = L.o_wt, a.o_tscr = L.o_tscr, a.o_mu = L.o_mu;
     a.o_li = L.o_li, a.o_lfull = L.o_lfull, a.o_c = L.o_c, a.ld = L.ld, a.d = D, a.clean = clean;
+    a.lfull_here = front;
     ctx->mvt_inv_pending = true;
     ctx->mvt_inv_queued = false;
+    if (front) return VB_OK;      // (row scales and scalars: the unpack's launch; L: the side stream's prep)
     hipLaunchKernelGGL(mvt_prep_kernel, dim3((unsigned)gx, chi ? 2 : 1), dim3(256), 0, st, (const double*)(base + L.o_wt),
                        (const double*)(base + L.o_lt), (const double*)(base + L.o_mu), base + L.o_li, base + L.o_lfull,
                        base + L.o_c, zero_scal ? base + L.o_scal : (double*)nullptr, D, L.ld, chi, df, n_inv, base + L.o_invs,
@@ -967,7 +1084,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
     return fail(ctx, VB_ERR_STATE, "chi == NULL needs %lld (or all %lld) device chi-square(%g) draws (vb_chisq_generate)",
                 (long long)n, (long long)n_total, df);
   if (dev_factors) {      // throughput mode: mu, L', L^-1 from theta on the device; the samples go through L' (see header)
-    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true, chi_rows, df, n, true));
+    VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host, true, chi_rows, df, n, true, /*lfull_main=*/sym_root));
     // reference-identical sampling (approximations.py:348): x = mu + (z Sigma^(1/2)) / s with the SYMMETRIC root, formed
     // on the device from the unpacked factor (VB_ERR_UNSUPPORTED: not resolved to 1e-12 -- the caller's LAPACK route)
     if (sym_root) {
@@ -1401,10 +1518,31 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     if (direct && d <= 512 && mvt_env_on("VB_MVT_CHAIN")) {
       // (direct route, moderate D: product and pack as ONE launch over the lower 32 x 32 tiles -- mvt_chain_kernel)
       const int nt = (D + 31) / 32;
+      // a blocking call's results leave with the kernel's own stores (ChainHost; VB_MVT_CHAIN_FETCH=0: the gathering launch)
+      double tail[5];
+      const FetchSeg segs[2] = {{base + L.o_grad + 1, plen * sizeof(double), grad_direct},
+                                {base + L.o_grad + 1 + plen, sizeof tail, tail}};
+      FetchPlan plan;
+      ChainHost H;
+      if (grad_direct && mvt_env_on("VB_MVT_FLAGSYNC") && mvt_env_on("VB_MVT_CHAIN_FETCH")) {
+        VB_TRY(fetch_plan(ctx, segs, 2, &plan));
+        if (plan.ok) {
+          H.grad = (double*)(plan.dev + plan.first[0]);
+          H.tail = (double*)(plan.dev + plan.first[1]);
+          H.ticket = plan.ticket, H.done = plan.done_dev, H.seq = plan.seq;
+        }
+      }
       hipLaunchKernelGGL(mvt_chain_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, (const double*)(base + L.o_wt),
                          (const double*)(base + L.o_lfull), L.ld, D, (const double*)S.sums, S.off_col, S.off_c, scale,
-                         base + L.o_grad, scale_dev, (const double*)(base + L.o_scal + 8));
+                         base + L.o_grad, scale_dev, (const double*)(base + L.o_scal + 8), H);
       VB_HIP(ctx, hipGetLastError());
+      if (H.grad) {
+        VB_TRY(fetch_wait(ctx, st, plan, segs));
+        packed_out[0] = tail[4];
+        if (res_out)
+          for (int q = 0; q < 4; ++q) res_out[q] = tail[q];
+        return VB_OK;
+      }
     } else {
     GemmArgs gs;
     gs.A = direct ? base + L.o_wt : S.sums + S.off_c;      // direct: L^-T M instead of S L
