@@ -7,7 +7,8 @@
   VB_MVT_FLAGSYNC=0      gradient by a device-to-host copy + stream synchronisation instead of mapped memory and a
                          polled completion word: the same numbers through another door -- bit-identical;
   VB_MVT_FUSED_ROWS=0    (round 6) log p / log prior and maha / log q / c_n by two row kernels instead of one pass over samples
-                         and noise: every sum is formed in the same order -- bit-identical;
+                         and noise: every sum is formed in the same order -- bit-identical (compared with VB_MVT_EPI_ROWS=0 on
+                         both sides: where the epilogue route applies it replaces both);
   VB_MVT_CHAIN=0         (round 6) the chain rule's D x D x D product as an MFMA launch + a pack kernel instead of one launch
                          over the lower 32 x 32 tiles: another order of the k sum -- equal to rounding;
   VB_MVT_CHAIN_FETCH=0   (round 6) the gradient gathered into mapped memory by a launch of its own behind the chain-rule kernel
@@ -15,6 +16,9 @@
   VB_MVT_UNPACK=0        (round 6) the parameter read across the bus as the 32 x 32 tiles it is transposed in, and a prep launch on the
                          main stream for the row scales, instead of one coalesced pass that takes them along: the same values by
                          the same expressions -- bit-identical;
+  VB_MVT_EPI_ROWS=0      (round 6) log p / log prior / maha by a pass over samples and noise instead of the sampling product's
+                         epilogue + the noise rows' norms: other groupings of the same sums -- equal to rounding, the tempering
+                         walk's outcome included (eps, ESS: compared to rounding as well);
   VB_GRAM_XCD=0          (round 6) the Gram product's split workgroups in plain dispatch order instead of one split per XCD:
                          the same tiles and slabs, placed elsewhere -- bit-identical.
 Parity with the oracle is tests/test_gpu_objectives.py / test_gpu_full_size.py (all switches at their defaults)."""
@@ -77,13 +81,25 @@ SHAPES = [(5, 64), (50, 1000), (130, 513), (256, 4096), (300, 2048)]
 def test_step_routes_agree(vb, D, N, df, resample, batches):
     call = lambda: _step(vb, D, N, df, resample, batches, steps=3, seed=D + N)
     base = call()
+    # the two row-pass routes against each other (bit for bit), the epilogue route switched off in both
+    pass_fused = _with({'VB_MVT_EPI_ROWS': '0'}, call)
+    pass_split = _with({'VB_MVT_EPI_ROWS': '0', 'VB_MVT_FUSED_ROWS': '0'}, call)
+    for (v0, g0, e0, s0), (v1, g1, e1, s1) in zip(pass_fused, pass_split):
+        assert e0 == e1 and s0 == s1 and v0 == v1
+        np.testing.assert_array_equal(g0, g1)
     for env, exact in (({'VB_MVT_SIDE_INVERSE': '0'}, True), ({'VB_MVT_FLAGSYNC': '0'}, True),
-                       ({'VB_MVT_FUSED_ROWS': '0'}, True), ({'VB_MVT_CHAIN': '0'}, False),
+                       ({'VB_MVT_FUSED_ROWS': '0'}, None), ({'VB_MVT_CHAIN': '0'}, False),
                        ({'VB_MVT_CHAIN_FETCH': '0'}, True), ({'VB_GRAM_XCD': '0'}, True), ({'VB_MVT_UNPACK': '0'}, True),
+                       ({'VB_MVT_EPI_ROWS': '0'}, None),
                        ({'VB_MVT_DIRECT': '0'}, False),
                        ({'VB_MVT_DIRECT': '0', 'VB_MVT_SIDE_INVERSE': '0', 'VB_MVT_FLAGSYNC': '0'}, False)):
         other = _with(env, call)
         for (v0, g0, e0, s0), (v1, g1, e1, s1) in zip(base, other):
+            if exact is None:      # (log q itself differs in the last bits: so may the walk's last levels)
+                assert abs(e0 - e1) <= 1e-10 * max(abs(e0), 1e-300) and abs(s0 - s1) <= 1e-8 * abs(s0), (env, e0, e1, s0, s1)
+                assert abs(v0 - v1) <= 1e-10 * abs(v0), env
+                assert G.rel_err(g0, g1) < 1e-9, (env, G.rel_err(g0, g1))
+                continue
             assert e0 == e1 and s0 == s1, env
             if exact:
                 assert v0 == v1, env
@@ -110,3 +126,38 @@ def test_gaussian_member_routes_agree(vb):
     v1, g1 = _with({'VB_MVT_DIRECT': '0', 'VB_MVT_SIDE_INVERSE': '0', 'VB_MVT_FLAGSYNC': '0'}, call)
     assert abs(v0 - v1) <= 1e-13 * abs(v0)
     assert G.rel_err(g0, g1) < 1e-11
+
+
+def test_epilogue_rows_route_does_not_depend_on_history(vb):
+    """Round 6: the C3-type call takes log p / log prior out of the sampling product's epilogue and the Mahalanobis terms from
+    the noise rows' norms (VB_MVT_EPI_ROWS).  The norms come with the Philox normals once a reader has asked for them, and
+    from a pass over the noise before that -- the same bits either way: the first call of a fresh engine (nobody has asked) and
+    a later one (norms generated with the noise, look-ahead included) return identical results for identical inputs."""
+    from viabel_amd import _lib
+    D, N, df = 48, 2048, 9.0
+    rng = np.random.RandomState(5)
+    model_args = (0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D)))
+    prior = np.concatenate([0.1 * rng.randn(D), 0.4 + 0.1 * rng.rand(D)])
+    A = rng.randn(D, D)
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(A @ A.T / D + 0.5 * np.eye(D))])
+
+    def calls(k):
+        approx = vb.MultivariateT(D, df, seed=3, rng='philox')
+        obj = vb.DISInclusiveKL(approx, vb.GaussianModel(*model_args), N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+                                temper_prior_params=prior, use_resampling=False)
+        return [obj(theta + 0.01 * i) for i in range(k)]
+    old = _lib.default_engine()
+    fresh = _lib.Engine(0)
+    _lib.set_default_engine(fresh)
+    try:
+        first = calls(5)          # call 0: norms by a pass; later ones: generated with the (look-ahead) noise
+        again = calls(5)          # the same requests on an engine whose slot has been asked already
+        for (v0, g0), (v1, g1) in zip(first, again):
+            assert v0 == v1
+            np.testing.assert_array_equal(g0, g1)
+        off = _with({'VB_MVT_EPI_ROWS': '0'}, lambda: calls(2))
+        for (v0, g0), (v1, g1) in zip(first, off):
+            assert abs(v0 - v1) <= 1e-10 * abs(v0) and G.rel_err(g0, g1) < 1e-9
+    finally:
+        _lib.set_default_engine(old)
+        fresh.close()

@@ -307,6 +307,20 @@ static bool noise_ahead_on() {
   return !(e && atoi(e) == 0);
 }
 
+const double* noise_row_norms(vb_ctx* ctx, NoiseSlot& s, hipStream_t st) {
+  if (!s.buf.ptr || s.d > 512 || s.n <= 0) return nullptr;
+  const NoiseReq &a = s.ahead.last, &b = s.norms_req;
+  if (a.valid && b.valid && req_same_but_stream(a, b) && a.stream == b.stream && s.norms.ptr && a.n == s.n && a.d == s.d &&
+      s.norms.bytes >= (size_t)s.n * sizeof(double))
+    return (const double*)s.norms.ptr;
+  s.want_norms = true;
+  s.norms_req.valid = false;
+  if (ensure(ctx, s.norms, (size_t)s.n * sizeof(double)) != VB_OK) return nullptr;
+  if (rng_row_norms(ctx, st, (const double*)s.buf.ptr, s.ld, s.n, s.d, (double*)s.norms.ptr) != VB_OK) return nullptr;
+  if (a.valid && a.n == s.n && a.d == s.d) s.norms_req = a;      // (Philox contents the slot keeps track of: good until they change)
+  return (const double*)s.norms.ptr;
+}
+
 void noise_prefetch(vb_ctx* ctx) {
   if (!ctx || !noise_ahead_on()) return;
   bool ordered = false;      // main_stream_write once, and only when something is generated
@@ -328,7 +342,13 @@ void noise_prefetch(vb_ctx* ctx) {
     NoiseReq nx = h.last;
     if (hinted) nx.seed = h.hint.seed, nx.stream = h.hint.stream;
     else nx.stream = h.last.stream + (uint64_t)h.delta;
-    if (rng_fill(ctx, (double*)h.shadow.ptr, s.ld, nx.kind, nx.df, nx.seed, nx.stream, nx.row_offset, nx.n, nx.d) != VB_OK) continue;
+    // (row norms ride along once a reader has asked for them: NoiseSlot::want_norms)
+    const bool with_norms = s.want_norms && nx.kind == VB_NOISE_NORMAL && nx.d <= 512 &&
+                            ensure(ctx, h.shadow_norms, (size_t)nx.n * sizeof(double)) == VB_OK;
+    if (rng_fill(ctx, (double*)h.shadow.ptr, s.ld, nx.kind, nx.df, nx.seed, nx.stream, nx.row_offset, nx.n, nx.d,
+                 with_norms ? (double*)h.shadow_norms.ptr : (double*)nullptr) != VB_OK)
+      continue;
+    h.pre_norms = with_norms;
     h.pre = nx;
     ++ctx->ahead_generated;
   }
@@ -515,6 +535,8 @@ int vb_destroy(vb_ctx* ctx) {
   for (auto& s : ctx->noise) {
     if (s.buf.ptr) (void)hipFree(s.buf.ptr);
     if (s.ahead.shadow.ptr) (void)hipFree(s.ahead.shadow.ptr);
+    if (s.norms.ptr) (void)hipFree(s.norms.ptr);
+    if (s.ahead.shadow_norms.ptr) (void)hipFree(s.ahead.shadow_norms.ptr);
   }
   if (ctx->chi_ahead.shadow.ptr) (void)hipFree(ctx->chi_ahead.shadow.ptr);
   for (auto& r : ctx->results)
@@ -641,6 +663,12 @@ int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
         ctx->mvt_theta.clear();
       }
       std::swap(s.buf, h.shadow);
+      s.norms_req.valid = false;
+      if (h.pre_norms) {
+        std::swap(s.norms, h.shadow_norms);
+        s.norms_req = r;
+      }
+      h.pre_norms = false;
       h.pre.valid = false;
       ++ctx->ahead_adopted;
       req_observe(h, r);
@@ -650,7 +678,12 @@ int vb_noise_generate(vb_ctx* ctx, int slot, int kind, double df, uint64_t seed,
   VB_TRY(noise_alloc(ctx, slot, n, d, true));
   NoiseSlot& s = ctx->noise[slot];
   s.ahead.pre.valid = false;      // (a shadow that was not asked for is dropped)
-  VB_TRY(rng_fill(ctx, (double*)s.buf.ptr, s.ld, kind, df, seed, stream, row_offset, n, d));
+  s.norms_req.valid = false;
+  const bool with_norms = s.want_norms && kind == VB_NOISE_NORMAL && d <= 512;
+  if (with_norms) VB_TRY(ensure(ctx, s.norms, (size_t)n * sizeof(double)));
+  VB_TRY(rng_fill(ctx, (double*)s.buf.ptr, s.ld, kind, df, seed, stream, row_offset, n, d,
+                  with_norms ? (double*)s.norms.ptr : (double*)nullptr));
+  if (with_norms) s.norms_req = r;
   req_observe(s.ahead, r);
   return VB_OK;
 }

@@ -114,6 +114,8 @@ struct NoiseReq {
 // generator, objectives.py:455) can name it instead: vb_noise_hint_seed.  A wrong prediction is never adopted.
 struct NoiseAhead {
   DeviceBuffer shadow;
+  DeviceBuffer shadow_norms;             // row norms of the shadow (NoiseSlot::norms), generated with it when pre_norms
+  bool pre_norms = false;
   int64_t shadow_d = 0, shadow_ld = 0;   // geometry the shadow's pad columns were zeroed for
   NoiseReq last, pre;                    // what the live buffer holds; what the shadow holds (pre.valid)
   NoiseReq hint;                         // the caller's own prediction of the next request (vb_noise_hint_seed), used once
@@ -124,7 +126,17 @@ struct NoiseSlot {
   DeviceBuffer buf;
   int64_t n = 0, d = 0, ld = 0;   // ld: row stride in doubles (multiple of 16)
   NoiseAhead ahead;
+  // sum_c e_rc^2 of every row (rng_normal_kernel), formed while the Philox normals are generated once a reader has asked for
+  // them (want_norms: noise_row_norms); they describe the buffer's contents only while norms_req equals ahead.last
+  DeviceBuffer norms;
+  NoiseReq norms_req;
+  bool want_norms = false;
 };
+// the row norms of the slot's CURRENT contents (at most 512 columns: else nullptr): the ones formed with the contents, or --
+// contents of another origin, or generated before anybody asked -- formed now by a pass over the matrix on `st`
+// (rng_row_norms_kernel: the same bits); from now on the slot's Philox fills bring theirs along
+const double* noise_row_norms(vb_ctx* ctx, NoiseSlot& s, hipStream_t st);
+int rng_row_norms(vb_ctx* ctx, hipStream_t st, const double* src, int64_t ld, int64_t n, int64_t d, double* norms);
 
 // Software pipeline over three HIP streams (prep | streaming kernel | finalize + collectives), used
 // by the asynchronous batch entry points so that consecutive batches overlap.
@@ -737,7 +749,7 @@ int fit_step_enqueue(vb_ctx* ctx, const FitStep& step);
 
 // Philox noise generation (vb_rng.hip)
 int rng_fill(vb_ctx* ctx, double* dst, int64_t ld, int kind, double df, uint64_t seed,
-             uint64_t stream, int64_t row_offset, int64_t n, int64_t d);
+             uint64_t stream, int64_t row_offset, int64_t n, int64_t d, double* norms = nullptr);
 int rng_chisquare(vb_ctx* ctx, double* dst, double df, uint64_t seed, uint64_t stream, int64_t row_offset, int64_t n);
 
 // regression targets: G = R X - Z / prior_sd^2 (n x d, contraction over the n_data observations), split over the

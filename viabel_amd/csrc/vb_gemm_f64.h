@@ -110,6 +110,20 @@ struct EpiPairs : std::false_type {};
 template <class E>
 struct EpiPairs<E, std::void_t<decltype(std::declval<E>().pair(0, 0, 0, 0.0, 0.0))>> : std::true_type {};
 
+// EpiRowSums (LDS-DMA kernel, round 6): a functor that defines `double* rowpart` gets, besides its stores, the sum over the
+// TILE's columns of a pair of per-element terms for every row of the tile:
+//   d2v rows_pair(int row, int col, double acc0, double acc1) const   -- elements (row, col), (row, col + 1): stores, returns
+//                                                                        the two terms, each summed over the two elements
+//   d2v rows_one(int row, int col, double acc) const                  -- one element
+//   void rows_out(int row, int bn, d2v total) const                   -- the row's terms over column block bn
+// Order of a row's sum: a lane's column pairs in fragment order, the four lanes of the row (quad shuffles), the wave of the
+// left half of the tile then the right one -- fixed, so the sums are reproducible.  (The multivariate t's DIS refresh takes
+// log p and log prior of a diagonal-Gaussian target and prior out of its sampling product this way: vb_mvt.hip.)
+template <class E, class = void>
+struct EpiRowSums : std::false_type {};
+template <class E>
+struct EpiRowSums<E, std::void_t<decltype(std::declval<E>().rowpart)>> : std::true_type {};
+
 template <class E, class = void>
 struct EpiColsum : std::false_type {};
 template <class E>
@@ -400,7 +414,7 @@ inline unsigned gemm_f64_launch(hipStream_t st, GemmArgs g, int splits, int n_cu
   // (round 6: a REDUCING epilogue may take them too when the caller asks for it by cfg = 7 / 8 -- its per-tile partial sums
   // are then grouped by 64 x 32 tiles: another, equally fixed, summation order)
   constexpr bool kNarrowOk = A_KCONTIG && !EpiColsum<Epi>::value;
-  constexpr bool kNarrowAuto = kNarrowOk && !EpiReduces<Epi>::value;
+  constexpr bool kNarrowAuto = kNarrowOk && !EpiReduces<Epi>::value && !EpiRowSums<Epi>::value;
   if (splits < 1) splits = 1;
   int ks = g.batch ? g.K : gemm_tiles(g.K, splits);   // batch mode: `splits` is the number of products
   g.k_split = gemm_tiles(ks, kGemmBK) * kGemmBK;

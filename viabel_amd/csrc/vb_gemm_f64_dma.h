@@ -429,6 +429,33 @@ __device__ __forceinline__ void gemm_f64_dma_tile(const GemmArgs& g, const Epi& 
       __syncthreads();
     }
   }
+  // ---- epilogue with per-row sums over the tile's columns (EpiRowSums, vb_gemm_f64.h) -----------------------------------
+  if constexpr (EpiRowSums<Epi>::value) {
+    d2v* rsum = reinterpret_cast<d2v*>(gemm_lds);      // [2 (left / right half of the tile)][BM]; the stages are free by now
+#pragma unroll
+    for (int a = 0; a < AF; ++a) {
+      const int lrow = frag_row(a, 4 * fblk + fk), row = m0 + lrow;      // the same row for every fragment r of this lane
+      d2v s = (d2v){0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < NB; r += 2) {
+        const int col = n0 + frag_col(r, fblk, fj);
+        if (row < g.M && col + 1 < g.N) {
+          s += epi.rows_pair(row, col, acc[a][r], acc[a][r + 1]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            if (row < g.M && col + q < g.N) s += epi.rows_one(row, col + q, acc[a][r + q]);
+        }
+      }
+      s.x += __shfl_xor(s.x, 1, 64), s.y += __shfl_xor(s.y, 1, 64);      // the row's four lanes: fj = lane & 3
+      s.x += __shfl_xor(s.x, 2, 64), s.y += __shfl_xor(s.y, 2, 64);
+      if (fj == 0) rsum[wn * BM + lrow] = s;
+    }
+    __syncthreads();
+    if (t < BM && m0 + t < g.M) epi.rows_out(m0 + t, bn, rsum[t] + rsum[BM + t]);
+    dep.publish(bm, bn, bz);
+    return;
+  }
   // ---- epilogue (as gemm_f64_kernel) -------------------------------------------------------------------------
 #pragma unroll
   for (int a = 0; a < AF; ++a)

@@ -37,6 +37,71 @@ struct EpiSampleT {         // X = mu + acc / s_n
   }
 };
 
+// EpiSampleT that also leaves, per row and column block, the block's share of log p (diagonal-Gaussian target: mean m0,
+// inverse variances iv) and of the tempering prior's log density (mean q0, inverse variances q1) -- EpiRowSums,
+// vb_gemm_f64.h: the DIS refresh then needs no pass over the samples at all (round 6).  rowpart[(2 bn + q) n_stride + row].
+struct EpiSampleTRows {
+  double* X;
+  int64_t ld;
+  const double* mu;
+  const double* inv_s;      // may be nullptr (the Gaussian member: no row scales)
+  const double *m0, *iv, *q0, *q1;
+  double* rowpart;
+  int64_t n_stride;
+  __device__ void operator()(int, int row, int col, double acc) const {      // (the register-staged kernel: stores only)
+    X[(int64_t)row * ld + col] = inv_s ? fma(acc, inv_s[row], mu[col]) : acc + mu[col];
+  }
+  __device__ d2v rows_one(int row, int col, double acc) const {
+    const double z = inv_s ? fma(acc, inv_s[row], mu[col]) : acc + mu[col];
+    X[(int64_t)row * ld + col] = z;
+    const double dz = z - m0[col], dq = z - q0[col];
+    return (d2v){-0.5 * dz * dz * iv[col], -0.5 * dq * dq * q1[col]};
+  }
+  __device__ d2v rows_pair(int row, int col, double a0, double a1) const {
+    const d2v m = *reinterpret_cast<const d2v*>(mu + col);
+    d2v z;
+    if (inv_s) {
+      const double is = inv_s[row];
+      z = (d2v){fma(a0, is, m.x), fma(a1, is, m.y)};
+    } else {
+      z = (d2v){a0 + m.x, a1 + m.y};
+    }
+    *reinterpret_cast<d2v*>(X + (int64_t)row * ld + col) = z;
+    const d2v dz = z - *reinterpret_cast<const d2v*>(m0 + col), dq = z - *reinterpret_cast<const d2v*>(q0 + col);
+    const d2v v = *reinterpret_cast<const d2v*>(iv + col), q = *reinterpret_cast<const d2v*>(q1 + col);
+    return (d2v){fma(-0.5 * dz.x * dz.x, v.x, -0.5 * dz.y * dz.y * v.y), fma(-0.5 * dq.x * dq.x, q.x, -0.5 * dq.y * dq.y * q.y)};
+  }
+  __device__ void rows_out(int row, int bn, d2v tot) const {
+    rowpart[(int64_t)(2 * bn) * n_stride + row] = tot.x;
+    rowpart[(int64_t)(2 * bn + 1) * n_stride + row] = tot.y;
+  }
+};
+
+// ... and the kernel that finishes the rows: the column blocks' shares in block order, the constants, and the t family's own
+// row statistics from the noise rows' norms (rng_normal_kernel: maha_n = r_n^2 sum_c e_nc^2) -- what
+// model_prior_maha_rows_kernel (vb_rows.hip) leaves, without reading either matrix
+__global__ void __launch_bounds__(256) mvt_rows_combine_kernel(const double* __restrict__ rowpart, int64_t n_stride, int nparts,
+                                                               int64_t n, int d, double c0, double qc,
+                                                               const double* __restrict__ norms, const double* __restrict__ rs,
+                                                               double df, double lq_const, double* __restrict__ lp,
+                                                               double* __restrict__ lprior, double* __restrict__ maha,
+                                                               double* __restrict__ lq, double* __restrict__ cn) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  double a = 0.0, a2 = 0.0;
+  for (int b = 0; b < nparts; ++b) {
+    a += rowpart[(int64_t)(2 * b) * n_stride + row];
+    a2 += rowpart[(int64_t)(2 * b + 1) * n_stride + row];
+  }
+  lp[row] = a + c0;
+  lprior[row] = a2 + qc;
+  const double r = rs ? rs[row] : 1.0;
+  const double t = (r * r) * norms[row];
+  maha[row] = t;
+  lq[row] = df > 0.0 ? lq_const - 0.5 * (df + d) * log1p(t / df) : lq_const - 0.5 * t;
+  cn[row] = df > 0.0 ? (df + d) / (df + t) : 1.0;
+}
+
 struct EpiSubVec {          // E = acc - c   (c = mu L^-T)
   double* E;
   int64_t ld;
@@ -1152,17 +1217,38 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   g.N = (int)d;
   g.K = (int)d;
   g.tri_mode = chol_samples ? 1 : 0;      // throughput mode: the root is L' (zero below the diagonal) -- half the product
-  gemm_f64_launch<true>(st, g, 1, n_cu, EpiSampleT{base + L.o_x, L.ld, base + L.o_mu, base + L.o_invs});
-  VB_HIP(ctx, hipGetLastError());
-
   // (samples through the symmetric root: their residuals (x - mu) L^-T are a product, not the scaled noise)
   // throughput mode with a row-kernel target: ONE pass over samples and noise for log p, log prior, maha, log q, c_n
   const bool fuse_rows = chol_samples && mvt_env_on("VB_MVT_FUSED_ROWS") &&
                          (ctx->model.id == VB_MODEL_GAUSS_DIAG || ctx->model.id == VB_MODEL_FUNNEL);
+  // ... or no pass over the samples at all (round 6; diagonal-Gaussian target and prior, at most 512 columns): log p and log
+  // prior leave the sampling product's epilogue per column block, the noise rows' norms -- formed when Philox normals are
+  // generated, else by a pass over the noise alone -- give the Mahalanobis terms, a kernel over the N rows puts them together.
+  // Which route is taken depends on the shapes and the target only, never on what ran before.  VB_MVT_EPI_ROWS=0: the pass.
+  const double* norms = nullptr;
+  if (fuse_rows && ctx->model.id == VB_MODEL_GAUSS_DIAG && ctx->temper.kind == VB_PRIOR_DIAG_GAUSSIAN && d <= 512 &&
+      mvt_env_on("VB_MVT_EPI_ROWS") && gemm_uses_dma(g))
+    norms = noise_row_norms(ctx, const_cast<NoiseSlot&>(ns), st);      // (the slot is the context's own)
+  constexpr int kEpiRowsBN = 64;      // column block of tile configuration 4 (64 x 64, two stages: this product's own choice)
+  if (norms)
+    gemm_f64_launch<true>(st, g, 1, n_cu,
+                          EpiSampleTRows{base + L.o_x, L.ld, base + L.o_mu, base + L.o_invs,
+                                         ctx->model.p0, ctx->model.p1, base + L.o_prior, base + L.o_prior + L.ld, base + L.o_u, n},
+                          4);
+  else
+    gemm_f64_launch<true>(st, g, 1, n_cu, EpiSampleT{base + L.o_x, L.ld, base + L.o_mu, base + L.o_invs});
+  VB_HIP(ctx, hipGetLastError());
+
   double lq_const = 0.0;
   VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors, chol_samples ? &ns : nullptr,
                        fuse_rows ? &lq_const : nullptr));
-  if (fuse_rows) {
+  if (norms) {
+    hipLaunchKernelGGL(mvt_rows_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)(base + L.o_u), n,
+                       (int)((d + kEpiRowsBN - 1) / kEpiRowsBN), n, (int)d, ctx->model.c0, c0p, norms,
+                       (const double*)(base + L.o_invs), df, lq_const, base + L.o_lp + mine,
+                       base + L.o_lprior + mine, base + L.o_maha, base + L.o_lq + mine, base + L.o_part);
+    VB_HIP(ctx, hipGetLastError());
+  } else if (fuse_rows) {
     VB_TRY(model_prior_maha_rows(ctx, base + L.o_x, L.ld, n, d, base + L.o_lp + mine, base + L.o_prior, base + L.o_prior + L.ld,
                                  c0p, base + L.o_lprior + mine, (const double*)ns.buf.ptr, ns.ld, base + L.o_invs, df, lq_const,
                                  base + L.o_maha, base + L.o_lq + mine, base + L.o_part));
