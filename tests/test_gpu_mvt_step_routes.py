@@ -161,3 +161,30 @@ def test_epilogue_rows_route_does_not_depend_on_history(vb):
     finally:
         _lib.set_default_engine(old)
         fresh.close()
+
+
+@pytest.mark.parametrize('N,exact', [(4096, True), (16384, True), (40000, False)])
+def test_psis_weights_in_weights_out(vb, N, exact):
+    """Round 6: the smoothing kernel reads the weights and writes them back itself (PsisWeightsIo) instead of a prep and an apply
+    launch around it (VB_PSIS_FUSED_IO=0).  The same values; the same bits while a thread owns one weight (N <= 16 384: the
+    prep kernel's slices and summation order), the total of the weights in another grouping beyond."""
+    D, df = 32, 9.0
+    rng = np.random.RandomState(N % 97)
+    model = vb.GaussianModel(0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D)))
+    prior = np.concatenate([np.zeros(D), 0.3 * np.ones(D)])
+    A = rng.randn(D, D)
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(A @ A.T / D + 0.6 * np.eye(D))])
+
+    def call():
+        obj = vb.DISInclusiveKL(vb.MultivariateT(D, df, seed=4, rng='philox'), model, N, ess_target=N // 8,
+                                temper_prior=vb.MFGaussian(D), temper_prior_params=prior, use_resampling=False, psis_smooth=True)
+        out = [obj(theta + 0.01 * i) for i in range(3)]
+        return out, obj._khat
+    (a, ka), (b, kb) = call(), _with({'VB_PSIS_FUSED_IO': '0'}, call)
+    assert np.isfinite(ka) and ka == kb
+    for (v0, g0), (v1, g1) in zip(a, b):
+        if exact:
+            assert v0 == v1
+            np.testing.assert_array_equal(g0, g1)
+        else:
+            assert abs(v0 - v1) <= 1e-13 * abs(v0) and G.rel_err(g0, g1) < 1e-12

@@ -604,7 +604,8 @@ int lr_elbo_grad_enqueue(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, 
 // vb_psis.hip
 int log_weights_enqueue(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int family, double df,
                         const double* theta_src);
-int psis_enqueue(vb_ctx* ctx, int64_t n, double reff);
+int psis_enqueue(vb_ctx* ctx, int64_t n, double reff, const double* weights_in = nullptr, double* weights_out = nullptr,
+                 double* khat_out = nullptr, bool* fused_out = nullptr);
 int mvt_dis_psis_enqueue(vb_ctx* ctx, int64_t n_total, double reff);
 int psis_tail_size(int64_t n, double reff);
 

@@ -1358,6 +1358,13 @@ int mvt_dis_psis_enqueue(vb_ctx* ctx, int64_t n_total, double reff) {
   double* lw = (double*)ctx->psis_lw.ptr;
   // (slice totals: 16 doubles behind the smoothed vector's 16-double result area)
   double* totals = lw + nn + 16;
+  // (round 6: one launch when the multi-workgroup smoothing kernel applies -- it reads the weights and writes them back itself)
+  bool fused = false;
+  VB_TRY(psis_enqueue(ctx, n_total, reff, base + L.o_w, base + L.o_w, base + L.o_scal + 11, &fused));
+  if (fused) {
+    ctx->psis_n = 0;
+    return VB_OK;
+  }
   const int slices = (int)((n_total + 1023) / 1024) < kPsisPrepWg ? (int)((n_total + 1023) / 1024) : kPsisPrepWg;
   hipLaunchKernelGGL(mvt_psis_prep_kernel, dim3((unsigned)slices), dim3(1024), 0, st, (const double*)(base + L.o_w), n_total, lw,
                      totals);

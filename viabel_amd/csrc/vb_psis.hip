@@ -566,10 +566,22 @@ struct PgBarrier {
   }
 };
 
+// Round 6: weights in, weights out.  The DIS objectives smooth WEIGHTS (normalised, non-negative), not log weights: a prep
+// launch took their logarithms and slice totals, an apply launch turned the smoothed log weights back (total x exp) --
+// 4 + 5 us of kernels and two launch gaps around a 43-us kernel.  With io.w_in set the kernel reads the weights itself
+// (x = log w, the workgroups' totals exchanged at the first barrier, added in workgroup order) and writes
+// io.w_out[i] = total * exp(x_i) and k-hat at the end: the same values (for N <= 16 384 the same bits: one element per thread,
+// the prep kernel's slices and order).
+struct PsisWeightsIo {
+  const double* w_in = nullptr;
+  double* w_out = nullptr;
+  double* khat_out = nullptr;
+};
+
 template <int E>
 __global__ void __launch_bounds__(kPsisThreads) psis_grid_kernel(double* __restrict__ x, int64_t n, int m_tail,
                                                                  double* __restrict__ out, char* __restrict__ work,
-                                                                 unsigned long long bar_base) {
+                                                                 unsigned long long bar_base, PsisWeightsIo io) {
   __shared__ double sh[17];
   __shared__ int hist[kPgBins];
   __shared__ double tv[kPsisTailCap];
@@ -614,14 +626,34 @@ __global__ void __launch_bounds__(kPsisThreads) psis_grid_kernel(double* __restr
   // 1. x -= max(x)   (_psis.py:166)
   double r[E];
   double mx = -INFINITY;
+  double sw = 0.0;
 #pragma unroll
   for (int u = 0; u < E; ++u) {
     const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
-    r[u] = i < n ? x[i] : 0.0;
+    if (io.w_in) {
+      const double wv = i < n ? io.w_in[i] : 0.0;
+      sw += wv;
+      r[u] = i < n ? log(wv) : 0.0;      // log 0 = -inf: a weight that stays zero
+    } else {
+      r[u] = i < n ? x[i] : 0.0;
+    }
     if (i < n) mx = fmax(mx, r[u]);
   }
   mx = ps_block_max(mx, sh);
   if (t == 0) pg_st(&wgval[g], mx);
+  if (io.w_in) {      // this workgroup's share of sum w: the wave by shuffles, the sixteen waves in order (mvt_psis_prep_kernel's)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sw += __shfl_down(sw, off, 64);
+    __syncthreads();
+    if (lane == 0) sh[wave] = sw;
+    __syncthreads();
+    if (t == 0) {
+      double tw = 0.0;
+      for (int q = 0; q < 16; ++q) tw += sh[q];
+      pg_st(&wgval[2 * kPgMaxWg + g], tw);
+    }
+    __syncthreads();
+  }
   barrier.wait();
   mx = pg_ld(&wgval[0]);
   for (int q = 1; q < G; ++q) mx = fmax(mx, pg_ld(&wgval[q]));
@@ -960,13 +992,21 @@ __global__ void __launch_bounds__(kPsisThreads) psis_grid_kernel(double* __restr
   for (int q = 0; q < G; ++q) tot += pg_ld(&wgval[kPgMaxWg + q]);
   const double lse = log(tot) + new_max;
   const bool poisoned = pg_ld(&bar[2]) == bar_base + 1;
+  double wtot = 0.0;
+  if (io.w_out)
+    for (int q = 0; q < G; ++q) wtot += pg_ld(&wgval[2 * kPgMaxWg + q]);
 #pragma unroll
   for (int u = 0; u < E; ++u) {
     const int64_t i = i0 + t + (int64_t)u * kPsisThreads;
-    if (i < n) x[i] = poisoned ? NAN : r[u] - lse;
+    if (i < n) {
+      const double v = poisoned ? NAN : r[u] - lse;
+      x[i] = v;
+      if (io.w_out) io.w_out[i] = wtot * exp(v);      // (mvt_psis_apply_kernel's expression)
+    }
   }
   PG_MARK();
   if (g == 0 && t == 0) {
+    if (io.khat_out) io.khat_out[0] = poisoned ? NAN : k;
     out[0] = poisoned ? NAN : k;
     out[1] = poisoned ? NAN : (double)tail_count;      // (k-hat AND the tail count NaN: the poison's signature)
     out[2] = xcutoff;
@@ -1008,7 +1048,14 @@ int psis_tail_size(int64_t n, double reff) {   // _psis.py:158
 }
 
 // smooth the n log weights in ctx->psis_lw in place; out_dev = [khat, n_tail, xcutoff, sigma]
-int psis_enqueue(vb_ctx* ctx, int64_t n, double reff) {
+// weights_in != nullptr (round 6): smooth WEIGHTS -- their logarithms go to ctx->psis_lw as before, weights_out[i] = sum(w) x
+// exp(smoothed log weight), khat_out[0] = k-hat -- in the same launch, when the multi-workgroup kernel applies; *fused_out says
+// whether it did (false: nothing was launched for them, the caller takes the three-launch route)
+int psis_enqueue(vb_ctx* ctx, int64_t n, double reff, const double* weights_in, double* weights_out, double* khat_out,
+                 bool* fused_out) {
+  if (fused_out) *fused_out = false;
+  const char* fuse_s = getenv("VB_PSIS_FUSED_IO");      // 0: prep / apply launches around the kernel (cross-check)
+  if (weights_in && fuse_s && atoi(fuse_s) == 0) return VB_OK;
   if (n <= 1) return fail(ctx, VB_ERR_INVALID, "More than one log-weight needed.");
   if (!(reff > 0.0)) return fail(ctx, VB_ERR_INVALID, "Reff must be positive");
   const int m_tail = psis_tail_size(n, reff);
@@ -1043,16 +1090,20 @@ int psis_enqueue(vb_ctx* ctx, int64_t n, double reff) {
     const unsigned long long bar_base = ctx->psis_bar_base;
     char* work = (char*)ctx->psis_work.ptr;
     double* out = lw + round_up(n, 16);
+    PsisWeightsIo io;
+    if (weights_in) io.w_in = weights_in, io.w_out = weights_out, io.khat_out = khat_out;
     if (per_thread == 1)
-      hipLaunchKernelGGL(psis_grid_kernel<1>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base);
+      hipLaunchKernelGGL(psis_grid_kernel<1>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base, io);
     else if (per_thread == 2)
-      hipLaunchKernelGGL(psis_grid_kernel<2>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base);
+      hipLaunchKernelGGL(psis_grid_kernel<2>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base, io);
     else
-      hipLaunchKernelGGL(psis_grid_kernel<4>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base);
+      hipLaunchKernelGGL(psis_grid_kernel<4>, dim3(wgs), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail, out, work, bar_base, io);
     VB_HIP(ctx, hipGetLastError());
     ctx->psis_bar_base += (unsigned long long)wgs * kPgBarriers;      // (a launch that did not happen adds nothing)
+    if (fused_out) *fused_out = io.w_in != nullptr;
     return VB_OK;
   }
+  if (weights_in) return VB_OK;      // (the single-workgroup kernel reads log weights: the caller prepares them and calls again)
   if (n <= (int64_t)kPsisRegs * kPsisThreads)
     hipLaunchKernelGGL(psis_kernel<true>, dim3(1), dim3(kPsisThreads), 0, ctx->stream, lw, n, m_tail,
                        lw + round_up(n, 16));
