@@ -926,9 +926,12 @@ def fullrank_fit_leg(vb, iters=300):
     hist = {}
     n_host = max(20, iters // 10)
     for mode, on_device, n_it in (('optimize_device', True, iters), ('optimize_host', False, n_host)):
+        # (warm-up of the timed size on the device, with an objective and optimiser of its own: the 1.26-GB iterate history on
+        # both sides -- device rows, the host array's pages -- is allocated once per size, not per fit)
+        RMSProp(0.001).optimize(n_it if on_device else n_host, vb.ExclusiveKL(vb.FullRankGaussian(d, rng='philox'), model, N_MC),
+                                theta, on_device=on_device)
         obj = vb.ExclusiveKL(vb.FullRankGaussian(d, rng='philox'), model, N_MC)      # same Philox streams in both modes
         opt = RMSProp(0.001)
-        opt.optimize(n_host, obj, theta, on_device=on_device)
         t0 = time.perf_counter()
         res = opt.optimize(n_it, obj, theta, on_device=on_device)
         out[mode + '_us_per_iteration'] = 1e6 * (time.perf_counter() - t0) / n_it

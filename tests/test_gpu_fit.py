@@ -347,3 +347,28 @@ def test_streamed_rows_equal_the_single_copy(family, n_iters, hist_len):
     for a, b in zip(plain, streamed):
         np.testing.assert_array_equal(a, b)
     assert plain[2].shape == (hist_len, theta.size) and np.isfinite(plain[4]).all() and np.isfinite(plain[5]).all()
+
+
+@pytest.mark.parametrize('problem', ['mf_gaussian_funnel', 'fullrank_corr'])
+@pytest.mark.parametrize('n_iters', [57, 7])
+def test_iterate_average_formed_on_the_device_is_numpys(problem, n_iters, monkeypatch):
+    """Round 6: ``opt_param`` -- the mean of the last fifth of the iterates (optimization.py:120-126) -- from the rows still
+    resident on the device (vb_fit_history_mean) instead of numpy's pass over the returned history: the same additions in
+    the same order, so the same bits as the host loop's ``np.mean``."""
+    from viabel_amd import optimization as opt_mod, _lib
+    monkeypatch.setattr(opt_mod, '_DEVICE_MEAN_MIN', 0)
+    make, init = {'mf_gaussian_funnel': _mf_gaussian_funnel, 'fullrank_corr': _fullrank_corr}[problem]()
+    obj_h, obj_d = _pair(make)
+    opt_h, opt_d = _pair(_optimizers()['rmsprop'])
+    calls = []
+    eng = _lib.default_engine()
+    real = eng.fit_history_mean
+    monkeypatch.setattr(eng, 'fit_history_mean', lambda rows, p: calls.append(rows) or real(rows, p))
+    host = opt_h.optimize(n_iters, obj_h, init, on_device=False)
+    dev = opt_d.optimize(n_iters, obj_d, init, on_device=True)
+    assert calls == [max(1, int((n_iters - 1) * 0.2))]      # the device formed it
+    _assert_same(host, dev)
+    np.testing.assert_array_equal(dev['opt_param'], np.mean(dev['variational_param_history'][-calls[0]:], axis=0))
+    # nothing resident: a clear error, not stale numbers
+    with pytest.raises(_lib.EngineError):
+        eng.fit_history_mean(10 ** 6, init.size)

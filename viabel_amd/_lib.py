@@ -118,6 +118,7 @@ SIGNATURES = {
                               ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _c_double_p,
                               ctypes.c_int64, _c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_int,
                               _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p]),
+    'vb_fit_history_mean': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
     'vb_log_weights_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                 ctypes.c_double, _c_double_p, _c_double_p]),
     'vb_psis_smooth': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_double, _c_double_p,
@@ -1038,6 +1039,13 @@ class Engine:
             _dptr(history) if hist_len else None, int(hist_len),
             _dptr(directions) if log_directions else None, _dptr(gradients) if log_gradients else None))
         return theta, values, history, state, directions, gradients
+
+    def fit_history_mean(self, rows, p):
+        """``np.mean(history[-rows:], axis=0)`` of the iterates the last ``fit`` kept, formed on the device from the rows still
+        resident there (``vb_fit_history_mean``): the same additions in the same order, without the host's pass over them."""
+        mean = pinned_array(p)
+        self._check(self._lib.vb_fit_history_mean(self._ctx, int(rows), int(p), _dptr(mean)))
+        return mean
 
     # ------------------------------------------------------------------ multi-GPU
     @staticmethod

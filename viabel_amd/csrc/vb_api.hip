@@ -2316,6 +2316,7 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
   const int64_t o_theta = carve(p), o_out = carve(1 + p), o_s1 = carve(p), o_s2 = carve(p),
                 o_val = carve(n_iters), o_hist = carve(hist_len * p), o_dirs = carve(directions ? n_iters * p : 0),
                 o_grads = carve(gradients ? n_iters * p : 0);
+  ctx->fit_hist_len = 0;      // (the kept iterates of an earlier fit are about to be overwritten)
   VB_TRY(ensure(ctx, ctx->fit_work, (size_t)off * sizeof(double)));
   double* base = (double*)ctx->fit_work.ptr;
   double* theta_dev = base + o_theta;
@@ -2451,7 +2452,43 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
                                hipMemcpyDeviceToHost, st));
   VB_TRY(rows.finish());
   VB_HIP(ctx, hipStreamSynchronize(st));
+  ctx->fit_hist_off = o_hist, ctx->fit_hist_len = hist_len, ctx->fit_hist_p = p, ctx->fit_out_off = o_out;      // (vb_fit_history_mean)
   return VB_OK;
+}
+
+namespace {
+// out[j] = (h[0][j] + h[1][j] + ... in row order) / rows: numpy's add.reduce over the leading axis followed by true_divide
+__global__ void __launch_bounds__(256) fit_history_mean_kernel(const double* __restrict__ h, int64_t rows, int64_t p,
+                                                               double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= p) return;
+  double s = h[j];
+  for (int64_t r0 = 1; r0 < rows; r0 += 8) {      // eight rows' loads in flight, added in row order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = h[(r0 + u < rows ? r0 + u : rows - 1) * p + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (r0 + u < rows) s += v[u];
+  }
+  out[j] = s / (double)rows;
+}
+}  // namespace
+
+int vb_fit_history_mean(vb_ctx* ctx, int64_t rows, int64_t p, double* mean) {
+  if (!ctx || !mean || rows <= 0 || p <= 0) return fail(ctx, VB_ERR_INVALID, "bad argument");
+  if (!ctx->fit_work.ptr || ctx->fit_hist_len < rows || ctx->fit_hist_p != p)
+    return fail(ctx, VB_ERR_STATE, "no resident iterate history of %lld rows x %lld (the last fit kept %lld x %lld)", (long long)rows,
+                (long long)p, (long long)ctx->fit_hist_len, (long long)ctx->fit_hist_p);
+  VB_HIP(ctx, hipSetDevice(ctx->device));
+  VB_TRY(main_stream_write(ctx));
+  const double* h = (const double*)ctx->fit_work.ptr + ctx->fit_hist_off + (ctx->fit_hist_len - rows) * p;
+  double* out = (double*)ctx->fit_work.ptr + ctx->fit_out_off;      // (the fit's own [value | gradient] area: free once it has returned)
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(fit_history_mean_kernel, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, st, h, rows, p, out);
+  VB_HIP(ctx, hipGetLastError());
+  const FetchSeg seg[1] = {{out, (size_t)p * sizeof(double), mean}};
+  return fetch_blocking(ctx, st, seg, 1);
 }
 
 // ---- measurement --------------------------------------------------------------------------------

@@ -543,6 +543,13 @@ class ExclusiveKL(StochasticVariationalObjective):
                        first_stream=first, state=state, hist_len=hist_len, log_directions=log_directions,
                        log_gradients=log_gradients, slot_aux=_LR_SLOT)
 
+    def device_history_mean(self, rows):
+        """``np.mean(history[-rows:], axis=0)`` of the iterates the last ``device_fit`` kept -- the iterate average
+        ``optimization.py:120-126`` returns as ``opt_param`` -- formed on the device from the rows still resident there
+        (``vb_fit_history_mean``): the same additions in the same order as numpy's, without its pass over ``rows`` iterates on
+        the host (60 x 4.2 MB at D = 1024 dense: 7 ms)."""
+        return self._engine().fit_history_mean(rows, self.approx.var_param_dim)
+
     def _mvt_exclusive_kl(self, approx):
         """Entropy-form ELBO for the multivariate t: sampling, model gradient and the D x D contraction
         sum_n g_n (z_n / s_n)' on the device; the O(D^3) chain rule through the symmetric root on the host (the

@@ -157,10 +157,19 @@ class StochasticGradientOptimizer(Optimizer):
             log['descent_dir_history'] = directions
         if tail is not None:
             window = max(1, int((n_iters - 1) * tail))
-            log['opt_param'] = np.mean(history[-window:], axis=0)
+            # (the same mean from the rows still on the device: numpy's order of additions, no host pass over `window` iterates)
+            if window <= kept and window * p >= _DEVICE_MEAN_MIN:
+                log['opt_param'] = np.asarray(objective.device_history_mean(window))
+            else:
+                log['opt_param'] = np.mean(history[-window:], axis=0)
         else:
             log['opt_param'] = theta
         return log
+
+
+# iterate averages of at least this many numbers are formed on the device (vb_fit_history_mean); below, numpy's pass is cheaper
+# than a launch and a copy
+_DEVICE_MEAN_MIN = 1 << 20
 
 
 def _ema_update(state, decay, grad_sq):
