@@ -26,7 +26,11 @@ namespace vb {
 namespace {
 
 constexpr int kBsParts = 2;                       // workgroups per candidate (the N samples in two blocks): with up to 112
-                                                  // candidates one 1024-thread workgroup per CU holds the whole launch
+                                                  // candidates one 1024-thread workgroup per CU holds the whole launch.
+                                                  // (Round 6, VB_DIS_CLOCK: at N = 16 384 a round is ~8 us of replay + planning by
+                                                  // one wave and ~5.3 us of sums -- 8 192 exponentials per workgroup; FOUR parts
+                                                  // halve the sums and double the workgroups that replay: rounds 9.2 -> 12.7 us, C3
+                                                  // call 192 -> 208 us.  Two it stays.)
 constexpr int kBsHeapLevels = 6;                  // a round without a model: every midpoint of six levels
 constexpr int kBsPath = 56;                       // nodes of a predicted path per round (one lane of a wave per level)
 constexpr int kBsMaxCand = 2 * kBsPath;           // >= 2^6 - 1
@@ -465,16 +469,27 @@ __global__ void __launch_bounds__(1024) dis_spec_round_kernel(const double* __re
   const int c = blockIdx.x / kBsParts, part = blockIdx.x % kBsParts;
   const int64_t per = (n + kBsParts - 1) / kBsParts;
   const int64_t i_begin = part * per, i_end = i_begin + per < n ? i_begin + per : n;
+#ifdef VB_DIS_CLOCK
+  const long long dbg0 = wall_clock64();
+#endif
   BsSample pre[4];
   bs_preload(lp, b, lprior, i_begin, i_end, pre);
   const double sum_ls = scal_in[0];
   bs_advance(plan, tab, prev_plan, prev_res, eps_prev, ess_target, max_its, true);
+#ifdef VB_DIS_CLOCK
+  const long long dbg1 = wall_clock64();
+#endif
   if (blockIdx.x == 0)
     for (int e = threadIdx.x; e < kBsPlan; e += blockDim.x) plan_out[e] = plan[e];
   if (c >= (int)plan[H_NCAND]) return;
   const double guess = plan[kBsHdr + c];
   bs_sums<false>(lp, b, lprior, pre, sum_ls, guess, i_begin, i_end, nullptr, nullptr, sh,
                  res_out + (c * kBsParts + part) * 3);
+#ifdef VB_DIS_CLOCK      // (tools/build_variant.sh disclk "-DVB_DIS_CLOCK": phase times of a round, 100 MHz ticks)
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
+    printf("[dis round] block %d mode %d ncand %d: advance %lld sums %lld ticks (10 ns)\n", (int)blockIdx.x, (int)plan[H_MODE],
+           (int)plan[H_NCAND], dbg1 - dbg0, wall_clock64() - dbg1);
+#endif
 }
 
 // Last step (:358-366): replay the last round; finish what is left of the walk (normally nothing) level by level,
