@@ -49,6 +49,13 @@ enum {
   H_FIN, H_FIN_S1, H_FIN_S2, H_FIN_MX, H_FIN_EPS  // the final midpoint's sums once evaluated (:358-359)
 };
 
+#ifdef VB_DIS_CLOCK
+__device__ long long bs_dbg[8];
+#define BS_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) bs_dbg[k] = wall_clock64(); } while (0)
+#else
+#define BS_MARK(k) do { } while (0)
+#endif
+
 struct BsState {
   double lower, upper, lo2, up2, ess_lo, ess_up, ess_lo2, ess_up2;
   int level, status, fin;
@@ -265,7 +272,9 @@ __device__ void bs_build(const BsState& s, double* plan, double ess_target, int 
   double a = 0.0, b = 0.0;
   if (!s.fin) {
     const int remaining = max_its - s.level + 1;          // decisions + the final midpoint
-    if (remaining > 1 && !bs_predict(s, ess_target, a, b)) {
+    const bool no_model = remaining > 1 && !bs_predict(s, ess_target, a, b);
+    BS_MARK(3);
+    if (no_model) {
       mode = 1;
       len_a = remaining < kBsHeapLevels ? remaining : kBsHeapLevels;
       ncand = (1 << len_a) - 1;
@@ -294,20 +303,20 @@ __device__ void bs_build(const BsState& s, double* plan, double ess_target, int 
         const double x = lane == 0 ? a : b;
         double lower = s.lower, upper = s.upper;
         double* out = eps + lane * kBsPath;               // B's nodes are compacted below
+        // (VB_DIS_CLOCK: ~67 ns a level -- a dozen dependent fp64 / select instructions of ONE wave --, 3 us of every path round
+        // at 45 levels, with selects as with the branches this loop had first; together with the table's reload (1.6 us), the
+        // replay (1-1.8 us) and the model (0.5-1.3 us) the ~8 us a path round spends before its sums)
         for (int k = 0; k < len_a; ++k) {
           const double guess = (lower + upper) / 2.0;
           out[k] = guess;
-          if (k < n_dec) {
-            const bool left = x < guess;                  // the cell that holds x: `upper = guess` (:353)
-            if (left) {
-              dir |= 1ull << k;
-              upper = guess;
-            } else {
-              lower = guess;
-            }
-          }
+          const bool dec = k < n_dec;
+          const bool left = x < guess;                    // the cell that holds x: `upper = guess` (:353)
+          dir |= (unsigned long long)(dec && left) << k;
+          upper = dec && left ? guess : upper;
+          lower = dec && !left ? guess : lower;
         }
       }
+      BS_MARK(4);
       const unsigned lo32 = (unsigned)dir, hi32 = (unsigned)(dir >> 32);
       dir_a = ((unsigned long long)__shfl(hi32, 0, 64) << 32) | __shfl(lo32, 0, 64);
       dir_b = ((unsigned long long)__shfl(hi32, 1, 64) << 32) | __shfl(lo32, 1, 64);
@@ -346,16 +355,19 @@ __device__ __forceinline__ BsState bs_load_state(const double* plan) {
 __device__ void bs_advance(double* plan, double* tab, const double* __restrict__ prev_plan,
                            const double* __restrict__ prev_res, double eps_prev, double ess_target, int max_its,
                            bool build) {
+  BS_MARK(0);
   if (prev_plan) {       // one round trip: the whole table, not only the previous round's candidates (672 doubles)
     for (int e = threadIdx.x; e < kBsPlan; e += blockDim.x) plan[e] = prev_plan[e];
     for (int e = threadIdx.x; e < kBsRes; e += blockDim.x) tab[e] = prev_res[e];
     __syncthreads();
   }
+  BS_MARK(1);
   if (threadIdx.x < 64) {
     BsState s;
     if (prev_plan) {
       s = bs_load_state(plan);
       bs_walk(s, plan, tab, ess_target, max_its);
+      BS_MARK(2);
     } else {
       s.lower = 0.0, s.upper = eps_prev, s.lo2 = s.up2 = 0.0;
       s.ess_lo = s.ess_up = s.ess_lo2 = s.ess_up2 = NAN;
@@ -486,9 +498,10 @@ __global__ void __launch_bounds__(1024) dis_spec_round_kernel(const double* __re
   bs_sums<false>(lp, b, lprior, pre, sum_ls, guess, i_begin, i_end, nullptr, nullptr, sh,
                  res_out + (c * kBsParts + part) * 3);
 #ifdef VB_DIS_CLOCK      // (tools/build_variant.sh disclk "-DVB_DIS_CLOCK": phase times of a round, 100 MHz ticks)
-  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))
-    printf("[dis round] block %d mode %d ncand %d: advance %lld sums %lld ticks (10 ns)\n", (int)blockIdx.x, (int)plan[H_MODE],
-           (int)plan[H_NCAND], dbg1 - dbg0, wall_clock64() - dbg1);
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("[dis round] mode %d ncand %d: advance %lld (load %lld walk %lld predict %lld paths %lld rest %lld) sums %lld ticks (10 ns)\n",
+           (int)plan[H_MODE], (int)plan[H_NCAND], dbg1 - dbg0, bs_dbg[1] - bs_dbg[0], bs_dbg[2] - bs_dbg[1], bs_dbg[3] - bs_dbg[2],
+           bs_dbg[4] - bs_dbg[3], dbg1 - bs_dbg[4], wall_clock64() - dbg1);
 #endif
 }
 
