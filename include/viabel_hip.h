@@ -528,6 +528,10 @@ int vb_fit(vb_ctx* ctx, int slot, int slot_aux, int64_t n, int64_t d, int64_t n_
  * (60 rows of 4.2 MB at the headline shape: 7 ms of numpy on the host, 23 us per iteration of a 300-iteration fit).
  * VB_ERR_STATE: no such history (no fit yet, fewer rows kept, another p, or the work buffer has been reused).        */
 int vb_fit_history_mean(vb_ctx* ctx, int64_t rows, int64_t p, double* mean);
+/* Observability (tests): how many DIS refreshes of the dense families took log p / log prior out of the sampling product's
+ * epilogue (no pass over the samples: VB_MVT_EPI_ROWS), and how many steps had the chain-rule kernel store the gradient into the
+ * mapped result buffer itself (VB_MVT_CHAIN_FETCH).                                                                         */
+int vb_mvt_route_stats(vb_ctx* ctx, uint64_t* epilogue_rows, uint64_t* chain_fetch);
 
 /* ---- LRGaussian (approximations.py:610-731) under DISInclusiveKL / AlphaDivergence (objectives.py:283-463) ----
  * theta = [mu (d) | log_sigma (d) | B (d x k, row-major)], x = mu + B z + sigma eps with the n x d block of the noise

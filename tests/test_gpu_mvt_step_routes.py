@@ -188,3 +188,35 @@ def test_psis_weights_in_weights_out(vb, N, exact):
             np.testing.assert_array_equal(g0, g1)
         else:
             assert abs(v0 - v1) <= 1e-13 * abs(v0) and G.rel_err(g0, g1) < 1e-12
+
+
+@pytest.mark.parametrize('D,N', [(48, 77), (80, 1000), (144, 4100), (256, 1024), (512, 2048)])
+@pytest.mark.parametrize('df', [0.0, 6.0])
+def test_epilogue_rows_route_over_tile_shapes(vb, D, N, df):
+    """The sampling product's row-summing epilogue (EpiRowSums) where the column blocks are ragged (D not a multiple of 64), the
+    row tiles are (N not a multiple of 64), one block and eight blocks wide -- and for the Gaussian member (df = 0: no row
+    scales): against the row-pass route, to rounding."""
+    rng = np.random.RandomState(D + N)
+    model = vb.GaussianModel(0.3 * rng.randn(D), np.exp(0.2 * rng.randn(D)))
+    prior = np.concatenate([0.1 * rng.randn(D), 0.4 + 0.1 * rng.rand(D)])
+    A = rng.randn(D, D)
+    theta = np.concatenate([0.1 * rng.randn(D), ofam.psd_to_free(A @ A.T / D + 0.5 * np.eye(D))])
+
+    def call():
+        approx = vb.MultivariateT(D, df, seed=6, rng='philox') if df > 0 else vb.FullRankGaussian(D, seed=6, rng='philox')
+        obj = vb.DISInclusiveKL(approx, model, N, ess_target=max(8, N // 8), temper_prior=vb.MFGaussian(D),
+                                temper_prior_params=prior, use_resampling=False)
+        return [obj(theta + 0.01 * i) + (obj._eps, obj._ess) for i in range(2)]
+    from viabel_amd import _lib
+    eng = _lib.default_engine()
+    before = eng.mvt_route_stats()
+    on = call()
+    mid = eng.mvt_route_stats()
+    off = _with({'VB_MVT_EPI_ROWS': '0'}, call)
+    after = eng.mvt_route_stats()
+    assert mid[0] == before[0] + 2 and after[0] == mid[0]      # both refreshes took the epilogue route; none with the switch off
+    small = (D + D * (D + 1) // 2) * 8 + 128 <= (1 << 20)       # (the mapped staging buffer takes results up to 1 MB)
+    assert mid[1] == before[1] + (2 if small else 0)           # ... and the chain-rule kernel brought the gradient home
+    for (v0, g0, e0, s0), (v1, g1, e1, s1) in zip(on, off):
+        assert abs(e0 - e1) <= 1e-10 * max(abs(e0), 1e-300) and abs(s0 - s1) <= 1e-8 * abs(s0)
+        assert abs(v0 - v1) <= 1e-10 * abs(v0) and G.rel_err(g0, g1) < 1e-9

@@ -119,6 +119,7 @@ SIGNATURES = {
                               ctypes.c_int64, _c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_int,
                               _c_double_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p]),
     'vb_fit_history_mean': (ctypes.c_int, [_ctx_p, ctypes.c_int64, ctypes.c_int64, _c_double_p]),
+    'vb_mvt_route_stats': (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     'vb_log_weights_meanfield': (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                 ctypes.c_double, _c_double_p, _c_double_p]),
     'vb_psis_smooth': (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_double, _c_double_p,
@@ -1039,6 +1040,13 @@ class Engine:
             _dptr(history) if hist_len else None, int(hist_len),
             _dptr(directions) if log_directions else None, _dptr(gradients) if log_gradients else None))
         return theta, values, history, state, directions, gradients
+
+    def mvt_route_stats(self):
+        """(refreshes that took log p / log prior from the sampling product's epilogue, steps whose chain-rule kernel stored the
+        gradient into the mapped result buffer itself) -- ``vb_mvt_route_stats``."""
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._lib.vb_mvt_route_stats(self._ctx, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
 
     def fit_history_mean(self, rows, p):
         """``np.mean(history[-rows:], axis=0)`` of the iterates the last ``fit`` kept, formed on the device from the rows still

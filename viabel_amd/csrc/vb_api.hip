@@ -2475,6 +2475,13 @@ __global__ void __launch_bounds__(256) fit_history_mean_kernel(const double* __r
 }
 }  // namespace
 
+int vb_mvt_route_stats(vb_ctx* ctx, uint64_t* epilogue_rows, uint64_t* chain_fetch) {
+  if (!ctx || !epilogue_rows || !chain_fetch) return fail(ctx, VB_ERR_INVALID, "NULL argument");
+  *epilogue_rows = ctx->mvt_epi_rows_calls;
+  *chain_fetch = ctx->mvt_chain_fetch_calls;
+  return VB_OK;
+}
+
 int vb_fit_history_mean(vb_ctx* ctx, int64_t rows, int64_t p, double* mean) {
   if (!ctx || !mean || rows <= 0 || p <= 0) return fail(ctx, VB_ERR_INVALID, "bad argument");
   if (!ctx->fit_work.ptr || ctx->fit_hist_len < rows || ctx->fit_hist_p != p)

@@ -1243,6 +1243,7 @@ int mvt_dis_refresh(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t n_total
   VB_TRY(mvt_residuals(ctx, L, base, n, d, df, theta_host, linv_host, mine, dev_factors, chol_samples ? &ns : nullptr,
                        fuse_rows ? &lq_const : nullptr));
   if (norms) {
+    ++ctx->mvt_epi_rows_calls;
     hipLaunchKernelGGL(mvt_rows_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)(base + L.o_u), n,
                        (int)((d + kEpiRowsBN - 1) / kEpiRowsBN), n, (int)d, ctx->model.c0, c0p, norms,
                        (const double*)(base + L.o_invs), df, lq_const, base + L.o_lp + mine,
@@ -1630,6 +1631,7 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
                          base + L.o_grad, scale_dev, (const double*)(base + L.o_scal + 8), H);
       VB_HIP(ctx, hipGetLastError());
       if (H.grad) {
+        ++ctx->mvt_chain_fetch_calls;
         VB_TRY(fetch_wait(ctx, st, plan, segs));
         packed_out[0] = tail[4];
         if (res_out)
