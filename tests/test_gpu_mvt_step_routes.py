@@ -220,3 +220,38 @@ def test_epilogue_rows_route_over_tile_shapes(vb, D, N, df):
     for (v0, g0, e0, s0), (v1, g1, e1, s1) in zip(on, off):
         assert abs(e0 - e1) <= 1e-10 * max(abs(e0), 1e-300) and abs(s0 - s1) <= 1e-8 * abs(s0)
         assert abs(v0 - v1) <= 1e-10 * abs(v0) and G.rel_err(g0, g1) < 1e-9
+
+
+def test_newton_schulz_hinted_step_count_is_bit_identical(vb):
+    """Round 6: the symmetric root's Newton-Schulz iteration (reference-identical mode, approximations.py:348) launches as many
+    steps at once as the previous root of that size needed and replays the step-by-step control on their residuals afterwards
+    (one synchronisation instead of three); the states are the same states, so results are bit-identical to the step-by-step
+    control (VB_NS_HINT=0) -- over parameters whose roots need more steps than the hint, fewer by one, fewer by many (the
+    restart) and the same number."""
+    D, N, df = 64, 4096, 7.0
+    rng = np.random.RandomState(17)
+    model = vb.GaussianModel(0.2 * rng.randn(D), np.exp(0.1 * rng.randn(D)))
+    A = rng.randn(D, D)
+    mu = 0.1 * rng.randn(D)
+    covs = [A @ A.T / D + 0.5 * np.eye(D),                 # moderate
+            A @ A.T / D + 0.5 * np.eye(D) + 1e-3,          # nearly the same: the hint holds
+            A @ A.T / D + 1e-4 * np.eye(D),                # ill conditioned: more steps
+            np.eye(D) * 1.7,                               # a multiple of the identity: far fewer steps (restart)
+            A @ A.T / D + 0.5 * np.eye(D),
+            np.diag(np.linspace(0.5, 2.0, D))]
+    thetas = [np.concatenate([mu, ofam.psd_to_free(c)]) for c in covs]
+
+    def call():
+        out = []
+        ekl = vb.ExclusiveKL(vb.MultivariateT(D, df, seed=2), model, N)
+        dis = vb.DISInclusiveKL(vb.MultivariateT(D, df, seed=2), model, N, ess_target=N // 8, temper_prior=vb.MFGaussian(D),
+                                temper_prior_params=np.concatenate([np.zeros(D), 0.3 * np.ones(D)]), use_resampling=False)
+        for th in thetas:
+            np.random.seed(5)
+            out.append(ekl(th))
+            out.append(dis(th))
+        return out
+    hinted, plain = call(), _with({'VB_NS_HINT': '0'}, call)
+    for (v0, g0), (v1, g1) in zip(hinted, plain):
+        assert v0 == v1
+        np.testing.assert_array_equal(g0, g1)

@@ -290,6 +290,7 @@ struct vb_ctx {
   vb::DeviceBuffer fit_work;            // device-resident fit: [theta | out | state | value history | iterates]
   int64_t fit_out_off = 0;
   uint64_t mvt_epi_rows_calls = 0, mvt_chain_fetch_calls = 0;      // vb_mvt_route_stats
+  int ns_hint_m[2] = {0, 0}, ns_hint_steps[2] = {0, 0};      // steps the last Newton-Schulz root ([0]) / Frechet iteration ([1]) of size m ended with
   int64_t fit_hist_off = 0, fit_hist_len = 0, fit_hist_p = 0;      // where the last fit's kept iterates sit in fit_work (len 0: none)
   // vb_fit's per-iteration rows (iterates, directions, gradients) leave while the next iterations run: a copy stream, a
   // ring of pinned slots, one event pair per slot (vb_api.hip, FitRowStream)

@@ -262,44 +262,24 @@ __global__ void __launch_bounds__(256) ns_finish_kernel(const double* __restrict
 // info = [steps, last residual, ||Y Y - M0||_F over the leading d_check x d_cols block].  VB_ERR_UNSUPPORTED: no
 // convergence.  Pinned partial-sum ring: the caller has called ensure_pinned for (kNsMaxSteps + 2) * n_part doubles.
 constexpr int kNsMaxSteps = 40;
-static int ns_run(vb_ctx* ctx, int m, int64_t ld, double* set0, double* set1, const double* M0, int d_check, int* cur_out,
-                  double* info, int d_cols = 0) {
-  const int64_t mat = (int64_t)m * ld;
-  const int n_cu = ctx->prop.multiProcessorCount;
-  const int64_t n_part = round_up(gemm_max_blocks(m, m), 16);
-  hipStream_t st = ctx->stream;
-  double* set[2] = {set0, set1};
-  auto residual = [&](int slot) {
-    double s = 0.0;
-    const double* hp = ctx->pin_host + (int64_t)slot * n_part;
-    for (int64_t i = 0; i < n_part; ++i) s += hp[i];
-    return sqrt(s);
-  };
-  int cur = 0, done = 0;
-  bool converged = false;
+// What the step-by-step control below would do, given the residuals of the steps applied so far (residual[j]: ||I - Z Y||_F
+// of the state BEFORE step j).  Returns the number of steps it ends with, or -1 - k when it needs k more residuals first.
+// (The control launches in groups -- four, then what is known to be missing, else one -- and applies every step of a group
+// whether or not an earlier one of it met a stopping rule: the count it ends with is part of the result's bits.)
+struct NsControl {
+  int done = 0, stop_at = kNsMaxSteps + 1;
+  bool converged = false, failed = false;
   double res = 0.0, prev = 1e300;
-  const double floor_tol = 4e-16 * (double)m;
-  // The iteration is quadratic: a residual below 1e-4 BEFORE step k is ~1e-8 after it and at the rounding floor after
-  // step k + 1 -- so once such a residual has been read, two steps from there finish the job (the accuracy check at the
-  // end is the safety net), and the floor itself need not be observed.
-  int stop_at = kNsMaxSteps + 1;      // steps to apply in all (known once a small residual has been seen)
-  while (!converged && done < kNsMaxSteps) {
-    const int group = done == 0 ? 4 : (stop_at <= kNsMaxSteps ? stop_at - done : 1);
-    for (int k = 0; k < group; ++k) {
-      double *Y = set[cur], *T = Y + mat, *Z = Y + 2 * mat;
-      // T = (3 I - Z Y) / 2 with ||I - Z Y||_F^2 of the state BEFORE this step into partial slot `done + k`
-      gemm_f64_launch<true>(st, square(Z, Y, ld, m), 1, n_cu, EpiNsT{T, ld, ctx->pin_dev + (int64_t)(done + k) * n_part});
-      GemmArgs g = square(Y, T, ld, m);      // batch 0: Y T, batch 1: T Z
-      g.batch = 1;
-      g.batch_a = mat, g.batch_b = mat;
-      gemm_f64_launch<true>(st, g, 2, n_cu, EpiStoreBatch{set[cur ^ 1], ld, 2 * mat});
-      cur ^= 1;
-    }
-    VB_HIP(ctx, hipGetLastError());
-    VB_HIP(ctx, hipStreamSynchronize(st));
+  int next_group() const { return done == 0 ? 4 : (stop_at <= kNsMaxSteps ? stop_at - done : 1); }
+  // consume the residuals of the next group (they must be there)
+  void take_group(const double* residual, double floor_tol) {
+    const int group = next_group();
     for (int k = 0; k < group && !converged; ++k) {
-      res = residual(done + k);
-      if (!std::isfinite(res)) return VB_ERR_UNSUPPORTED;
+      res = residual[done + k];
+      if (!std::isfinite(res)) {
+        failed = true;
+        return;
+      }
       if (res < floor_tol || (res < 1e-7 && res > 0.5 * prev)) converged = true;      // (later steps of the group: harmless)
       if (res < 1e-4 && stop_at > kNsMaxSteps) stop_at = done + k + 2;
       prev = res;
@@ -307,12 +287,83 @@ static int ns_run(vb_ctx* ctx, int m, int64_t ld, double* set0, double* set1, co
     done += group;
     if (done >= stop_at) converged = true;
   }
-  if (!converged) return VB_ERR_UNSUPPORTED;
+  bool finished() const { return failed || converged || done >= kNsMaxSteps; }
+};
+
+// hint (round 6): the number of steps the previous root of this size ended with (0: none).  The iteration used to run in
+// groups with a stream synchronisation behind each -- the host reads the residuals and decides -- : three wake-ups per root
+// at the sizes of the t family's reference-identical mode, ~24 us each in a 0.7-ms call.  With a hint that many steps are
+// launched at once and the control above is replayed on their residuals afterwards: when it ends where the hint said, or one
+// step earlier (that state is still in the other set), one synchronisation has done; when it wants more, the remaining groups
+// run as before; when it would have stopped two or more steps earlier the state is gone: *restart = true and the caller starts
+// over without a hint.  The states are the same states whichever way they were launched: the result is bit-identical.
+static int ns_run(vb_ctx* ctx, int m, int64_t ld, double* set0, double* set1, const double* M0, int d_check, int* cur_out,
+                  double* info, int d_cols = 0, int hint = 0, bool* restart = nullptr) {
+  const int64_t mat = (int64_t)m * ld;
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int64_t n_part = round_up(gemm_max_blocks(m, m), 16);
+  hipStream_t st = ctx->stream;
+  double* set[2] = {set0, set1};
+  if (restart) *restart = false;
+  std::vector<double> residual;      // residual[j], j < applied
+  int applied = 0, cur = 0;
+  auto launch_steps = [&](int count) {
+    for (int k = 0; k < count; ++k) {
+      double *Y = set[cur], *T = Y + mat, *Z = Y + 2 * mat;
+      // T = (3 I - Z Y) / 2 with ||I - Z Y||_F^2 of the state BEFORE this step into partial slot `applied + k`
+      gemm_f64_launch<true>(st, square(Z, Y, ld, m), 1, n_cu, EpiNsT{T, ld, ctx->pin_dev + (int64_t)(applied + k) * n_part});
+      GemmArgs g = square(Y, T, ld, m);      // batch 0: Y T, batch 1: T Z
+      g.batch = 1;
+      g.batch_a = mat, g.batch_b = mat;
+      gemm_f64_launch<true>(st, g, 2, n_cu, EpiStoreBatch{set[cur ^ 1], ld, 2 * mat});
+      cur ^= 1;
+    }
+  };
+  auto read_residuals = [&](int count) {      // (after a synchronisation)
+    for (int k = 0; k < count; ++k) {
+      double s = 0.0;
+      const double* hp = ctx->pin_host + (int64_t)(applied + k) * n_part;
+      for (int64_t i = 0; i < n_part; ++i) s += hp[i];
+      residual.push_back(sqrt(s));
+    }
+    applied += count;
+  };
+  const double floor_tol = 4e-16 * (double)m;
+  NsControl c;
+  if (hint >= 4 && hint <= kNsMaxSteps && restart) {
+    launch_steps(hint);
+    VB_HIP(ctx, hipGetLastError());
+    VB_HIP(ctx, hipStreamSynchronize(st));
+    read_residuals(hint);
+    while (!c.finished() && c.done + c.next_group() <= applied) c.take_group(residual.data(), floor_tol);
+    if (c.failed) return VB_ERR_UNSUPPORTED;
+    if (c.finished() && c.converged && c.done < applied - 1) {      // the control would have stopped two or more steps ago
+      *restart = true;
+      return VB_OK;
+    }
+  }
+  // the step-by-step control (all of it without a hint; what the hinted launch left otherwise)
+  while (!c.finished()) {
+    const int group = c.next_group();
+    const int missing = c.done + group - applied;      // (> 0 here: the loop above took every complete group)
+    if (missing > 0) {
+      launch_steps(missing);
+      VB_HIP(ctx, hipGetLastError());
+      VB_HIP(ctx, hipStreamSynchronize(st));
+      read_residuals(missing);
+    }
+    c.take_group(residual.data(), floor_tol);
+    if (c.failed) return VB_ERR_UNSUPPORTED;
+  }
+  if (!c.converged) return VB_ERR_UNSUPPORTED;
+  // the state after c.done steps: set[c.done & 1] -- the set the launches ended in, or (hinted launch, one step more than the
+  // control wanted) the other one, whose Y and Z the extra step only read
+  cur = c.done & 1;
   double* Y = set[cur];
   gemm_f64_launch<true>(st, square(Y, Y, ld, m), 1, n_cu, EpiResidual{M0, ld, d_check, ctx->pin_dev + (int64_t)kNsMaxSteps * n_part, d_cols});
   VB_HIP(ctx, hipGetLastError());
   *cur_out = cur;
-  info[0] = (double)done, info[1] = res, info[2] = -1.0;      // [2]: read by the caller after its own last launch + sync
+  info[0] = (double)c.done, info[1] = c.res, info[2] = -1.0;      // [2]: read by the caller after its own last launch + sync
   return VB_OK;
 }
 
@@ -335,16 +386,24 @@ int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, 
   hipStream_t st = ctx->stream;
   // the ring of partial sums starts from zero -- cleared by the DEVICE, in stream order (a host memset would have to wait
   // for the stream first: one wake-up per root, ~20 us of a 0.2 ms iteration)
-  VB_HIP(ctx, hipMemsetAsync(ctx->pin_dev, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double), st));
-  VB_HIP(ctx, hipMemsetAsync(scal, 0, sizeof(double), st));
-  gemm_f64_launch<true>(st, square(Lfull, Lt, ld, m), 1, n_cu, EpiStore{M0, ld});
-  hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, (const double*)M0, m, ld, scal);
-  hipLaunchKernelGGL(ns_scale_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, M0, m, ld, base,
-                     base + 2 * mat, (const double*)scal);
-  VB_HIP(ctx, hipGetLastError());
   int cur = 0;
   double loc[3];
-  VB_TRY(ns_run(ctx, m, ld, base, base + 3 * mat, M0, m, &cur, loc));
+  const bool hint_on = !(getenv("VB_NS_HINT") && atoi(getenv("VB_NS_HINT")) == 0);      // (0: the step-by-step control only)
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    VB_HIP(ctx, hipMemsetAsync(ctx->pin_dev, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double), st));
+    VB_HIP(ctx, hipMemsetAsync(scal, 0, sizeof(double), st));
+    gemm_f64_launch<true>(st, square(Lfull, Lt, ld, m), 1, n_cu, EpiStore{M0, ld});
+    hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, (const double*)M0, m, ld, scal);
+    hipLaunchKernelGGL(ns_scale_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, M0, m, ld, base,
+                       base + 2 * mat, (const double*)scal);
+    VB_HIP(ctx, hipGetLastError());
+    // (the previous root of this size says how many steps to launch at once: ns_run; a wrong guess that cannot be used starts over)
+    const int hint = (attempt == 0 && hint_on && ctx->ns_hint_m[0] == m) ? ctx->ns_hint_steps[0] : 0;
+    bool restart = false;
+    VB_TRY(ns_run(ctx, m, ld, base, base + 3 * mat, M0, m, &cur, loc, 0, hint, &restart));
+    if (!restart) break;
+  }
+  ctx->ns_hint_m[0] = m, ctx->ns_hint_steps[0] = (int)loc[0];
   hipLaunchKernelGGL(ns_finish_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st,
                      (const double*)(base + (int64_t)cur * 3 * mat), m, ld, (const double*)scal, root, 0);
   if (inv_root)
@@ -430,6 +489,10 @@ int sym_sqrt_frechet_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, con
   double* base = (double*)ctx->scratch.ptr;
   double *M0 = base + 6 * mat, *A = base + 7 * mat, *scal = A + small;
   hipStream_t st = ctx->stream;
+  int cur = 0;
+  double loc[3];
+  const bool hint_on = !(getenv("VB_NS_HINT") && atoi(getenv("VB_NS_HINT")) == 0);
+  for (int attempt = 0; attempt < 2; ++attempt) {
   VB_HIP(ctx, hipMemsetAsync(ctx->pin_dev, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double), st));      // (as sym_sqrt_dev)
   VB_HIP(ctx, hipMemsetAsync(scal, 0, 4 * sizeof(double), st));
   gemm_f64_launch<true>(st, square(Lfull, Lt, ld, (int)d), 1, n_cu, EpiStore{A, ld});
@@ -438,12 +501,15 @@ int sym_sqrt_frechet_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, con
   hipLaunchKernelGGL(ns_block_init_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, (const double*)A, E, (int)d, ld, ld2,
                      base, base + 2 * mat, M0, scal);
   VB_HIP(ctx, hipGetLastError());
-  int cur = 0;
-  double loc[3];
+  const int hint = (attempt == 0 && hint_on && ctx->ns_hint_m[1] == m) ? ctx->ns_hint_steps[1] : 0;
+  bool restart = false;
   // the safety net covers the block that CARRIES the derivative too: rows [0, d) x columns [0, 2 d) of
   // Y Y - M0, i.e. R R - Sigma and (es / c) (R X + X R - E) -- the latter relative to an off-diagonal block scaled to a tenth
   // of the diagonal blocks' norm; an ill-conditioned Sigma whose X has not converged hands the call to the host route
-  VB_TRY(ns_run(ctx, m, ld2, base, base + 3 * mat, M0, (int)d, &cur, loc, m));
+  VB_TRY(ns_run(ctx, m, ld2, base, base + 3 * mat, M0, (int)d, &cur, loc, m, hint, &restart));
+  if (!restart) break;
+  }
+  ctx->ns_hint_m[1] = m, ctx->ns_hint_steps[1] = (int)loc[0];
   hipLaunchKernelGGL(ns_block_finish_kernel, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, st,
                      (const double*)(base + (int64_t)cur * 3 * mat), (int)d, ld, ld2, (const double*)scal, X);
   VB_HIP(ctx, hipGetLastError());
