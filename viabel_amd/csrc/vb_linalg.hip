@@ -493,21 +493,21 @@ int sym_sqrt_frechet_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, con
   double loc[3];
   const bool hint_on = !(getenv("VB_NS_HINT") && atoi(getenv("VB_NS_HINT")) == 0);
   for (int attempt = 0; attempt < 2; ++attempt) {
-  VB_HIP(ctx, hipMemsetAsync(ctx->pin_dev, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double), st));      // (as sym_sqrt_dev)
-  VB_HIP(ctx, hipMemsetAsync(scal, 0, 4 * sizeof(double), st));
-  gemm_f64_launch<true>(st, square(Lfull, Lt, ld, (int)d), 1, n_cu, EpiStore{A, ld});
-  hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, st, (const double*)A, (int)d, ld, scal);
-  hipLaunchKernelGGL(ns_sumsq_kernel, dim3(1), dim3(1024), 0, st, E, (int)d, ld, scal);
-  hipLaunchKernelGGL(ns_block_init_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, (const double*)A, E, (int)d, ld, ld2,
-                     base, base + 2 * mat, M0, scal);
-  VB_HIP(ctx, hipGetLastError());
-  const int hint = (attempt == 0 && hint_on && ctx->ns_hint_m[1] == m) ? ctx->ns_hint_steps[1] : 0;
-  bool restart = false;
-  // the safety net covers the block that CARRIES the derivative too: rows [0, d) x columns [0, 2 d) of
-  // Y Y - M0, i.e. R R - Sigma and (es / c) (R X + X R - E) -- the latter relative to an off-diagonal block scaled to a tenth
-  // of the diagonal blocks' norm; an ill-conditioned Sigma whose X has not converged hands the call to the host route
-  VB_TRY(ns_run(ctx, m, ld2, base, base + 3 * mat, M0, (int)d, &cur, loc, m, hint, &restart));
-  if (!restart) break;
+    VB_HIP(ctx, hipMemsetAsync(ctx->pin_dev, 0, (size_t)((kNsMaxSteps + 2) * n_part) * sizeof(double), st));      // (as sym_sqrt_dev)
+    VB_HIP(ctx, hipMemsetAsync(scal, 0, 4 * sizeof(double), st));
+    gemm_f64_launch<true>(st, square(Lfull, Lt, ld, (int)d), 1, n_cu, EpiStore{A, ld});
+    hipLaunchKernelGGL(ns_norm_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, st, (const double*)A, (int)d, ld, scal);
+    hipLaunchKernelGGL(ns_sumsq_kernel, dim3(1), dim3(1024), 0, st, E, (int)d, ld, scal);
+    hipLaunchKernelGGL(ns_block_init_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st, (const double*)A, E, (int)d, ld, ld2,
+                       base, base + 2 * mat, M0, scal);
+    VB_HIP(ctx, hipGetLastError());
+    const int hint = (attempt == 0 && hint_on && ctx->ns_hint_m[1] == m) ? ctx->ns_hint_steps[1] : 0;
+    bool restart = false;
+    // the safety net covers the block that CARRIES the derivative too: rows [0, d) x columns [0, 2 d) of
+    // Y Y - M0, i.e. R R - Sigma and (es / c) (R X + X R - E) -- the latter relative to an off-diagonal block scaled to a tenth
+    // of the diagonal blocks' norm; an ill-conditioned Sigma whose X has not converged hands the call to the host route
+    VB_TRY(ns_run(ctx, m, ld2, base, base + 3 * mat, M0, (int)d, &cur, loc, m, hint, &restart));
+    if (!restart) break;
   }
   ctx->ns_hint_m[1] = m, ctx->ns_hint_steps[1] = (int)loc[0];
   hipLaunchKernelGGL(ns_block_finish_kernel, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, st,
