@@ -984,6 +984,10 @@ static void legacy_spec_enqueue_next(vb_ctx* ctx) {
 // called from the draw entry points and from fetch_blocking's wait.
 static void legacy_spec_poll(vb_ctx* ctx) {
   LegacySpec* Sp = ctx->legacy_spec;
+  if (Sp && Sp->active && !Sp->failed && Sp->in_flight < 0 && Sp->n_finished < Sp->n_reqs) {
+    legacy_spec_enqueue_next(ctx);      // (a job whose start was deferred to the caller's first wait: vb_legacy_round_end)
+    return;
+  }
   if (!Sp || !Sp->active || Sp->in_flight < 0) return;
   LegacySpec& S = *Sp;
   if (*(volatile unsigned long long*)(S.land_host + 344) != S.seq) return;
@@ -1257,7 +1261,13 @@ int vb_legacy_round_end(vb_ctx* ctx, vb_legacy_rng* rng) {
   S.failed = false;
   S.active = true;
   ++S.launched;
-  legacy_spec_enqueue_next(ctx);
+  // Round 6: a round of SEVERAL draws belongs to a family whose call is long (the t family: chi-square, then normals, then
+  // 0.6 ms of root, products and bisection) -- enqueuing the first draw here costs the host ~0.15 ms (twenty-odd launches)
+  // in front of the call's own first launch.  Its start waits for the caller's first wait instead (legacy_poll: in front of
+  // the first stream synchronisation, where the host would idle), or for the request itself.  One-draw rounds (the
+  // mean-field families: the draw IS the call) start at once.  VB_LEGACY_DEFER=0: always at once.
+  const char* de = getenv("VB_LEGACY_DEFER");
+  if (S.n_reqs < 2 || (de && atoi(de) == 0)) legacy_spec_enqueue_next(ctx);
   return VB_OK;
 }
 
@@ -2534,3 +2544,9 @@ int vb_profile_read(vb_ctx* ctx, int64_t* launches, int64_t* evals, double* tota
 }
 
 }  // extern "C"
+
+namespace vb {
+void legacy_poll(vb_ctx* ctx) {
+  if (ctx) ::legacy_spec_poll(ctx);
+}
+}  // namespace vb

@@ -619,6 +619,11 @@ int sync_streams(vb_ctx* ctx);   // main + pipeline streams
 // blocking device -> host fetch of small results: one gathering kernel into mapped memory + a polled completion word
 // (vb_api.hip); plain copies + hipStreamSynchronize above 1 MB
 int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs);
+// A look-ahead draw of numpy's streams may have finished (its end state landed in pinned memory): take note and enqueue the
+// job's NEXT request, which starts from that state.  Cheap (one pinned word read); called wherever the host has just waited
+// for the device anyway -- a job of two draws (the t family: chi-square, then normals) used to get its second draw started
+// only at the call's final wait, 0.45 ms after the first had finished (round 6, profiles/r06_c3_parity_timeline.txt).
+void legacy_poll(vb_ctx* ctx);
 // the same in two halves around a producer kernel that writes the mapped buffer itself (vb_api.hip)
 struct FetchPlan {
   bool ok = false;

@@ -106,11 +106,15 @@ int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* r
   // the off-diagonal block is scaled to a tenth of the diagonal blocks' norm (X is linear in E)
   const double e_scale = (e && fro_e > 0.0) ? 0.1 * fro / fro_e : 0.0;
   VB_HIP(ctx, hipMemsetAsync(base, 0, (size_t)(5 * mat) * sizeof(double), st));   // pad columns stay zero
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));   // earlier users of the staging buffer are done
+  legacy_poll(ctx);
   memset(h, 0, (size_t)mat * sizeof(double));
   for (int64_t i = 0; i < m; ++i) h[i * ld + i] = 1.0;
   VB_HIP(ctx, hipMemcpyAsync(Z[0], h, (size_t)mat * sizeof(double), hipMemcpyHostToDevice, st));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   for (int64_t i = 0; i < m; ++i) h[i * ld + i] = 0.0;
   for (int64_t i = 0; i < d; ++i)
     for (int64_t j = 0; j < d; ++j) {
@@ -149,7 +153,9 @@ int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* r
       cur ^= 1;
     }
     VB_HIP(ctx, hipGetLastError());
+    legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
     VB_HIP(ctx, hipStreamSynchronize(st));
+    legacy_poll(ctx);
     for (int k = 0; k < group && !converged; ++k) {
       res = residual(it + k);
       if (!std::isfinite(res)) return fail(ctx, VB_ERR_NUMERIC, "matrix square root: iteration diverged");
@@ -165,11 +171,15 @@ int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* r
   gemm_f64_launch<true>(st, square(Y[cur], Y[cur], ld, m), 1, n_cu,
                         EpiResidual{M0, ld, (int)d, part_base + (int64_t)kMaxSteps * pstride});
   VB_HIP(ctx, hipGetLastError());
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   acc = residual(kMaxSteps);
 
   VB_HIP(ctx, hipMemcpyAsync(h, Y[cur], (size_t)mat * sizeof(double), hipMemcpyDeviceToHost, st));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   const double sc = sqrt(fro);
   for (int64_t i = 0; i < d; ++i)
     for (int64_t j = 0; j <= i; ++j) {   // symmetrise the rounding away
@@ -184,7 +194,9 @@ int sym_sqrt(vb_ctx* ctx, const double* a, const double* e, int64_t d, double* r
   }
   if (inv_root) {   // Z -> (A / c)^(-1/2): the inverse root comes with the iteration
     VB_HIP(ctx, hipMemcpyAsync(h, Z[cur], (size_t)mat * sizeof(double), hipMemcpyDeviceToHost, st));
+    legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
     VB_HIP(ctx, hipStreamSynchronize(st));
+    legacy_poll(ctx);
     for (int64_t i = 0; i < d; ++i)
       for (int64_t j = 0; j <= i; ++j) {
         const double v = 0.5 * (h[i * ld + j] + h[j * ld + i]) / sc;
@@ -333,7 +345,9 @@ static int ns_run(vb_ctx* ctx, int m, int64_t ld, double* set0, double* set1, co
   if (hint >= 4 && hint <= kNsMaxSteps && restart) {
     launch_steps(hint);
     VB_HIP(ctx, hipGetLastError());
+    legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
     VB_HIP(ctx, hipStreamSynchronize(st));
+    legacy_poll(ctx);
     read_residuals(hint);
     while (!c.finished() && c.done + c.next_group() <= applied) c.take_group(residual.data(), floor_tol);
     if (c.failed) return VB_ERR_UNSUPPORTED;
@@ -349,7 +363,9 @@ static int ns_run(vb_ctx* ctx, int m, int64_t ld, double* set0, double* set1, co
     if (missing > 0) {
       launch_steps(missing);
       VB_HIP(ctx, hipGetLastError());
+      legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
       VB_HIP(ctx, hipStreamSynchronize(st));
+      legacy_poll(ctx);
       read_residuals(missing);
     }
     c.take_group(residual.data(), floor_tol);
@@ -410,7 +426,9 @@ int sym_sqrt_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, int64_t d, 
     hipLaunchKernelGGL(ns_finish_kernel, dim3((unsigned)((mat + 255) / 256)), dim3(256), 0, st,
                        (const double*)(base + (int64_t)cur * 3 * mat + 2 * mat), m, ld, (const double*)scal, inv_root, 1);
   VB_HIP(ctx, hipGetLastError());
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   double acc = 0.0;
   for (int64_t i = 0; i < n_part; ++i) acc += ctx->pin_host[(int64_t)kNsMaxSteps * n_part + i];
   acc = sqrt(acc);
@@ -513,7 +531,9 @@ int sym_sqrt_frechet_dev(vb_ctx* ctx, const double* Lfull, const double* Lt, con
   hipLaunchKernelGGL(ns_block_finish_kernel, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, st,
                      (const double*)(base + (int64_t)cur * 3 * mat), (int)d, ld, ld2, (const double*)scal, X);
   VB_HIP(ctx, hipGetLastError());
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   double acc = 0.0;
   for (int64_t i = 0; i < n_part; ++i) acc += ctx->pin_host[(int64_t)kNsMaxSteps * n_part + i];
   acc = sqrt(acc);
@@ -620,7 +640,9 @@ int lr_path_terms(vb_ctx* ctx, const NoiseSlot& ns, const NoiseSlot& nz, int64_t
   VB_HIP(ctx, hipMemcpyAsync(tail + 2 * d, base + o_s3, (size_t)k2 * sizeof(double), hipMemcpyDeviceToDevice, st));
   if (ctx->comm) VB_TRY(comm_allreduce_sum(ctx, st, pack, (size_t)out_len));
   VB_HIP(ctx, hipMemcpyAsync(out_host, pack, (size_t)out_len * sizeof(double), hipMemcpyDeviceToHost, st));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   return VB_OK;
 }
 

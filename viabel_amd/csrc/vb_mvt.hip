@@ -365,7 +365,9 @@ int temper_prior_set(vb_ctx* ctx, int kind, int64_t d, double df, const double* 
   }
   VB_TRY(ensure(ctx, T.buf, host.size() * sizeof(double)));
   VB_HIP(ctx, hipMemcpyAsync(T.buf.ptr, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  legacy_poll(ctx);
   T.kind = kind, T.d = d, T.ld = ld, T.df = df, T.c0 = c0;
   return VB_OK;
 }
@@ -467,7 +469,9 @@ static int upload_padded(vb_ctx* ctx, double* dst, int64_t ld, const double* src
   for (int64_t i = 0; i < rows; ++i)
     for (int64_t j = 0; j < cols; ++j) tmp[(size_t)i * ld + j] = transpose ? src[j * cols + i] : src[i * cols + j];
   VB_HIP(ctx, hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  legacy_poll(ctx);
   return VB_OK;
 }
 
@@ -850,7 +854,9 @@ static int mvt_factors_device(vb_ctx* ctx, const MvtLayout& L, double* base, int
   // asynchronous and nothing here waits for the stream
   if (ctx->mvt_pin_doubles < p) {
     if (ctx->mvt_pin) {
+      legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
       VB_HIP(ctx, hipStreamSynchronize(st));
+      legacy_poll(ctx);
       VB_HIP(ctx, hipHostFree(ctx->mvt_pin));
       ctx->mvt_pin = nullptr;
     }
@@ -960,7 +966,9 @@ static int mvt_residuals(vb_ctx* ctx, const MvtLayout& L, double* base, int64_t 
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_li, li, (size_t)sq * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_mu, vec, (size_t)(2 * L.ld) * sizeof(double), hipMemcpyHostToDevice,
                                ctx->stream));
+    legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
     VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    legacy_poll(ctx);
   } else if (!factors_ready) {
     VB_TRY(mvt_factors_device(ctx, L, base, d, theta_host));
   }
@@ -1455,7 +1463,9 @@ int mvt_dis_weights_get(vb_ctx* ctx, double* w_host, int64_t n_total, int resamp
   const MvtLayout L = mvt_layout(ctx, ctx->mvt_n, ctx->mvt_n_total, ctx->mvt_d);
   VB_HIP(ctx, hipMemcpyAsync(w_host, (double*)ctx->mvt_state.ptr + (resampled ? L.o_wres : L.o_w), (size_t)n_total * sizeof(double),
                              hipMemcpyDeviceToHost, ctx->stream));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  legacy_poll(ctx);
   return VB_OK;
 }
 
@@ -1470,7 +1480,9 @@ int mvt_dis_state_get(vb_ctx* ctx, double* logp_host, double* logq_host, int64_t
     VB_HIP(ctx, hipMemcpyAsync(logp_host, base + L.o_lp, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
   if (logq_host)
     VB_HIP(ctx, hipMemcpyAsync(logq_host, base + L.o_lqcopy, (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, st));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   return VB_OK;
 }
 
@@ -1480,7 +1492,9 @@ int mvt_dis_scalars_get(vb_ctx* ctx, double out[4]) {
   const MvtLayout L = mvt_layout(ctx, ctx->mvt_n, ctx->mvt_n_total, ctx->mvt_d);
   double* base = (double*)ctx->mvt_state.ptr;
   VB_HIP(ctx, hipMemcpyAsync(out, base + L.o_scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  legacy_poll(ctx);
   return VB_OK;
 }
 
@@ -1510,7 +1524,9 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     // the caller's weights of THIS rank's rows (resampling counts of a host draw, or weights it smoothed / clipped itself)
     // go into the count area: the resident tempered weights of the refresh stay what they are
     VB_HIP(ctx, hipMemcpyAsync(base + L.o_wres, w_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
     VB_HIP(ctx, hipStreamSynchronize(st));
+    legacy_poll(ctx);
     wdev = base + L.o_wres;
   } else {
     if (!packed_out) return fail(ctx, VB_ERR_UNSUPPORTED, "device-resident weights: packed gradient only");
@@ -1670,7 +1686,9 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
       double tail[5];
       VB_HIP(ctx, hipMemcpyAsync(grad_direct, base + L.o_grad + 1, plen * sizeof(double), hipMemcpyDeviceToHost, st));
       VB_HIP(ctx, hipMemcpyAsync(tail, base + L.o_grad + 1 + plen, sizeof tail, hipMemcpyDeviceToHost, st));
+      legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
       VB_HIP(ctx, hipStreamSynchronize(st));
+      legacy_poll(ctx);
       packed_out[0] = tail[4];
       if (res_out)
         for (int q = 0; q < 4; ++q) res_out[q] = tail[q];
@@ -1678,7 +1696,9 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
     }
     VB_HIP(ctx, hipMemcpyAsync(packed_out, base + L.o_grad, (1 + plen) * sizeof(double), hipMemcpyDeviceToHost, st));
     if (res_out) VB_HIP(ctx, hipMemcpyAsync(res_out, base + L.o_scal + 8, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
     VB_HIP(ctx, hipStreamSynchronize(st));
+    legacy_poll(ctx);
     return VB_OK;
   }
   double sc[2];
@@ -1686,7 +1706,9 @@ int mvt_dis_grad(vb_ctx* ctx, int64_t n, int64_t d, double df, const double* the
   VB_HIP(ctx, hipMemcpyAsync(dmu_out, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpy2DAsync(gram_out, (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)L.ld * sizeof(double),
                                (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   *wsum_out = sc[0];
   *wlogq_out = sc[1];
   return VB_OK;
@@ -1786,7 +1808,9 @@ int mvt_path_terms(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64
   VB_HIP(ctx, hipMemcpyAsync(e_w, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpy2DAsync(low.data(), (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)ldw * sizeof(double),
                                (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   for (int64_t i = 0; i < d; ++i)
     for (int64_t j = 0; j <= i; ++j) m_w[i * d + j] = m_w[j * d + i] = low[(size_t)(i * d + j)];
   (void)n_total;
@@ -1816,7 +1840,9 @@ int mvt_elbo_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64_
   VB_HIP(ctx, hipMemcpyAsync(g_sum, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpy2DAsync(c_full, (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)ld * sizeof(double),
                                (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   // the per-sample additive constant of f; the all-reduced sums cover every rank's rows
   *f_sum += (double)(ctx->comm ? n_total : n) * ctx->model.c0;
   return VB_OK;
@@ -2074,7 +2100,9 @@ int mvt_alpha_sums(vb_ctx* ctx, const NoiseSlot& ns, int64_t n, int64_t d, int64
   VB_HIP(ctx, hipMemcpyAsync(g_sum, S.sums + S.off_col, (size_t)d * sizeof(double), hipMemcpyDeviceToHost, st));
   VB_HIP(ctx, hipMemcpy2DAsync(c_full, (size_t)d * sizeof(double), S.sums + S.off_c, (size_t)ld * sizeof(double),
                                (size_t)d * sizeof(double), (size_t)d, hipMemcpyDeviceToHost, st));
+  legacy_poll(ctx);      // (before the wait: the host enqueues a look-ahead draw instead of idling; after it: what landed meanwhile)
   VB_HIP(ctx, hipStreamSynchronize(st));
+  legacy_poll(ctx);
   *w_sum = two[0];
   *value = two[1];
   return VB_OK;
