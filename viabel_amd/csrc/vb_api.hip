@@ -154,6 +154,7 @@ int fetch_wait(vb_ctx* ctx, hipStream_t st, const FetchPlan& plan, const FetchSe
   if (st == ctx->stream) noise_prefetch(ctx);      // the next call's noise behind the producing kernel, while the host polls
   volatile unsigned long long* word = plan.host + plan.o_done;
   bool seen = false;
+  ::legacy_spec_poll(ctx);      // (a look-ahead draw whose start was deferred to the caller's first wait: this may be it)
   for (unsigned spins = 0; spins < 2000000u && !seen; ++spins) {      // ~10 ms, then the stream
     seen = *word == plan.seq;
     if (!seen) {
@@ -176,7 +177,9 @@ int fetch_blocking(vb_ctx* ctx, hipStream_t st, const FetchSeg* segs, int n_segs
       if (segs[k].bytes)
         VB_HIP(ctx, hipMemcpyAsync(segs[k].dst, segs[k].src, segs[k].bytes, hipMemcpyDeviceToHost, st));
     if (st == ctx->stream) noise_prefetch(ctx);      // the next call's noise behind this call's copies, while the host waits
+    ::legacy_spec_poll(ctx);      // (in front of the wait: the host enqueues a look-ahead draw instead of idling)
     VB_HIP(ctx, hipStreamSynchronize(st));
+    ::legacy_spec_poll(ctx);
     return comm_check(ctx);
   }
   FetchArgs a;
@@ -218,6 +221,7 @@ int push_small(vb_ctx* ctx, hipStream_t st, const void* host_src, size_t bytes, 
                                    hipMemcpyHostToDevice, st));
     else
       VB_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st));
+    ::legacy_spec_poll(ctx);      // (in front of the wait, as in fetch_blocking)
     VB_HIP(ctx, hipStreamSynchronize(st));      // caller keeps ownership of `host_src`
     return VB_OK;
   }
@@ -1261,13 +1265,17 @@ int vb_legacy_round_end(vb_ctx* ctx, vb_legacy_rng* rng) {
   S.failed = false;
   S.active = true;
   ++S.launched;
-  // Round 6: a round of SEVERAL draws belongs to a family whose call is long (the t family: chi-square, then normals, then
-  // 0.6 ms of root, products and bisection) -- enqueuing the first draw here costs the host ~0.15 ms (twenty-odd launches)
-  // in front of the call's own first launch.  Its start waits for the caller's first wait instead (legacy_poll: in front of
-  // the first stream synchronisation, where the host would idle), or for the request itself.  One-draw rounds (the
-  // mean-field families: the draw IS the call) start at once.  VB_LEGACY_DEFER=0: always at once.
+  // Round 6: the multivariate t's round (chi-square, then normals) belongs to a long call -- 0.6 ms of root, products and
+  // bisection with stream synchronisations inside -- and enqueuing its first draw here costs the host ~0.15 ms (twenty-odd
+  // launches) in front of the call's own first launch.  Its start waits for the caller's first wait instead (legacy_poll: in
+  // front of the root's synchronisation, where the host would idle), or for the request itself.  Every other round starts at
+  // once.  VB_LEGACY_DEFER=0: always at once.
+  // Measured and NOT done: deferring every multi-draw round (the low-rank family's two normal draws: 377-405 -> 430-449 us -- its
+  // call has no wait before the final one), or any round whose last job nobody had to wait for (the dense Gaussian family:
+  // 630 -> 680-700 us -- its first wait, the pageable parameter upload, is a blocking call, not a wait the host could use).
   const char* de = getenv("VB_LEGACY_DEFER");
-  if (S.n_reqs < 2 || (de && atoi(de) == 0)) legacy_spec_enqueue_next(ctx);
+  const bool t_round = S.n_reqs >= 2 && S.reqs[0].prog == 0;      // chi-square first: the multivariate t
+  if (!t_round || (de && atoi(de) == 0)) legacy_spec_enqueue_next(ctx);
   return VB_OK;
 }
 
